@@ -1,0 +1,491 @@
+// gto_capi.cpp -- C entry points of the CPU ORACLE (test infrastructure, not product code).
+// Loaded with ctypes from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
+#include "gto.hpp"
+
+#include <memory>
+#include <sstream>
+
+using namespace gto;
+
+namespace
+{
+thread_local std::string g_error;
+
+struct Handle
+{
+  Params par;
+  Graph graph;
+  PHIndex index;
+};
+
+struct GenoHandle
+{
+  Handle * h;
+  std::unique_ptr<Genotyper> g;
+};
+
+// records text: one record per line, fields separated by blanks:  pos0  REF  ALT1,ALT2  [INFO]
+// INFO carries GT_ID / GT_ANTI_HAPLOTYPE exactly as src/graph/constructor.cpp:1540-1588 reads them
+// (only for records with a single alt).
+std::vector<VarRecord> parse_records(std::string const & text)
+{
+  std::vector<VarRecord> out;
+  std::istringstream in(text);
+  std::string line;
+  while (std::getline(in, line))
+  {
+    if (line.empty() || line[0] == '#')
+      continue;
+    std::istringstream ls(line);
+    VarRecord r;
+    std::string alts, info;
+    long pos;
+    ls >> pos >> r.ref >> alts;
+    ls >> info;
+    r.pos = static_cast<uint32_t>(pos);
+    std::size_t a = 0;
+    while (a <= alts.size())
+    {
+      std::size_t const b = alts.find(',', a);
+      AltAllele alt;
+      alt.seq = alts.substr(a, b == std::string::npos ? std::string::npos : b - a);
+      r.alts.push_back(alt);
+      if (b == std::string::npos)
+        break;
+      a = b + 1;
+    }
+    if (r.alts.size() == 1 && !info.empty() && info != ".")
+    {
+      std::size_t s = 0;
+      while (s <= info.size())
+      {
+        std::size_t const e = info.find(';', s);
+        std::string const kv = info.substr(s, e == std::string::npos ? std::string::npos : e - s);
+        std::size_t const eq = kv.find('=');
+        if (eq != std::string::npos)
+        {
+          std::string const key = kv.substr(0, eq), val = kv.substr(eq + 1);
+          if (key == "GT_ID")
+          {
+            long const id = std::stol(val);
+            r.ref_events.insert(-id);
+            r.alts[0].events.insert(id);
+          }
+          else if (key == "GT_ANTI_HAPLOTYPE")
+          {
+            std::size_t c = 0;
+            while (c <= val.size())
+            {
+              std::size_t const d = val.find(',', c);
+              r.alts[0].anti_events.insert(std::stol(val.substr(c, d == std::string::npos ? std::string::npos : d - c)));
+              if (d == std::string::npos)
+                break;
+              c = d + 1;
+            }
+          }
+        }
+        if (e == std::string::npos)
+          break;
+        s = e + 1;
+      }
+    }
+    out.push_back(std::move(r));
+  }
+  return out;
+}
+
+void put_path_stream(std::vector<uint32_t> & out, GenotypePaths const & g)
+{
+  out.push_back(static_cast<uint32_t>(g.paths.size()));
+  out.push_back(g.longest_path_length);
+  for (auto const & p : g.paths)
+  {
+    out.push_back(p.start);
+    out.push_back(p.end);
+    out.push_back(p.read_start_index);
+    out.push_back(p.read_end_index);
+    out.push_back(p.mismatches);
+    out.push_back(static_cast<uint32_t>(p.var_order.size()));
+    for (std::size_t i = 0; i < p.var_order.size(); ++i)
+    {
+      out.push_back(p.var_order[i]);
+      out.push_back(static_cast<uint32_t>(p.nums[i].size()));
+      for (uint16_t n : p.nums[i])
+        out.push_back(n);
+    }
+  }
+}
+
+ReadRecord make_record(long i, uint8_t const * codes, uint32_t const * offs, uint16_t const * flags, int32_t const * tid,
+                       int32_t const * mtid, int64_t const * pos, int64_t const * isize, uint8_t const * mapq,
+                       uint8_t const * score_diff, uint64_t const * name, int32_t const * sample, int32_t const * rg)
+{
+  ReadRecord r;
+  r.seq.assign(codes + offs[i], codes + offs[i + 1]);
+  for (auto & c : r.seq)
+    if ((c & 15) == 0)
+      c = 15; // '=' becomes N when the character is assigned to a seqan Iupac
+  r.flag = flags ? flags[i] : 0;
+  r.tid = tid ? tid[i] : 0;
+  r.mtid = mtid ? mtid[i] : 0;
+  r.pos = pos ? pos[i] : 0;
+  r.isize = isize ? isize[i] : 0;
+  r.mapq = mapq ? mapq[i] : 60;
+  r.score_diff = score_diff ? score_diff[i] : 0;
+  r.name = name ? std::to_string(name[i]) : std::to_string(i);
+  r.sample = sample ? sample[i] : 0;
+  r.rg = rg ? rg[i] : 0;
+  return r;
+}
+
+} // namespace
+
+extern "C"
+{
+  char const * gto_last_error() { return g_error.c_str(); }
+
+  void * gto_new(char const * reference, long region_begin, char const * records_text, int is_sv_graph, int hq_reads,
+                 int force_both, long max_index_labels)
+  {
+    try
+    {
+      auto h = std::make_unique<Handle>();
+      h->par.is_sv_graph = is_sv_graph != 0;
+      h->par.hq_reads = hq_reads != 0;
+      h->par.force_align_both_orientations = force_both != 0;
+      h->par.max_index_labels = max_index_labels;
+      h->graph.is_sv_graph = is_sv_graph != 0;
+      h->graph.region_begin = region_begin;
+      h->graph.add_genomic_region(reference, parse_records(records_text));
+      h->graph.create_special_positions();
+      h->index = index_graph(h->graph, max_index_labels);
+      return h.release();
+    }
+    catch (std::exception const & e)
+    {
+      g_error = e.what();
+      return nullptr;
+    }
+  }
+
+  void gto_free(void * p) { delete static_cast<Handle *>(p); }
+
+  // out: n_ref, n_var, n_special, dna bytes (ref nodes then var nodes), n_events (events + anti events over all var nodes)
+  void gto_graph_counts(void * p, long * out)
+  {
+    Graph const & g = static_cast<Handle *>(p)->graph;
+    long dna = 0, ev = 0;
+    for (auto const & r : g.ref_nodes)
+      dna += static_cast<long>(r.label.dna.size());
+    for (auto const & v : g.var_nodes)
+    {
+      dna += static_cast<long>(v.label.dna.size());
+      ev += static_cast<long>(v.events.size() + v.anti_events.size());
+    }
+    out[0] = static_cast<long>(g.ref_nodes.size());
+    out[1] = static_cast<long>(g.var_nodes.size());
+    out[2] = static_cast<long>(g.ref_reach_poses.size());
+    out[3] = dna;
+    out[4] = ev;
+  }
+
+  // events: per var node  n_events, n_anti, then the values (sorted ascending) as int64
+  void gto_graph_dump(void * p, uint32_t * ref_order, uint32_t * ref_len, uint32_t * ref_nvar, uint32_t * ref_first_var,
+                      uint32_t * var_order, uint32_t * var_len, uint32_t * var_out_ref, char * dna, uint32_t * ref_reach_poses,
+                      uint32_t * actual_poses, int64_t * events)
+  {
+    Graph const & g = static_cast<Handle *>(p)->graph;
+    long d = 0;
+    for (std::size_t r = 0; r < g.ref_nodes.size(); ++r)
+    {
+      auto const & n = g.ref_nodes[r];
+      ref_order[r] = n.label.order;
+      ref_len[r] = static_cast<uint32_t>(n.label.dna.size());
+      ref_nvar[r] = static_cast<uint32_t>(n.out_var_ids.size());
+      ref_first_var[r] = n.out_var_ids.empty() ? INVALID_ID : n.out_var_ids[0];
+      std::memcpy(dna + d, n.label.dna.data(), n.label.dna.size());
+      d += static_cast<long>(n.label.dna.size());
+    }
+    long e = 0;
+    for (std::size_t v = 0; v < g.var_nodes.size(); ++v)
+    {
+      auto const & n = g.var_nodes[v];
+      var_order[v] = n.label.order;
+      var_len[v] = static_cast<uint32_t>(n.label.dna.size());
+      var_out_ref[v] = n.out_ref_id;
+      std::memcpy(dna + d, n.label.dna.data(), n.label.dna.size());
+      d += static_cast<long>(n.label.dna.size());
+      std::set<long> ev(n.events.begin(), n.events.end()), an(n.anti_events.begin(), n.anti_events.end());
+      events[e++] = static_cast<int64_t>(ev.size());
+      events[e++] = static_cast<int64_t>(an.size());
+      for (long x : ev)
+        events[e++] = x;
+      for (long x : an)
+        events[e++] = x;
+    }
+    for (std::size_t i = 0; i < g.ref_reach_poses.size(); ++i)
+    {
+      ref_reach_poses[i] = g.ref_reach_poses[i];
+      actual_poses[i] = g.actual_poses[i];
+    }
+  }
+
+  long gto_all_ref(void * p, char * out, long cap)
+  {
+    std::string const s = static_cast<Handle *>(p)->graph.get_all_ref();
+    if (static_cast<long>(s.size()) <= cap)
+      std::memcpy(out, s.data(), s.size());
+    return static_cast<long>(s.size());
+  }
+
+  long gto_index_num_keys(void * p) { return static_cast<long>(static_cast<Handle *>(p)->index.hamming0.size()); }
+
+  long gto_index_num_labels(void * p)
+  {
+    long n = 0;
+    for (auto const & kv : static_cast<Handle *>(p)->index.hamming0)
+      n += static_cast<long>(kv.second.size());
+    return n;
+  }
+
+  // keys ascending; counts per key; labels (start,end,var) in bucket order
+  void gto_index_dump(void * p, uint64_t * keys, uint32_t * counts, uint32_t * labels)
+  {
+    auto const & m = static_cast<Handle *>(p)->index.hamming0;
+    std::vector<uint64_t> ks;
+    ks.reserve(m.size());
+    for (auto const & kv : m)
+      ks.push_back(kv.first);
+    std::sort(ks.begin(), ks.end());
+    long l = 0;
+    for (std::size_t i = 0; i < ks.size(); ++i)
+    {
+      auto const & v = m.at(ks[i]);
+      keys[i] = ks[i];
+      counts[i] = static_cast<uint32_t>(v.size());
+      for (auto const & lab : v)
+      {
+        labels[l++] = lab.start_index;
+        labels[l++] = lab.end_index;
+        labels[l++] = lab.variant_id;
+      }
+    }
+  }
+
+  long gto_index_get(void * p, uint64_t key, uint32_t * out, long cap)
+  {
+    auto const v = static_cast<Handle *>(p)->index.get(key);
+    for (long i = 0; i < static_cast<long>(v.size()) && i < cap; ++i)
+    {
+      out[3 * i] = v[i].start_index;
+      out[3 * i + 1] = v[i].end_index;
+      out[3 * i + 2] = v[i].variant_id;
+    }
+    return static_cast<long>(v.size());
+  }
+
+  int gto_index_check(void * p)
+  {
+    auto * h = static_cast<Handle *>(p);
+    return h->index.check(h->graph) ? 1 : 0;
+  }
+
+  // per k-mer label lists of one read: exact lists then Hamming-1 lists.  stream: n_k, then for each of the 2*n_k lists:
+  // count, (start,end,var)*count
+  long gto_query_read(void * p, uint8_t const * codes, long len, uint32_t * out, long cap)
+  {
+    auto * h = static_cast<Handle *>(p);
+    std::vector<uint8_t> read(codes, codes + len);
+    auto const r0 = query_index(read, h->index);
+    auto const r1 = query_index_hamming1(read, h->index);
+    std::vector<uint32_t> s;
+    s.push_back(static_cast<uint32_t>(r0.size()));
+    for (auto const * lists : {&r0, &r1})
+      for (auto const & l : *lists)
+      {
+        s.push_back(static_cast<uint32_t>(l.size()));
+        for (auto const & x : l)
+        {
+          s.push_back(x.start_index);
+          s.push_back(x.end_index);
+          s.push_back(x.variant_id);
+        }
+      }
+    if (static_cast<long>(s.size()) <= cap)
+      std::memcpy(out, s.data(), s.size() * 4);
+    return static_cast<long>(s.size());
+  }
+
+  // align_read() for n records; stream per read: forward GenotypePaths then reverse GenotypePaths (see put_path_stream)
+  long gto_align(void * p, long n, uint8_t const * codes, uint32_t const * offs, uint16_t const * flags, int32_t const * tid,
+                 int32_t const * mtid, int64_t const * isize, uint32_t * out, long cap)
+  {
+    try
+    {
+      auto * h = static_cast<Handle *>(p);
+      std::vector<uint32_t> s;
+      for (long i = 0; i < n; ++i)
+      {
+        ReadRecord const r = make_record(i, codes, offs, flags, tid, mtid, nullptr, isize, nullptr, nullptr, nullptr, nullptr, nullptr);
+        auto const gp = align_read(r, h->index, h->graph, h->par);
+        put_path_stream(s, gp.first);
+        put_path_stream(s, gp.second);
+      }
+      if (static_cast<long>(s.size()) <= cap)
+        std::memcpy(out, s.data(), s.size() * 4);
+      return static_cast<long>(s.size());
+    }
+    catch (std::exception const & e)
+    {
+      g_error = e.what();
+      return -1;
+    }
+  }
+
+  void * gto_genotyper_new(void * p, long n_samples, long n_rg)
+  {
+    auto * h = static_cast<Handle *>(p);
+    auto * g = new GenoHandle;
+    g->h = h;
+    g->g = std::make_unique<Genotyper>(h->graph, h->index, h->par, static_cast<std::size_t>(n_samples), static_cast<std::size_t>(n_rg));
+    return g;
+  }
+
+  void gto_genotyper_free(void * p) { delete static_cast<GenoHandle *>(p); }
+
+  int gto_genotyper_push(void * p, long n, uint8_t const * codes, uint32_t const * offs, uint16_t const * flags,
+                         int32_t const * tid, int32_t const * mtid, int64_t const * pos, int64_t const * isize,
+                         uint8_t const * mapq, uint8_t const * score_diff, uint64_t const * name, int32_t const * sample,
+                         int32_t const * rg)
+  {
+    try
+    {
+      auto * g = static_cast<GenoHandle *>(p);
+      for (long i = 0; i < n; ++i)
+        g->g->push(make_record(i, codes, offs, flags, tid, mtid, pos, isize, mapq, score_diff, name, sample, rg));
+      return 0;
+    }
+    catch (std::exception const & e)
+    {
+      g_error = e.what();
+      return -1;
+    }
+  }
+
+  long gto_genotyper_num_haplotypes(void * p) { return static_cast<long>(static_cast<GenoHandle *>(p)->g->writer.haplotypes.size()); }
+
+  // Canonical score stream (u32 words), per haplotype:
+  //   id, num, clipped_reads, mapq_squared lo, hi,
+  //   per allele: clipped_bp lo,hi, mapq_squared lo,hi, score_diff, mismatches, r1f, r1r, r2f, r2r
+  //   per sample: max_log_score, ambiguous_depth, ambiguous_depth_alt, alt_proper_pair_depth,
+  //               gt_coverage[num], log_score[num(num+1)/2],
+  //               per allele: n_conn, then n_conn * (hap2, counts[num(hap2)])   (hap2 ascending)
+  long gto_scores_dump(void * p, uint32_t * out, long cap)
+  {
+    auto const & W = static_cast<GenoHandle *>(p)->g->writer;
+    std::vector<uint32_t> s;
+    auto put64 = [&s](uint64_t x)
+    {
+      s.push_back(static_cast<uint32_t>(x));
+      s.push_back(static_cast<uint32_t>(x >> 32));
+    };
+    for (auto const & h : W.haplotypes)
+    {
+      s.push_back(h.id);
+      s.push_back(h.num);
+      s.push_back(h.clipped_reads);
+      put64(h.mapq_squared);
+      for (uint16_t a = 0; a < h.num; ++a)
+      {
+        put64(h.per_allele[a].clipped_bp);
+        put64(h.per_allele[a].mapq_squared);
+        s.push_back(h.per_allele[a].score_diff);
+        s.push_back(h.per_allele[a].mismatches);
+        s.push_back(h.read_strand[a].r1_forward);
+        s.push_back(h.read_strand[a].r1_reverse);
+        s.push_back(h.read_strand[a].r2_forward);
+        s.push_back(h.read_strand[a].r2_reverse);
+      }
+      for (auto const & hs : h.hap_samples)
+      {
+        s.push_back(hs.max_log_score);
+        s.push_back(hs.ambiguous_depth);
+        s.push_back(hs.ambiguous_depth_alt);
+        s.push_back(hs.alt_proper_pair_depth);
+        for (uint16_t c : hs.gt_coverage)
+          s.push_back(c);
+        for (uint16_t c : hs.log_score)
+          s.push_back(c);
+        for (auto const & m : hs.connections)
+        {
+          s.push_back(static_cast<uint32_t>(m.size()));
+          for (auto const & kv : m)
+          {
+            s.push_back(kv.first);
+            for (uint16_t c : kv.second)
+              s.push_back(c);
+          }
+        }
+      }
+    }
+    if (static_cast<long>(s.size()) <= cap)
+      std::memcpy(out, s.data(), s.size() * 4);
+    return static_cast<long>(s.size());
+  }
+
+  void gto_genotyper_counts(void * p, long * out)
+  {
+    auto * g = static_cast<GenoHandle *>(p);
+    out[0] = g->g->num_records;
+    out[1] = g->g->num_duplicated;
+    long parked = 0;
+    for (auto const & m : g->g->maps)
+      parked += static_cast<long>(m.size());
+    out[2] = parked;
+  }
+
+  // ---- small known-answer helpers (pinned against test/utilities/*.cpp, test/typer/test_path.cpp) ----
+  long gto_to_uint64_vec(uint8_t const * codes, long len, long i, uint64_t * out, long cap)
+  {
+    auto const v = to_uint64_vec(std::vector<uint8_t>(codes, codes + len), static_cast<std::size_t>(i));
+    for (long k = 0; k < static_cast<long>(v.size()) && k < cap; ++k)
+      out[k] = v[k];
+    return static_cast<long>(v.size());
+  }
+
+  void gto_hamming1(uint64_t key, uint64_t * out)
+  {
+    auto const h = hamming1_keys(key);
+    std::memcpy(out, h.data(), sizeof(uint64_t) * 96);
+  }
+
+  void gto_mismatches_of_last_base(uint64_t key, uint64_t * out)
+  {
+    auto const h = mismatches_of_last_base(key);
+    std::memcpy(out, h.data(), sizeof(uint64_t) * 3);
+  }
+
+  void gto_mismatches_of_first_base(uint64_t key, uint64_t * out)
+  {
+    auto const h = mismatches_of_first_base(key);
+    std::memcpy(out, h.data(), sizeof(uint64_t) * 3);
+  }
+
+  long gto_get_num_kmers(long len) { return static_cast<long>(get_num_kmers(static_cast<std::size_t>(len))); }
+  long gto_ith_kmer_offset(long len, long i) { return static_cast<long>(get_ith_kmer_offset(len, i)); }
+
+  // Path(p1,p2) of two id-less labels (test/typer/test_path.cpp:50-65); out: size,start,end,n_var_order,n_nums
+  void gto_path_merge_two_ref_labels(uint32_t s1, uint32_t e1, uint32_t rs1, uint32_t re1, uint32_t s2, uint32_t e2, uint32_t rs2,
+                                     uint32_t re2, uint32_t * out)
+  {
+    Graph g;
+    Path a(g, KmerLabel(s1, e1), static_cast<uint16_t>(rs1), static_cast<uint16_t>(re1), 0);
+    Path b(g, KmerLabel(s2, e2), static_cast<uint16_t>(rs2), static_cast<uint16_t>(re2), 0);
+    Path m(a, b);
+    out[0] = m.size();
+    out[1] = m.start;
+    out[2] = m.end;
+    out[3] = static_cast<uint32_t>(m.var_order.size());
+    out[4] = static_cast<uint32_t>(m.nums.size());
+  }
+}
