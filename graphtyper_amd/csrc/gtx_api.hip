@@ -1,0 +1,250 @@
+// gtx_api.hip -- the HIP kernels (gfx950) and the device half of the C ABI declared in include/gtx.h.
+//
+// align kernel : one wavefront (= one 64-thread workgroup, so the workgroup barrier is the wave barrier and every
+//                wave owns its LDS workspace) per (read, orientation) task; persistent grid-stride over tasks.
+// score kernel : one thread per score item (an unpaired read or a mate pair); integer atomics into flat accumulators.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "gtx_ctx.hpp"
+#include "score_core.hpp"
+
+namespace gtx
+{
+struct WaveHip
+{
+  static __device__ inline uint32_t lane() { return threadIdx.x & 63u; }
+  static __device__ inline void sync() { __syncthreads(); }
+  static __device__ inline uint64_t ballot(bool p) { return __ballot(p); }
+  static __device__ inline uint32_t excl_scan(uint32_t v, uint32_t & total)
+  {
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      uint32_t const y = __shfl_up(x, d);
+      if ((threadIdx.x & 63u) >= static_cast<uint32_t>(d))
+        x += y;
+    }
+    total = __shfl(x, 63);
+    return x - v;
+  }
+  static __device__ inline uint32_t atomic_add_u32(uint32_t * p, uint32_t v) { return atomicAdd(p, v); }
+  static __device__ inline void atomic_add_u64(unsigned long long * p, unsigned long long v) { atomicAdd(p, v); }
+};
+
+__global__ __launch_bounds__(64) void gtx_align_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
+                                                       uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
+                                                       uint32_t n_reads, uint32_t * __restrict__ records, uint32_t rec_words,
+                                                       uint32_t force_both)
+{
+  __shared__ AlignWorkspace ws;
+  uint32_t const n_tasks = 2u * n_reads;
+  for (uint32_t t = blockIdx.x; t < n_tasks; t += gridDim.x)
+  {
+    uint32_t const read = t >> 1, orient = t & 1u;
+    gtx_read_meta const m = meta[read];
+    uint32_t * rec = records + static_cast<uint64_t>(t) * rec_words;
+    uint32_t const len = m.l_qseq;
+    // align_read (alignment.cpp:331-363): reads shorter than 2K-1 stay unaligned; the reverse orientation is only
+    // computed for reads that are not part of a concordant pair
+    bool const skip = len < 2 * K - 1 || len > AlignCfg::MAX_READ || (orient == 1 && !needs_reverse(m, force_both != 0));
+    if (skip)
+    {
+      if ((threadIdx.x & 63u) == 0)
+      {
+        rec[0] = len > AlignCfg::MAX_READ ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
+        rec[1] = len << 16;
+      }
+      continue;
+    }
+    align_one<WaveHip>(g, ix, ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words);
+  }
+}
+
+__global__ __launch_bounds__(256) void gtx_score_kernel(GraphView g, ScoreParams par, gtx_score_item const * __restrict__ items,
+                                                        uint32_t n_items, uint32_t const * __restrict__ records,
+                                                        uint32_t rec_words, ScoreAcc acc, uint32_t * error_flag)
+{
+  uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_items)
+    return;
+  gtx_score_item const it = items[i];
+  score_item<WaveHip>(g, par, it, records, rec_words, acc, error_flag);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+thread_local std::string g_last_error;
+
+static bool hip_ok(hipError_t e, char const * what)
+{
+  if (e == hipSuccess)
+    return true;
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return false;
+}
+
+template <class T>
+static bool upload(std::vector<void *> & owned, T const *& dst, T const * src, size_t n, char const * what)
+{
+  void * p = nullptr;
+  size_t const bytes = (n ? n : 1) * sizeof(T);
+  if (!hip_ok(hipMalloc(&p, bytes), what))
+    return false;
+  owned.push_back(p);
+  if (n && !hip_ok(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice), what))
+    return false;
+  dst = static_cast<T const *>(p);
+  return true;
+}
+
+int ctx_upload(gtx_ctx & c, int device)
+{
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+  {
+    g_last_error = "no HIP device visible (libgtx has no CPU path)";
+    return GTX_ERR_NO_DEVICE;
+  }
+  if (device >= n_dev)
+  {
+    g_last_error = "device index out of range";
+    return GTX_ERR_NO_DEVICE;
+  }
+  if (!hip_ok(hipSetDevice(device), "hipSetDevice"))
+    return GTX_ERR_HIP;
+  c.device = device;
+  HostGraph const & h = c.graph;
+  GraphView v = h.view();
+  bool ok = true;
+  ok = ok && upload(c.dev_allocs, v.ref_order, h.ref_order.data(), h.ref_order.size(), "ref_order");
+  ok = ok && upload(c.dev_allocs, v.ref_len, h.ref_len.data(), h.ref_len.size(), "ref_len");
+  ok = ok && upload(c.dev_allocs, v.ref_dna, h.ref_dna.data(), h.ref_dna.size(), "ref_dna");
+  ok = ok && upload(c.dev_allocs, v.ref_nvar, h.ref_nvar.data(), h.ref_nvar.size(), "ref_nvar");
+  ok = ok && upload(c.dev_allocs, v.ref_first_var, h.ref_first_var.data(), h.ref_first_var.size(), "ref_first_var");
+  ok = ok && upload(c.dev_allocs, v.var_order, h.var_order.data(), h.var_order.size(), "var_order");
+  ok = ok && upload(c.dev_allocs, v.var_len, h.var_len.data(), h.var_len.size(), "var_len");
+  ok = ok && upload(c.dev_allocs, v.var_dna, h.var_dna.data(), h.var_dna.size(), "var_dna");
+  ok = ok && upload(c.dev_allocs, v.var_out_ref, h.var_out_ref.data(), h.var_out_ref.size(), "var_out_ref");
+  ok = ok && upload(c.dev_allocs, v.site_ref_reach, h.site_ref_reach.data(), h.site_ref_reach.size(), "site_ref_reach");
+  ok = ok && upload(c.dev_allocs, v.site_special_base, h.site_special_base.data(), h.site_special_base.size(), "site_special_base");
+  ok = ok && upload(c.dev_allocs, v.special_ref_reach, h.special_ref_reach.data(), h.special_ref_reach.size(), "special_ref_reach");
+  ok = ok && upload(c.dev_allocs, v.special_actual, h.special_actual.data(), h.special_actual.size(), "special_actual");
+  ok = ok && upload(c.dev_allocs, v.pos_bucket, h.pos_bucket.data(), h.pos_bucket.size(), "pos_bucket");
+  ok = ok && upload(c.dev_allocs, v.dna, h.dna.data(), h.dna.size(), "dna");
+  ok = ok && upload(c.dev_allocs, v.tri_off, h.tri_off.data(), h.tri_off.size(), "tri_off");
+  ok = ok && upload(c.dev_allocs, v.allele_off, h.allele_off.data(), h.allele_off.size(), "allele_off");
+  IndexView ix{};
+  ix.log2_cap = c.index.log2_cap;
+  ix.max_index_labels = static_cast<uint32_t>(c.params.max_index_labels);
+  ok = ok && upload(c.dev_allocs, ix.slots, c.index.slots.data(), c.index.slots.size(), "index slots");
+  ok = ok && upload(c.dev_allocs, ix.labels, c.index.dev_labels.data(), c.index.dev_labels.size(), "index labels");
+  void * ef = nullptr;
+  ok = ok && hip_ok(hipMalloc(&ef, sizeof(uint32_t)), "error flag");
+  if (ok)
+  {
+    c.dev_allocs.push_back(ef);
+    c.d_error_flag = static_cast<uint32_t *>(ef);
+    ok = hip_ok(hipMemset(ef, 0, sizeof(uint32_t)), "error flag");
+  }
+  if (!ok)
+    return GTX_ERR_HIP;
+  c.dev_graph = v;
+  c.dev_index = ix;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+    c.n_cu = prop.multiProcessorCount;
+  return GTX_OK;
+}
+
+void ctx_release_device(gtx_ctx & c)
+{
+  if (c.device >= 0)
+    (void)hipSetDevice(c.device);
+  for (void * p : c.dev_allocs)
+    (void)hipFree(p);
+  c.dev_allocs.clear();
+}
+
+} // namespace gtx
+
+using namespace gtx;
+
+extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta,
+                               uint32_t n_reads, uint32_t * d_records, uint32_t rec_words, void * stream)
+{
+  if (!c || !d_seq || !d_meta || !d_records || rec_words < 8)
+  {
+    g_last_error = "gtx_align_batch: bad argument";
+    return GTX_ERR_ARG;
+  }
+  if (c->device < 0)
+  {
+    g_last_error = "context was created without a device (libgtx has no CPU path)";
+    return GTX_ERR_NO_DEVICE;
+  }
+  if (n_reads == 0)
+    return GTX_OK;
+  // LDS admits ~10 single-wave workgroups per CU; oversubscribe a little and grid-stride the rest
+  uint32_t const max_blocks = static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256) * 16u;
+  uint64_t const tasks = 2ull * n_reads;
+  uint32_t const blocks = static_cast<uint32_t>(tasks < max_blocks ? tasks : max_blocks);
+  hipLaunchKernelGGL(gtx_align_kernel, dim3(blocks), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph, c->dev_index,
+                     d_seq, seq_stride, d_meta, n_reads, d_records, rec_words,
+                     static_cast<uint32_t>(c->params.force_align_both_orientations != 0));
+  if (!hip_ok(hipGetLastError(), "gtx_align_kernel launch"))
+    return GTX_ERR_HIP;
+  return GTX_OK;
+}
+
+extern "C" int gtx_score_batch(gtx_ctx * c, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records,
+                               uint32_t rec_words, const gtx_score_buffers * acc, void * stream)
+{
+  if (!c || !d_items || !d_records || !acc || !acc->d_log_score || !acc->d_gt_cov || !acc->d_hap_u32 || !acc->d_stat_u64 ||
+      !acc->d_stat_u32 || !acc->d_conn_log || !acc->d_conn_count)
+  {
+    g_last_error = "gtx_score_batch: bad argument";
+    return GTX_ERR_ARG;
+  }
+  if (c->device < 0)
+  {
+    g_last_error = "context was created without a device (libgtx has no CPU path)";
+    return GTX_ERR_NO_DEVICE;
+  }
+  if (n_items == 0)
+    return GTX_OK;
+  ScoreAcc a;
+  a.n_samples = acc->n_samples;
+  a.conn_cap = acc->conn_cap;
+  a.log_score = acc->d_log_score;
+  a.gt_cov = acc->d_gt_cov;
+  a.hap_u32 = acc->d_hap_u32;
+  a.stat_u64 = reinterpret_cast<unsigned long long *>(acc->d_stat_u64);
+  a.stat_u32 = acc->d_stat_u32;
+  a.conn_log = acc->d_conn_log;
+  a.conn_count = acc->d_conn_count;
+  ScoreParams par{static_cast<uint32_t>(c->params.is_sv_graph != 0), static_cast<uint32_t>(c->params.hq_reads != 0),
+                  static_cast<uint32_t>(c->params.is_segment_calling != 0), 0};
+  uint32_t const blocks = (n_items + 255u) / 256u;
+  hipLaunchKernelGGL(gtx_score_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), c->dev_graph, par, d_items,
+                     n_items, d_records, rec_words, a, c->d_error_flag);
+  if (!hip_ok(hipGetLastError(), "gtx_score_kernel launch"))
+    return GTX_ERR_HIP;
+  return GTX_OK;
+}
+
+extern "C" int gtx_ctx_error_count(gtx_ctx * c, uint32_t * out)
+{
+  if (!c || !out)
+    return GTX_ERR_ARG;
+  *out = 0;
+  if (c->device < 0)
+    return GTX_OK;
+  if (!hip_ok(hipMemcpy(out, c->d_error_flag, sizeof(uint32_t), hipMemcpyDeviceToHost), "error flag"))
+    return GTX_ERR_HIP;
+  return GTX_OK;
+}

@@ -1,0 +1,333 @@
+// gtx_capi.cpp -- host half of the C ABI (include/gtx.h): context life cycle, inspection, finalisation and the
+// per-record stream logic.  No compute on reads happens here.
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+
+#include "gtx_ctx.hpp"
+
+using namespace gtx;
+
+extern "C"
+{
+  const char * gtx_strerror(int status)
+  {
+    switch (status)
+    {
+    case GTX_OK: return "ok";
+    case GTX_ERR_ARG: return "bad argument";
+    case GTX_ERR_NO_DEVICE: return "no HIP device (libgtx has no CPU path)";
+    case GTX_ERR_HIP: return "HIP runtime error";
+    case GTX_ERR_UNSUPPORTED: return "graph outside the supported envelope";
+    case GTX_ERR_CAPACITY: return "caller buffer too small";
+    case GTX_ERR_GRAPH: return "malformed graph view";
+    default: return "unknown status";
+    }
+  }
+
+  const char * gtx_last_error(void) { return g_last_error.c_str(); }
+
+  int gtx_ctx_create(const gtx_graph_view * graph, const gtx_params * params, int device, gtx_ctx ** out)
+  {
+    if (!graph || !params || !out)
+    {
+      g_last_error = "gtx_ctx_create: NULL argument";
+      return GTX_ERR_ARG;
+    }
+    *out = nullptr;
+    auto c = std::make_unique<gtx_ctx>();
+    c->params = *params;
+    std::string const err = flatten_graph(*graph, *params, c->graph);
+    if (!err.empty())
+    {
+      g_last_error = err;
+      return err.rfind("unsupported", 0) == 0 ? GTX_ERR_UNSUPPORTED : GTX_ERR_GRAPH;
+    }
+    build_index(c->graph, c->index);
+    if (device >= 0)
+    {
+      int const rc = ctx_upload(*c, device);
+      if (rc != GTX_OK)
+      {
+        ctx_release_device(*c);
+        return rc;
+      }
+    }
+    *out = c.release();
+    return GTX_OK;
+  }
+
+  void gtx_ctx_destroy(gtx_ctx * c)
+  {
+    if (!c)
+      return;
+    ctx_release_device(*c);
+    delete c;
+  }
+
+  int gtx_ctx_special_positions(const gtx_ctx * c, uint32_t * n_special, uint32_t * ref_reach_poses, uint32_t * actual_poses,
+                                uint32_t cap)
+  {
+    if (!c || !n_special)
+      return GTX_ERR_ARG;
+    uint32_t const n = static_cast<uint32_t>(c->graph.special_actual.size());
+    *n_special = n;
+    if (ref_reach_poses || actual_poses)
+    {
+      if (cap < n)
+        return GTX_ERR_CAPACITY;
+      if (ref_reach_poses)
+        std::memcpy(ref_reach_poses, c->graph.special_ref_reach.data(), n * sizeof(uint32_t));
+      if (actual_poses)
+        std::memcpy(actual_poses, c->graph.special_actual.data(), n * sizeof(uint32_t));
+    }
+    return GTX_OK;
+  }
+
+  int gtx_ctx_score_layout(const gtx_ctx * c, gtx_score_layout * out)
+  {
+    if (!c || !out)
+      return GTX_ERR_ARG;
+    out->n_hap = c->graph.n_hap;
+    out->total_tri = c->graph.total_tri;
+    out->total_allele = c->graph.total_allele;
+    return GTX_OK;
+  }
+
+  int gtx_ctx_haplotypes(const gtx_ctx * c, uint32_t * hap_order, uint32_t * hap_cnum, uint64_t * tri_off, uint64_t * allele_off)
+  {
+    if (!c)
+      return GTX_ERR_ARG;
+    HostGraph const & g = c->graph;
+    for (uint32_t h = 0; h < g.n_hap; ++h)
+    {
+      if (hap_order)
+        hap_order[h] = g.var_order[g.ref_first_var[h]];
+      if (hap_cnum)
+        hap_cnum[h] = g.ref_nvar[h];
+      if (tri_off)
+        tri_off[h] = g.tri_off[h];
+      if (allele_off)
+        allele_off[h] = g.allele_off[h];
+    }
+    return GTX_OK;
+  }
+
+  int gtx_index_stats(const gtx_ctx * c, uint64_t * n_keys, uint64_t * n_labels)
+  {
+    if (!c)
+      return GTX_ERR_ARG;
+    if (n_keys)
+      *n_keys = c->index.keys.size();
+    if (n_labels)
+      *n_labels = c->index.labels.size();
+    return GTX_OK;
+  }
+
+  int gtx_index_get(const gtx_ctx * c, uint64_t key, gtx_label * out, uint32_t cap, uint32_t * n)
+  {
+    if (!c || !n)
+      return GTX_ERR_ARG;
+    *n = 0;
+    HostIndex const & ix = c->index;
+    if (ix.slots.empty())
+      return GTX_OK;
+    uint64_t const mask = (1ull << ix.log2_cap) - 1;
+    uint64_t h = hash_key(key, ix.log2_cap);
+    while (ix.slots[h].cnt != 0)
+    {
+      if (ix.slots[h].key == key)
+      {
+        *n = ix.slots[h].cnt;
+        if (out)
+        {
+          if (cap < *n)
+            return GTX_ERR_CAPACITY;
+          std::memcpy(out, ix.labels.data() + ix.slots[h].off, sizeof(gtx_label) * *n);
+        }
+        return GTX_OK;
+      }
+      h = (h + 1) & mask;
+    }
+    return GTX_OK;
+  }
+
+  int gtx_index_dump(const gtx_ctx * c, uint64_t * keys, uint32_t * counts, gtx_label * labels)
+  {
+    if (!c)
+      return GTX_ERR_ARG;
+    HostIndex const & ix = c->index;
+    for (size_t k = 0; k < ix.keys.size(); ++k)
+    {
+      if (keys)
+        keys[k] = ix.keys[k];
+      if (counts)
+        counts[k] = ix.key_off[k + 1] - ix.key_off[k];
+    }
+    if (labels && !ix.labels.empty())
+      std::memcpy(labels, ix.labels.data(), sizeof(gtx_label) * ix.labels.size());
+    return GTX_OK;
+  }
+
+  // haplotype.cpp:19-44 (saturating u8 / u16 counters) and :560 (sequential guard of explain_to_score)
+  int gtx_scores_finalize(uint32_t * log_score, uint64_t n_log, uint32_t * gt_cov, uint64_t n_cov, uint32_t * hap_u32,
+                          uint64_t n_hap_cells, uint64_t * n_saturated)
+  {
+    if (!gt_cov || !hap_u32 || !n_saturated)
+      return GTX_ERR_ARG;
+    (void)log_score;
+    (void)n_log;
+    uint64_t sat = 0;
+    for (uint64_t i = 0; i < n_cov; ++i)
+      if (gt_cov[i] > 0xFFFFu)
+        gt_cov[i] = 0xFFFFu;
+    for (uint64_t i = 0; i < n_hap_cells; ++i)
+    {
+      uint32_t * cell = hap_u32 + 4 * i;
+      // a read is only added while max_log_score < 0xFFFF - epsilon, epsilon in [4,8]: below 0xFFFF - 8 no read was refused
+      if (cell[0] >= 0xFFFFu - 8u)
+        ++sat;
+      for (int k = 1; k < 4; ++k)
+        if (cell[k] > 0xFFu)
+          cell[k] = 0xFFu;
+    }
+    *n_saturated = sat;
+    return GTX_OK;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stream: the per-record control flow of parallel_reader_genotype_only / genotype_only for non-SV graphs
+// (src/utilities/hts_parallel_reader.cpp:570-708, 245-338)
+// ---------------------------------------------------------------------------------------------------------------
+struct gtx_stream
+{
+  gtx_params params{};
+  std::vector<std::unordered_map<uint64_t, gtx_rec_meta>> parked; // per read group: read name -> parked mate
+  bool have_prev = false;
+  int32_t prev_tid = 0, prev_pos = 0;
+  std::vector<uint8_t> prev_seq;
+  uint32_t prev_len = 0;
+  uint32_t prev_align_index = 0;
+  uint32_t next_align_index = 0;
+  uint64_t n_records = 0, n_duplicated = 0;
+};
+
+extern "C"
+{
+  int gtx_stream_create(const gtx_params * params, uint32_t n_read_groups, gtx_stream ** out)
+  {
+    if (!params || !out || n_read_groups == 0)
+      return GTX_ERR_ARG;
+    auto s = std::make_unique<gtx_stream>();
+    s->params = *params;
+    s->parked.resize(n_read_groups);
+    *out = s.release();
+    return GTX_OK;
+  }
+
+  void gtx_stream_destroy(gtx_stream * s) { delete s; }
+
+  int gtx_stream_push(gtx_stream * s, const gtx_stream_record * recs, const uint8_t * seq, uint32_t seq_stride, uint32_t n,
+                      uint8_t * align_seq, gtx_read_meta * align_meta, uint32_t align_cap, uint32_t * n_align,
+                      gtx_score_item * items, uint32_t item_cap, uint32_t * n_items)
+  {
+    if (!s || !recs || !seq || !align_seq || !align_meta || !n_align || !items || !n_items)
+      return GTX_ERR_ARG;
+    uint32_t na = 0, ni = 0;
+    for (uint32_t i = 0; i < n; ++i)
+    {
+      gtx_stream_record const & r = recs[i];
+      if ((r.flag & s->params.sam_flag_filter) != 0) // hts_parallel_reader.cpp:658
+        continue;
+      if (r.rg >= s->parked.size())
+      {
+        g_last_error = "gtx_stream_push: read group index out of range";
+        return GTX_ERR_ARG;
+      }
+      ++s->n_records;
+      uint8_t const * rseq = seq + static_cast<uint64_t>(i) * seq_stride;
+      uint32_t const nbytes = (static_cast<uint32_t>(r.l_qseq) + 1u) / 2u;
+      if (nbytes > seq_stride)
+        return GTX_ERR_ARG;
+      // equal_pos_seq (include/graphtyper/utilities/hts_utils.hpp:110-128): same tid, pos, length and packed bytes
+      bool const dup = s->have_prev && r.tid == s->prev_tid && r.pos == s->prev_pos && r.l_qseq == s->prev_len &&
+                       std::memcmp(rseq, s->prev_seq.data(), nbytes) == 0;
+      uint32_t align_index;
+      if (dup)
+      {
+        ++s->n_duplicated;
+        align_index = s->prev_align_index; // prev_paths are reused as they are (hts_parallel_reader.cpp:666-684)
+      }
+      else
+      {
+        if (na >= align_cap)
+          return GTX_ERR_CAPACITY;
+        std::memcpy(align_seq + static_cast<uint64_t>(na) * seq_stride, rseq, nbytes);
+        align_meta[na] = gtx_read_meta{r.l_qseq, r.flag, r.tid, r.mtid, r.isize};
+        align_index = s->next_align_index++;
+        ++na;
+        s->have_prev = true;
+        s->prev_tid = r.tid;
+        s->prev_pos = r.pos;
+        s->prev_len = r.l_qseq;
+        s->prev_seq.assign(rseq, rseq + nbytes);
+        s->prev_align_index = align_index;
+      }
+      gtx_rec_meta const me{align_index, r.flag, r.mapq, r.score_diff, r.pos, r.isize};
+      auto & map = s->parked[r.rg];
+      auto it = map.find(r.name_id);
+      if (it == map.end())
+      {
+        if (r.flag & 1u) // IS_PAIRED: wait for the mate (hts_parallel_reader.cpp:283-290)
+        {
+          map.emplace(r.name_id, me);
+          continue;
+        }
+        if (ni >= item_cap)
+          return GTX_ERR_CAPACITY;
+        gtx_score_item item{};
+        item.first = me;
+        item.second.align_index = GTX_INVALID_ID;
+        item.sample = r.sample;
+        items[ni++] = item;
+        continue;
+      }
+      if ((it->second.flag & 64u) == (r.flag & 64u)) // both mates claim the same IS_FIRST_IN_PAIR: the reference exits (:306-315)
+      {
+        g_last_error = "gtx_stream_push: two reads with one name have the same IS_FIRST_IN_PAIR";
+        return GTX_ERR_ARG;
+      }
+      if (ni >= item_cap)
+        return GTX_ERR_CAPACITY;
+      gtx_score_item item{};
+      item.first = it->second;
+      item.second = me;
+      item.sample = r.sample;
+      items[ni++] = item;
+      map.erase(it);
+    }
+    *n_align = na;
+    *n_items = ni;
+    return GTX_OK;
+  }
+
+  int gtx_stream_counts(const gtx_stream * s, uint64_t * n_records, uint64_t * n_duplicated, uint64_t * n_parked)
+  {
+    if (!s)
+      return GTX_ERR_ARG;
+    if (n_records)
+      *n_records = s->n_records;
+    if (n_duplicated)
+      *n_duplicated = s->n_duplicated;
+    if (n_parked)
+    {
+      uint64_t p = 0;
+      for (auto const & m : s->parked)
+        p += m.size();
+      *n_parked = p;
+    }
+    return GTX_OK;
+  }
+}

@@ -1,0 +1,116 @@
+// gtx_flat.hpp -- flat (SoA) graph + k-mer index as the kernels see them, and the host containers that own them.
+//
+// The reference keeps the graph as vectors of RefNode/VarNode objects with std::vector<char> labels
+// (include/graphtyper/graph/graph.hpp:40-134) and the index as phmap::flat_hash_map<uint64_t, std::vector<KmerLabel>>
+// (include/graphtyper/index/ph_index.hpp:14-36).  Here both are flat arrays so that one upload puts them in HBM and a
+// wavefront can address them with plain offsets.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/gtx.h"
+
+namespace gtx
+{
+constexpr uint32_t K = GTX_K;
+constexpr uint32_t INVALID = GTX_INVALID_ID;
+constexpr uint32_t SPECIAL_START = GTX_SPECIAL_START;
+constexpr uint32_t POS_BUCKET_SHIFT = 6; // position -> ref node table has one entry per 64 bp
+constexpr uint32_t MAX_ALLELES = 64;     // allele sets are one 64-bit mask per (path, site)
+
+// A k-mer occurrence as stored on the device: KmerLabel (kmer_label.hpp:13-41) with variant_id already resolved to
+// (site, allele) -- what Path's constructor derives through Graph::get_variant_order/get_variant_num (path.cpp:13-36).
+struct DevLabel
+{
+  uint32_t start, end;
+  uint32_t site;   // ref node index the variant hangs from, INVALID when the label carries no variant
+  uint32_t allele; // Graph::get_variant_num()
+};
+
+struct IndexSlot // open addressed, linear probing; cnt == 0 marks an empty slot
+{
+  uint64_t key;
+  uint32_t off, cnt;
+};
+
+// Plain-pointer view handed to kernels (device pointers) and to the host emulation in tests (host pointers).
+struct GraphView
+{
+  uint32_t n_ref, n_var, n_special, n_bucket;
+  uint32_t first_order; // ref_order[0]
+  uint32_t padding;     // back-scan distance of get_locations_of_an_actual_position (graph.cpp:973)
+  uint32_t is_sv_graph;
+  uint32_t pad0;
+  const uint32_t * ref_order;
+  const uint32_t * ref_len;
+  const uint32_t * ref_dna;
+  const uint32_t * ref_nvar;
+  const uint32_t * ref_first_var;
+  const uint32_t * var_order;
+  const uint32_t * var_len;
+  const uint32_t * var_dna;
+  const uint32_t * var_out_ref;
+  const uint32_t * site_ref_reach;    // [n_ref] reach of allele 0 of the site after ref node r (0 when no site)
+  const uint32_t * site_special_base; // [n_ref] first special index of the site, INVALID when it has none
+  const uint32_t * special_ref_reach; // Graph::ref_reach_poses
+  const uint32_t * special_actual;    // Graph::actual_poses
+  const uint32_t * pos_bucket;        // [n_bucket] last ref node whose order <= first_order + 64*b
+  const char * dna;
+  // score accumulator layout (haplotype h <-> site h, graph.cpp:680-704)
+  const uint64_t * tri_off;    // [n_ref] offset of the genotype triangle of site r
+  const uint64_t * allele_off; // [n_ref]
+  uint64_t total_tri, total_allele;
+  uint32_t n_hap, pad1;
+};
+
+struct IndexView
+{
+  const IndexSlot * slots;
+  const DevLabel * labels;
+  uint32_t log2_cap;
+  uint32_t max_index_labels;
+};
+
+struct HostGraph
+{
+  std::vector<uint32_t> ref_order, ref_len, ref_dna, ref_nvar, ref_first_var;
+  std::vector<uint32_t> var_order, var_len, var_dna, var_out_ref;
+  std::vector<uint32_t> site_ref_reach, site_special_base, special_ref_reach, special_actual, pos_bucket;
+  std::vector<uint32_t> event_off; // [2*n_var+1] (empty when the graph has no events)
+  std::vector<int64_t> event_val;
+  std::vector<uint64_t> tri_off, allele_off;
+  std::string dna;
+  uint64_t total_tri = 0, total_allele = 0;
+  uint32_t n_hap = 0;
+  uint32_t padding = 1000;
+  bool is_sv_graph = false;
+
+  GraphView view() const;
+};
+
+struct HostIndex
+{
+  // reference-order content: keys ascending, labels of one key in emission (bucket) order
+  std::vector<uint64_t> keys;
+  std::vector<uint32_t> key_off; // [n_keys+1]
+  std::vector<gtx_label> labels;
+  // device form
+  std::vector<IndexSlot> slots;
+  std::vector<DevLabel> dev_labels;
+  uint32_t log2_cap = 0;
+};
+
+// returns "" on success, else a description of what is wrong with the view
+std::string flatten_graph(gtx_graph_view const & g, gtx_params const & par, HostGraph & out);
+void build_index(HostGraph const & g, HostIndex & out);
+
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint64_t hash_key(uint64_t key, uint32_t log2_cap)
+{
+  return (key * 0x9E3779B97F4A7C15ull) >> (64 - log2_cap);
+}
+
+} // namespace gtx

@@ -1,0 +1,422 @@
+// gtx_host.cpp -- host side of libgtx: graph flattening, special positions, k-mer index construction.
+//
+// Index construction here is NOT the reference's forward sweep with a deque of partial k-mers
+// (src/index/indexer.cpp:26-291).  It enumerates, for every end position in sweep order, the K-base walks that end
+// there by walking the graph BACKWARDS, branching over the alleles of each site in ascending order.  That visits
+// walks in exactly the order the reference's sublists hold them (later site = more significant), so
+// bucket order -- which decides Path order downstream -- is identical, while every end position is independent
+// (no sweep state), which is what a later GPU build of the index needs.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "gtx_flat.hpp"
+
+namespace gtx
+{
+GraphView HostGraph::view() const
+{
+  GraphView v{};
+  v.n_ref = static_cast<uint32_t>(ref_order.size());
+  v.n_var = static_cast<uint32_t>(var_order.size());
+  v.n_special = static_cast<uint32_t>(special_actual.size());
+  v.n_bucket = static_cast<uint32_t>(pos_bucket.size());
+  v.first_order = ref_order.empty() ? 0 : ref_order[0];
+  v.padding = padding;
+  v.is_sv_graph = is_sv_graph;
+  v.ref_order = ref_order.data();
+  v.ref_len = ref_len.data();
+  v.ref_dna = ref_dna.data();
+  v.ref_nvar = ref_nvar.data();
+  v.ref_first_var = ref_first_var.data();
+  v.var_order = var_order.data();
+  v.var_len = var_len.data();
+  v.var_dna = var_dna.data();
+  v.var_out_ref = var_out_ref.data();
+  v.site_ref_reach = site_ref_reach.data();
+  v.site_special_base = site_special_base.data();
+  v.special_ref_reach = special_ref_reach.data();
+  v.special_actual = special_actual.data();
+  v.pos_bucket = pos_bucket.data();
+  v.dna = dna.data();
+  v.tri_off = tri_off.data();
+  v.allele_off = allele_off.data();
+  v.total_tri = total_tri;
+  v.total_allele = total_allele;
+  v.n_hap = n_hap;
+  return v;
+}
+
+std::string flatten_graph(gtx_graph_view const & g, gtx_params const & par, HostGraph & out)
+{
+  if (g.n_ref == 0)
+    return "graph has no reference node";
+  if (!g.ref_order || !g.ref_len || !g.ref_dna_off || !g.ref_nvar || !g.ref_first_var || !g.dna)
+    return "NULL reference-node table";
+  if (g.n_var && (!g.var_order || !g.var_len || !g.var_dna_off || !g.var_out_ref))
+    return "NULL variant-node table";
+  uint32_t const R = g.n_ref, V = g.n_var;
+  out = HostGraph();
+  out.is_sv_graph = par.is_sv_graph != 0;
+  out.padding = (par.is_sv_graph || par.is_segment_calling) ? 1000000u : 1000u; // graph.cpp:973
+  out.ref_order.assign(g.ref_order, g.ref_order + R);
+  out.ref_len.assign(g.ref_len, g.ref_len + R);
+  out.ref_nvar.assign(g.ref_nvar, g.ref_nvar + R);
+  out.ref_first_var.assign(g.ref_first_var, g.ref_first_var + R);
+  out.var_order.assign(g.var_order, g.var_order + V);
+  out.var_len.assign(g.var_len, g.var_len + V);
+  out.var_out_ref.assign(g.var_out_ref, g.var_out_ref + V);
+  // repack the sequence arena: ref nodes then var nodes, each contiguous
+  out.ref_dna.resize(R);
+  out.var_dna.resize(V);
+  for (uint32_t r = 0; r < R; ++r)
+  {
+    if (static_cast<uint64_t>(g.ref_dna_off[r]) + g.ref_len[r] > g.dna_len)
+      return "reference node sequence outside the arena";
+    out.ref_dna[r] = static_cast<uint32_t>(out.dna.size());
+    out.dna.append(g.dna + g.ref_dna_off[r], g.ref_len[r]);
+  }
+  for (uint32_t v = 0; v < V; ++v)
+  {
+    if (static_cast<uint64_t>(g.var_dna_off[v]) + g.var_len[v] > g.dna_len)
+      return "variant node sequence outside the arena";
+    if (g.var_len[v] == 0)
+      return "variant node with empty sequence";
+    out.var_dna[v] = static_cast<uint32_t>(out.dna.size());
+    out.dna.append(g.dna + g.var_dna_off[v], g.var_len[v]);
+  }
+  // structure: ref r -> vars [first, first+nvar) -> ref r+1
+  uint32_t next_var = 0;
+  for (uint32_t r = 0; r < R; ++r)
+  {
+    uint32_t const n = out.ref_nvar[r];
+    if (r + 1 == R)
+    {
+      if (n != 0)
+        return "last reference node has outgoing variants";
+      break;
+    }
+    if (n == 0)
+      return "inner reference node without a variant site";
+    if (n > MAX_ALLELES)
+      return "unsupported: a site has more than 64 alleles";
+    if (out.ref_first_var[r] != next_var)
+      return "variant nodes are not laid out site by site";
+    if (next_var + n > V)
+      return "variant node index out of range";
+    for (uint32_t i = 0; i < n; ++i)
+    {
+      if (out.var_out_ref[next_var + i] != r + 1)
+        return "variant node does not lead to the next reference node";
+      if (out.var_order[next_var + i] != out.ref_order[r] + out.ref_len[r])
+        return "variant node order does not follow its reference node";
+    }
+    if (out.ref_order[r + 1] != out.var_order[next_var] + out.var_len[next_var])
+      return "reference node order does not follow the reference allele";
+    next_var += n;
+  }
+  if (next_var != V)
+    return "dangling variant nodes";
+  // events
+  if (g.event_off && g.event_val)
+  {
+    out.event_off.assign(g.event_off, g.event_off + 2 * V + 1);
+    out.event_val.assign(g.event_val, g.event_val + out.event_off.back());
+    if (out.event_off.back() == 0)
+    {
+      out.event_off.clear();
+      out.event_val.clear();
+    }
+  }
+  // special positions: Graph::create_special_positions (graph.cpp:384-407) + add_special_pos (:1759-1773)
+  out.site_ref_reach.assign(R, 0);
+  out.site_special_base.assign(R, INVALID);
+  for (uint32_t r = 0; r + 1 < R; ++r)
+  {
+    uint32_t const fv = out.ref_first_var[r], n = out.ref_nvar[r];
+    uint32_t const ref_reach = out.var_order[fv] + out.var_len[fv] - 1;
+    out.site_ref_reach[r] = ref_reach;
+    if (n <= 1)
+      continue;
+    uint32_t max_reach = 0;
+    for (uint32_t i = 1; i < n; ++i)
+      max_reach = std::max(max_reach, out.var_order[fv + i] + out.var_len[fv + i] - 1);
+    if (max_reach > ref_reach)
+      out.site_special_base[r] = static_cast<uint32_t>(out.special_actual.size());
+    for (uint32_t reach = ref_reach + 1; reach <= max_reach; ++reach)
+    {
+      out.special_ref_reach.push_back(ref_reach);
+      out.special_actual.push_back(reach);
+    }
+  }
+  // position -> reference node buckets
+  uint32_t const first = out.ref_order[0];
+  uint32_t const last = out.ref_order[R - 1] + out.ref_len[R - 1];
+  uint32_t const nb = ((last - first) >> POS_BUCKET_SHIFT) + 2;
+  out.pos_bucket.assign(nb, 0);
+  uint32_t rr = 0;
+  for (uint32_t b = 0; b < nb; ++b)
+  {
+    uint32_t const p = first + (b << POS_BUCKET_SHIFT);
+    while (rr + 1 < R && out.ref_order[rr + 1] <= p)
+      ++rr;
+    out.pos_bucket[b] = rr;
+  }
+  // haplotype h <-> site h (Graph::get_all_haplotypes, graph.cpp:680-704); accumulator offsets
+  out.n_hap = V == 0 ? 0 : R - 1;
+  out.tri_off.assign(R, 0);
+  out.allele_off.assign(R, 0);
+  for (uint32_t r = 0; r + 1 < R; ++r)
+  {
+    uint64_t const c = out.ref_nvar[r];
+    out.tri_off[r] = out.total_tri;
+    out.allele_off[r] = out.total_allele;
+    out.total_tri += c * (c + 1) / 2;
+    out.total_allele += c;
+  }
+  return "";
+}
+
+namespace
+{
+struct Emit
+{
+  uint64_t key;
+  gtx_label label;
+};
+
+struct Walker
+{
+  HostGraph const & g;
+  std::vector<Emit> & out;
+  bool has_events;
+  // walk state (backwards): var nodes visited, how many bases of each were used
+  uint32_t vars[K];
+  uint32_t used[K];
+  uint32_t n_vars = 0;
+  uint32_t end_label = 0;
+
+  static int code(char c)
+  {
+    switch (c)
+    {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'T': return 3;
+    default: return -1;
+    }
+  }
+
+  uint32_t special_of(uint32_t site, uint32_t pos) const // Graph::get_special_pos (graph.cpp:1775-1782)
+  {
+    uint32_t const rr = g.site_ref_reach[site];
+    return pos > rr ? SPECIAL_START + g.site_special_base[site] + (pos - rr - 1) : pos;
+  }
+
+  // the pruning rules of the forward sweep, evaluated on a finished walk (see file header / DESIGN.md)
+  bool walk_is_kept() const
+  {
+    // entry_has_too_many_nonrefs (indexer.cpp:13-20): counted over the non-reference alleles of the walk
+    uint32_t cnt = 0;
+    uint64_t num = 1;
+    for (uint32_t i = 0; i < n_vars; ++i)
+    {
+      uint32_t const v = vars[i];
+      uint32_t const site = g.var_out_ref[v] - 1;
+      if (v != g.ref_first_var[site])
+      {
+        ++cnt;
+        num = std::min<uint64_t>(num * g.ref_nvar[site], 1u << 30);
+      }
+    }
+    if (cnt > 1 && (num > 181 || cnt > 4))
+      return false;
+    if (!has_events)
+      return true;
+    // anti events (indexer.cpp:114-140): walking forward, a node is refused when one of its events is among the anti
+    // events gathered so far; a node's own anti events count from its second base on.
+    std::vector<int64_t> anti;
+    for (uint32_t i = n_vars; i-- > 0;) // vars[] is in backward order
+    {
+      uint32_t const v = vars[i];
+      int64_t const * ev = g.event_val.data() + g.event_off[2 * v];
+      uint32_t const n_ev = g.event_off[2 * v + 1] - g.event_off[2 * v];
+      int64_t const * an = g.event_val.data() + g.event_off[2 * v + 1];
+      uint32_t const n_an = g.event_off[2 * v + 2] - g.event_off[2 * v + 1];
+      for (uint32_t e = 0; e < n_ev; ++e)
+        if (std::find(anti.begin(), anti.end(), ev[e]) != anti.end())
+          return false;
+      if (used[i] >= 2)
+        for (uint32_t e = 0; e < n_ev; ++e)
+          if (std::find(an, an + n_an, ev[e]) != an + n_an)
+            return false;
+      anti.insert(anti.end(), an, an + n_an);
+    }
+    return true;
+  }
+
+  void finish(uint64_t key, uint32_t start_label)
+  {
+    if (!walk_is_kept())
+      return;
+    if (n_vars == 0)
+    {
+      out.push_back({key, {start_label, end_label, INVALID}});
+      return;
+    }
+    // IndexEntry::variant_id is a std::set: ascending ids.  vars[] is descending already (backward walk).
+    for (uint32_t i = n_vars; i-- > 0;)
+      out.push_back({key, {start_label, end_label, vars[i]}});
+  }
+
+  // take bases [.., off] of a node backwards; `have` bases collected so far in `key` (placed from the low end up)
+  void back_ref(uint32_t r, int64_t off, uint32_t have, uint64_t key)
+  {
+    char const * dna = g.dna.data() + g.ref_dna[r];
+    while (off >= 0)
+    {
+      int const c = code(dna[off]);
+      if (c < 0)
+        return;
+      key |= static_cast<uint64_t>(c) << (2 * have);
+      if (++have == K)
+      {
+        finish(key, g.ref_order[r] + static_cast<uint32_t>(off));
+        return;
+      }
+      --off;
+    }
+    if (r == 0)
+      return;
+    uint32_t const site = r - 1, fv = g.ref_first_var[site], n = g.ref_nvar[site];
+    for (uint32_t a = 0; a < n; ++a)
+      back_var(fv + a, static_cast<int64_t>(g.var_len[fv + a]) - 1, have, key);
+  }
+
+  void back_var(uint32_t v, int64_t off, uint32_t have, uint64_t key)
+  {
+    char const * dna = g.dna.data() + g.var_dna[v];
+    uint32_t const site = g.var_out_ref[v] - 1;
+    uint32_t const slot = n_vars++;
+    vars[slot] = v;
+    used[slot] = 0;
+    bool done = false;
+    while (off >= 0)
+    {
+      int const c = code(dna[off]);
+      if (c < 0)
+      {
+        done = true;
+        break;
+      }
+      key |= static_cast<uint64_t>(c) << (2 * have);
+      ++used[slot];
+      if (++have == K)
+      {
+        finish(key, special_of(site, g.var_order[v] + static_cast<uint32_t>(off)));
+        done = true;
+        break;
+      }
+      --off;
+    }
+    if (!done)
+      back_ref(site, static_cast<int64_t>(g.ref_len[site]) - 1, have, key);
+    --n_vars;
+  }
+};
+
+} // namespace
+
+void build_index(HostGraph const & g, HostIndex & out)
+{
+  out = HostIndex();
+  std::vector<Emit> em;
+  uint32_t const R = static_cast<uint32_t>(g.ref_order.size());
+  em.reserve(g.dna.size() + g.dna.size() / 4);
+  Walker w{g, em, !g.event_off.empty()};
+  for (uint32_t r = 0; r < R; ++r)
+  {
+    // fast path inside a reference node: a rolling 2-bit window while the k-mer stays within this node
+    char const * dna = g.dna.data() + g.ref_dna[r];
+    uint32_t const len = g.ref_len[r];
+    uint64_t roll = 0;
+    uint32_t valid = 0;
+    for (uint32_t d = 0; d < len; ++d)
+    {
+      int const c = Walker::code(dna[d]);
+      if (c < 0)
+      {
+        valid = 0;
+        continue;
+      }
+      roll = (roll << 2) | static_cast<uint64_t>(c);
+      ++valid;
+      if (valid >= K)
+        em.push_back({roll, {g.ref_order[r] + d - (K - 1), g.ref_order[r] + d, INVALID}});
+      else if (valid == d + 1) // window reaches back past the node start: enumerate through the previous site(s)
+      {
+        w.n_vars = 0;
+        w.end_label = g.ref_order[r] + d;
+        w.back_ref(r, d, 0, 0);
+      }
+    }
+    if (r + 1 == R || g.ref_nvar[r] == 0)
+      continue;
+    uint32_t const fv = g.ref_first_var[r];
+    for (uint32_t a = 0; a < g.ref_nvar[r]; ++a)
+    {
+      uint32_t const v = fv + a;
+      for (uint32_t d = 0; d < g.var_len[v]; ++d)
+      {
+        w.n_vars = 0;
+        w.end_label = w.special_of(r, g.var_order[v] + d);
+        w.back_var(v, d, 0, 0);
+      }
+    }
+  }
+  // group by key keeping emission order inside a key
+  std::vector<uint32_t> perm(em.size());
+  std::iota(perm.begin(), perm.end(), 0u);
+  std::stable_sort(perm.begin(), perm.end(), [&em](uint32_t a, uint32_t b) { return em[a].key < em[b].key; });
+  out.labels.reserve(em.size());
+  for (std::size_t i = 0; i < perm.size(); ++i)
+  {
+    Emit const & e = em[perm[i]];
+    if (i == 0 || e.key != out.keys.back())
+    {
+      out.keys.push_back(e.key);
+      out.key_off.push_back(static_cast<uint32_t>(out.labels.size()));
+    }
+    out.labels.push_back(e.label);
+  }
+  out.key_off.push_back(static_cast<uint32_t>(out.labels.size()));
+  // device form
+  uint32_t log2_cap = 4;
+  while ((1ull << log2_cap) < 2 * out.keys.size() + 1)
+    ++log2_cap;
+  out.log2_cap = log2_cap;
+  out.slots.assign(1ull << log2_cap, IndexSlot{0, 0, 0});
+  uint64_t const mask = (1ull << log2_cap) - 1;
+  for (std::size_t k = 0; k < out.keys.size(); ++k)
+  {
+    uint64_t h = hash_key(out.keys[k], log2_cap);
+    while (out.slots[h].cnt != 0)
+      h = (h + 1) & mask;
+    out.slots[h] = IndexSlot{out.keys[k], out.key_off[k], out.key_off[k + 1] - out.key_off[k]};
+  }
+  out.dev_labels.resize(out.labels.size());
+  for (std::size_t i = 0; i < out.labels.size(); ++i)
+  {
+    gtx_label const & l = out.labels[i];
+    DevLabel d{l.start_index, l.end_index, INVALID, 0};
+    if (l.variant_id != INVALID)
+    {
+      d.site = g.var_out_ref[l.variant_id] - 1;
+      d.allele = l.variant_id - g.ref_first_var[d.site];
+    }
+    out.dev_labels[i] = d;
+  }
+}
+
+} // namespace gtx

@@ -1,0 +1,511 @@
+// score_core.hpp -- per read / per mate pair work of the scoring kernel (one thread per score item).
+//
+// Restates, over the alignment records in HBM and integer atomics into flat accumulators:
+//   update_unpaired_read_paths / update_paths / get_better_paths      src/typer/alignment.cpp:365-620
+//   compare_pair_of_genotype_paths (single and pair)                   src/typer/genotype_paths.cpp:943-1169
+//   are_genotype_paths_good, push_to_haplotype_scores, update_haplotype_scores_geno  src/typer/vcf_writer.cpp:28-250,503-676
+//   Haplotype::add_coverage / *_to_stats / explain_to_score / coverage_to_gts        src/graph/haplotype.cpp:180-585
+// Every effect of a read on shared state is an integer addition, so the order in which items are scored does not
+// matter below the saturation guard of explain_to_score (checked by gtx_scores_finalize).
+#pragma once
+#include "align_core.hpp"
+
+namespace gtx
+{
+constexpr uint16_t F_PAIRED = 1, F_PROPER_PAIR = 2, F_UNMAPPED = 4, F_SEQ_REVERSED = 16, F_FIRST_IN_PAIR = 64, F_MAPQ_BAD = 4096;
+constexpr uint32_t NO_COVERAGE = 0xFFFFu, MULTI_ALT_COVERAGE = 0xFFFEu, MULTI_REF_COVERAGE = 0xFFFDu; // haplotype.hpp:86-88
+constexpr uint32_t SCORE_MAX_HAPS = 24; // distinct variant sites one read can touch in this kernel
+
+struct ScoreParams
+{
+  uint32_t is_sv_graph, hq_reads, is_segment_calling, pad;
+};
+
+struct RecPath
+{
+  uint32_t start, end, rs, re, mism, nvar;
+  uint32_t const * vars; // nvar * (site, mask_lo, mask_hi)
+};
+
+struct Geno // one GenotypePaths as seen by the scorer
+{
+  uint32_t const * rec;
+  uint32_t n_paths, longest, read_len;
+  uint32_t flags, mapq, score_diff;
+  bool proper_pair; // ml_insert_size != INSERT_SIZE_WHEN_NOT_PROPER_PAIR
+};
+
+GTX_DEV Geno geno_of(uint32_t const * records, uint32_t rec_words, uint32_t align_index, uint32_t orient)
+{
+  Geno g;
+  g.rec = records + (static_cast<uint64_t>(align_index) * 2 + orient) * rec_words;
+  g.n_paths = g.rec[0] & 0xFFFFu;
+  g.longest = g.rec[1] & 0xFFFFu;
+  g.read_len = g.rec[1] >> 16;
+  g.flags = 0;
+  g.mapq = 255;
+  g.score_diff = 0;
+  g.proper_pair = false;
+  return g;
+}
+
+GTX_DEV uint32_t const * path_at(uint32_t const * w, RecPath & p) // returns the position behind the path
+{
+  p.start = w[0];
+  p.end = w[1];
+  p.rs = w[2] & 0xFFFFu;
+  p.re = w[2] >> 16;
+  p.mism = w[3] & 0xFFFFu;
+  p.nvar = w[3] >> 16;
+  p.vars = w + 4;
+  return w + 4 + 3 * p.nvar;
+}
+
+GTX_DEV uint32_t first_mismatches(Geno const & g) // paths[0].mismatches
+{
+  return g.rec[2 + 3] & 0xFFFFu;
+}
+
+GTX_DEV uint32_t alternative_call_count(Geno const & g) // genotype_paths.cpp:1040-1053
+{
+  uint32_t c = 0;
+  uint32_t const * w = g.rec + 2;
+  for (uint32_t i = 0; i < g.n_paths; ++i)
+  {
+    RecPath p;
+    w = path_at(w, p);
+    for (uint32_t k = 0; k < p.nvar; ++k)
+      c += (p.vars[3 * k + 1] & 1u) == 0u;
+  }
+  return c;
+}
+
+// genotype_paths.cpp:943-974
+GTX_DEV int compare_single(Geno const & g1, Geno const & g2)
+{
+  uint32_t const t1 = g1.longest, t2 = g2.longest, MIN = 94;
+  if (t1 > t2 && t1 > MIN)
+    return 1;
+  if (t2 > t1 && t2 > MIN)
+    return 2;
+  if (t1 == t2 && t1 > MIN)
+    return first_mismatches(g2) < first_mismatches(g1) ? 2 : 1;
+  return 0;
+}
+
+// genotype_paths.cpp:976-1169
+GTX_DEV int compare_pairs(Geno const & a1, Geno const & a2, Geno const & b1, Geno const & b2)
+{
+  uint32_t const T11 = a1.n_paths ? a1.longest : 0, T12 = a2.n_paths ? a2.longest : 0;
+  uint32_t const T21 = b1.n_paths ? b1.longest : 0, T22 = b2.n_paths ? b2.longest : 0;
+  uint32_t const M1 = T11 > T12 ? T11 : T12, M2 = T21 > T22 ? T21 : T22;
+  uint32_t const P1 = a1.read_len, P2 = a2.read_len, MIN = 94;
+  bool const perfect1 = T11 >= P1 && T12 >= P2, perfect2 = T21 >= P1 && T22 >= P2;
+  if (perfect1 || perfect2)
+  {
+    if (perfect1 && perfect2)
+    {
+      uint32_t const mm1 = first_mismatches(a1) + first_mismatches(a2), mm2 = first_mismatches(b1) + first_mismatches(b2);
+      if (mm1 != mm2)
+        return mm1 < mm2 ? 1 : 2;
+      uint32_t const n1 = a1.n_paths + a2.n_paths, n2 = b1.n_paths + b2.n_paths;
+      if (n1 != n2)
+        return n1 < n2 ? 1 : 2;
+      return alternative_call_count(a1) + alternative_call_count(a2) >= alternative_call_count(b1) + alternative_call_count(b2) ? 1 : 2;
+    }
+    return perfect1 ? 1 : 2;
+  }
+  if (M2 >= MIN && M2 > M1)
+    return 2;
+  if (M1 >= MIN && M1 > M2)
+    return 1;
+  if (M1 >= MIN && M2 >= MIN)
+  {
+    uint32_t mm1 = 10, mm2 = 10;
+    if (T11 == M1 && first_mismatches(a1) < mm1)
+      mm1 = first_mismatches(a1);
+    if (T12 == M1 && first_mismatches(a2) < mm1)
+      mm1 = first_mismatches(a2);
+    if (T21 == M2 && first_mismatches(b1) < mm2)
+      mm2 = first_mismatches(b1);
+    if (T22 == M2 && first_mismatches(b2) < mm2)
+      mm2 = first_mismatches(b2);
+    if (mm1 != mm2)
+      return mm1 < mm2 ? 1 : 2;
+    uint32_t const mn1 = T11 < T12 ? T11 : T12, mn2 = T21 < T22 ? T21 : T22;
+    if (mn1 < mn2)
+      return 1;
+    if (mn2 < mn1)
+      return 2;
+    return 0;
+  }
+  if (M2 == 0u && T11 >= 63u && T12 >= 63u)
+    return 1;
+  if (M1 == 0u && T21 >= 63u && T22 >= 63u)
+    return 2;
+  return 1;
+}
+
+// vcf_writer.cpp:28-60
+GTX_DEV bool geno_is_good(GraphView const & g, ScoreParams const & par, Geno const & ge, bool & fully, bool & unique)
+{
+  fully = true;
+  unique = true;
+  if (ge.n_paths == 0)
+    return false;
+  uint32_t const * w = ge.rec + 2;
+  RecPath p0;
+  uint32_t r0s = 0, r0e = 0;
+  for (uint32_t i = 0; i < ge.n_paths; ++i)
+  {
+    RecPath p;
+    w = path_at(w, p);
+    if (p.re - p.rs + 1u != ge.read_len)
+      fully = false;
+    uint32_t const rs_ = g_ref_reach_pos(g, p.start), re_ = g_ref_reach_pos(g, p.end);
+    if (i == 0)
+    {
+      p0 = p;
+      r0s = rs_;
+      r0e = re_;
+    }
+    else if (r0s != rs_ && r0e != re_)
+      unique = false; // all_paths_unique (genotype_paths.cpp:219-231)
+  }
+  uint32_t const size0 = p0.re - p0.rs + 1u;
+  if (!fully && (!unique || size0 < 63))
+    return false;
+  double const ratio = static_cast<double>(p0.mism) / static_cast<double>(size0);
+  if (ratio > 0.05)
+    return false;
+  if (!fully && ratio > 0.025)
+    return false;
+  if (par.is_sv_graph && (!fully || size0 < 90 || ratio > 0.03))
+    return false;
+  if (par.hq_reads && (!fully || size0 < 90 || ratio > 0.035))
+    return false;
+  return true;
+}
+
+struct RecentHap // one entry of `recent_ids` + the haplotype's transient explains/coverage (vcf_writer.cpp:519-585)
+{
+  uint32_t site;
+  uint32_t coverage;
+  uint64_t explains;
+  bool overlapping;
+};
+
+GTX_DEV uint32_t add_coverage(uint32_t coverage, uint32_t c) // haplotype.cpp:180-227
+{
+  if (coverage == NO_COVERAGE)
+    return c;
+  if (coverage == MULTI_ALT_COVERAGE)
+    return c == 0 ? MULTI_REF_COVERAGE : coverage;
+  if (coverage == MULTI_REF_COVERAGE)
+    return coverage;
+  if (coverage != c)
+    return (coverage == 0 || c == 0) ? MULTI_REF_COVERAGE : MULTI_ALT_COVERAGE;
+  return coverage;
+}
+
+struct ScoreAcc // device pointers, see gtx_score_buffers in include/gtx.h
+{
+  uint32_t n_samples;
+  uint32_t conn_cap;
+  uint32_t * log_score;
+  uint32_t * gt_cov;
+  uint32_t * hap_u32;
+  unsigned long long * stat_u64;
+  uint32_t * stat_u32;
+  uint32_t * conn_log;
+  uint32_t * conn_count;
+};
+
+template <class W>
+GTX_DEV void emit_conn(ScoreAcc const & acc, uint32_t sample, uint32_t h1, uint32_t b1, uint32_t h2, uint32_t b2, uint32_t count)
+{
+  if (count == 0)
+    return;
+  uint32_t const slot = W::atomic_add_u32(acc.conn_count, 1u);
+  if (slot >= acc.conn_cap)
+  {
+    W::atomic_add_u32(acc.conn_count + 1, 1u);
+    return;
+  }
+  uint32_t * e = acc.conn_log + static_cast<uint64_t>(slot) * 6;
+  e[0] = sample;
+  e[1] = h1;
+  e[2] = b1;
+  e[3] = h2;
+  e[4] = b2;
+  e[5] = count;
+}
+
+// push_to_haplotype_scores (vcf_writer.cpp:503-676).  Fills `recent` (ascending site) for the connection merge of the
+// caller; returns the number of entries, or 0xFFFFFFFF when the read touches more sites than SCORE_MAX_HAPS.
+template <class W>
+GTX_DEV uint32_t push_to_haplotype_scores(GraphView const & g, ScoreAcc const & acc, Geno const & ge, bool fully, bool unique,
+                                          uint32_t sample, RecentHap * recent)
+{
+  uint32_t const clipped_bp = ge.read_len - ge.longest;
+  uint32_t const mismatches = first_mismatches(ge);
+  uint32_t n = 0;
+  uint32_t const * w = ge.rec + 2;
+  for (uint32_t i = 0; i < ge.n_paths; ++i)
+  {
+    RecPath p;
+    w = path_at(w, p);
+    int64_t const s_reach = g_ref_reach_pos(g, p.start), e_reach = g_ref_reach_pos(g, p.end);
+    for (uint32_t k = 0; k < p.nvar; ++k)
+    {
+      uint32_t const site = p.vars[3 * k];
+      uint64_t const mask = (static_cast<uint64_t>(p.vars[3 * k + 2]) << 32) | p.vars[3 * k + 1];
+      if (mask == 0)
+        continue;
+      int64_t const order = site_order(g, site);
+      bool const overlapping = s_reach + 3 <= order && e_reach - 3 > order;
+      uint32_t j = 0;
+      for (; j < n; ++j)
+        if (recent[j].site == site)
+          break;
+      if (j == n)
+      {
+        if (n >= SCORE_MAX_HAPS)
+          return 0xFFFFFFFFu;
+        recent[n++] = RecentHap{site, NO_COVERAGE, 0, false};
+      }
+      RecentHap & rh = recent[j];
+      rh.overlapping = rh.overlapping || overlapping;
+      rh.explains |= mask;
+      if ((mask & (mask - 1)) == 0)
+        rh.coverage = add_coverage(rh.coverage, static_cast<uint32_t>(__builtin_ctzll(mask)));
+      else
+      {
+        rh.coverage = add_coverage(rh.coverage, 1);
+        rh.coverage = add_coverage(rh.coverage, (mask & 1ull) ? 0u : 2u);
+      }
+    }
+  }
+  // std::map order: ascending haplotype index
+  for (uint32_t a = 1; a < n; ++a)
+  {
+    RecentHap const x = recent[a];
+    uint32_t b = a;
+    while (b > 0 && recent[b - 1].site > x.site)
+    {
+      recent[b] = recent[b - 1];
+      --b;
+    }
+    recent[b] = x;
+  }
+  // connections between the sites of this read (vcf_writer.cpp:587-636)
+  for (uint32_t a = 0; a < n; ++a)
+  {
+    uint32_t const n1 = static_cast<uint32_t>(__builtin_popcountll(recent[a].explains));
+    if (n1 == 0 || n1 > 64)
+      continue;
+    for (uint32_t b = a + 1; b < n; ++b)
+    {
+      uint32_t const n2 = static_cast<uint32_t>(__builtin_popcountll(recent[b].explains));
+      if (n2 == 0 || n2 > 64)
+        continue;
+      uint32_t const weight = n1 * n2;
+      uint32_t const repeat = weight >= 3 ? 6 / weight : 1;
+      if (repeat == 0)
+        continue;
+      for (uint64_t m1 = recent[a].explains; m1; m1 &= m1 - 1)
+        for (uint64_t m2 = recent[b].explains; m2; m2 &= m2 - 1)
+          emit_conn<W>(acc, sample, recent[a].site, static_cast<uint32_t>(__builtin_ctzll(m1)), recent[b].site,
+                       static_cast<uint32_t>(__builtin_ctzll(m2)), repeat);
+    }
+  }
+  // move the explanations to statistics, likelihood and depth (vcf_writer.cpp:638-673)
+  uint64_t const nh = g.n_hap;
+  for (uint32_t a = 0; a < n; ++a)
+  {
+    RecentHap const & rh = recent[a];
+    uint32_t const h = rh.site;
+    uint32_t const cnum = g.ref_nvar[h];
+    uint64_t const aoff = g.allele_off[h];
+    uint32_t const cov = rh.coverage;
+    bool const unique_allele = cov < MULTI_REF_COVERAGE;
+    // clipped_reads_to_stats (haplotype.cpp:229-244)
+    if (clipped_bp != 0)
+    {
+      if (cov != NO_COVERAGE)
+        W::atomic_add_u32(acc.stat_u32 + h, 1u);
+      if (unique_allele)
+        W::atomic_add_u64(acc.stat_u64 + nh + 2 * (aoff + cov) + 0, (static_cast<uint64_t>(clipped_bp) * 1000u) / ge.read_len);
+    }
+    // mapq_to_stats (:246-261)
+    if (ge.mapq != 255)
+    {
+      uint64_t const sq = static_cast<uint64_t>(ge.mapq) * ge.mapq;
+      if (cov != NO_COVERAGE)
+        W::atomic_add_u64(acc.stat_u64 + h, sq);
+      if (unique_allele)
+        W::atomic_add_u64(acc.stat_u64 + nh + 2 * (aoff + cov) + 1, sq);
+    }
+    if (unique_allele)
+    {
+      uint32_t * s32 = acc.stat_u32 + nh + 6 * (aoff + cov);
+      // strand_to_stats (:263-287)
+      bool const fwd = (ge.flags & F_SEQ_REVERSED) == 0, first = (ge.flags & F_FIRST_IN_PAIR) != 0;
+      W::atomic_add_u32(s32 + (fwd ? (first ? 2 : 4) : (first ? 3 : 5)), 1u);
+      // mismatches_to_stats (:289-300), uint8_t argument
+      uint32_t const mm8 = mismatches & 0xFFu;
+      if (mm8 != 0)
+        W::atomic_add_u32(s32 + 1, (mm8 * 1000u) / ge.read_len);
+      // score_diff_to_stats (:302-311)
+      if (ge.score_diff != 0)
+        W::atomic_add_u32(s32 + 0, ge.score_diff);
+    }
+    // explain_to_score (:462-585)
+    long e = 12;
+    e -= static_cast<long>(mismatches);
+    if (!unique)
+      e -= 3;
+    if (ge.flags & F_MAPQ_BAD)
+      e -= 2;
+    if (!fully)
+      e -= 3;
+    if (!rh.overlapping)
+      e -= 1;
+    uint32_t const eps = static_cast<uint32_t>((e > 8 ? e : 8) - 4);
+    uint32_t * cell = acc.hap_u32 + (static_cast<uint64_t>(sample) * nh + h) * 4;
+    W::atomic_add_u32(cell + 0, eps);
+    uint32_t * ls = acc.log_score + static_cast<uint64_t>(sample) * g.total_tri + g.tri_off[h];
+    uint32_t idx = 0;
+    for (uint32_t y = 0; y < cnum; ++y)
+    {
+      bool const ey = (rh.explains >> y) & 1ull;
+      for (uint32_t x = 0; x <= y; ++x, ++idx)
+      {
+        bool const ex = (rh.explains >> x) & 1ull;
+        if (ex && ey)
+          W::atomic_add_u32(ls + idx, eps);
+        else if (ex || ey)
+          W::atomic_add_u32(ls + idx, eps - 1);
+      }
+    }
+    // coverage_to_gts (:315-361)
+    if (cov == MULTI_REF_COVERAGE)
+      W::atomic_add_u32(cell + 1, 1u);
+    else if (cov == MULTI_ALT_COVERAGE)
+    {
+      W::atomic_add_u32(cell + 1, 1u);
+      W::atomic_add_u32(cell + 2, 1u);
+      if (ge.proper_pair)
+        W::atomic_add_u32(cell + 3, 1u);
+    }
+    else if (cov != NO_COVERAGE)
+    {
+      W::atomic_add_u32(acc.gt_cov + static_cast<uint64_t>(sample) * g.total_allele + aoff + cov, 1u);
+      if (cov > 0 && ge.proper_pair)
+        W::atomic_add_u32(cell + 3, 1u);
+    }
+  }
+  return n;
+}
+
+// one call of genotype_only() that reaches the writer (hts_parallel_reader.cpp:283-337)
+template <class W>
+GTX_DEV void score_item(GraphView const & g, ScoreParams const & par, gtx_score_item const & it, uint32_t const * records,
+                        uint32_t rec_words, ScoreAcc const & acc, uint32_t * error_flag)
+{
+  RecentHap r1[SCORE_MAX_HAPS], r2[SCORE_MAX_HAPS];
+  if (it.second.align_index == INVALID)
+  {
+    // update_unpaired_read_paths (alignment.cpp:365-455).  clipped_count() returns 0/1, so IS_CLIPPED is never set.
+    gtx_rec_meta const & m = it.first;
+    Geno fwd = geno_of(records, rec_words, m.align_index, 0), rev = geno_of(records, rec_words, m.align_index, 1);
+    int const which = compare_single(fwd, rev);
+    if (which == 0)
+      return;
+    Geno & ge = which == 1 ? fwd : rev;
+    ge.flags = (which == 1 ? m.flag : (m.flag ^ F_SEQ_REVERSED)) & ~static_cast<uint32_t>(F_PROPER_PAIR) & 0xFFFFu;
+    ge.mapq = m.mapq;
+    if (m.mapq < 25)
+      ge.flags |= F_MAPQ_BAD;
+    ge.score_diff = m.score_diff;
+    if (par.is_segment_calling)
+      return;
+    bool fully, unique;
+    if (geno_is_good(g, par, ge, fully, unique))
+      if (push_to_haplotype_scores<W>(g, acc, ge, fully, unique, it.sample, r1) == 0xFFFFFFFFu)
+        W::atomic_add_u32(error_flag, 1u);
+    return;
+  }
+  // update_paths for both records (alignment.cpp:482-545): only the forward-orientation geno gets IS_MAPQ_BAD
+  Geno q[4];
+  gtx_rec_meta const * ms[2] = {&it.first, &it.second};
+  for (int r = 0; r < 2; ++r)
+  {
+    gtx_rec_meta const & m = *ms[r];
+    Geno & f = q[2 * r];
+    Geno & v = q[2 * r + 1];
+    f = geno_of(records, rec_words, m.align_index, 0);
+    v = geno_of(records, rec_words, m.align_index, 1);
+    f.flags = (m.flag & ~static_cast<uint32_t>(F_PROPER_PAIR)) & 0xFFFFu;
+    if (m.mapq < 25)
+      f.flags |= F_MAPQ_BAD;
+    v.flags = ((m.flag ^ F_SEQ_REVERSED) & ~static_cast<uint32_t>(F_PROPER_PAIR)) & 0xFFFFu;
+    f.mapq = v.mapq = m.mapq;
+    f.score_diff = v.score_diff = m.score_diff;
+    f.proper_pair = v.proper_pair = true; // ml_insert_size = |isize|, never INSERT_SIZE_WHEN_NOT_PROPER_PAIR for int32 isize
+  }
+  // get_better_paths (alignment.cpp:557-620)
+  int arr[4] = {-1, -1, -1, -1};
+  for (int k = 0; k < 4; ++k)
+    arr[((q[k].flags & F_FIRST_IN_PAIR) != 0) + 2 * ((q[k].flags & F_SEQ_REVERSED) == 0)] = k;
+  if (arr[0] < 0 || arr[1] < 0 || arr[2] < 0 || arr[3] < 0)
+    return;
+  int const which = compare_pairs(q[arr[3]], q[arr[0]], q[arr[1]], q[arr[2]]);
+  if (which == 0)
+    return;
+  Geno & first = which == 1 ? q[arr[3]] : q[arr[1]];
+  Geno & second = which == 1 ? q[arr[0]] : q[arr[2]];
+  first.flags |= F_PROPER_PAIR;
+  second.flags |= F_PROPER_PAIR;
+  // update_haplotype_scores_geno, pair overload (vcf_writer.cpp:143-250)
+  bool f1, u1, f2, u2;
+  bool const good1 = geno_is_good(g, par, first, f1, u1), good2 = geno_is_good(g, par, second, f2, u2);
+  if (par.is_segment_calling && (!good1 || !good2))
+    return;
+  uint32_t n1 = 0, n2 = 0;
+  if (good1)
+    n1 = push_to_haplotype_scores<W>(g, acc, first, f1, u1, it.sample, r1);
+  if (good2)
+    n2 = push_to_haplotype_scores<W>(g, acc, second, f2, u2, it.sample, r2);
+  if (n1 == 0xFFFFFFFFu || n2 == 0xFFFFFFFFu)
+  {
+    W::atomic_add_u32(error_flag, 1u);
+    return;
+  }
+  // cross links between the two mates' sites: every (site, allele) key of one mate gets one count towards every key
+  // of the other mate that lies on a later site (vcf_writer.cpp:186-227)
+  for (uint32_t a = 0; a < n1; ++a)
+  {
+    uint32_t const c1 = static_cast<uint32_t>(__builtin_popcountll(r1[a].explains));
+    if (c1 == 0 || c1 > 64)
+      continue;
+    for (uint32_t b = 0; b < n2; ++b)
+    {
+      uint32_t const c2 = static_cast<uint32_t>(__builtin_popcountll(r2[b].explains));
+      if (c2 == 0 || c2 > 64 || r1[a].site == r2[b].site)
+        continue;
+      bool const fwd = r2[b].site > r1[a].site;
+      for (uint64_t m1 = r1[a].explains; m1; m1 &= m1 - 1)
+        for (uint64_t m2 = r2[b].explains; m2; m2 &= m2 - 1)
+        {
+          uint32_t const b1 = static_cast<uint32_t>(__builtin_ctzll(m1)), b2 = static_cast<uint32_t>(__builtin_ctzll(m2));
+          if (fwd)
+            emit_conn<W>(acc, it.sample, r1[a].site, b1, r2[b].site, b2, 1);
+          else
+            emit_conn<W>(acc, it.sample, r2[b].site, b2, r1[a].site, b1, 1);
+        }
+    }
+  }
+}
+
+} // namespace gtx

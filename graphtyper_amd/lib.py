@@ -1,0 +1,370 @@
+"""ctypes binding of libgtx.so (C ABI in include/gtx.h) + helpers that build the SoA graph view from variant records.
+
+PyTorch is used by callers only for device memory, streams and torch.distributed; everything that touches reads runs
+inside libgtx's HIP kernels.  There is no CPU path: without the built library or without a GPU the calls fail loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "libgtx.so")
+INVALID_ID = 0xFFFFFFFF
+SPECIAL_START = 0xD0000000
+
+ST_LABEL_OVERFLOW, ST_PATH_OVERFLOW, ST_DFS_OVERFLOW, ST_RECORD_OVERFLOW = 1, 2, 4, 8
+
+# names every build of libgtx.so must export (checked by tests/test_abi.py against include/gtx.h)
+EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy", "gtx_ctx_special_positions",
+           "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_index_stats", "gtx_index_get", "gtx_index_dump",
+           "gtx_align_batch", "gtx_score_batch", "gtx_ctx_error_count", "gtx_scores_finalize", "gtx_stream_create",
+           "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_counts"]
+
+
+class GraphView(C.Structure):
+    _fields_ = [("n_ref", C.c_uint32), ("n_var", C.c_uint32),
+                ("ref_order", C.c_void_p), ("ref_len", C.c_void_p), ("ref_dna_off", C.c_void_p), ("ref_nvar", C.c_void_p),
+                ("ref_first_var", C.c_void_p), ("var_order", C.c_void_p), ("var_len", C.c_void_p),
+                ("var_dna_off", C.c_void_p), ("var_out_ref", C.c_void_p), ("dna", C.c_void_p), ("dna_len", C.c_uint64),
+                ("event_off", C.c_void_p), ("event_val", C.c_void_p)]
+
+
+class Params(C.Structure):
+    _fields_ = [("max_index_labels", C.c_int32), ("is_sv_graph", C.c_int32), ("hq_reads", C.c_int32),
+                ("force_align_both_orientations", C.c_int32), ("is_segment_calling", C.c_int32),
+                ("sam_flag_filter", C.c_int32)]
+
+
+class ScoreLayout(C.Structure):
+    _fields_ = [("n_hap", C.c_uint32), ("total_tri", C.c_uint64), ("total_allele", C.c_uint64)]
+
+
+class ScoreBuffers(C.Structure):
+    _fields_ = [("n_samples", C.c_uint32), ("d_log_score", C.c_void_p), ("d_gt_cov", C.c_void_p), ("d_hap_u32", C.c_void_p),
+                ("d_stat_u64", C.c_void_p), ("d_stat_u32", C.c_void_p), ("d_conn_log", C.c_void_p),
+                ("d_conn_count", C.c_void_p), ("conn_cap", C.c_uint32)]
+
+
+READ_META = np.dtype([("l_qseq", np.uint16), ("flag", np.uint16), ("tid", np.int32), ("mtid", np.int32), ("isize", np.int32)], align=True)
+REC_META = np.dtype([("align_index", np.uint32), ("flag", np.uint16), ("mapq", np.uint8), ("score_diff", np.uint8),
+                     ("pos", np.int32), ("isize", np.int32)], align=True)
+SCORE_ITEM = np.dtype([("first", REC_META), ("second", REC_META), ("sample", np.uint32), ("reserved", np.uint32)], align=True)
+STREAM_RECORD = np.dtype([("flag", np.uint16), ("mapq", np.uint8), ("score_diff", np.uint8), ("tid", np.int32),
+                          ("mtid", np.int32), ("pos", np.int32), ("isize", np.int32), ("l_qseq", np.uint16),
+                          ("rg", np.uint16), ("sample", np.uint32), ("name_id", np.uint64)], align=True)
+LABEL = np.dtype([("start_index", np.uint32), ("end_index", np.uint32), ("variant_id", np.uint32)], align=True)
+assert READ_META.itemsize == 16 and REC_META.itemsize == 16 and SCORE_ITEM.itemsize == 40 and STREAM_RECORD.itemsize == 40
+
+
+def build(force=False):
+    """compile libgtx.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)"""
+    src_dir = os.path.join(HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir)] + [os.path.join(ROOT, "include", "gtx.h")]
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+        subprocess.check_call(["make", "-C", src_dir, "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """the loaded library; raises if it has not been built (never falls back to anything else)"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libgtx.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        L.gtx_strerror.restype = C.c_char_p
+        L.gtx_strerror.argtypes = [C.c_int]
+        L.gtx_last_error.restype = C.c_char_p
+        L.gtx_ctx_create.argtypes = [C.POINTER(GraphView), C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]
+        L.gtx_ctx_destroy.argtypes = [C.c_void_p]
+        L.gtx_ctx_special_positions.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_uint32]
+        L.gtx_ctx_score_layout.argtypes = [C.c_void_p, C.POINTER(ScoreLayout)]
+        L.gtx_ctx_haplotypes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gtx_index_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.gtx_index_get.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.gtx_index_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gtx_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                      C.c_void_p]
+        L.gtx_score_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(ScoreBuffers),
+                                      C.c_void_p]
+        L.gtx_ctx_error_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.gtx_scores_finalize.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                          C.POINTER(C.c_uint64)]
+        L.gtx_stream_create.argtypes = [C.POINTER(Params), C.c_uint32, C.POINTER(C.c_void_p)]
+        L.gtx_stream_destroy.argtypes = [C.c_void_p]
+        L.gtx_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                      C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.gtx_stream_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        _lib = L
+    return _lib
+
+
+class GtxError(RuntimeError):
+    def __init__(self, status):
+        L = lib()
+        self.status = status
+        super().__init__("%s: %s" % (L.gtx_strerror(status).decode(), L.gtx_last_error().decode()))
+
+
+def check(status):
+    if status != 0:
+        raise GtxError(status)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# host-side graph construction from variant records (the subset of Graph::add_genomic_region, src/graph/graph.cpp:41-339,
+# that needs no record merging: add_all_variants=false and no record overlaps the next one; merged multi-allelic sites
+# are SURVEY.md 8(f) row 1)
+# ------------------------------------------------------------------------------------------------------------------
+def parse_events(info):
+    """GT_ID / GT_ANTI_HAPLOTYPE of a single-alt record (src/graph/constructor.cpp:1540-1588) ->
+    (ref_events, alt_events, alt_anti_events)"""
+    ref_ev, alt_ev, alt_anti = [], [], []
+    if info and info != ".":
+        for kv in info.split(";"):
+            if "=" not in kv:
+                continue
+            k, v = kv.split("=", 1)
+            if k == "GT_ID":
+                ref_ev.append(-int(v))
+                alt_ev.append(int(v))
+            elif k == "GT_ANTI_HAPLOTYPE":
+                alt_anti.extend(int(x) for x in v.split(","))
+    return ref_ev, alt_ev, alt_anti
+
+
+def common_suffix_size(ref, alts):  # VarRecord::get_common_suffix (src/graph/var_record.cpp:381-406)
+    if not ref or any(len(a) == 0 for a in alts):
+        return 0
+    n = 0
+    while n < len(ref) - 1 and all(n < len(a) - 1 and a[len(a) - 1 - n] == ref[len(ref) - 1 - n] for a in alts):
+        n += 1
+    return n
+
+
+def graph_from_records(reference, records, region_begin=0, region_end=0xFFFFFFFF):
+    """reference: str of the region; records: [(pos0, ref, [alts], info)] sorted by pos0 (contig coordinates, 0-based).
+    Returns a dict of numpy arrays laid out as gtx_graph_view expects."""
+    recs = []
+    for pos, ref, alts, info in records:  # graph.cpp:48-80
+        ev = parse_events(info) if len(alts) == 1 else ([], [], [])
+        alts = [(a, ev[1], ev[2]) for a in alts if a and "N" not in a]
+        if "N" in ref or "*" in ref or not alts or pos < region_begin:
+            continue
+        if pos >= region_end:
+            break
+        recs.append([pos, ref, alts, ev[0]])
+    for a, b in zip(recs, recs[1:]):
+        if b[0] < a[0] + len(a[1]):
+            raise ValueError("overlapping variant records need the reference's merge rules (not built yet)")
+    out = []
+    for pos, ref, alts, ref_ev in recs:  # graph.cpp:243-293
+        alts = [a for a in alts if a[0] != ref]
+        if not alts:
+            continue
+        if len(alts) >= 2559:
+            alts = alts[:2558]
+        n = common_suffix_size(ref, [a[0] for a in alts])
+        if n:
+            ref = ref[:-n]
+            alts = [(a[0][:-n], a[1], a[2]) for a in alts]
+        alts.sort(key=lambda a: a[0])
+        out.append((pos, ref, alts, ref_ev))
+    ref_order, ref_seq, ref_nvar, ref_first_var = [], [], [], []
+    var_order, var_seq, var_out_ref, var_events = [], [], [], []
+    start = region_begin
+    L = len(reference)
+
+    def ref_slice(a, b):
+        a, b = min(max(a - region_begin, 0), L), min(max(b - region_begin, 0), L)
+        return reference[a:b]
+
+    for pos, ref, alts, ref_ev in out:  # graph.cpp:295-301 -> add_reference :584-625, add_variants :548-582
+        end = max(start, min(pos, L + region_begin))
+        ref_order.append(start + 1)
+        ref_seq.append(ref_slice(start, end))
+        ref_nvar.append(len(alts) + 1)
+        ref_first_var.append(len(var_order))
+        nxt = len(ref_order)
+        var_order.append(pos + 1)
+        var_seq.append(ref)
+        var_out_ref.append(nxt)
+        var_events.append((ref_ev, []))
+        for a, ev, anti in alts:
+            var_order.append(pos + 1)
+            var_seq.append(a)
+            var_out_ref.append(nxt)
+            var_events.append((ev, anti))
+        start = pos + len(ref)
+    ref_order.append(start + 1)
+    ref_seq.append(ref_slice(start, L + region_begin))
+    ref_nvar.append(0)
+    ref_first_var.append(INVALID_ID)
+    dna = "".join(ref_seq) + "".join(var_seq)
+    ref_len = np.array([len(s) for s in ref_seq], np.uint32)
+    var_len = np.array([len(s) for s in var_seq], np.uint32)
+    ref_off = np.concatenate([[0], np.cumsum(ref_len)[:-1]]).astype(np.uint32)
+    base = int(ref_len.sum())
+    var_off = (base + np.concatenate([[0], np.cumsum(var_len)[:-1]])).astype(np.uint32) if len(var_len) else np.zeros(0, np.uint32)
+    ev_off = [0]
+    ev_val = []
+    for ev, anti in var_events:
+        ev_val.extend(sorted(ev))
+        ev_off.append(len(ev_val))
+        ev_val.extend(sorted(anti))
+        ev_off.append(len(ev_val))
+    return dict(ref_order=np.array(ref_order, np.uint32), ref_len=ref_len, ref_dna_off=ref_off,
+                ref_nvar=np.array(ref_nvar, np.uint32), ref_first_var=np.array(ref_first_var, np.uint32),
+                var_order=np.array(var_order, np.uint32), var_len=var_len, var_dna_off=var_off,
+                var_out_ref=np.array(var_out_ref, np.uint32), dna=np.frombuffer(dna.encode(), np.uint8).copy(),
+                event_off=np.array(ev_off, np.uint32), event_val=np.array(ev_val, np.int64))
+
+
+def pack_nibbles(codes, stride=None):
+    """[n, L] 4-bit codes -> [n, stride] BAM-packed bytes (high nibble first)"""
+    codes = np.asarray(codes, np.uint8)
+    n, L = codes.shape
+    nb = (L + 1) // 2
+    stride = stride or ((nb + 15) // 16) * 16
+    if L % 2:
+        codes = np.concatenate([codes, np.zeros((n, 1), np.uint8)], axis=1)
+    out = np.zeros((n, stride), np.uint8)
+    out[:, :nb] = (codes[:, 0::2] << 4) | codes[:, 1::2]
+    return out
+
+
+class Context:
+    """gtx_ctx: flat graph + index (host) and, for device >= 0, their copies in HBM"""
+
+    def __init__(self, graph, device=0, max_index_labels=75, is_sv_graph=False, hq_reads=False, force_both=False,
+                 is_segment_calling=False, sam_flag_filter=3840):
+        L = lib()
+        self.g = {k: np.ascontiguousarray(v) for k, v in graph.items()}
+        g = self.g
+        has_ev = len(g.get("event_val", ())) > 0
+        self.view = GraphView(len(g["ref_order"]), len(g["var_order"]), _p(g["ref_order"]), _p(g["ref_len"]),
+                              _p(g["ref_dna_off"]), _p(g["ref_nvar"]), _p(g["ref_first_var"]), _p(g["var_order"]),
+                              _p(g["var_len"]), _p(g["var_dna_off"]), _p(g["var_out_ref"]), _p(g["dna"]), len(g["dna"]),
+                              _p(g["event_off"]) if has_ev else None, _p(g["event_val"]) if has_ev else None)
+        self.params = Params(max_index_labels, int(is_sv_graph), int(hq_reads), int(force_both), int(is_segment_calling),
+                             sam_flag_filter)
+        h = C.c_void_p()
+        check(L.gtx_ctx_create(C.byref(self.view), C.byref(self.params), device, C.byref(h)))
+        self.h = h
+        self.device = device
+        lay = ScoreLayout()
+        check(L.gtx_ctx_score_layout(self.h, C.byref(lay)))
+        self.n_hap, self.total_tri, self.total_allele = int(lay.n_hap), int(lay.total_tri), int(lay.total_allele)
+        self.hap_order = np.zeros(self.n_hap, np.uint32)
+        self.hap_cnum = np.zeros(self.n_hap, np.uint32)
+        self.tri_off = np.zeros(self.n_hap, np.uint64)
+        self.allele_off = np.zeros(self.n_hap, np.uint64)
+        check(L.gtx_ctx_haplotypes(self.h, _p(self.hap_order), _p(self.hap_cnum), _p(self.tri_off), _p(self.allele_off)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gtx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def special_positions(self):
+        L = lib()
+        n = C.c_uint32()
+        check(L.gtx_ctx_special_positions(self.h, C.byref(n), None, None, 0))
+        rr, ap = np.zeros(n.value, np.uint32), np.zeros(n.value, np.uint32)
+        check(L.gtx_ctx_special_positions(self.h, C.byref(n), _p(rr), _p(ap), n.value))
+        return rr, ap
+
+    def index_stats(self):
+        nk, nl = C.c_uint64(), C.c_uint64()
+        check(lib().gtx_index_stats(self.h, C.byref(nk), C.byref(nl)))
+        return int(nk.value), int(nl.value)
+
+    def index_get(self, key):
+        out = np.zeros(4096, LABEL)
+        n = C.c_uint32()
+        check(lib().gtx_index_get(self.h, C.c_uint64(key), _p(out), 4096, C.byref(n)))
+        return [tuple(int(x) for x in out[i]) for i in range(n.value)]
+
+    def index_dump(self):
+        nk, nl = self.index_stats()
+        keys, counts, labels = np.zeros(nk, np.uint64), np.zeros(nk, np.uint32), np.zeros(nl, LABEL)
+        check(lib().gtx_index_dump(self.h, _p(keys), _p(counts), _p(labels)))
+        lab = np.stack([labels["start_index"], labels["end_index"], labels["variant_id"]], axis=1) if nl else np.zeros((0, 3), np.uint32)
+        return keys, counts, lab
+
+    def error_count(self):
+        n = C.c_uint32()
+        check(lib().gtx_ctx_error_count(self.h, C.byref(n)))
+        return int(n.value)
+
+
+class Stream:
+    """gtx_stream: which records align, which reuse the previous alignment, which pairs / reads get scored"""
+
+    def __init__(self, params, n_read_groups=1):
+        h = C.c_void_p()
+        check(lib().gtx_stream_create(C.byref(params), n_read_groups, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().gtx_stream_destroy(self.h)
+            self.h = None
+
+    def push(self, recs, seq):
+        """recs: STREAM_RECORD array, seq: [n, stride] packed bases -> (align_seq, align_meta, items)"""
+        recs = np.ascontiguousarray(recs, STREAM_RECORD)
+        seq = np.ascontiguousarray(seq, np.uint8)
+        n, stride = seq.shape
+        a_seq = np.zeros((n, stride), np.uint8)
+        a_meta = np.zeros(n, READ_META)
+        items = np.zeros(n, SCORE_ITEM)
+        na, ni = C.c_uint32(), C.c_uint32()
+        check(lib().gtx_stream_push(self.h, _p(recs), _p(seq), stride, n, _p(a_seq), _p(a_meta), n, C.byref(na), _p(items), n,
+                                    C.byref(ni)))
+        return a_seq[:na.value], a_meta[:na.value], items[:ni.value]
+
+    def counts(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(lib().gtx_stream_counts(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(records=int(a.value), duplicated=int(b.value), parked=int(c.value))
+
+
+def parse_records(words, n_reads, rec_words, hap_order):
+    """decode gtx_align_batch records into the same structure tests/oracle_lib.parse_path_stream returns
+    (plus 'status'); Path::var_order is looked up through hap_order"""
+    words = np.asarray(words, np.uint32).reshape(n_reads * 2, rec_words)
+    out = []
+    for i in range(n_reads):
+        pair = []
+        for o in range(2):
+            w = words[2 * i + o]
+            npaths, status = int(w[0]) & 0xFFFF, int(w[0]) >> 16
+            longest, rlen = int(w[1]) & 0xFFFF, int(w[1]) >> 16
+            k = 2
+            paths = []
+            for _ in range(npaths):
+                st, en, rsre, mmnv = int(w[k]), int(w[k + 1]), int(w[k + 2]), int(w[k + 3])
+                k += 4
+                vs = []
+                for _v in range(mmnv >> 16):
+                    hap, mask = int(w[k]), int(w[k + 1]) | (int(w[k + 2]) << 32)
+                    k += 3
+                    vs.append((int(hap_order[hap]), tuple(a for a in range(64) if (mask >> a) & 1)))
+                paths.append(dict(start=st, end=en, rs=rsre & 0xFFFF, re=rsre >> 16, mm=mmnv & 0xFFFF, vars=vs))
+            pair.append(dict(longest=longest, paths=paths, status=status, read_len=rlen))
+        out.append(tuple(pair))
+    return out

@@ -1,0 +1,88 @@
+"""Synthetic inputs for the hot path: uniform random reference, SNP / indel variant records,
+diploid 150 bp reads with substitution errors and Ns.  All seeds fixed; numpy only."""
+import numpy as np
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_CODE_OF_BASE = np.array([1, 2, 4, 8], dtype=np.uint8)  # A C G T -> BAM/IUPAC 4-bit code
+
+
+def make_reference(n, seed=42):
+    """n i.i.d. uniform bases as a uint8 array of base indices (0..3)"""
+    return np.random.default_rng(seed).integers(0, 4, size=n, dtype=np.uint8)
+
+
+def bases_to_str(b):
+    return _ACGT[b].tobytes().decode()
+
+
+def make_snp_records(ref, every=1000, seed=7, region_begin=0, first=None):
+    """one biallelic SNP every `every` bp; returns [(pos0, ref, [alt], None)] with contig coordinates"""
+    rng = np.random.default_rng(seed)
+    first = every // 2 if first is None else first
+    pos = np.arange(first, len(ref) - 1, every)
+    alt = (ref[pos] + rng.integers(1, 4, size=len(pos), dtype=np.uint8)) % 4
+    return [(int(p) + region_begin, "ACGT"[ref[p]], ["ACGT"[a]], None) for p, a in zip(pos, alt)]
+
+
+def make_indel_records(ref, every=500, seed=11, region_begin=0, max_len=6):
+    """alternating SNP / insertion / deletion records, spaced so that none overlaps the next (no merging needed)"""
+    rng = np.random.default_rng(seed)
+    recs = []
+    p = every // 2
+    kind = 0
+    while p + max_len + 2 < len(ref):
+        if kind % 3 == 0:
+            a = (ref[p] + rng.integers(1, 4)) % 4
+            recs.append((p + region_begin, "ACGT"[ref[p]], ["ACGT"[a]], None))
+        elif kind % 3 == 1:
+            ins = rng.integers(0, 4, size=int(rng.integers(1, max_len + 1)), dtype=np.uint8)
+            recs.append((p + region_begin, "ACGT"[ref[p]], ["ACGT"[ref[p]] + bases_to_str(ins)], None))
+        else:
+            dl = int(rng.integers(1, max_len + 1))
+            recs.append((p + region_begin, bases_to_str(ref[p:p + dl + 1]), ["ACGT"[ref[p]]], None))
+        kind += 1
+        p += every
+    return recs
+
+
+def make_reads(ref, records, n, read_len=150, seed=123, err=0.005, n_rate=0.001, region_begin=0, rev_frac=0.0):
+    """n reads drawn from a diploid sample (each record het with p=0.5 on haplotype 1, haplotype 0 = reference).
+    Returns (codes [n, read_len] uint8 4-bit codes, pos0 [n] int64 contig coordinates of the read start on the reference).
+    Only substitution/indel records produced by make_snp_records / make_indel_records are understood."""
+    rng = np.random.default_rng(seed)
+    # haplotype 1 = reference with a random half of the records applied
+    hap = []
+    cur = 0
+    take = rng.random(len(records)) < 0.5
+    for (p, r, alts, _), t in zip(records, take):
+        p -= region_begin
+        hap.append(ref[cur:p])
+        if t:
+            hap.append(np.array(["ACGT".index(c) for c in alts[0]], dtype=np.uint8))
+        else:
+            hap.append(ref[p:p + len(r)])
+        cur = p + len(r)
+    hap.append(ref[cur:])
+    hap1 = np.concatenate(hap)
+    haps = [ref, hap1]
+    which = rng.integers(0, 2, size=n)
+    out = np.zeros((n, read_len), dtype=np.uint8)
+    pos = np.zeros(n, dtype=np.int64)
+    for h in (0, 1):
+        idx = np.nonzero(which == h)[0]
+        src = haps[h]
+        start = rng.integers(0, len(src) - read_len, size=len(idx))
+        gather = start[:, None] + np.arange(read_len)[None, :]
+        out[idx] = src[gather]
+        pos[idx] = start + region_begin  # approximate for haplotype 1 (indels shift by a few bp)
+    # substitution errors
+    e = rng.random(out.shape) < err
+    out = np.where(e, (out + rng.integers(1, 4, size=out.shape, dtype=np.uint8)) % 4, out).astype(np.uint8)
+    codes = _CODE_OF_BASE[out]
+    if rev_frac > 0:
+        rv = rng.random(n) < rev_frac
+        rc = _CODE_OF_BASE[3 - out[:, ::-1]]
+        codes = np.where(rv[:, None], rc, codes)
+    nmask = rng.random(codes.shape) < n_rate
+    codes = np.where(nmask, np.uint8(15), codes).astype(np.uint8)
+    return np.ascontiguousarray(codes), pos

@@ -1,0 +1,236 @@
+/* gtx.h -- C ABI of libgtx.so: MI355X-native read -> pangenome-graph alignment + genotype scoring.
+ *
+ * The reference (graphtyper v2.7.7) has no FFI seam; this header is the boundary a maintainer would call
+ * from the three C++ sites the hot path sits behind:
+ *
+ *   gtx_ctx_create      replaces  PHIndex index_graph(Graph const&)            include/graphtyper/index/indexer.hpp:16
+ *                       + the upload of the immutable global `gyper::graph`     include/graphtyper/graph/graph.hpp:171
+ *   gtx_align_batch     replaces  align_read(bam1_t*, seq, rseq, PHIndex const&) include/graphtyper/typer/alignment.hpp:15-18
+ *   gtx_score_batch     replaces  update_unpaired_read_paths / update_paths / get_better_paths
+ *                                                                               include/graphtyper/typer/alignment.hpp:20-33
+ *                       and       VcfWriter::update_haplotype_scores_geno (both overloads)
+ *                                                                               include/graphtyper/typer/vcf_writer.hpp:33-41
+ *   gtx_scores_finalize replaces  reading VcfWriter::haplotypes[*].hap_samples[*] / var_stats after the read loop
+ *                                                                               src/utilities/hts_parallel_reader.cpp:782-1033
+ *   gtx_stream_*        mirrors   the per-record logic of parallel_reader_genotype_only / genotype_only
+ *                                 (flag filter, duplicate reuse, mate parking)  src/utilities/hts_parallel_reader.cpp:245-338,570-708
+ *
+ * Conventions: plain pointers and sizes only; the caller allocates and owns every buffer; a context is immutable
+ * after creation and may be used from several host threads; every function returns a status code (0 = ok) and never
+ * aborts; results for a read do not depend on batch composition or order.  All compute runs on the GPU -- there is no
+ * CPU fallback: without a usable HIP device gtx_ctx_create fails with GTX_ERR_NO_DEVICE.
+ */
+#ifndef GTX_H
+#define GTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GTX_INVALID_ID 0xFFFFFFFFu
+#define GTX_SPECIAL_START 0xD0000000u /* include/graphtyper/constants.hpp.in:33 */
+#define GTX_K 32
+
+enum
+{
+  GTX_OK = 0,
+  GTX_ERR_ARG = 1,         /* NULL / inconsistent arguments */
+  GTX_ERR_NO_DEVICE = 2,   /* no HIP device: the product has no CPU path */
+  GTX_ERR_HIP = 3,         /* a HIP runtime call failed (see gtx_last_error) */
+  GTX_ERR_UNSUPPORTED = 4, /* graph outside the supported envelope (e.g. a site with > 64 alleles) */
+  GTX_ERR_CAPACITY = 5,    /* a caller-provided buffer is too small */
+  GTX_ERR_GRAPH = 6        /* malformed graph view */
+};
+
+/* per read x orientation status bits written by gtx_align_batch (word 0, bits 16..31 of a result record) */
+enum
+{
+  GTX_ST_LABEL_OVERFLOW = 1, /* one k-mer list returned more labels than the kernel's staging buffer */
+  GTX_ST_PATH_OVERFLOW = 2,  /* more live paths / variant sites per path than the kernel's tables */
+  GTX_ST_DFS_OVERFLOW = 4,   /* graph walk produced more candidate sequences than the kernel's table */
+  GTX_ST_RECORD_OVERFLOW = 8 /* result did not fit rec_words */
+};
+
+/* Graph as SoA node tables = the reference's Graph::ref_nodes / var_nodes (include/graphtyper/graph/graph.hpp:40-134):
+ * strictly alternating  ref node r -> its ref_nvar[r] var nodes (allele 0 = reference allele) -> ref node r+1.
+ * Orders are 1-based contig positions (Label::order).  dna holds every node's bases back to back.
+ * events: per var node two sets (events, anti_events) in CSR form; may be NULL when no node has events. */
+typedef struct gtx_graph_view
+{
+  uint32_t n_ref, n_var;
+  const uint32_t * ref_order;     /* [n_ref] Label::order */
+  const uint32_t * ref_len;       /* [n_ref] Label::dna.size() */
+  const uint32_t * ref_dna_off;   /* [n_ref] offset into dna */
+  const uint32_t * ref_nvar;      /* [n_ref] RefNode::out_degree() */
+  const uint32_t * ref_first_var; /* [n_ref] RefNode::get_var_index(0) (ignored when ref_nvar == 0) */
+  const uint32_t * var_order;     /* [n_var] */
+  const uint32_t * var_len;       /* [n_var] */
+  const uint32_t * var_dna_off;   /* [n_var] */
+  const uint32_t * var_out_ref;   /* [n_var] VarNode::out_ref_id */
+  const char * dna;
+  uint64_t dna_len;
+  const uint32_t * event_off; /* [2*n_var+1] or NULL: events of var v = event_val[event_off[2v] .. event_off[2v+1]),
+                                 anti events = event_val[event_off[2v+1] .. event_off[2v+2]) */
+  const int64_t * event_val;
+} gtx_graph_view;
+
+/* Options the path reads (include/graphtyper/utilities/options.hpp:34,82,87,89,90) */
+typedef struct gtx_params
+{
+  int32_t max_index_labels;              /* 75 */
+  int32_t is_sv_graph;                   /* Graph::is_sv_graph */
+  int32_t hq_reads;                      /* Options::hq_reads */
+  int32_t force_align_both_orientations; /* Options::force_align_both_orientations */
+  int32_t is_segment_calling;            /* Options::is_segment_calling */
+  int32_t sam_flag_filter;               /* 3840 */
+} gtx_params;
+
+/* One KmerLabel (include/graphtyper/index/kmer_label.hpp:13-41) */
+typedef struct gtx_label
+{
+  uint32_t start_index, end_index, variant_id;
+} gtx_label;
+
+/* Per read fields of bam1_t the path looks at (src/typer/alignment.cpp:331-363) */
+typedef struct gtx_read_meta
+{
+  uint16_t l_qseq; /* bases */
+  uint16_t flag;
+  int32_t tid, mtid;
+  int32_t isize;
+} gtx_read_meta;
+
+/* Per record fields consumed by update_unpaired_read_paths / update_paths (src/typer/alignment.cpp:365-545) */
+typedef struct gtx_rec_meta
+{
+  uint32_t align_index; /* which gtx_align_batch result this record uses (duplicate reads reuse their predecessor's) */
+  uint16_t flag;
+  uint8_t mapq;
+  uint8_t score_diff; /* AS-XS as get_score_diff() computes it (src/typer/alignment.cpp:140-325) */
+  int32_t pos;        /* bam core.pos */
+  int32_t isize;
+} gtx_rec_meta;
+
+/* One call of genotype_only() that reaches the VcfWriter: an unpaired record (second.align_index == GTX_INVALID_ID)
+ * or a mate pair (first = the parked mate, second = the record that completed the pair). */
+typedef struct gtx_score_item
+{
+  gtx_rec_meta first, second;
+  uint32_t sample; /* pn_index */
+  uint32_t reserved;
+} gtx_score_item;
+
+typedef struct gtx_ctx gtx_ctx;
+
+/* sizes of the score accumulators for this graph */
+typedef struct gtx_score_layout
+{
+  uint32_t n_hap;        /* = number of variant sites = Graph::get_all_haplotypes().size() */
+  uint64_t total_tri;    /* sum over haplotypes of cnum*(cnum+1)/2 */
+  uint64_t total_allele; /* sum over haplotypes of cnum */
+} gtx_score_layout;
+
+const char * gtx_strerror(int status);
+const char * gtx_last_error(void); /* thread local detail of the last failing call */
+
+/* Builds the k-mer index of the graph (index_graph), flattens graph + index and uploads both to `device`. */
+int gtx_ctx_create(const gtx_graph_view * graph, const gtx_params * params, int device, gtx_ctx ** out);
+void gtx_ctx_destroy(gtx_ctx *);
+
+/* Graph facts derived at creation (Graph::create_special_positions, graph.cpp:384-407). out arrays may be NULL. */
+int gtx_ctx_special_positions(const gtx_ctx *, uint32_t * n_special, uint32_t * ref_reach_poses, uint32_t * actual_poses,
+                              uint32_t cap);
+int gtx_ctx_score_layout(const gtx_ctx *, gtx_score_layout * out);
+/* hap_order[n_hap], hap_cnum[n_hap], tri_off[n_hap], allele_off[n_hap] */
+int gtx_ctx_haplotypes(const gtx_ctx *, uint32_t * hap_order, uint32_t * hap_cnum, uint64_t * tri_off, uint64_t * allele_off);
+
+/* Index inspection (host copy, reference order): PHIndex::get(key) */
+int gtx_index_stats(const gtx_ctx *, uint64_t * n_keys, uint64_t * n_labels);
+int gtx_index_get(const gtx_ctx *, uint64_t key, gtx_label * out, uint32_t cap, uint32_t * n);
+/* keys ascending, counts per key, labels in bucket order */
+int gtx_index_dump(const gtx_ctx *, uint64_t * keys, uint32_t * counts, gtx_label * labels);
+
+/* ---- device entry points.  All `d_` pointers are DEVICE pointers owned by the caller. ----
+ *
+ * d_seq      : n_reads * seq_stride bytes, BAM 4-bit packed bases (bam_get_seq layout: high nibble first)
+ * d_meta     : n_reads gtx_read_meta
+ * d_records  : n_reads * 2 * rec_words uint32; record (read i, orientation o) starts at (2*i+o)*rec_words:
+ *    w0 = n_paths | status << 16, w1 = longest_path_length | l_qseq << 16, then per path
+ *    start, end, read_start_index | read_end_index << 16, mismatches | n_var << 16, n_var * (hap, mask_lo, mask_hi)
+ *    hap = haplotype (variant site) index, Path::var_order = hap_order[hap] of gtx_ctx_haplotypes;
+ *    mask bit a set <=> allele a in Path::nums
+ * stream     : hipStream_t or NULL */
+int gtx_align_batch(gtx_ctx *, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
+                    uint32_t * d_records, uint32_t rec_words, void * stream);
+
+/* Score accumulators (all uint32 / uint64, zero-initialised by the caller; sample-major):
+ *   d_log_score [n_samples * total_tri]      HapSample::log_score
+ *   d_gt_cov    [n_samples * total_allele]   HapSample::gt_coverage
+ *   d_hap_u32   [n_samples * n_hap * 4]      max_log_score, ambiguous_depth, ambiguous_depth_alt, alt_proper_pair_depth
+ *   d_stat_u64  [n_hap + 2*total_allele]     per hap mapq_squared; per allele clipped_bp, mapq_squared
+ *   d_stat_u32  [n_hap + 6*total_allele]     per hap clipped_reads; per allele score_diff, mismatches, r1f, r1r, r2f, r2r
+ *   d_conn_log  [conn_cap * 6]               appended (sample, hap1, allele1, hap2, allele2, count); d_conn_count[0] = entries
+ * Sums are unsaturated; gtx_scores_finalize applies the reference's saturation rules. */
+typedef struct gtx_score_buffers
+{
+  uint32_t n_samples;
+  uint32_t * d_log_score;
+  uint32_t * d_gt_cov;
+  uint32_t * d_hap_u32;
+  uint64_t * d_stat_u64;
+  uint32_t * d_stat_u32;
+  uint32_t * d_conn_log;
+  uint32_t * d_conn_count; /* [2]: entries appended, entries dropped because conn_cap was reached */
+  uint32_t conn_cap;
+} gtx_score_buffers;
+
+int gtx_score_batch(gtx_ctx *, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records,
+                    uint32_t rec_words, const gtx_score_buffers * acc, void * stream);
+
+/* number of score items the kernel refused so far because one read touched more variant sites than its table holds
+ * (must be 0 for the accumulators to be complete) */
+int gtx_ctx_error_count(gtx_ctx *, uint32_t * out);
+
+/* Host-side clamp of downloaded accumulators to the reference's stored types (haplotype.cpp:19-44: u8 -> 255,
+ * u16 -> 0xFFFF).  Returns the number of (haplotype,sample) cells whose max_log_score reached the sequential
+ * saturation guard of explain_to_score (haplotype.cpp:560) -- those cells need a sequential replay and are
+ * reported, never silently clamped. */
+int gtx_scores_finalize(uint32_t * log_score, uint64_t n_log, uint32_t * gt_cov, uint64_t n_cov, uint32_t * hap_u32,
+                        uint64_t n_hap_cells, uint64_t * n_saturated);
+
+/* ---- host mirror of the per-record control flow (no device work) ----
+ * Feed records in merged stream order; the stream decides which records are filtered, which reuse the previous
+ * alignment (equal_pos_seq) and which pairs / unpaired reads reach the scorer. */
+typedef struct gtx_stream gtx_stream;
+
+typedef struct gtx_stream_record
+{
+  uint16_t flag;
+  uint8_t mapq;
+  uint8_t score_diff;
+  int32_t tid, mtid;
+  int32_t pos;
+  int32_t isize;
+  uint16_t l_qseq;
+  uint16_t rg;      /* read group index (mate maps are per read group) */
+  uint32_t sample;  /* pn_index */
+  uint64_t name_id; /* identity of the read name (equal ids <=> equal QNAME) */
+} gtx_stream_record;
+
+int gtx_stream_create(const gtx_params * params, uint32_t n_read_groups, gtx_stream ** out);
+void gtx_stream_destroy(gtx_stream *);
+/* seq: n * seq_stride bytes of BAM 4-bit packed bases (host).  For every record appends at most one alignment task
+ * (copying its packed sequence + gtx_read_meta) and at most one score item.  Capacities are in elements. */
+int gtx_stream_push(gtx_stream *, const gtx_stream_record * recs, const uint8_t * seq, uint32_t seq_stride, uint32_t n,
+                    uint8_t * align_seq, gtx_read_meta * align_meta, uint32_t align_cap, uint32_t * n_align,
+                    gtx_score_item * items, uint32_t item_cap, uint32_t * n_items);
+/* number of accepted / duplicated records so far and mates still parked */
+int gtx_stream_counts(const gtx_stream *, uint64_t * n_records, uint64_t * n_duplicated, uint64_t * n_parked);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GTX_H */

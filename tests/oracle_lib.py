@@ -55,6 +55,9 @@ def lib():
                   "gto_scores_dump", "gto_to_uint64_vec", "gto_get_num_kmers", "gto_ith_kmer_offset", "gto_all_ref",
                   "gto_genotyper_num_haplotypes"):
             getattr(L, f).restype = C.c_long
+        L.gto_get_num_kmers.argtypes = [C.c_long]
+        L.gto_ith_kmer_offset.argtypes = [C.c_long, C.c_long]
+        L.gto_path_merge_two_ref_labels.argtypes = [C.c_uint32] * 8 + [C.c_void_p]
         _lib = L
     return _lib
 
@@ -108,9 +111,9 @@ class Oracle:
 
     def all_ref(self):
         L = lib()
-        n = L.gto_all_ref(C.c_void_p(self.h), None, 0)
+        n = L.gto_all_ref(C.c_void_p(self.h), None, C.c_long(0))
         buf = C.create_string_buffer(n)
-        L.gto_all_ref(C.c_void_p(self.h), buf, n)
+        L.gto_all_ref(C.c_void_p(self.h), buf, C.c_long(n))
         return buf.raw.decode()
 
     # ---- index
@@ -119,7 +122,7 @@ class Oracle:
         if isinstance(key, str):
             key = to_uint64(key)
         out = np.zeros(3 * 4096, np.uint32)
-        n = L.gto_index_get(C.c_void_p(self.h), C.c_uint64(key), _p(out), 4096)
+        n = L.gto_index_get(C.c_void_p(self.h), C.c_uint64(key), _p(out), C.c_long(4096))
         return [tuple(int(x) for x in out[3 * i:3 * i + 3]) for i in range(n)]
 
     def index_check(self):
@@ -138,9 +141,9 @@ class Oracle:
     def query_read(self, codes):
         L = lib()
         codes = np.ascontiguousarray(codes, dtype=np.uint8)
-        n = L.gto_query_read(C.c_void_p(self.h), _p(codes), len(codes), None, 0)
+        n = L.gto_query_read(C.c_void_p(self.h), _p(codes), C.c_long(len(codes)), None, C.c_long(0))
         out = np.zeros(n, np.uint32)
-        L.gto_query_read(C.c_void_p(self.h), _p(codes), len(codes), _p(out), n)
+        L.gto_query_read(C.c_void_p(self.h), _p(codes), C.c_long(len(codes)), _p(out), C.c_long(n))
         return out
 
     # ---- align
@@ -155,7 +158,8 @@ class Oracle:
         cap = 1 << 16
         while True:
             out = np.zeros(cap, np.uint32)
-            w = L.gto_align(C.c_void_p(self.h), n, _p(codes), _p(offs), _p(flags), _p(tid), _p(mtid), _p(isize), _p(out), cap)
+            w = L.gto_align(C.c_void_p(self.h), C.c_long(n), _p(codes), _p(offs), _p(flags), _p(tid), _p(mtid), _p(isize), _p(out),
+                            C.c_long(cap))
             if w < 0:
                 raise RuntimeError(L.gto_last_error().decode())
             if w <= cap:
@@ -212,15 +216,15 @@ class OracleGenotyper:
 
         a = [arr(flags, np.uint16), arr(tid, np.int32), arr(mtid, np.int32), arr(pos, np.int64), arr(isize, np.int64),
              arr(mapq, np.uint8), arr(score_diff, np.uint8), arr(name, np.uint64), arr(sample, np.int32), arr(rg, np.int32)]
-        rc = L.gto_genotyper_push(C.c_void_p(self.g), len(reads), _p(codes), _p(offs), *[_p(x) for x in a])
+        rc = L.gto_genotyper_push(C.c_void_p(self.g), C.c_long(len(reads)), _p(codes), _p(offs), *[_p(x) for x in a])
         if rc != 0:
             raise RuntimeError(L.gto_last_error().decode())
 
     def scores(self):
         L = lib()
-        n = L.gto_scores_dump(C.c_void_p(self.g), None, 0)
+        n = L.gto_scores_dump(C.c_void_p(self.g), None, C.c_long(0))
         out = np.zeros(n, np.uint32)
-        L.gto_scores_dump(C.c_void_p(self.g), _p(out), n)
+        L.gto_scores_dump(C.c_void_p(self.g), _p(out), C.c_long(n))
         return out
 
     def counts(self):

@@ -1,0 +1,105 @@
+"""Host-side product code (graph flattening, special positions, backward-enumeration index builder) against the
+CPU oracle.  No GPU needed: contexts are created with device=-1 (inspection only; no compute entry point works)."""
+import numpy as np
+import pytest
+
+from fixtures import contig
+from graphtyper_amd import lib as gtx
+from graphtyper_amd import synth
+from oracle_lib import Oracle
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    gtx.build()
+
+
+def _compare(reference, records, region_begin=0):
+    o = Oracle(reference, records, region_begin=region_begin)
+    g = gtx.graph_from_records(reference, records, region_begin=region_begin)
+    og = o.graph()
+    # node tables
+    for k in ("ref_order", "ref_len", "ref_nvar", "var_order", "var_len", "var_out_ref"):
+        assert np.array_equal(g[k], og[k]), k
+    inner = og["ref_nvar"] > 0
+    assert np.array_equal(g["ref_first_var"][inner], og["ref_first_var"][inner])
+    assert g["dna"].tobytes() == og["dna"].tobytes()
+    c = gtx.Context(g, device=-1)
+    rr, ap = c.special_positions()
+    assert np.array_equal(rr, og["ref_reach_poses"]) and np.array_equal(ap, og["actual_poses"])
+    # index: same keys, same label count per key, same labels in the same bucket order
+    k1, c1, l1 = o.index_dump()
+    k2, c2, l2 = c.index_dump()
+    assert np.array_equal(k1, k2)
+    assert np.array_equal(c1, c2)
+    assert np.array_equal(l1, l2)
+    return o, c
+
+
+@pytest.mark.parametrize("chrom", ["chr1", "chr2", "chr3", "chr4", "chr9", "chr10"])
+def test_index_test_contigs(chrom):
+    ref, recs = contig(chrom)
+    _compare(ref, recs)
+
+
+def test_events_prune_walks():
+    # chr9: the alt at 5 carries anti event 2, the insertion at 10 carries event 2 (test/index/test_index.cpp:352-398)
+    ref, recs = contig("chr9")
+    _, c = _compare(ref, recs)
+    from oracle_lib import to_uint64
+    assert c.index_get(to_uint64("AGGGGAGTGGGGGGGGGGGGGGGGGGGGGGGG")) == []
+    assert len(c.index_get(to_uint64("G" * 32))) == 36
+
+
+def test_synthetic_snp_graph():
+    ref = synth.make_reference(120000, seed=5)
+    recs = synth.make_snp_records(ref, every=100, seed=9, region_begin=1000000)
+    _compare(synth.bases_to_str(ref), recs, region_begin=1000000)
+
+
+def test_synthetic_indel_graph():
+    ref = synth.make_reference(60000, seed=6)
+    recs = synth.make_indel_records(ref, every=37, seed=3, region_begin=5000)
+    _compare(synth.bases_to_str(ref), recs, region_begin=5000)
+
+
+def test_dense_adjacent_sites_hit_the_pruning_rules():
+    # SNPs every 3 bp: walks cross up to 11 sites, so entry_has_too_many_nonrefs (indexer.cpp:13-20) decides a lot
+    ref = synth.make_reference(3000, seed=8)
+    recs = synth.make_snp_records(ref, every=3, seed=2, first=40)
+    _compare(synth.bases_to_str(ref), recs)
+    # multi-allelic sites with different allele lengths right next to each other (special positions in labels)
+    s = synth.bases_to_str(ref)
+    recs = []
+    p = 50
+    rng = np.random.default_rng(4)
+    while p < 2900:
+        r = s[p]
+        alts = sorted({r + "ACGT"[rng.integers(4)], "ACGT"[("ACGT".index(r) + 1) % 4], r + "GG" + "ACGT"[rng.integers(4)]})
+        recs.append((p, r, alts, None))
+        p += int(rng.integers(1, 9))
+    _compare(s, recs)
+
+
+def test_reference_with_n_runs():
+    ref, recs = contig("chr4")
+    s = "ACGTTGCA" * 20 + "N" * 7 + ref + "NN" + "TTGACCA" * 15
+    recs = [(p + 167, r, a, i) for p, r, a, i in recs]
+    _compare(s, recs)
+
+
+def test_unsupported_graph_is_refused_loudly():
+    ref = "ACGT" * 100
+    alts = sorted({"A" + "C" * k for k in range(1, 70)})
+    g = gtx.graph_from_records(ref, [(40, "A", alts, None)])
+    with pytest.raises(gtx.GtxError) as e:
+        gtx.Context(g, device=-1)
+    assert "64 alleles" in str(e.value)
+
+
+def test_no_cpu_path():
+    ref, recs = contig("chr1")
+    c = gtx.Context(gtx.graph_from_records(ref, recs), device=-1)
+    dummy = np.zeros(64, np.uint8)
+    rc = gtx.lib().gtx_align_batch(c.h, gtx._p(dummy), 16, gtx._p(dummy), 1, gtx._p(dummy), 64, None)
+    assert rc == 2  # GTX_ERR_NO_DEVICE

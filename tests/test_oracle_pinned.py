@@ -15,9 +15,9 @@ def test_converting_reads():  # :17-31
     k1, k2 = "TTTCCCCAGGTTTCCCCAGGTTTCCCCAGGTT", "TTGCCCAGGTTTCCCCAGGTTTCCCCTTTGGA"
     out = np.zeros(8, np.uint64)
     codes = encode(read)
-    assert lib().gto_to_uint64_vec(_p(codes), len(codes), 0, _p(out), 8) == 1
+    assert lib().gto_to_uint64_vec(_p(codes), C.c_long(len(codes)), C.c_long(0), _p(out), C.c_long(8)) == 1
     assert int(out[0]) == to_uint64(k1) and to_dna_str(int(out[0])) == k1
-    assert lib().gto_to_uint64_vec(_p(codes), len(codes), 31, _p(out), 8) == 1
+    assert lib().gto_to_uint64_vec(_p(codes), C.c_long(len(codes)), C.c_long(31), _p(out), C.c_long(8)) == 1
     assert int(out[0]) == to_uint64(k2) and to_dna_str(int(out[0])) == k2
 
 
@@ -77,7 +77,7 @@ def test_get_ith_kmer():  # :49-71 (offset of the centred i-th k-mer)
 def _keys(read, i):
     codes = encode(read)
     out = np.zeros(512, np.uint64)
-    n = lib().gto_to_uint64_vec(_p(codes), len(codes), i, _p(out), 512)
+    n = lib().gto_to_uint64_vec(_p(codes), C.c_long(len(codes)), C.c_long(i), _p(out), C.c_long(512))
     return [to_dna_str(int(x)) for x in out[:n]]
 
 
