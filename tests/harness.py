@@ -1,0 +1,190 @@
+"""Shared test plumbing: run the alignment / scoring kernels either on the GPU through libgtx's C ABI (GpuBackend,
+used by the `-m gpu` parity tests) or through the host emulation of the kernel sources (EmuBackend, tests/emu, a
+debugging aid for containers without a GPU), and put results into the oracle's canonical forms for exact comparison."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from graphtyper_amd import lib as gtx
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REC_WORDS = 64
+FLAG_PAIRED, FLAG_REVERSED, FLAG_MATE_REVERSED, FLAG_FIRST, FLAG_SECOND = 1, 16, 32, 64, 128
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Accumulators:
+    """host copy of the score accumulators (layout: include/gtx.h, gtx_score_buffers)"""
+
+    def __init__(self, ctx, n_samples, conn_cap=1 << 20):
+        self.n_samples = n_samples
+        self.conn_cap = conn_cap
+        self.log_score = np.zeros(n_samples * ctx.total_tri, np.uint32)
+        self.gt_cov = np.zeros(n_samples * ctx.total_allele, np.uint32)
+        self.hap_u32 = np.zeros(n_samples * ctx.n_hap * 4, np.uint32)
+        self.stat_u64 = np.zeros(ctx.n_hap + 2 * ctx.total_allele, np.uint64)
+        self.stat_u32 = np.zeros(ctx.n_hap + 6 * ctx.total_allele, np.uint32)
+        self.conn_log = np.zeros(conn_cap * 6, np.uint32)
+        self.conn_count = np.zeros(2, np.uint32)
+
+    def arrays(self):
+        return [self.log_score, self.gt_cov, self.hap_u32, self.stat_u64, self.stat_u32, self.conn_log, self.conn_count]
+
+
+class EmuBackend:
+    name = "emu"
+
+    def __init__(self, graph, **params):
+        so = os.path.join(HERE, "emu", "libgtx_emu.so")
+        subprocess.check_call(["make", "-C", os.path.join(HERE, "emu"), "-s"])
+        self.L = C.CDLL(so)
+        self.L.emu_new.restype = C.c_void_p
+        self.ctx = gtx.Context(graph, device=-1, **params)  # host inspection context (layout tables, index dump)
+        err = C.create_string_buffer(256)
+        self.h = self.L.emu_new(C.byref(self.ctx.view), C.byref(self.ctx.params), err, 256)
+        if not self.h:
+            raise RuntimeError(err.value.decode())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.emu_free(C.c_void_p(self.h))
+            self.h = None
+
+    def align(self, seq, meta, rec_words=REC_WORDS):
+        seq = np.ascontiguousarray(seq, np.uint8)
+        meta = np.ascontiguousarray(meta, gtx.READ_META)
+        n = len(meta)
+        rec = np.zeros(n * 2 * rec_words, np.uint32)
+        self.L.emu_align(C.c_void_p(self.h), _p(seq), C.c_uint32(seq.shape[1]), _p(meta), C.c_uint32(n), _p(rec), C.c_uint32(rec_words))
+        return rec
+
+    def score(self, items, records, n_samples=1, rec_words=REC_WORDS):
+        items = np.ascontiguousarray(items, gtx.SCORE_ITEM)
+        acc = Accumulators(self.ctx, n_samples)
+        buf = gtx.ScoreBuffers(n_samples, _p(acc.log_score), _p(acc.gt_cov), _p(acc.hap_u32), _p(acc.stat_u64), _p(acc.stat_u32),
+                               _p(acc.conn_log), _p(acc.conn_count), acc.conn_cap)
+        errors = self.L.emu_score(C.c_void_p(self.h), _p(items), C.c_uint32(len(items)), _p(records), C.c_uint32(rec_words), C.byref(buf))
+        assert errors == 0
+        return acc
+
+
+class GpuBackend:
+    """libgtx's C ABI on cuda:0; torch only owns the device buffers"""
+    name = "gpu"
+
+    def __init__(self, graph, **params):
+        import torch
+        self.torch = torch
+        assert torch.cuda.is_available(), "GpuBackend needs a GPU"
+        self.ctx = gtx.Context(graph, device=0, **params)
+
+    def _dev(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to("cuda:0")
+
+    def align(self, seq, meta, rec_words=REC_WORDS):
+        torch = self.torch
+        seq = np.ascontiguousarray(seq, np.uint8)
+        meta = np.ascontiguousarray(meta, gtx.READ_META)
+        n = len(meta)
+        d_seq, d_meta = self._dev(seq), self._dev(meta)
+        d_rec = torch.zeros(max(n, 1) * 2 * rec_words, dtype=torch.int32, device="cuda:0")
+        gtx.check(gtx.lib().gtx_align_batch(self.ctx.h, d_seq.data_ptr(), seq.shape[1], d_meta.data_ptr(), n, d_rec.data_ptr(),
+                                            rec_words, None))
+        torch.cuda.synchronize()
+        self.d_rec = d_rec
+        return d_rec.cpu().numpy().view(np.uint32)[:n * 2 * rec_words]
+
+    def score(self, items, records, n_samples=1, rec_words=REC_WORDS):
+        torch = self.torch
+        items = np.ascontiguousarray(items, gtx.SCORE_ITEM)
+        acc = Accumulators(self.ctx, n_samples)
+        d_items = self._dev(items)
+        d_rec = self._dev(np.ascontiguousarray(records, np.uint32))
+        devs = [self._dev(a) for a in acc.arrays()]
+        buf = gtx.ScoreBuffers(n_samples, *[d.data_ptr() for d in devs], acc.conn_cap)
+        gtx.check(gtx.lib().gtx_score_batch(self.ctx.h, d_items.data_ptr(), len(items), d_rec.data_ptr(), rec_words, C.byref(buf),
+                                            None))
+        torch.cuda.synchronize()
+        assert self.ctx.error_count() == 0
+        for host, dev in zip(acc.arrays(), devs):
+            host[...] = dev.cpu().numpy().view(host.dtype)
+        return acc
+
+
+def read_meta(lengths, flags=None, tid=None, mtid=None, isize=None):
+    n = len(lengths)
+    m = np.zeros(n, gtx.READ_META)
+    m["l_qseq"] = lengths
+    if flags is not None:
+        m["flag"] = flags
+    if tid is not None:
+        m["tid"] = tid
+    if mtid is not None:
+        m["mtid"] = mtid
+    if isize is not None:
+        m["isize"] = isize
+    return m
+
+
+def pack_ragged(reads):
+    """list of code arrays of different lengths -> packed [n, stride] + lengths"""
+    L = max(len(r) for r in reads)
+    codes = np.zeros((len(reads), L), np.uint8)
+    for i, r in enumerate(reads):
+        codes[i, :len(r)] = r
+    return gtx.pack_nibbles(codes), np.array([len(r) for r in reads], np.uint16)
+
+
+def strip(paths_pairs):
+    """drop the fields only the product reports so that results compare with the oracle's structure"""
+    out = []
+    for pair in paths_pairs:
+        out.append(tuple(dict(longest=g["longest"], paths=g["paths"]) for g in pair))
+    return out
+
+
+def canonical_scores(ctx, acc):
+    """accumulators + connection log -> the oracle's score word stream (oracle/gto_capi.cpp: gto_scores_dump)"""
+    L = gtx.lib()
+    nsat = C.c_uint64()
+    gtx.check(L.gtx_scores_finalize(_p(acc.log_score), len(acc.log_score), _p(acc.gt_cov), len(acc.gt_cov), _p(acc.hap_u32),
+                                    len(acc.hap_u32) // 4, C.byref(nsat)))
+    assert nsat.value == 0, "a (haplotype,sample) reached the sequential saturation guard"
+    assert acc.conn_count[1] == 0, "connection log overflow"
+    conn = {}
+    log = acc.conn_log[:6 * int(acc.conn_count[0])].reshape(-1, 6)
+    for s, h1, b1, h2, b2, c in log:
+        d = conn.setdefault((int(s), int(h1), int(b1)), {})
+        v = d.setdefault(int(h2), np.zeros(int(ctx.hap_cnum[h2]), np.int64))
+        v[int(b2)] += int(c)
+    out = []
+    nh = ctx.n_hap
+
+    def put64(x):
+        out.extend([int(x) & 0xFFFFFFFF, int(x) >> 32])
+
+    for h in range(nh):
+        cnum, aoff, toff = int(ctx.hap_cnum[h]), int(ctx.allele_off[h]), int(ctx.tri_off[h])
+        out.extend([int(ctx.hap_order[h]), cnum, int(acc.stat_u32[h])])
+        put64(acc.stat_u64[h])
+        for a in range(cnum):
+            put64(acc.stat_u64[nh + 2 * (aoff + a)])
+            put64(acc.stat_u64[nh + 2 * (aoff + a) + 1])
+            out.extend(int(x) for x in acc.stat_u32[nh + 6 * (aoff + a): nh + 6 * (aoff + a) + 6])
+        for s in range(acc.n_samples):
+            out.extend(int(x) for x in acc.hap_u32[(s * nh + h) * 4:(s * nh + h) * 4 + 4])
+            out.extend(int(x) for x in acc.gt_cov[s * ctx.total_allele + aoff: s * ctx.total_allele + aoff + cnum])
+            tri = cnum * (cnum + 1) // 2
+            out.extend(int(x) for x in acc.log_score[s * ctx.total_tri + toff: s * ctx.total_tri + toff + tri])
+            for a in range(cnum):
+                d = conn.get((s, h, a), {})
+                out.append(len(d))
+                for h2 in sorted(d):
+                    out.append(h2)
+                    out.extend(int(min(x, 0xFFFF)) for x in d[h2])
+    return np.array(out, np.uint32)

@@ -1,0 +1,141 @@
+"""Seeded inputs shared by the emulation (CPU) and GPU parity tests."""
+import numpy as np
+
+from fixtures import contig
+from graphtyper_amd import lib as gtx
+from graphtyper_amd import synth
+from oracle_lib import encode
+
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+
+
+def revcomp(s):
+    return "".join(COMP[c] for c in reversed(s))
+
+
+def mutate(s, positions, rng):
+    s = list(s)
+    for p in positions:
+        s[p] = "ACGT"[("ACGT".index(s[p]) + int(rng.integers(1, 4))) % 4] if s[p] in "ACGT" else "A"
+    return "".join(s)
+
+
+def haplotype_strings(ref, recs):
+    """every allele combination of a few-record contig: list of (sequence)"""
+    seqs = [""]
+    cur = 0
+    for pos, r, alts, _ in recs:
+        seqs = [s + ref[cur:pos] for s in seqs]
+        seqs = [s + a for s in seqs for a in [r] + [x for x in alts if not x.startswith("<")]]
+        cur = pos + len(r)
+    return [s + ref[cur:] for s in seqs]
+
+
+def contig_reads(chrom, seed=1):
+    """hand-made 63-66 bp reads over one index_test contig: every allele combination, with 0-2 mismatches, an N,
+    and the reverse complement"""
+    rng = np.random.default_rng(seed)
+    ref, recs = contig(chrom)
+    reads = []
+    for h in haplotype_strings(ref, recs):
+        if "N" in h:
+            h = h[:h.index("N")]
+        for L in (63, 64, len(h)):
+            if L > len(h) or L < 63:
+                continue
+            for start in {0, len(h) - L}:
+                s = h[start:start + L]
+                reads.append(s)
+                reads.append(mutate(s, rng.choice(L, 1, replace=False), rng))
+                reads.append(mutate(s, rng.choice(L, 2, replace=False), rng))
+                n = list(s)
+                n[int(rng.integers(L))] = "N"
+                reads.append("".join(n))
+                reads.append(revcomp(s))
+    return ref, recs, reads
+
+
+def synthetic_case(kind, n_ref=40000, n_reads=300, seed=0, region_begin=1000000, read_len=150, err=0.005, n_rate=0.001):
+    ref = synth.make_reference(n_ref, seed=seed + 100)
+    if kind == "snp1k":
+        recs = synth.make_snp_records(ref, 1000, seed=seed + 1, region_begin=region_begin)
+    elif kind == "snp100":
+        recs = synth.make_snp_records(ref, 100, seed=seed + 2, region_begin=region_begin)
+    elif kind == "snp25":
+        recs = synth.make_snp_records(ref, 25, seed=seed + 3, region_begin=region_begin)
+    elif kind == "indel":
+        recs = synth.make_indel_records(ref, 60, seed=seed + 4, region_begin=region_begin)
+    else:
+        raise ValueError(kind)
+    codes, pos = synth.make_reads(ref, recs, n_reads, read_len=read_len, seed=seed + 5, err=err, n_rate=n_rate,
+                                  region_begin=region_begin, rev_frac=0.0)
+    return synth.bases_to_str(ref), recs, codes, pos
+
+
+def stream_records(n, pos, flags=None, mapq=None, sample=None, name=None, isize=None, l_qseq=150, tid=0, mtid=0, score_diff=None):
+    r = np.zeros(n, gtx.STREAM_RECORD)
+    r["pos"] = pos
+    r["l_qseq"] = l_qseq
+    r["tid"] = tid
+    r["mtid"] = mtid
+    r["mapq"] = 60 if mapq is None else mapq
+    r["flag"] = 0 if flags is None else flags
+    r["sample"] = 0 if sample is None else sample
+    r["name_id"] = np.arange(n) if name is None else name
+    r["isize"] = 0 if isize is None else isize
+    r["score_diff"] = 0 if score_diff is None else score_diff
+    return r
+
+
+def paired_case(kind="snp100", n_ref=30000, n_pairs=150, seed=0, region_begin=500000, read_len=150, n_samples=2,
+                discordant_frac=0.1, dup_frac=0.05, lowq_frac=0.1):
+    """position-sorted stream of FR pairs + a few unpaired reads, duplicates, low-MAPQ and filtered records.
+    Returns (reference string, records, codes [n, L], STREAM_RECORD array)."""
+    rng = np.random.default_rng(seed + 77)
+    ref = synth.make_reference(n_ref, seed=seed + 200)
+    every = {"snp1k": 1000, "snp100": 100, "snp25": 25}.get(kind, 100)
+    recs = synth.make_snp_records(ref, every, seed=seed + 6, region_begin=region_begin) if kind != "indel" else \
+        synth.make_indel_records(ref, 60, seed=seed + 7, region_begin=region_begin)
+    # haplotype 1 of every sample = reference with a random half of the SNPs (substitutions only keeps coordinates)
+    rows = []
+    for i in range(n_pairs):
+        sample = int(rng.integers(n_samples))
+        hap = ref.copy()
+        if kind != "indel":
+            take = np.random.default_rng(1000 + sample).random(len(recs)) < 0.5
+            if rng.random() < 0.5:
+                for (p, r, alts, _), t in zip(recs, take):
+                    if t:
+                        hap[p - region_begin] = "ACGT".index(alts[0])
+        ins = int(np.clip(rng.normal(400, 50), read_len + 10, 900))
+        start = int(rng.integers(0, n_ref - ins))
+        a = hap[start:start + read_len].copy()
+        b = hap[start + ins - read_len:start + ins].copy()
+        for x in (a, b):
+            e = rng.random(read_len) < 0.005
+            x[e] = (x[e] + rng.integers(1, 4, size=int(e.sum()))) % 4
+        mapq = 10 if rng.random() < lowq_frac else 60
+        kindp = rng.random()
+        name = i
+        if kindp < discordant_frac:  # same strand -> both orientations are aligned
+            if rng.random() < 0.5:  # second mate stored on the other strand: only its reverse orientation aligns
+                b = (3 - b[::-1]).astype(np.uint8)
+            rows.append((start, a, 1 | 64, ins, mapq, sample, name))
+            rows.append((start + ins - read_len, b, 1 | 128, -ins, mapq, sample, name))
+        elif kindp < discordant_frac + 0.1:  # unpaired
+            rows.append((start, a, 0, 0, mapq, sample, name))
+        else:
+            rows.append((start, a, 1 | 2 | 32 | 64, ins, mapq, sample, name))
+            rows.append((start + ins - read_len, b, 1 | 2 | 16 | 128, -ins, mapq, sample, name))
+        if rng.random() < dup_frac:  # an unpaired PCR duplicate of the first mate right behind it (other name, other sample)
+            rows.append((start, a, 0, 0, 60, int(rng.integers(n_samples)), 10_000_000 + i))
+        if rng.random() < 0.05:  # a record the flag filter drops (secondary)
+            rows.append((start, a, 256, 0, 60, sample, 20_000_000 + i))
+    rows.sort(key=lambda r: r[0])  # stable: duplicates stay behind their original
+    n = len(rows)
+    codes = np.zeros((n, read_len), np.uint8)
+    rec = np.zeros(n, gtx.STREAM_RECORD)
+    for i, (p, bases, flag, isize, mapq, sample, name) in enumerate(rows):
+        codes[i] = np.array([1, 2, 4, 8], np.uint8)[bases]
+        rec[i] = (flag, mapq, int(rng.integers(0, 60)), 0, 0, p + region_begin, isize, read_len, 0, sample, name)
+    return synth.bases_to_str(ref), recs, codes, rec

@@ -1,0 +1,87 @@
+"""Kernel sources run through the host emulation (tests/emu) against the oracle.  A debugging aid for containers
+without a GPU -- the parity claims of record are the `-m gpu` tests, which run the same cases through libgtx."""
+import numpy as np
+import pytest
+
+import harness
+import scenarios
+from graphtyper_amd import lib as gtx
+from oracle_lib import Oracle, encode
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    gtx.build()
+
+
+def check_align(backend, oracle, reads, flags=None, tid=None, mtid=None, isize=None, allow_overflow=False):
+    """kernel records == oracle GenotypePaths for every read; reads whose status word reports a table overflow are
+    only tolerated where the test says so (low-complexity contigs) and are never compared as if they were results"""
+    seq, lens = harness.pack_ragged(reads)
+    meta = harness.read_meta(lens, flags, tid, mtid, isize)
+    rec = backend.align(seq, meta)
+    got = gtx.parse_records(rec, len(reads), harness.REC_WORDS, backend.ctx.hap_order)
+    want = oracle.align(reads, flags=flags, tid=tid, mtid=mtid, isize=isize)
+    n_over = 0
+    for i, (a, b) in enumerate(zip(got, want)):
+        for o in range(2):
+            if a[o]["status"] != 0:
+                assert allow_overflow, "read %d orientation %d: kernel table overflow %d" % (i, o, a[o]["status"])
+                assert a[o]["paths"] == [] and a[o]["longest"] == 0
+                n_over += 1
+                continue
+            ga = dict(longest=a[o]["longest"], paths=a[o]["paths"])
+            assert ga == b[o], "read %d orientation %d: kernel %r != oracle %r" % (i, o, ga, b[o])
+    return rec, n_over
+
+
+@pytest.mark.parametrize("chrom", ["chr1", "chr2", "chr3", "chr9"])
+def test_align_index_test_contigs(chrom):
+    ref, recs, reads = scenarios.contig_reads(chrom)
+    o = Oracle(ref, recs, force_both=True)
+    b = harness.EmuBackend(gtx.graph_from_records(ref, recs), force_both=True)
+    _, n_over = check_align(b, o, [encode(r) for r in reads], allow_overflow=(chrom == "chr9"))
+    assert n_over < len(reads)  # chr9 is 80 bp of poly-G: most seeds hit 36 positions
+
+
+@pytest.mark.parametrize("kind", ["snp1k", "snp100", "snp25", "indel"])
+def test_align_synthetic(kind):
+    ref, recs, codes, pos = scenarios.synthetic_case(kind, n_ref=20000, n_reads=120, region_begin=777000)
+    o = Oracle(ref, recs, region_begin=777000)
+    b = harness.EmuBackend(gtx.graph_from_records(ref, recs, region_begin=777000))
+    check_align(b, o, list(codes))
+
+
+def run_stream(backend, oracle, codes, rec, n_samples, n_rg=1):
+    """product: gtx_stream -> align -> score; oracle: Genotyper::push; compares the canonical score streams"""
+    og = oracle.genotyper(n_samples, n_rg)
+    og.push(list(codes), flags=rec["flag"], tid=rec["tid"], mtid=rec["mtid"], pos=rec["pos"], isize=rec["isize"],
+            mapq=rec["mapq"], score_diff=rec["score_diff"], name=rec["name_id"], sample=rec["sample"], rg=rec["rg"])
+    want = og.scores()
+    st = gtx.Stream(backend.ctx.params, n_rg)
+    seq = gtx.pack_nibbles(codes)
+    # feed in two pushes to exercise state carried across calls (duplicate detection, parked mates)
+    h = len(rec) // 2
+    parts = [st.push(rec[:h], seq[:h]), st.push(rec[h:], seq[h:])]
+    a_seq = np.concatenate([p[0] for p in parts])
+    a_meta = np.concatenate([p[1] for p in parts])
+    items = np.concatenate([p[2] for p in parts])
+    assert st.counts() == og.counts()
+    records = backend.align(a_seq, a_meta)
+    status = records.reshape(-1, harness.REC_WORDS)[:, 0] >> 16
+    assert not status.any(), "kernel table overflow"
+    acc = backend.score(items, records, n_samples)
+    got = harness.canonical_scores(backend.ctx, acc)
+    assert len(got) == len(want)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, "score streams differ at words %s" % bad[:10]
+    return want
+
+
+@pytest.mark.parametrize("kind", ["snp100", "snp25", "indel"])
+def test_stream_scores(kind):
+    ref, recs, codes, rec = scenarios.paired_case(kind, n_ref=12000, n_pairs=70, region_begin=310000)
+    o = Oracle(ref, recs, region_begin=310000)
+    b = harness.EmuBackend(gtx.graph_from_records(ref, recs, region_begin=310000))
+    want = run_stream(b, o, codes, rec, n_samples=2)
+    assert want.sum() > 0

@@ -65,7 +65,7 @@ def test_synthetic_indel_graph():
 
 def test_dense_adjacent_sites_hit_the_pruning_rules():
     # SNPs every 3 bp: walks cross up to 11 sites, so entry_has_too_many_nonrefs (indexer.cpp:13-20) decides a lot
-    ref = synth.make_reference(3000, seed=8)
+    ref = synth.make_reference(900, seed=8)
     recs = synth.make_snp_records(ref, every=3, seed=2, first=40)
     _compare(synth.bases_to_str(ref), recs)
     # multi-allelic sites with different allele lengths right next to each other (special positions in labels)
@@ -73,7 +73,7 @@ def test_dense_adjacent_sites_hit_the_pruning_rules():
     recs = []
     p = 50
     rng = np.random.default_rng(4)
-    while p < 2900:
+    while p < 800:
         r = s[p]
         alts = sorted({r + "ACGT"[rng.integers(4)], "ACGT"[("ACGT".index(r) + 1) % 4], r + "GG" + "ACGT"[rng.integers(4)]})
         recs.append((p, r, alts, None))
