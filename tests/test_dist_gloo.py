@@ -1,0 +1,69 @@
+"""N>1 path on CPU: two gloo ranks each score their shard of the items (through the host emulation of the score
+kernel), all-reduce the accumulators and must end with exactly the single-process result."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import harness
+import scenarios
+from graphtyper_amd import lib as gtx
+from graphtyper_amd.dist import reduce_scores, shard_bounds, shard_pairs_by_name
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 100, 101):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def test_mates_stay_together():
+    names = np.array([5, 9, 5, 7, 9, 7, 1, 1])
+    owner = shard_pairs_by_name(names, 2)
+    for nm in set(names.tolist()):
+        assert len(set(owner[names == nm].tolist())) == 1
+
+
+def _worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    ref, recs, codes, rec = scenarios.paired_case("snp100", n_ref=8000, n_pairs=30, region_begin=0, n_samples=2)
+    b = harness.EmuBackend(gtx.graph_from_records(ref, recs))
+    st = gtx.Stream(b.ctx.params, 1)
+    a_seq, a_meta, items = st.push(rec, gtx.pack_nibbles(codes))
+    records = np.load(os.path.join(tmp, "records.npy"))
+    lo, hi = shard_bounds(len(items), world, rank)
+    acc = b.score(items[lo:hi], records, 2)
+    tensors = [torch.from_numpy(a.view(np.int64 if a.dtype == np.uint64 else np.int32)) for a in
+               (acc.log_score, acc.gt_cov, acc.hap_u32, acc.stat_u64, acc.stat_u32)]
+    reduce_scores(dist, tensors)
+    if rank == 0:
+        np.save(os.path.join(tmp, "reduced.npy"), np.concatenate([t.numpy().astype(np.int64) for t in tensors]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_reduce_equals_single_pass(tmp_path):
+    gtx.build()
+    ref, recs, codes, rec = scenarios.paired_case("snp100", n_ref=8000, n_pairs=30, region_begin=0, n_samples=2)
+    b = harness.EmuBackend(gtx.graph_from_records(ref, recs))
+    st = gtx.Stream(b.ctx.params, 1)
+    a_seq, a_meta, items = st.push(rec, gtx.pack_nibbles(codes))
+    records = b.align(a_seq, a_meta)
+    np.save(tmp_path / "records.npy", records)
+    acc = b.score(items, records, 2)
+    single = np.concatenate([a.astype(np.int64) for a in (acc.log_score, acc.gt_cov, acc.hap_u32, acc.stat_u64, acc.stat_u32)])
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    reduced = np.load(tmp_path / "reduced.npy")
+    assert np.array_equal(single, reduced)
+    assert single.sum() > 0

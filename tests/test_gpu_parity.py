@@ -1,0 +1,81 @@
+"""Parity tests proper: the HIP kernels, called through libgtx's C ABI on a real MI355X, against the CPU oracle.
+Bit-exact (integer / index work): alignment records == oracle GenotypePaths, score accumulators == oracle
+haplotype state, for every read."""
+import os
+
+import numpy as np
+import pytest
+
+import harness
+import scenarios
+from graphtyper_amd import lib as gtx
+from oracle_lib import Oracle, encode
+from test_emu_parity import check_align, run_stream
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    assert os.path.exists(gtx.LIB_PATH), "libgtx.so must be built (HIP path, no fallback)"
+
+
+@pytest.mark.parametrize("chrom", ["chr1", "chr2", "chr3", "chr9"])
+def test_align_index_test_contigs(chrom):
+    ref, recs, reads = scenarios.contig_reads(chrom)
+    o = Oracle(ref, recs, force_both=True)
+    b = harness.GpuBackend(gtx.graph_from_records(ref, recs), force_both=True)
+    _, n_over = check_align(b, o, [encode(r) for r in reads], allow_overflow=(chrom == "chr9"))
+    assert n_over < len(reads)
+
+
+@pytest.mark.parametrize("kind", ["snp1k", "snp100", "snp25", "indel"])
+def test_align_synthetic(kind):
+    ref, recs, codes, pos = scenarios.synthetic_case(kind, n_ref=200000, n_reads=20000, region_begin=1000000)
+    o = Oracle(ref, recs, region_begin=1000000)
+    b = harness.GpuBackend(gtx.graph_from_records(ref, recs, region_begin=1000000))
+    check_align(b, o, list(codes))
+
+
+def test_align_ragged_and_short_reads():
+    ref, recs, codes, pos = scenarios.synthetic_case("snp100", n_ref=30000, n_reads=400, region_begin=5000)
+    rng = np.random.default_rng(3)
+    reads = [c[:int(L)] for c, L in zip(codes, rng.integers(40, 151, size=len(codes)))]  # 40..150 bp; < 63 stay unaligned
+    reads.append(np.full(100, 15, np.uint8))  # all N
+    reads.append(codes[0][:63])
+    o = Oracle(ref, recs, region_begin=5000)
+    b = harness.GpuBackend(gtx.graph_from_records(ref, recs, region_begin=5000))
+    check_align(b, o, reads)
+
+
+def test_align_is_independent_of_batch_composition():
+    ref, recs, codes, pos = scenarios.synthetic_case("snp100", n_ref=50000, n_reads=3000, region_begin=0)
+    b = harness.GpuBackend(gtx.graph_from_records(ref, recs))
+    seq = gtx.pack_nibbles(codes)
+    meta = harness.read_meta(np.full(len(codes), 150))
+    whole = b.align(seq, meta).reshape(len(codes), -1).copy()
+    perm = np.random.default_rng(1).permutation(len(codes))
+    shuffled = b.align(seq[perm], meta[perm]).reshape(len(codes), -1)
+    assert np.array_equal(whole[perm], shuffled)
+
+
+@pytest.mark.parametrize("kind", ["snp100", "snp25", "indel"])
+def test_stream_scores(kind):
+    ref, recs, codes, rec = scenarios.paired_case(kind, n_ref=100000, n_pairs=8000, region_begin=310000, n_samples=3)
+    o = Oracle(ref, recs, region_begin=310000)
+    b = harness.GpuBackend(gtx.graph_from_records(ref, recs, region_begin=310000))
+    want = run_stream(b, o, codes, rec, n_samples=3)
+    assert want.sum() > 0
+
+
+def test_scores_do_not_depend_on_item_order():
+    ref, recs, codes, rec = scenarios.paired_case("snp100", n_ref=60000, n_pairs=4000, region_begin=0, n_samples=2)
+    b = harness.GpuBackend(gtx.graph_from_records(ref, recs))
+    st = gtx.Stream(b.ctx.params, 1)
+    a_seq, a_meta, items = st.push(rec, gtx.pack_nibbles(codes))
+    records = b.align(a_seq, a_meta)
+    s1 = harness.canonical_scores(b.ctx, b.score(items, records, 2))
+    s2 = harness.canonical_scores(b.ctx, b.score(items[::-1].copy(), records, 2))
+    assert np.array_equal(s1, s2)
