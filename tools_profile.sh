@@ -1,0 +1,36 @@
+#!/bin/bash
+# Profiling recipe used for profiles/: run on the GPU box from the repo root (gpurun -- 'bash tools_profile.sh r01').
+# 1) kernel trace + stats of the bench command; 2) PMC passes (own runs, no trace domains) for instruction mix and HBM bytes.
+set -u
+TAG=${1:-r01}
+READS=${2:-2000000}
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+REPO=$PWD
+cd /tmp
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o bench -- python $REPO/bench.py --reads $READS --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $OUT/pmc_sq -o bench -- python $REPO/bench.py --reads $READS --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_pmc_sq.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT -d $OUT/pmc_sq2 -o bench -- python $REPO/bench.py --reads $READS --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_pmc_sq2.log 2>&1
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o bench -- python $REPO/bench.py --reads $READS --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_pmc_fetch.log 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_write -o bench -- python $REPO/bench.py --reads $READS --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_pmc_write.log 2>&1
+cd $REPO
+find $OUT -type f ! -name '*.csv' ! -name '*.log' -delete
+find $OUT -name '*.csv' -size +4M -delete
+find $OUT -name '*.csv' | head -50
+for f in $OUT/*.log; do grep -m1 "^{" $f | cut -c1-400; done
+python - <<PY
+import csv, glob, os, collections
+out = "$OUT"
+for f in sorted(glob.glob(out + "/**/*kernel_stats.csv", recursive=True)):
+    print("==", f); print(open(f).read()[:3000])
+for f in sorted(glob.glob(out + "/**/*counter_collection.csv", recursive=True)):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for row in csv.DictReader(open(f)):
+        k = row.get("Kernel_Name", "?")[:60]
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[(k, row["Counter_Name"])] += 1
+    print("==", f)
+    for k, d in agg.items():
+        for c, v in d.items():
+            print("  %-60s %-24s sum=%.6g launches=%d" % (k, c, v, cnt[(k, c)]))
+PY
