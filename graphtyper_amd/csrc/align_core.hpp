@@ -1,14 +1,14 @@
 // align_core.hpp -- per-read work of the alignment kernel: one wavefront per (read, orientation).
 //
 // What the reference does per read (src/typer/alignment.cpp:23-103, find_genotype_paths_of_one_of_the_sequences) with
-// heap containers, restated over fixed tables in LDS:
-//   * k-mer extraction + index probes are wave-parallel (97 keys per k-mer spread over the 64 lanes, stable
-//     prefix-sum compaction of the hits so label order equals the reference's key order / bucket order);
-//   * seed chaining, graph walks and the path filters are short, data dependent and branchy: lane 0 runs them on
-//     the LDS tables while the other lanes wait (round 1; see DESIGN.md for what moves to all lanes next).
+// heap containers, restated over fixed tables in LDS.
 //
-// The code is written against a `W` (wave) policy so that tests/emu can run the very same source on host threads
-// (64 threads + barriers standing in for one wavefront).  The product instantiates it with WaveHip only.
+// Execution style ("wave-uniform + lane lambdas"): all 64 lanes run the same control flow on the same values (state
+// lives in LDS, scalars are replicated), LDS writes are done by the leader lane only, and the data-parallel pieces --
+// read unpacking, 2-bit key assembly, the 97 index probes per k-mer, stable hit compaction, character comparison of a
+// read against graph sequence, table copies -- are expressed as lambdas over the lane index plus wave primitives
+// (ballot, exclusive scan).  A policy type W supplies those primitives: WaveHip (gtx_api.hip) maps them to the
+// hardware; tests/emu supplies a sequential stand-in so the very same source can be debugged without a GPU.
 #pragma once
 #include <cstdint>
 
@@ -28,19 +28,23 @@ constexpr uint32_t MAX_SEED_NUMBER_ALLOWING_MISMATCHES = 64;
 constexpr uint32_t MAX_SEED_NUMBER_FOR_WALKING = 256;
 constexpr uint32_t MAX_NUM_LOCATIONS_PER_PATH = 256;
 
+// graph sequence is stored as codes: IUPAC letters keep their 4-bit BAM code (A=1 C=2 G=4 T=8 N=15), '<' and '>'
+// (SV breakpoint tags, graph_utils.hpp:20-23) become DNA_KILL, anything else DNA_OTHER (equal to no read character)
+constexpr uint8_t DNA_KILL = 0x80, DNA_OTHER = 0x40;
+
 struct AlignCfg
 {
   static constexpr uint32_t MAX_READ = 256;  // bases
   static constexpr uint32_t MAX_KMERS = 8;   // get_num_kmers(MAX_READ)
-  static constexpr uint32_t LBL_CAP = 128;   // labels of one k-mer list
-  static constexpr uint32_t MAXP = 32;       // live paths
-  static constexpr uint32_t MAXPP = 32;      // paths made from one label list
+  static constexpr uint32_t LBL_CAP = 80;    // labels of one k-mer list (multi-key lists are cut at 75 by the reference)
+  static constexpr uint32_t MAXP = 24;       // live paths
+  static constexpr uint32_t MAXPP = 16;      // paths made from one label list
   static constexpr uint32_t MAXV = 8;        // variant sites per path
   static constexpr uint32_t CAND_CAP = 32;   // sequences alive in one graph walk
   static constexpr uint32_t MAXIDS = 8;      // variant nodes on one walked sequence
-  static constexpr uint32_t LOC_CAP = 32;    // graph locations of one path end
+  static constexpr uint32_t LOC_CAP = 16;    // graph locations of one path end
   static constexpr uint32_t WL_CAP = 64;     // labels kept by walk_read_ends/starts
-  static constexpr uint32_t WLISTS = 16;     // label lists kept by walk_read_ends/starts
+  static constexpr uint32_t WLISTS = 8;      // label lists kept by walk_read_ends/starts
   static constexpr uint32_t KEY_CAP = 388;   // to_uint64_vec can return up to 4*97 keys
 };
 
@@ -57,6 +61,7 @@ struct DPath // gyper::Path (include/graphtyper/typer/path.hpp:18-79)
   uint16_t mism, nvar;
   PVar v[AlignCfg::MAXV];
 };
+constexpr uint32_t DPATH_WORDS = sizeof(DPath) / 4;
 
 struct Loc // gyper::Location (include/graphtyper/graph/location.hpp)
 {
@@ -72,29 +77,36 @@ struct Cand // one element of var_and_refs / var_ids / end_pos in Graph::get_lab
   uint32_t nids;
   uint32_t ids[AlignCfg::MAXIDS];
 };
+constexpr uint32_t CAND_WORDS = sizeof(Cand) / 4;
+
+struct WalkBuffers // alive only during walk_read_starts / walk_read_ends
+{
+  DPath pp[AlignCfg::MAXPP];
+  Cand cand[AlignCfg::CAND_CAP];
+  Loc locs[AlignCfg::LOC_CAP];
+  DevLabel dfs_out[AlignCfg::WL_CAP]; // labels of the current iterative_dfs call
+};
 
 struct AlignWorkspace // lives in LDS, one per wavefront
 {
   uint8_t rd[AlignCfg::MAX_READ]; // read as 4-bit IUPAC codes, orientation applied
   DevLabel lbl[AlignCfg::LBL_CAP];
   DPath paths[AlignCfg::MAXP];
-  DPath pp[AlignCfg::MAXPP];
+  DPath orig, np; // Path temporaries of add_next/prev_kmer_labels
   union
   {
-    uint64_t keybuf[AlignCfg::KEY_CAP];
-    Cand cand[AlignCfg::CAND_CAP];
+    uint64_t keybuf[AlignCfg::KEY_CAP]; // keys of a multi-key list, then (offset | count << 32) of every probed key
+    WalkBuffers w;                      // (pp is also used while seeding, never at the same time as keybuf)
   } u;
-  Loc locs[AlignCfg::LOC_CAP];
-  DevLabel wl[AlignCfg::WL_CAP];
+  DevLabel wl[AlignCfg::WL_CAP]; // best label lists of a walk (must survive the add_*_kmer_labels calls)
   uint32_t wl_off[AlignCfg::WLISTS + 1];
   uint32_t wl_idx[AlignCfg::WLISTS];
-  DevLabel dfs_out[AlignCfg::WL_CAP]; // labels of the current iterative_dfs call
   // per k-mer exact-probe results
   uint64_t key0[AlignCfg::MAX_KMERS];
   uint32_t nkeys0[AlignCfg::MAX_KMERS];
   uint32_t off0[AlignCfg::MAX_KMERS];
   uint32_t cnt0[AlignCfg::MAX_KMERS];
-  uint32_t n_paths, longest, status, n_lbl, n_keys, read_len, n_wl, n_wlists, n_dfs, scratch;
+  uint32_t n_paths, longest, status, n_lbl, n_keys, read_len, n_wl, n_wlists;
 };
 
 GTX_DEV uint64_t pv_mask(PVar const & v)
@@ -102,22 +114,27 @@ GTX_DEV uint64_t pv_mask(PVar const & v)
   return (static_cast<uint64_t>(v.mhi) << 32) | v.mlo;
 }
 
-GTX_DEV void pv_set(PVar & v, uint64_t m)
-{
-  v.mlo = static_cast<uint32_t>(m);
-  v.mhi = static_cast<uint32_t>(m >> 32);
-}
-
 GTX_DEV uint32_t path_size(DPath const & p)
 {
   return static_cast<uint32_t>(p.re) - static_cast<uint32_t>(p.rs) + 1u;
 }
 
-GTX_DEV char code_to_char(uint32_t c)
+#define GTX_LEAD if (W::leader())
+
+// word-wise LDS -> LDS copy of a table entry, one word per lane
+template <class W, class T>
+GTX_DEV void copy_entry(T & dst, T const & src)
 {
-  // seq_nt16_str (htslib) assigned to a seqan Iupac: '=' is not an IUPAC letter and becomes N
-  // (src/utilities/hts_parallel_reader.cpp:226-243)
-  return "NACMGRSVTWYHKDBN"[c & 15u];
+  static_assert(sizeof(T) % 4 == 0 && sizeof(T) / 4 <= 64, "entry must be at most 64 words");
+  if (&dst == &src)
+    return;
+  uint32_t * d = reinterpret_cast<uint32_t *>(&dst);
+  uint32_t const * s = reinterpret_cast<uint32_t const *>(&src);
+  W::lanes([&](uint32_t l) {
+    if (l < sizeof(T) / 4)
+      d[l] = s[l];
+  });
+  W::lds_sync();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -146,6 +163,11 @@ GTX_DEV uint32_t g_special_of(GraphView const & g, uint32_t site, uint32_t pos)
   return pos > rr ? SPECIAL_START + g.site_special_base[site] + (pos - rr - 1) : pos;
 }
 
+GTX_DEV uint32_t site_order(GraphView const & g, uint32_t site)
+{
+  return g.ref_order[site] + g.ref_len[site]; // order of the site's variant nodes
+}
+
 // last reference node whose order is <= pos (the `rr` of graph.cpp:950-955); pos >= first_order required
 GTX_DEV uint32_t g_ref_node_at(GraphView const & g, uint32_t pos)
 {
@@ -161,6 +183,7 @@ GTX_DEV uint32_t g_ref_node_at(GraphView const & g, uint32_t pos)
 // Graph::get_locations_of_a_position (graph.cpp:1154-1185 -> 931-1029).  The reference scans reference nodes
 // backwards and looks every variant node up in path.var_order; here the (few) sites of the path are visited in
 // descending order instead, which yields the same locations in the same order.
+template <class W>
 GTX_DEV uint32_t get_locations(GraphView const & g, uint32_t pos, DPath const & path, Loc * locs, uint32_t cap, uint32_t & status)
 {
   bool const special = g_is_special(g, pos);
@@ -171,7 +194,7 @@ GTX_DEV uint32_t get_locations(GraphView const & g, uint32_t pos, DPath const & 
     return 0;
   if (g.n_ref == 1)
   {
-    locs[0] = Loc{1, 0, g.ref_order[0], pos - g.ref_order[0]};
+    GTX_LEAD locs[0] = Loc{1, 0, g.ref_order[0], pos - g.ref_order[0]};
     return 1;
   }
   int64_t rr = g_ref_node_at(g, pos);
@@ -179,20 +202,20 @@ GTX_DEV uint32_t get_locations(GraphView const & g, uint32_t pos, DPath const & 
   {
     if (!special)
     {
-      locs[0] = Loc{1, static_cast<uint32_t>(rr), g.ref_order[rr], pos - g.ref_order[rr]};
+      GTX_LEAD locs[0] = Loc{1, static_cast<uint32_t>(rr), g.ref_order[rr], pos - g.ref_order[rr]};
       return 1;
     }
     --rr;
   }
   // sites rr' <= rr with reach(rr') + PADDING > pos, descending; only sites the path carries can contribute
   bool const path_empty = path.start == path.end;
+  uint32_t const nvar = path.nvar;
   int64_t bound = rr + 1;
   for (;;)
   {
-    // next site of the path below `bound` (largest first); a site listed twice counts once (std::find -> first)
     int64_t best = -1;
     uint32_t best_j = 0;
-    for (uint32_t j = 0; j < path.nvar; ++j)
+    for (uint32_t j = 0; j < nvar; ++j)
     {
       int64_t const s = path.v[j].site;
       if (s < bound && s > best)
@@ -200,8 +223,6 @@ GTX_DEV uint32_t get_locations(GraphView const & g, uint32_t pos, DPath const & 
         best = s;
         best_j = j;
       }
-      else if (s == best && j < best_j)
-        best_j = j;
     }
     if (best < 0)
       break;
@@ -215,7 +236,8 @@ GTX_DEV uint32_t get_locations(GraphView const & g, uint32_t pos, DPath const & 
     for (uint32_t i = 0; i < nv; ++i)
     {
       uint32_t const v = fv + i;
-      if (pos >= g.var_order[v] && pos <= g.var_order[v] + g.var_len[v] - 1)
+      uint32_t const vo = g.var_order[v];
+      if (pos >= vo && pos <= vo + g.var_len[v] - 1)
         if (path_empty || ((mask >> i) & 1ull))
         {
           if (n >= cap)
@@ -223,7 +245,8 @@ GTX_DEV uint32_t get_locations(GraphView const & g, uint32_t pos, DPath const & 
             status |= GTX_ST_DFS_OVERFLOW;
             return n;
           }
-          locs[n++] = Loc{2, v, g.var_order[v], pos - g.var_order[v]};
+          GTX_LEAD locs[n] = Loc{2, v, vo, pos - vo};
+          ++n;
         }
     }
   }
@@ -237,177 +260,62 @@ GTX_DEV uint32_t get_locations(GraphView const & g, uint32_t pos, DPath const & 
 // ---------------------------------------------------------------------------------------------------------------
 struct SubRead
 {
-  uint8_t const * rd; // codes of the whole read
+  uint8_t const * rd; // codes of the whole read (LDS)
   uint32_t begin;     // first base of the sub-read
   uint32_t len;       // L
 };
 
-// compares graph characters dna[0..n) with sub-read characters starting at read offset `at` (forward), stops at L.
-// Returns the mismatch count capped at max+1 (= dead); '<' or '>' in the compared range kills (graph_utils.hpp:7-37).
-GTX_DEV uint32_t cmp_forward(SubRead const & sr, uint32_t at, char const * dna, uint32_t n, uint32_t mism, uint32_t maxmm)
+// count_mismatches / count_mismatches_backward (graph_utils.hpp:7-69) of graph codes dna[0..n) against the sub-read,
+// 64 characters per step, one per lane.  forward: dna[i] <-> sub-read[at+i]; backward: the candidate already covers
+// the last `at` characters and dna is prepended, dna[n-1-i] <-> sub-read[L-1-at-i].  Comparison stops at the
+// sub-read's end.  Returns the running count capped at max+1 (= dead); a '<' / '>' in the compared range kills.
+// (The reference stops counting at max+1 or at the tag, whichever comes first -- both mean "rejected".)
+template <class W, bool BACKWARD>
+GTX_DEV uint32_t cmp_codes(SubRead const & sr, uint32_t at, uint8_t const * dna, uint32_t n, uint32_t mism, uint32_t maxmm)
 {
-  for (uint32_t i = 0; i < n && at + i < sr.len; ++i)
+  if (mism > maxmm)
+    return maxmm + 1;
+  uint32_t const room = at < sr.len ? sr.len - at : 0;
+  uint32_t const m = n < room ? n : room;
+  for (uint32_t base = 0; base < m; base += 64)
   {
+    typename W::template PerLane<bool> kill, mm;
+    W::lanes([&](uint32_t l) {
+      uint32_t const i = base + l;
+      bool k = false, x = false;
+      if (i < m)
+      {
+        uint8_t const gc = BACKWARD ? dna[n - 1 - i] : dna[i];
+        uint8_t const rc = BACKWARD ? sr.rd[sr.begin + sr.len - 1 - at - i] : sr.rd[sr.begin + at + i];
+        k = gc == DNA_KILL;
+        x = gc != rc && rc != 15 && gc != 15;
+      }
+      kill[l] = k;
+      mm[l] = x;
+    });
+    if (W::ballot(kill) != 0)
+      return maxmm + 1;
+    mism += static_cast<uint32_t>(__builtin_popcountll(W::ballot(mm)));
     if (mism > maxmm)
       return maxmm + 1;
-    char const gc = dna[i];
-    if (gc == '>' || gc == '<')
-      return maxmm + 1;
-    char const rc = code_to_char(sr.rd[sr.begin + at + i]);
-    if (gc != rc && rc != 'N' && gc != 'N')
-      ++mism;
   }
-  return mism > maxmm ? maxmm + 1 : mism;
+  return mism;
 }
 
-// backward flavour: the candidate already covers the last `at` characters of the sub-read; dna[0..n) is prepended,
-// i.e. dna[n-1] aligns with sub-read character L-1-at (graph_utils.hpp:39-69).
-GTX_DEV uint32_t cmp_backward(SubRead const & sr, uint32_t at, char const * dna, uint32_t n, uint32_t mism, uint32_t maxmm)
-{
-  for (uint32_t i = 0; i < n && at + i < sr.len; ++i)
-  {
-    if (mism > maxmm)
-      return maxmm + 1;
-    char const gc = dna[n - 1 - i];
-    if (gc == '>' || gc == '<')
-      return maxmm + 1;
-    char const rc = code_to_char(sr.rd[sr.begin + sr.len - 1 - at - i]);
-    if (gc != rc && rc != 'N' && gc != 'N')
-      ++mism;
-  }
-  return mism > maxmm ? maxmm + 1 : mism;
-}
-
-GTX_DEV void cand_erase(Cand * c, uint32_t & n, uint32_t j)
+template <class W>
+GTX_DEV void cand_erase(Cand * c, uint32_t n, uint32_t j)
 {
   for (uint32_t k = j; k + 1 < n; ++k)
-    c[k] = c[k + 1];
-  --n;
+    copy_entry<W>(c[k], c[k + 1]);
 }
 
-// appends the labels of one start location; returns false on table overflow
-GTX_DEV bool labels_forward(GraphView const & g, Loc const & s, SubRead const & sr, uint32_t & max_mismatches, Cand * cand,
-                            DevLabel * out, uint32_t & n_out, uint32_t out_cap, uint32_t & status)
+// Emits the labels of the candidates that tie the fewest mismatches (graph.cpp:1375-1437 / 1636-1698).
+// `fixed_pos` = start position (forward) or end position (backward) shared by all labels of this location.
+template <class W, bool BACKWARD>
+GTX_DEV bool emit_best(GraphView const & g, Cand const * cand, uint32_t n, uint32_t L, uint32_t fixed_pos, uint32_t & max_mismatches,
+                       DevLabel * out, uint32_t & n_out, uint32_t out_cap, uint32_t & status)
 {
-  uint32_t const L = sr.len;
-  uint32_t const maxmm = max_mismatches;
-  uint32_t n = 1;
-  Cand & c0 = cand[0];
-  c0.nids = 0;
-  uint32_t site = INVALID; // site whose alleles come next (`vars`), INVALID = none
-  if (s.type == 2)
-  {
-    uint32_t const v = s.node;
-    c0.ids[c0.nids++] = v;
-    uint32_t const vlen = g.var_len[v] - s.offset;
-    c0.mism = cmp_forward(sr, 0, g.dna + g.var_dna[v] + s.offset, vlen, 0, maxmm);
-    c0.len = vlen;
-    uint32_t const vsite = g.var_out_ref[v] - 1;
-    if (c0.len >= L)
-      c0.pos = g_special_of(g, vsite, (g.var_order[v] + g.var_len[v] - 1) - (c0.len - L));
-    else
-    {
-      uint32_t const r = g.var_out_ref[v];
-      c0.mism = cmp_forward(sr, c0.len, g.dna + g.ref_dna[r], g.ref_len[r], c0.mism, maxmm);
-      c0.len += g.ref_len[r];
-      c0.pos = (g.ref_order[r] + g.ref_len[r] - 1) - (c0.len - L);
-      if (g.ref_nvar[r] > 0)
-        site = r;
-    }
-  }
-  else
-  {
-    uint32_t const r = s.node;
-    uint32_t const rl = g.ref_len[r] - s.offset;
-    c0.mism = cmp_forward(sr, 0, g.dna + g.ref_dna[r] + s.offset, rl, 0, maxmm);
-    c0.len = rl;
-    c0.pos = (g.ref_order[r] + g.ref_len[r] - 1) - (c0.len - L);
-    if (g.ref_nvar[r] > 0)
-      site = r;
-  }
-
-  if (site != INVALID && cand[0].len < L)
-  {
-    bool all_long = false;
-    while (!all_long && n < 128 && site != INVALID)
-    {
-      all_long = true;
-      uint32_t const r = site + 1; // reference node behind the site
-      uint32_t const fv = g.ref_first_var[site], nv = g.ref_nvar[site];
-      char const * rdna = g.dna + g.ref_dna[r];
-      uint32_t const rlen = g.ref_len[r];
-      uint32_t const rreach = g.ref_order[r] + rlen - 1;
-      uint32_t original = n;
-      for (uint32_t j = 0; j < original; ++j)
-      {
-        if (cand[j].len >= L)
-          continue;
-        for (uint32_t i = 0; i + 1 < nv; ++i)
-        {
-          uint32_t const v = fv + i;
-          uint32_t len = cand[j].len;
-          uint32_t mm = cmp_forward(sr, len, g.dna + g.var_dna[v], g.var_len[v], cand[j].mism, maxmm);
-          len += g.var_len[v];
-          bool const enough = len >= L;
-          if (!enough)
-          {
-            mm = cmp_forward(sr, len, rdna, rlen, mm, maxmm);
-            len += rlen;
-          }
-          if (mm <= maxmm)
-          {
-            if (n >= AlignCfg::CAND_CAP || cand[j].nids >= AlignCfg::MAXIDS)
-            {
-              status |= GTX_ST_DFS_OVERFLOW;
-              return false;
-            }
-            Cand & nc = cand[n++];
-            nc = cand[j];
-            nc.ids[nc.nids++] = v;
-            nc.len = len;
-            nc.mism = mm;
-            if (len < L)
-              all_long = false;
-            nc.pos = enough ? g_special_of(g, site, (g.var_order[v] + g.var_len[v] - 1) - (len - L)) : rreach - (len - L);
-          }
-        }
-        uint32_t const v = fv + nv - 1;
-        Cand & c = cand[j];
-        c.mism = cmp_forward(sr, c.len, g.dna + g.var_dna[v], g.var_len[v], c.mism, maxmm);
-        c.len += g.var_len[v];
-        bool const enough = c.len >= L;
-        if (!enough)
-        {
-          c.mism = cmp_forward(sr, c.len, rdna, rlen, c.mism, maxmm);
-          c.len += rlen;
-        }
-        if (c.mism <= maxmm)
-        {
-          if (c.nids >= AlignCfg::MAXIDS)
-          {
-            status |= GTX_ST_DFS_OVERFLOW;
-            return false;
-          }
-          c.ids[c.nids++] = v;
-          if (c.len < L)
-            all_long = false;
-          c.pos = enough ? g_special_of(g, site, (g.var_order[v] + g.var_len[v] - 1) - (c.len - L)) : rreach - (c.len - L);
-        }
-        else
-        {
-          cand_erase(cand, n, j);
-          --original;
-          --j;
-        }
-      }
-      if (all_long)
-        break;
-      site = g.ref_nvar[r] > 0 ? r : INVALID;
-    }
-  }
-
-  // keep the sequences with the fewest mismatches (graph.cpp:1375-1402); `<` tightens the budget and restarts
-  uint32_t first_out = n_out;
+  uint32_t const first_out = n_out;
   for (uint32_t j = 0; j < n; ++j)
   {
     if (cand[j].len < L)
@@ -420,198 +328,227 @@ GTX_DEV bool labels_forward(GraphView const & g, Loc const & s, SubRead const & 
       max_mismatches = mm;
       n_out = first_out;
     }
-    uint32_t start_pos = s.order + s.offset;
-    if (s.type == 2)
-      start_pos = g_special_of(g, g.var_out_ref[s.node] - 1, start_pos);
-    uint32_t const nl = cand[j].nids == 0 ? 1 : cand[j].nids;
+    uint32_t const nids = cand[j].nids;
+    uint32_t const nl = nids == 0 ? 1 : nids;
     if (n_out + nl > out_cap)
     {
       status |= GTX_ST_DFS_OVERFLOW;
       return false;
     }
-    if (cand[j].nids == 0)
-      out[n_out++] = DevLabel{start_pos, cand[j].pos, INVALID, 0};
+    uint32_t const p = cand[j].pos;
+    uint32_t const s = BACKWARD ? p : fixed_pos, e = BACKWARD ? fixed_pos : p;
+    if (nids == 0)
+    {
+      GTX_LEAD out[n_out] = DevLabel{s, e, INVALID, 0};
+      ++n_out;
+    }
     else
-      for (uint32_t k = 0; k < cand[j].nids; ++k)
+      for (uint32_t k = 0; k < nids; ++k)
       {
         uint32_t const v = cand[j].ids[k];
         uint32_t const vs = g.var_out_ref[v] - 1;
-        out[n_out++] = DevLabel{start_pos, cand[j].pos, vs, v - g.ref_first_var[vs]};
+        GTX_LEAD out[n_out] = DevLabel{s, e, vs, v - g.ref_first_var[vs]};
+        ++n_out;
       }
   }
+  W::lds_sync();
   return true;
 }
 
-GTX_DEV bool labels_backward(GraphView const & g, Loc const & e, SubRead const & sr, uint32_t & max_mismatches, Cand * cand,
-                             DevLabel * out, uint32_t & n_out, uint32_t out_cap, uint32_t & status)
+// One start (forward) or end (backward) location: extends over variant sites until every candidate covers the
+// sub-read, keeps candidates within the mismatch budget, appends the labels of the best ones to `out`.
+template <class W, bool BACKWARD>
+GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr, uint32_t & max_mismatches, Cand * cand,
+                         DevLabel * out, uint32_t & n_out, uint32_t out_cap, uint32_t & status)
 {
+  uint8_t const * dna = reinterpret_cast<uint8_t const *>(g.dna);
   uint32_t const L = sr.len;
   uint32_t const maxmm = max_mismatches;
   uint32_t n = 1;
-  Cand & c0 = cand[0];
-  c0.nids = 0;
-  uint32_t site = INVALID; // site whose alleles are prepended next
-  if (e.type == 2)
+  uint32_t site = INVALID; // site whose alleles come next, INVALID = none
+  uint32_t const s_type = s.type, s_node = s.node, s_offset = s.offset, s_order = s.order;
   {
-    uint32_t const v = e.node;
-    c0.ids[c0.nids++] = v;
-    uint32_t const vlen = e.offset + 1;
-    c0.mism = cmp_backward(sr, 0, g.dna + g.var_dna[v], vlen, 0, maxmm);
-    c0.len = vlen;
-    uint32_t const vsite = g.var_out_ref[v] - 1;
-    if (c0.len >= L)
-      c0.pos = g_special_of(g, vsite, g.var_order[v] + (c0.len - L));
+    uint32_t len, mism, pos, nids = 0, id0 = 0;
+    if (s_type == 2)
+    {
+      uint32_t const v = s_node;
+      nids = 1;
+      id0 = v;
+      uint32_t const vsite = g.var_out_ref[v] - 1;
+      uint32_t const vo = g.var_order[v], vl = g.var_len[v];
+      if (!BACKWARD)
+      {
+        len = vl - s_offset;
+        mism = cmp_codes<W, false>(sr, 0, dna + g.var_dna[v] + s_offset, len, 0, maxmm);
+        if (len >= L)
+          pos = g_special_of(g, vsite, (vo + vl - 1) - (len - L));
+        else
+        {
+          uint32_t const r = g.var_out_ref[v];
+          uint32_t const rl = g.ref_len[r];
+          mism = cmp_codes<W, false>(sr, len, dna + g.ref_dna[r], rl, mism, maxmm);
+          len += rl;
+          pos = (g.ref_order[r] + rl - 1) - (len - L);
+          if (g.ref_nvar[r] > 0)
+            site = r;
+        }
+      }
+      else
+      {
+        len = s_offset + 1;
+        mism = cmp_codes<W, true>(sr, 0, dna + g.var_dna[v], len, 0, maxmm);
+        if (len >= L)
+          pos = g_special_of(g, vsite, vo + (len - L));
+        else
+        {
+          uint32_t const r = vsite;
+          uint32_t const rl = g.ref_len[r];
+          mism = cmp_codes<W, true>(sr, len, dna + g.ref_dna[r], rl, mism, maxmm);
+          len += rl;
+          pos = g.ref_order[r] + (len - L);
+          if (r != 0)
+            site = r - 1;
+        }
+      }
+    }
     else
     {
-      uint32_t const r = vsite;
-      c0.mism = cmp_backward(sr, c0.len, g.dna + g.ref_dna[r], g.ref_len[r], c0.mism, maxmm);
-      c0.len += g.ref_len[r];
-      c0.pos = g.ref_order[r] + (c0.len - L);
-      if (r != 0)
+      uint32_t const r = s_node;
+      uint32_t const rl = g.ref_len[r];
+      if (!BACKWARD)
+      {
+        len = rl - s_offset;
+        mism = cmp_codes<W, false>(sr, 0, dna + g.ref_dna[r] + s_offset, len, 0, maxmm);
+        pos = (g.ref_order[r] + rl - 1) - (len - L);
+        if (g.ref_nvar[r] > 0)
+          site = r;
+      }
+      else
+      {
+        if (r != 0)
+          site = r - 1;
+        len = s_offset + 1;
+        mism = cmp_codes<W, true>(sr, 0, dna + g.ref_dna[r], len, 0, maxmm);
+        pos = g.ref_order[r] + (len - L);
+      }
+    }
+    GTX_LEAD
+    {
+      cand[0].len = len;
+      cand[0].mism = mism;
+      cand[0].pos = pos;
+      cand[0].nids = nids;
+      cand[0].ids[0] = id0;
+    }
+    W::lds_sync();
+  }
+
+  if (site != INVALID && cand[0].len < L)
+  {
+    bool all_long = false;
+    while (!all_long && n < 128 && site != INVALID)
+    {
+      all_long = true;
+      uint32_t const r = BACKWARD ? site : site + 1; // reference node appended (forward) / prepended (backward)
+      uint32_t const fv = g.ref_first_var[site], nv = g.ref_nvar[site];
+      uint8_t const * rdna = dna + g.ref_dna[r];
+      uint32_t const rlen = g.ref_len[r];
+      uint32_t const rorder = g.ref_order[r];
+      uint32_t original = n;
+      for (uint32_t j = 0; j < original; ++j)
+      {
+        uint32_t const jlen = cand[j].len, jmism = cand[j].mism, jn = cand[j].nids;
+        if (jlen >= L)
+          continue;
+        for (uint32_t i = 0; i < nv; ++i)
+        {
+          bool const last = i + 1 == nv; // the last allele extends candidate j in place, the others branch off copies
+          uint32_t const v = fv + i;
+          uint32_t const vo = g.var_order[v], vl = g.var_len[v];
+          uint32_t len = jlen;
+          uint32_t mm = cmp_codes<W, BACKWARD>(sr, len, dna + g.var_dna[v], vl, jmism, maxmm);
+          len += vl;
+          bool const enough = len >= L;
+          if (!enough)
+          {
+            mm = cmp_codes<W, BACKWARD>(sr, len, rdna, rlen, mm, maxmm);
+            len += rlen;
+          }
+          if (mm <= maxmm)
+          {
+            if ((!last && n >= AlignCfg::CAND_CAP) || jn >= AlignCfg::MAXIDS)
+            {
+              status |= GTX_ST_DFS_OVERFLOW;
+              return false;
+            }
+            uint32_t pos;
+            if (!BACKWARD)
+              pos = enough ? g_special_of(g, site, (vo + vl - 1) - (len - L)) : (rorder + rlen - 1) - (len - L);
+            else
+              pos = enough ? g_special_of(g, site, vo + (len - L)) : rorder + (len - L);
+            uint32_t const dst = last ? j : n;
+            if (!last)
+            {
+              copy_entry<W>(cand[n], cand[j]);
+              ++n;
+            }
+            GTX_LEAD
+            {
+              Cand & nc = cand[dst];
+              nc.ids[jn] = v;
+              nc.nids = jn + 1;
+              nc.len = len;
+              nc.mism = mm;
+              nc.pos = pos;
+            }
+            W::lds_sync();
+            if (len < L)
+              all_long = false;
+          }
+          else if (last)
+          {
+            cand_erase<W>(cand, n, j);
+            --n;
+            --original;
+            --j;
+          }
+        }
+      }
+      if (all_long)
+        break;
+      if (!BACKWARD)
+        site = g.ref_nvar[r] > 0 ? r : INVALID;
+      else
+      {
+        if (r == 0)
+          break;
         site = r - 1;
-    }
-  }
-  else
-  {
-    uint32_t const r = e.node;
-    if (r != 0)
-      site = r - 1;
-    uint32_t const rl = e.offset + 1;
-    c0.mism = cmp_backward(sr, 0, g.dna + g.ref_dna[r], rl, 0, maxmm);
-    c0.len = rl;
-    c0.pos = g.ref_order[r] + (c0.len - L);
-  }
-
-  if (site != INVALID && cand[0].len < L)
-  {
-    bool all_long = false;
-    while (!all_long && n < 128 && site != INVALID)
-    {
-      all_long = true;
-      uint32_t const r = site; // reference node in front of the site
-      uint32_t const fv = g.ref_first_var[site], nv = g.ref_nvar[site];
-      char const * rdna = g.dna + g.ref_dna[r];
-      uint32_t const rlen = g.ref_len[r];
-      uint32_t original = n;
-      for (uint32_t j = 0; j < original; ++j)
-      {
-        if (cand[j].len >= L)
-          continue;
-        for (uint32_t i = 0; i + 1 < nv; ++i)
-        {
-          uint32_t const v = fv + i;
-          uint32_t len = cand[j].len;
-          uint32_t mm = cmp_backward(sr, len, g.dna + g.var_dna[v], g.var_len[v], cand[j].mism, maxmm);
-          len += g.var_len[v];
-          bool const enough = len >= L;
-          if (!enough)
-          {
-            mm = cmp_backward(sr, len, rdna, rlen, mm, maxmm);
-            len += rlen;
-          }
-          if (mm <= maxmm)
-          {
-            if (n >= AlignCfg::CAND_CAP || cand[j].nids >= AlignCfg::MAXIDS)
-            {
-              status |= GTX_ST_DFS_OVERFLOW;
-              return false;
-            }
-            Cand & nc = cand[n++];
-            nc = cand[j];
-            nc.ids[nc.nids++] = v;
-            nc.len = len;
-            nc.mism = mm;
-            if (len < L)
-              all_long = false;
-            nc.pos = enough ? g_special_of(g, site, g.var_order[v] + (len - L)) : g.ref_order[r] + (len - L);
-          }
-        }
-        uint32_t const v = fv + nv - 1;
-        Cand & c = cand[j];
-        c.mism = cmp_backward(sr, c.len, g.dna + g.var_dna[v], g.var_len[v], c.mism, maxmm);
-        c.len += g.var_len[v];
-        bool const enough = c.len >= L;
-        if (!enough)
-        {
-          c.mism = cmp_backward(sr, c.len, rdna, rlen, c.mism, maxmm);
-          c.len += rlen;
-        }
-        if (c.mism <= maxmm)
-        {
-          if (c.nids >= AlignCfg::MAXIDS)
-          {
-            status |= GTX_ST_DFS_OVERFLOW;
-            return false;
-          }
-          c.ids[c.nids++] = v;
-          if (c.len < L)
-            all_long = false;
-          c.pos = enough ? g_special_of(g, site, g.var_order[v] + (c.len - L)) : g.ref_order[r] + (c.len - L);
-        }
-        else
-        {
-          cand_erase(cand, n, j);
-          --original;
-          --j;
-        }
       }
-      if (all_long)
-        break;
-      if (r == 0)
-        break;
-      site = r - 1;
     }
   }
 
-  uint32_t first_out = n_out;
-  for (uint32_t j = 0; j < n; ++j)
-  {
-    if (cand[j].len < L)
-      continue;
-    uint32_t const mm = cand[j].mism;
-    if (mm > max_mismatches)
-      continue;
-    if (mm < max_mismatches)
-    {
-      max_mismatches = mm;
-      n_out = first_out;
-    }
-    uint32_t end_pos = e.order + e.offset;
-    if (e.type == 2)
-      end_pos = g_special_of(g, g.var_out_ref[e.node] - 1, end_pos);
-    uint32_t const nl = cand[j].nids == 0 ? 1 : cand[j].nids;
-    if (n_out + nl > out_cap)
-    {
-      status |= GTX_ST_DFS_OVERFLOW;
-      return false;
-    }
-    if (cand[j].nids == 0)
-      out[n_out++] = DevLabel{cand[j].pos, end_pos, INVALID, 0};
-    else
-      for (uint32_t k = 0; k < cand[j].nids; ++k)
-      {
-        uint32_t const v = cand[j].ids[k];
-        uint32_t const vs = g.var_out_ref[v] - 1;
-        out[n_out++] = DevLabel{cand[j].pos, end_pos, vs, v - g.ref_first_var[vs]};
-      }
-  }
-  return true;
+  uint32_t fixed = s_order + s_offset;
+  if (s_type == 2)
+    fixed = g_special_of(g, g.var_out_ref[s_node] - 1, fixed);
+  return emit_best<W, BACKWARD>(g, cand, n, L, fixed, max_mismatches, out, n_out, out_cap, status);
 }
 
 // Graph::iterative_dfs (graph.cpp:1703-1754): labels of all locations that tie the fewest mismatches
+template <class W>
 GTX_DEV uint32_t iterative_dfs(GraphView const & g, AlignWorkspace & ws, uint32_t n_locs, bool backward, SubRead const & sr,
-                               uint32_t & max_mismatches)
+                               uint32_t & max_mismatches, uint32_t & status)
 {
   uint32_t n_out = 0;
   if (n_locs > 1024)
     return 0;
+  WalkBuffers & wb = ws.u.w;
   for (uint32_t k = 0; k < n_locs; ++k)
   {
     uint32_t mm = max_mismatches;
     uint32_t const before = n_out;
     uint32_t after = n_out;
-    bool ok = backward ? labels_backward(g, ws.locs[k], sr, mm, ws.u.cand, ws.dfs_out, after, AlignCfg::WL_CAP, ws.status)
-                       : labels_forward(g, ws.locs[k], sr, mm, ws.u.cand, ws.dfs_out, after, AlignCfg::WL_CAP, ws.status);
+    bool const ok = backward ? labels_walk<W, true>(g, wb.locs[k], sr, mm, wb.cand, wb.dfs_out, after, AlignCfg::WL_CAP, status)
+                             : labels_walk<W, false>(g, wb.locs[k], sr, mm, wb.cand, wb.dfs_out, after, AlignCfg::WL_CAP, status);
     if (!ok)
       return 0;
     if (after == before)
@@ -619,15 +556,15 @@ GTX_DEV uint32_t iterative_dfs(GraphView const & g, AlignWorkspace & ws, uint32_
     if (mm < max_mismatches)
     {
       max_mismatches = mm;
-      // labels = new_labels
-      uint32_t const cnt = after - before;
-      for (uint32_t i = 0; i < cnt; ++i)
-        ws.dfs_out[i] = ws.dfs_out[before + i];
+      uint32_t const cnt = after - before; // labels = new_labels
+      if (before != 0)
+        for (uint32_t i = 0; i < cnt; ++i)
+          copy_entry<W>(wb.dfs_out[i], wb.dfs_out[before + i]);
       n_out = cnt;
     }
     else if (mm == max_mismatches)
       n_out = after;
-    // mm > max_mismatches cannot happen: the walk never returns labels above its budget
+    // mm > max_mismatches cannot happen: a walk never returns labels above its budget
   }
   return n_out;
 }
@@ -637,150 +574,191 @@ GTX_DEV uint32_t iterative_dfs(GraphView const & g, AlignWorkspace & ws, uint32_
 // ---------------------------------------------------------------------------------------------------------------
 
 // find_all_nonduplicated_paths (genotype_paths.cpp:32-66) + Path::merge_with_current (path.cpp:105-129)
-GTX_DEV uint32_t make_pp(AlignWorkspace & ws, DevLabel const * ll, uint32_t n, uint32_t rs, uint32_t re, uint32_t mism)
+template <class W>
+GTX_DEV uint32_t make_pp(DPath * pp, DevLabel const * ll, uint32_t n, uint32_t rs, uint32_t re, uint32_t mism, uint32_t & status)
 {
   uint32_t npp = 0;
   for (uint32_t i = 0; i < n; ++i)
   {
-    DevLabel const l = ll[i];
+    uint32_t const ls = ll[i].start, le = ll[i].end, lsite = ll[i].site, lall = ll[i].allele;
     uint32_t d = 0;
     for (; d < npp; ++d)
-      if (ws.pp[d].start == l.start && ws.pp[d].end == l.end)
+      if (pp[d].start == ls && pp[d].end == le)
         break;
     if (d == npp)
     {
       if (npp >= AlignCfg::MAXPP)
       {
-        ws.status |= GTX_ST_PATH_OVERFLOW;
+        status |= GTX_ST_PATH_OVERFLOW;
         return npp;
       }
-      DPath & p = ws.pp[npp++];
-      p.start = l.start;
-      p.end = l.end;
-      p.rs = static_cast<uint16_t>(rs);
-      p.re = static_cast<uint16_t>(re);
-      p.mism = static_cast<uint16_t>(mism);
-      p.nvar = 0;
-      if (l.site != INVALID)
+      GTX_LEAD
       {
-        p.v[0].site = l.site;
-        pv_set(p.v[0], 1ull << l.allele);
-        p.nvar = 1;
+        DPath & p = pp[npp];
+        p.start = ls;
+        p.end = le;
+        p.rs = static_cast<uint16_t>(rs);
+        p.re = static_cast<uint16_t>(re);
+        p.mism = static_cast<uint16_t>(mism);
+        p.nvar = lsite != INVALID ? 1 : 0;
+        if (lsite != INVALID)
+        {
+          p.v[0].site = lsite;
+          p.v[0].mlo = static_cast<uint32_t>(1ull << lall);
+          p.v[0].mhi = static_cast<uint32_t>((1ull << lall) >> 32);
+        }
       }
+      W::lds_sync();
+      ++npp;
       continue;
     }
-    if (l.site == INVALID)
+    if (lsite == INVALID)
       continue;
-    DPath & p = ws.pp[d];
+    DPath & p = pp[d];
+    uint32_t const nvar = p.nvar;
     uint32_t k = 0;
-    for (; k < p.nvar; ++k)
-      if (p.v[k].site == l.site)
+    for (; k < nvar; ++k)
+      if (p.v[k].site == lsite)
         break;
-    if (k < p.nvar)
-      pv_set(p.v[k], pv_mask(p.v[k]) | (1ull << l.allele));
-    else
+    if (k == nvar && nvar >= AlignCfg::MAXV)
     {
-      if (p.nvar >= AlignCfg::MAXV)
-      {
-        ws.status |= GTX_ST_PATH_OVERFLOW;
-        return npp;
-      }
-      p.v[p.nvar].site = l.site;
-      pv_set(p.v[p.nvar], 1ull << l.allele);
-      ++p.nvar;
+      status |= GTX_ST_PATH_OVERFLOW;
+      return npp;
     }
+    GTX_LEAD
+    {
+      if (k < nvar)
+      {
+        p.v[k].mlo |= static_cast<uint32_t>(1ull << lall);
+        p.v[k].mhi |= static_cast<uint32_t>((1ull << lall) >> 32);
+      }
+      else
+      {
+        p.v[nvar].site = lsite;
+        p.v[nvar].mlo = static_cast<uint32_t>(1ull << lall);
+        p.v[nvar].mhi = static_cast<uint32_t>((1ull << lall) >> 32);
+        p.nvar = static_cast<uint16_t>(nvar + 1);
+      }
+    }
+    W::lds_sync();
   }
   return npp;
 }
 
-// Path::Path(p1, p2) (path.cpp:38-82): everything from p2, allele sets of shared sites intersected with p1's, p1's
-// other sites appended, start/read_start_index taken from p1.  false <=> the reference returns early on an empty
-// intersection (its caller then discards the half merged object).
+// Path::Path(p1, p2) (path.cpp:38-82) into `np` (LDS): everything from p2, allele sets of shared sites intersected
+// with p1's, p1's other sites appended, start/read_start_index taken from p1.  false <=> the reference returns early
+// on an empty intersection (its caller then discards the half merged object).
+template <class W>
 GTX_DEV bool merge_paths(DPath const & p1, DPath const & p2, DPath & np, uint32_t & status)
 {
-  np = p2;
-  for (uint32_t i = 0; i < p1.nvar; ++i)
+  copy_entry<W>(np, p2);
+  uint32_t const n1 = p1.nvar;
+  uint32_t nn = np.nvar;
+  for (uint32_t i = 0; i < n1; ++i)
   {
+    uint32_t const s1 = p1.v[i].site;
     uint32_t j = 0;
-    for (; j < np.nvar; ++j)
-      if (np.v[j].site == p1.v[i].site)
+    for (; j < nn; ++j)
+      if (np.v[j].site == s1)
         break;
-    if (j < np.nvar)
+    if (j < nn)
     {
-      uint64_t const m = pv_mask(np.v[j]) & pv_mask(p1.v[i]);
-      pv_set(np.v[j], m);
-      if (m == 0)
+      uint32_t const lo = np.v[j].mlo & p1.v[i].mlo, hi = np.v[j].mhi & p1.v[i].mhi;
+      if ((lo | hi) == 0)
         return false;
+      GTX_LEAD
+      {
+        np.v[j].mlo = lo;
+        np.v[j].mhi = hi;
+      }
     }
     else
     {
-      if (np.nvar >= AlignCfg::MAXV)
+      if (nn >= AlignCfg::MAXV)
       {
         status |= GTX_ST_PATH_OVERFLOW;
         return false;
       }
-      np.v[np.nvar++] = p1.v[i];
+      GTX_LEAD np.v[nn] = p1.v[i];
+      ++nn;
     }
+    W::lds_sync();
   }
-  np.rs = p1.rs;
-  np.start = p1.start;
-  np.mism = static_cast<uint16_t>(np.mism + p1.mism);
+  GTX_LEAD
+  {
+    np.nvar = static_cast<uint16_t>(nn);
+    np.rs = p1.rs;
+    np.start = p1.start;
+    np.mism = static_cast<uint16_t>(np.mism + p1.mism);
+  }
+  W::lds_sync();
   return true;
 }
 
-GTX_DEV void push_path(AlignWorkspace & ws, DPath const & p)
+// appends to ws.paths; n_paths is tracked by the caller
+template <class W>
+GTX_DEV bool push_path(AlignWorkspace & ws, uint32_t & n_paths, DPath const & p, uint32_t & status)
 {
-  if (ws.n_paths >= AlignCfg::MAXP)
+  if (n_paths >= AlignCfg::MAXP)
   {
-    ws.status |= GTX_ST_PATH_OVERFLOW;
-    return;
+    status |= GTX_ST_PATH_OVERFLOW;
+    return false;
   }
-  ws.paths[ws.n_paths++] = p;
+  copy_entry<W>(ws.paths[n_paths], p);
+  ++n_paths;
+  return true;
 }
 
+template <class W>
 GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t n, uint32_t rs, uint32_t re, uint32_t mism,
-                             bool prev)
+                             bool prev, uint32_t & n_paths, uint32_t & longest, uint32_t & status)
 {
-  uint32_t const npp = make_pp(ws, ll, n, rs, re, mism);
-  if (ws.status)
+  if (n == 0)
     return;
-  uint32_t const original_size = ws.n_paths;
+  DPath * pp = ws.u.w.pp;
+  uint32_t const npp = make_pp<W>(pp, ll, n, rs, re, mism, status);
+  if (status)
+    return;
+  uint32_t const original_size = n_paths;
   uint64_t matched = 0;
   for (uint32_t i = 0; i < original_size; ++i)
   {
     if (prev ? (ws.paths[i].rs != re) : (ws.paths[i].re != rs))
       continue;
     bool once = false;
-    DPath const original = ws.paths[i];
+    copy_entry<W>(ws.orig, ws.paths[i]);
+    uint32_t const o_start = ws.orig.start, o_end = ws.orig.end;
     for (uint32_t j = 0; j < npp; ++j)
     {
-      DPath np;
       bool ok;
       if (prev)
       {
-        if (!(ws.pp[j].end == original.start))
+        if (!(pp[j].end == o_start))
           continue;
-        ok = merge_paths(ws.pp[j], original, np, ws.status);
+        ok = merge_paths<W>(pp[j], ws.orig, ws.np, status);
       }
       else
       {
-        if (!(original.end == ws.pp[j].start))
+        if (!(o_end == pp[j].start))
           continue;
-        ok = merge_paths(original, ws.pp[j], np, ws.status);
+        ok = merge_paths<W>(ws.orig, pp[j], ws.np, status);
       }
-      if (ws.status)
+      if (status)
         return;
       if (!ok)
         continue;
       matched |= 1ull << j;
       if (once)
-        push_path(ws, np);
+      {
+        if (!push_path<W>(ws, n_paths, ws.np, status))
+          return;
+      }
       else
       {
-        uint32_t const sz = path_size(np);
-        if (sz > ws.longest)
-          ws.longest = sz;
-        ws.paths[i] = np;
+        uint32_t const sz = path_size(ws.np);
+        if (sz > longest)
+          longest = sz;
+        copy_entry<W>(ws.paths[i], ws.np);
         once = true;
       }
     }
@@ -788,190 +766,219 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
   for (uint32_t j = 0; j < npp; ++j)
     if (!((matched >> j) & 1ull))
     {
-      uint32_t const sz = path_size(ws.pp[j]);
-      if (sz > ws.longest)
-        ws.longest = sz;
-      push_path(ws, ws.pp[j]);
+      uint32_t const sz = path_size(pp[j]);
+      if (sz > longest)
+        longest = sz;
+      if (!push_path<W>(ws, n_paths, pp[j], status))
+        return;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // path filters (genotype_paths.cpp)
 // ---------------------------------------------------------------------------------------------------------------
-GTX_DEV void remove_short_paths(AlignWorkspace & ws) // :824-834
+
+// stable removal of the paths whose bit in `drop` is set
+template <class W>
+GTX_DEV uint32_t compact_paths(AlignWorkspace & ws, uint32_t n_paths, uint64_t drop)
 {
-  if (ws.longest <= 1)
-    return;
+  if (drop == 0)
+    return n_paths;
   uint32_t k = 0;
-  for (uint32_t i = 0; i < ws.n_paths; ++i)
-    if (!(path_size(ws.paths[i]) < ws.longest))
+  for (uint32_t i = 0; i < n_paths; ++i)
+    if (!((drop >> i) & 1ull))
     {
       if (k != i)
-        ws.paths[k] = ws.paths[i];
+        copy_entry<W>(ws.paths[k], ws.paths[i]);
       ++k;
     }
-  ws.n_paths = k;
+  return k;
 }
 
-GTX_DEV void update_longest(AlignWorkspace & ws) // :858-864
+template <class W>
+GTX_DEV uint32_t remove_short_paths(AlignWorkspace & ws, uint32_t n_paths, uint32_t longest) // :824-834
+{
+  if (longest <= 1)
+    return n_paths;
+  uint64_t drop = 0;
+  for (uint32_t i = 0; i < n_paths; ++i)
+    if (path_size(ws.paths[i]) < longest)
+      drop |= 1ull << i;
+  return compact_paths<W>(ws, n_paths, drop);
+}
+
+GTX_DEV uint32_t longest_of(AlignWorkspace const & ws, uint32_t n_paths) // :858-864
 {
   uint32_t m = 0;
-  for (uint32_t i = 0; i < ws.n_paths; ++i)
+  for (uint32_t i = 0; i < n_paths; ++i)
   {
     uint32_t const s = path_size(ws.paths[i]);
     if (s > m)
       m = s;
   }
-  ws.longest = m;
+  return m;
 }
 
-GTX_DEV void remove_paths_with_too_many_mismatches(AlignWorkspace & ws) // :360-380
+template <class W>
+GTX_DEV uint32_t remove_paths_with_too_many_mismatches(AlignWorkspace & ws, uint32_t n_paths) // :360-380
 {
-  if (ws.n_paths == 0)
-    return;
+  if (n_paths == 0)
+    return 0;
   uint32_t mn = 10;
-  for (uint32_t i = 0; i < ws.n_paths; ++i)
+  for (uint32_t i = 0; i < n_paths; ++i)
     if (ws.paths[i].mism < mn)
       mn = ws.paths[i].mism;
-  uint32_t k = 0;
-  for (uint32_t i = 0; i < ws.n_paths; ++i)
-    if (!(ws.paths[i].mism > mn))
-    {
-      if (k != i)
-        ws.paths[k] = ws.paths[i];
-      ++k;
-    }
-  ws.n_paths = k;
+  uint64_t drop = 0;
+  for (uint32_t i = 0; i < n_paths; ++i)
+    if (ws.paths[i].mism > mn)
+      drop |= 1ull << i;
+  return compact_paths<W>(ws, n_paths, drop);
 }
 
 GTX_DEV bool all_paths_unique(GraphView const & g, DPath const * paths, uint32_t n) // :219-231
 {
+  if (n < 2)
+    return true;
+  uint32_t const s0 = g_ref_reach_pos(g, paths[0].start), e0 = g_ref_reach_pos(g, paths[0].end);
   for (uint32_t i = 1; i < n; ++i)
-    if (g_ref_reach_pos(g, paths[0].start) != g_ref_reach_pos(g, paths[i].start) &&
-        g_ref_reach_pos(g, paths[0].end) != g_ref_reach_pos(g, paths[i].end))
+    if (s0 != g_ref_reach_pos(g, paths[i].start) && e0 != g_ref_reach_pos(g, paths[i].end))
       return false;
   return true;
 }
 
 GTX_DEV bool path_is_reference(DPath const & p) // path.cpp:176-185
 {
-  for (uint32_t k = 0; k < p.nvar; ++k)
-    if (!(pv_mask(p.v[k]) & 1ull))
+  uint32_t const nv = p.nvar;
+  for (uint32_t k = 0; k < nv; ++k)
+    if (!(p.v[k].mlo & 1u))
       return false;
   return true;
 }
 
-GTX_DEV void remove_non_ref_paths_when_read_matches_ref(GraphView const & g, AlignWorkspace & ws) // :460-474
+template <class W>
+GTX_DEV uint32_t remove_non_ref_paths_when_read_matches_ref(GraphView const & g, AlignWorkspace & ws, uint32_t n_paths) // :460-474
 {
-  if (all_paths_unique(g, ws.paths, ws.n_paths))
-    return;
-  bool any = false;
-  for (uint32_t i = 0; i < ws.n_paths; ++i)
-    if (path_is_reference(ws.paths[i]))
-      any = true;
-  if (!any)
-    return;
-  uint32_t k = 0;
-  for (uint32_t i = 0; i < ws.n_paths; ++i)
-    if (path_is_reference(ws.paths[i]))
-    {
-      if (k != i)
-        ws.paths[k] = ws.paths[i];
-      ++k;
-    }
-  ws.n_paths = k;
+  if (all_paths_unique(g, ws.paths, n_paths))
+    return n_paths;
+  uint64_t nonref = 0;
+  for (uint32_t i = 0; i < n_paths; ++i)
+    if (!path_is_reference(ws.paths[i]))
+      nonref |= 1ull << i;
+  uint64_t const all = n_paths >= 64 ? ~0ull : ((1ull << n_paths) - 1);
+  if (nonref == all)
+    return n_paths; // no path supports only the reference
+  return compact_paths<W>(ws, n_paths, nonref);
 }
 
-GTX_DEV void remove_fully_special_paths(GraphView const & g, AlignWorkspace & ws) // :476-481
+template <class W>
+GTX_DEV uint32_t remove_fully_special_paths(GraphView const & g, AlignWorkspace & ws, uint32_t n_paths) // :476-481
 {
-  uint32_t k = 0;
-  for (uint32_t i = 0; i < ws.n_paths; ++i)
-    if (g_ref_reach_pos(g, ws.paths[i].start) != g_ref_reach_pos(g, ws.paths[i].end))
-    {
-      if (k != i)
-        ws.paths[k] = ws.paths[i];
-      ++k;
-    }
-  ws.n_paths = k;
+  uint64_t drop = 0;
+  for (uint32_t i = 0; i < n_paths; ++i)
+    if (g_ref_reach_pos(g, ws.paths[i].start) == g_ref_reach_pos(g, ws.paths[i].end))
+      drop |= 1ull << i;
+  return compact_paths<W>(ws, n_paths, drop);
 }
 
-GTX_DEV uint32_t site_order(GraphView const & g, uint32_t site)
+template <class W>
+GTX_DEV void remove_support_from_read_ends(GraphView const & g, AlignWorkspace & ws, uint32_t n_paths) // :382-432
 {
-  return g.ref_order[site] + g.ref_len[site]; // order of the site's variant nodes
-}
-
-GTX_DEV void remove_support_from_read_ends(GraphView const & g, AlignWorkspace & ws) // :382-432
-{
-  for (uint32_t i = 0; i < ws.n_paths; ++i)
+  for (uint32_t i = 0; i < n_paths; ++i)
   {
     DPath & p = ws.paths[i];
-    if (p.nvar == 0)
+    uint32_t const nvar = p.nvar;
+    if (nvar == 0)
       continue;
-    bool const ss = g_is_special(g, p.start), es = g_is_special(g, p.end);
+    uint32_t const pstart = p.start, pend = p.end;
+    bool const ss = g_is_special(g, pstart), es = g_is_special(g, pend);
     if (!ss && !es)
       continue;
     // std::minmax_element: first smallest, last largest
     uint32_t imin = 0, imax = 0;
-    for (uint32_t k = 1; k < p.nvar; ++k)
+    uint32_t omin = site_order(g, p.v[0].site), omax = omin;
+    for (uint32_t k = 1; k < nvar; ++k)
     {
-      if (site_order(g, p.v[k].site) < site_order(g, p.v[imin].site))
+      uint32_t const o = site_order(g, p.v[k].site);
+      if (o < omin)
+      {
+        omin = o;
         imin = k;
-      if (!(site_order(g, p.v[k].site) < site_order(g, p.v[imax].site)))
+      }
+      if (!(o < omax))
+      {
+        omax = o;
         imax = k;
+      }
     }
-    if (es && static_cast<int64_t>(g_actual_pos(g, p.end)) <= static_cast<int64_t>(site_order(g, p.v[imax].site)) + 4)
-      pv_set(p.v[imax], 0);
+    bool const clear_max = es && static_cast<int64_t>(g_actual_pos(g, pend)) <= static_cast<int64_t>(omax) + 4;
+    bool clear_min = false;
     if (ss)
     {
       bool ambiguous = true;
-      if (g_is_special(g, p.start + 4u))
-        ambiguous = g_ref_reach_pos(g, p.start) != g_ref_reach_pos(g, p.start + 4u);
-      if (ambiguous)
-        pv_set(p.v[imin], 0);
+      if (g_is_special(g, pstart + 4u))
+        ambiguous = g_ref_reach_pos(g, pstart) != g_ref_reach_pos(g, pstart + 4u);
+      clear_min = ambiguous;
     }
+    GTX_LEAD
+    {
+      if (clear_max)
+      {
+        p.v[imax].mlo = 0;
+        p.v[imax].mhi = 0;
+      }
+      if (clear_min)
+      {
+        p.v[imin].mlo = 0;
+        p.v[imin].mhi = 0;
+      }
+    }
+    W::lds_sync();
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // GenotypePaths::walk_read_ends / walk_read_starts (genotype_paths.cpp:483-553 / 555-621)
 // ---------------------------------------------------------------------------------------------------------------
-GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts)
+template <class W>
+GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, uint32_t & n_paths, uint32_t & longest,
+                       uint32_t & status)
 {
   uint32_t const L = ws.read_len;
-  if (ws.n_paths == 0 || path_size(ws.paths[0]) == L)
+  if (n_paths == 0 || path_size(ws.paths[0]) == L)
     return;
-  if (ws.n_paths > MAX_SEED_NUMBER_FOR_WALKING)
+  if (n_paths > MAX_SEED_NUMBER_FOR_WALKING)
     return;
   int maximum_mismatches = -1;
-  if (ws.n_paths > MAX_SEED_NUMBER_ALLOWING_MISMATCHES)
+  if (n_paths > MAX_SEED_NUMBER_ALLOWING_MISMATCHES)
     maximum_mismatches = 0;
   uint32_t best = 7;
-  ws.n_wl = 0;
-  ws.n_wlists = 0;
-  ws.wl_off[0] = 0;
-  for (uint32_t i = 0; i < ws.n_paths; ++i)
+  uint32_t n_wl = 0, n_wlists = 0;
+  WalkBuffers & wb = ws.u.w;
+  for (uint32_t i = 0; i < n_paths; ++i)
   {
     DPath const & path = ws.paths[i];
+    uint32_t const prs = path.rs, pre = path.re;
     SubRead sr;
     sr.rd = ws.rd;
     uint32_t n_locs;
     if (starts)
     {
-      if (path.rs == 0)
+      if (prs == 0)
         continue;
       sr.begin = 0;
-      sr.len = path.rs + 1u;
-      n_locs = get_locations(g, path.start, path, ws.locs, AlignCfg::LOC_CAP, ws.status);
+      sr.len = prs + 1u;
+      n_locs = get_locations<W>(g, path.start, path, wb.locs, AlignCfg::LOC_CAP, status);
     }
     else
     {
-      if (path.re == L - 1)
+      if (pre == L - 1)
         continue;
-      n_locs = get_locations(g, path.end, path, ws.locs, AlignCfg::LOC_CAP, ws.status);
-      sr.begin = path.re;
-      sr.len = L - path.re;
+      n_locs = get_locations<W>(g, path.end, path, wb.locs, AlignCfg::LOC_CAP, status);
+      sr.begin = pre;
+      sr.len = L - pre;
     }
-    if (ws.status)
+    W::lds_sync();
+    if (status)
       return;
     if (n_locs == 0 || n_locs > MAX_NUM_LOCATIONS_PER_PATH)
       continue;
@@ -983,41 +990,47 @@ GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts)
     }
     else
       mm = static_cast<uint32_t>(maximum_mismatches);
-    uint32_t const nl = iterative_dfs(g, ws, n_locs, starts, sr, mm);
-    if (ws.status)
+    uint32_t const nl = iterative_dfs<W>(g, ws, n_locs, starts, sr, mm, status);
+    if (status)
       return;
     if (nl == 0)
       continue;
     if (mm < best)
     {
-      ws.n_wl = 0;
-      ws.n_wlists = 0;
+      n_wl = 0;
+      n_wlists = 0;
       best = mm;
     }
     if (mm == best)
     {
-      if (ws.n_wlists >= AlignCfg::WLISTS || ws.n_wl + nl > AlignCfg::WL_CAP)
+      if (n_wlists >= AlignCfg::WLISTS || n_wl + nl > AlignCfg::WL_CAP)
       {
-        ws.status |= GTX_ST_DFS_OVERFLOW;
+        status |= GTX_ST_DFS_OVERFLOW;
         return;
       }
       for (uint32_t k = 0; k < nl; ++k)
-        ws.wl[ws.n_wl + k] = ws.dfs_out[k];
-      ws.wl_idx[ws.n_wlists] = starts ? path.rs : path.re;
-      ws.n_wl += nl;
-      ++ws.n_wlists;
-      ws.wl_off[ws.n_wlists] = ws.n_wl;
+        copy_entry<W>(ws.wl[n_wl + k], wb.dfs_out[k]);
+      GTX_LEAD
+      {
+        ws.wl_idx[n_wlists] = starts ? prs : pre;
+        ws.wl_off[n_wlists] = n_wl;
+        ws.wl_off[n_wlists + 1] = n_wl + nl;
+      }
+      W::lds_sync();
+      n_wl += nl;
+      ++n_wlists;
     }
   }
-  for (uint32_t k = 0; k < ws.n_wlists; ++k)
+  for (uint32_t k = 0; k < n_wlists; ++k)
   {
     DevLabel const * ll = ws.wl + ws.wl_off[k];
     uint32_t const n = ws.wl_off[k + 1] - ws.wl_off[k];
+    uint32_t const idx = ws.wl_idx[k];
     if (starts)
-      add_kmer_labels(ws, ll, n, 0, ws.wl_idx[k], best, true);
+      add_kmer_labels<W>(ws, ll, n, 0, idx, best, true, n_paths, longest, status);
     else
-      add_kmer_labels(ws, ll, n, ws.wl_idx[k], L - 1, best, false);
-    if (ws.status)
+      add_kmer_labels<W>(ws, ll, n, idx, L - 1, best, false, n_paths, longest, status);
+    if (status)
       return;
   }
 }
@@ -1026,7 +1039,8 @@ GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts)
 // k-mer keys (src/utilities/type_conversions.cpp:207-288) and index probes (src/index/ph_index.cpp:66-107)
 // ---------------------------------------------------------------------------------------------------------------
 
-// to_uint64_vec for a k-mer with ambiguous bases; serial, rare.  Returns the number of keys (0 = gave up, > 97 partial keys)
+// to_uint64_vec for a k-mer with ambiguous bases; sequential by nature (list order is the contract), leader only.
+// Returns the number of keys (0 = gave up, > 97 partial keys)
 GTX_DEV uint32_t expand_keys(uint8_t const * rd, uint32_t at, uint64_t * keys)
 {
   uint32_t n = 1;
@@ -1111,54 +1125,66 @@ GTX_DEV uint32_t reverse_bits32(uint32_t x)
 
 // Wave-parallel probe of a key list (`nkeys` keys: either keybuf[0..nkeys) or the 96 Hamming-1 neighbours of `base`
 // generated on the fly) with the multi_get rule: a list of more than one key whose hits total more than
-// max_index_labels yields nothing.  Labels land in ws.lbl in key order, bucket order inside a key.
+// max_index_labels yields nothing.  Labels land in ws.lbl in key order, bucket order inside a key (stable prefix-sum
+// compaction).  Returns the number of labels.
 template <class W>
-GTX_DEV void probe_list(IndexView const & ix, AlignWorkspace & ws, bool hamming, uint64_t base, uint32_t nkeys)
+GTX_DEV uint32_t probe_list(IndexView const & ix, AlignWorkspace & ws, bool hamming, uint64_t base, uint32_t nkeys, uint32_t & status)
 {
-  uint32_t const lane = W::lane();
-  constexpr uint32_t ROUNDS = (AlignCfg::KEY_CAP + 63) / 64;
-  uint32_t off[ROUNDS], cnt[ROUNDS], pre[ROUNDS];
-  uint32_t total = 0;
   uint32_t const rounds = (nkeys + 63) / 64;
-  for (uint32_t t = 0; t < ROUNDS; ++t)
+  uint64_t * kres = ws.u.keybuf; // key j is replaced by (offset | count << 32)
+  uint32_t total = 0;
+  for (uint32_t t = 0; t < rounds; ++t)
   {
-    if (t >= rounds)
-      break;
-    uint32_t const j = t * 64 + lane;
-    off[t] = 0;
-    cnt[t] = 0;
-    if (j < nkeys)
-    {
-      uint64_t key;
-      if (hamming)
-        key = base ^ (static_cast<uint64_t>(j % 3 + 1) << (2 * (j / 3))); // type_conversions.cpp:272-288
-      else
-        key = ws.u.keybuf[j];
-      index_find(ix, key, off[t], cnt[t]);
-    }
-    uint32_t round_total;
-    pre[t] = total + W::excl_scan(cnt[t], round_total);
-    total += round_total;
+    typename W::template PerLane<uint32_t> cnt;
+    W::lanes([&](uint32_t l) {
+      uint32_t const j = t * 64 + l;
+      uint32_t o = 0, c = 0;
+      if (j < nkeys)
+      {
+        uint64_t const key = hamming ? base ^ (static_cast<uint64_t>(j % 3 + 1) << (2 * (j / 3))) // type_conversions.cpp:272-288
+                                     : kres[j];
+        index_find(ix, key, o, c);
+        kres[j] = static_cast<uint64_t>(o) | (static_cast<uint64_t>(c) << 32);
+      }
+      cnt[l] = c;
+    });
+    total += W::sum(cnt);
   }
+  W::lds_sync();
   if (nkeys > 1 && total > ix.max_index_labels)
-    total = 0; // ph_index.cpp:84-89
+    return 0; // ph_index.cpp:84-89
   if (total > AlignCfg::LBL_CAP)
   {
-    if (lane == 0)
-      ws.status |= GTX_ST_LABEL_OVERFLOW;
-    total = 0;
+    status |= GTX_ST_LABEL_OVERFLOW;
+    return 0;
   }
-  if (total != 0)
-    for (uint32_t t = 0; t < ROUNDS; ++t)
-    {
-      if (t >= rounds)
-        break;
-      for (uint32_t k = 0; k < cnt[t]; ++k)
-        ws.lbl[pre[t] + k] = ix.labels[off[t] + k];
-    }
-  if (lane == 0)
-    ws.n_lbl = total;
-  W::sync();
+  if (total == 0)
+    return 0;
+  uint32_t done = 0;
+  for (uint32_t t = 0; t < rounds; ++t)
+  {
+    typename W::template PerLane<uint32_t> cnt, pre;
+    W::lanes([&](uint32_t l) {
+      uint32_t const j = t * 64 + l;
+      cnt[l] = j < nkeys ? static_cast<uint32_t>(kres[j] >> 32) : 0u;
+    });
+    uint32_t round_total;
+    W::excl_scan(cnt, pre, round_total);
+    if (round_total != 0)
+      W::lanes([&](uint32_t l) {
+        uint32_t const j = t * 64 + l;
+        uint32_t const c = cnt[l];
+        if (c != 0)
+        {
+          uint32_t const o = static_cast<uint32_t>(kres[j]);
+          for (uint32_t k = 0; k < c; ++k)
+            ws.lbl[done + pre[l] + k] = ix.labels[o + k];
+        }
+      });
+    done += round_total;
+  }
+  W::lds_sync();
+  return total;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1168,160 +1194,176 @@ template <class W>
 GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace & ws, uint8_t const * seq4, uint32_t len,
                        bool reverse, uint32_t * rec, uint32_t rec_words)
 {
-  uint32_t const lane = W::lane();
   // -- load the read: BAM nibbles -> one code per byte; the reverse orientation is the reverse complement, and
   //    complementing an IUPAC code is reversing its 4 bits (A<->T, C<->G)
-  for (uint32_t i = lane; i < len; i += 64)
-  {
-    uint32_t const src = reverse ? (len - 1 - i) : i;
-    uint32_t c = (seq4[src >> 1] >> ((~src & 1u) << 2)) & 15u;
-    if (c == 0)
-      c = 15;
-    if (reverse)
-      c = ((c & 1u) << 3) | ((c & 2u) << 1) | ((c & 4u) >> 1) | ((c & 8u) >> 3);
-    ws.rd[i] = static_cast<uint8_t>(c);
-  }
-  if (lane == 0)
-  {
-    ws.n_paths = 0;
-    ws.longest = 0;
-    ws.status = 0;
-    ws.read_len = len;
-  }
-  W::sync();
+  for (uint32_t base = 0; base < len; base += 64)
+    W::lanes([&](uint32_t l) {
+      uint32_t const i = base + l;
+      if (i < len)
+      {
+        uint32_t const src = reverse ? (len - 1 - i) : i;
+        uint32_t c = (seq4[src >> 1] >> ((~src & 1u) << 2)) & 15u;
+        if (c == 0)
+          c = 15; // '=' assigned to a seqan Iupac becomes N (hts_parallel_reader.cpp:226-243)
+        if (reverse)
+          c = ((c & 1u) << 3) | ((c & 2u) << 1) | ((c & 4u) >> 1) | ((c & 8u) >> 3);
+        ws.rd[i] = static_cast<uint8_t>(c);
+      }
+    });
+  GTX_LEAD ws.read_len = len;
+  W::lds_sync();
 
+  uint32_t n_paths = 0, longest = 0, status = 0;
   uint32_t const n_k = len < K ? 0 : 1 + (len - K) / (K - 1); // kmer_help_functions.cpp:10-17
   // -- exact keys of every k-mer.  Unambiguous k-mer: lanes 0..31 each hold one base, two ballots give the low/high
   //    bit planes, interleaving them gives the key (first base in the top bits, type_conversions.cpp:75-87).
+  bool all_common = n_k > 0;
   for (uint32_t i = 0; i < n_k; ++i)
   {
-    uint32_t const c = lane < K ? ws.rd[(K - 1) * i + lane] : 1u;
-    bool const single = (c & (c - 1u)) == 0u && c != 0u;
-    uint64_t const amb = W::ballot(!single);
-    uint32_t const two = (c == 2u) ? 1u : (c == 4u) ? 2u : (c == 8u) ? 3u : 0u;
-    uint32_t const b0 = static_cast<uint32_t>(W::ballot(lane < K && (two & 1u)));
-    uint32_t const b1 = static_cast<uint32_t>(W::ballot(lane < K && (two & 2u)));
+    typename W::template PerLane<bool> amb_l, b0_l, b1_l;
+    W::lanes([&](uint32_t l) {
+      uint32_t const c = l < K ? ws.rd[(K - 1) * i + l] : 1u;
+      bool const single = (c & (c - 1u)) == 0u && c != 0u;
+      uint32_t const two = (c == 2u) ? 1u : (c == 4u) ? 2u : (c == 8u) ? 3u : 0u;
+      amb_l[l] = !single;
+      b0_l[l] = l < K && (two & 1u);
+      b1_l[l] = l < K && (two & 2u);
+    });
+    uint64_t const amb = W::ballot(amb_l);
+    uint32_t const b0 = static_cast<uint32_t>(W::ballot(b0_l)), b1 = static_cast<uint32_t>(W::ballot(b1_l));
     if (amb == 0)
     {
       uint64_t const key = spread_bits(reverse_bits32(b0)) | (spread_bits(reverse_bits32(b1)) << 1);
       uint32_t off, cnt;
       index_find(ix, key, off, cnt);
-      if (lane == 0)
+      GTX_LEAD
       {
         ws.key0[i] = key;
         ws.nkeys0[i] = 1;
         ws.off0[i] = off;
         ws.cnt0[i] = cnt;
       }
+      // stop if every k-mer is extremely common (alignment.cpp:35-49); only single-key lists can reach 512 labels
+      if (cnt < MAX_UNIQUE_KMER_POSITIONS)
+        all_common = false;
     }
-    else if (lane == 0)
+    else
     {
-      ws.nkeys0[i] = 2; // "not a single key"; the list is generated when the k-mer is processed
-      ws.cnt0[i] = 0;
+      GTX_LEAD
+      {
+        ws.nkeys0[i] = 2; // "not a single key"; the list is generated when the k-mer is processed
+        ws.cnt0[i] = 0;
+      }
+      all_common = false;
     }
   }
-  W::sync();
-  // -- stop if every k-mer is extremely common (alignment.cpp:35-49); only single-key lists can reach 512 labels
-  bool all_common = n_k > 0;
-  for (uint32_t i = 0; i < n_k; ++i)
-    if (!(ws.nkeys0[i] == 1 && ws.cnt0[i] >= MAX_UNIQUE_KMER_POSITIONS))
-      all_common = false;
+  W::lds_sync();
 
   if (!all_common && n_k > 0)
   {
-    for (uint32_t i = 0; i < n_k; ++i)
+    for (uint32_t i = 0; i < n_k && !status; ++i)
     {
       uint32_t const rs = (K - 1) * i, re = rs + (K - 1);
       bool const single = ws.nkeys0[i] == 1;
+      uint32_t n_lbl;
       if (single)
       {
         // exact list: one key, never cut (ph_index.cpp:84)
         uint32_t const cnt = ws.cnt0[i], off = ws.off0[i];
-        uint32_t n = cnt;
+        n_lbl = cnt;
         if (cnt > AlignCfg::LBL_CAP)
         {
-          if (lane == 0)
-            ws.status |= GTX_ST_LABEL_OVERFLOW;
-          n = 0;
+          status |= GTX_ST_LABEL_OVERFLOW;
+          break;
         }
-        for (uint32_t k = lane; k < n; k += 64)
-          ws.lbl[k] = ix.labels[off + k];
-        if (lane == 0)
-          ws.n_lbl = n;
-        W::sync();
+        for (uint32_t b = 0; b < cnt; b += 64)
+          W::lanes([&](uint32_t l) {
+            if (b + l < cnt)
+              ws.lbl[b + l] = ix.labels[off + b + l];
+          });
+        W::lds_sync();
       }
       else
       {
-        if (lane == 0)
-          ws.n_keys = expand_keys(ws.rd, rs, ws.u.keybuf);
-        W::sync();
-        probe_list<W>(ix, ws, false, 0, ws.n_keys);
+        uint32_t nk = 0;
+        GTX_LEAD
+        {
+          nk = expand_keys(ws.rd, rs, ws.u.keybuf);
+          ws.n_keys = nk;
+        }
+        W::lds_sync();
+        nk = ws.n_keys;
+        n_lbl = probe_list<W>(ix, ws, false, 0, nk, status);
+        if (status)
+          break;
       }
-      if (lane == 0 && !ws.status)
-        add_kmer_labels(ws, ws.lbl, ws.n_lbl, rs, re, 0, false);
-      W::sync();
+      add_kmer_labels<W>(ws, ws.lbl, n_lbl, rs, re, 0, false, n_paths, longest, status);
+      if (status)
+        break;
       // Hamming-1 list: the 96 neighbours of a unique exact key, else the exact list again
-      // (kmer_help_functions.cpp:97-119 keeps multi-key lists as they are)
+      // (kmer_help_functions.cpp:97-119 keeps multi-key lists as they are, so ws.lbl is already what multi_get returns)
       if (single)
-        probe_list<W>(ix, ws, true, ws.key0[i], 96);
-      // (multi-key list: ws.lbl still holds exactly what multi_get returns for it)
-      if (lane == 0 && !ws.status)
-        add_kmer_labels(ws, ws.lbl, ws.n_lbl, rs, re, 1, false);
-      W::sync();
-    }
-    if (lane == 0 && !ws.status)
-    {
-      remove_short_paths(ws);
-      walk_read(g, ws, true);
-      if (!ws.status)
-        walk_read(g, ws, false);
-      if (!ws.status)
       {
-        update_longest(ws);
-        remove_short_paths(ws);
-        remove_paths_with_too_many_mismatches(ws);
+        n_lbl = probe_list<W>(ix, ws, true, ws.key0[i], 96, status);
+        if (status)
+          break;
+      }
+      add_kmer_labels<W>(ws, ws.lbl, n_lbl, rs, re, 1, false, n_paths, longest, status);
+    }
+    if (!status)
+    {
+      n_paths = remove_short_paths<W>(ws, n_paths, longest);
+      walk_read<W>(g, ws, true, n_paths, longest, status);
+      if (!status)
+        walk_read<W>(g, ws, false, n_paths, longest, status);
+      if (!status)
+      {
+        longest = longest_of(ws, n_paths);
+        n_paths = remove_short_paths<W>(ws, n_paths, longest);
+        n_paths = remove_paths_with_too_many_mismatches<W>(ws, n_paths);
         if (g.is_sv_graph)
-          remove_fully_special_paths(g, ws);
-        remove_non_ref_paths_when_read_matches_ref(g, ws);
-        update_longest(ws);
-        remove_short_paths(ws);
+          n_paths = remove_fully_special_paths<W>(g, ws, n_paths);
+        n_paths = remove_non_ref_paths_when_read_matches_ref<W>(g, ws, n_paths);
+        longest = longest_of(ws, n_paths);
+        n_paths = remove_short_paths<W>(ws, n_paths, longest);
         if (g.is_sv_graph)
-          remove_support_from_read_ends(g, ws);
+          remove_support_from_read_ends<W>(g, ws, n_paths);
       }
     }
-    W::sync();
   }
 
   // -- result record (layout: include/gtx.h, gtx_align_batch)
-  if (lane == 0)
+  uint32_t np = status ? 0 : n_paths;
+  uint32_t w = 2;
+  for (uint32_t i = 0; i < np; ++i)
   {
-    uint32_t status = ws.status;
-    uint32_t np = status ? 0 : ws.n_paths;
-    uint32_t w = 2;
-    for (uint32_t i = 0; i < np; ++i)
+    DPath const & p = ws.paths[i];
+    uint32_t const nvar = p.nvar;
+    if (w + 4 + 3 * nvar > rec_words)
     {
-      DPath const & p = ws.paths[i];
-      if (w + 4 + 3 * p.nvar > rec_words)
-      {
-        status |= GTX_ST_RECORD_OVERFLOW;
-        np = 0;
-        break;
-      }
-      rec[w++] = p.start;
-      rec[w++] = p.end;
-      rec[w++] = static_cast<uint32_t>(p.rs) | (static_cast<uint32_t>(p.re) << 16);
-      rec[w++] = static_cast<uint32_t>(p.mism) | (static_cast<uint32_t>(p.nvar) << 16);
-      for (uint32_t k = 0; k < p.nvar; ++k)
-      {
-        rec[w++] = p.v[k].site;
-        rec[w++] = p.v[k].mlo;
-        rec[w++] = p.v[k].mhi;
-      }
+      status |= GTX_ST_RECORD_OVERFLOW;
+      np = 0;
+      break;
     }
-    rec[0] = np | (status << 16);
-    rec[1] = ((status || np == 0) ? 0 : ws.longest) | (len << 16);
+    uint32_t const * src = reinterpret_cast<uint32_t const *>(&p);
+    uint32_t const nw = 4 + 3 * nvar;
+    W::lanes([&](uint32_t l) {
+      if (l < nw)
+      {
+        uint32_t x = src[l];
+        if (l == 3)
+          x = static_cast<uint32_t>(p.mism) | (nvar << 16);
+        rec[w + l] = x;
+      }
+    });
+    w += nw;
   }
-  W::sync();
+  GTX_LEAD
+  {
+    rec[0] = np | (status << 16);
+    rec[1] = ((status || np == 0) ? 0 : longest) | (len << 16);
+  }
+  W::lds_sync();
 }
 
 // align_read (alignment.cpp:331-363): which orientations a record gets

@@ -17,12 +17,33 @@ namespace gtx
 {
 struct WaveHip
 {
-  static __device__ inline uint32_t lane() { return threadIdx.x & 63u; }
-  static __device__ inline void sync() { __syncthreads(); }
-  static __device__ inline uint64_t ballot(bool p) { return __ballot(p); }
-  static __device__ inline uint32_t excl_scan(uint32_t v, uint32_t & total)
+  template <class T>
+  struct PerLane
   {
-    uint32_t x = v;
+    T v;
+    __device__ inline T & operator[](uint32_t) { return v; }
+    __device__ inline T const & operator[](uint32_t) const { return v; }
+  };
+  template <class F>
+  static __device__ inline void lanes(F && f)
+  {
+    f(threadIdx.x & 63u);
+  }
+  static __device__ inline bool leader() { return (threadIdx.x & 63u) == 0; }
+  // one wave per workgroup: the workgroup barrier orders the leader's LDS writes before everybody's reads
+  static __device__ inline void lds_sync() { __syncthreads(); }
+  static __device__ inline uint64_t ballot(PerLane<bool> const & p) { return __ballot(p.v); }
+  static __device__ inline uint32_t sum(PerLane<uint32_t> const & p)
+  {
+    uint32_t x = p.v;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+      x += __shfl_xor(x, d);
+    return x;
+  }
+  static __device__ inline void excl_scan(PerLane<uint32_t> const & in, PerLane<uint32_t> & out, uint32_t & total)
+  {
+    uint32_t x = in.v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1)
     {
@@ -31,7 +52,7 @@ struct WaveHip
         x += y;
     }
     total = __shfl(x, 63);
-    return x - v;
+    out.v = x - in.v;
   }
   static __device__ inline uint32_t atomic_add_u32(uint32_t * p, uint32_t v) { return atomicAdd(p, v); }
   static __device__ inline void atomic_add_u64(unsigned long long * p, unsigned long long v) { atomicAdd(p, v); }
@@ -135,7 +156,7 @@ int ctx_upload(gtx_ctx & c, int device)
   ok = ok && upload(c.dev_allocs, v.special_ref_reach, h.special_ref_reach.data(), h.special_ref_reach.size(), "special_ref_reach");
   ok = ok && upload(c.dev_allocs, v.special_actual, h.special_actual.data(), h.special_actual.size(), "special_actual");
   ok = ok && upload(c.dev_allocs, v.pos_bucket, h.pos_bucket.data(), h.pos_bucket.size(), "pos_bucket");
-  ok = ok && upload(c.dev_allocs, v.dna, h.dna.data(), h.dna.size(), "dna");
+  ok = ok && upload(c.dev_allocs, v.dna, h.codes.data(), h.codes.size(), "dna codes");
   ok = ok && upload(c.dev_allocs, v.tri_off, h.tri_off.data(), h.tri_off.size(), "tri_off");
   ok = ok && upload(c.dev_allocs, v.allele_off, h.allele_off.data(), h.allele_off.size(), "allele_off");
   IndexView ix{};

@@ -56,7 +56,7 @@ struct GraphView
   const uint32_t * special_ref_reach; // Graph::ref_reach_poses
   const uint32_t * special_actual;    // Graph::actual_poses
   const uint32_t * pos_bucket;        // [n_bucket] last ref node whose order <= first_order + 64*b
-  const char * dna;
+  const char * dna; // graph sequence as codes (see align_core.hpp: DNA_KILL / DNA_OTHER), same offsets as the characters
   // score accumulator layout (haplotype h <-> site h, graph.cpp:680-704)
   const uint64_t * tri_off;    // [n_ref] offset of the genotype triangle of site r
   const uint64_t * allele_off; // [n_ref]
@@ -80,7 +80,8 @@ struct HostGraph
   std::vector<uint32_t> event_off; // [2*n_var+1] (empty when the graph has no events)
   std::vector<int64_t> event_val;
   std::vector<uint64_t> tri_off, allele_off;
-  std::string dna;
+  std::string dna;   // characters (index construction)
+  std::string codes; // the same arena as comparison codes (kernels)
   uint64_t total_tri = 0, total_allele = 0;
   uint32_t n_hap = 0;
   uint32_t padding = 1000;

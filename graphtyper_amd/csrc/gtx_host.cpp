@@ -38,7 +38,7 @@ GraphView HostGraph::view() const
   v.special_ref_reach = special_ref_reach.data();
   v.special_actual = special_actual.data();
   v.pos_bucket = pos_bucket.data();
-  v.dna = dna.data();
+  v.dna = codes.data();
   v.tri_off = tri_off.data();
   v.allele_off = allele_off.data();
   v.total_tri = total_tri;
@@ -84,6 +84,20 @@ std::string flatten_graph(gtx_graph_view const & g, gtx_params const & par, Host
       return "variant node with empty sequence";
     out.var_dna[v] = static_cast<uint32_t>(out.dna.size());
     out.dna.append(g.dna + g.var_dna_off[v], g.var_len[v]);
+  }
+  // comparison codes: IUPAC letters keep their BAM 4-bit code, '<' / '>' kill a walk, anything else matches nothing
+  out.codes.resize(out.dna.size());
+  for (size_t i = 0; i < out.dna.size(); ++i)
+  {
+    char const c = out.dna[i];
+    char const * tbl = "=ACMGRSVTWYHKDBN";
+    uint8_t code = 0x40;
+    for (int k = 1; k < 16; ++k)
+      if (tbl[k] == c)
+        code = static_cast<uint8_t>(k);
+    if (c == '<' || c == '>')
+      code = 0x80;
+    out.codes[i] = static_cast<char>(code);
   }
   // structure: ref r -> vars [first, first+nvar) -> ref r+1
   uint32_t next_var = 0;

@@ -1,9 +1,7 @@
 // emu.cpp -- TEST HARNESS ONLY: runs the kernel sources (graphtyper_amd/csrc/align_core.hpp, score_core.hpp) on the
-// host, with 64 OS threads + barriers standing in for the 64 lanes of one wavefront.  It exists so that kernel logic
+// host, with a sequential stand-in for the wavefront (lane lambdas are looped over the 64 lanes).  It exists so that kernel logic
 // can be debugged in a container without a GPU; it is never built into, linked against or loaded by libgtx.so, and
 // nothing outside tests/ uses it.  Parity claims are made by the `-m gpu` tests through the C ABI only.
-#include <pthread.h>
-
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -16,47 +14,48 @@
 
 namespace
 {
-struct EmuWaveCtx
-{
-  pthread_barrier_t bar;
-  uint64_t slots[64];
-};
-
-thread_local uint32_t t_lane = 0;
-thread_local EmuWaveCtx * t_ctx = nullptr;
-
+// Sequential stand-in for one wavefront: lane lambdas run for lane 0..63 one after the other, per-lane values are
+// arrays of 64, the wave-uniform parts of the kernel source run once.
 struct WaveEmu
 {
-  static uint32_t lane() { return t_lane; }
-  static void sync()
+  template <class T>
+  struct PerLane
   {
-    if (t_ctx)
-      pthread_barrier_wait(&t_ctx->bar);
+    T v[64];
+    T & operator[](uint32_t l) { return v[l]; }
+    T const & operator[](uint32_t l) const { return v[l]; }
+  };
+  template <class F>
+  static void lanes(F && f)
+  {
+    for (uint32_t l = 0; l < 64; ++l)
+      f(l);
   }
-  static uint64_t ballot(bool p)
+  static bool leader() { return true; }
+  static void lds_sync() {}
+  static uint64_t ballot(PerLane<bool> const & p)
   {
-    t_ctx->slots[t_lane] = p ? 1u : 0u;
-    sync();
     uint64_t m = 0;
-    for (int i = 0; i < 64; ++i)
-      m |= t_ctx->slots[i] << i;
-    sync();
+    for (uint32_t l = 0; l < 64; ++l)
+      m |= static_cast<uint64_t>(p.v[l] ? 1u : 0u) << l;
     return m;
   }
-  static uint32_t excl_scan(uint32_t v, uint32_t & total)
+  static uint32_t sum(PerLane<uint32_t> const & p)
   {
-    t_ctx->slots[t_lane] = v;
-    sync();
-    uint32_t pre = 0, tot = 0;
-    for (uint32_t i = 0; i < 64; ++i)
+    uint32_t s = 0;
+    for (uint32_t l = 0; l < 64; ++l)
+      s += p.v[l];
+    return s;
+  }
+  static void excl_scan(PerLane<uint32_t> const & in, PerLane<uint32_t> & out, uint32_t & total)
+  {
+    uint32_t s = 0;
+    for (uint32_t l = 0; l < 64; ++l)
     {
-      if (i < t_lane)
-        pre += static_cast<uint32_t>(t_ctx->slots[i]);
-      tot += static_cast<uint32_t>(t_ctx->slots[i]);
+      out.v[l] = s;
+      s += in.v[l];
     }
-    sync();
-    total = tot;
-    return pre;
+    total = s;
   }
   static uint32_t atomic_add_u32(uint32_t * p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
   static void atomic_add_u64(unsigned long long * p, unsigned long long v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
@@ -98,40 +97,23 @@ extern "C"
     GraphView const g = e.graph.view();
     IndexView ix{e.index.slots.data(), e.index.dev_labels.data(), e.index.log2_cap, static_cast<uint32_t>(e.params.max_index_labels)};
     auto ws = std::make_unique<AlignWorkspace>();
-    EmuWaveCtx wctx;
-    pthread_barrier_init(&wctx.bar, nullptr, 64);
     bool const force_both = e.params.force_align_both_orientations != 0;
-    auto body = [&](uint32_t lane)
+    for (uint32_t t = 0; t < 2 * n_reads; ++t)
     {
-      t_lane = lane;
-      t_ctx = &wctx;
-      for (uint32_t t = 0; t < 2 * n_reads; ++t)
+      uint32_t const read = t >> 1, orient = t & 1u;
+      gtx_read_meta const m = meta[read];
+      uint32_t * rec = records + static_cast<uint64_t>(t) * rec_words;
+      uint32_t const len = m.l_qseq;
+      bool const skip = len < 2 * K - 1 || len > AlignCfg::MAX_READ || (orient == 1 && !needs_reverse(m, force_both));
+      if (skip)
       {
-        uint32_t const read = t >> 1, orient = t & 1u;
-        gtx_read_meta const m = meta[read];
-        uint32_t * rec = records + static_cast<uint64_t>(t) * rec_words;
-        uint32_t const len = m.l_qseq;
-        bool const skip = len < 2 * K - 1 || len > AlignCfg::MAX_READ || (orient == 1 && !needs_reverse(m, force_both));
-        if (skip)
-        {
-          if (lane == 0)
-          {
-            rec[0] = len > AlignCfg::MAX_READ ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
-            rec[1] = len << 16;
-          }
-          continue;
-        }
-        align_one<WaveEmu>(g, ix, *ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words);
+        rec[0] = len > AlignCfg::MAX_READ ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
+        rec[1] = len << 16;
+        continue;
       }
-    };
-    std::vector<std::thread> th;
-    for (uint32_t l = 1; l < 64; ++l)
-      th.emplace_back(body, l);
-    body(0);
-    for (auto & t : th)
-      t.join();
-    pthread_barrier_destroy(&wctx.bar);
-    t_ctx = nullptr;
+      std::memset(ws.get(), 0xAB, sizeof(AlignWorkspace)); // LDS is not zeroed between reads
+      align_one<WaveEmu>(g, ix, *ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words);
+    }
     return 0;
   }
 
@@ -155,7 +137,6 @@ extern "C"
     ScoreParams par{static_cast<uint32_t>(e.params.is_sv_graph != 0), static_cast<uint32_t>(e.params.hq_reads != 0),
                     static_cast<uint32_t>(e.params.is_segment_calling != 0), 0};
     uint32_t errors = 0;
-    t_ctx = nullptr;
     for (uint32_t i = 0; i < n_items; ++i)
       score_item<WaveEmu>(g, par, items[i], records, rec_words, a, &errors);
     return static_cast<int>(errors);

@@ -46,7 +46,7 @@ def test_align_index_test_contigs(chrom):
 
 @pytest.mark.parametrize("kind", ["snp1k", "snp100", "snp25", "indel"])
 def test_align_synthetic(kind):
-    ref, recs, codes, pos = scenarios.synthetic_case(kind, n_ref=20000, n_reads=120, region_begin=777000)
+    ref, recs, codes, pos = scenarios.synthetic_case(kind, n_ref=100000, n_reads=6000, region_begin=777000)
     o = Oracle(ref, recs, region_begin=777000)
     b = harness.EmuBackend(gtx.graph_from_records(ref, recs, region_begin=777000))
     check_align(b, o, list(codes))
@@ -80,7 +80,7 @@ def run_stream(backend, oracle, codes, rec, n_samples, n_rg=1):
 
 @pytest.mark.parametrize("kind", ["snp100", "snp25", "indel"])
 def test_stream_scores(kind):
-    ref, recs, codes, rec = scenarios.paired_case(kind, n_ref=12000, n_pairs=70, region_begin=310000)
+    ref, recs, codes, rec = scenarios.paired_case(kind, n_ref=40000, n_pairs=1500, region_begin=310000)
     o = Oracle(ref, recs, region_begin=310000)
     b = harness.EmuBackend(gtx.graph_from_records(ref, recs, region_begin=310000))
     want = run_stream(b, o, codes, rec, n_samples=2)
