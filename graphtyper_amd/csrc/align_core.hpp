@@ -1187,6 +1187,131 @@ GTX_DEV uint32_t probe_list(IndexView const & ix, AlignWorkspace & ws, bool hamm
   return total;
 }
 
+// bucket of a half key (see IndexView::hslots): (offset, count) into hlist, count 0 when the half does not occur
+GTX_DEV void half_find(IndexView const & ix, uint64_t hk, uint32_t & off, uint32_t & cnt)
+{
+  uint64_t const mask = (1ull << ix.h_log2_cap) - 1;
+  uint64_t h = hash_key(hk, ix.h_log2_cap);
+  for (;;)
+  {
+    IndexSlot const s = ix.hslots[h];
+    if (s.cnt == 0)
+    {
+      off = 0;
+      cnt = 0;
+      return;
+    }
+    if (s.key == hk)
+    {
+      off = s.off;
+      cnt = s.cnt;
+      return;
+    }
+    h = (h + 1) & mask;
+  }
+}
+
+constexpr uint32_t HALF_BUCKET_CAP = 64; // one lane per bucket entry; larger buckets (low-complexity sequence) use the 96 direct probes
+
+// The Hamming-1 list of a unique exact key `q` (kmer_help_functions.cpp:97-119 + ph_index.cpp:66-107) without probing
+// the 96 neighbours: an indexed key at Hamming distance 1 differs from q in one base, so it agrees with q on the left
+// 16 bases or on the right 16 bases -- two bucket lookups find every candidate.  Candidates are put in the order the
+// reference visits them (neighbour j = 3*bb + m-1, type_conversions.cpp:272-288) before their labels are copied, and
+// the >max_index_labels rule of multi_get is applied to the total.  Returns false when a bucket is too large for this
+// route (the caller then probes the 96 keys directly); n_lbl is the number of labels placed in ws.lbl.
+template <class W>
+GTX_DEV bool hamming1_by_halves(IndexView const & ix, AlignWorkspace & ws, uint64_t q, uint32_t & n_lbl)
+{
+  uint32_t o[2], c[2];
+  half_find(ix, q >> 32, o[0], c[0]);
+  half_find(ix, (q & 0xFFFFFFFFull) | (1ull << 32), o[1], c[1]);
+  if (c[0] > ix.half_bucket_cap || c[1] > ix.half_bucket_cap)
+    return false;
+  uint64_t * cand = ws.u.keybuf; // (label offset) | (label count << 32) | (j << 56)
+  uint32_t ncand = 0;
+  for (uint32_t side = 0; side < 2; ++side)
+  {
+    uint32_t const cs = c[side], os = o[side];
+    if (cs == 0)
+      continue;
+    typename W::template PerLane<uint32_t> valid, pre;
+    typename W::template PerLane<uint64_t> packed;
+    W::lanes([&](uint32_t l) {
+      uint32_t ok = 0;
+      uint64_t pk = 0;
+      if (l < cs)
+      {
+        HalfEntry const e = ix.hlist[os + l];
+        uint64_t const x = e.key ^ q;
+        uint64_t const groups = (x | (x >> 1)) & 0x5555555555555555ull; // one bit per differing base
+        if (groups != 0 && (groups & (groups - 1)) == 0)
+        {
+          uint32_t const bit = static_cast<uint32_t>(__builtin_ctzll(groups)); // = 2*bb
+          uint64_t const m = (x >> bit) & 3u;
+          uint64_t const j = 3u * (bit >> 1) + (m - 1);
+          ok = 1;
+          pk = static_cast<uint64_t>(e.off) | (static_cast<uint64_t>(e.cnt) << 32) | (j << 56);
+        }
+      }
+      valid[l] = ok;
+      packed[l] = pk;
+    });
+    uint32_t nv;
+    W::excl_scan(valid, pre, nv);
+    if (nv != 0)
+      W::lanes([&](uint32_t l) {
+        if (valid[l])
+          cand[ncand + pre[l]] = packed[l];
+      });
+    ncand += nv;
+  }
+  W::lds_sync();
+  if (ncand == 0)
+  {
+    n_lbl = 0;
+    return true;
+  }
+  // order by j (few entries: insertion sort by the leader), total label count
+  GTX_LEAD
+  {
+    for (uint32_t a = 1; a < ncand; ++a)
+    {
+      uint64_t const x = cand[a];
+      uint32_t b = a;
+      while (b > 0 && (cand[b - 1] >> 56) > (x >> 56))
+      {
+        cand[b] = cand[b - 1];
+        --b;
+      }
+      cand[b] = x;
+    }
+  }
+  W::lds_sync();
+  uint32_t total = 0;
+  for (uint32_t a = 0; a < ncand; ++a)
+    total += static_cast<uint32_t>(cand[a] >> 32) & 0xFFFFFFu;
+  if (total > ix.max_index_labels) // the list has 96 keys: ph_index.cpp:84-89 applies
+  {
+    n_lbl = 0;
+    return true;
+  }
+  uint32_t done = 0;
+  for (uint32_t a = 0; a < ncand; ++a)
+  {
+    uint64_t const e = cand[a];
+    uint32_t const off = static_cast<uint32_t>(e), cnt = static_cast<uint32_t>(e >> 32) & 0xFFFFFFu;
+    for (uint32_t b = 0; b < cnt; b += 64)
+      W::lanes([&](uint32_t l) {
+        if (b + l < cnt)
+          ws.lbl[done + b + l] = ix.labels[off + b + l];
+      });
+    done += cnt;
+  }
+  W::lds_sync();
+  n_lbl = total;
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // one (read, orientation): find_genotype_paths_of_one_of_the_sequences (alignment.cpp:23-103)
 // ---------------------------------------------------------------------------------------------------------------
@@ -1304,7 +1429,9 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
       // (kmer_help_functions.cpp:97-119 keeps multi-key lists as they are, so ws.lbl is already what multi_get returns)
       if (single)
       {
-        n_lbl = probe_list<W>(ix, ws, true, ws.key0[i], 96, status);
+        uint64_t const q = ws.key0[i];
+        if (!hamming1_by_halves<W>(ix, ws, q, n_lbl))
+          n_lbl = probe_list<W>(ix, ws, true, q, 96, status);
         if (status)
           break;
       }

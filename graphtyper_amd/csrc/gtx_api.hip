@@ -5,7 +5,9 @@
 // score kernel : one thread per score item (an unpaired read or a mate pair); integer atomics into flat accumulators.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -164,6 +166,12 @@ int ctx_upload(gtx_ctx & c, int device)
   ix.max_index_labels = static_cast<uint32_t>(c.params.max_index_labels);
   ok = ok && upload(c.dev_allocs, ix.slots, c.index.slots.data(), c.index.slots.size(), "index slots");
   ok = ok && upload(c.dev_allocs, ix.labels, c.index.dev_labels.data(), c.index.dev_labels.size(), "index labels");
+  ix.h_log2_cap = c.index.h_log2_cap;
+  ix.half_bucket_cap = HALF_BUCKET_CAP;
+  if (char const * e = std::getenv("GTX_HALF_BUCKET_CAP")) // A/B switch for benchmarking: 0 = probe the 96 neighbours directly
+    ix.half_bucket_cap = static_cast<uint32_t>(std::min<long>(std::max<long>(std::atol(e), 0), HALF_BUCKET_CAP));
+  ok = ok && upload(c.dev_allocs, ix.hslots, c.index.hslots.data(), c.index.hslots.size(), "half-key slots");
+  ok = ok && upload(c.dev_allocs, ix.hlist, c.index.hlist.data(), c.index.hlist.size(), "half-key buckets");
   void * ef = nullptr;
   ok = ok && hip_ok(hipMalloc(&ef, sizeof(uint32_t)), "error flag");
   if (ok)

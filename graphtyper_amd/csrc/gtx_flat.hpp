@@ -64,12 +64,25 @@ struct GraphView
   uint32_t n_hap, pad1;
 };
 
+// One indexed key inside a half-key bucket (see HostIndex::hlist)
+struct HalfEntry
+{
+  uint64_t key;
+  uint32_t off, cnt; // its labels
+};
+
 struct IndexView
 {
   const IndexSlot * slots;
   const DevLabel * labels;
   uint32_t log2_cap;
   uint32_t max_index_labels;
+  // half-key (pigeonhole) tables for the Hamming-1 lists: a key within Hamming distance 1 of q shares q's left or
+  // right 16 bases exactly, so the 96 neighbour probes of the reference become two bucket lookups
+  const IndexSlot * hslots; // key = half | side << 32 ; off/cnt into hlist
+  const HalfEntry * hlist;
+  uint32_t h_log2_cap;
+  uint32_t half_bucket_cap; // buckets above this size use the 96 direct probes instead (0 = always probe directly)
 };
 
 struct HostGraph
@@ -100,6 +113,11 @@ struct HostIndex
   std::vector<IndexSlot> slots;
   std::vector<DevLabel> dev_labels;
   uint32_t log2_cap = 0;
+  // half-key tables: hlist = all keys ascending (buckets of equal left half are contiguous) followed by all keys
+  // ordered by right half; hslots maps (side, half) -> bucket
+  std::vector<IndexSlot> hslots;
+  std::vector<HalfEntry> hlist;
+  uint32_t h_log2_cap = 0;
 };
 
 // returns "" on success, else a description of what is wrong with the view

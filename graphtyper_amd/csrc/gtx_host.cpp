@@ -419,6 +419,45 @@ void build_index(HostGraph const & g, HostIndex & out)
       h = (h + 1) & mask;
     out.slots[h] = IndexSlot{out.keys[k], out.key_off[k], out.key_off[k + 1] - out.key_off[k]};
   }
+  // half-key buckets
+  {
+    size_t const n = out.keys.size();
+    out.hlist.resize(2 * n);
+    for (size_t k = 0; k < n; ++k)
+      out.hlist[k] = HalfEntry{out.keys[k], out.key_off[k], out.key_off[k + 1] - out.key_off[k]};
+    std::vector<uint32_t> by_right(n);
+    std::iota(by_right.begin(), by_right.end(), 0u);
+    std::sort(by_right.begin(), by_right.end(), [&](uint32_t a, uint32_t b) {
+      uint32_t const ra = static_cast<uint32_t>(out.keys[a]), rb = static_cast<uint32_t>(out.keys[b]);
+      return ra != rb ? ra < rb : out.keys[a] < out.keys[b];
+    });
+    for (size_t k = 0; k < n; ++k)
+      out.hlist[n + k] = out.hlist[by_right[k]];
+    uint32_t hl = 4;
+    while ((1ull << hl) < 4 * n + 1)
+      ++hl;
+    out.h_log2_cap = hl;
+    out.hslots.assign(1ull << hl, IndexSlot{0, 0, 0});
+    uint64_t const hmask = (1ull << hl) - 1;
+    for (int side = 0; side < 2; ++side)
+    {
+      size_t const base = side * n;
+      size_t k = 0;
+      while (k < n)
+      {
+        uint64_t const half = side == 0 ? (out.hlist[base + k].key >> 32) : (out.hlist[base + k].key & 0xFFFFFFFFull);
+        size_t e = k + 1;
+        while (e < n && (side == 0 ? (out.hlist[base + e].key >> 32) : (out.hlist[base + e].key & 0xFFFFFFFFull)) == half)
+          ++e;
+        uint64_t const hk = half | (static_cast<uint64_t>(side) << 32);
+        uint64_t h = hash_key(hk, hl);
+        while (out.hslots[h].cnt != 0)
+          h = (h + 1) & hmask;
+        out.hslots[h] = IndexSlot{hk, static_cast<uint32_t>(base + k), static_cast<uint32_t>(e - k)};
+        k = e;
+      }
+    }
+  }
   out.dev_labels.resize(out.labels.size());
   for (std::size_t i = 0; i < out.labels.size(); ++i)
   {

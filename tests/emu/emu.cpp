@@ -3,6 +3,7 @@
 // can be debugged in a container without a GPU; it is never built into, linked against or loaded by libgtx.so, and
 // nothing outside tests/ uses it.  Parity claims are made by the `-m gpu` tests through the C ABI only.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -95,7 +96,10 @@ extern "C"
     using namespace gtx;
     Emu & e = *static_cast<Emu *>(p);
     GraphView const g = e.graph.view();
-    IndexView ix{e.index.slots.data(), e.index.dev_labels.data(), e.index.log2_cap, static_cast<uint32_t>(e.params.max_index_labels)};
+    IndexView ix{e.index.slots.data(), e.index.dev_labels.data(), e.index.log2_cap, static_cast<uint32_t>(e.params.max_index_labels),
+                 e.index.hslots.data(), e.index.hlist.data(), e.index.h_log2_cap, HALF_BUCKET_CAP};
+    if (char const * cap = std::getenv("GTX_HALF_BUCKET_CAP"))
+      ix.half_bucket_cap = static_cast<uint32_t>(std::atol(cap));
     auto ws = std::make_unique<AlignWorkspace>();
     bool const force_both = e.params.force_align_both_orientations != 0;
     for (uint32_t t = 0; t < 2 * n_reads; ++t)

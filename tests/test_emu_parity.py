@@ -85,3 +85,17 @@ def test_stream_scores(kind):
     b = harness.EmuBackend(gtx.graph_from_records(ref, recs, region_begin=310000))
     want = run_stream(b, o, codes, rec, n_samples=2)
     assert want.sum() > 0
+
+
+def test_direct_probes_and_half_key_buckets_agree(monkeypatch):
+    """the Hamming-1 lists come from two half-key bucket lookups; with the bucket cap forced to 0 the kernel probes the
+    96 neighbours directly like the reference does -- both routes must give the oracle's result"""
+    ref, recs, codes, pos = scenarios.synthetic_case("snp100", n_ref=60000, n_reads=3000, region_begin=0, err=0.02)
+    o = Oracle(ref, recs)
+    b = harness.EmuBackend(gtx.graph_from_records(ref, recs))
+    monkeypatch.setenv("GTX_HALF_BUCKET_CAP", "0")
+    check_align(b, o, list(codes))
+    monkeypatch.setenv("GTX_HALF_BUCKET_CAP", "1")
+    check_align(b, o, list(codes))
+    monkeypatch.delenv("GTX_HALF_BUCKET_CAP")
+    check_align(b, o, list(codes))
