@@ -182,6 +182,15 @@ def main():
     n_aligned = int(((rec_head[0::2] & 0xFFFF) > 0).sum().item())
     errors = ctx.error_count()
 
+    prof = ctx.profile()
+    if rank == 0 and prof[15] > 0:
+        names = ["load read", "keys + exact probes", "exact labels", "chain exact", "hamming lookup", "chain hamming",
+                 "walk starts", "walk ends", "filters", "record"]
+        tot = float(prof[:10].sum())
+        sys.stderr.write("phase cycles per read-orientation (profiling build), %d tasks:\n" % prof[15])
+        for k, nm in enumerate(names):
+            sys.stderr.write("  %-22s %10.0f  %5.1f%%\n" % (nm, prof[k] / float(prof[15]), 100.0 * prof[k] / tot))
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()

@@ -46,6 +46,9 @@ struct AlignCfg
   static constexpr uint32_t WL_CAP = 64;     // labels kept by walk_read_ends/starts
   static constexpr uint32_t WLISTS = 8;      // label lists kept by walk_read_ends/starts
   static constexpr uint32_t KEY_CAP = 388;   // to_uint64_vec can return up to 4*97 keys
+  static constexpr uint32_t KC = 5;          // k-mers whose index lookups are issued together up front (reads <= 187 bp)
+  static constexpr uint32_t HE_CAP = 4;      // half-key bucket entries fetched up front per (k-mer, side)
+  static constexpr uint32_t XL_CAP = 4;      // exact labels fetched up front per k-mer
 };
 
 struct PVar
@@ -106,6 +109,10 @@ struct AlignWorkspace // lives in LDS, one per wavefront
   uint32_t nkeys0[AlignCfg::MAX_KMERS];
   uint32_t off0[AlignCfg::MAX_KMERS];
   uint32_t cnt0[AlignCfg::MAX_KMERS];
+  // lookups of the first KC k-mers, issued together so that their memory latencies overlap
+  uint32_t hoff[AlignCfg::KC][2], hcnt[AlignCfg::KC][2];
+  HalfEntry he[AlignCfg::KC][2][AlignCfg::HE_CAP];
+  DevLabel xl[AlignCfg::KC][AlignCfg::XL_CAP];
   uint32_t n_paths, longest, status, n_lbl, n_keys, read_len, n_wl, n_wlists;
 };
 
@@ -120,6 +127,20 @@ GTX_DEV uint32_t path_size(DPath const & p)
 }
 
 #define GTX_LEAD if (W::leader())
+
+// phase timing (profiling build only: make -C graphtyper_amd/csrc prof -> libgtx_prof.so)
+#ifdef GTX_PROF
+#define GTX_PROF_BEGIN unsigned long long _pt = W::clock();
+#define GTX_PROF_TICK(k)                                   \
+  {                                                        \
+    unsigned long long const _pn = W::clock();             \
+    GTX_LEAD W::atomic_add_u64(g.prof + (k), _pn - _pt);   \
+    _pt = W::clock();                                      \
+  }
+#else
+#define GTX_PROF_BEGIN
+#define GTX_PROF_TICK(k)
+#endif
 
 // word-wise LDS -> LDS copy of a table entry, one word per lane
 template <class W, class T>
@@ -1213,12 +1234,71 @@ GTX_DEV void half_find(IndexView const & ix, uint64_t hk, uint32_t & off, uint32
 
 constexpr uint32_t HALF_BUCKET_CAP = 64; // one lane per bucket entry; larger buckets (low-complexity sequence) use the 96 direct probes
 
+// Candidate test shared by both routes below: is `key` at Hamming distance exactly 1 from q, and which neighbour is it?
+GTX_DEV bool hamming1_neighbour(uint64_t key, uint64_t q, uint32_t & j)
+{
+  uint64_t const x = key ^ q;
+  uint64_t const groups = (x | (x >> 1)) & 0x5555555555555555ull; // one bit per differing base
+  if (groups == 0 || (groups & (groups - 1)) != 0)
+    return false;
+  uint32_t const bit = static_cast<uint32_t>(__builtin_ctzll(groups)); // = 2*bb
+  j = 3u * (bit >> 1) + static_cast<uint32_t>((x >> bit) & 3u) - 1u;   // type_conversions.cpp:272-288
+  return true;
+}
+
+// Orders the collected candidates ((label offset) | (label count << 32) | (j << 56) in ws.u.keybuf) by neighbour number,
+// applies the >max_index_labels rule of multi_get (ph_index.cpp:84-89; the list has 96 keys) and copies their labels to
+// ws.lbl.  Returns the number of labels.
+template <class W>
+GTX_DEV uint32_t hamming1_finish(IndexView const & ix, AlignWorkspace & ws, uint32_t ncand)
+{
+  uint64_t * cand = ws.u.keybuf;
+  if (ncand == 0)
+    return 0;
+  if (ncand > 1)
+  {
+    GTX_LEAD
+    {
+      for (uint32_t a = 1; a < ncand; ++a)
+      {
+        uint64_t const x = cand[a];
+        uint32_t b = a;
+        while (b > 0 && (cand[b - 1] >> 56) > (x >> 56))
+        {
+          cand[b] = cand[b - 1];
+          --b;
+        }
+        cand[b] = x;
+      }
+    }
+    W::lds_sync();
+  }
+  uint32_t total = 0;
+  for (uint32_t a = 0; a < ncand; ++a)
+    total += static_cast<uint32_t>(cand[a] >> 32) & 0xFFFFFFu;
+  if (total > ix.max_index_labels)
+    return 0;
+  uint32_t done = 0;
+  for (uint32_t a = 0; a < ncand; ++a)
+  {
+    uint64_t const e = cand[a];
+    uint32_t const off = static_cast<uint32_t>(e), cnt = static_cast<uint32_t>(e >> 32) & 0xFFFFFFu;
+    for (uint32_t b = 0; b < cnt; b += 64)
+      W::lanes([&](uint32_t l) {
+        if (b + l < cnt)
+          ws.lbl[done + b + l] = ix.labels[off + b + l];
+      });
+    done += cnt;
+  }
+  W::lds_sync();
+  return total;
+}
+
 // The Hamming-1 list of a unique exact key `q` (kmer_help_functions.cpp:97-119 + ph_index.cpp:66-107) without probing
 // the 96 neighbours: an indexed key at Hamming distance 1 differs from q in one base, so it agrees with q on the left
 // 16 bases or on the right 16 bases -- two bucket lookups find every candidate.  Candidates are put in the order the
-// reference visits them (neighbour j = 3*bb + m-1, type_conversions.cpp:272-288) before their labels are copied, and
-// the >max_index_labels rule of multi_get is applied to the total.  Returns false when a bucket is too large for this
-// route (the caller then probes the 96 keys directly); n_lbl is the number of labels placed in ws.lbl.
+// reference visits them (neighbour j = 3*bb + m-1) before their labels are copied.  Returns false when a bucket is too
+// large for this route (the caller then probes the 96 keys directly); n_lbl is the number of labels placed in ws.lbl.
 template <class W>
 GTX_DEV bool hamming1_by_halves(IndexView const & ix, AlignWorkspace & ws, uint64_t q, uint32_t & n_lbl)
 {
@@ -1227,7 +1307,7 @@ GTX_DEV bool hamming1_by_halves(IndexView const & ix, AlignWorkspace & ws, uint6
   half_find(ix, (q & 0xFFFFFFFFull) | (1ull << 32), o[1], c[1]);
   if (c[0] > ix.half_bucket_cap || c[1] > ix.half_bucket_cap)
     return false;
-  uint64_t * cand = ws.u.keybuf; // (label offset) | (label count << 32) | (j << 56)
+  uint64_t * cand = ws.u.keybuf;
   uint32_t ncand = 0;
   for (uint32_t side = 0; side < 2; ++side)
   {
@@ -1237,20 +1317,15 @@ GTX_DEV bool hamming1_by_halves(IndexView const & ix, AlignWorkspace & ws, uint6
     typename W::template PerLane<uint32_t> valid, pre;
     typename W::template PerLane<uint64_t> packed;
     W::lanes([&](uint32_t l) {
-      uint32_t ok = 0;
+      uint32_t ok = 0, j = 0;
       uint64_t pk = 0;
       if (l < cs)
       {
         HalfEntry const e = ix.hlist[os + l];
-        uint64_t const x = e.key ^ q;
-        uint64_t const groups = (x | (x >> 1)) & 0x5555555555555555ull; // one bit per differing base
-        if (groups != 0 && (groups & (groups - 1)) == 0)
+        if (hamming1_neighbour(e.key, q, j))
         {
-          uint32_t const bit = static_cast<uint32_t>(__builtin_ctzll(groups)); // = 2*bb
-          uint64_t const m = (x >> bit) & 3u;
-          uint64_t const j = 3u * (bit >> 1) + (m - 1);
           ok = 1;
-          pk = static_cast<uint64_t>(e.off) | (static_cast<uint64_t>(e.cnt) << 32) | (j << 56);
+          pk = static_cast<uint64_t>(e.off) | (static_cast<uint64_t>(e.cnt) << 32) | (static_cast<uint64_t>(j) << 56);
         }
       }
       valid[l] = ok;
@@ -1266,50 +1341,35 @@ GTX_DEV bool hamming1_by_halves(IndexView const & ix, AlignWorkspace & ws, uint6
     ncand += nv;
   }
   W::lds_sync();
-  if (ncand == 0)
+  n_lbl = hamming1_finish<W>(ix, ws, ncand);
+  return true;
+}
+
+// Same list from the bucket entries that were fetched up front (ws.he): at most 2*HE_CAP entries, wave-uniform code
+template <class W>
+GTX_DEV uint32_t hamming1_from_cache(IndexView const & ix, AlignWorkspace & ws, uint32_t i, uint64_t q)
+{
+  uint64_t * cand = ws.u.keybuf;
+  uint32_t ncand = 0;
+  for (uint32_t side = 0; side < 2; ++side)
   {
-    n_lbl = 0;
-    return true;
-  }
-  // order by j (few entries: insertion sort by the leader), total label count
-  GTX_LEAD
-  {
-    for (uint32_t a = 1; a < ncand; ++a)
+    uint32_t const cs = ws.hcnt[i][side];
+    for (uint32_t e = 0; e < cs; ++e)
     {
-      uint64_t const x = cand[a];
-      uint32_t b = a;
-      while (b > 0 && (cand[b - 1] >> 56) > (x >> 56))
+      uint32_t j;
+      if (hamming1_neighbour(ws.he[i][side][e].key, q, j))
       {
-        cand[b] = cand[b - 1];
-        --b;
+        uint64_t const pk = static_cast<uint64_t>(ws.he[i][side][e].off) | (static_cast<uint64_t>(ws.he[i][side][e].cnt) << 32) |
+                            (static_cast<uint64_t>(j) << 56);
+        GTX_LEAD cand[ncand] = pk;
+        ++ncand;
       }
-      cand[b] = x;
     }
   }
+  if (ncand == 0)
+    return 0;
   W::lds_sync();
-  uint32_t total = 0;
-  for (uint32_t a = 0; a < ncand; ++a)
-    total += static_cast<uint32_t>(cand[a] >> 32) & 0xFFFFFFu;
-  if (total > ix.max_index_labels) // the list has 96 keys: ph_index.cpp:84-89 applies
-  {
-    n_lbl = 0;
-    return true;
-  }
-  uint32_t done = 0;
-  for (uint32_t a = 0; a < ncand; ++a)
-  {
-    uint64_t const e = cand[a];
-    uint32_t const off = static_cast<uint32_t>(e), cnt = static_cast<uint32_t>(e >> 32) & 0xFFFFFFu;
-    for (uint32_t b = 0; b < cnt; b += 64)
-      W::lanes([&](uint32_t l) {
-        if (b + l < cnt)
-          ws.lbl[done + b + l] = ix.labels[off + b + l];
-      });
-    done += cnt;
-  }
-  W::lds_sync();
-  n_lbl = total;
-  return true;
+  return hamming1_finish<W>(ix, ws, ncand);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1319,6 +1379,7 @@ template <class W>
 GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace & ws, uint8_t const * seq4, uint32_t len,
                        bool reverse, uint32_t * rec, uint32_t rec_words)
 {
+  GTX_PROF_BEGIN
   // -- load the read: BAM nibbles -> one code per byte; the reverse orientation is the reverse complement, and
   //    complementing an IUPAC code is reversing its 4 bits (A<->T, C<->G)
   for (uint32_t base = 0; base < len; base += 64)
@@ -1337,12 +1398,12 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
     });
   GTX_LEAD ws.read_len = len;
   W::lds_sync();
+  GTX_PROF_TICK(0)
 
   uint32_t n_paths = 0, longest = 0, status = 0;
   uint32_t const n_k = len < K ? 0 : 1 + (len - K) / (K - 1); // kmer_help_functions.cpp:10-17
   // -- exact keys of every k-mer.  Unambiguous k-mer: lanes 0..31 each hold one base, two ballots give the low/high
   //    bit planes, interleaving them gives the key (first base in the top bits, type_conversions.cpp:75-87).
-  bool all_common = n_k > 0;
   for (uint32_t i = 0; i < n_k; ++i)
   {
     typename W::template PerLane<bool> amb_l, b0_l, b1_l;
@@ -1356,33 +1417,73 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
     });
     uint64_t const amb = W::ballot(amb_l);
     uint32_t const b0 = static_cast<uint32_t>(W::ballot(b0_l)), b1 = static_cast<uint32_t>(W::ballot(b1_l));
-    if (amb == 0)
+    uint64_t const key = spread_bits(reverse_bits32(b0)) | (spread_bits(reverse_bits32(b1)) << 1);
+    GTX_LEAD
     {
-      uint64_t const key = spread_bits(reverse_bits32(b0)) | (spread_bits(reverse_bits32(b1)) << 1);
-      uint32_t off, cnt;
-      index_find(ix, key, off, cnt);
-      GTX_LEAD
-      {
-        ws.key0[i] = key;
-        ws.nkeys0[i] = 1;
-        ws.off0[i] = off;
-        ws.cnt0[i] = cnt;
-      }
-      // stop if every k-mer is extremely common (alignment.cpp:35-49); only single-key lists can reach 512 labels
-      if (cnt < MAX_UNIQUE_KMER_POSITIONS)
-        all_common = false;
-    }
-    else
-    {
-      GTX_LEAD
-      {
-        ws.nkeys0[i] = 2; // "not a single key"; the list is generated when the k-mer is processed
-        ws.cnt0[i] = 0;
-      }
-      all_common = false;
+      ws.key0[i] = key;
+      ws.nkeys0[i] = amb == 0 ? 1 : 2; // 2 = "not a single key"; that list is generated when the k-mer is processed
+      ws.cnt0[i] = 0;
     }
   }
   W::lds_sync();
+  // -- all index lookups of the read at once, one per lane, so that their memory latencies overlap:
+  //    lane 3i: exact key of k-mer i (PHIndex::get), lanes 3i+1 / 3i+2: its left / right half-key bucket
+  uint32_t const kc = n_k < AlignCfg::KC ? n_k : AlignCfg::KC;
+  bool const use_halves = ix.half_bucket_cap != 0;
+  W::lanes([&](uint32_t l) {
+    uint32_t const i = l / 3, w = l % 3;
+    if (l < 3 * n_k && ws.nkeys0[i] == 1 && (w == 0 || (i < kc && use_halves)))
+    {
+      uint64_t const q = ws.key0[i];
+      uint32_t off, cnt;
+      if (w == 0)
+      {
+        index_find(ix, q, off, cnt);
+        ws.off0[i] = off;
+        ws.cnt0[i] = cnt;
+      }
+      else
+      {
+        half_find(ix, w == 1 ? (q >> 32) : ((q & 0xFFFFFFFFull) | (1ull << 32)), off, cnt);
+        ws.hoff[i][w - 1] = off;
+        ws.hcnt[i][w - 1] = cnt;
+      }
+    }
+  });
+  W::lds_sync();
+  // -- ... and everything those lookups point at that is small enough to be staged: bucket entries and exact labels
+  W::lanes([&](uint32_t l) {
+    constexpr uint32_t NH = 2 * AlignCfg::HE_CAP;
+    if (l < AlignCfg::KC * NH)
+    {
+      uint32_t const i = l / NH, side = (l / AlignCfg::HE_CAP) % 2, e = l % AlignCfg::HE_CAP;
+      if (i < kc && use_halves && ws.nkeys0[i] == 1)
+      {
+        uint32_t const cnt = ws.hcnt[i][side];
+        if (cnt <= AlignCfg::HE_CAP && e < cnt)
+          ws.he[i][side][e] = ix.hlist[ws.hoff[i][side] + e];
+      }
+    }
+    else if (l < AlignCfg::KC * NH + AlignCfg::KC * AlignCfg::XL_CAP)
+    {
+      uint32_t const m = l - AlignCfg::KC * NH;
+      uint32_t const i = m / AlignCfg::XL_CAP, e = m % AlignCfg::XL_CAP;
+      if (i < kc && ws.nkeys0[i] == 1)
+      {
+        uint32_t const cnt = ws.cnt0[i];
+        if (cnt <= AlignCfg::XL_CAP && e < cnt)
+          ws.xl[i][e] = ix.labels[ws.off0[i] + e];
+      }
+    }
+  });
+  static_assert(AlignCfg::KC * (2 * AlignCfg::HE_CAP + AlignCfg::XL_CAP) <= 64, "staging needs one lane per entry");
+  W::lds_sync();
+  // -- stop if every k-mer is extremely common (alignment.cpp:35-49); only single-key lists can reach 512 labels
+  bool all_common = n_k > 0;
+  for (uint32_t i = 0; i < n_k; ++i)
+    if (!(ws.nkeys0[i] == 1 && ws.cnt0[i] >= MAX_UNIQUE_KMER_POSITIONS))
+      all_common = false;
+  GTX_PROF_TICK(1)
 
   if (!all_common && n_k > 0)
   {
@@ -1391,6 +1492,7 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
       uint32_t const rs = (K - 1) * i, re = rs + (K - 1);
       bool const single = ws.nkeys0[i] == 1;
       uint32_t n_lbl;
+      DevLabel const * exact_labels = ws.lbl;
       if (single)
       {
         // exact list: one key, never cut (ph_index.cpp:84)
@@ -1401,12 +1503,17 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
           status |= GTX_ST_LABEL_OVERFLOW;
           break;
         }
-        for (uint32_t b = 0; b < cnt; b += 64)
-          W::lanes([&](uint32_t l) {
-            if (b + l < cnt)
-              ws.lbl[b + l] = ix.labels[off + b + l];
-          });
-        W::lds_sync();
+        if (i < kc && cnt <= AlignCfg::XL_CAP)
+          exact_labels = ws.xl[i]; // staged up front
+        else
+        {
+          for (uint32_t b = 0; b < cnt; b += 64)
+            W::lanes([&](uint32_t l) {
+              if (b + l < cnt)
+                ws.lbl[b + l] = ix.labels[off + b + l];
+            });
+          W::lds_sync();
+        }
       }
       else
       {
@@ -1422,7 +1529,9 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
         if (status)
           break;
       }
-      add_kmer_labels<W>(ws, ws.lbl, n_lbl, rs, re, 0, false, n_paths, longest, status);
+      GTX_PROF_TICK(2)
+      add_kmer_labels<W>(ws, exact_labels, n_lbl, rs, re, 0, false, n_paths, longest, status);
+      GTX_PROF_TICK(3)
       if (status)
         break;
       // Hamming-1 list: the 96 neighbours of a unique exact key, else the exact list again
@@ -1430,19 +1539,25 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
       if (single)
       {
         uint64_t const q = ws.key0[i];
-        if (!hamming1_by_halves<W>(ix, ws, q, n_lbl))
+        if (i < kc && use_halves && ws.hcnt[i][0] <= AlignCfg::HE_CAP && ws.hcnt[i][1] <= AlignCfg::HE_CAP)
+          n_lbl = hamming1_from_cache<W>(ix, ws, i, q);
+        else if (!use_halves || !hamming1_by_halves<W>(ix, ws, q, n_lbl))
           n_lbl = probe_list<W>(ix, ws, true, q, 96, status);
         if (status)
           break;
       }
+      GTX_PROF_TICK(4)
       add_kmer_labels<W>(ws, ws.lbl, n_lbl, rs, re, 1, false, n_paths, longest, status);
+      GTX_PROF_TICK(5)
     }
     if (!status)
     {
       n_paths = remove_short_paths<W>(ws, n_paths, longest);
       walk_read<W>(g, ws, true, n_paths, longest, status);
+      GTX_PROF_TICK(6)
       if (!status)
         walk_read<W>(g, ws, false, n_paths, longest, status);
+      GTX_PROF_TICK(7)
       if (!status)
       {
         longest = longest_of(ws, n_paths);
@@ -1459,6 +1574,7 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
     }
   }
 
+  GTX_PROF_TICK(8)
   // -- result record (layout: include/gtx.h, gtx_align_batch)
   uint32_t np = status ? 0 : n_paths;
   uint32_t w = 2;
@@ -1491,6 +1607,10 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
     rec[1] = ((status || np == 0) ? 0 : longest) | (len << 16);
   }
   W::lds_sync();
+  GTX_PROF_TICK(9)
+#ifdef GTX_PROF
+  GTX_LEAD W::atomic_add_u64(g.prof + 15, 1);
+#endif
 }
 
 // align_read (alignment.cpp:331-363): which orientations a record gets

@@ -56,36 +56,55 @@ struct WaveHip
     total = __shfl(x, 63);
     out.v = x - in.v;
   }
+  static __device__ inline unsigned long long clock() { return clock64(); }
   static __device__ inline uint32_t atomic_add_u32(uint32_t * p, uint32_t v) { return atomicAdd(p, v); }
   static __device__ inline void atomic_add_u64(unsigned long long * p, unsigned long long v) { atomicAdd(p, v); }
 };
 
+constexpr uint32_t TASK_CHUNK = 4; // reads a wave claims per visit to the task counter
+
 __global__ __launch_bounds__(64) void gtx_align_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
                                                        uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
                                                        uint32_t n_reads, uint32_t * __restrict__ records, uint32_t rec_words,
-                                                       uint32_t force_both)
+                                                       uint32_t force_both, uint32_t * task_counter)
 {
   __shared__ AlignWorkspace ws;
-  uint32_t const n_tasks = 2u * n_reads;
-  for (uint32_t t = blockIdx.x; t < n_tasks; t += gridDim.x)
+  __shared__ uint32_t task_base;
+  // Reads are claimed dynamically (one atomic per TASK_CHUNK reads): the grid is sized to what is resident at once and
+  // reads differ in cost (mismatches, ambiguous bases, the optional reverse orientation), a static split leaves CUs idle.
+  for (;;)
   {
-    uint32_t const read = t >> 1, orient = t & 1u;
-    gtx_read_meta const m = meta[read];
-    uint32_t * rec = records + static_cast<uint64_t>(t) * rec_words;
-    uint32_t const len = m.l_qseq;
-    // align_read (alignment.cpp:331-363): reads shorter than 2K-1 stay unaligned; the reverse orientation is only
-    // computed for reads that are not part of a concordant pair
-    bool const skip = len < 2 * K - 1 || len > AlignCfg::MAX_READ || (orient == 1 && !needs_reverse(m, force_both != 0));
-    if (skip)
+    if ((threadIdx.x & 63u) == 0)
+      task_base = atomicAdd(task_counter, TASK_CHUNK);
+    __syncthreads();
+    uint32_t const base = task_base;
+    __syncthreads();
+    if (base >= n_reads)
+      break;
+    uint32_t const end = base + TASK_CHUNK < n_reads ? base + TASK_CHUNK : n_reads;
+    for (uint32_t read = base; read < end; ++read)
     {
-      if ((threadIdx.x & 63u) == 0)
+      gtx_read_meta const m = meta[read];
+      uint32_t const len = m.l_qseq;
+      // align_read (alignment.cpp:331-363): reads shorter than 2K-1 stay unaligned; the reverse orientation is only
+      // computed for reads that are not part of a concordant pair
+      bool const too_short = len < 2 * K - 1, too_long = len > AlignCfg::MAX_READ;
+      bool const rev = needs_reverse(m, force_both != 0);
+      for (uint32_t orient = 0; orient < 2; ++orient)
       {
-        rec[0] = len > AlignCfg::MAX_READ ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
-        rec[1] = len << 16;
+        uint32_t * rec = records + (static_cast<uint64_t>(read) * 2 + orient) * rec_words;
+        if (too_short || too_long || (orient == 1 && !rev))
+        {
+          if ((threadIdx.x & 63u) == 0)
+          {
+            rec[0] = too_long ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
+            rec[1] = len << 16;
+          }
+          continue;
+        }
+        align_one<WaveHip>(g, ix, ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words);
       }
-      continue;
     }
-    align_one<WaveHip>(g, ix, ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words);
   }
 }
 
@@ -172,6 +191,21 @@ int ctx_upload(gtx_ctx & c, int device)
     ix.half_bucket_cap = static_cast<uint32_t>(std::min<long>(std::max<long>(std::atol(e), 0), HALF_BUCKET_CAP));
   ok = ok && upload(c.dev_allocs, ix.hslots, c.index.hslots.data(), c.index.hslots.size(), "half-key slots");
   ok = ok && upload(c.dev_allocs, ix.hlist, c.index.hlist.data(), c.index.hlist.size(), "half-key buckets");
+  void * pf = nullptr;
+  ok = ok && hip_ok(hipMalloc(&pf, 32 * sizeof(unsigned long long)), "profile counters");
+  if (ok)
+  {
+    c.dev_allocs.push_back(pf);
+    v.prof = static_cast<unsigned long long *>(pf);
+    ok = hip_ok(hipMemset(pf, 0, 32 * sizeof(unsigned long long)), "profile counters");
+  }
+  void * tc = nullptr;
+  ok = ok && hip_ok(hipMalloc(&tc, gtx_ctx::N_TASK_COUNTERS * sizeof(uint32_t)), "task counters");
+  if (ok)
+  {
+    c.dev_allocs.push_back(tc);
+    c.d_task_counters = static_cast<uint32_t *>(tc);
+  }
   void * ef = nullptr;
   ok = ok && hip_ok(hipMalloc(&ef, sizeof(uint32_t)), "error flag");
   if (ok)
@@ -187,6 +221,9 @@ int ctx_upload(gtx_ctx & c, int device)
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess)
     c.n_cu = prop.multiProcessorCount;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_kernel, 64, 0) == hipSuccess && per_cu > 0)
+    c.align_blocks_per_cu = per_cu;
   return GTX_OK;
 }
 
@@ -218,13 +255,16 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
   }
   if (n_reads == 0)
     return GTX_OK;
-  // LDS admits ~10 single-wave workgroups per CU; oversubscribe a little and grid-stride the rest
-  uint32_t const max_blocks = static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256) * 16u;
-  uint64_t const tasks = 2ull * n_reads;
-  uint32_t const blocks = static_cast<uint32_t>(tasks < max_blocks ? tasks : max_blocks);
+  // as many single-wave workgroups as are resident at once (LDS bound); they pull reads from a shared counter
+  uint32_t const max_blocks = static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256) * static_cast<uint32_t>(c->align_blocks_per_cu);
+  uint64_t const chunks = (static_cast<uint64_t>(n_reads) + TASK_CHUNK - 1) / TASK_CHUNK;
+  uint32_t const blocks = static_cast<uint32_t>(chunks < max_blocks ? chunks : max_blocks);
+  uint32_t * counter = c->d_task_counters + (c->launch_seq.fetch_add(1) % gtx_ctx::N_TASK_COUNTERS);
+  if (!hip_ok(hipMemsetAsync(counter, 0, sizeof(uint32_t), static_cast<hipStream_t>(stream)), "task counter reset"))
+    return GTX_ERR_HIP;
   hipLaunchKernelGGL(gtx_align_kernel, dim3(blocks), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph, c->dev_index,
                      d_seq, seq_stride, d_meta, n_reads, d_records, rec_words,
-                     static_cast<uint32_t>(c->params.force_align_both_orientations != 0));
+                     static_cast<uint32_t>(c->params.force_align_both_orientations != 0), counter);
   if (!hip_ok(hipGetLastError(), "gtx_align_kernel launch"))
     return GTX_ERR_HIP;
   return GTX_OK;
@@ -274,6 +314,19 @@ extern "C" int gtx_ctx_error_count(gtx_ctx * c, uint32_t * out)
   if (c->device < 0)
     return GTX_OK;
   if (!hip_ok(hipMemcpy(out, c->d_error_flag, sizeof(uint32_t), hipMemcpyDeviceToHost), "error flag"))
+    return GTX_ERR_HIP;
+  return GTX_OK;
+}
+
+// phase cycle counters of the profiling build (all zero in the normal build); out[32]
+extern "C" int gtx_ctx_profile(gtx_ctx * c, uint64_t * out)
+{
+  if (!c || !out)
+    return GTX_ERR_ARG;
+  std::memset(out, 0, 32 * sizeof(uint64_t));
+  if (c->device < 0 || !c->dev_graph.prof)
+    return GTX_OK;
+  if (!hip_ok(hipMemcpy(out, c->dev_graph.prof, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost), "profile counters"))
     return GTX_ERR_HIP;
   return GTX_OK;
 }

@@ -1,5 +1,6 @@
 // gtx_ctx.hpp -- the opaque context behind gtx_ctx* (host copies + device copies of graph and index)
 #pragma once
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -16,6 +17,10 @@ struct gtx_ctx
   gtx::GraphView dev_graph{};
   gtx::IndexView dev_index{};
   uint32_t * d_error_flag = nullptr;
+  static constexpr unsigned N_TASK_COUNTERS = 64; // one per launch in flight (launches may overlap on different streams)
+  uint32_t * d_task_counters = nullptr;
+  std::atomic<unsigned> launch_seq{0};
+  int align_blocks_per_cu = 8;
 };
 
 namespace gtx

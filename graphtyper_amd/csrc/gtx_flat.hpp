@@ -62,6 +62,7 @@ struct GraphView
   const uint64_t * allele_off; // [n_ref]
   uint64_t total_tri, total_allele;
   uint32_t n_hap, pad1;
+  unsigned long long * prof; // [32] phase cycle counters, only written by the GTX_PROF build (libgtx_prof.so)
 };
 
 // One indexed key inside a half-key bucket (see HostIndex::hlist)

@@ -11,7 +11,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "libgtx.so")
+LIB_PATH = os.path.join(HERE, os.environ.get("GTX_LIB", "libgtx.so"))  # GTX_LIB=libgtx_prof.so selects the phase-timing build
 INVALID_ID = 0xFFFFFFFF
 SPECIAL_START = 0xD0000000
 
@@ -20,7 +20,7 @@ ST_LABEL_OVERFLOW, ST_PATH_OVERFLOW, ST_DFS_OVERFLOW, ST_RECORD_OVERFLOW = 1, 2,
 # names every build of libgtx.so must export (checked by tests/test_abi.py against include/gtx.h)
 EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy", "gtx_ctx_special_positions",
            "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_index_stats", "gtx_index_get", "gtx_index_dump",
-           "gtx_align_batch", "gtx_score_batch", "gtx_ctx_error_count", "gtx_scores_finalize", "gtx_stream_create",
+           "gtx_align_batch", "gtx_score_batch", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_stream_create",
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_counts"]
 
 
@@ -94,6 +94,7 @@ def lib():
         L.gtx_score_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(ScoreBuffers),
                                       C.c_void_p]
         L.gtx_ctx_error_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.gtx_ctx_profile.argtypes = [C.c_void_p, C.c_void_p]
         L.gtx_scores_finalize.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                           C.POINTER(C.c_uint64)]
         L.gtx_stream_create.argtypes = [C.POINTER(Params), C.c_uint32, C.POINTER(C.c_void_p)]
@@ -304,6 +305,11 @@ class Context:
         check(lib().gtx_index_dump(self.h, _p(keys), _p(counts), _p(labels)))
         lab = np.stack([labels["start_index"], labels["end_index"], labels["variant_id"]], axis=1) if nl else np.zeros((0, 3), np.uint32)
         return keys, counts, lab
+
+    def profile(self):
+        out = np.zeros(32, np.uint64)
+        check(lib().gtx_ctx_profile(self.h, _p(out)))
+        return out
 
     def error_count(self):
         n = C.c_uint32()

@@ -194,6 +194,9 @@ int gtx_score_batch(gtx_ctx *, const gtx_score_item * d_items, uint32_t n_items,
  * (must be 0 for the accumulators to be complete) */
 int gtx_ctx_error_count(gtx_ctx *, uint32_t * out);
 
+/* out[32]: per-phase shader-cycle sums of the alignment kernel; only the profiling build (libgtx_prof.so) fills them */
+int gtx_ctx_profile(gtx_ctx *, uint64_t * out);
+
 /* Host-side clamp of downloaded accumulators to the reference's stored types (haplotype.cpp:19-44: u8 -> 255,
  * u16 -> 0xFFFF).  Returns the number of (haplotype,sample) cells whose max_log_score reached the sequential
  * saturation guard of explain_to_score (haplotype.cpp:560) -- those cells need a sequential replay and are
