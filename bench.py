@@ -30,7 +30,7 @@ REGION_LEN = 1000000
 READ_LEN = 150
 
 
-def make_reads_on_device(torch, ref_bases, records, n, seed, device):
+def make_reads_on_device(torch, ref_bases, records, n, seed, device, REGION_LEN=REGION_LEN):
     """diploid sample: haplotype 0 = reference, haplotype 1 = reference with a random half of the SNPs; 0.5 % substitution
     errors, 0.1 % N; position sorted; returns packed nibbles [n, 80] (uint8) and read start positions"""
     g = torch.Generator(device=device)
@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--snp-every", type=int, default=1000)
+    ap.add_argument("--region-len", type=int, default=REGION_LEN, help="experiments only; the reported workload is 1 Mb")
     ap.add_argument("--cpu-sample", type=int, default=300_000, help="reads timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -104,7 +105,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     # ---- graph + index (replicated on every GPU) ----
-    ref = synth.make_reference(REGION_LEN, seed=42)
+    ref = synth.make_reference(args.region_len, seed=42)
     records = synth.make_snp_records(ref, args.snp_every, seed=7, region_begin=REGION_BEGIN)
     ref_str = synth.bases_to_str(ref)
     t0 = time.time()
@@ -114,7 +115,7 @@ def main():
 
     # ---- reads, resident in HBM before the timed region ----
     n = args.reads
-    d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=1234 + rank, device=device)
+    d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=1234 + rank, device=device, REGION_LEN=args.region_len)
     meta = np.zeros(1, gtx.READ_META)
     meta["l_qseq"] = READ_LEN
     d_meta = torch.from_numpy(np.repeat(meta, n).view(np.uint8).reshape(n, 16).copy()).to(device)

@@ -116,6 +116,12 @@ struct AlignWorkspace // lives in LDS, one per wavefront
   uint32_t n_paths, longest, status, n_lbl, n_keys, read_len, n_wl, n_wlists;
 };
 
+#define GTX_LEAD if (W::leader())
+
+// Values that are equal on all lanes by construction (loaded from LDS state or from graph tables at a uniform address)
+// are moved to scalar registers: control flow on them then compiles to scalar branches instead of exec-mask juggling.
+#define GTX_U(x) W::uni(x)
+
 GTX_DEV uint64_t pv_mask(PVar const & v)
 {
   return (static_cast<uint64_t>(v.mhi) << 32) | v.mlo;
@@ -126,7 +132,12 @@ GTX_DEV uint32_t path_size(DPath const & p)
   return static_cast<uint32_t>(p.re) - static_cast<uint32_t>(p.rs) + 1u;
 }
 
-#define GTX_LEAD if (W::leader())
+template <class W>
+GTX_DEV uint32_t upath_size(DPath const & p) // wave-uniform
+{
+  uint32_t const w = GTX_U(reinterpret_cast<uint32_t const *>(&p)[2]); // rs | re << 16
+  return (w >> 16) - (w & 0xFFFFu) + 1u;
+}
 
 // phase timing (profiling build only: make -C graphtyper_amd/csrc prof -> libgtx_prof.so)
 #ifdef GTX_PROF
@@ -189,14 +200,41 @@ GTX_DEV uint32_t site_order(GraphView const & g, uint32_t site)
   return g.ref_order[site] + g.ref_len[site]; // order of the site's variant nodes
 }
 
+// wave-uniform variants of the helpers above (arguments uniform, results in scalar registers)
+template <class W>
+GTX_DEV uint32_t ug_ref_reach_pos(GraphView const & g, uint32_t pos)
+{
+  return g_is_special(g, pos) ? GTX_U(g.special_ref_reach[pos - SPECIAL_START]) : pos;
+}
+
+template <class W>
+GTX_DEV uint32_t ug_actual_pos(GraphView const & g, uint32_t pos)
+{
+  return g_is_special(g, pos) ? GTX_U(g.special_actual[pos - SPECIAL_START]) : pos;
+}
+
+template <class W>
+GTX_DEV uint32_t ug_special_of(GraphView const & g, uint32_t site, uint32_t pos)
+{
+  uint32_t const rr = GTX_U(g.site_ref_reach[site]);
+  return pos > rr ? SPECIAL_START + GTX_U(g.site_special_base[site]) + (pos - rr - 1) : pos;
+}
+
+template <class W>
+GTX_DEV uint32_t ug_site_order(GraphView const & g, uint32_t site)
+{
+  return GTX_U(g.ref_order[site]) + GTX_U(g.ref_len[site]);
+}
+
 // last reference node whose order is <= pos (the `rr` of graph.cpp:950-955); pos >= first_order required
+template <class W>
 GTX_DEV uint32_t g_ref_node_at(GraphView const & g, uint32_t pos)
 {
   uint32_t b = (pos - g.first_order) >> POS_BUCKET_SHIFT;
   if (b >= g.n_bucket)
     b = g.n_bucket - 1;
-  uint32_t r = g.pos_bucket[b];
-  while (r + 1 < g.n_ref && g.ref_order[r + 1] <= pos)
+  uint32_t r = GTX_U(g.pos_bucket[b]);
+  while (r + 1 < g.n_ref && GTX_U(g.ref_order[r + 1]) <= pos)
     ++r;
   return r;
 }
@@ -207,9 +245,10 @@ GTX_DEV uint32_t g_ref_node_at(GraphView const & g, uint32_t pos)
 template <class W>
 GTX_DEV uint32_t get_locations(GraphView const & g, uint32_t pos, DPath const & path, Loc * locs, uint32_t cap, uint32_t & status)
 {
+  pos = GTX_U(pos);
   bool const special = g_is_special(g, pos);
   if (special)
-    pos = g.special_actual[pos - SPECIAL_START];
+    pos = GTX_U(g.special_actual[pos - SPECIAL_START]);
   uint32_t n = 0;
   if (pos < g.first_order)
     return 0;
@@ -218,27 +257,30 @@ GTX_DEV uint32_t get_locations(GraphView const & g, uint32_t pos, DPath const & 
     GTX_LEAD locs[0] = Loc{1, 0, g.ref_order[0], pos - g.ref_order[0]};
     return 1;
   }
-  int64_t rr = g_ref_node_at(g, pos);
-  if (pos < g.ref_order[rr] + g.ref_len[rr])
+  int32_t rr = static_cast<int32_t>(g_ref_node_at<W>(g, pos));
   {
-    if (!special)
+    uint32_t const ro = GTX_U(g.ref_order[rr]), rl = GTX_U(g.ref_len[rr]);
+    if (pos < ro + rl)
     {
-      GTX_LEAD locs[0] = Loc{1, static_cast<uint32_t>(rr), g.ref_order[rr], pos - g.ref_order[rr]};
-      return 1;
+      if (!special)
+      {
+        GTX_LEAD locs[0] = Loc{1, static_cast<uint32_t>(rr), ro, pos - ro};
+        return 1;
+      }
+      --rr;
     }
-    --rr;
   }
   // sites rr' <= rr with reach(rr') + PADDING > pos, descending; only sites the path carries can contribute
-  bool const path_empty = path.start == path.end;
-  uint32_t const nvar = path.nvar;
-  int64_t bound = rr + 1;
+  bool const path_empty = GTX_U(path.start) == GTX_U(path.end);
+  uint32_t const nvar = GTX_U(static_cast<uint32_t>(path.nvar));
+  int32_t bound = rr + 1;
   for (;;)
   {
-    int64_t best = -1;
+    int32_t best = -1;
     uint32_t best_j = 0;
     for (uint32_t j = 0; j < nvar; ++j)
     {
-      int64_t const s = path.v[j].site;
+      int32_t const s = static_cast<int32_t>(GTX_U(path.v[j].site));
       if (s < bound && s > best)
       {
         best = s;
@@ -249,16 +291,16 @@ GTX_DEV uint32_t get_locations(GraphView const & g, uint32_t pos, DPath const & 
       break;
     bound = best;
     uint32_t const site = static_cast<uint32_t>(best);
-    int64_t const reach = static_cast<int64_t>(g.ref_order[site]) + g.ref_len[site] - 1;
+    int64_t const reach = static_cast<int64_t>(GTX_U(g.ref_order[site])) + GTX_U(g.ref_len[site]) - 1;
     if (!(reach + static_cast<int64_t>(g.padding) > static_cast<int64_t>(pos)))
       break; // the reference stops its backward scan here; lower sites reach even less far
-    uint32_t const fv = g.ref_first_var[site], nv = g.ref_nvar[site];
-    uint64_t const mask = pv_mask(path.v[best_j]);
+    uint32_t const fv = GTX_U(g.ref_first_var[site]), nv = GTX_U(g.ref_nvar[site]);
+    uint64_t const mask = (static_cast<uint64_t>(GTX_U(path.v[best_j].mhi)) << 32) | GTX_U(path.v[best_j].mlo);
     for (uint32_t i = 0; i < nv; ++i)
     {
       uint32_t const v = fv + i;
-      uint32_t const vo = g.var_order[v];
-      if (pos >= vo && pos <= vo + g.var_len[v] - 1)
+      uint32_t const vo = GTX_U(g.var_order[v]);
+      if (pos >= vo && pos <= vo + GTX_U(g.var_len[v]) - 1)
         if (path_empty || ((mask >> i) & 1ull))
         {
           if (n >= cap)
@@ -294,6 +336,9 @@ struct SubRead
 template <class W, bool BACKWARD>
 GTX_DEV uint32_t cmp_codes(SubRead const & sr, uint32_t at, uint8_t const * dna, uint32_t n, uint32_t mism, uint32_t maxmm)
 {
+  mism = GTX_U(mism);
+  n = GTX_U(n);
+  at = GTX_U(at);
   if (mism > maxmm)
     return maxmm + 1;
   uint32_t const room = at < sr.len ? sr.len - at : 0;
@@ -339,9 +384,9 @@ GTX_DEV bool emit_best(GraphView const & g, Cand const * cand, uint32_t n, uint3
   uint32_t const first_out = n_out;
   for (uint32_t j = 0; j < n; ++j)
   {
-    if (cand[j].len < L)
+    if (GTX_U(cand[j].len) < L)
       continue;
-    uint32_t const mm = cand[j].mism;
+    uint32_t const mm = GTX_U(cand[j].mism);
     if (mm > max_mismatches)
       continue;
     if (mm < max_mismatches)
@@ -349,14 +394,14 @@ GTX_DEV bool emit_best(GraphView const & g, Cand const * cand, uint32_t n, uint3
       max_mismatches = mm;
       n_out = first_out;
     }
-    uint32_t const nids = cand[j].nids;
+    uint32_t const nids = GTX_U(cand[j].nids);
     uint32_t const nl = nids == 0 ? 1 : nids;
     if (n_out + nl > out_cap)
     {
       status |= GTX_ST_DFS_OVERFLOW;
       return false;
     }
-    uint32_t const p = cand[j].pos;
+    uint32_t const p = GTX_U(cand[j].pos);
     uint32_t const s = BACKWARD ? p : fixed_pos, e = BACKWARD ? fixed_pos : p;
     if (nids == 0)
     {
@@ -366,9 +411,9 @@ GTX_DEV bool emit_best(GraphView const & g, Cand const * cand, uint32_t n, uint3
     else
       for (uint32_t k = 0; k < nids; ++k)
       {
-        uint32_t const v = cand[j].ids[k];
-        uint32_t const vs = g.var_out_ref[v] - 1;
-        GTX_LEAD out[n_out] = DevLabel{s, e, vs, v - g.ref_first_var[vs]};
+        uint32_t const v = GTX_U(cand[j].ids[k]);
+        uint32_t const vs = GTX_U(g.var_out_ref[v]) - 1;
+        GTX_LEAD out[n_out] = DevLabel{s, e, vs, v - GTX_U(g.ref_first_var[vs])};
         ++n_out;
       }
   }
@@ -387,7 +432,7 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
   uint32_t const maxmm = max_mismatches;
   uint32_t n = 1;
   uint32_t site = INVALID; // site whose alleles come next, INVALID = none
-  uint32_t const s_type = s.type, s_node = s.node, s_offset = s.offset, s_order = s.order;
+  uint32_t const s_type = GTX_U(s.type), s_node = GTX_U(s.node), s_offset = GTX_U(s.offset), s_order = GTX_U(s.order);
   {
     uint32_t len, mism, pos, nids = 0, id0 = 0;
     if (s_type == 2)
@@ -395,38 +440,39 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
       uint32_t const v = s_node;
       nids = 1;
       id0 = v;
-      uint32_t const vsite = g.var_out_ref[v] - 1;
-      uint32_t const vo = g.var_order[v], vl = g.var_len[v];
+      uint32_t const vout = GTX_U(g.var_out_ref[v]);
+      uint32_t const vsite = vout - 1;
+      uint32_t const vo = GTX_U(g.var_order[v]), vl = GTX_U(g.var_len[v]), vd = GTX_U(g.var_dna[v]);
       if (!BACKWARD)
       {
         len = vl - s_offset;
-        mism = cmp_codes<W, false>(sr, 0, dna + g.var_dna[v] + s_offset, len, 0, maxmm);
+        mism = cmp_codes<W, false>(sr, 0, dna + vd + s_offset, len, 0, maxmm);
         if (len >= L)
-          pos = g_special_of(g, vsite, (vo + vl - 1) - (len - L));
+          pos = ug_special_of<W>(g, vsite, (vo + vl - 1) - (len - L));
         else
         {
-          uint32_t const r = g.var_out_ref[v];
-          uint32_t const rl = g.ref_len[r];
-          mism = cmp_codes<W, false>(sr, len, dna + g.ref_dna[r], rl, mism, maxmm);
+          uint32_t const r = vout;
+          uint32_t const rl = GTX_U(g.ref_len[r]);
+          mism = cmp_codes<W, false>(sr, len, dna + GTX_U(g.ref_dna[r]), rl, mism, maxmm);
           len += rl;
-          pos = (g.ref_order[r] + rl - 1) - (len - L);
-          if (g.ref_nvar[r] > 0)
+          pos = (GTX_U(g.ref_order[r]) + rl - 1) - (len - L);
+          if (GTX_U(g.ref_nvar[r]) > 0)
             site = r;
         }
       }
       else
       {
         len = s_offset + 1;
-        mism = cmp_codes<W, true>(sr, 0, dna + g.var_dna[v], len, 0, maxmm);
+        mism = cmp_codes<W, true>(sr, 0, dna + vd, len, 0, maxmm);
         if (len >= L)
-          pos = g_special_of(g, vsite, vo + (len - L));
+          pos = ug_special_of<W>(g, vsite, vo + (len - L));
         else
         {
           uint32_t const r = vsite;
-          uint32_t const rl = g.ref_len[r];
-          mism = cmp_codes<W, true>(sr, len, dna + g.ref_dna[r], rl, mism, maxmm);
+          uint32_t const rl = GTX_U(g.ref_len[r]);
+          mism = cmp_codes<W, true>(sr, len, dna + GTX_U(g.ref_dna[r]), rl, mism, maxmm);
           len += rl;
-          pos = g.ref_order[r] + (len - L);
+          pos = GTX_U(g.ref_order[r]) + (len - L);
           if (r != 0)
             site = r - 1;
         }
@@ -435,13 +481,13 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
     else
     {
       uint32_t const r = s_node;
-      uint32_t const rl = g.ref_len[r];
+      uint32_t const rl = GTX_U(g.ref_len[r]), rd_ = GTX_U(g.ref_dna[r]);
       if (!BACKWARD)
       {
         len = rl - s_offset;
-        mism = cmp_codes<W, false>(sr, 0, dna + g.ref_dna[r] + s_offset, len, 0, maxmm);
-        pos = (g.ref_order[r] + rl - 1) - (len - L);
-        if (g.ref_nvar[r] > 0)
+        mism = cmp_codes<W, false>(sr, 0, dna + rd_ + s_offset, len, 0, maxmm);
+        pos = (s_order + rl - 1) - (len - L); // s_order is the node's order
+        if (GTX_U(g.ref_nvar[r]) > 0)
           site = r;
       }
       else
@@ -449,8 +495,8 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
         if (r != 0)
           site = r - 1;
         len = s_offset + 1;
-        mism = cmp_codes<W, true>(sr, 0, dna + g.ref_dna[r], len, 0, maxmm);
-        pos = g.ref_order[r] + (len - L);
+        mism = cmp_codes<W, true>(sr, 0, dna + rd_, len, 0, maxmm);
+        pos = s_order + (len - L);
       }
     }
     GTX_LEAD
@@ -464,30 +510,30 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
     W::lds_sync();
   }
 
-  if (site != INVALID && cand[0].len < L)
+  if (site != INVALID && GTX_U(cand[0].len) < L)
   {
     bool all_long = false;
     while (!all_long && n < 128 && site != INVALID)
     {
       all_long = true;
       uint32_t const r = BACKWARD ? site : site + 1; // reference node appended (forward) / prepended (backward)
-      uint32_t const fv = g.ref_first_var[site], nv = g.ref_nvar[site];
-      uint8_t const * rdna = dna + g.ref_dna[r];
-      uint32_t const rlen = g.ref_len[r];
-      uint32_t const rorder = g.ref_order[r];
+      uint32_t const fv = GTX_U(g.ref_first_var[site]), nv = GTX_U(g.ref_nvar[site]);
+      uint8_t const * rdna = dna + GTX_U(g.ref_dna[r]);
+      uint32_t const rlen = GTX_U(g.ref_len[r]);
+      uint32_t const rorder = GTX_U(g.ref_order[r]);
       uint32_t original = n;
       for (uint32_t j = 0; j < original; ++j)
       {
-        uint32_t const jlen = cand[j].len, jmism = cand[j].mism, jn = cand[j].nids;
+        uint32_t const jlen = GTX_U(cand[j].len), jmism = GTX_U(cand[j].mism), jn = GTX_U(cand[j].nids);
         if (jlen >= L)
           continue;
         for (uint32_t i = 0; i < nv; ++i)
         {
           bool const last = i + 1 == nv; // the last allele extends candidate j in place, the others branch off copies
           uint32_t const v = fv + i;
-          uint32_t const vo = g.var_order[v], vl = g.var_len[v];
+          uint32_t const vo = GTX_U(g.var_order[v]), vl = GTX_U(g.var_len[v]);
           uint32_t len = jlen;
-          uint32_t mm = cmp_codes<W, BACKWARD>(sr, len, dna + g.var_dna[v], vl, jmism, maxmm);
+          uint32_t mm = cmp_codes<W, BACKWARD>(sr, len, dna + GTX_U(g.var_dna[v]), vl, jmism, maxmm);
           len += vl;
           bool const enough = len >= L;
           if (!enough)
@@ -504,9 +550,9 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
             }
             uint32_t pos;
             if (!BACKWARD)
-              pos = enough ? g_special_of(g, site, (vo + vl - 1) - (len - L)) : (rorder + rlen - 1) - (len - L);
+              pos = enough ? ug_special_of<W>(g, site, (vo + vl - 1) - (len - L)) : (rorder + rlen - 1) - (len - L);
             else
-              pos = enough ? g_special_of(g, site, vo + (len - L)) : rorder + (len - L);
+              pos = enough ? ug_special_of<W>(g, site, vo + (len - L)) : rorder + (len - L);
             uint32_t const dst = last ? j : n;
             if (!last)
             {
@@ -538,7 +584,7 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
       if (all_long)
         break;
       if (!BACKWARD)
-        site = g.ref_nvar[r] > 0 ? r : INVALID;
+        site = GTX_U(g.ref_nvar[r]) > 0 ? r : INVALID;
       else
       {
         if (r == 0)
@@ -550,7 +596,7 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
 
   uint32_t fixed = s_order + s_offset;
   if (s_type == 2)
-    fixed = g_special_of(g, g.var_out_ref[s_node] - 1, fixed);
+    fixed = ug_special_of<W>(g, GTX_U(g.var_out_ref[s_node]) - 1, fixed);
   return emit_best<W, BACKWARD>(g, cand, n, L, fixed, max_mismatches, out, n_out, out_cap, status);
 }
 
@@ -601,10 +647,10 @@ GTX_DEV uint32_t make_pp(DPath * pp, DevLabel const * ll, uint32_t n, uint32_t r
   uint32_t npp = 0;
   for (uint32_t i = 0; i < n; ++i)
   {
-    uint32_t const ls = ll[i].start, le = ll[i].end, lsite = ll[i].site, lall = ll[i].allele;
+    uint32_t const ls = GTX_U(ll[i].start), le = GTX_U(ll[i].end), lsite = GTX_U(ll[i].site), lall = GTX_U(ll[i].allele);
     uint32_t d = 0;
     for (; d < npp; ++d)
-      if (pp[d].start == ls && pp[d].end == le)
+      if (GTX_U(pp[d].start) == ls && GTX_U(pp[d].end) == le)
         break;
     if (d == npp)
     {
@@ -636,10 +682,10 @@ GTX_DEV uint32_t make_pp(DPath * pp, DevLabel const * ll, uint32_t n, uint32_t r
     if (lsite == INVALID)
       continue;
     DPath & p = pp[d];
-    uint32_t const nvar = p.nvar;
+    uint32_t const nvar = GTX_U(static_cast<uint32_t>(p.nvar));
     uint32_t k = 0;
     for (; k < nvar; ++k)
-      if (p.v[k].site == lsite)
+      if (GTX_U(p.v[k].site) == lsite)
         break;
     if (k == nvar && nvar >= AlignCfg::MAXV)
     {
@@ -673,18 +719,18 @@ template <class W>
 GTX_DEV bool merge_paths(DPath const & p1, DPath const & p2, DPath & np, uint32_t & status)
 {
   copy_entry<W>(np, p2);
-  uint32_t const n1 = p1.nvar;
-  uint32_t nn = np.nvar;
+  uint32_t const n1 = GTX_U(static_cast<uint32_t>(p1.nvar));
+  uint32_t nn = GTX_U(static_cast<uint32_t>(np.nvar));
   for (uint32_t i = 0; i < n1; ++i)
   {
-    uint32_t const s1 = p1.v[i].site;
+    uint32_t const s1 = GTX_U(p1.v[i].site);
     uint32_t j = 0;
     for (; j < nn; ++j)
-      if (np.v[j].site == s1)
+      if (GTX_U(np.v[j].site) == s1)
         break;
     if (j < nn)
     {
-      uint32_t const lo = np.v[j].mlo & p1.v[i].mlo, hi = np.v[j].mhi & p1.v[i].mhi;
+      uint32_t const lo = GTX_U(np.v[j].mlo & p1.v[i].mlo), hi = GTX_U(np.v[j].mhi & p1.v[i].mhi);
       if ((lo | hi) == 0)
         return false;
       GTX_LEAD
@@ -744,23 +790,23 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
   uint64_t matched = 0;
   for (uint32_t i = 0; i < original_size; ++i)
   {
-    if (prev ? (ws.paths[i].rs != re) : (ws.paths[i].re != rs))
+    if (prev ? (GTX_U(static_cast<uint32_t>(ws.paths[i].rs)) != re) : (GTX_U(static_cast<uint32_t>(ws.paths[i].re)) != rs))
       continue;
     bool once = false;
     copy_entry<W>(ws.orig, ws.paths[i]);
-    uint32_t const o_start = ws.orig.start, o_end = ws.orig.end;
+    uint32_t const o_start = GTX_U(ws.orig.start), o_end = GTX_U(ws.orig.end);
     for (uint32_t j = 0; j < npp; ++j)
     {
       bool ok;
       if (prev)
       {
-        if (!(pp[j].end == o_start))
+        if (!(GTX_U(pp[j].end) == o_start))
           continue;
         ok = merge_paths<W>(pp[j], ws.orig, ws.np, status);
       }
       else
       {
-        if (!(o_end == pp[j].start))
+        if (!(o_end == GTX_U(pp[j].start)))
           continue;
         ok = merge_paths<W>(ws.orig, pp[j], ws.np, status);
       }
@@ -776,7 +822,7 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
       }
       else
       {
-        uint32_t const sz = path_size(ws.np);
+        uint32_t const sz = upath_size<W>(ws.np);
         if (sz > longest)
           longest = sz;
         copy_entry<W>(ws.paths[i], ws.np);
@@ -787,7 +833,7 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
   for (uint32_t j = 0; j < npp; ++j)
     if (!((matched >> j) & 1ull))
     {
-      uint32_t const sz = path_size(pp[j]);
+      uint32_t const sz = upath_size<W>(pp[j]);
       if (sz > longest)
         longest = sz;
       if (!push_path<W>(ws, n_paths, pp[j], status))
@@ -823,17 +869,18 @@ GTX_DEV uint32_t remove_short_paths(AlignWorkspace & ws, uint32_t n_paths, uint3
     return n_paths;
   uint64_t drop = 0;
   for (uint32_t i = 0; i < n_paths; ++i)
-    if (path_size(ws.paths[i]) < longest)
+    if (upath_size<W>(ws.paths[i]) < longest)
       drop |= 1ull << i;
   return compact_paths<W>(ws, n_paths, drop);
 }
 
+template <class W>
 GTX_DEV uint32_t longest_of(AlignWorkspace const & ws, uint32_t n_paths) // :858-864
 {
   uint32_t m = 0;
   for (uint32_t i = 0; i < n_paths; ++i)
   {
-    uint32_t const s = path_size(ws.paths[i]);
+    uint32_t const s = upath_size<W>(ws.paths[i]);
     if (s > m)
       m = s;
   }
@@ -847,31 +894,36 @@ GTX_DEV uint32_t remove_paths_with_too_many_mismatches(AlignWorkspace & ws, uint
     return 0;
   uint32_t mn = 10;
   for (uint32_t i = 0; i < n_paths; ++i)
-    if (ws.paths[i].mism < mn)
-      mn = ws.paths[i].mism;
+  {
+    uint32_t const m = GTX_U(static_cast<uint32_t>(ws.paths[i].mism));
+    if (m < mn)
+      mn = m;
+  }
   uint64_t drop = 0;
   for (uint32_t i = 0; i < n_paths; ++i)
-    if (ws.paths[i].mism > mn)
+    if (GTX_U(static_cast<uint32_t>(ws.paths[i].mism)) > mn)
       drop |= 1ull << i;
   return compact_paths<W>(ws, n_paths, drop);
 }
 
+template <class W>
 GTX_DEV bool all_paths_unique(GraphView const & g, DPath const * paths, uint32_t n) // :219-231
 {
   if (n < 2)
     return true;
-  uint32_t const s0 = g_ref_reach_pos(g, paths[0].start), e0 = g_ref_reach_pos(g, paths[0].end);
+  uint32_t const s0 = ug_ref_reach_pos<W>(g, GTX_U(paths[0].start)), e0 = ug_ref_reach_pos<W>(g, GTX_U(paths[0].end));
   for (uint32_t i = 1; i < n; ++i)
-    if (s0 != g_ref_reach_pos(g, paths[i].start) && e0 != g_ref_reach_pos(g, paths[i].end))
+    if (s0 != ug_ref_reach_pos<W>(g, GTX_U(paths[i].start)) && e0 != ug_ref_reach_pos<W>(g, GTX_U(paths[i].end)))
       return false;
   return true;
 }
 
+template <class W>
 GTX_DEV bool path_is_reference(DPath const & p) // path.cpp:176-185
 {
-  uint32_t const nv = p.nvar;
+  uint32_t const nv = GTX_U(static_cast<uint32_t>(p.nvar));
   for (uint32_t k = 0; k < nv; ++k)
-    if (!(p.v[k].mlo & 1u))
+    if (!(GTX_U(p.v[k].mlo) & 1u))
       return false;
   return true;
 }
@@ -879,11 +931,11 @@ GTX_DEV bool path_is_reference(DPath const & p) // path.cpp:176-185
 template <class W>
 GTX_DEV uint32_t remove_non_ref_paths_when_read_matches_ref(GraphView const & g, AlignWorkspace & ws, uint32_t n_paths) // :460-474
 {
-  if (all_paths_unique(g, ws.paths, n_paths))
+  if (all_paths_unique<W>(g, ws.paths, n_paths))
     return n_paths;
   uint64_t nonref = 0;
   for (uint32_t i = 0; i < n_paths; ++i)
-    if (!path_is_reference(ws.paths[i]))
+    if (!path_is_reference<W>(ws.paths[i]))
       nonref |= 1ull << i;
   uint64_t const all = n_paths >= 64 ? ~0ull : ((1ull << n_paths) - 1);
   if (nonref == all)
@@ -896,7 +948,7 @@ GTX_DEV uint32_t remove_fully_special_paths(GraphView const & g, AlignWorkspace 
 {
   uint64_t drop = 0;
   for (uint32_t i = 0; i < n_paths; ++i)
-    if (g_ref_reach_pos(g, ws.paths[i].start) == g_ref_reach_pos(g, ws.paths[i].end))
+    if (ug_ref_reach_pos<W>(g, GTX_U(ws.paths[i].start)) == ug_ref_reach_pos<W>(g, GTX_U(ws.paths[i].end)))
       drop |= 1ull << i;
   return compact_paths<W>(ws, n_paths, drop);
 }
@@ -907,19 +959,19 @@ GTX_DEV void remove_support_from_read_ends(GraphView const & g, AlignWorkspace &
   for (uint32_t i = 0; i < n_paths; ++i)
   {
     DPath & p = ws.paths[i];
-    uint32_t const nvar = p.nvar;
+    uint32_t const nvar = GTX_U(static_cast<uint32_t>(p.nvar));
     if (nvar == 0)
       continue;
-    uint32_t const pstart = p.start, pend = p.end;
+    uint32_t const pstart = GTX_U(p.start), pend = GTX_U(p.end);
     bool const ss = g_is_special(g, pstart), es = g_is_special(g, pend);
     if (!ss && !es)
       continue;
     // std::minmax_element: first smallest, last largest
     uint32_t imin = 0, imax = 0;
-    uint32_t omin = site_order(g, p.v[0].site), omax = omin;
+    uint32_t omin = ug_site_order<W>(g, GTX_U(p.v[0].site)), omax = omin;
     for (uint32_t k = 1; k < nvar; ++k)
     {
-      uint32_t const o = site_order(g, p.v[k].site);
+      uint32_t const o = ug_site_order<W>(g, GTX_U(p.v[k].site));
       if (o < omin)
       {
         omin = o;
@@ -931,13 +983,13 @@ GTX_DEV void remove_support_from_read_ends(GraphView const & g, AlignWorkspace &
         imax = k;
       }
     }
-    bool const clear_max = es && static_cast<int64_t>(g_actual_pos(g, pend)) <= static_cast<int64_t>(omax) + 4;
+    bool const clear_max = es && static_cast<int64_t>(ug_actual_pos<W>(g, pend)) <= static_cast<int64_t>(omax) + 4;
     bool clear_min = false;
     if (ss)
     {
       bool ambiguous = true;
       if (g_is_special(g, pstart + 4u))
-        ambiguous = g_ref_reach_pos(g, pstart) != g_ref_reach_pos(g, pstart + 4u);
+        ambiguous = ug_ref_reach_pos<W>(g, pstart) != ug_ref_reach_pos<W>(g, pstart + 4u);
       clear_min = ambiguous;
     }
     GTX_LEAD
@@ -964,8 +1016,8 @@ template <class W>
 GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, uint32_t & n_paths, uint32_t & longest,
                        uint32_t & status)
 {
-  uint32_t const L = ws.read_len;
-  if (n_paths == 0 || path_size(ws.paths[0]) == L)
+  uint32_t const L = GTX_U(ws.read_len);
+  if (n_paths == 0 || upath_size<W>(ws.paths[0]) == L)
     return;
   if (n_paths > MAX_SEED_NUMBER_FOR_WALKING)
     return;
@@ -978,7 +1030,7 @@ GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, ui
   for (uint32_t i = 0; i < n_paths; ++i)
   {
     DPath const & path = ws.paths[i];
-    uint32_t const prs = path.rs, pre = path.re;
+    uint32_t const prs = GTX_U(static_cast<uint32_t>(path.rs)), pre = GTX_U(static_cast<uint32_t>(path.re));
     SubRead sr;
     sr.rd = ws.rd;
     uint32_t n_locs;
@@ -1044,9 +1096,10 @@ GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, ui
   }
   for (uint32_t k = 0; k < n_wlists; ++k)
   {
-    DevLabel const * ll = ws.wl + ws.wl_off[k];
-    uint32_t const n = ws.wl_off[k + 1] - ws.wl_off[k];
-    uint32_t const idx = ws.wl_idx[k];
+    uint32_t const o0 = GTX_U(ws.wl_off[k]);
+    DevLabel const * ll = ws.wl + o0;
+    uint32_t const n = GTX_U(ws.wl_off[k + 1]) - o0;
+    uint32_t const idx = GTX_U(ws.wl_idx[k]);
     if (starts)
       add_kmer_labels<W>(ws, ll, n, 0, idx, best, true, n_paths, longest, status);
     else
@@ -1100,28 +1153,51 @@ GTX_DEV uint32_t expand_keys(uint8_t const * rd, uint32_t at, uint64_t * keys)
   return n;
 }
 
-// PHIndex lookup of one key: (offset, count) of its labels, count 0 when absent
-GTX_DEV void index_find(IndexView const & ix, uint64_t key, uint32_t & off, uint32_t & cnt)
+// lookup in a bucketed table (gtx_flat.hpp: BUCKET_SLOTS): the whole 64-byte bucket is fetched at once
+GTX_DEV void bucket_find(IndexSlot const * slots, uint32_t log2_buckets, uint64_t key, uint32_t & off, uint32_t & cnt)
 {
-  uint64_t const mask = (1ull << ix.log2_cap) - 1;
-  uint64_t h = hash_key(key, ix.log2_cap);
-  for (;;)
+  uint64_t const mask = (1ull << log2_buckets) - 1;
+  for (uint64_t b = hash_key(key, log2_buckets);; b = (b + 1) & mask)
   {
-    IndexSlot const s = ix.slots[h];
-    if (s.cnt == 0)
+    IndexSlot const * p = slots + b * BUCKET_SLOTS;
+    IndexSlot const s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
+    if (s0.cnt != 0 && s0.key == key)
+    {
+      off = s0.off;
+      cnt = s0.cnt;
+      return;
+    }
+    if (s1.cnt != 0 && s1.key == key)
+    {
+      off = s1.off;
+      cnt = s1.cnt;
+      return;
+    }
+    if (s2.cnt != 0 && s2.key == key)
+    {
+      off = s2.off;
+      cnt = s2.cnt;
+      return;
+    }
+    if (s3.cnt != 0 && s3.key == key)
+    {
+      off = s3.off;
+      cnt = s3.cnt;
+      return;
+    }
+    if (s3.cnt == 0) // slots fill front to back: an empty last slot means the key did not spill further
     {
       off = 0;
       cnt = 0;
       return;
     }
-    if (s.key == key)
-    {
-      off = s.off;
-      cnt = s.cnt;
-      return;
-    }
-    h = (h + 1) & mask;
   }
+}
+
+// PHIndex lookup of one key: (offset, count) of its labels, count 0 when absent
+GTX_DEV void index_find(IndexView const & ix, uint64_t key, uint32_t & off, uint32_t & cnt)
+{
+  bucket_find(ix.slots, ix.log2_cap, key, off, cnt);
 }
 
 GTX_DEV uint64_t spread_bits(uint32_t x) // bit i -> bit 2i
@@ -1171,6 +1247,7 @@ GTX_DEV uint32_t probe_list(IndexView const & ix, AlignWorkspace & ws, bool hamm
     });
     total += W::sum(cnt);
   }
+  total = GTX_U(total);
   W::lds_sync();
   if (nkeys > 1 && total > ix.max_index_labels)
     return 0; // ph_index.cpp:84-89
@@ -1211,25 +1288,7 @@ GTX_DEV uint32_t probe_list(IndexView const & ix, AlignWorkspace & ws, bool hamm
 // bucket of a half key (see IndexView::hslots): (offset, count) into hlist, count 0 when the half does not occur
 GTX_DEV void half_find(IndexView const & ix, uint64_t hk, uint32_t & off, uint32_t & cnt)
 {
-  uint64_t const mask = (1ull << ix.h_log2_cap) - 1;
-  uint64_t h = hash_key(hk, ix.h_log2_cap);
-  for (;;)
-  {
-    IndexSlot const s = ix.hslots[h];
-    if (s.cnt == 0)
-    {
-      off = 0;
-      cnt = 0;
-      return;
-    }
-    if (s.key == hk)
-    {
-      off = s.off;
-      cnt = s.cnt;
-      return;
-    }
-    h = (h + 1) & mask;
-  }
+  bucket_find(ix.hslots, ix.h_log2_cap, hk, off, cnt);
 }
 
 constexpr uint32_t HALF_BUCKET_CAP = 64; // one lane per bucket entry; larger buckets (low-complexity sequence) use the 96 direct probes
@@ -1275,13 +1334,13 @@ GTX_DEV uint32_t hamming1_finish(IndexView const & ix, AlignWorkspace & ws, uint
   }
   uint32_t total = 0;
   for (uint32_t a = 0; a < ncand; ++a)
-    total += static_cast<uint32_t>(cand[a] >> 32) & 0xFFFFFFu;
+    total += GTX_U(static_cast<uint32_t>(cand[a] >> 32)) & 0xFFFFFFu;
   if (total > ix.max_index_labels)
     return 0;
   uint32_t done = 0;
   for (uint32_t a = 0; a < ncand; ++a)
   {
-    uint64_t const e = cand[a];
+    uint64_t const e = GTX_U(cand[a]);
     uint32_t const off = static_cast<uint32_t>(e), cnt = static_cast<uint32_t>(e >> 32) & 0xFFFFFFu;
     for (uint32_t b = 0; b < cnt; b += 64)
       W::lanes([&](uint32_t l) {
@@ -1353,11 +1412,11 @@ GTX_DEV uint32_t hamming1_from_cache(IndexView const & ix, AlignWorkspace & ws, 
   uint32_t ncand = 0;
   for (uint32_t side = 0; side < 2; ++side)
   {
-    uint32_t const cs = ws.hcnt[i][side];
+    uint32_t const cs = GTX_U(ws.hcnt[i][side]);
     for (uint32_t e = 0; e < cs; ++e)
     {
       uint32_t j;
-      if (hamming1_neighbour(ws.he[i][side][e].key, q, j))
+      if (hamming1_neighbour(GTX_U(ws.he[i][side][e].key), q, j))
       {
         uint64_t const pk = static_cast<uint64_t>(ws.he[i][side][e].off) | (static_cast<uint64_t>(ws.he[i][side][e].cnt) << 32) |
                             (static_cast<uint64_t>(j) << 56);
@@ -1481,7 +1540,7 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
   // -- stop if every k-mer is extremely common (alignment.cpp:35-49); only single-key lists can reach 512 labels
   bool all_common = n_k > 0;
   for (uint32_t i = 0; i < n_k; ++i)
-    if (!(ws.nkeys0[i] == 1 && ws.cnt0[i] >= MAX_UNIQUE_KMER_POSITIONS))
+    if (!(GTX_U(ws.nkeys0[i]) == 1 && GTX_U(ws.cnt0[i]) >= MAX_UNIQUE_KMER_POSITIONS))
       all_common = false;
   GTX_PROF_TICK(1)
 
@@ -1490,13 +1549,13 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
     for (uint32_t i = 0; i < n_k && !status; ++i)
     {
       uint32_t const rs = (K - 1) * i, re = rs + (K - 1);
-      bool const single = ws.nkeys0[i] == 1;
+      bool const single = GTX_U(ws.nkeys0[i]) == 1;
       uint32_t n_lbl;
       DevLabel const * exact_labels = ws.lbl;
       if (single)
       {
         // exact list: one key, never cut (ph_index.cpp:84)
-        uint32_t const cnt = ws.cnt0[i], off = ws.off0[i];
+        uint32_t const cnt = GTX_U(ws.cnt0[i]), off = GTX_U(ws.off0[i]);
         n_lbl = cnt;
         if (cnt > AlignCfg::LBL_CAP)
         {
@@ -1524,7 +1583,7 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
           ws.n_keys = nk;
         }
         W::lds_sync();
-        nk = ws.n_keys;
+        nk = GTX_U(ws.n_keys);
         n_lbl = probe_list<W>(ix, ws, false, 0, nk, status);
         if (status)
           break;
@@ -1538,8 +1597,8 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
       // (kmer_help_functions.cpp:97-119 keeps multi-key lists as they are, so ws.lbl is already what multi_get returns)
       if (single)
       {
-        uint64_t const q = ws.key0[i];
-        if (i < kc && use_halves && ws.hcnt[i][0] <= AlignCfg::HE_CAP && ws.hcnt[i][1] <= AlignCfg::HE_CAP)
+        uint64_t const q = GTX_U(ws.key0[i]);
+        if (i < kc && use_halves && GTX_U(ws.hcnt[i][0]) <= AlignCfg::HE_CAP && GTX_U(ws.hcnt[i][1]) <= AlignCfg::HE_CAP)
           n_lbl = hamming1_from_cache<W>(ix, ws, i, q);
         else if (!use_halves || !hamming1_by_halves<W>(ix, ws, q, n_lbl))
           n_lbl = probe_list<W>(ix, ws, true, q, 96, status);
@@ -1560,13 +1619,13 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
       GTX_PROF_TICK(7)
       if (!status)
       {
-        longest = longest_of(ws, n_paths);
+        longest = longest_of<W>(ws, n_paths);
         n_paths = remove_short_paths<W>(ws, n_paths, longest);
         n_paths = remove_paths_with_too_many_mismatches<W>(ws, n_paths);
         if (g.is_sv_graph)
           n_paths = remove_fully_special_paths<W>(g, ws, n_paths);
         n_paths = remove_non_ref_paths_when_read_matches_ref<W>(g, ws, n_paths);
-        longest = longest_of(ws, n_paths);
+        longest = longest_of<W>(ws, n_paths);
         n_paths = remove_short_paths<W>(ws, n_paths, longest);
         if (g.is_sv_graph)
           remove_support_from_read_ends<W>(g, ws, n_paths);
@@ -1581,7 +1640,7 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
   for (uint32_t i = 0; i < np; ++i)
   {
     DPath const & p = ws.paths[i];
-    uint32_t const nvar = p.nvar;
+    uint32_t const nvar = GTX_U(static_cast<uint32_t>(p.nvar));
     if (w + 4 + 3 * nvar > rec_words)
     {
       status |= GTX_ST_RECORD_OVERFLOW;

@@ -32,8 +32,30 @@ struct WaveHip
     f(threadIdx.x & 63u);
   }
   static __device__ inline bool leader() { return (threadIdx.x & 63u) == 0; }
-  // one wave per workgroup: the workgroup barrier orders the leader's LDS writes before everybody's reads
-  static __device__ inline void lds_sync() { __syncthreads(); }
+  // value known to be equal on all lanes -> scalar register
+  static __device__ inline uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+  static __device__ inline int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+  static __device__ inline bool uni(bool v) { return __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)) != 0; }
+  static __device__ inline uint64_t uni(uint64_t v)
+  {
+    uint32_t const lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+    uint32_t const hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+  }
+  // Orders the leader's LDS writes before the other lanes' reads.  All 64 lanes belong to one wavefront whose LDS
+  // instructions are issued and serviced in program order, so no hardware wait is needed: the wavefront-scope fences
+  // only stop the compiler from moving or merging LDS accesses across this point (GTX_HARD_SYNC=1 at build time
+  // falls back to a real workgroup barrier for A/B checks).
+  static __device__ inline void lds_sync()
+  {
+#ifdef GTX_HARD_SYNC
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+  }
   static __device__ inline uint64_t ballot(PerLane<bool> const & p) { return __ballot(p.v); }
   static __device__ inline uint32_t sum(PerLane<uint32_t> const & p)
   {
@@ -61,7 +83,10 @@ struct WaveHip
   static __device__ inline void atomic_add_u64(unsigned long long * p, unsigned long long v) { atomicAdd(p, v); }
 };
 
-constexpr uint32_t TASK_CHUNK = 4; // reads a wave claims per visit to the task counter
+#ifndef GTX_TASK_CHUNK
+#define GTX_TASK_CHUNK 4
+#endif
+constexpr uint32_t TASK_CHUNK = GTX_TASK_CHUNK; // reads a wave claims per visit to the task counter
 
 __global__ __launch_bounds__(64) void gtx_align_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
                                                        uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
@@ -70,6 +95,11 @@ __global__ __launch_bounds__(64) void gtx_align_kernel(GraphView g, IndexView ix
 {
   __shared__ AlignWorkspace ws;
   __shared__ uint32_t task_base;
+#ifdef GTX_PAD_LDS // occupancy experiment: waste LDS to lower the number of resident waves
+  __shared__ uint32_t lds_pad[GTX_PAD_LDS / 4];
+  if (n_reads == 0xFFFFFFFFu)
+    lds_pad[threadIdx.x] = 1;
+#endif
   // Reads are claimed dynamically (one atomic per TASK_CHUNK reads): the grid is sized to what is resident at once and
   // reads differ in cost (mismatches, ambiguous bases, the optional reverse orientation), a static split leaves CUs idle.
   for (;;)

@@ -134,23 +134,24 @@ extern "C"
     if (ix.slots.empty())
       return GTX_OK;
     uint64_t const mask = (1ull << ix.log2_cap) - 1;
-    uint64_t h = hash_key(key, ix.log2_cap);
-    while (ix.slots[h].cnt != 0)
-    {
-      if (ix.slots[h].key == key)
+    for (uint64_t b = hash_key(key, ix.log2_cap);; b = (b + 1) & mask)
+      for (uint32_t k = 0; k < BUCKET_SLOTS; ++k)
       {
-        *n = ix.slots[h].cnt;
-        if (out)
+        IndexSlot const & s = ix.slots[b * BUCKET_SLOTS + k];
+        if (s.cnt == 0)
+          return GTX_OK;
+        if (s.key == key)
         {
-          if (cap < *n)
-            return GTX_ERR_CAPACITY;
-          std::memcpy(out, ix.labels.data() + ix.slots[h].off, sizeof(gtx_label) * *n);
+          *n = s.cnt;
+          if (out)
+          {
+            if (cap < *n)
+              return GTX_ERR_CAPACITY;
+            std::memcpy(out, ix.labels.data() + s.off, sizeof(gtx_label) * *n);
+          }
+          return GTX_OK;
         }
-        return GTX_OK;
       }
-      h = (h + 1) & mask;
-    }
-    return GTX_OK;
   }
 
   int gtx_index_dump(const gtx_ctx * c, uint64_t * keys, uint32_t * counts, gtx_label * labels)

@@ -28,7 +28,11 @@ struct DevLabel
   uint32_t allele; // Graph::get_variant_num()
 };
 
-struct IndexSlot // open addressed, linear probing; cnt == 0 marks an empty slot
+// Hash tables are bucketed: BUCKET_SLOTS consecutive slots (64 bytes) share one hash value, so a lookup is normally one
+// 64-byte fetch; a full bucket spills into the next one.  cnt == 0 marks an empty slot.
+constexpr uint32_t BUCKET_SLOTS = 4;
+
+struct IndexSlot
 {
   uint64_t key;
   uint32_t off, cnt;
@@ -76,7 +80,7 @@ struct IndexView
 {
   const IndexSlot * slots;
   const DevLabel * labels;
-  uint32_t log2_cap;
+  uint32_t log2_cap; // log2 of the number of buckets
   uint32_t max_index_labels;
   // half-key (pigeonhole) tables for the Hamming-1 lists: a key within Hamming distance 1 of q shares q's left or
   // right 16 bases exactly, so the 96 neighbour probes of the reference become two bucket lookups

@@ -342,6 +342,18 @@ struct Walker
 
 } // namespace
 
+static void bucket_insert(std::vector<IndexSlot> & slots, uint32_t log2_buckets, IndexSlot const & s)
+{
+  uint64_t const mask = (1ull << log2_buckets) - 1;
+  for (uint64_t b = hash_key(s.key, log2_buckets);; b = (b + 1) & mask)
+    for (uint32_t k = 0; k < BUCKET_SLOTS; ++k)
+      if (slots[b * BUCKET_SLOTS + k].cnt == 0)
+      {
+        slots[b * BUCKET_SLOTS + k] = s;
+        return;
+      }
+}
+
 void build_index(HostGraph const & g, HostIndex & out)
 {
   out = HostIndex();
@@ -406,19 +418,13 @@ void build_index(HostGraph const & g, HostIndex & out)
   }
   out.key_off.push_back(static_cast<uint32_t>(out.labels.size()));
   // device form
-  uint32_t log2_cap = 4;
-  while ((1ull << log2_cap) < 2 * out.keys.size() + 1)
+  uint32_t log2_cap = 2;
+  while ((static_cast<uint64_t>(BUCKET_SLOTS) << log2_cap) < 2 * out.keys.size() + 1)
     ++log2_cap;
   out.log2_cap = log2_cap;
-  out.slots.assign(1ull << log2_cap, IndexSlot{0, 0, 0});
-  uint64_t const mask = (1ull << log2_cap) - 1;
+  out.slots.assign(static_cast<uint64_t>(BUCKET_SLOTS) << log2_cap, IndexSlot{0, 0, 0});
   for (std::size_t k = 0; k < out.keys.size(); ++k)
-  {
-    uint64_t h = hash_key(out.keys[k], log2_cap);
-    while (out.slots[h].cnt != 0)
-      h = (h + 1) & mask;
-    out.slots[h] = IndexSlot{out.keys[k], out.key_off[k], out.key_off[k + 1] - out.key_off[k]};
-  }
+    bucket_insert(out.slots, log2_cap, IndexSlot{out.keys[k], out.key_off[k], out.key_off[k + 1] - out.key_off[k]});
   // half-key buckets
   {
     size_t const n = out.keys.size();
@@ -433,12 +439,11 @@ void build_index(HostGraph const & g, HostIndex & out)
     });
     for (size_t k = 0; k < n; ++k)
       out.hlist[n + k] = out.hlist[by_right[k]];
-    uint32_t hl = 4;
-    while ((1ull << hl) < 4 * n + 1)
+    uint32_t hl = 2;
+    while ((static_cast<uint64_t>(BUCKET_SLOTS) << hl) < 4 * n + 1)
       ++hl;
     out.h_log2_cap = hl;
-    out.hslots.assign(1ull << hl, IndexSlot{0, 0, 0});
-    uint64_t const hmask = (1ull << hl) - 1;
+    out.hslots.assign(static_cast<uint64_t>(BUCKET_SLOTS) << hl, IndexSlot{0, 0, 0});
     for (int side = 0; side < 2; ++side)
     {
       size_t const base = side * n;
@@ -450,10 +455,7 @@ void build_index(HostGraph const & g, HostIndex & out)
         while (e < n && (side == 0 ? (out.hlist[base + e].key >> 32) : (out.hlist[base + e].key & 0xFFFFFFFFull)) == half)
           ++e;
         uint64_t const hk = half | (static_cast<uint64_t>(side) << 32);
-        uint64_t h = hash_key(hk, hl);
-        while (out.hslots[h].cnt != 0)
-          h = (h + 1) & hmask;
-        out.hslots[h] = IndexSlot{hk, static_cast<uint32_t>(base + k), static_cast<uint32_t>(e - k)};
+        bucket_insert(out.hslots, hl, IndexSlot{hk, static_cast<uint32_t>(base + k), static_cast<uint32_t>(e - k)});
         k = e;
       }
     }

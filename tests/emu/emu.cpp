@@ -33,6 +33,11 @@ struct WaveEmu
       f(l);
   }
   static bool leader() { return true; }
+  template <class T>
+  static T uni(T v)
+  {
+    return v;
+  }
   static void lds_sync() {}
   static uint64_t ballot(PerLane<bool> const & p)
   {
