@@ -782,6 +782,93 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
 {
   if (n == 0)
     return;
+  if (n == 1 && !prev)
+  {
+    // One label = one new path P with at most one variant site.  Specialisation of the general code below: P can only
+    // ever replace in place (a path merges with the single P at most once), and Path(p1, P) is p1 with its end, read
+    // end and mismatches advanced and P's site moved to the front of the site list (path.cpp:38-82 keeps p2's sites
+    // first), its allele set intersected when p1 already carries the site.
+    uint32_t const ls = GTX_U(ll[0].start), le = GTX_U(ll[0].end), lsite = GTX_U(ll[0].site), lall = GTX_U(ll[0].allele);
+    uint32_t const lmlo = lsite != INVALID ? static_cast<uint32_t>(1ull << lall) : 0u;
+    uint32_t const lmhi = lsite != INVALID ? static_cast<uint32_t>((1ull << lall) >> 32) : 0u;
+    bool matched = false;
+    uint32_t const original_size = n_paths;
+    for (uint32_t i = 0; i < original_size; ++i)
+    {
+      DPath & p = ws.paths[i];
+      uint32_t const w2 = GTX_U(reinterpret_cast<uint32_t const *>(&p)[2]); // rs | re << 16
+      if ((w2 >> 16) != rs || GTX_U(p.end) != ls)
+        continue;
+      uint32_t const nvar = GTX_U(static_cast<uint32_t>(p.nvar));
+      uint32_t j = nvar, mlo = lmlo, mhi = lmhi;
+      if (lsite != INVALID)
+      {
+        for (j = 0; j < nvar; ++j)
+          if (GTX_U(p.v[j].site) == lsite)
+            break;
+        if (j < nvar)
+        {
+          mlo &= GTX_U(p.v[j].mlo);
+          mhi &= GTX_U(p.v[j].mhi);
+          if ((mlo | mhi) == 0)
+            continue; // empty allele intersection: this path does not merge
+        }
+        else if (nvar >= AlignCfg::MAXV)
+        {
+          status |= GTX_ST_PATH_OVERFLOW;
+          return;
+        }
+      }
+      GTX_LEAD
+      {
+        if (lsite != INVALID)
+        {
+          for (uint32_t k = j; k > 0; --k) // sites before j (or all of them) move one place back
+            p.v[k] = p.v[k - 1];
+          p.v[0].site = lsite;
+          p.v[0].mlo = mlo;
+          p.v[0].mhi = mhi;
+          if (j == nvar)
+            p.nvar = static_cast<uint16_t>(nvar + 1);
+        }
+        p.end = le;
+        p.re = static_cast<uint16_t>(re);
+        p.mism = static_cast<uint16_t>(p.mism + mism);
+      }
+      W::lds_sync();
+      matched = true;
+      uint32_t const sz = re - (w2 & 0xFFFFu) + 1u;
+      if (sz > longest)
+        longest = sz;
+    }
+    if (!matched)
+    {
+      if (n_paths >= AlignCfg::MAXP)
+      {
+        status |= GTX_ST_PATH_OVERFLOW;
+        return;
+      }
+      GTX_LEAD
+      {
+        DPath & p = ws.paths[n_paths];
+        p.start = ls;
+        p.end = le;
+        p.rs = static_cast<uint16_t>(rs);
+        p.re = static_cast<uint16_t>(re);
+        p.mism = static_cast<uint16_t>(mism);
+        p.nvar = lsite != INVALID ? 1 : 0;
+        p.v[0].site = lsite;
+        p.v[0].mlo = lmlo;
+        p.v[0].mhi = lmhi;
+      }
+      W::lds_sync();
+      ++n_paths;
+      uint32_t const sz = re - rs + 1u;
+      if (sz > longest)
+        longest = sz;
+    }
+    return;
+  }
   DPath * pp = ws.u.w.pp;
   uint32_t const npp = make_pp<W>(pp, ll, n, rs, re, mism, status);
   if (status)
@@ -1033,28 +1120,20 @@ GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, ui
     uint32_t const prs = GTX_U(static_cast<uint32_t>(path.rs)), pre = GTX_U(static_cast<uint32_t>(path.re));
     SubRead sr;
     sr.rd = ws.rd;
-    uint32_t n_locs;
     if (starts)
     {
       if (prs == 0)
         continue;
       sr.begin = 0;
       sr.len = prs + 1u;
-      n_locs = get_locations<W>(g, path.start, path, wb.locs, AlignCfg::LOC_CAP, status);
     }
     else
     {
       if (pre == L - 1)
         continue;
-      n_locs = get_locations<W>(g, path.end, path, wb.locs, AlignCfg::LOC_CAP, status);
       sr.begin = pre;
       sr.len = L - pre;
     }
-    W::lds_sync();
-    if (status)
-      return;
-    if (n_locs == 0 || n_locs > MAX_NUM_LOCATIONS_PER_PATH)
-      continue;
     uint32_t mm;
     if (maximum_mismatches < 0)
     {
@@ -1063,9 +1142,53 @@ GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, ui
     }
     else
       mm = static_cast<uint32_t>(maximum_mismatches);
-    uint32_t const nl = iterative_dfs<W>(g, ws, n_locs, starts, sr, mm, status);
-    if (status)
-      return;
+    uint32_t const anchor = GTX_U(starts ? path.start : path.end);
+    uint32_t nl;
+    // Shortcut for the common geometry: the anchor is an ordinary position inside a reference node and the sub-read
+    // fits in what is left of that node.  get_locations would return that single 'R' location and the walk a single
+    // sequence without ever reaching a variant site (graph.cpp:1232-1243 / 1484-1496), so the result is one id-less
+    // label or nothing -- computed here without going through the location / candidate tables.
+    bool shortcut = false;
+    if (!g_is_special(g, anchor) && anchor >= g.first_order && g.n_ref > 1)
+    {
+      uint32_t const rr = g_ref_node_at<W>(g, anchor);
+      uint32_t const ro = GTX_U(g.ref_order[rr]), rl = GTX_U(g.ref_len[rr]);
+      if (anchor < ro + rl)
+      {
+        uint32_t const offset = anchor - ro;
+        uint32_t const avail = starts ? offset + 1 : rl - offset;
+        if (avail >= sr.len)
+        {
+          shortcut = true;
+          uint8_t const * dna = reinterpret_cast<uint8_t const *>(g.dna) + GTX_U(g.ref_dna[rr]);
+          uint32_t const budget = mm;
+          uint32_t const got = starts ? cmp_codes<W, true>(sr, 0, dna, offset + 1, 0, budget)
+                                      : cmp_codes<W, false>(sr, 0, dna + offset, avail, 0, budget);
+          if (got <= budget)
+          {
+            mm = got;
+            nl = 1;
+            GTX_LEAD wb.dfs_out[0] = starts ? DevLabel{anchor - (sr.len - 1), anchor, INVALID, 0}
+                                            : DevLabel{anchor, anchor + (sr.len - 1), INVALID, 0};
+            W::lds_sync();
+          }
+          else
+            nl = 0;
+        }
+      }
+    }
+    if (!shortcut)
+    {
+      uint32_t const n_locs = get_locations<W>(g, anchor, path, wb.locs, AlignCfg::LOC_CAP, status);
+      W::lds_sync();
+      if (status)
+        return;
+      if (n_locs == 0 || n_locs > MAX_NUM_LOCATIONS_PER_PATH)
+        continue;
+      nl = iterative_dfs<W>(g, ws, n_locs, starts, sr, mm, status);
+      if (status)
+        return;
+    }
     if (nl == 0)
       continue;
     if (mm < best)
@@ -1458,6 +1581,10 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
   GTX_LEAD ws.read_len = len;
   W::lds_sync();
   GTX_PROF_TICK(0)
+#if defined(GTX_STOP_AFTER) && GTX_STOP_AFTER == 0
+  GTX_LEAD { rec[0] = 0; rec[1] = len << 16; }
+  return;
+#endif
 
   uint32_t n_paths = 0, longest = 0, status = 0;
   uint32_t const n_k = len < K ? 0 : 1 + (len - K) / (K - 1); // kmer_help_functions.cpp:10-17
@@ -1543,6 +1670,10 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
     if (!(GTX_U(ws.nkeys0[i]) == 1 && GTX_U(ws.cnt0[i]) >= MAX_UNIQUE_KMER_POSITIONS))
       all_common = false;
   GTX_PROF_TICK(1)
+#if defined(GTX_STOP_AFTER) && GTX_STOP_AFTER == 1
+  GTX_LEAD { rec[0] = ws.cnt0[0] + ws.hcnt[0][0]; rec[1] = len << 16; }
+  return;
+#endif
 
   if (!all_common && n_k > 0)
   {
@@ -1598,7 +1729,9 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
       if (single)
       {
         uint64_t const q = GTX_U(ws.key0[i]);
-        if (i < kc && use_halves && GTX_U(ws.hcnt[i][0]) <= AlignCfg::HE_CAP && GTX_U(ws.hcnt[i][1]) <= AlignCfg::HE_CAP)
+        if (i < kc && use_halves && n_lbl > 0 && GTX_U(ws.hcnt[i][0]) == 1 && GTX_U(ws.hcnt[i][1]) == 1)
+          n_lbl = 0; // q is indexed, so it is the one key in each of its half-key buckets: no neighbour exists
+        else if (i < kc && use_halves && GTX_U(ws.hcnt[i][0]) <= AlignCfg::HE_CAP && GTX_U(ws.hcnt[i][1]) <= AlignCfg::HE_CAP)
           n_lbl = hamming1_from_cache<W>(ix, ws, i, q);
         else if (!use_halves || !hamming1_by_halves<W>(ix, ws, q, n_lbl))
           n_lbl = probe_list<W>(ix, ws, true, q, 96, status);
@@ -1609,6 +1742,10 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
       add_kmer_labels<W>(ws, ws.lbl, n_lbl, rs, re, 1, false, n_paths, longest, status);
       GTX_PROF_TICK(5)
     }
+#if defined(GTX_STOP_AFTER) && GTX_STOP_AFTER == 2
+    GTX_LEAD { rec[0] = n_paths; rec[1] = len << 16; }
+    return;
+#endif
     if (!status)
     {
       n_paths = remove_short_paths<W>(ws, n_paths, longest);
@@ -1617,6 +1754,10 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
       if (!status)
         walk_read<W>(g, ws, false, n_paths, longest, status);
       GTX_PROF_TICK(7)
+#if defined(GTX_STOP_AFTER) && GTX_STOP_AFTER == 4
+      GTX_LEAD { rec[0] = n_paths; rec[1] = len << 16; }
+      return;
+#endif
       if (!status)
       {
         longest = longest_of<W>(ws, n_paths);

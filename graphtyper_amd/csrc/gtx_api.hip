@@ -84,7 +84,7 @@ struct WaveHip
 };
 
 #ifndef GTX_TASK_CHUNK
-#define GTX_TASK_CHUNK 4
+#define GTX_TASK_CHUNK 16
 #endif
 constexpr uint32_t TASK_CHUNK = GTX_TASK_CHUNK; // reads a wave claims per visit to the task counter
 
