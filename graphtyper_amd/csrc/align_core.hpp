@@ -51,6 +51,11 @@ struct AlignCfg
   static constexpr uint32_t XL_CAP = 4;      // exact labels fetched up front per k-mer
 };
 
+struct alignas(16) uint4_t // 16-byte move
+{
+  uint32_t x, y, z, w;
+};
+
 struct PVar
 {
   uint32_t site;
@@ -1238,36 +1243,39 @@ GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, ui
 
 // to_uint64_vec for a k-mer with ambiguous bases; sequential by nature (list order is the contract), leader only.
 // Returns the number of keys (0 = gave up, > 97 partial keys)
+// (keys are produced in plane form: appending base value b at base index t sets bit t of the low / high word)
 GTX_DEV uint32_t expand_keys(uint8_t const * rd, uint32_t at, uint64_t * keys)
 {
   uint32_t n = 1;
   keys[0] = 0;
-  for (uint32_t i = at; i < at + K; ++i)
+  for (uint32_t t = 0; t < K; ++t)
   {
     uint32_t const origin = n;
     if (origin > 97)
       return 0;
-    uint32_t const code = rd[i] & 15u;
+    uint32_t const code = rd[at + t] & 15u;
+    auto with = [t](uint64_t k, uint64_t b) { return k | ((b & 1u) << t) | ((b >> 1) << (32 + t)); };
     for (uint32_t u = 0; u < origin; ++u)
     {
       if (code == 15u || code == 0u)
       {
-        keys[n++] = keys[u] * 4 + 0;
-        keys[n++] = keys[u] * 4 + 1;
-        keys[n++] = keys[u] * 4 + 2;
-        keys[u] = (keys[u] << 2) + 3;
+        keys[n++] = with(keys[u], 0);
+        keys[n++] = with(keys[u], 1);
+        keys[n++] = with(keys[u], 2);
+        keys[u] = with(keys[u], 3);
       }
       else
       {
         int left = __builtin_popcount(code);
+        uint64_t const base = keys[u];
         for (uint32_t b = 0; b < 4; ++b)
         {
           if (!(code & (1u << b)))
             continue;
           if (left == 1)
-            keys[u] = keys[u] * 4 + b;
+            keys[u] = with(base, b);
           else
-            keys[n++] = keys[u] * 4 + b;
+            keys[n++] = with(base, b);
           --left;
         }
       }
@@ -1284,36 +1292,13 @@ GTX_DEV void bucket_find(IndexSlot const * slots, uint32_t log2_buckets, uint64_
   {
     IndexSlot const * p = slots + b * BUCKET_SLOTS;
     IndexSlot const s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
-    if (s0.cnt != 0 && s0.key == key)
-    {
-      off = s0.off;
-      cnt = s0.cnt;
+    bool const m0 = s0.cnt != 0 && s0.key == key, m1 = s1.cnt != 0 && s1.key == key;
+    bool const m2 = s2.cnt != 0 && s2.key == key, m3 = s3.cnt != 0 && s3.key == key;
+    off = m0 ? s0.off : m1 ? s1.off : m2 ? s2.off : m3 ? s3.off : 0u;
+    cnt = m0 ? s0.cnt : m1 ? s1.cnt : m2 ? s2.cnt : m3 ? s3.cnt : 0u;
+    // slots fill front to back: an empty last slot means nothing ever spilled out of this bucket
+    if (m0 || m1 || m2 || m3 || s3.cnt == 0)
       return;
-    }
-    if (s1.cnt != 0 && s1.key == key)
-    {
-      off = s1.off;
-      cnt = s1.cnt;
-      return;
-    }
-    if (s2.cnt != 0 && s2.key == key)
-    {
-      off = s2.off;
-      cnt = s2.cnt;
-      return;
-    }
-    if (s3.cnt != 0 && s3.key == key)
-    {
-      off = s3.off;
-      cnt = s3.cnt;
-      return;
-    }
-    if (s3.cnt == 0) // slots fill front to back: an empty last slot means the key did not spill further
-    {
-      off = 0;
-      cnt = 0;
-      return;
-    }
   }
 }
 
@@ -1321,26 +1306,6 @@ GTX_DEV void bucket_find(IndexSlot const * slots, uint32_t log2_buckets, uint64_
 GTX_DEV void index_find(IndexView const & ix, uint64_t key, uint32_t & off, uint32_t & cnt)
 {
   bucket_find(ix.slots, ix.log2_cap, key, off, cnt);
-}
-
-GTX_DEV uint64_t spread_bits(uint32_t x) // bit i -> bit 2i
-{
-  uint64_t v = x;
-  v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
-  v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
-  v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
-  v = (v | (v << 2)) & 0x3333333333333333ull;
-  v = (v | (v << 1)) & 0x5555555555555555ull;
-  return v;
-}
-
-GTX_DEV uint32_t reverse_bits32(uint32_t x)
-{
-  x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
-  x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
-  x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
-  x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
-  return (x >> 16) | (x << 16);
 }
 
 // Wave-parallel probe of a key list (`nkeys` keys: either keybuf[0..nkeys) or the 96 Hamming-1 neighbours of `base`
@@ -1361,7 +1326,9 @@ GTX_DEV uint32_t probe_list(IndexView const & ix, AlignWorkspace & ws, bool hamm
       uint32_t o = 0, c = 0;
       if (j < nkeys)
       {
-        uint64_t const key = hamming ? base ^ (static_cast<uint64_t>(j % 3 + 1) << (2 * (j / 3))) // type_conversions.cpp:272-288
+        // neighbour j of the reference's list (type_conversions.cpp:272-288): base 31 - j/3 changed by xor j%3 + 1
+        uint32_t const hb = 31u - j / 3u, hm = j % 3u + 1u;
+        uint64_t const key = hamming ? base ^ ((static_cast<uint64_t>(hm & 1u) << hb) | (static_cast<uint64_t>(hm >> 1) << (32u + hb)))
                                      : kres[j];
         index_find(ix, key, o, c);
         kres[j] = static_cast<uint64_t>(o) | (static_cast<uint64_t>(c) << 32);
@@ -1414,17 +1381,29 @@ GTX_DEV void half_find(IndexView const & ix, uint64_t hk, uint32_t & off, uint32
   bucket_find(ix.hslots, ix.h_log2_cap, hk, off, cnt);
 }
 
+// table key of the bucket holding every indexed k-mer with the same 16 first (side 0) / last (side 1) bases as q
+GTX_DEV uint64_t half_key(uint64_t q, uint32_t side)
+{
+  uint32_t const lo = static_cast<uint32_t>(q), hi = static_cast<uint32_t>(q >> 32);
+  uint64_t const half = side == 0 ? ((lo & 0xFFFFu) | ((hi & 0xFFFFu) << 16)) : ((lo >> 16) | (hi & 0xFFFF0000u));
+  return half | (static_cast<uint64_t>(side) << 32);
+}
+
 constexpr uint32_t HALF_BUCKET_CAP = 64; // one lane per bucket entry; larger buckets (low-complexity sequence) use the 96 direct probes
 
 // Candidate test shared by both routes below: is `key` at Hamming distance exactly 1 from q, and which neighbour is it?
+// (plane-form keys; the reference numbers neighbours by bb = position counted from the LAST base and m = xor of the
+// 2-bit code, j = 3*bb + m-1, type_conversions.cpp:272-288)
 GTX_DEV bool hamming1_neighbour(uint64_t key, uint64_t q, uint32_t & j)
 {
   uint64_t const x = key ^ q;
-  uint64_t const groups = (x | (x >> 1)) & 0x5555555555555555ull; // one bit per differing base
-  if (groups == 0 || (groups & (groups - 1)) != 0)
+  uint32_t const d0 = static_cast<uint32_t>(x), d1 = static_cast<uint32_t>(x >> 32);
+  uint32_t const bases = d0 | d1; // one bit per differing base
+  if (bases == 0 || (bases & (bases - 1)) != 0)
     return false;
-  uint32_t const bit = static_cast<uint32_t>(__builtin_ctzll(groups)); // = 2*bb
-  j = 3u * (bit >> 1) + static_cast<uint32_t>((x >> bit) & 3u) - 1u;   // type_conversions.cpp:272-288
+  uint32_t const b = static_cast<uint32_t>(__builtin_ctz(bases));
+  uint32_t const m = ((d0 >> b) & 1u) | (((d1 >> b) & 1u) << 1);
+  j = 3u * (31u - b) + m - 1u;
   return true;
 }
 
@@ -1485,8 +1464,8 @@ template <class W>
 GTX_DEV bool hamming1_by_halves(IndexView const & ix, AlignWorkspace & ws, uint64_t q, uint32_t & n_lbl)
 {
   uint32_t o[2], c[2];
-  half_find(ix, q >> 32, o[0], c[0]);
-  half_find(ix, (q & 0xFFFFFFFFull) | (1ull << 32), o[1], c[1]);
+  half_find(ix, half_key(q, 0), o[0], c[0]);
+  half_find(ix, half_key(q, 1), o[1], c[1]);
   if (c[0] > ix.half_bucket_cap || c[1] > ix.half_bucket_cap)
     return false;
   uint64_t * cand = ws.u.keybuf;
@@ -1603,7 +1582,7 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
     });
     uint64_t const amb = W::ballot(amb_l);
     uint32_t const b0 = static_cast<uint32_t>(W::ballot(b0_l)), b1 = static_cast<uint32_t>(W::ballot(b1_l));
-    uint64_t const key = spread_bits(reverse_bits32(b0)) | (spread_bits(reverse_bits32(b1)) << 1);
+    uint64_t const key = (static_cast<uint64_t>(b1) << 32) | b0; // plane form (gtx_flat.hpp: plane_key)
     GTX_LEAD
     {
       ws.key0[i] = key;
@@ -1622,43 +1601,33 @@ GTX_DEV void align_one(GraphView const & g, IndexView const & ix, AlignWorkspace
     {
       uint64_t const q = ws.key0[i];
       uint32_t off, cnt;
-      if (w == 0)
-      {
-        index_find(ix, q, off, cnt);
-        ws.off0[i] = off;
-        ws.cnt0[i] = cnt;
-      }
-      else
-      {
-        half_find(ix, w == 1 ? (q >> 32) : ((q & 0xFFFFFFFFull) | (1ull << 32)), off, cnt);
-        ws.hoff[i][w - 1] = off;
-        ws.hcnt[i][w - 1] = cnt;
-      }
+      bucket_find(w == 0 ? ix.slots : ix.hslots, w == 0 ? ix.log2_cap : ix.h_log2_cap, w == 0 ? q : half_key(q, w - 1), off, cnt);
+      uint32_t * o = w == 0 ? &ws.off0[i] : &ws.hoff[i][w - 1];
+      uint32_t * c = w == 0 ? &ws.cnt0[i] : &ws.hcnt[i][w - 1];
+      *o = off;
+      *c = cnt;
     }
   });
   W::lds_sync();
   // -- ... and everything those lookups point at that is small enough to be staged: bucket entries and exact labels
   W::lanes([&](uint32_t l) {
+    // both kinds of staged entry are 16 bytes: one predicated 16-byte copy per lane
     constexpr uint32_t NH = 2 * AlignCfg::HE_CAP;
-    if (l < AlignCfg::KC * NH)
+    bool const is_half = l < AlignCfg::KC * NH;
+    uint32_t const m = is_half ? l : l - AlignCfg::KC * NH;
+    uint32_t const per = is_half ? NH : AlignCfg::XL_CAP;
+    uint32_t const i = m / per, e = is_half ? m % AlignCfg::HE_CAP : m % AlignCfg::XL_CAP;
+    uint32_t const side = (m / AlignCfg::HE_CAP) % 2;
+    if (l < AlignCfg::KC * (NH + AlignCfg::XL_CAP) && i < kc && ws.nkeys0[i] == 1 && (!is_half || use_halves))
     {
-      uint32_t const i = l / NH, side = (l / AlignCfg::HE_CAP) % 2, e = l % AlignCfg::HE_CAP;
-      if (i < kc && use_halves && ws.nkeys0[i] == 1)
+      uint32_t const cnt = is_half ? ws.hcnt[i][side] : ws.cnt0[i];
+      uint32_t const off = is_half ? ws.hoff[i][side] : ws.off0[i];
+      if (cnt <= (is_half ? AlignCfg::HE_CAP : AlignCfg::XL_CAP) && e < cnt)
       {
-        uint32_t const cnt = ws.hcnt[i][side];
-        if (cnt <= AlignCfg::HE_CAP && e < cnt)
-          ws.he[i][side][e] = ix.hlist[ws.hoff[i][side] + e];
-      }
-    }
-    else if (l < AlignCfg::KC * NH + AlignCfg::KC * AlignCfg::XL_CAP)
-    {
-      uint32_t const m = l - AlignCfg::KC * NH;
-      uint32_t const i = m / AlignCfg::XL_CAP, e = m % AlignCfg::XL_CAP;
-      if (i < kc && ws.nkeys0[i] == 1)
-      {
-        uint32_t const cnt = ws.cnt0[i];
-        if (cnt <= AlignCfg::XL_CAP && e < cnt)
-          ws.xl[i][e] = ix.labels[ws.off0[i] + e];
+        static_assert(sizeof(HalfEntry) == 16 && sizeof(DevLabel) == 16, "staged entries are copied as 16-byte words");
+        uint4_t const * src = is_half ? reinterpret_cast<uint4_t const *>(ix.hlist + off + e) : reinterpret_cast<uint4_t const *>(ix.labels + off + e);
+        uint4_t * dst = is_half ? reinterpret_cast<uint4_t *>(&ws.he[i][side][e]) : reinterpret_cast<uint4_t *>(&ws.xl[i][e]);
+        *dst = *src;
       }
     }
   });

@@ -134,6 +134,7 @@ extern "C"
     if (ix.slots.empty())
       return GTX_OK;
     uint64_t const mask = (1ull << ix.log2_cap) - 1;
+    key = plane_key(key); // the table is keyed in plane form
     for (uint64_t b = hash_key(key, ix.log2_cap);; b = (b + 1) & mask)
       for (uint32_t k = 0; k < BUCKET_SLOTS; ++k)
       {

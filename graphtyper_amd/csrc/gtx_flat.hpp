@@ -21,7 +21,7 @@ constexpr uint32_t MAX_ALLELES = 64;     // allele sets are one 64-bit mask per 
 
 // A k-mer occurrence as stored on the device: KmerLabel (kmer_label.hpp:13-41) with variant_id already resolved to
 // (site, allele) -- what Path's constructor derives through Graph::get_variant_order/get_variant_num (path.cpp:13-36).
-struct DevLabel
+struct alignas(16) DevLabel
 {
   uint32_t start, end;
   uint32_t site;   // ref node index the variant hangs from, INVALID when the label carries no variant
@@ -32,7 +32,7 @@ struct DevLabel
 // 64-byte fetch; a full bucket spills into the next one.  cnt == 0 marks an empty slot.
 constexpr uint32_t BUCKET_SLOTS = 4;
 
-struct IndexSlot
+struct alignas(16) IndexSlot
 {
   uint64_t key;
   uint32_t off, cnt;
@@ -70,7 +70,7 @@ struct GraphView
 };
 
 // One indexed key inside a half-key bucket (see HostIndex::hlist)
-struct HalfEntry
+struct alignas(16) HalfEntry
 {
   uint64_t key;
   uint32_t off, cnt; // its labels
@@ -118,8 +118,8 @@ struct HostIndex
   std::vector<IndexSlot> slots;
   std::vector<DevLabel> dev_labels;
   uint32_t log2_cap = 0;
-  // half-key tables: hlist = all keys ascending (buckets of equal left half are contiguous) followed by all keys
-  // ordered by right half; hslots maps (side, half) -> bucket
+  // device tables (plane-form keys).  Half-key tables: hlist = all keys grouped by the 16 first bases followed by all
+  // keys grouped by the 16 last bases; hslots maps (side, half) -> bucket
   std::vector<IndexSlot> hslots;
   std::vector<HalfEntry> hlist;
   uint32_t h_log2_cap = 0;
@@ -128,6 +128,22 @@ struct HostIndex
 // returns "" on success, else a description of what is wrong with the view
 std::string flatten_graph(gtx_graph_view const & g, gtx_params const & par, HostGraph & out);
 void build_index(HostGraph const & g, HostIndex & out);
+
+// Device tables are keyed by the k-mer in PLANE form: bit j of the low word = low bit of base j's 2-bit code, bit j of
+// the high word = its high bit (base 0 = first base).  A wavefront gets both words straight from two ballots over the
+// 32 bases, so no bit interleaving is needed on the device; the reference's key layout (type_conversions.cpp:75-87:
+// first base in the top two bits) is kept for everything the host reports.
+inline uint64_t plane_key(uint64_t key)
+{
+  uint64_t lo = 0, hi = 0;
+  for (unsigned j = 0; j < 32; ++j)
+  {
+    uint64_t const two = (key >> (2 * (31 - j))) & 3u;
+    lo |= (two & 1u) << j;
+    hi |= (two >> 1) << j;
+  }
+  return (hi << 32) | lo;
+}
 
 #if defined(__HIPCC__)
 __host__ __device__

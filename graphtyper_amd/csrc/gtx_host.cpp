@@ -424,21 +424,19 @@ void build_index(HostGraph const & g, HostIndex & out)
   out.log2_cap = log2_cap;
   out.slots.assign(static_cast<uint64_t>(BUCKET_SLOTS) << log2_cap, IndexSlot{0, 0, 0});
   for (std::size_t k = 0; k < out.keys.size(); ++k)
-    bucket_insert(out.slots, log2_cap, IndexSlot{out.keys[k], out.key_off[k], out.key_off[k + 1] - out.key_off[k]});
-  // half-key buckets
+    bucket_insert(out.slots, log2_cap, IndexSlot{plane_key(out.keys[k]), out.key_off[k], out.key_off[k + 1] - out.key_off[k]});
+  // half-key buckets (plane-form keys: the 16 first bases are bits 0..15 of both words, the 16 last bases bits 16..31)
   {
     size_t const n = out.keys.size();
+    auto half_of = [](uint64_t pk, int side) -> uint64_t
+    {
+      uint32_t const lo = static_cast<uint32_t>(pk), hi = static_cast<uint32_t>(pk >> 32);
+      return side == 0 ? ((lo & 0xFFFFu) | ((hi & 0xFFFFu) << 16)) : ((lo >> 16) | (hi & 0xFFFF0000u));
+    };
+    std::vector<HalfEntry> all(n);
+    for (size_t k = 0; k < n; ++k)
+      all[k] = HalfEntry{plane_key(out.keys[k]), out.key_off[k], out.key_off[k + 1] - out.key_off[k]};
     out.hlist.resize(2 * n);
-    for (size_t k = 0; k < n; ++k)
-      out.hlist[k] = HalfEntry{out.keys[k], out.key_off[k], out.key_off[k + 1] - out.key_off[k]};
-    std::vector<uint32_t> by_right(n);
-    std::iota(by_right.begin(), by_right.end(), 0u);
-    std::sort(by_right.begin(), by_right.end(), [&](uint32_t a, uint32_t b) {
-      uint32_t const ra = static_cast<uint32_t>(out.keys[a]), rb = static_cast<uint32_t>(out.keys[b]);
-      return ra != rb ? ra < rb : out.keys[a] < out.keys[b];
-    });
-    for (size_t k = 0; k < n; ++k)
-      out.hlist[n + k] = out.hlist[by_right[k]];
     uint32_t hl = 2;
     while ((static_cast<uint64_t>(BUCKET_SLOTS) << hl) < 4 * n + 1)
       ++hl;
@@ -446,16 +444,24 @@ void build_index(HostGraph const & g, HostIndex & out)
     out.hslots.assign(static_cast<uint64_t>(BUCKET_SLOTS) << hl, IndexSlot{0, 0, 0});
     for (int side = 0; side < 2; ++side)
     {
+      std::vector<uint32_t> order(n);
+      std::iota(order.begin(), order.end(), 0u);
+      std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        uint64_t const ha = half_of(all[a].key, side), hb = half_of(all[b].key, side);
+        return ha != hb ? ha < hb : all[a].key < all[b].key;
+      });
       size_t const base = side * n;
+      for (size_t k = 0; k < n; ++k)
+        out.hlist[base + k] = all[order[k]];
       size_t k = 0;
       while (k < n)
       {
-        uint64_t const half = side == 0 ? (out.hlist[base + k].key >> 32) : (out.hlist[base + k].key & 0xFFFFFFFFull);
+        uint64_t const half = half_of(out.hlist[base + k].key, side);
         size_t e = k + 1;
-        while (e < n && (side == 0 ? (out.hlist[base + e].key >> 32) : (out.hlist[base + e].key & 0xFFFFFFFFull)) == half)
+        while (e < n && half_of(out.hlist[base + e].key, side) == half)
           ++e;
-        uint64_t const hk = half | (static_cast<uint64_t>(side) << 32);
-        bucket_insert(out.hslots, hl, IndexSlot{hk, static_cast<uint32_t>(base + k), static_cast<uint32_t>(e - k)});
+        bucket_insert(out.hslots, hl, IndexSlot{half | (static_cast<uint64_t>(side) << 32), static_cast<uint32_t>(base + k),
+                                                static_cast<uint32_t>(e - k)});
         k = e;
       }
     }
