@@ -30,7 +30,7 @@ REGION_LEN = 1000000
 READ_LEN = 150
 
 
-def make_reads_on_device(torch, ref_bases, records, n, seed, device, REGION_LEN=REGION_LEN):
+def make_reads_on_device(torch, ref_bases, records, n, seed, device, REGION_LEN=REGION_LEN, err_rate=0.005, n_rate=0.001):
     """diploid sample: haplotype 0 = reference, haplotype 1 = reference with a random half of the SNPs; 0.5 % substitution
     errors, 0.1 % N; position sorted; returns packed nibbles [n, 80] (uint8) and read start positions"""
     g = torch.Generator(device=device)
@@ -54,11 +54,11 @@ def make_reads_on_device(torch, ref_bases, records, n, seed, device, REGION_LEN=
         st = starts_all[a:b]
         which = torch.randint(0, 2, (b - a,), generator=g, device=device)
         bases = haps[which[:, None], st[:, None] + ar[None, :]]
-        err = torch.rand((b - a, READ_LEN), generator=g, device=device) < 0.005
+        err = torch.rand((b - a, READ_LEN), generator=g, device=device) < err_rate
         shift = torch.randint(1, 4, (b - a, READ_LEN), generator=g, device=device, dtype=torch.uint8)
         bases = torch.where(err, (bases + shift) % 4, bases)
         codes = code_of[bases.long()]
-        nmask = torch.rand((b - a, READ_LEN), generator=g, device=device) < 0.001
+        nmask = torch.rand((b - a, READ_LEN), generator=g, device=device) < n_rate
         codes = torch.where(nmask, torch.full_like(codes, 15), codes)
         out_seq[a:b, :75] = (codes[:, 0::2] << 4) | codes[:, 1::2]
         out_seq[a:b, 75:] = 0
@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--snp-every", type=int, default=1000)
+    ap.add_argument("--err", type=float, default=0.005, help="experiments only; the reported workload uses 0.005")
+    ap.add_argument("--nrate", type=float, default=0.001, help="experiments only; the reported workload uses 0.001")
     ap.add_argument("--region-len", type=int, default=REGION_LEN, help="experiments only; the reported workload is 1 Mb")
     ap.add_argument("--cpu-sample", type=int, default=300_000, help="reads timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -115,7 +117,7 @@ def main():
 
     # ---- reads, resident in HBM before the timed region ----
     n = args.reads
-    d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=1234 + rank, device=device, REGION_LEN=args.region_len)
+    d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=1234 + rank, device=device, REGION_LEN=args.region_len, err_rate=args.err, n_rate=args.nrate)
     meta = np.zeros(1, gtx.READ_META)
     meta["l_qseq"] = READ_LEN
     d_meta = torch.from_numpy(np.repeat(meta, n).view(np.uint8).reshape(n, 16).copy()).to(device)
