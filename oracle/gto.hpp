@@ -240,6 +240,245 @@ struct VarRecord // include/graphtyper/graph/var_record.hpp
   std::string ref;
   std::unordered_set<long> ref_events, ref_anti_events;
   std::vector<AltAllele> alts;
+  bool is_sv = false;
+
+  void clear() // var_record.cpp:154-167
+  {
+    pos = 0;
+    ref.clear();
+    alts.clear();
+    ref_events.clear();
+    ref_anti_events.clear();
+    is_sv = false;
+  }
+
+  bool is_snp_or_snps() const // var_record.cpp:416-419
+  {
+    for (auto const & a : alts)
+      if (a.seq.size() != ref.size())
+        return false;
+    return true;
+  }
+
+  bool is_any_seq_larger_than(long val) const // var_record.cpp:408-414
+  {
+    if (static_cast<long>(ref.size()) > val)
+      return true;
+    for (auto const & a : alts)
+      if (static_cast<long>(a.seq.size()) > val)
+        return true;
+    return false;
+  }
+
+  void add_suffix(std::string const & suffix) // var_record.cpp:373-379
+  {
+    for (auto & a : alts)
+      a.seq += suffix;
+    ref += suffix;
+  }
+
+  // helpers of var_record.cpp:24-109
+  void absorb_ref_events(VarRecord const & o)
+  {
+    ref_events.insert(o.ref_events.begin(), o.ref_events.end());
+    ref_anti_events.insert(o.ref_anti_events.begin(), o.ref_anti_events.end());
+  }
+  static void absorb_ref_events(AltAllele & a, VarRecord const & o)
+  {
+    a.events.insert(o.ref_events.begin(), o.ref_events.end());
+    a.anti_events.insert(o.ref_anti_events.begin(), o.ref_anti_events.end());
+  }
+  void insert_prior_sequence(VarRecord const & previous) // :31-47
+  {
+    std::string const prefix = previous.ref.substr(0, pos - previous.pos);
+    ref = prefix + ref;
+    for (auto & a : alts)
+      a.seq = prefix + a.seq;
+    pos = previous.pos;
+  }
+  static void extend_record(VarRecord & current, VarRecord const & previous) // :49-64
+  {
+    std::string const tail = previous.ref.substr(current.ref.size());
+    for (auto & a : current.alts)
+      a.seq += tail;
+    current.ref += tail;
+  }
+  static void extend_smaller_record(VarRecord & current, VarRecord & previous) // :66-79
+  {
+    if (current.ref.size() < previous.ref.size())
+      extend_record(current, previous);
+    else if (current.ref.size() > previous.ref.size())
+      extend_record(previous, current);
+  }
+  void move_alts(std::vector<AltAllele> && from) // :81-107 (only alts already there before the call count as duplicates)
+  {
+    std::size_t const original = alts.size();
+    for (auto & pa : from)
+    {
+      bool unique = true;
+      for (std::size_t a = 0; a < original; ++a)
+        if (alts[a].seq == pa.seq)
+        {
+          unique = false;
+          break;
+        }
+      if (unique)
+        alts.push_back(std::move(pa));
+    }
+  }
+  static AltAllele make_alt(AltAllele const & prev, AltAllele const & curr, long jump) // alt.cpp:60-96
+  {
+    AltAllele n(prev);
+    n.seq += curr.seq.substr(jump);
+    n.events.insert(curr.events.begin(), curr.events.end());
+    n.anti_events.insert(curr.anti_events.begin(), curr.anti_events.end());
+    return n;
+  }
+  static bool is_ok_to_merge_alts(AltAllele const & prev, AltAllele const & curr) // alt.cpp:98-141
+  {
+    for (long e : curr.events)
+      if (e >= 0 && prev.anti_events.count(e))
+        return false;
+    return true;
+  }
+
+  // GenomicRegion::add_reference_to_record_if_they_have_a_matching_prefix (src/graph/genomic_region.cpp:17-67, 236-256),
+  // applied to every VCF record by the constructor (src/graph/constructor.cpp:1740-1744) before the graph is built:
+  // while the reference allele is a prefix of (or has as prefix) an alt, or two alts are prefix related, one more
+  // reference base is appended to all alleles
+  void extend_while_prefix_related(std::string const & reference, long region_begin)
+  {
+    if (is_sv)
+      return;
+    auto prefix_match = [](std::string const & a, std::string const & b)
+    {
+      std::size_t const n = std::min(a.size(), b.size());
+      return a.compare(0, n, b, 0, n) == 0;
+    };
+    auto related = [&]()
+    {
+      for (auto const & a : alts)
+        if (prefix_match(ref, a.seq))
+          return true;
+      for (std::size_t i = 0; i + 1 < alts.size(); ++i)
+        for (std::size_t j = i + 1; j < alts.size(); ++j)
+          if (prefix_match(alts[i].seq, alts[j].seq))
+          {
+            if (alts[i].seq == alts[j].seq)
+              throw std::runtime_error("duplicated alt alleles");
+            return true;
+          }
+      return false;
+    };
+    std::size_t at = static_cast<std::size_t>(static_cast<long>(pos) - region_begin) + ref.size();
+    while (at < reference.size() && reference[at] != 'N' && related())
+    {
+      ref.push_back(reference[at]);
+      for (auto & a : alts)
+        a.seq.push_back(reference[at]);
+      ++at;
+    }
+  }
+
+  void merge_one_path(VarRecord && prev) // var_record.cpp:179-200
+  {
+    if (prev.pos < pos)
+      insert_prior_sequence(prev);
+    extend_smaller_record(*this, prev);
+    absorb_ref_events(prev);
+    for (auto & a : alts)
+      absorb_ref_events(a, prev);
+    move_alts(std::move(prev.alts));
+  }
+
+  void merge(VarRecord && prev, long EXTRA_SUFFIX) // var_record.cpp:270-371
+  {
+    long const jump_size = static_cast<long>(pos) - static_cast<long>(prev.pos);
+    long const oref_size = static_cast<long>(ref.size());
+    if (jump_size > 0)
+      insert_prior_sequence(prev);
+    long const oref_size_pre = static_cast<long>(ref.size());
+    extend_smaller_record(*this, prev);
+    long const extension_size = static_cast<long>(ref.size()) - oref_size_pre;
+    std::vector<AltAllele> fresh;
+    for (auto const & prev_alt : prev.alts)
+    {
+      if (static_cast<long>(prev_alt.seq.size()) <= oref_size)
+        continue;
+      long const offset = static_cast<long>(ref.size()) - static_cast<long>(prev_alt.seq.size());
+      if (jump_size - offset < 0)
+        continue;
+      long suffix_matches = 0;
+      long const smaller = static_cast<long>(std::min(ref.size(), prev_alt.seq.size()));
+      for (long k = 0; k < smaller; ++k)
+      {
+        if (ref[ref.size() - 1 - k] != prev_alt.seq[prev_alt.seq.size() - 1 - k])
+          break;
+        ++suffix_matches;
+      }
+      if (suffix_matches >= extension_size + EXTRA_SUFFIX)
+      {
+        AltAllele prefix_alt(prev_alt);
+        prefix_alt.seq = prev_alt.seq.substr(0, jump_size - offset);
+        for (auto const & curr_alt : alts)
+          if (is_ok_to_merge_alts(prefix_alt, curr_alt))
+            fresh.push_back(make_alt(prefix_alt, curr_alt, jump_size));
+      }
+    }
+    absorb_ref_events(prev);
+    for (auto & a : alts)
+      absorb_ref_events(a, prev);
+    prev.alts.erase(std::remove_if(prev.alts.begin(), prev.alts.end(),
+                                   [this](AltAllele const & pa)
+                                   {
+                                     for (long ae : pa.anti_events)
+                                       if (ref_events.count(ae))
+                                         return true;
+                                     return false;
+                                   }),
+                    prev.alts.end());
+    move_alts(std::move(prev.alts));
+    move_alts(std::move(fresh));
+  }
+
+  void merge_all(VarRecord && prev) // var_record.cpp:202-268
+  {
+    if (prev.pos + prev.ref.size() != pos)
+    {
+      merge(std::move(prev), 0);
+      return;
+    }
+    std::vector<AltAllele> fresh;
+    for (auto const & prev_alt : prev.alts)
+    {
+      for (auto const & curr_alt : alts)
+        if (is_ok_to_merge_alts(prev_alt, curr_alt))
+          fresh.push_back(make_alt(prev_alt, curr_alt, 0));
+      AltAllele n(prev_alt);
+      n.seq += ref;
+      n.events.insert(ref_events.begin(), ref_events.end());
+      n.anti_events.insert(ref_anti_events.begin(), ref_anti_events.end());
+      fresh.push_back(std::move(n));
+    }
+    for (auto & a : alts)
+    {
+      a.seq = prev.ref + a.seq;
+      absorb_ref_events(a, prev);
+    }
+    pos = prev.pos;
+    ref = prev.ref + ref;
+    absorb_ref_events(prev);
+    move_alts(std::move(fresh));
+    alts.erase(std::remove_if(alts.begin(), alts.end(),
+                              [](AltAllele const & a)
+                              {
+                                for (long ae : a.anti_events)
+                                  if (a.events.count(ae))
+                                    return true;
+                                return false;
+                              }),
+               alts.end());
+  }
 
   // var_record.cpp:381-406
   std::size_t common_suffix_size() const
@@ -277,15 +516,14 @@ struct Graph
 {
   bool is_sv_graph = false;
   bool is_segment_calling = false;
+  bool add_all_variants = false; // Options::add_all_variants (include/graphtyper/utilities/options.hpp:77)
   long region_begin = 0, region_end = 0xFFFFFFFFl;
   std::vector<RefNode> ref_nodes;
   std::vector<VarNode> var_nodes;
   std::unordered_map<uint32_t, std::vector<uint32_t>> ref_reach_to_special_pos;
   std::vector<uint32_t> ref_reach_poses, actual_poses;
 
-  // graph.cpp:41-339, restricted to records that need no merging: add_all_variants=false and no
-  // record overlaps the next one (the merge rules of graph.cpp:81-240 / var_record.cpp are SURVEY
-  // 8(f) row 1 and not restated yet -- overlapping input is rejected loudly).
+  // graph.cpp:41-339
   void add_genomic_region(std::string const & reference, std::vector<VarRecord> records)
   {
     for (auto & r : records) // graph.cpp:48-59
@@ -305,9 +543,64 @@ struct Graph
         records.resize(v);
         break;
       }
-    for (std::size_t i = 0; i + 1 < records.size(); ++i) // graph.cpp:213-240 would merge these
-      if (records[i + 1].pos < records[i].pos + records[i].ref.size())
-        throw std::runtime_error("gto: overlapping variant records need the merge rules (not restated yet)");
+    long const n_rec = static_cast<long>(records.size());
+    if (add_all_variants) // graph.cpp:81-167
+    {
+      long constexpr MAX_VAR_MERGE_DIST = 10, MAX_INDEL_MERGE_DIST = 2;
+      for (long i = 0; i < n_rec; ++i)
+        while (i + 1 < n_rec)
+        {
+          VarRecord & curr = records[i];
+          VarRecord & next = records[i + 1];
+          long const curr_end = static_cast<long>(curr.pos + curr.ref.size());
+          if (static_cast<long>(next.pos) > curr_end + MAX_VAR_MERGE_DIST)
+            break;
+          if ((!curr.is_snp_or_snps() || !next.is_snp_or_snps()) && static_cast<long>(next.pos) > curr_end + MAX_INDEL_MERGE_DIST)
+            break;
+          if (static_cast<long>(next.pos) >= curr_end && (curr.alts.size() > 42 || next.alts.size() > 42 ||
+                                                          curr.is_any_seq_larger_than(20) || next.is_any_seq_larger_than(20)))
+            break;
+          if ((curr.alts.size() + 1) * (next.alts.size() + 1) >= (MAX_NUMBER_OF_HAPLOTYPES - 1))
+            next.merge_one_path(std::move(curr));
+          else
+          {
+            if (static_cast<long>(next.pos) > curr_end)
+            {
+              long const a = std::min<long>(curr_end - region_begin, static_cast<long>(reference.size()));
+              long const b = std::min<long>(static_cast<long>(next.pos) - region_begin, static_cast<long>(reference.size()));
+              curr.add_suffix(reference.substr(a, b - a));
+            }
+            next.merge_all(std::move(curr));
+          }
+          if (next.alts.size() >= MAX_NUMBER_OF_HAPLOTYPES - 1)
+            next.alts.resize(MAX_NUMBER_OF_HAPLOTYPES - 1);
+          curr.clear();
+          ++i;
+        }
+    }
+    else // graph.cpp:169-240
+    {
+      for (long i = 0; i < n_rec; ++i)
+        while (i + 1 < n_rec && records[i + 1].pos < records[i].pos + records[i].ref.size())
+        {
+          VarRecord & curr = records[i];
+          VarRecord & next = records[i + 1];
+          if (is_sv_graph && (curr.is_sv || next.is_sv))
+          {
+            if (curr.is_sv && next.is_sv)
+              next.merge_one_path(std::move(curr));
+            else if (curr.is_sv)
+              next = std::move(curr); // the small variant overlapping an SV breakpoint is dropped
+            // else: the previous (small) variant is dropped
+          }
+          else if (curr.alts.size() > 100 || (next.pos - curr.pos) < 4)
+            next.merge_one_path(std::move(curr));
+          else
+            next.merge(std::move(curr), 4);
+          curr.clear();
+          ++i;
+        }
+    }
     for (auto & r : records) // graph.cpp:243-251
       r.alts.erase(std::remove_if(r.alts.begin(), r.alts.end(), [&](AltAllele const & a) { return a.seq == r.ref; }),
                    r.alts.end());

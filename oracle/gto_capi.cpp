@@ -2,6 +2,7 @@
 // Loaded with ctypes from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
 #include "gto.hpp"
 
+#include <cctype>
 #include <memory>
 #include <sstream>
 
@@ -26,7 +27,8 @@ struct GenoHandle
 
 // records text: one record per line, fields separated by blanks:  pos0  REF  ALT1,ALT2  [INFO]
 // INFO carries GT_ID / GT_ANTI_HAPLOTYPE exactly as src/graph/constructor.cpp:1540-1588 reads them
-// (only for records with a single alt).
+// (only for records with a single alt), and -- for tests that set events directly like test/graph/test_graph.cpp --
+// RE= / RA= (reference allele events / anti events) and E<i>= / A<i>= (events / anti events of alt i), comma separated.
 std::vector<VarRecord> parse_records(std::string const & text)
 {
   std::vector<VarRecord> out;
@@ -53,6 +55,52 @@ std::vector<VarRecord> parse_records(std::string const & text)
       if (b == std::string::npos)
         break;
       a = b + 1;
+    }
+    auto split_longs = [](std::string const & val)
+    {
+      std::vector<long> out;
+      std::size_t c = 0;
+      while (c <= val.size())
+      {
+        std::size_t const d = val.find(',', c);
+        std::string const tok = val.substr(c, d == std::string::npos ? std::string::npos : d - c);
+        if (!tok.empty())
+          out.push_back(std::stol(tok));
+        if (d == std::string::npos)
+          break;
+        c = d + 1;
+      }
+      return out;
+    };
+    if (!info.empty() && info != ".")
+    {
+      std::size_t s = 0;
+      while (s <= info.size())
+      {
+        std::size_t const e = info.find(';', s);
+        std::string const kv = info.substr(s, e == std::string::npos ? std::string::npos : e - s);
+        std::size_t const eq = kv.find('=');
+        if (eq != std::string::npos)
+        {
+          std::string const key = kv.substr(0, eq), val = kv.substr(eq + 1);
+          if (key == "RE")
+            for (long x : split_longs(val))
+              r.ref_events.insert(x);
+          else if (key == "RA")
+            for (long x : split_longs(val))
+              r.ref_anti_events.insert(x);
+          else if ((key[0] == 'E' || key[0] == 'A') && key.size() > 1 && std::isdigit(static_cast<unsigned char>(key[1])))
+          {
+            std::size_t const ai = std::stoul(key.substr(1));
+            if (ai < r.alts.size())
+              for (long x : split_longs(val))
+                (key[0] == 'E' ? r.alts[ai].events : r.alts[ai].anti_events).insert(x);
+          }
+        }
+        if (e == std::string::npos)
+          break;
+        s = e + 1;
+      }
     }
     if (r.alts.size() == 1 && !info.empty() && info != ".")
     {
@@ -145,7 +193,7 @@ extern "C"
   char const * gto_last_error() { return g_error.c_str(); }
 
   void * gto_new(char const * reference, long region_begin, char const * records_text, int is_sv_graph, int hq_reads,
-                 int force_both, long max_index_labels)
+                 int force_both, long max_index_labels, int add_all_variants, int extend_prefix)
   {
     try
     {
@@ -156,7 +204,12 @@ extern "C"
       h->par.max_index_labels = max_index_labels;
       h->graph.is_sv_graph = is_sv_graph != 0;
       h->graph.region_begin = region_begin;
-      h->graph.add_genomic_region(reference, parse_records(records_text));
+      h->graph.add_all_variants = add_all_variants != 0;
+      std::vector<VarRecord> records = parse_records(records_text);
+      if (extend_prefix)
+        for (auto & r : records)
+          r.extend_while_prefix_related(reference, region_begin);
+      h->graph.add_genomic_region(reference, std::move(records));
       h->graph.create_special_positions();
       h->index = index_graph(h->graph, max_index_labels);
       return h.release();

@@ -46,7 +46,7 @@ def lib():
         L = C.CDLL(build())
         L.gto_last_error.restype = C.c_char_p
         L.gto_new.restype = C.c_void_p
-        L.gto_new.argtypes = [C.c_char_p, C.c_long, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_long]
+        L.gto_new.argtypes = [C.c_char_p, C.c_long, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int]
         L.gto_free.argtypes = [C.c_void_p]
         L.gto_genotyper_new.restype = C.c_void_p
         L.gto_genotyper_new.argtypes = [C.c_void_p, C.c_long, C.c_long]
@@ -82,10 +82,10 @@ def pack_reads(reads):
 
 class Oracle:
     def __init__(self, reference, records, region_begin=0, is_sv_graph=False, hq_reads=False, force_both=False,
-                 max_index_labels=75):
+                 max_index_labels=75, add_all_variants=False, extend_prefix=False):
         L = lib()
         self.h = L.gto_new(reference.encode(), region_begin, records_text(records).encode(), int(is_sv_graph),
-                           int(hq_reads), int(force_both), max_index_labels)
+                           int(hq_reads), int(force_both), max_index_labels, int(add_all_variants), int(extend_prefix))
         if not self.h:
             raise RuntimeError(L.gto_last_error().decode())
 
