@@ -21,7 +21,8 @@ ST_LABEL_OVERFLOW, ST_PATH_OVERFLOW, ST_DFS_OVERFLOW, ST_RECORD_OVERFLOW = 1, 2,
 EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy", "gtx_ctx_special_positions",
            "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_index_stats", "gtx_index_get", "gtx_index_dump",
            "gtx_align_batch", "gtx_score_batch", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_stream_create",
-           "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_counts"]
+           "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_get_view",
+           "gtx_graph_destroy"]
 
 
 class GraphView(C.Structure):
@@ -102,6 +103,10 @@ def lib():
         L.gtx_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                       C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.gtx_stream_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.gtx_graph_build.argtypes = [C.c_char_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.c_void_p)]
+        L.gtx_graph_get_view.argtypes = [C.c_void_p, C.POINTER(GraphView)]
+        L.gtx_graph_destroy.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -123,9 +128,8 @@ def _p(a):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# host-side graph construction from variant records (the subset of Graph::add_genomic_region, src/graph/graph.cpp:41-339,
-# that needs no record merging: add_all_variants=false and no record overlaps the next one; merged multi-allelic sites
-# are SURVEY.md 8(f) row 1)
+# binding of the host graph builder gtx_graph_build (Graph::add_genomic_region, src/graph/graph.cpp:41-339, including the
+# record merge rules) -- SURVEY.md 8(f) row 1
 # ------------------------------------------------------------------------------------------------------------------
 def parse_events(info):
     """GT_ID / GT_ANTI_HAPLOTYPE of a single-alt record (src/graph/constructor.cpp:1540-1588) ->
@@ -144,91 +148,87 @@ def parse_events(info):
     return ref_ev, alt_ev, alt_anti
 
 
-def common_suffix_size(ref, alts):  # VarRecord::get_common_suffix (src/graph/var_record.cpp:381-406)
-    if not ref or any(len(a) == 0 for a in alts):
-        return 0
-    n = 0
-    while n < len(ref) - 1 and all(n < len(a) - 1 and a[len(a) - 1 - n] == ref[len(ref) - 1 - n] for a in alts):
-        n += 1
-    return n
+class _Allele(C.Structure):
+    _fields_ = [("seq", C.c_char_p), ("len", C.c_uint32), ("events", C.POINTER(C.c_int64)), ("n_events", C.c_uint32),
+                ("anti_events", C.POINTER(C.c_int64)), ("n_anti_events", C.c_uint32)]
 
 
-def graph_from_records(reference, records, region_begin=0, region_end=0xFFFFFFFF):
+class _Record(C.Structure):
+    _fields_ = [("pos", C.c_uint32), ("n_alleles", C.c_uint32), ("alleles", C.POINTER(_Allele)), ("is_sv", C.c_int32)]
+
+
+def _explicit_events(info, n_alts):
+    """test syntax used by tests/test_graph_vectors.py: RE= / RA= (reference allele events / anti events),
+    E<i>= / A<i>= (alt i); comma separated integers"""
+    ev = [([], []) for _ in range(n_alts + 1)]
+    if info and info != ".":
+        for kv in info.split(";"):
+            if "=" not in kv:
+                continue
+            k, v = kv.split("=", 1)
+            if k in ("RE", "RA") or (k[0] in "EA" and k[1:].isdigit()):
+                vals = [int(x) for x in v.split(",") if x]
+                if k == "RE":
+                    ev[0][0].extend(vals)
+                elif k == "RA":
+                    ev[0][1].extend(vals)
+                elif int(k[1:]) < n_alts:
+                    ev[int(k[1:]) + 1][0 if k[0] == "E" else 1].extend(vals)
+    return ev
+
+
+def graph_from_records(reference, records, region_begin=0, region_end=0xFFFFFFFF, add_all_variants=False,
+                       extend_prefix=False, is_sv_graph=False):
     """reference: str of the region; records: [(pos0, ref, [alts], info)] sorted by pos0 (contig coordinates, 0-based).
-    Returns a dict of numpy arrays laid out as gtx_graph_view expects."""
-    recs = []
-    for pos, ref, alts, info in records:  # graph.cpp:48-80
-        ev = parse_events(info) if len(alts) == 1 else ([], [], [])
-        alts = [(a, ev[1], ev[2]) for a in alts if a and "N" not in a]
-        if "N" in ref or "*" in ref or not alts or pos < region_begin:
-            continue
-        if pos >= region_end:
-            break
-        recs.append([pos, ref, alts, ev[0]])
-    for a, b in zip(recs, recs[1:]):
-        if b[0] < a[0] + len(a[1]):
-            raise ValueError("overlapping variant records need the reference's merge rules (not built yet)")
-    out = []
-    for pos, ref, alts, ref_ev in recs:  # graph.cpp:243-293
-        alts = [a for a in alts if a[0] != ref]
-        if not alts:
-            continue
-        if len(alts) >= 2559:
-            alts = alts[:2558]
-        n = common_suffix_size(ref, [a[0] for a in alts])
-        if n:
-            ref = ref[:-n]
-            alts = [(a[0][:-n], a[1], a[2]) for a in alts]
-        alts.sort(key=lambda a: a[0])
-        out.append((pos, ref, alts, ref_ev))
-    ref_order, ref_seq, ref_nvar, ref_first_var = [], [], [], []
-    var_order, var_seq, var_out_ref, var_events = [], [], [], []
-    start = region_begin
-    L = len(reference)
+    Calls gtx_graph_build (C++: filters, record merging, node emission) and returns the node tables as numpy arrays laid
+    out as gtx_graph_view expects."""
+    L = lib()
+    keep = []
+    recs = (_Record * max(len(records), 1))()
+    for i, (pos, ref, alts, info) in enumerate(records):
+        ev = _explicit_events(info, len(alts))
+        if len(alts) == 1:
+            r_ev, a_ev, a_anti = parse_events(info)
+            ev[0][0].extend(r_ev)
+            ev[1][0].extend(a_ev)
+            ev[1][1].extend(a_anti)
+        als = (_Allele * (len(alts) + 1))()
+        for j, seq in enumerate([ref] + list(alts)):
+            b = seq.encode()
+            e = (C.c_int64 * max(len(ev[j][0]), 1))(*ev[j][0])
+            a = (C.c_int64 * max(len(ev[j][1]), 1))(*ev[j][1])
+            keep.extend([b, e, a])
+            als[j] = _Allele(b, len(b), e, len(ev[j][0]), a, len(ev[j][1]))
+        keep.append(als)
+        recs[i] = _Record(pos, len(alts) + 1, als, 0)
+    h = C.c_void_p()
+    refb = reference.encode()
+    check(L.gtx_graph_build(refb, len(refb), region_begin, region_end, recs, len(records), int(add_all_variants),
+                            int(is_sv_graph), int(extend_prefix), C.byref(h)))
+    try:
+        v = GraphView()
+        check(L.gtx_graph_get_view(h, C.byref(v)))
 
-    def ref_slice(a, b):
-        a, b = min(max(a - region_begin, 0), L), min(max(b - region_begin, 0), L)
-        return reference[a:b]
+        def arr(ptr, n, dt):
+            if not ptr or n == 0:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(n,)).copy()
 
-    for pos, ref, alts, ref_ev in out:  # graph.cpp:295-301 -> add_reference :584-625, add_variants :548-582
-        end = max(start, min(pos, L + region_begin))
-        ref_order.append(start + 1)
-        ref_seq.append(ref_slice(start, end))
-        ref_nvar.append(len(alts) + 1)
-        ref_first_var.append(len(var_order))
-        nxt = len(ref_order)
-        var_order.append(pos + 1)
-        var_seq.append(ref)
-        var_out_ref.append(nxt)
-        var_events.append((ref_ev, []))
-        for a, ev, anti in alts:
-            var_order.append(pos + 1)
-            var_seq.append(a)
-            var_out_ref.append(nxt)
-            var_events.append((ev, anti))
-        start = pos + len(ref)
-    ref_order.append(start + 1)
-    ref_seq.append(ref_slice(start, L + region_begin))
-    ref_nvar.append(0)
-    ref_first_var.append(INVALID_ID)
-    dna = "".join(ref_seq) + "".join(var_seq)
-    ref_len = np.array([len(s) for s in ref_seq], np.uint32)
-    var_len = np.array([len(s) for s in var_seq], np.uint32)
-    ref_off = np.concatenate([[0], np.cumsum(ref_len)[:-1]]).astype(np.uint32)
-    base = int(ref_len.sum())
-    var_off = (base + np.concatenate([[0], np.cumsum(var_len)[:-1]])).astype(np.uint32) if len(var_len) else np.zeros(0, np.uint32)
-    ev_off = [0]
-    ev_val = []
-    for ev, anti in var_events:
-        ev_val.extend(sorted(ev))
-        ev_off.append(len(ev_val))
-        ev_val.extend(sorted(anti))
-        ev_off.append(len(ev_val))
-    return dict(ref_order=np.array(ref_order, np.uint32), ref_len=ref_len, ref_dna_off=ref_off,
-                ref_nvar=np.array(ref_nvar, np.uint32), ref_first_var=np.array(ref_first_var, np.uint32),
-                var_order=np.array(var_order, np.uint32), var_len=var_len, var_dna_off=var_off,
-                var_out_ref=np.array(var_out_ref, np.uint32), dna=np.frombuffer(dna.encode(), np.uint8).copy(),
-                event_off=np.array(ev_off, np.uint32), event_val=np.array(ev_val, np.int64))
+        R, V = v.n_ref, v.n_var
+        g = dict(ref_order=arr(v.ref_order, R, np.uint32), ref_len=arr(v.ref_len, R, np.uint32),
+                 ref_dna_off=arr(v.ref_dna_off, R, np.uint32), ref_nvar=arr(v.ref_nvar, R, np.uint32),
+                 ref_first_var=arr(v.ref_first_var, R, np.uint32), var_order=arr(v.var_order, V, np.uint32),
+                 var_len=arr(v.var_len, V, np.uint32), var_dna_off=arr(v.var_dna_off, V, np.uint32),
+                 var_out_ref=arr(v.var_out_ref, V, np.uint32), dna=arr(v.dna, v.dna_len, np.uint8))
+        if v.event_off:
+            g["event_off"] = arr(v.event_off, 2 * V + 1, np.uint32)
+            g["event_val"] = arr(v.event_val, int(g["event_off"][-1]), np.int64)
+        else:
+            g["event_off"] = np.zeros(2 * V + 1, np.uint32)
+            g["event_val"] = np.zeros(0, np.int64)
+        return g
+    finally:
+        L.gtx_graph_destroy(h)
 
 
 def pack_nibbles(codes, stride=None):

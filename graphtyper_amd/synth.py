@@ -86,3 +86,26 @@ def make_reads(ref, records, n, read_len=150, seed=123, err=0.005, n_rate=0.001,
     nmask = rng.random(codes.shape) < n_rate
     codes = np.where(nmask, np.uint8(15), codes).astype(np.uint8)
     return np.ascontiguousarray(codes), pos
+
+
+def make_cluster_records(ref, every=500, seed=13, region_begin=0):
+    """clusters of three biallelic sites a few bp apart (SNP, SNP, 1-6 bp insertion or deletion): with add_all_variants
+    every cluster merges into one multi-allelic site (the cfg3-like graph)"""
+    rng = np.random.default_rng(seed)
+    recs = []
+    p = every // 2
+    while p + 30 < len(ref):
+        q = p
+        for k in range(3):
+            if k < 2:
+                a = (ref[q] + rng.integers(1, 4)) % 4
+                recs.append((q + region_begin, "ACGT"[ref[q]], ["ACGT"[a]], None))
+                q += int(rng.integers(2, 6))
+            elif rng.random() < 0.5:
+                ins = rng.integers(0, 4, size=int(rng.integers(1, 7)), dtype=np.uint8)
+                recs.append((q + region_begin, "ACGT"[ref[q]], ["ACGT"[ref[q]] + bases_to_str(ins)], None))
+            else:
+                dl = int(rng.integers(1, 7))
+                recs.append((q + region_begin, bases_to_str(ref[q:q + dl + 1]), ["ACGT"[ref[q]]], None))
+        p += every
+    return recs

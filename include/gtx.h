@@ -77,6 +77,38 @@ typedef struct gtx_graph_view
   const int64_t * event_val;
 } gtx_graph_view;
 
+/* ---- host graph builder: variant records + reference sequence -> node tables ----
+ * replaces Graph::add_genomic_region(std::vector<char>&&, std::vector<VarRecord>&&, GenomicRegion&&)
+ *          include/graphtyper/graph/graph.hpp:60-62, src/graph/graph.cpp:41-339 (filters, record merging, node emission)
+ * and, with extend_prefix, GenomicRegion::add_reference_to_record_if_they_have_a_matching_prefix
+ *          src/graph/genomic_region.cpp:236-256 (what the constructor applies to every VCF record, constructor.cpp:1740-1744) */
+typedef struct gtx_allele
+{
+  const char * seq;
+  uint32_t len;
+  const int64_t * events; /* Ref/Alt::events (include/graphtyper/graph/alt.hpp:19-20) */
+  uint32_t n_events;
+  const int64_t * anti_events;
+  uint32_t n_anti_events;
+} gtx_allele;
+
+typedef struct gtx_record /* VarRecord (include/graphtyper/graph/var_record.hpp:15-20); alleles[0] is REF */
+{
+  uint32_t pos; /* 0-based contig position */
+  uint32_t n_alleles;
+  const gtx_allele * alleles;
+  int32_t is_sv;
+} gtx_record;
+
+typedef struct gtx_graph gtx_graph; /* owns the node tables a gtx_graph_view points into */
+
+/* records sorted by pos; region = [region_begin, region_end) 0-based, reference[0] is contig position region_begin */
+int gtx_graph_build(const char * reference, uint64_t reference_len, int64_t region_begin, int64_t region_end,
+                    const gtx_record * records, uint32_t n_records, int add_all_variants, int is_sv_graph, int extend_prefix,
+                    gtx_graph ** out);
+int gtx_graph_get_view(const gtx_graph *, gtx_graph_view * out);
+void gtx_graph_destroy(gtx_graph *);
+
 /* Options the path reads (include/graphtyper/utilities/options.hpp:34,82,87,89,90) */
 typedef struct gtx_params
 {

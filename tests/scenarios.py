@@ -65,6 +65,8 @@ def synthetic_case(kind, n_ref=40000, n_reads=300, seed=0, region_begin=1000000,
         recs = synth.make_snp_records(ref, 25, seed=seed + 3, region_begin=region_begin)
     elif kind == "indel":
         recs = synth.make_indel_records(ref, 60, seed=seed + 4, region_begin=region_begin)
+    elif kind == "cluster":  # merged multi-allelic sites: build the graph with add_all_variants=True
+        recs = synth.make_cluster_records(ref, 150, seed=seed + 8, region_begin=region_begin)
     else:
         raise ValueError(kind)
     codes, pos = synth.make_reads(ref, recs, n_reads, read_len=read_len, seed=seed + 5, err=err, n_rate=n_rate,

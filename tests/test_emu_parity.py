@@ -99,3 +99,17 @@ def test_direct_probes_and_half_key_buckets_agree(monkeypatch):
     check_align(b, o, list(codes))
     monkeypatch.delenv("GTX_HALF_BUCKET_CAP")
     check_align(b, o, list(codes))
+
+
+def test_align_and_score_on_merged_multiallelic_graph():
+    """cfg3-like graph: clusters of SNP, SNP, indel merged by add_all_variants into 8-allele sites (special positions,
+    allele sets with several members, explain_to_score over 36-entry genotype triangles)"""
+    ref, recs, codes, pos = scenarios.synthetic_case("cluster", n_ref=60000, n_reads=4000, region_begin=20000)
+    o = Oracle(ref, recs, region_begin=20000, add_all_variants=True)
+    g = gtx.graph_from_records(ref, recs, region_begin=20000, add_all_variants=True)
+    assert int(g["ref_nvar"].max()) >= 6
+    b = harness.EmuBackend(g)
+    check_align(b, o, list(codes))
+    rec = scenarios.stream_records(len(codes), pos, sample=np.arange(len(codes)) % 3)
+    order = np.argsort(pos, kind="stable")
+    run_stream(b, o, codes[order], rec[order], n_samples=3)

@@ -79,3 +79,17 @@ def test_scores_do_not_depend_on_item_order():
     s1 = harness.canonical_scores(b.ctx, b.score(items, records, 2))
     s2 = harness.canonical_scores(b.ctx, b.score(items[::-1].copy(), records, 2))
     assert np.array_equal(s1, s2)
+
+
+def test_merged_multiallelic_graph():
+    """cfg3-like: add_all_variants merges clusters of SNP, SNP, indel into multi-allelic sites (graph built by
+    gtx_graph_build); 30 samples"""
+    ref, recs, codes, pos = scenarios.synthetic_case("cluster", n_ref=300000, n_reads=30000, region_begin=1000000)
+    o = Oracle(ref, recs, region_begin=1000000, add_all_variants=True)
+    g = gtx.graph_from_records(ref, recs, region_begin=1000000, add_all_variants=True)
+    assert int(g["ref_nvar"].max()) >= 6
+    b = harness.GpuBackend(g)
+    check_align(b, o, list(codes))
+    order = np.argsort(pos, kind="stable")
+    rec = scenarios.stream_records(len(codes), pos, sample=np.arange(len(codes)) % 30)
+    run_stream(b, o, codes[order], rec[order], n_samples=30)

@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+from graphtyper_amd import lib as gtx
 from oracle_lib import Oracle
 
 CASES = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "graph_cases.json")))
@@ -90,3 +91,80 @@ def test_variant_overlapping_an_n():  # test/graph/test_graph.cpp:1436-1519 (thr
     assert len(r) == 2 and v == ["G", "GA"]
     g = Oracle(ref, [(51, "G", ["GN", "GNN"], None)], add_all_variants=True).graph()
     assert node_tables(g) == ([ref], [])
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"][:60] for c in CASES])
+def test_product_graph_matches_reference_tests(case):
+    gtx.build()
+    g = gtx.graph_from_records(case["reference"], records_of(case), region_begin=case["region_begin"],
+                               add_all_variants=case["add_all_variants"], extend_prefix=case["extend_prefix"])
+    check_expectations(case, g)
+
+
+def _random_records(rng, ref, n_sites, with_events):
+    """clusters of SNPs / insertions / deletions, some overlapping, some adjacent, some far apart"""
+    recs = []
+    pos = int(rng.integers(3, 12))
+    ev = 1
+    while len(recs) < n_sites and pos + 12 < len(ref):
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            r = ref[pos]
+            alts = sorted({"ACGT"[(("ACGT".index(r)) + int(k)) % 4] for k in rng.integers(1, 4, size=int(rng.integers(1, 3)))})
+        elif kind == 1:
+            r = ref[pos]
+            alts = [r + "".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=int(rng.integers(1, 5))))]
+        elif kind == 2:
+            d = int(rng.integers(1, 7))
+            r = ref[pos:pos + d + 1]
+            alts = [ref[pos]]
+        else:
+            r = ref[pos:pos + 2]
+            alts = sorted({ref[pos] + "ACGT"[int(rng.integers(4))] for _ in range(2)} - {r})
+            if not alts:
+                alts = [ref[pos]]
+        info = None
+        if with_events and len(alts) == 1 and rng.random() < 0.5:
+            info = "GT_ID=%d" % ev
+            if ev > 1 and rng.random() < 0.5:
+                info += ";GT_ANTI_HAPLOTYPE=%d" % int(rng.integers(1, ev))
+            ev += 1
+        recs.append((pos, r, alts, info))
+        pos += int(rng.choice([0, 1, 1, 2, 3, 5, 9, 14, 40]))
+        if recs and pos < recs[-1][0]:
+            pos = recs[-1][0]
+    return recs
+
+
+@pytest.mark.parametrize("add_all", [False, True])
+@pytest.mark.parametrize("with_events", [False, True])
+def test_product_graph_equals_oracle_on_random_records(add_all, with_events):
+    gtx.build()
+    rng = np.random.default_rng(17 + 2 * add_all + with_events)
+    n_checked = 0
+    for trial in range(150):
+        ref = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=int(rng.integers(80, 400))))
+        recs = _random_records(rng, ref, int(rng.integers(1, 14)), with_events)
+        begin = int(rng.integers(0, 3)) * 1000
+        recs = [(p + begin, r, a, i) for p, r, a, i in recs]
+        try:
+            og = Oracle(ref, recs, region_begin=begin, add_all_variants=add_all, extend_prefix=True).graph()
+        except RuntimeError:
+            continue  # e.g. duplicated alts after prefix extension: the reference aborts on those
+        g = gtx.graph_from_records(ref, recs, region_begin=begin, add_all_variants=add_all, extend_prefix=True)
+        for k in ("ref_order", "ref_len", "ref_nvar", "var_order", "var_len", "var_out_ref"):
+            assert np.array_equal(g[k], og[k]), (trial, k)
+        assert node_tables(g) == node_tables(og), trial
+        # events per variant node
+        oe = og["events"]
+        pos_ = 0
+        for v in range(len(g["var_order"])):
+            ne, na = int(oe[pos_]), int(oe[pos_ + 1])
+            want_e = sorted(int(x) for x in oe[pos_ + 2:pos_ + 2 + ne])
+            want_a = sorted(int(x) for x in oe[pos_ + 2 + ne:pos_ + 2 + ne + na])
+            pos_ += 2 + ne + na
+            o0, o1, o2 = (int(x) for x in g["event_off"][2 * v:2 * v + 3])
+            assert [int(x) for x in g["event_val"][o0:o1]] == want_e, (trial, v)
+            assert [int(x) for x in g["event_val"][o1:o2]] == want_a, (trial, v)
+        n_checked += 1
+    assert n_checked > 100
