@@ -1,0 +1,1583 @@
+// align_core.inl -- the table-size dependent part of the alignment kernel.  Included inside a namespace that defines
+// `struct AlignCfg` (see align_core.hpp: once with the LDS-sized tables of the main pass, once with the large tables of
+// the second pass for reads that overflowed).  No include guard on purpose.
+
+struct PVar
+{
+  uint32_t site;
+  uint32_t mlo, mhi; // allele set (Path::nums[i]) as a 64-bit mask
+};
+
+struct DPath // gyper::Path (include/graphtyper/typer/path.hpp:18-79)
+{
+  uint32_t start, end;
+  uint16_t rs, re; // read_start_index, read_end_index
+  uint16_t mism, nvar;
+  PVar v[AlignCfg::MAXV];
+};
+constexpr uint32_t DPATH_WORDS = sizeof(DPath) / 4;
+
+struct Loc // gyper::Location (include/graphtyper/graph/location.hpp)
+{
+  uint32_t type; // 0 = 'U', 1 = 'R', 2 = 'V'
+  uint32_t node, order, offset;
+};
+
+struct Cand // one element of var_and_refs / var_ids / end_pos in Graph::get_labels_forward (graph.cpp:1192-1196)
+{
+  uint32_t len;  // var_and_refs[j].size()
+  uint32_t mism; // mismatches of its first min(len, L) characters against the sub-read; max+1 once it is dead
+  uint32_t pos;  // end_pos[j] (forward) or start_pos[j] (backward)
+  uint32_t nids;
+  uint32_t ids[AlignCfg::MAXIDS];
+};
+constexpr uint32_t CAND_WORDS = sizeof(Cand) / 4;
+
+struct WalkBuffers // alive only during walk_read_starts / walk_read_ends
+{
+  DPath pp[AlignCfg::MAXPP];
+  Cand cand[AlignCfg::CAND_CAP];
+  Loc locs[AlignCfg::LOC_CAP];
+  DevLabel dfs_out[AlignCfg::WL_CAP]; // labels of the current iterative_dfs call
+};
+
+struct AlignWorkspace // lives in LDS, one per wavefront
+{
+  uint8_t rd[AlignCfg::MAX_READ]; // read as 4-bit IUPAC codes, orientation applied
+  DevLabel lbl[AlignCfg::LBL_CAP];
+  DPath paths[AlignCfg::MAXP];
+  DPath orig, np; // Path temporaries of add_next/prev_kmer_labels
+  union
+  {
+    uint64_t keybuf[AlignCfg::KEY_CAP]; // keys of a multi-key list, then (offset | count << 32) of every probed key
+    WalkBuffers w;                      // (pp is also used while seeding, never at the same time as keybuf)
+  } u;
+  DevLabel wl[AlignCfg::WL_CAP]; // best label lists of a walk (must survive the add_*_kmer_labels calls)
+  uint32_t wl_off[AlignCfg::WLISTS + 1];
+  uint32_t wl_idx[AlignCfg::WLISTS];
+  // per k-mer exact-probe results
+  uint64_t key0[AlignCfg::MAX_KMERS];
+  uint32_t nkeys0[AlignCfg::MAX_KMERS];
+  uint32_t off0[AlignCfg::MAX_KMERS];
+  uint32_t cnt0[AlignCfg::MAX_KMERS];
+  // lookups of the first KC k-mers, issued together so that their memory latencies overlap
+  uint32_t hoff[AlignCfg::KC][2], hcnt[AlignCfg::KC][2];
+  HalfEntry he[AlignCfg::KC][2][AlignCfg::HE_CAP];
+  DevLabel xl[AlignCfg::KC][AlignCfg::XL_CAP];
+  uint32_t n_paths, longest, status, n_lbl, n_keys, read_len, n_wl, n_wlists;
+};
+
+GTX_DEV uint64_t pv_mask(PVar const & v)
+{
+  return (static_cast<uint64_t>(v.mhi) << 32) | v.mlo;
+}
+
+GTX_DEV uint32_t path_size(DPath const & p)
+{
+  return static_cast<uint32_t>(p.re) - static_cast<uint32_t>(p.rs) + 1u;
+}
+
+template <class W>
+GTX_DEV uint32_t upath_size(DPath const & p) // wave-uniform
+{
+  uint32_t const w = GTX_U(reinterpret_cast<uint32_t const *>(&p)[2]); // rs | re << 16
+  return (w >> 16) - (w & 0xFFFFu) + 1u;
+}
+
+// Graph::get_locations_of_a_position (graph.cpp:1154-1185 -> 931-1029).  The reference scans reference nodes
+// backwards and looks every variant node up in path.var_order; here the (few) sites of the path are visited in
+// descending order instead, which yields the same locations in the same order.
+template <class W>
+GTX_DEV uint32_t get_locations(GraphView const & g, uint32_t pos, DPath const & path, Loc * locs, uint32_t cap, uint32_t & status)
+{
+  pos = GTX_U(pos);
+  bool const special = g_is_special(g, pos);
+  if (special)
+    pos = GTX_U(g.special_actual[pos - SPECIAL_START]);
+  uint32_t n = 0;
+  if (pos < g.first_order)
+    return 0;
+  if (g.n_ref == 1)
+  {
+    GTX_LEAD locs[0] = Loc{1, 0, g.ref_order[0], pos - g.ref_order[0]};
+    return 1;
+  }
+  int32_t rr = static_cast<int32_t>(g_ref_node_at<W>(g, pos));
+  {
+    uint32_t const ro = GTX_U(g.ref_order[rr]), rl = GTX_U(g.ref_len[rr]);
+    if (pos < ro + rl)
+    {
+      if (!special)
+      {
+        GTX_LEAD locs[0] = Loc{1, static_cast<uint32_t>(rr), ro, pos - ro};
+        return 1;
+      }
+      --rr;
+    }
+  }
+  // sites rr' <= rr with reach(rr') + PADDING > pos, descending; only sites the path carries can contribute
+  bool const path_empty = GTX_U(path.start) == GTX_U(path.end);
+  uint32_t const nvar = GTX_U(static_cast<uint32_t>(path.nvar));
+  int32_t bound = rr + 1;
+  for (;;)
+  {
+    int32_t best = -1;
+    uint32_t best_j = 0;
+    for (uint32_t j = 0; j < nvar; ++j)
+    {
+      int32_t const s = static_cast<int32_t>(GTX_U(path.v[j].site));
+      if (s < bound && s > best)
+      {
+        best = s;
+        best_j = j;
+      }
+    }
+    if (best < 0)
+      break;
+    bound = best;
+    uint32_t const site = static_cast<uint32_t>(best);
+    int64_t const reach = static_cast<int64_t>(GTX_U(g.ref_order[site])) + GTX_U(g.ref_len[site]) - 1;
+    if (!(reach + static_cast<int64_t>(g.padding) > static_cast<int64_t>(pos)))
+      break; // the reference stops its backward scan here; lower sites reach even less far
+    uint32_t const fv = GTX_U(g.ref_first_var[site]), nv = GTX_U(g.ref_nvar[site]);
+    uint64_t const mask = (static_cast<uint64_t>(GTX_U(path.v[best_j].mhi)) << 32) | GTX_U(path.v[best_j].mlo);
+    for (uint32_t i = 0; i < nv; ++i)
+    {
+      uint32_t const v = fv + i;
+      uint32_t const vo = GTX_U(g.var_order[v]);
+      if (pos >= vo && pos <= vo + GTX_U(g.var_len[v]) - 1)
+        if (path_empty || ((mask >> i) & 1ull))
+        {
+          if (n >= cap)
+          {
+            status |= GTX_ST_DFS_OVERFLOW;
+            return n;
+          }
+          GTX_LEAD locs[n] = Loc{2, v, vo, pos - vo};
+          ++n;
+        }
+    }
+  }
+  return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// graph walks: Graph::get_labels_forward / get_labels_backward (graph.cpp:1187-1439 / 1441-1701)
+// Sequences are never materialised: a candidate keeps its length and the mismatches of its already compared prefix
+// (count_mismatches restarts from 0 every time in the reference, which is the same sum).
+// ---------------------------------------------------------------------------------------------------------------
+struct SubRead
+{
+  uint8_t const * rd; // codes of the whole read (LDS)
+  uint32_t begin;     // first base of the sub-read
+  uint32_t len;       // L
+};
+
+// count_mismatches / count_mismatches_backward (graph_utils.hpp:7-69) of graph codes dna[0..n) against the sub-read,
+// 64 characters per step, one per lane.  forward: dna[i] <-> sub-read[at+i]; backward: the candidate already covers
+// the last `at` characters and dna is prepended, dna[n-1-i] <-> sub-read[L-1-at-i].  Comparison stops at the
+// sub-read's end.  Returns the running count capped at max+1 (= dead); a '<' / '>' in the compared range kills.
+// (The reference stops counting at max+1 or at the tag, whichever comes first -- both mean "rejected".)
+template <class W, bool BACKWARD>
+GTX_DEV uint32_t cmp_codes(SubRead const & sr, uint32_t at, uint8_t const * dna, uint32_t n, uint32_t mism, uint32_t maxmm)
+{
+  mism = GTX_U(mism);
+  n = GTX_U(n);
+  at = GTX_U(at);
+  if (mism > maxmm)
+    return maxmm + 1;
+  uint32_t const room = at < sr.len ? sr.len - at : 0;
+  uint32_t const m = n < room ? n : room;
+  for (uint32_t base = 0; base < m; base += 64)
+  {
+    typename W::template PerLane<bool> kill, mm;
+    W::lanes([&](uint32_t l) {
+      uint32_t const i = base + l;
+      bool k = false, x = false;
+      if (i < m)
+      {
+        uint8_t const gc = BACKWARD ? dna[n - 1 - i] : dna[i];
+        uint8_t const rc = BACKWARD ? sr.rd[sr.begin + sr.len - 1 - at - i] : sr.rd[sr.begin + at + i];
+        k = gc == DNA_KILL;
+        x = gc != rc && rc != 15 && gc != 15;
+      }
+      kill[l] = k;
+      mm[l] = x;
+    });
+    if (W::ballot(kill) != 0)
+      return maxmm + 1;
+    mism += static_cast<uint32_t>(__builtin_popcountll(W::ballot(mm)));
+    if (mism > maxmm)
+      return maxmm + 1;
+  }
+  return mism;
+}
+
+template <class W>
+GTX_DEV void cand_erase(Cand * c, uint32_t n, uint32_t j)
+{
+  for (uint32_t k = j; k + 1 < n; ++k)
+    copy_entry<W>(c[k], c[k + 1]);
+}
+
+// Emits the labels of the candidates that tie the fewest mismatches (graph.cpp:1375-1437 / 1636-1698).
+// `fixed_pos` = start position (forward) or end position (backward) shared by all labels of this location.
+template <class W, bool BACKWARD>
+GTX_DEV bool emit_best(GraphView const & g, Cand const * cand, uint32_t n, uint32_t L, uint32_t fixed_pos, uint32_t & max_mismatches,
+                       DevLabel * out, uint32_t & n_out, uint32_t out_cap, uint32_t & status)
+{
+  uint32_t const first_out = n_out;
+  for (uint32_t j = 0; j < n; ++j)
+  {
+    if (GTX_U(cand[j].len) < L)
+      continue;
+    uint32_t const mm = GTX_U(cand[j].mism);
+    if (mm > max_mismatches)
+      continue;
+    if (mm < max_mismatches)
+    {
+      max_mismatches = mm;
+      n_out = first_out;
+    }
+    uint32_t const nids = GTX_U(cand[j].nids);
+    uint32_t const nl = nids == 0 ? 1 : nids;
+    if (n_out + nl > out_cap)
+    {
+      status |= GTX_ST_DFS_OVERFLOW;
+      return false;
+    }
+    uint32_t const p = GTX_U(cand[j].pos);
+    uint32_t const s = BACKWARD ? p : fixed_pos, e = BACKWARD ? fixed_pos : p;
+    if (nids == 0)
+    {
+      GTX_LEAD out[n_out] = DevLabel{s, e, INVALID, 0};
+      ++n_out;
+    }
+    else
+      for (uint32_t k = 0; k < nids; ++k)
+      {
+        uint32_t const v = GTX_U(cand[j].ids[k]);
+        uint32_t const vs = GTX_U(g.var_out_ref[v]) - 1;
+        GTX_LEAD out[n_out] = DevLabel{s, e, vs, v - GTX_U(g.ref_first_var[vs])};
+        ++n_out;
+      }
+  }
+  W::lds_sync();
+  return true;
+}
+
+// One start (forward) or end (backward) location: extends over variant sites until every candidate covers the
+// sub-read, keeps candidates within the mismatch budget, appends the labels of the best ones to `out`.
+template <class W, bool BACKWARD>
+GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr, uint32_t & max_mismatches, Cand * cand,
+                         DevLabel * out, uint32_t & n_out, uint32_t out_cap, uint32_t & status)
+{
+  uint8_t const * dna = reinterpret_cast<uint8_t const *>(g.dna);
+  uint32_t const L = sr.len;
+  uint32_t const maxmm = max_mismatches;
+  uint32_t n = 1;
+  uint32_t site = INVALID; // site whose alleles come next, INVALID = none
+  uint32_t const s_type = GTX_U(s.type), s_node = GTX_U(s.node), s_offset = GTX_U(s.offset), s_order = GTX_U(s.order);
+  {
+    uint32_t len, mism, pos, nids = 0, id0 = 0;
+    if (s_type == 2)
+    {
+      uint32_t const v = s_node;
+      nids = 1;
+      id0 = v;
+      uint32_t const vout = GTX_U(g.var_out_ref[v]);
+      uint32_t const vsite = vout - 1;
+      uint32_t const vo = GTX_U(g.var_order[v]), vl = GTX_U(g.var_len[v]), vd = GTX_U(g.var_dna[v]);
+      if (!BACKWARD)
+      {
+        len = vl - s_offset;
+        mism = cmp_codes<W, false>(sr, 0, dna + vd + s_offset, len, 0, maxmm);
+        if (len >= L)
+          pos = ug_special_of<W>(g, vsite, (vo + vl - 1) - (len - L));
+        else
+        {
+          uint32_t const r = vout;
+          uint32_t const rl = GTX_U(g.ref_len[r]);
+          mism = cmp_codes<W, false>(sr, len, dna + GTX_U(g.ref_dna[r]), rl, mism, maxmm);
+          len += rl;
+          pos = (GTX_U(g.ref_order[r]) + rl - 1) - (len - L);
+          if (GTX_U(g.ref_nvar[r]) > 0)
+            site = r;
+        }
+      }
+      else
+      {
+        len = s_offset + 1;
+        mism = cmp_codes<W, true>(sr, 0, dna + vd, len, 0, maxmm);
+        if (len >= L)
+          pos = ug_special_of<W>(g, vsite, vo + (len - L));
+        else
+        {
+          uint32_t const r = vsite;
+          uint32_t const rl = GTX_U(g.ref_len[r]);
+          mism = cmp_codes<W, true>(sr, len, dna + GTX_U(g.ref_dna[r]), rl, mism, maxmm);
+          len += rl;
+          pos = GTX_U(g.ref_order[r]) + (len - L);
+          if (r != 0)
+            site = r - 1;
+        }
+      }
+    }
+    else
+    {
+      uint32_t const r = s_node;
+      uint32_t const rl = GTX_U(g.ref_len[r]), rd_ = GTX_U(g.ref_dna[r]);
+      if (!BACKWARD)
+      {
+        len = rl - s_offset;
+        mism = cmp_codes<W, false>(sr, 0, dna + rd_ + s_offset, len, 0, maxmm);
+        pos = (s_order + rl - 1) - (len - L); // s_order is the node's order
+        if (GTX_U(g.ref_nvar[r]) > 0)
+          site = r;
+      }
+      else
+      {
+        if (r != 0)
+          site = r - 1;
+        len = s_offset + 1;
+        mism = cmp_codes<W, true>(sr, 0, dna + rd_, len, 0, maxmm);
+        pos = s_order + (len - L);
+      }
+    }
+    GTX_LEAD
+    {
+      cand[0].len = len;
+      cand[0].mism = mism;
+      cand[0].pos = pos;
+      cand[0].nids = nids;
+      cand[0].ids[0] = id0;
+    }
+    W::lds_sync();
+  }
+
+  if (site != INVALID && GTX_U(cand[0].len) < L)
+  {
+    bool all_long = false;
+    while (!all_long && n < 128 && site != INVALID)
+    {
+      all_long = true;
+      uint32_t const r = BACKWARD ? site : site + 1; // reference node appended (forward) / prepended (backward)
+      uint32_t const fv = GTX_U(g.ref_first_var[site]), nv = GTX_U(g.ref_nvar[site]);
+      uint8_t const * rdna = dna + GTX_U(g.ref_dna[r]);
+      uint32_t const rlen = GTX_U(g.ref_len[r]);
+      uint32_t const rorder = GTX_U(g.ref_order[r]);
+      uint32_t original = n;
+      for (uint32_t j = 0; j < original; ++j)
+      {
+        uint32_t const jlen = GTX_U(cand[j].len), jmism = GTX_U(cand[j].mism), jn = GTX_U(cand[j].nids);
+        if (jlen >= L)
+          continue;
+        for (uint32_t i = 0; i < nv; ++i)
+        {
+          bool const last = i + 1 == nv; // the last allele extends candidate j in place, the others branch off copies
+          uint32_t const v = fv + i;
+          uint32_t const vo = GTX_U(g.var_order[v]), vl = GTX_U(g.var_len[v]);
+          uint32_t len = jlen;
+          uint32_t mm = cmp_codes<W, BACKWARD>(sr, len, dna + GTX_U(g.var_dna[v]), vl, jmism, maxmm);
+          len += vl;
+          bool const enough = len >= L;
+          if (!enough)
+          {
+            mm = cmp_codes<W, BACKWARD>(sr, len, rdna, rlen, mm, maxmm);
+            len += rlen;
+          }
+          if (mm <= maxmm)
+          {
+            if ((!last && n >= AlignCfg::CAND_CAP) || jn >= AlignCfg::MAXIDS)
+            {
+              status |= GTX_ST_DFS_OVERFLOW;
+              return false;
+            }
+            uint32_t pos;
+            if (!BACKWARD)
+              pos = enough ? ug_special_of<W>(g, site, (vo + vl - 1) - (len - L)) : (rorder + rlen - 1) - (len - L);
+            else
+              pos = enough ? ug_special_of<W>(g, site, vo + (len - L)) : rorder + (len - L);
+            uint32_t const dst = last ? j : n;
+            if (!last)
+            {
+              copy_entry<W>(cand[n], cand[j]);
+              ++n;
+            }
+            GTX_LEAD
+            {
+              Cand & nc = cand[dst];
+              nc.ids[jn] = v;
+              nc.nids = jn + 1;
+              nc.len = len;
+              nc.mism = mm;
+              nc.pos = pos;
+            }
+            W::lds_sync();
+            if (len < L)
+              all_long = false;
+          }
+          else if (last)
+          {
+            cand_erase<W>(cand, n, j);
+            --n;
+            --original;
+            --j;
+          }
+        }
+      }
+      if (all_long)
+        break;
+      if (!BACKWARD)
+        site = GTX_U(g.ref_nvar[r]) > 0 ? r : INVALID;
+      else
+      {
+        if (r == 0)
+          break;
+        site = r - 1;
+      }
+    }
+  }
+
+  uint32_t fixed = s_order + s_offset;
+  if (s_type == 2)
+    fixed = ug_special_of<W>(g, GTX_U(g.var_out_ref[s_node]) - 1, fixed);
+  return emit_best<W, BACKWARD>(g, cand, n, L, fixed, max_mismatches, out, n_out, out_cap, status);
+}
+
+// Graph::iterative_dfs (graph.cpp:1703-1754): labels of all locations that tie the fewest mismatches
+template <class W>
+GTX_DEV uint32_t iterative_dfs(GraphView const & g, AlignWorkspace & ws, uint32_t n_locs, bool backward, SubRead const & sr,
+                               uint32_t & max_mismatches, uint32_t & status)
+{
+  uint32_t n_out = 0;
+  if (n_locs > 1024)
+    return 0;
+  WalkBuffers & wb = ws.u.w;
+  for (uint32_t k = 0; k < n_locs; ++k)
+  {
+    uint32_t mm = max_mismatches;
+    uint32_t const before = n_out;
+    uint32_t after = n_out;
+    bool const ok = backward ? labels_walk<W, true>(g, wb.locs[k], sr, mm, wb.cand, wb.dfs_out, after, AlignCfg::WL_CAP, status)
+                             : labels_walk<W, false>(g, wb.locs[k], sr, mm, wb.cand, wb.dfs_out, after, AlignCfg::WL_CAP, status);
+    if (!ok)
+      return 0;
+    if (after == before)
+      continue; // no labels from this location
+    if (mm < max_mismatches)
+    {
+      max_mismatches = mm;
+      uint32_t const cnt = after - before; // labels = new_labels
+      if (before != 0)
+        for (uint32_t i = 0; i < cnt; ++i)
+          copy_entry<W>(wb.dfs_out[i], wb.dfs_out[before + i]);
+      n_out = cnt;
+    }
+    else if (mm == max_mismatches)
+      n_out = after;
+    // mm > max_mismatches cannot happen: a walk never returns labels above its budget
+  }
+  return n_out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// seed chaining: GenotypePaths::add_next_kmer_labels / add_prev_kmer_labels (genotype_paths.cpp:294-352 / 233-292)
+// ---------------------------------------------------------------------------------------------------------------
+
+// find_all_nonduplicated_paths (genotype_paths.cpp:32-66) + Path::merge_with_current (path.cpp:105-129)
+template <class W>
+GTX_DEV uint32_t make_pp(DPath * pp, DevLabel const * ll, uint32_t n, uint32_t rs, uint32_t re, uint32_t mism, uint32_t & status)
+{
+  uint32_t npp = 0;
+  for (uint32_t i = 0; i < n; ++i)
+  {
+    uint32_t const ls = GTX_U(ll[i].start), le = GTX_U(ll[i].end), lsite = GTX_U(ll[i].site), lall = GTX_U(ll[i].allele);
+    uint32_t d = 0;
+    for (; d < npp; ++d)
+      if (GTX_U(pp[d].start) == ls && GTX_U(pp[d].end) == le)
+        break;
+    if (d == npp)
+    {
+      if (npp >= AlignCfg::MAXPP)
+      {
+        status |= GTX_ST_PATH_OVERFLOW;
+        return npp;
+      }
+      GTX_LEAD
+      {
+        DPath & p = pp[npp];
+        p.start = ls;
+        p.end = le;
+        p.rs = static_cast<uint16_t>(rs);
+        p.re = static_cast<uint16_t>(re);
+        p.mism = static_cast<uint16_t>(mism);
+        p.nvar = lsite != INVALID ? 1 : 0;
+        if (lsite != INVALID)
+        {
+          p.v[0].site = lsite;
+          p.v[0].mlo = static_cast<uint32_t>(1ull << lall);
+          p.v[0].mhi = static_cast<uint32_t>((1ull << lall) >> 32);
+        }
+      }
+      W::lds_sync();
+      ++npp;
+      continue;
+    }
+    if (lsite == INVALID)
+      continue;
+    DPath & p = pp[d];
+    uint32_t const nvar = GTX_U(static_cast<uint32_t>(p.nvar));
+    uint32_t k = 0;
+    for (; k < nvar; ++k)
+      if (GTX_U(p.v[k].site) == lsite)
+        break;
+    if (k == nvar && nvar >= AlignCfg::MAXV)
+    {
+      status |= GTX_ST_PATH_OVERFLOW;
+      return npp;
+    }
+    GTX_LEAD
+    {
+      if (k < nvar)
+      {
+        p.v[k].mlo |= static_cast<uint32_t>(1ull << lall);
+        p.v[k].mhi |= static_cast<uint32_t>((1ull << lall) >> 32);
+      }
+      else
+      {
+        p.v[nvar].site = lsite;
+        p.v[nvar].mlo = static_cast<uint32_t>(1ull << lall);
+        p.v[nvar].mhi = static_cast<uint32_t>((1ull << lall) >> 32);
+        p.nvar = static_cast<uint16_t>(nvar + 1);
+      }
+    }
+    W::lds_sync();
+  }
+  return npp;
+}
+
+// Path::Path(p1, p2) (path.cpp:38-82) into `np` (LDS): everything from p2, allele sets of shared sites intersected
+// with p1's, p1's other sites appended, start/read_start_index taken from p1.  false <=> the reference returns early
+// on an empty intersection (its caller then discards the half merged object).
+template <class W>
+GTX_DEV bool merge_paths(DPath const & p1, DPath const & p2, DPath & np, uint32_t & status)
+{
+  copy_entry<W>(np, p2);
+  uint32_t const n1 = GTX_U(static_cast<uint32_t>(p1.nvar));
+  uint32_t nn = GTX_U(static_cast<uint32_t>(np.nvar));
+  for (uint32_t i = 0; i < n1; ++i)
+  {
+    uint32_t const s1 = GTX_U(p1.v[i].site);
+    uint32_t j = 0;
+    for (; j < nn; ++j)
+      if (GTX_U(np.v[j].site) == s1)
+        break;
+    if (j < nn)
+    {
+      uint32_t const lo = GTX_U(np.v[j].mlo & p1.v[i].mlo), hi = GTX_U(np.v[j].mhi & p1.v[i].mhi);
+      if ((lo | hi) == 0)
+        return false;
+      GTX_LEAD
+      {
+        np.v[j].mlo = lo;
+        np.v[j].mhi = hi;
+      }
+    }
+    else
+    {
+      if (nn >= AlignCfg::MAXV)
+      {
+        status |= GTX_ST_PATH_OVERFLOW;
+        return false;
+      }
+      GTX_LEAD np.v[nn] = p1.v[i];
+      ++nn;
+    }
+    W::lds_sync();
+  }
+  GTX_LEAD
+  {
+    np.nvar = static_cast<uint16_t>(nn);
+    np.rs = p1.rs;
+    np.start = p1.start;
+    np.mism = static_cast<uint16_t>(np.mism + p1.mism);
+  }
+  W::lds_sync();
+  return true;
+}
+
+// appends to ws.paths; n_paths is tracked by the caller
+template <class W>
+GTX_DEV bool push_path(AlignWorkspace & ws, uint32_t & n_paths, DPath const & p, uint32_t & status)
+{
+  if (n_paths >= AlignCfg::MAXP)
+  {
+    status |= GTX_ST_PATH_OVERFLOW;
+    return false;
+  }
+  copy_entry<W>(ws.paths[n_paths], p);
+  ++n_paths;
+  return true;
+}
+
+template <class W>
+GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t n, uint32_t rs, uint32_t re, uint32_t mism,
+                             bool prev, uint32_t & n_paths, uint32_t & longest, uint32_t & status)
+{
+  if (n == 0)
+    return;
+  if (n == 1 && !prev)
+  {
+    // One label = one new path P with at most one variant site.  Specialisation of the general code below: P can only
+    // ever replace in place (a path merges with the single P at most once), and Path(p1, P) is p1 with its end, read
+    // end and mismatches advanced and P's site moved to the front of the site list (path.cpp:38-82 keeps p2's sites
+    // first), its allele set intersected when p1 already carries the site.
+    uint32_t const ls = GTX_U(ll[0].start), le = GTX_U(ll[0].end), lsite = GTX_U(ll[0].site), lall = GTX_U(ll[0].allele);
+    uint32_t const lmlo = lsite != INVALID ? static_cast<uint32_t>(1ull << lall) : 0u;
+    uint32_t const lmhi = lsite != INVALID ? static_cast<uint32_t>((1ull << lall) >> 32) : 0u;
+    bool matched = false;
+    uint32_t const original_size = n_paths;
+    for (uint32_t i = 0; i < original_size; ++i)
+    {
+      DPath & p = ws.paths[i];
+      uint32_t const w2 = GTX_U(reinterpret_cast<uint32_t const *>(&p)[2]); // rs | re << 16
+      if ((w2 >> 16) != rs || GTX_U(p.end) != ls)
+        continue;
+      uint32_t const nvar = GTX_U(static_cast<uint32_t>(p.nvar));
+      uint32_t j = nvar, mlo = lmlo, mhi = lmhi;
+      if (lsite != INVALID)
+      {
+        for (j = 0; j < nvar; ++j)
+          if (GTX_U(p.v[j].site) == lsite)
+            break;
+        if (j < nvar)
+        {
+          mlo &= GTX_U(p.v[j].mlo);
+          mhi &= GTX_U(p.v[j].mhi);
+          if ((mlo | mhi) == 0)
+            continue; // empty allele intersection: this path does not merge
+        }
+        else if (nvar >= AlignCfg::MAXV)
+        {
+          status |= GTX_ST_PATH_OVERFLOW;
+          return;
+        }
+      }
+      GTX_LEAD
+      {
+        if (lsite != INVALID)
+        {
+          for (uint32_t k = j; k > 0; --k) // sites before j (or all of them) move one place back
+            p.v[k] = p.v[k - 1];
+          p.v[0].site = lsite;
+          p.v[0].mlo = mlo;
+          p.v[0].mhi = mhi;
+          if (j == nvar)
+            p.nvar = static_cast<uint16_t>(nvar + 1);
+        }
+        p.end = le;
+        p.re = static_cast<uint16_t>(re);
+        p.mism = static_cast<uint16_t>(p.mism + mism);
+      }
+      W::lds_sync();
+      matched = true;
+      uint32_t const sz = re - (w2 & 0xFFFFu) + 1u;
+      if (sz > longest)
+        longest = sz;
+    }
+    if (!matched)
+    {
+      if (n_paths >= AlignCfg::MAXP)
+      {
+        status |= GTX_ST_PATH_OVERFLOW;
+        return;
+      }
+      GTX_LEAD
+      {
+        DPath & p = ws.paths[n_paths];
+        p.start = ls;
+        p.end = le;
+        p.rs = static_cast<uint16_t>(rs);
+        p.re = static_cast<uint16_t>(re);
+        p.mism = static_cast<uint16_t>(mism);
+        p.nvar = lsite != INVALID ? 1 : 0;
+        p.v[0].site = lsite;
+        p.v[0].mlo = lmlo;
+        p.v[0].mhi = lmhi;
+      }
+      W::lds_sync();
+      ++n_paths;
+      uint32_t const sz = re - rs + 1u;
+      if (sz > longest)
+        longest = sz;
+    }
+    return;
+  }
+  DPath * pp = ws.u.w.pp;
+  uint32_t const npp = make_pp<W>(pp, ll, n, rs, re, mism, status);
+  if (status)
+    return;
+  uint32_t const original_size = n_paths;
+  BitSet<AlignCfg::MAXPP> matched;
+  for (uint32_t i = 0; i < original_size; ++i)
+  {
+    if (prev ? (GTX_U(static_cast<uint32_t>(ws.paths[i].rs)) != re) : (GTX_U(static_cast<uint32_t>(ws.paths[i].re)) != rs))
+      continue;
+    bool once = false;
+    copy_entry<W>(ws.orig, ws.paths[i]);
+    uint32_t const o_start = GTX_U(ws.orig.start), o_end = GTX_U(ws.orig.end);
+    for (uint32_t j = 0; j < npp; ++j)
+    {
+      bool ok;
+      if (prev)
+      {
+        if (!(GTX_U(pp[j].end) == o_start))
+          continue;
+        ok = merge_paths<W>(pp[j], ws.orig, ws.np, status);
+      }
+      else
+      {
+        if (!(o_end == GTX_U(pp[j].start)))
+          continue;
+        ok = merge_paths<W>(ws.orig, pp[j], ws.np, status);
+      }
+      if (status)
+        return;
+      if (!ok)
+        continue;
+      matched.set(j);
+      if (once)
+      {
+        if (!push_path<W>(ws, n_paths, ws.np, status))
+          return;
+      }
+      else
+      {
+        uint32_t const sz = upath_size<W>(ws.np);
+        if (sz > longest)
+          longest = sz;
+        copy_entry<W>(ws.paths[i], ws.np);
+        once = true;
+      }
+    }
+  }
+  for (uint32_t j = 0; j < npp; ++j)
+    if (!matched.get(j))
+    {
+      uint32_t const sz = upath_size<W>(pp[j]);
+      if (sz > longest)
+        longest = sz;
+      if (!push_path<W>(ws, n_paths, pp[j], status))
+        return;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// path filters (genotype_paths.cpp)
+// ---------------------------------------------------------------------------------------------------------------
+
+using PathSet = BitSet<AlignCfg::MAXP>;
+
+// stable removal of the paths whose bit in `drop` is set
+template <class W>
+GTX_DEV uint32_t compact_paths(AlignWorkspace & ws, uint32_t n_paths, PathSet const & drop)
+{
+  if (!drop.any())
+    return n_paths;
+  uint32_t k = 0;
+  for (uint32_t i = 0; i < n_paths; ++i)
+    if (!drop.get(i))
+    {
+      if (k != i)
+        copy_entry<W>(ws.paths[k], ws.paths[i]);
+      ++k;
+    }
+  return k;
+}
+
+template <class W>
+GTX_DEV uint32_t remove_short_paths(AlignWorkspace & ws, uint32_t n_paths, uint32_t longest) // :824-834
+{
+  if (longest <= 1)
+    return n_paths;
+  PathSet drop;
+  for (uint32_t i = 0; i < n_paths; ++i)
+    if (upath_size<W>(ws.paths[i]) < longest)
+      drop.set(i);
+  return compact_paths<W>(ws, n_paths, drop);
+}
+
+template <class W>
+GTX_DEV uint32_t longest_of(AlignWorkspace const & ws, uint32_t n_paths) // :858-864
+{
+  uint32_t m = 0;
+  for (uint32_t i = 0; i < n_paths; ++i)
+  {
+    uint32_t const s = upath_size<W>(ws.paths[i]);
+    if (s > m)
+      m = s;
+  }
+  return m;
+}
+
+template <class W>
+GTX_DEV uint32_t remove_paths_with_too_many_mismatches(AlignWorkspace & ws, uint32_t n_paths) // :360-380
+{
+  if (n_paths == 0)
+    return 0;
+  uint32_t mn = 10;
+  for (uint32_t i = 0; i < n_paths; ++i)
+  {
+    uint32_t const m = GTX_U(static_cast<uint32_t>(ws.paths[i].mism));
+    if (m < mn)
+      mn = m;
+  }
+  PathSet drop;
+  for (uint32_t i = 0; i < n_paths; ++i)
+    if (GTX_U(static_cast<uint32_t>(ws.paths[i].mism)) > mn)
+      drop.set(i);
+  return compact_paths<W>(ws, n_paths, drop);
+}
+
+template <class W>
+GTX_DEV bool all_paths_unique(GraphView const & g, DPath const * paths, uint32_t n) // :219-231
+{
+  if (n < 2)
+    return true;
+  uint32_t const s0 = ug_ref_reach_pos<W>(g, GTX_U(paths[0].start)), e0 = ug_ref_reach_pos<W>(g, GTX_U(paths[0].end));
+  for (uint32_t i = 1; i < n; ++i)
+    if (s0 != ug_ref_reach_pos<W>(g, GTX_U(paths[i].start)) && e0 != ug_ref_reach_pos<W>(g, GTX_U(paths[i].end)))
+      return false;
+  return true;
+}
+
+template <class W>
+GTX_DEV bool path_is_reference(DPath const & p) // path.cpp:176-185
+{
+  uint32_t const nv = GTX_U(static_cast<uint32_t>(p.nvar));
+  for (uint32_t k = 0; k < nv; ++k)
+    if (!(GTX_U(p.v[k].mlo) & 1u))
+      return false;
+  return true;
+}
+
+template <class W>
+GTX_DEV uint32_t remove_non_ref_paths_when_read_matches_ref(GraphView const & g, AlignWorkspace & ws, uint32_t n_paths) // :460-474
+{
+  if (all_paths_unique<W>(g, ws.paths, n_paths))
+    return n_paths;
+  PathSet nonref;
+  for (uint32_t i = 0; i < n_paths; ++i)
+    if (!path_is_reference<W>(ws.paths[i]))
+      nonref.set(i);
+  if (nonref.count() == n_paths)
+    return n_paths; // no path supports only the reference
+  return compact_paths<W>(ws, n_paths, nonref);
+}
+
+template <class W>
+GTX_DEV uint32_t remove_fully_special_paths(GraphView const & g, AlignWorkspace & ws, uint32_t n_paths) // :476-481
+{
+  PathSet drop;
+  for (uint32_t i = 0; i < n_paths; ++i)
+    if (ug_ref_reach_pos<W>(g, GTX_U(ws.paths[i].start)) == ug_ref_reach_pos<W>(g, GTX_U(ws.paths[i].end)))
+      drop.set(i);
+  return compact_paths<W>(ws, n_paths, drop);
+}
+
+template <class W>
+GTX_DEV void remove_support_from_read_ends(GraphView const & g, AlignWorkspace & ws, uint32_t n_paths) // :382-432
+{
+  for (uint32_t i = 0; i < n_paths; ++i)
+  {
+    DPath & p = ws.paths[i];
+    uint32_t const nvar = GTX_U(static_cast<uint32_t>(p.nvar));
+    if (nvar == 0)
+      continue;
+    uint32_t const pstart = GTX_U(p.start), pend = GTX_U(p.end);
+    bool const ss = g_is_special(g, pstart), es = g_is_special(g, pend);
+    if (!ss && !es)
+      continue;
+    // std::minmax_element: first smallest, last largest
+    uint32_t imin = 0, imax = 0;
+    uint32_t omin = ug_site_order<W>(g, GTX_U(p.v[0].site)), omax = omin;
+    for (uint32_t k = 1; k < nvar; ++k)
+    {
+      uint32_t const o = ug_site_order<W>(g, GTX_U(p.v[k].site));
+      if (o < omin)
+      {
+        omin = o;
+        imin = k;
+      }
+      if (!(o < omax))
+      {
+        omax = o;
+        imax = k;
+      }
+    }
+    bool const clear_max = es && static_cast<int64_t>(ug_actual_pos<W>(g, pend)) <= static_cast<int64_t>(omax) + 4;
+    bool clear_min = false;
+    if (ss)
+    {
+      bool ambiguous = true;
+      if (g_is_special(g, pstart + 4u))
+        ambiguous = ug_ref_reach_pos<W>(g, pstart) != ug_ref_reach_pos<W>(g, pstart + 4u);
+      clear_min = ambiguous;
+    }
+    GTX_LEAD
+    {
+      if (clear_max)
+      {
+        p.v[imax].mlo = 0;
+        p.v[imax].mhi = 0;
+      }
+      if (clear_min)
+      {
+        p.v[imin].mlo = 0;
+        p.v[imin].mhi = 0;
+      }
+    }
+    W::lds_sync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GenotypePaths::walk_read_ends / walk_read_starts (genotype_paths.cpp:483-553 / 555-621)
+// ---------------------------------------------------------------------------------------------------------------
+template <class W>
+GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, uint32_t & n_paths, uint32_t & longest,
+                       uint32_t & status)
+{
+  uint32_t const L = GTX_U(ws.read_len);
+  if (n_paths == 0 || upath_size<W>(ws.paths[0]) == L)
+    return;
+  if (n_paths > MAX_SEED_NUMBER_FOR_WALKING)
+    return;
+  int maximum_mismatches = -1;
+  if (n_paths > MAX_SEED_NUMBER_ALLOWING_MISMATCHES)
+    maximum_mismatches = 0;
+  uint32_t best = 7;
+  uint32_t n_wl = 0, n_wlists = 0;
+  WalkBuffers & wb = ws.u.w;
+  for (uint32_t i = 0; i < n_paths; ++i)
+  {
+    DPath const & path = ws.paths[i];
+    uint32_t const prs = GTX_U(static_cast<uint32_t>(path.rs)), pre = GTX_U(static_cast<uint32_t>(path.re));
+    SubRead sr;
+    sr.rd = ws.rd;
+    if (starts)
+    {
+      if (prs == 0)
+        continue;
+      sr.begin = 0;
+      sr.len = prs + 1u;
+    }
+    else
+    {
+      if (pre == L - 1)
+        continue;
+      sr.begin = pre;
+      sr.len = L - pre;
+    }
+    uint32_t mm;
+    if (maximum_mismatches < 0)
+    {
+      uint32_t const budget = 2 + sr.len / 11;
+      mm = budget < best ? budget : best;
+    }
+    else
+      mm = static_cast<uint32_t>(maximum_mismatches);
+    uint32_t const anchor = GTX_U(starts ? path.start : path.end);
+    uint32_t nl;
+    // Shortcut for the common geometry: the anchor is an ordinary position inside a reference node and the sub-read
+    // fits in what is left of that node.  get_locations would return that single 'R' location and the walk a single
+    // sequence without ever reaching a variant site (graph.cpp:1232-1243 / 1484-1496), so the result is one id-less
+    // label or nothing -- computed here without going through the location / candidate tables.
+    bool shortcut = false;
+    if (!g_is_special(g, anchor) && anchor >= g.first_order && g.n_ref > 1)
+    {
+      uint32_t const rr = g_ref_node_at<W>(g, anchor);
+      uint32_t const ro = GTX_U(g.ref_order[rr]), rl = GTX_U(g.ref_len[rr]);
+      if (anchor < ro + rl)
+      {
+        uint32_t const offset = anchor - ro;
+        uint32_t const avail = starts ? offset + 1 : rl - offset;
+        if (avail >= sr.len)
+        {
+          shortcut = true;
+          uint8_t const * dna = reinterpret_cast<uint8_t const *>(g.dna) + GTX_U(g.ref_dna[rr]);
+          uint32_t const budget = mm;
+          uint32_t const got = starts ? cmp_codes<W, true>(sr, 0, dna, offset + 1, 0, budget)
+                                      : cmp_codes<W, false>(sr, 0, dna + offset, avail, 0, budget);
+          if (got <= budget)
+          {
+            mm = got;
+            nl = 1;
+            GTX_LEAD wb.dfs_out[0] = starts ? DevLabel{anchor - (sr.len - 1), anchor, INVALID, 0}
+                                            : DevLabel{anchor, anchor + (sr.len - 1), INVALID, 0};
+            W::lds_sync();
+          }
+          else
+            nl = 0;
+        }
+      }
+    }
+    if (!shortcut)
+    {
+      uint32_t const n_locs = get_locations<W>(g, anchor, path, wb.locs, AlignCfg::LOC_CAP, status);
+      W::lds_sync();
+      if (status)
+        return;
+      if (n_locs == 0 || n_locs > MAX_NUM_LOCATIONS_PER_PATH)
+        continue;
+      nl = iterative_dfs<W>(g, ws, n_locs, starts, sr, mm, status);
+      if (status)
+        return;
+    }
+    if (nl == 0)
+      continue;
+    if (mm < best)
+    {
+      n_wl = 0;
+      n_wlists = 0;
+      best = mm;
+    }
+    if (mm == best)
+    {
+      if (n_wlists >= AlignCfg::WLISTS || n_wl + nl > AlignCfg::WL_CAP)
+      {
+        status |= GTX_ST_DFS_OVERFLOW;
+        return;
+      }
+      for (uint32_t k = 0; k < nl; ++k)
+        copy_entry<W>(ws.wl[n_wl + k], wb.dfs_out[k]);
+      GTX_LEAD
+      {
+        ws.wl_idx[n_wlists] = starts ? prs : pre;
+        ws.wl_off[n_wlists] = n_wl;
+        ws.wl_off[n_wlists + 1] = n_wl + nl;
+      }
+      W::lds_sync();
+      n_wl += nl;
+      ++n_wlists;
+    }
+  }
+  for (uint32_t k = 0; k < n_wlists; ++k)
+  {
+    uint32_t const o0 = GTX_U(ws.wl_off[k]);
+    DevLabel const * ll = ws.wl + o0;
+    uint32_t const n = GTX_U(ws.wl_off[k + 1]) - o0;
+    uint32_t const idx = GTX_U(ws.wl_idx[k]);
+    if (starts)
+      add_kmer_labels<W>(ws, ll, n, 0, idx, best, true, n_paths, longest, status);
+    else
+      add_kmer_labels<W>(ws, ll, n, idx, L - 1, best, false, n_paths, longest, status);
+    if (status)
+      return;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k-mer keys (src/utilities/type_conversions.cpp:207-288) and index probes (src/index/ph_index.cpp:66-107)
+// ---------------------------------------------------------------------------------------------------------------
+
+// to_uint64_vec for a k-mer with ambiguous bases; sequential by nature (list order is the contract), leader only.
+// Returns the number of keys (0 = gave up, > 97 partial keys)
+// (keys are produced in plane form: appending base value b at base index t sets bit t of the low / high word)
+GTX_DEV uint32_t expand_keys(uint8_t const * rd, uint32_t at, uint64_t * keys)
+{
+  uint32_t n = 1;
+  keys[0] = 0;
+  for (uint32_t t = 0; t < K; ++t)
+  {
+    uint32_t const origin = n;
+    if (origin > 97)
+      return 0;
+    uint32_t const code = rd[at + t] & 15u;
+    auto with = [t](uint64_t k, uint64_t b) { return k | ((b & 1u) << t) | ((b >> 1) << (32 + t)); };
+    for (uint32_t u = 0; u < origin; ++u)
+    {
+      if (code == 15u || code == 0u)
+      {
+        keys[n++] = with(keys[u], 0);
+        keys[n++] = with(keys[u], 1);
+        keys[n++] = with(keys[u], 2);
+        keys[u] = with(keys[u], 3);
+      }
+      else
+      {
+        int left = __builtin_popcount(code);
+        uint64_t const base = keys[u];
+        for (uint32_t b = 0; b < 4; ++b)
+        {
+          if (!(code & (1u << b)))
+            continue;
+          if (left == 1)
+            keys[u] = with(base, b);
+          else
+            keys[n++] = with(base, b);
+          --left;
+        }
+      }
+    }
+  }
+  return n;
+}
+
+// Wave-parallel probe of a key list (`nkeys` keys: either keybuf[0..nkeys) or the 96 Hamming-1 neighbours of `base`
+// generated on the fly) with the multi_get rule: a list of more than one key whose hits total more than
+// max_index_labels yields nothing.  Labels land in ws.lbl in key order, bucket order inside a key (stable prefix-sum
+// compaction).  Returns the number of labels.
+template <class W>
+GTX_DEV uint32_t probe_list(IndexView const & ix, AlignWorkspace & ws, bool hamming, uint64_t base, uint32_t nkeys, uint32_t & status)
+{
+  uint32_t const rounds = (nkeys + 63) / 64;
+  uint64_t * kres = ws.u.keybuf; // key j is replaced by (offset | count << 32)
+  uint32_t total = 0;
+  for (uint32_t t = 0; t < rounds; ++t)
+  {
+    typename W::template PerLane<uint32_t> cnt;
+    W::lanes([&](uint32_t l) {
+      uint32_t const j = t * 64 + l;
+      uint32_t o = 0, c = 0;
+      if (j < nkeys)
+      {
+        // neighbour j of the reference's list (type_conversions.cpp:272-288): base 31 - j/3 changed by xor j%3 + 1
+        uint32_t const hb = 31u - j / 3u, hm = j % 3u + 1u;
+        uint64_t const key = hamming ? base ^ ((static_cast<uint64_t>(hm & 1u) << hb) | (static_cast<uint64_t>(hm >> 1) << (32u + hb)))
+                                     : kres[j];
+        index_find(ix, key, o, c);
+        kres[j] = static_cast<uint64_t>(o) | (static_cast<uint64_t>(c) << 32);
+      }
+      cnt[l] = c;
+    });
+    total += W::sum(cnt);
+  }
+  total = GTX_U(total);
+  W::lds_sync();
+  if (nkeys > 1 && total > ix.max_index_labels)
+    return 0; // ph_index.cpp:84-89
+  if (total > AlignCfg::LBL_CAP)
+  {
+    status |= GTX_ST_LABEL_OVERFLOW;
+    return 0;
+  }
+  if (total == 0)
+    return 0;
+  uint32_t done = 0;
+  for (uint32_t t = 0; t < rounds; ++t)
+  {
+    typename W::template PerLane<uint32_t> cnt, pre;
+    W::lanes([&](uint32_t l) {
+      uint32_t const j = t * 64 + l;
+      cnt[l] = j < nkeys ? static_cast<uint32_t>(kres[j] >> 32) : 0u;
+    });
+    uint32_t round_total;
+    W::excl_scan(cnt, pre, round_total);
+    if (round_total != 0)
+      W::lanes([&](uint32_t l) {
+        uint32_t const j = t * 64 + l;
+        uint32_t const c = cnt[l];
+        if (c != 0)
+        {
+          uint32_t const o = static_cast<uint32_t>(kres[j]);
+          for (uint32_t k = 0; k < c; ++k)
+            ws.lbl[done + pre[l] + k] = ix.labels[o + k];
+        }
+      });
+    done += round_total;
+  }
+  W::lds_sync();
+  return total;
+}
+
+// Orders the collected candidates ((label offset) | (label count << 32) | (j << 56) in ws.u.keybuf) by neighbour number,
+// applies the >max_index_labels rule of multi_get (ph_index.cpp:84-89; the list has 96 keys) and copies their labels to
+// ws.lbl.  Returns the number of labels.
+template <class W>
+GTX_DEV uint32_t hamming1_finish(IndexView const & ix, AlignWorkspace & ws, uint32_t ncand)
+{
+  uint64_t * cand = ws.u.keybuf;
+  if (ncand == 0)
+    return 0;
+  if (ncand > 1)
+  {
+    GTX_LEAD
+    {
+      for (uint32_t a = 1; a < ncand; ++a)
+      {
+        uint64_t const x = cand[a];
+        uint32_t b = a;
+        while (b > 0 && (cand[b - 1] >> 56) > (x >> 56))
+        {
+          cand[b] = cand[b - 1];
+          --b;
+        }
+        cand[b] = x;
+      }
+    }
+    W::lds_sync();
+  }
+  uint32_t total = 0;
+  for (uint32_t a = 0; a < ncand; ++a)
+    total += GTX_U(static_cast<uint32_t>(cand[a] >> 32)) & 0xFFFFFFu;
+  if (total > ix.max_index_labels)
+    return 0;
+  uint32_t done = 0;
+  for (uint32_t a = 0; a < ncand; ++a)
+  {
+    uint64_t const e = GTX_U(cand[a]);
+    uint32_t const off = static_cast<uint32_t>(e), cnt = static_cast<uint32_t>(e >> 32) & 0xFFFFFFu;
+    for (uint32_t b = 0; b < cnt; b += 64)
+      W::lanes([&](uint32_t l) {
+        if (b + l < cnt)
+          ws.lbl[done + b + l] = ix.labels[off + b + l];
+      });
+    done += cnt;
+  }
+  W::lds_sync();
+  return total;
+}
+
+// The Hamming-1 list of a unique exact key `q` (kmer_help_functions.cpp:97-119 + ph_index.cpp:66-107) without probing
+// the 96 neighbours: an indexed key at Hamming distance 1 differs from q in one base, so it agrees with q on the left
+// 16 bases or on the right 16 bases -- two bucket lookups find every candidate.  Candidates are put in the order the
+// reference visits them (neighbour j = 3*bb + m-1) before their labels are copied.  Returns false when a bucket is too
+// large for this route (the caller then probes the 96 keys directly); n_lbl is the number of labels placed in ws.lbl.
+template <class W>
+GTX_DEV bool hamming1_by_halves(IndexView const & ix, AlignWorkspace & ws, uint64_t q, uint32_t & n_lbl)
+{
+  uint32_t o[2], c[2];
+  half_find(ix, half_key(q, 0), o[0], c[0]);
+  half_find(ix, half_key(q, 1), o[1], c[1]);
+  if (c[0] > ix.half_bucket_cap || c[1] > ix.half_bucket_cap)
+    return false;
+  uint64_t * cand = ws.u.keybuf;
+  uint32_t ncand = 0;
+  for (uint32_t side = 0; side < 2; ++side)
+  {
+    uint32_t const cs = c[side], os = o[side];
+    if (cs == 0)
+      continue;
+    typename W::template PerLane<uint32_t> valid, pre;
+    typename W::template PerLane<uint64_t> packed;
+    W::lanes([&](uint32_t l) {
+      uint32_t ok = 0, j = 0;
+      uint64_t pk = 0;
+      if (l < cs)
+      {
+        HalfEntry const e = ix.hlist[os + l];
+        if (hamming1_neighbour(e.key, q, j))
+        {
+          ok = 1;
+          pk = static_cast<uint64_t>(e.off) | (static_cast<uint64_t>(e.cnt) << 32) | (static_cast<uint64_t>(j) << 56);
+        }
+      }
+      valid[l] = ok;
+      packed[l] = pk;
+    });
+    uint32_t nv;
+    W::excl_scan(valid, pre, nv);
+    if (nv != 0)
+      W::lanes([&](uint32_t l) {
+        if (valid[l])
+          cand[ncand + pre[l]] = packed[l];
+      });
+    ncand += nv;
+  }
+  W::lds_sync();
+  n_lbl = hamming1_finish<W>(ix, ws, ncand);
+  return true;
+}
+
+// Same list from the bucket entries that were fetched up front (ws.he): at most 2*HE_CAP entries, wave-uniform code
+template <class W>
+GTX_DEV uint32_t hamming1_from_cache(IndexView const & ix, AlignWorkspace & ws, uint32_t i, uint64_t q)
+{
+  uint64_t * cand = ws.u.keybuf;
+  uint32_t ncand = 0;
+  for (uint32_t side = 0; side < 2; ++side)
+  {
+    uint32_t const cs = GTX_U(ws.hcnt[i][side]);
+    for (uint32_t e = 0; e < cs; ++e)
+    {
+      uint32_t j;
+      if (hamming1_neighbour(GTX_U(ws.he[i][side][e].key), q, j))
+      {
+        uint64_t const pk = static_cast<uint64_t>(ws.he[i][side][e].off) | (static_cast<uint64_t>(ws.he[i][side][e].cnt) << 32) |
+                            (static_cast<uint64_t>(j) << 56);
+        GTX_LEAD cand[ncand] = pk;
+        ++ncand;
+      }
+    }
+  }
+  if (ncand == 0)
+    return 0;
+  W::lds_sync();
+  return hamming1_finish<W>(ix, ws, ncand);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// one (read, orientation): find_genotype_paths_of_one_of_the_sequences (alignment.cpp:23-103)
+// ---------------------------------------------------------------------------------------------------------------
+// Leaves the paths in ws.paths; returns the status bits (non-zero = a table overflowed, the paths are not valid).
+template <class W>
+GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWorkspace & ws, uint8_t const * seq4, uint32_t len,
+                             bool reverse, uint32_t & n_paths_out, uint32_t & longest_out)
+{
+  GTX_PROF_BEGIN
+  // -- load the read: BAM nibbles -> one code per byte; the reverse orientation is the reverse complement, and
+  //    complementing an IUPAC code is reversing its 4 bits (A<->T, C<->G)
+  for (uint32_t base = 0; base < len; base += 64)
+    W::lanes([&](uint32_t l) {
+      uint32_t const i = base + l;
+      if (i < len)
+      {
+        uint32_t const src = reverse ? (len - 1 - i) : i;
+        uint32_t c = (seq4[src >> 1] >> ((~src & 1u) << 2)) & 15u;
+        if (c == 0)
+          c = 15; // '=' assigned to a seqan Iupac becomes N (hts_parallel_reader.cpp:226-243)
+        if (reverse)
+          c = ((c & 1u) << 3) | ((c & 2u) << 1) | ((c & 4u) >> 1) | ((c & 8u) >> 3);
+        ws.rd[i] = static_cast<uint8_t>(c);
+      }
+    });
+  GTX_LEAD ws.read_len = len;
+  W::lds_sync();
+  GTX_PROF_TICK(0)
+
+  uint32_t n_paths = 0, longest = 0, status = 0;
+  uint32_t const n_k = len < K ? 0 : 1 + (len - K) / (K - 1); // kmer_help_functions.cpp:10-17
+  // -- exact keys of every k-mer.  Unambiguous k-mer: lanes 0..31 each hold one base, two ballots give the low/high
+  //    bit planes, interleaving them gives the key (first base in the top bits, type_conversions.cpp:75-87).
+  for (uint32_t i = 0; i < n_k; ++i)
+  {
+    typename W::template PerLane<bool> amb_l, b0_l, b1_l;
+    W::lanes([&](uint32_t l) {
+      uint32_t const c = l < K ? ws.rd[(K - 1) * i + l] : 1u;
+      bool const single = (c & (c - 1u)) == 0u && c != 0u;
+      uint32_t const two = (c == 2u) ? 1u : (c == 4u) ? 2u : (c == 8u) ? 3u : 0u;
+      amb_l[l] = !single;
+      b0_l[l] = l < K && (two & 1u);
+      b1_l[l] = l < K && (two & 2u);
+    });
+    uint64_t const amb = W::ballot(amb_l);
+    uint32_t const b0 = static_cast<uint32_t>(W::ballot(b0_l)), b1 = static_cast<uint32_t>(W::ballot(b1_l));
+    uint64_t const key = (static_cast<uint64_t>(b1) << 32) | b0; // plane form (gtx_flat.hpp: plane_key)
+    GTX_LEAD
+    {
+      ws.key0[i] = key;
+      ws.nkeys0[i] = amb == 0 ? 1 : 2; // 2 = "not a single key"; that list is generated when the k-mer is processed
+      ws.cnt0[i] = 0;
+    }
+  }
+  W::lds_sync();
+  // -- all index lookups of the read at once, one per lane, so that their memory latencies overlap:
+  //    lane 3i: exact key of k-mer i (PHIndex::get), lanes 3i+1 / 3i+2: its left / right half-key bucket
+  uint32_t const kc = n_k < AlignCfg::KC ? n_k : AlignCfg::KC;
+  bool const use_halves = ix.half_bucket_cap != 0;
+  W::lanes([&](uint32_t l) {
+    uint32_t const i = l / 3, w = l % 3;
+    if (l < 3 * n_k && ws.nkeys0[i] == 1 && (w == 0 || (i < kc && use_halves)))
+    {
+      uint64_t const q = ws.key0[i];
+      uint32_t off, cnt;
+      bucket_find(w == 0 ? ix.slots : ix.hslots, w == 0 ? ix.log2_cap : ix.h_log2_cap, w == 0 ? q : half_key(q, w - 1), off, cnt);
+      uint32_t * o = w == 0 ? &ws.off0[i] : &ws.hoff[i][w - 1];
+      uint32_t * c = w == 0 ? &ws.cnt0[i] : &ws.hcnt[i][w - 1];
+      *o = off;
+      *c = cnt;
+    }
+  });
+  W::lds_sync();
+  // -- ... and everything those lookups point at that is small enough to be staged: bucket entries and exact labels
+  W::lanes([&](uint32_t l) {
+    // both kinds of staged entry are 16 bytes: one predicated 16-byte copy per lane
+    constexpr uint32_t NH = 2 * AlignCfg::HE_CAP;
+    bool const is_half = l < AlignCfg::KC * NH;
+    uint32_t const m = is_half ? l : l - AlignCfg::KC * NH;
+    uint32_t const per = is_half ? NH : AlignCfg::XL_CAP;
+    uint32_t const i = m / per, e = is_half ? m % AlignCfg::HE_CAP : m % AlignCfg::XL_CAP;
+    uint32_t const side = (m / AlignCfg::HE_CAP) % 2;
+    if (l < AlignCfg::KC * (NH + AlignCfg::XL_CAP) && i < kc && ws.nkeys0[i] == 1 && (!is_half || use_halves))
+    {
+      uint32_t const cnt = is_half ? ws.hcnt[i][side] : ws.cnt0[i];
+      uint32_t const off = is_half ? ws.hoff[i][side] : ws.off0[i];
+      if (cnt <= (is_half ? AlignCfg::HE_CAP : AlignCfg::XL_CAP) && e < cnt)
+      {
+        static_assert(sizeof(HalfEntry) == 16 && sizeof(DevLabel) == 16, "staged entries are copied as 16-byte words");
+        uint4_t const * src = is_half ? reinterpret_cast<uint4_t const *>(ix.hlist + off + e) : reinterpret_cast<uint4_t const *>(ix.labels + off + e);
+        uint4_t * dst = is_half ? reinterpret_cast<uint4_t *>(&ws.he[i][side][e]) : reinterpret_cast<uint4_t *>(&ws.xl[i][e]);
+        *dst = *src;
+      }
+    }
+  });
+  static_assert(AlignCfg::KC * (2 * AlignCfg::HE_CAP + AlignCfg::XL_CAP) <= 64, "staging needs one lane per entry");
+  W::lds_sync();
+  // -- stop if every k-mer is extremely common (alignment.cpp:35-49); only single-key lists can reach 512 labels
+  bool all_common = n_k > 0;
+  for (uint32_t i = 0; i < n_k; ++i)
+    if (!(GTX_U(ws.nkeys0[i]) == 1 && GTX_U(ws.cnt0[i]) >= MAX_UNIQUE_KMER_POSITIONS))
+      all_common = false;
+  GTX_PROF_TICK(1)
+
+  if (!all_common && n_k > 0)
+  {
+    for (uint32_t i = 0; i < n_k && !status; ++i)
+    {
+      uint32_t const rs = (K - 1) * i, re = rs + (K - 1);
+      bool const single = GTX_U(ws.nkeys0[i]) == 1;
+      uint32_t n_lbl;
+      DevLabel const * exact_labels = ws.lbl;
+      if (single)
+      {
+        // exact list: one key, never cut (ph_index.cpp:84)
+        uint32_t const cnt = GTX_U(ws.cnt0[i]), off = GTX_U(ws.off0[i]);
+        n_lbl = cnt;
+        if (cnt > AlignCfg::LBL_CAP)
+        {
+          status |= GTX_ST_LABEL_OVERFLOW;
+          break;
+        }
+        if (i < kc && cnt <= AlignCfg::XL_CAP)
+          exact_labels = ws.xl[i]; // staged up front
+        else
+        {
+          for (uint32_t b = 0; b < cnt; b += 64)
+            W::lanes([&](uint32_t l) {
+              if (b + l < cnt)
+                ws.lbl[b + l] = ix.labels[off + b + l];
+            });
+          W::lds_sync();
+        }
+      }
+      else
+      {
+        uint32_t nk = 0;
+        GTX_LEAD
+        {
+          nk = expand_keys(ws.rd, rs, ws.u.keybuf);
+          ws.n_keys = nk;
+        }
+        W::lds_sync();
+        nk = GTX_U(ws.n_keys);
+        n_lbl = probe_list<W>(ix, ws, false, 0, nk, status);
+        if (status)
+          break;
+      }
+      GTX_PROF_TICK(2)
+      add_kmer_labels<W>(ws, exact_labels, n_lbl, rs, re, 0, false, n_paths, longest, status);
+      GTX_PROF_TICK(3)
+      if (status)
+        break;
+      // Hamming-1 list: the 96 neighbours of a unique exact key, else the exact list again
+      // (kmer_help_functions.cpp:97-119 keeps multi-key lists as they are, so ws.lbl is already what multi_get returns)
+      if (single)
+      {
+        uint64_t const q = GTX_U(ws.key0[i]);
+        if (i < kc && use_halves && n_lbl > 0 && GTX_U(ws.hcnt[i][0]) == 1 && GTX_U(ws.hcnt[i][1]) == 1)
+          n_lbl = 0; // q is indexed, so it is the one key in each of its half-key buckets: no neighbour exists
+        else if (i < kc && use_halves && GTX_U(ws.hcnt[i][0]) <= AlignCfg::HE_CAP && GTX_U(ws.hcnt[i][1]) <= AlignCfg::HE_CAP)
+          n_lbl = hamming1_from_cache<W>(ix, ws, i, q);
+        else if (!use_halves || !hamming1_by_halves<W>(ix, ws, q, n_lbl))
+          n_lbl = probe_list<W>(ix, ws, true, q, 96, status);
+        if (status)
+          break;
+      }
+      GTX_PROF_TICK(4)
+      add_kmer_labels<W>(ws, ws.lbl, n_lbl, rs, re, 1, false, n_paths, longest, status);
+      GTX_PROF_TICK(5)
+    }
+    if (!status)
+    {
+      n_paths = remove_short_paths<W>(ws, n_paths, longest);
+      walk_read<W>(g, ws, true, n_paths, longest, status);
+      GTX_PROF_TICK(6)
+      if (!status)
+        walk_read<W>(g, ws, false, n_paths, longest, status);
+      GTX_PROF_TICK(7)
+      if (!status)
+      {
+        longest = longest_of<W>(ws, n_paths);
+        n_paths = remove_short_paths<W>(ws, n_paths, longest);
+        n_paths = remove_paths_with_too_many_mismatches<W>(ws, n_paths);
+        if (g.is_sv_graph)
+          n_paths = remove_fully_special_paths<W>(g, ws, n_paths);
+        n_paths = remove_non_ref_paths_when_read_matches_ref<W>(g, ws, n_paths);
+        longest = longest_of<W>(ws, n_paths);
+        n_paths = remove_short_paths<W>(ws, n_paths, longest);
+        if (g.is_sv_graph)
+          remove_support_from_read_ends<W>(g, ws, n_paths);
+      }
+    }
+  }
+
+  GTX_PROF_TICK(8)
+#ifdef GTX_PROF
+  GTX_LEAD W::atomic_add_u64(g.prof + 15, 1);
+#endif
+  n_paths_out = n_paths;
+  longest_out = longest;
+  return status;
+}
+
+// words of the result record of the paths in ws.paths (layout: include/gtx.h, gtx_align_batch)
+template <class W>
+GTX_DEV uint32_t record_size(AlignWorkspace const & ws, uint32_t n_paths)
+{
+  uint32_t w = 2;
+  for (uint32_t i = 0; i < n_paths; ++i)
+    w += 4 + 3 * GTX_U(static_cast<uint32_t>(ws.paths[i].nvar));
+  return w;
+}
+
+// path part of the record (words 2..); `body` has room for record_size() - 2 words
+template <class W>
+GTX_DEV void write_record_body(AlignWorkspace const & ws, uint32_t n_paths, uint32_t * body)
+{
+  uint32_t w = 0;
+  for (uint32_t i = 0; i < n_paths; ++i)
+  {
+    DPath const & p = ws.paths[i];
+    uint32_t const nvar = GTX_U(static_cast<uint32_t>(p.nvar));
+    uint32_t const * src = reinterpret_cast<uint32_t const *>(&p);
+    uint32_t const nw = 4 + 3 * nvar;
+    W::lanes([&](uint32_t l) {
+      for (uint32_t x = l; x < nw; x += 64)
+      {
+        uint32_t v = src[x];
+        if (x == 3)
+          v = static_cast<uint32_t>(p.mism) | (nvar << 16);
+        body[w + x] = v;
+      }
+    });
+    w += nw;
+  }
+}
+
+// one (read, orientation) of the main pass: result into its record slot
+template <class W>
+GTX_DEV uint32_t align_one(GraphView const & g, IndexView const & ix, AlignWorkspace & ws, uint8_t const * seq4, uint32_t len,
+                           bool reverse, uint32_t * rec, uint32_t rec_words)
+{
+  uint32_t np = 0, longest = 0;
+  uint32_t status = align_paths<W>(g, ix, ws, seq4, len, reverse, np, longest);
+  if (status)
+    np = 0;
+  else if (record_size<W>(ws, np) > rec_words)
+  {
+    status = GTX_ST_RECORD_OVERFLOW;
+    np = 0;
+  }
+  GTX_PROF_BEGIN
+  write_record_body<W>(ws, np, rec + 2);
+  GTX_LEAD
+  {
+    rec[0] = np | (status << 16);
+    rec[1] = (np == 0 ? 0 : longest) | (len << 16);
+  }
+  W::lds_sync();
+  GTX_PROF_TICK(9)
+  return status;
+}

@@ -1,0 +1,264 @@
+// graph_dev.hpp -- device-side helpers that do not depend on the kernel's table sizes: graph / special-position
+// lookups, the bucketed index tables, half keys, wave-policy macros.  (Split from align_core: see align_core.hpp.)
+//
+// What the reference does per read (src/typer/alignment.cpp:23-103, find_genotype_paths_of_one_of_the_sequences) with
+// heap containers, restated over fixed tables in LDS.
+//
+// Execution style ("wave-uniform + lane lambdas"): all 64 lanes run the same control flow on the same values (state
+// lives in LDS, scalars are replicated), LDS writes are done by the leader lane only, and the data-parallel pieces --
+// read unpacking, 2-bit key assembly, the 97 index probes per k-mer, stable hit compaction, character comparison of a
+// read against graph sequence, table copies -- are expressed as lambdas over the lane index plus wave primitives
+// (ballot, exclusive scan).  A policy type W supplies those primitives: WaveHip (gtx_api.hip) maps them to the
+// hardware; tests/emu supplies a sequential stand-in so the very same source can be debugged without a GPU.
+#pragma once
+#include <cstdint>
+
+#include "gtx_flat.hpp"
+
+#if defined(__HIPCC__)
+#define GTX_DEV __device__ inline
+#else
+#define GTX_DEV inline
+#endif
+
+namespace gtx
+{
+// include/graphtyper/constants.hpp.in:43-48
+constexpr uint32_t MAX_UNIQUE_KMER_POSITIONS = 512;
+constexpr uint32_t MAX_SEED_NUMBER_ALLOWING_MISMATCHES = 64;
+constexpr uint32_t MAX_SEED_NUMBER_FOR_WALKING = 256;
+constexpr uint32_t MAX_NUM_LOCATIONS_PER_PATH = 256;
+
+// graph sequence is stored as codes: IUPAC letters keep their 4-bit BAM code (A=1 C=2 G=4 T=8 N=15), '<' and '>'
+// (SV breakpoint tags, graph_utils.hpp:20-23) become DNA_KILL, anything else DNA_OTHER (equal to no read character)
+constexpr uint8_t DNA_KILL = 0x80, DNA_OTHER = 0x40;
+
+struct alignas(16) uint4_t // 16-byte move
+{
+  uint32_t x, y, z, w;
+};
+
+#define GTX_LEAD if (W::leader())
+
+// Values that are equal on all lanes by construction (loaded from LDS state or from graph tables at a uniform address)
+// are moved to scalar registers: control flow on them then compiles to scalar branches instead of exec-mask juggling.
+#define GTX_U(x) W::uni(x)
+
+// phase timing (profiling build only: make -C graphtyper_amd/csrc prof -> libgtx_prof.so)
+#ifdef GTX_PROF
+#define GTX_PROF_BEGIN unsigned long long _pt = W::clock();
+#define GTX_PROF_TICK(k)                                   \
+  {                                                        \
+    unsigned long long const _pn = W::clock();             \
+    GTX_LEAD W::atomic_add_u64(g.prof + (k), _pn - _pt);   \
+    _pt = W::clock();                                      \
+  }
+#else
+#define GTX_PROF_BEGIN
+#define GTX_PROF_TICK(k)
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// graph helpers
+// ---------------------------------------------------------------------------------------------------------------
+GTX_DEV bool g_is_special(GraphView const & g, uint32_t pos)
+{
+  return pos >= SPECIAL_START && (pos - SPECIAL_START) < g.n_special; // graph.cpp:1784-1787
+}
+
+GTX_DEV uint32_t g_ref_reach_pos(GraphView const & g, uint32_t pos)
+{
+  return g_is_special(g, pos) ? g.special_ref_reach[pos - SPECIAL_START] : pos; // graph.cpp:1789-1795
+}
+
+GTX_DEV uint32_t g_actual_pos(GraphView const & g, uint32_t pos)
+{
+  return g_is_special(g, pos) ? g.special_actual[pos - SPECIAL_START] : pos; // graph.cpp:1797-1803
+}
+
+// Graph::get_special_pos for a position inside an allele of `site` (graph.cpp:1775-1782); identity up to the
+// reference allele's reach.
+GTX_DEV uint32_t g_special_of(GraphView const & g, uint32_t site, uint32_t pos)
+{
+  uint32_t const rr = g.site_ref_reach[site];
+  return pos > rr ? SPECIAL_START + g.site_special_base[site] + (pos - rr - 1) : pos;
+}
+
+GTX_DEV uint32_t site_order(GraphView const & g, uint32_t site)
+{
+  return g.ref_order[site] + g.ref_len[site]; // order of the site's variant nodes
+}
+
+// wave-uniform variants of the helpers above (arguments uniform, results in scalar registers)
+template <class W>
+GTX_DEV uint32_t ug_ref_reach_pos(GraphView const & g, uint32_t pos)
+{
+  return g_is_special(g, pos) ? GTX_U(g.special_ref_reach[pos - SPECIAL_START]) : pos;
+}
+
+template <class W>
+GTX_DEV uint32_t ug_actual_pos(GraphView const & g, uint32_t pos)
+{
+  return g_is_special(g, pos) ? GTX_U(g.special_actual[pos - SPECIAL_START]) : pos;
+}
+
+template <class W>
+GTX_DEV uint32_t ug_special_of(GraphView const & g, uint32_t site, uint32_t pos)
+{
+  uint32_t const rr = GTX_U(g.site_ref_reach[site]);
+  return pos > rr ? SPECIAL_START + GTX_U(g.site_special_base[site]) + (pos - rr - 1) : pos;
+}
+
+template <class W>
+GTX_DEV uint32_t ug_site_order(GraphView const & g, uint32_t site)
+{
+  return GTX_U(g.ref_order[site]) + GTX_U(g.ref_len[site]);
+}
+
+// last reference node whose order is <= pos (the `rr` of graph.cpp:950-955); pos >= first_order required
+template <class W>
+GTX_DEV uint32_t g_ref_node_at(GraphView const & g, uint32_t pos)
+{
+  uint32_t b = (pos - g.first_order) >> POS_BUCKET_SHIFT;
+  if (b >= g.n_bucket)
+    b = g.n_bucket - 1;
+  uint32_t r = GTX_U(g.pos_bucket[b]);
+  while (r + 1 < g.n_ref && GTX_U(g.ref_order[r + 1]) <= pos)
+    ++r;
+  return r;
+}
+
+// word-wise LDS -> LDS copy of a table entry, one word per lane
+template <class W, class T>
+GTX_DEV void copy_entry(T & dst, T const & src)
+{
+  static_assert(sizeof(T) % 4 == 0, "entries are copied word-wise");
+  if (&dst == &src)
+    return;
+  uint32_t * d = reinterpret_cast<uint32_t *>(&dst);
+  uint32_t const * s = reinterpret_cast<uint32_t const *>(&src);
+  W::lanes([&](uint32_t l) {
+    if constexpr (sizeof(T) / 4 <= 64)
+    {
+      if (l < sizeof(T) / 4)
+        d[l] = s[l];
+    }
+    else
+      for (uint32_t w = l; w < sizeof(T) / 4; w += 64) // the second pass' entries are longer than one wave
+        d[w] = s[w];
+  });
+  W::lds_sync();
+}
+
+// small fixed bit set held in registers (one word for the main pass' table sizes)
+template <uint32_t N>
+struct BitSet
+{
+  static constexpr uint32_t WORDS = (N + 63) / 64;
+  uint64_t w[WORDS];
+  GTX_DEV BitSet()
+  {
+    for (uint32_t i = 0; i < WORDS; ++i)
+      w[i] = 0;
+  }
+  GTX_DEV void set(uint32_t i)
+  {
+    if constexpr (WORDS == 1)
+      w[0] |= 1ull << i;
+    else
+      for (uint32_t k = 0; k < WORDS; ++k) // no dynamic indexing: keeps the words in registers
+        w[k] |= (k == (i >> 6)) ? (1ull << (i & 63u)) : 0ull;
+  }
+  GTX_DEV bool get(uint32_t i) const
+  {
+    if constexpr (WORDS == 1)
+      return (w[0] >> i) & 1ull;
+    else
+    {
+      uint64_t v = 0;
+      for (uint32_t k = 0; k < WORDS; ++k)
+        v |= (k == (i >> 6)) ? w[k] : 0ull;
+      return (v >> (i & 63u)) & 1ull;
+    }
+  }
+  GTX_DEV bool any() const
+  {
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < WORDS; ++i)
+      v |= w[i];
+    return v != 0;
+  }
+  GTX_DEV uint32_t count() const
+  {
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < WORDS; ++i)
+      c += static_cast<uint32_t>(__builtin_popcountll(w[i]));
+    return c;
+  }
+};
+
+// lookup in a bucketed table (gtx_flat.hpp: BUCKET_SLOTS): the whole 64-byte bucket is fetched at once
+GTX_DEV void bucket_find(IndexSlot const * slots, uint32_t log2_buckets, uint64_t key, uint32_t & off, uint32_t & cnt)
+{
+  uint64_t const mask = (1ull << log2_buckets) - 1;
+  for (uint64_t b = hash_key(key, log2_buckets);; b = (b + 1) & mask)
+  {
+    IndexSlot const * p = slots + b * BUCKET_SLOTS;
+    IndexSlot const s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
+    bool const m0 = s0.cnt != 0 && s0.key == key, m1 = s1.cnt != 0 && s1.key == key;
+    bool const m2 = s2.cnt != 0 && s2.key == key, m3 = s3.cnt != 0 && s3.key == key;
+    off = m0 ? s0.off : m1 ? s1.off : m2 ? s2.off : m3 ? s3.off : 0u;
+    cnt = m0 ? s0.cnt : m1 ? s1.cnt : m2 ? s2.cnt : m3 ? s3.cnt : 0u;
+    // slots fill front to back: an empty last slot means nothing ever spilled out of this bucket
+    if (m0 || m1 || m2 || m3 || s3.cnt == 0)
+      return;
+  }
+}
+
+// PHIndex lookup of one key: (offset, count) of its labels, count 0 when absent
+GTX_DEV void index_find(IndexView const & ix, uint64_t key, uint32_t & off, uint32_t & cnt)
+{
+  bucket_find(ix.slots, ix.log2_cap, key, off, cnt);
+}
+
+// bucket of a half key (see IndexView::hslots): (offset, count) into hlist, count 0 when the half does not occur
+GTX_DEV void half_find(IndexView const & ix, uint64_t hk, uint32_t & off, uint32_t & cnt)
+{
+  bucket_find(ix.hslots, ix.h_log2_cap, hk, off, cnt);
+}
+
+// table key of the bucket holding every indexed k-mer with the same 16 first (side 0) / last (side 1) bases as q
+GTX_DEV uint64_t half_key(uint64_t q, uint32_t side)
+{
+  uint32_t const lo = static_cast<uint32_t>(q), hi = static_cast<uint32_t>(q >> 32);
+  uint64_t const half = side == 0 ? ((lo & 0xFFFFu) | ((hi & 0xFFFFu) << 16)) : ((lo >> 16) | (hi & 0xFFFF0000u));
+  return half | (static_cast<uint64_t>(side) << 32);
+}
+
+constexpr uint32_t HALF_BUCKET_CAP = 64; // one lane per bucket entry; larger buckets (low-complexity sequence) use the 96 direct probes
+
+// Candidate test shared by both routes below: is `key` at Hamming distance exactly 1 from q, and which neighbour is it?
+// (plane-form keys; the reference numbers neighbours by bb = position counted from the LAST base and m = xor of the
+// 2-bit code, j = 3*bb + m-1, type_conversions.cpp:272-288)
+GTX_DEV bool hamming1_neighbour(uint64_t key, uint64_t q, uint32_t & j)
+{
+  uint64_t const x = key ^ q;
+  uint32_t const d0 = static_cast<uint32_t>(x), d1 = static_cast<uint32_t>(x >> 32);
+  uint32_t const bases = d0 | d1; // one bit per differing base
+  if (bases == 0 || (bases & (bases - 1)) != 0)
+    return false;
+  uint32_t const b = static_cast<uint32_t>(__builtin_ctz(bases));
+  uint32_t const m = ((d0 >> b) & 1u) | (((d1 >> b) & 1u) << 1);
+  j = 3u * (31u - b) + m - 1u;
+  return true;
+}
+
+// align_read (alignment.cpp:331-363): which orientations a record gets
+GTX_DEV bool needs_reverse(gtx_read_meta const & m, bool force_both)
+{
+  bool const one = (m.flag & 1u) == 0u || (m.tid == m.mtid && m.isize > -1200 && m.isize < 1200 &&
+                                           (((m.flag & 16u) != 0u) != ((m.flag & 32u) != 0u)));
+  return !one || force_both;
+}
+
+} // namespace gtx

@@ -13,6 +13,7 @@
 #include <string>
 
 #include "gtx_ctx.hpp"
+#include "align_core.hpp"
 #include "score_core.hpp"
 
 namespace gtx
@@ -83,6 +84,13 @@ struct WaveHip
   static __device__ inline void atomic_add_u64(unsigned long long * p, unsigned long long v) { atomicAdd(p, v); }
 };
 
+// Second pass: the workspace is in global memory, so the leader's stores must have completed (vmcnt) before the other
+// lanes load them; the workgroup barrier of a one-wave workgroup is exactly that wait.
+struct WaveHipMem : WaveHip
+{
+  static __device__ inline void lds_sync() { __syncthreads(); }
+};
+
 #ifndef GTX_TASK_CHUNK
 #define GTX_TASK_CHUNK 16
 #endif
@@ -91,7 +99,9 @@ constexpr uint32_t TASK_CHUNK = GTX_TASK_CHUNK; // reads a wave claims per visit
 __global__ __launch_bounds__(64) void gtx_align_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
                                                        uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
                                                        uint32_t n_reads, uint32_t * __restrict__ records, uint32_t rec_words,
-                                                       uint32_t force_both, uint32_t * task_counter)
+                                                       uint32_t force_both, uint32_t * task_counter,
+                                                       uint32_t * __restrict__ big_tasks, uint32_t big_task_cap,
+                                                       uint32_t * big_state, uint32_t force_big)
 {
   __shared__ AlignWorkspace ws;
   __shared__ uint32_t task_base;
@@ -132,21 +142,121 @@ __global__ __launch_bounds__(64) void gtx_align_kernel(GraphView g, IndexView ix
           }
           continue;
         }
-        align_one<WaveHip>(g, ix, ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words);
+        uint32_t const st =
+          align_one<WaveHip>(g, ix, ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words);
+        // a table of this pass overflowed: queue the task for the second pass (gtx_align_big_kernel)
+        if (big_tasks && ((st & (GTX_ST_LABEL_OVERFLOW | GTX_ST_PATH_OVERFLOW | GTX_ST_DFS_OVERFLOW | GTX_ST_RECORD_OVERFLOW)) || force_big) &&
+            (threadIdx.x & 63u) == 0)
+        {
+          uint32_t const slot = atomicAdd(big_state, 1u);
+          if (slot < big_task_cap)
+            big_tasks[slot] = read * 2 + orient;
+          else
+            atomicAdd(big_state + 3, 1u);
+        }
       }
+    }
+  }
+}
+
+// Second pass over the queued (read, orientation) tasks: same algorithm instantiated over tables large enough for what
+// the reference's own limits admit; one workspace in HBM per workgroup.  The queue is usually empty or tiny.
+__global__ __launch_bounds__(64) void gtx_align_big_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
+                                                           uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
+                                                           uint32_t * __restrict__ records, uint32_t rec_words,
+                                                           uint32_t const * __restrict__ big_tasks, uint32_t big_task_cap,
+                                                           uint32_t * big_state, big::AlignWorkspace * workspaces,
+                                                           uint32_t * __restrict__ arena, unsigned long long arena_words)
+{
+  __shared__ unsigned long long slot;
+  big::AlignWorkspace & ws = workspaces[blockIdx.x];
+  uint32_t const queued = big_state[0] < big_task_cap ? big_state[0] : big_task_cap;
+  for (;;)
+  {
+    if ((threadIdx.x & 63u) == 0)
+      slot = atomicAdd(big_state + 1, 1u);
+    __syncthreads();
+    uint32_t const t = static_cast<uint32_t>(slot);
+    __syncthreads();
+    if (t >= queued)
+      break;
+    uint32_t const task = big_tasks[t], read = task >> 1, orient = task & 1u;
+    uint32_t const len = meta[read].l_qseq;
+    uint32_t * rec = records + static_cast<uint64_t>(task) * rec_words;
+    uint32_t np = 0, longest = 0, ext = 0;
+    uint32_t status = big::align_paths<WaveHipMem>(g, ix, ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest);
+    uint32_t * body = rec + 2;
+    unsigned long long off = 0;
+    if (status)
+      np = 0;
+    else
+    {
+      uint32_t const size = big::record_size<WaveHipMem>(ws, np);
+      if (size > rec_words)
+      {
+        // long record: reserve room in the arena; the slot keeps the header and the offset
+        if ((threadIdx.x & 63u) == 0)
+          slot = atomicAdd(reinterpret_cast<unsigned long long *>(big_state + 4), static_cast<unsigned long long>(size - 2));
+        __syncthreads();
+        off = slot;
+        __syncthreads();
+        if (off + (size - 2) > arena_words || off + (size - 2) > 0xFFFFFFFFull)
+        {
+          status = GTX_ST_RECORD_OVERFLOW;
+          np = 0;
+        }
+        else
+        {
+          body = arena + off;
+          ext = GTX_ST_EXTERNAL;
+        }
+      }
+    }
+    big::write_record_body<WaveHipMem>(ws, np, body);
+    if ((threadIdx.x & 63u) == 0)
+    {
+      rec[0] = np | ((status | ext) << 16);
+      rec[1] = (np == 0 ? 0 : longest) | (len << 16);
+      if (ext)
+        rec[2] = static_cast<uint32_t>(off);
     }
   }
 }
 
 __global__ __launch_bounds__(256) void gtx_score_kernel(GraphView g, ScoreParams par, gtx_score_item const * __restrict__ items,
                                                         uint32_t n_items, uint32_t const * __restrict__ records,
-                                                        uint32_t rec_words, ScoreAcc acc, uint32_t * error_flag)
+                                                        uint32_t rec_words, ScoreAcc acc, uint32_t * error_flag,
+                                                        uint32_t * __restrict__ big_queue, uint32_t big_queue_cap,
+                                                        uint32_t * big_state)
 {
   uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_items)
     return;
   gtx_score_item const it = items[i];
-  score_item<WaveHip>(g, par, it, records, rec_words, acc, error_flag);
+  RecentHap r1[SCORE_MAX_HAPS], r2[SCORE_MAX_HAPS];
+  if (score_item<WaveHip>(g, par, it, records, rec_words, acc, r1, r2, SCORE_MAX_HAPS))
+    return;
+  // a read of this item touches more variant sites than the tables above hold (long results of the alignment's second
+  // pass): nothing was added yet, queue the item for gtx_score_big_kernel
+  uint32_t const slot = big_queue ? atomicAdd(big_state, 1u) : big_queue_cap;
+  if (slot < big_queue_cap)
+    big_queue[slot] = i;
+  else
+    atomicAdd(error_flag, 1u);
+}
+
+// Second scoring pass: the queued items over per-thread tables in HBM.
+__global__ __launch_bounds__(64) void gtx_score_big_kernel(GraphView g, ScoreParams par, gtx_score_item const * __restrict__ items,
+                                                           uint32_t const * __restrict__ records, uint32_t rec_words, ScoreAcc acc,
+                                                           uint32_t * error_flag, uint32_t const * __restrict__ big_queue,
+                                                           uint32_t big_queue_cap, uint32_t const * big_state, RecentHap * tables)
+{
+  uint32_t const queued = big_state[0] < big_queue_cap ? big_state[0] : big_queue_cap;
+  uint32_t const tid = blockIdx.x * blockDim.x + threadIdx.x, n_threads = gridDim.x * blockDim.x;
+  RecentHap * r1 = tables + static_cast<uint64_t>(tid) * 2 * SCORE_MAX_HAPS_BIG;
+  for (uint32_t q = tid; q < queued; q += n_threads)
+    if (!score_item<WaveHip>(g, par, items[big_queue[q]], records, rec_words, acc, r1, r1 + SCORE_MAX_HAPS_BIG, SCORE_MAX_HAPS_BIG))
+      atomicAdd(error_flag, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -244,6 +354,51 @@ int ctx_upload(gtx_ctx & c, int device)
     c.d_error_flag = static_cast<uint32_t *>(ef);
     ok = hip_ok(hipMemset(ef, 0, sizeof(uint32_t)), "error flag");
   }
+  if (ok && !c.params.no_second_pass)
+  {
+    // second pass: queue, one HBM workspace per workgroup (one workgroup per CU is plenty for the few queued reads), arena
+    hipDeviceProp_t prop;
+    c.big_blocks = hipGetDeviceProperties(&prop, device) == hipSuccess ? static_cast<uint32_t>(prop.multiProcessorCount) : 256u;
+    c.big_record_words = c.params.big_record_words ? c.params.big_record_words : (16ull << 20);
+    void * p = nullptr;
+    ok = ok && hip_ok(hipMalloc(&p, 8 * sizeof(uint32_t)), "second-pass state");
+    if (ok)
+    {
+      c.dev_allocs.push_back(p);
+      c.d_big_state = static_cast<uint32_t *>(p);
+    }
+    ok = ok && hip_ok(hipMalloc(&p, static_cast<size_t>(c.big_blocks) * sizeof(big::AlignWorkspace)), "second-pass workspaces");
+    if (ok)
+    {
+      c.dev_allocs.push_back(p);
+      c.d_big_ws = p;
+    }
+    ok = ok && hip_ok(hipMalloc(&p, c.big_record_words * sizeof(uint32_t)), "big-record arena");
+    if (ok)
+    {
+      c.dev_allocs.push_back(p);
+      c.d_big_records = static_cast<uint32_t *>(p);
+    }
+    ok = ok && hip_ok(hipMalloc(&p, 2 * sizeof(uint32_t)), "second-pass score state");
+    if (ok)
+    {
+      c.dev_allocs.push_back(p);
+      c.d_score_state = static_cast<uint32_t *>(p);
+    }
+    ok = ok && hip_ok(hipMalloc(&p, gtx_ctx::SCORE_QUEUE_CAP * sizeof(uint32_t)), "second-pass score queue");
+    if (ok)
+    {
+      c.dev_allocs.push_back(p);
+      c.d_score_queue = static_cast<uint32_t *>(p);
+    }
+    ok = ok && hip_ok(hipMalloc(&p, static_cast<size_t>(gtx_ctx::SCORE_BIG_THREADS) * 2 * SCORE_MAX_HAPS_BIG * sizeof(RecentHap)),
+                      "second-pass score tables");
+    if (ok)
+    {
+      c.dev_allocs.push_back(p);
+      c.d_score_tables = p;
+    }
+  }
   if (!ok)
     return GTX_ERR_HIP;
   c.dev_graph = v;
@@ -264,6 +419,9 @@ void ctx_release_device(gtx_ctx & c)
   for (void * p : c.dev_allocs)
     (void)hipFree(p);
   c.dev_allocs.clear();
+  if (c.d_big_tasks)
+    (void)hipFree(c.d_big_tasks);
+  c.d_big_tasks = nullptr;
 }
 
 } // namespace gtx
@@ -292,11 +450,43 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
   uint32_t * counter = c->d_task_counters + (c->launch_seq.fetch_add(1) % gtx_ctx::N_TASK_COUNTERS);
   if (!hip_ok(hipMemsetAsync(counter, 0, sizeof(uint32_t), static_cast<hipStream_t>(stream)), "task counter reset"))
     return GTX_ERR_HIP;
+  bool const second_pass = c->d_big_state != nullptr;
+  if (second_pass)
+  {
+    // the queue holds every task of a small batch and 8 Mi tasks of a large one (tasks beyond it keep their status bit)
+    uint64_t const want = std::min<uint64_t>(2ull * n_reads, 8ull << 20);
+    if (want > c->big_task_cap)
+    {
+      if (c->d_big_tasks && !hip_ok(hipFree(c->d_big_tasks), "second-pass queue")) // (synchronises with earlier launches)
+        return GTX_ERR_HIP;
+      c->d_big_tasks = nullptr;
+      c->big_task_cap = 0;
+      void * p = nullptr;
+      if (!hip_ok(hipMalloc(&p, want * sizeof(uint32_t)), "second-pass queue"))
+        return GTX_ERR_HIP;
+      c->d_big_tasks = static_cast<uint32_t *>(p);
+      c->big_task_cap = static_cast<uint32_t>(want);
+    }
+    if (!hip_ok(hipMemsetAsync(c->d_big_state, 0, 8 * sizeof(uint32_t), static_cast<hipStream_t>(stream)), "second-pass state reset"))
+      return GTX_ERR_HIP;
+  }
+  char const * fb = std::getenv("GTX_FORCE_SECOND_PASS"); // test switch: every task is redone by the second pass
+  bool const force_big = fb && fb[0] == '1';
   hipLaunchKernelGGL(gtx_align_kernel, dim3(blocks), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph, c->dev_index,
                      d_seq, seq_stride, d_meta, n_reads, d_records, rec_words,
-                     static_cast<uint32_t>(c->params.force_align_both_orientations != 0), counter);
+                     static_cast<uint32_t>(c->params.force_align_both_orientations != 0), counter,
+                     second_pass ? c->d_big_tasks : nullptr, c->big_task_cap, c->d_big_state, static_cast<uint32_t>(force_big));
   if (!hip_ok(hipGetLastError(), "gtx_align_kernel launch"))
     return GTX_ERR_HIP;
+  if (second_pass)
+  {
+    hipLaunchKernelGGL(gtx_align_big_kernel, dim3(c->big_blocks), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph,
+                       c->dev_index, d_seq, seq_stride, d_meta, d_records, rec_words, c->d_big_tasks, c->big_task_cap, c->d_big_state,
+                       static_cast<big::AlignWorkspace *>(c->d_big_ws), c->d_big_records,
+                       static_cast<unsigned long long>(c->big_record_words));
+    if (!hip_ok(hipGetLastError(), "gtx_align_big_kernel launch"))
+      return GTX_ERR_HIP;
+  }
   return GTX_OK;
 }
 
@@ -326,13 +516,52 @@ extern "C" int gtx_score_batch(gtx_ctx * c, const gtx_score_item * d_items, uint
   a.stat_u32 = acc->d_stat_u32;
   a.conn_log = acc->d_conn_log;
   a.conn_count = acc->d_conn_count;
+  a.big_records = c->d_big_records;
   ScoreParams par{static_cast<uint32_t>(c->params.is_sv_graph != 0), static_cast<uint32_t>(c->params.hq_reads != 0),
                   static_cast<uint32_t>(c->params.is_segment_calling != 0), 0};
   uint32_t const blocks = (n_items + 255u) / 256u;
+  bool const second_pass = c->d_score_state != nullptr;
+  if (second_pass &&
+      !hip_ok(hipMemsetAsync(c->d_score_state, 0, 2 * sizeof(uint32_t), static_cast<hipStream_t>(stream)), "second-pass state reset"))
+    return GTX_ERR_HIP;
   hipLaunchKernelGGL(gtx_score_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), c->dev_graph, par, d_items,
-                     n_items, d_records, rec_words, a, c->d_error_flag);
+                     n_items, d_records, rec_words, a, c->d_error_flag, second_pass ? c->d_score_queue : nullptr,
+                     second_pass ? gtx_ctx::SCORE_QUEUE_CAP : 0u, c->d_score_state);
   if (!hip_ok(hipGetLastError(), "gtx_score_kernel launch"))
     return GTX_ERR_HIP;
+  if (second_pass)
+  {
+    hipLaunchKernelGGL(gtx_score_big_kernel, dim3(gtx_ctx::SCORE_BIG_THREADS / 64), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       c->dev_graph, par, d_items, d_records, rec_words, a, c->d_error_flag, c->d_score_queue,
+                       gtx_ctx::SCORE_QUEUE_CAP, c->d_score_state, static_cast<RecentHap *>(c->d_score_tables));
+    if (!hip_ok(hipGetLastError(), "gtx_score_big_kernel launch"))
+      return GTX_ERR_HIP;
+  }
+  return GTX_OK;
+}
+
+extern "C" int gtx_ctx_big_records(gtx_ctx * c, const uint32_t ** d_words, uint64_t * capacity_words, uint64_t * used_words,
+                                   uint64_t * tasks)
+{
+  if (!c || !d_words || !capacity_words)
+    return GTX_ERR_ARG;
+  *d_words = c->d_big_records;
+  *capacity_words = c->d_big_records ? c->big_record_words : 0;
+  if (used_words)
+    *used_words = 0;
+  if (tasks)
+    *tasks = 0;
+  if ((used_words || tasks) && c->d_big_state)
+  {
+    uint32_t st[8];
+    if (!hip_ok(hipMemcpy(st, c->d_big_state, sizeof(st), hipMemcpyDeviceToHost), "second-pass state"))
+      return GTX_ERR_HIP;
+    uint64_t const used = (static_cast<uint64_t>(st[5]) << 32) | st[4];
+    if (used_words)
+      *used_words = std::min<uint64_t>(used, c->big_record_words);
+    if (tasks)
+      *tasks = std::min<uint32_t>(st[0], c->big_task_cap);
+  }
   return GTX_OK;
 }
 

@@ -21,6 +21,19 @@ struct gtx_ctx
   uint32_t * d_task_counters = nullptr;
   std::atomic<unsigned> launch_seq{0};
   int align_blocks_per_cu = 8;
+  // second pass (reads that overflowed the LDS-sized tables): task list, HBM workspaces, arena for long records
+  uint32_t * d_big_tasks = nullptr;  // (read * 2 + orientation) of every queued task
+  uint32_t big_task_cap = 0;
+  uint32_t * d_big_state = nullptr;  // [0] tasks queued, [1] claim cursor, [2] arena cursor (words), [3] tasks dropped (list full)
+  void * d_big_ws = nullptr;         // big_blocks workspaces
+  uint32_t big_blocks = 0;
+  uint32_t * d_big_records = nullptr;
+  uint64_t big_record_words = 0;
+  // second scoring pass (items whose reads touch more variant sites than the main pass' tables hold)
+  static constexpr uint32_t SCORE_QUEUE_CAP = 1u << 20, SCORE_BIG_THREADS = 1024;
+  uint32_t * d_score_state = nullptr; // [0] items queued
+  uint32_t * d_score_queue = nullptr;
+  void * d_score_tables = nullptr;
 };
 
 namespace gtx

@@ -8,13 +8,14 @@
 // Every effect of a read on shared state is an integer addition, so the order in which items are scored does not
 // matter below the saturation guard of explain_to_score (checked by gtx_scores_finalize).
 #pragma once
-#include "align_core.hpp"
+#include "graph_dev.hpp"
 
 namespace gtx
 {
 constexpr uint16_t F_PAIRED = 1, F_PROPER_PAIR = 2, F_UNMAPPED = 4, F_SEQ_REVERSED = 16, F_FIRST_IN_PAIR = 64, F_MAPQ_BAD = 4096;
 constexpr uint32_t NO_COVERAGE = 0xFFFFu, MULTI_ALT_COVERAGE = 0xFFFEu, MULTI_REF_COVERAGE = 0xFFFDu; // haplotype.hpp:86-88
-constexpr uint32_t SCORE_MAX_HAPS = 24; // distinct variant sites one read can touch in this kernel
+constexpr uint32_t SCORE_MAX_HAPS = 24;      // distinct variant sites one read can touch in the main scoring pass
+constexpr uint32_t SCORE_MAX_HAPS_BIG = 1024; // ... in the second pass (tables in HBM)
 
 struct ScoreParams
 {
@@ -30,15 +31,18 @@ struct RecPath
 struct Geno // one GenotypePaths as seen by the scorer
 {
   uint32_t const * rec;
+  uint32_t const * body; // path words: behind the header, or in the big-record arena (GTX_ST_EXTERNAL)
   uint32_t n_paths, longest, read_len;
   uint32_t flags, mapq, score_diff;
   bool proper_pair; // ml_insert_size != INSERT_SIZE_WHEN_NOT_PROPER_PAIR
 };
 
-GTX_DEV Geno geno_of(uint32_t const * records, uint32_t rec_words, uint32_t align_index, uint32_t orient)
+GTX_DEV Geno geno_of(uint32_t const * records, uint32_t rec_words, uint32_t const * big_records, uint32_t align_index,
+                     uint32_t orient)
 {
   Geno g;
   g.rec = records + (static_cast<uint64_t>(align_index) * 2 + orient) * rec_words;
+  g.body = ((g.rec[0] >> 16) & GTX_ST_EXTERNAL) ? big_records + g.rec[2] : g.rec + 2;
   g.n_paths = g.rec[0] & 0xFFFFu;
   g.longest = g.rec[1] & 0xFFFFu;
   g.read_len = g.rec[1] >> 16;
@@ -63,13 +67,13 @@ GTX_DEV uint32_t const * path_at(uint32_t const * w, RecPath & p) // returns the
 
 GTX_DEV uint32_t first_mismatches(Geno const & g) // paths[0].mismatches
 {
-  return g.rec[2 + 3] & 0xFFFFu;
+  return g.body[3] & 0xFFFFu;
 }
 
 GTX_DEV uint32_t alternative_call_count(Geno const & g) // genotype_paths.cpp:1040-1053
 {
   uint32_t c = 0;
-  uint32_t const * w = g.rec + 2;
+  uint32_t const * w = g.body;
   for (uint32_t i = 0; i < g.n_paths; ++i)
   {
     RecPath p;
@@ -153,7 +157,7 @@ GTX_DEV bool geno_is_good(GraphView const & g, ScoreParams const & par, Geno con
   unique = true;
   if (ge.n_paths == 0)
     return false;
-  uint32_t const * w = ge.rec + 2;
+  uint32_t const * w = ge.body;
   RecPath p0;
   uint32_t r0s = 0, r0e = 0;
   for (uint32_t i = 0; i < ge.n_paths; ++i)
@@ -219,6 +223,7 @@ struct ScoreAcc // device pointers, see gtx_score_buffers in include/gtx.h
   uint32_t * stat_u32;
   uint32_t * conn_log;
   uint32_t * conn_count;
+  uint32_t const * big_records; // the context's arena for records longer than rec_words
 };
 
 template <class W>
@@ -241,16 +246,13 @@ GTX_DEV void emit_conn(ScoreAcc const & acc, uint32_t sample, uint32_t h1, uint3
   e[5] = count;
 }
 
-// push_to_haplotype_scores (vcf_writer.cpp:503-676).  Fills `recent` (ascending site) for the connection merge of the
-// caller; returns the number of entries, or 0xFFFFFFFF when the read touches more sites than SCORE_MAX_HAPS.
-template <class W>
-GTX_DEV uint32_t push_to_haplotype_scores(GraphView const & g, ScoreAcc const & acc, Geno const & ge, bool fully, bool unique,
-                                          uint32_t sample, RecentHap * recent)
+// push_to_haplotype_scores (vcf_writer.cpp:503-676), first half: the sites the read's paths touch with their explain
+// masks and coverage, ascending site (the reference's std::map order).  No effect on shared state.  Returns the number
+// of entries, or 0xFFFFFFFF when the read touches more than `cap` sites.
+GTX_DEV uint32_t collect_recent(GraphView const & g, Geno const & ge, RecentHap * recent, uint32_t cap)
 {
-  uint32_t const clipped_bp = ge.read_len - ge.longest;
-  uint32_t const mismatches = first_mismatches(ge);
   uint32_t n = 0;
-  uint32_t const * w = ge.rec + 2;
+  uint32_t const * w = ge.body;
   for (uint32_t i = 0; i < ge.n_paths; ++i)
   {
     RecPath p;
@@ -270,7 +272,7 @@ GTX_DEV uint32_t push_to_haplotype_scores(GraphView const & g, ScoreAcc const & 
           break;
       if (j == n)
       {
-        if (n >= SCORE_MAX_HAPS)
+        if (n >= cap)
           return 0xFFFFFFFFu;
         recent[n++] = RecentHap{site, NO_COVERAGE, 0, false};
       }
@@ -298,6 +300,16 @@ GTX_DEV uint32_t push_to_haplotype_scores(GraphView const & g, ScoreAcc const & 
     }
     recent[b] = x;
   }
+  return n;
+}
+
+// push_to_haplotype_scores, second half: everything the read adds to the accumulators
+template <class W>
+GTX_DEV void apply_recent(GraphView const & g, ScoreAcc const & acc, Geno const & ge, bool fully, bool unique, uint32_t sample,
+                          RecentHap const * recent, uint32_t n)
+{
+  uint32_t const clipped_bp = ge.read_len - ge.longest;
+  uint32_t const mismatches = first_mismatches(ge);
   // connections between the sites of this read (vcf_writer.cpp:587-636)
   for (uint32_t a = 0; a < n; ++a)
   {
@@ -405,23 +417,23 @@ GTX_DEV uint32_t push_to_haplotype_scores(GraphView const & g, ScoreAcc const & 
         W::atomic_add_u32(cell + 3, 1u);
     }
   }
-  return n;
 }
 
 // one call of genotype_only() that reaches the writer (hts_parallel_reader.cpp:283-337)
+// r1 / r2: tables of `cap` entries each.  Returns false, with nothing added to the accumulators, when a read of the item
+// touches more than `cap` variant sites (the caller then redoes the item with larger tables).
 template <class W>
-GTX_DEV void score_item(GraphView const & g, ScoreParams const & par, gtx_score_item const & it, uint32_t const * records,
-                        uint32_t rec_words, ScoreAcc const & acc, uint32_t * error_flag)
+GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_item const & it, uint32_t const * records,
+                        uint32_t rec_words, ScoreAcc const & acc, RecentHap * r1, RecentHap * r2, uint32_t cap)
 {
-  RecentHap r1[SCORE_MAX_HAPS], r2[SCORE_MAX_HAPS];
   if (it.second.align_index == INVALID)
   {
     // update_unpaired_read_paths (alignment.cpp:365-455).  clipped_count() returns 0/1, so IS_CLIPPED is never set.
     gtx_rec_meta const & m = it.first;
-    Geno fwd = geno_of(records, rec_words, m.align_index, 0), rev = geno_of(records, rec_words, m.align_index, 1);
+    Geno fwd = geno_of(records, rec_words, acc.big_records, m.align_index, 0), rev = geno_of(records, rec_words, acc.big_records, m.align_index, 1);
     int const which = compare_single(fwd, rev);
     if (which == 0)
-      return;
+      return true;
     Geno & ge = which == 1 ? fwd : rev;
     ge.flags = (which == 1 ? m.flag : (m.flag ^ F_SEQ_REVERSED)) & ~static_cast<uint32_t>(F_PROPER_PAIR) & 0xFFFFu;
     ge.mapq = m.mapq;
@@ -429,12 +441,16 @@ GTX_DEV void score_item(GraphView const & g, ScoreParams const & par, gtx_score_
       ge.flags |= F_MAPQ_BAD;
     ge.score_diff = m.score_diff;
     if (par.is_segment_calling)
-      return;
+      return true;
     bool fully, unique;
     if (geno_is_good(g, par, ge, fully, unique))
-      if (push_to_haplotype_scores<W>(g, acc, ge, fully, unique, it.sample, r1) == 0xFFFFFFFFu)
-        W::atomic_add_u32(error_flag, 1u);
-    return;
+    {
+      uint32_t const n = collect_recent(g, ge, r1, cap);
+      if (n == 0xFFFFFFFFu)
+        return false;
+      apply_recent<W>(g, acc, ge, fully, unique, it.sample, r1, n);
+    }
+    return true;
   }
   // update_paths for both records (alignment.cpp:482-545): only the forward-orientation geno gets IS_MAPQ_BAD
   Geno q[4];
@@ -444,8 +460,8 @@ GTX_DEV void score_item(GraphView const & g, ScoreParams const & par, gtx_score_
     gtx_rec_meta const & m = *ms[r];
     Geno & f = q[2 * r];
     Geno & v = q[2 * r + 1];
-    f = geno_of(records, rec_words, m.align_index, 0);
-    v = geno_of(records, rec_words, m.align_index, 1);
+    f = geno_of(records, rec_words, acc.big_records, m.align_index, 0);
+    v = geno_of(records, rec_words, acc.big_records, m.align_index, 1);
     f.flags = (m.flag & ~static_cast<uint32_t>(F_PROPER_PAIR)) & 0xFFFFu;
     if (m.mapq < 25)
       f.flags |= F_MAPQ_BAD;
@@ -459,10 +475,10 @@ GTX_DEV void score_item(GraphView const & g, ScoreParams const & par, gtx_score_
   for (int k = 0; k < 4; ++k)
     arr[((q[k].flags & F_FIRST_IN_PAIR) != 0) + 2 * ((q[k].flags & F_SEQ_REVERSED) == 0)] = k;
   if (arr[0] < 0 || arr[1] < 0 || arr[2] < 0 || arr[3] < 0)
-    return;
+    return true;
   int const which = compare_pairs(q[arr[3]], q[arr[0]], q[arr[1]], q[arr[2]]);
   if (which == 0)
-    return;
+    return true;
   Geno & first = which == 1 ? q[arr[3]] : q[arr[1]];
   Geno & second = which == 1 ? q[arr[0]] : q[arr[2]];
   first.flags |= F_PROPER_PAIR;
@@ -471,17 +487,18 @@ GTX_DEV void score_item(GraphView const & g, ScoreParams const & par, gtx_score_
   bool f1, u1, f2, u2;
   bool const good1 = geno_is_good(g, par, first, f1, u1), good2 = geno_is_good(g, par, second, f2, u2);
   if (par.is_segment_calling && (!good1 || !good2))
-    return;
+    return true;
   uint32_t n1 = 0, n2 = 0;
   if (good1)
-    n1 = push_to_haplotype_scores<W>(g, acc, first, f1, u1, it.sample, r1);
+    n1 = collect_recent(g, first, r1, cap);
   if (good2)
-    n2 = push_to_haplotype_scores<W>(g, acc, second, f2, u2, it.sample, r2);
+    n2 = collect_recent(g, second, r2, cap);
   if (n1 == 0xFFFFFFFFu || n2 == 0xFFFFFFFFu)
-  {
-    W::atomic_add_u32(error_flag, 1u);
-    return;
-  }
+    return false;
+  if (good1)
+    apply_recent<W>(g, acc, first, f1, u1, it.sample, r1, n1);
+  if (good2)
+    apply_recent<W>(g, acc, second, f2, u2, it.sample, r2, n2);
   // cross links between the two mates' sites: every (site, allele) key of one mate gets one count towards every key
   // of the other mate that lies on a later site (vcf_writer.cpp:186-227)
   for (uint32_t a = 0; a < n1; ++a)
@@ -506,6 +523,7 @@ GTX_DEV void score_item(GraphView const & g, ScoreParams const & par, gtx_score_
         }
     }
   }
+  return true;
 }
 
 } // namespace gtx

@@ -15,12 +15,13 @@ LIB_PATH = os.path.join(HERE, os.environ.get("GTX_LIB", "libgtx.so"))  # GTX_LIB
 INVALID_ID = 0xFFFFFFFF
 SPECIAL_START = 0xD0000000
 
-ST_LABEL_OVERFLOW, ST_PATH_OVERFLOW, ST_DFS_OVERFLOW, ST_RECORD_OVERFLOW = 1, 2, 4, 8
+ST_LABEL_OVERFLOW, ST_PATH_OVERFLOW, ST_DFS_OVERFLOW, ST_RECORD_OVERFLOW, ST_EXTERNAL = 1, 2, 4, 8, 16
+ST_ERROR_MASK = 15
 
 # names every build of libgtx.so must export (checked by tests/test_abi.py against include/gtx.h)
 EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy", "gtx_ctx_special_positions",
            "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_index_stats", "gtx_index_get", "gtx_index_dump",
-           "gtx_align_batch", "gtx_score_batch", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_stream_create",
+           "gtx_align_batch", "gtx_score_batch", "gtx_ctx_big_records", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_stream_create",
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_get_view",
            "gtx_graph_destroy"]
 
@@ -36,7 +37,7 @@ class GraphView(C.Structure):
 class Params(C.Structure):
     _fields_ = [("max_index_labels", C.c_int32), ("is_sv_graph", C.c_int32), ("hq_reads", C.c_int32),
                 ("force_align_both_orientations", C.c_int32), ("is_segment_calling", C.c_int32),
-                ("sam_flag_filter", C.c_int32)]
+                ("sam_flag_filter", C.c_int32), ("no_second_pass", C.c_int32), ("big_record_words", C.c_uint32)]
 
 
 class ScoreLayout(C.Structure):
@@ -248,7 +249,7 @@ class Context:
     """gtx_ctx: flat graph + index (host) and, for device >= 0, their copies in HBM"""
 
     def __init__(self, graph, device=0, max_index_labels=75, is_sv_graph=False, hq_reads=False, force_both=False,
-                 is_segment_calling=False, sam_flag_filter=3840):
+                 is_segment_calling=False, sam_flag_filter=3840, no_second_pass=False, big_record_words=0):
         L = lib()
         self.g = {k: np.ascontiguousarray(v) for k, v in graph.items()}
         g = self.g
@@ -258,7 +259,7 @@ class Context:
                               _p(g["var_len"]), _p(g["var_dna_off"]), _p(g["var_out_ref"]), _p(g["dna"]), len(g["dna"]),
                               _p(g["event_off"]) if has_ev else None, _p(g["event_val"]) if has_ev else None)
         self.params = Params(max_index_labels, int(is_sv_graph), int(hq_reads), int(force_both), int(is_segment_calling),
-                             sam_flag_filter)
+                             sam_flag_filter, int(no_second_pass), int(big_record_words))
         h = C.c_void_p()
         check(L.gtx_ctx_create(C.byref(self.view), C.byref(self.params), device, C.byref(h)))
         self.h = h
@@ -311,6 +312,19 @@ class Context:
         check(lib().gtx_ctx_profile(self.h, _p(out)))
         return out
 
+    def big_records(self):
+        """(used part of the big-record arena as a host array, number of tasks the last align batch sent through the
+        second pass)"""
+        ptr, cap, used, tasks = C.c_void_p(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(lib().gtx_ctx_big_records(self.h, C.byref(ptr), C.byref(cap), C.byref(used), C.byref(tasks)))
+        out = np.zeros(int(used.value), np.uint32)
+        if used.value:
+            hip = C.CDLL("libamdhip64.so")
+            rc = hip.hipMemcpy(_p(out), ptr, C.c_size_t(out.nbytes), C.c_int(2))  # hipMemcpyDeviceToHost
+            if rc != 0:
+                raise RuntimeError(f"hipMemcpy failed ({rc})")
+        return out, int(tasks.value)
+
     def error_count(self):
         n = C.c_uint32()
         check(lib().gtx_ctx_error_count(self.h, C.byref(n)))
@@ -349,9 +363,10 @@ class Stream:
         return dict(records=int(a.value), duplicated=int(b.value), parked=int(c.value))
 
 
-def parse_records(words, n_reads, rec_words, hap_order):
+def parse_records(words, n_reads, rec_words, hap_order, big_records=None):
     """decode gtx_align_batch records into the same structure tests/oracle_lib.parse_path_stream returns
-    (plus 'status'); Path::var_order is looked up through hap_order"""
+    (plus 'status', with the GTX_ST_EXTERNAL bit removed); Path::var_order is looked up through hap_order.
+    big_records: the context's big-record arena (needed when a record carries GTX_ST_EXTERNAL)"""
     words = np.asarray(words, np.uint32).reshape(n_reads * 2, rec_words)
     out = []
     for i in range(n_reads):
@@ -361,6 +376,9 @@ def parse_records(words, n_reads, rec_words, hap_order):
             npaths, status = int(w[0]) & 0xFFFF, int(w[0]) >> 16
             longest, rlen = int(w[1]) & 0xFFFF, int(w[1]) >> 16
             k = 2
+            if status & ST_EXTERNAL:
+                w, k = big_records, int(w[2])
+                status &= ~ST_EXTERNAL
             paths = []
             for _ in range(npaths):
                 st, en, rsre, mmnv = int(w[k]), int(w[k + 1]), int(w[k + 2]), int(w[k + 3])

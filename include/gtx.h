@@ -51,8 +51,10 @@ enum
   GTX_ST_LABEL_OVERFLOW = 1, /* one k-mer list returned more labels than the kernel's staging buffer */
   GTX_ST_PATH_OVERFLOW = 2,  /* more live paths / variant sites per path than the kernel's tables */
   GTX_ST_DFS_OVERFLOW = 4,   /* graph walk produced more candidate sequences than the kernel's table */
-  GTX_ST_RECORD_OVERFLOW = 8 /* result did not fit rec_words */
+  GTX_ST_RECORD_OVERFLOW = 8, /* result fits neither rec_words nor the context's big-record arena */
+  GTX_ST_EXTERNAL = 16        /* not an error: the path words of this record are in the big-record arena (see gtx_align_batch) */
 };
+#define GTX_ST_ERROR_MASK 15u
 
 /* Graph as SoA node tables = the reference's Graph::ref_nodes / var_nodes (include/graphtyper/graph/graph.hpp:40-134):
  * strictly alternating  ref node r -> its ref_nvar[r] var nodes (allele 0 = reference allele) -> ref node r+1.
@@ -118,6 +120,8 @@ typedef struct gtx_params
   int32_t force_align_both_orientations; /* Options::force_align_both_orientations */
   int32_t is_segment_calling;            /* Options::is_segment_calling */
   int32_t sam_flag_filter;               /* 3840 */
+  int32_t no_second_pass;                /* 1: reads that overflow the main pass' tables keep their status bit (A/B tests) */
+  uint32_t big_record_words;             /* capacity of the big-record arena in uint32 words, 0 = 16 Mi */
 } gtx_params;
 
 /* One KmerLabel (include/graphtyper/index/kmer_label.hpp:13-41) */
@@ -194,7 +198,14 @@ int gtx_index_dump(const gtx_ctx *, uint64_t * keys, uint32_t * counts, gtx_labe
  *    start, end, read_start_index | read_end_index << 16, mismatches | n_var << 16, n_var * (hap, mask_lo, mask_hi)
  *    hap = haplotype (variant site) index, Path::var_order = hap_order[hap] of gtx_ctx_haplotypes;
  *    mask bit a set <=> allele a in Path::nums
- * stream     : hipStream_t or NULL */
+ *    A record with GTX_ST_EXTERNAL (a result with more paths than rec_words holds) keeps w0/w1 and has w2 = word offset
+ *    of its path words in the context's big-record arena (gtx_ctx_big_records).  The arena is rewound by every
+ *    gtx_align_batch, so records must be scored / downloaded before the context aligns the next batch.
+ * stream     : hipStream_t or NULL
+ * Two passes: the main kernel keeps a read's tables in LDS; the few reads that exceed them (repeats: hundreds of seed
+ * locations) are queued on the device and redone by a second kernel over HBM-resident tables that hold what the
+ * reference's own limits allow, so they get the same result as any other read.  Only a read beyond those tables too
+ * keeps an overflow status (and no paths).  Calls on one context must not overlap in time (stream-order them). */
 int gtx_align_batch(gtx_ctx *, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
                     uint32_t * d_records, uint32_t rec_words, void * stream);
 
@@ -225,6 +236,11 @@ int gtx_score_batch(gtx_ctx *, const gtx_score_item * d_items, uint32_t n_items,
 /* number of score items the kernel refused so far because one read touched more variant sites than its table holds
  * (must be 0 for the accumulators to be complete) */
 int gtx_ctx_error_count(gtx_ctx *, uint32_t * out);
+
+/* device pointer and capacity (uint32 words) of the big-record arena; used_words (may be NULL) = words the last
+ * gtx_align_batch filled, tasks (may be NULL) = (read, orientation) tasks it sent through the second pass
+ * (both synchronise with the device) */
+int gtx_ctx_big_records(gtx_ctx *, const uint32_t ** d_words, uint64_t * capacity_words, uint64_t * used_words, uint64_t * tasks);
 
 /* out[32]: per-phase shader-cycle sums of the alignment kernel; only the profiling build (libgtx_prof.so) fills them */
 int gtx_ctx_profile(gtx_ctx *, uint64_t * out);

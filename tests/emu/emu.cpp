@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../graphtyper_amd/csrc/gtx_flat.hpp"
+#include "../../graphtyper_amd/csrc/align_core.hpp"
 #include "../../graphtyper_amd/csrc/score_core.hpp"
 
 namespace
@@ -73,6 +74,9 @@ struct Emu
   gtx_params params{};
   gtx::HostGraph graph;
   gtx::HostIndex index;
+  std::vector<uint32_t> arena; // big-record arena (see gtx_align_batch)
+  uint64_t arena_used = 0;
+  uint64_t second_pass_tasks = 0;
 };
 
 } // namespace
@@ -107,6 +111,13 @@ extern "C"
     if (char const * cap = std::getenv("GTX_HALF_BUCKET_CAP"))
       ix.half_bucket_cap = static_cast<uint32_t>(std::atol(cap));
     auto ws = std::make_unique<AlignWorkspace>();
+    auto big_ws = std::make_unique<big::AlignWorkspace>();
+    bool const second_pass = !e.params.no_second_pass;
+    char const * fe = std::getenv("GTX_FORCE_SECOND_PASS");
+    bool const force_big = fe && fe[0] == '1';
+    e.arena.assign(e.params.big_record_words ? e.params.big_record_words : (1u << 20), 0xABABABABu);
+    e.arena_used = 0;
+    e.second_pass_tasks = 0;
     bool const force_both = e.params.force_align_both_orientations != 0;
     for (uint32_t t = 0; t < 2 * n_reads; ++t)
     {
@@ -122,9 +133,57 @@ extern "C"
         continue;
       }
       std::memset(ws.get(), 0xAB, sizeof(AlignWorkspace)); // LDS is not zeroed between reads
-      align_one<WaveEmu>(g, ix, *ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words);
+      uint32_t const st = align_one<WaveEmu>(g, ix, *ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words);
+      if (!second_pass || !(st || force_big))
+        continue;
+      // second pass (gtx_align_big_kernel)
+      ++e.second_pass_tasks;
+      std::memset(static_cast<void *>(big_ws.get()), 0xAB, sizeof(big::AlignWorkspace));
+      uint32_t np = 0, longest = 0, ext = 0;
+      uint32_t status = big::align_paths<WaveEmu>(g, ix, *big_ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest);
+      uint32_t * body = rec + 2;
+      uint64_t off = 0;
+      if (status)
+        np = 0;
+      else
+      {
+        uint32_t const size = big::record_size<WaveEmu>(*big_ws, np);
+        if (size > rec_words)
+        {
+          off = e.arena_used;
+          e.arena_used += size - 2;
+          if (off + (size - 2) > e.arena.size())
+          {
+            status = GTX_ST_RECORD_OVERFLOW;
+            np = 0;
+          }
+          else
+          {
+            body = e.arena.data() + off;
+            ext = GTX_ST_EXTERNAL;
+          }
+        }
+      }
+      big::write_record_body<WaveEmu>(*big_ws, np, body);
+      rec[0] = np | ((status | ext) << 16);
+      rec[1] = (np == 0 ? 0 : longest) | (len << 16);
+      if (ext)
+        rec[2] = static_cast<uint32_t>(off);
     }
     return 0;
+  }
+
+  int emu_big_records(void * p, const uint32_t ** words, uint64_t * capacity_words)
+  {
+    Emu & e = *static_cast<Emu *>(p);
+    *words = e.arena.data();
+    *capacity_words = e.arena.size();
+    return 0;
+  }
+
+  uint64_t emu_second_pass_tasks(void * p) { return static_cast<Emu *>(p)->second_pass_tasks; }
+
+  int emu_workspace_bytes(int big) { return static_cast<int>(big ? sizeof(gtx::big::AlignWorkspace) : sizeof(gtx::AlignWorkspace));
   }
 
   // same contract as gtx_score_batch, host pointers; returns the number of refused items
@@ -144,11 +203,19 @@ extern "C"
     a.stat_u32 = acc->d_stat_u32;
     a.conn_log = acc->d_conn_log;
     a.conn_count = acc->d_conn_count;
+    a.big_records = e.arena.data();
     ScoreParams par{static_cast<uint32_t>(e.params.is_sv_graph != 0), static_cast<uint32_t>(e.params.hq_reads != 0),
                     static_cast<uint32_t>(e.params.is_segment_calling != 0), 0};
     uint32_t errors = 0;
+    std::vector<RecentHap> small(2 * SCORE_MAX_HAPS), large(2 * SCORE_MAX_HAPS_BIG);
     for (uint32_t i = 0; i < n_items; ++i)
-      score_item<WaveEmu>(g, par, items[i], records, rec_words, a, &errors);
+      if (!score_item<WaveEmu>(g, par, items[i], records, rec_words, a, small.data(), small.data() + SCORE_MAX_HAPS, SCORE_MAX_HAPS))
+      {
+        // second scoring pass (gtx_score_big_kernel)
+        if (e.params.no_second_pass ||
+            !score_item<WaveEmu>(g, par, items[i], records, rec_words, a, large.data(), large.data() + SCORE_MAX_HAPS_BIG, SCORE_MAX_HAPS_BIG))
+          ++errors;
+      }
     return static_cast<int>(errors);
   }
 }

@@ -63,6 +63,13 @@ class EmuBackend:
         self.L.emu_align(C.c_void_p(self.h), _p(seq), C.c_uint32(seq.shape[1]), _p(meta), C.c_uint32(n), _p(rec), C.c_uint32(rec_words))
         return rec
 
+    def big_records(self):
+        ptr, cap = C.POINTER(C.c_uint32)(), C.c_uint64()
+        self.L.emu_big_records(C.c_void_p(self.h), C.byref(ptr), C.byref(cap))
+        self.L.emu_second_pass_tasks.restype = C.c_uint64
+        tasks = int(self.L.emu_second_pass_tasks(C.c_void_p(self.h)))
+        return np.ctypeslib.as_array(ptr, shape=(int(cap.value),)).copy(), tasks
+
     def score(self, items, records, n_samples=1, rec_words=REC_WORDS):
         items = np.ascontiguousarray(items, gtx.SCORE_ITEM)
         acc = Accumulators(self.ctx, n_samples)
@@ -98,6 +105,9 @@ class GpuBackend:
         torch.cuda.synchronize()
         self.d_rec = d_rec
         return d_rec.cpu().numpy().view(np.uint32)[:n * 2 * rec_words]
+
+    def big_records(self):
+        return self.ctx.big_records()
 
     def score(self, items, records, n_samples=1, rec_words=REC_WORDS):
         torch = self.torch

@@ -67,8 +67,28 @@ def synthetic_case(kind, n_ref=40000, n_reads=300, seed=0, region_begin=1000000,
         recs = synth.make_indel_records(ref, 60, seed=seed + 4, region_begin=region_begin)
     elif kind == "cluster":  # merged multi-allelic sites: build the graph with add_all_variants=True
         recs = synth.make_cluster_records(ref, 150, seed=seed + 8, region_begin=region_begin)
+    elif kind == "snp7":  # > 8 variant sites per read and wide graph walks: second-pass territory
+        recs = synth.make_snp_records(ref, 7, seed=seed + 9, region_begin=region_begin)
+    elif kind == "repeat":
+        # tandem repeat: 24 copies (16 of them diverged by 1.5 %) of a 180 bp unit in the middle of the region -> a read from it seeds at
+        # dozens of places, results have more paths than a record slot holds
+        rng = np.random.default_rng(seed + 10)
+        unit = rng.integers(0, 4, size=180).astype(np.uint8)
+        at = n_ref // 2
+        for c in range(24):
+            u = unit.copy()
+            e = (rng.random(len(u)) < 0.015) & (c % 3 != 0)  # every third copy is exact
+            u[e] = (u[e] + rng.integers(1, 4, size=int(e.sum()))) % 4
+            ref[at + c * 180:at + (c + 1) * 180] = u
+        recs = synth.make_snp_records(ref, 40, seed=seed + 11, region_begin=region_begin)
     else:
         raise ValueError(kind)
+    if kind == "repeat":  # reads from the repeat and its flanks only
+        lo, hi = n_ref // 2 - 400, n_ref // 2 + 24 * 180 + 400
+        sub = [r for r in recs if lo < r[0] - region_begin < hi - 2]
+        codes, pos = synth.make_reads(ref[lo:hi], sub, n_reads, read_len=read_len, seed=seed + 5, err=err, n_rate=n_rate,
+                                      region_begin=region_begin + lo, rev_frac=0.0)
+        return synth.bases_to_str(ref), recs, codes, pos
     codes, pos = synth.make_reads(ref, recs, n_reads, read_len=read_len, seed=seed + 5, err=err, n_rate=n_rate,
                                   region_begin=region_begin, rev_frac=0.0)
     return synth.bases_to_str(ref), recs, codes, pos

@@ -10,7 +10,7 @@ import harness
 import scenarios
 from graphtyper_amd import lib as gtx
 from oracle_lib import Oracle, encode
-from test_emu_parity import check_align, run_stream
+from test_emu_parity import check_align, forced_second_pass_case, run_stream, second_pass_case
 
 pytestmark = pytest.mark.gpu
 
@@ -27,8 +27,7 @@ def test_align_index_test_contigs(chrom):
     ref, recs, reads = scenarios.contig_reads(chrom)
     o = Oracle(ref, recs, force_both=True)
     b = harness.GpuBackend(gtx.graph_from_records(ref, recs), force_both=True)
-    _, n_over = check_align(b, o, [encode(r) for r in reads], allow_overflow=(chrom == "chr9"))
-    assert n_over < len(reads)
+    check_align(b, o, [encode(r) for r in reads])
 
 
 @pytest.mark.parametrize("kind", ["snp1k", "snp100", "snp25", "indel"])
@@ -93,3 +92,12 @@ def test_merged_multiallelic_graph():
     order = np.argsort(pos, kind="stable")
     rec = scenarios.stream_records(len(codes), pos, sample=np.arange(len(codes)) % 30)
     run_stream(b, o, codes[order], rec[order], n_samples=30)
+
+
+@pytest.mark.parametrize("kind", ["repeat", "snp7"])
+def test_second_pass(kind):
+    second_pass_case(harness.GpuBackend, kind, 5000)
+
+
+def test_forced_second_pass(monkeypatch):
+    forced_second_pass_case(harness.GpuBackend, monkeypatch, 6000)
