@@ -85,11 +85,37 @@ struct WaveHip
 };
 
 // Second pass: the workspace is in global memory, so the leader's stores must have completed (vmcnt) before the other
-// lanes load them; the workgroup barrier of a one-wave workgroup is exactly that wait.
+// lanes load them: workgroup-scope release/acquire fences are exactly that wait (one CU, one L1: no cache maintenance).
+// The wave barrier between them is the convergence point that keeps the compiler from letting lanes run ahead of the
+// leader (a workgroup barrier would be dropped for a one-wave workgroup and leave nothing to anchor on).
 struct WaveHipMem : WaveHip
 {
-  static __device__ inline void lds_sync() { __syncthreads(); }
+  static __device__ inline void mem_sync()
+  {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  static __device__ inline void lds_sync() { mem_sync(); }
 };
+
+// The leader takes `n` units from a device counter; every lane gets the old value (readfirstlane is the convergence
+// point: no lane continues before the leader's atomic has returned).
+static __device__ inline uint32_t wave_claim(uint32_t * counter, uint32_t n)
+{
+  uint32_t v = 0;
+  if ((threadIdx.x & 63u) == 0)
+    v = atomicAdd(counter, n);
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+static __device__ inline unsigned long long wave_claim64(unsigned long long * counter, unsigned long long n)
+{
+  unsigned long long v = 0;
+  if ((threadIdx.x & 63u) == 0)
+    v = atomicAdd(counter, n);
+  return WaveHip::uni(static_cast<uint64_t>(v));
+}
 
 #ifndef GTX_TASK_CHUNK
 #define GTX_TASK_CHUNK 16
@@ -104,7 +130,6 @@ __global__ __launch_bounds__(64) void gtx_align_kernel(GraphView g, IndexView ix
                                                        uint32_t * big_state, uint32_t force_big)
 {
   __shared__ AlignWorkspace ws;
-  __shared__ uint32_t task_base;
 #ifdef GTX_PAD_LDS // occupancy experiment: waste LDS to lower the number of resident waves
   __shared__ uint32_t lds_pad[GTX_PAD_LDS / 4];
   if (n_reads == 0xFFFFFFFFu)
@@ -114,11 +139,7 @@ __global__ __launch_bounds__(64) void gtx_align_kernel(GraphView g, IndexView ix
   // reads differ in cost (mismatches, ambiguous bases, the optional reverse orientation), a static split leaves CUs idle.
   for (;;)
   {
-    if ((threadIdx.x & 63u) == 0)
-      task_base = atomicAdd(task_counter, TASK_CHUNK);
-    __syncthreads();
-    uint32_t const base = task_base;
-    __syncthreads();
+    uint32_t const base = wave_claim(task_counter, TASK_CHUNK);
     if (base >= n_reads)
       break;
     uint32_t const end = base + TASK_CHUNK < n_reads ? base + TASK_CHUNK : n_reads;
@@ -168,38 +189,32 @@ __global__ __launch_bounds__(64) void gtx_align_big_kernel(GraphView g, IndexVie
                                                            uint32_t * big_state, big::AlignWorkspace * workspaces,
                                                            uint32_t * __restrict__ arena, unsigned long long arena_words)
 {
-  __shared__ unsigned long long slot;
   big::AlignWorkspace & ws = workspaces[blockIdx.x];
   uint32_t const queued = big_state[0] < big_task_cap ? big_state[0] : big_task_cap;
   for (;;)
   {
-    if ((threadIdx.x & 63u) == 0)
-      slot = atomicAdd(big_state + 1, 1u);
-    __syncthreads();
-    uint32_t const t = static_cast<uint32_t>(slot);
-    __syncthreads();
+    uint32_t const t = wave_claim(big_state + 1, 1u);
     if (t >= queued)
       break;
-    uint32_t const task = big_tasks[t], read = task >> 1, orient = task & 1u;
-    uint32_t const len = meta[read].l_qseq;
+    uint32_t const task = WaveHip::uni(big_tasks[t]), read = task >> 1, orient = task & 1u;
+    uint32_t const len = WaveHip::uni(static_cast<uint32_t>(meta[read].l_qseq));
     uint32_t * rec = records + static_cast<uint64_t>(task) * rec_words;
     uint32_t np = 0, longest = 0, ext = 0;
     uint32_t status = big::align_paths<WaveHipMem>(g, ix, ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest);
+    status = WaveHip::uni(status);
+    np = WaveHip::uni(np);
+    longest = WaveHip::uni(longest);
     uint32_t * body = rec + 2;
     unsigned long long off = 0;
     if (status)
       np = 0;
     else
     {
-      uint32_t const size = big::record_size<WaveHipMem>(ws, np);
+      uint32_t const size = WaveHip::uni(big::record_size<WaveHipMem>(ws, np));
       if (size > rec_words)
       {
-        // long record: reserve room in the arena; the slot keeps the header and the offset
-        if ((threadIdx.x & 63u) == 0)
-          slot = atomicAdd(reinterpret_cast<unsigned long long *>(big_state + 4), static_cast<unsigned long long>(size - 2));
-        __syncthreads();
-        off = slot;
-        __syncthreads();
+        // long record: room in the arena; the slot keeps the header and the offset
+        off = wave_claim64(reinterpret_cast<unsigned long long *>(big_state + 4), size - 2);
         if (off + (size - 2) > arena_words || off + (size - 2) > 0xFFFFFFFFull)
         {
           status = GTX_ST_RECORD_OVERFLOW;
@@ -220,6 +235,7 @@ __global__ __launch_bounds__(64) void gtx_align_big_kernel(GraphView g, IndexVie
       if (ext)
         rec[2] = static_cast<uint32_t>(off);
     }
+    WaveHipMem::mem_sync();
   }
 }
 

@@ -279,7 +279,10 @@ class Context:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     def special_positions(self):
         L = lib()

@@ -115,6 +115,8 @@ extern "C"
     bool const second_pass = !e.params.no_second_pass;
     char const * fe = std::getenv("GTX_FORCE_SECOND_PASS");
     bool const force_big = fe && fe[0] == '1';
+    char const * fl = std::getenv("GTX_EMU_FILL"); // what uninitialised workspace memory looks like
+    int const fill = fl ? std::atoi(fl) : 0xAB;
     e.arena.assign(e.params.big_record_words ? e.params.big_record_words : (1u << 20), 0xABABABABu);
     e.arena_used = 0;
     e.second_pass_tasks = 0;
@@ -132,13 +134,13 @@ extern "C"
         rec[1] = len << 16;
         continue;
       }
-      std::memset(ws.get(), 0xAB, sizeof(AlignWorkspace)); // LDS is not zeroed between reads
+      std::memset(ws.get(), fill, sizeof(AlignWorkspace)); // LDS is not zeroed between reads
       uint32_t const st = align_one<WaveEmu>(g, ix, *ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words);
       if (!second_pass || !(st || force_big))
         continue;
       // second pass (gtx_align_big_kernel)
       ++e.second_pass_tasks;
-      std::memset(static_cast<void *>(big_ws.get()), 0xAB, sizeof(big::AlignWorkspace));
+      std::memset(static_cast<void *>(big_ws.get()), fill, sizeof(big::AlignWorkspace));
       uint32_t np = 0, longest = 0, ext = 0;
       uint32_t status = big::align_paths<WaveEmu>(g, ix, *big_ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest);
       uint32_t * body = rec + 2;

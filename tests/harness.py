@@ -40,7 +40,7 @@ class EmuBackend:
     name = "emu"
 
     def __init__(self, graph, **params):
-        so = os.path.join(HERE, "emu", "libgtx_emu.so")
+        so = os.environ.get("GTX_EMU_LIB") or os.path.join(HERE, "emu", "libgtx_emu.so")
         subprocess.check_call(["make", "-C", os.path.join(HERE, "emu"), "-s"])
         self.L = C.CDLL(so)
         self.L.emu_new.restype = C.c_void_p
