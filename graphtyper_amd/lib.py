@@ -22,7 +22,7 @@ ST_ERROR_MASK = 15
 EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy", "gtx_ctx_special_positions",
            "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_index_stats", "gtx_index_get", "gtx_index_dump",
            "gtx_align_batch", "gtx_score_batch", "gtx_ctx_big_records", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_stream_create",
-           "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_get_view",
+           "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
            "gtx_graph_destroy"]
 
 
@@ -106,6 +106,8 @@ def lib():
         L.gtx_stream_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.gtx_graph_build.argtypes = [C.c_char_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_void_p)]
+        L.gtx_graph_from_files.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                           C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.gtx_graph_get_view.argtypes = [C.c_void_p, C.POINTER(GraphView)]
         L.gtx_graph_destroy.argtypes = [C.c_void_p]
         _lib = L
@@ -206,6 +208,12 @@ def graph_from_records(reference, records, region_begin=0, region_end=0xFFFFFFFF
     refb = reference.encode()
     check(L.gtx_graph_build(refb, len(refb), region_begin, region_end, recs, len(records), int(add_all_variants),
                             int(is_sv_graph), int(extend_prefix), C.byref(h)))
+    return _graph_tables(h)
+
+
+def _graph_tables(h):
+    """node tables of a gtx_graph as numpy arrays laid out as gtx_graph_view expects; destroys the handle"""
+    L = lib()
     try:
         v = GraphView()
         check(L.gtx_graph_get_view(h, C.byref(v)))
@@ -230,6 +238,16 @@ def graph_from_records(reference, records, region_begin=0, region_end=0xFFFFFFFF
         return g
     finally:
         L.gtx_graph_destroy(h)
+
+
+def graph_from_files(fasta, vcf, region, add_all_variants=False, is_sv_graph=False):
+    """gtx_graph_from_files (construct_graph, src/graph/constructor.cpp:1597-1777): node tables + (begin, end) of the
+    reference span that was read (0-based)"""
+    h = C.c_void_p()
+    b, e = C.c_int64(), C.c_int64()
+    check(lib().gtx_graph_from_files(str(fasta).encode(), (str(vcf) if vcf else "").encode(), region.encode(), int(add_all_variants),
+                                     int(is_sv_graph), C.byref(h), C.byref(b), C.byref(e)))
+    return _graph_tables(h), (int(b.value), int(e.value))
 
 
 def pack_nibbles(codes, stride=None):

@@ -108,6 +108,15 @@ typedef struct gtx_graph gtx_graph; /* owns the node tables a gtx_graph_view poi
 int gtx_graph_build(const char * reference, uint64_t reference_len, int64_t region_begin, int64_t region_end,
                     const gtx_record * records, uint32_t n_records, int add_all_variants, int is_sv_graph, int extend_prefix,
                     gtx_graph ** out);
+/* Graph of one region straight from files: replaces construct_graph(reference_filename, vcf_filename, region, is_sv_graph,
+ * use_index) (include/graphtyper/graph/constructor.hpp, src/graph/constructor.cpp:1597-1777) with split_multi_allelic
+ * (:1033-1077) and the small-variant branch of add_var_record (:1208-1262, 1493-1595) for graphs without structural-variant
+ * alleles (an SV allele returns GTX_ERR_UNSUPPORTED).  fasta_path: plain FASTA, its .fai is used when present;
+ * vcf_path: plain or gzip/bgzip VCF, NULL or "" for a reference-only graph; region: "chr", "chr:begin" or "chr:begin-end"
+ * (1-based, GenomicRegion, src/graph/genomic_region.cpp:73-113).  region_begin / region_end (may be NULL) receive the
+ * 0-based span [begin, end) of the reference bases that were read. */
+int gtx_graph_from_files(const char * fasta_path, const char * vcf_path, const char * region, int add_all_variants, int is_sv_graph,
+                         gtx_graph ** out, int64_t * region_begin, int64_t * region_end);
 int gtx_graph_get_view(const gtx_graph *, gtx_graph_view * out);
 void gtx_graph_destroy(gtx_graph *);
 
