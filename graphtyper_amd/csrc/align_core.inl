@@ -65,6 +65,9 @@ struct AlignWorkspace // lives in LDS, one per wavefront
   HalfEntry he[AlignCfg::KC][2][AlignCfg::HE_CAP];
   DevLabel xl[AlignCfg::KC][AlignCfg::XL_CAP];
   uint32_t n_paths, longest, status, n_lbl, n_keys, read_len, n_wl, n_wlists;
+#ifdef GTX_PROF
+  unsigned long long prof_acc[16]; // phase cycle sums of this wave (profiling build)
+#endif
 };
 
 GTX_DEV uint64_t pv_mask(PVar const & v)
@@ -1515,7 +1518,7 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
 
   GTX_PROF_TICK(8)
 #ifdef GTX_PROF
-  GTX_LEAD W::atomic_add_u64(g.prof + 15, 1);
+  GTX_LEAD ws.prof_acc[15] += 1;
 #endif
   n_paths_out = n_paths;
   longest_out = longest;

@@ -46,11 +46,12 @@ struct alignas(16) uint4_t // 16-byte move
 
 // phase timing (profiling build only: make -C graphtyper_amd/csrc prof -> libgtx_prof.so)
 #ifdef GTX_PROF
+// (per-wave sums in the workspace, flushed once when the wave retires: one global atomic per tick would serialise)
 #define GTX_PROF_BEGIN unsigned long long _pt = W::clock();
 #define GTX_PROF_TICK(k)                                   \
   {                                                        \
     unsigned long long const _pn = W::clock();             \
-    GTX_LEAD W::atomic_add_u64(g.prof + (k), _pn - _pt);   \
+    GTX_LEAD ws.prof_acc[k] += _pn - _pt;                  \
     _pt = W::clock();                                      \
   }
 #else

@@ -135,6 +135,11 @@ __global__ __launch_bounds__(64) void gtx_align_kernel(GraphView g, IndexView ix
   if (n_reads == 0xFFFFFFFFu)
     lds_pad[threadIdx.x] = 1;
 #endif
+#ifdef GTX_PROF
+  if (threadIdx.x < 16)
+    ws.prof_acc[threadIdx.x] = 0;
+  WaveHip::lds_sync();
+#endif
   // Reads are claimed dynamically (one atomic per TASK_CHUNK reads): the grid is sized to what is resident at once and
   // reads differ in cost (mismatches, ambiguous bases, the optional reverse orientation), a static split leaves CUs idle.
   for (;;)
@@ -178,6 +183,11 @@ __global__ __launch_bounds__(64) void gtx_align_kernel(GraphView g, IndexView ix
       }
     }
   }
+#ifdef GTX_PROF
+  WaveHip::lds_sync();
+  if (threadIdx.x < 16)
+    atomicAdd(g.prof + threadIdx.x, ws.prof_acc[threadIdx.x]);
+#endif
 }
 
 // Second pass over the queued (read, orientation) tasks: same algorithm instantiated over tables large enough for what
@@ -190,6 +200,11 @@ __global__ __launch_bounds__(64) void gtx_align_big_kernel(GraphView g, IndexVie
                                                            uint32_t * __restrict__ arena, unsigned long long arena_words)
 {
   big::AlignWorkspace & ws = workspaces[blockIdx.x];
+#ifdef GTX_PROF
+  if (threadIdx.x < 16)
+    ws.prof_acc[threadIdx.x] = 0; // (second-pass cycles are not added to the report)
+  WaveHipMem::mem_sync();
+#endif
   uint32_t const queued = big_state[0] < big_task_cap ? big_state[0] : big_task_cap;
   for (;;)
   {
@@ -382,6 +397,7 @@ int ctx_upload(gtx_ctx & c, int device)
     {
       c.dev_allocs.push_back(p);
       c.d_big_state = static_cast<uint32_t *>(p);
+      ok = hip_ok(hipMemset(p, 0, 8 * sizeof(uint32_t)), "second-pass state");
     }
     ok = ok && hip_ok(hipMalloc(&p, static_cast<size_t>(c.big_blocks) * sizeof(big::AlignWorkspace)), "second-pass workspaces");
     if (ok)
@@ -483,7 +499,8 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
       c->d_big_tasks = static_cast<uint32_t *>(p);
       c->big_task_cap = static_cast<uint32_t>(want);
     }
-    if (!hip_ok(hipMemsetAsync(c->d_big_state, 0, 8 * sizeof(uint32_t), static_cast<hipStream_t>(stream)), "second-pass state reset"))
+    // (words 4..5, the arena cursor, live until gtx_ctx_big_records_rewind)
+    if (!hip_ok(hipMemsetAsync(c->d_big_state, 0, 4 * sizeof(uint32_t), static_cast<hipStream_t>(stream)), "second-pass state reset"))
       return GTX_ERR_HIP;
   }
   char const * fb = std::getenv("GTX_FORCE_SECOND_PASS"); // test switch: every task is redone by the second pass
@@ -578,6 +595,16 @@ extern "C" int gtx_ctx_big_records(gtx_ctx * c, const uint32_t ** d_words, uint6
     if (tasks)
       *tasks = std::min<uint32_t>(st[0], c->big_task_cap);
   }
+  return GTX_OK;
+}
+
+extern "C" int gtx_ctx_big_records_rewind(gtx_ctx * c, void * stream)
+{
+  if (!c)
+    return GTX_ERR_ARG;
+  if (c->d_big_state &&
+      !hip_ok(hipMemsetAsync(c->d_big_state + 4, 0, 2 * sizeof(uint32_t), static_cast<hipStream_t>(stream)), "arena rewind"))
+    return GTX_ERR_HIP;
   return GTX_OK;
 }
 

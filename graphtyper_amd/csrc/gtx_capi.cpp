@@ -2,6 +2,8 @@
 // per-record stream logic.  No compute on reads happens here.
 #include <cstring>
 #include <memory>
+#include <map>
+#include <tuple>
 #include <string>
 #include <unordered_map>
 
@@ -195,6 +197,121 @@ extern "C"
           cell[k] = 0xFFu;
     }
     *n_saturated = sat;
+    return GTX_OK;
+  }
+
+  // hts_parallel_reader.cpp:782-904.  Connection counts are uint16_t cells incremented without a guard in the reference
+  // (vcf_writer.cpp:136), i.e. sums modulo 65536.
+  int gtx_phase_flags(const gtx_ctx * c, uint32_t n_samples, const uint32_t * gt_cov, const uint32_t * conn_log, uint64_t n_conn,
+                      gtx_phase_entry * out, uint64_t cap, uint64_t * n_out)
+  {
+    if (!c || !gt_cov || (n_conn && !conn_log) || !n_out || (cap && !out))
+      return GTX_ERR_ARG;
+    gtx::HostGraph const & g = c->graph;
+    uint64_t const n_hap = g.n_hap;
+    // connections grouped by (sample, hap1, allele1, hap2): support vector over hap2's alleles
+    struct Key
+    {
+      uint32_t s, h1, a1, h2;
+      bool operator<(Key const & o) const { return std::tie(h1, h2, s, a1) < std::tie(o.h1, o.h2, o.s, o.a1); }
+    };
+    std::map<Key, std::vector<uint16_t>> conn;
+    for (uint64_t i = 0; i < n_conn; ++i)
+    {
+      uint32_t const * e = conn_log + 6 * i;
+      if (e[0] >= n_samples || e[1] >= n_hap || e[3] >= n_hap || e[2] >= g.ref_nvar[e[1]] || e[4] >= g.ref_nvar[e[3]])
+      {
+        gtx::g_last_error = "gtx_phase_flags: connection entry out of range";
+        return GTX_ERR_ARG;
+      }
+      auto & v = conn[Key{e[0], e[1], e[2], e[3]}];
+      if (v.empty())
+        v.assign(g.ref_nvar[e[3]], 0);
+      v[e[4]] = static_cast<uint16_t>(v[e[4]] + e[5]);
+    }
+    constexpr int8_t HAP = 1, ANTI = 2; // IS_ANY_HAP_SUPPORT, IS_ANY_ANTI_HAP_SUPPORT (constants.hpp.in:56-57)
+    using PhKey = std::pair<uint16_t, uint16_t>;
+    std::map<PhKey, std::map<PhKey, int8_t>> ph;
+    auto cov = [&](uint64_t s, uint64_t h, uint64_t a) { return gt_cov[s * g.total_allele + g.allele_off[h] + a]; };
+    auto total = [&](uint64_t s, uint64_t h)
+    {
+      double t = 0.0;
+      for (uint32_t a = 0; a < g.ref_nvar[h]; ++a)
+        t += cov(s, h, a);
+      return t;
+    };
+    auto it = conn.begin();
+    while (it != conn.end())
+    {
+      // one (hap1, hap2) group; the reference only looks at pairs whose variant orders are < 100 apart (:800-801)
+      uint32_t const h1 = it->first.h1, h2 = it->first.h2;
+      auto group_end = it;
+      while (group_end != conn.end() && group_end->first.h1 == h1 && group_end->first.h2 == h2)
+        ++group_end;
+      // Haplotype::gt.id = order of the site's variant nodes (graph.cpp:680-704)
+      bool const near = h2 > h1 && static_cast<long>(g.var_order[g.ref_first_var[h2]]) < static_cast<long>(g.var_order[g.ref_first_var[h1]]) + 100;
+      if (near)
+        for (auto e = it; e != group_end; ++e)
+        {
+          uint32_t const s = e->first.s, cov1 = e->first.a1;
+          if (cov1 == 0)
+            continue; // skip reference (:812)
+          double const total1 = total(s, h1), total2 = total(s, h2);
+          uint32_t const c1 = cov(s, h1, cov1);
+          bool const clearly1 = c1 >= 4 || static_cast<double>(c1) / total1 >= 0.28;
+          bool const not1 = c1 <= 2 || static_cast<double>(c1) / total1 < 0.22;
+          auto & row = ph[{static_cast<uint16_t>(h1), static_cast<uint16_t>(cov1)}];
+          std::vector<uint16_t> const & support_vec = e->second;
+          long total_support = 0;
+          for (uint16_t v : support_vec)
+            total_support += v;
+          for (uint32_t cov2 = 1; cov2 < support_vec.size(); ++cov2)
+          {
+            double const support = static_cast<double>(support_vec[cov2]);
+            uint32_t const c2 = cov(s, h2, cov2);
+            bool const clearly2 = c2 >= 4 || static_cast<double>(c2) / total2 >= 0.28;
+            bool const not2 = c2 <= 2 || static_cast<double>(c2) / total2 < 0.22;
+            int8_t flag;
+            if (not1 && not2)
+              continue;
+            if ((not1 && clearly2) || (not2 && clearly1))
+              flag = ANTI;
+            else
+            {
+              if (total_support <= 2)
+                continue;
+              if (clearly1 && clearly2 && support / static_cast<double>(total_support) > 0.78)
+                flag = HAP;
+              else if (support / static_cast<double>(total_support) < 0.22)
+                flag = ANTI;
+              else
+                continue;
+            }
+            row[{static_cast<uint16_t>(h2), static_cast<uint16_t>(cov2)}] |= flag;
+          }
+        }
+      it = group_end;
+    }
+    uint64_t n = 0;
+    auto put = [&](PhKey a, PhKey b, int8_t f)
+    {
+      if (n < cap)
+        out[n] = gtx_phase_entry{a.first, a.second, b.first, b.second, f, 0};
+      ++n;
+    };
+    for (auto const & r : ph)
+    {
+      if (r.second.empty())
+        put(r.first, PhKey{0xFFFF, 0xFFFF}, 0);
+      for (auto const & e : r.second)
+        put(r.first, e.first, e.second);
+    }
+    *n_out = n;
+    if (n > cap)
+    {
+      gtx::g_last_error = "gtx_phase_flags: output buffer too small";
+      return GTX_ERR_CAPACITY;
+    }
     return GTX_OK;
   }
 }

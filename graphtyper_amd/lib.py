@@ -21,7 +21,7 @@ ST_ERROR_MASK = 15
 # names every build of libgtx.so must export (checked by tests/test_abi.py against include/gtx.h)
 EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy", "gtx_ctx_special_positions",
            "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_index_stats", "gtx_index_get", "gtx_index_dump",
-           "gtx_align_batch", "gtx_score_batch", "gtx_ctx_big_records", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_stream_create",
+           "gtx_align_batch", "gtx_score_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
            "gtx_graph_destroy"]
 
@@ -54,6 +54,8 @@ READ_META = np.dtype([("l_qseq", np.uint16), ("flag", np.uint16), ("tid", np.int
 REC_META = np.dtype([("align_index", np.uint32), ("flag", np.uint16), ("mapq", np.uint8), ("score_diff", np.uint8),
                      ("pos", np.int32), ("isize", np.int32)], align=True)
 SCORE_ITEM = np.dtype([("first", REC_META), ("second", REC_META), ("sample", np.uint32), ("reserved", np.uint32)], align=True)
+PHASE_ENTRY = np.dtype([("hap1", np.uint16), ("allele1", np.uint16), ("hap2", np.uint16), ("allele2", np.uint16),
+                        ("flags", np.int8), ("reserved", np.uint8)], align=True)
 STREAM_RECORD = np.dtype([("flag", np.uint16), ("mapq", np.uint8), ("score_diff", np.uint8), ("tid", np.int32),
                           ("mtid", np.int32), ("pos", np.int32), ("isize", np.int32), ("l_qseq", np.uint16),
                           ("rg", np.uint16), ("sample", np.uint32), ("name_id", np.uint64)], align=True)
@@ -99,6 +101,8 @@ def lib():
         L.gtx_ctx_profile.argtypes = [C.c_void_p, C.c_void_p]
         L.gtx_scores_finalize.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                           C.POINTER(C.c_uint64)]
+        L.gtx_phase_flags.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                      C.POINTER(C.c_uint64)]
         L.gtx_stream_create.argtypes = [C.POINTER(Params), C.c_uint32, C.POINTER(C.c_void_p)]
         L.gtx_stream_destroy.argtypes = [C.c_void_p]
         L.gtx_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
@@ -345,6 +349,26 @@ class Context:
             if rc != 0:
                 raise RuntimeError(f"hipMemcpy failed ({rc})")
         return out, int(tasks.value)
+
+    def rewind_big_records(self):
+        check(lib().gtx_ctx_big_records_rewind(self.h, None))
+
+    def phase_flags(self, n_samples, gt_cov, conn_log, n_conn):
+        """gtx_phase_flags: rows (hap1, allele1, hap2, allele2, flags) as an int array [n, 5]"""
+        gt_cov = np.ascontiguousarray(gt_cov, np.uint32)
+        conn_log = np.ascontiguousarray(conn_log, np.uint32)
+        n = C.c_uint64()
+        cap = 1024
+        while True:
+            out = np.zeros(cap, PHASE_ENTRY)
+            rc = lib().gtx_phase_flags(self.h, n_samples, _p(gt_cov), _p(conn_log), C.c_uint64(n_conn), _p(out), C.c_uint64(cap),
+                                       C.byref(n))
+            if rc == 5 and n.value > cap:  # GTX_ERR_CAPACITY
+                cap = int(n.value)
+                continue
+            check(rc)
+            out = out[:n.value]
+            return np.stack([out["hap1"], out["allele1"], out["hap2"], out["allele2"], out["flags"]], axis=1).astype(np.int64)
 
     def error_count(self):
         n = C.c_uint32()

@@ -208,8 +208,9 @@ int gtx_index_dump(const gtx_ctx *, uint64_t * keys, uint32_t * counts, gtx_labe
  *    hap = haplotype (variant site) index, Path::var_order = hap_order[hap] of gtx_ctx_haplotypes;
  *    mask bit a set <=> allele a in Path::nums
  *    A record with GTX_ST_EXTERNAL (a result with more paths than rec_words holds) keeps w0/w1 and has w2 = word offset
- *    of its path words in the context's big-record arena (gtx_ctx_big_records).  The arena is rewound by every
- *    gtx_align_batch, so records must be scored / downloaded before the context aligns the next batch.
+ *    of its path words in the context's big-record arena (gtx_ctx_big_records).  Like d_records the arena is meant to
+ *    stay resident while a region is processed (a parked mate is scored batches later): it only grows until
+ *    gtx_ctx_big_records_rewind; when it is full such a read ends with GTX_ST_RECORD_OVERFLOW.
  * stream     : hipStream_t or NULL
  * Two passes: the main kernel keeps a read's tables in LDS; the few reads that exceed them (repeats: hundreds of seed
  * locations) are queued on the device and redone by a second kernel over HBM-resident tables that hold what the
@@ -246,10 +247,13 @@ int gtx_score_batch(gtx_ctx *, const gtx_score_item * d_items, uint32_t n_items,
  * (must be 0 for the accumulators to be complete) */
 int gtx_ctx_error_count(gtx_ctx *, uint32_t * out);
 
-/* device pointer and capacity (uint32 words) of the big-record arena; used_words (may be NULL) = words the last
- * gtx_align_batch filled, tasks (may be NULL) = (read, orientation) tasks it sent through the second pass
+/* device pointer and capacity (uint32 words) of the big-record arena; used_words (may be NULL) = words filled since the
+ * last rewind, tasks (may be NULL) = (read, orientation) tasks the last gtx_align_batch sent through the second pass
  * (both synchronise with the device) */
 int gtx_ctx_big_records(gtx_ctx *, const uint32_t ** d_words, uint64_t * capacity_words, uint64_t * used_words, uint64_t * tasks);
+
+/* forget every GTX_ST_EXTERNAL record (call between regions, when d_records is recycled) */
+int gtx_ctx_big_records_rewind(gtx_ctx *, void * stream);
 
 /* out[32]: per-phase shader-cycle sums of the alignment kernel; only the profiling build (libgtx_prof.so) fills them */
 int gtx_ctx_profile(gtx_ctx *, uint64_t * out);
@@ -260,6 +264,22 @@ int gtx_ctx_profile(gtx_ctx *, uint64_t * out);
  * reported, never silently clamped. */
 int gtx_scores_finalize(uint32_t * log_score, uint64_t n_log, uint32_t * gt_cov, uint64_t n_cov, uint32_t * hap_u32,
                         uint64_t n_hap_cells, uint64_t * n_saturated);
+
+/* Phasing flags between alt alleles of variant sites less than 100 bp apart: replaces the `ph` construction of
+ * parallel_reader_genotype_only (src/utilities/hts_parallel_reader.cpp:782-904).  Host only.
+ * gt_cov: finalised d_gt_cov; conn_log / n_conn: the downloaded connection log.  Rows come in the order of the reference's
+ * std::map (hap1, allele1, hap2, allele2); an outer key that exists without any flag under it (the reference inserts it
+ * as soon as a connection exists) is one row with hap2 = allele2 = 0xFFFF, flags = 0.
+ * flags: 1 = IS_ANY_HAP_SUPPORT, 2 = IS_ANY_ANTI_HAP_SUPPORT (include/graphtyper/constants.hpp.in:56-57), or-ed over samples.
+ * *n receives the number of rows (GTX_ERR_CAPACITY when it exceeds cap). */
+typedef struct gtx_phase_entry
+{
+  uint16_t hap1, allele1, hap2, allele2;
+  int8_t flags;
+  uint8_t reserved;
+} gtx_phase_entry;
+int gtx_phase_flags(const gtx_ctx *, uint32_t n_samples, const uint32_t * gt_cov, const uint32_t * conn_log, uint64_t n_conn,
+                    gtx_phase_entry * out, uint64_t cap, uint64_t * n);
 
 /* ---- host mirror of the per-record control flow (no device work) ----
  * Feed records in merged stream order; the stream decides which records are filtered, which reuse the previous

@@ -24,6 +24,7 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <numeric>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -2431,6 +2432,72 @@ struct Genotyper
     genotype_only(rec, true);
     prev = rec;
     have_prev = true;
+  }
+
+  // hts_parallel_reader.cpp:782-904: phasing flags between alt alleles of sites less than 100 bp apart, from the
+  // per-sample allele depths and allele-pair connection counts.  Keys are (haplotype index, allele) as uint16_t; an outer
+  // key is created as soon as a connection exists, whether or not a flag is set under it.
+  using PhKey = std::pair<uint16_t, uint16_t>;
+  std::map<PhKey, std::map<PhKey, int8_t>> phase_flags() const
+  {
+    constexpr int8_t IS_ANY_HAP_SUPPORT = 1, IS_ANY_ANTI_HAP_SUPPORT = 2; // include/graphtyper/constants.hpp.in:56-57
+    std::map<PhKey, std::map<PhKey, int8_t>> ph;
+    auto const & haps = writer.haplotypes;
+    for (long ps1 = 0; ps1 < static_cast<long>(haps.size()) - 1l; ++ps1)
+    {
+      auto const & hap1 = haps[ps1];
+      long const order1 = hap1.id;
+      for (long ps2 = ps1 + 1l; ps2 < static_cast<long>(haps.size()); ++ps2)
+      {
+        auto const & hap2 = haps[ps2];
+        long const order2 = hap2.id;
+        if (order2 >= order1 + 100)
+          break;
+        for (long s = 0; s < static_cast<long>(hap1.hap_samples.size()); ++s)
+        {
+          auto const & hs1 = hap1.hap_samples[s];
+          auto const & hs2 = hap2.hap_samples[s];
+          double const total1 = std::accumulate(hs1.gt_coverage.begin(), hs1.gt_coverage.end(), 0.0);
+          double const total2 = std::accumulate(hs2.gt_coverage.begin(), hs2.gt_coverage.end(), 0.0);
+          for (long cov1 = 1; cov1 < static_cast<long>(hap1.num); ++cov1)
+          {
+            auto const & conn = hs1.connections[cov1];
+            auto find_it = conn.find(static_cast<uint16_t>(ps2));
+            if (find_it == conn.end())
+              continue;
+            bool const is_clearly_seen1 = hs1.gt_coverage[cov1] >= 4 || static_cast<double>(hs1.gt_coverage[cov1]) / total1 >= 0.28;
+            bool const is_not_seen1 = hs1.gt_coverage[cov1] <= 2 || static_cast<double>(hs1.gt_coverage[cov1]) / total1 < 0.22;
+            auto & row = ph[{static_cast<uint16_t>(ps1), static_cast<uint16_t>(cov1)}];
+            std::vector<uint16_t> const & support_vec = find_it->second;
+            long const total_support = std::accumulate(support_vec.begin(), support_vec.end(), 0l);
+            for (long cov2 = 1; cov2 < static_cast<long>(support_vec.size()); ++cov2)
+            {
+              double const support = static_cast<double>(support_vec[cov2]);
+              int8_t is_good = 0;
+              bool const is_clearly_seen2 = hs2.gt_coverage[cov2] >= 4 || static_cast<double>(hs2.gt_coverage[cov2]) / total2 >= 0.28;
+              bool const is_not_seen2 = hs2.gt_coverage[cov2] <= 2 || static_cast<double>(hs2.gt_coverage[cov2]) / total2 < 0.22;
+              if (is_not_seen1 && is_not_seen2)
+                continue;
+              if ((is_not_seen1 && is_clearly_seen2) || (is_not_seen2 && is_clearly_seen1))
+                is_good = IS_ANY_ANTI_HAP_SUPPORT;
+              else
+              {
+                if (total_support <= 2)
+                  continue;
+                if (is_clearly_seen1 && is_clearly_seen2 && support / static_cast<double>(total_support) > 0.78)
+                  is_good = IS_ANY_HAP_SUPPORT;
+                else if (support / static_cast<double>(total_support) < 0.22)
+                  is_good = IS_ANY_ANTI_HAP_SUPPORT;
+                else
+                  continue;
+              }
+              row[{static_cast<uint16_t>(ps2), static_cast<uint16_t>(cov2)}] |= is_good;
+            }
+          }
+        }
+      }
+    }
+    return ph;
   }
 };
 

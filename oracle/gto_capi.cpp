@@ -486,6 +486,31 @@ extern "C"
     return static_cast<long>(s.size());
   }
 
+  // phase flags (hts_parallel_reader.cpp:782-904): rows of (hap1, allele1, hap2, allele2, flags); an outer key without
+  // any flag under it is one row with hap2 = allele2 = 0xFFFF, flags = 0.  Returns the number of rows.
+  long gto_phase_flags(void * p, int32_t * out, long cap_rows)
+  {
+    auto ph = static_cast<GenoHandle *>(p)->g->phase_flags();
+    long n = 0;
+    auto put = [&](int a, int b, int c, int d, int f)
+    {
+      if (n < cap_rows)
+      {
+        int32_t * o = out + 5 * n;
+        o[0] = a; o[1] = b; o[2] = c; o[3] = d; o[4] = f;
+      }
+      ++n;
+    };
+    for (auto const & r : ph)
+    {
+      if (r.second.empty())
+        put(r.first.first, r.first.second, 0xFFFF, 0xFFFF, 0);
+      for (auto const & e : r.second)
+        put(r.first.first, r.first.second, e.first.first, e.first.second, e.second);
+    }
+    return n;
+  }
+
   void gto_genotyper_counts(void * p, long * out)
   {
     auto * g = static_cast<GenoHandle *>(p);

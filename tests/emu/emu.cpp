@@ -117,8 +117,8 @@ extern "C"
     bool const force_big = fe && fe[0] == '1';
     char const * fl = std::getenv("GTX_EMU_FILL"); // what uninitialised workspace memory looks like
     int const fill = fl ? std::atoi(fl) : 0xAB;
-    e.arena.assign(e.params.big_record_words ? e.params.big_record_words : (1u << 20), 0xABABABABu);
-    e.arena_used = 0;
+    if (e.arena.empty()) // grows until emu_big_records_rewind, like the device arena
+      e.arena.assign(e.params.big_record_words ? e.params.big_record_words : (1u << 20), 0xABABABABu);
     e.second_pass_tasks = 0;
     bool const force_both = e.params.force_align_both_orientations != 0;
     for (uint32_t t = 0; t < 2 * n_reads; ++t)
@@ -179,9 +179,11 @@ extern "C"
   {
     Emu & e = *static_cast<Emu *>(p);
     *words = e.arena.data();
-    *capacity_words = e.arena.size();
+    *capacity_words = e.arena_used;
     return 0;
   }
+
+  void emu_big_records_rewind(void * p) { static_cast<Emu *>(p)->arena_used = 0; }
 
   uint64_t emu_second_pass_tasks(void * p) { return static_cast<Emu *>(p)->second_pass_tasks; }
 

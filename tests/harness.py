@@ -63,6 +63,9 @@ class EmuBackend:
         self.L.emu_align(C.c_void_p(self.h), _p(seq), C.c_uint32(seq.shape[1]), _p(meta), C.c_uint32(n), _p(rec), C.c_uint32(rec_words))
         return rec
 
+    def rewind_big_records(self):
+        self.L.emu_big_records_rewind(C.c_void_p(self.h))
+
     def big_records(self):
         ptr, cap = C.POINTER(C.c_uint32)(), C.c_uint64()
         self.L.emu_big_records(C.c_void_p(self.h), C.byref(ptr), C.byref(cap))
@@ -108,6 +111,9 @@ class GpuBackend:
 
     def big_records(self):
         return self.ctx.big_records()
+
+    def rewind_big_records(self):
+        self.ctx.rewind_big_records()
 
     def score(self, items, records, n_samples=1, rec_words=REC_WORDS):
         torch = self.torch

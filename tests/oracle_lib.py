@@ -227,6 +227,15 @@ class OracleGenotyper:
         L.gto_scores_dump(C.c_void_p(self.g), _p(out), C.c_long(n))
         return out
 
+    def phase_flags(self):
+        """rows (hap1, allele1, hap2, allele2, flags) of the `ph` map (gto_phase_flags)"""
+        L = lib()
+        L.gto_phase_flags.restype = C.c_long
+        n = L.gto_phase_flags(C.c_void_p(self.g), None, C.c_long(0))
+        out = np.zeros((max(n, 1), 5), np.int32)
+        L.gto_phase_flags(C.c_void_p(self.g), _p(out), C.c_long(n))
+        return out[:n].astype(np.int64)
+
     def counts(self):
         c = (C.c_long * 3)()
         lib().gto_genotyper_counts(C.c_void_p(self.g), c)

@@ -75,6 +75,12 @@ def run_stream(backend, oracle, codes, rec, n_samples, n_rg=1):
     assert len(got) == len(want)
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, "score streams differ at words %s" % bad[:10]
+    # phasing flags from the finalised depths and the connection log (hts_parallel_reader.cpp:782-904)
+    gt_cov = np.minimum(acc.gt_cov, 0xFFFF).astype(np.uint32)
+    ph = backend.ctx.phase_flags(n_samples, gt_cov, acc.conn_log, int(acc.conn_count[0]))
+    want_ph = og.phase_flags()
+    assert ph.shape == want_ph.shape and np.array_equal(ph, want_ph), "phase flags differ"
+    run_stream.last_phase_rows = len(ph)
     return want
 
 
@@ -85,6 +91,15 @@ def test_stream_scores(kind):
     b = harness.EmuBackend(gtx.graph_from_records(ref, recs, region_begin=310000))
     want = run_stream(b, o, codes, rec, n_samples=2)
     assert want.sum() > 0
+
+
+def test_phase_flags_have_content():
+    """dense SNPs, 2 samples with different haplotypes: the `ph` rows compared inside run_stream must not be vacuous"""
+    ref, recs, codes, rec = scenarios.paired_case("snp25", n_ref=20000, n_pairs=3000, region_begin=310000)
+    o = Oracle(ref, recs, region_begin=310000)
+    b = harness.EmuBackend(gtx.graph_from_records(ref, recs, region_begin=310000))
+    run_stream(b, o, codes, rec, n_samples=2)
+    assert run_stream.last_phase_rows > 50
 
 
 def test_direct_probes_and_half_key_buckets_agree(monkeypatch):
@@ -132,6 +147,14 @@ def second_pass_case(Backend, kind, n_reads):
     seq, lens = harness.pack_ragged(list(codes))
     rec1 = b1.align(seq, harness.read_meta(lens))
     assert int(((rec1.reshape(-1, harness.REC_WORDS)[:, 0] >> 16) != 0).sum()) == tasks
+    # the arena outlives a batch (a parked mate is scored batches later): two batches, then decode both
+    whole = gtx.parse_records(rec, len(codes), harness.REC_WORDS, b.ctx.hap_order, b.big_records()[0])
+    b.rewind_big_records()
+    half = len(codes) // 2
+    meta = harness.read_meta(lens)
+    parts = np.concatenate([b.align(seq[:half], meta[:half]), b.align(seq[half:], meta[half:])])
+    assert gtx.parse_records(parts, len(codes), harness.REC_WORDS, b.ctx.hap_order, b.big_records()[0]) == whole
+    b.rewind_big_records()
     order = np.argsort(pos, kind="stable")
     srec = scenarios.stream_records(len(codes), pos, sample=np.arange(len(codes)) % 2)
     run_stream(b, o, codes[order], srec[order], n_samples=2)
