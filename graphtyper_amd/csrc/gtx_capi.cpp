@@ -323,7 +323,60 @@ extern "C"
 struct gtx_stream
 {
   gtx_params params{};
-  std::vector<std::unordered_map<uint64_t, gtx_rec_meta>> parked; // per read group: read name -> parked mate
+  struct Parked
+  {
+    gtx_rec_meta meta;
+    uint32_t sample;
+  };
+  std::vector<std::unordered_map<uint64_t, Parked>> parked; // per read group: read name -> parked mate
+  // SV calling: coverage filter state (hts_parallel_reader.cpp:594-633)
+  std::vector<double> avg_cov_by_readlen;
+  std::vector<std::vector<uint16_t>> bin_counts;
+  long first_pos = 0;
+
+  bool update_bin_count(gtx_stream_record const & r)
+  {
+    if (!params.is_sv_graph || avg_cov_by_readlen.empty())
+      return true;
+    if (r.sample >= avg_cov_by_readlen.size() || avg_cov_by_readlen[r.sample] <= 0.0)
+      return true;
+    uint16_t const max_bin_count = static_cast<uint16_t>(std::min(65535l, static_cast<long>(avg_cov_by_readlen[r.sample] * 50.0 * 3.0 + 0.5)));
+    if (bin_counts.size() <= r.sample)
+      bin_counts.resize(r.sample + 1);
+    auto & bins = bin_counts[r.sample];
+    long const bin = (static_cast<long>(r.pos) - first_pos) / 50l;
+    if (bin >= static_cast<long>(bins.size()))
+    {
+      bins.resize(bin + 1, 0u);
+      ++bins[bin];
+      return true;
+    }
+    if (bin < 0) // cannot happen in a position-sorted stream
+      return true;
+    if (bins[bin] > max_bin_count)
+      return false;
+    ++bins[bin];
+    return true;
+  }
+
+  // hts_parallel_reader.cpp:528-568
+  static bool is_good_read(gtx_stream_record const & r)
+  {
+    if (r.flag & 4u) // IS_UNMAPPED
+      return false;
+    bool const is_mate_far_away = r.tid != r.mtid || std::labs(static_cast<long>(r.pos) - r.mpos) > 200000;
+    if (r.mapq <= 15 && is_mate_far_away)
+      return false;
+    if (r.n_cigar >= 2)
+    {
+      constexpr uint32_t SOFT_CLIP = 4; // BAM_CSOFT_CLIP, 'S'
+      bool const front_s = (r.cigar_front & 15u) == SOFT_CLIP, back_s = (r.cigar_back & 15u) == SOFT_CLIP;
+      bool const is_one_clipped = (front_s && (r.cigar_front >> 4) >= 12) || (back_s && (r.cigar_back >> 4) >= 12);
+      if ((front_s && back_s) || (r.mapq <= 15 && is_one_clipped))
+        return false;
+    }
+    return true;
+  }
   bool have_prev = false;
   int32_t prev_tid = 0, prev_pos = 0;
   std::vector<uint8_t> prev_seq;
@@ -358,7 +411,7 @@ extern "C"
     for (uint32_t i = 0; i < n; ++i)
     {
       gtx_stream_record const & r = recs[i];
-      if ((r.flag & s->params.sam_flag_filter) != 0) // hts_parallel_reader.cpp:658
+      if ((r.flag & s->params.sam_flag_filter) != 0 || (s->params.is_sv_graph && !gtx_stream::is_good_read(r))) // :658-663
         continue;
       if (r.rg >= s->parked.size())
       {
@@ -374,13 +427,21 @@ extern "C"
       bool const dup = s->have_prev && r.tid == s->prev_tid && r.pos == s->prev_pos && r.l_qseq == s->prev_len &&
                        std::memcmp(rseq, s->prev_seq.data(), nbytes) == 0;
       uint32_t align_index;
+      if (!s->have_prev)
+        s->first_pos = r.pos; // the first record that passes the filters anchors the coverage bins (:594)
       if (dup)
       {
+        (void)s->update_bin_count(r);
         ++s->n_duplicated;
         align_index = s->prev_align_index; // prev_paths are reused as they are (hts_parallel_reader.cpp:666-684)
       }
       else
       {
+        if (!s->update_bin_count(r) && s->have_prev) // too many reads in this bin: the record is skipped (:685-690)
+        {
+          --s->n_records;
+          continue;
+        }
         if (na >= align_cap)
           return GTX_ERR_CAPACITY;
         std::memcpy(align_seq + static_cast<uint64_t>(na) * seq_stride, rseq, nbytes);
@@ -401,7 +462,7 @@ extern "C"
       {
         if (r.flag & 1u) // IS_PAIRED: wait for the mate (hts_parallel_reader.cpp:283-290)
         {
-          map.emplace(r.name_id, me);
+          map.emplace(r.name_id, gtx_stream::Parked{me, r.sample});
           continue;
         }
         if (ni >= item_cap)
@@ -413,7 +474,7 @@ extern "C"
         items[ni++] = item;
         continue;
       }
-      if ((it->second.flag & 64u) == (r.flag & 64u)) // both mates claim the same IS_FIRST_IN_PAIR: the reference exits (:306-315)
+      if ((it->second.meta.flag & 64u) == (r.flag & 64u)) // both mates claim the same IS_FIRST_IN_PAIR: the reference exits (:306-315)
       {
         g_last_error = "gtx_stream_push: two reads with one name have the same IS_FIRST_IN_PAIR";
         return GTX_ERR_ARG;
@@ -421,13 +482,46 @@ extern "C"
       if (ni >= item_cap)
         return GTX_ERR_CAPACITY;
       gtx_score_item item{};
-      item.first = it->second;
+      item.first = it->second.meta;
       item.second = me;
       item.sample = r.sample;
       items[ni++] = item;
       map.erase(it);
     }
     *n_align = na;
+    *n_items = ni;
+    return GTX_OK;
+  }
+
+  int gtx_stream_set_coverage(gtx_stream * s, const double * avg_cov_by_readlen, uint32_t n_samples)
+  {
+    if (!s || (n_samples && !avg_cov_by_readlen))
+      return GTX_ERR_ARG;
+    s->avg_cov_by_readlen.assign(avg_cov_by_readlen, avg_cov_by_readlen + n_samples);
+    return GTX_OK;
+  }
+
+  int gtx_stream_finish(gtx_stream * s, gtx_score_item * items, uint32_t item_cap, uint32_t * n_items)
+  {
+    if (!s || !n_items || (item_cap && !items))
+      return GTX_ERR_ARG;
+    uint32_t ni = 0;
+    if (s->params.is_sv_graph)
+      for (auto const & map : s->parked)
+        for (auto const & kv : map)
+        {
+          if (ni >= item_cap)
+            return GTX_ERR_CAPACITY; // nothing was forgotten: call again with room for gtx_stream_counts' parked reads
+          gtx_score_item item{};
+          item.first = kv.second.meta;
+          item.second = kv.second.meta;
+          item.second.flag ^= (64u | 16u); // IS_FIRST_IN_PAIR | IS_SEQ_REVERSED (:729-730)
+          item.sample = kv.second.sample;
+          item.kind = GTX_ITEM_LEFTOVER;
+          items[ni++] = item;
+        }
+    for (auto & map : s->parked)
+      map.clear();
     *n_items = ni;
     return GTX_OK;
   }

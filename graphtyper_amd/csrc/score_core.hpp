@@ -486,6 +486,18 @@ GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_
   // update_haplotype_scores_geno, pair overload (vcf_writer.cpp:143-250)
   bool f1, u1, f2, u2;
   bool const good1 = geno_is_good(g, par, first, f1, u1), good2 = geno_is_good(g, par, second, f2, u2);
+  if (it.kind & GTX_ITEM_LEFTOVER)
+  {
+    // a read whose mate never came (hts_parallel_reader.cpp:733-744): the single-read overload on better_paths.first
+    if (!par.is_segment_calling && good1)
+    {
+      uint32_t const n = collect_recent(g, first, r1, cap);
+      if (n == 0xFFFFFFFFu)
+        return false;
+      apply_recent<W>(g, acc, first, f1, u1, it.sample, r1, n);
+    }
+    return true;
+  }
   if (par.is_segment_calling && (!good1 || !good2))
     return true;
   uint32_t n1 = 0, n2 = 0;

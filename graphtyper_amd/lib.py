@@ -22,7 +22,7 @@ ST_ERROR_MASK = 15
 EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy", "gtx_ctx_special_positions",
            "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_index_stats", "gtx_index_get", "gtx_index_dump",
            "gtx_align_batch", "gtx_score_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
-           "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
+           "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_set_coverage", "gtx_stream_finish", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
            "gtx_graph_destroy"]
 
 
@@ -53,14 +53,16 @@ class ScoreBuffers(C.Structure):
 READ_META = np.dtype([("l_qseq", np.uint16), ("flag", np.uint16), ("tid", np.int32), ("mtid", np.int32), ("isize", np.int32)], align=True)
 REC_META = np.dtype([("align_index", np.uint32), ("flag", np.uint16), ("mapq", np.uint8), ("score_diff", np.uint8),
                      ("pos", np.int32), ("isize", np.int32)], align=True)
-SCORE_ITEM = np.dtype([("first", REC_META), ("second", REC_META), ("sample", np.uint32), ("reserved", np.uint32)], align=True)
+SCORE_ITEM = np.dtype([("first", REC_META), ("second", REC_META), ("sample", np.uint32), ("kind", np.uint32)], align=True)
+ITEM_LEFTOVER = 1
 PHASE_ENTRY = np.dtype([("hap1", np.uint16), ("allele1", np.uint16), ("hap2", np.uint16), ("allele2", np.uint16),
                         ("flags", np.int8), ("reserved", np.uint8)], align=True)
 STREAM_RECORD = np.dtype([("flag", np.uint16), ("mapq", np.uint8), ("score_diff", np.uint8), ("tid", np.int32),
                           ("mtid", np.int32), ("pos", np.int32), ("isize", np.int32), ("l_qseq", np.uint16),
-                          ("rg", np.uint16), ("sample", np.uint32), ("name_id", np.uint64)], align=True)
+                          ("rg", np.uint16), ("sample", np.uint32), ("name_id", np.uint64), ("mpos", np.int32),
+                          ("n_cigar", np.uint32), ("cigar_front", np.uint32), ("cigar_back", np.uint32)], align=True)
 LABEL = np.dtype([("start_index", np.uint32), ("end_index", np.uint32), ("variant_id", np.uint32)], align=True)
-assert READ_META.itemsize == 16 and REC_META.itemsize == 16 and SCORE_ITEM.itemsize == 40 and STREAM_RECORD.itemsize == 40
+assert READ_META.itemsize == 16 and REC_META.itemsize == 16 and SCORE_ITEM.itemsize == 40 and STREAM_RECORD.itemsize == 56
 
 
 def build(force=False):
@@ -107,6 +109,8 @@ def lib():
         L.gtx_stream_destroy.argtypes = [C.c_void_p]
         L.gtx_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                       C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.gtx_stream_set_coverage.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.gtx_stream_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.gtx_stream_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.gtx_graph_build.argtypes = [C.c_char_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_void_p)]
@@ -401,6 +405,18 @@ class Stream:
         check(lib().gtx_stream_push(self.h, _p(recs), _p(seq), stride, n, _p(a_seq), _p(a_meta), n, C.byref(na), _p(items), n,
                                     C.byref(ni)))
         return a_seq[:na.value], a_meta[:na.value], items[:ni.value]
+
+    def set_coverage(self, avg_cov_by_readlen):
+        a = np.ascontiguousarray(avg_cov_by_readlen, np.float64)
+        check(lib().gtx_stream_set_coverage(self.h, _p(a), len(a)))
+
+    def finish(self):
+        """end of the stream -> leftover items (SV calling), parked reads are forgotten"""
+        cap = max(self.counts()["parked"], 1)
+        items = np.zeros(cap, SCORE_ITEM)
+        ni = C.c_uint32()
+        check(lib().gtx_stream_finish(self.h, _p(items), cap, C.byref(ni)))
+        return items[:ni.value]
 
     def counts(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -13,7 +13,11 @@
  *   gtx_scores_finalize replaces  reading VcfWriter::haplotypes[*].hap_samples[*] / var_stats after the read loop
  *                                                                               src/utilities/hts_parallel_reader.cpp:782-1033
  *   gtx_stream_*        mirrors   the per-record logic of parallel_reader_genotype_only / genotype_only
- *                                 (flag filter, duplicate reuse, mate parking)  src/utilities/hts_parallel_reader.cpp:245-338,570-708
+ *                                 (flag filter, duplicate reuse, mate parking; SV calling: record filter, coverage
+ *                                 filter, leftover reads)                       src/utilities/hts_parallel_reader.cpp:245-338,528-772
+ *   gtx_phase_flags     replaces  the `ph` construction                         src/utilities/hts_parallel_reader.cpp:782-904
+ *   gtx_graph_build     replaces  Graph::add_genomic_region                     src/graph/graph.cpp:41-339
+ *   gtx_graph_from_files replaces construct_graph (graphs without SV alleles)   src/graph/constructor.cpp:1597-1777
  *
  * Conventions: plain pointers and sizes only; the caller allocates and owns every buffer; a context is immutable
  * after creation and may be used from several host threads; every function returns a status code (0 = ok) and never
@@ -160,12 +164,16 @@ typedef struct gtx_rec_meta
 } gtx_rec_meta;
 
 /* One call of genotype_only() that reaches the VcfWriter: an unpaired record (second.align_index == GTX_INVALID_ID)
- * or a mate pair (first = the parked mate, second = the record that completed the pair). */
+ * or a mate pair (first = the parked mate, second = the record that completed the pair).
+ * kind GTX_ITEM_LEFTOVER (SV calling, src/utilities/hts_parallel_reader.cpp:719-745): a read whose mate never came;
+ * second = the same record with IS_FIRST_IN_PAIR | IS_SEQ_REVERSED toggled, the better orientation pair is chosen as for
+ * mates but only its first member is scored, alone. */
+#define GTX_ITEM_LEFTOVER 1u
 typedef struct gtx_score_item
 {
   gtx_rec_meta first, second;
   uint32_t sample; /* pn_index */
-  uint32_t reserved;
+  uint32_t kind;   /* 0 or GTX_ITEM_LEFTOVER */
 } gtx_score_item;
 
 typedef struct gtx_ctx gtx_ctx;
@@ -298,6 +306,10 @@ typedef struct gtx_stream_record
   uint16_t rg;      /* read group index (mate maps are per read group) */
   uint32_t sample;  /* pn_index */
   uint64_t name_id; /* identity of the read name (equal ids <=> equal QNAME) */
+  /* only read when gtx_params::is_sv_graph (record filter of SV calling, hts_parallel_reader.cpp:528-568) */
+  int32_t mpos;
+  uint32_t n_cigar;
+  uint32_t cigar_front, cigar_back; /* raw BAM cigar words (op | len << 4) of the first / last operation */
 } gtx_stream_record;
 
 int gtx_stream_create(const gtx_params * params, uint32_t n_read_groups, gtx_stream ** out);
@@ -307,6 +319,13 @@ void gtx_stream_destroy(gtx_stream *);
 int gtx_stream_push(gtx_stream *, const gtx_stream_record * recs, const uint8_t * seq, uint32_t seq_stride, uint32_t n,
                     uint8_t * align_seq, gtx_read_meta * align_meta, uint32_t align_cap, uint32_t * n_align,
                     gtx_score_item * items, uint32_t item_cap, uint32_t * n_items);
+/* SV calling only, optional: the (extreme) coverage filter (hts_parallel_reader.cpp:594-633) drops a record once its
+ * sample has more than avg_cov_by_readlen[sample] * 150 accepted records in the record's 50 bp bin.  Without this call
+ * (or with a value <= 0 for a sample) nothing is dropped -- Options::no_filter_on_coverage. */
+int gtx_stream_set_coverage(gtx_stream *, const double * avg_cov_by_readlen, uint32_t n_samples);
+/* End of the record stream.  SV calling: emits one GTX_ITEM_LEFTOVER item per read still waiting for its mate
+ * (hts_parallel_reader.cpp:717-772); always forgets the parked reads. */
+int gtx_stream_finish(gtx_stream *, gtx_score_item * items, uint32_t item_cap, uint32_t * n_items);
 /* number of accepted / duplicated records so far and mates still parked */
 int gtx_stream_counts(const gtx_stream *, uint64_t * n_records, uint64_t * n_duplicated, uint64_t * n_parked);
 

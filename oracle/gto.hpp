@@ -1848,6 +1848,10 @@ struct ReadRecord
   std::string name;
   int sample = 0;
   int rg = 0;
+  // fields only the SV-mode record filter looks at (hts_parallel_reader.cpp:528-568)
+  int64_t mpos = 0;
+  uint32_t n_cigar = 0;
+  uint32_t cigar_front = 0, cigar_back = 0; // raw BAM cigar words (op | len << 4) of the first and last operation
 };
 
 // alignment.cpp:331-363
@@ -2404,6 +2408,7 @@ struct Genotyper
       {
         update_paths(gp, rec);
         map[rec.name] = std::move(gp);
+        parked_sample[rec.name] = rec.sample;
       }
       else if (GenotypePaths * sel = update_unpaired_read_paths(gp, rec))
         writer.update_haplotype_scores_geno(*sel, rec.sample);
@@ -2418,21 +2423,108 @@ struct Genotyper
     map.erase(it);
   }
 
-  void push(ReadRecord const & rec) // hts_parallel_reader.cpp:640-708 (first record and loop body)
+  // SV calling only: hts_parallel_reader.cpp:528-568
+  static bool is_good_read(ReadRecord const & r)
   {
-    if ((rec.flag & par.sam_flag_filter) != 0)
-      return;
-    ++num_records;
-    if (have_prev && equal_pos_seq(prev, rec))
+    if ((r.flag & IS_UNMAPPED) != 0u)
+      return false;
+    static constexpr char CIGAR_MAP[16] = {'M', 'I', 'D', 'N', 'S', 'H', 'P', '=', 'X', 'B', '*', '*', '*', '*', '*', '*'};
+    bool const is_mate_far_away = r.tid != r.mtid || std::abs(r.pos - r.mpos) > 200000;
+    if (r.mapq <= 15 && is_mate_far_away)
+      return false;
+    if (r.n_cigar >= 2)
     {
+      char const front = CIGAR_MAP[r.cigar_front & 15], back = CIGAR_MAP[r.cigar_back & 15];
+      uint32_t const count_front = r.cigar_front >> 4, count_back = r.cigar_back >> 4;
+      bool const is_one_clipped = (front == 'S' && count_front >= 12) || (back == 'S' && count_back >= 12);
+      bool const are_both_clipped = front == 'S' && back == 'S';
+      if (are_both_clipped || (r.mapq <= 15 && is_one_clipped))
+        return false;
+    }
+    return true;
+  }
+
+  // (extreme) coverage filter of SV calling: hts_parallel_reader.cpp:594-633
+  std::vector<double> avg_cov_by_readlen; // per sample; empty = filter has nothing to go by
+  bool no_filter_on_coverage = false;
+  std::vector<std::vector<uint16_t>> bin_counts;
+  long first_pos = 0;
+
+  bool update_bin_count(ReadRecord const & rec)
+  {
+    if (!(graph.is_sv_graph && !no_filter_on_coverage))
+      return true;
+    long const sample_i = rec.sample;
+    if (sample_i >= static_cast<long>(avg_cov_by_readlen.size()) || avg_cov_by_readlen[sample_i] <= 0.0)
+      return true;
+    uint16_t const max_bin_count = static_cast<uint16_t>(std::min(65535l, static_cast<long>(avg_cov_by_readlen[sample_i] * 50.0 * 3.0 + 0.5)));
+    if (static_cast<long>(bin_counts.size()) <= sample_i)
+      bin_counts.resize(sample_i + 1);
+    auto & sample_bin_counts = bin_counts[sample_i];
+    long const bin = (rec.pos - first_pos) / 50l;
+    if (bin >= static_cast<long>(sample_bin_counts.size()))
+    {
+      sample_bin_counts.resize(bin + 1, 0u);
+      ++sample_bin_counts[bin];
+      return true;
+    }
+    if (sample_bin_counts[bin] > max_bin_count)
+      return false;
+    ++sample_bin_counts[bin];
+    return true;
+  }
+
+  void push(ReadRecord const & rec) // hts_parallel_reader.cpp:570-708 (first record and loop body)
+  {
+    if ((rec.flag & par.sam_flag_filter) != 0 || (graph.is_sv_graph && !is_good_read(rec)))
+      return;
+    if (!have_prev) // the first record that passes the filters
+    {
+      first_pos = rec.pos;
+      update_bin_count(rec);
+      ++num_records;
+      genotype_only(rec, true);
+      prev = rec;
+      have_prev = true;
+      return;
+    }
+    ++num_records;
+    if (equal_pos_seq(prev, rec))
+    {
+      update_bin_count(rec);
       ++num_duplicated;
       genotype_only(rec, false);
       return;
     }
+    if (!update_bin_count(rec))
+    {
+      --num_records; // skipped
+      return;
+    }
     genotype_only(rec, true);
     prev = rec;
-    have_prev = true;
   }
+
+  // SV calling only: reads whose mate never showed up are scored on their own (hts_parallel_reader.cpp:717-772).
+  // `sample_of_rg`: the reference derives the sample from the file / read group; the parked read's own sample is that.
+  void finish()
+  {
+    if (graph.is_sv_graph)
+      for (auto & map : maps)
+        for (auto & kv : map)
+        {
+          std::pair<GenotypePaths, GenotypePaths> copy(kv.second);
+          copy.first.flags ^= (IS_FIRST_IN_PAIR | IS_SEQ_REVERSED);
+          copy.second.flags ^= (IS_FIRST_IN_PAIR | IS_SEQ_REVERSED);
+          auto better = get_better_paths(kv.second, copy);
+          if (better.first)
+            writer.update_haplotype_scores_geno(*better.first, parked_sample.at(kv.first));
+        }
+    for (auto & map : maps)
+      map.clear();
+    parked_sample.clear();
+  }
+  std::unordered_map<std::string, int> parked_sample;
 
   // hts_parallel_reader.cpp:782-904: phasing flags between alt alleles of sites less than 100 bp apart, from the
   // per-sample allele depths and allele-pair connection counts.  Keys are (haplotype index, allele) as uint16_t; an outer

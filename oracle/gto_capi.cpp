@@ -425,6 +425,44 @@ extern "C"
     }
   }
 
+  // same as gto_genotyper_push plus the fields of the SV-mode record filter (any of them may be NULL = 0)
+  int gto_genotyper_push_ex(void * p, long n, uint8_t const * codes, uint32_t const * offs, uint16_t const * flags,
+                            int32_t const * tid, int32_t const * mtid, int64_t const * pos, int64_t const * isize,
+                            uint8_t const * mapq, uint8_t const * score_diff, uint64_t const * name, int32_t const * sample,
+                            int32_t const * rg, int64_t const * mpos, uint32_t const * n_cigar, uint32_t const * cigar_front,
+                            uint32_t const * cigar_back)
+  {
+    try
+    {
+      auto * g = static_cast<GenoHandle *>(p);
+      for (long i = 0; i < n; ++i)
+      {
+        ReadRecord r = make_record(i, codes, offs, flags, tid, mtid, pos, isize, mapq, score_diff, name, sample, rg);
+        r.mpos = mpos ? mpos[i] : 0;
+        r.n_cigar = n_cigar ? n_cigar[i] : 0;
+        r.cigar_front = cigar_front ? cigar_front[i] : 0;
+        r.cigar_back = cigar_back ? cigar_back[i] : 0;
+        g->g->push(r);
+      }
+      return 0;
+    }
+    catch (std::exception const & e)
+    {
+      g_error = e.what();
+      return -1;
+    }
+  }
+
+  void gto_genotyper_set_coverage(void * p, double const * avg_cov_by_readlen, long n, int no_filter_on_coverage)
+  {
+    auto & g = *static_cast<GenoHandle *>(p)->g;
+    g.avg_cov_by_readlen.assign(avg_cov_by_readlen, avg_cov_by_readlen + n);
+    g.no_filter_on_coverage = no_filter_on_coverage != 0;
+  }
+
+  // end of the record stream (SV calling scores the reads whose mate never came)
+  void gto_genotyper_finish(void * p) { static_cast<GenoHandle *>(p)->g->finish(); }
+
   long gto_genotyper_num_haplotypes(void * p) { return static_cast<long>(static_cast<GenoHandle *>(p)->g->writer.haplotypes.size()); }
 
   // Canonical score stream (u32 words), per haplotype:

@@ -207,7 +207,7 @@ class OracleGenotyper:
             self.g = None
 
     def push(self, reads, flags=None, tid=None, mtid=None, pos=None, isize=None, mapq=None, score_diff=None, name=None,
-             sample=None, rg=None):
+             sample=None, rg=None, mpos=None, n_cigar=None, cigar_front=None, cigar_back=None):
         L = lib()
         codes, offs = pack_reads(reads)
 
@@ -215,10 +215,18 @@ class OracleGenotyper:
             return None if a is None else np.ascontiguousarray(a, t)
 
         a = [arr(flags, np.uint16), arr(tid, np.int32), arr(mtid, np.int32), arr(pos, np.int64), arr(isize, np.int64),
-             arr(mapq, np.uint8), arr(score_diff, np.uint8), arr(name, np.uint64), arr(sample, np.int32), arr(rg, np.int32)]
-        rc = L.gto_genotyper_push(C.c_void_p(self.g), C.c_long(len(reads)), _p(codes), _p(offs), *[_p(x) for x in a])
+             arr(mapq, np.uint8), arr(score_diff, np.uint8), arr(name, np.uint64), arr(sample, np.int32), arr(rg, np.int32),
+             arr(mpos, np.int64), arr(n_cigar, np.uint32), arr(cigar_front, np.uint32), arr(cigar_back, np.uint32)]
+        rc = L.gto_genotyper_push_ex(C.c_void_p(self.g), C.c_long(len(reads)), _p(codes), _p(offs), *[_p(x) for x in a])
         if rc != 0:
             raise RuntimeError(L.gto_last_error().decode())
+
+    def set_coverage(self, avg_cov_by_readlen, no_filter_on_coverage=False):
+        a = np.ascontiguousarray(avg_cov_by_readlen, np.float64)
+        lib().gto_genotyper_set_coverage(C.c_void_p(self.g), _p(a), C.c_long(len(a)), C.c_int(int(no_filter_on_coverage)))
+
+    def finish(self):
+        lib().gto_genotyper_finish(C.c_void_p(self.g))
 
     def scores(self):
         L = lib()

@@ -159,5 +159,5 @@ def paired_case(kind="snp100", n_ref=30000, n_pairs=150, seed=0, region_begin=50
     rec = np.zeros(n, gtx.STREAM_RECORD)
     for i, (p, bases, flag, isize, mapq, sample, name) in enumerate(rows):
         codes[i] = np.array([1, 2, 4, 8], np.uint8)[bases]
-        rec[i] = (flag, mapq, int(rng.integers(0, 60)), 0, 0, p + region_begin, isize, read_len, 0, sample, name)
+        rec[i] = (flag, mapq, int(rng.integers(0, 60)), 0, 0, p + region_begin, isize, read_len, 0, sample, name, 0, 0, 0, 0)
     return synth.bases_to_str(ref), recs, codes, rec

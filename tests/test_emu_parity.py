@@ -181,3 +181,52 @@ def forced_second_pass_case(Backend, monkeypatch, n_reads):
 
 def test_forced_second_pass(monkeypatch):
     forced_second_pass_case(harness.EmuBackend, monkeypatch, 2000)
+
+
+def sv_stream_case(Backend, n_pairs):
+    """host logic that only SV calling runs (hts_parallel_reader.cpp:528-568 record filter, :594-633 coverage filter,
+    :717-772 leftovers), on a SNP graph flagged is_sv_graph (what the reference's own tests do, test/help_functions.hpp)"""
+    ref, recs, codes, rec = scenarios.paired_case("snp100", n_ref=30000, n_pairs=n_pairs, region_begin=310000, n_samples=2)
+    rng = np.random.default_rng(5)
+    n = len(rec)
+    rec["mpos"] = rec["pos"] + rec["isize"]
+    far = rng.random(n) < 0.1
+    rec["mpos"][far] += 300000
+    rec["mapq"][rng.random(n) < 0.15] = 12
+    rec["flag"][rng.random(n) < 0.03] |= 4  # unmapped
+    kinds = rng.integers(0, 6, size=n)  # 0: no cigar, 1: 150M, 2: 20S130M, 3: 130M20S, 4: 10S130M10S, 5: 5S145M
+    S, M = 4, 0
+    rec["n_cigar"] = np.array([0, 1, 2, 2, 3, 2])[kinds]
+    rec["cigar_front"] = np.array([0, 150 << 4 | M, 20 << 4 | S, 130 << 4 | M, 10 << 4 | S, 5 << 4 | S], np.uint32)[kinds]
+    rec["cigar_back"] = np.array([0, 150 << 4 | M, 130 << 4 | M, 20 << 4 | S, 10 << 4 | S, 145 << 4 | M], np.uint32)[kinds]
+    keep = np.ones(n, bool)  # lose some second mates: their partners become leftovers
+    second = np.nonzero((rec["flag"] & 128) != 0)[0]
+    keep[second[rng.random(len(second)) < 0.2]] = False
+    rec, codes = rec[keep], codes[keep]
+    o = Oracle(ref, recs, region_begin=310000, is_sv_graph=True)
+    b = Backend(gtx.graph_from_records(ref, recs, region_begin=310000, is_sv_graph=True), is_sv_graph=True)
+    cov = [0.02, 0.05]  # -> at most 4 / 8 reads per 50 bp bin and sample
+    og = o.genotyper(2, 1)
+    og.set_coverage(cov)
+    og.push(list(codes), flags=rec["flag"], tid=rec["tid"], mtid=rec["mtid"], pos=rec["pos"], isize=rec["isize"],
+            mapq=rec["mapq"], score_diff=rec["score_diff"], name=rec["name_id"], sample=rec["sample"], rg=rec["rg"],
+            mpos=rec["mpos"], n_cigar=rec["n_cigar"], cigar_front=rec["cigar_front"], cigar_back=rec["cigar_back"])
+    st = gtx.Stream(b.ctx.params, 1)
+    st.set_coverage(cov)
+    a_seq, a_meta, items = st.push(rec, gtx.pack_nibbles(codes))
+    counts = st.counts()
+    assert counts == og.counts()
+    assert 0 < counts["records"] < len(rec) * 0.9 and counts["parked"] > 10  # filters bite, leftovers exist
+    og.finish()
+    left = st.finish()
+    assert len(left) == counts["parked"] and (left["kind"] == gtx.ITEM_LEFTOVER).all() and st.counts()["parked"] == 0
+    records = b.align(a_seq, a_meta)
+    acc = b.score(np.concatenate([items, left]), records, 2)
+    got, want = harness.canonical_scores(b.ctx, acc), og.scores()
+    assert len(got) == len(want) and np.array_equal(got, want)
+    # the leftovers contribute: without them the scores differ
+    assert not np.array_equal(harness.canonical_scores(b.ctx, b.score(items, records, 2)), want)
+
+
+def test_sv_calling_host_logic():
+    sv_stream_case(harness.EmuBackend, 1500)

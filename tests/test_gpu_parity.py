@@ -10,7 +10,7 @@ import harness
 import scenarios
 from graphtyper_amd import lib as gtx
 from oracle_lib import Oracle, encode
-from test_emu_parity import check_align, forced_second_pass_case, run_stream, second_pass_case
+from test_emu_parity import check_align, forced_second_pass_case, run_stream, second_pass_case, sv_stream_case
 
 pytestmark = pytest.mark.gpu
 
@@ -101,3 +101,7 @@ def test_second_pass(kind):
 
 def test_forced_second_pass(monkeypatch):
     forced_second_pass_case(harness.GpuBackend, monkeypatch, 6000)
+
+
+def test_sv_calling_host_logic():
+    sv_stream_case(harness.GpuBackend, 6000)
