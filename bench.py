@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- reads/s of the alignment + genotype-scoring hot path on MI355X.
 
-A "step" is one pass of the hot path (gtx_align_batch + gtx_score_batch through libgtx's C ABI) over one batch of
+A "step" is one pass of the hot path (gtx_align_batch + gtx_score_batch + gtx_calls_batch through libgtx's C ABI) over one batch of
 synthetic reads that is already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: 1 sample, 10 M
 synthetic 150 bp reads, one 1 Mb region (chr20:1000001-2000000), SNP-only graph.  With --gpus N every rank gets its own
 10 M reads of the same region (weak scaling; graph + index replicated per GPU) and the per-sample score vectors are
@@ -145,6 +145,8 @@ def main():
     stream = torch.cuda.Stream(device=device)
     sp = C.c_void_p(stream.cuda_stream)
     align_ms = []
+    d_phred = torch.zeros(max(ctx.total_tri, 1), dtype=torch.uint8, device=device)
+    d_calls = torch.zeros(max(ctx.n_hap, 1) * gtx.SAMPLE_CALL.itemsize, dtype=torch.uint8, device=device)
 
     def step(timed):
         with torch.cuda.stream(stream):
@@ -158,6 +160,8 @@ def main():
             gtx.check(L.gtx_score_batch(ctx.h, d_items.data_ptr(), n, d_rec.data_ptr(), REC_WORDS, C.byref(buf), sp))
             if world > 1:
                 reduce_scores(dist, [acc["log_score"], acc["gt_cov"], acc["hap_u32"], acc["stat_u64"], acc["stat_u32"]])
+            # genotype calls (PL, GT, GQ, depths) from the summed accumulators
+            gtx.check(L.gtx_calls_batch(ctx.h, C.byref(buf), d_phred.data_ptr(), d_calls.data_ptr(), sp))
         return (e0, e1)
 
     for _ in range(args.warmup):
@@ -181,7 +185,9 @@ def main():
 
     # sanity on the results of the last step: every record must be a result, not an overflow
     rec_head = d_rec.view(n * 2, REC_WORDS)[:, 0]
-    n_overflow = int(((rec_head >> 16) != 0).sum().item())
+    n_overflow = int((((rec_head >> 16) & gtx.ST_ERROR_MASK) != 0).sum().item())
+    calls = d_calls.cpu().numpy().view(gtx.SAMPLE_CALL)[:ctx.n_hap]
+    n_nonref_calls = int((calls["gt_second"] > 0).sum())
     n_aligned = int(((rec_head[0::2] & 0xFFFF) > 0).sum().item())
     errors = ctx.error_count()
 
@@ -218,7 +224,7 @@ def main():
         "config": {"workload": "cfg2: 1 sample, %d synthetic %d bp reads per GPU, chr20:1000001-2000000 (1 Mb), SNP-only graph "
                                "(1 SNP / %d bp), unpaired, 0.5%% substitutions, 0.1%% N" % (n, READ_LEN, args.snp_every),
                    "reads_per_gpu": n, "index_keys": n_keys, "index_labels": n_labels, "haplotypes": ctx.n_hap,
-                   "ctx_create_s": round(t_ctx, 3), "reads_aligned": n_aligned, "reads_overflowed": n_overflow,
+                   "ctx_create_s": round(t_ctx, 3), "reads_aligned": n_aligned, "reads_overflowed": n_overflow, "nonref_genotype_calls": n_nonref_calls,
                    "score_items_refused": errors, "parallelism": "reads sharded over %d GPU(s), graph+index replicated" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": "gtx_align_kernel", "kernel_ms": align_avg_ms,

@@ -290,6 +290,16 @@ __global__ __launch_bounds__(64) void gtx_score_big_kernel(GraphView g, ScorePar
       atomicAdd(error_flag, 1u);
 }
 
+// One thread per (sample, haplotype): call_cell in score_core.hpp.
+__global__ __launch_bounds__(256) void gtx_calls_kernel(GraphView g, uint32_t n_samples, uint32_t const * __restrict__ log_score,
+                                                        uint32_t const * __restrict__ gt_cov, uint32_t const * __restrict__ hap_u32,
+                                                        uint8_t * __restrict__ phred, gtx_sample_call * __restrict__ calls)
+{
+  uint64_t const cell = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (cell < static_cast<uint64_t>(n_samples) * g.n_hap)
+    call_cell(g, cell, log_score, gt_cov, hap_u32, phred, calls);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 thread_local std::string g_last_error;
 
@@ -604,6 +614,28 @@ extern "C" int gtx_ctx_big_records_rewind(gtx_ctx * c, void * stream)
     return GTX_ERR_ARG;
   if (c->d_big_state &&
       !hip_ok(hipMemsetAsync(c->d_big_state + 4, 0, 2 * sizeof(uint32_t), static_cast<hipStream_t>(stream)), "arena rewind"))
+    return GTX_ERR_HIP;
+  return GTX_OK;
+}
+
+extern "C" int gtx_calls_batch(gtx_ctx * c, const gtx_score_buffers * acc, uint8_t * d_phred, gtx_sample_call * d_calls, void * stream)
+{
+  if (!c || !acc || !d_phred || !d_calls || !acc->d_log_score || !acc->d_gt_cov || !acc->d_hap_u32)
+  {
+    g_last_error = "gtx_calls_batch: bad argument";
+    return GTX_ERR_ARG;
+  }
+  if (c->device < 0)
+  {
+    g_last_error = "context was created without a device (libgtx has no CPU path)";
+    return GTX_ERR_NO_DEVICE;
+  }
+  uint64_t const cells = static_cast<uint64_t>(acc->n_samples) * c->dev_graph.n_hap;
+  if (cells == 0)
+    return GTX_OK;
+  hipLaunchKernelGGL(gtx_calls_kernel, dim3(static_cast<uint32_t>((cells + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     c->dev_graph, acc->n_samples, acc->d_log_score, acc->d_gt_cov, acc->d_hap_u32, d_phred, d_calls);
+  if (!hip_ok(hipGetLastError(), "gtx_calls_kernel launch"))
     return GTX_ERR_HIP;
   return GTX_OK;
 }

@@ -538,4 +538,69 @@ GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_
   return true;
 }
 
+// Genotype call of one (sample, haplotype) cell from the accumulators: get_haplotype_phred (src/typer/vcf.cpp:47-82) and
+// the SampleCall built from it (src/typer/sample_call.cpp:34-131: constructor, get_gt_call, get_gq); the saturating
+// stores of the reference's u8 / u16 counters (haplotype.cpp:19-44) are applied on the fly.
+GTX_DEV void call_cell(GraphView const & g, uint64_t cell, uint32_t const * log_score, uint32_t const * gt_cov, uint32_t const * hap_u32,
+                       uint8_t * phred, gtx_sample_call * calls)
+{
+  uint32_t const s = static_cast<uint32_t>(cell / g.n_hap), h = static_cast<uint32_t>(cell % g.n_hap);
+  uint32_t const cnum = g.ref_nvar[h], n_tri = cnum * (cnum + 1) / 2;
+  uint32_t const * ls = log_score + static_cast<uint64_t>(s) * g.total_tri + g.tri_off[h];
+  uint8_t * ph = phred + static_cast<uint64_t>(s) * g.total_tri + g.tri_off[h];
+  uint32_t mx = 0, mn = 0xFFFFFFFFu;
+  for (uint32_t i = 0; i < n_tri; ++i)
+  {
+    uint32_t const v = ls[i];
+    mx = v > mx ? v : mx;
+    mn = v < mn ? v : mn;
+  }
+  // PL = llround((max - score) * 10 log10(2)), 255 when that is >= 255, all 0 when every genotype scores the same
+  double const LOG10_HALF_times_10 = 3.01029995663981195213738894724493026768189881462108541;
+  uint32_t gt_x = 0, gt_y = 0, zeros = 0, next_lowest = 255;
+  bool have_gt = false;
+  uint32_t i = 0;
+  for (uint32_t y = 0; y < cnum; ++y)
+    for (uint32_t x = 0; x <= y; ++x, ++i)
+    {
+      uint32_t p = 0;
+      if (mx != mn)
+      {
+        long long const score = llround(static_cast<double>(mx - ls[i]) * LOG10_HALF_times_10);
+        p = score < 255 ? static_cast<uint32_t>(score) : 255u;
+      }
+      ph[i] = static_cast<uint8_t>(p);
+      if (p == 0)
+      {
+        ++zeros;
+        if (!have_gt)
+        {
+          have_gt = true;
+          gt_x = x;
+          gt_y = y;
+        }
+      }
+      else if (p < next_lowest)
+        next_lowest = p;
+    }
+  uint32_t const * cov = gt_cov + static_cast<uint64_t>(s) * g.total_allele + g.allele_off[h];
+  uint32_t const * cu = hap_u32 + cell * 4;
+  auto sat8 = [](uint32_t v) { return v > 0xFFu ? 0xFFu : v; };
+  auto sat16 = [](uint32_t v) { return v > 0xFFFFu ? 0xFFFFu : v; };
+  uint32_t const ambiguous = sat8(cu[1]), ambiguous_alt = sat8(cu[2]), alt_pp = sat8(cu[3]);
+  uint32_t alt_depth = ambiguous;
+  for (uint32_t a = 1; a < cnum; ++a)
+    alt_depth += sat16(cov[a]);
+  gtx_sample_call c;
+  c.gt_first = static_cast<uint16_t>(gt_x);
+  c.gt_second = static_cast<uint16_t>(gt_y);
+  c.ref_total_depth = static_cast<uint16_t>(sat16(sat16(cov[0]) + ambiguous - ambiguous_alt));
+  c.alt_total_depth = static_cast<uint16_t>(sat16(alt_depth));
+  c.gq = static_cast<uint8_t>(zeros > 1 ? 0u : next_lowest);
+  c.ambiguous_depth = static_cast<uint8_t>(ambiguous);
+  c.alt_proper_pair_depth = static_cast<uint8_t>(alt_pp);
+  c.reserved = 0;
+  calls[cell] = c;
+}
+
 } // namespace gtx

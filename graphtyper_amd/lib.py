@@ -21,7 +21,7 @@ ST_ERROR_MASK = 15
 # names every build of libgtx.so must export (checked by tests/test_abi.py against include/gtx.h)
 EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy", "gtx_ctx_special_positions",
            "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_index_stats", "gtx_index_get", "gtx_index_dump",
-           "gtx_align_batch", "gtx_score_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
+           "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_set_coverage", "gtx_stream_finish", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
            "gtx_graph_destroy"]
 
@@ -55,6 +55,9 @@ REC_META = np.dtype([("align_index", np.uint32), ("flag", np.uint16), ("mapq", n
                      ("pos", np.int32), ("isize", np.int32)], align=True)
 SCORE_ITEM = np.dtype([("first", REC_META), ("second", REC_META), ("sample", np.uint32), ("kind", np.uint32)], align=True)
 ITEM_LEFTOVER = 1
+SAMPLE_CALL = np.dtype([("gt_first", np.uint16), ("gt_second", np.uint16), ("ref_total_depth", np.uint16),
+                        ("alt_total_depth", np.uint16), ("gq", np.uint8), ("ambiguous_depth", np.uint8),
+                        ("alt_proper_pair_depth", np.uint8), ("reserved", np.uint8)], align=True)
 PHASE_ENTRY = np.dtype([("hap1", np.uint16), ("allele1", np.uint16), ("hap2", np.uint16), ("allele2", np.uint16),
                         ("flags", np.int8), ("reserved", np.uint8)], align=True)
 STREAM_RECORD = np.dtype([("flag", np.uint16), ("mapq", np.uint8), ("score_diff", np.uint8), ("tid", np.int32),
@@ -62,7 +65,8 @@ STREAM_RECORD = np.dtype([("flag", np.uint16), ("mapq", np.uint8), ("score_diff"
                           ("rg", np.uint16), ("sample", np.uint32), ("name_id", np.uint64), ("mpos", np.int32),
                           ("n_cigar", np.uint32), ("cigar_front", np.uint32), ("cigar_back", np.uint32)], align=True)
 LABEL = np.dtype([("start_index", np.uint32), ("end_index", np.uint32), ("variant_id", np.uint32)], align=True)
-assert READ_META.itemsize == 16 and REC_META.itemsize == 16 and SCORE_ITEM.itemsize == 40 and STREAM_RECORD.itemsize == 56
+assert READ_META.itemsize == 16 and REC_META.itemsize == 16 and SCORE_ITEM.itemsize == 40 and STREAM_RECORD.itemsize == 56 \
+    and SAMPLE_CALL.itemsize == 12
 
 
 def build(force=False):
@@ -99,6 +103,10 @@ def lib():
                                       C.c_void_p]
         L.gtx_score_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(ScoreBuffers),
                                       C.c_void_p]
+        L.gtx_calls_batch.argtypes = [C.c_void_p, C.POINTER(ScoreBuffers), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gtx_ctx_big_records.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                          C.POINTER(C.c_uint64)]
+        L.gtx_ctx_big_records_rewind.argtypes = [C.c_void_p, C.c_void_p]
         L.gtx_ctx_error_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.gtx_ctx_profile.argtypes = [C.c_void_p, C.c_void_p]
         L.gtx_scores_finalize.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,

@@ -266,6 +266,22 @@ int gtx_ctx_big_records_rewind(gtx_ctx *, void * stream);
 /* out[32]: per-phase shader-cycle sums of the alignment kernel; only the profiling build (libgtx_prof.so) fills them */
 int gtx_ctx_profile(gtx_ctx *, uint64_t * out);
 
+/* Per (sample, haplotype) genotype call on the device: replaces get_haplotype_phred (src/typer/vcf.cpp:47-82) and the
+ * SampleCall the reference builds from it in Vcf::add_haplotype (src/typer/vcf.cpp:1507-1530; constructor, get_gt_call and
+ * get_gq of src/typer/sample_call.cpp:34-131).  Reads the accumulators of gtx_score_batch as they are (unsaturated sums;
+ * the clamps of gtx_scores_finalize are applied on the fly).
+ *   d_phred [n_samples * total_tri]  uint8   PL of every genotype, layout of d_log_score
+ *   d_calls [n_samples * n_hap]      gtx_sample_call, index sample * n_hap + hap */
+typedef struct gtx_sample_call
+{
+  uint16_t gt_first, gt_second;              /* SampleCall::get_gt_call(): first genotype (x <= y) with PL 0 */
+  uint16_t ref_total_depth, alt_total_depth; /* SampleCall::ref_total_depth / alt_total_depth */
+  uint8_t gq;                                /* SampleCall::get_gq() */
+  uint8_t ambiguous_depth, alt_proper_pair_depth;
+  uint8_t reserved;
+} gtx_sample_call;
+int gtx_calls_batch(gtx_ctx *, const gtx_score_buffers * acc, uint8_t * d_phred, gtx_sample_call * d_calls, void * stream);
+
 /* Host-side clamp of downloaded accumulators to the reference's stored types (haplotype.cpp:19-44: u8 -> 255,
  * u16 -> 0xFFFF).  Returns the number of (haplotype,sample) cells whose max_log_score reached the sequential
  * saturation guard of explain_to_score (haplotype.cpp:560) -- those cells need a sequential replay and are

@@ -20,6 +20,7 @@
 #pragma once
 #include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <deque>
@@ -2525,6 +2526,88 @@ struct Genotyper
     parked_sample.clear();
   }
   std::unordered_map<std::string, int> parked_sample;
+
+  // Vcf::add_haplotype (src/typer/vcf.cpp:1507-1530): per haplotype and sample the SampleCall the reference builds --
+  // get_haplotype_phred (vcf.cpp:47-82), SampleCall constructor / get_gt_call / get_gq (sample_call.cpp:34-131).
+  struct Call
+  {
+    std::vector<uint8_t> phred;
+    uint16_t gt_first = 0, gt_second = 0, ref_total_depth = 0, alt_total_depth = 0;
+    uint8_t gq = 0, ambiguous_depth = 0, alt_proper_pair_depth = 0;
+  };
+  std::vector<std::vector<Call>> sample_calls() const // [haplotype][sample]
+  {
+    std::vector<std::vector<Call>> out;
+    for (auto const & hap : writer.haplotypes)
+    {
+      std::vector<Call> row;
+      for (auto const & hs : hap.hap_samples)
+      {
+        Call c;
+        long const num = static_cast<long>(hs.log_score.size());
+        uint16_t const max_log_score = *std::max_element(hs.log_score.begin(), hs.log_score.end());
+        bool const all_equal = std::find_if(hs.log_score.begin(), hs.log_score.end(), [max_log_score](uint16_t v) { return v != max_log_score; }) == hs.log_score.end();
+        if (all_equal)
+          c.phred.assign(num, 0u);
+        else
+        {
+          c.phred.assign(num, 255u);
+          for (long i = 0; i < num; ++i)
+          {
+            double const LOG10_HALF_times_10 = 3.01029995663981195213738894724493026768189881462108541;
+            long const score = std::llround((max_log_score - hs.log_score[i]) * LOG10_HALF_times_10);
+            if (score < 255u)
+              c.phred[i] = static_cast<uint8_t>(score);
+          }
+        }
+        // SampleCall::SampleCall
+        uint32_t const ref_depth = hs.gt_coverage[0] + hs.ambiguous_depth - hs.ambiguous_depth_alt;
+        c.ref_total_depth = static_cast<uint16_t>(std::min<uint32_t>(0xFFFFu, ref_depth));
+        uint32_t const alt_depth = std::accumulate(hs.gt_coverage.begin() + 1, hs.gt_coverage.end(), 0u) + hs.ambiguous_depth;
+        c.alt_total_depth = static_cast<uint16_t>(std::min<uint32_t>(0xFFFFu, alt_depth));
+        c.ambiguous_depth = hs.ambiguous_depth;
+        c.alt_proper_pair_depth = hs.alt_proper_pair_depth;
+        // get_gt_call
+        {
+          std::size_t i = 0;
+          bool found = false;
+          for (std::size_t y = 0; y < hs.gt_coverage.size() && !found; ++y)
+            for (std::size_t x = 0; x <= y; ++x, ++i)
+              if (c.phred[i] == 0)
+              {
+                c.gt_first = static_cast<uint16_t>(x);
+                c.gt_second = static_cast<uint16_t>(y);
+                found = true;
+                break;
+              }
+        }
+        // get_gq
+        {
+          bool seen_zero = false, two_zeros = false;
+          uint8_t next_lowest_phred = 255;
+          for (auto const p : c.phred)
+          {
+            if (p == 0)
+            {
+              if (!seen_zero)
+                seen_zero = true;
+              else
+              {
+                two_zeros = true;
+                break;
+              }
+            }
+            else if (p < next_lowest_phred)
+              next_lowest_phred = p;
+          }
+          c.gq = two_zeros ? 0 : next_lowest_phred;
+        }
+        row.push_back(std::move(c));
+      }
+      out.push_back(std::move(row));
+    }
+    return out;
+  }
 
   // hts_parallel_reader.cpp:782-904: phasing flags between alt alleles of sites less than 100 bp apart, from the
   // per-sample allele depths and allele-pair connection counts.  Keys are (haplotype index, allele) as uint16_t; an outer

@@ -524,6 +524,24 @@ extern "C"
     return static_cast<long>(s.size());
   }
 
+  // sample calls (Vcf::add_haplotype): u32 words, per haplotype, per sample:
+  //   gt_first, gt_second, gq, ref_total_depth, alt_total_depth, ambiguous_depth, alt_proper_pair_depth, n_phred, phred...
+  long gto_calls_dump(void * p, uint32_t * out, long cap)
+  {
+    auto const calls = static_cast<GenoHandle *>(p)->g->sample_calls();
+    std::vector<uint32_t> s;
+    for (auto const & row : calls)
+      for (auto const & c : row)
+      {
+        s.insert(s.end(), {c.gt_first, c.gt_second, c.gq, c.ref_total_depth, c.alt_total_depth, c.ambiguous_depth, c.alt_proper_pair_depth,
+                           static_cast<uint32_t>(c.phred.size())});
+        s.insert(s.end(), c.phred.begin(), c.phred.end());
+      }
+    if (static_cast<long>(s.size()) <= cap)
+      std::memcpy(out, s.data(), s.size() * 4);
+    return static_cast<long>(s.size());
+  }
+
   // phase flags (hts_parallel_reader.cpp:782-904): rows of (hap1, allele1, hap2, allele2, flags); an outer key without
   // any flag under it is one row with hap2 = allele2 = 0xFFFF, flags = 0.  Returns the number of rows.
   long gto_phase_flags(void * p, int32_t * out, long cap_rows)

@@ -2,6 +2,7 @@
 // host, with a sequential stand-in for the wavefront (lane lambdas are looped over the 64 lanes).  It exists so that kernel logic
 // can be debugged in a container without a GPU; it is never built into, linked against or loaded by libgtx.so, and
 // nothing outside tests/ uses it.  Parity claims are made by the `-m gpu` tests through the C ABI only.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -186,6 +187,18 @@ extern "C"
   void emu_big_records_rewind(void * p) { static_cast<Emu *>(p)->arena_used = 0; }
 
   uint64_t emu_second_pass_tasks(void * p) { return static_cast<Emu *>(p)->second_pass_tasks; }
+
+  // same contract as gtx_calls_batch, host pointers
+  int emu_calls(void * p, const gtx_score_buffers * acc, uint8_t * phred, gtx_sample_call * calls)
+  {
+    using namespace gtx;
+    Emu & e = *static_cast<Emu *>(p);
+    GraphView const g = e.graph.view();
+    uint64_t const cells = static_cast<uint64_t>(acc->n_samples) * g.n_hap;
+    for (uint64_t cell = 0; cell < cells; ++cell)
+      call_cell(g, cell, acc->d_log_score, acc->d_gt_cov, acc->d_hap_u32, phred, calls);
+    return 0;
+  }
 
   int emu_workspace_bytes(int big) { return static_cast<int>(big ? sizeof(gtx::big::AlignWorkspace) : sizeof(gtx::AlignWorkspace));
   }

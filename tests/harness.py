@@ -82,6 +82,15 @@ class EmuBackend:
         assert errors == 0
         return acc
 
+    def calls(self, acc, n_samples):
+        """gtx_calls_batch contract on the host: (phred [n_samples * total_tri] u8, SAMPLE_CALL [n_samples * n_hap])"""
+        buf = gtx.ScoreBuffers(n_samples, _p(acc.log_score), _p(acc.gt_cov), _p(acc.hap_u32), _p(acc.stat_u64), _p(acc.stat_u32),
+                               _p(acc.conn_log), _p(acc.conn_count), acc.conn_cap)
+        phred = np.zeros(n_samples * self.ctx.total_tri, np.uint8)
+        calls = np.zeros(n_samples * self.ctx.n_hap, gtx.SAMPLE_CALL)
+        self.L.emu_calls(C.c_void_p(self.h), C.byref(buf), _p(phred), _p(calls))
+        return phred, calls
+
 
 class GpuBackend:
     """libgtx's C ABI on cuda:0; torch only owns the device buffers"""
@@ -130,6 +139,17 @@ class GpuBackend:
         for host, dev in zip(acc.arrays(), devs):
             host[...] = dev.cpu().numpy().view(host.dtype)
         return acc
+
+    def calls(self, acc, n_samples):
+        torch = self.torch
+        devs = [self._dev(a) for a in acc.arrays()]
+        buf = gtx.ScoreBuffers(n_samples, *[d.data_ptr() for d in devs], acc.conn_cap)
+        d_phred = torch.zeros(max(n_samples * self.ctx.total_tri, 1), dtype=torch.uint8, device="cuda:0")
+        d_calls = torch.zeros(max(n_samples * self.ctx.n_hap, 1) * gtx.SAMPLE_CALL.itemsize, dtype=torch.uint8, device="cuda:0")
+        gtx.check(gtx.lib().gtx_calls_batch(self.ctx.h, C.byref(buf), d_phred.data_ptr(), d_calls.data_ptr(), None))
+        torch.cuda.synchronize()
+        return (d_phred.cpu().numpy()[:n_samples * self.ctx.total_tri],
+                d_calls.cpu().numpy().view(gtx.SAMPLE_CALL)[:n_samples * self.ctx.n_hap])
 
 
 def read_meta(lengths, flags=None, tid=None, mtid=None, isize=None):
@@ -203,4 +223,19 @@ def canonical_scores(ctx, acc):
                 for h2 in sorted(d):
                     out.append(h2)
                     out.extend(int(min(x, 0xFFFF)) for x in d[h2])
+    return np.array(out, np.uint32)
+
+
+def canonical_calls(ctx, phred, calls, n_samples):
+    """(phred, SAMPLE_CALL) -> the oracle's call word stream (oracle/gto_capi.cpp: gto_calls_dump)"""
+    out = []
+    for h in range(ctx.n_hap):
+        cnum = int(ctx.hap_cnum[h])
+        n_tri = cnum * (cnum + 1) // 2
+        for s in range(n_samples):
+            c = calls[s * ctx.n_hap + h]
+            out += [int(c["gt_first"]), int(c["gt_second"]), int(c["gq"]), int(c["ref_total_depth"]), int(c["alt_total_depth"]),
+                    int(c["ambiguous_depth"]), int(c["alt_proper_pair_depth"]), n_tri]
+            o = s * ctx.total_tri + int(ctx.tri_off[h])
+            out += phred[o:o + n_tri].tolist()
     return np.array(out, np.uint32)

@@ -235,6 +235,15 @@ class OracleGenotyper:
         L.gto_scores_dump(C.c_void_p(self.g), _p(out), C.c_long(n))
         return out
 
+    def calls(self):
+        """word stream of the per haplotype / sample SampleCalls (gto_calls_dump)"""
+        L = lib()
+        L.gto_calls_dump.restype = C.c_long
+        n = L.gto_calls_dump(C.c_void_p(self.g), None, C.c_long(0))
+        out = np.zeros(max(n, 1), np.uint32)
+        L.gto_calls_dump(C.c_void_p(self.g), _p(out), C.c_long(n))
+        return out[:n]
+
     def phase_flags(self):
         """rows (hap1, allele1, hap2, allele2, flags) of the `ph` map (gto_phase_flags)"""
         L = lib()

@@ -21,3 +21,10 @@ def test_strerror():
     L = gtx.lib()
     assert L.gtx_strerror(0) == b"ok"
     assert b"no HIP device" in L.gtx_strerror(2)
+
+
+def test_binding_declares_argument_types_for_every_entry_point():
+    """ctypes passes an undeclared Python int as a 32-bit C int: a device pointer would be truncated"""
+    L = gtx.lib()
+    missing = [n for n in gtx.EXPORTS if getattr(L, n).argtypes is None and n not in ("gtx_last_error",)]
+    assert missing == []

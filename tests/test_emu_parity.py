@@ -75,6 +75,11 @@ def run_stream(backend, oracle, codes, rec, n_samples, n_rg=1):
     assert len(got) == len(want)
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, "score streams differ at words %s" % bad[:10]
+    # genotype calls: PL, GT, GQ, depths per haplotype and sample (vcf.cpp:47-82, sample_call.cpp:34-131)
+    phred, calls = backend.calls(acc, n_samples)
+    got_calls, want_calls = harness.canonical_calls(backend.ctx, phred, calls, n_samples), og.calls()
+    assert len(got_calls) == len(want_calls) and np.array_equal(got_calls, want_calls), "sample calls differ"
+    assert len(np.unique(phred)) > 5 and (calls["gt_second"] > 0).any()  # not vacuous
     # phasing flags from the finalised depths and the connection log (hts_parallel_reader.cpp:782-904)
     gt_cov = np.minimum(acc.gt_cov, 0xFFFF).astype(np.uint32)
     ph = backend.ctx.phase_flags(n_samples, gt_cov, acc.conn_log, int(acc.conn_count[0]))
