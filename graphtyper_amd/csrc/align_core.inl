@@ -64,6 +64,7 @@ struct AlignWorkspace // lives in LDS, one per wavefront
   uint32_t hoff[AlignCfg::KC][2], hcnt[AlignCfg::KC][2];
   HalfEntry he[AlignCfg::KC][2][AlignCfg::HE_CAP];
   DevLabel xl[AlignCfg::KC][AlignCfg::XL_CAP];
+  uint32_t fs_start[AlignCfg::KC], fs_end[AlignCfg::KC]; // the one label of every k-mer (fast seeding)
   uint32_t n_paths, longest, status, n_lbl, n_keys, read_len, n_wl, n_wlists;
 #ifdef GTX_PROF
   unsigned long long prof_acc[16]; // phase cycle sums of this wave (profiling build)
@@ -1418,16 +1419,87 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
   });
   static_assert(AlignCfg::KC * (2 * AlignCfg::HE_CAP + AlignCfg::XL_CAP) <= 64, "staging needs one lane per entry");
   W::lds_sync();
+  // -- fast seeding.  Most reads: every k-mer has exactly one label in its exact and Hamming-1 lists together (an exact
+  //    hit without indexed neighbours, or one substitution error and a single neighbour), none of them on a variant, and
+  //    consecutive labels abut.  The loop below would chain them into one path; that path is written directly, one
+  //    k-mer per lane.  Anything else (no label, several labels, a variant, a gap, an ambiguous base) takes the loop.
+  bool seeded = false;
+  if (use_halves && n_k > 0 && n_k == kc)
+  {
+    typename W::template PerLane<bool> bad_l;
+    typename W::template PerLane<uint32_t> mm_l;
+    W::lanes([&](uint32_t l) {
+      bool bad = false;
+      uint32_t mm = 0;
+      if (l < n_k)
+      {
+        uint32_t const c0 = ws.cnt0[l];
+        bad = ws.nkeys0[l] != 1 || c0 > 1 || ws.hcnt[l][0] > AlignCfg::HE_CAP || ws.hcnt[l][1] > AlignCfg::HE_CAP;
+        if (!bad)
+        {
+          uint64_t const q = ws.key0[l];
+          uint32_t nb = 0, nb_off = 0;
+          for (uint32_t side = 0; side < 2; ++side)
+            for (uint32_t e = 0; e < ws.hcnt[l][side]; ++e)
+            {
+              HalfEntry const & he = ws.he[l][side][e];
+              uint32_t j;
+              if (hamming1_neighbour(he.key, q, j)) // (a neighbour shares exactly one half with q: it is in one bucket only)
+              {
+                nb += he.cnt;
+                nb_off = he.off;
+              }
+            }
+          bad = c0 + nb != 1;
+          if (!bad)
+          {
+            DevLabel const lb = c0 ? ws.xl[l][0] : ix.labels[nb_off];
+            mm = c0 ? 0u : 1u;
+            bad = lb.site != INVALID;
+            ws.fs_start[l] = lb.start;
+            ws.fs_end[l] = lb.end;
+          }
+        }
+      }
+      bad_l[l] = bad;
+      mm_l[l] = mm;
+    });
+    if (W::ballot(bad_l) == 0)
+    {
+      W::lds_sync();
+      typename W::template PerLane<bool> gap_l;
+      W::lanes([&](uint32_t l) { gap_l[l] = l + 1 < n_k && ws.fs_end[l] != ws.fs_start[l + 1]; });
+      if (W::ballot(gap_l) == 0)
+      {
+        uint32_t const mism = W::sum(mm_l);
+        GTX_LEAD
+        {
+          DPath & p = ws.paths[0];
+          p.start = ws.fs_start[0];
+          p.end = ws.fs_end[n_k - 1];
+          p.rs = 0;
+          p.re = static_cast<uint16_t>((K - 1) * n_k);
+          p.mism = static_cast<uint16_t>(mism);
+          p.nvar = 0;
+        }
+        W::lds_sync();
+        n_paths = 1;
+        longest = (K - 1) * n_k + 1;
+        seeded = true;
+      }
+    }
+  }
   // -- stop if every k-mer is extremely common (alignment.cpp:35-49); only single-key lists can reach 512 labels
   bool all_common = n_k > 0;
-  for (uint32_t i = 0; i < n_k; ++i)
-    if (!(GTX_U(ws.nkeys0[i]) == 1 && GTX_U(ws.cnt0[i]) >= MAX_UNIQUE_KMER_POSITIONS))
-      all_common = false;
+  if (!seeded)
+    for (uint32_t i = 0; i < n_k; ++i)
+      if (!(GTX_U(ws.nkeys0[i]) == 1 && GTX_U(ws.cnt0[i]) >= MAX_UNIQUE_KMER_POSITIONS))
+        all_common = false;
   GTX_PROF_TICK(1)
 
-  if (!all_common && n_k > 0)
+  if (seeded || (!all_common && n_k > 0))
   {
-    for (uint32_t i = 0; i < n_k && !status; ++i)
+    for (uint32_t i = seeded ? n_k : 0u; i < n_k && !status; ++i)
     {
       uint32_t const rs = (K - 1) * i, re = rs + (K - 1);
       bool const single = GTX_U(ws.nkeys0[i]) == 1;
