@@ -1322,6 +1322,55 @@ GTX_DEV uint32_t hamming1_from_cache(IndexView const & ix, AlignWorkspace & ws, 
   return hamming1_finish<W>(ix, ws, ncand);
 }
 
+// Everything after seeding for the read the fast seeding produced: one path without variant sites that starts at read
+// base 0.  walk_read_starts has nothing to do; walk_read_ends extends it iff the rest of the read matches the reference
+// node the path ends in within the budget (the shortcut of walk_read); of the filters only "more than 10 mismatches"
+// can act on a single path.  Returns false when the geometry needs the general code (path end not inside a reference
+// node with room for the rest of the read).
+template <class W>
+GTX_DEV bool finish_single_path(GraphView const & g, AlignWorkspace & ws, uint32_t & n_paths, uint32_t & longest)
+{
+  uint32_t const L = GTX_U(ws.read_len);
+  DPath & p = ws.paths[0];
+  uint32_t const pre = GTX_U(static_cast<uint32_t>(p.re));
+  uint32_t mism = GTX_U(static_cast<uint32_t>(p.mism));
+  if (pre != L - 1)
+  {
+    uint32_t const anchor = GTX_U(p.end);
+    if (g_is_special(g, anchor) || anchor < g.first_order || g.n_ref <= 1)
+      return false;
+    uint32_t const rr = g_ref_node_at<W>(g, anchor);
+    uint32_t const ro = GTX_U(g.ref_order[rr]), rl = GTX_U(g.ref_len[rr]);
+    SubRead sr;
+    sr.rd = ws.rd;
+    sr.begin = pre;
+    sr.len = L - pre;
+    if (!(anchor < ro + rl) || rl - (anchor - ro) < sr.len)
+      return false;
+    uint32_t const budget = 2 + sr.len / 11 < 7 ? 2 + sr.len / 11 : 7; // genotype_paths.cpp:505-511, best starts at 7
+    uint8_t const * dna = reinterpret_cast<uint8_t const *>(g.dna) + GTX_U(g.ref_dna[rr]) + (anchor - ro);
+    uint32_t const got = cmp_codes<W, false>(sr, 0, dna, rl - (anchor - ro), 0, budget);
+    if (got <= budget)
+    {
+      mism += got;
+      GTX_LEAD
+      {
+        p.end = anchor + (sr.len - 1);
+        p.re = static_cast<uint16_t>(L - 1);
+        p.mism = static_cast<uint16_t>(mism);
+      }
+      W::lds_sync();
+      longest = L;
+    }
+  }
+  if (mism > 10) // remove_paths_with_too_many_mismatches (genotype_paths.cpp:360-380) on one path
+  {
+    n_paths = 0;
+    longest = 0;
+  }
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // one (read, orientation): find_genotype_paths_of_one_of_the_sequences (alignment.cpp:23-103)
 // ---------------------------------------------------------------------------------------------------------------
@@ -1564,7 +1613,7 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
       add_kmer_labels<W>(ws, ws.lbl, n_lbl, rs, re, 1, false, n_paths, longest, status);
       GTX_PROF_TICK(5)
     }
-    if (!status)
+    if (!status && !(seeded && finish_single_path<W>(g, ws, n_paths, longest)))
     {
       n_paths = remove_short_paths<W>(ws, n_paths, longest);
       walk_read<W>(g, ws, true, n_paths, longest, status);
