@@ -1382,20 +1382,30 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
   GTX_PROF_BEGIN
   // -- load the read: BAM nibbles -> one code per byte; the reverse orientation is the reverse complement, and
   //    complementing an IUPAC code is reversing its 4 bits (A<->T, C<->G)
-  for (uint32_t base = 0; base < len; base += 64)
-    W::lanes([&](uint32_t l) {
-      uint32_t const i = base + l;
-      if (i < len)
+  //    (four bases per lane, one 4-byte store: reads up to 256 bp in one pass)
+  static_assert(AlignCfg::MAX_READ <= 256 && AlignCfg::MAX_READ % 4 == 0, "one pass of 64 lanes x 4 bases");
+  W::lanes([&](uint32_t l) {
+    if (4 * l < len)
+    {
+      uint32_t packed = 0;
+      for (uint32_t k = 0; k < 4; ++k)
       {
-        uint32_t const src = reverse ? (len - 1 - i) : i;
-        uint32_t c = (seq4[src >> 1] >> ((~src & 1u) << 2)) & 15u;
-        if (c == 0)
-          c = 15; // '=' assigned to a seqan Iupac becomes N (hts_parallel_reader.cpp:226-243)
-        if (reverse)
-          c = ((c & 1u) << 3) | ((c & 2u) << 1) | ((c & 4u) >> 1) | ((c & 8u) >> 3);
-        ws.rd[i] = static_cast<uint8_t>(c);
+        uint32_t const i = 4 * l + k;
+        uint32_t c = 15;
+        if (i < len)
+        {
+          uint32_t const src = reverse ? (len - 1 - i) : i;
+          c = (seq4[src >> 1] >> ((~src & 1u) << 2)) & 15u;
+          if (c == 0)
+            c = 15; // '=' assigned to a seqan Iupac becomes N (hts_parallel_reader.cpp:226-243)
+          if (reverse)
+            c = ((c & 1u) << 3) | ((c & 2u) << 1) | ((c & 4u) >> 1) | ((c & 8u) >> 3);
+        }
+        packed |= c << (8 * k);
       }
-    });
+      reinterpret_cast<uint32_t *>(ws.rd)[l] = packed;
+    }
+  });
   GTX_LEAD ws.read_len = len;
   W::lds_sync();
   GTX_PROF_TICK(0)
@@ -1404,25 +1414,32 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
   uint32_t const n_k = len < K ? 0 : 1 + (len - K) / (K - 1); // kmer_help_functions.cpp:10-17
   // -- exact keys of every k-mer.  Unambiguous k-mer: lanes 0..31 each hold one base, two ballots give the low/high
   //    bit planes, interleaving them gives the key (first base in the top bits, type_conversions.cpp:75-87).
-  for (uint32_t i = 0; i < n_k; ++i)
+  //    Two k-mers per pass: lanes 0..31 hold k-mer i, lanes 32..63 k-mer i+1; each ballot serves both.
+  static_assert(K == 32, "two 32-base k-mers per 64-lane wave");
+  for (uint32_t i = 0; i < n_k; i += 2)
   {
     typename W::template PerLane<bool> amb_l, b0_l, b1_l;
     W::lanes([&](uint32_t l) {
-      uint32_t const c = l < K ? ws.rd[(K - 1) * i + l] : 1u;
+      uint32_t const km = i + (l >> 5);
+      uint32_t const c = km < n_k ? ws.rd[(K - 1) * km + (l & 31u)] : 1u;
       bool const single = (c & (c - 1u)) == 0u && c != 0u;
       uint32_t const two = (c == 2u) ? 1u : (c == 4u) ? 2u : (c == 8u) ? 3u : 0u;
       amb_l[l] = !single;
-      b0_l[l] = l < K && (two & 1u);
-      b1_l[l] = l < K && (two & 2u);
+      b0_l[l] = (two & 1u) != 0u;
+      b1_l[l] = (two & 2u) != 0u;
     });
-    uint64_t const amb = W::ballot(amb_l);
-    uint32_t const b0 = static_cast<uint32_t>(W::ballot(b0_l)), b1 = static_cast<uint32_t>(W::ballot(b1_l));
-    uint64_t const key = (static_cast<uint64_t>(b1) << 32) | b0; // plane form (gtx_flat.hpp: plane_key)
+    uint64_t const amb = W::ballot(amb_l), b0 = W::ballot(b0_l), b1 = W::ballot(b1_l);
     GTX_LEAD
     {
-      ws.key0[i] = key;
-      ws.nkeys0[i] = amb == 0 ? 1 : 2; // 2 = "not a single key"; that list is generated when the k-mer is processed
-      ws.cnt0[i] = 0;
+      for (uint32_t h = 0; h < 2 && i + h < n_k; ++h)
+      {
+        uint32_t const a = static_cast<uint32_t>(amb >> (32 * h));
+        // plane form (gtx_flat.hpp: plane_key): low word = low bits of the bases, high word = high bits
+        ws.key0[i + h] = (static_cast<uint64_t>(static_cast<uint32_t>(b1 >> (32 * h))) << 32) | static_cast<uint32_t>(b0 >> (32 * h));
+        ws.nkeys0[i + h] = a == 0 ? 1 : 2; // 2 = "not a single key"; that list is generated when the k-mer is processed
+        ws.cnt0[i + h] = 0;
+        ws.off0[i + h] = a; // (multi-key k-mers have no exact slot: keep the ambiguous positions here)
+      }
     }
   }
   W::lds_sync();
@@ -1579,13 +1596,44 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
       else
       {
         uint32_t nk = 0;
-        GTX_LEAD
+        uint32_t const amb = GTX_U(ws.off0[i]);
+        if ((amb & (amb - 1u)) == 0u)
         {
-          nk = expand_keys(ws.rd, rs, ws.u.keybuf);
-          ws.n_keys = nk;
+          // one ambiguous base (nearly always a single N): to_uint64_vec's list is the key with the LAST admissible base
+          // at that position followed by the other admissible bases in ascending order (type_conversions.cpp:207-266:
+          // the last one replaces the key in place, the others are appended) -- one key per lane, no sequential expansion
+          uint32_t const t0 = static_cast<uint32_t>(__builtin_ctz(amb));
+          uint32_t const code = GTX_U(static_cast<uint32_t>(ws.rd[rs + t0])) & 15u;
+          uint32_t const set = (code == 0u || code == 15u) ? 15u : code;
+          uint32_t const last = 31u - static_cast<uint32_t>(__builtin_clz(set));
+          nk = static_cast<uint32_t>(__builtin_popcount(set));
+          uint64_t const base = GTX_U(ws.key0[i]); // the ambiguous base contributed no bits
+          W::lanes([&](uint32_t l) {
+            if (l < nk)
+            {
+              uint32_t b = last;
+              if (l > 0)
+              {
+                uint32_t rest = set & ~(1u << last);
+                for (uint32_t k = 1; k < l; ++k)
+                  rest &= rest - 1u;
+                b = static_cast<uint32_t>(__builtin_ctz(rest));
+              }
+              ws.u.keybuf[l] = base | (static_cast<uint64_t>(b & 1u) << t0) | (static_cast<uint64_t>(b >> 1) << (32u + t0));
+            }
+          });
+          W::lds_sync();
         }
-        W::lds_sync();
-        nk = GTX_U(ws.n_keys);
+        else
+        {
+          GTX_LEAD
+          {
+            nk = expand_keys(ws.rd, rs, ws.u.keybuf);
+            ws.n_keys = nk;
+          }
+          W::lds_sync();
+          nk = GTX_U(ws.n_keys);
+        }
         n_lbl = probe_list<W>(ix, ws, false, 0, nk, status);
         if (status)
           break;

@@ -52,6 +52,28 @@ def test_align_synthetic(kind):
     check_align(b, o, list(codes))
 
 
+def iupac_case(Backend, n_reads):
+    """reads with IUPAC ambiguity codes of every kind (2-, 3- and 4-base sets; 1 % of the bases): key lists in
+    to_uint64_vec order for one ambiguous base per k-mer (vector path) and for several (sequential expansion, up to the
+    97-partial-keys bail-out)"""
+    ref, recs, codes, pos = scenarios.synthetic_case("snp100", n_ref=40000, n_reads=n_reads, region_begin=1000, n_rate=0.0)
+    rng = np.random.default_rng(11)
+    codes = codes.copy()
+    amb = rng.random(codes.shape) < 0.01
+    # widen the true base to a set that contains it (so most reads still align) or, sometimes, to an unrelated set
+    extra = rng.integers(1, 16, size=codes.shape).astype(np.uint8)
+    codes[amb] = np.where(rng.random(int(amb.sum())) < 0.8, codes[amb] | extra[amb], extra[amb])
+    dense = rng.random(len(codes)) < 0.02  # a few reads with many ambiguous bases
+    codes[dense, 40:60] = 15
+    o = Oracle(ref, recs, region_begin=1000)
+    b = Backend(gtx.graph_from_records(ref, recs, region_begin=1000))
+    check_align(b, o, list(codes))
+
+
+def test_align_iupac_codes():
+    iupac_case(harness.EmuBackend, 3000)
+
+
 def run_stream(backend, oracle, codes, rec, n_samples, n_rg=1):
     """product: gtx_stream -> align -> score; oracle: Genotyper::push; compares the canonical score streams"""
     og = oracle.genotyper(n_samples, n_rg)
