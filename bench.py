@@ -199,6 +199,7 @@ def main():
         sys.stderr.write("phase cycles per read-orientation (profiling build), %d tasks:\n" % prof[15])
         for k, nm in enumerate(names):
             sys.stderr.write("  %-22s %10.0f  %5.1f%%\n" % (nm, prof[k] / float(prof[15]), 100.0 * prof[k] / tot))
+        sys.stderr.write("  fast-seeded tasks      %9.1f%%\n" % (100.0 * prof[14] / float(prof[15])))
 
     if rank != 0:
         if world > 1:

@@ -17,21 +17,24 @@ namespace gtx
 // main pass: tables sized for LDS (a read that exceeds one gets a status bit and goes to the second pass)
 struct AlignCfg
 {
+  // Sized so that a workspace is at most 8 KB: 20 single-wave workgroups per CU (160 KB LDS).  The kernel is bound by
+  // the latency of its dependent memory round trips, so resident waves are throughput; what does not fit is exact work
+  // for the second pass, not a loss.
   static constexpr uint32_t MAX_READ = 256;  // bases
   static constexpr uint32_t MAX_KMERS = 8;   // get_num_kmers(MAX_READ)
-  static constexpr uint32_t LBL_CAP = 80;    // labels of one k-mer list (multi-key lists are cut at 75 by the reference)
-  static constexpr uint32_t MAXP = 24;       // live paths
-  static constexpr uint32_t MAXPP = 16;      // paths made from one label list
+  static constexpr uint32_t LBL_CAP = 40;    // labels of one k-mer list (multi-key lists are cut at 75 by the reference)
+  static constexpr uint32_t MAXP = 16;       // live paths
+  static constexpr uint32_t MAXPP = 12;      // paths made from one label list
   static constexpr uint32_t MAXV = 8;        // variant sites per path
-  static constexpr uint32_t CAND_CAP = 32;   // sequences alive in one graph walk
-  static constexpr uint32_t MAXIDS = 8;      // variant nodes on one walked sequence
+  static constexpr uint32_t CAND_CAP = 24;   // sequences alive in one graph walk
+  static constexpr uint32_t MAXIDS = 6;      // variant nodes on one walked sequence
   static constexpr uint32_t LOC_CAP = 16;    // graph locations of one path end
-  static constexpr uint32_t WL_CAP = 64;     // labels kept by walk_read_ends/starts
+  static constexpr uint32_t WL_CAP = 32;     // labels kept by walk_read_ends/starts
   static constexpr uint32_t WLISTS = 8;      // label lists kept by walk_read_ends/starts
-  static constexpr uint32_t KEY_CAP = 388;   // to_uint64_vec can return up to 4*97 keys
+  static constexpr uint32_t KEY_CAP = 192;   // keys of a multi-key list (to_uint64_vec can return up to 4*97)
   static constexpr uint32_t KC = 5;          // k-mers whose index lookups are issued together up front (reads <= 187 bp)
   static constexpr uint32_t HE_CAP = 4;      // half-key bucket entries fetched up front per (k-mer, side)
-  static constexpr uint32_t XL_CAP = 4;      // exact labels fetched up front per k-mer
+  static constexpr uint32_t XL_CAP = 2;      // exact labels fetched up front per k-mer
 };
 
 #include "align_core.inl"

@@ -65,6 +65,7 @@ struct AlignWorkspace // lives in LDS, one per wavefront
   HalfEntry he[AlignCfg::KC][2][AlignCfg::HE_CAP];
   DevLabel xl[AlignCfg::KC][AlignCfg::XL_CAP];
   uint32_t fs_start[AlignCfg::KC], fs_end[AlignCfg::KC]; // the one label of every k-mer (fast seeding)
+  uint32_t aoff[AlignCfg::MAX_KMERS][4], acnt[AlignCfg::MAX_KMERS][4]; // exact slots of the keys of a k-mer with one ambiguous base
   uint32_t n_paths, longest, status, n_lbl, n_keys, read_len, n_wl, n_wlists;
 #ifdef GTX_PROF
   unsigned long long prof_acc[16]; // phase cycle sums of this wave (profiling build)
@@ -1089,7 +1090,7 @@ GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, ui
 // to_uint64_vec for a k-mer with ambiguous bases; sequential by nature (list order is the contract), leader only.
 // Returns the number of keys (0 = gave up, > 97 partial keys)
 // (keys are produced in plane form: appending base value b at base index t sets bit t of the low / high word)
-GTX_DEV uint32_t expand_keys(uint8_t const * rd, uint32_t at, uint64_t * keys)
+GTX_DEV uint32_t expand_keys(uint8_t const * rd, uint32_t at, uint64_t * keys, uint32_t cap)
 {
   uint32_t n = 1;
   keys[0] = 0;
@@ -1098,6 +1099,8 @@ GTX_DEV uint32_t expand_keys(uint8_t const * rd, uint32_t at, uint64_t * keys)
     uint32_t const origin = n;
     if (origin > 97)
       return 0;
+    if (4 * origin > cap)
+      return 0xFFFFFFFFu; // the list may outgrow this pass' key buffer
     uint32_t const code = rd[at + t] & 15u;
     auto with = [t](uint64_t k, uint64_t b) { return k | ((b & 1u) << t) | ((b >> 1) << (32 + t)); };
     for (uint32_t u = 0; u < origin; ++u)
@@ -1444,12 +1447,47 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
   }
   W::lds_sync();
   // -- all index lookups of the read at once, one per lane, so that their memory latencies overlap:
-  //    lane 3i: exact key of k-mer i (PHIndex::get), lanes 3i+1 / 3i+2: its left / right half-key bucket
+  //    lane 3i: exact key of k-mer i (PHIndex::get), lanes 3i+1 / 3i+2: its left / right half-key bucket;
+  //    lanes 32 + 4i + w: key w of k-mer i when it has exactly one ambiguous base (its list has 2..4 keys)
   uint32_t const kc = n_k < AlignCfg::KC ? n_k : AlignCfg::KC;
   bool const use_halves = ix.half_bucket_cap != 0;
+  static_assert(3 * AlignCfg::MAX_KMERS <= 32 && 32 + 4 * AlignCfg::MAX_KMERS <= 64, "lane map of the lookups");
   W::lanes([&](uint32_t l) {
     uint32_t const i = l / 3, w = l % 3;
-    if (l < 3 * n_k && ws.nkeys0[i] == 1 && (w == 0 || (i < kc && use_halves)))
+    if (l >= 32)
+    {
+      uint32_t const ai = (l - 32) >> 2, aw = (l - 32) & 3u;
+      if (ai < n_k && ws.nkeys0[ai] != 1)
+      {
+        uint32_t const amb = ws.off0[ai];
+        uint32_t off = 0, cnt = aw == 0 ? 0xFFFFFFFFu : 0u; // several ambiguous bases: "unknown", left to the general loop
+        if ((amb & (amb - 1u)) == 0u)
+        {
+          // list order of to_uint64_vec: the last admissible base first, then the others ascending (see the loop below)
+          uint32_t const t0 = static_cast<uint32_t>(__builtin_ctz(amb));
+          uint32_t const code = ws.rd[(K - 1) * ai + t0] & 15u;
+          uint32_t const set = (code == 0u || code == 15u) ? 15u : code;
+          cnt = 0;
+          if (aw < static_cast<uint32_t>(__builtin_popcount(set)))
+          {
+            uint32_t const last = 31u - static_cast<uint32_t>(__builtin_clz(set));
+            uint32_t b = last;
+            if (aw > 0)
+            {
+              uint32_t rest = set & ~(1u << last);
+              for (uint32_t k = 1; k < aw; ++k)
+                rest &= rest - 1u;
+              b = static_cast<uint32_t>(__builtin_ctz(rest));
+            }
+            uint64_t const key = ws.key0[ai] | (static_cast<uint64_t>(b & 1u) << t0) | (static_cast<uint64_t>(b >> 1) << (32u + t0));
+            bucket_find(ix.slots, ix.log2_cap, key, off, cnt);
+          }
+        }
+        ws.aoff[ai][aw] = off;
+        ws.acnt[ai][aw] = cnt;
+      }
+    }
+    else if (l < 3 * n_k && ws.nkeys0[i] == 1 && (w == 0 || (i < kc && use_halves)))
     {
       uint64_t const q = ws.key0[i];
       uint32_t off, cnt;
@@ -1470,7 +1508,21 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
     uint32_t const per = is_half ? NH : AlignCfg::XL_CAP;
     uint32_t const i = m / per, e = is_half ? m % AlignCfg::HE_CAP : m % AlignCfg::XL_CAP;
     uint32_t const side = (m / AlignCfg::HE_CAP) % 2;
-    if (l < AlignCfg::KC * (NH + AlignCfg::XL_CAP) && i < kc && ws.nkeys0[i] == 1 && (!is_half || use_halves))
+    if (l < AlignCfg::KC * (NH + AlignCfg::XL_CAP) && i < kc && ws.nkeys0[i] != 1)
+    {
+      // k-mer with one ambiguous base whose keys have exactly one label between them: stage that label
+      if (!is_half && e == 0)
+      {
+        uint32_t const c0 = ws.acnt[i][0], c1 = ws.acnt[i][1], c2 = ws.acnt[i][2], c3 = ws.acnt[i][3];
+        if (c0 <= 1 && c0 + c1 + c2 + c3 == 1) // (c0 = 0xFFFFFFFF marks "unknown")
+        {
+          uint32_t const w1 = c0 ? 0u : c1 ? 1u : c2 ? 2u : 3u;
+          ws.xl[i][0] = ix.labels[ws.aoff[i][w1]];
+          ws.cnt0[i] = 1; // (cnt0 of a multi-key k-mer is otherwise 0 and unused)
+        }
+      }
+    }
+    else if (l < AlignCfg::KC * (NH + AlignCfg::XL_CAP) && i < kc && (!is_half || use_halves))
     {
       uint32_t const cnt = is_half ? ws.hcnt[i][side] : ws.cnt0[i];
       uint32_t const off = is_half ? ws.hoff[i][side] : ws.off0[i];
@@ -1500,8 +1552,22 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
       if (l < n_k)
       {
         uint32_t const c0 = ws.cnt0[l];
-        bad = ws.nkeys0[l] != 1 || c0 > 1 || ws.hcnt[l][0] > AlignCfg::HE_CAP || ws.hcnt[l][1] > AlignCfg::HE_CAP;
-        if (!bad)
+        if (ws.nkeys0[l] != 1)
+        {
+          // One ambiguous base and one label among its keys.  The loop below adds a multi-key list twice (0 and 1
+          // mismatches, kmer_help_functions.cpp:97-119); the copy with the mismatch never merges into the chain, is
+          // shorter than it (or, from k-mer 0, the same chain with one more mismatch) and is dropped by
+          // remove_short_paths / remove_paths_with_too_many_mismatches -- the chain itself is what remains.
+          bad = c0 != 1;
+          if (!bad)
+          {
+            DevLabel const lb = ws.xl[l][0];
+            bad = lb.site != INVALID;
+            ws.fs_start[l] = lb.start;
+            ws.fs_end[l] = lb.end;
+          }
+        }
+        else if (!(bad = c0 > 1 || ws.hcnt[l][0] > AlignCfg::HE_CAP || ws.hcnt[l][1] > AlignCfg::HE_CAP))
         {
           uint64_t const q = ws.key0[l];
           uint32_t nb = 0, nb_off = 0;
@@ -1562,6 +1628,9 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
       if (!(GTX_U(ws.nkeys0[i]) == 1 && GTX_U(ws.cnt0[i]) >= MAX_UNIQUE_KMER_POSITIONS))
         all_common = false;
   GTX_PROF_TICK(1)
+#ifdef GTX_PROF
+  GTX_LEAD ws.prof_acc[14] += seeded ? 1 : 0;
+#endif
 
   if (seeded || (!all_common && n_k > 0))
   {
@@ -1628,11 +1697,16 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
         {
           GTX_LEAD
           {
-            nk = expand_keys(ws.rd, rs, ws.u.keybuf);
+            nk = expand_keys(ws.rd, rs, ws.u.keybuf, AlignCfg::KEY_CAP);
             ws.n_keys = nk;
           }
           W::lds_sync();
           nk = GTX_U(ws.n_keys);
+          if (nk == 0xFFFFFFFFu)
+          {
+            status |= GTX_ST_LABEL_OVERFLOW;
+            break;
+          }
         }
         n_lbl = probe_list<W>(ix, ws, false, 0, nk, status);
         if (status)
