@@ -130,11 +130,11 @@ __global__ __launch_bounds__(64) void gtx_align_kernel(GraphView g, IndexView ix
                                                        uint32_t * big_state, uint32_t force_big)
 {
   __shared__ AlignWorkspace ws;
-#ifdef GTX_PAD_LDS // occupancy experiment: waste LDS to lower the number of resident waves
-  __shared__ uint32_t lds_pad[GTX_PAD_LDS / 4];
-  if (n_reads == 0xFFFFFFFFu)
-    lds_pad[threadIdx.x] = 1;
-#endif
+  // The packed bases of the next read are fetched while the current one is processed (the wave is bound by the latency
+  // of its dependent memory round trips; this one is taken off the chain) and handed over through LDS.
+  __shared__ uint32_t seq_words[AlignCfg::MAX_READ / 8];
+  bool const prefetch = ((seq_stride | static_cast<uint32_t>(reinterpret_cast<uintptr_t>(seq))) & 3u) == 0u && seq_stride <= AlignCfg::MAX_READ / 2;
+  uint32_t const lane = threadIdx.x & 63u;
 #ifdef GTX_PROF
   if (threadIdx.x < 16)
     ws.prof_acc[threadIdx.x] = 0;
@@ -148,10 +148,23 @@ __global__ __launch_bounds__(64) void gtx_align_kernel(GraphView g, IndexView ix
     if (base >= n_reads)
       break;
     uint32_t const end = base + TASK_CHUNK < n_reads ? base + TASK_CHUNK : n_reads;
+    uint32_t next_word = 0;
+    if (prefetch && 4 * lane < seq_stride)
+      next_word = reinterpret_cast<uint32_t const *>(seq + static_cast<uint64_t>(base) * seq_stride)[lane];
     for (uint32_t read = base; read < end; ++read)
     {
       gtx_read_meta const m = meta[read];
       uint32_t const len = m.l_qseq;
+      uint8_t const * read_seq = seq + static_cast<uint64_t>(read) * seq_stride;
+      if (prefetch)
+      {
+        if (4 * lane < seq_stride)
+          seq_words[lane] = next_word;
+        WaveHip::lds_sync();
+        if (read + 1 < end && 4 * lane < seq_stride)
+          next_word = reinterpret_cast<uint32_t const *>(read_seq + seq_stride)[lane];
+        read_seq = reinterpret_cast<uint8_t const *>(seq_words);
+      }
       // align_read (alignment.cpp:331-363): reads shorter than 2K-1 stay unaligned; the reverse orientation is only
       // computed for reads that are not part of a concordant pair
       bool const too_short = len < 2 * K - 1, too_long = len > AlignCfg::MAX_READ;
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(64) void gtx_align_kernel(GraphView g, IndexView ix
           continue;
         }
         uint32_t const st =
-          align_one<WaveHip>(g, ix, ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words);
+          align_one<WaveHip>(g, ix, ws, read_seq, len, orient == 1, rec, rec_words);
         // a table of this pass overflowed: queue the task for the second pass (gtx_align_big_kernel)
         if (big_tasks && ((st & (GTX_ST_LABEL_OVERFLOW | GTX_ST_PATH_OVERFLOW | GTX_ST_DFS_OVERFLOW | GTX_ST_RECORD_OVERFLOW)) || force_big) &&
             (threadIdx.x & 63u) == 0)
