@@ -65,6 +65,7 @@ struct AlignWorkspace // lives in LDS, one per wavefront
   HalfEntry he[AlignCfg::KC][2][AlignCfg::HE_CAP];
   DevLabel xl[AlignCfg::KC][AlignCfg::XL_CAP];
   uint32_t fs_start[AlignCfg::KC], fs_end[AlignCfg::KC]; // the one label of every k-mer (fast seeding)
+  uint32_t fs_site, fs_allele;                           // ... and the one variant among them
   uint32_t aoff[AlignCfg::MAX_KMERS][4], acnt[AlignCfg::MAX_KMERS][4]; // exact slots of the keys of a k-mer with one ambiguous base
   uint32_t n_paths, longest, status, n_lbl, n_keys, read_len, n_wl, n_wlists;
 #ifdef GTX_PROF
@@ -1544,10 +1545,10 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
   bool seeded = false;
   if (use_halves && n_k > 0 && n_k == kc)
   {
-    typename W::template PerLane<bool> bad_l;
+    typename W::template PerLane<bool> bad_l, var_l;
     typename W::template PerLane<uint32_t> mm_l;
     W::lanes([&](uint32_t l) {
-      bool bad = false;
+      bool bad = false, has_var = false;
       uint32_t mm = 0;
       if (l < n_k)
       {
@@ -1582,8 +1583,7 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
                 nb_off = he.off;
               }
             }
-          bad = c0 + nb != 1;
-          if (!bad)
+          if (c0 + nb == 1)
           {
             DevLabel const lb = c0 ? ws.xl[l][0] : ix.labels[nb_off];
             mm = c0 ? 0u : 1u;
@@ -1591,12 +1591,46 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
             ws.fs_start[l] = lb.start;
             ws.fs_end[l] = lb.end;
           }
+          else if (c0 == 1 && nb <= 3 && !g.is_sv_graph)
+          {
+            // The read carries one allele of a variant site and the only Hamming-1 neighbours are the same interval on
+            // the site's other alleles (a SNP).  In the loop below each of those starts a path with one more mismatch
+            // that shares every later label and the chain's end with the exact one, so it walks the same tail and
+            // loses to it in remove_short_paths / remove_paths_with_too_many_mismatches; the exact chain, carrying
+            // {site, allele}, is what remains.  A neighbour anywhere else could out-walk the chain: not handled here.
+            DevLabel const lb = ws.xl[l][0];
+            bad = lb.site == INVALID;
+            for (uint32_t side = 0; side < 2 && !bad; ++side)
+              for (uint32_t e = 0; e < ws.hcnt[l][side]; ++e)
+              {
+                HalfEntry const & he = ws.he[l][side][e];
+                uint32_t j;
+                if (hamming1_neighbour(he.key, q, j))
+                  for (uint32_t k = 0; k < he.cnt; ++k)
+                  {
+                    DevLabel const nl = ix.labels[he.off + k];
+                    bad = bad || nl.start != lb.start || nl.end != lb.end || nl.site != lb.site;
+                  }
+              }
+            if (!bad)
+            {
+              has_var = true;
+              ws.fs_start[l] = lb.start;
+              ws.fs_end[l] = lb.end;
+              ws.fs_site = lb.site; // (one writer, or the read is left to the loop)
+              ws.fs_allele = lb.allele;
+            }
+          }
+          else
+            bad = true;
         }
       }
       bad_l[l] = bad;
+      var_l[l] = has_var;
       mm_l[l] = mm;
     });
-    if (W::ballot(bad_l) == 0)
+    uint64_t const with_var = W::ballot(var_l);
+    if (W::ballot(bad_l) == 0 && (with_var & (with_var - 1)) == 0)
     {
       W::lds_sync();
       typename W::template PerLane<bool> gap_l;
@@ -1612,7 +1646,14 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
           p.rs = 0;
           p.re = static_cast<uint16_t>((K - 1) * n_k);
           p.mism = static_cast<uint16_t>(mism);
-          p.nvar = 0;
+          p.nvar = with_var ? 1 : 0;
+          if (with_var)
+          {
+            uint32_t const allele = ws.fs_allele;
+            p.v[0].site = ws.fs_site;
+            p.v[0].mlo = static_cast<uint32_t>(1ull << allele);
+            p.v[0].mhi = static_cast<uint32_t>((1ull << allele) >> 32);
+          }
         }
         W::lds_sync();
         n_paths = 1;

@@ -122,7 +122,7 @@ static __device__ inline unsigned long long wave_claim64(unsigned long long * co
 #endif
 constexpr uint32_t TASK_CHUNK = GTX_TASK_CHUNK; // reads a wave claims per visit to the task counter
 
-__global__ __launch_bounds__(64) void gtx_align_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void gtx_align_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
                                                        uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
                                                        uint32_t n_reads, uint32_t * __restrict__ records, uint32_t rec_words,
                                                        uint32_t force_both, uint32_t * task_counter,
