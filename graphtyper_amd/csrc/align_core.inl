@@ -2,6 +2,8 @@
 // `struct AlignCfg` (see align_core.hpp: once with the LDS-sized tables of the main pass, once with the large tables of
 // the second pass for reads that overflowed).  No include guard on purpose.
 
+struct Here {}; // tag of this instantiation's namespace: keeps argument-dependent lookup from finding the other instantiation
+
 struct PVar
 {
   uint32_t site;
@@ -70,6 +72,28 @@ struct AlignWorkspace // lives in LDS, one per wavefront
   uint32_t n_paths, longest, status, n_lbl, n_keys, read_len, n_wl, n_wlists;
 #ifdef GTX_PROF
   unsigned long long prof_acc[16]; // phase cycle sums of this wave (profiling build)
+#endif
+};
+
+// What the first pass (gtx_align_express_kernel) needs: the read, its keys and staged lookups, and room for the single
+// path it can produce.  Field names are those of AlignWorkspace: the seeding code is written once over either.
+struct SeedWorkspace
+{
+  uint8_t rd[AlignCfg::MAX_READ];
+  DPath paths[1];
+  uint64_t key0[AlignCfg::MAX_KMERS];
+  uint32_t nkeys0[AlignCfg::MAX_KMERS];
+  uint32_t off0[AlignCfg::MAX_KMERS];
+  uint32_t cnt0[AlignCfg::MAX_KMERS];
+  uint32_t hoff[AlignCfg::KC][2], hcnt[AlignCfg::KC][2];
+  HalfEntry he[AlignCfg::KC][2][AlignCfg::HE_CAP];
+  DevLabel xl[AlignCfg::KC][AlignCfg::XL_CAP];
+  uint32_t fs_start[AlignCfg::KC], fs_end[AlignCfg::KC];
+  uint32_t fs_site, fs_allele;
+  uint32_t aoff[AlignCfg::MAX_KMERS][4], acnt[AlignCfg::MAX_KMERS][4];
+  uint32_t read_len;
+#ifdef GTX_PROF
+  unsigned long long prof_acc[16];
 #endif
 };
 
@@ -1331,8 +1355,8 @@ GTX_DEV uint32_t hamming1_from_cache(IndexView const & ix, AlignWorkspace & ws, 
 // node the path ends in within the budget (the shortcut of walk_read); of the filters only "more than 10 mismatches"
 // can act on a single path.  Returns false when the geometry needs the general code (path end not inside a reference
 // node with room for the rest of the read).
-template <class W>
-GTX_DEV bool finish_single_path(GraphView const & g, AlignWorkspace & ws, uint32_t & n_paths, uint32_t & longest)
+template <class W, class WS>
+GTX_DEV bool finish_single_path(Here, GraphView const & g, WS & ws, uint32_t & n_paths, uint32_t & longest)
 {
   uint32_t const L = GTX_U(ws.read_len);
   DPath & p = ws.paths[0];
@@ -1378,10 +1402,12 @@ GTX_DEV bool finish_single_path(GraphView const & g, AlignWorkspace & ws, uint32
 // ---------------------------------------------------------------------------------------------------------------
 // one (read, orientation): find_genotype_paths_of_one_of_the_sequences (alignment.cpp:23-103)
 // ---------------------------------------------------------------------------------------------------------------
-// Leaves the paths in ws.paths; returns the status bits (non-zero = a table overflowed, the paths are not valid).
-template <class W>
-GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWorkspace & ws, uint8_t const * seq4, uint32_t len,
-                             bool reverse, uint32_t & n_paths_out, uint32_t & longest_out)
+// Stages shared by both passes: unpack the read, build the exact keys, issue every index lookup of the read at once, stage
+// what they point at, and (try_fast) attempt the fast seeding.  Returns true when the fast seeding produced the read's
+// single path in ws.paths[0] (n_paths = 1, longest set).
+template <class W, class WS>
+GTX_DEV bool seed_stage(Here, GraphView const & g, IndexView const & ix, WS & ws, uint8_t const * seq4, uint32_t len, bool reverse,
+                        bool try_fast, uint32_t & n_paths, uint32_t & longest)
 {
   GTX_PROF_BEGIN
   // -- load the read: BAM nibbles -> one code per byte; the reverse orientation is the reverse complement, and
@@ -1414,7 +1440,6 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
   W::lds_sync();
   GTX_PROF_TICK(0)
 
-  uint32_t n_paths = 0, longest = 0, status = 0;
   uint32_t const n_k = len < K ? 0 : 1 + (len - K) / (K - 1); // kmer_help_functions.cpp:10-17
   // -- exact keys of every k-mer.  Unambiguous k-mer: lanes 0..31 each hold one base, two ballots give the low/high
   //    bit planes, interleaving them gives the key (first base in the top bits, type_conversions.cpp:75-87).
@@ -1543,7 +1568,7 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
   //    consecutive labels abut.  The loop below would chain them into one path; that path is written directly, one
   //    k-mer per lane.  Anything else (no label, several labels, a variant, a gap, an ambiguous base) takes the loop.
   bool seeded = false;
-  if (use_halves && n_k > 0 && n_k == kc)
+  if (try_fast && use_halves && n_k > 0 && n_k == kc)
   {
     typename W::template PerLane<bool> bad_l, var_l;
     typename W::template PerLane<uint32_t> mm_l;
@@ -1662,17 +1687,32 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
       }
     }
   }
+  GTX_PROF_TICK(1)
+#ifdef GTX_PROF
+  GTX_LEAD ws.prof_acc[14] += seeded ? 1 : 0;
+#endif
+  return seeded;
+}
+
+// Leaves the paths in ws.paths; returns the status bits (non-zero = a table overflowed, the paths are not valid).
+// try_fast = false: the first pass already found that this read is not one of the simple ones.
+template <class W>
+GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWorkspace & ws, uint8_t const * seq4, uint32_t len,
+                             bool reverse, uint32_t & n_paths_out, uint32_t & longest_out, bool try_fast = true)
+{
+  GTX_PROF_BEGIN
+  uint32_t n_paths = 0, longest = 0, status = 0;
+  uint32_t const n_k = len < K ? 0 : 1 + (len - K) / (K - 1); // kmer_help_functions.cpp:10-17
+  uint32_t const kc = n_k < AlignCfg::KC ? n_k : AlignCfg::KC;
+  bool const use_halves = ix.half_bucket_cap != 0;
+  bool const seeded = seed_stage<W>(Here{}, g, ix, ws, seq4, len, reverse, try_fast, n_paths, longest);
+  GTX_PROF_RESET
   // -- stop if every k-mer is extremely common (alignment.cpp:35-49); only single-key lists can reach 512 labels
   bool all_common = n_k > 0;
   if (!seeded)
     for (uint32_t i = 0; i < n_k; ++i)
       if (!(GTX_U(ws.nkeys0[i]) == 1 && GTX_U(ws.cnt0[i]) >= MAX_UNIQUE_KMER_POSITIONS))
         all_common = false;
-  GTX_PROF_TICK(1)
-#ifdef GTX_PROF
-  GTX_LEAD ws.prof_acc[14] += seeded ? 1 : 0;
-#endif
-
   if (seeded || (!all_common && n_k > 0))
   {
     for (uint32_t i = seeded ? n_k : 0u; i < n_k && !status; ++i)
@@ -1776,7 +1816,7 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
       add_kmer_labels<W>(ws, ws.lbl, n_lbl, rs, re, 1, false, n_paths, longest, status);
       GTX_PROF_TICK(5)
     }
-    if (!status && !(seeded && finish_single_path<W>(g, ws, n_paths, longest)))
+    if (!status && !(seeded && finish_single_path<W>(Here{}, g, ws, n_paths, longest)))
     {
       n_paths = remove_short_paths<W>(ws, n_paths, longest);
       walk_read<W>(g, ws, true, n_paths, longest, status);
@@ -1810,8 +1850,8 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
 }
 
 // words of the result record of the paths in ws.paths (layout: include/gtx.h, gtx_align_batch)
-template <class W>
-GTX_DEV uint32_t record_size(AlignWorkspace const & ws, uint32_t n_paths)
+template <class W, class WS>
+GTX_DEV uint32_t record_size(Here, WS const & ws, uint32_t n_paths)
 {
   uint32_t w = 2;
   for (uint32_t i = 0; i < n_paths; ++i)
@@ -1820,8 +1860,8 @@ GTX_DEV uint32_t record_size(AlignWorkspace const & ws, uint32_t n_paths)
 }
 
 // path part of the record (words 2..); `body` has room for record_size() - 2 words
-template <class W>
-GTX_DEV void write_record_body(AlignWorkspace const & ws, uint32_t n_paths, uint32_t * body)
+template <class W, class WS>
+GTX_DEV void write_record_body(Here, WS const & ws, uint32_t n_paths, uint32_t * body)
 {
   uint32_t w = 0;
   for (uint32_t i = 0; i < n_paths; ++i)
@@ -1846,19 +1886,19 @@ GTX_DEV void write_record_body(AlignWorkspace const & ws, uint32_t n_paths, uint
 // one (read, orientation) of the main pass: result into its record slot
 template <class W>
 GTX_DEV uint32_t align_one(GraphView const & g, IndexView const & ix, AlignWorkspace & ws, uint8_t const * seq4, uint32_t len,
-                           bool reverse, uint32_t * rec, uint32_t rec_words)
+                           bool reverse, uint32_t * rec, uint32_t rec_words, bool try_fast = true)
 {
   uint32_t np = 0, longest = 0;
-  uint32_t status = align_paths<W>(g, ix, ws, seq4, len, reverse, np, longest);
+  uint32_t status = align_paths<W>(g, ix, ws, seq4, len, reverse, np, longest, try_fast);
   if (status)
     np = 0;
-  else if (record_size<W>(ws, np) > rec_words)
+  else if (record_size<W>(Here{}, ws, np) > rec_words)
   {
     status = GTX_ST_RECORD_OVERFLOW;
     np = 0;
   }
   GTX_PROF_BEGIN
-  write_record_body<W>(ws, np, rec + 2);
+  write_record_body<W>(Here{}, ws, np, rec + 2);
   GTX_LEAD
   {
     rec[0] = np | (status << 16);
@@ -1867,4 +1907,33 @@ GTX_DEV uint32_t align_one(GraphView const & g, IndexView const & ix, AlignWorks
   W::lds_sync();
   GTX_PROF_TICK(9)
   return status;
+}
+
+// First pass, one (read, orientation): the read either is one of the simple ones -- fast seeding gives its single path and
+// finish_single_path completes it -- and its record is written, or nothing is written and the caller queues it for the
+// general pass (returns false).
+template <class W>
+GTX_DEV bool express_one(GraphView const & g, IndexView const & ix, SeedWorkspace & ws, uint8_t const * seq4, uint32_t len,
+                         bool reverse, uint32_t * rec, uint32_t rec_words)
+{
+  uint32_t np = 0, longest = 0;
+  if (!seed_stage<W>(Here{}, g, ix, ws, seq4, len, reverse, true, np, longest))
+    return false;
+  if (!finish_single_path<W>(Here{}, g, ws, np, longest))
+    return false;
+  if (record_size<W>(Here{}, ws, np) > rec_words)
+    return false;
+  GTX_PROF_BEGIN
+  write_record_body<W>(Here{}, ws, np, rec + 2);
+  GTX_LEAD
+  {
+    rec[0] = np;
+    rec[1] = (np == 0 ? 0 : longest) | (len << 16);
+  }
+  W::lds_sync();
+  GTX_PROF_TICK(9)
+#ifdef GTX_PROF
+  GTX_LEAD ws.prof_acc[15] += 1;
+#endif
+  return true;
 }

@@ -48,6 +48,7 @@ struct alignas(16) uint4_t // 16-byte move
 #ifdef GTX_PROF
 // (per-wave sums in the workspace, flushed once when the wave retires: one global atomic per tick would serialise)
 #define GTX_PROF_BEGIN unsigned long long _pt = W::clock();
+#define GTX_PROF_RESET _pt = W::clock();
 #define GTX_PROF_TICK(k)                                   \
   {                                                        \
     unsigned long long const _pn = W::clock();             \
@@ -56,6 +57,7 @@ struct alignas(16) uint4_t // 16-byte move
   }
 #else
 #define GTX_PROF_BEGIN
+#define GTX_PROF_RESET
 #define GTX_PROF_TICK(k)
 #endif
 

@@ -122,17 +122,24 @@ static __device__ inline unsigned long long wave_claim64(unsigned long long * co
 #endif
 constexpr uint32_t TASK_CHUNK = GTX_TASK_CHUNK; // reads a wave claims per visit to the task counter
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void gtx_align_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
-                                                       uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
-                                                       uint32_t n_reads, uint32_t * __restrict__ records, uint32_t rec_words,
-                                                       uint32_t force_both, uint32_t * task_counter,
-                                                       uint32_t * __restrict__ big_tasks, uint32_t big_task_cap,
-                                                       uint32_t * big_state, uint32_t force_big)
+// Pass 1 (express): every (read, orientation) task.  The simple reads -- one label per k-mer, abutting, at most one
+// variant, tail inside a reference node -- are finished here with a workspace of 2 KB, i.e. at full occupancy (the
+// kernel is bound by the latency of its dependent memory round trips, resident waves are throughput).  Every other
+// task is queued for pass 2.
+__global__ __launch_bounds__(64) void gtx_align_express_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
+                                                               uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
+                                                               uint32_t n_reads, uint32_t * __restrict__ records,
+                                                               uint32_t rec_words, uint32_t force_both, uint32_t * task_counter,
+                                                               uint32_t * __restrict__ queue, uint32_t * queue_count,
+                                                               uint32_t queue_all)
 {
-  __shared__ AlignWorkspace ws;
-  // The packed bases of the next read are fetched while the current one is processed (the wave is bound by the latency
-  // of its dependent memory round trips; this one is taken off the chain) and handed over through LDS.
+  __shared__ SeedWorkspace ws;
+  // The packed bases of the next read are fetched while the current one is processed (one round trip off the chain)
+  // and handed over through LDS.
   __shared__ uint32_t seq_words[AlignCfg::MAX_READ / 8];
+  // Tasks for pass 2 are collected per chunk and appended with one atomic: a counter takes ~90 M atomics/s, one per task
+  // would set the pace of this kernel.
+  __shared__ uint32_t pending[2 * TASK_CHUNK];
   bool const prefetch = ((seq_stride | static_cast<uint32_t>(reinterpret_cast<uintptr_t>(seq))) & 3u) == 0u && seq_stride <= AlignCfg::MAX_READ / 2;
   uint32_t const lane = threadIdx.x & 63u;
 #ifdef GTX_PROF
@@ -141,14 +148,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void gt
   WaveHip::lds_sync();
 #endif
   // Reads are claimed dynamically (one atomic per TASK_CHUNK reads): the grid is sized to what is resident at once and
-  // reads differ in cost (mismatches, ambiguous bases, the optional reverse orientation), a static split leaves CUs idle.
+  // reads differ in cost, a static split leaves CUs idle.
   for (;;)
   {
     uint32_t const base = wave_claim(task_counter, TASK_CHUNK);
     if (base >= n_reads)
       break;
     uint32_t const end = base + TASK_CHUNK < n_reads ? base + TASK_CHUNK : n_reads;
-    uint32_t next_word = 0;
+    uint32_t next_word = 0, n_pending = 0;
     if (prefetch && 4 * lane < seq_stride)
       next_word = reinterpret_cast<uint32_t const *>(seq + static_cast<uint64_t>(base) * seq_stride)[lane];
     for (uint32_t read = base; read < end; ++read)
@@ -174,26 +181,77 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void gt
         uint32_t * rec = records + (static_cast<uint64_t>(read) * 2 + orient) * rec_words;
         if (too_short || too_long || (orient == 1 && !rev))
         {
-          if ((threadIdx.x & 63u) == 0)
+          if (lane == 0)
           {
             rec[0] = too_long ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
             rec[1] = len << 16;
           }
           continue;
         }
-        uint32_t const st =
-          align_one<WaveHip>(g, ix, ws, read_seq, len, orient == 1, rec, rec_words);
-        // a table of this pass overflowed: queue the task for the second pass (gtx_align_big_kernel)
-        if (big_tasks && ((st & (GTX_ST_LABEL_OVERFLOW | GTX_ST_PATH_OVERFLOW | GTX_ST_DFS_OVERFLOW | GTX_ST_RECORD_OVERFLOW)) || force_big) &&
-            (threadIdx.x & 63u) == 0)
+        if (queue_all || !express_one<WaveHip>(g, ix, ws, read_seq, len, orient == 1, rec, rec_words))
         {
-          uint32_t const slot = atomicAdd(big_state, 1u);
-          if (slot < big_task_cap)
-            big_tasks[slot] = read * 2 + orient;
-          else
-            atomicAdd(big_state + 3, 1u);
+          if (lane == 0)
+            pending[n_pending] = read * 2 + orient;
+          ++n_pending;
         }
       }
+    }
+    if (n_pending)
+    {
+      WaveHip::lds_sync();
+      uint32_t const at = wave_claim(queue_count, n_pending); // (the queue has room for every task)
+      if (lane < n_pending)
+        queue[at + lane] = pending[lane];
+      WaveHip::lds_sync();
+    }
+  }
+#ifdef GTX_PROF
+  WaveHip::lds_sync();
+  if (threadIdx.x < 16)
+    atomicAdd(g.prof + threadIdx.x, ws.prof_acc[threadIdx.x]);
+#endif
+}
+
+// Pass 2 (general): the queued tasks through the full algorithm over LDS tables.  A task that exceeds them goes on to
+// pass 3 (gtx_align_big_kernel).
+__global__ __launch_bounds__(64) void gtx_align_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
+                                                       uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
+                                                       uint32_t * __restrict__ records, uint32_t rec_words,
+                                                       uint32_t const * __restrict__ queue, uint32_t const * queue_count,
+                                                       uint32_t * task_counter, uint32_t * __restrict__ big_tasks,
+                                                       uint32_t big_task_cap, uint32_t * big_state, uint32_t force_big)
+{
+  __shared__ AlignWorkspace ws;
+#ifdef GTX_PROF
+  if (threadIdx.x < 16)
+    ws.prof_acc[threadIdx.x] = 0;
+  WaveHip::lds_sync();
+#endif
+  uint32_t const queued = queue_count[0];
+  constexpr uint32_t CLAIM = 8; // tasks per visit to the counter (at 1 the counter, not the work, would set the pace)
+  for (uint32_t t = 0, t_end = 0;; ++t)
+  {
+    if (t == t_end)
+    {
+      t = wave_claim(task_counter, CLAIM);
+      if (t >= queued)
+        break;
+      t_end = t + CLAIM < queued ? t + CLAIM : queued;
+    }
+    uint32_t const task = WaveHip::uni(queue[t]), read = task >> 1, orient = task & 1u;
+    uint32_t const len = WaveHip::uni(static_cast<uint32_t>(meta[read].l_qseq));
+    uint32_t * rec = records + static_cast<uint64_t>(task) * rec_words;
+    uint32_t const st = align_one<WaveHip>(g, ix, ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words,
+                                           /*try_fast=*/false);
+    // a table of this pass overflowed: queue the task for the next pass (gtx_align_big_kernel)
+    if (big_tasks && ((st & (GTX_ST_LABEL_OVERFLOW | GTX_ST_PATH_OVERFLOW | GTX_ST_DFS_OVERFLOW | GTX_ST_RECORD_OVERFLOW)) || force_big) &&
+        (threadIdx.x & 63u) == 0)
+    {
+      uint32_t const slot = atomicAdd(big_state, 1u);
+      if (slot < big_task_cap)
+        big_tasks[slot] = task;
+      else
+        atomicAdd(big_state + 3, 1u);
     }
   }
 #ifdef GTX_PROF
@@ -238,7 +296,7 @@ __global__ __launch_bounds__(64) void gtx_align_big_kernel(GraphView g, IndexVie
       np = 0;
     else
     {
-      uint32_t const size = WaveHip::uni(big::record_size<WaveHipMem>(ws, np));
+      uint32_t const size = WaveHip::uni(big::record_size<WaveHipMem>(big::Here{}, ws, np));
       if (size > rec_words)
       {
         // long record: room in the arena; the slot keeps the header and the offset
@@ -255,7 +313,7 @@ __global__ __launch_bounds__(64) void gtx_align_big_kernel(GraphView g, IndexVie
         }
       }
     }
-    big::write_record_body<WaveHipMem>(ws, np, body);
+    big::write_record_body<WaveHipMem>(big::Here{}, ws, np, body);
     if ((threadIdx.x & 63u) == 0)
     {
       rec[0] = np | ((status | ext) << 16);
@@ -464,6 +522,8 @@ int ctx_upload(gtx_ctx & c, int device)
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_kernel, 64, 0) == hipSuccess && per_cu > 0)
     c.align_blocks_per_cu = per_cu;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express_kernel, 64, 0) == hipSuccess && per_cu > 0)
+    c.express_blocks_per_cu = per_cu;
   return GTX_OK;
 }
 
@@ -474,6 +534,9 @@ void ctx_release_device(gtx_ctx & c)
   for (void * p : c.dev_allocs)
     (void)hipFree(p);
   c.dev_allocs.clear();
+  if (c.d_queue)
+    (void)hipFree(c.d_queue);
+  c.d_queue = nullptr;
   if (c.d_big_tasks)
     (void)hipFree(c.d_big_tasks);
   c.d_big_tasks = nullptr;
@@ -498,13 +561,23 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
   }
   if (n_reads == 0)
     return GTX_OK;
-  // as many single-wave workgroups as are resident at once (LDS bound); they pull reads from a shared counter
-  uint32_t const max_blocks = static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256) * static_cast<uint32_t>(c->align_blocks_per_cu);
-  uint64_t const chunks = (static_cast<uint64_t>(n_reads) + TASK_CHUNK - 1) / TASK_CHUNK;
-  uint32_t const blocks = static_cast<uint32_t>(chunks < max_blocks ? chunks : max_blocks);
-  uint32_t * counter = c->d_task_counters + (c->launch_seq.fetch_add(1) % gtx_ctx::N_TASK_COUNTERS);
-  if (!hip_ok(hipMemsetAsync(counter, 0, sizeof(uint32_t), static_cast<hipStream_t>(stream)), "task counter reset"))
+  // per launch: [0] read counter of pass 1, [1] task counter of pass 2, [2] number of tasks queued for pass 2
+  uint32_t * counters = c->d_task_counters + 4 * (c->launch_seq.fetch_add(1) % (gtx_ctx::N_TASK_COUNTERS / 4));
+  if (!hip_ok(hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), static_cast<hipStream_t>(stream)), "task counter reset"))
     return GTX_ERR_HIP;
+  // queue of pass 2: room for every task (a graph on which no read is simple sends them all)
+  if (2ull * n_reads > c->queue_cap)
+  {
+    if (c->d_queue && !hip_ok(hipFree(c->d_queue), "pass-2 queue")) // (synchronises with earlier launches)
+      return GTX_ERR_HIP;
+    c->d_queue = nullptr;
+    c->queue_cap = 0;
+    void * p = nullptr;
+    if (!hip_ok(hipMalloc(&p, 2ull * n_reads * sizeof(uint32_t)), "pass-2 queue"))
+      return GTX_ERR_HIP;
+    c->d_queue = static_cast<uint32_t *>(p);
+    c->queue_cap = 2ull * n_reads;
+  }
   bool const second_pass = c->d_big_state != nullptr;
   if (second_pass)
   {
@@ -526,12 +599,23 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
     if (!hip_ok(hipMemsetAsync(c->d_big_state, 0, 4 * sizeof(uint32_t), static_cast<hipStream_t>(stream)), "second-pass state reset"))
       return GTX_ERR_HIP;
   }
-  char const * fb = std::getenv("GTX_FORCE_SECOND_PASS"); // test switch: every task is redone by the second pass
-  bool const force_big = fb && fb[0] == '1';
-  hipLaunchKernelGGL(gtx_align_kernel, dim3(blocks), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph, c->dev_index,
+  // test switch: 1 = every task goes through all three passes (the last one decides), 2 = every task is done by pass 2
+  char const * fb = std::getenv("GTX_FORCE_SECOND_PASS");
+  uint32_t const force = fb ? static_cast<uint32_t>(std::atoi(fb)) : 0u;
+  // grids: as many single-wave workgroups as are resident at once; they pull work from shared counters
+  uint32_t const n_cu = static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256);
+  uint64_t const chunks = (static_cast<uint64_t>(n_reads) + TASK_CHUNK - 1) / TASK_CHUNK;
+  uint32_t const blocks1 = static_cast<uint32_t>(std::min<uint64_t>(chunks, static_cast<uint64_t>(n_cu) * c->express_blocks_per_cu));
+  uint32_t const blocks2 = static_cast<uint32_t>(std::min<uint64_t>(2ull * n_reads, static_cast<uint64_t>(n_cu) * c->align_blocks_per_cu));
+  hipLaunchKernelGGL(gtx_align_express_kernel, dim3(blocks1), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph, c->dev_index,
                      d_seq, seq_stride, d_meta, n_reads, d_records, rec_words,
-                     static_cast<uint32_t>(c->params.force_align_both_orientations != 0), counter,
-                     second_pass ? c->d_big_tasks : nullptr, c->big_task_cap, c->d_big_state, static_cast<uint32_t>(force_big));
+                     static_cast<uint32_t>(c->params.force_align_both_orientations != 0), counters, c->d_queue, counters + 2,
+                     static_cast<uint32_t>(force != 0));
+  if (!hip_ok(hipGetLastError(), "gtx_align_express_kernel launch"))
+    return GTX_ERR_HIP;
+  hipLaunchKernelGGL(gtx_align_kernel, dim3(blocks2), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph, c->dev_index, d_seq,
+                     seq_stride, d_meta, d_records, rec_words, c->d_queue, counters + 2, counters + 1,
+                     second_pass ? c->d_big_tasks : nullptr, c->big_task_cap, c->d_big_state, static_cast<uint32_t>(force == 1));
   if (!hip_ok(hipGetLastError(), "gtx_align_kernel launch"))
     return GTX_ERR_HIP;
   if (second_pass)

@@ -20,7 +20,9 @@ struct gtx_ctx
   static constexpr unsigned N_TASK_COUNTERS = 64; // one per launch in flight (launches may overlap on different streams)
   uint32_t * d_task_counters = nullptr;
   std::atomic<unsigned> launch_seq{0};
-  int align_blocks_per_cu = 8;
+  int align_blocks_per_cu = 8, express_blocks_per_cu = 16;
+  uint32_t * d_queue = nullptr; // tasks pass 1 hands to pass 2 (grow-only)
+  uint64_t queue_cap = 0;
   // second pass (reads that overflowed the LDS-sized tables): task list, HBM workspaces, arena for long records
   uint32_t * d_big_tasks = nullptr;  // (read * 2 + orientation) of every queued task
   uint32_t big_task_cap = 0;

@@ -77,7 +77,8 @@ struct Emu
   gtx::HostIndex index;
   std::vector<uint32_t> arena; // big-record arena (see gtx_align_batch)
   uint64_t arena_used = 0;
-  uint64_t second_pass_tasks = 0;
+  uint64_t second_pass_tasks = 0; // tasks that reached the last pass (HBM tables)
+  uint64_t general_tasks = 0;     // tasks pass 1 handed to pass 2
 };
 
 } // namespace
@@ -114,8 +115,11 @@ extern "C"
     auto ws = std::make_unique<AlignWorkspace>();
     auto big_ws = std::make_unique<big::AlignWorkspace>();
     bool const second_pass = !e.params.no_second_pass;
-    char const * fe = std::getenv("GTX_FORCE_SECOND_PASS");
-    bool const force_big = fe && fe[0] == '1';
+    char const * fe = std::getenv("GTX_FORCE_SECOND_PASS"); // 1: every task through all passes, 2: every task done by pass 2
+    int const force = fe ? std::atoi(fe) : 0;
+    bool const force_big = force == 1;
+    auto seed_ws = std::make_unique<SeedWorkspace>();
+    e.general_tasks = 0;
     char const * fl = std::getenv("GTX_EMU_FILL"); // what uninitialised workspace memory looks like
     int const fill = fl ? std::atoi(fl) : 0xAB;
     if (e.arena.empty()) // grows until emu_big_records_rewind, like the device arena
@@ -135,8 +139,15 @@ extern "C"
         rec[1] = len << 16;
         continue;
       }
-      std::memset(ws.get(), fill, sizeof(AlignWorkspace)); // LDS is not zeroed between reads
-      uint32_t const st = align_one<WaveEmu>(g, ix, *ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words);
+      // pass 1 (gtx_align_express_kernel)
+      std::memset(static_cast<void *>(seed_ws.get()), fill, sizeof(SeedWorkspace)); // LDS is not zeroed between reads
+      if (!force && express_one<WaveEmu>(g, ix, *seed_ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words))
+        continue;
+      // pass 2 (gtx_align_kernel)
+      ++e.general_tasks;
+      std::memset(static_cast<void *>(ws.get()), fill, sizeof(AlignWorkspace));
+      uint32_t const st = align_one<WaveEmu>(g, ix, *ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words,
+                                             /*try_fast=*/false);
       if (!second_pass || !(st || force_big))
         continue;
       // second pass (gtx_align_big_kernel)
@@ -150,7 +161,7 @@ extern "C"
         np = 0;
       else
       {
-        uint32_t const size = big::record_size<WaveEmu>(*big_ws, np);
+        uint32_t const size = big::record_size<WaveEmu>(big::Here{}, *big_ws, np);
         if (size > rec_words)
         {
           off = e.arena_used;
@@ -167,7 +178,7 @@ extern "C"
           }
         }
       }
-      big::write_record_body<WaveEmu>(*big_ws, np, body);
+      big::write_record_body<WaveEmu>(big::Here{}, *big_ws, np, body);
       rec[0] = np | ((status | ext) << 16);
       rec[1] = (np == 0 ? 0 : longest) | (len << 16);
       if (ext)
@@ -185,6 +196,8 @@ extern "C"
   }
 
   void emu_big_records_rewind(void * p) { static_cast<Emu *>(p)->arena_used = 0; }
+
+  uint64_t emu_general_tasks(void * p) { return static_cast<Emu *>(p)->general_tasks; }
 
   uint64_t emu_second_pass_tasks(void * p) { return static_cast<Emu *>(p)->second_pass_tasks; }
 
