@@ -126,7 +126,7 @@ constexpr uint32_t TASK_CHUNK = GTX_TASK_CHUNK; // reads a wave claims per visit
 // variant, tail inside a reference node -- are finished here with a workspace of 2 KB, i.e. at full occupancy (the
 // kernel is bound by the latency of its dependent memory round trips, resident waves are throughput).  Every other
 // task is queued for pass 2.
-__global__ __launch_bounds__(64) void gtx_align_express_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void gtx_align_express_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
                                                                uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
                                                                uint32_t n_reads, uint32_t * __restrict__ records,
                                                                uint32_t rec_words, uint32_t force_both, uint32_t * task_counter,
@@ -200,8 +200,8 @@ __global__ __launch_bounds__(64) void gtx_align_express_kernel(GraphView g, Inde
     {
       WaveHip::lds_sync();
       uint32_t const at = wave_claim(queue_count, n_pending); // (the queue has room for every task)
-      if (lane < n_pending)
-        queue[at + lane] = pending[lane];
+      for (uint32_t k = lane; k < n_pending; k += 64)
+        queue[at + k] = pending[k];
       WaveHip::lds_sync();
     }
   }
