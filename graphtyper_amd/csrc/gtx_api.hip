@@ -126,7 +126,7 @@ constexpr uint32_t TASK_CHUNK = GTX_TASK_CHUNK; // reads a wave claims per visit
 // variant, tail inside a reference node -- are finished here with a workspace of 2 KB, i.e. at full occupancy (the
 // kernel is bound by the latency of its dependent memory round trips, resident waves are throughput).  Every other
 // task is queued for pass 2.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void gtx_align_express_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void gtx_align_express_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
                                                                uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
                                                                uint32_t n_reads, uint32_t * __restrict__ records,
                                                                uint32_t rec_words, uint32_t force_both, uint32_t * task_counter,
@@ -537,6 +537,12 @@ void ctx_release_device(gtx_ctx & c)
   if (c.d_queue)
     (void)hipFree(c.d_queue);
   c.d_queue = nullptr;
+  for (auto & e : c.pass_events)
+    if (e)
+    {
+      (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+      e = nullptr;
+    }
   if (c.d_big_tasks)
     (void)hipFree(c.d_big_tasks);
   c.d_big_tasks = nullptr;
@@ -607,17 +613,24 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
   uint64_t const chunks = (static_cast<uint64_t>(n_reads) + TASK_CHUNK - 1) / TASK_CHUNK;
   uint32_t const blocks1 = static_cast<uint32_t>(std::min<uint64_t>(chunks, static_cast<uint64_t>(n_cu) * c->express_blocks_per_cu));
   uint32_t const blocks2 = static_cast<uint32_t>(std::min<uint64_t>(2ull * n_reads, static_cast<uint64_t>(n_cu) * c->align_blocks_per_cu));
+  bool const timed = c->pass_events[0] != nullptr;
+  if (timed)
+    (void)hipEventRecord(static_cast<hipEvent_t>(c->pass_events[0]), static_cast<hipStream_t>(stream));
   hipLaunchKernelGGL(gtx_align_express_kernel, dim3(blocks1), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph, c->dev_index,
                      d_seq, seq_stride, d_meta, n_reads, d_records, rec_words,
                      static_cast<uint32_t>(c->params.force_align_both_orientations != 0), counters, c->d_queue, counters + 2,
                      static_cast<uint32_t>(force != 0));
   if (!hip_ok(hipGetLastError(), "gtx_align_express_kernel launch"))
     return GTX_ERR_HIP;
+  if (timed)
+    (void)hipEventRecord(static_cast<hipEvent_t>(c->pass_events[1]), static_cast<hipStream_t>(stream));
   hipLaunchKernelGGL(gtx_align_kernel, dim3(blocks2), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph, c->dev_index, d_seq,
                      seq_stride, d_meta, d_records, rec_words, c->d_queue, counters + 2, counters + 1,
                      second_pass ? c->d_big_tasks : nullptr, c->big_task_cap, c->d_big_state, static_cast<uint32_t>(force == 1));
   if (!hip_ok(hipGetLastError(), "gtx_align_kernel launch"))
     return GTX_ERR_HIP;
+  if (timed)
+    (void)hipEventRecord(static_cast<hipEvent_t>(c->pass_events[2]), static_cast<hipStream_t>(stream));
   if (second_pass)
   {
     hipLaunchKernelGGL(gtx_align_big_kernel, dim3(c->big_blocks), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph,
@@ -626,6 +639,40 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
                        static_cast<unsigned long long>(c->big_record_words));
     if (!hip_ok(hipGetLastError(), "gtx_align_big_kernel launch"))
       return GTX_ERR_HIP;
+  }
+  if (timed)
+    (void)hipEventRecord(static_cast<hipEvent_t>(c->pass_events[3]), static_cast<hipStream_t>(stream));
+  return GTX_OK;
+}
+
+extern "C" int gtx_ctx_pass_times(gtx_ctx * c, float * ms, uint32_t * queued)
+{
+  if (!c || !ms)
+    return GTX_ERR_ARG;
+  ms[0] = ms[1] = ms[2] = 0.0f;
+  if (queued)
+    *queued = 0;
+  if (c->device < 0)
+    return GTX_ERR_NO_DEVICE;
+  if (!c->pass_events[0]) // first call: create the events; the next gtx_align_batch is timed
+  {
+    for (auto & e : c->pass_events)
+    {
+      hipEvent_t ev;
+      if (!hip_ok(hipEventCreate(&ev), "pass events"))
+        return GTX_ERR_HIP;
+      e = ev;
+    }
+    return GTX_OK;
+  }
+  if (!hip_ok(hipEventSynchronize(static_cast<hipEvent_t>(c->pass_events[3])), "pass events"))
+    return GTX_OK; // nothing was timed yet
+  for (int k = 0; k < 3; ++k)
+    (void)hipEventElapsedTime(ms + k, static_cast<hipEvent_t>(c->pass_events[k]), static_cast<hipEvent_t>(c->pass_events[k + 1]));
+  if (queued)
+  {
+    unsigned const last = (c->launch_seq.load() + gtx_ctx::N_TASK_COUNTERS / 4 - 1) % (gtx_ctx::N_TASK_COUNTERS / 4);
+    (void)hipMemcpy(queued, c->d_task_counters + 4 * last + 2, sizeof(uint32_t), hipMemcpyDeviceToHost);
   }
   return GTX_OK;
 }

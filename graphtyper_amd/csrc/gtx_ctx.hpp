@@ -23,6 +23,7 @@ struct gtx_ctx
   int align_blocks_per_cu = 8, express_blocks_per_cu = 16;
   uint32_t * d_queue = nullptr; // tasks pass 1 hands to pass 2 (grow-only)
   uint64_t queue_cap = 0;
+  void * pass_events[4] = {nullptr, nullptr, nullptr, nullptr}; // hipEvent_t around the three passes (gtx_ctx_pass_times)
   // second pass (reads that overflowed the LDS-sized tables): task list, HBM workspaces, arena for long records
   uint32_t * d_big_tasks = nullptr;  // (read * 2 + orientation) of every queued task
   uint32_t big_task_cap = 0;

@@ -21,7 +21,7 @@ ST_ERROR_MASK = 15
 # names every build of libgtx.so must export (checked by tests/test_abi.py against include/gtx.h)
 EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy", "gtx_ctx_special_positions",
            "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_index_stats", "gtx_index_get", "gtx_index_dump",
-           "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
+           "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_pass_times", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_set_coverage", "gtx_stream_finish", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
            "gtx_graph_destroy"]
 
@@ -107,6 +107,7 @@ def lib():
         L.gtx_ctx_big_records.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                           C.POINTER(C.c_uint64)]
         L.gtx_ctx_big_records_rewind.argtypes = [C.c_void_p, C.c_void_p]
+        L.gtx_ctx_pass_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.gtx_ctx_error_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.gtx_ctx_profile.argtypes = [C.c_void_p, C.c_void_p]
         L.gtx_scores_finalize.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -361,6 +362,14 @@ class Context:
             if rc != 0:
                 raise RuntimeError(f"hipMemcpy failed ({rc})")
         return out, int(tasks.value)
+
+    def pass_times(self):
+        """(ms of the express / general / HBM-table pass of the last align batch, tasks handed to the general pass);
+        the first call only arms the timing"""
+        ms = (C.c_float * 3)()
+        q = C.c_uint32()
+        check(lib().gtx_ctx_pass_times(self.h, ms, C.byref(q)))
+        return [float(x) for x in ms], int(q.value)
 
     def rewind_big_records(self):
         check(lib().gtx_ctx_big_records_rewind(self.h, None))

@@ -260,6 +260,10 @@ int gtx_ctx_error_count(gtx_ctx *, uint32_t * out);
  * (both synchronise with the device) */
 int gtx_ctx_big_records(gtx_ctx *, const uint32_t ** d_words, uint64_t * capacity_words, uint64_t * used_words, uint64_t * tasks);
 
+/* Durations (ms, HIP events on the launch stream) of the three passes of the last gtx_align_batch -- express, general,
+ * HBM tables -- and the number of tasks the express pass handed on.  The first call only arms the timing. */
+int gtx_ctx_pass_times(gtx_ctx *, float * ms /* [3] */, uint32_t * queued_for_pass2);
+
 /* forget every GTX_ST_EXTERNAL record (call between regions, when d_records is recycled) */
 int gtx_ctx_big_records_rewind(gtx_ctx *, void * stream);
 
