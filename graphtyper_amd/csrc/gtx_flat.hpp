@@ -135,13 +135,26 @@ void build_index(HostGraph const & g, HostIndex & out);
 // first base in the top two bits) is kept for everything the host reports.
 inline uint64_t plane_key(uint64_t key)
 {
-  uint64_t lo = 0, hi = 0;
-  for (unsigned j = 0; j < 32; ++j)
+  // base j (0 = first base = top bit pair of `key`) -> bit j of the low-bit plane (low word) and of the high-bit plane
+  auto compact_even_bits = [](uint64_t x) // bits 0,2,4,.. of x -> bits 0..31
   {
-    uint64_t const two = (key >> (2 * (31 - j))) & 3u;
-    lo |= (two & 1u) << j;
-    hi |= (two >> 1) << j;
-  }
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    return static_cast<uint32_t>(x);
+  };
+  auto reverse32 = [](uint32_t v)
+  {
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    return (v >> 16) | (v << 16);
+  };
+  uint64_t const lo = reverse32(compact_even_bits(key)), hi = reverse32(compact_even_bits(key >> 1));
   return (hi << 32) | lo;
 }
 

@@ -7,8 +7,12 @@
 // bucket order -- which decides Path order downstream -- is identical, while every end position is independent
 // (no sweep state), which is what a later GPU build of the index needs.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 #include "gtx_flat.hpp"
 
@@ -342,6 +346,29 @@ struct Walker
 
 } // namespace
 
+// Stable LSD radix sort of (key, payload) pairs on the low `key_bits` bits of the key, 16 bits per pass.
+static void radix_sort_pairs(std::vector<std::pair<uint64_t, uint32_t>> & v, unsigned key_bits)
+{
+  std::vector<std::pair<uint64_t, uint32_t>> tmp(v.size());
+  std::vector<uint32_t> count(1u << 16);
+  for (unsigned shift = 0; shift < key_bits; shift += 16)
+  {
+    std::fill(count.begin(), count.end(), 0u);
+    for (auto const & e : v)
+      ++count[(e.first >> shift) & 0xFFFFu];
+    uint32_t sum = 0;
+    for (auto & c : count)
+    {
+      uint32_t const n = c;
+      c = sum;
+      sum += n;
+    }
+    for (auto const & e : v)
+      tmp[count[(e.first >> shift) & 0xFFFFu]++] = e;
+    v.swap(tmp);
+  }
+}
+
 static void bucket_insert(std::vector<IndexSlot> & slots, uint32_t log2_buckets, IndexSlot const & s)
 {
   uint64_t const mask = (1ull << log2_buckets) - 1;
@@ -354,8 +381,29 @@ static void bucket_insert(std::vector<IndexSlot> & slots, uint32_t log2_buckets,
       }
 }
 
+// Inserts in bucket order: the table is written front to back instead of at a million random places (which bucket a
+// spilled slot lands in depends on the order, what a lookup finds does not).
+static void bucket_insert_all(std::vector<IndexSlot> & slots, uint32_t log2_buckets, std::vector<IndexSlot> const & items)
+{
+  std::vector<std::pair<uint64_t, uint32_t>> order(items.size());
+  for (std::size_t i = 0; i < items.size(); ++i)
+    order[i] = {hash_key(items[i].key, log2_buckets), static_cast<uint32_t>(i)};
+  radix_sort_pairs(order, log2_buckets);
+  for (auto const & o : order)
+    bucket_insert(slots, log2_buckets, items[o.second]);
+}
+
 void build_index(HostGraph const & g, HostIndex & out)
 {
+  bool const timing = std::getenv("GTX_TIMING") != nullptr; // stage times on stderr
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](char const * what)
+  {
+    auto const now = std::chrono::steady_clock::now();
+    if (timing)
+      std::fprintf(stderr, "[gtx] build_index %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   out = HostIndex();
   std::vector<Emit> em;
   uint32_t const R = static_cast<uint32_t>(g.ref_order.size());
@@ -401,14 +449,16 @@ void build_index(HostGraph const & g, HostIndex & out)
       }
     }
   }
+  lap("enumerate k-mers");
   // group by key keeping emission order inside a key
-  std::vector<uint32_t> perm(em.size());
-  std::iota(perm.begin(), perm.end(), 0u);
-  std::stable_sort(perm.begin(), perm.end(), [&em](uint32_t a, uint32_t b) { return em[a].key < em[b].key; });
+  std::vector<std::pair<uint64_t, uint32_t>> perm(em.size());
+  for (std::size_t i = 0; i < em.size(); ++i)
+    perm[i] = {em[i].key, static_cast<uint32_t>(i)};
+  radix_sort_pairs(perm, 64);
   out.labels.reserve(em.size());
   for (std::size_t i = 0; i < perm.size(); ++i)
   {
-    Emit const & e = em[perm[i]];
+    Emit const & e = em[perm[i].second];
     if (i == 0 || e.key != out.keys.back())
     {
       out.keys.push_back(e.key);
@@ -417,14 +467,24 @@ void build_index(HostGraph const & g, HostIndex & out)
     out.labels.push_back(e.label);
   }
   out.key_off.push_back(static_cast<uint32_t>(out.labels.size()));
-  // device form
+  lap("group by key");
+  // device form: (plane key, label offset, label count) of every key, then the exact table (own thread) and the two
+  // half-key tables
+  std::vector<HalfEntry> all(out.keys.size());
+  for (std::size_t k = 0; k < out.keys.size(); ++k)
+    all[k] = HalfEntry{plane_key(out.keys[k]), out.key_off[k], out.key_off[k + 1] - out.key_off[k]};
+  lap("plane keys");
   uint32_t log2_cap = 2;
   while ((static_cast<uint64_t>(BUCKET_SLOTS) << log2_cap) < 2 * out.keys.size() + 1)
     ++log2_cap;
   out.log2_cap = log2_cap;
-  out.slots.assign(static_cast<uint64_t>(BUCKET_SLOTS) << log2_cap, IndexSlot{0, 0, 0});
-  for (std::size_t k = 0; k < out.keys.size(); ++k)
-    bucket_insert(out.slots, log2_cap, IndexSlot{plane_key(out.keys[k]), out.key_off[k], out.key_off[k + 1] - out.key_off[k]});
+  std::thread exact_table([&out, &all, log2_cap] {
+    out.slots.assign(static_cast<uint64_t>(BUCKET_SLOTS) << log2_cap, IndexSlot{0, 0, 0});
+    std::vector<IndexSlot> items(all.size());
+    for (std::size_t k = 0; k < all.size(); ++k)
+      items[k] = IndexSlot{all[k].key, all[k].off, all[k].cnt};
+    bucket_insert_all(out.slots, log2_cap, items);
+  });
   // half-key buckets (plane-form keys: the 16 first bases are bits 0..15 of both words, the 16 last bases bits 16..31)
   {
     size_t const n = out.keys.size();
@@ -433,26 +493,28 @@ void build_index(HostGraph const & g, HostIndex & out)
       uint32_t const lo = static_cast<uint32_t>(pk), hi = static_cast<uint32_t>(pk >> 32);
       return side == 0 ? ((lo & 0xFFFFu) | ((hi & 0xFFFFu) << 16)) : ((lo >> 16) | (hi & 0xFFFF0000u));
     };
-    std::vector<HalfEntry> all(n);
-    for (size_t k = 0; k < n; ++k)
-      all[k] = HalfEntry{plane_key(out.keys[k]), out.key_off[k], out.key_off[k + 1] - out.key_off[k]};
     out.hlist.resize(2 * n);
     uint32_t hl = 2;
     while ((static_cast<uint64_t>(BUCKET_SLOTS) << hl) < 4 * n + 1)
       ++hl;
     out.h_log2_cap = hl;
     out.hslots.assign(static_cast<uint64_t>(BUCKET_SLOTS) << hl, IndexSlot{0, 0, 0});
-    for (int side = 0; side < 2; ++side)
+    std::vector<IndexSlot> side_items[2];
+    auto build_side = [&](int side)
     {
-      std::vector<uint32_t> order(n);
-      std::iota(order.begin(), order.end(), 0u);
-      std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-        uint64_t const ha = half_of(all[a].key, side), hb = half_of(all[b].key, side);
-        return ha != hb ? ha < hb : all[a].key < all[b].key;
-      });
+      // group the keys by this half (order of the groups and inside a group does not matter to the kernel, which
+      // orders its candidates by neighbour number): out.keys ascending is already grouped by the first 16 bases; for
+      // the last 16 bases a stable radix sort on the low 32 bits of the 2-bit key
+      std::vector<std::pair<uint64_t, uint32_t>> order(n);
+      for (size_t k = 0; k < n; ++k)
+        order[k] = {out.keys[k], static_cast<uint32_t>(k)};
+      if (side == 1)
+        radix_sort_pairs(order, 32);
       size_t const base = side * n;
       for (size_t k = 0; k < n; ++k)
-        out.hlist[base + k] = all[order[k]];
+        out.hlist[base + k] = all[order[k].second];
+      std::vector<IndexSlot> & items = side_items[side];
+      items.reserve(n);
       size_t k = 0;
       while (k < n)
       {
@@ -460,12 +522,22 @@ void build_index(HostGraph const & g, HostIndex & out)
         size_t e = k + 1;
         while (e < n && half_of(out.hlist[base + e].key, side) == half)
           ++e;
-        bucket_insert(out.hslots, hl, IndexSlot{half | (static_cast<uint64_t>(side) << 32), static_cast<uint32_t>(base + k),
-                                                static_cast<uint32_t>(e - k)});
+        items.push_back(IndexSlot{half | (static_cast<uint64_t>(side) << 32), static_cast<uint32_t>(base + k),
+                                  static_cast<uint32_t>(e - k)});
         k = e;
       }
-    }
+    };
+    std::thread other_side(build_side, 1);
+    build_side(0);
+    other_side.join();
+    std::vector<IndexSlot> half_items(std::move(side_items[0]));
+    half_items.insert(half_items.end(), side_items[1].begin(), side_items[1].end());
+    lap("  half lists");
+    bucket_insert_all(out.hslots, hl, half_items);
   }
+  lap("half-key tables");
+  exact_table.join();
+  lap("exact table (rest)");
   out.dev_labels.resize(out.labels.size());
   for (std::size_t i = 0; i < out.labels.size(); ++i)
   {
@@ -478,6 +550,7 @@ void build_index(HostGraph const & g, HostIndex & out)
     }
     out.dev_labels[i] = d;
   }
+  lap("device labels");
 }
 
 } // namespace gtx
