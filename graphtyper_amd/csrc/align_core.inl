@@ -1367,17 +1367,34 @@ GTX_DEV bool finish_single_path(Here, GraphView const & g, WS & ws, uint32_t & n
     uint32_t const anchor = GTX_U(p.end);
     if (g_is_special(g, anchor) || anchor < g.first_order || g.n_ref <= 1)
       return false;
-    uint32_t const rr = g_ref_node_at<W>(g, anchor);
-    uint32_t const ro = GTX_U(g.ref_order[rr]), rl = GTX_U(g.ref_len[rr]);
     SubRead sr;
     sr.rd = ws.rd;
     sr.begin = pre;
     sr.len = L - pre;
-    if (!(anchor < ro + rl) || rl - (anchor - ro) < sr.len)
-      return false;
+    uint8_t const * dna;
+    uint32_t room;
+    if (g.pos_info)
+    {
+      // one table lookup instead of the bucket -> node order -> node tables chain (this wave is latency-bound)
+      if (anchor - g.first_order >= g.n_pos_info)
+        return false;
+      uint32_t const w = GTX_U(g.pos_info[anchor - g.first_order]);
+      if (w == INVALID || (w & 255u) < sr.len) // (room is capped at 255: a longer tail takes the general code)
+        return false;
+      room = w & 255u;
+      dna = reinterpret_cast<uint8_t const *>(g.dna) + (w >> 8);
+    }
+    else
+    {
+      uint32_t const rr = g_ref_node_at<W>(g, anchor);
+      uint32_t const ro = GTX_U(g.ref_order[rr]), rl = GTX_U(g.ref_len[rr]);
+      if (!(anchor < ro + rl) || rl - (anchor - ro) < sr.len)
+        return false;
+      room = rl - (anchor - ro);
+      dna = reinterpret_cast<uint8_t const *>(g.dna) + GTX_U(g.ref_dna[rr]) + (anchor - ro);
+    }
     uint32_t const budget = 2 + sr.len / 11 < 7 ? 2 + sr.len / 11 : 7; // genotype_paths.cpp:505-511, best starts at 7
-    uint8_t const * dna = reinterpret_cast<uint8_t const *>(g.dna) + GTX_U(g.ref_dna[rr]) + (anchor - ro);
-    uint32_t const got = cmp_codes<W, false>(sr, 0, dna, rl - (anchor - ro), 0, budget);
+    uint32_t const got = cmp_codes<W, false>(sr, 0, dna, room, 0, budget);
     if (got <= budget)
     {
       mism += got;

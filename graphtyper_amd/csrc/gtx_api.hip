@@ -158,9 +158,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void gt
     uint32_t next_word = 0, n_pending = 0;
     if (prefetch && 4 * lane < seq_stride)
       next_word = reinterpret_cast<uint32_t const *>(seq + static_cast<uint64_t>(base) * seq_stride)[lane];
+    gtx_read_meta next_meta = meta[base];
     for (uint32_t read = base; read < end; ++read)
     {
-      gtx_read_meta const m = meta[read];
+      gtx_read_meta const m = next_meta;
+      if (read + 1 < end)
+        next_meta = meta[read + 1]; // (needed one read later: off the latency chain)
       uint32_t const len = m.l_qseq;
       uint8_t const * read_seq = seq + static_cast<uint64_t>(read) * seq_stride;
       if (prefetch)
@@ -429,6 +432,8 @@ int ctx_upload(gtx_ctx & c, int device)
   ok = ok && upload(c.dev_allocs, v.special_ref_reach, h.special_ref_reach.data(), h.special_ref_reach.size(), "special_ref_reach");
   ok = ok && upload(c.dev_allocs, v.special_actual, h.special_actual.data(), h.special_actual.size(), "special_actual");
   ok = ok && upload(c.dev_allocs, v.pos_bucket, h.pos_bucket.data(), h.pos_bucket.size(), "pos_bucket");
+  if (!h.pos_info.empty())
+    ok = ok && upload(c.dev_allocs, v.pos_info, h.pos_info.data(), h.pos_info.size(), "pos_info");
   ok = ok && upload(c.dev_allocs, v.dna, h.codes.data(), h.codes.size(), "dna codes");
   ok = ok && upload(c.dev_allocs, v.tri_off, h.tri_off.data(), h.tri_off.size(), "tri_off");
   ok = ok && upload(c.dev_allocs, v.allele_off, h.allele_off.data(), h.allele_off.size(), "allele_off");
@@ -555,7 +560,7 @@ using namespace gtx;
 extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta,
                                uint32_t n_reads, uint32_t * d_records, uint32_t rec_words, void * stream)
 {
-  if (!c || !d_seq || !d_meta || !d_records || rec_words < 8)
+  if (!c || rec_words < 8 || (n_reads != 0 && (!d_seq || !d_meta || !d_records)))
   {
     g_last_error = "gtx_align_batch: bad argument";
     return GTX_ERR_ARG;
@@ -565,7 +570,7 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
     g_last_error = "context was created without a device (libgtx has no CPU path)";
     return GTX_ERR_NO_DEVICE;
   }
-  if (n_reads == 0)
+  if (n_reads == 0) // an empty batch is valid (and its buffers may be NULL)
     return GTX_OK;
   // per launch: [0] read counter of pass 1, [1] task counter of pass 2, [2] number of tasks queued for pass 2
   uint32_t * counters = c->d_task_counters + 4 * (c->launch_seq.fetch_add(1) % (gtx_ctx::N_TASK_COUNTERS / 4));

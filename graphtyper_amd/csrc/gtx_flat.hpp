@@ -60,6 +60,10 @@ struct GraphView
   const uint32_t * special_ref_reach; // Graph::ref_reach_poses
   const uint32_t * special_actual;    // Graph::actual_poses
   const uint32_t * pos_bucket;        // [n_bucket] last ref node whose order <= first_order + 64*b
+  // [n_pos_info] per position first_order + i: INVALID when it is not inside a reference node, else
+  // (offset of its base in `dna` << 8) | min(255, bases of that node from it on); NULL when the arena is > 16 MB
+  const uint32_t * pos_info;
+  uint32_t n_pos_info, pad2;
   const char * dna; // graph sequence as codes (see align_core.hpp: DNA_KILL / DNA_OTHER), same offsets as the characters
   // score accumulator layout (haplotype h <-> site h, graph.cpp:680-704)
   const uint64_t * tri_off;    // [n_ref] offset of the genotype triangle of site r
@@ -94,7 +98,7 @@ struct HostGraph
 {
   std::vector<uint32_t> ref_order, ref_len, ref_dna, ref_nvar, ref_first_var;
   std::vector<uint32_t> var_order, var_len, var_dna, var_out_ref;
-  std::vector<uint32_t> site_ref_reach, site_special_base, special_ref_reach, special_actual, pos_bucket;
+  std::vector<uint32_t> site_ref_reach, site_special_base, special_ref_reach, special_actual, pos_bucket, pos_info;
   std::vector<uint32_t> event_off; // [2*n_var+1] (empty when the graph has no events)
   std::vector<int64_t> event_val;
   std::vector<uint64_t> tri_off, allele_off;

@@ -261,3 +261,41 @@ def sv_stream_case(Backend, n_pairs):
 
 def test_sv_calling_host_logic():
     sv_stream_case(harness.EmuBackend, 1500)
+
+
+def edge_case(Backend):
+    """boundary inputs of gtx_align_batch: no reads; reads of the maximum length and one base more; a row stride that is
+    not a multiple of 4 (no prefetch path); record slots too small for any path (everything lands in the arena)"""
+    ref, recs, codes, pos = scenarios.synthetic_case("snp100", n_ref=30000, n_reads=300, region_begin=5000, read_len=256)
+    o = Oracle(ref, recs, region_begin=5000)
+    b = Backend(gtx.graph_from_records(ref, recs, region_begin=5000))
+    # 1. empty batch
+    rec = b.align(np.zeros((0, 16), np.uint8), harness.read_meta(np.zeros(0, np.uint16)))
+    assert rec.size == 0
+    # 2. 256 bp reads (the library's maximum) equal the oracle; 257 bp is refused with a status, not answered
+    check_align(b, o, list(codes))
+    long_codes = np.concatenate([codes[:4], np.full((4, 1), 1, np.uint8)], axis=1)
+    seq, lens = harness.pack_ragged(list(long_codes))
+    r = b.align(seq, harness.read_meta(lens)).reshape(-1, harness.REC_WORDS)
+    assert ((r[:, 0] >> 16) == gtx.ST_RECORD_OVERFLOW).all() and (r[:, 0] & 0xFFFF == 0).all()
+    # 3. odd row stride
+    reads150 = [c[:150] for c in codes[:200]]
+    want = o.align(reads150)
+    packed = gtx.pack_nibbles(np.stack(reads150), stride=75)
+    r = b.align(packed, harness.read_meta(np.full(len(reads150), 150)))
+    got = gtx.parse_records(r, len(reads150), harness.REC_WORDS, b.ctx.hap_order, b.big_records()[0])
+    assert [dict(longest=a[0]["longest"], paths=a[0]["paths"]) for a in got] == [w[0] for w in want]
+    # 4. the smallest record slot the API accepts: every aligned read is an external record
+    b.rewind_big_records()
+    seq, lens = harness.pack_ragged(reads150)
+    r8 = b.align(seq, harness.read_meta(lens), rec_words=8)
+    big, _ = b.big_records()
+    got8 = gtx.parse_records(r8, len(reads150), 8, b.ctx.hap_order, big)
+    assert [dict(longest=a[0]["longest"], paths=a[0]["paths"]) for a in got8] == [w[0] for w in want]
+    st8 = r8.reshape(-1, 8)[0::2, 0] >> 16
+    aligned = np.array([len(w[0]["paths"]) > 0 for w in want])
+    assert ((st8[aligned] & gtx.ST_EXTERNAL) != 0).all() and not (st8 & gtx.ST_ERROR_MASK).any()
+
+
+def test_edge_cases():
+    edge_case(harness.EmuBackend)

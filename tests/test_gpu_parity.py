@@ -10,7 +10,7 @@ import harness
 import scenarios
 from graphtyper_amd import lib as gtx
 from oracle_lib import Oracle, encode
-from test_emu_parity import check_align, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case
+from test_emu_parity import check_align, edge_case, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case
 
 pytestmark = pytest.mark.gpu
 
@@ -109,3 +109,7 @@ def test_sv_calling_host_logic():
 
 def test_align_iupac_codes():
     iupac_case(harness.GpuBackend, 10000)
+
+
+def test_edge_cases():
+    edge_case(harness.GpuBackend)
