@@ -1534,11 +1534,20 @@ GTX_DEV bool seed_stage(Here, GraphView const & g, IndexView const & ix, WS & ws
     {
       uint64_t const q = ws.key0[i];
       uint32_t off, cnt;
-      bucket_find(w == 0 ? ix.slots : ix.hslots, w == 0 ? ix.log2_cap : ix.h_log2_cap, w == 0 ? q : half_key(q, w - 1), off, cnt);
+      IndexSlot const * hit;
+      bucket_find(w == 0 ? ix.slots : ix.hslots, w == 0 ? ix.log2_cap : ix.h_log2_cap, w == 0 ? q : half_key(q, w - 1), off, cnt,
+                  &hit);
       uint32_t * o = w == 0 ? &ws.off0[i] : &ws.hoff[i][w - 1];
       uint32_t * c = w == 0 ? &ws.cnt0[i] : &ws.hcnt[i][w - 1];
       *o = off;
       *c = cnt;
+      if (cnt == 1 && i < kc)
+      {
+        // a single label / a single bucket entry is inline in the slot (same cache line): no second round trip
+        uint4_t const payload = *reinterpret_cast<uint4_t const *>(hit->p);
+        static_assert(sizeof(HalfEntry) == 16 && sizeof(DevLabel) == 16, "staged entries are 16-byte words");
+        *(w == 0 ? reinterpret_cast<uint4_t *>(&ws.xl[i][0]) : reinterpret_cast<uint4_t *>(&ws.he[i][w - 1][0])) = payload;
+      }
     }
   });
   W::lds_sync();
@@ -1569,7 +1578,7 @@ GTX_DEV bool seed_stage(Here, GraphView const & g, IndexView const & ix, WS & ws
     {
       uint32_t const cnt = is_half ? ws.hcnt[i][side] : ws.cnt0[i];
       uint32_t const off = is_half ? ws.hoff[i][side] : ws.off0[i];
-      if (cnt <= (is_half ? AlignCfg::HE_CAP : AlignCfg::XL_CAP) && e < cnt)
+      if (cnt > 1 && cnt <= (is_half ? AlignCfg::HE_CAP : AlignCfg::XL_CAP) && e < cnt) // (a single entry came with its slot)
       {
         static_assert(sizeof(HalfEntry) == 16 && sizeof(DevLabel) == 16, "staged entries are copied as 16-byte words");
         uint4_t const * src = is_half ? reinterpret_cast<uint4_t const *>(ix.hlist + off + e) : reinterpret_cast<uint4_t const *>(ix.labels + off + e);

@@ -200,20 +200,27 @@ struct BitSet
   }
 };
 
-// lookup in a bucketed table (gtx_flat.hpp: BUCKET_SLOTS): the whole 64-byte bucket is fetched at once
-GTX_DEV void bucket_find(IndexSlot const * slots, uint32_t log2_buckets, uint64_t key, uint32_t & off, uint32_t & cnt)
+// lookup in a bucketed table (gtx_flat.hpp: BUCKET_SLOTS): the whole 128-byte bucket is one cache line; `hit` (may be
+// NULL) receives the slot that matched, whose inline payload is then an L1 hit
+GTX_DEV void bucket_find(IndexSlot const * slots, uint32_t log2_buckets, uint64_t key, uint32_t & off, uint32_t & cnt,
+                         IndexSlot const ** hit = nullptr)
 {
   uint64_t const mask = (1ull << log2_buckets) - 1;
   for (uint64_t b = hash_key(key, log2_buckets);; b = (b + 1) & mask)
   {
     IndexSlot const * p = slots + b * BUCKET_SLOTS;
-    IndexSlot const s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
-    bool const m0 = s0.cnt != 0 && s0.key == key, m1 = s1.cnt != 0 && s1.key == key;
-    bool const m2 = s2.cnt != 0 && s2.key == key, m3 = s3.cnt != 0 && s3.key == key;
-    off = m0 ? s0.off : m1 ? s1.off : m2 ? s2.off : m3 ? s3.off : 0u;
-    cnt = m0 ? s0.cnt : m1 ? s1.cnt : m2 ? s2.cnt : m3 ? s3.cnt : 0u;
+    uint64_t const k0 = p[0].key, k1 = p[1].key, k2 = p[2].key, k3 = p[3].key;
+    uint32_t const c0 = p[0].cnt, c1 = p[1].cnt, c2 = p[2].cnt, c3 = p[3].cnt;
+    bool const m0 = c0 != 0 && k0 == key, m1 = c1 != 0 && k1 == key;
+    bool const m2 = c2 != 0 && k2 == key, m3 = c3 != 0 && k3 == key;
+    uint32_t const m = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u;
+    bool const any = m0 || m1 || m2 || m3;
+    off = any ? p[m].off : 0u;
+    cnt = m0 ? c0 : m1 ? c1 : m2 ? c2 : m3 ? c3 : 0u;
+    if (hit)
+      *hit = any ? p + m : nullptr;
     // slots fill front to back: an empty last slot means nothing ever spilled out of this bucket
-    if (m0 || m1 || m2 || m3 || s3.cnt == 0)
+    if (any || c3 == 0)
       return;
   }
 }

@@ -32,10 +32,14 @@ struct alignas(16) DevLabel
 // 64-byte fetch; a full bucket spills into the next one.  cnt == 0 marks an empty slot.
 constexpr uint32_t BUCKET_SLOTS = 4;
 
-struct alignas(16) IndexSlot
+struct alignas(32) IndexSlot
 {
   uint64_t key;
   uint32_t off, cnt;
+  // What a count of 1 points at, inline: the one label of the key (exact table: start, end, site, allele) or the one
+  // entry of the half-key bucket (key low, key high, label offset, label count).  A lookup that ends in a single entry --
+  // nearly all of them -- then costs one memory round trip instead of two (the kernels are bound by that latency).
+  uint32_t p[4];
 };
 
 // Plain-pointer view handed to kernels (device pointers) and to the host emulation in tests (host pointers).

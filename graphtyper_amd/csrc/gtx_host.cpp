@@ -482,6 +482,18 @@ void build_index(HostGraph const & g, HostIndex & out)
   }
   out.key_off.push_back(static_cast<uint32_t>(out.labels.size()));
   lap("group by key");
+  out.dev_labels.resize(out.labels.size());
+  for (std::size_t i = 0; i < out.labels.size(); ++i)
+  {
+    gtx_label const & l = out.labels[i];
+    DevLabel d{l.start_index, l.end_index, INVALID, 0};
+    if (l.variant_id != INVALID)
+    {
+      d.site = g.var_out_ref[l.variant_id] - 1;
+      d.allele = l.variant_id - g.ref_first_var[d.site];
+    }
+    out.dev_labels[i] = d;
+  }
   // device form: (plane key, label offset, label count) of every key, then the exact table (own thread) and the two
   // half-key tables
   std::vector<HalfEntry> all(out.keys.size());
@@ -493,10 +505,20 @@ void build_index(HostGraph const & g, HostIndex & out)
     ++log2_cap;
   out.log2_cap = log2_cap;
   std::thread exact_table([&out, &all, log2_cap] {
-    out.slots.assign(static_cast<uint64_t>(BUCKET_SLOTS) << log2_cap, IndexSlot{0, 0, 0});
+    out.slots.assign(static_cast<uint64_t>(BUCKET_SLOTS) << log2_cap, IndexSlot{0, 0, 0, {0, 0, 0, 0}});
     std::vector<IndexSlot> items(all.size());
     for (std::size_t k = 0; k < all.size(); ++k)
-      items[k] = IndexSlot{all[k].key, all[k].off, all[k].cnt};
+    {
+      items[k] = IndexSlot{all[k].key, all[k].off, all[k].cnt, {0, 0, 0, 0}};
+      if (all[k].cnt == 1) // inline copy of the one label
+      {
+        DevLabel const & d = out.dev_labels[all[k].off];
+        items[k].p[0] = d.start;
+        items[k].p[1] = d.end;
+        items[k].p[2] = d.site;
+        items[k].p[3] = d.allele;
+      }
+    }
     bucket_insert_all(out.slots, log2_cap, items);
   });
   // half-key buckets (plane-form keys: the 16 first bases are bits 0..15 of both words, the 16 last bases bits 16..31)
@@ -512,7 +534,7 @@ void build_index(HostGraph const & g, HostIndex & out)
     while ((static_cast<uint64_t>(BUCKET_SLOTS) << hl) < 4 * n + 1)
       ++hl;
     out.h_log2_cap = hl;
-    out.hslots.assign(static_cast<uint64_t>(BUCKET_SLOTS) << hl, IndexSlot{0, 0, 0});
+    out.hslots.assign(static_cast<uint64_t>(BUCKET_SLOTS) << hl, IndexSlot{0, 0, 0, {0, 0, 0, 0}});
     std::vector<IndexSlot> side_items[2];
     auto build_side = [&](int side)
     {
@@ -536,8 +558,17 @@ void build_index(HostGraph const & g, HostIndex & out)
         size_t e = k + 1;
         while (e < n && half_of(out.hlist[base + e].key, side) == half)
           ++e;
-        items.push_back(IndexSlot{half | (static_cast<uint64_t>(side) << 32), static_cast<uint32_t>(base + k),
-                                  static_cast<uint32_t>(e - k)});
+        IndexSlot s{half | (static_cast<uint64_t>(side) << 32), static_cast<uint32_t>(base + k), static_cast<uint32_t>(e - k),
+                    {0, 0, 0, 0}};
+        if (e - k == 1) // inline copy of the one bucket entry
+        {
+          HalfEntry const & he = out.hlist[base + k];
+          s.p[0] = static_cast<uint32_t>(he.key);
+          s.p[1] = static_cast<uint32_t>(he.key >> 32);
+          s.p[2] = he.off;
+          s.p[3] = he.cnt;
+        }
+        items.push_back(s);
         k = e;
       }
     };
@@ -552,18 +583,6 @@ void build_index(HostGraph const & g, HostIndex & out)
   lap("half-key tables");
   exact_table.join();
   lap("exact table (rest)");
-  out.dev_labels.resize(out.labels.size());
-  for (std::size_t i = 0; i < out.labels.size(); ++i)
-  {
-    gtx_label const & l = out.labels[i];
-    DevLabel d{l.start_index, l.end_index, INVALID, 0};
-    if (l.variant_id != INVALID)
-    {
-      d.site = g.var_out_ref[l.variant_id] - 1;
-      d.allele = l.variant_id - g.ref_first_var[d.site];
-    }
-    out.dev_labels[i] = d;
-  }
   lap("device labels");
 }
 
