@@ -1597,10 +1597,10 @@ GTX_DEV bool seed_stage(Here, GraphView const & g, IndexView const & ix, WS & ws
   if (try_fast && use_halves && n_k > 0 && n_k == kc)
   {
     typename W::template PerLane<bool> bad_l, var_l;
-    typename W::template PerLane<uint32_t> mm_l;
+    typename W::template PerLane<uint32_t> mm_l, why_l;
     W::lanes([&](uint32_t l) {
       bool bad = false, has_var = false;
-      uint32_t mm = 0;
+      uint32_t mm = 0, why = 0;
       if (l < n_k)
       {
         uint32_t const c0 = ws.cnt0[l];
@@ -1611,16 +1611,19 @@ GTX_DEV bool seed_stage(Here, GraphView const & g, IndexView const & ix, WS & ws
           // shorter than it (or, from k-mer 0, the same chain with one more mismatch) and is dropped by
           // remove_short_paths / remove_paths_with_too_many_mismatches -- the chain itself is what remains.
           bad = c0 != 1;
+          why = 1; // ambiguous base(s) without exactly one label
           if (!bad)
           {
             DevLabel const lb = ws.xl[l][0];
             bad = lb.site != INVALID;
+            why = 2; // ambiguous base on a variant
             ws.fs_start[l] = lb.start;
             ws.fs_end[l] = lb.end;
           }
         }
         else if (!(bad = c0 > 1 || ws.hcnt[l][0] > AlignCfg::HE_CAP || ws.hcnt[l][1] > AlignCfg::HE_CAP))
         {
+          why = 3;
           uint64_t const q = ws.key0[l];
           uint32_t nb = 0, nb_off = 0;
           for (uint32_t side = 0; side < 2; ++side)
@@ -1639,11 +1642,13 @@ GTX_DEV bool seed_stage(Here, GraphView const & g, IndexView const & ix, WS & ws
             DevLabel const lb = c0 ? ws.xl[l][0] : ix.labels[nb_off];
             mm = c0 ? 0u : 1u;
             bad = lb.site != INVALID;
+            why = 4; // the one label is a neighbour's (or an exact one) on a variant
             ws.fs_start[l] = lb.start;
             ws.fs_end[l] = lb.end;
           }
           else if (c0 == 1 && nb <= 3 && !g.is_sv_graph)
           {
+            why = 5; // exact label + neighbours that are not "the same SNP"
             // The read carries one allele of a variant site and the only Hamming-1 neighbours are the same interval on
             // the site's other alleles (a SNP).  In the loop below each of those starts a path with one more mismatch
             // that shares every later label and the chain's end with the exact one, so it walks the same tail and
@@ -1673,19 +1678,44 @@ GTX_DEV bool seed_stage(Here, GraphView const & g, IndexView const & ix, WS & ws
             }
           }
           else
+          {
             bad = true;
+            why = c0 + nb == 0 ? 6 : 7; // no label at all / several labels
+          }
         }
+        else
+          why = 8; // many exact labels or big half buckets
       }
       bad_l[l] = bad;
       var_l[l] = has_var;
       mm_l[l] = mm;
+      why_l[l] = bad ? why : 0u;
     });
+#ifdef GTX_EMU_NOTES // diagnostics of the host emulation: why the task leaves the express pass
+    {
+      uint32_t first_why = 0;
+      W::lanes([&](uint32_t l) {
+        if (first_why == 0 && why_l[l] != 0)
+          first_why = why_l[l];
+      });
+      if (first_why)
+        W::note(first_why);
+    }
+#endif
     uint64_t const with_var = W::ballot(var_l);
+#ifdef GTX_EMU_NOTES
+    if (W::ballot(bad_l) == 0 && (with_var & (with_var - 1)) != 0)
+      W::note(10); // two k-mers on variants
+#endif
     if (W::ballot(bad_l) == 0 && (with_var & (with_var - 1)) == 0)
     {
       W::lds_sync();
       typename W::template PerLane<bool> gap_l;
       W::lanes([&](uint32_t l) { gap_l[l] = l + 1 < n_k && ws.fs_end[l] != ws.fs_start[l + 1]; });
+#ifdef GTX_EMU_NOTES
+      if (W::ballot(gap_l) != 0)
+        W::note(9); // labels do not abut
+#endif
       if (W::ballot(gap_l) == 0)
       {
         uint32_t const mism = W::sum(mm_l);
@@ -1946,7 +1976,12 @@ GTX_DEV bool express_one(GraphView const & g, IndexView const & ix, SeedWorkspac
   if (!seed_stage<W>(Here{}, g, ix, ws, seq4, len, reverse, true, np, longest))
     return false;
   if (!finish_single_path<W>(Here{}, g, ws, np, longest))
+  {
+#ifdef GTX_EMU_NOTES
+    W::note(11); // the tail does not fit in the reference node the chain ends in
+#endif
     return false;
+  }
   if (record_size<W>(Here{}, ws, np) > rec_words)
     return false;
   GTX_PROF_BEGIN

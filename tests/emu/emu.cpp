@@ -19,8 +19,11 @@ namespace
 {
 // Sequential stand-in for one wavefront: lane lambdas run for lane 0..63 one after the other, per-lane values are
 // arrays of 64, the wave-uniform parts of the kernel source run once.
+uint64_t g_notes[16]; // why a task left the express pass (W::note), test diagnostics only
+
 struct WaveEmu
 {
+  static void note(uint32_t k) { ++g_notes[k & 15u]; }
   template <class T>
   struct PerLane
   {
@@ -196,6 +199,16 @@ extern "C"
   }
 
   void emu_big_records_rewind(void * p) { static_cast<Emu *>(p)->arena_used = 0; }
+
+  void emu_notes(uint64_t * out, int reset)
+  {
+    for (int i = 0; i < 16; ++i)
+    {
+      out[i] = g_notes[i];
+      if (reset)
+        g_notes[i] = 0;
+    }
+  }
 
   uint64_t emu_general_tasks(void * p) { return static_cast<Emu *>(p)->general_tasks; }
 
