@@ -1916,14 +1916,17 @@ GTX_DEV uint32_t record_size(Here, WS const & ws, uint32_t n_paths)
 }
 
 // path part of the record (words 2..); `body` has room for record_size() - 2 words
+// Returns GTX_REC_HAS_VARIANTS when a path carries a variant site, else 0 (bit 31 of the record's second word: lets the
+// scorer skip the 85 % of the reads that cannot add anything without parsing their paths).
 template <class W, class WS>
-GTX_DEV void write_record_body(Here, WS const & ws, uint32_t n_paths, uint32_t * body)
+GTX_DEV uint32_t write_record_body(Here, WS const & ws, uint32_t n_paths, uint32_t * body)
 {
-  uint32_t w = 0;
+  uint32_t w = 0, any_var = 0;
   for (uint32_t i = 0; i < n_paths; ++i)
   {
     DPath const & p = ws.paths[i];
     uint32_t const nvar = GTX_U(static_cast<uint32_t>(p.nvar));
+    any_var |= nvar;
     uint32_t const * src = reinterpret_cast<uint32_t const *>(&p);
     uint32_t const nw = 4 + 3 * nvar;
     W::lanes([&](uint32_t l) {
@@ -1937,6 +1940,7 @@ GTX_DEV void write_record_body(Here, WS const & ws, uint32_t n_paths, uint32_t *
     });
     w += nw;
   }
+  return any_var ? GTX_REC_HAS_VARIANTS : 0u;
 }
 
 // one (read, orientation) of the main pass: result into its record slot
@@ -1954,11 +1958,11 @@ GTX_DEV uint32_t align_one(GraphView const & g, IndexView const & ix, AlignWorks
     np = 0;
   }
   GTX_PROF_BEGIN
-  write_record_body<W>(Here{}, ws, np, rec + 2);
+  uint32_t const has_var = write_record_body<W>(Here{}, ws, np, rec + 2);
   GTX_LEAD
   {
     rec[0] = np | (status << 16);
-    rec[1] = (np == 0 ? 0 : longest) | (len << 16);
+    rec[1] = (np == 0 ? 0 : longest) | (len << 16) | has_var;
   }
   W::lds_sync();
   GTX_PROF_TICK(9)
@@ -1985,11 +1989,11 @@ GTX_DEV bool express_one(GraphView const & g, IndexView const & ix, SeedWorkspac
   if (record_size<W>(Here{}, ws, np) > rec_words)
     return false;
   GTX_PROF_BEGIN
-  write_record_body<W>(Here{}, ws, np, rec + 2);
+  uint32_t const has_var = write_record_body<W>(Here{}, ws, np, rec + 2);
   GTX_LEAD
   {
     rec[0] = np;
-    rec[1] = (np == 0 ? 0 : longest) | (len << 16);
+    rec[1] = (np == 0 ? 0 : longest) | (len << 16) | has_var;
   }
   W::lds_sync();
   GTX_PROF_TICK(9)

@@ -316,11 +316,11 @@ __global__ __launch_bounds__(64) void gtx_align_big_kernel(GraphView g, IndexVie
         }
       }
     }
-    big::write_record_body<WaveHipMem>(big::Here{}, ws, np, body);
+    uint32_t const has_var = big::write_record_body<WaveHipMem>(big::Here{}, ws, np, body);
     if ((threadIdx.x & 63u) == 0)
     {
       rec[0] = np | ((status | ext) << 16);
-      rec[1] = (np == 0 ? 0 : longest) | (len << 16);
+      rec[1] = (np == 0 ? 0 : longest) | (len << 16) | has_var;
       if (ext)
         rec[2] = static_cast<uint32_t>(off);
     }

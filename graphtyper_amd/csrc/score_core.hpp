@@ -35,6 +35,7 @@ struct Geno // one GenotypePaths as seen by the scorer
   uint32_t n_paths, longest, read_len;
   uint32_t flags, mapq, score_diff;
   bool proper_pair; // ml_insert_size != INSERT_SIZE_WHEN_NOT_PROPER_PAIR
+  bool has_var;     // some path carries a variant site (else the read cannot add anything to the accumulators)
 };
 
 GTX_DEV Geno geno_of(uint32_t const * records, uint32_t rec_words, uint32_t const * big_records, uint32_t align_index,
@@ -45,7 +46,8 @@ GTX_DEV Geno geno_of(uint32_t const * records, uint32_t rec_words, uint32_t cons
   g.body = ((g.rec[0] >> 16) & GTX_ST_EXTERNAL) ? big_records + g.rec[2] : g.rec + 2;
   g.n_paths = g.rec[0] & 0xFFFFu;
   g.longest = g.rec[1] & 0xFFFFu;
-  g.read_len = g.rec[1] >> 16;
+  g.read_len = (g.rec[1] >> 16) & 0x7FFFu;
+  g.has_var = (g.rec[1] & GTX_REC_HAS_VARIANTS) != 0;
   g.flags = 0;
   g.mapq = 255;
   g.score_diff = 0;
@@ -431,6 +433,8 @@ GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_
     // update_unpaired_read_paths (alignment.cpp:365-455).  clipped_count() returns 0/1, so IS_CLIPPED is never set.
     gtx_rec_meta const & m = it.first;
     Geno fwd = geno_of(records, rec_words, acc.big_records, m.align_index, 0), rev = geno_of(records, rec_words, acc.big_records, m.align_index, 1);
+    if (!fwd.has_var && !rev.has_var)
+      return true; // whichever orientation wins, it touches no variant site: nothing to add
     int const which = compare_single(fwd, rev);
     if (which == 0)
       return true;
@@ -470,6 +474,8 @@ GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_
     f.score_diff = v.score_diff = m.score_diff;
     f.proper_pair = v.proper_pair = true; // ml_insert_size = |isize|, never INSERT_SIZE_WHEN_NOT_PROPER_PAIR for int32 isize
   }
+  if (!q[0].has_var && !q[1].has_var && !q[2].has_var && !q[3].has_var)
+    return true; // no orientation of either mate touches a variant site: nothing to add
   // get_better_paths (alignment.cpp:557-620)
   int arr[4] = {-1, -1, -1, -1};
   for (int k = 0; k < 4; ++k)

@@ -452,7 +452,7 @@ def parse_records(words, n_reads, rec_words, hap_order, big_records=None):
         for o in range(2):
             w = words[2 * i + o]
             npaths, status = int(w[0]) & 0xFFFF, int(w[0]) >> 16
-            longest, rlen = int(w[1]) & 0xFFFF, int(w[1]) >> 16
+            longest, rlen = int(w[1]) & 0xFFFF, (int(w[1]) >> 16) & 0x7FFF  # (bit 31: REC_HAS_VARIANTS)
             k = 2
             if status & ST_EXTERNAL:
                 w, k = big_records, int(w[2])

@@ -59,6 +59,7 @@ enum
   GTX_ST_EXTERNAL = 16        /* not an error: the path words of this record are in the big-record arena (see gtx_align_batch) */
 };
 #define GTX_ST_ERROR_MASK 15u
+#define GTX_REC_HAS_VARIANTS 0x80000000u /* bit 31 of record word 1: some path of the record carries a variant site */
 
 /* Graph as SoA node tables = the reference's Graph::ref_nodes / var_nodes (include/graphtyper/graph/graph.hpp:40-134):
  * strictly alternating  ref node r -> its ref_nvar[r] var nodes (allele 0 = reference allele) -> ref node r+1.
@@ -211,7 +212,7 @@ int gtx_index_dump(const gtx_ctx *, uint64_t * keys, uint32_t * counts, gtx_labe
  * d_seq      : n_reads * seq_stride bytes, BAM 4-bit packed bases (bam_get_seq layout: high nibble first)
  * d_meta     : n_reads gtx_read_meta
  * d_records  : n_reads * 2 * rec_words uint32; record (read i, orientation o) starts at (2*i+o)*rec_words:
- *    w0 = n_paths | status << 16, w1 = longest_path_length | l_qseq << 16, then per path
+ *    w0 = n_paths | status << 16, w1 = longest_path_length | l_qseq << 16 | GTX_REC_HAS_VARIANTS, then per path
  *    start, end, read_start_index | read_end_index << 16, mismatches | n_var << 16, n_var * (hap, mask_lo, mask_hi)
  *    hap = haplotype (variant site) index, Path::var_order = hap_order[hap] of gtx_ctx_haplotypes;
  *    mask bit a set <=> allele a in Path::nums

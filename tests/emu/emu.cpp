@@ -181,9 +181,9 @@ extern "C"
           }
         }
       }
-      big::write_record_body<WaveEmu>(big::Here{}, *big_ws, np, body);
+      uint32_t const has_var = big::write_record_body<WaveEmu>(big::Here{}, *big_ws, np, body);
       rec[0] = np | ((status | ext) << 16);
-      rec[1] = (np == 0 ? 0 : longest) | (len << 16);
+      rec[1] = (np == 0 ? 0 : longest) | (len << 16) | has_var;
       if (ext)
         rec[2] = static_cast<uint32_t>(off);
     }
