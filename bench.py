@@ -124,6 +124,7 @@ def main():
     items = np.zeros(n, gtx.SCORE_ITEM)
     items["first"]["align_index"] = np.arange(n, dtype=np.uint32)
     items["first"]["mapq"] = 60
+    items["first"]["flag"] = gtx.FLAG_FORWARD_ONLY  # unpaired reads are aligned forward only (what gtx_stream_push sets)
     items["first"]["pos"] = d_pos.cpu().numpy().astype(np.int32)
     items["second"]["align_index"] = gtx.INVALID_ID
     d_items = torch.from_numpy(items.view(np.uint8).reshape(n, gtx.SCORE_ITEM.itemsize).copy()).to(device)

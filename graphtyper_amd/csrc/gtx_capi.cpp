@@ -382,6 +382,7 @@ struct gtx_stream
   std::vector<uint8_t> prev_seq;
   uint32_t prev_len = 0;
   uint32_t prev_align_index = 0;
+  bool prev_forward_only = false; // the previous alignment task had no reverse orientation
   uint32_t next_align_index = 0;
   uint64_t n_records = 0, n_duplicated = 0;
 };
@@ -454,8 +455,13 @@ extern "C"
         s->prev_len = r.l_qseq;
         s->prev_seq.assign(rseq, rseq + nbytes);
         s->prev_align_index = align_index;
+        // align_read (alignment.cpp:341-352): forward only for unpaired reads and concordant pairs
+        bool const one_orientation = (r.flag & 1u) == 0u || (r.tid == r.mtid && r.isize > -1200 && r.isize < 1200 &&
+                                                              (((r.flag & 16u) != 0u) != ((r.flag & 32u) != 0u)));
+        s->prev_forward_only = one_orientation && !s->params.force_align_both_orientations;
       }
-      gtx_rec_meta const me{align_index, r.flag, r.mapq, r.score_diff, r.pos, r.isize};
+      gtx_rec_meta const me{align_index, static_cast<uint16_t>(r.flag | (s->prev_forward_only ? GTX_FLAG_FORWARD_ONLY : 0u)), r.mapq,
+                            r.score_diff, r.pos, r.isize};
       auto & map = s->parked[r.rg];
       auto it = map.find(r.name_id);
       if (it == map.end())

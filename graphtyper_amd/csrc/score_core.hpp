@@ -55,6 +55,16 @@ GTX_DEV Geno geno_of(uint32_t const * records, uint32_t rec_words, uint32_t cons
   return g;
 }
 
+// the reverse orientation of a read that was aligned forward only: an empty result, nothing is fetched
+GTX_DEV Geno empty_orientation(Geno const & fwd)
+{
+  Geno g = fwd;
+  g.n_paths = 0;
+  g.longest = 0;
+  g.has_var = false;
+  return g;
+}
+
 GTX_DEV uint32_t const * path_at(uint32_t const * w, RecPath & p) // returns the position behind the path
 {
   p.start = w[0];
@@ -432,14 +442,16 @@ GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_
   {
     // update_unpaired_read_paths (alignment.cpp:365-455).  clipped_count() returns 0/1, so IS_CLIPPED is never set.
     gtx_rec_meta const & m = it.first;
-    Geno fwd = geno_of(records, rec_words, acc.big_records, m.align_index, 0), rev = geno_of(records, rec_words, acc.big_records, m.align_index, 1);
+    uint32_t const mflag = m.flag & 0x7FFFu; // (without GTX_FLAG_FORWARD_ONLY)
+    Geno fwd = geno_of(records, rec_words, acc.big_records, m.align_index, 0);
+    Geno rev = (m.flag & GTX_FLAG_FORWARD_ONLY) ? empty_orientation(fwd) : geno_of(records, rec_words, acc.big_records, m.align_index, 1);
     if (!fwd.has_var && !rev.has_var)
       return true; // whichever orientation wins, it touches no variant site: nothing to add
     int const which = compare_single(fwd, rev);
     if (which == 0)
       return true;
     Geno & ge = which == 1 ? fwd : rev;
-    ge.flags = (which == 1 ? m.flag : (m.flag ^ F_SEQ_REVERSED)) & ~static_cast<uint32_t>(F_PROPER_PAIR) & 0xFFFFu;
+    ge.flags = (which == 1 ? mflag : (mflag ^ F_SEQ_REVERSED)) & ~static_cast<uint32_t>(F_PROPER_PAIR) & 0xFFFFu;
     ge.mapq = m.mapq;
     if (m.mapq < 25)
       ge.flags |= F_MAPQ_BAD;
@@ -464,12 +476,13 @@ GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_
     gtx_rec_meta const & m = *ms[r];
     Geno & f = q[2 * r];
     Geno & v = q[2 * r + 1];
+    uint32_t const mflag = m.flag & 0x7FFFu; // (without GTX_FLAG_FORWARD_ONLY)
     f = geno_of(records, rec_words, acc.big_records, m.align_index, 0);
-    v = geno_of(records, rec_words, acc.big_records, m.align_index, 1);
-    f.flags = (m.flag & ~static_cast<uint32_t>(F_PROPER_PAIR)) & 0xFFFFu;
+    v = (m.flag & GTX_FLAG_FORWARD_ONLY) ? empty_orientation(f) : geno_of(records, rec_words, acc.big_records, m.align_index, 1);
+    f.flags = (mflag & ~static_cast<uint32_t>(F_PROPER_PAIR)) & 0xFFFFu;
     if (m.mapq < 25)
       f.flags |= F_MAPQ_BAD;
-    v.flags = ((m.flag ^ F_SEQ_REVERSED) & ~static_cast<uint32_t>(F_PROPER_PAIR)) & 0xFFFFu;
+    v.flags = ((mflag ^ F_SEQ_REVERSED) & ~static_cast<uint32_t>(F_PROPER_PAIR)) & 0xFFFFu;
     f.mapq = v.mapq = m.mapq;
     f.score_diff = v.score_diff = m.score_diff;
     f.proper_pair = v.proper_pair = true; // ml_insert_size = |isize|, never INSERT_SIZE_WHEN_NOT_PROPER_PAIR for int32 isize

@@ -55,6 +55,7 @@ REC_META = np.dtype([("align_index", np.uint32), ("flag", np.uint16), ("mapq", n
                      ("pos", np.int32), ("isize", np.int32)], align=True)
 SCORE_ITEM = np.dtype([("first", REC_META), ("second", REC_META), ("sample", np.uint32), ("kind", np.uint32)], align=True)
 ITEM_LEFTOVER = 1
+FLAG_FORWARD_ONLY = 0x8000
 SAMPLE_CALL = np.dtype([("gt_first", np.uint16), ("gt_second", np.uint16), ("ref_total_depth", np.uint16),
                         ("alt_total_depth", np.uint16), ("gq", np.uint8), ("ambiguous_depth", np.uint8),
                         ("alt_proper_pair_depth", np.uint8), ("reserved", np.uint8)], align=True)

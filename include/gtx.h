@@ -153,6 +153,11 @@ typedef struct gtx_read_meta
   int32_t isize;
 } gtx_read_meta;
 
+/* gtx_rec_meta::flag, besides the SAM bits: the reverse orientation of the read this record uses was not aligned
+ * (align_read aligns forward only for unpaired reads and concordant pairs, alignment.cpp:341-352), its record is empty
+ * by construction and the scorer does not fetch it.  Set by gtx_stream_push; optional for hand-made items. */
+#define GTX_FLAG_FORWARD_ONLY 0x8000u
+
 /* Per record fields consumed by update_unpaired_read_paths / update_paths (src/typer/alignment.cpp:365-545) */
 typedef struct gtx_rec_meta
 {
