@@ -38,6 +38,7 @@ struct AlignCfg
 };
 
 #include "align_core.inl"
+#include "express4.inl"
 
 // second pass: the same code over large tables that live in HBM (one workspace per workgroup)
 namespace big

@@ -118,7 +118,7 @@ static __device__ inline unsigned long long wave_claim64(unsigned long long * co
 }
 
 #ifndef GTX_TASK_CHUNK
-#define GTX_TASK_CHUNK 16
+#define GTX_TASK_CHUNK 64
 #endif
 constexpr uint32_t TASK_CHUNK = GTX_TASK_CHUNK; // reads a wave claims per visit to the task counter
 
@@ -213,6 +213,73 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void gt
   if (threadIdx.x < 16)
     atomicAdd(g.prof + threadIdx.x, ws.prof_acc[threadIdx.x]);
 #endif
+}
+
+// Pass 1, four reads per wavefront (express4.inl): the default.  Group gi of 16 lanes takes read `first + gi` of the
+// chunk; the forward task of a read is finished here or queued, a reverse-orientation task (discordant pairs,
+// force_align_both_orientations) always goes to pass 2.
+__global__ __launch_bounds__(64) void gtx_align_express4_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
+                                                                uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
+                                                                uint32_t n_reads, uint32_t * __restrict__ records,
+                                                                uint32_t rec_words, uint32_t force_both, uint32_t * task_counter,
+                                                                uint32_t * __restrict__ queue, uint32_t * queue_count,
+                                                                uint32_t queue_all)
+{
+  __shared__ Express4Workspace ws;
+  __shared__ uint32_t pending[2 * TASK_CHUNK];
+  uint32_t const lane = threadIdx.x & 63u;
+  for (;;)
+  {
+    uint32_t const base = wave_claim(task_counter, TASK_CHUNK);
+    if (base >= n_reads)
+      break;
+    uint32_t const end = base + TASK_CHUNK < n_reads ? base + TASK_CHUNK : n_reads;
+    uint32_t n_pending = 0;
+    for (uint32_t first = base; first < end; first += 4)
+    {
+      uint32_t const n_valid = end - first < 4 ? end - first : 4;
+      // reverse orientations: queued when align_read asks for them, else an empty record
+      uint32_t const gi = lane >> 4;
+      bool rev = false;
+      if (gi < n_valid)
+      {
+        gtx_read_meta const m = meta[first + gi];
+        uint32_t const len = m.l_qseq;
+        rev = needs_reverse(m, force_both != 0) && len >= 2 * K - 1 && len <= AlignCfg::MAX_READ;
+        if (!rev && (lane & 15u) == 0)
+        {
+          uint32_t * rec = records + (static_cast<uint64_t>(first + gi) * 2 + 1) * rec_words;
+          rec[0] = len > AlignCfg::MAX_READ ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
+          rec[1] = len << 16;
+        }
+      }
+      unsigned long long const REV = __ballot(rev);
+      uint32_t const fwd_mask = express4<WaveHip>(g, ix, ws, seq, seq_stride, meta, first, n_valid, records, rec_words, queue_all != 0);
+      for (uint32_t k = 0; k < n_valid; ++k)
+      {
+        if ((fwd_mask >> k) & 1u)
+        {
+          if (lane == 0)
+            pending[n_pending] = (first + k) * 2;
+          ++n_pending;
+        }
+        if ((REV >> (16 * k)) & 1ull)
+        {
+          if (lane == 0)
+            pending[n_pending] = (first + k) * 2 + 1;
+          ++n_pending;
+        }
+      }
+    }
+    if (n_pending)
+    {
+      WaveHip::lds_sync();
+      uint32_t const at = wave_claim(queue_count, n_pending); // (the queue has room for every task)
+      for (uint32_t k = lane; k < n_pending; k += 64)
+        queue[at + k] = pending[k];
+      WaveHip::lds_sync();
+    }
+  }
 }
 
 // Pass 2 (general): the queued tasks through the full algorithm over LDS tables.  A task that exceeds them goes on to
@@ -529,6 +596,8 @@ int ctx_upload(gtx_ctx & c, int device)
     c.align_blocks_per_cu = per_cu;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express_kernel, 64, 0) == hipSuccess && per_cu > 0)
     c.express_blocks_per_cu = per_cu;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express4_kernel, 64, 0) == hipSuccess && per_cu > 0)
+    c.express4_blocks_per_cu = per_cu;
   return GTX_OK;
 }
 
@@ -621,10 +690,20 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
   bool const timed = c->pass_events[0] != nullptr;
   if (timed)
     (void)hipEventRecord(static_cast<hipEvent_t>(c->pass_events[0]), static_cast<hipStream_t>(stream));
-  hipLaunchKernelGGL(gtx_align_express_kernel, dim3(blocks1), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph, c->dev_index,
-                     d_seq, seq_stride, d_meta, n_reads, d_records, rec_words,
-                     static_cast<uint32_t>(c->params.force_align_both_orientations != 0), counters, c->d_queue, counters + 2,
-                     static_cast<uint32_t>(force != 0));
+  char const * e4 = std::getenv("GTX_EXPRESS4"); // A/B switch: 0 = one read per wavefront in pass 1
+  if (!(e4 && e4[0] == '0'))
+  {
+    uint32_t const blocks4 = static_cast<uint32_t>(std::min<uint64_t>(chunks, static_cast<uint64_t>(n_cu) * c->express4_blocks_per_cu));
+    hipLaunchKernelGGL(gtx_align_express4_kernel, dim3(blocks4), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph,
+                       c->dev_index, d_seq, seq_stride, d_meta, n_reads, d_records, rec_words,
+                       static_cast<uint32_t>(c->params.force_align_both_orientations != 0), counters, c->d_queue, counters + 2,
+                       static_cast<uint32_t>(force != 0));
+  }
+  else
+    hipLaunchKernelGGL(gtx_align_express_kernel, dim3(blocks1), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph,
+                       c->dev_index, d_seq, seq_stride, d_meta, n_reads, d_records, rec_words,
+                       static_cast<uint32_t>(c->params.force_align_both_orientations != 0), counters, c->d_queue, counters + 2,
+                       static_cast<uint32_t>(force != 0));
   if (!hip_ok(hipGetLastError(), "gtx_align_express_kernel launch"))
     return GTX_ERR_HIP;
   if (timed)

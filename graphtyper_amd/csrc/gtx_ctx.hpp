@@ -20,7 +20,7 @@ struct gtx_ctx
   static constexpr unsigned N_TASK_COUNTERS = 64; // one per launch in flight (launches may overlap on different streams)
   uint32_t * d_task_counters = nullptr;
   std::atomic<unsigned> launch_seq{0};
-  int align_blocks_per_cu = 8, express_blocks_per_cu = 16;
+  int align_blocks_per_cu = 8, express_blocks_per_cu = 16, express4_blocks_per_cu = 8;
   uint32_t * d_queue = nullptr; // tasks pass 1 hands to pass 2 (grow-only)
   uint64_t queue_cap = 0;
   void * pass_events[4] = {nullptr, nullptr, nullptr, nullptr}; // hipEvent_t around the three passes (gtx_ctx_pass_times)

@@ -129,30 +129,22 @@ extern "C"
       e.arena.assign(e.params.big_record_words ? e.params.big_record_words : (1u << 20), 0xABABABABu);
     e.second_pass_tasks = 0;
     bool const force_both = e.params.force_align_both_orientations != 0;
-    for (uint32_t t = 0; t < 2 * n_reads; ++t)
+    char const * e4 = std::getenv("GTX_EXPRESS4"); // 0: one read per wavefront in pass 1
+    bool const four = !(e4 && e4[0] == '0');
+    auto e4_ws = std::make_unique<Express4Workspace>();
+    // passes 2 and 3 for one task
+    auto general = [&](uint32_t t)
     {
       uint32_t const read = t >> 1, orient = t & 1u;
-      gtx_read_meta const m = meta[read];
       uint32_t * rec = records + static_cast<uint64_t>(t) * rec_words;
-      uint32_t const len = m.l_qseq;
-      bool const skip = len < 2 * K - 1 || len > AlignCfg::MAX_READ || (orient == 1 && !needs_reverse(m, force_both));
-      if (skip)
-      {
-        rec[0] = len > AlignCfg::MAX_READ ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
-        rec[1] = len << 16;
-        continue;
-      }
-      // pass 1 (gtx_align_express_kernel)
-      std::memset(static_cast<void *>(seed_ws.get()), fill, sizeof(SeedWorkspace)); // LDS is not zeroed between reads
-      if (!force && express_one<WaveEmu>(g, ix, *seed_ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words))
-        continue;
+      uint32_t const len = meta[read].l_qseq;
       // pass 2 (gtx_align_kernel)
       ++e.general_tasks;
       std::memset(static_cast<void *>(ws.get()), fill, sizeof(AlignWorkspace));
       uint32_t const st = align_one<WaveEmu>(g, ix, *ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words,
                                              /*try_fast=*/false);
       if (!second_pass || !(st || force_big))
-        continue;
+        return;
       // second pass (gtx_align_big_kernel)
       ++e.second_pass_tasks;
       std::memset(static_cast<void *>(big_ws.get()), fill, sizeof(big::AlignWorkspace));
@@ -186,6 +178,52 @@ extern "C"
       rec[1] = (np == 0 ? 0 : longest) | (len << 16) | has_var;
       if (ext)
         rec[2] = static_cast<uint32_t>(off);
+    };
+    auto empty_record = [&](uint32_t t, uint32_t len)
+    {
+      uint32_t * rec = records + static_cast<uint64_t>(t) * rec_words;
+      rec[0] = len > AlignCfg::MAX_READ ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
+      rec[1] = len << 16;
+    };
+    if (four)
+    {
+      // pass 1, four reads per wavefront (gtx_align_express4_kernel)
+      for (uint32_t first = 0; first < n_reads; first += 4)
+      {
+        uint32_t const n_valid = n_reads - first < 4 ? n_reads - first : 4;
+        std::memset(static_cast<void *>(e4_ws.get()), fill, sizeof(Express4Workspace));
+        uint32_t const mask = express4<WaveEmu>(g, ix, *e4_ws, seq, seq_stride, meta, first, n_valid, records, rec_words, force != 0);
+        for (uint32_t k = 0; k < n_valid; ++k)
+        {
+          uint32_t const read = first + k, len = meta[read].l_qseq;
+          if ((mask >> k) & 1u)
+            general(read * 2);
+          bool const rev = needs_reverse(meta[read], force_both) && len >= 2 * K - 1 && len <= AlignCfg::MAX_READ;
+          if (rev)
+            general(read * 2 + 1);
+          else
+            empty_record(read * 2 + 1, len);
+        }
+      }
+      return 0;
+    }
+    for (uint32_t t = 0; t < 2 * n_reads; ++t)
+    {
+      uint32_t const read = t >> 1, orient = t & 1u;
+      gtx_read_meta const m = meta[read];
+      uint32_t * rec = records + static_cast<uint64_t>(t) * rec_words;
+      uint32_t const len = m.l_qseq;
+      bool const skip = len < 2 * K - 1 || len > AlignCfg::MAX_READ || (orient == 1 && !needs_reverse(m, force_both));
+      if (skip)
+      {
+        empty_record(t, len);
+        continue;
+      }
+      // pass 1 (gtx_align_express_kernel)
+      std::memset(static_cast<void *>(seed_ws.get()), fill, sizeof(SeedWorkspace)); // LDS is not zeroed between reads
+      if (!force && express_one<WaveEmu>(g, ix, *seed_ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words))
+        continue;
+      general(t);
     }
     return 0;
   }
