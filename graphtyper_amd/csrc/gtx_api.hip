@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void gt
 // Pass 1, four reads per wavefront (express4.inl): the default.  Group gi of 16 lanes takes read `first + gi` of the
 // chunk; the forward task of a read is finished here or queued, a reverse-orientation task (discordant pairs,
 // force_align_both_orientations) always goes to pass 2.
-__global__ __launch_bounds__(64) void gtx_align_express4_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void gtx_align_express4_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
                                                                 uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
                                                                 uint32_t n_reads, uint32_t * __restrict__ records,
                                                                 uint32_t rec_words, uint32_t force_both, uint32_t * task_counter,

@@ -299,3 +299,27 @@ def edge_case(Backend):
 
 def test_edge_cases():
     edge_case(harness.EmuBackend)
+
+
+def express_variants_case(Backend, monkeypatch, n_reads):
+    """pass 1 exists in two forms -- four reads per wavefront (default) and one read per wavefront (GTX_EXPRESS4=0);
+    they must write the same record words for ragged reads, paired flags that ask for the reverse orientation, N bases"""
+    for kind, aav in (("snp100", False), ("cluster", True)):
+        ref, recs, codes, pos = scenarios.synthetic_case(kind, n_ref=100000, n_reads=n_reads, region_begin=1000, err=0.02,
+                                                         n_rate=0.004, seed=3)
+        b = Backend(gtx.graph_from_records(ref, recs, region_begin=1000, add_all_variants=aav))
+        rng = np.random.default_rng(1)
+        reads = [c[:int(L)] for c, L in zip(codes, rng.integers(50, 151, size=len(codes)))]
+        seq, lens = harness.pack_ragged(reads)
+        flags = rng.choice([0, 1 | 64, 1 | 2 | 32 | 64], size=len(reads)).astype(np.uint16)
+        meta = harness.read_meta(lens, flags=flags, isize=rng.integers(-2000, 2000, size=len(reads)))
+        monkeypatch.setenv("GTX_EXPRESS4", "0")
+        one = b.align(seq, meta).copy()
+        monkeypatch.setenv("GTX_EXPRESS4", "1")
+        four = b.align(seq, meta).copy()
+        assert np.array_equal(one, four)
+        assert ((four.reshape(-1, harness.REC_WORDS)[:, 0] & 0xFFFF) > 0).sum() > n_reads // 2
+
+
+def test_express_variants_agree(monkeypatch):
+    express_variants_case(harness.EmuBackend, monkeypatch, 8000)

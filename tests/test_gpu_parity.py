@@ -10,7 +10,7 @@ import harness
 import scenarios
 from graphtyper_amd import lib as gtx
 from oracle_lib import Oracle, encode
-from test_emu_parity import check_align, edge_case, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case
+from test_emu_parity import check_align, edge_case, express_variants_case, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case
 
 pytestmark = pytest.mark.gpu
 
@@ -113,3 +113,7 @@ def test_align_iupac_codes():
 
 def test_edge_cases():
     edge_case(harness.GpuBackend)
+
+
+def test_express_variants_agree(monkeypatch):
+    express_variants_case(harness.GpuBackend, monkeypatch, 40000)
