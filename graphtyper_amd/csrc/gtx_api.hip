@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void gt
 
 // Pass 2 (general): the queued tasks through the full algorithm over LDS tables.  A task that exceeds them goes on to
 // pass 3 (gtx_align_big_kernel).
-__global__ __launch_bounds__(64) void gtx_align_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void gtx_align_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
                                                        uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
                                                        uint32_t * __restrict__ records, uint32_t rec_words,
                                                        uint32_t const * __restrict__ queue, uint32_t const * queue_count,
@@ -395,26 +395,50 @@ __global__ __launch_bounds__(64) void gtx_align_big_kernel(GraphView g, IndexVie
   }
 }
 
-__global__ __launch_bounds__(256) void gtx_score_kernel(GraphView g, ScoreParams par, gtx_score_item const * __restrict__ items,
-                                                        uint32_t n_items, uint32_t const * __restrict__ records,
-                                                        uint32_t rec_words, ScoreAcc acc, uint32_t * error_flag,
-                                                        uint32_t * __restrict__ big_queue, uint32_t big_queue_cap,
-                                                        uint32_t * big_state)
+// Scoring, stage 1 (triage): one thread per item reads the record header(s) and decides whether the item can add
+// anything; 85 % of the cfg2 items cannot and end here.  No per-thread tables, so this kernel runs at full occupancy.
+// The others are appended to a work queue, one atomic per wavefront.
+__global__ __launch_bounds__(256) void gtx_score_triage_kernel(gtx_score_item const * __restrict__ items, uint32_t n_items,
+                                                               uint32_t const * __restrict__ records, uint32_t rec_words,
+                                                               uint32_t * __restrict__ work_queue, uint32_t * work_count)
 {
   uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_items)
+  bool const work = i < n_items && !item_is_trivial(items[i], records, rec_words);
+  unsigned long long const mask = __ballot(work);
+  if (mask == 0)
     return;
-  gtx_score_item const it = items[i];
-  RecentHap r1[SCORE_MAX_HAPS], r2[SCORE_MAX_HAPS];
-  if (score_item<WaveHip>(g, par, it, records, rec_words, acc, r1, r2, SCORE_MAX_HAPS))
-    return;
-  // a read of this item touches more variant sites than the tables above hold (long results of the alignment's second
-  // pass): nothing was added yet, queue the item for gtx_score_big_kernel
-  uint32_t const slot = big_queue ? atomicAdd(big_state, 1u) : big_queue_cap;
-  if (slot < big_queue_cap)
-    big_queue[slot] = i;
-  else
-    atomicAdd(error_flag, 1u);
+  uint32_t const lane = threadIdx.x & 63u;
+  uint32_t base = 0;
+  if (lane == static_cast<uint32_t>(__builtin_ctzll(mask)))
+    base = atomicAdd(work_count, static_cast<uint32_t>(__builtin_popcountll(mask)));
+  base = __shfl(base, __builtin_ctzll(mask));
+  if (work)
+    work_queue[base + static_cast<uint32_t>(__builtin_popcountll(mask & ((1ull << lane) - 1ull)))] = i;
+}
+
+// Scoring, stage 2: the items of the work queue, one thread each (orientation / pair selection, path checks, atomics).
+__global__ __launch_bounds__(256) void gtx_score_kernel(GraphView g, ScoreParams par, gtx_score_item const * __restrict__ items,
+                                                        uint32_t const * __restrict__ work_queue, uint32_t const * work_count,
+                                                        uint32_t const * __restrict__ records, uint32_t rec_words, ScoreAcc acc,
+                                                        uint32_t * error_flag, uint32_t * __restrict__ big_queue,
+                                                        uint32_t big_queue_cap, uint32_t * big_state)
+{
+  uint32_t const n_work = work_count[0];
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_work; w += gridDim.x * blockDim.x)
+  {
+    uint32_t const i = work_queue[w];
+    gtx_score_item const it = items[i];
+    RecentHap r1[SCORE_MAX_HAPS], r2[SCORE_MAX_HAPS];
+    if (score_item<WaveHip>(g, par, it, records, rec_words, acc, r1, r2, SCORE_MAX_HAPS))
+      continue;
+    // a read of this item touches more variant sites than the tables above hold (long results of the alignment's last
+    // pass): nothing was added yet, queue the item for gtx_score_big_kernel
+    uint32_t const slot = big_queue ? atomicAdd(big_state, 1u) : big_queue_cap;
+    if (slot < big_queue_cap)
+      big_queue[slot] = i;
+    else
+      atomicAdd(error_flag, 1u);
+  }
 }
 
 // Second scoring pass: the queued items over per-thread tables in HBM.
@@ -611,6 +635,9 @@ void ctx_release_device(gtx_ctx & c)
   if (c.d_queue)
     (void)hipFree(c.d_queue);
   c.d_queue = nullptr;
+  if (c.d_score_work)
+    (void)hipFree(c.d_score_work);
+  c.d_score_work = nullptr;
   for (auto & e : c.pass_events)
     if (e)
     {
@@ -795,9 +822,29 @@ extern "C" int gtx_score_batch(gtx_ctx * c, const gtx_score_item * d_items, uint
   if (second_pass &&
       !hip_ok(hipMemsetAsync(c->d_score_state, 0, 2 * sizeof(uint32_t), static_cast<hipStream_t>(stream)), "second-pass state reset"))
     return GTX_ERR_HIP;
-  hipLaunchKernelGGL(gtx_score_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), c->dev_graph, par, d_items,
-                     n_items, d_records, rec_words, a, c->d_error_flag, second_pass ? c->d_score_queue : nullptr,
-                     second_pass ? gtx_ctx::SCORE_QUEUE_CAP : 0u, c->d_score_state);
+  // work queue of stage 2: room for every item
+  if (n_items > c->score_work_cap)
+  {
+    if (c->d_score_work && !hip_ok(hipFree(c->d_score_work), "score work queue")) // (synchronises with earlier launches)
+      return GTX_ERR_HIP;
+    c->d_score_work = nullptr;
+    c->score_work_cap = 0;
+    void * p = nullptr;
+    if (!hip_ok(hipMalloc(&p, (static_cast<size_t>(n_items) + 1) * sizeof(uint32_t)), "score work queue"))
+      return GTX_ERR_HIP;
+    c->d_score_work = static_cast<uint32_t *>(p); // [0] = count, [1..] = item indices
+    c->score_work_cap = n_items;
+  }
+  if (!hip_ok(hipMemsetAsync(c->d_score_work, 0, sizeof(uint32_t), static_cast<hipStream_t>(stream)), "score work queue reset"))
+    return GTX_ERR_HIP;
+  hipLaunchKernelGGL(gtx_score_triage_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_items, n_items, d_records,
+                     rec_words, c->d_score_work + 1, c->d_score_work);
+  if (!hip_ok(hipGetLastError(), "gtx_score_triage_kernel launch"))
+    return GTX_ERR_HIP;
+  uint32_t const work_blocks = std::min<uint32_t>(blocks, static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256) * 8u);
+  hipLaunchKernelGGL(gtx_score_kernel, dim3(work_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), c->dev_graph, par, d_items,
+                     c->d_score_work + 1, c->d_score_work, d_records, rec_words, a, c->d_error_flag,
+                     second_pass ? c->d_score_queue : nullptr, second_pass ? gtx_ctx::SCORE_QUEUE_CAP : 0u, c->d_score_state);
   if (!hip_ok(hipGetLastError(), "gtx_score_kernel launch"))
     return GTX_ERR_HIP;
   if (second_pass)

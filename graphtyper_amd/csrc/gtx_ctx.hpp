@@ -37,6 +37,8 @@ struct gtx_ctx
   uint32_t * d_score_state = nullptr; // [0] items queued
   uint32_t * d_score_queue = nullptr;
   void * d_score_tables = nullptr;
+  uint32_t * d_score_work = nullptr; // [0] number of items the triage kernel found worth scoring, [1..] their indices (grow-only)
+  uint32_t score_work_cap = 0;
 };
 
 namespace gtx

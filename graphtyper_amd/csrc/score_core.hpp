@@ -432,6 +432,26 @@ GTX_DEV void apply_recent(GraphView const & g, ScoreAcc const & acc, Geno const 
 }
 
 // one call of genotype_only() that reaches the writer (hts_parallel_reader.cpp:283-337)
+// Triage: true when no orientation of the item's read(s) carries a variant site -- whatever the orientation / pair
+// selection decides, nothing can be added to the accumulators (the same early exits are inside score_item).  Costs one
+// record header per read whose reverse orientation was not aligned.
+GTX_DEV bool item_is_trivial(gtx_score_item const & it, uint32_t const * records, uint32_t rec_words)
+{
+  gtx_rec_meta const * ms[2] = {&it.first, &it.second};
+  for (int r = 0; r < 2; ++r)
+  {
+    gtx_rec_meta const & m = *ms[r];
+    if (r == 1 && m.align_index == INVALID)
+      break;
+    uint32_t const * rec = records + static_cast<uint64_t>(m.align_index) * 2 * rec_words;
+    if (rec[1] & GTX_REC_HAS_VARIANTS)
+      return false;
+    if (!(m.flag & GTX_FLAG_FORWARD_ONLY) && (rec[rec_words + 1] & GTX_REC_HAS_VARIANTS))
+      return false;
+  }
+  return true;
+}
+
 // r1 / r2: tables of `cap` entries each.  Returns false, with nothing added to the accumulators, when a read of the item
 // touches more than `cap` variant sites (the caller then redoes the item with larger tables).
 template <class W>

@@ -290,7 +290,9 @@ extern "C"
     uint32_t errors = 0;
     std::vector<RecentHap> small(2 * SCORE_MAX_HAPS), large(2 * SCORE_MAX_HAPS_BIG);
     for (uint32_t i = 0; i < n_items; ++i)
-      if (!score_item<WaveEmu>(g, par, items[i], records, rec_words, a, small.data(), small.data() + SCORE_MAX_HAPS, SCORE_MAX_HAPS))
+      if (item_is_trivial(items[i], records, rec_words)) // stage 1 (gtx_score_triage_kernel)
+        continue;
+      else if (!score_item<WaveEmu>(g, par, items[i], records, rec_words, a, small.data(), small.data() + SCORE_MAX_HAPS, SCORE_MAX_HAPS))
       {
         // second scoring pass (gtx_score_big_kernel)
         if (e.params.no_second_pass ||
