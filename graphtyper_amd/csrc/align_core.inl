@@ -1025,7 +1025,29 @@ GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, ui
     // sequence without ever reaching a variant site (graph.cpp:1232-1243 / 1484-1496), so the result is one id-less
     // label or nothing -- computed here without going through the location / candidate tables.
     bool shortcut = false;
-    if (!g_is_special(g, anchor) && anchor >= g.first_order && g.n_ref > 1)
+    if (!starts && g.pos_info && !g_is_special(g, anchor) && anchor >= g.first_order && g.n_ref > 1 && anchor - g.first_order < g.n_pos_info &&
+        sr.len <= 255)
+    {
+      // the same shortcut through the position table: one lookup instead of bucket -> node order -> node tables
+      uint32_t const w = GTX_U(g.pos_info[anchor - g.first_order]);
+      if (w != INVALID && (w & 255u) >= sr.len)
+      {
+        shortcut = true;
+        uint8_t const * dna = reinterpret_cast<uint8_t const *>(g.dna) + (w >> 8);
+        uint32_t const budget = mm;
+        uint32_t const got = cmp_codes<W, false>(sr, 0, dna, w & 255u, 0, budget);
+        if (got <= budget)
+        {
+          mm = got;
+          nl = 1;
+          GTX_LEAD wb.dfs_out[0] = DevLabel{anchor, anchor + (sr.len - 1), INVALID, 0};
+          W::lds_sync();
+        }
+        else
+          nl = 0;
+      }
+    }
+    if (!shortcut && !g_is_special(g, anchor) && anchor >= g.first_order && g.n_ref > 1)
     {
       uint32_t const rr = g_ref_node_at<W>(g, anchor);
       uint32_t const ro = GTX_U(g.ref_order[rr]), rl = GTX_U(g.ref_len[rr]);
