@@ -235,7 +235,7 @@ def main():
                    "ctx_create_s": round(t_ctx, 3), "reads_aligned": n_aligned, "reads_overflowed": n_overflow, "nonref_genotype_calls": n_nonref_calls,
                    "score_items_refused": errors, "parallelism": "reads sharded over %d GPU(s), graph+index replicated" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": "gtx_align_express_kernel", "kernel_ms": express_ms,
+                     "traffic": traffic, "kernel": "gtx_align_express4_kernel", "kernel_ms": express_ms,
                      "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,
                      "align_passes_ms": {"express": pass_ms[0], "general": pass_ms[1], "hbm_tables": pass_ms[2],
                                          "all_three_avg": align_avg_ms, "tasks_handed_to_general": n_pass2, "tasks_completed_by_express": n_express}},

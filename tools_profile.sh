@@ -35,10 +35,10 @@ json.dump(summary, open(out + "/pmc_summary.json", "w"), indent=1, sort_keys=Tru
 ks = sorted(glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True))
 if ks:
     shutil.copy(ks[0], out + "/kernel_stats.csv")
-al = summary.get("gtx::gtx_align_express_kernel", {})
+al = summary.get("gtx::gtx_align_express4_kernel", {})
 if "FETCH_SIZE" in al and "WRITE_SIZE" in al:
     b = (al["FETCH_SIZE"] + al["WRITE_SIZE"]) * 1024
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools_profile.sh), one gtx_align_express_kernel launch over $READS reads (cfg2); bytes = (FETCH_SIZE + WRITE_SIZE) * 1024; FETCH_SIZE is reported raw -- the x2 gfx950 correction of the guide is calibrated for 16 B/lane coalesced streams, not for this kernel's narrow scattered loads",
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools_profile.sh), one gtx_align_express4_kernel launch over $READS reads (cfg2); bytes = (FETCH_SIZE + WRITE_SIZE) * 1024; FETCH_SIZE is reported raw -- the x2 gfx950 correction of the guide is calibrated for 16 B/lane coalesced streams, not for this kernel's narrow scattered loads",
                "reads_per_launch": $READS, "fetch_size_kb": al["FETCH_SIZE"], "write_size_kb": al["WRITE_SIZE"],
                "align_kernel_hbm_bytes_per_launch": b, "bytes_per_read": b / $READS}, open(out + "/pmc_traffic.json", "w"), indent=1)
 for f in sorted(glob.glob(out + "/**/*kernel_stats.csv", recursive=True)):
