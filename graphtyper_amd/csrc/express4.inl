@@ -8,11 +8,14 @@
 //
 // A group either writes the read's record (same words express_one writes) or reports that the task needs pass 2;
 // it never writes a partial result.  What it declines: reads over 187 bp (more than KC k-mers), k-mers with several
-// ambiguous bases, every case seed_stage's fast seeding declines, tails that leave the reference node.
+// ambiguous bases, every case seed_stage's fast seeding declines (except a single k-mer without any label, which it
+// handles: see the run selection below), walks that leave the reference node.
 
 struct Express4Tail // handed from a group's leader lane to its 16 lanes
 {
-  uint32_t dna_off, tail_len, pre, ok;
+  uint32_t dna_off, tail_len, pre; // walk at the read's end: arena offset of the path's last base, characters, read offset
+  uint32_t head_off, head_len, prs; // walk at the read's start (backwards from the path's first base)
+  uint32_t ok;
 };
 
 struct Express4Workspace
@@ -232,20 +235,23 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
     }
   }
 
-  // ---- fast seeding, lane j < n_k of a group = k-mer j (the rules and their justification: seed_stage)
-  PB bad_l, var_l, mm_l;
+  // ---- fast seeding, lane j < n_k of a group = k-mer j (the rules and their justification: seed_stage).
+  //      One k-mer of the read may have no label at all (two or more errors, an error next to an N): a "hole".
+  PB bad_l, var_l, mm_l, hole_l;
   W::lanes([&](uint32_t l) {
     uint32_t const gi = l >> 4, j = l & 15u;
     SeedWorkspace & s = ws.s[gi];
-    bool bad = false, has_var = false, mm = false;
+    bool bad = false, has_var = false, mm = false, hole = false;
     if (alive_l[l] && j < nk_l[l])
     {
       uint32_t const c0 = s.cnt0[j];
       if (s.nkeys0[j] != 1)
       {
-        uint32_t const a0 = s.acnt[j][0], a1 = s.acnt[j][1], a2 = s.acnt[j][2], a3 = s.acnt[j][3];
-        bad = j >= 4 || a0 > 1 || a0 + a1 + a2 + a3 != 1;
-        if (!bad)
+        uint32_t const a0 = j < 4 ? s.acnt[j][0] : 0xFFFFFFFFu, a1 = j < 4 ? s.acnt[j][1] : 0u, a2 = j < 4 ? s.acnt[j][2] : 0u,
+                       a3 = j < 4 ? s.acnt[j][3] : 0u;
+        hole = a0 == 0 && a1 + a2 + a3 == 0;
+        bad = !hole && (a0 > 1 || a0 + a1 + a2 + a3 != 1);
+        if (!bad && !hole)
         {
           DevLabel const lb = s.xl[j][0];
           bad = lb.site != INVALID;
@@ -268,7 +274,9 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
               nb_off = he.off;
             }
           }
-        if (c0 + nb == 1)
+        if (c0 + nb == 0)
+          hole = true;
+        else if (c0 + nb == 1)
         {
           DevLabel const lb = c0 ? s.xl[j][0] : ix.labels[nb_off];
           mm = c0 == 0;
@@ -308,40 +316,90 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
     bad_l[l] = bad;
     var_l[l] = has_var;
     mm_l[l] = mm;
+    hole_l[l] = hole;
   });
-  uint64_t const BAD = W::ballot(bad_l), VAR = W::ballot(var_l), MM = W::ballot(mm_l);
+  uint64_t const BAD = W::ballot(bad_l), VAR = W::ballot(var_l), MM = W::ballot(mm_l), HOLE = W::ballot(hole_l);
   W::lds_sync();
+  // ---- the run of k-mers that makes the path: all of them, or -- with one hole -- the longer side of the hole.  (The
+  //      shorter side chains into a shorter path that remove_short_paths drops before the walks, genotype_paths.cpp:
+  //      824-834; equal sides would both survive: left to pass 2.  A hole and a variant together: left to pass 2.)
+  PU lo_l, hi_l; // first / last k-mer of the run
+  PB run_ok_l;
+  W::lanes([&](uint32_t l) {
+    uint32_t const sh = 16 * (l >> 4), n_k = nk_l[l];
+    uint32_t const bad = static_cast<uint32_t>(BAD >> sh) & 0xFFFFu, var = static_cast<uint32_t>(VAR >> sh) & 0xFFFFu,
+                   hole = static_cast<uint32_t>(HOLE >> sh) & 0xFFFFu;
+    bool ok = alive_l[l] && bad == 0 && (var & (var - 1u)) == 0;
+    uint32_t lo = 0, hi = n_k ? n_k - 1 : 0;
+    if (ok && hole != 0)
+    {
+      uint32_t const h = static_cast<uint32_t>(__builtin_ctz(hole));
+      uint32_t const left = h, right = n_k - 1 - h; // k-mers on either side
+      ok = (hole & (hole - 1u)) == 0 && var == 0 && left != right;
+      if (left > right)
+        hi = h - 1;
+      else
+        lo = h + 1;
+      // A run that starts (after the hole) with a multi-key k-mer starts with two parallel chains, the list and its
+      // +1-mismatch copy; the start walk then yields one label list per chain, the second list finds no chain left to
+      // merge with, becomes a path of its own and is walked to a duplicate of the result (the reference really returns
+      // the path twice): left to pass 2.
+      if (ok && lo > 0 && ws.s[l >> 4].nkeys0[lo] != 1)
+        ok = false;
+    }
+    run_ok_l[l] = ok;
+    lo_l[l] = lo;
+    hi_l[l] = hi;
+  });
   PB gap_l;
   W::lanes([&](uint32_t l) {
     uint32_t const gi = l >> 4, j = l & 15u;
-    gap_l[l] = alive_l[l] && j + 1 < nk_l[l] && ws.s[gi].fs_end[j] != ws.s[gi].fs_start[j + 1];
+    gap_l[l] = run_ok_l[l] && j >= lo_l[l] && j < hi_l[l] && ws.s[gi].fs_end[j] != ws.s[gi].fs_start[j + 1];
   });
   uint64_t const GAP = W::ballot(gap_l);
 
-  // ---- the single path and the geometry of its tail (leader lane of every group)
+  // ---- the single path and the geometry of the walks at its two ends (leader lane of every group).  Both walks are
+  //      the shortcut of walk_read: the missing part of the read has to lie in the reference node the path touches.
   PB seeded_l;
   PU mism_l;
   W::lanes([&](uint32_t l) {
     uint32_t const gi = l >> 4, sh = 16 * gi;
-    uint32_t const bad = static_cast<uint32_t>(BAD >> sh) & 0xFFFFu, var = static_cast<uint32_t>(VAR >> sh) & 0xFFFFu,
-                   gap = static_cast<uint32_t>(GAP >> sh) & 0xFFFFu, mm = static_cast<uint32_t>(MM >> sh) & 0xFFFFu;
-    bool const seeded = alive_l[l] && bad == 0 && gap == 0 && (var & (var - 1u)) == 0;
+    uint32_t const gap = static_cast<uint32_t>(GAP >> sh) & 0xFFFFu, mm = static_cast<uint32_t>(MM >> sh) & 0xFFFFu;
+    bool const seeded = run_ok_l[l] && gap == 0;
     seeded_l[l] = seeded;
-    mism_l[l] = static_cast<uint32_t>(__builtin_popcount(mm));
+    uint32_t const lo = lo_l[l], hi = hi_l[l];
+    uint32_t const run_mask = seeded ? ((2u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+    mism_l[l] = static_cast<uint32_t>(__builtin_popcount(mm & run_mask));
     if ((l & 15u) == 0)
     {
-      Express4Tail t{0, 0, 0, 0};
+      Express4Tail t{0, 0, 0, 0, 0, 0, 0};
       if (seeded)
       {
-        uint32_t const n_k = nk_l[l], L = len_l[l], pre = (K - 1) * n_k;
-        uint32_t const anchor = ws.s[gi].fs_end[n_k - 1];
+        uint32_t const L = len_l[l], prs = (K - 1) * lo, pre = (K - 1) * (hi + 1);
         t.pre = pre;
+        t.prs = prs;
         t.ok = 1;
-        if (pre != L - 1)
+        bool const table = g.pos_info && g.n_ref > 1;
+        if (prs != 0) // walk_read_starts: read bases 0..prs against the node, backwards from the path's start
         {
-          // finish_single_path: the rest of the read has to fit in the reference node the chain ends in
+          uint32_t const anchor = ws.s[gi].fs_start[lo];
           t.ok = 0;
-          if (g.pos_info && !g_is_special(g, anchor) && anchor >= g.first_order && g.n_ref > 1 && anchor - g.first_order < g.n_pos_info)
+          if (table && !g_is_special(g, anchor) && anchor >= g.first_order && anchor - g.first_order < g.n_pos_info)
+          {
+            uint32_t const w = g.pos_info[anchor - g.first_order];
+            if (w != INVALID && static_cast<uint32_t>(g.pos_back[anchor - g.first_order]) >= prs && prs + 1 <= 255)
+            {
+              t.ok = 1;
+              t.head_off = w >> 8;
+              t.head_len = prs + 1;
+            }
+          }
+        }
+        if (t.ok && pre != L - 1) // walk_read_ends (finish_single_path)
+        {
+          uint32_t const anchor = ws.s[gi].fs_end[hi];
+          t.ok = 0;
+          if (table && !g_is_special(g, anchor) && anchor >= g.first_order && anchor - g.first_order < g.n_pos_info)
           {
             uint32_t const w = g.pos_info[anchor - g.first_order];
             if (w != INVALID && (w & 255u) >= L - pre)
@@ -358,36 +416,52 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
   });
   W::lds_sync();
 
-  // ---- tail compare, 16 characters per group and round (count_mismatches, graph_utils.hpp:7-69)
-  PU got_l;
-  PB killed_l;
+  // ---- the two compares, 16 characters per group and round (count_mismatches[_backward], graph_utils.hpp:7-69)
+  PU got_l, hgot_l;
+  PB killed_l, hkilled_l;
   W::lanes([&](uint32_t l) {
     got_l[l] = 0;
+    hgot_l[l] = 0;
     killed_l[l] = false;
+    hkilled_l[l] = false;
   });
-  constexpr uint32_t TAIL_ROUNDS = 2; // tails are at most K - 1 = 31 characters + the overlap
-  for (uint32_t r = 0; r < TAIL_ROUNDS; ++r)
+  for (uint32_t r = 0; r < AlignCfg::MAX_READ / 16; ++r)
   {
-    PB k_l, x_l;
+    PB k_l, x_l, hk_l, hx_l, any_l;
     W::lanes([&](uint32_t l) {
       uint32_t const gi = l >> 4, i = 16 * r + (l & 15u);
       Express4Tail const t = ws.tail[gi];
-      bool k = false, x = false;
-      if (seeded_l[l] && t.ok && i < t.tail_len)
+      bool k = false, x = false, hk = false, hx = false;
+      bool const on = seeded_l[l] && t.ok;
+      if (on && i < t.tail_len)
       {
         uint8_t const gc = reinterpret_cast<uint8_t const *>(g.dna)[t.dna_off + i];
         uint8_t const rc = ws.s[gi].rd[t.pre + i];
         k = gc == DNA_KILL;
         x = gc != rc && rc != 15 && gc != 15;
       }
+      if (on && i < t.head_len)
+      {
+        uint8_t const gc = reinterpret_cast<uint8_t const *>(g.dna)[t.head_off - i];
+        uint8_t const rc = ws.s[gi].rd[t.prs - i];
+        hk = gc == DNA_KILL;
+        hx = gc != rc && rc != 15 && gc != 15;
+      }
       k_l[l] = k;
       x_l[l] = x;
+      hk_l[l] = hk;
+      hx_l[l] = hx;
+      any_l[l] = on && (16 * r < t.tail_len || 16 * r < t.head_len);
     });
-    uint64_t const KILL = W::ballot(k_l), X = W::ballot(x_l);
+    if (W::ballot(any_l) == 0)
+      break;
+    uint64_t const KILL = W::ballot(k_l), X = W::ballot(x_l), HKILL = W::ballot(hk_l), HX = W::ballot(hx_l);
     W::lanes([&](uint32_t l) {
       uint32_t const sh = 16 * (l >> 4);
       got_l[l] = got_l[l] + static_cast<uint32_t>(__builtin_popcount(static_cast<uint32_t>(X >> sh) & 0xFFFFu));
+      hgot_l[l] = hgot_l[l] + static_cast<uint32_t>(__builtin_popcount(static_cast<uint32_t>(HX >> sh) & 0xFFFFu));
       killed_l[l] = killed_l[l] || (static_cast<uint32_t>(KILL >> sh) & 0xFFFFu) != 0;
+      hkilled_l[l] = hkilled_l[l] || (static_cast<uint32_t>(HKILL >> sh) & 0xFFFFu) != 0;
     });
   }
 
@@ -403,8 +477,18 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
       if (!fail && (l & 15u) == 0)
       {
         SeedWorkspace const & s = ws.s[gi];
-        uint32_t const n_k = nk_l[l], L = len_l[l];
-        uint32_t end = s.fs_end[n_k - 1], re = (K - 1) * n_k, mism = mism_l[l], longest = (K - 1) * n_k + 1;
+        uint32_t const L = len_l[l], lo = lo_l[l], hi = hi_l[l];
+        uint32_t start = s.fs_start[lo], end = s.fs_end[hi], rs = t.prs, re = t.pre, mism = mism_l[l];
+        if (t.head_len)
+        {
+          uint32_t const budget = 2 + t.head_len / 11 < 7 ? 2 + t.head_len / 11 : 7; // genotype_paths.cpp:571-577
+          if (!hkilled_l[l] && hgot_l[l] <= budget)
+          {
+            start -= t.head_len - 1;
+            rs = 0;
+            mism += hgot_l[l];
+          }
+        }
         if (t.tail_len)
         {
           uint32_t const budget = 2 + t.tail_len / 11 < 7 ? 2 + t.tail_len / 11 : 7; // genotype_paths.cpp:505-511
@@ -413,9 +497,9 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
             end += t.tail_len - 1;
             re = L - 1;
             mism += got_l[l];
-            longest = L;
           }
         }
+        uint32_t longest = re - rs + 1;
         uint64_t const with_var = (VAR >> (16 * gi)) & 0xFFFFu;
         uint32_t np = 1;
         if (mism > 10) // remove_paths_with_too_many_mismatches on one path
@@ -428,9 +512,9 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
         rec[1] = longest | (L << 16) | ((np && with_var) ? GTX_REC_HAS_VARIANTS : 0u);
         if (np)
         {
-          rec[2] = s.fs_start[0];
+          rec[2] = start;
           rec[3] = end;
-          rec[4] = re << 16; // read_start_index 0
+          rec[4] = rs | (re << 16);
           rec[5] = mism | ((with_var ? 1u : 0u) << 16);
           if (with_var)
           {

@@ -524,7 +524,10 @@ int ctx_upload(gtx_ctx & c, int device)
   ok = ok && upload(c.dev_allocs, v.special_actual, h.special_actual.data(), h.special_actual.size(), "special_actual");
   ok = ok && upload(c.dev_allocs, v.pos_bucket, h.pos_bucket.data(), h.pos_bucket.size(), "pos_bucket");
   if (!h.pos_info.empty())
+  {
     ok = ok && upload(c.dev_allocs, v.pos_info, h.pos_info.data(), h.pos_info.size(), "pos_info");
+    ok = ok && upload(c.dev_allocs, v.pos_back, h.pos_back.data(), h.pos_back.size(), "pos_back");
+  }
   ok = ok && upload(c.dev_allocs, v.dna, h.codes.data(), h.codes.size(), "dna codes");
   ok = ok && upload(c.dev_allocs, v.tri_off, h.tri_off.data(), h.tri_off.size(), "tri_off");
   ok = ok && upload(c.dev_allocs, v.allele_off, h.allele_off.data(), h.allele_off.size(), "allele_off");

@@ -43,6 +43,7 @@ GraphView HostGraph::view() const
   v.special_actual = special_actual.data();
   v.pos_bucket = pos_bucket.data();
   v.pos_info = pos_info.empty() ? nullptr : pos_info.data();
+  v.pos_back = pos_back.empty() ? nullptr : pos_back.data();
   v.n_pos_info = static_cast<uint32_t>(pos_info.size());
   v.dna = codes.data();
   v.tri_off = tri_off.data();
@@ -184,14 +185,17 @@ std::string flatten_graph(gtx_graph_view const & g, gtx_params const & par, Host
   }
   // position -> where its base is and how far its reference node goes on (the tail compare of the simple reads)
   out.pos_info.clear();
+  out.pos_back.clear();
   if (out.codes.size() < (1u << 24))
   {
     out.pos_info.assign(last - first, INVALID);
+    out.pos_back.assign(last - first, 0);
     for (uint32_t r = 0; r < R; ++r)
       for (uint32_t d = 0; d < out.ref_len[r]; ++d)
       {
         uint32_t const room = out.ref_len[r] - d;
         out.pos_info[out.ref_order[r] - first + d] = ((out.ref_dna[r] + d) << 8) | (room < 255 ? room : 255);
+        out.pos_back[out.ref_order[r] - first + d] = static_cast<uint8_t>(d < 255 ? d : 255);
       }
   }
   // haplotype h <-> site h (Graph::get_all_haplotypes, graph.cpp:680-704); accumulator offsets
