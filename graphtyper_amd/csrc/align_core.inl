@@ -1663,10 +1663,16 @@ GTX_DEV bool seed_stage(Here, GraphView const & g, IndexView const & ix, WS & ws
           {
             DevLabel const lb = c0 ? ws.xl[l][0] : ix.labels[nb_off];
             mm = c0 ? 0u : 1u;
-            bad = lb.site != INVALID;
-            why = 4; // the one label is a neighbour's (or an exact one) on a variant
             ws.fs_start[l] = lb.start;
             ws.fs_end[l] = lb.end;
+            if (lb.site != INVALID) // the only label there is lies on a variant (e.g. an error inside a k-mer over a SNP)
+            {
+              bad = g.is_sv_graph != 0;
+              why = 4;
+              has_var = !bad;
+              ws.fs_site = lb.site;
+              ws.fs_allele = lb.allele;
+            }
           }
           else if (c0 == 1 && nb <= 3 && !g.is_sv_graph)
           {

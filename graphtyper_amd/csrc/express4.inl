@@ -280,9 +280,15 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
         {
           DevLabel const lb = c0 ? s.xl[j][0] : ix.labels[nb_off];
           mm = c0 == 0;
-          bad = lb.site != INVALID;
           s.fs_start[j] = lb.start;
           s.fs_end[j] = lb.end;
+          if (lb.site != INVALID) // the only label there is lies on a variant (e.g. an error inside a k-mer over a SNP)
+          {
+            bad = g.is_sv_graph != 0;
+            has_var = !bad;
+            s.fs_site = lb.site;
+            s.fs_allele = lb.allele;
+          }
         }
         else if (c0 == 1 && nb <= 3 && !g.is_sv_graph)
         {
