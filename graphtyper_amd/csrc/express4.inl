@@ -16,6 +16,9 @@ struct Express4Tail // handed from a group's leader lane to its 16 lanes
   uint32_t dna_off, tail_len, pre; // walk at the read's end: arena offset of the path's last base, characters, read offset
   uint32_t head_off, head_len, prs; // walk at the read's start (backwards from the path's first base)
   uint32_t ok;
+  // a tail that runs over one SNP-like site (every allele one base): characters [0, room) in the node the path ends in,
+  // character `room` against the alleles, the rest in the next reference node
+  uint32_t room, nall, alleles, next_off, site; // alleles: one comparison code per byte
 };
 
 struct Express4Workspace
@@ -378,7 +381,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
     mism_l[l] = static_cast<uint32_t>(__builtin_popcount(mm & run_mask));
     if ((l & 15u) == 0)
     {
-      Express4Tail t{0, 0, 0, 0, 0, 0, 0};
+      Express4Tail t{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       if (seeded)
       {
         uint32_t const L = len_l[l], prs = (K - 1) * lo, pre = (K - 1) * (hi + 1);
@@ -408,11 +411,46 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
           if (table && !g_is_special(g, anchor) && anchor >= g.first_order && anchor - g.first_order < g.n_pos_info)
           {
             uint32_t const w = g.pos_info[anchor - g.first_order];
-            if (w != INVALID && (w & 255u) >= L - pre)
+            uint32_t const tail_len = L - pre;
+            if (w != INVALID && (w & 255u) >= tail_len)
             {
               t.ok = 1;
               t.dna_off = w >> 8;
-              t.tail_len = L - pre;
+              t.tail_len = tail_len;
+              t.room = tail_len;
+            }
+            else if (w != INVALID && (w & 255u) < 255u && !g.is_sv_graph && (VAR >> sh & 0xFFFFu) == 0 && g.pos_node)
+            {
+              // The tail leaves the node over a variant site.  When every allele of that site is a single base (a SNP)
+              // and the rest fits in the next reference node, Graph::get_labels_forward has one candidate per allele,
+              // they differ in that one character, and the labels of the best ones share (start, end): one path whose
+              // allele set is the best alleles (make_pp unites labels with equal ends).
+              uint32_t const r = g.pos_node[anchor - g.first_order], room = w & 255u;
+              if (r != INVALID && r + 1 < g.n_ref)
+              {
+                uint32_t const nv = g.ref_nvar[r], fv = g.ref_first_var[r];
+                uint32_t const rest = tail_len - room - 1;
+                bool snp = nv >= 2 && nv <= 4 && g.ref_len[r + 1] >= rest;
+                uint32_t codes = 0;
+                for (uint32_t a = 0; a < 4 && snp; ++a)
+                  if (a < nv)
+                  {
+                    snp = g.var_len[fv + a] == 1;
+                    if (snp)
+                      codes |= static_cast<uint32_t>(reinterpret_cast<uint8_t const *>(g.dna)[g.var_dna[fv + a]]) << (8 * a);
+                  }
+                if (snp)
+                {
+                  t.ok = 1;
+                  t.dna_off = w >> 8;
+                  t.tail_len = tail_len;
+                  t.room = room;
+                  t.nall = nv;
+                  t.alleles = codes;
+                  t.next_off = g.ref_dna[r + 1];
+                  t.site = r;
+                }
+              }
             }
           }
         }
@@ -439,9 +477,9 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
       Express4Tail const t = ws.tail[gi];
       bool k = false, x = false, hk = false, hx = false;
       bool const on = seeded_l[l] && t.ok;
-      if (on && i < t.tail_len)
+      if (on && i < t.tail_len && i != t.room) // (character `room`, if inside the tail, is the variant: verdict below)
       {
-        uint8_t const gc = reinterpret_cast<uint8_t const *>(g.dna)[t.dna_off + i];
+        uint8_t const gc = reinterpret_cast<uint8_t const *>(g.dna)[i < t.room ? t.dna_off + i : t.next_off + (i - t.room - 1)];
         uint8_t const rc = ws.s[gi].rd[t.pre + i];
         k = gc == DNA_KILL;
         x = gc != rc && rc != 15 && gc != 15;
@@ -495,18 +533,42 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
             mism += hgot_l[l];
           }
         }
+        uint32_t tail_site = INVALID, tail_mask = 0;
         if (t.tail_len)
         {
           uint32_t const budget = 2 + t.tail_len / 11 < 7 ? 2 + t.tail_len / 11 : 7; // genotype_paths.cpp:505-511
-          if (!killed_l[l] && got_l[l] <= budget)
+          uint32_t got = got_l[l];
+          bool killed = killed_l[l];
+          if (t.nall) // the character over the variant site: the alleles that mismatch least
+          {
+            uint8_t const rc = s.rd[t.pre + t.room];
+            uint32_t best = 2;
+            for (uint32_t a = 0; a < t.nall; ++a)
+            {
+              uint8_t const gc = static_cast<uint8_t>(t.alleles >> (8 * a));
+              killed = killed || gc == DNA_KILL;
+              uint32_t const xa = (gc != rc && rc != 15 && gc != 15) ? 1u : 0u;
+              if (xa < best)
+              {
+                best = xa;
+                tail_mask = 0;
+              }
+              if (xa == best)
+                tail_mask |= 1u << a;
+            }
+            got += best;
+          }
+          if (!killed && got <= budget)
           {
             end += t.tail_len - 1;
             re = L - 1;
-            mism += got_l[l];
+            mism += got;
+            if (t.nall)
+              tail_site = t.site;
           }
         }
         uint32_t longest = re - rs + 1;
-        uint64_t const with_var = (VAR >> (16 * gi)) & 0xFFFFu;
+        uint64_t const with_var = ((VAR >> (16 * gi)) & 0xFFFFu) | (tail_site != INVALID ? 1u : 0u);
         uint32_t np = 1;
         if (mism > 10) // remove_paths_with_too_many_mismatches on one path
         {
@@ -522,7 +584,13 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
           rec[3] = end;
           rec[4] = rs | (re << 16);
           rec[5] = mism | ((with_var ? 1u : 0u) << 16);
-          if (with_var)
+          if (tail_site != INVALID)
+          {
+            rec[6] = tail_site;
+            rec[7] = tail_mask;
+            rec[8] = 0;
+          }
+          else if (with_var)
           {
             uint32_t const allele = s.fs_allele;
             rec[6] = s.fs_site;

@@ -527,6 +527,7 @@ int ctx_upload(gtx_ctx & c, int device)
   {
     ok = ok && upload(c.dev_allocs, v.pos_info, h.pos_info.data(), h.pos_info.size(), "pos_info");
     ok = ok && upload(c.dev_allocs, v.pos_back, h.pos_back.data(), h.pos_back.size(), "pos_back");
+    ok = ok && upload(c.dev_allocs, v.pos_node, h.pos_node.data(), h.pos_node.size(), "pos_node");
   }
   ok = ok && upload(c.dev_allocs, v.dna, h.codes.data(), h.codes.size(), "dna codes");
   ok = ok && upload(c.dev_allocs, v.tri_off, h.tri_off.data(), h.tri_off.size(), "tri_off");

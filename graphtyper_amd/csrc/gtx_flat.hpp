@@ -68,6 +68,7 @@ struct GraphView
   // (offset of its base in `dna` << 8) | min(255, bases of that node from it on); NULL when the arena is > 16 MB
   const uint32_t * pos_info;
   const uint8_t * pos_back; // [n_pos_info] min(255, bases of the position's reference node before it) (backward compares)
+  const uint32_t * pos_node; // [n_pos_info] index of the reference node the position lies in (INVALID when in none)
   uint32_t n_pos_info, pad2;
   const char * dna; // graph sequence as codes (see align_core.hpp: DNA_KILL / DNA_OTHER), same offsets as the characters
   // score accumulator layout (haplotype h <-> site h, graph.cpp:680-704)
@@ -105,6 +106,7 @@ struct HostGraph
   std::vector<uint32_t> var_order, var_len, var_dna, var_out_ref;
   std::vector<uint32_t> site_ref_reach, site_special_base, special_ref_reach, special_actual, pos_bucket, pos_info;
   std::vector<uint8_t> pos_back;
+  std::vector<uint32_t> pos_node;
   std::vector<uint32_t> event_off; // [2*n_var+1] (empty when the graph has no events)
   std::vector<int64_t> event_val;
   std::vector<uint64_t> tri_off, allele_off;

@@ -44,6 +44,7 @@ GraphView HostGraph::view() const
   v.pos_bucket = pos_bucket.data();
   v.pos_info = pos_info.empty() ? nullptr : pos_info.data();
   v.pos_back = pos_back.empty() ? nullptr : pos_back.data();
+  v.pos_node = pos_node.empty() ? nullptr : pos_node.data();
   v.n_pos_info = static_cast<uint32_t>(pos_info.size());
   v.dna = codes.data();
   v.tri_off = tri_off.data();
@@ -186,16 +187,19 @@ std::string flatten_graph(gtx_graph_view const & g, gtx_params const & par, Host
   // position -> where its base is and how far its reference node goes on (the tail compare of the simple reads)
   out.pos_info.clear();
   out.pos_back.clear();
+  out.pos_node.clear();
   if (out.codes.size() < (1u << 24))
   {
     out.pos_info.assign(last - first, INVALID);
     out.pos_back.assign(last - first, 0);
+    out.pos_node.assign(last - first, INVALID);
     for (uint32_t r = 0; r < R; ++r)
       for (uint32_t d = 0; d < out.ref_len[r]; ++d)
       {
         uint32_t const room = out.ref_len[r] - d;
         out.pos_info[out.ref_order[r] - first + d] = ((out.ref_dna[r] + d) << 8) | (room < 255 ? room : 255);
         out.pos_back[out.ref_order[r] - first + d] = static_cast<uint8_t>(d < 255 ? d : 255);
+        out.pos_node[out.ref_order[r] - first + d] = r;
       }
   }
   // haplotype h <-> site h (Graph::get_all_haplotypes, graph.cpp:680-704); accumulator offsets
