@@ -14,7 +14,7 @@ namespace gtx
 {
 constexpr uint16_t F_PAIRED = 1, F_PROPER_PAIR = 2, F_UNMAPPED = 4, F_SEQ_REVERSED = 16, F_FIRST_IN_PAIR = 64, F_MAPQ_BAD = 4096;
 constexpr uint32_t NO_COVERAGE = 0xFFFFu, MULTI_ALT_COVERAGE = 0xFFFEu, MULTI_REF_COVERAGE = 0xFFFDu; // haplotype.hpp:86-88
-constexpr uint32_t SCORE_MAX_HAPS = 24;      // distinct variant sites one read can touch in the main scoring pass
+constexpr uint32_t SCORE_MAX_HAPS = 8;       // distinct variant sites one read can touch in the main scoring pass (per-thread tables)
 constexpr uint32_t SCORE_MAX_HAPS_BIG = 1024; // ... in the second pass (tables in HBM)
 
 struct ScoreParams
