@@ -25,6 +25,7 @@ struct Express4Workspace
 {
   SeedWorkspace s[4];
   Express4Tail tail[4];
+  uint32_t ksite[4][AlignCfg::KC], kallele[4][AlignCfg::KC]; // the variant (site, allele) of every k-mer's label
 };
 
 // Returns a 4-bit mask: bit gi set = task first + gi must go through pass 2.
@@ -240,11 +241,11 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
 
   // ---- fast seeding, lane j < n_k of a group = k-mer j (the rules and their justification: seed_stage).
   //      One k-mer of the read may have no label at all (two or more errors, an error next to an N): a "hole".
-  PB bad_l, var_l, mm_l, hole_l;
+  PB bad_l, var_l, mm_l, hole_l, par_l; // par: the k-mer also starts a parallel (+1 mismatch) chain when it opens a run
   W::lanes([&](uint32_t l) {
     uint32_t const gi = l >> 4, j = l & 15u;
     SeedWorkspace & s = ws.s[gi];
-    bool bad = false, has_var = false, mm = false, hole = false;
+    bool bad = false, has_var = false, mm = false, hole = false, par = false;
     if (alive_l[l] && j < nk_l[l])
     {
       uint32_t const c0 = s.cnt0[j];
@@ -254,6 +255,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
                        a3 = j < 4 ? s.acnt[j][3] : 0u;
         hole = a0 == 0 && a1 + a2 + a3 == 0;
         bad = !hole && (a0 > 1 || a0 + a1 + a2 + a3 != 1);
+        par = true; // a multi-key list is added twice (0 and 1 mismatches)
         if (!bad && !hole)
         {
           DevLabel const lb = s.xl[j][0];
@@ -289,8 +291,8 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
           {
             bad = g.is_sv_graph != 0;
             has_var = !bad;
-            s.fs_site = lb.site;
-            s.fs_allele = lb.allele;
+            ws.ksite[gi][j] = lb.site;
+            ws.kallele[gi][j] = lb.allele;
           }
         }
         else if (c0 == 1 && nb <= 3 && !g.is_sv_graph)
@@ -312,10 +314,11 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
           if (!bad)
           {
             has_var = true;
+            par = true; // the site's other alleles start chains with one more mismatch
             s.fs_start[j] = lb.start;
             s.fs_end[j] = lb.end;
-            s.fs_site = lb.site;
-            s.fs_allele = lb.allele;
+            ws.ksite[gi][j] = lb.site;
+            ws.kallele[gi][j] = lb.allele;
           }
         }
         else
@@ -326,34 +329,37 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
     var_l[l] = has_var;
     mm_l[l] = mm;
     hole_l[l] = hole;
+    par_l[l] = par;
   });
-  uint64_t const BAD = W::ballot(bad_l), VAR = W::ballot(var_l), MM = W::ballot(mm_l), HOLE = W::ballot(hole_l);
+  uint64_t const BAD = W::ballot(bad_l), VAR = W::ballot(var_l), MM = W::ballot(mm_l), HOLE = W::ballot(hole_l), PAR = W::ballot(par_l);
   W::lds_sync();
   // ---- the run of k-mers that makes the path: all of them, or -- with one hole -- the longer side of the hole.  (The
   //      shorter side chains into a shorter path that remove_short_paths drops before the walks, genotype_paths.cpp:
-  //      824-834; equal sides would both survive: left to pass 2.  A hole and a variant together: left to pass 2.)
+  //      824-834; equal sides would both survive: left to pass 2.)  Any number of the run's k-mers may lie on a variant
+  //      (one site per k-mer): the chain collects the sites, most recent first (path.cpp:38-82 keeps p2's sites first).
   PU lo_l, hi_l; // first / last k-mer of the run
   PB run_ok_l;
   W::lanes([&](uint32_t l) {
     uint32_t const sh = 16 * (l >> 4), n_k = nk_l[l];
     uint32_t const bad = static_cast<uint32_t>(BAD >> sh) & 0xFFFFu, var = static_cast<uint32_t>(VAR >> sh) & 0xFFFFu,
                    hole = static_cast<uint32_t>(HOLE >> sh) & 0xFFFFu;
-    bool ok = alive_l[l] && bad == 0 && (var & (var - 1u)) == 0;
+    (void)var;
+    bool ok = alive_l[l] && bad == 0;
     uint32_t lo = 0, hi = n_k ? n_k - 1 : 0;
     if (ok && hole != 0)
     {
       uint32_t const h = static_cast<uint32_t>(__builtin_ctz(hole));
       uint32_t const left = h, right = n_k - 1 - h; // k-mers on either side
-      ok = (hole & (hole - 1u)) == 0 && var == 0 && left != right;
+      ok = (hole & (hole - 1u)) == 0 && left != right;
       if (left > right)
         hi = h - 1;
       else
         lo = h + 1;
-      // A run that starts (after the hole) with a multi-key k-mer starts with two parallel chains, the list and its
-      // +1-mismatch copy; the start walk then yields one label list per chain, the second list finds no chain left to
-      // merge with, becomes a path of its own and is walked to a duplicate of the result (the reference really returns
-      // the path twice): left to pass 2.
-      if (ok && lo > 0 && ws.s[l >> 4].nkeys0[lo] != 1)
+      // A run that starts (after the hole) with a multi-key k-mer, or with a k-mer on a variant whose other alleles are
+      // indexed, starts with parallel chains (the list's +1-mismatch copy, the other alleles); the start walk then yields
+      // one label list per chain, the later lists find no chain left to merge with, become paths of their own and are
+      // walked to duplicates of the result (the reference really returns the path twice): left to pass 2.
+      if (ok && lo > 0 && ((static_cast<uint32_t>(PAR >> sh) >> lo) & 1u))
         ok = false;
     }
     run_ok_l[l] = ok;
@@ -419,7 +425,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
               t.tail_len = tail_len;
               t.room = tail_len;
             }
-            else if (w != INVALID && (w & 255u) < 255u && !g.is_sv_graph && (VAR >> sh & 0xFFFFu) == 0 && g.pos_node)
+            else if (w != INVALID && (w & 255u) < 255u && !g.is_sv_graph && g.pos_node)
             {
               // The tail leaves the node over a variant site.  When every allele of that site is a single base (a SNP)
               // and the rest fits in the next reference node, Graph::get_labels_forward has one candidate per allele,
@@ -568,7 +574,43 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
           }
         }
         uint32_t longest = re - rs + 1;
-        uint64_t const with_var = ((VAR >> (16 * gi)) & 0xFFFFu) | (tail_site != INVALID ? 1u : 0u);
+        // variant sites of the path: every merge puts the new label's site in front, intersecting the allele sets when
+        // the path already carries the site (path.cpp:38-82); an empty intersection makes the merge fail (declined)
+        uint32_t vs[AlignCfg::KC + 1], nvar = 0;
+        uint64_t vm[AlignCfg::KC + 1];
+        uint32_t const var_run = static_cast<uint32_t>((VAR >> (16 * gi)) & 0xFFFFu) & (((2u << hi) - 1u) & ~((1u << lo) - 1u));
+        bool clash = false;
+        auto push_front = [&](uint32_t site, uint64_t mask)
+        {
+          uint32_t k = 0;
+          while (k < nvar && vs[k] != site)
+            ++k;
+          if (k < nvar)
+          {
+            mask &= vm[k];
+            clash = clash || mask == 0;
+          }
+          else
+            ++nvar;
+          for (; k > 0; --k)
+          {
+            vs[k] = vs[k - 1];
+            vm[k] = vm[k - 1];
+          }
+          vs[0] = site;
+          vm[0] = mask;
+        };
+        for (uint32_t k = lo; k <= hi; ++k)
+          if ((var_run >> k) & 1u)
+            push_front(ws.ksite[gi][k], 1ull << ws.kallele[gi][k]);
+        if (tail_site != INVALID)
+          push_front(tail_site, tail_mask);
+        bool const with_var = nvar != 0;
+        if (clash || 6 + 3 * nvar > rec_words)
+        {
+          fail = true; // (nothing written: pass 2 redoes the task)
+          nvar = 0;
+        }
         uint32_t np = 1;
         if (mism > 10) // remove_paths_with_too_many_mismatches on one path
         {
@@ -576,26 +618,22 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
           longest = 0;
         }
         uint32_t * rec = records + static_cast<uint64_t>(first + gi) * 2 * rec_words;
-        rec[0] = np;
-        rec[1] = longest | (L << 16) | ((np && with_var) ? GTX_REC_HAS_VARIANTS : 0u);
-        if (np)
+        if (!fail)
         {
-          rec[2] = start;
-          rec[3] = end;
-          rec[4] = rs | (re << 16);
-          rec[5] = mism | ((with_var ? 1u : 0u) << 16);
-          if (tail_site != INVALID)
+          rec[0] = np;
+          rec[1] = longest | (L << 16) | ((np && with_var) ? GTX_REC_HAS_VARIANTS : 0u);
+          if (np)
           {
-            rec[6] = tail_site;
-            rec[7] = tail_mask;
-            rec[8] = 0;
-          }
-          else if (with_var)
-          {
-            uint32_t const allele = s.fs_allele;
-            rec[6] = s.fs_site;
-            rec[7] = static_cast<uint32_t>(1ull << allele);
-            rec[8] = static_cast<uint32_t>((1ull << allele) >> 32);
+            rec[2] = start;
+            rec[3] = end;
+            rec[4] = rs | (re << 16);
+            rec[5] = mism | (nvar << 16);
+            for (uint32_t k = 0; k < nvar; ++k)
+            {
+              rec[6 + 3 * k] = vs[k];
+              rec[7 + 3 * k] = static_cast<uint32_t>(vm[k]);
+              rec[8 + 3 * k] = static_cast<uint32_t>(vm[k] >> 32);
+            }
           }
         }
       }

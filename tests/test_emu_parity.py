@@ -310,6 +310,11 @@ def express_variants_case(Backend, monkeypatch, n_reads):
         b = Backend(gtx.graph_from_records(ref, recs, region_begin=1000, add_all_variants=aav))
         rng = np.random.default_rng(1)
         reads = [c[:int(L)] for c, L in zip(codes, rng.integers(50, 151, size=len(codes)))]
+        # ... and reads with five k-mers (156..187 bp: the most pass 1 takes) and longer ones (pass 2)
+        ref_l, _, codes_l, _ = scenarios.synthetic_case(kind, n_ref=100000, n_reads=n_reads // 4, region_begin=1000, err=0.02,
+                                                        n_rate=0.004, seed=3, read_len=200)
+        assert ref_l == ref
+        reads += [c[:int(L)] for c, L in zip(codes_l, rng.integers(150, 201, size=len(codes_l)))]
         seq, lens = harness.pack_ragged(reads)
         flags = rng.choice([0, 1 | 64, 1 | 2 | 32 | 64], size=len(reads)).astype(np.uint16)
         meta = harness.read_meta(lens, flags=flags, isize=rng.integers(-2000, 2000, size=len(reads)))
@@ -319,6 +324,12 @@ def express_variants_case(Backend, monkeypatch, n_reads):
         four = b.align(seq, meta).copy()
         assert np.array_equal(one, four)
         assert ((four.reshape(-1, harness.REC_WORDS)[:, 0] & 0xFFFF) > 0).sum() > n_reads // 2
+        o = Oracle(ref, recs, region_begin=1000, add_all_variants=aav)  # and both equal the oracle on the long reads
+        tail = slice(len(reads) - 300, len(reads))
+        got = gtx.parse_records(four.reshape(-1, 2 * harness.REC_WORDS)[tail].reshape(-1), 300, harness.REC_WORDS, b.ctx.hap_order,
+                                b.big_records()[0])
+        want = o.align(reads[tail], flags=flags[tail], isize=meta["isize"][tail])
+        assert [[dict(longest=x["longest"], paths=x["paths"]) for x in pair] for pair in got] == [list(w) for w in want]
 
 
 def test_express_variants_agree(monkeypatch):
