@@ -26,6 +26,8 @@ struct Express4Workspace
   SeedWorkspace s[4];
   Express4Tail tail[4];
   uint32_t ksite[4][AlignCfg::KC], kallele[4][AlignCfg::KC]; // the variant (site, allele) of every k-mer's label
+  uint32_t vsite[4][AlignCfg::KC + 1];                       // the path's sites in record order (built by the leader lane)
+  uint64_t vmask[4][AlignCfg::KC + 1];
 };
 
 // Returns a 4-bit mask: bit gi set = task first + gi must go through pass 2.
@@ -576,8 +578,9 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
         uint32_t longest = re - rs + 1;
         // variant sites of the path: every merge puts the new label's site in front, intersecting the allele sets when
         // the path already carries the site (path.cpp:38-82); an empty intersection makes the merge fail (declined)
-        uint32_t vs[AlignCfg::KC + 1], nvar = 0;
-        uint64_t vm[AlignCfg::KC + 1];
+        uint32_t * vs = ws.vsite[gi]; // (in LDS: indexed arrays in registers would spill)
+        uint64_t * vm = ws.vmask[gi];
+        uint32_t nvar = 0;
         uint32_t const var_run = static_cast<uint32_t>((VAR >> (16 * gi)) & 0xFFFFu) & (((2u << hi) - 1u) & ~((1u << lo) - 1u));
         bool clash = false;
         auto push_front = [&](uint32_t site, uint64_t mask)
