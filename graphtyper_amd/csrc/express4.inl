@@ -603,11 +603,14 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
           vs[0] = site;
           vm[0] = mask;
         };
-        for (uint32_t k = lo; k <= hi; ++k)
-          if ((var_run >> k) & 1u)
-            push_front(ws.ksite[gi][k], 1ull << ws.kallele[gi][k]);
-        if (tail_site != INVALID)
-          push_front(tail_site, tail_mask);
+        if (var_run != 0 || tail_site != INVALID) // (most reads of a sparse graph carry no variant: skip all of this)
+        {
+          for (uint32_t k = lo; k <= hi; ++k)
+            if ((var_run >> k) & 1u)
+              push_front(ws.ksite[gi][k], 1ull << ws.kallele[gi][k]);
+          if (tail_site != INVALID)
+            push_front(tail_site, tail_mask);
+        }
         bool const with_var = nvar != 0;
         if (clash || 6 + 3 * nvar > rec_words)
         {

@@ -117,3 +117,13 @@ def test_edge_cases():
 
 def test_express_variants_agree(monkeypatch):
     express_variants_case(harness.GpuBackend, monkeypatch, 40000)
+
+
+def test_pass_times_are_reported():
+    """gtx_ctx_pass_times: HIP-event durations of the three alignment passes (what bench.py prices the roofline on)"""
+    ref, recs, codes, pos = scenarios.synthetic_case("snp100", n_ref=50000, n_reads=20000, region_begin=0)
+    b = harness.GpuBackend(gtx.graph_from_records(ref, recs))
+    assert b.ctx.pass_times() == ([0.0, 0.0, 0.0], 0)  # arms the timing
+    b.align(gtx.pack_nibbles(codes), harness.read_meta(np.full(len(codes), 150)))
+    ms, handed_on = b.ctx.pass_times()
+    assert all(x > 0 for x in ms) and 0 < handed_on < len(codes)
