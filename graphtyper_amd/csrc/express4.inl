@@ -11,28 +11,69 @@
 // ambiguous bases, every case seed_stage's fast seeding declines (except a single k-mer without any label, which it
 // handles: see the run selection below), walks that leave the reference node.
 
-struct Express4Tail // handed from a group's leader lane to its 16 lanes
+// Two builds of the pass.  The lean one is for graphs whose sites lie far apart (a k-mer meets at most one site, the walk
+// at the read's end at most one); the wide one, for dense graphs, takes k-mers with several labels on one interval (a
+// k-mer over up to KS sites) and tails over up to TS SNP-like sites, at the price of more registers and LDS.  They
+// decide the same reads the same way where both accept; the wide one merely declines fewer.
+struct Express4Lean
 {
-  uint32_t dna_off, tail_len, pre; // walk at the read's end: arena offset of the path's last base, characters, read offset
-  uint32_t head_off, head_len, prs; // walk at the read's start (backwards from the path's first base)
-  uint32_t ok;
-  // a tail that runs over one SNP-like site (every allele one base): characters [0, room) in the node the path ends in,
-  // character `room` against the alleles, the rest in the next reference node
-  uint32_t room, nall, alleles, next_off, site; // alleles: one comparison code per byte
+  static constexpr uint32_t KS = 1;                 // variant sites of one k-mer
+  static constexpr uint32_t NB_MAX = 3;             // labels of a k-mer's Hamming-1 neighbours that are looked at
+  static constexpr uint32_t TS = 1;                 // variant sites under the walk at the read's end
+  static constexpr uint32_t VS_CAP = AlignCfg::KC + 1; // variant sites of the path
+  static constexpr bool END_ON_SITE = false;        // paths whose last base lies on a SNP are walked on here
 };
 
+struct Express4Wide
+{
+  static constexpr uint32_t KS = 4, NB_MAX = 16, TS = 3, VS_CAP = 16;
+  static constexpr bool END_ON_SITE = true;
+};
+
+template <class E4>
+struct Express4Tail // handed from a group's leader lane to its 16 lanes
+{
+  uint32_t tail_len, pre;           // walk at the read's end: characters (from the path's last base on), read offset
+  uint32_t head_off, head_len, prs; // walk at the read's start (backwards from the path's first base)
+  uint32_t ok;
+  // A tail may run over SNP-like sites (every allele one base).  Tail character site_at[k] lies on site k; the characters
+  // before site 0 lie in the reference node the path ends in, those after site k in the reference node that follows it:
+  // character i of stretch k sits at arena offset seg_base[k] + i.
+  uint32_t nsite;
+  uint32_t site_at[E4::TS], seg_base[E4::TS + 1];
+  uint32_t nall[E4::TS], alleles[E4::TS], site[E4::TS]; // alleles: one comparison code per byte
+  uint32_t afirst[E4::TS];                              // index of the first of them (0 unless the walk starts inside an allele)
+};
+
+template <class E4>
 struct Express4Workspace
 {
   SeedWorkspace s[4];
-  Express4Tail tail[4];
-  uint32_t ksite[4][AlignCfg::KC], kallele[4][AlignCfg::KC]; // the variant (site, allele) of every k-mer's label
-  uint32_t vsite[4][AlignCfg::KC + 1];                       // the path's sites in record order (built by the leader lane)
-  uint64_t vmask[4][AlignCfg::KC + 1];
+  Express4Tail<E4> tail[4];
+  // the variant sites of every k-mer's labels, in label order, and the alleles the labels name
+  uint32_t kn[4][AlignCfg::KC], ksite[4][AlignCfg::KC][E4::KS];
+  uint64_t kmask[4][AlignCfg::KC][E4::KS];
+  uint32_t vsite[4][E4::VS_CAP]; // the path's sites in record order (built by the leader lane)
+  uint64_t vmask[4][E4::VS_CAP];
 };
 
+#ifdef GTX_EMU_NOTES // diagnostics of the host emulation (tests/emu): why a task leaves this pass
+#define GTX_E4_NOTE(cond, code)                                                                                                    \
+  do                                                                                                                               \
+  {                                                                                                                                \
+    if (cond)                                                                                                                      \
+      W::note(code);                                                                                                               \
+  } while (0)
+#else
+#define GTX_E4_NOTE(cond, code)                                                                                                    \
+  do                                                                                                                               \
+  {                                                                                                                                \
+  } while (0)
+#endif
+
 // Returns a 4-bit mask: bit gi set = task first + gi must go through pass 2.
-template <class W>
-GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Workspace & ws, uint8_t const * seq, uint32_t seq_stride,
+template <class W, class E4>
+GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Workspace<E4> & ws, uint8_t const * seq, uint32_t seq_stride,
                           gtx_read_meta const * meta, uint32_t first, uint32_t n_valid, uint32_t * records, uint32_t rec_words,
                           bool decline_all = false)
 {
@@ -59,6 +100,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
     }
     bool const candidate = valid && !too_short && !too_long;
     bool const fits = candidate && n_k <= KC && use_halves && rec_words >= 9 && !decline_all; // (decline_all: test switch)
+    GTX_E4_NOTE((l & 15u) == 0 && candidate && !fits, 11);
     alive_l[l] = fits;
     pass2_l[l] = candidate && !fits;
     len_l[l] = len;
@@ -211,6 +253,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
           }
         }
         s.acnt[ai][aw] = cnt;
+        s.aoff[ai][aw] = off;
       }
     });
   }
@@ -250,26 +293,62 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
     bool bad = false, has_var = false, mm = false, hole = false, par = false;
     if (alive_l[l] && j < nk_l[l])
     {
-      uint32_t const c0 = s.cnt0[j];
-      if (s.nkeys0[j] != 1)
+      // The labels that make the k-mer's path have to share (start, end): labels with equal ends are one path
+      // (find_all_nonduplicated_paths, genotype_paths.cpp:32-66) whose allele set per site is the union over the labels
+      // (Path::merge_with_current, path.cpp:105-129); sites keep the order of their first label.
+      uint32_t nsites = 0;
+      DevLabel l0{0, 0, INVALID, 0};
+      bool first_label = true;
+      auto take = [&](DevLabel const & lb, bool only_one)
       {
-        uint32_t const a0 = j < 4 ? s.acnt[j][0] : 0xFFFFFFFFu, a1 = j < 4 ? s.acnt[j][1] : 0u, a2 = j < 4 ? s.acnt[j][2] : 0u,
-                       a3 = j < 4 ? s.acnt[j][3] : 0u;
-        hole = a0 == 0 && a1 + a2 + a3 == 0;
-        bad = !hole && (a0 > 1 || a0 + a1 + a2 + a3 != 1);
-        par = true; // a multi-key list is added twice (0 and 1 mismatches)
-        if (!bad && !hole)
+        if (first_label)
         {
-          DevLabel const lb = s.xl[j][0];
-          bad = lb.site != INVALID;
+          l0 = lb;
+          first_label = false;
           s.fs_start[j] = lb.start;
           s.fs_end[j] = lb.end;
         }
+        bad = bad || lb.start != l0.start || lb.end != l0.end || (lb.site == INVALID && !only_one);
+        if (!bad && lb.site != INVALID)
+        {
+          uint32_t i = 0;
+          while (i < nsites && ws.ksite[gi][j][i] != lb.site)
+            ++i;
+          if (i == nsites)
+          {
+            if (nsites == E4::KS)
+            {
+              bad = true;
+              return;
+            }
+            ws.ksite[gi][j][i] = lb.site;
+            ws.kmask[gi][j][i] = 0;
+            ++nsites;
+          }
+          ws.kmask[gi][j][i] |= 1ull << lb.allele;
+        }
+      };
+      uint32_t const c0 = s.cnt0[j];
+      if (s.nkeys0[j] != 1)
+      {
+        // one ambiguous base: the labels of its (up to four) keys in to_uint64_vec order.  A multi-key list gets no
+        // Hamming-1 lookup and is added twice (0 and 1 mismatches): a parallel chain.
+        uint32_t const a0 = j < 4 ? s.acnt[j][0] : 0xFFFFFFFFu;
+        uint32_t total = a0;
+        for (uint32_t aw = 1; aw < 4; ++aw)
+          total = (total == 0xFFFFFFFFu || j >= 4) ? 0xFFFFFFFFu : total + s.acnt[j][aw];
+        hole = total == 0;
+        bad = !hole && total > E4::KS + 1;
+        par = true;
+        if (!bad && !hole)
+          for (uint32_t aw = 0; aw < 4; ++aw)
+            for (uint32_t k = 0; k < s.acnt[j][aw] && !bad; ++k)
+              take(total == 1 ? s.xl[j][0] : ix.labels[s.aoff[j][aw] + k], total == 1);
       }
-      else if (!(bad = c0 > 1 || s.hcnt[j][0] > HE_CAP || s.hcnt[j][1] > HE_CAP))
+      else if (!(bad = c0 > E4::KS || s.hcnt[j][0] > HE_CAP || s.hcnt[j][1] > HE_CAP))
       {
         uint64_t const q = s.key0[j];
-        uint32_t nb = 0, nb_off = 0;
+        uint32_t nb = 0, nb_keys = 0, nb_off = 0;
         for (uint32_t side = 0; side < 2; ++side)
           for (uint32_t e = 0; e < s.hcnt[j][side]; ++e)
           {
@@ -278,54 +357,56 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
             if (hamming1_neighbour(he.key, q, nn))
             {
               nb += he.cnt;
+              ++nb_keys;
               nb_off = he.off;
             }
           }
+        // the labels of the exact key, else -- no exact hit, ONE neighbouring key -- that key's (one more mismatch)
+        uint32_t const n_own = c0 ? c0 : nb;
         if (c0 + nb == 0)
           hole = true;
-        else if (c0 + nb == 1)
+        else if ((c0 == 0 && nb_keys != 1) || n_own > E4::KS || nb > E4::NB_MAX)
         {
-          DevLabel const lb = c0 ? s.xl[j][0] : ix.labels[nb_off];
-          mm = c0 == 0;
-          s.fs_start[j] = lb.start;
-          s.fs_end[j] = lb.end;
-          if (lb.site != INVALID) // the only label there is lies on a variant (e.g. an error inside a k-mer over a SNP)
-          {
-            bad = g.is_sv_graph != 0;
-            has_var = !bad;
-            ws.ksite[gi][j] = lb.site;
-            ws.kallele[gi][j] = lb.allele;
-          }
-        }
-        else if (c0 == 1 && nb <= 3 && !g.is_sv_graph)
-        {
-          DevLabel const lb = s.xl[j][0];
-          bad = lb.site == INVALID;
-          for (uint32_t side = 0; side < 2 && !bad; ++side)
-            for (uint32_t e = 0; e < s.hcnt[j][side]; ++e)
-            {
-              HalfEntry const & he = s.he[j][side][e];
-              uint32_t nn;
-              if (hamming1_neighbour(he.key, q, nn))
-                for (uint32_t k = 0; k < he.cnt; ++k)
-                {
-                  DevLabel const nl = ix.labels[he.off + k];
-                  bad = bad || nl.start != lb.start || nl.end != lb.end || nl.site != lb.site;
-                }
-            }
-          if (!bad)
-          {
-            has_var = true;
-            par = true; // the site's other alleles start chains with one more mismatch
-            s.fs_start[j] = lb.start;
-            s.fs_end[j] = lb.end;
-            ws.ksite[gi][j] = lb.site;
-            ws.kallele[gi][j] = lb.allele;
-          }
+          bad = true;
+          GTX_E4_NOTE(true, 2); // neighbours of several keys without an exact hit / too many labels
         }
         else
-          bad = true;
+        {
+          mm = c0 == 0;
+          for (uint32_t k = 0; k < n_own && !bad; ++k)
+            take(c0 == 1 ? s.xl[j][0] : ix.labels[(c0 ? s.off0[j] : nb_off) + k], n_own == 1);
+          if (!bad && c0 != 0 && nb != 0)
+          {
+            // Neighbouring keys of an exact hit: the sites' other alleles.  They start chains with one more mismatch
+            // that end where the exact chain ends, as long as they are the same interval over the same sites.
+            bad = nsites == 0;
+            for (uint32_t side = 0; side < 2 && !bad; ++side)
+              for (uint32_t e = 0; e < s.hcnt[j][side]; ++e)
+              {
+                HalfEntry const & he = s.he[j][side][e];
+                uint32_t nn;
+                if (hamming1_neighbour(he.key, q, nn))
+                  for (uint32_t k = 0; k < he.cnt; ++k)
+                  {
+                    DevLabel const nl = ix.labels[he.off + k];
+                    bool known = false;
+                    for (uint32_t i = 0; i < nsites; ++i)
+                      known = known || ws.ksite[gi][j][i] == nl.site;
+                    bad = bad || nl.start != l0.start || nl.end != l0.end || !known;
+                  }
+              }
+            par = true;
+          }
+          GTX_E4_NOTE(bad, 3); // the k-mer's labels are not one interval / its neighbours lie elsewhere
+        }
       }
+      // labels on variants (also the only ones there are: e.g. an error inside a k-mer over a SNP)
+      bad = bad || (nsites != 0 && g.is_sv_graph != 0);
+      has_var = !bad && !hole && nsites != 0;
+      ws.kn[gi][j] = nsites;
+      GTX_E4_NOTE(bad && s.nkeys0[j] != 1, 1); // a k-mer with ambiguous bases: several intervals / too many labels
+      GTX_E4_NOTE(bad && s.nkeys0[j] == 1 && c0 > E4::KS, 4); // more exact labels than the build takes
+      GTX_E4_NOTE(bad && s.nkeys0[j] == 1 && c0 <= E4::KS && (s.hcnt[j][0] > HE_CAP || s.hcnt[j][1] > HE_CAP), 5); // a crowded half-key bucket
     }
     bad_l[l] = bad;
     var_l[l] = has_var;
@@ -364,6 +445,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
       if (ok && lo > 0 && ((static_cast<uint32_t>(PAR >> sh) >> lo) & 1u))
         ok = false;
     }
+    GTX_E4_NOTE((l & 15u) == 0 && alive_l[l] && bad == 0 && !ok, 6); // two holes, equal sides, parallel chains after the hole
     run_ok_l[l] = ok;
     lo_l[l] = lo;
     hi_l[l] = hi;
@@ -383,13 +465,16 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
     uint32_t const gi = l >> 4, sh = 16 * gi;
     uint32_t const gap = static_cast<uint32_t>(GAP >> sh) & 0xFFFFu, mm = static_cast<uint32_t>(MM >> sh) & 0xFFFFu;
     bool const seeded = run_ok_l[l] && gap == 0;
+    GTX_E4_NOTE((l & 15u) == 0 && run_ok_l[l] && gap != 0, 7); // labels do not abut
     seeded_l[l] = seeded;
     uint32_t const lo = lo_l[l], hi = hi_l[l];
     uint32_t const run_mask = seeded ? ((2u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
     mism_l[l] = static_cast<uint32_t>(__builtin_popcount(mm & run_mask));
     if ((l & 15u) == 0)
     {
-      Express4Tail t{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      Express4Tail<E4> t{};
+      for (uint32_t k = 0; k < E4::TS; ++k)
+        t.site_at[k] = INVALID;
       if (seeded)
       {
         uint32_t const L = len_l[l], prs = (K - 1) * lo, pre = (K - 1) * (hi + 1);
@@ -420,25 +505,66 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
           {
             uint32_t const w = g.pos_info[anchor - g.first_order];
             uint32_t const tail_len = L - pre;
+            t.seg_base[0] = w >> 8;
             if (w != INVALID && (w & 255u) >= tail_len)
             {
               t.ok = 1;
-              t.dna_off = w >> 8;
               t.tail_len = tail_len;
-              t.room = tail_len;
             }
-            else if (w != INVALID && (w & 255u) < 255u && !g.is_sv_graph && g.pos_node)
+            else if (((E4::END_ON_SITE && w == INVALID) || (w != INVALID && (w & 255u) < 255u)) && !g.is_sv_graph && g.pos_node)
             {
-              // The tail leaves the node over a variant site.  When every allele of that site is a single base (a SNP)
-              // and the rest fits in the next reference node, Graph::get_labels_forward has one candidate per allele,
-              // they differ in that one character, and the labels of the best ones share (start, end): one path whose
-              // allele set is the best alleles (make_pp unites labels with equal ends).
-              uint32_t const r = g.pos_node[anchor - g.first_order], room = w & 255u;
-              if (r != INVALID && r + 1 < g.n_ref)
+              // The tail leaves the node over variant sites.  When every allele of such a site is a single base (a SNP)
+              // and the rest fits in the reference node after the last of them, Graph::get_labels_forward has one
+              // candidate per combination of alleles, they differ in those characters only, and the labels of the best
+              // ones share (start, end): one path whose allele sets are the best alleles of every site (make_pp unites
+              // labels with equal ends).
+              uint32_t r = INVALID;
+              uint32_t at = 0; // tail character on the next site
+              uint32_t n = 0;
+              bool done = false;
+              if (w != INVALID)
+              {
+                r = g.pos_node[anchor - g.first_order];
+                at = w & 255u;
+              }
+              else if (E4::END_ON_SITE)
+              {
+                // The path ends ON a variant base: the walk starts inside the allele the path carries there (Graph::
+                // get_locations_of_a_position offers variant nodes the path has, graph.cpp:1154-1185), its first
+                // character is that base again, and its labels name the allele: the site moves to the front of the list.
+                for (uint32_t i = 0; i < ws.kn[gi][hi] && n == 0; ++i)
+                {
+                  uint32_t const site = ws.ksite[gi][hi][i];
+                  uint64_t const mask = ws.kmask[gi][hi][i];
+                  uint32_t const nv = g.ref_nvar[site], fv = g.ref_first_var[site];
+                  if (g.var_order[fv] != anchor || (mask & (mask - 1ull)) != 0 || site + 1 >= g.n_ref)
+                    continue;
+                  bool snp = nv <= 4;
+                  for (uint32_t a = 0; a < 4 && snp; ++a)
+                    if (a < nv)
+                      snp = g.var_len[fv + a] == 1;
+                  if (!snp)
+                    break;
+                  uint32_t const a = static_cast<uint32_t>(__builtin_ctzll(mask));
+                  t.site_at[0] = 0;
+                  t.nall[0] = 1;
+                  t.afirst[0] = a;
+                  t.alleles[0] = reinterpret_cast<uint8_t const *>(g.dna)[g.var_dna[fv + a]];
+                  t.site[0] = site;
+                  t.seg_base[1] = g.ref_dna[site + 1] - 1;
+                  n = 1;
+                  uint32_t const next_len = g.ref_len[site + 1];
+                  done = next_len >= tail_len - 1;
+                  at = 1 + next_len;
+                  r = site + 1;
+                }
+                if (n == 0)
+                  r = INVALID;
+              }
+              while (!done && n < E4::TS && r != INVALID && r + 1 < g.n_ref)
               {
                 uint32_t const nv = g.ref_nvar[r], fv = g.ref_first_var[r];
-                uint32_t const rest = tail_len - room - 1;
-                bool snp = nv >= 2 && nv <= 4 && g.ref_len[r + 1] >= rest;
+                bool snp = nv >= 2 && nv <= 4;
                 uint32_t codes = 0;
                 for (uint32_t a = 0; a < 4 && snp; ++a)
                   if (a < nv)
@@ -447,22 +573,36 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
                     if (snp)
                       codes |= static_cast<uint32_t>(reinterpret_cast<uint8_t const *>(g.dna)[g.var_dna[fv + a]]) << (8 * a);
                   }
-                if (snp)
-                {
-                  t.ok = 1;
-                  t.dna_off = w >> 8;
-                  t.tail_len = tail_len;
-                  t.room = room;
-                  t.nall = nv;
-                  t.alleles = codes;
-                  t.next_off = g.ref_dna[r + 1];
-                  t.site = r;
-                }
+                if (!snp)
+                  break;
+                t.site_at[n] = at;
+                t.nall[n] = nv;
+                t.afirst[n] = 0;
+                t.alleles[n] = codes;
+                t.site[n] = r;
+                t.seg_base[n + 1] = g.ref_dna[r + 1] - (at + 1);
+                ++n;
+                uint32_t const next_len = g.ref_len[r + 1];
+                if (next_len >= tail_len - at - 1)
+                  done = true;
+                at += 1 + next_len;
+                ++r;
               }
+              if (done)
+              {
+                t.ok = 1;
+                t.tail_len = tail_len;
+                t.nsite = n;
+              }
+              else
+                for (uint32_t k = 0; k < E4::TS; ++k)
+                  t.site_at[k] = INVALID;
             }
           }
         }
       }
+      GTX_E4_NOTE(seeded && !t.ok && t.prs != 0 && t.head_len == 0, 8); // the walk at the read's start leaves the node
+      GTX_E4_NOTE(seeded && !t.ok && !(t.prs != 0 && t.head_len == 0), 9); // the walk at the read's end is not simple
       ws.tail[gi] = t;
     }
   });
@@ -482,12 +622,21 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
     PB k_l, x_l, hk_l, hx_l, any_l;
     W::lanes([&](uint32_t l) {
       uint32_t const gi = l >> 4, i = 16 * r + (l & 15u);
-      Express4Tail const t = ws.tail[gi];
+      Express4Tail<E4> const & t = ws.tail[gi];
       bool k = false, x = false, hk = false, hx = false;
       bool const on = seeded_l[l] && t.ok;
-      if (on && i < t.tail_len && i != t.room) // (character `room`, if inside the tail, is the variant: verdict below)
+      uint32_t base = t.seg_base[0];
+      bool on_site = false; // (the characters over variant sites: verdict below)
+      for (uint32_t sk = 0; sk < E4::TS; ++sk)
       {
-        uint8_t const gc = reinterpret_cast<uint8_t const *>(g.dna)[i < t.room ? t.dna_off + i : t.next_off + (i - t.room - 1)];
+        uint32_t const sa = t.site_at[sk];
+        on_site = on_site || i == sa;
+        if (sa != INVALID && i > sa)
+          base = t.seg_base[sk + 1];
+      }
+      if (on && i < t.tail_len && !on_site)
+      {
+        uint8_t const gc = reinterpret_cast<uint8_t const *>(g.dna)[base + i];
         uint8_t const rc = ws.s[gi].rd[t.pre + i];
         k = gc == DNA_KILL;
         x = gc != rc && rc != 15 && gc != 15;
@@ -524,7 +673,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
     bool fail = pass2_l[l];
     if (alive_l[l])
     {
-      Express4Tail const t = ws.tail[gi];
+      Express4Tail<E4> const & t = ws.tail[gi];
       fail = !(seeded_l[l] && t.ok);
       if (!fail && (l & 15u) == 0)
       {
@@ -541,38 +690,43 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
             mism += hgot_l[l];
           }
         }
-        uint32_t tail_site = INVALID, tail_mask = 0;
+        uint32_t tail_sites = 0;
+        uint32_t tail_mask[E4::TS];
         if (t.tail_len)
         {
           uint32_t const budget = 2 + t.tail_len / 11 < 7 ? 2 + t.tail_len / 11 : 7; // genotype_paths.cpp:505-511
           uint32_t got = got_l[l];
           bool killed = killed_l[l];
-          if (t.nall) // the character over the variant site: the alleles that mismatch least
+          for (uint32_t sk = 0; sk < E4::TS; ++sk) // the characters over the variant sites: the alleles that mismatch least
           {
-            uint8_t const rc = s.rd[t.pre + t.room];
-            uint32_t best = 2;
-            for (uint32_t a = 0; a < t.nall; ++a)
+            tail_mask[sk] = 0;
+            if (sk < t.nsite)
             {
-              uint8_t const gc = static_cast<uint8_t>(t.alleles >> (8 * a));
-              killed = killed || gc == DNA_KILL;
-              uint32_t const xa = (gc != rc && rc != 15 && gc != 15) ? 1u : 0u;
-              if (xa < best)
-              {
-                best = xa;
-                tail_mask = 0;
-              }
-              if (xa == best)
-                tail_mask |= 1u << a;
+              uint8_t const rc = s.rd[t.pre + t.site_at[sk]];
+              uint32_t best = 2;
+              for (uint32_t a = 0; a < 4; ++a)
+                if (a < t.nall[sk])
+                {
+                  uint8_t const gc = static_cast<uint8_t>(t.alleles[sk] >> (8 * a));
+                  killed = killed || gc == DNA_KILL;
+                  uint32_t const xa = (gc != rc && rc != 15 && gc != 15) ? 1u : 0u;
+                  if (xa < best)
+                  {
+                    best = xa;
+                    tail_mask[sk] = 0;
+                  }
+                  if (xa == best)
+                    tail_mask[sk] |= 1u << a;
+                }
+              got += best;
             }
-            got += best;
           }
           if (!killed && got <= budget)
           {
             end += t.tail_len - 1;
             re = L - 1;
             mism += got;
-            if (t.nall)
-              tail_site = t.site;
+            tail_sites = t.nsite;
           }
         }
         uint32_t longest = re - rs + 1;
@@ -593,8 +747,13 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
             mask &= vm[k];
             clash = clash || mask == 0;
           }
-          else
+          else if (nvar < E4::VS_CAP)
             ++nvar;
+          else
+          {
+            clash = true; // more sites than the list holds: pass 2
+            return;
+          }
           for (; k > 0; --k)
           {
             vs[k] = vs[k - 1];
@@ -603,15 +762,19 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
           vs[0] = site;
           vm[0] = mask;
         };
-        if (var_run != 0 || tail_site != INVALID) // (most reads of a sparse graph carry no variant: skip all of this)
+        if (var_run != 0 || tail_sites != 0) // (most reads of a sparse graph carry no variant: skip all of this)
         {
+          // a k-mer's (or the tail's) sites keep their label order in front of the older ones: pushed last to first
           for (uint32_t k = lo; k <= hi; ++k)
             if ((var_run >> k) & 1u)
-              push_front(ws.ksite[gi][k], 1ull << ws.kallele[gi][k]);
-          if (tail_site != INVALID)
-            push_front(tail_site, tail_mask);
+              for (uint32_t i = ws.kn[gi][k]; i-- > 0;)
+                push_front(ws.ksite[gi][k][i], ws.kmask[gi][k][i]);
+          for (uint32_t sk = E4::TS; sk-- > 0;)
+            if (sk < tail_sites)
+              push_front(t.site[sk], static_cast<uint64_t>(tail_mask[sk]) << t.afirst[sk]);
         }
         bool const with_var = nvar != 0;
+        GTX_E4_NOTE(clash || 6 + 3 * nvar > rec_words, 10); // allele sets do not intersect / too many sites
         if (clash || 6 + 3 * nvar > rec_words)
         {
           fail = true; // (nothing written: pass 2 redoes the task)

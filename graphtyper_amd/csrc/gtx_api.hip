@@ -218,14 +218,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void gt
 // Pass 1, four reads per wavefront (express4.inl): the default.  Group gi of 16 lanes takes read `first + gi` of the
 // chunk; the forward task of a read is finished here or queued, a reverse-orientation task (discordant pairs,
 // force_align_both_orientations) always goes to pass 2.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void gtx_align_express4_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
-                                                                uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
-                                                                uint32_t n_reads, uint32_t * __restrict__ records,
-                                                                uint32_t rec_words, uint32_t force_both, uint32_t * task_counter,
-                                                                uint32_t * __restrict__ queue, uint32_t * queue_count,
-                                                                uint32_t queue_all)
+template <class E4>
+__device__ __forceinline__ void express4_pass(GraphView const & g, IndexView const & ix, uint8_t const * __restrict__ seq, uint32_t seq_stride,
+                                              gtx_read_meta const * __restrict__ meta, uint32_t n_reads, uint32_t * __restrict__ records,
+                                              uint32_t rec_words, uint32_t force_both, uint32_t * task_counter,
+                                              uint32_t * __restrict__ queue, uint32_t * queue_count, uint32_t queue_all)
 {
-  __shared__ Express4Workspace ws;
+  __shared__ Express4Workspace<E4> ws;
   __shared__ uint32_t pending[2 * TASK_CHUNK];
   uint32_t const lane = threadIdx.x & 63u;
   for (;;)
@@ -254,7 +253,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void gt
         }
       }
       unsigned long long const REV = __ballot(rev);
-      uint32_t const fwd_mask = express4<WaveHip>(g, ix, ws, seq, seq_stride, meta, first, n_valid, records, rec_words, queue_all != 0);
+      uint32_t const fwd_mask = express4<WaveHip, E4>(g, ix, ws, seq, seq_stride, meta, first, n_valid, records, rec_words, queue_all != 0);
       for (uint32_t k = 0; k < n_valid; ++k)
       {
         if ((fwd_mask >> k) & 1u)
@@ -280,6 +279,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void gt
       WaveHip::lds_sync();
     }
   }
+}
+
+#define GTX_EXPRESS4_ARGS                                                                                                          \
+  GraphView g, IndexView ix, uint8_t const *__restrict__ seq, uint32_t seq_stride, gtx_read_meta const *__restrict__ meta,         \
+    uint32_t n_reads, uint32_t *__restrict__ records, uint32_t rec_words, uint32_t force_both, uint32_t *task_counter,             \
+    uint32_t *__restrict__ queue, uint32_t *queue_count, uint32_t queue_all
+
+// the lean build: graphs whose variant sites lie far apart (ctx_upload picks by the mean distance between sites)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void gtx_align_express4_kernel(GTX_EXPRESS4_ARGS)
+{
+  express4_pass<Express4Lean>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, task_counter, queue, queue_count,
+                              queue_all);
+}
+
+// the wide build: dense graphs (k-mers over several sites, tails over several SNPs)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void gtx_align_express4_wide_kernel(GTX_EXPRESS4_ARGS)
+{
+  express4_pass<Express4Wide>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, task_counter, queue, queue_count,
+                              queue_all);
 }
 
 // Pass 2 (general): the queued tasks through the full algorithm over LDS tables.  A task that exceeds them goes on to
@@ -626,6 +644,9 @@ int ctx_upload(gtx_ctx & c, int device)
     c.express_blocks_per_cu = per_cu;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express4_kernel, 64, 0) == hipSuccess && per_cu > 0)
     c.express4_blocks_per_cu = per_cu;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express4_wide_kernel, 64, 0) == hipSuccess && per_cu > 0)
+    c.express4_wide_blocks_per_cu = per_cu;
+  c.express4_wide = express4_prefers_wide(h.ref_len.data(), h.ref_nvar.data(), h.ref_len.size());
   return GTX_OK;
 }
 
@@ -724,11 +745,14 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
   char const * e4 = std::getenv("GTX_EXPRESS4"); // A/B switch: 0 = one read per wavefront in pass 1
   if (!(e4 && e4[0] == '0'))
   {
-    uint32_t const blocks4 = static_cast<uint32_t>(std::min<uint64_t>(chunks, static_cast<uint64_t>(n_cu) * c->express4_blocks_per_cu));
-    hipLaunchKernelGGL(gtx_align_express4_kernel, dim3(blocks4), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph,
-                       c->dev_index, d_seq, seq_stride, d_meta, n_reads, d_records, rec_words,
-                       static_cast<uint32_t>(c->params.force_align_both_orientations != 0), counters, c->d_queue, counters + 2,
-                       static_cast<uint32_t>(force != 0));
+    // GTX_EXPRESS4=lean / wide force a build (tests); else by the graph's density
+    bool const wide = e4 && e4[0] == 'w' ? true : e4 && e4[0] == 'l' ? false : c->express4_wide;
+    uint32_t const blocks4 = static_cast<uint32_t>(std::min<uint64_t>(
+      chunks, static_cast<uint64_t>(n_cu) * (wide ? c->express4_wide_blocks_per_cu : c->express4_blocks_per_cu)));
+    hipLaunchKernelGGL(wide ? gtx_align_express4_wide_kernel : gtx_align_express4_kernel, dim3(blocks4), dim3(64), 0,
+                       static_cast<hipStream_t>(stream), c->dev_graph, c->dev_index, d_seq, seq_stride, d_meta, n_reads, d_records,
+                       rec_words, static_cast<uint32_t>(c->params.force_align_both_orientations != 0), counters, c->d_queue,
+                       counters + 2, static_cast<uint32_t>(force != 0));
   }
   else
     hipLaunchKernelGGL(gtx_align_express_kernel, dim3(blocks1), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph,

@@ -21,6 +21,8 @@ struct gtx_ctx
   uint32_t * d_task_counters = nullptr;
   std::atomic<unsigned> launch_seq{0};
   int align_blocks_per_cu = 8, express_blocks_per_cu = 16, express4_blocks_per_cu = 8;
+  int express4_wide_blocks_per_cu = 8;
+  bool express4_wide = false; // pass 1 runs gtx_align_express4_wide_kernel (express4_prefers_wide, gtx_flat.hpp)
   uint32_t * d_queue = nullptr; // tasks pass 1 hands to pass 2 (grow-only)
   uint64_t queue_cap = 0;
   void * pass_events[4] = {nullptr, nullptr, nullptr, nullptr}; // hipEvent_t around the three passes (gtx_ctx_pass_times)

@@ -170,6 +170,19 @@ inline uint64_t plane_key(uint64_t key)
   return (hi << 32) | lo;
 }
 
+// Pass 1 of the alignment has a lean and a wide build (express4.inl); the wide one pays off when a k-mer or the walk at a
+// read's end often meets two variant sites: graphs with a site every < 200 bases on average.
+inline bool express4_prefers_wide(uint32_t const * ref_len, uint32_t const * ref_nvar, std::size_t n_ref)
+{
+  uint64_t bases = 0, sites = 0;
+  for (std::size_t r = 0; r < n_ref; ++r)
+  {
+    bases += ref_len[r];
+    sites += ref_nvar[r] ? 1u : 0u;
+  }
+  return sites != 0 && bases / sites < 200;
+}
+
 #if defined(__HIPCC__)
 __host__ __device__
 #endif

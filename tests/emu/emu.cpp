@@ -131,7 +131,10 @@ extern "C"
     bool const force_both = e.params.force_align_both_orientations != 0;
     char const * e4 = std::getenv("GTX_EXPRESS4"); // 0: one read per wavefront in pass 1
     bool const four = !(e4 && e4[0] == '0');
-    auto e4_ws = std::make_unique<Express4Workspace>();
+    // lean / wide build of pass 1: forced by GTX_EXPRESS4=lean|wide, else by the graph's density (as gtx_align_batch does)
+    bool const wide = e4 && e4[0] == 'w' ? true : e4 && e4[0] == 'l' ? false : express4_prefers_wide(g.ref_len, g.ref_nvar, g.n_ref);
+    auto e4_ws = std::make_unique<Express4Workspace<Express4Lean>>();
+    auto e4_wide_ws = std::make_unique<Express4Workspace<Express4Wide>>();
     // passes 2 and 3 for one task
     auto general = [&](uint32_t t)
     {
@@ -191,8 +194,17 @@ extern "C"
       for (uint32_t first = 0; first < n_reads; first += 4)
       {
         uint32_t const n_valid = n_reads - first < 4 ? n_reads - first : 4;
-        std::memset(static_cast<void *>(e4_ws.get()), fill, sizeof(Express4Workspace));
-        uint32_t const mask = express4<WaveEmu>(g, ix, *e4_ws, seq, seq_stride, meta, first, n_valid, records, rec_words, force != 0);
+        uint32_t mask;
+        if (wide)
+        {
+          std::memset(static_cast<void *>(e4_wide_ws.get()), fill, sizeof(Express4Workspace<Express4Wide>));
+          mask = express4<WaveEmu, Express4Wide>(g, ix, *e4_wide_ws, seq, seq_stride, meta, first, n_valid, records, rec_words, force != 0);
+        }
+        else
+        {
+          std::memset(static_cast<void *>(e4_ws.get()), fill, sizeof(Express4Workspace<Express4Lean>));
+          mask = express4<WaveEmu, Express4Lean>(g, ix, *e4_ws, seq, seq_stride, meta, first, n_valid, records, rec_words, force != 0);
+        }
         for (uint32_t k = 0; k < n_valid; ++k)
         {
           uint32_t const read = first + k, len = meta[read].l_qseq;

@@ -302,9 +302,10 @@ def test_edge_cases():
 
 
 def express_variants_case(Backend, monkeypatch, n_reads):
-    """pass 1 exists in two forms -- four reads per wavefront (default) and one read per wavefront (GTX_EXPRESS4=0);
-    they must write the same record words for ragged reads, paired flags that ask for the reverse orientation, N bases"""
-    for kind, aav in (("snp100", False), ("cluster", True)):
+    """pass 1 exists in three forms -- four reads per wavefront in a lean and a wide build (picked by the graph's density;
+    GTX_EXPRESS4=lean|wide force one) and one read per wavefront (GTX_EXPRESS4=0); they must write the same record words
+    for ragged reads, paired flags that ask for the reverse orientation, N bases, sparse and dense graphs"""
+    for kind, aav in (("snp100", False), ("cluster", True), ("snp25", False), ("indel", False)):
         ref, recs, codes, pos = scenarios.synthetic_case(kind, n_ref=100000, n_reads=n_reads, region_begin=1000, err=0.02,
                                                          n_rate=0.004, seed=3)
         b = Backend(gtx.graph_from_records(ref, recs, region_begin=1000, add_all_variants=aav))
@@ -320,9 +321,13 @@ def express_variants_case(Backend, monkeypatch, n_reads):
         meta = harness.read_meta(lens, flags=flags, isize=rng.integers(-2000, 2000, size=len(reads)))
         monkeypatch.setenv("GTX_EXPRESS4", "0")
         one = b.align(seq, meta).copy()
-        monkeypatch.setenv("GTX_EXPRESS4", "1")
+        monkeypatch.setenv("GTX_EXPRESS4", "lean")
         four = b.align(seq, meta).copy()
         assert np.array_equal(one, four)
+        monkeypatch.setenv("GTX_EXPRESS4", "wide")
+        wide = b.align(seq, meta).copy()
+        assert np.array_equal(one, wide)
+        monkeypatch.delenv("GTX_EXPRESS4")
         assert ((four.reshape(-1, harness.REC_WORDS)[:, 0] & 0xFFFF) > 0).sum() > n_reads // 2
         o = Oracle(ref, recs, region_begin=1000, add_all_variants=aav)  # and both equal the oracle on the long reads
         tail = slice(len(reads) - 300, len(reads))
