@@ -22,12 +22,16 @@ struct Express4Lean
   static constexpr uint32_t TS = 1;                 // variant sites under the walk at the read's end
   static constexpr uint32_t VS_CAP = AlignCfg::KC + 1; // variant sites of the path
   static constexpr bool END_ON_SITE = false;        // paths whose last base lies on a SNP are walked on here
+  static constexpr uint32_t AMB_LABELS = 1;         // labels a k-mer with an ambiguous base may have between its keys
+  static constexpr bool AMB_ON_VARIANT = true;      // ... and whether they may lie on a variant
 };
 
 struct Express4Wide
 {
   static constexpr uint32_t KS = 4, NB_MAX = 16, TS = 3, VS_CAP = 16;
   static constexpr bool END_ON_SITE = true;
+  static constexpr uint32_t AMB_LABELS = 5;
+  static constexpr bool AMB_ON_VARIANT = true;
 };
 
 template <class E4>
@@ -296,36 +300,38 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
       // The labels that make the k-mer's path have to share (start, end): labels with equal ends are one path
       // (find_all_nonduplicated_paths, genotype_paths.cpp:32-66) whose allele set per site is the union over the labels
       // (Path::merge_with_current, path.cpp:105-129); sites keep the order of their first label.
+      // (every loop below has a compile-time trip count: the lean build's collapse to straight code)
       uint32_t nsites = 0;
-      DevLabel l0{0, 0, INVALID, 0};
+      uint32_t ks[E4::KS];
+      uint64_t km[E4::KS];
+      for (uint32_t i = 0; i < E4::KS; ++i)
+      {
+        ks[i] = INVALID;
+        km[i] = 0;
+      }
+      uint32_t l0_start = 0, l0_end = 0;
       bool first_label = true;
       auto take = [&](DevLabel const & lb, bool only_one)
       {
         if (first_label)
         {
-          l0 = lb;
+          l0_start = lb.start;
+          l0_end = lb.end;
           first_label = false;
-          s.fs_start[j] = lb.start;
-          s.fs_end[j] = lb.end;
         }
-        bad = bad || lb.start != l0.start || lb.end != l0.end || (lb.site == INVALID && !only_one);
+        bad = bad || lb.start != l0_start || lb.end != l0_end || (lb.site == INVALID && !only_one);
         if (!bad && lb.site != INVALID)
         {
-          uint32_t i = 0;
-          while (i < nsites && ws.ksite[gi][j][i] != lb.site)
-            ++i;
-          if (i == nsites)
-          {
-            if (nsites == E4::KS)
+          bool placed = false;
+          for (uint32_t i = 0; i < E4::KS; ++i)
+            if (!placed && (ks[i] == lb.site || i == nsites))
             {
-              bad = true;
-              return;
+              ks[i] = lb.site;
+              km[i] |= 1ull << lb.allele;
+              placed = true;
+              nsites = i == nsites ? nsites + 1 : nsites;
             }
-            ws.ksite[gi][j][i] = lb.site;
-            ws.kmask[gi][j][i] = 0;
-            ++nsites;
-          }
-          ws.kmask[gi][j][i] |= 1ull << lb.allele;
+          bad = !placed; // more sites than the build takes
         }
       };
       uint32_t const c0 = s.cnt0[j];
@@ -338,12 +344,17 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
         for (uint32_t aw = 1; aw < 4; ++aw)
           total = (total == 0xFFFFFFFFu || j >= 4) ? 0xFFFFFFFFu : total + s.acnt[j][aw];
         hole = total == 0;
-        bad = !hole && total > E4::KS + 1;
+        bad = !hole && total > E4::AMB_LABELS;
         par = true;
         if (!bad && !hole)
-          for (uint32_t aw = 0; aw < 4; ++aw)
-            for (uint32_t k = 0; k < s.acnt[j][aw] && !bad; ++k)
-              take(total == 1 ? s.xl[j][0] : ix.labels[s.aoff[j][aw] + k], total == 1);
+        {
+          if (total == 1)
+            take(s.xl[j][0], true);
+          else if (E4::AMB_LABELS > 1)
+            for (uint32_t aw = 0; aw < 4; ++aw)
+              for (uint32_t k = 0; k < s.acnt[j][aw] && !bad; ++k)
+                take(ix.labels[s.aoff[j][aw] + k], false);
+        }
       }
       else if (!(bad = c0 > E4::KS || s.hcnt[j][0] > HE_CAP || s.hcnt[j][1] > HE_CAP))
       {
@@ -373,8 +384,10 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
         else
         {
           mm = c0 == 0;
-          for (uint32_t k = 0; k < n_own && !bad; ++k)
-            take(c0 == 1 ? s.xl[j][0] : ix.labels[(c0 ? s.off0[j] : nb_off) + k], n_own == 1);
+          uint32_t const own_off = c0 ? s.off0[j] : nb_off;
+          for (uint32_t k = 0; k < E4::KS; ++k)
+            if (k < n_own && !bad)
+              take(c0 == 1 ? s.xl[j][0] : ix.labels[own_off + k], n_own == 1);
           if (!bad && c0 != 0 && nb != 0)
           {
             // Neighbouring keys of an exact hit: the sites' other alleles.  They start chains with one more mismatch
@@ -390,9 +403,9 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
                   {
                     DevLabel const nl = ix.labels[he.off + k];
                     bool known = false;
-                    for (uint32_t i = 0; i < nsites; ++i)
-                      known = known || ws.ksite[gi][j][i] == nl.site;
-                    bad = bad || nl.start != l0.start || nl.end != l0.end || !known;
+                    for (uint32_t i = 0; i < E4::KS; ++i)
+                      known = known || (i < nsites && ks[i] == nl.site);
+                    bad = bad || nl.start != l0_start || nl.end != l0_end || !known;
                   }
               }
             par = true;
@@ -401,9 +414,23 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
         }
       }
       // labels on variants (also the only ones there are: e.g. an error inside a k-mer over a SNP)
-      bad = bad || (nsites != 0 && g.is_sv_graph != 0);
+      bad = bad || (nsites != 0 && (g.is_sv_graph != 0 || (s.nkeys0[j] != 1 && !E4::AMB_ON_VARIANT)));
       has_var = !bad && !hole && nsites != 0;
-      ws.kn[gi][j] = nsites;
+      if (!bad && !hole)
+      {
+        s.fs_start[j] = l0_start;
+        s.fs_end[j] = l0_end;
+      }
+      if (has_var)
+      {
+        ws.kn[gi][j] = nsites;
+        for (uint32_t i = 0; i < E4::KS; ++i)
+          if (i < nsites)
+          {
+            ws.ksite[gi][j][i] = ks[i];
+            ws.kmask[gi][j][i] = km[i];
+          }
+      }
       GTX_E4_NOTE(bad && s.nkeys0[j] != 1, 1); // a k-mer with ambiguous bases: several intervals / too many labels
       GTX_E4_NOTE(bad && s.nkeys0[j] == 1 && c0 > E4::KS, 4); // more exact labels than the build takes
       GTX_E4_NOTE(bad && s.nkeys0[j] == 1 && c0 <= E4::KS && (s.hcnt[j][0] > HE_CAP || s.hcnt[j][1] > HE_CAP), 5); // a crowded half-key bucket
@@ -532,7 +559,8 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
                 // The path ends ON a variant base: the walk starts inside the allele the path carries there (Graph::
                 // get_locations_of_a_position offers variant nodes the path has, graph.cpp:1154-1185), its first
                 // character is that base again, and its labels name the allele: the site moves to the front of the list.
-                for (uint32_t i = 0; i < ws.kn[gi][hi] && n == 0; ++i)
+                uint32_t const hi_sites = ((VAR >> (16 * gi + hi)) & 1ull) ? ws.kn[gi][hi] : 0u;
+                for (uint32_t i = 0; i < hi_sites && n == 0; ++i)
                 {
                   uint32_t const site = ws.ksite[gi][hi][i];
                   uint64_t const mask = ws.kmask[gi][hi][i];

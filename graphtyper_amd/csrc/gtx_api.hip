@@ -294,7 +294,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void gt
 }
 
 // the wide build: dense graphs (k-mers over several sites, tails over several SNPs)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void gtx_align_express4_wide_kernel(GTX_EXPRESS4_ARGS)
+#ifndef GTX_WIDE_WAVES
+#define GTX_WIDE_WAVES 4 // resident waves per SIMD the register budget is set for
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_WIDE_WAVES))) void gtx_align_express4_wide_kernel(GTX_EXPRESS4_ARGS)
 {
   express4_pass<Express4Wide>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, task_counter, queue, queue_count,
                               queue_all);
@@ -646,7 +649,7 @@ int ctx_upload(gtx_ctx & c, int device)
     c.express4_blocks_per_cu = per_cu;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express4_wide_kernel, 64, 0) == hipSuccess && per_cu > 0)
     c.express4_wide_blocks_per_cu = per_cu;
-  c.express4_wide = express4_prefers_wide(h.ref_len.data(), h.ref_nvar.data(), h.ref_len.size());
+  c.express4_wide = express4_prefers_wide(c.index);
   return GTX_OK;
 }
 

@@ -170,17 +170,18 @@ inline uint64_t plane_key(uint64_t key)
   return (hi << 32) | lo;
 }
 
-// Pass 1 of the alignment has a lean and a wide build (express4.inl); the wide one pays off when a k-mer or the walk at a
-// read's end often meets two variant sites: graphs with a site every < 200 bases on average.
-inline bool express4_prefers_wide(uint32_t const * ref_len, uint32_t const * ref_nvar, std::size_t n_ref)
+// Pass 1 of the alignment has a lean and a wide build (express4.inl).  The wide one runs ~45 % longer per read and
+// finishes the reads whose k-mers lie over two or more variant sites, which the lean one hands to the general pass at
+// ~20x the cost: it pays off once more than ~2 % of the indexed keys carry several labels (measured: a SNP every 100
+// bases at regular distances -- no such key -- is 17 % faster with the lean build, a SNP every 25 bases -- every read
+// has such a k-mer -- 1.8x faster with the wide one).
+inline bool express4_prefers_wide(HostIndex const & ix)
 {
-  uint64_t bases = 0, sites = 0;
-  for (std::size_t r = 0; r < n_ref; ++r)
-  {
-    bases += ref_len[r];
-    sites += ref_nvar[r] ? 1u : 0u;
-  }
-  return sites != 0 && bases / sites < 200;
+  uint64_t several = 0;
+  std::size_t const n = ix.keys.size();
+  for (std::size_t k = 0; k < n; ++k)
+    several += ix.key_off[k + 1] - ix.key_off[k] >= 2 ? 1u : 0u;
+  return n != 0 && several * 50 > n;
 }
 
 #if defined(__HIPCC__)

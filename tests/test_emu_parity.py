@@ -319,15 +319,23 @@ def express_variants_case(Backend, monkeypatch, n_reads):
         seq, lens = harness.pack_ragged(reads)
         flags = rng.choice([0, 1 | 64, 1 | 2 | 32 | 64], size=len(reads)).astype(np.uint16)
         meta = harness.read_meta(lens, flags=flags, isize=rng.integers(-2000, 2000, size=len(reads)))
-        monkeypatch.setenv("GTX_EXPRESS4", "0")
-        one = b.align(seq, meta).copy()
-        monkeypatch.setenv("GTX_EXPRESS4", "lean")
-        four = b.align(seq, meta).copy()
+        def run(mode):  # (long records go to the context's arena: rewound so that their offsets compare)
+            monkeypatch.setenv("GTX_EXPRESS4", mode)
+            b.rewind_big_records()
+            words = b.align(seq, meta).copy()
+            arena, _ = b.big_records()
+            return words, np.asarray(arena).copy()
+
+        one, one_arena = run("0")
+        four, four_arena = run("lean")
         assert np.array_equal(one, four)
-        monkeypatch.setenv("GTX_EXPRESS4", "wide")
-        wide = b.align(seq, meta).copy()
+        wide, wide_arena = run("wide")
         assert np.array_equal(one, wide)
         monkeypatch.delenv("GTX_EXPRESS4")
+        ext = ((four.reshape(-1, harness.REC_WORDS)[:, 0] >> 16) & gtx.ST_EXTERNAL) != 0
+        if ext.any():  # (the indel graph at the GPU suite's size has records longer than a slot)
+            used = int((four.reshape(-1, harness.REC_WORDS)[ext, 2]).max())
+            assert np.array_equal(one_arena[:used], four_arena[:used]) and np.array_equal(one_arena[:used], wide_arena[:used])
         assert ((four.reshape(-1, harness.REC_WORDS)[:, 0] & 0xFFFF) > 0).sum() > n_reads // 2
         o = Oracle(ref, recs, region_begin=1000, add_all_variants=aav)  # and both equal the oracle on the long reads
         tail = slice(len(reads) - 300, len(reads))
