@@ -80,8 +80,97 @@ struct WaveHip
     out.v = x - in.v;
   }
   static __device__ inline unsigned long long clock() { return clock64(); }
-  static __device__ inline uint32_t atomic_add_u32(uint32_t * p, uint32_t v) { return atomicAdd(p, v); }
+  static __device__ inline void atomic_add_u32(uint32_t * p, uint32_t v) { atomicAdd(p, v); }
   static __device__ inline void atomic_add_u64(unsigned long long * p, unsigned long long v) { atomicAdd(p, v); }
+  // next free slot of a log every lane appends to (fetch-and-increment).  The lanes that are here together ask with one
+  // atomic: a single device counter sustains ~90 M returning atomics a second, a dense graph wants more log entries.
+  static __device__ inline uint32_t atomic_claim_u32(uint32_t * p)
+  {
+    unsigned long long const here = __ballot(1);
+    uint32_t const lane = threadIdx.x & 63u, leader = static_cast<uint32_t>(__builtin_ctzll(here));
+    uint32_t base = 0;
+    if (lane == leader)
+      base = atomicAdd(p, static_cast<uint32_t>(__builtin_popcountll(here)));
+    base = __shfl(base, static_cast<int>(leader));
+    return base + static_cast<uint32_t>(__builtin_popcountll(here & ((1ull << lane) - 1ull)));
+  }
+};
+
+// Scoring adds small integers to per-(haplotype, sample) counters, and the reads of a workgroup -- neighbours in a
+// position-sorted stream -- hit the same few counters: 1 500 reads deep, every counter of a site would take thousands of
+// same-address atomics at the L2.  The workgroup therefore sums into an LDS table keyed by the counter's address first and
+// sends one atomic per (counter, workgroup visit) to memory.  Sums are order-free, so the accumulators come out the same.
+struct ScoreCombiner
+{
+  static constexpr uint32_t N = 1024, PROBES = 8;
+  unsigned long long key[N]; // counter address | 1 when the counter is 64 bits wide; 0 = free
+  unsigned long long val[N];
+};
+
+struct WaveHipCombine : WaveHip
+{
+  static __device__ inline ScoreCombiner & table()
+  {
+    __shared__ ScoreCombiner t;
+    return t;
+  }
+  static __device__ inline bool combine(unsigned long long key, unsigned long long v)
+  {
+    ScoreCombiner & t = table();
+    uint32_t h = static_cast<uint32_t>((key * 0x9E3779B97F4A7C15ull) >> 54) & (ScoreCombiner::N - 1);
+    for (uint32_t probe = 0; probe < ScoreCombiner::PROBES; ++probe)
+    {
+      unsigned long long const old = atomicCAS(&t.key[h], 0ull, key);
+      if (old == 0ull || old == key)
+      {
+        atomicAdd(&t.val[h], v);
+        return true;
+      }
+      h = (h + 1u) & (ScoreCombiner::N - 1);
+    }
+    return false; // crowded (many samples in one workgroup): straight to memory
+  }
+  static __device__ inline void atomic_add_u32(uint32_t * p, uint32_t v)
+  {
+    if (!combine(reinterpret_cast<unsigned long long>(p), v))
+      atomicAdd(p, v);
+  }
+  static __device__ inline void atomic_add_u64(unsigned long long * p, unsigned long long v)
+  {
+    if (!combine(reinterpret_cast<unsigned long long>(p) | 1ull, v))
+      atomicAdd(p, v);
+  }
+  // all threads of the workgroup
+  static __device__ inline void clear()
+  {
+    ScoreCombiner & t = table();
+    for (uint32_t i = threadIdx.x; i < ScoreCombiner::N; i += blockDim.x)
+    {
+      t.key[i] = 0;
+      t.val[i] = 0;
+    }
+    __syncthreads();
+  }
+  static __device__ inline void flush()
+  {
+    ScoreCombiner & t = table();
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < ScoreCombiner::N; i += blockDim.x)
+    {
+      unsigned long long const k = t.key[i];
+      if (k != 0ull)
+      {
+        unsigned long long const v = t.val[i];
+        if (k & 1ull)
+          atomicAdd(reinterpret_cast<unsigned long long *>(k & ~1ull), v);
+        else
+          atomicAdd(reinterpret_cast<uint32_t *>(k), static_cast<uint32_t>(v));
+        t.key[i] = 0;
+        t.val[i] = 0;
+      }
+    }
+    __syncthreads();
+  }
 };
 
 // Second pass: the workspace is in global memory, so the leader's stores must have completed (vmcnt) before the other
@@ -445,24 +534,31 @@ __global__ __launch_bounds__(256) void gtx_score_kernel(GraphView g, ScoreParams
                                                         uint32_t big_queue_cap, uint32_t * big_state)
 {
   uint32_t const n_work = work_count[0];
-  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_work; w += gridDim.x * blockDim.x)
+  WaveHipCombine::clear();
+  // (every thread of the workgroup makes the same number of visits: the table is flushed after each)
+  for (uint32_t first = blockIdx.x * blockDim.x; first < n_work; first += gridDim.x * blockDim.x)
   {
-    uint32_t const i = work_queue[w];
-    gtx_score_item const it = items[i];
-    RecentHap r1[SCORE_MAX_HAPS], r2[SCORE_MAX_HAPS];
-    if (score_item<WaveHip>(g, par, it, records, rec_words, acc, r1, r2, SCORE_MAX_HAPS))
-      continue;
-    // a read of this item touches more variant sites than the tables above hold (long results of the alignment's last
-    // pass): nothing was added yet, queue the item for gtx_score_big_kernel
-    uint32_t const slot = big_queue ? atomicAdd(big_state, 1u) : big_queue_cap;
-    if (slot < big_queue_cap)
-      big_queue[slot] = i;
-    else
-      atomicAdd(error_flag, 1u);
+    uint32_t const w = first + threadIdx.x;
+    if (w < n_work)
+    {
+      uint32_t const i = work_queue[w];
+      gtx_score_item const it = items[i];
+      RecentHap r1[SCORE_MAX_HAPS], r2[SCORE_MAX_HAPS];
+      if (!score_item<WaveHipCombine>(g, par, it, records, rec_words, acc, r1, r2, SCORE_MAX_HAPS))
+      {
+        // a read of this item touches more variant sites than the tables above hold (long results of the alignment's
+        // last pass): nothing was added yet, queue the item for gtx_score_big_kernel
+        uint32_t const slot = big_queue ? atomicAdd(big_state, 1u) : big_queue_cap;
+        if (slot < big_queue_cap)
+          big_queue[slot] = i;
+        else
+          atomicAdd(error_flag, 1u);
+      }
+    }
+    WaveHipCombine::flush();
   }
 }
 
-// Second scoring pass: the queued items over per-thread tables in HBM.
 __global__ __launch_bounds__(64) void gtx_score_big_kernel(GraphView g, ScoreParams par, gtx_score_item const * __restrict__ items,
                                                            uint32_t const * __restrict__ records, uint32_t rec_words, ScoreAcc acc,
                                                            uint32_t * error_flag, uint32_t const * __restrict__ big_queue,

@@ -243,7 +243,7 @@ GTX_DEV void emit_conn(ScoreAcc const & acc, uint32_t sample, uint32_t h1, uint3
 {
   if (count == 0)
     return;
-  uint32_t const slot = W::atomic_add_u32(acc.conn_count, 1u);
+  uint32_t const slot = W::atomic_claim_u32(acc.conn_count);
   if (slot >= acc.conn_cap)
   {
     W::atomic_add_u32(acc.conn_count + 1, 1u);

@@ -69,7 +69,8 @@ struct WaveEmu
     total = s;
   }
   static unsigned long long clock() { return 0; }
-  static uint32_t atomic_add_u32(uint32_t * p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+  static void atomic_add_u32(uint32_t * p, uint32_t v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+  static uint32_t atomic_claim_u32(uint32_t * p) { return __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
   static void atomic_add_u64(unsigned long long * p, unsigned long long v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 };
 
