@@ -138,10 +138,11 @@ def main():
                stat_u64=torch.zeros(nh + 2 * ctx.total_allele, dtype=torch.int64, device=device),
                stat_u32=torch.zeros(nh + 6 * ctx.total_allele, dtype=torch.int32, device=device),
                conn_log=torch.zeros(conn_cap * 6, dtype=torch.int32, device=device),
-               conn_count=torch.zeros(2, dtype=torch.int32, device=device))
+               conn_count=torch.zeros(2, dtype=torch.int32, device=device),
+               conn_near=torch.zeros(max(n_samples * ctx.total_near, 1), dtype=torch.int32, device=device))
     buf = gtx.ScoreBuffers(n_samples, acc["log_score"].data_ptr(), acc["gt_cov"].data_ptr(), acc["hap_u32"].data_ptr(),
                            acc["stat_u64"].data_ptr(), acc["stat_u32"].data_ptr(), acc["conn_log"].data_ptr(),
-                           acc["conn_count"].data_ptr(), conn_cap)
+                           acc["conn_count"].data_ptr(), conn_cap, acc["conn_near"].data_ptr())
     L = gtx.lib()
     stream = torch.cuda.Stream(device=device)
     sp = C.c_void_p(stream.cuda_stream)
@@ -160,7 +161,7 @@ def main():
             e1.record(stream)
             gtx.check(L.gtx_score_batch(ctx.h, d_items.data_ptr(), n, d_rec.data_ptr(), REC_WORDS, C.byref(buf), sp))
             if world > 1:
-                reduce_scores(dist, [acc["log_score"], acc["gt_cov"], acc["hap_u32"], acc["stat_u64"], acc["stat_u32"]])
+                reduce_scores(dist, [acc["log_score"], acc["gt_cov"], acc["hap_u32"], acc["stat_u64"], acc["stat_u32"], acc["conn_near"]])
             # genotype calls (PL, GT, GQ, depths) from the summed accumulators
             gtx.check(L.gtx_calls_batch(ctx.h, C.byref(buf), d_phred.data_ptr(), d_calls.data_ptr(), sp))
         return (e0, e1)
@@ -193,6 +194,7 @@ def main():
     n_nonref_calls = int((calls["gt_second"] > 0).sum())
     n_aligned = int(((rec_head[0::2] & 0xFFFF) > 0).sum().item())
     errors = ctx.error_count()
+    conn_logged, conn_dropped = (int(x) for x in acc["conn_count"].cpu().numpy())
 
     prof = ctx.profile()
     if rank == 0 and prof[15] > 0:
@@ -233,7 +235,7 @@ def main():
                                "(1 SNP / %d bp), unpaired, 0.5%% substitutions, 0.1%% N" % (n, READ_LEN, args.snp_every),
                    "reads_per_gpu": n, "index_keys": n_keys, "index_labels": n_labels, "haplotypes": ctx.n_hap,
                    "ctx_create_s": round(t_ctx, 3), "reads_aligned": n_aligned, "reads_overflowed": n_overflow, "nonref_genotype_calls": n_nonref_calls,
-                   "score_items_refused": errors, "parallelism": "reads sharded over %d GPU(s), graph+index replicated" % world},
+                   "score_items_refused": errors, "connections_logged": conn_logged, "connections_dropped": conn_dropped, "parallelism": "reads sharded over %d GPU(s), graph+index replicated" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": "gtx_align_express4_kernel", "kernel_ms": express_ms,
                      "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,

@@ -649,6 +649,8 @@ int ctx_upload(gtx_ctx & c, int device)
   ok = ok && upload(c.dev_allocs, v.dna, h.codes.data(), h.codes.size(), "dna codes");
   ok = ok && upload(c.dev_allocs, v.tri_off, h.tri_off.data(), h.tri_off.size(), "tri_off");
   ok = ok && upload(c.dev_allocs, v.allele_off, h.allele_off.data(), h.allele_off.size(), "allele_off");
+  ok = ok && upload(c.dev_allocs, v.near_last, h.near_last.data(), h.near_last.size(), "near_last");
+  ok = ok && upload(c.dev_allocs, v.near_off, h.near_off.data(), h.near_off.size(), "near_off");
   IndexView ix{};
   ix.log2_cap = c.index.log2_cap;
   ix.max_index_labels = static_cast<uint32_t>(c.params.max_index_labels);
@@ -941,6 +943,7 @@ extern "C" int gtx_score_batch(gtx_ctx * c, const gtx_score_item * d_items, uint
   a.stat_u32 = acc->d_stat_u32;
   a.conn_log = acc->d_conn_log;
   a.conn_count = acc->d_conn_count;
+  a.conn_near = acc->d_conn_near;
   a.big_records = c->d_big_records;
   ScoreParams par{static_cast<uint32_t>(c->params.is_sv_graph != 0), static_cast<uint32_t>(c->params.hq_reads != 0),
                   static_cast<uint32_t>(c->params.is_segment_calling != 0), 0};

@@ -94,6 +94,22 @@ extern "C"
     out->n_hap = c->graph.n_hap;
     out->total_tri = c->graph.total_tri;
     out->total_allele = c->graph.total_allele;
+    out->total_near = c->graph.total_near;
+    return GTX_OK;
+  }
+
+  int gtx_ctx_near_pairs(const gtx_ctx * c, uint32_t * near_last, uint64_t * near_off)
+  {
+    if (!c)
+      return GTX_ERR_ARG;
+    HostGraph const & g = c->graph;
+    for (uint32_t h = 0; h < g.n_hap; ++h)
+    {
+      if (near_last)
+        near_last[h] = g.near_last[h];
+      if (near_off)
+        near_off[h] = g.near_off[h];
+    }
     return GTX_OK;
   }
 
@@ -203,7 +219,7 @@ extern "C"
   // hts_parallel_reader.cpp:782-904.  Connection counts are uint16_t cells incremented without a guard in the reference
   // (vcf_writer.cpp:136), i.e. sums modulo 65536.
   int gtx_phase_flags(const gtx_ctx * c, uint32_t n_samples, const uint32_t * gt_cov, const uint32_t * conn_log, uint64_t n_conn,
-                      gtx_phase_entry * out, uint64_t cap, uint64_t * n_out)
+                      const uint32_t * conn_near, gtx_phase_entry * out, uint64_t cap, uint64_t * n_out)
   {
     if (!c || !gt_cov || (n_conn && !conn_log) || !n_out || (cap && !out))
       return GTX_ERR_ARG;
@@ -229,6 +245,33 @@ extern "C"
         v.assign(g.ref_nvar[e[3]], 0);
       v[e[4]] = static_cast<uint16_t>(v[e[4]] + e[5]);
     }
+    if (conn_near) // the dense counters of near pairs: a row exists as soon as one of its cells was counted
+      for (uint32_t s = 0; s < n_samples; ++s)
+        for (uint32_t h1 = 0; h1 < n_hap; ++h1)
+        {
+          uint32_t const last = g.near_last[h1];
+          if (last == h1)
+            continue;
+          uint64_t const first = g.allele_off[h1 + 1], width = g.allele_off[last] + g.ref_nvar[last] - first;
+          for (uint32_t a1 = 0; a1 < g.ref_nvar[h1]; ++a1)
+          {
+            uint32_t const * row = conn_near + s * g.total_near + g.near_off[h1] + a1 * width;
+            for (uint32_t h2 = h1 + 1; h2 <= last; ++h2)
+            {
+              uint32_t const * cell = row + (g.allele_off[h2] - first);
+              bool any = false;
+              for (uint32_t a2 = 0; a2 < g.ref_nvar[h2]; ++a2)
+                any = any || cell[a2] != 0;
+              if (!any)
+                continue;
+              auto & v = conn[Key{s, h1, a1, h2}];
+              if (v.empty())
+                v.assign(g.ref_nvar[h2], 0);
+              for (uint32_t a2 = 0; a2 < g.ref_nvar[h2]; ++a2)
+                v[a2] = static_cast<uint16_t>(v[a2] + cell[a2]);
+            }
+          }
+        }
     constexpr int8_t HAP = 1, ANTI = 2; // IS_ANY_HAP_SUPPORT, IS_ANY_ANTI_HAP_SUPPORT (constants.hpp.in:56-57)
     using PhKey = std::pair<uint16_t, uint16_t>;
     std::map<PhKey, std::map<PhKey, int8_t>> ph;

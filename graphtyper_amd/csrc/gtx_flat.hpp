@@ -76,6 +76,11 @@ struct GraphView
   const uint64_t * allele_off; // [n_ref]
   uint64_t total_tri, total_allele;
   uint32_t n_hap, pad1;
+  // connections between near sites (hts_parallel_reader.cpp:800-801 reads pairs less than 100 positions apart): site r's
+  // window is the sites r+1 .. near_last[r]; its counters are a [cnum(r)] x [alleles of the window] block at near_off[r]
+  const uint32_t * near_last; // [n_ref] (= r when the window is empty)
+  const uint64_t * near_off;  // [n_ref]
+  uint64_t total_near;
   unsigned long long * prof; // [32] phase cycle counters, only written by the GTX_PROF build (libgtx_prof.so)
 };
 
@@ -109,10 +114,11 @@ struct HostGraph
   std::vector<uint32_t> pos_node;
   std::vector<uint32_t> event_off; // [2*n_var+1] (empty when the graph has no events)
   std::vector<int64_t> event_val;
-  std::vector<uint64_t> tri_off, allele_off;
+  std::vector<uint64_t> tri_off, allele_off, near_off;
+  std::vector<uint32_t> near_last;
   std::string dna;   // characters (index construction)
   std::string codes; // the same arena as comparison codes (kernels)
-  uint64_t total_tri = 0, total_allele = 0;
+  uint64_t total_tri = 0, total_allele = 0, total_near = 0;
   uint32_t n_hap = 0;
   uint32_t padding = 1000;
   bool is_sv_graph = false;

@@ -51,6 +51,9 @@ GraphView HostGraph::view() const
   v.allele_off = allele_off.data();
   v.total_tri = total_tri;
   v.total_allele = total_allele;
+  v.near_last = near_last.data();
+  v.near_off = near_off.data();
+  v.total_near = total_near;
   v.n_hap = n_hap;
   return v;
 }
@@ -213,6 +216,19 @@ std::string flatten_graph(gtx_graph_view const & g, gtx_params const & par, Host
     out.allele_off[r] = out.total_allele;
     out.total_tri += c * (c + 1) / 2;
     out.total_allele += c;
+  }
+  // windows of the near-pair connection counters: the haplotypes whose order is < 100 above this one's
+  out.near_last.assign(R, 0);
+  out.near_off.assign(R, 0);
+  for (uint32_t r = 0; r + 1 < R; ++r)
+  {
+    uint32_t last = r;
+    uint64_t const order = out.var_order[out.ref_first_var[r]];
+    while (last + 2 < R && out.var_order[out.ref_first_var[last + 1]] < order + 100)
+      ++last;
+    out.near_last[r] = last;
+    out.near_off[r] = out.total_near;
+    out.total_near += static_cast<uint64_t>(out.ref_nvar[r]) * (out.allele_off[last] + out.ref_nvar[last] - out.allele_off[r] - out.ref_nvar[r]);
   }
   return "";
 }

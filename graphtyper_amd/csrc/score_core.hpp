@@ -235,14 +235,24 @@ struct ScoreAcc // device pointers, see gtx_score_buffers in include/gtx.h
   uint32_t * stat_u32;
   uint32_t * conn_log;
   uint32_t * conn_count;
+  uint32_t * conn_near; // NULL: every connection is logged
   uint32_t const * big_records; // the context's arena for records longer than rec_words
 };
 
 template <class W>
-GTX_DEV void emit_conn(ScoreAcc const & acc, uint32_t sample, uint32_t h1, uint32_t b1, uint32_t h2, uint32_t b2, uint32_t count)
+GTX_DEV void emit_conn(GraphView const & g, ScoreAcc const & acc, uint32_t sample, uint32_t h1, uint32_t b1, uint32_t h2, uint32_t b2,
+                       uint32_t count)
 {
   if (count == 0)
     return;
+  if (acc.conn_near && h2 > h1 && h2 <= g.near_last[h1])
+  {
+    // a pair genotyping reads (hts_parallel_reader.cpp:800-801): dense counters, no log entry
+    uint64_t const first = g.allele_off[h1 + 1];
+    uint64_t const width = g.allele_off[g.near_last[h1]] + g.ref_nvar[g.near_last[h1]] - first;
+    W::atomic_add_u32(acc.conn_near + sample * g.total_near + g.near_off[h1] + b1 * width + (g.allele_off[h2] - first) + b2, count);
+    return;
+  }
   uint32_t const slot = W::atomic_claim_u32(acc.conn_count);
   if (slot >= acc.conn_cap)
   {
@@ -339,7 +349,7 @@ GTX_DEV void apply_recent(GraphView const & g, ScoreAcc const & acc, Geno const 
         continue;
       for (uint64_t m1 = recent[a].explains; m1; m1 &= m1 - 1)
         for (uint64_t m2 = recent[b].explains; m2; m2 &= m2 - 1)
-          emit_conn<W>(acc, sample, recent[a].site, static_cast<uint32_t>(__builtin_ctzll(m1)), recent[b].site,
+          emit_conn<W>(g, acc, sample, recent[a].site, static_cast<uint32_t>(__builtin_ctzll(m1)), recent[b].site,
                        static_cast<uint32_t>(__builtin_ctzll(m2)), repeat);
     }
   }
@@ -568,9 +578,9 @@ GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_
         {
           uint32_t const b1 = static_cast<uint32_t>(__builtin_ctzll(m1)), b2 = static_cast<uint32_t>(__builtin_ctzll(m2));
           if (fwd)
-            emit_conn<W>(acc, it.sample, r1[a].site, b1, r2[b].site, b2, 1);
+            emit_conn<W>(g, acc, it.sample, r1[a].site, b1, r2[b].site, b2, 1);
           else
-            emit_conn<W>(acc, it.sample, r2[b].site, b2, r1[a].site, b1, 1);
+            emit_conn<W>(g, acc, it.sample, r2[b].site, b2, r1[a].site, b1, 1);
         }
     }
   }

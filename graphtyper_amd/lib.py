@@ -20,7 +20,7 @@ ST_ERROR_MASK = 15
 
 # names every build of libgtx.so must export (checked by tests/test_abi.py against include/gtx.h)
 EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy", "gtx_ctx_special_positions",
-           "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_index_stats", "gtx_index_get", "gtx_index_dump",
+           "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_ctx_near_pairs", "gtx_index_stats", "gtx_index_get", "gtx_index_dump",
            "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_pass_times", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_set_coverage", "gtx_stream_finish", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
            "gtx_graph_destroy"]
@@ -41,13 +41,13 @@ class Params(C.Structure):
 
 
 class ScoreLayout(C.Structure):
-    _fields_ = [("n_hap", C.c_uint32), ("total_tri", C.c_uint64), ("total_allele", C.c_uint64)]
+    _fields_ = [("n_hap", C.c_uint32), ("total_tri", C.c_uint64), ("total_allele", C.c_uint64), ("total_near", C.c_uint64)]
 
 
 class ScoreBuffers(C.Structure):
     _fields_ = [("n_samples", C.c_uint32), ("d_log_score", C.c_void_p), ("d_gt_cov", C.c_void_p), ("d_hap_u32", C.c_void_p),
                 ("d_stat_u64", C.c_void_p), ("d_stat_u32", C.c_void_p), ("d_conn_log", C.c_void_p),
-                ("d_conn_count", C.c_void_p), ("conn_cap", C.c_uint32)]
+                ("d_conn_count", C.c_void_p), ("conn_cap", C.c_uint32), ("d_conn_near", C.c_void_p)]
 
 
 READ_META = np.dtype([("l_qseq", np.uint16), ("flag", np.uint16), ("tid", np.int32), ("mtid", np.int32), ("isize", np.int32)], align=True)
@@ -113,8 +113,9 @@ def lib():
         L.gtx_ctx_profile.argtypes = [C.c_void_p, C.c_void_p]
         L.gtx_scores_finalize.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                           C.POINTER(C.c_uint64)]
-        L.gtx_phase_flags.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+        L.gtx_phase_flags.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
                                       C.POINTER(C.c_uint64)]
+        L.gtx_ctx_near_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.gtx_stream_create.argtypes = [C.POINTER(Params), C.c_uint32, C.POINTER(C.c_void_p)]
         L.gtx_stream_destroy.argtypes = [C.c_void_p]
         L.gtx_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
@@ -303,11 +304,15 @@ class Context:
         lay = ScoreLayout()
         check(L.gtx_ctx_score_layout(self.h, C.byref(lay)))
         self.n_hap, self.total_tri, self.total_allele = int(lay.n_hap), int(lay.total_tri), int(lay.total_allele)
+        self.total_near = int(lay.total_near)
         self.hap_order = np.zeros(self.n_hap, np.uint32)
         self.hap_cnum = np.zeros(self.n_hap, np.uint32)
         self.tri_off = np.zeros(self.n_hap, np.uint64)
         self.allele_off = np.zeros(self.n_hap, np.uint64)
         check(L.gtx_ctx_haplotypes(self.h, _p(self.hap_order), _p(self.hap_cnum), _p(self.tri_off), _p(self.allele_off)))
+        self.near_last = np.zeros(self.n_hap, np.uint32)  # layout of the near-pair connection counters (d_conn_near)
+        self.near_off = np.zeros(self.n_hap, np.uint64)
+        check(L.gtx_ctx_near_pairs(self.h, _p(self.near_last), _p(self.near_off)))
 
     def close(self):
         if getattr(self, "h", None):
@@ -375,16 +380,19 @@ class Context:
     def rewind_big_records(self):
         check(lib().gtx_ctx_big_records_rewind(self.h, None))
 
-    def phase_flags(self, n_samples, gt_cov, conn_log, n_conn):
+    def phase_flags(self, n_samples, gt_cov, conn_log, n_conn, conn_near=None):
         """gtx_phase_flags: rows (hap1, allele1, hap2, allele2, flags) as an int array [n, 5]"""
         gt_cov = np.ascontiguousarray(gt_cov, np.uint32)
         conn_log = np.ascontiguousarray(conn_log, np.uint32)
+        if conn_near is not None:
+            conn_near = np.ascontiguousarray(conn_near, np.uint32)
+            assert len(conn_near) == n_samples * self.total_near
         n = C.c_uint64()
         cap = 1024
         while True:
             out = np.zeros(cap, PHASE_ENTRY)
-            rc = lib().gtx_phase_flags(self.h, n_samples, _p(gt_cov), _p(conn_log), C.c_uint64(n_conn), _p(out), C.c_uint64(cap),
-                                       C.byref(n))
+            rc = lib().gtx_phase_flags(self.h, n_samples, _p(gt_cov), _p(conn_log), C.c_uint64(n_conn),
+                                       _p(conn_near) if conn_near is not None else None, _p(out), C.c_uint64(cap), C.byref(n))
             if rc == 5 and n.value > cap:  # GTX_ERR_CAPACITY
                 cap = int(n.value)
                 continue

@@ -190,6 +190,7 @@ typedef struct gtx_score_layout
   uint32_t n_hap;        /* = number of variant sites = Graph::get_all_haplotypes().size() */
   uint64_t total_tri;    /* sum over haplotypes of cnum*(cnum+1)/2 */
   uint64_t total_allele; /* sum over haplotypes of cnum */
+  uint64_t total_near;   /* connection counters between near haplotypes (gtx_ctx_near_pairs) */
 } gtx_score_layout;
 
 const char * gtx_strerror(int status);
@@ -205,6 +206,8 @@ int gtx_ctx_special_positions(const gtx_ctx *, uint32_t * n_special, uint32_t * 
 int gtx_ctx_score_layout(const gtx_ctx *, gtx_score_layout * out);
 /* hap_order[n_hap], hap_cnum[n_hap], tri_off[n_hap], allele_off[n_hap] */
 int gtx_ctx_haplotypes(const gtx_ctx *, uint32_t * hap_order, uint32_t * hap_cnum, uint64_t * tri_off, uint64_t * allele_off);
+/* layout of d_conn_near: near_last[n_hap], near_off[n_hap] */
+int gtx_ctx_near_pairs(const gtx_ctx *, uint32_t * near_last, uint64_t * near_off);
 
 /* Index inspection (host copy, reference order): PHIndex::get(key) */
 int gtx_index_stats(const gtx_ctx *, uint64_t * n_keys, uint64_t * n_labels);
@@ -240,6 +243,12 @@ int gtx_align_batch(gtx_ctx *, const uint8_t * d_seq, uint32_t seq_stride, const
  *   d_stat_u64  [n_hap + 2*total_allele]     per hap mapq_squared; per allele clipped_bp, mapq_squared
  *   d_stat_u32  [n_hap + 6*total_allele]     per hap clipped_reads; per allele score_diff, mismatches, r1f, r1r, r2f, r2r
  *   d_conn_log  [conn_cap * 6]               appended (sample, hap1, allele1, hap2, allele2, count); d_conn_count[0] = entries
+ *   d_conn_near [n_samples * total_near]     or NULL.  HapSample::connections between haplotypes less than 100 positions apart
+ *                                            (the only ones genotyping reads, hts_parallel_reader.cpp:800-801) as dense counters:
+ *                                            haplotype h with the haplotypes h+1 .. near_last[h], entry near_off[h] +
+ *                                            allele1 * (alleles of the window) + (allele_off[h2] - allele_off[h+1]) + allele2.
+ *                                            With it only the farther pairs (two mates, dense graphs) go to d_conn_log -- a log
+ *                                            entry per read and pair does not scale to dense graphs; NULL: everything is logged.
  * Sums are unsaturated; gtx_scores_finalize applies the reference's saturation rules. */
 typedef struct gtx_score_buffers
 {
@@ -252,6 +261,7 @@ typedef struct gtx_score_buffers
   uint32_t * d_conn_log;
   uint32_t * d_conn_count; /* [2]: entries appended, entries dropped because conn_cap was reached */
   uint32_t conn_cap;
+  uint32_t * d_conn_near;
 } gtx_score_buffers;
 
 int gtx_score_batch(gtx_ctx *, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records,
@@ -301,7 +311,8 @@ int gtx_scores_finalize(uint32_t * log_score, uint64_t n_log, uint32_t * gt_cov,
 
 /* Phasing flags between alt alleles of variant sites less than 100 bp apart: replaces the `ph` construction of
  * parallel_reader_genotype_only (src/utilities/hts_parallel_reader.cpp:782-904).  Host only.
- * gt_cov: finalised d_gt_cov; conn_log / n_conn: the downloaded connection log.  Rows come in the order of the reference's
+ * gt_cov: finalised d_gt_cov; conn_log / n_conn: the downloaded connection log; conn_near: the downloaded d_conn_near (or
+ * NULL when the batches were scored without it).  Rows come in the order of the reference's
  * std::map (hap1, allele1, hap2, allele2); an outer key that exists without any flag under it (the reference inserts it
  * as soon as a connection exists) is one row with hap2 = allele2 = 0xFFFF, flags = 0.
  * flags: 1 = IS_ANY_HAP_SUPPORT, 2 = IS_ANY_ANTI_HAP_SUPPORT (include/graphtyper/constants.hpp.in:56-57), or-ed over samples.
@@ -313,6 +324,7 @@ typedef struct gtx_phase_entry
   uint8_t reserved;
 } gtx_phase_entry;
 int gtx_phase_flags(const gtx_ctx *, uint32_t n_samples, const uint32_t * gt_cov, const uint32_t * conn_log, uint64_t n_conn,
+                    const uint32_t * conn_near, /* the downloaded d_conn_near or NULL */
                     gtx_phase_entry * out, uint64_t cap, uint64_t * n);
 
 /* ---- host mirror of the per-record control flow (no device work) ----

@@ -297,6 +297,7 @@ extern "C"
     a.stat_u32 = acc->d_stat_u32;
     a.conn_log = acc->d_conn_log;
     a.conn_count = acc->d_conn_count;
+    a.conn_near = acc->d_conn_near;
     a.big_records = e.arena.data();
     ScoreParams par{static_cast<uint32_t>(e.params.is_sv_graph != 0), static_cast<uint32_t>(e.params.hq_reads != 0),
                     static_cast<uint32_t>(e.params.is_segment_calling != 0), 0};

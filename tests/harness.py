@@ -21,7 +21,7 @@ def _p(a):
 class Accumulators:
     """host copy of the score accumulators (layout: include/gtx.h, gtx_score_buffers)"""
 
-    def __init__(self, ctx, n_samples, conn_cap=1 << 20):
+    def __init__(self, ctx, n_samples, conn_cap=1 << 20, near=True):
         self.n_samples = n_samples
         self.conn_cap = conn_cap
         self.log_score = np.zeros(n_samples * ctx.total_tri, np.uint32)
@@ -31,9 +31,16 @@ class Accumulators:
         self.stat_u32 = np.zeros(ctx.n_hap + 6 * ctx.total_allele, np.uint32)
         self.conn_log = np.zeros(conn_cap * 6, np.uint32)
         self.conn_count = np.zeros(2, np.uint32)
+        # dense counters of the connections between near haplotypes; without them every connection goes to the log
+        self.conn_near = np.zeros(n_samples * ctx.total_near, np.uint32) if near else None
 
     def arrays(self):
-        return [self.log_score, self.gt_cov, self.hap_u32, self.stat_u64, self.stat_u32, self.conn_log, self.conn_count]
+        a = [self.log_score, self.gt_cov, self.hap_u32, self.stat_u64, self.stat_u32, self.conn_log, self.conn_count]
+        return a + ([self.conn_near] if self.conn_near is not None else [])
+
+    def buffers(self, pointers):
+        """gtx_score_buffers over `pointers` (one per array of arrays(), host or device)"""
+        return gtx.ScoreBuffers(self.n_samples, *pointers[:7], self.conn_cap, pointers[7] if self.conn_near is not None else None)
 
 
 class EmuBackend:
@@ -73,19 +80,17 @@ class EmuBackend:
         tasks = int(self.L.emu_second_pass_tasks(C.c_void_p(self.h)))
         return np.ctypeslib.as_array(ptr, shape=(int(cap.value),)).copy(), tasks
 
-    def score(self, items, records, n_samples=1, rec_words=REC_WORDS):
+    def score(self, items, records, n_samples=1, rec_words=REC_WORDS, near=True):
         items = np.ascontiguousarray(items, gtx.SCORE_ITEM)
-        acc = Accumulators(self.ctx, n_samples)
-        buf = gtx.ScoreBuffers(n_samples, _p(acc.log_score), _p(acc.gt_cov), _p(acc.hap_u32), _p(acc.stat_u64), _p(acc.stat_u32),
-                               _p(acc.conn_log), _p(acc.conn_count), acc.conn_cap)
+        acc = Accumulators(self.ctx, n_samples, near=near)
+        buf = acc.buffers([_p(a) for a in acc.arrays()])
         errors = self.L.emu_score(C.c_void_p(self.h), _p(items), C.c_uint32(len(items)), _p(records), C.c_uint32(rec_words), C.byref(buf))
         assert errors == 0
         return acc
 
     def calls(self, acc, n_samples):
         """gtx_calls_batch contract on the host: (phred [n_samples * total_tri] u8, SAMPLE_CALL [n_samples * n_hap])"""
-        buf = gtx.ScoreBuffers(n_samples, _p(acc.log_score), _p(acc.gt_cov), _p(acc.hap_u32), _p(acc.stat_u64), _p(acc.stat_u32),
-                               _p(acc.conn_log), _p(acc.conn_count), acc.conn_cap)
+        buf = acc.buffers([_p(a) for a in acc.arrays()])
         phred = np.zeros(n_samples * self.ctx.total_tri, np.uint8)
         calls = np.zeros(n_samples * self.ctx.n_hap, gtx.SAMPLE_CALL)
         self.L.emu_calls(C.c_void_p(self.h), C.byref(buf), _p(phred), _p(calls))
@@ -124,14 +129,14 @@ class GpuBackend:
     def rewind_big_records(self):
         self.ctx.rewind_big_records()
 
-    def score(self, items, records, n_samples=1, rec_words=REC_WORDS):
+    def score(self, items, records, n_samples=1, rec_words=REC_WORDS, near=True):
         torch = self.torch
         items = np.ascontiguousarray(items, gtx.SCORE_ITEM)
-        acc = Accumulators(self.ctx, n_samples)
+        acc = Accumulators(self.ctx, n_samples, near=near)
         d_items = self._dev(items)
         d_rec = self._dev(np.ascontiguousarray(records, np.uint32))
         devs = [self._dev(a) for a in acc.arrays()]
-        buf = gtx.ScoreBuffers(n_samples, *[d.data_ptr() for d in devs], acc.conn_cap)
+        buf = acc.buffers([d.data_ptr() for d in devs])
         gtx.check(gtx.lib().gtx_score_batch(self.ctx.h, d_items.data_ptr(), len(items), d_rec.data_ptr(), rec_words, C.byref(buf),
                                             None))
         torch.cuda.synchronize()
@@ -143,7 +148,7 @@ class GpuBackend:
     def calls(self, acc, n_samples):
         torch = self.torch
         devs = [self._dev(a) for a in acc.arrays()]
-        buf = gtx.ScoreBuffers(n_samples, *[d.data_ptr() for d in devs], acc.conn_cap)
+        buf = acc.buffers([d.data_ptr() for d in devs])
         d_phred = torch.zeros(max(n_samples * self.ctx.total_tri, 1), dtype=torch.uint8, device="cuda:0")
         d_calls = torch.zeros(max(n_samples * self.ctx.n_hap, 1) * gtx.SAMPLE_CALL.itemsize, dtype=torch.uint8, device="cuda:0")
         gtx.check(gtx.lib().gtx_calls_batch(self.ctx.h, C.byref(buf), d_phred.data_ptr(), d_calls.data_ptr(), None))
@@ -198,6 +203,23 @@ def canonical_scores(ctx, acc):
         d = conn.setdefault((int(s), int(h1), int(b1)), {})
         v = d.setdefault(int(h2), np.zeros(int(ctx.hap_cnum[h2]), np.int64))
         v[int(b2)] += int(c)
+    if acc.conn_near is not None:  # dense counters of the near pairs (layout: include/gtx.h, d_conn_near)
+        near = acc.conn_near.reshape(acc.n_samples, ctx.total_near) if ctx.total_near else np.zeros((acc.n_samples, 0), np.uint32)
+        for s in range(acc.n_samples):
+            for h1 in np.nonzero(ctx.near_last > np.arange(ctx.n_hap))[0]:
+                h1, last = int(h1), int(ctx.near_last[h1])
+                first = int(ctx.allele_off[h1 + 1])
+                width = int(ctx.allele_off[last]) + int(ctx.hap_cnum[last]) - first
+                block = near[s, int(ctx.near_off[h1]):int(ctx.near_off[h1]) + int(ctx.hap_cnum[h1]) * width].reshape(-1, width)
+                if not block.any():
+                    continue
+                for b1 in range(int(ctx.hap_cnum[h1])):
+                    for h2 in range(h1 + 1, last + 1):
+                        cell = block[b1, int(ctx.allele_off[h2]) - first:int(ctx.allele_off[h2]) - first + int(ctx.hap_cnum[h2])]
+                        if cell.any():
+                            d = conn.setdefault((s, h1, b1), {})
+                            v = d.setdefault(h2, np.zeros(int(ctx.hap_cnum[h2]), np.int64))
+                            v += cell.astype(np.int64)
     out = []
     nh = ctx.n_hap
 

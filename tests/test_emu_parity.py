@@ -97,6 +97,11 @@ def run_stream(backend, oracle, codes, rec, n_samples, n_rg=1):
     assert len(got) == len(want)
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, "score streams differ at words %s" % bad[:10]
+    # connections between near sites went to the dense counters; without them every pair is logged: same content
+    acc_log = backend.score(items, records, n_samples, near=False)
+    assert np.array_equal(harness.canonical_scores(backend.ctx, acc_log), got)
+    assert int(acc.conn_count[0]) <= int(acc_log.conn_count[0])
+    run_stream.logged = (int(acc.conn_count[0]), int(acc_log.conn_count[0]))
     # genotype calls: PL, GT, GQ, depths per haplotype and sample (vcf.cpp:47-82, sample_call.cpp:34-131)
     phred, calls = backend.calls(acc, n_samples)
     got_calls, want_calls = harness.canonical_calls(backend.ctx, phred, calls, n_samples), og.calls()
@@ -104,7 +109,7 @@ def run_stream(backend, oracle, codes, rec, n_samples, n_rg=1):
     assert len(np.unique(phred)) > 5 and (calls["gt_second"] > 0).any()  # not vacuous
     # phasing flags from the finalised depths and the connection log (hts_parallel_reader.cpp:782-904)
     gt_cov = np.minimum(acc.gt_cov, 0xFFFF).astype(np.uint32)
-    ph = backend.ctx.phase_flags(n_samples, gt_cov, acc.conn_log, int(acc.conn_count[0]))
+    ph = backend.ctx.phase_flags(n_samples, gt_cov, acc.conn_log, int(acc.conn_count[0]), acc.conn_near)
     want_ph = og.phase_flags()
     assert ph.shape == want_ph.shape and np.array_equal(ph, want_ph), "phase flags differ"
     run_stream.last_phase_rows = len(ph)

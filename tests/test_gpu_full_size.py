@@ -35,10 +35,11 @@ def _buffers(torch, ctx, device, conn_cap=1 << 24):
                stat_u64=torch.zeros(nh + 2 * ctx.total_allele, dtype=torch.int64, device=device),
                stat_u32=torch.zeros(nh + 6 * ctx.total_allele, dtype=torch.int32, device=device),
                conn_log=torch.zeros(conn_cap * 6, dtype=torch.int32, device=device),
-               conn_count=torch.zeros(2, dtype=torch.int32, device=device))
+               conn_count=torch.zeros(2, dtype=torch.int32, device=device),
+               conn_near=torch.zeros(max(ctx.total_near, 1), dtype=torch.int32, device=device))
     buf = gtx.ScoreBuffers(1, acc["log_score"].data_ptr(), acc["gt_cov"].data_ptr(), acc["hap_u32"].data_ptr(),
                            acc["stat_u64"].data_ptr(), acc["stat_u32"].data_ptr(), acc["conn_log"].data_ptr(),
-                           acc["conn_count"].data_ptr(), conn_cap)
+                           acc["conn_count"].data_ptr(), conn_cap, acc["conn_near"].data_ptr())
     return acc, buf
 
 
@@ -128,7 +129,7 @@ def test_cfg2_full_size_properties():
     whole, ph_w, ca_w = score([d_items])
     halves, ph_h, ca_h = score([d_items[: n // 2], d_items[n // 2:]])
     back, ph_b, ca_b = score([torch.flip(d_items, dims=[0]).contiguous()])
-    for name in ("log_score", "gt_cov", "hap_u32", "stat_u64", "stat_u32"):
+    for name in ("log_score", "gt_cov", "hap_u32", "stat_u64", "stat_u32", "conn_near"):
         assert torch.equal(whole[name], halves[name]), name + ": whole batch != its two halves"
         assert torch.equal(whole[name], back[name]), name + ": depends on the item order"
     assert torch.equal(ph_w, ph_h) and torch.equal(ca_w, ca_h) and torch.equal(ph_w, ph_b) and torch.equal(ca_w, ca_b)
