@@ -314,7 +314,8 @@ __device__ __forceinline__ void express4_pass(GraphView const & g, IndexView con
                                               uint32_t * __restrict__ queue, uint32_t * queue_count, uint32_t queue_all)
 {
   __shared__ Express4Workspace<E4> ws;
-  __shared__ uint32_t pending[2 * TASK_CHUNK];
+  __shared__ uint8_t pending[2 * TASK_CHUNK]; // tasks handed on, as offsets from the chunk's first task
+  static_assert(2 * TASK_CHUNK <= 256, "pending[] holds task offsets as bytes");
   uint32_t const lane = threadIdx.x & 63u;
   for (;;)
   {
@@ -348,13 +349,13 @@ __device__ __forceinline__ void express4_pass(GraphView const & g, IndexView con
         if ((fwd_mask >> k) & 1u)
         {
           if (lane == 0)
-            pending[n_pending] = (first + k) * 2;
+            pending[n_pending] = static_cast<uint8_t>((first + k - base) * 2);
           ++n_pending;
         }
         if ((REV >> (16 * k)) & 1ull)
         {
           if (lane == 0)
-            pending[n_pending] = (first + k) * 2 + 1;
+            pending[n_pending] = static_cast<uint8_t>((first + k - base) * 2 + 1);
           ++n_pending;
         }
       }
@@ -364,7 +365,7 @@ __device__ __forceinline__ void express4_pass(GraphView const & g, IndexView con
       WaveHip::lds_sync();
       uint32_t const at = wave_claim(queue_count, n_pending); // (the queue has room for every task)
       for (uint32_t k = lane; k < n_pending; k += 64)
-        queue[at + k] = pending[k];
+        queue[at + k] = base * 2 + pending[k];
       WaveHip::lds_sync();
     }
   }
@@ -376,7 +377,10 @@ __device__ __forceinline__ void express4_pass(GraphView const & g, IndexView con
     uint32_t *__restrict__ queue, uint32_t *queue_count, uint32_t queue_all
 
 // the lean build: graphs whose variant sites lie far apart (ctx_upload picks by the mean distance between sites)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void gtx_align_express4_kernel(GTX_EXPRESS4_ARGS)
+#ifndef GTX_LEAN_WAVES
+#define GTX_LEAN_WAVES 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_LEAN_WAVES))) void gtx_align_express4_kernel(GTX_EXPRESS4_ARGS)
 {
   express4_pass<Express4Lean>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, task_counter, queue, queue_count,
                               queue_all);
