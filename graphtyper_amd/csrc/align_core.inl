@@ -1146,9 +1146,10 @@ GTX_DEV uint32_t expand_keys(uint8_t const * rd, uint32_t at, uint64_t * keys, u
     uint32_t const origin = n;
     if (origin > 97)
       return 0;
-    if (4 * origin > cap)
-      return 0xFFFFFFFFu; // the list may outgrow this pass' key buffer
     uint32_t const code = rd[at + t] & 15u;
+    uint32_t const fan = (code == 15u || code == 0u) ? 4u : static_cast<uint32_t>(__builtin_popcount(code));
+    if (fan * origin > cap)
+      return 0xFFFFFFFFu; // the list outgrows this pass' key buffer
     auto with = [t](uint64_t k, uint64_t b) { return k | ((b & 1u) << t) | ((b >> 1) << (32 + t)); };
     for (uint32_t u = 0; u < origin; ++u)
     {

@@ -458,14 +458,33 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
     uint32_t lo = 0, hi = n_k ? n_k - 1 : 0;
     if (ok && hole != 0)
     {
-      uint32_t const h = static_cast<uint32_t>(__builtin_ctz(hole));
-      uint32_t const left = h, right = n_k - 1 - h; // k-mers on either side
-      ok = (hole & (hole - 1u)) == 0 && left != right;
-      if (left > right)
-        hi = h - 1;
-      else
-        lo = h + 1;
-      // A run that starts (after the hole) with a multi-key k-mer, or with a k-mer on a variant whose other alleles are
+      // the longest run of k-mers with labels; it has to be the only one of its length
+      uint32_t best_lo = 0, best_len = 0, second = 0, cur_lo = 0, cur_len = 0;
+      for (uint32_t k = 0; k <= KC; ++k)
+      {
+        bool const labelled = k < n_k && ((hole >> k) & 1u) == 0;
+        if (labelled)
+        {
+          cur_lo = cur_len == 0 ? k : cur_lo;
+          ++cur_len;
+        }
+        else
+        {
+          if (cur_len > best_len)
+          {
+            second = best_len;
+            best_len = cur_len;
+            best_lo = cur_lo;
+          }
+          else if (cur_len > second)
+            second = cur_len;
+          cur_len = 0;
+        }
+      }
+      ok = best_len > second;
+      lo = best_lo;
+      hi = best_lo + (best_len ? best_len - 1 : 0);
+      // A run that starts (after a hole) with a multi-key k-mer, or with a k-mer on a variant whose other alleles are
       // indexed, starts with parallel chains (the list's +1-mismatch copy, the other alleles); the start walk then yields
       // one label list per chain, the later lists find no chain left to merge with, become paths of their own and are
       // walked to duplicates of the result (the reference really returns the path twice): left to pass 2.
