@@ -152,8 +152,9 @@ def main():
 
     def step(timed):
         with torch.cuda.stream(stream):
-            for t in acc.values():
-                t.zero_()
+            for name, t in acc.items():
+                if name != "conn_log":  # (the log's content is defined by conn_count)
+                    t.zero_()
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(stream)
