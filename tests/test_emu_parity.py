@@ -352,3 +352,17 @@ def express_variants_case(Backend, monkeypatch, n_reads):
 
 def test_express_variants_agree(monkeypatch):
     express_variants_case(harness.EmuBackend, monkeypatch, 8000)
+
+
+def test_three_ambiguous_bases_stay_in_the_lds_pass():
+    """a k-mer with three Ns expands to 64 keys: within the main pass' key table (it used to be sent to the HBM-table
+    pass by a conservative bound), and equal to the oracle"""
+    ref, recs, codes, pos = scenarios.synthetic_case("snp100", n_ref=40000, n_reads=300, region_begin=1000, n_rate=0.0)
+    rng = np.random.default_rng(5)
+    for c in codes:
+        at = 31 * int(rng.integers(0, 4)) + rng.choice(32, size=3, replace=False)
+        c[at] = 15
+    o = Oracle(ref, recs, region_begin=1000)
+    b = harness.EmuBackend(gtx.graph_from_records(ref, recs, region_begin=1000))
+    check_align(b, o, list(codes))
+    assert b.big_records()[1] == 0  # no task reached the last pass

@@ -3,6 +3,7 @@ CPU oracle.  No GPU needed: contexts are created with device=-1 (inspection only
 import numpy as np
 import pytest
 
+import scenarios
 from fixtures import contig
 from graphtyper_amd import lib as gtx
 from graphtyper_amd import synth
@@ -103,3 +104,21 @@ def test_no_cpu_path():
     dummy = np.zeros(64, np.uint8)
     rc = gtx.lib().gtx_align_batch(c.h, gtx._p(dummy), 16, gtx._p(dummy), 1, gtx._p(dummy), 64, None)
     assert rc == 2  # GTX_ERR_NO_DEVICE
+
+
+def test_near_pair_layout():
+    """gtx_ctx_near_pairs: windows of the dense connection counters = the haplotypes whose order is < 100 above
+    (hts_parallel_reader.cpp:800-801), offsets = running sum of cnum(h) * alleles of the window"""
+    for kind, aav in (("snp25", False), ("snp100", False), ("cluster", True)):
+        ref, recs, _, _ = scenarios.synthetic_case(kind, n_ref=20000, n_reads=1, region_begin=0)
+        ctx = gtx.Context(gtx.graph_from_records(ref, recs, add_all_variants=aav), device=-1)
+        order, cnum = ctx.hap_order.astype(np.int64), ctx.hap_cnum.astype(np.int64)
+        total = 0
+        for h in range(ctx.n_hap):
+            last = h
+            while last + 1 < ctx.n_hap and order[last + 1] < order[h] + 100:
+                last += 1
+            assert int(ctx.near_last[h]) == last and int(ctx.near_off[h]) == total
+            total += int(cnum[h] * cnum[h + 1:last + 1].sum())
+        assert total == ctx.total_near
+        assert (ctx.total_near == 0) == (kind == "snp100")  # (sites exactly 100 apart are not near)
