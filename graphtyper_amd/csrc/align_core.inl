@@ -990,6 +990,12 @@ GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, ui
   uint32_t best = 7;
   uint32_t n_wl = 0, n_wlists = 0;
   WalkBuffers & wb = ws.u.w;
+  // Paths that end at the same ordinary position with the same part of the read left over (the +1-mismatch copies of a
+  // chain, the other alleles of a site behind them) ask for the same walk: its outcome depends on the path only through
+  // the variant nodes get_locations offers, and an ordinary position inside a reference node offers none.  The labels
+  // of the last such walk stay in wb.dfs_out; a second identical request reuses them (the budget can only have shrunk
+  // to that walk's own mismatch count or below: same labels or none).
+  uint32_t memo_anchor = INVALID, memo_idx = 0, memo_nl = 0, memo_mm = 0;
   for (uint32_t i = 0; i < n_paths; ++i)
   {
     DPath const & path = ws.paths[i];
@@ -1020,12 +1026,18 @@ GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, ui
       mm = static_cast<uint32_t>(maximum_mismatches);
     uint32_t const anchor = GTX_U(starts ? path.start : path.end);
     uint32_t nl;
+    bool const reuse = anchor == memo_anchor && memo_idx == (starts ? prs : pre);
     // Shortcut for the common geometry: the anchor is an ordinary position inside a reference node and the sub-read
     // fits in what is left of that node.  get_locations would return that single 'R' location and the walk a single
     // sequence without ever reaching a variant site (graph.cpp:1232-1243 / 1484-1496), so the result is one id-less
     // label or nothing -- computed here without going through the location / candidate tables.
-    bool shortcut = false;
-    if (!starts && g.pos_info && !g_is_special(g, anchor) && anchor >= g.first_order && g.n_ref > 1 && anchor - g.first_order < g.n_pos_info &&
+    bool shortcut = reuse;
+    if (reuse)
+    {
+      nl = (memo_nl != 0 && memo_mm <= mm) ? memo_nl : 0;
+      mm = nl ? memo_mm : mm;
+    }
+    if (!shortcut && !starts && g.pos_info && !g_is_special(g, anchor) && anchor >= g.first_order && g.n_ref > 1 && anchor - g.first_order < g.n_pos_info &&
         sr.len <= 255)
     {
       // the same shortcut through the position table: one lookup instead of bucket -> node order -> node tables
@@ -1086,7 +1098,16 @@ GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, ui
       nl = iterative_dfs<W>(g, ws, n_locs, starts, sr, mm, status);
       if (status)
         return;
+      // remember the walk when its start did not depend on the path: one location, inside a reference node
+      bool const plain = n_locs == 1 && GTX_U(wb.locs[0].type) != 2 && g.pos_info && anchor >= g.first_order &&
+                         anchor - g.first_order < g.n_pos_info && GTX_U(g.pos_info[anchor - g.first_order]) != INVALID;
+      memo_anchor = plain ? anchor : INVALID;
+      memo_idx = starts ? prs : pre;
+      memo_nl = nl;
+      memo_mm = mm;
     }
+    else if (!reuse)
+      memo_anchor = INVALID; // (the shortcut wrote its label to wb.dfs_out)
     if (nl == 0)
       continue;
     if (mm < best)

@@ -69,6 +69,14 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 3
         ms, handed = ctx.pass_times()
+        prof = ctx.profile()
+        if prof[15] > 0:  # GTX_LIB=libgtx_prof.so: cycles per phase of the general algorithm, per task that ran it
+            names = ["load read", "keys + exact probes", "exact labels", "chain exact", "hamming lookup", "chain hamming",
+                     "walk starts", "walk ends", "filters", "record"]
+            tot = float(prof[:10].sum())
+            for k, nm in enumerate(names):
+                sys.stderr.write("  %-22s %10.0f  %5.1f%%\n" % (nm, prof[k] / float(prof[15]), 100.0 * prof[k] / tot))
+            sys.stderr.write("  tasks %d\n" % prof[15])
         heads = d_rec.view(n * 2, rw)[:, 0]
         print(json.dumps({"kind": kind, "reads": n, "sites": int(nh), "max_alleles": int(ctx.hap_cnum.max()), "reads_per_s": n / dt,
                           "ms_per_step": 1e3 * dt, "express_ms": ms[0], "general_ms": ms[1], "hbm_tables_ms": ms[2],
