@@ -122,6 +122,13 @@ GTX_DEV uint32_t ug_site_order(GraphView const & g, uint32_t site)
 template <class W>
 GTX_DEV uint32_t g_ref_node_at(GraphView const & g, uint32_t pos)
 {
+  if (g.pos_node && pos - g.first_order < g.n_pos_info)
+  {
+    // the position table answers in one load when the position lies inside a reference node (the usual case)
+    uint32_t const direct = GTX_U(g.pos_node[pos - g.first_order]);
+    if (direct != INVALID)
+      return direct;
+  }
   uint32_t b = (pos - g.first_order) >> POS_BUCKET_SHIFT;
   if (b >= g.n_bucket)
     b = g.n_bucket - 1;
