@@ -22,6 +22,7 @@ struct Express4Lean
   static constexpr uint32_t TS = 1;                 // variant sites under the walk at the read's end
   static constexpr uint32_t VS_CAP = AlignCfg::KC + 1; // variant sites of the path
   static constexpr bool END_ON_SITE = false;        // paths whose last base lies on a SNP are walked on here
+  static constexpr bool INDEL_TAIL = false;         // walks at the read's end over a site with alleles of any length
   static constexpr uint32_t AMB_LABELS = 1;         // labels a k-mer with an ambiguous base may have between its keys
   static constexpr bool AMB_ON_VARIANT = true;      // ... and whether they may lie on a variant
 };
@@ -30,8 +31,32 @@ struct Express4Wide
 {
   static constexpr uint32_t KS = 4, NB_MAX = 16, TS = 3, VS_CAP = 16;
   static constexpr bool END_ON_SITE = true;
+  static constexpr bool INDEL_TAIL = true;
   static constexpr uint32_t AMB_LABELS = 5;
   static constexpr bool AMB_ON_VARIANT = true;
+};
+
+template <bool ON>
+struct Express4IndelTail // in the tail handed to the lanes
+{
+  uint32_t indel, cmp_len;
+};
+
+template <>
+struct Express4IndelTail<false> // (the lean build carries none of it)
+{
+};
+
+template <bool ON>
+struct Express4IndelAlleles // written by the leader lane only when it meets such a site
+{
+  uint32_t next_off, next_order;
+  uint32_t alen[4], aoff[4];
+};
+
+template <>
+struct Express4IndelAlleles<false>
+{
 };
 
 template <class E4>
@@ -47,6 +72,10 @@ struct Express4Tail // handed from a group's leader lane to its 16 lanes
   uint32_t site_at[E4::TS], seg_base[E4::TS + 1];
   uint32_t nall[E4::TS], alleles[E4::TS], site[E4::TS]; // alleles: one comparison code per byte
   uint32_t afirst[E4::TS];                              // index of the first of them (0 unless the walk starts inside an allele)
+  // A tail over ONE site with alleles of any length (an indel): characters [0, x.cmp_len) lie in the node the path ends
+  // in, then allele a's bases, then the reference node after the site (Express4IndelAlleles in the workspace).  One
+  // candidate per allele, compared separately; site[0] / nall[0] name the site.
+  Express4IndelTail<E4::INDEL_TAIL> x;
 };
 
 template <class E4>
@@ -54,6 +83,7 @@ struct Express4Workspace
 {
   SeedWorkspace s[4];
   Express4Tail<E4> tail[4];
+  Express4IndelAlleles<E4::INDEL_TAIL> xtail[4];
   // the variant sites of every k-mer's labels, in label order, and the alleles the labels name
   uint32_t kn[4][AlignCfg::KC], ksite[4][AlignCfg::KC][E4::KS];
   uint64_t kmask[4][AlignCfg::KC][E4::KS];
@@ -556,6 +586,8 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
             {
               t.ok = 1;
               t.tail_len = tail_len;
+              if constexpr (E4::INDEL_TAIL)
+                t.x.cmp_len = tail_len;
             }
             else if (((E4::END_ON_SITE && w == INVALID) || (w != INVALID && (w & 255u) < 255u)) && !g.is_sv_graph && g.pos_node)
             {
@@ -621,7 +653,36 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
                       codes |= static_cast<uint32_t>(reinterpret_cast<uint8_t const *>(g.dna)[g.var_dna[fv + a]]) << (8 * a);
                   }
                 if (!snp)
+                {
+                  if constexpr (E4::INDEL_TAIL)
+                  if (n == 0 && nv >= 2 && nv <= 4)
+                  {
+                    // alleles of any length: every one has to end inside the tail with at least one character left for
+                    // the next reference node, and that node has to hold the rest (else the walk ends inside an allele
+                    // or runs over a second site: pass 2)
+                    bool fits = true;
+                    uint32_t const next_len = g.ref_len[r + 1];
+                    for (uint32_t a = 0; a < 4; ++a)
+                      if (a < nv)
+                      {
+                        uint32_t const vl = g.var_len[fv + a];
+                        fits = fits && at + vl < tail_len && tail_len - at - vl <= next_len;
+                        ws.xtail[gi].alen[a] = vl;
+                        ws.xtail[gi].aoff[a] = g.var_dna[fv + a];
+                      }
+                    if (fits)
+                    {
+                      t.x.indel = 1;
+                      t.x.cmp_len = at;
+                      ws.xtail[gi].next_off = g.ref_dna[r + 1];
+                      ws.xtail[gi].next_order = g.ref_order[r + 1];
+                      t.site[0] = r;
+                      t.nall[0] = nv;
+                      done = true;
+                    }
+                  }
                   break;
+                }
                 t.site_at[n] = at;
                 t.nall[n] = nv;
                 t.afirst[n] = 0;
@@ -640,6 +701,9 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
                 t.ok = 1;
                 t.tail_len = tail_len;
                 t.nsite = n;
+                if constexpr (E4::INDEL_TAIL)
+                  if (!t.x.indel)
+                    t.x.cmp_len = tail_len;
               }
               else
                 for (uint32_t k = 0; k < E4::TS; ++k)
@@ -681,7 +745,10 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
         if (sa != INVALID && i > sa)
           base = t.seg_base[sk + 1];
       }
-      if (on && i < t.tail_len && !on_site)
+      uint32_t cmp_len = t.tail_len; // (an indel tail: only the characters in front of the site)
+      if constexpr (E4::INDEL_TAIL)
+        cmp_len = t.x.cmp_len;
+      if (on && i < cmp_len && !on_site)
       {
         uint8_t const gc = reinterpret_cast<uint8_t const *>(g.dna)[base + i];
         uint8_t const rc = ws.s[gi].rd[t.pre + i];
@@ -711,6 +778,51 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
       killed_l[l] = killed_l[l] || (static_cast<uint32_t>(KILL >> sh) & 0xFFFFu) != 0;
       hkilled_l[l] = hkilled_l[l] || (static_cast<uint32_t>(HKILL >> sh) & 0xFFFFu) != 0;
     });
+  }
+
+  // ---- tails over an indel site: the rest of the tail against every allele's candidate (allele bases, then the next
+  //      reference node), 16 characters per group and round
+  PU amm_l[4];
+  W::lanes([&](uint32_t l) {
+    for (uint32_t a = 0; a < 4; ++a)
+      amm_l[a][l] = 0;
+  });
+  if constexpr (E4::INDEL_TAIL)
+  {
+    PB ind_l;
+    W::lanes([&](uint32_t l) {
+      Express4Tail<E4> const & t = ws.tail[l >> 4];
+      ind_l[l] = seeded_l[l] && t.ok && t.x.indel;
+    });
+    if (W::ballot(ind_l) != 0)
+      for (uint32_t a = 0; a < 4; ++a)
+        for (uint32_t r = 0; r < AlignCfg::MAX_READ / 16; ++r)
+        {
+          PB x_l, any_l;
+          W::lanes([&](uint32_t l) {
+            uint32_t const gi = l >> 4;
+            Express4Tail<E4> const & t = ws.tail[gi];
+            bool const on = ind_l[l] && a < t.nall[0];
+            uint32_t const i = t.x.cmp_len + 16 * r + (l & 15u);
+            bool x = false;
+            if (on && i < t.tail_len)
+            {
+              Express4IndelAlleles<E4::INDEL_TAIL> const & xa = ws.xtail[gi];
+              uint32_t const k = i - t.x.cmp_len, al = xa.alen[a];
+              uint8_t const gc = reinterpret_cast<uint8_t const *>(g.dna)[k < al ? xa.aoff[a] + k : xa.next_off + (k - al)];
+              uint8_t const rc = ws.s[gi].rd[t.pre + i];
+              x = gc != rc && rc != 15 && gc != 15;
+            }
+            x_l[l] = x;
+            any_l[l] = on && t.x.cmp_len + 16 * r < t.tail_len;
+          });
+          if (W::ballot(any_l) == 0)
+            break;
+          uint64_t const XA = W::ballot(x_l);
+          W::lanes([&](uint32_t l) {
+            amm_l[a][l] = amm_l[a][l] + static_cast<uint32_t>(__builtin_popcount(static_cast<uint32_t>(XA >> (16 * (l >> 4))) & 0xFFFFu));
+          });
+        }
   }
 
   // ---- verdict and record (leader lanes)
@@ -768,13 +880,50 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
               got += best;
             }
           }
+          bool tie = false;
+          uint32_t best_allele = 0;
+          bool indel = false;
+          if constexpr (E4::INDEL_TAIL)
+            indel = t.x.indel != 0;
+          if (indel)
+          {
+            // one candidate per allele; the best one's label is the walk's result.  Candidates of different allele
+            // lengths end at different positions: a tie would be two labels, two paths (pass 2)
+            uint32_t best = INVALID, n_best = 0;
+            for (uint32_t a = 0; a < 4; ++a)
+              if (a < t.nall[0])
+              {
+                uint32_t const m = amm_l[a][l];
+                if (m < best)
+                {
+                  best = m;
+                  best_allele = a;
+                  n_best = 1;
+                }
+                else if (m == best)
+                  ++n_best;
+              }
+            got += best;
+            tie = n_best != 1 && got <= budget;
+          }
           if (!killed && got <= budget)
           {
-            end += t.tail_len - 1;
             re = L - 1;
             mism += got;
-            tail_sites = t.nsite;
+            if (indel)
+            {
+              if constexpr (E4::INDEL_TAIL)
+                end = ws.xtail[gi].next_order + (t.tail_len - t.x.cmp_len - ws.xtail[gi].alen[best_allele]) - 1;
+              tail_sites = 1;
+              tail_mask[0] = 1u << best_allele;
+            }
+            else
+            {
+              end += t.tail_len - 1;
+              tail_sites = t.nsite;
+            }
           }
+          fail = fail || tie;
         }
         uint32_t longest = re - rs + 1;
         // variant sites of the path: every merge puts the new label's site in front, intersecting the allele sets when

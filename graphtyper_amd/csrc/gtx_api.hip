@@ -751,7 +751,7 @@ int ctx_upload(gtx_ctx & c, int device)
     c.express4_blocks_per_cu = per_cu;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express4_wide_kernel, 64, 0) == hipSuccess && per_cu > 0)
     c.express4_wide_blocks_per_cu = per_cu;
-  c.express4_wide = express4_prefers_wide(c.index);
+  c.express4_wide = express4_prefers_wide(c.graph, c.index);
   return GTX_OK;
 }
 

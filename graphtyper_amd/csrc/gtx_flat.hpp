@@ -181,13 +181,27 @@ inline uint64_t plane_key(uint64_t key)
 // ~20x the cost: it pays off once more than ~2 % of the indexed keys carry several labels (measured: a SNP every 100
 // bases at regular distances -- no such key -- is 17 % faster with the lean build, a SNP every 25 bases -- every read
 // has such a k-mer -- 1.8x faster with the wide one).
-inline bool express4_prefers_wide(HostIndex const & ix)
+inline bool express4_prefers_wide(HostGraph const & g, HostIndex const & ix)
 {
   uint64_t several = 0;
   std::size_t const n = ix.keys.size();
   for (std::size_t k = 0; k < n; ++k)
     several += ix.key_off[k + 1] - ix.key_off[k] >= 2 ? 1u : 0u;
-  return n != 0 && several * 50 > n;
+  if (n != 0 && several * 50 > n)
+    return true;
+  // ... or once the walk at a read's end (26 characters of a 150 bp read) meets an indel site for more than ~8 % of the
+  // reads: only the wide build walks over alleles of unequal length (an indel every 60 bases: 44 % of the tasks reach
+  // the general pass with the lean build, 20 % with the wide one)
+  uint64_t bases = 0, indel_sites = 0;
+  for (std::size_t r = 0; r < g.ref_len.size(); ++r)
+  {
+    bases += g.ref_len[r];
+    bool indel = false;
+    for (uint32_t a = 0; a < g.ref_nvar[r]; ++a)
+      indel = indel || g.var_len[g.ref_first_var[r] + a] != 1;
+    indel_sites += indel ? 1u : 0u;
+  }
+  return indel_sites * 325 > bases;
 }
 
 #if defined(__HIPCC__)

@@ -133,7 +133,7 @@ extern "C"
     char const * e4 = std::getenv("GTX_EXPRESS4"); // 0: one read per wavefront in pass 1
     bool const four = !(e4 && e4[0] == '0');
     // lean / wide build of pass 1: forced by GTX_EXPRESS4=lean|wide, else by the graph's density (as gtx_align_batch does)
-    bool const wide = e4 && e4[0] == 'w' ? true : e4 && e4[0] == 'l' ? false : express4_prefers_wide(e.index);
+    bool const wide = e4 && e4[0] == 'w' ? true : e4 && e4[0] == 'l' ? false : express4_prefers_wide(e.graph, e.index);
     auto e4_ws = std::make_unique<Express4Workspace<Express4Lean>>();
     auto e4_wide_ws = std::make_unique<Express4Workspace<Express4Wide>>();
     // passes 2 and 3 for one task
