@@ -23,6 +23,7 @@ struct Express4Lean
   static constexpr uint32_t VS_CAP = AlignCfg::KC + 1; // variant sites of the path
   static constexpr bool END_ON_SITE = false;        // paths whose last base lies on a SNP are walked on here
   static constexpr bool INDEL_TAIL = false;         // walks at the read's end over a site with alleles of any length
+  static constexpr uint32_t HE_SCAN = 0;            // entries of a crowded half-key bucket that are searched for the neighbours
   static constexpr uint32_t AMB_LABELS = 1;         // labels a k-mer with an ambiguous base may have between its keys
   static constexpr bool AMB_ON_VARIANT = true;      // ... and whether they may lie on a variant
 };
@@ -32,6 +33,7 @@ struct Express4Wide
   static constexpr uint32_t KS = 4, NB_MAX = 16, TS = 3, VS_CAP = 16;
   static constexpr bool END_ON_SITE = true;
   static constexpr bool INDEL_TAIL = true;
+  static constexpr uint32_t HE_SCAN = 16;
   static constexpr uint32_t AMB_LABELS = 5;
   static constexpr bool AMB_ON_VARIANT = true;
 };
@@ -315,6 +317,55 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
             ws.s[gi].he[j >> 1][j & 1u][e] = ix.hlist[ws.s[gi].hoff[j >> 1][j & 1u] + e];
         });
       W::lds_sync();
+    }
+    if constexpr (E4::HE_SCAN != 0)
+    {
+      // Crowded buckets (sites a few bases apart: every combination of their alleles shares the 16-mer beside them): only
+      // the Hamming-1 neighbours of the k-mer matter; the bucket is read through and up to HE_CAP of them are kept.
+      PB scan_l;
+      W::lanes([&](uint32_t l) {
+        uint32_t const gi = l >> 4, j = l & 15u;
+        bool scan = false;
+        if (alive_l[l] && j < 2 * nk_l[l])
+        {
+          uint32_t const c = ws.s[gi].hcnt[j >> 1][j & 1u];
+          scan = ws.s[gi].nkeys0[j >> 1] == 1 && c > HE_CAP && c <= E4::HE_SCAN;
+        }
+        scan_l[l] = scan;
+      });
+      if (W::ballot(scan_l) != 0)
+      {
+        W::lanes([&](uint32_t l) {
+          uint32_t const gi = l >> 4, j = l & 15u;
+          if (scan_l[l])
+          {
+            SeedWorkspace & s = ws.s[gi];
+            uint64_t const q = s.key0[j >> 1];
+            uint32_t const c = s.hcnt[j >> 1][j & 1u], off = s.hoff[j >> 1][j & 1u];
+            uint32_t kept = 0;
+            for (uint32_t e = 0; e < E4::HE_SCAN; e += 2)
+            {
+              // (two at a time: independent loads)
+              HalfEntry const a = ix.hlist[off + (e < c ? e : 0u)], b = ix.hlist[off + (e + 1 < c ? e + 1 : 0u)];
+              uint32_t nn;
+              if (e < c && hamming1_neighbour(a.key, q, nn))
+              {
+                if (kept < HE_CAP)
+                  s.he[j >> 1][j & 1u][kept] = a;
+                ++kept;
+              }
+              if (e + 1 < c && hamming1_neighbour(b.key, q, nn))
+              {
+                if (kept < HE_CAP)
+                  s.he[j >> 1][j & 1u][kept] = b;
+                ++kept;
+              }
+            }
+            s.hcnt[j >> 1][j & 1u] = kept; // (more than HE_CAP: the k-mer is declined below)
+          }
+        });
+        W::lds_sync();
+      }
     }
   }
 
