@@ -38,6 +38,8 @@ struct Express4Wide
   static constexpr bool AMB_ON_VARIANT = true;
 };
 
+constexpr uint32_t EXPRESS4_INDEL_ALLELES = 8; // alleles of a site the walk at the read's end may cross when they differ in length
+
 template <bool ON>
 struct Express4IndelTail // in the tail handed to the lanes
 {
@@ -52,8 +54,9 @@ struct Express4IndelTail<false> // (the lean build carries none of it)
 template <bool ON>
 struct Express4IndelAlleles // written by the leader lane only when it meets such a site
 {
-  uint32_t next_off, next_order;
-  uint32_t alen[4], aoff[4];
+  uint32_t next_off, next_order, site_order; // (the alleles of a site share their order)
+  uint32_t alen[EXPRESS4_INDEL_ALLELES], aoff[EXPRESS4_INDEL_ALLELES];
+  uint32_t amm[EXPRESS4_INDEL_ALLELES]; // mismatches of allele a's candidate behind the common part (summed by the leader lane)
 };
 
 template <>
@@ -706,27 +709,31 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
                 if (!snp)
                 {
                   if constexpr (E4::INDEL_TAIL)
-                  if (n == 0 && nv >= 2 && nv <= 4)
+                  if (n == 0 && nv >= 2 && nv <= EXPRESS4_INDEL_ALLELES)
                   {
                     // alleles of any length: every one has to end inside the tail with at least one character left for
                     // the next reference node, and that node has to hold the rest (else the walk ends inside an allele
                     // or runs over a second site: pass 2)
                     bool fits = true;
                     uint32_t const next_len = g.ref_len[r + 1];
-                    for (uint32_t a = 0; a < 4; ++a)
+                    for (uint32_t a = 0; a < EXPRESS4_INDEL_ALLELES; ++a)
                       if (a < nv)
                       {
                         uint32_t const vl = g.var_len[fv + a];
-                        fits = fits && at + vl < tail_len && tail_len - at - vl <= next_len;
+                        // (an allele the tail ends in -- or at the end of -- is compared as far as the tail goes)
+                        fits = fits && (at + vl >= tail_len || tail_len - at - vl <= next_len);
                         ws.xtail[gi].alen[a] = vl;
                         ws.xtail[gi].aoff[a] = g.var_dna[fv + a];
+                        ws.xtail[gi].amm[a] = 0;
                       }
+                    GTX_E4_NOTE(!fits, 13); // behind an allele of the indel site the tail runs over the next site
                     if (fits)
                     {
                       t.x.indel = 1;
                       t.x.cmp_len = at;
                       ws.xtail[gi].next_off = g.ref_dna[r + 1];
                       ws.xtail[gi].next_order = g.ref_order[r + 1];
+                      ws.xtail[gi].site_order = g.ref_order[r] + g.ref_len[r];
                       t.site[0] = r;
                       t.nall[0] = nv;
                       done = true;
@@ -833,11 +840,6 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
 
   // ---- tails over an indel site: the rest of the tail against every allele's candidate (allele bases, then the next
   //      reference node), 16 characters per group and round
-  PU amm_l[4];
-  W::lanes([&](uint32_t l) {
-    for (uint32_t a = 0; a < 4; ++a)
-      amm_l[a][l] = 0;
-  });
   if constexpr (E4::INDEL_TAIL)
   {
     PB ind_l;
@@ -846,7 +848,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
       ind_l[l] = seeded_l[l] && t.ok && t.x.indel;
     });
     if (W::ballot(ind_l) != 0)
-      for (uint32_t a = 0; a < 4; ++a)
+      for (uint32_t a = 0; a < EXPRESS4_INDEL_ALLELES; ++a)
         for (uint32_t r = 0; r < AlignCfg::MAX_READ / 16; ++r)
         {
           PB x_l, any_l;
@@ -871,7 +873,8 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
             break;
           uint64_t const XA = W::ballot(x_l);
           W::lanes([&](uint32_t l) {
-            amm_l[a][l] = amm_l[a][l] + static_cast<uint32_t>(__builtin_popcount(static_cast<uint32_t>(XA >> (16 * (l >> 4))) & 0xFFFFu));
+            if ((l & 15u) == 0 && ind_l[l])
+              ws.xtail[l >> 4].amm[a] += static_cast<uint32_t>(__builtin_popcount(static_cast<uint32_t>(XA >> (16 * (l >> 4))) & 0xFFFFu));
           });
         }
   }
@@ -932,41 +935,45 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
             }
           }
           bool tie = false;
-          uint32_t best_allele = 0;
+          uint32_t indel_end = 0, indel_mask = 0;
           bool indel = false;
           if constexpr (E4::INDEL_TAIL)
             indel = t.x.indel != 0;
-          if (indel)
-          {
-            // one candidate per allele; the best one's label is the walk's result.  Candidates of different allele
-            // lengths end at different positions: a tie would be two labels, two paths (pass 2)
-            uint32_t best = INVALID, n_best = 0;
-            for (uint32_t a = 0; a < 4; ++a)
-              if (a < t.nall[0])
-              {
-                uint32_t const m = amm_l[a][l];
-                if (m < best)
+          if constexpr (E4::INDEL_TAIL)
+            if (indel)
+            {
+              // One candidate per allele; the labels of the best ones are the walk's result.  A candidate's last
+              // character lies in the reference node behind the site, or inside the allele (then a position of the
+              // variant node, special beyond the reference allele's reach: graph.cpp:1232-1243).  Best candidates
+              // that end at the same position are one label list with equal ends, i.e. one path with all their
+              // alleles; different ends would be several paths (pass 2).
+              uint32_t best = INVALID;
+              for (uint32_t a = 0; a < EXPRESS4_INDEL_ALLELES; ++a)
+                if (a < t.nall[0] && ws.xtail[gi].amm[a] < best)
+                  best = ws.xtail[gi].amm[a];
+              got += best;
+              uint32_t const beyond = t.tail_len - t.x.cmp_len;
+              for (uint32_t a = 0; a < EXPRESS4_INDEL_ALLELES; ++a)
+                if (a < t.nall[0] && ws.xtail[gi].amm[a] == best)
                 {
-                  best = m;
-                  best_allele = a;
-                  n_best = 1;
+                  uint32_t const al = ws.xtail[gi].alen[a];
+                  uint32_t const e = beyond > al ? ws.xtail[gi].next_order + (beyond - al) - 1
+                                                 : g_special_of(g, t.site[0], ws.xtail[gi].site_order + beyond - 1);
+                  tie = tie || (indel_mask != 0 && e != indel_end);
+                  indel_end = e;
+                  indel_mask |= 1u << a;
                 }
-                else if (m == best)
-                  ++n_best;
-              }
-            got += best;
-            tie = n_best != 1 && got <= budget;
-          }
+              tie = tie && got <= budget;
+            }
           if (!killed && got <= budget)
           {
             re = L - 1;
             mism += got;
             if (indel)
             {
-              if constexpr (E4::INDEL_TAIL)
-                end = ws.xtail[gi].next_order + (t.tail_len - t.x.cmp_len - ws.xtail[gi].alen[best_allele]) - 1;
+              end = indel_end;
               tail_sites = 1;
-              tail_mask[0] = 1u << best_allele;
+              tail_mask[0] = indel_mask;
             }
             else
             {
@@ -974,6 +981,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
               tail_sites = t.nsite;
             }
           }
+          GTX_E4_NOTE(tie, 12); // the best alleles of an indel site end at different positions: several paths
           fail = fail || tie;
         }
         uint32_t longest = re - rs + 1;
