@@ -6,6 +6,8 @@
 //   add_var_record             src/graph/constructor.cpp:1208-1595  (small-variant branch :1493-1588: non-ACGT alts are
 //                                                                     dropped, GT_ID / GT_ANTI_HAPLOTYPE become events)
 //   GenomicRegion(string)      src/graph/genomic_region.cpp:73-113
+//   SV deletions               src/graph/constructor.cpp:1257-1349 (INFO fields, size defaults), add_sv_deletion :478-514,
+//                              append_sv_tag_to_node :155-161.  The other SV types (DUP, INV, INS, BND) are refused.
 // and then hands the records to the builder behind gtx_graph_build (record merging, node emission).
 // Own parsers: the reference reads FASTA through seqan's FaiIndex (bases arrive as Dna5: anything but ACGT is N) and VCF
 // lines through seqan / tabix; here the FASTA is read through its .fai when present (else scanned) and the VCF -- plain
@@ -163,6 +165,7 @@ bool read_fasta_region(std::string const & path, std::string const & chr, long b
 struct Rec // one biallelic VarRecord in the making
 {
   uint32_t pos;
+  bool is_sv = false;
   std::string ref, alt;
   std::vector<int64_t> ref_events, alt_events, alt_anti;
 };
@@ -212,6 +215,7 @@ extern "C" int gtx_graph_from_files(const char * fasta_path, const char * vcf_pa
     return GTX_ERR_ARG;
   }
   std::vector<Rec> recs;
+  unsigned n_sv = 0; // Graph::SVs.size(): numbers the SV tags
   if (vcf_path && vcf_path[0])
   {
     gzFile z = gzopen(vcf_path, "rb"); // reads plain text as well; bgzip files are concatenated gzip members
@@ -256,11 +260,80 @@ extern "C" int gtx_graph_from_files(const char * fasta_path, const char * vcf_pa
       {
         if (alt.empty() || alt[0] == '.')
           continue; // :1064-1068
+        if (is_sv_alt(alt) && is_sv_graph && alt.compare(0, 4, "<DEL") == 0)
+        {
+          // a deletion: the reference allele is the base at the position, the alternative allele that base, any inserted
+          // sequence, and the reference behind the deleted stretch up to EXTRA_SEQUENCE_LENGTH + 1 characters, closed by
+          // the SV tag that stops walks and k-mers at the allele's end
+          constexpr std::size_t EXTRA_SEQUENCE_LENGTH = 152; // constructor.cpp:1437
+          std::string sv_type, seq, ins_seq;
+          long sv_size = 0, sv_len = 0;
+          for (std::string const & kv : split(info, ';'))
+          {
+            std::size_t const eq = kv.find('=');
+            if (eq == std::string::npos)
+              continue;
+            std::string const key = kv.substr(0, eq), val = kv.substr(eq + 1);
+            if (key == "SVTYPE")
+              sv_type = val;
+            else if (key == "SVSIZE")
+              sv_size = std::atol(val.c_str());
+            else if (key == "SVLEN")
+              sv_len = std::atol(val.c_str());
+            else if (key == "SEQ")
+              seq = val;
+            else if (key == "SVINSSEQ")
+              ins_seq = val;
+          }
+          if (sv_type != "DEL" && sv_type != "DEL:ME:ALU")
+          {
+            gzclose(z);
+            g_last_error = "gtx_graph_from_files: allele '" + alt + "' at " + reg.chr + ":" + col[1] + " without SVTYPE=DEL";
+            return GTX_ERR_ARG;
+          }
+          if (sv_len < 0)
+            sv_len = -sv_len; // :1331-1332
+          if (sv_len == 0)    // :1335-1346
+            sv_len = sv_size ? sv_size : seq.size() ? static_cast<long>(seq.size()) : static_cast<long>(ins_seq.size());
+          if (sv_size == 0)
+            sv_size = sv_len; // :1349-1350
+          Rec r;
+          r.pos = static_cast<uint32_t>(pos0);
+          r.is_sv = true;
+          std::string piece;
+          if (!read_fasta_region(fasta_path, reg.chr, pos0, pos0 + 1, r.ref, err) || r.ref.size() != 1)
+          {
+            gzclose(z);
+            g_last_error = "gtx_graph_from_files: no reference base at " + reg.chr + ":" + col[1];
+            return GTX_ERR_ARG;
+          }
+          r.alt = r.ref;
+          if (!seq.empty() && seq[0] != '.')
+            r.alt += seq;
+          else if (!ins_seq.empty() && ins_seq[0] != '.')
+            r.alt += ins_seq;
+          if (r.alt.size() < EXTRA_SEQUENCE_LENGTH + 1)
+          {
+            long const from = pos0 + static_cast<long>(seq.size()) + sv_size + 1;
+            if (!read_fasta_region(fasta_path, reg.chr, from, from + static_cast<long>(EXTRA_SEQUENCE_LENGTH + 1 - r.alt.size()), piece, err))
+            {
+              gzclose(z);
+              g_last_error = "gtx_graph_from_files: " + err;
+              return GTX_ERR_ARG;
+            }
+            r.alt += piece; // (clipped at the contig's end, like seqan's readRegion)
+          }
+          char tag[16];
+          std::snprintf(tag, sizeof tag, "<SV:%07u>", n_sv++);
+          r.alt += tag;
+          recs.push_back(std::move(r));
+          continue;
+        }
         if (is_sv_alt(alt))
         {
           gzclose(z);
           g_last_error = "gtx_graph_from_files: structural variant allele '" + alt + "' at " + reg.chr + ":" + col[1] +
-                         (is_sv_graph ? " (SV alleles are not built by this library yet)" : " in a non-SV graph");
+                         (is_sv_graph ? " (of the SV types only deletions are built by this library yet)" : " in a non-SV graph");
           return GTX_ERR_UNSUPPORTED;
         }
         if (alt.find_first_not_of("ACGT") != std::string::npos)
@@ -302,7 +375,7 @@ extern "C" int gtx_graph_from_files(const char * fasta_path, const char * vcf_pa
                                 static_cast<uint32_t>(r.ref_events.size()), nullptr, 0};
     alleles[2 * i + 1] = gtx_allele{r.alt.data(), static_cast<uint32_t>(r.alt.size()), r.alt_events.data(),
                                     static_cast<uint32_t>(r.alt_events.size()), r.alt_anti.data(), static_cast<uint32_t>(r.alt_anti.size())};
-    records[i] = gtx_record{r.pos, 2, &alleles[2 * i], 0};
+    records[i] = gtx_record{r.pos, 2, &alleles[2 * i], r.is_sv ? 1 : 0};
   }
   long const end = reg.begin + static_cast<long>(refseq.size());
   if (region_begin)

@@ -17,7 +17,7 @@
  *                                 filter, leftover reads)                       src/utilities/hts_parallel_reader.cpp:245-338,528-772
  *   gtx_phase_flags     replaces  the `ph` construction                         src/utilities/hts_parallel_reader.cpp:782-904
  *   gtx_graph_build     replaces  Graph::add_genomic_region                     src/graph/graph.cpp:41-339
- *   gtx_graph_from_files replaces construct_graph (graphs without SV alleles)   src/graph/constructor.cpp:1597-1777
+ *   gtx_graph_from_files replaces construct_graph (small variants, SV deletions) src/graph/constructor.cpp:1597-1777
  *
  * Conventions: plain pointers and sizes only; the caller allocates and owns every buffer; a context is immutable
  * after creation and may be used from several host threads; every function returns a status code (0 = ok) and never
@@ -115,8 +115,8 @@ int gtx_graph_build(const char * reference, uint64_t reference_len, int64_t regi
                     gtx_graph ** out);
 /* Graph of one region straight from files: replaces construct_graph(reference_filename, vcf_filename, region, is_sv_graph,
  * use_index) (include/graphtyper/graph/constructor.hpp, src/graph/constructor.cpp:1597-1777) with split_multi_allelic
- * (:1033-1077) and the small-variant branch of add_var_record (:1208-1262, 1493-1595) for graphs without structural-variant
- * alleles (an SV allele returns GTX_ERR_UNSUPPORTED).  fasta_path: plain FASTA, its .fai is used when present;
+ * (:1033-1077), the small-variant branch of add_var_record (:1208-1262, 1493-1595) and, in an SV graph, its deletion
+ * branch (add_sv_deletion, :478-514); any other structural-variant allele returns GTX_ERR_UNSUPPORTED.  fasta_path: plain FASTA, its .fai is used when present;
  * vcf_path: plain or gzip/bgzip VCF, NULL or "" for a reference-only graph; region: "chr", "chr:begin" or "chr:begin-end"
  * (1-based, GenomicRegion, src/graph/genomic_region.cpp:73-113).  region_begin / region_end (may be NULL) receive the
  * 0-based span [begin, end) of the reference bases that were read. */

@@ -83,7 +83,9 @@ std::vector<VarRecord> parse_records(std::string const & text)
         if (eq != std::string::npos)
         {
           std::string const key = kv.substr(0, eq), val = kv.substr(eq + 1);
-          if (key == "RE")
+          if (key == "SV") // the record is a structural variant whose alleles the caller synthesised (VarRecord::is_sv)
+            r.is_sv = val != "0";
+          else if (key == "RE")
             for (long x : split_longs(val))
               r.ref_events.insert(x);
           else if (key == "RA")

@@ -91,8 +91,10 @@ def test_gzip_vcf_and_unindexed_fasta_give_the_same_graphs(tmp_path):
 
 def test_sv_alleles_and_bad_input_are_refused_loudly():
     fa, vcf = os.path.join(GOLDEN, "index_test.fa"), os.path.join(GOLDEN, "index_test.vcf")
-    with pytest.raises(gtx.GtxError, match="structural variant"):
-        gtx.graph_from_files(fa, vcf, "chr5", is_sv_graph=True)
+    with pytest.raises(gtx.GtxError, match="only deletions"):
+        gtx.graph_from_files(fa, vcf, "chr6", is_sv_graph=True)  # <DUP>, <INV>
+    with pytest.raises(gtx.GtxError, match="only deletions"):
+        gtx.graph_from_files(fa, vcf, "chr7", is_sv_graph=True)  # <INS:ME:ALU>
     with pytest.raises(gtx.GtxError, match="non-SV graph"):
         gtx.graph_from_files(fa, vcf, "chr6", is_sv_graph=False)
     with pytest.raises(gtx.GtxError, match="not found"):
@@ -101,3 +103,27 @@ def test_sv_alleles_and_bad_input_are_refused_loudly():
         gtx.graph_from_files(fa + ".missing", vcf, "chr1")
     g, span = gtx.graph_from_files(fa, None, "chr1:11-20")  # reference only
     assert span == (10, 20) and len(g["var_order"]) == 0 and g["dna"].tobytes() == b"AGGTTTCCCC"
+
+
+def test_sv_deletion_graph_equals_the_oracles():
+    """chr5 of the fixture: `<DEL>` with SVSIZE=70.  gtx_graph_from_files synthesises the alleles (add_sv_deletion,
+    constructor.cpp:478-514); graph and index have to equal the oracle's, which is pinned on the reference's known answers
+    for this contig (tests/test_oracle_pinned.py::test_index_chr5 <- test/index/test_index.cpp:246-312)"""
+    from fixtures import sv_contig
+    from oracle_lib import Oracle
+    fa, vcf = os.path.join(GOLDEN, "index_test.fa"), os.path.join(GOLDEN, "index_test.vcf")
+    g, span = gtx.graph_from_files(fa, vcf, "chr5", is_sv_graph=True)
+    assert span == (0, 280)
+    ref, recs = sv_contig("chr5")
+    o = Oracle(ref, recs, is_sv_graph=True)
+    og = o.graph()
+    for k in ("ref_order", "ref_len", "ref_nvar", "var_order", "var_len", "var_out_ref"):
+        assert np.array_equal(g[k], og[k]), k
+    assert g["dna"].tobytes() == og["dna"].tobytes()
+    assert g["dna"].tobytes().decode().endswith("<SV:0000000>" + "C" * 70 + "G" * 70 + "T" * 70) or b"<SV:0000000>" in g["dna"].tobytes()
+    c = gtx.Context(g, device=-1, is_sv_graph=True)
+    rr, ap = c.special_positions()
+    assert np.array_equal(rr, og["ref_reach_poses"]) and np.array_equal(ap, og["actual_poses"])
+    k1, c1, l1 = o.index_dump()
+    k2, c2, l2 = c.index_dump()
+    assert np.array_equal(k1, k2) and np.array_equal(c1, c2) and np.array_equal(l1, l2)

@@ -372,3 +372,30 @@ def test_three_ambiguous_bases_stay_in_the_lds_pass():
     b = harness.EmuBackend(gtx.graph_from_records(ref, recs, region_begin=1000))
     check_align(b, o, list(codes))
     assert b.big_records()[1] == 0  # no task reached the last pass
+
+
+def sv_deletion_case(Backend):
+    """the SV graph of the fixture's chr5 (`<DEL>` of 70 C, built by gtx_graph_from_files): reads from the reference and
+    from the deleted haplotype (…AAAA|GGGG…), with errors; poly-A / poly-G seeds at dozens of places, so most tasks go
+    through every pass"""
+    import os
+    from fixtures import sv_contig
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g, _ = gtx.graph_from_files(os.path.join(golden, "index_test.fa"), os.path.join(golden, "index_test.vcf"), "chr5", is_sv_graph=True)
+    ref, recs = sv_contig("chr5")
+    o = Oracle(ref, recs, is_sv_graph=True, force_both=True)
+    b = Backend(g, is_sv_graph=True, force_both=True)
+    deleted = ref[:70] + ref[140:]
+    rng = np.random.default_rng(2)
+    reads = []
+    for hap in (ref, deleted):
+        for start in range(0, len(hap) - 100, 7):
+            s = hap[start:start + 100]
+            reads.append(encode(s))
+            reads.append(encode(scenarios.mutate(s, rng.choice(100, 2, replace=False), rng)))
+    _, n_over = check_align(b, o, reads, allow_overflow=True)
+    assert n_over < len(reads)  # (some answers came through)
+
+
+def test_align_over_an_sv_deletion():
+    sv_deletion_case(harness.EmuBackend)

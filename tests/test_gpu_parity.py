@@ -10,7 +10,7 @@ import harness
 import scenarios
 from graphtyper_amd import lib as gtx
 from oracle_lib import Oracle, encode
-from test_emu_parity import check_align, edge_case, express_variants_case, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case
+from test_emu_parity import check_align, sv_deletion_case, edge_case, express_variants_case, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case
 
 pytestmark = pytest.mark.gpu
 
@@ -127,3 +127,7 @@ def test_pass_times_are_reported():
     b.align(gtx.pack_nibbles(codes), harness.read_meta(np.full(len(codes), 150)))
     ms, handed_on = b.ctx.pass_times()
     assert all(x > 0 for x in ms) and 0 < handed_on < len(codes)
+
+
+def test_align_over_an_sv_deletion():
+    sv_deletion_case(harness.GpuBackend)

@@ -161,3 +161,24 @@ def test_index_events(chrom):  # :352-446  (GT_ID / GT_ANTI_HAPLOTYPE; GT_HAPLOT
     else:
         lab = o.index_get("AGGGGGAGTGGGGGGGGGGGGGGGGGGGGGGG")
         assert sorted(l[2] for l in lab) == [1, 3]
+
+
+# ---------------------------------------------------------------- test/index/test_index.cpp:246-312 (an SV deletion)
+def test_index_chr5():
+    from fixtures import sv_contig
+    ref, recs = sv_contig("chr5")
+    o = Oracle(ref, recs, is_sv_graph=True)  # (create_test_graph's fourth argument is construct_graph's is_sv_graph)
+    assert o.index_check()
+    assert o.all_ref() == "A" * 70 + "C" * 70 + "G" * 70 + "T" * 70
+    K = 32
+    assert len(o.index_get(("A" * 32))) == 40
+    l1 = o.index_get(("A" * 31 + "G"))
+    assert len(l1) == 1 and (l1[0][0], l1[0][1]) == (40, SPECIAL_START)
+    l2 = o.index_get(("A" * 30 + "GG"))
+    assert len(l2) == 1 and (l2[0][0], l2[0][1]) == (41, SPECIAL_START + 1)
+    l3 = o.index_get(("A" + "G" * 31))
+    assert len(l3) == 1 and (l3[0][0], l3[0][1]) == (70, SPECIAL_START + 30)
+    l4 = o.index_get(("G" * 32))
+    assert len(l4) == 2 * (71 - K)
+    assert sum(1 for lb in l4 if lb[0] == SPECIAL_START + 1) == 1
+    assert len(o.index_get(("T" * 32))) == 2 * (71 - K)
