@@ -182,3 +182,15 @@ def test_index_chr5():
     assert len(l4) == 2 * (71 - K)
     assert sum(1 for lb in l4 if lb[0] == SPECIAL_START + 1) == 1
     assert len(o.index_get(("T" * 32))) == 2 * (71 - K)
+
+
+# ---------------------------------------------------------------- test/graph/test_haplotypes.cpp:12-40
+def test_haplotype_with_one_genotype():
+    """two records at one position merge into one site: Graph::get_all_haplotypes() has one haplotype with three alleles
+    (REQUIRE(haps.size() == 1); REQUIRE(haps[0].get_genotype_num() == 3)); the product's builder and layout agree"""
+    from graphtyper_amd import lib as gtx
+    recs = [(1, "GTACG", ["G"], "."), (1, "G", ["K"], ".")]
+    og = Oracle("SGTACGEEF", recs).graph()
+    assert int((og["ref_nvar"] > 0).sum()) == 1 and int(og["ref_nvar"].max()) == 3
+    ctx = gtx.Context(gtx.graph_from_records("SGTACGEEF", recs), device=-1)
+    assert ctx.n_hap == 1 and list(ctx.hap_cnum) == [3] and ctx.total_tri == 6 and ctx.total_allele == 3
