@@ -81,3 +81,50 @@ def test_genotype_calls_recover_the_sample():
             assert (gt1, gt2) == (0, 0) and phred[0] == 0 and alt_depth == 0, (k, gt1, gt2, list(phred), ref_depth, alt_depth)
         assert gq > 0
     assert at == len(words) and n_het > 30
+
+
+def test_reads_of_an_indel_haplotype_come_back_with_its_alleles():
+    """SNPs, insertions and deletions every 80 bp: error-free reads cut from the alternative haplotype must align as one
+    path over the whole read without mismatches and carry, at every site well inside the read, the allele the haplotype
+    has there (graph walks over alleles of unequal length, special positions of inserted bases)"""
+    n_ref, rb, L, n_reads = 30000, 500000, 150, 400
+    rng = np.random.default_rng(4)
+    ref = synth.make_reference(n_ref, seed=11)
+    recs = synth.make_indel_records(ref, 80, seed=6, region_begin=rb)
+    take = rng.random(len(recs)) < 0.5
+    hap, coord, cur = [], [], 0  # the haplotype and, per base, the reference coordinate it came from (-1: inserted)
+    for (p, r, alts, _), t in zip(recs, take):
+        p -= rb
+        hap.append(ref[cur:p])
+        coord.append(np.arange(cur, p))
+        if t:
+            a = np.array(["ACGT".index(c) for c in alts[0]], np.uint8)
+            c = np.full(len(a), -1)
+            c[0] = p
+            hap.append(a)
+            coord.append(c)
+        else:
+            hap.append(ref[p:p + len(r)])
+            coord.append(np.arange(p, p + len(r)))
+        cur = p + len(r)
+    hap.append(ref[cur:])
+    coord.append(np.arange(cur, n_ref))
+    hap1, coord1 = np.concatenate(hap), np.concatenate(coord)
+    o = Oracle(synth.bases_to_str(ref), recs, region_begin=rb)
+    start = rng.integers(1, len(hap1) - L, size=n_reads)
+    got = o.align([CODE[hap1[s:s + L]] for s in start])
+    site_pos = np.array([p - rb for p, _, _, _ in recs])
+    site_end = site_pos + np.array([len(r[1]) for r in recs])
+    n_sites = 0
+    for i, (fwd, _rev) in enumerate(got):
+        assert len(fwd["paths"]) == 1, (i, fwd)
+        p = fwd["paths"][0]
+        assert (p["mm"], p["rs"], p["re"]) == (0, 0, L - 1), (i, p)
+        seen = {order: nums for order, nums in p["vars"]}
+        cs = coord1[start[i]:start[i] + L]
+        cs = cs[cs >= 0]
+        for k in np.nonzero((site_pos > cs.min() + 3) & (site_end < cs.max() - 3))[0]:
+            nums = seen.get(int(rb + site_pos[k] + 1))
+            assert nums is not None and (1 if take[k] else 0) in nums, (i, k, seen)
+            n_sites += 1
+    assert n_sites > 300
