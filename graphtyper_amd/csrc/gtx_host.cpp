@@ -384,25 +384,63 @@ struct Walker
 
 } // namespace
 
-// Stable LSD radix sort of (key, payload) pairs on the low `key_bits` bits of the key, 16 bits per pass.
+// ---- a team of host threads for the index build (GTX_HOST_THREADS overrides; the build is ~1 M keys per Mb of graph)
+static unsigned host_threads()
+{
+  if (char const * e = std::getenv("GTX_HOST_THREADS"))
+    return static_cast<unsigned>(std::max(1, std::atoi(e)));
+  unsigned const hw = std::thread::hardware_concurrency();
+  return std::max(1u, std::min(hw ? hw : 1u, 8u)); // (measured on a 256-thread host: 1 / 4 / 8 / 16 / 32 threads = 0.25 / 0.21 / 0.17 / 0.23 / 0.42 s:
+                                                   //  the stages are short and memory-bound, a larger team costs more to start than it saves)
+}
+
+// runs fn(t, begin, end) over T contiguous slices of [0, n)
+template <class F>
+static void parallel_slices(std::size_t n, unsigned T, F fn)
+{
+  if (T <= 1 || n < 4096)
+  {
+    fn(0u, std::size_t(0), n);
+    return;
+  }
+  std::vector<std::thread> team;
+  team.reserve(T);
+  for (unsigned t = 0; t < T; ++t)
+    team.emplace_back([=, &fn] { fn(t, n * t / T, n * (t + 1) / T); });
+  for (auto & th : team)
+    th.join();
+}
+
+// Stable LSD radix sort of (key, payload) pairs on the low `key_bits` bits of the key, 16 bits per pass; every pass is
+// done by the team: per-slice histograms, offsets in (digit, slice) order -- which keeps it stable --, parallel scatter.
 static void radix_sort_pairs(std::vector<std::pair<uint64_t, uint32_t>> & v, unsigned key_bits)
 {
-  std::vector<std::pair<uint64_t, uint32_t>> tmp(v.size());
-  std::vector<uint32_t> count(1u << 16);
+  std::size_t const n = v.size();
+  unsigned const T = n < (1u << 16) ? 1u : host_threads();
+  std::vector<std::pair<uint64_t, uint32_t>> tmp(n);
+  std::vector<uint32_t> count(static_cast<std::size_t>(T) << 16);
   for (unsigned shift = 0; shift < key_bits; shift += 16)
   {
     std::fill(count.begin(), count.end(), 0u);
-    for (auto const & e : v)
-      ++count[(e.first >> shift) & 0xFFFFu];
+    parallel_slices(n, T, [&](unsigned t, std::size_t b, std::size_t e) {
+      uint32_t * c = count.data() + (static_cast<std::size_t>(t) << 16);
+      for (std::size_t i = b; i < e; ++i)
+        ++c[(v[i].first >> shift) & 0xFFFFu];
+    });
     uint32_t sum = 0;
-    for (auto & c : count)
-    {
-      uint32_t const n = c;
-      c = sum;
-      sum += n;
-    }
-    for (auto const & e : v)
-      tmp[count[(e.first >> shift) & 0xFFFFu]++] = e;
+    for (uint32_t d = 0; d < (1u << 16); ++d)
+      for (unsigned t = 0; t < T; ++t)
+      {
+        uint32_t & c = count[(static_cast<std::size_t>(t) << 16) + d];
+        uint32_t const k = c;
+        c = sum;
+        sum += k;
+      }
+    parallel_slices(n, T, [&](unsigned t, std::size_t b, std::size_t e) {
+      uint32_t * c = count.data() + (static_cast<std::size_t>(t) << 16);
+      for (std::size_t i = b; i < e; ++i)
+        tmp[c[(v[i].first >> shift) & 0xFFFFu]++] = v[i];
+    });
     v.swap(tmp);
   }
 }
@@ -420,15 +458,62 @@ static void bucket_insert(std::vector<IndexSlot> & slots, uint32_t log2_buckets,
 }
 
 // Inserts in bucket order: the table is written front to back instead of at a million random places (which bucket a
-// spilled slot lands in depends on the order, what a lookup finds does not).
+// spilled slot lands in depends on the order, what a lookup finds does not).  The team splits the sorted items at bucket
+// boundaries; a thread may only write buckets of its own range, an item that would spill past it waits for the
+// sequential sweep at the end (linear probing without deletions: any insertion order gives a table lookups can read).
 static void bucket_insert_all(std::vector<IndexSlot> & slots, uint32_t log2_buckets, std::vector<IndexSlot> const & items)
 {
-  std::vector<std::pair<uint64_t, uint32_t>> order(items.size());
-  for (std::size_t i = 0; i < items.size(); ++i)
-    order[i] = {hash_key(items[i].key, log2_buckets), static_cast<uint32_t>(i)};
+  std::size_t const n = items.size();
+  std::vector<std::pair<uint64_t, uint32_t>> order(n);
+  unsigned const T = n < (1u << 16) ? 1u : host_threads();
+  parallel_slices(n, T, [&](unsigned, std::size_t b, std::size_t e) {
+    for (std::size_t i = b; i < e; ++i)
+      order[i] = {hash_key(items[i].key, log2_buckets), static_cast<uint32_t>(i)};
+  });
   radix_sort_pairs(order, log2_buckets);
-  for (auto const & o : order)
-    bucket_insert(slots, log2_buckets, items[o.second]);
+  if (T <= 1)
+  {
+    for (auto const & o : order)
+      bucket_insert(slots, log2_buckets, items[o.second]);
+    return;
+  }
+  // slice boundaries moved forward to the next change of bucket
+  std::vector<std::size_t> cut(T + 1);
+  for (unsigned t = 0; t <= T; ++t)
+  {
+    std::size_t c = n * t / T;
+    while (c > 0 && c < n && order[c].first == order[c - 1].first)
+      ++c;
+    cut[t] = c;
+  }
+  std::vector<std::vector<uint32_t>> late(T);
+  std::vector<std::thread> team;
+  for (unsigned t = 0; t < T; ++t)
+    team.emplace_back([&, t] {
+      std::size_t const b = cut[t], e = cut[t + 1];
+      if (b >= e)
+        return;
+      uint64_t const limit = e < n ? order[e].first : (1ull << log2_buckets); // first bucket of the next slice
+      for (std::size_t i = b; i < e; ++i)
+      {
+        IndexSlot const & s = items[order[i].second];
+        bool placed = false;
+        for (uint64_t bk = order[i].first; bk < limit && !placed; ++bk)
+          for (uint32_t k = 0; k < BUCKET_SLOTS && !placed; ++k)
+            if (slots[bk * BUCKET_SLOTS + k].cnt == 0)
+            {
+              slots[bk * BUCKET_SLOTS + k] = s;
+              placed = true;
+            }
+        if (!placed)
+          late[t].push_back(order[i].second);
+      }
+    });
+  for (auto & th : team)
+    th.join();
+  for (auto const & l : late)
+    for (uint32_t i : l)
+      bucket_insert(slots, log2_buckets, items[i]);
 }
 
 void build_index(HostGraph const & g, HostIndex & out)
@@ -507,44 +592,52 @@ void build_index(HostGraph const & g, HostIndex & out)
   out.key_off.push_back(static_cast<uint32_t>(out.labels.size()));
   lap("group by key");
   out.dev_labels.resize(out.labels.size());
-  for (std::size_t i = 0; i < out.labels.size(); ++i)
-  {
-    gtx_label const & l = out.labels[i];
-    DevLabel d{l.start_index, l.end_index, INVALID, 0};
-    if (l.variant_id != INVALID)
+  parallel_slices(out.labels.size(), host_threads(), [&](unsigned, std::size_t b, std::size_t e) {
+    for (std::size_t i = b; i < e; ++i)
     {
-      d.site = g.var_out_ref[l.variant_id] - 1;
-      d.allele = l.variant_id - g.ref_first_var[d.site];
+      gtx_label const & l = out.labels[i];
+      DevLabel d{l.start_index, l.end_index, INVALID, 0};
+      if (l.variant_id != INVALID)
+      {
+        d.site = g.var_out_ref[l.variant_id] - 1;
+        d.allele = l.variant_id - g.ref_first_var[d.site];
+      }
+      out.dev_labels[i] = d;
     }
-    out.dev_labels[i] = d;
-  }
+  });
   // device form: (plane key, label offset, label count) of every key, then the exact table (own thread) and the two
   // half-key tables
   std::vector<HalfEntry> all(out.keys.size());
-  for (std::size_t k = 0; k < out.keys.size(); ++k)
-    all[k] = HalfEntry{plane_key(out.keys[k]), out.key_off[k], out.key_off[k + 1] - out.key_off[k]};
+  parallel_slices(out.keys.size(), host_threads(), [&](unsigned, std::size_t b, std::size_t e) {
+    for (std::size_t k = b; k < e; ++k)
+      all[k] = HalfEntry{plane_key(out.keys[k]), out.key_off[k], out.key_off[k + 1] - out.key_off[k]};
+  });
   lap("plane keys");
   uint32_t log2_cap = 2;
   while ((static_cast<uint64_t>(BUCKET_SLOTS) << log2_cap) < 2 * out.keys.size() + 1)
     ++log2_cap;
   out.log2_cap = log2_cap;
-  std::thread exact_table([&out, &all, log2_cap] {
+  unsigned const T = host_threads();
+  {
     out.slots.assign(static_cast<uint64_t>(BUCKET_SLOTS) << log2_cap, IndexSlot{0, 0, 0, {0, 0, 0, 0}});
     std::vector<IndexSlot> items(all.size());
-    for (std::size_t k = 0; k < all.size(); ++k)
-    {
-      items[k] = IndexSlot{all[k].key, all[k].off, all[k].cnt, {0, 0, 0, 0}};
-      if (all[k].cnt == 1) // inline copy of the one label
+    parallel_slices(all.size(), T, [&](unsigned, std::size_t b, std::size_t e) {
+      for (std::size_t k = b; k < e; ++k)
       {
-        DevLabel const & d = out.dev_labels[all[k].off];
-        items[k].p[0] = d.start;
-        items[k].p[1] = d.end;
-        items[k].p[2] = d.site;
-        items[k].p[3] = d.allele;
+        items[k] = IndexSlot{all[k].key, all[k].off, all[k].cnt, {0, 0, 0, 0}};
+        if (all[k].cnt == 1) // inline copy of the one label
+        {
+          DevLabel const & d = out.dev_labels[all[k].off];
+          items[k].p[0] = d.start;
+          items[k].p[1] = d.end;
+          items[k].p[2] = d.site;
+          items[k].p[3] = d.allele;
+        }
       }
-    }
+    });
     bucket_insert_all(out.slots, log2_cap, items);
-  });
+  }
+  lap("exact table");
   // half-key buckets (plane-form keys: the 16 first bases are bits 0..15 of both words, the 16 last bases bits 16..31)
   {
     size_t const n = out.keys.size();
@@ -566,13 +659,17 @@ void build_index(HostGraph const & g, HostIndex & out)
       // orders its candidates by neighbour number): out.keys ascending is already grouped by the first 16 bases; for
       // the last 16 bases a stable radix sort on the low 32 bits of the 2-bit key
       std::vector<std::pair<uint64_t, uint32_t>> order(n);
-      for (size_t k = 0; k < n; ++k)
-        order[k] = {out.keys[k], static_cast<uint32_t>(k)};
+      parallel_slices(n, T, [&](unsigned, std::size_t b, std::size_t e) {
+        for (size_t k = b; k < e; ++k)
+          order[k] = {out.keys[k], static_cast<uint32_t>(k)};
+      });
       if (side == 1)
         radix_sort_pairs(order, 32);
       size_t const base = side * n;
-      for (size_t k = 0; k < n; ++k)
-        out.hlist[base + k] = all[order[k].second];
+      parallel_slices(n, T, [&](unsigned, std::size_t b, std::size_t e) {
+        for (size_t k = b; k < e; ++k)
+          out.hlist[base + k] = all[order[k].second];
+      });
       std::vector<IndexSlot> & items = side_items[side];
       items.reserve(n);
       size_t k = 0;
@@ -596,18 +693,14 @@ void build_index(HostGraph const & g, HostIndex & out)
         k = e;
       }
     };
-    std::thread other_side(build_side, 1);
     build_side(0);
-    other_side.join();
+    build_side(1);
     std::vector<IndexSlot> half_items(std::move(side_items[0]));
     half_items.insert(half_items.end(), side_items[1].begin(), side_items[1].end());
     lap("  half lists");
     bucket_insert_all(out.hslots, hl, half_items);
   }
   lap("half-key tables");
-  exact_table.join();
-  lap("exact table (rest)");
-  lap("device labels");
 }
 
 } // namespace gtx
