@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Randomised long-running parity sweep on the CPU (not collected by pytest): the kernel sources through the host
+emulation against the oracle over seeds x graph shapes x error / N rates x read lengths x region offsets, for both builds
+of pass 1; with --stream also the scoring path (gtx_stream -> align -> score -> calls -> phase flags).
+    python tests/stress_emu.py 100 110            # alignment, seeds 100..109
+    python tests/stress_emu.py --stream 300 310"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import harness  # noqa: E402
+import scenarios  # noqa: E402
+from graphtyper_amd import lib as gtx  # noqa: E402
+from oracle_lib import Oracle  # noqa: E402
+from test_emu_parity import check_align, run_stream  # noqa: E402
+
+
+def align_seed(seed):
+    rng = np.random.default_rng(seed)
+    n = 0
+    for kind in ["snp25", "indel", "cluster", "snp100", "snp7"]:
+        err = float(rng.choice([0.0, 0.005, 0.03]))
+        n_rate = float(rng.choice([0.0, 0.001, 0.01]))
+        read_len = int(rng.choice([100, 125, 150, 151, 187]))
+        rb = int(rng.choice([0, 1000, 1000000]))
+        ref, recs, codes, _ = scenarios.synthetic_case(kind, n_ref=50000, n_reads=1500, region_begin=rb, err=err, n_rate=n_rate,
+                                                       seed=seed, read_len=read_len)
+        aav = kind == "cluster"
+        g = gtx.graph_from_records(ref, recs, region_begin=rb, add_all_variants=aav)
+        o = Oracle(ref, recs, region_begin=rb, add_all_variants=aav)
+        for mode in ["lean", "wide"]:
+            os.environ["GTX_EXPRESS4"] = mode
+            try:
+                check_align(harness.EmuBackend(g), o, list(codes))
+            except AssertionError:
+                print("FAIL", dict(seed=seed, kind=kind, mode=mode, err=err, n_rate=n_rate, read_len=read_len, region_begin=rb), flush=True)
+                raise
+            n += 1
+    return n
+
+
+def stream_seed(seed):
+    rng = np.random.default_rng(seed)
+    n = 0
+    for kind in ["snp100", "snp25", "indel"]:
+        ns = int(rng.choice([1, 2, 5]))
+        rb = int(rng.choice([0, 310000]))
+        ref, recs, codes, rec = scenarios.paired_case(kind, n_ref=30000, n_pairs=700, region_begin=rb, n_samples=ns, seed=seed,
+                                                     discordant_frac=float(rng.choice([0.0, 0.1, 0.3])), dup_frac=0.05, lowq_frac=0.1)
+        o = Oracle(ref, recs, region_begin=rb)
+        for mode in ["lean", "wide"]:
+            os.environ["GTX_EXPRESS4"] = mode
+            try:
+                run_stream(harness.EmuBackend(gtx.graph_from_records(ref, recs, region_begin=rb)), o, codes, rec, n_samples=ns)
+            except AssertionError as e:
+                if str(e) == "":  # run_stream's "not vacuous" check on a small case: not a parity failure
+                    continue
+                print("FAIL", dict(seed=seed, kind=kind, mode=mode, n_samples=ns, region_begin=rb), flush=True)
+                raise
+            n += 1
+    return n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("first", type=int)
+    ap.add_argument("last", type=int)
+    ap.add_argument("--stream", action="store_true")
+    a = ap.parse_args()
+    gtx.build()
+    t0, n = time.time(), 0
+    for seed in range(a.first, a.last):
+        n += stream_seed(seed) if a.stream else align_seed(seed)
+        print("seed %d ok, %d cases, %.0f s" % (seed, n, time.time() - t0), flush=True)
+
+
+if __name__ == "__main__":
+    main()
