@@ -36,7 +36,7 @@ def _worker(rank, world, port, tmp):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    ref, recs, codes, rec = scenarios.paired_case("snp100", n_ref=8000, n_pairs=30, region_begin=0, n_samples=2)
+    ref, recs, codes, rec = scenarios.paired_case("snp25", n_ref=8000, n_pairs=30, region_begin=0, n_samples=2)
     b = harness.EmuBackend(gtx.graph_from_records(ref, recs))
     st = gtx.Stream(b.ctx.params, 1)
     a_seq, a_meta, items = st.push(rec, gtx.pack_nibbles(codes))
@@ -44,8 +44,10 @@ def _worker(rank, world, port, tmp):
     lo, hi = shard_bounds(len(items), world, rank)
     acc = b.score(items[lo:hi], records, 2)
     tensors = [torch.from_numpy(a.view(np.int64 if a.dtype == np.uint64 else np.int32)) for a in
-               (acc.log_score, acc.gt_cov, acc.hap_u32, acc.stat_u64, acc.stat_u32)]
+               (acc.log_score, acc.gt_cov, acc.hap_u32, acc.stat_u64, acc.stat_u32, acc.conn_near)]
     reduce_scores(dist, tensors)
+    # the far-pair connection log is not reduced: every rank keeps its entries
+    np.save(os.path.join(tmp, "log_%d.npy" % rank), acc.conn_log[:6 * int(acc.conn_count[0])])
     if rank == 0:
         np.save(os.path.join(tmp, "reduced.npy"), np.concatenate([t.numpy().astype(np.int64) for t in tensors]))
     dist.barrier()
@@ -54,16 +56,28 @@ def _worker(rank, world, port, tmp):
 
 def test_two_rank_reduce_equals_single_pass(tmp_path):
     gtx.build()
-    ref, recs, codes, rec = scenarios.paired_case("snp100", n_ref=8000, n_pairs=30, region_begin=0, n_samples=2)
+    ref, recs, codes, rec = scenarios.paired_case("snp25", n_ref=8000, n_pairs=30, region_begin=0, n_samples=2)
     b = harness.EmuBackend(gtx.graph_from_records(ref, recs))
     st = gtx.Stream(b.ctx.params, 1)
     a_seq, a_meta, items = st.push(rec, gtx.pack_nibbles(codes))
     records = b.align(a_seq, a_meta)
     np.save(tmp_path / "records.npy", records)
     acc = b.score(items, records, 2)
-    single = np.concatenate([a.astype(np.int64) for a in (acc.log_score, acc.gt_cov, acc.hap_u32, acc.stat_u64, acc.stat_u32)])
+    parts = (acc.log_score, acc.gt_cov, acc.hap_u32, acc.stat_u64, acc.stat_u32, acc.conn_near)
+    single = np.concatenate([a.astype(np.int64) for a in parts])
     port = 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     reduced = np.load(tmp_path / "reduced.npy")
     assert np.array_equal(single, reduced)
-    assert single.sum() > 0
+    assert single.sum() > 0 and acc.conn_near.sum() > 0
+    # reduced counters + the ranks' logs side by side = the single-process state (connections included)
+    both = harness.Accumulators(b.ctx, 2)
+    at = 0
+    for dst in (both.log_score, both.gt_cov, both.hap_u32, both.stat_u64, both.stat_u32, both.conn_near):
+        dst[...] = reduced[at:at + len(dst)].astype(dst.dtype)
+        at += len(dst)
+    logs = np.concatenate([np.load(tmp_path / ("log_%d.npy" % r)) for r in range(2)])
+    both.conn_log[:len(logs)] = logs
+    both.conn_count[0] = len(logs) // 6
+    assert int(acc.conn_count[0]) == len(logs) // 6 > 0
+    assert np.array_equal(harness.canonical_scores(b.ctx, acc), harness.canonical_scores(b.ctx, both))
