@@ -128,3 +128,38 @@ def test_reads_of_an_indel_haplotype_come_back_with_its_alleles():
             assert nums is not None and (1 if take[k] else 0) in nums, (i, k, seen)
             n_sites += 1
     assert n_sites > 300
+
+
+def _one_site_scores(read_codes, pos, **push_kw):
+    """log_score triangle, gt_cov and max_log_score of a one-SNP graph after one read (layout: harness.canonical_scores)"""
+    ref = synth.make_reference(400, seed=5)
+    p = 200
+    alt = "ACGT"[(int(ref[p]) + 1) % 4]
+    recs = [(p, "ACGT"[int(ref[p])], [alt], None)]
+    o = Oracle(synth.bases_to_str(ref), recs)
+    g = o.genotyper(1, 1)
+    reads = []
+    for kind, start, n_err in read_codes:
+        bases = ref[start:start + 150].copy()
+        if kind == "alt":
+            bases[p - start] = "ACGT".index(alt)
+        for k in range(n_err):  # substitutions far from the site
+            bases[5 + 7 * k] = (bases[5 + 7 * k] + 1) % 4
+        reads.append(CODE[bases])
+    g.push(reads, pos=np.array([s for _, s, _ in read_codes]) + pos, **push_kw)
+    w = g.scores()
+    # hap header 3 + mapq_squared 2 + 2 alleles x (2 + 2 + 6) = 25 words, then the sample: 4 hap_u32, 2 gt_cov, 3 log_score
+    assert w[1] == 2
+    return list(w[31:34]), list(w[29:31]), int(w[25])
+
+
+def test_explain_to_score_on_one_read():
+    """Haplotype::explain_to_score (haplotype.cpp:462-585) as SURVEY.md 8(a17) states it: eps = max(12 - mismatches - ...,
+    8) - 4; a genotype gets eps when both its alleles are explained, eps - 1 when one is, 0 when none"""
+    assert _one_site_scores([("ref", 100, 0)], 0) == ([8, 7, 0], [1, 0], 8)
+    assert _one_site_scores([("alt", 100, 0)], 0) == ([0, 7, 8], [0, 1], 8)
+    assert _one_site_scores([("alt", 100, 1)], 0) == ([0, 6, 7], [0, 1], 7)
+    assert _one_site_scores([("alt", 100, 3)], 0) == ([0, 4, 5], [0, 1], 5)
+    assert _one_site_scores([("alt", 100, 5)], 0) == ([0, 3, 4], [0, 1], 4)  # eps never drops below 4
+    both, cov, _ = _one_site_scores([("ref", 100, 0), ("alt", 110, 0), ("alt", 90, 0)], 0)
+    assert both == [8, 21, 16] and cov == [1, 2]
