@@ -163,3 +163,10 @@ def test_explain_to_score_on_one_read():
     assert _one_site_scores([("alt", 100, 5)], 0) == ([0, 3, 4], [0, 1], 4)  # eps never drops below 4
     both, cov, _ = _one_site_scores([("ref", 100, 0), ("alt", 110, 0), ("alt", 90, 0)], 0)
     assert both == [8, 21, 16] and cov == [1, 2]
+
+
+def test_explain_to_score_penalties():
+    """... - 2 for MAPQ below 25 (alignment.cpp:365-480 sets IS_MAPQ_BAD), floor at 8 before the final - 4"""
+    assert _one_site_scores([("alt", 100, 0)], 0, mapq=np.array([20]))[0] == [0, 5, 6]
+    assert _one_site_scores([("alt", 100, 1)], 0, mapq=np.array([20]))[0] == [0, 4, 5]
+    assert _one_site_scores([("alt", 100, 3)], 0, mapq=np.array([20]))[0] == [0, 3, 4]
