@@ -35,10 +35,14 @@ def align_seed(seed):
         aav = kind == "cluster"
         g = gtx.graph_from_records(ref, recs, region_begin=rb, add_all_variants=aav)
         o = Oracle(ref, recs, region_begin=rb, add_all_variants=aav)
+        # paired flags: unpaired, discordant (both orientations), proper pair (forward only); ragged lengths
+        flags = rng.choice([0, 1 | 64, 1 | 2 | 32 | 64], size=len(codes)).astype(np.uint16)
+        isize = rng.integers(-2000, 2000, size=len(codes))
+        reads = [c[:int(n)] for c, n in zip(codes, rng.integers(max(50, read_len - 60), read_len + 1, size=len(codes)))]
         for mode in ["lean", "wide"]:
             os.environ["GTX_EXPRESS4"] = mode
             try:
-                check_align(harness.EmuBackend(g), o, list(codes))
+                check_align(harness.EmuBackend(g), o, reads, flags=flags, isize=isize)
             except AssertionError:
                 print("FAIL", dict(seed=seed, kind=kind, mode=mode, err=err, n_rate=n_rate, read_len=read_len, region_begin=rb), flush=True)
                 raise
