@@ -170,3 +170,30 @@ def test_explain_to_score_penalties():
     assert _one_site_scores([("alt", 100, 0)], 0, mapq=np.array([20]))[0] == [0, 5, 6]
     assert _one_site_scores([("alt", 100, 1)], 0, mapq=np.array([20]))[0] == [0, 4, 5]
     assert _one_site_scores([("alt", 100, 3)], 0, mapq=np.array([20]))[0] == [0, 3, 4]
+
+
+def test_reverse_complemented_reads_align_in_the_second_orientation():
+    """align_read (alignment.cpp:331-363): an unpaired read and the mate of a concordant pair are aligned as given only;
+    a paired read that is not part of a concordant pair is also tried reverse-complemented.  A reverse-complemented
+    error-free read must then come back in the second orientation exactly as the original does in the first"""
+    n_ref, rb, L = 20000, 100000, 150
+    rng = np.random.default_rng(12)
+    ref = synth.make_reference(n_ref, seed=21)
+    recs = synth.make_snp_records(ref, 100, seed=2, region_begin=rb)
+    o = Oracle(synth.bases_to_str(ref), recs, region_begin=rb)
+    n = 100
+    start = rng.integers(1, n_ref - L, size=n)
+    fwd_reads = [CODE[ref[s:s + L]] for s in start]
+    rc_reads = [CODE[3 - ref[s:s + L][::-1]] for s in start]
+    zeros = np.zeros(n, np.int32)
+    a = o.align(fwd_reads)
+    assert all(x[0]["paths"] and not x[1]["paths"] for x in a)
+    unpaired = o.align(rc_reads)
+    assert all(not x[0]["paths"] and not x[1]["paths"] for x in unpaired)  # forward only, and forward does not match
+    discordant = np.full(n, 1 | 64, np.uint16)  # paired, not a proper pair, insert size far beyond 1200
+    b = o.align(rc_reads, flags=discordant, tid=zeros, mtid=zeros, isize=np.full(n, 50000))
+    for i in range(n):
+        assert b[i][1] == a[i][0] and not b[i][0]["paths"], i
+    proper = np.full(n, 1 | 2 | 32 | 64, np.uint16)  # paired, proper pair, mate reverse, first in pair
+    c = o.align(rc_reads, flags=proper, tid=zeros, mtid=zeros, isize=np.full(n, 400))
+    assert all(not x[0]["paths"] and not x[1]["paths"] for x in c)
