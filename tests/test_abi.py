@@ -28,3 +28,14 @@ def test_binding_declares_argument_types_for_every_entry_point():
     L = gtx.lib()
     missing = [n for n in gtx.EXPORTS if getattr(L, n).argtypes is None and n not in ("gtx_last_error",)]
     assert missing == []
+
+
+def test_header_is_plain_c(tmp_path):
+    """the boundary is a C ABI: include/gtx.h has to compile as C99 (no C++ types in the signatures) and link against
+    the library"""
+    import subprocess
+    src = tmp_path / "use_gtx.c"
+    src.write_text('#include "gtx.h"\nint main(void) { gtx_params p; gtx_score_buffers b; (void)p; (void)b; '
+                   'return gtx_strerror(0) == 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-c",
+                           str(src), "-o", str(tmp_path / "use_gtx.o")])
