@@ -168,3 +168,27 @@ def test_product_graph_equals_oracle_on_random_records(add_all, with_events):
             assert [int(x) for x in g["event_val"][o1:o2]] == want_a, (trial, v)
         n_checked += 1
     assert n_checked > 100
+
+
+# test/graph/test_graph.cpp:1436-1519 "Variant overlapping a N on the reference genome": three graphs in one test case
+# (the extractor takes one graph per case, so these are written out here)
+N_REFERENCE = "GCTGCGGCGGGCGTCGCGGCCGCCCCCGGGGAGCCCGGCGGGCGCCGGCGCGNCCCCCCCCCCACCCCACGTCTCGTCGCGCGCGC"
+
+
+@pytest.mark.parametrize("records,n_ref,n_var,var_dna", [
+    ([(51, "GN", ["GA"], None)], 1, 0, []),               # the reference allele has an N: nothing is added
+    ([(51, "G", ["GN", "GA"], None)], 2, 2, ["G", "GA"]),  # an alternative allele has an N: that allele is dropped
+    ([(51, "G", ["GN", "GNN"], None)], 1, 0, []),         # every alternative allele has an N: the variant is removed
+])
+@pytest.mark.parametrize("builder", ["oracle", "product"])
+def test_variant_overlapping_an_n(records, n_ref, n_var, var_dna, builder):
+    assert len(N_REFERENCE) == 86
+    if builder == "oracle":
+        g = Oracle(N_REFERENCE, records, add_all_variants=True).graph()
+    else:
+        g = gtx.graph_from_records(N_REFERENCE, records, add_all_variants=True)
+    got_ref, got_var = node_tables(g)
+    assert len(got_ref) == n_ref and len(got_var) == n_var
+    assert got_var == var_dna
+    if n_ref == 1:
+        assert got_ref[0] == N_REFERENCE
