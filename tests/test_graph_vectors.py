@@ -192,3 +192,26 @@ def test_variant_overlapping_an_n(records, n_ref, n_var, var_dna, builder):
     assert got_var == var_dna
     if n_ref == 1:
         assert got_ref[0] == N_REFERENCE
+
+
+def test_merged_nodes_carry_the_union_of_events():
+    """test/graph/test_graph.cpp:2330-2431: three adjacent SNPs with parity events merge (add_all_variants) into one site;
+    the reference allele CAG has events {-1,-2,-3} and anti-events {2,3}, the alternative TGA events {1,2,3} and
+    anti-events {-2,-3} -- in the oracle's graph and in the product's event tables"""
+    case = [c for c in CASES if c["name"].startswith("parity events test case 2")][0]
+    recs = records_of(case)
+    want = [({-1, -2, -3}, {2, 3}), ({1, 2, 3}, {-2, -3})]
+    og = Oracle(case["reference"], recs, add_all_variants=True, extend_prefix=case["extend_prefix"]).graph()
+    ev, at = [int(x) for x in og["events"]], 0
+    for events, anti in want:  # per var node: n_events, n_anti, then the values
+        ne, na = ev[at], ev[at + 1]
+        assert set(ev[at + 2:at + 2 + ne]) == events and set(ev[at + 2 + ne:at + 2 + ne + na]) == anti
+        at += 2 + ne + na
+    assert at == len(ev)
+    g = gtx.graph_from_records(case["reference"], recs, add_all_variants=True, extend_prefix=case["extend_prefix"])
+    _, var_dna = node_tables(g)
+    assert var_dna == ["CAG", "TGA"]
+    off, val = [int(x) for x in g["event_off"]], [int(x) for x in g["event_val"]]
+    for v, (events, anti) in enumerate(want):  # slots 2v = events, 2v+1 = anti-events of var node v
+        assert set(val[off[2 * v]:off[2 * v + 1]]) == events
+        assert set(val[off[2 * v + 1]:off[2 * v + 2]]) == anti
