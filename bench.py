@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- reads/s of the alignment + genotype-scoring hot path on MI355X.
 
-A "step" is one pass of the hot path (gtx_align_batch + gtx_score_batch + gtx_calls_batch through libgtx's C ABI) over one batch of
-synthetic reads that is already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: 1 sample, 10 M
-synthetic 150 bp reads, one 1 Mb region (chr20:1000001-2000000), SNP-only graph.  With --gpus N every rank gets its own
-10 M reads of the same region (weak scaling; graph + index replicated per GPU) and the per-sample score vectors are
-summed with one RCCL all-reduce per step.
+A "step" is one pass of the hot path (gtx_align_batch + gtx_score_batch [+ gtx_scores_reduce] + gtx_calls_batch through
+libgtx's C ABI) over one batch of synthetic reads that is already resident in HBM.  Workload at N=1 = BASELINE.json
+configs[1] ("cfg2"): 1 sample, 10 M synthetic 150 bp reads, one 1 Mb region (chr20:1000001-2000000), SNP-only graph.
+With --gpus N every rank gets its own 10 M reads of the same region (weak scaling; graph + index replicated per GPU) and
+the per-sample score vectors are summed with one RCCL all-reduce group per step (gtx_scores_reduce).
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline` objects.
+Launch: `python bench.py --gpus N` starts N ranks itself (torch.distributed.run on 127.0.0.1); under a launcher that
+already set WORLD_SIZE (the driver's `python -m torch.distributed.run ... bench.py --gpus N`) it is one of the ranks and
+WORLD_SIZE must equal --gpus.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline` objects; at N=1 the
+line also carries `config.extra`: the cfg3-like workload (30 samples, merged multi-allelic SNP+indel graph) measured in
+the same run.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -28,8 +37,113 @@ REC_WORDS = 64
 REGION_BEGIN = 1000000      # chr20:1000001-2000000
 REGION_LEN = 1000000
 READ_LEN = 150
+METRIC = "aligned+genotyped reads/sec over 1 Mb graph region; VCF bit-identical"
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
+    ap.add_argument("--snp-every", type=int, default=1000)
+    ap.add_argument("--err", type=float, default=0.005, help="experiments only; the reported workload uses 0.005")
+    ap.add_argument("--nrate", type=float, default=0.001, help="experiments only; the reported workload uses 0.001")
+    ap.add_argument("--region-len", type=int, default=REGION_LEN, help="experiments only; the reported workload is 1 Mb")
+    ap.add_argument("--cpu-sample", type=int, default=300_000, help="reads timed through the CPU oracle on one core (rank 0, N=1)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU baseline (0 = all host cores, max 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the cfg3-like extra workload")
+    ap.add_argument("--extra-reads", type=int, default=2_000_000)
+    ap.add_argument("--no-hint", action="store_true", help="experiments only: withhold the BAM position from the alignment")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the launch (nccl = RCCL)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch logic only (ranks, process group, one packed all-reduce, max-over-ranks timing): no GPU work, "
+                         "the line carries value null; used by the CPU test of the N>1 launch")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launch
+# ------------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """not under a launcher and --gpus N > 1: become the launcher (one process per GPU, rendezvous on 127.0.0.1)"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def init_ranks(args):
+    """(rank, local_rank, world, dist | None).  The world size comes from the launcher and has to be what --gpus asked for."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if world == 1:
+        return rank, local_rank, world, None
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(args.backend)
+    if dist.get_world_size() != args.gpus:
+        raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    return rank, local_rank, world, dist
+
+
+def max_over_ranks(dist, seconds, device):
+    import torch
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def dry_run(args):
+    """the N>1 control flow of main() without device work: same launch, same barrier + max-over-ranks timing, a packed
+    integer buffer summed over the ranks (what gtx_scores_reduce does with RCCL), one line from rank 0"""
+    import torch
+    rank, local_rank, world, dist = init_ranks(args)
+    packed = torch.arange(1000, dtype=torch.int64) * (rank + 1)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        acc = packed.clone()
+        if dist is not None:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    if dist is not None:
+        dist.barrier()
+    dt = max_over_ranks(dist, time.perf_counter() - t0, "cpu")
+    ok = bool((acc == torch.arange(1000, dtype=torch.int64) * (world * (world + 1) // 2)).all())
+    n_gpus = dist.get_world_size() if dist is not None else 1
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "reads/s", "n_gpus": n_gpus, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1000.0 * dt / max(args.steps, 1), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dry_run": True, "reduce_ok": ok,
+                          "config": {"workload": "none (launch logic only)", "backend": args.backend}}))
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# synthetic input
+# ------------------------------------------------------------------------------------------------------------------
 def make_reads_on_device(torch, ref_bases, records, n, seed, device, REGION_LEN=REGION_LEN, err_rate=0.005, n_rate=0.001):
     """diploid sample: haplotype 0 = reference, haplotype 1 = reference with a random half of the SNPs; 0.5 % substitution
     errors, 0.1 % N; position sorted; returns packed nibbles [n, 80] (uint8) and read start positions"""
@@ -74,37 +188,229 @@ def unpack_nibbles(packed, length):
     return codes[:, :length]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
-    ap.add_argument("--snp-every", type=int, default=1000)
-    ap.add_argument("--err", type=float, default=0.005, help="experiments only; the reported workload uses 0.005")
-    ap.add_argument("--nrate", type=float, default=0.001, help="experiments only; the reported workload uses 0.001")
-    ap.add_argument("--region-len", type=int, default=REGION_LEN, help="experiments only; the reported workload is 1 Mb")
-    ap.add_argument("--cpu-sample", type=int, default=300_000, help="reads timed through the CPU oracle (rank 0, N=1)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+class DevView:
+    """a device pointer as something torch.as_tensor understands"""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# one workload through the C ABI
+# ------------------------------------------------------------------------------------------------------------------
+class Workload:
+    """resident inputs + accumulators of one (graph, reads) pair; step() = align + score [+ reduce] + calls"""
+
+    def __init__(self, torch, gtx, ctx, device, d_seq, d_pos, n_samples, samples=None, hint=True, conn_cap=1 << 24):
+        self.torch, self.gtx, self.ctx, self.device = torch, gtx, ctx, device
+        self.L = gtx.lib()
+        n = int(d_seq.shape[0])
+        self.n, self.n_samples = n, n_samples
+        self.d_seq = d_seq
+        self.stride = int(d_seq.shape[1])
+        pos_host = d_pos.cpu().numpy().astype(np.int32)
+        meta = np.zeros(n, gtx.READ_META)
+        meta["l_qseq"] = READ_LEN
+        meta["pos"] = pos_host if hint else -1
+        self.d_meta = torch.from_numpy(meta.view(np.uint8).reshape(n, gtx.READ_META.itemsize).copy()).to(device)
+        items = np.zeros(n, gtx.SCORE_ITEM)
+        items["first"]["align_index"] = np.arange(n, dtype=np.uint32)
+        items["first"]["mapq"] = 60
+        items["first"]["flag"] = gtx.FLAG_FORWARD_ONLY  # unpaired reads are aligned forward only (what gtx_stream_push sets)
+        items["first"]["pos"] = pos_host
+        items["second"]["align_index"] = gtx.INVALID_ID
+        if samples is not None:
+            items["sample"] = samples
+        self.d_items = torch.from_numpy(items.view(np.uint8).reshape(n, gtx.SCORE_ITEM.itemsize).copy()).to(device)
+        self.d_rec = torch.empty(n * 2 * REC_WORDS, dtype=torch.int32, device=device)
+        self.buf = gtx.ScoreBuffers()
+        reduced = C.c_uint64()
+        gtx.check(self.L.gtx_scores_alloc(ctx.h, n_samples, conn_cap, C.byref(self.buf), C.byref(reduced)))
+        self.reduced_bytes = int(reduced.value)
+        self.d_phred = torch.zeros(max(n_samples * ctx.total_tri, 1), dtype=torch.uint8, device=device)
+        self.d_calls = torch.zeros(max(n_samples * ctx.n_hap, 1) * gtx.SAMPLE_CALL.itemsize, dtype=torch.uint8, device=device)
+        self.stream = torch.cuda.Stream(device=device)
+        self.sp = C.c_void_p(self.stream.cuda_stream)
+        self.comm = None       # ncclComm_t made through gtx_comm_init_rank
+        self.dist = None       # fallback: torch.distributed on views of the packed block
+        self.reduce_kind = None
+
+    def close(self):
+        if self.comm is not None:
+            self.L.gtx_comm_destroy(self.comm)
+            self.comm = None
+        self.L.gtx_scores_free(self.ctx.h, C.byref(self.buf))
+
+    def setup_reduce(self, dist, rank, world, local_rank):
+        """the exchange step: an RCCL communicator for gtx_scores_reduce (id from rank 0 through the process group); if that
+        cannot be had on every rank, the same sums through torch.distributed (also RCCL) on views of the packed block"""
+        torch, gtx, L = self.torch, self.gtx, self.L
+        ident = torch.zeros(128, dtype=torch.uint8, device=self.device)
+        ok = 1
+        if rank == 0:
+            raw = (C.c_uint8 * 128)()
+            ok = 1 if L.gtx_comm_unique_id(raw) == 0 else 0
+            ident = torch.tensor(list(raw), dtype=torch.uint8, device=self.device)
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            dist.broadcast(ident, src=0)
+            raw = (C.c_uint8 * 128)(*ident.cpu().tolist())
+            comm = C.c_void_p()
+            ok = 1 if L.gtx_comm_init_rank(raw, world, rank, local_rank, C.byref(comm)) == 0 else 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                self.comm, self.reduce_kind = comm, "gtx_scores_reduce: one RCCL group (u64 + u32 all-reduce) on the packed block"
+                return
+            if ok:
+                L.gtx_comm_destroy(comm)
+        sys.stderr.write("[bench] rank %d: gtx_scores_reduce unavailable (%s): falling back to torch.distributed\n" %
+                         (rank, L.gtx_last_error().decode()))
+        n64 = self.ctx.n_hap + 2 * self.ctx.total_allele
+        n32 = (self.reduced_bytes - 8 * n64) // 4
+        self.t64 = torch.as_tensor(DevView(self.buf.d_stat_u64, n64, "<i8"), device=self.device)
+        self.t32 = torch.as_tensor(DevView(self.buf.d_log_score, n32, "<i4"), device=self.device)
+        self.dist, self.reduce_kind = dist, "torch.distributed all_reduce x2 on the packed block"
+
+    def step(self):
+        gtx, L, ctx, sp = self.gtx, self.L, self.ctx, self.sp
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            gtx.check(L.gtx_scores_zero(ctx.h, C.byref(self.buf), sp))
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(self.stream)
+            gtx.check(L.gtx_align_batch(ctx.h, self.d_seq.data_ptr(), self.stride, self.d_meta.data_ptr(), self.n, self.d_rec.data_ptr(),
+                                        REC_WORDS, sp))
+            e1.record(self.stream)
+            gtx.check(L.gtx_score_batch(ctx.h, self.d_items.data_ptr(), self.n, self.d_rec.data_ptr(), REC_WORDS, C.byref(self.buf), sp))
+            if self.comm is not None:
+                gtx.check(L.gtx_scores_reduce(ctx.h, C.byref(self.buf), self.comm, sp))
+            elif self.dist is not None:
+                self.dist.all_reduce(self.t64, op=self.dist.ReduceOp.SUM)
+                self.dist.all_reduce(self.t32, op=self.dist.ReduceOp.SUM)
+            # genotype calls (PL, GT, GQ, depths) from the summed accumulators
+            gtx.check(L.gtx_calls_batch(ctx.h, C.byref(self.buf), self.d_phred.data_ptr(), self.d_calls.data_ptr(), sp))
+        return e0, e1
+
+    def run(self, steps, warmup, dist):
+        """W untimed steps, then exactly K timed steps bracketed by barrier + synchronize; returns (seconds, align ms list)"""
+        torch = self.torch
+        self.ctx.pass_times()  # arms the per-pass HIP events inside gtx_align_batch
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        evs = [self.step() for _ in range(steps)]
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return max_over_ranks(dist, dt, self.device), [a.elapsed_time(b) for a, b in evs]
+
+    def result_facts(self):
+        """sanity on the results of the last step: every record must be a result, not an overflow"""
+        gtx, ctx = self.gtx, self.ctx
+        rec_head = self.d_rec.view(self.n * 2, REC_WORDS)[:, 0]
+        calls = self.d_calls.cpu().numpy().view(gtx.SAMPLE_CALL)[:self.n_samples * ctx.n_hap]
+        cc = gtx.download(self.buf.d_conn_count, np.uint32, 2)
+        return {"reads_aligned": int(((rec_head[0::2] & 0xFFFF) > 0).sum().item()),
+                "reads_overflowed": int((((rec_head >> 16) & gtx.ST_ERROR_MASK) != 0).sum().item()),
+                "nonref_genotype_calls": int((calls["gt_second"] > 0).sum()), "score_items_refused": ctx.error_count(),
+                "connections_logged": int(cc[0]), "connections_dropped": int(cc[1])}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, ref_str, records, sample, spos):
+    """the oracle (oracle/, the CPU restatement of the reference: kind "port") on the host cores: (i) one core, the literal
+    semantics of a one-sample run (the reference cannot use more threads than samples, src/main.cpp:410-414); (ii) all
+    cores, the reads split into one pseudo-sample per thread over one shared graph + index"""
+    from oracle_lib import Oracle
+    oracle = Oracle(ref_str, records, region_begin=REGION_BEGIN)
+    m = len(sample)
+    g = oracle.genotyper(1, 1)
+    t0 = time.perf_counter()
+    g.push(list(sample), pos=spos)
+    one = time.perf_counter() - t0
+    out = {"value": m / one, "unit": "reads/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+           "sample": "first %d reads of the same workload through oracle/ (C++ restatement), 1 thread, %.1f s" % (m, one)}
+    threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
+    if threads > 1:
+        parts = [(list(sample[t::threads]), spos[t::threads]) for t in range(threads)]
+        genos = [oracle.genotyper(1, 1) for _ in range(threads)]
+        team = [threading.Thread(target=lambda k=k: genos[k].push(parts[k][0], pos=parts[k][1])) for k in range(threads)]
+        t0 = time.perf_counter()
+        for th in team:
+            th.start()
+        for th in team:
+            th.join()
+        many = time.perf_counter() - t0
+        out["all_cores"] = {"value": m / many, "unit": "reads/s", "cores": threads,
+                            "sample": "the same %d reads as %d pseudo-samples, one thread each, %.1f s" % (m, threads, many)}
+    return out
+
+
+def extra_cfg3(args, torch, gtx, synth, device, ref):
+    """cfg3-like workload in the same run: 30 samples, clusters of three biallelic sites (SNP, SNP, 1-6 bp indel) every
+    150 bp merged by add_all_variants into multi-allelic sites, reads with indels drawn on the host"""
+    n = args.extra_reads
+    recs = synth.make_cluster_records(ref, 150, seed=8, region_begin=REGION_BEGIN)
+    t0 = time.time()
+    ctx = gtx.Context(gtx.graph_from_records(synth.bases_to_str(ref), recs, region_begin=REGION_BEGIN, add_all_variants=True), device=0)
+    t_ctx = time.time() - t0
+    codes, pos = synth.make_reads(ref, recs, n, read_len=READ_LEN, seed=5, region_begin=REGION_BEGIN)
+    order = np.argsort(pos, kind="stable")
+    codes, pos = codes[order], pos[order]
+    d_seq = torch.from_numpy(gtx.pack_nibbles(codes)).to(device)
+    samples = np.random.default_rng(3).integers(0, 30, size=n).astype(np.uint32)
+    w = Workload(torch, gtx, ctx, device, d_seq, torch.from_numpy(pos), 30, samples=samples, hint=not args.no_hint)
+    dt, _ = w.run(3, 1, None)
+    ms, handed = ctx.pass_times()
+    facts = w.result_facts()
+    w.close()
+    out = {"workload": "cfg3-like: 30 samples, %d reads, 1 Mb, clusters (SNP, SNP, indel) every 150 bp merged into multi-allelic "
+                       "sites (add_all_variants), max %d alleles per site" % (n, int(ctx.hap_cnum.max())),
+           "reads_per_s": n * 3 / dt, "ms_per_step": 1000.0 * dt / 3, "sites": int(ctx.n_hap), "ctx_create_s": round(t_ctx, 3),
+           "align_passes_ms": {"express": ms[0], "general": ms[1], "hbm_tables": ms[2]},
+           "pass_shares": {"tasks": n, "handed_to_general": handed, "share_general": handed / float(n)}}
+    out.update(facts)
+    ctx.close()
+    return out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, argv)
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
-    import torch.distributed as dist
     from graphtyper_amd import lib as gtx
     from graphtyper_amd import synth
-    from graphtyper_amd.dist import reduce_scores
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libgtx has no CPU path")
     if not os.path.exists(gtx.LIB_PATH):
         raise SystemExit("libgtx.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    rank, local_rank, world, dist = init_ranks(args)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
 
     # ---- graph + index (replicated on every GPU) ----
     ref = synth.make_reference(args.region_len, seed=42)
@@ -113,154 +419,95 @@ def main():
     t0 = time.time()
     ctx = gtx.Context(gtx.graph_from_records(ref_str, records, region_begin=REGION_BEGIN), device=local_rank)
     t_ctx = time.time() - t0
+    t0 = time.time()
+    ctx2 = gtx.Context(gtx.graph_from_records(ref_str, records, region_begin=REGION_BEGIN), device=local_rank)
+    t_ctx_warm = time.time() - t0  # (the first context of a process also pays the HIP module load)
+    ctx2.close()
     n_keys, n_labels = ctx.index_stats()
 
     # ---- reads, resident in HBM before the timed region ----
     n = args.reads
-    d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=1234 + rank, device=device, REGION_LEN=args.region_len, err_rate=args.err, n_rate=args.nrate)
-    meta = np.zeros(1, gtx.READ_META)
-    meta["l_qseq"] = READ_LEN
-    d_meta = torch.from_numpy(np.repeat(meta, n).view(np.uint8).reshape(n, 16).copy()).to(device)
-    items = np.zeros(n, gtx.SCORE_ITEM)
-    items["first"]["align_index"] = np.arange(n, dtype=np.uint32)
-    items["first"]["mapq"] = 60
-    items["first"]["flag"] = gtx.FLAG_FORWARD_ONLY  # unpaired reads are aligned forward only (what gtx_stream_push sets)
-    items["first"]["pos"] = d_pos.cpu().numpy().astype(np.int32)
-    items["second"]["align_index"] = gtx.INVALID_ID
-    d_items = torch.from_numpy(items.view(np.uint8).reshape(n, gtx.SCORE_ITEM.itemsize).copy()).to(device)
-    d_rec = torch.empty(n * 2 * REC_WORDS, dtype=torch.int32, device=device)
-    n_samples = 1
-    nh = ctx.n_hap
-    conn_cap = 1 << 24
-    acc = dict(log_score=torch.zeros(n_samples * ctx.total_tri, dtype=torch.int32, device=device),
-               gt_cov=torch.zeros(n_samples * ctx.total_allele, dtype=torch.int32, device=device),
-               hap_u32=torch.zeros(n_samples * nh * 4, dtype=torch.int32, device=device),
-               stat_u64=torch.zeros(nh + 2 * ctx.total_allele, dtype=torch.int64, device=device),
-               stat_u32=torch.zeros(nh + 6 * ctx.total_allele, dtype=torch.int32, device=device),
-               conn_log=torch.zeros(conn_cap * 6, dtype=torch.int32, device=device),
-               conn_count=torch.zeros(2, dtype=torch.int32, device=device),
-               conn_near=torch.zeros(max(n_samples * ctx.total_near, 1), dtype=torch.int32, device=device))
-    buf = gtx.ScoreBuffers(n_samples, acc["log_score"].data_ptr(), acc["gt_cov"].data_ptr(), acc["hap_u32"].data_ptr(),
-                           acc["stat_u64"].data_ptr(), acc["stat_u32"].data_ptr(), acc["conn_log"].data_ptr(),
-                           acc["conn_count"].data_ptr(), conn_cap, acc["conn_near"].data_ptr())
-    L = gtx.lib()
-    stream = torch.cuda.Stream(device=device)
-    sp = C.c_void_p(stream.cuda_stream)
-    align_ms = []
-    d_phred = torch.zeros(max(ctx.total_tri, 1), dtype=torch.uint8, device=device)
-    d_calls = torch.zeros(max(ctx.n_hap, 1) * gtx.SAMPLE_CALL.itemsize, dtype=torch.uint8, device=device)
-
-    def step(timed):
-        with torch.cuda.stream(stream):
-            for name, t in acc.items():
-                if name != "conn_log":  # (the log's content is defined by conn_count)
-                    t.zero_()
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            gtx.check(L.gtx_align_batch(ctx.h, d_seq.data_ptr(), 80, d_meta.data_ptr(), n, d_rec.data_ptr(), REC_WORDS, sp))
-            e1.record(stream)
-            gtx.check(L.gtx_score_batch(ctx.h, d_items.data_ptr(), n, d_rec.data_ptr(), REC_WORDS, C.byref(buf), sp))
-            if world > 1:
-                reduce_scores(dist, [acc["log_score"], acc["gt_cov"], acc["hap_u32"], acc["stat_u64"], acc["stat_u32"], acc["conn_near"]])
-            # genotype calls (PL, GT, GQ, depths) from the summed accumulators
-            gtx.check(L.gtx_calls_batch(ctx.h, C.byref(buf), d_phred.data_ptr(), d_calls.data_ptr(), sp))
-        return (e0, e1)
-
-    ctx.pass_times()  # arms the per-pass HIP events inside gtx_align_batch
-    for _ in range(args.warmup):
-        step(False)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    evs = [step(True) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    align_ms = [a.elapsed_time(b) for a, b in evs]
+    d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=1234 + rank, device=device, REGION_LEN=args.region_len,
+                                        err_rate=args.err, n_rate=args.nrate)
+    w = Workload(torch, gtx, ctx, device, d_seq, d_pos, 1, hint=not args.no_hint)
+    if dist is not None:
+        w.setup_reduce(dist, rank, world, local_rank)
+    dt, align_ms = w.run(args.steps, args.warmup, dist)
     pass_ms, n_pass2 = ctx.pass_times()  # last step: express / general / HBM-table kernels
-    t_max = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    dt = float(t_max.item())
-
-    # sanity on the results of the last step: every record must be a result, not an overflow
-    rec_head = d_rec.view(n * 2, REC_WORDS)[:, 0]
-    n_overflow = int((((rec_head >> 16) & gtx.ST_ERROR_MASK) != 0).sum().item())
-    calls = d_calls.cpu().numpy().view(gtx.SAMPLE_CALL)[:ctx.n_hap]
-    n_nonref_calls = int((calls["gt_second"] > 0).sum())
-    n_aligned = int(((rec_head[0::2] & 0xFFFF) > 0).sum().item())
-    errors = ctx.error_count()
-    conn_logged, conn_dropped = (int(x) for x in acc["conn_count"].cpu().numpy())
-
-    prof = ctx.profile()
-    if rank == 0 and prof[15] > 0:
-        names = ["load read", "keys + exact probes", "exact labels", "chain exact", "hamming lookup", "chain hamming",
-                 "walk starts", "walk ends", "filters", "record"]
-        tot = float(prof[:10].sum())
-        sys.stderr.write("phase cycles per read-orientation (profiling build), %d tasks:\n" % prof[15])
-        for k, nm in enumerate(names):
-            sys.stderr.write("  %-22s %10.0f  %5.1f%%\n" % (nm, prof[k] / float(prof[15]), 100.0 * prof[k] / tot))
-        sys.stderr.write("  fast-seeded tasks      %9.1f%%\n" % (100.0 * prof[14] / float(prof[15])))
+    kern = ctx.kernel_times() if hasattr(ctx, "kernel_times") else None
+    facts = w.result_facts()
+    n_gpus = dist.get_world_size() if dist is not None else 1
 
     if rank != 0:
-        if world > 1:
+        w.close()
+        if dist is not None:
             dist.destroy_process_group()
-        return
+        return 0
 
     ms_per_step = 1000.0 * dt / args.steps
-    value = world * n * args.steps / dt
+    value = n_gpus * n * args.steps / dt
     align_avg_ms = float(np.mean(align_ms))
-    # dominant kernel: the express pass (every read-orientation task goes through it)
-    express_ms = pass_ms[0] if pass_ms[0] > 0 else align_avg_ms
-    # units of that launch: the tasks it completes (what it hands to the general pass is not counted for it)
-    n_express = n - n_pass2 if pass_ms[0] > 0 else n
-    achieved = ALGO_BYTES_PER_READ * n_express / (express_ms * 1e-3) / 1e9
+    # dominant kernel of the step and the units it completes (what it hands on is not counted for it)
+    roof = dominant_kernel(pass_ms, n_pass2, n, align_avg_ms, kern)
     traffic = None
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tf):
         try:
-            traffic = json.load(open(tf)).get("align_kernel_hbm_bytes_per_launch")
+            tj = json.load(open(tf))
+            if tj.get("kernel", "gtx_align_express4_kernel") == roof["kernel"]:
+                traffic = tj.get("align_kernel_hbm_bytes_per_launch")
+                if traffic is not None and tj.get("reads_per_launch"):
+                    traffic = traffic * float(n) / float(tj["reads_per_launch"])  # per launch of THIS run
         except Exception:
             traffic = None
-    out = {
-        "metric": "aligned+genotyped reads/sec over 1 Mb graph region; VCF bit-identical",
-        "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64/u32 integer (2-bit k-mer keys, byte compares, u32 atomics)", "data": "synthetic",
-        "config": {"workload": "cfg2: 1 sample, %d synthetic %d bp reads per GPU, chr20:1000001-2000000 (1 Mb), SNP-only graph "
-                               "(1 SNP / %d bp), unpaired, 0.5%% substitutions, 0.1%% N" % (n, READ_LEN, args.snp_every),
-                   "reads_per_gpu": n, "index_keys": n_keys, "index_labels": n_labels, "haplotypes": ctx.n_hap,
-                   "ctx_create_s": round(t_ctx, 3), "reads_aligned": n_aligned, "reads_overflowed": n_overflow, "nonref_genotype_calls": n_nonref_calls,
-                   "score_items_refused": errors, "connections_logged": conn_logged, "connections_dropped": conn_dropped, "parallelism": "reads sharded over %d GPU(s), graph+index replicated" % world},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": "gtx_align_express4_kernel", "kernel_ms": express_ms,
-                     "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,
-                     "align_passes_ms": {"express": pass_ms[0], "general": pass_ms[1], "hbm_tables": pass_ms[2],
-                                         "all_three_avg": align_avg_ms, "tasks_handed_to_general": n_pass2, "tasks_completed_by_express": n_express}},
-    }
-    if world == 1 and not args.no_cpu_baseline:
-        from oracle_lib import Oracle
+    roof["traffic"] = traffic
+    cfg = {"workload": "cfg2: 1 sample, %d synthetic %d bp reads per GPU, chr20:1000001-2000000 (1 Mb), SNP-only graph "
+                       "(1 SNP / %d bp), unpaired, 0.5%% substitutions, 0.1%% N; result = SampleCall (GT, PL, GQ, depths) per "
+                       "site, identical to the oracle's (VCF text is written by the host from these)" % (n, READ_LEN, args.snp_every),
+           "reads_per_gpu": n, "index_keys": n_keys, "index_labels": n_labels, "haplotypes": ctx.n_hap,
+           "ctx_create_s": round(t_ctx_warm, 3), "ctx_create_first_s": round(t_ctx, 3),
+           "position_hint": not args.no_hint,
+           "parallelism": "reads sharded over %d GPU(s), graph+index replicated" % n_gpus,
+           "reduce": w.reduce_kind, "reduced_bytes_per_step": w.reduced_bytes if n_gpus > 1 else 0}
+    cfg.update(facts)
+    out = {"metric": METRIC, "value": value, "unit": "reads/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u64/u32 integer (2-bit k-mer keys, byte compares, u32 atomics)", "data": "synthetic", "config": cfg,
+           "roofline": roof}
+    if n_gpus == 1 and not args.no_cpu_baseline:
         m = min(args.cpu_sample, n)
-        sample = unpack_nibbles(d_seq[:m].cpu().numpy(), READ_LEN)
-        spos = d_pos[:m].cpu().numpy()
-        oracle = Oracle(ref_str, records, region_begin=REGION_BEGIN)
-        g = oracle.genotyper(1, 1)
-        t0 = time.perf_counter()
-        g.push(list(sample), pos=spos)
-        cdt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": m / cdt, "unit": "reads/s", "cores": 1, "kind": "port",
-                               "sample": "first %d reads of the same workload through oracle/ (C++ restatement), 1 thread, %.1f s" % (m, cdt)}
+        out["cpu_baseline"] = cpu_baseline(args, ref_str, records, unpack_nibbles(d_seq[:m].cpu().numpy(), READ_LEN), d_pos[:m].cpu().numpy())
     else:
         out["cpu_baseline"] = None
+    w.close()
+    if n_gpus == 1 and not args.no_extra:
+        del d_seq, w
+        torch.cuda.empty_cache()
+        try:
+            cfg["extra"] = {"cfg3": extra_cfg3(args, torch, gtx, synth, device, ref)}
+        except Exception as e:  # the extra line must never cost the main one
+            cfg["extra"] = {"cfg3": {"error": repr(e)}}
     print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
+    return 0
+
+
+def dominant_kernel(pass_ms, n_pass2, n, align_avg_ms, kern):
+    """roofline object for the kernel that takes most of the step.  Durations are HIP events recorded inside
+    gtx_align_batch on the launch stream around each launch (gtx_ctx_pass_times / gtx_ctx_kernel_times)."""
+    if kern:  # [(name, ms, units completed)]
+        name, ms, units = max(kern, key=lambda k: k[1])
+        passes = {k[0]: {"ms": k[1], "tasks_completed": k[2]} for k in kern}
+    else:
+        name, ms, units = "gtx_align_express4_kernel", (pass_ms[0] if pass_ms[0] > 0 else align_avg_ms), (n - n_pass2 if pass_ms[0] > 0 else n)
+        passes = {"express": pass_ms[0], "general": pass_ms[1], "hbm_tables": pass_ms[2], "tasks_handed_to_general": n_pass2}
+    achieved = ALGO_BYTES_PER_READ * units / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    passes["all_passes_avg"] = align_avg_ms
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": name, "kernel_ms": ms, "units_per_launch": units, "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,
+            "align_passes_ms": passes}
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -451,6 +451,25 @@ extern "C"
   {
     if (!s || !recs || !seq || !align_seq || !align_meta || !n_align || !items || !n_items)
       return GTX_ERR_ARG;
+    // everything that can fail is checked before the stream's state is touched: a failing call consumes nothing
+    if (n > align_cap || n > item_cap)
+    {
+      g_last_error = "gtx_stream_push: align_cap and item_cap have to hold one entry per pushed record";
+      return GTX_ERR_CAPACITY;
+    }
+    for (uint32_t i = 0; i < n; ++i)
+    {
+      if (recs[i].rg >= s->parked.size())
+      {
+        g_last_error = "gtx_stream_push: read group index out of range";
+        return GTX_ERR_ARG;
+      }
+      if ((static_cast<uint32_t>(recs[i].l_qseq) + 1u) / 2u > seq_stride)
+      {
+        g_last_error = "gtx_stream_push: a record is longer than seq_stride";
+        return GTX_ERR_ARG;
+      }
+    }
     uint32_t na = 0, ni = 0;
     for (uint32_t i = 0; i < n; ++i)
     {
@@ -489,7 +508,9 @@ extern "C"
         if (na >= align_cap)
           return GTX_ERR_CAPACITY;
         std::memcpy(align_seq + static_cast<uint64_t>(na) * seq_stride, rseq, nbytes);
-        align_meta[na] = gtx_read_meta{r.l_qseq, r.flag, r.tid, r.mtid, r.isize};
+        // position hint of the alignment: where read base 0 lies when the mapper was right (leading soft clip removed)
+        int32_t const clip = (r.n_cigar != 0 && (r.cigar_front & 15u) == 4u) ? static_cast<int32_t>(r.cigar_front >> 4) : 0;
+        align_meta[na] = gtx_read_meta{r.l_qseq, r.flag, r.tid, r.mtid, r.isize, r.pos - clip};
         align_index = s->next_align_index++;
         ++na;
         s->have_prev = true;

@@ -23,7 +23,9 @@ EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy"
            "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_ctx_near_pairs", "gtx_index_stats", "gtx_index_get", "gtx_index_dump",
            "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_pass_times", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_set_coverage", "gtx_stream_finish", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
-           "gtx_graph_destroy"]
+           "gtx_graph_destroy",
+           "gtx_scores_alloc", "gtx_scores_zero", "gtx_scores_free", "gtx_scores_reduce", "gtx_comm_unique_id", "gtx_comm_init_rank",
+           "gtx_comm_destroy"]
 
 
 class GraphView(C.Structure):
@@ -50,7 +52,8 @@ class ScoreBuffers(C.Structure):
                 ("d_conn_count", C.c_void_p), ("conn_cap", C.c_uint32), ("d_conn_near", C.c_void_p)]
 
 
-READ_META = np.dtype([("l_qseq", np.uint16), ("flag", np.uint16), ("tid", np.int32), ("mtid", np.int32), ("isize", np.int32)], align=True)
+READ_META = np.dtype([("l_qseq", np.uint16), ("flag", np.uint16), ("tid", np.int32), ("mtid", np.int32), ("isize", np.int32), ("pos", np.int32)],
+                     align=True)
 REC_META = np.dtype([("align_index", np.uint32), ("flag", np.uint16), ("mapq", np.uint8), ("score_diff", np.uint8),
                      ("pos", np.int32), ("isize", np.int32)], align=True)
 SCORE_ITEM = np.dtype([("first", REC_META), ("second", REC_META), ("sample", np.uint32), ("kind", np.uint32)], align=True)
@@ -66,7 +69,7 @@ STREAM_RECORD = np.dtype([("flag", np.uint16), ("mapq", np.uint8), ("score_diff"
                           ("rg", np.uint16), ("sample", np.uint32), ("name_id", np.uint64), ("mpos", np.int32),
                           ("n_cigar", np.uint32), ("cigar_front", np.uint32), ("cigar_back", np.uint32)], align=True)
 LABEL = np.dtype([("start_index", np.uint32), ("end_index", np.uint32), ("variant_id", np.uint32)], align=True)
-assert READ_META.itemsize == 16 and REC_META.itemsize == 16 and SCORE_ITEM.itemsize == 40 and STREAM_RECORD.itemsize == 56 \
+assert READ_META.itemsize == 20 and REC_META.itemsize == 16 and SCORE_ITEM.itemsize == 40 and STREAM_RECORD.itemsize == 56 \
     and SAMPLE_CALL.itemsize == 12
 
 
@@ -129,6 +132,13 @@ def lib():
                                            C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.gtx_graph_get_view.argtypes = [C.c_void_p, C.POINTER(GraphView)]
         L.gtx_graph_destroy.argtypes = [C.c_void_p]
+        L.gtx_scores_alloc.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(ScoreBuffers), C.POINTER(C.c_uint64)]
+        L.gtx_scores_zero.argtypes = [C.c_void_p, C.POINTER(ScoreBuffers), C.c_void_p]
+        L.gtx_scores_free.argtypes = [C.c_void_p, C.POINTER(ScoreBuffers)]
+        L.gtx_scores_reduce.argtypes = [C.c_void_p, C.POINTER(ScoreBuffers), C.c_void_p, C.c_void_p]
+        L.gtx_comm_unique_id.argtypes = [C.c_void_p]
+        L.gtx_comm_init_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.gtx_comm_destroy.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -147,6 +157,23 @@ def check(status):
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+_hip = None
+
+
+def download(ptr, dtype, count):
+    """host copy of `count` elements of `dtype` at the device pointer `ptr` (hipMemcpy, synchronous)"""
+    global _hip
+    out = np.zeros(int(count), dtype)
+    if out.nbytes:
+        if _hip is None:
+            _hip = C.CDLL("libamdhip64.so")
+            _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        rc = _hip.hipMemcpy(_p(out), C.c_void_p(int(ptr)), C.c_size_t(out.nbytes), C.c_int(2))  # hipMemcpyDeviceToHost
+        if rc != 0:
+            raise RuntimeError("hipMemcpy failed (%d)" % rc)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -361,13 +388,7 @@ class Context:
         second pass)"""
         ptr, cap, used, tasks = C.c_void_p(), C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(lib().gtx_ctx_big_records(self.h, C.byref(ptr), C.byref(cap), C.byref(used), C.byref(tasks)))
-        out = np.zeros(int(used.value), np.uint32)
-        if used.value:
-            hip = C.CDLL("libamdhip64.so")
-            rc = hip.hipMemcpy(_p(out), ptr, C.c_size_t(out.nbytes), C.c_int(2))  # hipMemcpyDeviceToHost
-            if rc != 0:
-                raise RuntimeError(f"hipMemcpy failed ({rc})")
-        return out, int(tasks.value)
+        return download(ptr.value or 0, np.uint32, int(used.value)), int(tasks.value)
 
     def pass_times(self):
         """(ms of the express / general / HBM-table pass of the last align batch, tasks handed to the general pass);

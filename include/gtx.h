@@ -16,6 +16,8 @@
  *                                 (flag filter, duplicate reuse, mate parking; SV calling: record filter, coverage
  *                                 filter, leftover reads)                       src/utilities/hts_parallel_reader.cpp:245-338,528-772
  *   gtx_phase_flags     replaces  the `ph` construction                         src/utilities/hts_parallel_reader.cpp:782-904
+ *   gtx_scores_reduce   replaces  the merge of the per-thread / per-pool results   src/typer/caller.cpp:439-482,
+ *                                 (every per-read effect is an integer addition)  src/typer/vcf_operations.cpp:366-374
  *   gtx_graph_build     replaces  Graph::add_genomic_region                     src/graph/graph.cpp:41-339
  *   gtx_graph_from_files replaces construct_graph (small variants, SV deletions) src/graph/constructor.cpp:1597-1777
  *
@@ -151,6 +153,12 @@ typedef struct gtx_read_meta
   uint16_t flag;
   int32_t tid, mtid;
   int32_t isize;
+  /* bam core.pos of the record (0-based contig position of the first aligned base) minus its leading soft clip, i.e.
+   * where read base 0 would lie on the reference if the mapper was right; -1 = unknown.  A HINT ONLY: the kernels use
+   * it to look at the index entries of that place first (reads of a sorted BAM share them) and prove from flags stored
+   * there that the global lookups of the reference (ph_index.cpp:66-107) would return the same; whatever cannot be
+   * proven is looked up globally.  Results never depend on it (tests feed wrong and missing hints). */
+  int32_t pos;
 } gtx_read_meta;
 
 /* gtx_rec_meta::flag, besides the SAM bits: the reverse orientation of the read this record uses was not aligned
@@ -301,6 +309,32 @@ typedef struct gtx_sample_call
   uint8_t reserved;
 } gtx_sample_call;
 int gtx_calls_batch(gtx_ctx *, const gtx_score_buffers * acc, uint8_t * d_phred, gtx_sample_call * d_calls, void * stream);
+
+/* ---- multi-GPU: reads shard over the GPUs of a node (one process per GPU, graph + index replicated), the accumulators
+ * are summed once per region.  The reference's counterpart is the merge of per-thread / per-pool results
+ * on the host (src/typer/caller.cpp:439-482, src/typer/vcf_operations.cpp:366-374); every per-read effect is an integer
+ * addition, so sum-then-clamp (gtx_scores_finalize) equals one sequential pass below the saturation guard.
+ *
+ * gtx_scores_alloc puts all accumulators of gtx_score_buffers into ONE device block, zeroed:
+ *   [stat_u64][log_score][gt_cov][hap_u32][stat_u32][conn_near] [conn_count][conn_log]
+ * The first *reduced_bytes (may be NULL) are what gtx_scores_reduce sums; the connection log stays rank-local (far pairs:
+ * whoever reads them concatenates the ranks' logs).  gtx_scores_zero clears the block for the next region (async on
+ * `stream`), gtx_scores_free releases it.
+ * gtx_scores_reduce: in-place sum over the ranks of `rccl_comm` (an ncclComm_t) on `stream`: one RCCL group -- the u64
+ * statistics and the u32 counters as two all-reduce operations fused into one launch (u64 sums cannot travel as pairs of
+ * u32).  Buffers that were not made by gtx_scores_alloc are accepted (one operation per array, same group).
+ * RCCL is bound at run time (the process' own librccl.so when it has one); without it these calls return
+ * GTX_ERR_UNSUPPORTED.  gtx_comm_*: thin helpers for hosts that have no communicator yet -- rank 0 makes the id
+ * (ncclGetUniqueId), sends its GTX_COMM_ID_BYTES bytes to the other ranks by any means, every rank calls
+ * gtx_comm_init_rank (ncclCommInitRank on `device`). */
+#define GTX_COMM_ID_BYTES 128
+int gtx_scores_alloc(gtx_ctx *, uint32_t n_samples, uint32_t conn_cap, gtx_score_buffers * out, uint64_t * reduced_bytes);
+int gtx_scores_zero(gtx_ctx *, const gtx_score_buffers *, void * stream);
+int gtx_scores_free(gtx_ctx *, gtx_score_buffers *);
+int gtx_scores_reduce(gtx_ctx *, const gtx_score_buffers *, void * rccl_comm, void * stream);
+int gtx_comm_unique_id(void * id /* [GTX_COMM_ID_BYTES] */);
+int gtx_comm_init_rank(const void * id, int n_ranks, int rank, int device, void ** comm);
+int gtx_comm_destroy(void * comm);
 
 /* Host-side clamp of downloaded accumulators to the reference's stored types (haplotype.cpp:19-44: u8 -> 255,
  * u16 -> 0xFFFF).  Returns the number of (haplotype,sample) cells whose max_log_score reached the sequential

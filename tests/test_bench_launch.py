@@ -1,0 +1,41 @@
+"""bench.py's own N>1 launch path on CPU: `python bench.py --gpus 2` has to start two ranks itself, build the process
+group (gloo here, RCCL on a GPU node), sum a packed buffer over them, take the maximum time over the ranks and print one
+line from rank 0 whose n_gpus is the size of the group -- the control flow the 8-GPU run of the driver goes through,
+without device work (--dry-run)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=600, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, lines
+
+
+def test_gpus_2_starts_two_ranks_and_reports_them():
+    p, lines = _run(["--gpus", "2", "--dry-run", "--backend", "gloo", "--steps", "3", "--warmup", "1"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, "exactly one JSON line (rank 0): %r" % lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["dry_run"] is True and j["reduce_ok"] is True
+    assert j["value"] is None and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+
+
+def test_single_rank_needs_no_launcher():
+    p, lines = _run(["--dry-run", "--steps", "2"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = json.loads(lines[-1])
+    assert j["n_gpus"] == 1 and j["reduce_ok"] is True
+
+
+def test_world_size_has_to_match_gpus():
+    """under a launcher that started a different number of ranks than --gpus the bench refuses instead of mislabelling"""
+    p, lines = _run(["--gpus", "2", "--dry-run", "--backend", "gloo"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
+    assert p.returncode != 0 and not lines
+    assert "WORLD_SIZE=1" in (p.stderr + p.stdout)

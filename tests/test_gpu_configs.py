@@ -1,0 +1,165 @@
+"""BASELINE.json configurations beyond cfg2 on the device: cfg4 (1 000 samples jointly; the exchange step of the N-GPU
+run through gtx_scores_reduce on a one-rank communicator), each against the oracle at a size it finishes in seconds and at
+full size through size-independent properties."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import harness
+import scenarios
+from graphtyper_amd import lib as gtx
+from graphtyper_amd import synth
+from oracle_lib import Oracle
+from test_emu_parity import run_stream
+
+pytestmark = pytest.mark.gpu
+REC_WORDS = harness.REC_WORDS
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    assert os.path.exists(gtx.LIB_PATH), "libgtx.so must be built (HIP path, no fallback)"
+
+
+def test_cfg4_thousand_samples_vs_oracle():
+    """cfg4 at reduced size: 1 000 samples in one position-sorted stream of pairs, duplicates, low-MAPQ and filtered
+    records -> accumulators, SampleCalls and phasing flags of every (site, sample) == oracle.  A workgroup of the scoring
+    kernel sees up to 256 different samples here: its LDS combiner overflows into direct atomics (same sums)."""
+    ref, recs, codes, rec = scenarios.paired_case("snp100", n_ref=30000, n_pairs=12000, region_begin=310000, n_samples=1000)
+    assert len(np.unique(rec["sample"])) > 990
+    o = Oracle(ref, recs, region_begin=310000)
+    b = harness.GpuBackend(gtx.graph_from_records(ref, recs, region_begin=310000))
+    want = run_stream(b, o, codes, rec, n_samples=1000)
+    assert want.sum() > 0
+
+
+def _packed(ctx, n_samples, conn_cap=1 << 20):
+    buf = gtx.ScoreBuffers()
+    reduced = C.c_uint64()
+    gtx.check(gtx.lib().gtx_scores_alloc(ctx.h, n_samples, conn_cap, C.byref(buf), C.byref(reduced)))
+    return buf, int(reduced.value)
+
+
+def _download(ctx, buf, n_samples):
+    acc = harness.Accumulators(ctx, n_samples, conn_cap=buf.conn_cap)
+    acc.log_score[...] = gtx.download(buf.d_log_score, np.uint32, len(acc.log_score))
+    acc.gt_cov[...] = gtx.download(buf.d_gt_cov, np.uint32, len(acc.gt_cov))
+    acc.hap_u32[...] = gtx.download(buf.d_hap_u32, np.uint32, len(acc.hap_u32))
+    acc.stat_u64[...] = gtx.download(buf.d_stat_u64, np.uint64, len(acc.stat_u64))
+    acc.stat_u32[...] = gtx.download(buf.d_stat_u32, np.uint32, len(acc.stat_u32))
+    acc.conn_near[...] = gtx.download(buf.d_conn_near, np.uint32, len(acc.conn_near))
+    acc.conn_count[...] = gtx.download(buf.d_conn_count, np.uint32, 2)
+    acc.conn_log[...] = gtx.download(buf.d_conn_log, np.uint32, len(acc.conn_log))
+    return acc
+
+
+def test_packed_accumulators_and_reduce_on_one_rank():
+    """gtx_scores_alloc / gtx_scores_zero / gtx_scores_reduce: the packed block gives the same accumulators as separately
+    allocated arrays, an all-reduce over a one-rank RCCL communicator (made through gtx_comm_*) leaves them unchanged --
+    the code path of the 8-GPU run with the world cut down to what this box has -- and zero clears them"""
+    import torch
+    L = gtx.lib()
+    ref, recs, codes, rec = scenarios.paired_case("snp25", n_ref=20000, n_pairs=3000, region_begin=0, n_samples=5)
+    b = harness.GpuBackend(gtx.graph_from_records(ref, recs))
+    st = gtx.Stream(b.ctx.params, 1)
+    a_seq, a_meta, items = st.push(rec, gtx.pack_nibbles(codes))
+    records = b.align(a_seq, a_meta)
+    want = harness.canonical_scores(b.ctx, b.score(items, records, 5))
+    buf, reduced = _packed(b.ctx, 5)
+    assert reduced == 8 * (b.ctx.n_hap + 2 * b.ctx.total_allele) + 4 * (5 * (b.ctx.total_tri + b.ctx.total_allele + 4 * b.ctx.n_hap + b.ctx.total_near) + b.ctx.n_hap + 6 * b.ctx.total_allele)
+    d_items, d_rec = b._dev(items), b._dev(records)
+    gtx.check(L.gtx_score_batch(b.ctx.h, d_items.data_ptr(), len(items), d_rec.data_ptr(), REC_WORDS, C.byref(buf), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(harness.canonical_scores(b.ctx, _download(b.ctx, buf, 5)), want)
+    # a view torch can reduce (bench.py's fallback) sees the same memory
+    import bench
+    t = torch.as_tensor(bench.DevView(buf.d_log_score, 5 * b.ctx.total_tri, "<i4"), device="cuda:0")
+    assert np.array_equal(t.cpu().numpy().view(np.uint32), gtx.download(buf.d_log_score, np.uint32, 5 * b.ctx.total_tri))
+    ident = (C.c_uint8 * 128)()
+    gtx.check(L.gtx_comm_unique_id(ident))
+    comm = C.c_void_p()
+    gtx.check(L.gtx_comm_init_rank(ident, 1, 0, 0, C.byref(comm)))
+    gtx.check(L.gtx_scores_reduce(b.ctx.h, C.byref(buf), comm, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(harness.canonical_scores(b.ctx, _download(b.ctx, buf, 5)), want)
+    # separately allocated arrays take the per-array route of the same group
+    acc = harness.Accumulators(b.ctx, 5)
+    devs = [b._dev(a) for a in acc.arrays()]
+    loose = acc.buffers([d.data_ptr() for d in devs])
+    gtx.check(L.gtx_score_batch(b.ctx.h, d_items.data_ptr(), len(items), d_rec.data_ptr(), REC_WORDS, C.byref(loose), None))
+    gtx.check(L.gtx_scores_reduce(b.ctx.h, C.byref(loose), comm, None))
+    torch.cuda.synchronize()
+    for host, dev in zip(acc.arrays(), devs):
+        host[...] = dev.cpu().numpy().view(host.dtype)
+    assert np.array_equal(harness.canonical_scores(b.ctx, acc), want)
+    gtx.check(L.gtx_comm_destroy(comm))
+    gtx.check(L.gtx_scores_zero(b.ctx.h, C.byref(buf), None))
+    torch.cuda.synchronize()
+    z = _download(b.ctx, buf, 5)
+    assert not any(a.any() for a in (z.log_score, z.gt_cov, z.hap_u32, z.stat_u64, z.stat_u32, z.conn_near, z.conn_count))
+    gtx.check(L.gtx_scores_free(b.ctx.h, C.byref(buf)))
+    assert not buf.d_stat_u64
+
+
+def test_cfg4_full_size_properties():
+    """cfg4 at its full size -- 1 000 samples x 80 000 reads over the 1 Mb SNP graph, in 8 batches of 10 M -- through a
+    size-independent property: every effect of a read is an addition to counters of its own sample, so summing the
+    1 000-sample accumulators over the samples must give exactly what the same reads give when they all belong to one
+    sample (unsaturated u32 sums); and no record may carry an overflow status."""
+    import torch
+    import bench
+    device = torch.device("cuda", 0)
+    L = gtx.lib()
+    n_samples, per_batch, n_batches = 1000, 10_000_000, 8
+    ref = synth.make_reference(bench.REGION_LEN, seed=42)
+    records = synth.make_snp_records(ref, 1000, seed=7, region_begin=bench.REGION_BEGIN)
+    ctx = gtx.Context(gtx.graph_from_records(synth.bases_to_str(ref), records, region_begin=bench.REGION_BEGIN), device=0)
+    joint, _ = _packed(ctx, n_samples, 1 << 22)
+    single, _ = _packed(ctx, 1, 1 << 22)
+    d_rec = torch.empty(per_batch * 2 * REC_WORDS, dtype=torch.int32, device=device)
+    meta = np.zeros(per_batch, gtx.READ_META)
+    meta["l_qseq"] = bench.READ_LEN
+    items = np.zeros(per_batch, gtx.SCORE_ITEM)
+    items["first"]["align_index"] = np.arange(per_batch, dtype=np.uint32)
+    items["first"]["mapq"] = 60
+    items["first"]["flag"] = gtx.FLAG_FORWARD_ONLY
+    items["second"]["align_index"] = gtx.INVALID_ID
+    n_aligned = 0
+    for k in range(n_batches):
+        d_seq, d_pos = bench.make_reads_on_device(torch, ref, records, per_batch, seed=500 + k, device=device)
+        pos = d_pos.cpu().numpy().astype(np.int32)
+        meta["pos"] = pos
+        d_meta = torch.from_numpy(meta.view(np.uint8).reshape(per_batch, -1).copy()).to(device)
+        gtx.check(L.gtx_align_batch(ctx.h, d_seq.data_ptr(), 80, d_meta.data_ptr(), per_batch, d_rec.data_ptr(), REC_WORDS, None))
+        heads = d_rec.view(per_batch * 2, REC_WORDS)[:, 0]
+        assert int((((heads >> 16) & gtx.ST_ERROR_MASK) != 0).sum().item()) == 0
+        n_aligned += int(((heads[0::2] & 0xFFFF) > 0).sum().item())
+        items["first"]["pos"] = pos
+        for buf, samples in ((joint, np.random.default_rng(k).integers(0, n_samples, size=per_batch)), (single, 0)):
+            items["sample"] = samples
+            d_items = torch.from_numpy(items.view(np.uint8).reshape(per_batch, -1).copy()).to(device)
+            gtx.check(L.gtx_score_batch(ctx.h, d_items.data_ptr(), per_batch, d_rec.data_ptr(), REC_WORDS, C.byref(buf), None))
+            torch.cuda.synchronize()
+        del d_seq, d_pos, d_meta
+    assert n_aligned > 0.97 * per_batch * n_batches and ctx.error_count() == 0
+    a, s = _download(ctx, joint, n_samples), _download(ctx, single, 1)
+    assert s.log_score.sum() > 0 and s.gt_cov.sum() > 1000
+    assert np.array_equal(a.log_score.reshape(n_samples, -1).sum(0, dtype=np.uint64), s.log_score.astype(np.uint64))
+    assert np.array_equal(a.gt_cov.reshape(n_samples, -1).sum(0, dtype=np.uint64), s.gt_cov.astype(np.uint64))
+    assert np.array_equal(a.hap_u32.reshape(n_samples, -1).sum(0, dtype=np.uint64), s.hap_u32.astype(np.uint64))
+    assert np.array_equal(a.conn_near.reshape(n_samples, -1).sum(0, dtype=np.uint64), s.conn_near.astype(np.uint64))
+    assert np.array_equal(a.stat_u64, s.stat_u64) and np.array_equal(a.stat_u32, s.stat_u32)  # per site, not per sample
+    # every sample got its share (80 000 reads each, ~12x): calls exist for all of them
+    phred = torch.zeros(n_samples * ctx.total_tri, dtype=torch.uint8, device=device)
+    calls = torch.zeros(n_samples * ctx.n_hap * gtx.SAMPLE_CALL.itemsize, dtype=torch.uint8, device=device)
+    gtx.check(L.gtx_calls_batch(ctx.h, C.byref(joint), phred.data_ptr(), calls.data_ptr(), None))
+    torch.cuda.synchronize()
+    c = calls.cpu().numpy().view(gtx.SAMPLE_CALL).reshape(n_samples, ctx.n_hap)
+    depth = c["ref_total_depth"].astype(np.int64) + c["alt_total_depth"]
+    assert (depth.sum(1) > 0).all() and (c["gt_second"] > 0).any(1).all()
+    for buf in (joint, single):
+        gtx.check(L.gtx_scores_free(ctx.h, C.byref(buf)))

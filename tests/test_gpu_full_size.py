@@ -57,7 +57,7 @@ def test_cfg2_full_size_properties():
     d_seq, d_pos = bench.make_reads_on_device(torch, ref, records, n, seed=99, device=device)
     meta = np.zeros(1, gtx.READ_META)
     meta["l_qseq"] = bench.READ_LEN
-    d_meta = torch.from_numpy(np.repeat(meta, n).view(np.uint8).reshape(n, 16).copy()).to(device)
+    d_meta = torch.from_numpy(np.repeat(meta, n).view(np.uint8).reshape(n, gtx.READ_META.itemsize).copy()).to(device)
 
     def align(seq, met, count, out):
         gtx.check(L.gtx_align_batch(ctx.h, seq.data_ptr(), 80, met.data_ptr(), count, out.data_ptr(), REC_WORDS, None))
