@@ -39,6 +39,10 @@ struct AlignCfg
 
 #include "align_core.inl"
 #include "express4.inl"
+} // namespace gtx
+#include "hinted.hpp"
+namespace gtx
+{
 
 // second pass: the same code over large tables that live in HBM (one workspace per workgroup)
 namespace big

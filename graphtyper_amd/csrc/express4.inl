@@ -28,6 +28,9 @@ struct Express4Lean
   static constexpr bool AMB_ON_VARIANT = true;      // ... and whether they may lie on a variant
 };
 
+static_assert(AlignCfg::HE_CAP == HINT_HE_CAP && Express4Lean::NB_MAX == HINT_NB_MAX && Express4Lean::KS == 1,
+              "build_hints (gtx_host.cpp) restates the lean seeding rule with these limits");
+
 struct Express4Wide
 {
   static constexpr uint32_t KS = 4, NB_MAX = 16, TS = 3, VS_CAP = 16;
@@ -110,11 +113,12 @@ struct Express4Workspace
   } while (0)
 #endif
 
-// Returns a 4-bit mask: bit gi set = task first + gi must go through pass 2.
+// Returns a 4-bit mask: bit gi set = task first + gi must go through pass 2.  With `rid` the four reads are rid[0..3]
+// (a slice of the queue the position-hinted pass filled) instead of first .. first + 3.
 template <class W, class E4>
 GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Workspace<E4> & ws, uint8_t const * seq, uint32_t seq_stride,
                           gtx_read_meta const * meta, uint32_t first, uint32_t n_valid, uint32_t * records, uint32_t rec_words,
-                          bool decline_all = false)
+                          bool decline_all = false, uint32_t const * rid = nullptr)
 {
   using PB = typename W::template PerLane<bool>;
   using PU = typename W::template PerLane<uint32_t>;
@@ -123,17 +127,19 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
 
   // ---- per group: the read, whether it is a candidate at all
   PB alive_l, pass2_l;
-  PU len_l, nk_l;
+  PU len_l, nk_l, read_l;
   W::lanes([&](uint32_t l) {
     uint32_t const gi = l >> 4;
     bool const valid = gi < n_valid;
-    uint32_t const len = valid ? static_cast<uint32_t>(meta[first + gi].l_qseq) : 0u;
+    uint32_t const read = !valid ? 0u : rid ? rid[gi] : first + gi;
+    read_l[l] = read;
+    uint32_t const len = valid ? static_cast<uint32_t>(meta[read].l_qseq) : 0u;
     bool const too_short = len < 2 * K - 1, too_long = len > AlignCfg::MAX_READ;
     uint32_t const n_k = len < K ? 0 : 1 + (len - K) / (K - 1);
     if (valid && (too_short || too_long) && (l & 15u) == 0)
     {
       // align_read (alignment.cpp:331-363): reads shorter than 2K-1 stay unaligned
-      uint32_t * rec = records + static_cast<uint64_t>(first + gi) * 2 * rec_words;
+      uint32_t * rec = records + static_cast<uint64_t>(read) * 2 * rec_words;
       rec[0] = too_long ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
       rec[1] = len << 16;
     }
@@ -158,7 +164,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
       uint32_t const gi = l >> 4, word = it * 16 + (l & 15u), len = len_l[l];
       if (alive_l[l] && 4 * word < len)
       {
-        uint8_t const * seq4 = seq + static_cast<uint64_t>(first + gi) * seq_stride;
+        uint8_t const * seq4 = seq + static_cast<uint64_t>(read_l[l]) * seq_stride;
         uint32_t packed = 0;
         for (uint32_t k = 0; k < 4; ++k)
         {
@@ -1041,7 +1047,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
           np = 0;
           longest = 0;
         }
-        uint32_t * rec = records + static_cast<uint64_t>(first + gi) * 2 * rec_words;
+        uint32_t * rec = records + static_cast<uint64_t>(read_l[l]) * 2 * rec_words;
         if (!fail)
         {
           rec[0] = np;

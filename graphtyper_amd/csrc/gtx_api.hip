@@ -396,6 +396,123 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_WIDE_WAV
                               queue_all);
 }
 
+// Pass 0 (hinted.hpp): ONE READ PER LANE.  Every read of the batch comes through here first: the reverse-orientation
+// task is settled (empty record, or queued for pass 2 when align_read asks for it), reads outside the length limits get
+// their empty records, and the forward task is finished from the position hint where the flags of that place prove the
+// global lookups -- else the read is queued for pass 1 (express4 over the queue).  One atomic per wavefront and queue.
+__global__ __launch_bounds__(256) void gtx_align_hinted_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq, uint32_t seq_stride,
+                                                               gtx_read_meta const * __restrict__ meta, uint32_t n_reads,
+                                                               uint32_t * __restrict__ records, uint32_t rec_words, uint32_t force_both,
+                                                               uint32_t * __restrict__ queue1, uint32_t * queue1_count,
+                                                               uint32_t * __restrict__ queue2, uint32_t * queue2_count, uint32_t decline_all)
+{
+  uint32_t const read = blockIdx.x * blockDim.x + threadIdx.x;
+  bool fwd = false, rev = false;
+  if (read < n_reads)
+  {
+    gtx_read_meta const m = meta[read];
+    uint32_t const len = m.l_qseq;
+    uint32_t * rec = records + static_cast<uint64_t>(read) * 2 * rec_words;
+    bool const outside = len < 2 * K - 1 || len > AlignCfg::MAX_READ; // align_read (alignment.cpp:331-363): stay unaligned
+    rev = !outside && needs_reverse(m, force_both != 0);
+    if (!rev)
+    {
+      rec[rec_words] = len > AlignCfg::MAX_READ ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
+      rec[rec_words + 1] = len << 16;
+    }
+    if (outside)
+    {
+      rec[0] = len > AlignCfg::MAX_READ ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
+      rec[1] = len << 16;
+    }
+    else
+      fwd = decline_all != 0 || !hinted_one(g, ix, seq + static_cast<uint64_t>(read) * seq_stride, seq_stride, m, rec, rec_words);
+  }
+  uint32_t const lane = threadIdx.x & 63u;
+  unsigned long long const F = __ballot(fwd), R = __ballot(rev);
+  if (F != 0)
+  {
+    uint32_t base = 0;
+    if (lane == 0)
+      base = atomicAdd(queue1_count, static_cast<uint32_t>(__builtin_popcountll(F)));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (fwd)
+      queue1[base + static_cast<uint32_t>(__builtin_popcountll(F & ((1ull << lane) - 1ull)))] = read;
+  }
+  if (R != 0)
+  {
+    uint32_t base = 0;
+    if (lane == 0)
+      base = atomicAdd(queue2_count, static_cast<uint32_t>(__builtin_popcountll(R)));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (rev)
+      queue2[base + static_cast<uint32_t>(__builtin_popcountll(R & ((1ull << lane) - 1ull)))] = read * 2 + 1;
+  }
+}
+
+// Pass 1 behind pass 0: express4 over the queue of forward tasks the position-hinted pass declined (four reads per
+// wavefront as above, the reads of a group come from the queue instead of lying side by side).
+template <class E4>
+__device__ __forceinline__ void express4_queue_pass(GraphView const & g, IndexView const & ix, uint8_t const * __restrict__ seq,
+                                                    uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
+                                                    uint32_t * __restrict__ records, uint32_t rec_words, uint32_t * task_counter,
+                                                    uint32_t const * __restrict__ queue1, uint32_t const * queue1_count,
+                                                    uint32_t * __restrict__ queue2, uint32_t * queue2_count, uint32_t * handed_on,
+                                                    uint32_t queue_all)
+{
+  __shared__ Express4Workspace<E4> ws;
+  __shared__ uint32_t pending[TASK_CHUNK];
+  uint32_t const lane = threadIdx.x & 63u;
+  uint32_t const n = queue1_count[0];
+  for (;;)
+  {
+    uint32_t const base = wave_claim(task_counter, TASK_CHUNK);
+    if (base >= n)
+      break;
+    uint32_t const end = base + TASK_CHUNK < n ? base + TASK_CHUNK : n;
+    uint32_t n_pending = 0;
+    for (uint32_t first = base; first < end; first += 4)
+    {
+      uint32_t const n_valid = end - first < 4 ? end - first : 4;
+      uint32_t const fwd_mask = express4<WaveHip, E4>(g, ix, ws, seq, seq_stride, meta, 0, n_valid, records, rec_words, queue_all != 0, queue1 + first);
+      for (uint32_t k = 0; k < n_valid; ++k)
+        if ((fwd_mask >> k) & 1u)
+        {
+          if (lane == 0)
+            pending[n_pending] = queue1[first + k] * 2;
+          ++n_pending;
+        }
+    }
+    if (n_pending)
+    {
+      WaveHip::lds_sync();
+      uint32_t const at = wave_claim(queue2_count, n_pending); // (the queue has room for every task)
+      if (lane == 0)
+        atomicAdd(handed_on, n_pending);
+      for (uint32_t k = lane; k < n_pending; k += 64)
+        queue2[at + k] = pending[k];
+      WaveHip::lds_sync();
+    }
+  }
+}
+
+#define GTX_EXPRESS4Q_ARGS                                                                                                         \
+  GraphView g, IndexView ix, uint8_t const *__restrict__ seq, uint32_t seq_stride, gtx_read_meta const *__restrict__ meta,         \
+    uint32_t *__restrict__ records, uint32_t rec_words, uint32_t *task_counter, uint32_t const *__restrict__ queue1,               \
+    uint32_t const *queue1_count, uint32_t *__restrict__ queue2, uint32_t *queue2_count, uint32_t *handed_on, uint32_t queue_all
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_LEAN_WAVES))) void gtx_align_express4q_kernel(GTX_EXPRESS4Q_ARGS)
+{
+  express4_queue_pass<Express4Lean>(g, ix, seq, seq_stride, meta, records, rec_words, task_counter, queue1, queue1_count, queue2,
+                                    queue2_count, handed_on, queue_all);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_WIDE_WAVES))) void gtx_align_express4q_wide_kernel(GTX_EXPRESS4Q_ARGS)
+{
+  express4_queue_pass<Express4Wide>(g, ix, seq, seq_stride, meta, records, rec_words, task_counter, queue1, queue1_count, queue2,
+                                    queue2_count, handed_on, queue_all);
+}
+
 // Pass 2 (general): the queued tasks through the full algorithm over LDS tables.  A task that exceeds them goes on to
 // pass 3 (gtx_align_big_kernel).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void gtx_align_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
@@ -452,7 +569,8 @@ __global__ __launch_bounds__(64) void gtx_align_big_kernel(GraphView g, IndexVie
                                                            uint32_t * __restrict__ records, uint32_t rec_words,
                                                            uint32_t const * __restrict__ big_tasks, uint32_t big_task_cap,
                                                            uint32_t * big_state, big::AlignWorkspace * workspaces,
-                                                           uint32_t * __restrict__ arena, unsigned long long arena_words)
+                                                           uint32_t * __restrict__ arena, unsigned long long arena_words,
+                                                           unsigned long long * arena_cursor)
 {
   big::AlignWorkspace & ws = workspaces[blockIdx.x];
 #ifdef GTX_PROF
@@ -484,7 +602,7 @@ __global__ __launch_bounds__(64) void gtx_align_big_kernel(GraphView g, IndexVie
       if (size > rec_words)
       {
         // long record: room in the arena; the slot keeps the header and the offset
-        off = wave_claim64(reinterpret_cast<unsigned long long *>(big_state + 4), size - 2);
+        off = wave_claim64(arena_cursor, size - 2);
         if (off + (size - 2) > arena_words || off + (size - 2) > 0xFFFFFFFFull)
         {
           status = GTX_ST_RECORD_OVERFLOW;
@@ -611,6 +729,116 @@ static bool upload(std::vector<void *> & owned, T const *& dst, T const * src, s
   return true;
 }
 
+template <class T>
+static bool dev_alloc(T *& dst, size_t n, char const * what, bool zero = false)
+{
+  void * p = nullptr;
+  if (!hip_ok(hipMalloc(&p, (n ? n : 1) * sizeof(T)), what))
+    return false;
+  if (zero && !hip_ok(hipMemset(p, 0, (n ? n : 1) * sizeof(T)), what))
+  {
+    (void)hipFree(p);
+    return false;
+  }
+  dst = static_cast<T *>(p);
+  return true;
+}
+
+// ---- per-call scratch (gtx_ctx.hpp) ----------------------------------------------------------------------------
+static void scratch_free(CallScratch & s)
+{
+  void * ptrs[] = {s.d_counters, s.d_queue1, s.d_queue, s.d_big_tasks, s.d_big_state, s.d_big_ws, s.d_score_state, s.d_score_queue,
+                   s.d_score_tables, s.d_score_work};
+  for (void * p : ptrs)
+    if (p)
+      (void)hipFree(p);
+  for (auto & e : s.pass_events)
+    if (e)
+      (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+  if (s.done)
+    (void)hipEventDestroy(static_cast<hipEvent_t>(s.done));
+  s = CallScratch();
+}
+
+static std::unique_ptr<CallScratch> scratch_new(gtx_ctx & c)
+{
+  auto s = std::make_unique<CallScratch>();
+  hipEvent_t ev;
+  bool ok = hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "scratch event");
+  if (ok)
+    s->done = ev;
+  ok = ok && dev_alloc(s->d_counters, 8, "task counters", true);
+  if (ok && !c.params.no_second_pass)
+  {
+    ok = ok && dev_alloc(s->d_big_state, 8, "second-pass state", true);
+    void * ws = nullptr;
+    ok = ok && hip_ok(hipMalloc(&ws, static_cast<size_t>(c.big_blocks) * sizeof(big::AlignWorkspace)), "second-pass workspaces");
+    s->d_big_ws = ws;
+    ok = ok && dev_alloc(s->d_score_state, 2, "second-pass score state", true);
+    ok = ok && dev_alloc(s->d_score_queue, gtx_ctx::SCORE_QUEUE_CAP, "second-pass score queue");
+    RecentHap * tables = nullptr;
+    ok = ok && dev_alloc(tables, static_cast<size_t>(gtx_ctx::SCORE_BIG_THREADS) * 2 * SCORE_MAX_HAPS_BIG, "second-pass score tables");
+    s->d_score_tables = tables;
+  }
+  if (!ok)
+  {
+    scratch_free(*s);
+    return nullptr;
+  }
+  return s;
+}
+
+// A scratch nobody is inside of: the one this stream used last (stream order separates the calls), else one whose last
+// launch has completed, else a new one.
+static CallScratch * scratch_acquire(gtx_ctx & c, hipStream_t stream)
+{
+  std::lock_guard<std::mutex> lock(c.pool_mutex);
+  CallScratch * pick = nullptr;
+  for (auto & s : c.pool)
+    if (!s->busy && s->used && s->last_stream == stream)
+      pick = s.get();
+  if (!pick)
+    for (auto & s : c.pool)
+      if (!pick && !s->busy && (!s->used || hipEventQuery(static_cast<hipEvent_t>(s->done)) == hipSuccess))
+        pick = s.get();
+  if (!pick)
+  {
+    auto s = scratch_new(c);
+    if (!s)
+      return nullptr;
+    pick = s.get();
+    c.pool.push_back(std::move(s));
+  }
+  pick->busy = true;
+  return pick;
+}
+
+static void scratch_release(gtx_ctx & c, CallScratch * s, hipStream_t stream, bool was_align)
+{
+  (void)hipEventRecord(static_cast<hipEvent_t>(s->done), stream);
+  std::lock_guard<std::mutex> lock(c.pool_mutex);
+  s->used = true;
+  s->last_stream = stream;
+  s->busy = false;
+  if (was_align)
+    c.last_align = s;
+}
+
+template <class T>
+static bool grow(T *& p, uint64_t & cap, uint64_t want, char const * what)
+{
+  if (want <= cap)
+    return true;
+  if (p && !hip_ok(hipFree(p), what)) // (synchronises with earlier launches)
+    return false;
+  p = nullptr;
+  cap = 0;
+  if (!dev_alloc(p, want, what))
+    return false;
+  cap = want;
+  return true;
+}
+
 int ctx_upload(gtx_ctx & c, int device)
 {
   int n_dev = 0;
@@ -655,17 +883,18 @@ int ctx_upload(gtx_ctx & c, int device)
   ok = ok && upload(c.dev_allocs, v.allele_off, h.allele_off.data(), h.allele_off.size(), "allele_off");
   ok = ok && upload(c.dev_allocs, v.near_last, h.near_last.data(), h.near_last.size(), "near_last");
   ok = ok && upload(c.dev_allocs, v.near_off, h.near_off.data(), h.near_off.size(), "near_off");
-  IndexView ix{};
-  ix.log2_cap = c.index.log2_cap;
-  ix.max_index_labels = static_cast<uint32_t>(c.params.max_index_labels);
+  uint32_t half_cap = HALF_BUCKET_CAP;
+  if (char const * e = std::getenv("GTX_HALF_BUCKET_CAP")) // A/B switch for benchmarking: 0 = probe the 96 neighbours directly
+    half_cap = static_cast<uint32_t>(std::min<long>(std::max<long>(std::atol(e), 0), HALF_BUCKET_CAP));
+  IndexView ix = c.index.view(static_cast<uint32_t>(c.params.max_index_labels), half_cap);
   ok = ok && upload(c.dev_allocs, ix.slots, c.index.slots.data(), c.index.slots.size(), "index slots");
   ok = ok && upload(c.dev_allocs, ix.labels, c.index.dev_labels.data(), c.index.dev_labels.size(), "index labels");
-  ix.h_log2_cap = c.index.h_log2_cap;
-  ix.half_bucket_cap = HALF_BUCKET_CAP;
-  if (char const * e = std::getenv("GTX_HALF_BUCKET_CAP")) // A/B switch for benchmarking: 0 = probe the 96 neighbours directly
-    ix.half_bucket_cap = static_cast<uint32_t>(std::min<long>(std::max<long>(std::atol(e), 0), HALF_BUCKET_CAP));
   ok = ok && upload(c.dev_allocs, ix.hslots, c.index.hslots.data(), c.index.hslots.size(), "half-key slots");
   ok = ok && upload(c.dev_allocs, ix.hlist, c.index.hlist.data(), c.index.hlist.size(), "half-key buckets");
+  ok = ok && upload(c.dev_allocs, ix.ref4, c.index.ref4.data(), c.index.ref4.size(), "reference nibbles");
+  ok = ok && upload(c.dev_allocs, ix.pos_flags, c.index.pos_flags.data(), c.index.pos_flags.size(), "position flags");
+  ok = ok && upload(c.dev_allocs, ix.filt[0], c.index.filt[0].data(), c.index.filt[0].size(), "half-key filter 0");
+  ok = ok && upload(c.dev_allocs, ix.filt[1], c.index.filt[1].data(), c.index.filt[1].size(), "half-key filter 1");
   void * pf = nullptr;
   ok = ok && hip_ok(hipMalloc(&pf, 32 * sizeof(unsigned long long)), "profile counters");
   if (ok)
@@ -673,13 +902,6 @@ int ctx_upload(gtx_ctx & c, int device)
     c.dev_allocs.push_back(pf);
     v.prof = static_cast<unsigned long long *>(pf);
     ok = hip_ok(hipMemset(pf, 0, 32 * sizeof(unsigned long long)), "profile counters");
-  }
-  void * tc = nullptr;
-  ok = ok && hip_ok(hipMalloc(&tc, gtx_ctx::N_TASK_COUNTERS * sizeof(uint32_t)), "task counters");
-  if (ok)
-  {
-    c.dev_allocs.push_back(tc);
-    c.d_task_counters = static_cast<uint32_t *>(tc);
   }
   void * ef = nullptr;
   ok = ok && hip_ok(hipMalloc(&ef, sizeof(uint32_t)), "error flag");
@@ -689,59 +911,34 @@ int ctx_upload(gtx_ctx & c, int device)
     c.d_error_flag = static_cast<uint32_t *>(ef);
     ok = hip_ok(hipMemset(ef, 0, sizeof(uint32_t)), "error flag");
   }
+  hipDeviceProp_t prop;
+  bool const have_prop = hipGetDeviceProperties(&prop, device) == hipSuccess;
+  if (have_prop)
+    c.n_cu = prop.multiProcessorCount;
   if (ok && !c.params.no_second_pass)
   {
-    // second pass: queue, one HBM workspace per workgroup (one workgroup per CU is plenty for the few queued reads), arena
-    hipDeviceProp_t prop;
-    c.big_blocks = hipGetDeviceProperties(&prop, device) == hipSuccess ? static_cast<uint32_t>(prop.multiProcessorCount) : 256u;
+    // HBM-table pass: one workspace per workgroup (one workgroup per CU is plenty for the few queued reads), arena
+    c.big_blocks = have_prop ? static_cast<uint32_t>(prop.multiProcessorCount) : 256u;
     c.big_record_words = c.params.big_record_words ? c.params.big_record_words : (16ull << 20);
     void * p = nullptr;
-    ok = ok && hip_ok(hipMalloc(&p, 8 * sizeof(uint32_t)), "second-pass state");
-    if (ok)
-    {
-      c.dev_allocs.push_back(p);
-      c.d_big_state = static_cast<uint32_t *>(p);
-      ok = hip_ok(hipMemset(p, 0, 8 * sizeof(uint32_t)), "second-pass state");
-    }
-    ok = ok && hip_ok(hipMalloc(&p, static_cast<size_t>(c.big_blocks) * sizeof(big::AlignWorkspace)), "second-pass workspaces");
-    if (ok)
-    {
-      c.dev_allocs.push_back(p);
-      c.d_big_ws = p;
-    }
     ok = ok && hip_ok(hipMalloc(&p, c.big_record_words * sizeof(uint32_t)), "big-record arena");
     if (ok)
     {
       c.dev_allocs.push_back(p);
       c.d_big_records = static_cast<uint32_t *>(p);
     }
-    ok = ok && hip_ok(hipMalloc(&p, 2 * sizeof(uint32_t)), "second-pass score state");
+    ok = ok && hip_ok(hipMalloc(&p, sizeof(unsigned long long)), "arena cursor");
     if (ok)
     {
       c.dev_allocs.push_back(p);
-      c.d_score_state = static_cast<uint32_t *>(p);
-    }
-    ok = ok && hip_ok(hipMalloc(&p, gtx_ctx::SCORE_QUEUE_CAP * sizeof(uint32_t)), "second-pass score queue");
-    if (ok)
-    {
-      c.dev_allocs.push_back(p);
-      c.d_score_queue = static_cast<uint32_t *>(p);
-    }
-    ok = ok && hip_ok(hipMalloc(&p, static_cast<size_t>(gtx_ctx::SCORE_BIG_THREADS) * 2 * SCORE_MAX_HAPS_BIG * sizeof(RecentHap)),
-                      "second-pass score tables");
-    if (ok)
-    {
-      c.dev_allocs.push_back(p);
-      c.d_score_tables = p;
+      c.d_arena_cursor = static_cast<unsigned long long *>(p);
+      ok = hip_ok(hipMemset(p, 0, sizeof(unsigned long long)), "arena cursor");
     }
   }
   if (!ok)
     return GTX_ERR_HIP;
   c.dev_graph = v;
   c.dev_index = ix;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) == hipSuccess)
-    c.n_cu = prop.multiProcessorCount;
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_kernel, 64, 0) == hipSuccess && per_cu > 0)
     c.align_blocks_per_cu = per_cu;
@@ -752,36 +949,50 @@ int ctx_upload(gtx_ctx & c, int device)
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express4_wide_kernel, 64, 0) == hipSuccess && per_cu > 0)
     c.express4_wide_blocks_per_cu = per_cu;
   c.express4_wide = express4_prefers_wide(c.graph, c.index);
+  // the first scratch now, so that the first call does not pay for it
+  auto s = scratch_new(c);
+  if (!s)
+    return GTX_ERR_HIP;
+  c.pool.push_back(std::move(s));
   return GTX_OK;
 }
 
 void ctx_release_device(gtx_ctx & c)
 {
   if (c.device >= 0)
+  {
     (void)hipSetDevice(c.device);
+    (void)hipDeviceSynchronize();
+  }
+  for (auto & s : c.pool)
+    scratch_free(*s);
+  c.pool.clear();
+  c.last_align = nullptr;
   for (void * p : c.dev_allocs)
     (void)hipFree(p);
   c.dev_allocs.clear();
-  if (c.d_queue)
-    (void)hipFree(c.d_queue);
-  c.d_queue = nullptr;
-  if (c.d_score_work)
-    (void)hipFree(c.d_score_work);
-  c.d_score_work = nullptr;
-  for (auto & e : c.pass_events)
-    if (e)
-    {
-      (void)hipEventDestroy(static_cast<hipEvent_t>(e));
-      e = nullptr;
-    }
-  if (c.d_big_tasks)
-    (void)hipFree(c.d_big_tasks);
-  c.d_big_tasks = nullptr;
 }
 
 } // namespace gtx
 
 using namespace gtx;
+
+namespace
+{
+// RAII: the scratch goes back to the pool when the entry point returns, however it returns
+struct ScratchHold
+{
+  gtx_ctx & c;
+  CallScratch * s;
+  hipStream_t stream;
+  bool align;
+  ~ScratchHold()
+  {
+    if (s)
+      scratch_release(c, s, stream, align);
+  }
+};
+} // namespace
 
 extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta,
                                uint32_t n_reads, uint32_t * d_records, uint32_t rec_words, void * stream)
@@ -798,45 +1009,32 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
   }
   if (n_reads == 0) // an empty batch is valid (and its buffers may be NULL)
     return GTX_OK;
-  // per launch: [0] read counter of pass 1, [1] task counter of pass 2, [2] number of tasks queued for pass 2
-  uint32_t * counters = c->d_task_counters + 4 * (c->launch_seq.fetch_add(1) % (gtx_ctx::N_TASK_COUNTERS / 4));
-  if (!hip_ok(hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), static_cast<hipStream_t>(stream)), "task counter reset"))
+  hipStream_t const st = static_cast<hipStream_t>(stream);
+  if (!hip_ok(hipSetDevice(c->device), "hipSetDevice"))
     return GTX_ERR_HIP;
-  // queue of pass 2: room for every task (a graph on which no read is simple sends them all)
-  if (2ull * n_reads > c->queue_cap)
-  {
-    if (c->d_queue && !hip_ok(hipFree(c->d_queue), "pass-2 queue")) // (synchronises with earlier launches)
-      return GTX_ERR_HIP;
-    c->d_queue = nullptr;
-    c->queue_cap = 0;
-    void * p = nullptr;
-    if (!hip_ok(hipMalloc(&p, 2ull * n_reads * sizeof(uint32_t)), "pass-2 queue"))
-      return GTX_ERR_HIP;
-    c->d_queue = static_cast<uint32_t *>(p);
-    c->queue_cap = 2ull * n_reads;
-  }
-  bool const second_pass = c->d_big_state != nullptr;
+  ScratchHold hold{*c, scratch_acquire(*c, st), st, true};
+  CallScratch * s = hold.s;
+  if (!s)
+    return GTX_ERR_HIP;
+  uint32_t * counters = s->d_counters;
+  if (!hip_ok(hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), st), "task counter reset"))
+    return GTX_ERR_HIP;
+  // queues: room for every task (a graph on which no read is simple sends them all)
+  if (!grow(s->d_queue, s->queue_cap, 2ull * n_reads, "pass-2 queue") || !grow(s->d_queue1, s->queue1_cap, n_reads, "pass-1 queue"))
+    return GTX_ERR_HIP;
+  bool const second_pass = s->d_big_state != nullptr;
   if (second_pass)
   {
     // the queue holds every task of a small batch and 8 Mi tasks of a large one (tasks beyond it keep their status bit)
     uint64_t const want = std::min<uint64_t>(2ull * n_reads, 8ull << 20);
-    if (want > c->big_task_cap)
-    {
-      if (c->d_big_tasks && !hip_ok(hipFree(c->d_big_tasks), "second-pass queue")) // (synchronises with earlier launches)
-        return GTX_ERR_HIP;
-      c->d_big_tasks = nullptr;
-      c->big_task_cap = 0;
-      void * p = nullptr;
-      if (!hip_ok(hipMalloc(&p, want * sizeof(uint32_t)), "second-pass queue"))
-        return GTX_ERR_HIP;
-      c->d_big_tasks = static_cast<uint32_t *>(p);
-      c->big_task_cap = static_cast<uint32_t>(want);
-    }
-    // (words 4..5, the arena cursor, live until gtx_ctx_big_records_rewind)
-    if (!hip_ok(hipMemsetAsync(c->d_big_state, 0, 4 * sizeof(uint32_t), static_cast<hipStream_t>(stream)), "second-pass state reset"))
+    uint64_t cap = s->big_task_cap;
+    if (!grow(s->d_big_tasks, cap, want, "second-pass queue"))
+      return GTX_ERR_HIP;
+    s->big_task_cap = static_cast<uint32_t>(cap);
+    if (!hip_ok(hipMemsetAsync(s->d_big_state, 0, 4 * sizeof(uint32_t), st), "second-pass state reset"))
       return GTX_ERR_HIP;
   }
-  // test switch: 1 = every task goes through all three passes (the last one decides), 2 = every task is done by pass 2
+  // test switch: 1 = every task goes through all passes (the last one decides), 2 = every task is done by pass 2
   char const * fb = std::getenv("GTX_FORCE_SECOND_PASS");
   uint32_t const force = fb ? static_cast<uint32_t>(std::atoi(fb)) : 0u;
   // grids: as many single-wave workgroups as are resident at once; they pull work from shared counters
@@ -844,81 +1042,143 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
   uint64_t const chunks = (static_cast<uint64_t>(n_reads) + TASK_CHUNK - 1) / TASK_CHUNK;
   uint32_t const blocks1 = static_cast<uint32_t>(std::min<uint64_t>(chunks, static_cast<uint64_t>(n_cu) * c->express_blocks_per_cu));
   uint32_t const blocks2 = static_cast<uint32_t>(std::min<uint64_t>(2ull * n_reads, static_cast<uint64_t>(n_cu) * c->align_blocks_per_cu));
-  bool const timed = c->pass_events[0] != nullptr;
-  if (timed)
-    (void)hipEventRecord(static_cast<hipEvent_t>(c->pass_events[0]), static_cast<hipStream_t>(stream));
-  char const * e4 = std::getenv("GTX_EXPRESS4"); // A/B switch: 0 = one read per wavefront in pass 1
-  if (!(e4 && e4[0] == '0'))
+  bool timed = false;
   {
-    // GTX_EXPRESS4=lean / wide force a build (tests); else by the graph's density
-    bool const wide = e4 && e4[0] == 'w' ? true : e4 && e4[0] == 'l' ? false : c->express4_wide;
-    uint32_t const blocks4 = static_cast<uint32_t>(std::min<uint64_t>(
-      chunks, static_cast<uint64_t>(n_cu) * (wide ? c->express4_wide_blocks_per_cu : c->express4_blocks_per_cu)));
-    hipLaunchKernelGGL(wide ? gtx_align_express4_wide_kernel : gtx_align_express4_kernel, dim3(blocks4), dim3(64), 0,
-                       static_cast<hipStream_t>(stream), c->dev_graph, c->dev_index, d_seq, seq_stride, d_meta, n_reads, d_records,
-                       rec_words, static_cast<uint32_t>(c->params.force_align_both_orientations != 0), counters, c->d_queue,
-                       counters + 2, static_cast<uint32_t>(force != 0));
+    std::lock_guard<std::mutex> lock(c->pool_mutex);
+    timed = c->timing_armed;
   }
-  else
-    hipLaunchKernelGGL(gtx_align_express_kernel, dim3(blocks1), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph,
-                       c->dev_index, d_seq, seq_stride, d_meta, n_reads, d_records, rec_words,
-                       static_cast<uint32_t>(c->params.force_align_both_orientations != 0), counters, c->d_queue, counters + 2,
-                       static_cast<uint32_t>(force != 0));
-  if (!hip_ok(hipGetLastError(), "gtx_align_express_kernel launch"))
-    return GTX_ERR_HIP;
-  if (timed)
-    (void)hipEventRecord(static_cast<hipEvent_t>(c->pass_events[1]), static_cast<hipStream_t>(stream));
-  hipLaunchKernelGGL(gtx_align_kernel, dim3(blocks2), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph, c->dev_index, d_seq,
-                     seq_stride, d_meta, d_records, rec_words, c->d_queue, counters + 2, counters + 1,
-                     second_pass ? c->d_big_tasks : nullptr, c->big_task_cap, c->d_big_state, static_cast<uint32_t>(force == 1));
-  if (!hip_ok(hipGetLastError(), "gtx_align_kernel launch"))
-    return GTX_ERR_HIP;
-  if (timed)
-    (void)hipEventRecord(static_cast<hipEvent_t>(c->pass_events[2]), static_cast<hipStream_t>(stream));
-  if (second_pass)
-  {
-    hipLaunchKernelGGL(gtx_align_big_kernel, dim3(c->big_blocks), dim3(64), 0, static_cast<hipStream_t>(stream), c->dev_graph,
-                       c->dev_index, d_seq, seq_stride, d_meta, d_records, rec_words, c->d_big_tasks, c->big_task_cap, c->d_big_state,
-                       static_cast<big::AlignWorkspace *>(c->d_big_ws), c->d_big_records,
-                       static_cast<unsigned long long>(c->big_record_words));
-    if (!hip_ok(hipGetLastError(), "gtx_align_big_kernel launch"))
-      return GTX_ERR_HIP;
-  }
-  if (timed)
-    (void)hipEventRecord(static_cast<hipEvent_t>(c->pass_events[3]), static_cast<hipStream_t>(stream));
-  return GTX_OK;
-}
-
-extern "C" int gtx_ctx_pass_times(gtx_ctx * c, float * ms, uint32_t * queued)
-{
-  if (!c || !ms)
-    return GTX_ERR_ARG;
-  ms[0] = ms[1] = ms[2] = 0.0f;
-  if (queued)
-    *queued = 0;
-  if (c->device < 0)
-    return GTX_ERR_NO_DEVICE;
-  if (!c->pass_events[0]) // first call: create the events; the next gtx_align_batch is timed
-  {
-    for (auto & e : c->pass_events)
+  if (timed && !s->pass_events[0])
+    for (auto & e : s->pass_events)
     {
       hipEvent_t ev;
       if (!hip_ok(hipEventCreate(&ev), "pass events"))
         return GTX_ERR_HIP;
       e = ev;
     }
-    return GTX_OK;
-  }
-  if (!hip_ok(hipEventSynchronize(static_cast<hipEvent_t>(c->pass_events[3])), "pass events"))
-    return GTX_OK; // nothing was timed yet
-  for (int k = 0; k < 3; ++k)
-    (void)hipEventElapsedTime(ms + k, static_cast<hipEvent_t>(c->pass_events[k]), static_cast<hipEvent_t>(c->pass_events[k + 1]));
-  if (queued)
+  s->timed = false;
+  auto mark = [&](int k)
   {
-    unsigned const last = (c->launch_seq.load() + gtx_ctx::N_TASK_COUNTERS / 4 - 1) % (gtx_ctx::N_TASK_COUNTERS / 4);
-    (void)hipMemcpy(queued, c->d_task_counters + 4 * last + 2, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (timed)
+      (void)hipEventRecord(static_cast<hipEvent_t>(s->pass_events[k]), st);
+  };
+  uint32_t const force_both = static_cast<uint32_t>(c->params.force_align_both_orientations != 0);
+  char const * e4 = std::getenv("GTX_EXPRESS4"); // A/B switch: 0 = one read per wavefront in pass 1
+  char const * eh = std::getenv("GTX_HINT");     // A/B switch: 0 = no position-hinted pass
+  bool const four = !(e4 && e4[0] == '0');
+  bool const hinted = four && !(eh && eh[0] == '0');
+  // GTX_EXPRESS4=lean / wide force a build (tests); else by the graph's density
+  bool const wide = e4 && e4[0] == 'w' ? true : e4 && e4[0] == 'l' ? false : c->express4_wide;
+  uint32_t const blocks4 = static_cast<uint32_t>(std::min<uint64_t>(
+    chunks, static_cast<uint64_t>(n_cu) * (wide ? c->express4_wide_blocks_per_cu : c->express4_blocks_per_cu)));
+  mark(0);
+  if (hinted)
+  {
+    // pass 0: one read per lane from the position hint; what it declines is queued for pass 1.  (GTX_HINT=decline: the
+    // pass runs but declines everything -- a test of the queue plumbing)
+    hipLaunchKernelGGL(gtx_align_hinted_kernel, dim3((n_reads + 255u) / 256u), dim3(256), 0, st, c->dev_graph, c->dev_index, d_seq,
+                       seq_stride, d_meta, n_reads, d_records, rec_words, force_both, s->d_queue1, counters + 3, s->d_queue, counters + 2,
+                       static_cast<uint32_t>(force != 0 || (eh && eh[0] == 'd')));
+    if (!hip_ok(hipGetLastError(), "gtx_align_hinted_kernel launch"))
+      return GTX_ERR_HIP;
+    mark(1);
+    hipLaunchKernelGGL(wide ? gtx_align_express4q_wide_kernel : gtx_align_express4q_kernel, dim3(blocks4), dim3(64), 0, st, c->dev_graph,
+                       c->dev_index, d_seq, seq_stride, d_meta, d_records, rec_words, counters, s->d_queue1, counters + 3, s->d_queue,
+                       counters + 2, counters + 4, static_cast<uint32_t>(force != 0));
   }
+  else
+  {
+    mark(1);
+    if (four)
+      hipLaunchKernelGGL(wide ? gtx_align_express4_wide_kernel : gtx_align_express4_kernel, dim3(blocks4), dim3(64), 0, st, c->dev_graph,
+                         c->dev_index, d_seq, seq_stride, d_meta, n_reads, d_records, rec_words, force_both, counters, s->d_queue,
+                         counters + 2, static_cast<uint32_t>(force != 0));
+    else
+      hipLaunchKernelGGL(gtx_align_express_kernel, dim3(blocks1), dim3(64), 0, st, c->dev_graph, c->dev_index, d_seq, seq_stride, d_meta,
+                         n_reads, d_records, rec_words, force_both, counters, s->d_queue, counters + 2, static_cast<uint32_t>(force != 0));
+  }
+  if (!hip_ok(hipGetLastError(), "express kernel launch"))
+    return GTX_ERR_HIP;
+  mark(2);
+  hipLaunchKernelGGL(gtx_align_kernel, dim3(blocks2), dim3(64), 0, st, c->dev_graph, c->dev_index, d_seq, seq_stride, d_meta, d_records,
+                     rec_words, s->d_queue, counters + 2, counters + 1, second_pass ? s->d_big_tasks : nullptr, s->big_task_cap,
+                     s->d_big_state, static_cast<uint32_t>(force == 1));
+  if (!hip_ok(hipGetLastError(), "gtx_align_kernel launch"))
+    return GTX_ERR_HIP;
+  mark(3);
+  if (second_pass)
+  {
+    hipLaunchKernelGGL(gtx_align_big_kernel, dim3(c->big_blocks), dim3(64), 0, st, c->dev_graph, c->dev_index, d_seq, seq_stride, d_meta,
+                       d_records, rec_words, s->d_big_tasks, s->big_task_cap, s->d_big_state, static_cast<big::AlignWorkspace *>(s->d_big_ws),
+                       c->d_big_records, static_cast<unsigned long long>(c->big_record_words), c->d_arena_cursor);
+    if (!hip_ok(hipGetLastError(), "gtx_align_big_kernel launch"))
+      return GTX_ERR_HIP;
+  }
+  mark(4);
+  s->timed = timed;
+  s->timed_reads = n_reads;
   return GTX_OK;
+}
+
+// (ms[4], tasks[4]) of the last timed gtx_align_batch: position-hinted pass, express pass, general pass, HBM-table pass
+static int kernel_times(gtx_ctx * c, float * ms, uint32_t * tasks)
+{
+  for (int k = 0; k < 4; ++k)
+  {
+    ms[k] = 0.0f;
+    tasks[k] = 0;
+  }
+  if (c->device < 0)
+    return GTX_ERR_NO_DEVICE;
+  CallScratch * s = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(c->pool_mutex);
+    if (!c->timing_armed) // first call: the next gtx_align_batch is timed
+    {
+      c->timing_armed = true;
+      return GTX_OK;
+    }
+    s = c->last_align;
+  }
+  if (!s || !s->timed)
+    return GTX_OK; // nothing was timed yet
+  if (!hip_ok(hipSetDevice(c->device), "hipSetDevice") || !hip_ok(hipEventSynchronize(static_cast<hipEvent_t>(s->pass_events[4])), "pass events"))
+    return GTX_ERR_HIP;
+  for (int k = 0; k < 4; ++k)
+    (void)hipEventElapsedTime(ms + k, static_cast<hipEvent_t>(s->pass_events[k]), static_cast<hipEvent_t>(s->pass_events[k + 1]));
+  uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, big[4] = {0, 0, 0, 0};
+  (void)hipMemcpy(cnt, s->d_counters, sizeof(cnt), hipMemcpyDeviceToHost);
+  if (s->d_big_state)
+    (void)hipMemcpy(big, s->d_big_state, sizeof(big), hipMemcpyDeviceToHost);
+  // forward tasks only: reverse-orientation tasks all go to the general pass
+  uint32_t const hbm = std::min<uint32_t>(big[0], s->big_task_cap);
+  bool const hinted = ms[0] > 0.0f && cnt[3] + cnt[4] != 0;
+  tasks[0] = hinted || ms[0] > 0.0f ? s->timed_reads - cnt[3] : 0;
+  tasks[1] = hinted || ms[0] > 0.0f ? cnt[3] - cnt[4] : s->timed_reads - std::min(cnt[2], s->timed_reads);
+  tasks[2] = cnt[2] - std::min(hbm, cnt[2]);
+  tasks[3] = hbm;
+  return GTX_OK;
+}
+
+extern "C" int gtx_ctx_kernel_times(gtx_ctx * c, float * ms, uint32_t * tasks)
+{
+  if (!c || !ms || !tasks)
+    return GTX_ERR_ARG;
+  return kernel_times(c, ms, tasks);
+}
+
+extern "C" int gtx_ctx_pass_times(gtx_ctx * c, float * ms, uint32_t * queued)
+{
+  if (!c || !ms)
+    return GTX_ERR_ARG;
+  float m4[4];
+  uint32_t t4[4];
+  int const rc = kernel_times(c, m4, t4);
+  ms[0] = m4[0] + m4[1]; // everything in front of the general pass
+  ms[1] = m4[2];
+  ms[2] = m4[3];
+  if (queued)
+    *queued = t4[2] + t4[3];
+  return rc;
 }
 
 extern "C" int gtx_score_batch(gtx_ctx * c, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records,
@@ -937,6 +1197,13 @@ extern "C" int gtx_score_batch(gtx_ctx * c, const gtx_score_item * d_items, uint
   }
   if (n_items == 0)
     return GTX_OK;
+  hipStream_t const st = static_cast<hipStream_t>(stream);
+  if (!hip_ok(hipSetDevice(c->device), "hipSetDevice"))
+    return GTX_ERR_HIP;
+  ScratchHold hold{*c, scratch_acquire(*c, st), st, false};
+  CallScratch * s = hold.s;
+  if (!s)
+    return GTX_ERR_HIP;
   ScoreAcc a;
   a.n_samples = acc->n_samples;
   a.conn_cap = acc->conn_cap;
@@ -952,40 +1219,31 @@ extern "C" int gtx_score_batch(gtx_ctx * c, const gtx_score_item * d_items, uint
   ScoreParams par{static_cast<uint32_t>(c->params.is_sv_graph != 0), static_cast<uint32_t>(c->params.hq_reads != 0),
                   static_cast<uint32_t>(c->params.is_segment_calling != 0), 0};
   uint32_t const blocks = (n_items + 255u) / 256u;
-  bool const second_pass = c->d_score_state != nullptr;
-  if (second_pass &&
-      !hip_ok(hipMemsetAsync(c->d_score_state, 0, 2 * sizeof(uint32_t), static_cast<hipStream_t>(stream)), "second-pass state reset"))
+  bool const second_pass = s->d_score_state != nullptr;
+  if (second_pass && !hip_ok(hipMemsetAsync(s->d_score_state, 0, 2 * sizeof(uint32_t), st), "second-pass state reset"))
     return GTX_ERR_HIP;
-  // work queue of stage 2: room for every item
-  if (n_items > c->score_work_cap)
-  {
-    if (c->d_score_work && !hip_ok(hipFree(c->d_score_work), "score work queue")) // (synchronises with earlier launches)
-      return GTX_ERR_HIP;
-    c->d_score_work = nullptr;
-    c->score_work_cap = 0;
-    void * p = nullptr;
-    if (!hip_ok(hipMalloc(&p, (static_cast<size_t>(n_items) + 1) * sizeof(uint32_t)), "score work queue"))
-      return GTX_ERR_HIP;
-    c->d_score_work = static_cast<uint32_t *>(p); // [0] = count, [1..] = item indices
-    c->score_work_cap = n_items;
-  }
-  if (!hip_ok(hipMemsetAsync(c->d_score_work, 0, sizeof(uint32_t), static_cast<hipStream_t>(stream)), "score work queue reset"))
+  // work queue of stage 2: room for every item ([0] = count, [1..] = item indices)
+  uint64_t cap = s->score_work_cap ? static_cast<uint64_t>(s->score_work_cap) + 1 : 0;
+  if (!grow(s->d_score_work, cap, static_cast<uint64_t>(n_items) + 1, "score work queue"))
     return GTX_ERR_HIP;
-  hipLaunchKernelGGL(gtx_score_triage_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_items, n_items, d_records,
-                     rec_words, c->d_score_work + 1, c->d_score_work);
+  s->score_work_cap = static_cast<uint32_t>(cap - 1);
+  if (!hip_ok(hipMemsetAsync(s->d_score_work, 0, sizeof(uint32_t), st), "score work queue reset"))
+    return GTX_ERR_HIP;
+  hipLaunchKernelGGL(gtx_score_triage_kernel, dim3(blocks), dim3(256), 0, st, d_items, n_items, d_records, rec_words, s->d_score_work + 1,
+                     s->d_score_work);
   if (!hip_ok(hipGetLastError(), "gtx_score_triage_kernel launch"))
     return GTX_ERR_HIP;
   uint32_t const work_blocks = std::min<uint32_t>(blocks, static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256) * 8u);
-  hipLaunchKernelGGL(gtx_score_kernel, dim3(work_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), c->dev_graph, par, d_items,
-                     c->d_score_work + 1, c->d_score_work, d_records, rec_words, a, c->d_error_flag,
-                     second_pass ? c->d_score_queue : nullptr, second_pass ? gtx_ctx::SCORE_QUEUE_CAP : 0u, c->d_score_state);
+  hipLaunchKernelGGL(gtx_score_kernel, dim3(work_blocks), dim3(256), 0, st, c->dev_graph, par, d_items, s->d_score_work + 1, s->d_score_work,
+                     d_records, rec_words, a, c->d_error_flag, second_pass ? s->d_score_queue : nullptr,
+                     second_pass ? gtx_ctx::SCORE_QUEUE_CAP : 0u, s->d_score_state);
   if (!hip_ok(hipGetLastError(), "gtx_score_kernel launch"))
     return GTX_ERR_HIP;
   if (second_pass)
   {
-    hipLaunchKernelGGL(gtx_score_big_kernel, dim3(gtx_ctx::SCORE_BIG_THREADS / 64), dim3(64), 0, static_cast<hipStream_t>(stream),
-                       c->dev_graph, par, d_items, d_records, rec_words, a, c->d_error_flag, c->d_score_queue,
-                       gtx_ctx::SCORE_QUEUE_CAP, c->d_score_state, static_cast<RecentHap *>(c->d_score_tables));
+    hipLaunchKernelGGL(gtx_score_big_kernel, dim3(gtx_ctx::SCORE_BIG_THREADS / 64), dim3(64), 0, st, c->dev_graph, par, d_items, d_records,
+                       rec_words, a, c->d_error_flag, s->d_score_queue, gtx_ctx::SCORE_QUEUE_CAP, s->d_score_state,
+                       static_cast<RecentHap *>(s->d_score_tables));
     if (!hip_ok(hipGetLastError(), "gtx_score_big_kernel launch"))
       return GTX_ERR_HIP;
   }
@@ -1003,16 +1261,27 @@ extern "C" int gtx_ctx_big_records(gtx_ctx * c, const uint32_t ** d_words, uint6
     *used_words = 0;
   if (tasks)
     *tasks = 0;
-  if ((used_words || tasks) && c->d_big_state)
+  if ((used_words || tasks) && c->d_arena_cursor)
   {
-    uint32_t st[8];
-    if (!hip_ok(hipMemcpy(st, c->d_big_state, sizeof(st), hipMemcpyDeviceToHost), "second-pass state"))
+    if (!hip_ok(hipSetDevice(c->device), "hipSetDevice"))
       return GTX_ERR_HIP;
-    uint64_t const used = (static_cast<uint64_t>(st[5]) << 32) | st[4];
+    unsigned long long used = 0;
+    if (!hip_ok(hipMemcpy(&used, c->d_arena_cursor, sizeof(used), hipMemcpyDeviceToHost), "arena cursor"))
+      return GTX_ERR_HIP;
     if (used_words)
       *used_words = std::min<uint64_t>(used, c->big_record_words);
-    if (tasks)
-      *tasks = std::min<uint32_t>(st[0], c->big_task_cap);
+    CallScratch * s = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(c->pool_mutex);
+      s = c->last_align;
+    }
+    if (tasks && s && s->d_big_state)
+    {
+      uint32_t queued = 0;
+      if (!hip_ok(hipMemcpy(&queued, s->d_big_state, sizeof(queued), hipMemcpyDeviceToHost), "second-pass state"))
+        return GTX_ERR_HIP;
+      *tasks = std::min<uint32_t>(queued, s->big_task_cap);
+    }
   }
   return GTX_OK;
 }
@@ -1021,8 +1290,8 @@ extern "C" int gtx_ctx_big_records_rewind(gtx_ctx * c, void * stream)
 {
   if (!c)
     return GTX_ERR_ARG;
-  if (c->d_big_state &&
-      !hip_ok(hipMemsetAsync(c->d_big_state + 4, 0, 2 * sizeof(uint32_t), static_cast<hipStream_t>(stream)), "arena rewind"))
+  if (c->d_arena_cursor &&
+      !hip_ok(hipMemsetAsync(c->d_arena_cursor, 0, sizeof(unsigned long long), static_cast<hipStream_t>(stream)), "arena rewind"))
     return GTX_ERR_HIP;
   return GTX_OK;
 }
@@ -1042,6 +1311,8 @@ extern "C" int gtx_calls_batch(gtx_ctx * c, const gtx_score_buffers * acc, uint8
   uint64_t const cells = static_cast<uint64_t>(acc->n_samples) * c->dev_graph.n_hap;
   if (cells == 0)
     return GTX_OK;
+  if (!hip_ok(hipSetDevice(c->device), "hipSetDevice"))
+    return GTX_ERR_HIP;
   hipLaunchKernelGGL(gtx_calls_kernel, dim3(static_cast<uint32_t>((cells + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      c->dev_graph, acc->n_samples, acc->d_log_score, acc->d_gt_cov, acc->d_hap_u32, d_phred, d_calls);
   if (!hip_ok(hipGetLastError(), "gtx_calls_kernel launch"))

@@ -1,10 +1,50 @@
 // gtx_ctx.hpp -- the opaque context behind gtx_ctx* (host copies + device copies of graph and index)
 #pragma once
 #include <atomic>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "gtx_flat.hpp"
+
+namespace gtx
+{
+// Everything a gtx_align_batch / gtx_score_batch call writes besides the caller's buffers: queues between the passes,
+// device counters, workspaces of the HBM-table passes, timing events.  A call owns one CallScratch from entry until its
+// last launch is enqueued; the scratch is handed to the next call on the same stream at once (stream order keeps them
+// apart) and to a call on another stream once its `done` event has completed.  That is what makes the entry points
+// re-entrant: the reference calls align_read / update_haplotype_scores_geno from `jobs` threads at the same time
+// (src/typer/caller.cpp:399-436) against one immutable index + graph.
+struct CallScratch
+{
+  bool busy = false;         // a host thread is inside an entry point with it (guarded by gtx_ctx::pool_mutex)
+  void * last_stream = nullptr;
+  bool used = false;         // `done` has been recorded at least once
+  void * done = nullptr;     // hipEvent_t recorded behind the last launch that uses this scratch
+  // [0] read / queue-1 claim counter of pass 1, [1] task counter of pass 2, [2] tasks queued for pass 2,
+  // [3] forward tasks the position-hinted pass handed to pass 1, [4] forward tasks pass 1 handed to pass 2
+  uint32_t * d_counters = nullptr;
+  uint32_t * d_queue1 = nullptr; // reads whose forward task the position-hinted pass declined (grow-only)
+  uint64_t queue1_cap = 0;
+  uint32_t * d_queue = nullptr;  // (read * 2 + orientation) tasks for pass 2 (grow-only)
+  uint64_t queue_cap = 0;
+  void * pass_events[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // around the four alignment launches
+  bool timed = false;            // the events above bracket a finished call
+  uint32_t timed_reads = 0;
+  // HBM-table pass (reads that overflowed the LDS-sized tables)
+  uint32_t * d_big_tasks = nullptr;
+  uint32_t big_task_cap = 0;
+  uint32_t * d_big_state = nullptr; // [0] tasks queued, [1] claim cursor, [3] tasks dropped (list full)
+  void * d_big_ws = nullptr;
+  // second scoring pass (items whose reads touch more variant sites than the main pass' tables hold)
+  uint32_t * d_score_state = nullptr; // [0] items queued
+  uint32_t * d_score_queue = nullptr;
+  void * d_score_tables = nullptr;
+  uint32_t * d_score_work = nullptr; // [0] number of items the triage kernel found worth scoring, [1..] their indices (grow-only)
+  uint32_t score_work_cap = 0;
+};
+} // namespace gtx
 
 struct gtx_ctx
 {
@@ -17,30 +57,20 @@ struct gtx_ctx
   gtx::GraphView dev_graph{};
   gtx::IndexView dev_index{};
   uint32_t * d_error_flag = nullptr;
-  static constexpr unsigned N_TASK_COUNTERS = 64; // one per launch in flight (launches may overlap on different streams)
-  uint32_t * d_task_counters = nullptr;
-  std::atomic<unsigned> launch_seq{0};
   int align_blocks_per_cu = 8, express_blocks_per_cu = 16, express4_blocks_per_cu = 8;
   int express4_wide_blocks_per_cu = 8;
   bool express4_wide = false; // pass 1 runs gtx_align_express4_wide_kernel (express4_prefers_wide, gtx_flat.hpp)
-  uint32_t * d_queue = nullptr; // tasks pass 1 hands to pass 2 (grow-only)
-  uint64_t queue_cap = 0;
-  void * pass_events[4] = {nullptr, nullptr, nullptr, nullptr}; // hipEvent_t around the three passes (gtx_ctx_pass_times)
-  // second pass (reads that overflowed the LDS-sized tables): task list, HBM workspaces, arena for long records
-  uint32_t * d_big_tasks = nullptr;  // (read * 2 + orientation) of every queued task
-  uint32_t big_task_cap = 0;
-  uint32_t * d_big_state = nullptr;  // [0] tasks queued, [1] claim cursor, [2] arena cursor (words), [3] tasks dropped (list full)
-  void * d_big_ws = nullptr;         // big_blocks workspaces
   uint32_t big_blocks = 0;
+  static constexpr uint32_t SCORE_QUEUE_CAP = 1u << 20, SCORE_BIG_THREADS = 1024;
+  // arena for records longer than a record slot: shared by all calls (it only grows; the cursor is a device counter)
   uint32_t * d_big_records = nullptr;
   uint64_t big_record_words = 0;
-  // second scoring pass (items whose reads touch more variant sites than the main pass' tables hold)
-  static constexpr uint32_t SCORE_QUEUE_CAP = 1u << 20, SCORE_BIG_THREADS = 1024;
-  uint32_t * d_score_state = nullptr; // [0] items queued
-  uint32_t * d_score_queue = nullptr;
-  void * d_score_tables = nullptr;
-  uint32_t * d_score_work = nullptr; // [0] number of items the triage kernel found worth scoring, [1..] their indices (grow-only)
-  uint32_t score_work_cap = 0;
+  unsigned long long * d_arena_cursor = nullptr;
+  // pool of per-call scratch (see CallScratch)
+  std::mutex pool_mutex;
+  std::vector<std::unique_ptr<gtx::CallScratch>> pool;
+  gtx::CallScratch * last_align = nullptr; // scratch of the most recent gtx_align_batch (pass times, second-pass task count)
+  bool timing_armed = false;
 };
 
 namespace gtx

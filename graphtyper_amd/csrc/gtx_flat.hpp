@@ -103,7 +103,42 @@ struct IndexView
   const HalfEntry * hlist;
   uint32_t h_log2_cap;
   uint32_t half_bucket_cap; // buckets above this size use the 96 direct probes instead (0 = always probe directly)
+  // ---- position-hinted pass (hinted.hpp).  A read of a sorted BAM comes with the place the mapper put it; the tables
+  // below are ordered by reference position, so neighbouring reads share their cache lines, and they carry the PROOF
+  // that the global lookups of the reference would return exactly the one label of that place.
+  // ref4: the linear reference of the region (= the graph's path over every site's allele 0) as BAM nibble codes,
+  //   8 bases per word, base 8w+j in bits 28-4j; entry 0 is contig position hint_first (0-based); 4 padding words.
+  // pos_flags[i], about the 32-mer that starts at hint_first + i (K_i) and about the position itself:
+  //   HINT_EXACT_OK   a read k-mer equal to K_i has exactly the label (i, i+31[, site, allele 0]) and every indexed
+  //                   Hamming-1 neighbour of K_i is that same interval on the same site (express4's seeding rule);
+  //   HINT_SINGLE_OK  K_i has that one label (and it may be used: not on a variant of an SV graph);
+  //   HINT_L1 / R1    K_i is the only indexed key with its 16 first / last bases;
+  //   bits 4..11      min(255, bases from this position to the end of its reference node), 0 = not in a reference node;
+  //   bits 12..31     the site K_i's label lies on (HINT_NO_SITE: none).
+  // filt[side]: one bit per hash of every indexed key's 16 first (side 0) / last (side 1) bases in nibble form: a clear
+  //   bit proves that no indexed key has that half.
+  const uint32_t * ref4;
+  const uint32_t * pos_flags;
+  const uint32_t * filt[2];
+  uint32_t hint_first, n_hint, filt_log2, pad_hint;
 };
+
+constexpr uint32_t HINT_EXACT_OK = 1u, HINT_SINGLE_OK = 2u, HINT_L1 = 4u, HINT_R1 = 8u, HINT_ROOM_SHIFT = 4u, HINT_SITE_SHIFT = 12u;
+constexpr uint32_t HINT_NO_SITE = 0xFFFFFu;
+// limits of express4's lean seeding rule that HINT_EXACT_OK restates on the host (static_asserts in express4.inl)
+constexpr uint32_t HINT_HE_CAP = 4, HINT_NB_MAX = 3;
+
+// hash of a 16-base half in nibble form (w0 = bases 0..7, w1 = bases 8..15; base j in bits 28-4j) -> filter bit
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t hint_filter_bit(uint32_t w0, uint32_t w1, uint32_t log2_bits)
+{
+  uint64_t h = ((static_cast<uint64_t>(w0) << 32) | w1) * 0x9E3779B97F4A7C15ull;
+  h ^= h >> 29;
+  h *= 0xBF58476D1CE4E5B9ull;
+  return static_cast<uint32_t>(h >> (64 - log2_bits));
+}
 
 struct HostGraph
 {
@@ -141,6 +176,11 @@ struct HostIndex
   std::vector<IndexSlot> hslots;
   std::vector<HalfEntry> hlist;
   uint32_t h_log2_cap = 0;
+  // position-hinted pass (IndexView::ref4 ...)
+  std::vector<uint32_t> ref4, pos_flags, filt[2];
+  uint32_t hint_first = 0, n_hint = 0, filt_log2 = 0;
+
+  IndexView view(uint32_t max_index_labels, uint32_t half_bucket_cap) const; // over the host copies
 };
 
 // returns "" on success, else a description of what is wrong with the view

@@ -516,6 +516,236 @@ static void bucket_insert_all(std::vector<IndexSlot> & slots, uint32_t log2_buck
       bucket_insert(slots, log2_buckets, items[i]);
 }
 
+IndexView HostIndex::view(uint32_t max_index_labels, uint32_t half_bucket_cap) const
+{
+  IndexView ix{};
+  ix.slots = slots.data();
+  ix.labels = dev_labels.data();
+  ix.log2_cap = log2_cap;
+  ix.max_index_labels = max_index_labels;
+  ix.hslots = hslots.data();
+  ix.hlist = hlist.data();
+  ix.h_log2_cap = h_log2_cap;
+  ix.half_bucket_cap = half_bucket_cap;
+  ix.ref4 = ref4.data();
+  ix.pos_flags = pos_flags.data();
+  ix.filt[0] = filt[0].data();
+  ix.filt[1] = filt[1].data();
+  ix.hint_first = hint_first;
+  ix.n_hint = n_hint;
+  ix.filt_log2 = filt_log2;
+  return ix;
+}
+
+// Tables of the position-hinted pass (IndexView::ref4 ..., hinted.hpp).  For every reference position: what a read
+// k-mer that equals -- or is one substitution / one ambiguous base away from -- the reference 32-mer of that place
+// would get from the global lookups, decided here once from the finished index.
+static void build_hints(HostGraph const & g, HostIndex & out)
+{
+  uint32_t const R = static_cast<uint32_t>(g.ref_order.size());
+  out.ref4.clear();
+  out.pos_flags.clear();
+  out.filt[0].clear();
+  out.filt[1].clear();
+  out.n_hint = 0;
+  out.filt_log2 = 5;
+  out.hint_first = g.ref_order.empty() ? 0 : g.ref_order[0] - 1; // order = 1-based contig position
+  if (R == 0 || R - 1 >= HINT_NO_SITE)
+  {
+    out.ref4.assign(8, 0);
+    out.pos_flags.assign(1, 0);
+    out.filt[0].assign(1, 0);
+    out.filt[1].assign(1, 0);
+    return;
+  }
+  // linear reference = reference nodes and allele 0 of every site, in order
+  uint32_t const first = g.ref_order[0], last = g.ref_order[R - 1] + g.ref_len[R - 1];
+  uint32_t const n = last - first;
+  std::vector<uint8_t> base(n, 15);  // nibble codes (A=1 C=2 G=4 T=8, anything else 15)
+  std::vector<uint8_t> room(n, 0);   // bases to the end of the reference node (capped), 0 outside reference nodes
+  auto nib = [](char c) -> uint8_t { return c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 4 : c == 'T' ? 8 : 15; };
+  for (uint32_t r = 0; r < R; ++r)
+  {
+    uint32_t const at = g.ref_order[r] - first;
+    for (uint32_t d = 0; d < g.ref_len[r]; ++d)
+    {
+      base[at + d] = nib(g.dna[g.ref_dna[r] + d]);
+      uint32_t const left = g.ref_len[r] - d;
+      room[at + d] = static_cast<uint8_t>(left < 255 ? left : 255);
+    }
+    if (r + 1 < R && g.ref_nvar[r] != 0)
+    {
+      uint32_t const v = g.ref_first_var[r], vat = g.var_order[v] - first;
+      for (uint32_t d = 0; d < g.var_len[v]; ++d)
+        base[vat + d] = nib(g.dna[g.var_dna[v] + d]);
+    }
+  }
+  out.n_hint = n;
+  out.ref4.assign(n / 8 + 5, 0);
+  for (uint32_t i = 0; i < n; ++i)
+    out.ref4[i >> 3] |= static_cast<uint32_t>(base[i]) << (28 - 4 * (i & 7u));
+  // per key: how many keys share its first / last 16 bases, and whether its Hamming-1 neighbours are "the same interval
+  // on the same site" (what express4's seeding lambda requires of the neighbours of an exact hit)
+  std::size_t const nk = out.keys.size();
+  std::vector<uint32_t> lcount(nk, 0), rcount(nk, 0), nb(nk, 0);
+  std::vector<uint8_t> nb_same(nk, 1);
+  auto distance1 = [](uint64_t a, uint64_t b)
+  {
+    uint64_t const x = a ^ b, bases = (x | (x >> 1)) & 0x5555555555555555ull;
+    return bases != 0 && (bases & (bases - 1)) == 0;
+  };
+  auto one_label_of = [&](std::size_t k, DevLabel & l)
+  {
+    if (out.key_off[k + 1] - out.key_off[k] != 1)
+      return false;
+    l = out.dev_labels[out.key_off[k]];
+    return true;
+  };
+  auto judge_group = [&](std::vector<uint32_t> const & members, std::vector<uint32_t> & count)
+  {
+    for (uint32_t a : members)
+    {
+      count[a] = static_cast<uint32_t>(members.size());
+      DevLabel la{};
+      bool const single = one_label_of(a, la);
+      for (uint32_t b : members)
+        if (a != b && distance1(out.keys[a], out.keys[b]))
+        {
+          nb[a] += out.key_off[b + 1] - out.key_off[b];
+          for (uint32_t k = out.key_off[b]; k < out.key_off[b + 1]; ++k)
+          {
+            DevLabel const & lb = out.dev_labels[k];
+            if (!single || la.site == INVALID || lb.site != la.site || lb.start != la.start || lb.end != la.end)
+              nb_same[a] = 0;
+          }
+        }
+    }
+  };
+  {
+    std::vector<uint32_t> members;
+    for (std::size_t k = 0; k < nk;) // keys ascending: equal first 16 bases are neighbours in the array
+    {
+      std::size_t e = k + 1;
+      while (e < nk && (out.keys[e] >> 32) == (out.keys[k] >> 32))
+        ++e;
+      if (e - k > 1 && e - k <= 64)
+      {
+        members.clear();
+        for (std::size_t m = k; m < e; ++m)
+          members.push_back(static_cast<uint32_t>(m));
+        judge_group(members, lcount);
+      }
+      else
+        for (std::size_t m = k; m < e; ++m)
+        {
+          lcount[m] = static_cast<uint32_t>(e - k);
+          nb_same[m] = e - k == 1 ? nb_same[m] : 0; // (crowded: never judged, never EXACT_OK)
+        }
+      k = e;
+    }
+    std::vector<std::pair<uint64_t, uint32_t>> order(nk);
+    for (std::size_t k = 0; k < nk; ++k)
+      order[k] = {out.keys[k] & 0xFFFFFFFFull, static_cast<uint32_t>(k)};
+    radix_sort_pairs(order, 32);
+    for (std::size_t k = 0; k < nk;)
+    {
+      std::size_t e = k + 1;
+      while (e < nk && order[e].first == order[k].first)
+        ++e;
+      if (e - k > 1 && e - k <= 64)
+      {
+        members.clear();
+        for (std::size_t m = k; m < e; ++m)
+          members.push_back(order[m].second);
+        judge_group(members, rcount);
+      }
+      else
+        for (std::size_t m = k; m < e; ++m)
+        {
+          rcount[order[m].second] = static_cast<uint32_t>(e - k);
+          nb_same[order[m].second] = e - k == 1 ? nb_same[order[m].second] : 0;
+        }
+      k = e;
+    }
+  }
+  // filters over the halves of every indexed key (nibble form, as the kernel hashes them)
+  uint32_t fl = 10;
+  while ((1ull << fl) < 16ull * (nk + 1) && fl < 31)
+    ++fl;
+  out.filt_log2 = fl;
+  out.filt[0].assign((1ull << fl) / 32, 0);
+  out.filt[1].assign((1ull << fl) / 32, 0);
+  auto nibble_words = [](uint32_t half, uint32_t & w0, uint32_t & w1) // 16 bases, 2 bits each, first base in the top bits
+  {
+    w0 = w1 = 0;
+    for (uint32_t j = 0; j < 8; ++j)
+    {
+      w0 |= (1u << ((half >> (30 - 2 * j)) & 3u)) << (28 - 4 * j);
+      w1 |= (1u << ((half >> (14 - 2 * j)) & 3u)) << (28 - 4 * j);
+    }
+  };
+  for (std::size_t k = 0; k < nk; ++k)
+    for (uint32_t side = 0; side < 2; ++side)
+    {
+      uint32_t w0, w1;
+      nibble_words(static_cast<uint32_t>(side == 0 ? out.keys[k] >> 32 : out.keys[k]), w0, w1);
+      uint32_t const bit = hint_filter_bit(w0, w1, fl);
+      out.filt[side][bit >> 5] |= 1u << (bit & 31u);
+    }
+  // per position
+  out.pos_flags.assign(n, HINT_NO_SITE << HINT_SITE_SHIFT);
+  parallel_slices(n, host_threads(), [&](unsigned, std::size_t b, std::size_t e) {
+    uint64_t roll = 0;
+    uint32_t valid = 0;
+    std::size_t const from = b >= K - 1 ? b - (K - 1) : 0; // warm the window up so that position b itself is judged
+    for (std::size_t i = from; i < e + K - 1 && i < n; ++i)
+    {
+      // window ends at i, starts at i - 31
+      uint8_t const c = base[i];
+      if (c == 15)
+        valid = 0;
+      else
+      {
+        roll = (roll << 2) | (c == 1 ? 0u : c == 2 ? 1u : c == 4 ? 2u : 3u);
+        ++valid;
+      }
+      if (i + 1 < K)
+        continue;
+      std::size_t const p = i + 1 - K;
+      if (p < b || p >= e)
+        continue;
+      uint32_t f = static_cast<uint32_t>(room[p]) << HINT_ROOM_SHIFT;
+      uint32_t site = HINT_NO_SITE;
+      if (valid >= K)
+      {
+        auto it = std::lower_bound(out.keys.begin(), out.keys.end(), roll);
+        if (it != out.keys.end() && *it == roll)
+        {
+          std::size_t const k = static_cast<std::size_t>(it - out.keys.begin());
+          DevLabel l{};
+          uint32_t const order = first + static_cast<uint32_t>(p);
+          if (one_label_of(k, l) && l.start == order && l.end == order + K - 1 && (l.site == INVALID || l.allele == 0) &&
+              !(l.site != INVALID && g.is_sv_graph))
+          {
+            site = l.site == INVALID ? HINT_NO_SITE : l.site;
+            f |= HINT_SINGLE_OK;
+            if (lcount[k] == 1)
+              f |= HINT_L1;
+            if (rcount[k] == 1)
+              f |= HINT_R1;
+            bool const few = lcount[k] <= HINT_HE_CAP && rcount[k] <= HINT_HE_CAP;
+            if (few && (nb[k] == 0 || (nb_same[k] && nb[k] <= HINT_NB_MAX)))
+              f |= HINT_EXACT_OK;
+          }
+        }
+      }
+      out.pos_flags[p] = f | (site << HINT_SITE_SHIFT);
+    }
+  });
+  for (uint32_t p = n >= K - 1 ? n - (K - 1) : 0; p < n; ++p) // the last 31 positions start no 32-mer
+    out.pos_flags[p] = (static_cast<uint32_t>(room[p]) << HINT_ROOM_SHIFT) | (HINT_NO_SITE << HINT_SITE_SHIFT);
+}
+
 void build_index(HostGraph const & g, HostIndex & out)
 {
   bool const timing = std::getenv("GTX_TIMING") != nullptr; // stage times on stderr
@@ -701,6 +931,8 @@ void build_index(HostGraph const & g, HostIndex & out)
     bucket_insert_all(out.hslots, hl, half_items);
   }
   lap("half-key tables");
+  build_hints(g, out);
+  lap("position hints");
 }
 
 } // namespace gtx

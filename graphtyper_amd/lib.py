@@ -25,7 +25,7 @@ EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy"
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_set_coverage", "gtx_stream_finish", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
            "gtx_graph_destroy",
            "gtx_scores_alloc", "gtx_scores_zero", "gtx_scores_free", "gtx_scores_reduce", "gtx_comm_unique_id", "gtx_comm_init_rank",
-           "gtx_comm_destroy"]
+           "gtx_comm_destroy", "gtx_ctx_kernel_times"]
 
 
 class GraphView(C.Structure):
@@ -112,6 +112,7 @@ def lib():
                                           C.POINTER(C.c_uint64)]
         L.gtx_ctx_big_records_rewind.argtypes = [C.c_void_p, C.c_void_p]
         L.gtx_ctx_pass_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+        L.gtx_ctx_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.gtx_ctx_error_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.gtx_ctx_profile.argtypes = [C.c_void_p, C.c_void_p]
         L.gtx_scores_finalize.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -397,6 +398,13 @@ class Context:
         q = C.c_uint32()
         check(lib().gtx_ctx_pass_times(self.h, ms, C.byref(q)))
         return [float(x) for x in ms], int(q.value)
+
+    def kernel_times(self):
+        """[(kernel, ms, forward tasks completed)] of the four launches of the last timed align batch"""
+        ms, tasks = (C.c_float * 4)(), (C.c_uint32 * 4)()
+        check(lib().gtx_ctx_kernel_times(self.h, ms, tasks))
+        names = ("gtx_align_hinted_kernel", "gtx_align_express4_kernel", "gtx_align_kernel", "gtx_align_big_kernel")
+        return [(n, float(m), int(t)) for n, m, t in zip(names, ms, tasks)]
 
     def rewind_big_records(self):
         check(lib().gtx_ctx_big_records_rewind(self.h, None))

@@ -240,7 +240,12 @@ int gtx_index_dump(const gtx_ctx *, uint64_t * keys, uint32_t * counts, gtx_labe
  * Two passes: the main kernel keeps a read's tables in LDS; the few reads that exceed them (repeats: hundreds of seed
  * locations) are queued on the device and redone by a second kernel over HBM-resident tables that hold what the
  * reference's own limits allow, so they get the same result as any other read.  Only a read beyond those tables too
- * keeps an overflow status (and no paths).  Calls on one context must not overlap in time (stream-order them). */
+ * keeps an overflow status (and no paths).
+ * In front of them runs the position-hinted pass (gtx_read_meta::pos): one read per lane, finished there when the flags of
+ * the hinted place prove what the global lookups would return; everything else goes on to the passes above unchanged.
+ * Re-entrant: calls on one context may overlap in time from several host threads and streams, like align_read is called
+ * from the reference's worker threads (src/typer/caller.cpp:399-436); each call draws its queues, counters and
+ * workspaces from a pool inside the context. */
 int gtx_align_batch(gtx_ctx *, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
                     uint32_t * d_records, uint32_t rec_words, void * stream);
 
@@ -284,9 +289,15 @@ int gtx_ctx_error_count(gtx_ctx *, uint32_t * out);
  * (both synchronise with the device) */
 int gtx_ctx_big_records(gtx_ctx *, const uint32_t ** d_words, uint64_t * capacity_words, uint64_t * used_words, uint64_t * tasks);
 
-/* Durations (ms, HIP events on the launch stream) of the three passes of the last gtx_align_batch -- express, general,
- * HBM tables -- and the number of tasks the express pass handed on.  The first call only arms the timing. */
+/* Durations (ms, HIP events on the launch stream) of the passes of the last gtx_align_batch -- everything in front of the
+ * general pass (position-hinted + express), general, HBM tables -- and the number of tasks handed to the general pass.
+ * The first call only arms the timing. */
 int gtx_ctx_pass_times(gtx_ctx *, float * ms /* [3] */, uint32_t * queued_for_pass2);
+
+/* The same for the four launches of gtx_align_batch one by one -- position-hinted pass (one read per lane), express pass,
+ * general pass, HBM-table pass: ms[4] and the forward tasks each of them completed, tasks[4] (reverse-orientation tasks all
+ * go to the general pass and are counted there). */
+int gtx_ctx_kernel_times(gtx_ctx *, float * ms /* [4] */, uint32_t * tasks /* [4] */);
 
 /* forget every GTX_ST_EXTERNAL record (call between regions, when d_records is recycled) */
 int gtx_ctx_big_records_rewind(gtx_ctx *, void * stream);

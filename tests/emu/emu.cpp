@@ -83,6 +83,7 @@ struct Emu
   uint64_t arena_used = 0;
   uint64_t second_pass_tasks = 0; // tasks that reached the last pass (HBM tables)
   uint64_t general_tasks = 0;     // tasks pass 1 handed to pass 2
+  uint64_t hinted_done = 0;       // forward tasks the position-hinted pass finished
 };
 
 } // namespace
@@ -112,8 +113,7 @@ extern "C"
     using namespace gtx;
     Emu & e = *static_cast<Emu *>(p);
     GraphView const g = e.graph.view();
-    IndexView ix{e.index.slots.data(), e.index.dev_labels.data(), e.index.log2_cap, static_cast<uint32_t>(e.params.max_index_labels),
-                 e.index.hslots.data(), e.index.hlist.data(), e.index.h_log2_cap, HALF_BUCKET_CAP};
+    IndexView ix = e.index.view(static_cast<uint32_t>(e.params.max_index_labels), HALF_BUCKET_CAP);
     if (char const * cap = std::getenv("GTX_HALF_BUCKET_CAP"))
       ix.half_bucket_cap = static_cast<uint32_t>(std::atol(cap));
     auto ws = std::make_unique<AlignWorkspace>();
@@ -189,6 +189,55 @@ extern "C"
       rec[0] = len > AlignCfg::MAX_READ ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
       rec[1] = len << 16;
     };
+    char const * eh = std::getenv("GTX_HINT"); // 0: no position-hinted pass, d(ecline): the pass declines every task
+    if (four && !(eh && eh[0] == '0'))
+    {
+      // pass 0, one read per lane from the position hint (gtx_align_hinted_kernel), then pass 1 over its queue
+      // (gtx_align_express4q_kernel), as gtx_align_batch launches them
+      std::vector<uint32_t> queue1;
+      e.hinted_done = 0;
+      for (uint32_t read = 0; read < n_reads; ++read)
+      {
+        gtx_read_meta const m = meta[read];
+        uint32_t const len = m.l_qseq;
+        bool const outside = len < 2 * K - 1 || len > AlignCfg::MAX_READ;
+        bool const rev = !outside && needs_reverse(m, force_both);
+        if (!rev)
+          empty_record(read * 2 + 1, len);
+        if (outside)
+          empty_record(read * 2, len);
+        else if (force != 0 || (eh && eh[0] == 'd') ||
+                 !hinted_one(g, ix, seq + static_cast<uint64_t>(read) * seq_stride, seq_stride, m, records + static_cast<uint64_t>(read) * 2 * rec_words, rec_words))
+          queue1.push_back(read);
+        else
+          ++e.hinted_done;
+      }
+      for (uint32_t read = 0; read < n_reads; ++read) // (the reverse tasks pass 0 queued for pass 2)
+      {
+        uint32_t const len = meta[read].l_qseq;
+        if (len >= 2 * K - 1 && len <= AlignCfg::MAX_READ && needs_reverse(meta[read], force_both))
+          general(read * 2 + 1);
+      }
+      for (uint32_t first = 0; first < queue1.size(); first += 4)
+      {
+        uint32_t const n_valid = queue1.size() - first < 4 ? static_cast<uint32_t>(queue1.size() - first) : 4;
+        uint32_t mask;
+        if (wide)
+        {
+          std::memset(static_cast<void *>(e4_wide_ws.get()), fill, sizeof(Express4Workspace<Express4Wide>));
+          mask = express4<WaveEmu, Express4Wide>(g, ix, *e4_wide_ws, seq, seq_stride, meta, 0, n_valid, records, rec_words, force != 0, queue1.data() + first);
+        }
+        else
+        {
+          std::memset(static_cast<void *>(e4_ws.get()), fill, sizeof(Express4Workspace<Express4Lean>));
+          mask = express4<WaveEmu, Express4Lean>(g, ix, *e4_ws, seq, seq_stride, meta, 0, n_valid, records, rec_words, force != 0, queue1.data() + first);
+        }
+        for (uint32_t k = 0; k < n_valid; ++k)
+          if ((mask >> k) & 1u)
+            general(queue1[first + k] * 2);
+      }
+      return 0;
+    }
     if (four)
     {
       // pass 1, four reads per wavefront (gtx_align_express4_kernel)
@@ -260,6 +309,8 @@ extern "C"
         g_notes[i] = 0;
     }
   }
+
+  uint64_t emu_hinted_done(void * p) { return static_cast<Emu *>(p)->hinted_done; }
 
   uint64_t emu_general_tasks(void * p) { return static_cast<Emu *>(p)->general_tasks; }
 

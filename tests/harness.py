@@ -73,6 +73,11 @@ class EmuBackend:
     def rewind_big_records(self):
         self.L.emu_big_records_rewind(C.c_void_p(self.h))
 
+    def hinted_done(self):
+        """forward tasks the position-hinted pass finished in the last align call"""
+        self.L.emu_hinted_done.restype = C.c_uint64
+        return int(self.L.emu_hinted_done(C.c_void_p(self.h)))
+
     def big_records(self):
         ptr, cap = C.POINTER(C.c_uint32)(), C.c_uint64()
         self.L.emu_big_records(C.c_void_p(self.h), C.byref(ptr), C.byref(cap))
@@ -106,6 +111,7 @@ class GpuBackend:
         self.torch = torch
         assert torch.cuda.is_available(), "GpuBackend needs a GPU"
         self.ctx = gtx.Context(graph, device=0, **params)
+        self.ctx.pass_times()  # arms the per-launch timing (hinted_done reads the task counts that come with it)
 
     def _dev(self, a):
         return self.torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to("cuda:0")
@@ -125,6 +131,10 @@ class GpuBackend:
 
     def big_records(self):
         return self.ctx.big_records()
+
+    def hinted_done(self):
+        """forward tasks the position-hinted pass finished in the last align call (needs armed timing)"""
+        return self.ctx.kernel_times()[0][2]
 
     def rewind_big_records(self):
         self.ctx.rewind_big_records()
@@ -157,10 +167,12 @@ class GpuBackend:
                 d_calls.cpu().numpy().view(gtx.SAMPLE_CALL)[:n_samples * self.ctx.n_hap])
 
 
-def read_meta(lengths, flags=None, tid=None, mtid=None, isize=None):
+def read_meta(lengths, flags=None, tid=None, mtid=None, isize=None, pos=None):
+    """pos: the position hint of every read (0-based contig position of read base 0), None = unknown (-1)"""
     n = len(lengths)
     m = np.zeros(n, gtx.READ_META)
     m["l_qseq"] = lengths
+    m["pos"] = -1 if pos is None else pos
     if flags is not None:
         m["flag"] = flags
     if tid is not None:

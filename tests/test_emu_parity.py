@@ -14,12 +14,27 @@ def _built():
     gtx.build()
 
 
-def check_align(backend, oracle, reads, flags=None, tid=None, mtid=None, isize=None, allow_overflow=False):
+def check_align(backend, oracle, reads, flags=None, tid=None, mtid=None, isize=None, allow_overflow=False, pos=None):
     """kernel records == oracle GenotypePaths for every read; reads whose status word reports a table overflow are
-    only tolerated where the test says so (low-complexity contigs) and are never compared as if they were results"""
+    only tolerated where the test says so (low-complexity contigs) and are never compared as if they were results.
+    pos: position hints (gtx_read_meta::pos).  The records must not depend on them: the batch is also aligned without
+    hints, with every hint off by one base and with the hints of other reads, and all four results must be the same words."""
     seq, lens = harness.pack_ragged(reads)
-    meta = harness.read_meta(lens, flags, tid, mtid, isize)
+    meta = harness.read_meta(lens, flags, tid, mtid, isize, pos)
+    if pos is not None:
+        pos = np.asarray(pos, np.int64)
+        variants = [None, pos + 1, pos - 31, np.roll(pos, 1)]
+        words = []
+        for v in variants:
+            words.append(backend.align(seq, harness.read_meta(lens, flags, tid, mtid, isize, v)).copy())
+            if v is None:
+                assert backend.hinted_done() == 0, "a read without a hint was finished by the position-hinted pass"
     rec = backend.align(seq, meta)
+    check_align.hinted_done = backend.hinted_done()
+    if pos is not None:
+        for v, w in zip(variants, words):
+            diff = np.nonzero((w != rec).reshape(len(reads), -1).any(1))[0]
+            assert len(diff) == 0, "records depend on the position hint (reads %s, hint variant %r)" % (diff[:5], None if v is None else "shifted")
     big, _ = backend.big_records()
     got = gtx.parse_records(rec, len(reads), harness.REC_WORDS, backend.ctx.hap_order, big)
     want = oracle.align(reads, flags=flags, tid=tid, mtid=mtid, isize=isize)
@@ -49,7 +64,13 @@ def test_align_synthetic(kind):
     ref, recs, codes, pos = scenarios.synthetic_case(kind, n_ref=100000, n_reads=6000, region_begin=777000)
     o = Oracle(ref, recs, region_begin=777000)
     b = harness.EmuBackend(gtx.graph_from_records(ref, recs, region_begin=777000))
-    check_align(b, o, list(codes))
+    check_align(b, o, list(codes), pos=pos)
+    # the position-hinted pass has to carry its share of the reads (else the hints were not understood)
+    share = check_align.hinted_done / float(len(codes))
+    assert share >= {"snp1k": 0.70, "snp100": 0.10, "snp25": 0.0, "indel": 0.05}[kind], share
+    print("position-hinted share", kind, share)
+    test_align_synthetic.share = getattr(test_align_synthetic, "share", {})
+    test_align_synthetic.share[kind] = share
 
 
 def iupac_case(Backend, n_reads):

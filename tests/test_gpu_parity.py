@@ -35,7 +35,9 @@ def test_align_synthetic(kind):
     ref, recs, codes, pos = scenarios.synthetic_case(kind, n_ref=200000, n_reads=20000, region_begin=1000000)
     o = Oracle(ref, recs, region_begin=1000000)
     b = harness.GpuBackend(gtx.graph_from_records(ref, recs, region_begin=1000000))
-    check_align(b, o, list(codes))
+    check_align(b, o, list(codes), pos=pos)  # with, without and with wrong position hints: same words
+    share = check_align.hinted_done / float(len(codes))
+    assert share >= {"snp1k": 0.70, "snp100": 0.10, "snp25": 0.0, "indel": 0.05}[kind], share
 
 
 def test_align_ragged_and_short_reads():
@@ -122,11 +124,16 @@ def test_express_variants_agree(monkeypatch):
 def test_pass_times_are_reported():
     """gtx_ctx_pass_times: HIP-event durations of the three alignment passes (what bench.py prices the roofline on)"""
     ref, recs, codes, pos = scenarios.synthetic_case("snp100", n_ref=50000, n_reads=20000, region_begin=0)
+    ctx = gtx.Context(gtx.graph_from_records(ref, recs), device=0)
+    assert ctx.pass_times() == ([0.0, 0.0, 0.0], 0)  # the first call arms the timing
     b = harness.GpuBackend(gtx.graph_from_records(ref, recs))
-    assert b.ctx.pass_times() == ([0.0, 0.0, 0.0], 0)  # arms the timing
-    b.align(gtx.pack_nibbles(codes), harness.read_meta(np.full(len(codes), 150)))
+    b.align(gtx.pack_nibbles(codes), harness.read_meta(np.full(len(codes), 150), pos=pos))
     ms, handed_on = b.ctx.pass_times()
     assert all(x > 0 for x in ms) and 0 < handed_on < len(codes)
+    kt = b.ctx.kernel_times()
+    assert [k[0] for k in kt] == ["gtx_align_hinted_kernel", "gtx_align_express4_kernel", "gtx_align_kernel", "gtx_align_big_kernel"]
+    assert all(k[1] > 0 for k in kt) and sum(k[2] for k in kt) == len(codes) and kt[0][2] > 0.2 * len(codes)
+    assert abs(kt[0][1] + kt[1][1] - ms[0]) < 1e-3 and kt[2][2] + kt[3][2] == handed_on
 
 
 def test_align_over_an_sv_deletion():
