@@ -163,3 +163,59 @@ def test_cfg4_full_size_properties():
     assert (depth.sum(1) > 0).all() and (c["gt_second"] > 0).any(1).all()
     for buf in (joint, single):
         gtx.check(L.gtx_scores_free(ctx.h, C.byref(buf)))
+
+
+def test_two_host_threads_share_one_context():
+    """re-entrancy of the boundary (the reference calls align_read / update_haplotype_scores_geno from `jobs` worker
+    threads against one index + graph, src/typer/caller.cpp:399-436): two host threads, each with its own stream and
+    buffers, call gtx_align_batch + gtx_score_batch on ONE context at the same time, several rounds; every result must
+    equal what one thread alone gets"""
+    import threading
+    import torch
+    L = gtx.lib()
+    b = harness.GpuBackend(gtx.graph_from_records(*scenarios.synthetic_case("snp100", n_ref=200000, n_reads=10, region_begin=0)[:2]))
+    jobs = []
+    for t in range(2):
+        ref, recs, codes, pos = scenarios.synthetic_case("snp100", n_ref=200000, n_reads=150000, region_begin=0, seed=0)
+        codes, pos = codes[t::2], pos[t::2]  # (same graph, different reads per thread)
+        order = np.argsort(pos, kind="stable")
+        rec = scenarios.stream_records(len(codes), pos[order], sample=np.arange(len(codes)) % 3)
+        st = gtx.Stream(b.ctx.params, 1)
+        a_seq, a_meta, items = st.push(rec, gtx.pack_nibbles(codes[order]))
+        records = b.align(a_seq, a_meta).copy()
+        want = harness.canonical_scores(b.ctx, b.score(items, records, 3))
+        jobs.append((a_seq, a_meta, items, records, want))
+    results, errors = [[] for _ in jobs], []
+
+    def work(t):
+        try:
+            a_seq, a_meta, items, _, _ = jobs[t]
+            stream = torch.cuda.Stream(device="cuda:0")
+            sp = C.c_void_p(stream.cuda_stream)
+            d_seq, d_meta, d_items = b._dev(a_seq), b._dev(a_meta), b._dev(items)
+            d_rec = torch.zeros(len(a_meta) * 2 * REC_WORDS, dtype=torch.int32, device="cuda:0")
+            torch.cuda.synchronize()
+            for _ in range(6):
+                buf, _ = _packed(b.ctx, 3)
+                d_rec.zero_()
+                torch.cuda.current_stream().synchronize()
+                gtx.check(L.gtx_align_batch(b.ctx.h, d_seq.data_ptr(), a_seq.shape[1], d_meta.data_ptr(), len(a_meta), d_rec.data_ptr(), REC_WORDS, sp))
+                gtx.check(L.gtx_score_batch(b.ctx.h, d_items.data_ptr(), len(items), d_rec.data_ptr(), REC_WORDS, C.byref(buf), sp))
+                stream.synchronize()
+                results[t].append((d_rec.cpu().numpy().view(np.uint32).copy(), harness.canonical_scores(b.ctx, _download(b.ctx, buf, 3))))
+                gtx.check(L.gtx_scores_free(b.ctx.h, C.byref(buf)))
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+
+    team = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in team:
+        th.start()
+    for th in team:
+        th.join()
+    assert not errors, errors
+    for t, (_, _, _, records, want) in enumerate(jobs):
+        assert len(results[t]) == 6
+        for rec, scores in results[t]:
+            assert np.array_equal(rec, records), "thread %d: alignment records differ from the single-thread run" % t
+            assert np.array_equal(scores, want), "thread %d: accumulators differ from the single-thread run" % t
+    assert b.ctx.error_count() == 0
