@@ -406,11 +406,46 @@ __global__ __launch_bounds__(256) void gtx_align_hinted_kernel(GraphView g, Inde
                                                                uint32_t * __restrict__ queue1, uint32_t * queue1_count,
                                                                uint32_t * __restrict__ queue2, uint32_t * queue2_count, uint32_t decline_all)
 {
-  uint32_t const read = blockIdx.x * blockDim.x + threadIdx.x;
+  // The 64 reads of a wavefront lie side by side in memory: their bases (80 B each) and their meta records (20 B each)
+  // are fetched with coalesced loads -- 1 KB and 256 B per instruction instead of 64 scattered lines -- and handed to
+  // the lanes through LDS (row pitch 80 B = 20 banks: 16-byte reads of 16 neighbouring lanes hit all 64 banks once).
+  constexpr uint32_t ROW_BYTES = HINT_MAX_READ / 2, ROW_VEC = ROW_BYTES / 16, META_WORDS = sizeof(gtx_read_meta) / 4;
+  __shared__ uint4_t s_seq[4][64 * ROW_VEC];
+  __shared__ uint32_t s_meta[4][64 * META_WORDS];
+  static_assert(sizeof(gtx_read_meta) % 4 == 0, "meta records are staged word-wise");
+  uint32_t const lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t const wave_first = blockIdx.x * blockDim.x + wave * 64u;
+  uint32_t const read = wave_first + lane;
+  bool const full = wave_first + 64u <= n_reads; // (uniform per wavefront)
+  bool const staged = full && seq_stride == ROW_BYTES && (reinterpret_cast<uintptr_t>(seq) & 15u) == 0;
+  if (full)
+  {
+    uint32_t const * src = reinterpret_cast<uint32_t const *>(meta + wave_first);
+#pragma unroll
+    for (uint32_t it = 0; it < META_WORDS; ++it)
+      s_meta[wave][it * 64 + lane] = src[it * 64 + lane];
+  }
+  if (staged)
+  {
+    uint4_t const * src = reinterpret_cast<uint4_t const *>(seq + static_cast<uint64_t>(wave_first) * ROW_BYTES);
+#pragma unroll
+    for (uint32_t it = 0; it < ROW_VEC; ++it)
+      s_seq[wave][it * 64 + lane] = src[it * 64 + lane];
+  }
+  WaveHip::lds_sync();
   bool fwd = false, rev = false;
   if (read < n_reads)
   {
-    gtx_read_meta const m = meta[read];
+    gtx_read_meta m;
+    if (full)
+    {
+      uint32_t * mw = reinterpret_cast<uint32_t *>(&m);
+#pragma unroll
+      for (uint32_t k = 0; k < META_WORDS; ++k)
+        mw[k] = s_meta[wave][lane * META_WORDS + k];
+    }
+    else
+      m = meta[read];
     uint32_t const len = m.l_qseq;
     uint32_t * rec = records + static_cast<uint64_t>(read) * 2 * rec_words;
     bool const outside = len < 2 * K - 1 || len > AlignCfg::MAX_READ; // align_read (alignment.cpp:331-363): stay unaligned
@@ -425,10 +460,19 @@ __global__ __launch_bounds__(256) void gtx_align_hinted_kernel(GraphView g, Inde
       rec[0] = len > AlignCfg::MAX_READ ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
       rec[1] = len << 16;
     }
+    else if (decline_all != 0)
+      fwd = true;
+    else if (staged)
+    {
+      uint32_t const * row = reinterpret_cast<uint32_t const *>(&s_seq[wave][lane * ROW_VEC]);
+      fwd = !hinted_one(g, ix, row, reinterpret_cast<uint8_t const *>(row), seq_stride, m, rec, rec_words);
+    }
     else
-      fwd = decline_all != 0 || !hinted_one(g, ix, seq + static_cast<uint64_t>(read) * seq_stride, seq_stride, m, rec, rec_words);
+    {
+      uint8_t const * seq4 = seq + static_cast<uint64_t>(read) * seq_stride;
+      fwd = !hinted_one(g, ix, reinterpret_cast<uint32_t const *>(seq4), seq4, seq_stride, m, rec, rec_words);
+    }
   }
-  uint32_t const lane = threadIdx.x & 63u;
   unsigned long long const F = __ballot(fwd), R = __ballot(rev);
   if (F != 0)
   {

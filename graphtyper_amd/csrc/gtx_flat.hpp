@@ -19,6 +19,11 @@ constexpr uint32_t SPECIAL_START = GTX_SPECIAL_START;
 constexpr uint32_t POS_BUCKET_SHIFT = 6; // position -> ref node table has one entry per 64 bp
 constexpr uint32_t MAX_ALLELES = 64;     // allele sets are one 64-bit mask per (path, site)
 
+struct alignas(8) uint2_t // 8-byte move
+{
+  uint32_t x, y;
+};
+
 // A k-mer occurrence as stored on the device: KmerLabel (kmer_label.hpp:13-41) with variant_id already resolved to
 // (site, allele) -- what Path's constructor derives through Graph::get_variant_order/get_variant_num (path.cpp:13-36).
 struct alignas(16) DevLabel
@@ -108,36 +113,48 @@ struct IndexView
   // that the global lookups of the reference would return exactly the one label of that place.
   // ref4: the linear reference of the region (= the graph's path over every site's allele 0) as BAM nibble codes,
   //   8 bases per word, base 8w+j in bits 28-4j; entry 0 is contig position hint_first (0-based); 4 padding words.
-  // pos_flags[i], about the 32-mer that starts at hint_first + i (K_i) and about the position itself:
-  //   HINT_EXACT_OK   a read k-mer equal to K_i has exactly the label (i, i+31[, site, allele 0]) and every indexed
-  //                   Hamming-1 neighbour of K_i is that same interval on the same site (express4's seeding rule);
-  //   HINT_SINGLE_OK  K_i has that one label (and it may be used: not on a variant of an SV graph);
-  //   HINT_L1 / R1    K_i is the only indexed key with its 16 first / last bases;
-  //   bits 4..11      min(255, bases from this position to the end of its reference node), 0 = not in a reference node;
-  //   bits 12..31     the site K_i's label lies on (HINT_NO_SITE: none).
-  // filt[side]: one bit per hash of every indexed key's 16 first (side 0) / last (side 1) bases in nibble form: a clear
-  //   bit proves that no indexed key has that half.
+  // pos_flags[i] (two words), about the 32-mer that starts at hint_first + i (K_i) and about the position itself:
+  //  x  HINT_SINGLE_OK  K_i is indexed with exactly the label (i, i+31[, site, allele 0]) (and it may be used: not on a
+  //                     variant of an SV graph);
+  //     HINT_EXACT_OK   ... and every indexed Hamming-1 neighbour of K_i is that same interval on the same site
+  //                     (express4's seeding rule for an exact hit); HINT_PAR: there are such neighbours (the k-mer
+  //                     starts a parallel +1-mismatch chain);
+  //     HINT_L1 / R1    K_i is the only indexed key with its 16 first / last bases;
+  //     HINT_ALT_OK     K_i lies over exactly one site, a SNP (every allele one base, at most 4), and the key of every
+  //                     other allele -- K_i with that base replaced -- passes the HINT_EXACT_OK test with its own label
+  //                     (i, i+31, site, allele); bits 8..15: the allele number of base A, C, G, T there (2 bits each,
+  //                     0 = not an alternative allele); y bits 16..20: the offset of that base in the k-mer;
+  //     bits 12.. of x  see HINT_SITE_SHIFT: the site K_i's label lies on (HINT_NO_SITE: none);
+  //  y  bits 0..7       min(255, bases from this position to the end of its reference node), 0 = not in a reference node;
+  //     bits 8..15      min(255, bases of that node in front of the position).
+  // filt[side]: blocked Bloom filter over every indexed key's 16 first (side 0) / last (side 1) bases in nibble form (two
+  //   bits of one word per half): a clear bit proves that no indexed key has that half.
   const uint32_t * ref4;
-  const uint32_t * pos_flags;
+  const uint2_t * pos_flags;
   const uint32_t * filt[2];
-  uint32_t hint_first, n_hint, filt_log2, pad_hint;
+  uint32_t hint_first, n_hint, filt_log2 /* log2 of the number of words */, pad_hint;
 };
 
-constexpr uint32_t HINT_EXACT_OK = 1u, HINT_SINGLE_OK = 2u, HINT_L1 = 4u, HINT_R1 = 8u, HINT_ROOM_SHIFT = 4u, HINT_SITE_SHIFT = 12u;
-constexpr uint32_t HINT_NO_SITE = 0xFFFFFu;
+constexpr uint32_t HINT_EXACT_OK = 1u, HINT_SINGLE_OK = 2u, HINT_L1 = 4u, HINT_R1 = 8u, HINT_PAR = 16u, HINT_ALT_OK = 32u;
+constexpr uint32_t HINT_ALTIDX_SHIFT = 8u, HINT_SITE_SHIFT = 12u + 4u; // x: flags 0..7, allele numbers 8..15, site 16..31
+constexpr uint32_t HINT_NO_SITE = 0xFFFFu;
+constexpr uint32_t HINT_BACK_SHIFT = 8u, HINT_SNPOFF_SHIFT = 16u; // y
 // limits of express4's lean seeding rule that HINT_EXACT_OK restates on the host (static_asserts in express4.inl)
 constexpr uint32_t HINT_HE_CAP = 4, HINT_NB_MAX = 3;
 
-// hash of a 16-base half in nibble form (w0 = bases 0..7, w1 = bases 8..15; base j in bits 28-4j) -> filter bit
+// hash of a 16-base half in nibble form (w0 = bases 0..7, w1 = bases 8..15; base j in bits 28-4j) -> (word, two-bit mask)
+// of the blocked Bloom filter
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline uint32_t hint_filter_bit(uint32_t w0, uint32_t w1, uint32_t log2_bits)
+inline void hint_filter_slot(uint32_t w0, uint32_t w1, uint32_t log2_words, uint32_t & word, uint32_t & mask)
 {
   uint64_t h = ((static_cast<uint64_t>(w0) << 32) | w1) * 0x9E3779B97F4A7C15ull;
   h ^= h >> 29;
   h *= 0xBF58476D1CE4E5B9ull;
-  return static_cast<uint32_t>(h >> (64 - log2_bits));
+  h ^= h >> 32;
+  word = static_cast<uint32_t>(h >> (64 - log2_words));
+  mask = (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
 }
 
 struct HostGraph
@@ -177,7 +194,8 @@ struct HostIndex
   std::vector<HalfEntry> hlist;
   uint32_t h_log2_cap = 0;
   // position-hinted pass (IndexView::ref4 ...)
-  std::vector<uint32_t> ref4, pos_flags, filt[2];
+  std::vector<uint32_t> ref4, filt[2];
+  std::vector<uint2_t> pos_flags;
   uint32_t hint_first = 0, n_hint = 0, filt_log2 = 0;
 
   IndexView view(uint32_t max_index_labels, uint32_t half_bucket_cap) const; // over the host copies

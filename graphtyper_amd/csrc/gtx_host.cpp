@@ -548,12 +548,12 @@ static void build_hints(HostGraph const & g, HostIndex & out)
   out.filt[0].clear();
   out.filt[1].clear();
   out.n_hint = 0;
-  out.filt_log2 = 5;
+  out.filt_log2 = 0;
   out.hint_first = g.ref_order.empty() ? 0 : g.ref_order[0] - 1; // order = 1-based contig position
   if (R == 0 || R - 1 >= HINT_NO_SITE)
   {
     out.ref4.assign(8, 0);
-    out.pos_flags.assign(1, 0);
+    out.pos_flags.assign(1, uint2_t{0, 0});
     out.filt[0].assign(1, 0);
     out.filt[1].assign(1, 0);
     return;
@@ -561,8 +561,8 @@ static void build_hints(HostGraph const & g, HostIndex & out)
   // linear reference = reference nodes and allele 0 of every site, in order
   uint32_t const first = g.ref_order[0], last = g.ref_order[R - 1] + g.ref_len[R - 1];
   uint32_t const n = last - first;
-  std::vector<uint8_t> base(n, 15);  // nibble codes (A=1 C=2 G=4 T=8, anything else 15)
-  std::vector<uint8_t> room(n, 0);   // bases to the end of the reference node (capped), 0 outside reference nodes
+  std::vector<uint8_t> base(n, 15);       // nibble codes (A=1 C=2 G=4 T=8, anything else 15)
+  std::vector<uint8_t> room(n, 0), back(n, 0); // bases to the end / from the start of the reference node (capped), 0 outside
   auto nib = [](char c) -> uint8_t { return c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 4 : c == 'T' ? 8 : 15; };
   for (uint32_t r = 0; r < R; ++r)
   {
@@ -572,6 +572,7 @@ static void build_hints(HostGraph const & g, HostIndex & out)
       base[at + d] = nib(g.dna[g.ref_dna[r] + d]);
       uint32_t const left = g.ref_len[r] - d;
       room[at + d] = static_cast<uint8_t>(left < 255 ? left : 255);
+      back[at + d] = static_cast<uint8_t>(d < 255 ? d : 255);
     }
     if (r + 1 < R && g.ref_nvar[r] != 0)
     {
@@ -668,13 +669,13 @@ static void build_hints(HostGraph const & g, HostIndex & out)
       k = e;
     }
   }
-  // filters over the halves of every indexed key (nibble form, as the kernel hashes them)
-  uint32_t fl = 10;
-  while ((1ull << fl) < 16ull * (nk + 1) && fl < 31)
+  // filters over the halves of every indexed key (nibble form, as the kernel hashes them): 32 bits per key and side
+  uint32_t fl = 5;
+  while ((1ull << fl) < nk + 1 && fl < 28)
     ++fl;
   out.filt_log2 = fl;
-  out.filt[0].assign((1ull << fl) / 32, 0);
-  out.filt[1].assign((1ull << fl) / 32, 0);
+  out.filt[0].assign(1ull << fl, 0);
+  out.filt[1].assign(1ull << fl, 0);
   auto nibble_words = [](uint32_t half, uint32_t & w0, uint32_t & w1) // 16 bases, 2 bits each, first base in the top bits
   {
     w0 = w1 = 0;
@@ -687,13 +688,30 @@ static void build_hints(HostGraph const & g, HostIndex & out)
   for (std::size_t k = 0; k < nk; ++k)
     for (uint32_t side = 0; side < 2; ++side)
     {
-      uint32_t w0, w1;
+      uint32_t w0, w1, word, mask;
       nibble_words(static_cast<uint32_t>(side == 0 ? out.keys[k] >> 32 : out.keys[k]), w0, w1);
-      uint32_t const bit = hint_filter_bit(w0, w1, fl);
-      out.filt[side][bit >> 5] |= 1u << (bit & 31u);
+      hint_filter_slot(w0, w1, fl, word, mask);
+      out.filt[side][word] |= mask;
     }
+  // the verdict express4's seeding rule gives a read k-mer that equals indexed key k: its one label has to be
+  // (order, order + 31, site, allele) and its indexed neighbours that same interval on that site
+  auto exact_verdict = [&](std::size_t k, uint32_t order, uint32_t want_site, uint32_t want_allele, bool & par)
+  {
+    DevLabel l{};
+    if (!one_label_of(k, l) || l.start != order || l.end != order + K - 1 || l.site != want_site || (l.site != INVALID && l.allele != want_allele))
+      return false;
+    par = nb[k] != 0;
+    return lcount[k] <= HINT_HE_CAP && rcount[k] <= HINT_HE_CAP && (nb[k] == 0 || (nb_same[k] && nb[k] <= HINT_NB_MAX));
+  };
+  auto find_key = [&](uint64_t key, std::size_t & k)
+  {
+    auto it = std::lower_bound(out.keys.begin(), out.keys.end(), key);
+    k = static_cast<std::size_t>(it - out.keys.begin());
+    return it != out.keys.end() && *it == key;
+  };
   // per position
-  out.pos_flags.assign(n, HINT_NO_SITE << HINT_SITE_SHIFT);
+  uint2_t const nothing{HINT_NO_SITE << HINT_SITE_SHIFT, 0};
+  out.pos_flags.assign(n, nothing);
   parallel_slices(n, host_threads(), [&](unsigned, std::size_t b, std::size_t e) {
     uint64_t roll = 0;
     uint32_t valid = 0;
@@ -714,36 +732,60 @@ static void build_hints(HostGraph const & g, HostIndex & out)
       std::size_t const p = i + 1 - K;
       if (p < b || p >= e)
         continue;
-      uint32_t f = static_cast<uint32_t>(room[p]) << HINT_ROOM_SHIFT;
+      uint32_t x = 0, y = static_cast<uint32_t>(room[p]) | (static_cast<uint32_t>(back[p]) << HINT_BACK_SHIFT);
       uint32_t site = HINT_NO_SITE;
-      if (valid >= K)
+      std::size_t k = 0;
+      if (valid >= K && find_key(roll, k))
       {
-        auto it = std::lower_bound(out.keys.begin(), out.keys.end(), roll);
-        if (it != out.keys.end() && *it == roll)
+        DevLabel l{};
+        uint32_t const order = first + static_cast<uint32_t>(p);
+        if (one_label_of(k, l) && l.start == order && l.end == order + K - 1 && (l.site == INVALID || l.allele == 0) &&
+            !(l.site != INVALID && g.is_sv_graph))
         {
-          std::size_t const k = static_cast<std::size_t>(it - out.keys.begin());
-          DevLabel l{};
-          uint32_t const order = first + static_cast<uint32_t>(p);
-          if (one_label_of(k, l) && l.start == order && l.end == order + K - 1 && (l.site == INVALID || l.allele == 0) &&
-              !(l.site != INVALID && g.is_sv_graph))
+          site = l.site == INVALID ? HINT_NO_SITE : l.site;
+          x |= HINT_SINGLE_OK;
+          if (lcount[k] == 1)
+            x |= HINT_L1;
+          if (rcount[k] == 1)
+            x |= HINT_R1;
+          bool par = false;
+          if (exact_verdict(k, order, l.site, 0, par))
+            x |= HINT_EXACT_OK | (par ? HINT_PAR : 0u);
+          // the other alleles of a SNP under the k-mer
+          if (l.site != INVALID)
           {
-            site = l.site == INVALID ? HINT_NO_SITE : l.site;
-            f |= HINT_SINGLE_OK;
-            if (lcount[k] == 1)
-              f |= HINT_L1;
-            if (rcount[k] == 1)
-              f |= HINT_R1;
-            bool const few = lcount[k] <= HINT_HE_CAP && rcount[k] <= HINT_HE_CAP;
-            if (few && (nb[k] == 0 || (nb_same[k] && nb[k] <= HINT_NB_MAX)))
-              f |= HINT_EXACT_OK;
+            uint32_t const fv = g.ref_first_var[l.site], nv = g.ref_nvar[l.site];
+            bool snp = nv >= 2 && nv <= 4 && g.var_order[fv] >= order && g.var_order[fv] <= order + K - 1;
+            for (uint32_t a = 0; a < nv && snp; ++a)
+              snp = g.var_len[fv + a] == 1 && nib(g.dna[g.var_dna[fv + a]]) != 15;
+            if (snp)
+            {
+              uint32_t const off = g.var_order[fv] - order; // base of the k-mer that lies on the site
+              uint32_t idx_of = 0;
+              for (uint32_t a = 1; a < nv && snp; ++a)
+              {
+                uint8_t const cb = nib(g.dna[g.var_dna[fv + a]]);
+                uint32_t const two = cb == 1 ? 0u : cb == 2 ? 1u : cb == 4 ? 2u : 3u;
+                uint64_t const key = (roll & ~(3ull << (2 * (K - 1 - off)))) | (static_cast<uint64_t>(two) << (2 * (K - 1 - off)));
+                std::size_t ka = 0;
+                bool pa = false;
+                snp = key != roll && ((idx_of >> (2 * two)) & 3u) == 0 && find_key(key, ka) && exact_verdict(ka, order, l.site, a, pa);
+                idx_of |= a << (2 * two);
+              }
+              if (snp)
+              {
+                x |= HINT_ALT_OK | (idx_of << HINT_ALTIDX_SHIFT);
+                y |= off << HINT_SNPOFF_SHIFT;
+              }
+            }
           }
         }
       }
-      out.pos_flags[p] = f | (site << HINT_SITE_SHIFT);
+      out.pos_flags[p] = uint2_t{x | (site << HINT_SITE_SHIFT), y};
     }
   });
   for (uint32_t p = n >= K - 1 ? n - (K - 1) : 0; p < n; ++p) // the last 31 positions start no 32-mer
-    out.pos_flags[p] = (static_cast<uint32_t>(room[p]) << HINT_ROOM_SHIFT) | (HINT_NO_SITE << HINT_SITE_SHIFT);
+    out.pos_flags[p] = uint2_t{HINT_NO_SITE << HINT_SITE_SHIFT, static_cast<uint32_t>(room[p]) | (static_cast<uint32_t>(back[p]) << HINT_BACK_SHIFT)};
 }
 
 void build_index(HostGraph const & g, HostIndex & out)

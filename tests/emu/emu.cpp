@@ -21,6 +21,13 @@ namespace
 // arrays of 64, the wave-uniform parts of the kernel source run once.
 uint64_t g_notes[16]; // why a task left the express pass (W::note), test diagnostics only
 
+} // namespace
+namespace gtx
+{
+void hint_note(uint32_t k) { ++g_notes[k & 15u]; }
+} // namespace gtx
+namespace
+{
 struct WaveEmu
 {
   static void note(uint32_t k) { ++g_notes[k & 15u]; }
@@ -207,7 +214,8 @@ extern "C"
         if (outside)
           empty_record(read * 2, len);
         else if (force != 0 || (eh && eh[0] == 'd') ||
-                 !hinted_one(g, ix, seq + static_cast<uint64_t>(read) * seq_stride, seq_stride, m, records + static_cast<uint64_t>(read) * 2 * rec_words, rec_words))
+                 !hinted_one(g, ix, reinterpret_cast<uint32_t const *>(seq + static_cast<uint64_t>(read) * seq_stride),
+                             seq + static_cast<uint64_t>(read) * seq_stride, seq_stride, m, records + static_cast<uint64_t>(read) * 2 * rec_words, rec_words))
           queue1.push_back(read);
         else
           ++e.hinted_done;
@@ -326,6 +334,15 @@ extern "C"
     for (uint64_t cell = 0; cell < cells; ++cell)
       call_cell(g, cell, acc->d_log_score, acc->d_gt_cov, acc->d_hap_u32, phred, calls);
     return 0;
+  }
+
+  // the position-hint tables of the index (IndexView::pos_flags): n = positions; flags may be NULL
+  uint32_t emu_hint_flags(void * p, uint32_t * flags, uint32_t cap)
+  {
+    Emu & e = *static_cast<Emu *>(p);
+    for (uint32_t i = 0; flags && i < e.index.n_hint && i < cap; ++i)
+      flags[i] = e.index.pos_flags[i].x;
+    return e.index.n_hint;
   }
 
   int emu_workspace_bytes(int big) { return static_cast<int>(big ? sizeof(gtx::big::AlignWorkspace) : sizeof(gtx::AlignWorkspace));

@@ -25,12 +25,12 @@ from test_emu_parity import check_align, run_stream  # noqa: E402
 def align_seed(seed):
     rng = np.random.default_rng(seed)
     n = 0
-    for kind in ["snp25", "indel", "cluster", "snp100", "snp7"]:
+    for kind in ["snp1k", "snp25", "indel", "cluster", "snp100", "snp7"]:
         err = float(rng.choice([0.0, 0.005, 0.03]))
         n_rate = float(rng.choice([0.0, 0.001, 0.01]))
         read_len = int(rng.choice([100, 125, 150, 151, 187]))
         rb = int(rng.choice([0, 1000, 1000000]))
-        ref, recs, codes, _ = scenarios.synthetic_case(kind, n_ref=50000, n_reads=1500, region_begin=rb, err=err, n_rate=n_rate,
+        ref, recs, codes, pos = scenarios.synthetic_case(kind, n_ref=50000, n_reads=1500, region_begin=rb, err=err, n_rate=n_rate,
                                                        seed=seed, read_len=read_len)
         aav = kind == "cluster"
         g = gtx.graph_from_records(ref, recs, region_begin=rb, add_all_variants=aav)
@@ -42,7 +42,10 @@ def align_seed(seed):
         for mode in ["lean", "wide"]:
             os.environ["GTX_EXPRESS4"] = mode
             try:
-                check_align(harness.EmuBackend(g), o, reads, flags=flags, isize=isize)
+                # position hints: right for most reads, a few bases off or absent for the others; check_align also runs
+                # the batch without hints, with shifted hints and with other reads' hints (records must not depend on them)
+                hint = np.where(rng.random(len(pos)) < 0.9, pos, np.where(rng.random(len(pos)) < 0.5, pos + rng.integers(-3, 4, size=len(pos)), -1))
+                check_align(harness.EmuBackend(g), o, reads, flags=flags, isize=isize, pos=hint)
             except AssertionError:
                 print("FAIL", dict(seed=seed, kind=kind, mode=mode, err=err, n_rate=n_rate, read_len=read_len, region_begin=rb), flush=True)
                 raise

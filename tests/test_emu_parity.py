@@ -32,8 +32,15 @@ def check_align(backend, oracle, reads, flags=None, tid=None, mtid=None, isize=N
     rec = backend.align(seq, meta)
     check_align.hinted_done = backend.hinted_done()
     if pos is not None:
+        # (a record that went to the big-record arena keeps an arena offset in its slot, which differs from call to call:
+        # only its two header words are compared here -- the position-hinted pass never writes such records)
+        a = rec.reshape(2 * len(reads), -1)
+        external = ((a[:, 0] >> 16) & gtx.ST_EXTERNAL) != 0
         for v, w in zip(variants, words):
-            diff = np.nonzero((w != rec).reshape(len(reads), -1).any(1))[0]
+            w = w.reshape(2 * len(reads), -1)
+            differ = (w != a)
+            differ[external, 2:] = False
+            diff = np.nonzero(differ.any(1))[0] // 2
             assert len(diff) == 0, "records depend on the position hint (reads %s, hint variant %r)" % (diff[:5], None if v is None else "shifted")
     big, _ = backend.big_records()
     got = gtx.parse_records(rec, len(reads), harness.REC_WORDS, backend.ctx.hap_order, big)
