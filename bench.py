@@ -353,17 +353,21 @@ def cpu_baseline(args, ref_str, records, sample, spos):
            "sample": "first %d reads of the same workload through oracle/ (C++ restatement), 1 thread, %.1f s" % (m, one)}
     threads = args.cpu_threads or min(os.cpu_count() or 1, 256)
     if threads > 1:
+        # every hardware thread its own pseudo-sample of m/8 reads (bounded: the whole leg stays around 10-20 s)
+        per = max(m // 8, 1000)
+        packed_t = pack_reads(list(sample[:per]))
+        pos_t = pos64[:per]
         genos = [oracle.genotyper(1, 1) for _ in range(threads)]
-        team = [threading.Thread(target=lambda k=k: genos[k].push(None, pos=pos64, packed=packed)) for k in range(threads)]
+        team = [threading.Thread(target=lambda k=k: genos[k].push(None, pos=pos_t, packed=packed_t)) for k in range(threads)]
         t0 = time.perf_counter()
         for th in team:
             th.start()
         for th in team:
             th.join()
         many = time.perf_counter() - t0
-        out["all_cores"] = {"value": threads * m / many, "unit": "reads/s", "cores": threads,
-                            "sample": "%d pseudo-samples of those %d reads, one thread each over one shared graph + index, %.1f s" %
-                                      (threads, m, many)}
+        out["all_cores"] = {"value": threads * per / many, "unit": "reads/s", "cores": threads,
+                            "sample": "%d pseudo-samples of the first %d of those reads, one thread each over one shared graph + index, %.1f s" %
+                                      (threads, per, many)}
     return out
 
 
@@ -457,10 +461,9 @@ def main(argv=None):
     if os.path.exists(tf):
         try:
             tj = json.load(open(tf))
-            if tj.get("kernel", "gtx_align_express4_kernel") == roof["kernel"]:
-                traffic = tj.get("align_kernel_hbm_bytes_per_launch")
-                if traffic is not None and tj.get("reads_per_launch"):
-                    traffic = traffic * float(n) / float(tj["reads_per_launch"])  # per launch of THIS run
+            tk = tj.get("kernels", {}).get(roof["kernel"])
+            if tk and tk.get("hbm_bytes_per_launch") is not None and tj.get("reads_per_launch"):
+                traffic = tk["hbm_bytes_per_launch"] * float(n) / float(tj["reads_per_launch"])  # per launch of THIS run
         except Exception:
             traffic = None
     roof["traffic"] = traffic
@@ -496,20 +499,36 @@ def main(argv=None):
     return 0
 
 
+# Algorithmic bytes per forward task of each alignment kernel: what ITS algorithm has to move.
+# The global-lookup passes are priced as SURVEY.md 8(d) prices the reference (388 key slots probed per read-orientation).
+# The position-hinted pass proves the outcome of those probes from per-position flags and never issues them: 20 B meta +
+# 80 B bases + 84 B reference nibbles + 48 B position flags + 4 B filter word + 24 B record + 8 B reverse-orientation header.
+KERNEL_BYTES = {"gtx_align_hinted_kernel": 268, "gtx_align_express4_kernel": ALGO_BYTES_PER_READ, "gtx_align_kernel": ALGO_BYTES_PER_READ,
+                "gtx_align_big_kernel": ALGO_BYTES_PER_READ}
+
+
 def dominant_kernel(pass_ms, n_pass2, n, align_avg_ms, kern):
     """roofline object for the kernel that takes most of the step.  Durations are HIP events recorded inside
-    gtx_align_batch on the launch stream around each launch (gtx_ctx_pass_times / gtx_ctx_kernel_times)."""
+    gtx_align_batch on the launch stream around each launch (gtx_ctx_kernel_times)."""
     if kern:  # [(name, ms, units completed)]
         name, ms, units = max(kern, key=lambda k: k[1])
-        passes = {k[0]: {"ms": k[1], "tasks_completed": k[2]} for k in kern}
+        passes = {k[0]: {"ms": k[1], "tasks_completed": k[2], "algorithmic_bytes_per_task": KERNEL_BYTES[k[0]],
+                         "achieved_gbs": (KERNEL_BYTES[k[0]] * k[2] / (k[1] * 1e-3) / 1e9) if k[1] > 0 else 0.0} for k in kern}
     else:
         name, ms, units = "gtx_align_express4_kernel", (pass_ms[0] if pass_ms[0] > 0 else align_avg_ms), (n - n_pass2 if pass_ms[0] > 0 else n)
         passes = {"express": pass_ms[0], "general": pass_ms[1], "hbm_tables": pass_ms[2], "tasks_handed_to_general": n_pass2}
-    achieved = ALGO_BYTES_PER_READ * units / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    passes["all_passes_avg"] = align_avg_ms
+    per = KERNEL_BYTES.get(name, ALGO_BYTES_PER_READ)
+    achieved = per * units / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    total_ms = sum(k[1] for k in kern) if kern else align_avg_ms
+    # the whole alignment step priced as the reference's algorithm (every read at SURVEY's 3 296 B): how fast a
+    # probe-per-key implementation would have to move data to keep up -- continuity with round 1, NOT a hardware fraction
+    ref_equiv = ALGO_BYTES_PER_READ * n / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "kernel": name, "kernel_ms": ms, "units_per_launch": units, "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,
-            "align_passes_ms": passes}
+            "kernel": name, "kernel_ms": ms, "units_per_launch": units, "algorithmic_bytes_per_read": per,
+            "align_kernels": passes, "align_all_kernels_ms": total_ms, "align_wall_ms": align_avg_ms,
+            "reference_algorithm_equivalent": {"bytes_per_read": ALGO_BYTES_PER_READ, "gbs": ref_equiv,
+                                               "note": "SURVEY 8(d) pricing (388 probes per read) of all reads over the sum of the alignment kernels; "
+                                                       "exceeds the HBM peak because the position-hinted pass does not issue those probes"}}
 
 
 if __name__ == "__main__":
