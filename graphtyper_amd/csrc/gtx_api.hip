@@ -432,6 +432,16 @@ __global__ __launch_bounds__(256) void gtx_align_hinted_kernel(GraphView g, Inde
     for (uint32_t it = 0; it < ROW_VEC; ++it)
       s_seq[wave][it * 64 + lane] = src[it * 64 + lane];
   }
+  else if (read < n_reads)
+  {
+    // any other layout (another stride, an unaligned buffer, the last wavefront of a batch): every lane brings its own
+    // row, byte-wise as far as the stride goes, zeros behind it
+    uint8_t const * src = seq + static_cast<uint64_t>(read) * seq_stride;
+    uint8_t * dst = reinterpret_cast<uint8_t *>(&s_seq[wave][lane * ROW_VEC]);
+#pragma unroll 1
+    for (uint32_t k = 0; k < ROW_BYTES; ++k)
+      dst[k] = k < seq_stride ? src[k] : static_cast<uint8_t>(0);
+  }
   WaveHip::lds_sync();
   bool fwd = false, rev = false;
   if (read < n_reads)
@@ -462,15 +472,10 @@ __global__ __launch_bounds__(256) void gtx_align_hinted_kernel(GraphView g, Inde
     }
     else if (decline_all != 0)
       fwd = true;
-    else if (staged)
-    {
-      uint32_t const * row = reinterpret_cast<uint32_t const *>(&s_seq[wave][lane * ROW_VEC]);
-      fwd = !hinted_one(g, ix, row, reinterpret_cast<uint8_t const *>(row), seq_stride, m, rec, rec_words);
-    }
     else
     {
-      uint8_t const * seq4 = seq + static_cast<uint64_t>(read) * seq_stride;
-      fwd = !hinted_one(g, ix, reinterpret_cast<uint32_t const *>(seq4), seq4, seq_stride, m, rec, rec_words);
+      uint32_t const * row = reinterpret_cast<uint32_t const *>(&s_seq[wave][lane * ROW_VEC]);
+      fwd = !hinted_one(g, ix, row, reinterpret_cast<uint8_t const *>(row), ROW_BYTES, m, rec, rec_words);
     }
   }
   unsigned long long const F = __ballot(fwd), R = __ballot(rev);

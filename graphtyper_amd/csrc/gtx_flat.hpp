@@ -112,7 +112,7 @@ struct IndexView
   // below are ordered by reference position, so neighbouring reads share their cache lines, and they carry the PROOF
   // that the global lookups of the reference would return exactly the one label of that place.
   // ref4: the linear reference of the region (= the graph's path over every site's allele 0) as BAM nibble codes,
-  //   8 bases per word, base 8w+j in bits 28-4j; entry 0 is contig position hint_first (0-based); 4 padding words.
+  //   8 bases per word, base 8w+j in bits 28-4j; entry 0 is contig position hint_first (0-based); 24 padding words.
   // pos_flags[i] (two words), about the 32-mer that starts at hint_first + i (K_i) and about the position itself:
   //  x  HINT_SINGLE_OK  K_i is indexed with exactly the label (i, i+31[, site, allele 0]) (and it may be used: not on a
   //                     variant of an SV graph);

@@ -552,7 +552,7 @@ static void build_hints(HostGraph const & g, HostIndex & out)
   out.hint_first = g.ref_order.empty() ? 0 : g.ref_order[0] - 1; // order = 1-based contig position
   if (R == 0 || R - 1 >= HINT_NO_SITE)
   {
-    out.ref4.assign(8, 0);
+    out.ref4.assign(32, 0);
     out.pos_flags.assign(1, uint2_t{0, 0});
     out.filt[0].assign(1, 0);
     out.filt[1].assign(1, 0);
@@ -582,7 +582,7 @@ static void build_hints(HostGraph const & g, HostIndex & out)
     }
   }
   out.n_hint = n;
-  out.ref4.assign(n / 8 + 5, 0);
+  out.ref4.assign(n / 8 + 24, 0); // (padded: the kernel loads 21 words from any position without a bounds test)
   for (uint32_t i = 0; i < n; ++i)
     out.ref4[i >> 3] |= static_cast<uint32_t>(base[i]) << (28 - 4 * (i & 7u));
   // per key: how many keys share its first / last 16 bases, and whether its Hamming-1 neighbours are "the same interval

@@ -84,33 +84,43 @@ constexpr uint32_t nib_range_mask(uint32_t w, uint32_t a, uint32_t b)
   return from & ~upto;
 }
 
-// 16 nibbles from nibble A on, as two words (A is a compile-time constant)
-template <uint32_t A>
-GTX_DEV void nib_extract16(uint32_t const (&r)[HINT_WORDS], uint32_t & w0, uint32_t & w1)
+// 16 bases of the read from base A on, as two words (A is a compile-time constant inside a k-mer, hence inside the read);
+// read from the row again instead of being kept in registers all along
+template <uint32_t A, class Row>
+GTX_DEV void nib_extract16(Row row, uint32_t & w0, uint32_t & w1)
 {
   constexpr uint32_t W = A / 8, S = 4 * (A % 8);
+  uint32_t const a = hint_bswap(row[W]), b = hint_bswap(row[W + 1]);
   if constexpr (S == 0)
   {
-    w0 = r[W];
-    w1 = r[W + 1];
+    w0 = a;
+    w1 = b;
   }
   else
   {
-    w0 = (r[W] << S) | (r[W + 1] >> (32 - S));
-    w1 = (r[W + 1] << S) | ((W + 2 < HINT_WORDS ? r[W + 2] : 0u) >> (32 - S));
+    uint32_t const c = hint_bswap(row[W + 2]);
+    w0 = (a << S) | (b >> (32 - S));
+    w1 = (b << S) | (c >> (32 - S));
   }
 }
 
-// What the compare of the read with the reference under it says, summed while the words stream by (nothing but these
-// counters and the read's own words stays in registers):
+// What the compare of the read with the reference under it says, summed while the words stream by.  Packed (the pass is
+// bound by memory latency times resident waves: registers are occupancy):
+//   k[I]   per k-mer, 6 bits each: substitutions among its unambiguous bases, ... in its 16 first bases, ambiguous bases,
+//          ... in its 16 first bases, ambiguous bases whose set does not hold the reference base
+//   upto   mismatches by the walks' rule in [0, 31 j), 8 bits each for j = 1..4;  more: j = 5 (bits 0..7), the whole
+//          read (bits 8..15), and the mismatch flags of the boundary bases 31 j, j = 1..4 (bits 16..19)
 struct HintCounts
 {
-  uint32_t mis[AlignCfg::KC], mis_left[AlignCfg::KC]; // per k-mer: substitutions among its unambiguous bases (left = 16 first)
-  uint32_t amb[AlignCfg::KC], amb_left[AlignCfg::KC]; // ... ambiguous bases
-  uint32_t amb_out[AlignCfg::KC];                     // ... ambiguous bases whose set does not hold the reference base
-  uint32_t upto[AlignCfg::KC + 1]; // mismatches (the walks' rule) in [0, 31 j); upto[0]: in the whole read
-  uint32_t edge[AlignCfg::KC];     // ... at base 31 j itself
+  uint32_t k[AlignCfg::KC];
+  uint32_t upto, more;
 };
+constexpr uint32_t HC_MIS = 0, HC_MIS_LEFT = 6, HC_AMB = 12, HC_AMB_LEFT = 18, HC_AMB_OUT = 24;
+
+GTX_DEV uint32_t hc_get(uint32_t packed, uint32_t shift)
+{
+  return (packed >> shift) & 63u;
+}
 
 template <uint32_t W, uint32_t I>
 GTX_DEV void hint_count_kmer(uint32_t mk, uint32_t am, uint32_t ao, uint32_t mt, HintCounts & h)
@@ -119,25 +129,40 @@ GTX_DEV void hint_count_kmer(uint32_t mk, uint32_t am, uint32_t ao, uint32_t mt,
   constexpr uint32_t M = nib_range_mask(W, A, A + 32), ML = nib_range_mask(W, A, A + 16);
   constexpr uint32_t C = nib_range_mask(W, 0, A + (K - 1)), E = I == 0 ? 0u : nib_range_mask(W, A, A + 1);
   if constexpr (M != 0)
-  {
-    h.mis[I] += static_cast<uint32_t>(__builtin_popcount(mk & M));
-    h.amb[I] += static_cast<uint32_t>(__builtin_popcount(am & M));
-    h.amb_out[I] += static_cast<uint32_t>(__builtin_popcount(ao & M));
-  }
+    h.k[I] += static_cast<uint32_t>(__builtin_popcount(mk & M)) + (static_cast<uint32_t>(__builtin_popcount(am & M)) << HC_AMB) +
+              (static_cast<uint32_t>(__builtin_popcount(ao & M)) << HC_AMB_OUT);
   if constexpr (ML != 0)
-  {
-    h.mis_left[I] += static_cast<uint32_t>(__builtin_popcount(mk & ML));
-    h.amb_left[I] += static_cast<uint32_t>(__builtin_popcount(am & ML));
-  }
+    h.k[I] += (static_cast<uint32_t>(__builtin_popcount(mk & ML)) << HC_MIS_LEFT) + (static_cast<uint32_t>(__builtin_popcount(am & ML)) << HC_AMB_LEFT);
   if constexpr (C != 0)
-    h.upto[I + 1] += static_cast<uint32_t>(__builtin_popcount(mt & C));
+  {
+    if constexpr (I < 4)
+      h.upto += static_cast<uint32_t>(__builtin_popcount(mt & C)) << (8 * I);
+    else
+      h.more += static_cast<uint32_t>(__builtin_popcount(mt & C));
+  }
   if constexpr (E != 0)
-    h.edge[I] += static_cast<uint32_t>(__builtin_popcount(mt & E));
+    h.more += static_cast<uint32_t>(__builtin_popcount(mt & E)) << (15 + I);
+}
+
+// mismatches in [0, 31 j), j = 1..5 / in the whole read / at base 31 j, j = 1..4
+GTX_DEV uint32_t hc_upto(HintCounts const & h, uint32_t j)
+{
+  return j == 5 ? (h.more & 255u) : ((h.upto >> (8 * (j - 1))) & 255u);
+}
+
+GTX_DEV uint32_t hc_all(HintCounts const & h)
+{
+  return (h.more >> 8) & 255u;
+}
+
+GTX_DEV uint32_t hc_edge(HintCounts const & h, uint32_t j)
+{
+  return (h.more >> (15 + j)) & 1u;
 }
 
 // word W of the read (rw: 8 bases, base j in bits 28-4j; `have` bases of the read lie in it) against the reference (gw)
 template <uint32_t W>
-GTX_DEV uint32_t hint_word(uint32_t rw, uint32_t gw, uint32_t have, HintCounts & h)
+GTX_DEV void hint_word(uint32_t rw, uint32_t gw, uint32_t have, HintCounts & h)
 {
   uint32_t const keep = have >= 8 ? 0xFFFFFFFFu : have == 0 ? 0u : ~(0xFFFFFFFFu >> (4 * have));
   rw &= keep;
@@ -154,42 +179,31 @@ GTX_DEV uint32_t hint_word(uint32_t rw, uint32_t gw, uint32_t have, HintCounts &
   hint_count_kmer<W, 2>(mk, am, ao, mt, h);
   hint_count_kmer<W, 3>(mk, am, ao, mt, h);
   hint_count_kmer<W, 4>(mk, am, ao, mt, h);
-  h.upto[0] += static_cast<uint32_t>(__builtin_popcount(mt));
-  return rw;
+  h.more += static_cast<uint32_t>(__builtin_popcount(mt)) << 8;
 }
 
 template <uint32_t W, class Row>
-GTX_DEV void hint_compare_from(Row row, uint32_t seq_stride, uint32_t const * refw, uint32_t sh, uint32_t L, uint32_t prev, uint32_t (&r)[HINT_WORDS],
-                               HintCounts & h)
+GTX_DEV void hint_compare_from(Row row, uint32_t seq_stride, uint32_t const * refw, uint32_t sh, uint32_t L, uint32_t prev, HintCounts & h)
 {
   if constexpr (W < HINT_WORDS)
   {
+    // (no branches around the loads: the reference array is padded by HINT_WORDS + 1 words and a row has at least
+    // seq_stride bytes, so every lane may load every word and the loads of all words are in flight together; what
+    // lies beyond the read is masked inside hint_word)
     uint32_t const have = L > 8 * W ? L - 8 * W : 0u; // bases of the read in this word
-    uint32_t rw = 0, gw = 0, next = 0;
-    if (have != 0)
-    {
-      if (4 * W < seq_stride)
-        rw = hint_bswap(row[W]);
-      next = refw[W + 1];
-      gw = sh == 0 ? prev : ((prev << sh) | (next >> (32 - sh)));
-    }
-    r[W] = hint_word<W>(rw, gw, have, h);
-    hint_compare_from<W + 1>(row, seq_stride, refw, sh, L, next, r, h);
+    bool const in_row = 4 * W < seq_stride; // (uniform; a select, not a branch around the load)
+    uint32_t const rw = hint_bswap(row[in_row ? W : 0u]) & (in_row ? 0xFFFFFFFFu : 0u);
+    uint32_t const next = refw[W + 1];
+    uint32_t const gw = sh == 0 ? prev : ((prev << sh) | (next >> (32 - sh)));
+    hint_word<W>(rw, gw, have, h);
+    hint_compare_from<W + 1>(row, seq_stride, refw, sh, L, next, h);
   }
 }
 
 template <class Row>
-GTX_DEV void hint_compare(Row row, uint32_t seq_stride, uint32_t const * refw, uint32_t sh, uint32_t L, uint32_t (&r)[HINT_WORDS], HintCounts & h)
+GTX_DEV void hint_compare(Row row, uint32_t seq_stride, uint32_t const * refw, uint32_t sh, uint32_t L, HintCounts & h)
 {
-  hint_compare_from<0>(row, seq_stride, refw, sh, L, refw[0], r, h);
-}
-
-// the half's bits of the blocked Bloom filter are all set: an indexed key MAY have these 16 bases
-GTX_DEV bool hint_half_maybe(IndexView const & ix, uint32_t side, uint32_t w0, uint32_t w1)
-{
-  uint32_t word, mask;
-  hint_filter_slot(w0, w1, ix.filt_log2, word, mask);
-  return (ix.filt[side][word] & mask) == mask;
+  hint_compare_from<0>(row, seq_stride, refw, sh, L, refw[0], h);
 }
 
 enum : uint32_t
@@ -199,38 +213,44 @@ enum : uint32_t
   HINT_K_HOLE = 2   // the k-mer has no label at all
 };
 
-struct HintKmer
+// one k-mer's verdict in a word: kind (bits 0..1), mm (2: the label comes from the Hamming-1 list, one more mismatch), par (3:
+// the k-mer also starts a parallel chain -- matters when it opens the run behind a hole), allele (4..5) and site (16..31,
+// HINT_NO_SITE: none) of the label
+constexpr uint32_t HK_MM = 4u, HK_PAR = 8u, HK_ALLELE_SHIFT = 4u, HK_SITE_SHIFT = 16u;
+
+GTX_DEV uint32_t hk_make(uint32_t kind, uint32_t site, uint32_t allele, bool mm, bool par)
 {
-  uint32_t kind;
-  uint32_t site, allele; // of the label (site HINT_NO_SITE: none)
-  bool mm;               // the label comes from the Hamming-1 list: one more mismatch
-  bool par;              // the k-mer also starts a parallel chain (matters when it opens the run behind a hole)
-};
+  return kind | (mm ? HK_MM : 0u) | (par ? HK_PAR : 0u) | (allele << HK_ALLELE_SHIFT) | (site << HK_SITE_SHIFT);
+}
 
 // What the global lookups of the reference return for k-mer I of the read, proven from the flags of the hinted place
 // (cases in the file header; a hole needs both halves of the k-mer to occur in no indexed key, or to be K's own halves
 // while the k-mer is two or more substitutions away from K).
+// What the global lookups of the reference return for k-mer I of the read, as far as the flags of the hinted place
+// say.  The verdict may hang on one or both halves of the k-mer occurring in no indexed key (HK_NEED_LEFT / RIGHT): the
+// caller probes the filters for all k-mers at once -- one memory round trip instead of one per k-mer -- and turns the
+// verdict into a decline when a needed half may occur.
+constexpr uint32_t HK_NEED_LEFT = 64u, HK_NEED_RIGHT = 128u;
+
 template <uint32_t I>
-GTX_DEV HintKmer hint_kmer(IndexView const & ix, uint32_t idx, uint8_t const * seq4, uint32_t const (&r)[HINT_WORDS], HintCounts const & h)
+GTX_DEV uint32_t hint_kmer(uint2_t const f, uint8_t const * seq4, HintCounts const & h)
 {
   constexpr uint32_t A = (K - 1) * I;
-  uint2_t const f = ix.pos_flags[idx + A];
-  uint32_t const mis = h.mis[I], mis_left = h.mis_left[I], mis_right = mis - mis_left;
-  uint32_t const amb = h.amb[I], amb_left = h.amb_left[I];
-  uint32_t const amb_out = h.amb_out[I]; // ambiguous bases whose set does not hold the reference base
-  HintKmer k{HINT_K_DECLINE, f.x >> HINT_SITE_SHIFT, 0u, false, false};
+  uint32_t const mis = hc_get(h.k[I], HC_MIS), mis_left = hc_get(h.k[I], HC_MIS_LEFT), mis_right = mis - mis_left;
+  uint32_t const amb = hc_get(h.k[I], HC_AMB), amb_left = hc_get(h.k[I], HC_AMB_LEFT);
+  uint32_t const amb_out = hc_get(h.k[I], HC_AMB_OUT); // ambiguous bases whose set does not hold the reference base
+  uint32_t const site = f.x >> HINT_SITE_SHIFT;
+  uint32_t const declined = hk_make(HINT_K_DECLINE, site, 0u, false, false);
   bool const single = (f.x & HINT_SINGLE_OK) != 0, l1 = single && (f.x & HINT_L1) != 0, r1 = single && (f.x & HINT_R1) != 0;
   if (amb == 0 && mis == 0)
   {
-    k.kind = (f.x & HINT_EXACT_OK) ? HINT_K_LABEL : HINT_K_DECLINE;
-    k.par = (f.x & HINT_PAR) != 0;
-    GTX_HINT_NOTE(k.kind == HINT_K_DECLINE ? 1 : 0); // exact k-mer, but the place is not provably simple
-    return k;
+    GTX_HINT_NOTE((f.x & HINT_EXACT_OK) ? 0 : 1); // exact k-mer, but the place is not provably simple
+    return hk_make((f.x & HINT_EXACT_OK) ? HINT_K_LABEL : HINT_K_DECLINE, site, 0u, false, (f.x & HINT_PAR) != 0);
   }
   if (amb > 1)
   {
     GTX_HINT_NOTE(7);
-    return k;
+    return declined;
   }
   if (amb == 0 && mis == 1 && (f.x & HINT_ALT_OK) != 0)
   {
@@ -240,17 +260,10 @@ GTX_DEV HintKmer hint_kmer(IndexView const & ix, uint32_t idx, uint8_t const * s
     uint32_t const two = rb == 1 ? 0u : rb == 2 ? 1u : rb == 4 ? 2u : 3u;
     uint32_t const allele = (f.x >> (HINT_ALTIDX_SHIFT + 2 * two)) & 3u;
     if (allele != 0)
-    {
-      k.kind = HINT_K_LABEL;
-      k.allele = allele;
-      k.par = true; // (the reference allele's key is its neighbour)
-      return k;
-    }
+      return hk_make(HINT_K_LABEL, site, allele, false, true); // (par: the reference allele's key is its neighbour)
   }
-  // the k-mer is not K: which of its halves are K's, which must be shown to occur in no indexed key
-  uint32_t l0, l1w, r0, r1w;
-  nib_extract16<A>(r, l0, l1w);
-  nib_extract16<A + 16>(r, r0, r1w);
+  // the k-mer is not K: a half without a difference is K's own -- K alone must have it (flag) --, a half with one must
+  // occur in no indexed key (filter probe by the caller)
   if (amb == 0)
   {
     if (mis == 1)
@@ -259,24 +272,15 @@ GTX_DEV HintKmer hint_kmer(IndexView const & ix, uint32_t idx, uint8_t const * s
       if (!(left ? r1 : l1))
       {
         GTX_HINT_NOTE(3); // one substitution, the other half is shared with further keys (a variant there)
-        return k;
+        return declined;
       }
-      if (hint_half_maybe(ix, left ? 0u : 1u, left ? l0 : r0, left ? l1w : r1w))
-      {
-        GTX_HINT_NOTE(4); // one substitution, its half may occur in the index (a variant allele, or a filter collision)
-        return k;
-      }
-      k.kind = HINT_K_LABEL;
-      k.mm = true;
-      return k;
+      return hk_make(HINT_K_LABEL, site, 0u, true, false) | (left ? HK_NEED_LEFT : HK_NEED_RIGHT);
     }
-    // two or more substitutions: no label at all when neither half leads to an indexed key within distance 1 -- a half
-    // without a substitution is K's own (K alone must have it: K itself is too far away), a half with one must occur in
-    // no indexed key
-    bool const ok = (mis_left == 0 ? l1 : !hint_half_maybe(ix, 0u, l0, l1w)) && (mis_right == 0 ? r1 : !hint_half_maybe(ix, 1u, r0, r1w));
-    k.kind = ok ? HINT_K_HOLE : HINT_K_DECLINE;
+    // two or more substitutions: no label at all (K itself is too far away to be a neighbour)
+    bool const ok = (mis_left != 0 || l1) && (mis_right != 0 || r1);
     GTX_HINT_NOTE(ok ? 0 : 6);
-    return k;
+    return hk_make(ok ? HINT_K_HOLE : HINT_K_DECLINE, site, 0u, false, false) | (mis_left != 0 ? HK_NEED_LEFT : 0u) |
+           (mis_right != 0 ? HK_NEED_RIGHT : 0u);
   }
   // one ambiguous base (a multi-key list: exact lookups only, src/utilities/kmer_help_functions.cpp:97-119)
   bool const amb_is_left = amb_left == 1;
@@ -286,23 +290,49 @@ GTX_DEV HintKmer hint_kmer(IndexView const & ix, uint32_t idx, uint8_t const * s
     if (!(amb_is_left ? r1 : l1))
     {
       GTX_HINT_NOTE(5);
-      return k;
+      return declined;
     }
-    k.kind = amb_out == 0 ? HINT_K_LABEL : HINT_K_HOLE; // (a set without the reference base: none of its keys is K)
-    k.par = true;
-    return k;
+    return hk_make(amb_out == 0 ? HINT_K_LABEL : HINT_K_HOLE, site, 0u, false, true); // (a set without the reference base: none of its keys is K)
   }
   // ... plus substitutions: none of its keys is K.  Either everything lies in one half (the other one is K's), or the
-  // substitutions lie in the half without the ambiguous base, which then is one concrete 16-mer
+  // substitutions lie in the half without the ambiguous base, which then is one concrete 16-mer to probe
+  uint32_t need = 0;
   bool ok = false;
   if (amb_is_left)
-    ok = mis_right == 0 ? r1 : (mis_left == 0 && !hint_half_maybe(ix, 1u, r0, r1w));
+  {
+    ok = mis_right == 0 ? r1 : mis_left == 0;
+    need = mis_right == 0 ? 0u : HK_NEED_RIGHT;
+  }
   else
-    ok = mis_left == 0 ? l1 : (mis_right == 0 && !hint_half_maybe(ix, 0u, l0, l1w));
-  k.kind = ok ? HINT_K_HOLE : HINT_K_DECLINE;
-  k.par = true;
+  {
+    ok = mis_left == 0 ? l1 : mis_right == 0;
+    need = mis_left == 0 ? 0u : HK_NEED_LEFT;
+  }
   GTX_HINT_NOTE(ok ? 0 : 7);
-  return k;
+  return hk_make(ok ? HINT_K_HOLE : HINT_K_DECLINE, site, 0u, false, true) | (ok ? need : 0u);
+}
+
+// filter probe of one half of k-mer I when the verdict hangs on it: where to look ...
+template <uint32_t I, uint32_t SIDE, class Row>
+GTX_DEV void hint_probe_slot(IndexView const & ix, uint32_t verdict, Row row, uint32_t & word, uint32_t & mask)
+{
+  word = 0;
+  mask = 0;
+  if (verdict & (SIDE == 0 ? HK_NEED_LEFT : HK_NEED_RIGHT))
+  {
+    uint32_t w0, w1;
+    nib_extract16<(K - 1) * I + 16 * SIDE>(row, w0, w1);
+    hint_filter_slot(w0, w1, ix.filt_log2, word, mask);
+  }
+}
+
+// ... and what the looked-up filter words say: the verdict stands, or the k-mer is declined
+GTX_DEV uint32_t hint_probe_verdict(uint32_t verdict, uint32_t left_word, uint32_t left_mask, uint32_t right_word, uint32_t right_mask)
+{
+  bool const maybe = ((verdict & HK_NEED_LEFT) && (left_word & left_mask) == left_mask) ||
+                     ((verdict & HK_NEED_RIGHT) && (right_word & right_mask) == right_mask);
+  GTX_HINT_NOTE(maybe ? 4 : 0); // a half that has to be absent may occur in the index (a variant allele, or a filter collision)
+  return maybe ? (verdict & ~3u) | HINT_K_DECLINE : verdict;
 }
 
 // The forward task of one read.  Returns true when the record was written, false = declined (nothing written).
@@ -325,24 +355,58 @@ GTX_DEV bool hinted_one(GraphView const & g, IndexView const & ix, Row row, uint
     return false;
   uint32_t const n_k = 1 + (L - K) / (K - 1);
   // ---- the read and the reference under it, 8 bases per word, aligned to the read
-  uint32_t r[HINT_WORDS];
   HintCounts h{};
   uint32_t const * refw = ix.ref4 + (idx >> 3);
   uint32_t const sh = 4 * (idx & 7u);
-  hint_compare(row, seq_stride, refw, sh, L, r, h);
+  // ---- the flags of the k-mers' places (their second words also describe the positions the walks start from); all
+  //      issued together with the reference words: one round trip
+  uint2_t const f0 = ix.pos_flags[idx], f1 = ix.pos_flags[idx + (K - 1)];
+  uint2_t const f2 = ix.pos_flags[idx + (n_k > 2 ? 2 * (K - 1) : 0u)], f3 = ix.pos_flags[idx + (n_k > 3 ? 3 * (K - 1) : 0u)];
+  uint2_t const f4 = ix.pos_flags[idx + (n_k > 4 ? 4 * (K - 1) : 0u)];
+  uint32_t const y_end = ix.pos_flags[idx + (K - 1) * n_k].y; // the position behind the last k-mer (31 n_k <= L - 1: inside the read)
+  hint_compare(row, seq_stride, refw, sh, L, h);
   // ---- every k-mer: the label of its place, no label at all, or not provable
-  HintKmer const k0 = hint_kmer<0>(ix, idx, seq4, r, h), k1 = hint_kmer<1>(ix, idx, seq4, r, h);
-  HintKmer const none{HINT_K_HOLE, HINT_NO_SITE, 0u, false, false};
-  HintKmer const k2 = n_k > 2 ? hint_kmer<2>(ix, idx, seq4, r, h) : none;
-  HintKmer const k3 = n_k > 3 ? hint_kmer<3>(ix, idx, seq4, r, h) : none;
-  HintKmer const k4 = n_k > 4 ? hint_kmer<4>(ix, idx, seq4, r, h) : none;
-  if (k0.kind == HINT_K_DECLINE || k1.kind == HINT_K_DECLINE || k2.kind == HINT_K_DECLINE || k3.kind == HINT_K_DECLINE ||
-      k4.kind == HINT_K_DECLINE)
+  uint32_t const none = hk_make(HINT_K_HOLE, HINT_NO_SITE, 0u, false, false);
+  uint32_t k0 = hint_kmer<0>(f0, seq4, h), k1 = hint_kmer<1>(f1, seq4, h);
+  uint32_t k2 = n_k > 2 ? hint_kmer<2>(f2, seq4, h) : none;
+  uint32_t k3 = n_k > 3 ? hint_kmer<3>(f3, seq4, h) : none;
+  uint32_t k4 = n_k > 4 ? hint_kmer<4>(f4, seq4, h) : none;
+  if ((k0 & 3u) == HINT_K_DECLINE || (k1 & 3u) == HINT_K_DECLINE || (k2 & 3u) == HINT_K_DECLINE || (k3 & 3u) == HINT_K_DECLINE ||
+      (k4 & 3u) == HINT_K_DECLINE)
     return false;
-  uint32_t const labelled = (k0.kind == HINT_K_LABEL ? 1u : 0u) | (k1.kind == HINT_K_LABEL ? 2u : 0u) | (k2.kind == HINT_K_LABEL ? 4u : 0u) |
-                            (k3.kind == HINT_K_LABEL ? 8u : 0u) | (k4.kind == HINT_K_LABEL ? 16u : 0u);
-  uint32_t const par = (k0.par ? 1u : 0u) | (k1.par ? 2u : 0u) | (k2.par ? 4u : 0u) | (k3.par ? 8u : 0u) | (k4.par ? 16u : 0u);
-  uint32_t const mmk = (k0.mm ? 1u : 0u) | (k1.mm ? 2u : 0u) | (k2.mm ? 4u : 0u) | (k3.mm ? 8u : 0u) | (k4.mm ? 16u : 0u);
+  if ((k0 | k1 | k2 | k3 | k4) & (HK_NEED_LEFT | HK_NEED_RIGHT))
+  {
+    // ---- the filter probes of all k-mers together: one round trip
+    uint32_t wl0, ml0, wr0, mr0, wl1, ml1, wr1, mr1, wl2, ml2, wr2, mr2, wl3, ml3, wr3, mr3, wl4, ml4, wr4, mr4;
+    hint_probe_slot<0, 0>(ix, k0, row, wl0, ml0);
+    hint_probe_slot<0, 1>(ix, k0, row, wr0, mr0);
+    hint_probe_slot<1, 0>(ix, k1, row, wl1, ml1);
+    hint_probe_slot<1, 1>(ix, k1, row, wr1, mr1);
+    hint_probe_slot<2, 0>(ix, k2, row, wl2, ml2);
+    hint_probe_slot<2, 1>(ix, k2, row, wr2, mr2);
+    hint_probe_slot<3, 0>(ix, k3, row, wl3, ml3);
+    hint_probe_slot<3, 1>(ix, k3, row, wr3, mr3);
+    hint_probe_slot<4, 0>(ix, k4, row, wl4, ml4);
+    hint_probe_slot<4, 1>(ix, k4, row, wr4, mr4);
+    uint32_t const * fl = ix.filt[0];
+    uint32_t const * fr = ix.filt[1];
+    uint32_t const xl0 = fl[wl0], xr0 = fr[wr0], xl1 = fl[wl1], xr1 = fr[wr1], xl2 = fl[wl2], xr2 = fr[wr2], xl3 = fl[wl3], xr3 = fr[wr3],
+                   xl4 = fl[wl4], xr4 = fr[wr4];
+    k0 = hint_probe_verdict(k0, xl0, ml0, xr0, mr0);
+    k1 = hint_probe_verdict(k1, xl1, ml1, xr1, mr1);
+    k2 = hint_probe_verdict(k2, xl2, ml2, xr2, mr2);
+    k3 = hint_probe_verdict(k3, xl3, ml3, xr3, mr3);
+    k4 = hint_probe_verdict(k4, xl4, ml4, xr4, mr4);
+  }
+  if ((k0 & 3u) == HINT_K_DECLINE || (k1 & 3u) == HINT_K_DECLINE || (k2 & 3u) == HINT_K_DECLINE || (k3 & 3u) == HINT_K_DECLINE ||
+      (k4 & 3u) == HINT_K_DECLINE)
+    return false;
+  auto bits = [&](uint32_t flag, uint32_t want) // one bit per k-mer
+  {
+    return ((k0 & flag) == want ? 1u : 0u) | ((k1 & flag) == want ? 2u : 0u) | ((k2 & flag) == want ? 4u : 0u) | ((k3 & flag) == want ? 8u : 0u) |
+           ((k4 & flag) == want ? 16u : 0u);
+  };
+  uint32_t const labelled = bits(3u, HINT_K_LABEL), par = bits(HK_PAR, HK_PAR), mmk = bits(HK_MM, HK_MM);
   // ---- the run of k-mers that makes the path (express4.inl: the longest run of labelled k-mers, which has to be the
   //      only one of its length; the shorter side of a hole chains into a path remove_short_paths drops)
   uint32_t lo = 0, hi = n_k - 1;
@@ -381,21 +445,19 @@ GTX_DEV bool hinted_one(GraphView const & g, IndexView const & ix, Row row, uint
   }
   uint32_t const run = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
   uint32_t mism = static_cast<uint32_t>(__builtin_popcount(mmk & run));
-  // ---- the read in front of the run and behind it: the walks' shortcut, both inside the reference node the path touches.
-  //      Mismatches in [0, x) for the k-mer boundaries x = 31 j:
+  // ---- the read in front of the run and behind it: the walks' shortcut, both inside the reference node the path touches
   uint32_t const prs = (K - 1) * lo, pre = (K - 1) * (hi + 1);
   uint32_t start = g.first_order + idx + prs, rs = prs;
   if (prs != 0) // walk_read_starts (genotype_paths.cpp:555-621)
   {
-    uint32_t const y = ix.pos_flags[idx + prs].y;
+    uint32_t const y = lo == 1 ? f1.y : lo == 2 ? f2.y : lo == 3 ? f3.y : f4.y; // (position 31 lo is k-mer lo's own place)
     if ((y & 255u) == 0 || ((y >> HINT_BACK_SHIFT) & 255u) < prs)
     {
       GTX_HINT_NOTE(11);
       return false; // (the walk leaves the node: express4 / general pass)
     }
     uint32_t const head_len = prs + 1;
-    // mismatches in [0, prs]: the boundary base itself is nibble 31 lo
-    uint32_t const upto = lo == 1 ? h.upto[1] + h.edge[1] : lo == 2 ? h.upto[2] + h.edge[2] : lo == 3 ? h.upto[3] + h.edge[3] : h.upto[4] + h.edge[4];
+    uint32_t const upto = hc_upto(h, lo) + hc_edge(h, lo); // mismatches in [0, prs]: the boundary base itself is base 31 lo
     uint32_t const budget = 2 + head_len / 11 < 7 ? 2 + head_len / 11 : 7; // genotype_paths.cpp:571-577
     if (upto <= budget)
     {
@@ -408,14 +470,13 @@ GTX_DEV bool hinted_one(GraphView const & g, IndexView const & ix, Row row, uint
   if (pre != L - 1) // walk_read_ends (genotype_paths.cpp:483-553)
   {
     uint32_t const tail_len = L - pre;
-    uint32_t const room = ix.pos_flags[idx + pre].y & 255u;
-    if (room < tail_len)
+    uint32_t const y = hi + 1 == n_k ? y_end : hi == 0 ? f1.y : hi == 1 ? f2.y : hi == 2 ? f3.y : f4.y;
+    if ((y & 255u) < tail_len)
     {
       GTX_HINT_NOTE(8);
       return false; // (the tail leaves the node, or the path ends on a variant: express4)
     }
-    uint32_t const before = hi == 0 ? h.upto[1] : hi == 1 ? h.upto[2] : hi == 2 ? h.upto[3] : hi == 3 ? h.upto[4] : h.upto[5];
-    uint32_t const got = h.upto[0] - before;
+    uint32_t const got = hc_all(h) - hc_upto(h, hi + 1);
     uint32_t const budget = 2 + tail_len / 11 < 7 ? 2 + tail_len / 11 : 7; // genotype_paths.cpp:505-511
     if (got <= budget)
     {
@@ -426,22 +487,21 @@ GTX_DEV bool hinted_one(GraphView const & g, IndexView const & ix, Row row, uint
   }
   // ---- variant sites of the path, most recent k-mer first (Path(p1, p2), path.cpp:38-82); a site under two
   //      neighbouring k-mers is one entry (the same base, hence the same allele)
-  uint32_t vs[5], va[5];
+  uint32_t vs[5];
   uint32_t nvar = 0;
-  uint32_t last = HINT_NO_SITE;
+  uint32_t last = HINT_NO_SITE << HK_SITE_SHIFT;
   bool clash = false;
-  auto push = [&](uint32_t k, HintKmer const & km)
+  auto push = [&](uint32_t k, uint32_t km)
   {
-    if (((run >> k) & 1u) && km.site != HINT_NO_SITE)
+    if (((run >> k) & 1u) && (km >> HK_SITE_SHIFT) != HINT_NO_SITE)
     {
-      if (km.site == last)
-        clash = clash || va[nvar - 1] != km.allele;
+      uint32_t const entry = km & ((0xFFFFu << HK_SITE_SHIFT) | (3u << HK_ALLELE_SHIFT));
+      if ((entry >> HK_SITE_SHIFT) == (last >> HK_SITE_SHIFT))
+        clash = clash || entry != last;
       else
       {
-        vs[nvar] = km.site;
-        va[nvar] = km.allele;
-        ++nvar;
-        last = km.site;
+        vs[nvar++] = entry;
+        last = entry;
       }
     }
   };
@@ -469,8 +529,8 @@ GTX_DEV bool hinted_one(GraphView const & g, IndexView const & ix, Row row, uint
     for (uint32_t k = 0; k < 5; ++k)
       if (k < nvar)
       {
-        rec[6 + 3 * k] = vs[k];
-        rec[7 + 3 * k] = 1u << va[k];
+        rec[6 + 3 * k] = vs[k] >> HK_SITE_SHIFT;
+        rec[7 + 3 * k] = 1u << ((vs[k] >> HK_ALLELE_SHIFT) & 3u);
         rec[8 + 3 * k] = 0u;
       }
   }
