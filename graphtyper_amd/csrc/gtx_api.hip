@@ -400,18 +400,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_WIDE_WAV
 // task is settled (empty record, or queued for pass 2 when align_read asks for it), reads outside the length limits get
 // their empty records, and the forward task is finished from the position hint where the flags of that place prove the
 // global lookups -- else the read is queued for pass 1 (express4 over the queue).  One atomic per wavefront and queue.
-__global__ __launch_bounds__(256) void gtx_align_hinted_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq, uint32_t seq_stride,
-                                                               gtx_read_meta const * __restrict__ meta, uint32_t n_reads,
-                                                               uint32_t * __restrict__ records, uint32_t rec_words, uint32_t force_both,
-                                                               uint32_t * __restrict__ queue1, uint32_t * queue1_count,
-                                                               uint32_t * __restrict__ queue2, uint32_t * queue2_count, uint32_t decline_all)
+template <uint32_t WAVES>
+__device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const & ix, uint8_t const * __restrict__ seq, uint32_t seq_stride,
+                                            gtx_read_meta const * __restrict__ meta, uint32_t n_reads, uint32_t * __restrict__ records,
+                                            uint32_t rec_words, uint32_t force_both, uint32_t * __restrict__ queue1, uint32_t * queue1_count,
+                                            uint32_t * __restrict__ queue2, uint32_t * queue2_count, uint32_t decline_all)
 {
   // The 64 reads of a wavefront lie side by side in memory: their bases (80 B each) and their meta records (20 B each)
   // are fetched with coalesced loads -- 1 KB and 256 B per instruction instead of 64 scattered lines -- and handed to
   // the lanes through LDS (row pitch 80 B = 20 banks: 16-byte reads of 16 neighbouring lanes hit all 64 banks once).
   constexpr uint32_t ROW_BYTES = HINT_MAX_READ / 2, ROW_VEC = ROW_BYTES / 16, META_WORDS = sizeof(gtx_read_meta) / 4;
-  __shared__ uint4_t s_seq[4][64 * ROW_VEC];
-  __shared__ uint32_t s_meta[4][64 * META_WORDS];
+  __shared__ uint4_t s_seq[WAVES][64 * ROW_VEC];
+  __shared__ uint32_t s_meta[WAVES][64 * META_WORDS];
+  __shared__ uint32_t s_count[2][WAVES], s_base[2];
   static_assert(sizeof(gtx_read_meta) % 4 == 0, "meta records are staged word-wise");
   uint32_t const lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t const wave_first = blockIdx.x * blockDim.x + wave * 64u;
@@ -457,7 +458,8 @@ __global__ __launch_bounds__(256) void gtx_align_hinted_kernel(GraphView g, Inde
     else
       m = meta[read];
     uint32_t const len = m.l_qseq;
-    uint32_t * rec = records + static_cast<uint64_t>(read) * 2 * rec_words;
+    // (decline_all & 2: timing experiment -- results land in the first 1 024 record slots, i.e. stay in the L2)
+    uint32_t * rec = records + static_cast<uint64_t>((decline_all & 2u) ? (read & 1023u) : read) * 2 * rec_words;
     bool const outside = len < 2 * K - 1 || len > AlignCfg::MAX_READ; // align_read (alignment.cpp:331-363): stay unaligned
     rev = !outside && needs_reverse(m, force_both != 0);
     if (!rev)
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(256) void gtx_align_hinted_kernel(GraphView g, Inde
       rec[0] = len > AlignCfg::MAX_READ ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
       rec[1] = len << 16;
     }
-    else if (decline_all != 0)
+    else if ((decline_all & 1u) != 0)
       fwd = true;
     else
     {
@@ -478,25 +480,60 @@ __global__ __launch_bounds__(256) void gtx_align_hinted_kernel(GraphView g, Inde
       fwd = !hinted_one(g, ix, row, reinterpret_cast<uint8_t const *>(row), ROW_BYTES, m, rec, rec_words);
     }
   }
+  // Queue appends: ONE atomic per workgroup and queue (a device counter takes ~100 M returning atomics a second; one per
+  // wavefront -- 156 k per 10 M reads -- set the pace of this kernel).  Every wavefront posts its counts, the first one
+  // claims room for the workgroup, every wavefront writes at its offset.
   unsigned long long const F = __ballot(fwd), R = __ballot(rev);
-  if (F != 0)
+  if (lane == 0)
   {
-    uint32_t base = 0;
-    if (lane == 0)
-      base = atomicAdd(queue1_count, static_cast<uint32_t>(__builtin_popcountll(F)));
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (fwd)
-      queue1[base + static_cast<uint32_t>(__builtin_popcountll(F & ((1ull << lane) - 1ull)))] = read;
+    s_count[0][wave] = static_cast<uint32_t>(__builtin_popcountll(F));
+    s_count[1][wave] = static_cast<uint32_t>(__builtin_popcountll(R));
   }
-  if (R != 0)
+  __syncthreads();
+  if (threadIdx.x < 2)
   {
-    uint32_t base = 0;
-    if (lane == 0)
-      base = atomicAdd(queue2_count, static_cast<uint32_t>(__builtin_popcountll(R)));
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (rev)
-      queue2[base + static_cast<uint32_t>(__builtin_popcountll(R & ((1ull << lane) - 1ull)))] = read * 2 + 1;
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < WAVES; ++w)
+      total += s_count[threadIdx.x][w];
+    s_base[threadIdx.x] = total ? atomicAdd(threadIdx.x == 0 ? queue1_count : queue2_count, total) : 0u;
   }
+  __syncthreads();
+  uint32_t off1 = s_base[0], off2 = s_base[1];
+  for (uint32_t w = 0; w < WAVES; ++w)
+    if (w < wave)
+    {
+      off1 += s_count[0][w];
+      off2 += s_count[1][w];
+    }
+  if (fwd)
+    queue1[off1 + static_cast<uint32_t>(__builtin_popcountll(F & ((1ull << lane) - 1ull)))] = read;
+  if (rev)
+    queue2[off2 + static_cast<uint32_t>(__builtin_popcountll(R & ((1ull << lane) - 1ull)))] = read * 2 + 1;
+}
+
+#define GTX_HINTED_ARGS                                                                                                            \
+  GraphView g, IndexView ix, uint8_t const *__restrict__ seq, uint32_t seq_stride, gtx_read_meta const *__restrict__ meta,         \
+    uint32_t n_reads, uint32_t *__restrict__ records, uint32_t rec_words, uint32_t force_both, uint32_t *__restrict__ queue1,      \
+    uint32_t *queue1_count, uint32_t *__restrict__ queue2, uint32_t *queue2_count, uint32_t decline_all
+#define GTX_HINTED_PASS(W) hinted_pass<W>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, queue1, queue1_count, queue2, queue2_count, decline_all)
+
+#ifndef GTX_HINT_WAVES
+#define GTX_HINT_WAVES 16 // wavefronts per workgroup of the position-hinted pass
+#endif
+__global__ __launch_bounds__(64 * GTX_HINT_WAVES) void gtx_align_hinted_kernel(GTX_HINTED_ARGS)
+{
+  GTX_HINTED_PASS(GTX_HINT_WAVES);
+}
+
+// (smaller workgroups for A/B runs: GTX_HINT_WAVES=4 / 8 in the environment)
+__global__ __launch_bounds__(256) void gtx_align_hinted4_kernel(GTX_HINTED_ARGS)
+{
+  GTX_HINTED_PASS(4);
+}
+
+__global__ __launch_bounds__(512) void gtx_align_hinted8_kernel(GTX_HINTED_ARGS)
+{
+  GTX_HINTED_PASS(8);
 }
 
 // Pass 1 behind pass 0: express4 over the queue of forward tasks the position-hinted pass declined (four reads per
@@ -1124,9 +1161,12 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
   {
     // pass 0: one read per lane from the position hint; what it declines is queued for pass 1.  (GTX_HINT=decline: the
     // pass runs but declines everything -- a test of the queue plumbing)
-    hipLaunchKernelGGL(gtx_align_hinted_kernel, dim3((n_reads + 255u) / 256u), dim3(256), 0, st, c->dev_graph, c->dev_index, d_seq,
+    char const * hw = std::getenv("GTX_HINT_WAVES"); // A/B switch: wavefronts per workgroup of pass 0 (4, 8; default 16)
+    uint32_t const hint_threads = hw && hw[0] == '4' ? 256u : hw && hw[0] == '8' ? 512u : 64u * GTX_HINT_WAVES;
+    hipLaunchKernelGGL(hint_threads == 256u ? gtx_align_hinted4_kernel : hint_threads == 512u ? gtx_align_hinted8_kernel : gtx_align_hinted_kernel,
+                       dim3((n_reads + hint_threads - 1u) / hint_threads), dim3(hint_threads), 0, st, c->dev_graph, c->dev_index, d_seq,
                        seq_stride, d_meta, n_reads, d_records, rec_words, force_both, s->d_queue1, counters + 3, s->d_queue, counters + 2,
-                       static_cast<uint32_t>(force != 0 || (eh && eh[0] == 'd')));
+                       static_cast<uint32_t>(force != 0 || (eh && eh[0] == 'd')) | (eh && eh[0] == 'x' ? 2u : 0u));
     if (!hip_ok(hipGetLastError(), "gtx_align_hinted_kernel launch"))
       return GTX_ERR_HIP;
     mark(1);

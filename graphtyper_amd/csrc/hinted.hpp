@@ -182,28 +182,56 @@ GTX_DEV void hint_word(uint32_t rw, uint32_t gw, uint32_t have, HintCounts & h)
   h.more += static_cast<uint32_t>(__builtin_popcount(mt)) << 8;
 }
 
-template <uint32_t W, class Row>
-GTX_DEV void hint_compare_from(Row row, uint32_t seq_stride, uint32_t const * refw, uint32_t sh, uint32_t L, uint32_t prev, HintCounts & h)
+// Pins the counters in registers at this point.  Without it the optimiser sinks the per-word arithmetic to where the
+// counters are read -- behind all the loads' uses -- and keeps the forty loaded words alive until then: 130 VGPRs and 3
+// waves per SIMD.  (The pass is bound by memory latency times resident waves: registers are occupancy.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GTX_PIN(x) asm volatile("" : "+v"(x))
+#else
+#define GTX_PIN(x) ((void)0)
+#endif
+
+GTX_DEV void hint_pin(HintCounts & h)
+{
+  GTX_PIN(h.k[0]);
+  GTX_PIN(h.k[1]);
+  GTX_PIN(h.k[2]);
+  GTX_PIN(h.k[3]);
+  GTX_PIN(h.k[4]);
+  GTX_PIN(h.upto);
+  GTX_PIN(h.more);
+}
+
+template <uint32_t W>
+GTX_DEV void hint_compare_words(uint32_t const (&rr)[HINT_WORDS], uint32_t const (&gg)[HINT_WORDS + 1], uint32_t sh, uint32_t L, HintCounts & h)
 {
   if constexpr (W < HINT_WORDS)
   {
-    // (no branches around the loads: the reference array is padded by HINT_WORDS + 1 words and a row has at least
-    // seq_stride bytes, so every lane may load every word and the loads of all words are in flight together; what
-    // lies beyond the read is masked inside hint_word)
     uint32_t const have = L > 8 * W ? L - 8 * W : 0u; // bases of the read in this word
-    bool const in_row = 4 * W < seq_stride; // (uniform; a select, not a branch around the load)
-    uint32_t const rw = hint_bswap(row[in_row ? W : 0u]) & (in_row ? 0xFFFFFFFFu : 0u);
-    uint32_t const next = refw[W + 1];
-    uint32_t const gw = sh == 0 ? prev : ((prev << sh) | (next >> (32 - sh)));
-    hint_word<W>(rw, gw, have, h);
-    hint_compare_from<W + 1>(row, seq_stride, refw, sh, L, next, h);
+    uint32_t const gw = sh == 0 ? gg[W] : ((gg[W] << sh) | (gg[W + 1] >> (32 - sh)));
+    hint_word<W>(hint_bswap(rr[W]), gw, have, h);
+    hint_pin(h);
+    hint_compare_words<W + 1>(rr, gg, sh, L, h);
   }
 }
 
+// No branches around the loads: the reference array is padded by HINT_WORDS + 4 words and a row has at least seq_stride
+// bytes, so every lane may load every word and all loads are in flight together; what lies beyond the read is masked
+// inside hint_word.
 template <class Row>
 GTX_DEV void hint_compare(Row row, uint32_t seq_stride, uint32_t const * refw, uint32_t sh, uint32_t L, HintCounts & h)
 {
-  hint_compare_from<0>(row, seq_stride, refw, sh, L, refw[0], h);
+  uint32_t rr[HINT_WORDS], gg[HINT_WORDS + 1];
+#pragma unroll
+  for (uint32_t w = 0; w <= HINT_WORDS; ++w)
+    gg[w] = refw[w];
+#pragma unroll
+  for (uint32_t w = 0; w < HINT_WORDS; ++w)
+  {
+    bool const in_row = 4 * w < seq_stride; // (uniform; a select, not a branch around the load)
+    rr[w] = row[in_row ? w : 0u] & (in_row ? 0xFFFFFFFFu : 0u);
+  }
+  hint_compare_words<0>(rr, gg, sh, L, h);
 }
 
 enum : uint32_t
@@ -487,7 +515,7 @@ GTX_DEV bool hinted_one(GraphView const & g, IndexView const & ix, Row row, uint
   }
   // ---- variant sites of the path, most recent k-mer first (Path(p1, p2), path.cpp:38-82); a site under two
   //      neighbouring k-mers is one entry (the same base, hence the same allele)
-  uint32_t vs[5];
+  uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0; // (named registers: an indexed array would live in scratch memory)
   uint32_t nvar = 0;
   uint32_t last = HINT_NO_SITE << HK_SITE_SHIFT;
   bool clash = false;
@@ -500,7 +528,12 @@ GTX_DEV bool hinted_one(GraphView const & g, IndexView const & ix, Row row, uint
         clash = clash || entry != last;
       else
       {
-        vs[nvar++] = entry;
+        v0 = nvar == 0 ? entry : v0;
+        v1 = nvar == 1 ? entry : v1;
+        v2 = nvar == 2 ? entry : v2;
+        v3 = nvar == 3 ? entry : v3;
+        v4 = nvar == 4 ? entry : v4;
+        ++nvar;
         last = entry;
       }
     }
@@ -526,13 +559,20 @@ GTX_DEV bool hinted_one(GraphView const & g, IndexView const & ix, Row row, uint
     rec[3] = end;
     rec[4] = rs | (re << 16);
     rec[5] = mism | (nvar << 16);
-    for (uint32_t k = 0; k < 5; ++k)
+    auto put = [&](uint32_t k, uint32_t entry)
+    {
       if (k < nvar)
       {
-        rec[6 + 3 * k] = vs[k] >> HK_SITE_SHIFT;
-        rec[7 + 3 * k] = 1u << ((vs[k] >> HK_ALLELE_SHIFT) & 3u);
+        rec[6 + 3 * k] = entry >> HK_SITE_SHIFT;
+        rec[7 + 3 * k] = 1u << ((entry >> HK_ALLELE_SHIFT) & 3u);
         rec[8 + 3 * k] = 0u;
       }
+    };
+    put(0, v0);
+    put(1, v1);
+    put(2, v2);
+    put(3, v3);
+    put(4, v4);
   }
   return true;
 }
