@@ -979,6 +979,7 @@ int ctx_upload(gtx_ctx & c, int device)
   ok = ok && upload(c.dev_allocs, ix.hlist, c.index.hlist.data(), c.index.hlist.size(), "half-key buckets");
   ok = ok && upload(c.dev_allocs, ix.ref4, c.index.ref4.data(), c.index.ref4.size(), "reference nibbles");
   ok = ok && upload(c.dev_allocs, ix.pos_flags, c.index.pos_flags.data(), c.index.pos_flags.size(), "position flags");
+  ok = ok && upload(c.dev_allocs, ix.tail_info, c.index.tail_info.data(), c.index.tail_info.size(), "tail sites");
   ok = ok && upload(c.dev_allocs, ix.filt[0], c.index.filt[0].data(), c.index.filt[0].size(), "half-key filter 0");
   ok = ok && upload(c.dev_allocs, ix.filt[1], c.index.filt[1].data(), c.index.filt[1].size(), "half-key filter 1");
   void * pf = nullptr;

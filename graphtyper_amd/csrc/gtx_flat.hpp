@@ -129,8 +129,13 @@ struct IndexView
   //     bits 8..15      min(255, bases of that node in front of the position).
   // filt[side]: blocked Bloom filter over every indexed key's 16 first (side 0) / last (side 1) bases in nibble form (two
   //   bits of one word per half): a clear bit proves that no indexed key has that half.
+  // tail_info[i]: the site behind the reference node position i lies in, when a walk from i may cross it the simple way
+  //   (a SNP: 2..4 alleles of one base A/C/G/T each; not in an SV graph):  x = HINT_TAIL_OK | alleles << 2 (count, 3 bits) |
+  //   min(255, length of the reference node behind the site) << 8 | the alleles' nibble codes << 16 (4 bits each);
+  //   y = the site's index.
   const uint32_t * ref4;
   const uint2_t * pos_flags;
+  const uint2_t * tail_info;
   const uint32_t * filt[2];
   uint32_t hint_first, n_hint, filt_log2 /* log2 of the number of words */, pad_hint;
 };
@@ -139,6 +144,7 @@ constexpr uint32_t HINT_EXACT_OK = 1u, HINT_SINGLE_OK = 2u, HINT_L1 = 4u, HINT_R
 constexpr uint32_t HINT_ALTIDX_SHIFT = 8u, HINT_SITE_SHIFT = 12u + 4u; // x: flags 0..7, allele numbers 8..15, site 16..31
 constexpr uint32_t HINT_NO_SITE = 0xFFFFu;
 constexpr uint32_t HINT_BACK_SHIFT = 8u, HINT_SNPOFF_SHIFT = 16u; // y
+constexpr uint32_t HINT_TAIL_OK = 1u, HINT_TAIL_NALL_SHIFT = 2u, HINT_TAIL_NEXT_SHIFT = 8u, HINT_TAIL_CODES_SHIFT = 16u; // tail_info.x
 // limits of express4's lean seeding rule that HINT_EXACT_OK restates on the host (static_asserts in express4.inl)
 constexpr uint32_t HINT_HE_CAP = 4, HINT_NB_MAX = 3;
 
@@ -195,7 +201,7 @@ struct HostIndex
   uint32_t h_log2_cap = 0;
   // position-hinted pass (IndexView::ref4 ...)
   std::vector<uint32_t> ref4, filt[2];
-  std::vector<uint2_t> pos_flags;
+  std::vector<uint2_t> pos_flags, tail_info;
   uint32_t hint_first = 0, n_hint = 0, filt_log2 = 0;
 
   IndexView view(uint32_t max_index_labels, uint32_t half_bucket_cap) const; // over the host copies

@@ -529,6 +529,7 @@ IndexView HostIndex::view(uint32_t max_index_labels, uint32_t half_bucket_cap) c
   ix.half_bucket_cap = half_bucket_cap;
   ix.ref4 = ref4.data();
   ix.pos_flags = pos_flags.data();
+  ix.tail_info = tail_info.data();
   ix.filt[0] = filt[0].data();
   ix.filt[1] = filt[1].data();
   ix.hint_first = hint_first;
@@ -545,6 +546,7 @@ static void build_hints(HostGraph const & g, HostIndex & out)
   uint32_t const R = static_cast<uint32_t>(g.ref_order.size());
   out.ref4.clear();
   out.pos_flags.clear();
+  out.tail_info.clear();
   out.filt[0].clear();
   out.filt[1].clear();
   out.n_hint = 0;
@@ -554,6 +556,7 @@ static void build_hints(HostGraph const & g, HostIndex & out)
   {
     out.ref4.assign(32, 0);
     out.pos_flags.assign(1, uint2_t{0, 0});
+    out.tail_info.assign(1, uint2_t{0, 0});
     out.filt[0].assign(1, 0);
     out.filt[1].assign(1, 0);
     return;
@@ -580,6 +583,27 @@ static void build_hints(HostGraph const & g, HostIndex & out)
       for (uint32_t d = 0; d < g.var_len[v]; ++d)
         base[vat + d] = nib(g.dna[g.var_dna[v] + d]);
     }
+  }
+  // the site behind every reference node, as a walk at the read's end may cross it (tail_info)
+  out.tail_info.assign(n, uint2_t{0, 0});
+  for (uint32_t r = 0; r + 1 < R && !g.is_sv_graph; ++r)
+  {
+    uint32_t const fv = g.ref_first_var[r], nv = g.ref_nvar[r];
+    bool snp = nv >= 2 && nv <= 4;
+    uint32_t codes = 0;
+    for (uint32_t a = 0; a < nv && snp; ++a)
+    {
+      uint8_t const c = g.var_len[fv + a] == 1 ? nib(g.dna[g.var_dna[fv + a]]) : 15;
+      snp = c != 15;
+      codes |= static_cast<uint32_t>(c) << (4 * a);
+    }
+    if (!snp)
+      continue;
+    uint32_t const next_len = g.ref_len[r + 1] < 255 ? g.ref_len[r + 1] : 255;
+    uint2_t const t{HINT_TAIL_OK | (nv << HINT_TAIL_NALL_SHIFT) | (next_len << HINT_TAIL_NEXT_SHIFT) | (codes << HINT_TAIL_CODES_SHIFT), r};
+    uint32_t const at = g.ref_order[r] - first;
+    for (uint32_t d = 0; d < g.ref_len[r]; ++d)
+      out.tail_info[at + d] = t;
   }
   out.n_hint = n;
   out.ref4.assign(n / 8 + 24, 0); // (padded: the kernel loads 21 words from any position without a bounds test)

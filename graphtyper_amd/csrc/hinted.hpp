@@ -392,6 +392,7 @@ GTX_DEV bool hinted_one(GraphView const & g, IndexView const & ix, Row row, uint
   uint2_t const f2 = ix.pos_flags[idx + (n_k > 2 ? 2 * (K - 1) : 0u)], f3 = ix.pos_flags[idx + (n_k > 3 ? 3 * (K - 1) : 0u)];
   uint2_t const f4 = ix.pos_flags[idx + (n_k > 4 ? 4 * (K - 1) : 0u)];
   uint32_t const y_end = ix.pos_flags[idx + (K - 1) * n_k].y; // the position behind the last k-mer (31 n_k <= L - 1: inside the read)
+  uint2_t const t_end = ix.tail_info[idx + (K - 1) * n_k];    // ... and the site behind its reference node
   hint_compare(row, seq_stride, refw, sh, L, h);
   // ---- every k-mer: the label of its place, no label at all, or not provable
   uint32_t const none = hk_make(HINT_K_HOLE, HINT_NO_SITE, 0u, false, false);
@@ -495,16 +496,50 @@ GTX_DEV bool hinted_one(GraphView const & g, IndexView const & ix, Row row, uint
     }
   }
   uint32_t end = g.first_order + idx + pre, re = pre;
+  uint32_t tail_site = 0, tail_mask = 0; // the site the walk at the read's end crossed, with its best alleles
   if (pre != L - 1) // walk_read_ends (genotype_paths.cpp:483-553)
   {
     uint32_t const tail_len = L - pre;
     uint32_t const y = hi + 1 == n_k ? y_end : hi == 0 ? f1.y : hi == 1 ? f2.y : hi == 2 ? f3.y : f4.y;
-    if ((y & 255u) < tail_len)
+    uint32_t const room = y & 255u;
+    uint32_t got = hc_all(h) - hc_upto(h, hi + 1);
+    if (room < tail_len)
     {
-      GTX_HINT_NOTE(8);
-      return false; // (the tail leaves the node, or the path ends on a variant: express4)
+      // The tail leaves the node.  Over ONE site whose alleles are single bases, with the rest inside the reference node
+      // behind it, Graph::get_labels_forward has one candidate per allele, they differ in that character only, and the
+      // labels of the best ones share their ends: one path with the site's best alleles (express4.inl, lean build).  The
+      // reference allele and the node behind the site ARE the linear reference, so the compare above already holds
+      // every other character.
+      uint32_t const at = room; // tail character that lies on the site
+      uint32_t const next_len = (t_end.x >> HINT_TAIL_NEXT_SHIFT) & 255u;
+      if (hi + 1 != n_k || room == 0 || (t_end.x & HINT_TAIL_OK) == 0 || next_len < tail_len - at - 1)
+      {
+        GTX_HINT_NOTE(8);
+        return false; // (ends on a variant, an indel, a second site: express4 / general pass)
+      }
+      uint32_t const p = pre + at;
+      uint32_t const rc0 = (seq4[p >> 1] >> ((~p & 1u) << 2)) & 15u, rc = rc0 == 0 ? 15u : rc0; // ('=' reads as N)
+      uint32_t const nall = (t_end.x >> HINT_TAIL_NALL_SHIFT) & 7u, codes = t_end.x >> HINT_TAIL_CODES_SHIFT;
+      uint32_t best = 2, mask = 0;
+#pragma unroll
+      for (uint32_t a = 0; a < 4; ++a)
+        if (a < nall)
+        {
+          uint32_t const gc = (codes >> (4 * a)) & 15u;
+          uint32_t const xa = (gc != rc && rc != 15u) ? 1u : 0u; // (the alleles are A, C, G or T)
+          if (xa < best)
+          {
+            best = xa;
+            mask = 0;
+          }
+          if (xa == best)
+            mask |= 1u << a;
+        }
+      uint32_t const x0 = ((codes & 15u) != rc && rc != 15u) ? 1u : 0u; // what the compare with the reference allele counted there
+      got = got - x0 + best;
+      tail_site = t_end.y;
+      tail_mask = mask;
     }
-    uint32_t const got = hc_all(h) - hc_upto(h, hi + 1);
     uint32_t const budget = 2 + tail_len / 11 < 7 ? 2 + tail_len / 11 : 7; // genotype_paths.cpp:505-511
     if (got <= budget)
     {
@@ -512,32 +547,38 @@ GTX_DEV bool hinted_one(GraphView const & g, IndexView const & ix, Row row, uint
       mism += got;
       end += tail_len - 1;
     }
+    else
+      tail_mask = 0; // (the path stays as it is: no site from the walk)
   }
   // ---- variant sites of the path, most recent k-mer first (Path(p1, p2), path.cpp:38-82); a site under two
   //      neighbouring k-mers is one entry (the same base, hence the same allele)
-  uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0; // (named registers: an indexed array would live in scratch memory)
+  uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0; // site << 16 | allele mask (named registers: an indexed array would live in scratch)
   uint32_t nvar = 0;
-  uint32_t last = HINT_NO_SITE << HK_SITE_SHIFT;
+  uint32_t last = 0xFFFFFFFFu;
   bool clash = false;
+  auto append = [&](uint32_t entry)
+  {
+    if ((entry >> 16) == (last >> 16))
+      clash = clash || entry != last;
+    else
+    {
+      v0 = nvar == 0 ? entry : v0;
+      v1 = nvar == 1 ? entry : v1;
+      v2 = nvar == 2 ? entry : v2;
+      v3 = nvar == 3 ? entry : v3;
+      v4 = nvar == 4 ? entry : v4;
+      v5 = nvar == 5 ? entry : v5;
+      ++nvar;
+      last = entry;
+    }
+  };
   auto push = [&](uint32_t k, uint32_t km)
   {
     if (((run >> k) & 1u) && (km >> HK_SITE_SHIFT) != HINT_NO_SITE)
-    {
-      uint32_t const entry = km & ((0xFFFFu << HK_SITE_SHIFT) | (3u << HK_ALLELE_SHIFT));
-      if ((entry >> HK_SITE_SHIFT) == (last >> HK_SITE_SHIFT))
-        clash = clash || entry != last;
-      else
-      {
-        v0 = nvar == 0 ? entry : v0;
-        v1 = nvar == 1 ? entry : v1;
-        v2 = nvar == 2 ? entry : v2;
-        v3 = nvar == 3 ? entry : v3;
-        v4 = nvar == 4 ? entry : v4;
-        ++nvar;
-        last = entry;
-      }
-    }
+      append(((km >> HK_SITE_SHIFT) << 16) | (1u << ((km >> HK_ALLELE_SHIFT) & 3u)));
   };
+  if (tail_mask != 0) // (the walk's labels are merged last: their site comes first)
+    append((tail_site << 16) | tail_mask);
   push(4, k4);
   push(3, k3);
   push(2, k2);
@@ -563,8 +604,8 @@ GTX_DEV bool hinted_one(GraphView const & g, IndexView const & ix, Row row, uint
     {
       if (k < nvar)
       {
-        rec[6 + 3 * k] = entry >> HK_SITE_SHIFT;
-        rec[7 + 3 * k] = 1u << ((entry >> HK_ALLELE_SHIFT) & 3u);
+        rec[6 + 3 * k] = entry >> 16;
+        rec[7 + 3 * k] = entry & 0xFFFFu;
         rec[8 + 3 * k] = 0u;
       }
     };
@@ -573,6 +614,7 @@ GTX_DEV bool hinted_one(GraphView const & g, IndexView const & ix, Row row, uint
     put(2, v2);
     put(3, v3);
     put(4, v4);
+    put(5, v5);
   }
   return true;
 }
