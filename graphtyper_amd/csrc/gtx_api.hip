@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void gt
                                                        uint32_t * __restrict__ records, uint32_t rec_words,
                                                        uint32_t const * __restrict__ queue, uint32_t const * queue_count,
                                                        uint32_t * task_counter, uint32_t * __restrict__ big_tasks,
-                                                       uint32_t big_task_cap, uint32_t * big_state, uint32_t force_big)
+                                                       uint32_t big_task_cap, uint32_t * big_state, uint32_t force_big, uint32_t task_base)
 {
   __shared__ AlignWorkspace ws;
 #ifdef GTX_PROF
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void gt
     {
       uint32_t const slot = atomicAdd(big_state, 1u);
       if (slot < big_task_cap)
-        big_tasks[slot] = task;
+        big_tasks[slot] = task_base + task; // (the HBM-table pass runs once over the whole batch)
       else
         atomicAdd(big_state + 3, 1u);
     }
@@ -838,9 +838,15 @@ static void scratch_free(CallScratch & s)
   for (void * p : ptrs)
     if (p)
       (void)hipFree(p);
-  for (auto & e : s.pass_events)
+  for (auto & row : s.time_events)
+    for (auto & e : row)
+      if (e)
+        (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+  for (auto & e : s.sync_events)
     if (e)
       (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+  if (s.side_stream)
+    (void)hipStreamDestroy(static_cast<hipStream_t>(s.side_stream));
   if (s.done)
     (void)hipEventDestroy(static_cast<hipEvent_t>(s.done));
   s = CallScratch();
@@ -853,7 +859,7 @@ static std::unique_ptr<CallScratch> scratch_new(gtx_ctx & c)
   bool ok = hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "scratch event");
   if (ok)
     s->done = ev;
-  ok = ok && dev_alloc(s->d_counters, 8, "task counters", true);
+  ok = ok && dev_alloc(s->d_counters, 8 * CallScratch::MAX_PARTS, "task counters", true);
   if (ok && !c.params.no_second_pass)
   {
     ok = ok && dev_alloc(s->d_big_state, 8, "second-pass state", true);
@@ -1103,8 +1109,7 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
   CallScratch * s = hold.s;
   if (!s)
     return GTX_ERR_HIP;
-  uint32_t * counters = s->d_counters;
-  if (!hip_ok(hipMemsetAsync(counters, 0, 8 * sizeof(uint32_t), st), "task counter reset"))
+  if (!hip_ok(hipMemsetAsync(s->d_counters, 0, 8 * CallScratch::MAX_PARTS * sizeof(uint32_t), st), "task counter reset"))
     return GTX_ERR_HIP;
   // queues: room for every task (a graph on which no read is simple sends them all)
   if (!grow(s->d_queue, s->queue_cap, 2ull * n_reads, "pass-2 queue") || !grow(s->d_queue1, s->queue1_cap, n_reads, "pass-1 queue"))
@@ -1124,30 +1129,12 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
   // test switch: 1 = every task goes through all passes (the last one decides), 2 = every task is done by pass 2
   char const * fb = std::getenv("GTX_FORCE_SECOND_PASS");
   uint32_t const force = fb ? static_cast<uint32_t>(std::atoi(fb)) : 0u;
-  // grids: as many single-wave workgroups as are resident at once; they pull work from shared counters
   uint32_t const n_cu = static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256);
-  uint64_t const chunks = (static_cast<uint64_t>(n_reads) + TASK_CHUNK - 1) / TASK_CHUNK;
-  uint32_t const blocks1 = static_cast<uint32_t>(std::min<uint64_t>(chunks, static_cast<uint64_t>(n_cu) * c->express_blocks_per_cu));
-  uint32_t const blocks2 = static_cast<uint32_t>(std::min<uint64_t>(2ull * n_reads, static_cast<uint64_t>(n_cu) * c->align_blocks_per_cu));
   bool timed = false;
   {
     std::lock_guard<std::mutex> lock(c->pool_mutex);
     timed = c->timing_armed;
   }
-  if (timed && !s->pass_events[0])
-    for (auto & e : s->pass_events)
-    {
-      hipEvent_t ev;
-      if (!hip_ok(hipEventCreate(&ev), "pass events"))
-        return GTX_ERR_HIP;
-      e = ev;
-    }
-  s->timed = false;
-  auto mark = [&](int k)
-  {
-    if (timed)
-      (void)hipEventRecord(static_cast<hipEvent_t>(s->pass_events[k]), st);
-  };
   uint32_t const force_both = static_cast<uint32_t>(c->params.force_align_both_orientations != 0);
   char const * e4 = std::getenv("GTX_EXPRESS4"); // A/B switch: 0 = one read per wavefront in pass 1
   char const * eh = std::getenv("GTX_HINT");     // A/B switch: 0 = no position-hinted pass
@@ -1155,57 +1142,129 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
   bool const hinted = four && !(eh && eh[0] == '0');
   // GTX_EXPRESS4=lean / wide force a build (tests); else by the graph's density
   bool const wide = e4 && e4[0] == 'w' ? true : e4 && e4[0] == 'l' ? false : c->express4_wide;
-  uint32_t const blocks4 = static_cast<uint32_t>(std::min<uint64_t>(
-    chunks, static_cast<uint64_t>(n_cu) * (wide ? c->express4_wide_blocks_per_cu : c->express4_blocks_per_cu)));
-  mark(0);
-  if (hinted)
+  // A large batch is cut into parts.  The general pass of a part -- few tasks, each a long chain of dependent memory
+  // round trips on one wavefront -- runs on a second stream beside the position-hinted and express passes of the next
+  // part, which leave most of a CU's wave slots and issue cycles idle while they wait for memory themselves.
+  char const * ep = std::getenv("GTX_PARTS"); // A/B switch: number of parts (1 = no overlap)
+  uint32_t parts = hinted && n_reads >= (1u << 20) ? 4u : 1u;
+  if (ep)
+    parts = static_cast<uint32_t>(std::min<long>(std::max<long>(std::atol(ep), 1), CallScratch::MAX_PARTS));
+  if (parts > 1 && !s->side_stream)
   {
-    // pass 0: one read per lane from the position hint; what it declines is queued for pass 1.  (GTX_HINT=decline: the
-    // pass runs but declines everything -- a test of the queue plumbing)
-    char const * hw = std::getenv("GTX_HINT_WAVES"); // A/B switch: wavefronts per workgroup of pass 0 (4, 8; default 16)
-    uint32_t const hint_threads = hw && hw[0] == '4' ? 256u : hw && hw[0] == '8' ? 512u : 64u * GTX_HINT_WAVES;
-    hipLaunchKernelGGL(hint_threads == 256u ? gtx_align_hinted4_kernel : hint_threads == 512u ? gtx_align_hinted8_kernel : gtx_align_hinted_kernel,
-                       dim3((n_reads + hint_threads - 1u) / hint_threads), dim3(hint_threads), 0, st, c->dev_graph, c->dev_index, d_seq,
-                       seq_stride, d_meta, n_reads, d_records, rec_words, force_both, s->d_queue1, counters + 3, s->d_queue, counters + 2,
-                       static_cast<uint32_t>(force != 0 || (eh && eh[0] == 'd')) | (eh && eh[0] == 'x' ? 2u : 0u));
-    if (!hip_ok(hipGetLastError(), "gtx_align_hinted_kernel launch"))
+    hipStream_t side;
+    if (!hip_ok(hipStreamCreateWithFlags(&side, hipStreamNonBlocking), "side stream"))
       return GTX_ERR_HIP;
-    mark(1);
-    hipLaunchKernelGGL(wide ? gtx_align_express4q_wide_kernel : gtx_align_express4q_kernel, dim3(blocks4), dim3(64), 0, st, c->dev_graph,
-                       c->dev_index, d_seq, seq_stride, d_meta, d_records, rec_words, counters, s->d_queue1, counters + 3, s->d_queue,
-                       counters + 2, counters + 4, static_cast<uint32_t>(force != 0));
+    s->side_stream = side;
+    for (auto & e : s->sync_events)
+    {
+      hipEvent_t ev;
+      if (!hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "sync events"))
+        return GTX_ERR_HIP;
+      e = ev;
+    }
   }
-  else
+  if (timed && !s->time_events[0][0])
+    for (auto & row : s->time_events)
+      for (auto & e : row)
+      {
+        hipEvent_t ev;
+        if (!hip_ok(hipEventCreate(&ev), "pass events"))
+          return GTX_ERR_HIP;
+        e = ev;
+      }
+  s->timed = false;
+  hipStream_t const sg = parts > 1 ? static_cast<hipStream_t>(s->side_stream) : st; // stream of the general / HBM-table passes
+  auto mark = [&](uint32_t part, int k, hipStream_t on)
   {
-    mark(1);
-    if (four)
-      hipLaunchKernelGGL(wide ? gtx_align_express4_wide_kernel : gtx_align_express4_kernel, dim3(blocks4), dim3(64), 0, st, c->dev_graph,
-                         c->dev_index, d_seq, seq_stride, d_meta, n_reads, d_records, rec_words, force_both, counters, s->d_queue,
-                         counters + 2, static_cast<uint32_t>(force != 0));
-    else
-      hipLaunchKernelGGL(gtx_align_express_kernel, dim3(blocks1), dim3(64), 0, st, c->dev_graph, c->dev_index, d_seq, seq_stride, d_meta,
-                         n_reads, d_records, rec_words, force_both, counters, s->d_queue, counters + 2, static_cast<uint32_t>(force != 0));
+    if (timed)
+      (void)hipEventRecord(static_cast<hipEvent_t>(s->time_events[part][k]), on);
+  };
+  if (parts > 1)
+  {
+    // (the side stream starts behind everything the caller's stream holds so far: the resets above, the caller's uploads)
+    (void)hipEventRecord(static_cast<hipEvent_t>(s->sync_events[CallScratch::MAX_PARTS]), st);
+    (void)hipStreamWaitEvent(sg, static_cast<hipEvent_t>(s->sync_events[CallScratch::MAX_PARTS]), 0);
   }
-  if (!hip_ok(hipGetLastError(), "express kernel launch"))
-    return GTX_ERR_HIP;
-  mark(2);
-  hipLaunchKernelGGL(gtx_align_kernel, dim3(blocks2), dim3(64), 0, st, c->dev_graph, c->dev_index, d_seq, seq_stride, d_meta, d_records,
-                     rec_words, s->d_queue, counters + 2, counters + 1, second_pass ? s->d_big_tasks : nullptr, s->big_task_cap,
-                     s->d_big_state, static_cast<uint32_t>(force == 1));
-  if (!hip_ok(hipGetLastError(), "gtx_align_kernel launch"))
-    return GTX_ERR_HIP;
-  mark(3);
+  uint32_t const step = parts == 1 ? n_reads : ((n_reads / parts + 1023u) / 1024u) * 1024u;
+  uint32_t used_parts = 0;
+  for (uint32_t first = 0; first < n_reads; first += step, ++used_parts)
+  {
+    uint32_t const n = std::min(step, n_reads - first), part = used_parts;
+    uint32_t * counters = s->d_counters + 8 * part;
+    uint8_t const * seq = d_seq + static_cast<uint64_t>(first) * seq_stride;
+    gtx_read_meta const * meta = d_meta + first;
+    uint32_t * records = d_records + static_cast<uint64_t>(first) * 2 * rec_words;
+    uint32_t * queue1 = s->d_queue1 + first;
+    uint32_t * queue2 = s->d_queue + 2ull * first;
+    // grids: as many single-wave workgroups as are resident at once; they pull work from shared counters
+    uint64_t const chunks = (static_cast<uint64_t>(n) + TASK_CHUNK - 1) / TASK_CHUNK;
+    uint32_t const blocks1 = static_cast<uint32_t>(std::min<uint64_t>(chunks, static_cast<uint64_t>(n_cu) * c->express_blocks_per_cu));
+    uint32_t const blocks2 = static_cast<uint32_t>(std::min<uint64_t>(2ull * n, static_cast<uint64_t>(n_cu) * c->align_blocks_per_cu));
+    uint32_t const blocks4 = static_cast<uint32_t>(std::min<uint64_t>(
+      chunks, static_cast<uint64_t>(n_cu) * (wide ? c->express4_wide_blocks_per_cu : c->express4_blocks_per_cu)));
+    mark(part, 0, st);
+    if (hinted)
+    {
+      // pass 0: one read per lane from the position hint; what it declines is queued for pass 1.  (GTX_HINT=decline: the
+      // pass runs but declines everything -- a test of the queue plumbing)
+      char const * hw = std::getenv("GTX_HINT_WAVES"); // A/B switch: wavefronts per workgroup of pass 0 (4, 8; default 16)
+      uint32_t const hint_threads = hw && hw[0] == '4' ? 256u : hw && hw[0] == '8' ? 512u : 64u * GTX_HINT_WAVES;
+      hipLaunchKernelGGL(hint_threads == 256u ? gtx_align_hinted4_kernel : hint_threads == 512u ? gtx_align_hinted8_kernel : gtx_align_hinted_kernel,
+                         dim3((n + hint_threads - 1u) / hint_threads), dim3(hint_threads), 0, st, c->dev_graph, c->dev_index, seq, seq_stride,
+                         meta, n, records, rec_words, force_both, queue1, counters + 3, queue2, counters + 2,
+                         static_cast<uint32_t>(force != 0 || (eh && eh[0] == 'd')) | (eh && eh[0] == 'x' ? 2u : 0u));
+      if (!hip_ok(hipGetLastError(), "gtx_align_hinted_kernel launch"))
+        return GTX_ERR_HIP;
+      mark(part, 1, st);
+      hipLaunchKernelGGL(wide ? gtx_align_express4q_wide_kernel : gtx_align_express4q_kernel, dim3(blocks4), dim3(64), 0, st, c->dev_graph,
+                         c->dev_index, seq, seq_stride, meta, records, rec_words, counters, queue1, counters + 3, queue2, counters + 2,
+                         counters + 4, static_cast<uint32_t>(force != 0));
+    }
+    else
+    {
+      mark(part, 1, st);
+      if (four)
+        hipLaunchKernelGGL(wide ? gtx_align_express4_wide_kernel : gtx_align_express4_kernel, dim3(blocks4), dim3(64), 0, st, c->dev_graph,
+                           c->dev_index, seq, seq_stride, meta, n, records, rec_words, force_both, counters, queue2, counters + 2,
+                           static_cast<uint32_t>(force != 0));
+      else
+        hipLaunchKernelGGL(gtx_align_express_kernel, dim3(blocks1), dim3(64), 0, st, c->dev_graph, c->dev_index, seq, seq_stride, meta, n,
+                           records, rec_words, force_both, counters, queue2, counters + 2, static_cast<uint32_t>(force != 0));
+    }
+    if (!hip_ok(hipGetLastError(), "express kernel launch"))
+      return GTX_ERR_HIP;
+    mark(part, 2, st);
+    if (parts > 1)
+    {
+      (void)hipEventRecord(static_cast<hipEvent_t>(s->sync_events[part]), st);
+      (void)hipStreamWaitEvent(sg, static_cast<hipEvent_t>(s->sync_events[part]), 0);
+    }
+    mark(part, 3, sg);
+    hipLaunchKernelGGL(gtx_align_kernel, dim3(blocks2), dim3(64), 0, sg, c->dev_graph, c->dev_index, seq, seq_stride, meta, records, rec_words,
+                       queue2, counters + 2, counters + 1, second_pass ? s->d_big_tasks : nullptr, s->big_task_cap, s->d_big_state,
+                       static_cast<uint32_t>(force == 1), 2u * first);
+    if (!hip_ok(hipGetLastError(), "gtx_align_kernel launch"))
+      return GTX_ERR_HIP;
+    mark(part, 4, sg);
+  }
   if (second_pass)
   {
-    hipLaunchKernelGGL(gtx_align_big_kernel, dim3(c->big_blocks), dim3(64), 0, st, c->dev_graph, c->dev_index, d_seq, seq_stride, d_meta,
+    hipLaunchKernelGGL(gtx_align_big_kernel, dim3(c->big_blocks), dim3(64), 0, sg, c->dev_graph, c->dev_index, d_seq, seq_stride, d_meta,
                        d_records, rec_words, s->d_big_tasks, s->big_task_cap, s->d_big_state, static_cast<big::AlignWorkspace *>(s->d_big_ws),
                        c->d_big_records, static_cast<unsigned long long>(c->big_record_words), c->d_arena_cursor);
     if (!hip_ok(hipGetLastError(), "gtx_align_big_kernel launch"))
       return GTX_ERR_HIP;
   }
-  mark(4);
+  mark(0, 5, sg);
+  if (parts > 1)
+  {
+    // the caller's stream goes on when the side stream is through
+    (void)hipEventRecord(static_cast<hipEvent_t>(s->sync_events[CallScratch::MAX_PARTS]), sg);
+    (void)hipStreamWaitEvent(st, static_cast<hipEvent_t>(s->sync_events[CallScratch::MAX_PARTS]), 0);
+  }
   s->timed = timed;
   s->timed_reads = n_reads;
+  s->timed_parts = used_parts;
   return GTX_OK;
 }
 
@@ -1231,20 +1290,40 @@ static int kernel_times(gtx_ctx * c, float * ms, uint32_t * tasks)
   }
   if (!s || !s->timed)
     return GTX_OK; // nothing was timed yet
-  if (!hip_ok(hipSetDevice(c->device), "hipSetDevice") || !hip_ok(hipEventSynchronize(static_cast<hipEvent_t>(s->pass_events[4])), "pass events"))
+  if (!hip_ok(hipSetDevice(c->device), "hipSetDevice") || !hip_ok(hipEventSynchronize(static_cast<hipEvent_t>(s->time_events[0][5])), "pass events"))
     return GTX_ERR_HIP;
-  for (int k = 0; k < 4; ++k)
-    (void)hipEventElapsedTime(ms + k, static_cast<hipEvent_t>(s->pass_events[k]), static_cast<hipEvent_t>(s->pass_events[k + 1]));
-  uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, big[4] = {0, 0, 0, 0};
+  uint32_t cnt[8 * CallScratch::MAX_PARTS] = {}, big[4] = {0, 0, 0, 0};
   (void)hipMemcpy(cnt, s->d_counters, sizeof(cnt), hipMemcpyDeviceToHost);
   if (s->d_big_state)
     (void)hipMemcpy(big, s->d_big_state, sizeof(big), hipMemcpyDeviceToHost);
+  uint32_t queued2 = 0, queued1 = 0, handed = 0;
+  float last_general_end = 0.0f;
+  for (uint32_t p = 0; p < s->timed_parts; ++p)
+  {
+    float d = 0.0f;
+    auto ev = [&](int k) { return static_cast<hipEvent_t>(s->time_events[p][k]); };
+    if (hipEventElapsedTime(&d, ev(0), ev(1)) == hipSuccess)
+      ms[0] += d;
+    if (hipEventElapsedTime(&d, ev(1), ev(2)) == hipSuccess)
+      ms[1] += d;
+    if (hipEventElapsedTime(&d, ev(3), ev(4)) == hipSuccess)
+      ms[2] += d;
+    queued2 += cnt[8 * p + 2];
+    queued1 += cnt[8 * p + 3];
+    handed += cnt[8 * p + 4];
+    (void)last_general_end;
+  }
+  {
+    float d = 0.0f;
+    if (hipEventElapsedTime(&d, static_cast<hipEvent_t>(s->time_events[s->timed_parts - 1][4]), static_cast<hipEvent_t>(s->time_events[0][5])) == hipSuccess)
+      ms[3] = d;
+  }
   // forward tasks only: reverse-orientation tasks all go to the general pass
   uint32_t const hbm = std::min<uint32_t>(big[0], s->big_task_cap);
-  bool const hinted = ms[0] > 0.0f && cnt[3] + cnt[4] != 0;
-  tasks[0] = hinted || ms[0] > 0.0f ? s->timed_reads - cnt[3] : 0;
-  tasks[1] = hinted || ms[0] > 0.0f ? cnt[3] - cnt[4] : s->timed_reads - std::min(cnt[2], s->timed_reads);
-  tasks[2] = cnt[2] - std::min(hbm, cnt[2]);
+  bool const hinted = ms[0] > 0.0f;
+  tasks[0] = hinted ? s->timed_reads - queued1 : 0;
+  tasks[1] = hinted ? queued1 - handed : s->timed_reads - std::min(queued2, s->timed_reads);
+  tasks[2] = queued2 - std::min(hbm, queued2);
   tasks[3] = hbm;
   return GTX_OK;
 }

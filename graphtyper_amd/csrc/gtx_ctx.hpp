@@ -22,16 +22,19 @@ struct CallScratch
   void * last_stream = nullptr;
   bool used = false;         // `done` has been recorded at least once
   void * done = nullptr;     // hipEvent_t recorded behind the last launch that uses this scratch
-  // [0] read / queue-1 claim counter of pass 1, [1] task counter of pass 2, [2] tasks queued for pass 2,
-  // [3] forward tasks the position-hinted pass handed to pass 1, [4] forward tasks pass 1 handed to pass 2
+  // per part of the batch, 8 words: [0] read / queue-1 claim counter of pass 1, [1] task counter of pass 2, [2] tasks queued
+  // for pass 2, [3] forward tasks the position-hinted pass handed to pass 1, [4] forward tasks pass 1 handed to pass 2
   uint32_t * d_counters = nullptr;
   uint32_t * d_queue1 = nullptr; // reads whose forward task the position-hinted pass declined (grow-only)
   uint64_t queue1_cap = 0;
   uint32_t * d_queue = nullptr;  // (read * 2 + orientation) tasks for pass 2 (grow-only)
   uint64_t queue_cap = 0;
-  void * pass_events[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // around the four alignment launches
-  bool timed = false;            // the events above bracket a finished call
-  uint32_t timed_reads = 0;
+  static constexpr uint32_t MAX_PARTS = 8; // parts a large batch is cut into (their general passes overlap the next part)
+  void * side_stream = nullptr;            // hipStream_t of the general / HBM-table passes when a batch has several parts
+  void * sync_events[MAX_PARTS + 1] = {};  // hipEvent_t (no timing): part p's express pass done; [MAX_PARTS]: fork / join
+  void * time_events[MAX_PARTS][6] = {};   // per part: around hinted, express (caller's stream), general (side stream); [0][5] = end
+  bool timed = false;                      // the events above bracket a finished call
+  uint32_t timed_reads = 0, timed_parts = 0;
   // HBM-table pass (reads that overflowed the LDS-sized tables)
   uint32_t * d_big_tasks = nullptr;
   uint32_t big_task_cap = 0;
