@@ -445,6 +445,14 @@ def main(argv=None):
     facts = w.result_facts()
     n_gpus = dist.get_world_size() if dist is not None else 1
 
+    prof = ctx.profile()
+    if rank == 0 and prof[15] > 0:  # GTX_LIB=libgtx_prof.so: shader cycles per phase of the general algorithm, per task that ran it
+        names = ["load read", "keys + exact probes", "exact labels", "chain exact", "hamming lookup", "chain hamming",
+                 "walk starts", "walk ends", "filters", "record"]
+        tot = float(prof[:10].sum())
+        sys.stderr.write("phase cycles per task of the general pass (profiling build), %d tasks:\n" % prof[15])
+        for k, nm in enumerate(names):
+            sys.stderr.write("  %-22s %10.0f  %5.1f%%\n" % (nm, prof[k] / float(prof[15]), 100.0 * prof[k] / tot))
     if rank != 0:
         w.close()
         if dist is not None:

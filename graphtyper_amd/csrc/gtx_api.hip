@@ -1142,11 +1142,13 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
   bool const hinted = four && !(eh && eh[0] == '0');
   // GTX_EXPRESS4=lean / wide force a build (tests); else by the graph's density
   bool const wide = e4 && e4[0] == 'w' ? true : e4 && e4[0] == 'l' ? false : c->express4_wide;
-  // A large batch is cut into parts.  The general pass of a part -- few tasks, each a long chain of dependent memory
-  // round trips on one wavefront -- runs on a second stream beside the position-hinted and express passes of the next
-  // part, which leave most of a CU's wave slots and issue cycles idle while they wait for memory themselves.
-  char const * ep = std::getenv("GTX_PARTS"); // A/B switch: number of parts (1 = no overlap)
-  uint32_t parts = hinted && n_reads >= (1u << 20) ? 4u : 1u;
+  // A batch can be cut into parts whose general passes run on a second stream beside the front passes of the next part
+  // (GTX_PARTS=n).  Measured on cfg2 it does not pay: the general pass is bound by instruction issue and wave slots, not
+  // by memory latency -- ~6 000 wave instructions per task, one task per wavefront, a full grid holds all of a CU's LDS --
+  // so its parts neither shrink with their share of the tasks (0.7 ms for a quarter of them against 1.0 ms for all) nor
+  // leave room for the other stream: 3.1 / 3.6 / 4.7 / 6.6 ms per step with 1 / 2 / 4 / 8 parts.  Default: one part.
+  char const * ep = std::getenv("GTX_PARTS");
+  uint32_t parts = 1u;
   if (ep)
     parts = static_cast<uint32_t>(std::min<long>(std::max<long>(std::atol(ep), 1), CallScratch::MAX_PARTS));
   if (parts > 1 && !s->side_stream)
