@@ -296,6 +296,60 @@ def test_sv_calling_host_logic():
     sv_stream_case(harness.EmuBackend, 1500)
 
 
+def cfg5_case(Backend, tmp_path, n_ref, n_del, n_ins, n_samples, pairs_per_sv, background_pairs):
+    """BASELINE cfg5 (`genotype_sv`): an SV-augmented graph built from FASTA + VCF by the product's constructor
+    (gtx_graph_from_files: <DEL> of 50..5 000 bp, <INS> with both 152-bp breakpoint alleles), n_samples samples, FR pairs
+    over the breakpoints, through the SV-calling stream logic (record filter, coverage filter, leftovers) -> align -> score ->
+    SampleCalls; the oracle gets the records of the constructor's restatement (tests/sv_constructor.py)."""
+    import sv_constructor
+    from test_sv_constructor import _write
+    seqs, lines, codes, rec = scenarios.sv_case(n_ref=n_ref, n_del=n_del, n_ins=n_ins, n_samples=n_samples, pairs_per_sv=pairs_per_sv,
+                                                background_pairs=background_pairs)
+    fa, vcf = _write(tmp_path, seqs, lines)
+    g, (rb, re_) = gtx.graph_from_files(fa, vcf, "chrS", is_sv_graph=True)
+    assert g["dna"].tobytes().decode().count("<SV:") == n_del + 2 * n_ins
+    o = Oracle(seqs["chrS"], sv_constructor.sv_records(seqs, lines, "chrS"), is_sv_graph=True, extend_prefix=True)
+    b = Backend(g, is_sv_graph=True)
+    cov = [0.5] * n_samples
+    og = o.genotyper(n_samples, 1)
+    og.set_coverage(cov)
+    og.push(list(codes), flags=rec["flag"], tid=rec["tid"], mtid=rec["mtid"], pos=rec["pos"], isize=rec["isize"],
+            mapq=rec["mapq"], score_diff=rec["score_diff"], name=rec["name_id"], sample=rec["sample"], rg=rec["rg"],
+            mpos=rec["mpos"], n_cigar=rec["n_cigar"], cigar_front=rec["cigar_front"], cigar_back=rec["cigar_back"])
+    st = gtx.Stream(b.ctx.params, 1)
+    st.set_coverage(cov)
+    a_seq, a_meta, items = st.push(rec, gtx.pack_nibbles(codes))
+    assert st.counts() == og.counts()
+    og.finish()
+    left = st.finish()
+    records = b.align(a_seq, a_meta)
+    status = records.reshape(-1, harness.REC_WORDS)[:, 0] >> 16
+    assert not (status & gtx.ST_ERROR_MASK).any(), "kernel table overflow"
+    # every alignment against the oracle's, read by read
+    want_paths = o.align([codes[i] for i in range(len(codes))], flags=rec["flag"], tid=rec["tid"], mtid=rec["mtid"], isize=rec["isize"])
+    big, _ = b.big_records()
+    got_paths = gtx.parse_records(records, len(a_meta), harness.REC_WORDS, b.ctx.hap_order, big)
+    dup_free = st.counts()["duplicated"] == 0 and len(a_meta) == len(rec)
+    if dup_free:  # (record i <-> alignment i only when nothing was filtered or reused)
+        for i, (a, w) in enumerate(zip(got_paths, want_paths)):
+            for k in range(2):
+                assert dict(longest=a[k]["longest"], paths=a[k]["paths"]) == w[k], "read %d orientation %d" % (i, k)
+    acc = b.score(np.concatenate([items, left]), records, n_samples)
+    got, want = harness.canonical_scores(b.ctx, acc), og.scores()
+    assert len(got) == len(want) and np.array_equal(got, want), "score streams differ"
+    phred, calls = b.calls(acc, n_samples)
+    assert np.array_equal(harness.canonical_calls(b.ctx, phred, calls, n_samples), og.calls()), "sample calls differ"
+    # not vacuous: alternative SV alleles are called somewhere, and reads did align onto breakpoint alleles
+    assert (calls["gt_second"] > 0).any()
+    on_sv = sum(1 for pr in got_paths for k in range(2) for p in pr[k]["paths"] if any(al != (0,) for _, al in p["vars"]))
+    assert on_sv > n_del + n_ins, on_sv
+    return on_sv
+
+
+def test_cfg5_sv_graph_small(tmp_path):
+    cfg5_case(harness.EmuBackend, tmp_path, n_ref=60000, n_del=8, n_ins=4, n_samples=5, pairs_per_sv=30, background_pairs=150)
+
+
 def edge_case(Backend):
     """boundary inputs of gtx_align_batch: no reads; reads of the maximum length and one base more; a row stride that is
     not a multiple of 4 (no prefetch path); record slots too small for any path (everything lands in the arena)"""

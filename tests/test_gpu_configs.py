@@ -219,3 +219,13 @@ def test_two_host_threads_share_one_context():
             assert np.array_equal(rec, records), "thread %d: alignment records differ from the single-thread run" % t
             assert np.array_equal(scores, want), "thread %d: accumulators differ from the single-thread run" % t
     assert b.ctx.error_count() == 0
+
+
+def test_cfg5_sv_graph(tmp_path):
+    """BASELINE cfg5 on the device: `genotype_sv`, 100 samples, a 1 Mb SV-augmented graph (100 <DEL> of 50..5 000 bp, 50 <INS>
+    with 152-bp breakpoint alleles, built from FASTA + VCF by gtx_graph_from_files), FR pairs over every breakpoint plus
+    background -> SV stream logic -> align -> score -> calls == oracle"""
+    from test_emu_parity import cfg5_case
+    on_sv = cfg5_case(harness.GpuBackend, tmp_path, n_ref=1_000_000, n_del=100, n_ins=50, n_samples=100, pairs_per_sv=160,
+                      background_pairs=12000)
+    assert on_sv > 2000
