@@ -718,10 +718,10 @@ __global__ __launch_bounds__(64) void gtx_align_big_kernel(GraphView g, IndexVie
 // The others are appended to a work queue, one atomic per wavefront.
 __global__ __launch_bounds__(256) void gtx_score_triage_kernel(gtx_score_item const * __restrict__ items, uint32_t n_items,
                                                                uint32_t const * __restrict__ records, uint32_t rec_words,
-                                                               uint32_t * __restrict__ work_queue, uint32_t * work_count)
+                                                               uint32_t * __restrict__ work_queue, uint32_t * work_count, uint32_t keeps_depth)
 {
   uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool const work = i < n_items && !item_is_trivial(items[i], records, rec_words);
+  bool const work = i < n_items && !item_is_trivial(items[i], records, rec_words, keeps_depth != 0);
   unsigned long long const mask = __ballot(work);
   if (mask == 0)
     return;
@@ -1387,6 +1387,13 @@ extern "C" int gtx_score_batch(gtx_ctx * c, const gtx_score_item * d_items, uint
   a.conn_count = acc->d_conn_count;
   a.conn_near = acc->d_conn_near;
   a.big_records = c->d_big_records;
+  a.ref_depth = c->params.is_sv_graph ? acc->d_ref_depth : nullptr;
+  a.ref_depth_len = acc->ref_depth_len;
+  if (a.ref_depth && a.ref_depth_len != c->graph.ref_order.back() + c->graph.ref_len.back() - c->graph.ref_order.front())
+  {
+    g_last_error = "gtx_score_batch: ref_depth_len is not the length of the region's reference (gtx_score_layout::ref_depth_len)";
+    return GTX_ERR_ARG;
+  }
   ScoreParams par{static_cast<uint32_t>(c->params.is_sv_graph != 0), static_cast<uint32_t>(c->params.hq_reads != 0),
                   static_cast<uint32_t>(c->params.is_segment_calling != 0), 0};
   uint32_t const blocks = (n_items + 255u) / 256u;
@@ -1401,7 +1408,7 @@ extern "C" int gtx_score_batch(gtx_ctx * c, const gtx_score_item * d_items, uint
   if (!hip_ok(hipMemsetAsync(s->d_score_work, 0, sizeof(uint32_t), st), "score work queue reset"))
     return GTX_ERR_HIP;
   hipLaunchKernelGGL(gtx_score_triage_kernel, dim3(blocks), dim3(256), 0, st, d_items, n_items, d_records, rec_words, s->d_score_work + 1,
-                     s->d_score_work);
+                     s->d_score_work, static_cast<uint32_t>(a.ref_depth != nullptr));
   if (!hip_ok(hipGetLastError(), "gtx_score_triage_kernel launch"))
     return GTX_ERR_HIP;
   uint32_t const work_blocks = std::min<uint32_t>(blocks, static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256) * 8u);

@@ -95,6 +95,29 @@ extern "C"
     out->total_tri = c->graph.total_tri;
     out->total_allele = c->graph.total_allele;
     out->total_near = c->graph.total_near;
+    out->ref_depth_len = c->graph.ref_order.empty() ? 0u : c->graph.ref_order.back() + c->graph.ref_len.back() - c->graph.ref_order.front();
+    return GTX_OK;
+  }
+
+  int gtx_ref_depth_finalize(uint32_t * ref_depth, uint32_t n_samples, uint32_t ref_depth_len, uint64_t * n_saturated)
+  {
+    if (!ref_depth && n_samples != 0)
+      return GTX_ERR_ARG;
+    uint64_t sat = 0;
+    for (uint32_t s = 0; s < n_samples; ++s)
+    {
+      uint32_t * row = ref_depth + static_cast<uint64_t>(s) * (ref_depth_len + 1u);
+      uint32_t run = 0;
+      for (uint32_t i = 0; i < ref_depth_len; ++i)
+      {
+        run += row[i]; // (modulo 2^32: the -1 entries are 0xFFFFFFFF)
+        row[i] = run < 0xFFFFu ? run : 0xFFFFu;
+        sat += run >= 0xFFFFu ? 1u : 0u;
+      }
+      row[ref_depth_len] = 0;
+    }
+    if (n_saturated)
+      *n_saturated = sat;
     return GTX_OK;
   }
 

@@ -91,8 +91,9 @@ bool nccl_ok(ncclResult_t e, char const * what)
 // Sizes (in elements) of the accumulator sections for this graph and sample count
 struct Sections
 {
-  uint64_t stat_u64, log_score, gt_cov, hap_u32, stat_u32, conn_near;
-  uint64_t u32_total() const { return log_score + gt_cov + hap_u32 + stat_u32 + conn_near; }
+  uint64_t stat_u64, log_score, gt_cov, hap_u32, stat_u32, conn_near, ref_depth;
+  uint32_t ref_depth_len;
+  uint64_t u32_total() const { return log_score + gt_cov + hap_u32 + stat_u32 + conn_near + ref_depth; }
 };
 
 Sections sections_of(gtx_ctx const & c, uint32_t n_samples)
@@ -105,6 +106,9 @@ Sections sections_of(gtx_ctx const & c, uint32_t n_samples)
   s.hap_u32 = static_cast<uint64_t>(n_samples) * g.n_hap * 4;
   s.stat_u32 = g.n_hap + 6 * g.total_allele;
   s.conn_near = static_cast<uint64_t>(n_samples) * g.total_near;
+  // SV calling keeps the reference-depth track (a difference array: one word more than positions)
+  s.ref_depth_len = g.ref_order.empty() ? 0u : g.ref_order.back() + g.ref_len.back() - g.ref_order.front();
+  s.ref_depth = c.params.is_sv_graph ? static_cast<uint64_t>(n_samples) * (s.ref_depth_len + 1u) : 0u;
   return s;
 }
 
@@ -113,7 +117,8 @@ bool is_packed(Sections const & s, gtx_score_buffers const & b)
 {
   uint32_t const * u32 = reinterpret_cast<uint32_t const *>(b.d_stat_u64 + s.stat_u64);
   return b.d_log_score == u32 && b.d_gt_cov == u32 + s.log_score && b.d_hap_u32 == b.d_gt_cov + s.gt_cov &&
-         b.d_stat_u32 == b.d_hap_u32 + s.hap_u32 && (b.d_conn_near == nullptr || b.d_conn_near == b.d_stat_u32 + s.stat_u32);
+         b.d_stat_u32 == b.d_hap_u32 + s.hap_u32 && b.d_conn_near == b.d_stat_u32 + s.stat_u32 &&
+         (s.ref_depth == 0 ? true : b.d_ref_depth == b.d_conn_near + s.conn_near);
 }
 } // namespace
 
@@ -153,7 +158,9 @@ extern "C"
     out->d_hap_u32 = out->d_gt_cov + s.gt_cov;
     out->d_stat_u32 = out->d_hap_u32 + s.hap_u32;
     out->d_conn_near = out->d_stat_u32 + s.stat_u32;
-    out->d_conn_count = out->d_conn_near + s.conn_near;
+    out->d_ref_depth = s.ref_depth ? out->d_conn_near + s.conn_near : nullptr;
+    out->ref_depth_len = s.ref_depth ? s.ref_depth_len : 0u;
+    out->d_conn_count = out->d_conn_near + s.conn_near + s.ref_depth;
     out->d_conn_log = out->d_conn_count + 2;
     out->conn_cap = conn_cap;
     if (reduced_bytes)
@@ -166,7 +173,7 @@ extern "C"
     if (!c || !b || !b->d_stat_u64)
       return GTX_ERR_ARG;
     Sections const s = sections_of(*c, b->n_samples);
-    if (!is_packed(s, *b) || b->d_conn_count != b->d_stat_u32 + s.stat_u32 + s.conn_near)
+    if (!is_packed(s, *b) || b->d_conn_count != b->d_stat_u32 + s.stat_u32 + s.conn_near + s.ref_depth)
     {
       g_last_error = "gtx_scores_zero: buffers were not made by gtx_scores_alloc";
       return GTX_ERR_ARG;
@@ -265,9 +272,11 @@ extern "C"
     };
     sum(b->d_stat_u64, s.stat_u64, ncclUint64);
     if (is_packed(s, *b))
-      sum(b->d_log_score, s.u32_total() - (b->d_conn_near ? 0 : s.conn_near), ncclUint32);
+      sum(b->d_log_score, s.u32_total(), ncclUint32);
     else
     {
+      if (b->d_ref_depth)
+        sum(b->d_ref_depth, static_cast<uint64_t>(b->n_samples) * (b->ref_depth_len + 1u), ncclUint32);
       sum(b->d_log_score, s.log_score, ncclUint32);
       sum(b->d_gt_cov, s.gt_cov, ncclUint32);
       sum(b->d_hap_u32, s.hap_u32, ncclUint32);

@@ -237,7 +237,107 @@ struct ScoreAcc // device pointers, see gtx_score_buffers in include/gtx.h
   uint32_t * conn_count;
   uint32_t * conn_near; // NULL: every connection is logged
   uint32_t const * big_records; // the context's arena for records longer than rec_words
+  uint32_t * ref_depth = nullptr; // SV calling: [n_samples][ref_depth_len + 1] difference array of ReferenceDepth (NULL: not kept)
+  uint32_t ref_depth_len = 0;
 };
+
+// ReferenceDepth::add_genotype_paths (src/graph/reference_depth.cpp:109-201): every accepted read adds one to the depth of
+// its sample over the reference span of its path -- or, with several paths, over the union of their spans (each trimmed
+// by 4 positions at both ends when it is 50 or longer).  Kept as a difference array (+1 at the first position, -1 behind
+// the last one: two atomics per span instead of one per position); gtx_ref_depth_finalize turns it into depths.
+template <class W>
+GTX_DEV void add_ref_depth(GraphView const & g, ScoreAcc const & acc, Geno const & ge, uint32_t sample)
+{
+  if (!acc.ref_depth || ge.n_paths == 0)
+    return;
+  long const offset = g.first_order, size = acc.ref_depth_len;
+  uint32_t * depth = acc.ref_depth + static_cast<uint64_t>(sample) * (acc.ref_depth_len + 1u);
+  auto span_of = [&](RecPath const & p, long & a, long & b)
+  {
+    a = static_cast<long>(g_ref_reach_pos(g, p.start)) - static_cast<long>(p.rs);
+    b = static_cast<long>(g_ref_reach_pos(g, p.end)) + (static_cast<long>(ge.read_len) - 1 - static_cast<long>(p.re));
+  };
+  auto to_index = [&](long a, long b, long & i0, long & i1) // start_pos_to_index / end_pos_to_index (:220-229), clipped to the array
+  {
+    i0 = a < offset ? 0 : a - offset;
+    i1 = b > offset + size ? size : b + 1 - offset;
+    if (i1 > size)
+      i1 = size;
+    return i0 < size && i1 > i0;
+  };
+  RecPath p;
+  uint32_t const * w = path_at(ge.body, p);
+  if (p.re - p.rs + 1 < 63)
+    return;
+  long a, b, i0, i1;
+  if (ge.n_paths == 1)
+  {
+    span_of(p, a, b);
+    if (to_index(a, b, i0, i1))
+    {
+      W::atomic_add_u32(depth + i0, 1u);
+      W::atomic_add_u32(depth + i1, 0xFFFFFFFFu);
+    }
+    return;
+  }
+  // union of the spans, swept from the left without sorting them: the next piece starts at the smallest start behind what
+  // is covered so far and runs while spans touch or overlap it
+  long covered = -1; // last index covered so far
+  for (;;)
+  {
+    long best0 = -1, best1 = -1;
+    w = ge.body;
+    for (uint32_t k = 0; k < ge.n_paths; ++k)
+    {
+      w = path_at(w, p);
+      span_of(p, a, b);
+      if (b - a >= 50)
+      {
+        a += 4;
+        b -= 4;
+      }
+      if (b < offset || !to_index(a, b, i0, i1))
+        continue;
+      if (i0 <= covered)
+        i0 = covered + 1;
+      if (i0 >= i1)
+        continue;
+      if (best0 < 0 || i0 < best0 || (i0 == best0 && i1 > best1))
+      {
+        best0 = i0;
+        best1 = i1;
+      }
+    }
+    if (best0 < 0)
+      break;
+    // extend the piece by every span that starts inside it or right behind it
+    for (bool grown = true; grown;)
+    {
+      grown = false;
+      w = ge.body;
+      for (uint32_t k = 0; k < ge.n_paths; ++k)
+      {
+        w = path_at(w, p);
+        span_of(p, a, b);
+        if (b - a >= 50)
+        {
+          a += 4;
+          b -= 4;
+        }
+        if (b < offset || !to_index(a, b, i0, i1))
+          continue;
+        if (i0 <= best1 && i1 > best1)
+        {
+          best1 = i1;
+          grown = true;
+        }
+      }
+    }
+    W::atomic_add_u32(depth + best0, 1u);
+    W::atomic_add_u32(depth + best1, 0xFFFFFFFFu);
+    covered = best1 - 1;
+  }
+}
 
 template <class W>
 GTX_DEV void emit_conn(GraphView const & g, ScoreAcc const & acc, uint32_t sample, uint32_t h1, uint32_t b1, uint32_t h2, uint32_t b2,
@@ -445,8 +545,10 @@ GTX_DEV void apply_recent(GraphView const & g, ScoreAcc const & acc, Geno const 
 // Triage: true when no orientation of the item's read(s) carries a variant site -- whatever the orientation / pair
 // selection decides, nothing can be added to the accumulators (the same early exits are inside score_item).  Costs one
 // record header per read whose reverse orientation was not aligned.
-GTX_DEV bool item_is_trivial(gtx_score_item const & it, uint32_t const * records, uint32_t rec_words)
+GTX_DEV bool item_is_trivial(gtx_score_item const & it, uint32_t const * records, uint32_t rec_words, bool keeps_depth = false)
 {
+  if (keeps_depth && it.second.align_index != INVALID)
+    return false; // (SV calling: every selected pair counts for the reference depth, with or without variant sites)
   gtx_rec_meta const * ms[2] = {&it.first, &it.second};
   for (int r = 0; r < 2; ++r)
   {
@@ -517,7 +619,7 @@ GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_
     f.score_diff = v.score_diff = m.score_diff;
     f.proper_pair = v.proper_pair = true; // ml_insert_size = |isize|, never INSERT_SIZE_WHEN_NOT_PROPER_PAIR for int32 isize
   }
-  if (!q[0].has_var && !q[1].has_var && !q[2].has_var && !q[3].has_var)
+  if (!acc.ref_depth && !q[0].has_var && !q[1].has_var && !q[2].has_var && !q[3].has_var)
     return true; // no orientation of either mate touches a variant site: nothing to add
   // get_better_paths (alignment.cpp:557-620)
   int arr[4] = {-1, -1, -1, -1};
@@ -532,6 +634,11 @@ GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_
   Geno & second = which == 1 ? q[arr[0]] : q[arr[2]];
   first.flags |= F_PROPER_PAIR;
   second.flags |= F_PROPER_PAIR;
+  // SV calling: the reads of a selected pair count for the reference depth (hts_parallel_reader.cpp:324-329), a leftover
+  // read alone (:739-741)
+  add_ref_depth<W>(g, acc, first, it.sample);
+  if (!(it.kind & GTX_ITEM_LEFTOVER))
+    add_ref_depth<W>(g, acc, second, it.sample);
   // update_haplotype_scores_geno, pair overload (vcf_writer.cpp:143-250)
   bool f1, u1, f2, u2;
   bool const good1 = geno_is_good(g, par, first, f1, u1), good2 = geno_is_good(g, par, second, f2, u2);

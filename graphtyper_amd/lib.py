@@ -25,7 +25,7 @@ EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy"
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_set_coverage", "gtx_stream_finish", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
            "gtx_graph_destroy",
            "gtx_scores_alloc", "gtx_scores_zero", "gtx_scores_free", "gtx_scores_reduce", "gtx_comm_unique_id", "gtx_comm_init_rank",
-           "gtx_comm_destroy", "gtx_ctx_kernel_times"]
+           "gtx_comm_destroy", "gtx_ctx_kernel_times", "gtx_ref_depth_finalize"]
 
 
 class GraphView(C.Structure):
@@ -43,13 +43,15 @@ class Params(C.Structure):
 
 
 class ScoreLayout(C.Structure):
-    _fields_ = [("n_hap", C.c_uint32), ("total_tri", C.c_uint64), ("total_allele", C.c_uint64), ("total_near", C.c_uint64)]
+    _fields_ = [("n_hap", C.c_uint32), ("total_tri", C.c_uint64), ("total_allele", C.c_uint64), ("total_near", C.c_uint64),
+                ("ref_depth_len", C.c_uint32)]
 
 
 class ScoreBuffers(C.Structure):
     _fields_ = [("n_samples", C.c_uint32), ("d_log_score", C.c_void_p), ("d_gt_cov", C.c_void_p), ("d_hap_u32", C.c_void_p),
                 ("d_stat_u64", C.c_void_p), ("d_stat_u32", C.c_void_p), ("d_conn_log", C.c_void_p),
-                ("d_conn_count", C.c_void_p), ("conn_cap", C.c_uint32), ("d_conn_near", C.c_void_p)]
+                ("d_conn_count", C.c_void_p), ("conn_cap", C.c_uint32), ("d_conn_near", C.c_void_p),
+                ("d_ref_depth", C.c_void_p), ("ref_depth_len", C.c_uint32)]
 
 
 READ_META = np.dtype([("l_qseq", np.uint16), ("flag", np.uint16), ("tid", np.int32), ("mtid", np.int32), ("isize", np.int32), ("pos", np.int32)],
@@ -120,6 +122,7 @@ def lib():
         L.gtx_phase_flags.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
                                       C.POINTER(C.c_uint64)]
         L.gtx_ctx_near_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gtx_ref_depth_finalize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
         L.gtx_stream_create.argtypes = [C.POINTER(Params), C.c_uint32, C.POINTER(C.c_void_p)]
         L.gtx_stream_destroy.argtypes = [C.c_void_p]
         L.gtx_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
@@ -333,6 +336,7 @@ class Context:
         check(L.gtx_ctx_score_layout(self.h, C.byref(lay)))
         self.n_hap, self.total_tri, self.total_allele = int(lay.n_hap), int(lay.total_tri), int(lay.total_allele)
         self.total_near = int(lay.total_near)
+        self.ref_depth_len = int(lay.ref_depth_len)
         self.hap_order = np.zeros(self.n_hap, np.uint32)
         self.hap_cnum = np.zeros(self.n_hap, np.uint32)
         self.tri_off = np.zeros(self.n_hap, np.uint64)

@@ -199,6 +199,7 @@ typedef struct gtx_score_layout
   uint64_t total_tri;    /* sum over haplotypes of cnum*(cnum+1)/2 */
   uint64_t total_allele; /* sum over haplotypes of cnum */
   uint64_t total_near;   /* connection counters between near haplotypes (gtx_ctx_near_pairs) */
+  uint32_t ref_depth_len; /* positions of the region's reference (Graph::reference.size()): length of the depth track */
 } gtx_score_layout;
 
 const char * gtx_strerror(int status);
@@ -275,6 +276,14 @@ typedef struct gtx_score_buffers
   uint32_t * d_conn_count; /* [2]: entries appended, entries dropped because conn_cap was reached */
   uint32_t conn_cap;
   uint32_t * d_conn_near;
+  /* SV calling (gtx_params::is_sv_graph), optional: the reference-depth track of ReferenceDepth::add_genotype_paths
+   * (src/graph/reference_depth.cpp:109-201) -- per sample the number of accepted reads over every position of the region's
+   * reference, which the SV post-processing of the calls reads (reformat_sv_vcf_records).  [n_samples * (ref_depth_len + 1)]
+   * uint32, zero-initialised, kept as a DIFFERENCE array (+1 where a read's span starts, -1 behind its end: two atomics
+   * per span); gtx_ref_depth_finalize turns the downloaded array into depths.  ref_depth_len = gtx_score_layout::
+   * ref_depth_len.  NULL: not kept. */
+  uint32_t * d_ref_depth;
+  uint32_t ref_depth_len;
 } gtx_score_buffers;
 
 int gtx_score_batch(gtx_ctx *, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records,
@@ -327,7 +336,7 @@ int gtx_calls_batch(gtx_ctx *, const gtx_score_buffers * acc, uint8_t * d_phred,
  * addition, so sum-then-clamp (gtx_scores_finalize) equals one sequential pass below the saturation guard.
  *
  * gtx_scores_alloc puts all accumulators of gtx_score_buffers into ONE device block, zeroed:
- *   [stat_u64][log_score][gt_cov][hap_u32][stat_u32][conn_near] [conn_count][conn_log]
+ *   [stat_u64][log_score][gt_cov][hap_u32][stat_u32][conn_near][ref_depth (SV graphs)] [conn_count][conn_log]
  * The first *reduced_bytes (may be NULL) are what gtx_scores_reduce sums; the connection log stays rank-local (far pairs:
  * whoever reads them concatenates the ranks' logs).  gtx_scores_zero clears the block for the next region (async on
  * `stream`), gtx_scores_free releases it.
@@ -353,6 +362,12 @@ int gtx_comm_destroy(void * comm);
  * reported, never silently clamped. */
 int gtx_scores_finalize(uint32_t * log_score, uint64_t n_log, uint32_t * gt_cov, uint64_t n_cov, uint32_t * hap_u32,
                         uint64_t n_hap_cells, uint64_t * n_saturated);
+
+/* In-place on the downloaded difference array of gtx_score_buffers::d_ref_depth: running sums per sample, clamped to the
+ * reference's uint16 (the first ref_depth_len words of every sample's row become its depths; the last word is scratch).
+ * *n_saturated (may be NULL) counts the positions that reached 0xFFFF.  The reference saturates there when a read has
+ * several paths and wraps around when it has one (reference_depth.cpp:141-145 has no check); this function clamps. */
+int gtx_ref_depth_finalize(uint32_t * ref_depth, uint32_t n_samples, uint32_t ref_depth_len, uint64_t * n_saturated);
 
 /* Phasing flags between alt alleles of variant sites less than 100 bp apart: replaces the `ph` construction of
  * parallel_reader_genotype_only (src/utilities/hts_parallel_reader.cpp:782-904).  Host only.

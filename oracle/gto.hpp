@@ -526,8 +526,10 @@ struct Graph
   std::vector<uint32_t> ref_reach_poses, actual_poses;
 
   // graph.cpp:41-339
+  std::size_t reference_size = 0; // Graph::reference.size()
   void add_genomic_region(std::string const & reference, std::vector<VarRecord> records)
   {
+    reference_size = reference.size();
     for (auto & r : records) // graph.cpp:48-59
       r.alts.erase(std::remove_if(r.alts.begin(), r.alts.end(),
                                   [](AltAllele const & a) { return a.seq.empty() || a.seq.find('N') != std::string::npos; }),
@@ -2372,6 +2374,69 @@ struct VcfWriter // src/typer/vcf_writer.cpp
 };
 
 // ---------------------------------------------------------------------------
+// ReferenceDepth (src/graph/reference_depth.cpp:17-28, 109-201, 220-229): per sample the number of accepted reads
+// over every reference position; SV calling only (hts_parallel_reader.cpp:505-508)
+// ---------------------------------------------------------------------------
+struct ReferenceDepth
+{
+  Graph const * graph = nullptr;
+  uint32_t reference_offset = 0;
+  std::vector<std::vector<uint16_t>> depths;
+
+  void init(Graph const & g, long sample_count)
+  {
+    graph = &g;
+    reference_offset = g.ref_nodes.empty() ? 0 : g.ref_nodes[0].label.order;
+    depths.assign(static_cast<std::size_t>(sample_count), std::vector<uint16_t>(g.reference_size, 0));
+  }
+  long start_pos_to_index(long start_pos) const { return start_pos < reference_offset ? 0 : start_pos - reference_offset; }
+  long end_pos_to_index(long end_pos, long depth_size) const
+  {
+    return end_pos > reference_offset + depth_size ? depth_size : end_pos + 1 - reference_offset;
+  }
+  void add_genotype_paths(GenotypePaths const & geno, long sample_index) // :109-201
+  {
+    if (depths.empty() || sample_index >= static_cast<long>(depths.size()))
+      return;
+    if (geno.paths.empty() || geno.paths[0].size() < 63)
+      return;
+    auto & depth = depths[sample_index];
+    long const size = static_cast<long>(depth.size());
+    if (geno.paths.size() == 1)
+    {
+      Path const & path = geno.paths[0];
+      long const start_pos = static_cast<long>(graph->get_ref_reach_pos(path.start)) - path.read_start_index;
+      long const end_pos = static_cast<long>(graph->get_ref_reach_pos(path.end)) + (geno.read_length - 1 - path.read_end_index);
+      long const start_index = start_pos_to_index(start_pos), end_index = end_pos_to_index(end_pos, size);
+      if (start_index < size)
+        for (long i = start_index; i < end_index && i < size; ++i) // (an end in front of the start: nothing -- the reference's
+          ++depth[i];                                              //  iterator loop would run away there)
+      return;
+    }
+    std::unordered_set<long> local_depth;
+    for (Path const & path : geno.paths)
+    {
+      long start_pos = static_cast<long>(graph->get_ref_reach_pos(path.start)) - path.read_start_index;
+      long end_pos = static_cast<long>(graph->get_ref_reach_pos(path.end)) + (geno.read_length - 1 - path.read_end_index);
+      if (end_pos - start_pos >= 50)
+      {
+        start_pos += 4;
+        end_pos -= 4;
+      }
+      if (end_pos < reference_offset)
+        continue;
+      long const start_index = start_pos_to_index(start_pos), end_index = end_pos_to_index(end_pos, size);
+      if (start_index < size)
+        for (long i = start_index; i < end_index && i < size; ++i)
+          local_depth.insert(i);
+    }
+    for (long i : local_depth)
+      if (depth[i] < 0xFFFFul)
+        ++depth[i];
+  }
+};
+
+// ---------------------------------------------------------------------------
 // per-record driver  (src/utilities/hts_parallel_reader.cpp:245-338, 655-708) for non-SV graphs
 // ---------------------------------------------------------------------------
 struct Genotyper
@@ -2389,7 +2454,10 @@ struct Genotyper
   Genotyper(Graph const & g, PHIndex const & i, Params const & p, std::size_t n_samples, std::size_t n_rg)
     : graph(g), index(i), par(p), writer(g, p, n_samples), maps(n_rg)
   {
+    if (g.is_sv_graph) // hts_parallel_reader.cpp:505-508
+      reference_depth.init(g, static_cast<long>(n_samples));
   }
+  ReferenceDepth reference_depth;
 
   static bool equal_pos_seq(ReadRecord const & a, ReadRecord const & b) // include/graphtyper/utilities/hts_utils.hpp:110-128
   {
@@ -2420,7 +2488,14 @@ struct Genotyper
       throw std::runtime_error("gto: two reads named " + rec.name + " have the same IS_FIRST_IN_PAIR");
     auto better = get_better_paths(it->second, gp);
     if (better.first)
+    {
+      if (graph.is_sv_graph) // hts_parallel_reader.cpp:324-329
+      {
+        reference_depth.add_genotype_paths(*better.first, rec.sample);
+        reference_depth.add_genotype_paths(*better.second, rec.sample);
+      }
       writer.update_haplotype_scores_geno(better, rec.sample);
+    }
     map.erase(it);
   }
 
@@ -2519,7 +2594,10 @@ struct Genotyper
           copy.second.flags ^= (IS_FIRST_IN_PAIR | IS_SEQ_REVERSED);
           auto better = get_better_paths(kv.second, copy);
           if (better.first)
+          {
+            reference_depth.add_genotype_paths(*better.first, parked_sample.at(kv.first)); // hts_parallel_reader.cpp:739-741
             writer.update_haplotype_scores_geno(*better.first, parked_sample.at(kv.first));
+          }
         }
     for (auto & map : maps)
       map.clear();

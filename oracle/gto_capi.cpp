@@ -569,6 +569,19 @@ extern "C"
     return n;
   }
 
+  // ReferenceDepth::depths of one sample (SV calling): returns the number of positions; out may be NULL
+  long gto_reference_depth(void * p, long sample, uint16_t * out, long cap)
+  {
+    auto * g = static_cast<GenoHandle *>(p);
+    auto const & d = g->g->reference_depth.depths;
+    if (sample < 0 || sample >= static_cast<long>(d.size()))
+      return 0;
+    long const n = static_cast<long>(d[sample].size());
+    for (long i = 0; out && i < n && i < cap; ++i)
+      out[i] = d[sample][i];
+    return n;
+  }
+
   void gto_genotyper_counts(void * p, long * out)
   {
     auto * g = static_cast<GenoHandle *>(p);

@@ -367,12 +367,14 @@ extern "C"
     a.conn_count = acc->d_conn_count;
     a.conn_near = acc->d_conn_near;
     a.big_records = e.arena.data();
+    a.ref_depth = e.params.is_sv_graph ? acc->d_ref_depth : nullptr;
+    a.ref_depth_len = acc->ref_depth_len;
     ScoreParams par{static_cast<uint32_t>(e.params.is_sv_graph != 0), static_cast<uint32_t>(e.params.hq_reads != 0),
                     static_cast<uint32_t>(e.params.is_segment_calling != 0), 0};
     uint32_t errors = 0;
     std::vector<RecentHap> small(2 * SCORE_MAX_HAPS), large(2 * SCORE_MAX_HAPS_BIG);
     for (uint32_t i = 0; i < n_items; ++i)
-      if (item_is_trivial(items[i], records, rec_words)) // stage 1 (gtx_score_triage_kernel)
+      if (item_is_trivial(items[i], records, rec_words, a.ref_depth != nullptr)) // stage 1 (gtx_score_triage_kernel)
         continue;
       else if (!score_item<WaveEmu>(g, par, items[i], records, rec_words, a, small.data(), small.data() + SCORE_MAX_HAPS, SCORE_MAX_HAPS))
       {

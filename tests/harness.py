@@ -33,14 +33,25 @@ class Accumulators:
         self.conn_count = np.zeros(2, np.uint32)
         # dense counters of the connections between near haplotypes; without them every connection goes to the log
         self.conn_near = np.zeros(n_samples * ctx.total_near, np.uint32) if near else None
+        # SV calling: the reference-depth track (difference array, one word more than positions per sample)
+        self.ref_depth_len = ctx.ref_depth_len
+        self.ref_depth = np.zeros(n_samples * (ctx.ref_depth_len + 1), np.uint32) if (near and ctx.params.is_sv_graph) else None
 
     def arrays(self):
         a = [self.log_score, self.gt_cov, self.hap_u32, self.stat_u64, self.stat_u32, self.conn_log, self.conn_count]
-        return a + ([self.conn_near] if self.conn_near is not None else [])
+        return a + ([self.conn_near] if self.conn_near is not None else []) + ([self.ref_depth] if self.ref_depth is not None else [])
 
     def buffers(self, pointers):
         """gtx_score_buffers over `pointers` (one per array of arrays(), host or device)"""
-        return gtx.ScoreBuffers(self.n_samples, *pointers[:7], self.conn_cap, pointers[7] if self.conn_near is not None else None)
+        return gtx.ScoreBuffers(self.n_samples, *pointers[:7], self.conn_cap, pointers[7] if self.conn_near is not None else None,
+                                pointers[8] if self.ref_depth is not None else None, self.ref_depth_len if self.ref_depth is not None else 0)
+
+    def depths(self):
+        """the finalised reference-depth track [n_samples, ref_depth_len] (gtx_ref_depth_finalize on a copy)"""
+        d = self.ref_depth.copy()
+        sat = C.c_uint64()
+        gtx.check(gtx.lib().gtx_ref_depth_finalize(_p(d), self.n_samples, self.ref_depth_len, C.byref(sat)))
+        return d.reshape(self.n_samples, self.ref_depth_len + 1)[:, :self.ref_depth_len]
 
 
 class EmuBackend:

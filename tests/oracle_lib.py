@@ -256,6 +256,15 @@ class OracleGenotyper:
         L.gto_phase_flags(C.c_void_p(self.g), _p(out), C.c_long(n))
         return out[:n].astype(np.int64)
 
+    def reference_depth(self, sample):
+        """ReferenceDepth::depths[sample] (SV calling only; empty otherwise)"""
+        L = lib()
+        L.gto_reference_depth.restype = C.c_long
+        n = L.gto_reference_depth(C.c_void_p(self.g), C.c_long(sample), None, C.c_long(0))
+        out = np.zeros(max(n, 1), np.uint16)
+        L.gto_reference_depth(C.c_void_p(self.g), C.c_long(sample), _p(out), C.c_long(n))
+        return out[:n]
+
     def counts(self):
         c = (C.c_long * 3)()
         lib().gto_genotyper_counts(C.c_void_p(self.g), c)

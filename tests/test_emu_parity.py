@@ -288,6 +288,8 @@ def sv_stream_case(Backend, n_pairs):
     acc = b.score(np.concatenate([items, left]), records, 2)
     got, want = harness.canonical_scores(b.ctx, acc), og.scores()
     assert len(got) == len(want) and np.array_equal(got, want)
+    depths = acc.depths()  # (reads with several paths on the dense SNP graph: the union branch of the depth track)
+    assert depths.any() and all(np.array_equal(depths[s_i], og.reference_depth(s_i).astype(np.uint32)) for s_i in range(2))
     # the leftovers contribute: without them the scores differ
     assert not np.array_equal(harness.canonical_scores(b.ctx, b.score(items, records, 2)), want)
 
@@ -339,6 +341,11 @@ def cfg5_case(Backend, tmp_path, n_ref, n_del, n_ins, n_samples, pairs_per_sv, b
     assert len(got) == len(want) and np.array_equal(got, want), "score streams differ"
     phred, calls = b.calls(acc, n_samples)
     assert np.array_equal(harness.canonical_calls(b.ctx, phred, calls, n_samples), og.calls()), "sample calls differ"
+    # the reference-depth track of SV calling (ReferenceDepth::add_genotype_paths), every sample, every position
+    depths = acc.depths()
+    assert depths.shape[1] == len(seqs["chrS"]) and depths.any()
+    for s_i in range(n_samples):
+        assert np.array_equal(depths[s_i], og.reference_depth(s_i).astype(np.uint32)), "reference depth of sample %d differs" % s_i
     # not vacuous: alternative SV alleles are called somewhere, and reads did align onto breakpoint alleles
     assert (calls["gt_second"] > 0).any()
     on_sv = sum(1 for pr in got_paths for k in range(2) for p in pr[k]["paths"] if any(al != (0,) for _, al in p["vars"]))
