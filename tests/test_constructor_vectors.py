@@ -91,10 +91,10 @@ def test_gzip_vcf_and_unindexed_fasta_give_the_same_graphs(tmp_path):
 
 def test_sv_alleles_and_bad_input_are_refused_loudly():
     fa, vcf = os.path.join(GOLDEN, "index_test.fa"), os.path.join(GOLDEN, "index_test.vcf")
-    with pytest.raises(gtx.GtxError, match="only deletions"):
-        gtx.graph_from_files(fa, vcf, "chr6", is_sv_graph=True)  # <DUP>, <INV>
-    with pytest.raises(gtx.GtxError, match="only deletions"):
-        gtx.graph_from_files(fa, vcf, "chr7", is_sv_graph=True)  # <INS:ME:ALU>
+    g, _ = gtx.graph_from_files(fa, vcf, "chr6", is_sv_graph=True)  # <DUP>, <INV>: two breakpoint records each
+    assert g["dna"].tobytes().count(b"<SV:") == 4 and len(g["ref_order"]) == 5
+    g, _ = gtx.graph_from_files(fa, vcf, "chr7", is_sv_graph=True)  # <INS:ME:ALU> is skipped like the reference skips it
+    assert len(g["var_order"]) == 0
     with pytest.raises(gtx.GtxError, match="non-SV graph"):
         gtx.graph_from_files(fa, vcf, "chr6", is_sv_graph=False)
     with pytest.raises(gtx.GtxError, match="not found"):
