@@ -487,6 +487,11 @@ extern "C"
         g_last_error = "gtx_stream_push: read group index out of range";
         return GTX_ERR_ARG;
       }
+      if (recs[i].l_qseq > GTX_MAX_READ)
+      {
+        g_last_error = "gtx_stream_push: a read of " + std::to_string(recs[i].l_qseq) + " bases (the kernels align up to 256)";
+        return GTX_ERR_UNSUPPORTED;
+      }
       if ((static_cast<uint32_t>(recs[i].l_qseq) + 1u) / 2u > seq_stride)
       {
         g_last_error = "gtx_stream_push: a record is longer than seq_stride";

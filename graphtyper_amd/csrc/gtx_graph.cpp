@@ -241,6 +241,29 @@ extern "C"
       g_last_error = "gtx_graph_build: NULL argument";
       return GTX_ERR_ARG;
     }
+    // the records have to be what the constructor hands to Graph::add_genomic_region: sorted by position
+    // (constructor.cpp:1749-1757) and inside the reference that came with them (the constructor drops records that leave
+    // the region, :1660-1662; check_if_var_records_match_reference_genome, :1736).  A record outside it used to slip through
+    // and leave nodes of length 0 or lost sites behind.
+    for (uint32_t r = 0; r < n_records; ++r)
+    {
+      if (records[r].n_alleles < 1 || !records[r].alleles)
+      {
+        g_last_error = "gtx_graph_build: record " + std::to_string(r) + " has no alleles";
+        return GTX_ERR_ARG;
+      }
+      if (r > 0 && records[r].pos < records[r - 1].pos)
+      {
+        g_last_error = "gtx_graph_build: records are not sorted by position (record " + std::to_string(r) + ")";
+        return GTX_ERR_ARG;
+      }
+      long const pos = records[r].pos, ref_len = records[r].alleles[0].len;
+      if (pos >= region_begin && pos + ref_len > region_begin + static_cast<long>(reference_len))
+      {
+        g_last_error = "gtx_graph_build: record " + std::to_string(r) + " at " + std::to_string(pos) + " leaves the reference sequence";
+        return GTX_ERR_ARG;
+      }
+    }
     std::string const refseq(reference, reference_len);
     auto ref_slice = [&](long a, long b)
     {

@@ -17,15 +17,19 @@ def shard_bounds(n_items, world, rank):
 def shard_pairs_by_name(name_ids, world):
     """rank of every record such that both mates of a pair (equal name id) land on the same rank and a rank gets a
     contiguous block of the position-sorted stream where possible: a record goes where the first record with its name
-    went."""
+    went.
+
+    What sharding is exact for: the stateful parts of the record stream -- duplicate reuse (a record equal in position
+    and sequence to its predecessor takes over the predecessor's alignment, hts_parallel_reader.cpp:666-684) and the
+    coverage filter of SV calling (per-sample bin counts, :594-633) -- depend on which records are neighbours.  Run
+    gtx_stream_push over the WHOLE stream (on every rank, or once) and shard its OUTPUT, the alignment tasks and score
+    items, as tests/test_dist_gloo.py and bench.py do: that gives the single-process accumulators exactly.  Sharding the
+    records before the stream is exact only without duplicates at shard boundaries and without the coverage filter."""
     name_ids = np.asarray(name_ids)
     n = len(name_ids)
-    first_seen = {}
-    owner = np.empty(n, np.int32)
-    for i, nm in enumerate(name_ids.tolist()):
-        j = first_seen.setdefault(nm, i)
-        owner[i] = min(world - 1, j * world // max(n, 1))
-    return owner
+    _, first_index, inverse = np.unique(name_ids, return_index=True, return_inverse=True)
+    first = first_index[inverse]  # position of the first record with this name
+    return np.minimum(world - 1, first * world // max(n, 1)).astype(np.int32)
 
 
 def reduce_scores(dist, tensors, group=None):

@@ -19,7 +19,7 @@
  *   gtx_scores_reduce   replaces  the merge of the per-thread / per-pool results   src/typer/caller.cpp:439-482,
  *                                 (every per-read effect is an integer addition)  src/typer/vcf_operations.cpp:366-374
  *   gtx_graph_build     replaces  Graph::add_genomic_region                     src/graph/graph.cpp:41-339
- *   gtx_graph_from_files replaces construct_graph (small variants, SV deletions) src/graph/constructor.cpp:1597-1777
+ *   gtx_graph_from_files replaces construct_graph (small variants, structural variants) src/graph/constructor.cpp:1597-1777
  *
  * Conventions: plain pointers and sizes only; the caller allocates and owns every buffer; a context is immutable
  * after creation and may be used from several host threads; every function returns a status code (0 = ok) and never
@@ -111,7 +111,8 @@ typedef struct gtx_record /* VarRecord (include/graphtyper/graph/var_record.hpp:
 
 typedef struct gtx_graph gtx_graph; /* owns the node tables a gtx_graph_view points into */
 
-/* records sorted by pos; region = [region_begin, region_end) 0-based, reference[0] is contig position region_begin */
+/* records sorted by pos; region = [region_begin, region_end) 0-based, reference[0] is contig position region_begin.
+ * GTX_ERR_ARG when the records are not sorted or one that starts inside the region runs past the reference sequence. */
 int gtx_graph_build(const char * reference, uint64_t reference_len, int64_t region_begin, int64_t region_end,
                     const gtx_record * records, uint32_t n_records, int add_all_variants, int is_sv_graph, int extend_prefix,
                     gtx_graph ** out);
@@ -145,6 +146,11 @@ typedef struct gtx_label
 {
   uint32_t start_index, end_index, variant_id;
 } gtx_label;
+
+/* Longest read the kernels align (the reference has no limit; its MAX_READ_LENGTH constant, constants.hpp.in:27, is 151).
+ * A longer read gets empty records carrying GTX_ST_RECORD_OVERFLOW in every pass, and gtx_stream_push refuses a batch
+ * that holds one (GTX_ERR_UNSUPPORTED) instead of letting it vanish from the accumulators. */
+#define GTX_MAX_READ 256
 
 /* Per read fields of bam1_t the path looks at (src/typer/alignment.cpp:331-363) */
 typedef struct gtx_read_meta

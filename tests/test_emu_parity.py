@@ -58,7 +58,7 @@ def check_align(backend, oracle, reads, flags=None, tid=None, mtid=None, isize=N
     return rec, n_over
 
 
-@pytest.mark.parametrize("chrom", ["chr1", "chr2", "chr3", "chr9"])
+@pytest.mark.parametrize("chrom", ["chr1", "chr2", "chr3", "chr9", "chr10", "chr11"])
 def test_align_index_test_contigs(chrom):
     ref, recs, reads = scenarios.contig_reads(chrom)
     o = Oracle(ref, recs, force_both=True)
@@ -162,18 +162,23 @@ def test_phase_flags_have_content():
     assert run_stream.last_phase_rows > 50
 
 
-def test_direct_probes_and_half_key_buckets_agree(monkeypatch):
+def direct_probes_case(Backend, monkeypatch, n_reads):
     """the Hamming-1 lists come from two half-key bucket lookups; with the bucket cap forced to 0 the kernel probes the
-    96 neighbours directly like the reference does -- both routes must give the oracle's result"""
-    ref, recs, codes, pos = scenarios.synthetic_case("snp100", n_ref=60000, n_reads=3000, region_begin=0, err=0.02)
+    96 neighbours directly like the reference does -- both routes must give the oracle's result (the cap is read when the
+    context is made on the device and at every call in the emulation: a backend per setting serves both)"""
+    ref, recs, codes, pos = scenarios.synthetic_case("snp100", n_ref=60000, n_reads=n_reads, region_begin=0, err=0.02)
     o = Oracle(ref, recs)
-    b = harness.EmuBackend(gtx.graph_from_records(ref, recs))
-    monkeypatch.setenv("GTX_HALF_BUCKET_CAP", "0")
-    check_align(b, o, list(codes))
-    monkeypatch.setenv("GTX_HALF_BUCKET_CAP", "1")
-    check_align(b, o, list(codes))
-    monkeypatch.delenv("GTX_HALF_BUCKET_CAP")
-    check_align(b, o, list(codes))
+    g = gtx.graph_from_records(ref, recs)
+    for cap in ("0", "1", None):
+        if cap is None:
+            monkeypatch.delenv("GTX_HALF_BUCKET_CAP")
+        else:
+            monkeypatch.setenv("GTX_HALF_BUCKET_CAP", cap)
+        check_align(Backend(g), o, list(codes), pos=pos if cap != "1" else None)
+
+
+def test_direct_probes_and_half_key_buckets_agree(monkeypatch):
+    direct_probes_case(harness.EmuBackend, monkeypatch, 3000)
 
 
 def test_align_and_score_on_merged_multiallelic_graph():
@@ -449,7 +454,33 @@ def test_express_variants_agree(monkeypatch):
     express_variants_case(harness.EmuBackend, monkeypatch, 8000)
 
 
-def test_three_ambiguous_bases_stay_in_the_lds_pass():
+def n_runs_case(Backend, n_reads):
+    """reference Ns (what chr4 of the reference's fixture is about, test/index/test_index.cpp:211-244): runs of 1..40 N every
+    few hundred bases -- k-mers over them are not indexed, walks over them match any read base, reads lose seeds there"""
+    ref, recs, codes, pos = scenarios.synthetic_case("snp100", n_ref=40000, n_reads=1, region_begin=7000)
+    rng = np.random.default_rng(12)
+    s = list(ref)
+    at = 150
+    while at < len(s) - 400:
+        n = int(rng.integers(1, 41))
+        s[at:at + n] = "N" * n
+        at += int(rng.integers(150, 500))
+    ref = "".join(s)
+    recs = [r for r in recs if "N" not in ref[r[0] - 7000 - 1:r[0] - 7000 + 2]]
+    from graphtyper_amd import synth
+    base = np.array(["ACGTN".index(c) for c in ref], np.uint8)
+    codes, pos = synth.make_reads(np.where(base == 4, rng.integers(0, 4, len(base)), base).astype(np.uint8), recs, n_reads, seed=3,
+                                  region_begin=7000)
+    o = Oracle(ref, recs, region_begin=7000)
+    b = Backend(gtx.graph_from_records(ref, recs, region_begin=7000))
+    check_align(b, o, list(codes), pos=pos)
+
+
+def test_align_reference_with_n_runs():
+    n_runs_case(harness.EmuBackend, 3000)
+
+
+def three_n_case(Backend):
     """a k-mer with three Ns expands to 64 keys: within the main pass' key table (it used to be sent to the HBM-table
     pass by a conservative bound), and equal to the oracle"""
     ref, recs, codes, pos = scenarios.synthetic_case("snp100", n_ref=40000, n_reads=300, region_begin=1000, n_rate=0.0)
@@ -458,9 +489,13 @@ def test_three_ambiguous_bases_stay_in_the_lds_pass():
         at = 31 * int(rng.integers(0, 4)) + rng.choice(32, size=3, replace=False)
         c[at] = 15
     o = Oracle(ref, recs, region_begin=1000)
-    b = harness.EmuBackend(gtx.graph_from_records(ref, recs, region_begin=1000))
-    check_align(b, o, list(codes))
+    b = Backend(gtx.graph_from_records(ref, recs, region_begin=1000))
+    check_align(b, o, list(codes), pos=pos)
     assert b.big_records()[1] == 0  # no task reached the last pass
+
+
+def test_three_ambiguous_bases_stay_in_the_lds_pass():
+    three_n_case(harness.EmuBackend)
 
 
 def sv_deletion_case(Backend):

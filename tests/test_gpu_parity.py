@@ -10,7 +10,7 @@ import harness
 import scenarios
 from graphtyper_amd import lib as gtx
 from oracle_lib import Oracle, encode
-from test_emu_parity import check_align, sv_deletion_case, edge_case, express_variants_case, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case
+from test_emu_parity import check_align, direct_probes_case, n_runs_case, three_n_case, sv_deletion_case, edge_case, express_variants_case, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case
 
 pytestmark = pytest.mark.gpu
 
@@ -22,7 +22,7 @@ def _gpu():
     assert os.path.exists(gtx.LIB_PATH), "libgtx.so must be built (HIP path, no fallback)"
 
 
-@pytest.mark.parametrize("chrom", ["chr1", "chr2", "chr3", "chr9"])
+@pytest.mark.parametrize("chrom", ["chr1", "chr2", "chr3", "chr9", "chr10", "chr11"])
 def test_align_index_test_contigs(chrom):
     ref, recs, reads = scenarios.contig_reads(chrom)
     o = Oracle(ref, recs, force_both=True)
@@ -138,3 +138,15 @@ def test_pass_times_are_reported():
 
 def test_align_over_an_sv_deletion():
     sv_deletion_case(harness.GpuBackend)
+
+
+def test_direct_probes_and_half_key_buckets_agree(monkeypatch):
+    direct_probes_case(harness.GpuBackend, monkeypatch, 20000)
+
+
+def test_three_ambiguous_bases_stay_in_the_lds_pass():
+    three_n_case(harness.GpuBackend)
+
+
+def test_align_reference_with_n_runs():
+    n_runs_case(harness.GpuBackend, 20000)

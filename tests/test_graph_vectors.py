@@ -215,3 +215,17 @@ def test_merged_nodes_carry_the_union_of_events():
     for v, (events, anti) in enumerate(want):  # slots 2v = events, 2v+1 = anti-events of var node v
         assert set(val[off[2 * v]:off[2 * v + 1]]) == events
         assert set(val[off[2 * v + 1]:off[2 * v + 2]]) == anti
+
+
+def test_graph_build_validates_its_records():
+    """records out of order, or running past the reference they came with, are an error -- not a graph with lost sites or
+    empty nodes"""
+    ref = "ACGT" * 50
+    with pytest.raises(gtx.GtxError, match="not sorted"):
+        gtx.graph_from_records(ref, [(50, "G", ["T"], None), (10, "G", ["A"], None)])
+    with pytest.raises(gtx.GtxError, match="leaves the reference"):
+        gtx.graph_from_records(ref, [(198, "GTAC", ["G"], None)])
+    with pytest.raises(gtx.GtxError, match="leaves the reference"):
+        gtx.graph_from_records(ref, [(500, "A", ["C"], None)])
+    g = gtx.graph_from_records(ref, [(10, "G", ["A"], None), (50, "G", ["T"], None), (196, "ACGT", ["A"], None)])
+    assert len(g["ref_order"]) == 4
