@@ -15,6 +15,7 @@
 #include <thread>
 
 #include "gtx_flat.hpp"
+#include "index_build.hpp"
 
 namespace gtx
 {
@@ -609,65 +610,23 @@ static void build_hints(HostGraph const & g, HostIndex & out)
   out.ref4.assign(n / 8 + 24, 0); // (padded: the kernel loads 21 words from any position without a bounds test)
   for (uint32_t i = 0; i < n; ++i)
     out.ref4[i >> 3] |= static_cast<uint32_t>(base[i]) << (28 - 4 * (i & 7u));
-  // per key: how many keys share its first / last 16 bases, and whether its Hamming-1 neighbours are "the same interval
-  // on the same site" (what express4's seeding lambda requires of the neighbours of an exact hit)
+  // per key: the keys that share its first / last 16 bases (groups), then the neighbour verdict (index_build.hpp)
   std::size_t const nk = out.keys.size();
-  std::vector<uint32_t> lcount(nk, 0), rcount(nk, 0), nb(nk, 0);
+  std::vector<uint32_t> lbegin(nk), lsize(nk), rorder(nk), rbegin(nk), rsize(nk), nb(nk, 0);
   std::vector<uint8_t> nb_same(nk, 1);
-  auto distance1 = [](uint64_t a, uint64_t b)
+  for (std::size_t k = 0; k < nk;) // keys ascending: equal first 16 bases are neighbours in the array
   {
-    uint64_t const x = a ^ b, bases = (x | (x >> 1)) & 0x5555555555555555ull;
-    return bases != 0 && (bases & (bases - 1)) == 0;
-  };
-  auto one_label_of = [&](std::size_t k, DevLabel & l)
-  {
-    if (out.key_off[k + 1] - out.key_off[k] != 1)
-      return false;
-    l = out.dev_labels[out.key_off[k]];
-    return true;
-  };
-  auto judge_group = [&](std::vector<uint32_t> const & members, std::vector<uint32_t> & count)
-  {
-    for (uint32_t a : members)
+    std::size_t e = k + 1;
+    while (e < nk && (out.keys[e] >> 32) == (out.keys[k] >> 32))
+      ++e;
+    for (std::size_t m = k; m < e; ++m)
     {
-      count[a] = static_cast<uint32_t>(members.size());
-      DevLabel la{};
-      bool const single = one_label_of(a, la);
-      for (uint32_t b : members)
-        if (a != b && distance1(out.keys[a], out.keys[b]))
-        {
-          nb[a] += out.key_off[b + 1] - out.key_off[b];
-          for (uint32_t k = out.key_off[b]; k < out.key_off[b + 1]; ++k)
-          {
-            DevLabel const & lb = out.dev_labels[k];
-            if (!single || la.site == INVALID || lb.site != la.site || lb.start != la.start || lb.end != la.end)
-              nb_same[a] = 0;
-          }
-        }
+      lbegin[m] = static_cast<uint32_t>(k);
+      lsize[m] = static_cast<uint32_t>(e - k);
     }
-  };
+    k = e;
+  }
   {
-    std::vector<uint32_t> members;
-    for (std::size_t k = 0; k < nk;) // keys ascending: equal first 16 bases are neighbours in the array
-    {
-      std::size_t e = k + 1;
-      while (e < nk && (out.keys[e] >> 32) == (out.keys[k] >> 32))
-        ++e;
-      if (e - k > 1 && e - k <= 64)
-      {
-        members.clear();
-        for (std::size_t m = k; m < e; ++m)
-          members.push_back(static_cast<uint32_t>(m));
-        judge_group(members, lcount);
-      }
-      else
-        for (std::size_t m = k; m < e; ++m)
-        {
-          lcount[m] = static_cast<uint32_t>(e - k);
-          nb_same[m] = e - k == 1 ? nb_same[m] : 0; // (crowded: never judged, never EXACT_OK)
-        }
-      k = e;
-    }
     std::vector<std::pair<uint64_t, uint32_t>> order(nk);
     for (std::size_t k = 0; k < nk; ++k)
       order[k] = {out.keys[k] & 0xFFFFFFFFull, static_cast<uint32_t>(k)};
@@ -677,22 +636,25 @@ static void build_hints(HostGraph const & g, HostIndex & out)
       std::size_t e = k + 1;
       while (e < nk && order[e].first == order[k].first)
         ++e;
-      if (e - k > 1 && e - k <= 64)
+      for (std::size_t m = k; m < e; ++m)
       {
-        members.clear();
-        for (std::size_t m = k; m < e; ++m)
-          members.push_back(order[m].second);
-        judge_group(members, rcount);
+        rorder[m] = order[m].second;
+        rbegin[order[m].second] = static_cast<uint32_t>(k);
+        rsize[order[m].second] = static_cast<uint32_t>(e - k);
       }
-      else
-        for (std::size_t m = k; m < e; ++m)
-        {
-          rcount[order[m].second] = static_cast<uint32_t>(e - k);
-          nb_same[order[m].second] = e - k == 1 ? nb_same[order[m].second] : 0;
-        }
       k = e;
     }
   }
+  HintKeys const t{out.keys.data(), out.key_off.data(), out.dev_labels.data(), static_cast<uint32_t>(nk), lbegin.data(), lsize.data(),
+                   rorder.data(), rbegin.data(), rsize.data()};
+  parallel_slices(nk, host_threads(), [&](unsigned, std::size_t b, std::size_t e) {
+    for (std::size_t k = b; k < e; ++k)
+    {
+      uint32_t same = 1;
+      hint_judge_key(t, static_cast<uint32_t>(k), nb[k], same);
+      nb_same[k] = static_cast<uint8_t>(same);
+    }
+  });
   // filters over the halves of every indexed key (nibble form, as the kernel hashes them): 32 bits per key and side
   uint32_t fl = 5;
   while ((1ull << fl) < nk + 1 && fl < 28)
@@ -700,116 +662,21 @@ static void build_hints(HostGraph const & g, HostIndex & out)
   out.filt_log2 = fl;
   out.filt[0].assign(1ull << fl, 0);
   out.filt[1].assign(1ull << fl, 0);
-  auto nibble_words = [](uint32_t half, uint32_t & w0, uint32_t & w1) // 16 bases, 2 bits each, first base in the top bits
-  {
-    w0 = w1 = 0;
-    for (uint32_t j = 0; j < 8; ++j)
-    {
-      w0 |= (1u << ((half >> (30 - 2 * j)) & 3u)) << (28 - 4 * j);
-      w1 |= (1u << ((half >> (14 - 2 * j)) & 3u)) << (28 - 4 * j);
-    }
-  };
   for (std::size_t k = 0; k < nk; ++k)
     for (uint32_t side = 0; side < 2; ++side)
     {
       uint32_t w0, w1, word, mask;
-      nibble_words(static_cast<uint32_t>(side == 0 ? out.keys[k] >> 32 : out.keys[k]), w0, w1);
+      hint_nibble_words(static_cast<uint32_t>(side == 0 ? out.keys[k] >> 32 : out.keys[k]), w0, w1);
       hint_filter_slot(w0, w1, fl, word, mask);
       out.filt[side][word] |= mask;
     }
-  // the verdict express4's seeding rule gives a read k-mer that equals indexed key k: its one label has to be
-  // (order, order + 31, site, allele) and its indexed neighbours that same interval on that site
-  auto exact_verdict = [&](std::size_t k, uint32_t order, uint32_t want_site, uint32_t want_allele, bool & par)
-  {
-    DevLabel l{};
-    if (!one_label_of(k, l) || l.start != order || l.end != order + K - 1 || l.site != want_site || (l.site != INVALID && l.allele != want_allele))
-      return false;
-    par = nb[k] != 0;
-    return lcount[k] <= HINT_HE_CAP && rcount[k] <= HINT_HE_CAP && (nb[k] == 0 || (nb_same[k] && nb[k] <= HINT_NB_MAX));
-  };
-  auto find_key = [&](uint64_t key, std::size_t & k)
-  {
-    auto it = std::lower_bound(out.keys.begin(), out.keys.end(), key);
-    k = static_cast<std::size_t>(it - out.keys.begin());
-    return it != out.keys.end() && *it == key;
-  };
   // per position
-  uint2_t const nothing{HINT_NO_SITE << HINT_SITE_SHIFT, 0};
-  out.pos_flags.assign(n, nothing);
+  GraphView const gv = g.view();
+  out.pos_flags.assign(n, uint2_t{HINT_NO_SITE << HINT_SITE_SHIFT, 0});
   parallel_slices(n, host_threads(), [&](unsigned, std::size_t b, std::size_t e) {
-    uint64_t roll = 0;
-    uint32_t valid = 0;
-    std::size_t const from = b >= K - 1 ? b - (K - 1) : 0; // warm the window up so that position b itself is judged
-    for (std::size_t i = from; i < e + K - 1 && i < n; ++i)
-    {
-      // window ends at i, starts at i - 31
-      uint8_t const c = base[i];
-      if (c == 15)
-        valid = 0;
-      else
-      {
-        roll = (roll << 2) | (c == 1 ? 0u : c == 2 ? 1u : c == 4 ? 2u : 3u);
-        ++valid;
-      }
-      if (i + 1 < K)
-        continue;
-      std::size_t const p = i + 1 - K;
-      if (p < b || p >= e)
-        continue;
-      uint32_t x = 0, y = static_cast<uint32_t>(room[p]) | (static_cast<uint32_t>(back[p]) << HINT_BACK_SHIFT);
-      uint32_t site = HINT_NO_SITE;
-      std::size_t k = 0;
-      if (valid >= K && find_key(roll, k))
-      {
-        DevLabel l{};
-        uint32_t const order = first + static_cast<uint32_t>(p);
-        if (one_label_of(k, l) && l.start == order && l.end == order + K - 1 && (l.site == INVALID || l.allele == 0) &&
-            !(l.site != INVALID && g.is_sv_graph))
-        {
-          site = l.site == INVALID ? HINT_NO_SITE : l.site;
-          x |= HINT_SINGLE_OK;
-          if (lcount[k] == 1)
-            x |= HINT_L1;
-          if (rcount[k] == 1)
-            x |= HINT_R1;
-          bool par = false;
-          if (exact_verdict(k, order, l.site, 0, par))
-            x |= HINT_EXACT_OK | (par ? HINT_PAR : 0u);
-          // the other alleles of a SNP under the k-mer
-          if (l.site != INVALID)
-          {
-            uint32_t const fv = g.ref_first_var[l.site], nv = g.ref_nvar[l.site];
-            bool snp = nv >= 2 && nv <= 4 && g.var_order[fv] >= order && g.var_order[fv] <= order + K - 1;
-            for (uint32_t a = 0; a < nv && snp; ++a)
-              snp = g.var_len[fv + a] == 1 && nib(g.dna[g.var_dna[fv + a]]) != 15;
-            if (snp)
-            {
-              uint32_t const off = g.var_order[fv] - order; // base of the k-mer that lies on the site
-              uint32_t idx_of = 0;
-              for (uint32_t a = 1; a < nv && snp; ++a)
-              {
-                uint8_t const cb = nib(g.dna[g.var_dna[fv + a]]);
-                uint32_t const two = cb == 1 ? 0u : cb == 2 ? 1u : cb == 4 ? 2u : 3u;
-                uint64_t const key = (roll & ~(3ull << (2 * (K - 1 - off)))) | (static_cast<uint64_t>(two) << (2 * (K - 1 - off)));
-                std::size_t ka = 0;
-                bool pa = false;
-                snp = key != roll && ((idx_of >> (2 * two)) & 3u) == 0 && find_key(key, ka) && exact_verdict(ka, order, l.site, a, pa);
-                idx_of |= a << (2 * two);
-              }
-              if (snp)
-              {
-                x |= HINT_ALT_OK | (idx_of << HINT_ALTIDX_SHIFT);
-                y |= off << HINT_SNPOFF_SHIFT;
-              }
-            }
-          }
-        }
-      }
-      out.pos_flags[p] = uint2_t{x | (site << HINT_SITE_SHIFT), y};
-    }
+    for (std::size_t p = b; p < e; ++p)
+      out.pos_flags[p] = hint_position_flags(gv, t, nb.data(), nb_same.data(), base.data(), room.data(), back.data(), n, static_cast<uint32_t>(p));
   });
-  for (uint32_t p = n >= K - 1 ? n - (K - 1) : 0; p < n; ++p) // the last 31 positions start no 32-mer
-    out.pos_flags[p] = uint2_t{HINT_NO_SITE << HINT_SITE_SHIFT, static_cast<uint32_t>(room[p]) | (static_cast<uint32_t>(back[p]) << HINT_BACK_SHIFT)};
 }
 
 void build_index(HostGraph const & g, HostIndex & out)

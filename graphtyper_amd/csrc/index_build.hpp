@@ -1,0 +1,184 @@
+// index_build.hpp -- the per-key and per-position decisions behind the tables of the position-hinted pass
+// (IndexView::pos_flags, filt; hinted.hpp), written once over plain arrays so that the host build (gtx_host.cpp, contexts
+// without a device and the test emulation) and the device build (gtx_index_dev.hip: one thread per key / per position)
+// run the same text.
+#pragma once
+#include "graph_dev.hpp"
+
+#if defined(__HIPCC__)
+#define GTX_HD __host__ __device__ inline
+#else
+#define GTX_HD inline
+#endif
+
+namespace gtx
+{
+// the finished index as plain arrays (host or device pointers)
+struct HintKeys
+{
+  uint64_t const * keys;    // [n_keys] ascending, the reference's 2-bit layout (first base in the top bits)
+  uint32_t const * key_off; // [n_keys + 1] labels of key k = labels[key_off[k] .. key_off[k + 1])
+  DevLabel const * labels;  // in key order, bucket order inside a key
+  uint32_t n_keys;
+  // keys that share their 16 first bases are neighbours in `keys` (left group of k = keys [lbegin[k], lbegin[k] + lsize[k]));
+  // rorder lists the key indices ordered by their 16 last bases (right group of k = rorder[rbegin[k] .. rbegin[k] + rsize[k]))
+  uint32_t const * lbegin;
+  uint32_t const * lsize;
+  uint32_t const * rorder;
+  uint32_t const * rbegin;
+  uint32_t const * rsize;
+};
+
+GTX_HD bool hint_distance1(uint64_t a, uint64_t b) // exactly one base differs
+{
+  uint64_t const x = a ^ b, bases = (x | (x >> 1)) & 0x5555555555555555ull;
+  return bases != 0 && (bases & (bases - 1)) == 0;
+}
+
+// Hamming-1 neighbours of key k among the keys that share one of its halves: how many labels they have together (nb), and
+// whether every one of those labels is k's own interval on k's own site (what express4's seeding rule asks of the
+// neighbours of an exact hit).  A crowded group (more than 64 keys: low-complexity sequence) is not looked through: same = 0.
+GTX_HD void hint_judge_key(HintKeys const & t, uint32_t k, uint32_t & nb, uint32_t & same)
+{
+  nb = 0;
+  same = 1;
+  bool const single = t.key_off[k + 1] - t.key_off[k] == 1;
+  DevLabel const la = t.labels[t.key_off[k]];
+  auto look = [&](uint32_t b)
+  {
+    if (b == k || !hint_distance1(t.keys[k], t.keys[b]))
+      return;
+    nb += t.key_off[b + 1] - t.key_off[b];
+    for (uint32_t i = t.key_off[b]; i < t.key_off[b + 1]; ++i)
+    {
+      DevLabel const lb = t.labels[i];
+      if (!single || la.site == INVALID || lb.site != la.site || lb.start != la.start || lb.end != la.end)
+        same = 0;
+    }
+  };
+  if (t.lsize[k] > 64)
+    same = 0;
+  else
+    for (uint32_t i = 0; i < t.lsize[k]; ++i)
+      look(t.lbegin[k] + i);
+  if (t.rsize[k] > 64)
+    same = 0;
+  else
+    for (uint32_t i = 0; i < t.rsize[k]; ++i)
+      look(t.rorder[t.rbegin[k] + i]);
+}
+
+GTX_HD bool hint_find_key(HintKeys const & t, uint64_t key, uint32_t & k)
+{
+  uint32_t lo = 0, hi = t.n_keys;
+  while (lo < hi)
+  {
+    uint32_t const mid = lo + (hi - lo) / 2;
+    if (t.keys[mid] < key)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  k = lo;
+  return lo < t.n_keys && t.keys[lo] == key;
+}
+
+// the verdict express4's seeding rule gives a read k-mer that equals indexed key k: its one label has to be
+// (order, order + 31, site, allele) and its indexed neighbours that same interval on that site
+GTX_HD bool hint_exact_verdict(HintKeys const & t, uint32_t const * nb, uint8_t const * nb_same, uint32_t k, uint32_t order, uint32_t want_site,
+                                uint32_t want_allele, bool & par)
+{
+  if (t.key_off[k + 1] - t.key_off[k] != 1)
+    return false;
+  DevLabel const l = t.labels[t.key_off[k]];
+  if (l.start != order || l.end != order + K - 1 || l.site != want_site || (l.site != INVALID && l.allele != want_allele))
+    return false;
+  par = nb[k] != 0;
+  return t.lsize[k] <= HINT_HE_CAP && t.rsize[k] <= HINT_HE_CAP && (nb[k] == 0 || (nb_same[k] && nb[k] <= HINT_NB_MAX));
+}
+
+GTX_HD uint32_t hint_two_bits(uint32_t nibble) // A=1 C=2 G=4 T=8 -> 0..3
+{
+  return nibble == 1 ? 0u : nibble == 2 ? 1u : nibble == 4 ? 2u : 3u;
+}
+
+GTX_HD uint32_t hint_acgt(uint8_t code) // graph comparison code -> nibble of A/C/G/T, 15 for anything else
+{
+  return (code == 1 || code == 2 || code == 4 || code == 8) ? code : 15u;
+}
+
+// IndexView::pos_flags[p]: `base` = the linear reference as nibbles (15 = not ACGT), `room` / `back` = bases to the end /
+// from the start of the position's reference node (capped at 255, 0 outside reference nodes), n = positions
+GTX_HD uint2_t hint_position_flags(GraphView const & g, HintKeys const & t, uint32_t const * nb, uint8_t const * nb_same, uint8_t const * base,
+                                    uint8_t const * room, uint8_t const * back, uint32_t n, uint32_t p)
+{
+  uint32_t x = 0, y = static_cast<uint32_t>(room[p]) | (static_cast<uint32_t>(back[p]) << HINT_BACK_SHIFT);
+  uint32_t site = HINT_NO_SITE;
+  uint64_t key = 0;
+  bool valid = p + K <= n;
+  for (uint32_t j = 0; j < K && valid; ++j)
+  {
+    uint32_t const c = base[p + j];
+    valid = c != 15;
+    key = (key << 2) | hint_two_bits(c);
+  }
+  uint32_t k = 0;
+  if (valid && hint_find_key(t, key, k) && t.key_off[k + 1] - t.key_off[k] == 1)
+  {
+    DevLabel const l = t.labels[t.key_off[k]];
+    uint32_t const order = g.first_order + p;
+    if (l.start == order && l.end == order + K - 1 && (l.site == INVALID || l.allele == 0) && !(l.site != INVALID && g.is_sv_graph))
+    {
+      site = l.site == INVALID ? HINT_NO_SITE : l.site;
+      x |= HINT_SINGLE_OK;
+      if (t.lsize[k] == 1)
+        x |= HINT_L1;
+      if (t.rsize[k] == 1)
+        x |= HINT_R1;
+      bool par = false;
+      if (hint_exact_verdict(t, nb, nb_same, k, order, l.site, 0, par))
+        x |= HINT_EXACT_OK | (par ? HINT_PAR : 0u);
+      // the other alleles of a SNP under the k-mer
+      if (l.site != INVALID)
+      {
+        uint32_t const fv = g.ref_first_var[l.site], nv = g.ref_nvar[l.site];
+        bool snp = nv >= 2 && nv <= 4 && g.var_order[fv] >= order && g.var_order[fv] <= order + K - 1;
+        for (uint32_t a = 0; a < nv && snp; ++a)
+          snp = g.var_len[fv + a] == 1 && hint_acgt(static_cast<uint8_t>(g.dna[g.var_dna[fv + a]])) != 15;
+        if (snp)
+        {
+          uint32_t const off = g.var_order[fv] - order; // base of the k-mer that lies on the site
+          uint32_t idx_of = 0;
+          for (uint32_t a = 1; a < nv && snp; ++a)
+          {
+            uint32_t const two = hint_two_bits(hint_acgt(static_cast<uint8_t>(g.dna[g.var_dna[fv + a]])));
+            uint64_t const alt = (key & ~(3ull << (2 * (K - 1 - off)))) | (static_cast<uint64_t>(two) << (2 * (K - 1 - off)));
+            uint32_t ka = 0;
+            bool pa = false;
+            snp = alt != key && ((idx_of >> (2 * two)) & 3u) == 0 && hint_find_key(t, alt, ka) && hint_exact_verdict(t, nb, nb_same, ka, order, l.site, a, pa);
+            idx_of |= a << (2 * two);
+          }
+          if (snp)
+          {
+            x |= HINT_ALT_OK | (idx_of << HINT_ALTIDX_SHIFT);
+            y |= off << HINT_SNPOFF_SHIFT;
+          }
+        }
+      }
+    }
+  }
+  return uint2_t{x | (site << HINT_SITE_SHIFT), y};
+}
+
+// 16 bases (2 bits each, first base in the top bits) as the two nibble words the kernel hashes
+GTX_HD void hint_nibble_words(uint32_t half, uint32_t & w0, uint32_t & w1)
+{
+  w0 = w1 = 0;
+  for (uint32_t j = 0; j < 8; ++j)
+  {
+    w0 |= (1u << ((half >> (30 - 2 * j)) & 3u)) << (28 - 4 * j);
+    w1 |= (1u << ((half >> (14 - 2 * j)) & 3u)) << (28 - 4 * j);
+  }
+}
+
+} // namespace gtx
