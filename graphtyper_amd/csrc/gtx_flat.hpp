@@ -209,7 +209,28 @@ struct HostIndex
 
 // returns "" on success, else a description of what is wrong with the view
 std::string flatten_graph(gtx_graph_view const & g, gtx_params const & par, HostGraph & out);
-void build_index(HostGraph const & g, HostIndex & out);
+
+// one indexed 32-mer occurrence as the enumeration emits it (emission order = the reference's bucket order)
+struct Emit
+{
+  uint64_t key;
+  gtx_label label;
+};
+
+// what the position-hinted pass needs of the GRAPH alone (no index): the linear reference as nibbles, per position the
+// bases to the end / from the start of its reference node, the packed ref4 words and the tail_info table
+struct HintGraphTables
+{
+  std::vector<uint8_t> base, room, back;
+  std::vector<uint32_t> ref4;
+  std::vector<uint2_t> tail_info;
+  uint32_t hint_first = 0, n = 0; // n = 0: the graph has too many sites for the tables (no position-hinted pass)
+};
+
+void enumerate_kmers(HostGraph const & g, std::vector<Emit> & out);                 // index_graph's sweep (host threads)
+void hint_graph_tables(HostGraph const & g, HintGraphTables & out);
+void build_tables_host(HostGraph const & g, std::vector<Emit> const & em, HostIndex & out); // grouping, hash tables, hint tables
+void build_index(HostGraph const & g, HostIndex & out);                             // both of the above
 
 // Device tables are keyed by the k-mer in PLANE form: bit j of the low word = low bit of base j's 2-bit code, bit j of
 // the high word = its high bit (base 0 = first base).  A wavefront gets both words straight from two ballots over the
@@ -245,13 +266,9 @@ inline uint64_t plane_key(uint64_t key)
 // ~20x the cost: it pays off once more than ~2 % of the indexed keys carry several labels (measured: a SNP every 100
 // bases at regular distances -- no such key -- is 17 % faster with the lean build, a SNP every 25 bases -- every read
 // has such a k-mer -- 1.8x faster with the wide one).
-inline bool express4_prefers_wide(HostGraph const & g, HostIndex const & ix)
+inline bool express4_prefers_wide(HostGraph const & g, uint64_t n_keys, uint64_t keys_with_several_labels)
 {
-  uint64_t several = 0;
-  std::size_t const n = ix.keys.size();
-  for (std::size_t k = 0; k < n; ++k)
-    several += ix.key_off[k + 1] - ix.key_off[k] >= 2 ? 1u : 0u;
-  if (n != 0 && several * 50 > n)
+  if (n_keys != 0 && keys_with_several_labels * 50 > n_keys)
     return true;
   // ... or once the walk at a read's end (26 characters of a 150 bp read) meets an indel site for more than ~8 % of the
   // reads: only the wide build walks over alleles of unequal length (an indel every 60 bases: 44 % of the tasks reach
@@ -266,6 +283,15 @@ inline bool express4_prefers_wide(HostGraph const & g, HostIndex const & ix)
     indel_sites += indel ? 1u : 0u;
   }
   return indel_sites * 325 > bases;
+}
+
+inline bool express4_prefers_wide(HostGraph const & g, HostIndex const & ix)
+{
+  uint64_t several = 0;
+  std::size_t const n = ix.keys.size();
+  for (std::size_t k = 0; k < n; ++k)
+    several += ix.key_off[k + 1] - ix.key_off[k] >= 2 ? 1u : 0u;
+  return express4_prefers_wide(g, n, several);
 }
 
 #if defined(__HIPCC__)

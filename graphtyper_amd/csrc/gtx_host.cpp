@@ -236,12 +236,6 @@ std::string flatten_graph(gtx_graph_view const & g, gtx_params const & par, Host
 
 namespace
 {
-struct Emit
-{
-  uint64_t key;
-  gtx_label label;
-};
-
 struct Walker
 {
   HostGraph const & g;
@@ -542,51 +536,40 @@ IndexView HostIndex::view(uint32_t max_index_labels, uint32_t half_bucket_cap) c
 // Tables of the position-hinted pass (IndexView::ref4 ..., hinted.hpp).  For every reference position: what a read
 // k-mer that equals -- or is one substitution / one ambiguous base away from -- the reference 32-mer of that place
 // would get from the global lookups, decided here once from the finished index.
-static void build_hints(HostGraph const & g, HostIndex & out)
+void hint_graph_tables(HostGraph const & g, HintGraphTables & t)
 {
   uint32_t const R = static_cast<uint32_t>(g.ref_order.size());
-  out.ref4.clear();
-  out.pos_flags.clear();
-  out.tail_info.clear();
-  out.filt[0].clear();
-  out.filt[1].clear();
-  out.n_hint = 0;
-  out.filt_log2 = 0;
-  out.hint_first = g.ref_order.empty() ? 0 : g.ref_order[0] - 1; // order = 1-based contig position
+  t = HintGraphTables();
+  t.hint_first = g.ref_order.empty() ? 0 : g.ref_order[0] - 1; // order = 1-based contig position
   if (R == 0 || R - 1 >= HINT_NO_SITE)
-  {
-    out.ref4.assign(32, 0);
-    out.pos_flags.assign(1, uint2_t{0, 0});
-    out.tail_info.assign(1, uint2_t{0, 0});
-    out.filt[0].assign(1, 0);
-    out.filt[1].assign(1, 0);
     return;
-  }
   // linear reference = reference nodes and allele 0 of every site, in order
   uint32_t const first = g.ref_order[0], last = g.ref_order[R - 1] + g.ref_len[R - 1];
   uint32_t const n = last - first;
-  std::vector<uint8_t> base(n, 15);       // nibble codes (A=1 C=2 G=4 T=8, anything else 15)
-  std::vector<uint8_t> room(n, 0), back(n, 0); // bases to the end / from the start of the reference node (capped), 0 outside
+  t.n = n;
+  t.base.assign(n, 15); // nibble codes (A=1 C=2 G=4 T=8, anything else 15)
+  t.room.assign(n, 0);  // bases to the end / from the start of the reference node (capped), 0 outside reference nodes
+  t.back.assign(n, 0);
   auto nib = [](char c) -> uint8_t { return c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 4 : c == 'T' ? 8 : 15; };
   for (uint32_t r = 0; r < R; ++r)
   {
     uint32_t const at = g.ref_order[r] - first;
     for (uint32_t d = 0; d < g.ref_len[r]; ++d)
     {
-      base[at + d] = nib(g.dna[g.ref_dna[r] + d]);
+      t.base[at + d] = nib(g.dna[g.ref_dna[r] + d]);
       uint32_t const left = g.ref_len[r] - d;
-      room[at + d] = static_cast<uint8_t>(left < 255 ? left : 255);
-      back[at + d] = static_cast<uint8_t>(d < 255 ? d : 255);
+      t.room[at + d] = static_cast<uint8_t>(left < 255 ? left : 255);
+      t.back[at + d] = static_cast<uint8_t>(d < 255 ? d : 255);
     }
     if (r + 1 < R && g.ref_nvar[r] != 0)
     {
       uint32_t const v = g.ref_first_var[r], vat = g.var_order[v] - first;
       for (uint32_t d = 0; d < g.var_len[v]; ++d)
-        base[vat + d] = nib(g.dna[g.var_dna[v] + d]);
+        t.base[vat + d] = nib(g.dna[g.var_dna[v] + d]);
     }
   }
   // the site behind every reference node, as a walk at the read's end may cross it (tail_info)
-  out.tail_info.assign(n, uint2_t{0, 0});
+  t.tail_info.assign(n, uint2_t{0, 0});
   for (uint32_t r = 0; r + 1 < R && !g.is_sv_graph; ++r)
   {
     uint32_t const fv = g.ref_first_var[r], nv = g.ref_nvar[r];
@@ -601,15 +584,41 @@ static void build_hints(HostGraph const & g, HostIndex & out)
     if (!snp)
       continue;
     uint32_t const next_len = g.ref_len[r + 1] < 255 ? g.ref_len[r + 1] : 255;
-    uint2_t const t{HINT_TAIL_OK | (nv << HINT_TAIL_NALL_SHIFT) | (next_len << HINT_TAIL_NEXT_SHIFT) | (codes << HINT_TAIL_CODES_SHIFT), r};
+    uint2_t const ti{HINT_TAIL_OK | (nv << HINT_TAIL_NALL_SHIFT) | (next_len << HINT_TAIL_NEXT_SHIFT) | (codes << HINT_TAIL_CODES_SHIFT), r};
     uint32_t const at = g.ref_order[r] - first;
     for (uint32_t d = 0; d < g.ref_len[r]; ++d)
-      out.tail_info[at + d] = t;
+      t.tail_info[at + d] = ti;
   }
-  out.n_hint = n;
-  out.ref4.assign(n / 8 + 24, 0); // (padded: the kernel loads 21 words from any position without a bounds test)
+  t.ref4.assign(n / 8 + 24, 0); // (padded: the kernel loads 21 words from any position without a bounds test)
   for (uint32_t i = 0; i < n; ++i)
-    out.ref4[i >> 3] |= static_cast<uint32_t>(base[i]) << (28 - 4 * (i & 7u));
+    t.ref4[i >> 3] |= static_cast<uint32_t>(t.base[i]) << (28 - 4 * (i & 7u));
+}
+
+// Tables of the position-hinted pass (IndexView::ref4 ..., hinted.hpp).  For every reference position: what a read
+// k-mer that equals -- or is one substitution / one ambiguous base away from -- the reference 32-mer of that place
+// would get from the global lookups, decided here once from the finished index.
+static void build_hints(HostGraph const & g, HostIndex & out)
+{
+  HintGraphTables gt;
+  hint_graph_tables(g, gt);
+  out.hint_first = gt.hint_first;
+  out.n_hint = gt.n;
+  out.filt_log2 = 0;
+  if (gt.n == 0)
+  {
+    out.ref4.assign(32, 0);
+    out.pos_flags.assign(1, uint2_t{0, 0});
+    out.tail_info.assign(1, uint2_t{0, 0});
+    out.filt[0].assign(1, 0);
+    out.filt[1].assign(1, 0);
+    return;
+  }
+  uint32_t const n = gt.n;
+  std::vector<uint8_t> const & base = gt.base;
+  std::vector<uint8_t> const & room = gt.room;
+  std::vector<uint8_t> const & back = gt.back;
+  out.ref4 = std::move(gt.ref4);
+  out.tail_info = std::move(gt.tail_info);
   // per key: the keys that share its first / last 16 bases (groups), then the neighbour verdict (index_build.hpp)
   std::size_t const nk = out.keys.size();
   std::vector<uint32_t> lbegin(nk), lsize(nk), rorder(nk), rbegin(nk), rsize(nk), nb(nk, 0);
@@ -681,6 +690,107 @@ static void build_hints(HostGraph const & g, HostIndex & out)
 
 void build_index(HostGraph const & g, HostIndex & out)
 {
+  std::vector<Emit> em;
+  enumerate_kmers(g, em);
+  build_tables_host(g, em, out);
+}
+
+// index_graph's sweep (indexer.cpp:246-291): every end position is independent, so the reference nodes (with the site
+// behind each) are cut into contiguous ranges for the host team; concatenated in order the ranges give the sweep's order.
+void enumerate_kmers(HostGraph const & g, std::vector<Emit> & em)
+{
+  uint32_t const R = static_cast<uint32_t>(g.ref_order.size());
+  unsigned const T = R < 64 ? 1u : host_threads();
+  std::vector<std::vector<Emit>> part(T);
+  // ranges of equal sequence length
+  std::vector<uint32_t> cut(T + 1, R);
+  {
+    uint64_t total = 0;
+    for (uint32_t r = 0; r < R; ++r)
+      total += g.ref_len[r] + 8;
+    uint64_t run = 0;
+    unsigned t = 1;
+    cut[0] = 0;
+    for (uint32_t r = 0; r < R && t < T; ++r)
+    {
+      run += g.ref_len[r] + 8;
+      if (run * T >= total * t)
+        cut[t++] = r + 1;
+    }
+  }
+  auto work = [&](unsigned t)
+  {
+    std::vector<Emit> & out = part[t];
+    uint32_t const r0 = cut[t], r1 = cut[t + 1];
+    if (r0 >= r1)
+      return;
+    uint64_t bases = 0;
+    for (uint32_t r = r0; r < r1; ++r)
+      bases += g.ref_len[r];
+    out.reserve(bases + bases / 4 + 64);
+    Walker w{g, out, !g.event_off.empty()};
+    for (uint32_t r = r0; r < r1; ++r)
+    {
+      // fast path inside a reference node: a rolling 2-bit window while the k-mer stays within this node
+      char const * dna = g.dna.data() + g.ref_dna[r];
+      uint32_t const len = g.ref_len[r];
+      uint64_t roll = 0;
+      uint32_t valid = 0;
+      for (uint32_t d = 0; d < len; ++d)
+      {
+        int const c = Walker::code(dna[d]);
+        if (c < 0)
+        {
+          valid = 0;
+          continue;
+        }
+        roll = (roll << 2) | static_cast<uint64_t>(c);
+        ++valid;
+        if (valid >= K)
+          out.push_back({roll, {g.ref_order[r] + d - (K - 1), g.ref_order[r] + d, INVALID}});
+        else if (valid == d + 1) // window reaches back past the node start: enumerate through the previous site(s)
+        {
+          w.n_vars = 0;
+          w.end_label = g.ref_order[r] + d;
+          w.back_ref(r, d, 0, 0);
+        }
+      }
+      if (r + 1 == R || g.ref_nvar[r] == 0)
+        continue;
+      uint32_t const fv = g.ref_first_var[r];
+      for (uint32_t a = 0; a < g.ref_nvar[r]; ++a)
+      {
+        uint32_t const v = fv + a;
+        for (uint32_t d = 0; d < g.var_len[v]; ++d)
+        {
+          w.n_vars = 0;
+          w.end_label = w.special_of(r, g.var_order[v] + d);
+          w.back_var(v, d, 0, 0);
+        }
+      }
+    }
+  };
+  if (T == 1)
+    work(0);
+  else
+  {
+    std::vector<std::thread> team;
+    for (unsigned t = 0; t < T; ++t)
+      team.emplace_back(work, t);
+    for (auto & th : team)
+      th.join();
+  }
+  std::size_t total = 0;
+  for (auto const & p : part)
+    total += p.size();
+  em.clear();
+  em.reserve(total);
+  for (auto const & p : part)
+    em.insert(em.end(), p.begin(), p.end());
+}
+
+void build_tables_host(HostGraph const & g, std::vector<Emit> const & em, HostIndex & out)
+{
   bool const timing = std::getenv("GTX_TIMING") != nullptr; // stage times on stderr
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](char const * what)
@@ -691,51 +801,6 @@ void build_index(HostGraph const & g, HostIndex & out)
     t_last = now;
   };
   out = HostIndex();
-  std::vector<Emit> em;
-  uint32_t const R = static_cast<uint32_t>(g.ref_order.size());
-  em.reserve(g.dna.size() + g.dna.size() / 4);
-  Walker w{g, em, !g.event_off.empty()};
-  for (uint32_t r = 0; r < R; ++r)
-  {
-    // fast path inside a reference node: a rolling 2-bit window while the k-mer stays within this node
-    char const * dna = g.dna.data() + g.ref_dna[r];
-    uint32_t const len = g.ref_len[r];
-    uint64_t roll = 0;
-    uint32_t valid = 0;
-    for (uint32_t d = 0; d < len; ++d)
-    {
-      int const c = Walker::code(dna[d]);
-      if (c < 0)
-      {
-        valid = 0;
-        continue;
-      }
-      roll = (roll << 2) | static_cast<uint64_t>(c);
-      ++valid;
-      if (valid >= K)
-        em.push_back({roll, {g.ref_order[r] + d - (K - 1), g.ref_order[r] + d, INVALID}});
-      else if (valid == d + 1) // window reaches back past the node start: enumerate through the previous site(s)
-      {
-        w.n_vars = 0;
-        w.end_label = g.ref_order[r] + d;
-        w.back_ref(r, d, 0, 0);
-      }
-    }
-    if (r + 1 == R || g.ref_nvar[r] == 0)
-      continue;
-    uint32_t const fv = g.ref_first_var[r];
-    for (uint32_t a = 0; a < g.ref_nvar[r]; ++a)
-    {
-      uint32_t const v = fv + a;
-      for (uint32_t d = 0; d < g.var_len[v]; ++d)
-      {
-        w.n_vars = 0;
-        w.end_label = w.special_of(r, g.var_order[v] + d);
-        w.back_var(v, d, 0, 0);
-      }
-    }
-  }
-  lap("enumerate k-mers");
   // group by key keeping emission order inside a key
   std::vector<std::pair<uint64_t, uint32_t>> perm(em.size());
   for (std::size_t i = 0; i < em.size(); ++i)
