@@ -975,19 +975,6 @@ int ctx_upload(gtx_ctx & c, int device)
   ok = ok && upload(c.dev_allocs, v.allele_off, h.allele_off.data(), h.allele_off.size(), "allele_off");
   ok = ok && upload(c.dev_allocs, v.near_last, h.near_last.data(), h.near_last.size(), "near_last");
   ok = ok && upload(c.dev_allocs, v.near_off, h.near_off.data(), h.near_off.size(), "near_off");
-  uint32_t half_cap = HALF_BUCKET_CAP;
-  if (char const * e = std::getenv("GTX_HALF_BUCKET_CAP")) // A/B switch for benchmarking: 0 = probe the 96 neighbours directly
-    half_cap = static_cast<uint32_t>(std::min<long>(std::max<long>(std::atol(e), 0), HALF_BUCKET_CAP));
-  IndexView ix = c.index.view(static_cast<uint32_t>(c.params.max_index_labels), half_cap);
-  ok = ok && upload(c.dev_allocs, ix.slots, c.index.slots.data(), c.index.slots.size(), "index slots");
-  ok = ok && upload(c.dev_allocs, ix.labels, c.index.dev_labels.data(), c.index.dev_labels.size(), "index labels");
-  ok = ok && upload(c.dev_allocs, ix.hslots, c.index.hslots.data(), c.index.hslots.size(), "half-key slots");
-  ok = ok && upload(c.dev_allocs, ix.hlist, c.index.hlist.data(), c.index.hlist.size(), "half-key buckets");
-  ok = ok && upload(c.dev_allocs, ix.ref4, c.index.ref4.data(), c.index.ref4.size(), "reference nibbles");
-  ok = ok && upload(c.dev_allocs, ix.pos_flags, c.index.pos_flags.data(), c.index.pos_flags.size(), "position flags");
-  ok = ok && upload(c.dev_allocs, ix.tail_info, c.index.tail_info.data(), c.index.tail_info.size(), "tail sites");
-  ok = ok && upload(c.dev_allocs, ix.filt[0], c.index.filt[0].data(), c.index.filt[0].size(), "half-key filter 0");
-  ok = ok && upload(c.dev_allocs, ix.filt[1], c.index.filt[1].data(), c.index.filt[1].size(), "half-key filter 1");
   void * pf = nullptr;
   ok = ok && hip_ok(hipMalloc(&pf, 32 * sizeof(unsigned long long)), "profile counters");
   if (ok)
@@ -1031,7 +1018,6 @@ int ctx_upload(gtx_ctx & c, int device)
   if (!ok)
     return GTX_ERR_HIP;
   c.dev_graph = v;
-  c.dev_index = ix;
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_kernel, 64, 0) == hipSuccess && per_cu > 0)
     c.align_blocks_per_cu = per_cu;
@@ -1041,7 +1027,6 @@ int ctx_upload(gtx_ctx & c, int device)
     c.express4_blocks_per_cu = per_cu;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express4_wide_kernel, 64, 0) == hipSuccess && per_cu > 0)
     c.express4_wide_blocks_per_cu = per_cu;
-  c.express4_wide = express4_prefers_wide(c.graph, c.index);
   // the first scratch now, so that the first call does not pay for it
   auto s = scratch_new(c);
   if (!s)

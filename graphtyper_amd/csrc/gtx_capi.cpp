@@ -1,5 +1,6 @@
 // gtx_capi.cpp -- host half of the C ABI (include/gtx.h): context life cycle, inspection, finalisation and the
 // per-record stream logic.  No compute on reads happens here.
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <map>
@@ -46,15 +47,31 @@ extern "C"
       g_last_error = err;
       return err.rfind("unsupported", 0) == 0 ? GTX_ERR_UNSUPPORTED : GTX_ERR_GRAPH;
     }
-    build_index(c->graph, c->index);
-    if (device >= 0)
+    char const * hb = std::getenv("GTX_INDEX_BUILD"); // A/B switch: "host" builds the tables on the host and uploads them
+    if (device < 0)
     {
-      int const rc = ctx_upload(*c, device);
+      build_index(c->graph, c->index);
+      c->n_keys = static_cast<uint32_t>(c->index.keys.size());
+      c->n_labels = static_cast<uint32_t>(c->index.labels.size());
+      c->index_downloaded = true;
+    }
+    else
+    {
+      // the host enumerates the 32-mers (index_graph's sweep) and derives the graph's own hint arrays; everything
+      // else -- grouping, hash tables, hint tables -- is built on the device (gtx_index_dev.hip)
+      std::vector<Emit> em;
+      enumerate_kmers(c->graph, em);
+      HintGraphTables gt;
+      hint_graph_tables(c->graph, gt);
+      int rc = ctx_upload(*c, device);
+      if (rc == GTX_OK)
+        rc = build_index_device(*c, em, gt);
       if (rc != GTX_OK)
       {
         ctx_release_device(*c);
         return rc;
       }
+      (void)hb;
     }
     *out = c.release();
     return GTX_OK;
@@ -160,10 +177,16 @@ extern "C"
     if (!c)
       return GTX_ERR_ARG;
     if (n_keys)
-      *n_keys = c->index.keys.size();
+      *n_keys = c->n_keys;
     if (n_labels)
-      *n_labels = c->index.labels.size();
+      *n_labels = c->n_labels;
     return GTX_OK;
+  }
+
+  // (a device-built index keeps its keys and labels on the device: they are fetched when somebody looks)
+  static int inspectable(const gtx_ctx * c)
+  {
+    return c->index_downloaded ? GTX_OK : download_index(*const_cast<gtx_ctx *>(c));
   }
 
   int gtx_index_get(const gtx_ctx * c, uint64_t key, gtx_label * out, uint32_t cap, uint32_t * n)
@@ -171,35 +194,29 @@ extern "C"
     if (!c || !n)
       return GTX_ERR_ARG;
     *n = 0;
+    if (int const rc = inspectable(c))
+      return rc;
     HostIndex const & ix = c->index;
-    if (ix.slots.empty())
+    auto it = std::lower_bound(ix.keys.begin(), ix.keys.end(), key); // PHIndex::get(key)
+    if (it == ix.keys.end() || *it != key)
       return GTX_OK;
-    uint64_t const mask = (1ull << ix.log2_cap) - 1;
-    key = plane_key(key); // the table is keyed in plane form
-    for (uint64_t b = hash_key(key, ix.log2_cap);; b = (b + 1) & mask)
-      for (uint32_t k = 0; k < BUCKET_SLOTS; ++k)
-      {
-        IndexSlot const & s = ix.slots[b * BUCKET_SLOTS + k];
-        if (s.cnt == 0)
-          return GTX_OK;
-        if (s.key == key)
-        {
-          *n = s.cnt;
-          if (out)
-          {
-            if (cap < *n)
-              return GTX_ERR_CAPACITY;
-            std::memcpy(out, ix.labels.data() + s.off, sizeof(gtx_label) * *n);
-          }
-          return GTX_OK;
-        }
-      }
+    std::size_t const k = static_cast<std::size_t>(it - ix.keys.begin());
+    *n = ix.key_off[k + 1] - ix.key_off[k];
+    if (out)
+    {
+      if (cap < *n)
+        return GTX_ERR_CAPACITY;
+      std::memcpy(out, ix.labels.data() + ix.key_off[k], sizeof(gtx_label) * *n);
+    }
+    return GTX_OK;
   }
 
   int gtx_index_dump(const gtx_ctx * c, uint64_t * keys, uint32_t * counts, gtx_label * labels)
   {
     if (!c)
       return GTX_ERR_ARG;
+    if (int const rc = inspectable(c))
+      return rc;
     HostIndex const & ix = c->index;
     for (size_t k = 0; k < ix.keys.size(); ++k)
     {

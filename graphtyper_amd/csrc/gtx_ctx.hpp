@@ -74,11 +74,20 @@ struct gtx_ctx
   std::vector<std::unique_ptr<gtx::CallScratch>> pool;
   gtx::CallScratch * last_align = nullptr; // scratch of the most recent gtx_align_batch (pass times, second-pass task count)
   bool timing_armed = false;
+  // index facts of a device-built index (gtx_index_dev.hip); its keys / labels in reference order stay on the device and
+  // are downloaded into `index` when an inspection entry point asks for them
+  uint32_t n_keys = 0, n_labels = 0;
+  uint64_t * d_keys = nullptr;
+  uint32_t * d_key_off = nullptr;
+  gtx_label * d_labels_sorted = nullptr;
+  bool index_downloaded = false;
 };
 
 namespace gtx
 {
 extern thread_local std::string g_last_error;
-int ctx_upload(gtx_ctx & c, int device);
+int ctx_upload(gtx_ctx & c, int device); // graph tables + per-call scratch (no index)
 void ctx_release_device(gtx_ctx & c);
+int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, HintGraphTables const & gt); // gtx_index_dev.hip
+int download_index(gtx_ctx & c);
 } // namespace gtx

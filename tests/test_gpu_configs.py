@@ -229,3 +229,48 @@ def test_cfg5_sv_graph(tmp_path):
     on_sv = cfg5_case(harness.GpuBackend, tmp_path, n_ref=1_000_000, n_del=100, n_ins=50, n_samples=100, pairs_per_sv=160,
                       background_pairs=12000)
     assert on_sv > 2000
+
+
+@pytest.mark.parametrize("case", ["chr1", "chr2", "chr3", "chr4", "chr9", "chr10", "chr11", "snp100", "indel", "dense", "cluster", "sv"])
+def test_device_built_index_equals_the_oracles(case):
+    """the index is built on the device (gtx_index_dev.hip: sort, grouping, hash tables, hint tables; the host only
+    enumerates the k-mers): keys, label counts and the labels in bucket order, fetched back through gtx_index_dump, must equal
+    the oracle's index_graph on the scenarios of tests/test_host_parity.py -- whose oracle side is pinned on the reference's
+    test/index/test_index.cpp -- and gtx_index_get must find what PHIndex::get finds"""
+    from fixtures import contig, sv_contig
+    kw, okw = {}, {}
+    rb = 0
+    if case.startswith("chr"):
+        ref, recs = contig(case)
+    elif case == "snp100":
+        rb = 1000000
+        r = synth.make_reference(120000, seed=5)
+        ref, recs = synth.bases_to_str(r), synth.make_snp_records(r, every=100, seed=9, region_begin=rb)
+    elif case == "indel":
+        rb = 5000
+        r = synth.make_reference(60000, seed=6)
+        ref, recs = synth.bases_to_str(r), synth.make_indel_records(r, every=37, seed=3, region_begin=rb)
+    elif case == "dense":
+        r = synth.make_reference(900, seed=8)
+        ref, recs = synth.bases_to_str(r), synth.make_snp_records(r, every=3, seed=2, first=40)
+    elif case == "cluster":
+        ref, recs, _, _ = scenarios.synthetic_case("cluster", n_ref=60000, n_reads=1, region_begin=0)
+        kw, okw = dict(add_all_variants=True), dict(add_all_variants=True)
+    else:
+        ref, recs = sv_contig("chr5")
+        kw, okw = dict(is_sv_graph=True), dict(is_sv_graph=True)
+    o = Oracle(ref, recs, region_begin=rb, **okw)
+    g = gtx.graph_from_records(ref, recs, region_begin=rb, **kw)
+    c = gtx.Context(g, device=0, is_sv_graph=(case == "sv"))
+    k1, c1, l1 = o.index_dump()
+    assert c.index_stats() == (len(k1), len(l1))
+    k2, c2, l2 = c.index_dump()
+    assert np.array_equal(k1, k2) and np.array_equal(c1, c2) and np.array_equal(l1, l2)
+    rng = np.random.default_rng(1)
+    for k in rng.choice(len(k1), size=min(len(k1), 200), replace=False):
+        assert c.index_get(int(k1[k])) == o.index_get(int(k1[k]))
+    assert c.index_get(int(k1[0]) ^ 0x5555) == o.index_get(int(k1[0]) ^ 0x5555)
+    # and the host build (contexts without a device, the test emulation) gives the same
+    h = gtx.Context(g, device=-1, is_sv_graph=(case == "sv"))
+    k3, c3, l3 = h.index_dump()
+    assert np.array_equal(k1, k3) and np.array_equal(c1, c3) and np.array_equal(l1, l3)
