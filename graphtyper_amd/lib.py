@@ -25,7 +25,7 @@ EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy"
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_set_coverage", "gtx_stream_finish", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
            "gtx_graph_destroy",
            "gtx_scores_alloc", "gtx_scores_zero", "gtx_scores_free", "gtx_scores_reduce", "gtx_comm_unique_id", "gtx_comm_init_rank",
-           "gtx_comm_destroy", "gtx_ctx_kernel_times", "gtx_ref_depth_finalize"]
+           "gtx_comm_destroy", "gtx_ctx_kernel_times", "gtx_ref_depth_finalize", "gtx_vcf_records"]
 
 
 class GraphView(C.Structure):
@@ -123,6 +123,7 @@ def lib():
                                       C.POINTER(C.c_uint64)]
         L.gtx_ctx_near_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.gtx_ref_depth_finalize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+        L.gtx_vcf_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.gtx_stream_create.argtypes = [C.POINTER(Params), C.c_uint32, C.POINTER(C.c_void_p)]
         L.gtx_stream_destroy.argtypes = [C.c_void_p]
         L.gtx_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
@@ -313,6 +314,13 @@ def pack_nibbles(codes, stride=None):
     return out
 
 
+class VcfRequest(C.Structure):
+    _fields_ = [("contig", C.c_char_p), ("sample_names", C.POINTER(C.c_char_p)), ("n_samples", C.c_uint32),
+                ("region_begin", C.c_uint32), ("region_end", C.c_uint32), ("filter_zero_qual", C.c_int32),
+                ("variant_suffix_id", C.c_char_p), ("gt_cov", C.c_void_p), ("stat_u64", C.c_void_p), ("stat_u32", C.c_void_p),
+                ("phred", C.c_void_p), ("calls", C.c_void_p)]
+
+
 class Context:
     """gtx_ctx: flat graph + index (host) and, for device >= 0, their copies in HBM"""
 
@@ -412,6 +420,20 @@ class Context:
 
     def rewind_big_records(self):
         check(lib().gtx_ctx_big_records_rewind(self.h, None))
+
+    def vcf_records(self, contig, sample_names, gt_cov, stat_u64, stat_u32, phred, calls, region_begin=0, region_end=0xFFFFFFFF,
+                    filter_zero_qual=False, variant_suffix_id=None):
+        """gtx_vcf_records: the VCF records (column line first) of the region's variant sites as bytes; all arrays are host copies"""
+        names = (C.c_char_p * max(1, len(sample_names)))(*[n.encode() for n in sample_names])
+        keep = [np.ascontiguousarray(gt_cov, np.uint32), np.ascontiguousarray(stat_u64, np.uint64), np.ascontiguousarray(stat_u32, np.uint32),
+                np.ascontiguousarray(phred, np.uint8), np.ascontiguousarray(calls, SAMPLE_CALL)]
+        rq = VcfRequest(contig.encode(), names, len(sample_names), region_begin, region_end, int(filter_zero_qual),
+                        variant_suffix_id.encode() if variant_suffix_id else None, *[C.c_void_p(a.ctypes.data) for a in keep])
+        n = C.c_uint64()
+        check(lib().gtx_vcf_records(self.h, C.byref(rq), None, C.c_uint64(0), C.byref(n)))
+        buf = C.create_string_buffer(int(n.value) + 1)
+        check(lib().gtx_vcf_records(self.h, C.byref(rq), buf, C.c_uint64(n.value), C.byref(n)))
+        return buf.raw[:int(n.value)]
 
     def phase_flags(self, n_samples, gt_cov, conn_log, n_conn, conn_near=None):
         """gtx_phase_flags: rows (hap1, allele1, hap2, allele2, flags) as an int array [n, 5]"""

@@ -18,6 +18,7 @@
  *   gtx_phase_flags     replaces  the `ph` construction                         src/utilities/hts_parallel_reader.cpp:782-904
  *   gtx_scores_reduce   replaces  the merge of the per-thread / per-pool results   src/typer/caller.cpp:439-482,
  *                                 (every per-read effect is an integer addition)  src/typer/vcf_operations.cpp:366-374
+ *   gtx_vcf_records     replaces  Vcf::add_haplotype + generate_infos + write_record   src/typer/vcf.cpp:767-1151,1507-1611
  *   gtx_graph_build     replaces  Graph::add_genomic_region                     src/graph/graph.cpp:41-339
  *   gtx_graph_from_files replaces construct_graph (small variants, structural variants) src/graph/constructor.cpp:1597-1777
  *
@@ -118,8 +119,9 @@ int gtx_graph_build(const char * reference, uint64_t reference_len, int64_t regi
                     gtx_graph ** out);
 /* Graph of one region straight from files: replaces construct_graph(reference_filename, vcf_filename, region, is_sv_graph,
  * use_index) (include/graphtyper/graph/constructor.hpp, src/graph/constructor.cpp:1597-1777) with split_multi_allelic
- * (:1033-1077), the small-variant branch of add_var_record (:1208-1262, 1493-1595) and, in an SV graph, its deletion
- * branch (add_sv_deletion, :478-514); any other structural-variant allele returns GTX_ERR_UNSUPPORTED.  fasta_path: plain FASTA, its .fai is used when present;
+ * (:1033-1077), the small-variant branch of add_var_record (:1208-1262, 1493-1595) and, in an SV graph, the structural
+ * variant branches: breakends (:312-476), <DEL> (:478-514), <INS> (:515-725), <DUP> (:727-871), <INV> (:873-1031) and
+ * transform_sv_records (:1079-1206).  fasta_path: plain FASTA, its .fai is used when present;
  * vcf_path: plain or gzip/bgzip VCF, NULL or "" for a reference-only graph; region: "chr", "chr:begin" or "chr:begin-end"
  * (1-based, GenomicRegion, src/graph/genomic_region.cpp:73-113).  region_begin / region_end (may be NULL) receive the
  * 0-based span [begin, end) of the reference bases that were read. */
@@ -335,6 +337,32 @@ typedef struct gtx_sample_call
   uint8_t reserved;
 } gtx_sample_call;
 int gtx_calls_batch(gtx_ctx *, const gtx_score_buffers * acc, uint8_t * d_phred, gtx_sample_call * d_calls, void * stream);
+
+/* ---- VCF text of the region (host side).  One record per variant site, the line the reference writes
+ * for the Variant it makes of a haplotype: Vcf::add_haplotype (src/typer/vcf.cpp:1507-1611) -> Variant::scan_calls /
+ * generate_infos (src/typer/variant.cpp:230-1096, VarStats::write_stats src/typer/var_stats.cpp:53-141) ->
+ * Vcf::write_record (vcf.cpp:767-1149: CHROM POS ID REF ALT QUAL FILTER INFO GT:AD:MD:DP:GQ:PL, PL and GQ through
+ * binned_pl) with the region filter of Vcf::write_records (vcf.cpp:1161-1275).  In front of the records stands the column
+ * line (#CHROM ... FORMAT sample names); the description lines of the header are not produced.
+ * All arrays are HOST copies: the accumulators of gtx_score_batch (raw sums or finalized) and the outputs of
+ * gtx_calls_batch for the same n_samples.  Not built: variant break-down / pool merge (vcf_operations.cpp) and the SV
+ * post-processing of the calls (reformat_sv_vcf_records): a context of an SV graph returns GTX_ERR_UNSUPPORTED.
+ * Writes min(*len, cap) bytes to out (may be NULL with cap 0 to ask for the length). */
+typedef struct gtx_vcf_request
+{
+  const char * contig;               /* CHROM */
+  const char * const * sample_names; /* [n_samples] */
+  uint32_t n_samples;
+  uint32_t region_begin, region_end; /* 1-based positions on the contig, inclusive; sites outside are skipped */
+  int32_t filter_zero_qual;          /* FILTER_ZERO_QUAL of write_record: sites with QUAL 0 are skipped */
+  const char * variant_suffix_id;    /* Options::variant_suffix_id or NULL */
+  const uint32_t * gt_cov;           /* [n_samples * total_allele] */
+  const uint64_t * stat_u64;         /* layout of gtx_score_buffers::d_stat_u64 */
+  const uint32_t * stat_u32;         /* layout of gtx_score_buffers::d_stat_u32 */
+  const uint8_t * phred;             /* [n_samples * total_tri] of gtx_calls_batch */
+  const gtx_sample_call * calls;     /* [n_samples * n_hap] of gtx_calls_batch */
+} gtx_vcf_request;
+int gtx_vcf_records(const gtx_ctx *, const gtx_vcf_request *, char * out, uint64_t cap, uint64_t * len);
 
 /* ---- multi-GPU: reads shard over the GPUs of a node (one process per GPU, graph + index replicated), the accumulators
  * are summed once per region.  The reference's counterpart is the merge of per-thread / per-pool results

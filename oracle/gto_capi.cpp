@@ -1,6 +1,7 @@
 // gto_capi.cpp -- C entry points of the CPU ORACLE (test infrastructure, not product code).
 // Loaded with ctypes from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
 #include "gto.hpp"
+#include "gto_vcf.hpp"
 
 #include <cctype>
 #include <memory>
@@ -581,6 +582,33 @@ extern "C"
       out[i] = d[sample][i];
     return n;
   }
+
+  // VCF records of the genotyper's sites (gto_vcf.hpp).  sample_names: '\n'-separated.  Returns the text length; copies
+  // min(length, cap) bytes.
+  long gto_vcf_records(void * p, char const * contig, char const * sample_names, uint32_t region_begin, uint32_t region_end,
+                       int filter_zero_qual, char const * suffix_id, char * out, long cap)
+  {
+    vcf::WriteOptions o;
+    o.contig = contig;
+    {
+      std::stringstream ss(sample_names ? sample_names : "");
+      std::string n;
+      while (std::getline(ss, n, '\n'))
+        if (!n.empty())
+          o.sample_names.push_back(n);
+    }
+    o.region_begin = region_begin;
+    o.region_end = region_end;
+    o.filter_zero_qual = filter_zero_qual != 0;
+    o.variant_suffix_id = suffix_id ? suffix_id : "";
+    std::string const text = vcf::records(*static_cast<GenoHandle *>(p)->g, o);
+    if (out && cap > 0)
+      std::memcpy(out, text.data(), static_cast<std::size_t>(std::min<long>(cap, static_cast<long>(text.size()))));
+    return static_cast<long>(text.size());
+  }
+
+  uint16_t gto_binned_pl(unsigned pl) { return vcf::binned_pl(pl); }
+  double gto_p_hwe_excess_het(int het, int hom1, int hom2) { return vcf::p_hwe_excess_het(het, hom1, hom2); }
 
   void gto_genotyper_counts(void * p, long * out)
   {

@@ -265,6 +265,17 @@ class OracleGenotyper:
         L.gto_reference_depth(C.c_void_p(self.g), C.c_long(sample), _p(out), C.c_long(n))
         return out[:n]
 
+    def vcf_records(self, contig, sample_names, region_begin=0, region_end=0xFFFFFFFF, filter_zero_qual=False, suffix_id=None):
+        """oracle/gto_vcf.hpp: the VCF records (column line first) of the genotyper's variant sites as bytes"""
+        L = lib()
+        L.gto_vcf_records.restype = C.c_long
+        args = (C.c_void_p(self.g), contig.encode(), "\n".join(sample_names).encode(), C.c_uint32(region_begin), C.c_uint32(region_end),
+                C.c_int(int(filter_zero_qual)), suffix_id.encode() if suffix_id else None)
+        n = L.gto_vcf_records(*args, None, C.c_long(0))
+        buf = C.create_string_buffer(n + 1)
+        L.gto_vcf_records(*args, buf, C.c_long(n))
+        return buf.raw[:n]
+
     def counts(self):
         c = (C.c_long * 3)()
         lib().gto_genotyper_counts(C.c_void_p(self.g), c)

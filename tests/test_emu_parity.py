@@ -141,6 +141,21 @@ def run_stream(backend, oracle, codes, rec, n_samples, n_rg=1):
     want_ph = og.phase_flags()
     assert ph.shape == want_ph.shape and np.array_equal(ph, want_ph), "phase flags differ"
     run_stream.last_phase_rows = len(ph)
+    # VCF text of the region's sites: Vcf::add_haplotype -> scan_calls / generate_infos -> write_record (oracle/gto_vcf.hpp)
+    if not backend.ctx.params.is_sv_graph:
+        names = ["SAMP%02d" % i for i in range(n_samples)]
+        lo, hi = int(backend.ctx.hap_order[len(backend.ctx.hap_order) // 4]), int(backend.ctx.hap_order[-2])
+        for kw in (dict(), dict(region_begin=lo, region_end=hi, filter_zero_qual=True)):
+            got_vcf = backend.ctx.vcf_records("chrT", names, acc.gt_cov, acc.stat_u64, acc.stat_u32, phred, calls,
+                                              variant_suffix_id="x1" if kw else None, **kw)
+            want_vcf = og.vcf_records("chrT", names, suffix_id="x1" if kw else None, **kw)
+            if got_vcf != want_vcf:
+                gl, wl = got_vcf.split(b"\n"), want_vcf.split(b"\n")
+                bad = [i for i in range(min(len(gl), len(wl))) if gl[i] != wl[i]]
+                raise AssertionError("VCF text differs (%d vs %d lines), first at line %s:\n%r\n%r" % (len(gl), len(wl), bad[:1], gl[bad[0]] if bad else b"", wl[bad[0]] if bad else b""))
+            if not kw:
+                run_stream.vcf_full = got_vcf
+        run_stream.vcf = got_vcf
     return want
 
 

@@ -1,0 +1,149 @@
+"""VCF text of a genotyped region: gtx_vcf_records (graphtyper_amd/csrc/gtx_vcf.cpp) against the
+oracle's restatement of Vcf::add_haplotype -> Variant::scan_calls / generate_infos -> Vcf::write_record (oracle/gto_vcf.hpp),
+byte for byte, on stream scenarios deep enough to reach every FILTER and the logistic models; plus what can be checked
+without the oracle: the binning table against the reference's own constants, the HWE p-value against its definition, and
+the arithmetic relations between the fields of a record.  The alignment / scoring in front runs through the emulation here
+and on the device in tests/test_gpu_parity.py (same run_stream)."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import harness
+import scenarios
+from graphtyper_amd import lib as gtx
+from oracle_lib import Oracle, lib as olib
+from test_emu_parity import run_stream
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_binned_pl_equals_the_reference_table():
+    want = json.load(open(os.path.join(HERE, "golden", "binned_pl.json")))["binned_pl"]
+    L = olib()
+    L.gto_binned_pl.restype = C.c_uint16
+    assert [int(L.gto_binned_pl(C.c_uint(i))) for i in range(256)] == want
+
+
+def test_excess_het_p_value_is_the_exact_test():
+    """p_hwe_excess_het (snp_hwe.cpp): P(#het >= observed | allele counts) under Hardy-Weinberg, Wigginton et al. 2005"""
+    L = olib()
+    L.gto_p_hwe_excess_het.restype = C.c_double
+
+    def exact(het, hom1, hom2):
+        n = het + hom1 + hom2
+        na = 2 * min(hom1, hom2) + het  # copies of the rarer allele
+        nb = 2 * n - na
+        if het == 0 and (hom1 == 0 or hom2 == 0):
+            return 1.0
+
+        def logp(h):  # probability of h heterozygotes given na, nb
+            return (h * math.log(2) + math.lgamma(n + 1) - math.lgamma((na - h) // 2 + 1) - math.lgamma(h + 1) - math.lgamma((nb - h) // 2 + 1)
+                    + math.lgamma(na + 1) + math.lgamma(nb + 1) - math.lgamma(2 * n + 1))
+        hs = range(na % 2, na + 1, 2)
+        tot = sum(math.exp(logp(h)) for h in hs)
+        return min(1.0, sum(math.exp(logp(h)) for h in hs if h >= het) / tot)
+    for het, a, b in [(0, 5, 0), (3, 10, 1), (10, 3, 3), (50, 20, 30), (1, 0, 0), (7, 100, 0), (0, 4, 4), (120, 500, 9)]:
+        got = L.gto_p_hwe_excess_het(C.c_int(het), C.c_int(a), C.c_int(b))
+        assert abs(got - exact(het, a, b)) < 1e-9 * max(1.0, got), (het, a, b, got, exact(het, a, b))
+
+
+def _parse(text):
+    lines = text.decode().split("\n")
+    assert lines[-1] == "" and lines[0].startswith("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO")
+    names = lines[0].split("\t")[9:]
+    out = []
+    for l in lines[1:-1]:
+        f = l.split("\t")
+        assert len(f) == 9 + len(names), l
+        info = dict(kv.split("=", 1) for kv in f[7].split(";"))
+        assert list(info) == sorted(info), "INFO keys are written in std::map order"
+        out.append(dict(chrom=f[0], pos=int(f[1]), id=f[2], ref=f[3], alts=f[4].split(","), qual=int(f[5]), filt=f[6], info=info, fmt=f[8],
+                        samples=[s.split(":") for s in f[9:]]))
+    return names, out
+
+
+def _check_records(records, binned):
+    """relations the reference's code implies between the fields of one record"""
+    bins = sorted(set(binned))
+    for r in records:
+        n_all = 1 + len(r["alts"])
+        assert r["fmt"] == "GT:AD:MD:DP:GQ:PL"
+        ac = [0] * n_all
+        genotyped = 0
+        qual_floor = 0
+        for gt, ad, md, dp, gq, pl in r["samples"]:
+            ad = [int(x) for x in ad.split(",")]
+            pl = [int(x) for x in pl.split(",")]
+            assert len(ad) == n_all and len(pl) == n_all * (n_all + 1) // 2
+            assert int(dp) == sum(ad) + int(md)
+            assert all(p in bins for p in pl) and int(gq) in bins and int(gq) <= 99
+            qual_floor += pl[0]
+            if gt != "./.":
+                genotyped += 1
+                a, b = (int(x) for x in gt.split("/"))
+                assert a <= b and pl[b * (b + 1) // 2 + a] == 0
+            else:
+                assert not any(pl)
+                a = b = 0
+            ac[a] += 1
+            ac[b] += 1
+        assert int(r["info"]["AN"]) == 2 * genotyped
+        assert [int(x) for x in r["info"]["AC"].split(",")] == ac[1:]
+        assert r["qual"] >= 0 and (r["qual"] == 0) == (qual_floor == 0)  # QUAL sums the unbinned PL[0]
+        assert int(r["info"]["RefLen"]) == len(r["ref"])
+        assert r["id"].startswith("%s:%d:%s" % (r["chrom"], r["pos"], r["info"]["VarType"]))
+        assert ("LowQUAL" in r["filt"]) == (r["qual"] < 10)
+        if r["info"]["ABHet"] != "-1":
+            assert ("LowABHet" in r["filt"]) == (float(r["info"]["ABHet"]) < 0.175)
+        if int(r["info"]["AN"]) >= 6:
+            assert ("LowQD" in r["filt"]) == (float(r["info"]["QD"]) < 6.0)
+            assert ("LowAAScore" in r["filt"]) == (not any(float(x) > 0.15 for x in r["info"]["AAScore"].split(",")))
+
+
+@pytest.mark.parametrize("kind", ["snp100", "indel", "cluster"])
+def test_vcf_text_deep(kind):
+    rb = 310000
+    if kind != "snp100":  # unpaired reads cut from haplotypes that carry the alleles
+        ref, recs, codes, pos = scenarios.synthetic_case(kind, n_ref=9000, n_reads=5000, region_begin=rb, seed=3)
+        kw = dict(add_all_variants=True) if kind == "cluster" else {}
+        order = np.argsort(pos, kind="stable")
+        rec = scenarios.stream_records(len(codes), pos, sample=np.arange(len(codes)) % 4)[order]
+        codes, n_samples = codes[order], 4
+    else:
+        ref, recs, codes, rec = scenarios.paired_case(kind, n_ref=6000, n_pairs=2400, region_begin=rb, n_samples=4, lowq_frac=0.03)
+        kw, n_samples = {}, 4
+    o = Oracle(ref, recs, region_begin=rb, **kw)
+    b = harness.EmuBackend(gtx.graph_from_records(ref, recs, region_begin=rb, **kw))
+    run_stream(b, o, codes, rec, n_samples=n_samples)  # compares the text with the oracle's, whole region and a filtered part
+    names, records = _parse(run_stream.vcf_full)
+    assert names == ["SAMP%02d" % i for i in range(n_samples)] and len(records) == b.ctx.n_hap
+    binned = json.load(open(os.path.join(HERE, "golden", "binned_pl.json")))["binned_pl"]
+    _check_records(records, binned)
+    filters = set(x for r in records for x in r["filt"].split(";"))
+    assert "PASS" in filters and len(filters) >= 3, filters
+    assert any(float(x) > 0.15 for r in records for x in r["info"]["AAScore"].split(","))
+    assert any(s[0] not in ("0/0", "./.") and s[0][0] == s[0][2] for r in records for s in r["samples"]), "no homozygous alt call"
+    if kind == "cluster":
+        assert max(len(r["alts"]) for r in records) >= 5 and any(r["info"]["VarType"] == "XG" for r in records)
+    if kind == "indel":
+        assert any(r["info"]["VarType"] == "IG" for r in records)
+
+
+def test_vcf_text_without_samples_and_of_sv_graphs():
+    ref, recs, codes, rec = scenarios.paired_case("snp100", n_ref=3000, n_pairs=10, region_begin=1000)
+    g = gtx.graph_from_records(ref, recs, region_begin=1000)
+    c = gtx.Context(g, device=-1)
+    z = lambda n, t: np.zeros(max(1, n), t)
+    text = c.vcf_records("chr1", [], z(0, np.uint32), z(c.n_hap + 2 * c.total_allele, np.uint64), z(c.n_hap + 6 * c.total_allele, np.uint32),
+                         z(0, np.uint8), z(0, gtx.SAMPLE_CALL))
+    lines = text.decode().split("\n")
+    assert lines[0] == "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO" and len(lines) == c.n_hap + 2
+    assert all(l.split("\t")[6] == "." and l.count("\t") == 7 for l in lines[1:-1])
+    sv = gtx.Context(g, device=-1, is_sv_graph=True)
+    with pytest.raises(gtx.GtxError) as e:
+        sv.vcf_records("chr1", [], z(0, np.uint32), z(1, np.uint64), z(1, np.uint32), z(0, np.uint8), z(0, gtx.SAMPLE_CALL))
+    assert e.value.status == 4  # GTX_ERR_UNSUPPORTED
