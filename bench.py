@@ -319,7 +319,14 @@ class Workload:
         rec_head = self.d_rec.view(self.n * 2, REC_WORDS)[:, 0]
         calls = self.d_calls.cpu().numpy().view(gtx.SAMPLE_CALL)[:self.n_samples * ctx.n_hap]
         cc = gtx.download(self.buf.d_conn_count, np.uint32, 2)
-        return {"reads_aligned": int(((rec_head[0::2] & 0xFFFF) > 0).sum().item()),
+        # VCF text of the region from the last step's results (host side, outside the timed region)
+        t0 = time.perf_counter()
+        nh, ta = ctx.n_hap, ctx.total_allele
+        text = ctx.vcf_records("chr20", ["SAMP%04d" % i for i in range(self.n_samples)],
+                               gtx.download(self.buf.d_gt_cov, np.uint32, self.n_samples * ta), gtx.download(self.buf.d_stat_u64, np.uint64, nh + 2 * ta),
+                               gtx.download(self.buf.d_stat_u32, np.uint32, nh + 6 * ta), self.d_phred.cpu().numpy()[:self.n_samples * ctx.total_tri], calls)
+        self.vcf = {"records": text.count(b"\n") - 1, "bytes": len(text), "pass": text.count(b"\tPASS\t"), "host_ms": round((time.perf_counter() - t0) * 1e3, 2)}
+        return {"reads_aligned": int(((rec_head[0::2] & 0xFFFF) > 0).sum().item()), "vcf_text": self.vcf,
                 "reads_overflowed": int((((rec_head >> 16) & gtx.ST_ERROR_MASK) != 0).sum().item()),
                 "nonref_genotype_calls": int((calls["gt_second"] > 0).sum()), "score_items_refused": ctx.error_count(),
                 "connections_logged": int(cc[0]), "connections_dropped": int(cc[1])}
@@ -477,7 +484,8 @@ def main(argv=None):
     roof["traffic"] = traffic
     cfg = {"workload": "cfg2: 1 sample, %d synthetic %d bp reads per GPU, chr20:1000001-2000000 (1 Mb), SNP-only graph "
                        "(1 SNP / %d bp), unpaired, 0.5%% substitutions, 0.1%% N; result = SampleCall (GT, PL, GQ, depths) per "
-                       "site, identical to the oracle's (VCF text is written by the host from these)" % (n, READ_LEN, args.snp_every),
+                       "site, identical to the oracle's; gtx_vcf_records writes the region's VCF records from them on the host after the "
+                       "timed steps (config.vcf_text; records byte-identical to the oracle's in the tests, unbroken sites)" % (n, READ_LEN, args.snp_every),
            "reads_per_gpu": n, "index_keys": n_keys, "index_labels": n_labels, "haplotypes": ctx.n_hap,
            "ctx_create_s": round(t_ctx_warm, 3), "ctx_create_first_s": round(t_ctx, 3),
            "position_hint": not args.no_hint,
