@@ -35,6 +35,7 @@ struct AlignCfg
   static constexpr uint32_t KC = 5;          // k-mers whose index lookups are issued together up front (reads <= 187 bp)
   static constexpr uint32_t HE_CAP = 4;      // half-key bucket entries fetched up front per (k-mer, side)
   static constexpr uint32_t XL_CAP = 2;      // exact labels fetched up front per k-mer
+  static constexpr uint32_t MW = 2;          // 32-bit words of an allele set: alleles 0..63 (a label beyond is an overflow)
 };
 
 #include "align_core.inl"
@@ -64,8 +65,36 @@ struct AlignCfg
   static constexpr uint32_t KC = 5;
   static constexpr uint32_t HE_CAP = 4;
   static constexpr uint32_t XL_CAP = 4;
+  static constexpr uint32_t MW = 2;
 };
 #include "align_core.inl"
 } // namespace big
+
+// a further HBM-table pass for graphs that have a site with more than 64 alleles (merged clusters: up to
+// MAX_NUMBER_OF_HAPLOTYPES = 2560, include/graphtyper/constants.hpp.in:23): allele sets of GTX_WIDE_MASK_WORDS words.  The
+// passes in front hand on every task that meets an allele number >= 64 (GTX_ST_WIDE_ALLELE).
+namespace wide
+{
+struct AlignCfg // (a path with its allele sets is 5 KB here: fewer of them than in big::, what exceeds them keeps its status)
+{
+  static constexpr uint32_t MAX_READ = 256;
+  static constexpr uint32_t MAX_KMERS = 8;
+  static constexpr uint32_t LBL_CAP = 2048;
+  static constexpr uint32_t MAXP = 128;
+  static constexpr uint32_t MAXPP = 128;
+  static constexpr uint32_t MAXV = 16;
+  static constexpr uint32_t CAND_CAP = 8192; // one round of a walk over a site branches into every allele within the mismatch budget
+  static constexpr uint32_t MAXIDS = 24;
+  static constexpr uint32_t LOC_CAP = 256;
+  static constexpr uint32_t WL_CAP = 2048;
+  static constexpr uint32_t WLISTS = 256;
+  static constexpr uint32_t KEY_CAP = 388;
+  static constexpr uint32_t KC = 5;
+  static constexpr uint32_t HE_CAP = 4;
+  static constexpr uint32_t XL_CAP = 4;
+  static constexpr uint32_t MW = GTX_WIDE_MASK_WORDS;
+};
+#include "align_core.inl"
+} // namespace wide
 
 } // namespace gtx

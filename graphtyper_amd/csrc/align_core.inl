@@ -7,8 +7,10 @@ struct Here {}; // tag of this instantiation's namespace: keeps argument-depende
 struct PVar
 {
   uint32_t site;
-  uint32_t mlo, mhi; // allele set (Path::nums[i]) as a 64-bit mask
+  uint32_t m[AlignCfg::MW]; // allele set (Path::nums[i]) as a bit mask of 32 * MW alleles: two words in the LDS and HBM passes,
+                            // MAX_NUMBER_OF_HAPLOTYPES bits (constants.hpp.in:23) in the pass for graphs with wider sites
 };
+constexpr uint32_t PVAR_WORDS = 1 + AlignCfg::MW;
 
 struct DPath // gyper::Path (include/graphtyper/typer/path.hpp:18-79)
 {
@@ -97,9 +99,70 @@ struct SeedWorkspace
 #endif
 };
 
-GTX_DEV uint64_t pv_mask(PVar const & v)
+// allele sets.  Readers apply GTX_U per word (the tables are wave-uniform), writers run on the leader lane.
+GTX_DEV bool pv_fits(uint32_t allele) // an allele beyond this pass' masks: the task overflows to the pass that holds it
 {
-  return (static_cast<uint64_t>(v.mhi) << 32) | v.mlo;
+  return allele < 32u * AlignCfg::MW;
+}
+
+template <class W>
+GTX_DEV bool pv_has(PVar const & v, uint32_t allele)
+{
+  return allele < 32u * AlignCfg::MW && ((GTX_U(v.m[allele >> 5]) >> (allele & 31u)) & 1u);
+}
+
+GTX_DEV void pv_set_single(PVar & v, uint32_t allele)
+{
+  for (uint32_t w = 0; w < AlignCfg::MW; ++w)
+    v.m[w] = 0;
+  v.m[allele >> 5] = 1u << (allele & 31u);
+}
+
+GTX_DEV void pv_add(PVar & v, uint32_t allele)
+{
+  v.m[allele >> 5] |= 1u << (allele & 31u);
+}
+
+GTX_DEV void pv_clear(PVar & v)
+{
+  for (uint32_t w = 0; w < AlignCfg::MW; ++w)
+    v.m[w] = 0;
+}
+
+template <class W>
+GTX_DEV bool pv_meet_any(PVar const & a, PVar const & b)
+{
+  uint32_t any = 0;
+  for (uint32_t w = 0; w < AlignCfg::MW; ++w)
+    any |= GTX_U(a.m[w]) & GTX_U(b.m[w]);
+  return any != 0;
+}
+
+GTX_DEV void pv_meet(PVar & a, PVar const & b)
+{
+  for (uint32_t w = 0; w < AlignCfg::MW; ++w)
+    a.m[w] &= b.m[w];
+}
+
+// copy of a path: only the part in use (a path of the wide-site pass is 13 KB, nearly all of it unused mask words)
+template <class W>
+GTX_DEV void copy_path(DPath & dst, DPath const & src)
+{
+  if constexpr (DPATH_WORDS <= 64)
+    copy_entry<W>(dst, src);
+  else
+  {
+    if (&dst == &src)
+      return;
+    uint32_t const words = 4 + PVAR_WORDS * GTX_U(static_cast<uint32_t>(src.nvar));
+    uint32_t * d = reinterpret_cast<uint32_t *>(&dst);
+    uint32_t const * s = reinterpret_cast<uint32_t const *>(&src);
+    W::lanes([&](uint32_t l) {
+      for (uint32_t w = l; w < words; w += 64)
+        d[w] = s[w];
+    });
+    W::lds_sync();
+  }
 }
 
 GTX_DEV uint32_t path_size(DPath const & p)
@@ -170,18 +233,25 @@ GTX_DEV uint32_t get_locations(GraphView const & g, uint32_t pos, DPath const & 
     if (!(reach + static_cast<int64_t>(g.padding) > static_cast<int64_t>(pos)))
       break; // the reference stops its backward scan here; lower sites reach even less far
     uint32_t const fv = GTX_U(g.ref_first_var[site]), nv = GTX_U(g.ref_nvar[site]);
-    uint64_t const mask = (static_cast<uint64_t>(GTX_U(path.v[best_j].mhi)) << 32) | GTX_U(path.v[best_j].mlo);
     for (uint32_t i = 0; i < nv; ++i)
     {
       uint32_t const v = fv + i;
       uint32_t const vo = GTX_U(g.var_order[v]);
       if (pos >= vo && pos <= vo + GTX_U(g.var_len[v]) - 1)
-        if (path_empty || ((mask >> i) & 1ull))
+        if (path_empty || pv_has<W>(path.v[best_j], i))
         {
           if (n >= cap)
           {
-            status |= GTX_ST_DFS_OVERFLOW;
-            return n;
+            // beyond the table: with room for MAX_NUM_LOCATIONS_PER_PATH the caller only needs the count (it skips a path
+            // with more locations, genotype_paths.cpp:508, 585: a site of a thousand alleles has that many), else the
+            // task is for the pass with the larger table
+            if (cap < MAX_NUM_LOCATIONS_PER_PATH)
+            {
+              status |= GTX_ST_DFS_OVERFLOW;
+              return n;
+            }
+            ++n;
+            continue;
           }
           GTX_LEAD locs[n] = Loc{2, v, vo, pos - vo};
           ++n;
@@ -523,6 +593,11 @@ GTX_DEV uint32_t make_pp(DPath * pp, DevLabel const * ll, uint32_t n, uint32_t r
   for (uint32_t i = 0; i < n; ++i)
   {
     uint32_t const ls = GTX_U(ll[i].start), le = GTX_U(ll[i].end), lsite = GTX_U(ll[i].site), lall = GTX_U(ll[i].allele);
+    if (lsite != INVALID && !pv_fits(lall))
+    {
+      status |= GTX_ST_PATH_OVERFLOW | GTX_ST_WIDE_ALLELE;
+      return npp;
+    }
     uint32_t d = 0;
     for (; d < npp; ++d)
       if (GTX_U(pp[d].start) == ls && GTX_U(pp[d].end) == le)
@@ -546,8 +621,7 @@ GTX_DEV uint32_t make_pp(DPath * pp, DevLabel const * ll, uint32_t n, uint32_t r
         if (lsite != INVALID)
         {
           p.v[0].site = lsite;
-          p.v[0].mlo = static_cast<uint32_t>(1ull << lall);
-          p.v[0].mhi = static_cast<uint32_t>((1ull << lall) >> 32);
+          pv_set_single(p.v[0], lall);
         }
       }
       W::lds_sync();
@@ -570,15 +644,11 @@ GTX_DEV uint32_t make_pp(DPath * pp, DevLabel const * ll, uint32_t n, uint32_t r
     GTX_LEAD
     {
       if (k < nvar)
-      {
-        p.v[k].mlo |= static_cast<uint32_t>(1ull << lall);
-        p.v[k].mhi |= static_cast<uint32_t>((1ull << lall) >> 32);
-      }
+        pv_add(p.v[k], lall);
       else
       {
         p.v[nvar].site = lsite;
-        p.v[nvar].mlo = static_cast<uint32_t>(1ull << lall);
-        p.v[nvar].mhi = static_cast<uint32_t>((1ull << lall) >> 32);
+        pv_set_single(p.v[nvar], lall);
         p.nvar = static_cast<uint16_t>(nvar + 1);
       }
     }
@@ -593,7 +663,7 @@ GTX_DEV uint32_t make_pp(DPath * pp, DevLabel const * ll, uint32_t n, uint32_t r
 template <class W>
 GTX_DEV bool merge_paths(DPath const & p1, DPath const & p2, DPath & np, uint32_t & status)
 {
-  copy_entry<W>(np, p2);
+  copy_path<W>(np, p2);
   uint32_t const n1 = GTX_U(static_cast<uint32_t>(p1.nvar));
   uint32_t nn = GTX_U(static_cast<uint32_t>(np.nvar));
   for (uint32_t i = 0; i < n1; ++i)
@@ -605,14 +675,9 @@ GTX_DEV bool merge_paths(DPath const & p1, DPath const & p2, DPath & np, uint32_
         break;
     if (j < nn)
     {
-      uint32_t const lo = GTX_U(np.v[j].mlo & p1.v[i].mlo), hi = GTX_U(np.v[j].mhi & p1.v[i].mhi);
-      if ((lo | hi) == 0)
+      if (!pv_meet_any<W>(np.v[j], p1.v[i]))
         return false;
-      GTX_LEAD
-      {
-        np.v[j].mlo = lo;
-        np.v[j].mhi = hi;
-      }
+      GTX_LEAD pv_meet(np.v[j], p1.v[i]);
     }
     else
     {
@@ -646,7 +711,7 @@ GTX_DEV bool push_path(AlignWorkspace & ws, uint32_t & n_paths, DPath const & p,
     status |= GTX_ST_PATH_OVERFLOW;
     return false;
   }
-  copy_entry<W>(ws.paths[n_paths], p);
+  copy_path<W>(ws.paths[n_paths], p);
   ++n_paths;
   return true;
 }
@@ -664,8 +729,11 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
     // end and mismatches advanced and P's site moved to the front of the site list (path.cpp:38-82 keeps p2's sites
     // first), its allele set intersected when p1 already carries the site.
     uint32_t const ls = GTX_U(ll[0].start), le = GTX_U(ll[0].end), lsite = GTX_U(ll[0].site), lall = GTX_U(ll[0].allele);
-    uint32_t const lmlo = lsite != INVALID ? static_cast<uint32_t>(1ull << lall) : 0u;
-    uint32_t const lmhi = lsite != INVALID ? static_cast<uint32_t>((1ull << lall) >> 32) : 0u;
+    if (lsite != INVALID && !pv_fits(lall))
+    {
+      status |= GTX_ST_PATH_OVERFLOW | GTX_ST_WIDE_ALLELE;
+      return;
+    }
     bool matched = false;
     uint32_t const original_size = n_paths;
     for (uint32_t i = 0; i < original_size; ++i)
@@ -675,7 +743,7 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
       if ((w2 >> 16) != rs || GTX_U(p.end) != ls)
         continue;
       uint32_t const nvar = GTX_U(static_cast<uint32_t>(p.nvar));
-      uint32_t j = nvar, mlo = lmlo, mhi = lmhi;
+      uint32_t j = nvar;
       if (lsite != INVALID)
       {
         for (j = 0; j < nvar; ++j)
@@ -683,9 +751,7 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
             break;
         if (j < nvar)
         {
-          mlo &= GTX_U(p.v[j].mlo);
-          mhi &= GTX_U(p.v[j].mhi);
-          if ((mlo | mhi) == 0)
+          if (!pv_has<W>(p.v[j], lall))
             continue; // empty allele intersection: this path does not merge
         }
         else if (nvar >= AlignCfg::MAXV)
@@ -701,8 +767,7 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
           for (uint32_t k = j; k > 0; --k) // sites before j (or all of them) move one place back
             p.v[k] = p.v[k - 1];
           p.v[0].site = lsite;
-          p.v[0].mlo = mlo;
-          p.v[0].mhi = mhi;
+          pv_set_single(p.v[0], lall); // ({allele} met with a set that holds it)
           if (j == nvar)
             p.nvar = static_cast<uint16_t>(nvar + 1);
         }
@@ -733,8 +798,10 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
         p.mism = static_cast<uint16_t>(mism);
         p.nvar = lsite != INVALID ? 1 : 0;
         p.v[0].site = lsite;
-        p.v[0].mlo = lmlo;
-        p.v[0].mhi = lmhi;
+        if (lsite != INVALID)
+          pv_set_single(p.v[0], lall);
+        else
+          pv_clear(p.v[0]);
       }
       W::lds_sync();
       ++n_paths;
@@ -755,7 +822,7 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
     if (prev ? (GTX_U(static_cast<uint32_t>(ws.paths[i].rs)) != re) : (GTX_U(static_cast<uint32_t>(ws.paths[i].re)) != rs))
       continue;
     bool once = false;
-    copy_entry<W>(ws.orig, ws.paths[i]);
+    copy_path<W>(ws.orig, ws.paths[i]);
     uint32_t const o_start = GTX_U(ws.orig.start), o_end = GTX_U(ws.orig.end);
     for (uint32_t j = 0; j < npp; ++j)
     {
@@ -787,7 +854,7 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
         uint32_t const sz = upath_size<W>(ws.np);
         if (sz > longest)
           longest = sz;
-        copy_entry<W>(ws.paths[i], ws.np);
+        copy_path<W>(ws.paths[i], ws.np);
         once = true;
       }
     }
@@ -820,7 +887,7 @@ GTX_DEV uint32_t compact_paths(AlignWorkspace & ws, uint32_t n_paths, PathSet co
     if (!drop.get(i))
     {
       if (k != i)
-        copy_entry<W>(ws.paths[k], ws.paths[i]);
+        copy_path<W>(ws.paths[k], ws.paths[i]);
       ++k;
     }
   return k;
@@ -887,7 +954,7 @@ GTX_DEV bool path_is_reference(DPath const & p) // path.cpp:176-185
 {
   uint32_t const nv = GTX_U(static_cast<uint32_t>(p.nvar));
   for (uint32_t k = 0; k < nv; ++k)
-    if (!(GTX_U(p.v[k].mlo) & 1u))
+    if (!(GTX_U(p.v[k].m[0]) & 1u))
       return false;
   return true;
 }
@@ -958,15 +1025,9 @@ GTX_DEV void remove_support_from_read_ends(GraphView const & g, AlignWorkspace &
     GTX_LEAD
     {
       if (clear_max)
-      {
-        p.v[imax].mlo = 0;
-        p.v[imax].mhi = 0;
-      }
+        pv_clear(p.v[imax]);
       if (clear_min)
-      {
-        p.v[imin].mlo = 0;
-        p.v[imin].mhi = 0;
-      }
+        pv_clear(p.v[imin]);
     }
     W::lds_sync();
   }
@@ -1689,7 +1750,7 @@ GTX_DEV bool seed_stage(Here, GraphView const & g, IndexView const & ix, WS & ws
             ws.fs_end[l] = lb.end;
             if (lb.site != INVALID) // the only label there is lies on a variant (e.g. an error inside a k-mer over a SNP)
             {
-              bad = g.is_sv_graph != 0;
+              bad = g.is_sv_graph != 0 || !pv_fits(lb.allele);
               why = 4;
               has_var = !bad;
               ws.fs_site = lb.site;
@@ -1705,7 +1766,7 @@ GTX_DEV bool seed_stage(Here, GraphView const & g, IndexView const & ix, WS & ws
             // loses to it in remove_short_paths / remove_paths_with_too_many_mismatches; the exact chain, carrying
             // {site, allele}, is what remains.  A neighbour anywhere else could out-walk the chain: not handled here.
             DevLabel const lb = ws.xl[l][0];
-            bad = lb.site == INVALID;
+            bad = lb.site == INVALID || !pv_fits(lb.allele);
             for (uint32_t side = 0; side < 2 && !bad; ++side)
               for (uint32_t e = 0; e < ws.hcnt[l][side]; ++e)
               {
@@ -1780,10 +1841,8 @@ GTX_DEV bool seed_stage(Here, GraphView const & g, IndexView const & ix, WS & ws
           p.nvar = with_var ? 1 : 0;
           if (with_var)
           {
-            uint32_t const allele = ws.fs_allele;
             p.v[0].site = ws.fs_site;
-            p.v[0].mlo = static_cast<uint32_t>(1ull << allele);
-            p.v[0].mhi = static_cast<uint32_t>((1ull << allele) >> 32);
+            pv_set_single(p.v[0], ws.fs_allele);
           }
         }
         W::lds_sync();
@@ -1961,7 +2020,7 @@ GTX_DEV uint32_t record_size(Here, WS const & ws, uint32_t n_paths)
 {
   uint32_t w = 2;
   for (uint32_t i = 0; i < n_paths; ++i)
-    w += 4 + 3 * GTX_U(static_cast<uint32_t>(ws.paths[i].nvar));
+    w += 4 + PVAR_WORDS * GTX_U(static_cast<uint32_t>(ws.paths[i].nvar));
   return w;
 }
 
@@ -1978,7 +2037,7 @@ GTX_DEV uint32_t write_record_body(Here, WS const & ws, uint32_t n_paths, uint32
     uint32_t const nvar = GTX_U(static_cast<uint32_t>(p.nvar));
     any_var |= nvar;
     uint32_t const * src = reinterpret_cast<uint32_t const *>(&p);
-    uint32_t const nw = 4 + 3 * nvar;
+    uint32_t const nw = 4 + PVAR_WORDS * nvar;
     W::lanes([&](uint32_t l) {
       for (uint32_t x = l; x < nw; x += 64)
       {
@@ -1990,7 +2049,7 @@ GTX_DEV uint32_t write_record_body(Here, WS const & ws, uint32_t n_paths, uint32
     });
     w += nw;
   }
-  return any_var ? GTX_REC_HAS_VARIANTS : 0u;
+  return (any_var ? GTX_REC_HAS_VARIANTS : 0u) | (AlignCfg::MW > 2 ? GTX_REC_WIDE : 0u);
 }
 
 // one (read, orientation) of the main pass: result into its record slot
@@ -2011,7 +2070,7 @@ GTX_DEV uint32_t align_one(GraphView const & g, IndexView const & ix, AlignWorks
   uint32_t const has_var = write_record_body<W>(Here{}, ws, np, rec + 2);
   GTX_LEAD
   {
-    rec[0] = np | (status << 16);
+    rec[0] = np | ((status & ~GTX_ST_WIDE_ALLELE) << 16);
     rec[1] = (np == 0 ? 0 : longest) | (len << 16) | has_var;
   }
   W::lds_sync();

@@ -409,7 +409,8 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
           l0_end = lb.end;
           first_label = false;
         }
-        bad = bad || lb.start != l0_start || lb.end != l0_end || (lb.site == INVALID && !only_one);
+        bad = bad || lb.start != l0_start || lb.end != l0_end || (lb.site == INVALID && !only_one) ||
+              (lb.site != INVALID && lb.allele >= 64u); // (an allele beyond the 64-bit sets of this pass: left to the general passes)
         if (!bad && lb.site != INVALID)
         {
           bool placed = false;

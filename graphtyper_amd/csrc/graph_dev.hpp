@@ -38,6 +38,10 @@ struct alignas(16) uint4_t // 16-byte move
   uint32_t x, y, z, w;
 };
 
+// internal status bit (never stored in a record): the task met an allele number beyond the allele sets of the pass it was
+// in; together with GTX_ST_PATH_OVERFLOW it sends the task on, in the end to the pass with GTX_WIDE_MASK_WORDS-word sets
+constexpr uint32_t GTX_ST_WIDE_ALLELE = 32u;
+
 #define GTX_LEAD if (W::leader())
 
 // Values that are equal on all lanes by construction (loaded from LDS state or from graph tables at a uniform address)

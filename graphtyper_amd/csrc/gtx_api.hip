@@ -650,68 +650,88 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void gt
 
 // Second pass over the queued (read, orientation) tasks: same algorithm instantiated over tables large enough for what
 // the reference's own limits admit; one workspace in HBM per workgroup.  The queue is usually empty or tiny.
-__global__ __launch_bounds__(64) void gtx_align_big_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
-                                                           uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
-                                                           uint32_t * __restrict__ records, uint32_t rec_words,
-                                                           uint32_t const * __restrict__ big_tasks, uint32_t big_task_cap,
-                                                           uint32_t * big_state, big::AlignWorkspace * workspaces,
-                                                           uint32_t * __restrict__ arena, unsigned long long arena_words,
-                                                           unsigned long long * arena_cursor)
-{
-  big::AlignWorkspace & ws = workspaces[blockIdx.x];
-#ifdef GTX_PROF
-  if (threadIdx.x < 16)
-    ws.prof_acc[threadIdx.x] = 0; // (second-pass cycles are not added to the report)
-  WaveHipMem::mem_sync();
-#endif
-  uint32_t const queued = big_state[0] < big_task_cap ? big_state[0] : big_task_cap;
-  for (;;)
-  {
-    uint32_t const t = wave_claim(big_state + 1, 1u);
-    if (t >= queued)
-      break;
-    uint32_t const task = WaveHip::uni(big_tasks[t]), read = task >> 1, orient = task & 1u;
-    uint32_t const len = WaveHip::uni(static_cast<uint32_t>(meta[read].l_qseq));
-    uint32_t * rec = records + static_cast<uint64_t>(task) * rec_words;
-    uint32_t np = 0, longest = 0, ext = 0;
-    uint32_t status = big::align_paths<WaveHipMem>(g, ix, ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest);
-    status = WaveHip::uni(status);
-    np = WaveHip::uni(np);
-    longest = WaveHip::uni(longest);
-    uint32_t * body = rec + 2;
-    unsigned long long off = 0;
-    if (status)
-      np = 0;
-    else
-    {
-      uint32_t const size = WaveHip::uni(big::record_size<WaveHipMem>(big::Here{}, ws, np));
-      if (size > rec_words)
-      {
-        // long record: room in the arena; the slot keeps the header and the offset
-        off = wave_claim64(arena_cursor, size - 2);
-        if (off + (size - 2) > arena_words || off + (size - 2) > 0xFFFFFFFFull)
-        {
-          status = GTX_ST_RECORD_OVERFLOW;
-          np = 0;
-        }
-        else
-        {
-          body = arena + off;
-          ext = GTX_ST_EXTERNAL;
-        }
-      }
-    }
-    uint32_t const has_var = big::write_record_body<WaveHipMem>(big::Here{}, ws, np, body);
-    if ((threadIdx.x & 63u) == 0)
-    {
-      rec[0] = np | ((status | ext) << 16);
-      rec[1] = (np == 0 ? 0 : longest) | (len << 16) | has_var;
-      if (ext)
-        rec[2] = static_cast<uint32_t>(off);
-    }
-    WaveHipMem::mem_sync();
+// A graph with a site of more than 64 alleles has a further pass of the same shape behind it (NS = wide: allele sets of
+// GTX_WIDE_MASK_WORDS words, a larger table of walk candidates: one round of a walk branches into every allele of a site):
+// a task that met an allele number >= 64 or overflowed a table is handed on to it (next_tasks / next_state).
+#define GTX_HBM_PASS_KERNEL(NAME, NS)                                                                                              \
+  __global__ __launch_bounds__(64) void NAME(GraphView g, IndexView ix, uint8_t const * __restrict__ seq, uint32_t seq_stride,      \
+                                             gtx_read_meta const * __restrict__ meta, uint32_t * __restrict__ records,             \
+                                             uint32_t rec_words, uint32_t const * __restrict__ big_tasks, uint32_t big_task_cap,   \
+                                             uint32_t * big_state, NS::AlignWorkspace * workspaces, uint32_t * __restrict__ arena, \
+                                             unsigned long long arena_words, unsigned long long * arena_cursor,                    \
+                                             uint32_t * __restrict__ next_tasks, uint32_t next_cap, uint32_t * next_state)         \
+  {                                                                                                                                \
+    NS::AlignWorkspace & ws = workspaces[blockIdx.x];                                                                              \
+    GTX_HBM_PASS_PROF_INIT                                                                                                         \
+    uint32_t const queued = big_state[0] < big_task_cap ? big_state[0] : big_task_cap;                                             \
+    for (;;)                                                                                                                       \
+    {                                                                                                                              \
+      uint32_t const t = wave_claim(big_state + 1, 1u);                                                                            \
+      if (t >= queued)                                                                                                             \
+        break;                                                                                                                     \
+      uint32_t const task = WaveHip::uni(big_tasks[t]), read = task >> 1, orient = task & 1u;                                      \
+      uint32_t const len = WaveHip::uni(static_cast<uint32_t>(meta[read].l_qseq));                                                 \
+      uint32_t * rec = records + static_cast<uint64_t>(task) * rec_words;                                                          \
+      uint32_t np = 0, longest = 0, ext = 0;                                                                                       \
+      uint32_t status =                                                                                                            \
+        NS::align_paths<WaveHipMem>(g, ix, ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest);     \
+      status = WaveHip::uni(status);                                                                                               \
+      np = WaveHip::uni(np);                                                                                                       \
+      longest = WaveHip::uni(longest);                                                                                             \
+      if (status && next_tasks && (threadIdx.x & 63u) == 0) /* an allele >= 64, or a table the next pass has larger */            \
+      {                                                                                                                            \
+        uint32_t const slot = atomicAdd(next_state, 1u);                                                                           \
+        if (slot < next_cap)                                                                                                       \
+          next_tasks[slot] = task;                                                                                                 \
+        else                                                                                                                       \
+          atomicAdd(next_state + 3, 1u);                                                                                           \
+      }                                                                                                                            \
+      status &= ~GTX_ST_WIDE_ALLELE;                                                                                               \
+      uint32_t * body = rec + 2;                                                                                                   \
+      unsigned long long off = 0;                                                                                                  \
+      if (status)                                                                                                                  \
+        np = 0;                                                                                                                    \
+      else                                                                                                                         \
+      {                                                                                                                            \
+        uint32_t const size = WaveHip::uni(NS::record_size<WaveHipMem>(NS::Here{}, ws, np));                                       \
+        if (size > rec_words)                                                                                                      \
+        {                                                                                                                          \
+          /* long record: room in the arena; the slot keeps the header and the offset */                                           \
+          off = wave_claim64(arena_cursor, size - 2);                                                                              \
+          if (off + (size - 2) > arena_words || off + (size - 2) > 0xFFFFFFFFull)                                                  \
+          {                                                                                                                        \
+            status = GTX_ST_RECORD_OVERFLOW;                                                                                       \
+            np = 0;                                                                                                                \
+          }                                                                                                                        \
+          else                                                                                                                     \
+          {                                                                                                                        \
+            body = arena + off;                                                                                                    \
+            ext = GTX_ST_EXTERNAL;                                                                                                 \
+          }                                                                                                                        \
+        }                                                                                                                          \
+      }                                                                                                                            \
+      uint32_t const has_var = NS::write_record_body<WaveHipMem>(NS::Here{}, ws, np, body);                                        \
+      if ((threadIdx.x & 63u) == 0)                                                                                                \
+      {                                                                                                                            \
+        rec[0] = np | ((status | ext) << 16);                                                                                      \
+        rec[1] = (np == 0 ? 0 : longest) | (len << 16) | (np == 0 ? 0u : has_var);                                                 \
+        if (ext)                                                                                                                   \
+          rec[2] = static_cast<uint32_t>(off);                                                                                     \
+      }                                                                                                                            \
+      WaveHipMem::mem_sync();                                                                                                      \
+    }                                                                                                                              \
   }
-}
+
+#ifdef GTX_PROF
+#define GTX_HBM_PASS_PROF_INIT                                                                                                     \
+  if (threadIdx.x < 16)                                                                                                            \
+    ws.prof_acc[threadIdx.x] = 0; /* (second-pass cycles are not added to the report) */                                           \
+  WaveHipMem::mem_sync();
+#else
+#define GTX_HBM_PASS_PROF_INIT
+#endif
+GTX_HBM_PASS_KERNEL(gtx_align_big_kernel, big)
+GTX_HBM_PASS_KERNEL(gtx_align_wide_kernel, wide)
 
 // Scoring, stage 1 (triage): one thread per item reads the record header(s) and decides whether the item can add
 // anything; 85 % of the cfg2 items cannot and end here.  No per-thread tables, so this kernel runs at full occupancy.
@@ -767,17 +787,36 @@ __global__ __launch_bounds__(256) void gtx_score_kernel(GraphView g, ScoreParams
   }
 }
 
+template <class RH, uint32_t CAP>
+GTX_DEV void score_big_pass(GraphView const & g, ScoreParams const & par, gtx_score_item const * __restrict__ items,
+                            uint32_t const * __restrict__ records, uint32_t rec_words, ScoreAcc const & acc, uint32_t * error_flag,
+                            uint32_t const * __restrict__ big_queue, uint32_t big_queue_cap, uint32_t const * big_state, RH * tables)
+{
+  uint32_t const queued = big_state[0] < big_queue_cap ? big_state[0] : big_queue_cap;
+  uint32_t const tid = blockIdx.x * blockDim.x + threadIdx.x, n_threads = gridDim.x * blockDim.x;
+  RH * r1 = tables + static_cast<uint64_t>(tid) * 2 * CAP;
+  for (uint32_t q = tid; q < queued; q += n_threads)
+    if (!score_item<WaveHip>(g, par, items[big_queue[q]], records, rec_words, acc, r1, r1 + CAP, CAP))
+      atomicAdd(error_flag, 1u);
+}
+
 __global__ __launch_bounds__(64) void gtx_score_big_kernel(GraphView g, ScoreParams par, gtx_score_item const * __restrict__ items,
                                                            uint32_t const * __restrict__ records, uint32_t rec_words, ScoreAcc acc,
                                                            uint32_t * error_flag, uint32_t const * __restrict__ big_queue,
                                                            uint32_t big_queue_cap, uint32_t const * big_state, RecentHap * tables)
 {
-  uint32_t const queued = big_state[0] < big_queue_cap ? big_state[0] : big_queue_cap;
-  uint32_t const tid = blockIdx.x * blockDim.x + threadIdx.x, n_threads = gridDim.x * blockDim.x;
-  RecentHap * r1 = tables + static_cast<uint64_t>(tid) * 2 * SCORE_MAX_HAPS_BIG;
-  for (uint32_t q = tid; q < queued; q += n_threads)
-    if (!score_item<WaveHip>(g, par, items[big_queue[q]], records, rec_words, acc, r1, r1 + SCORE_MAX_HAPS_BIG, SCORE_MAX_HAPS_BIG))
-      atomicAdd(error_flag, 1u);
+  score_big_pass<RecentHap, SCORE_MAX_HAPS_BIG>(g, par, items, records, rec_words, acc, error_flag, big_queue, big_queue_cap, big_state, tables);
+}
+
+// the same for graphs with a site of more than 64 alleles: explain sets of GTX_WIDE_MASK_WORDS words (records with
+// GTX_REC_WIDE are refused by the passes in front)
+__global__ __launch_bounds__(64) void gtx_score_wide_kernel(GraphView g, ScoreParams par, gtx_score_item const * __restrict__ items,
+                                                            uint32_t const * __restrict__ records, uint32_t rec_words, ScoreAcc acc,
+                                                            uint32_t * error_flag, uint32_t const * __restrict__ big_queue,
+                                                            uint32_t big_queue_cap, uint32_t const * big_state, RecentHapWide * tables)
+{
+  score_big_pass<RecentHapWide, SCORE_MAX_HAPS_WIDE>(g, par, items, records, rec_words, acc, error_flag, big_queue, big_queue_cap, big_state,
+                                                     tables);
 }
 
 // One thread per (sample, haplotype): call_cell in score_core.hpp.
@@ -834,7 +873,7 @@ static bool dev_alloc(T *& dst, size_t n, char const * what, bool zero = false)
 static void scratch_free(CallScratch & s)
 {
   void * ptrs[] = {s.d_counters, s.d_queue1, s.d_queue, s.d_big_tasks, s.d_big_state, s.d_big_ws, s.d_score_state, s.d_score_queue,
-                   s.d_score_tables, s.d_score_work};
+                   s.d_score_tables, s.d_score_work, s.d_wide_tasks, s.d_wide_ws};
   for (void * p : ptrs)
     if (p)
       (void)hipFree(p);
@@ -862,15 +901,32 @@ static std::unique_ptr<CallScratch> scratch_new(gtx_ctx & c)
   ok = ok && dev_alloc(s->d_counters, 8 * CallScratch::MAX_PARTS, "task counters", true);
   if (ok && !c.params.no_second_pass)
   {
-    ok = ok && dev_alloc(s->d_big_state, 8, "second-pass state", true);
+    ok = ok && dev_alloc(s->d_big_state, 16, "second-pass state", true);
     void * ws = nullptr;
     ok = ok && hip_ok(hipMalloc(&ws, static_cast<size_t>(c.big_blocks) * sizeof(big::AlignWorkspace)), "second-pass workspaces");
     s->d_big_ws = ws;
+    if (ok && c.has_wide_sites)
+    {
+      s->d_wide_state = s->d_big_state + 8;
+      ok = ok && dev_alloc(s->d_wide_tasks, CallScratch::WIDE_TASK_CAP, "wide-site pass queue");
+      void * wws = nullptr;
+      ok = ok && hip_ok(hipMalloc(&wws, static_cast<size_t>(CallScratch::WIDE_BLOCKS) * sizeof(wide::AlignWorkspace)), "wide-site pass workspaces");
+      s->d_wide_ws = wws;
+    }
     ok = ok && dev_alloc(s->d_score_state, 2, "second-pass score state", true);
     ok = ok && dev_alloc(s->d_score_queue, gtx_ctx::SCORE_QUEUE_CAP, "second-pass score queue");
-    RecentHap * tables = nullptr;
-    ok = ok && dev_alloc(tables, static_cast<size_t>(gtx_ctx::SCORE_BIG_THREADS) * 2 * SCORE_MAX_HAPS_BIG, "second-pass score tables");
-    s->d_score_tables = tables;
+    if (c.has_wide_sites)
+    {
+      RecentHapWide * tables = nullptr;
+      ok = ok && dev_alloc(tables, static_cast<size_t>(gtx_ctx::SCORE_BIG_THREADS) * 2 * SCORE_MAX_HAPS_WIDE, "wide-site score tables");
+      s->d_score_tables = tables;
+    }
+    else
+    {
+      RecentHap * tables = nullptr;
+      ok = ok && dev_alloc(tables, static_cast<size_t>(gtx_ctx::SCORE_BIG_THREADS) * 2 * SCORE_MAX_HAPS_BIG, "second-pass score tables");
+      s->d_score_tables = tables;
+    }
   }
   if (!ok)
   {
@@ -1108,7 +1164,7 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
     if (!grow(s->d_big_tasks, cap, want, "second-pass queue"))
       return GTX_ERR_HIP;
     s->big_task_cap = static_cast<uint32_t>(cap);
-    if (!hip_ok(hipMemsetAsync(s->d_big_state, 0, 4 * sizeof(uint32_t), st), "second-pass state reset"))
+    if (!hip_ok(hipMemsetAsync(s->d_big_state, 0, 12 * sizeof(uint32_t), st), "second-pass state reset"))
       return GTX_ERR_HIP;
   }
   // test switch: 1 = every task goes through all passes (the last one decides), 2 = every task is done by pass 2
@@ -1238,9 +1294,20 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
   {
     hipLaunchKernelGGL(gtx_align_big_kernel, dim3(c->big_blocks), dim3(64), 0, sg, c->dev_graph, c->dev_index, d_seq, seq_stride, d_meta,
                        d_records, rec_words, s->d_big_tasks, s->big_task_cap, s->d_big_state, static_cast<big::AlignWorkspace *>(s->d_big_ws),
-                       c->d_big_records, static_cast<unsigned long long>(c->big_record_words), c->d_arena_cursor);
+                       c->d_big_records, static_cast<unsigned long long>(c->big_record_words), c->d_arena_cursor, s->d_wide_tasks,
+                       CallScratch::WIDE_TASK_CAP, s->d_wide_state);
     if (!hip_ok(hipGetLastError(), "gtx_align_big_kernel launch"))
       return GTX_ERR_HIP;
+    if (s->d_wide_tasks) // graphs with a site of more than 64 alleles: the tasks that met an allele number >= 64
+    {
+      hipLaunchKernelGGL(gtx_align_wide_kernel, dim3(CallScratch::WIDE_BLOCKS), dim3(64), 0, sg, c->dev_graph, c->dev_index, d_seq, seq_stride,
+                         d_meta, d_records, rec_words, s->d_wide_tasks, CallScratch::WIDE_TASK_CAP, s->d_wide_state,
+                         static_cast<wide::AlignWorkspace *>(s->d_wide_ws), c->d_big_records,
+                         static_cast<unsigned long long>(c->big_record_words), c->d_arena_cursor, static_cast<uint32_t *>(nullptr), 0u,
+                         static_cast<uint32_t *>(nullptr));
+      if (!hip_ok(hipGetLastError(), "gtx_align_wide_kernel launch"))
+        return GTX_ERR_HIP;
+    }
   }
   mark(0, 5, sg);
   if (parts > 1)
@@ -1404,9 +1471,14 @@ extern "C" int gtx_score_batch(gtx_ctx * c, const gtx_score_item * d_items, uint
     return GTX_ERR_HIP;
   if (second_pass)
   {
-    hipLaunchKernelGGL(gtx_score_big_kernel, dim3(gtx_ctx::SCORE_BIG_THREADS / 64), dim3(64), 0, st, c->dev_graph, par, d_items, d_records,
-                       rec_words, a, c->d_error_flag, s->d_score_queue, gtx_ctx::SCORE_QUEUE_CAP, s->d_score_state,
-                       static_cast<RecentHap *>(s->d_score_tables));
+    if (c->has_wide_sites)
+      hipLaunchKernelGGL(gtx_score_wide_kernel, dim3(gtx_ctx::SCORE_BIG_THREADS / 64), dim3(64), 0, st, c->dev_graph, par, d_items, d_records,
+                         rec_words, a, c->d_error_flag, s->d_score_queue, gtx_ctx::SCORE_QUEUE_CAP, s->d_score_state,
+                         static_cast<RecentHapWide *>(s->d_score_tables));
+    else
+      hipLaunchKernelGGL(gtx_score_big_kernel, dim3(gtx_ctx::SCORE_BIG_THREADS / 64), dim3(64), 0, st, c->dev_graph, par, d_items, d_records,
+                         rec_words, a, c->d_error_flag, s->d_score_queue, gtx_ctx::SCORE_QUEUE_CAP, s->d_score_state,
+                         static_cast<RecentHap *>(s->d_score_tables));
     if (!hip_ok(hipGetLastError(), "gtx_score_big_kernel launch"))
       return GTX_ERR_HIP;
   }

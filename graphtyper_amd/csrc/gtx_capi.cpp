@@ -47,6 +47,8 @@ extern "C"
       g_last_error = err;
       return err.rfind("unsupported", 0) == 0 ? GTX_ERR_UNSUPPORTED : GTX_ERR_GRAPH;
     }
+    for (uint32_t n : c->graph.ref_nvar)
+      c->has_wide_sites = c->has_wide_sites || n > 64;
     char const * hb = std::getenv("GTX_INDEX_BUILD"); // A/B switch: "host" builds the tables on the host and uploads them
     if (device < 0)
     {

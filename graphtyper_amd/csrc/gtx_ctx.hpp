@@ -40,6 +40,11 @@ struct CallScratch
   uint32_t big_task_cap = 0;
   uint32_t * d_big_state = nullptr; // [0] tasks queued, [1] claim cursor, [3] tasks dropped (list full)
   void * d_big_ws = nullptr;
+  // wide-site pass (graphs with a site of more than 64 alleles only): tasks that met an allele number >= 64
+  uint32_t * d_wide_tasks = nullptr;
+  uint32_t * d_wide_state = nullptr; // inside d_big_state's allocation (same layout)
+  void * d_wide_ws = nullptr;
+  static constexpr uint32_t WIDE_TASK_CAP = 1u << 20, WIDE_BLOCKS = 64;
   // second scoring pass (items whose reads touch more variant sites than the main pass' tables hold)
   uint32_t * d_score_state = nullptr; // [0] items queued
   uint32_t * d_score_queue = nullptr;
@@ -64,6 +69,7 @@ struct gtx_ctx
   int express4_wide_blocks_per_cu = 8;
   bool express4_wide = false; // pass 1 runs gtx_align_express4_wide_kernel (express4_prefers_wide, gtx_flat.hpp)
   uint32_t big_blocks = 0;
+  bool has_wide_sites = false; // some site has more than 64 alleles: the wide-site passes (alignment, scoring) exist
   static constexpr uint32_t SCORE_QUEUE_CAP = 1u << 20, SCORE_BIG_THREADS = 1024;
   // arena for records longer than a record slot: shared by all calls (it only grows; the cursor is a device counter)
   uint32_t * d_big_records = nullptr;

@@ -17,7 +17,7 @@ constexpr uint32_t K = GTX_K;
 constexpr uint32_t INVALID = GTX_INVALID_ID;
 constexpr uint32_t SPECIAL_START = GTX_SPECIAL_START;
 constexpr uint32_t POS_BUCKET_SHIFT = 6; // position -> ref node table has one entry per 64 bp
-constexpr uint32_t MAX_ALLELES = 64;     // allele sets are one 64-bit mask per (path, site)
+constexpr uint32_t MAX_ALLELES = 32u * GTX_WIDE_MASK_WORDS; // MAX_NUMBER_OF_HAPLOTYPES (constants.hpp.in:23); sets of 64 in the front passes
 
 struct alignas(8) uint2_t // 8-byte move
 {

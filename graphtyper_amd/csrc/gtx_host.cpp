@@ -125,7 +125,7 @@ std::string flatten_graph(gtx_graph_view const & g, gtx_params const & par, Host
     if (n == 0)
       return "inner reference node without a variant site";
     if (n > MAX_ALLELES)
-      return "unsupported: a site has more than 64 alleles";
+      return "unsupported: a site has more alleles than the reference's MAX_NUMBER_OF_HAPLOTYPES (2560)";
     if (out.ref_first_var[r] != next_var)
       return "variant nodes are not laid out site by site";
     if (next_var + n > V)

@@ -16,6 +16,7 @@ constexpr uint16_t F_PAIRED = 1, F_PROPER_PAIR = 2, F_UNMAPPED = 4, F_SEQ_REVERS
 constexpr uint32_t NO_COVERAGE = 0xFFFFu, MULTI_ALT_COVERAGE = 0xFFFEu, MULTI_REF_COVERAGE = 0xFFFDu; // haplotype.hpp:86-88
 constexpr uint32_t SCORE_MAX_HAPS = 8;       // distinct variant sites one read can touch in the main scoring pass (per-thread tables)
 constexpr uint32_t SCORE_MAX_HAPS_BIG = 1024; // ... in the second pass (tables in HBM)
+constexpr uint32_t SCORE_MAX_HAPS_WIDE = 128; // ... in the second pass of a graph with a site of more than 64 alleles (wide sets)
 
 struct ScoreParams
 {
@@ -25,7 +26,10 @@ struct ScoreParams
 struct RecPath
 {
   uint32_t start, end, rs, re, mism, nvar;
-  uint32_t const * vars; // nvar * (site, mask_lo, mask_hi)
+  uint32_t const * vars; // nvar * (site, mask words): 2 mask words, GTX_WIDE_MASK_WORDS in a record with GTX_REC_WIDE
+  uint32_t stride;       // words per site
+  GTX_DEV uint32_t const * mask(uint32_t k) const { return vars + stride * k + 1; }
+  GTX_DEV uint32_t site(uint32_t k) const { return vars[stride * k]; }
 };
 
 struct Geno // one GenotypePaths as seen by the scorer
@@ -36,6 +40,7 @@ struct Geno // one GenotypePaths as seen by the scorer
   uint32_t flags, mapq, score_diff;
   bool proper_pair; // ml_insert_size != INSERT_SIZE_WHEN_NOT_PROPER_PAIR
   bool has_var;     // some path carries a variant site (else the read cannot add anything to the accumulators)
+  bool wide;        // GTX_REC_WIDE: allele sets of GTX_WIDE_MASK_WORDS words
 };
 
 GTX_DEV Geno geno_of(uint32_t const * records, uint32_t rec_words, uint32_t const * big_records, uint32_t align_index,
@@ -46,8 +51,9 @@ GTX_DEV Geno geno_of(uint32_t const * records, uint32_t rec_words, uint32_t cons
   g.body = ((g.rec[0] >> 16) & GTX_ST_EXTERNAL) ? big_records + g.rec[2] : g.rec + 2;
   g.n_paths = g.rec[0] & 0xFFFFu;
   g.longest = g.rec[1] & 0xFFFFu;
-  g.read_len = (g.rec[1] >> 16) & 0x7FFFu;
+  g.read_len = (g.rec[1] >> 16) & 0x3FFFu;
   g.has_var = (g.rec[1] & GTX_REC_HAS_VARIANTS) != 0;
+  g.wide = (g.rec[1] & GTX_REC_WIDE) != 0;
   g.flags = 0;
   g.mapq = 255;
   g.score_diff = 0;
@@ -62,10 +68,11 @@ GTX_DEV Geno empty_orientation(Geno const & fwd)
   g.n_paths = 0;
   g.longest = 0;
   g.has_var = false;
+  g.wide = false;
   return g;
 }
 
-GTX_DEV uint32_t const * path_at(uint32_t const * w, RecPath & p) // returns the position behind the path
+GTX_DEV uint32_t const * path_at(uint32_t const * w, RecPath & p, bool wide = false) // returns the position behind the path
 {
   p.start = w[0];
   p.end = w[1];
@@ -74,7 +81,8 @@ GTX_DEV uint32_t const * path_at(uint32_t const * w, RecPath & p) // returns the
   p.mism = w[3] & 0xFFFFu;
   p.nvar = w[3] >> 16;
   p.vars = w + 4;
-  return w + 4 + 3 * p.nvar;
+  p.stride = wide ? 1u + GTX_WIDE_MASK_WORDS : 3u;
+  return w + 4 + p.stride * p.nvar;
 }
 
 GTX_DEV uint32_t first_mismatches(Geno const & g) // paths[0].mismatches
@@ -89,9 +97,9 @@ GTX_DEV uint32_t alternative_call_count(Geno const & g) // genotype_paths.cpp:10
   for (uint32_t i = 0; i < g.n_paths; ++i)
   {
     RecPath p;
-    w = path_at(w, p);
+    w = path_at(w, p, g.wide);
     for (uint32_t k = 0; k < p.nvar; ++k)
-      c += (p.vars[3 * k + 1] & 1u) == 0u;
+      c += (p.mask(k)[0] & 1u) == 0u;
   }
   return c;
 }
@@ -175,7 +183,7 @@ GTX_DEV bool geno_is_good(GraphView const & g, ScoreParams const & par, Geno con
   for (uint32_t i = 0; i < ge.n_paths; ++i)
   {
     RecPath p;
-    w = path_at(w, p);
+    w = path_at(w, p, ge.wide);
     if (p.re - p.rs + 1u != ge.read_len)
       fully = false;
     uint32_t const rs_ = g_ref_reach_pos(g, p.start), re_ = g_ref_reach_pos(g, p.end);
@@ -203,13 +211,50 @@ GTX_DEV bool geno_is_good(GraphView const & g, ScoreParams const & par, Geno con
   return true;
 }
 
-struct RecentHap // one entry of `recent_ids` + the haplotype's transient explains/coverage (vcf_writer.cpp:519-585)
+// Haplotype::explains (std::bitset<MAX_NUMBER_OF_HAPLOTYPES>, haplotype.hpp) as NW 64-bit words: one word where every
+// site has at most 64 alleles, GTX_WIDE_MASK_WORDS / 2 in the scoring pass of graphs with wider sites
+template <uint32_t NW>
+struct AlleleSet
+{
+  uint64_t w[NW];
+  static constexpr uint32_t WORDS32 = 2 * NW;
+  GTX_DEV void clear()
+  {
+    for (uint32_t i = 0; i < NW; ++i)
+      w[i] = 0;
+  }
+  GTX_DEV void add_words(uint32_t const * m, uint32_t n32) // n32 <= WORDS32, even
+  {
+    for (uint32_t i = 0; i < n32 / 2; ++i)
+      w[i] |= (static_cast<uint64_t>(m[2 * i + 1]) << 32) | m[2 * i];
+  }
+  GTX_DEV uint32_t count() const
+  {
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < NW; ++i)
+      c += static_cast<uint32_t>(__builtin_popcountll(w[i]));
+    return c;
+  }
+  GTX_DEV bool test(uint32_t a) const { return a < 64 * NW && ((w[a >> 6] >> (a & 63u)) & 1ull); }
+  template <class F>
+  GTX_DEV void for_each(F && f) const // alleles ascending
+  {
+    for (uint32_t i = 0; i < NW; ++i)
+      for (uint64_t m = w[i]; m; m &= m - 1)
+        f(64 * i + static_cast<uint32_t>(__builtin_ctzll(m)));
+  }
+};
+
+template <uint32_t NW>
+struct RecentHapT // one entry of `recent_ids` + the haplotype's transient explains/coverage (vcf_writer.cpp:519-585)
 {
   uint32_t site;
   uint32_t coverage;
-  uint64_t explains;
+  AlleleSet<NW> explains;
   bool overlapping;
 };
+using RecentHap = RecentHapT<1>;
+using RecentHapWide = RecentHapT<GTX_WIDE_MASK_WORDS / 2>;
 
 GTX_DEV uint32_t add_coverage(uint32_t coverage, uint32_t c) // haplotype.cpp:180-227
 {
@@ -266,7 +311,7 @@ GTX_DEV void add_ref_depth(GraphView const & g, ScoreAcc const & acc, Geno const
     return i0 < size && i1 > i0;
   };
   RecPath p;
-  uint32_t const * w = path_at(ge.body, p);
+  uint32_t const * w = path_at(ge.body, p, ge.wide);
   if (p.re - p.rs + 1 < 63)
     return;
   long a, b, i0, i1;
@@ -289,7 +334,7 @@ GTX_DEV void add_ref_depth(GraphView const & g, ScoreAcc const & acc, Geno const
     w = ge.body;
     for (uint32_t k = 0; k < ge.n_paths; ++k)
     {
-      w = path_at(w, p);
+      w = path_at(w, p, ge.wide);
       span_of(p, a, b);
       if (b - a >= 50)
       {
@@ -317,7 +362,7 @@ GTX_DEV void add_ref_depth(GraphView const & g, ScoreAcc const & acc, Geno const
       w = ge.body;
       for (uint32_t k = 0; k < ge.n_paths; ++k)
       {
-        w = path_at(w, p);
+        w = path_at(w, p, ge.wide);
         span_of(p, a, b);
         if (b - a >= 50)
         {
@@ -371,20 +416,32 @@ GTX_DEV void emit_conn(GraphView const & g, ScoreAcc const & acc, uint32_t sampl
 // push_to_haplotype_scores (vcf_writer.cpp:503-676), first half: the sites the read's paths touch with their explain
 // masks and coverage, ascending site (the reference's std::map order).  No effect on shared state.  Returns the number
 // of entries, or 0xFFFFFFFF when the read touches more than `cap` sites.
-GTX_DEV uint32_t collect_recent(GraphView const & g, Geno const & ge, RecentHap * recent, uint32_t cap)
+template <uint32_t NW>
+GTX_DEV uint32_t collect_recent(GraphView const & g, Geno const & ge, RecentHapT<NW> * recent, uint32_t cap)
 {
+  using RecentHap = RecentHapT<NW>;
   uint32_t n = 0;
   uint32_t const * w = ge.body;
+  uint32_t const mw = ge.wide ? GTX_WIDE_MASK_WORDS : 2u;
+  if (mw > AlleleSet<NW>::WORDS32)
+    return 0xFFFFFFFFu; // a record with wide allele sets: for the pass whose tables hold them
   for (uint32_t i = 0; i < ge.n_paths; ++i)
   {
     RecPath p;
-    w = path_at(w, p);
+    w = path_at(w, p, ge.wide);
     int64_t const s_reach = g_ref_reach_pos(g, p.start), e_reach = g_ref_reach_pos(g, p.end);
     for (uint32_t k = 0; k < p.nvar; ++k)
     {
-      uint32_t const site = p.vars[3 * k];
-      uint64_t const mask = (static_cast<uint64_t>(p.vars[3 * k + 2]) << 32) | p.vars[3 * k + 1];
-      if (mask == 0)
+      uint32_t const site = p.site(k);
+      uint32_t const * const mask = p.mask(k);
+      uint32_t members = 0, lowest = 0;
+      for (uint32_t x = mw; x-- > 0;)
+        if (mask[x])
+        {
+          members += static_cast<uint32_t>(__builtin_popcount(mask[x]));
+          lowest = 32 * x + static_cast<uint32_t>(__builtin_ctz(mask[x]));
+        }
+      if (members == 0)
         continue;
       int64_t const order = site_order(g, site);
       bool const overlapping = s_reach + 3 <= order && e_reach - 3 > order;
@@ -396,17 +453,21 @@ GTX_DEV uint32_t collect_recent(GraphView const & g, Geno const & ge, RecentHap 
       {
         if (n >= cap)
           return 0xFFFFFFFFu;
-        recent[n++] = RecentHap{site, NO_COVERAGE, 0, false};
+        RecentHap & fresh = recent[n++];
+        fresh.site = site;
+        fresh.coverage = NO_COVERAGE;
+        fresh.explains.clear();
+        fresh.overlapping = false;
       }
       RecentHap & rh = recent[j];
       rh.overlapping = rh.overlapping || overlapping;
-      rh.explains |= mask;
-      if ((mask & (mask - 1)) == 0)
-        rh.coverage = add_coverage(rh.coverage, static_cast<uint32_t>(__builtin_ctzll(mask)));
+      rh.explains.add_words(mask, mw);
+      if (members == 1)
+        rh.coverage = add_coverage(rh.coverage, lowest);
       else
       {
         rh.coverage = add_coverage(rh.coverage, 1);
-        rh.coverage = add_coverage(rh.coverage, (mask & 1ull) ? 0u : 2u);
+        rh.coverage = add_coverage(rh.coverage, (mask[0] & 1u) ? 0u : 2u);
       }
     }
   }
@@ -426,31 +487,31 @@ GTX_DEV uint32_t collect_recent(GraphView const & g, Geno const & ge, RecentHap 
 }
 
 // push_to_haplotype_scores, second half: everything the read adds to the accumulators
-template <class W>
+template <class W, uint32_t NW>
 GTX_DEV void apply_recent(GraphView const & g, ScoreAcc const & acc, Geno const & ge, bool fully, bool unique, uint32_t sample,
-                          RecentHap const * recent, uint32_t n)
+                          RecentHapT<NW> const * recent, uint32_t n)
 {
+  using RecentHap = RecentHapT<NW>;
   uint32_t const clipped_bp = ge.read_len - ge.longest;
   uint32_t const mismatches = first_mismatches(ge);
   // connections between the sites of this read (vcf_writer.cpp:587-636)
   for (uint32_t a = 0; a < n; ++a)
   {
-    uint32_t const n1 = static_cast<uint32_t>(__builtin_popcountll(recent[a].explains));
+    uint32_t const n1 = recent[a].explains.count();
     if (n1 == 0 || n1 > 64)
       continue;
     for (uint32_t b = a + 1; b < n; ++b)
     {
-      uint32_t const n2 = static_cast<uint32_t>(__builtin_popcountll(recent[b].explains));
+      uint32_t const n2 = recent[b].explains.count();
       if (n2 == 0 || n2 > 64)
         continue;
       uint32_t const weight = n1 * n2;
       uint32_t const repeat = weight >= 3 ? 6 / weight : 1;
       if (repeat == 0)
         continue;
-      for (uint64_t m1 = recent[a].explains; m1; m1 &= m1 - 1)
-        for (uint64_t m2 = recent[b].explains; m2; m2 &= m2 - 1)
-          emit_conn<W>(g, acc, sample, recent[a].site, static_cast<uint32_t>(__builtin_ctzll(m1)), recent[b].site,
-                       static_cast<uint32_t>(__builtin_ctzll(m2)), repeat);
+      recent[a].explains.for_each([&](uint32_t b1) {
+        recent[b].explains.for_each([&](uint32_t b2) { emit_conn<W>(g, acc, sample, recent[a].site, b1, recent[b].site, b2, repeat); });
+      });
     }
   }
   // move the explanations to statistics, likelihood and depth (vcf_writer.cpp:638-673)
@@ -512,10 +573,10 @@ GTX_DEV void apply_recent(GraphView const & g, ScoreAcc const & acc, Geno const 
     uint32_t idx = 0;
     for (uint32_t y = 0; y < cnum; ++y)
     {
-      bool const ey = (rh.explains >> y) & 1ull;
+      bool const ey = rh.explains.test(y);
       for (uint32_t x = 0; x <= y; ++x, ++idx)
       {
-        bool const ex = (rh.explains >> x) & 1ull;
+        bool const ex = rh.explains.test(x);
         if (ex && ey)
           W::atomic_add_u32(ls + idx, eps);
         else if (ex || ey)
@@ -566,9 +627,9 @@ GTX_DEV bool item_is_trivial(gtx_score_item const & it, uint32_t const * records
 
 // r1 / r2: tables of `cap` entries each.  Returns false, with nothing added to the accumulators, when a read of the item
 // touches more than `cap` variant sites (the caller then redoes the item with larger tables).
-template <class W>
+template <class W, uint32_t NW>
 GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_item const & it, uint32_t const * records,
-                        uint32_t rec_words, ScoreAcc const & acc, RecentHap * r1, RecentHap * r2, uint32_t cap)
+                        uint32_t rec_words, ScoreAcc const & acc, RecentHapT<NW> * r1, RecentHapT<NW> * r2, uint32_t cap)
 {
   if (it.second.align_index == INVALID)
   {
@@ -671,24 +732,23 @@ GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_
   // of the other mate that lies on a later site (vcf_writer.cpp:186-227)
   for (uint32_t a = 0; a < n1; ++a)
   {
-    uint32_t const c1 = static_cast<uint32_t>(__builtin_popcountll(r1[a].explains));
+    uint32_t const c1 = r1[a].explains.count();
     if (c1 == 0 || c1 > 64)
       continue;
     for (uint32_t b = 0; b < n2; ++b)
     {
-      uint32_t const c2 = static_cast<uint32_t>(__builtin_popcountll(r2[b].explains));
+      uint32_t const c2 = r2[b].explains.count();
       if (c2 == 0 || c2 > 64 || r1[a].site == r2[b].site)
         continue;
       bool const fwd = r2[b].site > r1[a].site;
-      for (uint64_t m1 = r1[a].explains; m1; m1 &= m1 - 1)
-        for (uint64_t m2 = r2[b].explains; m2; m2 &= m2 - 1)
-        {
-          uint32_t const b1 = static_cast<uint32_t>(__builtin_ctzll(m1)), b2 = static_cast<uint32_t>(__builtin_ctzll(m2));
+      r1[a].explains.for_each([&](uint32_t b1) {
+        r2[b].explains.for_each([&](uint32_t b2) {
           if (fwd)
             emit_conn<W>(g, acc, it.sample, r1[a].site, b1, r2[b].site, b2, 1);
           else
             emit_conn<W>(g, acc, it.sample, r2[b].site, b2, r1[a].site, b1, 1);
-        }
+        });
+      });
     }
   }
   return true;

@@ -505,6 +505,9 @@ class Stream:
         return dict(records=int(a.value), duplicated=int(b.value), parked=int(c.value))
 
 
+REC_WIDE, WIDE_MASK_WORDS = 0x40000000, 80  # include/gtx.h: GTX_REC_WIDE, GTX_WIDE_MASK_WORDS
+
+
 def parse_records(words, n_reads, rec_words, hap_order, big_records=None):
     """decode gtx_align_batch records into the same structure tests/oracle_lib.parse_path_stream returns
     (plus 'status', with the GTX_ST_EXTERNAL bit removed); Path::var_order is looked up through hap_order.
@@ -516,7 +519,8 @@ def parse_records(words, n_reads, rec_words, hap_order, big_records=None):
         for o in range(2):
             w = words[2 * i + o]
             npaths, status = int(w[0]) & 0xFFFF, int(w[0]) >> 16
-            longest, rlen = int(w[1]) & 0xFFFF, (int(w[1]) >> 16) & 0x7FFF  # (bit 31: REC_HAS_VARIANTS)
+            longest, rlen = int(w[1]) & 0xFFFF, (int(w[1]) >> 16) & 0x3FFF  # (bit 31: REC_HAS_VARIANTS, bit 30: REC_WIDE)
+            mw = WIDE_MASK_WORDS if int(w[1]) & REC_WIDE else 2
             k = 2
             if status & ST_EXTERNAL:
                 w, k = big_records, int(w[2])
@@ -527,9 +531,10 @@ def parse_records(words, n_reads, rec_words, hap_order, big_records=None):
                 k += 4
                 vs = []
                 for _v in range(mmnv >> 16):
-                    hap, mask = int(w[k]), int(w[k + 1]) | (int(w[k + 2]) << 32)
-                    k += 3
-                    vs.append((int(hap_order[hap]), tuple(a for a in range(64) if (mask >> a) & 1)))
+                    hap = int(w[k])
+                    alleles = tuple(32 * x + a for x in range(mw) if w[k + 1 + x] for a in range(32) if (int(w[k + 1 + x]) >> a) & 1)
+                    k += 1 + mw
+                    vs.append((int(hap_order[hap]), alleles))
                 paths.append(dict(start=st, end=en, rs=rsre & 0xFFFF, re=rsre >> 16, mm=mmnv & 0xFFFF, vars=vs))
             pair.append(dict(longest=longest, paths=paths, status=status, read_len=rlen))
         out.append(tuple(pair))

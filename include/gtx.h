@@ -62,7 +62,12 @@ enum
   GTX_ST_EXTERNAL = 16        /* not an error: the path words of this record are in the big-record arena (see gtx_align_batch) */
 };
 #define GTX_ST_ERROR_MASK 15u
+/* allele sets of a record: two words (alleles 0..63), or -- in a record whose second word carries GTX_REC_WIDE -- this many
+ * words (MAX_NUMBER_OF_HAPLOTYPES = 2560 alleles, include/graphtyper/constants.hpp.in:23) */
+#define GTX_WIDE_MASK_WORDS 80u
 #define GTX_REC_HAS_VARIANTS 0x80000000u /* bit 31 of record word 1: some path of the record carries a variant site */
+#define GTX_REC_WIDE 0x40000000u         /* bit 30 of record word 1: every site of the record is (hap, GTX_WIDE_MASK_WORDS mask words)
+                                            instead of (hap, mask_lo, mask_hi) -- a path names an allele >= 64 */
 
 /* Graph as SoA node tables = the reference's Graph::ref_nodes / var_nodes (include/graphtyper/graph/graph.hpp:40-134):
  * strictly alternating  ref node r -> its ref_nvar[r] var nodes (allele 0 = reference allele) -> ref node r+1.
@@ -240,7 +245,8 @@ int gtx_index_dump(const gtx_ctx *, uint64_t * keys, uint32_t * counts, gtx_labe
  *    w0 = n_paths | status << 16, w1 = longest_path_length | l_qseq << 16 | GTX_REC_HAS_VARIANTS, then per path
  *    start, end, read_start_index | read_end_index << 16, mismatches | n_var << 16, n_var * (hap, mask_lo, mask_hi)
  *    hap = haplotype (variant site) index, Path::var_order = hap_order[hap] of gtx_ctx_haplotypes;
- *    mask bit a set <=> allele a in Path::nums
+ *    mask bit a set <=> allele a in Path::nums; in a record with GTX_REC_WIDE in w1 a site is (hap, GTX_WIDE_MASK_WORDS
+ *    mask words) -- only graphs with a site of more than 64 alleles produce those, and they are always GTX_ST_EXTERNAL
  *    A record with GTX_ST_EXTERNAL (a result with more paths than rec_words holds) keeps w0/w1 and has w2 = word offset
  *    of its path words in the context's big-record arena (gtx_ctx_big_records).  Like d_records the arena is meant to
  *    stay resident while a region is processed (a parked mate is scored batches later): it only grows until

@@ -89,6 +89,7 @@ struct Emu
   std::vector<uint32_t> arena; // big-record arena (see gtx_align_batch)
   uint64_t arena_used = 0;
   uint64_t second_pass_tasks = 0; // tasks that reached the last pass (HBM tables)
+  uint64_t wide_pass_tasks = 0;   // tasks that went on to the pass with wide allele sets
   uint64_t general_tasks = 0;     // tasks pass 1 handed to pass 2
   uint64_t hinted_done = 0;       // forward tasks the position-hinted pass finished
 };
@@ -143,6 +144,47 @@ extern "C"
     bool const wide = e4 && e4[0] == 'w' ? true : e4 && e4[0] == 'l' ? false : express4_prefers_wide(e.graph, e.index);
     auto e4_ws = std::make_unique<Express4Workspace<Express4Lean>>();
     auto e4_wide_ws = std::make_unique<Express4Workspace<Express4Wide>>();
+    bool has_wide_sites = false;
+    for (uint32_t n : e.graph.ref_nvar)
+      has_wide_sites = has_wide_sites || n > 64;
+    auto wide_ws = has_wide_sites ? std::make_unique<wide::AlignWorkspace>() : nullptr;
+    e.wide_pass_tasks = 0;
+    // one task through an HBM-table pass (the body of GTX_HBM_PASS_KERNEL in gtx_api.hip); returns the pass' status
+    auto hbm_pass = [&](auto &, auto && align, auto && size_of, auto && write_body, uint32_t * rec, uint32_t len) -> uint32_t
+    {
+      uint32_t np = 0, longest = 0, ext = 0;
+      uint32_t const raw = align(np, longest);
+      uint32_t status = raw & ~GTX_ST_WIDE_ALLELE;
+      uint32_t * body = rec + 2;
+      uint64_t off = 0;
+      if (status)
+        np = 0;
+      else
+      {
+        uint32_t const size = size_of(np);
+        if (size > rec_words)
+        {
+          off = e.arena_used;
+          if (off + (size - 2) > e.arena.size())
+          {
+            status = GTX_ST_RECORD_OVERFLOW;
+            np = 0;
+          }
+          else
+          {
+            e.arena_used += size - 2;
+            body = e.arena.data() + off;
+            ext = GTX_ST_EXTERNAL;
+          }
+        }
+      }
+      uint32_t const has_var = write_body(np, body);
+      rec[0] = np | ((status | ext) << 16);
+      rec[1] = (np == 0 ? 0 : longest) | (len << 16) | (np == 0 ? 0u : has_var);
+      if (ext)
+        rec[2] = static_cast<uint32_t>(off);
+      return raw;
+    };
     // passes 2 and 3 for one task
     auto general = [&](uint32_t t)
     {
@@ -156,39 +198,24 @@ extern "C"
                                              /*try_fast=*/false);
       if (!second_pass || !(st || force_big))
         return;
-      // second pass (gtx_align_big_kernel)
+      // second pass (gtx_align_big_kernel), and for a graph with a site of more than 64 alleles the pass behind it
+      // (gtx_align_wide_kernel) for the tasks that met an allele number >= 64
       ++e.second_pass_tasks;
       std::memset(static_cast<void *>(big_ws.get()), fill, sizeof(big::AlignWorkspace));
-      uint32_t np = 0, longest = 0, ext = 0;
-      uint32_t status = big::align_paths<WaveEmu>(g, ix, *big_ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest);
-      uint32_t * body = rec + 2;
-      uint64_t off = 0;
-      if (status)
-        np = 0;
-      else
-      {
-        uint32_t const size = big::record_size<WaveEmu>(big::Here{}, *big_ws, np);
-        if (size > rec_words)
-        {
-          off = e.arena_used;
-          e.arena_used += size - 2;
-          if (off + (size - 2) > e.arena.size())
-          {
-            status = GTX_ST_RECORD_OVERFLOW;
-            np = 0;
-          }
-          else
-          {
-            body = e.arena.data() + off;
-            ext = GTX_ST_EXTERNAL;
-          }
-        }
-      }
-      uint32_t const has_var = big::write_record_body<WaveEmu>(big::Here{}, *big_ws, np, body);
-      rec[0] = np | ((status | ext) << 16);
-      rec[1] = (np == 0 ? 0 : longest) | (len << 16) | has_var;
-      if (ext)
-        rec[2] = static_cast<uint32_t>(off);
+      uint32_t const bst = hbm_pass(
+        *big_ws, [&](uint32_t & np, uint32_t & longest)
+        { return big::align_paths<WaveEmu>(g, ix, *big_ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest); },
+        [&](uint32_t np) { return big::record_size<WaveEmu>(big::Here{}, *big_ws, np); },
+        [&](uint32_t np, uint32_t * body) { return big::write_record_body<WaveEmu>(big::Here{}, *big_ws, np, body); }, rec, len);
+      if (!bst || !has_wide_sites)
+        return;
+      ++e.wide_pass_tasks;
+      std::memset(static_cast<void *>(wide_ws.get()), fill, sizeof(wide::AlignWorkspace));
+      hbm_pass(
+        *wide_ws, [&](uint32_t & np, uint32_t & longest)
+        { return wide::align_paths<WaveEmu>(g, ix, *wide_ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest); },
+        [&](uint32_t np) { return wide::record_size<WaveEmu>(wide::Here{}, *wide_ws, np); },
+        [&](uint32_t np, uint32_t * body) { return wide::write_record_body<WaveEmu>(wide::Here{}, *wide_ws, np, body); }, rec, len);
     };
     auto empty_record = [&](uint32_t t, uint32_t len)
     {
@@ -323,6 +350,7 @@ extern "C"
   uint64_t emu_general_tasks(void * p) { return static_cast<Emu *>(p)->general_tasks; }
 
   uint64_t emu_second_pass_tasks(void * p) { return static_cast<Emu *>(p)->second_pass_tasks; }
+  uint64_t emu_wide_pass_tasks(void * p) { return static_cast<Emu *>(p)->wide_pass_tasks; }
 
   // same contract as gtx_calls_batch, host pointers
   int emu_calls(void * p, const gtx_score_buffers * acc, uint8_t * phred, gtx_sample_call * calls)
@@ -373,14 +401,22 @@ extern "C"
                     static_cast<uint32_t>(e.params.is_segment_calling != 0), 0};
     uint32_t errors = 0;
     std::vector<RecentHap> small(2 * SCORE_MAX_HAPS), large(2 * SCORE_MAX_HAPS_BIG);
+    bool has_wide_sites = false;
+    for (uint32_t n : e.graph.ref_nvar)
+      has_wide_sites = has_wide_sites || n > 64;
+    std::vector<RecentHapWide> wide_tables(has_wide_sites ? 2 * SCORE_MAX_HAPS_WIDE : 0);
     for (uint32_t i = 0; i < n_items; ++i)
       if (item_is_trivial(items[i], records, rec_words, a.ref_depth != nullptr)) // stage 1 (gtx_score_triage_kernel)
         continue;
       else if (!score_item<WaveEmu>(g, par, items[i], records, rec_words, a, small.data(), small.data() + SCORE_MAX_HAPS, SCORE_MAX_HAPS))
       {
-        // second scoring pass (gtx_score_big_kernel)
-        if (e.params.no_second_pass ||
-            !score_item<WaveEmu>(g, par, items[i], records, rec_words, a, large.data(), large.data() + SCORE_MAX_HAPS_BIG, SCORE_MAX_HAPS_BIG))
+        // second scoring pass (gtx_score_big_kernel; gtx_score_wide_kernel for a graph with a site of more than 64 alleles)
+        if (e.params.no_second_pass)
+          ++errors;
+        else if (has_wide_sites)
+          errors += !score_item<WaveEmu>(g, par, items[i], records, rec_words, a, wide_tables.data(), wide_tables.data() + SCORE_MAX_HAPS_WIDE,
+                                         SCORE_MAX_HAPS_WIDE);
+        else if (!score_item<WaveEmu>(g, par, items[i], records, rec_words, a, large.data(), large.data() + SCORE_MAX_HAPS_BIG, SCORE_MAX_HAPS_BIG))
           ++errors;
       }
     return static_cast<int>(errors);

@@ -240,3 +240,56 @@ def sv_case(n_ref=60000, n_del=8, n_ins=4, n_samples=4, pairs_per_sv=30, backgro
         codes[i] = np.array([1, 2, 4, 8], np.uint8)[bases]
         rec[i] = (flag, mapq, int(rng.integers(0, 60)), 0, 0, p, isize, read_len, 0, sample, nm, mpos, 1, read_len << 4 | M, read_len << 4 | M)
     return {"chrS": ref_s}, lines, codes, rec
+
+
+def wide_site_case(seed=0, region_begin=20000, n_ref=3000, step=3, err=0.004):
+    """graph with sites of more than 64 alleles (allele sets beyond the 64-bit masks of the front passes; the reference
+    allows MAX_NUMBER_OF_HAPLOTYPES = 2560): site A = one record with 99 insertion alleles (100 alleles), site B = a 12-bp
+    deletion overlapped by 6 SNP records of 3 alternative alleles each -- add_all_variants merges overlapping records into
+    every combination (2 * 4^5 = 2048 alleles) until the product reaches 2559, the sixth SNP then joins by
+    VarRecord::merge_one_path (graph.cpp:119-124) --, plus ordinary SNPs.  Reads are tiled over both sites from four
+    haplotypes that carry alleles with high numbers.  Returns (reference string, records, codes, pos0, (pA, pB))."""
+    rng = np.random.default_rng(seed + 4242)
+    ref = synth.make_reference(n_ref, seed=seed + 300)
+    b2s = synth.bases_to_str
+    pA, pB = 700, 1500
+    ins = []
+    while len(ins) < 99:
+        s = b2s(rng.integers(0, 4, size=int(rng.integers(5, 13)), dtype=np.uint8))
+        if s not in ins:
+            ins.append(s)
+    recs = [(pA + region_begin, b2s(ref[pA:pA + 1]), [b2s(ref[pA:pA + 1]) + s for s in ins], None)]
+    recs.append((pB + region_begin, b2s(ref[pB:pB + 13]), [b2s(ref[pB:pB + 1])], None))
+    snp_at = [pB + 1, pB + 3, pB + 5, pB + 7, pB + 9, pB + 11]
+    for q in snp_at:
+        recs.append((q + region_begin, b2s(ref[q:q + 1]), ["ACGT"[(int(ref[q]) + k) % 4] for k in (1, 2, 3)], None))
+    for q in list(range(100, 600, 90)) + list(range(900, 1400, 110)) + list(range(1700, n_ref - 100, 130)):
+        recs.append((q + region_begin, b2s(ref[q:q + 1]), ["ACGT"[(int(ref[q]) + 1) % 4]], None))
+    recs.sort(key=lambda r: r[0])
+
+    def haplotype(ins_k, deletion, snp_choice):
+        h = [ref[:pA + 1]]
+        if ins_k is not None:
+            h.append(np.array(["ACGT".index(c) for c in ins[ins_k]], np.uint8))
+        h.append(ref[pA + 1:pB + 1])
+        if not deletion:
+            mid = ref[pB + 1:pB + 13].copy()
+            for q, k in zip(snp_at, snp_choice):
+                if k:
+                    mid[q - pB - 1] = (int(ref[q]) + k) % 4
+            h.append(mid)
+        h.append(ref[pB + 13:])
+        return np.concatenate(h)
+    haps = [haplotype(None, False, (0,) * 6), haplotype(70, False, (3, 3, 2, 0, 1, 0)), haplotype(5, True, None),
+            haplotype(98, False, (1, 2, 3, 3, 3, 2)), haplotype(64, False, (0, 0, 0, 0, 3, 3))]
+    codes, pos = [], []
+    for h in haps:
+        for centre in (pA, pB):
+            for start in range(max(0, centre - 170), centre + 30, step):
+                r = h[start:start + 150].copy()
+                e = rng.random(150) < err
+                r[e] = (r[e] + rng.integers(1, 4, size=int(e.sum()))) % 4
+                codes.append(synth._CODE_OF_BASE[r])
+                pos.append(start + region_begin)
+    order = np.argsort(np.array(pos), kind="stable")
+    return b2s(ref), recs, np.ascontiguousarray(np.array(codes, np.uint8)[order]), np.array(pos, np.int64)[order], (pA, pB)

@@ -274,3 +274,11 @@ def test_device_built_index_equals_the_oracles(case):
     h = gtx.Context(g, device=-1, is_sv_graph=(case == "sv"))
     k3, c3, l3 = h.index_dump()
     assert np.array_equal(k1, k3) and np.array_equal(c1, c3) and np.array_equal(l1, l3)
+
+
+def test_sites_with_more_than_64_alleles_on_the_device():
+    """a 100-allele site and a merged cluster of > 1000 alleles: gtx_align_wide_kernel / gtx_score_wide_kernel == oracle
+    (alignment records with every kind of hint, scores, calls over the half-million-entry genotype triangle, VCF text)"""
+    from test_wide_sites import wide_sites_case
+    b = wide_sites_case(harness.GpuBackend)
+    assert b.ctx.n_hap > 10

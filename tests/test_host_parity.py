@@ -90,12 +90,23 @@ def test_reference_with_n_runs():
 
 
 def test_unsupported_graph_is_refused_loudly():
+    """70 alleles are fine (tests/test_wide_sites.py aligns and scores over such sites); a view that claims more alleles
+    than the reference's MAX_NUMBER_OF_HAPLOTYPES is outside the envelope and refused by name"""
     ref = "ACGT" * 100
     alts = sorted({"A" + "C" * k for k in range(1, 70)})
     g = gtx.graph_from_records(ref, [(40, "A", alts, None)])
+    c = gtx.Context(g, device=-1)
+    assert int(c.hap_cnum.max()) == 70
+    # (gtx_graph_build caps a record at 2558 alternative alleles like graph.cpp:260-263, so the view is made by hand)
+    n = 2600
+    dna = ref[:40] + "".join("ACGT"[k % 4] for k in range(n)) + ref[41:]
+    view = dict(ref_order=np.array([1, 42], np.uint32), ref_len=np.array([40, len(ref) - 41], np.uint32),
+                ref_dna_off=np.array([0, 40 + n], np.uint32), ref_nvar=np.array([n, 0], np.uint32), ref_first_var=np.array([0, n], np.uint32),
+                var_order=np.full(n, 41, np.uint32), var_len=np.ones(n, np.uint32), var_dna_off=np.arange(40, 40 + n, dtype=np.uint32),
+                var_out_ref=np.ones(n, np.uint32), dna=np.frombuffer(dna.encode(), np.uint8))
     with pytest.raises(gtx.GtxError) as e:
-        gtx.Context(g, device=-1)
-    assert "64 alleles" in str(e.value)
+        gtx.Context(view, device=-1)
+    assert "MAX_NUMBER_OF_HAPLOTYPES" in str(e.value) and e.value.status == 4
 
 
 def test_no_cpu_path():
