@@ -47,7 +47,7 @@ enum
   GTX_ERR_ARG = 1,         /* NULL / inconsistent arguments */
   GTX_ERR_NO_DEVICE = 2,   /* no HIP device: the product has no CPU path */
   GTX_ERR_HIP = 3,         /* a HIP runtime call failed (see gtx_last_error) */
-  GTX_ERR_UNSUPPORTED = 4, /* graph outside the supported envelope (e.g. a site with > 64 alleles) */
+  GTX_ERR_UNSUPPORTED = 4, /* outside the supported envelope (a site with more alleles than MAX_NUMBER_OF_HAPLOTYPES, VCF text of an SV graph, ...) */
   GTX_ERR_CAPACITY = 5,    /* a caller-provided buffer is too small */
   GTX_ERR_GRAPH = 6        /* malformed graph view */
 };
