@@ -15,6 +15,7 @@
 #include "gtx_ctx.hpp"
 #include "align_core.hpp"
 #include "score_core.hpp"
+#include "score_replay.hpp"
 
 namespace gtx
 {
@@ -819,6 +820,38 @@ __global__ __launch_bounds__(64) void gtx_score_wide_kernel(GraphView g, ScorePa
                                                      tables);
 }
 
+// gtx_scores_replay: every item again, in replay mode (score_core.hpp: ScoreAcc::replay_*) -- nothing is added, the
+// explain_to_score calls on the marked cells are logged.  Rare (a cell reaches the guard at ~8 000x), so one launch with the
+// HBM tables serves every item.
+template <class RH, uint32_t CAP>
+GTX_DEV void score_replay_pass(GraphView const & g, ScoreParams const & par, gtx_score_item const * __restrict__ items, uint32_t n_items,
+                               uint32_t const * __restrict__ records, uint32_t rec_words, ScoreAcc acc, uint32_t * error_flag, RH * tables)
+{
+  uint32_t const tid = blockIdx.x * blockDim.x + threadIdx.x, n_threads = gridDim.x * blockDim.x;
+  RH * r1 = tables + static_cast<uint64_t>(tid) * 2 * CAP;
+  for (uint32_t i = tid; i < n_items; i += n_threads)
+  {
+    acc.replay_item = i;
+    if (!score_item<WaveHip>(g, par, items[i], records, rec_words, acc, r1, r1 + CAP, CAP))
+      atomicAdd(error_flag, 1u);
+  }
+}
+
+__global__ __launch_bounds__(64) void gtx_score_replay_kernel(GraphView g, ScoreParams par, gtx_score_item const * __restrict__ items,
+                                                              uint32_t n_items, uint32_t const * __restrict__ records, uint32_t rec_words,
+                                                              ScoreAcc acc, uint32_t * error_flag, RecentHap * tables)
+{
+  score_replay_pass<RecentHap, SCORE_MAX_HAPS_BIG>(g, par, items, n_items, records, rec_words, acc, error_flag, tables);
+}
+
+__global__ __launch_bounds__(64) void gtx_score_replay_wide_kernel(GraphView g, ScoreParams par, gtx_score_item const * __restrict__ items,
+                                                                   uint32_t n_items, uint32_t const * __restrict__ records,
+                                                                   uint32_t rec_words, ScoreAcc acc, uint32_t * error_flag,
+                                                                   RecentHapWide * tables)
+{
+  score_replay_pass<RecentHapWide, SCORE_MAX_HAPS_WIDE>(g, par, items, n_items, records, rec_words, acc, error_flag, tables);
+}
+
 // One thread per (sample, haplotype): call_cell in score_core.hpp.
 __global__ __launch_bounds__(256) void gtx_calls_kernel(GraphView g, uint32_t n_samples, uint32_t const * __restrict__ log_score,
                                                         uint32_t const * __restrict__ gt_cov, uint32_t const * __restrict__ hap_u32,
@@ -1483,6 +1516,134 @@ extern "C" int gtx_score_batch(gtx_ctx * c, const gtx_score_item * d_items, uint
       return GTX_ERR_HIP;
   }
   return GTX_OK;
+}
+
+// Sequential replay of the cells that reached the saturation guard of explain_to_score (score_replay.hpp).
+extern "C" int gtx_scores_replay(gtx_ctx * c, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records,
+                                 uint32_t rec_words, const gtx_score_buffers * acc, void * stream, uint64_t * n_replayed,
+                                 uint64_t * n_unsupported)
+{
+  if (!c || !acc || !acc->d_log_score || !acc->d_hap_u32 || (n_items && (!d_items || !d_records)))
+  {
+    g_last_error = "gtx_scores_replay: bad argument";
+    return GTX_ERR_ARG;
+  }
+  if (c->device < 0)
+  {
+    g_last_error = "context was created without a device (libgtx has no CPU path)";
+    return GTX_ERR_NO_DEVICE;
+  }
+  if (n_replayed)
+    *n_replayed = 0;
+  if (n_unsupported)
+    *n_unsupported = 0;
+  hipStream_t const st = static_cast<hipStream_t>(stream);
+  if (!hip_ok(hipSetDevice(c->device), "hipSetDevice") || !hip_ok(hipStreamSynchronize(st), "stream synchronize"))
+    return GTX_ERR_HIP;
+  HostGraph const & g = c->graph;
+  uint64_t const n_cells = static_cast<uint64_t>(acc->n_samples) * g.n_hap;
+  std::vector<uint32_t> cells(4 * n_cells);
+  if (!hip_ok(hipMemcpy(cells.data(), acc->d_hap_u32, cells.size() * sizeof(uint32_t), hipMemcpyDeviceToHost), "cells"))
+    return GTX_ERR_HIP;
+  std::vector<uint32_t> marked((n_cells + 31) / 32, 0u);
+  uint64_t n_marked = 0, unsupported = 0;
+  for (uint64_t cell = 0; cell < n_cells; ++cell)
+  {
+    uint32_t const m = cells[4 * cell];
+    if ((m & GTX_CELL_REPLAYED) || m < SATURATION_GUARD)
+      continue;
+    if (g.ref_nvar[cell % g.n_hap] > 64) // (the log keeps 64-bit explain sets)
+    {
+      ++unsupported;
+      continue;
+    }
+    marked[cell >> 5] |= 1u << (cell & 31u);
+    ++n_marked;
+  }
+  if (n_unsupported)
+    *n_unsupported = unsupported;
+  if (n_marked == 0)
+    return GTX_OK;
+  ScratchHold hold{*c, scratch_acquire(*c, st), st, false};
+  CallScratch * s = hold.s;
+  if (!s || !s->d_score_tables)
+  {
+    g_last_error = "gtx_scores_replay: the context has no second scoring pass (gtx_params::no_second_pass)";
+    return s ? GTX_ERR_UNSUPPORTED : GTX_ERR_HIP;
+  }
+  uint32_t * d_marked = nullptr;
+  uint32_t * d_count = nullptr;
+  ReplayEntry * d_log = nullptr;
+  uint32_t cap = 1u << 20;
+  std::vector<ReplayEntry> log;
+  bool ok = dev_alloc(d_marked, marked.size(), "replay bitmap") && dev_alloc(d_count, 1, "replay count") &&
+            hip_ok(hipMemcpy(d_marked, marked.data(), marked.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "replay bitmap");
+  for (int attempt = 0; ok && attempt < 2; ++attempt) // (a second launch when the log was too small)
+  {
+    ok = dev_alloc(d_log, cap, "replay log") && hip_ok(hipMemset(d_count, 0, sizeof(uint32_t)), "replay count");
+    if (!ok)
+      break;
+    ScoreAcc a;
+    a.n_samples = acc->n_samples;
+    a.conn_cap = 0;
+    a.log_score = acc->d_log_score;
+    a.gt_cov = acc->d_gt_cov;
+    a.hap_u32 = acc->d_hap_u32;
+    a.stat_u64 = reinterpret_cast<unsigned long long *>(acc->d_stat_u64);
+    a.stat_u32 = acc->d_stat_u32;
+    a.conn_log = acc->d_conn_log;
+    a.conn_count = acc->d_conn_count;
+    a.conn_near = acc->d_conn_near;
+    a.big_records = c->d_big_records;
+    a.replay_cells = d_marked;
+    a.replay_log = d_log;
+    a.replay_count = d_count;
+    a.replay_cap = cap;
+    ScoreParams par{static_cast<uint32_t>(c->params.is_sv_graph != 0), static_cast<uint32_t>(c->params.hq_reads != 0),
+                    static_cast<uint32_t>(c->params.is_segment_calling != 0), 0};
+    if (c->has_wide_sites)
+      hipLaunchKernelGGL(gtx_score_replay_wide_kernel, dim3(gtx_ctx::SCORE_BIG_THREADS / 64), dim3(64), 0, st, c->dev_graph, par, d_items, n_items,
+                         d_records, rec_words, a, c->d_error_flag, static_cast<RecentHapWide *>(s->d_score_tables));
+    else
+      hipLaunchKernelGGL(gtx_score_replay_kernel, dim3(gtx_ctx::SCORE_BIG_THREADS / 64), dim3(64), 0, st, c->dev_graph, par, d_items, n_items,
+                         d_records, rec_words, a, c->d_error_flag, static_cast<RecentHap *>(s->d_score_tables));
+    uint32_t wanted = 0;
+    ok = hip_ok(hipGetLastError(), "gtx_score_replay_kernel launch") && hip_ok(hipStreamSynchronize(st), "replay") &&
+         hip_ok(hipMemcpy(&wanted, d_count, sizeof(wanted), hipMemcpyDeviceToHost), "replay count");
+    if (ok && wanted <= cap)
+    {
+      log.resize(wanted);
+      ok = wanted == 0 || hip_ok(hipMemcpy(log.data(), d_log, static_cast<size_t>(wanted) * sizeof(ReplayEntry), hipMemcpyDeviceToHost), "replay log");
+      break;
+    }
+    (void)hipFree(d_log);
+    d_log = nullptr;
+    cap = wanted;
+    if (attempt == 1)
+    {
+      g_last_error = "gtx_scores_replay: the log kept growing";
+      ok = false;
+    }
+  }
+  if (ok)
+  {
+    std::vector<ReplayedCell> const done = replay_cells(g, log);
+    for (ReplayedCell const & rc : done)
+    {
+      uint32_t const h = rc.cell % g.n_hap, sample = rc.cell / g.n_hap;
+      uint32_t const head = rc.max_log_score | GTX_CELL_REPLAYED;
+      ok = ok && hip_ok(hipMemcpy(acc->d_hap_u32 + 4ull * rc.cell, &head, sizeof(head), hipMemcpyHostToDevice), "replayed cell") &&
+           hip_ok(hipMemcpy(acc->d_log_score + static_cast<uint64_t>(sample) * g.total_tri + g.tri_off[h], rc.log_score.data(),
+                            rc.log_score.size() * sizeof(uint32_t), hipMemcpyHostToDevice),
+                  "replayed scores");
+    }
+    if (n_replayed)
+      *n_replayed = done.size();
+  }
+  for (void * p : {static_cast<void *>(d_marked), static_cast<void *>(d_count), static_cast<void *>(d_log)})
+    if (p)
+      (void)hipFree(p);
+  return ok ? GTX_OK : GTX_ERR_HIP;
 }
 
 extern "C" int gtx_ctx_big_records(gtx_ctx * c, const uint32_t ** d_words, uint64_t * capacity_words, uint64_t * used_words,

@@ -248,7 +248,9 @@ extern "C"
     {
       uint32_t * cell = hap_u32 + 4 * i;
       // a read is only added while max_log_score < 0xFFFF - epsilon, epsilon in [4,8]: below 0xFFFF - 8 no read was refused
-      if (cell[0] >= 0xFFFFu - 8u)
+      if (cell[0] & 0x80000000u) // replayed in call order by gtx_scores_replay: the exact value
+        cell[0] &= 0x7FFFFFFFu;
+      else if (cell[0] >= 0xFFFFu - 8u)
         ++sat;
       for (int k = 1; k < 4; ++k)
         if (cell[k] > 0xFFu)

@@ -284,6 +284,23 @@ struct ScoreAcc // device pointers, see gtx_score_buffers in include/gtx.h
   uint32_t const * big_records; // the context's arena for records longer than rec_words
   uint32_t * ref_depth = nullptr; // SV calling: [n_samples][ref_depth_len + 1] difference array of ReferenceDepth (NULL: not kept)
   uint32_t ref_depth_len = 0;
+  // replay mode (gtx_scores_replay): nothing is added to the accumulators; instead every explain_to_score call on a marked
+  // (haplotype, sample) cell is logged with its epsilon and explain set, keyed by the item that caused it
+  uint32_t const * replay_cells = nullptr; // bitmap over cells sample * n_hap + hap (NULL: normal scoring)
+  struct ReplayEntry * replay_log = nullptr;
+  uint32_t * replay_count = nullptr; // [0] entries wanted, capacity replay_cap
+  uint32_t replay_cap = 0;
+  uint32_t replay_item = 0; // index of the item being scored (set per thread)
+};
+
+// one call of Haplotype::explain_to_score (haplotype.cpp:462-585) on a cell whose max_log_score reached the sequential
+// guard at :560 -- the only place where the order of the reads matters
+struct ReplayEntry
+{
+  uint32_t item, cell;  // score item (its position in the region's item sequence = the reference's call order), cell
+  uint32_t order_eps;   // epsilon_exponent | which read of the item << 8
+  uint32_t mask_lo, mask_hi; // explains (sites of at most 64 alleles)
+  uint32_t pad;
 };
 
 // ReferenceDepth::add_genotype_paths (src/graph/reference_depth.cpp:109-201): every accepted read adds one to the depth of
@@ -487,11 +504,41 @@ GTX_DEV uint32_t collect_recent(GraphView const & g, Geno const & ge, RecentHapT
 }
 
 // push_to_haplotype_scores, second half: everything the read adds to the accumulators
+// epsilon_exponent of explain_to_score (haplotype.cpp:471-501; no low-quality-base penalty in genotype-only mode)
+GTX_DEV uint32_t explain_epsilon(Geno const & ge, bool fully, bool unique, bool overlapping)
+{
+  long e = 12;
+  e -= static_cast<long>(first_mismatches(ge));
+  if (!unique)
+    e -= 3;
+  if (ge.flags & F_MAPQ_BAD)
+    e -= 2;
+  if (!fully)
+    e -= 3;
+  if (!overlapping)
+    e -= 1;
+  return static_cast<uint32_t>((e > 8 ? e : 8) - 4);
+}
+
 template <class W, uint32_t NW>
 GTX_DEV void apply_recent(GraphView const & g, ScoreAcc const & acc, Geno const & ge, bool fully, bool unique, uint32_t sample,
-                          RecentHapT<NW> const * recent, uint32_t n)
+                          RecentHapT<NW> const * recent, uint32_t n, uint32_t order = 0)
 {
   using RecentHap = RecentHapT<NW>;
+  if (acc.replay_cells)
+  {
+    for (uint32_t a = 0; a < n; ++a)
+    {
+      uint32_t const cell = sample * g.n_hap + recent[a].site;
+      if (!((acc.replay_cells[cell >> 5] >> (cell & 31u)) & 1u))
+        continue;
+      uint32_t const slot = W::atomic_claim_u32(acc.replay_count);
+      if (slot < acc.replay_cap)
+        acc.replay_log[slot] = ReplayEntry{acc.replay_item, cell, explain_epsilon(ge, fully, unique, recent[a].overlapping) | (order << 8),
+                                           static_cast<uint32_t>(recent[a].explains.w[0]), static_cast<uint32_t>(recent[a].explains.w[0] >> 32), 0u};
+    }
+    return;
+  }
   uint32_t const clipped_bp = ge.read_len - ge.longest;
   uint32_t const mismatches = first_mismatches(ge);
   // connections between the sites of this read (vcf_writer.cpp:587-636)
@@ -556,17 +603,7 @@ GTX_DEV void apply_recent(GraphView const & g, ScoreAcc const & acc, Geno const 
         W::atomic_add_u32(s32 + 0, ge.score_diff);
     }
     // explain_to_score (:462-585)
-    long e = 12;
-    e -= static_cast<long>(mismatches);
-    if (!unique)
-      e -= 3;
-    if (ge.flags & F_MAPQ_BAD)
-      e -= 2;
-    if (!fully)
-      e -= 3;
-    if (!rh.overlapping)
-      e -= 1;
-    uint32_t const eps = static_cast<uint32_t>((e > 8 ? e : 8) - 4);
+    uint32_t const eps = explain_epsilon(ge, fully, unique, rh.overlapping);
     uint32_t * cell = acc.hap_u32 + (static_cast<uint64_t>(sample) * nh + h) * 4;
     W::atomic_add_u32(cell + 0, eps);
     uint32_t * ls = acc.log_score + static_cast<uint64_t>(sample) * g.total_tri + g.tri_off[h];
@@ -697,9 +734,12 @@ GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_
   second.flags |= F_PROPER_PAIR;
   // SV calling: the reads of a selected pair count for the reference depth (hts_parallel_reader.cpp:324-329), a leftover
   // read alone (:739-741)
-  add_ref_depth<W>(g, acc, first, it.sample);
-  if (!(it.kind & GTX_ITEM_LEFTOVER))
-    add_ref_depth<W>(g, acc, second, it.sample);
+  if (!acc.replay_cells)
+  {
+    add_ref_depth<W>(g, acc, first, it.sample);
+    if (!(it.kind & GTX_ITEM_LEFTOVER))
+      add_ref_depth<W>(g, acc, second, it.sample);
+  }
   // update_haplotype_scores_geno, pair overload (vcf_writer.cpp:143-250)
   bool f1, u1, f2, u2;
   bool const good1 = geno_is_good(g, par, first, f1, u1), good2 = geno_is_good(g, par, second, f2, u2);
@@ -727,7 +767,9 @@ GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_
   if (good1)
     apply_recent<W>(g, acc, first, f1, u1, it.sample, r1, n1);
   if (good2)
-    apply_recent<W>(g, acc, second, f2, u2, it.sample, r2, n2);
+    apply_recent<W>(g, acc, second, f2, u2, it.sample, r2, n2, 1);
+  if (acc.replay_cells)
+    return true; // (replay mode: the connections between the mates were counted by the scoring pass)
   // cross links between the two mates' sites: every (site, allele) key of one mate gets one count towards every key
   // of the other mate that lies on a later site (vcf_writer.cpp:186-227)
   for (uint32_t a = 0; a < n1; ++a)

@@ -16,6 +16,7 @@
  *                                 (flag filter, duplicate reuse, mate parking; SV calling: record filter, coverage
  *                                 filter, leftover reads)                       src/utilities/hts_parallel_reader.cpp:245-338,528-772
  *   gtx_phase_flags     replaces  the `ph` construction                         src/utilities/hts_parallel_reader.cpp:782-904
+ *   gtx_scores_replay   replays   the saturation guard of Haplotype::explain_to_score     src/graph/haplotype.cpp:560
  *   gtx_scores_reduce   replaces  the merge of the per-thread / per-pool results   src/typer/caller.cpp:439-482,
  *                                 (every per-read effect is an integer addition)  src/typer/vcf_operations.cpp:366-374
  *   gtx_vcf_records     replaces  Vcf::add_haplotype + generate_infos + write_record   src/typer/vcf.cpp:767-1151,1507-1611
@@ -395,6 +396,20 @@ int gtx_scores_reduce(gtx_ctx *, const gtx_score_buffers *, void * rccl_comm, vo
 int gtx_comm_unique_id(void * id /* [GTX_COMM_ID_BYTES] */);
 int gtx_comm_init_rank(const void * id, int n_ranks, int rank, int device, void ** comm);
 int gtx_comm_destroy(void * comm);
+
+/* The one order-dependent step of the scoring: Haplotype::explain_to_score stops adding to a (haplotype, sample) once its
+ * max_log_score has come within epsilon of 0xFFFF (src/graph/haplotype.cpp:560; roughly 8 000 reads over one site in one
+ * sample), and which reads are dropped then depends on the order of the calls.  gtx_score_batch adds without the guard.
+ * gtx_scores_replay finds the cells whose sum reached the guard, goes over the region's items once more -- ALL of them, in
+ * the order they were produced (gtx_stream_push / gtx_stream_finish order = the order in which genotype_only reaches the
+ * VcfWriter), against the same resident d_records -- logs the explain_to_score calls on those cells, replays them one by
+ * one on the host as the reference does and stores the exact log_score rows and max_log_score back into `acc` (device).
+ * Call it after the last gtx_score_batch of a region (single process: with reads sharded over several GPUs the call order
+ * is spread over the ranks) and before gtx_calls_batch / downloading.  n_replayed: cells replayed; n_unsupported: cells at
+ * the guard that lie on a site of more than 64 alleles (left as they are, reported by gtx_scores_finalize).  Synchronises
+ * with `stream`. */
+int gtx_scores_replay(gtx_ctx *, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records, uint32_t rec_words,
+                      const gtx_score_buffers * acc, void * stream, uint64_t * n_replayed, uint64_t * n_unsupported);
 
 /* Host-side clamp of downloaded accumulators to the reference's stored types (haplotype.cpp:19-44: u8 -> 255,
  * u16 -> 0xFFFF).  Returns the number of (haplotype,sample) cells whose max_log_score reached the sequential

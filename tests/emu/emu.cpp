@@ -14,6 +14,7 @@
 #include "../../graphtyper_amd/csrc/gtx_flat.hpp"
 #include "../../graphtyper_amd/csrc/align_core.hpp"
 #include "../../graphtyper_amd/csrc/score_core.hpp"
+#include "../../graphtyper_amd/csrc/score_replay.hpp"
 
 namespace
 {
@@ -420,5 +421,66 @@ extern "C"
           ++errors;
       }
     return static_cast<int>(errors);
+  }
+
+  // gtx_scores_replay over host arrays: marks the cells at the guard, logs their explain_to_score calls with the kernel
+  // source in replay mode, replays them with the library's host code (score_replay.hpp).  Returns the cells replayed.
+  long emu_score_replay(void * p, const gtx_score_item * items, uint32_t n_items, const uint32_t * records, uint32_t rec_words,
+                        const gtx_score_buffers * acc)
+  {
+    using namespace gtx;
+    Emu & e = *static_cast<Emu *>(p);
+    GraphView const g = e.graph.view();
+    uint64_t const n_cells = static_cast<uint64_t>(acc->n_samples) * e.graph.n_hap;
+    std::vector<uint32_t> marked((n_cells + 31) / 32, 0u);
+    uint64_t n_marked = 0;
+    for (uint64_t cell = 0; cell < n_cells; ++cell)
+    {
+      uint32_t const m = acc->d_hap_u32[4 * cell];
+      if ((m & GTX_CELL_REPLAYED) || m < SATURATION_GUARD || e.graph.ref_nvar[cell % e.graph.n_hap] > 64)
+        continue;
+      marked[cell >> 5] |= 1u << (cell & 31u);
+      ++n_marked;
+    }
+    if (n_marked == 0)
+      return 0;
+    std::vector<ReplayEntry> log(1u << 22);
+    uint32_t count = 0;
+    ScoreAcc a;
+    a.n_samples = acc->n_samples;
+    a.conn_cap = 0;
+    a.log_score = acc->d_log_score;
+    a.gt_cov = acc->d_gt_cov;
+    a.hap_u32 = acc->d_hap_u32;
+    a.stat_u64 = reinterpret_cast<unsigned long long *>(acc->d_stat_u64);
+    a.stat_u32 = acc->d_stat_u32;
+    a.conn_log = acc->d_conn_log;
+    a.conn_count = acc->d_conn_count;
+    a.conn_near = acc->d_conn_near;
+    a.big_records = e.arena.data();
+    a.replay_cells = marked.data();
+    a.replay_log = log.data();
+    a.replay_count = &count;
+    a.replay_cap = static_cast<uint32_t>(log.size());
+    ScoreParams par{static_cast<uint32_t>(e.params.is_sv_graph != 0), static_cast<uint32_t>(e.params.hq_reads != 0),
+                    static_cast<uint32_t>(e.params.is_segment_calling != 0), 0};
+    std::vector<RecentHap> large(2 * SCORE_MAX_HAPS_BIG);
+    for (uint32_t i = 0; i < n_items; ++i)
+    {
+      a.replay_item = i;
+      if (!score_item<WaveEmu>(g, par, items[i], records, rec_words, a, large.data(), large.data() + SCORE_MAX_HAPS_BIG, SCORE_MAX_HAPS_BIG))
+        return -1;
+    }
+    if (count > log.size())
+      return -2;
+    log.resize(count);
+    std::vector<ReplayedCell> const done = replay_cells(e.graph, log);
+    for (ReplayedCell const & rc : done)
+    {
+      uint32_t const h = rc.cell % e.graph.n_hap, sample = rc.cell / e.graph.n_hap;
+      acc->d_hap_u32[4ull * rc.cell] = rc.max_log_score | GTX_CELL_REPLAYED;
+      std::copy(rc.log_score.begin(), rc.log_score.end(), acc->d_log_score + static_cast<uint64_t>(sample) * e.graph.total_tri + e.graph.tri_off[h]);
+    }
+    return static_cast<long>(done.size());
   }
 }

@@ -104,6 +104,15 @@ class EmuBackend:
         assert errors == 0
         return acc
 
+    def score_replay(self, items, records, acc, rec_words=REC_WORDS):
+        """gtx_scores_replay on the host arrays of `acc` (in place); returns the number of cells replayed"""
+        items = np.ascontiguousarray(items, gtx.SCORE_ITEM)
+        buf = acc.buffers([_p(a) for a in acc.arrays()])
+        self.L.emu_score_replay.restype = C.c_long
+        n = self.L.emu_score_replay(C.c_void_p(self.h), _p(items), C.c_uint32(len(items)), _p(records), C.c_uint32(rec_words), C.byref(buf))
+        assert n >= 0
+        return int(n)
+
     def calls(self, acc, n_samples):
         """gtx_calls_batch contract on the host: (phred [n_samples * total_tri] u8, SAMPLE_CALL [n_samples * n_hap])"""
         buf = acc.buffers([_p(a) for a in acc.arrays()])
@@ -166,6 +175,22 @@ class GpuBackend:
             host[...] = dev.cpu().numpy().view(host.dtype)
         return acc
 
+    def score_replay(self, items, records, acc, rec_words=REC_WORDS):
+        torch = self.torch
+        items = np.ascontiguousarray(items, gtx.SCORE_ITEM)
+        d_items = self._dev(items)
+        d_rec = self._dev(np.ascontiguousarray(records, np.uint32))
+        devs = [self._dev(a) for a in acc.arrays()]
+        buf = acc.buffers([d.data_ptr() for d in devs])
+        n, bad = C.c_uint64(), C.c_uint64()
+        gtx.check(gtx.lib().gtx_scores_replay(self.ctx.h, d_items.data_ptr(), len(items), d_rec.data_ptr(), rec_words, C.byref(buf), None,
+                                              C.byref(n), C.byref(bad)))
+        torch.cuda.synchronize()
+        assert bad.value == 0 and self.ctx.error_count() == 0
+        for host, dev in zip(acc.arrays(), devs):
+            host[...] = dev.cpu().numpy().view(host.dtype)
+        return int(n.value)
+
     def calls(self, acc, n_samples):
         torch = self.torch
         devs = [self._dev(a) for a in acc.arrays()]
@@ -218,7 +243,7 @@ def canonical_scores(ctx, acc):
     nsat = C.c_uint64()
     gtx.check(L.gtx_scores_finalize(_p(acc.log_score), len(acc.log_score), _p(acc.gt_cov), len(acc.gt_cov), _p(acc.hap_u32),
                                     len(acc.hap_u32) // 4, C.byref(nsat)))
-    assert nsat.value == 0, "a (haplotype,sample) reached the sequential saturation guard"
+    assert nsat.value == 0, "a (haplotype,sample) reached the sequential saturation guard (gtx_scores_replay was not run)"
     assert acc.conn_count[1] == 0, "connection log overflow"
     conn = {}
     log = acc.conn_log[:6 * int(acc.conn_count[0])].reshape(-1, 6)

@@ -282,3 +282,10 @@ def test_sites_with_more_than_64_alleles_on_the_device():
     from test_wide_sites import wide_sites_case
     b = wide_sites_case(harness.GpuBackend)
     assert b.ctx.n_hap > 10
+
+
+def test_saturation_guard_is_replayed_on_the_device():
+    """gtx_scores_replay: 10 500 reads of one sample over one SNP drive max_log_score past 0xFFFF; the replayed cell equals
+    the oracle's sequential explain_to_score (haplotype.cpp:560)"""
+    from test_saturation import saturation_case
+    saturation_case(harness.GpuBackend)
