@@ -28,8 +28,7 @@ struct Express4Lean
   static constexpr bool AMB_ON_VARIANT = true;      // ... and whether they may lie on a variant
 };
 
-static_assert(AlignCfg::HE_CAP == HINT_HE_CAP && Express4Lean::NB_MAX == HINT_NB_MAX && Express4Lean::KS == 1,
-              "build_hints (gtx_host.cpp) restates the lean seeding rule with these limits");
+static_assert(Express4Lean::KS == 1, "one variant site per k-mer in the position flags");
 
 struct Express4Wide
 {
@@ -40,6 +39,9 @@ struct Express4Wide
   static constexpr uint32_t AMB_LABELS = 5;
   static constexpr bool AMB_ON_VARIANT = true;
 };
+
+static_assert(Express4Wide::HE_SCAN == HINT_HE_CAP && Express4Wide::NB_MAX == HINT_NB_MAX,
+              "hint_exact_verdict (index_build.hpp) restates the wide seeding rule with these limits");
 
 constexpr uint32_t EXPRESS4_INDEL_ALLELES = 8; // alleles of a site the walk at the read's end may cross when they differ in length
 

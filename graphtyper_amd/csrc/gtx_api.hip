@@ -607,7 +607,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void gt
                                                        uint32_t * __restrict__ records, uint32_t rec_words,
                                                        uint32_t const * __restrict__ queue, uint32_t const * queue_count,
                                                        uint32_t * task_counter, uint32_t * __restrict__ big_tasks,
-                                                       uint32_t big_task_cap, uint32_t * big_state, uint32_t force_big, uint32_t task_base)
+                                                       uint32_t big_task_cap, uint32_t * big_state, uint32_t force_big, uint32_t task_base,
+                                                       uint32_t claim)
 {
   __shared__ AlignWorkspace ws;
 #ifdef GTX_PROF
@@ -616,7 +617,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void gt
   WaveHip::lds_sync();
 #endif
   uint32_t const queued = queue_count[0];
-  constexpr uint32_t CLAIM = 8; // tasks per visit to the counter (at 1 the counter, not the work, would set the pace)
+  uint32_t const CLAIM = claim; // tasks per visit to the counter (one atomic per task: the counter, not the work, sets the pace of a long
+                                // queue; large claims: the last claims of a short queue decide when the pass ends)
   for (uint32_t t = 0, t_end = 0;; ++t)
   {
     if (t == t_end)
@@ -1200,6 +1202,9 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
     if (!hip_ok(hipMemsetAsync(s->d_big_state, 0, 12 * sizeof(uint32_t), st), "second-pass state reset"))
       return GTX_ERR_HIP;
   }
+  // tasks a wave of the general pass claims per visit to the counter
+  char const * gc = std::getenv("GTX_GENERAL_CLAIM");
+  uint32_t const general_claim = gc && std::atoi(gc) > 0 ? static_cast<uint32_t>(std::atoi(gc)) : 4u; // (A/B at cfg2: 8 / 4 / 2 / 1 = 1.03 / 0.88 / 0.88 / 1.06 ms)
   // test switch: 1 = every task goes through all passes (the last one decides), 2 = every task is done by pass 2
   char const * fb = std::getenv("GTX_FORCE_SECOND_PASS");
   uint32_t const force = fb ? static_cast<uint32_t>(std::atoi(fb)) : 0u;
@@ -1318,7 +1323,7 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
     mark(part, 3, sg);
     hipLaunchKernelGGL(gtx_align_kernel, dim3(blocks2), dim3(64), 0, sg, c->dev_graph, c->dev_index, seq, seq_stride, meta, records, rec_words,
                        queue2, counters + 2, counters + 1, second_pass ? s->d_big_tasks : nullptr, s->big_task_cap, s->d_big_state,
-                       static_cast<uint32_t>(force == 1), 2u * first);
+                       static_cast<uint32_t>(force == 1), 2u * first, general_claim);
     if (!hip_ok(hipGetLastError(), "gtx_align_kernel launch"))
       return GTX_ERR_HIP;
     mark(part, 4, sg);

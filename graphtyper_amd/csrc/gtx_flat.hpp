@@ -145,8 +145,11 @@ constexpr uint32_t HINT_ALTIDX_SHIFT = 8u, HINT_SITE_SHIFT = 12u + 4u; // x: fla
 constexpr uint32_t HINT_NO_SITE = 0xFFFFu;
 constexpr uint32_t HINT_BACK_SHIFT = 8u, HINT_SNPOFF_SHIFT = 16u; // y
 constexpr uint32_t HINT_TAIL_OK = 1u, HINT_TAIL_NALL_SHIFT = 2u, HINT_TAIL_NEXT_SHIFT = 8u, HINT_TAIL_CODES_SHIFT = 16u; // tail_info.x
-// limits of express4's lean seeding rule that HINT_EXACT_OK restates on the host (static_asserts in express4.inl)
-constexpr uint32_t HINT_HE_CAP = 4, HINT_NB_MAX = 3;
+// HINT_EXACT_OK restates express4's seeding rule for an exact hit when the index is built; these are the limits of the
+// rule's wide form (static_asserts in express4.inl): how many keys may share a half with the k-mer's key, how many labels
+// its Hamming-1 neighbours may have together.  (The verdict is about the reference's lookups, not about which build of
+// pass 1 runs behind pass 0: neighbours on the k-mer's own interval and site end where the chain ends, whatever their number.)
+constexpr uint32_t HINT_HE_CAP = 16, HINT_NB_MAX = 16;
 
 // hash of a 16-base half in nibble form (w0 = bases 0..7, w1 = bases 8..15; base j in bits 28-4j) -> (word, two-bit mask)
 // of the blocked Bloom filter
