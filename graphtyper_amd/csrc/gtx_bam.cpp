@@ -1,0 +1,551 @@
+// gtx_bam.cpp -- BAM ingest in front of gtx_stream_push, host side, zlib only.
+//
+// What the reference does with htslib before a record reaches genotype_only():
+//   HtsReader::open                      src/utilities/hts_reader.cpp:17-124   header, @RG -> (read group, sample) tables, region
+//   HtsReader::get_next_read_in_order    hts_reader.cpp:166-303                records of one position sorted by (l_qseq, packed bases)
+//   HtsParallelReader::open/read_record  src/utilities/hts_parallel_reader.cpp:66-136   k-way merge of the files by
+//                                        (tid, pos, l_qseq, packed bases)       include/graphtyper/utilities/hts_utils.hpp:48-108
+//   HtsReader::get_sample_and_rg_index   hts_reader.cpp:354-387                RG tag -> read group / sample index
+//   get_score_diff                       src/typer/alignment.cpp:140-325       AS - XS from the aux fields, with its parsing quirks
+// Here: BGZF is a series of gzip members, which zlib's gzread reads through; a BAM record is parsed in place into a
+// gtx_stream_record + its packed bases (copied verbatim: the kernels read BAM nibbles).  Equal keys keep file order, then
+// position in the file (the reference's std::sort / heap leave the order of exact duplicates unspecified; their results do
+// not depend on it).  Not read: CRAM (needs htslib's codecs), the .bai / .csi index -- a region is applied by scanning.
+#include "gtx_ctx.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace
+{
+struct Rec // one BAM record as the merge needs it
+{
+  gtx_stream_record r{};
+  std::vector<uint8_t> seq; // (l_qseq + 1) / 2 bytes
+  int64_t end_pos = 0;      // first reference position behind the alignment
+};
+
+// gt_pos_seq_same_pos / gt_pos_seq (hts_utils.hpp:48-108) as "a comes before b"
+bool seq_before(Rec const & a, Rec const & b)
+{
+  if (a.r.l_qseq != b.r.l_qseq)
+    return a.r.l_qseq < b.r.l_qseq;
+  return a.seq < b.seq; // bytewise, equal lengths
+}
+
+bool record_before(Rec const & a, Rec const & b)
+{
+  if (a.r.tid != b.r.tid)
+    return a.r.tid < b.r.tid;
+  if (a.r.pos != b.r.pos)
+    return a.r.pos < b.r.pos;
+  return seq_before(a, b);
+}
+
+uint64_t name_hash(char const * s, size_t n) // identity of a read name: 64-bit FNV-1a
+{
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n; ++i)
+    h = (h ^ static_cast<uint8_t>(s[i])) * 1099511628211ull;
+  return h;
+}
+
+struct File
+{
+  gzFile fp = nullptr;
+  std::string path;
+  std::vector<std::string> ref_names;
+  std::vector<std::string> samples;          // of this file, in header order
+  std::map<std::string, uint32_t> rg2index;  // read group id -> index in this file
+  std::vector<uint32_t> rg2sample;           // -> sample index in this file
+  uint32_t sample_offset = 0, rg_offset = 0;
+  // region (by scanning): records of contig `want_tid` that overlap [begin, end)
+  int32_t want_tid = -2;
+  int64_t begin = 0, end = INT64_MAX;
+  bool eof = false;
+  Rec ahead;                   // the first record of the next position
+  bool have_ahead = false;
+  std::deque<Rec> same_pos;    // the records of the current position, in order
+  std::vector<uint8_t> buf;
+
+  bool read_exact(void * dst, unsigned n)
+  {
+    return gzread(fp, dst, n) == static_cast<int>(n);
+  }
+
+  uint32_t num_rg() const { return std::max<uint32_t>(1, static_cast<uint32_t>(rg2sample.size())); }
+
+  // alignment.cpp:140-325
+  static uint8_t score_diff(uint8_t const * it, uint32_t l_aux)
+  {
+    uint32_t i = 0;
+    int64_t as = -1, xs = -1;
+    auto load = [&](auto tag, bool is_as, bool is_xs)
+    {
+      decltype(tag) num;
+      std::memcpy(&num, it + i, sizeof(num));
+      if (is_as)
+        as = num;
+      else if (is_xs)
+        xs = num;
+      i += sizeof(num);
+    };
+    while (i < l_aux)
+    {
+      i += 3;
+      if (i > l_aux)
+        break;
+      char const type = static_cast<char>(it[i - 1]);
+      bool const is_s = it[i - 2] == 'S', is_as = is_s && it[i - 3] == 'A', is_xs = is_s && it[i - 3] == 'X';
+      switch (type)
+      {
+      case 'A': ++i; break;
+      case 'Z':
+        while (i < l_aux && it[i] != '\0' && it[i] != '\n')
+          ++i;
+        ++i;
+        break;
+      case 'c': load(int8_t(), is_as, is_xs); break;
+      case 'C': load(uint8_t(), is_as, is_xs); break;
+      case 's': load(int16_t(), is_as, is_xs); break;
+      case 'S': load(uint16_t(), is_as, is_xs); break;
+      case 'i': load(int32_t(), is_as, is_xs); break;
+      case 'I': load(uint32_t(), is_as, is_xs); break;
+      case 'f': i += 4; break;
+      default: i = l_aux; break; // unknown tag type: the reference stops here
+      }
+    }
+    if (as == -1 || as < xs)
+      return 0;
+    if (xs == -1)
+      xs = 0;
+    int64_t const diff = as - xs;
+    return diff < 255 ? static_cast<uint8_t>(diff) : 255;
+  }
+
+  // bam_aux_get(rec, "RG"): htslib walks the fields by their types
+  static bool find_rg(uint8_t const * aux, uint32_t l_aux, std::string & out)
+  {
+    uint32_t i = 0;
+    while (i + 3 <= l_aux)
+    {
+      char const t0 = static_cast<char>(aux[i]), t1 = static_cast<char>(aux[i + 1]), type = static_cast<char>(aux[i + 2]);
+      i += 3;
+      uint32_t size = 0;
+      switch (type)
+      {
+      case 'A': case 'c': case 'C': size = 1; break;
+      case 's': case 'S': size = 2; break;
+      case 'i': case 'I': case 'f': size = 4; break;
+      case 'd': size = 8; break;
+      case 'Z': case 'H':
+      {
+        uint32_t j = i;
+        while (j < l_aux && aux[j] != '\0')
+          ++j;
+        if (t0 == 'R' && t1 == 'G' && type == 'Z')
+        {
+          out.assign(reinterpret_cast<char const *>(aux + i), j - i);
+          return true;
+        }
+        size = j - i + 1;
+        break;
+      }
+      case 'B':
+      {
+        if (i + 5 > l_aux)
+          return false;
+        char const sub = static_cast<char>(aux[i]);
+        uint32_t n;
+        std::memcpy(&n, aux + i + 1, 4);
+        uint32_t const w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+        size = 5 + n * w;
+        break;
+      }
+      default: return false;
+      }
+      i += size;
+    }
+    return false;
+  }
+
+  // next record of the file that lies in the region; false at the end of the file (or behind the region)
+  bool read_one(Rec & out, std::string & err)
+  {
+    for (;;)
+    {
+      if (eof)
+        return false;
+      int32_t block = 0;
+      int const got = gzread(fp, &block, 4);
+      if (got == 0)
+      {
+        eof = true;
+        return false;
+      }
+      if (got != 4 || block < 32)
+      {
+        err = path + ": truncated BAM record";
+        eof = true;
+        return false;
+      }
+      buf.resize(static_cast<size_t>(block));
+      if (!read_exact(buf.data(), static_cast<unsigned>(block)))
+      {
+        err = path + ": truncated BAM record";
+        eof = true;
+        return false;
+      }
+      uint8_t const * p = buf.data();
+      int32_t tid, pos, l_seq, mtid, mpos, tlen;
+      uint8_t l_read_name, mapq;
+      uint16_t n_cigar, flag;
+      std::memcpy(&tid, p, 4);
+      std::memcpy(&pos, p + 4, 4);
+      l_read_name = p[8];
+      mapq = p[9];
+      std::memcpy(&n_cigar, p + 12, 2);
+      std::memcpy(&flag, p + 14, 2);
+      std::memcpy(&l_seq, p + 16, 4);
+      std::memcpy(&mtid, p + 20, 4);
+      std::memcpy(&mpos, p + 24, 4);
+      std::memcpy(&tlen, p + 28, 4);
+      size_t const o_name = 32, o_cigar = o_name + l_read_name, o_seq = o_cigar + 4ull * n_cigar,
+                   o_qual = o_seq + (static_cast<size_t>(l_seq) + 1) / 2, o_aux = o_qual + static_cast<size_t>(l_seq);
+      if (l_seq < 0 || o_aux > buf.size())
+      {
+        err = path + ": malformed BAM record";
+        eof = true;
+        return false;
+      }
+      // reference span of the alignment (bam_endpos: M, D, N, =, X consume the reference; at least one position)
+      int64_t span = 0;
+      uint32_t first = 0, last = 0;
+      for (uint32_t c = 0; c < n_cigar; ++c)
+      {
+        uint32_t w;
+        std::memcpy(&w, p + o_cigar + 4ull * c, 4);
+        if (c == 0)
+          first = w;
+        last = w;
+        uint32_t const op = w & 15u;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8)
+          span += w >> 4;
+      }
+      int64_t const end_pos = static_cast<int64_t>(pos) + (span > 0 ? span : 1);
+      if (want_tid != -2)
+      {
+        if (tid != want_tid || end_pos <= begin)
+        {
+          if (tid > want_tid && tid >= 0 && want_tid >= 0)
+          {
+            eof = true; // sorted file: behind the contig
+            return false;
+          }
+          continue;
+        }
+        if (pos >= end)
+        {
+          eof = true;
+          return false;
+        }
+      }
+      if (l_seq > 0xFFFF)
+      {
+        err = path + ": a read of more than 65535 bases";
+        eof = true;
+        return false;
+      }
+      out.r = gtx_stream_record{};
+      out.r.flag = flag;
+      out.r.mapq = mapq;
+      out.r.tid = tid;
+      out.r.mtid = mtid;
+      out.r.pos = pos;
+      out.r.isize = tlen;
+      out.r.l_qseq = static_cast<uint16_t>(l_seq);
+      out.r.mpos = mpos;
+      out.r.n_cigar = n_cigar;
+      out.r.cigar_front = first;
+      out.r.cigar_back = last;
+      out.r.name_id = name_hash(reinterpret_cast<char const *>(p + o_name), l_read_name ? l_read_name - 1u : 0u);
+      uint32_t const l_aux = static_cast<uint32_t>(buf.size() - o_aux);
+      out.r.score_diff = score_diff(p + o_aux, l_aux);
+      uint32_t rg = 0, sample = 0;
+      if (rg2sample.size() > 1) // hts_reader.cpp:354-387
+      {
+        std::string id;
+        if (!find_rg(p + o_aux, l_aux, id))
+        {
+          err = path + ": a record without RG tag in a file with several read groups";
+          eof = true;
+          return false;
+        }
+        auto it = rg2index.find(id);
+        if (it == rg2index.end())
+        {
+          err = path + ": unknown read group " + id;
+          eof = true;
+          return false;
+        }
+        rg = it->second;
+        sample = rg2sample[rg];
+      }
+      out.r.rg = static_cast<uint16_t>(rg + rg_offset);
+      out.r.sample = sample + sample_offset;
+      out.seq.assign(p + o_seq, p + o_qual);
+      out.end_pos = end_pos;
+      return true;
+    }
+  }
+
+  // HtsReader::get_next_read_in_order: the records of one position (the reference compares core.pos only), sorted
+  bool next(Rec & out, std::string & err)
+  {
+    if (same_pos.empty())
+    {
+      if (!have_ahead)
+        have_ahead = read_one(ahead, err);
+      if (!have_ahead)
+        return false;
+      int32_t const pos = ahead.r.pos;
+      std::vector<Rec> group;
+      group.push_back(std::move(ahead));
+      have_ahead = false;
+      Rec r;
+      while (read_one(r, err))
+      {
+        if (r.r.pos != pos)
+        {
+          ahead = std::move(r);
+          have_ahead = true;
+          break;
+        }
+        group.push_back(std::move(r));
+        r = Rec();
+      }
+      std::stable_sort(group.begin(), group.end(), seq_before);
+      for (auto & g : group)
+        same_pos.push_back(std::move(g));
+    }
+    out = std::move(same_pos.front());
+    same_pos.pop_front();
+    return true;
+  }
+};
+} // namespace
+
+struct gtx_reads
+{
+  std::vector<std::unique_ptr<File>> files;
+  std::vector<std::string> samples;
+  uint32_t n_rg = 0;
+  // merge front: one record per file that still has some
+  std::vector<std::pair<Rec, uint32_t>> front;
+  std::string error;
+};
+
+namespace
+{
+int fail(gtx_reads * r, std::string const & msg, int status)
+{
+  gtx::g_last_error = msg;
+  delete r;
+  return status;
+}
+} // namespace
+
+extern "C" int gtx_reads_open(const char * const * bam_paths, uint32_t n_paths, const char * region, gtx_reads ** out)
+{
+  if (!bam_paths || n_paths == 0 || !out)
+    return GTX_ERR_ARG;
+  *out = nullptr;
+  auto * r = new gtx_reads();
+  // "chr", "chr:begin", "chr:begin-end" (1-based, inclusive like a samtools region); "" / "." / NULL: everything
+  std::string contig;
+  int64_t begin = 0, end = INT64_MAX;
+  bool const whole = !region || std::strlen(region) <= 1;
+  if (!whole)
+  {
+    std::string const s(region);
+    size_t const colon = s.rfind(':');
+    contig = s.substr(0, colon);
+    if (colon != std::string::npos)
+    {
+      std::string rest = s.substr(colon + 1);
+      rest.erase(std::remove(rest.begin(), rest.end(), ','), rest.end());
+      size_t const dash = rest.find('-');
+      begin = std::max<int64_t>(0, std::atoll(rest.substr(0, dash).c_str()) - 1);
+      if (dash != std::string::npos && dash + 1 < rest.size())
+        end = std::atoll(rest.substr(dash + 1).c_str());
+    }
+  }
+  for (uint32_t f = 0; f < n_paths; ++f)
+  {
+    auto file = std::make_unique<File>();
+    file->path = bam_paths[f] ? bam_paths[f] : "";
+    file->fp = gzopen(file->path.c_str(), "rb");
+    if (!file->fp)
+      return fail(r, "could not open " + file->path, GTX_ERR_IO);
+    gzbuffer(file->fp, 1u << 18);
+    char magic[4];
+    int32_t l_text = 0, n_ref = 0;
+    if (!file->read_exact(magic, 4) || std::memcmp(magic, "BAM\1", 4) != 0 || !file->read_exact(&l_text, 4) || l_text < 0)
+    {
+      gzclose(file->fp);
+      return fail(r, file->path + " is not a BAM file (CRAM is not read)", GTX_ERR_UNSUPPORTED);
+    }
+    std::string text(static_cast<size_t>(l_text), '\0');
+    if ((l_text && !file->read_exact(&text[0], static_cast<unsigned>(l_text))) || !file->read_exact(&n_ref, 4) || n_ref < 0)
+    {
+      gzclose(file->fp);
+      return fail(r, file->path + ": truncated header", GTX_ERR_IO);
+    }
+    for (int32_t i = 0; i < n_ref; ++i)
+    {
+      int32_t l_name = 0, l_ref = 0;
+      std::string name;
+      if (!file->read_exact(&l_name, 4) || l_name <= 0 || (name.resize(static_cast<size_t>(l_name)), !file->read_exact(&name[0], static_cast<unsigned>(l_name))) ||
+          !file->read_exact(&l_ref, 4))
+      {
+        gzclose(file->fp);
+        return fail(r, file->path + ": truncated header", GTX_ERR_IO);
+      }
+      name.resize(std::strlen(name.c_str()));
+      file->ref_names.push_back(name);
+    }
+    // @RG lines -> read groups and samples (hts_reader.cpp:31-80: first "\tID:", last "\tSM:")
+    size_t at = 0;
+    while (at < text.size())
+    {
+      size_t const nl = std::min(text.find('\n', at), text.size());
+      std::string const line = text.substr(at, nl - at);
+      at = nl + 1;
+      if (line.rfind("@RG", 0) != 0)
+        continue;
+      size_t const pid = line.find("\tID:"), psm = line.rfind("\tSM:");
+      if (pid == std::string::npos || psm == std::string::npos)
+      {
+        gzclose(file->fp);
+        return fail(r, file->path + ": an @RG line without ID or SM", GTX_ERR_ARG);
+      }
+      size_t const eid = std::min(line.find('\t', pid + 1), line.size()), esm = std::min(line.find('\t', psm + 1), line.size());
+      std::string const id = line.substr(pid + 4, eid - pid - 4), sm = line.substr(psm + 4, esm - psm - 4);
+      file->rg2index[id] = static_cast<uint32_t>(file->rg2sample.size());
+      auto it = std::find(file->samples.begin(), file->samples.end(), sm);
+      file->rg2sample.push_back(static_cast<uint32_t>(it - file->samples.begin()));
+      if (it == file->samples.end())
+        file->samples.push_back(sm);
+    }
+    if (file->samples.empty()) // the file name up to its first '.' (hts_reader.cpp:83-91)
+    {
+      std::string s = file->path.substr(file->path.rfind('/') + 1);
+      if (s.find('.') != std::string::npos)
+        s = s.substr(0, s.find('.'));
+      file->samples.push_back(s);
+    }
+    if (!whole)
+    {
+      auto it = std::find(file->ref_names.begin(), file->ref_names.end(), contig);
+      if (it == file->ref_names.end())
+      {
+        gzclose(file->fp);
+        return fail(r, file->path + ": no contig " + contig, GTX_ERR_ARG);
+      }
+      file->want_tid = static_cast<int32_t>(it - file->ref_names.begin());
+      file->begin = begin;
+      file->end = end;
+    }
+    file->sample_offset = static_cast<uint32_t>(r->samples.size());
+    file->rg_offset = r->n_rg;
+    r->samples.insert(r->samples.end(), file->samples.begin(), file->samples.end());
+    r->n_rg += file->num_rg();
+    r->files.push_back(std::move(file));
+  }
+  for (uint32_t f = 0; f < r->files.size(); ++f)
+  {
+    Rec rec;
+    if (r->files[f]->next(rec, r->error))
+      r->front.emplace_back(std::move(rec), f);
+    if (!r->error.empty())
+    {
+      std::string const e = r->error;
+      for (auto & fl : r->files)
+        gzclose(fl->fp);
+      return fail(r, e, GTX_ERR_IO);
+    }
+  }
+  *out = r;
+  return GTX_OK;
+}
+
+extern "C" int gtx_reads_info(const gtx_reads * r, uint32_t * n_samples, uint32_t * n_read_groups)
+{
+  if (!r)
+    return GTX_ERR_ARG;
+  if (n_samples)
+    *n_samples = static_cast<uint32_t>(r->samples.size());
+  if (n_read_groups)
+    *n_read_groups = r->n_rg;
+  return GTX_OK;
+}
+
+extern "C" const char * gtx_reads_sample_name(const gtx_reads * r, uint32_t i)
+{
+  return r && i < r->samples.size() ? r->samples[i].c_str() : nullptr;
+}
+
+extern "C" int gtx_reads_next(gtx_reads * r, gtx_stream_record * recs, uint8_t * seq, uint32_t seq_stride, uint32_t cap, uint32_t * n)
+{
+  if (!r || !recs || !seq || !n)
+    return GTX_ERR_ARG;
+  *n = 0;
+  while (*n < cap && !r->front.empty())
+  {
+    // the smallest record; equal keys: the file that was opened first
+    size_t best = 0;
+    for (size_t i = 1; i < r->front.size(); ++i)
+      if (record_before(r->front[i].first, r->front[best].first))
+        best = i;
+    Rec & rec = r->front[best].first;
+    if (rec.seq.size() > seq_stride)
+    {
+      gtx::g_last_error = "gtx_reads_next: a read does not fit in seq_stride";
+      return GTX_ERR_ARG;
+    }
+    recs[*n] = rec.r;
+    uint8_t * row = seq + static_cast<size_t>(*n) * seq_stride;
+    std::memcpy(row, rec.seq.data(), rec.seq.size());
+    std::memset(row + rec.seq.size(), 0, seq_stride - rec.seq.size());
+    ++*n;
+    uint32_t const f = r->front[best].second;
+    Rec next;
+    if (r->files[f]->next(next, r->error))
+      r->front[best].first = std::move(next);
+    else
+      r->front.erase(r->front.begin() + static_cast<long>(best));
+    if (!r->error.empty())
+    {
+      gtx::g_last_error = r->error;
+      return GTX_ERR_IO;
+    }
+  }
+  return GTX_OK;
+}
+
+extern "C" void gtx_reads_close(gtx_reads * r)
+{
+  if (!r)
+    return;
+  for (auto & f : r->files)
+    if (f->fp)
+      gzclose(f->fp);
+  delete r;
+}

@@ -25,6 +25,7 @@ extern "C"
     case GTX_ERR_UNSUPPORTED: return "graph outside the supported envelope";
     case GTX_ERR_CAPACITY: return "caller buffer too small";
     case GTX_ERR_GRAPH: return "malformed graph view";
+    case GTX_ERR_IO: return "file could not be read";
     default: return "unknown status";
     }
   }

@@ -25,7 +25,8 @@ EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy"
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_set_coverage", "gtx_stream_finish", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
            "gtx_graph_destroy",
            "gtx_scores_alloc", "gtx_scores_zero", "gtx_scores_free", "gtx_scores_reduce", "gtx_comm_unique_id", "gtx_comm_init_rank",
-           "gtx_comm_destroy", "gtx_ctx_kernel_times", "gtx_ref_depth_finalize", "gtx_vcf_records", "gtx_scores_replay"]
+           "gtx_comm_destroy", "gtx_ctx_kernel_times", "gtx_ref_depth_finalize", "gtx_vcf_records", "gtx_scores_replay", "gtx_reads_open", "gtx_reads_info",
+           "gtx_reads_sample_name", "gtx_reads_next", "gtx_reads_close"]
 
 
 class GraphView(C.Structure):
@@ -124,6 +125,13 @@ def lib():
         L.gtx_ctx_near_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.gtx_ref_depth_finalize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
         L.gtx_vcf_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.gtx_reads_open.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.gtx_reads_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.gtx_reads_sample_name.argtypes = [C.c_void_p, C.c_uint32]
+        L.gtx_reads_sample_name.restype = C.c_char_p
+        L.gtx_reads_next.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.gtx_reads_close.argtypes = [C.c_void_p]
+        L.gtx_reads_close.restype = None
         L.gtx_scores_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.gtx_stream_create.argtypes = [C.POINTER(Params), C.c_uint32, C.POINTER(C.c_void_p)]
@@ -314,6 +322,39 @@ def pack_nibbles(codes, stride=None):
     out = np.zeros((n, stride), np.uint8)
     out[:, :nb] = (codes[:, 0::2] << 4) | codes[:, 1::2]
     return out
+
+
+class Reads:
+    """gtx_reads: BAM files merged into the record stream gtx_stream_push takes"""
+
+    def __init__(self, paths, region=None):
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        h = C.c_void_p()
+        check(lib().gtx_reads_open(arr, len(paths), region.encode() if region else None, C.byref(h)))
+        self.h = h
+        ns, nrg = C.c_uint32(), C.c_uint32()
+        check(lib().gtx_reads_info(self.h, C.byref(ns), C.byref(nrg)))
+        self.n_read_groups = int(nrg.value)
+        self.samples = [lib().gtx_reads_sample_name(self.h, i).decode() for i in range(ns.value)]
+
+    def next(self, cap, seq_stride=80):
+        """(STREAM_RECORD [n], packed bases [n, seq_stride]); n = 0 at the end"""
+        recs = np.zeros(cap, STREAM_RECORD)
+        seq = np.zeros((cap, seq_stride), np.uint8)
+        n = C.c_uint32()
+        check(lib().gtx_reads_next(self.h, _p(recs), _p(seq), seq_stride, cap, C.byref(n)))
+        return recs[:n.value], seq[:n.value]
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gtx_reads_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class VcfRequest(C.Structure):

@@ -20,6 +20,7 @@
  *   gtx_scores_reduce   replaces  the merge of the per-thread / per-pool results   src/typer/caller.cpp:439-482,
  *                                 (every per-read effect is an integer addition)  src/typer/vcf_operations.cpp:366-374
  *   gtx_vcf_records     replaces  Vcf::add_haplotype + generate_infos + write_record   src/typer/vcf.cpp:767-1151,1507-1611
+ *   gtx_reads_*         replaces  HtsReader / HtsParallelReader for BAM files            src/utilities/hts_reader.cpp:17-303
  *   gtx_graph_build     replaces  Graph::add_genomic_region                     src/graph/graph.cpp:41-339
  *   gtx_graph_from_files replaces construct_graph (small variants, structural variants) src/graph/constructor.cpp:1597-1777
  *
@@ -50,7 +51,8 @@ enum
   GTX_ERR_HIP = 3,         /* a HIP runtime call failed (see gtx_last_error) */
   GTX_ERR_UNSUPPORTED = 4, /* outside the supported envelope (a site with more alleles than MAX_NUMBER_OF_HAPLOTYPES, VCF text of an SV graph, ...) */
   GTX_ERR_CAPACITY = 5,    /* a caller-provided buffer is too small */
-  GTX_ERR_GRAPH = 6        /* malformed graph view */
+  GTX_ERR_GRAPH = 6,       /* malformed graph view */
+  GTX_ERR_IO = 7           /* a file could not be opened or is truncated / malformed */
 };
 
 /* per read x orientation status bits written by gtx_align_batch (word 0, bits 16..31 of a result record) */
@@ -481,6 +483,26 @@ int gtx_stream_set_coverage(gtx_stream *, const double * avg_cov_by_readlen, uin
 int gtx_stream_finish(gtx_stream *, gtx_score_item * items, uint32_t item_cap, uint32_t * n_items);
 /* number of accepted / duplicated records so far and mates still parked */
 int gtx_stream_counts(const gtx_stream *, uint64_t * n_records, uint64_t * n_duplicated, uint64_t * n_parked);
+
+/* ---- BAM ingest in front of gtx_stream_push (host).  Replaces, for BAM files, what the reference
+ * does with htslib before a record reaches genotype_only(): HtsReader::open (src/utilities/hts_reader.cpp:17-124: header,
+ * @RG lines -> read group and sample tables, sample name from the file name when there is none),
+ * HtsReader::get_next_read_in_order (:166-303: the records of one position sorted by length, then packed bases),
+ * HtsParallelReader::open / read_record (src/utilities/hts_parallel_reader.cpp:66-136: k-way merge of the files by
+ * (tid, pos, l_qseq, packed bases), include/graphtyper/utilities/hts_utils.hpp:48-108), get_sample_and_rg_index
+ * (hts_reader.cpp:354-387) and get_score_diff (src/typer/alignment.cpp:140-325).  Records come out as gtx_stream_record +
+ * packed bases, ready for gtx_stream_push; samples and read groups are numbered across the files in the order given.
+ * Needs zlib only (BGZF is a series of gzip members).  Not read: CRAM, the .bai / .csi index -- `region` ("chr",
+ * "chr:begin-end", 1-based inclusive; NULL, "" or "." = everything) is applied by scanning the sorted file for the records
+ * that overlap it, as sam_itr_querys would return them.  Records with equal sort keys keep file order (the reference's
+ * std::sort / heap leave the order of exact duplicates open; results do not depend on it).
+ * gtx_reads_next fills up to cap records (n = 0: end); a read whose packed bases exceed seq_stride is an error. */
+typedef struct gtx_reads gtx_reads;
+int gtx_reads_open(const char * const * bam_paths, uint32_t n_paths, const char * region, gtx_reads ** out);
+int gtx_reads_info(const gtx_reads *, uint32_t * n_samples, uint32_t * n_read_groups);
+const char * gtx_reads_sample_name(const gtx_reads *, uint32_t i);
+int gtx_reads_next(gtx_reads *, gtx_stream_record * recs, uint8_t * seq, uint32_t seq_stride, uint32_t cap, uint32_t * n);
+void gtx_reads_close(gtx_reads *);
 
 #ifdef __cplusplus
 }

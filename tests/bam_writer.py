@@ -1,0 +1,107 @@
+"""Test infrastructure: a minimal BAM writer (BGZF blocks with the BC extra field + EOF block, SAM spec 4.1 / 4.2) and a
+Python restatement of the reference's record order and of get_score_diff, for tests/test_bam_ingest.py.
+  order:      HtsReader::get_next_read_in_order (src/utilities/hts_reader.cpp:166-303: records of one core.pos sorted by
+              gt_pos_seq_same_pos, hts_utils.hpp:83-108, taken from the back) + the heap of HtsParallelReader
+              (hts_parallel_reader.cpp:66-136, gt_pos_seq hts_utils.hpp:48-81); equal keys: file order (unspecified upstream)
+  score diff: get_score_diff (src/typer/alignment.cpp:140-325)"""
+import struct
+import zlib
+
+import numpy as np
+
+
+def bgzf(data, block=60000):
+    out = bytearray()
+    for at in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if at is None else data[at:at + block]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = c.compress(chunk) + c.flush()
+        bsize = len(comp) + 25  # total block size - 1
+        out += struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, bsize)
+        out += comp + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+    return bytes(out)
+
+
+def pack_seq(codes):
+    """4-bit codes [L] -> BAM packed bases"""
+    c = list(int(x) for x in codes) + [0]
+    return bytes((c[2 * i] << 4) | c[2 * i + 1] for i in range((len(codes) + 1) // 2))
+
+
+def aux_field(tag, typ, value):
+    t = tag.encode() + typ.encode()
+    if typ == "Z":
+        return t + value.encode() + b"\0"
+    if typ == "A":
+        return t + value.encode()
+    if typ == "B":  # (subtype, values)
+        sub, vals = value
+        return t + sub.encode() + struct.pack("<I", len(vals)) + b"".join(struct.pack("<" + {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[sub], v) for v in vals)
+    return t + struct.pack("<" + {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[typ], value)
+
+
+def record(name, flag, tid, pos, mapq, cigar, mtid, mpos, tlen, codes, aux=()):
+    """cigar: [(op, len)], op in 'MIDNSHP=X'; aux: [(tag, type, value)]"""
+    nm = name.encode() + b"\0"
+    cig = b"".join(struct.pack("<I", (n << 4) | "MIDNSHP=X".index(op)) for op, n in cigar)
+    body = struct.pack("<iiBBHHHIiii", tid, pos, len(nm), mapq, 4680, len(cigar), flag, len(codes), mtid, mpos, tlen)
+    body += nm + cig + pack_seq(codes) + bytes([30] * len(codes)) + b"".join(aux_field(*a) for a in aux)
+    return struct.pack("<i", len(body)) + body
+
+
+def write_bam(path, refs, header_text, records):
+    """refs: [(name, length)]; records: bytes from record(), already in file order"""
+    data = b"BAM\1" + struct.pack("<i", len(header_text)) + header_text.encode() + struct.pack("<i", len(refs))
+    for name, length in refs:
+        data += struct.pack("<i", len(name) + 1) + name.encode() + b"\0" + struct.pack("<i", length)
+    data += b"".join(records)
+    open(path, "wb").write(bgzf(data))
+
+
+def score_diff(aux):
+    """get_score_diff over [(tag, type, value)] in file order"""
+    a = x = -1
+    for tag, typ, value in aux:
+        if typ in "AZ" or typ == "f":
+            continue
+        if typ not in "cCsSiI":
+            break  # a type the parser does not know (B, H, d): it stops
+        if tag == "AS":
+            a = value
+        elif tag == "XS":
+            x = value
+    if a == -1 or a < x:
+        return 0
+    diff = a - (0 if x == -1 else x)
+    return diff if diff < 255 else 255
+
+
+def merged_order(files):
+    """files: per file a list of dicts (tid, pos, codes) in file order -> [(file, index)] in the order the reference reads them"""
+    def seq_key(r):
+        return (len(r["codes"]), pack_seq(r["codes"]))
+    per_file = []
+    for f, recs in enumerate(files):
+        out, i = [], 0
+        while i < len(recs):
+            j = i
+            while j < len(recs) and recs[j]["pos"] == recs[i]["pos"]:
+                j += 1
+            out += sorted(range(i, j), key=lambda k: seq_key(recs[k]))  # stable
+            i = j
+        per_file.append(out)
+    heads = [0] * len(files)
+    order = []
+    while True:
+        best = None
+        for f in range(len(files)):
+            if heads[f] < len(per_file[f]):
+                r = files[f][per_file[f][heads[f]]]
+                key = (r["tid"], r["pos"]) + seq_key(r)
+                if best is None or key < best[0]:
+                    best = (key, f)
+        if best is None:
+            return order
+        f = best[1]
+        order.append((f, per_file[f][heads[f]]))
+        heads[f] += 1

@@ -289,3 +289,9 @@ def test_saturation_guard_is_replayed_on_the_device():
     the oracle's sequential explain_to_score (haplotype.cpp:560)"""
     from test_saturation import saturation_case
     saturation_case(harness.GpuBackend)
+
+
+def test_bam_files_to_vcf_text_on_the_device(tmp_path):
+    """BAM files -> gtx_reads -> gtx_stream -> gtx_align_batch -> gtx_score_batch -> gtx_calls_batch -> gtx_vcf_records == oracle"""
+    from test_bam_ingest import bam_to_calls_case
+    bam_to_calls_case(harness.GpuBackend, tmp_path)
