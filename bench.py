@@ -384,7 +384,10 @@ def extra_cfg3(args, torch, gtx, synth, device, ref):
     n = args.extra_reads
     recs = synth.make_cluster_records(ref, 150, seed=8, region_begin=REGION_BEGIN)
     t0 = time.time()
-    ctx = gtx.Context(gtx.graph_from_records(synth.bases_to_str(ref), recs, region_begin=REGION_BEGIN, add_all_variants=True), device=0)
+    graph = gtx.graph_from_records(synth.bases_to_str(ref), recs, region_begin=REGION_BEGIN, add_all_variants=True)
+    t_graph = time.time() - t0
+    t0 = time.time()
+    ctx = gtx.Context(graph, device=0)
     t_ctx = time.time() - t0
     codes, pos = synth.make_reads(ref, recs, n, read_len=READ_LEN, seed=5, region_begin=REGION_BEGIN)
     order = np.argsort(pos, kind="stable")
@@ -399,6 +402,7 @@ def extra_cfg3(args, torch, gtx, synth, device, ref):
     out = {"workload": "cfg3-like: 30 samples, %d reads, 1 Mb, clusters (SNP, SNP, indel) every 150 bp merged into multi-allelic "
                        "sites (add_all_variants), max %d alleles per site" % (n, int(ctx.hap_cnum.max())),
            "reads_per_s": n * 3 / dt, "ms_per_step": 1000.0 * dt / 3, "sites": int(ctx.n_hap), "ctx_create_s": round(t_ctx, 3),
+           "graph_build_s": round(t_graph, 3),
            "align_passes_ms": {"express": ms[0], "general": ms[1], "hbm_tables": ms[2]},
            "pass_shares": {"tasks": n, "handed_to_general": handed, "share_general": handed / float(n)}}
     out.update(facts)

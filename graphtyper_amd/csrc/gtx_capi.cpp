@@ -1,6 +1,8 @@
 // gtx_capi.cpp -- host half of the C ABI (include/gtx.h): context life cycle, inspection, finalisation and the
 // per-record stream logic.  No compute on reads happens here.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <map>
@@ -62,13 +64,26 @@ extern "C"
     {
       // the host enumerates the 32-mers (index_graph's sweep) and derives the graph's own hint arrays; everything
       // else -- grouping, hash tables, hint tables -- is built on the device (gtx_index_dev.hip)
+      bool const timing = std::getenv("GTX_TIMING") != nullptr; // stage times on stderr
+      auto t_last = std::chrono::steady_clock::now();
+      auto lap = [&](char const * what)
+      {
+        auto const now = std::chrono::steady_clock::now();
+        if (timing)
+          std::fprintf(stderr, "[gtx] ctx_create %-24s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+      };
       std::vector<Emit> em;
       enumerate_kmers(c->graph, em);
+      lap("enumerate k-mers (host)");
       HintGraphTables gt;
       hint_graph_tables(c->graph, gt);
+      lap("graph hint arrays (host)");
       int rc = ctx_upload(*c, device);
+      lap("graph upload + scratch");
       if (rc == GTX_OK)
         rc = build_index_device(*c, em, gt);
+      lap("index build (device)");
       if (rc != GTX_OK)
       {
         ctx_release_device(*c);

@@ -1,0 +1,6 @@
+for t in 8 16 32 64; do
+  GTX_HOST_THREADS=$t python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+j = json.loads(sys.stdin.readline())
+print('threads $t: cfg2 ctx %.3f s (first %.3f), cfg3 ctx %.3f s' % (j['config']['ctx_create_s'], j['config']['ctx_create_first_s'], j['config']['extra']['cfg3']['ctx_create_s']))"
+done
