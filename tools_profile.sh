@@ -19,5 +19,5 @@ find $OUT -name '*.csv' | head -50
 for f in $OUT/*.log; do grep -m1 "^{" $f | cut -c1-400; done
 python tools_profile_summary.py $OUT $READS
 # only then drop what is too large to bring back
-find $OUT -type f ! -name '*.csv' ! -name '*.log' -delete
+find $OUT -type f ! -name '*.csv' ! -name '*.log' ! -name '*.json' -delete
 find $OUT -name '*.csv' -size +4M -delete
