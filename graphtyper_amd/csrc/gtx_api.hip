@@ -445,7 +445,8 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
       dst[k] = k < seq_stride ? src[k] : static_cast<uint8_t>(0);
   }
   WaveHip::lds_sync();
-  bool fwd = false, rev = false;
+  bool fwd = false, rev = false, staged_rec = false;
+  static_assert(HINT_STAGE_WORDS == 16 && HINT_STAGE_WORDS * 4 <= HINT_MAX_READ / 2, "a staged record is four 16-byte parts inside the read's row");
   if (read < n_reads)
   {
     gtx_read_meta m;
@@ -465,8 +466,14 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
     rev = !outside && needs_reverse(m, force_both != 0);
     if (!rev)
     {
-      rec[rec_words] = len > AlignCfg::MAX_READ ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
-      rec[rec_words + 1] = len << 16;
+      uint32_t const h0 = len > AlignCfg::MAX_READ ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
+      if ((rec_words & 1u) == 0 && (reinterpret_cast<uintptr_t>(records) & 7u) == 0)
+        *reinterpret_cast<uint2_t *>(rec + rec_words) = uint2_t{h0, len << 16}; // (one store instruction, not two)
+      else
+      {
+        rec[rec_words] = h0;
+        rec[rec_words + 1] = len << 16;
+      }
     }
     if (outside)
     {
@@ -477,8 +484,33 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
       fwd = true;
     else
     {
-      uint32_t const * row = reinterpret_cast<uint32_t const *>(&s_seq[wave][lane * ROW_VEC]);
-      fwd = !hinted_one(g, ix, row, reinterpret_cast<uint8_t const *>(row), ROW_BYTES, m, rec, rec_words);
+      // The record goes to the lane's own row in LDS first (the bases are not needed any more once hinted_one writes) and
+      // from there to memory four lanes per record: a wavefront's 64 record slots are 64 different cache lines, and what
+      // the store path charges is line visits per instruction -- 16 per instruction this way instead of 64.
+      uint32_t * row = reinterpret_cast<uint32_t *>(&s_seq[wave][lane * ROW_VEC]);
+      uint32_t const where = hinted_one(g, ix, row, reinterpret_cast<uint8_t const *>(row), ROW_BYTES, m, rec, rec_words, row);
+      fwd = where == 0;
+      staged_rec = where == 2;
+    }
+  }
+  {
+    unsigned long long const S = __ballot(staged_rec);
+    if (S != 0)
+    {
+      // records of HINT_STAGE_WORDS words: lanes 4r .. 4r+3 of a round carry record 16 * round + r, 16 bytes each
+      uint32_t const part = lane & 3u;
+#pragma unroll
+      for (uint32_t round = 0; round < 4; ++round)
+      {
+        uint32_t const r = round * 16u + (lane >> 2);
+        if ((S >> r) & 1ull)
+        {
+          uint4_t const v = s_seq[wave][r * ROW_VEC + part];
+          uint32_t const rd = wave_first + r;
+          uint32_t * dst = records + static_cast<uint64_t>((decline_all & 2u) ? (rd & 1023u) : rd) * 2 * rec_words;
+          *reinterpret_cast<uint4_t *>(dst + 4 * part) = v;
+        }
+      }
     }
   }
   // Queue appends: ONE atomic per workgroup and queue (a device counter takes ~100 M returning atomics a second; one per

@@ -111,8 +111,9 @@ struct IndexView
   // ---- position-hinted pass (hinted.hpp).  A read of a sorted BAM comes with the place the mapper put it; the tables
   // below are ordered by reference position, so neighbouring reads share their cache lines, and they carry the PROOF
   // that the global lookups of the reference would return exactly the one label of that place.
-  // ref4: the linear reference of the region (= the graph's path over every site's allele 0) as BAM nibble codes,
-  //   8 bases per word, base 8w+j in bits 28-4j; entry 0 is contig position hint_first (0-based); 24 padding words.
+  // refp: the linear reference of the region (= the graph's path over every site's allele 0) as four bit planes of its BAM
+  //   nibble codes: 4 words (planes 0..3) per 32 positions, position hint_first + 32q + j at bit j of words 4q .. 4q+3;
+  //   6 padding groups of zeros.
   // pos_flags[i] (two words), about the 32-mer that starts at hint_first + i (K_i) and about the position itself:
   //  x  HINT_SINGLE_OK  K_i is indexed with exactly the label (i, i+31[, site, allele 0]) (and it may be used: not on a
   //                     variant of an SV graph);
@@ -133,7 +134,7 @@ struct IndexView
   //   (a SNP: 2..4 alleles of one base A/C/G/T each; not in an SV graph):  x = HINT_TAIL_OK | alleles << 2 (count, 3 bits) |
   //   min(255, length of the reference node behind the site) << 8 | the alleles' nibble codes << 16 (4 bits each);
   //   y = the site's index.
-  const uint32_t * ref4;
+  const uint32_t * refp;
   const uint2_t * pos_flags;
   const uint2_t * tail_info;
   const uint32_t * filt[2];
@@ -202,8 +203,8 @@ struct HostIndex
   std::vector<IndexSlot> hslots;
   std::vector<HalfEntry> hlist;
   uint32_t h_log2_cap = 0;
-  // position-hinted pass (IndexView::ref4 ...)
-  std::vector<uint32_t> ref4, filt[2];
+  // position-hinted pass (IndexView::refp ...)
+  std::vector<uint32_t> refp, filt[2];
   std::vector<uint2_t> pos_flags, tail_info;
   uint32_t hint_first = 0, n_hint = 0, filt_log2 = 0;
 
@@ -221,11 +222,11 @@ struct Emit
 };
 
 // what the position-hinted pass needs of the GRAPH alone (no index): the linear reference as nibbles, per position the
-// bases to the end / from the start of its reference node, the packed ref4 words and the tail_info table
+// bases to the end / from the start of its reference node, the reference bit planes and the tail_info table
 struct HintGraphTables
 {
   std::vector<uint8_t> base, room, back;
-  std::vector<uint32_t> ref4;
+  std::vector<uint32_t> refp;
   std::vector<uint2_t> tail_info;
   uint32_t hint_first = 0, n = 0; // n = 0: the graph has too many sites for the tables (no position-hinted pass)
 };

@@ -522,7 +522,7 @@ IndexView HostIndex::view(uint32_t max_index_labels, uint32_t half_bucket_cap) c
   ix.hlist = hlist.data();
   ix.h_log2_cap = h_log2_cap;
   ix.half_bucket_cap = half_bucket_cap;
-  ix.ref4 = ref4.data();
+  ix.refp = refp.data();
   ix.pos_flags = pos_flags.data();
   ix.tail_info = tail_info.data();
   ix.filt[0] = filt[0].data();
@@ -533,7 +533,7 @@ IndexView HostIndex::view(uint32_t max_index_labels, uint32_t half_bucket_cap) c
   return ix;
 }
 
-// Tables of the position-hinted pass (IndexView::ref4 ..., hinted.hpp).  For every reference position: what a read
+// Tables of the position-hinted pass (IndexView::refp ..., hinted.hpp).  For every reference position: what a read
 // k-mer that equals -- or is one substitution / one ambiguous base away from -- the reference 32-mer of that place
 // would get from the global lookups, decided here once from the finished index.
 void hint_graph_tables(HostGraph const & g, HintGraphTables & t)
@@ -589,12 +589,13 @@ void hint_graph_tables(HostGraph const & g, HintGraphTables & t)
     for (uint32_t d = 0; d < g.ref_len[r]; ++d)
       t.tail_info[at + d] = ti;
   }
-  t.ref4.assign(n / 8 + 24, 0); // (padded: the kernel loads 21 words from any position without a bounds test)
+  t.refp.assign(4 * (static_cast<std::size_t>(n) / 32 + 8), 0); // (padded: the kernel loads 6 groups from any position without a bounds test)
   for (uint32_t i = 0; i < n; ++i)
-    t.ref4[i >> 3] |= static_cast<uint32_t>(t.base[i]) << (28 - 4 * (i & 7u));
+    for (uint32_t b = 0; b < 4; ++b)
+      t.refp[4 * (i >> 5) + b] |= ((static_cast<uint32_t>(t.base[i]) >> b) & 1u) << (i & 31u);
 }
 
-// Tables of the position-hinted pass (IndexView::ref4 ..., hinted.hpp).  For every reference position: what a read
+// Tables of the position-hinted pass (IndexView::refp ..., hinted.hpp).  For every reference position: what a read
 // k-mer that equals -- or is one substitution / one ambiguous base away from -- the reference 32-mer of that place
 // would get from the global lookups, decided here once from the finished index.
 static void build_hints(HostGraph const & g, HostIndex & out)
@@ -606,7 +607,7 @@ static void build_hints(HostGraph const & g, HostIndex & out)
   out.filt_log2 = 0;
   if (gt.n == 0)
   {
-    out.ref4.assign(32, 0);
+    out.refp.assign(32, 0);
     out.pos_flags.assign(1, uint2_t{0, 0});
     out.tail_info.assign(1, uint2_t{0, 0});
     out.filt[0].assign(1, 0);
@@ -617,7 +618,7 @@ static void build_hints(HostGraph const & g, HostIndex & out)
   std::vector<uint8_t> const & base = gt.base;
   std::vector<uint8_t> const & room = gt.room;
   std::vector<uint8_t> const & back = gt.back;
-  out.ref4 = std::move(gt.ref4);
+  out.refp = std::move(gt.refp);
   out.tail_info = std::move(gt.tail_info);
   // per key: the keys that share its first / last 16 bases (groups), then the neighbour verdict (index_build.hpp)
   std::size_t const nk = out.keys.size();

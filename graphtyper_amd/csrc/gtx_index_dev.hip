@@ -478,11 +478,11 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, HintGraphTable
   bool const hints = gt.n != 0;
   uint32_t *d_f0 = pool.get<uint32_t>(hints ? (1ull << fl) : 1, "filter 0", true), *d_f1 = pool.get<uint32_t>(hints ? (1ull << fl) : 1, "filter 1", true);
   uint2_t * d_flags = pool.get<uint2_t>(hints ? gt.n : 1, "position flags", true);
-  uint32_t * d_ref4 = nullptr;
+  uint32_t * d_refp = nullptr;
   uint2_t * d_tail = nullptr;
   std::vector<uint32_t> const one_word(32, 0);
   std::vector<uint2_t> const one_pair(1, uint2_t{0, 0});
-  if (!to_device(pool, d_ref4, hints ? gt.ref4 : one_word, "reference nibbles") || !to_device(pool, d_tail, hints ? gt.tail_info : one_pair, "tail sites"))
+  if (!to_device(pool, d_refp, hints ? gt.refp : one_word, "reference planes") || !to_device(pool, d_tail, hints ? gt.tail_info : one_pair, "tail sites"))
     return GTX_ERR_HIP;
   if (hints)
   {
@@ -508,7 +508,7 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, HintGraphTable
   ix.hslots = pool.keep(d_hslots, c.dev_allocs);
   ix.hlist = pool.keep(d_hlist, c.dev_allocs);
   ix.h_log2_cap = hl;
-  ix.ref4 = pool.keep(d_ref4, c.dev_allocs);
+  ix.refp = pool.keep(d_refp, c.dev_allocs);
   ix.pos_flags = pool.keep(d_flags, c.dev_allocs);
   ix.tail_info = pool.keep(d_tail, c.dev_allocs);
   ix.filt[0] = pool.keep(d_f0, c.dev_allocs);

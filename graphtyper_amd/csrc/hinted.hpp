@@ -215,11 +215,11 @@ GTX_DEV void hint_compare_words(uint32_t const (&rr)[HINT_WORDS], uint32_t const
   }
 }
 
-// No branches around the loads: the reference array is padded by HINT_WORDS + 4 words and a row has at least seq_stride
-// bytes, so every lane may load every word and all loads are in flight together; what lies beyond the read is masked
-// inside hint_word.
+// The compare on nibble words (8 bases per word, read and reference alike): the first form of this pass, ~1 300 vector
+// instructions per read.  Kept as the definition the plane form below is tested against (tests/test_hint_compare.py).
+// refw: reference nibble words from the word that holds the read's first base (base 8w+j in bits 28-4j), sh = 4 * (phase).
 template <class Row>
-GTX_DEV void hint_compare(Row row, uint32_t seq_stride, uint32_t const * refw, uint32_t sh, uint32_t L, HintCounts & h)
+GTX_DEV void hint_compare_nibbles(Row row, uint32_t seq_stride, uint32_t const * refw, uint32_t sh, uint32_t L, HintCounts & h)
 {
   uint32_t rr[HINT_WORDS], gg[HINT_WORDS + 1];
 #pragma unroll
@@ -232,6 +232,109 @@ GTX_DEV void hint_compare(Row row, uint32_t seq_stride, uint32_t const * refw, u
     rr[w] = row[in_row ? w : 0u] & (in_row ? 0xFFFFFFFFu : 0u);
   }
   hint_compare_words<0>(rr, gg, sh, L, h);
+}
+
+// ---- the compare on bit planes.  Per-nibble questions (differs? one base or a set? N?) cost a handful of shifts and
+// masks per 8 bases on nibble words; on four 1-bit planes (bit b of every base's code) the same questions are plain
+// bitwise operations over 32 bases at once.  The reference is stored as planes when the index is built (IndexView::refp);
+// the read's nibbles are transposed here: the four bits `b` of the nibbles of a 16-bit half are gathered into one nibble
+// by ONE 24-bit multiply (the partial products of the four source bits land on distinct bits, so nothing carries), two
+// halves make a byte (8 bases), four words a plane word (32 bases).
+constexpr uint32_t HINT_PLANE_WORDS = HINT_MAX_READ / 32;
+static_assert(HINT_MAX_READ % 32 == 0 && HINT_PLANE_WORDS == AlignCfg::KC, "five k-mers, five plane words");
+
+// bit B of the 8 bases of row word w (a little-endian load of 4 BAM bytes: byte i holds base 2i in its high and base 2i+1
+// in its low nibble) as a byte, base j at bit j.  hi = w >> 16.
+template <uint32_t B>
+GTX_DEV uint32_t nib_plane_byte(uint32_t w, uint32_t hi)
+{
+  // source bits of a half, by base: base 1 at bit B, base 0 at 4+B, base 3 at 8+B, base 2 at 12+B; they go to 12+B .. 15+B
+  constexpr uint32_t M = (1u << 13) | (1u << 8) | (1u << 7) | (1u << 2);
+  uint32_t const pl = (w & (0x1111u << B)) * M, ph = (hi & (0x1111u << B)) * M;
+  return ((pl >> (12 + B)) & 0xFu) | ((ph >> (8 + B)) & 0xF0u);
+}
+
+GTX_DEV uint32_t hint_funnel(uint32_t lo, uint32_t hi, uint32_t s) // bits [s, s + 32) of hi:lo, s in 0..31
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(hi, lo, s);
+#else
+  return s == 0 ? lo : (lo >> s) | (hi << (32 - s));
+#endif
+}
+
+// refp: the reference planes from the group of 32 positions that holds the read's first base (4 words per group: planes
+// 0..3, position 32q+j at bit j), s = that base's bit in its group.  Same counters as hint_compare_nibbles.
+template <class Row>
+GTX_DEV void hint_compare(Row row, uint32_t seq_stride, uint32_t const * refp, uint32_t s, uint32_t L, HintCounts & h)
+{
+  uint32_t mk[HINT_PLANE_WORDS], am[HINT_PLANE_WORDS], ao[HINT_PLANE_WORDS], mt[HINT_PLANE_WORDS + 1];
+  // all loads first (no branches around them: the plane array is padded, a row has at least seq_stride bytes)
+  uint32_t gg[4 * (HINT_PLANE_WORDS + 1)], rr[HINT_WORDS];
+#pragma unroll
+  for (uint32_t w = 0; w < 4 * (HINT_PLANE_WORDS + 1); ++w)
+    gg[w] = refp[w];
+#pragma unroll
+  for (uint32_t w = 0; w < HINT_WORDS; ++w)
+  {
+    bool const in_row = 4 * w < seq_stride; // (uniform; a select, not a branch around the load)
+    rr[w] = row[in_row ? w : 0u] & (in_row ? 0xFFFFFFFFu : 0u);
+  }
+#pragma unroll
+  for (uint32_t W = 0; W < HINT_PLANE_WORDS; ++W)
+  {
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+    {
+      uint32_t const w = rr[4 * W + k], hi = w >> 16;
+      r0 |= nib_plane_byte<0>(w, hi) << (8 * k);
+      r1 |= nib_plane_byte<1>(w, hi) << (8 * k);
+      r2 |= nib_plane_byte<2>(w, hi) << (8 * k);
+      r3 |= nib_plane_byte<3>(w, hi) << (8 * k);
+    }
+    uint32_t const g0 = hint_funnel(gg[4 * W + 0], gg[4 * W + 4], s), g1 = hint_funnel(gg[4 * W + 1], gg[4 * W + 5], s);
+    uint32_t const g2 = hint_funnel(gg[4 * W + 2], gg[4 * W + 6], s), g3 = hint_funnel(gg[4 * W + 3], gg[4 * W + 7], s);
+    uint32_t const v = L >= 32 * W + 32 ? 0xFFFFFFFFu : L <= 32 * W ? 0u : (1u << (L - 32 * W)) - 1u; // bases of the read
+    uint32_t const differ = ((r0 ^ g0) | (r1 ^ g1) | (r2 ^ g2) | (r3 ^ g3)) & v;
+    uint32_t const odd = r0 ^ r1 ^ r2 ^ r3, three = (r0 & r1 & (r2 | r3)) | (r2 & r3 & (r0 | r1));
+    uint32_t const amb = ~(odd & ~three) & v;                              // not exactly one base: '=' (0), N, every other IUPAC set
+    uint32_t const r_any = ((r0 & r1 & r2 & r3) | ~(r0 | r1 | r2 | r3)) & v; // N or '=' (which the reference reads as N)
+    uint32_t const shares = (r0 & g0) | (r1 & g1) | (r2 & g2) | (r3 & g3);   // the read's set holds the reference base
+    mk[W] = differ & ~amb;
+    am[W] = amb;
+    ao[W] = amb & ~(shares | r_any);
+    mt[W] = differ & ~r_any & ~(g0 & g1 & g2 & g3); // count_mismatches (graph_utils.hpp:7-69)
+    GTX_PIN(mk[W]);
+    GTX_PIN(am[W]);
+    GTX_PIN(ao[W]);
+    GTX_PIN(mt[W]);
+  }
+  mt[HINT_PLANE_WORDS] = 0;
+  // ---- counters.  k-mer I is bases [31 I, 31 I + 32): a 32-bit window of the flag words (I = 0: word 0)
+  uint32_t prefix = 0; // mismatches in the plane words in front of the current one
+#pragma unroll
+  for (uint32_t I = 0; I < AlignCfg::KC; ++I)
+  {
+    uint32_t const W0 = ((K - 1) * I) / 32, o = ((K - 1) * I) % 32;
+    uint32_t const nxt = W0 + 1 < HINT_PLANE_WORDS ? W0 + 1 : W0; // (o = 0 only for I = 0: the next word is not looked at)
+    uint32_t const wm = o == 0 ? mk[W0] : (mk[W0] >> o) | (mk[nxt] << (32 - o));
+    uint32_t const wa = o == 0 ? am[W0] : (am[W0] >> o) | (am[nxt] << (32 - o));
+    uint32_t const wo = o == 0 ? ao[W0] : (ao[W0] >> o) | (ao[nxt] << (32 - o));
+    h.k[I] = static_cast<uint32_t>(__builtin_popcount(wm)) | (static_cast<uint32_t>(__builtin_popcount(wm & 0xFFFFu)) << HC_MIS_LEFT) |
+             (static_cast<uint32_t>(__builtin_popcount(wa)) << HC_AMB) | (static_cast<uint32_t>(__builtin_popcount(wa & 0xFFFFu)) << HC_AMB_LEFT) |
+             (static_cast<uint32_t>(__builtin_popcount(wo)) << HC_AMB_OUT);
+    // mismatches by the walks' rule in [0, 31 (I + 1)): the words in front of word I + the low 31 - I bits of word I
+    uint32_t const upto = prefix + static_cast<uint32_t>(__builtin_popcount(mt[I] & (0x7FFFFFFFu >> I)));
+    if (I < 4)
+      h.upto |= upto << (8 * I);
+    else
+      h.more |= upto;
+    prefix += static_cast<uint32_t>(__builtin_popcount(mt[I]));
+    if (I > 0) // the boundary base 31 I
+      h.more |= ((mt[W0] >> o) & 1u) << (15 + I);
+  }
+  h.more |= prefix << 8; // the whole read
 }
 
 enum : uint32_t
@@ -365,9 +468,14 @@ GTX_DEV uint32_t hint_probe_verdict(uint32_t verdict, uint32_t left_word, uint32
 
 // The forward task of one read.  Returns true when the record was written, false = declined (nothing written).
 // `row`: the read's packed bases as words (global memory, or the copy the kernel staged in LDS); seq4 = the same bytes.
+// `stage` (may be NULL): room for HINT_STAGE_WORDS words; a record that fits is written there instead (zeros behind its
+// end) and the caller moves it to its slot -- the kernel does that four lanes per record.  Returns 0 = declined, 1 = the
+// record is in `rec`, 2 = it is in `stage`.
+constexpr uint32_t HINT_STAGE_WORDS = 16; // a record of up to three variant sites (6 + 3 * 3 words)
+
 template <class Row>
-GTX_DEV bool hinted_one(GraphView const & g, IndexView const & ix, Row row, uint8_t const * seq4, uint32_t seq_stride, gtx_read_meta const & m,
-                        uint32_t * rec, uint32_t rec_words)
+GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, uint8_t const * seq4, uint32_t seq_stride, gtx_read_meta const & m,
+                            uint32_t * rec, uint32_t rec_words, uint32_t * stage = nullptr)
 {
   uint32_t const L = m.l_qseq;
   if (L < 2 * K - 1 || L > HINT_MAX_READ || m.pos < 0 || ix.n_hint == 0)
@@ -384,8 +492,8 @@ GTX_DEV bool hinted_one(GraphView const & g, IndexView const & ix, Row row, uint
   uint32_t const n_k = 1 + (L - K) / (K - 1);
   // ---- the read and the reference under it, 8 bases per word, aligned to the read
   HintCounts h{};
-  uint32_t const * refw = ix.ref4 + (idx >> 3);
-  uint32_t const sh = 4 * (idx & 7u);
+  uint32_t const * refw = ix.refp + 4 * (idx >> 5);
+  uint32_t const sh = idx & 31u;
   // ---- the flags of the k-mers' places (their second words also describe the positions the walks start from); all
   //      issued together with the reference words: one round trip
   uint2_t const f0 = ix.pos_flags[idx], f1 = ix.pos_flags[idx + (K - 1)];
@@ -592,6 +700,14 @@ GTX_DEV bool hinted_one(GraphView const & g, IndexView const & ix, Row row, uint
     np = 0;
     longest = 0;
   }
+  bool const to_stage = stage != nullptr && rec_words >= HINT_STAGE_WORDS && 6 + 3 * nvar <= HINT_STAGE_WORDS;
+  if (to_stage)
+  {
+    rec = stage;
+#pragma unroll
+    for (uint32_t k = 2; k < HINT_STAGE_WORDS; ++k)
+      rec[k] = 0u;
+  }
   rec[0] = np;
   rec[1] = longest | (L << 16) | ((np && nvar) ? GTX_REC_HAS_VARIANTS : 0u);
   if (np)
@@ -616,7 +732,7 @@ GTX_DEV bool hinted_one(GraphView const & g, IndexView const & ix, Row row, uint
     put(4, v4);
     put(5, v5);
   }
-  return true;
+  return to_stage ? 2u : 1u;
 }
 
 } // namespace gtx

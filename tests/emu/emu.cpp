@@ -423,6 +423,35 @@ extern "C"
     return static_cast<int>(errors);
   }
 
+  // The compare of the position-hinted pass in its two forms (hinted.hpp): nibble words (the definition) and bit planes
+  // (what the kernel runs).  base: reference nibble codes [n_base], idx: position of the read's first base, row: the read's
+  // packed bases (>= 80 bytes), L bases.  out: k[0..4], upto, more of the nibble form, then of the plane form.
+  void emu_hint_compare(const uint8_t * base, uint32_t n_base, uint32_t idx, const uint8_t * row, uint32_t L, uint32_t * out)
+  {
+    using namespace gtx;
+    std::vector<uint32_t> ref4(n_base / 8 + 32, 0), refp(4 * (n_base / 32 + 8), 0);
+    for (uint32_t i = 0; i < n_base; ++i)
+    {
+      ref4[i >> 3] |= static_cast<uint32_t>(base[i]) << (28 - 4 * (i & 7u));
+      for (uint32_t b = 0; b < 4; ++b)
+        refp[4 * (i >> 5) + b] |= ((static_cast<uint32_t>(base[i]) >> b) & 1u) << (i & 31u);
+    }
+    uint32_t words[20];
+    std::memcpy(words, row, 80);
+    HintCounts a{}, b{};
+    hint_compare_nibbles(words, 80u, ref4.data() + (idx >> 3), 4 * (idx & 7u), L, a);
+    hint_compare(words, 80u, refp.data() + 4 * (idx >> 5), idx & 31u, L, b);
+    for (int i = 0; i < 5; ++i)
+    {
+      out[i] = a.k[i];
+      out[7 + i] = b.k[i];
+    }
+    out[5] = a.upto;
+    out[6] = a.more;
+    out[12] = b.upto;
+    out[13] = b.more;
+  }
+
   // gtx_scores_replay over host arrays: marks the cells at the guard, logs their explain_to_score calls with the kernel
   // source in replay mode, replays them with the library's host code (score_replay.hpp).  Returns the cells replayed.
   long emu_score_replay(void * p, const gtx_score_item * items, uint32_t n_items, const uint32_t * records, uint32_t rec_words,
