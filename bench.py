@@ -33,7 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALGO_BYTES_PER_READ = 3296  # B(L) = 86 + 796*n_k + (L - 31*n_k) at L=150, n_k=4
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
-REC_WORDS = int(os.environ.get("GTX_BENCH_REC_WORDS", "64"))  # uint32 words of a record slot (gtx_align_batch: rec_words)
+REC_WORDS = int(os.environ.get("GTX_BENCH_REC_WORDS", "64"))  # uint32 words of a record slot (rec_words of gtx_align_batch; A/B switch)
 REGION_BEGIN = 1000000      # chr20:1000001-2000000
 REGION_LEN = 1000000
 READ_LEN = 150
