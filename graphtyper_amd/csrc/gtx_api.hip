@@ -488,7 +488,8 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
       // from there to memory four lanes per record: a wavefront's 64 record slots are 64 different cache lines, and what
       // the store path charges is line visits per instruction -- 16 per instruction this way instead of 64.
       uint32_t * row = reinterpret_cast<uint32_t *>(&s_seq[wave][lane * ROW_VEC]);
-      uint32_t const where = hinted_one(g, ix, row, reinterpret_cast<uint8_t const *>(row), ROW_BYTES, m, rec, rec_words, row);
+      bool const can_stage = (rec_words & 3u) == 0 && (reinterpret_cast<uintptr_t>(records) & 15u) == 0; // (16-byte stores into the slots)
+      uint32_t const where = hinted_one(g, ix, row, reinterpret_cast<uint8_t const *>(row), ROW_BYTES, m, rec, rec_words, can_stage ? row : nullptr);
       fwd = where == 0;
       staged_rec = where == 2;
     }

@@ -150,3 +150,22 @@ def test_three_ambiguous_bases_stay_in_the_lds_pass():
 
 def test_align_reference_with_n_runs():
     n_runs_case(harness.GpuBackend, 20000)
+
+
+@pytest.mark.parametrize("rec_words", [16, 18, 24, 100])
+def test_record_slot_sizes(rec_words):
+    """rec_words is the caller's choice (gtx_align_batch): slots of 16, 24 and 100 words take the staged 16-byte stores of the
+    position-hinted pass, 18 words (slots that are not 16-byte aligned) the word-wise ones; a record that does not fit its
+    slot goes to the arena.  The parsed paths must be those of 64-word slots."""
+    ref, recs, codes, pos = scenarios.synthetic_case("snp100", n_ref=30000, n_reads=3000, region_begin=1000)
+    b = harness.GpuBackend(gtx.graph_from_records(ref, recs, region_begin=1000))
+    seq, lens = harness.pack_ragged(list(codes))
+    meta = harness.read_meta(lens, pos=pos)
+    want = gtx.parse_records(b.align(seq, meta), len(codes), harness.REC_WORDS, b.ctx.hap_order, b.big_records()[0])
+    done64 = b.hinted_done()
+    b.rewind_big_records()
+    rec = b.align(seq, meta, rec_words=rec_words)
+    assert not ((rec.reshape(-1, rec_words)[:, 0] >> 16) & gtx.ST_ERROR_MASK).any()
+    got = gtx.parse_records(rec, len(codes), rec_words, b.ctx.hap_order, b.big_records()[0])
+    assert got == want
+    assert b.hinted_done() > len(codes) // 2 and (rec_words < 24 or b.hinted_done() == done64)
