@@ -33,6 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALGO_BYTES_PER_READ = 3296  # B(L) = 86 + 796*n_k + (L - 31*n_k) at L=150, n_k=4
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+USE_TASK_FLAGS = os.environ.get("GTX_BENCH_FLAGS", "1") != "0"  # the dense side array of the records (A/B switch)
 REC_WORDS = int(os.environ.get("GTX_BENCH_REC_WORDS", "64"))  # uint32 words of a record slot (rec_words of gtx_align_batch; A/B switch)
 REGION_BEGIN = 1000000      # chr20:1000001-2000000
 REGION_LEN = 1000000
@@ -223,6 +224,8 @@ class Workload:
             items["sample"] = samples
         self.d_items = torch.from_numpy(items.view(np.uint8).reshape(n, gtx.SCORE_ITEM.itemsize).copy()).to(device)
         self.d_rec = torch.empty(n * 2 * REC_WORDS, dtype=torch.int32, device=device)
+        # dense side array of the records (one byte per task): gtx_align_batch_flags / gtx_score_batch_flags
+        self.d_flags = torch.zeros(n * 2, dtype=torch.uint8, device=device) if USE_TASK_FLAGS else None
         self.buf = gtx.ScoreBuffers()
         reduced = C.c_uint64()
         gtx.check(self.L.gtx_scores_alloc(ctx.h, n_samples, conn_cap, C.byref(self.buf), C.byref(reduced)))
@@ -281,10 +284,11 @@ class Workload:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(self.stream)
-            gtx.check(L.gtx_align_batch(ctx.h, self.d_seq.data_ptr(), self.stride, self.d_meta.data_ptr(), self.n, self.d_rec.data_ptr(),
-                                        REC_WORDS, sp))
+            fl = self.d_flags.data_ptr() if self.d_flags is not None else None
+            gtx.check(L.gtx_align_batch_flags(ctx.h, self.d_seq.data_ptr(), self.stride, self.d_meta.data_ptr(), self.n, self.d_rec.data_ptr(),
+                                              REC_WORDS, fl, sp))
             e1.record(self.stream)
-            gtx.check(L.gtx_score_batch(ctx.h, self.d_items.data_ptr(), self.n, self.d_rec.data_ptr(), REC_WORDS, C.byref(self.buf), sp))
+            gtx.check(L.gtx_score_batch_flags(ctx.h, self.d_items.data_ptr(), self.n, self.d_rec.data_ptr(), REC_WORDS, fl, C.byref(self.buf), sp))
             if self.comm is not None:
                 gtx.check(L.gtx_scores_reduce(ctx.h, C.byref(self.buf), self.comm, sp))
             elif self.dist is not None:
@@ -492,7 +496,7 @@ def main(argv=None):
                        "timed steps (config.vcf_text; records byte-identical to the oracle's in the tests, unbroken sites)" % (n, READ_LEN, args.snp_every),
            "reads_per_gpu": n, "index_keys": n_keys, "index_labels": n_labels, "haplotypes": ctx.n_hap,
            "ctx_create_s": round(t_ctx_warm, 3), "ctx_create_first_s": round(t_ctx, 3),
-           "position_hint": not args.no_hint,
+           "position_hint": not args.no_hint, "task_flags_side_array": USE_TASK_FLAGS,
            "parallelism": "reads sharded over %d GPU(s), graph+index replicated" % n_gpus,
            "reduce": w.reduce_kind, "reduced_bytes_per_step": w.reduced_bytes if n_gpus > 1 else 0}
     cfg.update(facts)

@@ -405,7 +405,8 @@ template <uint32_t WAVES>
 __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const & ix, uint8_t const * __restrict__ seq, uint32_t seq_stride,
                                             gtx_read_meta const * __restrict__ meta, uint32_t n_reads, uint32_t * __restrict__ records,
                                             uint32_t rec_words, uint32_t force_both, uint32_t * __restrict__ queue1, uint32_t * queue1_count,
-                                            uint32_t * __restrict__ queue2, uint32_t * queue2_count, uint32_t decline_all)
+                                            uint32_t * __restrict__ queue2, uint32_t * queue2_count, uint32_t decline_all,
+                                            uint8_t * __restrict__ task_flags)
 {
   // The 64 reads of a wavefront lie side by side in memory: their bases (80 B each) and their meta records (20 B each)
   // are fetched with coalesced loads -- 1 KB and 256 B per instruction instead of 64 scattered lines -- and handed to
@@ -446,6 +447,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
   }
   WaveHip::lds_sync();
   bool fwd = false, rev = false, staged_rec = false;
+  uint32_t fwd_flag = 0;
   static_assert(HINT_STAGE_WORDS == 16 && HINT_STAGE_WORDS * 4 <= HINT_MAX_READ / 2, "a staged record is four 16-byte parts inside the read's row");
   if (read < n_reads)
   {
@@ -492,6 +494,16 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
       uint32_t const where = hinted_one(g, ix, row, reinterpret_cast<uint8_t const *>(row), ROW_BYTES, m, rec, rec_words, can_stage ? row : nullptr);
       fwd = where == 0;
       staged_rec = where == 2;
+      fwd_flag = where == 0 ? 0u : ((where == 2 ? row[1] : rec[1]) >> 31);
+    }
+    // the dense side array (gtx_align_batch_flags): what this pass settles -- the forward task it finished, the reverse
+    // task that is not aligned at all; the queued tasks get theirs from gtx_task_flags_fixup_kernel behind the last pass
+    if (task_flags)
+    {
+      if (!fwd)
+        task_flags[2ull * read] = static_cast<uint8_t>(fwd_flag);
+      if (!rev)
+        task_flags[2ull * read + 1] = 0;
     }
   }
   {
@@ -548,8 +560,8 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
 #define GTX_HINTED_ARGS                                                                                                            \
   GraphView g, IndexView ix, uint8_t const *__restrict__ seq, uint32_t seq_stride, gtx_read_meta const *__restrict__ meta,         \
     uint32_t n_reads, uint32_t *__restrict__ records, uint32_t rec_words, uint32_t force_both, uint32_t *__restrict__ queue1,      \
-    uint32_t *queue1_count, uint32_t *__restrict__ queue2, uint32_t *queue2_count, uint32_t decline_all
-#define GTX_HINTED_PASS(W) hinted_pass<W>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, queue1, queue1_count, queue2, queue2_count, decline_all)
+    uint32_t *queue1_count, uint32_t *__restrict__ queue2, uint32_t *queue2_count, uint32_t decline_all, uint8_t *__restrict__ task_flags
+#define GTX_HINTED_PASS(W) hinted_pass<W>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, queue1, queue1_count, queue2, queue2_count, decline_all, task_flags)
 
 #ifndef GTX_HINT_WAVES
 #define GTX_HINT_WAVES 16 // wavefronts per workgroup of the position-hinted pass
@@ -772,22 +784,61 @@ GTX_HBM_PASS_KERNEL(gtx_align_wide_kernel, wide)
 // Scoring, stage 1 (triage): one thread per item reads the record header(s) and decides whether the item can add
 // anything; 85 % of the cfg2 items cannot and end here.  No per-thread tables, so this kernel runs at full occupancy.
 // The others are appended to a work queue, one atomic per wavefront.
-__global__ __launch_bounds__(256) void gtx_score_triage_kernel(gtx_score_item const * __restrict__ items, uint32_t n_items,
-                                                               uint32_t const * __restrict__ records, uint32_t rec_words,
-                                                               uint32_t * __restrict__ work_queue, uint32_t * work_count, uint32_t keeps_depth)
+// The dense side array of gtx_align_batch_flags for the tasks a queue names (queue1: reads whose forward task the
+// position-hinted pass declined; queue2: the tasks of the general pass): one header read per queued task, behind the last pass.
+__global__ __launch_bounds__(256) void gtx_task_flags_fixup_kernel(uint32_t const * __restrict__ records, uint32_t rec_words,
+                                                                   uint8_t * __restrict__ task_flags, uint32_t const * __restrict__ queue1,
+                                                                   uint32_t const * queue1_count, uint32_t const * __restrict__ queue2,
+                                                                   uint32_t const * queue2_count)
 {
+  uint32_t const n1 = queue1 ? queue1_count[0] : 0u, n2 = queue2_count[0];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += gridDim.x * blockDim.x)
+  {
+    uint32_t const task = i < n1 ? 2u * queue1[i] : queue2[i - n1];
+    task_flags[task] = static_cast<uint8_t>(records[static_cast<uint64_t>(task) * rec_words + 1] >> 31);
+  }
+}
+
+// ... and for every task of a batch (batches aligned without the position-hinted pass)
+__global__ __launch_bounds__(256) void gtx_task_flags_all_kernel(uint32_t const * __restrict__ records, uint32_t rec_words,
+                                                                 uint8_t * __restrict__ task_flags, uint32_t n_tasks)
+{
+  uint32_t const task = blockIdx.x * blockDim.x + threadIdx.x;
+  if (task < n_tasks)
+    task_flags[task] = static_cast<uint8_t>(records[static_cast<uint64_t>(task) * rec_words + 1] >> 31);
+}
+
+constexpr uint32_t TRIAGE_THREADS = 1024;
+__global__ __launch_bounds__(TRIAGE_THREADS) void gtx_score_triage_kernel(gtx_score_item const * __restrict__ items, uint32_t n_items,
+                                                                          uint32_t const * __restrict__ records, uint32_t rec_words,
+                                                                          uint32_t * __restrict__ work_queue, uint32_t * work_count,
+                                                                          uint32_t keeps_depth, uint8_t const * __restrict__ task_flags)
+{
+  // one queue append per WORKGROUP (a device counter takes a few hundred million returning atomics a second: one per
+  // wavefront -- 156 k per 10 M items -- set the pace of this kernel)
+  __shared__ uint32_t s_count[TRIAGE_THREADS / 64], s_base;
   uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool const work = i < n_items && !item_is_trivial(items[i], records, rec_words, keeps_depth != 0);
+  bool const work = i < n_items && !item_is_trivial(items[i], records, rec_words, keeps_depth != 0, task_flags);
   unsigned long long const mask = __ballot(work);
-  if (mask == 0)
-    return;
-  uint32_t const lane = threadIdx.x & 63u;
-  uint32_t base = 0;
-  if (lane == static_cast<uint32_t>(__builtin_ctzll(mask)))
-    base = atomicAdd(work_count, static_cast<uint32_t>(__builtin_popcountll(mask)));
-  base = __shfl(base, __builtin_ctzll(mask));
+  uint32_t const lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (lane == 0)
+    s_count[wave] = static_cast<uint32_t>(__builtin_popcountll(mask));
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < TRIAGE_THREADS / 64; ++w)
+      total += s_count[w];
+    s_base = total ? atomicAdd(work_count, total) : 0u;
+  }
+  __syncthreads();
   if (work)
-    work_queue[base + static_cast<uint32_t>(__builtin_popcountll(mask & ((1ull << lane) - 1ull)))] = i;
+  {
+    uint32_t at = s_base;
+    for (uint32_t w = 0; w < wave; ++w)
+      at += s_count[w];
+    work_queue[at + static_cast<uint32_t>(__builtin_popcountll(mask & ((1ull << lane) - 1ull)))] = i;
+  }
 }
 
 // Scoring, stage 2: the items of the work queue, one thread each (orientation / pair selection, path checks, atomics).
@@ -1199,6 +1250,12 @@ struct ScratchHold
 extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta,
                                uint32_t n_reads, uint32_t * d_records, uint32_t rec_words, void * stream)
 {
+  return gtx_align_batch_flags(c, d_seq, seq_stride, d_meta, n_reads, d_records, rec_words, nullptr, stream);
+}
+
+extern "C" int gtx_align_batch_flags(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta,
+                                     uint32_t n_reads, uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream)
+{
   if (!c || rec_words < 8 || (n_reads != 0 && (!d_seq || !d_meta || !d_records)))
   {
     g_last_error = "gtx_align_batch: bad argument";
@@ -1326,7 +1383,8 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
       hipLaunchKernelGGL(hint_threads == 256u ? gtx_align_hinted4_kernel : hint_threads == 512u ? gtx_align_hinted8_kernel : gtx_align_hinted_kernel,
                          dim3((n + hint_threads - 1u) / hint_threads), dim3(hint_threads), 0, st, c->dev_graph, c->dev_index, seq, seq_stride,
                          meta, n, records, rec_words, force_both, queue1, counters + 3, queue2, counters + 2,
-                         static_cast<uint32_t>(force != 0 || (eh && eh[0] == 'd')) | (eh && eh[0] == 'x' ? 2u : 0u));
+                         static_cast<uint32_t>(force != 0 || (eh && eh[0] == 'd')) | (eh && eh[0] == 'x' ? 2u : 0u),
+                         d_task_flags ? d_task_flags + 2ull * first : static_cast<uint8_t *>(nullptr));
       if (!hip_ok(hipGetLastError(), "gtx_align_hinted_kernel launch"))
         return GTX_ERR_HIP;
       mark(part, 1, st);
@@ -1377,6 +1435,26 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
                          static_cast<unsigned long long>(c->big_record_words), c->d_arena_cursor, static_cast<uint32_t *>(nullptr), 0u,
                          static_cast<uint32_t *>(nullptr));
       if (!hip_ok(hipGetLastError(), "gtx_align_wide_kernel launch"))
+        return GTX_ERR_HIP;
+    }
+  }
+  if (d_task_flags)
+  {
+    // the dense side array for what the position-hinted pass did not settle (its queue and the general pass' queue, per
+    // part), or -- without that pass -- for every task
+    uint32_t part = 0;
+    for (uint32_t first = 0; first < n_reads; first += step, ++part)
+    {
+      uint32_t const n = std::min(step, n_reads - first);
+      uint32_t const * counters = s->d_counters + 8 * part;
+      uint32_t const * rec_part = d_records + static_cast<uint64_t>(first) * 2 * rec_words;
+      uint8_t * flags_part = d_task_flags + 2ull * first;
+      if (hinted)
+        hipLaunchKernelGGL(gtx_task_flags_fixup_kernel, dim3(n_cu * 4u), dim3(256), 0, sg, rec_part, rec_words, flags_part, s->d_queue1 + first,
+                           counters + 3, s->d_queue + 2ull * first, counters + 2);
+      else
+        hipLaunchKernelGGL(gtx_task_flags_all_kernel, dim3((2u * n + 255u) / 256u), dim3(256), 0, sg, rec_part, rec_words, flags_part, 2u * n);
+      if (!hip_ok(hipGetLastError(), "task flags launch"))
         return GTX_ERR_HIP;
     }
   }
@@ -1478,6 +1556,12 @@ extern "C" int gtx_ctx_pass_times(gtx_ctx * c, float * ms, uint32_t * queued)
 extern "C" int gtx_score_batch(gtx_ctx * c, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records,
                                uint32_t rec_words, const gtx_score_buffers * acc, void * stream)
 {
+  return gtx_score_batch_flags(c, d_items, n_items, d_records, rec_words, nullptr, acc, stream);
+}
+
+extern "C" int gtx_score_batch_flags(gtx_ctx * c, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records,
+                                     uint32_t rec_words, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream)
+{
   if (!c || !d_items || !d_records || !acc || !acc->d_log_score || !acc->d_gt_cov || !acc->d_hap_u32 || !acc->d_stat_u64 ||
       !acc->d_stat_u32 || !acc->d_conn_log || !acc->d_conn_count)
   {
@@ -1530,8 +1614,8 @@ extern "C" int gtx_score_batch(gtx_ctx * c, const gtx_score_item * d_items, uint
   s->score_work_cap = static_cast<uint32_t>(cap - 1);
   if (!hip_ok(hipMemsetAsync(s->d_score_work, 0, sizeof(uint32_t), st), "score work queue reset"))
     return GTX_ERR_HIP;
-  hipLaunchKernelGGL(gtx_score_triage_kernel, dim3(blocks), dim3(256), 0, st, d_items, n_items, d_records, rec_words, s->d_score_work + 1,
-                     s->d_score_work, static_cast<uint32_t>(a.ref_depth != nullptr));
+  hipLaunchKernelGGL(gtx_score_triage_kernel, dim3((n_items + TRIAGE_THREADS - 1) / TRIAGE_THREADS), dim3(TRIAGE_THREADS), 0, st, d_items, n_items, d_records, rec_words, s->d_score_work + 1,
+                     s->d_score_work, static_cast<uint32_t>(a.ref_depth != nullptr), d_task_flags);
   if (!hip_ok(hipGetLastError(), "gtx_score_triage_kernel launch"))
     return GTX_ERR_HIP;
   uint32_t const work_blocks = std::min<uint32_t>(blocks, static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256) * 8u);

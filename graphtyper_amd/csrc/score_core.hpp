@@ -643,7 +643,10 @@ GTX_DEV void apply_recent(GraphView const & g, ScoreAcc const & acc, Geno const 
 // Triage: true when no orientation of the item's read(s) carries a variant site -- whatever the orientation / pair
 // selection decides, nothing can be added to the accumulators (the same early exits are inside score_item).  Costs one
 // record header per read whose reverse orientation was not aligned.
-GTX_DEV bool item_is_trivial(gtx_score_item const & it, uint32_t const * records, uint32_t rec_words, bool keeps_depth = false)
+// task_flags (may be NULL): the dense side array of gtx_align_batch_flags -- one byte per (read, orientation) instead of one
+// cache line per record header.
+GTX_DEV bool item_is_trivial(gtx_score_item const & it, uint32_t const * records, uint32_t rec_words, bool keeps_depth = false,
+                             uint8_t const * task_flags = nullptr)
 {
   if (keeps_depth && it.second.align_index != INVALID)
     return false; // (SV calling: every selected pair counts for the reference depth, with or without variant sites)
@@ -653,6 +656,13 @@ GTX_DEV bool item_is_trivial(gtx_score_item const & it, uint32_t const * records
     gtx_rec_meta const & m = *ms[r];
     if (r == 1 && m.align_index == INVALID)
       break;
+    if (task_flags)
+    {
+      uint8_t const * f = task_flags + 2ull * m.align_index;
+      if ((f[0] & GTX_TASK_HAS_VARIANTS) || (!(m.flag & GTX_FLAG_FORWARD_ONLY) && (f[1] & GTX_TASK_HAS_VARIANTS)))
+        return false;
+      continue;
+    }
     uint32_t const * rec = records + static_cast<uint64_t>(m.align_index) * 2 * rec_words;
     if (rec[1] & GTX_REC_HAS_VARIANTS)
       return false;

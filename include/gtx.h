@@ -267,6 +267,14 @@ int gtx_index_dump(const gtx_ctx *, uint64_t * keys, uint32_t * counts, gtx_labe
 int gtx_align_batch(gtx_ctx *, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
                     uint32_t * d_records, uint32_t rec_words, void * stream);
 
+/* gtx_align_batch with a dense side array: d_task_flags[2 * read + orientation] (one byte per task, indexed like d_records,
+ * so the caller offsets the pointer per batch the same way) receives GTX_TASK_HAS_VARIANTS when the task's record carries a
+ * variant site -- the one fact the first stage of gtx_score_batch needs of nearly every record.  With it that stage reads
+ * one byte per read instead of one cache line per record header (gtx_score_batch_flags).  NULL: plain gtx_align_batch. */
+#define GTX_TASK_HAS_VARIANTS 1u
+int gtx_align_batch_flags(gtx_ctx *, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
+                          uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream);
+
 /* Score accumulators (all uint32 / uint64, zero-initialised by the caller; sample-major):
  *   d_log_score [n_samples * total_tri]      HapSample::log_score
  *   d_gt_cov    [n_samples * total_allele]   HapSample::gt_coverage
@@ -305,6 +313,10 @@ typedef struct gtx_score_buffers
 
 int gtx_score_batch(gtx_ctx *, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records,
                     uint32_t rec_words, const gtx_score_buffers * acc, void * stream);
+/* ... with the side array of gtx_align_batch_flags (bytes 2 * align_index + orientation relative to d_task_flags, i.e. the
+ * array that runs beside d_records); same results */
+int gtx_score_batch_flags(gtx_ctx *, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records, uint32_t rec_words,
+                          const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream);
 
 /* number of score items the kernel refused so far because one read touched more variant sites than its table holds
  * (must be 0 for the accumulators to be complete) */

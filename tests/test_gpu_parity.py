@@ -169,3 +169,41 @@ def test_record_slot_sizes(rec_words):
     got = gtx.parse_records(rec, len(codes), rec_words, b.ctx.hap_order, b.big_records()[0])
     assert got == want
     assert b.hinted_done() > len(codes) // 2 and (rec_words < 24 or b.hinted_done() == done64)
+
+
+@pytest.mark.parametrize("hint", [True, False])
+def test_task_flags_side_array(hint):
+    """gtx_align_batch_flags / gtx_score_batch_flags: the dense byte per (read, orientation) equals bit 31 of the record's
+    second word for every task -- whichever pass finished it -- and scoring with it gives the same accumulators"""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    ref, recs, codes, rec = scenarios.paired_case("snp100", n_ref=40000, n_pairs=6000, region_begin=310000, n_samples=3)
+    b = harness.GpuBackend(gtx.graph_from_records(ref, recs, region_begin=310000))
+    st = gtx.Stream(b.ctx.params, 1)
+    a_seq, a_meta, items = st.push(rec, gtx.pack_nibbles(codes))
+    if not hint:
+        a_meta = a_meta.copy()
+        a_meta["pos"] = -1
+    n = len(a_meta)
+    d_seq, d_meta = b._dev(a_seq), b._dev(a_meta)
+    d_rec = torch.zeros(n * 2 * harness.REC_WORDS, dtype=torch.int32, device="cuda:0")
+    d_flags = torch.full((2 * n,), 0x55, dtype=torch.uint8, device="cuda:0")
+    L = gtx.lib()
+    gtx.check(L.gtx_align_batch_flags(b.ctx.h, d_seq.data_ptr(), a_seq.shape[1], d_meta.data_ptr(), n, d_rec.data_ptr(), harness.REC_WORDS,
+                                      d_flags.data_ptr(), None))
+    torch.cuda.synchronize()
+    records = d_rec.cpu().numpy().view(np.uint32)
+    flags = d_flags.cpu().numpy()
+    want = (records.reshape(2 * n, harness.REC_WORDS)[:, 1] >> 31).astype(np.uint8)
+    assert np.array_equal(flags, want) and 0 < int(want.sum()) < n
+    assert (want[1::2] != 0).any(), "no reverse-orientation task with a variant: the scenario does not cover the general pass' tasks"
+    acc = b.score(items, records, 3)
+    acc2 = harness.Accumulators(b.ctx, 3)
+    devs = [b._dev(a) for a in acc2.arrays()]
+    buf = acc2.buffers([d.data_ptr() for d in devs])
+    gtx.check(L.gtx_score_batch_flags(b.ctx.h, b._dev(np.ascontiguousarray(items, gtx.SCORE_ITEM)).data_ptr(), len(items), d_rec.data_ptr(),
+                                      harness.REC_WORDS, d_flags.data_ptr(), C.byref(buf), None))
+    torch.cuda.synchronize()
+    for host, dev in zip(acc2.arrays(), devs):
+        host[...] = dev.cpu().numpy().view(host.dtype)
+    assert np.array_equal(harness.canonical_scores(b.ctx, acc), harness.canonical_scores(b.ctx, acc2))
