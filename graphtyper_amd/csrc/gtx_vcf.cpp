@@ -40,11 +40,16 @@ struct Binned
 };
 const Binned BINNED;
 
-void put_u(std::string & s, uint64_t v)
+void put_u(std::string & s, uint64_t v) // (most of a VCF line is small integers: digits by hand, not through printf)
 {
   char b[24];
-  int const n = std::snprintf(b, sizeof(b), "%llu", static_cast<unsigned long long>(v));
-  s.append(b, static_cast<size_t>(n));
+  int n = 24;
+  do
+  {
+    b[--n] = static_cast<char>('0' + v % 10);
+    v /= 10;
+  } while (v != 0);
+  s.append(b + n, static_cast<size_t>(24 - n));
 }
 
 void put_g(std::string & s, double v, int precision) // ostream << double at that precision, default float format
