@@ -7,15 +7,17 @@
 //                                        (tid, pos, l_qseq, packed bases)       include/graphtyper/utilities/hts_utils.hpp:48-108
 //   HtsReader::get_sample_and_rg_index   hts_reader.cpp:354-387                RG tag -> read group / sample index
 //   get_score_diff                       src/typer/alignment.cpp:140-325       AS - XS from the aux fields, with its parsing quirks
-// Here: BGZF is a series of gzip members, which zlib's gzread reads through; a BAM record is parsed in place into a
+// Here: BGZF members are inflated one at a time (zlib, raw deflate); a BAM record is parsed in place into a
 // gtx_stream_record + its packed bases (copied verbatim: the kernels read BAM nibbles).  Equal keys keep file order, then
 // position in the file (the reference's std::sort / heap leave the order of exact duplicates unspecified; their results do
-// not depend on it).  Not read: CRAM (needs htslib's codecs), the .bai / .csi index -- a region is applied by scanning.
+// not depend on it).  A region starts from the .bai when there is one (else the file is scanned from its head).  Not read:
+// CRAM (needs htslib's codecs), .csi indices.
 #include "gtx_ctx.hpp"
 
 #include <zlib.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -25,6 +27,189 @@
 
 namespace
 {
+// BGZF: a series of gzip members of at most 64 KB, each with its compressed size in a "BC" extra field (SAM spec 4.1); a
+// virtual offset = (file offset of a member) << 16 | offset in its data.  Members are inflated one at a time (raw
+// deflate), which is what makes seeking by virtual offset possible.
+class Bgzf
+{
+public:
+  ~Bgzf() { close(); }
+  bool open(std::string const & path)
+  {
+    fp_ = std::fopen(path.c_str(), "rb");
+    return fp_ != nullptr;
+  }
+  void close()
+  {
+    if (fp_)
+      std::fclose(fp_);
+    fp_ = nullptr;
+  }
+  bool is_open() const { return fp_ != nullptr; }
+  // reads n bytes; returns the number read (short at the end of the file), -1 on a malformed member
+  long read(void * dst, size_t n)
+  {
+    size_t done = 0;
+    while (done < n)
+    {
+      if (at_ == data_.size() && !next_block())
+        return bad_ ? -1 : static_cast<long>(done);
+      size_t const take = std::min(n - done, data_.size() - at_);
+      std::memcpy(static_cast<uint8_t *>(dst) + done, data_.data() + at_, take);
+      at_ += take;
+      done += take;
+    }
+    return static_cast<long>(done);
+  }
+  bool seek(uint64_t voffset)
+  {
+    if (std::fseek(fp_, static_cast<long>(voffset >> 16), SEEK_SET) != 0)
+      return false;
+    data_.clear();
+    at_ = 0;
+    if ((voffset & 0xFFFFu) == 0)
+      return true;
+    if (!next_block() || (voffset & 0xFFFFu) > data_.size())
+      return false;
+    at_ = voffset & 0xFFFFu;
+    return true;
+  }
+
+private:
+  bool next_block()
+  {
+    for (;;)
+    {
+      uint8_t h[18];
+      size_t const got = std::fread(h, 1, 18, fp_);
+      if (got == 0)
+        return false; // end of the file
+      if (got != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4))
+        return fail();
+      unsigned const xlen = h[10] | (h[11] << 8);
+      // the BC field is the first extra field in every writer there is; look through the extra fields anyway
+      std::vector<uint8_t> extra(xlen);
+      std::memcpy(extra.data(), h + 12, std::min<size_t>(6, xlen));
+      if (xlen > 6 && std::fread(extra.data() + 6, 1, xlen - 6, fp_) != xlen - 6)
+        return fail();
+      long bsize = -1;
+      for (unsigned i = 0; i + 4 <= xlen;)
+      {
+        unsigned const slen = extra[i + 2] | (extra[i + 3] << 8);
+        if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2 && i + 6 <= xlen)
+          bsize = extra[i + 4] | (extra[i + 5] << 8);
+        i += 4 + slen;
+      }
+      if (bsize < 0)
+        return fail();
+      long const clen = bsize + 1 - 12 - static_cast<long>(xlen) - 8; // compressed data between header and CRC32 / ISIZE
+      if (clen < 0)
+        return fail();
+      comp_.resize(static_cast<size_t>(clen) + 8);
+      if (std::fread(comp_.data(), 1, comp_.size(), fp_) != comp_.size())
+        return fail();
+      uint32_t isize;
+      std::memcpy(&isize, comp_.data() + clen + 4, 4);
+      if (isize > 65536)
+        return fail();
+      data_.resize(isize);
+      at_ = 0;
+      if (isize == 0)
+        continue; // (the end-of-file marker, or an empty member)
+      z_stream z{};
+      if (inflateInit2(&z, -15) != Z_OK)
+        return fail();
+      z.next_in = comp_.data();
+      z.avail_in = static_cast<uInt>(clen);
+      z.next_out = data_.data();
+      z.avail_out = isize;
+      int const rc = inflate(&z, Z_FINISH);
+      inflateEnd(&z);
+      if (rc != Z_STREAM_END || z.avail_out != 0)
+        return fail();
+      return true;
+    }
+  }
+  bool fail()
+  {
+    bad_ = true;
+    return false;
+  }
+  std::FILE * fp_ = nullptr;
+  std::vector<uint8_t> comp_, data_;
+  size_t at_ = 0;
+  bool bad_ = false;
+};
+
+// Where to start reading for a region: the .bai beside the BAM (SAM spec 5.2).  The smallest chunk start among the bins that
+// can hold an overlapping record, not below the linear index' offset for the region's first 16 kb window: no overlapping
+// record of a sorted file starts in front of it.  (Reading goes on sequentially from there -- records of other bins in
+// between are filtered like any other -- and stops behind the region.)  false: no usable index.
+bool bai_start(std::string const & bam_path, int32_t tid, int64_t begin, int64_t end, bool & any, uint64_t & voffset)
+{
+  std::FILE * fp = std::fopen((bam_path + ".bai").c_str(), "rb");
+  if (!fp && bam_path.size() > 4)
+    fp = std::fopen((bam_path.substr(0, bam_path.size() - 4) + ".bai").c_str(), "rb");
+  if (!fp)
+    return false;
+  auto rd = [&](void * d, size_t n) { return std::fread(d, 1, n, fp) == n; };
+  char magic[4];
+  int32_t n_ref = 0;
+  bool ok = rd(magic, 4) && std::memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && tid >= 0 && tid < n_ref;
+  any = false;
+  voffset = UINT64_MAX;
+  int64_t const last = std::min<int64_t>(end, (1ll << 29)) - 1;
+  for (int32_t r = 0; ok && r <= tid; ++r)
+  {
+    int32_t n_bin = 0;
+    ok = rd(&n_bin, 4);
+    uint64_t best = UINT64_MAX;
+    for (int32_t b = 0; ok && b < n_bin; ++b)
+    {
+      uint32_t bin = 0;
+      int32_t n_chunk = 0;
+      ok = rd(&bin, 4) && rd(&n_chunk, 4) && n_chunk >= 0;
+      for (int32_t c = 0; ok && c < n_chunk; ++c)
+      {
+        uint64_t cb = 0, ce = 0;
+        ok = rd(&cb, 8) && rd(&ce, 8);
+        if (!ok || r != tid || bin == 37450) // (37450: the pseudo-bin with the mapped / unmapped counts)
+          continue;
+        // does the bin overlap [begin, last]?  level l holds bins of 2^(29 - 3 l) bases from offset ((8^l - 1) / 7)
+        bool overlaps = false;
+        for (int l = 0, first = 0; l <= 5; first += 1 << (3 * l), ++l)
+        {
+          int const shift = 29 - 3 * l;
+          if (bin >= static_cast<uint32_t>(first) && bin < static_cast<uint32_t>(first + (1 << (3 * l))))
+          {
+            int64_t const k = bin - first;
+            overlaps = k >= (begin >> shift) && k <= (last >> shift);
+          }
+        }
+        if (overlaps && cb < best)
+          best = cb;
+      }
+    }
+    int32_t n_intv = 0;
+    ok = ok && rd(&n_intv, 4) && n_intv >= 0;
+    uint64_t linear = 0;
+    for (int32_t i = 0; ok && i < n_intv; ++i)
+    {
+      uint64_t io = 0;
+      ok = rd(&io, 8);
+      if (ok && r == tid && i == (begin >> 14))
+        linear = io;
+    }
+    if (ok && r == tid && best != UINT64_MAX)
+    {
+      any = true;
+      voffset = std::max(best, linear);
+    }
+  }
+  std::fclose(fp);
+  return ok;
+}
+
 struct Rec // one BAM record as the merge needs it
 {
   gtx_stream_record r{};
@@ -59,7 +244,7 @@ uint64_t name_hash(char const * s, size_t n) // identity of a read name: 64-bit 
 
 struct File
 {
-  gzFile fp = nullptr;
+  Bgzf fp;
   std::string path;
   std::vector<std::string> ref_names;
   std::vector<std::string> samples;          // of this file, in header order
@@ -70,6 +255,7 @@ struct File
   int32_t want_tid = -2;
   int64_t begin = 0, end = INT64_MAX;
   bool eof = false;
+  bool indexed = false;        // the scan started from the .bai
   Rec ahead;                   // the first record of the next position
   bool have_ahead = false;
   std::deque<Rec> same_pos;    // the records of the current position, in order
@@ -77,7 +263,7 @@ struct File
 
   bool read_exact(void * dst, unsigned n)
   {
-    return gzread(fp, dst, n) == static_cast<int>(n);
+    return fp.read(dst, n) == static_cast<long>(n);
   }
 
   uint32_t num_rg() const { return std::max<uint32_t>(1, static_cast<uint32_t>(rg2sample.size())); }
@@ -184,7 +370,7 @@ struct File
       if (eof)
         return false;
       int32_t block = 0;
-      int const got = gzread(fp, &block, 4);
+      long const got = fp.read(&block, 4);
       if (got == 0)
       {
         eof = true;
@@ -391,21 +577,17 @@ extern "C" int gtx_reads_open(const char * const * bam_paths, uint32_t n_paths, 
   {
     auto file = std::make_unique<File>();
     file->path = bam_paths[f] ? bam_paths[f] : "";
-    file->fp = gzopen(file->path.c_str(), "rb");
-    if (!file->fp)
+    if (!file->fp.open(file->path))
       return fail(r, "could not open " + file->path, GTX_ERR_IO);
-    gzbuffer(file->fp, 1u << 18);
     char magic[4];
     int32_t l_text = 0, n_ref = 0;
     if (!file->read_exact(magic, 4) || std::memcmp(magic, "BAM\1", 4) != 0 || !file->read_exact(&l_text, 4) || l_text < 0)
     {
-      gzclose(file->fp);
       return fail(r, file->path + " is not a BAM file (CRAM is not read)", GTX_ERR_UNSUPPORTED);
     }
     std::string text(static_cast<size_t>(l_text), '\0');
     if ((l_text && !file->read_exact(&text[0], static_cast<unsigned>(l_text))) || !file->read_exact(&n_ref, 4) || n_ref < 0)
     {
-      gzclose(file->fp);
       return fail(r, file->path + ": truncated header", GTX_ERR_IO);
     }
     for (int32_t i = 0; i < n_ref; ++i)
@@ -415,7 +597,6 @@ extern "C" int gtx_reads_open(const char * const * bam_paths, uint32_t n_paths, 
       if (!file->read_exact(&l_name, 4) || l_name <= 0 || (name.resize(static_cast<size_t>(l_name)), !file->read_exact(&name[0], static_cast<unsigned>(l_name))) ||
           !file->read_exact(&l_ref, 4))
       {
-        gzclose(file->fp);
         return fail(r, file->path + ": truncated header", GTX_ERR_IO);
       }
       name.resize(std::strlen(name.c_str()));
@@ -433,7 +614,6 @@ extern "C" int gtx_reads_open(const char * const * bam_paths, uint32_t n_paths, 
       size_t const pid = line.find("\tID:"), psm = line.rfind("\tSM:");
       if (pid == std::string::npos || psm == std::string::npos)
       {
-        gzclose(file->fp);
         return fail(r, file->path + ": an @RG line without ID or SM", GTX_ERR_ARG);
       }
       size_t const eid = std::min(line.find('\t', pid + 1), line.size()), esm = std::min(line.find('\t', psm + 1), line.size());
@@ -456,12 +636,22 @@ extern "C" int gtx_reads_open(const char * const * bam_paths, uint32_t n_paths, 
       auto it = std::find(file->ref_names.begin(), file->ref_names.end(), contig);
       if (it == file->ref_names.end())
       {
-        gzclose(file->fp);
         return fail(r, file->path + ": no contig " + contig, GTX_ERR_ARG);
       }
       file->want_tid = static_cast<int32_t>(it - file->ref_names.begin());
       file->begin = begin;
       file->end = end;
+      // with a .bai the scan starts at the first place an overlapping record can be, else behind the header
+      bool any = false;
+      uint64_t voffset = 0;
+      if (bai_start(file->path, file->want_tid, begin, end, any, voffset))
+      {
+        file->indexed = true;
+        if (!any)
+          file->eof = true; // the index knows of no record there
+        else if (!file->fp.seek(voffset))
+          return fail(r, file->path + ": the index points outside the file", GTX_ERR_IO);
+      }
     }
     file->sample_offset = static_cast<uint32_t>(r->samples.size());
     file->rg_offset = r->n_rg;
@@ -477,8 +667,6 @@ extern "C" int gtx_reads_open(const char * const * bam_paths, uint32_t n_paths, 
     if (!r->error.empty())
     {
       std::string const e = r->error;
-      for (auto & fl : r->files)
-        gzclose(fl->fp);
       return fail(r, e, GTX_ERR_IO);
     }
   }
@@ -544,8 +732,5 @@ extern "C" void gtx_reads_close(gtx_reads * r)
 {
   if (!r)
     return;
-  for (auto & f : r->files)
-    if (f->fp)
-      gzclose(f->fp);
   delete r;
 }

@@ -504,9 +504,10 @@ int gtx_stream_counts(const gtx_stream *, uint64_t * n_records, uint64_t * n_dup
  * (tid, pos, l_qseq, packed bases), include/graphtyper/utilities/hts_utils.hpp:48-108), get_sample_and_rg_index
  * (hts_reader.cpp:354-387) and get_score_diff (src/typer/alignment.cpp:140-325).  Records come out as gtx_stream_record +
  * packed bases, ready for gtx_stream_push; samples and read groups are numbered across the files in the order given.
- * Needs zlib only (BGZF is a series of gzip members).  Not read: CRAM, the .bai / .csi index -- `region` ("chr",
- * "chr:begin-end", 1-based inclusive; NULL, "" or "." = everything) is applied by scanning the sorted file for the records
- * that overlap it, as sam_itr_querys would return them.  Records with equal sort keys keep file order (the reference's
+ * Needs zlib only (BGZF members are inflated one by one, so virtual offsets can be sought).  `region` ("chr",
+ * "chr:begin-end", 1-based inclusive; NULL, "" or "." = everything) yields the records that overlap it, as sam_itr_querys
+ * would return them: with a .bai beside the file (<bam>.bai or <name>.bai) the scan starts at the first place the index
+ * allows an overlapping record, without one at the head of the file.  Not read: CRAM, .csi indices.  Records with equal sort keys keep file order (the reference's
  * std::sort / heap leave the order of exact duplicates open; results do not depend on it).
  * gtx_reads_next fills up to cap records (n = 0: end); a read whose packed bases exceed seq_stride is an error. */
 typedef struct gtx_reads gtx_reads;

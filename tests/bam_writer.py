@@ -49,13 +49,67 @@ def record(name, flag, tid, pos, mapq, cigar, mtid, mpos, tlen, codes, aux=()):
     return struct.pack("<i", len(body)) + body
 
 
-def write_bam(path, refs, header_text, records):
-    """refs: [(name, length)]; records: bytes from record(), already in file order"""
-    data = b"BAM\1" + struct.pack("<i", len(header_text)) + header_text.encode() + struct.pack("<i", len(refs))
+def write_bam(path, refs, header_text, records, index=None, poison=False):
+    """refs: [(name, length)]; records: bytes from record(), already in file order.
+    index: [(tid, pos, end)] per record -> also writes path + ".bai" (SAM spec 5.2: bins, chunks, 16 kb linear index);
+    poison: a BGZF member of garbage between the header and the records -- a reader that scans from the head fails on it,
+    one that seeks through the index never sees it."""
+    head = b"BAM\1" + struct.pack("<i", len(header_text)) + header_text.encode() + struct.pack("<i", len(refs))
     for name, length in refs:
-        data += struct.pack("<i", len(name) + 1) + name.encode() + b"\0" + struct.pack("<i", length)
-    data += b"".join(records)
-    open(path, "wb").write(bgzf(data))
+        head += struct.pack("<i", len(name) + 1) + name.encode() + b"\0" + struct.pack("<i", length)
+    out = bytearray(bgzf(head)[:-28])  # (without the end-of-file member)
+    if poison:
+        out += bgzf(b"\xff" * 300)[:-28]
+    voffs = []
+    block, block_start = bytearray(), len(out)
+    pieces = []
+    for r in records:
+        if len(block) + len(r) > 60000 and block:
+            pieces.append(bytes(block))
+            comp = bgzf(bytes(block))[:-28]
+            out += comp
+            block, block_start = bytearray(), len(out)
+        voffs.append((block_start << 16) | len(block))
+        block += r
+    if block:
+        out += bgzf(bytes(block))[:-28]
+    end_voff = len(out) << 16
+    out += bgzf(b"")  # the end-of-file member
+    open(path, "wb").write(bytes(out))
+    if index is None:
+        return
+    assert len(index) == len(records)
+
+    def reg2bin(beg, end):
+        end -= 1
+        for shift, first in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+            if beg >> shift == end >> shift:
+                return first + (beg >> shift)
+        return 0
+    bai = bytearray(b"BAI\1" + struct.pack("<i", len(refs)))
+    for tid in range(len(refs)):
+        bins, linear = {}, {}
+        for k, (t, pos, end) in enumerate(index):
+            if t != tid:
+                continue
+            v0, v1 = voffs[k], voffs[k + 1] if k + 1 < len(voffs) else end_voff
+            chunks = bins.setdefault(reg2bin(pos, max(end, pos + 1)), [])
+            if chunks and chunks[-1][1] == v0:
+                chunks[-1][1] = v1
+            else:
+                chunks.append([v0, v1])
+            for w in range(pos >> 14, ((max(end, pos + 1) - 1) >> 14) + 1):
+                linear[w] = min(linear.get(w, v0), v0)
+        bai += struct.pack("<i", len(bins))
+        for b in sorted(bins):
+            bai += struct.pack("<Ii", b, len(bins[b])) + b"".join(struct.pack("<QQ", c0, c1) for c0, c1 in bins[b])
+        n_intv = max(linear) + 1 if linear else 0
+        bai += struct.pack("<i", n_intv)
+        last = 0
+        for w in range(n_intv):
+            last = linear.get(w, last)
+            bai += struct.pack("<Q", last)
+    open(path + ".bai", "wb").write(bytes(bai))
 
 
 def score_diff(aux):

@@ -113,6 +113,38 @@ def test_record_stream_of_several_bam_files(tmp_path, seed):
     assert any(bw.score_diff(r["aux"]) == 0 and any(a[0] == "AS" for a in r["aux"]) and any(a[1] == "B" for a in r["aux"]) for r, _, _ in want)
 
 
+def test_region_through_the_bai_index(tmp_path):
+    """with a .bai beside the file the scan starts where the index says: a member of garbage between the header and the
+    records is never read (without the index the same file fails), the records are the overlapping ones, and a region the
+    index knows nothing about is empty"""
+    rng = np.random.default_rng(5)
+    refs = [("chrA", 400000), ("chrB", 900000)]
+    recs = []
+    for tid in (0, 1):
+        for p in np.sort(rng.integers(0, refs[tid][1] - 400, size=4000)):
+            L = 150
+            codes = rng.choice([1, 2, 4, 8], size=L).astype(np.uint8)
+            recs.append(dict(tid=tid, pos=int(p), codes=codes, flag=0, mapq=60, cigar=[("M", 100), ("D", int(rng.integers(1, 200))), ("M", 50)], mtid=-1, mpos=-1,
+                             tlen=0, aux=[("AS", "C", 100)], rg=None, name="r%d" % len(recs)))
+    header = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
+    span = lambda r: sum(n for op, n in r["cigar"] if op in "MDN=X")
+    path = str(tmp_path / "big.bam")
+    blobs = [bw.record(r["name"], r["flag"], r["tid"], r["pos"], r["mapq"], r["cigar"], r["mtid"], r["mpos"], r["tlen"], r["codes"], r["aux"]) for r in recs]
+    bw.write_bam(path, refs, header, blobs, index=[(r["tid"], r["pos"], r["pos"] + span(r)) for r in recs], poison=True)
+    for region, tid, lo, hi in (("chrB:500001-520000", 1, 500000, 520000), ("chrA:1-3000", 0, 0, 3000), ("chrB:880000-900000", 1, 879999, 900000)):
+        want, _, _ = _expected([recs], [[]], keep=lambda r: r["tid"] == tid and r["pos"] < hi and r["pos"] + span(r) > lo)
+        assert len(want) > 20
+        _check(gtx.Reads([path], region=region), want)
+    import os
+    os.rename(path + ".bai", path + ".hidden")
+    with pytest.raises(gtx.GtxError):  # no index: the scan from the head runs into the garbage
+        gtx.Reads([path], region="chrB:500001-520000")
+    # an index without any bin for the region: nothing to read (and nothing is scanned)
+    bw.write_bam(path, refs, header, blobs[:4000], index=[(r["tid"], r["pos"], r["pos"] + span(r)) for r in recs[:4000]], poison=True)
+    recs_b, _ = gtx.Reads([path], region="chrB:1000-2000").next(10)
+    assert len(recs_b) == 0
+
+
 def test_region_returns_the_overlapping_records(tmp_path):
     files, paths, headers = _random_files(tmp_path, 7)
     lo, hi = 150, 300  # 1-based inclusive region chrB:150-300 = 0-based [149, 300)
