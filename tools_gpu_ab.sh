@@ -14,8 +14,9 @@ import json, glob
 for f in sorted(glob.glob("gpurun_out/ab/*.json")):
     try:
         d = json.loads(open(f).read().strip().splitlines()[-1])
-        r = d["roofline"]["align_passes_ms"]
-        print("%-40s %7.1f M/s  step %6.2f  express %5.2f general %5.2f hbm %5.2f score+calls %6.2f handed %d" % (f.split("/")[-1], d["value"] / 1e6, d["ms_per_step"], r["express"], r["general"], r["hbm_tables"], d["ms_per_step"] - r["all_three_avg"], r["tasks_handed_to_general"]))
+        k = d["roofline"]["align_kernels"]
+        print("%-40s %7.1f M/s  step %6.2f  " % (f.split("/")[-1], d["value"] / 1e6, d["ms_per_step"]) +
+              " ".join("%s %.3f" % (n.replace("gtx_align_", "").replace("_kernel", ""), v["ms"]) for n, v in k.items()))
     except Exception as e:
         print(f, "unreadable", e)
 PY
