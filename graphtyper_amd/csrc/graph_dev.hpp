@@ -42,7 +42,15 @@ struct alignas(16) uint4_t // 16-byte move
 // in; together with GTX_ST_PATH_OVERFLOW it sends the task on, in the end to the pass with GTX_WIDE_MASK_WORDS-word sets
 constexpr uint32_t GTX_ST_WIDE_ALLELE = 32u;
 
+// Wave-uniform sections that write shared state.  Every lane holds the same values there, so on the device all lanes
+// simply execute the section -- 64 identical stores to one address are one store -- which saves the exec-mask save /
+// restore around each of them (the general pass is bound by scalar instructions: one per cycle and CU).  The emulation
+// (and the profiling build, whose counters are incremented inside such sections) runs them on the leader only.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GTX_PROF)
+#define GTX_LEAD
+#else
 #define GTX_LEAD if (W::leader())
+#endif
 
 // Values that are equal on all lanes by construction (loaded from LDS state or from graph tables at a uniform address)
 // are moved to scalar registers: control flow on them then compiles to scalar branches instead of exec-mask juggling.
