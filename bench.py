@@ -402,6 +402,14 @@ def extra_cfg3(args, torch, gtx, synth, device, ref):
     dt, _ = w.run(3, 1, None)
     ms, handed = ctx.pass_times()
     facts = w.result_facts()
+    prof = ctx.profile()
+    if prof[15] > 0:  # GTX_LIB=libgtx_prof.so
+        names = ["load read", "keys + exact probes", "exact labels", "chain exact", "hamming lookup", "chain hamming",
+                 "walk starts", "walk ends", "filters", "record"]
+        tot = float(prof[:10].sum())
+        sys.stderr.write("cfg3-like: phase cycles per task of the general pass (profiling build), %d tasks:\n" % prof[15])
+        for k, nm in enumerate(names):
+            sys.stderr.write("  %-22s %10.0f  %5.1f%%\n" % (nm, prof[k] / float(prof[15]), 100.0 * prof[k] / tot))
     w.close()
     out = {"workload": "cfg3-like: 30 samples, %d reads, 1 Mb, clusters (SNP, SNP, indel) every 150 bp merged into multi-allelic "
                        "sites (add_all_variants), max %d alleles per site" % (n, int(ctx.hap_cnum.max())),
