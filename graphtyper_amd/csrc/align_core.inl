@@ -313,6 +313,37 @@ GTX_DEV uint32_t cmp_codes(SubRead const & sr, uint32_t at, uint8_t const * dna,
   return mism;
 }
 
+// cmp_codes for a piece of at most 64 characters that is already in registers, character k of the compare order in lane k
+// (forward: dna[k]; backward: dna[n-1-k]).  Same counting, same kill rule, no memory access besides the read's codes in LDS.
+template <class W, bool BACKWARD, class Codes>
+GTX_DEV uint32_t cmp_lane_codes(SubRead const & sr, uint32_t at, Codes const & code, uint32_t n, uint32_t mism, uint32_t maxmm)
+{
+  mism = GTX_U(mism);
+  n = GTX_U(n);
+  at = GTX_U(at);
+  if (mism > maxmm)
+    return maxmm + 1;
+  uint32_t const room = at < sr.len ? sr.len - at : 0;
+  uint32_t const m = n < room ? n : room; // (<= 64: the caller's condition)
+  typename W::template PerLane<bool> kill, mm;
+  W::lanes([&](uint32_t l) {
+    bool k = false, x = false;
+    if (l < m)
+    {
+      uint8_t const gc = static_cast<uint8_t>(code[l]);
+      uint8_t const rc = BACKWARD ? sr.rd[sr.begin + sr.len - 1 - at - l] : sr.rd[sr.begin + at + l];
+      k = gc == DNA_KILL;
+      x = gc != rc && rc != 15 && gc != 15;
+    }
+    kill[l] = k;
+    mm[l] = x;
+  });
+  if (W::ballot(kill) != 0)
+    return maxmm + 1;
+  mism += static_cast<uint32_t>(__builtin_popcountll(W::ballot(mm)));
+  return mism > maxmm ? maxmm + 1 : mism;
+}
+
 template <class W>
 GTX_DEV void cand_erase(Cand * c, uint32_t n, uint32_t j)
 {
@@ -467,6 +498,38 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
       uint32_t const rlen = GTX_U(g.ref_len[r]);
       uint32_t const rorder = GTX_U(g.ref_order[r]);
       uint32_t original = n;
+      // The site's tables and bases once, in two round trips for all alleles together (lane i: allele i's order, length and
+      // up to WALK_ALLELE_BYTES of its bases in compare order; lane k: character k of the reference node behind / in front
+      // of the site), instead of three dependent fetches per (candidate, allele) inside the loops below -- on a graph of
+      // merged multi-allelic sites the walk at the read's end was half of the general pass.
+      constexpr uint32_t WALK_ALLELE_BYTES = 16;
+      bool const staged = nv <= 64;
+      typename W::template PerLane<uint32_t> a_order, a_len, a_dna, a_b0, a_b1, a_b2, a_b3, r_code;
+      W::lanes([&](uint32_t l) {
+        uint32_t vo = 0, vl = 0, vd = 0;
+        if (staged && l < nv)
+        {
+          vo = g.var_order[fv + l];
+          vl = g.var_len[fv + l];
+          vd = g.var_dna[fv + l];
+        }
+        a_order[l] = vo;
+        a_len[l] = vl;
+        a_dna[l] = vd;
+        r_code[l] = l < rlen ? static_cast<uint32_t>(BACKWARD ? rdna[rlen - 1 - l] : rdna[l]) : 0u;
+      });
+      W::lanes([&](uint32_t l) {
+        uint32_t b[4] = {0, 0, 0, 0};
+        uint32_t const vl = a_len[l], vd = a_dna[l];
+        if (staged && l < nv && vl <= WALK_ALLELE_BYTES)
+          for (uint32_t k = 0; k < WALK_ALLELE_BYTES; ++k)
+            if (k < vl)
+              b[k >> 2] |= static_cast<uint32_t>(BACKWARD ? dna[vd + vl - 1 - k] : dna[vd + k]) << (8 * (k & 3u));
+        a_b0[l] = b[0];
+        a_b1[l] = b[1];
+        a_b2[l] = b[2];
+        a_b3[l] = b[3];
+      });
       for (uint32_t j = 0; j < original; ++j)
       {
         uint32_t const jlen = GTX_U(cand[j].len), jmism = GTX_U(cand[j].mism), jn = GTX_U(cand[j].nids);
@@ -476,14 +539,31 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
         {
           bool const last = i + 1 == nv; // the last allele extends candidate j in place, the others branch off copies
           uint32_t const v = fv + i;
-          uint32_t const vo = GTX_U(g.var_order[v]), vl = GTX_U(g.var_len[v]);
+          uint32_t const vo = staged ? W::from_lane(a_order, i) : GTX_U(g.var_order[v]);
+          uint32_t const vl = staged ? W::from_lane(a_len, i) : GTX_U(g.var_len[v]);
           uint32_t len = jlen;
-          uint32_t mm = cmp_codes<W, BACKWARD>(sr, len, dna + GTX_U(g.var_dna[v]), vl, jmism, maxmm);
+          uint32_t mm;
+          if (staged && vl <= WALK_ALLELE_BYTES)
+          {
+            uint32_t const w0 = W::from_lane(a_b0, i), w1 = W::from_lane(a_b1, i), w2 = W::from_lane(a_b2, i), w3 = W::from_lane(a_b3, i);
+            typename W::template PerLane<uint32_t> a_code;
+            W::lanes([&](uint32_t l) {
+              uint32_t const w = l < 4 ? w0 : l < 8 ? w1 : l < 12 ? w2 : w3;
+              a_code[l] = (w >> (8 * (l & 3u))) & 255u;
+            });
+            mm = cmp_lane_codes<W, BACKWARD>(sr, len, a_code, vl, jmism, maxmm);
+          }
+          else
+            mm = cmp_codes<W, BACKWARD>(sr, len, dna + (staged ? W::from_lane(a_dna, i) : GTX_U(g.var_dna[v])), vl, jmism, maxmm);
           len += vl;
           bool const enough = len >= L;
           if (!enough)
           {
-            mm = cmp_codes<W, BACKWARD>(sr, len, rdna, rlen, mm, maxmm);
+            // (what is compared of the reference node: its first min(rlen, L - len) characters)
+            if ((rlen < L - len ? rlen : L - len) <= 64)
+              mm = cmp_lane_codes<W, BACKWARD>(sr, len, r_code, rlen, mm, maxmm);
+            else
+              mm = cmp_codes<W, BACKWARD>(sr, len, rdna, rlen, mm, maxmm);
             len += rlen;
           }
           if (mm <= maxmm)

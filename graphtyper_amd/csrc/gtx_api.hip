@@ -34,6 +34,8 @@ struct WaveHip
     f(threadIdx.x & 63u);
   }
   static __device__ inline bool leader() { return (threadIdx.x & 63u) == 0; }
+  // the value lane `lane` (wave-uniform) holds
+  static __device__ inline uint32_t from_lane(PerLane<uint32_t> const & p, uint32_t lane) { return __builtin_amdgcn_readlane(p.v, lane); }
   // value known to be equal on all lanes -> scalar register
   static __device__ inline uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
   static __device__ inline int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -39,6 +39,7 @@ struct WaveEmu
     T & operator[](uint32_t l) { return v[l]; }
     T const & operator[](uint32_t l) const { return v[l]; }
   };
+  static uint32_t from_lane(PerLane<uint32_t> const & p, uint32_t lane) { return p.v[lane]; }
   template <class F>
   static void lanes(F && f)
   {
