@@ -233,12 +233,40 @@ GTX_DEV uint32_t get_locations(GraphView const & g, uint32_t pos, DPath const & 
     if (!(reach + static_cast<int64_t>(g.padding) > static_cast<int64_t>(pos)))
       break; // the reference stops its backward scan here; lower sites reach even less far
     uint32_t const fv = GTX_U(g.ref_first_var[site]), nv = GTX_U(g.ref_nvar[site]);
+    // which alleles hold the position: lane i asks for allele i (one round trip for the site instead of two dependent
+    // fetches per allele), the hits are then taken in allele order
+    unsigned long long hits = 0;
+    typename W::template PerLane<uint32_t> vo_l;
+    if (nv <= 64)
+    {
+      typename W::template PerLane<bool> hit_l;
+      W::lanes([&](uint32_t l) {
+        bool h = false;
+        uint32_t vo = 0;
+        if (l < nv)
+        {
+          vo = g.var_order[fv + l];
+          h = pos >= vo && pos <= vo + g.var_len[fv + l] - 1 &&
+              (path_empty || (l < 32u * AlignCfg::MW && ((path.v[best_j].m[l >> 5] >> (l & 31u)) & 1u)));
+        }
+        hit_l[l] = h;
+        vo_l[l] = vo;
+      });
+      hits = W::ballot(hit_l);
+    }
     for (uint32_t i = 0; i < nv; ++i)
     {
+      if (nv <= 64)
+      {
+        if (hits == 0)
+          break;
+        i = static_cast<uint32_t>(__builtin_ctzll(hits));
+        hits &= hits - 1;
+      }
       uint32_t const v = fv + i;
-      uint32_t const vo = GTX_U(g.var_order[v]);
-      if (pos >= vo && pos <= vo + GTX_U(g.var_len[v]) - 1)
-        if (path_empty || pv_has<W>(path.v[best_j], i))
+      uint32_t const vo = nv <= 64 ? W::from_lane(vo_l, i) : GTX_U(g.var_order[v]);
+      if (nv <= 64 || (pos >= vo && pos <= vo + GTX_U(g.var_len[v]) - 1))
+        if (nv <= 64 || path_empty || pv_has<W>(path.v[best_j], i))
         {
           if (n >= cap)
           {
