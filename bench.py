@@ -55,6 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU baseline (0 = all host hardware threads, max 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the cfg3-like extra workload")
+    ap.add_argument("--read-sets", type=int, default=2, help="resident read sets the steps take in turn (1 = the same reads every step)")
     ap.add_argument("--extra-reads", type=int, default=2_000_000)
     ap.add_argument("--no-hint", action="store_true", help="experiments only: withhold the BAM position from the alignment")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the launch (nccl = RCCL)")
@@ -207,22 +208,11 @@ class Workload:
         self.L = gtx.lib()
         n = int(d_seq.shape[0])
         self.n, self.n_samples = n, n_samples
-        self.d_seq = d_seq
         self.stride = int(d_seq.shape[1])
-        pos_host = d_pos.cpu().numpy().astype(np.int32)
-        meta = np.zeros(n, gtx.READ_META)
-        meta["l_qseq"] = READ_LEN
-        meta["pos"] = pos_host if hint else -1
-        self.d_meta = torch.from_numpy(meta.view(np.uint8).reshape(n, gtx.READ_META.itemsize).copy()).to(device)
-        items = np.zeros(n, gtx.SCORE_ITEM)
-        items["first"]["align_index"] = np.arange(n, dtype=np.uint32)
-        items["first"]["mapq"] = 60
-        items["first"]["flag"] = gtx.FLAG_FORWARD_ONLY  # unpaired reads are aligned forward only (what gtx_stream_push sets)
-        items["first"]["pos"] = pos_host
-        items["second"]["align_index"] = gtx.INVALID_ID
-        if samples is not None:
-            items["sample"] = samples
-        self.d_items = torch.from_numpy(items.view(np.uint8).reshape(n, gtx.SCORE_ITEM.itemsize).copy()).to(device)
+        self.hint, self.samples = hint, samples
+        self.sets = []   # resident read sets (bases, meta, score items); step k works on set k mod len(sets)
+        self.steps_done = 0
+        self.add_reads(d_seq, d_pos)
         self.d_rec = torch.empty(n * 2 * REC_WORDS, dtype=torch.int32, device=device)
         # dense side array of the records (one byte per task): gtx_align_batch_flags / gtx_score_batch_flags
         self.d_flags = torch.zeros(n * 2, dtype=torch.uint8, device=device) if USE_TASK_FLAGS else None
@@ -237,6 +227,27 @@ class Workload:
         self.comm = None       # ncclComm_t made through gtx_comm_init_rank
         self.dist = None       # fallback: torch.distributed on views of the packed block
         self.reduce_kind = None
+
+    def add_reads(self, d_seq, d_pos):
+        """another resident read set of the same size: the steps take the sets in turn, so that no step finds its own
+        reads (or their records) in a cache"""
+        torch, gtx, n = self.torch, self.gtx, self.n
+        assert int(d_seq.shape[0]) == n and int(d_seq.shape[1]) == self.stride
+        pos_host = d_pos.cpu().numpy().astype(np.int32)
+        meta = np.zeros(n, gtx.READ_META)
+        meta["l_qseq"] = READ_LEN
+        meta["pos"] = pos_host if self.hint else -1
+        d_meta = torch.from_numpy(meta.view(np.uint8).reshape(n, gtx.READ_META.itemsize).copy()).to(self.device)
+        items = np.zeros(n, gtx.SCORE_ITEM)
+        items["first"]["align_index"] = np.arange(n, dtype=np.uint32)
+        items["first"]["mapq"] = 60
+        items["first"]["flag"] = gtx.FLAG_FORWARD_ONLY  # unpaired reads are aligned forward only (what gtx_stream_push sets)
+        items["first"]["pos"] = pos_host
+        items["second"]["align_index"] = gtx.INVALID_ID
+        if self.samples is not None:
+            items["sample"] = self.samples
+        d_items = torch.from_numpy(items.view(np.uint8).reshape(n, gtx.SCORE_ITEM.itemsize).copy()).to(self.device)
+        self.sets.append((d_seq, d_meta, d_items))
 
     def close(self):
         if self.comm is not None:
@@ -279,16 +290,18 @@ class Workload:
     def step(self):
         gtx, L, ctx, sp = self.gtx, self.L, self.ctx, self.sp
         torch = self.torch
+        d_seq, d_meta, d_items = self.sets[self.steps_done % len(self.sets)]
+        self.steps_done += 1
         with torch.cuda.stream(self.stream):
             gtx.check(L.gtx_scores_zero(ctx.h, C.byref(self.buf), sp))
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(self.stream)
             fl = self.d_flags.data_ptr() if self.d_flags is not None else None
-            gtx.check(L.gtx_align_batch_flags(ctx.h, self.d_seq.data_ptr(), self.stride, self.d_meta.data_ptr(), self.n, self.d_rec.data_ptr(),
+            gtx.check(L.gtx_align_batch_flags(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, self.d_rec.data_ptr(),
                                               REC_WORDS, fl, sp))
             e1.record(self.stream)
-            gtx.check(L.gtx_score_batch_flags(ctx.h, self.d_items.data_ptr(), self.n, self.d_rec.data_ptr(), REC_WORDS, fl, C.byref(self.buf), sp))
+            gtx.check(L.gtx_score_batch_flags(ctx.h, d_items.data_ptr(), self.n, self.d_rec.data_ptr(), REC_WORDS, fl, C.byref(self.buf), sp))
             if self.comm is not None:
                 gtx.check(L.gtx_scores_reduce(ctx.h, C.byref(self.buf), self.comm, sp))
             elif self.dist is not None:
@@ -399,7 +412,12 @@ def extra_cfg3(args, torch, gtx, synth, device, ref):
     d_seq = torch.from_numpy(gtx.pack_nibbles(codes)).to(device)
     samples = np.random.default_rng(3).integers(0, 30, size=n).astype(np.uint32)
     w = Workload(torch, gtx, ctx, device, d_seq, torch.from_numpy(pos), 30, samples=samples, hint=not args.no_hint)
-    dt, _ = w.run(3, 1, None)
+    if args.read_sets > 1:  # a second set of reads: the steps alternate
+        codes2, pos2 = synth.make_reads(ref, recs, n, read_len=READ_LEN, seed=6, region_begin=REGION_BEGIN)
+        order2 = np.argsort(pos2, kind="stable")
+        w.add_reads(torch.from_numpy(gtx.pack_nibbles(codes2[order2])).to(device), torch.from_numpy(pos2[order2]))
+    steps = 4
+    dt, _ = w.run(steps, 2, None)
     ms, handed = ctx.pass_times()
     facts = w.result_facts()
     prof = ctx.profile()
@@ -413,7 +431,7 @@ def extra_cfg3(args, torch, gtx, synth, device, ref):
     w.close()
     out = {"workload": "cfg3-like: 30 samples, %d reads, 1 Mb, clusters (SNP, SNP, indel) every 150 bp merged into multi-allelic "
                        "sites (add_all_variants), max %d alleles per site" % (n, int(ctx.hap_cnum.max())),
-           "reads_per_s": n * 3 / dt, "ms_per_step": 1000.0 * dt / 3, "sites": int(ctx.n_hap), "ctx_create_s": round(t_ctx, 3),
+           "reads_per_s": n * steps / dt, "ms_per_step": 1000.0 * dt / steps, "steps": steps, "resident_read_sets": len(w.sets), "sites": int(ctx.n_hap), "ctx_create_s": round(t_ctx, 3),
            "graph_build_s": round(t_graph, 3),
            "align_passes_ms": {"express": ms[0], "general": ms[1], "hbm_tables": ms[2]},
            "pass_shares": {"tasks": n, "handed_to_general": handed, "share_general": handed / float(n)}}
@@ -460,6 +478,9 @@ def main(argv=None):
     d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=1234 + rank, device=device, REGION_LEN=args.region_len,
                                         err_rate=args.err, n_rate=args.nrate)
     w = Workload(torch, gtx, ctx, device, d_seq, d_pos, 1, hint=not args.no_hint)
+    for k in range(1, max(args.read_sets, 1)):  # the steps alternate between resident read sets (different reads, same size)
+        w.add_reads(*make_reads_on_device(torch, ref, records, n, seed=1234 + rank + 7919 * k, device=device, REGION_LEN=args.region_len,
+                                          err_rate=args.err, n_rate=args.nrate))
     if dist is not None:
         w.setup_reduce(dist, rank, world, local_rank)
     dt, align_ms = w.run(args.steps, args.warmup, dist)
@@ -504,7 +525,7 @@ def main(argv=None):
                        "timed steps (config.vcf_text; records byte-identical to the oracle's in the tests, unbroken sites)" % (n, READ_LEN, args.snp_every),
            "reads_per_gpu": n, "index_keys": n_keys, "index_labels": n_labels, "haplotypes": ctx.n_hap,
            "ctx_create_s": round(t_ctx_warm, 3), "ctx_create_first_s": round(t_ctx, 3),
-           "position_hint": not args.no_hint, "task_flags_side_array": USE_TASK_FLAGS,
+           "position_hint": not args.no_hint, "task_flags_side_array": USE_TASK_FLAGS, "resident_read_sets": len(w.sets),
            "parallelism": "reads sharded over %d GPU(s), graph+index replicated" % n_gpus,
            "reduce": w.reduce_kind, "reduced_bytes_per_step": w.reduced_bytes if n_gpus > 1 else 0}
     cfg.update(facts)

@@ -125,7 +125,10 @@ struct IndexView
   //                     other allele -- K_i with that base replaced -- passes the HINT_EXACT_OK test with its own label
   //                     (i, i+31, site, allele); bits 8..15: the allele number of base A, C, G, T there (2 bits each,
   //                     0 = not an alternative allele); y bits 16..20: the offset of that base in the k-mer;
-  //     bits 12.. of x  see HINT_SITE_SHIFT: the site K_i's label lies on (HINT_NO_SITE: none);
+  //     HINT_MULTI      (with HINT_EXACT_OK, without HINT_SINGLE_OK) K_i lies over a merged site and 2..HINT_OWN_MAX of its
+  //                     alleles spell it: that many labels, all (i, i+31) on that site; bits 8..15: the set of their
+  //                     allele numbers (all below HINT_MASK_BITS); the neighbours as for HINT_EXACT_OK;
+  //     bits 16.. of x  see HINT_SITE_SHIFT: the site K_i's label lies on (HINT_NO_SITE: none);
   //  y  bits 0..7       min(255, bases from this position to the end of its reference node), 0 = not in a reference node;
   //     bits 8..15      min(255, bases of that node in front of the position).
   // filt[side]: blocked Bloom filter over every indexed key's 16 first (side 0) / last (side 1) bases in nibble form (two
@@ -142,6 +145,8 @@ struct IndexView
 };
 
 constexpr uint32_t HINT_EXACT_OK = 1u, HINT_SINGLE_OK = 2u, HINT_L1 = 4u, HINT_R1 = 8u, HINT_PAR = 16u, HINT_ALT_OK = 32u;
+constexpr uint32_t HINT_MULTI = 64u; // K_i has several labels, all (i, i+31) on one site: bits 8..15 of x are the set of their alleles
+constexpr uint32_t HINT_OWN_MAX = 4u, HINT_MASK_BITS = 8u; // (express4's KS labels per k-mer; the allele numbers the byte holds)
 constexpr uint32_t HINT_ALTIDX_SHIFT = 8u, HINT_SITE_SHIFT = 12u + 4u; // x: flags 0..7, allele numbers 8..15, site 16..31
 constexpr uint32_t HINT_NO_SITE = 0xFFFFu;
 constexpr uint32_t HINT_BACK_SHIFT = 8u, HINT_SNPOFF_SHIFT = 16u; // y

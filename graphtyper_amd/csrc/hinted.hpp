@@ -346,8 +346,8 @@ enum : uint32_t
 
 // one k-mer's verdict in a word: kind (bits 0..1), mm (2: the label comes from the Hamming-1 list, one more mismatch), par (3:
 // the k-mer also starts a parallel chain -- matters when it opens the run behind a hole), allele (4..5) and site (16..31,
-// HINT_NO_SITE: none) of the label
-constexpr uint32_t HK_MM = 4u, HK_PAR = 8u, HK_ALLELE_SHIFT = 4u, HK_SITE_SHIFT = 16u;
+// HINT_NO_SITE: none) of the label; bits 8..15: the allele set of a k-mer with several labels (HINT_MULTI), else 0
+constexpr uint32_t HK_MM = 4u, HK_PAR = 8u, HK_ALLELE_SHIFT = 4u, HK_SET_SHIFT = 8u, HK_SITE_SHIFT = 16u;
 
 GTX_DEV uint32_t hk_make(uint32_t kind, uint32_t site, uint32_t allele, bool mm, bool par)
 {
@@ -376,7 +376,19 @@ GTX_DEV uint32_t hint_kmer(uint2_t const f, uint8_t const * seq4, HintCounts con
   if (amb == 0 && mis == 0)
   {
     GTX_HINT_NOTE((f.x & HINT_EXACT_OK) ? 0 : 1); // exact k-mer, but the place is not provably simple
-    return hk_make((f.x & HINT_EXACT_OK) ? HINT_K_LABEL : HINT_K_DECLINE, site, 0u, false, (f.x & HINT_PAR) != 0);
+    uint32_t const set = (f.x & HINT_MULTI) ? ((f.x >> HINT_ALTIDX_SHIFT) & 255u) << HK_SET_SHIFT : 0u; // (several alleles of a merged site)
+    return hk_make((f.x & HINT_EXACT_OK) ? HINT_K_LABEL : HINT_K_DECLINE, site, 0u, false, (f.x & HINT_PAR) != 0) | set;
+  }
+  if (amb == 2 && mis == 0 && (amb_left == 0 || amb_left == 2))
+  {
+    // two ambiguous bases in one half, the rest == K: the (up to 16) keys of the expansion all carry K's other half,
+    // which K alone has -> of the expansion only K can be indexed, and it is in there when both sets hold its base
+    if (!(amb_left == 2 ? r1 : l1))
+    {
+      GTX_HINT_NOTE(5);
+      return declined;
+    }
+    return hk_make(amb_out == 0 ? HINT_K_LABEL : HINT_K_HOLE, site, 0u, false, true);
   }
   if (amb > 1)
   {
@@ -667,7 +679,17 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   auto append = [&](uint32_t entry)
   {
     if ((entry >> 16) == (last >> 16))
-      clash = clash || entry != last;
+    {
+      // the site again (under the neighbouring k-mer, or the walk's): the allele sets are intersected (path.cpp:38-82)
+      last &= entry | 0xFFFF0000u;
+      clash = clash || (last & 0xFFFFu) == 0;
+      v0 = nvar == 1 ? last : v0;
+      v1 = nvar == 2 ? last : v1;
+      v2 = nvar == 3 ? last : v2;
+      v3 = nvar == 4 ? last : v3;
+      v4 = nvar == 5 ? last : v4;
+      v5 = nvar == 6 ? last : v5;
+    }
     else
     {
       v0 = nvar == 0 ? entry : v0;
@@ -683,7 +705,10 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   auto push = [&](uint32_t k, uint32_t km)
   {
     if (((run >> k) & 1u) && (km >> HK_SITE_SHIFT) != HINT_NO_SITE)
-      append(((km >> HK_SITE_SHIFT) << 16) | (1u << ((km >> HK_ALLELE_SHIFT) & 3u)));
+    {
+      uint32_t const set = (km >> HK_SET_SHIFT) & 255u;
+      append(((km >> HK_SITE_SHIFT) << 16) | (set ? set : 1u << ((km >> HK_ALLELE_SHIFT) & 3u)));
+    }
   };
   if (tail_mask != 0) // (the walk's labels are merged last: their site comes first)
     append((tail_site << 16) | tail_mask);

@@ -42,8 +42,14 @@ GTX_HD void hint_judge_key(HintKeys const & t, uint32_t k, uint32_t & nb, uint32
 {
   nb = 0;
   same = 1;
-  bool const single = t.key_off[k + 1] - t.key_off[k] == 1;
   DevLabel const la = t.labels[t.key_off[k]];
+  // (k's own labels: one, or up to HINT_OWN_MAX on one interval of one site -- the alleles of a merged site that share the k-mer)
+  bool uniform = t.key_off[k + 1] - t.key_off[k] <= HINT_OWN_MAX;
+  for (uint32_t i = t.key_off[k] + 1; i < t.key_off[k + 1] && uniform; ++i)
+  {
+    DevLabel const lb = t.labels[i];
+    uniform = la.site != INVALID && lb.site == la.site && lb.start == la.start && lb.end == la.end;
+  }
   auto look = [&](uint32_t b)
   {
     if (b == k || !hint_distance1(t.keys[k], t.keys[b]))
@@ -52,7 +58,7 @@ GTX_HD void hint_judge_key(HintKeys const & t, uint32_t k, uint32_t & nb, uint32
     for (uint32_t i = t.key_off[b]; i < t.key_off[b + 1]; ++i)
     {
       DevLabel const lb = t.labels[i];
-      if (!single || la.site == INVALID || lb.site != la.site || lb.start != la.start || lb.end != la.end)
+      if (!uniform || la.site == INVALID || lb.site != la.site || lb.start != la.start || lb.end != la.end)
         same = 0;
     }
   };
@@ -83,8 +89,35 @@ GTX_HD bool hint_find_key(HintKeys const & t, uint64_t key, uint32_t & k)
   return lo < t.n_keys && t.keys[lo] == key;
 }
 
-// the verdict express4's seeding rule gives a read k-mer that equals indexed key k: its one label has to be
-// (order, order + 31, site, allele) and its indexed neighbours that same interval on that site
+// the verdict express4's seeding rule gives a read k-mer that equals indexed key k whose labels all lie on (order, order + 31)
+// of one site (hint_own_labels below): its indexed neighbours have to be that same interval on that site
+GTX_HD bool hint_neighbours_ok(HintKeys const & t, uint32_t const * nb, uint8_t const * nb_same, uint32_t k, bool & par)
+{
+  par = nb[k] != 0;
+  return t.lsize[k] <= HINT_HE_CAP && t.rsize[k] <= HINT_HE_CAP && (nb[k] == 0 || (nb_same[k] && nb[k] <= HINT_NB_MAX));
+}
+
+// Key k's labels when there are several: all (order, order + 31) on one site, alleles below HINT_MASK_BITS -> their set
+// (0 = not of that form).  These are the alleles of a merged site that share the k-mer (express4.inl: labels with equal
+// ends are one path whose allele set is the union over the labels).
+GTX_HD uint32_t hint_own_labels(HintKeys const & t, uint32_t k, uint32_t order, uint32_t & site)
+{
+  uint32_t const n = t.key_off[k + 1] - t.key_off[k];
+  if (n < 2 || n > HINT_OWN_MAX)
+    return 0;
+  uint32_t mask = 0;
+  site = t.labels[t.key_off[k]].site;
+  for (uint32_t i = t.key_off[k]; i < t.key_off[k + 1]; ++i)
+  {
+    DevLabel const l = t.labels[i];
+    if (l.start != order || l.end != order + K - 1 || l.site == INVALID || l.site != site || l.allele >= HINT_MASK_BITS)
+      return 0;
+    mask |= 1u << l.allele;
+  }
+  return mask;
+}
+
+// ... and with one label: it has to be (order, order + 31, site, allele)
 GTX_HD bool hint_exact_verdict(HintKeys const & t, uint32_t const * nb, uint8_t const * nb_same, uint32_t k, uint32_t order, uint32_t want_site,
                                 uint32_t want_allele, bool & par)
 {
@@ -93,8 +126,7 @@ GTX_HD bool hint_exact_verdict(HintKeys const & t, uint32_t const * nb, uint8_t 
   DevLabel const l = t.labels[t.key_off[k]];
   if (l.start != order || l.end != order + K - 1 || l.site != want_site || (l.site != INVALID && l.allele != want_allele))
     return false;
-  par = nb[k] != 0;
-  return t.lsize[k] <= HINT_HE_CAP && t.rsize[k] <= HINT_HE_CAP && (nb[k] == 0 || (nb_same[k] && nb[k] <= HINT_NB_MAX));
+  return hint_neighbours_ok(t, nb, nb_same, k, par);
 }
 
 GTX_HD uint32_t hint_two_bits(uint32_t nibble) // A=1 C=2 G=4 T=8 -> 0..3
@@ -123,7 +155,20 @@ GTX_HD uint2_t hint_position_flags(GraphView const & g, HintKeys const & t, uint
     key = (key << 2) | hint_two_bits(c);
   }
   uint32_t k = 0;
-  if (valid && hint_find_key(t, key, k) && t.key_off[k + 1] - t.key_off[k] == 1)
+  bool const found = valid && hint_find_key(t, key, k);
+  if (found && t.key_off[k + 1] - t.key_off[k] > 1 && !g.is_sv_graph)
+  {
+    // the k-mer lies over a merged site and several of its alleles spell it
+    uint32_t msite = INVALID;
+    uint32_t const mask = hint_own_labels(t, k, g.first_order + p, msite);
+    bool par = false;
+    if (mask != 0 && msite < HINT_NO_SITE && hint_neighbours_ok(t, nb, nb_same, k, par))
+    {
+      site = msite;
+      x |= HINT_EXACT_OK | HINT_MULTI | (par ? HINT_PAR : 0u) | (mask << HINT_ALTIDX_SHIFT);
+    }
+  }
+  if (found && t.key_off[k + 1] - t.key_off[k] == 1)
   {
     DevLabel const l = t.labels[t.key_off[k]];
     uint32_t const order = g.first_order + p;

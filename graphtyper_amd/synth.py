@@ -51,19 +51,24 @@ def make_reads(ref, records, n, read_len=150, seed=123, err=0.005, n_rate=0.001,
     Only substitution/indel records produced by make_snp_records / make_indel_records are understood."""
     rng = np.random.default_rng(seed)
     # haplotype 1 = reference with a random half of the records applied
-    hap = []
+    hap, at = [], []  # at: the reference coordinate under every base of haplotype 1 (what a mapper reports as POS)
     cur = 0
     take = rng.random(len(records)) < 0.5
     for (p, r, alts, _), t in zip(records, take):
         p -= region_begin
         hap.append(ref[cur:p])
+        at.append(np.arange(cur, p))
         if t:
             hap.append(np.array(["ACGT".index(c) for c in alts[0]], dtype=np.uint8))
+            at.append(p + np.minimum(np.arange(len(alts[0])), len(r) - 1))
         else:
             hap.append(ref[p:p + len(r)])
+            at.append(np.arange(p, p + len(r)))
         cur = p + len(r)
     hap.append(ref[cur:])
+    at.append(np.arange(cur, len(ref)))
     hap1 = np.concatenate(hap)
+    at1 = np.concatenate(at)
     haps = [ref, hap1]
     which = rng.integers(0, 2, size=n)
     out = np.zeros((n, read_len), dtype=np.uint8)
@@ -74,7 +79,7 @@ def make_reads(ref, records, n, read_len=150, seed=123, err=0.005, n_rate=0.001,
         start = rng.integers(0, len(src) - read_len, size=len(idx))
         gather = start[:, None] + np.arange(read_len)[None, :]
         out[idx] = src[gather]
-        pos[idx] = start + region_begin  # approximate for haplotype 1 (indels shift by a few bp)
+        pos[idx] = (start if h == 0 else at1[start]) + region_begin
     # substitution errors
     e = rng.random(out.shape) < err
     out = np.where(e, (out + rng.integers(1, 4, size=out.shape, dtype=np.uint8)) % 4, out).astype(np.uint8)

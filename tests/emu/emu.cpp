@@ -20,12 +20,13 @@ namespace
 {
 // Sequential stand-in for one wavefront: lane lambdas run for lane 0..63 one after the other, per-lane values are
 // arrays of 64, the wave-uniform parts of the kernel source run once.
-uint64_t g_notes[16]; // why a task left the express pass (W::note), test diagnostics only
+uint64_t g_notes[16];  // why a task left the express pass (W::note), test diagnostics only
+uint64_t g_hnotes[16]; // ... and the position-hinted pass (hint_note)
 
 } // namespace
 namespace gtx
 {
-void hint_note(uint32_t k) { ++g_notes[k & 15u]; }
+void hint_note(uint32_t k) { ++g_hnotes[k & 15u]; }
 } // namespace gtx
 namespace
 {
@@ -344,6 +345,16 @@ extern "C"
       out[i] = g_notes[i];
       if (reset)
         g_notes[i] = 0;
+    }
+  }
+
+  void emu_hint_notes(uint64_t * out, int reset)
+  {
+    for (int i = 0; i < 16; ++i)
+    {
+      out[i] = g_hnotes[i];
+      if (reset)
+        g_hnotes[i] = 0;
     }
   }
 

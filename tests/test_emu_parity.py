@@ -95,11 +95,38 @@ def iupac_case(Backend, n_reads):
     codes[dense, 40:60] = 15
     o = Oracle(ref, recs, region_begin=1000)
     b = Backend(gtx.graph_from_records(ref, recs, region_begin=1000))
-    check_align(b, o, list(codes))
+    check_align(b, o, list(codes), pos=pos)
 
 
 def test_align_iupac_codes():
     iupac_case(harness.EmuBackend, 3000)
+
+
+def two_ambiguous_case(Backend, n_reads):
+    """two ambiguity codes in one k-mer: in the same half (the position-hinted pass proves the result from the other
+    half) or one in each (left to the global lookups); sets with and without the true base"""
+    ref, recs, codes, pos = scenarios.synthetic_case("snp1k", n_ref=40000, n_reads=n_reads, region_begin=1000, n_rate=0.0)
+    rng = np.random.default_rng(12)
+    codes = codes.copy()
+    same_half = 0
+    for c in codes:
+        k, half = int(rng.integers(0, 4)), int(rng.integers(0, 2))
+        a, b2 = rng.choice(16, size=2, replace=False)
+        split = rng.random() < 0.3
+        at = [31 * k + 16 * half + int(a), 31 * k + 16 * (half ^ 1 if split else half) + int(b2)]
+        same_half += not split
+        for x in at:
+            r = rng.random()
+            c[x] = 15 if r < 0.6 else (c[x] | int(rng.integers(1, 16))) if r < 0.85 else int(rng.integers(1, 16))
+    o = Oracle(ref, recs, region_begin=1000)
+    b = Backend(gtx.graph_from_records(ref, recs, region_begin=1000))
+    check_align(b, o, list(codes), pos=pos)
+    return check_align.hinted_done, same_half
+
+
+def test_two_ambiguous_bases_in_one_kmer():
+    done, same_half = two_ambiguous_case(harness.EmuBackend, 1500)
+    assert done > same_half // 2, "the position-hinted pass takes none of the k-mers with two ambiguous bases in one half"
 
 
 def run_stream(backend, oracle, codes, rec, n_samples, n_rg=1):
@@ -204,7 +231,9 @@ def test_align_and_score_on_merged_multiallelic_graph():
     g = gtx.graph_from_records(ref, recs, region_begin=20000, add_all_variants=True)
     assert int(g["ref_nvar"].max()) >= 6
     b = harness.EmuBackend(g)
-    check_align(b, o, list(codes))
+    check_align(b, o, list(codes), pos=pos)
+    # (608 of 4000 without the k-mers that several alleles of a merged site spell, HINT_MULTI; 700 with them)
+    assert check_align.hinted_done > 650, "the position-hinted pass does not take k-mers over merged sites"
     rec = scenarios.stream_records(len(codes), pos, sample=np.arange(len(codes)) % 3)
     order = np.argsort(pos, kind="stable")
     run_stream(b, o, codes[order], rec[order], n_samples=3)
