@@ -649,7 +649,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_WIDE_WAV
 
 // Pass 2 (general): the queued tasks through the full algorithm over LDS tables.  A task that exceeds them goes on to
 // pass 3 (gtx_align_big_kernel).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void gtx_align_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
+#ifndef GTX_GENERAL_WAVES
+#define GTX_GENERAL_WAVES 5 // resident waves per SIMD the register budget of the general pass is set for
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_GENERAL_WAVES))) void gtx_align_kernel(GraphView g, IndexView ix, uint8_t const * __restrict__ seq,
                                                        uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
                                                        uint32_t * __restrict__ records, uint32_t rec_words,
                                                        uint32_t const * __restrict__ queue, uint32_t const * queue_count,
