@@ -220,3 +220,10 @@ def bam_to_calls_case(Backend, tmp_path):
 def test_bam_files_to_vcf_text(tmp_path):
     text = bam_to_calls_case(harness.EmuBackend, tmp_path)
     assert b"person0\tperson1" in text.split(b"\n")[0] and b"\t0/1:" in text
+
+
+def test_damaged_bam_files_are_refused_not_crashed_on(tmp_path):
+    """a few seeds of tests/fuzz_bam.py: damaged records, headers, BGZF members and truncated files end in GTX_ERR_* (or in
+    the records that are still readable), never in a crash of the calling process"""
+    import fuzz_bam
+    assert fuzz_bam.run(0, 24, tmp=str(tmp_path)) == 0

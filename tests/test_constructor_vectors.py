@@ -127,3 +127,10 @@ def test_sv_deletion_graph_equals_the_oracles():
     k1, c1, l1 = o.index_dump()
     k2, c2, l2 = c.index_dump()
     assert np.array_equal(k1, k2) and np.array_equal(c1, c2) and np.array_equal(l1, l2)
+
+
+def test_damaged_input_files_are_refused_not_crashed_on(tmp_path):
+    """a few seeds of tests/fuzz_files.py: damaged VCF lines and fields, FASTA index and FASTA bytes, truncated files end in
+    GTX_ERR_* (or in the graph of what is still readable), never in a crash of the calling process"""
+    import fuzz_files
+    assert fuzz_files.run(0, 20, tmp=str(tmp_path)) == 0
