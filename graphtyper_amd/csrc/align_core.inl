@@ -2019,8 +2019,37 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
       else
       {
         uint32_t nk = 0;
+        n_lbl = 0;
         uint32_t const amb = GTX_U(ws.off0[i]);
-        if ((amb & (amb - 1u)) == 0u)
+        if ((amb & (amb - 1u)) == 0u && i < AlignCfg::MAX_KMERS && GTX_U(ws.acnt[i][0]) != 0xFFFFFFFFu)
+        {
+          // One ambiguous base: seed_stage probed the 2..4 keys of its list with all the other lookups of the read (ws.acnt /
+          // ws.aoff, in to_uint64_vec order) -- no second visit to the index, the labels are one fetch away (or staged already).
+          uint32_t const c0 = GTX_U(ws.acnt[i][0]), c1 = GTX_U(ws.acnt[i][1]), c2 = GTX_U(ws.acnt[i][2]), c3 = GTX_U(ws.acnt[i][3]);
+          uint32_t const total = c0 + c1 + c2 + c3;
+          n_lbl = total;
+          if (total > ix.max_index_labels)
+            n_lbl = 0; // multi_get: a list of several keys with more hits than that yields nothing (ph_index.cpp:84-89)
+          else if (total > AlignCfg::LBL_CAP)
+          {
+            status |= GTX_ST_LABEL_OVERFLOW;
+            break;
+          }
+          else if (total != 0)
+          {
+            uint32_t const o0 = GTX_U(ws.aoff[i][0]), o1 = GTX_U(ws.aoff[i][1]), o2 = GTX_U(ws.aoff[i][2]), o3 = GTX_U(ws.aoff[i][3]);
+            bool const staged = total == 1 && i < kc && GTX_U(ws.cnt0[i]) == 1; // (seed_stage put the one label into ws.xl[i][0])
+            for (uint32_t b = 0; b < total; b += 64)
+              W::lanes([&](uint32_t l) {
+                uint32_t const e = b + l;
+                if (e < total)
+                  ws.lbl[e] = staged ? ws.xl[i][0]
+                                     : ix.labels[e < c0 ? o0 + e : e < c0 + c1 ? o1 + (e - c0) : e < c0 + c1 + c2 ? o2 + (e - c0 - c1) : o3 + (e - c0 - c1 - c2)];
+              });
+            W::lds_sync();
+          }
+        }
+        else if ((amb & (amb - 1u)) == 0u)
         {
           // one ambiguous base (nearly always a single N): to_uint64_vec's list is the key with the LAST admissible base
           // at that position followed by the other admissible bases in ascending order (type_conversions.cpp:207-266:
@@ -2047,6 +2076,37 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
           });
           W::lds_sync();
         }
+        else if (__builtin_popcount(amb) == 2)
+        {
+          // Two ambiguous bases A (first in the read) and B: after A the list is [last(A), the other bases of A ascending];
+          // B replaces every entry by its version with last(B) and appends, entry by entry, the versions with B's other
+          // bases ascending (the same rule applied to a list of |A| keys) -- at most 16 keys, one per lane.
+          uint32_t const ta = static_cast<uint32_t>(__builtin_ctz(amb)), tb = 31u - static_cast<uint32_t>(__builtin_clz(amb));
+          uint32_t const ca = GTX_U(static_cast<uint32_t>(ws.rd[rs + ta])) & 15u, cb = GTX_U(static_cast<uint32_t>(ws.rd[rs + tb])) & 15u;
+          uint32_t const sa = (ca == 0u || ca == 15u) ? 15u : ca, sb = (cb == 0u || cb == 15u) ? 15u : cb;
+          uint32_t const la = 31u - static_cast<uint32_t>(__builtin_clz(sa)), lb = 31u - static_cast<uint32_t>(__builtin_clz(sb));
+          uint32_t const ma = static_cast<uint32_t>(__builtin_popcount(sa)), mb = static_cast<uint32_t>(__builtin_popcount(sb));
+          nk = ma * mb;
+          uint64_t const base = GTX_U(ws.key0[i]);
+          auto other = [](uint32_t set, uint32_t last, uint32_t k) // the k-th smallest base of the set without its last one
+          {
+            uint32_t rest = set & ~(1u << last);
+            for (uint32_t j = 0; j < k; ++j)
+              rest &= rest - 1u;
+            return static_cast<uint32_t>(__builtin_ctz(rest));
+          };
+          W::lanes([&](uint32_t l) {
+            if (l < nk)
+            {
+              uint32_t const u = l < ma ? l : (l - ma) / (mb - 1u);
+              uint32_t const ba = u == 0 ? la : other(sa, la, u - 1u);
+              uint32_t const bb = l < ma ? lb : other(sb, lb, (l - ma) % (mb - 1u));
+              ws.u.keybuf[l] = base | (static_cast<uint64_t>(ba & 1u) << ta) | (static_cast<uint64_t>(ba >> 1) << (32u + ta)) |
+                               (static_cast<uint64_t>(bb & 1u) << tb) | (static_cast<uint64_t>(bb >> 1) << (32u + tb));
+            }
+          });
+          W::lds_sync();
+        }
         else
         {
           GTX_LEAD
@@ -2062,7 +2122,8 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
             break;
           }
         }
-        n_lbl = probe_list<W>(ix, ws, false, 0, nk, status);
+        if (nk != 0)
+          n_lbl = probe_list<W>(ix, ws, false, 0, nk, status);
         if (status)
           break;
       }
