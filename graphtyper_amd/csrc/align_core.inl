@@ -1228,6 +1228,29 @@ GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, ui
           nl = 0;
       }
     }
+    if (!shortcut && starts && g.pos_info && g.pos_back && !g_is_special(g, anchor) && anchor >= g.first_order && g.n_ref > 1 &&
+        anchor - g.first_order < g.n_pos_info && sr.len <= 255)
+    {
+      // ... and backwards: the node has to reach far enough in front of the anchor (pos_back, capped at 255)
+      uint32_t const w = GTX_U(g.pos_info[anchor - g.first_order]);
+      uint32_t const back = GTX_U(static_cast<uint32_t>(g.pos_back[anchor - g.first_order]));
+      if (w != INVALID && back >= sr.len - 1)
+      {
+        shortcut = true;
+        uint8_t const * dna = reinterpret_cast<uint8_t const *>(g.dna) + (w >> 8) - (sr.len - 1); // (its last character is the anchor's)
+        uint32_t const budget = mm;
+        uint32_t const got = cmp_codes<W, true>(sr, 0, dna, sr.len, 0, budget);
+        if (got <= budget)
+        {
+          mm = got;
+          nl = 1;
+          GTX_LEAD wb.dfs_out[0] = DevLabel{anchor - (sr.len - 1), anchor, INVALID, 0};
+          W::lds_sync();
+        }
+        else
+          nl = 0;
+      }
+    }
     if (!shortcut && !g_is_special(g, anchor) && anchor >= g.first_order && g.n_ref > 1)
     {
       uint32_t const rr = g_ref_node_at<W>(g, anchor);
