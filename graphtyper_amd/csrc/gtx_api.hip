@@ -565,21 +565,27 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
     uint32_t *queue1_count, uint32_t *__restrict__ queue2, uint32_t *queue2_count, uint32_t decline_all, uint8_t *__restrict__ task_flags
 #define GTX_HINTED_PASS(W) hinted_pass<W>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, queue1, queue1_count, queue2, queue2_count, decline_all, task_flags)
 
+#ifndef GTX_HINT_VGPRS
+#define GTX_HINT_VGPRS 80
+#endif
 #ifndef GTX_HINT_WAVES
 // Wavefronts per workgroup of the position-hinted pass.  A workgroup's LDS (6.4 KB per wavefront) is held until its last
 // wavefront is through: with 16-wave workgroups one fits a CU and every workgroup's start (nothing to overlap the first
-// loads with) and end are paid with idle SIMDs; three 8-wave workgroups per CU overlap them (0.845 -> 0.78 ms at cfg2).
-#define GTX_HINT_WAVES 8
+// loads with) and end are paid with idle SIMDs; several small workgroups per CU overlap them (cfg2: 16 waves 0.845 ms,
+// 8 waves 0.77-0.78, 4 waves with 80 registers -- six resident workgroups -- 0.755).
+#define GTX_HINT_WAVES 4
 #endif
-__global__ __launch_bounds__(64 * GTX_HINT_WAVES) void gtx_align_hinted_kernel(GTX_HINTED_ARGS)
+// (80 registers: six wavefronts per SIMD = three of these workgroups per CU, which their LDS also allows; the compiler
+// takes 83-85 when left alone -- allocated as 88: five wavefronts, two workgroups)
+__global__ __launch_bounds__(64 * GTX_HINT_WAVES) __attribute__((amdgpu_num_vgpr(GTX_HINT_VGPRS))) void gtx_align_hinted_kernel(GTX_HINTED_ARGS)
 {
   GTX_HINTED_PASS(GTX_HINT_WAVES);
 }
 
-// (other workgroup sizes for A/B runs: GTX_HINT_WAVES=4 / 16 in the environment)
-__global__ __launch_bounds__(256) void gtx_align_hinted4_kernel(GTX_HINTED_ARGS)
+// (other workgroup sizes for A/B runs: GTX_HINT_WAVES=8 / 16 in the environment)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(GTX_HINT_VGPRS))) void gtx_align_hinted8_kernel(GTX_HINTED_ARGS)
 {
-  GTX_HINTED_PASS(4);
+  GTX_HINTED_PASS(8);
 }
 
 __global__ __launch_bounds__(1024) void gtx_align_hinted16_kernel(GTX_HINTED_ARGS)
@@ -1386,9 +1392,9 @@ extern "C" int gtx_align_batch_flags(gtx_ctx * c, const uint8_t * d_seq, uint32_
     {
       // pass 0: one read per lane from the position hint; what it declines is queued for pass 1.  (GTX_HINT=decline: the
       // pass runs but declines everything -- a test of the queue plumbing)
-      char const * hw = std::getenv("GTX_HINT_WAVES"); // A/B switch: wavefronts per workgroup of pass 0 (4, 16; default 8)
-      uint32_t const hint_threads = hw && hw[0] == '4' ? 256u : hw && hw[0] == '1' ? 1024u : 64u * GTX_HINT_WAVES;
-      hipLaunchKernelGGL(hint_threads == 256u ? gtx_align_hinted4_kernel : hint_threads == 1024u ? gtx_align_hinted16_kernel : gtx_align_hinted_kernel,
+      char const * hw = std::getenv("GTX_HINT_WAVES"); // A/B switch: wavefronts per workgroup of pass 0 (8, 16; default 4)
+      uint32_t const hint_threads = hw && hw[0] == '8' ? 512u : hw && hw[0] == '1' ? 1024u : 64u * GTX_HINT_WAVES;
+      hipLaunchKernelGGL(hint_threads == 512u ? gtx_align_hinted8_kernel : hint_threads == 1024u ? gtx_align_hinted16_kernel : gtx_align_hinted_kernel,
                          dim3((n + hint_threads - 1u) / hint_threads), dim3(hint_threads), 0, st, c->dev_graph, c->dev_index, seq, seq_stride,
                          meta, n, records, rec_words, force_both, queue1, counters + 3, queue2, counters + 2,
                          static_cast<uint32_t>(force != 0 || (eh && eh[0] == 'd')) | (eh && eh[0] == 'x' ? 2u : 0u),
