@@ -386,6 +386,7 @@ GTX_DEV bool emit_best(GraphView const & g, Cand const * cand, uint32_t n, uint3
                        DevLabel * out, uint32_t & n_out, uint32_t out_cap, uint32_t & status)
 {
   uint32_t const first_out = n_out;
+  constexpr uint32_t PENDING = 0xFFFFFFFFu; // (no allele number reaches this: a site has at most a few thousand)
   for (uint32_t j = 0; j < n; ++j)
   {
     if (GTX_U(cand[j].len) < L)
@@ -413,14 +414,28 @@ GTX_DEV bool emit_best(GraphView const & g, Cand const * cand, uint32_t n, uint3
       ++n_out;
     }
     else
-      for (uint32_t k = 0; k < nids; ++k)
-      {
-        uint32_t const v = GTX_U(cand[j].ids[k]);
-        uint32_t const vs = GTX_U(g.var_out_ref[v]) - 1;
-        GTX_LEAD out[n_out] = DevLabel{s, e, vs, v - GTX_U(g.ref_first_var[vs])};
-        ++n_out;
-      }
+    {
+      // the variant node of every label for now (allele = PENDING); site and allele number are looked up for all labels
+      // together below -- two dependent fetches in all instead of two per label, one after the other
+      W::lanes([&](uint32_t l) {
+        for (uint32_t k = l; k < nids; k += 64)
+          out[n_out + k] = DevLabel{s, e, cand[j].ids[k], PENDING};
+      });
+      n_out += nids;
+    }
   }
+  W::lds_sync();
+  for (uint32_t b = first_out; b < n_out; b += 64)
+    W::lanes([&](uint32_t l) {
+      uint32_t const k = b + l;
+      if (k < n_out && out[k].allele == PENDING && out[k].site != INVALID)
+      {
+        uint32_t const v = out[k].site;
+        uint32_t const vs = g.var_out_ref[v] - 1;
+        out[k].site = vs;
+        out[k].allele = v - g.ref_first_var[vs];
+      }
+    });
   W::lds_sync();
   return true;
 }
@@ -447,6 +462,10 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
       uint32_t const vout = GTX_U(g.var_out_ref[v]);
       uint32_t const vsite = vout - 1;
       uint32_t const vo = GTX_U(g.var_order[v]), vl = GTX_U(g.var_len[v]), vd = GTX_U(g.var_dna[v]);
+      // (the tables of the reference node that follows / precedes the allele are fetched before the allele is compared: one
+      // round trip instead of one per table behind the compare)
+      uint32_t const r = BACKWARD ? vsite : vout;
+      uint32_t const rl = GTX_U(g.ref_len[r]), rdo = GTX_U(g.ref_dna[r]), rord = GTX_U(g.ref_order[r]), rnv = GTX_U(g.ref_nvar[r]);
       if (!BACKWARD)
       {
         len = vl - s_offset;
@@ -455,12 +474,10 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
           pos = ug_special_of<W>(g, vsite, (vo + vl - 1) - (len - L));
         else
         {
-          uint32_t const r = vout;
-          uint32_t const rl = GTX_U(g.ref_len[r]);
-          mism = cmp_codes<W, false>(sr, len, dna + GTX_U(g.ref_dna[r]), rl, mism, maxmm);
+          mism = cmp_codes<W, false>(sr, len, dna + rdo, rl, mism, maxmm);
           len += rl;
-          pos = (GTX_U(g.ref_order[r]) + rl - 1) - (len - L);
-          if (GTX_U(g.ref_nvar[r]) > 0)
+          pos = (rord + rl - 1) - (len - L);
+          if (rnv > 0)
             site = r;
         }
       }
@@ -472,11 +489,9 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
           pos = ug_special_of<W>(g, vsite, vo + (len - L));
         else
         {
-          uint32_t const r = vsite;
-          uint32_t const rl = GTX_U(g.ref_len[r]);
-          mism = cmp_codes<W, true>(sr, len, dna + GTX_U(g.ref_dna[r]), rl, mism, maxmm);
+          mism = cmp_codes<W, true>(sr, len, dna + rdo, rl, mism, maxmm);
           len += rl;
-          pos = GTX_U(g.ref_order[r]) + (len - L);
+          pos = rord + (len - L);
           if (r != 0)
             site = r - 1;
         }
@@ -485,13 +500,13 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
     else
     {
       uint32_t const r = s_node;
-      uint32_t const rl = GTX_U(g.ref_len[r]), rd_ = GTX_U(g.ref_dna[r]);
+      uint32_t const rl = GTX_U(g.ref_len[r]), rd_ = GTX_U(g.ref_dna[r]), rnv = GTX_U(g.ref_nvar[r]); // (one round trip)
       if (!BACKWARD)
       {
         len = rl - s_offset;
         mism = cmp_codes<W, false>(sr, 0, dna + rd_ + s_offset, len, 0, maxmm);
         pos = (s_order + rl - 1) - (len - L); // s_order is the node's order
-        if (GTX_U(g.ref_nvar[r]) > 0)
+        if (rnv > 0)
           site = r;
       }
       else
@@ -525,6 +540,10 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
       uint8_t const * rdna = dna + GTX_U(g.ref_dna[r]);
       uint32_t const rlen = GTX_U(g.ref_len[r]);
       uint32_t const rorder = GTX_U(g.ref_order[r]);
+      // (with them, in the same round trip: what the end of the round and the special positions of the site ask for)
+      uint32_t const r_nvar = GTX_U(g.ref_nvar[r]);
+      uint32_t const s_reach = GTX_U(g.site_ref_reach[site]), s_base = GTX_U(g.site_special_base[site]);
+      auto special_of = [&](uint32_t p) { return p > s_reach ? SPECIAL_START + s_base + (p - s_reach - 1) : p; }; // (g_special_of)
       uint32_t original = n;
       // The site's tables and bases once, in two round trips for all alleles together (lane i: allele i's order, length and
       // up to WALK_ALLELE_BYTES of its bases in compare order; lane k: character k of the reference node behind / in front
@@ -603,9 +622,9 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
             }
             uint32_t pos;
             if (!BACKWARD)
-              pos = enough ? ug_special_of<W>(g, site, (vo + vl - 1) - (len - L)) : (rorder + rlen - 1) - (len - L);
+              pos = enough ? special_of((vo + vl - 1) - (len - L)) : (rorder + rlen - 1) - (len - L);
             else
-              pos = enough ? ug_special_of<W>(g, site, vo + (len - L)) : rorder + (len - L);
+              pos = enough ? special_of(vo + (len - L)) : rorder + (len - L);
             uint32_t const dst = last ? j : n;
             if (!last)
             {
@@ -637,7 +656,7 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
       if (all_long)
         break;
       if (!BACKWARD)
-        site = GTX_U(g.ref_nvar[r]) > 0 ? r : INVALID;
+        site = r_nvar > 0 ? r : INVALID;
       else
       {
         if (r == 0)
