@@ -4,10 +4,12 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <map>
 #include <tuple>
 #include <string>
+#include <thread>
 #include <unordered_map>
 
 #include "gtx_ctx.hpp"
@@ -74,11 +76,34 @@ extern "C"
         t_last = now;
       };
       std::vector<Emit> em;
-      enumerate_kmers(c->graph, em);
-      lap("enumerate k-mers (host)");
       HintGraphTables gt;
-      hint_graph_tables(c->graph, gt);
-      lap("graph hint arrays (host)");
+      {
+        // (the graph's own hint arrays are a serial pass over its positions, ~10 ms per Mb: beside the enumeration)
+        std::exception_ptr side_error;
+        std::thread side([&] {
+          try
+          {
+            hint_graph_tables(c->graph, gt);
+          }
+          catch (...)
+          {
+            side_error = std::current_exception();
+          }
+        });
+        try
+        {
+          enumerate_kmers(c->graph, em);
+        }
+        catch (...)
+        {
+          side.join();
+          throw;
+        }
+        side.join();
+        if (side_error)
+          std::rethrow_exception(side_error);
+      }
+      lap("enumerate k-mers + graph hint arrays (host)");
       int rc = ctx_upload(*c, device);
       lap("graph upload + scratch");
       if (rc == GTX_OK)

@@ -701,7 +701,11 @@ void build_index(HostGraph const & g, HostIndex & out)
 void enumerate_kmers(HostGraph const & g, std::vector<Emit> & em)
 {
   uint32_t const R = static_cast<uint32_t>(g.ref_order.size());
-  unsigned const T = R < 64 ? 1u : host_threads();
+  // (the one stage of a device context's build that is still on the host; its slices are long and independent, so it takes
+  // a larger team than the other stages: 8 / 16 / 32 / 64 threads = 62 / 42 / 28 / 22 ms on the merged-cluster graph)
+  unsigned T = R < 64 ? 1u : host_threads();
+  if (T > 1 && !std::getenv("GTX_HOST_THREADS"))
+    T = std::max(T, std::min(std::thread::hardware_concurrency(), 64u));
   std::vector<std::vector<Emit>> part(T);
   // ranges of equal sequence length
   std::vector<uint32_t> cut(T + 1, R);
