@@ -157,7 +157,7 @@ constexpr uint32_t HINT_TAIL_OK = 1u, HINT_TAIL_NALL_SHIFT = 2u, HINT_TAIL_NEXT_
 // pass 1 runs behind pass 0: neighbours on the k-mer's own interval and site end where the chain ends, whatever their number.)
 constexpr uint32_t HINT_HE_CAP = 16, HINT_NB_MAX = 16;
 
-// hash of a 16-base half in nibble form (w0 = bases 0..7, w1 = bases 8..15; base j in bits 28-4j) -> (word, two-bit mask)
+// hash of a 16-base half in nibble form (w0 = bases 0..7, w1 = bases 8..15; base j in bits 28-4j) -> (word, mask of up to four bits)
 // of the blocked Bloom filter
 #if defined(__HIPCC__)
 __host__ __device__
@@ -172,7 +172,10 @@ inline void hint_filter_slot(uint32_t w0, uint32_t w1, uint32_t log2_words, uint
   h *= 0x85EBCA77u;
   h ^= h >> 16;
   word = log2_words >= 32 ? h : h >> (32 - log2_words);
-  mask = (1u << (h & 31u)) | (1u << ((h >> 5) & 31u)); // (log2_words <= 22: bits the word index does not use)
+  // four bits of the word, from a second mix (32 bits per key and side: a word is about an eighth full, four bits make a
+  // chance hit of a half that occurs nowhere rare; with two bits it was ~1 % of the probes: 8 % of what the pass declined at cfg2)
+  uint32_t const h2 = h * 0x9E3779B1u;
+  mask = (1u << (h2 >> 27)) | (1u << ((h2 >> 22) & 31u)) | (1u << ((h2 >> 17) & 31u)) | (1u << ((h2 >> 12) & 31u));
 }
 
 struct HostGraph
