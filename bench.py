@@ -488,6 +488,13 @@ def extra_cfg3(args, torch, gtx, synth, device, ref):
         sys.stderr.write("cfg3-like: phase cycles per task of the general pass (profiling build), %d tasks:\n" % prof[15])
         for k, nm in enumerate(names):
             sys.stderr.write("  %-22s %10.0f  %5.1f%%\n" % (nm, prof[k] / float(prof[15]), 100.0 * prof[k] / tot))
+    if prof[31] > 0:
+        names = ["unpack reads", "keys", "index lookups", "half-key entries", "seeding verdict", "run + walk geometry", "compares",
+                 "indel-tail compares", "verdict + record"]
+        tot = float(prof[16:25].sum())
+        sys.stderr.write("cfg3-like: phase cycles per group of four reads of the express pass (profiling build), %d groups:\n" % prof[31])
+        for k, nm in enumerate(names):
+            sys.stderr.write("  %-22s %10.0f  %5.1f%%\n" % (nm, prof[16 + k] / float(prof[31]), 100.0 * prof[16 + k] / tot))
     w.close()
     out = {"workload": "cfg3-like: 30 samples, %d reads, 1 Mb, clusters (SNP, SNP, indel) every 150 bp merged into multi-allelic "
                        "sites (add_all_variants), max %d alleles per site" % (n, int(ctx.hap_cnum.max())),
@@ -557,6 +564,13 @@ def main(argv=None):
         sys.stderr.write("phase cycles per task of the general pass (profiling build), %d tasks:\n" % prof[15])
         for k, nm in enumerate(names):
             sys.stderr.write("  %-22s %10.0f  %5.1f%%\n" % (nm, prof[k] / float(prof[15]), 100.0 * prof[k] / tot))
+    if rank == 0 and prof[31] > 0:
+        names = ["unpack reads", "keys", "index lookups", "half-key entries", "seeding verdict", "run + walk geometry", "compares",
+                 "indel-tail compares", "verdict + record"]
+        tot = float(prof[16:25].sum())
+        sys.stderr.write("phase cycles per group of four reads of the express pass (profiling build), %d groups:\n" % prof[31])
+        for k, nm in enumerate(names):
+            sys.stderr.write("  %-22s %10.0f  %5.1f%%\n" % (nm, prof[16 + k] / float(prof[31]), 100.0 * prof[16 + k] / tot))
     if rank != 0:
         w.close()
         if dist is not None:

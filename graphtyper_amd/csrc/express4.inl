@@ -99,6 +99,10 @@ struct Express4Workspace
   uint64_t kmask[4][AlignCfg::KC][E4::KS];
   uint32_t vsite[4][E4::VS_CAP]; // the path's sites in record order (built by the leader lane)
   uint64_t vmask[4][E4::VS_CAP];
+  uint8_t nbk[4][8];             // SLOT_NB_KNOWN of every k-mer's exact slot (the neighbours' labels need not be fetched)
+#ifdef GTX_PROF
+  unsigned long long prof_acc[16]; // phase cycles of the profiling build (libgtx_prof.so)
+#endif
 };
 
 #ifdef GTX_EMU_NOTES // diagnostics of the host emulation (tests/emu): why a task leaves this pass
@@ -126,16 +130,34 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
   using PU = typename W::template PerLane<uint32_t>;
   constexpr uint32_t KC = AlignCfg::KC, HE_CAP = AlignCfg::HE_CAP;
   bool const use_halves = ix.half_bucket_cap != 0;
+  GTX_PROF_BEGIN
 
   // ---- per group: the read, whether it is a candidate at all
   PB alive_l, pass2_l;
   PU len_l, nk_l, read_l;
+  // (the lane's share of the packed bases -- two bytes per round of the unpacking below -- is fetched together with the
+  // read's length: both hang on the read number only, and fetching the bases behind the length was a third of this pass'
+  // first phase)
+  static_assert(AlignCfg::MAX_READ / 64 == 4, "four rounds of 64 bases: two 32-bit words of raw bytes per lane");
+  PU raw01_l, raw23_l;
   W::lanes([&](uint32_t l) {
     uint32_t const gi = l >> 4;
     bool const valid = gi < n_valid;
     uint32_t const read = !valid ? 0u : rid ? rid[gi] : first + gi;
     read_l[l] = read;
     uint32_t const len = valid ? static_cast<uint32_t>(meta[read].l_qseq) : 0u;
+    {
+      uint8_t const * seq4 = seq + static_cast<uint64_t>(read) * seq_stride;
+      uint32_t raw[4];
+      for (uint32_t it = 0; it < 4; ++it)
+      {
+        uint32_t const at = 2 * (it * 16 + (l & 15u));
+        uint32_t const b0 = (valid && at < seq_stride) ? seq4[at] : 0u, b1 = (valid && at + 1 < seq_stride) ? seq4[at + 1] : 0u;
+        raw[it] = b0 | (b1 << 8);
+      }
+      raw01_l[l] = raw[0] | (raw[1] << 16);
+      raw23_l[l] = raw[2] | (raw[3] << 16);
+    }
     bool const too_short = len < 2 * K - 1, too_long = len > AlignCfg::MAX_READ;
     uint32_t const n_k = len < K ? 0 : 1 + (len - K) / (K - 1);
     if (valid && (too_short || too_long) && (l & 15u) == 0)
@@ -166,7 +188,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
       uint32_t const gi = l >> 4, word = it * 16 + (l & 15u), len = len_l[l];
       if (alive_l[l] && 4 * word < len)
       {
-        uint8_t const * seq4 = seq + static_cast<uint64_t>(read_l[l]) * seq_stride;
+        uint32_t const two = ((it < 2 ? raw01_l[l] : raw23_l[l]) >> (16 * (it & 1u))) & 0xFFFFu; // bytes 2 word, 2 word + 1 of the row
         uint32_t packed = 0;
         for (uint32_t k = 0; k < 4; ++k)
         {
@@ -174,7 +196,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
           uint32_t c = 15;
           if (i < len)
           {
-            c = (seq4[i >> 1] >> ((~i & 1u) << 2)) & 15u;
+            c = (((two >> (8 * (k >> 1))) & 255u) >> ((~i & 1u) << 2)) & 15u;
             if (c == 0)
               c = 15; // '=' assigned to a seqan Iupac becomes N (hts_parallel_reader.cpp:226-243)
           }
@@ -184,6 +206,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
       }
     });
   W::lds_sync();
+  GTX_PROF_TICK(0)
 
   // ---- exact keys in plane form: two rounds of 16 bases per k-mer, each ballot serves the four groups
   for (uint32_t i = 0; i < KC; ++i)
@@ -226,6 +249,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
     });
   }
   W::lds_sync();
+  GTX_PROF_TICK(1)
 
   // ---- index lookups: lane j of a group = (k-mer j / 3, exact | left half | right half); a single label / bucket entry
   //      comes inline with its slot
@@ -239,13 +263,14 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
       if (s.nkeys0[i] == 1)
       {
         uint64_t const q = s.key0[i];
-        uint32_t off, cnt;
+        uint32_t off, cnt, slot_flags;
         IndexSlot const * hit;
-        bucket_find(w == 0 ? ix.slots : ix.hslots, w == 0 ? ix.log2_cap : ix.h_log2_cap, w == 0 ? q : half_key(q, w - 1), off, cnt, &hit);
+        bucket_find(w == 0 ? ix.slots : ix.hslots, w == 0 ? ix.log2_cap : ix.h_log2_cap, w == 0 ? q : half_key(q, w - 1), off, cnt, &hit, &slot_flags);
         if (w == 0)
         {
           s.off0[i] = off;
           s.cnt0[i] = cnt;
+          ws.nbk[gi][i] = (slot_flags & SLOT_NB_KNOWN) ? 1 : 0;
         }
         else
         {
@@ -305,6 +330,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
     });
   }
   W::lds_sync();
+  GTX_PROF_TICK(2)
 
   // ---- half-key buckets with 2..HE_CAP entries (a SNP under the k-mer, an error next to one): fetch the entries
   {
@@ -380,6 +406,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
     }
   }
 
+  GTX_PROF_TICK(3)
   // ---- fast seeding, lane j < n_k of a group = k-mer j (the rules and their justification: seed_stage).
   //      One k-mer of the read may have no label at all (two or more errors, an error next to an N): a "hole".
   PB bad_l, var_l, mm_l, hole_l, par_l; // par: the k-mer also starts a parallel (+1 mismatch) chain when it opens a run
@@ -486,7 +513,8 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
             // Neighbouring keys of an exact hit: the sites' other alleles.  They start chains with one more mismatch
             // that end where the exact chain ends, as long as they are the same interval over the same sites.
             bad = nsites == 0;
-            for (uint32_t side = 0; side < 2 && !bad; ++side)
+            // (SLOT_NB_KNOWN: the index build has looked at the neighbours' labels already -- they pass)
+            for (uint32_t side = 0; side < 2 && !bad && !ws.nbk[gi][j]; ++side)
               for (uint32_t e = 0; e < s.hcnt[j][side]; ++e)
               {
                 HalfEntry const & he = s.he[j][side][e];
@@ -536,6 +564,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
   });
   uint64_t const BAD = W::ballot(bad_l), VAR = W::ballot(var_l), MM = W::ballot(mm_l), HOLE = W::ballot(hole_l), PAR = W::ballot(par_l);
   W::lds_sync();
+  GTX_PROF_TICK(4)
   // ---- the run of k-mers that makes the path: all of them, or -- with one hole -- the longer side of the hole.  (The
   //      shorter side chains into a shorter path that remove_short_paths drops before the walks, genotype_paths.cpp:
   //      824-834; equal sides would both survive: left to pass 2.)  Any number of the run's k-mers may lie on a variant
@@ -785,6 +814,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
     }
   });
   W::lds_sync();
+  GTX_PROF_TICK(5)
 
   // ---- the two compares, 16 characters per group and round (count_mismatches[_backward], graph_utils.hpp:7-69)
   PU got_l, hgot_l;
@@ -847,6 +877,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
     });
   }
 
+  GTX_PROF_TICK(6)
   // ---- tails over an indel site: the rest of the tail against every allele's candidate (allele bases, then the next
   //      reference node), 16 characters per group and round
   if constexpr (E4::INDEL_TAIL)
@@ -888,6 +919,7 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
         }
   }
 
+  GTX_PROF_TICK(7)
   // ---- verdict and record (leader lanes)
   PB fail_l;
   W::lanes([&](uint32_t l) {
@@ -1075,5 +1107,9 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
   });
   uint64_t const FAIL = W::ballot(fail_l);
   W::lds_sync();
+  GTX_PROF_TICK(8)
+#ifdef GTX_PROF
+  GTX_LEAD ws.prof_acc[15] += 1;
+#endif
   return (FAIL & 1ull ? 1u : 0u) | (FAIL >> 16 & 1ull ? 2u : 0u) | (FAIL >> 32 & 1ull ? 4u : 0u) | (FAIL >> 48 & 1ull ? 8u : 0u);
 }

@@ -222,7 +222,7 @@ struct BitSet
 // lookup in a bucketed table (gtx_flat.hpp: BUCKET_SLOTS): the whole 128-byte bucket is one cache line; `hit` (may be
 // NULL) receives the slot that matched, whose inline payload is then an L1 hit
 GTX_DEV void bucket_find(IndexSlot const * slots, uint32_t log2_buckets, uint64_t key, uint32_t & off, uint32_t & cnt,
-                         IndexSlot const ** hit = nullptr)
+                         IndexSlot const ** hit = nullptr, uint32_t * flags = nullptr)
 {
   uint64_t const mask = (1ull << log2_buckets) - 1;
   for (uint64_t b = hash_key(key, log2_buckets);; b = (b + 1) & mask)
@@ -234,10 +234,13 @@ GTX_DEV void bucket_find(IndexSlot const * slots, uint32_t log2_buckets, uint64_
     bool const m2 = c2 != 0 && k2 == key, m3 = c3 != 0 && k3 == key;
     uint32_t const m = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u;
     bool const any = m0 || m1 || m2 || m3;
-    off = any ? p[m].off : 0u;
+    uint32_t const raw_off = any ? p[m].off : 0u; // (with the flag bit of gtx_flat.hpp: SLOT_NB_KNOWN)
+    off = raw_off & SLOT_OFF_MASK;
     cnt = m0 ? c0 : m1 ? c1 : m2 ? c2 : m3 ? c3 : 0u;
     if (hit)
       *hit = any ? p + m : nullptr;
+    if (flags)
+      *flags = raw_off & ~SLOT_OFF_MASK;
     // slots fill front to back: an empty last slot means nothing ever spilled out of this bucket
     if (any || c3 == 0)
       return;

@@ -607,6 +607,11 @@ __device__ __forceinline__ void express4_queue_pass(GraphView const & g, IndexVi
   __shared__ uint32_t pending[TASK_CHUNK];
   uint32_t const lane = threadIdx.x & 63u;
   uint32_t const n = queue1_count[0];
+#ifdef GTX_PROF
+  if (threadIdx.x < 16)
+    ws.prof_acc[threadIdx.x] = 0;
+  WaveHip::lds_sync();
+#endif
   for (;;)
   {
     uint32_t const base = wave_claim(task_counter, TASK_CHUNK);
@@ -637,6 +642,11 @@ __device__ __forceinline__ void express4_queue_pass(GraphView const & g, IndexVi
       WaveHip::lds_sync();
     }
   }
+#ifdef GTX_PROF
+  WaveHip::lds_sync();
+  if (threadIdx.x < 16)
+    atomicAdd(g.prof + 16 + threadIdx.x, ws.prof_acc[threadIdx.x]); // (second half of the counters: the express pass, per group of four reads)
+#endif
 }
 
 #define GTX_EXPRESS4Q_ARGS                                                                                                         \

@@ -37,6 +37,12 @@ struct alignas(16) DevLabel
 // 64-byte fetch; a full bucket spills into the next one.  cnt == 0 marks an empty slot.
 constexpr uint32_t BUCKET_SLOTS = 4;
 
+// exact table only: bit 31 of a slot's offset word says that every label of every indexed Hamming-1 neighbour of the key lies
+// on the interval the key's own labels share and on one of their sites (hint_judge_key) -- what express4's seeding rule asks
+// of the neighbours of an exact hit, so that it need not fetch their labels.  Lookups return the offset without it.
+// (In the offset, not the count: a lookup tests four counts per bucket and uses one offset.)
+constexpr uint32_t SLOT_NB_KNOWN = 0x80000000u, SLOT_OFF_MASK = 0x7FFFFFFFu;
+
 struct alignas(32) IndexSlot
 {
   uint64_t key;

@@ -660,11 +660,34 @@ static void build_hints(HostGraph const & g, HostIndex & out)
   parallel_slices(nk, host_threads(), [&](unsigned, std::size_t b, std::size_t e) {
     for (std::size_t k = b; k < e; ++k)
     {
-      uint32_t same = 1;
-      hint_judge_key(t, static_cast<uint32_t>(k), nb[k], same);
-      nb_same[k] = static_cast<uint8_t>(same);
+      uint32_t same = 1, known = 0;
+      hint_judge_key(t, static_cast<uint32_t>(k), nb[k], same, known);
+      nb_same[k] = static_cast<uint8_t>(same | (known << 1)); // (bit 1: SLOT_NB_KNOWN of the key's slot, set below)
     }
   });
+  // the exact table's slots of the keys whose neighbours are known (gtx_flat.hpp: SLOT_NB_KNOWN)
+  if (!out.slots.empty())
+    parallel_slices(nk, host_threads(), [&](unsigned, std::size_t b, std::size_t e) {
+      uint64_t const mask = (1ull << out.log2_cap) - 1;
+      for (std::size_t k = b; k < e; ++k)
+        if ((nb_same[k] & 2u) != 0 && nb[k] != 0)
+        {
+          uint64_t const key = plane_key(out.keys[k]);
+          bool done = false;
+          for (uint64_t bk = hash_key(key, out.log2_cap); !done; bk = (bk + 1) & mask)
+            for (uint32_t j = 0; j < BUCKET_SLOTS && !done; ++j)
+            {
+              IndexSlot & sl = out.slots[bk * BUCKET_SLOTS + j];
+              if (sl.cnt == 0)
+                done = true; // (cannot happen: every key is in the table)
+              else if (sl.key == key)
+              {
+                sl.off |= SLOT_NB_KNOWN;
+                done = true;
+              }
+            }
+        }
+    });
   // filters over the halves of every indexed key (nibble form, as the kernel hashes them): 32 bits per key and side
   uint32_t fl = 5;
   while ((1ull << fl) < nk + 1 && fl < 28)

@@ -280,15 +280,34 @@ __global__ void k_half_tables(uint64_t const * pk, uint32_t const * key_off, uin
   }
 }
 
-__global__ void k_judge_keys(HintKeys t, uint32_t * nb, uint8_t * nb_same, uint32_t * filt0, uint32_t * filt1, uint32_t filt_log2)
+__global__ void k_judge_keys(HintKeys t, uint32_t * nb, uint8_t * nb_same, uint32_t * filt0, uint32_t * filt1, uint32_t filt_log2,
+                             uint64_t const * pk, IndexSlot * slots, uint32_t log2_cap)
 {
   uint32_t const k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= t.n_keys)
     return;
-  uint32_t n = 0, same = 1;
-  hint_judge_key(t, k, n, same);
+  uint32_t n = 0, same = 1, known = 0;
+  hint_judge_key(t, k, n, same, known);
   nb[k] = n;
-  nb_same[k] = static_cast<uint8_t>(same);
+  nb_same[k] = static_cast<uint8_t>(same | (known << 1));
+  if (known && n != 0)
+  {
+    // the key's slot of the exact table gets SLOT_NB_KNOWN (gtx_flat.hpp)
+    uint64_t const key = pk[k], mask = (1ull << log2_cap) - 1;
+    bool done = false;
+    for (uint64_t b = hash_key(key, log2_cap); !done; b = (b + 1) & mask)
+      for (uint32_t j = 0; j < BUCKET_SLOTS && !done; ++j)
+      {
+        IndexSlot * sl = slots + b * BUCKET_SLOTS + j;
+        if (sl->cnt == 0)
+          done = true; // (cannot happen: every key is in the table)
+        else if (sl->key == key)
+        {
+          atomicOr(&sl->off, SLOT_NB_KNOWN);
+          done = true;
+        }
+      }
+  }
   for (uint32_t side = 0; side < 2; ++side)
   {
     uint32_t w0, w1, word, mask;
@@ -494,7 +513,7 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, HintGraphTable
       return GTX_ERR_HIP;
     HintKeys const t{d_keys, d_key_off, d_dev_labels, n_keys, d_lbegin, d_lsize, d_rorder, d_rbegin, d_rsize};
     if (n_keys)
-      hipLaunchKernelGGL(k_judge_keys, dim3(blocks_for(n_keys)), dim3(TB), 0, nullptr, t, d_nb, d_same, d_f0, d_f1, fl);
+      hipLaunchKernelGGL(k_judge_keys, dim3(blocks_for(n_keys)), dim3(TB), 0, nullptr, t, d_nb, d_same, d_f0, d_f1, fl, d_pk, d_slots, log2_cap);
     hipLaunchKernelGGL(k_position_flags, dim3(blocks_for(gt.n)), dim3(TB), 0, nullptr, c.dev_graph, t, d_nb, d_same, d_base, d_room, d_back, gt.n, d_flags);
   }
   uint32_t several = 0;

@@ -38,10 +38,20 @@ GTX_HD bool hint_distance1(uint64_t a, uint64_t b) // exactly one base differs
 // Hamming-1 neighbours of key k among the keys that share one of its halves: how many labels they have together (nb), and
 // whether every one of those labels is k's own interval on k's own site (what express4's seeding rule asks of the
 // neighbours of an exact hit).  A crowded group (more than 64 keys: low-complexity sequence) is not looked through: same = 0.
-GTX_HD void hint_judge_key(HintKeys const & t, uint32_t k, uint32_t & nb, uint32_t & same)
+GTX_HD void hint_judge_key(HintKeys const & t, uint32_t k, uint32_t & nb, uint32_t & same, uint32_t & known)
 {
   nb = 0;
   same = 1;
+  // `known` (SLOT_NB_KNOWN): the key's own labels share one interval and all lie on sites; every neighbour label has that
+  // interval and one of those sites (express4.inl: the neighbours of an exact hit)
+  known = 1;
+  uint32_t const own0 = t.key_off[k], own1 = t.key_off[k + 1];
+  for (uint32_t i = own0; i < own1; ++i)
+  {
+    DevLabel const lb = t.labels[i];
+    if (lb.site == INVALID || lb.start != t.labels[own0].start || lb.end != t.labels[own0].end)
+      known = 0;
+  }
   DevLabel const la = t.labels[t.key_off[k]];
   // (k's own labels: one, or up to HINT_OWN_MAX on one interval of one site -- the alleles of a merged site that share the k-mer)
   bool uniform = t.key_off[k + 1] - t.key_off[k] <= HINT_OWN_MAX;
@@ -60,8 +70,15 @@ GTX_HD void hint_judge_key(HintKeys const & t, uint32_t k, uint32_t & nb, uint32
       DevLabel const lb = t.labels[i];
       if (!uniform || la.site == INVALID || lb.site != la.site || lb.start != la.start || lb.end != la.end)
         same = 0;
+      bool among = false;
+      for (uint32_t o = own0; o < own1 && !among && known; ++o)
+        among = t.labels[o].site == lb.site;
+      if (!among || lb.start != la.start || lb.end != la.end)
+        known = 0;
     }
   };
+  if (own1 - own0 > 64 || t.lsize[k] > 64 || t.rsize[k] > 64)
+    known = 0;
   if (t.lsize[k] > 64)
     same = 0;
   else
@@ -94,7 +111,7 @@ GTX_HD bool hint_find_key(HintKeys const & t, uint64_t key, uint32_t & k)
 GTX_HD bool hint_neighbours_ok(HintKeys const & t, uint32_t const * nb, uint8_t const * nb_same, uint32_t k, bool & par)
 {
   par = nb[k] != 0;
-  return t.lsize[k] <= HINT_HE_CAP && t.rsize[k] <= HINT_HE_CAP && (nb[k] == 0 || (nb_same[k] && nb[k] <= HINT_NB_MAX));
+  return t.lsize[k] <= HINT_HE_CAP && t.rsize[k] <= HINT_HE_CAP && (nb[k] == 0 || ((nb_same[k] & 1u) && nb[k] <= HINT_NB_MAX));
 }
 
 // Key k's labels when there are several: all (order, order + 31) on one site, alleles below HINT_MASK_BITS -> their set
