@@ -665,8 +665,10 @@ static void build_hints(HostGraph const & g, HostIndex & out)
       nb_same[k] = static_cast<uint8_t>(same | (known << 1)); // (bit 1: SLOT_NB_KNOWN of the key's slot, set below)
     }
   });
-  // the exact table's slots of the keys whose neighbours are known (gtx_flat.hpp: SLOT_NB_KNOWN)
-  if (!out.slots.empty())
+  // the exact table's slots of the keys whose neighbours are known (gtx_flat.hpp: SLOT_NB_KNOWN; GTX_NB_KNOWN=0: a test
+  // switch that leaves the bit clear everywhere, so that the kernels verify the neighbours themselves)
+  char const * nbk = std::getenv("GTX_NB_KNOWN");
+  if (!out.slots.empty() && !(nbk && nbk[0] == '0'))
     parallel_slices(nk, host_threads(), [&](unsigned, std::size_t b, std::size_t e) {
       uint64_t const mask = (1ull << out.log2_cap) - 1;
       for (std::size_t k = b; k < e; ++k)

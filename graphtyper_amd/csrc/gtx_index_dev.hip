@@ -290,7 +290,7 @@ __global__ void k_judge_keys(HintKeys t, uint32_t * nb, uint8_t * nb_same, uint3
   hint_judge_key(t, k, n, same, known);
   nb[k] = n;
   nb_same[k] = static_cast<uint8_t>(same | (known << 1));
-  if (known && n != 0)
+  if (known && n != 0 && slots)
   {
     // the key's slot of the exact table gets SLOT_NB_KNOWN (gtx_flat.hpp)
     uint64_t const key = pk[k], mask = (1ull << log2_cap) - 1;
@@ -513,7 +513,11 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, HintGraphTable
       return GTX_ERR_HIP;
     HintKeys const t{d_keys, d_key_off, d_dev_labels, n_keys, d_lbegin, d_lsize, d_rorder, d_rbegin, d_rsize};
     if (n_keys)
-      hipLaunchKernelGGL(k_judge_keys, dim3(blocks_for(n_keys)), dim3(TB), 0, nullptr, t, d_nb, d_same, d_f0, d_f1, fl, d_pk, d_slots, log2_cap);
+    {
+      char const * nbk = std::getenv("GTX_NB_KNOWN"); // test switch: 0 = no slot gets SLOT_NB_KNOWN
+      hipLaunchKernelGGL(k_judge_keys, dim3(blocks_for(n_keys)), dim3(TB), 0, nullptr, t, d_nb, d_same, d_f0, d_f1, fl, d_pk,
+                         (nbk && nbk[0] == '0') ? static_cast<IndexSlot *>(nullptr) : d_slots, log2_cap);
+    }
     hipLaunchKernelGGL(k_position_flags, dim3(blocks_for(gt.n)), dim3(TB), 0, nullptr, c.dev_graph, t, d_nb, d_same, d_base, d_room, d_back, gt.n, d_flags);
   }
   uint32_t several = 0;

@@ -1,5 +1,7 @@
 """Kernel sources run through the host emulation (tests/emu) against the oracle.  A debugging aid for containers
 without a GPU -- the parity claims of record are the `-m gpu` tests, which run the same cases through libgtx."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -567,3 +569,29 @@ def sv_deletion_case(Backend):
 
 def test_align_over_an_sv_deletion():
     sv_deletion_case(harness.EmuBackend)
+
+
+def test_neighbour_flag_of_the_index_changes_nothing(monkeypatch):
+    """SLOT_NB_KNOWN (the index build's verdict on the neighbours of a key) only spares the express pass a fetch: with the
+    bit left clear everywhere (GTX_NB_KNOWN=0) the same tasks are finished by the same pass with the same words"""
+    ref, recs, codes, pos = scenarios.synthetic_case("cluster", n_ref=50000, n_reads=3000, region_begin=20000)
+    g = gtx.graph_from_records(ref, recs, region_begin=20000, add_all_variants=True)
+    reads = list(codes)
+    seq, lens = harness.pack_ragged(reads)
+    out = []
+    for switch in (None, "0"):
+        if switch is None:
+            monkeypatch.delenv("GTX_NB_KNOWN", raising=False)
+        else:
+            monkeypatch.setenv("GTX_NB_KNOWN", switch)
+        monkeypatch.setenv("GTX_EXPRESS4", "wide")
+        b = harness.EmuBackend(g)
+        rec = b.align(seq, harness.read_meta(lens)).copy()
+        b.L.emu_general_tasks.restype = C.c_uint64
+        out.append((rec, int(b.L.emu_general_tasks(C.c_void_p(b.h)))))
+    assert out[0][1] == out[1][1] and out[0][1] > 0
+    a, c = out[0][0].reshape(2 * len(reads), -1), out[1][0].reshape(2 * len(reads), -1)
+    external = ((a[:, 0] >> 16) & gtx.ST_EXTERNAL) != 0
+    differ = a != c
+    differ[external, 2:] = False
+    assert not differ.any()
