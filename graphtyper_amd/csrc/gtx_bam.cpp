@@ -17,19 +17,167 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <deque>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace
 {
 // BGZF: a series of gzip members of at most 64 KB, each with its compressed size in a "BC" extra field (SAM spec 4.1); a
 // virtual offset = (file offset of a member) << 16 | offset in its data.  Members are inflated one at a time (raw
-// deflate), which is what makes seeking by virtual offset possible.
+// deflate), which is what makes seeking by virtual offset possible -- and what makes them independent: inflating is nine
+// tenths of the time of reading a BAM file, so a reader keeps up to RING members in flight.  The calling thread reads
+// the compressed members ahead (sequential file reads), a small team of worker threads shared by all open readers
+// inflates them, and the caller takes them in file order; a member nobody has started on when the caller needs it is
+// inflated by the caller itself, so a reader is never slower than without the team (many readers on many host threads
+// each still get their own core).  The team lives while a reader is open (GTX_BGZF_THREADS sizes it, 0 = none).
+struct InflateJob
+{
+  std::vector<uint8_t> comp, data;
+  long clen = 0;
+  std::atomic<int> state{2}; // 0 queued, 1 being inflated, 2 done
+  bool ok = false;
+  std::mutex m;
+  std::condition_variable cv;
+};
+
+void inflate_member(InflateJob & j)
+{
+  j.ok = false;
+  z_stream z{};
+  if (inflateInit2(&z, -15) == Z_OK)
+  {
+    z.next_in = j.comp.data();
+    z.avail_in = static_cast<uInt>(j.clen);
+    z.next_out = j.data.data();
+    z.avail_out = static_cast<uInt>(j.data.size());
+    int const rc = inflate(&z, Z_FINISH);
+    inflateEnd(&z);
+    j.ok = rc == Z_STREAM_END && z.avail_out == 0;
+  }
+  {
+    // (notified under the lock: the reader may free the job as soon as it sees it done, and it sees that only after
+    // this thread has let go of the mutex -- the last thing it touches)
+    std::lock_guard<std::mutex> lock(j.m);
+    j.state.store(2);
+    j.cv.notify_all();
+  }
+}
+
+class InflateTeam
+{
+public:
+  static void acquire()
+  {
+    std::lock_guard<std::mutex> lock(gate());
+    if (users()++ == 0)
+    {
+      unsigned n = std::min(std::max(std::thread::hardware_concurrency(), 1u), 16u);
+      if (char const * e = std::getenv("GTX_BGZF_THREADS"))
+        n = static_cast<unsigned>(std::max(0, std::atoi(e)));
+      self() = new InflateTeam(n);
+    }
+  }
+  static void release()
+  {
+    InflateTeam * gone = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(gate());
+      if (--users() == 0)
+      {
+        gone = self();
+        self() = nullptr;
+      }
+    }
+    delete gone;
+  }
+  // hands a queued job to the team (no team: it stays queued and its reader inflates it when it gets there)
+  static void submit(InflateJob * j)
+  {
+    InflateTeam * t = self();
+    if (!t || t->workers_.empty())
+      return;
+    {
+      std::lock_guard<std::mutex> lock(t->m_);
+      t->queue_.push_back(j);
+    }
+    t->cv_.notify_one();
+  }
+  // forgets the jobs of a reader that goes away (none of them is running any more: the reader has waited for those)
+  static void forget(InflateJob const * first, InflateJob const * last)
+  {
+    InflateTeam * t = self();
+    if (!t)
+      return;
+    std::lock_guard<std::mutex> lock(t->m_);
+    t->queue_.erase(std::remove_if(t->queue_.begin(), t->queue_.end(), [&](InflateJob * j) { return j >= first && j < last; }), t->queue_.end());
+  }
+
+private:
+  explicit InflateTeam(unsigned n)
+  {
+    for (unsigned i = 0; i < n; ++i)
+      workers_.emplace_back([this] { run(); });
+  }
+  ~InflateTeam()
+  {
+    {
+      std::lock_guard<std::mutex> lock(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto & w : workers_)
+      w.join();
+  }
+  void run()
+  {
+    for (;;)
+    {
+      InflateJob * j = nullptr;
+      {
+        std::unique_lock<std::mutex> lock(m_);
+        cv_.wait(lock, [this] { return stop_ || !queue_.empty(); });
+        if (stop_)
+          return;
+        j = queue_.front();
+        queue_.pop_front();
+        int expect = 0;
+        if (!j->state.compare_exchange_strong(expect, 1)) // (its reader got there first)
+          continue;
+      }
+      inflate_member(*j);
+    }
+  }
+  static std::mutex & gate()
+  {
+    static std::mutex m;
+    return m;
+  }
+  static int & users()
+  {
+    static int n = 0;
+    return n;
+  }
+  static InflateTeam *& self()
+  {
+    static InflateTeam * t = nullptr;
+    return t;
+  }
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<InflateJob *> queue_;
+  std::vector<std::thread> workers_;
+  bool stop_ = false;
+};
+
 class Bgzf
 {
 public:
@@ -37,12 +185,22 @@ public:
   bool open(std::string const & path)
   {
     fp_ = std::fopen(path.c_str(), "rb");
+    if (fp_)
+    {
+      InflateTeam::acquire();
+      ring_.reset(new InflateJob[RING]);
+    }
     return fp_ != nullptr;
   }
   void close()
   {
     if (fp_)
+    {
+      drain();
+      ring_.reset();
+      InflateTeam::release();
       std::fclose(fp_);
+    }
     fp_ = nullptr;
   }
   bool is_open() const { return fp_ != nullptr; }
@@ -63,6 +221,7 @@ public:
   }
   bool seek(uint64_t voffset)
   {
+    drain();
     if (std::fseek(fp_, static_cast<long>(voffset >> 16), SEEK_SET) != 0)
       return false;
     data_.clear();
@@ -76,22 +235,26 @@ public:
   }
 
 private:
-  bool next_block()
+  static constexpr unsigned RING = 16; // members in flight per reader (1 MB of data at most)
+  enum Ahead { MORE, END, BROKEN };
+
+  // the next member of the file into job j (compressed bytes only); END at the end of the file, BROKEN on a malformed member
+  Ahead read_member(InflateJob & j)
   {
     for (;;)
     {
       uint8_t h[18];
       size_t const got = std::fread(h, 1, 18, fp_);
       if (got == 0)
-        return false; // end of the file
+        return END;
       if (got != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4))
-        return fail();
+        return BROKEN;
       unsigned const xlen = h[10] | (h[11] << 8);
       // the BC field is the first extra field in every writer there is; look through the extra fields anyway
       std::vector<uint8_t> extra(xlen);
       std::memcpy(extra.data(), h + 12, std::min<size_t>(6, xlen));
       if (xlen > 6 && std::fread(extra.data() + 6, 1, xlen - 6, fp_) != xlen - 6)
-        return fail();
+        return BROKEN;
       long bsize = -1;
       for (unsigned i = 0; i + 4 <= xlen;)
       {
@@ -101,34 +264,83 @@ private:
         i += 4 + slen;
       }
       if (bsize < 0)
-        return fail();
+        return BROKEN;
       long const clen = bsize + 1 - 12 - static_cast<long>(xlen) - 8; // compressed data between header and CRC32 / ISIZE
       if (clen < 0)
-        return fail();
-      comp_.resize(static_cast<size_t>(clen) + 8);
-      if (std::fread(comp_.data(), 1, comp_.size(), fp_) != comp_.size())
-        return fail();
+        return BROKEN;
+      j.comp.resize(static_cast<size_t>(clen) + 8);
+      if (std::fread(j.comp.data(), 1, j.comp.size(), fp_) != j.comp.size())
+        return BROKEN;
       uint32_t isize;
-      std::memcpy(&isize, comp_.data() + clen + 4, 4);
+      std::memcpy(&isize, j.comp.data() + clen + 4, 4);
       if (isize > 65536)
-        return fail();
-      data_.resize(isize);
-      at_ = 0;
+        return BROKEN;
       if (isize == 0)
         continue; // (the end-of-file marker, or an empty member)
-      z_stream z{};
-      if (inflateInit2(&z, -15) != Z_OK)
-        return fail();
-      z.next_in = comp_.data();
-      z.avail_in = static_cast<uInt>(clen);
-      z.next_out = data_.data();
-      z.avail_out = isize;
-      int const rc = inflate(&z, Z_FINISH);
-      inflateEnd(&z);
-      if (rc != Z_STREAM_END || z.avail_out != 0)
-        return fail();
-      return true;
+      j.clen = clen;
+      j.data.resize(isize);
+      return MORE;
     }
+  }
+  // reads members ahead until the ring is full or the file ends / breaks (which is reported when the caller gets there)
+  void fill()
+  {
+    while (ahead_ == MORE && tail_ - head_ < RING)
+    {
+      InflateJob & j = ring_[tail_ % RING];
+      Ahead const a = read_member(j);
+      if (a != MORE)
+      {
+        ahead_ = a;
+        break;
+      }
+      j.state.store(0);
+      ++tail_;
+      InflateTeam::submit(&j);
+    }
+  }
+  bool next_block()
+  {
+    fill();
+    if (head_ == tail_)
+    {
+      if (ahead_ == BROKEN)
+        return fail();
+      return false; // end of the file
+    }
+    InflateJob & j = ring_[head_ % RING];
+    int expect = 0;
+    if (j.state.compare_exchange_strong(expect, 1))
+      inflate_member(j); // (nobody has started on it: this thread does)
+    else
+    {
+      std::unique_lock<std::mutex> lock(j.m);
+      j.cv.wait(lock, [&] { return j.state.load() == 2; });
+    }
+    ++head_;
+    if (!j.ok)
+      return fail();
+    data_.swap(j.data);
+    at_ = 0;
+    return true;
+  }
+  // nothing of this reader is in flight or queued afterwards
+  void drain()
+  {
+    if (!ring_)
+      return;
+    for (; head_ < tail_; ++head_)
+    {
+      InflateJob & j = ring_[head_ % RING];
+      int expect = 0;
+      if (j.state.compare_exchange_strong(expect, 2))
+        continue; // (never started)
+      std::unique_lock<std::mutex> lock(j.m);
+      j.cv.wait(lock, [&] { return j.state.load() == 2; });
+    }
+    InflateTeam::forget(ring_.get(), ring_.get() + RING);
+    head_ = tail_ = 0;
+    ahead_ = MORE;
   }
   bool fail()
   {
@@ -136,7 +348,10 @@ private:
     return false;
   }
   std::FILE * fp_ = nullptr;
-  std::vector<uint8_t> comp_, data_;
+  std::unique_ptr<InflateJob[]> ring_;
+  uint64_t head_ = 0, tail_ = 0; // members taken / read ahead
+  Ahead ahead_ = MORE;
+  std::vector<uint8_t> data_;
   size_t at_ = 0;
   bool bad_ = false;
 };
