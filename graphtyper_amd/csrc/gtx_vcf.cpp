@@ -15,7 +15,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace
@@ -219,11 +221,16 @@ extern "C" int gtx_vcf_records(const gtx_ctx * c, const gtx_vcf_request * rq, ch
   }
   text += '\n';
   std::string const contig = rq->contig;
+  // The records of the sites are independent of each other: the sites are cut into contiguous ranges for a team of host
+  // threads (every record walks the sample-major arrays of all samples -- cache misses, not arithmetic), every range writes
+  // its own text, the texts are joined in order.
+  auto write_sites = [&](uint32_t h_begin, uint32_t h_end, std::string & text, std::string & error) -> int
+  {
   std::vector<AlleleStats> al;
   std::vector<std::pair<const char *, uint32_t>> seqs;
   std::vector<CallView> calls(ns);
   std::vector<double> qd_alt, aa_score;
-  for (uint32_t h = 0; h < nh; ++h)
+  for (uint32_t h = h_begin; h < h_end; ++h)
   {
     uint32_t const cnum = g.ref_nvar[h], v0 = g.ref_first_var[h], n_tri = cnum * (cnum + 1) / 2;
     uint64_t const aoff = g.allele_off[h], toff = g.tri_off[h];
@@ -267,7 +274,7 @@ extern "C" int gtx_vcf_records(const gtx_ctx * c, const gtx_vcf_request * rq, ch
       uint32_t const g1 = cv.c->gt_first, g2 = cv.c->gt_second, amb = cv.c->ambiguous_depth;
       if (g1 >= cnum || g2 >= cnum)
       {
-        gtx::g_last_error = "gtx_vcf_records: a call names an allele the site does not have";
+        error = "gtx_vcf_records: a call names an allele the site does not have";
         return GTX_ERR_ARG;
       }
       qual += cv.phred[0];
@@ -653,6 +660,56 @@ extern "C" int gtx_vcf_records(const gtx_ctx * c, const gtx_vcf_request * rq, ch
       }
     }
     text += '\n';
+  }
+  return GTX_OK;
+  };
+  unsigned T = 1;
+  if (static_cast<uint64_t>(nh) * (ns + 1) >= 200000) // (small jobs: a team costs more to start than it saves)
+  {
+    T = std::min(std::max(std::thread::hardware_concurrency(), 1u), 32u);
+    if (char const * e = std::getenv("GTX_HOST_THREADS"))
+      T = static_cast<unsigned>(std::max(1, std::atoi(e)));
+    T = std::min<unsigned>(T, std::max<uint32_t>(nh / 16, 1));
+  }
+  if (T <= 1)
+  {
+    std::string error;
+    int const rc = write_sites(0, nh, text, error);
+    if (rc != GTX_OK)
+    {
+      gtx::g_last_error = error;
+      return rc;
+    }
+  }
+  else
+  {
+    std::vector<std::string> part(T), error(T);
+    std::vector<int> status(T, GTX_OK);
+    std::vector<std::thread> team;
+    for (unsigned t = 0; t < T; ++t)
+      team.emplace_back([&, t] {
+        uint32_t const b = static_cast<uint32_t>(static_cast<uint64_t>(nh) * t / T), e = static_cast<uint32_t>(static_cast<uint64_t>(nh) * (t + 1) / T);
+        part[t].reserve(static_cast<size_t>(e - b) * (400 + 24 * static_cast<size_t>(ns)));
+        try
+        {
+          status[t] = write_sites(b, e, part[t], error[t]);
+        }
+        catch (...)
+        {
+          status[t] = GTX_ERR_ARG;
+          error[t] = "gtx_vcf_records: out of memory";
+        }
+      });
+    for (auto & th : team)
+      th.join();
+    for (unsigned t = 0; t < T; ++t)
+      if (status[t] != GTX_OK)
+      {
+        gtx::g_last_error = error[t];
+        return status[t];
+      }
+    for (unsigned t = 0; t < T; ++t)
+      text += part[t];
   }
   *len = text.size();
   if (out && cap)

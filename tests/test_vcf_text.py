@@ -147,3 +147,30 @@ def test_vcf_text_without_samples_and_of_sv_graphs():
     with pytest.raises(gtx.GtxError) as e:
         sv.vcf_records("chr1", [], z(0, np.uint32), z(1, np.uint64), z(1, np.uint32), z(0, np.uint8), z(0, gtx.SAMPLE_CALL))
     assert e.value.status == 4  # GTX_ERR_UNSUPPORTED
+
+
+def test_records_written_by_a_team_of_host_threads_are_the_same_bytes(monkeypatch):
+    """large jobs are cut into site ranges for host threads: the text must not depend on the team"""
+    from graphtyper_amd import synth
+    ref = synth.make_reference(300000, seed=42)
+    recs = synth.make_snp_records(ref, 300, seed=7, region_begin=1000)
+    ctx = gtx.Context(gtx.graph_from_records(synth.bases_to_str(ref), recs, region_begin=1000), device=-1)
+    ns = 250
+    nh, ta, tt = ctx.n_hap, ctx.total_allele, ctx.total_tri
+    assert nh * (ns + 1) >= 200000
+    rng = np.random.default_rng(1)
+    gt_cov = rng.integers(0, 30, size=ns * ta).astype(np.uint32)
+    stat_u64 = rng.integers(0, 1000, size=nh + 2 * ta).astype(np.uint64)
+    stat_u32 = rng.integers(0, 1000, size=nh + 6 * ta).astype(np.uint32)
+    phred = rng.integers(0, 255, size=ns * tt).astype(np.uint8)
+    calls = np.zeros(ns * nh, gtx.SAMPLE_CALL)
+    calls["gt_second"] = rng.integers(0, 2, size=ns * nh)
+    calls["ref_total_depth"] = rng.integers(0, 40, size=ns * nh)
+    calls["alt_total_depth"] = rng.integers(0, 40, size=ns * nh)
+    calls["gq"] = rng.integers(0, 99, size=ns * nh)
+    names = ["S%04d" % i for i in range(ns)]
+    texts = []
+    for team in ("1", "3", "7"):
+        monkeypatch.setenv("GTX_HOST_THREADS", team)
+        texts.append(ctx.vcf_records("chr1", names, gt_cov, stat_u64, stat_u32, phred, calls))
+    assert texts[0] == texts[1] == texts[2] and texts[0].count(b"\n") == nh + 1
