@@ -227,3 +227,29 @@ def test_damaged_bam_files_are_refused_not_crashed_on(tmp_path):
     the records that are still readable), never in a crash of the calling process"""
     import fuzz_bam
     assert fuzz_bam.run(0, 24, tmp=str(tmp_path)) == 0
+
+
+@pytest.mark.parametrize("team", ["0", "3"])
+def test_readers_on_several_host_threads_share_the_inflate_team(tmp_path, monkeypatch, team):
+    """the BGZF members of all open readers are inflated by one team of worker threads (or by the readers themselves,
+    GTX_BGZF_THREADS=0): four readers on four host threads, each over several files, must each see the reference's order"""
+    import threading
+    monkeypatch.setenv("GTX_BGZF_THREADS", team)
+    files, paths, headers = _random_files(tmp_path, 11)
+    want, samples, n_rg = _expected(files, headers)
+    failures = []
+
+    def one():
+        try:
+            for _ in range(3):
+                reads = gtx.Reads(paths)
+                _check(reads, want)
+                reads.close()
+        except Exception as e:  # (an assertion in a thread would otherwise be lost)
+            failures.append(repr(e))
+    team_of_hosts = [threading.Thread(target=one) for _ in range(4)]
+    for t in team_of_hosts:
+        t.start()
+    for t in team_of_hosts:
+        t.join()
+    assert not failures, failures[0]
