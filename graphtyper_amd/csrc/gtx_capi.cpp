@@ -104,6 +104,11 @@ extern "C"
           std::rethrow_exception(side_error);
       }
       lap("enumerate k-mers + graph hint arrays (host)");
+      if (em.size() >= SLOT_OFF_MASK) // (label offsets are 31 bits in the index slots: gtx_flat.hpp, SLOT_NB_KNOWN)
+      {
+        gtx::g_last_error = "gtx_ctx_create: more than 2^31 k-mer labels in one region";
+        return GTX_ERR_UNSUPPORTED;
+      }
       int rc = ctx_upload(*c, device);
       lap("graph upload + scratch");
       if (rc == GTX_OK)
