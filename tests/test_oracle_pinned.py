@@ -119,6 +119,22 @@ def test_index_chr1():  # :17-81
     assert o.index_get(d) == [(12, 43, 1)]
 
 
+def test_index_chr1_lookups_of_the_retired_aligner_test():
+    """test/typer/test_gyper_aligner.cpp:28-96 (a test of the reference's former aligner class, no longer built upstream): its
+    four lookups on the chr1 graph still state what the index holds -- the repeated k-mer at three places, a unique
+    reference k-mer, the k-mer over the G allele at the same place, and a k-mer that is nowhere.  (That class counted
+    positions from 0; the index of today counts from 1, test/index/test_index.cpp:17-81 above.)"""
+    o, ref = _oracle("chr1")
+    common = o.index_get("TTTCCCCAGGTTTCCCCAGGTTTCCCCAGGTT")
+    assert len(common) == 3
+    assert sorted(s - 1 for s, _, _ in common) == [3, 13, 23] and sorted(e - 1 for _, e, _ in common) == [34, 44, 54]
+    unique = o.index_get("TTCCCCAGGTTTCCCCAGGTTTCCCCTTTGGA")
+    assert [(s - 1, e - 1) for s, e, _ in unique] == [(34, 65)]
+    on_variant = o.index_get("TTGCCCAGGTTTCCCCAGGTTTCCCCTTTGGA")
+    assert [(s - 1, e - 1) for s, e, _ in on_variant] == [(34, 65)] and on_variant[0][2] != unique[0][2]
+    assert o.index_get("A" * 32) == []
+
+
 def test_index_chr2():  # :83-143
     o, ref = _oracle("chr2")
     assert o.all_ref() == ref and o.index_check()
