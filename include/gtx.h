@@ -509,7 +509,10 @@ int gtx_stream_counts(const gtx_stream *, uint64_t * n_records, uint64_t * n_dup
  * would return them: with a .bai beside the file (<bam>.bai or <name>.bai) the scan starts at the first place the index
  * allows an overlapping record, without one at the head of the file.  Not read: CRAM, .csi indices.  Records with equal sort keys keep file order (the reference's
  * std::sort / heap leave the order of exact duplicates open; results do not depend on it).
- * gtx_reads_next fills up to cap records (n = 0: end); a read whose packed bases exceed seq_stride is an error. */
+ * gtx_reads_next fills up to cap records (n = 0: end); a read whose packed bases exceed seq_stride is an error.
+ * Threads: a gtx_reads is used by one thread at a time; several may be open on several host threads.  While any is open
+ * the library keeps a team of worker threads that inflate BGZF members ahead of the readers (environment:
+ * GTX_BGZF_THREADS, default up to 16, 0 = none: every reader inflates its own members); it is gone when the last closes. */
 typedef struct gtx_reads gtx_reads;
 int gtx_reads_open(const char * const * bam_paths, uint32_t n_paths, const char * region, gtx_reads ** out);
 int gtx_reads_info(const gtx_reads *, uint32_t * n_samples, uint32_t * n_read_groups);
