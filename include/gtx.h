@@ -368,7 +368,9 @@ int gtx_calls_batch(gtx_ctx *, const gtx_score_buffers * acc, uint8_t * d_phred,
  * All arrays are HOST copies: the accumulators of gtx_score_batch (raw sums or finalized) and the outputs of
  * gtx_calls_batch for the same n_samples.  Not built: variant break-down / pool merge (vcf_operations.cpp) and the SV
  * post-processing of the calls (reformat_sv_vcf_records): a context of an SV graph returns GTX_ERR_UNSUPPORTED.
- * Writes min(*len, cap) bytes to out (may be NULL with cap 0 to ask for the length). */
+ * Writes min(*len, cap) bytes to out (may be NULL with cap 0 to ask for the length).  Large jobs (sites x samples >=
+ * 200 000) are written by a team of host threads over ranges of sites (GTX_HOST_THREADS, default up to 32); the text does
+ * not depend on the team. */
 typedef struct gtx_vcf_request
 {
   const char * contig;               /* CHROM */
