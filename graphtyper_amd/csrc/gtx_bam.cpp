@@ -7,7 +7,8 @@
 //                                        (tid, pos, l_qseq, packed bases)       include/graphtyper/utilities/hts_utils.hpp:48-108
 //   HtsReader::get_sample_and_rg_index   hts_reader.cpp:354-387                RG tag -> read group / sample index
 //   get_score_diff                       src/typer/alignment.cpp:140-325       AS - XS from the aux fields, with its parsing quirks
-// Here: BGZF members are inflated one at a time (zlib, raw deflate); a BAM record is parsed in place into a
+// Here: BGZF members are inflated member by member (zlib, raw deflate; ahead of the reader by a team of worker threads,
+// see Bgzf below); a BAM record is parsed in place into a
 // gtx_stream_record + its packed bases (copied verbatim: the kernels read BAM nibbles).  Equal keys keep file order, then
 // position in the file (the reference's std::sort / heap leave the order of exact duplicates unspecified; their results do
 // not depend on it).  A region starts from the .bai when there is one (else the file is scanned from its head).  Not read:
