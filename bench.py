@@ -182,6 +182,16 @@ def make_reads_on_device(torch, ref_bases, records, n, seed, device, REGION_LEN=
     return out_seq, out_pos
 
 
+CFG2_READ_SEED = 1234  # read set k of rank r is drawn with seed CFG2_READ_SEED + r + 7919 k
+
+
+def cfg2_graph_inputs(synth, region_len=REGION_LEN, snp_every=1000):
+    """reference bases, SNP records and the reference as a string of the cfg2 graph (seed 42 / 7)"""
+    ref = synth.make_reference(region_len, seed=42)
+    records = synth.make_snp_records(ref, snp_every, seed=7, region_begin=REGION_BEGIN)
+    return ref, records, synth.bases_to_str(ref)
+
+
 def unpack_nibbles(packed, length):
     codes = np.empty((packed.shape[0], length + (length & 1)), np.uint8)
     nb = (length + 1) // 2
@@ -330,18 +340,39 @@ class Workload:
         dt = time.perf_counter() - t0
         return max_over_ranks(dist, dt, self.device), [a.elapsed_time(b) for a, b in evs]
 
+    def sample_names(self):
+        return ["SAMP%04d" % i for i in range(self.n_samples)]
+
+    def vcf_text(self):
+        """gtx_vcf_records over the results of the last step (host side): the region's VCF records as bytes, and the calls"""
+        gtx, ctx = self.gtx, self.ctx
+        self.torch.cuda.synchronize()
+        calls = self.d_calls.cpu().numpy().view(gtx.SAMPLE_CALL)[:self.n_samples * ctx.n_hap]
+        nh, ta = ctx.n_hap, ctx.total_allele
+        text = ctx.vcf_records("chr20", self.sample_names(),
+                               gtx.download(self.buf.d_gt_cov, np.uint32, self.n_samples * ta), gtx.download(self.buf.d_stat_u64, np.uint64, nh + 2 * ta),
+                               gtx.download(self.buf.d_stat_u32, np.uint32, nh + 6 * ta), self.d_phred.cpu().numpy()[:self.n_samples * ctx.total_tri], calls)
+        return text, calls
+
+    def calls_checksum(self, read_set=0):
+        """One more (untimed) step over resident read set `read_set`, then the SHA-256 of the VCF text gtx_vcf_records writes
+        from its results -- every site's GT, AD, DP, GQ, PL and INFO statistics of every sample.  tests/test_gpu_full_size.py
+        pushes the same reads (same seed) through the CPU oracle, all of them, and must arrive at the same digest."""
+        import hashlib
+        self.steps_done = read_set
+        self.step()
+        text, _ = self.vcf_text()
+        return {"vcf_sha256": hashlib.sha256(text).hexdigest(), "vcf_bytes": len(text), "read_set": read_set,
+                "what": "sha256 of the region's VCF records (gtx_vcf_records, column line first) after one step over read set %d" % read_set}
+
     def result_facts(self):
         """sanity on the results of the last step: every record must be a result, not an overflow"""
         gtx, ctx = self.gtx, self.ctx
         rec_head = self.d_rec.view(self.n * 2, REC_WORDS)[:, 0]
-        calls = self.d_calls.cpu().numpy().view(gtx.SAMPLE_CALL)[:self.n_samples * ctx.n_hap]
         cc = gtx.download(self.buf.d_conn_count, np.uint32, 2)
         # VCF text of the region from the last step's results (host side, outside the timed region)
         t0 = time.perf_counter()
-        nh, ta = ctx.n_hap, ctx.total_allele
-        text = ctx.vcf_records("chr20", ["SAMP%04d" % i for i in range(self.n_samples)],
-                               gtx.download(self.buf.d_gt_cov, np.uint32, self.n_samples * ta), gtx.download(self.buf.d_stat_u64, np.uint64, nh + 2 * ta),
-                               gtx.download(self.buf.d_stat_u32, np.uint32, nh + 6 * ta), self.d_phred.cpu().numpy()[:self.n_samples * ctx.total_tri], calls)
+        text, calls = self.vcf_text()
         self.vcf = {"records": text.count(b"\n") - 1, "bytes": len(text), "pass": text.count(b"\tPASS\t"), "host_ms": round((time.perf_counter() - t0) * 1e3, 2)}
         return {"reads_aligned": int(((rec_head[0::2] & 0xFFFF) > 0).sum().item()), "vcf_text": self.vcf,
                 "reads_overflowed": int((((rec_head >> 16) & gtx.ST_ERROR_MASK) != 0).sum().item()),
@@ -528,9 +559,7 @@ def main(argv=None):
     device = torch.device("cuda", local_rank)
 
     # ---- graph + index (replicated on every GPU) ----
-    ref = synth.make_reference(args.region_len, seed=42)
-    records = synth.make_snp_records(ref, args.snp_every, seed=7, region_begin=REGION_BEGIN)
-    ref_str = synth.bases_to_str(ref)
+    ref, records, ref_str = cfg2_graph_inputs(synth, args.region_len, args.snp_every)
     t0 = time.time()
     ctx = gtx.Context(gtx.graph_from_records(ref_str, records, region_begin=REGION_BEGIN), device=local_rank)
     t_ctx = time.time() - t0
@@ -542,11 +571,11 @@ def main(argv=None):
 
     # ---- reads, resident in HBM before the timed region ----
     n = args.reads
-    d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=1234 + rank, device=device, REGION_LEN=args.region_len,
+    d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=CFG2_READ_SEED + rank, device=device, REGION_LEN=args.region_len,
                                         err_rate=args.err, n_rate=args.nrate)
     w = Workload(torch, gtx, ctx, device, d_seq, d_pos, 1, hint=not args.no_hint)
     for k in range(1, max(args.read_sets, 1)):  # the steps alternate between resident read sets (different reads, same size)
-        w.add_reads(*make_reads_on_device(torch, ref, records, n, seed=1234 + rank + 7919 * k, device=device, REGION_LEN=args.region_len,
+        w.add_reads(*make_reads_on_device(torch, ref, records, n, seed=CFG2_READ_SEED + rank + 7919 * k, device=device, REGION_LEN=args.region_len,
                                           err_rate=args.err, n_rate=args.nrate))
     if dist is not None:
         w.setup_reduce(dist, rank, world, local_rank)
@@ -583,8 +612,10 @@ def main(argv=None):
     # dominant kernel of the step and the units it completes (what it hands on is not counted for it)
     roof = dominant_kernel(pass_ms, n_pass2, n, align_avg_ms, kern)
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tf):
+    import glob
+    tfs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))  # the latest round's PMC passes
+    tf = tfs[-1] if tfs else ""
+    if tf:
         try:
             tj = json.load(open(tf))
             tk = tj.get("kernels", {}).get(roof["kernel"])
@@ -593,16 +624,28 @@ def main(argv=None):
         except Exception:
             traffic = None
     roof["traffic"] = traffic
+    # (bench.py cannot run rocprofv3 on itself: the figure is the PMC measurement of tools/profile.sh on this workload, scaled
+    #  to this run's read count -- not a measurement of this run)
+    roof["traffic_source"] = ("profiles/" + os.path.basename(tf) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile.sh, FETCH doubled for gfx950; "
+                              "scaled by reads)") if traffic is not None else None
     cfg = {"workload": "cfg2: 1 sample, %d synthetic %d bp reads per GPU, chr20:1000001-2000000 (1 Mb), SNP-only graph "
                        "(1 SNP / %d bp), unpaired, 0.5%% substitutions, 0.1%% N; result = SampleCall (GT, PL, GQ, depths) per "
-                       "site, identical to the oracle's; gtx_vcf_records writes the region's VCF records from them on the host after the "
-                       "timed steps (config.vcf_text; records byte-identical to the oracle's in the tests, unbroken sites)" % (n, READ_LEN, args.snp_every),
+                       "site; gtx_vcf_records writes the region's VCF records from them on the host after the timed steps "
+                       "(config.vcf_text, config.calls_checksum: the digest the full-size GPU test reproduces from the oracle over all reads)" % (n, READ_LEN, args.snp_every),
            "reads_per_gpu": n, "index_keys": n_keys, "index_labels": n_labels, "haplotypes": ctx.n_hap,
            "ctx_create_s": round(t_ctx_warm, 3), "ctx_create_first_s": round(t_ctx, 3),
            "position_hint": not args.no_hint, "task_flags_side_array": USE_TASK_FLAGS, "resident_read_sets": len(w.sets),
            "parallelism": "reads sharded over %d GPU(s), graph+index replicated" % n_gpus,
            "reduce": w.reduce_kind, "reduced_bytes_per_step": w.reduced_bytes if n_gpus > 1 else 0}
     cfg.update(facts)
+    if n_gpus == 1:
+        try:
+            cfg["calls_checksum"] = w.calls_checksum(0)
+            cfg["calls_checksum"]["reads_seed"] = CFG2_READ_SEED
+            cfg["calls_checksum"]["checked_by"] = ("tests/test_gpu_full_size.py::test_cfg2_every_read_against_the_oracle: all reads of this set through "
+                                                   "oracle/ on the host cores -> accumulators, SampleCalls and VCF bytes equal")
+        except Exception as e:  # the extra field must never cost the main line
+            cfg["calls_checksum"] = {"error": repr(e)}
     out = {"metric": METRIC, "value": value, "unit": "reads/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u64/u32 integer (2-bit k-mer keys, byte compares, u32 atomics)", "data": "synthetic", "config": cfg,

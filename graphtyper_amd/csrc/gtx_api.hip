@@ -1380,7 +1380,9 @@ extern "C" int gtx_align_batch_flags(gtx_ctx * c, const uint8_t * d_seq, uint32_
     (void)hipEventRecord(static_cast<hipEvent_t>(s->sync_events[CallScratch::MAX_PARTS]), st);
     (void)hipStreamWaitEvent(sg, static_cast<hipEvent_t>(s->sync_events[CallScratch::MAX_PARTS]), 0);
   }
-  uint32_t const step = parts == 1 ? n_reads : ((n_reads / parts + 1023u) / 1024u) * 1024u;
+  // (whole kilo-reads per part, at least one: n_reads < parts must not give a step of 0, an inexact division must not give
+  //  a part more than asked for -- the counters, events and queues are sized for MAX_PARTS)
+  uint32_t const step = parts == 1 ? n_reads : std::max<uint32_t>(1024u, static_cast<uint32_t>(((static_cast<uint64_t>(n_reads) + parts - 1u) / parts + 1023u) / 1024u * 1024u));
   uint32_t used_parts = 0;
   for (uint32_t first = 0; first < n_reads; first += step, ++used_parts)
   {

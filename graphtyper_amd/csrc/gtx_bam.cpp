@@ -491,7 +491,12 @@ struct File
     int64_t as = -1, xs = -1;
     auto load = [&](auto tag, bool is_as, bool is_xs)
     {
-      decltype(tag) num;
+      decltype(tag) num = 0;
+      if (i + sizeof(num) > l_aux) // (a truncated aux area: the reference reads on into htslib's padding; here the field is not there)
+      {
+        i = l_aux;
+        return;
+      }
       std::memcpy(&num, it + i, sizeof(num));
       if (is_as)
         as = num;
@@ -535,12 +540,12 @@ struct File
   // bam_aux_get(rec, "RG"): htslib walks the fields by their types
   static bool find_rg(uint8_t const * aux, uint32_t l_aux, std::string & out)
   {
-    uint32_t i = 0;
+    uint64_t i = 0; // (64 bits: a hostile 'B' count must not wrap the cursor back into the area)
     while (i + 3 <= l_aux)
     {
       char const t0 = static_cast<char>(aux[i]), t1 = static_cast<char>(aux[i + 1]), type = static_cast<char>(aux[i + 2]);
       i += 3;
-      uint32_t size = 0;
+      uint64_t size = 0;
       switch (type)
       {
       case 'A': case 'c': case 'C': size = 1; break;
@@ -549,7 +554,7 @@ struct File
       case 'd': size = 8; break;
       case 'Z': case 'H':
       {
-        uint32_t j = i;
+        uint64_t j = i;
         while (j < l_aux && aux[j] != '\0')
           ++j;
         if (t0 == 'R' && t1 == 'G' && type == 'Z')
@@ -567,12 +572,14 @@ struct File
         char const sub = static_cast<char>(aux[i]);
         uint32_t n;
         std::memcpy(&n, aux + i + 1, 4);
-        uint32_t const w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-        size = 5 + n * w;
+        uint64_t const w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+        size = 5 + static_cast<uint64_t>(n) * w;
         break;
       }
       default: return false;
       }
+      if (i + size > l_aux) // a field that runs past the aux area: malformed record, no read group
+        return false;
       i += size;
     }
     return false;

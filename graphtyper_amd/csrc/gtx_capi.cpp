@@ -234,7 +234,7 @@ extern "C"
   // (a device-built index keeps its keys and labels on the device: they are fetched when somebody looks)
   static int inspectable(const gtx_ctx * c)
   {
-    return c->index_downloaded ? GTX_OK : download_index(*const_cast<gtx_ctx *>(c));
+    return c->index_downloaded.load(std::memory_order_acquire) ? GTX_OK : download_index(*const_cast<gtx_ctx *>(c));
   }
 
   int gtx_index_get(const gtx_ctx * c, uint64_t key, gtx_label * out, uint32_t cap, uint32_t * n)

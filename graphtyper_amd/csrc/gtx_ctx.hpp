@@ -86,7 +86,8 @@ struct gtx_ctx
   uint64_t * d_keys = nullptr;
   uint32_t * d_key_off = nullptr;
   gtx_label * d_labels_sorted = nullptr;
-  bool index_downloaded = false;
+  std::atomic<bool> index_downloaded{false}; // set (release) by download_index under index_mutex; readers check it first (acquire)
+  std::mutex index_mutex;
 };
 
 namespace gtx

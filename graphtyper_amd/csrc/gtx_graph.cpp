@@ -242,9 +242,11 @@ extern "C"
       return GTX_ERR_ARG;
     }
     // the records have to be what the constructor hands to Graph::add_genomic_region: sorted by position
-    // (constructor.cpp:1749-1757) and inside the reference that came with them (the constructor drops records that leave
-    // the region, :1660-1662; check_if_var_records_match_reference_genome, :1736).  A record outside it used to slip through
-    // and leave nodes of length 0 or lost sites behind.
+    // (constructor.cpp:1749-1757) and -- those the region filter below keeps (graph.cpp:60-79: records in front of the
+    // region are erased, the list is cut at the first one at or behind region_end) -- inside the reference that came with
+    // them (check_if_var_records_match_reference_genome, constructor.cpp:1736).  A kept record outside it used to slip
+    // through and leave nodes of length 0 or lost sites behind; a record behind the region is simply dropped, as the
+    // reference does (an SV breakpoint record moved by SVLEN lands there when the SV starts inside and ends outside).
     for (uint32_t r = 0; r < n_records; ++r)
     {
       if (records[r].n_alleles < 1 || !records[r].alleles)
@@ -258,7 +260,7 @@ extern "C"
         return GTX_ERR_ARG;
       }
       long const pos = records[r].pos, ref_len = records[r].alleles[0].len;
-      if (pos >= region_begin && pos + ref_len > region_begin + static_cast<long>(reference_len))
+      if (pos >= region_begin && pos < region_end && pos + ref_len > region_begin + static_cast<long>(reference_len))
       {
         g_last_error = "gtx_graph_build: record " + std::to_string(r) + " at " + std::to_string(pos) + " leaves the reference sequence";
         return GTX_ERR_ARG;

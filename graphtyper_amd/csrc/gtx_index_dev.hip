@@ -552,7 +552,11 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, HintGraphTable
 // the device-built index in reference order, for the inspection entry points (gtx_index_get / gtx_index_dump)
 int download_index(gtx_ctx & c)
 {
-  if (c.index_downloaded || c.device < 0)
+  if (c.device < 0)
+    return GTX_OK;
+  // (several host threads may inspect one context: the first one in fills the vectors, the others wait for it)
+  std::lock_guard<std::mutex> lock(c.index_mutex);
+  if (c.index_downloaded.load(std::memory_order_acquire))
     return GTX_OK;
   if (!ok_hip(hipSetDevice(c.device), "hipSetDevice"))
     return GTX_ERR_HIP;
@@ -565,7 +569,7 @@ int download_index(gtx_ctx & c)
     return GTX_ERR_HIP;
   if (c.n_keys == 0)
     c.index.key_off.assign(1, 0);
-  c.index_downloaded = true;
+  c.index_downloaded.store(true, std::memory_order_release);
   return GTX_OK;
 }
 

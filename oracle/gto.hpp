@@ -2434,6 +2434,12 @@ struct ReferenceDepth
       if (depth[i] < 0xFFFFul)
         ++depth[i];
   }
+  void merge_from(ReferenceDepth const & o) // (test infrastructure, see Genotyper::merge_from; clamped like gtx_ref_depth_finalize)
+  {
+    for (std::size_t s = 0; s < depths.size() && s < o.depths.size(); ++s)
+      for (std::size_t i = 0; i < depths[s].size(); ++i)
+        depths[s][i] = static_cast<uint16_t>(std::min<uint32_t>(0xFFFFu, static_cast<uint32_t>(depths[s][i]) + o.depths[s][i]));
+  }
 };
 
 // ---------------------------------------------------------------------------
@@ -2604,6 +2610,71 @@ struct Genotyper
     parked_sample.clear();
   }
   std::unordered_map<std::string, int> parked_sample;
+
+  // Test infrastructure, no counterpart in the reference: adds the accumulated state of another Genotyper over the same
+  // graph and samples into this one, so that a large read set can be pushed through several Genotypers on several host
+  // threads (tests/test_gpu_full_size.py: all 10 M reads of BASELINE cfg2).  Every per-read effect on a haplotype is an
+  // addition (explain_to_score, coverage_to_gts, *_to_stats, commit_connections), so the sum equals one sequential pass as
+  // long as no counter reaches its saturation point: the u8 / u16 depth counters saturate (haplotype.cpp:19-44) -- summed and
+  // clamped the same way here, which is order-free -- but explain_to_score's guard (haplotype.cpp:560) is sequential, so a
+  // cell whose summed max_log_score comes within 8 of 0xFFFF is refused.  Reads parked for their mates are not merged
+  // (shards must hold both mates).
+  void merge_from(Genotyper const & o)
+  {
+    if (o.writer.haplotypes.size() != writer.haplotypes.size())
+      throw std::runtime_error("gto: merge of genotypers over different graphs");
+    for (auto const & m : o.maps)
+      if (!m.empty())
+        throw std::runtime_error("gto: merge of a genotyper with parked mates");
+    for (std::size_t h = 0; h < writer.haplotypes.size(); ++h)
+    {
+      Haplotype & a = writer.haplotypes[h];
+      Haplotype const & b = o.writer.haplotypes[h];
+      if (a.num != b.num || a.hap_samples.size() != b.hap_samples.size())
+        throw std::runtime_error("gto: merge of genotypers with different samples");
+      a.clipped_reads += b.clipped_reads;
+      a.mapq_squared += b.mapq_squared;
+      for (std::size_t k = 0; k < a.per_allele.size(); ++k)
+      {
+        a.per_allele[k].clipped_bp += b.per_allele[k].clipped_bp;
+        a.per_allele[k].mapq_squared += b.per_allele[k].mapq_squared;
+        a.per_allele[k].score_diff += b.per_allele[k].score_diff;
+        a.per_allele[k].mismatches += b.per_allele[k].mismatches;
+        a.read_strand[k].r1_forward += b.read_strand[k].r1_forward;
+        a.read_strand[k].r1_reverse += b.read_strand[k].r1_reverse;
+        a.read_strand[k].r2_forward += b.read_strand[k].r2_forward;
+        a.read_strand[k].r2_reverse += b.read_strand[k].r2_reverse;
+      }
+      for (std::size_t s = 0; s < a.hap_samples.size(); ++s)
+      {
+        HapSample & x = a.hap_samples[s];
+        HapSample const & y = b.hap_samples[s];
+        uint32_t const mx = static_cast<uint32_t>(x.max_log_score) + y.max_log_score;
+        if (mx >= 0xFFFFu - 8u)
+          throw std::runtime_error("gto: merge would pass the saturation guard of explain_to_score");
+        x.max_log_score = static_cast<uint16_t>(mx);
+        for (std::size_t i = 0; i < x.log_score.size(); ++i)
+          x.log_score[i] = static_cast<uint16_t>(x.log_score[i] + y.log_score[i]); // (<= max_log_score: no wrap)
+        for (std::size_t i = 0; i < x.gt_coverage.size(); ++i)
+          x.gt_coverage[i] = static_cast<uint16_t>(std::min<uint32_t>(0xFFFFu, static_cast<uint32_t>(x.gt_coverage[i]) + y.gt_coverage[i]));
+        auto add8 = [](uint8_t & u, uint8_t v) { u = static_cast<uint8_t>(std::min<uint32_t>(0xFFu, static_cast<uint32_t>(u) + v)); };
+        add8(x.ambiguous_depth, y.ambiguous_depth);
+        add8(x.ambiguous_depth_alt, y.ambiguous_depth_alt);
+        add8(x.alt_proper_pair_depth, y.alt_proper_pair_depth);
+        for (std::size_t al = 0; al < x.connections.size(); ++al)
+          for (auto const & kv : y.connections[al])
+          {
+            auto ins = x.connections[al].insert({kv.first, std::vector<uint16_t>(kv.second.size())});
+            for (std::size_t i = 0; i < kv.second.size(); ++i)
+              ins.first->second[i] = static_cast<uint16_t>(ins.first->second[i] + kv.second[i]); // (wraps like the reference's ++)
+          }
+      }
+    }
+    num_records += o.num_records;
+    num_duplicated += o.num_duplicated;
+    if (graph.is_sv_graph)
+      reference_depth.merge_from(o.reference_depth);
+  }
 
   // Vcf::add_haplotype (src/typer/vcf.cpp:1507-1530): per haplotype and sample the SampleCall the reference builds --
   // get_haplotype_phred (vcf.cpp:47-82), SampleCall constructor / get_gt_call / get_gq (sample_call.cpp:34-131).

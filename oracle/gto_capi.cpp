@@ -207,6 +207,8 @@ extern "C"
       h->par.max_index_labels = max_index_labels;
       h->graph.is_sv_graph = is_sv_graph != 0;
       h->graph.region_begin = region_begin;
+      // GenomicRegion::end: the reference sequence handed over IS the region (read_reference_genome, constructor.cpp:1614-1616)
+      h->graph.region_end = region_begin + static_cast<long>(std::strlen(reference));
       h->graph.add_all_variants = add_all_variants != 0;
       std::vector<VarRecord> records = parse_records(records_text);
       if (extend_prefix)
@@ -609,6 +611,21 @@ extern "C"
 
   uint16_t gto_binned_pl(unsigned pl) { return vcf::binned_pl(pl); }
   double gto_p_hwe_excess_het(int het, int hom1, int hom2) { return vcf::p_hwe_excess_het(het, hom1, hom2); }
+
+  // dst += src (Genotyper::merge_from: test infrastructure for sharding the oracle over host threads); 0 = ok
+  int gto_genotyper_merge(void * dst, void * src)
+  {
+    try
+    {
+      static_cast<GenoHandle *>(dst)->g->merge_from(*static_cast<GenoHandle *>(src)->g);
+      return 0;
+    }
+    catch (std::exception const & e)
+    {
+      g_error = e.what();
+      return 1;
+    }
+  }
 
   void gto_genotyper_counts(void * p, long * out)
   {

@@ -276,7 +276,48 @@ class OracleGenotyper:
         L.gto_vcf_records(*args, buf, C.c_long(n))
         return buf.raw[:n]
 
+    def merge(self, other):
+        """self += other (Genotyper::merge_from: sums of the accumulated state; refused at the saturation guard)"""
+        L = lib()
+        L.gto_genotyper_merge.argtypes = [C.c_void_p, C.c_void_p]
+        if L.gto_genotyper_merge(C.c_void_p(self.g), C.c_void_p(other.g)) != 0:
+            raise RuntimeError(L.gto_last_error().decode())
+
     def counts(self):
         c = (C.c_long * 3)()
         lib().gto_genotyper_counts(C.c_void_p(self.g), c)
         return dict(records=int(c[0]), duplicated=int(c[1]), parked=int(c[2]))
+
+
+def sharded_genotyper(oracle, codes, pos, n_samples=1, samples=None, threads=None, mapq=None):
+    """All reads of a large UNPAIRED, position-sorted read set through the oracle on several host threads: contiguous
+    shards, one Genotyper each (the C++ calls release the GIL), summed into the first (Genotyper::merge_from).  codes:
+    [n, L] uint8 BAM codes.  A shard boundary only loses the reuse of the previous record's paths for an exact duplicate,
+    which is an optimisation of the reference, not part of the result."""
+    import threading
+    n, L = codes.shape
+    threads = max(1, min(threads or (os.cpu_count() or 1), 256, (n + 9999) // 10000))
+    cuts = [n * k // threads for k in range(threads + 1)]
+    genos = [oracle.genotyper(n_samples, 1) for _ in range(threads)]
+    errors = []
+
+    def work(k):
+        a, b = cuts[k], cuts[k + 1]
+        try:
+            flat = np.ascontiguousarray(codes[a:b]).reshape(-1)
+            offs = (np.arange(b - a + 1, dtype=np.uint64) * L).astype(np.uint32)
+            genos[k].push(None, pos=np.ascontiguousarray(pos[a:b], np.int64), packed=(flat, offs),
+                          sample=None if samples is None else samples[a:b], mapq=None if mapq is None else mapq[a:b])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    team = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+    for t in team:
+        t.start()
+    for t in team:
+        t.join()
+    if errors:
+        raise errors[0]
+    for g in genos[1:]:
+        genos[0].merge(g)
+    return genos[0], threads

@@ -81,6 +81,25 @@ def synthetic_case(kind, n_ref=40000, n_reads=300, seed=0, region_begin=1000000,
             u[e] = (u[e] + rng.integers(1, 4, size=int(e.sum()))) % 4
             ref[at + c * 180:at + (c + 1) * 180] = u
         recs = synth.make_snp_records(ref, 40, seed=seed + 11, region_begin=region_begin)
+    elif kind == "neardup":
+        # near-duplicate segments: 300 bp stretches copied elsewhere one substitution every ~40 bp apart (a 32-mer of the copy
+        # is the original's or its Hamming-1 neighbour: what the per-position flags of the hinted pass have to see through),
+        # plus homopolymer runs; SNPs every 100 bp on top
+        rng = np.random.default_rng(seed + 12)
+        n_seg = max(4, n_ref // 4000)
+        for _ in range(n_seg):
+            src = int(rng.integers(0, n_ref - 300))
+            seg = ref[src:src + 300].copy()
+            for _copy in range(int(rng.integers(1, 3))):
+                dst = int(rng.integers(0, n_ref - 300))
+                c = seg.copy()
+                at = np.arange(int(rng.integers(5, 40)), 300, 40)
+                c[at] = (c[at] + rng.integers(1, 4, size=len(at))) % 4
+                ref[dst:dst + 300] = c
+        for _ in range(n_seg):
+            at = int(rng.integers(0, n_ref - 80))
+            ref[at:at + int(rng.integers(20, 60))] = int(rng.integers(0, 4))
+        recs = synth.make_snp_records(ref, 100, seed=seed + 13, region_begin=region_begin)
     else:
         raise ValueError(kind)
     if kind == "repeat":  # reads from the repeat and its flanks only

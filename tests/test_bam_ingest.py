@@ -253,3 +253,28 @@ def test_readers_on_several_host_threads_share_the_inflate_team(tmp_path, monkey
     for t in team_of_hosts:
         t.join()
     assert not failures, failures[0]
+
+
+def test_array_field_with_a_hostile_count_ends_the_aux_walk(tmp_path):
+    """a 'B' aux field whose element count runs far past the record (count 0xFFFFFFF8, subtype c: a 32-bit cursor would
+    wrap back onto the same field and never leave it) in a file with two read groups -- the only case in which the reader
+    looks for the RG tag.  The record counts as one without a read group, which such a file does not allow (the reference
+    exits there, hts_reader.cpp:354-387): the reader must come back with that error instead of hanging."""
+    import os
+    import struct
+    import subprocess
+    import sys
+    refs = [("chrA", 5000)]
+    header = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chrA\tLN:5000\n@RG\tID:a\tSM:s1\n@RG\tID:b\tSM:s2\n"
+    codes = np.full(100, 1, np.uint8)
+    good = bw.record("r0", 0, 0, 100, 60, [("M", 100)], -1, -1, 0, codes, [("RG", "Z", "b")])
+    body = bw.record("r1", 0, 0, 200, 60, [("M", 100)], -1, -1, 0, codes, [])[4:]
+    body += b"XBBc" + struct.pack("<I", 0xFFFFFFF8) + b"\x01\x02\x03"
+    bad = struct.pack("<i", len(body)) + body
+    path = str(tmp_path / "hostile.bam")
+    bw.write_bam(path, refs, header, [good, bad])
+    child = ("import sys; sys.path.insert(0, %r)\nfrom graphtyper_amd import lib as gtx\nr = gtx.Reads([%r])\nn = 0\n"
+             "while True:\n    recs, seq = r.next(64)\n    if len(recs) == 0: break\n    n += len(recs)\nprint('records', n)\n") % (
+                 os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path)
+    out = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=60)
+    assert "without RG tag" in out.stderr, (out.stdout, out.stderr[-300:])

@@ -82,6 +82,22 @@ def test_align_synthetic(kind):
     test_align_synthetic.share[kind] = share
 
 
+def neardup_case(Backend, n_reads, n_ref=60000):
+    """a reference with planted near-duplicate segments (copies one substitution apart) and homopolymer runs, 1 % errors:
+    the flags of the position-hinted pass must know which places are provably simple; every record with correct, missing,
+    shifted and foreign hints against the oracle"""
+    ref, recs, codes, pos = scenarios.synthetic_case("neardup", n_ref=n_ref, n_reads=n_reads, region_begin=44000, err=0.01, n_rate=0.002)
+    o = Oracle(ref, recs, region_begin=44000)
+    b = Backend(gtx.graph_from_records(ref, recs, region_begin=44000))
+    check_align(b, o, list(codes), pos=pos, allow_overflow=False)
+    return check_align.hinted_done
+
+
+def test_align_near_duplicate_reference():
+    done = neardup_case(harness.EmuBackend, 3000)
+    assert 0 < done < 3000
+
+
 def iupac_case(Backend, n_reads):
     """reads with IUPAC ambiguity codes of every kind (2-, 3- and 4-base sets; 1 % of the bases): key lists in
     to_uint64_vec order for one ambiguous base per k-mer (vector path) and for several (sequential expansion, up to the
@@ -249,7 +265,7 @@ def second_pass_case(Backend, kind, n_reads):
     o = Oracle(ref, recs, region_begin=5000)
     g = gtx.graph_from_records(ref, recs, region_begin=5000)
     b = Backend(g)
-    rec, _ = check_align(b, o, list(codes))
+    rec, _ = check_align(b, o, list(codes), pos=pos)  # (with, without, with shifted and with foreign position hints)
     _, tasks = b.big_records()
     status = rec.reshape(-1, harness.REC_WORDS)[:, 0] >> 16
     assert tasks > n_reads // 2 and (status & gtx.ST_EXTERNAL).any()

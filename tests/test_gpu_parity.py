@@ -10,7 +10,7 @@ import harness
 import scenarios
 from graphtyper_amd import lib as gtx
 from oracle_lib import Oracle, encode
-from test_emu_parity import check_align, direct_probes_case, n_runs_case, three_n_case, sv_deletion_case, edge_case, express_variants_case, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case
+from test_emu_parity import check_align, neardup_case, direct_probes_case, n_runs_case, three_n_case, sv_deletion_case, edge_case, express_variants_case, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case
 
 pytestmark = pytest.mark.gpu
 
@@ -90,7 +90,8 @@ def test_merged_multiallelic_graph():
     g = gtx.graph_from_records(ref, recs, region_begin=1000000, add_all_variants=True)
     assert int(g["ref_nvar"].max()) >= 6
     b = harness.GpuBackend(g)
-    check_align(b, o, list(codes))
+    check_align(b, o, list(codes), pos=pos)  # (every record with correct, missing, shifted and foreign position hints)
+    assert check_align.hinted_done > len(codes) // 10
     order = np.argsort(pos, kind="stable")
     rec = scenarios.stream_records(len(codes), pos, sample=np.arange(len(codes)) % 30)
     run_stream(b, o, codes[order], rec[order], n_samples=30)
@@ -99,6 +100,11 @@ def test_merged_multiallelic_graph():
 @pytest.mark.parametrize("kind", ["repeat", "snp7"])
 def test_second_pass(kind):
     second_pass_case(harness.GpuBackend, kind, 5000 if kind == "repeat" else 3000)  # (snp7: ~200 connection entries per read)
+
+
+def test_align_near_duplicate_reference():
+    done = neardup_case(harness.GpuBackend, 20000, n_ref=200000)
+    assert 0 < done < 20000
 
 
 def test_forced_second_pass(monkeypatch):

@@ -142,3 +142,20 @@ def test_bad_sv_lines_are_errors_not_graphs(tmp_path):
     with pytest.raises(gtx.GtxError) as e:
         gtx.graph_from_files(fa, vcf, "chrA", is_sv_graph=False)  # (the reference exits: an SV in a non-SV graph)
     assert e.value.status == 4
+
+
+def test_sv_that_starts_inside_the_region_and_ends_behind_it(tmp_path):
+    """a tandem duplication / inversion moves its second breakpoint record by SVLEN (constructor.cpp:727-871, 873-1031): when
+    the SV starts inside the region and ends behind it, that record lies at or behind region_end and Graph::add_genomic_region
+    drops it (graph.cpp:72-79) -- the region's graph is still built, from the records that stay"""
+    seqs = _random_contigs(9, 4000)
+    a = seqs["chrA"]
+    lines = [
+        "chrA\t301\t.\t%s\t%s\t0\t.\t." % (a[300], "ACGT"[("ACGT".index(a[300]) + 1) % 4]),
+        "chrA\t901\t.\t%s\t<DUP>\t0\t.\tSVTYPE=DUP;SVLEN=500" % a[900],
+        "chrA\t1001\t.\t%s\t<INV>\t0\t.\tSVTYPE=INV;SVLEN=400" % a[1000],
+    ]
+    fa, vcf = _write(tmp_path, seqs, lines)
+    g_all, _ = _compare(fa, vcf, seqs, lines, "chrA", region="chrA:1-2000")   # both breakpoints of both SVs
+    g_cut, recs = _compare(fa, vcf, seqs, lines, "chrA", region="chrA:1-1200")  # second breakpoints at 1400 / 1401: dropped
+    assert len(g_cut["ref_order"]) < len(g_all["ref_order"]) and len(g_cut["var_order"]) >= 6

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the hot path on the indel-rich graph shapes of the test scenarios (cfg3-like), for DESIGN.md:
 1 Mb region, 1 M reads generated on the host, one sample; align + score + calls per step.
-Usage on a GPU box: python tools_bench_kinds.py [indel cluster]"""
+Usage on a GPU box: python tools/bench_kinds.py [indel cluster]"""
 import ctypes as C
 import json
 import os
@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

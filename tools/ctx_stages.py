@@ -5,7 +5,7 @@ import sys
 import time
 
 os.environ["GTX_TIMING"] = "1"
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from graphtyper_amd import lib as gtx, synth  # noqa: E402
 

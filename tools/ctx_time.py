@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Host time of gtx_ctx_create's flat graph + index build for the cfg2 graph, by size of the thread team
-(GTX_HOST_THREADS).  No GPU needed: python tools_ctx_time.py"""
+(GTX_HOST_THREADS).  No GPU needed: python tools/ctx_time.py"""
 import os
 import subprocess
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 if len(sys.argv) > 1:

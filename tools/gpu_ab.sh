@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library builds on one box: bash tools_gpu_ab.sh "<lib>:<snp-every>:<reads>[:<GTX_EXPRESS4>]" ...  (two rounds, interleaved)
+# A/B of library builds on one box: bash tools/gpu_ab.sh "<lib>:<snp-every>:<reads>[:<GTX_EXPRESS4>]" ...  (two rounds, interleaved)
 set -u
 mkdir -p gpurun_out/ab
 for round in 1 2; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of environment switches on one box: bash tools_gpu_ab_env.sh "VAR=a" "VAR=b" ...  (each argument is an env assignment list)
+# A/B of environment switches on one box: bash tools/gpu_ab_env.sh "VAR=a" "VAR=b" ...  (each argument is an env assignment list)
 set -u
 mkdir -p gpurun_out
 for round in 1 2; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# like tools_gpu_ab_env.sh, with the cfg3-like extra workload in the line
+# like tools/gpu_ab_env.sh, with the cfg3-like extra workload in the line
 set -u
 mkdir -p gpurun_out
 for round in 1 2; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel durations (rocprofv3 --kernel-trace --stats) of the cfg2 bench under an environment switch: bash tools_kt.sh VAR=a VAR=b
+# kernel durations (rocprofv3 --kernel-trace --stats) of the cfg2 bench under an environment switch: bash tools/kt.sh VAR=a VAR=b
 export TMPDIR=/tmp; R=$PWD; cd /tmp
 for cfg in "$@"; do
   rm -rf $R/gpurun_out/kt_tmp

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Profiling recipe used for profiles/: run on the GPU box from the repo root (gpurun -- 'bash tools_profile.sh r01').
+# Profiling recipe used for profiles/: run on the GPU box from the repo root (gpurun -- 'bash tools/profile.sh r01').
 # 1) kernel trace + stats of the bench command; 2) PMC passes (own runs, no trace domains) for instruction mix and HBM bytes.
 set -u
 TAG=${1:-r02}
@@ -17,7 +17,7 @@ rocprofv3 --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/
 cd $REPO
 find $OUT -name '*.csv' | head -50
 for f in $OUT/*.log; do grep -m1 "^{" $f | cut -c1-400; done
-python tools_profile_summary.py $OUT $READS
+python tools/profile_summary.py $OUT $READS
 # only then drop what is too large to bring back
 find $OUT -type f ! -name '*.csv' ! -name '*.log' ! -name '*.json' -delete
 find $OUT -name '*.csv' -size +4M -delete

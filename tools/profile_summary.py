@@ -1,4 +1,4 @@
-"""Condense the rocprofv3 output of tools_profile.sh into the files that are committed under profiles/:
+"""Condense the rocprofv3 output of tools/profile.sh into the files that are committed under profiles/:
 pmc_summary.json (counter sums per gtx kernel), pmc_traffic.json (HBM bytes per launch, read by bench.py for
 roofline.traffic), kernel_stats.csv (rocprofv3's own --stats table) and kernel_stats_gtx.csv (the same rows for this
 library's kernels and the rocPRIM sorts, names shortened)."""
@@ -41,7 +41,7 @@ try:  # passes whose CSVs were too large to bring back were summarised on the GP
                 summary[k].setdefault(c, v)
 except (OSError, ValueError):
     pass
-summary["_note"] = ("sums over the launches of one bench.py run (--reads %d, 1 step, no warm-up) per PMC pass; tools_profile.sh" % reads)
+summary["_note"] = ("sums over the launches of one bench.py run (--reads %d, 1 step, no warm-up) per PMC pass; tools/profile.sh" % reads)
 json.dump(summary, open(old, "w"), indent=1, sort_keys=True)
 
 ks = sorted(glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True))
@@ -67,7 +67,7 @@ for k, d in summary.items():
                                            "hbm_bytes_per_launch": b,
                                            "hbm_bytes_per_launch_uncorrected": (d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024 / n,
                                            "bytes_per_read_of_the_batch": b / reads}
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools_profile.sh) over one bench.py step of %d reads (cfg2, "
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/profile.sh) over one bench.py step of %d reads (cfg2, "
                    "no warm-up); per launch" % reads, "reads_per_launch": reads, "kernels": kernels}, open(out + "/pmc_traffic.json", "w"), indent=1)
 print(open(out + "/kernel_stats_gtx.csv").read() if ks else "no kernel stats")
 for k, v in kernels.items():
