@@ -451,7 +451,7 @@ GTX_DEV uint32_t hint_kmer(uint2_t const f, uint8_t const * seq4, HintCounts con
     ok = mis_left == 0 ? l1 : mis_right == 0;
     need = mis_left == 0 ? 0u : HK_NEED_LEFT;
   }
-  GTX_HINT_NOTE(ok ? 0 : 7);
+  GTX_HINT_NOTE(ok ? 0 : 12);
   return hk_make(ok ? HINT_K_HOLE : HINT_K_DECLINE, site, 0u, false, true) | (ok ? need : 0u);
 }
 
@@ -718,7 +718,10 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   push(1, k1);
   push(0, k0);
   if (clash || 6 + 3 * nvar > rec_words)
+  {
+    GTX_HINT_NOTE(13);
     return false;
+  }
   uint32_t np = 1, longest = re - rs + 1;
   if (mism > 10) // remove_paths_with_too_many_mismatches
   {

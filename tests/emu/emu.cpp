@@ -22,11 +22,17 @@ namespace
 // arrays of 64, the wave-uniform parts of the kernel source run once.
 uint64_t g_notes[16];  // why a task left the express pass (W::note), test diagnostics only
 uint64_t g_hnotes[16]; // ... and the position-hinted pass (hint_note)
+uint32_t g_last_hnote;  // the last non-zero note of the current hinted_one call: why THIS read was declined
 
 } // namespace
 namespace gtx
 {
-void hint_note(uint32_t k) { ++g_hnotes[k & 15u]; }
+void hint_note(uint32_t k)
+{
+  ++g_hnotes[k & 15u];
+  if (k)
+    g_last_hnote = k;
+}
 } // namespace gtx
 namespace
 {
@@ -95,6 +101,9 @@ struct Emu
   uint64_t wide_pass_tasks = 0;   // tasks that went on to the pass with wide allele sets
   uint64_t general_tasks = 0;     // tasks pass 1 handed to pass 2
   uint64_t hinted_done = 0;       // forward tasks the position-hinted pass finished
+  // diagnostics of the last emu_align (tools/decline_notes.py): per read the pass that finished its forward task (0 hinted,
+  // 1 express, 2 general, 3 HBM tables) and the note pass 0 left when it declined the read (0: none / no note)
+  std::vector<uint8_t> pass_of, hint_decline;
 };
 
 } // namespace
@@ -233,8 +242,11 @@ extern "C"
       // (gtx_align_express4q_kernel), as gtx_align_batch launches them
       std::vector<uint32_t> queue1;
       e.hinted_done = 0;
+      e.pass_of.assign(n_reads, 0);
+      e.hint_decline.assign(n_reads, 0);
       for (uint32_t read = 0; read < n_reads; ++read)
       {
+        g_last_hnote = 0;
         gtx_read_meta const m = meta[read];
         uint32_t const len = m.l_qseq;
         bool const outside = len < 2 * K - 1 || len > AlignCfg::MAX_READ;
@@ -246,7 +258,11 @@ extern "C"
         else if (force != 0 || (eh && eh[0] == 'd') ||
                  !hinted_one(g, ix, reinterpret_cast<uint32_t const *>(seq + static_cast<uint64_t>(read) * seq_stride),
                              seq + static_cast<uint64_t>(read) * seq_stride, seq_stride, m, records + static_cast<uint64_t>(read) * 2 * rec_words, rec_words))
+        {
           queue1.push_back(read);
+          e.pass_of[read] = 1;
+          e.hint_decline[read] = static_cast<uint8_t>(g_last_hnote ? g_last_hnote : 15u);
+        }
         else
           ++e.hinted_done;
       }
@@ -272,7 +288,11 @@ extern "C"
         }
         for (uint32_t k = 0; k < n_valid; ++k)
           if ((mask >> k) & 1u)
+          {
+            uint64_t const before = e.second_pass_tasks;
             general(queue1[first + k] * 2);
+            e.pass_of[queue1[first + k]] = e.second_pass_tasks != before ? 3 : 2;
+          }
       }
       return 0;
     }
@@ -359,6 +379,17 @@ extern "C"
   }
 
   uint64_t emu_hinted_done(void * p) { return static_cast<Emu *>(p)->hinted_done; }
+
+  // per read of the last emu_align with the position-hinted pass: finishing pass of the forward task, pass 0's decline note
+  void emu_pass_of(void * p, uint8_t * pass_of, uint8_t * hint_decline, uint32_t n)
+  {
+    Emu & e = *static_cast<Emu *>(p);
+    for (uint32_t i = 0; i < n && i < e.pass_of.size(); ++i)
+    {
+      pass_of[i] = e.pass_of[i];
+      hint_decline[i] = e.hint_decline[i];
+    }
+  }
 
   uint64_t emu_general_tasks(void * p) { return static_cast<Emu *>(p)->general_tasks; }
 
