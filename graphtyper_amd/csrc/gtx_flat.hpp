@@ -136,7 +136,8 @@ struct IndexView
   //                     allele numbers (all below HINT_MASK_BITS); the neighbours as for HINT_EXACT_OK;
   //     bits 16.. of x  see HINT_SITE_SHIFT: the site K_i's label lies on (HINT_NO_SITE: none);
   //  y  bits 0..7       min(255, bases from this position to the end of its reference node), 0 = not in a reference node;
-  //     bits 8..15      min(255, bases of that node in front of the position).
+  //     bits 8..15      min(255, bases of that node in front of the position);
+  //     bits 21..26     HINT_SNP_GROUP, reference base and allele count of the SNP under K_i (see below).
   // filt[side]: blocked Bloom filter over every indexed key's 16 first (side 0) / last (side 1) bases in nibble form (two
   //   bits of one word per half): a clear bit proves that no indexed key has that half.
   // tail_info[i]: the site behind the reference node position i lies in, when a walk from i may cross it the simple way
@@ -156,6 +157,11 @@ constexpr uint32_t HINT_OWN_MAX = 4u, HINT_MASK_BITS = 8u; // (express4's KS lab
 constexpr uint32_t HINT_ALTIDX_SHIFT = 8u, HINT_SITE_SHIFT = 12u + 4u; // x: flags 0..7, allele numbers 8..15, site 16..31
 constexpr uint32_t HINT_NO_SITE = 0xFFFFu;
 constexpr uint32_t HINT_BACK_SHIFT = 8u, HINT_SNPOFF_SHIFT = 16u; // y
+// y, with HINT_ALT_OK: HINT_SNP_GROUP = the keys of the site's alleles K_0 .. K_nv-1 (K_i with the base on the site replaced)
+// are alone with their halves -- every K_a is the only indexed key with its 16 bases on the SNP's side, and the keys that
+// share the 16 bases on the other side are exactly those nv keys; bits 22..23: the reference allele's base there (A C G T =
+// 0..3), bits 24..26: nv.  With it a read k-mer over the SNP is judged against the allele it carries, whichever that is.
+constexpr uint32_t HINT_SNP_GROUP = 1u << 21, HINT_REFB_SHIFT = 22u, HINT_NV_SHIFT = 24u;
 constexpr uint32_t HINT_TAIL_OK = 1u, HINT_TAIL_NALL_SHIFT = 2u, HINT_TAIL_NEXT_SHIFT = 8u, HINT_TAIL_CODES_SHIFT = 16u; // tail_info.x
 // HINT_EXACT_OK restates express4's seeding rule for an exact hit when the index is built; these are the limits of the
 // rule's wide form (static_asserts in express4.inl): how many keys may share a half with the k-mer's key, how many labels

@@ -367,60 +367,138 @@ template <uint32_t I>
 GTX_DEV uint32_t hint_kmer(uint2_t const f, uint8_t const * seq4, HintCounts const & h)
 {
   constexpr uint32_t A = (K - 1) * I;
-  uint32_t const mis = hc_get(h.k[I], HC_MIS), mis_left = hc_get(h.k[I], HC_MIS_LEFT), mis_right = mis - mis_left;
-  uint32_t const amb = hc_get(h.k[I], HC_AMB), amb_left = hc_get(h.k[I], HC_AMB_LEFT);
-  uint32_t const amb_out = hc_get(h.k[I], HC_AMB_OUT); // ambiguous bases whose set does not hold the reference base
+  uint32_t mis = hc_get(h.k[I], HC_MIS), mis_left = hc_get(h.k[I], HC_MIS_LEFT);
+  uint32_t amb = hc_get(h.k[I], HC_AMB), amb_left = hc_get(h.k[I], HC_AMB_LEFT);
+  uint32_t amb_out = hc_get(h.k[I], HC_AMB_OUT); // ambiguous bases whose set does not hold the reference base
   uint32_t const site = f.x >> HINT_SITE_SHIFT;
   uint32_t const declined = hk_make(HINT_K_DECLINE, site, 0u, false, false);
-  bool const single = (f.x & HINT_SINGLE_OK) != 0, l1 = single && (f.x & HINT_L1) != 0, r1 = single && (f.x & HINT_R1) != 0;
+  bool const single = (f.x & HINT_SINGLE_OK) != 0;
+  // gl / gr: who else has the 16 first / last bases of the key the read's k-mer is judged against is known -- that key
+  // alone, or (on the far side of a SNP under the k-mer, HINT_SNP_GROUP) the keys of the SNP's alleles and nobody else
+  bool gl = single && (f.x & HINT_L1) != 0, gr = single && (f.x & HINT_R1) != 0;
   if (amb == 0 && mis == 0)
   {
     GTX_HINT_NOTE((f.x & HINT_EXACT_OK) ? 0 : 1); // exact k-mer, but the place is not provably simple
     uint32_t const set = (f.x & HINT_MULTI) ? ((f.x >> HINT_ALTIDX_SHIFT) & 255u) << HK_SET_SHIFT : 0u; // (several alleles of a merged site)
     return hk_make((f.x & HINT_EXACT_OK) ? HINT_K_LABEL : HINT_K_DECLINE, site, 0u, false, (f.x & HINT_PAR) != 0) | set;
   }
+  // ---- a SNP under the k-mer: the read is judged against the key of the allele it carries.  The compare above ran against
+  //      the reference allele: a base on the site that is another allele's comes off the counters again.
+  uint32_t allele = 0, site_set = 0;
+  bool third = false, site_amb = false, site_left = false;
+  if ((f.x & HINT_ALT_OK) != 0)
+  {
+    uint32_t const off = (f.y >> HINT_SNPOFF_SHIFT) & 31u, at = A + off;
+    uint32_t const rb0 = (seq4[at >> 1] >> ((~at & 1u) << 2)) & 15u, rb = rb0 == 0 ? 15u : rb0; // ('=' reads as N)
+    bool const onehot = (rb & (rb - 1u)) == 0;
+    uint32_t const two = rb == 1 ? 0u : rb == 2 ? 1u : rb == 4 ? 2u : 3u, refb = (f.y >> HINT_REFB_SHIFT) & 3u;
+    bool const group = (f.y & HINT_SNP_GROUP) != 0;
+    if (onehot && two != refb)
+    {
+      uint32_t const a = (f.x >> (HINT_ALTIDX_SHIFT + 2 * two)) & 3u;
+      if (amb == 0 && mis == 1 && a != 0)
+        return hk_make(HINT_K_LABEL, site, a, false, true); // exactly the other allele's key (par: the reference allele's key is its neighbour)
+      if (group)
+      {
+        --mis;
+        mis_left -= off < K / 2 ? 1u : 0u;
+        allele = a;
+        third = a == 0; // a base no allele has: one difference against every allele's key
+      }
+    }
+    else if (!onehot && group)
+    {
+      // an ambiguous base ON the site: its expansion runs over the alleles whose base the set holds
+      site_amb = true;
+      --amb;
+      amb_left -= off < K / 2 ? 1u : 0u;
+      amb_out -= ((rb >> refb) & 1u) ? 0u : 1u;
+      site_set = (rb >> refb) & 1u;
+#pragma unroll
+      for (uint32_t b = 0; b < 4; ++b)
+      {
+        uint32_t const a = (f.x >> (HINT_ALTIDX_SHIFT + 2 * b)) & 3u;
+        site_set |= (a != 0 && ((rb >> b) & 1u)) ? 1u << a : 0u;
+      }
+    }
+    if (group)
+    {
+      gl = gr = true;
+      site_left = off < K / 2;
+    }
+  }
+  uint32_t const mis_right = mis - mis_left, amb_right = amb - amb_left;
+  if (site_amb)
+  {
+    // a multi-key list (exact lookups only, src/utilities/kmer_help_functions.cpp:97-119).  Its keys run over the bases of
+    // the set on the site; the half WITHOUT the site is shared with the allele keys only, so while that half is the
+    // reference's, a key of the list is indexed iff it is an allele's key
+    uint32_t const amb_far = site_left ? amb_right : amb_left, mis_far = site_left ? mis_right : mis_left;
+    if (amb_far != 0 || amb > 1)
+    {
+      GTX_HINT_NOTE(7);
+      return declined;
+    }
+    if (mis == 0)
+      return hk_make((site_set != 0 && amb_out == 0) ? HINT_K_LABEL : HINT_K_HOLE, site, 0u, false, true) | (site_set << HK_SET_SHIFT);
+    // substitutions: none of the keys is an allele's.  Far half clean: nobody else has it; else it is one concrete 16-mer to probe
+    return hk_make(HINT_K_HOLE, site, 0u, false, true) | (mis_far == 0 ? 0u : site_left ? HK_NEED_RIGHT : HK_NEED_LEFT);
+  }
+  if (third)
+  {
+    uint32_t const need_site = site_left ? HK_NEED_LEFT : HK_NEED_RIGHT, need_far = site_left ? HK_NEED_RIGHT : HK_NEED_LEFT;
+    uint32_t const amb_far = site_left ? amb_right : amb_left, mis_far = site_left ? mis_right : mis_left;
+    if (amb == 0)
+    {
+      // one key.  No exact hit (the far half belongs to the allele keys, and this is none of them); its Hamming-1 neighbours:
+      // every allele's key when nothing else differs -- their labels share the interval: one path with all alleles -- and
+      // whoever else has the 16 bases around the foreign base: the filter has to say nobody
+      if (mis == 0)
+        return hk_make(HINT_K_LABEL, site, 0u, true, false) | (((1u << ((f.y >> HINT_NV_SHIFT) & 7u)) - 1u) << HK_SET_SHIFT) | need_site;
+      return hk_make(HINT_K_HOLE, site, 0u, false, false) | need_site | (mis_far != 0 ? need_far : 0u);
+    }
+    // ambiguous bases besides: a multi-key list none of whose keys is an allele's
+    if (amb_far == 0 && mis_far == 0)
+      return hk_make(HINT_K_HOLE, site, 0u, false, true);
+    if (amb - amb_far == 0)
+      return hk_make(HINT_K_HOLE, site, 0u, false, true) | need_site;
+    GTX_HINT_NOTE(12);
+    return declined;
+  }
+  if (amb == 0 && mis == 0) // (the other allele's key with ambiguity taken off -- cannot happen -- or with the site's base only: handled above)
+    return hk_make(HINT_K_LABEL, site, allele, false, true);
   if (amb == 2 && mis == 0 && (amb_left == 0 || amb_left == 2))
   {
     // two ambiguous bases in one half, the rest == K: the (up to 16) keys of the expansion all carry K's other half,
     // which K alone has -> of the expansion only K can be indexed, and it is in there when both sets hold its base
-    if (!(amb_left == 2 ? r1 : l1))
+    if (!(amb_left == 2 ? gr : gl))
     {
       GTX_HINT_NOTE(5);
       return declined;
     }
-    return hk_make(amb_out == 0 ? HINT_K_LABEL : HINT_K_HOLE, site, 0u, false, true);
+    return hk_make(amb_out == 0 ? HINT_K_LABEL : HINT_K_HOLE, site, allele, false, true);
   }
   if (amb > 1)
   {
     GTX_HINT_NOTE(7);
     return declined;
   }
-  if (amb == 0 && mis == 1 && (f.x & HINT_ALT_OK) != 0)
-  {
-    // the other allele of the SNP under the k-mer?  (one difference, and the base on the site is an alternative allele)
-    uint32_t const at = A + ((f.y >> HINT_SNPOFF_SHIFT) & 31u);
-    uint32_t const rb = (seq4[at >> 1] >> ((~at & 1u) << 2)) & 15u;
-    uint32_t const two = rb == 1 ? 0u : rb == 2 ? 1u : rb == 4 ? 2u : 3u;
-    uint32_t const allele = (f.x >> (HINT_ALTIDX_SHIFT + 2 * two)) & 3u;
-    if (allele != 0)
-      return hk_make(HINT_K_LABEL, site, allele, false, true); // (par: the reference allele's key is its neighbour)
-  }
-  // the k-mer is not K: a half without a difference is K's own -- K alone must have it (flag) --, a half with one must
-  // occur in no indexed key (filter probe by the caller)
+  // the k-mer is not K: a half without a difference is K's own -- nobody but K (or the SNP's allele keys) may have it
+  // (flag) --, a half with one must occur in no indexed key (filter probe by the caller)
   if (amb == 0)
   {
     if (mis == 1)
     {
       bool const left = mis_left == 1;
-      if (!(left ? r1 : l1))
+      if (!(left ? gr : gl))
       {
         GTX_HINT_NOTE(3); // one substitution, the other half is shared with further keys (a variant there)
         return declined;
       }
-      return hk_make(HINT_K_LABEL, site, 0u, true, false) | (left ? HK_NEED_LEFT : HK_NEED_RIGHT);
+      return hk_make(HINT_K_LABEL, site, allele, true, false) | (left ? HK_NEED_LEFT : HK_NEED_RIGHT);
     }
     // two or more substitutions: no label at all (K itself is too far away to be a neighbour)
-    bool const ok = (mis_left != 0 || l1) && (mis_right != 0 || r1);
+    bool const ok = (mis_left != 0 || gl) && (mis_right != 0 || gr);
     GTX_HINT_NOTE(ok ? 0 : 6);
     return hk_make(ok ? HINT_K_HOLE : HINT_K_DECLINE, site, 0u, false, false) | (mis_left != 0 ? HK_NEED_LEFT : 0u) |
            (mis_right != 0 ? HK_NEED_RIGHT : 0u);
@@ -430,12 +508,12 @@ GTX_DEV uint32_t hint_kmer(uint2_t const f, uint8_t const * seq4, HintCounts con
   if (mis == 0)
   {
     // its keys differ from K in that base only: they share the other half with K
-    if (!(amb_is_left ? r1 : l1))
+    if (!(amb_is_left ? gr : gl))
     {
       GTX_HINT_NOTE(5);
       return declined;
     }
-    return hk_make(amb_out == 0 ? HINT_K_LABEL : HINT_K_HOLE, site, 0u, false, true); // (a set without the reference base: none of its keys is K)
+    return hk_make(amb_out == 0 ? HINT_K_LABEL : HINT_K_HOLE, site, allele, false, true); // (a set without the reference base: none of its keys is K)
   }
   // ... plus substitutions: none of its keys is K.  Either everything lies in one half (the other one is K's), or the
   // substitutions lie in the half without the ambiguous base, which then is one concrete 16-mer to probe
@@ -443,12 +521,12 @@ GTX_DEV uint32_t hint_kmer(uint2_t const f, uint8_t const * seq4, HintCounts con
   bool ok = false;
   if (amb_is_left)
   {
-    ok = mis_right == 0 ? r1 : mis_left == 0;
+    ok = mis_right == 0 ? gr : mis_left == 0;
     need = mis_right == 0 ? 0u : HK_NEED_RIGHT;
   }
   else
   {
-    ok = mis_left == 0 ? l1 : mis_right == 0;
+    ok = mis_left == 0 ? gl : mis_right == 0;
     need = mis_left == 0 ? 0u : HK_NEED_LEFT;
   }
   GTX_HINT_NOTE(ok ? 0 : 12);

@@ -211,6 +211,10 @@ GTX_HD uint2_t hint_position_flags(GraphView const & g, HintKeys const & t, uint
         {
           uint32_t const off = g.var_order[fv] - order; // base of the k-mer that lies on the site
           uint32_t idx_of = 0;
+          // the allele keys alone with their halves (HINT_SNP_GROUP): on the SNP's side every key by itself, on the other
+          // side the nv of them together (they share it by construction: a group of nv keys holds nobody else)
+          bool const snp_left = off < K / 2;
+          bool group = (snp_left ? t.lsize[k] : t.rsize[k]) == 1 && (snp_left ? t.rsize[k] : t.lsize[k]) == nv;
           for (uint32_t a = 1; a < nv && snp; ++a)
           {
             uint32_t const two = hint_two_bits(hint_acgt(static_cast<uint8_t>(g.dna[g.var_dna[fv + a]])));
@@ -219,11 +223,14 @@ GTX_HD uint2_t hint_position_flags(GraphView const & g, HintKeys const & t, uint
             bool pa = false;
             snp = alt != key && ((idx_of >> (2 * two)) & 3u) == 0 && hint_find_key(t, alt, ka) && hint_exact_verdict(t, nb, nb_same, ka, order, l.site, a, pa);
             idx_of |= a << (2 * two);
+            group = group && snp && (snp_left ? t.lsize[ka] : t.rsize[ka]) == 1;
           }
           if (snp)
           {
             x |= HINT_ALT_OK | (idx_of << HINT_ALTIDX_SHIFT);
             y |= off << HINT_SNPOFF_SHIFT;
+            uint32_t const refb = static_cast<uint32_t>(key >> (2 * (K - 1 - off))) & 3u;
+            y |= (group ? HINT_SNP_GROUP : 0u) | (refb << HINT_REFB_SHIFT) | (nv << HINT_NV_SHIFT);
           }
         }
       }

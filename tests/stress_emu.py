@@ -38,6 +38,11 @@ def align_seed(seed):
         # paired flags: unpaired, discordant (both orientations), proper pair (forward only); ragged lengths
         flags = rng.choice([0, 1 | 64, 1 | 2 | 32 | 64], size=len(codes)).astype(np.uint16)
         isize = rng.integers(-2000, 2000, size=len(codes))
+        if rng.random() < 0.5:  # IUPAC sets (2-, 3-, 4-base) on 1 % of the bases: the true base widened, or an unrelated set
+            codes = codes.copy()
+            amb = rng.random(codes.shape) < 0.01
+            extra = rng.integers(1, 16, size=codes.shape).astype(np.uint8)
+            codes[amb] = np.where(rng.random(int(amb.sum())) < 0.8, codes[amb] | extra[amb], extra[amb])
         reads = [c[:int(n)] for c, n in zip(codes, rng.integers(max(50, read_len - 60), read_len + 1, size=len(codes)))]
         for mode in ["lean", "wide"]:
             os.environ["GTX_EXPRESS4"] = mode
