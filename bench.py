@@ -34,6 +34,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 ALGO_BYTES_PER_READ = 3296  # B(L) = 86 + 796*n_k + (L - 31*n_k) at L=150, n_k=4
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 USE_TASK_FLAGS = os.environ.get("GTX_BENCH_FLAGS", "1") != "0"  # the dense side array of the records (A/B switch)
+PLANE_INPUT = os.environ.get("GTX_BENCH_PLANES", "1") != "0"    # reads resident as plane rows (0: BAM nibble rows, repacked inside every call)
 REC_WORDS = int(os.environ.get("GTX_BENCH_REC_WORDS", "64"))  # uint32 words of a record slot (rec_words of gtx_align_batch; A/B switch)
 REGION_BEGIN = 1000000      # chr20:1000001-2000000
 REGION_LEN = 1000000
@@ -214,16 +215,19 @@ class Workload:
     """resident inputs + accumulators of one (graph, reads) pair; step() = align + score [+ reduce] + calls"""
 
     def __init__(self, torch, gtx, ctx, device, d_seq, d_pos, n_samples, samples=None, hint=True, conn_cap=1 << 24):
+        """d_seq: [n, stride] BAM nibble rows on the device; they are repacked ONCE into plane rows (gtx_reads_to_planes, the
+        layout the kernels read -- what gtx_stream_push writes on the host side) and only those stay resident"""
         self.torch, self.gtx, self.ctx, self.device = torch, gtx, ctx, device
         self.L = gtx.lib()
         n = int(d_seq.shape[0])
         self.n, self.n_samples = n, n_samples
-        self.stride = int(d_seq.shape[1])
+        self.stride = (int(d_seq.shape[1]) + 15) // 16 * 16  # pitch of the plane rows
         self.hint, self.samples = hint, samples
         self.sets = []   # resident read sets (bases, meta, score items); step k works on set k mod len(sets)
         self.steps_done = 0
         self.add_reads(d_seq, d_pos)
-        self.d_rec = torch.empty(n * 2 * REC_WORDS, dtype=torch.int32, device=device)
+        self.align_fn = self.L.gtx_align_batch_planes if PLANE_INPUT else self.L.gtx_align_batch_flags
+        self.d_rec = torch.zeros(n * 2 * REC_WORDS, dtype=torch.int32, device=device)
         # dense side array of the records (one byte per task): gtx_align_batch_flags / gtx_score_batch_flags
         self.d_flags = torch.zeros(n * 2, dtype=torch.uint8, device=device) if USE_TASK_FLAGS else None
         self.buf = gtx.ScoreBuffers()
@@ -242,10 +246,16 @@ class Workload:
         """another resident read set of the same size: the steps take the sets in turn, so that no step finds its own
         reads (or their records) in a cache"""
         torch, gtx, n = self.torch, self.gtx, self.n
-        assert int(d_seq.shape[0]) == n and int(d_seq.shape[1]) == self.stride
+        assert int(d_seq.shape[0]) == n and (int(d_seq.shape[1]) + 15) // 16 * 16 == self.stride
+        if PLANE_INPUT:
+            d_planes = torch.empty((n, self.stride), dtype=torch.uint8, device=self.device)
+            gtx.check(self.L.gtx_reads_to_planes(self.ctx.h, d_seq.data_ptr(), int(d_seq.shape[1]), n, d_planes.data_ptr(), self.stride, None))
+            torch.cuda.synchronize()
+            d_seq = d_planes
         pos_host = d_pos.cpu().numpy().astype(np.int32)
         meta = np.zeros(n, gtx.READ_META)
         meta["l_qseq"] = READ_LEN
+        meta["flag"] = gtx.FLAG_FORWARD_ONLY  # unpaired reads: no reverse orientation, and nobody reads its (empty) record
         meta["pos"] = pos_host if self.hint else -1
         d_meta = torch.from_numpy(meta.view(np.uint8).reshape(n, gtx.READ_META.itemsize).copy()).to(self.device)
         items = np.zeros(n, gtx.SCORE_ITEM)
@@ -308,8 +318,7 @@ class Workload:
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(self.stream)
             fl = self.d_flags.data_ptr() if self.d_flags is not None else None
-            gtx.check(L.gtx_align_batch_flags(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, self.d_rec.data_ptr(),
-                                              REC_WORDS, fl, sp))
+            gtx.check(self.align_fn(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, self.d_rec.data_ptr(), REC_WORDS, fl, sp))
             e1.record(self.stream)
             gtx.check(L.gtx_score_batch_flags(ctx.h, d_items.data_ptr(), self.n, self.d_rec.data_ptr(), REC_WORDS, fl, C.byref(self.buf), sp))
             if self.comm is not None:
@@ -458,7 +467,7 @@ def extra_pcie_fed(w, torch, gtx, steps=3, chunks=4):
             with torch.cuda.stream(w.stream):
                 w.stream.wait_event(ready[b])
                 s_seq, s_meta, s_items = stage[b]
-                gtx.check(L.gtx_align_batch_flags(ctx.h, s_seq.data_ptr(), w.stride, s_meta.data_ptr(), c,
+                gtx.check(w.align_fn(ctx.h, s_seq.data_ptr(), w.stride, s_meta.data_ptr(), c,
                                                   w.d_rec.data_ptr() + 4 * 2 * REC_WORDS * k * c, REC_WORDS, (fl + 2 * k * c) if fl else None, sp))
                 gtx.check(L.gtx_score_batch_flags(ctx.h, s_items.data_ptr(), c, w.d_rec.data_ptr(), REC_WORDS, fl, C.byref(w.buf), sp))
                 free[b].record(w.stream)
@@ -634,7 +643,8 @@ def main(argv=None):
                        "(config.vcf_text, config.calls_checksum: the digest the full-size GPU test reproduces from the oracle over all reads)" % (n, READ_LEN, args.snp_every),
            "reads_per_gpu": n, "index_keys": n_keys, "index_labels": n_labels, "haplotypes": ctx.n_hap,
            "ctx_create_s": round(t_ctx_warm, 3), "ctx_create_first_s": round(t_ctx, 3),
-           "position_hint": not args.no_hint, "task_flags_side_array": USE_TASK_FLAGS, "resident_read_sets": len(w.sets),
+           "position_hint": not args.no_hint, "task_flags_side_array": USE_TASK_FLAGS,
+           "read_layout": "bit planes (gtx_align_batch_planes; repacked once from BAM nibbles by gtx_reads_to_planes before the timed region)" if PLANE_INPUT else "BAM nibbles (gtx_align_batch_flags repacks them inside every call)", "resident_read_sets": len(w.sets),
            "parallelism": "reads sharded over %d GPU(s), graph+index replicated" % n_gpus,
            "reduce": w.reduce_kind, "reduced_bytes_per_step": w.reduced_bytes if n_gpus > 1 else 0}
     cfg.update(facts)

@@ -1682,13 +1682,29 @@ GTX_DEV bool seed_stage(Here, GraphView const & g, IndexView const & ix, WS & ws
                         bool try_fast, uint32_t & n_paths, uint32_t & longest)
 {
   GTX_PROF_BEGIN
-  // -- load the read: BAM nibbles -> one code per byte; the reverse orientation is the reverse complement, and
-  //    complementing an IUPAC code is reversing its 4 bits (A<->T, C<->G)
-  //    (four bases per lane, one 4-byte store: reads up to 256 bp in one pass)
+  // -- load the read: bit planes (graph_dev.hpp; seq4 = the read's row) -> one code per byte, four bases per lane and one
+  //    4-byte store: reads up to 256 bp in one pass.  The reverse orientation is the reverse complement, and complementing
+  //    an IUPAC code is reversing its 4 bits (A<->T, C<->G): the forward codes go to LDS first and are turned around there.
   static_assert(AlignCfg::MAX_READ <= 256 && AlignCfg::MAX_READ % 4 == 0, "one pass of 64 lanes x 4 bases");
   W::lanes([&](uint32_t l) {
     if (4 * l < len)
     {
+      uint32_t const * gq = reinterpret_cast<uint32_t const *>(seq4) + 4u * ((4 * l) >> 5);
+      uint32_t packed = plane_codes4(gq[0], gq[1], gq[2], gq[3], (4 * l) & 31u);
+      // bases behind the read's end count as N, and so does '=' (assigned to a seqan Iupac it becomes N,
+      // hts_parallel_reader.cpp:226-243): both are zero bytes by now
+      uint32_t const inside = len - 4 * l >= 4 ? 0xFFFFFFFFu : (1u << (8 * (len - 4 * l))) - 1u;
+      packed &= inside;
+      uint32_t const zero = ~(packed | (packed >> 1) | (packed >> 2) | (packed >> 3)) & 0x01010101u;
+      packed |= zero * 15u;
+      reinterpret_cast<uint32_t *>(ws.rd)[l] = packed;
+    }
+  });
+  if (reverse)
+  {
+    W::lds_sync();
+    typename W::template PerLane<uint32_t> turned;
+    W::lanes([&](uint32_t l) {
       uint32_t packed = 0;
       for (uint32_t k = 0; k < 4; ++k)
       {
@@ -1696,18 +1712,19 @@ GTX_DEV bool seed_stage(Here, GraphView const & g, IndexView const & ix, WS & ws
         uint32_t c = 15;
         if (i < len)
         {
-          uint32_t const src = reverse ? (len - 1 - i) : i;
-          c = (seq4[src >> 1] >> ((~src & 1u) << 2)) & 15u;
-          if (c == 0)
-            c = 15; // '=' assigned to a seqan Iupac becomes N (hts_parallel_reader.cpp:226-243)
-          if (reverse)
-            c = ((c & 1u) << 3) | ((c & 2u) << 1) | ((c & 4u) >> 1) | ((c & 8u) >> 3);
+          c = ws.rd[len - 1 - i];
+          c = ((c & 1u) << 3) | ((c & 2u) << 1) | ((c & 4u) >> 1) | ((c & 8u) >> 3);
         }
         packed |= c << (8 * k);
       }
-      reinterpret_cast<uint32_t *>(ws.rd)[l] = packed;
-    }
-  });
+      turned[l] = packed;
+    });
+    W::lds_sync();
+    W::lanes([&](uint32_t l) {
+      if (4 * l < len)
+        reinterpret_cast<uint32_t *>(ws.rd)[l] = turned[l];
+    });
+  }
   GTX_LEAD ws.read_len = len;
   W::lds_sync();
   GTX_PROF_TICK(0)

@@ -135,10 +135,10 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
   // ---- per group: the read, whether it is a candidate at all
   PB alive_l, pass2_l;
   PU len_l, nk_l, read_l;
-  // (the lane's share of the packed bases -- two bytes per round of the unpacking below -- is fetched together with the
+  // (the lane's share of the read's bases -- four bases per round of the unpacking below -- is fetched together with the
   // read's length: both hang on the read number only, and fetching the bases behind the length was a third of this pass'
   // first phase)
-  static_assert(AlignCfg::MAX_READ / 64 == 4, "four rounds of 64 bases: two 32-bit words of raw bytes per lane");
+  static_assert(AlignCfg::MAX_READ / 64 == 4, "four rounds of 64 bases: two 32-bit words of plane nibbles per lane");
   PU raw01_l, raw23_l;
   W::lanes([&](uint32_t l) {
     uint32_t const gi = l >> 4;
@@ -147,13 +147,17 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
     read_l[l] = read;
     uint32_t const len = valid ? static_cast<uint32_t>(meta[read].l_qseq) : 0u;
     {
-      uint8_t const * seq4 = seq + static_cast<uint64_t>(read) * seq_stride;
+      // the read is a row of bit planes (graph_dev.hpp): the lane's four bases of round `it` are four bits of each of the
+      // four plane words of one 16-byte group; they are kept as four nibbles (plane 0 lowest) per round
+      uint4_t const * row = reinterpret_cast<uint4_t const *>(seq + static_cast<uint64_t>(read) * seq_stride);
       uint32_t raw[4];
       for (uint32_t it = 0; it < 4; ++it)
       {
-        uint32_t const at = 2 * (it * 16 + (l & 15u));
-        uint32_t const b0 = (valid && at < seq_stride) ? seq4[at] : 0u, b1 = (valid && at + 1 < seq_stride) ? seq4[at + 1] : 0u;
-        raw[it] = b0 | (b1 << 8);
+        uint32_t const base = 4 * (it * 16 + (l & 15u)), grp = base >> 5, o = base & 31u;
+        uint4_t gq{0, 0, 0, 0};
+        if (valid && (grp + 1) * PLANE_GROUP_BYTES <= seq_stride)
+          gq = row[grp];
+        raw[it] = ((gq.x >> o) & 15u) | (((gq.y >> o) & 15u) << 4) | (((gq.z >> o) & 15u) << 8) | (((gq.w >> o) & 15u) << 12);
       }
       raw01_l[l] = raw[0] | (raw[1] << 16);
       raw23_l[l] = raw[2] | (raw[3] << 16);
@@ -182,26 +186,21 @@ GTX_DEV uint32_t express4(GraphView const & g, IndexView const & ix, Express4Wor
     return (P2 & 1ull ? 1u : 0u) | (P2 >> 16 & 1ull ? 2u : 0u) | (P2 >> 32 & 1ull ? 4u : 0u) | (P2 >> 48 & 1ull ? 8u : 0u);
   }
 
-  // ---- unpack the reads (BAM nibbles -> one code per byte), 4 bases per lane and round
+  // ---- unpack the reads (bit planes -> one code per byte), 4 bases per lane and round
   for (uint32_t it = 0; it < AlignCfg::MAX_READ / 64; ++it)
     W::lanes([&](uint32_t l) {
       uint32_t const gi = l >> 4, word = it * 16 + (l & 15u), len = len_l[l];
       if (alive_l[l] && 4 * word < len)
       {
-        uint32_t const two = ((it < 2 ? raw01_l[l] : raw23_l[l]) >> (16 * (it & 1u))) & 0xFFFFu; // bytes 2 word, 2 word + 1 of the row
-        uint32_t packed = 0;
-        for (uint32_t k = 0; k < 4; ++k)
-        {
-          uint32_t const i = 4 * word + k;
-          uint32_t c = 15;
-          if (i < len)
-          {
-            c = (((two >> (8 * (k >> 1))) & 255u) >> ((~i & 1u) << 2)) & 15u;
-            if (c == 0)
-              c = 15; // '=' assigned to a seqan Iupac becomes N (hts_parallel_reader.cpp:226-243)
-          }
-          packed |= c << (8 * k);
-        }
+        uint32_t const four = ((it < 2 ? raw01_l[l] : raw23_l[l]) >> (16 * (it & 1u))) & 0xFFFFu; // four bases as four plane nibbles
+        uint32_t packed = plane_spread4(four & 15u) | (plane_spread4((four >> 4) & 15u) << 1) | (plane_spread4((four >> 8) & 15u) << 2) |
+                          (plane_spread4((four >> 12) & 15u) << 3);
+        // bases behind the read's end count as N, and so does '=' (assigned to a seqan Iupac it becomes N,
+        // hts_parallel_reader.cpp:226-243): both are zero bytes by now
+        uint32_t const inside = len - 4 * word >= 4 ? 0xFFFFFFFFu : (1u << (8 * (len - 4 * word))) - 1u;
+        packed &= inside;
+        uint32_t const zero = ~(packed | (packed >> 1) | (packed >> 2) | (packed >> 3)) & 0x01010101u;
+        packed |= zero * 15u;
         reinterpret_cast<uint32_t *>(ws.s[gi].rd)[word] = packed;
       }
     });

@@ -38,6 +38,92 @@ struct alignas(16) uint4_t // 16-byte move
   uint32_t x, y, z, w;
 };
 
+// ---- reads as bit planes (the layout every alignment kernel reads; gtx.h: gtx_align_batch_planes).  A read row of S bytes
+// (S a multiple of 16) is S / 16 groups of 32 bases, four words per group: word 4g + b holds bit b of the BAM codes (A=1 C=2
+// G=4 T=8, N=15, '='=0) of bases 32g .. 32g+31, base 32g + j at bit j.  The per-base questions of the position-hinted pass
+// (differs? one base or a set?) are plain bitwise operations on such words, a 2-bit key half is two shifts and an OR, and
+// no kernel transposes anything per read and step: the host (gtx_stream_push) or one repack at staging time does it once.
+constexpr uint32_t PLANE_GROUP_BYTES = 16;
+
+#if defined(__HIPCC__)
+#define GTX_HDI __host__ __device__ inline
+#else
+#define GTX_HDI inline
+#endif
+
+// BAM code of base i of a plane row
+GTX_HDI uint32_t plane_code_at(uint32_t const * row, uint32_t i)
+{
+  uint32_t const * g = row + 4u * (i >> 5);
+  uint32_t const s = i & 31u;
+  return ((g[0] >> s) & 1u) | (((g[1] >> s) & 1u) << 1) | (((g[2] >> s) & 1u) << 2) | (((g[3] >> s) & 1u) << 3);
+}
+
+// four bits -> four bytes (bit k to bit 0 of byte k): one multiply whose partial products land on distinct bits
+GTX_HDI uint32_t plane_spread4(uint32_t nibble)
+{
+  return (nibble * 0x00204081u) & 0x01010101u;
+}
+
+// the codes of bases o .. o+3 (o a multiple of 4) of a group, one per byte
+GTX_HDI uint32_t plane_codes4(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t o)
+{
+  return plane_spread4((p0 >> o) & 15u) | (plane_spread4((p1 >> o) & 15u) << 1) | (plane_spread4((p2 >> o) & 15u) << 2) |
+         (plane_spread4((p3 >> o) & 15u) << 3);
+}
+
+// bit B of the 8 bases of a little-endian word of 4 BAM bytes (byte i holds base 2i in its high and base 2i+1 in its low
+// nibble) as a byte, base j at bit j: the four bits `B` of the nibbles of a 16-bit half are gathered by ONE multiply whose
+// partial products do not collide.  hi = w >> 16.
+template <uint32_t B>
+GTX_HDI uint32_t nib_plane_byte(uint32_t w, uint32_t hi)
+{
+  // source bits of a half, by base: base 1 at bit B, base 0 at 4+B, base 3 at 8+B, base 2 at 12+B; they go to 12+B .. 15+B
+  constexpr uint32_t M = (1u << 13) | (1u << 8) | (1u << 7) | (1u << 2);
+  uint32_t const pl = (w & (0x1111u << B)) * M, ph = (hi & (0x1111u << B)) * M;
+  return ((pl >> (12 + B)) & 0xFu) | ((ph >> (8 + B)) & 0xF0u);
+}
+
+// one group of a plane row from (up to) 16 bytes of a BAM nibble row: w[k] = bytes 4k .. 4k+3 as a little-endian word (0
+// behind the end of the nibble row)
+GTX_HDI void planes_from_nibble_words(uint32_t const (&w)[4], uint32_t (&out)[4])
+{
+  out[0] = out[1] = out[2] = out[3] = 0;
+  for (uint32_t k = 0; k < 4; ++k)
+  {
+    uint32_t const hi = w[k] >> 16;
+    out[0] |= nib_plane_byte<0>(w[k], hi) << (8 * k);
+    out[1] |= nib_plane_byte<1>(w[k], hi) << (8 * k);
+    out[2] |= nib_plane_byte<2>(w[k], hi) << (8 * k);
+    out[3] |= nib_plane_byte<3>(w[k], hi) << (8 * k);
+  }
+}
+
+// a whole row: nibble row of `nib_bytes` bytes -> `groups` groups (bases beyond the nibble row: code 0)
+GTX_HDI void planes_from_nibbles(uint8_t const * nib, uint32_t nib_bytes, uint32_t * out, uint32_t groups)
+{
+  for (uint32_t g = 0; g < groups; ++g)
+  {
+    uint32_t w[4];
+    for (uint32_t k = 0; k < 4; ++k)
+    {
+      uint32_t v = 0;
+      for (uint32_t b = 0; b < 4; ++b)
+      {
+        uint32_t const at = 16u * g + 4u * k + b;
+        v |= (at < nib_bytes ? static_cast<uint32_t>(nib[at]) : 0u) << (8 * b);
+      }
+      w[k] = v;
+    }
+    uint32_t o[4];
+    planes_from_nibble_words(w, o);
+    out[4 * g + 0] = o[0];
+    out[4 * g + 1] = o[1];
+    out[4 * g + 2] = o[2];
+    out[4 * g + 3] = o[3];
+  }
+}
+
 // internal status bit (never stored in a record): the task met an allele number beyond the allele sets of the pass it was
 // in; together with GTX_ST_PATH_OVERFLOW it sends the task on, in the end to the pass with GTX_WIDE_MASK_WORDS-word sets
 constexpr uint32_t GTX_ST_WIDE_ALLELE = 32u;

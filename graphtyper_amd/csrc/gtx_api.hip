@@ -410,9 +410,10 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
                                             uint32_t * __restrict__ queue2, uint32_t * queue2_count, uint32_t decline_all,
                                             uint8_t * __restrict__ task_flags)
 {
-  // The 64 reads of a wavefront lie side by side in memory: their bases (80 B each) and their meta records (20 B each)
-  // are fetched with coalesced loads -- 1 KB and 256 B per instruction instead of 64 scattered lines -- and handed to
-  // the lanes through LDS (row pitch 80 B = 20 banks: 16-byte reads of 16 neighbouring lanes hit all 64 banks once).
+  // The 64 reads of a wavefront lie side by side in memory: their bases (80 B each: five 16-byte groups of four plane words,
+  // graph_dev.hpp) and their meta records (20 B each) are fetched with coalesced loads -- 1 KB and 256 B per instruction
+  // instead of 64 scattered lines -- and handed to the lanes through LDS (row pitch 80 B = 20 banks: 16-byte reads of 16
+  // neighbouring lanes hit all 64 banks once).
   constexpr uint32_t ROW_BYTES = HINT_MAX_READ / 2, ROW_VEC = ROW_BYTES / 16, META_WORDS = sizeof(gtx_read_meta) / 4;
   __shared__ uint4_t s_seq[WAVES][64 * ROW_VEC];
   __shared__ uint32_t s_meta[WAVES][64 * META_WORDS];
@@ -468,7 +469,10 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
     uint32_t * rec = records + static_cast<uint64_t>((decline_all & 2u) ? (read & 1023u) : read) * 2 * rec_words;
     bool const outside = len < 2 * K - 1 || len > AlignCfg::MAX_READ; // align_read (alignment.cpp:331-363): stay unaligned
     rev = !outside && needs_reverse(m, force_both != 0);
-    if (!rev)
+    // (GTX_FLAG_FORWARD_ONLY in the read's own flag word: the caller will never look at the reverse record of a read whose
+    //  reverse orientation is not aligned -- gtx_stream_push promises that for its items -- so its empty header, a cache line
+    //  visit per read for eight bytes, is not written)
+    if (!rev && (m.flag & GTX_FLAG_FORWARD_ONLY) == 0)
     {
       uint32_t const h0 = len > AlignCfg::MAX_READ ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
       if ((rec_words & 1u) == 0 && (reinterpret_cast<uintptr_t>(records) & 7u) == 0)
@@ -493,7 +497,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
       // the store path charges is line visits per instruction -- 16 per instruction this way instead of 64.
       uint32_t * row = reinterpret_cast<uint32_t *>(&s_seq[wave][lane * ROW_VEC]);
       bool const can_stage = (rec_words & 3u) == 0 && (reinterpret_cast<uintptr_t>(records) & 15u) == 0; // (16-byte stores into the slots)
-      uint32_t const where = hinted_one(g, ix, row, reinterpret_cast<uint8_t const *>(row), ROW_BYTES, m, rec, rec_words, can_stage ? row : nullptr);
+      uint32_t const where = hinted_one(g, ix, row, ROW_BYTES, m, rec, rec_words, can_stage ? row : nullptr);
       fwd = where == 0;
       staged_rec = where == 2;
       fwd_flag = where == 0 ? 0u : ((where == 2 ? row[1] : rec[1]) >> 31);
@@ -805,6 +809,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_GENERAL_
 GTX_HBM_PASS_KERNEL(gtx_align_big_kernel, big)
 GTX_HBM_PASS_KERNEL(gtx_align_wide_kernel, wide)
 
+// BAM nibble rows -> plane rows (graph_dev.hpp), one thread per (read, group of 32 bases): the one-off repack of callers that
+// hold bam_get_seq bytes on the device (gtx_reads_to_planes), and what gtx_align_batch does with its nibble rows before the
+// alignment kernels -- which read planes only -- run.
+__global__ __launch_bounds__(256) void gtx_planes_kernel(uint8_t const * __restrict__ seq, uint32_t seq_stride, uint32_t n_reads,
+                                                         uint32_t * __restrict__ planes, uint32_t groups)
+{
+  uint64_t const t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= static_cast<uint64_t>(n_reads) * groups)
+    return;
+  uint32_t const read = static_cast<uint32_t>(t / groups), grp = static_cast<uint32_t>(t % groups);
+  uint8_t const * row = seq + static_cast<uint64_t>(read) * seq_stride;
+  uint32_t w[4];
+  if ((seq_stride & 15u) == 0 && (reinterpret_cast<uintptr_t>(seq) & 15u) == 0 && 16u * (grp + 1) <= seq_stride)
+  {
+    uint4_t const v = reinterpret_cast<uint4_t const *>(row)[grp];
+    w[0] = v.x;
+    w[1] = v.y;
+    w[2] = v.z;
+    w[3] = v.w;
+  }
+  else
+    for (uint32_t k = 0; k < 4; ++k)
+    {
+      uint32_t v = 0;
+      for (uint32_t b = 0; b < 4; ++b)
+      {
+        uint32_t const at = 16u * grp + 4u * k + b;
+        v |= (at < seq_stride ? static_cast<uint32_t>(row[at]) : 0u) << (8 * b);
+      }
+      w[k] = v;
+    }
+  uint32_t o[4];
+  planes_from_nibble_words(w, o);
+  reinterpret_cast<uint4_t *>(planes)[t] = uint4_t{o[0], o[1], o[2], o[3]};
+}
+
 // Scoring, stage 1 (triage): one thread per item reads the record header(s) and decides whether the item can add
 // anything; 85 % of the cfg2 items cannot and end here.  No per-thread tables, so this kernel runs at full occupancy.
 // The others are appended to a work queue, one atomic per wavefront.
@@ -1016,7 +1056,7 @@ static bool dev_alloc(T *& dst, size_t n, char const * what, bool zero = false)
 static void scratch_free(CallScratch & s)
 {
   void * ptrs[] = {s.d_counters, s.d_queue1, s.d_queue, s.d_big_tasks, s.d_big_state, s.d_big_ws, s.d_score_state, s.d_score_queue,
-                   s.d_score_tables, s.d_score_work, s.d_wide_tasks, s.d_wide_ws};
+                   s.d_score_tables, s.d_score_work, s.d_wide_tasks, s.d_wide_ws, s.d_planes};
   for (void * p : ptrs)
     if (p)
       (void)hipFree(p);
@@ -1277,10 +1317,50 @@ extern "C" int gtx_align_batch(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_
   return gtx_align_batch_flags(c, d_seq, seq_stride, d_meta, n_reads, d_records, rec_words, nullptr, stream);
 }
 
+static int launch_planes_kernel(const uint8_t * d_seq, uint32_t seq_stride, uint32_t n_reads, uint8_t * d_planes, uint32_t plane_stride,
+                                hipStream_t st)
+{
+  uint32_t const groups = plane_stride / PLANE_GROUP_BYTES;
+  uint64_t const threads = static_cast<uint64_t>(n_reads) * groups;
+  if (threads == 0)
+    return GTX_OK;
+  if (threads > 0xFFFFFFFFull * 256ull)
+  {
+    g_last_error = "gtx_reads_to_planes: batch too large";
+    return GTX_ERR_ARG;
+  }
+  hipLaunchKernelGGL(gtx_planes_kernel, dim3(static_cast<uint32_t>((threads + 255u) / 256u)), dim3(256), 0, st, d_seq, seq_stride, n_reads,
+                     reinterpret_cast<uint32_t *>(d_planes), groups);
+  return hip_ok(hipGetLastError(), "gtx_planes_kernel launch") ? GTX_OK : GTX_ERR_HIP;
+}
+
+extern "C" int gtx_reads_to_planes(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_stride, uint32_t n_reads, uint8_t * d_planes,
+                                   uint32_t plane_stride, void * stream)
+{
+  if (!c || plane_stride == 0 || (plane_stride % PLANE_GROUP_BYTES) != 0 || (reinterpret_cast<uintptr_t>(d_planes) & 15u) != 0 ||
+      (n_reads != 0 && (!d_seq || !d_planes || seq_stride == 0)))
+  {
+    g_last_error = "gtx_reads_to_planes: bad argument (plane rows are 16-byte groups at a 16-byte aligned address)";
+    return GTX_ERR_ARG;
+  }
+  if (c->device < 0)
+  {
+    g_last_error = "context was created without a device (libgtx has no CPU path)";
+    return GTX_ERR_NO_DEVICE;
+  }
+  if (!hip_ok(hipSetDevice(c->device), "hipSetDevice"))
+    return GTX_ERR_HIP;
+  return launch_planes_kernel(d_seq, seq_stride, n_reads, d_planes, plane_stride, static_cast<hipStream_t>(stream));
+}
+
+static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
+                        uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, hipStream_t st);
+
+// BAM nibble rows: repacked into plane rows in the call's scratch, then the same kernels
 extern "C" int gtx_align_batch_flags(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta,
                                      uint32_t n_reads, uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream)
 {
-  if (!c || rec_words < 8 || (n_reads != 0 && (!d_seq || !d_meta || !d_records)))
+  if (!c || rec_words < 8 || (n_reads != 0 && (!d_seq || !d_meta || !d_records || seq_stride == 0)))
   {
     g_last_error = "gtx_align_batch: bad argument";
     return GTX_ERR_ARG;
@@ -1299,6 +1379,43 @@ extern "C" int gtx_align_batch_flags(gtx_ctx * c, const uint8_t * d_seq, uint32_
   CallScratch * s = hold.s;
   if (!s)
     return GTX_ERR_HIP;
+  uint32_t const plane_stride = (seq_stride + PLANE_GROUP_BYTES - 1u) / PLANE_GROUP_BYTES * PLANE_GROUP_BYTES;
+  if (!grow(s->d_planes, s->planes_cap, static_cast<uint64_t>(n_reads) * plane_stride, "plane rows"))
+    return GTX_ERR_HIP;
+  if (int const rc = launch_planes_kernel(d_seq, seq_stride, n_reads, s->d_planes, plane_stride, st))
+    return rc;
+  return align_planes(c, s, s->d_planes, plane_stride, d_meta, n_reads, d_records, rec_words, d_task_flags, st);
+}
+
+extern "C" int gtx_align_batch_planes(gtx_ctx * c, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta,
+                                      uint32_t n_reads, uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream)
+{
+  if (!c || rec_words < 8 || plane_stride == 0 || (plane_stride % PLANE_GROUP_BYTES) != 0 || (reinterpret_cast<uintptr_t>(d_planes) & 15u) != 0 ||
+      (n_reads != 0 && (!d_planes || !d_meta || !d_records)))
+  {
+    g_last_error = "gtx_align_batch_planes: bad argument (plane rows are 16-byte groups at a 16-byte aligned address)";
+    return GTX_ERR_ARG;
+  }
+  if (c->device < 0)
+  {
+    g_last_error = "context was created without a device (libgtx has no CPU path)";
+    return GTX_ERR_NO_DEVICE;
+  }
+  if (n_reads == 0)
+    return GTX_OK;
+  hipStream_t const st = static_cast<hipStream_t>(stream);
+  if (!hip_ok(hipSetDevice(c->device), "hipSetDevice"))
+    return GTX_ERR_HIP;
+  ScratchHold hold{*c, scratch_acquire(*c, st), st, true};
+  if (!hold.s)
+    return GTX_ERR_HIP;
+  return align_planes(c, hold.s, d_planes, plane_stride, d_meta, n_reads, d_records, rec_words, d_task_flags, st);
+}
+
+// the passes over plane rows (d_seq / seq_stride: the plane rows and their pitch)
+static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
+                        uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, hipStream_t st)
+{
   if (!hip_ok(hipMemsetAsync(s->d_counters, 0, 8 * CallScratch::MAX_PARTS * sizeof(uint32_t), st), "task counter reset"))
     return GTX_ERR_HIP;
   // queues: room for every task (a graph on which no read is simple sends them all)

@@ -13,6 +13,10 @@
 #include <unordered_map>
 
 #include "gtx_ctx.hpp"
+#include "graph_dev.hpp"
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 using namespace gtx;
 
@@ -453,9 +457,71 @@ extern "C"
 // stream: the per-record control flow of parallel_reader_genotype_only / genotype_only for non-SV graphs
 // (src/utilities/hts_parallel_reader.cpp:570-708, 245-338)
 // ---------------------------------------------------------------------------------------------------------------
+// ---- BAM nibble rows -> plane rows on the host (graph_dev.hpp: the layout the alignment kernels read).  With BMI2 one PEXT
+// gathers a plane's 16 bits of 16 bases; the pairs come out swapped (a byte holds the even base in its HIGH nibble).
+namespace
+{
+#if defined(__x86_64__)
+__attribute__((target("bmi2"))) void planes_row_bmi2(uint8_t const * nib, uint32_t nib_bytes, uint32_t * out, uint32_t groups)
+{
+  for (uint32_t g = 0; g < groups; ++g)
+  {
+    uint32_t o[4] = {0, 0, 0, 0};
+    for (uint32_t h = 0; h < 2; ++h)
+    {
+      uint32_t const at = 16u * g + 8u * h;
+      uint64_t x = 0;
+      if (at + 8u <= nib_bytes)
+        std::memcpy(&x, nib + at, 8);
+      else if (at < nib_bytes)
+        std::memcpy(&x, nib + at, nib_bytes - at);
+      for (uint32_t b = 0; b < 4; ++b)
+      {
+        uint32_t const r = static_cast<uint32_t>(_pext_u64(x, 0x1111111111111111ull << b));
+        o[b] |= (((r & 0x5555u) << 1) | ((r >> 1) & 0x5555u)) << (16 * h);
+      }
+    }
+    out[4 * g + 0] = o[0];
+    out[4 * g + 1] = o[1];
+    out[4 * g + 2] = o[2];
+    out[4 * g + 3] = o[3];
+  }
+}
+#define GTX_HAVE_BMI2_PATH 1
+#endif
+
+void planes_row(uint8_t const * nib, uint32_t nib_bytes, uint32_t * out, uint32_t groups)
+{
+#ifdef GTX_HAVE_BMI2_PATH
+  static bool const bmi2 = __builtin_cpu_supports("bmi2");
+  if (bmi2)
+  {
+    planes_row_bmi2(nib, nib_bytes, out, groups);
+    return;
+  }
+#endif
+  gtx::planes_from_nibbles(nib, nib_bytes, out, groups);
+}
+} // namespace
+
+extern "C" int gtx_pack_planes(const uint8_t * seq, uint32_t seq_stride, uint32_t n, uint8_t * planes, uint32_t plane_stride)
+{
+  if ((n != 0 && (!seq || !planes)) || seq_stride == 0 || plane_stride == 0 || (plane_stride % gtx::PLANE_GROUP_BYTES) != 0 ||
+      (reinterpret_cast<uintptr_t>(planes) & 3u) != 0)
+  {
+    gtx::g_last_error = "gtx_pack_planes: bad argument (plane rows are 16-byte groups of 32-bit words)";
+    return GTX_ERR_ARG;
+  }
+  for (uint32_t i = 0; i < n; ++i)
+    planes_row(seq + static_cast<uint64_t>(i) * seq_stride, seq_stride, reinterpret_cast<uint32_t *>(planes + static_cast<uint64_t>(i) * plane_stride),
+               plane_stride / gtx::PLANE_GROUP_BYTES);
+  return GTX_OK;
+}
+
 struct gtx_stream
 {
   gtx_params params{};
+  uint32_t plane_stride = 0; // != 0: gtx_stream_push writes the alignment tasks' bases as plane rows of this pitch
   struct Parked
   {
     gtx_rec_meta meta;
@@ -559,9 +625,9 @@ extern "C"
         g_last_error = "gtx_stream_push: a read of " + std::to_string(recs[i].l_qseq) + " bases (the kernels align up to 256)";
         return GTX_ERR_UNSUPPORTED;
       }
-      if ((static_cast<uint32_t>(recs[i].l_qseq) + 1u) / 2u > seq_stride)
+      if ((static_cast<uint32_t>(recs[i].l_qseq) + 1u) / 2u > seq_stride || (s->plane_stride && recs[i].l_qseq > 2u * s->plane_stride))
       {
-        g_last_error = "gtx_stream_push: a record is longer than seq_stride";
+        g_last_error = "gtx_stream_push: a record is longer than seq_stride (or than the plane rows of gtx_stream_set_planes)";
         return GTX_ERR_ARG;
       }
     }
@@ -602,10 +668,21 @@ extern "C"
         }
         if (na >= align_cap)
           return GTX_ERR_CAPACITY;
-        std::memcpy(align_seq + static_cast<uint64_t>(na) * seq_stride, rseq, nbytes);
+        if (s->plane_stride)
+          planes_row(rseq, nbytes, reinterpret_cast<uint32_t *>(align_seq + static_cast<uint64_t>(na) * s->plane_stride),
+                     s->plane_stride / gtx::PLANE_GROUP_BYTES);
+        else
+          std::memcpy(align_seq + static_cast<uint64_t>(na) * seq_stride, rseq, nbytes);
         // position hint of the alignment: where read base 0 lies when the mapper was right (leading soft clip removed)
         int32_t const clip = (r.n_cigar != 0 && (r.cigar_front & 15u) == 4u) ? static_cast<int32_t>(r.cigar_front >> 4) : 0;
-        align_meta[na] = gtx_read_meta{r.l_qseq, r.flag, r.tid, r.mtid, r.isize, r.pos - clip};
+        // align_read (alignment.cpp:341-352): forward only for unpaired reads and concordant pairs
+        bool const one_orientation = (r.flag & 1u) == 0u || (r.tid == r.mtid && r.isize > -1200 && r.isize < 1200 &&
+                                                              (((r.flag & 16u) != 0u) != ((r.flag & 32u) != 0u)));
+        s->prev_forward_only = one_orientation && !s->params.force_align_both_orientations;
+        // (every item made of this task carries GTX_FLAG_FORWARD_ONLY then: the task's reverse record is never read, and the
+        //  same bit in the read's flag word lets the alignment skip writing its empty header)
+        align_meta[na] = gtx_read_meta{r.l_qseq, static_cast<uint16_t>(r.flag | (s->prev_forward_only ? GTX_FLAG_FORWARD_ONLY : 0u)), r.tid, r.mtid,
+                                       r.isize, r.pos - clip};
         align_index = s->next_align_index++;
         ++na;
         s->have_prev = true;
@@ -614,10 +691,6 @@ extern "C"
         s->prev_len = r.l_qseq;
         s->prev_seq.assign(rseq, rseq + nbytes);
         s->prev_align_index = align_index;
-        // align_read (alignment.cpp:341-352): forward only for unpaired reads and concordant pairs
-        bool const one_orientation = (r.flag & 1u) == 0u || (r.tid == r.mtid && r.isize > -1200 && r.isize < 1200 &&
-                                                              (((r.flag & 16u) != 0u) != ((r.flag & 32u) != 0u)));
-        s->prev_forward_only = one_orientation && !s->params.force_align_both_orientations;
       }
       gtx_rec_meta const me{align_index, static_cast<uint16_t>(r.flag | (s->prev_forward_only ? GTX_FLAG_FORWARD_ONLY : 0u)), r.mapq,
                             r.score_diff, r.pos, r.isize};
@@ -655,6 +728,17 @@ extern "C"
     }
     *n_align = na;
     *n_items = ni;
+    return GTX_OK;
+  }
+
+  int gtx_stream_set_planes(gtx_stream * s, uint32_t plane_stride)
+  {
+    if (!s || (plane_stride % gtx::PLANE_GROUP_BYTES) != 0)
+    {
+      g_last_error = "gtx_stream_set_planes: the pitch of plane rows is a multiple of 16 bytes";
+      return GTX_ERR_ARG;
+    }
+    s->plane_stride = plane_stride;
     return GTX_OK;
   }
 

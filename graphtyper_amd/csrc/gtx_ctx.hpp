@@ -25,6 +25,8 @@ struct CallScratch
   // per part of the batch, 8 words: [0] read / queue-1 claim counter of pass 1, [1] task counter of pass 2, [2] tasks queued
   // for pass 2, [3] forward tasks the position-hinted pass handed to pass 1, [4] forward tasks pass 1 handed to pass 2
   uint32_t * d_counters = nullptr;
+  uint8_t * d_planes = nullptr;  // plane rows of a batch that came as BAM nibbles (gtx_align_batch; grow-only)
+  uint64_t planes_cap = 0;
   uint32_t * d_queue1 = nullptr; // reads whose forward task the position-hinted pass declined (grow-only)
   uint64_t queue1_cap = 0;
   uint32_t * d_queue = nullptr;  // (read * 2 + orientation) tasks for pass 2 (grow-only)

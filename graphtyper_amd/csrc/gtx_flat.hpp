@@ -169,8 +169,9 @@ constexpr uint32_t HINT_TAIL_OK = 1u, HINT_TAIL_NALL_SHIFT = 2u, HINT_TAIL_NEXT_
 // pass 1 runs behind pass 0: neighbours on the k-mer's own interval and site end where the chain ends, whatever their number.)
 constexpr uint32_t HINT_HE_CAP = 16, HINT_NB_MAX = 16;
 
-// hash of a 16-base half in nibble form (w0 = bases 0..7, w1 = bases 8..15; base j in bits 28-4j) -> (word, mask of up to four bits)
-// of the blocked Bloom filter
+// hash of a 16-base half as two bit planes of its 2-bit codes (A0 C1 G2 T3): w0 = the low bits, w1 = the high bits, base j of
+// the half at bit j (what a read in plane form yields with two shifts) -> (word, mask of up to four bits) of the blocked
+// Bloom filter
 #if defined(__HIPCC__)
 __host__ __device__
 #endif

@@ -701,7 +701,7 @@ static void build_hints(HostGraph const & g, HostIndex & out)
     for (uint32_t side = 0; side < 2; ++side)
     {
       uint32_t w0, w1, word, mask;
-      hint_nibble_words(static_cast<uint32_t>(side == 0 ? out.keys[k] >> 32 : out.keys[k]), w0, w1);
+      hint_half_planes(static_cast<uint32_t>(side == 0 ? out.keys[k] >> 32 : out.keys[k]), w0, w1);
       hint_filter_slot(w0, w1, fl, word, mask);
       out.filt[side][word] |= mask;
     }

@@ -311,7 +311,7 @@ __global__ void k_judge_keys(HintKeys t, uint32_t * nb, uint8_t * nb_same, uint3
   for (uint32_t side = 0; side < 2; ++side)
   {
     uint32_t w0, w1, word, mask;
-    hint_nibble_words(static_cast<uint32_t>(side == 0 ? t.keys[k] >> 32 : t.keys[k]), w0, w1);
+    hint_half_planes(static_cast<uint32_t>(side == 0 ? t.keys[k] >> 32 : t.keys[k]), w0, w1);
     hint_filter_slot(w0, w1, filt_log2, word, mask);
     atomicOr((side == 0 ? filt0 : filt1) + word, mask);
   }

@@ -4,7 +4,7 @@
 // (src/utilities/kmer_help_functions.cpp:53-119, src/index/ph_index.cpp:66-107) -- because it does not use where the
 // mapper put the read.  A record of a sorted BAM does carry that place (bam1_t::core.pos, handed over as
 // gtx_read_meta::pos).  This pass compares the read with the linear reference AT that place, bit-parallel on packed
-// nibbles, and takes the answers of the global lookups from flags computed once per reference position when the index
+// planes, and takes the answers of the global lookups from flags computed once per reference position when the index
 // was built (IndexView::pos_flags, gtx_host.cpp: build_hints) plus, for a k-mer with one substitution, one probe of a
 // half-key presence filter.  It finishes a read only when every lookup of the reference is PROVEN to return the one
 // label of that place:
@@ -84,24 +84,24 @@ constexpr uint32_t nib_range_mask(uint32_t w, uint32_t a, uint32_t b)
   return from & ~upto;
 }
 
-// 16 bases of the read from base A on, as two words (A is a compile-time constant inside a k-mer, hence inside the read);
-// read from the row again instead of being kept in registers all along
+// the 2-bit codes of 16 unambiguous bases of the read from base A on (A is a compile-time constant inside a k-mer, hence
+// inside the read), as the two planes hint_filter_slot hashes: lo / hi = low / high bit of A0 C1 G2 T3, base A + j at bit j.
+// `row` is the read in plane form (graph_dev.hpp): C and T have bit 0 of the code pair set (planes 1, 3), G and T bit 1 (2, 3).
 template <uint32_t A, class Row>
-GTX_DEV void nib_extract16(Row row, uint32_t & w0, uint32_t & w1)
+GTX_DEV void plane_extract16(Row row, uint32_t & lo, uint32_t & hi)
 {
-  constexpr uint32_t W = A / 8, S = 4 * (A % 8);
-  uint32_t const a = hint_bswap(row[W]), b = hint_bswap(row[W + 1]);
-  if constexpr (S == 0)
+  constexpr uint32_t W = A / 32, S = A % 32;
+  auto ext = [&](uint32_t b) -> uint32_t
   {
-    w0 = a;
-    w1 = b;
-  }
-  else
-  {
-    uint32_t const c = hint_bswap(row[W + 2]);
-    w0 = (a << S) | (b >> (32 - S));
-    w1 = (b << S) | (c >> (32 - S));
-  }
+    uint32_t const a = row[4 * W + b];
+    if constexpr (S <= 16)
+      return (a >> S) & 0xFFFFu;
+    else
+      return ((a >> S) | (row[4 * (W + 1) + b] << (32 - S))) & 0xFFFFu;
+  };
+  uint32_t const p1 = ext(1), p2 = ext(2), p3 = ext(3);
+  lo = p1 | p3;
+  hi = p2 | p3;
 }
 
 // What the compare of the read with the reference under it says, summed while the words stream by.  Packed (the pass is
@@ -243,17 +243,6 @@ GTX_DEV void hint_compare_nibbles(Row row, uint32_t seq_stride, uint32_t const *
 constexpr uint32_t HINT_PLANE_WORDS = HINT_MAX_READ / 32;
 static_assert(HINT_MAX_READ % 32 == 0 && HINT_PLANE_WORDS == AlignCfg::KC, "five k-mers, five plane words");
 
-// bit B of the 8 bases of row word w (a little-endian load of 4 BAM bytes: byte i holds base 2i in its high and base 2i+1
-// in its low nibble) as a byte, base j at bit j.  hi = w >> 16.
-template <uint32_t B>
-GTX_DEV uint32_t nib_plane_byte(uint32_t w, uint32_t hi)
-{
-  // source bits of a half, by base: base 1 at bit B, base 0 at 4+B, base 3 at 8+B, base 2 at 12+B; they go to 12+B .. 15+B
-  constexpr uint32_t M = (1u << 13) | (1u << 8) | (1u << 7) | (1u << 2);
-  uint32_t const pl = (w & (0x1111u << B)) * M, ph = (hi & (0x1111u << B)) * M;
-  return ((pl >> (12 + B)) & 0xFu) | ((ph >> (8 + B)) & 0xF0u);
-}
-
 GTX_DEV uint32_t hint_funnel(uint32_t lo, uint32_t hi, uint32_t s) // bits [s, s + 32) of hi:lo, s in 0..31
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -264,35 +253,25 @@ GTX_DEV uint32_t hint_funnel(uint32_t lo, uint32_t hi, uint32_t s) // bits [s, s
 }
 
 // refp: the reference planes from the group of 32 positions that holds the read's first base (4 words per group: planes
-// 0..3, position 32q+j at bit j), s = that base's bit in its group.  Same counters as hint_compare_nibbles.
+// 0..3, position 32q+j at bit j), s = that base's bit in its group.  row: the read in the same form (graph_dev.hpp), a row of
+// seq_stride bytes.  Same counters as hint_compare_nibbles.
 template <class Row>
 GTX_DEV void hint_compare(Row row, uint32_t seq_stride, uint32_t const * refp, uint32_t s, uint32_t L, HintCounts & h)
 {
   uint32_t mk[HINT_PLANE_WORDS], am[HINT_PLANE_WORDS], ao[HINT_PLANE_WORDS], mt[HINT_PLANE_WORDS + 1];
   // all loads first (no branches around them: the plane array is padded, a row has at least seq_stride bytes)
-  uint32_t gg[4 * (HINT_PLANE_WORDS + 1)], rr[HINT_WORDS];
+  // (the read's words come from the row -- LDS in the kernel -- group by group inside the loop: only the reference words,
+  //  a global round trip, are worth holding all at once)
+  uint32_t gg[4 * (HINT_PLANE_WORDS + 1)];
 #pragma unroll
   for (uint32_t w = 0; w < 4 * (HINT_PLANE_WORDS + 1); ++w)
     gg[w] = refp[w];
 #pragma unroll
-  for (uint32_t w = 0; w < HINT_WORDS; ++w)
-  {
-    bool const in_row = 4 * w < seq_stride; // (uniform; a select, not a branch around the load)
-    rr[w] = row[in_row ? w : 0u] & (in_row ? 0xFFFFFFFFu : 0u);
-  }
-#pragma unroll
   for (uint32_t W = 0; W < HINT_PLANE_WORDS; ++W)
   {
-    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 4; ++k)
-    {
-      uint32_t const w = rr[4 * W + k], hi = w >> 16;
-      r0 |= nib_plane_byte<0>(w, hi) << (8 * k);
-      r1 |= nib_plane_byte<1>(w, hi) << (8 * k);
-      r2 |= nib_plane_byte<2>(w, hi) << (8 * k);
-      r3 |= nib_plane_byte<3>(w, hi) << (8 * k);
-    }
+    bool const in_row = 16 * W < seq_stride; // (uniform; a select, not a branch around the loads)
+    uint32_t const at = in_row ? 4 * W : 0u, keep = in_row ? 0xFFFFFFFFu : 0u;
+    uint32_t const r0 = row[at + 0] & keep, r1 = row[at + 1] & keep, r2 = row[at + 2] & keep, r3 = row[at + 3] & keep;
     uint32_t const g0 = hint_funnel(gg[4 * W + 0], gg[4 * W + 4], s), g1 = hint_funnel(gg[4 * W + 1], gg[4 * W + 5], s);
     uint32_t const g2 = hint_funnel(gg[4 * W + 2], gg[4 * W + 6], s), g3 = hint_funnel(gg[4 * W + 3], gg[4 * W + 7], s);
     uint32_t const v = L >= 32 * W + 32 ? 0xFFFFFFFFu : L <= 32 * W ? 0u : (1u << (L - 32 * W)) - 1u; // bases of the read
@@ -363,8 +342,8 @@ GTX_DEV uint32_t hk_make(uint32_t kind, uint32_t site, uint32_t allele, bool mm,
 // verdict into a decline when a needed half may occur.
 constexpr uint32_t HK_NEED_LEFT = 64u, HK_NEED_RIGHT = 128u;
 
-template <uint32_t I>
-GTX_DEV uint32_t hint_kmer(uint2_t const f, uint8_t const * seq4, HintCounts const & h)
+template <uint32_t I, class Row>
+GTX_DEV uint32_t hint_kmer(uint2_t const f, Row row, HintCounts const & h)
 {
   constexpr uint32_t A = (K - 1) * I;
   uint32_t mis = hc_get(h.k[I], HC_MIS), mis_left = hc_get(h.k[I], HC_MIS_LEFT);
@@ -389,7 +368,7 @@ GTX_DEV uint32_t hint_kmer(uint2_t const f, uint8_t const * seq4, HintCounts con
   if ((f.x & HINT_ALT_OK) != 0)
   {
     uint32_t const off = (f.y >> HINT_SNPOFF_SHIFT) & 31u, at = A + off;
-    uint32_t const rb0 = (seq4[at >> 1] >> ((~at & 1u) << 2)) & 15u, rb = rb0 == 0 ? 15u : rb0; // ('=' reads as N)
+    uint32_t const rb0 = plane_code_at(row, at), rb = rb0 == 0 ? 15u : rb0; // ('=' reads as N)
     bool const onehot = (rb & (rb - 1u)) == 0;
     uint32_t const two = rb == 1 ? 0u : rb == 2 ? 1u : rb == 4 ? 2u : 3u, refb = (f.y >> HINT_REFB_SHIFT) & 3u;
     bool const group = (f.y & HINT_SNP_GROUP) != 0;
@@ -542,7 +521,7 @@ GTX_DEV void hint_probe_slot(IndexView const & ix, uint32_t verdict, Row row, ui
   if (verdict & (SIDE == 0 ? HK_NEED_LEFT : HK_NEED_RIGHT))
   {
     uint32_t w0, w1;
-    nib_extract16<(K - 1) * I + 16 * SIDE>(row, w0, w1);
+    plane_extract16<(K - 1) * I + 16 * SIDE>(row, w0, w1);
     hint_filter_slot(w0, w1, ix.filt_log2, word, mask);
   }
 }
@@ -557,14 +536,14 @@ GTX_DEV uint32_t hint_probe_verdict(uint32_t verdict, uint32_t left_word, uint32
 }
 
 // The forward task of one read.  Returns true when the record was written, false = declined (nothing written).
-// `row`: the read's packed bases as words (global memory, or the copy the kernel staged in LDS); seq4 = the same bytes.
+// `row`: the read in plane form as words (global memory, or the copy the kernel staged in LDS).
 // `stage` (may be NULL): room for HINT_STAGE_WORDS words; a record that fits is written there instead (zeros behind its
 // end) and the caller moves it to its slot -- the kernel does that four lanes per record.  Returns 0 = declined, 1 = the
 // record is in `rec`, 2 = it is in `stage`.
 constexpr uint32_t HINT_STAGE_WORDS = 16; // a record of up to three variant sites (6 + 3 * 3 words)
 
 template <class Row>
-GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, uint8_t const * seq4, uint32_t seq_stride, gtx_read_meta const & m,
+GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, uint32_t seq_stride, gtx_read_meta const & m,
                             uint32_t * rec, uint32_t rec_words, uint32_t * stage = nullptr)
 {
   uint32_t const L = m.l_qseq;
@@ -594,10 +573,10 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   hint_compare(row, seq_stride, refw, sh, L, h);
   // ---- every k-mer: the label of its place, no label at all, or not provable
   uint32_t const none = hk_make(HINT_K_HOLE, HINT_NO_SITE, 0u, false, false);
-  uint32_t k0 = hint_kmer<0>(f0, seq4, h), k1 = hint_kmer<1>(f1, seq4, h);
-  uint32_t k2 = n_k > 2 ? hint_kmer<2>(f2, seq4, h) : none;
-  uint32_t k3 = n_k > 3 ? hint_kmer<3>(f3, seq4, h) : none;
-  uint32_t k4 = n_k > 4 ? hint_kmer<4>(f4, seq4, h) : none;
+  uint32_t k0 = hint_kmer<0>(f0, row, h), k1 = hint_kmer<1>(f1, row, h);
+  uint32_t k2 = n_k > 2 ? hint_kmer<2>(f2, row, h) : none;
+  uint32_t k3 = n_k > 3 ? hint_kmer<3>(f3, row, h) : none;
+  uint32_t k4 = n_k > 4 ? hint_kmer<4>(f4, row, h) : none;
   if ((k0 & 3u) == HINT_K_DECLINE || (k1 & 3u) == HINT_K_DECLINE || (k2 & 3u) == HINT_K_DECLINE || (k3 & 3u) == HINT_K_DECLINE ||
       (k4 & 3u) == HINT_K_DECLINE)
     return false;
@@ -716,7 +695,7 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
         return false; // (ends on a variant, an indel, a second site: express4 / general pass)
       }
       uint32_t const p = pre + at;
-      uint32_t const rc0 = (seq4[p >> 1] >> ((~p & 1u) << 2)) & 15u, rc = rc0 == 0 ? 15u : rc0; // ('=' reads as N)
+      uint32_t const rc0 = plane_code_at(row, p), rc = rc0 == 0 ? 15u : rc0; // ('=' reads as N)
       uint32_t const nall = (t_end.x >> HINT_TAIL_NALL_SHIFT) & 7u, codes = t_end.x >> HINT_TAIL_CODES_SHIFT;
       uint32_t best = 2, mask = 0;
 #pragma unroll

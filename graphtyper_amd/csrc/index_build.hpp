@@ -239,14 +239,16 @@ GTX_HD uint2_t hint_position_flags(GraphView const & g, HintKeys const & t, uint
   return uint2_t{x | (site << HINT_SITE_SHIFT), y};
 }
 
-// 16 bases (2 bits each, first base in the top bits) as the two nibble words the kernel hashes
-GTX_HD void hint_nibble_words(uint32_t half, uint32_t & w0, uint32_t & w1)
+// 16 bases (2 bits each, first base in the top bits) as the two planes the kernel hashes (hint_filter_slot): bit j of
+// w0 / w1 = low / high bit of base j
+GTX_HD void hint_half_planes(uint32_t half, uint32_t & w0, uint32_t & w1)
 {
   w0 = w1 = 0;
-  for (uint32_t j = 0; j < 8; ++j)
+  for (uint32_t j = 0; j < 16; ++j)
   {
-    w0 |= (1u << ((half >> (30 - 2 * j)) & 3u)) << (28 - 4 * j);
-    w1 |= (1u << ((half >> (14 - 2 * j)) & 3u)) << (28 - 4 * j);
+    uint32_t const two = (half >> (30 - 2 * j)) & 3u;
+    w0 |= (two & 1u) << j;
+    w1 |= (two >> 1) << j;
   }
 }
 

@@ -26,7 +26,8 @@ EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy"
            "gtx_graph_destroy",
            "gtx_scores_alloc", "gtx_scores_zero", "gtx_scores_free", "gtx_scores_reduce", "gtx_comm_unique_id", "gtx_comm_init_rank",
            "gtx_comm_destroy", "gtx_ctx_kernel_times", "gtx_ref_depth_finalize", "gtx_vcf_records", "gtx_scores_replay", "gtx_reads_open", "gtx_reads_info",
-           "gtx_reads_sample_name", "gtx_reads_next", "gtx_reads_close", "gtx_align_batch_flags", "gtx_score_batch_flags"]
+           "gtx_reads_sample_name", "gtx_reads_next", "gtx_reads_close", "gtx_align_batch_flags", "gtx_score_batch_flags",
+           "gtx_pack_planes", "gtx_reads_to_planes", "gtx_align_batch_planes", "gtx_stream_set_planes"]
 
 
 class GraphView(C.Structure):
@@ -126,6 +127,10 @@ def lib():
         L.gtx_ref_depth_finalize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
         L.gtx_vcf_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.gtx_align_batch_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.gtx_pack_planes.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.gtx_reads_to_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.gtx_align_batch_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.gtx_stream_set_planes.argtypes = [C.c_void_p, C.c_uint32]
         L.gtx_score_batch_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(ScoreBuffers), C.c_void_p]
         L.gtx_reads_open.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.POINTER(C.c_void_p)]
         L.gtx_reads_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -326,6 +331,30 @@ def pack_nibbles(codes, stride=None):
     return out
 
 
+def pack_planes(seq, plane_stride=None):
+    """gtx_pack_planes: [n, stride] BAM nibble rows -> [n, plane_stride] plane rows (include/gtx.h: reads as bit planes)"""
+    seq = np.ascontiguousarray(seq, np.uint8)
+    n, stride = seq.shape
+    plane_stride = plane_stride or ((stride + 15) // 16) * 16
+    out = np.zeros((n, plane_stride), np.uint8)
+    check(lib().gtx_pack_planes(_p(seq), stride, n, _p(out), plane_stride))
+    return out
+
+
+def planes_reference(codes, plane_stride):
+    """the plane layout restated in numpy (tests): [n, L] codes -> [n, plane_stride] bytes"""
+    codes = np.asarray(codes, np.uint8)
+    n, L = codes.shape
+    groups = plane_stride // 16
+    padded = np.zeros((n, groups * 32), np.uint8)
+    padded[:, :L] = codes
+    out = np.zeros((n, groups, 4), np.uint32)
+    for b in range(4):
+        bits = ((padded >> b) & 1).reshape(n, groups, 32).astype(np.uint32)
+        out[:, :, b] = (bits << np.arange(32, dtype=np.uint32)).sum(axis=2, dtype=np.uint64).astype(np.uint32)
+    return out.reshape(n, groups * 4).view(np.uint8).reshape(n, plane_stride)
+
+
 class Reads:
     """gtx_reads: BAM files merged into the record stream gtx_stream_push takes"""
 
@@ -519,12 +548,17 @@ class Stream:
             lib().gtx_stream_destroy(self.h)
             self.h = None
 
+    def set_planes(self, plane_stride):
+        """gtx_stream_set_planes: push() then returns plane rows of that pitch (0: BAM nibble rows again)"""
+        check(lib().gtx_stream_set_planes(self.h, plane_stride))
+        self.plane_stride = plane_stride
+
     def push(self, recs, seq):
         """recs: STREAM_RECORD array, seq: [n, stride] packed bases -> (align_seq, align_meta, items)"""
         recs = np.ascontiguousarray(recs, STREAM_RECORD)
         seq = np.ascontiguousarray(seq, np.uint8)
         n, stride = seq.shape
-        a_seq = np.zeros((n, stride), np.uint8)
+        a_seq = np.zeros((n, getattr(self, "plane_stride", 0) or stride), np.uint8)
         a_meta = np.zeros(n, READ_META)
         items = np.zeros(n, SCORE_ITEM)
         na, ni = C.c_uint32(), C.c_uint32()

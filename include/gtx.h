@@ -179,7 +179,10 @@ typedef struct gtx_read_meta
 
 /* gtx_rec_meta::flag, besides the SAM bits: the reverse orientation of the read this record uses was not aligned
  * (align_read aligns forward only for unpaired reads and concordant pairs, alignment.cpp:341-352), its record is empty
- * by construction and the scorer does not fetch it.  Set by gtx_stream_push; optional for hand-made items. */
+ * by construction and the scorer does not fetch it.  Set by gtx_stream_push; optional for hand-made items.
+ * The same bit in gtx_read_meta::flag (gtx_stream_push sets it there as well) is the caller's promise never to look at the
+ * reverse record of that read when align_read does not ask for the reverse orientation: the alignment then does not write
+ * that record's empty header (its slot keeps what it held), and every item that uses the task has to carry the bit too. */
 #define GTX_FLAG_FORWARD_ONLY 0x8000u
 
 /* Per record fields consumed by update_unpaired_read_paths / update_paths (src/typer/alignment.cpp:365-545) */
@@ -274,6 +277,26 @@ int gtx_align_batch(gtx_ctx *, const uint8_t * d_seq, uint32_t seq_stride, const
 #define GTX_TASK_HAS_VARIANTS 1u
 int gtx_align_batch_flags(gtx_ctx *, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
                           uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream);
+
+/* ---- reads as bit planes: the layout the alignment kernels read.  north_star asks for "coalesced HBM loads of packed
+ * 2-bit reads"; BAM holds 4-bit codes (bam_get_seq: A=1 C=2 G=4 T=8, N=15 and the other IUPAC sets, '='=0), and the path must
+ * see every one of them (to_uint64_vec fans ambiguity codes out, src/utilities/type_conversions.cpp:207-266).  A plane row
+ * keeps all four bits, one plane each: a row of plane_stride bytes (a multiple of 16) is plane_stride / 16 groups of 32 bases,
+ * four little-endian 32-bit words per group -- word 4g + b holds bit b of the codes of bases 32g .. 32g+31, base 32g + j at
+ * bit j; bits behind the read's end are ignored.  For an unambiguous read planes 1|3 and 2|3 ARE the packed 2-bit bases (low
+ * and high bit of A0 C1 G2 T3), plane 0&1&2&3 is the N mask.  Same size as the BAM nibbles (80 bytes for 150 bp), but the per-base
+ * questions of the kernels become bitwise operations over 32 bases and nothing is transposed per read and step.
+ *   gtx_pack_planes        host: n BAM nibble rows (seq_stride bytes each) -> n plane rows
+ *   gtx_stream_set_planes  gtx_stream_push then writes align_seq as plane rows of that pitch (0: BAM nibble rows again)
+ *   gtx_reads_to_planes    device: the same repack for rows that already lie in HBM (one-off, e.g. behind the upload)
+ *   gtx_align_batch_planes gtx_align_batch_flags over plane rows (d_planes 16-byte aligned; d_task_flags may be NULL)
+ * gtx_align_batch / gtx_align_batch_flags still take bam_get_seq bytes: they repack into a buffer of the call's scratch
+ * first (80 bytes per read more traffic and memory) and run the same kernels. */
+int gtx_pack_planes(const uint8_t * seq, uint32_t seq_stride, uint32_t n, uint8_t * planes, uint32_t plane_stride);
+int gtx_reads_to_planes(gtx_ctx *, const uint8_t * d_seq, uint32_t seq_stride, uint32_t n_reads, uint8_t * d_planes, uint32_t plane_stride,
+                        void * stream);
+int gtx_align_batch_planes(gtx_ctx *, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
+                           uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream);
 
 /* Score accumulators (all uint32 / uint64, zero-initialised by the caller; sample-major):
  *   d_log_score [n_samples * total_tri]      HapSample::log_score
@@ -488,6 +511,8 @@ void gtx_stream_destroy(gtx_stream *);
 int gtx_stream_push(gtx_stream *, const gtx_stream_record * recs, const uint8_t * seq, uint32_t seq_stride, uint32_t n,
                     uint8_t * align_seq, gtx_read_meta * align_meta, uint32_t align_cap, uint32_t * n_align,
                     gtx_score_item * items, uint32_t item_cap, uint32_t * n_items);
+/* plane_stride != 0: align_seq receives plane rows of that pitch (see gtx_pack_planes) instead of copies of the BAM bytes */
+int gtx_stream_set_planes(gtx_stream *, uint32_t plane_stride);
 /* SV calling only, optional: the (extreme) coverage filter (hts_parallel_reader.cpp:594-633) drops a record once its
  * sample has more than avg_cov_by_readlen[sample] * 150 accepted records in the record's 50 bp bin.  Without this call
  * (or with a value <= 0 for a sample) nothing is dropped -- Options::no_filter_on_coverage. */

@@ -126,12 +126,19 @@ extern "C"
 
   void emu_free(void * p) { delete static_cast<Emu *>(p); }
 
-  // same contract as gtx_align_batch, host pointers
-  int emu_align(void * p, const uint8_t * seq, uint32_t seq_stride, const gtx_read_meta * meta, uint32_t n_reads,
+  // same contract as gtx_align_batch, host pointers: BAM nibble rows, repacked into plane rows first (what the library does
+  // with them on the device); the kernel sources below read plane rows only
+  int emu_align(void * p, const uint8_t * nibble_rows, uint32_t nibble_stride, const gtx_read_meta * meta, uint32_t n_reads,
                 uint32_t * records, uint32_t rec_words)
   {
     using namespace gtx;
     Emu & e = *static_cast<Emu *>(p);
+    uint32_t const seq_stride = (nibble_stride + PLANE_GROUP_BYTES - 1u) / PLANE_GROUP_BYTES * PLANE_GROUP_BYTES;
+    std::vector<uint32_t> plane_rows(static_cast<size_t>(n_reads) * (seq_stride / 4) + 4);
+    for (uint32_t r = 0; r < n_reads; ++r)
+      planes_from_nibbles(nibble_rows + static_cast<uint64_t>(r) * nibble_stride, nibble_stride, plane_rows.data() + static_cast<size_t>(r) * (seq_stride / 4),
+                          seq_stride / PLANE_GROUP_BYTES);
+    uint8_t const * seq = reinterpret_cast<uint8_t const *>(plane_rows.data());
     GraphView const g = e.graph.view();
     IndexView ix = e.index.view(static_cast<uint32_t>(e.params.max_index_labels), HALF_BUCKET_CAP);
     if (char const * cap = std::getenv("GTX_HALF_BUCKET_CAP"))
@@ -251,13 +258,13 @@ extern "C"
         uint32_t const len = m.l_qseq;
         bool const outside = len < 2 * K - 1 || len > AlignCfg::MAX_READ;
         bool const rev = !outside && needs_reverse(m, force_both);
-        if (!rev)
+        if (!rev && (m.flag & GTX_FLAG_FORWARD_ONLY) == 0) // (the caller never looks at that record: gtx.h, GTX_FLAG_FORWARD_ONLY)
           empty_record(read * 2 + 1, len);
         if (outside)
           empty_record(read * 2, len);
         else if (force != 0 || (eh && eh[0] == 'd') ||
-                 !hinted_one(g, ix, reinterpret_cast<uint32_t const *>(seq + static_cast<uint64_t>(read) * seq_stride),
-                             seq + static_cast<uint64_t>(read) * seq_stride, seq_stride, m, records + static_cast<uint64_t>(read) * 2 * rec_words, rec_words))
+                 !hinted_one(g, ix, reinterpret_cast<uint32_t const *>(seq + static_cast<uint64_t>(read) * seq_stride), seq_stride, m,
+                             records + static_cast<uint64_t>(read) * 2 * rec_words, rec_words))
         {
           queue1.push_back(read);
           e.pass_of[read] = 1;
@@ -479,11 +486,12 @@ extern "C"
       for (uint32_t b = 0; b < 4; ++b)
         refp[4 * (i >> 5) + b] |= ((static_cast<uint32_t>(base[i]) >> b) & 1u) << (i & 31u);
     }
-    uint32_t words[20];
+    uint32_t words[20], planes[20];
     std::memcpy(words, row, 80);
+    planes_from_nibbles(row, 80u, planes, 5u);
     HintCounts a{}, b{};
     hint_compare_nibbles(words, 80u, ref4.data() + (idx >> 3), 4 * (idx & 7u), L, a);
-    hint_compare(words, 80u, refp.data() + 4 * (idx >> 5), idx & 31u, L, b);
+    hint_compare(planes, 80u, refp.data() + 4 * (idx >> 5), idx & 31u, L, b);
     for (int i = 0; i < 5; ++i)
     {
       out[i] = a.k[i];
