@@ -611,6 +611,13 @@ __device__ __forceinline__ void express4_queue_pass(GraphView const & g, IndexVi
   __shared__ uint32_t pending[TASK_CHUNK];
   uint32_t const lane = threadIdx.x & 63u;
   uint32_t const n = queue1_count[0];
+  // Reads a wavefront claims per visit to the counter: TASK_CHUNK when the queue is long (one atomic per claim: a single
+  // counter takes ~100 M of them a second), but never so many that part of the grid stays without work -- behind the
+  // position-hinted pass the queue holds ~1 % of a batch, and with 64-read claims a quarter of the resident wavefronts
+  // walked 16 groups of four each while the others had exited (cfg2: 0.35 ms for 100 k reads).  Two claims per wavefront
+  // at least, whole groups of four.
+  uint32_t const per_wave = (n + gridDim.x - 1u) / gridDim.x;
+  uint32_t const chunk = per_wave >= 2u * TASK_CHUNK ? TASK_CHUNK : per_wave <= 8u ? 4u : ((per_wave / 2u + 3u) & ~3u);
 #ifdef GTX_PROF
   if (threadIdx.x < 16)
     ws.prof_acc[threadIdx.x] = 0;
@@ -618,10 +625,10 @@ __device__ __forceinline__ void express4_queue_pass(GraphView const & g, IndexVi
 #endif
   for (;;)
   {
-    uint32_t const base = wave_claim(task_counter, TASK_CHUNK);
+    uint32_t const base = wave_claim(task_counter, chunk);
     if (base >= n)
       break;
-    uint32_t const end = base + TASK_CHUNK < n ? base + TASK_CHUNK : n;
+    uint32_t const end = base + chunk < n ? base + chunk : n;
     uint32_t n_pending = 0;
     for (uint32_t first = base; first < end; first += 4)
     {
@@ -1531,7 +1538,11 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
       if (!hip_ok(hipGetLastError(), "gtx_align_hinted_kernel launch"))
         return GTX_ERR_HIP;
       mark(part, 1, st);
-      hipLaunchKernelGGL(wide ? gtx_align_express4q_wide_kernel : gtx_align_express4q_kernel, dim3(blocks4), dim3(64), 0, st, c->dev_graph,
+      // (the queue's length is known on the device only: the grid is what can be resident, or one wavefront per group of four
+      //  reads of a small batch; the kernel sizes its claims to the queue)
+      uint32_t const blocks4q = static_cast<uint32_t>(std::min<uint64_t>(
+        (static_cast<uint64_t>(n) + 3u) / 4u, static_cast<uint64_t>(n_cu) * (wide ? c->express4_wide_blocks_per_cu : c->express4_blocks_per_cu)));
+      hipLaunchKernelGGL(wide ? gtx_align_express4q_wide_kernel : gtx_align_express4q_kernel, dim3(blocks4q), dim3(64), 0, st, c->dev_graph,
                          c->dev_index, seq, seq_stride, meta, records, rec_words, counters, queue1, counters + 3, queue2, counters + 2,
                          counters + 4, static_cast<uint32_t>(force != 0));
     }

@@ -343,7 +343,7 @@ GTX_DEV uint32_t hk_make(uint32_t kind, uint32_t site, uint32_t allele, bool mm,
 constexpr uint32_t HK_NEED_LEFT = 64u, HK_NEED_RIGHT = 128u;
 
 template <uint32_t I, class Row>
-GTX_DEV uint32_t hint_kmer(uint2_t const f, Row row, HintCounts const & h)
+GTX_DEV uint32_t hint_kmer(uint2_t const f, Row row, HintCounts const & h, uint32_t & amb2)
 {
   constexpr uint32_t A = (K - 1) * I;
   uint32_t mis = hc_get(h.k[I], HC_MIS), mis_left = hc_get(h.k[I], HC_MIS_LEFT);
@@ -455,6 +455,14 @@ GTX_DEV uint32_t hint_kmer(uint2_t const f, Row row, HintCounts const & h)
       GTX_HINT_NOTE(5);
       return declined;
     }
+    return hk_make(amb_out == 0 ? HINT_K_LABEL : HINT_K_HOLE, site, allele, false, true);
+  }
+  if (amb == 2 && mis == 0 && amb_left == 1 && gl)
+  {
+    // one ambiguous base in each half, the rest == K: of the (up to 16) keys those with K's base on the left carry K's left
+    // half -- nobody else has it: K, or nothing --, the others carry one of three left halves a substitution away from K's,
+    // and the caller asks the filter about those three (amb2: this k-mer): all absent -> of the list only K can be indexed
+    amb2 |= 1u << I;
     return hk_make(amb_out == 0 ? HINT_K_LABEL : HINT_K_HOLE, site, allele, false, true);
   }
   if (amb > 1)
@@ -573,10 +581,11 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   hint_compare(row, seq_stride, refw, sh, L, h);
   // ---- every k-mer: the label of its place, no label at all, or not provable
   uint32_t const none = hk_make(HINT_K_HOLE, HINT_NO_SITE, 0u, false, false);
-  uint32_t k0 = hint_kmer<0>(f0, row, h), k1 = hint_kmer<1>(f1, row, h);
-  uint32_t k2 = n_k > 2 ? hint_kmer<2>(f2, row, h) : none;
-  uint32_t k3 = n_k > 3 ? hint_kmer<3>(f3, row, h) : none;
-  uint32_t k4 = n_k > 4 ? hint_kmer<4>(f4, row, h) : none;
+  uint32_t amb2 = 0; // k-mers with one ambiguous base in each half: three more filter probes (below)
+  uint32_t k0 = hint_kmer<0>(f0, row, h, amb2), k1 = hint_kmer<1>(f1, row, h, amb2);
+  uint32_t k2 = n_k > 2 ? hint_kmer<2>(f2, row, h, amb2) : none;
+  uint32_t k3 = n_k > 3 ? hint_kmer<3>(f3, row, h, amb2) : none;
+  uint32_t k4 = n_k > 4 ? hint_kmer<4>(f4, row, h, amb2) : none;
   if ((k0 & 3u) == HINT_K_DECLINE || (k1 & 3u) == HINT_K_DECLINE || (k2 & 3u) == HINT_K_DECLINE || (k3 & 3u) == HINT_K_DECLINE ||
       (k4 & 3u) == HINT_K_DECLINE)
     return false;
@@ -607,6 +616,51 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   if ((k0 & 3u) == HINT_K_DECLINE || (k1 & 3u) == HINT_K_DECLINE || (k2 & 3u) == HINT_K_DECLINE || (k3 & 3u) == HINT_K_DECLINE ||
       (k4 & 3u) == HINT_K_DECLINE)
     return false;
+  if (amb2 != 0)
+  {
+    // ---- a k-mer with one ambiguous base in each half (rare: one wavefront in fifteen meets one).  The three left halves
+    //      that carry another base than the reference's at the ambiguous position must occur in no indexed key.  One such
+    //      k-mer per read is looked at; a second one sends the read on.
+    if ((amb2 & (amb2 - 1u)) != 0)
+    {
+      GTX_HINT_NOTE(7);
+      return false;
+    }
+    uint32_t const A = (K - 1) * static_cast<uint32_t>(__builtin_ctz(amb2));
+    uint32_t p[4];
+#pragma unroll
+    for (uint32_t b = 0; b < 4; ++b)
+    {
+      uint32_t const w = A >> 5, sft = A & 31u;
+      uint32_t const lo_w = row[4 * w + b], hi_w = row[4 * (w + 1 < HINT_PLANE_WORDS ? w + 1 : w) + b];
+      p[b] = hint_funnel(lo_w, hi_w, sft) & 0xFFFFu; // bases A .. A+15 (A + 15 < 160: inside the row's five groups)
+    }
+    uint32_t const odd = p[0] ^ p[1] ^ p[2] ^ p[3], three = (p[0] & p[1] & (p[2] | p[3])) | (p[2] & p[3] & (p[0] | p[1]));
+    uint32_t const amb16 = ~(odd & ~three) & 0xFFFFu;
+    uint32_t const j = static_cast<uint32_t>(__builtin_ctz(amb16 | 0x10000u)) & 15u; // the ambiguous base of the left half
+    uint32_t const q = idx + A + j;                                                    // ... and the reference base under it
+    uint32_t const * rq = ix.refp + 4 * (q >> 5);
+    uint32_t const qs = q & 31u;
+    uint32_t const rc = ((rq[0] >> qs) & 1u) | (((rq[1] >> qs) & 1u) << 1) | (((rq[2] >> qs) & 1u) << 2) | (((rq[3] >> qs) & 1u) << 3);
+    uint32_t const ref_two = rc == 1 ? 0u : rc == 2 ? 1u : rc == 4 ? 2u : 3u;
+    uint32_t const lo0 = (p[1] | p[3]) & ~(1u << j), hi0 = (p[2] | p[3]) & ~(1u << j);
+    bool maybe = (rc & (rc - 1u)) != 0 || (amb16 & (amb16 - 1u)) != 0; // (a reference N there, or not exactly one ambiguous base: not provable)
+    uint32_t w3[3], m3[3];
+#pragma unroll
+    for (uint32_t t = 0; t < 3; ++t)
+    {
+      uint32_t const x = (ref_two + 1u + t) & 3u; // the three other bases
+      hint_filter_slot(lo0 | ((x & 1u) << j), hi0 | ((x >> 1) << j), ix.filt_log2, w3[t], m3[t]);
+    }
+    uint32_t const * fl = ix.filt[0];
+    uint32_t const y0 = fl[w3[0]], y1 = fl[w3[1]], y2 = fl[w3[2]];
+    maybe = maybe || (y0 & m3[0]) == m3[0] || (y1 & m3[1]) == m3[1] || (y2 & m3[2]) == m3[2];
+    if (maybe)
+    {
+      GTX_HINT_NOTE(4);
+      return false;
+    }
+  }
   auto bits = [&](uint32_t flag, uint32_t want) // one bit per k-mer
   {
     return ((k0 & flag) == want ? 1u : 0u) | ((k1 & flag) == want ? 2u : 0u) | ((k2 & flag) == want ? 4u : 0u) | ((k3 & flag) == want ? 8u : 0u) |
@@ -654,16 +708,79 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   // ---- the read in front of the run and behind it: the walks' shortcut, both inside the reference node the path touches
   uint32_t const prs = (K - 1) * lo, pre = (K - 1) * (hi + 1);
   uint32_t start = g.first_order + idx + prs, rs = prs;
+  // A walk that leaves its reference node over ONE site whose alleles are single bases (tail_info: HINT_TAIL_OK), with the
+  // rest inside the reference node on the other side: Graph::get_labels_forward / _backward has one candidate per allele,
+  // they differ in that character only, and the labels of the best ones share their ends -- one path with the site's best
+  // alleles (express4.inl).  The reference allele and both nodes ARE the linear reference, so the compare above already
+  // holds every other character.  `only` < 4: the walk starts INSIDE that allele (the path ends on the site's base and
+  // carries the allele: Graph::get_locations_of_a_position offers variant nodes the path has, graph.cpp:1154-1185).
+  // rc: the read's base on the site.  Returns the mismatches there for the best alleles (their set in `mask`) and what
+  // the compare with the reference allele had counted (x0).
+  auto site_choice = [&](uint32_t tx, uint32_t rc0, uint32_t only, uint32_t & mask, uint32_t & x0) -> uint32_t
+  {
+    uint32_t const rc = rc0 == 0 ? 15u : rc0; // ('=' reads as N)
+    uint32_t const nall = (tx >> HINT_TAIL_NALL_SHIFT) & 7u, codes = tx >> HINT_TAIL_CODES_SHIFT;
+    uint32_t best = 2;
+    mask = 0;
+#pragma unroll
+    for (uint32_t a = 0; a < 4; ++a)
+      if (a < nall && (only >= 4 || a == only))
+      {
+        uint32_t const gc = (codes >> (4 * a)) & 15u;
+        uint32_t const xa = (gc != rc && rc != 15u) ? 1u : 0u; // (the alleles are A, C, G or T)
+        if (xa < best)
+        {
+          best = xa;
+          mask = 0;
+        }
+        if (xa == best)
+          mask |= 1u << a;
+      }
+    x0 = ((codes & 15u) != rc && rc != 15u) ? 1u : 0u;
+    return best;
+  };
+  // the single allele k-mer `km` carries on `site` (4: it is another site, or a set of several)
+  auto carried = [&](uint32_t km, uint32_t site) -> uint32_t
+  {
+    uint32_t const set = (km >> HK_SET_SHIFT) & 255u;
+    if ((km >> HK_SITE_SHIFT) != site || (set & (set - 1u)) != 0)
+      return 4u;
+    return set ? static_cast<uint32_t>(__builtin_ctz(set)) : (km >> HK_ALLELE_SHIFT) & 3u;
+  };
+  uint32_t head_site = 0, head_mask = 0; // the site the walk at the read's start crossed, with its best alleles
   if (prs != 0) // walk_read_starts (genotype_paths.cpp:555-621)
   {
     uint32_t const y = lo == 1 ? f1.y : lo == 2 ? f2.y : lo == 3 ? f3.y : f4.y; // (position 31 lo is k-mer lo's own place)
-    if ((y & 255u) == 0 || ((y >> HINT_BACK_SHIFT) & 255u) < prs)
+    uint32_t const back = (y >> HINT_BACK_SHIFT) & 255u;
+    uint32_t upto = hc_upto(h, lo) + hc_edge(h, lo); // mismatches in [0, prs]: the boundary base itself is base 31 lo
+    if ((y & 255u) == 0 || back < prs)
     {
-      GTX_HINT_NOTE(11);
-      return false; // (the walk leaves the node: express4 / general pass)
+      // the walk leaves the node backwards: over the site in front of it (its base is read base ps), or -- the path
+      // starts ON a site's base -- out of the allele it carries into the node in front
+      bool const on_site = (y & 255u) == 0;
+      uint32_t const ps = on_site ? prs : prs - back - 1u;
+      if (idx + ps == 0)
+      {
+        GTX_HINT_NOTE(11);
+        return false;
+      }
+      uint32_t const q = idx + ps - 1u; // the position in front of the site: the last base of the node there
+      uint32_t const yq = ix.pos_flags[q].y;
+      uint2_t const tq = ix.tail_info[q];
+      uint32_t const km = lo == 1 ? k1 : lo == 2 ? k2 : lo == 3 ? k3 : k4;
+      uint32_t const only = on_site ? carried(km, tq.y) : 4u;
+      if ((yq & 255u) != 1u || (tq.x & HINT_TAIL_OK) == 0 || (ps != 0 && ((yq >> HINT_BACK_SHIFT) & 255u) + 1u < ps) || (on_site && only >= 4u))
+      {
+        GTX_HINT_NOTE(11);
+        return false; // (an indel, a second site, a set of alleles: express4 / general pass)
+      }
+      uint32_t mask = 0, x0 = 0;
+      uint32_t const best = site_choice(tq.x, plane_code_at(row, ps), only, mask, x0);
+      upto = upto - x0 + best;
+      head_site = tq.y;
+      head_mask = mask;
     }
     uint32_t const head_len = prs + 1;
-    uint32_t const upto = hc_upto(h, lo) + hc_edge(h, lo); // mismatches in [0, prs]: the boundary base itself is base 31 lo
     uint32_t const budget = 2 + head_len / 11 < 7 ? 2 + head_len / 11 : 7; // genotype_paths.cpp:571-577
     if (upto <= budget)
     {
@@ -671,6 +788,8 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
       rs = 0;
       mism += upto;
     }
+    else
+      head_mask = 0; // (the path stays as it is: no site from the walk)
   }
   uint32_t end = g.first_order + idx + pre, re = pre;
   uint32_t tail_site = 0, tail_mask = 0; // the site the walk at the read's end crossed, with its best alleles
@@ -682,39 +801,33 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
     uint32_t got = hc_all(h) - hc_upto(h, hi + 1);
     if (room < tail_len)
     {
-      // The tail leaves the node.  Over ONE site whose alleles are single bases, with the rest inside the reference node
-      // behind it, Graph::get_labels_forward has one candidate per allele, they differ in that character only, and the
-      // labels of the best ones share their ends: one path with the site's best alleles (express4.inl, lean build).  The
-      // reference allele and the node behind the site ARE the linear reference, so the compare above already holds
-      // every other character.
-      uint32_t const at = room; // tail character that lies on the site
-      uint32_t const next_len = (t_end.x >> HINT_TAIL_NEXT_SHIFT) & 255u;
-      if (hi + 1 != n_k || room == 0 || (t_end.x & HINT_TAIL_OK) == 0 || next_len < tail_len - at - 1)
+      // the tail leaves the node: over the site behind it (tail character `at`), or -- the path ends ON a site's base --
+      // out of the allele it carries into the node behind
+      bool const on_site = room == 0;
+      uint32_t const at = room;
+      uint2_t ti = t_end;
+      uint32_t only = 4u;
+      bool ok = true;
+      if (on_site)
+      {
+        uint32_t const q = idx + pre - 1u; // (pre >= 32) the last base of the node in front of the site
+        ok = (ix.pos_flags[q].y & 255u) == 1u;
+        ti = ix.tail_info[q];
+        only = carried(hi == 0 ? k0 : hi == 1 ? k1 : hi == 2 ? k2 : hi == 3 ? k3 : k4, ti.y);
+        ok = ok && only < 4u;
+      }
+      else if (hi + 1 != n_k)
+        ti = ix.tail_info[idx + pre]; // (the run ends in front of a label-less k-mer: the table entry of that place)
+      uint32_t const next_len = (ti.x >> HINT_TAIL_NEXT_SHIFT) & 255u;
+      if (!ok || (ti.x & HINT_TAIL_OK) == 0 || next_len < tail_len - at - 1)
       {
         GTX_HINT_NOTE(8);
-        return false; // (ends on a variant, an indel, a second site: express4 / general pass)
+        return false; // (an indel, a second site, a set of alleles: express4 / general pass)
       }
-      uint32_t const p = pre + at;
-      uint32_t const rc0 = plane_code_at(row, p), rc = rc0 == 0 ? 15u : rc0; // ('=' reads as N)
-      uint32_t const nall = (t_end.x >> HINT_TAIL_NALL_SHIFT) & 7u, codes = t_end.x >> HINT_TAIL_CODES_SHIFT;
-      uint32_t best = 2, mask = 0;
-#pragma unroll
-      for (uint32_t a = 0; a < 4; ++a)
-        if (a < nall)
-        {
-          uint32_t const gc = (codes >> (4 * a)) & 15u;
-          uint32_t const xa = (gc != rc && rc != 15u) ? 1u : 0u; // (the alleles are A, C, G or T)
-          if (xa < best)
-          {
-            best = xa;
-            mask = 0;
-          }
-          if (xa == best)
-            mask |= 1u << a;
-        }
-      uint32_t const x0 = ((codes & 15u) != rc && rc != 15u) ? 1u : 0u; // what the compare with the reference allele counted there
+      uint32_t mask = 0, x0 = 0;
+      uint32_t const best = site_choice(ti.x, plane_code_at(row, pre + at), only, mask, x0);
       got = got - x0 + best;
-      tail_site = t_end.y;
+      tail_site = ti.y;
       tail_mask = mask;
     }
     uint32_t const budget = 2 + tail_len / 11 < 7 ? 2 + tail_len / 11 : 7; // genotype_paths.cpp:505-511
@@ -774,7 +887,9 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   push(2, k2);
   push(1, k1);
   push(0, k0);
-  if (clash || 6 + 3 * nvar > rec_words)
+  if (head_mask != 0) // (Path(pp, original), genotype_paths.cpp:262: the original's sites stay in front, the start walk's come last)
+    append((head_site << 16) | head_mask);
+  if (clash || nvar > 6 || 6 + 3 * nvar > rec_words) // (six named registers hold the sites)
   {
     GTX_HINT_NOTE(13);
     return false;
