@@ -191,6 +191,31 @@ struct WaveHipMem : WaveHip
   static __device__ inline void lds_sync() { mem_sync(); }
 };
 
+// The bulk traffic of the position-hinted pass -- every read's bases and meta record in, every record out, each touched
+// once -- is marked non-temporal (the `nt` bit of the global load / store): it streams through the caches without pushing
+// out what the passes behind it live on (their code, the index and graph tables), which they would otherwise find cold at
+// every launch.  GTX_NO_NT at build time: plain accesses (A/B).
+#ifdef GTX_NO_NT
+template <class T>
+static __device__ inline T stream_load(T const * p) { return *p; }
+template <class T>
+static __device__ inline void stream_store(T * p, T const & v) { *p = v; }
+#else
+static __device__ inline uint32_t stream_load(uint32_t const * p) { return __builtin_nontemporal_load(p); }
+static __device__ inline uint4_t stream_load(uint4_t const * p)
+{
+  typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+  v4 const v = __builtin_nontemporal_load(reinterpret_cast<v4 const *>(p));
+  return uint4_t{v.x, v.y, v.z, v.w};
+}
+static __device__ inline void stream_store(uint4_t * p, uint4_t const & v)
+{
+  typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+  v4 const x = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(x, reinterpret_cast<v4 *>(p));
+}
+#endif
+
 // The leader takes `n` units from a device counter; every lane gets the old value (readfirstlane is the convergence
 // point: no lane continues before the leader's atomic has returned).
 static __device__ inline uint32_t wave_claim(uint32_t * counter, uint32_t n)
@@ -406,9 +431,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_WIDE_WAV
 template <uint32_t WAVES>
 __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const & ix, uint8_t const * __restrict__ seq, uint32_t seq_stride,
                                             gtx_read_meta const * __restrict__ meta, uint32_t n_reads, uint32_t * __restrict__ records,
-                                            uint32_t rec_words, uint32_t force_both, uint32_t * __restrict__ queue1, uint32_t * queue1_count,
-                                            uint32_t * __restrict__ queue2, uint32_t * queue2_count, uint32_t decline_all,
-                                            uint8_t * __restrict__ task_flags)
+                                            uint32_t rec_words, uint32_t force_both, uint32_t * __restrict__ queue1, uint32_t * __restrict__ queue2,
+                                            unsigned long long * queue_counts /* queue 2's fill count (low word), queue 1's (high word) */,
+                                            uint32_t decline_all, uint8_t * __restrict__ task_flags)
 {
   // The 64 reads of a wavefront lie side by side in memory: their bases (80 B each: five 16-byte groups of four plane words,
   // graph_dev.hpp) and their meta records (20 B each) are fetched with coalesced loads -- 1 KB and 256 B per instruction
@@ -429,14 +454,14 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
     uint32_t const * src = reinterpret_cast<uint32_t const *>(meta + wave_first);
 #pragma unroll
     for (uint32_t it = 0; it < META_WORDS; ++it)
-      s_meta[wave][it * 64 + lane] = src[it * 64 + lane];
+      s_meta[wave][it * 64 + lane] = stream_load(src + it * 64 + lane);
   }
   if (staged)
   {
     uint4_t const * src = reinterpret_cast<uint4_t const *>(seq + static_cast<uint64_t>(wave_first) * ROW_BYTES);
 #pragma unroll
     for (uint32_t it = 0; it < ROW_VEC; ++it)
-      s_seq[wave][it * 64 + lane] = src[it * 64 + lane];
+      s_seq[wave][it * 64 + lane] = stream_load(src + it * 64 + lane);
   }
   else if (read < n_reads)
   {
@@ -449,7 +474,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
       dst[k] = k < seq_stride ? src[k] : static_cast<uint8_t>(0);
   }
   WaveHip::lds_sync();
-  bool fwd = false, rev = false, staged_rec = false;
+  bool fwd = false, fwd2 = false, rev = false, staged_rec = false; // forward task to the express pass / straight to the general pass, reverse task
   uint32_t fwd_flag = 0;
   static_assert(HINT_STAGE_WORDS == 16 && HINT_STAGE_WORDS * 4 <= HINT_MAX_READ / 2, "a staged record is four 16-byte parts inside the read's row");
   if (read < n_reads)
@@ -499,14 +524,15 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
       bool const can_stage = (rec_words & 3u) == 0 && (reinterpret_cast<uintptr_t>(records) & 15u) == 0; // (16-byte stores into the slots)
       uint32_t const where = hinted_one(g, ix, row, ROW_BYTES, m, rec, rec_words, can_stage ? row : nullptr);
       fwd = where == 0;
+      fwd2 = where == HINT_TO_GENERAL;
       staged_rec = where == 2;
-      fwd_flag = where == 0 ? 0u : ((where == 2 ? row[1] : rec[1]) >> 31);
+      fwd_flag = (where == 0 || where == HINT_TO_GENERAL) ? 0u : ((where == 2 ? row[1] : rec[1]) >> 31);
     }
     // the dense side array (gtx_align_batch_flags): what this pass settles -- the forward task it finished, the reverse
     // task that is not aligned at all; the queued tasks get theirs from gtx_task_flags_fixup_kernel behind the last pass
     if (task_flags)
     {
-      if (!fwd)
+      if (!fwd && !fwd2)
         task_flags[2ull * read] = static_cast<uint8_t>(fwd_flag);
       if (!rev)
         task_flags[2ull * read + 1] = 0;
@@ -527,27 +553,36 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
           uint4_t const v = s_seq[wave][r * ROW_VEC + part];
           uint32_t const rd = wave_first + r;
           uint32_t * dst = records + static_cast<uint64_t>((decline_all & 2u) ? (rd & 1023u) : rd) * 2 * rec_words;
-          *reinterpret_cast<uint4_t *>(dst + 4 * part) = v;
+          stream_store(reinterpret_cast<uint4_t *>(dst + 4 * part), v);
         }
       }
     }
   }
-  // Queue appends: ONE atomic per workgroup and queue (a device counter takes ~100 M returning atomics a second; one per
-  // wavefront -- 156 k per 10 M reads -- set the pace of this kernel).  Every wavefront posts its counts, the first one
-  // claims room for the workgroup, every wavefront writes at its offset.
-  unsigned long long const F = __ballot(fwd), R = __ballot(rev);
+  // Queue appends: ONE atomic per workgroup for BOTH queues (a device counter takes ~100 M returning atomics a second; one
+  // per wavefront -- 156 k per 10 M reads -- set the pace of this kernel, and so did a second counter per workgroup once a
+  // quarter of the workgroups had something for each queue).  The two fill counts are neighbouring words -- queue 2's low,
+  // queue 1's high -- and take one 64-bit add.  Every wavefront posts its counts, the first thread claims room for the
+  // workgroup, every wavefront writes at its offset.
+  unsigned long long const F = __ballot(fwd), R = __ballot(rev), F2 = __ballot(fwd2);
   if (lane == 0)
   {
     s_count[0][wave] = static_cast<uint32_t>(__builtin_popcountll(F));
-    s_count[1][wave] = static_cast<uint32_t>(__builtin_popcountll(R));
+    s_count[1][wave] = static_cast<uint32_t>(__builtin_popcountll(R) + __builtin_popcountll(F2));
   }
   __syncthreads();
-  if (threadIdx.x < 2)
+  if (threadIdx.x == 0)
   {
-    uint32_t total = 0;
+    uint32_t total1 = 0, total2 = 0;
     for (uint32_t w = 0; w < WAVES; ++w)
-      total += s_count[threadIdx.x][w];
-    s_base[threadIdx.x] = total ? atomicAdd(threadIdx.x == 0 ? queue1_count : queue2_count, total) : 0u;
+    {
+      total1 += s_count[0][w];
+      total2 += s_count[1][w];
+    }
+    unsigned long long base = 0;
+    if (total1 | total2)
+      base = atomicAdd(queue_counts, (static_cast<unsigned long long>(total1) << 32) | total2);
+    s_base[0] = static_cast<uint32_t>(base >> 32);
+    s_base[1] = static_cast<uint32_t>(base);
   }
   __syncthreads();
   uint32_t off1 = s_base[0], off2 = s_base[1];
@@ -561,13 +596,15 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
     queue1[off1 + static_cast<uint32_t>(__builtin_popcountll(F & ((1ull << lane) - 1ull)))] = read;
   if (rev)
     queue2[off2 + static_cast<uint32_t>(__builtin_popcountll(R & ((1ull << lane) - 1ull)))] = read * 2 + 1;
+  if (fwd2)
+    queue2[off2 + static_cast<uint32_t>(__builtin_popcountll(R) + __builtin_popcountll(F2 & ((1ull << lane) - 1ull)))] = read * 2;
 }
 
 #define GTX_HINTED_ARGS                                                                                                            \
   GraphView g, IndexView ix, uint8_t const *__restrict__ seq, uint32_t seq_stride, gtx_read_meta const *__restrict__ meta,         \
     uint32_t n_reads, uint32_t *__restrict__ records, uint32_t rec_words, uint32_t force_both, uint32_t *__restrict__ queue1,      \
-    uint32_t *queue1_count, uint32_t *__restrict__ queue2, uint32_t *queue2_count, uint32_t decline_all, uint8_t *__restrict__ task_flags
-#define GTX_HINTED_PASS(W) hinted_pass<W>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, queue1, queue1_count, queue2, queue2_count, decline_all, task_flags)
+    uint32_t *__restrict__ queue2, unsigned long long *queue_counts, uint32_t decline_all, uint8_t *__restrict__ task_flags
+#define GTX_HINTED_PASS(W) hinted_pass<W>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, queue1, queue2, queue_counts, decline_all, task_flags)
 
 #ifndef GTX_HINT_VGPRS
 #define GTX_HINT_VGPRS 80
@@ -611,37 +648,20 @@ __device__ __forceinline__ void express4_queue_pass(GraphView const & g, IndexVi
   __shared__ uint32_t pending[TASK_CHUNK];
   uint32_t const lane = threadIdx.x & 63u;
   uint32_t const n = queue1_count[0];
-  // Reads a wavefront claims per visit to the counter: TASK_CHUNK when the queue is long (one atomic per claim: a single
-  // counter takes ~100 M of them a second), but never so many that part of the grid stays without work -- behind the
-  // position-hinted pass the queue holds ~1 % of a batch, and with 64-read claims a quarter of the resident wavefronts
-  // walked 16 groups of four each while the others had exited (cfg2: 0.35 ms for 100 k reads).  Two claims per wavefront
-  // at least, whole groups of four.
-  uint32_t const per_wave = (n + gridDim.x - 1u) / gridDim.x;
-  uint32_t const chunk = per_wave >= 2u * TASK_CHUNK ? TASK_CHUNK : per_wave <= 8u ? 4u : ((per_wave / 2u + 3u) & ~3u);
+  // The unit of work is a group of four reads.  Three quarters of a wavefront's even share are its own without asking
+  // (group w, w + G, w + 2 G, ... of a grid of G wavefronts: a single device counter takes ~100 M returning atomics a
+  // second, and thousands of wavefronts asking at the kernel's start was a tenth of a millisecond); the rest is claimed one
+  // group at a time, which is what evens out the end of the pass.
+  uint32_t const n_groups = (n + 3u) / 4u, G = gridDim.x;
+  uint32_t const own = (n_groups / G) * 3u / 4u;
 #ifdef GTX_PROF
   if (threadIdx.x < 16)
     ws.prof_acc[threadIdx.x] = 0;
   WaveHip::lds_sync();
 #endif
-  for (;;)
+  uint32_t n_pending = 0;
+  auto flush = [&]()
   {
-    uint32_t const base = wave_claim(task_counter, chunk);
-    if (base >= n)
-      break;
-    uint32_t const end = base + chunk < n ? base + chunk : n;
-    uint32_t n_pending = 0;
-    for (uint32_t first = base; first < end; first += 4)
-    {
-      uint32_t const n_valid = end - first < 4 ? end - first : 4;
-      uint32_t const fwd_mask = express4<WaveHip, E4>(g, ix, ws, seq, seq_stride, meta, 0, n_valid, records, rec_words, queue_all != 0, queue1 + first);
-      for (uint32_t k = 0; k < n_valid; ++k)
-        if ((fwd_mask >> k) & 1u)
-        {
-          if (lane == 0)
-            pending[n_pending] = queue1[first + k] * 2;
-          ++n_pending;
-        }
-    }
     if (n_pending)
     {
       WaveHip::lds_sync();
@@ -651,8 +671,28 @@ __device__ __forceinline__ void express4_queue_pass(GraphView const & g, IndexVi
       for (uint32_t k = lane; k < n_pending; k += 64)
         queue2[at + k] = pending[k];
       WaveHip::lds_sync();
+      n_pending = 0;
     }
+  };
+  for (uint32_t i = 0;; ++i)
+  {
+    uint32_t const grp = i < own ? blockIdx.x + i * G : own * G + wave_claim(task_counter, 1u);
+    if (grp >= n_groups)
+      break;
+    uint32_t const first = 4u * grp;
+    uint32_t const n_valid = n - first < 4 ? n - first : 4;
+    uint32_t const fwd_mask = express4<WaveHip, E4>(g, ix, ws, seq, seq_stride, meta, 0, n_valid, records, rec_words, queue_all != 0, queue1 + first);
+    for (uint32_t k = 0; k < n_valid; ++k)
+      if ((fwd_mask >> k) & 1u)
+      {
+        if (lane == 0)
+          pending[n_pending] = queue1[first + k] * 2;
+        ++n_pending;
+      }
+    if (n_pending + 4u > TASK_CHUNK)
+      flush();
   }
+  flush();
 #ifdef GTX_PROF
   WaveHip::lds_sync();
   if (threadIdx.x < 16)
@@ -688,7 +728,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_GENERAL_
                                                        uint32_t const * __restrict__ queue, uint32_t const * queue_count,
                                                        uint32_t * task_counter, uint32_t * __restrict__ big_tasks,
                                                        uint32_t big_task_cap, uint32_t * big_state, uint32_t force_big, uint32_t task_base,
-                                                       uint32_t claim)
+                                                       uint32_t claim, uint32_t * forward_done)
 {
   __shared__ AlignWorkspace ws;
 #ifdef GTX_PROF
@@ -697,18 +737,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_GENERAL_
   WaveHip::lds_sync();
 #endif
   uint32_t const queued = queue_count[0];
-  uint32_t const CLAIM = claim; // tasks per visit to the counter (one atomic per task: the counter, not the work, sets the pace of a long
-                                // queue; large claims: the last claims of a short queue decide when the pass ends)
-  for (uint32_t t = 0, t_end = 0;; ++t)
+  // tasks per visit to the counter (one atomic per task: the counter, not the work, sets the pace of a long queue; large
+  // claims: the last claims of a short queue decide when the pass ends -- a wavefront that draws a second claim of four
+  // ~70 us tasks finishes 0.3 ms after one that does not).  `claim` = 0: sized to the queue -- four tasks per visit while
+  // every wavefront gets 32 and more, two from twelve on, else one ...
+  uint32_t const per_wave = queued / gridDim.x;
+  uint32_t const CLAIM = claim ? claim : per_wave >= 32u ? 4u : per_wave >= 12u ? 2u : 1u;
+  // ... and three quarters of a wavefront's even share are its own without asking (task w, w + G, w + 2 G, ... of a grid
+  // of G wavefronts): thousands of wavefronts asking one counter at the kernel's start cost as much as the tasks
+  uint32_t const G = gridDim.x, own = claim ? 0u : per_wave * 3u / 4u;
+  uint32_t n_forward = 0; // forward tasks this wavefront did (statistics: one add per wavefront at the end)
+  for (uint32_t i = 0, t = 0, t_end = 0;; ++i, ++t)
   {
-    if (t == t_end)
+    if (i < own)
+      t = blockIdx.x + i * G;
+    else if (i == own || t == t_end)
     {
-      t = wave_claim(task_counter, CLAIM);
+      t = own * G + wave_claim(task_counter, CLAIM);
       if (t >= queued)
         break;
       t_end = t + CLAIM < queued ? t + CLAIM : queued;
     }
     uint32_t const task = WaveHip::uni(queue[t]), read = task >> 1, orient = task & 1u;
+    n_forward += orient == 0 ? 1u : 0u;
     uint32_t const len = WaveHip::uni(static_cast<uint32_t>(meta[read].l_qseq));
     uint32_t * rec = records + static_cast<uint64_t>(task) * rec_words;
     uint32_t const st = align_one<WaveHip>(g, ix, ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words,
@@ -724,6 +775,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_GENERAL_
         atomicAdd(big_state + 3, 1u);
     }
   }
+  if (n_forward && (threadIdx.x & 63u) == 0)
+    atomicAdd(forward_done, n_forward);
 #ifdef GTX_PROF
   WaveHip::lds_sync();
   if (threadIdx.x < 16)
@@ -815,6 +868,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_GENERAL_
 #endif
 GTX_HBM_PASS_KERNEL(gtx_align_big_kernel, big)
 GTX_HBM_PASS_KERNEL(gtx_align_wide_kernel, wide)
+
+// Reads a table once, front to back (experiment, GTX_WARM=1: the global-lookup passes behind the position-hinted pass see
+// ~1 % of a batch, too few probes to warm anything themselves, and every one of theirs is a cold miss).
+__global__ __launch_bounds__(256) void gtx_warm_kernel(uint4_t const * __restrict__ p, uint64_t n16, uint32_t * sink)
+{
+  uint32_t acc = 0;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+  {
+    uint4_t const v = p[i];
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x9E3779B9u) // (keeps the loads alive)
+    atomicAdd(sink, 1u);
+}
 
 // BAM nibble rows -> plane rows (graph_dev.hpp), one thread per (read, group of 32 bases): the one-off repack of callers that
 // hold bam_get_seq bytes on the device (gtx_reads_to_planes), and what gtx_align_batch does with its nibble rows before the
@@ -1442,7 +1509,7 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
   }
   // tasks a wave of the general pass claims per visit to the counter
   char const * gc = std::getenv("GTX_GENERAL_CLAIM");
-  uint32_t const general_claim = gc && std::atoi(gc) > 0 ? static_cast<uint32_t>(std::atoi(gc)) : 4u; // (A/B at cfg2: 8 / 4 / 2 / 1 = 1.03 / 0.88 / 0.88 / 1.06 ms)
+  uint32_t const general_claim = gc && std::atoi(gc) > 0 ? static_cast<uint32_t>(std::atoi(gc)) : 0u; // (0: the kernel sizes its claims to its queue)
   // test switch: 1 = every task goes through all passes (the last one decides), 2 = every task is done by pass 2
   char const * fb = std::getenv("GTX_FORCE_SECOND_PASS");
   uint32_t const force = fb ? static_cast<uint32_t>(std::atoi(fb)) : 0u;
@@ -1532,11 +1599,17 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
       uint32_t const hint_threads = hw && hw[0] == '8' ? 512u : hw && hw[0] == '1' ? 1024u : 64u * GTX_HINT_WAVES;
       hipLaunchKernelGGL(hint_threads == 512u ? gtx_align_hinted8_kernel : hint_threads == 1024u ? gtx_align_hinted16_kernel : gtx_align_hinted_kernel,
                          dim3((n + hint_threads - 1u) / hint_threads), dim3(hint_threads), 0, st, c->dev_graph, c->dev_index, seq, seq_stride,
-                         meta, n, records, rec_words, force_both, queue1, counters + 3, queue2, counters + 2,
+                         meta, n, records, rec_words, force_both, queue1, queue2, reinterpret_cast<unsigned long long *>(counters + 2),
                          static_cast<uint32_t>(force != 0 || (eh && eh[0] == 'd')) | (eh && eh[0] == 'x' ? 2u : 0u),
                          d_task_flags ? d_task_flags + 2ull * first : static_cast<uint8_t *>(nullptr));
       if (!hip_ok(hipGetLastError(), "gtx_align_hinted_kernel launch"))
         return GTX_ERR_HIP;
+      if (char const * ew = std::getenv("GTX_WARM"))
+        if (ew[0] != '0')
+          for (size_t k = 0; k < c->lookup_tables.size(); ++k)
+            if (ew[0] == '1' || (ew[0] - '2') == static_cast<int>(k)) // 1: every table, 2..5: one of them
+              hipLaunchKernelGGL(gtx_warm_kernel, dim3(n_cu * 8u), dim3(256), 0, st, static_cast<uint4_t const *>(c->lookup_tables[k].p),
+                                 c->lookup_tables[k].bytes / 16u, counters + 7);
       mark(part, 1, st);
       // (the queue's length is known on the device only: the grid is what can be resident, or one wavefront per group of four
       //  reads of a small batch; the kernel sizes its claims to the queue)
@@ -1568,7 +1641,7 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     mark(part, 3, sg);
     hipLaunchKernelGGL(gtx_align_kernel, dim3(blocks2), dim3(64), 0, sg, c->dev_graph, c->dev_index, seq, seq_stride, meta, records, rec_words,
                        queue2, counters + 2, counters + 1, second_pass ? s->d_big_tasks : nullptr, s->big_task_cap, s->d_big_state,
-                       static_cast<uint32_t>(force == 1), 2u * first, general_claim);
+                       static_cast<uint32_t>(force == 1), 2u * first, general_claim, counters + 5);
     if (!hip_ok(hipGetLastError(), "gtx_align_kernel launch"))
       return GTX_ERR_HIP;
     mark(part, 4, sg);
@@ -1653,7 +1726,7 @@ static int kernel_times(gtx_ctx * c, float * ms, uint32_t * tasks)
   (void)hipMemcpy(cnt, s->d_counters, sizeof(cnt), hipMemcpyDeviceToHost);
   if (s->d_big_state)
     (void)hipMemcpy(big, s->d_big_state, sizeof(big), hipMemcpyDeviceToHost);
-  uint32_t queued2 = 0, queued1 = 0, handed = 0;
+  uint32_t queued2 = 0, queued1 = 0, handed = 0, direct = 0;
   float last_general_end = 0.0f;
   for (uint32_t p = 0; p < s->timed_parts; ++p)
   {
@@ -1668,6 +1741,7 @@ static int kernel_times(gtx_ctx * c, float * ms, uint32_t * tasks)
     queued2 += cnt[8 * p + 2];
     queued1 += cnt[8 * p + 3];
     handed += cnt[8 * p + 4];
+    direct += cnt[8 * p + 5] - std::min(cnt[8 * p + 5], cnt[8 * p + 4]); // forward tasks of the general pass that did not come through pass 1
     (void)last_general_end;
   }
   {
@@ -1678,7 +1752,7 @@ static int kernel_times(gtx_ctx * c, float * ms, uint32_t * tasks)
   // forward tasks only: reverse-orientation tasks all go to the general pass
   uint32_t const hbm = std::min<uint32_t>(big[0], s->big_task_cap);
   bool const hinted = ms[0] > 0.0f;
-  tasks[0] = hinted ? s->timed_reads - queued1 : 0;
+  tasks[0] = hinted ? s->timed_reads - queued1 - direct : 0; // (direct: forward tasks the position-hinted pass sent straight to the general pass)
   tasks[1] = hinted ? queued1 - handed : s->timed_reads - std::min(queued2, s->timed_reads);
   tasks[2] = queued2 - std::min(hbm, queued2);
   tasks[3] = hbm;

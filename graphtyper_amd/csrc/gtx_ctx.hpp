@@ -23,7 +23,9 @@ struct CallScratch
   bool used = false;         // `done` has been recorded at least once
   void * done = nullptr;     // hipEvent_t recorded behind the last launch that uses this scratch
   // per part of the batch, 8 words: [0] read / queue-1 claim counter of pass 1, [1] task counter of pass 2, [2] tasks queued
-  // for pass 2, [3] forward tasks the position-hinted pass handed to pass 1, [4] forward tasks pass 1 handed to pass 2
+  // for pass 2, [3] forward tasks the position-hinted pass handed to pass 1, [4] forward tasks pass 1 handed to pass 2,
+  // [5] forward tasks pass 2 did (those beyond [4] came straight from the position-hinted pass); [2] and [3] are one 64-bit
+  // word for that pass' single add per workgroup
   uint32_t * d_counters = nullptr;
   uint8_t * d_planes = nullptr;  // plane rows of a batch that came as BAM nibbles (gtx_align_batch; grow-only)
   uint64_t planes_cap = 0;
@@ -88,6 +90,14 @@ struct gtx_ctx
   uint64_t * d_keys = nullptr;
   uint32_t * d_key_off = nullptr;
   gtx_label * d_labels_sorted = nullptr;
+  // the index tables the global-lookup passes probe at random (exact slots, half-key slots and buckets, labels): device
+  // ranges for gtx_warm_kernel (gtx_api.hip)
+  struct Range
+  {
+    void const * p;
+    uint64_t bytes;
+  };
+  std::vector<Range> lookup_tables;
   std::atomic<bool> index_downloaded{false}; // set (release) by download_index under index_mutex; readers check it first (acquire)
   std::mutex index_mutex;
 };

@@ -540,6 +540,10 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, HintGraphTable
   ix.n_hint = gt.n;
   ix.filt_log2 = hints ? fl : 0;
   c.dev_index = ix;
+  c.lookup_tables = {{d_slots, (static_cast<uint64_t>(BUCKET_SLOTS) << log2_cap) * sizeof(IndexSlot)},
+                     {d_hslots, (static_cast<uint64_t>(BUCKET_SLOTS) << hl) * sizeof(IndexSlot)},
+                     {d_hlist, 2ull * n_keys * sizeof(HalfEntry)},
+                     {d_dev_labels, static_cast<uint64_t>(E) * sizeof(DevLabel)}};
   c.n_keys = n_keys;
   c.n_labels = E;
   c.d_keys = pool.keep(d_keys, c.dev_allocs);

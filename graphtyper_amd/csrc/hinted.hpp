@@ -547,8 +547,9 @@ GTX_DEV uint32_t hint_probe_verdict(uint32_t verdict, uint32_t left_word, uint32
 // `row`: the read in plane form as words (global memory, or the copy the kernel staged in LDS).
 // `stage` (may be NULL): room for HINT_STAGE_WORDS words; a record that fits is written there instead (zeros behind its
 // end) and the caller moves it to its slot -- the kernel does that four lanes per record.  Returns 0 = declined, 1 = the
-// record is in `rec`, 2 = it is in `stage`.
+// record is in `rec`, 2 = it is in `stage`, HINT_TO_GENERAL = declined and known to be declined by the express pass too.
 constexpr uint32_t HINT_STAGE_WORDS = 16; // a record of up to three variant sites (6 + 3 * 3 words)
+constexpr uint32_t HINT_TO_GENERAL = 3;
 
 template <class Row>
 GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, uint32_t seq_stride, gtx_read_meta const & m,
@@ -697,8 +698,10 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
     // (a run that opens with a parallel chain behind a hole is returned twice by the reference: not here)
     if (best_len <= second || (best_lo > 0 && ((par >> best_lo) & 1u)))
     {
+      // (every k-mer's lists are known by now, and the express pass has this very rule: it would unpack the read, look
+      //  everything up and decline as well -- the read goes to the general pass directly)
       GTX_HINT_NOTE(10);
-      return false;
+      return HINT_TO_GENERAL;
     }
     lo = best_lo;
     hi = best_lo + best_len - 1;

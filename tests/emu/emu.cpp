@@ -247,7 +247,7 @@ extern "C"
     {
       // pass 0, one read per lane from the position hint (gtx_align_hinted_kernel), then pass 1 over its queue
       // (gtx_align_express4q_kernel), as gtx_align_batch launches them
-      std::vector<uint32_t> queue1;
+      std::vector<uint32_t> queue1, direct;
       e.hinted_done = 0;
       e.pass_of.assign(n_reads, 0);
       e.hint_decline.assign(n_reads, 0);
@@ -262,16 +262,32 @@ extern "C"
           empty_record(read * 2 + 1, len);
         if (outside)
           empty_record(read * 2, len);
-        else if (force != 0 || (eh && eh[0] == 'd') ||
-                 !hinted_one(g, ix, reinterpret_cast<uint32_t const *>(seq + static_cast<uint64_t>(read) * seq_stride), seq_stride, m,
-                             records + static_cast<uint64_t>(read) * 2 * rec_words, rec_words))
-        {
-          queue1.push_back(read);
-          e.pass_of[read] = 1;
-          e.hint_decline[read] = static_cast<uint8_t>(g_last_hnote ? g_last_hnote : 15u);
-        }
         else
-          ++e.hinted_done;
+        {
+          uint32_t const where = (force != 0 || (eh && eh[0] == 'd'))
+                                   ? 0u
+                                   : hinted_one(g, ix, reinterpret_cast<uint32_t const *>(seq + static_cast<uint64_t>(read) * seq_stride), seq_stride, m,
+                                                records + static_cast<uint64_t>(read) * 2 * rec_words, rec_words);
+          if (where == 0)
+          {
+            queue1.push_back(read);
+            e.pass_of[read] = 1;
+            e.hint_decline[read] = static_cast<uint8_t>(g_last_hnote ? g_last_hnote : 15u);
+          }
+          else if (where == HINT_TO_GENERAL) // (declined, and the express pass would decline as well: straight to the general pass)
+          {
+            direct.push_back(read);
+            e.hint_decline[read] = static_cast<uint8_t>(g_last_hnote ? g_last_hnote : 15u);
+          }
+          else
+            ++e.hinted_done;
+        }
+      }
+      for (uint32_t read : direct)
+      {
+        uint64_t const before = e.second_pass_tasks;
+        general(read * 2);
+        e.pass_of[read] = e.second_pass_tasks != before ? 3 : 2;
       }
       for (uint32_t read = 0; read < n_reads; ++read) // (the reverse tasks pass 0 queued for pass 2)
       {
