@@ -4,8 +4,10 @@
 A "step" is one pass of the hot path (gtx_align_batch + gtx_score_batch [+ gtx_scores_reduce] + gtx_calls_batch through
 libgtx's C ABI) over one batch of synthetic reads that is already resident in HBM.  Workload at N=1 = BASELINE.json
 configs[1] ("cfg2"): 1 sample, 10 M synthetic 150 bp reads, one 1 Mb region (chr20:1000001-2000000), SNP-only graph.
-With --gpus N every rank gets its own 10 M reads of the same region (weak scaling; graph + index replicated per GPU) and
-the per-sample score vectors are summed with one RCCL all-reduce group per step (gtx_scores_reduce).
+With --gpus N > 1 the workload is BASELINE.json configs[3] ("cfg4"): the reads of 1000 samples over the same region, sharded
+by read over the ranks (graph + index replicated per GPU), every rank accumulating into the block of all 1000 samples, and the
+ranks' blocks summed with one RCCL all-reduce group per step (gtx_scores_reduce).  --scaling weak (default): --reads per GPU
+(8 GPUs x 10 M = cfg4's 80 M reads); --scaling strong: --total-reads (80 M) split N ways.
 
 Launch: `python bench.py --gpus N` starts N ranks itself (torch.distributed.run on 127.0.0.1); under a launcher that
 already set WORLD_SIZE (the driver's `python -m torch.distributed.run ... bench.py --gpus N`) it is one of the ranks and
@@ -47,7 +49,12 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step (weak scaling; --scaling strong: see --total-reads)")
+    ap.add_argument("--samples", type=int, default=0,
+                    help="samples the reads belong to (0 = the config's: 1 at --gpus 1 = cfg2, 1000 at --gpus N > 1 = cfg4)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = --reads per GPU (8 GPUs x 10 M = the 80 M reads of cfg4), strong = --total-reads split N ways")
+    ap.add_argument("--total-reads", type=int, default=80_000_000, help="--scaling strong: reads of the whole job (cfg4: 1000 samples x 80 k)")
     ap.add_argument("--snp-every", type=int, default=1000)
     ap.add_argument("--err", type=float, default=0.005, help="experiments only; the reported workload uses 0.005")
     ap.add_argument("--nrate", type=float, default=0.001, help="experiments only; the reported workload uses 0.001")
@@ -116,32 +123,72 @@ def max_over_ranks(dist, seconds, device):
     return float(t.item())
 
 
+def job_shape(args, world):
+    """(samples, reads of this job per rank list) of the workload: cfg2 at one GPU, cfg4 -- 1000 samples, reads sharded over the
+    ranks -- at several"""
+    from graphtyper_amd.dist import shard_bounds
+    samples = args.samples or (1 if world == 1 else 1000)
+    if world > 1 and args.scaling == "strong":
+        per_rank = [hi - lo for lo, hi in (shard_bounds(args.total_reads, world, r) for r in range(world))]
+    else:
+        per_rank = [args.reads] * world
+    return samples, per_rank
+
+
 def dry_run(args):
-    """the N>1 control flow of main() without device work: same launch, same barrier + max-over-ranks timing, a packed
-    integer buffer summed over the ranks (what gtx_scores_reduce does with RCCL), one line from rank 0"""
+    """the N>1 control flow of main() without device work: same launch, same job shape (samples, reads per rank), same barrier
+    + max-over-ranks timing, and the exchange step of cfg4 -- the packed accumulator block of `samples` samples over the 1 000
+    biallelic sites of the cfg2 / cfg4 graph summed over the ranks as one int64 and one int32 tensor (what gtx_scores_reduce
+    does with RCCL); one line from rank 0"""
     import torch
     rank, local_rank, world, dist = init_ranks(args)
-    packed = torch.arange(1000, dtype=torch.int64) * (rank + 1)
+    samples, per_rank = job_shape(args, world)
+    n_hap, tri, alle = 1000, 3000, 2000  # (1 SNP / kb over 1 Mb: gtx_score_layout of that graph)
+    n64 = n_hap + 2 * alle
+    n32 = samples * (tri + alle + 4 * n_hap) + n_hap + 6 * alle
+    t64 = (torch.arange(n64, dtype=torch.int64) % 1009) * (rank + 1)
+    t32 = ((torch.arange(n32, dtype=torch.int64) % 65521) * (rank + 1)).to(torch.int32)
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
+    reduce_s = 0.0
     for _ in range(args.steps):
-        acc = packed.clone()
+        a64, a32 = t64.clone(), t32.clone()
+        r0 = time.perf_counter()
         if dist is not None:
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+            dist.all_reduce(a64, op=dist.ReduceOp.SUM)
+            dist.all_reduce(a32, op=dist.ReduceOp.SUM)
+        reduce_s += time.perf_counter() - r0
     if dist is not None:
         dist.barrier()
-    dt = max_over_ranks(dist, time.perf_counter() - t0, "cpu")
-    ok = bool((acc == torch.arange(1000, dtype=torch.int64) * (world * (world + 1) // 2)).all())
+    local = time.perf_counter() - t0
+    dt = max_over_ranks(dist, local, "cpu")
+    factor = world * (world + 1) // 2
+    ok = bool((a64 == (torch.arange(n64, dtype=torch.int64) % 1009) * factor).all()) and \
+        bool((a32.to(torch.int64) == (torch.arange(n32, dtype=torch.int64) % 65521) * factor).all())
+    per = gather_floats(dist, 1000.0 * local / max(args.steps, 1), "cpu")
     n_gpus = dist.get_world_size() if dist is not None else 1
     if rank == 0:
         print(json.dumps({"metric": METRIC, "value": None, "unit": "reads/s", "n_gpus": n_gpus, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": 1000.0 * dt / max(args.steps, 1), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dry_run": True, "reduce_ok": ok,
-                          "config": {"workload": "none (launch logic only)", "backend": args.backend}}))
+                          "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dry_run": True, "reduce_ok": ok,
+                          "config": {"workload": "none (launch logic only)", "backend": args.backend, "samples": samples, "reads_per_rank": per_rank,
+                                     "reduced_bytes_per_step": 8 * n64 + 4 * n32, "reduce_ms": 1000.0 * reduce_s / max(args.steps, 1),
+                                     "per_rank_ms_per_step": per}}))
     if dist is not None:
         dist.destroy_process_group()
     return 0 if ok else 1
+
+
+def gather_floats(dist, x, device):
+    """[x of rank 0, x of rank 1, ...] on every rank"""
+    import torch
+    if dist is None:
+        return [float(x)]
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -238,6 +285,7 @@ class Workload:
         self.d_calls = torch.zeros(max(n_samples * ctx.n_hap, 1) * gtx.SAMPLE_CALL.itemsize, dtype=torch.uint8, device=device)
         self.stream = torch.cuda.Stream(device=device)
         self.sp = C.c_void_p(self.stream.cuda_stream)
+        self.reduce_events = []  # HIP events around the exchange step of every step since the last run()
         self.comm = None       # ncclComm_t made through gtx_comm_init_rank
         self.dist = None       # fallback: torch.distributed on views of the packed block
         self.reduce_kind = None
@@ -321,11 +369,17 @@ class Workload:
             gtx.check(self.align_fn(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, self.d_rec.data_ptr(), REC_WORDS, fl, sp))
             e1.record(self.stream)
             gtx.check(L.gtx_score_batch_flags(ctx.h, d_items.data_ptr(), self.n, self.d_rec.data_ptr(), REC_WORDS, fl, C.byref(self.buf), sp))
-            if self.comm is not None:
-                gtx.check(L.gtx_scores_reduce(ctx.h, C.byref(self.buf), self.comm, sp))
-            elif self.dist is not None:
-                self.dist.all_reduce(self.t64, op=self.dist.ReduceOp.SUM)
-                self.dist.all_reduce(self.t32, op=self.dist.ReduceOp.SUM)
+            if self.comm is not None or self.dist is not None:
+                r0 = torch.cuda.Event(enable_timing=True)
+                r1 = torch.cuda.Event(enable_timing=True)
+                r0.record(self.stream)
+                if self.comm is not None:
+                    gtx.check(L.gtx_scores_reduce(ctx.h, C.byref(self.buf), self.comm, sp))
+                else:
+                    self.dist.all_reduce(self.t64, op=self.dist.ReduceOp.SUM)
+                    self.dist.all_reduce(self.t32, op=self.dist.ReduceOp.SUM)
+                r1.record(self.stream)
+                self.reduce_events.append((r0, r1))
             # genotype calls (PL, GT, GQ, depths) from the summed accumulators
             gtx.check(L.gtx_calls_batch(ctx.h, C.byref(self.buf), self.d_phred.data_ptr(), self.d_calls.data_ptr(), sp))
         return e0, e1
@@ -340,13 +394,16 @@ class Workload:
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+        self.reduce_events = []
         t0 = time.perf_counter()
         evs = [self.step() for _ in range(steps)]
         torch.cuda.synchronize()
+        self.local_s = time.perf_counter() - t0  # this rank's own time for its K steps (before waiting for the others)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        self.reduce_ms = float(np.mean([a.elapsed_time(b) for a, b in self.reduce_events])) if self.reduce_events else 0.0
         return max_over_ranks(dist, dt, self.device), [a.elapsed_time(b) for a, b in evs]
 
     def sample_names(self):
@@ -383,7 +440,14 @@ class Workload:
         t0 = time.perf_counter()
         text, calls = self.vcf_text()
         self.vcf = {"records": text.count(b"\n") - 1, "bytes": len(text), "pass": text.count(b"\tPASS\t"), "host_ms": round((time.perf_counter() - t0) * 1e3, 2)}
-        return {"reads_aligned": int(((rec_head[0::2] & 0xFFFF) > 0).sum().item()), "vcf_text": self.vcf,
+        # cells at the sequential saturation guard of explain_to_score (haplotype.cpp:560): a single process would replay them
+        # (gtx_scores_replay); with the reads sharded over ranks the call order is spread over the ranks, so the bench only
+        # makes sure there is none (cfg4: 12x per sample; the guard stands at ~8 000 reads over one site in one sample)
+        hap = self.torch.as_tensor(DevView(self.buf.d_hap_u32, self.n_samples * ctx.n_hap * 4, "<i4"), device=self.device)
+        at_guard = int((hap.view(-1, 4)[:, 0] >= 0xFFFF - 8).sum().item())
+        if at_guard and self.n_samples > 1:
+            sys.stderr.write("[bench] %d (haplotype, sample) cells reached the saturation guard: sums are not the reference's there\n" % at_guard)
+        return {"reads_aligned": int(((rec_head[0::2] & 0xFFFF) > 0).sum().item()), "vcf_text": self.vcf, "cells_at_saturation_guard": at_guard,
                 "reads_overflowed": int((((rec_head >> 16) & gtx.ST_ERROR_MASK) != 0).sum().item()),
                 "nonref_genotype_calls": int((calls["gt_second"] > 0).sum()), "score_items_refused": ctx.error_count(),
                 "connections_logged": int(cc[0]), "connections_dropped": int(cc[1])}
@@ -579,11 +643,19 @@ def main(argv=None):
     n_keys, n_labels = ctx.index_stats()
 
     # ---- reads, resident in HBM before the timed region ----
-    n = args.reads
+    # (one GPU: cfg2, 1 sample.  Several: cfg4 -- the reads of 1000 samples, sharded by read over the ranks, every rank holds
+    #  the accumulators of all samples and the ranks' blocks are summed once per step)
+    n_samples, per_rank = job_shape(args, world)
+    n = per_rank[rank]
+
+    def sample_ids(k):
+        return None if n_samples == 1 else np.random.default_rng(4242 + 7919 * k + rank).integers(0, n_samples, size=n).astype(np.uint32)
+
     d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=CFG2_READ_SEED + rank, device=device, REGION_LEN=args.region_len,
                                         err_rate=args.err, n_rate=args.nrate)
-    w = Workload(torch, gtx, ctx, device, d_seq, d_pos, 1, hint=not args.no_hint)
+    w = Workload(torch, gtx, ctx, device, d_seq, d_pos, n_samples, samples=sample_ids(0), hint=not args.no_hint)
     for k in range(1, max(args.read_sets, 1)):  # the steps alternate between resident read sets (different reads, same size)
+        w.samples = sample_ids(k)
         w.add_reads(*make_reads_on_device(torch, ref, records, n, seed=CFG2_READ_SEED + rank + 7919 * k, device=device, REGION_LEN=args.region_len,
                                           err_rate=args.err, n_rate=args.nrate))
     if dist is not None:
@@ -593,6 +665,8 @@ def main(argv=None):
     kern = ctx.kernel_times() if hasattr(ctx, "kernel_times") else None
     facts = w.result_facts()
     n_gpus = dist.get_world_size() if dist is not None else 1
+    per_rank_ms = gather_floats(dist, 1000.0 * w.local_s / args.steps, device)
+    reduce_ms = gather_floats(dist, w.reduce_ms, device)
 
     prof = ctx.profile()
     if rank == 0 and prof[15] > 0:  # GTX_LIB=libgtx_prof.so: shader cycles per phase of the general algorithm, per task that ran it
@@ -616,7 +690,7 @@ def main(argv=None):
         return 0
 
     ms_per_step = 1000.0 * dt / args.steps
-    value = n_gpus * n * args.steps / dt
+    value = sum(per_rank) * args.steps / dt
     align_avg_ms = float(np.mean(align_ms))
     # dominant kernel of the step and the units it completes (what it hands on is not counted for it)
     roof = dominant_kernel(pass_ms, n_pass2, n, align_avg_ms, kern)
@@ -637,18 +711,26 @@ def main(argv=None):
     #  to this run's read count -- not a measurement of this run)
     roof["traffic_source"] = ("profiles/" + os.path.basename(tf) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile.sh, FETCH doubled for gfx950; "
                               "scaled by reads)") if traffic is not None else None
-    cfg = {"workload": "cfg2: 1 sample, %d synthetic %d bp reads per GPU, chr20:1000001-2000000 (1 Mb), SNP-only graph "
-                       "(1 SNP / %d bp), unpaired, 0.5%% substitutions, 0.1%% N; result = SampleCall (GT, PL, GQ, depths) per "
-                       "site; gtx_vcf_records writes the region's VCF records from them on the host after the timed steps "
-                       "(config.vcf_text, config.calls_checksum: the digest the full-size GPU test reproduces from the oracle over all reads)" % (n, READ_LEN, args.snp_every),
+    if n_gpus == 1 and n_samples == 1:
+        what = "cfg2: 1 sample, %d synthetic %d bp reads per GPU" % (n, READ_LEN)
+    else:
+        what = ("cfg4: %d samples, %d synthetic %d bp reads in all, sharded by read over %d GPU(s) (%s; %s scaling), every rank holds the "
+                "accumulators of all samples, one packed sum over the ranks per step" %
+                (n_samples, sum(per_rank), READ_LEN, n_gpus, "%d per GPU" % n if len(set(per_rank)) == 1 else "%s per GPU" % per_rank, args.scaling))
+    cfg = {"workload": what + ", chr20:1000001-2000000 (1 Mb), SNP-only graph (1 SNP / %d bp), unpaired, 0.5%% substitutions, 0.1%% N; "
+                       "result = SampleCall (GT, PL, GQ, depths) per site and sample; gtx_vcf_records writes the region's VCF records from them on "
+                       "the host after the timed steps (config.vcf_text, config.calls_checksum: the digest the full-size GPU test reproduces "
+                       "from the oracle over all reads)" % args.snp_every,
+           "samples": n_samples, "reads_per_rank": per_rank,
            "reads_per_gpu": n, "index_keys": n_keys, "index_labels": n_labels, "haplotypes": ctx.n_hap,
            "ctx_create_s": round(t_ctx_warm, 3), "ctx_create_first_s": round(t_ctx, 3),
            "position_hint": not args.no_hint, "task_flags_side_array": USE_TASK_FLAGS,
            "read_layout": "bit planes (gtx_align_batch_planes; repacked once from BAM nibbles by gtx_reads_to_planes before the timed region)" if PLANE_INPUT else "BAM nibbles (gtx_align_batch_flags repacks them inside every call)", "resident_read_sets": len(w.sets),
            "parallelism": "reads sharded over %d GPU(s), graph+index replicated" % n_gpus,
-           "reduce": w.reduce_kind, "reduced_bytes_per_step": w.reduced_bytes if n_gpus > 1 else 0}
+           "reduce": w.reduce_kind, "reduced_bytes_per_step": w.reduced_bytes if n_gpus > 1 else 0,
+           "reduce_ms": max(reduce_ms) if n_gpus > 1 else 0.0, "reduce_ms_per_rank": reduce_ms, "per_rank_ms_per_step": per_rank_ms}
     cfg.update(facts)
-    if n_gpus == 1:
+    if n_gpus == 1 and n_samples == 1:
         try:
             cfg["calls_checksum"] = w.calls_checksum(0)
             cfg["calls_checksum"]["reads_seed"] = CFG2_READ_SEED
@@ -657,7 +739,7 @@ def main(argv=None):
         except Exception as e:  # the extra field must never cost the main line
             cfg["calls_checksum"] = {"error": repr(e)}
     out = {"metric": METRIC, "value": value, "unit": "reads/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling if n_gpus > 1 else "weak", "vs_baseline": None,
            "dtype": "u64/u32 integer (2-bit k-mer keys, byte compares, u32 atomics)", "data": "synthetic", "config": cfg,
            "roofline": roof}
     if n_gpus == 1 and not args.no_cpu_baseline:

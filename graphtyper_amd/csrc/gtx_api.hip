@@ -652,8 +652,10 @@ __device__ __forceinline__ void express4_queue_pass(GraphView const & g, IndexVi
   // (group w, w + G, w + 2 G, ... of a grid of G wavefronts: a single device counter takes ~100 M returning atomics a
   // second, and thousands of wavefronts asking at the kernel's start was a tenth of a millisecond); the rest is claimed one
   // group at a time, which is what evens out the end of the pass.
+  // (short queues only: on a long one -- dense graphs: a hundred groups per wavefront, of very different cost -- a fixed
+  //  share costs more in imbalance than the atomics do; the cfg3-like workload lost a tenth)
   uint32_t const n_groups = (n + 3u) / 4u, G = gridDim.x;
-  uint32_t const own = (n_groups / G) * 3u / 4u;
+  uint32_t const own = n_groups / G <= 8u ? (n_groups / G) * 3u / 4u : 0u;
 #ifdef GTX_PROF
   if (threadIdx.x < 16)
     ws.prof_acc[threadIdx.x] = 0;
@@ -745,7 +747,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_GENERAL_
   uint32_t const CLAIM = claim ? claim : per_wave >= 32u ? 4u : per_wave >= 12u ? 2u : 1u;
   // ... and three quarters of a wavefront's even share are its own without asking (task w, w + G, w + 2 G, ... of a grid
   // of G wavefronts): thousands of wavefronts asking one counter at the kernel's start cost as much as the tasks
-  uint32_t const G = gridDim.x, own = claim ? 0u : per_wave * 3u / 4u;
+  // (short queues only: a long one -- dense graphs -- holds tasks of very different cost, and a fixed share costs more in
+  //  imbalance than the atomics do)
+  uint32_t const G = gridDim.x, own = (claim || per_wave > 8u) ? 0u : per_wave * 3u / 4u;
   uint32_t n_forward = 0; // forward tasks this wavefront did (statistics: one add per wavefront at the end)
   for (uint32_t i = 0, t = 0, t_end = 0;; ++i, ++t)
   {

@@ -39,3 +39,22 @@ def test_world_size_has_to_match_gpus():
     p, lines = _run(["--gpus", "2", "--dry-run", "--backend", "gloo"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
     assert p.returncode != 0 and not lines
     assert "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+def test_two_ranks_run_the_cfg4_shape():
+    """N > 1 is BASELINE configs[3]: 1000 samples, reads sharded by read over the ranks, one packed sum of the 1000-sample
+    block per step.  The dry run sums a block of exactly that size over two gloo ranks and reports the job's shape, the
+    exchange's size and time and every rank's own step time; --scaling strong splits --total-reads over the ranks."""
+    p, lines = _run(["--gpus", "2", "--dry-run", "--backend", "gloo", "--steps", "2", "--warmup", "0"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    c = json.loads(lines[0])["config"]
+    assert c["samples"] == 1000 and c["reads_per_rank"] == [10_000_000, 10_000_000]
+    # u64 statistics of 1000 haplotypes + 2000 alleles, u32 counters of 1000 samples x (3000 + 2000 + 4000) + 1000 + 12000
+    assert c["reduced_bytes_per_step"] == 8 * 5000 + 4 * (1000 * 9000 + 13000)
+    assert c["reduce_ms"] > 0 and len(c["per_rank_ms_per_step"]) == 2 and all(x > 0 for x in c["per_rank_ms_per_step"])
+    p, lines = _run(["--gpus", "2", "--dry-run", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--scaling", "strong", "--total-reads", "80000001"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = json.loads(lines[0])
+    assert j["scaling"] == "strong" and j["config"]["reads_per_rank"] == [40_000_001, 40_000_000] and j["reduce_ok"] is True
+    p, lines = _run(["--dry-run", "--steps", "1"])  # one GPU stays cfg2
+    assert json.loads(lines[-1])["config"]["samples"] == 1 and json.loads(lines[-1])["scaling"] == "weak"
