@@ -194,14 +194,14 @@ def gather_floats(dist, x, device):
 # ------------------------------------------------------------------------------------------------------------------
 # synthetic input
 # ------------------------------------------------------------------------------------------------------------------
-def make_reads_on_device(torch, ref_bases, records, n, seed, device, REGION_LEN=REGION_LEN, err_rate=0.005, n_rate=0.001):
+def make_reads_on_device(torch, ref_bases, records, n, seed, device, REGION_LEN=REGION_LEN, err_rate=0.005, n_rate=0.001, region_begin=REGION_BEGIN):
     """diploid sample: haplotype 0 = reference, haplotype 1 = reference with a random half of the SNPs; 0.5 % substitution
     errors, 0.1 % N; position sorted; returns packed nibbles [n, 80] (uint8) and read start positions"""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     ref = torch.from_numpy(ref_bases).to(device)
     hap1 = ref.clone()
-    pos = torch.tensor([p - REGION_BEGIN for p, _, _, _ in records], device=device, dtype=torch.long)
+    pos = torch.tensor([p - region_begin for p, _, _, _ in records], device=device, dtype=torch.long)
     alt = torch.tensor(["ACGT".index(a[0]) for _, _, a, _ in records], device=device, dtype=torch.uint8)
     take = torch.rand(len(records), generator=g, device=device) < 0.5
     hap1[pos[take]] = alt[take]
@@ -226,7 +226,7 @@ def make_reads_on_device(torch, ref_bases, records, n, seed, device, REGION_LEN=
         codes = torch.where(nmask, torch.full_like(codes, 15), codes)
         out_seq[a:b, :75] = (codes[:, 0::2] << 4) | codes[:, 1::2]
         out_seq[a:b, 75:] = 0
-        out_pos[a:b] = st + REGION_BEGIN
+        out_pos[a:b] = st + region_begin
     return out_seq, out_pos
 
 
@@ -559,6 +559,237 @@ def extra_pcie_fed(w, torch, gtx, steps=3, chunks=4):
             "note": "inputs in pinned host memory, copied per step on a second stream under the previous part's kernels"}
 
 
+def extra_pipeline(args, torch, gtx, synth, device, ctx, ref, records, n=4_000_000, chunk=65536):
+    """BAM files -> VCF text, wall clock (never `value`): the reads of one sample as T position-sliced BAM files (what a
+    region split of one indexed BAM gives; written before the clock starts), T host threads -- the reference's worker threads,
+    src/typer/caller.cpp:399-436 -- each running gtx_reads_next (BGZF inflate on the library's team, record parse) ->
+    gtx_stream_push (flag filter, duplicate reuse, plane rows) -> pinned staging -> H2D -> gtx_align_batch_planes ->
+    gtx_score_batch_flags on its own stream against ONE context and ONE accumulator block; then gtx_calls_batch and
+    gtx_vcf_records.  Reports reads/s over the whole leg and where the host threads' time went."""
+    import tempfile
+    import threading
+    L = gtx.lib()
+    threads = max(1, min(16, (os.cpu_count() or 2) // 2))
+    d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=777, device=device, REGION_LEN=args.region_len, err_rate=args.err, n_rate=args.nrate)
+    codes = unpack_nibbles(d_seq.cpu().numpy(), READ_LEN)
+    pos = d_pos.cpu().numpy()
+    tmp = tempfile.mkdtemp(prefix="gtx_pipeline_")
+    cuts = [n * k // threads for k in range(threads + 1)]
+    paths = []
+    t0 = time.perf_counter()
+    for k in range(threads):
+        paths.append(os.path.join(tmp, "slice%02d.bam" % k))
+        synth.write_fixed_bam(paths[-1], "chr20", 64444167, "SAMP0000", codes[cuts[k]:cuts[k + 1]], pos[cuts[k]:cuts[k + 1]])
+    t_write = time.perf_counter() - t0
+    bam_bytes = sum(os.path.getsize(q) for q in paths)
+    # resident run over the same reads: what the pipeline has to reproduce
+    w = Workload(torch, gtx, ctx, device, d_seq, d_pos, 1, hint=True, conn_cap=1 << 20)
+    w.step()
+    want_text, _ = w.vcf_text()
+    w.close()
+    del w, d_seq
+    buf = gtx.ScoreBuffers()
+    gtx.check(L.gtx_scores_alloc(ctx.h, 1, 1 << 20, C.byref(buf), None))
+    stage_s = [dict(decode=0.0, push=0.0, enqueue=0.0, records=0, tasks=0) for _ in range(threads)]
+    errors = []
+
+    def worker(k):
+        try:
+            st_ = stage_s[k]
+            stream = torch.cuda.Stream(device=device)
+            sp = C.c_void_p(stream.cuda_stream)
+            push = gtx.Stream(ctx.params, 1)
+            push.set_planes(80)
+            reads = gtx.Reads([paths[k]])
+            pin = [torch.empty((chunk, 80), dtype=torch.uint8).pin_memory(), torch.empty((chunk, gtx.READ_META.itemsize), dtype=torch.uint8).pin_memory(),
+                   torch.empty((chunk, gtx.SCORE_ITEM.itemsize), dtype=torch.uint8).pin_memory()]
+            dev = [torch.empty_like(t, device=device) for t in pin]
+            mine = cuts[k + 1] - cuts[k]  # (records and their side array stay resident for the whole file: a duplicate read's item
+            d_rec = torch.zeros(max(mine, 1) * 2 * REC_WORDS, dtype=torch.int32, device=device)  # names its predecessor's task, batches ago)
+            d_fl = torch.zeros(max(mine, 1) * 2, dtype=torch.uint8, device=device)
+            done = torch.cuda.Event()
+            first = True
+            while True:
+                t = time.perf_counter()
+                recs, seq = reads.next(chunk)
+                st_["decode"] += time.perf_counter() - t
+                if len(recs) == 0:
+                    break
+                t = time.perf_counter()
+                a_seq, a_meta, items = push.push(recs, seq)
+                st_["push"] += time.perf_counter() - t
+                t = time.perf_counter()
+                na, ni, at = len(a_meta), len(items), st_["tasks"]  # (the stream numbers its tasks over the whole file: this batch's start at `at`)
+                if not first:
+                    done.synchronize()  # the staging buffers are free again
+                first = False
+                pin[0][:na].numpy()[...] = a_seq
+                pin[1][:na].numpy()[...] = a_meta.view(np.uint8).reshape(na, -1)
+                pin[2][:ni].numpy()[...] = items.view(np.uint8).reshape(ni, -1)
+                with torch.cuda.stream(stream):
+                    for d, h_, m in zip(dev, pin, (na, na, ni)):
+                        d[:m].copy_(h_[:m], non_blocking=True)
+                    gtx.check(L.gtx_align_batch_planes(ctx.h, dev[0].data_ptr(), 80, dev[1].data_ptr(), na, d_rec.data_ptr() + 4 * 2 * REC_WORDS * at, REC_WORDS,
+                                                       d_fl.data_ptr() + 2 * at, sp))
+                    gtx.check(L.gtx_score_batch_flags(ctx.h, dev[2].data_ptr(), ni, d_rec.data_ptr(), REC_WORDS, d_fl.data_ptr(), C.byref(buf), sp))
+                    done.record(stream)
+                st_["enqueue"] += time.perf_counter() - t
+                st_["records"] += len(recs)
+                st_["tasks"] += na
+            reads.close()
+            stream.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    team = [threading.Thread(target=worker, args=(k,)) for k in range(threads)]
+    for t in team:
+        t.start()
+    for t in team:
+        t.join()
+    torch.cuda.synchronize()
+    t_reads = time.perf_counter() - t0
+    if errors:
+        L.gtx_scores_free(ctx.h, C.byref(buf))
+        return {"error": errors[0]}
+    d_phred = torch.zeros(max(ctx.total_tri, 1), dtype=torch.uint8, device=device)
+    d_calls = torch.zeros(max(ctx.n_hap, 1) * gtx.SAMPLE_CALL.itemsize, dtype=torch.uint8, device=device)
+    gtx.check(L.gtx_calls_batch(ctx.h, C.byref(buf), d_phred.data_ptr(), d_calls.data_ptr(), None))
+    torch.cuda.synchronize()
+    nh, ta = ctx.n_hap, ctx.total_allele
+    calls = d_calls.cpu().numpy().view(gtx.SAMPLE_CALL)[:nh]
+    text = ctx.vcf_records("chr20", ["SAMP0000"], gtx.download(buf.d_gt_cov, np.uint32, ta), gtx.download(buf.d_stat_u64, np.uint64, nh + 2 * ta),
+                           gtx.download(buf.d_stat_u32, np.uint32, nh + 6 * ta), d_phred.cpu().numpy()[:ctx.total_tri], calls)
+    wall = time.perf_counter() - t0
+    L.gtx_scores_free(ctx.h, C.byref(buf))
+    for q in paths:
+        os.remove(q)
+    os.rmdir(tmp)
+    tot = {k: sum(s_[k] for s_ in stage_s) for k in ("decode", "push", "enqueue")}
+    return {"what": "BAM files -> gtx_reads_next -> gtx_stream_push (plane rows) -> pinned staging -> H2D -> align + score (one stream per host thread, "
+                    "one context, one accumulator block) -> gtx_calls_batch -> gtx_vcf_records; wall clock from opening the files to the VCF text",
+            "reads": int(sum(s_["records"] for s_ in stage_s)), "reads_per_s": n / wall, "wall_s": wall, "host_threads": threads,
+            "bgzf_inflate_team": os.environ.get("GTX_BGZF_THREADS", "library default (up to 16)"), "bam_files": threads, "bam_bytes": bam_bytes,
+            "read_loop_s": t_reads, "calls_and_vcf_text_s": wall - t_reads,
+            "host_thread_seconds": {k: round(v, 3) for k, v in tot.items()},
+            "slowest_thread_s": {k: round(max(s_[k] for s_ in stage_s), 3) for k in ("decode", "push", "enqueue")},
+            "records_per_s_per_thread": {"decode": n / max(tot["decode"], 1e-9), "push": n / max(tot["push"], 1e-9)},
+            "stage_bound_reads_per_s": n / max(max(s_["decode"] + s_["push"] + s_["enqueue"] for s_ in stage_s), 1e-9),
+            "vcf_equals_resident_run": bool(text == want_text), "vcf_bytes": len(text), "bam_write_s_before_the_clock": round(t_write, 2)}
+
+
+def extra_regions(args, torch, gtx, synth, device, ref, n_regions=20, region_len=50000, n_samples=30, depth=30):
+    """What `graphtyper genotype` does per region (the reference genotypes 50 kb regions, src/main.cpp:684), on the clock from the
+    variant records to the VCF text: 20 consecutive 50 kb regions, 30 samples at 30x (300 k reads per region, resident in HBM as
+    plane rows before the clock starts).  Per region: gtx_graph_build -> gtx_ctx_create (index build) -> gtx_align_batch_planes
+    -> gtx_score_batch_flags -> gtx_calls_batch -> download -> gtx_vcf_records.  Once one region after the other, once with
+    the next region's graph + context built on a second host thread while the current region's reads run."""
+    import threading
+    L = gtx.lib()
+    n = depth * n_samples * region_len // READ_LEN
+    regions = []
+    for r in range(n_regions):
+        rb = REGION_BEGIN + r * region_len
+        sub = np.ascontiguousarray(ref[r * region_len:(r + 1) * region_len])
+        recs = synth.make_snp_records(sub, args.snp_every, seed=100 + r, region_begin=rb)
+        d_seq, d_pos = make_reads_on_device(torch, sub, recs, n, seed=900 + r, device=device, REGION_LEN=region_len, region_begin=rb)
+        d_planes = torch.empty((n, 80), dtype=torch.uint8, device=device)
+        meta = np.zeros(n, gtx.READ_META)
+        meta["l_qseq"] = READ_LEN
+        meta["flag"] = gtx.FLAG_FORWARD_ONLY
+        meta["pos"] = d_pos.cpu().numpy().astype(np.int32)
+        items = np.zeros(n, gtx.SCORE_ITEM)
+        items["first"]["align_index"] = np.arange(n, dtype=np.uint32)
+        items["first"]["mapq"] = 60
+        items["first"]["flag"] = gtx.FLAG_FORWARD_ONLY
+        items["first"]["pos"] = meta["pos"]
+        items["second"]["align_index"] = gtx.INVALID_ID
+        items["sample"] = np.random.default_rng(r).integers(0, n_samples, size=n).astype(np.uint32)
+        regions.append(dict(rb=rb, ref_str=synth.bases_to_str(sub), recs=recs, d_seq=d_seq, d_planes=d_planes,
+                            d_meta=torch.from_numpy(meta.view(np.uint8).reshape(n, -1).copy()).to(device),
+                            d_items=torch.from_numpy(items.view(np.uint8).reshape(n, -1).copy()).to(device)))
+    d_rec = torch.zeros(n * 2 * REC_WORDS, dtype=torch.int32, device=device)
+    d_fl = torch.zeros(n * 2, dtype=torch.uint8, device=device)
+    names = ["SAMP%04d" % i for i in range(n_samples)]
+    first = True
+
+    def build(reg):
+        t0 = time.perf_counter()
+        g = gtx.graph_from_records(reg["ref_str"], reg["recs"], region_begin=reg["rb"])
+        t1 = time.perf_counter()
+        c = gtx.Context(g, device=device.index or 0)
+        return c, t1 - t0, time.perf_counter() - t1
+
+    def genotype(reg, c, t):
+        nonlocal first
+        if first:  # (the repack is part of staging, not of the region's clock: done for every region before the first timed run)
+            for q in regions:
+                gtx.check(L.gtx_reads_to_planes(c.h, q["d_seq"].data_ptr(), 80, n, q["d_planes"].data_ptr(), 80, None))
+            torch.cuda.synchronize()
+            first = False
+        t0 = time.perf_counter()
+        buf = gtx.ScoreBuffers()
+        gtx.check(L.gtx_scores_alloc(c.h, n_samples, 1 << 16, C.byref(buf), None))
+        d_phred = torch.empty(max(n_samples * c.total_tri, 1), dtype=torch.uint8, device=device)
+        d_calls = torch.empty(max(n_samples * c.n_hap, 1) * gtx.SAMPLE_CALL.itemsize, dtype=torch.uint8, device=device)
+        gtx.check(L.gtx_align_batch_planes(c.h, reg["d_planes"].data_ptr(), 80, reg["d_meta"].data_ptr(), n, d_rec.data_ptr(), REC_WORDS, d_fl.data_ptr(), None))
+        gtx.check(L.gtx_score_batch_flags(c.h, reg["d_items"].data_ptr(), n, d_rec.data_ptr(), REC_WORDS, d_fl.data_ptr(), C.byref(buf), None))
+        gtx.check(L.gtx_calls_batch(c.h, C.byref(buf), d_phred.data_ptr(), d_calls.data_ptr(), None))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nh, ta = c.n_hap, c.total_allele
+        text = c.vcf_records("chr20", names, gtx.download(buf.d_gt_cov, np.uint32, n_samples * ta), gtx.download(buf.d_stat_u64, np.uint64, nh + 2 * ta),
+                             gtx.download(buf.d_stat_u32, np.uint32, nh + 6 * ta), d_phred.cpu().numpy()[:n_samples * c.total_tri],
+                             d_calls.cpu().numpy().view(gtx.SAMPLE_CALL)[:n_samples * nh])
+        L.gtx_scores_free(c.h, C.byref(buf))
+        c.close()
+        t["gpu_step"] += t1 - t0
+        t["vcf_text"] += time.perf_counter() - t1
+        return text
+
+    def run(overlap):
+        t = dict(graph_build=0.0, ctx_create=0.0, gpu_step=0.0, vcf_text=0.0)
+        texts = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if not overlap:
+            for reg in regions:
+                c, tg, tc = build(reg)
+                t["graph_build"] += tg
+                t["ctx_create"] += tc
+                texts.append(genotype(reg, c, t))
+        else:
+            nxt = [None]
+
+            def prefetch(reg):
+                nxt[0] = build(reg)
+            th = threading.Thread(target=prefetch, args=(regions[0],))
+            th.start()
+            for k, reg in enumerate(regions):
+                th.join()
+                c, tg, tc = nxt[0]
+                t["graph_build"] += tg
+                t["ctx_create"] += tc
+                if k + 1 < len(regions):
+                    th = threading.Thread(target=prefetch, args=(regions[k + 1],))
+                    th.start()
+                texts.append(genotype(reg, c, t))
+        wall = time.perf_counter() - t0
+        return wall, t, texts
+
+    run(False)  # (warm-up: module load, first scratch, allocator)
+    wall_seq, t_seq, texts = run(False)
+    wall_ovl, t_ovl, texts2 = run(True)
+    return {"what": "%d consecutive %d bp regions, %d samples at %dx (%d reads per region, resident as plane rows): variant records -> gtx_graph_build -> "
+                    "gtx_ctx_create -> align + score + calls -> VCF text, wall clock" % (n_regions, region_len, n_samples, depth, n),
+            "regions_per_s": n_regions / wall_ovl, "reads_per_s": n_regions * n / wall_ovl, "wall_s": wall_ovl,
+            "one_after_the_other": {"regions_per_s": n_regions / wall_seq, "wall_s": wall_seq, "stage_s": {k: round(v, 4) for k, v in t_seq.items()}},
+            "next_region_built_on_a_second_host_thread": {"wall_s": wall_ovl, "stage_s": {k: round(v, 4) for k, v in t_ovl.items()}},
+            "vcf_bytes": sum(len(x) for x in texts), "same_text_both_ways": bool(texts == texts2),
+            "ms_per_region": {k: round(1e3 * v / n_regions, 3) for k, v in t_seq.items()}}
+
+
 def extra_cfg3(args, torch, gtx, synth, device, ref):
     """cfg3-like workload in the same run: 30 samples, clusters of three biallelic sites (SNP, SNP, 1-6 bp indel) every
     150 bp merged by add_all_variants into multi-allelic sites, reads with indels drawn on the host"""
@@ -753,6 +984,16 @@ def main(argv=None):
         except Exception as e:  # the extra line must never cost the main one
             cfg.setdefault("extra", {})["pcie_fed"] = {"error": repr(e)}
     w.close()
+    if n_gpus == 1 and n_samples == 1 and not args.no_extra:
+        try:
+            cfg.setdefault("extra", {})["pipeline"] = extra_pipeline(args, torch, gtx, synth, device, ctx, ref, records)
+        except Exception as e:  # the extra line must never cost the main one
+            cfg.setdefault("extra", {})["pipeline"] = {"error": repr(e)}
+    if n_gpus == 1 and n_samples == 1 and not args.no_extra:
+        try:
+            cfg.setdefault("extra", {})["regions"] = extra_regions(args, torch, gtx, synth, device, ref)
+        except Exception as e:  # the extra line must never cost the main one
+            cfg.setdefault("extra", {})["regions"] = {"error": repr(e)}
     if n_gpus == 1 and not args.no_extra:
         del d_seq, w
         torch.cuda.empty_cache()

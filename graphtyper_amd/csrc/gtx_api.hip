@@ -13,6 +13,7 @@
 #include <string>
 
 #include "gtx_ctx.hpp"
+#include "gtx_devmem.hpp"
 #include "align_core.hpp"
 #include "score_core.hpp"
 #include "score_replay.hpp"
@@ -676,9 +677,18 @@ __device__ __forceinline__ void express4_queue_pass(GraphView const & g, IndexVi
       n_pending = 0;
     }
   };
-  for (uint32_t i = 0;; ++i)
+  // (groups per visit to the counter: one on a short queue, up to sixteen -- the 64 reads of TASK_CHUNK -- on a long one,
+  //  where one atomic per group is 400 k atomics on one address: four milliseconds on the cfg3-like workload)
+  uint32_t const per_visit = n_groups / G >= 128u ? 16u : n_groups / G >= 32u ? 4u : 1u;
+  for (uint32_t i = 0, grp = 0, grp_end = 0;; ++i, ++grp)
   {
-    uint32_t const grp = i < own ? blockIdx.x + i * G : own * G + wave_claim(task_counter, 1u);
+    if (i < own)
+      grp = blockIdx.x + i * G;
+    else if (i == own || grp == grp_end)
+    {
+      grp = own * G + wave_claim(task_counter, per_visit);
+      grp_end = grp + per_visit;
+    }
     if (grp >= n_groups)
       break;
     uint32_t const first = 4u * grp;
@@ -1106,7 +1116,7 @@ static bool upload(std::vector<void *> & owned, T const *& dst, T const * src, s
 {
   void * p = nullptr;
   size_t const bytes = (n ? n : 1) * sizeof(T);
-  if (!hip_ok(hipMalloc(&p, bytes), what))
+  if (!hip_ok(gtx::dev_malloc(&p, bytes), what))
     return false;
   owned.push_back(p);
   if (n && !hip_ok(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice), what))
@@ -1119,11 +1129,11 @@ template <class T>
 static bool dev_alloc(T *& dst, size_t n, char const * what, bool zero = false)
 {
   void * p = nullptr;
-  if (!hip_ok(hipMalloc(&p, (n ? n : 1) * sizeof(T)), what))
+  if (!hip_ok(gtx::dev_malloc(&p, (n ? n : 1) * sizeof(T)), what))
     return false;
   if (zero && !hip_ok(hipMemset(p, 0, (n ? n : 1) * sizeof(T)), what))
   {
-    (void)hipFree(p);
+    (void)gtx::dev_free(p);
     return false;
   }
   dst = static_cast<T *>(p);
@@ -1137,7 +1147,7 @@ static void scratch_free(CallScratch & s)
                    s.d_score_tables, s.d_score_work, s.d_wide_tasks, s.d_wide_ws, s.d_planes};
   for (void * p : ptrs)
     if (p)
-      (void)hipFree(p);
+      (void)gtx::dev_free(p);
   for (auto & row : s.time_events)
     for (auto & e : row)
       if (e)
@@ -1164,14 +1174,14 @@ static std::unique_ptr<CallScratch> scratch_new(gtx_ctx & c)
   {
     ok = ok && dev_alloc(s->d_big_state, 16, "second-pass state", true);
     void * ws = nullptr;
-    ok = ok && hip_ok(hipMalloc(&ws, static_cast<size_t>(c.big_blocks) * sizeof(big::AlignWorkspace)), "second-pass workspaces");
+    ok = ok && hip_ok(gtx::dev_malloc(&ws, static_cast<size_t>(c.big_blocks) * sizeof(big::AlignWorkspace)), "second-pass workspaces");
     s->d_big_ws = ws;
     if (ok && c.has_wide_sites)
     {
       s->d_wide_state = s->d_big_state + 8;
       ok = ok && dev_alloc(s->d_wide_tasks, CallScratch::WIDE_TASK_CAP, "wide-site pass queue");
       void * wws = nullptr;
-      ok = ok && hip_ok(hipMalloc(&wws, static_cast<size_t>(CallScratch::WIDE_BLOCKS) * sizeof(wide::AlignWorkspace)), "wide-site pass workspaces");
+      ok = ok && hip_ok(gtx::dev_malloc(&wws, static_cast<size_t>(CallScratch::WIDE_BLOCKS) * sizeof(wide::AlignWorkspace)), "wide-site pass workspaces");
       s->d_wide_ws = wws;
     }
     ok = ok && dev_alloc(s->d_score_state, 2, "second-pass score state", true);
@@ -1238,7 +1248,7 @@ static bool grow(T *& p, uint64_t & cap, uint64_t want, char const * what)
 {
   if (want <= cap)
     return true;
-  if (p && !hip_ok(hipFree(p), what)) // (synchronises with earlier launches)
+  if (p && (!hip_ok(hipDeviceSynchronize(), what) || !hip_ok(gtx::dev_free(p), what))) // (earlier launches may still use the old buffer)
     return false;
   p = nullptr;
   cap = 0;
@@ -1293,7 +1303,7 @@ int ctx_upload(gtx_ctx & c, int device)
   ok = ok && upload(c.dev_allocs, v.near_last, h.near_last.data(), h.near_last.size(), "near_last");
   ok = ok && upload(c.dev_allocs, v.near_off, h.near_off.data(), h.near_off.size(), "near_off");
   void * pf = nullptr;
-  ok = ok && hip_ok(hipMalloc(&pf, 32 * sizeof(unsigned long long)), "profile counters");
+  ok = ok && hip_ok(gtx::dev_malloc(&pf, 32 * sizeof(unsigned long long)), "profile counters");
   if (ok)
   {
     c.dev_allocs.push_back(pf);
@@ -1301,7 +1311,7 @@ int ctx_upload(gtx_ctx & c, int device)
     ok = hip_ok(hipMemset(pf, 0, 32 * sizeof(unsigned long long)), "profile counters");
   }
   void * ef = nullptr;
-  ok = ok && hip_ok(hipMalloc(&ef, sizeof(uint32_t)), "error flag");
+  ok = ok && hip_ok(gtx::dev_malloc(&ef, sizeof(uint32_t)), "error flag");
   if (ok)
   {
     c.dev_allocs.push_back(ef);
@@ -1318,13 +1328,13 @@ int ctx_upload(gtx_ctx & c, int device)
     c.big_blocks = have_prop ? static_cast<uint32_t>(prop.multiProcessorCount) : 256u;
     c.big_record_words = c.params.big_record_words ? c.params.big_record_words : (16ull << 20);
     void * p = nullptr;
-    ok = ok && hip_ok(hipMalloc(&p, c.big_record_words * sizeof(uint32_t)), "big-record arena");
+    ok = ok && hip_ok(gtx::dev_malloc(&p, c.big_record_words * sizeof(uint32_t)), "big-record arena");
     if (ok)
     {
       c.dev_allocs.push_back(p);
       c.d_big_records = static_cast<uint32_t *>(p);
     }
-    ok = ok && hip_ok(hipMalloc(&p, sizeof(unsigned long long)), "arena cursor");
+    ok = ok && hip_ok(gtx::dev_malloc(&p, sizeof(unsigned long long)), "arena cursor");
     if (ok)
     {
       c.dev_allocs.push_back(p);
@@ -1364,7 +1374,7 @@ void ctx_release_device(gtx_ctx & c)
   c.pool.clear();
   c.last_align = nullptr;
   for (void * p : c.dev_allocs)
-    (void)hipFree(p);
+    (void)gtx::dev_free(p);
   c.dev_allocs.clear();
 }
 
@@ -1970,7 +1980,7 @@ extern "C" int gtx_scores_replay(gtx_ctx * c, const gtx_score_item * d_items, ui
       ok = wanted == 0 || hip_ok(hipMemcpy(log.data(), d_log, static_cast<size_t>(wanted) * sizeof(ReplayEntry), hipMemcpyDeviceToHost), "replay log");
       break;
     }
-    (void)hipFree(d_log);
+    (void)gtx::dev_free(d_log);
     d_log = nullptr;
     cap = wanted;
     if (attempt == 1)
@@ -1996,7 +2006,7 @@ extern "C" int gtx_scores_replay(gtx_ctx * c, const gtx_score_item * d_items, ui
   }
   for (void * p : {static_cast<void *>(d_marked), static_cast<void *>(d_count), static_cast<void *>(d_log)})
     if (p)
-      (void)hipFree(p);
+      (void)gtx::dev_free(p);
   return ok ? GTX_OK : GTX_ERR_HIP;
 }
 

@@ -1,0 +1,134 @@
+// gtx_devmem.cpp -- see gtx_devmem.hpp
+#include "gtx_devmem.hpp"
+
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace gtx
+{
+namespace
+{
+struct DevCache
+{
+  std::mutex m;
+  struct Block
+  {
+    int device;
+    size_t bytes;
+  };
+  std::unordered_map<void *, Block> live;                         // every block handed out or cached
+  std::map<std::pair<int, size_t>, std::vector<void *>> free_by; // (device, class size) -> cached blocks
+  size_t cached_bytes = 0;
+  size_t limit = 0;
+};
+
+DevCache & cache()
+{
+  static DevCache * c = new DevCache; // (never destroyed: the runtime may be gone before static destructors run)
+  return *c;
+}
+
+// size classes: powers of two up to 1 MiB, then multiples of 1 MiB up to 64 MiB, then multiples of 16 MiB
+size_t class_of(size_t bytes)
+{
+  if (bytes <= 256)
+    return 256;
+  if (bytes <= (1u << 20))
+  {
+    size_t c = 256;
+    while (c < bytes)
+      c <<= 1;
+    return c;
+  }
+  size_t const step = bytes <= (64ull << 20) ? (1ull << 20) : (16ull << 20);
+  return (bytes + step - 1) / step * step;
+}
+} // namespace
+
+hipError_t dev_malloc(void ** p, size_t bytes)
+{
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess)
+    return e;
+  size_t const cls = class_of(bytes);
+  DevCache & c = cache();
+  {
+    std::lock_guard<std::mutex> lock(c.m);
+    if (c.limit == 0)
+    {
+      char const * env = std::getenv("GTX_DEVICE_CACHE_MB");
+      c.limit = (env ? static_cast<size_t>(std::atoll(env)) : 8192u) << 20;
+      if (c.limit == 0)
+        c.limit = 1; // (0 MB: nothing is kept)
+    }
+    auto it = c.free_by.find({dev, cls});
+    if (it != c.free_by.end() && !it->second.empty())
+    {
+      *p = it->second.back();
+      it->second.pop_back();
+      c.cached_bytes -= cls;
+      return hipSuccess;
+    }
+  }
+  e = hipMalloc(p, cls);
+  if (e != hipSuccess)
+  {
+    // the cache may hold what the driver lacks: give it back and try once more
+    dev_cache_release();
+    e = hipMalloc(p, cls);
+    if (e != hipSuccess)
+      return e;
+  }
+  std::lock_guard<std::mutex> lock(c.m);
+  c.live[*p] = {dev, cls};
+  return hipSuccess;
+}
+
+hipError_t dev_free(void * p)
+{
+  if (!p)
+    return hipSuccess;
+  DevCache & c = cache();
+  {
+    std::lock_guard<std::mutex> lock(c.m);
+    auto it = c.live.find(p);
+    if (it == c.live.end())
+      return hipFree(p); // not ours
+    if (c.cached_bytes + it->second.bytes <= c.limit)
+    {
+      c.free_by[{it->second.device, it->second.bytes}].push_back(p);
+      c.cached_bytes += it->second.bytes;
+      return hipSuccess;
+    }
+    c.live.erase(it);
+  }
+  return hipFree(p);
+}
+
+void dev_cache_release()
+{
+  DevCache & c = cache();
+  std::vector<void *> all;
+  {
+    std::lock_guard<std::mutex> lock(c.m);
+    for (auto & kv : c.free_by)
+    {
+      for (void * p : kv.second)
+      {
+        all.push_back(p);
+        c.live.erase(p);
+      }
+      kv.second.clear();
+    }
+    c.cached_bytes = 0;
+  }
+  for (void * p : all)
+    (void)hipFree(p);
+}
+} // namespace gtx
+
+extern "C" void gtx_device_cache_release(void) { gtx::dev_cache_release(); }

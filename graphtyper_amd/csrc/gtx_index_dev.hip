@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "gtx_ctx.hpp"
+#include "gtx_devmem.hpp"
 #include "index_build.hpp"
 
 namespace gtx
@@ -48,7 +49,7 @@ struct Pool
     void * p = nullptr;
     if (!fine)
       return nullptr;
-    fine = ok_hip(hipMalloc(&p, (n ? n : 1) * sizeof(T)), what);
+    fine = ok_hip(gtx::dev_malloc(&p, (n ? n : 1) * sizeof(T)), what);
     if (fine && zero)
       fine = ok_hip(hipMemset(p, 0, (n ? n : 1) * sizeof(T)), what);
     if (p)
@@ -68,8 +69,10 @@ struct Pool
   }
   ~Pool()
   {
+    if (!temps.empty())
+      (void)hipDeviceSynchronize(); // (on an error path kernels may still be writing to them; freed blocks are handed out again)
     for (void * p : temps)
-      (void)hipFree(p);
+      (void)gtx::dev_free(p);
   }
 };
 

@@ -16,6 +16,7 @@
 #include <string>
 
 #include "gtx_ctx.hpp"
+#include "gtx_devmem.hpp"
 
 using namespace gtx;
 
@@ -142,10 +143,10 @@ extern "C"
     uint64_t const reduced = s.stat_u64 * 8 + s.u32_total() * 4;
     uint64_t const bytes = reduced + 2 * 4 + static_cast<uint64_t>(conn_cap) * 6 * 4;
     void * p = nullptr;
-    if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&p, bytes ? bytes : 8) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess)
+    if (hipSetDevice(c->device) != hipSuccess || gtx::dev_malloc(&p, bytes ? bytes : 8) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess)
     {
       if (p)
-        (void)hipFree(p);
+        (void)gtx::dev_free(p);
       g_last_error = "gtx_scores_alloc: hipMalloc of " + std::to_string(bytes) + " bytes failed";
       return GTX_ERR_HIP;
     }
@@ -191,7 +192,7 @@ extern "C"
   {
     if (!c || !b)
       return GTX_ERR_ARG;
-    if (b->d_stat_u64 && hipFree(b->d_stat_u64) != hipSuccess)
+    if (b->d_stat_u64 && (hipDeviceSynchronize() != hipSuccess || gtx::dev_free(b->d_stat_u64) != hipSuccess)) // (the block is handed out again: nothing may still use it)
     {
       g_last_error = "gtx_scores_free: hipFree failed";
       return GTX_ERR_HIP;

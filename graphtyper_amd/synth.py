@@ -114,3 +114,66 @@ def make_cluster_records(ref, every=500, seed=13, region_begin=0):
                 recs.append((q + region_begin, bases_to_str(ref[q:q + dl + 1]), ["ACGT"[ref[q]]], None))
         p += every
     return recs
+
+
+def write_fixed_bam(path, contig, contig_len, sample, codes, pos0, mapq=60, flag=0, threads=8, level=1):
+    """A position-sorted BAM of unpaired reads of one length, written without a per-record Python loop (benchmarks: the
+    pipeline leg of bench.py reads such files back through gtx_reads).  codes: [n, L] 4-bit BAM codes, pos0: [n] 0-based
+    positions (sorted).  Records: name r%09d, cigar LM, qualities 30, no aux fields; BGZF members of 236 records, deflated
+    on `threads` threads (zlib releases the GIL)."""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    codes = np.ascontiguousarray(codes, np.uint8)
+    n, L = codes.shape
+    nb = (L + 1) // 2
+    name_len = 11  # "r%09d" + NUL
+    rec = np.dtype([("block_size", "<i4"), ("refid", "<i4"), ("pos", "<i4"), ("l_read_name", "u1"), ("mapq", "u1"), ("bin", "<u2"),
+                    ("n_cigar", "<u2"), ("flag", "<u2"), ("l_seq", "<i4"), ("next_refid", "<i4"), ("next_pos", "<i4"), ("tlen", "<i4"),
+                    ("name", "u1", name_len), ("cigar", "<u4"), ("seq", "u1", nb), ("qual", "u1", L)])
+    out = np.zeros(n, rec)
+    out["block_size"] = rec.itemsize - 4
+    out["pos"] = pos0
+    out["l_read_name"] = name_len
+    out["mapq"] = mapq
+    beg = np.asarray(pos0, np.int64)
+    end = beg + L - 1
+    b = np.zeros(n, np.int64)
+    done = np.zeros(n, bool)
+    for shift, first in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):  # reg2bin (SAM spec 5.3)
+        hit = ~done & ((beg >> shift) == (end >> shift))
+        b[hit] = first + (beg[hit] >> shift)
+        done |= hit
+    out["bin"] = b
+    out["n_cigar"] = 1
+    out["flag"] = flag
+    out["l_seq"] = L
+    out["next_refid"] = -1
+    out["next_pos"] = -1
+    idx = np.arange(n, dtype=np.int64)
+    out["name"][:, 0] = ord("r")
+    for k in range(9):
+        out["name"][:, 1 + k] = 48 + (idx // 10 ** (8 - k)) % 10
+    out["cigar"] = L << 4
+    padded = codes if L % 2 == 0 else np.concatenate([codes, np.zeros((n, 1), np.uint8)], axis=1)
+    out["seq"] = (padded[:, 0::2] << 4) | padded[:, 1::2]
+    out["qual"] = 30
+    header_text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:%s\tLN:%d\n@RG\tID:%s\tSM:%s\n" % (contig, contig_len, sample, sample)
+    head = b"BAM\1" + struct.pack("<i", len(header_text)) + header_text.encode() + struct.pack("<i", 1)
+    head += struct.pack("<i", len(contig) + 1) + contig.encode() + b"\0" + struct.pack("<i", contig_len)
+
+    def member(chunk):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = c.compress(chunk) + c.flush()
+        return struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(comp) + 25) + comp + \
+            struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+
+    raw = out.view(np.uint8).reshape(n, rec.itemsize)
+    per = max(1, 65000 // rec.itemsize)
+    chunks = [head] + [raw[a:a + per].tobytes() for a in range(0, n, per)] + [b""]
+    with ThreadPoolExecutor(max(1, threads)) as pool:
+        members = list(pool.map(member, chunks))
+    with open(path, "wb") as f:
+        for m in members:
+            f.write(m)
+    return rec.itemsize
