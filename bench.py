@@ -790,11 +790,15 @@ def extra_regions(args, torch, gtx, synth, device, ref, n_regions=20, region_len
             "ms_per_region": {k: round(1e3 * v / n_regions, 3) for k, v in t_seq.items()}}
 
 
-def extra_cfg3(args, torch, gtx, synth, device, ref):
-    """cfg3-like workload in the same run: 30 samples, clusters of three biallelic sites (SNP, SNP, 1-6 bp indel) every
-    150 bp merged by add_all_variants into multi-allelic sites, reads with indels drawn on the host"""
+def extra_cfg3(args, torch, gtx, synth, device, ref, kind="cfg3"):
+    """BASELINE configs[2] in the same run: 30 samples joint over the same region, SNP+indel graph built with add_all_variants,
+    reads with indels drawn on the host.  kind "cfg3": the graph SURVEY.md 8(d) specifies -- a site every 100 bp, a tenth of
+    them 1-10 bp indels with a SNP within 10 bp that merges with them into a multi-allelic site; kind "clusters": the
+    stress graph of rounds 1-2 -- clusters of three sites (SNP, SNP, 1-6 bp indel) every 150 bp, every read over a merged
+    site of up to 8 alleles"""
     n = args.extra_reads
-    recs = synth.make_cluster_records(ref, 150, seed=8, region_begin=REGION_BEGIN)
+    recs = synth.make_cfg3_records(ref, 100, seed=17, region_begin=REGION_BEGIN) if kind == "cfg3" else \
+        synth.make_cluster_records(ref, 150, seed=8, region_begin=REGION_BEGIN)
     t0 = time.time()
     graph = gtx.graph_from_records(synth.bases_to_str(ref), recs, region_begin=REGION_BEGIN, add_all_variants=True)
     t_graph = time.time() - t0
@@ -831,8 +835,12 @@ def extra_cfg3(args, torch, gtx, synth, device, ref):
         for k, nm in enumerate(names):
             sys.stderr.write("  %-22s %10.0f  %5.1f%%\n" % (nm, prof[16 + k] / float(prof[31]), 100.0 * prof[16 + k] / tot))
     w.close()
-    out = {"workload": "cfg3-like: 30 samples, %d reads, 1 Mb, clusters (SNP, SNP, indel) every 150 bp merged into multi-allelic "
-                       "sites (add_all_variants), max %d alleles per site" % (n, int(ctx.hap_cnum.max())),
+    what = ("cfg3: 30 samples, %d reads, 1 Mb, a site every 100 bp, 10 %% of them 1-10 bp indels with a SNP within 10 bp (SURVEY 8(d)), merged by "
+            "add_all_variants, max %d alleles per site" if kind == "cfg3" else
+            "cfg3 stress graph: 30 samples, %d reads, 1 Mb, clusters (SNP, SNP, indel) every 150 bp merged into multi-allelic sites "
+            "(add_all_variants), max %d alleles per site") % (n, int(ctx.hap_cnum.max()))
+    kt = ctx.kernel_times()
+    out = {"workload": what, "align_kernels": {k[0]: {"ms": k[1], "tasks_completed": k[2]} for k in kt},
            "reads_per_s": n * steps / dt, "ms_per_step": 1000.0 * dt / steps, "steps": steps, "resident_read_sets": len(w.sets), "sites": int(ctx.n_hap), "ctx_create_s": round(t_ctx, 3),
            "graph_build_s": round(t_graph, 3),
            "align_passes_ms": {"express": ms[0], "general": ms[1], "hbm_tables": ms[2]},
@@ -998,7 +1006,8 @@ def main(argv=None):
         del d_seq, w
         torch.cuda.empty_cache()
         try:
-            cfg.setdefault("extra", {})["cfg3"] = extra_cfg3(args, torch, gtx, synth, device, ref)
+            cfg.setdefault("extra", {})["cfg3"] = extra_cfg3(args, torch, gtx, synth, device, ref, "cfg3")
+            cfg.setdefault("extra", {})["cfg3_clusters"] = extra_cfg3(args, torch, gtx, synth, device, ref, "clusters")
         except Exception as e:  # the extra line must never cost the main one
             cfg.setdefault("extra", {})["cfg3"] = {"error": repr(e)}
     print(json.dumps(out))

@@ -27,7 +27,8 @@ EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy"
            "gtx_scores_alloc", "gtx_scores_zero", "gtx_scores_free", "gtx_scores_reduce", "gtx_comm_unique_id", "gtx_comm_init_rank",
            "gtx_comm_destroy", "gtx_ctx_kernel_times", "gtx_ref_depth_finalize", "gtx_vcf_records", "gtx_scores_replay", "gtx_reads_open", "gtx_reads_info",
            "gtx_reads_sample_name", "gtx_reads_next", "gtx_reads_close", "gtx_align_batch_flags", "gtx_score_batch_flags",
-           "gtx_pack_planes", "gtx_reads_to_planes", "gtx_align_batch_planes", "gtx_stream_set_planes", "gtx_device_cache_release"]
+           "gtx_pack_planes", "gtx_reads_to_planes", "gtx_align_batch_planes", "gtx_stream_set_planes", "gtx_device_cache_release",
+           "gtx_disc_create", "gtx_disc_destroy", "gtx_disc_events_batch", "gtx_disc_first_pass"]
 
 
 class GraphView(C.Structure):
@@ -72,6 +73,12 @@ STREAM_RECORD = np.dtype([("flag", np.uint16), ("mapq", np.uint8), ("score_diff"
                           ("mtid", np.int32), ("pos", np.int32), ("isize", np.int32), ("l_qseq", np.uint16),
                           ("rg", np.uint16), ("sample", np.uint32), ("name_id", np.uint64), ("mpos", np.int32),
                           ("n_cigar", np.uint32), ("cigar_front", np.uint32), ("cigar_back", np.uint32)], align=True)
+DISC_READ = np.dtype([("pos", np.int32), ("flag", np.uint16), ("mapq", np.uint8), ("reserved", np.uint8), ("l_qseq", np.uint16),
+                      ("n_cigar", np.uint16), ("cigar_off", np.uint32)], align=True)
+DISC_EVENT = np.dtype([("read", np.uint32), ("pos", np.uint32), ("seq", np.uint32), ("len", np.uint16), ("type", np.uint8), ("hq", np.uint8),
+                       ("max_distance", np.uint16), ("reserved", np.uint16)], align=True)
+DISC_READ_OUT = np.dtype([("first_event", np.uint32), ("n_events", np.uint32), ("pos_end", np.int32), ("state", np.uint32)], align=True)
+assert DISC_READ.itemsize == 16 and DISC_EVENT.itemsize == 20 and DISC_READ_OUT.itemsize == 16
 LABEL = np.dtype([("start_index", np.uint32), ("end_index", np.uint32), ("variant_id", np.uint32)], align=True)
 assert READ_META.itemsize == 20 and REC_META.itemsize == 16 and SCORE_ITEM.itemsize == 40 and STREAM_RECORD.itemsize == 56 \
     and SAMPLE_CALL.itemsize == 12
@@ -127,6 +134,13 @@ def lib():
         L.gtx_ref_depth_finalize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
         L.gtx_vcf_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.gtx_align_batch_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.gtx_disc_create.argtypes = [C.c_char_p, C.c_uint64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
+        L.gtx_disc_destroy.argtypes = [C.c_void_p]
+        L.gtx_disc_destroy.restype = None
+        L.gtx_disc_events_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                            C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gtx_disc_first_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32,
+                                          C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.gtx_device_cache_release.argtypes = []
         L.gtx_device_cache_release.restype = None
         L.gtx_pack_planes.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]

@@ -116,6 +116,32 @@ def make_cluster_records(ref, every=500, seed=13, region_begin=0):
     return recs
 
 
+def make_cfg3_records(ref, every=100, indel_frac=0.1, seed=17, region_begin=0):
+    """SURVEY.md 8(d), the SNP+indel graph of cfg3: a biallelic site every `every` bp, `indel_frac` of them 1-10 bp insertions
+    or deletions instead of SNPs, each of those with a SNP 2-9 bp behind it so that add_all_variants (graph.cpp:81-167) merges
+    the two into one multi-allelic site.  Records do not overlap (make_reads applies them one after the other)."""
+    rng = np.random.default_rng(seed)
+    recs = []
+    p = every // 2
+    while p + 30 < len(ref):
+        if rng.random() < indel_frac:
+            if rng.random() < 0.5:
+                ins = rng.integers(0, 4, size=int(rng.integers(1, 11)), dtype=np.uint8)
+                recs.append((p + region_begin, "ACGT"[ref[p]], ["ACGT"[ref[p]] + bases_to_str(ins)], None))
+                q = p + int(rng.integers(2, 10))
+            else:
+                dl = int(rng.integers(1, 11))
+                recs.append((p + region_begin, bases_to_str(ref[p:p + dl + 1]), ["ACGT"[ref[p]]], None))
+                q = p + dl + int(rng.integers(2, 10))
+            a = (ref[q] + rng.integers(1, 4)) % 4
+            recs.append((q + region_begin, "ACGT"[ref[q]], ["ACGT"[a]], None))
+        else:
+            a = (ref[p] + rng.integers(1, 4)) % 4
+            recs.append((p + region_begin, "ACGT"[ref[p]], ["ACGT"[a]], None))
+        p += every
+    return recs
+
+
 def write_fixed_bam(path, contig, contig_len, sample, codes, pos0, mapq=60, flag=0, threads=8, level=1):
     """A position-sorted BAM of unpaired reads of one length, written without a per-record Python loop (benchmarks: the
     pipeline leg of bench.py reads such files back through gtx_reads).  codes: [n, L] 4-bit BAM codes, pos0: [n] 0-based

@@ -553,6 +553,68 @@ const char * gtx_reads_sample_name(const gtx_reads *, uint32_t i);
 int gtx_reads_next(gtx_reads *, gtx_stream_record * recs, uint8_t * seq, uint32_t seq_stride, uint32_t cap, uint32_t * n);
 void gtx_reads_close(gtx_reads *);
 
+/* ---- variant discovery, first slice.  Replaces, per sample, the first pass over the reads of a region:
+ * run_first_pass (src/typer/caller.cpp:488-1186) -- the SNP and indel events its CIGAR walk reads off the alignments
+ * (caller.cpp:583-775, Event / EventSupport include/graphtyper/typer/event.hpp:30-113, add_snp_event_to_bucket /
+ * add_indel_event_to_bucket src/typer/bucket.cpp:75-182), the correction for reads with 12 and more events and the phase
+ * counts between the events of a read (caller.cpp:777-822), the coverage difference arrays, and the two support filters
+ * (EventSupport::has_good_support src/typer/event.cpp:226-256 for SNPs; good / realignment support of indels,
+ * caller.cpp:990-1186).  Not built: what follows -- the haplotypes of the surviving events, the realignment of reads to the
+ * indels (paw::pairwise_alignment, a dependency that is absent from the reference tree), the second pass, the pool merge.
+ *   gtx_disc_create        the region's reference (upper-case letters; reference[0] = contig position region_begin, 0-based) on `device`
+ *   gtx_disc_events_batch  device: the events of n_reads reads in stream order.  d_planes: the reads as plane rows (gtx_pack_planes),
+ *                          d_qual: their base qualities (qual_stride bytes per read), d_reads / d_cigar: the bam1_t fields and the raw
+ *                          BAM cigar words.  d_events receives the events, a read's own behind each other in CIGAR order;
+ *                          d_read_out[i] says where (first_event, n_events).  d_counts[0] += events produced, d_counts[1] += events
+ *                          that did not fit event_cap (both zeroed by the caller; a pass with d_counts[1] != 0 has to be repeated
+ *                          with a larger buffer).
+ *   gtx_disc_first_pass    host: the downloaded arrays -> the events that survive the pass with their support, as a word stream:
+ *                          per event pos, type, length, its characters; hq_count, lq_count, proper_pairs, first_in_pairs,
+ *                          sequence_reversed, clipped, max_mapq, max_distance, uniq_pos1..3, span, has_realignment_support,
+ *                          has_indel_good_support, max_log_qual, number of phase entries; then per phase entry the other event
+ *                          (pos, type, length, characters) and its count.  Events in the reference's order (position; insertions,
+ *                          deletions, SNPs; sequence).  seq: the reads' BAM nibble rows (the inserted bases of an insertion are read
+ *                          from them), bucket_size: BUCKET_SIZE of the reference (it decides nothing about the result). */
+typedef struct gtx_disc gtx_disc;
+typedef struct gtx_disc_read
+{
+  int32_t pos;       /* core.pos */
+  uint16_t flag;     /* core.flag */
+  uint8_t mapq;      /* core.qual */
+  uint8_t reserved;
+  uint16_t l_qseq;
+  uint16_t n_cigar;
+  uint32_t cigar_off; /* its first word in the cigar array */
+} gtx_disc_read;
+typedef struct gtx_disc_event
+{
+  uint32_t read;         /* index of the read in its batch */
+  uint32_t pos;          /* Event::pos: contig position, 0-based */
+  uint32_t seq;          /* 'X': the read's base (ASCII); 'I': offset of the first inserted base in the read; 'D': offset of the first deleted base in the region */
+  uint16_t len;          /* Event::sequence.size() */
+  uint8_t type;          /* 'X', 'I', 'D' */
+  uint8_t hq;            /* 'X': base quality >= 25; indels: 1 */
+  uint16_t max_distance; /* 'X': min(read_pos, l_qseq - 1 - read_pos) */
+  uint16_t reserved;
+} gtx_disc_event;
+#define GTX_DISC_SKIPPED 0u /* no cigar, or in front of the region: the pass does not look at the read */
+#define GTX_DISC_COUNTED 1u
+#define GTX_DISC_END 2u     /* starts at or behind the region's end: the reference's pass ends here */
+typedef struct gtx_disc_read_out
+{
+  uint32_t first_event, n_events;
+  int32_t pos_end; /* region-relative end of the alignment (cov_down) */
+  uint32_t state;
+} gtx_disc_read_out;
+int gtx_disc_create(const char * reference, uint64_t reference_len, int64_t region_begin, int device, gtx_disc ** out);
+void gtx_disc_destroy(gtx_disc *);
+int gtx_disc_events_batch(gtx_disc *, const uint8_t * d_planes, uint32_t plane_stride, const uint8_t * d_qual, uint32_t qual_stride,
+                          const gtx_disc_read * d_reads, const uint32_t * d_cigar, uint32_t n_reads, gtx_disc_event * d_events, uint32_t event_cap,
+                          uint32_t * d_counts, gtx_disc_read_out * d_read_out, void * stream);
+int gtx_disc_first_pass(const gtx_disc *, const gtx_disc_read * reads, const uint32_t * cigar, const gtx_disc_read_out * read_out, uint32_t n_reads,
+                        const gtx_disc_event * events, uint64_t n_events, const uint8_t * seq, uint32_t seq_stride, uint32_t bucket_size,
+                        uint32_t * out, uint64_t cap, uint64_t * n_words);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,6 +2,7 @@
 // Loaded with ctypes from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
 #include "gto.hpp"
 #include "gto_vcf.hpp"
+#include "gto_discovery.hpp"
 
 #include <cctype>
 #include <memory>
@@ -636,6 +637,41 @@ extern "C"
     for (auto const & m : g->g->maps)
       parked += static_cast<long>(m.size());
     out[2] = parked;
+  }
+
+  // ---- discovery, first pass (gto_discovery.hpp): reads as arrays -> the canonical word stream of the surviving events
+  // codes: 4-bit BAM codes of all reads back to back (code_off[n + 1]), qual the same shape, cigar: raw BAM words (cigar_off[n + 1])
+  long gto_first_pass(char const * reference, long region_begin, long bucket_size, long n, int32_t const * pos, uint16_t const * flag,
+                      uint8_t const * mapq, uint32_t const * cigar, uint32_t const * cigar_off, uint8_t const * codes, uint8_t const * qual,
+                      uint32_t const * code_off, uint32_t * out, long cap)
+  {
+    try
+    {
+      static char const NT16[] = "=ACMGRSVTWYHKDBN";
+      std::vector<gto::disc::Read> reads(static_cast<std::size_t>(n));
+      for (long i = 0; i < n; ++i)
+      {
+        gto::disc::Read & r = reads[i];
+        r.pos = pos[i];
+        r.flag = flag[i];
+        r.mapq = mapq[i];
+        r.cigar.assign(cigar + cigar_off[i], cigar + cigar_off[i + 1]);
+        for (uint32_t k = code_off[i]; k < code_off[i + 1]; ++k)
+          r.sequence.push_back(NT16[codes[k] & 15]);
+        r.qual.assign(qual + code_off[i], qual + code_off[i + 1]);
+      }
+      gto::disc::FirstPass fp;
+      fp.run(reads, std::string(reference), region_begin, bucket_size);
+      std::vector<uint32_t> const s = fp.dump();
+      if (static_cast<long>(s.size()) <= cap)
+        std::memcpy(out, s.data(), s.size() * 4);
+      return static_cast<long>(s.size());
+    }
+    catch (std::exception const & e)
+    {
+      g_error = e.what();
+      return -1;
+    }
   }
 
   // ---- small known-answer helpers (pinned against test/utilities/*.cpp, test/typer/test_path.cpp) ----

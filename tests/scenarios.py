@@ -67,6 +67,8 @@ def synthetic_case(kind, n_ref=40000, n_reads=300, seed=0, region_begin=1000000,
         recs = synth.make_indel_records(ref, 60, seed=seed + 4, region_begin=region_begin)
     elif kind == "cluster":  # merged multi-allelic sites: build the graph with add_all_variants=True
         recs = synth.make_cluster_records(ref, 150, seed=seed + 8, region_begin=region_begin)
+    elif kind == "cfg3":  # SNP every 100 bp, a tenth of the sites short indels with a SNP close by (merged by add_all_variants)
+        recs = synth.make_cfg3_records(ref, 100, seed=seed + 14, region_begin=region_begin)
     elif kind == "snp7":  # > 8 variant sites per read and wide graph walks: second-pass territory
         recs = synth.make_snp_records(ref, 7, seed=seed + 9, region_begin=region_begin)
     elif kind == "repeat":

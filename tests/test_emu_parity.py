@@ -257,6 +257,27 @@ def test_align_and_score_on_merged_multiallelic_graph():
     run_stream(b, o, codes[order], rec[order], n_samples=3)
 
 
+def cfg3_case(Backend, n_reads, n_ref=120000):
+    """the SNP+indel graph SURVEY 8(d) specifies for BASELINE cfg3 (a site every 100 bp, a tenth of them short indels merged with
+    a SNP close by), 30 samples: every record with four kinds of hints, then the stream through scoring, calls and VCF text"""
+    ref, recs, codes, pos = scenarios.synthetic_case("cfg3", n_ref=n_ref, n_reads=n_reads, region_begin=1000000)
+    o = Oracle(ref, recs, region_begin=1000000, add_all_variants=True)
+    g = gtx.graph_from_records(ref, recs, region_begin=1000000, add_all_variants=True)
+    assert int(g["ref_nvar"].max()) >= 3
+    b = Backend(g)
+    check_align(b, o, list(codes), pos=pos)
+    done = check_align.hinted_done
+    order = np.argsort(pos, kind="stable")
+    rec = scenarios.stream_records(len(codes), pos, sample=np.arange(len(codes)) % 30)
+    run_stream(b, o, codes[order], rec[order], n_samples=30)
+    return done
+
+
+def test_cfg3_graph():
+    done = cfg3_case(harness.EmuBackend, 4000)
+    assert done > 0.7 * 4000, done
+
+
 def second_pass_case(Backend, kind, n_reads):
     """reads that exceed the main pass' LDS tables (repeats: dozens of seed locations; dense variation: > 8 sites per
     read, wide graph walks) are redone by the second pass and must equal the oracle like any other read; results longer

@@ -10,7 +10,7 @@ import harness
 import scenarios
 from graphtyper_amd import lib as gtx
 from oracle_lib import Oracle, encode
-from test_emu_parity import check_align, neardup_case, direct_probes_case, n_runs_case, three_n_case, sv_deletion_case, edge_case, express_variants_case, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case
+from test_emu_parity import check_align, cfg3_case, neardup_case, direct_probes_case, n_runs_case, three_n_case, sv_deletion_case, edge_case, express_variants_case, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case
 
 pytestmark = pytest.mark.gpu
 
@@ -95,6 +95,11 @@ def test_merged_multiallelic_graph():
     order = np.argsort(pos, kind="stable")
     rec = scenarios.stream_records(len(codes), pos, sample=np.arange(len(codes)) % 30)
     run_stream(b, o, codes[order], rec[order], n_samples=30)
+
+
+def test_cfg3_graph():
+    done = cfg3_case(harness.GpuBackend, 30000, n_ref=300000)
+    assert done > 0.7 * 30000, done
 
 
 @pytest.mark.parametrize("kind", ["repeat", "snp7"])

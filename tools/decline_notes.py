@@ -22,7 +22,7 @@ NOTES = {1: "exact k-mer, place not provably simple", 3: "one substitution, othe
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "snp1k"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
-add_all = kind == "cluster"
+add_all = kind in ("cluster", "cfg3")
 ref, recs, codes, pos = scenarios.synthetic_case(kind, n_ref=400000, n_reads=n, region_begin=1000000)
 b = harness.EmuBackend(gtx.graph_from_records(ref, recs, region_begin=1000000, add_all_variants=add_all))
 seq, lens = harness.pack_ragged(list(codes))
