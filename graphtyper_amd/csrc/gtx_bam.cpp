@@ -11,8 +11,8 @@
 // see Bgzf below); a BAM record is parsed in place into a
 // gtx_stream_record + its packed bases (copied verbatim: the kernels read BAM nibbles).  Equal keys keep file order, then
 // position in the file (the reference's std::sort / heap leave the order of exact duplicates unspecified; their results do
-// not depend on it).  A region starts from the .bai when there is one (else the file is scanned from its head).  Not read:
-// CRAM (needs htslib's codecs), .csi indices.
+// not depend on it).  A region starts from the .bai or .csi when there is one (else the file is scanned from its head).  Not read:
+// CRAM (needs htslib's codecs).
 #include "gtx_ctx.hpp"
 
 #include <zlib.h>
@@ -423,6 +423,79 @@ bool bai_start(std::string const & bam_path, int32_t tid, int64_t begin, int64_t
     }
   }
   std::fclose(fp);
+  return ok;
+}
+
+// The same from a .csi index (<bam>.csi; htslib's coordinate-sorted index with a free bin geometry: min_shift, depth; the
+// file is BGZF-compressed).  Level l of the bins holds 8^l bins of 2^(min_shift + 3 (depth - l)) bases from bin number
+// (8^l - 1) / 7; a bin carries `loffset`, the offset of the first record that overlaps it -- the lower bound the .bai
+// takes from its linear index comes from the smallest bin around the region's first base here.  false: no usable index.
+bool csi_start(std::string const & bam_path, int32_t tid, int64_t begin, int64_t end, bool & any, uint64_t & voffset)
+{
+  Bgzf z;
+  if (!z.open(bam_path + ".csi") && !(bam_path.size() > 4 && z.open(bam_path.substr(0, bam_path.size() - 4) + ".csi")))
+    return false;
+  auto rd = [&](void * d, size_t n) { return z.read(d, n) == static_cast<long>(n); };
+  char magic[4];
+  int32_t min_shift = 0, depth = 0, l_aux = 0, n_ref = 0;
+  bool ok = rd(magic, 4) && std::memcmp(magic, "CSI\1", 4) == 0 && rd(&min_shift, 4) && rd(&depth, 4) && rd(&l_aux, 4) && min_shift >= 0 &&
+            min_shift <= 32 && depth >= 0 && depth <= 10 && l_aux >= 0 && l_aux < (1 << 24);
+  if (ok && l_aux)
+  {
+    std::vector<char> aux(static_cast<size_t>(l_aux));
+    ok = rd(aux.data(), aux.size());
+  }
+  ok = ok && rd(&n_ref, 4) && tid >= 0 && tid < n_ref;
+  any = false;
+  voffset = UINT64_MAX;
+  int64_t const max_pos = 1ll << std::min(62, min_shift + 3 * depth);
+  int64_t const last = std::min<int64_t>(end, max_pos) - 1;
+  uint64_t const meta_bin = ((1ull << (3 * (depth + 1))) - 1) / 7 + 1; // the pseudo-bin with the mapped / unmapped counts
+  for (int32_t r = 0; ok && r <= tid; ++r)
+  {
+    int32_t n_bin = 0;
+    ok = rd(&n_bin, 4) && n_bin >= 0;
+    uint64_t best = UINT64_MAX, lower = 0;
+    int lower_level = -1;
+    for (int32_t b = 0; ok && b < n_bin; ++b)
+    {
+      uint32_t bin = 0;
+      uint64_t loffset = 0;
+      int32_t n_chunk = 0;
+      ok = rd(&bin, 4) && rd(&loffset, 8) && rd(&n_chunk, 4) && n_chunk >= 0;
+      bool overlaps = false;
+      if (ok && r == tid && bin != meta_bin)
+      {
+        uint64_t first = 0;
+        for (int l = 0; l <= depth; first += 1ull << (3 * l), ++l)
+        {
+          int const shift = min_shift + 3 * (depth - l);
+          if (bin >= first && bin < first + (1ull << (3 * l)))
+          {
+            int64_t const k = static_cast<int64_t>(bin - first);
+            overlaps = k >= (begin >> shift) && k <= (last >> shift);
+            if (k == (begin >> shift) && l > lower_level) // the smallest bin around the region's first base
+            {
+              lower_level = l;
+              lower = loffset;
+            }
+          }
+        }
+      }
+      for (int32_t c = 0; ok && c < n_chunk; ++c)
+      {
+        uint64_t cb = 0, ce = 0;
+        ok = rd(&cb, 8) && rd(&ce, 8);
+        if (ok && overlaps && cb < best)
+          best = cb;
+      }
+    }
+    if (ok && r == tid && best != UINT64_MAX)
+    {
+      any = true;
+      voffset = std::max(best, lower);
+    }
+  }
   return ok;
 }
 
@@ -867,7 +940,7 @@ extern "C" int gtx_reads_open(const char * const * bam_paths, uint32_t n_paths, 
       // with a .bai the scan starts at the first place an overlapping record can be, else behind the header
       bool any = false;
       uint64_t voffset = 0;
-      if (bai_start(file->path, file->want_tid, begin, end, any, voffset))
+      if (bai_start(file->path, file->want_tid, begin, end, any, voffset) || csi_start(file->path, file->want_tid, begin, end, any, voffset))
       {
         file->indexed = true;
         if (!any)

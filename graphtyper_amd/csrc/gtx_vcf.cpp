@@ -12,6 +12,7 @@
 #include "gtx_ctx.hpp"
 
 #include <algorithm>
+#include <zlib.h>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -714,5 +715,280 @@ extern "C" int gtx_vcf_records(const gtx_ctx * c, const gtx_vcf_request * rq, ch
   *len = text.size();
   if (out && cap)
     std::memcpy(out, text.data(), static_cast<size_t>(std::min<uint64_t>(cap, text.size())));
+  return GTX_OK;
+}
+
+// ---- the description lines of the header: Vcf::write_header (src/typer/vcf.cpp:526-760).  The texts are the file format
+// (tests/golden/vcf_header_definitions.txt holds the reference's own output for them; tests/test_vcf_text.py compares).
+namespace
+{
+struct HeaderLine
+{
+  char const * kind;   // INFO, FORMAT, FILTER
+  char const * id;
+  char const * number; // "" for FILTER lines
+  char const * type;
+  char const * description;
+};
+HeaderLine const HEADER_LINES[] = {
+  {"INFO", "AAScore", "A", "Float",
+   "Alternative allele confidence score in range [0.0,1.0]. The score is determined by a logistic regression model which was trained on GIAB truth data using other INFOs metrics as covariates."},
+  {"INFO", "ABHet", "1", "Float",
+   "Allele Balance for heterozygouscalls (read count of call2/(call1+call2)) where the called genotype is call1/call2. -1 if no heterozygous calls."},
+  {"INFO", "ABHom", "1", "Float",
+   "Allele Balance for homozygous calls(read count of A/(A+O)) where A is the called allele and O is anything else. -1 if no homozygous calls."},
+  {"INFO", "ABHetMulti", "R", "Float",
+   "List of Allele Balance values for heterozygous calls (alt/(ref+alt)). -1 if not available."},
+  {"INFO", "ABHomMulti", "R", "Float",
+   "List of Allele Balance values for homozygous calls (A/(A+0)) where A is the called allele and O is anything else. -1 if not available."},
+  {"INFO", "AC", "A", "Integer",
+   "Number of alternate alleles in called genotypes."},
+  {"INFO", "AF", "A", "Float",
+   "Allele frequency."},
+  {"INFO", "AN", "1", "Integer",
+   "Number of alleles in called genotypes."},
+  {"INFO", "CR", "1", "Integer",
+   "Number of clipped reads in the graph alignment."},
+  {"INFO", "CRal", ".", "String",
+   "Number of clipped bp per allele."},
+  {"INFO", "CRalt", "A", "Float",
+   "Percent of clipped reads per allele."},
+  {"INFO", "END", "1", "Integer",
+   "End position of an SV."},
+  {"INFO", "FEATURE", "1", "String",
+   "Gene feature."},
+  {"INFO", "GT_ANTI_HAPLOTYPE", ".", "String",
+   "Haplotype string with downstream variants  with no (or very low) evidence of being in the same haplotype. Used internally by Graphtyper."},
+  {"INFO", "GT_HAPLOTYPE", ".", "String",
+   "Haplotype string with downstream variants  with high evidence of being always in the same haplotype. Used internally by Graphtyper."},
+  {"INFO", "GT_ID", ".", "String",
+   "ID for variant. Used internally by Graphtyper."},
+  {"INFO", "HOMSEQ", ".", "String",
+   "Sequence of base pair identical homology at event breakpoints."},
+  {"INFO", "INV3", "0", "Flag",
+   "Inversion breakends open 3' of reported location"},
+  {"INFO", "INV5", "0", "Flag",
+   "Inversion breakends open 5' of reported location"},
+  {"INFO", "LEFT_SVINSSEQ", ".", "String",
+   "Known left side of insertion for an insertion of unknown length."},
+  {"INFO", "LOGF", "1", "Float",
+   "Output from logistic regression model."},
+  {"INFO", "MaxAAS", "A", "Integer",
+   "Maximum alternative allele support per alt. allele."},
+  {"INFO", "MaxAASR", "A", "Float",
+   "Maximum alternative allele support ratio per alt. allele."},
+  {"INFO", "MaxAltPP", "1", "Integer",
+   "Maximum number of proper pairs support the alternative allele."},
+  {"INFO", "MMal", ".", "String",
+   "Scaled mismatch count per allele."},
+  {"INFO", "MMalt", "A", "Float",
+   "Mismatch percent per alternative allele."},
+  {"INFO", "MQ", "1", "Integer",
+   "Root-mean-square mapping quality."},
+  {"INFO", "MQalt", "A", "Integer",
+   "Mapping qualities per alternative allele."},
+  {"INFO", "MQSal", ".", "String",
+   "Sum of squared mapping qualities per allele."},
+  {"INFO", "MQsquared", ".", "String",
+   "Sum of squared mapping qualities. Used to calculate MQ."},
+  {"INFO", "NCLUSTERS", "1", "Integer",
+   "Number of SV candidates in cluster."},
+  {"INFO", "NGT", "3", "Integer",
+   "Number of REF/REF, REF/ALT and ALT/ALTgenotypes, respectively."},
+  {"INFO", "NHet", "A", "Integer",
+   "Number of heterozygous genotype calls."},
+  {"INFO", "NHomRef", "A", "Integer",
+   "Number of homozygous reference genotype calls."},
+  {"INFO", "NHomAlt", "A", "Integer",
+   "Number of homozygous alternative genotype calls."},
+  {"INFO", "NUM_MERGED_SVS", "1", "Integer",
+   "Number of SVs merged."},
+  {"INFO", "OLD_VARIANT_ID", "1", "String",
+   "Variant ID from a VCF (SVs only)."},
+  {"INFO", "ORSTART", "1", "Integer",
+   "Start coordinate of sequence origin."},
+  {"INFO", "OREND", "1", "Integer",
+   "End coordinate of sequence origin."},
+  {"INFO", "QD", "1", "Float",
+   "QUAL divided by NonReferenceSeqDepth."},
+  {"INFO", "QDalt", "A", "Float",
+   "Simplified QD calculated separately for each allele against all other alleles."},
+  {"INFO", "PASS_AC", "A", "Integer",
+   "Number of alternate alleles in called genotyped that have FT = PASS."},
+  {"INFO", "PASS_AN", "1", "Integer",
+   "Number of genotype calls that haveFT = PASS."},
+  {"INFO", "PASS_ratio", "1", "Float",
+   "Ratio of genotype calls that haveFT = PASS."},
+  {"INFO", "PexcessHet", "A", "Float",
+   "Pval of excess heterozygous calls."},
+  {"INFO", "RefLen", "1", "Integer",
+   "Length of the reference allele."},
+  {"INFO", "RELATED_SV_ID", "1", "Integer",
+   "GraphTyper ID of a related SV."},
+  {"INFO", "RIGHT_SVINSSEQ", ".", "String",
+   "Known right side of insertion for an insertion of unknown length."},
+  {"INFO", "SB", "1", "Float",
+   "Strand bias (F/(F+R)) where F and R are forward and reverse strands, respectively. -1 if not available."},
+  {"INFO", "SBAlt", "1", "Float",
+   "Strand bias of alternative alleles only. -1 if not available."},
+  {"INFO", "SBF", "R", "Integer",
+   "Number of forward stranded reads per allele."},
+  {"INFO", "SBF1", "R", "Integer",
+   "Number of first forward stranded reads per allele."},
+  {"INFO", "SBF2", "R", "Integer",
+   "Number of second forward stranded reads per allele."},
+  {"INFO", "SBR", "R", "Integer",
+   "Number of reverse stranded reads per allele."},
+  {"INFO", "SBR1", "R", "Integer",
+   "Number of first reverse stranded reads per allele."},
+  {"INFO", "SBR2", "R", "Integer",
+   "Number of second reverse stranded reads per allele."},
+  {"INFO", "SDal", ".", "String",
+   "Score difference of AS and XS tags per allele."},
+  {"INFO", "SDalt", "A", "Float",
+   "Avergae score difference of AS and XS tags per alternative allele."},
+  {"INFO", "SEQ", "1", "String",
+   "Inserted sequence at variant site."},
+  {"INFO", "SeqDepth", "1", "Integer",
+   "Total accumulated sequencing depth over all the samples."},
+  {"INFO", "SV_ID", "1", "Integer",
+   "GraphTyper's ID on SV."},
+  {"INFO", "SVINSSEQ", ".", "String",
+   "Sequence of insertion."},
+  {"INFO", "SVLEN", "1", "Integer",
+   "Length of structural variant in bp. Negative lengths indicate a deletion."},
+  {"INFO", "SVMODEL", "1", "String",
+   "Model used for SV genotyping."},
+  {"INFO", "SVSIZE", "1", "Integer",
+   "Size of structural variant in bp. Always 50 or more."},
+  {"INFO", "SVTYPE", "1", "String",
+   "Type of structural variant."},
+  {"INFO", "VarType", "1", "String",
+   "First letter is program identifier,the second letter is variant type."},
+  {"FORMAT", "GT", "1", "String",
+   "GenoType call. ./. is called if there is no coverage at the variant site."},
+  {"FORMAT", "FT", "1", "String",
+   "Filter. PASS or FAILN where N is a number."},
+  {"FORMAT", "AD", "R", "Integer",
+   "Allelic depths for the ref and alt alleles in the order listed."},
+  {"FORMAT", "MD", "1", "Integer",
+   "Read depth of multiple alleles."},
+  {"FORMAT", "DP", "1", "Integer",
+   "Approximate read depth."},
+  {"FORMAT", "RA", "2", "Integer",
+   "Total read depth of the reference allele and all alternative alleles, including reads that support more than one allele."},
+  {"FORMAT", "PP", "1", "Integer",
+   "Number of reads that support non-reference haplotype that are proper pairs."},
+  {"FORMAT", "GQ", "1", "Integer",
+   "Genotype Quality."},
+  {"FORMAT", "PL", "G", "Integer",
+   "PHRED-scaled genotype likelihoods."},
+  {"FILTER", "PASS", "", "",
+   "All filters passed"},
+  {"FILTER", "LowAAScore", "", "",
+   "Alternative alleles have a low score."},
+  {"FILTER", "LowABHet", "", "",
+   "Allele balance of heterozygous carriers is below 17.5%."},
+  {"FILTER", "LowABHom", "", "",
+   "Allele balance of homozygous carriers is below 90%."},
+  {"FILTER", "LowQD", "", "",
+   "QD (quality by depth) is below 6.0."},
+  {"FILTER", "LowQUAL", "", "",
+   "QUAL score is less than 10."},
+  {"FILTER", "LowPratio", "", "",
+   "Ratio of PASSed calls was too low."},
+};
+} // namespace
+
+extern "C" int gtx_vcf_header(const gtx_vcf_header_request * rq, char * out, uint64_t cap, uint64_t * len)
+{
+  if (!rq || !len || (cap && !out) || (rq->n_contigs && (!rq->contig_names || !rq->contig_lengths)) || (rq->n_samples && !rq->sample_names))
+  {
+    gtx::g_last_error = "gtx_vcf_header: bad argument";
+    return GTX_ERR_ARG;
+  }
+  std::string s = "##fileformat=VCFv4.2\n##fileDate=";
+  s += rq->file_date ? rq->file_date : "";
+  s += "\n##source=Graphtyper\n##graphtyperVersion=";
+  s += rq->version ? rq->version : "";
+  if (rq->dirty)
+    s += "-dirty";
+  s += "\n##graphtyperGitBranch=";
+  s += rq->git_branch ? rq->git_branch : "";
+  s += "\n##graphtyperSHA1=";
+  s += rq->git_sha1 ? rq->git_sha1 : "";
+  s += "\n";
+  for (uint32_t i = 0; i < rq->n_contigs; ++i)
+    s += std::string("##contig=<ID=") + rq->contig_names[i] + ",length=" + std::to_string(rq->contig_lengths[i]) + ">\n";
+  for (HeaderLine const & h : HEADER_LINES)
+  {
+    s += std::string("##") + h.kind + "=<ID=" + h.id;
+    if (h.number[0])
+      s += std::string(",Number=") + h.number + ",Type=" + h.type;
+    s += std::string(",Description=\"") + h.description + "\">\n";
+  }
+  s += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO";
+  if (!rq->drop_genotypes && rq->n_samples)
+  {
+    s += "\tFORMAT";
+    for (uint32_t i = 0; i < rq->n_samples; ++i)
+      s += std::string("\t") + rq->sample_names[i];
+  }
+  s += "\n";
+  *len = s.size();
+  if (out)
+    std::memcpy(out, s.data(), std::min<uint64_t>(cap, s.size()));
+  return GTX_OK;
+}
+
+// ---- BGZF: the members htslib's bgzf_write makes (SAM spec 4.1): gzip members with the BC extra field, at most 0xff00 bytes of
+// input each, and the 28-byte empty member at the end of a file (what the reference's bgzf_stream writes its VCF through,
+// include/graphtyper/utilities/bgzf_stream.hpp).
+extern "C" int gtx_bgzf_compress(const void * in, uint64_t in_len, int level, int with_eof, void * out, uint64_t cap, uint64_t * out_len)
+{
+  if (!out_len || (in_len && !in) || (cap && !out))
+  {
+    gtx::g_last_error = "gtx_bgzf_compress: bad argument";
+    return GTX_ERR_ARG;
+  }
+  std::string res;
+  uint8_t const * p = static_cast<uint8_t const *>(in);
+  auto member = [&](uint8_t const * data, uint32_t n) -> bool
+  {
+    std::vector<uint8_t> buf(compressBound(n) + 64);
+    z_stream zs{};
+    if (deflateInit2(&zs, level < 0 ? Z_DEFAULT_COMPRESSION : std::min(level, 9), Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK)
+      return false;
+    zs.next_in = const_cast<Bytef *>(data);
+    zs.avail_in = n;
+    zs.next_out = buf.data();
+    zs.avail_out = static_cast<uInt>(buf.size());
+    int const rc = deflate(&zs, Z_FINISH);
+    uint32_t const clen = static_cast<uint32_t>(zs.total_out);
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END || clen + 26u > 0x10000u)
+      return false;
+    uint8_t head[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 0, 0};
+    uint16_t const bsize = static_cast<uint16_t>(clen + 25u);
+    head[16] = static_cast<uint8_t>(bsize & 255u);
+    head[17] = static_cast<uint8_t>(bsize >> 8);
+    res.append(reinterpret_cast<char const *>(head), 18);
+    res.append(reinterpret_cast<char const *>(buf.data()), clen);
+    uint32_t const tail[2] = {static_cast<uint32_t>(crc32(crc32(0L, Z_NULL, 0), data, n)), n};
+    res.append(reinterpret_cast<char const *>(tail), 8);
+    return true;
+  };
+  for (uint64_t at = 0; at < in_len; at += 0xff00u)
+    if (!member(p + at, static_cast<uint32_t>(std::min<uint64_t>(0xff00u, in_len - at))))
+    {
+      gtx::g_last_error = "gtx_bgzf_compress: deflate failed";
+      return GTX_ERR_IO;
+    }
+  if (with_eof && !member(p, 0))
+    return GTX_ERR_IO;
+  *out_len = res.size();
+  if (res.size() > cap)
+    return out ? GTX_ERR_CAPACITY : GTX_OK;
+  std::memcpy(out, res.data(), res.size());
   return GTX_OK;
 }

@@ -28,7 +28,7 @@ EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy"
            "gtx_comm_destroy", "gtx_ctx_kernel_times", "gtx_ref_depth_finalize", "gtx_vcf_records", "gtx_scores_replay", "gtx_reads_open", "gtx_reads_info",
            "gtx_reads_sample_name", "gtx_reads_next", "gtx_reads_close", "gtx_align_batch_flags", "gtx_score_batch_flags",
            "gtx_pack_planes", "gtx_reads_to_planes", "gtx_align_batch_planes", "gtx_stream_set_planes", "gtx_device_cache_release",
-           "gtx_disc_create", "gtx_disc_destroy", "gtx_disc_events_batch", "gtx_disc_first_pass"]
+           "gtx_disc_create", "gtx_disc_destroy", "gtx_disc_events_batch", "gtx_disc_first_pass", "gtx_vcf_header", "gtx_bgzf_compress"]
 
 
 class GraphView(C.Structure):
@@ -141,6 +141,8 @@ def lib():
                                             C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gtx_disc_first_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32,
                                           C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.gtx_vcf_header.argtypes = [C.POINTER(VcfHeaderRequest), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.gtx_bgzf_compress.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.gtx_device_cache_release.argtypes = []
         L.gtx_device_cache_release.restype = None
         L.gtx_pack_planes.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
@@ -402,6 +404,36 @@ class Reads:
             self.close()
         except Exception:
             pass
+
+
+class VcfHeaderRequest(C.Structure):
+    _fields_ = [("file_date", C.c_char_p), ("version", C.c_char_p), ("dirty", C.c_int32), ("git_branch", C.c_char_p), ("git_sha1", C.c_char_p),
+                ("contig_names", C.POINTER(C.c_char_p)), ("contig_lengths", C.POINTER(C.c_uint32)), ("n_contigs", C.c_uint32),
+                ("sample_names", C.POINTER(C.c_char_p)), ("n_samples", C.c_uint32), ("drop_genotypes", C.c_int32)]
+
+
+def vcf_header(file_date, version, contigs, sample_names, dirty=False, git_branch="", git_sha1="", drop_genotypes=False):
+    """gtx_vcf_header: contigs = [(name, length)] -> bytes"""
+    names = (C.c_char_p * max(1, len(contigs)))(*[c[0].encode() for c in contigs])
+    lens = (C.c_uint32 * max(1, len(contigs)))(*[c[1] for c in contigs])
+    samples = (C.c_char_p * max(1, len(sample_names)))(*[s_.encode() for s_ in sample_names])
+    rq = VcfHeaderRequest(file_date.encode(), version.encode(), int(dirty), git_branch.encode(), git_sha1.encode(), names, lens, len(contigs),
+                          samples, len(sample_names), int(drop_genotypes))
+    n = C.c_uint64()
+    check(lib().gtx_vcf_header(C.byref(rq), None, 0, C.byref(n)))
+    buf = C.create_string_buffer(int(n.value) + 1)
+    check(lib().gtx_vcf_header(C.byref(rq), buf, n.value, C.byref(n)))
+    return buf.raw[:int(n.value)]
+
+
+def bgzf_compress(data, level=-1, with_eof=True):
+    """gtx_bgzf_compress -> bytes"""
+    n = C.c_uint64()
+    src = C.create_string_buffer(data, len(data))
+    check(lib().gtx_bgzf_compress(src, len(data), level, int(with_eof), None, 0, C.byref(n)))
+    out = C.create_string_buffer(int(n.value) + 1)
+    check(lib().gtx_bgzf_compress(src, len(data), level, int(with_eof), out, n.value, C.byref(n)))
+    return out.raw[:int(n.value)]
 
 
 class VcfRequest(C.Structure):

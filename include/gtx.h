@@ -416,6 +416,33 @@ typedef struct gtx_vcf_request
 } gtx_vcf_request;
 int gtx_vcf_records(const gtx_ctx *, const gtx_vcf_request *, char * out, uint64_t cap, uint64_t * len);
 
+/* The header in front of the records: replaces Vcf::write_header (src/typer/vcf.cpp:526-760) -- ##fileformat, ##fileDate,
+ * ##source, the version / branch / SHA1 lines (the reference prints its build's constants: given here), one ##contig line per
+ * contig (Graph::contigs), the ##INFO / ##FORMAT / ##FILTER description lines and the column line (with FORMAT and the sample
+ * names unless genotypes are dropped or there is no sample).  gtx_vcf_records' own first line is that column line too: a
+ * caller that writes a file takes the header from here and the records from there without their first line. */
+typedef struct gtx_vcf_header_request
+{
+  const char * file_date;  /* YYYYMMDD (current_date(), vcf.cpp:36-45) */
+  const char * version;    /* graphtyper_VERSION_MAJOR.MINOR.PATCH */
+  int32_t dirty;           /* GIT_NUM_DIRTY_LINES != 0: "-dirty" behind the version */
+  const char * git_branch; /* GIT_BRANCH */
+  const char * git_sha1;   /* GIT_COMMIT_LONG_HASH */
+  const char * const * contig_names;
+  const uint32_t * contig_lengths;
+  uint32_t n_contigs;
+  const char * const * sample_names;
+  uint32_t n_samples;
+  int32_t drop_genotypes; /* is_dropping_genotypes */
+} gtx_vcf_header_request;
+int gtx_vcf_header(const gtx_vcf_header_request *, char * out, uint64_t cap, uint64_t * len);
+
+/* BGZF members of `in` (SAM spec 4.1: gzip members of at most 0xff00 input bytes with the BC extra field), with_eof: followed
+ * by the 28-byte empty member that ends a file -- what the reference's bgzf_stream (include/graphtyper/utilities/
+ * bgzf_stream.hpp) makes of the text it is given.  level: zlib's 0..9, -1 = default.  out may be NULL with cap 0 to ask for
+ * the size. */
+int gtx_bgzf_compress(const void * in, uint64_t in_len, int level, int with_eof, void * out, uint64_t cap, uint64_t * out_len);
+
 /* ---- multi-GPU: reads shard over the GPUs of a node (one process per GPU, graph + index replicated), the accumulators
  * are summed once per region.  The reference's counterpart is the merge of per-thread / per-pool results
  * on the host (src/typer/caller.cpp:439-482, src/typer/vcf_operations.cpp:366-374); every per-read effect is an integer
@@ -540,7 +567,7 @@ int gtx_stream_counts(const gtx_stream *, uint64_t * n_records, uint64_t * n_dup
  * Needs zlib only (BGZF members are inflated one by one, so virtual offsets can be sought).  `region` ("chr",
  * "chr:begin-end", 1-based inclusive; NULL, "" or "." = everything) yields the records that overlap it, as sam_itr_querys
  * would return them: with a .bai beside the file (<bam>.bai or <name>.bai) the scan starts at the first place the index
- * allows an overlapping record, without one at the head of the file.  Not read: CRAM, .csi indices.  Records with equal sort keys keep file order (the reference's
+ * allows an overlapping record -- or a .csi (<bam>.csi) --, without one at the head of the file.  Not read: CRAM.  Records with equal sort keys keep file order (the reference's
  * std::sort / heap leave the order of exact duplicates open; results do not depend on it).
  * gtx_reads_next fills up to cap records (n = 0: end); a read whose packed bases exceed seq_stride is an error.
  * Threads: a gtx_reads is used by one thread at a time; several may be open on several host threads.  While any is open

@@ -49,11 +49,13 @@ def record(name, flag, tid, pos, mapq, cigar, mtid, mpos, tlen, codes, aux=()):
     return struct.pack("<i", len(body)) + body
 
 
-def write_bam(path, refs, header_text, records, index=None, poison=False):
+def write_bam(path, refs, header_text, records, index=None, poison=False, csi=None):
     """refs: [(name, length)]; records: bytes from record(), already in file order.
     index: [(tid, pos, end)] per record -> also writes path + ".bai" (SAM spec 5.2: bins, chunks, 16 kb linear index);
     poison: a BGZF member of garbage between the header and the records -- a reader that scans from the head fails on it,
-    one that seeks through the index never sees it."""
+    one that seeks through the index never sees it.
+    csi = (min_shift, depth): the index goes to path + ".csi" instead (htslib's CSI: bins of a free geometry with their
+    loffset, the whole index BGZF-compressed)."""
     head = b"BAM\1" + struct.pack("<i", len(header_text)) + header_text.encode() + struct.pack("<i", len(refs))
     for name, length in refs:
         head += struct.pack("<i", len(name) + 1) + name.encode() + b"\0" + struct.pack("<i", length)
@@ -86,6 +88,44 @@ def write_bam(path, refs, header_text, records, index=None, poison=False):
             if beg >> shift == end >> shift:
                 return first + (beg >> shift)
         return 0
+    if csi is not None:
+        min_shift, depth = csi
+
+        def reg2bin_csi(beg, end):
+            end -= 1
+            s, t = min_shift, ((1 << (depth * 3)) - 1) // 7
+            for l in range(depth, 0, -1):
+                if beg >> s == end >> s:
+                    return t + (beg >> s)
+                s += 3
+                t -= 1 << ((l - 1) * 3)
+            return 0
+        out_csi = bytearray(b"CSI\1" + struct.pack("<iii", min_shift, depth, 0) + struct.pack("<i", len(refs)))
+        for tid in range(len(refs)):
+            bins = {}
+            for k, (t, pos, end) in enumerate(index):
+                if t != tid:
+                    continue
+                v0, v1 = voffs[k], voffs[k + 1] if k + 1 < len(voffs) else end_voff
+                e = bins.setdefault(reg2bin_csi(pos, max(end, pos + 1)), dict(chunks=[], lo=v0))
+                if e["chunks"] and e["chunks"][-1][1] == v0:
+                    e["chunks"][-1][1] = v1
+                else:
+                    e["chunks"].append([v0, v1])
+            # loffset of a bin: the offset of the first record that overlaps the bin's interval (records in other bins too)
+            for b in bins:
+                level, first = 0, 0
+                while not (first <= b < first + (1 << (3 * level))):
+                    first += 1 << (3 * level)
+                    level += 1
+                shift = min_shift + 3 * (depth - level)
+                b0, b1 = (b - first) << shift, ((b - first) + 1) << shift
+                bins[b]["lo"] = min(voffs[k] for k, (t, pos, end) in enumerate(index) if t == tid and pos < b1 and max(end, pos + 1) > b0)
+            out_csi += struct.pack("<i", len(bins))
+            for b in sorted(bins):
+                out_csi += struct.pack("<IQi", b, bins[b]["lo"], len(bins[b]["chunks"])) + b"".join(struct.pack("<QQ", c0, c1) for c0, c1 in bins[b]["chunks"])
+        open(path + ".csi", "wb").write(bgzf(bytes(out_csi)))
+        return
     bai = bytearray(b"BAI\1" + struct.pack("<i", len(refs)))
     for tid in range(len(refs)):
         bins, linear = {}, {}

@@ -145,6 +145,33 @@ def test_region_through_the_bai_index(tmp_path):
     assert len(recs_b) == 0
 
 
+@pytest.mark.parametrize("geometry", [(14, 5), (12, 6), (16, 3)])
+def test_region_through_a_csi_index(tmp_path, geometry):
+    """the same through a .csi (htslib's index with a free bin geometry, BGZF-compressed): the scan starts where the index says
+    -- the member of garbage behind the header is never read -- and yields the overlapping records"""
+    rng = np.random.default_rng(6)
+    refs = [("chrA", 400000), ("chrB", 900000)]
+    recs = []
+    for tid in (0, 1):
+        for p in np.sort(rng.integers(0, refs[tid][1] - 400, size=1500)):
+            codes = rng.choice([1, 2, 4, 8], size=150).astype(np.uint8)
+            recs.append(dict(tid=tid, pos=int(p), codes=codes, flag=0, mapq=60, cigar=[("M", 100), ("D", int(rng.integers(1, 200))), ("M", 50)], mtid=-1, mpos=-1,
+                             tlen=0, aux=[("AS", "C", 100)], rg=None, name="r%d" % len(recs)))
+    header = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
+    span = lambda r: sum(n for op, n in r["cigar"] if op in "MDN=X")
+    path = str(tmp_path / "csi.bam")
+    blobs = [bw.record(r["name"], r["flag"], r["tid"], r["pos"], r["mapq"], r["cigar"], r["mtid"], r["mpos"], r["tlen"], r["codes"], r["aux"]) for r in recs]
+    bw.write_bam(path, refs, header, blobs, index=[(r["tid"], r["pos"], r["pos"] + span(r)) for r in recs], poison=True, csi=geometry)
+    for region, tid, lo, hi in (("chrB:500001-520000", 1, 500000, 520000), ("chrA:1-9000", 0, 0, 9000), ("chrB:860000-900000", 1, 859999, 900000)):
+        want, _, _ = _expected([recs], [[]], keep=lambda r: r["tid"] == tid and r["pos"] < hi and r["pos"] + span(r) > lo)
+        assert len(want) > 5
+        _check(gtx.Reads([path], region=region), want)
+    import os
+    os.rename(path + ".csi", path + ".hidden")
+    with pytest.raises(gtx.GtxError):  # no index: the scan from the head runs into the garbage
+        gtx.Reads([path], region="chrB:500001-520000")
+
+
 def test_region_returns_the_overlapping_records(tmp_path):
     files, paths, headers = _random_files(tmp_path, 7)
     lo, hi = 150, 300  # 1-based inclusive region chrB:150-300 = 0-based [149, 300)

@@ -174,3 +174,42 @@ def test_records_written_by_a_team_of_host_threads_are_the_same_bytes(monkeypatc
         monkeypatch.setenv("GTX_HOST_THREADS", team)
         texts.append(ctx.vcf_records("chr1", names, gt_cov, stat_u64, stat_u32, phred, calls))
     assert texts[0] == texts[1] == texts[2] and texts[0].count(b"\n") == nh + 1
+
+
+def test_header_is_the_references_text():
+    """gtx_vcf_header: the ##INFO / ##FORMAT / ##FILTER lines are the reference's own output for them (tests/golden/
+    vcf_header_definitions.txt, made by make_vcf_header.py from Vcf::write_header's literals), the lines around them follow
+    vcf.cpp:526-548 and 691-758"""
+    import os
+    golden = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vcf_header_definitions.txt"), "rb").read()
+    text = gtx.vcf_header("20260927", "2.7.7", [("chr1", 1000), ("chr20", 64444167)], ["A", "B"], git_branch="master", git_sha1="abc")
+    head = (b"##fileformat=VCFv4.2\n##fileDate=20260927\n##source=Graphtyper\n##graphtyperVersion=2.7.7\n##graphtyperGitBranch=master\n"
+            b"##graphtyperSHA1=abc\n##contig=<ID=chr1,length=1000>\n##contig=<ID=chr20,length=64444167>\n")
+    assert text == head + golden + b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tA\tB\n"
+    assert golden.count(b"\n") == 83 and b"##INFO=<ID=SVMODEL" in golden
+    text = gtx.vcf_header("20260927", "2.7.7", [], ["A"], dirty=True, drop_genotypes=True)
+    assert b"##graphtyperVersion=2.7.7-dirty\n" in text and text.endswith(b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+
+
+def test_bgzf_members():
+    """gtx_bgzf_compress: members of at most 0xff00 bytes with the BC field and their own size in it, the input back through
+    zlib, and the end-of-file member htslib writes"""
+    import struct
+    import zlib
+    rng = np.random.default_rng(5)
+    data = bytes(rng.integers(65, 70, size=200000).astype(np.uint8))
+    blob = gtx.bgzf_compress(data, level=6)
+    eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    assert blob.endswith(eof)
+    at, out, sizes = 0, b"", []
+    while at < len(blob):
+        assert blob[at:at + 4] == b"\x1f\x8b\x08\x04" and blob[at + 12:at + 16] == b"BC\x02\x00"
+        bsize = struct.unpack("<H", blob[at + 16:at + 18])[0] + 1
+        payload = zlib.decompress(blob[at + 18:at + bsize - 8], -15)
+        crc, isize = struct.unpack("<II", blob[at + bsize - 8:at + bsize])
+        assert isize == len(payload) <= 0xff00 and crc == (zlib.crc32(payload) & 0xFFFFFFFF)
+        out += payload
+        sizes.append(isize)
+        at += bsize
+    assert out == data and sizes[-1] == 0 and sizes[:3] == [0xff00] * 3
+    assert gtx.bgzf_compress(b"", with_eof=True) == eof and gtx.bgzf_compress(b"", with_eof=False) == b""
