@@ -1019,8 +1019,9 @@ def main(argv=None):
 # Algorithmic bytes per forward task of each alignment kernel: what ITS algorithm has to move.
 # The global-lookup passes are priced as SURVEY.md 8(d) prices the reference (388 key slots probed per read-orientation).
 # The position-hinted pass proves the outcome of those probes from per-position flags and never issues them: 20 B meta +
-# 80 B bases + 84 B reference nibbles + 48 B position flags + 4 B filter word + 24 B record + 8 B reverse-orientation header.
-KERNEL_BYTES = {"gtx_align_hinted_kernel": 268, "gtx_align_express4_kernel": ALGO_BYTES_PER_READ, "gtx_align_kernel": ALGO_BYTES_PER_READ,
+# 80 B bases (plane row) + 84 B reference planes + 48 B position flags + 4 B filter word + 24 B record = 260 B (round 2's 268 B
+# minus the 8-byte header of the reverse record, which GTX_FLAG_FORWARD_ONLY reads no longer get).
+KERNEL_BYTES = {"gtx_align_hinted_kernel": 260, "gtx_align_express4_kernel": ALGO_BYTES_PER_READ, "gtx_align_kernel": ALGO_BYTES_PER_READ,
                 "gtx_align_big_kernel": ALGO_BYTES_PER_READ}
 
 
