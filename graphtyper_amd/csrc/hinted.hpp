@@ -671,6 +671,7 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   // ---- the run of k-mers that makes the path (express4.inl: the longest run of labelled k-mers, which has to be the
   //      only one of its length; the shorter side of a hole chains into a path remove_short_paths drops)
   uint32_t lo = 0, hi = n_k - 1;
+  bool par_start = false;
   if (labelled != (1u << n_k) - 1u)
   {
     uint32_t best_lo = 0, best_len = 0, second = 0, cur_lo = 0, cur_len = 0;
@@ -696,13 +697,17 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
       }
     }
     // (a run that opens with a parallel chain behind a hole is returned twice by the reference: not here)
-    if (best_len <= second || (best_lo > 0 && ((par >> best_lo) & 1u)))
+    if (best_len <= second)
     {
       // (every k-mer's lists are known by now, and the express pass has this very rule: it would unpack the read, look
       //  everything up and decline as well -- the read goes to the general pass directly)
       GTX_HINT_NOTE(10);
       return HINT_TO_GENERAL;
     }
+    // A run that opens, behind a label-less k-mer, with a k-mer that brings TWO label lists (a multi-key list is added with
+    // 0 and with 1 mismatch, alignment.cpp:57-63; an exact key with indexed neighbours has its own and theirs) starts two
+    // parallel chains: see `twin` below.
+    par_start = best_lo > 0 && ((par >> best_lo) & 1u) != 0;
     lo = best_lo;
     hi = best_lo + best_len - 1;
   }
@@ -751,6 +756,7 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
     return set ? static_cast<uint32_t>(__builtin_ctz(set)) : (km >> HK_ALLELE_SHIFT) & 3u;
   };
   uint32_t head_site = 0, head_mask = 0; // the site the walk at the read's start crossed, with its best alleles
+  bool head_on_site = false;             // ... which started inside the allele the path carries on a site
   if (prs != 0) // walk_read_starts (genotype_paths.cpp:555-621)
   {
     uint32_t const y = lo == 1 ? f1.y : lo == 2 ? f2.y : lo == 3 ? f3.y : f4.y; // (position 31 lo is k-mer lo's own place)
@@ -761,6 +767,7 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
       // the walk leaves the node backwards: over the site in front of it (its base is read base ps), or -- the path
       // starts ON a site's base -- out of the allele it carries into the node in front
       bool const on_site = (y & 255u) == 0;
+      head_on_site = on_site;
       uint32_t const ps = on_site ? prs : prs - back - 1u;
       if (idx + ps == 0)
       {
@@ -898,12 +905,76 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
     return false;
   }
   uint32_t np = 1, longest = re - rs + 1;
+  if (par_start && rs == 0)
+  {
+    // Two parallel chains P0 (m mismatches) and P1 (m + 1) opened the run, and the walk at the read's start succeeded for
+    // both.  walk_read_starts then holds the same label list twice (genotype_paths.cpp:596-612): the first copy extends P0
+    // and P1, the second finds no path left to merge with and becomes a path D of its own over read bases 0 .. 31 lo
+    // (add_prev_kmer_labels, :282-290).  walk_read_ends visits P0, P1, D in that order with a shrinking budget (:497-531):
+    // D's walk runs over the k-mers AND the tail and has to come in at the tail's own mismatch count -- possible exactly
+    // when no k-mer of the run took its label from a Hamming-1 list.  D then grows into a full-length twin of P0 with the
+    // same mismatches, survives remove_paths_with_too_many_mismatches beside it (P1 does not), and the reference really
+    // returns the path twice.  With at most one site the twin's site list is P0's (the same walks, the same best alleles).
+    // Left to the general pass: a read without a tail (D is then measured against 7, not against the tail), a failed tail
+    // walk (D may overtake P0 alone), twins over several sites (the order of a walk's sites is the walk's business).
+    // The two chains walk alike unless the walk starts INSIDE a variant node and the second chain is another allele's (an
+    // exact k-mer whose neighbours are the site's other alleles: its walk starts with a mismatch, its list is not kept, no
+    // D): a multi-key list (an ambiguity code in the k-mer) gives the same labels twice wherever it starts.
+    // ... and the second chain has to live as long as the first: another allele's chain dies where the next k-mer names the
+    // site again (a SNP on the k-mer's last base is the next k-mer's first: Path(p1, p2) finds no allele in common).
+    uint32_t const amb_lo = hc_get(lo == 1 ? h.k[1] : lo == 2 ? h.k[2] : lo == 3 ? h.k[3] : h.k[4], HC_AMB);
+    uint2_t const f_lo = lo == 1 ? f1 : lo == 2 ? f2 : lo == 3 ? f3 : f4;
+    bool two_chains = amb_lo != 0;
+    if (!two_chains)
+    {
+      uint32_t const off = (f_lo.y >> HINT_SNPOFF_SHIFT) & 31u;
+      if ((f_lo.x & HINT_ALT_OK) == 0 || off == K - 1)
+      {
+        // (neighbours that are not a SNP's alleles; a SNP on the k-mer's last base -- the next k-mer's first: whether the
+        //  other allele's chain lives on depends on what kind of list that k-mer brings)
+        GTX_HINT_NOTE(10);
+        return HINT_TO_GENERAL;
+      }
+      two_chains = off != 0;
+    }
+    if (two_chains)
+    {
+      // D reaches the read's end at the tail's mismatch count when bases 31 lo .. pre - 1 hold none: no k-mer of the run
+      // took its label from a Hamming-1 list -- or only the last one did, for a substitution on its last base, which is the
+      // tail walk's first (the chain counted it twice, the twin counts it once and is returned ALONE, one mismatch less)
+      // (counted by the walks' rule -- an ambiguity code that is not N is a character of its own there, whatever its k-mer's
+      //  lists found -- against the linear reference, which is what the walk sees as long as the run carries reference
+      //  alleles only: a run with another allele or a set of alleles is left to the general pass)
+      uint32_t const mm_run = mmk & run, km_hi = hi == 0 ? k0 : hi == 1 ? k1 : hi == 2 ? k2 : hi == 3 ? k3 : k4;
+      auto plain = [&](uint32_t k, uint32_t km) { return ((run >> k) & 1u) == 0 || (km & ((3u << HK_ALLELE_SHIFT) | (255u << HK_SET_SHIFT))) == 0; };
+      if (!(plain(0, k0) && plain(1, k1) && plain(2, k2) && plain(3, k3) && plain(4, k4)))
+      {
+        GTX_HINT_NOTE(10);
+        return HINT_TO_GENERAL;
+      }
+      bool const region_clean = hc_upto(h, hi + 1) == hc_upto(h, lo);
+      bool const last_only = mm_run == (1u << hi) && hi + 1 <= 4 && hc_edge(h, hi + 1) == 1 && ((km_hi >> HK_SET_SHIFT) & 255u) == 0;
+      bool const twin = region_clean && (mm_run == 0 || last_only);
+      if (pre == L - 1 || re != L - 1 || (twin && nvar > 1))
+      {
+        GTX_HINT_NOTE(10);
+        return HINT_TO_GENERAL;
+      }
+      if (twin && mm_run == 0)
+        np = 2;
+      else if (twin)
+        --mism;
+    }
+  }
   if (mism > 10) // remove_paths_with_too_many_mismatches
   {
     np = 0;
     longest = 0;
   }
-  bool const to_stage = stage != nullptr && rec_words >= HINT_STAGE_WORDS && 6 + 3 * nvar <= HINT_STAGE_WORDS;
+  uint32_t const path_words = 4 + 3 * nvar;
+  if (2 + np * path_words > rec_words)
+    return false;
+  bool const to_stage = stage != nullptr && rec_words >= HINT_STAGE_WORDS && 2 + (np ? np : 1u) * path_words <= HINT_STAGE_WORDS;
   if (to_stage)
   {
     rec = stage;
@@ -934,6 +1005,9 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
     put(3, v3);
     put(4, v4);
     put(5, v5);
+    if (np == 2) // the twin: the same words again
+      for (uint32_t k = 0; k < path_words; ++k)
+        rec[2 + path_words + k] = rec[2 + k];
   }
   return to_stage ? 2u : 1u;
 }
