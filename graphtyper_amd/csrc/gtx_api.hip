@@ -883,20 +883,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_GENERAL_
 GTX_HBM_PASS_KERNEL(gtx_align_big_kernel, big)
 GTX_HBM_PASS_KERNEL(gtx_align_wide_kernel, wide)
 
-// Reads a table once, front to back (experiment, GTX_WARM=1: the global-lookup passes behind the position-hinted pass see
-// ~1 % of a batch, too few probes to warm anything themselves, and every one of theirs is a cold miss).
-__global__ __launch_bounds__(256) void gtx_warm_kernel(uint4_t const * __restrict__ p, uint64_t n16, uint32_t * sink)
-{
-  uint32_t acc = 0;
-  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
-  {
-    uint4_t const v = p[i];
-    acc ^= v.x ^ v.y ^ v.z ^ v.w;
-  }
-  if (acc == 0x9E3779B9u) // (keeps the loads alive)
-    atomicAdd(sink, 1u);
-}
-
 // BAM nibble rows -> plane rows (graph_dev.hpp), one thread per (read, group of 32 bases): the one-off repack of callers that
 // hold bam_get_seq bytes on the device (gtx_reads_to_planes), and what gtx_align_batch does with its nibble rows before the
 // alignment kernels -- which read planes only -- run.
@@ -1545,6 +1531,11 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
   // by memory latency -- ~6 000 wave instructions per task, one task per wavefront, a full grid holds all of a CU's LDS --
   // so its parts neither shrink with their share of the tasks (0.7 ms for a quarter of them against 1.0 ms for all) nor
   // leave room for the other stream: 3.1 / 3.6 / 4.7 / 6.6 ms per step with 1 / 2 / 4 / 8 parts.  Default: one part.
+  // (Round 3, same finding with the short queues behind the position-hinted pass: pass 1 on a second stream beside a first
+  //  launch of pass 2 over what pass 0 sent it, a second launch of pass 2 behind both -- 1.53 ms per step against 1.36 ms
+  //  one after the other; side by side pass 1 took 0.41 ms instead of 0.19 ms and the two launches of pass 2 0.74 ms instead
+  //  of 0.38 ms.  Reading every lookup table once in front of pass 1 (to spare it the cold misses) did not move it either:
+  //  the cost of a short queue on this chip is the launch itself, per wavefront, not the tables' first touch.)
   char const * ep = std::getenv("GTX_PARTS");
   uint32_t parts = 1u;
   if (ep)
@@ -1618,12 +1609,6 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
                          d_task_flags ? d_task_flags + 2ull * first : static_cast<uint8_t *>(nullptr));
       if (!hip_ok(hipGetLastError(), "gtx_align_hinted_kernel launch"))
         return GTX_ERR_HIP;
-      if (char const * ew = std::getenv("GTX_WARM"))
-        if (ew[0] != '0')
-          for (size_t k = 0; k < c->lookup_tables.size(); ++k)
-            if (ew[0] == '1' || (ew[0] - '2') == static_cast<int>(k)) // 1: every table, 2..5: one of them
-              hipLaunchKernelGGL(gtx_warm_kernel, dim3(n_cu * 8u), dim3(256), 0, st, static_cast<uint4_t const *>(c->lookup_tables[k].p),
-                                 c->lookup_tables[k].bytes / 16u, counters + 7);
       mark(part, 1, st);
       // (the queue's length is known on the device only: the grid is what can be resident, or one wavefront per group of four
       //  reads of a small batch; the kernel sizes its claims to the queue)

@@ -8,6 +8,6 @@ for cfg in "$@"; do
 import sys, json
 j = json.loads(sys.stdin.readline())
 k = j['roofline']['align_kernels']
-print('%.3f G/s  step %.3f ms | ' % (j['value'] / 1e9, j['ms_per_step']) + ' '.join('%s %.3f' % (n.replace('gtx_align_', '').replace('_kernel', ''), v['ms']) for n, v in k.items()))")
+print('%.3f G/s  step %.3f ms %s | ' % (j['value'] / 1e9, j['ms_per_step'], str(j['config'].get('calls_checksum'))[:12]) + ' '.join('%s %.3f' % (n.replace('gtx_align_', '').replace('_kernel', ''), v['ms']) for n, v in k.items()))")
   echo "[$cfg] $out" | tee -a gpurun_out/ab_env.log
 done; done
