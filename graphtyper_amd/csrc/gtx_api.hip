@@ -4,6 +4,7 @@
 //                wave owns its LDS workspace) per (read, orientation) task; persistent grid-stride over tasks.
 // score kernel : one thread per score item (an unpaired read or a mate pair); integer atomics into flat accumulators.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <cstdio>
@@ -619,7 +620,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
 #endif
 // (80 registers: six wavefronts per SIMD = three of these workgroups per CU, which their LDS also allows; the compiler
 // takes 83-85 when left alone -- allocated as 88: five wavefronts, two workgroups)
-__global__ __launch_bounds__(64 * GTX_HINT_WAVES) __attribute__((amdgpu_num_vgpr(GTX_HINT_VGPRS))) void gtx_align_hinted_kernel(GTX_HINTED_ARGS)
+__global__ __launch_bounds__(64 * GTX_HINT_WAVES) __attribute__((amdgpu_num_vgpr(GTX_HINT_VGPRS), amdgpu_waves_per_eu(6, 6))) void gtx_align_hinted_kernel(GTX_HINTED_ARGS)
 {
   GTX_HINTED_PASS(GTX_HINT_WAVES);
 }
@@ -1244,6 +1245,31 @@ static bool grow(T *& p, uint64_t & cap, uint64_t want, char const * what)
   return true;
 }
 
+// GraphView::pos_info / pos_back / pos_node from the node tables (gtx_host.cpp: flatten_graph has the host's form)
+__global__ __launch_bounds__(256) void gtx_pos_tables_kernel(GraphView g, uint32_t n, uint32_t * __restrict__ pos_info, uint8_t * __restrict__ pos_back,
+                                                             uint32_t * __restrict__ pos_node)
+{
+  uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  uint32_t const order = g.first_order + i;
+  uint32_t lo = 0, hi = g.n_ref; // the last reference node that starts at or in front of the position
+  while (hi - lo > 1)
+  {
+    uint32_t const mid = (lo + hi) >> 1;
+    if (g.ref_order[mid] <= order)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  uint32_t const d = order - g.ref_order[lo], len = g.ref_len[lo];
+  bool const inside = d < len;
+  uint32_t const room = len - d;
+  pos_info[i] = inside ? ((g.ref_dna[lo] + d) << 8) | (room < 255 ? room : 255) : INVALID;
+  pos_back[i] = static_cast<uint8_t>(inside ? (d < 255 ? d : 255) : 0);
+  pos_node[i] = inside ? lo : INVALID;
+}
+
 int ctx_upload(gtx_ctx & c, int device)
 {
   int n_dev = 0;
@@ -1260,6 +1286,15 @@ int ctx_upload(gtx_ctx & c, int device)
   if (!hip_ok(hipSetDevice(device), "hipSetDevice"))
     return GTX_ERR_HIP;
   c.device = device;
+  bool const timing = std::getenv("GTX_TIMING") != nullptr; // stage times on stderr
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](char const * what)
+  {
+    auto const now = std::chrono::steady_clock::now();
+    if (timing)
+      std::fprintf(stderr, "[gtx]   upload: %-22s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   HostGraph const & h = c.graph;
   GraphView v = h.view();
   bool ok = true;
@@ -1277,17 +1312,37 @@ int ctx_upload(gtx_ctx & c, int device)
   ok = ok && upload(c.dev_allocs, v.special_ref_reach, h.special_ref_reach.data(), h.special_ref_reach.size(), "special_ref_reach");
   ok = ok && upload(c.dev_allocs, v.special_actual, h.special_actual.data(), h.special_actual.size(), "special_actual");
   ok = ok && upload(c.dev_allocs, v.pos_bucket, h.pos_bucket.data(), h.pos_bucket.size(), "pos_bucket");
-  if (!h.pos_info.empty())
-  {
-    ok = ok && upload(c.dev_allocs, v.pos_info, h.pos_info.data(), h.pos_info.size(), "pos_info");
-    ok = ok && upload(c.dev_allocs, v.pos_back, h.pos_back.data(), h.pos_back.size(), "pos_back");
-    ok = ok && upload(c.dev_allocs, v.pos_node, h.pos_node.data(), h.pos_node.size(), "pos_node");
-  }
   ok = ok && upload(c.dev_allocs, v.dna, h.codes.data(), h.codes.size(), "dna codes");
+  if (ok && h.pos_table_len != 0)
+  {
+    // position -> where its base is, how far its reference node goes on and back, which node it is: made here from the
+    // node tables (flatten_graph fills the host's copies for contexts without a device only)
+    uint32_t const n = h.pos_table_len;
+    void *pi = nullptr, *pb = nullptr, *pn = nullptr;
+    ok = hip_ok(gtx::dev_malloc(&pi, n * sizeof(uint32_t)), "pos_info");
+    if (ok)
+      c.dev_allocs.push_back(pi);
+    ok = ok && hip_ok(gtx::dev_malloc(&pb, n), "pos_back");
+    if (ok)
+      c.dev_allocs.push_back(pb);
+    ok = ok && hip_ok(gtx::dev_malloc(&pn, n * sizeof(uint32_t)), "pos_node");
+    if (ok)
+    {
+      c.dev_allocs.push_back(pn);
+      v.pos_info = static_cast<uint32_t *>(pi);
+      v.pos_back = static_cast<uint8_t *>(pb);
+      v.pos_node = static_cast<uint32_t *>(pn);
+      v.n_pos_info = n;
+      hipLaunchKernelGGL(gtx_pos_tables_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, v, n, static_cast<uint32_t *>(pi),
+                         static_cast<uint8_t *>(pb), static_cast<uint32_t *>(pn));
+      ok = hip_ok(hipGetLastError(), "gtx_pos_tables_kernel launch");
+    }
+  }
   ok = ok && upload(c.dev_allocs, v.tri_off, h.tri_off.data(), h.tri_off.size(), "tri_off");
   ok = ok && upload(c.dev_allocs, v.allele_off, h.allele_off.data(), h.allele_off.size(), "allele_off");
   ok = ok && upload(c.dev_allocs, v.near_last, h.near_last.data(), h.near_last.size(), "near_last");
   ok = ok && upload(c.dev_allocs, v.near_off, h.near_off.data(), h.near_off.size(), "near_off");
+  lap("graph tables");
   void * pf = nullptr;
   ok = ok && hip_ok(gtx::dev_malloc(&pf, 32 * sizeof(unsigned long long)), "profile counters");
   if (ok)
@@ -1304,8 +1359,10 @@ int ctx_upload(gtx_ctx & c, int device)
     c.d_error_flag = static_cast<uint32_t *>(ef);
     ok = hip_ok(hipMemset(ef, 0, sizeof(uint32_t)), "error flag");
   }
+  lap("counters");
   hipDeviceProp_t prop;
   bool const have_prop = hipGetDeviceProperties(&prop, device) == hipSuccess;
+  lap("device properties");
   if (have_prop)
     c.n_cu = prop.multiProcessorCount;
   if (ok && !c.params.no_second_pass)
@@ -1330,6 +1387,7 @@ int ctx_upload(gtx_ctx & c, int device)
   }
   if (!ok)
     return GTX_ERR_HIP;
+  lap("second-pass arena");
   c.dev_graph = v;
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_kernel, 64, 0) == hipSuccess && per_cu > 0)
@@ -1340,10 +1398,12 @@ int ctx_upload(gtx_ctx & c, int device)
     c.express4_blocks_per_cu = per_cu;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express4_wide_kernel, 64, 0) == hipSuccess && per_cu > 0)
     c.express4_wide_blocks_per_cu = per_cu;
+  lap("occupancy queries");
   // the first scratch now, so that the first call does not pay for it
   auto s = scratch_new(c);
   if (!s)
     return GTX_ERR_HIP;
+  lap("first scratch");
   c.pool.push_back(std::move(s));
   return GTX_OK;
 }

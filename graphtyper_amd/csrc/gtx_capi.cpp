@@ -48,9 +48,19 @@ extern "C"
       return GTX_ERR_ARG;
     }
     *out = nullptr;
+    bool const timing = std::getenv("GTX_TIMING") != nullptr; // stage times on stderr
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](char const * what)
+    {
+      auto const now = std::chrono::steady_clock::now();
+      if (timing)
+        std::fprintf(stderr, "[gtx] ctx_create %-24s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+      t_last = now;
+    };
     auto c = std::make_unique<gtx_ctx>();
     c->params = *params;
-    std::string const err = flatten_graph(*graph, *params, c->graph);
+    std::string const err = flatten_graph(*graph, *params, c->graph, device < 0); // (a device makes its position tables itself)
+    lap("flatten the graph (host)");
     if (!err.empty())
     {
       g_last_error = err;
@@ -68,47 +78,16 @@ extern "C"
     }
     else
     {
-      // the host enumerates the 32-mers (index_graph's sweep) and derives the graph's own hint arrays; everything
-      // else -- grouping, hash tables, hint tables -- is built on the device (gtx_index_dev.hip)
-      bool const timing = std::getenv("GTX_TIMING") != nullptr; // stage times on stderr
-      auto t_last = std::chrono::steady_clock::now();
-      auto lap = [&](char const * what)
-      {
-        auto const now = std::chrono::steady_clock::now();
-        if (timing)
-          std::fprintf(stderr, "[gtx] ctx_create %-24s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
-        t_last = now;
-      };
+      // the host lists the 32-mers of the sweep that walk through a site (index_graph's sweep); the ones inside a reference
+      // node -- one per position -- and everything else, grouping, hash tables, hint tables, are made on the device
+      // (gtx_index_dev.hip).  GTX_INDEX_RUNS=0: the host lists every k-mer (A/B, tests).
       std::vector<Emit> em;
-      HintGraphTables gt;
-      {
-        // (the graph's own hint arrays are a serial pass over its positions, ~10 ms per Mb: beside the enumeration)
-        std::exception_ptr side_error;
-        std::thread side([&] {
-          try
-          {
-            hint_graph_tables(c->graph, gt);
-          }
-          catch (...)
-          {
-            side_error = std::current_exception();
-          }
-        });
-        try
-        {
-          enumerate_kmers(c->graph, em);
-        }
-        catch (...)
-        {
-          side.join();
-          throw;
-        }
-        side.join();
-        if (side_error)
-          std::rethrow_exception(side_error);
-      }
-      lap("enumerate k-mers + graph hint arrays (host)");
-      if (em.size() >= SLOT_OFF_MASK) // (label offsets are 31 bits in the index slots: gtx_flat.hpp, SLOT_NB_KNOWN)
+      std::vector<EmitRun> runs;
+      char const * er = std::getenv("GTX_INDEX_RUNS");
+      bool const with_runs = !(er && er[0] == '0');
+      enumerate_kmers(c->graph, em, with_runs ? &runs : nullptr);
+      lap("list the k-mers through sites (host)");
+      if (em.size() + (runs.empty() ? 0ull : static_cast<uint64_t>(runs.back().dev_before) + runs.back().count) >= SLOT_OFF_MASK) // (label offsets are 31 bits in the index slots: gtx_flat.hpp, SLOT_NB_KNOWN)
       {
         gtx::g_last_error = "gtx_ctx_create: more than 2^31 k-mer labels in one region";
         return GTX_ERR_UNSUPPORTED;
@@ -116,7 +95,7 @@ extern "C"
       int rc = ctx_upload(*c, device);
       lap("graph upload + scratch");
       if (rc == GTX_OK)
-        rc = build_index_device(*c, em, gt);
+        rc = build_index_device(*c, em, runs);
       lap("index build (device)");
       if (rc != GTX_OK)
       {
@@ -279,6 +258,31 @@ extern "C"
     }
     if (labels && !ix.labels.empty())
       std::memcpy(labels, ix.labels.data(), sizeof(gtx_label) * ix.labels.size());
+    return GTX_OK;
+  }
+
+  int gtx_ctx_hint_table(const gtx_ctx * c, int which, void * out, uint64_t cap_bytes, uint64_t * bytes)
+  {
+    if (!c || !bytes || which < 0 || which > 4)
+      return GTX_ERR_ARG;
+    if (c->device >= 0)
+      return download_hint_table(*c, which, out, cap_bytes, bytes);
+    HostIndex const & ix = c->index;
+    void const * src = nullptr;
+    uint64_t n = 0;
+    switch (which)
+    {
+    case 0: src = ix.pos_flags.data(); n = ix.pos_flags.size() * sizeof(uint2_t); break;
+    case 1: src = ix.refp.data(); n = ix.refp.size() * sizeof(uint32_t); break;
+    case 2: src = ix.tail_info.data(); n = ix.tail_info.size() * sizeof(uint2_t); break;
+    default: src = ix.filt[which - 3].data(); n = ix.filt[which - 3].size() * sizeof(uint32_t); break;
+    }
+    *bytes = n;
+    if (!out)
+      return GTX_OK;
+    if (cap_bytes < n)
+      return GTX_ERR_CAPACITY;
+    std::memcpy(out, src, n);
     return GTX_OK;
   }
 

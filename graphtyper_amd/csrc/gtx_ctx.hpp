@@ -107,6 +107,7 @@ namespace gtx
 extern thread_local std::string g_last_error;
 int ctx_upload(gtx_ctx & c, int device); // graph tables + per-call scratch (no index)
 void ctx_release_device(gtx_ctx & c);
-int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, HintGraphTables const & gt); // gtx_index_dev.hip
+int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<EmitRun> const & runs); // gtx_index_dev.hip
 int download_index(gtx_ctx & c);
+int download_hint_table(gtx_ctx const & c, int which, void * out, uint64_t cap_bytes, uint64_t * bytes); // gtx_index_dev.hip
 } // namespace gtx

@@ -208,6 +208,9 @@ struct HostGraph
   uint32_t n_hap = 0;
   uint32_t padding = 1000;
   bool is_sv_graph = false;
+  // positions the pos_info / pos_back / pos_node tables cover (0: the arena is too large for them); the vectors themselves
+  // are filled for host use only -- a device context makes the tables on its device (flatten_graph: host_positions)
+  uint32_t pos_table_len = 0;
 
   GraphView view() const;
 };
@@ -236,7 +239,7 @@ struct HostIndex
 };
 
 // returns "" on success, else a description of what is wrong with the view
-std::string flatten_graph(gtx_graph_view const & g, gtx_params const & par, HostGraph & out);
+std::string flatten_graph(gtx_graph_view const & g, gtx_params const & par, HostGraph & out, bool host_positions = true);
 
 // one indexed 32-mer occurrence as the enumeration emits it (emission order = the reference's bucket order)
 struct Emit
@@ -255,7 +258,14 @@ struct HintGraphTables
   uint32_t hint_first = 0, n = 0; // n = 0: the graph has too many sites for the tables (no position-hinted pass)
 };
 
+// the in-node k-mers of reference node `node` from its 32nd position on (one per position), left to the device: `count` of
+// them, behind `host_before` listed k-mers and `dev_before` k-mers of earlier runs in the sweep's order
+struct EmitRun
+{
+  uint32_t node, host_before, dev_before, count;
+};
 void enumerate_kmers(HostGraph const & g, std::vector<Emit> & out);                 // index_graph's sweep (host threads)
+void enumerate_kmers(HostGraph const & g, std::vector<Emit> & out, std::vector<EmitRun> * runs); // ... with the in-node runs left out
 void hint_graph_tables(HostGraph const & g, HintGraphTables & out);
 void build_tables_host(HostGraph const & g, std::vector<Emit> const & em, HostIndex & out); // grouping, hash tables, hint tables
 void build_index(HostGraph const & g, HostIndex & out);                             // both of the above

@@ -59,7 +59,7 @@ GraphView HostGraph::view() const
   return v;
 }
 
-std::string flatten_graph(gtx_graph_view const & g, gtx_params const & par, HostGraph & out)
+std::string flatten_graph(gtx_graph_view const & g, gtx_params const & par, HostGraph & out, bool host_positions)
 {
   if (g.n_ref == 0)
     return "graph has no reference node";
@@ -99,17 +99,15 @@ std::string flatten_graph(gtx_graph_view const & g, gtx_params const & par, Host
   }
   // comparison codes: IUPAC letters keep their BAM 4-bit code, '<' / '>' kill a walk, anything else matches nothing
   out.codes.resize(out.dna.size());
-  for (size_t i = 0; i < out.dna.size(); ++i)
   {
-    char const c = out.dna[i];
+    uint8_t code_of[256];
+    std::memset(code_of, 0x40, sizeof(code_of));
     char const * tbl = "=ACMGRSVTWYHKDBN";
-    uint8_t code = 0x40;
     for (int k = 1; k < 16; ++k)
-      if (tbl[k] == c)
-        code = static_cast<uint8_t>(k);
-    if (c == '<' || c == '>')
-      code = 0x80;
-    out.codes[i] = static_cast<char>(code);
+      code_of[static_cast<uint8_t>(tbl[k])] = static_cast<uint8_t>(k);
+    code_of[static_cast<uint8_t>('<')] = code_of[static_cast<uint8_t>('>')] = 0x80;
+    for (size_t i = 0; i < out.dna.size(); ++i)
+      out.codes[i] = static_cast<char>(code_of[static_cast<uint8_t>(out.dna[i])]);
   }
   // structure: ref r -> vars [first, first+nvar) -> ref r+1
   uint32_t next_var = 0;
@@ -192,7 +190,8 @@ std::string flatten_graph(gtx_graph_view const & g, gtx_params const & par, Host
   out.pos_info.clear();
   out.pos_back.clear();
   out.pos_node.clear();
-  if (out.codes.size() < (1u << 24))
+  out.pos_table_len = out.codes.size() < (1u << 24) ? last - first : 0u;
+  if (out.pos_table_len != 0 && host_positions)
   {
     out.pos_info.assign(last - first, INVALID);
     out.pos_back.assign(last - first, 0);
@@ -723,27 +722,50 @@ void build_index(HostGraph const & g, HostIndex & out)
 
 // index_graph's sweep (indexer.cpp:246-291): every end position is independent, so the reference nodes (with the site
 // behind each) are cut into contiguous ranges for the host team; concatenated in order the ranges give the sweep's order.
-void enumerate_kmers(HostGraph const & g, std::vector<Emit> & em)
+void enumerate_kmers(HostGraph const & g, std::vector<Emit> & em) { enumerate_kmers(g, em, nullptr); }
+
+// With `runs`: the k-mers that lie inside ONE reference node of plain A/C/G/T -- one per position, all but the first 31
+// of a node -- are not listed but left to the device as runs (node, count); the list keeps everything that walks through a
+// site.  runs[i].host_before / dev_before place both kinds in the sweep's order (gtx_index_dev.hip, k_emit_runs).
+void enumerate_kmers(HostGraph const & g, std::vector<Emit> & em, std::vector<EmitRun> * runs)
 {
   uint32_t const R = static_cast<uint32_t>(g.ref_order.size());
   // (the one stage of a device context's build that is still on the host; its slices are long and independent, so it takes
   // a larger team than the other stages: 8 / 16 / 32 / 64 threads = 62 / 42 / 28 / 22 ms on the merged-cluster graph)
+  // (with runs the host's share is the positions within 31 bases behind a site and the sites' own: a small team does unless
+  //  the graph is mostly sites)
+  auto weight = [&](uint32_t r) -> uint64_t
+  {
+    if (!runs)
+      return g.ref_len[r] + 8;
+    uint64_t w = std::min<uint32_t>(g.ref_len[r], K - 1) + g.ref_len[r] / 64 + 1; // (+ the scan for other characters)
+    if (r + 1 < R)
+      for (uint32_t a = 0; a < g.ref_nvar[r]; ++a)
+        w += g.var_len[g.ref_first_var[r] + a];
+    return w;
+  };
+  uint64_t total = 0;
+  for (uint32_t r = 0; r < R; ++r)
+    total += weight(r);
   unsigned T = R < 64 ? 1u : host_threads();
   if (T > 1 && !std::getenv("GTX_HOST_THREADS"))
-    T = std::max(T, std::min(std::thread::hardware_concurrency(), 64u));
+  {
+    if (runs && total < 400000)
+      T = std::min(T, 4u);
+    else
+      T = std::max(T, std::min(std::thread::hardware_concurrency(), 64u));
+  }
   std::vector<std::vector<Emit>> part(T);
-  // ranges of equal sequence length
+  std::vector<std::vector<EmitRun>> part_runs(T);
+  // ranges of equal weight
   std::vector<uint32_t> cut(T + 1, R);
   {
-    uint64_t total = 0;
-    for (uint32_t r = 0; r < R; ++r)
-      total += g.ref_len[r] + 8;
     uint64_t run = 0;
     unsigned t = 1;
     cut[0] = 0;
     for (uint32_t r = 0; r < R && t < T; ++r)
     {
-      run += g.ref_len[r] + 8;
+      run += weight(r);
       if (run * T >= total * t)
         cut[t++] = r + 1;
     }
@@ -756,16 +778,29 @@ void enumerate_kmers(HostGraph const & g, std::vector<Emit> & em)
       return;
     uint64_t bases = 0;
     for (uint32_t r = r0; r < r1; ++r)
-      bases += g.ref_len[r];
+      bases += runs ? weight(r) : g.ref_len[r];
     out.reserve(bases + bases / 4 + 64);
     Walker w{g, out, !g.event_off.empty()};
     for (uint32_t r = r0; r < r1; ++r)
     {
       // fast path inside a reference node: a rolling 2-bit window while the k-mer stays within this node
       char const * dna = g.dna.data() + g.ref_dna[r];
-      uint32_t const len = g.ref_len[r];
+      uint32_t len = g.ref_len[r];
+      if (runs && len >= K)
+      {
+        bool plain = true;
+        for (uint32_t d = 0; d < len && plain; ++d)
+          plain = Walker::code(dna[d]) >= 0;
+        if (plain)
+        {
+          len = K - 1; // the positions whose window reaches back past the node's start, here; the others are the device's
+          part_runs[t].push_back(EmitRun{r, static_cast<uint32_t>(out.size()), 0u, g.ref_len[r] - (K - 1)});
+        }
+      }
       uint64_t roll = 0;
       uint32_t valid = 0;
+      // (a run's place in the list: behind the first 31 positions' k-mers -- set below)
+      EmitRun * const my_run = runs && len != g.ref_len[r] ? &part_runs[t].back() : nullptr;
       for (uint32_t d = 0; d < len; ++d)
       {
         int const c = Walker::code(dna[d]);
@@ -785,6 +820,8 @@ void enumerate_kmers(HostGraph const & g, std::vector<Emit> & em)
           w.back_ref(r, d, 0, 0);
         }
       }
+      if (my_run)
+        my_run->host_before = static_cast<uint32_t>(out.size());
       if (r + 1 == R || g.ref_nvar[r] == 0)
         continue;
       uint32_t const fv = g.ref_first_var[r];
@@ -810,13 +847,29 @@ void enumerate_kmers(HostGraph const & g, std::vector<Emit> & em)
     for (auto & th : team)
       th.join();
   }
-  std::size_t total = 0;
+  std::size_t listed = 0;
   for (auto const & p : part)
-    total += p.size();
+    listed += p.size();
   em.clear();
-  em.reserve(total);
+  em.reserve(listed);
   for (auto const & p : part)
     em.insert(em.end(), p.begin(), p.end());
+  if (runs)
+  {
+    runs->clear();
+    uint32_t host_base = 0, dev = 0;
+    for (unsigned t = 0; t < T; ++t)
+    {
+      for (EmitRun e : part_runs[t])
+      {
+        e.host_before += host_base;
+        e.dev_before = dev;
+        dev += e.count;
+        runs->push_back(e);
+      }
+      host_base += static_cast<uint32_t>(part[t].size());
+    }
+  }
 }
 
 void build_tables_host(HostGraph const & g, std::vector<Emit> const & em, HostIndex & out)

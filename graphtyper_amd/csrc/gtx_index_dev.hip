@@ -328,6 +328,128 @@ __global__ void k_position_flags(GraphView g, HintKeys t, uint32_t const * nb, u
     flags[p] = hint_position_flags(g, t, nb, nb_same, base, room, back, n, p);
 }
 
+// ---- the sweep's k-mers that lie inside one reference node of plain A/C/G/T (gtx_flat.hpp: EmitRun), one thread each:
+// the k-mer that starts at base k of the run's node, at its place in the sweep's order (host_before listed k-mers and
+// dev_before run k-mers in front of the run: index host_before + t for the t-th run k-mer overall)
+__global__ void k_emit_runs(GraphView g, EmitRun const * __restrict__ runs, uint32_t n_runs, uint32_t total, uint64_t * __restrict__ keys,
+                            gtx_label * __restrict__ labels)
+{
+  uint32_t const t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total)
+    return;
+  uint32_t lo = 0, hi = n_runs; // the last run with dev_before <= t
+  while (hi - lo > 1)
+  {
+    uint32_t const mid = (lo + hi) >> 1;
+    if (runs[mid].dev_before <= t)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  EmitRun const r = runs[lo];
+  uint32_t const k = t - r.dev_before;
+  char const * dna = g.dna + g.ref_dna[r.node] + k;
+  uint64_t key = 0;
+#pragma unroll 8
+  for (uint32_t i = 0; i < K; ++i) // (codes 1 2 4 8 = A C G T: the host checked the node)
+    key = (key << 2) | static_cast<uint64_t>(__ffs(static_cast<int>(dna[i])) - 1);
+  uint32_t const at = r.host_before + t, first = g.ref_order[r.node] + k;
+  keys[at] = key;
+  labels[at] = gtx_label{first, first + (K - 1), INVALID};
+}
+
+// ... and the listed ones to theirs: the j-th listed k-mer has the k-mers of every run with host_before <= j in front of it
+__global__ void k_place_listed(EmitRun const * __restrict__ runs, uint32_t n_runs, uint64_t const * __restrict__ lkeys,
+                               gtx_label const * __restrict__ llabels, uint32_t n, uint64_t * __restrict__ keys, gtx_label * __restrict__ labels)
+{
+  uint32_t const j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n)
+    return;
+  uint32_t lo = 0, hi = n_runs; // number of runs with host_before <= j
+  while (lo < hi)
+  {
+    uint32_t const mid = (lo + hi) >> 1;
+    if (runs[mid].host_before <= j)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  uint32_t const at = j + (lo ? runs[lo - 1].dev_before + runs[lo - 1].count : 0u);
+  keys[at] = lkeys[j];
+  labels[at] = llabels[j];
+}
+
+// ---- what the position-hinted pass needs of the graph alone (gtx_host.cpp: hint_graph_tables, the host's form): per
+// position of the linear reference its nibble, the bases of its reference node in front of and behind it, the site behind
+// its node as a tail walk may cross it; the reference as bit planes (a wavefront's 64 positions are two plane groups)
+__global__ void k_hint_graph(GraphView g, uint32_t n, uint8_t * __restrict__ base, uint8_t * __restrict__ room, uint8_t * __restrict__ back,
+                             uint2_t * __restrict__ tail, uint32_t * __restrict__ refp)
+{
+  uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t b = 0; // (behind the last position: no plane bit)
+  if (i < n)
+  {
+    auto nib = [](char c) -> uint32_t { return (c == 1 || c == 2 || c == 4 || c == 8) ? static_cast<uint32_t>(c) : 15u; };
+    uint32_t const order = g.first_order + i;
+    uint32_t lo = 0, hi = g.n_ref; // the last reference node that starts at or in front of the position
+    while (hi - lo > 1)
+    {
+      uint32_t const mid = (lo + hi) >> 1;
+      if (g.ref_order[mid] <= order)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    uint32_t const r = lo, d = order - g.ref_order[r], len = g.ref_len[r];
+    uint32_t rm = 0, bk = 0;
+    uint2_t ti{0, 0};
+    b = 15;
+    if (d < len)
+    {
+      b = nib(g.dna[g.ref_dna[r] + d]);
+      rm = len - d < 255 ? len - d : 255;
+      bk = d < 255 ? d : 255;
+      if (r + 1 < g.n_ref && !g.is_sv_graph)
+      {
+        uint32_t const fv = g.ref_first_var[r], nv = g.ref_nvar[r];
+        bool snp = nv >= 2 && nv <= 4;
+        uint32_t codes = 0;
+        for (uint32_t a = 0; a < nv && snp; ++a)
+        {
+          uint32_t const c = g.var_len[fv + a] == 1 ? nib(g.dna[g.var_dna[fv + a]]) : 15u;
+          snp = c != 15;
+          codes |= c << (4 * a);
+        }
+        if (snp)
+        {
+          uint32_t const next_len = g.ref_len[r + 1] < 255 ? g.ref_len[r + 1] : 255;
+          ti = uint2_t{HINT_TAIL_OK | (nv << HINT_TAIL_NALL_SHIFT) | (next_len << HINT_TAIL_NEXT_SHIFT) | (codes << HINT_TAIL_CODES_SHIFT), r};
+        }
+      }
+    }
+    else if (r + 1 < g.n_ref && g.ref_nvar[r] != 0)
+    {
+      uint32_t const v = g.ref_first_var[r], dv = order - g.var_order[v]; // (allele 0 of the site: the linear reference)
+      if (order >= g.var_order[v] && dv < g.var_len[v])
+        b = nib(g.dna[g.var_dna[v] + dv]);
+    }
+    base[i] = static_cast<uint8_t>(b);
+    room[i] = static_cast<uint8_t>(rm);
+    back[i] = static_cast<uint8_t>(bk);
+    tail[i] = ti;
+  }
+#pragma unroll
+  for (uint32_t bit = 0; bit < 4; ++bit)
+  {
+    unsigned long long const m = __ballot((b >> bit) & 1u);
+    if ((threadIdx.x & 63u) == 0)
+    {
+      refp[4 * (i >> 5) + bit] = static_cast<uint32_t>(m);
+      refp[4 * ((i >> 5) + 1) + bit] = static_cast<uint32_t>(m >> 32);
+    }
+  }
+}
+
 template <class T>
 bool to_device(Pool & pool, T *& d, std::vector<T> const & h, char const * what)
 {
@@ -383,33 +505,63 @@ bool groups_of(Pool & pool, uint32_t const * head, uint32_t n, uint32_t *& begin
 // Builds every index table on the device of `c` (its graph is already there: c.dev_graph) from the sweep's emission list.
 // Fills c.dev_index and the index facts the host keeps (key / label counts, the pass-1 build choice, device copies of
 // keys / key_off / labels for the inspection entry points).
-int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, HintGraphTables const & gt)
+int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<EmitRun> const & runs)
 {
   Pool pool;
-  uint32_t const E = static_cast<uint32_t>(em.size());
-  if (em.size() >= (1ull << 31))
+  uint32_t const n_listed = static_cast<uint32_t>(em.size());
+  uint64_t const n_run_kmers = runs.empty() ? 0ull : static_cast<uint64_t>(runs.back().dev_before) + runs.back().count;
+  if (em.size() + n_run_kmers >= (1ull << 31))
   {
     g_last_error = "index build: more than 2^31 indexed k-mers in one region";
     return GTX_ERR_UNSUPPORTED;
   }
+  uint32_t const E = n_listed + static_cast<uint32_t>(n_run_kmers);
   IndexView ix{};
   ix.max_index_labels = static_cast<uint32_t>(c.params.max_index_labels);
   ix.half_bucket_cap = HALF_BUCKET_CAP;
   if (char const * e = std::getenv("GTX_HALF_BUCKET_CAP")) // A/B switch for benchmarking: 0 = probe the 96 neighbours directly
     ix.half_bucket_cap = static_cast<uint32_t>(std::min<long>(std::max<long>(std::atol(e), 0), HALF_BUCKET_CAP));
-  // ---- emission list to the device (structure of arrays)
-  std::vector<uint64_t> h_keys(E);
-  std::vector<gtx_label> h_labels(E);
-  for (uint32_t i = 0; i < E; ++i)
-  {
-    h_keys[i] = em[i].key;
-    h_labels[i] = em[i].label;
-  }
-  uint64_t *d_keys_in = nullptr, *d_sorted = pool.get<uint64_t>(E, "sorted keys");
-  gtx_label * d_labels_in = nullptr;
+  // ---- emission list on the device (structure of arrays): the listed k-mers from the host, the runs' made here
+  uint64_t *d_keys_in = pool.get<uint64_t>(E, "emitted keys"), *d_sorted = pool.get<uint64_t>(E, "sorted keys");
+  gtx_label * d_labels_in = pool.get<gtx_label>(E, "emitted labels");
   uint32_t *d_iota = pool.get<uint32_t>(E, "iota"), *d_perm = pool.get<uint32_t>(E, "permutation");
-  if (!to_device(pool, d_keys_in, h_keys, "emitted keys") || !to_device(pool, d_labels_in, h_labels, "emitted labels") || !pool.fine)
+  if (!pool.fine)
     return GTX_ERR_HIP;
+  if (runs.empty())
+  {
+    std::vector<uint64_t> h_keys(E);
+    std::vector<gtx_label> h_labels(E);
+    for (uint32_t i = 0; i < E; ++i)
+    {
+      h_keys[i] = em[i].key;
+      h_labels[i] = em[i].label;
+    }
+    if (E != 0 && (!ok_hip(hipMemcpy(d_keys_in, h_keys.data(), E * sizeof(uint64_t), hipMemcpyHostToDevice), "emitted keys") ||
+                   !ok_hip(hipMemcpy(d_labels_in, h_labels.data(), E * sizeof(gtx_label), hipMemcpyHostToDevice), "emitted labels")))
+      return GTX_ERR_HIP;
+  }
+  else
+  {
+    std::vector<uint64_t> h_keys(n_listed);
+    std::vector<gtx_label> h_labels(n_listed);
+    for (uint32_t i = 0; i < n_listed; ++i)
+    {
+      h_keys[i] = em[i].key;
+      h_labels[i] = em[i].label;
+    }
+    uint64_t * d_lkeys = nullptr;
+    gtx_label * d_llabels = nullptr;
+    EmitRun * d_runs = nullptr;
+    if (!to_device(pool, d_lkeys, h_keys, "listed keys") || !to_device(pool, d_llabels, h_labels, "listed labels") ||
+        !to_device(pool, d_runs, runs, "k-mer runs"))
+      return GTX_ERR_HIP;
+    uint32_t const n_runs = static_cast<uint32_t>(runs.size());
+    hipLaunchKernelGGL(k_emit_runs, dim3(blocks_for(n_run_kmers)), dim3(TB), 0, nullptr, c.dev_graph, d_runs, n_runs,
+                       static_cast<uint32_t>(n_run_kmers), d_keys_in, d_labels_in);
+    if (n_listed)
+      hipLaunchKernelGGL(k_place_listed, dim3(blocks_for(n_listed)), dim3(TB), 0, nullptr, d_runs, n_runs, d_lkeys, d_llabels, n_listed, d_keys_in,
+                         d_labels_in);
+  }
   uint32_t n_keys = 0;
   uint64_t * d_keys = nullptr;
   uint32_t * d_key_off = nullptr;
@@ -497,23 +649,27 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, HintGraphTable
   uint32_t fl = 5;
   while ((1ull << fl) < static_cast<uint64_t>(n_keys) + 1 && fl < 28)
     ++fl;
-  bool const hints = gt.n != 0;
+  // (the graph's own part of them -- gtx_host.cpp: hint_graph_tables is the host's form -- is made here as well)
+  uint32_t const R = static_cast<uint32_t>(c.graph.ref_order.size());
+  uint32_t const hint_first = R ? c.graph.ref_order[0] - 1 : 0; // order = 1-based contig position
+  uint32_t const hint_n = (R == 0 || R - 1 >= HINT_NO_SITE) ? 0u : c.graph.ref_order[R - 1] + c.graph.ref_len[R - 1] - c.graph.ref_order[0];
+  bool const hints = hint_n != 0;
   uint32_t *d_f0 = pool.get<uint32_t>(hints ? (1ull << fl) : 1, "filter 0", true), *d_f1 = pool.get<uint32_t>(hints ? (1ull << fl) : 1, "filter 1", true);
-  uint2_t * d_flags = pool.get<uint2_t>(hints ? gt.n : 1, "position flags", true);
-  uint32_t * d_refp = nullptr;
-  uint2_t * d_tail = nullptr;
-  std::vector<uint32_t> const one_word(32, 0);
-  std::vector<uint2_t> const one_pair(1, uint2_t{0, 0});
-  if (!to_device(pool, d_refp, hints ? gt.refp : one_word, "reference planes") || !to_device(pool, d_tail, hints ? gt.tail_info : one_pair, "tail sites"))
+  uint2_t * d_flags = pool.get<uint2_t>(hints ? hint_n : 1, "position flags", true);
+  // (padded: the kernel loads 6 plane groups from any position without a bounds test)
+  uint32_t * d_refp = pool.get<uint32_t>(hints ? 4 * (static_cast<size_t>(hint_n) / 32 + 8) : 32, "reference planes", true);
+  uint2_t * d_tail = pool.get<uint2_t>(hints ? hint_n : 1, "tail sites", !hints);
+  if (!pool.fine)
     return GTX_ERR_HIP;
   if (hints)
   {
-    uint8_t *d_base = nullptr, *d_room = nullptr, *d_back = nullptr;
+    uint8_t *d_base = pool.get<uint8_t>(hint_n, "reference bases"), *d_room = pool.get<uint8_t>(hint_n, "node room"),
+            *d_back = pool.get<uint8_t>(hint_n, "node back");
     uint32_t * d_nb = pool.get<uint32_t>(n_keys, "neighbour labels");
     uint8_t * d_same = pool.get<uint8_t>(n_keys, "neighbour verdicts");
-    if (!to_device(pool, d_base, gt.base, "reference bases") || !to_device(pool, d_room, gt.room, "node room") ||
-        !to_device(pool, d_back, gt.back, "node back") || !pool.fine)
+    if (!pool.fine)
       return GTX_ERR_HIP;
+    hipLaunchKernelGGL(k_hint_graph, dim3((hint_n + TB - 1) / TB), dim3(TB), 0, nullptr, c.dev_graph, hint_n, d_base, d_room, d_back, d_tail, d_refp);
     HintKeys const t{d_keys, d_key_off, d_dev_labels, n_keys, d_lbegin, d_lsize, d_rorder, d_rbegin, d_rsize};
     if (n_keys)
     {
@@ -521,7 +677,7 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, HintGraphTable
       hipLaunchKernelGGL(k_judge_keys, dim3(blocks_for(n_keys)), dim3(TB), 0, nullptr, t, d_nb, d_same, d_f0, d_f1, fl, d_pk,
                          (nbk && nbk[0] == '0') ? static_cast<IndexSlot *>(nullptr) : d_slots, log2_cap);
     }
-    hipLaunchKernelGGL(k_position_flags, dim3(blocks_for(gt.n)), dim3(TB), 0, nullptr, c.dev_graph, t, d_nb, d_same, d_base, d_room, d_back, gt.n, d_flags);
+    hipLaunchKernelGGL(k_position_flags, dim3(blocks_for(hint_n)), dim3(TB), 0, nullptr, c.dev_graph, t, d_nb, d_same, d_base, d_room, d_back, hint_n, d_flags);
   }
   uint32_t several = 0;
   if (!ok_hip(hipGetLastError(), "kernels") || !ok_hip(hipDeviceSynchronize(), "kernels") ||
@@ -539,8 +695,8 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, HintGraphTable
   ix.tail_info = pool.keep(d_tail, c.dev_allocs);
   ix.filt[0] = pool.keep(d_f0, c.dev_allocs);
   ix.filt[1] = pool.keep(d_f1, c.dev_allocs);
-  ix.hint_first = gt.hint_first;
-  ix.n_hint = gt.n;
+  ix.hint_first = hint_first;
+  ix.n_hint = hint_n;
   ix.filt_log2 = hints ? fl : 0;
   c.dev_index = ix;
   c.lookup_tables = {{d_slots, (static_cast<uint64_t>(BUCKET_SLOTS) << log2_cap) * sizeof(IndexSlot)},
@@ -580,4 +736,29 @@ int download_index(gtx_ctx & c)
   return GTX_OK;
 }
 
+// one table of the position-hinted pass as the device holds it (inspection: gtx_ctx_hint_table)
+int download_hint_table(gtx_ctx const & c, int which, void * out, uint64_t cap_bytes, uint64_t * bytes)
+{
+  IndexView const & ix = c.dev_index;
+  uint64_t const filt_words = ix.n_hint ? (1ull << ix.filt_log2) : 1;
+  void const * src = nullptr;
+  uint64_t n = 0;
+  switch (which)
+  {
+  case 0: src = ix.pos_flags; n = static_cast<uint64_t>(ix.n_hint ? ix.n_hint : 1) * sizeof(uint2_t); break;
+  case 1: src = ix.refp; n = (ix.n_hint ? 4 * (static_cast<uint64_t>(ix.n_hint) / 32 + 8) : 32) * sizeof(uint32_t); break;
+  case 2: src = ix.tail_info; n = static_cast<uint64_t>(ix.n_hint ? ix.n_hint : 1) * sizeof(uint2_t); break;
+  case 3: src = ix.filt[0]; n = filt_words * sizeof(uint32_t); break;
+  case 4: src = ix.filt[1]; n = filt_words * sizeof(uint32_t); break;
+  default: return GTX_ERR_ARG;
+  }
+  *bytes = n;
+  if (!out)
+    return GTX_OK;
+  if (cap_bytes < n)
+    return GTX_ERR_CAPACITY;
+  if (!ok_hip(hipSetDevice(c.device), "hipSetDevice") || !ok_hip(hipMemcpy(out, src, n, hipMemcpyDeviceToHost), "hint table"))
+    return GTX_ERR_HIP;
+  return GTX_OK;
+}
 } // namespace gtx

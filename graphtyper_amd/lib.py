@@ -20,7 +20,7 @@ ST_ERROR_MASK = 15
 
 # names every build of libgtx.so must export (checked by tests/test_abi.py against include/gtx.h)
 EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy", "gtx_ctx_special_positions",
-           "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_ctx_near_pairs", "gtx_index_stats", "gtx_index_get", "gtx_index_dump",
+           "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_ctx_near_pairs", "gtx_index_stats", "gtx_index_get", "gtx_index_dump", "gtx_ctx_hint_table",
            "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_pass_times", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_set_coverage", "gtx_stream_finish", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
            "gtx_graph_destroy",
@@ -114,6 +114,7 @@ def lib():
         L.gtx_index_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.gtx_index_get.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.gtx_index_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gtx_ctx_hint_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.gtx_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                       C.c_void_p]
         L.gtx_score_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(ScoreBuffers),
@@ -512,6 +513,15 @@ class Context:
         check(lib().gtx_index_dump(self.h, _p(keys), _p(counts), _p(labels)))
         lab = np.stack([labels["start_index"], labels["end_index"], labels["variant_id"]], axis=1) if nl else np.zeros((0, 3), np.uint32)
         return keys, counts, lab
+
+    def hint_table(self, which):
+        """one table of the position-hinted pass as uint32 words (gtx_ctx_hint_table): 0 position flags, 1 reference planes,
+        2 tail sites, 3 / 4 half-key filters"""
+        n = C.c_uint64()
+        check(lib().gtx_ctx_hint_table(self.h, which, None, 0, C.byref(n)))
+        out = np.zeros(n.value // 4, np.uint32)
+        check(lib().gtx_ctx_hint_table(self.h, which, _p(out), n.value, C.byref(n)))
+        return out
 
     def profile(self):
         out = np.zeros(32, np.uint64)

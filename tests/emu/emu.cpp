@@ -126,6 +126,60 @@ extern "C"
 
   void emu_free(void * p) { delete static_cast<Emu *>(p); }
 
+  // The sweep listed in two ways (gtx_host.cpp: enumerate_kmers): every k-mer by the host, and with the in-node runs left to
+  // the device -- expanded here the way k_emit_runs / k_place_listed (gtx_index_dev.hip) do it.  Returns the number of
+  // k-mers, or -(1 + index of the first difference); n_listed / n_runs: what the host listed in the second form.
+  long emu_enumeration_check(void * p, uint64_t * n_listed, uint64_t * n_runs)
+  {
+    gtx::HostGraph const & g = static_cast<Emu *>(p)->graph;
+    std::vector<gtx::Emit> full, listed;
+    std::vector<gtx::EmitRun> runs;
+    gtx::enumerate_kmers(g, full);
+    gtx::enumerate_kmers(g, listed, &runs);
+    *n_listed = listed.size();
+    *n_runs = runs.size();
+    uint64_t const n_run = runs.empty() ? 0 : static_cast<uint64_t>(runs.back().dev_before) + runs.back().count;
+    std::vector<gtx::Emit> merged(listed.size() + n_run);
+    std::vector<uint8_t> written(merged.size(), 0);
+    size_t u = 0;
+    for (uint64_t t = 0; t < n_run; ++t)
+    {
+      while (u + 1 < runs.size() && runs[u + 1].dev_before <= t)
+        ++u;
+      gtx::EmitRun const & r = runs[u];
+      uint32_t const k = static_cast<uint32_t>(t) - r.dev_before;
+      uint64_t key = 0;
+      for (uint32_t i = 0; i < gtx::K; ++i)
+      {
+        int const code = g.codes[g.ref_dna[r.node] + k + i]; // (1 2 4 8 = A C G T)
+        key = (key << 2) | static_cast<uint64_t>(__builtin_ctz(static_cast<unsigned>(code)));
+      }
+      size_t const at = r.host_before + t;
+      if (at >= merged.size() || written[at])
+        return -1;
+      merged[at] = gtx::Emit{key, gtx_label{g.ref_order[r.node] + k, g.ref_order[r.node] + k + (gtx::K - 1), gtx::INVALID}};
+      written[at] = 1;
+    }
+    size_t lo = 0;
+    for (size_t j = 0; j < listed.size(); ++j)
+    {
+      while (lo < runs.size() && runs[lo].host_before <= j)
+        ++lo;
+      size_t const at = j + (lo ? runs[lo - 1].dev_before + runs[lo - 1].count : 0u);
+      if (at >= merged.size() || written[at])
+        return -1;
+      merged[at] = listed[j];
+      written[at] = 1;
+    }
+    if (merged.size() != full.size())
+      return -1;
+    for (size_t i = 0; i < full.size(); ++i)
+      if (merged[i].key != full[i].key || merged[i].label.start_index != full[i].label.start_index ||
+          merged[i].label.end_index != full[i].label.end_index || merged[i].label.variant_id != full[i].label.variant_id)
+        return -static_cast<long>(i) - 1;
+    return static_cast<long>(full.size());
+  }
+
   // same contract as gtx_align_batch, host pointers: BAM nibble rows, repacked into plane rows first (what the library does
   // with them on the device); the kernel sources below read plane rows only
   int emu_align(void * p, const uint8_t * nibble_rows, uint32_t nibble_stride, const gtx_read_meta * meta, uint32_t n_reads,

@@ -274,6 +274,9 @@ def test_device_built_index_equals_the_oracles(case):
     h = gtx.Context(g, device=-1, is_sv_graph=(case == "sv"))
     k3, c3, l3 = h.index_dump()
     assert np.array_equal(k1, k3) and np.array_equal(c1, c3) and np.array_equal(l1, l3)
+    # the tables of the position-hinted pass: the device's build == the host's (gtx_ctx_hint_table)
+    for which in range(5):
+        assert np.array_equal(c.hint_table(which), h.hint_table(which)), "hint table %d" % which
 
 
 def test_sites_with_more_than_64_alleles_on_the_device():
