@@ -286,7 +286,7 @@ struct Walker
       return true;
     // anti events (indexer.cpp:114-140): walking forward, a node is refused when one of its events is among the anti
     // events gathered so far; a node's own anti events count from its second base on.
-    std::vector<int64_t> anti;
+    // (the anti events so far are ranges of event_val, one per node behind: no list is built -- this runs once per k-mer)
     for (uint32_t i = n_vars; i-- > 0;) // vars[] is in backward order
     {
       uint32_t const v = vars[i];
@@ -294,14 +294,21 @@ struct Walker
       uint32_t const n_ev = g.event_off[2 * v + 1] - g.event_off[2 * v];
       int64_t const * an = g.event_val.data() + g.event_off[2 * v + 1];
       uint32_t const n_an = g.event_off[2 * v + 2] - g.event_off[2 * v + 1];
-      for (uint32_t e = 0; e < n_ev; ++e)
-        if (std::find(anti.begin(), anti.end(), ev[e]) != anti.end())
-          return false;
+      if (n_ev == 0)
+        continue;
+      for (uint32_t j = n_vars; j-- > i + 1;) // the nodes in front of this one on the walk
+      {
+        uint32_t const u = vars[j];
+        int64_t const * au = g.event_val.data() + g.event_off[2 * u + 1];
+        int64_t const * au_end = g.event_val.data() + g.event_off[2 * u + 2];
+        for (uint32_t e = 0; e < n_ev; ++e)
+          if (std::find(au, au_end, ev[e]) != au_end)
+            return false;
+      }
       if (used[i] >= 2)
         for (uint32_t e = 0; e < n_ev; ++e)
           if (std::find(an, an + n_an, ev[e]) != an + n_an)
             return false;
-      anti.insert(anti.end(), an, an + n_an);
     }
     return true;
   }

@@ -2,6 +2,7 @@
 // host, with a sequential stand-in for the wavefront (lane lambdas are looped over the 64 lanes).  It exists so that kernel logic
 // can be debugged in a container without a GPU; it is never built into, linked against or loaded by libgtx.so, and
 // nothing outside tests/ uses it.  Parity claims are made by the `-m gpu` tests through the C ABI only.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -125,6 +126,17 @@ extern "C"
   }
 
   void emu_free(void * p) { delete static_cast<Emu *>(p); }
+
+  // milliseconds of one listing of the sweep (tools: where a context's host time goes)
+  double emu_time_listing(void * p, int with_runs)
+  {
+    gtx::HostGraph const & g = static_cast<Emu *>(p)->graph;
+    std::vector<gtx::Emit> em;
+    std::vector<gtx::EmitRun> runs;
+    auto const t0 = std::chrono::steady_clock::now();
+    gtx::enumerate_kmers(g, em, with_runs ? &runs : nullptr);
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
 
   // The sweep listed in two ways (gtx_host.cpp: enumerate_kmers): every k-mer by the host, and with the in-node runs left to
   // the device -- expanded here the way k_emit_runs / k_place_listed (gtx_index_dev.hip) do it.  Returns the number of
