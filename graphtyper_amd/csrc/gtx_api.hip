@@ -135,15 +135,42 @@ struct WaveHipCombine : WaveHip
     }
     return false; // crowded (many samples in one workgroup): straight to memory
   }
+  // The lanes that are here together with the same (counter, addend) -- neighbours in the stream see the same site with the
+  // same alleles and the same epsilon -- send ONE add of addend x lanes through their first lane: 64 same-address LDS
+  // atomics take the LDS unit 64 turns each (a third of the kernel's time per CU before this), the ballots take none.
+  // Returns true for the lane that has to add *sum (false: another lane does it).
+  static __device__ inline bool wave_group(unsigned long long key, unsigned long long v, unsigned long long & sum)
+  {
+#ifdef GTX_NO_WAVE_GROUP // (A/B build: every lane for itself)
+    sum = v;
+    return true;
+#else
+    uint32_t const lane = threadIdx.x & 63u;
+    for (;;)
+    {
+      uint32_t const k_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(key)), k_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(key >> 32));
+      uint32_t const v_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)), v_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+      bool const same = key == ((static_cast<unsigned long long>(k_hi) << 32) | k_lo) && v == ((static_cast<unsigned long long>(v_hi) << 32) | v_lo);
+      unsigned long long const group = __ballot(same);
+      if (same)
+      {
+        sum = v * static_cast<unsigned long long>(__builtin_popcountll(group));
+        return lane == static_cast<uint32_t>(__builtin_ctzll(group));
+      }
+    }
+#endif
+  }
   static __device__ inline void atomic_add_u32(uint32_t * p, uint32_t v)
   {
-    if (!combine(reinterpret_cast<unsigned long long>(p), v))
-      atomicAdd(p, v);
+    unsigned long long sum;
+    if (wave_group(reinterpret_cast<unsigned long long>(p), v, sum) && !combine(reinterpret_cast<unsigned long long>(p), sum))
+      atomicAdd(p, static_cast<uint32_t>(sum));
   }
   static __device__ inline void atomic_add_u64(unsigned long long * p, unsigned long long v)
   {
-    if (!combine(reinterpret_cast<unsigned long long>(p) | 1ull, v))
-      atomicAdd(p, v);
+    unsigned long long sum;
+    if (wave_group(reinterpret_cast<unsigned long long>(p), v, sum) && !combine(reinterpret_cast<unsigned long long>(p) | 1ull, sum))
+      atomicAdd(p, sum);
   }
   // all threads of the workgroup
   static __device__ inline void clear()
@@ -981,7 +1008,12 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void gtx_score_triage_kernel(gtx_sc
 }
 
 // Scoring, stage 2: the items of the work queue, one thread each (orientation / pair selection, path checks, atomics).
-__global__ __launch_bounds__(256) void gtx_score_kernel(GraphView g, ScoreParams par, gtx_score_item const * __restrict__ items,
+#ifdef GTX_SCORE_WAVES // A/B builds: wavefronts per SIMD the compiler sizes the registers for
+#define GTX_SCORE_ATTR __attribute__((amdgpu_waves_per_eu(GTX_SCORE_WAVES, GTX_SCORE_WAVES)))
+#else
+#define GTX_SCORE_ATTR
+#endif
+__global__ __launch_bounds__(256) GTX_SCORE_ATTR void gtx_score_kernel(GraphView g, ScoreParams par, gtx_score_item const * __restrict__ items,
                                                         uint32_t const * __restrict__ work_queue, uint32_t const * work_count,
                                                         uint32_t const * __restrict__ records, uint32_t rec_words, ScoreAcc acc,
                                                         uint32_t * error_flag, uint32_t * __restrict__ big_queue,
@@ -1012,6 +1044,10 @@ __global__ __launch_bounds__(256) void gtx_score_kernel(GraphView g, ScoreParams
     WaveHipCombine::flush();
   }
 }
+
+// (Both stages in one launch -- a workgroup takes 1 024 items, keeps those with work in an LDS list and scores the list: no
+//  work queue through memory, one launch less -- measured slower, 1.36 ms per cfg2 step against 1.27: the triage streams
+//  400 MB and wants every wave slot, the scoring code's registers leave it 5 of 8.  Two kernels stay.)
 
 template <class RH, uint32_t CAP>
 GTX_DEV void score_big_pass(GraphView const & g, ScoreParams const & par, gtx_score_item const * __restrict__ items,
@@ -1398,6 +1434,9 @@ int ctx_upload(gtx_ctx & c, int device)
     c.express4_blocks_per_cu = per_cu;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express4_wide_kernel, 64, 0) == hipSuccess && per_cu > 0)
     c.express4_wide_blocks_per_cu = per_cu;
+  // (the scoring grid is what is resident, no more: 1.28 ms per cfg2 step against 1.32 with 8 workgroups per CU)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_score_kernel, 256, 0) == hipSuccess && per_cu > 0)
+    c.score_blocks_per_cu = per_cu;
   lap("occupancy queries");
   // the first scratch now, so that the first call does not pay for it
   auto s = scratch_new(c);
@@ -1905,7 +1944,7 @@ extern "C" int gtx_score_batch_flags(gtx_ctx * c, const gtx_score_item * d_items
                      s->d_score_work, static_cast<uint32_t>(a.ref_depth != nullptr), d_task_flags);
   if (!hip_ok(hipGetLastError(), "gtx_score_triage_kernel launch"))
     return GTX_ERR_HIP;
-  uint32_t const work_blocks = std::min<uint32_t>(blocks, static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256) * 8u);
+  uint32_t const work_blocks = std::min<uint32_t>(blocks, static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256) * c->score_blocks_per_cu);
   hipLaunchKernelGGL(gtx_score_kernel, dim3(work_blocks), dim3(256), 0, st, c->dev_graph, par, d_items, s->d_score_work + 1, s->d_score_work,
                      d_records, rec_words, a, c->d_error_flag, second_pass ? s->d_score_queue : nullptr,
                      second_pass ? gtx_ctx::SCORE_QUEUE_CAP : 0u, s->d_score_state);

@@ -71,6 +71,7 @@ struct gtx_ctx
   uint32_t * d_error_flag = nullptr;
   int align_blocks_per_cu = 8, express_blocks_per_cu = 16, express4_blocks_per_cu = 8;
   int express4_wide_blocks_per_cu = 8;
+  uint32_t score_blocks_per_cu = 8;  // resident 256-thread workgroups of gtx_score_kernel per CU
   bool express4_wide = false; // pass 1 runs gtx_align_express4_wide_kernel (express4_prefers_wide, gtx_flat.hpp)
   uint32_t big_blocks = 0;
   bool has_wide_sites = false; // some site has more than 64 alleles: the wide-site passes (alignment, scoring) exist
