@@ -63,6 +63,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU baseline (0 = all host hardware threads, max 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the cfg3-like extra workload")
+    ap.add_argument("--lanes", type=int, default=3, help="steps in flight (each with its own records and accumulators); 1 = one after the other")
+    ap.add_argument("--schedule", choices=["staggered", "lanes"], default="staggered",
+                    help="staggered = one stream carries the position-hinted pass of step k and then the scoring of step k-lanes+1, a second "
+                         "one the short queues behind every position-hinted pass; lanes = step k entirely on stream k mod lanes")
     ap.add_argument("--read-sets", type=int, default=2, help="resident read sets the steps take in turn (1 = the same reads every step)")
     ap.add_argument("--extra-reads", type=int, default=2_000_000)
     ap.add_argument("--no-hint", action="store_true", help="experiments only: withhold the BAM position from the alignment")
@@ -261,7 +265,7 @@ class DevView:
 class Workload:
     """resident inputs + accumulators of one (graph, reads) pair; step() = align + score [+ reduce] + calls"""
 
-    def __init__(self, torch, gtx, ctx, device, d_seq, d_pos, n_samples, samples=None, hint=True, conn_cap=1 << 24):
+    def __init__(self, torch, gtx, ctx, device, d_seq, d_pos, n_samples, samples=None, hint=True, conn_cap=1 << 24, lanes=1):
         """d_seq: [n, stride] BAM nibble rows on the device; they are repacked ONCE into plane rows (gtx_reads_to_planes, the
         layout the kernels read -- what gtx_stream_push writes on the host side) and only those stay resident"""
         self.torch, self.gtx, self.ctx, self.device = torch, gtx, ctx, device
@@ -285,6 +289,26 @@ class Workload:
         self.d_calls = torch.zeros(max(n_samples * ctx.n_hap, 1) * gtx.SAMPLE_CALL.itemsize, dtype=torch.uint8, device=device)
         self.stream = torch.cuda.Stream(device=device)
         self.sp = C.c_void_p(self.stream.cuda_stream)
+        # further lanes (--lanes): a step is still align -> score -> calls in stream order, but step k runs on lane k mod
+        # lanes with that lane's stream, records and accumulators, so that the short queues at the end of one step (express,
+        # general, scoring: latency-bound, the chip mostly idle) run beside the position-hinted pass of the next
+        self.lanes = [dict(stream=self.stream, sp=self.sp, buf=self.buf, d_rec=self.d_rec, d_flags=self.d_flags, d_phred=self.d_phred,
+                           d_calls=self.d_calls)]
+        for _ in range(1, max(1, lanes)):
+            lane = dict(stream=torch.cuda.Stream(device=device), buf=gtx.ScoreBuffers(),
+                        d_rec=torch.zeros(n * 2 * REC_WORDS, dtype=torch.int32, device=device),
+                        d_flags=torch.zeros(n * 2, dtype=torch.uint8, device=device) if USE_TASK_FLAGS else None,
+                        d_phred=torch.zeros_like(self.d_phred), d_calls=torch.zeros_like(self.d_calls))
+            lane["sp"] = C.c_void_p(lane["stream"].cuda_stream)
+            gtx.check(self.L.gtx_scores_alloc(ctx.h, n_samples, conn_cap, C.byref(lane["buf"]), C.byref(reduced)))
+            self.lanes.append(lane)
+        # (staggered schedule: the short queues behind every position-hinted pass, those of consecutive steps on different streams)
+        self.tail_streams = [torch.cuda.Stream(device=device) for _ in range(max(1, int(os.environ.get("GTX_BENCH_TAILS", "2"))))]
+        for ln in self.lanes:
+            ln["front"], ln["aligned"], ln["scored"] = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            for ev in (ln["front"], ln["aligned"], ln["scored"]):
+                ev.record(self.stream)  # (creates the HIP event: gtx_align_batch_planes_staged takes its handle)
+        self.staggered = False
         self.reduce_events = []  # HIP events around the exchange step of every step since the last run()
         self.comm = None       # ncclComm_t made through gtx_comm_init_rank
         self.dist = None       # fallback: torch.distributed on views of the packed block
@@ -321,7 +345,8 @@ class Workload:
         if self.comm is not None:
             self.L.gtx_comm_destroy(self.comm)
             self.comm = None
-        self.L.gtx_scores_free(self.ctx.h, C.byref(self.buf))
+        for lane in self.lanes:
+            self.L.gtx_scores_free(self.ctx.h, C.byref(lane["buf"]))
 
     def setup_reduce(self, dist, rank, world, local_rank):
         """the exchange step: an RCCL communicator for gtx_scores_reduce (id from rank 0 through the process group); if that
@@ -355,48 +380,115 @@ class Workload:
         self.t32 = torch.as_tensor(DevView(self.buf.d_log_score, n32, "<i4"), device=self.device)
         self.dist, self.reduce_kind = dist, "torch.distributed all_reduce x2 on the packed block"
 
-    def step(self):
-        gtx, L, ctx, sp = self.gtx, self.L, self.ctx, self.sp
+    def step(self, lane=0):
+        gtx, L, ctx = self.gtx, self.L, self.ctx
         torch = self.torch
+        ln = self.lanes[lane]
+        stream, sp, buf, d_rec, d_flags = ln["stream"], ln["sp"], ln["buf"], ln["d_rec"], ln["d_flags"]
         d_seq, d_meta, d_items = self.sets[self.steps_done % len(self.sets)]
         self.steps_done += 1
-        with torch.cuda.stream(self.stream):
-            gtx.check(L.gtx_scores_zero(ctx.h, C.byref(self.buf), sp))
+        with torch.cuda.stream(stream):
+            gtx.check(L.gtx_scores_zero(ctx.h, C.byref(buf), sp))
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(self.stream)
-            fl = self.d_flags.data_ptr() if self.d_flags is not None else None
-            gtx.check(self.align_fn(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, self.d_rec.data_ptr(), REC_WORDS, fl, sp))
-            e1.record(self.stream)
-            gtx.check(L.gtx_score_batch_flags(ctx.h, d_items.data_ptr(), self.n, self.d_rec.data_ptr(), REC_WORDS, fl, C.byref(self.buf), sp))
+            e0.record(stream)
+            fl = d_flags.data_ptr() if d_flags is not None else None
+            gtx.check(self.align_fn(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, d_rec.data_ptr(), REC_WORDS, fl, sp))
+            e1.record(stream)
+            gtx.check(L.gtx_score_batch_flags(ctx.h, d_items.data_ptr(), self.n, d_rec.data_ptr(), REC_WORDS, fl, C.byref(buf), sp))
             if self.comm is not None or self.dist is not None:
+                assert lane == 0  # (one communicator: the exchange steps of two lanes must not interleave)
                 r0 = torch.cuda.Event(enable_timing=True)
                 r1 = torch.cuda.Event(enable_timing=True)
-                r0.record(self.stream)
+                r0.record(stream)
                 if self.comm is not None:
-                    gtx.check(L.gtx_scores_reduce(ctx.h, C.byref(self.buf), self.comm, sp))
+                    gtx.check(L.gtx_scores_reduce(ctx.h, C.byref(buf), self.comm, sp))
                 else:
                     self.dist.all_reduce(self.t64, op=self.dist.ReduceOp.SUM)
                     self.dist.all_reduce(self.t32, op=self.dist.ReduceOp.SUM)
-                r1.record(self.stream)
+                r1.record(stream)
                 self.reduce_events.append((r0, r1))
             # genotype calls (PL, GT, GQ, depths) from the summed accumulators
-            gtx.check(L.gtx_calls_batch(ctx.h, C.byref(self.buf), self.d_phred.data_ptr(), self.d_calls.data_ptr(), sp))
+            gtx.check(L.gtx_calls_batch(ctx.h, C.byref(buf), ln["d_phred"].data_ptr(), ln["d_calls"].data_ptr(), sp))
         return e0, e1
+
+    def _score(self, ln, stream, after):
+        """score + calls of the step whose records lane `ln` holds, on `stream`, behind the events `after`"""
+        gtx, L, ctx, torch = self.gtx, self.L, self.ctx, self.torch
+        sp = C.c_void_p(stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            for ev in after:
+                stream.wait_event(ev)
+            fl = ln["d_flags"].data_ptr() if ln["d_flags"] is not None else None
+            gtx.check(L.gtx_scores_zero(ctx.h, C.byref(ln["buf"]), sp))
+            gtx.check(L.gtx_score_batch_flags(ctx.h, ln["items"].data_ptr(), self.n, ln["d_rec"].data_ptr(), REC_WORDS, fl, C.byref(ln["buf"]), sp))
+            gtx.check(L.gtx_calls_batch(ctx.h, C.byref(ln["buf"]), ln["d_phred"].data_ptr(), ln["d_calls"].data_ptr(), sp))
+            ln["scored"].record(stream)
+
+    def steps_staggered(self, steps):
+        """`steps` steps, three in flight on two streams.  Stream H carries what fills the chip, one kernel after the other:
+        the position-hinted pass of step k, then the scoring of step k-2.  Stream T carries the short queues behind every
+        position-hinted pass (gtx_align_batch_planes_staged: express, general, HBM tables -- 0.35 % of the reads,
+        latency-bound, most CUs idle), which drain beside H's kernels.  Every step is still align -> score -> calls on its own
+        records and accumulators; what is staggered is which step's work the chip sees when.  Returns the (start, end)
+        events of every align call (start on H, end on T)."""
+        gtx, L, ctx, torch = self.gtx, self.L, self.ctx, self.torch
+        H = self.lanes[0]["stream"]
+        spH = C.c_void_p(H.cuda_stream)
+        evs, flight = [], []
+        n_l = len(self.lanes)
+        for _ in range(steps):
+            ln = self.lanes[self.steps_done % n_l]
+            T = self.tail_streams[self.steps_done % len(self.tail_streams)]
+            spT = C.c_void_p(T.cuda_stream)
+            d_seq, d_meta, d_items = self.sets[self.steps_done % len(self.sets)]
+            self.steps_done += 1
+            with torch.cuda.stream(H):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(H)
+                fl = ln["d_flags"].data_ptr() if ln["d_flags"] is not None else None
+                gtx.check(L.gtx_align_batch_planes_staged(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, ln["d_rec"].data_ptr(),
+                                                          REC_WORDS, fl, spH, C.c_void_p(ln["front"].cuda_event), spT))
+            with torch.cuda.stream(T):
+                e1.record(T)
+                ln["aligned"].record(T)
+            ln["items"] = d_items
+            evs.append((e0, e1))
+            flight.append(ln)
+            if len(flight) == n_l:  # (the oldest step in flight: its queues had the last n_l - 1 position-hinted passes to drain)
+                old = flight.pop(0)
+                self._score(old, H, [old["aligned"]])
+        for old in flight:
+            self._score(old, H, [old["aligned"]])
+        return evs
 
     def run(self, steps, warmup, dist):
         """W untimed steps, then exactly K timed steps bracketed by barrier + synchronize; returns (seconds, align ms list)"""
         torch = self.torch
         self.ctx.pass_times()  # arms the per-pass HIP events inside gtx_align_batch
-        for _ in range(warmup):
-            self.step()
+        n_lanes = 1 if (self.comm is not None or self.dist is not None) else len(self.lanes)
+        stag = self.staggered and n_lanes >= 2 and PLANE_INPUT
+        for lane in range(1 if warmup > 0 else 0, n_lanes):
+            self.step(lane)  # (setup, not a step of the run: a stream's first call allocates that stream's scratch inside the library)
+            self.steps_done -= 1
+        if stag:
+            torch.cuda.synchronize()
+            self.steps_staggered(n_lanes)  # (setup as well: the scratches of calls in flight together)
+            self.steps_done -= n_lanes
+            torch.cuda.synchronize()
+            if warmup:
+                self.steps_staggered(warmup)
+        else:
+            for k in range(warmup):
+                self.step(k % n_lanes)
         torch.cuda.synchronize()
+        self.ctx.pass_times()  # (a query: the pass times asked for behind the timed steps are the mean over exactly those)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         self.reduce_events = []
         t0 = time.perf_counter()
-        evs = [self.step() for _ in range(steps)]
+        evs = self.steps_staggered(steps) if stag else [self.step(k % n_lanes) for k in range(steps)]
         torch.cuda.synchronize()
         self.local_s = time.perf_counter() - t0  # this rank's own time for its K steps (before waiting for the others)
         if dist is not None:
@@ -892,16 +984,29 @@ def main(argv=None):
 
     d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=CFG2_READ_SEED + rank, device=device, REGION_LEN=args.region_len,
                                         err_rate=args.err, n_rate=args.nrate)
-    w = Workload(torch, gtx, ctx, device, d_seq, d_pos, n_samples, samples=sample_ids(0), hint=not args.no_hint)
+    # (with an exchange step in every step -- N > 1 -- the steps stay on one stream: one communicator, one collective at a time)
+    w = Workload(torch, gtx, ctx, device, d_seq, d_pos, n_samples, samples=sample_ids(0), hint=not args.no_hint,
+                 lanes=args.lanes if dist is None else 1)
     for k in range(1, max(args.read_sets, 1)):  # the steps alternate between resident read sets (different reads, same size)
         w.samples = sample_ids(k)
         w.add_reads(*make_reads_on_device(torch, ref, records, n, seed=CFG2_READ_SEED + rank + 7919 * k, device=device, REGION_LEN=args.region_len,
                                           err_rate=args.err, n_rate=args.nrate))
     if dist is not None:
         w.setup_reduce(dist, rank, world, local_rank)
+    w.staggered = args.schedule == "staggered" and len(w.lanes) >= 2
     dt, align_ms = w.run(args.steps, args.warmup, dist)
     pass_ms, n_pass2 = ctx.pass_times()  # last step: express / general / HBM-table kernels
     kern = ctx.kernel_times() if hasattr(ctx, "kernel_times") else None
+    step_alone_ms = None
+    if len(w.lanes) > 1 and dist is None:
+        # (behind the timed region and the queries above: one step at a time on one stream -- a step's latency, where the
+        #  timed region measures the throughput of steps in flight on several streams)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            w.step(0)
+        torch.cuda.synchronize()
+        step_alone_ms = 1000.0 * (time.perf_counter() - t0) / 4
     facts = w.result_facts()
     n_gpus = dist.get_world_size() if dist is not None else 1
     per_rank_ms = gather_floats(dist, 1000.0 * w.local_s / args.steps, device)
@@ -965,6 +1070,13 @@ def main(argv=None):
            "ctx_create_s": round(t_ctx_warm, 3), "ctx_create_first_s": round(t_ctx, 3),
            "position_hint": not args.no_hint, "task_flags_side_array": USE_TASK_FLAGS,
            "read_layout": "bit planes (gtx_align_batch_planes; repacked once from BAM nibbles by gtx_reads_to_planes before the timed region)" if PLANE_INPUT else "BAM nibbles (gtx_align_batch_flags repacks them inside every call)", "resident_read_sets": len(w.sets),
+           "streams": {"steps_in_flight": len(w.lanes), "schedule": ("staggered" if w.staggered else "lanes") if len(w.lanes) > 1 else "serial",
+                       "step_alone_ms": step_alone_ms,
+                       "note": "every step is align -> score -> calls on its own records and accumulators. staggered: stream H carries, one "
+                               "kernel after the other, the position-hinted pass of step k and the scoring of step k-2; stream T the short "
+                               "express / general queues behind every position-hinted pass (gtx_align_batch_planes_staged: 0.35 % of the "
+                               "reads, latency-bound, most CUs idle), which drain beside H's kernels. ms_per_step = timed wall / steps (the "
+                               "last steps' scoring is inside the timed region); step_alone_ms = one step at a time on one stream"},
            "parallelism": "reads sharded over %d GPU(s), graph+index replicated" % n_gpus,
            "reduce": w.reduce_kind, "reduced_bytes_per_step": w.reduced_bytes if n_gpus > 1 else 0,
            "reduce_ms": max(reduce_ms) if n_gpus > 1 else 0.0, "reduce_ms_per_rank": reduce_ms, "per_rank_ms_per_step": per_rank_ms}

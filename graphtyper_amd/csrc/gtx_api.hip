@@ -974,7 +974,15 @@ __global__ __launch_bounds__(256) void gtx_task_flags_all_kernel(uint32_t const 
     task_flags[task] = static_cast<uint8_t>(records[static_cast<uint64_t>(task) * rec_words + 1] >> 31);
 }
 
-constexpr uint32_t TRIAGE_THREADS = 1024;
+// One-wave workgroups, sixteen items per thread (their loads are in flight together; one queue append per 1 024 items).
+// A host that keeps several batches in flight (gtx_align_batch_planes_staged) runs this kernel beside the resident one-wave
+// workgroups of another batch's express / general pass: a 1 024-thread workgroup then waits for sixteen free wave slots on
+// ONE CU -- 0.38 ms instead of 0.09, on some boxes a whole step at 1.45 ms instead of 1.07 -- where a one-wave workgroup
+// goes wherever a slot is.  Alone the small form costs 0.03 ms per 10 M items (GTX_TRIAGE_THREADS=1024 at build time: A/B).
+#ifndef GTX_TRIAGE_THREADS
+#define GTX_TRIAGE_THREADS 64
+#endif
+constexpr uint32_t TRIAGE_THREADS = GTX_TRIAGE_THREADS, TRIAGE_PER_THREAD = 1024 / GTX_TRIAGE_THREADS;
 __global__ __launch_bounds__(TRIAGE_THREADS) void gtx_score_triage_kernel(gtx_score_item const * __restrict__ items, uint32_t n_items,
                                                                           uint32_t const * __restrict__ records, uint32_t rec_words,
                                                                           uint32_t * __restrict__ work_queue, uint32_t * work_count,
@@ -982,29 +990,43 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void gtx_score_triage_kernel(gtx_sc
 {
   // one queue append per WORKGROUP (a device counter takes a few hundred million returning atomics a second: one per
   // wavefront -- 156 k per 10 M items -- set the pace of this kernel)
-  __shared__ uint32_t s_count[TRIAGE_THREADS / 64], s_base;
-  uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool const work = i < n_items && !item_is_trivial(items[i], records, rec_words, keeps_depth != 0, task_flags);
-  unsigned long long const mask = __ballot(work);
+  __shared__ uint32_t s_count[TRIAGE_PER_THREAD][TRIAGE_THREADS / 64], s_base;
   uint32_t const lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  if (lane == 0)
-    s_count[wave] = static_cast<uint32_t>(__builtin_popcountll(mask));
+  uint32_t const first = blockIdx.x * (TRIAGE_THREADS * TRIAGE_PER_THREAD);
+  bool work[TRIAGE_PER_THREAD];
+  unsigned long long mask[TRIAGE_PER_THREAD];
+#pragma unroll
+  for (uint32_t k = 0; k < TRIAGE_PER_THREAD; ++k)
+  {
+    uint32_t const i = first + k * TRIAGE_THREADS + threadIdx.x;
+    work[k] = i < n_items && !item_is_trivial(items[i], records, rec_words, keeps_depth != 0, task_flags);
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < TRIAGE_PER_THREAD; ++k)
+  {
+    mask[k] = __ballot(work[k]);
+    if (lane == 0)
+      s_count[k][wave] = static_cast<uint32_t>(__builtin_popcountll(mask[k]));
+  }
   __syncthreads();
   if (threadIdx.x == 0)
   {
     uint32_t total = 0;
-    for (uint32_t w = 0; w < TRIAGE_THREADS / 64; ++w)
-      total += s_count[w];
+    for (uint32_t k = 0; k < TRIAGE_PER_THREAD; ++k)
+      for (uint32_t w = 0; w < TRIAGE_THREADS / 64; ++w)
+        total += s_count[k][w];
     s_base = total ? atomicAdd(work_count, total) : 0u;
   }
   __syncthreads();
-  if (work)
-  {
-    uint32_t at = s_base;
-    for (uint32_t w = 0; w < wave; ++w)
-      at += s_count[w];
-    work_queue[at + static_cast<uint32_t>(__builtin_popcountll(mask & ((1ull << lane) - 1ull)))] = i;
-  }
+  uint32_t at = s_base;
+#pragma unroll
+  for (uint32_t k = 0; k < TRIAGE_PER_THREAD; ++k)
+    for (uint32_t w = 0; w < TRIAGE_THREADS / 64; ++w)
+    {
+      if (w == wave && work[k])
+        work_queue[at + static_cast<uint32_t>(__builtin_popcountll(mask[k] & ((1ull << lane) - 1ull)))] = first + k * TRIAGE_THREADS + threadIdx.x;
+      at += s_count[k][w];
+    }
 }
 
 // Scoring, stage 2: the items of the work queue, one thread each (orientation / pair selection, path checks, atomics).
@@ -1171,10 +1193,11 @@ static void scratch_free(CallScratch & s)
   for (void * p : ptrs)
     if (p)
       (void)gtx::dev_free(p);
-  for (auto & row : s.time_events)
-    for (auto & e : row)
-      if (e)
-        (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+  for (auto & slot : s.time_ring)
+    for (auto & row : slot)
+      for (auto & e : row)
+        if (e)
+          (void)hipEventDestroy(static_cast<hipEvent_t>(e));
   for (auto & e : s.sync_events)
     if (e)
       (void)hipEventDestroy(static_cast<hipEvent_t>(e));
@@ -1527,7 +1550,8 @@ extern "C" int gtx_reads_to_planes(gtx_ctx * c, const uint8_t * d_seq, uint32_t 
 }
 
 static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
-                        uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, hipStream_t st);
+                        uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, hipStream_t st, hipEvent_t front_event = nullptr,
+                        hipStream_t tail_stream = nullptr);
 
 // BAM nibble rows: repacked into plane rows in the call's scratch, then the same kernels
 extern "C" int gtx_align_batch_flags(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta,
@@ -1563,6 +1587,13 @@ extern "C" int gtx_align_batch_flags(gtx_ctx * c, const uint8_t * d_seq, uint32_
 extern "C" int gtx_align_batch_planes(gtx_ctx * c, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta,
                                       uint32_t n_reads, uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream)
 {
+  return gtx_align_batch_planes_staged(c, d_planes, plane_stride, d_meta, n_reads, d_records, rec_words, d_task_flags, stream, nullptr, nullptr);
+}
+
+extern "C" int gtx_align_batch_planes_staged(gtx_ctx * c, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta,
+                                             uint32_t n_reads, uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream,
+                                             void * front_event, void * tail_stream)
+{
   if (!c || rec_words < 8 || plane_stride == 0 || (plane_stride % PLANE_GROUP_BYTES) != 0 || (reinterpret_cast<uintptr_t>(d_planes) & 15u) != 0 ||
       (n_reads != 0 && (!d_planes || !d_meta || !d_records)))
   {
@@ -1574,20 +1605,34 @@ extern "C" int gtx_align_batch_planes(gtx_ctx * c, const uint8_t * d_planes, uin
     g_last_error = "context was created without a device (libgtx has no CPU path)";
     return GTX_ERR_NO_DEVICE;
   }
-  if (n_reads == 0)
-    return GTX_OK;
   hipStream_t const st = static_cast<hipStream_t>(stream);
+  if (tail_stream && !front_event)
+  {
+    g_last_error = "gtx_align_batch_planes_staged: a tail stream needs the front event (it is what the tail stream waits for)";
+    return GTX_ERR_ARG;
+  }
+  if (n_reads == 0)
+  {
+    if (front_event && (!hip_ok(hipSetDevice(c->device), "hipSetDevice") || !hip_ok(hipEventRecord(static_cast<hipEvent_t>(front_event), st), "front event")))
+      return GTX_ERR_HIP;
+    return GTX_OK;
+  }
   if (!hip_ok(hipSetDevice(c->device), "hipSetDevice"))
     return GTX_ERR_HIP;
   ScratchHold hold{*c, scratch_acquire(*c, st), st, true};
   if (!hold.s)
     return GTX_ERR_HIP;
-  return align_planes(c, hold.s, d_planes, plane_stride, d_meta, n_reads, d_records, rec_words, d_task_flags, st);
+  // (with a tail stream the call ends there: the scratch is free when THAT stream is through -- and is not handed to the
+  //  next call on `stream` by stream order, which would reset queues the tail still reads)
+  if (tail_stream && !std::getenv("GTX_PARTS"))
+    hold.stream = static_cast<hipStream_t>(tail_stream);
+  return align_planes(c, hold.s, d_planes, plane_stride, d_meta, n_reads, d_records, rec_words, d_task_flags, st, static_cast<hipEvent_t>(front_event),
+                      std::getenv("GTX_PARTS") ? nullptr : static_cast<hipStream_t>(tail_stream));
 }
 
 // the passes over plane rows (d_seq / seq_stride: the plane rows and their pitch)
 static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
-                        uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, hipStream_t st)
+                        uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, hipStream_t st, hipEvent_t front_event, hipStream_t tail_stream)
 {
   if (!hip_ok(hipMemsetAsync(s->d_counters, 0, 8 * CallScratch::MAX_PARTS * sizeof(uint32_t), st), "task counter reset"))
     return GTX_ERR_HIP;
@@ -1614,9 +1659,21 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
   uint32_t const force = fb ? static_cast<uint32_t>(std::atoi(fb)) : 0u;
   uint32_t const n_cu = static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256);
   bool timed = false;
+  uint32_t epoch = 0;
   {
     std::lock_guard<std::mutex> lock(c->pool_mutex);
     timed = c->timing_armed;
+    if (timed && c->epoch_queried) // the first timed call behind a query: a new epoch
+    {
+      ++c->time_epoch;
+      c->epoch_queried = false;
+    }
+    epoch = c->time_epoch;
+  }
+  if (timed && s->ring_epoch != epoch)
+  {
+    s->ring_epoch = epoch;
+    s->ring_used = 0;
   }
   uint32_t const force_both = static_cast<uint32_t>(c->params.force_align_both_orientations != 0);
   char const * e4 = std::getenv("GTX_EXPRESS4"); // A/B switch: 0 = one read per wavefront in pass 1
@@ -1653,9 +1710,22 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
       e = ev;
     }
   }
-  if (timed && !s->time_events[0][0])
-    for (auto & row : s->time_events)
-      for (auto & e : row)
+  // (calls beyond the ring are not timed: a query empties it)
+  if (timed && s->ring_used >= CallScratch::TIME_RING)
+    timed = false;
+  uint32_t const slot = timed ? s->ring_used : 0u;
+  if (timed && !s->time_ring[slot][0][0])
+    for (uint32_t p = 0; p < (parts > 1 ? CallScratch::MAX_PARTS : 1u); ++p)
+      for (auto & e : s->time_ring[slot][p])
+      {
+        hipEvent_t ev;
+        if (!hip_ok(hipEventCreate(&ev), "pass events"))
+          return GTX_ERR_HIP;
+        e = ev;
+      }
+  if (timed && parts > 1 && !s->time_ring[slot][1][0]) // (a slot made for a one-part call)
+    for (uint32_t p = 1; p < CallScratch::MAX_PARTS; ++p)
+      for (auto & e : s->time_ring[slot][p])
       {
         hipEvent_t ev;
         if (!hip_ok(hipEventCreate(&ev), "pass events"))
@@ -1663,11 +1733,24 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
         e = ev;
       }
   s->timed = false;
-  hipStream_t const sg = parts > 1 ? static_cast<hipStream_t>(s->side_stream) : st; // stream of the general / HBM-table passes
+  hipStream_t sg = parts > 1 ? static_cast<hipStream_t>(s->side_stream) : st; // stream of the general / HBM-table passes
+  hipStream_t s1 = st;                                                         // stream of the express pass
+  // gtx_align_batch_planes_staged with a tail stream: everything behind the front event goes there
+  auto front_done = [&]()
+  {
+    if (!front_event)
+      return;
+    (void)hipEventRecord(front_event, st);
+    if (tail_stream && tail_stream != st && parts == 1)
+    {
+      (void)hipStreamWaitEvent(tail_stream, front_event, 0);
+      s1 = sg = tail_stream;
+    }
+  };
   auto mark = [&](uint32_t part, int k, hipStream_t on)
   {
     if (timed)
-      (void)hipEventRecord(static_cast<hipEvent_t>(s->time_events[part][k]), on);
+      (void)hipEventRecord(static_cast<hipEvent_t>(s->time_ring[slot][part][k]), on);
   };
   if (parts > 1)
   {
@@ -1709,28 +1792,33 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
       if (!hip_ok(hipGetLastError(), "gtx_align_hinted_kernel launch"))
         return GTX_ERR_HIP;
       mark(part, 1, st);
+      // (gtx_align_batch_planes_staged: from here on the call is short queues -- the caller's other streams may come in)
+      if (first + step >= n_reads)
+        front_done();
       // (the queue's length is known on the device only: the grid is what can be resident, or one wavefront per group of four
       //  reads of a small batch; the kernel sizes its claims to the queue)
       uint32_t const blocks4q = static_cast<uint32_t>(std::min<uint64_t>(
         (static_cast<uint64_t>(n) + 3u) / 4u, static_cast<uint64_t>(n_cu) * (wide ? c->express4_wide_blocks_per_cu : c->express4_blocks_per_cu)));
-      hipLaunchKernelGGL(wide ? gtx_align_express4q_wide_kernel : gtx_align_express4q_kernel, dim3(blocks4q), dim3(64), 0, st, c->dev_graph,
+      hipLaunchKernelGGL(wide ? gtx_align_express4q_wide_kernel : gtx_align_express4q_kernel, dim3(blocks4q), dim3(64), 0, s1, c->dev_graph,
                          c->dev_index, seq, seq_stride, meta, records, rec_words, counters, queue1, counters + 3, queue2, counters + 2,
                          counters + 4, static_cast<uint32_t>(force != 0));
     }
     else
     {
       mark(part, 1, st);
+      if (first + step >= n_reads) // (no position-hinted pass: the event marks the call's start)
+        front_done();
       if (four)
-        hipLaunchKernelGGL(wide ? gtx_align_express4_wide_kernel : gtx_align_express4_kernel, dim3(blocks4), dim3(64), 0, st, c->dev_graph,
+        hipLaunchKernelGGL(wide ? gtx_align_express4_wide_kernel : gtx_align_express4_kernel, dim3(blocks4), dim3(64), 0, s1, c->dev_graph,
                            c->dev_index, seq, seq_stride, meta, n, records, rec_words, force_both, counters, queue2, counters + 2,
                            static_cast<uint32_t>(force != 0));
       else
-        hipLaunchKernelGGL(gtx_align_express_kernel, dim3(blocks1), dim3(64), 0, st, c->dev_graph, c->dev_index, seq, seq_stride, meta, n,
+        hipLaunchKernelGGL(gtx_align_express_kernel, dim3(blocks1), dim3(64), 0, s1, c->dev_graph, c->dev_index, seq, seq_stride, meta, n,
                            records, rec_words, force_both, counters, queue2, counters + 2, static_cast<uint32_t>(force != 0));
     }
     if (!hip_ok(hipGetLastError(), "express kernel launch"))
       return GTX_ERR_HIP;
-    mark(part, 2, st);
+    mark(part, 2, s1);
     if (parts > 1)
     {
       (void)hipEventRecord(static_cast<hipEvent_t>(s->sync_events[part]), st);
@@ -1792,11 +1880,17 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
   }
   s->timed = timed;
   s->timed_reads = n_reads;
-  s->timed_parts = used_parts;
+  if (timed)
+  {
+    s->ring_parts[slot] = used_parts;
+    ++s->ring_used;
+  }
   return GTX_OK;
 }
 
-// (ms[4], tasks[4]) of the last timed gtx_align_batch: position-hinted pass, express pass, general pass, HBM-table pass
+// (ms[4], tasks[4]): position-hinted pass, express pass, general pass, HBM-table pass.  ms: the mean over the timed
+// gtx_align_batch calls between the last two queries -- or since the last one --, of every stream's scratch (a host with
+// several calls in flight asks once, behind them); tasks: of the last of them.
 static int kernel_times(gtx_ctx * c, float * ms, uint32_t * tasks)
 {
   for (int k = 0; k < 4; ++k)
@@ -1807,45 +1901,67 @@ static int kernel_times(gtx_ctx * c, float * ms, uint32_t * tasks)
   if (c->device < 0)
     return GTX_ERR_NO_DEVICE;
   CallScratch * s = nullptr;
+  std::vector<CallScratch *> all;
   {
     std::lock_guard<std::mutex> lock(c->pool_mutex);
-    if (!c->timing_armed) // first call: the next gtx_align_batch is timed
+    if (!c->timing_armed) // first call: the calls from now on are timed
     {
       c->timing_armed = true;
       return GTX_OK;
     }
     s = c->last_align;
+    for (auto & u : c->pool)
+      if (u->ring_epoch == c->time_epoch)
+        all.push_back(u.get());
+    c->epoch_queried = true;
   }
   if (!s || !s->timed)
     return GTX_OK; // nothing was timed yet
-  if (!hip_ok(hipSetDevice(c->device), "hipSetDevice") || !hip_ok(hipEventSynchronize(static_cast<hipEvent_t>(s->time_events[0][5])), "pass events"))
+  if (!hip_ok(hipSetDevice(c->device), "hipSetDevice"))
     return GTX_ERR_HIP;
+  double sum[4] = {0, 0, 0, 0};
+  uint32_t calls = 0;
+  for (CallScratch * u : all)
+  {
+    uint32_t const used = std::min(u->ring_used, CallScratch::TIME_RING);
+    for (uint32_t slot = 0; slot < used; ++slot)
+    {
+      uint32_t const n_parts = u->ring_parts[slot];
+      if (n_parts == 0 || !hip_ok(hipEventSynchronize(static_cast<hipEvent_t>(u->time_ring[slot][0][5])), "pass events"))
+        continue;
+      for (uint32_t p = 0; p < n_parts; ++p)
+      {
+        float d = 0.0f;
+        auto ev = [&](int k) { return static_cast<hipEvent_t>(u->time_ring[slot][p][k]); };
+        if (hipEventElapsedTime(&d, ev(0), ev(1)) == hipSuccess)
+          sum[0] += d;
+        if (hipEventElapsedTime(&d, ev(1), ev(2)) == hipSuccess)
+          sum[1] += d;
+        if (hipEventElapsedTime(&d, ev(3), ev(4)) == hipSuccess)
+          sum[2] += d;
+      }
+      float d = 0.0f;
+      if (hipEventElapsedTime(&d, static_cast<hipEvent_t>(u->time_ring[slot][n_parts - 1][4]), static_cast<hipEvent_t>(u->time_ring[slot][0][5])) == hipSuccess)
+        sum[3] += d;
+      ++calls;
+    }
+  }
+  if (calls == 0)
+    return GTX_OK;
+  for (int k = 0; k < 4; ++k)
+    ms[k] = static_cast<float>(sum[k] / calls);
+  // (the last call's counters; the stream is through: its end event was waited for above)
   uint32_t cnt[8 * CallScratch::MAX_PARTS] = {}, big[4] = {0, 0, 0, 0};
   (void)hipMemcpy(cnt, s->d_counters, sizeof(cnt), hipMemcpyDeviceToHost);
   if (s->d_big_state)
     (void)hipMemcpy(big, s->d_big_state, sizeof(big), hipMemcpyDeviceToHost);
   uint32_t queued2 = 0, queued1 = 0, handed = 0, direct = 0;
-  float last_general_end = 0.0f;
-  for (uint32_t p = 0; p < s->timed_parts; ++p)
+  for (uint32_t p = 0; p < CallScratch::MAX_PARTS; ++p)
   {
-    float d = 0.0f;
-    auto ev = [&](int k) { return static_cast<hipEvent_t>(s->time_events[p][k]); };
-    if (hipEventElapsedTime(&d, ev(0), ev(1)) == hipSuccess)
-      ms[0] += d;
-    if (hipEventElapsedTime(&d, ev(1), ev(2)) == hipSuccess)
-      ms[1] += d;
-    if (hipEventElapsedTime(&d, ev(3), ev(4)) == hipSuccess)
-      ms[2] += d;
     queued2 += cnt[8 * p + 2];
     queued1 += cnt[8 * p + 3];
     handed += cnt[8 * p + 4];
     direct += cnt[8 * p + 5] - std::min(cnt[8 * p + 5], cnt[8 * p + 4]); // forward tasks of the general pass that did not come through pass 1
-    (void)last_general_end;
-  }
-  {
-    float d = 0.0f;
-    if (hipEventElapsedTime(&d, static_cast<hipEvent_t>(s->time_events[s->timed_parts - 1][4]), static_cast<hipEvent_t>(s->time_events[0][5])) == hipSuccess)
-      ms[3] = d;
   }
   // forward tasks only: reverse-orientation tasks all go to the general pass
   uint32_t const hbm = std::min<uint32_t>(big[0], s->big_task_cap);
@@ -1940,7 +2056,7 @@ extern "C" int gtx_score_batch_flags(gtx_ctx * c, const gtx_score_item * d_items
   s->score_work_cap = static_cast<uint32_t>(cap - 1);
   if (!hip_ok(hipMemsetAsync(s->d_score_work, 0, sizeof(uint32_t), st), "score work queue reset"))
     return GTX_ERR_HIP;
-  hipLaunchKernelGGL(gtx_score_triage_kernel, dim3((n_items + TRIAGE_THREADS - 1) / TRIAGE_THREADS), dim3(TRIAGE_THREADS), 0, st, d_items, n_items, d_records, rec_words, s->d_score_work + 1,
+  hipLaunchKernelGGL(gtx_score_triage_kernel, dim3((n_items + TRIAGE_THREADS * TRIAGE_PER_THREAD - 1) / (TRIAGE_THREADS * TRIAGE_PER_THREAD)), dim3(TRIAGE_THREADS), 0, st, d_items, n_items, d_records, rec_words, s->d_score_work + 1,
                      s->d_score_work, static_cast<uint32_t>(a.ref_depth != nullptr), d_task_flags);
   if (!hip_ok(hipGetLastError(), "gtx_score_triage_kernel launch"))
     return GTX_ERR_HIP;

@@ -36,9 +36,16 @@ struct CallScratch
   static constexpr uint32_t MAX_PARTS = 8; // parts a large batch is cut into (their general passes overlap the next part)
   void * side_stream = nullptr;            // hipStream_t of the general / HBM-table passes when a batch has several parts
   void * sync_events[MAX_PARTS + 1] = {};  // hipEvent_t (no timing): part p's express pass done; [MAX_PARTS]: fork / join
-  void * time_events[MAX_PARTS][6] = {};   // per part: around hinted, express (caller's stream), general (side stream); [0][5] = end
-  bool timed = false;                      // the events above bracket a finished call
-  uint32_t timed_reads = 0, timed_parts = 0;
+  // Pass times of the calls since the last gtx_ctx_kernel_times (a ring: a host that keeps several calls in flight asks
+  // once behind them).  Per call and part 6 events: around hinted, express (caller's stream), general (side stream);
+  // [0][5] = the call's end.  Created at a slot's first use.
+  static constexpr uint32_t TIME_RING = 32;
+  void * time_ring[TIME_RING][MAX_PARTS][6] = {};
+  uint32_t ring_parts[TIME_RING] = {}; // parts of the call in the slot
+  uint32_t ring_used = 0;              // calls recorded in epoch ring_epoch (the first TIME_RING of them are kept)
+  uint32_t ring_epoch = 0;             // gtx_ctx::time_epoch of the slots above
+  bool timed = false;                  // the last call was timed (its slot: ring_used - 1)
+  uint32_t timed_reads = 0;
   // HBM-table pass (reads that overflowed the LDS-sized tables)
   uint32_t * d_big_tasks = nullptr;
   uint32_t big_task_cap = 0;
@@ -85,6 +92,10 @@ struct gtx_ctx
   std::vector<std::unique_ptr<gtx::CallScratch>> pool;
   gtx::CallScratch * last_align = nullptr; // scratch of the most recent gtx_align_batch (pass times, second-pass task count)
   bool timing_armed = false;
+  // the timed calls between two queries are one epoch: the first timed call behind a query opens the next one (a scratch
+  // drops the slots of an older epoch when it records again; a query reads the current epoch only, as often as it likes)
+  uint32_t time_epoch = 0;
+  bool epoch_queried = false;
   // index facts of a device-built index (gtx_index_dev.hip); its keys / labels in reference order stay on the device and
   // are downloaded into `index` when an inspection entry point asks for them
   uint32_t n_keys = 0, n_labels = 0;

@@ -309,6 +309,16 @@ int gtx_reads_to_planes(gtx_ctx *, const uint8_t * d_seq, uint32_t seq_stride, u
                         void * stream);
 int gtx_align_batch_planes(gtx_ctx *, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
                            uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream);
+/* The same, for hosts that keep several batches in flight.  front_event (a hipEvent_t of the caller, may be NULL) is
+ * recorded on `stream` behind the position-hinted pass -- the one launch of the call that fills the chip.  What follows are
+ * the short queues of the express and general passes (a fraction of a percent of the reads, latency-bound, most CUs idle).
+ * tail_stream (may be NULL = `stream`; needs front_event): those passes are launched THERE, behind the event, and the call
+ * is complete when tail_stream is -- `stream` is free for the next batch's position-hinted pass, or for the scoring of an
+ * earlier one, while the queues drain beside it (bench.py: the staggered schedule, three batches in flight).  Without a
+ * position-hinted pass (no hint tables, GTX_HINT=0) the event marks the call's start. */
+int gtx_align_batch_planes_staged(gtx_ctx *, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
+                                  uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream, void * front_event,
+                                  void * tail_stream);
 
 /* Score accumulators (all uint32 / uint64, zero-initialised by the caller; sample-major):
  *   d_log_score [n_samples * total_tri]      HapSample::log_score
@@ -362,9 +372,12 @@ int gtx_ctx_error_count(gtx_ctx *, uint32_t * out);
  * (both synchronise with the device) */
 int gtx_ctx_big_records(gtx_ctx *, const uint32_t ** d_words, uint64_t * capacity_words, uint64_t * used_words, uint64_t * tasks);
 
-/* Durations (ms, HIP events on the launch stream) of the passes of the last gtx_align_batch -- everything in front of the
- * general pass (position-hinted + express), general, HBM tables -- and the number of tasks handed to the general pass.
- * The first call only arms the timing. */
+/* Durations (ms, HIP events on the launch stream) of the passes of gtx_align_batch -- everything in front of the general
+ * pass (position-hinted + express), general, HBM tables -- and the number of tasks handed to the general pass.  The
+ * first call only arms the timing.  From then on every call is timed (up to 32 per stream between two queries); a query
+ * waits for the calls recorded so far and returns the MEAN duration over them, all streams together -- a host that keeps
+ * several calls in flight asks once, behind them -- and the task counts of the last call.  The first timed call after a
+ * query starts a new series. */
 int gtx_ctx_pass_times(gtx_ctx *, float * ms /* [3] */, uint32_t * queued_for_pass2);
 
 /* The same for the four launches of gtx_align_batch one by one -- position-hinted pass (one read per lane), express pass,
