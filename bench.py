@@ -376,8 +376,9 @@ class Workload:
                          (rank, L.gtx_last_error().decode()))
         n64 = self.ctx.n_hap + 2 * self.ctx.total_allele
         n32 = (self.reduced_bytes - 8 * n64) // 4
-        self.t64 = torch.as_tensor(DevView(self.buf.d_stat_u64, n64, "<i8"), device=self.device)
-        self.t32 = torch.as_tensor(DevView(self.buf.d_log_score, n32, "<i4"), device=self.device)
+        for ln in self.lanes:
+            ln["t64"] = torch.as_tensor(DevView(ln["buf"].d_stat_u64, n64, "<i8"), device=self.device)
+            ln["t32"] = torch.as_tensor(DevView(ln["buf"].d_log_score, n32, "<i4"), device=self.device)
         self.dist, self.reduce_kind = dist, "torch.distributed all_reduce x2 on the packed block"
 
     def step(self, lane=0):
@@ -397,17 +398,8 @@ class Workload:
             e1.record(stream)
             gtx.check(L.gtx_score_batch_flags(ctx.h, d_items.data_ptr(), self.n, d_rec.data_ptr(), REC_WORDS, fl, C.byref(buf), sp))
             if self.comm is not None or self.dist is not None:
-                assert lane == 0  # (one communicator: the exchange steps of two lanes must not interleave)
-                r0 = torch.cuda.Event(enable_timing=True)
-                r1 = torch.cuda.Event(enable_timing=True)
-                r0.record(stream)
-                if self.comm is not None:
-                    gtx.check(L.gtx_scores_reduce(ctx.h, C.byref(buf), self.comm, sp))
-                else:
-                    self.dist.all_reduce(self.t64, op=self.dist.ReduceOp.SUM)
-                    self.dist.all_reduce(self.t32, op=self.dist.ReduceOp.SUM)
-                r1.record(stream)
-                self.reduce_events.append((r0, r1))
+                assert lane == 0  # (one communicator: the exchange steps of two streams must not interleave)
+                self._reduce(ln, stream, sp)
             # genotype calls (PL, GT, GQ, depths) from the summed accumulators
             gtx.check(L.gtx_calls_batch(ctx.h, C.byref(buf), ln["d_phred"].data_ptr(), ln["d_calls"].data_ptr(), sp))
         return e0, e1
@@ -422,8 +414,24 @@ class Workload:
             fl = ln["d_flags"].data_ptr() if ln["d_flags"] is not None else None
             gtx.check(L.gtx_scores_zero(ctx.h, C.byref(ln["buf"]), sp))
             gtx.check(L.gtx_score_batch_flags(ctx.h, ln["items"].data_ptr(), self.n, ln["d_rec"].data_ptr(), REC_WORDS, fl, C.byref(ln["buf"]), sp))
+            self._reduce(ln, stream, sp)
             gtx.check(L.gtx_calls_batch(ctx.h, C.byref(ln["buf"]), ln["d_phred"].data_ptr(), ln["d_calls"].data_ptr(), sp))
             ln["scored"].record(stream)
+
+    def _reduce(self, ln, stream, sp):
+        """the exchange step of a step whose accumulators lane `ln` holds (N > 1), on `stream` (inside `with torch.cuda.stream`)"""
+        if self.comm is None and self.dist is None:
+            return
+        torch = self.torch
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record(stream)
+        if self.comm is not None:
+            self.gtx.check(self.L.gtx_scores_reduce(self.ctx.h, C.byref(ln["buf"]), self.comm, sp))
+        else:
+            self.dist.all_reduce(ln["t64"], op=self.dist.ReduceOp.SUM)
+            self.dist.all_reduce(ln["t32"], op=self.dist.ReduceOp.SUM)
+        r1.record(stream)
+        self.reduce_events.append((r0, r1))
 
     def steps_staggered(self, steps):
         """`steps` steps, three in flight on two streams.  Stream H carries what fills the chip, one kernel after the other:
@@ -466,19 +474,22 @@ class Workload:
         """W untimed steps, then exactly K timed steps bracketed by barrier + synchronize; returns (seconds, align ms list)"""
         torch = self.torch
         self.ctx.pass_times()  # arms the per-pass HIP events inside gtx_align_batch
-        n_lanes = 1 if (self.comm is not None or self.dist is not None) else len(self.lanes)
-        stag = self.staggered and n_lanes >= 2 and PLANE_INPUT
-        for lane in range(1 if warmup > 0 else 0, n_lanes):
-            self.step(lane)  # (setup, not a step of the run: a stream's first call allocates that stream's scratch inside the library)
-            self.steps_done -= 1
+        exchange = self.comm is not None or self.dist is not None
+        stag = self.staggered and len(self.lanes) >= 2 and PLANE_INPUT
+        # (with an exchange step in every step -- N > 1 -- only the staggered schedule keeps steps in flight: its scoring, and with
+        #  it the exchange, is all on one stream; one communicator takes one collective at a time)
+        n_lanes = len(self.lanes) if (stag or not exchange) else 1
+        # (setup, not steps of the run: the first calls that are in flight together allocate their scratch inside the library)
         if stag:
-            torch.cuda.synchronize()
-            self.steps_staggered(n_lanes)  # (setup as well: the scratches of calls in flight together)
+            self.steps_staggered(n_lanes)
             self.steps_done -= n_lanes
             torch.cuda.synchronize()
             if warmup:
                 self.steps_staggered(warmup)
         else:
+            for lane in range(1, n_lanes):
+                self.step(lane)
+                self.steps_done -= 1
             for k in range(warmup):
                 self.step(k % n_lanes)
         torch.cuda.synchronize()
@@ -959,6 +970,8 @@ def main(argv=None):
     if not os.path.exists(gtx.LIB_PATH):
         raise SystemExit("libgtx.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
     rank, local_rank, world, dist = init_ranks(args)
+    if os.environ.get("GTX_BENCH_SHARE_DEVICE"):  # test switch: every rank on device 0 (the N > 1 control flow on a one-GPU box, --backend gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -984,9 +997,7 @@ def main(argv=None):
 
     d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=CFG2_READ_SEED + rank, device=device, REGION_LEN=args.region_len,
                                         err_rate=args.err, n_rate=args.nrate)
-    # (with an exchange step in every step -- N > 1 -- the steps stay on one stream: one communicator, one collective at a time)
-    w = Workload(torch, gtx, ctx, device, d_seq, d_pos, n_samples, samples=sample_ids(0), hint=not args.no_hint,
-                 lanes=args.lanes if dist is None else 1)
+    w = Workload(torch, gtx, ctx, device, d_seq, d_pos, n_samples, samples=sample_ids(0), hint=not args.no_hint, lanes=args.lanes)
     for k in range(1, max(args.read_sets, 1)):  # the steps alternate between resident read sets (different reads, same size)
         w.samples = sample_ids(k)
         w.add_reads(*make_reads_on_device(torch, ref, records, n, seed=CFG2_READ_SEED + rank + 7919 * k, device=device, REGION_LEN=args.region_len,
@@ -998,7 +1009,7 @@ def main(argv=None):
     pass_ms, n_pass2 = ctx.pass_times()  # last step: express / general / HBM-table kernels
     kern = ctx.kernel_times() if hasattr(ctx, "kernel_times") else None
     step_alone_ms = None
-    if len(w.lanes) > 1 and dist is None:
+    if len(w.lanes) > 1 and dist is None:  # (N = 1 only: with an exchange step every rank would have to take part)
         # (behind the timed region and the queries above: one step at a time on one stream -- a step's latency, where the
         #  timed region measures the throughput of steps in flight on several streams)
         torch.cuda.synchronize()

@@ -218,3 +218,56 @@ def test_task_flags_side_array(hint):
     for host, dev in zip(acc2.arrays(), devs):
         host[...] = dev.cpu().numpy().view(host.dtype)
     assert np.array_equal(harness.canonical_scores(b.ctx, acc), harness.canonical_scores(b.ctx, acc2))
+
+
+def test_batches_in_flight_equal_one_at_a_time():
+    """gtx_align_batch_planes_staged: three batches in flight -- position-hinted passes on one stream, the express / general
+    queues behind each on a second one, the front event between them -- leave the records and side bytes the plain call
+    leaves, batch by batch; and gtx_ctx_kernel_times then holds the mean over exactly those calls"""
+    import ctypes as C
+    import torch
+    ref, recs, codes, pos = scenarios.synthetic_case("snp100", n_ref=120000, n_reads=9000, region_begin=1000000, seed=3)
+    ctx = gtx.Context(gtx.graph_from_records(ref, recs, region_begin=1000000), device=0)
+    L = gtx.lib()
+    seq, lens = harness.pack_ragged(list(codes))
+    meta = harness.read_meta(lens, pos=pos)
+    stride = (seq.shape[1] + 15) // 16 * 16
+    planes = gtx.pack_planes(seq, stride)
+    parts = [(0, 3000), (3000, 7000), (7000, 9000)]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to("cuda:0")
+    want = []
+    for a, b in parts:  # one at a time, default stream
+        d_p, d_m = dev(planes[a:b]), dev(meta[a:b])
+        d_rec = torch.zeros((b - a) * 2 * harness.REC_WORDS, dtype=torch.int32, device="cuda:0")
+        d_fl = torch.zeros((b - a) * 2, dtype=torch.uint8, device="cuda:0")
+        gtx.check(L.gtx_align_batch_planes(ctx.h, d_p.data_ptr(), stride, d_m.data_ptr(), b - a, d_rec.data_ptr(), harness.REC_WORDS,
+                                           d_fl.data_ptr(), None))
+        torch.cuda.synchronize()
+        want.append((d_rec.cpu().numpy().copy(), d_fl.cpu().numpy().copy()))
+    ctx.pass_times()  # arms the timing
+    ctx.pass_times()
+    H, T = torch.cuda.Stream(), torch.cuda.Stream()
+    held, fronts = [], []
+    for a, b in parts:
+        d_p, d_m = dev(planes[a:b]), dev(meta[a:b])
+        d_rec = torch.zeros((b - a) * 2 * harness.REC_WORDS, dtype=torch.int32, device="cuda:0")
+        d_fl = torch.zeros((b - a) * 2, dtype=torch.uint8, device="cuda:0")
+        held.append((d_p, d_m, d_rec, d_fl))
+    torch.cuda.synchronize()
+    for (a, b), (d_p, d_m, d_rec, d_fl) in zip(parts, held):
+        ev = torch.cuda.Event()
+        ev.record(H)  # (creates the HIP event)
+        fronts.append(ev)
+        gtx.check(L.gtx_align_batch_planes_staged(ctx.h, d_p.data_ptr(), stride, d_m.data_ptr(), b - a, d_rec.data_ptr(), harness.REC_WORDS,
+                                                  d_fl.data_ptr(), C.c_void_p(H.cuda_stream), C.c_void_p(ev.cuda_event), C.c_void_p(T.cuda_stream)))
+    torch.cuda.synchronize()
+    for (w_rec, w_fl), (_, _, d_rec, d_fl) in zip(want, held):
+        assert np.array_equal(d_rec.cpu().numpy(), w_rec) and np.array_equal(d_fl.cpu().numpy(), w_fl)
+    kt = ctx.kernel_times()
+    assert kt[0][1] > 0 and kt[2][1] > 0  # mean durations over the three staged calls
+    assert kt == ctx.kernel_times()       # a second query without a call in between: the same series
+    assert 0 < kt[0][2] <= parts[-1][1] - parts[-1][0]  # task counts: the last call's
+    # a tail stream without the front event is refused
+    d_p, d_m, d_rec, d_fl = held[0]
+    assert L.gtx_align_batch_planes_staged(ctx.h, d_p.data_ptr(), stride, d_m.data_ptr(), 10, d_rec.data_ptr(), harness.REC_WORDS, None,
+                                           C.c_void_p(H.cuda_stream), None, C.c_void_p(T.cuda_stream)) != 0
