@@ -665,6 +665,7 @@ __global__ __launch_bounds__(1024) void gtx_align_hinted16_kernel(GTX_HINTED_ARG
 
 // Pass 1 behind pass 0: express4 over the queue of forward tasks the position-hinted pass declined (four reads per
 // wavefront as above, the reads of a group come from the queue instead of lying side by side).
+constexpr uint32_t EXPRESS_GROUPS_PER_WAVE = 4, GENERAL_TASKS_PER_WAVE = 3; // what a wavefront of a short queue should find to do
 template <class E4>
 __device__ __forceinline__ void express4_queue_pass(GraphView const & g, IndexView const & ix, uint8_t const * __restrict__ seq,
                                                     uint32_t seq_stride, gtx_read_meta const * __restrict__ meta,
@@ -683,7 +684,15 @@ __device__ __forceinline__ void express4_queue_pass(GraphView const & g, IndexVi
   // group at a time, which is what evens out the end of the pass.
   // (short queues only: on a long one -- dense graphs: a hundred groups per wavefront, of very different cost -- a fixed
   //  share costs more in imbalance than the atomics do; the cfg3-like workload lost a tenth)
-  uint32_t const n_groups = (n + 3u) / 4u, G = gridDim.x;
+  // A short queue is done by a part of the grid -- four groups per wavefront -- and the other wavefronts leave at once: every
+  // wavefront's first group costs five times a later one (instruction fetch, first-touch translation), and the more of
+  // them start at once on a CU the more each pays (cfg2, 5.2 k groups: 16 / 8 / 4 wavefronts per CU = 0.194 / 0.129 /
+  // 0.127 ms).
+  uint32_t const n_groups = (n + 3u) / 4u, G_all = gridDim.x;
+  uint32_t const G_want = (n_groups + EXPRESS_GROUPS_PER_WAVE - 1u) / EXPRESS_GROUPS_PER_WAVE;
+  uint32_t const G = G_want >= G_all ? G_all : G_want > 0u ? G_want : 1u;
+  if (blockIdx.x >= G)
+    return;
   uint32_t const own = n_groups / G <= 8u ? (n_groups / G) * 3u / 4u : 0u;
 #ifdef GTX_PROF
   if (threadIdx.x < 16)
@@ -777,17 +786,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_GENERAL_
   WaveHip::lds_sync();
 #endif
   uint32_t const queued = queue_count[0];
+  // (a short queue is done by a part of the grid, three tasks per wavefront, as in the express pass: cfg2, 7.6 k tasks:
+  //  20 / 12 / 8 / 4 wavefronts per CU = 0.38 / 0.33 / 0.33 / 0.40 ms)
+  uint32_t const G_all = gridDim.x, G_want = (queued + GENERAL_TASKS_PER_WAVE - 1u) / GENERAL_TASKS_PER_WAVE;
+  uint32_t const G = G_want >= G_all ? G_all : G_want > 0u ? G_want : 1u;
+  if (blockIdx.x >= G)
+    return;
   // tasks per visit to the counter (one atomic per task: the counter, not the work, sets the pace of a long queue; large
   // claims: the last claims of a short queue decide when the pass ends -- a wavefront that draws a second claim of four
   // ~70 us tasks finishes 0.3 ms after one that does not).  `claim` = 0: sized to the queue -- four tasks per visit while
   // every wavefront gets 32 and more, two from twelve on, else one ...
-  uint32_t const per_wave = queued / gridDim.x;
+  uint32_t const per_wave = queued / G;
   uint32_t const CLAIM = claim ? claim : per_wave >= 32u ? 4u : per_wave >= 12u ? 2u : 1u;
   // ... and three quarters of a wavefront's even share are its own without asking (task w, w + G, w + 2 G, ... of a grid
   // of G wavefronts): thousands of wavefronts asking one counter at the kernel's start cost as much as the tasks
   // (short queues only: a long one -- dense graphs -- holds tasks of very different cost, and a fixed share costs more in
   //  imbalance than the atomics do)
-  uint32_t const G = gridDim.x, own = (claim || per_wave > 8u) ? 0u : per_wave * 3u / 4u;
+  uint32_t const own = (claim || per_wave > 8u) ? 0u : per_wave * 3u / 4u;
   uint32_t n_forward = 0; // forward tasks this wavefront did (statistics: one add per wavefront at the end)
   for (uint32_t i = 0, t = 0, t_end = 0;; ++i, ++t)
   {
@@ -804,8 +819,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_GENERAL_
     n_forward += orient == 0 ? 1u : 0u;
     uint32_t const len = WaveHip::uni(static_cast<uint32_t>(meta[read].l_qseq));
     uint32_t * rec = records + static_cast<uint64_t>(task) * rec_words;
+#ifdef GTX_PROF
+    unsigned long long const task_t0 = clock64();
+#endif
     uint32_t const st = align_one<WaveHip>(g, ix, ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words,
                                            /*try_fast=*/false);
+#ifdef GTX_PROF
+    // (profiling build: how long the slowest tasks are -- a short queue ends with its longest task: [10] = the longest task's
+    //  cycles << 32 | its task id, [11] / [12] / [13] = tasks of more than 100 k / 200 k / 400 k cycles, [14] = this kernel's
+    //  first-to-last cycle span is left to the host's events)
+    if ((threadIdx.x & 63u) == 0)
+    {
+      unsigned long long const dt = clock64() - task_t0;
+      atomicMax(g.prof + 10, (dt << 32) | task);
+      if (dt > 100000ull)
+        atomicAdd(g.prof + 11, 1ull);
+      if (dt > 200000ull)
+        atomicAdd(g.prof + 12, 1ull);
+      if (dt > 400000ull)
+        atomicAdd(g.prof + 13, 1ull);
+    }
+#endif
     // a table of this pass overflowed: queue the task for the next pass (gtx_align_big_kernel)
     if (big_tasks && ((st & (GTX_ST_LABEL_OVERFLOW | GTX_ST_PATH_OVERFLOW | GTX_ST_DFS_OVERFLOW | GTX_ST_RECORD_OVERFLOW)) || force_big) &&
         (threadIdx.x & 63u) == 0)
@@ -1774,7 +1808,10 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     // grids: as many single-wave workgroups as are resident at once; they pull work from shared counters
     uint64_t const chunks = (static_cast<uint64_t>(n) + TASK_CHUNK - 1) / TASK_CHUNK;
     uint32_t const blocks1 = static_cast<uint32_t>(std::min<uint64_t>(chunks, static_cast<uint64_t>(n_cu) * c->express_blocks_per_cu));
-    uint32_t const blocks2 = static_cast<uint32_t>(std::min<uint64_t>(2ull * n, static_cast<uint64_t>(n_cu) * c->align_blocks_per_cu));
+    // (GTX_GENERAL_GRID=<wavefronts per CU>: A/B switch; default: as many as are resident)
+    char const * eg = std::getenv("GTX_GENERAL_GRID");
+    uint32_t const general_per_cu = eg && std::atoi(eg) > 0 ? static_cast<uint32_t>(std::atoi(eg)) : static_cast<uint32_t>(c->align_blocks_per_cu);
+    uint32_t const blocks2 = static_cast<uint32_t>(std::min<uint64_t>(2ull * n, static_cast<uint64_t>(n_cu) * general_per_cu));
     uint32_t const blocks4 = static_cast<uint32_t>(std::min<uint64_t>(
       chunks, static_cast<uint64_t>(n_cu) * (wide ? c->express4_wide_blocks_per_cu : c->express4_blocks_per_cu)));
     mark(part, 0, st);
@@ -1797,8 +1834,10 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
         front_done();
       // (the queue's length is known on the device only: the grid is what can be resident, or one wavefront per group of four
       //  reads of a small batch; the kernel sizes its claims to the queue)
-      uint32_t const blocks4q = static_cast<uint32_t>(std::min<uint64_t>(
-        (static_cast<uint64_t>(n) + 3u) / 4u, static_cast<uint64_t>(n_cu) * (wide ? c->express4_wide_blocks_per_cu : c->express4_blocks_per_cu)));
+      char const * eq = std::getenv("GTX_EXPRESS_GRID"); // (A/B switch: wavefronts per CU of the express pass)
+      uint32_t const express_per_cu = eq && std::atoi(eq) > 0 ? static_cast<uint32_t>(std::atoi(eq))
+                                                               : static_cast<uint32_t>(wide ? c->express4_wide_blocks_per_cu : c->express4_blocks_per_cu);
+      uint32_t const blocks4q = static_cast<uint32_t>(std::min<uint64_t>((static_cast<uint64_t>(n) + 3u) / 4u, static_cast<uint64_t>(n_cu) * express_per_cu));
       hipLaunchKernelGGL(wide ? gtx_align_express4q_wide_kernel : gtx_align_express4q_kernel, dim3(blocks4q), dim3(64), 0, s1, c->dev_graph,
                          c->dev_index, seq, seq_stride, meta, records, rec_words, counters, queue1, counters + 3, queue2, counters + 2,
                          counters + 4, static_cast<uint32_t>(force != 0));

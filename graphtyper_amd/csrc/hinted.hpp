@@ -672,9 +672,11 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   //      only one of its length; the shorter side of a hole chains into a path remove_short_paths drops)
   uint32_t lo = 0, hi = n_k - 1;
   bool par_start = false;
+  bool decided = false;                   // two runs of one length: the walks' outcome is worked out below, once for both
+  uint32_t two_rs = 0, two_re = 0, two_mism = 0;
   if (labelled != (1u << n_k) - 1u)
   {
-    uint32_t best_lo = 0, best_len = 0, second = 0, cur_lo = 0, cur_len = 0;
+    uint32_t best_lo = 0, best_len = 0, second = 0, second_lo = 0, n_best = 0, cur_lo = 0, cur_len = 0;
 #pragma unroll
     for (uint32_t k = 0; k <= AlignCfg::KC; ++k)
     {
@@ -688,26 +690,82 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
         if (cur_len > best_len)
         {
           second = best_len;
+          second_lo = best_lo;
           best_len = cur_len;
           best_lo = cur_lo;
+          n_best = 1;
+        }
+        else if (cur_len != 0 && cur_len == best_len)
+        {
+          second = cur_len;
+          second_lo = cur_lo;
+          ++n_best;
         }
         else if (cur_len > second)
+        {
           second = cur_len;
+          second_lo = cur_lo;
+        }
         cur_len = 0;
       }
     }
-    // (a run that opens with a parallel chain behind a hole is returned twice by the reference: not here)
     if (best_len <= second)
     {
-      // (every k-mer's lists are known by now, and the express pass has this very rule: it would unpack the read, look
-      //  everything up and decline as well -- the read goes to the general pass directly)
-      GTX_HINT_NOTE(10);
-      return HINT_TO_GENERAL;
+      // Two runs A (in front) and B of one length: both chains survive the first remove_short_paths and both are walked, A
+      // first, with ONE shrinking budget per direction (genotype_paths.cpp:483-621: a walk that comes in under the best so
+      // far drops the labels of the walks before it).  With the whole read inside one reference node every walk is one
+      // compare with the linear reference -- the counts of hint_compare -- and the outcome is arithmetic: each chain's span
+      // and mismatches behind the walks, the longer one stays (remove_short_paths).  Left to the general pass (which the
+      // express pass would only hand it to as well): more than two such runs, a k-mer that opens a parallel chain, a site
+      // under the read, chains that end up equally long (the reference returns both).
+      uint32_t const a_lo = best_lo, b_lo = second_lo, len = best_len;
+      uint32_t const run_a = ((1u << len) - 1u) << a_lo, run_b = ((1u << len) - 1u) << b_lo;
+      if (best_len == 0 || n_best != 2 || (f0.y & 255u) < L || (par & (run_a | run_b)) != 0)
+      {
+        GTX_HINT_NOTE(10);
+        return HINT_TO_GENERAL;
+      }
+      uint32_t const all = hc_all(h);
+      auto upto = [&](uint32_t j) { return j == 0 ? 0u : hc_upto(h, j); };
+      auto cap = [](uint32_t n, uint32_t best) { return 2u + n / 11u < best ? 2u + n / 11u : best; };
+      // walk_read_starts: the bases [0, 31 lo] in front of (and with) each chain's first base
+      uint32_t best = 7;
+      uint32_t const head_a = upto(a_lo) + (a_lo ? hc_edge(h, a_lo) : 0u), head_b = upto(b_lo) + hc_edge(h, b_lo);
+      bool got_a = a_lo != 0 && head_a <= cap((K - 1) * a_lo + 1u, best);
+      best = got_a ? head_a : best;
+      bool const got_b = head_b <= cap((K - 1) * b_lo + 1u, best);
+      got_a = got_a && !(got_b && head_b < best); // (cannot be: A's piece is inside B's)
+      uint32_t const rs_a = (got_a || a_lo == 0) ? 0u : (K - 1) * a_lo, rs_b = got_b ? 0u : (K - 1) * b_lo;
+      uint32_t mm_a = static_cast<uint32_t>(__builtin_popcount(mmk & run_a)) + (got_a ? head_a : 0u);
+      uint32_t mm_b = static_cast<uint32_t>(__builtin_popcount(mmk & run_b)) + (got_b ? head_b : 0u);
+      // walk_read_ends: the bases [31 (hi + 1), L) behind (and with) each chain's last base
+      uint32_t const end_a = (K - 1) * (a_lo + len), end_b = (K - 1) * (b_lo + len);
+      uint32_t const tail_a = all - upto(a_lo + len), tail_b = all - upto(b_lo + len);
+      best = 7;
+      bool end_ok_a = tail_a <= cap(L - end_a, best);
+      best = end_ok_a ? tail_a : best;
+      bool const end_ok_b = end_b != L - 1 && tail_b <= cap(L - end_b, best);
+      end_ok_a = end_ok_a && !(end_ok_b && tail_b < best); // (B's walk came in under A's: A's labels are dropped)
+      uint32_t const re_a = end_ok_a ? L - 1 : end_a, re_b = (end_ok_b || end_b == L - 1) ? L - 1 : end_b;
+      mm_a += end_ok_a ? tail_a : 0u;
+      mm_b += end_ok_b ? tail_b : 0u;
+      uint32_t const size_a = re_a - rs_a + 1u, size_b = re_b - rs_b + 1u;
+      if (size_a == size_b)
+      {
+        GTX_HINT_NOTE(10);
+        return HINT_TO_GENERAL;
+      }
+      bool const a_wins = size_a > size_b;
+      decided = true;
+      two_rs = a_wins ? rs_a : rs_b;
+      two_re = a_wins ? re_a : re_b;
+      two_mism = a_wins ? mm_a : mm_b;
+      best_lo = a_wins ? a_lo : b_lo;
     }
     // A run that opens, behind a label-less k-mer, with a k-mer that brings TWO label lists (a multi-key list is added with
     // 0 and with 1 mismatch, alignment.cpp:57-63; an exact key with indexed neighbours has its own and theirs) starts two
     // parallel chains: see `twin` below.
-    par_start = best_lo > 0 && ((par >> best_lo) & 1u) != 0;
+    par_start = !decided && best_lo > 0 && ((par >> best_lo) & 1u) != 0;
     lo = best_lo;
     hi = best_lo + best_len - 1;
   }
@@ -757,7 +815,7 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   };
   uint32_t head_site = 0, head_mask = 0; // the site the walk at the read's start crossed, with its best alleles
   bool head_on_site = false;             // ... which started inside the allele the path carries on a site
-  if (prs != 0) // walk_read_starts (genotype_paths.cpp:555-621)
+  if (prs != 0 && !decided) // walk_read_starts (genotype_paths.cpp:555-621)
   {
     uint32_t const y = lo == 1 ? f1.y : lo == 2 ? f2.y : lo == 3 ? f3.y : f4.y; // (position 31 lo is k-mer lo's own place)
     uint32_t const back = (y >> HINT_BACK_SHIFT) & 255u;
@@ -803,7 +861,15 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   }
   uint32_t end = g.first_order + idx + pre, re = pre;
   uint32_t tail_site = 0, tail_mask = 0; // the site the walk at the read's end crossed, with its best alleles
-  if (pre != L - 1) // walk_read_ends (genotype_paths.cpp:483-553)
+  if (decided) // (two runs of one length, inside one reference node: worked out above)
+  {
+    start = g.first_order + idx + two_rs;
+    rs = two_rs;
+    re = two_re;
+    end = g.first_order + idx + two_re;
+    mism = two_mism;
+  }
+  else if (pre != L - 1) // walk_read_ends (genotype_paths.cpp:483-553)
   {
     uint32_t const tail_len = L - pre;
     uint32_t const y = hi + 1 == n_k ? y_end : hi == 0 ? f1.y : hi == 1 ? f2.y : hi == 2 ? f3.y : f4.y;
