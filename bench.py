@@ -445,8 +445,13 @@ class Workload:
         spH = C.c_void_p(H.cuda_stream)
         evs, flight = [], []
         n_l = len(self.lanes)
+        pace = os.environ.get("GTX_BENCH_PACE", "0") != "0"  # (test switch; measured: no effect on the step, 1.5 % slower)
         for _ in range(steps):
             ln = self.lanes[self.steps_done % n_l]
+            if pace:
+                # (the host stays at most n_l steps ahead of the device: the lane's last scoring is through before its next step
+                #  is queued -- streams with dozens of queued cross-stream waits ran the same schedule at half the speed now and then)
+                ln["scored"].synchronize()
             T = self.tail_streams[self.steps_done % len(self.tail_streams)]
             spT = C.c_void_p(T.cuda_stream)
             d_seq, d_meta, d_items = self.sets[self.steps_done % len(self.sets)]
@@ -480,10 +485,32 @@ class Workload:
         #  it the exchange, is all on one stream; one communicator takes one collective at a time)
         n_lanes = len(self.lanes) if (stag or not exchange) else 1
         # (setup, not steps of the run: the first calls that are in flight together allocate their scratch inside the library)
+        self.calibration = None
         if stag:
             self.steps_staggered(n_lanes)
             self.steps_done -= n_lanes
             torch.cuda.synchronize()
+            # Setup as well: which schedule this box runs faster.  Steps in flight on two streams were 1.5-3 times SLOWER than
+            # one step at a time on about one box in six (same build, same driver; one step at a time is not affected), so the
+            # run looks before it chooses: a few steps each way, the slower rank decides for all.
+            def timed(fn, k):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                fn(k)
+                torch.cuda.synchronize()
+                self.steps_done -= k
+                return (time.perf_counter() - t) / k
+            t_stag = min(timed(self.steps_staggered, 2 * n_lanes) for _ in range(2))
+            t_one = min(timed(lambda k: [self.step(0) for _ in range(k)], 4) for _ in range(2))
+            both = torch.tensor([t_stag, t_one], dtype=torch.float64, device=self.device)
+            if dist is not None:
+                dist.all_reduce(both, op=dist.ReduceOp.MAX)
+            t_stag, t_one = (float(x) for x in both.cpu())
+            self.calibration = {"staggered_ms_per_step": 1000.0 * t_stag, "one_at_a_time_ms_per_step": 1000.0 * t_one}
+            if t_stag > t_one:
+                stag, n_lanes = False, 1
+                self.staggered = False
+        if stag:
             if warmup:
                 self.steps_staggered(warmup)
         else:
@@ -498,6 +525,7 @@ class Workload:
             dist.barrier()
         torch.cuda.synchronize()
         self.reduce_events = []
+        self.used_lanes = n_lanes
         t0 = time.perf_counter()
         evs = self.steps_staggered(steps) if stag else [self.step(k % n_lanes) for k in range(steps)]
         torch.cuda.synchronize()
@@ -1083,7 +1111,8 @@ def main(argv=None):
            "ctx_create_s": round(t_ctx_warm, 3), "ctx_create_first_s": round(t_ctx, 3),
            "position_hint": not args.no_hint, "task_flags_side_array": USE_TASK_FLAGS,
            "read_layout": "bit planes (gtx_align_batch_planes; repacked once from BAM nibbles by gtx_reads_to_planes before the timed region)" if PLANE_INPUT else "BAM nibbles (gtx_align_batch_flags repacks them inside every call)", "resident_read_sets": len(w.sets),
-           "streams": {"steps_in_flight": len(w.lanes), "schedule": ("staggered" if w.staggered else "lanes") if len(w.lanes) > 1 else "serial",
+           "streams": {"steps_in_flight": w.used_lanes, "schedule": ("staggered" if w.staggered else "lanes") if w.used_lanes > 1 else "one step at a time",
+                       "calibration": w.calibration,
                        "step_alone_ms": step_alone_ms,
                        "note": "every step is align -> score -> calls on its own records and accumulators. staggered: stream H carries, one "
                                "kernel after the other, the position-hinted pass of step k and the scoring of step k-2; stream T the short "

@@ -689,7 +689,8 @@ __device__ __forceinline__ void express4_queue_pass(GraphView const & g, IndexVi
   // them start at once on a CU the more each pays (cfg2, 5.2 k groups: 16 / 8 / 4 wavefronts per CU = 0.194 / 0.129 /
   // 0.127 ms).
   uint32_t const n_groups = (n + 3u) / 4u, G_all = gridDim.x;
-  uint32_t const G_want = (n_groups + EXPRESS_GROUPS_PER_WAVE - 1u) / EXPRESS_GROUPS_PER_WAVE;
+  uint32_t const per_wave_goal = (queue_all >> 8) ? (queue_all >> 8) : EXPRESS_GROUPS_PER_WAVE; // (bits 8..: A/B override)
+  uint32_t const G_want = (n_groups + per_wave_goal - 1u) / per_wave_goal;
   uint32_t const G = G_want >= G_all ? G_all : G_want > 0u ? G_want : 1u;
   if (blockIdx.x >= G)
     return;
@@ -730,7 +731,7 @@ __device__ __forceinline__ void express4_queue_pass(GraphView const & g, IndexVi
       break;
     uint32_t const first = 4u * grp;
     uint32_t const n_valid = n - first < 4 ? n - first : 4;
-    uint32_t const fwd_mask = express4<WaveHip, E4>(g, ix, ws, seq, seq_stride, meta, 0, n_valid, records, rec_words, queue_all != 0, queue1 + first);
+    uint32_t const fwd_mask = express4<WaveHip, E4>(g, ix, ws, seq, seq_stride, meta, 0, n_valid, records, rec_words, (queue_all & 1u) != 0, queue1 + first);
     for (uint32_t k = 0; k < n_valid; ++k)
       if ((fwd_mask >> k) & 1u)
       {
@@ -788,7 +789,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_GENERAL_
   uint32_t const queued = queue_count[0];
   // (a short queue is done by a part of the grid, three tasks per wavefront, as in the express pass: cfg2, 7.6 k tasks:
   //  20 / 12 / 8 / 4 wavefronts per CU = 0.38 / 0.33 / 0.33 / 0.40 ms)
-  uint32_t const G_all = gridDim.x, G_want = (queued + GENERAL_TASKS_PER_WAVE - 1u) / GENERAL_TASKS_PER_WAVE;
+  uint32_t const per_wave_goal = (force_big >> 8) ? (force_big >> 8) : GENERAL_TASKS_PER_WAVE; // (bits 8..: A/B override)
+  uint32_t const G_all = gridDim.x, G_want = (queued + per_wave_goal - 1u) / per_wave_goal;
   uint32_t const G = G_want >= G_all ? G_all : G_want > 0u ? G_want : 1u;
   if (blockIdx.x >= G)
     return;
@@ -841,7 +843,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_GENERAL_
     }
 #endif
     // a table of this pass overflowed: queue the task for the next pass (gtx_align_big_kernel)
-    if (big_tasks && ((st & (GTX_ST_LABEL_OVERFLOW | GTX_ST_PATH_OVERFLOW | GTX_ST_DFS_OVERFLOW | GTX_ST_RECORD_OVERFLOW)) || force_big) &&
+    if (big_tasks && ((st & (GTX_ST_LABEL_OVERFLOW | GTX_ST_PATH_OVERFLOW | GTX_ST_DFS_OVERFLOW | GTX_ST_RECORD_OVERFLOW)) || (force_big & 1u)) &&
         (threadIdx.x & 63u) == 0)
     {
       uint32_t const slot = atomicAdd(big_state, 1u);
@@ -1808,6 +1810,8 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     // grids: as many single-wave workgroups as are resident at once; they pull work from shared counters
     uint64_t const chunks = (static_cast<uint64_t>(n) + TASK_CHUNK - 1) / TASK_CHUNK;
     uint32_t const blocks1 = static_cast<uint32_t>(std::min<uint64_t>(chunks, static_cast<uint64_t>(n_cu) * c->express_blocks_per_cu));
+    char const * egw = std::getenv("GTX_GENERAL_PER_WAVE"); // (A/B switch: tasks a wavefront of a short queue should find)
+    uint32_t const general_goal = egw && std::atoi(egw) > 0 ? static_cast<uint32_t>(std::atoi(egw)) : 0u;
     // (GTX_GENERAL_GRID=<wavefronts per CU>: A/B switch; default: as many as are resident)
     char const * eg = std::getenv("GTX_GENERAL_GRID");
     uint32_t const general_per_cu = eg && std::atoi(eg) > 0 ? static_cast<uint32_t>(std::atoi(eg)) : static_cast<uint32_t>(c->align_blocks_per_cu);
@@ -1834,13 +1838,15 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
         front_done();
       // (the queue's length is known on the device only: the grid is what can be resident, or one wavefront per group of four
       //  reads of a small batch; the kernel sizes its claims to the queue)
+      char const * ew = std::getenv("GTX_EXPRESS_PER_WAVE"); // (A/B switch: groups a wavefront of a short queue should find)
+      uint32_t const express_goal = ew && std::atoi(ew) > 0 ? static_cast<uint32_t>(std::atoi(ew)) : 0u;
       char const * eq = std::getenv("GTX_EXPRESS_GRID"); // (A/B switch: wavefronts per CU of the express pass)
       uint32_t const express_per_cu = eq && std::atoi(eq) > 0 ? static_cast<uint32_t>(std::atoi(eq))
                                                                : static_cast<uint32_t>(wide ? c->express4_wide_blocks_per_cu : c->express4_blocks_per_cu);
       uint32_t const blocks4q = static_cast<uint32_t>(std::min<uint64_t>((static_cast<uint64_t>(n) + 3u) / 4u, static_cast<uint64_t>(n_cu) * express_per_cu));
       hipLaunchKernelGGL(wide ? gtx_align_express4q_wide_kernel : gtx_align_express4q_kernel, dim3(blocks4q), dim3(64), 0, s1, c->dev_graph,
                          c->dev_index, seq, seq_stride, meta, records, rec_words, counters, queue1, counters + 3, queue2, counters + 2,
-                         counters + 4, static_cast<uint32_t>(force != 0));
+                         counters + 4, static_cast<uint32_t>(force != 0) | (express_goal << 8));
     }
     else
     {
@@ -1866,7 +1872,7 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     mark(part, 3, sg);
     hipLaunchKernelGGL(gtx_align_kernel, dim3(blocks2), dim3(64), 0, sg, c->dev_graph, c->dev_index, seq, seq_stride, meta, records, rec_words,
                        queue2, counters + 2, counters + 1, second_pass ? s->d_big_tasks : nullptr, s->big_task_cap, s->d_big_state,
-                       static_cast<uint32_t>(force == 1), 2u * first, general_claim, counters + 5);
+                       static_cast<uint32_t>(force == 1) | (general_goal << 8), 2u * first, general_claim, counters + 5);
     if (!hip_ok(hipGetLastError(), "gtx_align_kernel launch"))
       return GTX_ERR_HIP;
     mark(part, 4, sg);
