@@ -302,8 +302,9 @@ class Workload:
             lane["sp"] = C.c_void_p(lane["stream"].cuda_stream)
             gtx.check(self.L.gtx_scores_alloc(ctx.h, n_samples, conn_cap, C.byref(lane["buf"]), C.byref(reduced)))
             self.lanes.append(lane)
-        # (staggered schedule: the short queues behind every position-hinted pass, those of consecutive steps on different streams)
-        self.tail_streams = [torch.cuda.Stream(device=device) for _ in range(max(1, int(os.environ.get("GTX_BENCH_TAILS", "2"))))]
+        # (staggered schedule: the short queues behind every position-hinted pass; GTX_BENCH_TAILS=2: those of consecutive steps on
+        #  two streams -- measured the same)
+        self.tail_streams = [torch.cuda.Stream(device=device) for _ in range(max(1, int(os.environ.get("GTX_BENCH_TAILS", "1"))))]
         for ln in self.lanes:
             ln["front"], ln["aligned"], ln["scored"] = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
             for ev in (ln["front"], ln["aligned"], ln["scored"]):
@@ -461,10 +462,10 @@ class Workload:
                 e0.record(H)
                 fl = ln["d_flags"].data_ptr() if ln["d_flags"] is not None else None
                 gtx.check(L.gtx_align_batch_planes_staged(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, ln["d_rec"].data_ptr(),
-                                                          REC_WORDS, fl, spH, C.c_void_p(ln["front"].cuda_event), spT))
+                                                          REC_WORDS, fl, spH, C.c_void_p(ln["front"].cuda_event), spT,
+                                                          C.c_void_p(ln["aligned"].cuda_event)))
             with torch.cuda.stream(T):
                 e1.record(T)
-                ln["aligned"].record(T)
             ln["items"] = d_items
             evs.append((e0, e1))
             flight.append(ln)

@@ -1587,7 +1587,7 @@ extern "C" int gtx_reads_to_planes(gtx_ctx * c, const uint8_t * d_seq, uint32_t 
 
 static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
                         uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, hipStream_t st, hipEvent_t front_event = nullptr,
-                        hipStream_t tail_stream = nullptr);
+                        hipStream_t tail_stream = nullptr, hipEvent_t done_event = nullptr, hipStream_t * last_stream = nullptr);
 
 // BAM nibble rows: repacked into plane rows in the call's scratch, then the same kernels
 extern "C" int gtx_align_batch_flags(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta,
@@ -1623,12 +1623,12 @@ extern "C" int gtx_align_batch_flags(gtx_ctx * c, const uint8_t * d_seq, uint32_
 extern "C" int gtx_align_batch_planes(gtx_ctx * c, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta,
                                       uint32_t n_reads, uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream)
 {
-  return gtx_align_batch_planes_staged(c, d_planes, plane_stride, d_meta, n_reads, d_records, rec_words, d_task_flags, stream, nullptr, nullptr);
+  return gtx_align_batch_planes_staged(c, d_planes, plane_stride, d_meta, n_reads, d_records, rec_words, d_task_flags, stream, nullptr, nullptr, nullptr);
 }
 
 extern "C" int gtx_align_batch_planes_staged(gtx_ctx * c, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta,
                                              uint32_t n_reads, uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream,
-                                             void * front_event, void * tail_stream)
+                                             void * front_event, void * tail_stream, void * done_event)
 {
   if (!c || rec_words < 8 || plane_stride == 0 || (plane_stride % PLANE_GROUP_BYTES) != 0 || (reinterpret_cast<uintptr_t>(d_planes) & 15u) != 0 ||
       (n_reads != 0 && (!d_planes || !d_meta || !d_records)))
@@ -1649,7 +1649,11 @@ extern "C" int gtx_align_batch_planes_staged(gtx_ctx * c, const uint8_t * d_plan
   }
   if (n_reads == 0)
   {
-    if (front_event && (!hip_ok(hipSetDevice(c->device), "hipSetDevice") || !hip_ok(hipEventRecord(static_cast<hipEvent_t>(front_event), st), "front event")))
+    if ((front_event || done_event) && !hip_ok(hipSetDevice(c->device), "hipSetDevice"))
+      return GTX_ERR_HIP;
+    if (front_event && !hip_ok(hipEventRecord(static_cast<hipEvent_t>(front_event), st), "front event"))
+      return GTX_ERR_HIP;
+    if (done_event && !hip_ok(hipEventRecord(static_cast<hipEvent_t>(done_event), st), "done event"))
       return GTX_ERR_HIP;
     return GTX_OK;
   }
@@ -1660,15 +1664,18 @@ extern "C" int gtx_align_batch_planes_staged(gtx_ctx * c, const uint8_t * d_plan
     return GTX_ERR_HIP;
   // (with a tail stream the call ends there: the scratch is free when THAT stream is through -- and is not handed to the
   //  next call on `stream` by stream order, which would reset queues the tail still reads)
-  if (tail_stream && !std::getenv("GTX_PARTS"))
-    hold.stream = static_cast<hipStream_t>(tail_stream);
-  return align_planes(c, hold.s, d_planes, plane_stride, d_meta, n_reads, d_records, rec_words, d_task_flags, st, static_cast<hipEvent_t>(front_event),
-                      std::getenv("GTX_PARTS") ? nullptr : static_cast<hipStream_t>(tail_stream));
+  hipStream_t last = st;
+  int const rc = align_planes(c, hold.s, d_planes, plane_stride, d_meta, n_reads, d_records, rec_words, d_task_flags, st,
+                              static_cast<hipEvent_t>(front_event), std::getenv("GTX_PARTS") ? nullptr : static_cast<hipStream_t>(tail_stream),
+                              static_cast<hipEvent_t>(done_event), &last);
+  hold.stream = last; // (the stream the call's last launch is on)
+  return rc;
 }
 
 // the passes over plane rows (d_seq / seq_stride: the plane rows and their pitch)
 static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
-                        uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, hipStream_t st, hipEvent_t front_event, hipStream_t tail_stream)
+                        uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, hipStream_t st, hipEvent_t front_event, hipStream_t tail_stream,
+                        hipEvent_t done_event, hipStream_t * last_stream)
 {
   if (!hip_ok(hipMemsetAsync(s->d_counters, 0, 8 * CallScratch::MAX_PARTS * sizeof(uint32_t), st), "task counter reset"))
     return GTX_ERR_HIP;
@@ -1732,7 +1739,15 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
   uint32_t parts = 1u;
   if (ep)
     parts = static_cast<uint32_t>(std::min<long>(std::max<long>(std::atol(ep), 1), CallScratch::MAX_PARTS));
-  if (parts > 1 && !s->side_stream)
+  // (gtx_align_batch_planes_staged with a done event: the HBM-table pass and what follows it on a stream of the scratch's own)
+  // (GTX_OWN_END=1: the HBM-table pass and what follows it on a stream of the scratch's own behind the general pass -- it has no
+  //  task on most batches but wants 196 registers per wavefront to be placed, 0.14 ms of waiting beside a full chip that the
+  //  tail stream need not share.  Measured: 1.12 ms per cfg2 step against 0.85 -- the runtime folds more streams than it has
+  //  hardware queues onto the same ones, and the schedule loses its overlap.  Off; the done event is recorded on the tail
+  //  stream.)
+  char const * eo = std::getenv("GTX_OWN_END");
+  bool const own_end = done_event != nullptr && tail_stream != nullptr && tail_stream != st && parts == 1 && eo && eo[0] == '1';
+  if ((parts > 1 || own_end) && !s->side_stream)
   {
     hipStream_t side;
     if (!hip_ok(hipStreamCreateWithFlags(&side, hipStreamNonBlocking), "side stream"))
@@ -1877,6 +1892,14 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
       return GTX_ERR_HIP;
     mark(part, 4, sg);
   }
+  if (own_end && sg == tail_stream)
+  {
+    // The HBM-table pass has no task on most batches but wants 196 registers per wavefront to be placed at all: beside a
+    // full chip that is 0.14 ms of waiting, which the tail stream -- the next batch's queues are behind it -- need not share.
+    (void)hipEventRecord(static_cast<hipEvent_t>(s->sync_events[0]), sg);
+    sg = static_cast<hipStream_t>(s->side_stream);
+    (void)hipStreamWaitEvent(sg, static_cast<hipEvent_t>(s->sync_events[0]), 0);
+  }
   if (second_pass)
   {
     hipLaunchKernelGGL(gtx_align_big_kernel, dim3(c->big_blocks), dim3(64), 0, sg, c->dev_graph, c->dev_index, d_seq, seq_stride, d_meta,
@@ -1917,6 +1940,10 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     }
   }
   mark(0, 5, sg);
+  if (done_event)
+    (void)hipEventRecord(done_event, sg);
+  if (last_stream)
+    *last_stream = sg;
   if (parts > 1)
   {
     // the caller's stream goes on when the side stream is through

@@ -150,7 +150,7 @@ def lib():
         L.gtx_reads_to_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.gtx_align_batch_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.gtx_align_batch_planes_staged.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
-                                                    C.c_void_p, C.c_void_p]
+                                                    C.c_void_p, C.c_void_p, C.c_void_p]
         L.gtx_stream_set_planes.argtypes = [C.c_void_p, C.c_uint32]
         L.gtx_score_batch_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(ScoreBuffers), C.c_void_p]
         L.gtx_reads_open.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.POINTER(C.c_void_p)]

@@ -315,10 +315,12 @@ int gtx_align_batch_planes(gtx_ctx *, const uint8_t * d_planes, uint32_t plane_s
  * tail_stream (may be NULL = `stream`; needs front_event): those passes are launched THERE, behind the event, and the call
  * is complete when tail_stream is -- `stream` is free for the next batch's position-hinted pass, or for the scoring of an
  * earlier one, while the queues drain beside it (bench.py: the staggered schedule, three batches in flight).  Without a
- * position-hinted pass (no hint tables, GTX_HINT=0) the event marks the call's start. */
+ * position-hinted pass (no hint tables, GTX_HINT=0) the event marks the call's start.
+ * done_event (may be NULL): recorded behind the call's LAST launch, on whichever stream that is -- what the reader of the
+ * batch's records waits for. */
 int gtx_align_batch_planes_staged(gtx_ctx *, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
                                   uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream, void * front_event,
-                                  void * tail_stream);
+                                  void * tail_stream, void * done_event);
 
 /* Score accumulators (all uint32 / uint64, zero-initialised by the caller; sample-major):
  *   d_log_score [n_samples * total_tri]      HapSample::log_score

@@ -255,11 +255,13 @@ def test_batches_in_flight_equal_one_at_a_time():
         held.append((d_p, d_m, d_rec, d_fl))
     torch.cuda.synchronize()
     for (a, b), (d_p, d_m, d_rec, d_fl) in zip(parts, held):
-        ev = torch.cuda.Event()
-        ev.record(H)  # (creates the HIP event)
-        fronts.append(ev)
+        ev, done = torch.cuda.Event(), torch.cuda.Event()
+        ev.record(H)  # (creates the HIP events)
+        done.record(H)
+        fronts.append((ev, done))
         gtx.check(L.gtx_align_batch_planes_staged(ctx.h, d_p.data_ptr(), stride, d_m.data_ptr(), b - a, d_rec.data_ptr(), harness.REC_WORDS,
-                                                  d_fl.data_ptr(), C.c_void_p(H.cuda_stream), C.c_void_p(ev.cuda_event), C.c_void_p(T.cuda_stream)))
+                                                  d_fl.data_ptr(), C.c_void_p(H.cuda_stream), C.c_void_p(ev.cuda_event), C.c_void_p(T.cuda_stream),
+                                                  C.c_void_p(done.cuda_event) if (a // 1000) % 2 else None))
     torch.cuda.synchronize()
     for (w_rec, w_fl), (_, _, d_rec, d_fl) in zip(want, held):
         assert np.array_equal(d_rec.cpu().numpy(), w_rec) and np.array_equal(d_fl.cpu().numpy(), w_fl)
@@ -270,4 +272,4 @@ def test_batches_in_flight_equal_one_at_a_time():
     # a tail stream without the front event is refused
     d_p, d_m, d_rec, d_fl = held[0]
     assert L.gtx_align_batch_planes_staged(ctx.h, d_p.data_ptr(), stride, d_m.data_ptr(), 10, d_rec.data_ptr(), harness.REC_WORDS, None,
-                                           C.c_void_p(H.cuda_stream), None, C.c_void_p(T.cuda_stream)) != 0
+                                           C.c_void_p(H.cuda_stream), None, C.c_void_p(T.cuda_stream), None) != 0
