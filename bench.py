@@ -942,12 +942,13 @@ def extra_cfg3(args, torch, gtx, synth, device, ref, kind="cfg3"):
     codes, pos = codes[order], pos[order]
     d_seq = torch.from_numpy(gtx.pack_nibbles(codes)).to(device)
     samples = np.random.default_rng(3).integers(0, 30, size=n).astype(np.uint32)
-    w = Workload(torch, gtx, ctx, device, d_seq, torch.from_numpy(pos), 30, samples=samples, hint=not args.no_hint)
+    w = Workload(torch, gtx, ctx, device, d_seq, torch.from_numpy(pos), 30, samples=samples, hint=not args.no_hint, lanes=args.lanes)
+    w.staggered = args.schedule == "staggered" and len(w.lanes) >= 2  # (the same schedule as the main workload, chosen the same way)
     if args.read_sets > 1:  # a second set of reads: the steps alternate
         codes2, pos2 = synth.make_reads(ref, recs, n, read_len=READ_LEN, seed=6, region_begin=REGION_BEGIN)
         order2 = np.argsort(pos2, kind="stable")
         w.add_reads(torch.from_numpy(gtx.pack_nibbles(codes2[order2])).to(device), torch.from_numpy(pos2[order2]))
-    steps = 4
+    steps = 9 if len(w.lanes) > 1 else 4
     dt, _ = w.run(steps, 2, None)
     ms, handed = ctx.pass_times()
     facts = w.result_facts()
@@ -973,7 +974,9 @@ def extra_cfg3(args, torch, gtx, synth, device, ref, kind="cfg3"):
             "(add_all_variants), max %d alleles per site") % (n, int(ctx.hap_cnum.max()))
     kt = ctx.kernel_times()
     out = {"workload": what, "align_kernels": {k[0]: {"ms": k[1], "tasks_completed": k[2]} for k in kt},
-           "reads_per_s": n * steps / dt, "ms_per_step": 1000.0 * dt / steps, "steps": steps, "resident_read_sets": len(w.sets), "sites": int(ctx.n_hap), "ctx_create_s": round(t_ctx, 3),
+           "reads_per_s": n * steps / dt, "ms_per_step": 1000.0 * dt / steps, "steps": steps,
+           "schedule": ("staggered, %d steps in flight" % w.used_lanes) if (w.staggered and w.used_lanes > 1) else "one step at a time",
+           "calibration": w.calibration, "resident_read_sets": len(w.sets), "sites": int(ctx.n_hap), "ctx_create_s": round(t_ctx, 3),
            "graph_build_s": round(t_graph, 3),
            "align_passes_ms": {"express": ms[0], "general": ms[1], "hbm_tables": ms[2]},
            "pass_shares": {"tasks": n, "handed_to_general": handed, "share_general": handed / float(n)}}
