@@ -235,11 +235,55 @@ std::string flatten_graph(gtx_graph_view const & g, gtx_params const & par, Host
 
 namespace
 {
+// The first and the last 31 bases of every node as 2-bit codes (a walk takes a node's bases from its end backwards, or --
+// its first piece -- from a position within 31 bases of a node's start back to that start: both are one shift and mask of
+// these instead of a loop over the bases).  sfx: the last base in bits 0-1, the one before it in bits 2-3, ...; pfx: base 0
+// in the highest of its 2 m bits (m = min(31, length)); *_ok: how many bases from that end are A/C/G/T.
+struct NodePacks
+{
+  std::vector<uint64_t> ref_sfx, ref_pfx, var_sfx, var_pfx;
+  std::vector<uint8_t> ref_sfx_ok, ref_pfx_ok, var_sfx_ok, var_pfx_ok;
+  static void pack(char const * dna, uint32_t len, uint64_t & sfx, uint8_t & sfx_ok, uint64_t & pfx, uint8_t & pfx_ok)
+  {
+    auto code = [](char c) -> int { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; };
+    uint32_t const m = len < K - 1 ? len : K - 1;
+    sfx = pfx = 0;
+    sfx_ok = pfx_ok = 0;
+    bool ok = true;
+    for (uint32_t i = 0; i < m; ++i)
+    {
+      int const c = code(dna[len - 1 - i]);
+      ok = ok && c >= 0;
+      sfx |= static_cast<uint64_t>(c < 0 ? 0 : c) << (2 * i);
+      sfx_ok = static_cast<uint8_t>(sfx_ok + (ok ? 1 : 0));
+    }
+    ok = true;
+    for (uint32_t j = 0; j < m; ++j)
+    {
+      int const c = code(dna[j]);
+      ok = ok && c >= 0;
+      pfx |= static_cast<uint64_t>(c < 0 ? 0 : c) << (2 * (m - 1 - j));
+      pfx_ok = static_cast<uint8_t>(pfx_ok + (ok ? 1 : 0));
+    }
+  }
+  explicit NodePacks(HostGraph const & g)
+  {
+    size_t const R = g.ref_order.size(), V = g.var_order.size();
+    ref_sfx.resize(R); ref_pfx.resize(R); ref_sfx_ok.resize(R); ref_pfx_ok.resize(R);
+    var_sfx.resize(V); var_pfx.resize(V); var_sfx_ok.resize(V); var_pfx_ok.resize(V);
+    for (size_t r = 0; r < R; ++r)
+      pack(g.dna.data() + g.ref_dna[r], g.ref_len[r], ref_sfx[r], ref_sfx_ok[r], ref_pfx[r], ref_pfx_ok[r]);
+    for (size_t v = 0; v < V; ++v)
+      pack(g.dna.data() + g.var_dna[v], g.var_len[v], var_sfx[v], var_sfx_ok[v], var_pfx[v], var_pfx_ok[v]);
+  }
+};
+
 struct Walker
 {
   HostGraph const & g;
   std::vector<Emit> & out;
   bool has_events;
+  NodePacks const & packs;
   // walk state (backwards): var nodes visited, how many bases of each were used
   uint32_t vars[K];
   uint32_t used[K];
@@ -327,58 +371,87 @@ struct Walker
       out.push_back({key, {start_label, end_label, vars[i]}});
   }
 
-  // take bases [.., off] of a node backwards; `have` bases collected so far in `key` (placed from the low end up)
+  // take bases [.., off] of a node backwards; `have` bases collected so far in `key` (placed from the low end up).  A walk
+  // enters a node at its last base, or starts -- have = 0 -- within 31 bases of a node's start: one shift and mask of the
+  // node's packed ends (NodePacks); a start deeper inside a long allele walks base by base.
   void back_ref(uint32_t r, int64_t off, uint32_t have, uint64_t key)
   {
-    char const * dna = g.dna.data() + g.ref_dna[r];
-    while (off >= 0)
+    uint32_t const len = g.ref_len[r];
+    uint32_t const n_here = static_cast<uint32_t>(off) + 1u, need = K - have, n = n_here < need ? n_here : need;
+    uint32_t const m = len < K - 1 ? len : K - 1;
+    if (static_cast<uint32_t>(off) + 1u == len && n <= m)
     {
-      int const c = code(dna[off]);
-      if (c < 0)
+      if (packs.ref_sfx_ok[r] < n)
         return;
-      key |= static_cast<uint64_t>(c) << (2 * have);
-      if (++have == K)
+      key |= (packs.ref_sfx[r] & ((1ull << (2 * n)) - 1ull)) << (2 * have);
+    }
+    else if (have == 0 && n_here <= m)
+    {
+      if (packs.ref_pfx_ok[r] < n_here)
+        return;
+      key = packs.ref_pfx[r] >> (2 * (m - n_here)); // (n = n_here: fewer than K bases to the node's start)
+    }
+    else
+    {
+      char const * dna = g.dna.data() + g.ref_dna[r];
+      for (uint32_t i = 0; i < n; ++i)
       {
-        finish(key, g.ref_order[r] + static_cast<uint32_t>(off));
-        return;
+        int const c = code(dna[off - i]);
+        if (c < 0)
+          return;
+        key |= static_cast<uint64_t>(c) << (2 * (have + i));
       }
-      --off;
+    }
+    have += n;
+    if (have == K)
+    {
+      finish(key, g.ref_order[r] + static_cast<uint32_t>(off) - (n - 1u));
+      return;
     }
     if (r == 0)
       return;
-    uint32_t const site = r - 1, fv = g.ref_first_var[site], n = g.ref_nvar[site];
-    for (uint32_t a = 0; a < n; ++a)
+    uint32_t const site = r - 1, fv = g.ref_first_var[site], nv = g.ref_nvar[site];
+    for (uint32_t a = 0; a < nv; ++a)
       back_var(fv + a, static_cast<int64_t>(g.var_len[fv + a]) - 1, have, key);
   }
 
   void back_var(uint32_t v, int64_t off, uint32_t have, uint64_t key)
   {
-    char const * dna = g.dna.data() + g.var_dna[v];
-    uint32_t const site = g.var_out_ref[v] - 1;
+    uint32_t const site = g.var_out_ref[v] - 1, len = g.var_len[v];
     uint32_t const slot = n_vars++;
     vars[slot] = v;
-    used[slot] = 0;
-    bool done = false;
-    while (off >= 0)
+    uint32_t const n_here = static_cast<uint32_t>(off) + 1u, need = K - have, n = n_here < need ? n_here : need;
+    uint32_t const m = len < K - 1 ? len : K - 1;
+    bool ok = true;
+    if (static_cast<uint32_t>(off) + 1u == len && n <= m)
     {
-      int const c = code(dna[off]);
-      if (c < 0)
-      {
-        done = true;
-        break;
-      }
-      key |= static_cast<uint64_t>(c) << (2 * have);
-      ++used[slot];
-      if (++have == K)
-      {
-        finish(key, special_of(site, g.var_order[v] + static_cast<uint32_t>(off)));
-        done = true;
-        break;
-      }
-      --off;
+      ok = packs.var_sfx_ok[v] >= n;
+      key |= (packs.var_sfx[v] & ((1ull << (2 * n)) - 1ull)) << (2 * have);
     }
-    if (!done)
-      back_ref(site, static_cast<int64_t>(g.ref_len[site]) - 1, have, key);
+    else if (have == 0 && n_here <= m)
+    {
+      ok = packs.var_pfx_ok[v] >= n_here;
+      key = packs.var_pfx[v] >> (2 * (m - n_here));
+    }
+    else
+    {
+      char const * dna = g.dna.data() + g.var_dna[v];
+      for (uint32_t i = 0; i < n && ok; ++i)
+      {
+        int const c = code(dna[off - i]);
+        ok = c >= 0;
+        key |= static_cast<uint64_t>(c < 0 ? 0 : c) << (2 * (have + i));
+      }
+    }
+    if (ok)
+    {
+      used[slot] = n;
+      have += n;
+      if (have == K)
+        finish(key, special_of(site, g.var_order[v] + static_cast<uint32_t>(off) - (n - 1u)));
+      else
+        back_ref(site, static_cast<int64_t>(g.ref_len[site]) - 1, have, key);
+    }
     --n_vars;
   }
 };
@@ -762,6 +835,7 @@ void enumerate_kmers(HostGraph const & g, std::vector<Emit> & em, std::vector<Em
     else
       T = std::max(T, std::min(std::thread::hardware_concurrency(), 64u));
   }
+  NodePacks const packs(g);
   std::vector<std::vector<Emit>> part(T);
   std::vector<std::vector<EmitRun>> part_runs(T);
   // ranges of equal weight
@@ -787,7 +861,7 @@ void enumerate_kmers(HostGraph const & g, std::vector<Emit> & em, std::vector<Em
     for (uint32_t r = r0; r < r1; ++r)
       bases += runs ? weight(r) : g.ref_len[r];
     out.reserve(bases + bases / 4 + 64);
-    Walker w{g, out, !g.event_off.empty()};
+    Walker w{g, out, !g.event_off.empty(), packs};
     for (uint32_t r = r0; r < r1; ++r)
     {
       // fast path inside a reference node: a rolling 2-bit window while the k-mer stays within this node
@@ -795,8 +869,19 @@ void enumerate_kmers(HostGraph const & g, std::vector<Emit> & em, std::vector<Em
       uint32_t len = g.ref_len[r];
       if (runs && len >= K)
       {
+        // (A/C/G/T only?  On the comparison codes -- 1 2 4 8 for those four -- eight bases at a time: no high nibble, no zero
+        //  byte, eight bits in all)
         bool plain = true;
-        for (uint32_t d = 0; d < len && plain; ++d)
+        char const * cd = g.codes.data() + g.ref_dna[r];
+        uint32_t d = 0;
+        for (; d + 8 <= len && plain; d += 8)
+        {
+          uint64_t w;
+          std::memcpy(&w, cd + d, 8);
+          plain = (w & 0xF0F0F0F0F0F0F0F0ull) == 0 && ((w - 0x0101010101010101ull) & ~w & 0x8080808080808080ull) == 0 &&
+                  __builtin_popcountll(w) == 8;
+        }
+        for (; d < len && plain; ++d)
           plain = Walker::code(dna[d]) >= 0;
         if (plain)
         {
