@@ -701,7 +701,7 @@ def extra_pipeline(args, torch, gtx, synth, device, ctx, ref, records, n=4_000_0
     import tempfile
     import threading
     L = gtx.lib()
-    threads = max(1, min(16, (os.cpu_count() or 2) // 2))
+    threads = max(1, min(int(os.environ.get("GTX_BENCH_PIPE_THREADS", "16")), (os.cpu_count() or 2) // 2))
     d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=777, device=device, REGION_LEN=args.region_len, err_rate=args.err, n_rate=args.nrate)
     codes = unpack_nibbles(d_seq.cpu().numpy(), READ_LEN)
     pos = d_pos.cpu().numpy()
