@@ -1019,7 +1019,14 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
         return HINT_TO_GENERAL;
       }
       bool const region_clean = hc_upto(h, hi + 1) == hc_upto(h, lo);
-      bool const last_only = mm_run == (1u << hi) && hi + 1 <= 4 && hc_edge(h, hi + 1) == 1 && ((km_hi >> HK_SET_SHIFT) & 255u) == 0;
+      if (mm_run == (1u << hi) && hi + 1 > 4)
+      {
+        // (the fifth k-mer of a read of 156 bases and more: whether its substitution sits on its last base -- base 155, the
+        //  tail walk's first -- is not among the compare's counts)
+        GTX_HINT_NOTE(10);
+        return HINT_TO_GENERAL;
+      }
+      bool const last_only = mm_run == (1u << hi) && hc_edge(h, hi + 1) == 1 && ((km_hi >> HK_SET_SHIFT) & 255u) == 0;
       bool const twin = region_clean && (mm_run == 0 || last_only);
       if (pre == L - 1 || re != L - 1 || (twin && nvar > 1))
       {

@@ -93,6 +93,38 @@ def neardup_case(Backend, n_reads, n_ref=60000):
     return check_align.hinted_done
 
 
+def five_kmer_case(Backend, n_reads):
+    """reads of 156-160 bases: five k-mers, the fifth ending on base 155 with four bases of tail behind it -- where the
+    position-hinted pass' rules for holes, parallel chains (an ambiguous base opening the run behind a hole) and runs of one
+    length meet its last counters; 2 % substitutions, 0.5 % N, SNPs every 100 and every 1000 bases"""
+    done = 0
+    for kind, seed in (("snp100", 5), ("snp1k", 6)):
+        ref, recs, codes, pos = scenarios.synthetic_case(kind, n_ref=60000, n_reads=n_reads, region_begin=20000, err=0.02, n_rate=0.005,
+                                                       seed=seed, read_len=160)
+        rng = np.random.default_rng(seed)
+        reads = [c[:int(n)].copy() for c, n in zip(codes, rng.integers(156, 161, size=len(codes)))]
+        # planted on every eighth read (on top of its own errors): k-mers 1 and 2 broken by two substitutions each, an ambiguous
+        # base in k-mer 3 -- the run of k-mers 3, 4 opens with a parallel chain behind a hole --, and one substitution in k-mer 4,
+        # on its last base (155, the tail walk's first) or next to it
+        sub = lambda c: np.uint8({1: 2, 2: 4, 4: 8, 8: 1}.get(int(c), 1))
+        for i in range(0, len(reads), 8):
+            r = reads[i]
+            for j in (33, 40, 66, 71):
+                r[j] = sub(r[j])
+            r[int(rng.integers(96, 120))] = 15
+            j = int(rng.choice([155, 155, 154, 130]))
+            r[j] = sub(r[j])
+        o = Oracle(ref, recs, region_begin=20000)
+        b = Backend(gtx.graph_from_records(ref, recs, region_begin=20000))
+        check_align(b, o, reads, pos=pos)
+        done += check_align.hinted_done
+    return done
+
+
+def test_align_five_kmer_reads():
+    assert five_kmer_case(harness.EmuBackend, 6000) > 6000
+
+
 def test_align_near_duplicate_reference():
     done = neardup_case(harness.EmuBackend, 3000)
     assert 0 < done < 3000

@@ -10,7 +10,7 @@ import harness
 import scenarios
 from graphtyper_amd import lib as gtx
 from oracle_lib import Oracle, encode
-from test_emu_parity import check_align, cfg3_case, neardup_case, direct_probes_case, n_runs_case, three_n_case, sv_deletion_case, edge_case, express_variants_case, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case
+from test_emu_parity import check_align, five_kmer_case, cfg3_case, neardup_case, direct_probes_case, n_runs_case, three_n_case, sv_deletion_case, edge_case, express_variants_case, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case
 
 pytestmark = pytest.mark.gpu
 
@@ -105,6 +105,10 @@ def test_cfg3_graph():
 @pytest.mark.parametrize("kind", ["repeat", "snp7"])
 def test_second_pass(kind):
     second_pass_case(harness.GpuBackend, kind, 5000 if kind == "repeat" else 3000)  # (snp7: ~200 connection entries per read)
+
+
+def test_align_five_kmer_reads():
+    assert five_kmer_case(harness.GpuBackend, 20000) > 20000
 
 
 def test_align_near_duplicate_reference():
