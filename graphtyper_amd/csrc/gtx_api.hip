@@ -867,8 +867,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_GENERAL_
 // A graph with a site of more than 64 alleles has a further pass of the same shape behind it (NS = wide: allele sets of
 // GTX_WIDE_MASK_WORDS words, a larger table of walk candidates: one round of a walk branches into every allele of a site):
 // a task that met an allele number >= 64 or overflowed a table is handed on to it (next_tasks / next_state).
+// (registers for four wavefronts per SIMD -- 128 instead of the 193 the compiler takes when left alone: the pass has no task on
+//  most batches, but every one of its workgroups has to be PLACED before it can see that, and beside another batch's kernels
+//  a wavefront of 196 registers waited 0.14 ms for room; what it spills only matters on the rare batch that needs the pass)
+#ifndef GTX_HBM_PASS_WAVES
+#define GTX_HBM_PASS_WAVES 4
+#endif
+#define GTX_HBM_PASS_ATTR __attribute__((amdgpu_waves_per_eu(GTX_HBM_PASS_WAVES, GTX_HBM_PASS_WAVES)))
 #define GTX_HBM_PASS_KERNEL(NAME, NS)                                                                                              \
-  __global__ __launch_bounds__(64) void NAME(GraphView g, IndexView ix, uint8_t const * __restrict__ seq, uint32_t seq_stride,      \
+  __global__ __launch_bounds__(64) GTX_HBM_PASS_ATTR void NAME(GraphView g, IndexView ix, uint8_t const * __restrict__ seq, uint32_t seq_stride, \
                                              gtx_read_meta const * __restrict__ meta, uint32_t * __restrict__ records,             \
                                              uint32_t rec_words, uint32_t const * __restrict__ big_tasks, uint32_t big_task_cap,   \
                                              uint32_t * big_state, NS::AlignWorkspace * workspaces, uint32_t * __restrict__ arena, \
