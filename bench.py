@@ -36,6 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 ALGO_BYTES_PER_READ = 3296  # B(L) = 86 + 796*n_k + (L - 31*n_k) at L=150, n_k=4
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 USE_TASK_FLAGS = os.environ.get("GTX_BENCH_FLAGS", "1") != "0"  # the dense side array of the records (A/B switch)
+USE_ITEM_WORDS = os.environ.get("GTX_BENCH_ITEM_WORDS", "1") != "0"  # gtx_score_batch_words (0: gtx_score_batch_flags; A/B)
 PLANE_INPUT = os.environ.get("GTX_BENCH_PLANES", "1") != "0"    # reads resident as plane rows (0: BAM nibble rows, repacked inside every call)
 REC_WORDS = int(os.environ.get("GTX_BENCH_REC_WORDS", "64"))  # uint32 words of a record slot (rec_words of gtx_align_batch; A/B switch)
 REGION_BEGIN = 1000000      # chr20:1000001-2000000
@@ -275,6 +276,7 @@ class Workload:
         self.stride = (int(d_seq.shape[1]) + 15) // 16 * 16  # pitch of the plane rows
         self.hint, self.samples = hint, samples
         self.sets = []   # resident read sets (bases, meta, score items); step k works on set k mod len(sets)
+        self.words = {}  # items' data_ptr -> their compact form (gtx_score_batch_words), or None
         self.steps_done = 0
         self.add_reads(d_seq, d_pos)
         self.align_fn = self.L.gtx_align_batch_planes if PLANE_INPUT else self.L.gtx_align_batch_flags
@@ -340,7 +342,10 @@ class Workload:
         if self.samples is not None:
             items["sample"] = self.samples
         d_items = torch.from_numpy(items.view(np.uint8).reshape(n, gtx.SCORE_ITEM.itemsize).copy()).to(self.device)
+        # (the items' compact form for the scorer's first stage -- gtx_item_words: 4 bytes per item beside the item's 40)
+        d_words = torch.from_numpy(gtx.item_words(items).view(np.uint8).copy()).to(self.device) if USE_TASK_FLAGS and USE_ITEM_WORDS else None
         self.sets.append((d_seq, d_meta, d_items))
+        self.words[int(d_items.data_ptr())] = d_words
 
     def close(self):
         if self.comm is not None:
@@ -397,13 +402,20 @@ class Workload:
             fl = d_flags.data_ptr() if d_flags is not None else None
             gtx.check(self.align_fn(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, d_rec.data_ptr(), REC_WORDS, fl, sp))
             e1.record(stream)
-            gtx.check(L.gtx_score_batch_flags(ctx.h, d_items.data_ptr(), self.n, d_rec.data_ptr(), REC_WORDS, fl, C.byref(buf), sp))
+            self._score_call(d_items, d_rec, fl, buf, sp)
             if self.comm is not None or self.dist is not None:
                 assert lane == 0  # (one communicator: the exchange steps of two streams must not interleave)
                 self._reduce(ln, stream, sp)
             # genotype calls (PL, GT, GQ, depths) from the summed accumulators
             gtx.check(L.gtx_calls_batch(ctx.h, C.byref(buf), ln["d_phred"].data_ptr(), ln["d_calls"].data_ptr(), sp))
         return e0, e1
+
+    def _score_call(self, d_items, d_rec, fl, buf, sp):
+        w = self.words.get(int(d_items.data_ptr()))
+        if w is not None and fl is not None:
+            self.gtx.check(self.L.gtx_score_batch_words(self.ctx.h, d_items.data_ptr(), w.data_ptr(), self.n, d_rec.data_ptr(), REC_WORDS, fl, C.byref(buf), sp))
+        else:
+            self.gtx.check(self.L.gtx_score_batch_flags(self.ctx.h, d_items.data_ptr(), self.n, d_rec.data_ptr(), REC_WORDS, fl, C.byref(buf), sp))
 
     def _score(self, ln, stream, after):
         """score + calls of the step whose records lane `ln` holds, on `stream`, behind the events `after`"""
@@ -414,7 +426,7 @@ class Workload:
                 stream.wait_event(ev)
             fl = ln["d_flags"].data_ptr() if ln["d_flags"] is not None else None
             gtx.check(L.gtx_scores_zero(ctx.h, C.byref(ln["buf"]), sp))
-            gtx.check(L.gtx_score_batch_flags(ctx.h, ln["items"].data_ptr(), self.n, ln["d_rec"].data_ptr(), REC_WORDS, fl, C.byref(ln["buf"]), sp))
+            self._score_call(ln["items"], ln["d_rec"], fl, ln["buf"], sp)
             self._reduce(ln, stream, sp)
             gtx.check(L.gtx_calls_batch(ctx.h, C.byref(ln["buf"]), ln["d_phred"].data_ptr(), ln["d_calls"].data_ptr(), sp))
             ln["scored"].record(stream)

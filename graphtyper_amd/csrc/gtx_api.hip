@@ -1029,7 +1029,8 @@ constexpr uint32_t TRIAGE_THREADS = GTX_TRIAGE_THREADS, TRIAGE_PER_THREAD = 1024
 __global__ __launch_bounds__(TRIAGE_THREADS) void gtx_score_triage_kernel(gtx_score_item const * __restrict__ items, uint32_t n_items,
                                                                           uint32_t const * __restrict__ records, uint32_t rec_words,
                                                                           uint32_t * __restrict__ work_queue, uint32_t * work_count,
-                                                                          uint32_t keeps_depth, uint8_t const * __restrict__ task_flags)
+                                                                          uint32_t keeps_depth, uint8_t const * __restrict__ task_flags,
+                                                                          uint32_t const * __restrict__ item_words)
 {
   // one queue append per WORKGROUP (a device counter takes a few hundred million returning atomics a second: one per
   // wavefront -- 156 k per 10 M items -- set the pace of this kernel)
@@ -1042,7 +1043,10 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void gtx_score_triage_kernel(gtx_sc
   for (uint32_t k = 0; k < TRIAGE_PER_THREAD; ++k)
   {
     uint32_t const i = first + k * TRIAGE_THREADS + threadIdx.x;
-    work[k] = i < n_items && !item_is_trivial(items[i], records, rec_words, keeps_depth != 0, task_flags);
+    // (gtx_score_batch_words: the read of an item of one forward-only read is in the compact array -- 4 bytes instead of 40)
+    uint32_t const w = item_words && i < n_items ? item_words[i] : GTX_ITEM_WORD_FULL;
+    work[k] = i < n_items && (w != GTX_ITEM_WORD_FULL ? (task_flags[2ull * w] & GTX_TASK_HAS_VARIANTS) != 0
+                                                      : !item_is_trivial(items[i], records, rec_words, keeps_depth != 0, task_flags));
   }
 #pragma unroll
   for (uint32_t k = 0; k < TRIAGE_PER_THREAD; ++k)
@@ -2080,8 +2084,44 @@ extern "C" int gtx_score_batch(gtx_ctx * c, const gtx_score_item * d_items, uint
   return gtx_score_batch_flags(c, d_items, n_items, d_records, rec_words, nullptr, acc, stream);
 }
 
+static int score_batch(gtx_ctx * c, const gtx_score_item * d_items, const uint32_t * d_item_words, uint32_t n_items, const uint32_t * d_records,
+                       uint32_t rec_words, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream);
+
 extern "C" int gtx_score_batch_flags(gtx_ctx * c, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records,
                                      uint32_t rec_words, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream)
+{
+  return score_batch(c, d_items, nullptr, n_items, d_records, rec_words, d_task_flags, acc, stream);
+}
+
+extern "C" int gtx_score_batch_words(gtx_ctx * c, const gtx_score_item * d_items, const uint32_t * d_item_words, uint32_t n_items,
+                                     const uint32_t * d_records, uint32_t rec_words, const uint8_t * d_task_flags, const gtx_score_buffers * acc,
+                                     void * stream)
+{
+  if (d_item_words && !d_task_flags)
+  {
+    g_last_error = "gtx_score_batch_words: the compact item array needs the task-flag array (gtx_align_batch_flags / _planes)";
+    return GTX_ERR_ARG;
+  }
+  return score_batch(c, d_items, d_item_words, n_items, d_records, rec_words, d_task_flags, acc, stream);
+}
+
+// gtx_score_batch_words' compact form of the items (host)
+extern "C" int gtx_item_words(const gtx_score_item * items, uint32_t n_items, uint32_t * words)
+{
+  if (n_items && (!items || !words))
+    return GTX_ERR_ARG;
+  for (uint32_t i = 0; i < n_items; ++i)
+  {
+    gtx_score_item const & it = items[i];
+    bool const one = it.second.align_index == GTX_INVALID_ID && it.kind == 0 && (it.first.flag & GTX_FLAG_FORWARD_ONLY) != 0 &&
+                     it.first.align_index != GTX_ITEM_WORD_FULL;
+    words[i] = one ? it.first.align_index : GTX_ITEM_WORD_FULL;
+  }
+  return GTX_OK;
+}
+
+static int score_batch(gtx_ctx * c, const gtx_score_item * d_items, const uint32_t * d_item_words, uint32_t n_items, const uint32_t * d_records,
+                       uint32_t rec_words, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream)
 {
   if (!c || !d_items || !d_records || !acc || !acc->d_log_score || !acc->d_gt_cov || !acc->d_hap_u32 || !acc->d_stat_u64 ||
       !acc->d_stat_u32 || !acc->d_conn_log || !acc->d_conn_count)
@@ -2136,7 +2176,7 @@ extern "C" int gtx_score_batch_flags(gtx_ctx * c, const gtx_score_item * d_items
   if (!hip_ok(hipMemsetAsync(s->d_score_work, 0, sizeof(uint32_t), st), "score work queue reset"))
     return GTX_ERR_HIP;
   hipLaunchKernelGGL(gtx_score_triage_kernel, dim3((n_items + TRIAGE_THREADS * TRIAGE_PER_THREAD - 1) / (TRIAGE_THREADS * TRIAGE_PER_THREAD)), dim3(TRIAGE_THREADS), 0, st, d_items, n_items, d_records, rec_words, s->d_score_work + 1,
-                     s->d_score_work, static_cast<uint32_t>(a.ref_depth != nullptr), d_task_flags);
+                     s->d_score_work, static_cast<uint32_t>(a.ref_depth != nullptr), d_task_flags, d_item_words);
   if (!hip_ok(hipGetLastError(), "gtx_score_triage_kernel launch"))
     return GTX_ERR_HIP;
   uint32_t const work_blocks = std::min<uint32_t>(blocks, static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256) * c->score_blocks_per_cu);

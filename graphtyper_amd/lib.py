@@ -26,7 +26,7 @@ EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy"
            "gtx_graph_destroy",
            "gtx_scores_alloc", "gtx_scores_zero", "gtx_scores_free", "gtx_scores_reduce", "gtx_comm_unique_id", "gtx_comm_init_rank",
            "gtx_comm_destroy", "gtx_ctx_kernel_times", "gtx_ref_depth_finalize", "gtx_vcf_records", "gtx_scores_replay", "gtx_reads_open", "gtx_reads_info",
-           "gtx_reads_sample_name", "gtx_reads_next", "gtx_reads_close", "gtx_align_batch_flags", "gtx_score_batch_flags",
+           "gtx_reads_sample_name", "gtx_reads_next", "gtx_reads_close", "gtx_align_batch_flags", "gtx_score_batch_flags", "gtx_score_batch_words", "gtx_item_words",
            "gtx_pack_planes", "gtx_reads_to_planes", "gtx_align_batch_planes", "gtx_align_batch_planes_staged", "gtx_stream_set_planes", "gtx_device_cache_release",
            "gtx_disc_create", "gtx_disc_destroy", "gtx_disc_events_batch", "gtx_disc_first_pass", "gtx_vcf_header", "gtx_bgzf_compress"]
 
@@ -148,6 +148,8 @@ def lib():
         L.gtx_device_cache_release.restype = None
         L.gtx_pack_planes.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
         L.gtx_reads_to_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.gtx_score_batch_words.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(ScoreBuffers), C.c_void_p]
+        L.gtx_item_words.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.gtx_align_batch_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.gtx_align_batch_planes_staged.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_void_p, C.c_void_p]
@@ -359,6 +361,14 @@ def pack_planes(seq, plane_stride=None):
     plane_stride = plane_stride or ((stride + 15) // 16) * 16
     out = np.zeros((n, plane_stride), np.uint8)
     check(lib().gtx_pack_planes(_p(seq), stride, n, _p(out), plane_stride))
+    return out
+
+
+def item_words(items):
+    """gtx_item_words: the compact form of score items for gtx_score_batch_words (one uint32 per item)"""
+    items = np.ascontiguousarray(items, SCORE_ITEM)
+    out = np.zeros(len(items), np.uint32)
+    check(lib().gtx_item_words(_p(items), len(items), _p(out)))
     return out
 
 

@@ -364,6 +364,16 @@ int gtx_score_batch(gtx_ctx *, const gtx_score_item * d_items, uint32_t n_items,
  * array that runs beside d_records); same results */
 int gtx_score_batch_flags(gtx_ctx *, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records, uint32_t rec_words,
                           const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream);
+/* ... and with the items once more in a compact form for the scorer's first stage, which only has to find the few items
+ * whose reads carry a variant site (one in six at a SNP per kilobase) and read 40 bytes per item to learn which read an
+ * item means: one word per item -- the read's align_index for an item of ONE read aligned forward only
+ * (GTX_FLAG_FORWARD_ONLY: what gtx_stream_push makes of an unpaired record, i.e. of most), GTX_ITEM_WORD_FULL for any
+ * other item (a pair, a left-over, a read aligned in both orientations: the stage reads the item itself).
+ * gtx_item_words (host) fills the array from the items.  Needs d_task_flags; same results. */
+#define GTX_ITEM_WORD_FULL 0xFFFFFFFFu
+int gtx_item_words(const gtx_score_item * items, uint32_t n_items, uint32_t * words);
+int gtx_score_batch_words(gtx_ctx *, const gtx_score_item * d_items, const uint32_t * d_item_words, uint32_t n_items, const uint32_t * d_records,
+                          uint32_t rec_words, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream);
 
 /* number of score items the kernel refused so far because one read touched more variant sites than its table holds
  * (must be 0 for the accumulators to be complete) */

@@ -193,6 +193,8 @@ def test_task_flags_side_array(hint):
     import ctypes as C
     torch = pytest.importorskip("torch")
     ref, recs, codes, rec = scenarios.paired_case("snp100", n_ref=40000, n_pairs=6000, region_begin=310000, n_samples=3)
+    rec = rec.copy()
+    rec["flag"][::3] &= np.uint16(0xFFFF & ~(1 | 2 | 8 | 32 | 64 | 128))  # every third record unpaired: forward-only items of one read
     b = harness.GpuBackend(gtx.graph_from_records(ref, recs, region_begin=310000))
     st = gtx.Stream(b.ctx.params, 1)
     a_seq, a_meta, items = st.push(rec, gtx.pack_nibbles(codes))
@@ -222,6 +224,22 @@ def test_task_flags_side_array(hint):
     for host, dev in zip(acc2.arrays(), devs):
         host[...] = dev.cpu().numpy().view(host.dtype)
     assert np.array_equal(harness.canonical_scores(b.ctx, acc), harness.canonical_scores(b.ctx, acc2))
+    # gtx_score_batch_words: the items' compact form for the first stage (one word per item; pairs and reads aligned in both
+    # orientations keep GTX_ITEM_WORD_FULL) -- the same accumulators
+    words = gtx.item_words(items)
+    one = words != 0xFFFFFFFF
+    assert 0 < int(one.sum()) < len(words)
+    assert np.array_equal(words[one], np.asarray(items)["first"]["align_index"][one])
+    acc3 = harness.Accumulators(b.ctx, 3)
+    devs = [b._dev(a) for a in acc3.arrays()]
+    buf = acc3.buffers([d.data_ptr() for d in devs])
+    gtx.check(L.gtx_score_batch_words(b.ctx.h, b._dev(np.ascontiguousarray(items, gtx.SCORE_ITEM)).data_ptr(), b._dev(words).data_ptr(), len(items),
+                                      d_rec.data_ptr(), harness.REC_WORDS, d_flags.data_ptr(), C.byref(buf), None))
+    torch.cuda.synchronize()
+    for host, dev in zip(acc3.arrays(), devs):
+        host[...] = dev.cpu().numpy().view(host.dtype)
+    assert np.array_equal(harness.canonical_scores(b.ctx, acc), harness.canonical_scores(b.ctx, acc3))
+    assert L.gtx_score_batch_words(b.ctx.h, None, b._dev(words).data_ptr(), 0, None, harness.REC_WORDS, None, C.byref(buf), None) != 0  # words need flags
 
 
 def test_batches_in_flight_equal_one_at_a_time():
