@@ -105,9 +105,12 @@ struct WaveHip
 // position-sorted stream -- hit the same few counters: 1 500 reads deep, every counter of a site would take thousands of
 // same-address atomics at the L2.  The workgroup therefore sums into an LDS table keyed by the counter's address first and
 // sends one atomic per (counter, workgroup visit) to memory.  Sums are order-free, so the accumulators come out the same.
+#ifndef GTX_SCORE_THREADS
+#define GTX_SCORE_THREADS 64 // threads of a gtx_score_kernel workgroup: one wavefront goes wherever a slot is beside another batch's queues (cfg2, steps in flight: 256 / 128 / 64 threads = 0.798 / 0.788 / 0.783 ms per step; alone the same)
+#endif
 struct ScoreCombiner
 {
-  static constexpr uint32_t N = 1024, PROBES = 8;
+  static constexpr uint32_t N = 4 * GTX_SCORE_THREADS, PROBES = 8; // (four entries per thread of the workgroup)
   unsigned long long key[N]; // counter address | 1 when the counter is 64 bits wide; 0 = free
   unsigned long long val[N];
 };
@@ -1082,7 +1085,7 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void gtx_score_triage_kernel(gtx_sc
 #else
 #define GTX_SCORE_ATTR
 #endif
-__global__ __launch_bounds__(256) GTX_SCORE_ATTR void gtx_score_kernel(GraphView g, ScoreParams par, gtx_score_item const * __restrict__ items,
+__global__ __launch_bounds__(GTX_SCORE_THREADS) GTX_SCORE_ATTR void gtx_score_kernel(GraphView g, ScoreParams par, gtx_score_item const * __restrict__ items,
                                                         uint32_t const * __restrict__ work_queue, uint32_t const * work_count,
                                                         uint32_t const * __restrict__ records, uint32_t rec_words, ScoreAcc acc,
                                                         uint32_t * error_flag, uint32_t * __restrict__ big_queue,
@@ -1505,7 +1508,7 @@ int ctx_upload(gtx_ctx & c, int device)
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express4_wide_kernel, 64, 0) == hipSuccess && per_cu > 0)
     c.express4_wide_blocks_per_cu = per_cu;
   // (the scoring grid is what is resident, no more: 1.28 ms per cfg2 step against 1.32 with 8 workgroups per CU)
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_score_kernel, 256, 0) == hipSuccess && per_cu > 0)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_score_kernel, GTX_SCORE_THREADS, 0) == hipSuccess && per_cu > 0)
     c.score_blocks_per_cu = per_cu;
   lap("occupancy queries");
   // the first scratch now, so that the first call does not pay for it
@@ -2164,7 +2167,7 @@ static int score_batch(gtx_ctx * c, const gtx_score_item * d_items, const uint32
   }
   ScoreParams par{static_cast<uint32_t>(c->params.is_sv_graph != 0), static_cast<uint32_t>(c->params.hq_reads != 0),
                   static_cast<uint32_t>(c->params.is_segment_calling != 0), 0};
-  uint32_t const blocks = (n_items + 255u) / 256u;
+  uint32_t const blocks = (n_items + GTX_SCORE_THREADS - 1u) / GTX_SCORE_THREADS;
   bool const second_pass = s->d_score_state != nullptr;
   if (second_pass && !hip_ok(hipMemsetAsync(s->d_score_state, 0, 2 * sizeof(uint32_t), st), "second-pass state reset"))
     return GTX_ERR_HIP;
@@ -2180,7 +2183,7 @@ static int score_batch(gtx_ctx * c, const gtx_score_item * d_items, const uint32
   if (!hip_ok(hipGetLastError(), "gtx_score_triage_kernel launch"))
     return GTX_ERR_HIP;
   uint32_t const work_blocks = std::min<uint32_t>(blocks, static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256) * c->score_blocks_per_cu);
-  hipLaunchKernelGGL(gtx_score_kernel, dim3(work_blocks), dim3(256), 0, st, c->dev_graph, par, d_items, s->d_score_work + 1, s->d_score_work,
+  hipLaunchKernelGGL(gtx_score_kernel, dim3(work_blocks), dim3(GTX_SCORE_THREADS), 0, st, c->dev_graph, par, d_items, s->d_score_work + 1, s->d_score_work,
                      d_records, rec_words, a, c->d_error_flag, second_pass ? s->d_score_queue : nullptr,
                      second_pass ? gtx_ctx::SCORE_QUEUE_CAP : 0u, s->d_score_state);
   if (!hip_ok(hipGetLastError(), "gtx_score_kernel launch"))
