@@ -88,3 +88,14 @@ def test_device_repack_and_plane_entry_point():
     assert np.array_equal(d_rec.cpu().numpy().view(np.uint32), want)
     with pytest.raises(gtx.GtxError):
         gtx.check(L.gtx_align_batch_planes(b.ctx.h, d96.data_ptr(), 90, d_meta.data_ptr(), n, d_rec.data_ptr(), harness.REC_WORDS, None, None))
+
+
+def test_item_words_host():
+    """gtx_item_words: the read's index for an item of one forward-only read, GTX_ITEM_WORD_FULL for everything else"""
+    items = np.zeros(6, gtx.SCORE_ITEM)
+    items["first"]["align_index"] = [5, 6, 7, 8, 9, 0xFFFFFFFF]
+    items["second"]["align_index"] = [gtx.INVALID_ID, 11, gtx.INVALID_ID, gtx.INVALID_ID, gtx.INVALID_ID, gtx.INVALID_ID]
+    items["first"]["flag"] = [gtx.FLAG_FORWARD_ONLY, gtx.FLAG_FORWARD_ONLY, 0, gtx.FLAG_FORWARD_ONLY | 16, gtx.FLAG_FORWARD_ONLY, gtx.FLAG_FORWARD_ONLY]
+    items["kind"] = [0, 0, 0, 0, 1, 0]
+    assert gtx.item_words(items).tolist() == [5, 0xFFFFFFFF, 0xFFFFFFFF, 8, 0xFFFFFFFF, 0xFFFFFFFF]
+    assert len(gtx.item_words(items[:0])) == 0
