@@ -1097,10 +1097,17 @@ __global__ __launch_bounds__(GTX_SCORE_THREADS) GTX_SCORE_ATTR void gtx_score_ke
   for (uint32_t first = blockIdx.x * blockDim.x; first < n_work; first += gridDim.x * blockDim.x)
   {
     uint32_t const w = first + threadIdx.x;
+#ifdef GTX_PROF // (profiling build: cycles of a visit's three parts, lane 0 of every workgroup: [25] item fetch, [26] scoring, [27] flush, [28] visits)
+    unsigned long long const t0 = clock64();
+    unsigned long long t1 = t0, t2 = t0;
+#endif
     if (w < n_work)
     {
       uint32_t const i = work_queue[w];
       gtx_score_item const it = items[i];
+#ifdef GTX_PROF
+      t1 = clock64() + (it.sample & 0u); // (behind the loads)
+#endif
       RecentHap r1[SCORE_MAX_HAPS], r2[SCORE_MAX_HAPS];
       if (!score_item<WaveHipCombine>(g, par, it, records, rec_words, acc, r1, r2, SCORE_MAX_HAPS))
       {
@@ -1112,8 +1119,20 @@ __global__ __launch_bounds__(GTX_SCORE_THREADS) GTX_SCORE_ATTR void gtx_score_ke
         else
           atomicAdd(error_flag, 1u);
       }
+#ifdef GTX_PROF
+      t2 = clock64();
+#endif
     }
     WaveHipCombine::flush();
+#ifdef GTX_PROF
+    if (threadIdx.x == 0 && w < n_work)
+    {
+      atomicAdd(g.prof + 25, t1 - t0);
+      atomicAdd(g.prof + 26, t2 - t1);
+      atomicAdd(g.prof + 27, clock64() - t2);
+      atomicAdd(g.prof + 28, 1ull);
+    }
+#endif
   }
 }
 
