@@ -458,12 +458,14 @@ class Workload:
         spH = C.c_void_p(H.cuda_stream)
         evs, flight = [], []
         n_l = len(self.lanes)
-        pace = os.environ.get("GTX_BENCH_PACE", "0") != "0"  # (test switch; measured: no effect on the step, 1.5 % slower)
+        pace = os.environ.get("GTX_BENCH_PACE", "1") != "0"
         for _ in range(steps):
             ln = self.lanes[self.steps_done % n_l]
             if pace:
-                # (the host stays at most n_l steps ahead of the device: the lane's last scoring is through before its next step
-                #  is queued -- streams with dozens of queued cross-stream waits ran the same schedule at half the speed now and then)
+                # The host stays at most n_l steps ahead of the device: the lane's last scoring is through before its next step is
+                # queued.  Unpaced, the host queues ten steps in a millisecond, every call finds all earlier ones still in flight
+                # and the library makes a new scratch for it (queues for 10 M reads: hipMalloc in the middle of the timed region) --
+                # now and then the same schedule ran at half the speed.  (1.5 % slower than unpaced when that does not happen.)
                 ln["scored"].synchronize()
             T = self.tail_streams[self.steps_done % len(self.tail_streams)]
             spT = C.c_void_p(T.cuda_stream)

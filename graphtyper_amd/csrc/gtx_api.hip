@@ -1326,7 +1326,7 @@ static std::unique_ptr<CallScratch> scratch_new(gtx_ctx & c)
 // launch has completed, else a new one.
 static CallScratch * scratch_acquire(gtx_ctx & c, hipStream_t stream)
 {
-  std::lock_guard<std::mutex> lock(c.pool_mutex);
+  std::unique_lock<std::mutex> lock(c.pool_mutex);
   CallScratch * pick = nullptr;
   for (auto & s : c.pool)
     if (!s->busy && s->used && s->last_stream == stream)
@@ -1335,6 +1335,22 @@ static CallScratch * scratch_acquire(gtx_ctx & c, hipStream_t stream)
     for (auto & s : c.pool)
       if (!pick && !s->busy && (!s->used || hipEventQuery(static_cast<hipEvent_t>(s->done)) == hipSuccess))
         pick = s.get();
+  if (!pick && c.pool.size() >= gtx_ctx::MAX_SCRATCH_IN_FLIGHT)
+  {
+    // A host that queues calls faster than the device does them would get a new scratch -- queues for a whole batch,
+    // hipMalloc in the middle of its stream of work -- for every call it is ahead: beyond a handful the call waits for the
+    // oldest one instead (the scratch that has been idle longest among those not held by a host thread).
+    for (auto & s : c.pool)
+      if (!s->busy && (!pick || s->use_seq < pick->use_seq))
+        pick = s.get();
+    if (pick)
+    {
+      pick->busy = true; // (ours from here on; the wait itself is outside the lock)
+      lock.unlock();
+      (void)hipEventSynchronize(static_cast<hipEvent_t>(pick->done));
+      return pick;
+    }
+  }
   if (!pick)
   {
     auto s = scratch_new(c);
@@ -1353,6 +1369,7 @@ static void scratch_release(gtx_ctx & c, CallScratch * s, hipStream_t stream, bo
   std::lock_guard<std::mutex> lock(c.pool_mutex);
   s->used = true;
   s->last_stream = stream;
+  s->use_seq = ++c.scratch_uses;
   s->busy = false;
   if (was_align)
     c.last_align = s;

@@ -21,6 +21,7 @@ struct CallScratch
   bool busy = false;         // a host thread is inside an entry point with it (guarded by gtx_ctx::pool_mutex)
   void * last_stream = nullptr;
   bool used = false;         // `done` has been recorded at least once
+  uint64_t use_seq = 0;      // gtx_ctx::scratch_uses at its last release (the smallest: the one whose work was queued longest ago)
   void * done = nullptr;     // hipEvent_t recorded behind the last launch that uses this scratch
   // per part of the batch, 8 words: [0] read / queue-1 claim counter of pass 1, [1] task counter of pass 2, [2] tasks queued
   // for pass 2, [3] forward tasks the position-hinted pass handed to pass 1, [4] forward tasks pass 1 handed to pass 2,
@@ -91,6 +92,8 @@ struct gtx_ctx
   std::mutex pool_mutex;
   std::vector<std::unique_ptr<gtx::CallScratch>> pool;
   gtx::CallScratch * last_align = nullptr; // scratch of the most recent gtx_align_batch (pass times, second-pass task count)
+  uint64_t scratch_uses = 0;
+  static constexpr size_t MAX_SCRATCH_IN_FLIGHT = 6; // scratches made for calls in flight before a call waits for one (gtx_api.hip: scratch_acquire)
   bool timing_armed = false;
   // the timed calls between two queries are one epoch: the first timed call behind a query opens the next one (a scratch
   // drops the slots of an older epoch when it records again; a query reads the current epoch only, as often as it likes)
