@@ -505,9 +505,9 @@ class Workload:
             self.steps_staggered(n_lanes)
             self.steps_done -= n_lanes
             torch.cuda.synchronize()
-            # Setup as well: which schedule this box runs faster.  Steps in flight on two streams were 1.5-3 times SLOWER than
-            # one step at a time on about one box in six (same build, same driver; one step at a time is not affected), so the
-            # run looks before it chooses: a few steps each way, the slower rank decides for all.
+            # Setup as well: which schedule runs faster here -- a few steps each way, the slower rank decides for all.  (Steps in
+            # flight depend on how the runtime folds streams onto hardware queues and on what else the host does; one step at
+            # a time does not.)
             def timed(fn, k):
                 torch.cuda.synchronize()
                 t = time.perf_counter()

@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(256) void gtx_task_flags_all_kernel(uint32_t const 
 // One-wave workgroups, sixteen items per thread (their loads are in flight together; one queue append per 1 024 items).
 // A host that keeps several batches in flight (gtx_align_batch_planes_staged) runs this kernel beside the resident one-wave
 // workgroups of another batch's express / general pass: a 1 024-thread workgroup then waits for sixteen free wave slots on
-// ONE CU -- 0.38 ms instead of 0.09, on some boxes a whole step at 1.45 ms instead of 1.07 -- where a one-wave workgroup
+// ONE CU -- 0.38 ms instead of 0.09 in a kernel trace -- where a one-wave workgroup
 // goes wherever a slot is.  Alone the small form costs 0.03 ms per 10 M items (GTX_TRIAGE_THREADS=1024 at build time: A/B).
 #ifndef GTX_TRIAGE_THREADS
 #define GTX_TRIAGE_THREADS 64
