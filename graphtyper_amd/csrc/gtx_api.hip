@@ -1335,14 +1335,22 @@ static CallScratch * scratch_acquire(gtx_ctx & c, hipStream_t stream)
     for (auto & s : c.pool)
       if (!pick && !s->busy && (!s->used || hipEventQuery(static_cast<hipEvent_t>(s->done)) == hipSuccess))
         pick = s.get();
-  if (!pick && c.pool.size() >= gtx_ctx::MAX_SCRATCH_IN_FLIGHT)
+  if (!pick)
   {
-    // A host that queues calls faster than the device does them would get a new scratch -- queues for a whole batch,
-    // hipMalloc in the middle of its stream of work -- for every call it is ahead: beyond a handful the call waits for the
-    // oldest one instead (the scratch that has been idle longest among those not held by a host thread).
+    // A host that queues calls on one stream faster than the device does them would get a new scratch -- queues for a whole
+    // batch, hipMalloc in the middle of its stream of work -- for every call it is ahead: beyond a handful in flight from
+    // this stream the call waits for the oldest of them instead.  (Calls of other streams -- a host thread per BAM pool -- have
+    // their own.)
+    size_t mine = 0;
     for (auto & s : c.pool)
-      if (!s->busy && (!pick || s->use_seq < pick->use_seq))
-        pick = s.get();
+      if (!s->busy && s->submit_stream == stream)
+      {
+        ++mine;
+        if (!pick || s->use_seq < pick->use_seq)
+          pick = s.get();
+      }
+    if (mine < gtx_ctx::MAX_SCRATCH_IN_FLIGHT)
+      pick = nullptr;
     if (pick)
     {
       pick->busy = true; // (ours from here on; the wait itself is outside the lock)
@@ -1363,8 +1371,9 @@ static CallScratch * scratch_acquire(gtx_ctx & c, hipStream_t stream)
   return pick;
 }
 
-static void scratch_release(gtx_ctx & c, CallScratch * s, hipStream_t stream, bool was_align)
+static void scratch_release(gtx_ctx & c, CallScratch * s, hipStream_t stream, bool was_align, hipStream_t submit_stream)
 {
+  s->submit_stream = submit_stream;
   (void)hipEventRecord(static_cast<hipEvent_t>(s->done), stream);
   std::lock_guard<std::mutex> lock(c.pool_mutex);
   s->used = true;
@@ -1583,12 +1592,13 @@ struct ScratchHold
 {
   gtx_ctx & c;
   CallScratch * s;
-  hipStream_t stream;
+  hipStream_t stream; // the stream the call's last launch is on (the entry points that end elsewhere than they began set it)
   bool align;
+  hipStream_t submit = stream; // the stream the call was made on
   ~ScratchHold()
   {
     if (s)
-      scratch_release(c, s, stream, align);
+      scratch_release(c, s, stream, align, submit);
   }
 };
 } // namespace

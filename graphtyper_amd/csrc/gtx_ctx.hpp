@@ -20,6 +20,7 @@ struct CallScratch
 {
   bool busy = false;         // a host thread is inside an entry point with it (guarded by gtx_ctx::pool_mutex)
   void * last_stream = nullptr;
+  void * submit_stream = nullptr; // the stream the last call that used it was made on
   bool used = false;         // `done` has been recorded at least once
   uint64_t use_seq = 0;      // gtx_ctx::scratch_uses at its last release (the smallest: the one whose work was queued longest ago)
   void * done = nullptr;     // hipEvent_t recorded behind the last launch that uses this scratch
@@ -93,7 +94,7 @@ struct gtx_ctx
   std::vector<std::unique_ptr<gtx::CallScratch>> pool;
   gtx::CallScratch * last_align = nullptr; // scratch of the most recent gtx_align_batch (pass times, second-pass task count)
   uint64_t scratch_uses = 0;
-  static constexpr size_t MAX_SCRATCH_IN_FLIGHT = 6; // scratches made for calls in flight before a call waits for one (gtx_api.hip: scratch_acquire)
+  static constexpr size_t MAX_SCRATCH_IN_FLIGHT = 4; // calls in flight from ONE stream before the next waits for the oldest (gtx_api.hip: scratch_acquire)
   bool timing_armed = false;
   // the timed calls between two queries are one epoch: the first timed call behind a query opens the next one (a scratch
   // drops the slots of an older epoch when it records again; a query reads the current epoch only, as often as it likes)
