@@ -814,7 +814,6 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
     return set ? static_cast<uint32_t>(__builtin_ctz(set)) : (km >> HK_ALLELE_SHIFT) & 3u;
   };
   uint32_t head_site = 0, head_mask = 0; // the site the walk at the read's start crossed, with its best alleles
-  bool head_on_site = false;             // ... which started inside the allele the path carries on a site
   if (prs != 0 && !decided) // walk_read_starts (genotype_paths.cpp:555-621)
   {
     uint32_t const y = lo == 1 ? f1.y : lo == 2 ? f2.y : lo == 3 ? f3.y : f4.y; // (position 31 lo is k-mer lo's own place)
@@ -825,7 +824,6 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
       // the walk leaves the node backwards: over the site in front of it (its base is read base ps), or -- the path
       // starts ON a site's base -- out of the allele it carries into the node in front
       bool const on_site = (y & 255u) == 0;
-      head_on_site = on_site;
       uint32_t const ps = on_site ? prs : prs - back - 1u;
       if (idx + ps == 0)
       {
