@@ -1257,7 +1257,8 @@ static bool dev_alloc(T *& dst, size_t n, char const * what, bool zero = false)
 // ---- per-call scratch (gtx_ctx.hpp) ----------------------------------------------------------------------------
 static void scratch_free(CallScratch & s)
 {
-  void * ptrs[] = {s.d_counters, s.d_queue1, s.d_queue, s.d_big_tasks, s.d_big_state, s.d_big_ws, s.d_score_state, s.d_score_queue,
+  // (d_big_state lies behind d_counters in one allocation: one reset for both)
+  void * ptrs[] = {s.d_counters, s.d_queue1, s.d_queue, s.d_big_tasks, s.d_big_ws, s.d_score_state, s.d_score_queue,
                    s.d_score_tables, s.d_score_work, s.d_wide_tasks, s.d_wide_ws, s.d_planes};
   for (void * p : ptrs)
     if (p)
@@ -1284,10 +1285,10 @@ static std::unique_ptr<CallScratch> scratch_new(gtx_ctx & c)
   bool ok = hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "scratch event");
   if (ok)
     s->done = ev;
-  ok = ok && dev_alloc(s->d_counters, 8 * CallScratch::MAX_PARTS, "task counters", true);
+  ok = ok && dev_alloc(s->d_counters, 8 * CallScratch::MAX_PARTS + 16, "task counters + second-pass state", true);
   if (ok && !c.params.no_second_pass)
   {
-    ok = ok && dev_alloc(s->d_big_state, 16, "second-pass state", true);
+    s->d_big_state = s->d_counters + 8 * CallScratch::MAX_PARTS;
     void * ws = nullptr;
     ok = ok && hip_ok(gtx::dev_malloc(&ws, static_cast<size_t>(c.big_blocks) * sizeof(big::AlignWorkspace)), "second-pass workspaces");
     s->d_big_ws = ws;
@@ -1299,7 +1300,7 @@ static std::unique_ptr<CallScratch> scratch_new(gtx_ctx & c)
       ok = ok && hip_ok(gtx::dev_malloc(&wws, static_cast<size_t>(CallScratch::WIDE_BLOCKS) * sizeof(wide::AlignWorkspace)), "wide-site pass workspaces");
       s->d_wide_ws = wws;
     }
-    ok = ok && dev_alloc(s->d_score_state, 2, "second-pass score state", true);
+    ok = ok && dev_alloc(s->d_score_state, 4, "second-pass score state", true); // ([2]: the work queue's count, reset with the rest)
     ok = ok && dev_alloc(s->d_score_queue, gtx_ctx::SCORE_QUEUE_CAP, "second-pass score queue");
     if (c.has_wide_sites)
     {
@@ -1737,7 +1738,8 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
                         uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, hipStream_t st, hipEvent_t front_event, hipStream_t tail_stream,
                         hipEvent_t done_event, hipStream_t * last_stream)
 {
-  if (!hip_ok(hipMemsetAsync(s->d_counters, 0, 8 * CallScratch::MAX_PARTS * sizeof(uint32_t), st), "task counter reset"))
+  // (the pass counters and, behind them, the state of the HBM-table and wide-site passes: one reset)
+  if (!hip_ok(hipMemsetAsync(s->d_counters, 0, (8 * CallScratch::MAX_PARTS + (s->d_big_state ? 12 : 0)) * sizeof(uint32_t), st), "task counter reset"))
     return GTX_ERR_HIP;
   // queues: room for every task (a graph on which no read is simple sends them all)
   if (!grow(s->d_queue, s->queue_cap, 2ull * n_reads, "pass-2 queue") || !grow(s->d_queue1, s->queue1_cap, n_reads, "pass-1 queue"))
@@ -1751,8 +1753,6 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     if (!grow(s->d_big_tasks, cap, want, "second-pass queue"))
       return GTX_ERR_HIP;
     s->big_task_cap = static_cast<uint32_t>(cap);
-    if (!hip_ok(hipMemsetAsync(s->d_big_state, 0, 12 * sizeof(uint32_t), st), "second-pass state reset"))
-      return GTX_ERR_HIP;
   }
   // tasks a wave of the general pass claims per visit to the counter
   char const * gc = std::getenv("GTX_GENERAL_CLAIM");
@@ -2215,21 +2215,22 @@ static int score_batch(gtx_ctx * c, const gtx_score_item * d_items, const uint32
                   static_cast<uint32_t>(c->params.is_segment_calling != 0), 0};
   uint32_t const blocks = (n_items + GTX_SCORE_THREADS - 1u) / GTX_SCORE_THREADS;
   bool const second_pass = s->d_score_state != nullptr;
-  if (second_pass && !hip_ok(hipMemsetAsync(s->d_score_state, 0, 2 * sizeof(uint32_t), st), "second-pass state reset"))
+  if (second_pass && !hip_ok(hipMemsetAsync(s->d_score_state, 0, 3 * sizeof(uint32_t), st), "second-pass state + work count reset"))
     return GTX_ERR_HIP;
   // work queue of stage 2: room for every item ([0] = count, [1..] = item indices)
   uint64_t cap = s->score_work_cap ? static_cast<uint64_t>(s->score_work_cap) + 1 : 0;
   if (!grow(s->d_score_work, cap, static_cast<uint64_t>(n_items) + 1, "score work queue"))
     return GTX_ERR_HIP;
   s->score_work_cap = static_cast<uint32_t>(cap - 1);
-  if (!hip_ok(hipMemsetAsync(s->d_score_work, 0, sizeof(uint32_t), st), "score work queue reset"))
+  uint32_t * const work_count = second_pass ? s->d_score_state + 2 : s->d_score_work; // (one reset where the second-pass state exists)
+  if (!second_pass && !hip_ok(hipMemsetAsync(s->d_score_work, 0, sizeof(uint32_t), st), "score work queue reset"))
     return GTX_ERR_HIP;
   hipLaunchKernelGGL(gtx_score_triage_kernel, dim3((n_items + TRIAGE_THREADS * TRIAGE_PER_THREAD - 1) / (TRIAGE_THREADS * TRIAGE_PER_THREAD)), dim3(TRIAGE_THREADS), 0, st, d_items, n_items, d_records, rec_words, s->d_score_work + 1,
-                     s->d_score_work, static_cast<uint32_t>(a.ref_depth != nullptr), d_task_flags, d_item_words);
+                     work_count, static_cast<uint32_t>(a.ref_depth != nullptr), d_task_flags, d_item_words);
   if (!hip_ok(hipGetLastError(), "gtx_score_triage_kernel launch"))
     return GTX_ERR_HIP;
   uint32_t const work_blocks = std::min<uint32_t>(blocks, static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256) * c->score_blocks_per_cu);
-  hipLaunchKernelGGL(gtx_score_kernel, dim3(work_blocks), dim3(GTX_SCORE_THREADS), 0, st, c->dev_graph, par, d_items, s->d_score_work + 1, s->d_score_work,
+  hipLaunchKernelGGL(gtx_score_kernel, dim3(work_blocks), dim3(GTX_SCORE_THREADS), 0, st, c->dev_graph, par, d_items, s->d_score_work + 1, work_count,
                      d_records, rec_words, a, c->d_error_flag, second_pass ? s->d_score_queue : nullptr,
                      second_pass ? gtx_ctx::SCORE_QUEUE_CAP : 0u, s->d_score_state);
   if (!hip_ok(hipGetLastError(), "gtx_score_kernel launch"))
