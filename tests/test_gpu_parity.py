@@ -243,7 +243,7 @@ def test_task_flags_side_array(hint):
 
 
 def test_batches_in_flight_equal_one_at_a_time():
-    """gtx_align_batch_planes_staged: three batches in flight -- position-hinted passes on one stream, the express / general
+    """gtx_align_batch_planes_staged: batches in flight -- position-hinted passes on one stream, the express / general
     queues behind each on a second one, the front event between them -- leave the records and side bytes the plain call
     leaves, batch by batch; and gtx_ctx_kernel_times then holds the mean over exactly those calls"""
     import ctypes as C
@@ -255,7 +255,8 @@ def test_batches_in_flight_equal_one_at_a_time():
     meta = harness.read_meta(lens, pos=pos)
     stride = (seq.shape[1] + 15) // 16 * 16
     planes = gtx.pack_planes(seq, stride)
-    parts = [(0, 3000), (3000, 7000), (7000, 9000)]
+    # (eight batches: more than the library keeps scratches in flight for one stream -- the later calls wait for the oldest)
+    parts = [(0, 1500), (1500, 3000), (3000, 4200), (4200, 5400), (5400, 6600), (6600, 7400), (7400, 8200), (8200, 9000)]
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to("cuda:0")
     want = []
     for a, b in parts:  # one at a time, default stream
