@@ -10,6 +10,8 @@
 // (ballot, exclusive scan).  A policy type W supplies those primitives: WaveHip (gtx_api.hip) maps them to the
 // hardware; tests/emu supplies a sequential stand-in so the very same source can be debugged without a GPU.
 #pragma once
+#include <type_traits>
+
 #include "graph_dev.hpp"
 
 namespace gtx
@@ -36,6 +38,7 @@ struct AlignCfg
   static constexpr uint32_t HE_CAP = 4;      // half-key bucket entries fetched up front per (k-mer, side)
   static constexpr uint32_t XL_CAP = 2;      // exact labels fetched up front per k-mer
   static constexpr uint32_t MW = 2;          // 32-bit words of an allele set: alleles 0..63 (a label beyond is an overflow)
+  static constexpr bool DYN = false;         // tables are arrays of the sizes above (true: pointers into a slab of HBM, sizes at run time)
 };
 
 #include "align_core.inl"
@@ -66,6 +69,7 @@ struct AlignCfg
   static constexpr uint32_t HE_CAP = 4;
   static constexpr uint32_t XL_CAP = 4;
   static constexpr uint32_t MW = 2;
+  static constexpr bool DYN = false;
 };
 #include "align_core.inl"
 } // namespace big
@@ -93,8 +97,61 @@ struct AlignCfg // (a path with its allele sets is 5 KB here: fewer of them than
   static constexpr uint32_t HE_CAP = 4;
   static constexpr uint32_t XL_CAP = 4;
   static constexpr uint32_t MW = GTX_WIDE_MASK_WORDS;
+  static constexpr bool DYN = false;
 };
 #include "align_core.inl"
 } // namespace wide
+
+// The last pass: EXACT.  The reference keeps its paths, labels and walk candidates in heap containers and has no limit on
+// any of them (genotype_paths.cpp:294-352: a read inside a 280-bp homopolymer chains 249 x 249 labels); every pass above
+// refuses what exceeds its tables and hands the task on, and this one must not refuse.  Its tables are pointers into a
+// slab of HBM that belongs to the workgroup for the duration of a task, cut to sizes computed at run time from the slab's
+// size (exact_layout, below): a first launch gives each of a few workgroups a part of the scratch's slab, a second launch
+// gives ONE workgroup the whole slab for what still did not fit -- so the only refusal left is a task that needs more
+// than the slab the caller configured (gtx_params::exact_pass_mb / GTX_EXACT_PASS_MB; 288 GB of HBM are there to be used).
+// The sizes that stay constants are proven bounds, not budgets: a path crosses at most one variant site per read base
+// (every allele holds at least one base), a walked sequence one variant node per base, walks are not done for more than
+// MAX_SEED_NUMBER_FOR_WALKING paths, a multi-key list is cut at max_index_labels.
+namespace exact
+{
+struct AlignCfg
+{
+  static constexpr uint32_t MAX_READ = 256;
+  static constexpr uint32_t MAX_KMERS = 8;
+  static constexpr uint32_t LBL_CAP = 1, MAXP = 1, MAXPP = 1, CAND_CAP = 1, WL_CAP = 1; // (run-time sizes: DynTables)
+  static constexpr uint32_t MAXV = MAX_READ;    // variant sites of a path
+  static constexpr uint32_t MAXIDS = MAX_READ;  // variant nodes of a walked sequence
+  static constexpr uint32_t LOC_CAP = 256;      // MAX_NUM_LOCATIONS_PER_PATH (beyond it the reference skips the path)
+  static constexpr uint32_t WLISTS = 256;       // MAX_SEED_NUMBER_FOR_WALKING
+  static constexpr uint32_t KEY_CAP = 388;      // 4 * 97 (type_conversions.cpp:207-266)
+  static constexpr uint32_t KC = 5;
+  static constexpr uint32_t HE_CAP = 4;
+  static constexpr uint32_t XL_CAP = 4;
+  static constexpr uint32_t MW = 2;
+  static constexpr bool DYN = true;
+};
+#include "align_core.inl"
+} // namespace exact
+
+namespace exactw // ... for graphs that have a site of more than 64 alleles
+{
+struct AlignCfg
+{
+  static constexpr uint32_t MAX_READ = 256;
+  static constexpr uint32_t MAX_KMERS = 8;
+  static constexpr uint32_t LBL_CAP = 1, MAXP = 1, MAXPP = 1, CAND_CAP = 1, WL_CAP = 1;
+  static constexpr uint32_t MAXV = MAX_READ;
+  static constexpr uint32_t MAXIDS = MAX_READ;
+  static constexpr uint32_t LOC_CAP = 256;
+  static constexpr uint32_t WLISTS = 256;
+  static constexpr uint32_t KEY_CAP = 388;
+  static constexpr uint32_t KC = 5;
+  static constexpr uint32_t HE_CAP = 4;
+  static constexpr uint32_t XL_CAP = 4;
+  static constexpr uint32_t MW = GTX_WIDE_MASK_WORDS;
+  static constexpr bool DYN = true;
+};
+#include "align_core.inl"
+} // namespace exactw
 
 } // namespace gtx

@@ -37,26 +37,52 @@ struct Cand // one element of var_and_refs / var_ids / end_pos in Graph::get_lab
 };
 constexpr uint32_t CAND_WORDS = sizeof(Cand) / 4;
 
+// A table of the workspace: an array of the configuration's size, or -- in the exact pass (AlignCfg::DYN, align_core.hpp) --
+// a pointer into the task's slab of HBM whose capacity is a run-time value of the workspace (cap_* below).  Indexing,
+// decay to a pointer and pointer arithmetic read the same on both.
+template <class T, uint32_t N>
+using TableOf = typename std::conditional<AlignCfg::DYN, T *, T[N]>::type;
+
 struct WalkBuffers // alive only during walk_read_starts / walk_read_ends
 {
-  DPath pp[AlignCfg::MAXPP];
-  Cand cand[AlignCfg::CAND_CAP];
+  TableOf<DPath, AlignCfg::MAXPP> pp;
+  TableOf<Cand, AlignCfg::CAND_CAP> cand;
   Loc locs[AlignCfg::LOC_CAP];
-  DevLabel dfs_out[AlignCfg::WL_CAP]; // labels of the current iterative_dfs call
+  TableOf<DevLabel, AlignCfg::WL_CAP> dfs_out; // labels of the current iterative_dfs call
 };
 
-struct AlignWorkspace // lives in LDS, one per wavefront
+// keybuf and the walk buffers are never alive at the same time: one storage for both -- unless the walk buffers are
+// pointers (exact pass), which the keys must not overwrite
+union WorkUnion
+{
+  uint64_t keybuf[AlignCfg::KEY_CAP]; // keys of a multi-key list, then (offset | count << 32) of every probed key
+  WalkBuffers w;                      // (pp is also used while seeding, never at the same time as keybuf)
+};
+struct WorkBoth
+{
+  uint64_t keybuf[AlignCfg::KEY_CAP];
+  WalkBuffers w;
+};
+
+// run-time table sizes and the side tables of the exact pass (empty in the passes with fixed tables)
+struct DynTables
+{
+  uint32_t cap_lbl, cap_p, cap_cand, cap_wl; // entries of lbl; of paths and pp; of cand; of wl and of dfs_out
+  uint32_t * pp_start, * pp_end;             // start / end of every pp entry, densely: what the searches of the chaining read
+  uint64_t * bits_p, * bits_pp;              // one bit per path / per pp entry (the drop and matched sets of the filters and the chaining)
+};
+struct NoDynTables
+{
+};
+
+struct AlignWorkspace : std::conditional<AlignCfg::DYN, DynTables, NoDynTables>::type // lives in LDS (HBM in the passes behind the general one), one per wavefront
 {
   uint8_t rd[AlignCfg::MAX_READ]; // read as 4-bit IUPAC codes, orientation applied
-  DevLabel lbl[AlignCfg::LBL_CAP];
-  DPath paths[AlignCfg::MAXP];
+  TableOf<DevLabel, AlignCfg::LBL_CAP> lbl;
+  TableOf<DPath, AlignCfg::MAXP> paths;
   DPath orig, np; // Path temporaries of add_next/prev_kmer_labels
-  union
-  {
-    uint64_t keybuf[AlignCfg::KEY_CAP]; // keys of a multi-key list, then (offset | count << 32) of every probed key
-    WalkBuffers w;                      // (pp is also used while seeding, never at the same time as keybuf)
-  } u;
-  DevLabel wl[AlignCfg::WL_CAP]; // best label lists of a walk (must survive the add_*_kmer_labels calls)
+  typename std::conditional<AlignCfg::DYN, WorkBoth, WorkUnion>::type u;
+  TableOf<DevLabel, AlignCfg::WL_CAP> wl; // best label lists of a walk (must survive the add_*_kmer_labels calls)
   uint32_t wl_off[AlignCfg::WLISTS + 1];
   uint32_t wl_idx[AlignCfg::WLISTS];
   // per k-mer exact-probe results
@@ -98,6 +124,183 @@ struct SeedWorkspace
   unsigned long long prof_acc[16];
 #endif
 };
+
+// ---- exact pass: cutting a slab of HBM into the tables of one task (AlignCfg::DYN; align_core.hpp: namespace exact) ----
+// The slab starts with the workspace itself; behind it, for a path capacity P: paths and pp (P entries each), lbl
+// (P + 128: a single exact key has no limit, a multi-key list stops at max_index_labels), wl and dfs_out (4 P + 4096
+// labels each), the walk candidates (cand_cap entries: the reference stops branching at 128 live sequences, one more round
+// over a site of n alleles makes at most 128 n of them -- exact_cand_cap of the graph's widest site), the dense start / end
+// tables of pp and two bit sets.  exact_path_capacity is the largest P that fits (0: the slab cannot even hold the fixed part).
+GTX_HDI uint32_t exact_cand_cap(uint32_t widest_site)
+{
+  return 128u * (widest_site < 2u ? 2u : widest_site) + 64u;
+}
+
+GTX_HDI uint64_t exact_fixed_bytes(uint32_t cand_cap)
+{
+  return ((sizeof(AlignWorkspace) + 255u) & ~static_cast<uint64_t>(255u)) + static_cast<uint64_t>(cand_cap) * sizeof(Cand) +
+         (128u + 2u * 4096u) * sizeof(DevLabel) + 16u * 256u; // (+ alignment slack of the ten tables)
+}
+
+GTX_HDI uint64_t exact_bytes_per_path()
+{
+  return 2u * sizeof(DPath) + 9u * sizeof(DevLabel) + 2u * sizeof(uint32_t) + 1u; // (+ two bits, rounded up)
+}
+
+GTX_HDI uint32_t exact_path_capacity(uint64_t slab_bytes, uint32_t cand_cap)
+{
+  uint64_t const fixed = exact_fixed_bytes(cand_cap) + 2u * 64u;
+  if (slab_bytes <= fixed)
+    return 0;
+  uint64_t const p = (slab_bytes - fixed) / exact_bytes_per_path();
+  return p > 0x7FFFFFFFull ? 0x7FFFFFFFu : static_cast<uint32_t>(p);
+}
+
+// bytes of a slab that holds P paths
+GTX_HDI uint64_t exact_slab_bytes(uint32_t paths, uint32_t cand_cap)
+{
+  return exact_fixed_bytes(cand_cap) + 2u * 64u + static_cast<uint64_t>(paths) * exact_bytes_per_path() + 256u;
+}
+
+// Points the tables of the workspace at the head of `slab` into it.  Returns false when the slab is too small for a single path.
+template <class W, class WS>
+GTX_DEV bool exact_setup(WS * ws_at_slab_head, uint64_t slab_bytes, uint32_t cand_cap)
+{
+  if constexpr (AlignCfg::DYN)
+  {
+    WS & ws = *ws_at_slab_head;
+    uint32_t const P = exact_path_capacity(slab_bytes, cand_cap);
+    if (P == 0)
+      return false;
+    GTX_LEAD
+    {
+      uint8_t * at = reinterpret_cast<uint8_t *>(ws_at_slab_head) + ((sizeof(WS) + 255u) & ~static_cast<uint64_t>(255u));
+      auto take = [&](uint64_t bytes)
+      {
+        uint8_t * r = at;
+        at += (bytes + 255u) & ~static_cast<uint64_t>(255u);
+        return r;
+      };
+      ws.cap_p = P;
+      ws.cap_lbl = P + 128u;
+      ws.cap_wl = 4u * P + 4096u;
+      ws.cap_cand = cand_cap;
+      ws.paths = reinterpret_cast<DPath *>(take(static_cast<uint64_t>(P) * sizeof(DPath)));
+      ws.u.w.pp = reinterpret_cast<DPath *>(take(static_cast<uint64_t>(P) * sizeof(DPath)));
+      ws.lbl = reinterpret_cast<DevLabel *>(take(static_cast<uint64_t>(ws.cap_lbl) * sizeof(DevLabel)));
+      ws.wl = reinterpret_cast<DevLabel *>(take(static_cast<uint64_t>(ws.cap_wl) * sizeof(DevLabel)));
+      ws.u.w.dfs_out = reinterpret_cast<DevLabel *>(take(static_cast<uint64_t>(ws.cap_wl) * sizeof(DevLabel)));
+      ws.u.w.cand = reinterpret_cast<Cand *>(take(static_cast<uint64_t>(cand_cap) * sizeof(Cand)));
+      ws.pp_start = reinterpret_cast<uint32_t *>(take(static_cast<uint64_t>(P) * sizeof(uint32_t)));
+      ws.pp_end = reinterpret_cast<uint32_t *>(take(static_cast<uint64_t>(P) * sizeof(uint32_t)));
+      ws.bits_p = reinterpret_cast<uint64_t *>(take((static_cast<uint64_t>(P) + 63u) / 64u * 8u));
+      ws.bits_pp = reinterpret_cast<uint64_t *>(take((static_cast<uint64_t>(P) + 63u) / 64u * 8u));
+    }
+    W::lds_sync();
+    return true;
+  }
+  else
+    return true;
+}
+
+// table capacities: the configuration's constants, or what the task's slab holds (exact pass)
+template <class WS>
+GTX_DEV uint32_t cap_lbl(WS const & ws)
+{
+  if constexpr (AlignCfg::DYN)
+    return ws.cap_lbl;
+  else
+    return AlignCfg::LBL_CAP;
+}
+template <class WS>
+GTX_DEV uint32_t cap_paths(WS const & ws)
+{
+  if constexpr (AlignCfg::DYN)
+    return ws.cap_p;
+  else
+    return AlignCfg::MAXP;
+}
+template <class WS>
+GTX_DEV uint32_t cap_pp(WS const & ws)
+{
+  if constexpr (AlignCfg::DYN)
+    return ws.cap_p;
+  else
+    return AlignCfg::MAXPP;
+}
+template <class WS>
+GTX_DEV uint32_t cap_cand(WS const & ws)
+{
+  if constexpr (AlignCfg::DYN)
+    return ws.cap_cand;
+  else
+    return AlignCfg::CAND_CAP;
+}
+template <class WS>
+GTX_DEV uint32_t cap_wl(WS const & ws)
+{
+  if constexpr (AlignCfg::DYN)
+    return ws.cap_wl;
+  else
+    return AlignCfg::WL_CAP;
+}
+
+// the dense start (chaining forwards) or end (backwards) table of the pp entries (exact pass)
+template <class WS>
+GTX_DEV uint32_t const * pp_keys(WS const & ws, bool ends)
+{
+  if constexpr (AlignCfg::DYN)
+    return ends ? ws.pp_end : ws.pp_start;
+  else
+    return nullptr;
+}
+
+// A set of path (or pp) numbers: registers in the passes with fixed tables (BitSet, graph_dev.hpp), words of the task's
+// slab in the exact pass.  Wave-uniform like everything else here: every lane sets the same bit and reads the same word.
+struct MemBits
+{
+  uint64_t * w;
+};
+template <class W>
+GTX_DEV void bits_set(MemBits & b, uint32_t i)
+{
+  GTX_LEAD b.w[i >> 6] |= 1ull << (i & 63u);
+  W::lds_sync();
+}
+template <class W>
+GTX_DEV bool bits_get(MemBits const & b, uint32_t i)
+{
+  return (GTX_U(b.w[i >> 6]) >> (i & 63u)) & 1ull;
+}
+// an empty set over n elements
+template <class W>
+GTX_DEV MemBits bits_clear(uint64_t * words, uint32_t n)
+{
+  uint32_t const nw = (n + 63u) / 64u;
+  for (uint32_t b = 0; b < nw; b += 64)
+    W::lanes([&](uint32_t l) {
+      if (b + l < nw)
+        words[b + l] = 0;
+    });
+  W::lds_sync();
+  return MemBits{words};
+}
+template <class W, class WS>
+GTX_DEV auto new_path_set(WS & ws, uint32_t n)
+{
+  if constexpr (AlignCfg::DYN)
+    return bits_clear<W>(ws.bits_p, n);
+  else
+    return BitSet<AlignCfg::MAXP>();
+}
+template <class W, class WS>
+GTX_DEV auto new_pp_set(WS & ws, uint32_t n)
+{
+  if constexpr (AlignCfg::DYN)
+    return bits_clear<W>(ws.bits_pp, n);
+  else
+    return BitSet<AlignCfg::MAXPP>();
+}
 
 // allele sets.  Readers apply GTX_U per word (the tables are wave-uniform), writers run on the leader lane.
 GTX_DEV bool pv_fits(uint32_t allele) // an allele beyond this pass' masks: the task overflows to the pass that holds it
@@ -372,11 +575,32 @@ GTX_DEV uint32_t cmp_lane_codes(SubRead const & sr, uint32_t at, Codes const & c
   return mism > maxmm ? maxmm + 1 : mism;
 }
 
+// copy of a walk candidate: only the part in use when the entry is long (the exact pass has room for a variant node per base)
+template <class W>
+GTX_DEV void copy_cand(Cand & dst, Cand const & src)
+{
+  if constexpr (CAND_WORDS <= 64)
+    copy_entry<W>(dst, src);
+  else
+  {
+    if (&dst == &src)
+      return;
+    uint32_t const words = 4 + GTX_U(src.nids);
+    uint32_t * d = reinterpret_cast<uint32_t *>(&dst);
+    uint32_t const * s = reinterpret_cast<uint32_t const *>(&src);
+    W::lanes([&](uint32_t l) {
+      for (uint32_t w = l; w < words; w += 64)
+        d[w] = s[w];
+    });
+    W::lds_sync();
+  }
+}
+
 template <class W>
 GTX_DEV void cand_erase(Cand * c, uint32_t n, uint32_t j)
 {
   for (uint32_t k = j; k + 1 < n; ++k)
-    copy_entry<W>(c[k], c[k + 1]);
+    copy_cand<W>(c[k], c[k + 1]);
 }
 
 // Emits the labels of the candidates that tie the fewest mismatches (graph.cpp:1375-1437 / 1636-1698).
@@ -443,7 +667,7 @@ GTX_DEV bool emit_best(GraphView const & g, Cand const * cand, uint32_t n, uint3
 // One start (forward) or end (backward) location: extends over variant sites until every candidate covers the
 // sub-read, keeps candidates within the mismatch budget, appends the labels of the best ones to `out`.
 template <class W, bool BACKWARD>
-GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr, uint32_t & max_mismatches, Cand * cand,
+GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr, uint32_t & max_mismatches, Cand * cand, uint32_t cand_cap,
                          DevLabel * out, uint32_t & n_out, uint32_t out_cap, uint32_t & status)
 {
   uint8_t const * dna = reinterpret_cast<uint8_t const *>(g.dna);
@@ -615,7 +839,7 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
           }
           if (mm <= maxmm)
           {
-            if ((!last && n >= AlignCfg::CAND_CAP) || jn >= AlignCfg::MAXIDS)
+            if ((!last && n >= cand_cap) || jn >= AlignCfg::MAXIDS)
             {
               status |= GTX_ST_DFS_OVERFLOW;
               return false;
@@ -628,7 +852,7 @@ GTX_DEV bool labels_walk(GraphView const & g, Loc const & s, SubRead const & sr,
             uint32_t const dst = last ? j : n;
             if (!last)
             {
-              copy_entry<W>(cand[n], cand[j]);
+              copy_cand<W>(cand[n], cand[j]);
               ++n;
             }
             GTX_LEAD
@@ -686,8 +910,8 @@ GTX_DEV uint32_t iterative_dfs(GraphView const & g, AlignWorkspace & ws, uint32_
     uint32_t mm = max_mismatches;
     uint32_t const before = n_out;
     uint32_t after = n_out;
-    bool const ok = backward ? labels_walk<W, true>(g, wb.locs[k], sr, mm, wb.cand, wb.dfs_out, after, AlignCfg::WL_CAP, status)
-                             : labels_walk<W, false>(g, wb.locs[k], sr, mm, wb.cand, wb.dfs_out, after, AlignCfg::WL_CAP, status);
+    bool const ok = backward ? labels_walk<W, true>(g, wb.locs[k], sr, mm, wb.cand, cap_cand(ws), wb.dfs_out, after, cap_wl(ws), status)
+                             : labels_walk<W, false>(g, wb.locs[k], sr, mm, wb.cand, cap_cand(ws), wb.dfs_out, after, cap_wl(ws), status);
     if (!ok)
       return 0;
     if (after == before)
@@ -713,8 +937,23 @@ GTX_DEV uint32_t iterative_dfs(GraphView const & g, AlignWorkspace & ws, uint32_
 // ---------------------------------------------------------------------------------------------------------------
 
 // find_all_nonduplicated_paths (genotype_paths.cpp:32-66) + Path::merge_with_current (path.cpp:105-129)
+// first entry j of a dense table with key[j] == want (exact pass: 64 entries per step, one per lane); n when there is none
 template <class W>
-GTX_DEV uint32_t make_pp(DPath * pp, DevLabel const * ll, uint32_t n, uint32_t rs, uint32_t re, uint32_t mism, uint32_t & status)
+GTX_DEV uint32_t find_pair(uint32_t const * a, uint32_t const * b, uint32_t n, uint32_t want_a, uint32_t want_b)
+{
+  for (uint32_t base = 0; base < n; base += 64)
+  {
+    typename W::template PerLane<bool> hit;
+    W::lanes([&](uint32_t l) { hit[l] = base + l < n && a[base + l] == want_a && b[base + l] == want_b; });
+    uint64_t const m = W::ballot(hit);
+    if (m != 0)
+      return base + static_cast<uint32_t>(__builtin_ctzll(m));
+  }
+  return n;
+}
+
+template <class W, class WS>
+GTX_DEV uint32_t make_pp(WS & ws, DPath * pp, DevLabel const * ll, uint32_t n, uint32_t rs, uint32_t re, uint32_t mism, uint32_t & status)
 {
   uint32_t npp = 0;
   for (uint32_t i = 0; i < n; ++i)
@@ -726,18 +965,26 @@ GTX_DEV uint32_t make_pp(DPath * pp, DevLabel const * ll, uint32_t n, uint32_t r
       return npp;
     }
     uint32_t d = 0;
-    for (; d < npp; ++d)
-      if (GTX_U(pp[d].start) == ls && GTX_U(pp[d].end) == le)
-        break;
+    if constexpr (AlignCfg::DYN)
+      d = find_pair<W>(ws.pp_start, ws.pp_end, npp, ls, le);
+    else
+      for (; d < npp; ++d)
+        if (GTX_U(pp[d].start) == ls && GTX_U(pp[d].end) == le)
+          break;
     if (d == npp)
     {
-      if (npp >= AlignCfg::MAXPP)
+      if (npp >= cap_pp(ws))
       {
         status |= GTX_ST_PATH_OVERFLOW;
         return npp;
       }
       GTX_LEAD
       {
+        if constexpr (AlignCfg::DYN)
+        {
+          ws.pp_start[npp] = ls;
+          ws.pp_end[npp] = le;
+        }
         DPath & p = pp[npp];
         p.start = ls;
         p.end = le;
@@ -833,7 +1080,7 @@ GTX_DEV bool merge_paths(DPath const & p1, DPath const & p2, DPath & np, uint32_
 template <class W>
 GTX_DEV bool push_path(AlignWorkspace & ws, uint32_t & n_paths, DPath const & p, uint32_t & status)
 {
-  if (n_paths >= AlignCfg::MAXP)
+  if (n_paths >= cap_paths(ws))
   {
     status |= GTX_ST_PATH_OVERFLOW;
     return false;
@@ -910,7 +1157,7 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
     }
     if (!matched)
     {
-      if (n_paths >= AlignCfg::MAXP)
+      if (n_paths >= cap_paths(ws))
       {
         status |= GTX_ST_PATH_OVERFLOW;
         return;
@@ -939,11 +1186,11 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
     return;
   }
   DPath * pp = ws.u.w.pp;
-  uint32_t const npp = make_pp<W>(pp, ll, n, rs, re, mism, status);
+  uint32_t const npp = make_pp<W>(ws, pp, ll, n, rs, re, mism, status);
   if (status)
     return;
   uint32_t const original_size = n_paths;
-  BitSet<AlignCfg::MAXPP> matched;
+  auto matched = new_pp_set<W>(ws, npp);
   for (uint32_t i = 0; i < original_size; ++i)
   {
     if (prev ? (GTX_U(static_cast<uint32_t>(ws.paths[i].rs)) != re) : (GTX_U(static_cast<uint32_t>(ws.paths[i].re)) != rs))
@@ -951,43 +1198,49 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
     bool once = false;
     copy_path<W>(ws.orig, ws.paths[i]);
     uint32_t const o_start = GTX_U(ws.orig.start), o_end = GTX_U(ws.orig.end);
-    for (uint32_t j = 0; j < npp; ++j)
+    // one pp entry that abuts the path: merged into it (the first one in place, further ones as new paths)
+    auto join = [&](uint32_t j) -> bool
     {
-      bool ok;
-      if (prev)
-      {
-        if (!(GTX_U(pp[j].end) == o_start))
-          continue;
-        ok = merge_paths<W>(pp[j], ws.orig, ws.np, status);
-      }
-      else
-      {
-        if (!(o_end == GTX_U(pp[j].start)))
-          continue;
-        ok = merge_paths<W>(ws.orig, pp[j], ws.np, status);
-      }
+      bool const ok = prev ? merge_paths<W>(pp[j], ws.orig, ws.np, status) : merge_paths<W>(ws.orig, pp[j], ws.np, status);
       if (status)
-        return;
+        return false;
       if (!ok)
-        continue;
-      matched.set(j);
+        return true;
+      bits_set<W>(matched, j);
       if (once)
+        return push_path<W>(ws, n_paths, ws.np, status);
+      uint32_t const sz = upath_size<W>(ws.np);
+      if (sz > longest)
+        longest = sz;
+      copy_path<W>(ws.paths[i], ws.np);
+      once = true;
+      return true;
+    };
+    if constexpr (AlignCfg::DYN)
+    {
+      // (thousands of entries: the abutting ones are found 64 at a time in the dense start / end table, then taken in order)
+      uint32_t const * key = pp_keys(ws, prev);
+      uint32_t const want = prev ? o_start : o_end;
+      for (uint32_t base = 0; base < npp; base += 64)
       {
-        if (!push_path<W>(ws, n_paths, ws.np, status))
-          return;
-      }
-      else
-      {
-        uint32_t const sz = upath_size<W>(ws.np);
-        if (sz > longest)
-          longest = sz;
-        copy_path<W>(ws.paths[i], ws.np);
-        once = true;
+        typename W::template PerLane<bool> hit;
+        W::lanes([&](uint32_t l) { hit[l] = base + l < npp && key[base + l] == want; });
+        for (uint64_t m = W::ballot(hit); m != 0; m &= m - 1)
+          if (!join(base + static_cast<uint32_t>(__builtin_ctzll(m))))
+            return;
       }
     }
+    else
+      for (uint32_t j = 0; j < npp; ++j)
+      {
+        if (prev ? !(GTX_U(pp[j].end) == o_start) : !(o_end == GTX_U(pp[j].start)))
+          continue;
+        if (!join(j))
+          return;
+      }
   }
   for (uint32_t j = 0; j < npp; ++j)
-    if (!matched.get(j))
+    if (!bits_get<W>(matched, j))
     {
       uint32_t const sz = upath_size<W>(pp[j]);
       if (sz > longest)
@@ -1001,17 +1254,15 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
 // path filters (genotype_paths.cpp)
 // ---------------------------------------------------------------------------------------------------------------
 
-using PathSet = BitSet<AlignCfg::MAXP>;
-
-// stable removal of the paths whose bit in `drop` is set
-template <class W>
-GTX_DEV uint32_t compact_paths(AlignWorkspace & ws, uint32_t n_paths, PathSet const & drop)
+// stable removal of the paths whose bit in `drop` is set (n_drop of them)
+template <class W, class PathSet>
+GTX_DEV uint32_t compact_paths(AlignWorkspace & ws, uint32_t n_paths, PathSet const & drop, uint32_t n_drop)
 {
-  if (!drop.any())
+  if (n_drop == 0)
     return n_paths;
   uint32_t k = 0;
   for (uint32_t i = 0; i < n_paths; ++i)
-    if (!drop.get(i))
+    if (!bits_get<W>(drop, i))
     {
       if (k != i)
         copy_path<W>(ws.paths[k], ws.paths[i]);
@@ -1025,11 +1276,15 @@ GTX_DEV uint32_t remove_short_paths(AlignWorkspace & ws, uint32_t n_paths, uint3
 {
   if (longest <= 1)
     return n_paths;
-  PathSet drop;
+  auto drop = new_path_set<W>(ws, n_paths);
+  uint32_t n_drop = 0;
   for (uint32_t i = 0; i < n_paths; ++i)
     if (upath_size<W>(ws.paths[i]) < longest)
-      drop.set(i);
-  return compact_paths<W>(ws, n_paths, drop);
+    {
+      bits_set<W>(drop, i);
+      ++n_drop;
+    }
+  return compact_paths<W>(ws, n_paths, drop, n_drop);
 }
 
 template <class W>
@@ -1057,11 +1312,15 @@ GTX_DEV uint32_t remove_paths_with_too_many_mismatches(AlignWorkspace & ws, uint
     if (m < mn)
       mn = m;
   }
-  PathSet drop;
+  auto drop = new_path_set<W>(ws, n_paths);
+  uint32_t n_drop = 0;
   for (uint32_t i = 0; i < n_paths; ++i)
     if (GTX_U(static_cast<uint32_t>(ws.paths[i].mism)) > mn)
-      drop.set(i);
-  return compact_paths<W>(ws, n_paths, drop);
+    {
+      bits_set<W>(drop, i);
+      ++n_drop;
+    }
+  return compact_paths<W>(ws, n_paths, drop, n_drop);
 }
 
 template <class W>
@@ -1091,23 +1350,31 @@ GTX_DEV uint32_t remove_non_ref_paths_when_read_matches_ref(GraphView const & g,
 {
   if (all_paths_unique<W>(g, ws.paths, n_paths))
     return n_paths;
-  PathSet nonref;
+  auto nonref = new_path_set<W>(ws, n_paths);
+  uint32_t n_nonref = 0;
   for (uint32_t i = 0; i < n_paths; ++i)
     if (!path_is_reference<W>(ws.paths[i]))
-      nonref.set(i);
-  if (nonref.count() == n_paths)
+    {
+      bits_set<W>(nonref, i);
+      ++n_nonref;
+    }
+  if (n_nonref == n_paths)
     return n_paths; // no path supports only the reference
-  return compact_paths<W>(ws, n_paths, nonref);
+  return compact_paths<W>(ws, n_paths, nonref, n_nonref);
 }
 
 template <class W>
 GTX_DEV uint32_t remove_fully_special_paths(GraphView const & g, AlignWorkspace & ws, uint32_t n_paths) // :476-481
 {
-  PathSet drop;
+  auto drop = new_path_set<W>(ws, n_paths);
+  uint32_t n_drop = 0;
   for (uint32_t i = 0; i < n_paths; ++i)
     if (ug_ref_reach_pos<W>(g, GTX_U(ws.paths[i].start)) == ug_ref_reach_pos<W>(g, GTX_U(ws.paths[i].end)))
-      drop.set(i);
-  return compact_paths<W>(ws, n_paths, drop);
+    {
+      bits_set<W>(drop, i);
+      ++n_drop;
+    }
+  return compact_paths<W>(ws, n_paths, drop, n_drop);
 }
 
 template <class W>
@@ -1329,7 +1596,7 @@ GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, ui
     }
     if (mm == best)
     {
-      if (n_wlists >= AlignCfg::WLISTS || n_wl + nl > AlignCfg::WL_CAP)
+      if (n_wlists >= AlignCfg::WLISTS || n_wl + nl > cap_wl(ws))
       {
         status |= GTX_ST_DFS_OVERFLOW;
         return;
@@ -1445,7 +1712,7 @@ GTX_DEV uint32_t probe_list(IndexView const & ix, AlignWorkspace & ws, bool hamm
   W::lds_sync();
   if (nkeys > 1 && total > ix.max_index_labels)
     return 0; // ph_index.cpp:84-89
-  if (total > AlignCfg::LBL_CAP)
+  if (total > cap_lbl(ws))
   {
     status |= GTX_ST_LABEL_OVERFLOW;
     return 0;
@@ -2058,7 +2325,7 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
         // exact list: one key, never cut (ph_index.cpp:84)
         uint32_t const cnt = GTX_U(ws.cnt0[i]), off = GTX_U(ws.off0[i]);
         n_lbl = cnt;
-        if (cnt > AlignCfg::LBL_CAP)
+        if (cnt > cap_lbl(ws))
         {
           status |= GTX_ST_LABEL_OVERFLOW;
           break;
@@ -2089,7 +2356,7 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
           n_lbl = total;
           if (total > ix.max_index_labels)
             n_lbl = 0; // multi_get: a list of several keys with more hits than that yields nothing (ph_index.cpp:84-89)
-          else if (total > AlignCfg::LBL_CAP)
+          else if (total > cap_lbl(ws))
           {
             status |= GTX_ST_LABEL_OVERFLOW;
             break;

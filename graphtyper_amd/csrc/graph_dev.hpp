@@ -305,6 +305,18 @@ struct BitSet
   }
 };
 
+// (the same two operations exist for sets that live in memory -- align_core.inl, MemBits --, hence the free functions)
+template <class W, uint32_t N>
+GTX_DEV void bits_set(BitSet<N> & b, uint32_t i)
+{
+  b.set(i);
+}
+template <class W, uint32_t N>
+GTX_DEV bool bits_get(BitSet<N> const & b, uint32_t i)
+{
+  return b.get(i);
+}
+
 // lookup in a bucketed table (gtx_flat.hpp: BUCKET_SLOTS): the whole 128-byte bucket is one cache line; `hit` (may be
 // NULL) receives the slot that matched, whose inline payload is then an L1 hit
 GTX_DEV void bucket_find(IndexSlot const * slots, uint32_t log2_buckets, uint64_t key, uint32_t & off, uint32_t & cnt,

@@ -15,92 +15,14 @@
 
 #include "gtx_ctx.hpp"
 #include "gtx_devmem.hpp"
+#include "wave_hip.hpp"
 #include "align_core.hpp"
+#include "gtx_hbm_passes.hpp"
 #include "score_core.hpp"
 #include "score_replay.hpp"
 
 namespace gtx
 {
-struct WaveHip
-{
-  template <class T>
-  struct PerLane
-  {
-    T v;
-    __device__ inline T & operator[](uint32_t) { return v; }
-    __device__ inline T const & operator[](uint32_t) const { return v; }
-  };
-  template <class F>
-  static __device__ inline void lanes(F && f)
-  {
-    f(threadIdx.x & 63u);
-  }
-  static __device__ inline bool leader() { return (threadIdx.x & 63u) == 0; }
-  // the value lane `lane` (wave-uniform) holds
-  static __device__ inline uint32_t from_lane(PerLane<uint32_t> const & p, uint32_t lane) { return __builtin_amdgcn_readlane(p.v, lane); }
-  // value known to be equal on all lanes -> scalar register
-  static __device__ inline uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-  static __device__ inline int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-  static __device__ inline bool uni(bool v) { return __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)) != 0; }
-  static __device__ inline uint64_t uni(uint64_t v)
-  {
-    uint32_t const lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
-    uint32_t const hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
-    return (static_cast<uint64_t>(hi) << 32) | lo;
-  }
-  // Orders the leader's LDS writes before the other lanes' reads.  All 64 lanes belong to one wavefront whose LDS
-  // instructions are issued and serviced in program order, so no hardware wait is needed: the wavefront-scope fences
-  // only stop the compiler from moving or merging LDS accesses across this point (GTX_HARD_SYNC=1 at build time
-  // falls back to a real workgroup barrier for A/B checks).
-  static __device__ inline void lds_sync()
-  {
-#ifdef GTX_HARD_SYNC
-    __syncthreads();
-#else
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
-  }
-  static __device__ inline uint64_t ballot(PerLane<bool> const & p) { return __ballot(p.v); }
-  static __device__ inline uint32_t sum(PerLane<uint32_t> const & p)
-  {
-    uint32_t x = p.v;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1)
-      x += __shfl_xor(x, d);
-    return x;
-  }
-  static __device__ inline void excl_scan(PerLane<uint32_t> const & in, PerLane<uint32_t> & out, uint32_t & total)
-  {
-    uint32_t x = in.v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1)
-    {
-      uint32_t const y = __shfl_up(x, d);
-      if ((threadIdx.x & 63u) >= static_cast<uint32_t>(d))
-        x += y;
-    }
-    total = __shfl(x, 63);
-    out.v = x - in.v;
-  }
-  static __device__ inline unsigned long long clock() { return clock64(); }
-  static __device__ inline void atomic_add_u32(uint32_t * p, uint32_t v) { atomicAdd(p, v); }
-  static __device__ inline void atomic_add_u64(unsigned long long * p, unsigned long long v) { atomicAdd(p, v); }
-  // next free slot of a log every lane appends to (fetch-and-increment).  The lanes that are here together ask with one
-  // atomic: a single device counter sustains ~90 M returning atomics a second, a dense graph wants more log entries.
-  static __device__ inline uint32_t atomic_claim_u32(uint32_t * p)
-  {
-    unsigned long long const here = __ballot(1);
-    uint32_t const lane = threadIdx.x & 63u, leader = static_cast<uint32_t>(__builtin_ctzll(here));
-    uint32_t base = 0;
-    if (lane == leader)
-      base = atomicAdd(p, static_cast<uint32_t>(__builtin_popcountll(here)));
-    base = __shfl(base, static_cast<int>(leader));
-    return base + static_cast<uint32_t>(__builtin_popcountll(here & ((1ull << lane) - 1ull)));
-  }
-};
-
 // Scoring adds small integers to per-(haplotype, sample) counters, and the reads of a workgroup -- neighbours in a
 // position-sorted stream -- hit the same few counters: 1 500 reads deep, every counter of a site would take thousands of
 // same-address atomics at the L2.  The workgroup therefore sums into an LDS table keyed by the counter's address first and
@@ -208,21 +130,6 @@ struct WaveHipCombine : WaveHip
   }
 };
 
-// Second pass: the workspace is in global memory, so the leader's stores must have completed (vmcnt) before the other
-// lanes load them: workgroup-scope release/acquire fences are exactly that wait (one CU, one L1: no cache maintenance).
-// The wave barrier between them is the convergence point that keeps the compiler from letting lanes run ahead of the
-// leader (a workgroup barrier would be dropped for a one-wave workgroup and leave nothing to anchor on).
-struct WaveHipMem : WaveHip
-{
-  static __device__ inline void mem_sync()
-  {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  }
-  static __device__ inline void lds_sync() { mem_sync(); }
-};
-
 // The bulk traffic of the position-hinted pass -- every read's bases and meta record in, every record out, each touched
 // once -- is marked non-temporal (the `nt` bit of the global load / store): it streams through the caches without pushing
 // out what the passes behind it live on (their code, the index and graph tables), which they would otherwise find cold at
@@ -247,24 +154,6 @@ static __device__ inline void stream_store(uint4_t * p, uint4_t const & v)
   __builtin_nontemporal_store(x, reinterpret_cast<v4 *>(p));
 }
 #endif
-
-// The leader takes `n` units from a device counter; every lane gets the old value (readfirstlane is the convergence
-// point: no lane continues before the leader's atomic has returned).
-static __device__ inline uint32_t wave_claim(uint32_t * counter, uint32_t n)
-{
-  uint32_t v = 0;
-  if ((threadIdx.x & 63u) == 0)
-    v = atomicAdd(counter, n);
-  return __builtin_amdgcn_readfirstlane(v);
-}
-
-static __device__ inline unsigned long long wave_claim64(unsigned long long * counter, unsigned long long n)
-{
-  unsigned long long v = 0;
-  if ((threadIdx.x & 63u) == 0)
-    v = atomicAdd(counter, n);
-  return WaveHip::uni(static_cast<uint64_t>(v));
-}
 
 #ifndef GTX_TASK_CHUNK
 #define GTX_TASK_CHUNK 64
@@ -865,98 +754,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_GENERAL_
 #endif
 }
 
-// Second pass over the queued (read, orientation) tasks: same algorithm instantiated over tables large enough for what
-// the reference's own limits admit; one workspace in HBM per workgroup.  The queue is usually empty or tiny.
-// A graph with a site of more than 64 alleles has a further pass of the same shape behind it (NS = wide: allele sets of
-// GTX_WIDE_MASK_WORDS words, a larger table of walk candidates: one round of a walk branches into every allele of a site):
-// a task that met an allele number >= 64 or overflowed a table is handed on to it (next_tasks / next_state).
-// (registers for four wavefronts per SIMD -- 128 instead of the 193 the compiler takes when left alone: the pass has no task on
-//  most batches, but every one of its workgroups has to be PLACED before it can see that, and beside another batch's kernels
-//  a wavefront of 196 registers waited 0.14 ms for room; what it spills only matters on the rare batch that needs the pass)
-#ifndef GTX_HBM_PASS_WAVES
-#define GTX_HBM_PASS_WAVES 4
-#endif
-#define GTX_HBM_PASS_ATTR __attribute__((amdgpu_waves_per_eu(GTX_HBM_PASS_WAVES, GTX_HBM_PASS_WAVES)))
-#define GTX_HBM_PASS_KERNEL(NAME, NS)                                                                                              \
-  __global__ __launch_bounds__(64) GTX_HBM_PASS_ATTR void NAME(GraphView g, IndexView ix, uint8_t const * __restrict__ seq, uint32_t seq_stride, \
-                                             gtx_read_meta const * __restrict__ meta, uint32_t * __restrict__ records,             \
-                                             uint32_t rec_words, uint32_t const * __restrict__ big_tasks, uint32_t big_task_cap,   \
-                                             uint32_t * big_state, NS::AlignWorkspace * workspaces, uint32_t * __restrict__ arena, \
-                                             unsigned long long arena_words, unsigned long long * arena_cursor,                    \
-                                             uint32_t * __restrict__ next_tasks, uint32_t next_cap, uint32_t * next_state)         \
-  {                                                                                                                                \
-    NS::AlignWorkspace & ws = workspaces[blockIdx.x];                                                                              \
-    GTX_HBM_PASS_PROF_INIT                                                                                                         \
-    uint32_t const queued = big_state[0] < big_task_cap ? big_state[0] : big_task_cap;                                             \
-    for (;;)                                                                                                                       \
-    {                                                                                                                              \
-      uint32_t const t = wave_claim(big_state + 1, 1u);                                                                            \
-      if (t >= queued)                                                                                                             \
-        break;                                                                                                                     \
-      uint32_t const task = WaveHip::uni(big_tasks[t]), read = task >> 1, orient = task & 1u;                                      \
-      uint32_t const len = WaveHip::uni(static_cast<uint32_t>(meta[read].l_qseq));                                                 \
-      uint32_t * rec = records + static_cast<uint64_t>(task) * rec_words;                                                          \
-      uint32_t np = 0, longest = 0, ext = 0;                                                                                       \
-      uint32_t status =                                                                                                            \
-        NS::align_paths<WaveHipMem>(g, ix, ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest);     \
-      status = WaveHip::uni(status);                                                                                               \
-      np = WaveHip::uni(np);                                                                                                       \
-      longest = WaveHip::uni(longest);                                                                                             \
-      if (status && next_tasks && (threadIdx.x & 63u) == 0) /* an allele >= 64, or a table the next pass has larger */            \
-      {                                                                                                                            \
-        uint32_t const slot = atomicAdd(next_state, 1u);                                                                           \
-        if (slot < next_cap)                                                                                                       \
-          next_tasks[slot] = task;                                                                                                 \
-        else                                                                                                                       \
-          atomicAdd(next_state + 3, 1u);                                                                                           \
-      }                                                                                                                            \
-      status &= ~GTX_ST_WIDE_ALLELE;                                                                                               \
-      uint32_t * body = rec + 2;                                                                                                   \
-      unsigned long long off = 0;                                                                                                  \
-      if (status)                                                                                                                  \
-        np = 0;                                                                                                                    \
-      else                                                                                                                         \
-      {                                                                                                                            \
-        uint32_t const size = WaveHip::uni(NS::record_size<WaveHipMem>(NS::Here{}, ws, np));                                       \
-        if (size > rec_words)                                                                                                      \
-        {                                                                                                                          \
-          /* long record: room in the arena; the slot keeps the header and the offset */                                           \
-          off = wave_claim64(arena_cursor, size - 2);                                                                              \
-          if (off + (size - 2) > arena_words || off + (size - 2) > 0xFFFFFFFFull)                                                  \
-          {                                                                                                                        \
-            status = GTX_ST_RECORD_OVERFLOW;                                                                                       \
-            np = 0;                                                                                                                \
-          }                                                                                                                        \
-          else                                                                                                                     \
-          {                                                                                                                        \
-            body = arena + off;                                                                                                    \
-            ext = GTX_ST_EXTERNAL;                                                                                                 \
-          }                                                                                                                        \
-        }                                                                                                                          \
-      }                                                                                                                            \
-      uint32_t const has_var = NS::write_record_body<WaveHipMem>(NS::Here{}, ws, np, body);                                        \
-      if ((threadIdx.x & 63u) == 0)                                                                                                \
-      {                                                                                                                            \
-        rec[0] = np | ((status | ext) << 16);                                                                                      \
-        rec[1] = (np == 0 ? 0 : longest) | (len << 16) | (np == 0 ? 0u : has_var);                                                 \
-        if (ext)                                                                                                                   \
-          rec[2] = static_cast<uint32_t>(off);                                                                                     \
-      }                                                                                                                            \
-      WaveHipMem::mem_sync();                                                                                                      \
-    }                                                                                                                              \
-  }
-
-#ifdef GTX_PROF
-#define GTX_HBM_PASS_PROF_INIT                                                                                                     \
-  if (threadIdx.x < 16)                                                                                                            \
-    ws.prof_acc[threadIdx.x] = 0; /* (second-pass cycles are not added to the report) */                                           \
-  WaveHipMem::mem_sync();
-#else
-#define GTX_HBM_PASS_PROF_INIT
-#endif
-GTX_HBM_PASS_KERNEL(gtx_align_big_kernel, big)
-GTX_HBM_PASS_KERNEL(gtx_align_wide_kernel, wide)
-
 // BAM nibble rows -> plane rows (graph_dev.hpp), one thread per (read, group of 32 bases): the one-off repack of callers that
 // hold bam_get_seq bytes on the device (gtx_reads_to_planes), and what gtx_align_batch does with its nibble rows before the
 // alignment kernels -- which read planes only -- run.
@@ -1259,7 +1056,7 @@ static void scratch_free(CallScratch & s)
 {
   // (d_big_state lies behind d_counters in one allocation: one reset for both)
   void * ptrs[] = {s.d_counters, s.d_queue1, s.d_queue, s.d_big_tasks, s.d_big_ws, s.d_score_state, s.d_score_queue,
-                   s.d_score_tables, s.d_score_work, s.d_wide_tasks, s.d_wide_ws, s.d_planes};
+                   s.d_score_tables, s.d_score_work, s.d_wide_tasks, s.d_wide_ws, s.d_planes, s.d_exact_tasks, s.d_exact_slab};
   for (void * p : ptrs)
     if (p)
       (void)gtx::dev_free(p);
@@ -1285,7 +1082,7 @@ static std::unique_ptr<CallScratch> scratch_new(gtx_ctx & c)
   bool ok = hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "scratch event");
   if (ok)
     s->done = ev;
-  ok = ok && dev_alloc(s->d_counters, 8 * CallScratch::MAX_PARTS + 16, "task counters + second-pass state", true);
+  ok = ok && dev_alloc(s->d_counters, 8 * CallScratch::MAX_PARTS + 48, "task counters + second-pass state", true); // (+ big, wide, exact x 3: 8 words each)
   if (ok && !c.params.no_second_pass)
   {
     s->d_big_state = s->d_counters + 8 * CallScratch::MAX_PARTS;
@@ -1300,6 +1097,12 @@ static std::unique_ptr<CallScratch> scratch_new(gtx_ctx & c)
       ok = ok && hip_ok(gtx::dev_malloc(&wws, static_cast<size_t>(CallScratch::WIDE_BLOCKS) * sizeof(wide::AlignWorkspace)), "wide-site pass workspaces");
       s->d_wide_ws = wws;
     }
+    // the exact pass: two queues (what did not fit the tables above; what did not fit a part of the slab) and the slab
+    s->d_exact_state = s->d_big_state + 16;
+    ok = ok && dev_alloc(s->d_exact_tasks, 2 * static_cast<size_t>(CallScratch::EXACT_TASK_CAP), "exact pass queues");
+    void * slab = nullptr;
+    ok = ok && hip_ok(gtx::dev_malloc(&slab, c.exact_slab_bytes), "exact pass slab");
+    s->d_exact_slab = static_cast<uint8_t *>(slab);
     ok = ok && dev_alloc(s->d_score_state, 4, "second-pass score state", true); // ([2]: the work queue's count, reset with the rest)
     ok = ok && dev_alloc(s->d_score_queue, gtx_ctx::SCORE_QUEUE_CAP, "second-pass score queue");
     if (c.has_wide_sites)
@@ -1525,6 +1328,16 @@ int ctx_upload(gtx_ctx & c, int device)
     // HBM-table pass: one workspace per workgroup (one workgroup per CU is plenty for the few queued reads), arena
     c.big_blocks = have_prop ? static_cast<uint32_t>(prop.multiProcessorCount) : 256u;
     c.big_record_words = c.params.big_record_words ? c.params.big_record_words : (16ull << 20);
+    // exact pass: the slab of a call in flight, and the walk candidates one task of this graph can have alive
+    {
+      uint32_t widest = 0;
+      for (uint32_t n : c.graph.ref_nvar)
+        widest = std::max(widest, n);
+      c.exact_cand_cap = exact::exact_cand_cap(widest);
+      char const * xm = std::getenv("GTX_EXACT_PASS_MB");
+      uint64_t mb = c.params.exact_pass_mb ? c.params.exact_pass_mb : (xm && std::atol(xm) > 0) ? static_cast<uint64_t>(std::atol(xm)) : (c.has_wide_sites ? 1024u : 256u);
+      c.exact_slab_bytes = mb << 20;
+    }
     void * p = nullptr;
     ok = ok && hip_ok(gtx::dev_malloc(&p, c.big_record_words * sizeof(uint32_t)), "big-record arena");
     if (ok)
@@ -1739,7 +1552,7 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
                         hipEvent_t done_event, hipStream_t * last_stream)
 {
   // (the pass counters and, behind them, the state of the HBM-table and wide-site passes: one reset)
-  if (!hip_ok(hipMemsetAsync(s->d_counters, 0, (8 * CallScratch::MAX_PARTS + (s->d_big_state ? 12 : 0)) * sizeof(uint32_t), st), "task counter reset"))
+  if (!hip_ok(hipMemsetAsync(s->d_counters, 0, (8 * CallScratch::MAX_PARTS + (s->d_big_state ? 48 : 0)) * sizeof(uint32_t), st), "task counter reset"))
     return GTX_ERR_HIP;
   // queues: room for every task (a graph on which no read is simple sends them all)
   if (!grow(s->d_queue, s->queue_cap, 2ull * n_reads, "pass-2 queue") || !grow(s->d_queue1, s->queue1_cap, n_reads, "pass-1 queue"))
@@ -1962,21 +1775,36 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
   }
   if (second_pass)
   {
-    hipLaunchKernelGGL(gtx_align_big_kernel, dim3(c->big_blocks), dim3(64), 0, sg, c->dev_graph, c->dev_index, d_seq, seq_stride, d_meta,
-                       d_records, rec_words, s->d_big_tasks, s->big_task_cap, s->d_big_state, static_cast<big::AlignWorkspace *>(s->d_big_ws),
-                       c->d_big_records, static_cast<unsigned long long>(c->big_record_words), c->d_arena_cursor, s->d_wide_tasks,
-                       CallScratch::WIDE_TASK_CAP, s->d_wide_state);
-    if (!hip_ok(hipGetLastError(), "gtx_align_big_kernel launch"))
-      return GTX_ERR_HIP;
-    if (s->d_wide_tasks) // graphs with a site of more than 64 alleles: the tasks that met an allele number >= 64
+    HbmPassArgs a;
+    a.g = c->dev_graph;
+    a.ix = c->dev_index;
+    a.seq = d_seq;
+    a.seq_stride = seq_stride;
+    a.meta = d_meta;
+    a.records = d_records;
+    a.rec_words = rec_words;
+    a.big_tasks = s->d_big_tasks;
+    a.big_task_cap = s->big_task_cap;
+    a.big_state = s->d_big_state;
+    a.big_blocks = c->big_blocks;
+    a.big_ws = s->d_big_ws;
+    a.wide_tasks = s->d_wide_tasks;
+    a.wide_state = s->d_wide_state;
+    a.wide_ws = s->d_wide_ws;
+    a.exact_tasks = s->d_exact_tasks;
+    a.exact_state = s->d_exact_state;
+    a.exact_slab = s->d_exact_slab;
+    a.exact_slab_bytes = c->exact_slab_bytes;
+    a.exact_cand_cap = c->exact_cand_cap;
+    a.wide_sites = c->has_wide_sites;
+    a.arena = c->d_big_records;
+    a.arena_words = c->big_record_words;
+    a.arena_cursor = c->d_arena_cursor;
+    char const * what = launch_hbm_passes(a, sg);
+    if (what)
     {
-      hipLaunchKernelGGL(gtx_align_wide_kernel, dim3(CallScratch::WIDE_BLOCKS), dim3(64), 0, sg, c->dev_graph, c->dev_index, d_seq, seq_stride,
-                         d_meta, d_records, rec_words, s->d_wide_tasks, CallScratch::WIDE_TASK_CAP, s->d_wide_state,
-                         static_cast<wide::AlignWorkspace *>(s->d_wide_ws), c->d_big_records,
-                         static_cast<unsigned long long>(c->big_record_words), c->d_arena_cursor, static_cast<uint32_t *>(nullptr), 0u,
-                         static_cast<uint32_t *>(nullptr));
-      if (!hip_ok(hipGetLastError(), "gtx_align_wide_kernel launch"))
-        return GTX_ERR_HIP;
+      (void)hip_ok(hipErrorLaunchFailure, what);
+      return GTX_ERR_HIP;
     }
   }
   if (d_task_flags)
@@ -2412,6 +2240,31 @@ extern "C" int gtx_ctx_big_records(gtx_ctx * c, const uint32_t ** d_words, uint6
       *tasks = std::min<uint32_t>(queued, s->big_task_cap);
     }
   }
+  return GTX_OK;
+}
+
+extern "C" int gtx_ctx_exact_pass_tasks(gtx_ctx * c, uint64_t * out)
+{
+  if (!c || !out)
+    return GTX_ERR_ARG;
+  out[0] = out[1] = out[2] = 0;
+  if (c->device < 0)
+    return GTX_ERR_NO_DEVICE;
+  CallScratch * s = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(c->pool_mutex);
+    s = c->last_align;
+  }
+  if (!s || !s->d_exact_state)
+    return GTX_OK;
+  if (!hip_ok(hipSetDevice(c->device), "hipSetDevice"))
+    return GTX_ERR_HIP;
+  uint32_t st[24]; // [0..7] first launch, [8..15] second, [16..23] what the second handed on (nothing takes it: the count is what is left)
+  if (!hip_ok(hipDeviceSynchronize(), "exact-pass state") || !hip_ok(hipMemcpy(st, s->d_exact_state, sizeof(st), hipMemcpyDeviceToHost), "exact-pass state"))
+    return GTX_ERR_HIP;
+  out[0] = st[0];
+  out[1] = st[8];
+  out[2] = st[16] + st[3] + st[11]; // (+ tasks a full queue dropped)
   return GTX_OK;
 }
 

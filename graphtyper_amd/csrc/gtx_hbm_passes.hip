@@ -1,0 +1,184 @@
+// gtx_hbm_passes.hip -- the alignment passes behind the general one: the same algorithm (align_core.inl) over tables that
+// live in HBM.  gtx_align_big_kernel (512 paths, 2 048 labels per k-mer), gtx_align_wide_kernel (allele sets of
+// GTX_WIDE_MASK_WORDS words) and the exact pass, gtx_align_exact(_wide)_kernel, whose tables have no fixed size.
+#include <hip/hip_runtime.h>
+
+#include "gtx_ctx.hpp"
+#include "wave_hip.hpp"
+#include "align_core.hpp"
+#include "gtx_hbm_passes.hpp"
+
+namespace gtx
+{
+// Second pass over the queued (read, orientation) tasks: same algorithm instantiated over tables large enough for what
+// the reference's own limits admit; one workspace in HBM per workgroup.  The queue is usually empty or tiny.
+// A graph with a site of more than 64 alleles has a further pass of the same shape behind it (NS = wide: allele sets of
+// GTX_WIDE_MASK_WORDS words, a larger table of walk candidates: one round of a walk branches into every allele of a site):
+// a task that met an allele number >= 64 or overflowed a table is handed on to it (next_tasks / next_state).
+// (registers for four wavefronts per SIMD -- 128 instead of the 193 the compiler takes when left alone: the pass has no task on
+//  most batches, but every one of its workgroups has to be PLACED before it can see that, and beside another batch's kernels
+//  a wavefront of 196 registers waited 0.14 ms for room; what it spills only matters on the rare batch that needs the pass)
+#ifndef GTX_HBM_PASS_WAVES
+#define GTX_HBM_PASS_WAVES 4
+#endif
+#define GTX_HBM_PASS_ATTR __attribute__((amdgpu_waves_per_eu(GTX_HBM_PASS_WAVES, GTX_HBM_PASS_WAVES)))
+#define GTX_HBM_PASS_KERNEL(NAME, NS)                                                                                              \
+  __global__ __launch_bounds__(64) GTX_HBM_PASS_ATTR void NAME(GraphView g, IndexView ix, uint8_t const * __restrict__ seq, uint32_t seq_stride, \
+                                             gtx_read_meta const * __restrict__ meta, uint32_t * __restrict__ records,             \
+                                             uint32_t rec_words, uint32_t const * __restrict__ big_tasks, uint32_t big_task_cap,   \
+                                             uint32_t * big_state, NS::AlignWorkspace * workspaces, uint32_t * __restrict__ arena, \
+                                             unsigned long long arena_words, unsigned long long * arena_cursor,                    \
+                                             uint32_t * __restrict__ next_tasks, uint32_t next_cap, uint32_t * next_state)         \
+  {                                                                                                                                \
+    NS::AlignWorkspace & ws = workspaces[blockIdx.x];                                                                              \
+    GTX_HBM_PASS_BODY(NS)                                                                                                          \
+  }
+
+#define GTX_HBM_PASS_BODY(NS)                                                                                                      \
+    GTX_HBM_PASS_PROF_INIT                                                                                                         \
+    uint32_t const queued = big_state[0] < big_task_cap ? big_state[0] : big_task_cap;                                             \
+    for (;;)                                                                                                                       \
+    {                                                                                                                              \
+      uint32_t const t = wave_claim(big_state + 1, 1u);                                                                            \
+      if (t >= queued)                                                                                                             \
+        break;                                                                                                                     \
+      uint32_t const task = WaveHip::uni(big_tasks[t]), read = task >> 1, orient = task & 1u;                                      \
+      uint32_t const len = WaveHip::uni(static_cast<uint32_t>(meta[read].l_qseq));                                                 \
+      uint32_t * rec = records + static_cast<uint64_t>(task) * rec_words;                                                          \
+      uint32_t np = 0, longest = 0, ext = 0;                                                                                       \
+      uint32_t status =                                                                                                            \
+        NS::align_paths<WaveHipMem>(g, ix, ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest);     \
+      status = WaveHip::uni(status);                                                                                               \
+      np = WaveHip::uni(np);                                                                                                       \
+      longest = WaveHip::uni(longest);                                                                                             \
+      if (status && next_tasks && (threadIdx.x & 63u) == 0) /* an allele >= 64, or a table the next pass has larger */            \
+      {                                                                                                                            \
+        uint32_t const slot = atomicAdd(next_state, 1u);                                                                           \
+        if (slot < next_cap)                                                                                                       \
+          next_tasks[slot] = task;                                                                                                 \
+        else                                                                                                                       \
+          atomicAdd(next_state + 3, 1u);                                                                                           \
+      }                                                                                                                            \
+      status &= ~GTX_ST_WIDE_ALLELE;                                                                                               \
+      uint32_t * body = rec + 2;                                                                                                   \
+      unsigned long long off = 0;                                                                                                  \
+      if (status)                                                                                                                  \
+        np = 0;                                                                                                                    \
+      else                                                                                                                         \
+      {                                                                                                                            \
+        uint32_t const size = WaveHip::uni(NS::record_size<WaveHipMem>(NS::Here{}, ws, np));                                       \
+        if (size > rec_words)                                                                                                      \
+        {                                                                                                                          \
+          /* long record: room in the arena; the slot keeps the header and the offset */                                           \
+          off = wave_claim64(arena_cursor, size - 2);                                                                              \
+          if (off + (size - 2) > arena_words || off + (size - 2) > 0xFFFFFFFFull)                                                  \
+          {                                                                                                                        \
+            status = GTX_ST_RECORD_OVERFLOW;                                                                                       \
+            np = 0;                                                                                                                \
+          }                                                                                                                        \
+          else                                                                                                                     \
+          {                                                                                                                        \
+            body = arena + off;                                                                                                    \
+            ext = GTX_ST_EXTERNAL;                                                                                                 \
+          }                                                                                                                        \
+        }                                                                                                                          \
+      }                                                                                                                            \
+      uint32_t const has_var = NS::write_record_body<WaveHipMem>(NS::Here{}, ws, np, body);                                        \
+      if ((threadIdx.x & 63u) == 0)                                                                                                \
+      {                                                                                                                            \
+        rec[0] = np | ((status | ext) << 16);                                                                                      \
+        rec[1] = (np == 0 ? 0 : longest) | (len << 16) | (np == 0 ? 0u : has_var);                                                 \
+        if (ext)                                                                                                                   \
+          rec[2] = static_cast<uint32_t>(off);                                                                                     \
+      }                                                                                                                            \
+      WaveHipMem::mem_sync();                                                                                                      \
+    }
+
+// The exact pass (align_core.hpp: namespace exact): the same body over a workspace whose tables are cut out of the
+// workgroup's part of a slab of HBM at run time.  Launched twice: EXACT_PARTS workgroups with a part each, then one workgroup
+// with the whole slab for what did not fit a part (its queue is the first launch's next_tasks).
+#define GTX_EXACT_PASS_KERNEL(NAME, NS)                                                                                            \
+  __global__ __launch_bounds__(64) GTX_HBM_PASS_ATTR void NAME(GraphView g, IndexView ix, uint8_t const * __restrict__ seq, uint32_t seq_stride, \
+                                             gtx_read_meta const * __restrict__ meta, uint32_t * __restrict__ records,             \
+                                             uint32_t rec_words, uint32_t const * __restrict__ big_tasks, uint32_t big_task_cap,   \
+                                             uint32_t * big_state, uint8_t * slab, unsigned long long part_bytes, uint32_t cand_cap, \
+                                             uint32_t * __restrict__ arena,                                                        \
+                                             unsigned long long arena_words, unsigned long long * arena_cursor,                    \
+                                             uint32_t * __restrict__ next_tasks, uint32_t next_cap, uint32_t * next_state)         \
+  {                                                                                                                                \
+    if (big_state[0] == 0) /* (nearly every batch: nothing reached this pass) */                                                   \
+      return;                                                                                                                      \
+    NS::AlignWorkspace & ws = *reinterpret_cast<NS::AlignWorkspace *>(slab + static_cast<unsigned long long>(blockIdx.x) * part_bytes); \
+    if (!NS::exact_setup<WaveHipMem>(&ws, part_bytes, cand_cap))                                                                   \
+    {                                                                                                                              \
+      /* a part that cannot hold one path: everything goes on to the launch that has the whole slab (or keeps its status) */      \
+      if (blockIdx.x == 0 && (threadIdx.x & 63u) == 0 && next_tasks)                                                               \
+      {                                                                                                                            \
+        uint32_t const q = big_state[0] < big_task_cap ? big_state[0] : big_task_cap;                                              \
+        for (uint32_t t = 0; t < q; ++t)                                                                                           \
+        {                                                                                                                          \
+          uint32_t const slot = atomicAdd(next_state, 1u);                                                                         \
+          if (slot < next_cap)                                                                                                     \
+            next_tasks[slot] = big_tasks[t];                                                                                       \
+          else                                                                                                                     \
+            atomicAdd(next_state + 3, 1u);                                                                                         \
+        }                                                                                                                          \
+      }                                                                                                                            \
+      return;                                                                                                                      \
+    }                                                                                                                              \
+    GTX_HBM_PASS_BODY(NS)                                                                                                          \
+  }
+
+#ifdef GTX_PROF
+#define GTX_HBM_PASS_PROF_INIT                                                                                                     \
+  if (threadIdx.x < 16)                                                                                                            \
+    ws.prof_acc[threadIdx.x] = 0; /* (second-pass cycles are not added to the report) */                                           \
+  WaveHipMem::mem_sync();
+#else
+#define GTX_HBM_PASS_PROF_INIT
+#endif
+GTX_HBM_PASS_KERNEL(gtx_align_big_kernel, big)
+GTX_HBM_PASS_KERNEL(gtx_align_wide_kernel, wide)
+GTX_EXACT_PASS_KERNEL(gtx_align_exact_kernel, exact)
+GTX_EXACT_PASS_KERNEL(gtx_align_exact_wide_kernel, exactw)
+
+
+uint64_t big_workspace_bytes() { return sizeof(big::AlignWorkspace); }
+uint64_t wide_workspace_bytes() { return sizeof(wide::AlignWorkspace); }
+
+char const * launch_hbm_passes(HbmPassArgs const & a, hipStream_t stream)
+{
+  unsigned long long const arena_words = a.arena_words;
+  bool const wide_pass = a.wide_tasks != nullptr;
+  hipLaunchKernelGGL(gtx_align_big_kernel, dim3(a.big_blocks), dim3(64), 0, stream, a.g, a.ix, a.seq, a.seq_stride, a.meta, a.records, a.rec_words,
+                     a.big_tasks, a.big_task_cap, a.big_state, static_cast<big::AlignWorkspace *>(a.big_ws), a.arena, arena_words, a.arena_cursor,
+                     wide_pass ? a.wide_tasks : a.exact_tasks, wide_pass ? CallScratch::WIDE_TASK_CAP : CallScratch::EXACT_TASK_CAP,
+                     wide_pass ? a.wide_state : a.exact_state);
+  if (hipGetLastError() != hipSuccess)
+    return "gtx_align_big_kernel launch";
+  if (wide_pass) // graphs with a site of more than 64 alleles: the tasks that met an allele number >= 64
+  {
+    hipLaunchKernelGGL(gtx_align_wide_kernel, dim3(CallScratch::WIDE_BLOCKS), dim3(64), 0, stream, a.g, a.ix, a.seq, a.seq_stride, a.meta, a.records,
+                       a.rec_words, a.wide_tasks, CallScratch::WIDE_TASK_CAP, a.wide_state, static_cast<wide::AlignWorkspace *>(a.wide_ws), a.arena,
+                       arena_words, a.arena_cursor, a.exact_tasks, CallScratch::EXACT_TASK_CAP, a.exact_state);
+    if (hipGetLastError() != hipSuccess)
+      return "gtx_align_wide_kernel launch";
+  }
+  // the exact pass: what exceeded the tables above, first with a part of the slab per workgroup, then -- one workgroup --
+  // with all of it.  Nearly always both find an empty queue and leave at once.
+  uint32_t * const q1 = a.exact_tasks, * const q2 = a.exact_tasks + CallScratch::EXACT_TASK_CAP;
+  uint32_t * const st1 = a.exact_state, * const st2 = a.exact_state + 8, * const st3 = a.exact_state + 16;
+  unsigned long long const part = (a.exact_slab_bytes / CallScratch::EXACT_PARTS) & ~255ull;
+  auto kernel = a.wide_sites ? gtx_align_exact_wide_kernel : gtx_align_exact_kernel;
+  hipLaunchKernelGGL(kernel, dim3(CallScratch::EXACT_PARTS), dim3(64), 0, stream, a.g, a.ix, a.seq, a.seq_stride, a.meta, a.records, a.rec_words, q1,
+                     CallScratch::EXACT_TASK_CAP, st1, a.exact_slab, part, a.exact_cand_cap, a.arena, arena_words, a.arena_cursor, q2,
+                     CallScratch::EXACT_TASK_CAP, st2);
+  // (what even the whole slab cannot hold is counted in st3: a queue of capacity 0)
+  hipLaunchKernelGGL(kernel, dim3(1), dim3(64), 0, stream, a.g, a.ix, a.seq, a.seq_stride, a.meta, a.records, a.rec_words, q2, CallScratch::EXACT_TASK_CAP,
+                     st2, a.exact_slab, static_cast<unsigned long long>(a.exact_slab_bytes), a.exact_cand_cap, a.arena, arena_words, a.arena_cursor, q2, 0u,
+                     st3);
+  if (hipGetLastError() != hipSuccess)
+    return "gtx_align_exact_kernel launch";
+  return nullptr;
+}
+} // namespace gtx

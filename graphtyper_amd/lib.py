@@ -21,7 +21,7 @@ ST_ERROR_MASK = 15
 # names every build of libgtx.so must export (checked by tests/test_abi.py against include/gtx.h)
 EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy", "gtx_ctx_special_positions",
            "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_ctx_near_pairs", "gtx_index_stats", "gtx_index_get", "gtx_index_dump", "gtx_ctx_hint_table",
-           "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_pass_times", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
+           "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_exact_pass_tasks", "gtx_ctx_pass_times", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_set_coverage", "gtx_stream_finish", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
            "gtx_graph_destroy",
            "gtx_scores_alloc", "gtx_scores_zero", "gtx_scores_free", "gtx_scores_reduce", "gtx_comm_unique_id", "gtx_comm_init_rank",
@@ -42,7 +42,8 @@ class GraphView(C.Structure):
 class Params(C.Structure):
     _fields_ = [("max_index_labels", C.c_int32), ("is_sv_graph", C.c_int32), ("hq_reads", C.c_int32),
                 ("force_align_both_orientations", C.c_int32), ("is_segment_calling", C.c_int32),
-                ("sam_flag_filter", C.c_int32), ("no_second_pass", C.c_int32), ("big_record_words", C.c_uint32)]
+                ("sam_flag_filter", C.c_int32), ("no_second_pass", C.c_int32), ("big_record_words", C.c_uint32),
+                ("exact_pass_mb", C.c_uint32)]
 
 
 class ScoreLayout(C.Structure):
@@ -87,9 +88,9 @@ assert READ_META.itemsize == 20 and REC_META.itemsize == 16 and SCORE_ITEM.items
 def build(force=False):
     """compile libgtx.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)"""
     src_dir = os.path.join(HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir)] + [os.path.join(ROOT, "include", "gtx.h")]
+    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if not f.startswith("build")] + [os.path.join(ROOT, "include", "gtx.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
-        subprocess.check_call(["make", "-C", src_dir, "-s"])
+        subprocess.check_call(["make", "-C", src_dir, "-s", "-j", str(min(8, os.cpu_count() or 1))])
     return LIB_PATH
 
 
@@ -123,6 +124,7 @@ def lib():
         L.gtx_ctx_big_records.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                           C.POINTER(C.c_uint64)]
         L.gtx_ctx_big_records_rewind.argtypes = [C.c_void_p, C.c_void_p]
+        L.gtx_ctx_exact_pass_tasks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.gtx_ctx_pass_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.gtx_ctx_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.gtx_ctx_error_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
@@ -460,7 +462,7 @@ class Context:
     """gtx_ctx: flat graph + index (host) and, for device >= 0, their copies in HBM"""
 
     def __init__(self, graph, device=0, max_index_labels=75, is_sv_graph=False, hq_reads=False, force_both=False,
-                 is_segment_calling=False, sam_flag_filter=3840, no_second_pass=False, big_record_words=0):
+                 is_segment_calling=False, sam_flag_filter=3840, no_second_pass=False, big_record_words=0, exact_pass_mb=0):
         L = lib()
         self.g = {k: np.ascontiguousarray(v) for k, v in graph.items()}
         g = self.g
@@ -470,7 +472,7 @@ class Context:
                               _p(g["var_len"]), _p(g["var_dna_off"]), _p(g["var_out_ref"]), _p(g["dna"]), len(g["dna"]),
                               _p(g["event_off"]) if has_ev else None, _p(g["event_val"]) if has_ev else None)
         self.params = Params(max_index_labels, int(is_sv_graph), int(hq_reads), int(force_both), int(is_segment_calling),
-                             sam_flag_filter, int(no_second_pass), int(big_record_words))
+                             sam_flag_filter, int(no_second_pass), int(big_record_words), int(exact_pass_mb))
         h = C.c_void_p()
         check(L.gtx_ctx_create(C.byref(self.view), C.byref(self.params), device, C.byref(h)))
         self.h = h
@@ -546,6 +548,13 @@ class Context:
         ptr, cap, used, tasks = C.c_void_p(), C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(lib().gtx_ctx_big_records(self.h, C.byref(ptr), C.byref(cap), C.byref(used), C.byref(tasks)))
         return download(ptr.value or 0, np.uint32, int(used.value)), int(tasks.value)
+
+    def exact_pass_tasks(self):
+        """(tasks of the last align batch that went through the exact pass with a part of its slab, again with the whole slab,
+        tasks that keep a table-overflow status even so)"""
+        out = (C.c_uint64 * 3)()
+        check(lib().gtx_ctx_exact_pass_tasks(self.h, out))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def pass_times(self):
         """(ms of the express / general / HBM-table pass of the last align batch, tasks handed to the general pass);

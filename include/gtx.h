@@ -149,6 +149,9 @@ typedef struct gtx_params
   int32_t sam_flag_filter;               /* 3840 */
   int32_t no_second_pass;                /* 1: reads that overflow the main pass' tables keep their status bit (A/B tests) */
   uint32_t big_record_words;             /* capacity of the big-record arena in uint32 words, 0 = 16 Mi */
+  uint32_t exact_pass_mb;                /* MiB of HBM per call in flight for the exact alignment pass (gtx_align_batch: the
+                                          * pass whose tables have no fixed size), 0 = the GTX_EXACT_PASS_MB environment
+                                          * variable, else 256 (1024 for a graph with a site of more than 64 alleles) */
 } gtx_params;
 
 /* One KmerLabel (include/graphtyper/index/kmer_label.hpp:13-41) */
@@ -270,10 +273,14 @@ int gtx_ctx_hint_table(const gtx_ctx *, int which, void * out, uint64_t cap_byte
  *    stay resident while a region is processed (a parked mate is scored batches later): it only grows until
  *    gtx_ctx_big_records_rewind; when it is full such a read ends with GTX_ST_RECORD_OVERFLOW.
  * stream     : hipStream_t or NULL
- * Two passes: the main kernel keeps a read's tables in LDS; the few reads that exceed them (repeats: hundreds of seed
- * locations) are queued on the device and redone by a second kernel over HBM-resident tables that hold what the
- * reference's own limits allow, so they get the same result as any other read.  Only a read beyond those tables too
- * keeps an overflow status (and no paths).
+ * Passes: the main kernel keeps a read's tables in LDS; the few reads that exceed them (repeats: hundreds of seed
+ * locations) are queued on the device and redone by a second kernel over larger tables in HBM (512 paths, 2048 labels
+ * per k-mer), and what exceeds those as well -- the reference has NO limit on the paths and labels of a read
+ * (src/typer/genotype_paths.cpp:294-352: a read inside a 280-bp homopolymer chains 249 x 249 labels) -- by the exact pass,
+ * whose tables are cut at run time out of a slab of HBM (gtx_params::exact_pass_mb per call in flight; first a part of the
+ * slab per task, then all of it).  Every read therefore gets the result the reference computes; an overflow status (and no
+ * paths) is left only on a read that needs more than the configured slab, or whose record finds the big-record arena full
+ * (GTX_ST_RECORD_OVERFLOW; a record counts its paths in 16 bits).  gtx_ctx_exact_pass_tasks tells how many tasks went that far.
  * In front of them runs the position-hinted pass (gtx_read_meta::pos): one read per lane, finished there when the flags of
  * the hinted place prove what the global lookups would return; everything else goes on to the passes above unchanged.
  * Re-entrant: calls on one context may overlap in time from several host threads and streams, like align_read is called
@@ -383,6 +390,10 @@ int gtx_ctx_error_count(gtx_ctx *, uint32_t * out);
  * last rewind, tasks (may be NULL) = (read, orientation) tasks the last gtx_align_batch sent through the second pass
  * (both synchronise with the device) */
 int gtx_ctx_big_records(gtx_ctx *, const uint32_t ** d_words, uint64_t * capacity_words, uint64_t * used_words, uint64_t * tasks);
+
+/* (read, orientation) tasks the last gtx_align_batch sent through the exact pass: out[0] with a part of the slab, out[1]
+ * again with the whole slab, out[2] = tasks that keep a table-overflow status even so (synchronises with the device) */
+int gtx_ctx_exact_pass_tasks(gtx_ctx *, uint64_t * out /* [3] */);
 
 /* Durations (ms, HIP events on the launch stream) of the passes of gtx_align_batch -- everything in front of the general
  * pass (position-hinted + express), general, HBM tables -- and the number of tasks handed to the general pass.  The

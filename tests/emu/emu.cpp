@@ -100,6 +100,8 @@ struct Emu
   uint64_t arena_used = 0;
   uint64_t second_pass_tasks = 0; // tasks that reached the last pass (HBM tables)
   uint64_t wide_pass_tasks = 0;   // tasks that went on to the pass with wide allele sets
+  uint64_t exact_pass_tasks[3] = {0, 0, 0}; // tasks that reached the exact pass (a part of the slab / the whole slab / still refused)
+  std::vector<uint8_t> exact_slab;
   uint64_t general_tasks = 0;     // tasks pass 1 handed to pass 2
   uint64_t hinted_done = 0;       // forward tasks the position-hinted pass finished
   // diagnostics of the last emu_align (tools/decline_notes.py): per read the pass that finished its forward task (0 hinted,
@@ -234,6 +236,16 @@ extern "C"
       has_wide_sites = has_wide_sites || n > 64;
     auto wide_ws = has_wide_sites ? std::make_unique<wide::AlignWorkspace>() : nullptr;
     e.wide_pass_tasks = 0;
+    uint32_t widest_site = 0;
+    for (uint32_t n : e.graph.ref_nvar)
+      widest_site = std::max(widest_site, n);
+    // the exact pass' slab (gtx_api.hip: exact_slab_mb; here one slab, used by one task at a time)
+    constexpr uint32_t EXACT_PARTS = 8;
+    char const * xm = std::getenv("GTX_EXACT_PASS_MB");
+    std::vector<uint8_t> & exact_slab = e.exact_slab;
+    if (exact_slab.empty())
+      exact_slab.resize(static_cast<size_t>(e.params.exact_pass_mb ? e.params.exact_pass_mb : xm && std::atol(xm) > 0 ? std::atol(xm) : (has_wide_sites ? 1024 : 256)) << 20);
+    e.exact_pass_tasks[0] = e.exact_pass_tasks[1] = e.exact_pass_tasks[2] = 0;
     // one task through an HBM-table pass (the body of GTX_HBM_PASS_KERNEL in gtx_api.hip); returns the pass' status
     auto hbm_pass = [&](auto &, auto && align, auto && size_of, auto && write_body, uint32_t * rec, uint32_t len) -> uint32_t
     {
@@ -292,15 +304,49 @@ extern "C"
         { return big::align_paths<WaveEmu>(g, ix, *big_ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest); },
         [&](uint32_t np) { return big::record_size<WaveEmu>(big::Here{}, *big_ws, np); },
         [&](uint32_t np, uint32_t * body) { return big::write_record_body<WaveEmu>(big::Here{}, *big_ws, np, body); }, rec, len);
-      if (!bst || !has_wide_sites)
-        return;
-      ++e.wide_pass_tasks;
-      std::memset(static_cast<void *>(wide_ws.get()), fill, sizeof(wide::AlignWorkspace));
-      hbm_pass(
-        *wide_ws, [&](uint32_t & np, uint32_t & longest)
-        { return wide::align_paths<WaveEmu>(g, ix, *wide_ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest); },
-        [&](uint32_t np) { return wide::record_size<WaveEmu>(wide::Here{}, *wide_ws, np); },
-        [&](uint32_t np, uint32_t * body) { return wide::write_record_body<WaveEmu>(wide::Here{}, *wide_ws, np, body); }, rec, len);
+      uint32_t last = bst;
+      if (bst && has_wide_sites)
+      {
+        ++e.wide_pass_tasks;
+        std::memset(static_cast<void *>(wide_ws.get()), fill, sizeof(wide::AlignWorkspace));
+        last = hbm_pass(
+          *wide_ws, [&](uint32_t & np, uint32_t & longest)
+          { return wide::align_paths<WaveEmu>(g, ix, *wide_ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest); },
+          [&](uint32_t np) { return wide::record_size<WaveEmu>(wide::Here{}, *wide_ws, np); },
+          [&](uint32_t np, uint32_t * body) { return wide::write_record_body<WaveEmu>(wide::Here{}, *wide_ws, np, body); }, rec, len);
+      }
+      // the exact pass (gtx_align_exact_kernel): first with a part of the slab, then with all of it
+      constexpr uint32_t TABLES = GTX_ST_LABEL_OVERFLOW | GTX_ST_PATH_OVERFLOW | GTX_ST_DFS_OVERFLOW;
+      for (uint32_t level = 0; level < 2 && (last & TABLES); ++level)
+      {
+        ++e.exact_pass_tasks[level];
+        uint64_t const bytes = level == 0 ? exact_slab.size() / EXACT_PARTS : exact_slab.size();
+        std::memset(exact_slab.data(), fill, 65536);
+        if (has_wide_sites)
+        {
+          auto * xws = reinterpret_cast<exactw::AlignWorkspace *>(exact_slab.data());
+          if (!exactw::exact_setup<WaveEmu>(xws, bytes, exactw::exact_cand_cap(widest_site)))
+            continue;
+          last = hbm_pass(
+            *xws, [&](uint32_t & np, uint32_t & longest)
+            { return exactw::align_paths<WaveEmu>(g, ix, *xws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest); },
+            [&](uint32_t np) { return exactw::record_size<WaveEmu>(exactw::Here{}, *xws, np); },
+            [&](uint32_t np, uint32_t * body) { return exactw::write_record_body<WaveEmu>(exactw::Here{}, *xws, np, body); }, rec, len);
+        }
+        else
+        {
+          auto * xws = reinterpret_cast<exact::AlignWorkspace *>(exact_slab.data());
+          if (!exact::exact_setup<WaveEmu>(xws, bytes, exact::exact_cand_cap(widest_site)))
+            continue;
+          last = hbm_pass(
+            *xws, [&](uint32_t & np, uint32_t & longest)
+            { return exact::align_paths<WaveEmu>(g, ix, *xws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest); },
+            [&](uint32_t np) { return exact::record_size<WaveEmu>(exact::Here{}, *xws, np); },
+            [&](uint32_t np, uint32_t * body) { return exact::write_record_body<WaveEmu>(exact::Here{}, *xws, np, body); }, rec, len);
+        }
+      }
+      if (last & TABLES)
+        ++e.exact_pass_tasks[2];
     };
     auto empty_record = [&](uint32_t t, uint32_t len)
     {
@@ -468,6 +514,7 @@ extern "C"
   }
 
   uint64_t emu_hinted_done(void * p) { return static_cast<Emu *>(p)->hinted_done; }
+  uint64_t emu_exact_pass_tasks(void * p, int level) { return static_cast<Emu *>(p)->exact_pass_tasks[level % 3]; }
 
   // per read of the last emu_align with the position-hinted pass: finishing pass of the forward task, pass 0's decline note
   void emu_pass_of(void * p, uint8_t * pass_of, uint8_t * hint_decline, uint32_t n)

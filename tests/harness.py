@@ -89,6 +89,11 @@ class EmuBackend:
         self.L.emu_hinted_done.restype = C.c_uint64
         return int(self.L.emu_hinted_done(C.c_void_p(self.h)))
 
+    def exact_pass_tasks(self):
+        """tasks of the last align call that went through the exact pass (a part of the slab, the whole slab, still refused)"""
+        self.L.emu_exact_pass_tasks.restype = C.c_uint64
+        return tuple(int(self.L.emu_exact_pass_tasks(C.c_void_p(self.h), k)) for k in range(3))
+
     def big_records(self):
         ptr, cap = C.POINTER(C.c_uint32)(), C.c_uint64()
         self.L.emu_big_records(C.c_void_p(self.h), C.byref(ptr), C.byref(cap))
@@ -151,6 +156,9 @@ class GpuBackend:
 
     def big_records(self):
         return self.ctx.big_records()
+
+    def exact_pass_tasks(self):
+        return self.ctx.exact_pass_tasks()
 
     def hinted_done(self):
         """forward tasks the position-hinted pass finished in the last align call (needs armed timing)"""

@@ -102,6 +102,47 @@ def synthetic_case(kind, n_ref=40000, n_reads=300, seed=0, region_begin=1000000,
             at = int(rng.integers(0, n_ref - 80))
             ref[at:at + int(rng.integers(20, 60))] = int(rng.integers(0, 4))
         recs = synth.make_snp_records(ref, 100, seed=seed + 13, region_begin=region_begin)
+    elif kind == "satellite":
+        # low-complexity repeats, where one exact k-mer has hundreds of places and the chains of a read multiply: a 280-bp
+        # homopolymer, two copies (270 and 286 bp, 1 % diverged) of one dinucleotide repeat, a 2 kb array of a 171-bp unit
+        # (0.5 % diverged copies), a trinucleotide repeat; SNPs every 50 bp, also inside the repeats.  The reference keeps
+        # every chain (genotype_paths.cpp:294-352 has no limit): reads from these places are what the exact pass is for.
+        rng = np.random.default_rng(seed + 15)
+        assert n_ref >= 16000
+        spots = {}
+        at = 2000
+        ref[at:at + 280] = 1
+        spots["homopolymer"] = (at, 280)
+        di = np.tile(np.array([0, 2], np.uint8), 143)
+        for k, (where, size) in enumerate(((5000, 270), (8000, 286))):
+            c = di[:size].copy()
+            e = rng.random(size) < 0.01
+            c[e] = (c[e] + rng.integers(1, 4, size=int(e.sum()))) % 4
+            ref[where:where + size] = c
+            spots["dinucleotide%d" % k] = (where, size)
+        unit = rng.integers(0, 4, size=171).astype(np.uint8)
+        at = 10000
+        for c in range(12):
+            u = unit.copy()
+            e = (rng.random(171) < 0.005) & (c % 2 == 1)
+            u[e] = (u[e] + rng.integers(1, 4, size=int(e.sum()))) % 4
+            ref[at + c * 171:at + (c + 1) * 171] = u
+        spots["array171"] = (at, 12 * 171)
+        ref[14000:14000 + 240] = np.tile(np.array([1, 0, 3], np.uint8), 80)
+        spots["trinucleotide"] = (14000, 240)
+        recs = synth.make_snp_records(ref, 50, seed=seed + 16, region_begin=region_begin)
+        codes, pos = [], []
+        per = max(1, n_reads // len(spots))
+        for k, (name, (where, size)) in enumerate(sorted(spots.items())):
+            lo, hi = where - 300, where + size + 300
+            sub = [r for r in recs if lo < r[0] - region_begin < hi - 2]
+            c, p = synth.make_reads(ref[lo:hi], sub, per, read_len=read_len, seed=seed + 17 + k, err=err, n_rate=n_rate,
+                                    region_begin=region_begin + lo, rev_frac=0.0)
+            codes.append(c)
+            pos.append(p)
+        codes, pos = np.concatenate(codes), np.concatenate(pos)
+        order = np.argsort(pos, kind="stable")
+        return synth.bases_to_str(ref), recs, np.ascontiguousarray(codes[order]), pos[order]
     else:
         raise ValueError(kind)
     if kind == "repeat":  # reads from the repeat and its flanks only

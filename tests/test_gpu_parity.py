@@ -10,7 +10,7 @@ import harness
 import scenarios
 from graphtyper_amd import lib as gtx
 from oracle_lib import Oracle, encode
-from test_emu_parity import check_align, five_kmer_case, cfg3_case, neardup_case, direct_probes_case, n_runs_case, three_n_case, sv_deletion_case, edge_case, express_variants_case, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case
+from test_emu_parity import check_align, five_kmer_case, cfg3_case, neardup_case, direct_probes_case, n_runs_case, three_n_case, sv_deletion_case, edge_case, express_variants_case, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case, satellite_case, homopolymer_case, dinucleotide_case
 
 pytestmark = pytest.mark.gpu
 
@@ -105,6 +105,25 @@ def test_cfg3_graph():
 @pytest.mark.parametrize("kind", ["repeat", "snp7"])
 def test_second_pass(kind):
     second_pass_case(harness.GpuBackend, kind, 5000 if kind == "repeat" else 3000)  # (snp7: ~200 connection entries per read)
+
+
+def test_satellite_repeats_reach_the_exact_pass():
+    """reads in long low-complexity repeats chain more paths than any fixed table holds: the exact pass (tables sized at run
+    time in a slab of HBM) must finish every one of them with the oracle's records, and the scores / calls / VCF text follow"""
+    satellite_case(harness.GpuBackend, 4000)
+    satellite_case(harness.GpuBackend, 1500, read_len=250, seed=4)
+
+
+def test_exact_pass_with_the_whole_slab():
+    satellite_case(harness.GpuBackend, 1000, seed=1, exact_pass_mb=8)
+
+
+def test_reads_in_a_long_homopolymer():
+    homopolymer_case(harness.GpuBackend)
+
+
+def test_reads_in_copies_of_a_dinucleotide_repeat():
+    dinucleotide_case(harness.GpuBackend)
 
 
 def test_align_five_kmer_reads():
