@@ -1014,11 +1014,36 @@ def extra_cfg3(args, torch, gtx, synth, device, ref, kind="cfg3"):
     them 1-10 bp indels with a SNP within 10 bp that merges with them into a multi-allelic site; kind "clusters": the
     stress graph of rounds 1-2 -- clusters of three sites (SNP, SNP, 1-6 bp indel) every 150 bp, every read over a merged
     site of up to 8 alleles"""
-    n = args.extra_reads
     recs = synth.make_cfg3_records(ref, 100, seed=17, region_begin=REGION_BEGIN) if kind == "cfg3" else \
         synth.make_cluster_records(ref, 150, seed=8, region_begin=REGION_BEGIN)
+    what = ("cfg3: 30 samples, %d reads, 1 Mb, a site every 100 bp, 10 %% of them 1-10 bp indels with a SNP within 10 bp (SURVEY 8(d)), merged by "
+            "add_all_variants, max %d alleles per site" if kind == "cfg3" else
+            "cfg3 stress graph: 30 samples, %d reads, 1 Mb, clusters (SNP, SNP, indel) every 150 bp merged into multi-allelic sites "
+            "(add_all_variants), max %d alleles per site")
+    return extra_workload(args, torch, gtx, synth, device, ref, recs, 30, True, what)
+
+
+def extra_repeats(args, torch, gtx, synth, device, ref):
+    """The main workload's shape (one sample, SNP every 1 kb) on a reference that is NOT i.i.d.: homopolymer runs, short tandem
+    repeats, satellite arrays and near-duplicate segments planted into it (synth.plant_repeats) -- what a real chromosome has.
+    There the per-position proofs of the position-hinted pass fail more often, one k-mer has hundreds of places, and the
+    chains of a read exceed every fixed table: the share of each pass, the tasks that reach the exact pass and
+    reads_overflowed (must be 0) are the figures."""
+    ref = ref.copy()
+    spots = synth.plant_repeats(ref, seed=21)
+    recs = synth.make_snp_records(ref, 1000, seed=7, region_begin=REGION_BEGIN)
+    covered = sum(s[2] for s in spots)
+    what = ("repeats: 1 sample, %%d reads, 1 Mb with %d planted repeats (%d homopolymer runs of 20-300 bp, %d di-/trinucleotide repeats, %d "
+            "arrays of a 171-bp unit, %d near-duplicate 300-bp segments: %.1f %%%% of the region), SNP every 1 kb, max %%d alleles per site" %
+            (len(spots), sum(s[0] == "homopolymer" for s in spots), sum(s[0] == "tandem" for s in spots), sum(s[0] == "array" for s in spots),
+             sum(s[0] == "near-duplicate" for s in spots), 100.0 * covered / len(ref)))
+    return extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False, what)
+
+
+def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_all, what):
+    n = args.extra_reads
     t0 = time.time()
-    graph = gtx.graph_from_records(synth.bases_to_str(ref), recs, region_begin=REGION_BEGIN, add_all_variants=True)
+    graph = gtx.graph_from_records(synth.bases_to_str(ref), recs, region_begin=REGION_BEGIN, add_all_variants=add_all)
     t_graph = time.time() - t0
     t0 = time.time()
     ctx = gtx.Context(graph, device=0)
@@ -1027,8 +1052,9 @@ def extra_cfg3(args, torch, gtx, synth, device, ref, kind="cfg3"):
     order = np.argsort(pos, kind="stable")
     codes, pos = codes[order], pos[order]
     d_seq = torch.from_numpy(gtx.pack_nibbles(codes)).to(device)
-    samples = np.random.default_rng(3).integers(0, 30, size=n).astype(np.uint32)
-    w = Workload(torch, gtx, ctx, device, d_seq, torch.from_numpy(pos), 30, samples=samples, hint=not args.no_hint, lanes=args.lanes)
+    samples = np.random.default_rng(3).integers(0, n_samples, size=n).astype(np.uint32)
+    w = Workload(torch, gtx, ctx, device, d_seq, torch.from_numpy(pos), n_samples, samples=samples if n_samples > 1 else None,
+                 hint=not args.no_hint, lanes=args.lanes)
     w.staggered = args.schedule == "staggered" and len(w.lanes) >= 2  # (the same schedule as the main workload, chosen the same way)
     if args.read_sets > 1:  # a second set of reads: the steps alternate
         codes2, pos2 = synth.make_reads(ref, recs, n, read_len=READ_LEN, seed=6, region_begin=REGION_BEGIN)
@@ -1053,11 +1079,9 @@ def extra_cfg3(args, torch, gtx, synth, device, ref, kind="cfg3"):
         sys.stderr.write("cfg3-like: phase cycles per group of four reads of the express pass (profiling build), %d groups:\n" % prof[31])
         for k, nm in enumerate(names):
             sys.stderr.write("  %-22s %10.0f  %5.1f%%\n" % (nm, prof[16 + k] / float(prof[31]), 100.0 * prof[16 + k] / tot))
+    exact = ctx.exact_pass_tasks()
     w.close()
-    what = ("cfg3: 30 samples, %d reads, 1 Mb, a site every 100 bp, 10 %% of them 1-10 bp indels with a SNP within 10 bp (SURVEY 8(d)), merged by "
-            "add_all_variants, max %d alleles per site" if kind == "cfg3" else
-            "cfg3 stress graph: 30 samples, %d reads, 1 Mb, clusters (SNP, SNP, indel) every 150 bp merged into multi-allelic sites "
-            "(add_all_variants), max %d alleles per site") % (n, int(ctx.hap_cnum.max()))
+    what = what % (n, int(ctx.hap_cnum.max()))
     kt = ctx.kernel_times()
     out = {"workload": what, "align_kernels": {k[0]: {"ms": k[1], "tasks_completed": k[2]} for k in kt},
            "reads_per_s": n * steps / dt, "ms_per_step": 1000.0 * dt / steps, "steps": steps,
@@ -1065,7 +1089,9 @@ def extra_cfg3(args, torch, gtx, synth, device, ref, kind="cfg3"):
            "calibration": w.calibration, "resident_read_sets": len(w.sets), "sites": int(ctx.n_hap), "ctx_create_s": round(t_ctx, 3),
            "graph_build_s": round(t_graph, 3),
            "align_passes_ms": {"express": ms[0], "general": ms[1], "hbm_tables": ms[2]},
-           "pass_shares": {"tasks": n, "handed_to_general": handed, "share_general": handed / float(n)}}
+           "pass_shares": {"tasks": n, "handed_to_general": handed, "share_general": handed / float(n),
+                           "position_hinted_share": kt[0][2] / float(n)},
+           "exact_pass": {"tasks_with_a_part_of_the_slab": exact[0], "tasks_with_the_whole_slab": exact[1], "tasks_refused": exact[2]}}
     out.update(facts)
     ctx.close()
     return out
@@ -1257,6 +1283,10 @@ def main(argv=None):
             cfg.setdefault("extra", {})["cfg3_clusters"] = extra_cfg3(args, torch, gtx, synth, device, ref, "clusters")
         except Exception as e:  # the extra line must never cost the main one
             cfg.setdefault("extra", {})["cfg3"] = {"error": repr(e)}
+        try:
+            cfg.setdefault("extra", {})["repeats"] = extra_repeats(args, torch, gtx, synth, device, ref)
+        except Exception as e:
+            cfg.setdefault("extra", {})["repeats"] = {"error": repr(e)}
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

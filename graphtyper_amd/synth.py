@@ -93,6 +93,49 @@ def make_reads(ref, records, n, read_len=150, seed=123, err=0.005, n_rate=0.001,
     return np.ascontiguousarray(codes), pos
 
 
+def plant_repeats(ref, seed=21, homopolymers=40, short_tandems=40, arrays=4, near_duplicates=200):
+    """Overwrites stretches of `ref` (in place) with what a real chromosome has and an i.i.d. reference lacks: homopolymer runs
+    of 20-300 bp, di- / trinucleotide repeats of 50-300 bp, satellite arrays (12 copies of a 171-bp unit, every other copy
+    0.5 % diverged) and near-duplicate segments (300 bp copied elsewhere with a substitution every ~40 bp).  Places are drawn
+    uniformly; returns [(kind, start, length)]."""
+    rng = np.random.default_rng(seed)
+    n = len(ref)
+    spots = []
+    for _ in range(homopolymers):
+        size = int(rng.choice([20, 35, 60, 100, 180, 300]))
+        at = int(rng.integers(0, n - size))
+        ref[at:at + size] = int(rng.integers(0, 4))
+        spots.append(("homopolymer", at, size))
+    for _ in range(short_tandems):
+        unit = rng.integers(0, 4, size=int(rng.integers(2, 4))).astype(np.uint8)
+        if len(set(unit.tolist())) == 1:
+            unit[0] = (unit[0] + 1) % 4
+        size = int(rng.choice([50, 90, 150, 300]))
+        at = int(rng.integers(0, n - size))
+        c = np.tile(unit, size // len(unit) + 1)[:size]
+        e = rng.random(size) < 0.01
+        c[e] = (c[e] + rng.integers(1, 4, size=int(e.sum()))) % 4
+        ref[at:at + size] = c
+        spots.append(("tandem", at, size))
+    for _ in range(arrays):
+        unit = rng.integers(0, 4, size=171).astype(np.uint8)
+        at = int(rng.integers(0, n - 12 * 171))
+        for c in range(12):
+            u = unit.copy()
+            e = (rng.random(171) < 0.005) & (c % 2 == 1)
+            u[e] = (u[e] + rng.integers(1, 4, size=int(e.sum()))) % 4
+            ref[at + c * 171:at + (c + 1) * 171] = u
+        spots.append(("array", at, 12 * 171))
+    for _ in range(near_duplicates):
+        src, dst = int(rng.integers(0, n - 300)), int(rng.integers(0, n - 300))
+        c = ref[src:src + 300].copy()
+        at = np.arange(int(rng.integers(5, 40)), 300, 40)
+        c[at] = (c[at] + rng.integers(1, 4, size=len(at))) % 4
+        ref[dst:dst + 300] = c
+        spots.append(("near-duplicate", dst, 300))
+    return spots
+
+
 def make_cluster_records(ref, every=500, seed=13, region_begin=0):
     """clusters of three biallelic sites a few bp apart (SNP, SNP, 1-6 bp insertion or deletion): with add_all_variants
     every cluster merges into one multi-allelic site (the cfg3-like graph)"""
