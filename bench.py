@@ -64,6 +64,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU baseline (0 = all host hardware threads, max 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the cfg3-like extra workload")
+    ap.add_argument("--no-reduce-check", action="store_true", help="N > 1: skip the check of the summed block against one GPU (rank 0 redoes every rank's reads)")
     ap.add_argument("--lanes", type=int, default=3, help="steps in flight (each with its own records and accumulators); 1 = one after the other")
     ap.add_argument("--schedule", choices=["staggered", "lanes"], default="staggered",
                     help="staggered = one stream carries the position-hinted pass of step k and then the scoring of step k-lanes+1, a second "
@@ -387,7 +388,8 @@ class Workload:
             ln["t32"] = torch.as_tensor(DevView(ln["buf"].d_log_score, n32, "<i4"), device=self.device)
         self.dist, self.reduce_kind = dist, "torch.distributed all_reduce x2 on the packed block"
 
-    def step(self, lane=0):
+    def step(self, lane=0, zero=True):
+        """one step on `lane`; zero=False: the accumulators keep what they hold (several read sets into one block)"""
         gtx, L, ctx = self.gtx, self.L, self.ctx
         torch = self.torch
         ln = self.lanes[lane]
@@ -395,7 +397,8 @@ class Workload:
         d_seq, d_meta, d_items = self.sets[self.steps_done % len(self.sets)]
         self.steps_done += 1
         with torch.cuda.stream(stream):
-            gtx.check(L.gtx_scores_zero(ctx.h, C.byref(buf), sp))
+            if zero:
+                gtx.check(L.gtx_scores_zero(ctx.h, C.byref(buf), sp))
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(stream)
@@ -577,6 +580,14 @@ class Workload:
         return {"vcf_sha256": hashlib.sha256(text).hexdigest(), "vcf_bytes": len(text), "read_set": read_set,
                 "what": "sha256 of the region's VCF records (gtx_vcf_records, column line first) after one step over read set %d" % read_set}
 
+    def block_digest(self, lane=0):
+        """SHA-256 of the packed accumulator block of `lane` (gtx_scores_alloc: [stat_u64 | the u32 sections], what
+        gtx_scores_reduce sums over the ranks)"""
+        import hashlib
+        self.torch.cuda.synchronize()
+        raw = self.gtx.download(self.lanes[lane]["buf"].d_stat_u64, np.uint8, self.reduced_bytes)
+        return hashlib.sha256(raw.tobytes()).hexdigest()
+
     def result_facts(self):
         """sanity on the results of the last step: every record must be a result, not an overflow"""
         gtx, ctx = self.gtx, self.ctx
@@ -597,6 +608,22 @@ class Workload:
                 "reads_overflowed": int((((rec_head >> 16) & gtx.ST_ERROR_MASK) != 0).sum().item()),
                 "nonref_genotype_calls": int((calls["gt_second"] > 0).sum()), "score_items_refused": ctx.error_count(),
                 "connections_logged": int(cc[0]), "connections_dropped": int(cc[1])}
+
+
+def pinned_digest(checksum, n_reads, args):
+    """the committed digest of the benchmark's own result (tests/golden/cfg2_vcf_digest.json: the oracle's VCF text over all
+    reads of read set 0) against this run's: the line says itself whether the records it timed are the right ones"""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "cfg2_vcf_digest.json")
+    try:
+        pin = json.load(open(path))
+    except (OSError, ValueError) as e:
+        return {"matches_pinned": None, "pinned": "unreadable: %r" % (e,)}
+    same_workload = (n_reads == pin["reads"] and args.snp_every == 1000 and args.err == 0.005 and args.nrate == 0.001 and
+                     args.region_len == REGION_LEN and CFG2_READ_SEED == pin["reads_seed"])
+    if not same_workload:
+        return {"matches_pinned": None, "pinned": "tests/golden/cfg2_vcf_digest.json is for the default workload (this run's differs)"}
+    return {"matches_pinned": checksum["vcf_sha256"] == pin["vcf_sha256"] and checksum["vcf_bytes"] == pin["vcf_bytes"],
+            "pinned": "tests/golden/cfg2_vcf_digest.json"}
 
 
 def cpu_model():
@@ -1136,8 +1163,8 @@ def main(argv=None):
     n_samples, per_rank = job_shape(args, world)
     n = per_rank[rank]
 
-    def sample_ids(k):
-        return None if n_samples == 1 else np.random.default_rng(4242 + 7919 * k + rank).integers(0, n_samples, size=n).astype(np.uint32)
+    def sample_ids(k, r=rank, count=None):
+        return None if n_samples == 1 else np.random.default_rng(4242 + 7919 * k + r).integers(0, n_samples, size=n if count is None else count).astype(np.uint32)
 
     d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=CFG2_READ_SEED + rank, device=device, REGION_LEN=args.region_len,
                                         err_rate=args.err, n_rate=args.nrate)
@@ -1166,6 +1193,40 @@ def main(argv=None):
     n_gpus = dist.get_world_size() if dist is not None else 1
     per_rank_ms = gather_floats(dist, 1000.0 * w.local_s / args.steps, device)
     reduce_ms = gather_floats(dist, w.reduce_ms, device)
+
+    # ---- N > 1: the exchange checks itself.  One more step over read set 0 on every rank leaves the SUM of the ranks' blocks in
+    # every rank's block; rank 0 then makes the reads of every rank again (their seeds are known), runs them one after the other
+    # into ONE block without an exchange, and the two blocks must be the same bytes: the first run on real xGMI says itself
+    # whether gtx_scores_reduce summed what one GPU computes.
+    reduce_check = None
+    if dist is not None and not args.no_reduce_check:
+        w.steps_done = 0
+        w.step(0)
+        summed = w.block_digest(0)
+        if rank == 0:
+            import hashlib
+            t0 = time.perf_counter()
+            n64 = ctx.n_hap + 2 * ctx.total_allele
+            sum64, sum32 = None, None
+            for r in range(world):
+                d_seq_r, d_pos_r = make_reads_on_device(torch, ref, records, per_rank[r], seed=CFG2_READ_SEED + r, device=device, REGION_LEN=args.region_len,
+                                                        err_rate=args.err, n_rate=args.nrate)
+                wc = Workload(torch, gtx, ctx, device, d_seq_r, d_pos_r, n_samples, samples=sample_ids(0, r, per_rank[r]), hint=not args.no_hint, lanes=1)
+                wc.step(0)
+                torch.cuda.synchronize()
+                raw = gtx.download(wc.buf.d_stat_u64, np.uint8, wc.reduced_bytes)
+                p64, p32 = raw[:8 * n64].view(np.uint64), raw[8 * n64:].view(np.uint32)
+                sum64 = p64.copy() if sum64 is None else sum64 + p64  # (wrap-around like the device's adds)
+                sum32 = p32.copy() if sum32 is None else sum32 + p32
+                wc.close()
+                del wc, d_seq_r, d_pos_r
+            alone = hashlib.sha256(sum64.tobytes() + sum32.tobytes()).hexdigest()
+            reduce_check = {"what": "block of read set 0 summed over the ranks (gtx_scores_reduce) against the same %d read sets run one after the other "
+                                    "on rank 0's GPU and added on the host, no exchange" % world,
+                            "summed_sha256": summed, "one_gpu_sha256": alone, "equal": summed == alone, "seconds": round(time.perf_counter() - t0, 2)}
+            if summed != alone:
+                sys.stderr.write("[bench] THE SUMMED BLOCK DIFFERS from the one-GPU block of the same reads\n")
+        dist.barrier()
 
     prof = ctx.profile()
     if rank == 0 and prof[15] > 0:  # GTX_LIB=libgtx_prof.so: shader cycles per phase of the general algorithm, per task that ran it
@@ -1240,12 +1301,14 @@ def main(argv=None):
                                "last steps' scoring is inside the timed region); step_alone_ms = one step at a time on one stream"},
            "parallelism": "reads sharded over %d GPU(s), graph+index replicated" % n_gpus,
            "reduce": w.reduce_kind, "reduced_bytes_per_step": w.reduced_bytes if n_gpus > 1 else 0,
-           "reduce_ms": max(reduce_ms) if n_gpus > 1 else 0.0, "reduce_ms_per_rank": reduce_ms, "per_rank_ms_per_step": per_rank_ms}
+           "reduce_ms": max(reduce_ms) if n_gpus > 1 else 0.0, "reduce_ms_per_rank": reduce_ms, "per_rank_ms_per_step": per_rank_ms,
+           "reduce_check": reduce_check}
     cfg.update(facts)
     if n_gpus == 1 and n_samples == 1:
         try:
             cfg["calls_checksum"] = w.calls_checksum(0)
             cfg["calls_checksum"]["reads_seed"] = CFG2_READ_SEED
+            cfg["calls_checksum"].update(pinned_digest(cfg["calls_checksum"], n, args))
             cfg["calls_checksum"]["checked_by"] = ("tests/test_gpu_full_size.py::test_cfg2_every_read_against_the_oracle: all reads of this set through "
                                                    "oracle/ on the host cores -> accumulators, SampleCalls and VCF bytes equal")
         except Exception as e:  # the extra field must never cost the main line
@@ -1259,6 +1322,40 @@ def main(argv=None):
         out["cpu_baseline"] = cpu_baseline(args, ref_str, records, unpack_nibbles(d_seq[:m].cpu().numpy(), READ_LEN), d_pos[:m].cpu().numpy())
     else:
         out["cpu_baseline"] = None
+    if n_gpus == 1 and n_samples == 1 and not args.no_extra:
+        try:  # the same schedule over 500 steps: a timed window of 15 ms cannot tell a 2 % effect from noise
+            calib, stag = w.calibration, w.staggered
+            dt_long, _ = w.run(500, 2, None)
+            cfg.setdefault("extra", {})["long_run"] = {"steps": 500, "ms_per_step": 1000.0 * dt_long / 500, "reads_per_s": n * 500 / dt_long,
+                                                       "schedule": ("staggered, %d steps in flight" % w.used_lanes) if (w.staggered and w.used_lanes > 1) else "one step at a time"}
+            w.calibration, w.staggered = calib, stag
+        except Exception as e:
+            cfg.setdefault("extra", {})["long_run"] = {"error": repr(e)}
+        try:  # BASELINE configs[3] as far as one GPU goes: the reads of 1000 samples, every rank's share of cfg4
+            w4 = Workload(torch, gtx, ctx, device, d_seq, d_pos, 1000, samples=np.random.default_rng(4242).integers(0, 1000, size=n).astype(np.uint32),
+                          hint=not args.no_hint, lanes=args.lanes)
+            w4.staggered = args.schedule == "staggered" and len(w4.lanes) >= 2
+            dt4, _ = w4.run(20, 2, None)
+            k4 = ctx.kernel_times()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                w4.step(0)
+            torch.cuda.synchronize()
+            alone4 = 1000.0 * (time.perf_counter() - t0) / 4
+            f4 = w4.result_facts()
+            cfg.setdefault("extra", {})["cfg4_one_gpu"] = {
+                "workload": "cfg4's share of one GPU: %d reads of 1000 samples (a sample per read at random), the accumulator block of all 1000 samples "
+                            "(%d bytes), no exchange" % (n, w4.reduced_bytes),
+                "reads_per_s": n * 20 / dt4, "ms_per_step": 1000.0 * dt4 / 20, "steps": 20, "step_alone_ms": alone4,
+                "schedule": ("staggered, %d steps in flight" % w4.used_lanes) if (w4.staggered and w4.used_lanes > 1) else "one step at a time",
+                "align_kernels": {k[0]: {"ms": k[1], "tasks_completed": k[2]} for k in k4},
+                "reads_overflowed": f4["reads_overflowed"], "score_items_refused": f4["score_items_refused"],
+                "cells_at_saturation_guard": f4["cells_at_saturation_guard"], "nonref_genotype_calls": f4["nonref_genotype_calls"]}
+            w4.close()
+            del w4
+        except Exception as e:
+            cfg.setdefault("extra", {})["cfg4_one_gpu"] = {"error": repr(e)}
     if n_gpus == 1 and not args.no_extra:
         try:
             cfg.setdefault("extra", {})["pcie_fed"] = extra_pcie_fed(w, torch, gtx)

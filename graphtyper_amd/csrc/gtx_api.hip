@@ -349,6 +349,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_WIDE_WAV
 // task is settled (empty record, or queued for pass 2 when align_read asks for it), reads outside the length limits get
 // their empty records, and the forward task is finished from the position hint where the flags of that place prove the
 // global lookups -- else the read is queued for pass 1 (express4 over the queue).  One atomic per wavefront and queue.
+// (profiling build only, GTX_HINT=x: a timing experiment that lets the results land in the first 1 024 record slots, i.e. stay in
+//  the L2 -- it destroys the results, so the release library has no such switch)
+#ifdef GTX_PROF
+#define GTX_HINT_REC_SLOT(read) ((decline_all & 2u) ? ((read) & 1023u) : (read))
+#else
+#define GTX_HINT_REC_SLOT(read) (read)
+#endif
 template <uint32_t WAVES>
 __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const & ix, uint8_t const * __restrict__ seq, uint32_t seq_stride,
                                             gtx_read_meta const * __restrict__ meta, uint32_t n_reads, uint32_t * __restrict__ records,
@@ -411,8 +418,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
     else
       m = meta[read];
     uint32_t const len = m.l_qseq;
-    // (decline_all & 2: timing experiment -- results land in the first 1 024 record slots, i.e. stay in the L2)
-    uint32_t * rec = records + static_cast<uint64_t>((decline_all & 2u) ? (read & 1023u) : read) * 2 * rec_words;
+    uint32_t * rec = records + static_cast<uint64_t>(GTX_HINT_REC_SLOT(read)) * 2 * rec_words;
     bool const outside = len < 2 * K - 1 || len > AlignCfg::MAX_READ; // align_read (alignment.cpp:331-363): stay unaligned
     rev = !outside && needs_reverse(m, force_both != 0);
     // (GTX_FLAG_FORWARD_ONLY in the read's own flag word: the caller will never look at the reverse record of a read whose
@@ -469,11 +475,18 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
       for (uint32_t round = 0; round < 4; ++round)
       {
         uint32_t const r = round * 16u + (lane >> 2);
-        if ((S >> r) & 1ull)
+        uint4_t const v = s_seq[wave][r * ROW_VEC + part];
+        // Only the parts the record reaches into are stored: a one-path record is 6 words (9 with a variant site) of the 16
+        // staged -- the slot's other bytes are nobody's to read, and writing them was 29 % of this kernel's HBM traffic
+        // (round 3: WRITE_SIZE 66 B per read for a 24-byte record).  Its length is in its own words: paths in word 0 (this
+        // quad's first lane has it), sites in word 5 (the second lane).
+        uint32_t const w0 = static_cast<uint32_t>(__shfl(static_cast<int>(v.x), static_cast<int>(lane & ~3u)));
+        uint32_t const w5 = static_cast<uint32_t>(__shfl(static_cast<int>(v.y), static_cast<int>((lane & ~3u) + 1u)));
+        uint32_t const np = w0 & 0xFFFFu, used = 2u + np * (4u + 3u * (np ? (w5 >> 16) : 0u));
+        if (((S >> r) & 1ull) && 4u * part < used)
         {
-          uint4_t const v = s_seq[wave][r * ROW_VEC + part];
           uint32_t const rd = wave_first + r;
-          uint32_t * dst = records + static_cast<uint64_t>((decline_all & 2u) ? (rd & 1023u) : rd) * 2 * rec_words;
+          uint32_t * dst = records + static_cast<uint64_t>(GTX_HINT_REC_SLOT(rd)) * 2 * rec_words;
           stream_store(reinterpret_cast<uint4_t *>(dst + 4 * part), v);
         }
       }
@@ -1716,7 +1729,11 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
       hipLaunchKernelGGL(hint_threads == 512u ? gtx_align_hinted8_kernel : hint_threads == 1024u ? gtx_align_hinted16_kernel : gtx_align_hinted_kernel,
                          dim3((n + hint_threads - 1u) / hint_threads), dim3(hint_threads), 0, st, c->dev_graph, c->dev_index, seq, seq_stride,
                          meta, n, records, rec_words, force_both, queue1, queue2, reinterpret_cast<unsigned long long *>(counters + 2),
-                         static_cast<uint32_t>(force != 0 || (eh && eh[0] == 'd')) | (eh && eh[0] == 'x' ? 2u : 0u),
+                         static_cast<uint32_t>(force != 0 || (eh && eh[0] == 'd'))
+#ifdef GTX_PROF
+                           | (eh && eh[0] == 'x' ? 2u : 0u)
+#endif
+                           ,
                          d_task_flags ? d_task_flags + 2ull * first : static_cast<uint8_t *>(nullptr));
       if (!hip_ok(hipGetLastError(), "gtx_align_hinted_kernel launch"))
         return GTX_ERR_HIP;

@@ -239,6 +239,11 @@ def test_cfg2_every_read_against_the_oracle():
         first = [i for i in range(min(len(gl), len(wl))) if gl[i] != wl[i]][:1]
         raise AssertionError("VCF text differs (%d vs %d lines), first at line %s" % (len(gl), len(wl), first))
     assert hashlib.sha256(want_text).hexdigest() == digest["vcf_sha256"]
+    # ... and the digest committed under tests/golden (bench.py reports `matches_pinned` against it) is the ORACLE's
+    import json
+    pin = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg2_vcf_digest.json")))
+    if n == pin["reads"]:
+        assert hashlib.sha256(want_text).hexdigest() == pin["vcf_sha256"] and len(want_text) == pin["vcf_bytes"]
     assert text.count(b"\n") - 1 == len(records) and (calls["gt_second"] > 0).sum() > len(records) // 4  # not vacuous
 
 
