@@ -276,6 +276,7 @@ class Workload:
         self.n, self.n_samples = n, n_samples
         self.stride = (int(d_seq.shape[1]) + 15) // 16 * 16  # pitch of the plane rows
         self.hint, self.samples = hint, samples
+        self.rewind = False  # step(): rewind the context's big-record arena first (one step at a time only: the arena is the context's)
         self.sets = []   # resident read sets (bases, meta, score items); step k works on set k mod len(sets)
         self.words = {}  # items' data_ptr -> their compact form (gtx_score_batch_words), or None
         self.steps_done = 0
@@ -397,6 +398,8 @@ class Workload:
         d_seq, d_meta, d_items = self.sets[self.steps_done % len(self.sets)]
         self.steps_done += 1
         with torch.cuda.stream(stream):
+            if self.rewind:  # (a step is a region's worth of records: the arena of the records longer than a slot starts over)
+                gtx.check(L.gtx_ctx_big_records_rewind(ctx.h, sp))
             if zero:
                 gtx.check(L.gtx_scores_zero(ctx.h, C.byref(buf), sp))
             e0 = torch.cuda.Event(enable_timing=True)
@@ -606,6 +609,9 @@ class Workload:
             sys.stderr.write("[bench] %d (haplotype, sample) cells reached the saturation guard: sums are not the reference's there\n" % at_guard)
         return {"reads_aligned": int(((rec_head[0::2] & 0xFFFF) > 0).sum().item()), "vcf_text": self.vcf, "cells_at_saturation_guard": at_guard,
                 "reads_overflowed": int((((rec_head >> 16) & gtx.ST_ERROR_MASK) != 0).sum().item()),
+                "reads_overflowed_by_kind": {name: int((((rec_head >> 16) & bit) != 0).sum().item())
+                                             for name, bit in (("labels", 1), ("paths", 2), ("walk", 4), ("record_arena_full", 8))},
+                "records_in_the_arena": int((((rec_head >> 16) & gtx.ST_EXTERNAL) != 0).sum().item()),
                 "nonref_genotype_calls": int((calls["gt_second"] > 0).sum()), "score_items_refused": ctx.error_count(),
                 "connections_logged": int(cc[0]), "connections_dropped": int(cc[1])}
 
@@ -1064,16 +1070,18 @@ def extra_repeats(args, torch, gtx, synth, device, ref):
             "arrays of a 171-bp unit, %d near-duplicate 300-bp segments: %.1f %%%% of the region), SNP every 1 kb, max %%d alleles per site" %
             (len(spots), sum(s[0] == "homopolymer" for s in spots), sum(s[0] == "tandem" for s in spots), sum(s[0] == "array" for s in spots),
              sum(s[0] == "near-duplicate" for s in spots), 100.0 * covered / len(ref)))
-    return extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False, what)
+    # (one step at a time, the arena rewound per step and sized for it: reads in repeats have records of hundreds of paths)
+    return extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False, what, lanes=1, big_record_words=1 << 27)
 
 
-def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_all, what):
+def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_all, what, lanes=None, big_record_words=0):
     n = args.extra_reads
+    lanes = args.lanes if lanes is None else lanes
     t0 = time.time()
     graph = gtx.graph_from_records(synth.bases_to_str(ref), recs, region_begin=REGION_BEGIN, add_all_variants=add_all)
     t_graph = time.time() - t0
     t0 = time.time()
-    ctx = gtx.Context(graph, device=0)
+    ctx = gtx.Context(graph, device=0, big_record_words=big_record_words)
     t_ctx = time.time() - t0
     codes, pos = synth.make_reads(ref, recs, n, read_len=READ_LEN, seed=5, region_begin=REGION_BEGIN)
     order = np.argsort(pos, kind="stable")
@@ -1081,7 +1089,8 @@ def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_al
     d_seq = torch.from_numpy(gtx.pack_nibbles(codes)).to(device)
     samples = np.random.default_rng(3).integers(0, n_samples, size=n).astype(np.uint32)
     w = Workload(torch, gtx, ctx, device, d_seq, torch.from_numpy(pos), n_samples, samples=samples if n_samples > 1 else None,
-                 hint=not args.no_hint, lanes=args.lanes)
+                 hint=not args.no_hint, lanes=lanes)
+    w.rewind = lanes == 1 and big_record_words != 0
     w.staggered = args.schedule == "staggered" and len(w.lanes) >= 2  # (the same schedule as the main workload, chosen the same way)
     if args.read_sets > 1:  # a second set of reads: the steps alternate
         codes2, pos2 = synth.make_reads(ref, recs, n, read_len=READ_LEN, seed=6, region_begin=REGION_BEGIN)

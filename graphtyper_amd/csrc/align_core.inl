@@ -74,8 +74,16 @@ struct DynTables
 struct NoDynTables
 {
 };
+// The passes with large fixed tables in HBM (AlignCfg::MAXPP > 64) keep the same dense start / end tables of pp, behind
+// pointers: the kernel points them at LDS (a few KB), where the 64-entries-per-step searches of the chaining cost a hundred
+// cycles instead of a round trip to HBM per step (round 4: a task with 512 paths took 50 ms in the HBM-table pass).
+struct PpKeyTables
+{
+  uint32_t * pp_start, * pp_end;
+};
+constexpr bool DENSE_PP_KEYS = AlignCfg::DYN || AlignCfg::MAXPP > 64;
 
-struct AlignWorkspace : std::conditional<AlignCfg::DYN, DynTables, NoDynTables>::type // lives in LDS (HBM in the passes behind the general one), one per wavefront
+struct AlignWorkspace : std::conditional<AlignCfg::DYN, DynTables, std::conditional<(AlignCfg::MAXPP > 64), PpKeyTables, NoDynTables>::type>::type // lives in LDS (HBM in the passes behind the general one), one per wavefront
 {
   uint8_t rd[AlignCfg::MAX_READ]; // read as 4-bit IUPAC codes, orientation applied
   TableOf<DevLabel, AlignCfg::LBL_CAP> lbl;
@@ -249,7 +257,7 @@ GTX_DEV uint32_t cap_wl(WS const & ws)
 template <class WS>
 GTX_DEV uint32_t const * pp_keys(WS const & ws, bool ends)
 {
-  if constexpr (AlignCfg::DYN)
+  if constexpr (DENSE_PP_KEYS)
     return ends ? ws.pp_end : ws.pp_start;
   else
     return nullptr;
@@ -965,7 +973,7 @@ GTX_DEV uint32_t make_pp(WS & ws, DPath * pp, DevLabel const * ll, uint32_t n, u
       return npp;
     }
     uint32_t d = 0;
-    if constexpr (AlignCfg::DYN)
+    if constexpr (DENSE_PP_KEYS)
       d = find_pair<W>(ws.pp_start, ws.pp_end, npp, ls, le);
     else
       for (; d < npp; ++d)
@@ -980,7 +988,7 @@ GTX_DEV uint32_t make_pp(WS & ws, DPath * pp, DevLabel const * ll, uint32_t n, u
       }
       GTX_LEAD
       {
-        if constexpr (AlignCfg::DYN)
+        if constexpr (DENSE_PP_KEYS)
         {
           ws.pp_start[npp] = ls;
           ws.pp_end[npp] = le;
@@ -1196,8 +1204,23 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
     if (prev ? (GTX_U(static_cast<uint32_t>(ws.paths[i].rs)) != re) : (GTX_U(static_cast<uint32_t>(ws.paths[i].re)) != rs))
       continue;
     bool once = false;
+    uint32_t const o_start = GTX_U(ws.paths[i].start), o_end = GTX_U(ws.paths[i].end);
+    if constexpr (DENSE_PP_KEYS)
+    {
+      // (no pp entry abuts this path: nothing to copy, nothing to merge)
+      uint32_t const * key = pp_keys(ws, prev);
+      uint32_t const want = prev ? o_start : o_end;
+      bool any = false;
+      for (uint32_t base = 0; base < npp && !any; base += 64)
+      {
+        typename W::template PerLane<bool> hit;
+        W::lanes([&](uint32_t l) { hit[l] = base + l < npp && key[base + l] == want; });
+        any = W::ballot(hit) != 0;
+      }
+      if (!any)
+        continue;
+    }
     copy_path<W>(ws.orig, ws.paths[i]);
-    uint32_t const o_start = GTX_U(ws.orig.start), o_end = GTX_U(ws.orig.end);
     // one pp entry that abuts the path: merged into it (the first one in place, further ones as new paths)
     auto join = [&](uint32_t j) -> bool
     {
@@ -1216,9 +1239,9 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
       once = true;
       return true;
     };
-    if constexpr (AlignCfg::DYN)
+    if constexpr (DENSE_PP_KEYS)
     {
-      // (thousands of entries: the abutting ones are found 64 at a time in the dense start / end table, then taken in order)
+      // (hundreds to thousands of entries: the abutting ones are found 64 at a time in the dense start / end table, then taken in order)
       uint32_t const * key = pp_keys(ws, prev);
       uint32_t const want = prev ? o_start : o_end;
       for (uint32_t base = 0; base < npp; base += 64)

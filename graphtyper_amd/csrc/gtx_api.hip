@@ -475,16 +475,13 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
       for (uint32_t round = 0; round < 4; ++round)
       {
         uint32_t const r = round * 16u + (lane >> 2);
-        uint4_t const v = s_seq[wave][r * ROW_VEC + part];
-        // Only the parts the record reaches into are stored: a one-path record is 6 words (9 with a variant site) of the 16
-        // staged -- the slot's other bytes are nobody's to read, and writing them was 29 % of this kernel's HBM traffic
-        // (round 3: WRITE_SIZE 66 B per read for a 24-byte record).  Its length is in its own words: paths in word 0 (this
-        // quad's first lane has it), sites in word 5 (the second lane).
-        uint32_t const w0 = static_cast<uint32_t>(__shfl(static_cast<int>(v.x), static_cast<int>(lane & ~3u)));
-        uint32_t const w5 = static_cast<uint32_t>(__shfl(static_cast<int>(v.y), static_cast<int>((lane & ~3u) + 1u)));
-        uint32_t const np = w0 & 0xFFFFu, used = 2u + np * (4u + 3u * (np ? (w5 >> 16) : 0u));
-        if (((S >> r) & 1ull) && 4u * part < used)
+        // (All four 16-byte parts of the staged record leave, 64 bytes for a record of 24: storing only the parts the record
+        //  reaches into -- round 4, WRITE_SIZE 66 -> 34 B per read -- made this kernel SLOWER, 0.44 -> 0.565 ms: a store that
+        //  covers half of a 64-byte piece of a line presumably becomes a read-modify-write at the memory side.  Fewer bytes need a
+        //  denser record layout, not narrower stores.)
+        if ((S >> r) & 1ull)
         {
+          uint4_t const v = s_seq[wave][r * ROW_VEC + part];
           uint32_t const rd = wave_first + r;
           uint32_t * dst = records + static_cast<uint64_t>(GTX_HINT_REC_SLOT(rd)) * 2 * rec_words;
           stream_store(reinterpret_cast<uint4_t *>(dst + 4 * part), v);

@@ -31,6 +31,11 @@ namespace gtx
                                              uint32_t * __restrict__ next_tasks, uint32_t next_cap, uint32_t * next_state)         \
   {                                                                                                                                \
     NS::AlignWorkspace & ws = workspaces[blockIdx.x];                                                                              \
+    /* the dense start / end tables of the chaining's searches live in LDS (align_core.inl: PpKeyTables) */                       \
+    __shared__ uint32_t s_pp_keys[2][NS::AlignCfg::MAXPP];                                                                         \
+    ws.pp_start = s_pp_keys[0];                                                                                                    \
+    ws.pp_end = s_pp_keys[1];                                                                                                      \
+    WaveHipMem::mem_sync();                                                                                                        \
     GTX_HBM_PASS_BODY(NS)                                                                                                          \
   }
 
@@ -97,6 +102,7 @@ namespace gtx
 // The exact pass (align_core.hpp: namespace exact): the same body over a workspace whose tables are cut out of the
 // workgroup's part of a slab of HBM at run time.  Launched twice: EXACT_PARTS workgroups with a part each, then one workgroup
 // with the whole slab for what did not fit a part (its queue is the first launch's next_tasks).
+constexpr uint32_t EXACT_LDS_KEYS = 4096; // paths whose dense start / end tables fit the exact pass' 32 KB of LDS
 #define GTX_EXACT_PASS_KERNEL(NAME, NS)                                                                                            \
   __global__ __launch_bounds__(64) GTX_HBM_PASS_ATTR void NAME(GraphView g, IndexView ix, uint8_t const * __restrict__ seq, uint32_t seq_stride, \
                                              gtx_read_meta const * __restrict__ meta, uint32_t * __restrict__ records,             \
@@ -126,6 +132,14 @@ namespace gtx
       }                                                                                                                            \
       return;                                                                                                                      \
     }                                                                                                                              \
+    /* (the dense start / end tables in LDS when the part's paths fit there, else where exact_setup put them in the slab) */       \
+    __shared__ uint32_t s_pp_keys[2][EXACT_LDS_KEYS];                                                                              \
+    if (ws.cap_p <= EXACT_LDS_KEYS)                                                                                                \
+    {                                                                                                                              \
+      ws.pp_start = s_pp_keys[0];                                                                                                  \
+      ws.pp_end = s_pp_keys[1];                                                                                                    \
+    }                                                                                                                              \
+    WaveHipMem::mem_sync();                                                                                                        \
     GTX_HBM_PASS_BODY(NS)                                                                                                          \
   }
 

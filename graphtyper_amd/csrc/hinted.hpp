@@ -1048,14 +1048,10 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   bool const to_stage = stage != nullptr && rec_words >= HINT_STAGE_WORDS && 2 + (np ? np : 1u) * path_words <= HINT_STAGE_WORDS;
   if (to_stage)
   {
-    // (the record leaves in 16-byte parts, only those it reaches into -- gtx_api.hip, hinted_pass --: zeros behind its end as far
-    //  as its last part goes, which is all a reader of the slot can be shown)
     rec = stage;
-    uint32_t const used = 2 + np * path_words, parts_end = (used + 3u) & ~3u;
 #pragma unroll
     for (uint32_t k = 2; k < HINT_STAGE_WORDS; ++k)
-      if (k < parts_end)
-        rec[k] = 0u;
+      rec[k] = 0u;
   }
   rec[0] = np;
   rec[1] = longest | (L << 16) | ((np && nvar) ? GTX_REC_HAS_VARIANTS : 0u);

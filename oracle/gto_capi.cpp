@@ -2,6 +2,7 @@
 // Loaded with ctypes from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
 #include "gto.hpp"
 #include "gto_vcf.hpp"
+#include "gto_sv.hpp"
 #include "gto_discovery.hpp"
 
 #include <cctype>
@@ -608,6 +609,62 @@ extern "C"
     if (out && cap > 0)
       std::memcpy(out, text.data(), static_cast<std::size_t>(std::min<long>(cap, static_cast<long>(text.size()))));
     return static_cast<long>(text.size());
+  }
+
+  // VCF records of an SV graph's calls (gto_sv.hpp: reformat_sv_vcf_records and the merge of genotype_sv).  sv_table: the text
+  // form of Graph::SVs; reference / first_pos: the region's reference sequence and the 1-based position of its first base.
+  // Returns the text length, or -1 (gto_last_error).
+  long gto_vcf_records_sv(void * p, char const * contig, char const * sample_names, uint32_t region_begin, uint32_t region_end,
+                          char const * sv_table, char const * reference, uint32_t first_pos, char * out, long cap)
+  {
+    try
+    {
+      vcf::WriteOptions o;
+      o.contig = contig;
+      std::stringstream ss(sample_names ? sample_names : "");
+      std::string n;
+      while (std::getline(ss, n, '\n'))
+        if (!n.empty())
+          o.sample_names.push_back(n);
+      o.region_begin = region_begin;
+      o.region_end = region_end;
+      vcf::RegionReference rr;
+      rr.reference = reference ? reference : "";
+      rr.first_pos = first_pos;
+      std::string const text = vcf::records_sv(*static_cast<GenoHandle *>(p)->g, o, vcf::parse_sv_table(sv_table ? sv_table : ""), rr);
+      if (out && cap > 0)
+        std::memcpy(out, text.data(), static_cast<std::size_t>(std::min<long>(cap, static_cast<long>(text.size()))));
+      return static_cast<long>(text.size());
+    }
+    catch (std::exception const & e)
+    {
+      g_error = e.what();
+      return -1;
+    }
+  }
+
+  // make_call_based_on_coverage of one SV over a depth track given directly (unit tests): out = coverage[0], coverage[1], PL x 3
+  int gto_coverage_call(char const * sv_table, long sv_index, uint16_t const * depth, long n_depth, uint32_t reference_offset, uint32_t * out)
+  {
+    try
+    {
+      auto const svs = vcf::parse_sv_table(sv_table);
+      ReferenceDepth rd;
+      rd.reference_offset = reference_offset;
+      rd.depths.assign(1, std::vector<uint16_t>(depth, depth + n_depth));
+      vcf::SampleCall const c = vcf::make_call_based_on_coverage(0, svs.at(static_cast<std::size_t>(sv_index)), rd);
+      out[0] = c.coverage[0];
+      out[1] = c.coverage[1];
+      out[2] = c.phred[0];
+      out[3] = c.phred[1];
+      out[4] = c.phred[2];
+      return 0;
+    }
+    catch (std::exception const & e)
+    {
+      g_error = e.what();
+      return 1;
+    }
   }
 
   uint16_t gto_binned_pl(unsigned pl) { return vcf::binned_pl(pl); }

@@ -1,0 +1,640 @@
+// gto_sv.hpp -- TEST INFRASTRUCTURE (part of the oracle): SV post-processing of the calls of an SV graph, restated from
+// the reference function by function.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it;
+// the product (graphtyper_amd/csrc/gtx_vcf.cpp) has its own implementation.
+//
+//   SV / SV table                       include/graphtyper/graph/sv.hpp:14-63, src/graph/sv.cpp:20-77
+//   make_bi_allelic_call                src/typer/sample_call.cpp:189-253
+//   make_call_based_on_coverage         src/typer/sample_call.cpp:255-385
+//   reformat_sv_vcf_records             src/graph/sv.cpp:117-655
+//   Variant::normalize & helpers        src/typer/variant.cpp:1120-1318, include/graphtyper/utilities/sequence_operations.hpp
+//   the SV branch of the pool's writer  src/utilities/hts_parallel_reader.cpp:984-1020 (add_haplotype per haplotype ->
+//                                       reformat_sv_vcf_records -> sort -> stats.clear())
+//   the merge of genotype_sv            src/utilities/genotype_sv.cpp:125 -> vcf_merge_and_break(force_no_break_down = true),
+//                                       src/typer/vcf_operations.cpp:480-700: normalize -> generate_infos -> drop when every alt is bad
+//   Vcf::write_records                  src/typer/vcf.cpp:1161-1275 (order, duplicates, the ".<n>" ID suffix)
+//
+// Parity unpinned: the reference holds no test and no golden output for this path (its own SV tests are commented out).
+// Not restated: the site that mixes SV and non-SV alleles (find_variant_sequences, variant.cpp:1880-2240) -- records() throws.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <sstream>
+#include <stdexcept>
+#include <unordered_map>
+
+#include "gto_vcf.hpp"
+
+namespace gto
+{
+namespace vcf
+{
+enum SVTYPE { NOT_SV = 0, DEL, DEL_ALU, DUP, INS, INS_ALU, INV, BND, OTHER };
+enum INVTYPE { NOT_INV = 0, INV3, INV5, BOTH_BREAKPOINTS };
+
+struct SV // sv.hpp:36-63
+{
+  SVTYPE type = NOT_SV;
+  std::string chrom;
+  int32_t begin = 0, length = 0, size = 0, end = 0, n_clusters = 0, num_merged_svs = -1, or_start = -1, or_end = -1, related_sv = -1;
+  std::string model = "AGGREGATED", old_variant_id;
+  INVTYPE inv_type = NOT_INV;
+  std::string seq, hom_seq, ins_seq, ins_seq_left, ins_seq_right, original_alt;
+
+  std::string get_type() const // sv.cpp:20-49
+  {
+    switch (type)
+    {
+    case DEL: return "DEL";
+    case DEL_ALU: return "DEL:ME:ALU";
+    case DUP: return "DUP";
+    case INS: return "INS";
+    case INS_ALU: return "INS:ME:ALU";
+    case INV: return "INV";
+    case BND: return "BND";
+    default: return "SV";
+    }
+  }
+  std::string get_allele() const // sv.cpp:51-64
+  {
+    std::ostringstream ss;
+    ss << '<' << get_type() << ":SVSIZE=";
+    if (size > 0)
+      ss << size;
+    else
+      ss << (ins_seq_left.size() + ins_seq_right.size()) << "+";
+    ss << '>';
+    return ss.str();
+  }
+};
+
+// The SV table as text, one SV per line, tab separated (tests/sv_constructor.py writes it for the oracle, gtx_graph_sv_table for
+// the product): type chrom begin length size end n_clusters num_merged_svs or_start or_end related_sv model old_variant_id
+// inv_type seq hom_seq ins_seq ins_seq_left ins_seq_right original_alt ("." = empty)
+inline std::vector<SV> parse_sv_table(std::string const & text)
+{
+  std::vector<SV> out;
+  std::stringstream ss(text);
+  std::string line;
+  while (std::getline(ss, line))
+  {
+    if (line.empty())
+      continue;
+    std::vector<std::string> f;
+    std::stringstream ls(line);
+    std::string tok;
+    while (std::getline(ls, tok, '\t'))
+      f.push_back(tok == "." ? std::string() : tok);
+    if (f.size() != 20)
+      throw std::runtime_error("SV table: a line has " + std::to_string(f.size()) + " fields, 20 expected");
+    SV sv;
+    static char const * const names[] = {"NOT_SV", "DEL", "DEL_ALU", "DUP", "INS", "INS_ALU", "INV", "BND", "OTHER"};
+    int t = -1;
+    for (int k = 0; k < 9; ++k)
+      if (f[0] == names[k])
+        t = k;
+    if (t < 0)
+      throw std::runtime_error("SV table: unknown type " + f[0]);
+    sv.type = static_cast<SVTYPE>(t);
+    sv.chrom = f[1];
+    sv.begin = std::stoi(f[2]);
+    sv.length = std::stoi(f[3]);
+    sv.size = std::stoi(f[4]);
+    sv.end = std::stoi(f[5]);
+    sv.n_clusters = std::stoi(f[6]);
+    sv.num_merged_svs = std::stoi(f[7]);
+    sv.or_start = std::stoi(f[8]);
+    sv.or_end = std::stoi(f[9]);
+    sv.related_sv = std::stoi(f[10]);
+    sv.model = f[11];
+    sv.old_variant_id = f[12];
+    sv.inv_type = f[13] == "INV3" ? INV3 : f[13] == "INV5" ? INV5 : f[13] == "BOTH" ? BOTH_BREAKPOINTS : NOT_INV;
+    sv.seq = f[14];
+    sv.hom_seq = f[15];
+    sv.ins_seq = f[16];
+    sv.ins_seq_left = f[17];
+    sv.ins_seq_right = f[18];
+    sv.original_alt = f[19];
+    out.push_back(std::move(sv));
+  }
+  return out;
+}
+
+inline long to_index(long x, long y) { return x + (y + 1) * y / 2; } // graph_help_functions.hpp
+
+inline SampleCall make_bi_allelic_call(SampleCall const & oc, long aa) // sample_call.cpp:189-253
+{
+  if (oc.coverage.size() == 2)
+    return oc;
+  SampleCall c;
+  c.coverage.push_back(oc.coverage[0]);
+  c.ambiguous_depth = oc.ambiguous_depth;
+  c.ref_total_depth = oc.ref_total_depth;
+  c.alt_total_depth = oc.alt_total_depth;
+  c.alt_proper_pair_depth = oc.alt_proper_pair_depth;
+  int32_t ambiguous_depth_alt = c.coverage[0] + c.ambiguous_depth - c.ref_total_depth;
+  ambiguous_depth_alt = std::min(static_cast<int32_t>(c.ambiguous_depth), ambiguous_depth_alt);
+  c.ambiguous_depth -= ambiguous_depth_alt;
+  int cov_aa = c.alt_total_depth - c.ambiguous_depth;
+  for (long a = 1; a < static_cast<long>(oc.coverage.size()); ++a)
+  {
+    if (a == aa + 1)
+      continue;
+    cov_aa -= static_cast<int>(oc.coverage[a]);
+    c.alt_total_depth = static_cast<uint16_t>(std::max(0, static_cast<int>(c.alt_total_depth) - static_cast<int>(oc.coverage[a])));
+    c.alt_proper_pair_depth = static_cast<uint8_t>(std::max(0, static_cast<int>(c.alt_proper_pair_depth) - static_cast<int>(oc.coverage[a])));
+  }
+  c.coverage.push_back(static_cast<unsigned short>(std::max(cov_aa, 0)));
+  int32_t const alt_not_proper = c.coverage[1] > c.alt_proper_pair_depth ? c.coverage[1] - c.alt_proper_pair_depth : 0;
+  int32_t const alt_proper = c.coverage[1] - alt_not_proper;
+  c.phred.resize(3, 0);
+  uint64_t constexpr ERROR_PHRED_PROPER = 24, ERROR_PHRED_NOT_PROPER = 12;
+  uint64_t const gt_00 = alt_proper * ERROR_PHRED_PROPER + alt_not_proper * ERROR_PHRED_NOT_PROPER;
+  uint64_t const gt_01 = static_cast<uint64_t>(3ul * (c.coverage[0] + static_cast<uint64_t>(c.coverage[1])));
+  uint64_t const gt_11 = c.coverage[0] * ERROR_PHRED_PROPER;
+  uint64_t const min_gt = std::min(gt_00, std::min(gt_01, gt_11));
+  c.phred[0] = static_cast<uint8_t>(std::min(static_cast<uint64_t>(0xFFu), gt_00 - min_gt));
+  c.phred[1] = static_cast<uint8_t>(std::min(static_cast<uint64_t>(0xFFu), gt_01 - min_gt));
+  c.phred[2] = static_cast<uint8_t>(std::min(static_cast<uint64_t>(0xFFu), gt_11 - min_gt));
+  return c;
+}
+
+inline uint16_t get_uint16(long val) { return static_cast<uint16_t>(std::max(0l, std::min(0xFFFFl, val))); } // sample_call.cpp:18-21
+
+template <class V>
+typename V::value_type median(V & vec) // sample_call.cpp:23-28 (an empty vector is undefined there; callers here never have one)
+{
+  if (vec.empty())
+    throw std::runtime_error("median of nothing: the SV is too short for the coverage model");
+  std::nth_element(vec.begin(), vec.begin() + vec.size() / 2, vec.end());
+  return vec[vec.size() / 2];
+}
+
+inline SampleCall make_call_based_on_coverage(long pn_index, SV const & sv, ReferenceDepth const & reference_depth) // sample_call.cpp:255-385
+{
+  SampleCall call;
+  long const abs_begin = sv.begin;
+  long const abs_end = sv.size < 190000 ? abs_begin + sv.size : abs_begin + 190000;
+  long constexpr N = 101, M = 20;
+  std::vector<uint16_t> depths_in, depths_out;
+  auto depth_at = [&](long abs_pos) -> uint16_t // ReferenceDepth::get_read_depth(uint32_t, long), reference_depth.cpp:59-76
+  {
+    auto const & depth = reference_depth.depths[pn_index];
+    if (depth.empty())
+      return 0;
+    long const index = std::min(reference_depth.start_pos_to_index(static_cast<uint32_t>(abs_pos)), static_cast<long>(depth.size()) - 1l);
+    return depth[index];
+  };
+  {
+    long const size = abs_end - abs_begin;
+    long N_in = std::min(N, size - 2 * M);
+    if (N_in % 2 == 0)
+      --N_in;
+    for (long i = 1; i <= N_in; ++i)
+      depths_in.push_back(depth_at((i * (size - 2 * M)) / (N_in + 1) + abs_begin + M));
+  }
+  for (long i = 1; i <= N / 2 + 1; ++i)
+    depths_out.push_back(depth_at(std::max(abs_begin - i * M, 0l)));
+  if (sv.size < 190000)
+    for (long i = 1; i <= N / 2; ++i)
+      depths_out.push_back(depth_at(std::max(abs_end + i * M, 0l)));
+  long const median_out = median(depths_out), median_in = median(depths_in);
+  uint64_t const ERROR = 12;
+  if (sv.type == DEL || sv.type == DEL_ALU)
+  {
+    call.coverage.push_back(get_uint16(median_in));
+    call.coverage.push_back(get_uint16(median_out - median_in));
+  }
+  else if (sv.type == DUP || sv.type == INV)
+  {
+    double const cmed = static_cast<double>(median_out + median_in) / 2.0;
+    long const dmed = median_in - median_out;
+    if (dmed <= 0)
+    {
+      call.coverage.push_back(get_uint16(std::lround(cmed)));
+      call.coverage.push_back(0);
+    }
+    else if (dmed >= 2 * median_in)
+    {
+      call.coverage.push_back(0);
+      call.coverage.push_back(get_uint16(std::lround(cmed)));
+    }
+    else
+    {
+      double const frac = static_cast<double>(dmed) / static_cast<double>(median_out);
+      call.coverage.push_back(get_uint16(std::lround((1.0 - frac) * cmed)));
+      call.coverage.push_back(get_uint16(static_cast<long>(cmed - call.coverage[0])));
+    }
+  }
+  else
+    throw std::runtime_error("coverage model: only deletions, duplications and inversions");
+  uint64_t gt_00 = call.coverage[1] * ERROR, gt_01 = static_cast<uint64_t>(3 * (call.coverage[0] + call.coverage[1])), gt_11 = call.coverage[0] * ERROR;
+  {
+    uint64_t const min_gt = std::min(gt_00, std::min(gt_01, gt_11));
+    gt_00 -= min_gt;
+    gt_01 -= min_gt;
+    gt_11 -= min_gt;
+  }
+  if (sv.size <= 100)
+  {
+    gt_00 = (gt_00 * 2) / 3;
+    gt_01 = (gt_01 * 2) / 3;
+    gt_11 = (gt_11 * 2) / 3;
+  }
+  else if (sv.size > 1000) // (the "> 10000" branch behind it is unreachable in the reference as well)
+  {
+    gt_00 = (gt_00 * 3) / 2;
+    gt_01 = (gt_01 * 3) / 2;
+    gt_11 = (gt_11 * 3) / 2;
+  }
+  call.phred.resize(3, 0);
+  call.phred[0] = static_cast<uint8_t>(std::min(static_cast<uint64_t>(0xFFu), gt_00));
+  call.phred[1] = static_cast<uint8_t>(std::min(static_cast<uint64_t>(0xFFu), gt_01));
+  call.phred[2] = static_cast<uint8_t>(std::min(static_cast<uint64_t>(0xFFu), gt_11));
+  return call;
+}
+
+// ---- sequence_operations.hpp:9-85
+inline void remove_common_prefix(uint32_t & pos, std::vector<std::string> & seqs, bool keep_one_match)
+{
+  if (seqs.size() <= 1 || seqs[0].size() <= 1)
+    return;
+  while (seqs[0].size() > 1)
+  {
+    for (std::size_t a = 1; a < seqs.size(); ++a)
+      if (seqs[a].size() <= 1 || seqs[a][0] != seqs[0][0] || (keep_one_match && seqs[a][1] != seqs[0][1]))
+        return;
+    ++pos;
+    for (auto & s : seqs)
+      s.erase(s.begin());
+  }
+}
+
+inline void remove_common_suffix(std::vector<std::string> & seqs)
+{
+  if (seqs.size() <= 1 || seqs[0].size() <= 1)
+    return;
+  while (seqs[0].size() > 1)
+  {
+    for (std::size_t a = 1; a < seqs.size(); ++a)
+      if (seqs[a].size() <= 1 || seqs[a].back() != seqs[0].back())
+        return;
+    for (auto & s : seqs)
+      s.pop_back();
+  }
+}
+
+// Graph::get_generated_reference_genome (graph.cpp:409-435) over one contig: `reference` starts at 1-based position first_pos
+struct RegionReference
+{
+  std::string reference;
+  uint32_t first_pos = 1;
+  std::string get(uint32_t & from, uint32_t & to) const
+  {
+    from = std::max(first_pos, from);
+    to = std::min(static_cast<uint32_t>(first_pos + reference.size()), to);
+    if (to < from)
+      return std::string();
+    return reference.substr(from - first_pos, to - from);
+  }
+};
+
+inline bool add_base_in_front(Variant & v, RegionReference const & rr, bool add_N = false) // variant.cpp:1135-1171
+{
+  uint32_t contig_pos = v.abs_pos, new_contig_pos = contig_pos - 1;
+  uint32_t const contig_pos_cp = contig_pos;
+  std::string first_base = rr.get(new_contig_pos, contig_pos);
+  if (first_base.size() != 1 || contig_pos_cp != contig_pos || new_contig_pos != contig_pos - 1)
+    return false;
+  bool const is_not_ACGT = first_base[0] != 'A' && first_base[0] != 'C' && first_base[0] != 'G' && first_base[0] != 'T';
+  if (!add_N && is_not_ACGT)
+    return false;
+  if (add_N && is_not_ACGT)
+    first_base[0] = 'N';
+  for (auto & seq : v.seqs)
+    if (seq.size() == 0 || seq.size() > 1 || seq[0] != '*')
+      seq.insert(seq.begin(), first_base[0]);
+  --v.abs_pos;
+  return true;
+}
+
+inline long normalize(Variant & v, RegionReference const & rr) // variant.cpp:1256-1315
+{
+  if (v.seqs.size() < 2)
+    return 0;
+  for (std::size_t i = 0; i < v.seqs.size(); ++i)
+  {
+    auto const & seq = v.seqs[i];
+    if (seq.empty() || seq[0] != v.seqs[0][0] || (i > 0 && seq == v.seqs[0]))
+      return 0;
+  }
+  remove_common_suffix(v.seqs);
+  auto all_last_bases_match = [&]()
+  {
+    for (std::size_t i = 1; i < v.seqs.size(); ++i)
+      if (v.seqs[i].back() != v.seqs[0].back())
+        return false;
+    return true;
+  };
+  long distance = 0;
+  while (all_last_bases_match())
+  {
+    if (!add_base_in_front(v, rr))
+      break;
+    ++distance;
+    remove_common_suffix(v.seqs);
+  }
+  remove_common_prefix(v.abs_pos, v.seqs, false);
+  return distance;
+}
+
+// reformat_sv_vcf_records (sv.cpp:117-655).  `svs` is Graph::SVs; positions are on one contig, so
+// absolute_pos.get_absolute_position(sv.chrom, sv.begin) is sv.begin.
+inline void reformat_sv_vcf_records(std::vector<Variant> & variants, std::vector<SV> const & svs, ReferenceDepth const & reference_depth, bool is_sv_graph)
+{
+  long const variants_original_size = static_cast<long>(variants.size());
+  std::vector<char> erase(variants.size(), 0);
+  std::unordered_map<int32_t, int32_t> related_svs;
+  std::vector<Variant> new_vars;
+
+  auto make_variant_with_combined_calls = [&](Variant const & var1, Variant const & var2) -> Variant // :232-308
+  {
+    Variant combined_var(var1);
+    for (long i = 0; i < static_cast<long>(var1.calls.size()); ++i)
+    {
+      auto & combined_call = combined_var.calls[i];
+      auto const & var2_call = var2.calls[i];
+      auto const gt_call2 = var2_call.get_gt_call();
+      auto const gt_call1 = combined_call.get_gt_call();
+      long const gq1 = var2_call.get_gq(), gq2 = combined_call.get_gq();
+      long max_gq = gq1, min_gq = gq2;
+      uint32_t const dp1 = combined_call.get_unique_depth();
+      if (gq1 > gq2)
+      {
+        combined_call = var2_call;
+        max_gq = gq1;
+        min_gq = gq2;
+      }
+      if (var1.calls[i].filter > 0 && var2.calls[i].filter > 0)
+        combined_call.filter = 3;
+      else if (var1.calls[i].filter > 0)
+        combined_call.filter = var1.calls[i].filter;
+      else if (var2.calls[i].filter > 0)
+        combined_call.filter = var2.calls[i].filter;
+      else if (dp1 >= 10u && var2_call.get_unique_depth() >= 10u)
+      {
+        auto const final_gt_call = combined_call.get_gt_call();
+        long const index = to_index(final_gt_call.first, final_gt_call.second);
+        if ((final_gt_call == gt_call1 && final_gt_call == gt_call2) && min_gq > 10)
+          combined_call.filter = 0;
+        else if (max_gq > 40 && (var1.calls[i].phred[index] + var2.calls[i].phred[index]) <= 20)
+          combined_call.filter = 0;
+        else if (max_gq > 30)
+          combined_call.filter = 1;
+        else
+          combined_call.filter = 2;
+      }
+      else
+        combined_call.filter = 3;
+    }
+    combined_var.stats = VarStats(); // stats.clear()
+    combined_var.generate_infos(is_sv_graph);
+    return combined_var;
+  };
+
+  auto add_sv_to_new_vars_vector = [&new_vars](Variant && var, SV const & sv, std::string const & model) // :310-391
+  {
+    if (sv.type != BND && !model.empty())
+    {
+      std::string & an = var.seqs[1];
+      an[an.size() - 1] = ':';
+      an += model;
+      an.push_back('>');
+    }
+    else if (sv.type == BND)
+      var.seqs[1] = sv.original_alt;
+    var.infos["SVTYPE"] = sv.get_type();
+    var.infos["END"] = std::to_string(sv.end < sv.begin ? sv.begin : sv.end);
+    if (sv.length != 0)
+    {
+      var.infos["SVSIZE"] = std::to_string(sv.size);
+      var.infos["SVLEN"] = std::to_string(sv.length);
+    }
+    if (model.size() > 0)
+      var.infos["SVMODEL"] = model;
+    if (sv.or_start != -1)
+    {
+      var.infos["ORSTART"] = std::to_string(sv.or_start);
+      var.infos["OREND"] = std::to_string(sv.or_end);
+    }
+    if (sv.seq.size() > 0)
+      var.infos["SEQ"] = sv.seq;
+    if (sv.n_clusters > 0)
+      var.infos["NCLUSTERS"] = std::to_string(sv.n_clusters);
+    if (sv.num_merged_svs >= 0)
+      var.infos["NUM_MERGED_SVS"] = std::to_string(sv.num_merged_svs);
+    if (sv.old_variant_id.size() > 0 && sv.old_variant_id != ".")
+      var.infos["OLD_VARIANT_ID"] = sv.old_variant_id;
+    if (sv.hom_seq.size() > 0)
+      var.infos["HOMSEQ"] = sv.hom_seq;
+    if (sv.ins_seq.size() > 0)
+      var.infos["SVINSSEQ"] = sv.ins_seq;
+    if (sv.ins_seq_left.size() > 0)
+      var.infos["LEFT_SVINSSEQ"] = sv.ins_seq_left;
+    if (sv.ins_seq_right.size() > 0)
+      var.infos["RIGHT_SVINSSEQ"] = sv.ins_seq_right;
+    if (sv.type == INV && sv.inv_type != NOT_INV)
+    {
+      if (sv.inv_type == INV3 || sv.inv_type == BOTH_BREAKPOINTS)
+        var.infos["INV3"] = "";
+      if (sv.inv_type == INV5 || sv.inv_type == BOTH_BREAKPOINTS)
+        var.infos["INV5"] = "";
+    }
+    new_vars.push_back(std::move(var));
+  };
+
+  for (long v = 0; v < variants_original_size; ++v)
+  {
+    Variant const & var = variants[v];
+    std::vector<long> sv_ids(var.seqs.size() - 1, -1l);
+    for (long a = 1; a < static_cast<long>(var.seqs.size()); ++a) // :130-150: "<SV:0000007>"
+    {
+      auto const & seq = var.seqs[a];
+      auto const at = seq.find('<');
+      if (at != std::string::npos && seq.size() - at > 11)
+      {
+        long const sv_id = std::stol(seq.substr(at + 4, 7));
+        if (sv_id < 0 || sv_id >= static_cast<long>(svs.size()))
+          throw std::runtime_error("an SV tag names SV " + std::to_string(sv_id) + " of " + std::to_string(svs.size()));
+        sv_ids[a - 1] = sv_id;
+      }
+    }
+    if (std::find_if(sv_ids.begin(), sv_ids.end(), [](long id) { return id != -1; }) == sv_ids.end())
+      continue;
+
+    auto make_new_sv_var = [&](Variant const & old_var, long aa) -> Variant // :176-230
+    {
+      Variant new_var;
+      new_var.abs_pos = old_var.abs_pos;
+      new_var.seqs.push_back(old_var.seqs[0]);
+      new_var.seqs.push_back(old_var.seqs[aa + 1]);
+      new_var.infos = old_var.infos;
+      new_var.stats = old_var.stats;
+      new_var.stats.per_allele[1] = old_var.stats.per_allele[aa + 1];
+      new_var.stats.read_strand[1] = old_var.stats.read_strand[aa + 1];
+      new_var.stats.per_allele.resize(2);
+      new_var.stats.read_strand.resize(2);
+      for (auto const & call : old_var.calls)
+        new_var.calls.push_back(make_bi_allelic_call(call, aa));
+      SV const & sv = svs[sv_ids[aa]];
+      if (sv.n_clusters > 0)
+        new_var.infos["NCLUSTERS"] = std::to_string(sv.n_clusters);
+      if (sv.num_merged_svs > 0)
+        new_var.infos["NUM_MERGED_SVS"] = std::to_string(sv.num_merged_svs);
+      new_var.infos["SV_ID"] = std::to_string(sv_ids[aa]);
+      if (sv.related_sv >= 0)
+        new_var.infos["RELATED_SV_ID"] = std::to_string(sv.related_sv);
+      new_var.abs_pos = static_cast<uint32_t>(sv.begin);
+      return new_var;
+    };
+
+    bool is_any_not_sv = false;
+    for (long aa = 0; aa < static_cast<long>(sv_ids.size()); ++aa)
+    {
+      if (sv_ids[aa] == -1l)
+      {
+        is_any_not_sv = true;
+        continue;
+      }
+      // add_sv_variant (:393-510)
+      Variant new_sv_var = make_new_sv_var(var, aa);
+      SV const & sv = svs[sv_ids[aa]];
+      if (sv.type != BND)
+      {
+        new_sv_var.seqs[0] = "N";
+        new_sv_var.seqs[1] = sv.get_allele();
+      }
+      if (sv.type == DUP && (sv.model == "BREAKPOINT1" || sv.model == "BREAKPOINT2"))
+        for (auto & call : new_sv_var.calls)
+        {
+          uint64_t constexpr ERROR = 25;
+          double constexpr minus_10log10_one_third = 4.77121255, minus_10log10_two_third = 1.76091259;
+          uint64_t gt_00 = call.coverage[1] * ERROR;
+          uint64_t gt_01 = static_cast<uint64_t>(0.499999999 + minus_10log10_one_third * static_cast<double>(call.coverage[1]) +
+                                                 minus_10log10_two_third * static_cast<double>(call.coverage[0]));
+          uint64_t gt_11 = 3ul * (call.coverage[0] + static_cast<uint64_t>(call.coverage[1]));
+          uint64_t const min_gt = std::min(gt_00, std::min(gt_01, gt_11));
+          call.phred[0] = static_cast<uint8_t>(std::min(static_cast<uint64_t>(0xFFu), gt_00 - min_gt));
+          call.phred[1] = static_cast<uint8_t>(std::min(static_cast<uint64_t>(0xFFu), gt_01 - min_gt));
+          call.phred[2] = static_cast<uint8_t>(std::min(static_cast<uint64_t>(0xFFu), gt_11 - min_gt));
+        }
+      if ((sv.type == INS || sv.type == INV) && related_svs.count(static_cast<int32_t>(sv_ids[aa])) == 1)
+      {
+        Variant const var_bp1 = new_vars[related_svs.at(static_cast<int32_t>(sv_ids[aa]))]; // (a copy: new_vars grows below)
+        add_sv_to_new_vars_vector(make_variant_with_combined_calls(new_sv_var, var_bp1), sv, "AGGREGATED");
+      }
+      if (is_sv_graph)
+      {
+        if (sv.type == DEL || sv.type == DEL_ALU)
+        {
+          Variant cov_var(new_sv_var);
+          for (long pn = 0; pn < static_cast<long>(cov_var.calls.size()); ++pn)
+            cov_var.calls[pn] = make_call_based_on_coverage(pn, sv, reference_depth);
+          add_sv_to_new_vars_vector(make_variant_with_combined_calls(new_sv_var, cov_var), sv, "AGGREGATED");
+          add_sv_to_new_vars_vector(std::move(cov_var), sv, "COVERAGE");
+        }
+        else if (sv.type == DUP && related_svs.count(static_cast<int32_t>(sv_ids[aa])) == 1)
+        {
+          Variant cov_var(new_sv_var);
+          for (long pn = 0; pn < static_cast<long>(cov_var.calls.size()); ++pn)
+            cov_var.calls[pn] = make_call_based_on_coverage(pn, sv, reference_depth);
+          Variant combined_var = make_variant_with_combined_calls(new_sv_var, cov_var);
+          Variant const other_bp_variant = new_vars[related_svs.at(static_cast<int32_t>(sv_ids[aa]))];
+          add_sv_to_new_vars_vector(make_variant_with_combined_calls(combined_var, other_bp_variant), sv, "AGGREGATED");
+          add_sv_to_new_vars_vector(std::move(cov_var), sv, "COVERAGE");
+        }
+        else if (sv.type == BND && new_sv_var.seqs[1].size() > 1 && new_sv_var.seqs[1][1] == '<')
+          throw std::runtime_error("breakend alleles that start with a tag (add_base_in_back, sv.cpp:497-502) are not restated");
+      }
+      if (sv.related_sv != -1)
+        related_svs[static_cast<int32_t>(sv.related_sv)] = static_cast<int32_t>(new_vars.size());
+      add_sv_to_new_vars_vector(std::move(new_sv_var), sv, sv.model);
+    }
+    if (is_any_not_sv)
+      throw std::runtime_error("a site with SV and non-SV alleles (find_variant_sequences, variant.cpp:1880-2240) is not restated");
+    erase[v] = 1;
+  }
+  for (long v = 0; v < variants_original_size; ++v)
+    if (!erase[v])
+      new_vars.push_back(std::move(variants[v]));
+  variants = std::move(new_vars);
+}
+
+// The VCF text of an SV graph's calls: what the pool's writer and the merge of genotype_sv make of the haplotypes (see the header).
+inline std::string records_sv(Genotyper const & g, WriteOptions const & o, std::vector<SV> const & svs, RegionReference const & rr, bool no_filter_bad_alts = false)
+{
+  std::vector<Variant> variants = haplotype_variants(g, o); // Vcf::add_haplotype per haplotype
+  reformat_sv_vcf_records(variants, svs, g.reference_depth, g.graph.is_sv_graph);
+  std::sort(variants.begin(), variants.end(), [](Variant const & a, Variant const & b) { return a.abs_pos < b.abs_pos || (a.abs_pos == b.abs_pos && a.seqs < b.seqs); });
+  for (auto & v : variants)
+    v.stats = VarStats();
+  // vcf_merge_and_break with force_no_break_down (one pool: nothing to add up)
+  std::vector<Variant> out_vars;
+  for (auto & v : variants)
+  {
+    if (normalize(v, rr) > 200)
+      continue;
+    std::vector<int8_t> const is_good_alt = v.generate_infos(g.graph.is_sv_graph);
+    if (!no_filter_bad_alts && std::all_of(is_good_alt.begin(), is_good_alt.end(), [](int8_t x) { return x == 0; }))
+      continue;
+    out_vars.push_back(std::move(v));
+  }
+  std::ostringstream out;
+  write_column_line(out, o);
+  if (out_vars.empty())
+    return out.str();
+  // Vcf::write_records (vcf.cpp:1161-1275); Variant::type is '.' on every variant of this path
+  std::vector<long> idx(out_vars.size());
+  for (std::size_t i = 0; i < idx.size(); ++i)
+    idx[i] = static_cast<long>(i);
+  auto const & vars = out_vars;
+  std::sort(idx.begin(), idx.end(), [&](long i, long j)
+  {
+    Variant const & a = vars[i];
+    Variant const & b = vars[j];
+    if (a.abs_pos != b.abs_pos)
+      return a.abs_pos < b.abs_pos;
+    int const a_vt = static_cast<int>(a.seqs[0].size() > a.seqs[1].size()) + 2 * static_cast<int>(a.seqs[0].size() == a.seqs[1].size());
+    int const b_vt = static_cast<int>(b.seqs[0].size() > b.seqs[1].size()) + 2 * static_cast<int>(b.seqs[0].size() == b.seqs[1].size());
+    if (a_vt != b_vt)
+      return a_vt < b_vt;
+    return a.seqs < b.seqs || (a.seqs == b.seqs && a.infos.size() > b.infos.size());
+  });
+  auto inside = [&](uint32_t pos) { return pos >= o.region_begin && pos <= o.region_end; };
+  if (inside(vars[idx[0]].abs_pos))
+    write_record(out, vars[idx[0]], o, g.graph.is_sv_graph, "");
+  long dup = -1;
+  for (std::size_t i = 1; i < idx.size(); ++i)
+  {
+    Variant const & prev = vars[idx[i - 1]];
+    Variant const & curr = vars[idx[i]];
+    if (curr.abs_pos > o.region_end)
+      break;
+    if (curr.abs_pos < o.region_begin)
+      continue;
+    if (curr.abs_pos == prev.abs_pos && curr.seqs == prev.seqs)
+      continue;
+    if (!(curr.abs_pos == prev.abs_pos && curr.determine_variant_type() == prev.determine_variant_type()))
+    {
+      write_record(out, curr, o, g.graph.is_sv_graph, "");
+      dup = -1;
+    }
+    else
+    {
+      ++dup;
+      write_record(out, curr, o, g.graph.is_sv_graph, "." + std::to_string(dup));
+    }
+  }
+  return out.str();
+}
+} // namespace vcf
+} // namespace gto

@@ -463,10 +463,12 @@ struct Variant
     }
   }
 
-  void generate_infos(bool is_sv_graph) // variant.cpp:430-1096
+  // returns is_good_alt (one flag per alternative allele)
+  std::vector<int8_t> generate_infos(bool is_sv_graph) // variant.cpp:430-1096
   {
     long const num_seqs = static_cast<long>(seqs.size());
     long const num_alts = num_seqs - 1;
+    std::vector<int8_t> is_good_alt(static_cast<std::size_t>(num_alts), 1);
     bool const is_stats = !stats.per_allele.empty();
     if (is_stats)
     {
@@ -480,6 +482,11 @@ struct Variant
       scan_calls();
     }
     infos["RefLen"] = std::to_string(seqs[0].size());
+    {
+      auto const end_it = infos.find("END"); // variant.cpp:467-481: END is never in front of POS (one contig: abs_pos is the position)
+      if (end_it != infos.end())
+        end_it->second = std::to_string(std::max(std::strtol(end_it->second.c_str(), nullptr, 10), static_cast<long>(abs_pos)));
+    }
     auto const & pa = stats.per_allele;
     {
       std::stringstream ss;
@@ -664,10 +671,12 @@ struct Variant
     {
       for (char const * k : {"ABHetMulti", "ABHomMulti", "CR", "QDalt", "MQ", "MQsquared", "SB", "SBAlt", "SBF", "SBR", "SBF1", "SBF2", "SBR1", "SBR2"})
         infos.erase(k);
-      return;
+      for (long a = 1; a < num_seqs; ++a)
+        is_good_alt[a - 1] = static_cast<int8_t>(pa[a].ac > 0);
+      return is_good_alt;
     }
     if (!is_stats)
-      return;
+      return is_good_alt;
     {
       std::ostringstream sd, mm, cr, mq;
       for (long s = 1; s < num_seqs; ++s)
@@ -754,6 +763,20 @@ struct Variant
       ss << logf;
       infos["LOGF"] = ss.str();
     }
+    for (long a = 0; a < num_alts; ++a) // variant.cpp:1036-1063
+    {
+      auto const & per_al = pa[a + 1];
+      if (per_al.total_depth == 0)
+      {
+        is_good_alt[a] = 0;
+        continue;
+      }
+      double const qd = qd_alt[a];
+      is_good_alt[a] = static_cast<int8_t>(qd >= 1.0 && per_al.maximum_alt_support >= 2 &&
+                                           (seqs.size() < 71 || (qd >= 1.5 && per_al.maximum_alt_support_ratio >= 0.2)) &&
+                                           (seqs.size() < 131 || (qd >= 2.0 && per_al.maximum_alt_support_ratio >= 0.225)));
+    }
+    return is_good_alt;
   }
 };
 
@@ -766,7 +789,8 @@ struct WriteOptions
   std::string variant_suffix_id;
 };
 
-inline void write_record(std::ostream & out, Variant const & var, WriteOptions const & o, bool is_sv_graph) // vcf.cpp:767-1149
+// `suffix`: what Vcf::write_records puts behind the ID of a record that shares position and type with the one in front of it
+inline void write_record(std::ostream & out, Variant const & var, WriteOptions const & o, bool is_sv_graph, std::string const & suffix = std::string()) // vcf.cpp:767-1149
 {
   (void)is_sv_graph;
   if (!var.calls.empty() && var.seqs.size() > 80)
@@ -787,6 +811,7 @@ inline void write_record(std::ostream & out, Variant const & var, WriteOptions c
   out << o.contig << '\t' << var.abs_pos << '\t' << o.contig << ':' << var.abs_pos << ':' << var.determine_variant_type();
   if (!var.suffix_id.empty())
     out << "[" << var.suffix_id << "]";
+  out << suffix;
   out << '\t' << var.seqs[0] << '\t' << var.seqs[1];
   for (std::size_t a = 2; a < var.seqs.size(); ++a)
     out << ',' << var.seqs[a];
@@ -924,9 +949,8 @@ inline void write_record(std::ostream & out, Variant const & var, WriteOptions c
 
 // the records of every variant site of the genotyper's graph (Vcf::add_haplotype per haplotype, generate_infos, the region
 // filter of write_records), after a column line
-inline std::string records(Genotyper const & g, WriteOptions const & o)
+inline void write_column_line(std::ostream & out, WriteOptions const & o)
 {
-  std::ostringstream out;
   out << "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO";
   if (!o.sample_names.empty())
   {
@@ -935,6 +959,12 @@ inline std::string records(Genotyper const & g, WriteOptions const & o)
       out << '\t' << s;
   }
   out << '\n';
+}
+
+// Vcf::add_haplotype (vcf.cpp:1507-1611) for every haplotype of the genotyper: one Variant per variant site
+inline std::vector<Variant> haplotype_variants(Genotyper const & g, WriteOptions const & o)
+{
+  std::vector<Variant> out;
   auto const calls = g.sample_calls();
   for (std::size_t h = 0; h < g.writer.haplotypes.size(); ++h)
   {
@@ -966,6 +996,17 @@ inline std::string records(Genotyper const & g, WriteOptions const & o)
       var.calls.push_back(std::move(sc));
     }
     var.suffix_id = o.variant_suffix_id;
+    out.push_back(std::move(var));
+  }
+  return out;
+}
+
+inline std::string records(Genotyper const & g, WriteOptions const & o)
+{
+  std::ostringstream out;
+  write_column_line(out, o);
+  for (Variant & var : haplotype_variants(g, o))
+  {
     var.generate_infos(g.graph.is_sv_graph);
     if (var.abs_pos < o.region_begin || var.abs_pos > o.region_end)
       continue;

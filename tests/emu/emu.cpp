@@ -213,6 +213,7 @@ extern "C"
       ix.half_bucket_cap = static_cast<uint32_t>(std::atol(cap));
     auto ws = std::make_unique<AlignWorkspace>();
     auto big_ws = std::make_unique<big::AlignWorkspace>();
+    std::vector<uint32_t> big_keys(2 * big::AlignCfg::MAXPP, 0xABABABABu), wide_keys(2 * wide::AlignCfg::MAXPP, 0xABABABABu);
     bool const second_pass = !e.params.no_second_pass;
     char const * fe = std::getenv("GTX_FORCE_SECOND_PASS"); // 1: every task through all passes, 2: every task done by pass 2
     int const force = fe ? std::atoi(fe) : 0;
@@ -299,6 +300,8 @@ extern "C"
       // (gtx_align_wide_kernel) for the tasks that met an allele number >= 64
       ++e.second_pass_tasks;
       std::memset(static_cast<void *>(big_ws.get()), fill, sizeof(big::AlignWorkspace));
+      big_ws->pp_start = big_keys.data(); // (the kernel points them at LDS)
+      big_ws->pp_end = big_keys.data() + big::AlignCfg::MAXPP;
       uint32_t const bst = hbm_pass(
         *big_ws, [&](uint32_t & np, uint32_t & longest)
         { return big::align_paths<WaveEmu>(g, ix, *big_ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest); },
@@ -309,6 +312,8 @@ extern "C"
       {
         ++e.wide_pass_tasks;
         std::memset(static_cast<void *>(wide_ws.get()), fill, sizeof(wide::AlignWorkspace));
+        wide_ws->pp_start = wide_keys.data();
+        wide_ws->pp_end = wide_keys.data() + wide::AlignCfg::MAXPP;
         last = hbm_pass(
           *wide_ws, [&](uint32_t & np, uint32_t & longest)
           { return wide::align_paths<WaveEmu>(g, ix, *wide_ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest); },
