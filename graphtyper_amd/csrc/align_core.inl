@@ -43,9 +43,21 @@ constexpr uint32_t CAND_WORDS = sizeof(Cand) / 4;
 template <class T, uint32_t N>
 using TableOf = typename std::conditional<AlignCfg::DYN, T *, T[N]>::type;
 
+// ... and the two tables of paths of the exact pass have a run-time PITCH as well: a path there has room for cap_v variant
+// sites (24 in the launch that gives every task a part of the slab, AlignCfg::MAXV -- the proven bound -- in the launch with
+// the whole slab), which makes it a tenth of the full struct and the part's capacity ten times what it would be.
+struct PathTable
+{
+  uint8_t * base;
+  uint32_t pitch;
+  GTX_DEV DPath & operator[](uint32_t i) const { return *reinterpret_cast<DPath *>(base + static_cast<uint64_t>(i) * pitch); }
+};
+template <uint32_t N>
+using PathsOf = typename std::conditional<AlignCfg::DYN, PathTable, DPath[N]>::type;
+
 struct WalkBuffers // alive only during walk_read_starts / walk_read_ends
 {
-  TableOf<DPath, AlignCfg::MAXPP> pp;
+  PathsOf<AlignCfg::MAXPP> pp;
   TableOf<Cand, AlignCfg::CAND_CAP> cand;
   Loc locs[AlignCfg::LOC_CAP];
   TableOf<DevLabel, AlignCfg::WL_CAP> dfs_out; // labels of the current iterative_dfs call
@@ -68,6 +80,7 @@ struct WorkBoth
 struct DynTables
 {
   uint32_t cap_lbl, cap_p, cap_cand, cap_wl; // entries of lbl; of paths and pp; of cand; of wl and of dfs_out
+  uint32_t cap_v;                            // variant sites a path of the two path tables has room for
   uint32_t * pp_start, * pp_end;             // start / end of every pp entry, densely: what the searches of the chaining read
   uint64_t * bits_p, * bits_pp;              // one bit per path / per pp entry (the drop and matched sets of the filters and the chaining)
 };
@@ -87,7 +100,7 @@ struct AlignWorkspace : std::conditional<AlignCfg::DYN, DynTables, std::conditio
 {
   uint8_t rd[AlignCfg::MAX_READ]; // read as 4-bit IUPAC codes, orientation applied
   TableOf<DevLabel, AlignCfg::LBL_CAP> lbl;
-  TableOf<DPath, AlignCfg::MAXP> paths;
+  PathsOf<AlignCfg::MAXP> paths;
   DPath orig, np; // Path temporaries of add_next/prev_kmer_labels
   typename std::conditional<AlignCfg::DYN, WorkBoth, WorkUnion>::type u;
   TableOf<DevLabel, AlignCfg::WL_CAP> wl; // best label lists of a walk (must survive the add_*_kmer_labels calls)
@@ -150,34 +163,36 @@ GTX_HDI uint64_t exact_fixed_bytes(uint32_t cand_cap)
          (128u + 2u * 4096u) * sizeof(DevLabel) + 16u * 256u; // (+ alignment slack of the ten tables)
 }
 
-GTX_HDI uint64_t exact_bytes_per_path()
+// bytes of one path with room for cap_v variant sites (the head of DPath + cap_v entries, 16-byte aligned)
+GTX_HDI uint32_t exact_path_pitch(uint32_t cap_v)
 {
-  return 2u * sizeof(DPath) + 9u * sizeof(DevLabel) + 2u * sizeof(uint32_t) + 1u; // (+ two bits, rounded up)
+  return (16u + cap_v * static_cast<uint32_t>(sizeof(PVar)) + 15u) & ~15u;
 }
 
-GTX_HDI uint32_t exact_path_capacity(uint64_t slab_bytes, uint32_t cand_cap)
+GTX_HDI uint64_t exact_bytes_per_path(uint32_t cap_v)
+{
+  return 2u * exact_path_pitch(cap_v) + 9u * sizeof(DevLabel) + 2u * sizeof(uint32_t) + 1u; // (+ two bits, rounded up)
+}
+
+GTX_HDI uint32_t exact_path_capacity(uint64_t slab_bytes, uint32_t cand_cap, uint32_t cap_v)
 {
   uint64_t const fixed = exact_fixed_bytes(cand_cap) + 2u * 64u;
   if (slab_bytes <= fixed)
     return 0;
-  uint64_t const p = (slab_bytes - fixed) / exact_bytes_per_path();
+  uint64_t const p = (slab_bytes - fixed) / exact_bytes_per_path(cap_v);
   return p > 0x7FFFFFFFull ? 0x7FFFFFFFu : static_cast<uint32_t>(p);
 }
 
-// bytes of a slab that holds P paths
-GTX_HDI uint64_t exact_slab_bytes(uint32_t paths, uint32_t cand_cap)
-{
-  return exact_fixed_bytes(cand_cap) + 2u * 64u + static_cast<uint64_t>(paths) * exact_bytes_per_path() + 256u;
-}
-
-// Points the tables of the workspace at the head of `slab` into it.  Returns false when the slab is too small for a single path.
+// Points the tables of the workspace at the head of `slab` into it; cap_v: the variant sites a path gets room for (at most
+// AlignCfg::MAXV).  Returns false when the slab is too small for a single path.
 template <class W, class WS>
-GTX_DEV bool exact_setup(WS * ws_at_slab_head, uint64_t slab_bytes, uint32_t cand_cap)
+GTX_DEV bool exact_setup(WS * ws_at_slab_head, uint64_t slab_bytes, uint32_t cand_cap, uint32_t cap_v)
 {
   if constexpr (AlignCfg::DYN)
   {
     WS & ws = *ws_at_slab_head;
-    uint32_t const P = exact_path_capacity(slab_bytes, cand_cap);
+    cap_v = cap_v < 1u ? 1u : cap_v > AlignCfg::MAXV ? AlignCfg::MAXV : cap_v;
+    uint32_t const P = exact_path_capacity(slab_bytes, cand_cap, cap_v);
     if (P == 0)
       return false;
     GTX_LEAD
@@ -189,12 +204,14 @@ GTX_DEV bool exact_setup(WS * ws_at_slab_head, uint64_t slab_bytes, uint32_t can
         at += (bytes + 255u) & ~static_cast<uint64_t>(255u);
         return r;
       };
+      uint32_t const pitch = exact_path_pitch(cap_v);
       ws.cap_p = P;
+      ws.cap_v = cap_v;
       ws.cap_lbl = P + 128u;
       ws.cap_wl = 4u * P + 4096u;
       ws.cap_cand = cand_cap;
-      ws.paths = reinterpret_cast<DPath *>(take(static_cast<uint64_t>(P) * sizeof(DPath)));
-      ws.u.w.pp = reinterpret_cast<DPath *>(take(static_cast<uint64_t>(P) * sizeof(DPath)));
+      ws.paths = PathTable{take(static_cast<uint64_t>(P) * pitch), pitch};
+      ws.u.w.pp = PathTable{take(static_cast<uint64_t>(P) * pitch), pitch};
       ws.lbl = reinterpret_cast<DevLabel *>(take(static_cast<uint64_t>(ws.cap_lbl) * sizeof(DevLabel)));
       ws.wl = reinterpret_cast<DevLabel *>(take(static_cast<uint64_t>(ws.cap_wl) * sizeof(DevLabel)));
       ws.u.w.dfs_out = reinterpret_cast<DevLabel *>(take(static_cast<uint64_t>(ws.cap_wl) * sizeof(DevLabel)));
@@ -235,6 +252,14 @@ GTX_DEV uint32_t cap_pp(WS const & ws)
     return ws.cap_p;
   else
     return AlignCfg::MAXPP;
+}
+template <class WS>
+GTX_DEV uint32_t cap_sites(WS const & ws) // variant sites of a path
+{
+  if constexpr (AlignCfg::DYN)
+    return ws.cap_v;
+  else
+    return AlignCfg::MAXV;
 }
 template <class WS>
 GTX_DEV uint32_t cap_cand(WS const & ws)
@@ -960,8 +985,8 @@ GTX_DEV uint32_t find_pair(uint32_t const * a, uint32_t const * b, uint32_t n, u
   return n;
 }
 
-template <class W, class WS>
-GTX_DEV uint32_t make_pp(WS & ws, DPath * pp, DevLabel const * ll, uint32_t n, uint32_t rs, uint32_t re, uint32_t mism, uint32_t & status)
+template <class W, class WS, class PP>
+GTX_DEV uint32_t make_pp(Here, WS & ws, PP & pp, DevLabel const * ll, uint32_t n, uint32_t rs, uint32_t re, uint32_t mism, uint32_t & status)
 {
   uint32_t npp = 0;
   for (uint32_t i = 0; i < n; ++i)
@@ -1018,7 +1043,7 @@ GTX_DEV uint32_t make_pp(WS & ws, DPath * pp, DevLabel const * ll, uint32_t n, u
     for (; k < nvar; ++k)
       if (GTX_U(p.v[k].site) == lsite)
         break;
-    if (k == nvar && nvar >= AlignCfg::MAXV)
+    if (k == nvar && nvar >= cap_sites(ws))
     {
       status |= GTX_ST_PATH_OVERFLOW;
       return npp;
@@ -1043,7 +1068,7 @@ GTX_DEV uint32_t make_pp(WS & ws, DPath * pp, DevLabel const * ll, uint32_t n, u
 // with p1's, p1's other sites appended, start/read_start_index taken from p1.  false <=> the reference returns early
 // on an empty intersection (its caller then discards the half merged object).
 template <class W>
-GTX_DEV bool merge_paths(DPath const & p1, DPath const & p2, DPath & np, uint32_t & status)
+GTX_DEV bool merge_paths(DPath const & p1, DPath const & p2, DPath & np, uint32_t max_sites, uint32_t & status)
 {
   copy_path<W>(np, p2);
   uint32_t const n1 = GTX_U(static_cast<uint32_t>(p1.nvar));
@@ -1063,7 +1088,7 @@ GTX_DEV bool merge_paths(DPath const & p1, DPath const & p2, DPath & np, uint32_
     }
     else
     {
-      if (nn >= AlignCfg::MAXV)
+      if (nn >= max_sites)
       {
         status |= GTX_ST_PATH_OVERFLOW;
         return false;
@@ -1118,12 +1143,13 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
     }
     bool matched = false;
     uint32_t const original_size = n_paths;
-    for (uint32_t i = 0; i < original_size; ++i)
+    // one path that ends where the label starts (false: a table is full)
+    auto extend = [&](uint32_t i) -> bool
     {
       DPath & p = ws.paths[i];
       uint32_t const w2 = GTX_U(reinterpret_cast<uint32_t const *>(&p)[2]); // rs | re << 16
       if ((w2 >> 16) != rs || GTX_U(p.end) != ls)
-        continue;
+        return true;
       uint32_t const nvar = GTX_U(static_cast<uint32_t>(p.nvar));
       uint32_t j = nvar;
       if (lsite != INVALID)
@@ -1134,12 +1160,12 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
         if (j < nvar)
         {
           if (!pv_has<W>(p.v[j], lall))
-            continue; // empty allele intersection: this path does not merge
+            return true; // empty allele intersection: this path does not merge
         }
-        else if (nvar >= AlignCfg::MAXV)
+        else if (nvar >= cap_sites(ws))
         {
           status |= GTX_ST_PATH_OVERFLOW;
-          return;
+          return false;
         }
       }
       GTX_LEAD
@@ -1162,7 +1188,34 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
       uint32_t const sz = re - (w2 & 0xFFFFu) + 1u;
       if (sz > longest)
         longest = sz;
+      return true;
+    };
+    if constexpr (DENSE_PP_KEYS)
+    {
+      // (hundreds of paths in HBM, and this is called once per label list of a walk: the paths that end at the label's start
+      //  are found 64 at a time -- one strided load per lane -- instead of one round trip to HBM per path)
+      for (uint32_t base = 0; base < original_size; base += 64)
+      {
+        typename W::template PerLane<bool> hit;
+        W::lanes([&](uint32_t l) {
+          uint32_t const i = base + l;
+          bool h = false;
+          if (i < original_size)
+          {
+            DPath const & p = ws.paths[i];
+            h = static_cast<uint32_t>(p.re) == rs && p.end == ls;
+          }
+          hit[l] = h;
+        });
+        for (uint64_t m = W::ballot(hit); m != 0; m &= m - 1)
+          if (!extend(base + static_cast<uint32_t>(__builtin_ctzll(m))))
+            return;
+      }
     }
+    else
+      for (uint32_t i = 0; i < original_size; ++i)
+        if (!extend(i))
+          return;
     if (!matched)
     {
       if (n_paths >= cap_paths(ws))
@@ -1193,38 +1246,62 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
     }
     return;
   }
-  DPath * pp = ws.u.w.pp;
-  uint32_t const npp = make_pp<W>(ws, pp, ll, n, rs, re, mism, status);
+  auto & pp = ws.u.w.pp;
+  uint32_t const npp = make_pp<W>(Here{}, ws, pp, ll, n, rs, re, mism, status);
   if (status)
     return;
   uint32_t const original_size = n_paths;
   auto matched = new_pp_set<W>(ws, npp);
-  for (uint32_t i = 0; i < original_size; ++i)
+  // one path whose read end (start) is where the new labels begin (end); false: a table is full
+  auto chain = [&](uint32_t i) -> bool
   {
     if (prev ? (GTX_U(static_cast<uint32_t>(ws.paths[i].rs)) != re) : (GTX_U(static_cast<uint32_t>(ws.paths[i].re)) != rs))
-      continue;
+      return true;
     bool once = false;
     uint32_t const o_start = GTX_U(ws.paths[i].start), o_end = GTX_U(ws.paths[i].end);
     if constexpr (DENSE_PP_KEYS)
     {
-      // (no pp entry abuts this path: nothing to copy, nothing to merge)
+      // how many pp entries abut this path, and the first of them
       uint32_t const * key = pp_keys(ws, prev);
       uint32_t const want = prev ? o_start : o_end;
-      bool any = false;
-      for (uint32_t base = 0; base < npp && !any; base += 64)
+      uint32_t n_hit = 0, first = 0;
+      for (uint32_t base = 0; base < npp; base += 64)
       {
         typename W::template PerLane<bool> hit;
         W::lanes([&](uint32_t l) { hit[l] = base + l < npp && key[base + l] == want; });
-        any = W::ballot(hit) != 0;
+        uint64_t const m = W::ballot(hit);
+        if (m != 0 && n_hit == 0)
+          first = base + static_cast<uint32_t>(__builtin_ctzll(m));
+        n_hit += static_cast<uint32_t>(__builtin_popcountll(m));
       }
-      if (!any)
-        continue;
+      if (n_hit == 0)
+        return true; // (nothing to copy, nothing to merge)
+      if (n_hit == 1 && !prev && GTX_U(static_cast<uint32_t>(ws.paths[i].nvar)) == 0 && GTX_U(static_cast<uint32_t>(pp[first].nvar)) == 0)
+      {
+        // The one abutting entry, and neither side carries a variant site (chains inside a reference node: the repeats
+        // that bring hundreds of paths here): Path(p1, p2) is p1 with p2's end, read end and mismatches -- in place, no copies
+        uint32_t const p_end = GTX_U(pp[first].end), p_re = GTX_U(static_cast<uint32_t>(pp[first].re)), p_mm = GTX_U(static_cast<uint32_t>(pp[first].mism));
+        uint32_t const o_rs = GTX_U(static_cast<uint32_t>(ws.paths[i].rs));
+        GTX_LEAD
+        {
+          DPath & p = ws.paths[i];
+          p.end = p_end;
+          p.re = static_cast<uint16_t>(p_re);
+          p.mism = static_cast<uint16_t>(p.mism + p_mm);
+        }
+        bits_set<W>(matched, first);
+        W::lds_sync();
+        uint32_t const sz = p_re - o_rs + 1u;
+        if (sz > longest)
+          longest = sz;
+        return true;
+      }
     }
     copy_path<W>(ws.orig, ws.paths[i]);
     // one pp entry that abuts the path: merged into it (the first one in place, further ones as new paths)
     auto join = [&](uint32_t j) -> bool
     {
-      bool const ok = prev ? merge_paths<W>(pp[j], ws.orig, ws.np, status) : merge_paths<W>(ws.orig, pp[j], ws.np, status);
+      bool const ok = prev ? merge_paths<W>(pp[j], ws.orig, ws.np, cap_sites(ws), status) : merge_paths<W>(ws.orig, pp[j], ws.np, cap_sites(ws), status);
       if (status)
         return false;
       if (!ok)
@@ -1250,7 +1327,7 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
         W::lanes([&](uint32_t l) { hit[l] = base + l < npp && key[base + l] == want; });
         for (uint64_t m = W::ballot(hit); m != 0; m &= m - 1)
           if (!join(base + static_cast<uint32_t>(__builtin_ctzll(m))))
-            return;
+            return false;
       }
     }
     else
@@ -1259,9 +1336,28 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
         if (prev ? !(GTX_U(pp[j].end) == o_start) : !(o_end == GTX_U(pp[j].start)))
           continue;
         if (!join(j))
-          return;
+          return false;
       }
+    return true;
+  };
+  if constexpr (DENSE_PP_KEYS)
+  {
+    for (uint32_t base = 0; base < original_size; base += 64) // (the paths at the right read index, 64 at a time)
+    {
+      typename W::template PerLane<bool> hit;
+      W::lanes([&](uint32_t l) {
+        uint32_t const i = base + l;
+        hit[l] = i < original_size && (prev ? static_cast<uint32_t>(ws.paths[i].rs) == re : static_cast<uint32_t>(ws.paths[i].re) == rs);
+      });
+      for (uint64_t m = W::ballot(hit); m != 0; m &= m - 1)
+        if (!chain(base + static_cast<uint32_t>(__builtin_ctzll(m))))
+          return;
+    }
   }
+  else
+    for (uint32_t i = 0; i < original_size; ++i)
+      if (!chain(i))
+        return;
   for (uint32_t j = 0; j < npp; ++j)
     if (!bits_get<W>(matched, j))
     {
@@ -1346,8 +1442,8 @@ GTX_DEV uint32_t remove_paths_with_too_many_mismatches(AlignWorkspace & ws, uint
   return compact_paths<W>(ws, n_paths, drop, n_drop);
 }
 
-template <class W>
-GTX_DEV bool all_paths_unique(GraphView const & g, DPath const * paths, uint32_t n) // :219-231
+template <class W, class Paths>
+GTX_DEV bool all_paths_unique(Here, GraphView const & g, Paths const & paths, uint32_t n) // :219-231
 {
   if (n < 2)
     return true;
@@ -1371,7 +1467,7 @@ GTX_DEV bool path_is_reference(DPath const & p) // path.cpp:176-185
 template <class W>
 GTX_DEV uint32_t remove_non_ref_paths_when_read_matches_ref(GraphView const & g, AlignWorkspace & ws, uint32_t n_paths) // :460-474
 {
-  if (all_paths_unique<W>(g, ws.paths, n_paths))
+  if (all_paths_unique<W>(Here{}, g, ws.paths, n_paths))
     return n_paths;
   auto nonref = new_path_set<W>(ws, n_paths);
   uint32_t n_nonref = 0;

@@ -1345,8 +1345,14 @@ int ctx_upload(gtx_ctx & c, int device)
         widest = std::max(widest, n);
       c.exact_cand_cap = exact::exact_cand_cap(widest);
       char const * xm = std::getenv("GTX_EXACT_PASS_MB");
-      uint64_t mb = c.params.exact_pass_mb ? c.params.exact_pass_mb : (xm && std::atol(xm) > 0) ? static_cast<uint64_t>(std::atol(xm)) : (c.has_wide_sites ? 1024u : 256u);
+      uint64_t mb = c.params.exact_pass_mb ? c.params.exact_pass_mb : (xm && std::atol(xm) > 0) ? static_cast<uint64_t>(std::atol(xm)) : (c.has_wide_sites ? 1024u : 512u);
       c.exact_slab_bytes = mb << 20;
+      // parts of 8 MB (64 MB where allele sets are wide), at most 64: the tasks that come this far come in bulk -- every read
+      // over one long repeat -- and what one task takes is milliseconds of dependent round trips
+      c.exact_parts = static_cast<uint32_t>(std::min<uint64_t>(64u, std::max<uint64_t>(1u, mb / (c.has_wide_sites ? 64u : 8u))));
+      if (char const * xp = std::getenv("GTX_EXACT_PARTS")) // (tests: smaller parts, so that tasks reach the launch with the whole slab)
+        if (std::atol(xp) > 0)
+          c.exact_parts = static_cast<uint32_t>(std::min<long>(std::atol(xp), 1024));
     }
     void * p = nullptr;
     ok = ok && hip_ok(gtx::dev_malloc(&p, c.big_record_words * sizeof(uint32_t)), "big-record arena");
@@ -1810,6 +1816,8 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     a.exact_slab = s->d_exact_slab;
     a.exact_slab_bytes = c->exact_slab_bytes;
     a.exact_cand_cap = c->exact_cand_cap;
+    a.exact_part_cand_cap = std::min<uint32_t>(c->exact_cand_cap, CallScratch::EXACT_PART_CANDIDATES);
+    a.exact_parts = c->exact_parts;
     a.wide_sites = c->has_wide_sites;
     a.arena = c->d_big_records;
     a.arena_words = c->big_record_words;

@@ -59,11 +59,13 @@ struct CallScratch
   void * d_wide_ws = nullptr;
   static constexpr uint32_t WIDE_TASK_CAP = 1u << 20, WIDE_BLOCKS = 64;
   // exact pass (align_core.hpp: namespace exact): tasks that exceeded the tables of the passes above; tables cut out of a slab
-  // at run time -- EXACT_PARTS workgroups with a part of it each, then one workgroup with all of it
+  // at run time -- gtx_ctx::exact_parts workgroups with a part of it each, then one workgroup with all of it
   uint32_t * d_exact_tasks = nullptr; // two queues of EXACT_TASK_CAP
   uint32_t * d_exact_state = nullptr; // inside d_big_state's allocation: [0..7] first launch, [8..15] second (same layout)
   uint8_t * d_exact_slab = nullptr;   // gtx_ctx::exact_slab_bytes
-  static constexpr uint32_t EXACT_TASK_CAP = 1u << 20, EXACT_PARTS = 8;
+  static constexpr uint32_t EXACT_TASK_CAP = 1u << 20;
+  static constexpr uint32_t EXACT_PART_SITES = 24;       // variant sites a path has room for while a task has a part of the slab
+  static constexpr uint32_t EXACT_PART_CANDIDATES = 8256; // ... and walk candidates (128 live sequences x 64 alleles + a round's slack)
   // second scoring pass (items whose reads touch more variant sites than the main pass' tables hold)
   uint32_t * d_score_state = nullptr; // [0] items queued
   uint32_t * d_score_queue = nullptr;
@@ -92,6 +94,7 @@ struct gtx_ctx
   bool has_wide_sites = false; // some site has more than 64 alleles: the wide-site passes (alignment, scoring) exist
   uint64_t exact_slab_bytes = 0; // slab of the exact alignment pass, per call in flight (gtx_params::exact_pass_mb / GTX_EXACT_PASS_MB)
   uint32_t exact_cand_cap = 0;   // walk candidates a task of that pass can have alive: exact_cand_cap(widest site of the graph)
+  uint32_t exact_parts = 0;      // workgroups (= parts of the slab) of the pass' first launch
   static constexpr uint32_t SCORE_QUEUE_CAP = 1u << 20, SCORE_BIG_THREADS = 1024;
   // arena for records longer than a record slot: shared by all calls (it only grows; the cursor is a device counter)
   uint32_t * d_big_records = nullptr;

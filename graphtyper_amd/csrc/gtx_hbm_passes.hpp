@@ -34,7 +34,9 @@ struct HbmPassArgs
   uint32_t * exact_state; // 3 x 8 words
   uint8_t * exact_slab;
   uint64_t exact_slab_bytes;
-  uint32_t exact_cand_cap;
+  uint32_t exact_cand_cap;      // walk candidates of a task that has the whole slab (the proven bound)
+  uint32_t exact_part_cand_cap; // ... of a task that has a part of it
+  uint32_t exact_parts;         // workgroups of the first launch
   bool wide_sites;
   // big-record arena
   uint32_t * arena;

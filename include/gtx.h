@@ -151,7 +151,7 @@ typedef struct gtx_params
   uint32_t big_record_words;             /* capacity of the big-record arena in uint32 words, 0 = 16 Mi */
   uint32_t exact_pass_mb;                /* MiB of HBM per call in flight for the exact alignment pass (gtx_align_batch: the
                                           * pass whose tables have no fixed size), 0 = the GTX_EXACT_PASS_MB environment
-                                          * variable, else 256 (1024 for a graph with a site of more than 64 alleles) */
+                                          * variable, else 512 (1024 for a graph with a site of more than 64 alleles) */
 } gtx_params;
 
 /* One KmerLabel (include/graphtyper/index/kmer_label.hpp:13-41) */

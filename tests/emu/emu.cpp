@@ -241,11 +241,15 @@ extern "C"
     for (uint32_t n : e.graph.ref_nvar)
       widest_site = std::max(widest_site, n);
     // the exact pass' slab (gtx_api.hip: exact_slab_mb; here one slab, used by one task at a time)
-    constexpr uint32_t EXACT_PARTS = 8;
+    constexpr uint32_t EXACT_PART_SITES = 24, EXACT_PART_CANDIDATES = 8256; // (gtx_ctx.hpp: CallScratch)
     char const * xm = std::getenv("GTX_EXACT_PASS_MB");
     std::vector<uint8_t> & exact_slab = e.exact_slab;
     if (exact_slab.empty())
-      exact_slab.resize(static_cast<size_t>(e.params.exact_pass_mb ? e.params.exact_pass_mb : xm && std::atol(xm) > 0 ? std::atol(xm) : (has_wide_sites ? 1024 : 256)) << 20);
+      exact_slab.resize(static_cast<size_t>(e.params.exact_pass_mb ? e.params.exact_pass_mb : xm && std::atol(xm) > 0 ? std::atol(xm) : (has_wide_sites ? 1024 : 512)) << 20);
+    uint64_t exact_parts = std::min<uint64_t>(64u, std::max<uint64_t>(1u, (exact_slab.size() >> 20) / (has_wide_sites ? 64u : 8u)));
+    if (char const * xp = std::getenv("GTX_EXACT_PARTS"))
+      if (std::atol(xp) > 0)
+        exact_parts = static_cast<uint64_t>(std::min<long>(std::atol(xp), 1024));
     e.exact_pass_tasks[0] = e.exact_pass_tasks[1] = e.exact_pass_tasks[2] = 0;
     // one task through an HBM-table pass (the body of GTX_HBM_PASS_KERNEL in gtx_api.hip); returns the pass' status
     auto hbm_pass = [&](auto &, auto && align, auto && size_of, auto && write_body, uint32_t * rec, uint32_t len) -> uint32_t
@@ -325,12 +329,13 @@ extern "C"
       for (uint32_t level = 0; level < 2 && (last & TABLES); ++level)
       {
         ++e.exact_pass_tasks[level];
-        uint64_t const bytes = level == 0 ? exact_slab.size() / EXACT_PARTS : exact_slab.size();
+        uint64_t const bytes = level == 0 ? ((exact_slab.size() / exact_parts) & ~255ull) : exact_slab.size();
+        uint32_t const cap_v = level == 0 ? EXACT_PART_SITES : exact::AlignCfg::MAXV;
         std::memset(exact_slab.data(), fill, 65536);
         if (has_wide_sites)
         {
           auto * xws = reinterpret_cast<exactw::AlignWorkspace *>(exact_slab.data());
-          if (!exactw::exact_setup<WaveEmu>(xws, bytes, exactw::exact_cand_cap(widest_site)))
+          if (!exactw::exact_setup<WaveEmu>(xws, bytes, level == 0 ? std::min(exactw::exact_cand_cap(widest_site), EXACT_PART_CANDIDATES) : exactw::exact_cand_cap(widest_site), cap_v))
             continue;
           last = hbm_pass(
             *xws, [&](uint32_t & np, uint32_t & longest)
@@ -341,7 +346,7 @@ extern "C"
         else
         {
           auto * xws = reinterpret_cast<exact::AlignWorkspace *>(exact_slab.data());
-          if (!exact::exact_setup<WaveEmu>(xws, bytes, exact::exact_cand_cap(widest_site)))
+          if (!exact::exact_setup<WaveEmu>(xws, bytes, level == 0 ? std::min(exact::exact_cand_cap(widest_site), EXACT_PART_CANDIDATES) : exact::exact_cand_cap(widest_site), cap_v))
             continue;
           last = hbm_pass(
             *xws, [&](uint32_t & np, uint32_t & longest)

@@ -96,20 +96,29 @@ class Builder:
     """state of one construct_graph call: the records made so far and Graph::SVs.size()"""
 
     def __init__(self, fa, chrom):
-        self.fa, self.chrom, self.n_sv, self.records = fa, chrom, 0, []
+        self.fa, self.chrom, self.n_sv, self.records, self.svs = fa, chrom, 0, [], []
 
     def tag(self):
         return "<SV:%07d>" % self.n_sv
 
-    def push_sv(self):
+    def push_sv(self, sv, model, related=None):
+        """graph.SVs.push_back(sv) with sv.model (and sv.related_sv: "next" / "prev") set just before, as the reference does it
+        on its one SV object -- what is set stays set for the pushes behind it"""
+        sv["model"] = model
+        if related == "next":
+            sv["related_sv"] = self.n_sv + 1
+        elif related == "prev":
+            sv["related_sv"] = self.n_sv - 1
+        self.svs.append(dict(sv))
         self.n_sv += 1
 
     def rd(self, begin, length, chrom=None):
         return self.fa.read(chrom or self.chrom, begin, length)
 
     # ---- add_sv_breakend :312-476
-    def breakend(self, var, alt):
+    def breakend(self, var, alt, sv):
         var["ref"] = self.rd(var["pos"], 1)
+        sv["original_alt"] = alt
 
         def chrom_name(c):
             return alt[alt.index(c) + 1:alt.rindex(":")]
@@ -144,7 +153,7 @@ class Builder:
                 bnd += complement(self.rd(pos - n, n, chrom2))[::-1]
                 bnd += self.tag()
         var["alts"].append(bnd)
-        self.push_sv()
+        self.push_sv(sv, sv["model"])
 
     # ---- add_sv_deletion :478-514
     def deletion(self, var, sv):
@@ -158,7 +167,7 @@ class Builder:
             alt1 += self.rd(var["pos"] + len(sv["seq"]) + sv["size"] + 1, E + 1 - len(alt1))
         alt1 += self.tag()
         var["alts"].append(alt1)
-        self.push_sv()
+        self.push_sv(sv, "BREAKPOINT")
 
     # ---- add_sv_insertion :515-725
     def insertion(self, var, sv, vcf_ref):
@@ -169,20 +178,20 @@ class Builder:
             if len(sv["seq"]) >= E:
                 alt1 += sv["seq"][:E]
                 alt1 += self.tag()
-                self.push_sv()
+                self.push_sv(sv, "BREAKPOINT1", "next")
                 alt2 += self.tag()
                 alt2 += sv["seq"][-E:]
-                self.push_sv()
+                self.push_sv(sv, "BREAKPOINT2", "prev")
             else:
                 padding = E - len(sv["seq"])
                 alt1 += sv["seq"]
                 alt1 += self.rd(var["pos"] + 1, padding)
                 alt1 += self.tag()
-                self.push_sv()
+                self.push_sv(sv, "BREAKPOINT1", "next")
                 alt2 += self.tag()
                 alt2 += self.rd(var["pos"] - padding, padding + 1)
                 alt2 += sv["seq"]
-                self.push_sv()
+                self.push_sv(sv, "BREAKPOINT2", "prev")
             var["alts"] += [alt1, alt2]
         elif sv["or_start"] != -1 and sv["or_end"] != -1:
             alt1 = self.rd(var["pos"], 1)
@@ -191,35 +200,35 @@ class Builder:
             if len(ins) >= E:
                 alt1 += ins[:E]
                 alt1 += self.tag()
-                self.push_sv()
+                self.push_sv(sv, "BREAKPOINT1", "next")
                 alt2 += self.tag()
                 alt2 += ins[-E:]
-                self.push_sv()
+                self.push_sv(sv, "BREAKPOINT2", "prev")
             else:
                 padding = E - len(ins)
                 alt1 += ins
                 alt1 += self.rd(var["pos"] + 1, padding)
                 alt1 += self.tag()
-                self.push_sv()
+                self.push_sv(sv, "BREAKPOINT1", "next")
                 alt2 += self.tag()
                 padding = min(padding, var["pos"])
                 alt2 += self.rd(var["pos"] - padding, padding)
                 alt2 += ins
-                self.push_sv()
+                self.push_sv(sv, "BREAKPOINT2", "prev")
             var["alts"] += [alt1, alt2]
         elif len(sv["ins_seq_left"]) > 0 or len(sv["ins_seq_right"]) > 0:
             left, right = sv["ins_seq_left"][:E], sv["ins_seq_right"][:E]
             if len(left) > 1 and len(right) > 0:
                 var["alts"].append(var["ref"] + left + self.tag())
-                self.push_sv()
+                self.push_sv(sv, "BREAKPOINT1", "next")
                 var["alts"].append(self.tag() + right)
-                self.push_sv()
+                self.push_sv(sv, "BREAKPOINT2", "prev")
             elif len(left) > 1:
                 var["alts"].append(var["ref"] + left + self.tag())
-                self.push_sv()
+                self.push_sv(sv, "BREAKPOINT1")
             elif len(right) > 0:
                 var["alts"].append(self.tag() + right)
-                self.push_sv()
+                self.push_sv(sv, "BREAKPOINT2")
 
     # ---- add_sv_duplication :727-871
     def duplication(self, var, sv):
@@ -235,22 +244,22 @@ class Builder:
                 if len(dup) >= E:
                     dup_begin += dup[:E]
                     dup_begin += self.tag()
-                    self.push_sv()
+                    self.push_sv(sv, "BREAKPOINT1", "next")
                     dup_end += self.tag()
                     dup_end += dup[-E:]
                     dup_end += sv["ins_seq"]
-                    self.push_sv()
+                    self.push_sv(sv, "BREAKPOINT2", "prev")
                 else:
                     padding = E - len(dup)
                     dup_begin += dup
                     dup_begin += self.rd(var["pos"] + 1, padding)
                     dup_begin += self.tag()
-                    self.push_sv()
+                    self.push_sv(sv, "BREAKPOINT1", "next")
                     padding = min(padding, var2["pos"])
                     dup_end += self.tag()
                     dup_end += self.rd(var2["pos"] - padding + 1, padding)
                     dup_end += dup
-                    self.push_sv()
+                    self.push_sv(sv, "BREAKPOINT2", "prev")
                 var["alts"].append(dup_begin)
                 var2["alts"].append(dup_end)
                 self.records.append(var2)
@@ -259,14 +268,14 @@ class Builder:
                 dup_begin += self.rd(sv["or_start"] - 1, E)
                 dup_begin += self.tag()
                 var["alts"].append(dup_begin)
-                self.push_sv()
+                self.push_sv(sv, "BREAKPOINT1")
         else:
             start = max(E, sv["or_end"])
             dup_begin = self.tag()
             dup_begin += self.rd(start - E, E)
             dup_begin += sv["ins_seq"]
             var["alts"].append(dup_begin)
-            self.push_sv()
+            self.push_sv(sv, "BREAKPOINT2")
 
     # ---- add_sv_inversion :873-1031
     def inversion(self, var, sv):
@@ -290,23 +299,23 @@ class Builder:
                 if len(inv) >= E:
                     inv_begin += inv[:E]
                     inv_begin += self.tag()
-                    self.push_sv()
+                    self.push_sv(sv, "BREAKPOINT1", "next")
                     inv_end += self.tag()
                     inv_end += inv[-E:]
                     inv_end += sv["ins_seq"]
-                    self.push_sv()
+                    self.push_sv(sv, "BREAKPOINT2", "prev")
                 else:
                     padding = E - len(inv)
                     inv_begin += inv
                     inv_begin += self.rd(var["pos"] + 1, padding)
                     inv_begin += self.tag()
-                    self.push_sv()
+                    self.push_sv(sv, "BREAKPOINT1", "next")
                     padding = min(padding, var2["pos"])
                     inv_end += self.tag()
                     inv_end += self.rd(var2["pos"] - padding + 1, padding)
                     inv_end += inv
                     inv_end += sv["ins_seq"]
-                    self.push_sv()
+                    self.push_sv(sv, "BREAKPOINT2", "prev")
                 var["alts"].append(inv_begin)
                 var2["alts"].append(inv_end)
                 self.records.append(var2)
@@ -314,30 +323,32 @@ class Builder:
                 dup = complement(self.rd(sv["or_start"] - 1, E))
                 inv = self.tag() + dup[::-1] + sv["ins_seq"]
                 var["alts"].append(inv)
-                self.push_sv()
+                self.push_sv(sv, "BREAKPOINT2")
         else:
             start = max(E, sv["or_end"])
             dup = complement(self.rd(start - E, E))
             inv = var["ref"] + sv["ins_seq"] + dup[::-1]
             inv += self.tag()
             var["alts"].append(inv)
-            self.push_sv()
+            self.push_sv(sv, "BREAKPOINT1")
 
     # ---- the SV branch of add_var_record :1264-1491
-    def add_sv(self, pos, vcf_ref, alt, info):
+    def add_sv(self, pos, vcf_ref, alt, info, vcf_id=""):
         var = dict(pos=pos, ref="", alts=[], is_sv=True)
-        sv = dict(type=None, begin=pos + 1, end=0, size=0, length=0, or_start=-1, or_end=-1, seq="", ins_seq="", ins_seq_left="",
-                  ins_seq_right="", inv_type=None)
+        sv = dict(type=None, chrom=self.chrom, begin=pos + 1, end=0, size=0, length=0, n_clusters=0, num_merged_svs=-1, or_start=-1, or_end=-1,
+                  related_sv=-1, model="AGGREGATED", old_variant_id=vcf_id, seq="", hom_seq="", ins_seq="", ins_seq_left="", ins_seq_right="",
+                  inv_type=None, original_alt="")
         is_a_dup = False
         for item in info.split(";"):
             key, _, val = item.partition("=")
             if key == "DUPSVLEN":
                 is_a_dup = True
             if key == "SVTYPE":
-                sv["type"] = {"DEL": "DEL", "DEL:ME:ALU": "DEL", "DUP": "DUP", "INV": "INV", "INS": "INS", "INS:ME:ALU": "INS_ALU",
+                sv["type"] = {"DEL": "DEL", "DEL:ME:ALU": "DEL_ALU", "DUP": "DUP", "INV": "INV", "INS": "INS", "INS:ME:ALU": "INS_ALU",
                               "BND": "BND"}.get(val, "OTHER")
-            elif key in ("END", "SVSIZE", "SVLEN", "ORSTART", "OREND"):
-                sv[{"END": "end", "SVSIZE": "size", "SVLEN": "length", "ORSTART": "or_start", "OREND": "or_end"}[key]] = int(val)
+            elif key in ("END", "SVSIZE", "SVLEN", "ORSTART", "OREND", "NCLUSTERS", "NUM_MERGED_SVS"):
+                sv[{"END": "end", "SVSIZE": "size", "SVLEN": "length", "ORSTART": "or_start", "OREND": "or_end", "NCLUSTERS": "n_clusters",
+                    "NUM_MERGED_SVS": "num_merged_svs"}[key]] = int(val)
             elif key in ("SEQ", "SVINSSEQ", "LEFT_SVINSSEQ", "RIGHT_SVINSSEQ", "DUPSVINSSEQ"):
                 if len(val) > 0 and val[0] != ".":
                     sv[{"SEQ": "seq", "SVINSSEQ": "ins_seq", "LEFT_SVINSSEQ": "ins_seq_left", "RIGHT_SVINSSEQ": "ins_seq_right",
@@ -369,8 +380,8 @@ class Builder:
                 if is_similar(self.rd(var["pos"] + 1, n), sv["seq"]):
                     sv["type"] = "DUP"
         if sv["type"] == "BND":
-            self.breakend(var, alt)
-        elif sv["type"] == "DEL":
+            self.breakend(var, alt, sv)
+        elif sv["type"] in ("DEL", "DEL_ALU"):
             self.deletion(var, sv)
         elif sv["type"] == "DUP":
             self.duplication(var, sv)
@@ -384,7 +395,18 @@ class Builder:
             self.records.append(var)
 
 
-def sv_records(seqs, vcf_lines, chrom, region_begin=0, region_end=0xFFFFFFFF):
+def sv_table_text(svs):
+    """Graph::SVs as the text the oracle (gto_sv.hpp: parse_sv_table) and gtx_graph_sv_table share: one SV per line, tab
+    separated, "." for an empty field"""
+    def f(x):
+        x = "" if x is None else str(x)
+        return x if x != "" else "."
+    cols = ("type", "chrom", "begin", "length", "size", "end", "n_clusters", "num_merged_svs", "or_start", "or_end", "related_sv", "model",
+            "old_variant_id", "inv_type", "seq", "hom_seq", "ins_seq", "ins_seq_left", "ins_seq_right", "original_alt")
+    return "".join("\t".join(f(sv[c]) for c in cols) + "\n" for sv in svs)
+
+
+def sv_records(seqs, vcf_lines, chrom, region_begin=0, region_end=0xFFFFFFFF, with_table=False):
     """construct_graph's record intake for an SV graph (:1650-1760): -> [(pos0, ref, [alts], info)] sorted by position, as the
     oracle takes them ("SV=1" marks VarRecord::is_sv).  vcf_lines: tab-separated VCF data lines."""
     fa = Fasta(seqs)
@@ -405,8 +427,9 @@ def sv_records(seqs, vcf_lines, chrom, region_begin=0, region_end=0xFFFFFFFF):
             if not transform_sv_records(fa, chrom, rec):
                 continue
             if len(rec["alt"]) >= 5 and any(c in rec["alt"] for c in "<[]"):
-                b.add_sv(rec["pos"], rec["ref"], rec["alt"], rec["info"])
+                b.add_sv(rec["pos"], rec["ref"], rec["alt"], rec["info"], f[2] if len(f) > 2 else "")
             elif all(c in "ACGT" for c in rec["alt"]):
                 b.records.append(dict(pos=rec["pos"], ref=rec["ref"], alts=[rec["alt"]], is_sv=False))
     out = sorted(b.records, key=lambda r: r["pos"])  # (stable; the reference's std::sort need not be for equal positions)
-    return [(r["pos"], r["ref"], r["alts"], "SV=1" if r["is_sv"] else ".") for r in out]
+    recs = [(r["pos"], r["ref"], r["alts"], "SV=1" if r["is_sv"] else ".") for r in out]
+    return (recs, sv_table_text(b.svs)) if with_table else recs

@@ -346,12 +346,15 @@ def test_second_pass(kind):
     second_pass_case(harness.EmuBackend, kind, 500)
 
 
-def satellite_case(Backend, n_reads, read_len=150, seed=0, exact_pass_mb=0):
+def satellite_case(Backend, n_reads, read_len=150, seed=0, exact_pass_mb=0, monkeypatch=None):
     """Low-complexity repeats (a 280-bp homopolymer, two copies of a dinucleotide repeat, a 2 kb array of a 171-bp unit, a
     trinucleotide repeat, SNPs every 50 bp inside them): one k-mer has hundreds of places there and the reference keeps
     every chain (genotype_paths.cpp:294-352 has no limit) -- more than any fixed table holds.  Such reads end in the exact
     pass, whose tables are sized at run time; no read may keep an overflow status, and records, scores, calls and VCF text
-    must be the oracle's.  exact_pass_mb: a slab so small that its parts hold nothing and the whole-slab launch does the work."""
+    must be the oracle's.  exact_pass_mb (with monkeypatch): a small slab cut into many parts, so that some tasks do not fit a
+    part and the launch with the whole slab does them."""
+    if exact_pass_mb:
+        monkeypatch.setenv("GTX_EXACT_PARTS", "64")
     ref, recs, codes, pos = scenarios.synthetic_case("satellite", n_ref=16000, n_reads=n_reads, seed=seed, region_begin=30000, read_len=read_len)
     o = Oracle(ref, recs, region_begin=30000)
     b = Backend(gtx.graph_from_records(ref, recs, region_begin=30000), exact_pass_mb=exact_pass_mb)
@@ -370,8 +373,8 @@ def test_satellite_repeats_reach_the_exact_pass():
     satellite_case(harness.EmuBackend, 400, read_len=250, seed=4)
 
 
-def test_exact_pass_with_the_whole_slab():
-    satellite_case(harness.EmuBackend, 400, seed=1, exact_pass_mb=8)
+def test_exact_pass_with_the_whole_slab(monkeypatch):
+    satellite_case(harness.EmuBackend, 400, read_len=250, seed=1, exact_pass_mb=48, monkeypatch=monkeypatch)
 
 
 def homopolymer_case(Backend):

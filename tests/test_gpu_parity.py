@@ -114,8 +114,8 @@ def test_satellite_repeats_reach_the_exact_pass():
     satellite_case(harness.GpuBackend, 1500, read_len=250, seed=4)
 
 
-def test_exact_pass_with_the_whole_slab():
-    satellite_case(harness.GpuBackend, 1000, seed=1, exact_pass_mb=8)
+def test_exact_pass_with_the_whole_slab(monkeypatch):
+    satellite_case(harness.GpuBackend, 1000, read_len=250, seed=1, exact_pass_mb=48, monkeypatch=monkeypatch)
 
 
 def test_reads_in_a_long_homopolymer():
