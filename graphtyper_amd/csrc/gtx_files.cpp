@@ -29,6 +29,11 @@
 #include "../../include/gtx.h"
 #include "gtx_ctx.hpp"
 
+namespace gtx
+{
+void graph_set_sv_table(gtx_graph * g, std::string table); // gtx_graph.cpp
+}
+
 namespace
 {
 struct Region
@@ -195,19 +200,37 @@ constexpr long EXTRA_SEQUENCE_LENGTH = 152; // constructor.cpp:1437
 
 enum SvType { SV_NONE, SV_DEL, SV_DEL_ALU, SV_DUP, SV_INS, SV_INS_ALU, SV_INV, SV_BND, SV_OTHER };
 
-struct SvFields // gyper::SV as far as the allele synthesis reads it (include/graphtyper/graph/sv.hpp:36-58)
+struct SvFields // gyper::SV (include/graphtyper/graph/sv.hpp:36-58): what the allele synthesis reads and what the calls' post-processing reads later
 {
   SvType type = SV_NONE;
   long begin = 0, length = 0, size = 0, end = 0, or_start = -1, or_end = -1;
+  long n_clusters = 0, num_merged_svs = -1, related_sv = -1;
   int inv_type = 0; // 1 = INV3, 2 = INV5
-  std::string seq, ins_seq, ins_seq_left, ins_seq_right;
+  std::string chrom, model = "AGGREGATED", old_variant_id;
+  std::string seq, ins_seq, ins_seq_left, ins_seq_right, original_alt;
 };
+
+// one line of gtx_graph_sv_table per registered SV
+std::string sv_table_line(SvFields const & sv)
+{
+  static char const * const TYPES[] = {"NOT_SV", "DEL", "DEL_ALU", "DUP", "INS", "INS_ALU", "INV", "BND", "OTHER"};
+  auto text = [](std::string const & v) { return v.empty() ? std::string(".") : v; };
+  std::string l = TYPES[sv.type];
+  l += '\t' + text(sv.chrom);
+  for (long v : {sv.begin, sv.length, sv.size, sv.end, sv.n_clusters, sv.num_merged_svs, sv.or_start, sv.or_end, sv.related_sv})
+    l += '\t' + std::to_string(v);
+  l += '\t' + text(sv.model) + '\t' + text(sv.old_variant_id) + '\t' + (sv.inv_type == 1 ? "INV3" : sv.inv_type == 2 ? "INV5" : ".");
+  l += '\t' + text(sv.seq) + "\t." /* HOMSEQ: never read by the constructor */ + '\t' + text(sv.ins_seq) + '\t' + text(sv.ins_seq_left) + '\t' + text(sv.ins_seq_right) +
+       '\t' + text(sv.original_alt) + '\n';
+  return l;
+}
 
 struct SvBuilder
 {
   std::string fasta, chr;
   unsigned * n_sv; // Graph::SVs.size(): numbers the SV tags
   std::string err;
+  std::string * table = nullptr; // Graph::SVs as text (gtx_graph_sv_table), a line per registered SV
 
   // read_reference_seq (constructor.cpp:245-257): bases [begin, begin + length) of `contig`, clipped to it
   std::string read(std::string const & contig, long begin, long length)
@@ -240,7 +263,17 @@ struct SvBuilder
     std::snprintf(t, sizeof t, "<SV:%07u>", *n_sv);
     return t;
   }
-  void register_sv() { ++*n_sv; }
+  // graph.SVs.push_back(sv) with the genotyping model set just before; relation +1 / -1: the SV registered next / before is
+  // the other breakpoint (sv.related_sv, constructor.cpp:551-560 and the like)
+  void register_sv(SvFields sv, char const * model, int relation = 0)
+  {
+    sv.model = model;
+    if (relation != 0)
+      sv.related_sv = static_cast<long>(*n_sv) + relation;
+    if (table)
+      *table += sv_table_line(sv);
+    ++*n_sv;
+  }
 
   static char complement(char c) // constructor.cpp:218-243
   {
@@ -291,8 +324,9 @@ struct SvBuilder
   }
 
   // add_sv_breakend (constructor.cpp:312-476)
-  bool breakend(Rec & var, std::string const & alt)
+  bool breakend(Rec & var, std::string const & alt, SvFields sv)
   {
+    sv.original_alt = alt;
     var.ref = read(var.pos, 1);
     auto chrom_of = [&](char c, std::string & name)
     {
@@ -362,7 +396,7 @@ struct SvBuilder
       }
     }
     var.alts.push_back(bnd);
-    register_sv();
+    register_sv(sv, sv.model.c_str());
     return true;
   }
 
@@ -379,21 +413,21 @@ struct SvBuilder
       alt1 += read(static_cast<long>(var.pos) + static_cast<long>(sv.seq.size()) + sv.size + 1, EXTRA_SEQUENCE_LENGTH + 1 - static_cast<long>(alt1.size()));
     alt1 += tag();
     var.alts.push_back(alt1);
-    register_sv();
+    register_sv(sv, "BREAKPOINT");
   }
 
   // two breakpoint alleles around an inserted sequence: its first EXTRA_SEQUENCE_LENGTH bases behind the padding base, its
   // last ones in front of the reference that follows (shared by insertions with SEQ and with an origin)
-  void two_breakpoints(Rec & var, std::string const & ins, std::string alt1, std::string alt2, long pad_from, bool alt2_has_base)
+  void two_breakpoints(Rec & var, SvFields const & sv, std::string const & ins, std::string alt1, std::string alt2, long pad_from, bool alt2_has_base)
   {
     if (static_cast<long>(ins.size()) >= EXTRA_SEQUENCE_LENGTH)
     {
       alt1 += ins.substr(0, EXTRA_SEQUENCE_LENGTH);
       alt1 += tag();
-      register_sv();
+      register_sv(sv, "BREAKPOINT1", +1);
       alt2 += tag();
       alt2 += ins.substr(ins.size() - EXTRA_SEQUENCE_LENGTH);
-      register_sv();
+      register_sv(sv, "BREAKPOINT2", -1);
     }
     else
     {
@@ -401,7 +435,7 @@ struct SvBuilder
       alt1 += ins;
       alt1 += read(static_cast<long>(var.pos) + 1, padding);
       alt1 += tag();
-      register_sv();
+      register_sv(sv, "BREAKPOINT1", +1);
       alt2 += tag();
       if (alt2_has_base) // (insertion with SEQ: the padding in front of the position and its base, constructor.cpp:577)
         alt2 += read(pad_from - padding, padding + 1);
@@ -411,7 +445,7 @@ struct SvBuilder
         alt2 += read(static_cast<long>(var.pos) - padding, padding);
       }
       alt2 += ins;
-      register_sv();
+      register_sv(sv, "BREAKPOINT2", -1);
     }
     var.alts.push_back(alt1);
     var.alts.push_back(alt2);
@@ -424,22 +458,23 @@ struct SvBuilder
     if (!sv.seq.empty())
     {
       std::string const base = read(var.pos, 1);
-      two_breakpoints(var, sv.seq, base, base, var.pos, true);
+      two_breakpoints(var, sv, sv.seq, base, base, var.pos, true);
     }
     else if (sv.or_start != -1 && sv.or_end != -1)
-      two_breakpoints(var, read_ends(sv.or_start - 1, sv.or_end, EXTRA_SEQUENCE_LENGTH), read(var.pos, 1), std::string(), var.pos, false);
+      two_breakpoints(var, sv, read_ends(sv.or_start - 1, sv.or_end, EXTRA_SEQUENCE_LENGTH), read(var.pos, 1), std::string(), var.pos, false);
     else if (!sv.ins_seq_left.empty() || !sv.ins_seq_right.empty())
     {
       std::string const left = sv.ins_seq_left.substr(0, EXTRA_SEQUENCE_LENGTH), right = sv.ins_seq_right.substr(0, EXTRA_SEQUENCE_LENGTH);
+      bool const both = left.size() > 1 && !right.empty(); // (only then the two breakpoints name each other)
       if (left.size() > 1)
       {
         var.alts.push_back(var.ref + left + tag());
-        register_sv();
+        register_sv(sv, "BREAKPOINT1", both ? +1 : 0);
       }
-      if ((left.size() > 1 && !right.empty()) || (left.size() <= 1 && !right.empty()))
+      if (!right.empty())
       {
         var.alts.push_back(tag() + right);
-        register_sv();
+        register_sv(sv, "BREAKPOINT2", both ? -1 : 0);
       }
     }
     // (else: the reference does not know how to add the insertion either and the record has no allele)
@@ -455,11 +490,11 @@ struct SvBuilder
     {
       head += body.substr(0, EXTRA_SEQUENCE_LENGTH);
       head += tag();
-      register_sv();
+      register_sv(sv, "BREAKPOINT1", +1);
       tail = tag();
       tail += body.substr(body.size() - EXTRA_SEQUENCE_LENGTH);
       tail += sv.ins_seq;
-      register_sv();
+      register_sv(sv, "BREAKPOINT2", -1);
     }
     else
     {
@@ -467,14 +502,14 @@ struct SvBuilder
       head += body;
       head += read(first_pos + 1, padding);
       head += tag();
-      register_sv();
+      register_sv(sv, "BREAKPOINT1", +1);
       padding = std::min<long>(padding, second_pos); // (not in front of the contig's start)
       tail = tag();
       tail += read(second_pos - padding + 1, padding);
       tail += body;
       if (tail_gets_ins)
         tail += sv.ins_seq;
-      register_sv();
+      register_sv(sv, "BREAKPOINT2", -1);
     }
     first.alts.push_back(head);
     second.alts.push_back(tail);
@@ -498,14 +533,14 @@ struct SvBuilder
       else // only the origin's start is known
       {
         var.alts.push_back(var.ref + sv.ins_seq + read(sv.or_start - 1, EXTRA_SEQUENCE_LENGTH) + tag());
-        register_sv();
+        register_sv(sv, "BREAKPOINT1");
       }
     }
     else // only the origin's end is known
     {
       long const from = std::max<long>(EXTRA_SEQUENCE_LENGTH, sv.or_end);
       var.alts.push_back(tag() + read(from - EXTRA_SEQUENCE_LENGTH, EXTRA_SEQUENCE_LENGTH) + sv.ins_seq);
-      register_sv();
+      register_sv(sv, "BREAKPOINT2");
     }
   }
 
@@ -536,14 +571,14 @@ struct SvBuilder
       else
       {
         var.alts.push_back(tag() + revcomp(read(sv.or_start - 1, EXTRA_SEQUENCE_LENGTH)) + sv.ins_seq);
-        register_sv();
+        register_sv(sv, "BREAKPOINT2");
       }
     }
     else
     {
       long const from = std::max<long>(EXTRA_SEQUENCE_LENGTH, sv.or_end);
       var.alts.push_back(var.ref + sv.ins_seq + revcomp(read(from - EXTRA_SEQUENCE_LENGTH, EXTRA_SEQUENCE_LENGTH)) + tag());
-      register_sv();
+      register_sv(sv, "BREAKPOINT1");
     }
   }
 };
@@ -607,7 +642,7 @@ bool transform_sv_record(SvBuilder & b, long & pos0, std::string & ref, std::str
 }
 
 // the SV branch of add_var_record (constructor.cpp:1264-1491).  0 = ok (records appended; possibly none), else a status
-int add_sv_record(SvBuilder & b, long pos0, std::string const & vcf_ref, std::string const & alt, std::string const & info,
+int add_sv_record(SvBuilder & b, long pos0, std::string const & vcf_ref, std::string const & alt, std::string const & info, std::string const & vcf_id,
                   std::vector<Rec> & recs, std::string & why)
 {
   Rec var;
@@ -615,6 +650,8 @@ int add_sv_record(SvBuilder & b, long pos0, std::string const & vcf_ref, std::st
   var.is_sv = true;
   SvFields sv;
   sv.begin = pos0 + 1;
+  sv.chrom = b.chr;
+  sv.old_variant_id = vcf_id; // constructor.cpp:1279-1280
   bool is_a_dup = false;
   for (std::string const & kv : split(info, ';'))
   {
@@ -636,11 +673,10 @@ int add_sv_record(SvBuilder & b, long pos0, std::string const & vcf_ref, std::st
       ok = parse_int(val, sv.or_start);
     else if (key == "OREND")
       ok = parse_int(val, sv.or_end);
-    else if (key == "NCLUSTERS" || key == "NUM_MERGED_SVS")
-    {
-      long ignored;
-      ok = parse_int(val, ignored);
-    }
+    else if (key == "NCLUSTERS")
+      ok = parse_int(val, sv.n_clusters);
+    else if (key == "NUM_MERGED_SVS")
+      ok = parse_int(val, sv.num_merged_svs);
     else if (key == "SEQ" || key == "SVINSSEQ" || key == "LEFT_SVINSSEQ" || key == "RIGHT_SVINSSEQ" || key == "DUPSVINSSEQ")
     {
       if (!val.empty() && val[0] != '.') // parse_info_str (constructor.cpp:61-77)
@@ -691,7 +727,7 @@ int add_sv_record(SvBuilder & b, long pos0, std::string const & vcf_ref, std::st
   switch (sv.type)
   {
   case SV_BND:
-    if (!b.breakend(var, alt))
+    if (!b.breakend(var, alt, sv))
     {
       why = "invalid breakend allele '" + alt + "'";
       return GTX_ERR_ARG;
@@ -747,7 +783,8 @@ extern "C" int gtx_graph_from_files(const char * fasta_path, const char * vcf_pa
   }
   std::vector<Rec> recs;
   unsigned n_sv = 0; // Graph::SVs.size(): numbers the SV tags
-  SvBuilder svb{fasta_path, reg.chr, &n_sv, std::string()};
+  std::string sv_table;
+  SvBuilder svb{fasta_path, reg.chr, &n_sv, std::string(), &sv_table};
   if (vcf_path && vcf_path[0])
   {
     gzFile z = gzopen(vcf_path, "rb"); // reads plain text as well; bgzip files are concatenated gzip members
@@ -805,7 +842,7 @@ extern "C" int gtx_graph_from_files(const char * fasta_path, const char * vcf_pa
             return GTX_ERR_UNSUPPORTED; // (the reference exits: constructor.cpp:1245-1256)
           }
           std::string why;
-          int const rc = add_sv_record(svb, rpos, rref, ralt, rinfo, recs, why);
+          int const rc = add_sv_record(svb, rpos, rref, ralt, rinfo, col.size() > 2 ? col[2] : std::string(), recs, why);
           if (rc != GTX_OK)
           {
             gzclose(z);
@@ -870,6 +907,9 @@ extern "C" int gtx_graph_from_files(const char * fasta_path, const char * vcf_pa
     *region_end = end;
   // extend_prefix = 1: add_reference_to_record_if_they_have_a_matching_prefix on every record (constructor.cpp:1740-1744)
   // (the region end the reference hands to add_genomic_region is the one of the region string, not clipped to the contig)
-  return gtx_graph_build(refseq.data(), refseq.size(), reg.begin, reg.end, records.data(), static_cast<uint32_t>(records.size()),
-                         add_all_variants, is_sv_graph, 1, out);
+  int const rc = gtx_graph_build(refseq.data(), refseq.size(), reg.begin, reg.end, records.data(), static_cast<uint32_t>(records.size()),
+                                 add_all_variants, is_sv_graph, 1, out);
+  if (rc == GTX_OK)
+    gtx::graph_set_sv_table(*out, std::move(sv_table));
+  return rc;
 }

@@ -227,7 +227,13 @@ struct gtx_graph
   std::vector<uint32_t> var_order, var_len, var_dna_off, var_out_ref, event_off;
   std::vector<int64_t> event_val;
   std::string dna;
+  std::string sv_table; // Graph::SVs of a graph made from files with structural variants (gtx_graph_sv_table)
 };
+
+namespace gtx
+{
+void graph_set_sv_table(gtx_graph * g, std::string table) { g->sv_table = std::move(table); }
+} // namespace gtx
 
 extern "C"
 {
@@ -485,6 +491,16 @@ extern "C"
     out->dna_len = g->dna.size();
     out->event_off = g->event_val.empty() ? nullptr : g->event_off.data();
     out->event_val = g->event_val.empty() ? nullptr : g->event_val.data();
+    return GTX_OK;
+  }
+
+  int gtx_graph_sv_table(const gtx_graph * g, char * out, uint64_t cap, uint64_t * len)
+  {
+    if (!g || !len)
+      return GTX_ERR_ARG;
+    *len = g->sv_table.size();
+    if (out && cap)
+      std::memcpy(out, g->sv_table.data(), static_cast<size_t>(std::min<uint64_t>(cap, g->sv_table.size())));
     return GTX_OK;
   }
 

@@ -21,7 +21,7 @@ ST_ERROR_MASK = 15
 # names every build of libgtx.so must export (checked by tests/test_abi.py against include/gtx.h)
 EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy", "gtx_ctx_special_positions",
            "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_ctx_near_pairs", "gtx_index_stats", "gtx_index_get", "gtx_index_dump", "gtx_ctx_hint_table",
-           "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_exact_pass_tasks", "gtx_ctx_pass_times", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
+           "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_exact_pass_tasks", "gtx_graph_sv_table", "gtx_ctx_pass_times", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_set_coverage", "gtx_stream_finish", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
            "gtx_graph_destroy",
            "gtx_scores_alloc", "gtx_scores_zero", "gtx_scores_free", "gtx_scores_reduce", "gtx_comm_unique_id", "gtx_comm_init_rank",
@@ -125,6 +125,7 @@ def lib():
                                           C.POINTER(C.c_uint64)]
         L.gtx_ctx_big_records_rewind.argtypes = [C.c_void_p, C.c_void_p]
         L.gtx_ctx_exact_pass_tasks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.gtx_graph_sv_table.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.gtx_ctx_pass_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.gtx_ctx_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.gtx_ctx_error_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
@@ -333,14 +334,23 @@ def _graph_tables(h):
         L.gtx_graph_destroy(h)
 
 
-def graph_from_files(fasta, vcf, region, add_all_variants=False, is_sv_graph=False):
+def graph_from_files(fasta, vcf, region, add_all_variants=False, is_sv_graph=False, with_sv_table=False):
     """gtx_graph_from_files (construct_graph, src/graph/constructor.cpp:1597-1777): node tables + (begin, end) of the
-    reference span that was read (0-based)"""
+    reference span that was read (0-based) [+ Graph::SVs as text: gtx_graph_sv_table]"""
+    L = lib()
     h = C.c_void_p()
     b, e = C.c_int64(), C.c_int64()
-    check(lib().gtx_graph_from_files(str(fasta).encode(), (str(vcf) if vcf else "").encode(), region.encode(), int(add_all_variants),
-                                     int(is_sv_graph), C.byref(h), C.byref(b), C.byref(e)))
-    return _graph_tables(h), (int(b.value), int(e.value))
+    check(L.gtx_graph_from_files(str(fasta).encode(), (str(vcf) if vcf else "").encode(), region.encode(), int(add_all_variants),
+                                 int(is_sv_graph), C.byref(h), C.byref(b), C.byref(e)))
+    table = None
+    if with_sv_table:
+        n = C.c_uint64()
+        check(L.gtx_graph_sv_table(h, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(int(n.value) + 1)
+        check(L.gtx_graph_sv_table(h, buf, int(n.value), C.byref(n)))
+        table = buf.raw[:int(n.value)].decode()
+    tables = _graph_tables(h)
+    return (tables, (int(b.value), int(e.value)), table) if with_sv_table else (tables, (int(b.value), int(e.value)))
 
 
 def pack_nibbles(codes, stride=None):

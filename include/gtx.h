@@ -136,6 +136,12 @@ int gtx_graph_build(const char * reference, uint64_t reference_len, int64_t regi
 int gtx_graph_from_files(const char * fasta_path, const char * vcf_path, const char * region, int add_all_variants, int is_sv_graph,
                          gtx_graph ** out, int64_t * region_begin, int64_t * region_end);
 int gtx_graph_get_view(const gtx_graph *, gtx_graph_view * out);
+/* Graph::SVs (include/graphtyper/graph/sv.hpp:36-63) of a graph made by gtx_graph_from_files with structural variants, as
+ * text: one SV per line in the order of the <SV:nnnnnnn> tags of the allele sequences, tab separated: type chrom begin length
+ * size end n_clusters num_merged_svs or_start or_end related_sv model old_variant_id inv_type seq hom_seq ins_seq
+ * ins_seq_left ins_seq_right original_alt ("." for an empty field).  gtx_vcf_records needs it for the calls of an SV graph.
+ * Writes min(*len, cap) bytes (out may be NULL with cap 0 to ask for the length). */
+int gtx_graph_sv_table(const gtx_graph *, char * out, uint64_t cap, uint64_t * len);
 void gtx_graph_destroy(gtx_graph *);
 
 /* Options the path reads (include/graphtyper/utilities/options.hpp:34,82,87,89,90) */

@@ -33,8 +33,12 @@ def _write(tmp_path, seqs, lines):
 
 def _compare(fa_path, vcf_path, seqs, lines, chrom, region=None):
     region = region or chrom
-    g, (rb, re_) = gtx.graph_from_files(fa_path, vcf_path, region, is_sv_graph=True)
-    recs = sv_constructor.sv_records(seqs, lines, chrom, region_begin=rb, region_end=re_ if ":" in region and "-" in region else 0xFFFFFFFF)
+    g, (rb, re_), table = gtx.graph_from_files(fa_path, vcf_path, region, is_sv_graph=True, with_sv_table=True)
+    recs, want_table = sv_constructor.sv_records(seqs, lines, chrom, region_begin=rb, region_end=re_ if ":" in region and "-" in region else 0xFFFFFFFF,
+                                                 with_table=True)
+    # Graph::SVs (what the calls' post-processing reads: type, breakpoint model, the other breakpoint, sizes, sequences)
+    assert table.split("\n") == want_table.split("\n")
+    assert table.count("\n") >= g["dna"].tobytes().decode().count("<SV:")  # (a breakpoint record behind the region is dropped, its SV stays registered)
     ref = "".join(c if c in "ACGT" else "N" for c in seqs[chrom].upper())[rb:re_]
     o = Oracle(ref, recs, region_begin=rb, is_sv_graph=True, extend_prefix=True)
     og = o.graph()
