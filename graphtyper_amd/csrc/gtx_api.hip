@@ -1347,12 +1347,16 @@ int ctx_upload(gtx_ctx & c, int device)
       char const * xm = std::getenv("GTX_EXACT_PASS_MB");
       uint64_t mb = c.params.exact_pass_mb ? c.params.exact_pass_mb : (xm && std::atol(xm) > 0) ? static_cast<uint64_t>(std::atol(xm)) : (c.has_wide_sites ? 1024u : 512u);
       c.exact_slab_bytes = mb << 20;
-      // parts of 8 MB (64 MB where allele sets are wide), at most 64: the tasks that come this far come in bulk -- every read
-      // over one long repeat -- and what one task takes is milliseconds of dependent round trips
-      c.exact_parts = static_cast<uint32_t>(std::min<uint64_t>(64u, std::max<uint64_t>(1u, mb / (c.has_wide_sites ? 64u : 8u))));
+      // at most 256 parts, none smaller than 2 MB (32 MB where allele sets are wide); the kernel makes as many as there are tasks:
+      // the tasks that come this far come in bulk -- every read over one long repeat -- and what one task takes is milliseconds
+      // of dependent round trips
+      c.exact_parts = static_cast<uint32_t>(std::min<uint64_t>(256u, std::max<uint64_t>(1u, mb / (c.has_wide_sites ? 32u : 2u))));
       if (char const * xp = std::getenv("GTX_EXACT_PARTS")) // (tests: smaller parts, so that tasks reach the launch with the whole slab)
         if (std::atol(xp) > 0)
+        {
           c.exact_parts = static_cast<uint32_t>(std::min<long>(std::atol(xp), 1024));
+          c.exact_fixed_parts = true;
+        }
     }
     void * p = nullptr;
     ok = ok && hip_ok(gtx::dev_malloc(&p, c.big_record_words * sizeof(uint32_t)), "big-record arena");
@@ -1818,6 +1822,7 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     a.exact_cand_cap = c->exact_cand_cap;
     a.exact_part_cand_cap = std::min<uint32_t>(c->exact_cand_cap, CallScratch::EXACT_PART_CANDIDATES);
     a.exact_parts = c->exact_parts;
+    a.exact_fixed_parts = c->exact_fixed_parts;
     a.wide_sites = c->has_wide_sites;
     a.arena = c->d_big_records;
     a.arena_words = c->big_record_words;

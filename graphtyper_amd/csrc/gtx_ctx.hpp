@@ -94,7 +94,8 @@ struct gtx_ctx
   bool has_wide_sites = false; // some site has more than 64 alleles: the wide-site passes (alignment, scoring) exist
   uint64_t exact_slab_bytes = 0; // slab of the exact alignment pass, per call in flight (gtx_params::exact_pass_mb / GTX_EXACT_PASS_MB)
   uint32_t exact_cand_cap = 0;   // walk candidates a task of that pass can have alive: exact_cand_cap(widest site of the graph)
-  uint32_t exact_parts = 0;      // workgroups (= parts of the slab) of the pass' first launch
+  uint32_t exact_parts = 0;      // workgroups (= the most parts of the slab) of the pass' first launch
+  bool exact_fixed_parts = false; // GTX_EXACT_PARTS (tests): always that many parts
   static constexpr uint32_t SCORE_QUEUE_CAP = 1u << 20, SCORE_BIG_THREADS = 1024;
   // arena for records longer than a record slot: shared by all calls (it only grows; the cursor is a device counter)
   uint32_t * d_big_records = nullptr;

@@ -107,14 +107,26 @@ constexpr uint32_t EXACT_LDS_KEYS = 4096; // paths whose dense start / end table
   __global__ __launch_bounds__(64) GTX_HBM_PASS_ATTR void NAME(GraphView g, IndexView ix, uint8_t const * __restrict__ seq, uint32_t seq_stride, \
                                              gtx_read_meta const * __restrict__ meta, uint32_t * __restrict__ records,             \
                                              uint32_t rec_words, uint32_t const * __restrict__ big_tasks, uint32_t big_task_cap,   \
-                                             uint32_t * big_state, uint8_t * slab, unsigned long long part_bytes, uint32_t cand_cap, \
-                                             uint32_t cap_v,                                                                       \
+                                             uint32_t * big_state, uint8_t * slab, unsigned long long part_bytes /* the slab's */,   \
+                                             unsigned long long min_part_bytes, uint32_t fixed_parts, uint32_t cand_cap, uint32_t cap_v, \
                                              uint32_t * __restrict__ arena,                                                        \
                                              unsigned long long arena_words, unsigned long long * arena_cursor,                    \
                                              uint32_t * __restrict__ next_tasks, uint32_t next_cap, uint32_t * next_state)         \
   {                                                                                                                                \
     if (big_state[0] == 0) /* (nearly every batch: nothing reached this pass) */                                                   \
       return;                                                                                                                      \
+    /* The slab is cut into as many parts as there are tasks, at most one per workgroup of the grid and none smaller than      */ \
+    /* min_part_bytes: a handful of tasks get large parts, thousands -- every read over one long repeat -- get small ones and    */ \
+    /* all of the grid (a task is milliseconds of dependent round trips: the tasks in flight are the pass' throughput).          */ \
+    {                                                                                                                              \
+      unsigned long long const q = big_state[0] < big_task_cap ? big_state[0] : big_task_cap;                                      \
+      unsigned long long parts = (q < gridDim.x && !fixed_parts) ? q : gridDim.x; /* (fixed_parts: a test switch, GTX_EXACT_PARTS) */ \
+      if (min_part_bytes && parts * min_part_bytes > part_bytes)                                                                   \
+        parts = part_bytes / min_part_bytes ? part_bytes / min_part_bytes : 1ull;                                                  \
+      if (blockIdx.x >= parts)                                                                                                     \
+        return;                                                                                                                    \
+      part_bytes = (part_bytes / parts) & ~255ull;                                                                                 \
+    }                                                                                                                              \
     NS::AlignWorkspace & ws = *reinterpret_cast<NS::AlignWorkspace *>(slab + static_cast<unsigned long long>(blockIdx.x) * part_bytes); \
     if (!NS::exact_setup<WaveHipMem>(&ws, part_bytes, cand_cap, cap_v))                                                            \
     {                                                                                                                              \
@@ -183,17 +195,17 @@ char const * launch_hbm_passes(HbmPassArgs const & a, hipStream_t stream)
   // with all of it.  Nearly always both find an empty queue and leave at once.
   uint32_t * const q1 = a.exact_tasks, * const q2 = a.exact_tasks + CallScratch::EXACT_TASK_CAP;
   uint32_t * const st1 = a.exact_state, * const st2 = a.exact_state + 8, * const st3 = a.exact_state + 16;
-  unsigned long long const part = (a.exact_slab_bytes / a.exact_parts) & ~255ull;
   auto kernel = a.wide_sites ? gtx_align_exact_wide_kernel : gtx_align_exact_kernel;
+  unsigned long long const slab_bytes = a.exact_slab_bytes, min_part = slab_bytes / a.exact_parts;
   // (a part's paths have room for EXACT_PART_SITES variant sites and its walks for exact_part_cand_cap candidates; the whole
   //  slab for the proven bounds: a site per read base, 128 live sequences times the alleles of the graph's widest site)
   hipLaunchKernelGGL(kernel, dim3(a.exact_parts), dim3(64), 0, stream, a.g, a.ix, a.seq, a.seq_stride, a.meta, a.records, a.rec_words, q1,
-                     CallScratch::EXACT_TASK_CAP, st1, a.exact_slab, part, a.exact_part_cand_cap, CallScratch::EXACT_PART_SITES, a.arena, arena_words,
-                     a.arena_cursor, q2, CallScratch::EXACT_TASK_CAP, st2);
+                     CallScratch::EXACT_TASK_CAP, st1, a.exact_slab, slab_bytes, min_part, a.exact_fixed_parts ? 1u : 0u, a.exact_part_cand_cap,
+                     CallScratch::EXACT_PART_SITES, a.arena,
+                     arena_words, a.arena_cursor, q2, CallScratch::EXACT_TASK_CAP, st2);
   // (what even the whole slab cannot hold is counted in st3: a queue of capacity 0)
   hipLaunchKernelGGL(kernel, dim3(1), dim3(64), 0, stream, a.g, a.ix, a.seq, a.seq_stride, a.meta, a.records, a.rec_words, q2, CallScratch::EXACT_TASK_CAP,
-                     st2, a.exact_slab, static_cast<unsigned long long>(a.exact_slab_bytes), a.exact_cand_cap, exact::AlignCfg::MAXV, a.arena, arena_words,
-                     a.arena_cursor, q2, 0u, st3);
+                     st2, a.exact_slab, slab_bytes, 0ull, 0u, a.exact_cand_cap, exact::AlignCfg::MAXV, a.arena, arena_words, a.arena_cursor, q2, 0u, st3);
   if (hipGetLastError() != hipSuccess)
     return "gtx_align_exact_kernel launch";
   return nullptr;

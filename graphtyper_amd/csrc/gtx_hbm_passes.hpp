@@ -37,6 +37,7 @@ struct HbmPassArgs
   uint32_t exact_cand_cap;      // walk candidates of a task that has the whole slab (the proven bound)
   uint32_t exact_part_cand_cap; // ... of a task that has a part of it
   uint32_t exact_parts;         // workgroups of the first launch
+  bool exact_fixed_parts;       // (test switch) always that many parts, however few tasks there are
   bool wide_sites;
   // big-record arena
   uint32_t * arena;

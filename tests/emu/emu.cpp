@@ -246,7 +246,7 @@ extern "C"
     std::vector<uint8_t> & exact_slab = e.exact_slab;
     if (exact_slab.empty())
       exact_slab.resize(static_cast<size_t>(e.params.exact_pass_mb ? e.params.exact_pass_mb : xm && std::atol(xm) > 0 ? std::atol(xm) : (has_wide_sites ? 1024 : 512)) << 20);
-    uint64_t exact_parts = std::min<uint64_t>(64u, std::max<uint64_t>(1u, (exact_slab.size() >> 20) / (has_wide_sites ? 64u : 8u)));
+    uint64_t exact_parts = std::min<uint64_t>(256u, std::max<uint64_t>(1u, (exact_slab.size() >> 20) / (has_wide_sites ? 32u : 2u))); // (the smallest part: as on the device with a full queue)
     if (char const * xp = std::getenv("GTX_EXACT_PARTS"))
       if (std::atol(xp) > 0)
         exact_parts = static_cast<uint64_t>(std::min<long>(std::atol(xp), 1024));
