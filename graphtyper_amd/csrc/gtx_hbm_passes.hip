@@ -102,9 +102,11 @@ namespace gtx
 // The exact pass (align_core.hpp: namespace exact): the same body over a workspace whose tables are cut out of the
 // workgroup's part of a slab of HBM at run time.  Launched twice: EXACT_PARTS workgroups with a part each, then one workgroup
 // with the whole slab for what did not fit a part (its queue is the first launch's next_tasks).
+// (at most one workgroup of this pass per CU, usually none with work: no register diet -- all the registers a wavefront can name)
+#define GTX_EXACT_PASS_ATTR __attribute__((amdgpu_waves_per_eu(1, 2)))
 constexpr uint32_t EXACT_LDS_KEYS = 4096; // paths whose dense start / end tables fit the exact pass' 32 KB of LDS
 #define GTX_EXACT_PASS_KERNEL(NAME, NS)                                                                                            \
-  __global__ __launch_bounds__(64) GTX_HBM_PASS_ATTR void NAME(GraphView g, IndexView ix, uint8_t const * __restrict__ seq, uint32_t seq_stride, \
+  __global__ __launch_bounds__(64) GTX_EXACT_PASS_ATTR void NAME(GraphView g, IndexView ix, uint8_t const * __restrict__ seq, uint32_t seq_stride, \
                                              gtx_read_meta const * __restrict__ meta, uint32_t * __restrict__ records,             \
                                              uint32_t rec_words, uint32_t const * __restrict__ big_tasks, uint32_t big_task_cap,   \
                                              uint32_t * big_state, uint8_t * slab, unsigned long long part_bytes /* the slab's */,   \

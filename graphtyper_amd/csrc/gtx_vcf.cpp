@@ -7,8 +7,8 @@
 // Input: the per (haplotype, sample) calls of gtx_calls_batch and the accumulators of gtx_score_batch, as host copies.
 // Here a site is a row of flat arrays, its INFO field a sorted list of (key, text) built once; numbers are printed with
 // printf's %g, which is what the reference's string streams do at the precision they set.
-// Not built: SV post-processing (reformat_sv_vcf_records) -- SV graphs are refused --, variant break-down and the merge of
-// pools (vcf_operations.cpp), the description lines of the header.
+// The calls of an SV graph take another road (sv_graph_records below: reformat_sv_vcf_records and what genotype_sv's merge does).
+// Not built: variant break-down and the merge of pools (vcf_operations.cpp).
 #include "gtx_ctx.hpp"
 
 #include <algorithm>
@@ -17,6 +17,8 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <map>
+#include <numeric>
 #include <string>
 #include <thread>
 #include <vector>
@@ -196,17 +198,975 @@ const char * variant_type(std::vector<std::pair<const char *, uint32_t>> const &
 }
 } // namespace
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The calls of an SV graph (cfg5, `genotype_sv`).  What the reference does between the haplotypes and the VCF text there:
+//   the pool's writer   src/utilities/hts_parallel_reader.cpp:984-1020   Vcf::add_haplotype per site -> reformat_sv_vcf_records
+//                                                                        -> sort by (position, alleles) -> stats.clear()
+//   reformat            src/graph/sv.cpp:117-655                         a site with SV alleles becomes one bi-allelic record per
+//                                                                        SV allele (make_bi_allelic_call, sample_call.cpp:189-253),
+//                                                                        moved to the SV's own position, REF "N", ALT <TYPE:SVSIZE=n:MODEL>;
+//                                                                        deletions (and the second breakpoint of a duplication)
+//                                                                        also get a record from the read depth inside / beside them
+//                                                                        (make_call_based_on_coverage, :255-385) and an AGGREGATED
+//                                                                        record that takes, per sample, the more confident of the
+//                                                                        two calls; the second breakpoint of an insertion / inversion
+//                                                                        is aggregated with the first
+//   the merge           src/utilities/genotype_sv.cpp:125 -> vcf_merge_and_break(force_no_break_down), vcf_operations.cpp:480-700:
+//                                                                        normalize -> generate_infos -> a record whose every
+//                                                                        alternative allele is uncalled is dropped
+//   the writer          src/typer/vcf.cpp:1161-1275                      order, duplicates, ".<n>" behind the ID of a record that
+//                                                                        shares position and type with the one in front of it
+// Built as a small pipeline over one struct (SvRecord); the per-site statistics of the alignment (VarStats) play no part here:
+// the reference clears them before it writes.  Not built: a site that mixes SV and non-SV alleles (find_variant_sequences,
+// variant.cpp:1880-2240), breakend alleles that start with a tag: GTX_ERR_UNSUPPORTED.
+// ---------------------------------------------------------------------------------------------------------------
+namespace
+{
+enum SvKind { K_NOT_SV, K_DEL, K_DEL_ALU, K_DUP, K_INS, K_INS_ALU, K_INV, K_BND, K_OTHER };
+
+struct SvEntry // one line of gtx_graph_sv_table
+{
+  SvKind kind = K_NOT_SV;
+  long begin = 0, length = 0, size = 0, end = 0, n_clusters = 0, num_merged_svs = -1, or_start = -1, or_end = -1, related = -1;
+  std::string model, old_id, inv, seq, hom_seq, ins_seq, ins_left, ins_right, original_alt;
+  char const * type_name() const
+  {
+    static char const * const N[] = {"SV", "DEL", "DEL:ME:ALU", "DUP", "INS", "INS:ME:ALU", "INV", "BND", "SV"};
+    return N[kind];
+  }
+  std::string allele() const // SV::get_allele (sv.cpp:51-64)
+  {
+    std::string a = "<";
+    a += type_name();
+    a += ":SVSIZE=";
+    if (size > 0)
+      put_u(a, static_cast<uint64_t>(size));
+    else
+    {
+      put_u(a, ins_left.size() + ins_right.size());
+      a += '+';
+    }
+    a += '>';
+    return a;
+  }
+};
+
+bool parse_sv_table(char const * text, std::vector<SvEntry> & out, std::string & why)
+{
+  static char const * const KINDS[] = {"NOT_SV", "DEL", "DEL_ALU", "DUP", "INS", "INS_ALU", "INV", "BND", "OTHER"};
+  for (char const * p = text ? text : ""; *p;)
+  {
+    char const * eol = std::strchr(p, '\n');
+    std::string const line(p, eol ? static_cast<size_t>(eol - p) : std::strlen(p));
+    p = eol ? eol + 1 : p + line.size();
+    if (line.empty())
+      continue;
+    std::vector<std::string> f;
+    for (size_t i = 0; i <= line.size();)
+    {
+      size_t const e = std::min(line.find('\t', i), line.size());
+      f.push_back(line.substr(i, e - i));
+      if (f.back() == ".")
+        f.back().clear();
+      i = e + 1;
+    }
+    if (f.size() != 20)
+    {
+      why = "a line of the SV table has " + std::to_string(f.size()) + " fields (20 expected)";
+      return false;
+    }
+    SvEntry sv;
+    int k = -1;
+    for (int i = 0; i < 9; ++i)
+      if (f[0] == KINDS[i])
+        k = i;
+    if (k < 0)
+    {
+      why = "unknown SV type '" + f[0] + "' in the SV table";
+      return false;
+    }
+    sv.kind = static_cast<SvKind>(k);
+    long * const nums[] = {&sv.begin, &sv.length, &sv.size, &sv.end, &sv.n_clusters, &sv.num_merged_svs, &sv.or_start, &sv.or_end, &sv.related};
+    for (int i = 0; i < 9; ++i)
+      *nums[i] = std::atol(f[2 + i].c_str());
+    sv.model = f[11];
+    sv.old_id = f[12];
+    sv.inv = f[13];
+    sv.seq = f[14];
+    sv.hom_seq = f[15];
+    sv.ins_seq = f[16];
+    sv.ins_left = f[17];
+    sv.ins_right = f[18];
+    sv.original_alt = f[19];
+    out.push_back(std::move(sv));
+  }
+  return true;
+}
+
+struct SvCall // SampleCall (include/graphtyper/typer/sample_call.hpp)
+{
+  std::vector<uint8_t> pl;
+  std::vector<uint16_t> ad;
+  uint16_t ref_total = 0, alt_total = 0;
+  uint8_t ambiguous = 0, alt_proper_pair = 0;
+  int filter = -1; // -1: not judged yet (SampleCall::check_filter judges by GQ the first time it is asked)
+
+  uint32_t unique_depth() const { return std::accumulate(ad.begin(), ad.end(), 0u); }
+  void genotype(uint32_t & a, uint32_t & b) const // the first genotype with PL 0, (0, 0) when there is none
+  {
+    size_t i = 0;
+    for (uint32_t y = 0; y < ad.size(); ++y)
+      for (uint32_t x = 0; x <= y; ++x, ++i)
+        if (i < pl.size() && pl[i] == 0)
+        {
+          a = x;
+          b = y;
+          return;
+        }
+    a = b = 0;
+  }
+  long gq() const // the second smallest PL; 0 when two genotypes share PL 0
+  {
+    bool zero = false;
+    long next = 255;
+    for (uint8_t p : pl)
+    {
+      if (p == 0)
+      {
+        if (zero)
+          return 0;
+        zero = true;
+      }
+      else if (p < next)
+        next = p;
+    }
+    return next;
+  }
+  int judged()
+  {
+    if (filter < 0)
+    {
+      long const q = gq();
+      filter = q >= 30 ? 0 : q >= 20 ? 1 : q >= 10 ? 2 : 3;
+    }
+    return filter;
+  }
+  uint8_t lowest_pl_without(uint32_t allele) const
+  {
+    uint8_t m = 255;
+    size_t i = 0;
+    for (uint32_t y = 0; y < ad.size(); ++y)
+      for (uint32_t x = 0; x <= y; ++x, ++i)
+        if (x != allele && y != allele && pl[i] < m)
+          m = pl[i];
+    return m;
+  }
+  void set_pl3(uint64_t g00, uint64_t g01, uint64_t g11)
+  {
+    pl.assign(3, 0);
+    pl[0] = static_cast<uint8_t>(std::min<uint64_t>(255, g00));
+    pl[1] = static_cast<uint8_t>(std::min<uint64_t>(255, g01));
+    pl[2] = static_cast<uint8_t>(std::min<uint64_t>(255, g11));
+  }
+};
+
+struct SvRecord // Variant, as far as this path uses it
+{
+  uint32_t pos = 0;
+  std::vector<std::string> alleles;
+  std::vector<SvCall> calls;
+  std::map<std::string, std::string> info;
+
+  bool has_sv_allele() const // Variant::is_sv (variant.cpp:1098-1118)
+  {
+    for (size_t a = 1; a < alleles.size(); ++a)
+      if (alleles[a].size() >= 5 && (alleles[a][0] == '<' || (alleles[a].size() > 100 && alleles[a].find('<') != std::string::npos)))
+        return true;
+    return false;
+  }
+  std::string type_code() const // Variant::determine_variant_type (variant.cpp:1430-1520)
+  {
+    enum { NONE, DEL, DUP, INS, BND, OTHER } sv = NONE;
+    size_t longer = 0;
+    for (auto const & s : alleles)
+    {
+      if (s.size() <= 1)
+        continue;
+      if (s.size() > 4 && s[0] == '<')
+      {
+        std::string const t = s.substr(1, 3);
+        sv = (t == "DEL" && (sv == NONE || sv == DEL)) ? DEL : (t == "DUP" && (sv == NONE || sv == DUP)) ? DUP : (t == "INS" && (sv == NONE || sv == INS)) ? INS : OTHER;
+      }
+      else if (s.find_first_of("[]") != std::string::npos)
+        sv = (sv == NONE || sv == BND) ? BND : OTHER;
+      else
+        ++longer;
+    }
+    switch (sv)
+    {
+    case DEL: return "DG";
+    case DUP: return "UG";
+    case INS: return "FG";
+    case BND: return "OG";
+    case OTHER: return "TG";
+    default: break;
+    }
+    if (longer == 0)
+      return "SG";
+    if (alleles.size() - longer == 1 || (alleles.size() - longer == 2 && alleles.back() == "*"))
+      return "IG";
+    return "XG";
+  }
+  uint64_t qual() const
+  {
+    uint64_t q = 0;
+    for (auto const & c : calls)
+      if (!c.pl.empty())
+        q += c.pl[0];
+    return q;
+  }
+};
+
+// make_bi_allelic_call (sample_call.cpp:189-253): the call of one site reduced to reference against alternative allele `aa`
+SvCall reduce_to_two_alleles(SvCall const & full, size_t aa)
+{
+  if (full.ad.size() == 2)
+    return full;
+  SvCall c;
+  c.ambiguous = full.ambiguous;
+  c.ref_total = full.ref_total;
+  c.alt_total = full.alt_total;
+  c.alt_proper_pair = full.alt_proper_pair;
+  int const ref_cov = full.ad[0];
+  // what was ambiguous between alternative alleles only is not ambiguous any more
+  int amb_alt = std::min<int>(c.ambiguous, ref_cov + c.ambiguous - c.ref_total);
+  c.ambiguous = static_cast<uint8_t>(c.ambiguous - amb_alt);
+  int alt_cov = c.alt_total - c.ambiguous;
+  for (size_t a = 1; a < full.ad.size(); ++a)
+    if (a != aa + 1)
+    {
+      alt_cov -= full.ad[a];
+      c.alt_total = static_cast<uint16_t>(std::max(0, static_cast<int>(c.alt_total) - static_cast<int>(full.ad[a])));
+      c.alt_proper_pair = static_cast<uint8_t>(std::max(0, static_cast<int>(c.alt_proper_pair) - static_cast<int>(full.ad[a])));
+    }
+  c.ad = {static_cast<uint16_t>(ref_cov), static_cast<uint16_t>(std::max(alt_cov, 0))};
+  int const not_proper = c.ad[1] > c.alt_proper_pair ? c.ad[1] - c.alt_proper_pair : 0, proper = c.ad[1] - not_proper;
+  uint64_t const g00 = 24ull * proper + 12ull * not_proper, g01 = 3ull * (static_cast<uint64_t>(c.ad[0]) + c.ad[1]), g11 = 24ull * c.ad[0];
+  uint64_t const low = std::min(g00, std::min(g01, g11));
+  c.set_pl3(g00 - low, g01 - low, g11 - low);
+  return c;
+}
+
+// make_call_based_on_coverage (sample_call.cpp:255-385): a deletion (duplication, inversion) judged by the read depth at up to
+// 101 points inside it against 101 points within a kilobase on either side; `depth`: one sample's finalised track, position
+// `first` at index 0
+bool call_from_depth(SvEntry const & sv, uint32_t const * depth, uint32_t n_depth, uint32_t first, SvCall & call)
+{
+  auto at = [&](long pos) -> long
+  {
+    if (n_depth == 0)
+      return 0;
+    long const i = pos < static_cast<long>(first) ? 0 : pos - static_cast<long>(first);
+    return static_cast<long>(std::min<uint32_t>(depth[std::min<long>(i, static_cast<long>(n_depth) - 1)], 0xFFFFu));
+  };
+  long const begin = sv.begin, end = begin + std::min<long>(sv.size, 190000);
+  long constexpr POINTS = 101, STEP = 20;
+  std::vector<long> inside, outside;
+  {
+    long const span = end - begin - 2 * STEP;
+    long n = std::min(POINTS, span);
+    if (n % 2 == 0)
+      --n;
+    for (long i = 1; i <= n; ++i)
+      inside.push_back(at((i * span) / (n + 1) + begin + STEP));
+  }
+  for (long i = 1; i <= POINTS / 2 + 1; ++i)
+    outside.push_back(at(std::max(begin - i * STEP, 0l)));
+  if (sv.size < 190000)
+    for (long i = 1; i <= POINTS / 2; ++i)
+      outside.push_back(at(std::max(end + i * STEP, 0l)));
+  if (inside.empty() || outside.empty())
+    return false; // (an SV of 40 bases or fewer: the reference takes the median of nothing)
+  auto median = [](std::vector<long> & v)
+  {
+    std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+    return v[v.size() / 2];
+  };
+  long const m_out = median(outside), m_in = median(inside);
+  auto u16 = [](long v) { return static_cast<uint16_t>(std::max(0l, std::min(0xFFFFl, v))); };
+  if (sv.kind == K_DEL || sv.kind == K_DEL_ALU)
+    call.ad = {u16(m_in), u16(m_out - m_in)};
+  else
+  {
+    double const centre = static_cast<double>(m_out + m_in) / 2.0;
+    long const gain = m_in - m_out;
+    if (gain <= 0)
+      call.ad = {u16(std::lround(centre)), 0};
+    else if (gain >= 2 * m_in)
+      call.ad = {0, u16(std::lround(centre))};
+    else
+    {
+      uint16_t const r = u16(std::lround((1.0 - static_cast<double>(gain) / static_cast<double>(m_out)) * centre));
+      call.ad = {r, u16(static_cast<long>(centre - r))};
+    }
+  }
+  uint64_t g00 = 12ull * call.ad[1], g01 = 3ull * (static_cast<uint64_t>(call.ad[0]) + call.ad[1]), g11 = 12ull * call.ad[0];
+  uint64_t const low = std::min(g00, std::min(g01, g11));
+  g00 -= low;
+  g01 -= low;
+  g11 -= low;
+  // (the model is trusted less for short SVs and more for long ones)
+  uint64_t const num = sv.size <= 100 ? 2 : sv.size > 1000 ? 3 : 1, den = sv.size <= 100 ? 3 : sv.size > 1000 ? 2 : 1;
+  call.set_pl3(g00 * num / den, g01 * num / den, g11 * num / den);
+  return true;
+}
+
+// Variant::scan_calls + generate_infos (variant.cpp:230-1096) as they run in an SV graph once the alignment statistics have been
+// cleared: the INFO fields that are functions of the calls.  Returns, per alternative allele, whether any sample was called with it.
+std::vector<char> summarise(SvRecord & r)
+{
+  size_t const n_alleles = r.alleles.size();
+  struct PerAllele
+  {
+    uint64_t qd_qual = 0, qd_depth = 0;
+    uint32_t ac = 0, pass_ac = 0, hom_ref = 0, het = 0, hom_alt = 0;
+    uint16_t max_support = 0;
+    double max_support_ratio = 0.0;
+  };
+  std::vector<PerAllele> al(n_alleles);
+  uint32_t genotyped = 0, passed = 0;
+  uint64_t seqdepth = 0, het_a = 0, het_b = 0, hom_a = 0, hom_b = 0;
+  uint8_t max_alt_pp = 0;
+  long qd_qual = 0, qd_depth = 0;
+  for (SvCall & c : r.calls)
+  {
+    uint32_t g1, g2;
+    c.genotype(g1, g2);
+    uint32_t const unique = c.unique_depth();
+    if (!c.pl.empty() && c.pl[0] > 0)
+    {
+      long const alt_depth = std::min<long>(10, static_cast<long>(unique - c.ad[0] + c.ambiguous));
+      if (alt_depth > 0)
+      {
+        qd_qual += std::min<long>(25 * alt_depth, c.pl[0]);
+        qd_depth += alt_depth;
+      }
+      for (int k = 0; k < 2; ++k)
+      {
+        uint32_t const a = k ? g2 : g1;
+        if ((k == 0 && a == 0) || (k == 1 && g1 == g2))
+          continue;
+        long const d = std::min<long>(10, static_cast<long>(c.ad[a]) + c.ambiguous);
+        if (d > 0)
+        {
+          al[a].qd_qual += static_cast<uint64_t>(std::min<long>(25 * d, c.lowest_pl_without(a)));
+          al[a].qd_depth += static_cast<uint64_t>(d);
+        }
+      }
+    }
+    max_alt_pp = std::max(max_alt_pp, c.alt_proper_pair);
+    for (uint32_t a = 1; a < n_alleles; ++a)
+    {
+      al[a].max_support = std::max(al[a].max_support, c.ad[a]);
+      if (unique > 0)
+        al[a].max_support_ratio = std::max(al[a].max_support_ratio, static_cast<double>(c.ad[a]) / static_cast<double>(unique));
+      if (g1 == a || g2 == a)
+        ++(g1 == g2 ? al[a].hom_alt : al[a].het);
+      else
+        ++al[a].hom_ref;
+    }
+    int const verdict = c.judged();
+    genotyped += std::any_of(c.pl.begin(), c.pl.end(), [](uint8_t p) { return p != 0; });
+    passed += verdict == 0;
+    if (g1 != g2)
+    {
+      het_a += c.ad[g1];
+      het_b += c.ad[g2];
+    }
+    else
+    {
+      hom_a += c.ad[g1];
+      hom_b += unique - c.ad[g1];
+    }
+    seqdepth += unique + c.ambiguous;
+    ++al[g1].ac;
+    ++al[g2].ac;
+    if (verdict == 0)
+    {
+      ++al[g1].pass_ac;
+      ++al[g2].pass_ac;
+    }
+  }
+  auto & info = r.info;
+  auto list = [&](char const * key, auto && value)
+  {
+    std::string s;
+    for (size_t a = 1; a < n_alleles; ++a)
+    {
+      if (a > 1)
+        s += ',';
+      value(s, al[a]);
+    }
+    info[key] = s;
+  };
+  info["RefLen"] = std::to_string(r.alleles[0].size());
+  {
+    auto const e = info.find("END"); // END is never in front of POS
+    if (e != info.end())
+      e->second = std::to_string(std::max(std::strtol(e->second.c_str(), nullptr, 10), static_cast<long>(r.pos)));
+  }
+  list("MaxAAS", [](std::string & s, PerAllele const & p) { put_u(s, p.max_support); });
+  list("MaxAASR", [](std::string & s, PerAllele const & p) { put_g(s, p.max_support_ratio, 4); });
+  list("NHomRef", [](std::string & s, PerAllele const & p) { put_u(s, p.hom_ref); });
+  list("NHet", [](std::string & s, PerAllele const & p) { put_u(s, p.het); });
+  list("NHomAlt", [](std::string & s, PerAllele const & p) { put_u(s, p.hom_alt); });
+  list("PexcessHet", [](std::string & s, PerAllele const & p) { put_g(s, excess_het_p(static_cast<int>(p.het), static_cast<int>(p.hom_ref), static_cast<int>(p.hom_alt)), 6); });
+  if (r.has_sv_allele())
+    info["MaxAltPP"] = std::to_string(static_cast<unsigned>(max_alt_pp));
+  list("AC", [](std::string & s, PerAllele const & p) { put_u(s, p.ac); });
+  info["AN"] = std::to_string(2ull * genotyped);
+  list("AF", [&](std::string & s, PerAllele const & p)
+       {
+         if (genotyped > 0)
+           put_g(s, static_cast<double>(p.ac) / static_cast<double>(2 * genotyped), 4);
+         else
+           s += "0.0";
+       });
+  list("PASS_AC", [](std::string & s, PerAllele const & p) { put_u(s, p.pass_ac); });
+  info["PASS_AN"] = std::to_string(2ull * passed);
+  if (genotyped > 0)
+  {
+    std::string s;
+    put_g(s, static_cast<double>(passed) / static_cast<double>(genotyped), 4);
+    info["PASS_ratio"] = s;
+  }
+  info["SeqDepth"] = std::to_string(seqdepth);
+  auto balance = [&](char const * key, uint64_t num, uint64_t other)
+  {
+    std::string s;
+    uint32_t const total = static_cast<uint32_t>(num + other);
+    if (total > 0)
+      put_g(s, static_cast<double>(static_cast<uint32_t>(num)) / static_cast<double>(total), 4);
+    else
+      s = "-1";
+    info[key] = s;
+  };
+  balance("ABHet", het_b, het_a);
+  balance("ABHom", hom_a, hom_b);
+  info["VarType"] = r.type_code();
+  {
+    std::string s;
+    put_g(s, qd_depth == 0 ? 0.0 : static_cast<double>(qd_qual) / static_cast<double>(qd_depth), 4);
+    info["QD"] = s;
+  }
+  // (what generate_infos computes next -- SB, MQ, the per-allele balances -- it erases again in an SV graph: variant.cpp:861-884)
+  std::vector<char> called(n_alleles - 1);
+  for (size_t a = 1; a < n_alleles; ++a)
+    called[a - 1] = al[a].ac > 0;
+  return called;
+}
+
+// make_variant_with_combined_calls (sv.cpp:232-308): per sample the more confident of two calls, and a verdict on their agreement
+SvRecord aggregate(SvRecord const & first, SvRecord const & second)
+{
+  SvRecord out = first;
+  for (size_t i = 0; i < first.calls.size(); ++i)
+  {
+    SvCall const & a = first.calls[i];
+    SvCall const & b = second.calls[i];
+    SvCall & c = out.calls[i];
+    uint32_t a1, a2, b1, b2;
+    a.genotype(a1, a2);
+    b.genotype(b1, b2);
+    long const gq_a = a.gq(), gq_b = b.gq();
+    if (gq_b > gq_a)
+      c = b;
+    long const high = gq_b, low = gq_a; // (sv.cpp:246-261: "max_gq" is the second call's GQ and "min_gq" the first call's, whichever is larger)
+    if (a.filter > 0 && b.filter > 0)
+      c.filter = 3;
+    else if (a.filter > 0)
+      c.filter = a.filter;
+    else if (b.filter > 0)
+      c.filter = b.filter;
+    else if (a.unique_depth() >= 10 && b.unique_depth() >= 10)
+    {
+      uint32_t c1, c2;
+      c.genotype(c1, c2);
+      size_t const idx = c1 + static_cast<size_t>(c2 + 1) * c2 / 2;
+      bool const agree = c1 == a1 && c2 == a2 && c1 == b1 && c2 == b2;
+      c.filter = (agree && low > 10) ? 0 : (high > 40 && static_cast<int>(a.pl[idx]) + static_cast<int>(b.pl[idx]) <= 20) ? 0 : high > 30 ? 1 : 2;
+    }
+    else
+      c.filter = 3;
+  }
+  summarise(out);
+  return out;
+}
+
+// left-alignment of a record whose alleles start with the same base (Variant::normalize, variant.cpp:1256-1315); returns how
+// far it moved.  `ref` is the region's reference from position `first` on.
+long left_align(SvRecord & r, std::string const & ref, uint32_t first)
+{
+  auto & al = r.alleles;
+  if (al.size() < 2)
+    return 0;
+  for (size_t i = 0; i < al.size(); ++i)
+    if (al[i].empty() || al[i][0] != al[0][0] || (i > 0 && al[i] == al[0]))
+      return 0;
+  auto strip_suffix = [&]()
+  {
+    while (al[0].size() > 1)
+    {
+      for (size_t a = 1; a < al.size(); ++a)
+        if (al[a].size() <= 1 || al[a].back() != al[0].back())
+          return;
+      for (auto & s : al)
+        s.pop_back();
+    }
+  };
+  auto same_last = [&]()
+  {
+    for (size_t a = 1; a < al.size(); ++a)
+      if (al[a].back() != al[0].back())
+        return false;
+    return true;
+  };
+  strip_suffix();
+  long moved = 0;
+  while (same_last())
+  {
+    // the base in front of the record (add_base_in_front): inside the region's reference and one of A, C, G, T
+    if (r.pos <= first || r.pos - 1 - first >= ref.size())
+      break;
+    char const b = ref[r.pos - 1 - first];
+    if (b != 'A' && b != 'C' && b != 'G' && b != 'T')
+      break;
+    for (auto & s : al)
+      if (s != "*")
+        s.insert(s.begin(), b);
+    --r.pos;
+    ++moved;
+    strip_suffix();
+  }
+  while (al[0].size() > 1) // remove_common_prefix, not keeping a match
+  {
+    bool all = true;
+    for (size_t a = 1; a < al.size(); ++a)
+      all = all && al[a].size() > 1 && al[a][0] == al[0][0];
+    if (!all)
+      break;
+    ++r.pos;
+    for (auto & s : al)
+      s.erase(s.begin());
+  }
+  return moved;
+}
+
+int sv_graph_records(gtx_ctx const * c, gtx_vcf_request const * rq, std::string & text)
+{
+  gtx::HostGraph const & g = c->graph;
+  uint32_t const nh = g.n_hap, ns = rq->n_samples;
+  std::vector<SvEntry> svs;
+  std::string why;
+  if (!parse_sv_table(rq->sv_table, svs, why))
+  {
+    gtx::g_last_error = "gtx_vcf_records: " + why;
+    return GTX_ERR_ARG;
+  }
+  uint32_t const first_pos = g.ref_order.empty() ? 1u : g.ref_order.front();
+  if (rq->ref_depth == nullptr && ns > 0)
+  {
+    gtx::g_last_error = "gtx_vcf_records: the calls of an SV graph need the reference-depth track (gtx_vcf_request::ref_depth)";
+    return GTX_ERR_ARG;
+  }
+  // ---- one record per site: Vcf::add_haplotype
+  std::vector<SvRecord> sites(nh);
+  for (uint32_t h = 0; h < nh; ++h)
+  {
+    uint32_t const cnum = g.ref_nvar[h], v0 = g.ref_first_var[h], n_tri = cnum * (cnum + 1) / 2;
+    SvRecord & r = sites[h];
+    r.pos = g.var_order[v0];
+    for (uint32_t a = 0; a < cnum; ++a)
+      r.alleles.emplace_back(g.dna.data() + g.var_dna[v0 + a], g.var_len[v0 + a]);
+    r.calls.resize(ns);
+    for (uint32_t s = 0; s < ns; ++s)
+    {
+      SvCall & call = r.calls[s];
+      const uint8_t * pl = rq->phred + static_cast<uint64_t>(s) * g.total_tri + g.tri_off[h];
+      const uint32_t * cov = rq->gt_cov + static_cast<uint64_t>(s) * g.total_allele + g.allele_off[h];
+      gtx_sample_call const & sc = rq->calls[static_cast<uint64_t>(s) * nh + h];
+      call.pl.assign(pl, pl + n_tri);
+      for (uint32_t a = 0; a < cnum; ++a)
+        call.ad.push_back(static_cast<uint16_t>(std::min<uint32_t>(cov[a], 0xFFFFu)));
+      call.ref_total = sc.ref_total_depth;
+      call.alt_total = sc.alt_total_depth;
+      call.ambiguous = sc.ambiguous_depth;
+      call.alt_proper_pair = sc.alt_proper_pair_depth;
+    }
+  }
+  // ---- reformat: the sites that carry SV alleles become the SVs' own records
+  std::vector<SvRecord> made, untouched;
+  std::map<long, size_t> first_breakpoint; // SV id -> the record (in `made`) of the breakpoint that names it as its partner
+  auto finish = [&](SvRecord && r, SvEntry const & sv, std::string const & model) // add_sv_to_new_vars_vector (sv.cpp:310-391)
+  {
+    if (sv.kind == K_BND)
+      r.alleles[1] = sv.original_alt;
+    else if (!model.empty())
+    {
+      r.alleles[1].back() = ':';
+      r.alleles[1] += model;
+      r.alleles[1] += '>';
+    }
+    auto & info = r.info;
+    info["SVTYPE"] = sv.type_name();
+    info["END"] = std::to_string(std::max(sv.begin, sv.end));
+    if (sv.length != 0)
+    {
+      info["SVSIZE"] = std::to_string(sv.size);
+      info["SVLEN"] = std::to_string(sv.length);
+    }
+    if (!model.empty())
+      info["SVMODEL"] = model;
+    if (sv.or_start != -1)
+    {
+      info["ORSTART"] = std::to_string(sv.or_start);
+      info["OREND"] = std::to_string(sv.or_end);
+    }
+    auto put = [&](char const * key, std::string const & v)
+    {
+      if (!v.empty())
+        info[key] = v;
+    };
+    put("SEQ", sv.seq);
+    if (sv.n_clusters > 0)
+      info["NCLUSTERS"] = std::to_string(sv.n_clusters);
+    if (sv.num_merged_svs >= 0)
+      info["NUM_MERGED_SVS"] = std::to_string(sv.num_merged_svs);
+    if (sv.old_id != ".")
+      put("OLD_VARIANT_ID", sv.old_id);
+    put("HOMSEQ", sv.hom_seq);
+    put("SVINSSEQ", sv.ins_seq);
+    put("LEFT_SVINSSEQ", sv.ins_left);
+    put("RIGHT_SVINSSEQ", sv.ins_right);
+    if (sv.kind == K_INV && !sv.inv.empty())
+    {
+      if (sv.inv == "INV3" || sv.inv == "BOTH")
+        info["INV3"] = "";
+      if (sv.inv == "INV5" || sv.inv == "BOTH")
+        info["INV5"] = "";
+    }
+    made.push_back(std::move(r));
+  };
+  for (uint32_t h = 0; h < nh; ++h)
+  {
+    SvRecord const & site = sites[h];
+    std::vector<long> id(site.alleles.size() - 1, -1);
+    bool any = false, plain = false;
+    for (size_t a = 1; a < site.alleles.size(); ++a)
+    {
+      size_t const at = site.alleles[a].find('<');
+      if (at != std::string::npos && site.alleles[a].size() - at > 11) // "<SV:nnnnnnn>"
+      {
+        id[a - 1] = std::atol(site.alleles[a].substr(at + 4, 7).c_str());
+        if (id[a - 1] < 0 || id[a - 1] >= static_cast<long>(svs.size()))
+        {
+          gtx::g_last_error = "gtx_vcf_records: an allele names SV " + std::to_string(id[a - 1]) + ", the SV table has " + std::to_string(svs.size());
+          return GTX_ERR_ARG;
+        }
+        any = true;
+      }
+      else
+        plain = true;
+    }
+    if (!any)
+    {
+      untouched.push_back(site);
+      continue;
+    }
+    if (plain)
+    {
+      gtx::g_last_error = "gtx_vcf_records: a site with SV and non-SV alleles is not supported";
+      return GTX_ERR_UNSUPPORTED;
+    }
+    for (size_t aa = 0; aa < id.size(); ++aa)
+    {
+      SvEntry const & sv = svs[static_cast<size_t>(id[aa])];
+      SvRecord r; // make_new_sv_var (sv.cpp:176-230) + add_sv_variant (:393-510)
+      r.pos = static_cast<uint32_t>(sv.begin);
+      r.alleles = {site.alleles[0], site.alleles[aa + 1]};
+      r.info = site.info;
+      for (SvCall const & call : site.calls)
+        r.calls.push_back(reduce_to_two_alleles(call, aa));
+      if (sv.n_clusters > 0)
+        r.info["NCLUSTERS"] = std::to_string(sv.n_clusters);
+      if (sv.num_merged_svs > 0)
+        r.info["NUM_MERGED_SVS"] = std::to_string(sv.num_merged_svs);
+      r.info["SV_ID"] = std::to_string(id[aa]);
+      if (sv.related >= 0)
+        r.info["RELATED_SV_ID"] = std::to_string(sv.related);
+      if (sv.kind != K_BND)
+        r.alleles = {"N", sv.allele()};
+      else if (r.alleles[1].size() > 1 && r.alleles[1][1] == '<')
+      {
+        gtx::g_last_error = "gtx_vcf_records: breakend alleles that start with a tag are not supported";
+        return GTX_ERR_UNSUPPORTED;
+      }
+      if (sv.kind == K_DUP && (sv.model == "BREAKPOINT1" || sv.model == "BREAKPOINT2")) // (a duplication's breakpoint: a third of the reads show it)
+        for (SvCall & call : r.calls)
+        {
+          uint64_t const g00 = 25ull * call.ad[1];
+          uint64_t const g01 = static_cast<uint64_t>(0.499999999 + 4.77121255 * static_cast<double>(call.ad[1]) + 1.76091259 * static_cast<double>(call.ad[0]));
+          uint64_t const g11 = 3ull * (static_cast<uint64_t>(call.ad[0]) + call.ad[1]);
+          uint64_t const low = std::min(g00, std::min(g01, g11));
+          call.set_pl3(g00 - low, g01 - low, g11 - low);
+        }
+      auto const partner = first_breakpoint.find(id[aa]);
+      bool const second = partner != first_breakpoint.end();
+      if ((sv.kind == K_INS || sv.kind == K_INV) && second)
+      {
+        SvRecord const other = made[partner->second];
+        finish(aggregate(r, other), sv, "AGGREGATED");
+      }
+      auto depth_record = [&](SvRecord & by_depth) -> bool
+      {
+        by_depth = r;
+        for (uint32_t s = 0; s < ns; ++s)
+        {
+          SvCall call;
+          if (!call_from_depth(sv, rq->ref_depth + static_cast<uint64_t>(s) * (rq->ref_depth_len + 1u), rq->ref_depth_len, first_pos, call))
+            return false;
+          by_depth.calls[s] = call;
+        }
+        return true;
+      };
+      if (g.is_sv_graph && (sv.kind == K_DEL || sv.kind == K_DEL_ALU || (sv.kind == K_DUP && second)))
+      {
+        SvRecord by_depth;
+        if (!depth_record(by_depth))
+        {
+          gtx::g_last_error = "gtx_vcf_records: SV " + std::to_string(id[aa]) + " is too short for the coverage model (40 bases or fewer)";
+          return GTX_ERR_UNSUPPORTED;
+        }
+        SvRecord both = aggregate(r, by_depth);
+        if (sv.kind == K_DUP)
+        {
+          SvRecord const other = made[partner->second];
+          both = aggregate(both, other);
+        }
+        finish(std::move(both), sv, "AGGREGATED");
+        finish(std::move(by_depth), sv, "COVERAGE");
+      }
+      if (sv.related != -1)
+        first_breakpoint[sv.related] = made.size();
+      finish(std::move(r), sv, sv.model);
+    }
+  }
+  for (SvRecord & r : untouched)
+    made.push_back(std::move(r));
+  std::stable_sort(made.begin(), made.end(), [](SvRecord const & a, SvRecord const & b) { return a.pos < b.pos || (a.pos == b.pos && a.alleles < b.alleles); });
+  // ---- the merge: left-align, summarise, drop what nobody was called with
+  std::string ref;
+  for (size_t n = 0; n < g.ref_order.size(); ++n)
+  {
+    ref.append(g.dna.data() + g.ref_dna[n], g.ref_len[n]);
+    if (g.ref_nvar[n] > 0)
+      ref.append(g.dna.data() + g.var_dna[g.ref_first_var[n]], g.var_len[g.ref_first_var[n]]);
+  }
+  std::vector<SvRecord> kept;
+  for (SvRecord & r : made)
+  {
+    if (left_align(r, ref, first_pos) > 200)
+      continue;
+    std::vector<char> const called = summarise(r);
+    if (std::none_of(called.begin(), called.end(), [](char x) { return x != 0; }))
+      continue;
+    kept.push_back(std::move(r));
+  }
+  // ---- the writer's order: position, then deletions before insertions before equal lengths, then the alleles
+  std::vector<size_t> order(kept.size());
+  std::iota(order.begin(), order.end(), size_t(0));
+  auto shape = [](SvRecord const & r) { return static_cast<int>(r.alleles[0].size() > r.alleles[1].size()) + 2 * static_cast<int>(r.alleles[0].size() == r.alleles[1].size()); };
+  std::sort(order.begin(), order.end(), [&](size_t i, size_t j)
+  {
+    SvRecord const & a = kept[i];
+    SvRecord const & b = kept[j];
+    if (a.pos != b.pos)
+      return a.pos < b.pos;
+    if (shape(a) != shape(b))
+      return shape(a) < shape(b);
+    return a.alleles < b.alleles || (a.alleles == b.alleles && a.info.size() > b.info.size());
+  });
+  long dup = -1;
+  for (size_t k = 0; k < order.size(); ++k)
+  {
+    SvRecord const & r = kept[order[k]];
+    std::string suffix;
+    if (k > 0)
+    {
+      SvRecord const & prev = kept[order[k - 1]];
+      if (r.pos > rq->region_end)
+        break;
+      if (r.pos < rq->region_begin)
+        continue;
+      if (r.pos == prev.pos && r.alleles == prev.alleles)
+        continue;
+      if (r.pos == prev.pos && r.type_code() == prev.type_code())
+        suffix = "." + std::to_string(++dup);
+      else
+        dup = -1;
+    }
+    else if (r.pos < rq->region_begin || r.pos > rq->region_end)
+      continue;
+    // ---- Vcf::write_record (vcf.cpp:767-1149)
+    if ((ns > 0 && r.alleles.size() > 80) || std::accumulate(r.alleles.begin(), r.alleles.end(), size_t(0), [](size_t n, std::string const & s) { return n + s.size(); }) > 16000)
+      continue;
+    uint64_t const qual = r.qual();
+    if (rq->filter_zero_qual && qual == 0)
+      continue;
+    bool const is_sv = r.has_sv_allele();
+    text += rq->contig;
+    text += '\t';
+    put_u(text, r.pos);
+    text += '\t';
+    text += rq->contig;
+    text += ':';
+    put_u(text, r.pos);
+    text += ':';
+    text += r.type_code();
+    if (rq->variant_suffix_id && rq->variant_suffix_id[0])
+    {
+      text += '[';
+      text += rq->variant_suffix_id;
+      text += ']';
+    }
+    text += suffix;
+    for (size_t a = 0; a < r.alleles.size(); ++a)
+    {
+      text += a < 2 ? '\t' : ',';
+      text += r.alleles[a];
+    }
+    text += '\t';
+    put_u(text, qual);
+    text += '\t';
+    if (ns == 0)
+      text += '.';
+    else
+    {
+      size_t const before = text.size();
+      auto fail = [&](char const * name)
+      {
+        if (text.size() != before)
+          text += ';';
+        text += name;
+      };
+      auto num = [&](char const * k) { return std::stod(r.info.at(k)); };
+      auto has = [&](char const * k) { return r.info.count(k) == 1; };
+      if (is_sv)
+      {
+        if (has("QD") && num("QD") < 6.0)
+          fail("LowQD");
+        if (qual < 10)
+          fail("LowQUAL");
+        if (has("AN") && has("PASS_AC") && has("PASS_ratio") && std::stoi(r.info.at("AN")) >= 100 && (r.info.at("PASS_AC") == "0" || num("PASS_ratio") < 0.01))
+          fail("LowPratio");
+      }
+      else
+      {
+        if (has("ABHet") && r.info.at("ABHet") != "-1" && num("ABHet") < 0.175)
+          fail("LowABHet");
+        if (has("ABHom") && r.info.at("ABHom") != "-1" && num("ABHom") < 0.85)
+          fail("LowABHom");
+        if (has("AN") && std::stoi(r.info.at("AN")) >= 6 && has("QD") && num("QD") < 6.0)
+          fail("LowQD");
+        if (qual < 10)
+          fail("LowQUAL");
+        if (has("AN") && has("PASS_ratio") && std::stoi(r.info.at("AN")) >= 500 && num("PASS_ratio") < 0.05)
+          fail("LowPratio");
+      }
+      if (text.size() == before)
+        text += "PASS";
+    }
+    text += '\t';
+    if (r.info.empty())
+      text += '.';
+    bool first_kv = true;
+    for (auto const & kv : r.info)
+    {
+      if (!first_kv)
+        text += ';';
+      first_kv = false;
+      text += kv.first;
+      if (!kv.second.empty())
+      {
+        text += '=';
+        text += kv.second;
+      }
+    }
+    if (ns)
+    {
+      text += is_sv ? "\tGT:FT:AD:MD:DP:RA:PP:GQ:PL" : "\tGT:AD:MD:DP:GQ:PL";
+      for (SvCall const & call0 : r.calls)
+      {
+        SvCall call = call0;
+        text += '\t';
+        if (std::none_of(call.pl.begin(), call.pl.end(), [](uint8_t p) { return p != 0; }))
+          text += "./.";
+        else
+        {
+          uint32_t g1, g2;
+          call.genotype(g1, g2);
+          put_u(text, g1);
+          text += '/';
+          put_u(text, g2);
+        }
+        long const gq = call.gq();
+        if (is_sv)
+        {
+          int const verdict = call.judged();
+          text += verdict == 0 ? ":PASS" : ":FAIL";
+          if (verdict != 0)
+            put_u(text, static_cast<uint64_t>(verdict));
+        }
+        for (size_t a = 0; a < call.ad.size(); ++a)
+        {
+          text += a ? ',' : ':';
+          put_u(text, call.ad[a]);
+        }
+        text += ':';
+        put_u(text, call.ambiguous);
+        text += ':';
+        put_u(text, call.unique_depth() + call.ambiguous);
+        if (is_sv)
+        {
+          text += ':';
+          put_u(text, call.ref_total);
+          text += ',';
+          put_u(text, call.alt_total);
+          text += ':';
+          put_u(text, call.alt_proper_pair);
+        }
+        text += ':';
+        put_u(text, std::min<uint16_t>(99, BINNED.v[gq]));
+        for (size_t i = 0; i < call.pl.size(); ++i)
+        {
+          text += i ? ',' : ':';
+          put_u(text, BINNED.v[call.pl[i]]);
+        }
+      }
+    }
+    text += '\n';
+  }
+  return GTX_OK;
+}
+} // namespace
+
 extern "C" int gtx_vcf_records(const gtx_ctx * c, const gtx_vcf_request * rq, char * out, uint64_t cap, uint64_t * len)
 {
   if (!c || !rq || !len || (cap && !out) || !rq->contig || !rq->gt_cov || !rq->stat_u64 || !rq->stat_u32 || !rq->phred || !rq->calls ||
       (rq->n_samples && !rq->sample_names))
     return GTX_ERR_ARG;
   gtx::HostGraph const & g = c->graph;
-  if (g.is_sv_graph)
-  {
-    gtx::g_last_error = "gtx_vcf_records: the SV post-processing of the calls (reformat_sv_vcf_records) is not built";
-    return GTX_ERR_UNSUPPORTED;
-  }
   uint32_t const nh = g.n_hap, ns = rq->n_samples;
   std::string text;
   text.reserve(static_cast<size_t>(nh) * (400 + 24 * static_cast<size_t>(ns)));
@@ -221,6 +1181,16 @@ extern "C" int gtx_vcf_records(const gtx_ctx * c, const gtx_vcf_request * rq, ch
     }
   }
   text += '\n';
+  if (g.is_sv_graph) // the calls of an SV graph go through the SV post-processing (sv_graph_records above)
+  {
+    int const rc = sv_graph_records(c, rq, text);
+    if (rc != GTX_OK)
+      return rc;
+    *len = text.size();
+    if (out && cap)
+      std::memcpy(out, text.data(), static_cast<size_t>(std::min<uint64_t>(cap, text.size())));
+    return GTX_OK;
+  }
   std::string const contig = rq->contig;
   // The records of the sites are independent of each other: the sites are cut into contiguous ranges for a team of host
   // threads (every record walks the sample-major arrays of all samples -- cache misses, not arithmetic), every range writes

@@ -465,7 +465,7 @@ class VcfRequest(C.Structure):
     _fields_ = [("contig", C.c_char_p), ("sample_names", C.POINTER(C.c_char_p)), ("n_samples", C.c_uint32),
                 ("region_begin", C.c_uint32), ("region_end", C.c_uint32), ("filter_zero_qual", C.c_int32),
                 ("variant_suffix_id", C.c_char_p), ("gt_cov", C.c_void_p), ("stat_u64", C.c_void_p), ("stat_u32", C.c_void_p),
-                ("phred", C.c_void_p), ("calls", C.c_void_p)]
+                ("phred", C.c_void_p), ("calls", C.c_void_p), ("sv_table", C.c_char_p), ("ref_depth", C.c_void_p), ("ref_depth_len", C.c_uint32)]
 
 
 class Context:
@@ -585,13 +585,19 @@ class Context:
         check(lib().gtx_ctx_big_records_rewind(self.h, None))
 
     def vcf_records(self, contig, sample_names, gt_cov, stat_u64, stat_u32, phred, calls, region_begin=0, region_end=0xFFFFFFFF,
-                    filter_zero_qual=False, variant_suffix_id=None):
-        """gtx_vcf_records: the VCF records (column line first) of the region's variant sites as bytes; all arrays are host copies"""
+                    filter_zero_qual=False, variant_suffix_id=None, sv_table=None, ref_depth=None):
+        """gtx_vcf_records: the VCF records (column line first) of the region's variant sites as bytes; all arrays are host copies.
+        SV graphs: sv_table = the text of gtx_graph_sv_table, ref_depth = the FINALISED reference-depth rows [n_samples, ref_depth_len + 1]"""
         names = (C.c_char_p * max(1, len(sample_names)))(*[n.encode() for n in sample_names])
         keep = [np.ascontiguousarray(gt_cov, np.uint32), np.ascontiguousarray(stat_u64, np.uint64), np.ascontiguousarray(stat_u32, np.uint32),
                 np.ascontiguousarray(phred, np.uint8), np.ascontiguousarray(calls, SAMPLE_CALL)]
+        if ref_depth is not None:
+            keep.append(np.ascontiguousarray(ref_depth, np.uint32))
+            assert keep[-1].size == len(sample_names) * (self.ref_depth_len + 1)
         rq = VcfRequest(contig.encode(), names, len(sample_names), region_begin, region_end, int(filter_zero_qual),
-                        variant_suffix_id.encode() if variant_suffix_id else None, *[C.c_void_p(a.ctypes.data) for a in keep])
+                        variant_suffix_id.encode() if variant_suffix_id else None, *[C.c_void_p(a.ctypes.data) for a in keep[:5]],
+                        sv_table.encode() if sv_table is not None else None, C.c_void_p(keep[5].ctypes.data) if ref_depth is not None else None,
+                        self.ref_depth_len if ref_depth is not None else 0)
         n = C.c_uint64()
         check(lib().gtx_vcf_records(self.h, C.byref(rq), None, C.c_uint64(0), C.byref(n)))
         buf = C.create_string_buffer(int(n.value) + 1)

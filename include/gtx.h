@@ -443,8 +443,15 @@ int gtx_calls_batch(gtx_ctx *, const gtx_score_buffers * acc, uint8_t * d_phred,
  * binned_pl) with the region filter of Vcf::write_records (vcf.cpp:1161-1275).  In front of the records stands the column
  * line (#CHROM ... FORMAT sample names); the description lines of the header are not produced.
  * All arrays are HOST copies: the accumulators of gtx_score_batch (raw sums or finalized) and the outputs of
- * gtx_calls_batch for the same n_samples.  Not built: variant break-down / pool merge (vcf_operations.cpp) and the SV
- * post-processing of the calls (reformat_sv_vcf_records): a context of an SV graph returns GTX_ERR_UNSUPPORTED.
+ * gtx_calls_batch for the same n_samples.  Not built: variant break-down / pool merge (vcf_operations.cpp).
+ * SV graphs (`genotype_sv`): the sites go through the SV post-processing of the calls instead -- reformat_sv_vcf_records
+ * (src/graph/sv.cpp:117-655: one bi-allelic record per SV allele at the SV's own position, REF N, ALT <TYPE:SVSIZE=n:MODEL>,
+ * models BREAKPOINT(1/2), COVERAGE from the reference-depth track and AGGREGATED), the sort and stats.clear() of the pool's
+ * writer (src/utilities/hts_parallel_reader.cpp:1003-1020) and what vcf_merge_and_break does for genotype_sv
+ * (force_no_break_down: normalize, generate_infos, drop a record nobody was called with; vcf_operations.cpp:480-700), written
+ * in the order and with the ID suffixes of Vcf::write_records (vcf.cpp:1161-1275); FORMAT GT:FT:AD:MD:DP:RA:PP:GQ:PL.
+ * Needs sv_table and ref_depth.  GTX_ERR_UNSUPPORTED: a site that mixes SV and non-SV alleles, a breakend allele that starts
+ * with its tag, an SV of 40 bases or fewer where the coverage model is asked.
  * Writes min(*len, cap) bytes to out (may be NULL with cap 0 to ask for the length).  Large jobs (sites x samples >=
  * 200 000) are written by a team of host threads over ranges of sites (GTX_HOST_THREADS, default up to 32); the text does
  * not depend on the team. */
@@ -461,6 +468,10 @@ typedef struct gtx_vcf_request
   const uint32_t * stat_u32;         /* layout of gtx_score_buffers::d_stat_u32 */
   const uint8_t * phred;             /* [n_samples * total_tri] of gtx_calls_batch */
   const gtx_sample_call * calls;     /* [n_samples * n_hap] of gtx_calls_batch */
+  /* SV graphs only (gtx_params::is_sv_graph; else ignored, may be NULL / 0): */
+  const char * sv_table;             /* Graph::SVs as text: gtx_graph_sv_table of the graph the context was made from */
+  const uint32_t * ref_depth;        /* [n_samples * (ref_depth_len + 1)]: the downloaded d_ref_depth after gtx_ref_depth_finalize */
+  uint32_t ref_depth_len;            /* gtx_score_layout::ref_depth_len */
 } gtx_vcf_request;
 int gtx_vcf_records(const gtx_ctx *, const gtx_vcf_request *, char * out, uint64_t cap, uint64_t * len);
 

@@ -276,6 +276,20 @@ class OracleGenotyper:
         L.gto_vcf_records(*args, buf, C.c_long(n))
         return buf.raw[:n]
 
+    def vcf_records_sv(self, contig, sample_names, sv_table, reference, first_pos, region_begin=0, region_end=0xFFFFFFFF):
+        """oracle/gto_sv.hpp: the VCF records of an SV graph's calls (reformat_sv_vcf_records + the merge of genotype_sv) as bytes;
+        reference / first_pos: the region's reference sequence and the 1-based position of its first base"""
+        L = lib()
+        L.gto_vcf_records_sv.restype = C.c_long
+        args = (C.c_void_p(self.g), contig.encode(), "\n".join(sample_names).encode(), C.c_uint32(region_begin), C.c_uint32(region_end),
+                sv_table.encode(), reference.encode(), C.c_uint32(first_pos))
+        n = L.gto_vcf_records_sv(*args, None, C.c_long(0))
+        if n < 0:
+            raise RuntimeError(L.gto_last_error().decode())
+        buf = C.create_string_buffer(n + 1)
+        L.gto_vcf_records_sv(*args, buf, C.c_long(n))
+        return buf.raw[:n]
+
     def merge(self, other):
         """self += other (Genotyper::merge_from: sums of the accumulated state; refused at the saturation guard)"""
         L = lib()

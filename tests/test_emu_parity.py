@@ -518,9 +518,11 @@ def cfg5_case(Backend, tmp_path, n_ref, n_del, n_ins, n_samples, pairs_per_sv, b
     seqs, lines, codes, rec = scenarios.sv_case(n_ref=n_ref, n_del=n_del, n_ins=n_ins, n_samples=n_samples, pairs_per_sv=pairs_per_sv,
                                                 background_pairs=background_pairs)
     fa, vcf = _write(tmp_path, seqs, lines)
-    g, (rb, re_) = gtx.graph_from_files(fa, vcf, "chrS", is_sv_graph=True)
+    g, (rb, re_), sv_table = gtx.graph_from_files(fa, vcf, "chrS", is_sv_graph=True, with_sv_table=True)
     assert g["dna"].tobytes().decode().count("<SV:") == n_del + 2 * n_ins
-    o = Oracle(seqs["chrS"], sv_constructor.sv_records(seqs, lines, "chrS"), is_sv_graph=True, extend_prefix=True)
+    sv_recs, want_table = sv_constructor.sv_records(seqs, lines, "chrS", with_table=True)
+    assert sv_table == want_table
+    o = Oracle(seqs["chrS"], sv_recs, is_sv_graph=True, extend_prefix=True)
     b = Backend(g, is_sv_graph=True)
     cov = [0.5] * n_samples
     og = o.genotyper(n_samples, 1)
@@ -556,6 +558,23 @@ def cfg5_case(Backend, tmp_path, n_ref, n_del, n_ins, n_samples, pairs_per_sv, b
     assert depths.shape[1] == len(seqs["chrS"]) and depths.any()
     for s_i in range(n_samples):
         assert np.array_equal(depths[s_i], og.reference_depth(s_i).astype(np.uint32)), "reference depth of sample %d differs" % s_i
+    # The VCF text of the calls: reformat_sv_vcf_records (one record per SV allele and genotyping model: BREAKPOINT(1/2),
+    # COVERAGE from the reference-depth track, AGGREGATED), the merge of genotype_sv, the writer's order and ID suffixes
+    names = ["SAMP%03d" % i for i in range(n_samples)]
+    ref_depth = acc.ref_depth.copy()
+    gtx.check(gtx.lib().gtx_ref_depth_finalize(harness._p(ref_depth), n_samples, acc.ref_depth_len, None))
+    got_vcf = b.ctx.vcf_records("chrS", names, acc.gt_cov, acc.stat_u64, acc.stat_u32, phred, calls, sv_table=sv_table, ref_depth=ref_depth)
+    want_vcf = og.vcf_records_sv("chrS", names, want_table, seqs["chrS"], 1)
+    if got_vcf != want_vcf:
+        gl, wl = got_vcf.split(b"\n"), want_vcf.split(b"\n")
+        bad = [i for i in range(min(len(gl), len(wl))) if gl[i] != wl[i]]
+        raise AssertionError("SV VCF text differs (%d vs %d lines), first at line %s:\n%r\n%r" %
+                             (len(gl), len(wl), bad[:1], gl[bad[0]][:600] if bad else b"", wl[bad[0]][:600] if bad else b""))
+    text = got_vcf.decode()
+    for model in ("BREAKPOINT>", "COVERAGE>", "AGGREGATED>", "BREAKPOINT1>", "BREAKPOINT2>"):
+        assert model in text, model
+    assert text.count("\n") - 1 >= n_del and ":PASS:" in text and "\t0/1:" in text  # (records nobody was called with are dropped)
+    cfg5_case.vcf = got_vcf
     # not vacuous: alternative SV alleles are called somewhere, and reads did align onto breakpoint alleles
     assert (calls["gt_second"] > 0).any()
     on_sv = sum(1 for pr in got_paths for k in range(2) for p in pr[k]["paths"] if any(al != (0,) for _, al in p["vars"]))
