@@ -1074,6 +1074,116 @@ def extra_repeats(args, torch, gtx, synth, device, ref):
     return extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False, what, lanes=1, big_record_words=1 << 27)
 
 
+def extra_cfg5(args, torch, gtx, synth, device, n_pairs_per_sv=160, background_pairs=12000, n_samples=100, steps=10, tile=8):
+    """BASELINE configs[4] as far as one GPU goes: `genotype_sv`, 100 samples over a 1 Mb SV-augmented graph -- 100 <DEL> of
+    50-5 000 bp and 50 <INS> with 152-bp breakpoint alleles, from FASTA + VCF through gtx_graph_from_files -- FR pairs over every
+    breakpoint plus background, the SV stream logic on the host (record filter, coverage filter, leftovers) before the clock,
+    then per step align + score (with the reference-depth track) + calls on the device; afterwards the SV post-processing of
+    the calls and the VCF text on the host (gtx_vcf_records: BREAKPOINT / COVERAGE / AGGREGATED records).  The read set is the
+    one of tests/test_gpu_configs.py::test_cfg5_sv_graph (72 k records: its generator is a Python loop per pair); the timed steps
+    run `tile` copies of it side by side in one batch (the same reads, `tile` times the depth), the VCF comes from one copy."""
+    import tempfile
+    L = gtx.lib()
+    t0 = time.time()
+    seqs, lines, codes, rec = synth.make_sv_case(n_ref=REGION_LEN, n_del=100, n_ins=50, n_samples=n_samples, pairs_per_sv=n_pairs_per_sv,
+                                                 background_pairs=background_pairs)
+    t_make = time.time() - t0
+    tmp = tempfile.mkdtemp(prefix="gtx_cfg5_")
+    fa, vcf = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "in.vcf")
+    with open(fa, "w") as f:
+        for name, sq in seqs.items():
+            f.write(">%s\n" % name)
+            f.write("\n".join(sq[i:i + 60] for i in range(0, len(sq), 60)) + "\n")
+    with open(vcf, "w") as f:
+        f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n" + "\n".join(lines) + "\n")
+    t0 = time.time()
+    graph, _, sv_table = gtx.graph_from_files(fa, vcf, "chrS", is_sv_graph=True, with_sv_table=True)
+    t_graph = time.time() - t0
+    os.remove(fa)
+    os.remove(vcf)
+    for extra in (fa + ".fai",):
+        if os.path.exists(extra):
+            os.remove(extra)
+    os.rmdir(tmp)
+    t0 = time.time()
+    ctx = gtx.Context(graph, device=0, is_sv_graph=True)
+    t_ctx = time.time() - t0
+    st = gtx.Stream(ctx.params, 1)
+    st.set_coverage([0.5] * n_samples)
+    t0 = time.time()
+    a_seq, a_meta, items = st.push(rec, gtx.pack_nibbles(codes))
+    left = st.finish()
+    t_stream = time.time() - t0
+    items = np.concatenate([items, left])
+    n_align, n_items = len(a_meta), len(items)
+    tiled = []
+    for k in range(tile):
+        it = items.copy()
+        for side in ("first", "second"):
+            ai = it[side]["align_index"]
+            it[side]["align_index"] = np.where(ai != gtx.INVALID_ID, ai + np.uint32(k * n_align), ai)
+        tiled.append(it)
+    tiled = np.concatenate(tiled)
+    d_seq = torch.from_numpy(np.ascontiguousarray(a_seq)).to(device).repeat(tile, 1)
+    d_meta = torch.from_numpy(a_meta.view(np.uint8).reshape(n_align, -1).copy()).to(device).repeat(tile, 1)
+    d_items = torch.from_numpy(tiled.view(np.uint8).reshape(len(tiled), -1).copy()).to(device)
+    d_rec = torch.zeros(tile * n_align * 2 * REC_WORDS, dtype=torch.int32, device=device)
+    buf = gtx.ScoreBuffers()
+    reduced = C.c_uint64()
+    gtx.check(L.gtx_scores_alloc(ctx.h, n_samples, 1 << 22, C.byref(buf), C.byref(reduced)))
+    d_phred = torch.zeros(max(n_samples * ctx.total_tri, 1), dtype=torch.uint8, device=device)
+    d_calls = torch.zeros(max(n_samples * ctx.n_hap, 1) * gtx.SAMPLE_CALL.itemsize, dtype=torch.uint8, device=device)
+    stream = torch.cuda.Stream(device=device)
+    sp = C.c_void_p(stream.cuda_stream)
+
+    def step(copies):
+        with torch.cuda.stream(stream):
+            gtx.check(L.gtx_ctx_big_records_rewind(ctx.h, sp))
+            gtx.check(L.gtx_scores_zero(ctx.h, C.byref(buf), sp))
+            gtx.check(L.gtx_align_batch(ctx.h, d_seq.data_ptr(), int(d_seq.shape[1]), d_meta.data_ptr(), copies * n_align, d_rec.data_ptr(), REC_WORDS, sp))
+            gtx.check(L.gtx_score_batch(ctx.h, d_items.data_ptr(), copies * n_items, d_rec.data_ptr(), REC_WORDS, C.byref(buf), sp))
+            gtx.check(L.gtx_calls_batch(ctx.h, C.byref(buf), d_phred.data_ptr(), d_calls.data_ptr(), sp))
+
+    for _ in range(2):
+        step(tile)
+    torch.cuda.synchronize()
+    ctx.pass_times()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(tile)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kt = ctx.kernel_times()
+    step(1)  # (one copy of the reads: what the VCF is written from)
+    torch.cuda.synchronize()
+    # the calls' post-processing and the VCF text (host)
+    t0 = time.perf_counter()
+    nh, ta = ctx.n_hap, ctx.total_allele
+    depth = gtx.download(buf.d_ref_depth, np.uint32, n_samples * (ctx.ref_depth_len + 1))
+    sat = C.c_uint64()
+    gtx.check(L.gtx_ref_depth_finalize(depth.ctypes.data_as(C.c_void_p), n_samples, ctx.ref_depth_len, C.byref(sat)))
+    calls = d_calls.cpu().numpy().view(gtx.SAMPLE_CALL)[:n_samples * nh]
+    text = ctx.vcf_records("chrS", ["SAMP%03d" % i for i in range(n_samples)], gtx.download(buf.d_gt_cov, np.uint32, n_samples * ta),
+                           gtx.download(buf.d_stat_u64, np.uint64, nh + 2 * ta), gtx.download(buf.d_stat_u32, np.uint32, nh + 6 * ta),
+                           d_phred.cpu().numpy()[:n_samples * ctx.total_tri], calls, sv_table=sv_table, ref_depth=depth)
+    t_vcf = time.perf_counter() - t0
+    rec_head = d_rec.view(tile * n_align * 2, REC_WORDS)[:n_align * 2, 0]
+    out = {"workload": "cfg5 on one GPU: genotype_sv, %d samples, %d x %d records per step (%d aligned reads, %d score items per copy), 1 Mb SV graph from files "
+                       "(100 <DEL> 50-5000 bp, 50 <INS> with breakpoint alleles: %d sites, %d SV table entries)" %
+                       (n_samples, tile, len(rec), n_align, n_items, nh, sv_table.count("\n")),
+           "reads_per_s": tile * len(rec) * steps / dt, "ms_per_step": 1000.0 * dt / steps, "steps": steps,
+           "align_kernels": {k[0]: {"ms": k[1], "tasks_completed": k[2]} for k in kt},
+           "host_before_the_clock_s": {"make_reads": round(t_make, 2), "graph_from_files": round(t_graph, 3), "ctx_create": round(t_ctx, 3), "stream_logic": round(t_stream, 3)},
+           "vcf": {"host_ms": round(1000.0 * t_vcf, 1), "bytes": len(text), "records": text.count(b"\n") - 1,
+                   "breakpoint": text.count(b":BREAKPOINT"), "coverage": text.count(b":COVERAGE>"), "aggregated": text.count(b":AGGREGATED>"),
+                   "sha256": __import__("hashlib").sha256(text).hexdigest()},
+           "reads_overflowed": int((((rec_head >> 16) & gtx.ST_ERROR_MASK) != 0).sum().item()), "score_items_refused": ctx.error_count(),
+           "ref_depth_positions_saturated": int(sat.value)}
+    L.gtx_scores_free(ctx.h, C.byref(buf))
+    ctx.close()
+    return out
+
+
 def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_all, what, lanes=None, big_record_words=0):
     n = args.extra_reads
     lanes = args.lanes if lanes is None else lanes
@@ -1393,6 +1503,10 @@ def main(argv=None):
             cfg.setdefault("extra", {})["repeats"] = extra_repeats(args, torch, gtx, synth, device, ref)
         except Exception as e:
             cfg.setdefault("extra", {})["repeats"] = {"error": repr(e)}
+        try:
+            cfg.setdefault("extra", {})["cfg5"] = extra_cfg5(args, torch, gtx, synth, device)
+        except Exception as e:
+            cfg.setdefault("extra", {})["cfg5"] = {"error": repr(e)}
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

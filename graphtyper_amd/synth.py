@@ -185,6 +185,86 @@ def make_cfg3_records(ref, every=100, indel_frac=0.1, seed=17, region_begin=0):
     return recs
 
 
+def make_sv_case(n_ref=60000, n_del=8, n_ins=4, n_samples=4, pairs_per_sv=30, background_pairs=200, seed=0, read_len=150):
+    """cfg5-like input: a random contig, SV deletions of 50..5 000 bp and SV insertions whose sequence is
+    longer than the 152-bp breakpoint window (so both breakpoint alleles are pure insertion sequence), FR pairs drawn from
+    diploid samples around every SV (each sample carries an SV on its second haplotype with p = 0.4) plus background pairs.
+    Returns ({contig: sequence}, VCF data lines, codes [n, L], STREAM_RECORD array sorted by position)."""
+    from . import lib as gtx
+    rng = np.random.default_rng(seed + 500)
+    ref = make_reference(n_ref, seed=seed + 501)
+    ref_s = bases_to_str(ref)
+    n_sv = n_del + n_ins
+    slots = np.linspace(2000, n_ref - 8000, n_sv).astype(int)
+    kinds = np.array(["DEL"] * n_del + ["INS"] * n_ins)
+    rng.shuffle(kinds)
+    svs, lines = [], []
+    for p, k in zip(slots, kinds):
+        p = int(p)
+        if k == "DEL":
+            size = int(rng.choice([50, 75, 150, 400, 1200, 5000]))
+            size = min(size, int(n_ref - p - 1000))
+            lines.append("chrS\t%d\t.\t%s\t<DEL>\t0\t.\tSVTYPE=DEL;SVSIZE=%d" % (p + 1, ref_s[p], size))
+            svs.append((p, "DEL", size, None))
+        else:
+            ins = rng.integers(0, 4, size=int(rng.integers(170, 420))).astype(np.uint8)
+            lines.append("chrS\t%d\t.\t%s\t<INS>\t0\t.\tSVTYPE=INS;SVLEN=%d;SEQ=%s" % (p + 1, ref_s[p], len(ins), bases_to_str(ins)))
+            svs.append((p, "INS", len(ins), ins))
+    # second haplotype of every sample: (sequence, reference coordinate of every base)
+    haps = []
+    for s in range(n_samples):
+        take = rng.random(n_sv) < 0.4
+        parts, coords, cur = [], [], 0
+        for (p, k, size, ins), t in zip(svs, take):
+            parts.append(ref[cur:p + 1])
+            coords.append(np.arange(cur, p + 1))
+            cur = p + 1
+            if t and k == "DEL":
+                cur = p + 1 + size
+            elif t:
+                parts.append(ins)
+                coords.append(np.full(len(ins), p))
+        parts.append(ref[cur:])
+        coords.append(np.arange(cur, n_ref))
+        haps.append((np.concatenate(parts), np.concatenate(coords)))
+    rows = []
+    name = 0
+
+    def pair(sample, around):
+        nonlocal name
+        seq, coord = (ref, np.arange(n_ref)) if rng.random() < 0.5 else haps[sample]
+        ins = int(np.clip(rng.normal(400, 50), read_len + 10, 900))
+        if around is None:
+            start = int(rng.integers(0, len(seq) - ins))
+        else:
+            at = int(np.searchsorted(coord, around))
+            start = int(np.clip(at - rng.integers(20, ins - 20), 0, len(seq) - ins))
+        a, b = seq[start:start + read_len].copy(), seq[start + ins - read_len:start + ins].copy()
+        for x in (a, b):
+            e = rng.random(read_len) < 0.004
+            x[e] = (x[e] + rng.integers(1, 4, size=int(e.sum()))) % 4
+        pa, pb = int(coord[start]), int(coord[start + ins - read_len])
+        mapq = 60 if rng.random() < 0.93 else 10
+        rows.append((pa, a, 1 | 2 | 32 | 64, pb - pa + read_len, mapq, sample, name, pb))
+        rows.append((pb, b, 1 | 2 | 16 | 128, -(pb - pa + read_len), mapq, sample, name, pa))
+        name += 1
+
+    for (p, k, size, _) in svs:
+        for _ in range(pairs_per_sv):
+            pair(int(rng.integers(n_samples)), p + (size // 2 if k == "DEL" and rng.random() < 0.5 else 0))
+    for _ in range(background_pairs):
+        pair(int(rng.integers(n_samples)), None)
+    rows.sort(key=lambda r: r[0])
+    n = len(rows)
+    codes = np.zeros((n, read_len), np.uint8)
+    rec = np.zeros(n, gtx.STREAM_RECORD)
+    M = 0
+    for i, (p, bases, flag, isize, mapq, sample, nm, mpos) in enumerate(rows):
+        codes[i] = np.array([1, 2, 4, 8], np.uint8)[bases]
+        rec[i] = (flag, mapq, int(rng.integers(0, 60)), 0, 0, p, isize, read_len, 0, sample, nm, mpos, 1, read_len << 4 | M, read_len << 4 | M)
+    return {"chrS": ref_s}, lines, codes, rec
+
+
 def write_fixed_bam(path, contig, contig_len, sample, codes, pos0, mapq=60, flag=0, threads=8, level=1):
     """A position-sorted BAM of unpaired reads of one length, written without a per-record Python loop (benchmarks: the
     pipeline leg of bench.py reads such files back through gtx_reads).  codes: [n, L] 4-bit BAM codes, pos0: [n] 0-based
