@@ -93,6 +93,7 @@ struct NoDynTables
 struct PpKeyTables
 {
   uint32_t * pp_start, * pp_end;
+  uint64_t * bits_pp; // one bit per pp entry (the bulk chaining's matched set)
 };
 constexpr bool DENSE_PP_KEYS = AlignCfg::DYN || AlignCfg::MAXPP > 64;
 
@@ -305,6 +306,20 @@ GTX_DEV bool bits_get(MemBits const & b, uint32_t i)
 {
   return (GTX_U(b.w[i >> 6]) >> (i & 63u)) & 1ull;
 }
+// 64 members at once: word `k` of the set
+template <class W>
+GTX_DEV uint64_t bits_word(MemBits const & b, uint32_t k)
+{
+  return GTX_U(b.w[k]);
+}
+// ... and word `k` of the set becomes `mask`
+template <class W>
+GTX_DEV void bits_set_word(MemBits & b, uint32_t k, uint64_t mask)
+{
+  GTX_LEAD b.w[k] = mask;
+  W::lds_sync();
+}
+
 // an empty set over n elements
 template <class W>
 GTX_DEV MemBits bits_clear(uint64_t * words, uint32_t n)
@@ -1123,11 +1138,133 @@ GTX_DEV bool push_path(AlignWorkspace & ws, uint32_t & n_paths, DPath const & p,
   return true;
 }
 
+// add_next_kmer_labels for the list that brings the passes with tables in HBM their work: the hundreds of places of one exact
+// k-mer inside a long repeat.  When no label carries a variant site and the labels come in ascending start order (the order
+// of the index' sweep for one key) the general code below does nothing but this: a path that ends where a label starts is
+// extended by it in place -- Path(p1, p2) of a site-free p2 is p1 with p2's end, read end and mismatches --, at most one label
+// per path (the starts are distinct), and the labels no path took are appended as new paths in label order.  Every step of
+// that is independent per path / per label, so it is done 64 at a time: a binary search of the path's end in the sorted
+// starts per lane, one store of the changed fields, an atomic OR into the set of taken labels, a prefix sum for the places of
+// the appended paths.  Returns false -- nothing touched -- when the list is not of that kind.
+template <class W, class WS>
+GTX_DEV bool chain_in_bulk(Here, WS & ws, DevLabel const * ll, uint32_t n, uint32_t rs, uint32_t re, uint32_t mism, uint32_t & n_paths,
+                           uint32_t & longest, uint32_t & status)
+{
+  if constexpr (!DENSE_PP_KEYS)
+    return false;
+  else
+  {
+    for (uint32_t base = 0; base < n; base += 64)
+    {
+      typename W::template PerLane<bool> bad;
+      W::lanes([&](uint32_t l) {
+        uint32_t const k = base + l;
+        bad[l] = k < n && (ll[k].site != INVALID || (k + 1 < n && !(ll[k].start < ll[k + 1].start)));
+      });
+      if (W::ballot(bad) != 0)
+        return false;
+    }
+    if (n > cap_pp(ws))
+    {
+      status |= GTX_ST_PATH_OVERFLOW;
+      return true;
+    }
+    uint32_t * const starts = ws.pp_start, * const ends = ws.pp_end;
+    for (uint32_t base = 0; base < n; base += 64)
+      W::lanes([&](uint32_t l) {
+        if (base + l < n)
+        {
+          starts[base + l] = ll[base + l].start;
+          ends[base + l] = ll[base + l].end;
+        }
+      });
+    MemBits taken = bits_clear<W>(ws.bits_pp, n); // (ends with the sync the tables above need as well)
+    uint32_t const original_size = n_paths;
+    for (uint32_t base = 0; base < original_size; base += 64)
+    {
+      typename W::template PerLane<uint32_t> size;
+      W::lanes([&](uint32_t l) {
+        uint32_t const i = base + l;
+        uint32_t sz = 0;
+        if (i < original_size)
+        {
+          DPath & p = ws.paths[i];
+          if (static_cast<uint32_t>(p.re) == rs)
+          {
+            uint32_t const want = p.end;
+            uint32_t lo = 0, hi = n;
+            while (lo < hi)
+            {
+              uint32_t const mid = (lo + hi) >> 1;
+              if (starts[mid] < want)
+                lo = mid + 1;
+              else
+                hi = mid;
+            }
+            if (lo < n && starts[lo] == want)
+            {
+              p.end = ends[lo];
+              p.re = static_cast<uint16_t>(re);
+              p.mism = static_cast<uint16_t>(p.mism + mism);
+              W::atomic_or_u64(taken.w + (lo >> 6), 1ull << (lo & 63u));
+              sz = re - static_cast<uint32_t>(p.rs) + 1u;
+            }
+          }
+        }
+        size[l] = sz;
+      });
+      uint32_t const m = W::max(size);
+      if (m > longest)
+        longest = m;
+    }
+    W::lds_sync();
+    uint32_t n_left = 0;
+    for (uint32_t base = 0; base < n; base += 64)
+    {
+      uint64_t const valid = n - base >= 64 ? ~0ull : ((1ull << (n - base)) - 1ull);
+      n_left += static_cast<uint32_t>(__builtin_popcountll(~GTX_U(taken.w[base >> 6]) & valid));
+    }
+    if (n_left == 0)
+      return true;
+    if (n_paths + n_left > cap_paths(ws))
+    {
+      status |= GTX_ST_PATH_OVERFLOW;
+      return true;
+    }
+    for (uint32_t base = 0; base < n; base += 64)
+    {
+      uint64_t const valid = n - base >= 64 ? ~0ull : ((1ull << (n - base)) - 1ull);
+      uint64_t const left = ~GTX_U(taken.w[base >> 6]) & valid;
+      if (left == 0)
+        continue;
+      W::lanes([&](uint32_t l) {
+        if ((left >> l) & 1ull)
+        {
+          DPath & p = ws.paths[n_paths + static_cast<uint32_t>(__builtin_popcountll(left & ((1ull << l) - 1ull)))];
+          p.start = starts[base + l];
+          p.end = ends[base + l];
+          p.rs = static_cast<uint16_t>(rs);
+          p.re = static_cast<uint16_t>(re);
+          p.mism = static_cast<uint16_t>(mism);
+          p.nvar = 0;
+        }
+      });
+      n_paths += static_cast<uint32_t>(__builtin_popcountll(left));
+    }
+    W::lds_sync();
+    if (re - rs + 1u > longest)
+      longest = re - rs + 1u;
+    return true;
+  }
+}
+
 template <class W>
 GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t n, uint32_t rs, uint32_t re, uint32_t mism,
                              bool prev, uint32_t & n_paths, uint32_t & longest, uint32_t & status)
 {
   if (n == 0)
+    return;
+  if (n >= 16 && !prev && chain_in_bulk<W>(Here{}, ws, ll, n, rs, re, mism, n_paths, longest, status))
     return;
   if (n == 1 && !prev)
   {
@@ -1373,6 +1510,31 @@ GTX_DEV void add_kmer_labels(AlignWorkspace & ws, DevLabel const * ll, uint32_t 
 // path filters (genotype_paths.cpp)
 // ---------------------------------------------------------------------------------------------------------------
 
+// The passes whose tables are in HBM (DENSE_PP_KEYS) meet hundreds to thousands of paths, and a loop that visits them one by
+// one is a round trip to HBM per path: there the filters look at 64 paths per step, one per lane.
+// mark_paths: the set of the paths for which `pred(path)` (evaluated by the path's lane) holds, and their number.
+template <class W, class Pred>
+GTX_DEV auto mark_paths(AlignWorkspace & ws, uint32_t n_paths, uint32_t & n_marked, Pred && pred)
+{
+  auto set = new_path_set<W>(ws, n_paths);
+  n_marked = 0;
+  for (uint32_t base = 0; base < n_paths; base += 64)
+  {
+    typename W::template PerLane<bool> hit;
+    W::lanes([&](uint32_t l) {
+      uint32_t const i = base + l;
+      hit[l] = i < n_paths && pred(ws.paths[i]);
+    });
+    uint64_t const m = W::ballot(hit);
+    if (m != 0)
+    {
+      bits_set_word<W>(set, base >> 6, m);
+      n_marked += static_cast<uint32_t>(__builtin_popcountll(m));
+    }
+  }
+  return set;
+}
+
 // stable removal of the paths whose bit in `drop` is set (n_drop of them)
 template <class W, class PathSet>
 GTX_DEV uint32_t compact_paths(AlignWorkspace & ws, uint32_t n_paths, PathSet const & drop, uint32_t n_drop)
@@ -1380,6 +1542,72 @@ GTX_DEV uint32_t compact_paths(AlignWorkspace & ws, uint32_t n_paths, PathSet co
   if (n_drop == 0)
     return n_paths;
   uint32_t k = 0;
+  if constexpr (DENSE_PP_KEYS)
+  {
+    // 64 paths per step: the survivors of a step that carry no variant site (16 bytes each) move together -- every lane holds
+    // its path before any lane writes, and a survivor never moves behind its place --, a step with a path that has sites
+    // moves its survivors one by one
+    for (uint32_t base = 0; base < n_paths; base += 64)
+    {
+      typename W::template PerLane<bool> keep_l, plain_l;
+      typename W::template PerLane<uint32_t> w0, w1, w2, w3;
+      uint64_t const dropped = bits_word<W>(drop, base >> 6);
+      W::lanes([&](uint32_t l) {
+        uint32_t const i = base + l;
+        bool keep = false, plain = true;
+        uint32_t a = 0, b = 0, c = 0, d = 0;
+        if (i < n_paths && !((dropped >> l) & 1ull))
+        {
+          keep = true;
+          uint32_t const * src = reinterpret_cast<uint32_t const *>(&ws.paths[i]);
+          a = src[0];
+          b = src[1];
+          c = src[2];
+          d = src[3];
+          plain = (d >> 16) == 0; // nvar
+        }
+        keep_l[l] = keep;
+        plain_l[l] = plain;
+        w0[l] = a;
+        w1[l] = b;
+        w2[l] = c;
+        w3[l] = d;
+      });
+      uint64_t const keep = W::ballot(keep_l);
+      if (keep == 0)
+        continue;
+      uint32_t const n_keep = static_cast<uint32_t>(__builtin_popcountll(keep));
+      if (k == base && n_keep == (n_paths - base < 64 ? n_paths - base : 64u))
+      {
+        k += n_keep; // (nothing dropped so far: the paths are where they belong)
+        continue;
+      }
+      if (W::ballot(plain_l) == ~0ull)
+      {
+        W::lanes([&](uint32_t l) {
+          if (keep_l[l])
+          {
+            uint32_t * dst = reinterpret_cast<uint32_t *>(&ws.paths[k + static_cast<uint32_t>(__builtin_popcountll(keep & ((1ull << l) - 1ull)))]);
+            dst[0] = w0[l];
+            dst[1] = w1[l];
+            dst[2] = w2[l];
+            dst[3] = w3[l];
+          }
+        });
+        W::lds_sync();
+        k += n_keep;
+      }
+      else
+        for (uint64_t m = keep; m != 0; m &= m - 1)
+        {
+          uint32_t const i = base + static_cast<uint32_t>(__builtin_ctzll(m));
+          if (k != i)
+            copy_path<W>(ws.paths[k], ws.paths[i]);
+          ++k;
+        }
+    }
+    return k;
+  }
   for (uint32_t i = 0; i < n_paths; ++i)
     if (!bits_get<W>(drop, i))
     {
@@ -1395,6 +1623,12 @@ GTX_DEV uint32_t remove_short_paths(AlignWorkspace & ws, uint32_t n_paths, uint3
 {
   if (longest <= 1)
     return n_paths;
+  if constexpr (DENSE_PP_KEYS)
+  {
+    uint32_t n_drop;
+    auto const drop = mark_paths<W>(ws, n_paths, n_drop, [&](DPath const & p) { return path_size(p) < longest; });
+    return compact_paths<W>(ws, n_paths, drop, n_drop);
+  }
   auto drop = new_path_set<W>(ws, n_paths);
   uint32_t n_drop = 0;
   for (uint32_t i = 0; i < n_paths; ++i)
@@ -1410,6 +1644,18 @@ template <class W>
 GTX_DEV uint32_t longest_of(AlignWorkspace const & ws, uint32_t n_paths) // :858-864
 {
   uint32_t m = 0;
+  if constexpr (DENSE_PP_KEYS)
+  {
+    for (uint32_t base = 0; base < n_paths; base += 64)
+    {
+      typename W::template PerLane<uint32_t> size;
+      W::lanes([&](uint32_t l) { size[l] = base + l < n_paths ? path_size(ws.paths[base + l]) : 0u; });
+      uint32_t const s = W::max(size);
+      if (s > m)
+        m = s;
+    }
+    return m;
+  }
   for (uint32_t i = 0; i < n_paths; ++i)
   {
     uint32_t const s = upath_size<W>(ws.paths[i]);
@@ -1425,6 +1671,23 @@ GTX_DEV uint32_t remove_paths_with_too_many_mismatches(AlignWorkspace & ws, uint
   if (n_paths == 0)
     return 0;
   uint32_t mn = 10;
+  if constexpr (DENSE_PP_KEYS)
+  {
+    for (uint32_t base = 0; base < n_paths; base += 64)
+    {
+      typename W::template PerLane<uint32_t> inv; // (10 - mismatches, so that the lanes' maximum is the fewest mismatches)
+      W::lanes([&](uint32_t l) {
+        uint32_t const mm = base + l < n_paths ? static_cast<uint32_t>(ws.paths[base + l].mism) : 10u;
+        inv[l] = mm < 10u ? 10u - mm : 0u;
+      });
+      uint32_t const best = 10u - W::max(inv);
+      if (best < mn)
+        mn = best;
+    }
+    uint32_t n_drop;
+    auto const drop = mark_paths<W>(ws, n_paths, n_drop, [&](DPath const & p) { return static_cast<uint32_t>(p.mism) > mn; });
+    return compact_paths<W>(ws, n_paths, drop, n_drop);
+  }
   for (uint32_t i = 0; i < n_paths; ++i)
   {
     uint32_t const m = GTX_U(static_cast<uint32_t>(ws.paths[i].mism));
@@ -1448,6 +1711,20 @@ GTX_DEV bool all_paths_unique(Here, GraphView const & g, Paths const & paths, ui
   if (n < 2)
     return true;
   uint32_t const s0 = ug_ref_reach_pos<W>(g, GTX_U(paths[0].start)), e0 = ug_ref_reach_pos<W>(g, GTX_U(paths[0].end));
+  if constexpr (DENSE_PP_KEYS)
+  {
+    for (uint32_t base = 1; base < n; base += 64)
+    {
+      typename W::template PerLane<bool> other;
+      W::lanes([&](uint32_t l) {
+        uint32_t const i = base + l;
+        other[l] = i < n && s0 != g_ref_reach_pos(g, paths[i].start) && e0 != g_ref_reach_pos(g, paths[i].end);
+      });
+      if (W::ballot(other) != 0)
+        return false;
+    }
+    return true;
+  }
   for (uint32_t i = 1; i < n; ++i)
     if (s0 != ug_ref_reach_pos<W>(g, GTX_U(paths[i].start)) && e0 != ug_ref_reach_pos<W>(g, GTX_U(paths[i].end)))
       return false;

@@ -316,6 +316,20 @@ GTX_DEV bool bits_get(BitSet<N> const & b, uint32_t i)
 {
   return b.get(i);
 }
+template <class W, uint32_t N>
+GTX_DEV uint64_t bits_word(BitSet<N> const & b, uint32_t k)
+{
+  uint64_t v = 0;
+  for (uint32_t w = 0; w < BitSet<N>::WORDS; ++w)
+    v |= w == k ? b.w[w] : 0ull;
+  return v;
+}
+template <class W, uint32_t N>
+GTX_DEV void bits_set_word(BitSet<N> & b, uint32_t k, uint64_t mask)
+{
+  for (uint32_t w = 0; w < BitSet<N>::WORDS; ++w)
+    b.w[w] = w == k ? mask : b.w[w];
+}
 
 // lookup in a bucketed table (gtx_flat.hpp: BUCKET_SLOTS): the whole 128-byte bucket is one cache line; `hit` (may be
 // NULL) receives the slot that matched, whose inline payload is then an L1 hit

@@ -33,8 +33,10 @@ namespace gtx
     NS::AlignWorkspace & ws = workspaces[blockIdx.x];                                                                              \
     /* the dense start / end tables of the chaining's searches live in LDS (align_core.inl: PpKeyTables) */                       \
     __shared__ uint32_t s_pp_keys[2][NS::AlignCfg::MAXPP];                                                                         \
+    __shared__ uint64_t s_pp_bits[NS::AlignCfg::MAXPP / 64 + 1];                                                                   \
     ws.pp_start = s_pp_keys[0];                                                                                                    \
     ws.pp_end = s_pp_keys[1];                                                                                                      \
+    ws.bits_pp = s_pp_bits;                                                                                                        \
     WaveHipMem::mem_sync();                                                                                                        \
     GTX_HBM_PASS_BODY(NS)                                                                                                          \
   }

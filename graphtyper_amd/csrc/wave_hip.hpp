@@ -71,6 +71,18 @@ struct WaveHip
     total = __shfl(x, 63);
     out.v = x - in.v;
   }
+  static __device__ inline uint32_t max(PerLane<uint32_t> const & p)
+  {
+    uint32_t x = p.v;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+    {
+      uint32_t const y = __shfl_xor(x, d);
+      x = y > x ? y : x;
+    }
+    return x;
+  }
+  static __device__ inline void atomic_or_u64(uint64_t * p, uint64_t v) { atomicOr(reinterpret_cast<unsigned long long *>(p), static_cast<unsigned long long>(v)); }
   static __device__ inline unsigned long long clock() { return clock64(); }
   static __device__ inline void atomic_add_u32(uint32_t * p, uint32_t v) { atomicAdd(p, v); }
   static __device__ inline void atomic_add_u64(unsigned long long * p, unsigned long long v) { atomicAdd(p, v); }

@@ -85,6 +85,14 @@ struct WaveEmu
     }
     total = s;
   }
+  static uint32_t max(PerLane<uint32_t> const & p)
+  {
+    uint32_t m = 0;
+    for (uint32_t l = 0; l < 64; ++l)
+      m = p.v[l] > m ? p.v[l] : m;
+    return m;
+  }
+  static void atomic_or_u64(uint64_t * p, uint64_t v) { *p |= v; }
   static unsigned long long clock() { return 0; }
   static void atomic_add_u32(uint32_t * p, uint32_t v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
   static uint32_t atomic_claim_u32(uint32_t * p) { return __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
@@ -214,6 +222,7 @@ extern "C"
     auto ws = std::make_unique<AlignWorkspace>();
     auto big_ws = std::make_unique<big::AlignWorkspace>();
     std::vector<uint32_t> big_keys(2 * big::AlignCfg::MAXPP, 0xABABABABu), wide_keys(2 * wide::AlignCfg::MAXPP, 0xABABABABu);
+    std::vector<uint64_t> big_bits(big::AlignCfg::MAXPP / 64 + 1, 0xABABABABABABABABull), wide_bits(wide::AlignCfg::MAXPP / 64 + 1, 0xABABABABABABABABull);
     bool const second_pass = !e.params.no_second_pass;
     char const * fe = std::getenv("GTX_FORCE_SECOND_PASS"); // 1: every task through all passes, 2: every task done by pass 2
     int const force = fe ? std::atoi(fe) : 0;
@@ -306,6 +315,7 @@ extern "C"
       std::memset(static_cast<void *>(big_ws.get()), fill, sizeof(big::AlignWorkspace));
       big_ws->pp_start = big_keys.data(); // (the kernel points them at LDS)
       big_ws->pp_end = big_keys.data() + big::AlignCfg::MAXPP;
+      big_ws->bits_pp = big_bits.data();
       uint32_t const bst = hbm_pass(
         *big_ws, [&](uint32_t & np, uint32_t & longest)
         { return big::align_paths<WaveEmu>(g, ix, *big_ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest); },
@@ -318,6 +328,7 @@ extern "C"
         std::memset(static_cast<void *>(wide_ws.get()), fill, sizeof(wide::AlignWorkspace));
         wide_ws->pp_start = wide_keys.data();
         wide_ws->pp_end = wide_keys.data() + wide::AlignCfg::MAXPP;
+        wide_ws->bits_pp = wide_bits.data();
         last = hbm_pass(
           *wide_ws, [&](uint32_t & np, uint32_t & longest)
           { return wide::align_paths<WaveEmu>(g, ix, *wide_ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, np, longest); },
