@@ -1237,7 +1237,8 @@ def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_al
            "align_passes_ms": {"express": ms[0], "general": ms[1], "hbm_tables": ms[2]},
            "pass_shares": {"tasks": n, "handed_to_general": handed, "share_general": handed / float(n),
                            "position_hinted_share": kt[0][2] / float(n)},
-           "exact_pass": {"tasks_with_a_part_of_the_slab": exact[0], "tasks_with_the_whole_slab": exact[1], "tasks_refused": exact[2]}}
+           "exact_pass": {"tasks_with_a_small_part_of_the_slab": exact[0], "tasks_with_a_large_part": exact[1], "tasks_with_the_whole_slab": exact[2],
+                          "tasks_refused": exact[3]}}
     out.update(facts)
     ctx.close()
     return out

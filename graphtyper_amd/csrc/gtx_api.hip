@@ -1109,7 +1109,7 @@ static std::unique_ptr<CallScratch> scratch_new(gtx_ctx & c)
     }
     // the exact pass: two queues (what did not fit the tables above; what did not fit a part of the slab) and the slab
     s->d_exact_state = s->d_big_state + 16;
-    ok = ok && dev_alloc(s->d_exact_tasks, 2 * static_cast<size_t>(CallScratch::EXACT_TASK_CAP), "exact pass queues");
+    ok = ok && dev_alloc(s->d_exact_tasks, 3 * static_cast<size_t>(CallScratch::EXACT_TASK_CAP), "exact pass queues");
     void * slab = nullptr;
     ok = ok && hip_ok(gtx::dev_malloc(&slab, c.exact_slab_bytes), "exact pass slab");
     s->d_exact_slab = static_cast<uint8_t *>(slab);
@@ -1689,6 +1689,11 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     {
       (void)hipStreamWaitEvent(tail_stream, front_event, 0);
       s1 = sg = tail_stream;
+      // (from here on the tail stream holds launches that use the scratch: an error return below must leave the caller's
+      //  ScratchHold recording `done` on THAT stream, else the next call on the front stream would reset counters and queues the
+      //  tail stream may still be reading)
+      if (last_stream)
+        *last_stream = tail_stream;
     }
   };
   auto mark = [&](uint32_t part, int k, hipStream_t on)
@@ -1902,8 +1907,11 @@ static int kernel_times(gtx_ctx * c, float * ms, uint32_t * tasks)
         all.push_back(u.get());
     c->epoch_queried = true;
   }
-  if (!s || !s->timed)
-    return GTX_OK; // nothing was timed yet
+  // ("nothing was timed" is decided by the ring's slots below, not by the last call: beyond TIME_RING calls of an epoch the last
+  //  one is untimed while up to TIME_RING earlier ones sit in the ring.  The query is meant to come behind the calls in flight:
+  //  ring_used / ring_parts of a scratch another host thread is inside of are read here without its lock.)
+  if (!s)
+    return GTX_OK;
   if (!hip_ok(hipSetDevice(c->device), "hipSetDevice"))
     return GTX_ERR_HIP;
   double sum[4] = {0, 0, 0, 0};
@@ -1934,10 +1942,12 @@ static int kernel_times(gtx_ctx * c, float * ms, uint32_t * tasks)
     }
   }
   if (calls == 0)
-    return GTX_OK;
+    return GTX_OK; // nothing was timed yet
   for (int k = 0; k < 4; ++k)
     ms[k] = static_cast<float>(sum[k] / calls);
-  // (the last call's counters; the stream is through: its end event was waited for above)
+  // (the last call's counters: when that call was beyond the ring its stream may still be busy -- wait for the scratch's own event)
+  if (s->done && s->used)
+    (void)hipEventSynchronize(static_cast<hipEvent_t>(s->done));
   uint32_t cnt[8 * CallScratch::MAX_PARTS] = {}, big[4] = {0, 0, 0, 0};
   (void)hipMemcpy(cnt, s->d_counters, sizeof(cnt), hipMemcpyDeviceToHost);
   if (s->d_big_state)
@@ -2274,7 +2284,7 @@ extern "C" int gtx_ctx_exact_pass_tasks(gtx_ctx * c, uint64_t * out)
 {
   if (!c || !out)
     return GTX_ERR_ARG;
-  out[0] = out[1] = out[2] = 0;
+  out[0] = out[1] = out[2] = out[3] = 0;
   if (c->device < 0)
     return GTX_ERR_NO_DEVICE;
   CallScratch * s = nullptr;
@@ -2286,12 +2296,13 @@ extern "C" int gtx_ctx_exact_pass_tasks(gtx_ctx * c, uint64_t * out)
     return GTX_OK;
   if (!hip_ok(hipSetDevice(c->device), "hipSetDevice"))
     return GTX_ERR_HIP;
-  uint32_t st[24]; // [0..7] first launch, [8..15] second, [16..23] what the second handed on (nothing takes it: the count is what is left)
+  uint32_t st[32]; // 8 words per launch (small parts, large parts, whole slab), then what the last handed on (nothing takes it: the count is what is left)
   if (!hip_ok(hipDeviceSynchronize(), "exact-pass state") || !hip_ok(hipMemcpy(st, s->d_exact_state, sizeof(st), hipMemcpyDeviceToHost), "exact-pass state"))
     return GTX_ERR_HIP;
   out[0] = st[0];
   out[1] = st[8];
-  out[2] = st[16] + st[3] + st[11]; // (+ tasks a full queue dropped)
+  out[2] = st[16];
+  out[3] = st[24] + st[3] + st[11] + st[19]; // (+ tasks a full queue dropped)
   return GTX_OK;
 }
 

@@ -60,11 +60,12 @@ struct CallScratch
   static constexpr uint32_t WIDE_TASK_CAP = 1u << 20, WIDE_BLOCKS = 64;
   // exact pass (align_core.hpp: namespace exact): tasks that exceeded the tables of the passes above; tables cut out of a slab
   // at run time -- gtx_ctx::exact_parts workgroups with a part of it each, then one workgroup with all of it
-  uint32_t * d_exact_tasks = nullptr; // two queues of EXACT_TASK_CAP
-  uint32_t * d_exact_state = nullptr; // inside d_big_state's allocation: [0..7] first launch, [8..15] second (same layout)
+  uint32_t * d_exact_tasks = nullptr; // three queues of EXACT_TASK_CAP (small parts, large parts, the whole slab)
+  uint32_t * d_exact_state = nullptr; // inside d_big_state's allocation: 8 words per launch (same layout) + 8 for what is left
   uint8_t * d_exact_slab = nullptr;   // gtx_ctx::exact_slab_bytes
   static constexpr uint32_t EXACT_TASK_CAP = 1u << 20;
-  static constexpr uint32_t EXACT_PART_SITES = 24;       // variant sites a path has room for while a task has a part of the slab
+  static constexpr uint32_t EXACT_LARGE_PARTS = 32, EXACT_LARGE_SITES = 64; // the launch between the small parts and the whole slab
+  static constexpr uint32_t EXACT_PART_SITES = 24;       // variant sites a path has room for while a task has a small part of the slab
   static constexpr uint32_t EXACT_PART_CANDIDATES = 8256; // ... and walk candidates (128 live sequences x 64 alleles + a round's slack)
   // second scoring pass (items whose reads touch more variant sites than the main pass' tables hold)
   uint32_t * d_score_state = nullptr; // [0] items queued

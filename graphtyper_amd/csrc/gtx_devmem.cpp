@@ -61,7 +61,8 @@ hipError_t dev_malloc(void ** p, size_t bytes)
     if (c.limit == 0)
     {
       char const * env = std::getenv("GTX_DEVICE_CACHE_MB");
-      c.limit = (env ? static_cast<size_t>(std::atoll(env)) : 8192u) << 20;
+      long long const mb = env ? std::atoll(env) : 8192; // (a negative value keeps nothing: it must not become a huge unsigned limit)
+      c.limit = static_cast<size_t>(mb < 0 ? 0 : mb) << 20;
       if (c.limit == 0)
         c.limit = 1; // (0 MB: nothing is kept)
     }

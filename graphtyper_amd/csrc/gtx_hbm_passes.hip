@@ -195,21 +195,26 @@ char const * launch_hbm_passes(HbmPassArgs const & a, hipStream_t stream)
     if (hipGetLastError() != hipSuccess)
       return "gtx_align_wide_kernel launch";
   }
-  // the exact pass: what exceeded the tables above, first with a part of the slab per workgroup, then -- one workgroup --
-  // with all of it.  Nearly always both find an empty queue and leave at once.
-  uint32_t * const q1 = a.exact_tasks, * const q2 = a.exact_tasks + CallScratch::EXACT_TASK_CAP;
-  uint32_t * const st1 = a.exact_state, * const st2 = a.exact_state + 8, * const st3 = a.exact_state + 16;
+  // the exact pass: what exceeded the tables above, with a small part of the slab per task (up to exact_parts of them side by
+  // side), then what did not fit with a large part (up to EXACT_LARGE_PARTS), then -- one workgroup -- with all of it.  Nearly
+  // always all three find an empty queue and leave at once.
+  // (a small part's paths have room for EXACT_PART_SITES variant sites and its walks for exact_part_cand_cap candidates, a large
+  //  part's for EXACT_LARGE_SITES, the whole slab for the proven bounds: a site per read base, 128 live sequences times the alleles
+  //  of the graph's widest site)
+  uint32_t * const q1 = a.exact_tasks, * const q2 = q1 + CallScratch::EXACT_TASK_CAP, * const q3 = q2 + CallScratch::EXACT_TASK_CAP;
+  uint32_t * const st1 = a.exact_state, * const st2 = st1 + 8, * const st3 = st2 + 8, * const st4 = st3 + 8;
   auto kernel = a.wide_sites ? gtx_align_exact_wide_kernel : gtx_align_exact_kernel;
   unsigned long long const slab_bytes = a.exact_slab_bytes, min_part = slab_bytes / a.exact_parts;
-  // (a part's paths have room for EXACT_PART_SITES variant sites and its walks for exact_part_cand_cap candidates; the whole
-  //  slab for the proven bounds: a site per read base, 128 live sequences times the alleles of the graph's widest site)
+  uint32_t const large_parts = a.exact_fixed_parts ? 1u : CallScratch::EXACT_LARGE_PARTS;
   hipLaunchKernelGGL(kernel, dim3(a.exact_parts), dim3(64), 0, stream, a.g, a.ix, a.seq, a.seq_stride, a.meta, a.records, a.rec_words, q1,
                      CallScratch::EXACT_TASK_CAP, st1, a.exact_slab, slab_bytes, min_part, a.exact_fixed_parts ? 1u : 0u, a.exact_part_cand_cap,
-                     CallScratch::EXACT_PART_SITES, a.arena,
-                     arena_words, a.arena_cursor, q2, CallScratch::EXACT_TASK_CAP, st2);
-  // (what even the whole slab cannot hold is counted in st3: a queue of capacity 0)
-  hipLaunchKernelGGL(kernel, dim3(1), dim3(64), 0, stream, a.g, a.ix, a.seq, a.seq_stride, a.meta, a.records, a.rec_words, q2, CallScratch::EXACT_TASK_CAP,
-                     st2, a.exact_slab, slab_bytes, 0ull, 0u, a.exact_cand_cap, exact::AlignCfg::MAXV, a.arena, arena_words, a.arena_cursor, q2, 0u, st3);
+                     CallScratch::EXACT_PART_SITES, a.arena, arena_words, a.arena_cursor, q2, CallScratch::EXACT_TASK_CAP, st2);
+  hipLaunchKernelGGL(kernel, dim3(large_parts), dim3(64), 0, stream, a.g, a.ix, a.seq, a.seq_stride, a.meta, a.records, a.rec_words, q2,
+                     CallScratch::EXACT_TASK_CAP, st2, a.exact_slab, slab_bytes, slab_bytes / large_parts, 0u, a.exact_cand_cap,
+                     CallScratch::EXACT_LARGE_SITES, a.arena, arena_words, a.arena_cursor, q3, CallScratch::EXACT_TASK_CAP, st3);
+  // (what even the whole slab cannot hold is counted in st4: a queue of capacity 0)
+  hipLaunchKernelGGL(kernel, dim3(1), dim3(64), 0, stream, a.g, a.ix, a.seq, a.seq_stride, a.meta, a.records, a.rec_words, q3, CallScratch::EXACT_TASK_CAP,
+                     st3, a.exact_slab, slab_bytes, 0ull, 0u, a.exact_cand_cap, exact::AlignCfg::MAXV, a.arena, arena_words, a.arena_cursor, q3, 0u, st4);
   if (hipGetLastError() != hipSuccess)
     return "gtx_align_exact_kernel launch";
   return nullptr;

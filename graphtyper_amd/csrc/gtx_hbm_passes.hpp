@@ -30,8 +30,8 @@ struct HbmPassArgs
   uint32_t * wide_state;
   void * wide_ws; // CallScratch::WIDE_BLOCKS x wide::AlignWorkspace
   // exact pass
-  uint32_t * exact_tasks; // two queues of CallScratch::EXACT_TASK_CAP
-  uint32_t * exact_state; // 3 x 8 words
+  uint32_t * exact_tasks; // three queues of CallScratch::EXACT_TASK_CAP
+  uint32_t * exact_state; // 4 x 8 words
   uint8_t * exact_slab;
   uint64_t exact_slab_bytes;
   uint32_t exact_cand_cap;      // walk candidates of a task that has the whole slab (the proven bound)

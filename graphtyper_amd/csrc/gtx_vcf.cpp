@@ -1954,8 +1954,13 @@ extern "C" int gtx_bgzf_compress(const void * in, uint64_t in_len, int level, in
       gtx::g_last_error = "gtx_bgzf_compress: deflate failed";
       return GTX_ERR_IO;
     }
-  if (with_eof && !member(p, 0))
-    return GTX_ERR_IO;
+  if (with_eof)
+  {
+    // the end-of-file marker is a fixed member (SAM spec 4.1.2), whatever the level: deflating nothing at level 0 gives a stored
+    // block and a member of 31 bytes, which htslib's bgzf_check_EOF does not take for the marker
+    static unsigned char const EOF_MEMBER[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    res.append(reinterpret_cast<char const *>(EOF_MEMBER), sizeof EOF_MEMBER);
+  }
   *out_len = res.size();
   if (res.size() > cap)
     return out ? GTX_ERR_CAPACITY : GTX_OK;

@@ -560,11 +560,11 @@ class Context:
         return download(ptr.value or 0, np.uint32, int(used.value)), int(tasks.value)
 
     def exact_pass_tasks(self):
-        """(tasks of the last align batch that went through the exact pass with a part of its slab, again with the whole slab,
-        tasks that keep a table-overflow status even so)"""
-        out = (C.c_uint64 * 3)()
+        """(tasks of the last align batch that went through the exact pass with a small part of its slab, again with a large part,
+        again with the whole slab, tasks that keep a table-overflow status even so)"""
+        out = (C.c_uint64 * 4)()
         check(lib().gtx_ctx_exact_pass_tasks(self.h, out))
-        return int(out[0]), int(out[1]), int(out[2])
+        return int(out[0]), int(out[1]), int(out[2]), int(out[3])
 
     def pass_times(self):
         """(ms of the express / general / HBM-table pass of the last align batch, tasks handed to the general pass);

@@ -283,8 +283,8 @@ int gtx_ctx_hint_table(const gtx_ctx *, int which, void * out, uint64_t cap_byte
  * locations) are queued on the device and redone by a second kernel over larger tables in HBM (512 paths, 2048 labels
  * per k-mer), and what exceeds those as well -- the reference has NO limit on the paths and labels of a read
  * (src/typer/genotype_paths.cpp:294-352: a read inside a 280-bp homopolymer chains 249 x 249 labels) -- by the exact pass,
- * whose tables are cut at run time out of a slab of HBM (gtx_params::exact_pass_mb per call in flight; first a part of the
- * slab per task, then all of it).  Every read therefore gets the result the reference computes; an overflow status (and no
+ * whose tables are cut at run time out of a slab of HBM (gtx_params::exact_pass_mb per call in flight; first a small
+ * part of the slab per task, then a large one, then all of it).  Every read therefore gets the result the reference computes; an overflow status (and no
  * paths) is left only on a read that needs more than the configured slab, or whose record finds the big-record arena full
  * (GTX_ST_RECORD_OVERFLOW; a record counts its paths in 16 bits).  gtx_ctx_exact_pass_tasks tells how many tasks went that far.
  * In front of them runs the position-hinted pass (gtx_read_meta::pos): one read per lane, finished there when the flags of
@@ -397,9 +397,10 @@ int gtx_ctx_error_count(gtx_ctx *, uint32_t * out);
  * (both synchronise with the device) */
 int gtx_ctx_big_records(gtx_ctx *, const uint32_t ** d_words, uint64_t * capacity_words, uint64_t * used_words, uint64_t * tasks);
 
-/* (read, orientation) tasks the last gtx_align_batch sent through the exact pass: out[0] with a part of the slab, out[1]
- * again with the whole slab, out[2] = tasks that keep a table-overflow status even so (synchronises with the device) */
-int gtx_ctx_exact_pass_tasks(gtx_ctx *, uint64_t * out /* [3] */);
+/* (read, orientation) tasks the last gtx_align_batch sent through the exact pass: out[0] with a small part of the slab, out[1]
+ * again with a large part, out[2] again with the whole slab, out[3] = tasks that keep a table-overflow status even so
+ * (synchronises with the device) */
+int gtx_ctx_exact_pass_tasks(gtx_ctx *, uint64_t * out /* [4] */);
 
 /* Durations (ms, HIP events on the launch stream) of the passes of gtx_align_batch -- everything in front of the general
  * pass (position-hinted + express), general, HBM tables -- and the number of tasks handed to the general pass.  The

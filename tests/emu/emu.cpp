@@ -108,7 +108,7 @@ struct Emu
   uint64_t arena_used = 0;
   uint64_t second_pass_tasks = 0; // tasks that reached the last pass (HBM tables)
   uint64_t wide_pass_tasks = 0;   // tasks that went on to the pass with wide allele sets
-  uint64_t exact_pass_tasks[3] = {0, 0, 0}; // tasks that reached the exact pass (a part of the slab / the whole slab / still refused)
+  uint64_t exact_pass_tasks[4] = {0, 0, 0, 0}; // tasks that reached the exact pass (a small part of the slab / a large part / the whole slab / still refused)
   std::vector<uint8_t> exact_slab;
   uint64_t general_tasks = 0;     // tasks pass 1 handed to pass 2
   uint64_t hinted_done = 0;       // forward tasks the position-hinted pass finished
@@ -250,7 +250,7 @@ extern "C"
     for (uint32_t n : e.graph.ref_nvar)
       widest_site = std::max(widest_site, n);
     // the exact pass' slab (gtx_api.hip: exact_slab_mb; here one slab, used by one task at a time)
-    constexpr uint32_t EXACT_PART_SITES = 24, EXACT_PART_CANDIDATES = 8256; // (gtx_ctx.hpp: CallScratch)
+    constexpr uint32_t EXACT_PART_SITES = 24, EXACT_PART_CANDIDATES = 8256, EXACT_LARGE_PARTS = 32, EXACT_LARGE_SITES = 64; // (gtx_ctx.hpp: CallScratch)
     char const * xm = std::getenv("GTX_EXACT_PASS_MB");
     std::vector<uint8_t> & exact_slab = e.exact_slab;
     if (exact_slab.empty())
@@ -259,7 +259,7 @@ extern "C"
     if (char const * xp = std::getenv("GTX_EXACT_PARTS"))
       if (std::atol(xp) > 0)
         exact_parts = static_cast<uint64_t>(std::min<long>(std::atol(xp), 1024));
-    e.exact_pass_tasks[0] = e.exact_pass_tasks[1] = e.exact_pass_tasks[2] = 0;
+    e.exact_pass_tasks[0] = e.exact_pass_tasks[1] = e.exact_pass_tasks[2] = e.exact_pass_tasks[3] = 0;
     // one task through an HBM-table pass (the body of GTX_HBM_PASS_KERNEL in gtx_api.hip); returns the pass' status
     auto hbm_pass = [&](auto &, auto && align, auto && size_of, auto && write_body, uint32_t * rec, uint32_t len) -> uint32_t
     {
@@ -337,11 +337,12 @@ extern "C"
       }
       // the exact pass (gtx_align_exact_kernel): first with a part of the slab, then with all of it
       constexpr uint32_t TABLES = GTX_ST_LABEL_OVERFLOW | GTX_ST_PATH_OVERFLOW | GTX_ST_DFS_OVERFLOW;
-      for (uint32_t level = 0; level < 2 && (last & TABLES); ++level)
+      bool const fixed_parts = std::getenv("GTX_EXACT_PARTS") != nullptr; // (the test switch: no large parts either)
+      for (uint32_t level = 0; level < 3 && (last & TABLES); ++level)
       {
         ++e.exact_pass_tasks[level];
-        uint64_t const bytes = level == 0 ? ((exact_slab.size() / exact_parts) & ~255ull) : exact_slab.size();
-        uint32_t const cap_v = level == 0 ? EXACT_PART_SITES : exact::AlignCfg::MAXV;
+        uint64_t const bytes = level == 0 ? ((exact_slab.size() / exact_parts) & ~255ull) : (level == 1 && !fixed_parts) ? ((exact_slab.size() / EXACT_LARGE_PARTS) & ~255ull) : exact_slab.size();
+        uint32_t const cap_v = level == 0 ? EXACT_PART_SITES : level == 1 ? EXACT_LARGE_SITES : exact::AlignCfg::MAXV;
         std::memset(exact_slab.data(), fill, 65536);
         if (has_wide_sites)
         {
@@ -367,7 +368,7 @@ extern "C"
         }
       }
       if (last & TABLES)
-        ++e.exact_pass_tasks[2];
+        ++e.exact_pass_tasks[3];
     };
     auto empty_record = [&](uint32_t t, uint32_t len)
     {
@@ -535,7 +536,7 @@ extern "C"
   }
 
   uint64_t emu_hinted_done(void * p) { return static_cast<Emu *>(p)->hinted_done; }
-  uint64_t emu_exact_pass_tasks(void * p, int level) { return static_cast<Emu *>(p)->exact_pass_tasks[level % 3]; }
+  uint64_t emu_exact_pass_tasks(void * p, int level) { return static_cast<Emu *>(p)->exact_pass_tasks[level & 3]; }
 
   // per read of the last emu_align with the position-hinted pass: finishing pass of the forward task, pass 0's decline note
   void emu_pass_of(void * p, uint8_t * pass_of, uint8_t * hint_decline, uint32_t n)

@@ -90,9 +90,9 @@ class EmuBackend:
         return int(self.L.emu_hinted_done(C.c_void_p(self.h)))
 
     def exact_pass_tasks(self):
-        """tasks of the last align call that went through the exact pass (a part of the slab, the whole slab, still refused)"""
+        """tasks of the last align call that went through the exact pass (a small part of the slab, a large part, the whole slab, still refused)"""
         self.L.emu_exact_pass_tasks.restype = C.c_uint64
-        return tuple(int(self.L.emu_exact_pass_tasks(C.c_void_p(self.h), k)) for k in range(3))
+        return tuple(int(self.L.emu_exact_pass_tasks(C.c_void_p(self.h), k)) for k in range(4))
 
     def big_records(self):
         ptr, cap = C.POINTER(C.c_uint32)(), C.c_uint64()
