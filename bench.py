@@ -738,7 +738,7 @@ def extra_pcie_fed(w, torch, gtx, steps=3, chunks=4):
             "note": "inputs in pinned host memory, copied per step on a second stream under the previous part's kernels"}
 
 
-def extra_pipeline(args, torch, gtx, synth, device, ctx, ref, records, n=4_000_000, chunk=65536):
+def extra_pipeline(args, torch, gtx, synth, device, ctx, ref, records, n=4_000_000, chunk=65536, threads=None):
     """BAM files -> VCF text, wall clock (never `value`): the reads of one sample as T position-sliced BAM files (what a
     region split of one indexed BAM gives; written before the clock starts), T host threads -- the reference's worker threads,
     src/typer/caller.cpp:399-436 -- each running gtx_reads_next (BGZF inflate on the library's team, record parse) ->
@@ -748,7 +748,7 @@ def extra_pipeline(args, torch, gtx, synth, device, ctx, ref, records, n=4_000_0
     import tempfile
     import threading
     L = gtx.lib()
-    threads = max(1, min(int(os.environ.get("GTX_BENCH_PIPE_THREADS", "16")), (os.cpu_count() or 2) // 2))
+    threads = max(1, min(int(os.environ.get("GTX_BENCH_PIPE_THREADS", "16")) if threads is None else threads, (os.cpu_count() or 2) // 2))
     d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=777, device=device, REGION_LEN=args.region_len, err_rate=args.err, n_rate=args.nrate)
     codes = unpack_nibbles(d_seq.cpu().numpy(), READ_LEN)
     pos = d_pos.cpu().numpy()
@@ -1485,6 +1485,11 @@ def main(argv=None):
     if n_gpus == 1 and n_samples == 1 and not args.no_extra:
         try:
             cfg.setdefault("extra", {})["pipeline"] = extra_pipeline(args, torch, gtx, synth, device, ctx, ref, records)
+            # the same leg with four times the host threads (and reads): where the host side stops scaling
+            wide = extra_pipeline(args, torch, gtx, synth, device, ctx, ref, records, n=16_000_000, threads=64)
+            cfg["extra"]["pipeline_64_threads"] = {k: wide.get(k) for k in ("reads", "reads_per_s", "wall_s", "host_threads", "bam_files", "host_thread_seconds",
+                                                                              "slowest_thread_s", "records_per_s_per_thread", "stage_bound_reads_per_s",
+                                                                              "vcf_equals_resident_run", "bam_write_s_before_the_clock", "error")}
         except Exception as e:  # the extra line must never cost the main one
             cfg.setdefault("extra", {})["pipeline"] = {"error": repr(e)}
     if n_gpus == 1 and n_samples == 1 and not args.no_extra:

@@ -46,6 +46,15 @@ def test_coverage_model_hand_worked():
     assert coverage_call(sv_line("DEL", 5001, 2000), depth2) == [0, 30, 255, 135, 0]
     # no deletion, 80 bp: inside = outside = 30 -> AD 30,0; 0 / 90 / 360 -> x 2/3 -> 0,60,240
     assert coverage_call(sv_line("DEL", 5001, 80), np.full(20000, 30, np.uint16)) == [30, 0, 0, 60, 240]
+    # homozygous, 80 bp: AD 0,30; 360 / 90 / 0, x 2/3 each -> 240, 60, 0
+    depth4 = np.full(20000, 30, np.uint16)
+    depth4[5000:5080] = 0
+    assert coverage_call(sv_line("DEL", 5001, 80), depth4) == [0, 30, 240, 60, 0]
+    # the points beside the SV are 20 bp apart, 51 in front and 50 behind: with reads only within 400 bp of it most of them see none
+    depth5 = np.zeros(20000, np.uint16)
+    depth5[4600:6400] = 30
+    depth5[5000:6000] = 15
+    assert coverage_call(sv_line("DEL", 5001, 1000), depth5)[:2] == [15, 0]
     # more reads inside than outside never gives a negative count
     depth3 = np.full(20000, 10, np.uint16)
     depth3[5000:5500] = 14
