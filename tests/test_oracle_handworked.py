@@ -263,3 +263,19 @@ def test_equal_orientations_keep_the_first():
     a = parse_scores(g.scores())[0]["alleles"][0]
     # (haplotype.cpp:262-281: a read without IS_FIRST_IN_PAIR counts as "read 2"; forward because the first orientation was kept)
     assert (a["r1f"], a["r1r"], a["r2f"], a["r2r"]) == (0, 0, 1, 0)
+
+
+def test_ten_reads_over_the_reference_test_contigs():
+    """tests/golden/handworked_paths.json: ten reads over index_test.fa chr1-chr3, their GenotypePaths worked by hand"""
+    import json
+    import os
+    from fixtures import contig
+    from oracle_lib import encode
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "handworked_paths.json")))["cases"]
+    assert len(cases) == 10
+    for c in cases:
+        ref, recs = contig(c["contig"])
+        got = Oracle(ref, recs).align([encode(c["read"])])[0][0]
+        want = [dict(start=p["start"], end=p["end"], rs=p["rs"], re=p["re"], mm=p["mm"], vars=[(o, tuple(a)) for o, a in p["vars"]]) for p in c["paths"]]
+        have = [dict(start=p["start"], end=p["end"], rs=p["rs"], re=p["re"], mm=p["mm"], vars=sorted((o, tuple(a)) for o, a in p["vars"])) for p in got["paths"]]
+        assert have == want, (c["contig"], c["why"], have, want)
