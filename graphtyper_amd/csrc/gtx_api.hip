@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_WIDE_WAV
 #else
 #define GTX_HINT_REC_SLOT(read) (read)
 #endif
-template <uint32_t WAVES>
+template <uint32_t WAVES, bool DENSE>
 __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const & ix, uint8_t const * __restrict__ seq, uint32_t seq_stride,
                                             gtx_read_meta const * __restrict__ meta, uint32_t n_reads, uint32_t * __restrict__ records,
                                             uint32_t rec_words, uint32_t force_both, uint32_t * __restrict__ queue1, uint32_t * __restrict__ queue2,
@@ -449,7 +449,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
       // the store path charges is line visits per instruction -- 16 per instruction this way instead of 64.
       uint32_t * row = reinterpret_cast<uint32_t *>(&s_seq[wave][lane * ROW_VEC]);
       bool const can_stage = (rec_words & 3u) == 0 && (reinterpret_cast<uintptr_t>(records) & 15u) == 0; // (16-byte stores into the slots)
-      uint32_t const where = hinted_one(g, ix, row, ROW_BYTES, m, rec, rec_words, can_stage ? row : nullptr);
+      uint32_t const where = hinted_one<DENSE>(g, ix, row, ROW_BYTES, m, rec, rec_words, can_stage ? row : nullptr);
       fwd = where == 0;
       fwd2 = where == HINT_TO_GENERAL;
       staged_rec = where == 2;
@@ -535,7 +535,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
   GraphView g, IndexView ix, uint8_t const *__restrict__ seq, uint32_t seq_stride, gtx_read_meta const *__restrict__ meta,         \
     uint32_t n_reads, uint32_t *__restrict__ records, uint32_t rec_words, uint32_t force_both, uint32_t *__restrict__ queue1,      \
     uint32_t *__restrict__ queue2, unsigned long long *queue_counts, uint32_t decline_all, uint8_t *__restrict__ task_flags
-#define GTX_HINTED_PASS(W) hinted_pass<W>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, queue1, queue2, queue_counts, decline_all, task_flags)
+#define GTX_HINTED_PASS(W, DENSE) hinted_pass<W, DENSE>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, queue1, queue2, queue_counts, decline_all, task_flags)
 
 #ifndef GTX_HINT_VGPRS
 #define GTX_HINT_VGPRS 80
@@ -551,18 +551,17 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
 // takes 83-85 when left alone -- allocated as 88: five wavefronts, two workgroups)
 __global__ __launch_bounds__(64 * GTX_HINT_WAVES) __attribute__((amdgpu_num_vgpr(GTX_HINT_VGPRS), amdgpu_waves_per_eu(6, 6))) void gtx_align_hinted_kernel(GTX_HINTED_ARGS)
 {
-  GTX_HINTED_PASS(GTX_HINT_WAVES);
+  GTX_HINTED_PASS(GTX_HINT_WAVES, false);
 }
 
-// (other workgroup sizes for A/B runs: GTX_HINT_WAVES=8 / 16 in the environment)
-__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(GTX_HINT_VGPRS))) void gtx_align_hinted8_kernel(GTX_HINTED_ARGS)
+#ifndef GTX_HINT_DENSE_WAVES
+#define GTX_HINT_DENSE_WAVES 4
+#endif
+// The dense build (hinted.hpp: k-mers over two sites, ...) for the graphs that get the wide express pass: what it saves is
+// a trip through that pass, fifty times the cost of a read here, so its own registers and occupancy matter less.
+__global__ __launch_bounds__(64 * GTX_HINT_WAVES) __attribute__((amdgpu_waves_per_eu(GTX_HINT_DENSE_WAVES, GTX_HINT_DENSE_WAVES))) void gtx_align_hinted_dense_kernel(GTX_HINTED_ARGS)
 {
-  GTX_HINTED_PASS(8);
-}
-
-__global__ __launch_bounds__(1024) void gtx_align_hinted16_kernel(GTX_HINTED_ARGS)
-{
-  GTX_HINTED_PASS(16);
+  GTX_HINTED_PASS(GTX_HINT_WAVES, true);
 }
 
 // Pass 1 behind pass 0: express4 over the queue of forward tasks the position-hinted pass declined (four reads per
@@ -1736,9 +1735,10 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     {
       // pass 0: one read per lane from the position hint; what it declines is queued for pass 1.  (GTX_HINT=decline: the
       // pass runs but declines everything -- a test of the queue plumbing)
-      char const * hw = std::getenv("GTX_HINT_WAVES"); // A/B switch: wavefronts per workgroup of pass 0 (8, 16; default 4)
-      uint32_t const hint_threads = hw && hw[0] == '8' ? 512u : hw && hw[0] == '1' ? 1024u : 64u * GTX_HINT_WAVES;
-      hipLaunchKernelGGL(hint_threads == 512u ? gtx_align_hinted8_kernel : hint_threads == 1024u ? gtx_align_hinted16_kernel : gtx_align_hinted_kernel,
+      char const * hb = std::getenv("GTX_HINT_BUILD"); // (test switch: lean | dense build of pass 0; default: dense beside the wide express pass)
+      bool const hint_dense = hb && hb[0] == 'd' ? true : hb && hb[0] == 'l' ? false : c->express4_wide;
+      uint32_t const hint_threads = 64u * GTX_HINT_WAVES;
+      hipLaunchKernelGGL(hint_dense ? gtx_align_hinted_dense_kernel : gtx_align_hinted_kernel,
                          dim3((n + hint_threads - 1u) / hint_threads), dim3(hint_threads), 0, st, c->dev_graph, c->dev_index, seq, seq_stride,
                          meta, n, records, rec_words, force_both, queue1, queue2, reinterpret_cast<unsigned long long *>(counters + 2),
                          static_cast<uint32_t>(force != 0 || (eh && eh[0] == 'd'))

@@ -143,7 +143,7 @@ struct IndexView
   // tail_info[i]: the site behind the reference node position i lies in, when a walk from i may cross it the simple way
   //   (a SNP: 2..4 alleles of one base A/C/G/T each; not in an SV graph):  x = HINT_TAIL_OK | alleles << 2 (count, 3 bits) |
   //   min(255, length of the reference node behind the site) << 8 | the alleles' nibble codes << 16 (4 bits each);
-  //   y = the site's index.
+  //   y = the site's index = the reference node i lies in (HINT_TAIL_NODE: whatever the site is like; not in an SV graph).
   const uint32_t * refp;
   const uint2_t * pos_flags;
   const uint2_t * tail_info;
@@ -153,6 +153,10 @@ struct IndexView
 
 constexpr uint32_t HINT_EXACT_OK = 1u, HINT_SINGLE_OK = 2u, HINT_L1 = 4u, HINT_R1 = 8u, HINT_PAR = 16u, HINT_ALT_OK = 32u;
 constexpr uint32_t HINT_MULTI = 64u; // K_i has several labels, all (i, i+31) on one site: bits 8..15 of x are the set of their alleles
+// HINT_TWO: K_i has 2..HINT_OWN_MAX labels, all (i, i+31), on TWO neighbouring sites s (x's site field) and s + 1, alleles
+// 0..3: bits 8..11 of x are the set of s's alleles, bits 12..15 that of s + 1's (labels come in ascending variant id --
+// IndexEntry::variant_id is a std::set -- so s's are first: the path's sites keep that order, path.cpp:105-129)
+constexpr uint32_t HINT_TWO = 128u;
 constexpr uint32_t HINT_OWN_MAX = 4u, HINT_MASK_BITS = 8u; // (express4's KS labels per k-mer; the allele numbers the byte holds)
 constexpr uint32_t HINT_ALTIDX_SHIFT = 8u, HINT_SITE_SHIFT = 12u + 4u; // x: flags 0..7, allele numbers 8..15, site 16..31
 constexpr uint32_t HINT_NO_SITE = 0xFFFFu;
@@ -162,6 +166,19 @@ constexpr uint32_t HINT_BACK_SHIFT = 8u, HINT_SNPOFF_SHIFT = 16u; // y
 // share the 16 bases on the other side are exactly those nv keys; bits 22..23: the reference allele's base there (A C G T =
 // 0..3), bits 24..26: nv.  With it a read k-mer over the SNP is judged against the allele it carries, whichever that is.
 constexpr uint32_t HINT_SNP_GROUP = 1u << 21, HINT_REFB_SHIFT = 22u, HINT_NV_SHIFT = 24u;
+// y bits 27..28 / 29..30 (HINT_FAR_LEFT / _RIGHT_SHIFT): how far the OTHER keys that share K_i's 16 first / last bases are from
+// K_i, in substitutions: 0 = one of them within 2 (or the group was too crowded to look through), 1 = all at least 3 away, 2 = at
+// least 4, 3 = at least 8 or there is none.  A read k-mer m substitutions from K_i inside one half can only meet keys of the
+// other half's group, and those are within m (exact hit) / m + 1 (Hamming-1 neighbour) of K_i: HINT_FAR_NEED(m) rules them out.
+constexpr uint32_t HINT_FAR_LEFT_SHIFT = 27u, HINT_FAR_RIGHT_SHIFT = 29u;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+constexpr uint32_t hint_far_need(uint32_t m) // the code that proves "nobody within m + 1"
+{
+  return m <= 1 ? 1u : m == 2 ? 2u : m <= 6 ? 3u : 4u;
+}
+constexpr uint32_t HINT_TAIL_NODE = 2u; // tail_info.x: y is the position's reference node (set inside every reference node that has a site behind it)
 constexpr uint32_t HINT_TAIL_OK = 1u, HINT_TAIL_NALL_SHIFT = 2u, HINT_TAIL_NEXT_SHIFT = 8u, HINT_TAIL_CODES_SHIFT = 16u; // tail_info.x
 // HINT_EXACT_OK restates express4's seeding rule for an exact hit when the index is built; these are the limits of the
 // rule's wide form (static_asserts in express4.inl): how many keys may share a half with the k-mer's key, how many labels

@@ -660,10 +660,8 @@ void hint_graph_tables(HostGraph const & g, HintGraphTables & t)
       snp = c != 15;
       codes |= static_cast<uint32_t>(c) << (4 * a);
     }
-    if (!snp)
-      continue;
     uint32_t const next_len = g.ref_len[r + 1] < 255 ? g.ref_len[r + 1] : 255;
-    uint2_t const ti{HINT_TAIL_OK | (nv << HINT_TAIL_NALL_SHIFT) | (next_len << HINT_TAIL_NEXT_SHIFT) | (codes << HINT_TAIL_CODES_SHIFT), r};
+    uint2_t const ti = !snp ? uint2_t{HINT_TAIL_NODE, r} : uint2_t{HINT_TAIL_NODE | HINT_TAIL_OK | (nv << HINT_TAIL_NALL_SHIFT) | (next_len << HINT_TAIL_NEXT_SHIFT) | (codes << HINT_TAIL_CODES_SHIFT), r};
     uint32_t const at = g.ref_order[r] - first;
     for (uint32_t d = 0; d < g.ref_len[r]; ++d)
       t.tail_info[at + d] = ti;

@@ -414,6 +414,7 @@ __global__ void k_hint_graph(GraphView g, uint32_t n, uint8_t * __restrict__ bas
         uint32_t const fv = g.ref_first_var[r], nv = g.ref_nvar[r];
         bool snp = nv >= 2 && nv <= 4;
         uint32_t codes = 0;
+        ti = uint2_t{HINT_TAIL_NODE, r};
         for (uint32_t a = 0; a < nv && snp; ++a)
         {
           uint32_t const c = g.var_len[fv + a] == 1 ? nib(g.dna[g.var_dna[fv + a]]) : 15u;
@@ -423,7 +424,7 @@ __global__ void k_hint_graph(GraphView g, uint32_t n, uint8_t * __restrict__ bas
         if (snp)
         {
           uint32_t const next_len = g.ref_len[r + 1] < 255 ? g.ref_len[r + 1] : 255;
-          ti = uint2_t{HINT_TAIL_OK | (nv << HINT_TAIL_NALL_SHIFT) | (next_len << HINT_TAIL_NEXT_SHIFT) | (codes << HINT_TAIL_CODES_SHIFT), r};
+          ti = uint2_t{HINT_TAIL_NODE | HINT_TAIL_OK | (nv << HINT_TAIL_NALL_SHIFT) | (next_len << HINT_TAIL_NEXT_SHIFT) | (codes << HINT_TAIL_CODES_SHIFT), r};
         }
       }
     }

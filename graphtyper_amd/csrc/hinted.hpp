@@ -327,6 +327,13 @@ enum : uint32_t
 // the k-mer also starts a parallel chain -- matters when it opens the run behind a hole), allele (4..5) and site (16..31,
 // HINT_NO_SITE: none) of the label; bits 8..15: the allele set of a k-mer with several labels (HINT_MULTI), else 0
 constexpr uint32_t HK_MM = 4u, HK_PAR = 8u, HK_ALLELE_SHIFT = 4u, HK_SET_SHIFT = 8u, HK_SITE_SHIFT = 16u;
+// HK_TWO (dense build; in the allele field, which a verdict with sets does not use): the labels lie on the sites `site` and
+// `site + 1`, bits 8..11 / 12..15 are the sets of their alleles (HINT_TWO)
+constexpr uint32_t HK_TWO = 1u << HK_ALLELE_SHIFT;
+GTX_DEV bool hk_is_two(uint32_t km) // (a verdict that names one allele has no set)
+{
+  return (km & HK_TWO) != 0 && ((km >> HK_SET_SHIFT) & 255u) != 0;
+}
 
 GTX_DEV uint32_t hk_make(uint32_t kind, uint32_t site, uint32_t allele, bool mm, bool par)
 {
@@ -342,7 +349,7 @@ GTX_DEV uint32_t hk_make(uint32_t kind, uint32_t site, uint32_t allele, bool mm,
 // verdict into a decline when a needed half may occur.
 constexpr uint32_t HK_NEED_LEFT = 64u, HK_NEED_RIGHT = 128u;
 
-template <uint32_t I, class Row>
+template <uint32_t I, bool DENSE, class Row>
 GTX_DEV uint32_t hint_kmer(uint2_t const f, Row row, HintCounts const & h, uint32_t & amb2)
 {
   constexpr uint32_t A = (K - 1) * I;
@@ -351,12 +358,26 @@ GTX_DEV uint32_t hint_kmer(uint2_t const f, Row row, HintCounts const & h, uint3
   uint32_t amb_out = hc_get(h.k[I], HC_AMB_OUT); // ambiguous bases whose set does not hold the reference base
   uint32_t const site = f.x >> HINT_SITE_SHIFT;
   uint32_t const declined = hk_make(HINT_K_DECLINE, site, 0u, false, false);
-  bool const single = (f.x & HINT_SINGLE_OK) != 0;
+  // K's own label list is known: the one label of its place (HINT_SINGLE_OK), or -- dense build -- the labels of several
+  // alleles of one site / of two sites on K's interval (HINT_MULTI, HINT_TWO: `own_set` goes into every verdict that names them)
+  bool const several = DENSE && (f.x & (HINT_MULTI | HINT_TWO)) != 0 && (f.x & HINT_EXACT_OK) != 0;
+  bool const single = (f.x & HINT_SINGLE_OK) != 0 || several;
+  uint32_t const own_set = several ? (((f.x >> HINT_ALTIDX_SHIFT) & 255u) << HK_SET_SHIFT) | ((f.x & HINT_TWO) ? HK_TWO : 0u) : 0u;
   // gl / gr: who else has the 16 first / last bases of the key the read's k-mer is judged against is known -- that key
   // alone, or (on the far side of a SNP under the k-mer, HINT_SNP_GROUP) the keys of the SNP's alleles and nobody else
   bool gl = single && (f.x & HINT_L1) != 0, gr = single && (f.x & HINT_R1) != 0;
+  // ... or (dense build) the others are too far from K to be met by a k-mer m substitutions from it (HINT_FAR_*)
+  uint32_t const far_l = DENSE && single ? (f.y >> HINT_FAR_LEFT_SHIFT) & 3u : 0u, far_r = DENSE && single ? (f.y >> HINT_FAR_RIGHT_SHIFT) & 3u : 0u;
+  auto GL = [&](uint32_t m) { return gl || far_l >= hint_far_need(m); };
+  auto GR = [&](uint32_t m) { return gr || far_r >= hint_far_need(m); };
   if (amb == 0 && mis == 0)
   {
+    if ((f.x & HINT_TWO) != 0) // (two sites under the k-mer: the dense build's)
+    {
+      GTX_HINT_NOTE(DENSE ? 0 : 1);
+      return hk_make(DENSE ? HINT_K_LABEL : HINT_K_DECLINE, site, 0u, false, (f.x & HINT_PAR) != 0) | HK_TWO |
+             (((f.x >> HINT_ALTIDX_SHIFT) & 255u) << HK_SET_SHIFT);
+    }
     GTX_HINT_NOTE((f.x & HINT_EXACT_OK) ? 0 : 1); // exact k-mer, but the place is not provably simple
     uint32_t const set = (f.x & HINT_MULTI) ? ((f.x >> HINT_ALTIDX_SHIFT) & 255u) << HK_SET_SHIFT : 0u; // (several alleles of a merged site)
     return hk_make((f.x & HINT_EXACT_OK) ? HINT_K_LABEL : HINT_K_DECLINE, site, 0u, false, (f.x & HINT_PAR) != 0) | set;
@@ -450,20 +471,21 @@ GTX_DEV uint32_t hint_kmer(uint2_t const f, Row row, HintCounts const & h, uint3
   {
     // two ambiguous bases in one half, the rest == K: the (up to 16) keys of the expansion all carry K's other half,
     // which K alone has -> of the expansion only K can be indexed, and it is in there when both sets hold its base
-    if (!(amb_left == 2 ? gr : gl))
+    // (... or whoever else has that half is three or more substitutions from K: the expansion's keys are within two)
+    if (!(amb_left == 2 ? GR(1) : GL(1)))
     {
       GTX_HINT_NOTE(5);
       return declined;
     }
-    return hk_make(amb_out == 0 ? HINT_K_LABEL : HINT_K_HOLE, site, allele, false, true);
+    return hk_make(amb_out == 0 ? HINT_K_LABEL : HINT_K_HOLE, site, allele, false, true) | own_set;
   }
-  if (amb == 2 && mis == 0 && amb_left == 1 && gl)
+  if (amb == 2 && mis == 0 && amb_left == 1 && GL(1))
   {
     // one ambiguous base in each half, the rest == K: of the (up to 16) keys those with K's base on the left carry K's left
     // half -- nobody else has it: K, or nothing --, the others carry one of three left halves a substitution away from K's,
     // and the caller asks the filter about those three (amb2: this k-mer): all absent -> of the list only K can be indexed
     amb2 |= 1u << I;
-    return hk_make(amb_out == 0 ? HINT_K_LABEL : HINT_K_HOLE, site, allele, false, true);
+    return hk_make(amb_out == 0 ? HINT_K_LABEL : HINT_K_HOLE, site, allele, false, true) | own_set;
   }
   if (amb > 1)
   {
@@ -471,21 +493,21 @@ GTX_DEV uint32_t hint_kmer(uint2_t const f, Row row, HintCounts const & h, uint3
     return declined;
   }
   // the k-mer is not K: a half without a difference is K's own -- nobody but K (or the SNP's allele keys) may have it
-  // (flag) --, a half with one must occur in no indexed key (filter probe by the caller)
+  // (flag), or nobody near enough to K (HINT_FAR_*) --, a half with one must occur in no indexed key (filter probe by the caller)
   if (amb == 0)
   {
     if (mis == 1)
     {
       bool const left = mis_left == 1;
-      if (!(left ? gr : gl))
+      if (!(left ? GR(1) : GL(1)))
       {
         GTX_HINT_NOTE(3); // one substitution, the other half is shared with further keys (a variant there)
         return declined;
       }
-      return hk_make(HINT_K_LABEL, site, allele, true, false) | (left ? HK_NEED_LEFT : HK_NEED_RIGHT);
+      return hk_make(HINT_K_LABEL, site, allele, true, false) | (left ? HK_NEED_LEFT : HK_NEED_RIGHT) | own_set;
     }
     // two or more substitutions: no label at all (K itself is too far away to be a neighbour)
-    bool const ok = (mis_left != 0 || gl) && (mis_right != 0 || gr);
+    bool const ok = (mis_left != 0 || GL(mis)) && (mis_right != 0 || GR(mis));
     GTX_HINT_NOTE(ok ? 0 : 6);
     return hk_make(ok ? HINT_K_HOLE : HINT_K_DECLINE, site, 0u, false, false) | (mis_left != 0 ? HK_NEED_LEFT : 0u) |
            (mis_right != 0 ? HK_NEED_RIGHT : 0u);
@@ -495,12 +517,12 @@ GTX_DEV uint32_t hint_kmer(uint2_t const f, Row row, HintCounts const & h, uint3
   if (mis == 0)
   {
     // its keys differ from K in that base only: they share the other half with K
-    if (!(amb_is_left ? gr : gl))
+    if (!(amb_is_left ? GR(1) : GL(1)))
     {
       GTX_HINT_NOTE(5);
       return declined;
     }
-    return hk_make(amb_out == 0 ? HINT_K_LABEL : HINT_K_HOLE, site, allele, false, true); // (a set without the reference base: none of its keys is K)
+    return hk_make(amb_out == 0 ? HINT_K_LABEL : HINT_K_HOLE, site, allele, false, true) | own_set; // (a set without the reference base: none of its keys is K)
   }
   // ... plus substitutions: none of its keys is K.  Either everything lies in one half (the other one is K's), or the
   // substitutions lie in the half without the ambiguous base, which then is one concrete 16-mer to probe
@@ -508,12 +530,12 @@ GTX_DEV uint32_t hint_kmer(uint2_t const f, Row row, HintCounts const & h, uint3
   bool ok = false;
   if (amb_is_left)
   {
-    ok = mis_right == 0 ? gr : mis_left == 0;
+    ok = mis_right == 0 ? GR(mis + 1u) : mis_left == 0;
     need = mis_right == 0 ? 0u : HK_NEED_RIGHT;
   }
   else
   {
-    ok = mis_left == 0 ? gl : mis_right == 0;
+    ok = mis_left == 0 ? GL(mis + 1u) : mis_right == 0;
     need = mis_left == 0 ? 0u : HK_NEED_LEFT;
   }
   GTX_HINT_NOTE(ok ? 0 : 12);
@@ -543,6 +565,155 @@ GTX_DEV uint32_t hint_probe_verdict(uint32_t verdict, uint32_t left_word, uint32
   return maybe ? (verdict & ~3u) | HINT_K_DECLINE : verdict;
 }
 
+// ---- dense build: the walk at the read's end over one or two sites with alleles of any length ----
+// mismatches by the walks' rule (count_mismatches, graph_utils.hpp:7-69) of read bases [ro, ro + n) against the linear
+// reference from hint position q on (bit planes on both sides, 32 bases a round)
+template <class Row>
+GTX_DEV uint32_t hint_mm_linear(Row row, uint32_t const * refp, uint32_t ro, uint32_t q, uint32_t n)
+{
+  uint32_t mm = 0;
+  for (uint32_t done = 0; done < n; done += 32)
+  {
+    uint32_t const a = ro + done, b = q + done, left = n - done;
+    uint32_t const rw = a >> 5, rs = a & 31u, gw = b >> 5, gs = b & 31u;
+    uint32_t const rw1 = rw + 1 < HINT_PLANE_WORDS ? rw + 1 : rw; // (what comes from it lies behind the read's row: masked by n)
+    uint32_t const v = left >= 32 ? 0xFFFFFFFFu : (1u << left) - 1u;
+    uint32_t const r0 = hint_funnel(row[4 * rw + 0], row[4 * rw1 + 0], rs), r1 = hint_funnel(row[4 * rw + 1], row[4 * rw1 + 1], rs);
+    uint32_t const r2 = hint_funnel(row[4 * rw + 2], row[4 * rw1 + 2], rs), r3 = hint_funnel(row[4 * rw + 3], row[4 * rw1 + 3], rs);
+    uint32_t const g0 = hint_funnel(refp[4 * gw + 0], refp[4 * gw + 4], gs), g1 = hint_funnel(refp[4 * gw + 1], refp[4 * gw + 5], gs);
+    uint32_t const g2 = hint_funnel(refp[4 * gw + 2], refp[4 * gw + 6], gs), g3 = hint_funnel(refp[4 * gw + 3], refp[4 * gw + 7], gs);
+    uint32_t const differ = (r0 ^ g0) | (r1 ^ g1) | (r2 ^ g2) | (r3 ^ g3);
+    uint32_t const r_any = (r0 & r1 & r2 & r3) | ~(r0 | r1 | r2 | r3); // N or '=' (which the reference reads as N)
+    mm += static_cast<uint32_t>(__builtin_popcount(differ & ~r_any & ~(g0 & g1 & g2 & g3) & v));
+  }
+  return mm;
+}
+
+// ... and against n bases of an allele (graph codes at `dna_off`); kill: a character that ends every walk (graph_dev.hpp)
+template <class Row>
+GTX_DEV uint32_t hint_mm_allele(GraphView const & g, Row row, uint32_t ro, uint32_t dna_off, uint32_t n, bool & kill)
+{
+  uint32_t mm = 0;
+  for (uint32_t j = 0; j < n; ++j)
+  {
+    uint8_t const gc = reinterpret_cast<uint8_t const *>(g.dna)[dna_off + j];
+    uint32_t const w = (ro + j) >> 5, sft = (ro + j) & 31u;
+    uint32_t const rc0 = ((row[4 * w] >> sft) & 1u) | (((row[4 * w + 1] >> sft) & 1u) << 1) | (((row[4 * w + 2] >> sft) & 1u) << 2) |
+                         (((row[4 * w + 3] >> sft) & 1u) << 3);
+    uint32_t const rc = rc0 == 0 ? 15u : rc0;
+    kill = kill || gc == DNA_KILL;
+    mm += (gc != rc && rc != 15u && gc != 15u) ? 1u : 0u;
+  }
+  return mm;
+}
+
+// Graph::get_labels_forward (graph.cpp:1187-1439) from a position inside reference node r when the `T` characters of the
+// walk (read bases pre .. pre + T - 1; the first `at` of them lie in node r) leave the node: one candidate per allele of the
+// site behind it -- the allele's bases, then node r + 1 -- and, when that does not hold the rest, per allele of the site
+// behind node r + 1 as well; the labels of the candidates with the fewest mismatches (at most `budget`) are the result.
+// When those end at ONE position they are one path (labels with equal ends, genotype_paths.cpp:32-66) whose allele sets
+// are the union over the candidates (path.cpp:105-129), site r first.
+// status: 0 = not this shape (a third site, an allele without a base, a killing character), 1 = `got` mismatches (INVALID:
+// no candidate within the budget), `end`, the sets; 2 = the best candidates end at different positions (several paths)
+struct HintWalk
+{
+  uint32_t status, got, end, mask1, mask2;
+};
+
+template <class Row>
+GTX_DEV HintWalk hint_tail_walk(GraphView const & g, IndexView const & ix, Row row, uint32_t idx, uint32_t pre, uint32_t T, uint32_t at,
+                                uint32_t r, uint32_t budget)
+{
+  HintWalk w{0u, INVALID, 0u, 0u, 0u};
+  if (r + 1 >= g.n_ref)
+    return w;
+  uint32_t const nv1 = g.ref_nvar[r], fv1 = g.ref_first_var[r];
+  if (nv1 < 2 || nv1 > 4)
+    return w;
+  uint32_t const n1 = g.ref_len[r + 1], o1 = g.ref_order[r + 1], rest = T - at;
+  bool const more = r + 2 < g.n_ref;
+  uint32_t const nv2 = more ? g.ref_nvar[r + 1] : 0u, fv2 = more ? g.ref_first_var[r + 1] : 0u;
+  uint32_t const n2 = more ? g.ref_len[r + 2] : 0u, o2 = more ? g.ref_order[r + 2] : 0u;
+  uint32_t const common = hint_mm_linear(row, ix.refp, pre, idx + pre, at);
+  bool kill = false, tie = false, odd = false;
+  auto candidate = [&](uint32_t mm, uint32_t end, uint32_t k1, uint32_t k2)
+  {
+    if (mm > budget)
+      return;
+    if (mm < w.got)
+    {
+      w.got = mm;
+      w.end = end;
+      w.mask1 = k1;
+      w.mask2 = k2;
+      tie = false;
+      return;
+    }
+    if (mm == w.got)
+    {
+      tie = tie || end != w.end || (k2 == 0) != (w.mask2 == 0);
+      w.mask1 |= k1;
+      w.mask2 |= k2;
+    }
+  };
+  for (uint32_t a = 0; a < 4; ++a)
+    if (a < nv1)
+    {
+      uint32_t const vl = g.var_len[fv1 + a], vo = g.var_dna[fv1 + a];
+      if (vl == 0)
+        return w;
+      uint32_t mm = common + hint_mm_allele(g, row, pre + at, vo, vl < rest ? vl : rest, kill);
+      if (rest <= vl)
+      {
+        candidate(mm, g_special_of(g, r, g.var_order[fv1 + a] + rest - 1u), 1u << a, 0u);
+        continue;
+      }
+      uint32_t const rem = rest - vl;
+      mm += hint_mm_linear(row, ix.refp, pre + at + vl, o1 - g.first_order, rem < n1 ? rem : n1);
+      if (rem <= n1)
+      {
+        candidate(mm, o1 + rem - 1u, 1u << a, 0u);
+        continue;
+      }
+      if (mm > budget) // (the reference drops the candidate here: count_mismatches against the budget, graph.cpp:1268)
+        continue;
+      if (nv2 < 2 || nv2 > 4)
+      {
+        odd = true;
+        continue;
+      }
+      uint32_t const rest2 = rem - n1, ro2 = pre + at + vl + n1;
+      for (uint32_t b = 0; b < 4; ++b)
+        if (b < nv2)
+        {
+          uint32_t const vl2 = g.var_len[fv2 + b];
+          if (vl2 == 0)
+          {
+            odd = true;
+            continue;
+          }
+          uint32_t mm2 = mm + hint_mm_allele(g, row, ro2, g.var_dna[fv2 + b], vl2 < rest2 ? vl2 : rest2, kill);
+          if (rest2 <= vl2)
+          {
+            candidate(mm2, g_special_of(g, r + 1, g.var_order[fv2 + b] + rest2 - 1u), 1u << a, 1u << b);
+            continue;
+          }
+          uint32_t const rem2 = rest2 - vl2;
+          if (rem2 > n2) // a third site
+          {
+            odd = odd || mm2 <= budget;
+            continue;
+          }
+          mm2 += hint_mm_linear(row, ix.refp, ro2 + vl2, o2 - g.first_order, rem2);
+          candidate(mm2, o2 + rem2 - 1u, 1u << a, 1u << b);
+        }
+    }
+  if (odd || kill)
+    return w;
+  w.status = tie ? 2u : 1u;
+  return w;
+}
+
 // The forward task of one read.  Returns true when the record was written, false = declined (nothing written).
 // `row`: the read in plane form as words (global memory, or the copy the kernel staged in LDS).
 // `stage` (may be NULL): room for HINT_STAGE_WORDS words; a record that fits is written there instead (zeros behind its
@@ -551,7 +722,9 @@ GTX_DEV uint32_t hint_probe_verdict(uint32_t verdict, uint32_t left_word, uint32
 constexpr uint32_t HINT_STAGE_WORDS = 16; // a record of up to three variant sites (6 + 3 * 3 words)
 constexpr uint32_t HINT_TO_GENERAL = 3;
 
-template <class Row>
+// DENSE: the build for graphs whose sites lie close together (k-mers over two sites, ...): more registers, the same
+// records where both builds finish a read.
+template <bool DENSE, class Row>
 GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, uint32_t seq_stride, gtx_read_meta const & m,
                             uint32_t * rec, uint32_t rec_words, uint32_t * stage = nullptr)
 {
@@ -583,10 +756,10 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   // ---- every k-mer: the label of its place, no label at all, or not provable
   uint32_t const none = hk_make(HINT_K_HOLE, HINT_NO_SITE, 0u, false, false);
   uint32_t amb2 = 0; // k-mers with one ambiguous base in each half: three more filter probes (below)
-  uint32_t k0 = hint_kmer<0>(f0, row, h, amb2), k1 = hint_kmer<1>(f1, row, h, amb2);
-  uint32_t k2 = n_k > 2 ? hint_kmer<2>(f2, row, h, amb2) : none;
-  uint32_t k3 = n_k > 3 ? hint_kmer<3>(f3, row, h, amb2) : none;
-  uint32_t k4 = n_k > 4 ? hint_kmer<4>(f4, row, h, amb2) : none;
+  uint32_t k0 = hint_kmer<0, DENSE>(f0, row, h, amb2), k1 = hint_kmer<1, DENSE>(f1, row, h, amb2);
+  uint32_t k2 = n_k > 2 ? hint_kmer<2, DENSE>(f2, row, h, amb2) : none;
+  uint32_t k3 = n_k > 3 ? hint_kmer<3, DENSE>(f3, row, h, amb2) : none;
+  uint32_t k4 = n_k > 4 ? hint_kmer<4, DENSE>(f4, row, h, amb2) : none;
   if ((k0 & 3u) == HINT_K_DECLINE || (k1 & 3u) == HINT_K_DECLINE || (k2 & 3u) == HINT_K_DECLINE || (k3 & 3u) == HINT_K_DECLINE ||
       (k4 & 3u) == HINT_K_DECLINE)
     return false;
@@ -808,7 +981,15 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   // the single allele k-mer `km` carries on `site` (4: it is another site, or a set of several)
   auto carried = [&](uint32_t km, uint32_t site) -> uint32_t
   {
-    uint32_t const set = (km >> HK_SET_SHIFT) & 255u;
+    uint32_t set = (km >> HK_SET_SHIFT) & 255u;
+    if (DENSE && hk_is_two(km))
+    {
+      uint32_t const s0 = km >> HK_SITE_SHIFT;
+      if (site != s0 && site != s0 + 1u)
+        return 4u;
+      set = site == s0 ? (set & 15u) : (set >> 4);
+      return (set & (set - 1u)) != 0 ? 4u : static_cast<uint32_t>(__builtin_ctz(set));
+    }
     if ((km >> HK_SITE_SHIFT) != site || (set & (set - 1u)) != 0)
       return 4u;
     return set ? static_cast<uint32_t>(__builtin_ctz(set)) : (km >> HK_ALLELE_SHIFT) & 3u;
@@ -859,6 +1040,7 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   }
   uint32_t end = g.first_order + idx + pre, re = pre;
   uint32_t tail_site = 0, tail_mask = 0; // the site the walk at the read's end crossed, with its best alleles
+  uint32_t tail_mask2 = 0;               // ... and (dense build) those of the site behind it, when the walk crossed that as well
   if (decided) // (two runs of one length, inside one reference node: worked out above)
   {
     start = g.first_order + idx + two_rs;
@@ -870,6 +1052,8 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   else if (pre != L - 1) // walk_read_ends (genotype_paths.cpp:483-553)
   {
     uint32_t const tail_len = L - pre;
+    uint32_t const budget = 2 + tail_len / 11 < 7 ? 2 + tail_len / 11 : 7; // genotype_paths.cpp:505-511
+    uint32_t tail_end = end + tail_len - 1; // (inside one reference node, or over SNP-like sites: the linear reference's position)
     uint32_t const y = hi + 1 == n_k ? y_end : hi == 0 ? f1.y : hi == 1 ? f2.y : hi == 2 ? f3.y : f4.y;
     uint32_t const room = y & 255u;
     uint32_t got = hc_all(h) - hc_upto(h, hi + 1);
@@ -895,24 +1079,52 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
       uint32_t const next_len = (ti.x >> HINT_TAIL_NEXT_SHIFT) & 255u;
       if (!ok || (ti.x & HINT_TAIL_OK) == 0 || next_len < tail_len - at - 1)
       {
-        GTX_HINT_NOTE(8);
-        return false; // (an indel, a second site, a set of alleles: express4 / general pass)
+        // (an indel, a second site, a set of alleles.  The dense build walks over up to two sites with alleles of any length
+        //  itself; what it cannot decide there -- best candidates with different ends: several paths -- the express pass
+        //  cannot either.  Lean build: express4 / general pass)
+        bool walked = false;
+        if constexpr (DENSE)
+          if (!on_site && (ti.x & HINT_TAIL_NODE) != 0 && tail_len <= 64)
+          {
+            HintWalk const w = hint_tail_walk(g, ix, row, idx, pre, tail_len, at, ti.y, budget);
+            if (w.status == 2)
+            {
+              GTX_HINT_NOTE(8);
+              return HINT_TO_GENERAL;
+            }
+            if (w.status == 1)
+            {
+              walked = true;
+              got = w.got; // (INVALID: no candidate within the budget -- the path stays as it is)
+              tail_end = w.end;
+              tail_site = ti.y;
+              tail_mask = w.mask1;
+              tail_mask2 = w.mask2;
+            }
+          }
+        if (!walked)
+        {
+          GTX_HINT_NOTE(8);
+          return false;
+        }
       }
-      uint32_t mask = 0, x0 = 0;
-      uint32_t const best = site_choice(ti.x, plane_code_at(row, pre + at), only, mask, x0);
-      got = got - x0 + best;
-      tail_site = ti.y;
-      tail_mask = mask;
+      else
+      {
+        uint32_t mask = 0, x0 = 0;
+        uint32_t const best = site_choice(ti.x, plane_code_at(row, pre + at), only, mask, x0);
+        got = got - x0 + best;
+        tail_site = ti.y;
+        tail_mask = mask;
+      }
     }
-    uint32_t const budget = 2 + tail_len / 11 < 7 ? 2 + tail_len / 11 : 7; // genotype_paths.cpp:505-511
     if (got <= budget)
     {
       re = L - 1;
       mism += got;
-      end += tail_len - 1;
+      end = tail_end;
     }
     else
-      tail_mask = 0; // (the path stays as it is: no site from the walk)
+      tail_mask = tail_mask2 = 0; // (the path stays as it is: no site from the walk)
   }
   // ---- variant sites of the path, most recent k-mer first (Path(p1, p2), path.cpp:38-82); a site under two
   //      neighbouring k-mers is one entry (the same base, hence the same allele)
@@ -922,7 +1134,38 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   bool clash = false;
   auto append = [&](uint32_t entry)
   {
-    if ((entry >> 16) == (last >> 16))
+    if constexpr (DENSE)
+    {
+      // (a k-mer may bring two sites: the list is not in the sites' order any more -- Path(p1, p2) looks a site of p1 up among
+      //  all of p2's, path.cpp:38-82)
+      bool found = false;
+      auto meet = [&](uint32_t & v, uint32_t at)
+      {
+        if (at < nvar && (v >> 16) == (entry >> 16))
+        {
+          v &= entry | 0xFFFF0000u;
+          clash = clash || (v & 0xFFFFu) == 0;
+          found = true;
+        }
+      };
+      meet(v0, 0);
+      meet(v1, 1);
+      meet(v2, 2);
+      meet(v3, 3);
+      meet(v4, 4);
+      meet(v5, 5);
+      if (!found)
+      {
+        v0 = nvar == 0 ? entry : v0;
+        v1 = nvar == 1 ? entry : v1;
+        v2 = nvar == 2 ? entry : v2;
+        v3 = nvar == 3 ? entry : v3;
+        v4 = nvar == 4 ? entry : v4;
+        v5 = nvar == 5 ? entry : v5;
+        ++nvar;
+      }
+    }
+    else if ((entry >> 16) == (last >> 16))
     {
       // the site again (under the neighbouring k-mer, or the walk's): the allele sets are intersected (path.cpp:38-82)
       last &= entry | 0xFFFF0000u;
@@ -951,11 +1194,19 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
     if (((run >> k) & 1u) && (km >> HK_SITE_SHIFT) != HINT_NO_SITE)
     {
       uint32_t const set = (km >> HK_SET_SHIFT) & 255u;
-      append(((km >> HK_SITE_SHIFT) << 16) | (set ? set : 1u << ((km >> HK_ALLELE_SHIFT) & 3u)));
+      if (DENSE && hk_is_two(km))
+      {
+        append(((km >> HK_SITE_SHIFT) << 16) | (set & 15u));
+        append((((km >> HK_SITE_SHIFT) + 1u) << 16) | (set >> 4));
+      }
+      else
+        append(((km >> HK_SITE_SHIFT) << 16) | (set ? set : 1u << ((km >> HK_ALLELE_SHIFT) & 3u)));
     }
   };
   if (tail_mask != 0) // (the walk's labels are merged last: their site comes first)
     append((tail_site << 16) | tail_mask);
+  if (tail_mask2 != 0)
+    append(((tail_site + 1u) << 16) | tail_mask2);
   push(4, k4);
   push(3, k3);
   push(2, k2);

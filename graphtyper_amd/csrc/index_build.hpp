@@ -134,6 +134,37 @@ GTX_HD uint32_t hint_own_labels(HintKeys const & t, uint32_t k, uint32_t order, 
   return mask;
 }
 
+// ... or on two neighbouring sites s < s + 1 (HINT_TWO): the sets of their alleles in bits 0..3 / 4..7 (0 = not of that form)
+GTX_HD uint32_t hint_own_labels_two(HintKeys const & t, uint32_t k, uint32_t order, uint32_t & site)
+{
+  uint32_t const n = t.key_off[k + 1] - t.key_off[k];
+  if (n < 2 || n > HINT_OWN_MAX)
+    return 0;
+  uint32_t lo = 0, hi = 0;
+  site = t.labels[t.key_off[k]].site;
+  if (site == INVALID)
+    return 0;
+  for (uint32_t i = t.key_off[k]; i < t.key_off[k + 1]; ++i)
+  {
+    DevLabel const l = t.labels[i];
+    if (l.start != order || l.end != order + K - 1 || l.site == INVALID || (l.site != site && l.site != site + 1) || l.allele >= 4u)
+      return 0;
+    if (l.site == site)
+      lo |= 1u << l.allele;
+    else
+      hi |= 1u << l.allele;
+  }
+  return hi == 0 ? 0u : lo | (hi << 4);
+}
+
+// express4's rule for the neighbours of an exact hit over several sites: every neighbour label is the k-mer's own interval
+// on one of its own sites (hint_judge_key: `known`, bit 1 of nb_same)
+GTX_HD bool hint_neighbours_known(HintKeys const & t, uint32_t const * nb, uint8_t const * nb_same, uint32_t k, bool & par)
+{
+  par = nb[k] != 0;
+  return t.lsize[k] <= HINT_HE_CAP && t.rsize[k] <= HINT_HE_CAP && (nb[k] == 0 || ((nb_same[k] & 2u) && nb[k] <= HINT_NB_MAX));
+}
+
 // ... and with one label: it has to be (order, order + 31, site, allele)
 GTX_HD bool hint_exact_verdict(HintKeys const & t, uint32_t const * nb, uint8_t const * nb_same, uint32_t k, uint32_t order, uint32_t want_site,
                                 uint32_t want_allele, bool & par)
@@ -173,6 +204,29 @@ GTX_HD uint2_t hint_position_flags(GraphView const & g, HintKeys const & t, uint
   }
   uint32_t k = 0;
   bool const found = valid && hint_find_key(t, key, k);
+  if (found)
+  {
+    // how far the other keys with K's halves are from K (HINT_FAR_*)
+    for (uint32_t side = 0; side < 2; ++side)
+    {
+      uint32_t const n_group = side == 0 ? t.lsize[k] : t.rsize[k];
+      uint32_t dmin = 64;
+      if (n_group > 64)
+        dmin = 0;
+      else
+        for (uint32_t i = 0; i < n_group; ++i)
+        {
+          uint32_t const b = side == 0 ? t.lbegin[k] + i : t.rorder[t.rbegin[k] + i];
+          if (b == k)
+            continue;
+          uint64_t const d = t.keys[k] ^ t.keys[b];
+          uint32_t const n_differ = static_cast<uint32_t>(__builtin_popcountll((d | (d >> 1)) & 0x5555555555555555ull));
+          dmin = n_differ < dmin ? n_differ : dmin;
+        }
+      uint32_t const code = dmin >= 8 ? 3u : dmin >= 4 ? 2u : dmin >= 3 ? 1u : 0u;
+      y |= code << (side == 0 ? HINT_FAR_LEFT_SHIFT : HINT_FAR_RIGHT_SHIFT);
+    }
+  }
   if (found && t.key_off[k + 1] - t.key_off[k] > 1 && !g.is_sv_graph)
   {
     // the k-mer lies over a merged site and several of its alleles spell it
@@ -183,6 +237,16 @@ GTX_HD uint2_t hint_position_flags(GraphView const & g, HintKeys const & t, uint
     {
       site = msite;
       x |= HINT_EXACT_OK | HINT_MULTI | (par ? HINT_PAR : 0u) | (mask << HINT_ALTIDX_SHIFT);
+    }
+    else if (mask == 0)
+    {
+      // ... or the k-mer lies over two neighbouring sites
+      uint32_t const two = hint_own_labels_two(t, k, g.first_order + p, msite);
+      if (two != 0 && msite + 1 < HINT_NO_SITE && hint_neighbours_known(t, nb, nb_same, k, par))
+      {
+        site = msite;
+        x |= HINT_EXACT_OK | HINT_TWO | (par ? HINT_PAR : 0u) | (two << HINT_ALTIDX_SHIFT);
+      }
     }
   }
   if (found && t.key_off[k + 1] - t.key_off[k] == 1)

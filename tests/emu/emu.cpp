@@ -239,6 +239,9 @@ extern "C"
     bool const four = !(e4 && e4[0] == '0');
     // lean / wide build of pass 1: forced by GTX_EXPRESS4=lean|wide, else by the graph's density (as gtx_align_batch does)
     bool const wide = e4 && e4[0] == 'w' ? true : e4 && e4[0] == 'l' ? false : express4_prefers_wide(e.graph, e.index);
+    // ... and of pass 0 (GTX_HINT_BUILD=lean|dense; default: the dense build on the graphs that get the wide express pass)
+    char const * hb = std::getenv("GTX_HINT_BUILD");
+    bool const hint_dense = hb && hb[0] == 'd' ? true : hb && hb[0] == 'l' ? false : express4_prefers_wide(e.graph, e.index);
     auto e4_ws = std::make_unique<Express4Workspace<Express4Lean>>();
     auto e4_wide_ws = std::make_unique<Express4Workspace<Express4Wide>>();
     bool has_wide_sites = false;
@@ -398,10 +401,11 @@ extern "C"
           empty_record(read * 2, len);
         else
         {
-          uint32_t const where = (force != 0 || (eh && eh[0] == 'd'))
-                                   ? 0u
-                                   : hinted_one(g, ix, reinterpret_cast<uint32_t const *>(seq + static_cast<uint64_t>(read) * seq_stride), seq_stride, m,
-                                                records + static_cast<uint64_t>(read) * 2 * rec_words, rec_words);
+          uint32_t const * row = reinterpret_cast<uint32_t const *>(seq + static_cast<uint64_t>(read) * seq_stride);
+          uint32_t * slot = records + static_cast<uint64_t>(read) * 2 * rec_words;
+          uint32_t const where = (force != 0 || (eh && eh[0] == 'd')) ? 0u
+                                 : hint_dense                          ? hinted_one<true>(g, ix, row, seq_stride, m, slot, rec_words)
+                                                                       : hinted_one<false>(g, ix, row, seq_stride, m, slot, rec_words);
           if (where == 0)
           {
             queue1.push_back(read);

@@ -46,6 +46,7 @@ def align_seed(seed):
         reads = [c[:int(n)] for c, n in zip(codes, rng.integers(max(50, read_len - 60), read_len + 1, size=len(codes)))]
         for mode in ["lean", "wide"]:
             os.environ["GTX_EXPRESS4"] = mode
+            os.environ["GTX_HINT_BUILD"] = "dense" if mode == "wide" else "lean"  # (both builds of pass 0 on every graph shape)
             try:
                 # position hints: right for most reads, a few bases off or absent for the others; check_align also runs
                 # the batch without hints, with shifted hints and with other reads' hints (records must not depend on them)
