@@ -185,6 +185,21 @@ GTX_DEV uint32_t g_special_of(GraphView const & g, uint32_t site, uint32_t pos)
   return pos > rr ? SPECIAL_START + g.site_special_base[site] + (pos - rr - 1) : pos;
 }
 
+// graph order of position `local` of a window: the linear reference in front of the site, the allele (special positions
+// beyond the reference allele's reach, graph.cpp:1775-1782), the linear reference behind the site's reference allele
+GTX_HDI uint32_t hint_win_order(GraphView const & g, HintWindow const & w, uint32_t local)
+{
+  if (local < HINT_WIN_BEFORE)
+    return w.site_order - (HINT_WIN_BEFORE - local);
+  uint32_t const k = local - HINT_WIN_BEFORE;
+  if (k < w.len_a)
+  {
+    uint32_t const pos = w.site_order + k, rr = g.site_ref_reach[w.site];
+    return pos > rr ? SPECIAL_START + g.site_special_base[w.site] + (pos - rr - 1) : pos;
+  }
+  return w.site_order + w.len_0 + (k - w.len_a);
+}
+
 GTX_DEV uint32_t site_order(GraphView const & g, uint32_t site)
 {
   return g.ref_order[site] + g.ref_len[site]; // order of the site's variant nodes

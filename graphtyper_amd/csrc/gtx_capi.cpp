@@ -263,7 +263,7 @@ extern "C"
 
   int gtx_ctx_hint_table(const gtx_ctx * c, int which, void * out, uint64_t cap_bytes, uint64_t * bytes)
   {
-    if (!c || !bytes || which < 0 || which > 4)
+    if (!c || !bytes || which < 0 || which > 6)
       return GTX_ERR_ARG;
     if (c->device >= 0)
       return download_hint_table(*c, which, out, cap_bytes, bytes);
@@ -275,7 +275,10 @@ extern "C"
     case 0: src = ix.pos_flags.data(); n = ix.pos_flags.size() * sizeof(uint2_t); break;
     case 1: src = ix.refp.data(); n = ix.refp.size() * sizeof(uint32_t); break;
     case 2: src = ix.tail_info.data(); n = ix.tail_info.size() * sizeof(uint2_t); break;
-    default: src = ix.filt[which - 3].data(); n = ix.filt[which - 3].size() * sizeof(uint32_t); break;
+    case 3:
+    case 4: src = ix.filt[which - 3].data(); n = ix.filt[which - 3].size() * sizeof(uint32_t); break;
+    case 5: src = ix.win.data(); n = ix.win.size() * sizeof(HintWindow); break;
+    default: src = ix.site_win.data(); n = ix.win.empty() ? 0 : ix.site_win.size() * sizeof(uint32_t); break;
     }
     *bytes = n;
     if (!out)

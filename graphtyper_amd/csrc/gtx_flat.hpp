@@ -102,6 +102,13 @@ struct alignas(16) HalfEntry
   uint32_t off, cnt; // its labels
 };
 
+constexpr uint32_t HINT_WIN_BEFORE = 160, HINT_WIN_ALLELE_MAX = 64, HINT_WIN_STRIDE = 384; // (160 + 64 + 160: twelve plane groups)
+struct HintWindow
+{
+  uint32_t site, allele, len_a /* bases of the allele */, len_0 /* ... of the site's reference allele */;
+  uint32_t site_order /* order of the site's variant nodes */, pad[3];
+};
+
 struct IndexView
 {
   const IndexSlot * slots;
@@ -149,7 +156,33 @@ struct IndexView
   const uint2_t * tail_info;
   const uint32_t * filt[2];
   uint32_t hint_first, n_hint, filt_log2 /* log2 of the number of words */, pad_hint;
+  // ---- allele windows (dense build of the pass).  A read that carries another allele than the reference's at a site does not
+  // lie on the linear reference; for the alternative alleles of the sites where that matters (HintWindow) the three tables
+  // above continue, behind position win_base, with one window of HINT_WIN_STRIDE positions per (site, allele): the
+  // HINT_WIN_BEFORE positions of the linear reference in front of the site, the allele's bases, the linear reference behind the
+  // site's reference allele.  A window position's entries mean what a position's of the linear reference mean, with the
+  // window's path in place of the linear reference (labels at hint_win_order()).  site_win[r]: first window of the site behind
+  // reference node r | number of its windows << 24 (alleles ascending).
+  const HintWindow * win;
+  const uint32_t * site_win;
+  uint32_t win_base, n_win, pad_win[2];
 };
+
+// positions the three per-position tables hold: the linear reference, padding up to win_base, the windows, padding
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t hint_win_base(uint32_t n_hint)
+{
+  return (n_hint / 64u + 5u) * 64u; // (whole plane groups, at least 8 of them behind the linear reference as before)
+}
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint64_t hint_total_positions(uint32_t n_hint, uint32_t n_win)
+{
+  return n_win == 0 ? n_hint : static_cast<uint64_t>(hint_win_base(n_hint)) + static_cast<uint64_t>(n_win) * HINT_WIN_STRIDE + 256u;
+}
 
 constexpr uint32_t HINT_EXACT_OK = 1u, HINT_SINGLE_OK = 2u, HINT_L1 = 4u, HINT_R1 = 8u, HINT_PAR = 16u, HINT_ALT_OK = 32u;
 constexpr uint32_t HINT_MULTI = 64u; // K_i has several labels, all (i, i+31) on one site: bits 8..15 of x are the set of their alleles
@@ -251,6 +284,9 @@ struct HostIndex
   std::vector<uint32_t> refp, filt[2];
   std::vector<uint2_t> pos_flags, tail_info;
   uint32_t hint_first = 0, n_hint = 0, filt_log2 = 0;
+  std::vector<HintWindow> win;
+  std::vector<uint32_t> site_win;
+  uint32_t win_base = 0;
 
   IndexView view(uint32_t max_index_labels, uint32_t half_bucket_cap) const; // over the host copies
 };
@@ -284,6 +320,7 @@ struct EmitRun
 void enumerate_kmers(HostGraph const & g, std::vector<Emit> & out);                 // index_graph's sweep (host threads)
 void enumerate_kmers(HostGraph const & g, std::vector<Emit> & out, std::vector<EmitRun> * runs); // ... with the in-node runs left out
 void hint_graph_tables(HostGraph const & g, HintGraphTables & out);
+void hint_list_windows(HostGraph const & g, std::vector<HintWindow> & win, std::vector<uint32_t> & site_win);
 void build_tables_host(HostGraph const & g, std::vector<Emit> const & em, HostIndex & out); // grouping, hash tables, hint tables
 void build_index(HostGraph const & g, HostIndex & out);                             // both of the above
 

@@ -609,6 +609,10 @@ IndexView HostIndex::view(uint32_t max_index_labels, uint32_t half_bucket_cap) c
   ix.hint_first = hint_first;
   ix.n_hint = n_hint;
   ix.filt_log2 = filt_log2;
+  ix.win = win.data();
+  ix.site_win = site_win.data();
+  ix.win_base = win_base;
+  ix.n_win = static_cast<uint32_t>(win.size());
   return ix;
 }
 
@@ -672,6 +676,34 @@ void hint_graph_tables(HostGraph const & g, HintGraphTables & t)
       t.refp[4 * (i >> 5) + b] |= ((static_cast<uint32_t>(t.base[i]) >> b) & 1u) << (i & 31u);
 }
 
+// the allele windows of a graph (IndexView::win): one per alternative allele of the sites hint_site_wants_windows() names, in
+// site and allele order, as many as `cap` admits (GTX_HINT_WINDOWS, default 16 384: 6.3 M table positions)
+void hint_list_windows(HostGraph const & g, std::vector<HintWindow> & win, std::vector<uint32_t> & site_win)
+{
+  win.clear();
+  site_win.assign(g.ref_order.size(), 0u);
+  char const * e = std::getenv("GTX_HINT_WINDOWS");
+  uint64_t const cap = e ? static_cast<uint64_t>(std::max(0l, std::atol(e))) : 16384u;
+  GraphView const gv = g.view();
+  uint32_t const R = static_cast<uint32_t>(g.ref_order.size());
+  if (R == 0 || R - 1 >= HINT_NO_SITE)
+    return;
+  for (uint32_t r = 0; r + 1 < R; ++r)
+  {
+    if (!hint_site_wants_windows(gv, r))
+      continue;
+    uint32_t const first = static_cast<uint32_t>(win.size());
+    uint32_t count = 0;
+    for (uint32_t a = 1; a < g.ref_nvar[r]; ++a)
+      if (hint_allele_gets_window(gv, r, a) && win.size() < cap)
+      {
+        win.push_back(HintWindow{r, a, g.var_len[g.ref_first_var[r] + a], g.var_len[g.ref_first_var[r]], g.ref_order[r] + g.ref_len[r], {0, 0, 0}});
+        ++count;
+      }
+    site_win[r] = count ? first | (count << 24) : 0u;
+  }
+}
+
 // Tables of the position-hinted pass (IndexView::refp ..., hinted.hpp).  For every reference position: what a read
 // k-mer that equals -- or is one substitution / one ambiguous base away from -- the reference 32-mer of that place
 // would get from the global lookups, decided here once from the finished index.
@@ -692,6 +724,40 @@ static void build_hints(HostGraph const & g, HostIndex & out)
     return;
   }
   uint32_t const n = gt.n;
+  // the allele windows continue the per-position arrays behind win_base
+  hint_list_windows(g, out.win, out.site_win);
+  uint32_t const n_win = static_cast<uint32_t>(out.win.size());
+  out.win_base = hint_win_base(n);
+  uint64_t const total = hint_total_positions(n, n_win);
+  GraphView const gv0 = g.view();
+  if (n_win)
+  {
+    std::vector<uint8_t> mbase = gt.base, mroom = gt.room, mback = gt.back;
+    std::vector<uint2_t> mtail = gt.tail_info;
+    gt.base.assign(total, 15);
+    gt.room.assign(total, 0);
+    gt.back.assign(total, 0);
+    gt.tail_info.assign(total, uint2_t{0, 0});
+    std::copy(mbase.begin(), mbase.end(), gt.base.begin());
+    std::copy(mroom.begin(), mroom.end(), gt.room.begin());
+    std::copy(mback.begin(), mback.end(), gt.back.begin());
+    std::copy(mtail.begin(), mtail.end(), gt.tail_info.begin());
+    parallel_slices(n_win, host_threads(), [&](unsigned, std::size_t b, std::size_t e) {
+      for (std::size_t w = b; w < e; ++w)
+        for (uint32_t local = 0; local < HINT_WIN_STRIDE; ++local)
+        {
+          std::size_t const p = out.win_base + w * HINT_WIN_STRIDE + local;
+          hint_window_cell(gv0, out.win[w], local, mbase.data(), mroom.data(), mback.data(), mtail.data(), n, gt.base[p], gt.room[p], gt.back[p], gt.tail_info[p]);
+        }
+    });
+    // (planes: the linear reference as before, nothing up to win_base, every window position its base -- 15 where it has none)
+    gt.refp.assign(4 * (total / 32 + 8), 0);
+    uint64_t const win_end = out.win_base + static_cast<uint64_t>(n_win) * HINT_WIN_STRIDE;
+    for (uint64_t i = 0; i < win_end; ++i)
+      if (i < n || i >= out.win_base)
+        for (uint32_t b = 0; b < 4; ++b)
+          gt.refp[4 * (i >> 5) + b] |= ((static_cast<uint32_t>(gt.base[i]) >> b) & 1u) << (i & 31u);
+  }
   std::vector<uint8_t> const & base = gt.base;
   std::vector<uint8_t> const & room = gt.room;
   std::vector<uint8_t> const & back = gt.back;
@@ -784,10 +850,19 @@ static void build_hints(HostGraph const & g, HostIndex & out)
     }
   // per position
   GraphView const gv = g.view();
-  out.pos_flags.assign(n, uint2_t{HINT_NO_SITE << HINT_SITE_SHIFT, 0});
+  out.pos_flags.assign(total, uint2_t{0, 0}); // (every position of the linear reference and of the windows is written below; the padding stays 0)
   parallel_slices(n, host_threads(), [&](unsigned, std::size_t b, std::size_t e) {
     for (std::size_t p = b; p < e; ++p)
       out.pos_flags[p] = hint_position_flags(gv, t, nb.data(), nb_same.data(), base.data(), room.data(), back.data(), n, static_cast<uint32_t>(p));
+  });
+  parallel_slices(n_win, host_threads(), [&](unsigned, std::size_t b, std::size_t e) {
+    for (std::size_t w = b; w < e; ++w)
+      for (uint32_t local = 0; local < HINT_WIN_STRIDE; ++local)
+      {
+        uint32_t const p = out.win_base + static_cast<uint32_t>(w) * HINT_WIN_STRIDE + local;
+        out.pos_flags[p] = hint_window_flags(gv, t, nb.data(), nb_same.data(), base.data(), room.data(), back.data(), static_cast<uint32_t>(total),
+                                             out.pos_flags.data(), n, out.win[w], local, p);
+      }
   });
 }
 

@@ -451,6 +451,46 @@ __global__ void k_hint_graph(GraphView g, uint32_t n, uint8_t * __restrict__ bas
   }
 }
 
+// ---- the allele windows behind the linear reference (IndexView::win; index_build.hpp): a thread per window position.  The
+// windows start at a multiple of 64 positions and are a multiple of 64 long: a wavefront's positions are two plane groups.
+__global__ void k_window_cells(GraphView g, HintWindow const * __restrict__ win, uint32_t n_win, uint32_t win_base, uint32_t n_main, uint8_t * base,
+                               uint8_t * room, uint8_t * back, uint2_t * tail, uint32_t * __restrict__ refp)
+{
+  uint32_t const t = blockIdx.x * blockDim.x + threadIdx.x, w = t / HINT_WIN_STRIDE, local = t % HINT_WIN_STRIDE;
+  uint32_t b = 0;
+  uint32_t const p = win_base + t;
+  if (w < n_win)
+  {
+    uint8_t c = 15, rm = 0, bk = 0;
+    uint2_t ti{0, 0};
+    hint_window_cell(g, win[w], local, base, room, back, tail, n_main, c, rm, bk, ti);
+    base[p] = c;
+    room[p] = rm;
+    back[p] = bk;
+    tail[p] = ti;
+    b = c;
+  }
+#pragma unroll
+  for (uint32_t bit = 0; bit < 4; ++bit)
+  {
+    unsigned long long const m = __ballot((b >> bit) & 1u);
+    if ((threadIdx.x & 63u) == 0 && w < n_win)
+    {
+      refp[4 * (p >> 5) + bit] = static_cast<uint32_t>(m);
+      refp[4 * ((p >> 5) + 1) + bit] = static_cast<uint32_t>(m >> 32);
+    }
+  }
+}
+
+__global__ void k_window_flags(GraphView g, HintKeys t, uint32_t const * nb, uint8_t const * nb_same, uint8_t const * base, uint8_t const * room,
+                               uint8_t const * back, uint32_t n_total, uint32_t n_main, HintWindow const * __restrict__ win, uint32_t n_win, uint32_t win_base,
+                               uint2_t * flags)
+{
+  uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x, w = i / HINT_WIN_STRIDE, local = i % HINT_WIN_STRIDE;
+  if (w < n_win)
+    flags[win_base + i] = hint_window_flags(g, t, nb, nb_same, base, room, back, n_total, flags, n_main, win[w], local, win_base + i);
+}
+
 template <class T>
 bool to_device(Pool & pool, T *& d, std::vector<T> const & h, char const * what)
 {
@@ -656,16 +696,27 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<Em
   uint32_t const hint_n = (R == 0 || R - 1 >= HINT_NO_SITE) ? 0u : c.graph.ref_order[R - 1] + c.graph.ref_len[R - 1] - c.graph.ref_order[0];
   bool const hints = hint_n != 0;
   uint32_t *d_f0 = pool.get<uint32_t>(hints ? (1ull << fl) : 1, "filter 0", true), *d_f1 = pool.get<uint32_t>(hints ? (1ull << fl) : 1, "filter 1", true);
-  uint2_t * d_flags = pool.get<uint2_t>(hints ? hint_n : 1, "position flags", true);
+  // (the allele windows continue the per-position tables behind win_base: gtx_flat.hpp)
+  std::vector<HintWindow> win;
+  std::vector<uint32_t> site_win;
+  if (hints)
+    hint_list_windows(c.graph, win, site_win);
+  uint32_t const n_win = static_cast<uint32_t>(win.size()), win_base = hint_win_base(hint_n);
+  uint64_t const hint_total = hint_total_positions(hint_n, n_win);
+  uint2_t * d_flags = pool.get<uint2_t>(hints ? hint_total : 1, "position flags", true);
   // (padded: the kernel loads 6 plane groups from any position without a bounds test)
-  uint32_t * d_refp = pool.get<uint32_t>(hints ? 4 * (static_cast<size_t>(hint_n) / 32 + 8) : 32, "reference planes", true);
-  uint2_t * d_tail = pool.get<uint2_t>(hints ? hint_n : 1, "tail sites", !hints);
+  uint32_t * d_refp = pool.get<uint32_t>(hints ? 4 * (static_cast<size_t>(hint_total) / 32 + 8) : 32, "reference planes", true);
+  uint2_t * d_tail = pool.get<uint2_t>(hints ? hint_total : 1, "tail sites", !hints || n_win != 0);
+  HintWindow * d_win = nullptr;
+  uint32_t * d_site_win = nullptr;
+  if (n_win && (!to_device(pool, d_win, win, "allele windows") || !to_device(pool, d_site_win, site_win, "windows of the sites")))
+    return GTX_ERR_HIP;
   if (!pool.fine)
     return GTX_ERR_HIP;
   if (hints)
   {
-    uint8_t *d_base = pool.get<uint8_t>(hint_n, "reference bases"), *d_room = pool.get<uint8_t>(hint_n, "node room"),
-            *d_back = pool.get<uint8_t>(hint_n, "node back");
+    uint8_t *d_base = pool.get<uint8_t>(hint_total, "reference bases", n_win != 0), *d_room = pool.get<uint8_t>(hint_total, "node room", n_win != 0),
+            *d_back = pool.get<uint8_t>(hint_total, "node back", n_win != 0);
     uint32_t * d_nb = pool.get<uint32_t>(n_keys, "neighbour labels");
     uint8_t * d_same = pool.get<uint8_t>(n_keys, "neighbour verdicts");
     if (!pool.fine)
@@ -679,6 +730,14 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<Em
                          (nbk && nbk[0] == '0') ? static_cast<IndexSlot *>(nullptr) : d_slots, log2_cap);
     }
     hipLaunchKernelGGL(k_position_flags, dim3(blocks_for(hint_n)), dim3(TB), 0, nullptr, c.dev_graph, t, d_nb, d_same, d_base, d_room, d_back, hint_n, d_flags);
+    if (n_win)
+    {
+      uint32_t const cells = n_win * HINT_WIN_STRIDE;
+      hipLaunchKernelGGL(k_window_cells, dim3((cells + TB - 1) / TB), dim3(TB), 0, nullptr, c.dev_graph, d_win, n_win, win_base, hint_n, d_base, d_room, d_back,
+                         d_tail, d_refp);
+      hipLaunchKernelGGL(k_window_flags, dim3((cells + TB - 1) / TB), dim3(TB), 0, nullptr, c.dev_graph, t, d_nb, d_same, d_base, d_room, d_back,
+                         static_cast<uint32_t>(hint_total), hint_n, d_win, n_win, win_base, d_flags);
+    }
   }
   uint32_t several = 0;
   if (!ok_hip(hipGetLastError(), "kernels") || !ok_hip(hipDeviceSynchronize(), "kernels") ||
@@ -699,6 +758,10 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<Em
   ix.hint_first = hint_first;
   ix.n_hint = hint_n;
   ix.filt_log2 = hints ? fl : 0;
+  ix.win = n_win ? pool.keep(d_win, c.dev_allocs) : nullptr;
+  ix.site_win = n_win ? pool.keep(d_site_win, c.dev_allocs) : nullptr;
+  ix.win_base = win_base;
+  ix.n_win = n_win;
   c.dev_index = ix;
   c.lookup_tables = {{d_slots, (static_cast<uint64_t>(BUCKET_SLOTS) << log2_cap) * sizeof(IndexSlot)},
                      {d_hslots, (static_cast<uint64_t>(BUCKET_SLOTS) << hl) * sizeof(IndexSlot)},
@@ -746,11 +809,13 @@ int download_hint_table(gtx_ctx const & c, int which, void * out, uint64_t cap_b
   uint64_t n = 0;
   switch (which)
   {
-  case 0: src = ix.pos_flags; n = static_cast<uint64_t>(ix.n_hint ? ix.n_hint : 1) * sizeof(uint2_t); break;
-  case 1: src = ix.refp; n = (ix.n_hint ? 4 * (static_cast<uint64_t>(ix.n_hint) / 32 + 8) : 32) * sizeof(uint32_t); break;
-  case 2: src = ix.tail_info; n = static_cast<uint64_t>(ix.n_hint ? ix.n_hint : 1) * sizeof(uint2_t); break;
+  case 0: src = ix.pos_flags; n = (ix.n_hint ? hint_total_positions(ix.n_hint, ix.n_win) : 1) * sizeof(uint2_t); break;
+  case 1: src = ix.refp; n = (ix.n_hint ? 4 * (hint_total_positions(ix.n_hint, ix.n_win) / 32 + 8) : 32) * sizeof(uint32_t); break;
+  case 2: src = ix.tail_info; n = (ix.n_hint ? hint_total_positions(ix.n_hint, ix.n_win) : 1) * sizeof(uint2_t); break;
   case 3: src = ix.filt[0]; n = filt_words * sizeof(uint32_t); break;
   case 4: src = ix.filt[1]; n = filt_words * sizeof(uint32_t); break;
+  case 5: src = ix.win; n = static_cast<uint64_t>(ix.n_win) * sizeof(HintWindow); break;
+  case 6: src = ix.site_win; n = ix.n_win ? static_cast<uint64_t>(c.graph.ref_order.size()) * sizeof(uint32_t) : 0; break;
   default: return GTX_ERR_ARG;
   }
   *bytes = n;
@@ -758,7 +823,7 @@ int download_hint_table(gtx_ctx const & c, int which, void * out, uint64_t cap_b
     return GTX_OK;
   if (cap_bytes < n)
     return GTX_ERR_CAPACITY;
-  if (!ok_hip(hipSetDevice(c.device), "hipSetDevice") || !ok_hip(hipMemcpy(out, src, n, hipMemcpyDeviceToHost), "hint table"))
+  if (n != 0 && (!ok_hip(hipSetDevice(c.device), "hipSetDevice") || !ok_hip(hipMemcpy(out, src, n, hipMemcpyDeviceToHost), "hint table")))
     return GTX_ERR_HIP;
   return GTX_OK;
 }

@@ -628,7 +628,7 @@ GTX_DEV HintWalk hint_tail_walk(GraphView const & g, IndexView const & ix, Row r
   if (r + 1 >= g.n_ref)
     return w;
   uint32_t const nv1 = g.ref_nvar[r], fv1 = g.ref_first_var[r];
-  if (nv1 < 2 || nv1 > 4)
+  if (nv1 < 2 || nv1 > HINT_MASK_BITS)
     return w;
   uint32_t const n1 = g.ref_len[r + 1], o1 = g.ref_order[r + 1], rest = T - at;
   bool const more = r + 2 < g.n_ref;
@@ -656,8 +656,8 @@ GTX_DEV HintWalk hint_tail_walk(GraphView const & g, IndexView const & ix, Row r
       w.mask2 |= k2;
     }
   };
-  for (uint32_t a = 0; a < 4; ++a)
-    if (a < nv1)
+#pragma unroll 1
+  for (uint32_t a = 0; a < nv1; ++a)
     {
       uint32_t const vl = g.var_len[fv1 + a], vo = g.var_dna[fv1 + a];
       if (vl == 0)
@@ -677,14 +677,14 @@ GTX_DEV HintWalk hint_tail_walk(GraphView const & g, IndexView const & ix, Row r
       }
       if (mm > budget) // (the reference drops the candidate here: count_mismatches against the budget, graph.cpp:1268)
         continue;
-      if (nv2 < 2 || nv2 > 4)
+      if (nv2 < 2 || nv2 > HINT_MASK_BITS)
       {
         odd = true;
         continue;
       }
       uint32_t const rest2 = rem - n1, ro2 = pre + at + vl + n1;
-      for (uint32_t b = 0; b < 4; ++b)
-        if (b < nv2)
+#pragma unroll 1
+      for (uint32_t b = 0; b < nv2; ++b)
         {
           uint32_t const vl2 = g.var_len[fv2 + b];
           if (vl2 == 0)
@@ -722,24 +722,23 @@ GTX_DEV HintWalk hint_tail_walk(GraphView const & g, IndexView const & ix, Row r
 constexpr uint32_t HINT_STAGE_WORDS = 16; // a record of up to three variant sites (6 + 3 * 3 words)
 constexpr uint32_t HINT_TO_GENERAL = 3;
 
-// DENSE: the build for graphs whose sites lie close together (k-mers over two sites, ...): more registers, the same
-// records where both builds finish a read.
+// DENSE: the build for graphs whose sites lie close together (k-mers over two sites, walks over sites with alleles of any
+// length, allele windows): more registers, the same records where both builds finish a read.
+// hinted_on_path: the read against the path that table position `idx` lies on -- the linear reference, or (pw != NULL, dense
+// build) the allele window *pw, whose position 0 is table position `wbase`.  mm_all: the compare's mismatches over the read.
 template <bool DENSE, class Row>
-GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, uint32_t seq_stride, gtx_read_meta const & m,
-                            uint32_t * rec, uint32_t rec_words, uint32_t * stage = nullptr)
+GTX_DEV uint32_t hinted_on_path(GraphView const & g, IndexView const & ix, Row row, uint32_t seq_stride, gtx_read_meta const & m, uint32_t idx,
+                                HintWindow const * pw, uint32_t wbase, uint32_t * rec, uint32_t rec_words, uint32_t * stage, uint32_t & mm_all)
 {
   uint32_t const L = m.l_qseq;
-  if (L < 2 * K - 1 || L > HINT_MAX_READ || m.pos < 0 || ix.n_hint == 0)
+  // graph order of table position p (of this path)
+  auto order_of = [&](uint32_t p) -> uint32_t
   {
-    GTX_HINT_NOTE(9);
-    return false;
-  }
-  // position of read base 0 in the hint tables
-  if (static_cast<uint32_t>(m.pos) < ix.hint_first)
-    return false;
-  uint32_t const idx = static_cast<uint32_t>(m.pos) - ix.hint_first;
-  if (idx >= ix.n_hint || L > ix.n_hint - idx)
-    return false;
+    if constexpr (DENSE)
+      if (pw)
+        return hint_win_order(g, *pw, p - wbase);
+    return g.first_order + p;
+  };
   uint32_t const n_k = 1 + (L - K) / (K - 1);
   // ---- the read and the reference under it, 8 bases per word, aligned to the read
   HintCounts h{};
@@ -753,6 +752,7 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   uint32_t const y_end = ix.pos_flags[idx + (K - 1) * n_k].y; // the position behind the last k-mer (31 n_k <= L - 1: inside the read)
   uint2_t const t_end = ix.tail_info[idx + (K - 1) * n_k];    // ... and the site behind its reference node
   hint_compare(row, seq_stride, refw, sh, L, h);
+  mm_all = hc_all(h);
   // ---- every k-mer: the label of its place, no label at all, or not provable
   uint32_t const none = hk_make(HINT_K_HOLE, HINT_NO_SITE, 0u, false, false);
   uint32_t amb2 = 0; // k-mers with one ambiguous base in each half: three more filter probes (below)
@@ -946,7 +946,7 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
   uint32_t mism = static_cast<uint32_t>(__builtin_popcount(mmk & run));
   // ---- the read in front of the run and behind it: the walks' shortcut, both inside the reference node the path touches
   uint32_t const prs = (K - 1) * lo, pre = (K - 1) * (hi + 1);
-  uint32_t start = g.first_order + idx + prs, rs = prs;
+  uint32_t start = order_of(idx + prs), rs = prs;
   // A walk that leaves its reference node over ONE site whose alleles are single bases (tail_info: HINT_TAIL_OK), with the
   // rest inside the reference node on the other side: Graph::get_labels_forward / _backward has one candidate per allele,
   // they differ in that character only, and the labels of the best ones share their ends -- one path with the site's best
@@ -1031,29 +1031,29 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
     uint32_t const budget = 2 + head_len / 11 < 7 ? 2 + head_len / 11 : 7; // genotype_paths.cpp:571-577
     if (upto <= budget)
     {
-      start -= prs;
+      start = order_of(idx);
       rs = 0;
       mism += upto;
     }
     else
       head_mask = 0; // (the path stays as it is: no site from the walk)
   }
-  uint32_t end = g.first_order + idx + pre, re = pre;
+  uint32_t end = order_of(idx + pre), re = pre;
   uint32_t tail_site = 0, tail_mask = 0; // the site the walk at the read's end crossed, with its best alleles
   uint32_t tail_mask2 = 0;               // ... and (dense build) those of the site behind it, when the walk crossed that as well
   if (decided) // (two runs of one length, inside one reference node: worked out above)
   {
-    start = g.first_order + idx + two_rs;
+    start = order_of(idx + two_rs);
     rs = two_rs;
     re = two_re;
-    end = g.first_order + idx + two_re;
+    end = order_of(idx + two_re);
     mism = two_mism;
   }
   else if (pre != L - 1) // walk_read_ends (genotype_paths.cpp:483-553)
   {
     uint32_t const tail_len = L - pre;
     uint32_t const budget = 2 + tail_len / 11 < 7 ? 2 + tail_len / 11 : 7; // genotype_paths.cpp:505-511
-    uint32_t tail_end = end + tail_len - 1; // (inside one reference node, or over SNP-like sites: the linear reference's position)
+    uint32_t tail_end = order_of(idx + L - 1u); // (inside one reference node, or over SNP-like sites: the path's own position)
     uint32_t const y = hi + 1 == n_k ? y_end : hi == 0 ? f1.y : hi == 1 ? f2.y : hi == 2 ? f3.y : f4.y;
     uint32_t const room = y & 255u;
     uint32_t got = hc_all(h) - hc_upto(h, hi + 1);
@@ -1332,6 +1332,68 @@ GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, 
         rec[2 + path_words + k] = rec[2 + k];
   }
   return to_stage ? 2u : 1u;
+}
+
+// The forward task of one read (see hinted_on_path for the return values): on the linear reference at the hinted place, and --
+// dense build, when that is declined -- on the window of the allele the read seems to carry: of the alternative alleles of
+// the (up to four) sites under the read that have windows, the one whose path the read differs least from, if that is less
+// than it differs from the linear reference.  Whatever path is tried, a record is only written when every lookup on it is proven.
+template <bool DENSE, class Row>
+GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, uint32_t seq_stride, gtx_read_meta const & m,
+                            uint32_t * rec, uint32_t rec_words, uint32_t * stage = nullptr)
+{
+  uint32_t const L = m.l_qseq;
+  if (L < 2 * K - 1 || L > HINT_MAX_READ || m.pos < 0 || ix.n_hint == 0)
+  {
+    GTX_HINT_NOTE(9);
+    return false;
+  }
+  // position of read base 0 in the hint tables
+  if (static_cast<uint32_t>(m.pos) < ix.hint_first)
+    return false;
+  uint32_t const idx = static_cast<uint32_t>(m.pos) - ix.hint_first;
+  if (idx >= ix.n_hint || L > ix.n_hint - idx)
+    return false;
+  uint32_t mm_main = 0xFFFFu;
+  uint32_t where = hinted_on_path<DENSE>(g, ix, row, seq_stride, m, idx, static_cast<HintWindow const *>(nullptr), 0u, rec, rec_words, stage, mm_main);
+  if constexpr (DENSE)
+  {
+    if (where == 0 && ix.n_win != 0 && mm_main != 0xFFFFu)
+    {
+      uint2_t const t0 = ix.tail_info[idx];
+      if ((t0.x & HINT_TAIL_NODE) != 0)
+      {
+        uint32_t best = mm_main, best_at = 0, best_w = INVALID, tried = 0;
+        uint32_t r = t0.y;
+#pragma unroll 1
+        for (uint32_t s = 0; s < 4 && r + 1 < g.n_ref; ++s, ++r)
+        {
+          uint32_t const off = g.ref_order[r] + g.ref_len[r] - (g.first_order + idx); // the read's base on the site's first position
+          if (off >= L)
+            break;
+          uint32_t const sw = ix.site_win[r], first = sw & 0xFFFFFFu, count = sw >> 24;
+#pragma unroll 1
+          for (uint32_t k = 0; k < count && tried < 8; ++k, ++tried)
+          {
+            uint32_t const at = ix.win_base + (first + k) * HINT_WIN_STRIDE + (HINT_WIN_BEFORE - off);
+            uint32_t const mm = hint_mm_linear(row, ix.refp, 0u, at, L);
+            if (mm < best)
+            {
+              best = mm;
+              best_at = at;
+              best_w = first + k;
+            }
+          }
+        }
+        if (best_w != INVALID)
+        {
+          uint32_t mm_w = 0;
+          where = hinted_on_path<DENSE>(g, ix, row, seq_stride, m, best_at, ix.win + best_w, ix.win_base + best_w * HINT_WIN_STRIDE, rec, rec_words, stage, mm_w);
+        }
+      }
+    }
+  }
+  return where;
 }
 
 } // namespace gtx

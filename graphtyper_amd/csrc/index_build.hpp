@@ -117,25 +117,27 @@ GTX_HD bool hint_neighbours_ok(HintKeys const & t, uint32_t const * nb, uint8_t 
 // Key k's labels when there are several: all (order, order + 31) on one site, alleles below HINT_MASK_BITS -> their set
 // (0 = not of that form).  These are the alleles of a merged site that share the k-mer (express4.inl: labels with equal
 // ends are one path whose allele set is the union over the labels).
-GTX_HD uint32_t hint_own_labels(HintKeys const & t, uint32_t k, uint32_t order, uint32_t & site)
+// (one label counts when it names another allele than the reference's: the k-mer of an allele window, or of a place whose
+//  reference path the index sweep pruned)
+GTX_HD uint32_t hint_own_labels(HintKeys const & t, uint32_t k, uint32_t exp_start, uint32_t exp_end, uint32_t & site)
 {
   uint32_t const n = t.key_off[k + 1] - t.key_off[k];
-  if (n < 2 || n > HINT_OWN_MAX)
+  if (n < 1 || n > HINT_OWN_MAX)
     return 0;
   uint32_t mask = 0;
   site = t.labels[t.key_off[k]].site;
   for (uint32_t i = t.key_off[k]; i < t.key_off[k + 1]; ++i)
   {
     DevLabel const l = t.labels[i];
-    if (l.start != order || l.end != order + K - 1 || l.site == INVALID || l.site != site || l.allele >= HINT_MASK_BITS)
+    if (l.start != exp_start || l.end != exp_end || l.site == INVALID || l.site != site || l.allele >= HINT_MASK_BITS)
       return 0;
     mask |= 1u << l.allele;
   }
-  return mask;
+  return (n == 1 && mask == 1u) ? 0u : mask; // (the reference allele alone: HINT_SINGLE_OK's case)
 }
 
 // ... or on two neighbouring sites s < s + 1 (HINT_TWO): the sets of their alleles in bits 0..3 / 4..7 (0 = not of that form)
-GTX_HD uint32_t hint_own_labels_two(HintKeys const & t, uint32_t k, uint32_t order, uint32_t & site)
+GTX_HD uint32_t hint_own_labels_two(HintKeys const & t, uint32_t k, uint32_t exp_start, uint32_t exp_end, uint32_t & site)
 {
   uint32_t const n = t.key_off[k + 1] - t.key_off[k];
   if (n < 2 || n > HINT_OWN_MAX)
@@ -147,7 +149,7 @@ GTX_HD uint32_t hint_own_labels_two(HintKeys const & t, uint32_t k, uint32_t ord
   for (uint32_t i = t.key_off[k]; i < t.key_off[k + 1]; ++i)
   {
     DevLabel const l = t.labels[i];
-    if (l.start != order || l.end != order + K - 1 || l.site == INVALID || (l.site != site && l.site != site + 1) || l.allele >= 4u)
+    if (l.start != exp_start || l.end != exp_end || l.site == INVALID || (l.site != site && l.site != site + 1) || l.allele >= 4u)
       return 0;
     if (l.site == site)
       lo |= 1u << l.allele;
@@ -166,13 +168,13 @@ GTX_HD bool hint_neighbours_known(HintKeys const & t, uint32_t const * nb, uint8
 }
 
 // ... and with one label: it has to be (order, order + 31, site, allele)
-GTX_HD bool hint_exact_verdict(HintKeys const & t, uint32_t const * nb, uint8_t const * nb_same, uint32_t k, uint32_t order, uint32_t want_site,
-                                uint32_t want_allele, bool & par)
+GTX_HD bool hint_exact_verdict(HintKeys const & t, uint32_t const * nb, uint8_t const * nb_same, uint32_t k, uint32_t exp_start, uint32_t exp_end,
+                                uint32_t want_site, uint32_t want_allele, bool & par)
 {
   if (t.key_off[k + 1] - t.key_off[k] != 1)
     return false;
   DevLabel const l = t.labels[t.key_off[k]];
-  if (l.start != order || l.end != order + K - 1 || l.site != want_site || (l.site != INVALID && l.allele != want_allele))
+  if (l.start != exp_start || l.end != exp_end || l.site != want_site || (l.site != INVALID && l.allele != want_allele))
     return false;
   return hint_neighbours_ok(t, nb, nb_same, k, par);
 }
@@ -189,8 +191,11 @@ GTX_HD uint32_t hint_acgt(uint8_t code) // graph comparison code -> nibble of A/
 
 // IndexView::pos_flags[p]: `base` = the linear reference as nibbles (15 = not ACGT), `room` / `back` = bases to the end /
 // from the start of the position's reference node (capped at 255, 0 outside reference nodes), n = positions
-GTX_HD uint2_t hint_position_flags(GraphView const & g, HintKeys const & t, uint32_t const * nb, uint8_t const * nb_same, uint8_t const * base,
-                                    uint8_t const * room, uint8_t const * back, uint32_t n, uint32_t p)
+// (exp_start, exp_end): where a label of the k-mer at p has to lie -- (first_order + p, + 31) on the linear reference, the
+// window's path in an allele window (`linear` false: the offsets of sites under the k-mer are not plain differences of
+// orders there, the SNP logic is left out)
+GTX_HD uint2_t hint_flags_at(GraphView const & g, HintKeys const & t, uint32_t const * nb, uint8_t const * nb_same, uint8_t const * base,
+                              uint8_t const * room, uint8_t const * back, uint32_t n, uint32_t p, uint32_t exp_start, uint32_t exp_end, bool linear)
 {
   uint32_t x = 0, y = static_cast<uint32_t>(room[p]) | (static_cast<uint32_t>(back[p]) << HINT_BACK_SHIFT);
   uint32_t site = HINT_NO_SITE;
@@ -227,11 +232,12 @@ GTX_HD uint2_t hint_position_flags(GraphView const & g, HintKeys const & t, uint
       y |= code << (side == 0 ? HINT_FAR_LEFT_SHIFT : HINT_FAR_RIGHT_SHIFT);
     }
   }
-  if (found && t.key_off[k + 1] - t.key_off[k] > 1 && !g.is_sv_graph)
+  bool const one_alt_label = found && t.key_off[k + 1] - t.key_off[k] == 1 && t.labels[t.key_off[k]].site != INVALID && t.labels[t.key_off[k]].allele != 0;
+  if (found && (t.key_off[k + 1] - t.key_off[k] > 1 || one_alt_label) && !g.is_sv_graph)
   {
     // the k-mer lies over a merged site and several of its alleles spell it
     uint32_t msite = INVALID;
-    uint32_t const mask = hint_own_labels(t, k, g.first_order + p, msite);
+    uint32_t const mask = hint_own_labels(t, k, exp_start, exp_end, msite);
     bool par = false;
     if (mask != 0 && msite < HINT_NO_SITE && hint_neighbours_ok(t, nb, nb_same, k, par))
     {
@@ -241,7 +247,7 @@ GTX_HD uint2_t hint_position_flags(GraphView const & g, HintKeys const & t, uint
     else if (mask == 0)
     {
       // ... or the k-mer lies over two neighbouring sites
-      uint32_t const two = hint_own_labels_two(t, k, g.first_order + p, msite);
+      uint32_t const two = hint_own_labels_two(t, k, exp_start, exp_end, msite);
       if (two != 0 && msite + 1 < HINT_NO_SITE && hint_neighbours_known(t, nb, nb_same, k, par))
       {
         site = msite;
@@ -252,8 +258,8 @@ GTX_HD uint2_t hint_position_flags(GraphView const & g, HintKeys const & t, uint
   if (found && t.key_off[k + 1] - t.key_off[k] == 1)
   {
     DevLabel const l = t.labels[t.key_off[k]];
-    uint32_t const order = g.first_order + p;
-    if (l.start == order && l.end == order + K - 1 && (l.site == INVALID || l.allele == 0) && !(l.site != INVALID && g.is_sv_graph))
+    uint32_t const order = exp_start;
+    if (l.start == exp_start && l.end == exp_end && (l.site == INVALID || l.allele == 0) && !(l.site != INVALID && g.is_sv_graph))
     {
       site = l.site == INVALID ? HINT_NO_SITE : l.site;
       x |= HINT_SINGLE_OK;
@@ -262,10 +268,10 @@ GTX_HD uint2_t hint_position_flags(GraphView const & g, HintKeys const & t, uint
       if (t.rsize[k] == 1)
         x |= HINT_R1;
       bool par = false;
-      if (hint_exact_verdict(t, nb, nb_same, k, order, l.site, 0, par))
+      if (hint_exact_verdict(t, nb, nb_same, k, exp_start, exp_end, l.site, 0, par))
         x |= HINT_EXACT_OK | (par ? HINT_PAR : 0u);
       // the other alleles of a SNP under the k-mer
-      if (l.site != INVALID)
+      if (l.site != INVALID && linear)
       {
         uint32_t const fv = g.ref_first_var[l.site], nv = g.ref_nvar[l.site];
         bool snp = nv >= 2 && nv <= 4 && g.var_order[fv] >= order && g.var_order[fv] <= order + K - 1;
@@ -285,7 +291,7 @@ GTX_HD uint2_t hint_position_flags(GraphView const & g, HintKeys const & t, uint
             uint64_t const alt = (key & ~(3ull << (2 * (K - 1 - off)))) | (static_cast<uint64_t>(two) << (2 * (K - 1 - off)));
             uint32_t ka = 0;
             bool pa = false;
-            snp = alt != key && ((idx_of >> (2 * two)) & 3u) == 0 && hint_find_key(t, alt, ka) && hint_exact_verdict(t, nb, nb_same, ka, order, l.site, a, pa);
+            snp = alt != key && ((idx_of >> (2 * two)) & 3u) == 0 && hint_find_key(t, alt, ka) && hint_exact_verdict(t, nb, nb_same, ka, exp_start, exp_end, l.site, a, pa);
             idx_of |= a << (2 * two);
             group = group && snp && (snp_left ? t.lsize[ka] : t.rsize[ka]) == 1;
           }
@@ -301,6 +307,105 @@ GTX_HD uint2_t hint_position_flags(GraphView const & g, HintKeys const & t, uint
     }
   }
   return uint2_t{x | (site << HINT_SITE_SHIFT), y};
+}
+
+GTX_HD uint2_t hint_position_flags(GraphView const & g, HintKeys const & t, uint32_t const * nb, uint8_t const * nb_same, uint8_t const * base,
+                                    uint8_t const * room, uint8_t const * back, uint32_t n, uint32_t p)
+{
+  return hint_flags_at(g, t, nb, nb_same, base, room, back, n, p, g.first_order + p, g.first_order + p + K - 1, true);
+}
+
+// ---- allele windows (IndexView::win) ----
+// Which sites get windows for their alternative alleles: those whose reads the linear reference's flags cannot settle -- an
+// allele of another length than one base, more than four alleles, or another site within a k-mer's reach (a SNP standing
+// alone is settled by HINT_SNP_GROUP)
+GTX_HD bool hint_site_wants_windows(GraphView const & g, uint32_t r)
+{
+  if (g.is_sv_graph || r + 1 >= g.n_ref)
+    return false;
+  uint32_t const nv = g.ref_nvar[r], fv = g.ref_first_var[r];
+  if (nv < 2 || nv > HINT_MASK_BITS || g.var_len[fv] == 0 || g.var_len[fv] > HINT_WIN_ALLELE_MAX)
+    return false;
+  bool plain = nv <= 4;
+  for (uint32_t a = 0; a < nv; ++a)
+    plain = plain && g.var_len[fv + a] == 1;
+  if (!plain)
+    return true;
+  bool const near_prev = r > 0 && g.ref_nvar[r - 1] != 0 && g.ref_len[r] < K - 1;
+  bool const near_next = r + 2 < g.n_ref && g.ref_nvar[r + 1] != 0 && g.ref_len[r + 1] < K - 1;
+  return near_prev || near_next;
+}
+
+GTX_HD bool hint_allele_gets_window(GraphView const & g, uint32_t r, uint32_t a)
+{
+  uint32_t const len = g.var_len[g.ref_first_var[r] + a];
+  return a != 0 && len != 0 && len <= HINT_WIN_ALLELE_MAX;
+}
+
+// one position of a window: base / room / back / tail entry (those of the linear reference's position it copies; inside the
+// allele: the allele's base, no node).  The node in front of the window's own site loses HINT_TAIL_OK: what hint_compare
+// counted on the site's position is the window's allele there, not the reference allele site_choice() assumes.
+GTX_HD void hint_window_cell(GraphView const & g, HintWindow const & w, uint32_t local, uint8_t const * mbase, uint8_t const * mroom,
+                             uint8_t const * mback, uint2_t const * mtail, uint32_t n_main, uint8_t & base, uint8_t & room, uint8_t & back, uint2_t & tail)
+{
+  base = 15;
+  room = back = 0;
+  tail = uint2_t{0, 0};
+  uint32_t order = 0;
+  if (local < HINT_WIN_BEFORE)
+  {
+    if (w.site_order < g.first_order + (HINT_WIN_BEFORE - local))
+      return;
+    order = w.site_order - (HINT_WIN_BEFORE - local);
+  }
+  else
+  {
+    uint32_t const k = local - HINT_WIN_BEFORE;
+    if (k < w.len_a)
+    {
+      base = static_cast<uint8_t>(hint_acgt(static_cast<uint8_t>(g.dna[g.var_dna[g.ref_first_var[w.site] + w.allele] + k])));
+      return;
+    }
+    if (k - w.len_a >= HINT_WIN_BEFORE)
+      return;
+    order = w.site_order + w.len_0 + (k - w.len_a);
+  }
+  uint32_t const m = order - g.first_order;
+  if (m >= n_main)
+    return;
+  base = mbase[m];
+  room = mroom[m];
+  back = mback[m];
+  tail = mtail[m];
+  if ((tail.x & HINT_TAIL_NODE) != 0 && tail.y == w.site)
+    tail.x = HINT_TAIL_NODE;
+}
+
+// ... and its flags: a k-mer that does not reach into the allele is a k-mer of the linear reference (that position's flags), one
+// that does is judged against the window's path
+GTX_HD uint2_t hint_window_flags(GraphView const & g, HintKeys const & t, uint32_t const * nb, uint8_t const * nb_same, uint8_t const * base,
+                                  uint8_t const * room, uint8_t const * back, uint32_t n_total, uint2_t const * main_flags, uint32_t n_main,
+                                  HintWindow const & w, uint32_t local, uint32_t p)
+{
+  uint2_t const none{HINT_NO_SITE << HINT_SITE_SHIFT, static_cast<uint32_t>(room[p]) | (static_cast<uint32_t>(back[p]) << HINT_BACK_SHIFT)};
+  if (local + K > HINT_WIN_STRIDE)
+    return none;
+  bool const reaches = local + K > HINT_WIN_BEFORE && local < HINT_WIN_BEFORE + w.len_a;
+  if (!reaches)
+  {
+    uint32_t order = 0;
+    if (local < HINT_WIN_BEFORE)
+    {
+      if (w.site_order < g.first_order + (HINT_WIN_BEFORE - local))
+        return none;
+      order = w.site_order - (HINT_WIN_BEFORE - local);
+    }
+    else
+      order = w.site_order + w.len_0 + (local - HINT_WIN_BEFORE - w.len_a);
+    uint32_t const m = order - g.first_order;
+    return m < n_main ? main_flags[m] : none;
+  }
+  return hint_flags_at(g, t, nb, nb_same, base, room, back, n_total, p, hint_win_order(g, w, local), hint_win_order(g, w, local + K - 1), false);
 }
 
 // 16 bases (2 bits each, first base in the top bits) as the two planes the kernel hashes (hint_filter_slot): bit j of

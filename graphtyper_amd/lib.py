@@ -540,11 +540,12 @@ class Context:
 
     def hint_table(self, which):
         """one table of the position-hinted pass as uint32 words (gtx_ctx_hint_table): 0 position flags, 1 reference planes,
-        2 tail sites, 3 / 4 half-key filters"""
+        2 tail sites, 3 / 4 half-key filters, 5 allele windows (8 words each), 6 first window | count << 24 per reference node"""
         n = C.c_uint64()
         check(lib().gtx_ctx_hint_table(self.h, which, None, 0, C.byref(n)))
         out = np.zeros(n.value // 4, np.uint32)
-        check(lib().gtx_ctx_hint_table(self.h, which, _p(out), n.value, C.byref(n)))
+        if n.value:
+            check(lib().gtx_ctx_hint_table(self.h, which, _p(out), n.value, C.byref(n)))
         return out
 
     def profile(self):

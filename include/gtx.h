@@ -259,7 +259,10 @@ int gtx_index_get(const gtx_ctx *, uint64_t key, gtx_label * out, uint32_t cap, 
 int gtx_index_dump(const gtx_ctx *, uint64_t * keys, uint32_t * counts, gtx_label * labels);
 /* Inspection of the position-hinted pass' tables as the context holds them (on its device, or on the host for an
  * inspection-only context): which = 0 per-position flags (2 x u32 per position), 1 the linear reference as bit planes,
- * 2 the site behind every position's node (2 x u32), 3 / 4 the filters over the first / last halves of the indexed keys.
+ * 2 the site behind every position's node (2 x u32), 3 / 4 the filters over the first / last halves of the indexed keys,
+ * 5 the allele windows (8 x u32 each: site, allele, bases of the allele, bases of the site's reference allele, order of the
+ * site's variant nodes, 3 unused) whose positions continue tables 0..2 behind the linear reference, 6 per reference node the
+ * first window of the site behind it | number of its windows << 24 (both empty for a graph without windows).
  * out == NULL: only *bytes.  Tests compare the device's build with the host's (gtx_index_dev.hip / gtx_host.cpp: the
  * reference has no such tables -- they restate what its index lookups would return at the place the mapper named). */
 int gtx_ctx_hint_table(const gtx_ctx *, int which, void * out, uint64_t cap_bytes, uint64_t * bytes);

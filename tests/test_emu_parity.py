@@ -283,8 +283,9 @@ def test_align_and_score_on_merged_multiallelic_graph():
     assert int(g["ref_nvar"].max()) >= 6
     b = harness.EmuBackend(g)
     check_align(b, o, list(codes), pos=pos)
-    # (608 of 4000 without the k-mers that several alleles of a merged site spell, HINT_MULTI; 700 with them)
-    assert check_align.hinted_done > 650, "the position-hinted pass does not take k-mers over merged sites"
+    # (608 of 4000 without the k-mers that several alleles of a merged site spell, HINT_MULTI; 700 with them; 2 715 with the
+    #  dense build: k-mers over two sites, walks over sites with alleles of any length, allele windows)
+    assert check_align.hinted_done > 2500, "the dense build of the position-hinted pass does not take the reads of merged sites"
     rec = scenarios.stream_records(len(codes), pos, sample=np.arange(len(codes)) % 3)
     order = np.argsort(pos, kind="stable")
     run_stream(b, o, codes[order], rec[order], n_samples=3)
@@ -308,7 +309,7 @@ def cfg3_case(Backend, n_reads, n_ref=120000):
 
 def test_cfg3_graph():
     done = cfg3_case(harness.EmuBackend, 4000)
-    assert done > 0.7 * 4000, done
+    assert done > 0.94 * 4000, done  # (3 853: the dense build of pass 0; 87 % with the lean one)
 
 
 def second_pass_case(Backend, kind, n_reads):

@@ -91,7 +91,7 @@ def test_merged_multiallelic_graph():
     assert int(g["ref_nvar"].max()) >= 6
     b = harness.GpuBackend(g)
     check_align(b, o, list(codes), pos=pos)  # (every record with correct, missing, shifted and foreign position hints)
-    assert check_align.hinted_done > len(codes) // 10
+    assert check_align.hinted_done > 0.65 * len(codes)  # (the dense build of pass 0: 70 %; 18 % with the lean one)
     order = np.argsort(pos, kind="stable")
     rec = scenarios.stream_records(len(codes), pos, sample=np.arange(len(codes)) % 30)
     run_stream(b, o, codes[order], rec[order], n_samples=30)
@@ -99,7 +99,7 @@ def test_merged_multiallelic_graph():
 
 def test_cfg3_graph():
     done = cfg3_case(harness.GpuBackend, 30000, n_ref=300000)
-    assert done > 0.7 * 30000, done
+    assert done > 0.94 * 30000, done
 
 
 @pytest.mark.parametrize("kind", ["repeat", "snp7"])
@@ -315,3 +315,25 @@ def test_batches_in_flight_equal_one_at_a_time():
     d_p, d_m, d_rec, d_fl = held[0]
     assert L.gtx_align_batch_planes_staged(ctx.h, d_p.data_ptr(), stride, d_m.data_ptr(), 10, d_rec.data_ptr(), harness.REC_WORDS, None,
                                            C.c_void_p(H.cuda_stream), None, C.c_void_p(T.cuda_stream), None) != 0
+
+
+@pytest.mark.parametrize("kind", ["cfg3", "cluster", "snp25"])
+def test_both_builds_of_pass_0_write_the_same_records(kind, monkeypatch):
+    """gtx_align_hinted_kernel and gtx_align_hinted_dense_kernel (GTX_HINT_BUILD) on one context: the same record words,
+    the dense build finishes more of a dense graph's reads itself; both equal the oracle (tests above run whichever is the default)"""
+    ref, recs, codes, pos = scenarios.synthetic_case(kind, n_ref=200000, n_reads=20000, region_begin=1000000, seed=2)
+    aav = kind in ("cluster", "cfg3")
+    g = gtx.graph_from_records(ref, recs, region_begin=1000000, add_all_variants=aav)
+    b = harness.GpuBackend(g)
+    seq, lens = harness.pack_ragged(list(codes))
+    meta = harness.read_meta(lens, pos=pos)
+    out, done = {}, {}
+    for build in ("lean", "dense"):
+        monkeypatch.setenv("GTX_HINT_BUILD", build)
+        out[build] = b.align(seq, meta).reshape(2 * len(lens), -1).copy()
+        done[build] = b.hinted_done()
+    external = ((out["lean"][:, 0] >> 16) & gtx.ST_EXTERNAL) != 0
+    differ = out["lean"] != out["dense"]
+    differ[external, 2:] = False
+    assert not differ.any(), np.nonzero(differ.any(1))[0][:5]
+    assert done["dense"] >= done["lean"] and (kind == "snp25" or done["dense"] > 1.05 * done["lean"])
