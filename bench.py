@@ -1218,6 +1218,8 @@ def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_al
         sys.stderr.write("cfg3-like: phase cycles per task of the general pass (profiling build), %d tasks:\n" % prof[15])
         for k, nm in enumerate(names):
             sys.stderr.write("  %-22s %10.0f  %5.1f%%\n" % (nm, prof[k] / float(prof[15]), 100.0 * prof[k] / tot))
+        sys.stderr.write("  longest task %d cycles (task %d); tasks over 100 k / 200 k / 400 k cycles: %d / %d / %d (all launches of the run)\n" %
+                         (int(prof[10]) >> 32, int(prof[10]) & 0xFFFFFFFF, prof[11], prof[12], prof[13]))
     if prof[31] > 0:
         names = ["unpack reads", "keys", "index lookups", "half-key entries", "seeding verdict", "run + walk geometry", "compares",
                  "indel-tail compares", "verdict + record"]

@@ -1,29 +1,41 @@
 #!/bin/bash
-# A/B of library builds on one box: bash tools/gpu_ab.sh "<lib>:<snp-every>:<reads>[:<GTX_EXPRESS4>]" ...  (two rounds, interleaved)
+# A/B on ONE box (box-to-box noise is a few percent), two interleaved rounds.  Every further argument is one variant:
+#   "[ENV=value ...] [-- bench.py arguments]"        e.g.  bash tools/gpu_ab.sh "GTX_LIB=libgtx.so" "GTX_LIB=libgtx_x.so -- --lanes 1"
+# Options in front of the variants:
+#   --extra        keep bench.py's extra legs and show the cfg3 leg in the line (default: the cfg2 step only, --no-extra)
+#   --leg <name>   run one extra leg alone instead (tools/run_extra_leg.py: cfg3 | clusters | repeats | cfg5)
+#   --rounds <n>   rounds (default 2)
 set -u
-mkdir -p gpurun_out/ab
-for round in 1 2; do
-  for spec in "$@"; do
-    IFS=: read lib every reads mode <<< "$spec"
-    tag="${lib%.so}_${every}_${mode:-auto}_$round"
-    GTX_LIB=$lib GTX_EXPRESS4=${mode:-} timeout 300 python bench.py --reads $reads --snp-every $every --no-cpu-baseline > gpurun_out/ab/$tag.json 2> gpurun_out/ab/$tag.err
-  done
+extra=0; leg=""; rounds=2
+while [ $# -gt 0 ]; do
+  case "$1" in
+    --extra) extra=1; shift ;;
+    --leg) leg=$2; shift 2 ;;
+    --rounds) rounds=$2; shift 2 ;;
+    *) break ;;
+  esac
 done
-python - <<'PY'
-import json, glob
-for f in sorted(glob.glob("gpurun_out/ab/*.json")):
-    try:
-        d = json.loads(open(f).read().strip().splitlines()[-1])
-        k = d["roofline"]["align_kernels"]
-        print("%-40s %7.1f M/s  step %6.2f  " % (f.split("/")[-1], d["value"] / 1e6, d["ms_per_step"]) +
-              " ".join("%s %.3f" % (n.replace("gtx_align_", "").replace("_kernel", ""), v["ms"]) for n, v in k.items()))
-    except Exception as e:
-        print(f, "unreadable", e)
-PY
-if [ "${GTX_AB_TRACE:-}" != "" ]; then
-  export TMPDIR=/tmp; R=$PWD; cd /tmp
-  rocprofv3 --output-format csv --kernel-trace --stats -d $R/gpurun_out/ab/trace -o t -- python $R/bench.py --reads 4000000 --snp-every $GTX_AB_TRACE --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/ab/trace.log 2>&1
-  cd $R
-  find gpurun_out/ab/trace -type f ! -name '*kernel_stats.csv' -delete
-  for f in $(find gpurun_out/ab/trace -name '*kernel_stats.csv'); do cut -c1-200 $f | head -14; done
-fi
+mkdir -p gpurun_out
+for round in $(seq 1 $rounds); do
+for v in "$@"; do
+  case "$v" in *" -- "*) e="${v%% -- *}"; b="${v#* -- }" ;; "-- "*) e=""; b="${v#-- }" ;; *) e="$v"; b="" ;; esac
+  if [ -n "$leg" ]; then
+    out=$(env $e python tools/run_extra_leg.py $leg --no-cpu-baseline $b 2>gpurun_out/ab.err | python -c "
+import sys, json
+j = json.loads(sys.stdin.readline())
+print('%.3f G/s  step %.3f ms | ' % (j['reads_per_s'] / 1e9, j['ms_per_step']) + ' '.join('%s %.3f' % (n.replace('gtx_align_', '').replace('_kernel', ''), x['ms']) for n, x in j['align_kernels'].items()) + ' | pass 0 %.3f general %.4f' % (j['pass_shares']['position_hinted_share'], j['pass_shares']['share_general']))")
+  else
+    out=$(env $e python bench.py --warmup 2 --no-cpu-baseline $([ $extra = 1 ] || echo --no-extra) $b 2>gpurun_out/ab.err | python -c "
+import sys, json
+j = json.loads(sys.stdin.readline())
+k = j['roofline']['align_kernels']
+s = '%.3f G/s  step %.3f ms | ' % (j['value'] / 1e9, j['ms_per_step']) + ' '.join('%s %.3f' % (n.replace('gtx_align_', '').replace('_kernel', ''), x['ms']) for n, x in k.items())
+s += ' | frac %.3f %s' % (j['roofline']['frac'], str(j['config'].get('calls_checksum', {}).get('vcf_sha256'))[:10])
+x = j['config'].get('extra', {}).get('cfg3')
+if x and 'reads_per_s' in x:
+    s += ' | cfg3 %.1f M/s step %.2f %s' % (x['reads_per_s'] / 1e6, x['ms_per_step'], {a: round(b, 2) for a, b in x['align_passes_ms'].items()})
+print(s)")
+  fi
+  echo "[$v] $out" | tee -a gpurun_out/ab.log
+  tail -2 gpurun_out/ab.err | grep -v amdgpu.ids
+done; done

@@ -4,7 +4,7 @@ set -u
 leg=${1:-cfg3}; shift
 mkdir -p gpurun_out
 GTX_LIB=libgtx_prof.so python tools/run_extra_leg.py "$leg" --no-cpu-baseline "$@" > gpurun_out/prof_${leg}.json 2> gpurun_out/prof_${leg}.txt
-grep -A12 "phase cycles" gpurun_out/prof_${leg}.txt
+grep -A13 "phase cycles" gpurun_out/prof_${leg}.txt
 python - <<PY
 import json
 j = json.load(open("gpurun_out/prof_${leg}.json"))
