@@ -1726,7 +1726,9 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     uint32_t const general_goal = egw && std::atoi(egw) > 0 ? static_cast<uint32_t>(std::atoi(egw)) : 0u;
     // (GTX_GENERAL_GRID=<wavefronts per CU>: A/B switch; default: as many as are resident)
     char const * eg = std::getenv("GTX_GENERAL_GRID");
-    uint32_t const general_per_cu = eg && std::atoi(eg) > 0 ? static_cast<uint32_t>(std::atoi(eg)) : static_cast<uint32_t>(c->align_blocks_per_cu);
+    // (a long queue -- the cfg3 graph: 48 k tasks -- is not done faster by more than 12 wavefronts per CU: 4 / 8 / 12 / 20 per CU =
+    //  1.51 / 0.91 / 0.70 / 0.76 ms, the longest task 0.5 M cycles with 4 per CU and 3.4 M with 20; what they queue for is per CU)
+    uint32_t const general_per_cu = eg && std::atoi(eg) > 0 ? static_cast<uint32_t>(std::atoi(eg)) : std::min<uint32_t>(static_cast<uint32_t>(c->align_blocks_per_cu), 12u);
     uint32_t const blocks2 = static_cast<uint32_t>(std::min<uint64_t>(2ull * n, static_cast<uint64_t>(n_cu) * general_per_cu));
     uint32_t const blocks4 = static_cast<uint32_t>(std::min<uint64_t>(
       chunks, static_cast<uint64_t>(n_cu) * (wide ? c->express4_wide_blocks_per_cu : c->express4_blocks_per_cu)));

@@ -630,7 +630,7 @@ void hint_graph_tables(HostGraph const & g, HintGraphTables & t)
   uint32_t const first = g.ref_order[0], last = g.ref_order[R - 1] + g.ref_len[R - 1];
   uint32_t const n = last - first;
   t.n = n;
-  t.base.assign(n, 15); // nibble codes (A=1 C=2 G=4 T=8, anything else 15)
+  t.base.assign(n, 15); // nibble codes: an IUPAC letter's 4-bit code (A=1 C=2 G=4 T=8 ... N=15), 0 for anything else (hint_plane_code)
   t.room.assign(n, 0);  // bases to the end / from the start of the reference node (capped), 0 outside reference nodes
   t.back.assign(n, 0);
   auto nib = [](char c) -> uint8_t { return c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 4 : c == 'T' ? 8 : 15; };
@@ -639,7 +639,7 @@ void hint_graph_tables(HostGraph const & g, HintGraphTables & t)
     uint32_t const at = g.ref_order[r] - first;
     for (uint32_t d = 0; d < g.ref_len[r]; ++d)
     {
-      t.base[at + d] = nib(g.dna[g.ref_dna[r] + d]);
+      t.base[at + d] = static_cast<uint8_t>(hint_plane_code(static_cast<uint8_t>(g.codes[g.ref_dna[r] + d])));
       uint32_t const left = g.ref_len[r] - d;
       t.room[at + d] = static_cast<uint8_t>(left < 255 ? left : 255);
       t.back[at + d] = static_cast<uint8_t>(d < 255 ? d : 255);
@@ -648,7 +648,7 @@ void hint_graph_tables(HostGraph const & g, HintGraphTables & t)
     {
       uint32_t const v = g.ref_first_var[r], vat = g.var_order[v] - first;
       for (uint32_t d = 0; d < g.var_len[v]; ++d)
-        t.base[vat + d] = nib(g.dna[g.var_dna[v] + d]);
+        t.base[vat + d] = static_cast<uint8_t>(hint_plane_code(static_cast<uint8_t>(g.codes[g.var_dna[v] + d])));
     }
   }
   // the site behind every reference node, as a walk at the read's end may cross it (tail_info)
@@ -661,7 +661,7 @@ void hint_graph_tables(HostGraph const & g, HintGraphTables & t)
     for (uint32_t a = 0; a < nv && snp; ++a)
     {
       uint8_t const c = g.var_len[fv + a] == 1 ? nib(g.dna[g.var_dna[fv + a]]) : 15;
-      snp = c != 15;
+      snp = c != 15; // (A, C, G or T)
       codes |= static_cast<uint32_t>(c) << (4 * a);
     }
     uint32_t const next_len = g.ref_len[r + 1] < 255 ? g.ref_len[r + 1] : 255;

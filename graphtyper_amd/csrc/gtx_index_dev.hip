@@ -406,7 +406,7 @@ __global__ void k_hint_graph(GraphView g, uint32_t n, uint8_t * __restrict__ bas
     b = 15;
     if (d < len)
     {
-      b = nib(g.dna[g.ref_dna[r] + d]);
+      b = hint_plane_code(static_cast<uint8_t>(g.dna[g.ref_dna[r] + d]));
       rm = len - d < 255 ? len - d : 255;
       bk = d < 255 ? d : 255;
       if (r + 1 < g.n_ref && !g.is_sv_graph)
@@ -432,7 +432,7 @@ __global__ void k_hint_graph(GraphView g, uint32_t n, uint8_t * __restrict__ bas
     {
       uint32_t const v = g.ref_first_var[r], dv = order - g.var_order[v]; // (allele 0 of the site: the linear reference)
       if (order >= g.var_order[v] && dv < g.var_len[v])
-        b = nib(g.dna[g.var_dna[v] + dv]);
+        b = hint_plane_code(static_cast<uint8_t>(g.dna[g.var_dna[v] + dv]));
     }
     base[i] = static_cast<uint8_t>(b);
     room[i] = static_cast<uint8_t>(rm);

@@ -189,6 +189,19 @@ GTX_HD uint32_t hint_acgt(uint8_t code) // graph comparison code -> nibble of A/
   return (code == 1 || code == 2 || code == 4 || code == 8) ? code : 15u;
 }
 
+// ... -> the nibble the reference planes hold for that base: an IUPAC letter's own 4-bit code (the walks compare characters: a
+// letter that is neither the read's nor N counts as a mismatch, graph_utils.hpp:7-69), 0 -- equal to no read base -- for
+// anything that is no IUPAC letter
+GTX_HD uint32_t hint_plane_code(uint8_t code)
+{
+  return (code >= 1 && code <= 15) ? code : 0u;
+}
+
+GTX_HD bool hint_is_acgt(uint32_t nibble)
+{
+  return nibble == 1 || nibble == 2 || nibble == 4 || nibble == 8;
+}
+
 // IndexView::pos_flags[p]: `base` = the linear reference as nibbles (15 = not ACGT), `room` / `back` = bases to the end /
 // from the start of the position's reference node (capped at 255, 0 outside reference nodes), n = positions
 // (exp_start, exp_end): where a label of the k-mer at p has to lie -- (first_order + p, + 31) on the linear reference, the
@@ -204,7 +217,7 @@ GTX_HD uint2_t hint_flags_at(GraphView const & g, HintKeys const & t, uint32_t c
   for (uint32_t j = 0; j < K && valid; ++j)
   {
     uint32_t const c = base[p + j];
-    valid = c != 15;
+    valid = hint_is_acgt(c);
     key = (key << 2) | hint_two_bits(c);
   }
   uint32_t k = 0;
@@ -363,7 +376,7 @@ GTX_HD void hint_window_cell(GraphView const & g, HintWindow const & w, uint32_t
     uint32_t const k = local - HINT_WIN_BEFORE;
     if (k < w.len_a)
     {
-      base = static_cast<uint8_t>(hint_acgt(static_cast<uint8_t>(g.dna[g.var_dna[g.ref_first_var[w.site] + w.allele] + k])));
+      base = static_cast<uint8_t>(hint_plane_code(static_cast<uint8_t>(g.dna[g.var_dna[g.ref_first_var[w.site] + w.allele] + k])));
       return;
     }
     if (k - w.len_a >= HINT_WIN_BEFORE)

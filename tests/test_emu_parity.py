@@ -705,6 +705,33 @@ def test_align_reference_with_n_runs():
     n_runs_case(harness.EmuBackend, 3000)
 
 
+def iupac_reference_case(Backend, n_reads):
+    """a reference with IUPAC letters other than N (hg38 has a few dozen): k-mers over them are not indexed; a walk over one
+    counts a mismatch against every read base but N (count_mismatches compares characters, graph_utils.hpp:7-69) -- the hint
+    tables of pass 0 have to carry the letter's own code, not N's"""
+    ref, recs, codes, pos = scenarios.synthetic_case("snp100", n_ref=40000, n_reads=1, region_begin=7000)
+    rng = np.random.default_rng(21)
+    s = list(ref)
+    at = 120
+    while at < len(s) - 300:
+        s[at] = "RYKMSWBDHV"[int(rng.integers(0, 10))]
+        at += int(rng.integers(60, 400))
+    ref2 = "".join(s)
+    recs = [r for r in recs if all(c in "ACGT" for c in ref2[r[0] - 7000 - 2:r[0] - 7000 + 3])]
+    from graphtyper_amd import synth
+    base = np.array(["ACGT".index(c) if c in "ACGT" else 4 for c in ref2], np.uint8)
+    codes, pos = synth.make_reads(np.where(base == 4, rng.integers(0, 4, len(base)), base).astype(np.uint8), recs, n_reads, seed=4,
+                                  region_begin=7000)
+    o = Oracle(ref2, recs, region_begin=7000)
+    b = Backend(gtx.graph_from_records(ref2, recs, region_begin=7000))
+    check_align(b, o, list(codes), pos=pos)
+    assert check_align.hinted_done > n_reads // 3
+
+
+def test_align_reference_with_iupac_letters():
+    iupac_reference_case(harness.EmuBackend, 3000)
+
+
 def three_n_case(Backend):
     """a k-mer with three Ns expands to 64 keys: within the main pass' key table (it used to be sent to the HBM-table
     pass by a conservative bound), and equal to the oracle"""

@@ -182,6 +182,11 @@ def test_three_ambiguous_bases_stay_in_the_lds_pass():
     three_n_case(harness.GpuBackend)
 
 
+def test_align_reference_with_iupac_letters():
+    from test_emu_parity import iupac_reference_case
+    iupac_reference_case(harness.GpuBackend, 20000)
+
+
 def test_align_reference_with_n_runs():
     n_runs_case(harness.GpuBackend, 20000)
 
