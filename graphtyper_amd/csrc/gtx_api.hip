@@ -1065,7 +1065,7 @@ static void scratch_free(CallScratch & s)
 {
   // (d_big_state lies behind d_counters in one allocation: one reset for both)
   void * ptrs[] = {s.d_counters, s.d_queue1, s.d_queue, s.d_big_tasks, s.d_big_ws, s.d_score_state, s.d_score_queue,
-                   s.d_score_tables, s.d_score_work, s.d_wide_tasks, s.d_wide_ws, s.d_planes, s.d_exact_tasks, s.d_exact_slab};
+                   s.d_score_tables, s.d_score_work, s.d_wide_tasks, s.d_wide_ws, s.d_planes, s.d_exact_tasks};
   for (void * p : ptrs)
     if (p)
       (void)gtx::dev_free(p);
@@ -1109,9 +1109,6 @@ static std::unique_ptr<CallScratch> scratch_new(gtx_ctx & c)
     // the exact pass: two queues (what did not fit the tables above; what did not fit a part of the slab) and the slab
     s->d_exact_state = s->d_big_state + 16;
     ok = ok && dev_alloc(s->d_exact_tasks, 3 * static_cast<size_t>(CallScratch::EXACT_TASK_CAP), "exact pass queues");
-    void * slab = nullptr;
-    ok = ok && hip_ok(gtx::dev_malloc(&slab, c.exact_slab_bytes), "exact pass slab");
-    s->d_exact_slab = static_cast<uint8_t *>(slab);
     ok = ok && dev_alloc(s->d_score_state, 4, "second-pass score state", true); // ([2]: the work queue's count, reset with the rest)
     ok = ok && dev_alloc(s->d_score_queue, gtx_ctx::SCORE_QUEUE_CAP, "second-pass score queue");
     if (c.has_wide_sites)
@@ -1409,6 +1406,13 @@ void ctx_release_device(gtx_ctx & c)
     scratch_free(*s);
   c.pool.clear();
   c.last_align = nullptr;
+  for (int k = 0; k < c.n_exact_slots; ++k)
+  {
+    if (c.exact_slot[k].idle)
+      (void)hipEventDestroy(static_cast<hipEvent_t>(c.exact_slot[k].idle));
+    c.exact_slot[k] = gtx_ctx::ExactSlot(); // (the slabs are among dev_allocs)
+  }
+  c.n_exact_slots = 0;
   for (void * p : c.dev_allocs)
     (void)gtx::dev_free(p);
   c.dev_allocs.clear();
@@ -1476,6 +1480,36 @@ extern "C" int gtx_reads_to_planes(gtx_ctx * c, const uint8_t * d_seq, uint32_t 
   if (!hip_ok(hipSetDevice(c->device), "hipSetDevice"))
     return GTX_ERR_HIP;
   return launch_planes_kernel(d_seq, seq_stride, n_reads, d_planes, plane_stride, static_cast<hipStream_t>(stream));
+}
+
+// the slab a call's exact launches use (gtx_ctx::exact_slot); c.exact_mutex is held by the caller.  *wait: the call's stream has
+// to wait for the slab's event first (every slab is busy)
+static gtx_ctx::ExactSlot const * exact_slot_for_call(gtx_ctx & c, bool * wait)
+{
+  *wait = false;
+  for (int k = 0; k < c.n_exact_slots; ++k)
+    if (hipEventQuery(static_cast<hipEvent_t>(c.exact_slot[k].idle)) == hipSuccess)
+      return &c.exact_slot[k];
+  if (c.n_exact_slots < gtx_ctx::EXACT_SLOTS)
+  {
+    void * p = nullptr;
+    hipEvent_t ev = nullptr;
+    bool ok = hip_ok(gtx::dev_malloc(&p, c.exact_slab_bytes), "exact pass slab");
+    if (ok)
+      c.dev_allocs.push_back(p);
+    ok = ok && hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "exact pass event");
+    if (ok)
+    {
+      c.exact_slot[c.n_exact_slots].slab = static_cast<uint8_t *>(p);
+      c.exact_slot[c.n_exact_slots].idle = ev;
+      return &c.exact_slot[c.n_exact_slots++];
+    }
+    if (c.n_exact_slots == 0)
+      return nullptr;
+  }
+  *wait = true;
+  c.next_exact_slot = (c.next_exact_slot + 1) % c.n_exact_slots;
+  return &c.exact_slot[c.next_exact_slot];
 }
 
 static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
@@ -1824,7 +1858,7 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     a.wide_ws = s->d_wide_ws;
     a.exact_tasks = s->d_exact_tasks;
     a.exact_state = s->d_exact_state;
-    a.exact_slab = s->d_exact_slab;
+    a.exact_slab = nullptr;
     a.exact_slab_bytes = c->exact_slab_bytes;
     a.exact_cand_cap = c->exact_cand_cap;
     a.exact_part_cand_cap = std::min<uint32_t>(c->exact_cand_cap, CallScratch::EXACT_PART_CANDIDATES);
@@ -1835,6 +1869,21 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     a.arena_words = c->big_record_words;
     a.arena_cursor = c->d_arena_cursor;
     char const * what = launch_hbm_passes(a, sg);
+    if (!what)
+    {
+      // the exact launches, with one of the context's slabs: chosen, waited for if need be, used and marked busy again in one
+      // critical section (the next call's wait has to see this call's record)
+      std::lock_guard<std::mutex> lock(c->exact_mutex);
+      bool wait = false;
+      gtx_ctx::ExactSlot const * slot = exact_slot_for_call(*c, &wait);
+      if (!slot)
+        return GTX_ERR_HIP;
+      if (wait)
+        (void)hipStreamWaitEvent(sg, static_cast<hipEvent_t>(slot->idle), 0);
+      a.exact_slab = slot->slab;
+      what = launch_exact_passes(a, sg);
+      (void)hipEventRecord(static_cast<hipEvent_t>(slot->idle), sg);
+    }
     if (what)
     {
       (void)hip_ok(hipErrorLaunchFailure, what);

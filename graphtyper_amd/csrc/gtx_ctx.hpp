@@ -62,7 +62,6 @@ struct CallScratch
   // at run time -- gtx_ctx::exact_parts workgroups with a part of it each, then one workgroup with all of it
   uint32_t * d_exact_tasks = nullptr; // three queues of EXACT_TASK_CAP (small parts, large parts, the whole slab)
   uint32_t * d_exact_state = nullptr; // inside d_big_state's allocation: 8 words per launch (same layout) + 8 for what is left
-  uint8_t * d_exact_slab = nullptr;   // gtx_ctx::exact_slab_bytes
   static constexpr uint32_t EXACT_TASK_CAP = 1u << 20;
   static constexpr uint32_t EXACT_LARGE_PARTS = 32, EXACT_LARGE_SITES = 64; // the launch between the small parts and the whole slab
   static constexpr uint32_t EXACT_PART_SITES = 24;       // variant sites a path has room for while a task has a small part of the slab
@@ -93,7 +92,22 @@ struct gtx_ctx
   bool express4_wide = false; // pass 1 runs gtx_align_express4_wide_kernel (express4_prefers_wide, gtx_flat.hpp)
   uint32_t big_blocks = 0;
   bool has_wide_sites = false; // some site has more than 64 alleles: the wide-site passes (alignment, scoring) exist
-  uint64_t exact_slab_bytes = 0; // slab of the exact alignment pass, per call in flight (gtx_params::exact_pass_mb / GTX_EXACT_PASS_MB)
+  // slab of the exact alignment pass (gtx_params::exact_pass_mb / GTX_EXACT_PASS_MB).  The context owns up to EXACT_SLOTS of them,
+  // each with an event behind the exact launches of the last call that used it.  A call takes the first slab whose event is
+  // through, makes a new one while there are fewer than EXACT_SLOTS, else lets its stream wait for one's event, in turn; it
+  // launches on its own stream and records the event again (all under exact_mutex, so that the next call's wait sees this
+  // call's record).  A caller that runs one batch at a time uses one slab, three batches in flight three, sixty-four host
+  // threads four -- not half a gigabyte per call in flight for a pass that nearly always finds its queue empty.
+  uint64_t exact_slab_bytes = 0;
+  struct ExactSlot
+  {
+    uint8_t * slab = nullptr;
+    void * idle = nullptr; // hipEvent_t behind the slab's last exact launches
+  };
+  static constexpr int EXACT_SLOTS = 4;
+  ExactSlot exact_slot[EXACT_SLOTS];
+  int n_exact_slots = 0, next_exact_slot = 0;
+  std::mutex exact_mutex;
   uint32_t exact_cand_cap = 0;   // walk candidates a task of that pass can have alive: exact_cand_cap(widest site of the graph)
   uint32_t exact_parts = 0;      // workgroups (= the most parts of the slab) of the pass' first launch
   bool exact_fixed_parts = false; // GTX_EXACT_PARTS (tests): always that many parts

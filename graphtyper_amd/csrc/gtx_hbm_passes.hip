@@ -195,6 +195,12 @@ char const * launch_hbm_passes(HbmPassArgs const & a, hipStream_t stream)
     if (hipGetLastError() != hipSuccess)
       return "gtx_align_wide_kernel launch";
   }
+  return nullptr;
+}
+
+char const * launch_exact_passes(HbmPassArgs const & a, hipStream_t stream)
+{
+  unsigned long long const arena_words = a.arena_words;
   // the exact pass: what exceeded the tables above, with a small part of the slab per task (up to exact_parts of them side by
   // side), then what did not fit with a large part (up to EXACT_LARGE_PARTS), then -- one workgroup -- with all of it.  Nearly
   // always all three find an empty queue and leave at once.

@@ -46,7 +46,10 @@ struct HbmPassArgs
 };
 
 // Launches the passes on `stream`; returns null, or the name of the launch that failed.
+// the HBM-table pass (and the wide-site pass of a graph that has one), then -- launch_exact_passes, with a.exact_slab chosen by
+// the caller -- the three launches of the exact pass; both return NULL or the name of the launch that failed
 char const * launch_hbm_passes(HbmPassArgs const & a, hipStream_t stream);
+char const * launch_exact_passes(HbmPassArgs const & a, hipStream_t stream);
 
 // bytes of one workspace of the HBM-table / wide-site pass
 uint64_t big_workspace_bytes();

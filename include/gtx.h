@@ -155,7 +155,7 @@ typedef struct gtx_params
   int32_t sam_flag_filter;               /* 3840 */
   int32_t no_second_pass;                /* 1: reads that overflow the main pass' tables keep their status bit (A/B tests) */
   uint32_t big_record_words;             /* capacity of the big-record arena in uint32 words, 0 = 16 Mi */
-  uint32_t exact_pass_mb;                /* MiB of HBM per call in flight for the exact alignment pass (gtx_align_batch: the
+  uint32_t exact_pass_mb;                /* MiB of HBM per slab of the exact alignment pass, of which a context makes one per batch in flight, up to four (gtx_align_batch: the
                                           * pass whose tables have no fixed size), 0 = the GTX_EXACT_PASS_MB environment
                                           * variable, else 512 (1024 for a graph with a site of more than 64 alleles) */
 } gtx_params;
@@ -286,7 +286,7 @@ int gtx_ctx_hint_table(const gtx_ctx *, int which, void * out, uint64_t cap_byte
  * locations) are queued on the device and redone by a second kernel over larger tables in HBM (512 paths, 2048 labels
  * per k-mer), and what exceeds those as well -- the reference has NO limit on the paths and labels of a read
  * (src/typer/genotype_paths.cpp:294-352: a read inside a 280-bp homopolymer chains 249 x 249 labels) -- by the exact pass,
- * whose tables are cut at run time out of a slab of HBM (gtx_params::exact_pass_mb per call in flight; first a small
+ * whose tables are cut at run time out of a slab of HBM (gtx_params::exact_pass_mb; a context makes one per batch in flight, up to four; first a small
  * part of the slab per task, then a large one, then all of it).  Every read therefore gets the result the reference computes; an overflow status (and no
  * paths) is left only on a read that needs more than the configured slab, or whose record finds the big-record arena full
  * (GTX_ST_RECORD_OVERFLOW; a record counts its paths in 16 bits).  gtx_ctx_exact_pass_tasks tells how many tasks went that far.
