@@ -70,6 +70,7 @@ def stream_seed(seed):
         o = Oracle(ref, recs, region_begin=rb)
         for mode in ["lean", "wide"]:
             os.environ["GTX_EXPRESS4"] = mode
+            os.environ["GTX_HINT_BUILD"] = "dense" if mode == "wide" else "lean"
             try:
                 run_stream(harness.EmuBackend(gtx.graph_from_records(ref, recs, region_begin=rb)), o, codes, rec, n_samples=ns)
             except AssertionError as e:
