@@ -45,6 +45,7 @@ struct AlignCfg
 #include "express4.inl"
 } // namespace gtx
 #include "hinted.hpp"
+#include "hinted_long.hpp"
 namespace gtx
 {
 

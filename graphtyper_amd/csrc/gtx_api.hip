@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_WIDE_WAV
 #else
 #define GTX_HINT_REC_SLOT(read) (read)
 #endif
-template <uint32_t WAVES, bool DENSE>
+template <uint32_t WAVES, bool DENSE, uint32_t NK = AlignCfg::KC>
 __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const & ix, uint8_t const * __restrict__ seq, uint32_t seq_stride,
                                             gtx_read_meta const * __restrict__ meta, uint32_t n_reads, uint32_t * __restrict__ records,
                                             uint32_t rec_words, uint32_t force_both, uint32_t * __restrict__ queue1, uint32_t * __restrict__ queue2,
@@ -367,8 +367,10 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
   // graph_dev.hpp) and their meta records (20 B each) are fetched with coalesced loads -- 1 KB and 256 B per instruction
   // instead of 64 scattered lines -- and handed to the lanes through LDS (row pitch 80 B = 20 banks: 16-byte reads of 16
   // neighbouring lanes hit all 64 banks once).
-  constexpr uint32_t ROW_BYTES = HINT_MAX_READ / 2, ROW_VEC = ROW_BYTES / 16, META_WORDS = sizeof(gtx_read_meta) / 4;
-  __shared__ uint4_t s_seq[WAVES][64 * ROW_VEC];
+  constexpr uint32_t ROW_BYTES = HintGeom<NK>::ROW_BYTES, ROW_VEC = ROW_BYTES / 16, META_WORDS = sizeof(gtx_read_meta) / 4;
+  // (rows of 128 bytes -- the eight-k-mer build -- lie one vector apart: 32-word rows would put every lane's word on two banks)
+  constexpr uint32_t ROW_PITCH = NK == AlignCfg::KC ? ROW_VEC : ROW_VEC + 1;
+  __shared__ uint4_t s_seq[WAVES][64 * ROW_PITCH];
   __shared__ uint32_t s_meta[WAVES][64 * META_WORDS];
   __shared__ uint32_t s_count[2][WAVES], s_base[2];
   static_assert(sizeof(gtx_read_meta) % 4 == 0, "meta records are staged word-wise");
@@ -389,14 +391,17 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
     uint4_t const * src = reinterpret_cast<uint4_t const *>(seq + static_cast<uint64_t>(wave_first) * ROW_BYTES);
 #pragma unroll
     for (uint32_t it = 0; it < ROW_VEC; ++it)
-      s_seq[wave][it * 64 + lane] = stream_load(src + it * 64 + lane);
+    {
+      uint32_t const v = it * 64 + lane; // (vector v of the wavefront's 64 rows: row v / ROW_VEC, part v % ROW_VEC)
+      s_seq[wave][ROW_PITCH == ROW_VEC ? v : (v / ROW_VEC) * ROW_PITCH + v % ROW_VEC] = stream_load(src + v);
+    }
   }
   else if (read < n_reads)
   {
     // any other layout (another stride, an unaligned buffer, the last wavefront of a batch): every lane brings its own
     // row, byte-wise as far as the stride goes, zeros behind it
     uint8_t const * src = seq + static_cast<uint64_t>(read) * seq_stride;
-    uint8_t * dst = reinterpret_cast<uint8_t *>(&s_seq[wave][lane * ROW_VEC]);
+    uint8_t * dst = reinterpret_cast<uint8_t *>(&s_seq[wave][lane * ROW_PITCH]);
 #pragma unroll 1
     for (uint32_t k = 0; k < ROW_BYTES; ++k)
       dst[k] = k < seq_stride ? src[k] : static_cast<uint8_t>(0);
@@ -404,7 +409,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
   WaveHip::lds_sync();
   bool fwd = false, fwd2 = false, rev = false, staged_rec = false; // forward task to the express pass / straight to the general pass, reverse task
   uint32_t fwd_flag = 0;
-  static_assert(HINT_STAGE_WORDS == 16 && HINT_STAGE_WORDS * 4 <= HINT_MAX_READ / 2, "a staged record is four 16-byte parts inside the read's row");
+  static_assert(HINT_STAGE_WORDS == 16 && HINT_STAGE_WORDS * 4 <= ROW_BYTES, "a staged record is four 16-byte parts inside the read's row");
   if (read < n_reads)
   {
     gtx_read_meta m;
@@ -447,9 +452,13 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
       // The record goes to the lane's own row in LDS first (the bases are not needed any more once hinted_one writes) and
       // from there to memory four lanes per record: a wavefront's 64 record slots are 64 different cache lines, and what
       // the store path charges is line visits per instruction -- 16 per instruction this way instead of 64.
-      uint32_t * row = reinterpret_cast<uint32_t *>(&s_seq[wave][lane * ROW_VEC]);
+      uint32_t * row = reinterpret_cast<uint32_t *>(&s_seq[wave][lane * ROW_PITCH]);
       bool const can_stage = (rec_words & 3u) == 0 && (reinterpret_cast<uintptr_t>(records) & 15u) == 0; // (16-byte stores into the slots)
-      uint32_t const where = hinted_one<DENSE>(g, ix, row, ROW_BYTES, m, rec, rec_words, can_stage ? row : nullptr);
+      uint32_t where;
+      if constexpr (NK == AlignCfg::KC)
+        where = hinted_one<DENSE>(g, ix, row, ROW_BYTES, m, rec, rec_words, can_stage ? row : nullptr);
+      else
+        where = hinted_long_one<NK>(g, ix, row, ROW_BYTES, m, rec, rec_words, can_stage ? row : nullptr);
       fwd = where == 0;
       fwd2 = where == HINT_TO_GENERAL;
       staged_rec = where == 2;
@@ -481,7 +490,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
         //  denser record layout, not narrower stores.)
         if ((S >> r) & 1ull)
         {
-          uint4_t const v = s_seq[wave][r * ROW_VEC + part];
+          uint4_t const v = s_seq[wave][r * ROW_PITCH + part];
           uint32_t const rd = wave_first + r;
           uint32_t * dst = records + static_cast<uint64_t>(GTX_HINT_REC_SLOT(rd)) * 2 * rec_words;
           stream_store(reinterpret_cast<uint4_t *>(dst + 4 * part), v);
@@ -535,7 +544,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
   GraphView g, IndexView ix, uint8_t const *__restrict__ seq, uint32_t seq_stride, gtx_read_meta const *__restrict__ meta,         \
     uint32_t n_reads, uint32_t *__restrict__ records, uint32_t rec_words, uint32_t force_both, uint32_t *__restrict__ queue1,      \
     uint32_t *__restrict__ queue2, unsigned long long *queue_counts, uint32_t decline_all, uint8_t *__restrict__ task_flags
-#define GTX_HINTED_PASS(W, DENSE) hinted_pass<W, DENSE>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, queue1, queue2, queue_counts, decline_all, task_flags)
+#define GTX_HINTED_PASS(W, ...) hinted_pass<W, __VA_ARGS__>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, queue1, queue2, queue_counts, decline_all, task_flags)
 
 #ifndef GTX_HINT_VGPRS
 #define GTX_HINT_VGPRS 80
@@ -562,6 +571,13 @@ __global__ __launch_bounds__(64 * GTX_HINT_WAVES) __attribute__((amdgpu_num_vgpr
 __global__ __launch_bounds__(64 * GTX_HINT_WAVES) __attribute__((amdgpu_waves_per_eu(GTX_HINT_DENSE_WAVES, GTX_HINT_DENSE_WAVES))) void gtx_align_hinted_dense_kernel(GTX_HINTED_ARGS)
 {
   GTX_HINTED_PASS(GTX_HINT_WAVES, true);
+}
+
+// The build for reads of up to 256 bases (hinted_long.hpp: eight k-mers, rows of 128 bytes, the lean build's proofs): chosen when
+// the rows are longer than 80 bytes.
+__global__ __launch_bounds__(64 * GTX_HINT_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void gtx_align_hinted_long_kernel(GTX_HINTED_ARGS)
+{
+  GTX_HINTED_PASS(GTX_HINT_WAVES, false, 8);
 }
 
 // Pass 1 behind pass 0: express4 over the queue of forward tasks the position-hinted pass declined (four reads per
@@ -1774,7 +1790,8 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
       char const * hb = std::getenv("GTX_HINT_BUILD"); // (test switch: lean | dense build of pass 0; default: dense beside the wide express pass)
       bool const hint_dense = hb && hb[0] == 'd' ? true : hb && hb[0] == 'l' ? false : c->express4_wide;
       uint32_t const hint_threads = 64u * GTX_HINT_WAVES;
-      hipLaunchKernelGGL(hint_dense ? gtx_align_hinted_dense_kernel : gtx_align_hinted_kernel,
+      bool const hint_long = seq_stride > HintGeom<AlignCfg::KC>::ROW_BYTES; // (rows for reads of more than 160 bases: the eight-k-mer build)
+      hipLaunchKernelGGL(hint_long ? gtx_align_hinted_long_kernel : hint_dense ? gtx_align_hinted_dense_kernel : gtx_align_hinted_kernel,
                          dim3((n + hint_threads - 1u) / hint_threads), dim3(hint_threads), 0, st, c->dev_graph, c->dev_index, seq, seq_stride,
                          meta, n, records, rec_words, force_both, queue1, queue2, reinterpret_cast<unsigned long long *>(counters + 2),
                          static_cast<uint32_t>(force != 0 || (eh && eh[0] == 'd'))

@@ -349,8 +349,8 @@ GTX_DEV uint32_t hk_make(uint32_t kind, uint32_t site, uint32_t allele, bool mm,
 // verdict into a decline when a needed half may occur.
 constexpr uint32_t HK_NEED_LEFT = 64u, HK_NEED_RIGHT = 128u;
 
-template <uint32_t I, bool DENSE, class Row>
-GTX_DEV uint32_t hint_kmer(uint2_t const f, Row row, HintCounts const & h, uint32_t & amb2)
+template <uint32_t I, bool DENSE, class Row, class Counts>
+GTX_DEV uint32_t hint_kmer(uint2_t const f, Row row, Counts const & h, uint32_t & amb2) // (Counts: HintCounts, or hinted_long.hpp's for eight k-mers)
 {
   constexpr uint32_t A = (K - 1) * I;
   uint32_t mis = hc_get(h.k[I], HC_MIS), mis_left = hc_get(h.k[I], HC_MIS_LEFT);

@@ -294,7 +294,8 @@ int gtx_ctx_hint_table(const gtx_ctx *, int which, void * out, uint64_t cap_byte
  * the hinted place prove what the global lookups would return; everything else goes on to the passes above unchanged.
  * (Two builds of it: graphs whose sites lie within a k-mer of each other get the one that also takes k-mers over two sites,
  * walks at the read's end over sites with alleles of any length, and reads that carry another allele than the reference's --
- * judged on that allele's path, whose tables continue the linear reference's: gtx_ctx_hint_table 5 / 6.)
+ * judged on that allele's path, whose tables continue the linear reference's: gtx_ctx_hint_table 5 / 6.  Rows of more than
+ * 80 bytes -- reads of up to 256 bases -- get a third build with eight k-mers.)
  * Re-entrant: calls on one context may overlap in time from several host threads and streams, like align_read is called
  * from the reference's worker threads (src/typer/caller.cpp:399-436); each call draws its queues, counters and
  * workspaces from a pool inside the context. */

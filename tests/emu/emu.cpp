@@ -403,9 +403,11 @@ extern "C"
         {
           uint32_t const * row = reinterpret_cast<uint32_t const *>(seq + static_cast<uint64_t>(read) * seq_stride);
           uint32_t * slot = records + static_cast<uint64_t>(read) * 2 * rec_words;
+          // (rows longer than 80 bytes: the eight-k-mer build, as gtx_align_batch chooses gtx_align_hinted_long_kernel)
           uint32_t const where = (force != 0 || (eh && eh[0] == 'd')) ? 0u
-                                 : hint_dense                          ? hinted_one<true>(g, ix, row, seq_stride, m, slot, rec_words)
-                                                                       : hinted_one<false>(g, ix, row, seq_stride, m, slot, rec_words);
+                                 : seq_stride > HintGeom<AlignCfg::KC>::ROW_BYTES ? hinted_long_one<8>(g, ix, row, seq_stride, m, slot, rec_words)
+                                 : hint_dense                                      ? hinted_one<true>(g, ix, row, seq_stride, m, slot, rec_words)
+                                                                                   : hinted_one<false>(g, ix, row, seq_stride, m, slot, rec_words);
           if (where == 0)
           {
             queue1.push_back(read);

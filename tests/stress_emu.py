@@ -28,7 +28,7 @@ def align_seed(seed):
     for kind in ["snp1k", "snp25", "indel", "cluster", "snp100", "snp7", "cfg3", "satellite", "repeat", "neardup"]:
         err = float(rng.choice([0.0, 0.005, 0.03]))
         n_rate = float(rng.choice([0.0, 0.001, 0.01]))
-        read_len = int(rng.choice([100, 125, 150, 151, 187]))
+        read_len = int(rng.choice([100, 125, 150, 151, 187, 200, 250, 256]))  # (> 160: the eight-k-mer build of pass 0)
         rb = int(rng.choice([0, 1000, 1000000]))
         ref, recs, codes, pos = scenarios.synthetic_case(kind, n_ref=50000, n_reads=600 if kind in ("satellite", "repeat") else 1500, region_begin=rb,
                                                        err=err, n_rate=n_rate, seed=seed, read_len=read_len)

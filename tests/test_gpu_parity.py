@@ -342,3 +342,10 @@ def test_both_builds_of_pass_0_write_the_same_records(kind, monkeypatch):
     differ[external, 2:] = False
     assert not differ.any(), np.nonzero(differ.any(1))[0][:5]
     assert done["dense"] >= done["lean"] and (kind == "snp25" or done["dense"] > 1.05 * done["lean"])
+
+
+@pytest.mark.parametrize("kind,read_len", [("snp1k", 250), ("snp100", 256), ("cfg3", 200)])
+def test_long_reads_through_pass_0(kind, read_len):
+    """reads of 161..256 bases: gtx_align_hinted_long_kernel (eight k-mers, rows of 128 bytes), records == oracle with four kinds of hints"""
+    from test_long_reads import long_read_case
+    long_read_case(harness.GpuBackend, kind, read_len, 6000, 0.9 if kind == "snp1k" else 0.2)
