@@ -372,15 +372,14 @@ GTX_DEV uint32_t hint_kmer(uint2_t const f, Row row, Counts const & h, uint32_t 
   auto GR = [&](uint32_t m) { return gr || far_r >= hint_far_need(m); };
   if (amb == 0 && mis == 0)
   {
-    if ((f.x & HINT_TWO) != 0) // (two sites under the k-mer: the dense build's)
-    {
-      GTX_HINT_NOTE(DENSE ? 0 : 1);
-      return hk_make(DENSE ? HINT_K_LABEL : HINT_K_DECLINE, site, 0u, false, (f.x & HINT_PAR) != 0) | HK_TWO |
-             (((f.x >> HINT_ALTIDX_SHIFT) & 255u) << HK_SET_SHIFT);
-    }
-    GTX_HINT_NOTE((f.x & HINT_EXACT_OK) ? 0 : 1); // exact k-mer, but the place is not provably simple
+    if constexpr (DENSE)
+      if ((f.x & HINT_TWO) != 0) // (two sites under the k-mer)
+        return hk_make(HINT_K_LABEL, site, 0u, false, (f.x & HINT_PAR) != 0) | HK_TWO | (((f.x >> HINT_ALTIDX_SHIFT) & 255u) << HK_SET_SHIFT);
+    // (lean build: a place with HINT_TWO is like one without HINT_EXACT_OK)
+    bool const exact_ok = DENSE ? (f.x & HINT_EXACT_OK) != 0 : (f.x & (HINT_EXACT_OK | HINT_TWO)) == HINT_EXACT_OK;
+    GTX_HINT_NOTE(exact_ok ? 0 : 1); // exact k-mer, but the place is not provably simple
     uint32_t const set = (f.x & HINT_MULTI) ? ((f.x >> HINT_ALTIDX_SHIFT) & 255u) << HK_SET_SHIFT : 0u; // (several alleles of a merged site)
-    return hk_make((f.x & HINT_EXACT_OK) ? HINT_K_LABEL : HINT_K_DECLINE, site, 0u, false, (f.x & HINT_PAR) != 0) | set;
+    return hk_make(exact_ok ? HINT_K_LABEL : HINT_K_DECLINE, site, 0u, false, (f.x & HINT_PAR) != 0) | set;
   }
   // ---- a SNP under the k-mer: the read is judged against the key of the allele it carries.  The compare above ran against
   //      the reference allele: a base on the site that is another allele's comes off the counters again.
@@ -1053,7 +1052,7 @@ GTX_DEV uint32_t hinted_on_path(GraphView const & g, IndexView const & ix, Row r
   {
     uint32_t const tail_len = L - pre;
     uint32_t const budget = 2 + tail_len / 11 < 7 ? 2 + tail_len / 11 : 7; // genotype_paths.cpp:505-511
-    uint32_t tail_end = order_of(idx + L - 1u); // (inside one reference node, or over SNP-like sites: the path's own position)
+    uint32_t tail_end = DENSE ? order_of(idx + L - 1u) : 0u; // (dense build; inside one reference node, or over SNP-like sites: the path's own position)
     uint32_t const y = hi + 1 == n_k ? y_end : hi == 0 ? f1.y : hi == 1 ? f2.y : hi == 2 ? f3.y : f4.y;
     uint32_t const room = y & 255u;
     uint32_t got = hc_all(h) - hc_upto(h, hi + 1);
@@ -1121,7 +1120,10 @@ GTX_DEV uint32_t hinted_on_path(GraphView const & g, IndexView const & ix, Row r
     {
       re = L - 1;
       mism += got;
-      end = tail_end;
+      if constexpr (DENSE)
+        end = tail_end;
+      else
+        end += tail_len - 1;
     }
     else
       tail_mask = tail_mask2 = 0; // (the path stays as it is: no site from the walk)
