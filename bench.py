@@ -267,7 +267,7 @@ class DevView:
 class Workload:
     """resident inputs + accumulators of one (graph, reads) pair; step() = align + score [+ reduce] + calls"""
 
-    def __init__(self, torch, gtx, ctx, device, d_seq, d_pos, n_samples, samples=None, hint=True, conn_cap=1 << 24, lanes=1):
+    def __init__(self, torch, gtx, ctx, device, d_seq, d_pos, n_samples, samples=None, hint=True, conn_cap=1 << 24, lanes=1, read_len=READ_LEN):
         """d_seq: [n, stride] BAM nibble rows on the device; they are repacked ONCE into plane rows (gtx_reads_to_planes, the
         layout the kernels read -- what gtx_stream_push writes on the host side) and only those stay resident"""
         self.torch, self.gtx, self.ctx, self.device = torch, gtx, ctx, device
@@ -275,7 +275,7 @@ class Workload:
         n = int(d_seq.shape[0])
         self.n, self.n_samples = n, n_samples
         self.stride = (int(d_seq.shape[1]) + 15) // 16 * 16  # pitch of the plane rows
-        self.hint, self.samples = hint, samples
+        self.hint, self.samples, self.read_len = hint, samples, read_len
         self.rewind = False  # step(): rewind the context's big-record arena first (one step at a time only: the arena is the context's)
         self.sets = []   # resident read sets (bases, meta, score items); step k works on set k mod len(sets)
         self.words = {}  # items' data_ptr -> their compact form (gtx_score_batch_words), or None
@@ -331,7 +331,7 @@ class Workload:
             d_seq = d_planes
         pos_host = d_pos.cpu().numpy().astype(np.int32)
         meta = np.zeros(n, gtx.READ_META)
-        meta["l_qseq"] = READ_LEN
+        meta["l_qseq"] = self.read_len
         meta["flag"] = gtx.FLAG_FORWARD_ONLY  # unpaired reads: no reverse orientation, and nobody reads its (empty) record
         meta["pos"] = pos_host if self.hint else -1
         d_meta = torch.from_numpy(meta.view(np.uint8).reshape(n, gtx.READ_META.itemsize).copy()).to(self.device)
@@ -1056,6 +1056,15 @@ def extra_cfg3(args, torch, gtx, synth, device, ref, kind="cfg3"):
     return extra_workload(args, torch, gtx, synth, device, ref, recs, 30, True, what)
 
 
+def extra_long_reads(args, torch, gtx, synth, device, ref):
+    """The main workload's graph (SNP every 1 kb, one sample) with reads of 250 bases (2 x 250 libraries): rows of 128 bytes, the
+    eight-k-mer build of the position-hinted pass (gtx_align_hinted_long_kernel); the express pass takes five k-mers, so what
+    that pass declines is a task of the general pass."""
+    recs = synth.make_snp_records(ref, 1000, seed=7, region_begin=REGION_BEGIN)
+    return extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False,
+                          "long reads: 1 sample, %d reads of 250 bases, 1 Mb, SNP every 1 kb, max %d alleles per site", read_len=250)
+
+
 def extra_repeats(args, torch, gtx, synth, device, ref):
     """The main workload's shape (one sample, SNP every 1 kb) on a reference that is NOT i.i.d.: homopolymer runs, short tandem
     repeats, satellite arrays and near-duplicate segments planted into it (synth.plant_repeats) -- what a real chromosome has.
@@ -1184,7 +1193,7 @@ def extra_cfg5(args, torch, gtx, synth, device, n_pairs_per_sv=160, background_p
     return out
 
 
-def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_all, what, lanes=None, big_record_words=0):
+def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_all, what, lanes=None, big_record_words=0, read_len=READ_LEN):
     n = args.extra_reads
     lanes = args.lanes if lanes is None else lanes
     t0 = time.time()
@@ -1193,17 +1202,17 @@ def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_al
     t0 = time.time()
     ctx = gtx.Context(graph, device=0, big_record_words=big_record_words)
     t_ctx = time.time() - t0
-    codes, pos = synth.make_reads(ref, recs, n, read_len=READ_LEN, seed=5, region_begin=REGION_BEGIN)
+    codes, pos = synth.make_reads(ref, recs, n, read_len=read_len, seed=5, region_begin=REGION_BEGIN)
     order = np.argsort(pos, kind="stable")
     codes, pos = codes[order], pos[order]
     d_seq = torch.from_numpy(gtx.pack_nibbles(codes)).to(device)
     samples = np.random.default_rng(3).integers(0, n_samples, size=n).astype(np.uint32)
     w = Workload(torch, gtx, ctx, device, d_seq, torch.from_numpy(pos), n_samples, samples=samples if n_samples > 1 else None,
-                 hint=not args.no_hint, lanes=lanes)
+                 hint=not args.no_hint, lanes=lanes, read_len=read_len)
     w.rewind = lanes == 1 and big_record_words != 0
     w.staggered = args.schedule == "staggered" and len(w.lanes) >= 2  # (the same schedule as the main workload, chosen the same way)
     if args.read_sets > 1:  # a second set of reads: the steps alternate
-        codes2, pos2 = synth.make_reads(ref, recs, n, read_len=READ_LEN, seed=6, region_begin=REGION_BEGIN)
+        codes2, pos2 = synth.make_reads(ref, recs, n, read_len=read_len, seed=6, region_begin=REGION_BEGIN)
         order2 = np.argsort(pos2, kind="stable")
         w.add_reads(torch.from_numpy(gtx.pack_nibbles(codes2[order2])).to(device), torch.from_numpy(pos2[order2]))
     steps = 9 if len(w.lanes) > 1 else 4
@@ -1507,6 +1516,10 @@ def main(argv=None):
             cfg.setdefault("extra", {})["cfg3_clusters"] = extra_cfg3(args, torch, gtx, synth, device, ref, "clusters")
         except Exception as e:  # the extra line must never cost the main one
             cfg.setdefault("extra", {})["cfg3"] = {"error": repr(e)}
+        try:
+            cfg.setdefault("extra", {})["long_reads"] = extra_long_reads(args, torch, gtx, synth, device, ref)
+        except Exception as e:
+            cfg.setdefault("extra", {})["long_reads"] = {"error": repr(e)}
         try:
             cfg.setdefault("extra", {})["repeats"] = extra_repeats(args, torch, gtx, synth, device, ref)
         except Exception as e:

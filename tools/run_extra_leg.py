@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One `extra` leg of bench.py on its own (for kernel traces: rocprofv3 --kernel-trace --stats -- python tools/run_extra_leg.py repeats).
-Usage: python tools/run_extra_leg.py {repeats|cfg5|cfg3|clusters} [bench.py arguments]"""
+Usage: python tools/run_extra_leg.py {repeats|long_reads|cfg5|cfg3|clusters} [bench.py arguments]"""
 import json
 import os
 import sys
@@ -18,6 +18,8 @@ device = torch.device("cuda", 0)
 ref, records, ref_str = bench.cfg2_graph_inputs(synth, args.region_len, args.snp_every)
 if leg == "repeats":
     out = bench.extra_repeats(args, torch, gtx, synth, device, ref)
+elif leg == "long_reads":
+    out = bench.extra_long_reads(args, torch, gtx, synth, device, ref)
 elif leg == "cfg5":
     out = bench.extra_cfg5(args, torch, gtx, synth, device)
 else:
