@@ -508,8 +508,8 @@ class Workload:
         # (setup, not steps of the run: the first calls that are in flight together allocate their scratch inside the library)
         self.calibration = None
         if stag:
-            self.steps_staggered(n_lanes)
-            self.steps_done -= n_lanes
+            self.steps_staggered(2 * n_lanes)  # (twice round: every lane's scratch and the context's exact-pass slabs exist afterwards)
+            self.steps_done -= 2 * n_lanes
             torch.cuda.synchronize()
             # Setup as well: which schedule runs faster here -- a few steps each way, the slower rank decides for all.  (Steps in
             # flight depend on how the runtime folds streams onto hardware queues and on what else the host does; one step at
@@ -521,8 +521,8 @@ class Workload:
                 torch.cuda.synchronize()
                 self.steps_done -= k
                 return (time.perf_counter() - t) / k
-            t_stag = min(timed(self.steps_staggered, 2 * n_lanes) for _ in range(2))
-            t_one = min(timed(lambda k: [self.step(0) for _ in range(k)], 4) for _ in range(2))
+            t_stag = min(timed(self.steps_staggered, 2 * n_lanes) for _ in range(3))
+            t_one = min(timed(lambda k: [self.step(0) for _ in range(k)], 4) for _ in range(3))
             both = torch.tensor([t_stag, t_one], dtype=torch.float64, device=self.device)
             if dist is not None:
                 dist.all_reduce(both, op=dist.ReduceOp.MAX)

@@ -423,7 +423,15 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
     else
       m = meta[read];
     uint32_t const len = m.l_qseq;
-    uint32_t * rec = records + static_cast<uint64_t>(GTX_HINT_REC_SLOT(read)) * 2 * rec_words;
+    // (the slot's address is made where it is needed -- the rare branches below, a record that is not staged -- behind a barrier
+    //  the optimiser cannot move it over: kept from here it costs two registers across the whole read, and with 80 that was six
+    //  spilled ones and 2 % of the kernel)
+    auto rec_at = [&]() -> uint32_t *
+    {
+      uint32_t r = GTX_HINT_REC_SLOT(read);
+      GTX_PIN(r);
+      return records + static_cast<uint64_t>(r) * 2 * rec_words;
+    };
     bool const outside = len < 2 * K - 1 || len > AlignCfg::MAX_READ; // align_read (alignment.cpp:331-363): stay unaligned
     rev = !outside && needs_reverse(m, force_both != 0);
     // (GTX_FLAG_FORWARD_ONLY in the read's own flag word: the caller will never look at the reverse record of a read whose
@@ -432,6 +440,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
     if (!rev && (m.flag & GTX_FLAG_FORWARD_ONLY) == 0)
     {
       uint32_t const h0 = len > AlignCfg::MAX_READ ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
+      uint32_t * const rec = rec_at();
       if ((rec_words & 1u) == 0 && (reinterpret_cast<uintptr_t>(records) & 7u) == 0)
         *reinterpret_cast<uint2_t *>(rec + rec_words) = uint2_t{h0, len << 16}; // (one store instruction, not two)
       else
@@ -442,6 +451,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
     }
     if (outside)
     {
+      uint32_t * const rec = rec_at();
       rec[0] = len > AlignCfg::MAX_READ ? (static_cast<uint32_t>(GTX_ST_RECORD_OVERFLOW) << 16) : 0u;
       rec[1] = len << 16;
     }
@@ -456,13 +466,13 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
       bool const can_stage = (rec_words & 3u) == 0 && (reinterpret_cast<uintptr_t>(records) & 15u) == 0; // (16-byte stores into the slots)
       uint32_t where;
       if constexpr (NK == AlignCfg::KC)
-        where = hinted_one<DENSE>(g, ix, row, ROW_BYTES, m, rec, rec_words, can_stage ? row : nullptr);
+        where = hinted_one<DENSE>(g, ix, row, ROW_BYTES, m, rec_at, rec_words, can_stage ? row : nullptr);
       else
-        where = hinted_long_one<NK>(g, ix, row, ROW_BYTES, m, rec, rec_words, can_stage ? row : nullptr);
+        where = hinted_long_one<NK>(g, ix, row, ROW_BYTES, m, rec_at(), rec_words, can_stage ? row : nullptr);
       fwd = where == 0;
       fwd2 = where == HINT_TO_GENERAL;
       staged_rec = where == 2;
-      fwd_flag = (where == 0 || where == HINT_TO_GENERAL) ? 0u : ((where == 2 ? row[1] : rec[1]) >> 31);
+      fwd_flag = (where == 0 || where == HINT_TO_GENERAL) ? 0u : ((where == 2 ? row[1] : rec_at()[1]) >> 31);
     }
     // the dense side array (gtx_align_batch_flags): what this pass settles -- the forward task it finished, the reverse
     // task that is not aligned at all; the queued tasks get theirs from gtx_task_flags_fixup_kernel behind the last pass

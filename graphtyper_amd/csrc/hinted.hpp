@@ -28,6 +28,8 @@
 // Per read: 20 B meta + 80 B bases + ~84 B of reference nibbles + 6 flag words, all but the bases shared with the
 // neighbouring reads of the sorted stream; no hash probe at all for an error-free read.  Included from align_core.hpp.
 #pragma once
+#include <type_traits>
+
 #include "graph_dev.hpp"
 
 namespace gtx
@@ -725,9 +727,20 @@ constexpr uint32_t HINT_TO_GENERAL = 3;
 // length, allele windows): more registers, the same records where both builds finish a read.
 // hinted_on_path: the read against the path that table position `idx` lies on -- the linear reference, or (pw != NULL, dense
 // build) the allele window *pw, whose position 0 is table position `wbase`.  mm_all: the compare's mismatches over the read.
-template <bool DENSE, class Row>
+// where a record that is not staged goes: a pointer, or something that yields it when asked (the kernel: the slot's address is
+// worked out where it is needed -- two registers less across the whole read)
+template <class R>
+GTX_DEV uint32_t * hint_rec_ptr(R const & r)
+{
+  if constexpr (std::is_pointer<R>::value)
+    return r;
+  else
+    return r();
+}
+
+template <bool DENSE, class Row, class Rec>
 GTX_DEV uint32_t hinted_on_path(GraphView const & g, IndexView const & ix, Row row, uint32_t seq_stride, gtx_read_meta const & m, uint32_t idx,
-                                HintWindow const * pw, uint32_t wbase, uint32_t * rec, uint32_t rec_words, uint32_t * stage, uint32_t & mm_all)
+                                HintWindow const * pw, uint32_t wbase, Rec rec_at, uint32_t rec_words, uint32_t * stage, uint32_t & mm_all)
 {
   uint32_t const L = m.l_qseq;
   // graph order of table position p (of this path)
@@ -1299,9 +1312,9 @@ GTX_DEV uint32_t hinted_on_path(GraphView const & g, IndexView const & ix, Row r
   if (2 + np * path_words > rec_words)
     return false;
   bool const to_stage = stage != nullptr && rec_words >= HINT_STAGE_WORDS && 2 + (np ? np : 1u) * path_words <= HINT_STAGE_WORDS;
+  uint32_t * rec = to_stage ? stage : hint_rec_ptr(rec_at);
   if (to_stage)
   {
-    rec = stage;
 #pragma unroll
     for (uint32_t k = 2; k < HINT_STAGE_WORDS; ++k)
       rec[k] = 0u;
@@ -1340,9 +1353,9 @@ GTX_DEV uint32_t hinted_on_path(GraphView const & g, IndexView const & ix, Row r
 // dense build, when that is declined -- on the window of the allele the read seems to carry: of the alternative alleles of
 // the (up to four) sites under the read that have windows, the one whose path the read differs least from, if that is less
 // than it differs from the linear reference.  Whatever path is tried, a record is only written when every lookup on it is proven.
-template <bool DENSE, class Row>
+template <bool DENSE, class Row, class Rec>
 GTX_DEV uint32_t hinted_one(GraphView const & g, IndexView const & ix, Row row, uint32_t seq_stride, gtx_read_meta const & m,
-                            uint32_t * rec, uint32_t rec_words, uint32_t * stage = nullptr)
+                            Rec rec, uint32_t rec_words, uint32_t * stage = nullptr)
 {
   uint32_t const L = m.l_qseq;
   if (L < 2 * K - 1 || L > HINT_MAX_READ || m.pos < 0 || ix.n_hint == 0)
