@@ -33,6 +33,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+# Steps in flight need their streams on different hardware queues.  The runtime folds a process's streams onto GPU_MAX_HW_QUEUES of
+# them (4 by default), in the order they are made; with four, the stream of the position-hinted pass and the stream of the queues
+# behind it now and then share one (the library's scratch makes side streams of its own as calls overlap), and the schedule runs at
+# the one-at-a-time rate (with 2 queues always: 1.18 against 0.79 ms per step).  Eight leave room.  (A host application sets the
+# same variable before it initialises HIP; an explicit setting of the caller's wins.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ALGO_BYTES_PER_READ = 3296  # B(L) = 86 + 796*n_k + (L - 31*n_k) at L=150, n_k=4
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 USE_TASK_FLAGS = os.environ.get("GTX_BENCH_FLAGS", "1") != "0"  # the dense side array of the records (A/B switch)

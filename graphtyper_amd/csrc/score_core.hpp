@@ -14,7 +14,10 @@ namespace gtx
 {
 constexpr uint16_t F_PAIRED = 1, F_PROPER_PAIR = 2, F_UNMAPPED = 4, F_SEQ_REVERSED = 16, F_FIRST_IN_PAIR = 64, F_MAPQ_BAD = 4096;
 constexpr uint32_t NO_COVERAGE = 0xFFFFu, MULTI_ALT_COVERAGE = 0xFFFEu, MULTI_REF_COVERAGE = 0xFFFDu; // haplotype.hpp:86-88
-constexpr uint32_t SCORE_MAX_HAPS = 8;       // distinct variant sites one read can touch in the main scoring pass (per-thread tables)
+#ifndef GTX_SCORE_MAX_HAPS
+#define GTX_SCORE_MAX_HAPS 8
+#endif
+constexpr uint32_t SCORE_MAX_HAPS = GTX_SCORE_MAX_HAPS; // distinct variant sites one read can touch in the main scoring pass (per-thread tables)
 constexpr uint32_t SCORE_MAX_HAPS_BIG = 1024; // ... in the second pass (tables in HBM)
 constexpr uint32_t SCORE_MAX_HAPS_WIDE = 128; // ... in the second pass of a graph with a site of more than 64 alleles (wide sets)
 
