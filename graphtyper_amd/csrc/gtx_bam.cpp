@@ -23,11 +23,13 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <limits>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace
@@ -822,6 +824,8 @@ struct File
     return true;
   }
 };
+
+#include "gtx_shrink.inl"
 } // namespace
 
 struct gtx_reads
@@ -1029,4 +1033,197 @@ extern "C" void gtx_reads_close(gtx_reads * r)
   if (!r)
     return;
   delete r;
+}
+
+// ---- the pre-filter (gtx_shrink.inl) ------------------------------------------------------------------------------------
+
+extern "C" void gtx_shrink_params_default(gtx_shrink_params * p)
+{
+  if (!p)
+    return;
+  *p = gtx_shrink_params{};
+  p->max_frag_len = 1000;        // options.hpp:63-69
+  p->min_num_matching = 55;
+  p->filter_mapq0 = 1;
+  p->no_filter_on_coverage = 0;  // options.hpp:50
+  p->min_read_len = 75;
+  p->min_read_len_low_mapq = 94;
+  p->min_unpaired_read_len = 94;
+  p->sam_flag_filter = 3840;     // options.hpp:90
+  p->as_filter_threshold = 40;
+  p->avg_cov_by_readlen = 0.0;   // unknown
+  p->change_read_names = 1;      // (release builds of the reference, bamshrink.cpp:24-28)
+  p->compress_level = 1;         // "wb1" (bamshrink.cpp:1263)
+}
+
+extern "C" int gtx_bam_shrink(const char * bam_in, const char * const * chroms, const int32_t * begins, const int32_t * ends, uint32_t n_intervals,
+                              const gtx_shrink_params * params, const char * bam_out, gtx_shrink_stats * stats)
+{
+  gtx_shrink_stats st{};
+  if (stats)
+    *stats = st;
+  if (!bam_in || !chroms || !begins || !ends || n_intervals == 0 || !bam_out)
+  {
+    gtx::g_last_error = "gtx_bam_shrink: bad argument (at least one interval is needed, bamshrink.cpp:1296-1300)";
+    return GTX_ERR_ARG;
+  }
+  gtx_shrink_params par;
+  if (params)
+    par = *params;
+  else
+    gtx_shrink_params_default(&par);
+  shrink::Limits lim;
+  lim.max_frag = par.max_frag_len;
+  lim.min_matching = par.min_num_matching;
+  lim.min_len = par.min_read_len;
+  lim.min_len_low_mapq = par.min_read_len_low_mapq;
+  lim.min_len_unpaired = par.min_unpaired_read_len;
+  lim.as_threshold = par.as_filter_threshold;
+  lim.drop_mapq0 = par.filter_mapq0 != 0;
+  lim.rename = par.change_read_names != 0;
+  lim.flag_filter = static_cast<uint32_t>(par.sam_flag_filter);
+  // bamshrink.cpp:1268-1271 and :710-711: without a coverage the default one caps the bins and nothing counts as "super high"
+  double const cov = par.avg_cov_by_readlen > 0.0 ? par.avg_cov_by_readlen : 0.30000001;
+  lim.deep_factor = par.avg_cov_by_readlen > 0.0 ? 2 : 1000;
+  lim.bin_cap = par.no_filter_on_coverage ? (std::numeric_limits<int>::max() / 10) : static_cast<long>(cov * 50.0 * 2.5);
+
+  std::string const path(bam_in);
+  shrink::Header head;
+  std::string err;
+  {
+    Bgzf fp;
+    if (!fp.open(path))
+    {
+      gtx::g_last_error = "could not open " + path;
+      return GTX_ERR_IO;
+    }
+    if (!shrink::read_header(fp, head, err, path))
+    {
+      gtx::g_last_error = err;
+      return GTX_ERR_UNSUPPORTED;
+    }
+  }
+  std::vector<int32_t> tids(n_intervals);
+  for (uint32_t i = 0; i < n_intervals; ++i)
+  {
+    std::string const chrom = chroms[i] ? chroms[i] : "";
+    auto it = std::find_if(head.refs.begin(), head.refs.end(), [&](auto const & r) { return r.first == chrom; });
+    if (it == head.refs.end() || begins[i] < 0 || ends[i] < begins[i])
+    {
+      gtx::g_last_error = path + ": no contig " + chrom + " (or an interval that ends in front of its begin)";
+      return GTX_ERR_ARG;
+    }
+    tids[i] = static_cast<int32_t>(it - head.refs.begin());
+  }
+  bool const one_contig = n_intervals == 1;
+  shrink::Header out_head = head;
+  if (one_contig) // only this contig stays in the header (bamshrink.cpp:1304-1335)
+  {
+    out_head.text = shrink::one_contig_text(head.text, head.refs[static_cast<size_t>(tids[0])].first);
+    out_head.refs.assign(1, head.refs[static_cast<size_t>(tids[0])]);
+  }
+  std::FILE * out = std::fopen(bam_out, "wb");
+  if (!out)
+  {
+    gtx::g_last_error = std::string("could not create ") + bam_out;
+    return GTX_ERR_IO;
+  }
+  std::vector<uint8_t> sink, packed;
+  auto flush = [&](bool last) -> bool
+  {
+    // whole 0xff00-byte members while more is coming; the rest stays in the sink
+    size_t const take = last ? sink.size() : sink.size() / 0xff00u * 0xff00u;
+    if (take == 0 && !last)
+      return true;
+    packed.resize(take + take / 8 + (take / 0xff00u + 2) * 64);
+    uint64_t n = 0;
+    if (gtx_bgzf_compress(sink.data(), take, par.compress_level, last ? 1 : 0, packed.data(), packed.size(), &n) != GTX_OK)
+      return false;
+    sink.erase(sink.begin(), sink.begin() + static_cast<long>(take));
+    return std::fwrite(packed.data(), 1, n, out) == n;
+  };
+  shrink::append_header(out_head, sink);
+  long read_num = 0;
+  int status = GTX_OK;
+  std::vector<uint8_t> buf;
+  for (uint32_t i = 0; i < n_intervals && status == GTX_OK; ++i)
+  {
+    // the records the reference asks its index for (bamshrink.cpp:681-699): those that overlap [first - pad, last + pad)
+    int64_t const pad = lim.max_frag - 100;
+    int64_t const from = std::max<int64_t>(static_cast<int64_t>(begins[i]) - pad, 0), to = static_cast<int64_t>(ends[i]) + pad;
+    Bgzf fp;
+    shrink::Header again;
+    if (!fp.open(path) || !shrink::read_header(fp, again, err, path))
+    {
+      gtx::g_last_error = "could not read " + path;
+      status = GTX_ERR_IO;
+      break;
+    }
+    bool any = true;
+    uint64_t voffset = 0;
+    if (bai_start(path, tids[i], from, to, any, voffset) || csi_start(path, tids[i], from, to, any, voffset))
+    {
+      if (!any)
+        continue;
+      if (!fp.seek(voffset))
+      {
+        gtx::g_last_error = path + ": the index points outside the file";
+        status = GTX_ERR_IO;
+        break;
+      }
+    }
+    shrink::Slice slice(lim, begins[i], ends[i], one_contig, read_num, sink, st);
+    for (;;)
+    {
+      shrink::Read r;
+      int const got = shrink::next_read(fp, buf, r);
+      if (got == 0)
+        break;
+      if (got < 0)
+      {
+        gtx::g_last_error = path + ": damaged BAM record";
+        status = GTX_ERR_IO;
+        break;
+      }
+      if (r.tid != tids[i])
+      {
+        if (r.tid > tids[i] || r.tid < 0)
+          break; // sorted file: behind the contig
+        continue;
+      }
+      if (r.pos >= to)
+        break;
+      int64_t span = 0;
+      for (size_t c = 0; c < r.cigar.size(); ++c)
+        if (r.op(c) == shrink::OP_M || r.op(c) == shrink::OP_D || r.op(c) == shrink::OP_N || r.op(c) == shrink::OP_EQ || r.op(c) == shrink::OP_X)
+          span += r.cnt(c);
+      if (static_cast<int64_t>(r.pos) + (span > 0 && !r.is(shrink::F_UNMAPPED) ? span : 1) <= from)
+        continue;
+      ++st.records_read;
+      slice.take(std::move(r));
+      if (sink.size() > (8u << 20) && !flush(false))
+      {
+        gtx::g_last_error = std::string("could not write ") + bam_out;
+        status = GTX_ERR_IO;
+        break;
+      }
+    }
+    if (status == GTX_OK)
+      slice.finish();
+  }
+  if (status == GTX_OK && !flush(true))
+  {
+    gtx::g_last_error = std::string("could not write ") + bam_out;
+    status = GTX_ERR_IO;
+  }
+  if (std::fclose(out) != 0 && status == GTX_OK)
+  {
+    gtx::g_last_error = std::string("could not write ") + bam_out;
+    status = GTX_ERR_IO;
+  }
+  if (status != GTX_OK)
+    std::remove(bam_out);
+  else if (stats)
+    *stats = st;
+  return status;
 }

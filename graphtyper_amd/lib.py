@@ -28,7 +28,8 @@ EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy"
            "gtx_comm_destroy", "gtx_ctx_kernel_times", "gtx_ref_depth_finalize", "gtx_vcf_records", "gtx_scores_replay", "gtx_reads_open", "gtx_reads_info",
            "gtx_reads_sample_name", "gtx_reads_next", "gtx_reads_close", "gtx_align_batch_flags", "gtx_score_batch_flags", "gtx_score_batch_words", "gtx_item_words",
            "gtx_pack_planes", "gtx_reads_to_planes", "gtx_align_batch_planes", "gtx_align_batch_planes_staged", "gtx_stream_set_planes", "gtx_device_cache_release",
-           "gtx_disc_create", "gtx_disc_destroy", "gtx_disc_events_batch", "gtx_disc_first_pass", "gtx_vcf_header", "gtx_bgzf_compress"]
+           "gtx_disc_create", "gtx_disc_destroy", "gtx_disc_events_batch", "gtx_disc_first_pass", "gtx_vcf_header", "gtx_bgzf_compress",
+           "gtx_shrink_params_default", "gtx_bam_shrink"]
 
 
 class GraphView(C.Structure):
@@ -37,6 +38,17 @@ class GraphView(C.Structure):
                 ("ref_first_var", C.c_void_p), ("var_order", C.c_void_p), ("var_len", C.c_void_p),
                 ("var_dna_off", C.c_void_p), ("var_out_ref", C.c_void_p), ("dna", C.c_void_p), ("dna_len", C.c_uint64),
                 ("event_off", C.c_void_p), ("event_val", C.c_void_p)]
+
+
+class ShrinkParams(C.Structure):
+    _fields_ = [("max_frag_len", C.c_int32), ("min_num_matching", C.c_int32), ("filter_mapq0", C.c_int32), ("no_filter_on_coverage", C.c_int32),
+                ("min_read_len", C.c_int32), ("min_read_len_low_mapq", C.c_int32), ("min_unpaired_read_len", C.c_int32), ("sam_flag_filter", C.c_int32),
+                ("as_filter_threshold", C.c_int64), ("avg_cov_by_readlen", C.c_double), ("change_read_names", C.c_int32), ("compress_level", C.c_int32)]
+
+
+class ShrinkStats(C.Structure):
+    _fields_ = [("records_read", C.c_uint64), ("records_written", C.c_uint64), ("pairs_kept", C.c_uint64), ("singles_kept", C.c_uint64),
+                ("dropped_by_depth", C.c_uint64)]
 
 
 class Params(C.Structure):
@@ -165,6 +177,10 @@ def lib():
         L.gtx_reads_next.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
         L.gtx_reads_close.argtypes = [C.c_void_p]
         L.gtx_reads_close.restype = None
+        L.gtx_shrink_params_default.argtypes = [C.POINTER(ShrinkParams)]
+        L.gtx_shrink_params_default.restype = None
+        L.gtx_bam_shrink.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(ShrinkParams),
+                                     C.c_char_p, C.POINTER(ShrinkStats)]
         L.gtx_scores_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.gtx_stream_create.argtypes = [C.POINTER(Params), C.c_uint32, C.POINTER(C.c_void_p)]
@@ -459,6 +475,27 @@ def bgzf_compress(data, level=-1, with_eof=True):
     out = C.create_string_buffer(int(n.value) + 1)
     check(lib().gtx_bgzf_compress(src, len(data), level, int(with_eof), out, n.value, C.byref(n)))
     return out.raw[:int(n.value)]
+
+
+def shrink_params(**kw):
+    """gtx_shrink_params with the reference's defaults, fields overridden by keyword"""
+    p = ShrinkParams()
+    lib().gtx_shrink_params_default(C.byref(p))
+    for k, v in kw.items():
+        assert hasattr(p, k), k
+        setattr(p, k, v)
+    return p
+
+
+def bam_shrink(bam_in, intervals, bam_out, params=None):
+    """gtx_bam_shrink; intervals: [(chrom, begin, end)] 0-based, both inside.  Returns the stats as a dict."""
+    n = len(intervals)
+    chroms = (C.c_char_p * n)(*[c.encode() for c, _, _ in intervals])
+    begins = (C.c_int32 * n)(*[b for _, b, _ in intervals])
+    ends = (C.c_int32 * n)(*[e for _, _, e in intervals])
+    st = ShrinkStats()
+    check(lib().gtx_bam_shrink(bam_in.encode(), chroms, begins, ends, n, C.byref(params) if params is not None else None, bam_out.encode(), C.byref(st)))
+    return {k: int(getattr(st, k)) for k, _ in ShrinkStats._fields_}
 
 
 class VcfRequest(C.Structure):

@@ -21,6 +21,7 @@
  *                                 (every per-read effect is an integer addition)  src/typer/vcf_operations.cpp:366-374
  *   gtx_vcf_records     replaces  Vcf::add_haplotype + generate_infos + write_record   src/typer/vcf.cpp:767-1151,1507-1611
  *   gtx_reads_*         replaces  HtsReader / HtsParallelReader for BAM files            src/utilities/hts_reader.cpp:17-303
+ *   gtx_bam_shrink      replaces  bamshrink (the read pre-filter)                        src/utilities/bamshrink.cpp:667-1371
  *   gtx_graph_build     replaces  Graph::add_genomic_region                     src/graph/graph.cpp:41-339
  *   gtx_graph_from_files replaces construct_graph (small variants, structural variants) src/graph/constructor.cpp:1597-1777
  *
@@ -646,6 +647,46 @@ int gtx_reads_info(const gtx_reads *, uint32_t * n_samples, uint32_t * n_read_gr
 const char * gtx_reads_sample_name(const gtx_reads *, uint32_t i);
 int gtx_reads_next(gtx_reads *, gtx_stream_record * recs, uint8_t * seq, uint32_t seq_stride, uint32_t cap, uint32_t * n);
 void gtx_reads_close(gtx_reads *);
+
+/* ---- the read pre-filter in front of the ingest (host).  gtx_bam_shrink replaces gyper::bamshrink / bamshrink_multi
+ * (src/utilities/bamshrink.cpp:1248-1371; the work is qualityFilterSlice2, :667-1045): from a coordinate-sorted BAM file it
+ * writes a BAM file with the records around the intervals that the caller is going to look at -- pairs and single reads that
+ * pass the mapping-quality / clipping / matching-bases / base-quality filters, adapters cut off pairs whose fragment is not
+ * longer than a read, reads dropped by their AS / XS / WS scores, Ns cut off the ends, at most max_bin_sum pairs per 50
+ * positions, only the RG / AS / XS / WS tags, two-level qualities, short read names -- sorted by begin position, in the
+ * reference's order.  Intervals are the reference's (chrom, begin, end): 0-based, both inside; records are taken from
+ * max_frag_len - 100 positions around each.  With ONE interval the output header keeps the @HD / @RG lines and that contig
+ * only and the records get contig number 0 (:909-922, :1304-1335); with several the header is copied.  The index beside the
+ * file (.bai / .csi, as for gtx_reads_open) is used when there is one; without one the file is scanned (the reference
+ * refuses).  gtx_shrink_params_default fills in the reference's option defaults (include/graphtyper/utilities/
+ * options.hpp:50,63-69,90); avg_cov_by_readlen <= 0 means "unknown": the default bin cap, and no record dropped as
+ * "super high depth" (:1268-1271).  The output is read back with gtx_reads_open.  Not read: CRAM. */
+typedef struct gtx_shrink_params
+{
+  int32_t max_frag_len;           /* bamshrink_max_fraglen, 1000 */
+  int32_t min_num_matching;       /* bamshrink_min_matching, 55 */
+  int32_t filter_mapq0;           /* !bamshrink_is_not_filtering_mapq0, 1 */
+  int32_t no_filter_on_coverage;  /* 0 */
+  int32_t min_read_len;           /* bamshrink_min_readlen, 75 */
+  int32_t min_read_len_low_mapq;  /* bamshrink_min_readlen_low_mapq, 94 */
+  int32_t min_unpaired_read_len;  /* bamshrink_min_unpair_readlen, 94 */
+  int32_t sam_flag_filter;        /* 3840 */
+  int64_t as_filter_threshold;    /* bamshrink_as_filter_threshold, 40 */
+  double avg_cov_by_readlen;      /* the sample's average coverage / read length; <= 0: unknown */
+  int32_t change_read_names;      /* 1: names become short counters (what a release build of the reference does) */
+  int32_t compress_level;         /* BGZF level of the output, 1 */
+} gtx_shrink_params;
+typedef struct gtx_shrink_stats
+{
+  uint64_t records_read;      /* records of the intervals' surroundings */
+  uint64_t records_written;
+  uint64_t pairs_kept;        /* pairs that went to the output queue */
+  uint64_t singles_kept;      /* single reads that did */
+  uint64_t dropped_by_depth;  /* reads dropped because their bin was full */
+} gtx_shrink_stats;
+void gtx_shrink_params_default(gtx_shrink_params *);
+int gtx_bam_shrink(const char * bam_in, const char * const * chroms, const int32_t * begins, const int32_t * ends, uint32_t n_intervals,
+                   const gtx_shrink_params * params /* NULL: defaults */, const char * bam_out, gtx_shrink_stats * stats /* may be NULL */);
 
 /* ---- variant discovery, first slice.  Replaces, per sample, the first pass over the reads of a region:
  * run_first_pass (src/typer/caller.cpp:488-1186) -- the SNP and indel events its CIGAR walk reads off the alignments

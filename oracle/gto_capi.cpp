@@ -4,6 +4,7 @@
 #include "gto_vcf.hpp"
 #include "gto_sv.hpp"
 #include "gto_discovery.hpp"
+#include "gto_shrink.hpp"
 
 #include <cctype>
 #include <memory>
@@ -774,5 +775,47 @@ extern "C"
     out[2] = m.end;
     out[3] = static_cast<uint32_t>(m.var_order.size());
     out[4] = static_cast<uint32_t>(m.nums.size());
+  }
+
+  // bamshrink over one interval (gto_shrink.hpp).  records: the BAM record stream of the whole file (block_size + record, ...);
+  // opts: maxFragLen, minNumMatching, is_filtering_mapq0, no_filter_on_coverage, minReadLen, minReadLenMapQ0, minUnpairedReadLen,
+  // as_filter_threshold, SUPER_HI_DEPTH, sam_flag_filter, change_read_names; read_num goes in and out (intervals of one call
+  // of the reference share it).  Returns the number of bytes of the output stream (-1: malformed input, -2: out too small).
+  long gto_bam_shrink(uint8_t const * records, long len, int rid, int interval_begin, int interval_end, long const * opts, double avg_cov,
+                      int is_single_contig, long * read_num, uint8_t * out, long cap)
+  {
+    gto_shrink::Options o;
+    o.maxFragLen = static_cast<int>(opts[0]);
+    o.minNumMatching = static_cast<int>(opts[1]);
+    o.is_filtering_mapq0 = opts[2] != 0;
+    o.no_filter_on_coverage = opts[3] != 0;
+    o.minReadLen = static_cast<int>(opts[4]);
+    o.minReadLenMapQ0 = static_cast<int>(opts[5]);
+    o.minUnpairedReadLen = static_cast<int>(opts[6]);
+    o.as_filter_threshold = opts[7];
+    o.SUPER_HI_DEPTH = opts[8];
+    o.sam_flag_filter = static_cast<int>(opts[9]);
+    o.change_read_names = opts[10] != 0;
+    o.avgCovByReadLen = avg_cov;
+    std::vector<gto_shrink::Record> in, res;
+    if (!gto_shrink::decode_records(records, static_cast<size_t>(len), in))
+      return -1;
+    gto_shrink::shrink_interval(o, in, rid, interval_begin, interval_end, *read_num, is_single_contig != 0, res);
+    std::vector<uint8_t> bytes;
+    for (auto const & r : res)
+      gto_shrink::encode_record(r, bytes);
+    if (static_cast<long>(bytes.size()) > cap)
+      return -2;
+    std::memcpy(out, bytes.data(), bytes.size());
+    return static_cast<long>(bytes.size());
+  }
+
+  long gto_shrink_header(char const * text, char const * chrom, char * out, long cap)
+  {
+    std::string const h = gto_shrink::single_contig_header(text, chrom);
+    if (static_cast<long>(h.size()) + 1 > cap)
+      return -2;
+    std::memcpy(out, h.c_str(), h.size() + 1);
+    return static_cast<long>(h.size());
   }
 }

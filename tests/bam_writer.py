@@ -40,12 +40,12 @@ def aux_field(tag, typ, value):
     return t + struct.pack("<" + {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[typ], value)
 
 
-def record(name, flag, tid, pos, mapq, cigar, mtid, mpos, tlen, codes, aux=()):
+def record(name, flag, tid, pos, mapq, cigar, mtid, mpos, tlen, codes, aux=(), qual=None):
     """cigar: [(op, len)], op in 'MIDNSHP=X'; aux: [(tag, type, value)]"""
     nm = name.encode() + b"\0"
     cig = b"".join(struct.pack("<I", (n << 4) | "MIDNSHP=X".index(op)) for op, n in cigar)
     body = struct.pack("<iiBBHHHIiii", tid, pos, len(nm), mapq, 4680, len(cigar), flag, len(codes), mtid, mpos, tlen)
-    body += nm + cig + pack_seq(codes) + bytes([30] * len(codes)) + b"".join(aux_field(*a) for a in aux)
+    body += nm + cig + pack_seq(codes) + (bytes([30] * len(codes)) if qual is None else bytes(int(q) for q in qual)) + b"".join(aux_field(*a) for a in aux)
     return struct.pack("<i", len(body)) + body
 
 

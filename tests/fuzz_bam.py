@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fuzz of gtx_reads_* (graphtyper_amd/csrc/gtx_bam.cpp), not collected by pytest (tests/test_bam_ingest.py runs a few seeds of
+"""Fuzz of gtx_reads_* and gtx_bam_shrink (graphtyper_amd/csrc/gtx_bam.cpp, gtx_shrink.inl), not collected by pytest (tests/test_bam_ingest.py runs a few seeds of
 it): corrupted BAM payloads (re-compressed, so the BGZF layer is intact and the record parser sees the damage), corrupted
 headers, truncated payloads / files, corrupted BGZF bytes.  Each case runs in a subprocess; anything but a clean exit with
 records or a GTX_ERR_* is a finding.
@@ -26,6 +26,11 @@ try:
     print("ok", n)
 except Exception as e:
     print("err", str(e)[:80])
+try:  # the pre-filter reads whole records (names, qualities, tags) from the same file
+    st = gtx.bam_shrink(sys.argv[1], [("chrA", 100, 2000)], sys.argv[1] + ".out", gtx.shrink_params(min_read_len=20, min_num_matching=10))
+    print("ok shrink", st["records_written"])
+except Exception as e:
+    print("err shrink", str(e)[:80])
 '''
 
 def payload(rng, n=60):
@@ -72,10 +77,12 @@ def run(seed0, seed1, tmp="/tmp"):
         open(path, "wb").write(data)
         region = "chrA:100-2000" if seed % 3 == 0 else ""
         p = subprocess.run([sys.executable, "-c", CHILD, path, region, os.path.dirname(HERE)], capture_output=True, text=True, timeout=120)
-        if p.returncode != 0 or not (p.stdout.startswith("ok") or p.stdout.startswith("err")):
+        if p.returncode != 0 or not (p.stdout.startswith("ok") or p.stdout.startswith("err")) or "shrink" not in p.stdout:
             bad += 1
             print("FINDING seed", seed, "kind", kind, "rc", p.returncode, p.stdout[:100], p.stderr[-300:])
         os.remove(path)
+        if os.path.exists(path + ".out"):
+            os.remove(path + ".out")
     return bad
 
 

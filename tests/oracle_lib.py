@@ -32,7 +32,7 @@ def to_dna_str(d, k=32):
 def build():
     if os.environ.get("GTO_LIB"):  # (tests/oracle_mutants/run_audit.py: a deliberately broken oracle, to see the tests notice)
         return os.environ["GTO_LIB"]
-    src = [os.path.join(ORACLE_DIR, f) for f in ("gto.hpp", "gto_capi.cpp", "gto_vcf.hpp", "gto_sv.hpp", "gto_discovery.hpp")]
+    src = [os.path.join(ORACLE_DIR, f) for f in ("gto.hpp", "gto_capi.cpp", "gto_vcf.hpp", "gto_sv.hpp", "gto_discovery.hpp", "gto_shrink.hpp")]
     so = os.path.join(ORACLE_DIR, "libgto.so")
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src if os.path.exists(s)):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])

@@ -1,4 +1,4 @@
-// sanitizer driver for gtx_reads_* (test tooling, not part of the product)
+// sanitizer driver for gtx_reads_* and gtx_bam_shrink (test tooling, not part of the product)
 #include "gtx.h"
 #include <cstdio>
 #include <cstdint>
@@ -27,6 +27,20 @@ int main(int argc, char ** argv)
       while (gtx_reads_next(r, recs.data(), seq.data(), 80, 64, &n) == 0 && n != 0)
         total += n;
       gtx_reads_close(r);
+    }
+    // the pre-filter over the same file (whole records: names, qualities, tags)
+    gtx_shrink_params par;
+    gtx_shrink_params_default(&par);
+    par.min_read_len = 20;
+    par.min_num_matching = 10;
+    char const * chroms[2] = {"chrA", "chr1"};
+    int32_t const begins[2] = {100, 9000}, ends[2] = {2000, 40000};
+    std::string const out = std::string(argv[a]) + ".shrunk";
+    for (int which = 0; which < 2; ++which)
+    {
+      gtx_shrink_stats st;
+      if (gtx_bam_shrink(argv[a], chroms + which, begins + which, ends + which, 1, &par, out.c_str(), &st) == 0)
+        std::remove(out.c_str());
     }
   }
   std::printf("ok\n");
