@@ -1077,7 +1077,7 @@ static bool dev_alloc(T *& dst, size_t n, char const * what, bool zero = false)
   void * p = nullptr;
   if (!hip_ok(gtx::dev_malloc(&p, (n ? n : 1) * sizeof(T)), what))
     return false;
-  if (zero && !hip_ok(hipMemset(p, 0, (n ? n : 1) * sizeof(T)), what))
+  if (zero && !hip_ok(gtx::dev_zero(p, (n ? n : 1) * sizeof(T)), what))
   {
     (void)gtx::dev_free(p);
     return false;
@@ -1339,7 +1339,7 @@ int ctx_upload(gtx_ctx & c, int device)
   {
     c.dev_allocs.push_back(pf);
     v.prof = static_cast<unsigned long long *>(pf);
-    ok = hip_ok(hipMemset(pf, 0, 32 * sizeof(unsigned long long)), "profile counters");
+    ok = hip_ok(gtx::dev_zero(pf, 32 * sizeof(unsigned long long)), "profile counters");
   }
   void * ef = nullptr;
   ok = ok && hip_ok(gtx::dev_malloc(&ef, sizeof(uint32_t)), "error flag");
@@ -1347,7 +1347,7 @@ int ctx_upload(gtx_ctx & c, int device)
   {
     c.dev_allocs.push_back(ef);
     c.d_error_flag = static_cast<uint32_t *>(ef);
-    ok = hip_ok(hipMemset(ef, 0, sizeof(uint32_t)), "error flag");
+    ok = hip_ok(gtx::dev_zero(ef, sizeof(uint32_t)), "error flag");
   }
   lap("counters");
   hipDeviceProp_t prop;
@@ -1392,7 +1392,7 @@ int ctx_upload(gtx_ctx & c, int device)
     {
       c.dev_allocs.push_back(p);
       c.d_arena_cursor = static_cast<unsigned long long *>(p);
-      ok = hip_ok(hipMemset(p, 0, sizeof(unsigned long long)), "arena cursor");
+      ok = hip_ok(gtx::dev_zero(p, sizeof(unsigned long long)), "arena cursor");
     }
   }
   if (!ok)
@@ -2256,7 +2256,7 @@ extern "C" int gtx_scores_replay(gtx_ctx * c, const gtx_score_item * d_items, ui
             hip_ok(hipMemcpy(d_marked, marked.data(), marked.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "replay bitmap");
   for (int attempt = 0; ok && attempt < 2; ++attempt) // (a second launch when the log was too small)
   {
-    ok = dev_alloc(d_log, cap, "replay log") && hip_ok(hipMemset(d_count, 0, sizeof(uint32_t)), "replay count");
+    ok = dev_alloc(d_log, cap, "replay log") && hip_ok(gtx::dev_zero(d_count, sizeof(uint32_t)), "replay count");
     if (!ok)
       break;
     ScoreAcc a;

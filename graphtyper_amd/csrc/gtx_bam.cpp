@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -37,7 +38,7 @@ namespace
 // BGZF: a series of gzip members of at most 64 KB, each with its compressed size in a "BC" extra field (SAM spec 4.1); a
 // virtual offset = (file offset of a member) << 16 | offset in its data.  Members are inflated one at a time (raw
 // deflate), which is what makes seeking by virtual offset possible -- and what makes them independent: inflating is nine
-// tenths of the time of reading a BAM file, so a reader keeps up to RING members in flight.  The calling thread reads
+// tenths of the time of reading a BAM file, so a reader keeps up to RING members in flight (refilled by halves).  The calling thread reads
 // the compressed members ahead (sequential file reads), a small team of worker threads shared by all open readers
 // inflates them, and the caller takes them in file order; a member nobody has started on when the caller needs it is
 // inflated by the caller itself, so a reader is never slower than without the team (many readers on many host threads
@@ -102,17 +103,24 @@ public:
     }
     delete gone;
   }
-  // hands a queued job to the team (no team: it stays queued and its reader inflates it when it gets there)
-  static void submit(InflateJob * j)
+  // hands queued jobs to the team (no team: they stay queued and their reader inflates them when it gets there).  The
+  // caller wakes at most ONE sleeping worker, and only when nobody is looking at the queue already: waking a thread costs the
+  // caller a system call -- a third of a millisecond where the host is a virtual machine and the worker's core is halted,
+  // as long as inflating the member takes -- so workers wake each other (run()) and linger a little before they sleep.
+  static void submit(InflateJob * const * jobs, size_t n)
   {
     InflateTeam * t = self();
-    if (!t || t->workers_.empty())
+    if (!t || t->workers_.empty() || n == 0)
       return;
+    bool wake;
     {
       std::lock_guard<std::mutex> lock(t->m_);
-      t->queue_.push_back(j);
+      t->queue_.insert(t->queue_.end(), jobs, jobs + n);
+      t->pending_.store(t->queue_.size(), std::memory_order_release);
+      wake = t->sleepers_ > 0 && t->lingering_.load(std::memory_order_acquire) == 0;
     }
-    t->cv_.notify_one();
+    if (wake)
+      t->cv_.notify_one();
   }
   // forgets the jobs of a reader that goes away (none of them is running any more: the reader has waited for those)
   static void forget(InflateJob const * first, InflateJob const * last)
@@ -122,11 +130,14 @@ public:
       return;
     std::lock_guard<std::mutex> lock(t->m_);
     t->queue_.erase(std::remove_if(t->queue_.begin(), t->queue_.end(), [&](InflateJob * j) { return j >= first && j < last; }), t->queue_.end());
+    t->pending_.store(t->queue_.size(), std::memory_order_release);
   }
 
 private:
   explicit InflateTeam(unsigned n)
   {
+    if (char const * e = std::getenv("GTX_BGZF_LINGER_US"))
+      linger_us_ = std::max(0, std::atoi(e));
     for (unsigned i = 0; i < n; ++i)
       workers_.emplace_back([this] { run(); });
   }
@@ -135,6 +146,7 @@ private:
     {
       std::lock_guard<std::mutex> lock(m_);
       stop_ = true;
+      stop_flag_.store(true);
     }
     cv_.notify_all();
     for (auto & w : workers_)
@@ -145,18 +157,45 @@ private:
     for (;;)
     {
       InflateJob * j = nullptr;
+      bool wake_next = false;
       {
         std::unique_lock<std::mutex> lock(m_);
-        cv_.wait(lock, [this] { return stop_ || !queue_.empty(); });
+        if (queue_.empty() && !stop_)
+        {
+          // nothing to do: look at the queue for a little while without sleeping (two workers at most do; a reader hands
+          // over its next members within that time when it is reading at all), then sleep
+          if (linger_us_ > 0 && lingering_.load(std::memory_order_relaxed) < 2)
+          {
+            lingering_.fetch_add(1, std::memory_order_acq_rel);
+            lock.unlock();
+            auto const until = std::chrono::steady_clock::now() + std::chrono::microseconds(linger_us_);
+            while (pending_.load(std::memory_order_acquire) == 0 && !stop_flag_.load(std::memory_order_relaxed) &&
+                   std::chrono::steady_clock::now() < until)
+              std::this_thread::yield();
+            lock.lock();
+            lingering_.fetch_sub(1, std::memory_order_acq_rel);
+          }
+          if (queue_.empty() && !stop_)
+          {
+            ++sleepers_;
+            cv_.wait(lock, [this] { return stop_ || !queue_.empty(); });
+            --sleepers_;
+          }
+        }
         if (stop_)
           return;
         j = queue_.front();
         queue_.pop_front();
+        pending_.store(queue_.size(), std::memory_order_release);
+        wake_next = !queue_.empty() && sleepers_ > 0; // more than this worker can take at once: the next worker is woken from here
         int expect = 0;
         if (!j->state.compare_exchange_strong(expect, 1)) // (its reader got there first)
-          continue;
+          j = nullptr;
       }
-      inflate_member(*j);
+      if (wake_next)
+        cv_.notify_one();
+      if (j)
+        inflate_member(*j);
     }
   }
   static std::mutex & gate()
@@ -174,11 +213,16 @@ private:
     static InflateTeam * t = nullptr;
     return t;
   }
+  int linger_us_ = 300;                  // GTX_BGZF_LINGER_US
   std::mutex m_;
   std::condition_variable cv_;
   std::deque<InflateJob *> queue_;
   std::vector<std::thread> workers_;
   bool stop_ = false;
+  int sleepers_ = 0;                     // workers inside cv_.wait (under m_)
+  std::atomic<int> lingering_{0};        // workers polling pending_ before they sleep
+  std::atomic<size_t> pending_{0};       // queue_.size() for those
+  std::atomic<bool> stop_flag_{false};
 };
 
 class Bgzf
@@ -238,7 +282,7 @@ public:
   }
 
 private:
-  static constexpr unsigned RING = 16; // members in flight per reader (1 MB of data at most)
+  static constexpr unsigned RING = 32; // members in flight per reader (2 MB of data at most)
   enum Ahead { MORE, END, BROKEN };
 
   // the next member of the file into job j (compressed bytes only); END at the end of the file, BROKEN on a malformed member
@@ -288,6 +332,10 @@ private:
   // reads members ahead until the ring is full or the file ends / breaks (which is reported when the caller gets there)
   void fill()
   {
+    if (tail_ - head_ > RING / 2) // (refilled by halves: the members go to the team in one hand-over)
+      return;
+    InflateJob * fresh[RING];
+    size_t n = 0;
     while (ahead_ == MORE && tail_ - head_ < RING)
     {
       InflateJob & j = ring_[tail_ % RING];
@@ -299,8 +347,9 @@ private:
       }
       j.state.store(0);
       ++tail_;
-      InflateTeam::submit(&j);
+      fresh[n++] = &j;
     }
+    InflateTeam::submit(fresh, n);
   }
   bool next_block()
   {

@@ -15,5 +15,13 @@ namespace gtx
 {
 hipError_t dev_malloc(void ** p, size_t bytes); // on the current device
 hipError_t dev_free(void * p);                  // back to the cache (NULL is fine)
+// Zeroes device memory and returns when it IS zero.  (hipMemset on device memory returns before the fill has run, and the fill
+// runs on the null stream: a kernel on a non-blocking stream -- every stream PyTorch makes -- is not ordered behind it, so a
+// counter block "zeroed" by a plain hipMemset can be cleared in the middle of the first call that counts in it.)
+inline hipError_t dev_zero(void * p, size_t bytes)
+{
+  hipError_t const e = hipMemsetAsync(p, 0, bytes, nullptr);
+  return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
 void dev_cache_release();                       // hipFree everything the cache holds
 } // namespace gtx

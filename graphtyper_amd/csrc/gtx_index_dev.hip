@@ -51,7 +51,7 @@ struct Pool
       return nullptr;
     fine = ok_hip(gtx::dev_malloc(&p, (n ? n : 1) * sizeof(T)), what);
     if (fine && zero)
-      fine = ok_hip(hipMemset(p, 0, (n ? n : 1) * sizeof(T)), what);
+      fine = ok_hip(gtx::dev_zero(p, (n ? n : 1) * sizeof(T)), what);
     if (p)
       temps.push_back(p);
     return static_cast<T *>(p);

@@ -143,7 +143,7 @@ extern "C"
     uint64_t const reduced = s.stat_u64 * 8 + s.u32_total() * 4;
     uint64_t const bytes = reduced + 2 * 4 + static_cast<uint64_t>(conn_cap) * 6 * 4;
     void * p = nullptr;
-    if (hipSetDevice(c->device) != hipSuccess || gtx::dev_malloc(&p, bytes ? bytes : 8) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess)
+    if (hipSetDevice(c->device) != hipSuccess || gtx::dev_malloc(&p, bytes ? bytes : 8) != hipSuccess || gtx::dev_zero(p, bytes) != hipSuccess)
     {
       if (p)
         (void)gtx::dev_free(p);
