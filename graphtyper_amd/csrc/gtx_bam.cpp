@@ -14,6 +14,7 @@
 // not depend on it).  A region starts from the .bai or .csi when there is one (else the file is scanned from its head).  Not read:
 // CRAM (needs htslib's codecs).
 #include "gtx_ctx.hpp"
+#include "gtx_inflate.hpp"
 
 #include <zlib.h>
 
@@ -55,9 +56,12 @@ struct InflateJob
 
 void inflate_member(InflateJob & j)
 {
-  j.ok = false;
+  // the library's own decoder (gtx_inflate.hpp: built for whole members of known size, 1.5-1.9 x zlib's rate); what it refuses --
+  // a damaged member, or a code whose tables do not fit its fixed ones -- gets zlib's verdict.  GTX_INFLATE=zlib: zlib only.
+  static bool const own = !(std::getenv("GTX_INFLATE") && std::strcmp(std::getenv("GTX_INFLATE"), "zlib") == 0);
+  j.ok = own && gtx::inflate_raw(j.comp.data(), static_cast<size_t>(j.clen), j.data.data(), j.data.size());
   z_stream z{};
-  if (inflateInit2(&z, -15) == Z_OK)
+  if (!j.ok && inflateInit2(&z, -15) == Z_OK)
   {
     z.next_in = j.comp.data();
     z.avail_in = static_cast<uInt>(j.clen);
@@ -1275,4 +1279,18 @@ extern "C" int gtx_bam_shrink(const char * bam_in, const char * const * chroms, 
   else if (stats)
     *stats = st;
   return status;
+}
+
+extern "C" int gtx_inflate_raw(const void * in, uint64_t in_len, void * out, uint64_t out_len)
+{
+  if ((in_len && !in) || (out_len && !out))
+    return GTX_ERR_ARG;
+  std::vector<uint8_t> padded(in_len + 8, 0); // (the decoder loads 8 bytes at a time: a BGZF member has its CRC32 and ISIZE there)
+  if (in_len)
+    std::memcpy(padded.data(), in, in_len);
+  uint8_t nothing = 0;
+  if (gtx::inflate_raw(padded.data(), in_len, out_len ? static_cast<uint8_t *>(out) : &nothing, out_len))
+    return GTX_OK;
+  gtx::g_last_error = "gtx_inflate_raw: not a DEFLATE stream of the given size";
+  return GTX_ERR_IO;
 }

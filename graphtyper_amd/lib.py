@@ -29,7 +29,7 @@ EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy"
            "gtx_reads_sample_name", "gtx_reads_next", "gtx_reads_close", "gtx_align_batch_flags", "gtx_score_batch_flags", "gtx_score_batch_words", "gtx_item_words",
            "gtx_pack_planes", "gtx_reads_to_planes", "gtx_align_batch_planes", "gtx_align_batch_planes_staged", "gtx_stream_set_planes", "gtx_device_cache_release",
            "gtx_disc_create", "gtx_disc_destroy", "gtx_disc_events_batch", "gtx_disc_first_pass", "gtx_vcf_header", "gtx_bgzf_compress",
-           "gtx_shrink_params_default", "gtx_bam_shrink"]
+           "gtx_shrink_params_default", "gtx_bam_shrink", "gtx_inflate_raw"]
 
 
 class GraphView(C.Structure):
@@ -177,6 +177,7 @@ def lib():
         L.gtx_reads_next.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
         L.gtx_reads_close.argtypes = [C.c_void_p]
         L.gtx_reads_close.restype = None
+        L.gtx_inflate_raw.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64]
         L.gtx_shrink_params_default.argtypes = [C.POINTER(ShrinkParams)]
         L.gtx_shrink_params_default.restype = None
         L.gtx_bam_shrink.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(ShrinkParams),
@@ -475,6 +476,13 @@ def bgzf_compress(data, level=-1, with_eof=True):
     out = C.create_string_buffer(int(n.value) + 1)
     check(lib().gtx_bgzf_compress(src, len(data), level, int(with_eof), out, n.value, C.byref(n)))
     return out.raw[:int(n.value)]
+
+
+def inflate_raw(data, out_len):
+    """gtx_inflate_raw -> bytes (raises GtxError on a stream that is not valid or not of that size)"""
+    out = C.create_string_buffer(max(out_len, 1))
+    check(lib().gtx_inflate_raw(data, len(data), out, out_len))
+    return out.raw[:out_len]
 
 
 def shrink_params(**kw):

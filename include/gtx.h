@@ -510,6 +510,11 @@ int gtx_vcf_header(const gtx_vcf_header_request *, char * out, uint64_t cap, uin
  * bgzf_stream.hpp) makes of the text it is given.  level: zlib's 0..9, -1 = default.  out may be NULL with cap 0 to ask for
  * the size. */
 int gtx_bgzf_compress(const void * in, uint64_t in_len, int level, int with_eof, void * out, uint64_t cap, uint64_t * out_len);
+/* The other direction for ONE member's payload: the raw DEFLATE stream `in` (RFC 1951; what lies between a BGZF member's
+ * header and its CRC32) into exactly out_len bytes -- the decoder the BAM readers use (graphtyper_amd/csrc/gtx_inflate.hpp:
+ * whole members of known size, 64-bit bit buffer, one table look-up per symbol; the reference reads through htslib's
+ * bgzf.c, which calls libdeflate or zlib).  GTX_ERR_IO: not a valid stream of that size. */
+int gtx_inflate_raw(const void * in, uint64_t in_len, void * out, uint64_t out_len);
 
 /* ---- multi-GPU: reads shard over the GPUs of a node (one process per GPU, graph + index replicated), the accumulators
  * are summed once per region.  The reference's counterpart is the merge of per-thread / per-pool results
