@@ -871,6 +871,30 @@ def extra_pipeline(args, torch, gtx, synth, device, ctx, ref, records, n=16_000_
                                               "vcf_lines_differing": sum(a != b for a, b in zip(text.split("\n"), want_text.split("\n")))})}
 
 
+def extra_shrink(args, torch, gtx, synth, device, ref, records, n=2_000_000):
+    """The read pre-filter in front of the ingest (gtx_bam_shrink = the reference's bamshrink; host only): one sample's BAM file
+    of `n` reads over the region -> the filtered BAM, on one host thread, wall clock.  Once with the reference's depth cap (at this
+    depth it drops most reads before they are written) and once without it (every read is trimmed, re-tagged and written)."""
+    import tempfile
+    d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=4242, device=device, REGION_LEN=args.region_len, err_rate=args.err, n_rate=args.nrate)
+    codes = unpack_nibbles(d_seq.cpu().numpy(), READ_LEN)
+    pos = d_pos.cpu().numpy()
+    tmp = tempfile.mkdtemp(prefix="gtx_shrink_")
+    src, dst = os.path.join(tmp, "in.bam"), os.path.join(tmp, "out.bam")
+    synth.write_fixed_bam(src, "chr20", 64444167, "SAMP0000", codes, pos)
+    out = {"what": "gtx_bam_shrink of one BAM file (%d reads of %d bases over %d bp) on one host thread: inflate, pair / single-read filters, "
+                   "trimming, tag rewrite, depth bins, deflate level 1" % (n, READ_LEN, args.region_len), "bam_bytes_in": os.path.getsize(src)}
+    for name, kw in (("with_depth_cap", dict(avg_cov_by_readlen=0.3)), ("without_depth_cap", dict(no_filter_on_coverage=1))):
+        t0 = time.perf_counter()
+        st = gtx.bam_shrink(src, [("chr20", REGION_BEGIN, REGION_BEGIN + args.region_len - 1)], dst, gtx.shrink_params(**kw))
+        dt = time.perf_counter() - t0
+        out[name] = {"seconds": round(dt, 3), "records_per_s": st["records_read"] / max(dt, 1e-9), "bam_bytes_out": os.path.getsize(dst), **st}
+    for q in (src, dst):
+        os.remove(q)
+    os.rmdir(tmp)
+    return out
+
+
 def extra_regions(args, torch, gtx, synth, device, ref, n_regions=20, region_len=50000, n_samples=30, depth=30):
     """What `graphtyper genotype` does per region (the reference genotypes 50 kb regions, src/main.cpp:684), on the clock from the
     variant records to the VCF text: 20 consecutive 50 kb regions, 30 samples at 30x (300 k reads per region, resident in HBM as
@@ -1519,6 +1543,10 @@ def main(argv=None):
                                                                               "vcf_equals_resident_run", "bam_write_s_before_the_clock", "error")}
         except Exception as e:  # the extra line must never cost the main one
             cfg.setdefault("extra", {})["pipeline"] = {"error": repr(e)}
+        try:
+            cfg.setdefault("extra", {})["shrink"] = extra_shrink(args, torch, gtx, synth, device, ref, records)
+        except Exception as e:
+            cfg.setdefault("extra", {})["shrink"] = {"error": repr(e)}
     if n_gpus == 1 and n_samples == 1 and not args.no_extra:
         try:
             cfg.setdefault("extra", {})["regions"] = extra_regions(args, torch, gtx, synth, device, ref)

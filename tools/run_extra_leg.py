@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One `extra` leg of bench.py on its own (for kernel traces: rocprofv3 --kernel-trace --stats -- python tools/run_extra_leg.py repeats).
-Usage: python tools/run_extra_leg.py {repeats|long_reads|cfg5|cfg3|clusters|pipeline|pipeline64} [bench.py arguments]"""
+Usage: python tools/run_extra_leg.py {repeats|long_reads|cfg5|cfg3|clusters|pipeline|pipeline64|shrink} [bench.py arguments]"""
 import json
 import os
 import sys
@@ -24,6 +24,8 @@ elif leg in ("pipeline", "pipeline64"):  # BAM files -> VCF text on 16 / 64 host
     ctx = gtx.Context(gtx.graph_from_records(ref_str, records, region_begin=bench.REGION_BEGIN), device=0)
     out = bench.extra_pipeline(args, torch, gtx, synth, device, ctx, ref, records, **(dict(n=16_000_000, threads=64) if leg == "pipeline64" else {}))
     out.pop("what", None)
+elif leg == "shrink":
+    out = bench.extra_shrink(args, torch, gtx, synth, device, ref, records)
 elif leg == "cfg5":
     out = bench.extra_cfg5(args, torch, gtx, synth, device)
 else:
