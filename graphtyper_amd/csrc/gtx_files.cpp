@@ -31,6 +31,13 @@
 
 namespace gtx
 {
+// gtx_tabix.cpp
+bool tabix_start(std::string const & vcf_path, std::string const & chrom, int64_t begin, int64_t end, bool & any, uint64_t & voffset);
+gzFile gz_open_at(std::string const & path, uint64_t voffset);
+} // namespace gtx
+
+namespace gtx
+{
 void graph_set_sv_table(gtx_graph * g, std::string table); // gtx_graph.cpp
 }
 
@@ -787,15 +794,29 @@ extern "C" int gtx_graph_from_files(const char * fasta_path, const char * vcf_pa
   SvBuilder svb{fasta_path, reg.chr, &n_sv, std::string(), &sv_table};
   if (vcf_path && vcf_path[0])
   {
-    gzFile z = gzopen(vcf_path, "rb"); // reads plain text as well; bgzip files are concatenated gzip members
-    if (!z)
+    // With a .tbi / .csi beside a bgzip file the scan starts where the index allows a record of the region and ends behind the
+    // region (the reference reads the region's records through tabix: open_tabix / setRegion, constructor.cpp:163-176); without
+    // one the whole file is read.
+    gzFile z = nullptr;
+    bool indexed = false, any = false;
+    uint64_t voffset = 0;
+    if (gtx::tabix_start(vcf_path, reg.chr, reg.begin, reg.end, any, voffset))
+    {
+      indexed = true;
+      if (any)
+        z = gtx::gz_open_at(vcf_path, voffset);
+    }
+    if (!indexed)
+      z = gzopen(vcf_path, "rb"); // reads plain text as well; bgzip files are concatenated gzip members
+    if (!z && !(indexed && !any))
     {
       g_last_error = std::string("gtx_graph_from_files: cannot open VCF ") + vcf_path;
       return GTX_ERR_ARG;
     }
     std::string line;
     std::vector<char> buf(1 << 16);
-    bool more = true;
+    bool more = z != nullptr;
+    bool seen_contig = false;
     while (more)
     {
       line.clear();
@@ -816,8 +837,15 @@ extern "C" int gtx_graph_from_files(const char * fasta_path, const char * vcf_pa
         continue;
       std::vector<std::string> const col = split(line, '\t');
       if (col.size() < 5 || col[0] != reg.chr) // (the reference reads the contig's records through tabix)
+      {
+        if (indexed && seen_contig)
+          break; // (an indexed file is sorted: behind the contig)
         continue;
+      }
+      seen_contig = true;
       long const pos0 = std::atol(col[1].c_str()) - 1;
+      if (indexed && pos0 >= reg.end)
+        break; // behind the region
       std::string const & ref = col[3];
       // constructor.cpp:1660-1662: the record has to lie inside the region
       if (pos0 < reg.begin || pos0 + static_cast<long>(ref.size()) > reg.end)
@@ -879,7 +907,8 @@ extern "C" int gtx_graph_from_files(const char * fasta_path, const char * vcf_pa
         recs.push_back(std::move(r));
       }
     }
-    gzclose(z);
+    if (z)
+      gzclose(z);
   }
   // constructor.cpp:1749-1757 (operator< compares positions only; a stable sort keeps file order among equals)
   if (!std::is_sorted(recs.begin(), recs.end(), [](Rec const & a, Rec const & b) { return a.pos < b.pos; }))

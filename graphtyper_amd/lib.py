@@ -29,7 +29,7 @@ EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy"
            "gtx_reads_sample_name", "gtx_reads_next", "gtx_reads_close", "gtx_align_batch_flags", "gtx_score_batch_flags", "gtx_score_batch_words", "gtx_item_words",
            "gtx_pack_planes", "gtx_reads_to_planes", "gtx_align_batch_planes", "gtx_align_batch_planes_staged", "gtx_stream_set_planes", "gtx_device_cache_release",
            "gtx_disc_create", "gtx_disc_destroy", "gtx_disc_events_batch", "gtx_disc_first_pass", "gtx_vcf_header", "gtx_bgzf_compress",
-           "gtx_shrink_params_default", "gtx_bam_shrink", "gtx_inflate_raw"]
+           "gtx_shrink_params_default", "gtx_bam_shrink", "gtx_inflate_raw", "gtx_tabix_build", "gtx_tabix_start"]
 
 
 class GraphView(C.Structure):
@@ -178,6 +178,8 @@ def lib():
         L.gtx_reads_close.argtypes = [C.c_void_p]
         L.gtx_reads_close.restype = None
         L.gtx_inflate_raw.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.gtx_tabix_build.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
+        L.gtx_tabix_start.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         L.gtx_shrink_params_default.argtypes = [C.POINTER(ShrinkParams)]
         L.gtx_shrink_params_default.restype = None
         L.gtx_bam_shrink.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(ShrinkParams),
@@ -483,6 +485,18 @@ def inflate_raw(data, out_len):
     out = C.create_string_buffer(max(out_len, 1))
     check(lib().gtx_inflate_raw(data, len(data), out, out_len))
     return out.raw[:out_len]
+
+
+def tabix_build(vcf_gz, min_shift=0, index_path=None):
+    """gtx_tabix_build: <vcf>.tbi (min_shift 0) or a .csi"""
+    check(lib().gtx_tabix_build(vcf_gz.encode(), min_shift, index_path.encode() if index_path else None))
+
+
+def tabix_start(vcf_gz, chrom, begin, end):
+    """gtx_tabix_start -> virtual offset, or None when the index knows of no record there"""
+    v, any_ = C.c_uint64(), C.c_int()
+    check(lib().gtx_tabix_start(vcf_gz.encode(), chrom.encode(), begin, end, C.byref(v), C.byref(any_)))
+    return int(v.value) if any_.value else None
 
 
 def shrink_params(**kw):

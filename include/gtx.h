@@ -516,6 +516,18 @@ int gtx_bgzf_compress(const void * in, uint64_t in_len, int level, int with_eof,
  * bgzf.c, which calls libdeflate or zlib).  GTX_ERR_IO: not a valid stream of that size. */
 int gtx_inflate_raw(const void * in, uint64_t in_len, void * out, uint64_t out_len);
 
+/* Coordinate index of a bgzip-compressed VCF file.  gtx_tabix_build replaces Vcf::write_tbi_index (src/typer/vcf.cpp:1308-1321:
+ * htslib's tbx_index_build with the VCF preset): min_shift 0 writes <vcf>.tbi (bins of 16 kb .. 512 Mb and the linear index),
+ * min_shift > 0 a .csi of that geometry (the reference's --csi uses 14) -- to index_path when given.  The file has to be
+ * BGZF (gtx_bgzf_compress, bgzip) and sorted by contig and position.  The formats are those of the tabix and CSI
+ * specifications; htslib's optional merging of sparse bins is not reproduced (any reader of the formats accepts the result).
+ * gtx_tabix_start: the virtual offset from which a sequential read finds every record of `chrom` that overlaps
+ * [begin, end) (0-based, end exclusive), from the .tbi / .csi beside the file; *any = 0: the index knows of none.
+ * gtx_graph_from_files uses the same look-up when its VCF has an index (the reference reads a region's records through
+ * tabix, src/graph/constructor.cpp:163-176). */
+int gtx_tabix_build(const char * vcf_gz_path, int min_shift, const char * index_path /* NULL: <vcf>.tbi or <vcf>.csi */);
+int gtx_tabix_start(const char * vcf_gz_path, const char * chrom, int64_t begin, int64_t end, uint64_t * voffset, int * any);
+
 /* ---- multi-GPU: reads shard over the GPUs of a node (one process per GPU, graph + index replicated), the accumulators
  * are summed once per region.  The reference's counterpart is the merge of per-thread / per-pool results
  * on the host (src/typer/caller.cpp:439-482, src/typer/vcf_operations.cpp:366-374); every per-read effect is an integer
