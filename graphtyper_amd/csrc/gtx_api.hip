@@ -1439,6 +1439,10 @@ void ctx_release_device(gtx_ctx & c)
     c.exact_slot[k] = gtx_ctx::ExactSlot(); // (the slabs are among dev_allocs)
   }
   c.n_exact_slots = 0;
+  for (void * st : c.pipeline_streams_all)
+    (void)hipStreamDestroy(static_cast<hipStream_t>(st));
+  c.pipeline_streams_all.clear();
+  c.pipeline_streams_idle.clear();
   for (void * p : c.dev_allocs)
     (void)gtx::dev_free(p);
   c.dev_allocs.clear();

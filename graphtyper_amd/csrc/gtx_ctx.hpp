@@ -116,6 +116,11 @@ struct gtx_ctx
   uint32_t * d_big_records = nullptr;
   uint64_t big_record_words = 0;
   unsigned long long * d_arena_cursor = nullptr;
+  // streams gtx_pipeline_run made for its host threads: they live as long as the context (scratches and exact-pass slots keep
+  // events that were recorded on them -- a destroyed stream behind such an event is an error at the next query), idle ones
+  // are taken again by the next run
+  std::mutex pipeline_mutex;
+  std::vector<void *> pipeline_streams_idle, pipeline_streams_all; // hipStream_t
   // pool of per-call scratch (see CallScratch)
   std::mutex pool_mutex;
   std::vector<std::unique_ptr<gtx::CallScratch>> pool;

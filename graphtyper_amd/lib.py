@@ -29,7 +29,7 @@ EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy"
            "gtx_reads_sample_name", "gtx_reads_next", "gtx_reads_close", "gtx_align_batch_flags", "gtx_score_batch_flags", "gtx_score_batch_words", "gtx_item_words",
            "gtx_pack_planes", "gtx_reads_to_planes", "gtx_align_batch_planes", "gtx_align_batch_planes_staged", "gtx_stream_set_planes", "gtx_device_cache_release",
            "gtx_disc_create", "gtx_disc_destroy", "gtx_disc_events_batch", "gtx_disc_first_pass", "gtx_vcf_header", "gtx_bgzf_compress",
-           "gtx_shrink_params_default", "gtx_bam_shrink", "gtx_inflate_raw", "gtx_tabix_build", "gtx_tabix_start"]
+           "gtx_shrink_params_default", "gtx_bam_shrink", "gtx_inflate_raw", "gtx_tabix_build", "gtx_tabix_start", "gtx_pipeline_run"]
 
 
 class GraphView(C.Structure):
@@ -38,6 +38,12 @@ class GraphView(C.Structure):
                 ("ref_first_var", C.c_void_p), ("var_order", C.c_void_p), ("var_len", C.c_void_p),
                 ("var_dna_off", C.c_void_p), ("var_out_ref", C.c_void_p), ("dna", C.c_void_p), ("dna_len", C.c_uint64),
                 ("event_off", C.c_void_p), ("event_val", C.c_void_p)]
+
+
+class PipelineStats(C.Structure):
+    _fields_ = [("records", C.c_uint64), ("tasks", C.c_uint64), ("items", C.c_uint64), ("decode_s", C.c_double), ("push_s", C.c_double),
+                ("enqueue_s", C.c_double), ("slowest_thread_s", C.c_double), ("loop_s", C.c_double), ("wall_s", C.c_double),
+                ("n_samples", C.c_uint32), ("n_threads", C.c_uint32)]
 
 
 class ShrinkParams(C.Structure):
@@ -178,6 +184,8 @@ def lib():
         L.gtx_reads_close.argtypes = [C.c_void_p]
         L.gtx_reads_close.restype = None
         L.gtx_inflate_raw.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.gtx_pipeline_run.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64,
+                                       C.POINTER(ScoreBuffers), C.POINTER(PipelineStats)]
         L.gtx_tabix_build.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
         L.gtx_tabix_start.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         L.gtx_shrink_params_default.argtypes = [C.POINTER(ShrinkParams)]
@@ -485,6 +493,15 @@ def inflate_raw(data, out_len):
     out = C.create_string_buffer(max(out_len, 1))
     check(lib().gtx_inflate_raw(data, len(data), out, out_len))
     return out.raw[:out_len]
+
+
+def pipeline_run(ctx, paths, n_threads, buf, rec_words, record_slots_per_thread, chunk=65536, region=None):
+    """gtx_pipeline_run over BAM files into the accumulator block `buf` (ScoreBuffers) -> its statistics as a dict"""
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    st = PipelineStats()
+    check(lib().gtx_pipeline_run(ctx.h, arr, len(paths), n_threads, region.encode() if region else None, chunk, rec_words, record_slots_per_thread,
+                                 C.byref(buf), C.byref(st)))
+    return {k: getattr(st, k) for k, _ in PipelineStats._fields_}
 
 
 def tabix_build(vcf_gz, min_shift=0, index_path=None):

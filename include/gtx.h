@@ -665,6 +665,27 @@ const char * gtx_reads_sample_name(const gtx_reads *, uint32_t i);
 int gtx_reads_next(gtx_reads *, gtx_stream_record * recs, uint8_t * seq, uint32_t seq_stride, uint32_t cap, uint32_t * n);
 void gtx_reads_close(gtx_reads *);
 
+/* ---- the host loop around the path, inside the library.  gtx_pipeline_run replaces the reference's worker threads over BAM
+ * pools (src/typer/caller.cpp:399-436, each running parallel_reader_genotype_only, src/utilities/hts_parallel_reader.cpp:
+ * 245-338): n_threads host threads, thread k with the files k, k + n_threads, ... (merged like gtx_reads_open merges them),
+ * each running gtx_reads_next -> gtx_stream_push (plane rows) -> pinned staging -> H2D -> gtx_align_batch_planes ->
+ * gtx_score_batch_flags on a stream of its own, two staging sets deep, all into the ONE accumulator block `acc` of the
+ * context (made by gtx_scores_alloc for at least the files' samples; samples are numbered by name in the order the groups
+ * bring them: position-sliced files of one sample are one sample).  chunk: records per batch; rec_words: words of a record slot; record_slots_per_thread: how many reads a thread's
+ * files may hold at most (their records stay on the device for the run: a mate's item names a task of batches ago).
+ * What follows is the caller's: gtx_calls_batch, gtx_vcf_records.  Reads of more than 160 bases are not taken by this loop. */
+typedef struct gtx_pipeline_stats
+{
+  uint64_t records, tasks, items;           /* records read; alignment tasks and score items made of them */
+  double decode_s, push_s, enqueue_s;       /* summed over the threads: gtx_reads_next, gtx_stream_push, copies + launches */
+  double slowest_thread_s;                  /* the largest per-thread sum of the three */
+  double loop_s;                            /* from the moment every thread has its buffers to the last stream's end */
+  double wall_s;                            /* the whole call (opening the files and allocating included) */
+  uint32_t n_samples, n_threads;
+} gtx_pipeline_stats;
+int gtx_pipeline_run(gtx_ctx *, const char * const * bam_paths, uint32_t n_paths, uint32_t n_threads, const char * region, uint32_t chunk,
+                     uint32_t rec_words, uint64_t record_slots_per_thread, const gtx_score_buffers * acc, gtx_pipeline_stats * stats);
+
 /* ---- the read pre-filter in front of the ingest (host).  gtx_bam_shrink replaces gyper::bamshrink / bamshrink_multi
  * (src/utilities/bamshrink.cpp:1248-1371; the work is qualityFilterSlice2, :667-1045): from a coordinate-sorted BAM file it
  * writes a BAM file with the records around the intervals that the caller is going to look at -- pairs and single reads that

@@ -298,3 +298,43 @@ def test_bam_files_to_vcf_text_on_the_device(tmp_path):
     """BAM files -> gtx_reads -> gtx_stream -> gtx_align_batch -> gtx_score_batch -> gtx_calls_batch -> gtx_vcf_records == oracle"""
     from test_bam_ingest import bam_to_calls_case
     bam_to_calls_case(harness.GpuBackend, tmp_path)
+
+
+@pytest.mark.parametrize("threads,chunk", [(2, 256), (1, 100), (2, 65536)])
+def test_the_librarys_own_host_loop(tmp_path, threads, chunk):
+    """gtx_pipeline_run (host threads, staging, copies and launches inside the library) over the two BAM files of the case above ==
+    the oracle's VCF text; with one thread both files are one merged stream, with small chunks mates arrive batches apart; twice
+    on one context (the streams of the first run are the second's)"""
+    import ctypes as C
+    import torch
+    from test_bam_ingest import bam_to_calls_case
+    import scenarios
+    want = bam_to_calls_case(harness.GpuBackend, tmp_path)
+    rb = 310000
+    ref, recs, _, rec = scenarios.paired_case("snp100", n_ref=12000, n_pairs=600, region_begin=rb, n_samples=2)
+    ctx = gtx.Context(gtx.graph_from_records(ref, recs, region_begin=rb), device=0)
+    L = gtx.lib()
+    paths = [str(tmp_path / "SAMP0.bam"), str(tmp_path / "SAMP1.bam")]
+    for again in range(2):
+        buf = gtx.ScoreBuffers()
+        gtx.check(L.gtx_scores_alloc(ctx.h, 2, 1 << 16, C.byref(buf), None))
+        st = gtx.pipeline_run(ctx, paths, threads, buf, harness.REC_WORDS, len(rec), chunk=chunk, region="chr7")
+        assert st["records"] == len(rec) and st["n_samples"] == 2 and st["n_threads"] == threads
+        d_phred = torch.zeros(max(2 * ctx.total_tri, 1), dtype=torch.uint8, device="cuda:0")
+        d_calls = torch.zeros(max(2 * ctx.n_hap, 1) * gtx.SAMPLE_CALL.itemsize, dtype=torch.uint8, device="cuda:0")
+        gtx.check(L.gtx_calls_batch(ctx.h, C.byref(buf), d_phred.data_ptr(), d_calls.data_ptr(), None))
+        torch.cuda.synchronize()
+        nh, ta = ctx.n_hap, ctx.total_allele
+        text = ctx.vcf_records("chr7", ["person0", "person1"], gtx.download(buf.d_gt_cov, np.uint32, 2 * ta), gtx.download(buf.d_stat_u64, np.uint64, nh + 2 * ta),
+                               gtx.download(buf.d_stat_u32, np.uint32, nh + 6 * ta), d_phred.cpu().numpy()[:2 * ctx.total_tri],
+                               d_calls.cpu().numpy().view(gtx.SAMPLE_CALL)[:2 * nh])
+        L.gtx_scores_free(ctx.h, C.byref(buf))
+        assert text == want
+    with pytest.raises(gtx.GtxError):  # fewer record slots than reads
+        buf = gtx.ScoreBuffers()
+        gtx.check(L.gtx_scores_alloc(ctx.h, 2, 1 << 16, C.byref(buf), None))
+        try:
+            gtx.pipeline_run(ctx, paths, threads, buf, harness.REC_WORDS, 10, chunk=chunk, region="chr7")
+        finally:
+            L.gtx_scores_free(ctx.h, C.byref(buf))
+    ctx.close()

@@ -18,5 +18,8 @@ for spec in sys.argv[1:]:
     threads, n = (int(x) for x in spec.split(":"))
     for rep in range(2):
         j = bench.extra_pipeline(args, torch, gtx, synth, device, ctx, ref, records, n=n, threads=threads)
+        if "error" in j and "reads_per_s" not in j:
+            print(threads, n, "FAILED:", j["error"], flush=True)
+            continue
         print("%d threads, %d reads: %.1f M reads/s wall %.2f loop %.2f | thread-s %s | slowest %s | equal %s" % (
-            j["host_threads"], n, j["reads_per_s"] / 1e6, j["wall_s"], j["read_loop_s"], j["host_thread_seconds"], j["slowest_thread_s"], j["vcf_equals_resident_run"]), flush=True)
+            j["host_threads"], n, j["reads_per_s"] / 1e6, j["wall_s"], j["read_loop_s"], j["host_thread_seconds"], j["slowest_thread_s"], j["vcf_equals_resident_run"]), "| native:", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in (j.get("native_loop") or {}).items() if k != "what"}, flush=True)
