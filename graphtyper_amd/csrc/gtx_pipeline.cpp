@@ -156,7 +156,9 @@ extern "C" int gtx_pipeline_run(gtx_ctx * c, const char * const * bam_paths, uin
            gtx::dev_malloc(&dev_meta[b], static_cast<size_t>(chunk) * sizeof(gtx_read_meta)) == hipSuccess &&
            gtx::dev_malloc(&dev_items[b], static_cast<size_t>(chunk) * sizeof(gtx_score_item)) == hipSuccess;
     size_t const rec_bytes = static_cast<size_t>(record_slots_per_thread) * 2 * rec_words * 4, fl_bytes = static_cast<size_t>(record_slots_per_thread) * 2;
-    ok = ok && gtx::dev_malloc(&d_rec, rec_bytes) == hipSuccess && gtx::dev_malloc(&d_fl, fl_bytes) == hipSuccess &&
+    // (the record slots are large and live for one run: straight from the driver, not through the library's cache of freed blocks --
+    //  sixteen of them would fill it and turn every later context's small allocations into driver calls)
+    ok = ok && hipMalloc(&d_rec, rec_bytes) == hipSuccess && hipMalloc(&d_fl, fl_bytes) == hipSuccess &&
          hipMemsetAsync(d_rec, 0, rec_bytes, st) == hipSuccess && hipMemsetAsync(d_fl, 0, fl_bytes, st) == hipSuccess;
     if (!ok)
       fail(GTX_ERR_HIP, "gtx_pipeline_run: could not allocate a thread's staging buffers / record slots");
@@ -278,8 +280,8 @@ extern "C" int gtx_pipeline_run(gtx_ctx * c, const char * const * bam_paths, uin
       (void)gtx::dev_free(dev_meta[b]);
       (void)gtx::dev_free(dev_items[b]);
     }
-    (void)gtx::dev_free(d_rec);
-    (void)gtx::dev_free(d_fl);
+    (void)hipFree(d_rec);
+    (void)hipFree(d_fl);
     if (st) // (kept for the context's life: see gtx_ctx::pipeline_streams_all)
     {
       std::lock_guard<std::mutex> lock(c->pipeline_mutex);
