@@ -115,6 +115,13 @@ def test_no_cpu_path():
     dummy = np.zeros(64, np.uint8)
     rc = gtx.lib().gtx_align_batch(c.h, gtx._p(dummy), 16, gtx._p(dummy), 1, gtx._p(dummy), 64, None)
     assert rc == 2  # GTX_ERR_NO_DEVICE
+    # the library's own host loop has no other place to compute either
+    import ctypes as C
+    paths = (C.c_char_p * 1)(b"/nonexistent.bam")
+    buf, st = gtx.ScoreBuffers(), gtx.PipelineStats()
+    buf.n_samples = 1
+    assert gtx.lib().gtx_pipeline_run(c.h, paths, 1, 1, None, 1024, 64, 1000, C.byref(buf), C.byref(st)) == 2
+    assert gtx.lib().gtx_pipeline_run(c.h, paths, 0, 1, None, 1024, 64, 1000, C.byref(buf), C.byref(st)) != 0  # (no files: a bad argument)
 
 
 def test_near_pair_layout():
