@@ -1294,3 +1294,74 @@ extern "C" int gtx_inflate_raw(const void * in, uint64_t in_len, void * out, uin
   gtx::g_last_error = "gtx_inflate_raw: not a DEFLATE stream of the given size";
   return GTX_ERR_IO;
 }
+
+// bamshrink_multi (bamshrink.cpp:1352-1371) with readIntervals (:1047-1130): the intervals of a file -- lines of "contig first
+// last", 1-based, sorted -- where a neighbour that begins within 2 * max_frag_len of the one before is one interval with it
+// (otherwise the output could not stay sorted); then the filter over all of them into one file with the whole header.
+extern "C" int gtx_bam_shrink_multi(const char * bam_in, const char * interval_file, const gtx_shrink_params * params, const char * bam_out,
+                                    gtx_shrink_stats * stats)
+{
+  if (!bam_in || !interval_file || !bam_out)
+  {
+    gtx::g_last_error = "gtx_bam_shrink_multi: bad argument";
+    return GTX_ERR_ARG;
+  }
+  gtx_shrink_params par;
+  if (params)
+    par = *params;
+  else
+    gtx_shrink_params_default(&par);
+  std::FILE * fp = std::fopen(interval_file, "r");
+  if (!fp)
+  {
+    gtx::g_last_error = std::string("Unable to locate interval file at: ") + interval_file;
+    return GTX_ERR_IO;
+  }
+  std::vector<std::string> names;
+  std::vector<int32_t> firsts, lasts;
+  char contig[1024];
+  long a = 0, b = 0;
+  int status = GTX_OK;
+  size_t n_lines = 0;
+  while (std::fscanf(fp, "%1023s %ld %ld", contig, &a, &b) == 3)
+  {
+    // (:1076-1086: a line other than the first counts only when something follows its last number -- the stream is asked for its
+    //  end before the interval is used, so the last line of a file that does not end in a newline is left out)
+    int const behind = std::fgetc(fp);
+    if (behind == EOF && n_lines > 0)
+      break;
+    if (behind != EOF)
+      std::ungetc(behind, fp);
+    ++n_lines;
+    int32_t const first = static_cast<int32_t>(a - 1), last = static_cast<int32_t>(b - 1);
+    if (!names.empty() && names.back() == contig)
+    {
+      if (first < firsts.back())
+      {
+        gtx::g_last_error = "The input intervals are not sorted.";
+        status = GTX_ERR_ARG;
+        break;
+      }
+      if (static_cast<long>(first) - lasts.back() <= 2l * par.max_frag_len)
+      {
+        lasts.back() = last; // (the reference takes the later interval's end, also when it is the smaller one)
+        continue;
+      }
+    }
+    names.emplace_back(contig);
+    firsts.push_back(first);
+    lasts.push_back(last);
+  }
+  std::fclose(fp);
+  if (status != GTX_OK)
+    return status;
+  if (names.empty())
+  {
+    gtx::g_last_error = std::string("The interval file \"") + interval_file + "\" contained no intervals!";
+    return GTX_ERR_ARG;
+  }
+  std::vector<char const *> chroms;
+  for (auto const & n : names)
+    chroms.push_back(n.c_str());
+  return gtx_bam_shrink(bam_in, chroms.data(), firsts.data(), lasts.data(), static_cast<uint32_t>(names.size()), &par, bam_out, stats);
+}

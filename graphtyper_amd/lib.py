@@ -29,7 +29,7 @@ EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy"
            "gtx_reads_sample_name", "gtx_reads_next", "gtx_reads_close", "gtx_align_batch_flags", "gtx_score_batch_flags", "gtx_score_batch_words", "gtx_item_words",
            "gtx_pack_planes", "gtx_reads_to_planes", "gtx_align_batch_planes", "gtx_align_batch_planes_staged", "gtx_stream_set_planes", "gtx_device_cache_release",
            "gtx_disc_create", "gtx_disc_destroy", "gtx_disc_events_batch", "gtx_disc_first_pass", "gtx_vcf_header", "gtx_bgzf_compress",
-           "gtx_shrink_params_default", "gtx_bam_shrink", "gtx_inflate_raw", "gtx_tabix_build", "gtx_tabix_start", "gtx_pipeline_run"]
+           "gtx_shrink_params_default", "gtx_bam_shrink", "gtx_inflate_raw", "gtx_tabix_build", "gtx_tabix_start", "gtx_pipeline_run", "gtx_bam_shrink_multi"]
 
 
 class GraphView(C.Structure):
@@ -183,6 +183,7 @@ def lib():
         L.gtx_reads_next.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
         L.gtx_reads_close.argtypes = [C.c_void_p]
         L.gtx_reads_close.restype = None
+        L.gtx_bam_shrink_multi.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(ShrinkParams), C.c_char_p, C.POINTER(ShrinkStats)]
         L.gtx_inflate_raw.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64]
         L.gtx_pipeline_run.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64,
                                        C.POINTER(ScoreBuffers), C.POINTER(PipelineStats)]
@@ -534,6 +535,13 @@ def bam_shrink(bam_in, intervals, bam_out, params=None):
     ends = (C.c_int32 * n)(*[e for _, _, e in intervals])
     st = ShrinkStats()
     check(lib().gtx_bam_shrink(bam_in.encode(), chroms, begins, ends, n, C.byref(params) if params is not None else None, bam_out.encode(), C.byref(st)))
+    return {k: int(getattr(st, k)) for k, _ in ShrinkStats._fields_}
+
+
+def bam_shrink_multi(bam_in, interval_file, bam_out, params=None):
+    """gtx_bam_shrink_multi: the intervals come from a file of 'contig first last' lines (1-based)"""
+    st = ShrinkStats()
+    check(lib().gtx_bam_shrink_multi(bam_in.encode(), interval_file.encode(), C.byref(params) if params is not None else None, bam_out.encode(), C.byref(st)))
     return {k: int(getattr(st, k)) for k, _ in ShrinkStats._fields_}
 
 

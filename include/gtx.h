@@ -725,6 +725,10 @@ typedef struct gtx_shrink_stats
 void gtx_shrink_params_default(gtx_shrink_params *);
 int gtx_bam_shrink(const char * bam_in, const char * const * chroms, const int32_t * begins, const int32_t * ends, uint32_t n_intervals,
                    const gtx_shrink_params * params /* NULL: defaults */, const char * bam_out, gtx_shrink_stats * stats /* may be NULL */);
+/* bamshrink_multi (src/utilities/bamshrink.cpp:1352-1371): the intervals come from a file of "contig first last" lines (1-based,
+ * sorted); neighbours that begin within 2 * max_frag_len of the one before are one interval (readIntervals, :1047-1130). */
+int gtx_bam_shrink_multi(const char * bam_in, const char * interval_file, const gtx_shrink_params * params, const char * bam_out,
+                         gtx_shrink_stats * stats);
 
 /* ---- variant discovery, first slice.  Replaces, per sample, the first pass over the reads of a region:
  * run_first_pass (src/typer/caller.cpp:488-1186) -- the SNP and indel events its CIGAR walk reads off the alignments

@@ -337,3 +337,32 @@ def test_short_names_and_the_name_hash():
         gtx.bam_shrink(d + "/in.bam", [("chr1", 0, 5000)], d + "/out.bam", gtx.shrink_params(no_filter_on_coverage=1))
         names = [r["name"] for r in parse_records(split_bam(d + "/out.bam")[2])]
     assert names[0] == "!" and names[30] == "?" and names[31] == "A" and names[92] == "~" and names[93] == "!\"" and names[94] == "\"\""
+
+
+def test_intervals_from_a_file(tmp_path):
+    """gtx_bam_shrink_multi (bamshrink_multi + readIntervals, bamshrink.cpp:1047-1130, 1352-1371): 1-based lines, neighbours
+    closer than 2 x maxFragLen are one interval, unsorted or empty files are refused"""
+    path = str(tmp_path / "in.bam")
+    stream = random_file(path, 31, 900, False)
+    iv = str(tmp_path / "iv.txt")
+    open(iv, "w").write("chr1 10001 12000\nchr1 13001 15000\nchr1 30001 36000\nchr2 9001 30000\n")  # the first two merge (1000 apart)
+    par = gtx.shrink_params()
+    out = str(tmp_path / "out.bam")
+    gtx.bam_shrink_multi(path, iv, out, par)
+    text, refs, got = split_bam(out)
+    assert got == oracle_shrink(stream, [(0, 10000, 14999), (0, 30000, 35999), (1, 9000, 29999)], par) and len(parse_records(got)) > 50
+    assert text == HEADER and refs == REFS
+    open(iv, "w").write("chr1 10001 12000\n")  # one interval: the header keeps that contig only
+    gtx.bam_shrink_multi(path, iv, out, par)
+    text, refs, got = split_bam(out)
+    assert refs == [REFS[0]] and got == oracle_shrink(stream, [(0, 10000, 11999)], par)
+    # the reference asks the stream for its end before it uses an interval: without a newline behind it the last line is left out
+    open(iv, "w").write("chr1 10001 12000\nchr2 9001 30000")
+    gtx.bam_shrink_multi(path, iv, out, par)
+    assert split_bam(out)[2] == oracle_shrink(stream, [(0, 10000, 11999)], par)
+    for bad in ("chr1 20001 22000\nchr1 10001 12000\n", "", "chr1 x y\n"):
+        open(iv, "w").write(bad)
+        with pytest.raises(gtx.GtxError):
+            gtx.bam_shrink_multi(path, iv, out, par)
+    with pytest.raises(gtx.GtxError):
+        gtx.bam_shrink_multi(path, str(tmp_path / "missing.txt"), out, par)
