@@ -16,6 +16,8 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <set>
+#include <iterator>
 #include <memory>
 #include <string>
 #include <vector>
@@ -210,6 +212,15 @@ extern "C" int gtx_disc_create(const char * reference, uint64_t reference_len, i
     return GTX_ERR_ARG;
   }
   *out = nullptr;
+  if (device == -1) // like gtx_ctx_create's -1: an object for the host stages only (the bookkeeping over events a device made elsewhere);
+  {                 // gtx_disc_events_batch refuses it -- there is no CPU path for the walk over the CIGARs
+    auto h = std::make_unique<gtx_disc>();
+    h->device = -1;
+    h->region_begin = region_begin;
+    h->reference.assign(reference, reference_len);
+    *out = h.release();
+    return GTX_OK;
+  }
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
   {
@@ -267,6 +278,11 @@ extern "C" int gtx_disc_events_batch(gtx_disc * d, const uint8_t * d_planes, uin
     g_last_error = "gtx_disc_events_batch: bad argument";
     return GTX_ERR_ARG;
   }
+  if (d->device < 0)
+  {
+    g_last_error = "gtx_disc_events_batch: the object was created without a device (libgtx has no CPU path)";
+    return GTX_ERR_NO_DEVICE;
+  }
   if (n_reads == 0)
     return GTX_OK;
   if (hipSetDevice(d->device) != hipSuccess)
@@ -309,7 +325,15 @@ struct Support // EventSupport (event.hpp:75-113): what the first pass fills
   uint16_t span = 1;
   bool realign = false, good = false;
   uint32_t max_log_qual = 0;
+  int32_t file_i = 0; // max_log_qual_file_i: the file whose reads gave max_log_qual
   std::map<Ev, uint16_t> phase;
+};
+
+struct PassState // what run_first_pass has when its two filters are through
+{
+  std::vector<std::map<Ev, Support>> buckets;
+  std::vector<uint32_t> up, down; // cov_up / cov_down
+  long REF = 0, B = 0, begin = 0;
 };
 
 uint16_t wrap16(uint32_t v) { return static_cast<uint16_t>(v); } // (the reference's counters are uint16_t and wrap)
@@ -326,19 +350,20 @@ bool good_snp(Support const & s, long cov) // EventSupport::has_good_support wit
 }
 } // namespace
 
-extern "C" int gtx_disc_first_pass(const gtx_disc * d, const gtx_disc_read * reads, const uint32_t * cigar, const gtx_disc_read_out * read_out,
-                                   uint32_t n_reads, const gtx_disc_event * events, uint64_t n_events, const uint8_t * seq, uint32_t seq_stride,
-                                   uint32_t bucket_size, uint32_t * out, uint64_t cap, uint64_t * n_words)
+// run_first_pass up to and including its two support filters (caller.cpp:488-1186) from the device's events
+static int first_pass_state(const gtx_disc * d, const gtx_disc_read * reads, const uint32_t * cigar, const gtx_disc_read_out * read_out, uint32_t n_reads,
+                            const gtx_disc_event * events, uint64_t n_events, const uint8_t * seq, uint32_t seq_stride, uint32_t bucket_size,
+                            int32_t file_index, PassState & state)
 {
-  if (!d || !n_words || bucket_size == 0 || (n_reads && (!reads || !cigar || !read_out || !seq)) || (n_events && !events) || (cap && !out))
-  {
-    g_last_error = "gtx_disc_first_pass: bad argument";
-    return GTX_ERR_ARG;
-  }
   std::string const & ref = d->reference;
   long const REF = static_cast<long>(ref.size()), B = bucket_size, begin = d->region_begin;
-  std::vector<std::map<Ev, Support>> buckets;
-  std::vector<uint32_t> up(REF, 0), down(REF, 0);
+  state.REF = REF;
+  state.B = B;
+  state.begin = begin;
+  std::vector<std::map<Ev, Support>> & buckets = state.buckets;
+  state.up.assign(REF, 0);
+  state.down.assign(REF, 0);
+  std::vector<uint32_t> &up = state.up, &down = state.down;
   static char const NT16[] = "=ACMGRSVTWYHKDBN";
   auto bucket_of = [&](uint32_t pos) -> std::map<Ev, Support> &
   {
@@ -522,12 +547,14 @@ extern "C" int gtx_disc_first_pass(const gtx_disc * d, const gtx_disc_read * rea
       {
         s.good = s.realign = true;
         s.max_log_qual = log_qual;
+        s.file_i = file_index;
         ++it;
       }
       else if (count >= 3.0 && log_qual > 0 && pp >= 1 && (hq >= 5 || s.max_mapq >= 25) && s.max_mapq >= 10 && cl < hq)
       {
         s.realign = true;
         s.max_log_qual = log_qual;
+        s.file_i = file_index;
         ++it;
       }
       else
@@ -538,33 +565,302 @@ extern "C" int gtx_disc_first_pass(const gtx_disc * d, const gtx_disc_read * rea
     for (long o = b * B, e = std::min(REF, (b + 1) * B); o < e; ++o)
       depth += delta(o);
   }
-  // the surviving events as a word stream: pos, type, length, characters, the support fields, the phase entries
-  std::vector<uint32_t> w;
-  auto put_ev = [&](Ev const & e)
+  return GTX_OK;
+}
+
+namespace
+{
+void put_ev(std::vector<uint32_t> & w, Ev const & e)
+{
+  w.push_back(e.pos);
+  w.push_back(e.type);
+  w.push_back(static_cast<uint32_t>(e.seq.size()));
+  for (char c : e.seq)
+    w.push_back(static_cast<uint32_t>(static_cast<unsigned char>(c)));
+}
+
+// an event with its support: the fields, (the file of the best support,) the phase entries
+void put_support(std::vector<uint32_t> & w, Ev const & e, Support const & s, bool with_file)
+{
+  put_ev(w, e);
+  for (uint32_t v : {uint32_t(wrap16(s.hq)), uint32_t(wrap16(s.lq)), uint32_t(wrap16(s.proper)), uint32_t(wrap16(s.first)), uint32_t(wrap16(s.reversed)),
+                     uint32_t(wrap16(s.clipped)), uint32_t(s.max_mapq), uint32_t(s.max_distance), uint32_t(s.u1), uint32_t(s.u2), uint32_t(s.u3),
+                     uint32_t(s.span), uint32_t(s.realign), uint32_t(s.good), s.max_log_qual})
+    w.push_back(v);
+  if (with_file)
+    w.push_back(static_cast<uint32_t>(s.file_i));
+  w.push_back(static_cast<uint32_t>(s.phase.size()));
+  for (auto const & ph : s.phase)
   {
-    w.push_back(e.pos);
-    w.push_back(e.type);
-    w.push_back(static_cast<uint32_t>(e.seq.size()));
-    for (char c : e.seq)
-      w.push_back(static_cast<uint32_t>(static_cast<unsigned char>(c)));
-  };
-  for (auto const & bucket : buckets)
-    for (auto const & kv : bucket)
-    {
-      put_ev(kv.first);
-      Support const & s = kv.second;
-      for (uint32_t v : {uint32_t(wrap16(s.hq)), uint32_t(wrap16(s.lq)), uint32_t(wrap16(s.proper)), uint32_t(wrap16(s.first)), uint32_t(wrap16(s.reversed)),
-                         uint32_t(wrap16(s.clipped)), uint32_t(s.max_mapq), uint32_t(s.max_distance), uint32_t(s.u1), uint32_t(s.u2), uint32_t(s.u3),
-                         uint32_t(s.span), uint32_t(s.realign), uint32_t(s.good), s.max_log_qual, uint32_t(s.phase.size())})
-        w.push_back(v);
-      for (auto const & ph : s.phase)
-      {
-        put_ev(ph.first);
-        w.push_back(ph.second);
-      }
-    }
+    put_ev(w, ph.first);
+    w.push_back(ph.second);
+  }
+}
+
+int hand_over(std::vector<uint32_t> const & w, uint32_t * out, uint64_t cap, uint64_t * n_words)
+{
   *n_words = w.size();
   if (w.size() <= cap && !w.empty())
     std::memcpy(out, w.data(), w.size() * 4);
   return w.size() <= cap ? GTX_OK : GTX_ERR_CAPACITY;
+}
+
+// HaplotypeInfo (caller.cpp:45-52): the events an event is seen with -- in some sample, in every sample that has it
+struct Together
+{
+  std::set<Ev> ever, always;
+};
+
+struct FileResult // what a file (or several, merged) leaves behind: Tindel_events and the haplotype map
+{
+  std::map<Ev, Support> indels;
+  std::map<Ev, Together> haplotypes;
+};
+
+void put_result(std::vector<uint32_t> & w, FileResult const & r)
+{
+  w.push_back(static_cast<uint32_t>(r.indels.size()));
+  for (auto const & kv : r.indels)
+    put_support(w, kv.first, kv.second, true);
+  w.push_back(static_cast<uint32_t>(r.haplotypes.size()));
+  for (auto const & kv : r.haplotypes)
+  {
+    put_ev(w, kv.first);
+    for (std::set<Ev> const * set : {&kv.second.ever, &kv.second.always})
+    {
+      w.push_back(static_cast<uint32_t>(set->size()));
+      for (Ev const & e : *set)
+        put_ev(w, e);
+    }
+  }
+}
+
+bool read_result(uint32_t const * w, uint64_t n, FileResult & r)
+{
+  uint64_t at = 0;
+  bool ok = true;
+  auto word = [&]() -> uint32_t
+  {
+    if (at >= n)
+    {
+      ok = false;
+      return 0;
+    }
+    return w[at++];
+  };
+  auto event = [&]()
+  {
+    Ev e;
+    e.pos = word();
+    e.type = static_cast<uint8_t>(word());
+    uint32_t const len = word();
+    if (!ok || len > n - at)
+    {
+      ok = false;
+      return e;
+    }
+    for (uint32_t k = 0; k < len; ++k)
+      e.seq.push_back(static_cast<char>(w[at + k]));
+    at += len;
+    return e;
+  };
+  if (n == 0)
+    return true;
+  for (uint32_t i = 0, m = word(); ok && i < m; ++i)
+  {
+    Ev e = event();
+    Support s;
+    s.hq = word(); s.lq = word(); s.proper = word(); s.first = word(); s.reversed = word(); s.clipped = word();
+    s.max_mapq = static_cast<uint8_t>(word()); s.max_distance = static_cast<uint8_t>(word());
+    s.u1 = static_cast<int32_t>(word()); s.u2 = static_cast<int32_t>(word()); s.u3 = static_cast<int32_t>(word());
+    s.span = static_cast<uint16_t>(word()); s.realign = word() != 0; s.good = word() != 0; s.max_log_qual = word();
+    s.file_i = static_cast<int32_t>(word());
+    for (uint32_t k = 0, np = word(); ok && k < np; ++k)
+    {
+      Ev pe = event();
+      s.phase[pe] = static_cast<uint16_t>(word());
+    }
+    r.indels.insert({std::move(e), std::move(s)});
+  }
+  for (uint32_t i = 0, m = word(); ok && i < m; ++i)
+  {
+    Ev e = event();
+    Together t;
+    for (std::set<Ev> * set : {&t.ever, &t.always})
+      for (uint32_t k = 0, ns = word(); ok && k < ns; ++k)
+        set->insert(event());
+    r.haplotypes.insert({std::move(e), std::move(t)});
+  }
+  return ok && at == n;
+}
+} // namespace
+
+extern "C" int gtx_disc_first_pass(const gtx_disc * d, const gtx_disc_read * reads, const uint32_t * cigar, const gtx_disc_read_out * read_out,
+                                   uint32_t n_reads, const gtx_disc_event * events, uint64_t n_events, const uint8_t * seq, uint32_t seq_stride,
+                                   uint32_t bucket_size, uint32_t * out, uint64_t cap, uint64_t * n_words)
+{
+  if (!d || !n_words || bucket_size == 0 || (n_reads && (!reads || !cigar || !read_out || !seq)) || (n_events && !events) || (cap && !out))
+  {
+    g_last_error = "gtx_disc_first_pass: bad argument";
+    return GTX_ERR_ARG;
+  }
+  PassState st;
+  int const rc = first_pass_state(d, reads, cigar, read_out, n_reads, events, n_events, seq, seq_stride, bucket_size, 0, st);
+  if (rc != GTX_OK)
+    return rc;
+  // the surviving events as a word stream: pos, type, length, characters, the support fields, the phase entries
+  std::vector<uint32_t> w;
+  for (auto const & bucket : st.buckets)
+    for (auto const & kv : bucket)
+      put_support(w, kv.first, kv.second, false);
+  return hand_over(w, out, cap, n_words);
+}
+
+// run_first_pass to its end (caller.cpp:1186-1365): for every event that is left, which later events within two buckets it
+// travels with -- "ever": in enough of the reads that cover both (by its phase counts and the coverage between the two; any
+// shared read when one of them is an indel), "always": those of them at most ten positions on -- the sample's haplotype map;
+// the SNPs then leave the buckets.  Output: the file's result (put_result: indels with their support, the haplotype map).
+extern "C" int gtx_disc_first_pass_haplotypes(const gtx_disc * d, const gtx_disc_read * reads, const uint32_t * cigar, const gtx_disc_read_out * read_out,
+                                              uint32_t n_reads, const gtx_disc_event * events, uint64_t n_events, const uint8_t * seq, uint32_t seq_stride,
+                                              uint32_t bucket_size, int32_t file_index, uint32_t * out, uint64_t cap, uint64_t * n_words)
+{
+  if (!d || !n_words || bucket_size == 0 || (n_reads && (!reads || !cigar || !read_out || !seq)) || (n_events && !events) || (cap && !out))
+  {
+    g_last_error = "gtx_disc_first_pass_haplotypes: bad argument";
+    return GTX_ERR_ARG;
+  }
+  PassState st;
+  int const rc = first_pass_state(d, reads, cigar, read_out, n_reads, events, n_events, seq, seq_stride, bucket_size, file_index, st);
+  if (rc != GTX_OK)
+    return rc;
+  long const REF = st.REF, B = st.B, begin = st.begin, NB = static_cast<long>(st.buckets.size());
+  auto delta = [&](long o) { return static_cast<long>(st.up[o]) - static_cast<long>(st.down[o]); };
+  FileResult res;
+  long depth = 0;
+  for (long b = 0; b < NB; ++b)
+  {
+    auto & bucket = st.buckets[b];
+    for (auto it = bucket.begin(); it != bucket.end();)
+    {
+      Ev const & ev = it->first;
+      Support const & info = it->second;
+      long const at = std::max(0l, static_cast<long>(ev.pos) - begin);
+      long cov = depth;
+      if (at + 1 > b * B)
+        for (long o = b * B; o <= at; ++o)
+          cov += delta(o);
+      Together & tg = res.haplotypes.insert({ev, Together()}).first->second;
+      double ratio = static_cast<double>(wrap16(info.hq) + wrap16(info.lq)) / static_cast<double>(cov);
+      if (ratio < 0.3)
+        ratio = 0.3;
+      // 1: seen together, 2: seen apart (caller.cpp:1216-1268; 0: too little coverage to say)
+      auto judge = [&](Ev const & other) -> int
+      {
+        auto const ph = info.phase.find(other);
+        if (ev.type != 'X' || other.type != 'X')
+          return (ph == info.phase.end() || ph->second == 0) ? 2 : 3;
+        long local = cov;
+        for (long o = at + 1, last = std::max(0l, static_cast<long>(other.pos) - begin); o <= last; ++o)
+          local -= o < REF ? static_cast<long>(st.down[o]) : 0l;
+        if (local <= 2)
+          return 0;
+        double const support = ph == info.phase.end() ? 0.0 : ph->second;
+        if ((support / static_cast<double>(local) / ratio) < 0.22)
+          return 2;
+        if ((support / static_cast<double>(local) / ratio) > 0.78)
+          return 1;
+        return 3;
+      };
+      auto look = [&](Ev const & other, bool may_be_always)
+      {
+        if (judge(other) & 1)
+        {
+          tg.ever.insert(other);
+          if (may_be_always && other.pos <= ev.pos + 10)
+            tg.always.insert(other);
+        }
+      };
+      for (auto it2 = std::next(it); it2 != bucket.end(); ++it2)
+        if (!(it2->first.pos == ev.pos && it2->first.type == ev.type)) // (alleles of one place exclude each other)
+          look(it2->first, true);
+      if (b + 1 < NB)
+        for (auto const & kv : st.buckets[b + 1])
+          look(kv.first, true);
+      if (b + 2 < NB)
+        for (auto const & kv : st.buckets[b + 2])
+        {
+          if (kv.first.pos >= ev.pos + 2 * B)
+            break;
+          look(kv.first, false);
+        }
+      if (ev.type == 'X')
+        it = bucket.erase(it);
+      else
+        ++it;
+    }
+    if (b * B >= REF)
+      break;
+    for (long o = b * B, e = std::min(REF, (b + 1) * B); o < e; ++o)
+      depth += delta(o);
+  }
+  for (auto & bucket : st.buckets)
+    for (auto & kv : bucket)
+      res.indels.insert(kv);
+  std::vector<uint32_t> w;
+  put_result(w, res);
+  return hand_over(w, out, cap, n_words);
+}
+
+// The results of two files (or of files merged before) as one: merge_haplotypes2 (caller.cpp:64-165) -- an event new to `into`
+// keeps of its "always" set what `into` has never seen; one known to both has the union of the "ever" sets and the
+// intersection of the "always" sets -- and the union of the indels (streamlined_discovery, :2853-2903: good support from any
+// file, the best max_log_qual with its file).  `into` may be empty.  Files are merged in their order.
+extern "C" int gtx_disc_merge(const uint32_t * into, uint64_t n_into, const uint32_t * from, uint64_t n_from, uint32_t * out, uint64_t cap,
+                              uint64_t * n_words)
+{
+  if (!n_words || (n_into && !into) || (n_from && !from) || (cap && !out))
+  {
+    g_last_error = "gtx_disc_merge: bad argument";
+    return GTX_ERR_ARG;
+  }
+  FileResult a, b;
+  if (!read_result(into, n_into, a) || !read_result(from, n_from, b))
+  {
+    g_last_error = "gtx_disc_merge: not a result of gtx_disc_first_pass_haplotypes / gtx_disc_merge";
+    return GTX_ERR_ARG;
+  }
+  if (a.haplotypes.empty())
+    a.haplotypes = std::move(b.haplotypes);
+  else
+    for (auto & kv : b.haplotypes)
+    {
+      auto ins = a.haplotypes.insert(kv);
+      Together & mine = ins.first->second;
+      if (ins.second)
+      {
+        for (auto it = mine.always.begin(); it != mine.always.end();)
+          it = a.haplotypes.count(*it) ? mine.always.erase(it) : std::next(it);
+        continue;
+      }
+      mine.ever.insert(kv.second.ever.begin(), kv.second.ever.end());
+      std::set<Ev> both;
+      std::set_intersection(mine.always.begin(), mine.always.end(), kv.second.always.begin(), kv.second.always.end(), std::inserter(both, both.begin()));
+      mine.always.swap(both);
+    }
+  for (auto & kv : b.indels)
+  {
+    auto ins = a.indels.insert(kv);
+    if (ins.second)
+      continue;
+    Support & old = ins.first->second;
+    old.good = old.good || kv.second.good;
+    if (kv.second.max_log_qual > old.max_log_qual)
+    {
+      old.max_log_qual = kv.second.max_log_qual;
+      old.file_i = kv.second.file_i;
+    }
+  }
+  std::vector<uint32_t> w;
+  put_result(w, a);
+  return hand_over(w, out, cap, n_words);
 }

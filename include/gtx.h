@@ -783,7 +783,7 @@ typedef struct gtx_disc_read_out
   int32_t pos_end; /* region-relative end of the alignment (cov_down) */
   uint32_t state;
 } gtx_disc_read_out;
-int gtx_disc_create(const char * reference, uint64_t reference_len, int64_t region_begin, int device, gtx_disc ** out);
+int gtx_disc_create(const char * reference, uint64_t reference_len, int64_t region_begin, int device /* -1: for the host stages only */, gtx_disc ** out);
 void gtx_disc_destroy(gtx_disc *);
 int gtx_disc_events_batch(gtx_disc *, const uint8_t * d_planes, uint32_t plane_stride, const uint8_t * d_qual, uint32_t qual_stride,
                           const gtx_disc_read * d_reads, const uint32_t * d_cigar, uint32_t n_reads, gtx_disc_event * d_events, uint32_t event_cap,
@@ -791,6 +791,20 @@ int gtx_disc_events_batch(gtx_disc *, const uint8_t * d_planes, uint32_t plane_s
 int gtx_disc_first_pass(const gtx_disc *, const gtx_disc_read * reads, const uint32_t * cigar, const gtx_disc_read_out * read_out, uint32_t n_reads,
                         const gtx_disc_event * events, uint64_t n_events, const uint8_t * seq, uint32_t seq_stride, uint32_t bucket_size,
                         uint32_t * out, uint64_t cap, uint64_t * n_words);
+
+/* The pass to its end (run_first_pass, src/typer/caller.cpp:1186-1365): for every event left by the two filters, the later events
+ * within two buckets it travels with -- "ever" (in enough of the reads that cover both, by the phase counts and the coverage
+ * between them; any shared read when an indel is involved) and "always" (those at most ten positions on): the sample's haplotype
+ * map (HaplotypeInfo, :45-52); the SNPs then leave the buckets.  The result of the file as words: n_indels, per indel the event
+ * (pos, type, length, characters), its support fields, file_index where its best support was found, its phase entries; then
+ * n_events, per event its "ever" and "always" sets (count + events each).
+ * gtx_disc_merge: two such results as one -- merge_haplotypes2 (:64-165) and the union of the files' indels
+ * (streamlined_discovery, :2853-2903); `into` may be empty; files are merged in their order.  What the reference does next --
+ * realignment of reads to the indels (paw::pairwise_alignment, absent from its tree) -- is not built. */
+int gtx_disc_first_pass_haplotypes(const gtx_disc *, const gtx_disc_read * reads, const uint32_t * cigar, const gtx_disc_read_out * read_out,
+                                   uint32_t n_reads, const gtx_disc_event * events, uint64_t n_events, const uint8_t * seq, uint32_t seq_stride,
+                                   uint32_t bucket_size, int32_t file_index, uint32_t * out, uint64_t cap, uint64_t * n_words);
+int gtx_disc_merge(const uint32_t * into, uint64_t n_into, const uint32_t * from, uint64_t n_from, uint32_t * out, uint64_t cap, uint64_t * n_words);
 
 #ifdef __cplusplus
 }

@@ -732,6 +732,138 @@ extern "C"
     }
   }
 
+  // the same pass to its end (the sample's haplotype map, the indels that are left) as the word stream of FirstPass::dump(Result);
+  // ev_out / ro_out (may be NULL): the per-read events and read states in the layout of gtx_disc_event / gtx_disc_read_out, for
+  // tests that feed the product's host stage without a device (ev_cap events; returns -2 when there are more)
+  long gto_first_pass_full(char const * reference, long region_begin, long bucket_size, long file_i, long n, int32_t const * pos, uint16_t const * flag,
+                           uint8_t const * mapq, uint32_t const * cigar, uint32_t const * cigar_off, uint8_t const * codes, uint8_t const * qual,
+                           uint32_t const * code_off, uint32_t * out, long cap, void * ev_out, long ev_cap, long * n_events, void * ro_out)
+  {
+    try
+    {
+      static char const NT16[] = "=ACMGRSVTWYHKDBN";
+      std::vector<gto::disc::Read> reads(static_cast<std::size_t>(n));
+      for (long i = 0; i < n; ++i)
+      {
+        gto::disc::Read & r = reads[i];
+        r.pos = pos[i];
+        r.flag = flag[i];
+        r.mapq = mapq[i];
+        r.cigar.assign(cigar + cigar_off[i], cigar + cigar_off[i + 1]);
+        for (uint32_t k = code_off[i]; k < code_off[i + 1]; ++k)
+          r.sequence.push_back(NT16[codes[k] & 15]);
+        r.qual.assign(qual + code_off[i], qual + code_off[i + 1]);
+      }
+      gto::disc::FirstPass fp;
+      fp.file_i = file_i;
+      fp.run(reads, std::string(reference), region_begin, bucket_size);
+      static_assert(sizeof(gto::disc::FirstPass::RawEvent) == 20 && sizeof(gto::disc::FirstPass::ReadOut) == 16, "layout of gtx_disc_event / gtx_disc_read_out");
+      if (n_events)
+        *n_events = static_cast<long>(fp.raw_events.size());
+      if (ev_out)
+      {
+        if (static_cast<long>(fp.raw_events.size()) > ev_cap)
+          return -2;
+        if (!fp.raw_events.empty())
+          std::memcpy(ev_out, fp.raw_events.data(), fp.raw_events.size() * sizeof(fp.raw_events[0]));
+      }
+      if (ro_out && n)
+        std::memcpy(ro_out, fp.read_outs.data(), fp.read_outs.size() * sizeof(fp.read_outs[0]));
+      fp.run_haplotypes(std::string(reference), region_begin, bucket_size);
+      std::vector<uint32_t> const s = gto::disc::FirstPass::dump(fp.result());
+      if (static_cast<long>(s.size()) <= cap)
+        std::memcpy(out, s.data(), s.size() * 4);
+      return static_cast<long>(s.size());
+    }
+    catch (std::exception const & e)
+    {
+      g_error = e.what();
+      return -1;
+    }
+  }
+
+  // merge_haplotypes2 + the union of the indels over two such word streams (the first may be empty: nothing merged yet)
+  long gto_disc_merge(uint32_t const * into, long n_into, uint32_t const * from, long n_from, uint32_t * out, long cap)
+  {
+    try
+    {
+      using FP = gto::disc::FirstPass;
+      auto parse = [](uint32_t const * w, long n)
+      {
+        FP::Result r;
+        long at = 0;
+        auto need = [&](long k) { if (at + k > n) throw std::runtime_error("gto_disc_merge: truncated stream"); };
+        auto event = [&]()
+        {
+          need(3);
+          gto::disc::Event e;
+          e.pos = w[at];
+          e.type = static_cast<char>(w[at + 1]);
+          long const len = w[at + 2];
+          at += 3;
+          need(len);
+          for (long k = 0; k < len; ++k)
+            e.sequence.push_back(static_cast<char>(w[at + k]));
+          at += len;
+          return e;
+        };
+        if (n == 0)
+          return r;
+        need(1);
+        long const n_indels = w[at++];
+        for (long i = 0; i < n_indels; ++i)
+        {
+          gto::disc::Event e = event();
+          gto::disc::EventSupport s;
+          need(17);
+          s.hq_count = w[at]; s.lq_count = w[at + 1]; s.proper_pairs = w[at + 2]; s.first_in_pairs = w[at + 3]; s.sequence_reversed = w[at + 4];
+          s.clipped = w[at + 5]; s.max_mapq = w[at + 6]; s.max_distance = w[at + 7]; s.uniq_pos1 = static_cast<int32_t>(w[at + 8]);
+          s.uniq_pos2 = static_cast<int32_t>(w[at + 9]); s.uniq_pos3 = static_cast<int32_t>(w[at + 10]); s.span = w[at + 11];
+          s.has_realignment_support = w[at + 12]; s.has_indel_good_support = w[at + 13]; s.max_log_qual = w[at + 14];
+          s.max_log_qual_file_i = static_cast<int32_t>(w[at + 15]);
+          long const n_phase = w[at + 16];
+          at += 17;
+          for (long k = 0; k < n_phase; ++k)
+          {
+            gto::disc::Event pe = event();
+            need(1);
+            s.phase[pe] = static_cast<uint16_t>(w[at++]);
+          }
+          r.indels.insert({e, s});
+        }
+        need(1);
+        long const n_haps = w[at++];
+        for (long i = 0; i < n_haps; ++i)
+        {
+          gto::disc::Event e = event();
+          FP::Thap t;
+          for (std::set<gto::disc::Event> * set : {&t.ever_together, &t.always_together})
+          {
+            need(1);
+            long const m = w[at++];
+            for (long k = 0; k < m; ++k)
+              set->insert(event());
+          }
+          r.haplotypes.insert({e, t});
+        }
+        if (at != n)
+          throw std::runtime_error("gto_disc_merge: words behind the stream");
+        return r;
+      };
+      FP::Result a = parse(into, n_into), b = parse(from, n_from);
+      FP::merge(a, b);
+      std::vector<uint32_t> const s = FP::dump(a);
+      if (static_cast<long>(s.size()) <= cap)
+        std::memcpy(out, s.data(), s.size() * 4);
+      return static_cast<long>(s.size());
+    }
+    catch (std::exception const & e)
+    {
+      g_error = e.what();
+      return -1;
+    }
+  }
+
   // ---- small known-answer helpers (pinned against test/utilities/*.cpp, test/typer/test_path.cpp) ----
   long gto_to_uint64_vec(uint8_t const * codes, long len, long i, uint64_t * out, long cap)
   {

@@ -2,8 +2,10 @@
 // the per-sample first pass over the reads of a region, run_first_pass (src/typer/caller.cpp:488-1186) up to and including its
 // two support filters -- SNP / indel events read off the CIGARs with their EventSupport, the phase counts between the events
 // of a read, the coverage difference arrays, has_good_support for SNPs, the good-support / realignment-support classes of
-// indels.  What follows in the reference (haplotypes of the surviving events, realignment through paw::pairwise_alignment
-// -- a dependency absent from the reference tree --, the second pass) is not restated.
+// indels; then the end of the pass (:1186-1365: which events of a sample travel together -- "ever" and "always" -- from the phase
+// counts and the coverage), merge_haplotypes2 (:64-165) and the union of the files' indels (streamlined_discovery, :2853-2903).
+// What follows in the reference (realignment through paw::pairwise_alignment -- a dependency absent from the reference tree --,
+// the second pass) is not restated.
 // PARITY UNPINNED: the reference holds no test or vector for discovery (test/typer has none); this follows the text line by line.
 #pragma once
 #include <algorithm>
@@ -11,6 +13,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -41,6 +44,7 @@ struct EventSupport
   uint16_t multi_count = 0, anti_count = 0, span = 1;
   bool has_realignment_support = false, has_indel_good_support = false;
   uint32_t max_log_qual = 0;
+  int32_t max_log_qual_file_i = 0; // (event.hpp: which file had the best support of an indel)
 
   int get_raw_support() const { return hq_count + lq_count; }
   double corrected_support() const { return static_cast<double>(hq_count) + static_cast<double>(lq_count) / 2.0; }
@@ -85,6 +89,29 @@ struct FirstPass
   using Events = std::map<Event, EventSupport>;
   std::vector<Events> buckets;
   std::vector<uint32_t> cov_up, cov_down;
+  // what the product's device kernel hands its host stage, made here so that the host stage can be tested without a device
+  // (include/gtx.h: gtx_disc_event, gtx_disc_read_out)
+  struct RawEvent
+  {
+    uint32_t read, pos, seq;
+    uint16_t len;
+    uint8_t type, hq;
+    uint16_t max_distance, reserved;
+  };
+  struct ReadOut
+  {
+    uint32_t first_event, n_events;
+    int32_t pos_end;
+    uint32_t state; // 0 skipped, 1 counted, 2 the pass ends here
+  };
+  std::vector<RawEvent> raw_events;
+  std::vector<ReadOut> read_outs;
+  long file_i = 0;
+  struct Thap // HaplotypeInfo (caller.cpp:45-52); ordered sets: only membership matters
+  {
+    std::set<Event> ever_together, always_together;
+  };
+  std::map<Event, Thap> sample_haplotypes;
 
   static bool is_clipped(Read const & r) // caller.cpp:167-196
   {
@@ -156,8 +183,11 @@ struct FirstPass
     cov_down.assign(REF_SIZE, 0);
     buckets.clear();
     static char const CIGAR_MAP[] = "MIDNSHP=XB******";
+    raw_events.clear();
+    read_outs.assign(reads.size(), ReadOut{0, 0, 0, 0});
     for (Read const & r : reads)
     {
+      size_t const read_index = static_cast<size_t>(&r - reads.data());
       if (r.cigar.empty() || r.pos < region_begin) // :517-526
         continue;
       long read_offset = 0, ref_offset = static_cast<long>(r.pos) - region_begin;
@@ -165,7 +195,12 @@ struct FirstPass
       if (bucket_index >= static_cast<long>(buckets.size()))
         buckets.resize(bucket_index + 1);
       if (ref_offset >= REF_SIZE)
+      {
+        read_outs[read_index].state = 2;
         break; // :551-561
+      }
+      read_outs[read_index].state = 1;
+      read_outs[read_index].first_event = static_cast<uint32_t>(raw_events.size());
       std::vector<Events::iterator> cigar_events;
       bool const is_read_clipped = is_clipped(r);
       long const l_qseq = static_cast<long>(r.sequence.size());
@@ -225,6 +260,8 @@ struct FirstPass
             if (max_distance > s.max_distance)
               s.max_distance = static_cast<uint8_t>(max_distance);
             cigar_events.push_back(it);
+            raw_events.push_back(RawEvent{static_cast<uint32_t>(read_index), static_cast<uint32_t>(ref_pos + region_begin), static_cast<uint32_t>(static_cast<unsigned char>(rb)), 1,
+                                          'X', static_cast<uint8_t>(r.qual[read_pos] >= 25), static_cast<uint16_t>(max_distance), 0});
           }
           read_offset += cigar_count;
           ref_offset += cigar_count;
@@ -245,6 +282,8 @@ struct FirstPass
             ++it->second.hq_count;
             common(it->second);
             cigar_events.push_back(it);
+            raw_events.push_back(RawEvent{static_cast<uint32_t>(read_index), static_cast<uint32_t>(region_begin + ref_offset), static_cast<uint32_t>(b),
+                                          static_cast<uint16_t>(e_ - b), 'I', 1, 0, 0});
           }
           read_offset += cigar_count;
           break;
@@ -266,6 +305,8 @@ struct FirstPass
             ++it->second.hq_count;
             common(it->second);
             cigar_events.push_back(it);
+            raw_events.push_back(RawEvent{static_cast<uint32_t>(read_index), static_cast<uint32_t>(region_begin + ref_offset), static_cast<uint32_t>(ref_offset),
+                                          static_cast<uint16_t>(cigar_count), 'D', 1, 0, 0});
           }
           ref_offset += cigar_count;
           break;
@@ -302,6 +343,8 @@ struct FirstPass
       long const pos_end = region_begin + std::min(ref_offset, REF_SIZE - 1); // :824-834
       ++cov_up[r.pos - region_begin];
       ++cov_down[pos_end - region_begin];
+      read_outs[read_index].n_events = static_cast<uint32_t>(raw_events.size()) - read_outs[read_index].first_event;
+      read_outs[read_index].pos_end = static_cast<int32_t>(pos_end - region_begin);
     }
     if ((static_cast<long>(buckets.size()) - 1l) * BUCKET_SIZE >= REF_SIZE) // :868-874
       buckets.resize(((REF_SIZE - 1) / BUCKET_SIZE) + 1);
@@ -390,6 +433,7 @@ struct FirstPass
           info.has_indel_good_support = true;
           info.has_realignment_support = true;
           info.max_log_qual = log_qual;
+          info.max_log_qual_file_i = static_cast<int32_t>(file_i);
           ++it;
         }
         else if (count >= 3.0 && log_qual > 0 && info.proper_pairs >= 1 && (info.hq_count >= 5 || info.max_mapq >= 25) && info.max_mapq >= 10 &&
@@ -397,6 +441,7 @@ struct FirstPass
         {
           info.has_realignment_support = true;
           info.max_log_qual = log_qual;
+          info.max_log_qual_file_i = static_cast<int32_t>(file_i);
           ++it;
         }
         else
@@ -406,6 +451,197 @@ struct FirstPass
         break;
       for (long offset = b * BUCKET_SIZE, end = std::min(REF_SIZE, (b + 1) * BUCKET_SIZE); offset < end; ++offset)
         depth += static_cast<long>(cov_up[offset]) - static_cast<long>(cov_down[offset]);
+    }
+  }
+
+  // The end of run_first_pass (caller.cpp:1186-1365): for every event left, which later events within two buckets it is seen
+  // with ("ever": in enough of the reads that cover both; "always": those at most 10 positions on), judged from its phase counts
+  // and the coverage between the two; the SNPs then leave the buckets (they live on in the haplotype map).
+  void run_haplotypes(std::string const & reference, long region_begin, long BUCKET_SIZE)
+  {
+    long const REF_SIZE = reference.size(), NUM_BUCKETS = buckets.size();
+    uint16_t const IS_ANY_HAP_SUPPORT = 1, IS_ANY_ANTI_HAP_SUPPORT = 2; // constants.hpp.in:56-57
+    auto update_coverage = [&](long & cov, long const pos, long const b)
+    {
+      long offset = pos + 1;
+      if (offset > b * BUCKET_SIZE)
+      {
+        offset = b * BUCKET_SIZE;
+        while (offset <= pos)
+        {
+          cov += static_cast<long>(cov_up[offset]) - static_cast<long>(cov_down[offset]);
+          ++offset;
+        }
+      }
+    };
+    sample_haplotypes.clear();
+    long depth = 0;
+    for (long b = 0; b < NUM_BUCKETS; ++b)
+    {
+      Events & bucket = buckets[b];
+      for (auto event_it = bucket.begin(); event_it != bucket.end();)
+      {
+        Event const & event = event_it->first;
+        EventSupport const & info = event_it->second;
+        long const begin = std::max(0l, static_cast<long>(event.pos) - region_begin);
+        long cov = depth;
+        Thap & hap = sample_haplotypes.insert({event, Thap()}).first->second;
+        update_coverage(cov, begin, b);
+        double support_ratio = static_cast<double>(info.get_raw_support()) / static_cast<double>(cov);
+        if (support_ratio < 0.3)
+          support_ratio = 0.3;
+        auto is_good_support = [&](long local_cov, long local_offset, Event const & other) -> uint16_t // :1216-1268
+        {
+          auto const find_it = info.phase.find(other);
+          bool const is_indel = event.type != 'X' || other.type != 'X';
+          if (is_indel)
+            return (find_it == info.phase.end() || find_it->second == 0) ? IS_ANY_ANTI_HAP_SUPPORT : (IS_ANY_HAP_SUPPORT | IS_ANY_ANTI_HAP_SUPPORT);
+          long const end = std::max(0l, static_cast<long>(other.pos) - region_begin);
+          while (local_offset <= end)
+          {
+            local_cov -= local_offset < REF_SIZE ? static_cast<long>(cov_down[local_offset]) : 0l; // (behind the region: nothing ends there)
+            ++local_offset;
+          }
+          if (local_cov <= 2)
+            return 0;
+          double const support = find_it == info.phase.end() ? 0.0 : find_it->second;
+          if ((support / static_cast<double>(local_cov) / support_ratio) < 0.22)
+            return IS_ANY_ANTI_HAP_SUPPORT;
+          if ((support / static_cast<double>(local_cov) / support_ratio) > 0.78)
+            return IS_ANY_HAP_SUPPORT;
+          return IS_ANY_ANTI_HAP_SUPPORT | IS_ANY_HAP_SUPPORT;
+        };
+        for (auto it2 = std::next(event_it); it2 != bucket.end(); ++it2) // this bucket (:1271-1294)
+        {
+          Event const & other = it2->first;
+          if (other.pos == event.pos && other.type == event.type)
+            continue;
+          if ((is_good_support(cov, begin + 1, other) & IS_ANY_HAP_SUPPORT) != 0)
+          {
+            hap.ever_together.insert(other);
+            if (other.pos <= event.pos + 10)
+              hap.always_together.insert(other);
+          }
+        }
+        if (b + 1 < NUM_BUCKETS) // the next one (:1297-1318)
+          for (auto const & kv : buckets[b + 1])
+            if ((is_good_support(cov, begin + 1, kv.first) & IS_ANY_HAP_SUPPORT) != 0)
+            {
+              hap.ever_together.insert(kv.first);
+              if (kv.first.pos <= event.pos + 10)
+                hap.always_together.insert(kv.first);
+            }
+        if (b + 2 < NUM_BUCKETS) // and the one behind it, up to two bucket sizes away (:1321-1342)
+          for (auto const & kv : buckets[b + 2])
+          {
+            if (kv.first.pos >= event.pos + 2 * BUCKET_SIZE)
+              break;
+            if ((is_good_support(cov, begin + 1, kv.first) & IS_ANY_HAP_SUPPORT) != 0)
+              hap.ever_together.insert(kv.first);
+          }
+        if (event_it->first.type == 'X') // :1345-1348
+          event_it = bucket.erase(event_it);
+        else
+          ++event_it;
+      }
+      if (b * BUCKET_SIZE >= REF_SIZE)
+        break;
+      for (long offset = b * BUCKET_SIZE, end = std::min(REF_SIZE, (b + 1) * BUCKET_SIZE); offset < end; ++offset)
+        depth += static_cast<long>(cov_up[offset]) - static_cast<long>(cov_down[offset]);
+    }
+  }
+
+  // what a file leaves behind: its indels (Tindel_events) and its haplotype map
+  struct Result
+  {
+    Events indels;
+    std::map<Event, Thap> haplotypes;
+  };
+  Result result() const
+  {
+    Result r;
+    for (auto const & bucket : buckets)
+      for (auto const & kv : bucket)
+        r.indels.insert(kv);
+    r.haplotypes = sample_haplotypes;
+    return r;
+  }
+  // merge_haplotypes2 (caller.cpp:64-165) and the union of the indels (streamlined_discovery, :2853-2903)
+  static void merge(Result & into, Result & from)
+  {
+    if (into.haplotypes.empty())
+      into.haplotypes = std::move(from.haplotypes);
+    else
+      for (auto & kv : from.haplotypes)
+      {
+        auto ins = into.haplotypes.insert(kv);
+        Thap & mine = ins.first->second;
+        if (ins.second)
+        {
+          for (auto it = mine.always_together.begin(); it != mine.always_together.end();)
+            it = into.haplotypes.count(*it) > 0 ? mine.always_together.erase(it) : std::next(it);
+        }
+        else
+        {
+          mine.ever_together.insert(kv.second.ever_together.begin(), kv.second.ever_together.end());
+          std::set<Event> both;
+          for (Event const & e : kv.second.always_together)
+            if (mine.always_together.count(e) > 0)
+              both.insert(e);
+          mine.always_together = std::move(both);
+        }
+      }
+    from.haplotypes.clear();
+    for (auto & kv : from.indels)
+    {
+      auto ins = into.indels.insert(kv);
+      if (!ins.second)
+      {
+        EventSupport & old_info = ins.first->second;
+        old_info.has_indel_good_support |= kv.second.has_indel_good_support;
+        if (kv.second.max_log_qual > old_info.max_log_qual)
+        {
+          old_info.max_log_qual = kv.second.max_log_qual;
+          old_info.max_log_qual_file_i = kv.second.max_log_qual_file_i;
+        }
+      }
+    }
+    from.indels.clear();
+  }
+  static std::vector<uint32_t> dump(Result const & r)
+  {
+    std::vector<uint32_t> s;
+    s.push_back(static_cast<uint32_t>(r.indels.size()));
+    for (auto const & kv : r.indels)
+      put_support(s, kv.first, kv.second, true);
+    s.push_back(static_cast<uint32_t>(r.haplotypes.size()));
+    for (auto const & kv : r.haplotypes)
+    {
+      put_event(s, kv.first);
+      for (std::set<Event> const * set : {&kv.second.ever_together, &kv.second.always_together})
+      {
+        s.push_back(static_cast<uint32_t>(set->size()));
+        for (Event const & e : *set)
+          put_event(s, e);
+      }
+    }
+    return s;
+  }
+  static void put_support(std::vector<uint32_t> & s, Event const & e, EventSupport const & i, bool with_file)
+  {
+    put_event(s, e);
+    for (uint32_t v : {uint32_t(i.hq_count), uint32_t(i.lq_count), uint32_t(i.proper_pairs), uint32_t(i.first_in_pairs), uint32_t(i.sequence_reversed),
+                       uint32_t(i.clipped), uint32_t(i.max_mapq), uint32_t(i.max_distance), uint32_t(i.uniq_pos1), uint32_t(i.uniq_pos2),
+                       uint32_t(i.uniq_pos3), uint32_t(i.span), uint32_t(i.has_realignment_support), uint32_t(i.has_indel_good_support),
+                       i.max_log_qual})
+      s.push_back(v);
+    if (with_file)
+      s.push_back(static_cast<uint32_t>(i.max_log_qual_file_i));
+    s.push_back(static_cast<uint32_t>(i.phase.size()));
+    for (auto const & ph : i.phase)
+    {
+      put_event(s, ph.first);
+      s.push_back(ph.second);
     }
   }
 

@@ -264,7 +264,205 @@ def test_oracle_runs_over_simulated_alignments():
     assert oracle_first_pass(ref, rb, reads, bucket_size=50).tolist() == oracle_first_pass(ref, rb, reads, bucket_size=777).tolist()
 
 
-def product_first_pass(reference, region_begin, reads, bucket_size=50, event_cap=None):
+def oracle_full(reference, region_begin, reads, bucket_size=50, file_i=0):
+    """the pass to its end through the oracle -> (result words, events, read states): the last two in the product's layouts"""
+    L = olib()
+    L.gto_first_pass_full.restype = C.c_long
+    n = len(reads)
+    pos = np.array([r["pos"] for r in reads], np.int32)
+    flag = np.array([r["flag"] for r in reads], np.uint16)
+    mapq = np.array([r["mapq"] for r in reads], np.uint8)
+    cg = np.array([w for r in reads for w in r["cigar"]] + [0], np.uint32)
+    cg_off = np.cumsum([0] + [len(r["cigar"]) for r in reads]).astype(np.uint32)
+    codes = np.array([CODE[c] for r in reads for c in r["seq"]] + [0], np.uint8)
+    qual = np.array([q for r in reads for q in r["qual"]] + [0], np.uint8)
+    c_off = np.cumsum([0] + [len(r["seq"]) for r in reads]).astype(np.uint32)
+    cap, ev_cap = 1 << 16, 64 * max(n, 1)
+    while True:
+        out = np.zeros(cap, np.uint32)
+        events = np.zeros(ev_cap, gtx.DISC_EVENT)
+        read_out = np.zeros(max(n, 1), gtx.DISC_READ_OUT)
+        n_ev = C.c_long()
+        w = L.gto_first_pass_full(reference.encode(), C.c_long(region_begin), C.c_long(bucket_size), C.c_long(file_i), C.c_long(n), _p(pos), _p(flag), _p(mapq),
+                                  _p(cg), _p(cg_off), _p(codes), _p(qual), _p(c_off), _p(out), C.c_long(cap), _p(events), C.c_long(ev_cap), C.byref(n_ev),
+                                  _p(read_out))
+        if w == -2:
+            ev_cap = int(n_ev.value)
+            continue
+        assert w >= 0, L.gto_last_error()
+        if w <= cap:
+            return out[:w], events[:n_ev.value], read_out[:n]
+        cap = int(w)
+
+
+def oracle_merge(a, b):
+    L = olib()
+    L.gto_disc_merge.restype = C.c_long
+    a, b = np.ascontiguousarray(a, np.uint32), np.ascontiguousarray(b, np.uint32)
+    out = np.zeros(len(a) + len(b) + 16, np.uint32)
+    w = L.gto_disc_merge(_p(a), C.c_long(len(a)), _p(b), C.c_long(len(b)), _p(out), C.c_long(len(out)))
+    assert 0 <= w <= len(out), L.gto_last_error()
+    return out[:w]
+
+
+def _host_inputs(reads):
+    n = len(reads)
+    stride = max(16, (max(len(r["seq"]) for r in reads) + 31) // 32 * 16)
+    codes = np.zeros((n, stride * 2), np.uint8)
+    dr = np.zeros(n, gtx.DISC_READ)
+    cg = []
+    for i, r in enumerate(reads):
+        codes[i, :len(r["seq"])] = [CODE[c] for c in r["seq"]]
+        dr[i] = (r["pos"], r["flag"], r["mapq"], 0, len(r["seq"]), len(r["cigar"]), len(cg))
+        cg.extend(r["cigar"])
+    return dr, np.array(cg + [0], np.uint32), gtx.pack_nibbles(codes, stride=stride), stride
+
+
+def product_host_stage(reference, region_begin, reads, events, read_out, bucket_size=50, file_i=None, handle=None):
+    """gtx_disc_first_pass (file_i None) or gtx_disc_first_pass_haplotypes over events made elsewhere (a device, or the oracle)"""
+    L = gtx.lib()
+    dr, cg, nib, stride = _host_inputs(reads)
+    h = handle
+    if h is None:
+        h = C.c_void_p()
+        gtx.check(L.gtx_disc_create(reference.encode(), len(reference), region_begin, -1, C.byref(h)))
+    events, read_out = np.ascontiguousarray(events, gtx.DISC_EVENT), np.ascontiguousarray(read_out, gtx.DISC_READ_OUT)
+    n_words, words = C.c_uint64(), np.zeros(1 << 16, np.uint32)
+    while True:
+        if file_i is None:
+            rc = L.gtx_disc_first_pass(h, _p(dr), _p(cg), _p(read_out), len(reads), _p(events), len(events), _p(nib), stride, bucket_size, _p(words), len(words),
+                                       C.byref(n_words))
+        else:
+            rc = L.gtx_disc_first_pass_haplotypes(h, _p(dr), _p(cg), _p(read_out), len(reads), _p(events), C.c_uint64(len(events)), _p(nib), stride, bucket_size,
+                                                  C.c_int32(file_i), _p(words), C.c_uint64(len(words)), C.byref(n_words))
+        if rc == 5 and n_words.value > len(words):
+            words = np.zeros(int(n_words.value), np.uint32)
+            continue
+        break
+    if handle is None:
+        L.gtx_disc_destroy(h)
+    assert rc == 0, gtx.lib().gtx_last_error()
+    return words[:n_words.value]
+
+
+def product_merge(a, b):
+    L = gtx.lib()
+    a, b = np.ascontiguousarray(a, np.uint32), np.ascontiguousarray(b, np.uint32)
+    out, n = np.zeros(len(a) + len(b) + 16, np.uint32), C.c_uint64()
+    gtx.check(L.gtx_disc_merge(_p(a), C.c_uint64(len(a)), _p(b), C.c_uint64(len(b)), _p(out), C.c_uint64(len(out)), C.byref(n)))
+    return out[:n.value]
+
+
+def parse_result(words):
+    """result words -> (indels [(pos, type, seq)], {event: (ever set, always set)})"""
+    i = 0
+
+    def ev():
+        nonlocal i
+        p, t, ln = int(words[i]), chr(int(words[i + 1])), int(words[i + 2])
+        s = "".join(chr(int(x)) for x in words[i + 3:i + 3 + ln])
+        i += 3 + ln
+        return (p, t, s)
+    indels = []
+    n = int(words[i]); i += 1
+    for _ in range(n):
+        e = ev()
+        i += 16
+        np_ = int(words[i]); i += 1
+        for _ in range(np_):
+            ev(); i += 1
+        indels.append(e)
+    haps = {}
+    n = int(words[i]); i += 1
+    for _ in range(n):
+        e = ev()
+        sets = []
+        for _ in range(2):
+            m = int(words[i]); i += 1
+            sets.append({ev() for _ in range(m)})
+        haps[e] = tuple(sets)
+    assert i == len(words)
+    return indels, haps
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_host_stages_equal_the_oracle(seed):
+    """the product's host stages over the events the oracle's walk makes (no device): the state behind the two filters, the pass to
+    its end (haplotype map, indels), and the merge of three files' results in their order"""
+    ref, rb, reads = simulate(seed, n_reads=3000 if seed % 2 else 1200, read_len=150 if seed != 4 else 250)
+    want_full, events, read_out = oracle_full(ref, rb, reads, file_i=0)
+    assert np.array_equal(product_host_stage(ref, rb, reads, events, read_out), oracle_first_pass(ref, rb, reads))
+    got_full = product_host_stage(ref, rb, reads, events, read_out, file_i=0)
+    assert np.array_equal(got_full, want_full)
+    indels, haps = parse_result(got_full)
+    assert len(haps) > 20 and any(ever for ever, _ in haps.values())
+    assert all(t != "X" for _, t, _ in indels) and all(always <= ever for ever, always in haps.values())
+    # three "files": the same region seen by other reads; merged in order
+    acc_o, acc_p = np.zeros(0, np.uint32), np.zeros(0, np.uint32)
+    for f in range(3):
+        _, _, rf = simulate(seed if f == 0 else 100 * seed + f, n_reads=1500, read_len=150)
+        wf, ev_f, ro_f = oracle_full(ref, rb, rf, file_i=f)
+        pf = product_host_stage(ref, rb, rf, ev_f, ro_f, file_i=f)
+        assert np.array_equal(pf, wf)
+        acc_o, acc_p = oracle_merge(acc_o, wf), product_merge(acc_p, pf)
+        assert np.array_equal(acc_p, acc_o)
+    indels, haps = parse_result(acc_p)
+    assert len(haps) > 20
+    with pytest.raises(gtx.GtxError):
+        product_merge(acc_p[:-1], acc_p)  # a cut stream is refused
+
+
+def test_two_snps_of_one_haplotype_travel_together():
+    """caller.cpp:1186-1365 worked by hand: 12 reads carry two SNPs five and sixty positions apart on one haplotype, 12 other reads
+    carry neither.  Every read that covers a pair of them shows both: support / coverage / support_ratio = 12 / 24 / 0.5 = 1 > 0.78
+    -> "ever together" for (first, second) and (first, third), (second, third); "always" only for the pair within ten positions.
+    Merged with a second sample that has the first SNP alone, its "always" set is emptied (the intersection), "ever" stays."""
+    rng = np.random.default_rng(7)
+    ref = "".join("ACGT"[i] for i in rng.integers(0, 4, 600))
+    rb, at = 2000, (300, 305, 360)
+    alts = ["ACGT"[("ACGT".index(ref[p]) + 1) % 4] for p in at]
+
+    def sample(carry, seed):
+        reads = []
+        for k in range(24):
+            start = 230 + 2 * k
+            seq = list(ref[start:start + 150])
+            if k % 2 == 0:
+                for p, a in zip(at, alts):
+                    if p in carry:
+                        seq[p - start] = a
+            reads.append(_read(rb + start, "".join(seq), cig(("M", 150)), flag=1 | 2 | (16 if (k // 2) % 2 else 0) | (64 if k % 3 else 128)))
+        return reads
+    one = sample(set(at), 1)
+    words, events, read_out = oracle_full(ref, rb, one, file_i=0)
+    got = product_host_stage(ref, rb, one, events, read_out, file_i=0)
+    assert np.array_equal(got, words)
+    indels, haps = parse_result(got)
+    e = [(rb + p, "X", a) for p, a in zip(at, alts)]
+    assert indels == [] and set(haps) == set(e)
+    assert haps[e[0]] == ({e[1], e[2]}, {e[1]}) and haps[e[1]] == ({e[2]}, set()) and haps[e[2]] == (set(), set())
+    two = sample({at[0]}, 2)
+    w2, ev2, ro2 = oracle_full(ref, rb, two, file_i=1)
+    p2 = product_host_stage(ref, rb, two, ev2, ro2, file_i=1)
+    assert np.array_equal(p2, w2) and parse_result(p2)[1] == {e[0]: (set(), set())}
+    merged = product_merge(got, p2)
+    assert np.array_equal(merged, oracle_merge(words, w2))
+    assert parse_result(merged)[1] == {e[0]: ({e[1], e[2]}, set()), e[1]: ({e[2]}, set()), e[2]: (set(), set())}
+    # the other order: the second sample's lone SNP first, then the sample with all three -- new events keep of their "always" what the
+    # accumulated map has not seen (the first SNP has been seen: it is not in anybody's set anyway), the known one takes the intersection
+    other = product_merge(p2, got)
+    assert np.array_equal(other, oracle_merge(w2, words)) and parse_result(other)[1] == parse_result(merged)[1]
+
+
+def test_no_device_no_events():
+    h = C.c_void_p()
+    gtx.check(gtx.lib().gtx_disc_create(b"ACGTACGT", 8, 0, -1, C.byref(h)))
+    d = np.zeros(64, np.uint8)
+    assert gtx.lib().gtx_disc_events_batch(h, _p(d), 16, _p(d), 32, _p(d), _p(d), 1, _p(d), 1, _p(d), _p(d), None) == 2  # GTX_ERR_NO_DEVICE
+    gtx.lib().gtx_disc_destroy(h)
+
+
+def product_first_pass(reference, region_begin, reads, bucket_size=50, event_cap=None, with_haplotypes=False):
     import torch
     L = gtx.lib()
     n = len(reads)
@@ -304,8 +502,11 @@ def product_first_pass(reference, region_begin, reads, bucket_size=50, event_cap
             words = np.zeros(int(n_words.value), np.uint32)
             continue
         break
+    full = None
+    if rc == 0 and with_haplotypes:  # the pass to its end over the same device events (the handle has the reference)
+        full = product_host_stage(reference, region_begin, reads, events[:min(int(counts[0]), cap)], read_out, bucket_size, file_i=3, handle=h)
     L.gtx_disc_destroy(h)
-    return rc, words[:n_words.value], counts
+    return (rc, words[:n_words.value], counts, full) if with_haplotypes else (rc, words[:n_words.value], counts)
 
 
 @pytest.mark.gpu
@@ -313,8 +514,9 @@ def product_first_pass(reference, region_begin, reads, bucket_size=50, event_cap
 def test_device_first_pass_equals_the_oracle(seed):
     ref, rb, reads = simulate(seed, n_reads=6000 if seed % 2 else 2500, read_len=150 if seed != 4 else 250)
     want = oracle_first_pass(ref, rb, reads)
-    rc, got, counts = product_first_pass(ref, rb, reads)
+    rc, got, counts, full = product_first_pass(ref, rb, reads, with_haplotypes=True)
     assert rc == 0 and counts[1] == 0 and counts[0] > len(reads) // 4
+    assert np.array_equal(full, oracle_full(ref, rb, reads, file_i=3)[0])  # ... and the pass to its end: indels + haplotype map
     assert len(got) == len(want) and np.array_equal(got, want), "first differing word %s" % np.nonzero(got[:min(len(got), len(want))] != want[:min(len(got), len(want))])[0][:5]
     assert len(parse(got)) > 20
     if seed == 1:  # an event buffer that is too small is reported, not silently cut
