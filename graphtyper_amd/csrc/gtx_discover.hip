@@ -9,6 +9,8 @@
 // Host: gtx_disc_first_pass keeps what is order-dependent in the reference -- which read sees an event first (span, the
 // three distinct start positions), the correction for reads with 12 and more events, the phase counts between the events
 // of a read -- by going over the reads in stream order, then applies the two support filters over the coverage arrays.
+// gtx_disc_first_pass_haplotypes takes the pass to its end (the sample's haplotype map, :1186-1365), gtx_disc_merge puts the files'
+// results together (merge_haplotypes2 :64-165, the union of the indels :2853-2903).
 // (Next: the per-event sums as a device sort + segmented reduction; only the reads with >= 12 events need the order.)
 #include <hip/hip_runtime.h>
 

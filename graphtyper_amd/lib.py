@@ -163,6 +163,9 @@ def lib():
                                             C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gtx_disc_first_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32,
                                           C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.gtx_disc_first_pass_haplotypes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32,
+                                                     C.c_uint32, C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.gtx_disc_merge.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.gtx_vcf_header.argtypes = [C.POINTER(VcfHeaderRequest), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.gtx_bgzf_compress.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.gtx_device_cache_release.argtypes = []
