@@ -897,7 +897,7 @@ def extra_pipeline(args, torch, gtx, synth, device, ctx, ref, records, n=16_000_
 
 def extra_shrink(args, torch, gtx, synth, device, ref, records, n=2_000_000):
     """The read pre-filter in front of the ingest (gtx_bam_shrink = the reference's bamshrink; host only): one sample's BAM file
-    of `n` reads over the region -> the filtered BAM, on one host thread, wall clock.  Once with the reference's depth cap (at this
+    of `n` reads over the region -> the filtered BAM, one host thread doing the filter's work, wall clock.  Once with the reference's depth cap (at this
     depth it drops most reads before they are written) and once without it (every read is trimmed, re-tagged and written)."""
     import tempfile
     d_seq, d_pos = make_reads_on_device(torch, ref, records, n, seed=4242, device=device, REGION_LEN=args.region_len, err_rate=args.err, n_rate=args.nrate)
@@ -906,8 +906,8 @@ def extra_shrink(args, torch, gtx, synth, device, ref, records, n=2_000_000):
     tmp = tempfile.mkdtemp(prefix="gtx_shrink_")
     src, dst = os.path.join(tmp, "in.bam"), os.path.join(tmp, "out.bam")
     synth.write_fixed_bam(src, "chr20", 64444167, "SAMP0000", codes, pos)
-    out = {"what": "gtx_bam_shrink of one BAM file (%d reads of %d bases over %d bp) on one host thread: inflate, pair / single-read filters, "
-                   "trimming, tag rewrite, depth bins, deflate level 1" % (n, READ_LEN, args.region_len), "bam_bytes_in": os.path.getsize(src)}
+    out = {"what": "gtx_bam_shrink of one BAM file (%d reads of %d bases over %d bp) on one host thread (the inflate team ahead of it, the output's BGZF members deflated on up to "
+                   "eight threads): pair / single-read filters, trimming, tag rewrite, depth bins, deflate level 1" % (n, READ_LEN, args.region_len), "bam_bytes_in": os.path.getsize(src)}
     for name, kw in (("with_depth_cap", dict(avg_cov_by_readlen=0.3)), ("without_depth_cap", dict(no_filter_on_coverage=1))):
         t0 = time.perf_counter()
         st = gtx.bam_shrink(src, [("chr20", REGION_BEGIN, REGION_BEGIN + args.region_len - 1)], dst, gtx.shrink_params(**kw))

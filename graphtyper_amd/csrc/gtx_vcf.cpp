@@ -1923,7 +1923,7 @@ extern "C" int gtx_bgzf_compress(const void * in, uint64_t in_len, int level, in
   }
   std::string res;
   uint8_t const * p = static_cast<uint8_t const *>(in);
-  auto member = [&](uint8_t const * data, uint32_t n) -> bool
+  auto member = [&](uint8_t const * data, uint32_t n, std::string & res) -> bool
   {
     std::vector<uint8_t> buf(compressBound(n) + 64);
     z_stream zs{};
@@ -1948,12 +1948,42 @@ extern "C" int gtx_bgzf_compress(const void * in, uint64_t in_len, int level, in
     res.append(reinterpret_cast<char const *>(tail), 8);
     return true;
   };
-  for (uint64_t at = 0; at < in_len; at += 0xff00u)
-    if (!member(p + at, static_cast<uint32_t>(std::min<uint64_t>(0xff00u, in_len - at))))
+  // members are independent: beyond a megabyte of input they are made on a few threads, each a run of consecutive members,
+  // and put together in order (the bytes are those of one thread)
+  uint64_t const n_members = (in_len + 0xff00u - 1) / 0xff00u;
+  unsigned const n_threads = n_members < 16 ? 1u : static_cast<unsigned>(std::min<uint64_t>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency() / 2)), n_members / 8));
+  std::vector<std::string> parts(std::max(1u, n_threads));
+  std::vector<char> failed(parts.size(), 0);
+  auto run = [&](unsigned k)
+  {
+    uint64_t const m0 = n_members * k / parts.size(), m1 = n_members * (k + 1) / parts.size();
+    for (uint64_t m = m0; m < m1 && !failed[k]; ++m)
+    {
+      uint64_t const at = m * 0xff00u;
+      if (!member(p + at, static_cast<uint32_t>(std::min<uint64_t>(0xff00u, in_len - at)), parts[k]))
+        failed[k] = 1;
+    }
+  };
+  if (parts.size() == 1)
+    run(0);
+  else
+  {
+    std::vector<std::thread> team;
+    for (unsigned k = 1; k < parts.size(); ++k)
+      team.emplace_back(run, k);
+    run(0);
+    for (auto & t : team)
+      t.join();
+  }
+  for (size_t k = 0; k < parts.size(); ++k)
+  {
+    if (failed[k])
     {
       gtx::g_last_error = "gtx_bgzf_compress: deflate failed";
       return GTX_ERR_IO;
     }
+    res += parts[k];
+  }
   if (with_eof)
   {
     // the end-of-file marker is a fixed member (SAM spec 4.1.2), whatever the level: deflating nothing at level 0 gives a stored

@@ -508,7 +508,7 @@ int gtx_vcf_header(const gtx_vcf_header_request *, char * out, uint64_t cap, uin
 /* BGZF members of `in` (SAM spec 4.1: gzip members of at most 0xff00 input bytes with the BC extra field), with_eof: followed
  * by the 28-byte empty member that ends a file -- what the reference's bgzf_stream (include/graphtyper/utilities/
  * bgzf_stream.hpp) makes of the text it is given.  level: zlib's 0..9, -1 = default.  out may be NULL with cap 0 to ask for
- * the size. */
+ * the size.  The members of an input of a megabyte and more are deflated on up to eight threads (the bytes are the same). */
 int gtx_bgzf_compress(const void * in, uint64_t in_len, int level, int with_eof, void * out, uint64_t cap, uint64_t * out_len);
 /* The other direction for ONE member's payload: the raw DEFLATE stream `in` (RFC 1951; what lies between a BGZF member's
  * header and its CRC32) into exactly out_len bytes -- the decoder the BAM readers use (graphtyper_amd/csrc/gtx_inflate.hpp:

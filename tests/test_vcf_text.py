@@ -215,6 +215,12 @@ def test_bgzf_members():
         at += bsize
     assert out == data and sizes[-1] == 0 and sizes[:3] == [0xff00] * 3
     assert gtx.bgzf_compress(b"", with_eof=True) == eof and gtx.bgzf_compress(b"", with_eof=False) == b""
+    # a large input is deflated on several threads, each a run of consecutive members: the bytes are those of one thread
+    big = bytes(rng.integers(65, 91, size=3_000_000).astype(np.uint8)) + data
+    for level in (1, 6):
+        one_by_one = b"".join(gtx.bgzf_compress(big[at:at + 0xff00], level=level, with_eof=False) for at in range(0, len(big), 0xff00))
+        assert gtx.bgzf_compress(big, level=level, with_eof=False) == one_by_one
+        assert gtx.bgzf_compress(big, level=level, with_eof=True) == one_by_one + eof
     # the marker is the same 28 bytes at every level (deflating nothing at level 0 would give a 31-byte stored-block member)
     for level in (0, 1, 9):
         blob = gtx.bgzf_compress(data[:70000], level=level)
