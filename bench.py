@@ -860,7 +860,7 @@ def extra_pipeline(args, torch, gtx, synth, device, ctx, ref, records, n=16_000_
     native = None
     try:
         if threads > 32:  # (beyond that every new stream's first call allocates its scratch at once: a storm of device allocations, not a loop's rate)
-            raise RuntimeError("not run with more than 32 host threads")
+            raise OverflowError
         buf2 = gtx.ScoreBuffers()
         gtx.check(L.gtx_scores_alloc(ctx.h, 1, 1 << 20, C.byref(buf2), None))
         t1 = time.perf_counter()
@@ -874,6 +874,8 @@ def extra_pipeline(args, torch, gtx, synth, device, ctx, ref, records, n=16_000_
                           "the leg above), reads_per_s_whole_call: opening the files and allocating included",
                   "reads_per_s": n / max(st["loop_s"] + (t_all - t_run), 1e-9), "reads_per_s_whole_call": n / max(t_all, 1e-9),
                   "vcf_equals_resident_run": bool(text2 == want_text), **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()}}
+    except OverflowError:
+        native = {"skipped": "not run with more than 32 host threads (measured: 15-25 M reads/s at 64, DESIGN.md section 0 item 8)"}
     except Exception as e:  # noqa: BLE001
         native = {"error": repr(e)}
     for q in paths:
