@@ -471,6 +471,9 @@ class Workload:
         evs, flight = [], []
         n_l = len(self.lanes)
         pace = os.environ.get("GTX_BENCH_PACE", "1") != "0"
+        score_on = os.environ.get("GTX_BENCH_SCORE_ON", "H")
+        if score_on == "S" and not hasattr(self, "score_stream"):
+            self.score_stream = torch.cuda.Stream(device=self.device)
         for _ in range(steps):
             ln = self.lanes[self.steps_done % n_l]
             if pace:
@@ -494,6 +497,12 @@ class Workload:
                 e1.record(T)
             ln["items"] = d_items
             evs.append((e0, e1))
+            if score_on == "T":  # (experiment: the step's scoring and calls behind its own queues, on the tail stream)
+                self._score(ln, T, [ln["aligned"]])
+                continue
+            if score_on == "S":  # (experiment: on a stream of its own, behind the step's last alignment pass)
+                self._score(ln, self.score_stream, [ln["aligned"]])
+                continue
             flight.append(ln)
             if len(flight) == n_l:  # (the oldest step in flight: its queues had the last n_l - 1 position-hinted passes to drain)
                 old = flight.pop(0)

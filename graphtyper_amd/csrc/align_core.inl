@@ -2075,6 +2075,70 @@ GTX_DEV uint32_t expand_keys(uint8_t const * rd, uint32_t at, uint64_t * keys, u
   return n;
 }
 
+// The same list, a key per lane, for any number of ambiguous bases (`amb`: their places in the k-mer; `base`: the key of the
+// other bases).  The list's order is a mixed-radix number read from the last ambiguous base backwards: when base j (set S_j of
+// s_j bases) meets a list of n entries, entry u keeps its place with the LAST base of S_j and entries n + u (s_j - 1) + k are its
+// copies with the k-th of the other bases, ascending -- so entry e of the final list is decoded by peeling one base at a time:
+// e < n: last(S_j), parent e; else parent (e - n) / (s_j - 1), base (e - n) % (s_j - 1).  The reference gives up (empty list)
+// when it starts ANY base position with more than 97 keys, so a list may only outgrow 97 on the k-mer's last base.
+// Returns the number of keys in ws.u.keybuf, 0 = gave up, 0xFFFFFFFF = the list outgrows this pass' key buffer.
+// (the leader's loop of expand_keys -- 32 positions times every key, each a dependent LDS update -- was 0.4 M cycles for three Ns)
+template <class W, class WS>
+GTX_DEV uint32_t expand_keys_lanes(WS & ws, uint32_t at, uint32_t amb, uint64_t base)
+{
+  auto set_of = [&](uint32_t t) {
+    uint32_t const code = GTX_U(static_cast<uint32_t>(ws.rd[at + t])) & 15u;
+    return (code == 0u || code == 15u) ? 15u : code;
+  };
+  uint32_t n = 1;
+  for (uint32_t rest = amb; rest; rest &= rest - 1u)
+  {
+    uint32_t const t = static_cast<uint32_t>(__builtin_ctz(rest));
+    (void)t;
+    if (n > 97)
+      return 0; // (the position behind the one that made the list this long)
+    uint32_t const fan = static_cast<uint32_t>(__builtin_popcount(set_of(t)));
+    if (fan * n > AlignCfg::KEY_CAP)
+      return 0xFFFFFFFFu;
+    n *= fan;
+  }
+  if (n > 97 && (amb >> 31) == 0u)
+    return 0; // (a base position follows the last ambiguous one)
+  uint32_t const total = n;
+  for (uint32_t b = 0; b < total; b += 64)
+    W::lanes([&](uint32_t l) {
+      uint32_t e = b + l;
+      if (e < total)
+      {
+        uint64_t key = base;
+        uint32_t size = total;
+        for (uint32_t rest = amb; rest;)
+        {
+          uint32_t const t = 31u - static_cast<uint32_t>(__builtin_clz(rest));
+          rest &= ~(1u << t);
+          uint32_t const set = set_of(t), fan = static_cast<uint32_t>(__builtin_popcount(set));
+          uint32_t const last = 31u - static_cast<uint32_t>(__builtin_clz(set));
+          uint32_t const before = size / fan;
+          uint32_t bs = last;
+          if (e >= before)
+          {
+            uint32_t const k = (e - before) % (fan - 1u);
+            e = (e - before) / (fan - 1u);
+            uint32_t others = set & ~(1u << last);
+            for (uint32_t x = 0; x < k; ++x)
+              others &= others - 1u;
+            bs = static_cast<uint32_t>(__builtin_ctz(others));
+          }
+          key |= (static_cast<uint64_t>(bs & 1u) << t) | (static_cast<uint64_t>(bs >> 1) << (32u + t));
+          size = before;
+        }
+        ws.u.keybuf[b + l] = key;
+      }
+    });
+  W::lds_sync();
+  return total;
+}
+
 // Wave-parallel probe of a key list (`nkeys` keys: either keybuf[0..nkeys) or the 96 Hamming-1 neighbours of `base`
 // generated on the fly) with the multi_get rule: a list of more than one key whose hits total more than
 // max_index_labels yields nothing.  Labels land in ws.lbl in key order, bucket order inside a key (stable prefix-sum
@@ -2831,13 +2895,7 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
         }
         else
         {
-          GTX_LEAD
-          {
-            nk = expand_keys(ws.rd, rs, ws.u.keybuf, AlignCfg::KEY_CAP);
-            ws.n_keys = nk;
-          }
-          W::lds_sync();
-          nk = GTX_U(ws.n_keys);
+          nk = expand_keys_lanes<W>(ws, rs, amb, GTX_U(ws.key0[i]));
           if (nk == 0xFFFFFFFFu)
           {
             status |= GTX_ST_LABEL_OVERFLOW;

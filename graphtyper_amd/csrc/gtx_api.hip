@@ -23,6 +23,14 @@
 
 namespace gtx
 {
+// profile counters (GraphView::prof): 32 sums, then -- profiling build -- the count and the entries of the general pass' task log
+#ifdef GTX_PROF
+constexpr uint64_t PROF_LOG_ENTRIES = 1u << 16, PROF_LOG_ENTRY = 16;
+#else
+constexpr uint64_t PROF_LOG_ENTRIES = 0, PROF_LOG_ENTRY = 16;
+#endif
+constexpr uint64_t PROF_WORDS = 40 + PROF_LOG_ENTRIES * PROF_LOG_ENTRY;
+
 // Scoring adds small integers to per-(haplotype, sample) counters, and the reads of a workgroup -- neighbours in a
 // position-sorted stream -- hit the same few counters: 1 500 reads deep, every counter of a site would take thousands of
 // same-address atomics at the L2.  The workgroup therefore sums into an LDS table keyed by the counter's address first and
@@ -750,6 +758,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_GENERAL_
     uint32_t * rec = records + static_cast<uint64_t>(task) * rec_words;
 #ifdef GTX_PROF
     unsigned long long const task_t0 = clock64();
+    unsigned long long phase0 = 0;
+    WaveHip::lds_sync();
+    if (threadIdx.x < 10)
+      phase0 = ws.prof_acc[threadIdx.x];
+    WaveHip::lds_sync();
 #endif
     uint32_t const st = align_one<WaveHip>(g, ix, ws, seq + static_cast<uint64_t>(read) * seq_stride, len, orient == 1, rec, rec_words,
                                            /*try_fast=*/false);
@@ -767,6 +780,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_GENERAL_
         atomicAdd(g.prof + 12, 1ull);
       if (dt > 400000ull)
         atomicAdd(g.prof + 13, 1ull);
+    }
+    // (the task log: one entry of PROF_LOG_ENTRY words per task of this pass -- task, workgroup, start, cycles, the hardware
+    //  id of the wavefront's place, the records' first words, then the cycles of phases 0..9; tools/task_log.py reads it)
+    {
+      unsigned long long slot = 0;
+      if ((threadIdx.x & 63u) == 0)
+        slot = atomicAdd(g.prof + 32, 1ull);
+      slot = WaveHip::uni(static_cast<uint64_t>(slot));
+      if (slot < PROF_LOG_ENTRIES)
+      {
+        unsigned long long * e = g.prof + 40 + slot * PROF_LOG_ENTRY;
+        if ((threadIdx.x & 63u) == 0)
+        {
+          e[0] = task;
+          e[1] = blockIdx.x;
+          e[2] = task_t0;
+          e[3] = clock64() - task_t0;
+          e[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11))) << 32);
+          e[5] = (static_cast<unsigned long long>(rec[1]) << 32) | rec[0];
+        }
+        if (threadIdx.x < 10)
+          e[6 + threadIdx.x] = ws.prof_acc[threadIdx.x] - phase0;
+      }
     }
 #endif
     // a table of this pass overflowed: queue the task for the next pass (gtx_align_big_kernel)
@@ -861,6 +897,19 @@ __global__ __launch_bounds__(256) void gtx_task_flags_all_kernel(uint32_t const 
 #define GTX_TRIAGE_THREADS 64
 #endif
 constexpr uint32_t TRIAGE_THREADS = GTX_TRIAGE_THREADS, TRIAGE_PER_THREAD = 1024 / GTX_TRIAGE_THREADS;
+// records that are not results: a table-overflow status nobody took away (GTX_ST_ERROR_MASK) -- one count per workgroup visit
+__global__ __launch_bounds__(256) void gtx_records_failed_kernel(uint32_t const * __restrict__ records, uint32_t rec_words, uint64_t n_slots,
+                                                                 unsigned long long * __restrict__ count)
+{
+  unsigned long long mine = 0;
+  for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < n_slots; t += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+    mine += ((records[t * rec_words] >> 16) & GTX_ST_ERROR_MASK) != 0u ? 1ull : 0ull;
+  for (int d = 32; d >= 1; d >>= 1)
+    mine += __shfl_xor(mine, d);
+  if ((threadIdx.x & 63u) == 0 && mine)
+    atomicAdd(count, mine);
+}
+
 __global__ __launch_bounds__(TRIAGE_THREADS) void gtx_score_triage_kernel(gtx_score_item const * __restrict__ items, uint32_t n_items,
                                                                           uint32_t const * __restrict__ records, uint32_t rec_words,
                                                                           uint32_t * __restrict__ work_queue, uint32_t * work_count,
@@ -1334,12 +1383,12 @@ int ctx_upload(gtx_ctx & c, int device)
   ok = ok && upload(c.dev_allocs, v.near_off, h.near_off.data(), h.near_off.size(), "near_off");
   lap("graph tables");
   void * pf = nullptr;
-  ok = ok && hip_ok(gtx::dev_malloc(&pf, 32 * sizeof(unsigned long long)), "profile counters");
+  ok = ok && hip_ok(gtx::dev_malloc(&pf, PROF_WORDS * sizeof(unsigned long long)), "profile counters");
   if (ok)
   {
     c.dev_allocs.push_back(pf);
     v.prof = static_cast<unsigned long long *>(pf);
-    ok = hip_ok(gtx::dev_zero(pf, 32 * sizeof(unsigned long long)), "profile counters");
+    ok = hip_ok(gtx::dev_zero(pf, PROF_WORDS * sizeof(unsigned long long)), "profile counters");
   }
   void * ef = nullptr;
   ok = ok && hip_ok(gtx::dev_malloc(&ef, sizeof(uint32_t)), "error flag");
@@ -1817,8 +1866,10 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
       if (!hip_ok(hipGetLastError(), "gtx_align_hinted_kernel launch"))
         return GTX_ERR_HIP;
       mark(part, 1, st);
-      // (gtx_align_batch_planes_staged: from here on the call is short queues -- the caller's other streams may come in)
-      if (first + step >= n_reads)
+      // (gtx_align_batch_planes_staged: from here on the call is short queues -- the caller's other streams may come in;
+      //  GTX_STAGED_FRONT=express: the express pass stays on the caller's stream as well and the front event is recorded behind it)
+      static bool const front_with_express = std::getenv("GTX_STAGED_FRONT") && std::getenv("GTX_STAGED_FRONT")[0] == 'e';
+      if (first + step >= n_reads && !front_with_express)
         front_done();
       // (the queue's length is known on the device only: the grid is what can be resident, or one wavefront per group of four
       //  reads of a small batch; the kernel sizes its claims to the queue)
@@ -1831,6 +1882,8 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
       hipLaunchKernelGGL(wide ? gtx_align_express4q_wide_kernel : gtx_align_express4q_kernel, dim3(blocks4q), dim3(64), 0, s1, c->dev_graph,
                          c->dev_index, seq, seq_stride, meta, records, rec_words, counters, queue1, counters + 3, queue2, counters + 2,
                          counters + 4, static_cast<uint32_t>(force != 0) | (express_goal << 8));
+      if (first + step >= n_reads && front_with_express)
+        front_done();
     }
     else
     {
@@ -2431,6 +2484,67 @@ extern "C" int gtx_ctx_error_count(gtx_ctx * c, uint32_t * out)
     return GTX_OK;
   if (!hip_ok(hipMemcpy(out, c->d_error_flag, sizeof(uint32_t), hipMemcpyDeviceToHost), "error flag"))
     return GTX_ERR_HIP;
+  return GTX_OK;
+}
+
+// How many of the 2 * n_reads record slots of gtx_align_batch hold a table-overflow status instead of a result (a record arena
+// that was full, an exact-pass slab too small, a read beyond the supported length): every one of them is a read the
+// accumulators lack.  Synchronises with `stream`.
+extern "C" int gtx_records_failed(gtx_ctx * c, const uint32_t * d_records, uint32_t rec_words, uint64_t n_reads, void * stream, uint64_t * out)
+{
+  if (!c || !out || rec_words < 8 || (n_reads && !d_records))
+    return GTX_ERR_ARG;
+  *out = 0;
+  if (c->device < 0)
+  {
+    g_last_error = "context was created without a device (libgtx has no CPU path)";
+    return GTX_ERR_NO_DEVICE;
+  }
+  if (n_reads == 0)
+    return GTX_OK;
+  if (!hip_ok(hipSetDevice(c->device), "hipSetDevice"))
+    return GTX_ERR_HIP;
+  hipStream_t const st = static_cast<hipStream_t>(stream);
+  void * d_count = nullptr;
+  if (!hip_ok(gtx::dev_malloc(&d_count, sizeof(unsigned long long)), "failed-record counter"))
+    return GTX_ERR_HIP;
+  unsigned long long n = 0;
+  bool ok = hip_ok(hipMemsetAsync(d_count, 0, sizeof n, st), "failed-record counter");
+  if (ok)
+  {
+    uint64_t const slots = 2ull * n_reads;
+    uint32_t const blocks = static_cast<uint32_t>(std::min<uint64_t>((slots + 255u) / 256u, 4096u));
+    hipLaunchKernelGGL(gtx_records_failed_kernel, dim3(blocks), dim3(256), 0, st, d_records, rec_words, slots, static_cast<unsigned long long *>(d_count));
+    ok = hip_ok(hipGetLastError(), "gtx_records_failed_kernel launch") &&
+         hip_ok(hipMemcpyAsync(&n, d_count, sizeof n, hipMemcpyDeviceToHost, st), "failed-record counter") &&
+         hip_ok(hipStreamSynchronize(st), "failed-record counter");
+  }
+  gtx::dev_free(d_count);
+  if (!ok)
+    return GTX_ERR_HIP;
+  *out = n;
+  return GTX_OK;
+}
+
+// the general pass' task log of the profiling build (no entry in the normal build): up to `cap` entries of 16 words into `out`,
+// their number into *n; the log is emptied
+extern "C" int gtx_ctx_profile_log(gtx_ctx * c, uint64_t * out, uint64_t cap, uint64_t * n)
+{
+  if (!c || !n || (cap && !out))
+    return GTX_ERR_ARG;
+  *n = 0;
+  if (c->device < 0 || !c->dev_graph.prof || PROF_LOG_ENTRIES == 0)
+    return GTX_OK;
+  unsigned long long count = 0;
+  if (!hip_ok(hipSetDevice(c->device), "hipSetDevice") || !hip_ok(hipDeviceSynchronize(), "profile log") ||
+      !hip_ok(hipMemcpy(&count, c->dev_graph.prof + 32, sizeof count, hipMemcpyDeviceToHost), "profile log"))
+    return GTX_ERR_HIP;
+  uint64_t const have = std::min<uint64_t>(std::min<uint64_t>(count, PROF_LOG_ENTRIES), cap);
+  if (have && !hip_ok(hipMemcpy(out, c->dev_graph.prof + 40, have * PROF_LOG_ENTRY * sizeof(uint64_t), hipMemcpyDeviceToHost), "profile log"))
+    return GTX_ERR_HIP;
+  if (!hip_ok(gtx::dev_zero(c->dev_graph.prof + 32, sizeof(unsigned long long)), "profile log"))
+    return GTX_ERR_HIP;
+  *n = have;
   return GTX_OK;
 }
 

@@ -59,7 +59,13 @@ void inflate_member(InflateJob & j)
   // the library's own decoder (gtx_inflate.hpp: built for whole members of known size, 1.5-1.9 x zlib's rate); what it refuses --
   // a damaged member, or a code whose tables do not fit its fixed ones -- gets zlib's verdict.  GTX_INFLATE=zlib: zlib only.
   static bool const own = !(std::getenv("GTX_INFLATE") && std::strcmp(std::getenv("GTX_INFLATE"), "zlib") == 0);
+  // (GTX_BGZF_CRC=0: the member's CRC32 is not compared -- htslib compares it, and it is what holds the decoder here to the file)
+  static bool const check_crc = !(std::getenv("GTX_BGZF_CRC") && std::getenv("GTX_BGZF_CRC")[0] == '0');
   j.ok = own && gtx::inflate_raw(j.comp.data(), static_cast<size_t>(j.clen), j.data.data(), j.data.size());
+  uint32_t want = 0;
+  std::memcpy(&want, j.comp.data() + j.clen, 4);
+  if (j.ok && check_crc && gtx::crc32_of(j.data.data(), j.data.size()) != want)
+    j.ok = false; // (zlib gets the member; a member that is damaged stays damaged)
   z_stream z{};
   if (!j.ok && inflateInit2(&z, -15) == Z_OK)
   {
@@ -69,7 +75,7 @@ void inflate_member(InflateJob & j)
     z.avail_out = static_cast<uInt>(j.data.size());
     int const rc = inflate(&z, Z_FINISH);
     inflateEnd(&z);
-    j.ok = rc == Z_STREAM_END && z.avail_out == 0;
+    j.ok = rc == Z_STREAM_END && z.avail_out == 0 && (!check_crc || gtx::crc32_of(j.data.data(), j.data.size()) == want);
   }
   {
     // (notified under the lock: the reader may free the job as soon as it sees it done, and it sees that only after

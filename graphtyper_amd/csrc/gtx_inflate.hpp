@@ -412,4 +412,41 @@ inline bool inflate_raw(uint8_t const * in, size_t in_len, uint8_t * out, size_t
   }
   return op == out_end;
 }
+
+// CRC-32 of a member's data (the gzip polynomial, reflected), eight bytes a step over eight tables: a BGZF member carries it
+// behind its deflate stream, and a reader that inflates with its own decoder owes the file that comparison.
+struct Crc32Tables
+{
+  uint32_t t[8][256];
+  Crc32Tables()
+  {
+    for (uint32_t i = 0; i < 256; ++i)
+    {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k)
+        c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      t[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int k = 1; k < 8; ++k)
+        t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 255u];
+  }
+};
+
+inline uint32_t crc32_of(uint8_t const * p, size_t n)
+{
+  static Crc32Tables const T;
+  uint32_t c = 0xFFFFFFFFu;
+  for (; n >= 8; n -= 8, p += 8)
+  {
+    uint64_t w;
+    std::memcpy(&w, p, 8);
+    w ^= c;
+    c = T.t[7][w & 255u] ^ T.t[6][(w >> 8) & 255u] ^ T.t[5][(w >> 16) & 255u] ^ T.t[4][(w >> 24) & 255u] ^ T.t[3][(w >> 32) & 255u] ^
+        T.t[2][(w >> 40) & 255u] ^ T.t[1][(w >> 48) & 255u] ^ T.t[0][w >> 56];
+  }
+  for (; n; --n, ++p)
+    c = T.t[0][(c ^ *p) & 255u] ^ (c >> 8);
+  return ~c;
+}
 } // namespace gtx

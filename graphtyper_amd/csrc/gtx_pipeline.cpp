@@ -39,7 +39,7 @@ struct Worker
   bool renumber = false;
   std::vector<std::string> paths;
   double decode = 0, push = 0, enqueue = 0;
-  uint64_t records = 0, tasks = 0, items = 0;
+  uint64_t records = 0, tasks = 0, items = 0, failed = 0;
   int status = GTX_OK;
   std::string error;
 };
@@ -109,6 +109,15 @@ extern "C" int gtx_pipeline_run(gtx_ctx * c, const char * const * bam_paths, uin
   {
     status = GTX_ERR_ARG;
     g_last_error = "gtx_pipeline_run: the files hold " + std::to_string(samples) + " samples, the accumulator block " + std::to_string(acc->n_samples);
+  }
+  // (the context's and the block's counters of refused work before the run: what the run adds is the run's)
+  uint32_t refused_before = 0, conn_dropped_before = 0;
+  if (status == GTX_OK)
+  {
+    uint32_t conn[2] = {0, 0};
+    (void)gtx_ctx_error_count(c, &refused_before);
+    if (acc->d_conn_count && hipSetDevice(c->device) == hipSuccess && hipMemcpy(conn, acc->d_conn_count, sizeof conn, hipMemcpyDeviceToHost) == hipSuccess)
+      conn_dropped_before = conn[1];
   }
   std::atomic<uint32_t> ready{0}, go{0};
   auto run = [&](Worker & w)
@@ -252,21 +261,33 @@ extern "C" int gtx_pipeline_run(gtx_ctx * c, const char * const * bam_paths, uin
       gtx_stream_counts(push, &n_rec, &n_dup, &n_parked);
       std::vector<gtx_score_item> left(std::max<uint64_t>(n_parked, 1));
       uint32_t ni = 0;
-      if (gtx_stream_finish(push, left.data(), static_cast<uint32_t>(left.size()), &ni) == GTX_OK && ni)
+      int const rc_fin = gtx_stream_finish(push, left.data(), static_cast<uint32_t>(left.size()), &ni);
+      if (rc_fin != GTX_OK) // (parked mates left unscored are a wrong result, not a detail)
+        w.status = rc_fin;
+      else if (ni)
       {
-        if (used[0])
-          (void)hipEventSynchronize(done[0]);
+        if (used[0] && hipEventSynchronize(done[0]) != hipSuccess)
+          w.status = GTX_ERR_HIP;
         for (uint32_t o = 0; o < ni && w.status == GTX_OK; o += chunk)
         {
           uint32_t const m = std::min(chunk, ni - o);
           std::memcpy(pin_items[0], left.data() + o, static_cast<size_t>(m) * sizeof(gtx_score_item));
-          if (submit(0, 0, m))
-            (void)hipEventSynchronize(done[0]);
+          if (submit(0, 0, m) && hipEventSynchronize(done[0]) != hipSuccess)
+            w.status = GTX_ERR_HIP;
         }
       }
     }
-    if (st)
-      (void)hipStreamSynchronize(st);
+    if (st && hipStreamSynchronize(st) != hipSuccess && w.status == GTX_OK)
+      w.status = GTX_ERR_HIP;
+    // (records that are a table-overflow status instead of a result: reads the accumulators lack)
+    if (w.status == GTX_OK && at && d_rec)
+    {
+      uint64_t failed = 0;
+      int const rc = gtx_records_failed(c, static_cast<uint32_t const *>(d_rec), rec_words, at, st, &failed);
+      if (rc != GTX_OK)
+        fail(rc, gtx_last_error());
+      w.failed = failed;
+    }
     if (push)
       gtx_stream_destroy(push);
     for (int b = 0; b < 2; ++b)
@@ -312,6 +333,7 @@ extern "C" int gtx_pipeline_run(gtx_ctx * c, const char * const * bam_paths, uin
       status = w.status;
       g_last_error = w.error;
     }
+    s.records_failed += w.failed;
     s.records += w.records;
     s.tasks += w.tasks;
     s.items += w.items;
@@ -319,6 +341,24 @@ extern "C" int gtx_pipeline_run(gtx_ctx * c, const char * const * bam_paths, uin
     s.push_s += w.push;
     s.enqueue_s += w.enqueue;
     s.slowest_thread_s = std::max(s.slowest_thread_s, w.decode + w.push + w.enqueue);
+  }
+  // What a capacity limit of the library dropped makes the block a wrong result, not a smaller one: records with a table-overflow
+  // status, score items over more sites than the scorer's table, far-pair connections beyond the log.  (acc is then undefined.)
+  if (status == GTX_OK && c->device >= 0)
+  {
+    uint32_t refused = 0, conn[2] = {0, 0};
+    (void)gtx_ctx_error_count(c, &refused);
+    if (acc->d_conn_count)
+      (void)hipMemcpy(conn, acc->d_conn_count, sizeof conn, hipMemcpyDeviceToHost);
+    s.score_items_refused = refused >= refused_before ? refused - refused_before : refused;
+    s.connections_dropped = conn[1] >= conn_dropped_before ? conn[1] - conn_dropped_before : conn[1];
+    if (s.records_failed || s.score_items_refused || s.connections_dropped)
+    {
+      status = GTX_ERR_CAPACITY;
+      g_last_error = "gtx_pipeline_run: the result is incomplete -- " + std::to_string(s.records_failed) + " records with a table-overflow status, " +
+                     std::to_string(s.score_items_refused) + " score items refused, " + std::to_string(s.connections_dropped) +
+                     " connections beyond the log (gtx_params.exact_pass_mb / big_record_words, gtx_scores_alloc's conn_cap)";
+    }
   }
   s.n_samples = samples;
   s.n_threads = n_threads;

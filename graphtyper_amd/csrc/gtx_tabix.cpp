@@ -145,10 +145,21 @@ private:
       next_off_ = here + static_cast<long>(bsize);
       if (isize == 0)
         continue;
+      if (isize > 65536) // (a BGZF member holds at most 64 KB: a damaged ISIZE must not size an allocation)
+      {
+        bad_ = true;
+        return false;
+      }
       data_.resize(isize);
       size_t const clen = bsize - 18 - 8;
-      bool ok = isize <= 65536 && inflate_raw(comp_.data(), clen, data_.data(), isize);
-      if (!ok && isize <= 65536)
+      bool ok = inflate_raw(comp_.data(), clen, data_.data(), isize);
+      if (ok) // (the member's CRC32 holds the library's own decoder to the file: what does not match goes to zlib)
+      {
+        uint32_t want;
+        std::memcpy(&want, comp_.data() + clen, 4);
+        ok = crc32_of(data_.data(), isize) == want;
+      }
+      if (!ok)
       {
         z_stream z{};
         if (inflateInit2(&z, -15) == Z_OK)
@@ -159,6 +170,9 @@ private:
           z.avail_out = isize;
           ok = inflate(&z, Z_FINISH) == Z_STREAM_END && z.avail_out == 0;
           inflateEnd(&z);
+          uint32_t want;
+          std::memcpy(&want, comp_.data() + clen, 4);
+          ok = ok && crc32_of(data_.data(), isize) == want;
         }
       }
       if (!ok)
@@ -368,7 +382,7 @@ gzFile gz_open_at(std::string const & path, uint64_t voffset)
 }
 } // namespace gtx
 
-extern "C" int gtx_tabix_build(const char * vcf_gz_path, int min_shift, const char * index_path)
+static int tabix_build_body(const char * vcf_gz_path, int min_shift, const char * index_path)
 {
   using namespace gtx;
   if (!vcf_gz_path || min_shift < 0 || min_shift > 30)
@@ -564,7 +578,7 @@ extern "C" int gtx_tabix_build(const char * vcf_gz_path, int min_shift, const ch
   return GTX_OK;
 }
 
-extern "C" int gtx_tabix_start(const char * vcf_gz_path, const char * chrom, int64_t begin, int64_t end, uint64_t * voffset, int * any)
+static int tabix_start_body(const char * vcf_gz_path, const char * chrom, int64_t begin, int64_t end, uint64_t * voffset, int * any)
 {
   if (!vcf_gz_path || !chrom || !voffset || !any || begin < 0)
     return GTX_ERR_ARG;
@@ -578,4 +592,31 @@ extern "C" int gtx_tabix_start(const char * vcf_gz_path, const char * chrom, int
   *any = a ? 1 : 0;
   *voffset = a ? v : 0;
   return GTX_OK;
+}
+
+// (nothing a damaged file can provoke -- an allocation that fails, a container's range check -- may cross the C boundary)
+extern "C" int gtx_tabix_build(const char * vcf_gz_path, int min_shift, const char * index_path)
+{
+  try
+  {
+    return tabix_build_body(vcf_gz_path, min_shift, index_path);
+  }
+  catch (std::exception const & e)
+  {
+    gtx::g_last_error = std::string("gtx_tabix_build: ") + e.what();
+    return GTX_ERR_IO;
+  }
+}
+
+extern "C" int gtx_tabix_start(const char * vcf_gz_path, const char * chrom, int64_t begin, int64_t end, uint64_t * voffset, int * any)
+{
+  try
+  {
+    return tabix_start_body(vcf_gz_path, chrom, begin, end, voffset, any);
+  }
+  catch (std::exception const & e)
+  {
+    gtx::g_last_error = std::string("gtx_tabix_start: ") + e.what();
+    return GTX_ERR_IO;
+  }
 }

@@ -21,7 +21,7 @@ ST_ERROR_MASK = 15
 # names every build of libgtx.so must export (checked by tests/test_abi.py against include/gtx.h)
 EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy", "gtx_ctx_special_positions",
            "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_ctx_near_pairs", "gtx_index_stats", "gtx_index_get", "gtx_index_dump", "gtx_ctx_hint_table",
-           "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_exact_pass_tasks", "gtx_graph_sv_table", "gtx_ctx_pass_times", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
+           "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_exact_pass_tasks", "gtx_graph_sv_table", "gtx_ctx_pass_times", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_ctx_profile_log", "gtx_records_failed", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_set_coverage", "gtx_stream_finish", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
            "gtx_graph_destroy",
            "gtx_scores_alloc", "gtx_scores_zero", "gtx_scores_free", "gtx_scores_reduce", "gtx_comm_unique_id", "gtx_comm_init_rank",
@@ -43,7 +43,8 @@ class GraphView(C.Structure):
 class PipelineStats(C.Structure):
     _fields_ = [("records", C.c_uint64), ("tasks", C.c_uint64), ("items", C.c_uint64), ("decode_s", C.c_double), ("push_s", C.c_double),
                 ("enqueue_s", C.c_double), ("slowest_thread_s", C.c_double), ("loop_s", C.c_double), ("wall_s", C.c_double),
-                ("n_samples", C.c_uint32), ("n_threads", C.c_uint32)]
+                ("n_samples", C.c_uint32), ("n_threads", C.c_uint32), ("records_failed", C.c_uint64), ("score_items_refused", C.c_uint64),
+                ("connections_dropped", C.c_uint64)]
 
 
 class ShrinkParams(C.Structure):
@@ -148,6 +149,8 @@ def lib():
         L.gtx_ctx_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.gtx_ctx_error_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.gtx_ctx_profile.argtypes = [C.c_void_p, C.c_void_p]
+        L.gtx_records_failed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.gtx_ctx_profile_log.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.gtx_scores_finalize.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                           C.POINTER(C.c_uint64)]
         L.gtx_phase_flags.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -639,6 +642,13 @@ class Context:
         out = np.zeros(32, np.uint64)
         check(lib().gtx_ctx_profile(self.h, _p(out)))
         return out
+
+    def profile_log(self, cap=1 << 16):
+        """the general pass' task log of the profiling build: rows of 16 words (include/gtx.h: gtx_ctx_profile_log)"""
+        out = np.zeros((cap, 16), np.uint64)
+        n = C.c_uint64()
+        check(lib().gtx_ctx_profile_log(self.h, _p(out), cap, C.byref(n)))
+        return out[:n.value]
 
     def big_records(self):
         """(used part of the big-record arena as a host array, number of tasks the last align batch sent through the

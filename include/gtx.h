@@ -423,11 +423,23 @@ int gtx_ctx_pass_times(gtx_ctx *, float * ms /* [3] */, uint32_t * queued_for_pa
  * go to the general pass and are counted there). */
 int gtx_ctx_kernel_times(gtx_ctx *, float * ms /* [4] */, uint32_t * tasks /* [4] */);
 
+/* How many of the 2 * n_reads record slots a gtx_align_batch call filled hold a table-overflow status (GTX_ST_ERROR_MASK in the
+ * header's status bits) instead of a result: a full record arena, an exact-pass slab too small, a read longer than the passes
+ * take.  Each is a read the accumulators will lack -- a host that wants the reference's result checks this is 0 (gtx_pipeline_run
+ * does).  The reverse slots of GTX_FLAG_FORWARD_ONLY reads are never written: they count as what the caller left there (zeros).
+ * Synchronises with `stream`. */
+int gtx_records_failed(gtx_ctx *, const uint32_t * d_records, uint32_t rec_words, uint64_t n_reads, void * stream, uint64_t * out);
+
 /* forget every GTX_ST_EXTERNAL record (call between regions, when d_records is recycled) */
 int gtx_ctx_big_records_rewind(gtx_ctx *, void * stream);
 
 /* out[32]: per-phase shader-cycle sums of the alignment kernel; only the profiling build (libgtx_prof.so) fills them */
 int gtx_ctx_profile(gtx_ctx *, uint64_t * out);
+
+/* The general pass' task log (profiling build only; the normal build holds none and returns *n = 0): up to `cap` entries of
+ * 16 words -- task, workgroup, start cycle, cycles, hardware id, the record's first two words, cycles of phases 0..9 -- into
+ * `out`; waits for the device, empties the log. */
+int gtx_ctx_profile_log(gtx_ctx *, uint64_t * out, uint64_t cap, uint64_t * n);
 
 /* Per (sample, haplotype) genotype call on the device: replaces get_haplotype_phred (src/typer/vcf.cpp:47-82) and the
  * SampleCall the reference builds from it in Vcf::add_haplotype (src/typer/vcf.cpp:1507-1530; constructor, get_gt_call and
@@ -682,7 +694,12 @@ typedef struct gtx_pipeline_stats
   double loop_s;                            /* from the moment every thread has its buffers to the last stream's end */
   double wall_s;                            /* the whole call (opening the files and allocating included) */
   uint32_t n_samples, n_threads;
+  /* what a capacity limit dropped -- any of them non-zero and the call returns GTX_ERR_CAPACITY (the block is then not a result): */
+  uint64_t records_failed;                  /* record slots with a table-overflow status (gtx_records_failed over every thread's slots) */
+  uint64_t score_items_refused;             /* gtx_ctx_error_count's increase over the run */
+  uint64_t connections_dropped;             /* far-pair connections beyond the block's log (conn_cap of gtx_scores_alloc) */
 } gtx_pipeline_stats;
+/* A non-OK return leaves `acc` undefined (the threads that did not fail have added into it): gtx_scores_zero before it is used again. */
 int gtx_pipeline_run(gtx_ctx *, const char * const * bam_paths, uint32_t n_paths, uint32_t n_threads, const char * region, uint32_t chunk,
                      uint32_t rec_words, uint64_t record_slots_per_thread, const gtx_score_buffers * acc, gtx_pipeline_stats * stats);
 

@@ -137,6 +137,33 @@ extern "C"
 
   void emu_free(void * p) { delete static_cast<Emu *>(p); }
 
+  // the two statements of to_uint64_vec for a k-mer of 32 codes: the sequential one (expand_keys, the reference's loop) and the
+  // key-per-lane one the general pass runs (expand_keys_lanes).  keys_*: room for 4 * 97 keys each; returns 1 when count and
+  // keys agree (the counts are returned through n_seq / n_lanes: 0 = gave up, 0xFFFFFFFF = beyond the pass' key buffer)
+  int emu_expand_keys(const uint8_t * codes32, uint64_t * keys_seq, uint64_t * keys_lanes, uint32_t * n_seq, uint32_t * n_lanes)
+  {
+    auto ws = std::make_unique<gtx::AlignWorkspace>();
+    uint32_t amb = 0;
+    uint64_t base = 0;
+    for (uint32_t t = 0; t < 32; ++t)
+    {
+      uint32_t const c = codes32[t] & 15u;
+      ws->rd[t] = static_cast<uint8_t>(c);
+      bool const single = (c & (c - 1u)) == 0u && c != 0u;
+      if (!single)
+        amb |= 1u << t;
+      uint64_t const two = c == 2u ? 1u : c == 4u ? 2u : c == 8u ? 3u : 0u;
+      base |= ((two & 1u) << t) | ((two >> 1) << (32u + t));
+    }
+    *n_seq = gtx::expand_keys(ws->rd, 0, keys_seq, gtx::AlignCfg::KEY_CAP);
+    *n_lanes = gtx::expand_keys_lanes<WaveEmu>(*ws, 0, amb, base);
+    uint32_t const n = *n_lanes == 0xFFFFFFFFu ? 0u : *n_lanes;
+    std::memcpy(keys_lanes, ws->u.keybuf, n * sizeof(uint64_t));
+    if (*n_seq != *n_lanes)
+      return 0;
+    return std::memcmp(keys_seq, keys_lanes, n * sizeof(uint64_t)) == 0 ? 1 : 0;
+  }
+
   // milliseconds of one listing of the sweep (tools: where a context's host time goes)
   double emu_time_listing(void * p, int with_runs)
   {
