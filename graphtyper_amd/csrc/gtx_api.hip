@@ -511,7 +511,12 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
           uint4_t const v = s_seq[wave][r * ROW_PITCH + part];
           uint32_t const rd = wave_first + r;
           uint32_t * dst = records + static_cast<uint64_t>(GTX_HINT_REC_SLOT(rd)) * 2 * rec_words;
+#ifdef GTX_X_HALF_REC_STORE /* (experiment build: what a 32-byte record would cost -- the first two parts of four, of a slot half as wide) */
+          if (part < 2)
+            stream_store(reinterpret_cast<uint4_t *>(records + static_cast<uint64_t>(GTX_HINT_REC_SLOT(rd)) * 8 + 4 * part), v);
+#elif !defined(GTX_X_NO_REC_STORE) /* (experiment build: the kernel without its record stores) */
           stream_store(reinterpret_cast<uint4_t *>(dst + 4 * part), v);
+#endif
         }
       }
     }
@@ -1922,7 +1927,13 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     sg = static_cast<hipStream_t>(s->side_stream);
     (void)hipStreamWaitEvent(sg, static_cast<hipEvent_t>(s->sync_events[0]), 0);
   }
-  if (second_pass)
+#ifdef GTX_EXPERIMENT
+  // (experiment builds only -- never the product: what a step would take if the passes that find empty queues cost nothing)
+  static bool const skip_hbm_passes = std::getenv("GTX_SKIP_HBM_PASSES") != nullptr;
+#else
+  constexpr bool skip_hbm_passes = false;
+#endif
+  if (second_pass && !skip_hbm_passes)
   {
     HbmPassArgs a;
     a.g = c->dev_graph;
@@ -2519,7 +2530,7 @@ extern "C" int gtx_records_failed(gtx_ctx * c, const uint32_t * d_records, uint3
          hip_ok(hipMemcpyAsync(&n, d_count, sizeof n, hipMemcpyDeviceToHost, st), "failed-record counter") &&
          hip_ok(hipStreamSynchronize(st), "failed-record counter");
   }
-  gtx::dev_free(d_count);
+  (void)gtx::dev_free(d_count);
   if (!ok)
     return GTX_ERR_HIP;
   *out = n;

@@ -1161,6 +1161,15 @@ int sv_graph_records(gtx_ctx const * c, gtx_vcf_request const * rq, std::string 
 }
 } // namespace
 
+namespace
+{
+// The records of the sites [h_begin, h_end) (Vcf::add_haplotype -> Variant::scan_calls / generate_infos -> Vcf::write_record).
+// With `good`: nothing is written; (*good)[h] receives generate_infos' verdict on the site's alternative alleles (is_good_alt,
+// variant.cpp:1040-1070) -- what vcf_merge_and_filter keeps of a site (gtx_vcf_sites below).
+int write_sites(gtx_ctx const * c, gtx_vcf_request const * rq, uint32_t h_begin, uint32_t h_end, std::string & text, std::string & error,
+                std::vector<std::vector<int8_t>> * good);
+} // namespace
+
 extern "C" int gtx_vcf_records(const gtx_ctx * c, const gtx_vcf_request * rq, char * out, uint64_t cap, uint64_t * len)
 {
   if (!c || !rq || !len || (cap && !out) || !rq->contig || !rq->gt_cov || !rq->stat_u64 || !rq->stat_u32 || !rq->phred || !rq->calls ||
@@ -1191,11 +1200,71 @@ extern "C" int gtx_vcf_records(const gtx_ctx * c, const gtx_vcf_request * rq, ch
       std::memcpy(out, text.data(), static_cast<size_t>(std::min<uint64_t>(cap, text.size())));
     return GTX_OK;
   }
-  std::string const contig = rq->contig;
   // The records of the sites are independent of each other: the sites are cut into contiguous ranges for a team of host
   // threads (every record walks the sample-major arrays of all samples -- cache misses, not arithmetic), every range writes
   // its own text, the texts are joined in order.
-  auto write_sites = [&](uint32_t h_begin, uint32_t h_end, std::string & text, std::string & error) -> int
+  unsigned T = 1;
+  if (static_cast<uint64_t>(nh) * (ns + 1) >= 200000) // (small jobs: a team costs more to start than it saves)
+  {
+    T = std::min(std::max(std::thread::hardware_concurrency(), 1u), 32u);
+    if (char const * e = std::getenv("GTX_HOST_THREADS"))
+      T = static_cast<unsigned>(std::max(1, std::atoi(e)));
+    T = std::min<unsigned>(T, std::max<uint32_t>(nh / 16, 1));
+  }
+  if (T <= 1)
+  {
+    std::string error;
+    int const rc = write_sites(c, rq, 0, nh, text, error, nullptr);
+    if (rc != GTX_OK)
+    {
+      gtx::g_last_error = error;
+      return rc;
+    }
+  }
+  else
+  {
+    std::vector<std::string> part(T), error(T);
+    std::vector<int> status(T, GTX_OK);
+    std::vector<std::thread> team;
+    for (unsigned t = 0; t < T; ++t)
+      team.emplace_back([&, t] {
+        uint32_t const b = static_cast<uint32_t>(static_cast<uint64_t>(nh) * t / T), e = static_cast<uint32_t>(static_cast<uint64_t>(nh) * (t + 1) / T);
+        part[t].reserve(static_cast<size_t>(e - b) * (400 + 24 * static_cast<size_t>(ns)));
+        try
+        {
+          status[t] = write_sites(c, rq, b, e, part[t], error[t], nullptr);
+        }
+        catch (...)
+        {
+          status[t] = GTX_ERR_ARG;
+          error[t] = "gtx_vcf_records: out of memory";
+        }
+      });
+    for (auto & th : team)
+      th.join();
+    for (unsigned t = 0; t < T; ++t)
+      if (status[t] != GTX_OK)
+      {
+        gtx::g_last_error = error[t];
+        return status[t];
+      }
+    for (unsigned t = 0; t < T; ++t)
+      text += part[t];
+  }
+  *len = text.size();
+  if (out && cap)
+    std::memcpy(out, text.data(), static_cast<size_t>(std::min<uint64_t>(cap, text.size())));
+  return GTX_OK;
+}
+
+namespace
+{
+int write_sites(gtx_ctx const * c, gtx_vcf_request const * rq, uint32_t h_begin, uint32_t h_end, std::string & text, std::string & error,
+                std::vector<std::vector<int8_t>> * good)
+{
+  gtx::HostGraph const & g = c->graph;
+  uint32_t const nh = g.n_hap, ns = rq->n_samples;
+  std::string const contig = rq->contig;
   {
   std::vector<AlleleStats> al;
   std::vector<std::pair<const char *, uint32_t>> seqs;
@@ -1310,6 +1379,23 @@ extern "C" int gtx_vcf_records(const gtx_ctx * c, const gtx_vcf_request * rq, ch
         ++al[g1].pass_ac;
         ++al[g2].pass_ac;
       }
+    }
+    if (good)
+    {
+      // generate_infos' last step (variant.cpp:1040-1070): an alternative allele nobody's reads reached is dropped, the others are
+      // held to QD per allele and to their best support in any one sample -- stricter on sites of 71 / 131 alleles and more
+      std::vector<int8_t> & out = (*good)[h];
+      out.assign(cnum - 1, 0);
+      for (uint32_t a = 1; a < cnum; ++a)
+      {
+        AlleleStats const & p = al[a];
+        if (p.total_depth == 0)
+          continue;
+        double const q = p.qd_depth > 0 ? static_cast<double>(p.qd_qual) / static_cast<double>(p.qd_depth) : 0.0;
+        out[a - 1] = static_cast<int8_t>(q >= 1.0 && p.max_alt_support >= 2 && (cnum < 71 || (q >= 1.5 && p.max_alt_support_ratio >= 0.2)) &&
+                                         (cnum < 131 || (q >= 2.0 && p.max_alt_support_ratio >= 0.225)));
+      }
+      continue;
     }
     // ---- what is skipped (vcf.cpp:775-830, 1226-1258)
     if (pos < rq->region_begin || pos > rq->region_end)
@@ -1632,55 +1718,123 @@ extern "C" int gtx_vcf_records(const gtx_ctx * c, const gtx_vcf_request * rq, ch
     }
     text += '\n';
   }
-  return GTX_OK;
-  };
-  unsigned T = 1;
-  if (static_cast<uint64_t>(nh) * (ns + 1) >= 200000) // (small jobs: a team costs more to start than it saves)
-  {
-    T = std::min(std::max(std::thread::hardware_concurrency(), 1u), 32u);
-    if (char const * e = std::getenv("GTX_HOST_THREADS"))
-      T = static_cast<unsigned>(std::max(1, std::atoi(e)));
-    T = std::min<unsigned>(T, std::max<uint32_t>(nh / 16, 1));
   }
-  if (T <= 1)
+  return GTX_OK;
+}
+} // namespace
+
+// ---- the sites a genotyping iteration hands to the next one: vcf_merge_and_filter (src/typer/vcf_operations.cpp:278-478).
+// The reference reads the pools' variants back (their calls already scanned into the statistics and cleared,
+// hts_parallel_reader.cpp:938-962), adds the pools' statistics, lets generate_infos judge the alternative alleles and writes
+// every allele it keeps as a bi-allelic record of its own: no samples, QUAL 0, FILTER ".", and in INFO the allele's number over
+// the whole file (GT_ID: alleles are counted from 1 in file order, kept or not), the alleles it cannot share a haplotype with
+// (GT_ANTI_HAPLOTYPE: the later kept alleles of its own site, then what `ph` says) and those it was always seen with
+// (GT_HAPLOTYPE) -- what the next iteration's graph construction turns into events (constructor.cpp:1540-1588).  Here the
+// statistics of all pools are one accumulator block (sums are sums), so the "merge" is the block itself.
+extern "C" int gtx_vcf_sites(const gtx_ctx * c, const gtx_vcf_request * rq, const gtx_phase_entry * ph, uint64_t n_ph, char * out, uint64_t cap,
+                             uint64_t * len)
+{
+  if (!c || !rq || !len || (cap && !out) || !rq->contig || !rq->gt_cov || !rq->stat_u64 || !rq->stat_u32 || !rq->phred || !rq->calls || (n_ph && !ph))
+    return GTX_ERR_ARG;
+  gtx::HostGraph const & g = c->graph;
+  if (g.is_sv_graph) // (the reference writes no haplotype sites from an SV graph: hts_parallel_reader.cpp:941)
   {
-    std::string error;
-    int const rc = write_sites(0, nh, text, error);
+    gtx::g_last_error = "gtx_vcf_sites: not for SV graphs";
+    return GTX_ERR_UNSUPPORTED;
+  }
+  uint32_t const nh = g.n_hap;
+  std::vector<std::vector<int8_t>> good(nh);
+  {
+    std::string none, error;
+    int const rc = write_sites(c, rq, 0, nh, none, error, &good);
     if (rc != GTX_OK)
     {
       gtx::g_last_error = error;
       return rc;
     }
   }
-  else
+  // hap_id2var_id: alleles in front of a site's first alternative one
+  std::vector<uint64_t> first_id(nh + 1, 0);
+  for (uint32_t h = 0; h < nh; ++h)
+    first_id[h + 1] = first_id[h] + (g.ref_nvar[h] - 1u);
+  // ph rows come in the map's order (hap1, allele1, hap2, allele2): the rows of one outer key are one run
+  auto const key_less = [](gtx_phase_entry const & e, std::pair<uint16_t, uint16_t> const & k)
+  { return e.hap1 < k.first || (e.hap1 == k.first && e.allele1 < k.second); };
+  std::string text = "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n";
+  std::string const contig = rq->contig;
+  std::vector<std::pair<const char *, uint32_t>> seqs(2);
+  std::string anti, hap;
+  for (uint32_t h = 0; h < nh; ++h)
   {
-    std::vector<std::string> part(T), error(T);
-    std::vector<int> status(T, GTX_OK);
-    std::vector<std::thread> team;
-    for (unsigned t = 0; t < T; ++t)
-      team.emplace_back([&, t] {
-        uint32_t const b = static_cast<uint32_t>(static_cast<uint64_t>(nh) * t / T), e = static_cast<uint32_t>(static_cast<uint64_t>(nh) * (t + 1) / T);
-        part[t].reserve(static_cast<size_t>(e - b) * (400 + 24 * static_cast<size_t>(ns)));
-        try
+    uint32_t const cnum = g.ref_nvar[h], v0 = g.ref_first_var[h];
+    uint32_t const pos = g.var_order[v0];
+    std::vector<int8_t> const & ok = good[h];
+    for (uint32_t a = 0; a + 1 < cnum; ++a)
+    {
+      uint64_t const var_id = first_id[h] + a + 1;
+      if (!ok[a])
+        continue;
+      anti.clear();
+      hap.clear();
+      for (uint32_t a2 = a + 1; a2 + 1 < cnum; ++a2)
+        if (ok[a2])
         {
-          status[t] = write_sites(b, e, part[t], error[t]);
+          if (!anti.empty())
+            anti += ',';
+          put_u(anti, var_id + a2 - a);
         }
-        catch (...)
-        {
-          status[t] = GTX_ERR_ARG;
-          error[t] = "gtx_vcf_records: out of memory";
-        }
-      });
-    for (auto & th : team)
-      th.join();
-    for (unsigned t = 0; t < T; ++t)
-      if (status[t] != GTX_OK)
+      // (the map's keys are 16-bit: std::make_pair<uint16_t, uint16_t>(var.hap_id, a + 1))
+      std::pair<uint16_t, uint16_t> const key(static_cast<uint16_t>(h), static_cast<uint16_t>(a + 1));
+      for (gtx_phase_entry const * e = std::lower_bound(ph, ph + n_ph, key, key_less); e != ph + n_ph && e->hap1 == key.first && e->allele1 == key.second; ++e)
       {
-        gtx::g_last_error = error[t];
-        return status[t];
+        if (e->hap2 == 0xFFFFu && e->allele2 == 0xFFFFu) // (an outer key without a flag under it)
+          continue;
+        if (e->allele2 == 0 || (e->flags != 1 && e->flags != 2))
+          continue;
+        if (e->hap2 >= nh)
+        {
+          gtx::g_last_error = "gtx_vcf_sites: a phase row names a haplotype the graph does not have";
+          return GTX_ERR_ARG;
+        }
+        std::string & to = e->flags == 1 ? hap : anti;
+        if (!to.empty())
+          to += ',';
+        put_u(to, first_id[e->hap2] + e->allele2);
       }
-    for (unsigned t = 0; t < T; ++t)
-      text += part[t];
+      seqs[0] = {g.dna.data() + g.var_dna[v0], g.var_len[v0]};
+      seqs[1] = {g.dna.data() + g.var_dna[v0 + a + 1], g.var_len[v0 + a + 1]};
+      if (static_cast<size_t>(seqs[0].second) + seqs[1].second > 16000) // (write_record, vcf.cpp:790-805)
+        continue;
+      text += contig;
+      text += '\t';
+      put_u(text, pos);
+      text += '\t';
+      text += contig;
+      text += ':';
+      put_u(text, pos);
+      text += ':';
+      text += variant_type(seqs);
+      text += '\t';
+      text.append(seqs[0].first, seqs[0].second);
+      text += '\t';
+      text.append(seqs[1].first, seqs[1].second);
+      text += "\t0\t.\t";
+      if (!anti.empty())
+      {
+        text += "GT_ANTI_HAPLOTYPE=";
+        text += anti;
+        text += ';';
+      }
+      if (!hap.empty())
+      {
+        text += "GT_HAPLOTYPE=";
+        text += hap;
+        text += ';';
+      }
+      text += "GT_ID=";
+      put_u(text, var_id);
+      text += '\n';
+    }
   }
   *len = text.size();
   if (out && cap)

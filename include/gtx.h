@@ -611,6 +611,17 @@ int gtx_phase_flags(const gtx_ctx *, uint32_t n_samples, const uint32_t * gt_cov
                     const uint32_t * conn_near, /* the downloaded d_conn_near or NULL */
                     gtx_phase_entry * out, uint64_t cap, uint64_t * n);
 
+/* The sites one genotyping iteration hands to the next: replaces vcf_merge_and_filter (src/typer/vcf_operations.cpp:278-478; the
+ * file genotype() feeds to the next construct_graph, src/utilities/genotype.cpp:520-575).  Every alternative allele that
+ * Variant::generate_infos keeps (variant.cpp:1040-1070: reads reached it, QD per allele >= 1, best support in one sample >= 2,
+ * stricter on sites of 71 / 131 and more alleles) is a bi-allelic record of its own without samples -- QUAL 0, FILTER ".", INFO
+ * GT_ID (the allele's number over the file, from 1, dropped alleles counted), GT_ANTI_HAPLOTYPE (later kept alleles of its site,
+ * then the alleles `ph` flags IS_ANY_ANTI_HAP_SUPPORT and nothing else), GT_HAPLOTYPE (those flagged IS_ANY_HAP_SUPPORT and
+ * nothing else).  rq: as for gtx_vcf_records over the accumulators of ALL pools (the reference adds the pools' statistics;
+ * here they are one block); region / filter_zero_qual / sample names are not used: every site of the graph is judged.
+ * ph / n_ph: the rows of gtx_phase_flags, in its order.  First line: the column line.  Not for SV graphs (GTX_ERR_UNSUPPORTED). */
+int gtx_vcf_sites(const gtx_ctx *, const gtx_vcf_request *, const gtx_phase_entry * ph, uint64_t n_ph, char * out, uint64_t cap, uint64_t * len);
+
 /* ---- host mirror of the per-record control flow (no device work) ----
  * Feed records in merged stream order; the stream decides which records are filtered, which reuse the previous
  * alignment (equal_pos_seq) and which pairs / unpaired reads reach the scorer. */

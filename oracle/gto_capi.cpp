@@ -612,6 +612,16 @@ extern "C"
     return static_cast<long>(text.size());
   }
 
+  // the sites-only records of vcf_merge_and_filter with the genotyper's own phasing flags (gto_vcf.hpp: sites)
+  long gto_vcf_sites(void * p, char const * contig, char * out, long cap)
+  {
+    Genotyper const & g = *static_cast<GenoHandle *>(p)->g;
+    std::string const text = vcf::sites(g, contig, g.phase_flags());
+    if (out && cap > 0)
+      std::memcpy(out, text.data(), static_cast<std::size_t>(std::min<long>(cap, static_cast<long>(text.size()))));
+    return static_cast<long>(text.size());
+  }
+
   // VCF records of an SV graph's calls (gto_sv.hpp: reformat_sv_vcf_records and the merge of genotype_sv).  sv_table: the text
   // form of Graph::SVs; reference / first_pos: the region's reference sequence and the 1-based position of its first base.
   // Returns the text length, or -1 (gto_last_error).

@@ -12,7 +12,8 @@
 //   Vcf::write_records            src/typer/vcf.cpp:1161-1275 (sites of one region are unique and sorted: the region filter)
 // with the std containers and string streams the reference uses.  Parity unpinned: the reference's tests hold no VCF text
 // (test/typer/test_vcf.cpp checks sample names and allele sequences only).  Not restated: the SV post-processing
-// (reformat_sv_vcf_records), variant break-down / pool merge (vcf_operations.cpp), the header's description lines.
+//   vcf_merge_and_filter          src/typer/vcf_operations.cpp:278-478 (sites(): the alleles the next iteration keeps, with their tags)
+// (reformat_sv_vcf_records: gto_sv.hpp), variant break-down (vcf_operations.cpp:480-), the header's description lines.
 // Only tests/ may use this file (through oracle/libgto.so).
 #pragma once
 #include "gto.hpp"
@@ -273,6 +274,7 @@ struct Variant
   VarStats stats;
   std::map<std::string, std::string> infos;
   std::string suffix_id;
+  int32_t hap_id = -1; // variant.hpp:30; Vcf::add_haplotype sets it to the haplotype's index (vcf.cpp:1509-1510)
 
   bool is_sv() const // variant.cpp:1098-1118
   {
@@ -999,6 +1001,95 @@ inline std::vector<Variant> haplotype_variants(Genotyper const & g, WriteOptions
     out.push_back(std::move(var));
   }
   return out;
+}
+
+// vcf_merge_and_filter (src/typer/vcf_operations.cpp:278-478) over the result of one calling pass: the sites-only records an
+// iteration hands to the next graph construction.  What the reference reads back from its pools are the variants of
+// parallel_reader_genotype_only's Vcf when no calls file is written (hts_parallel_reader.cpp:939-962): add_haplotype for every
+// haplotype (hap_id = its index), scan_calls, calls cleared.  Further pools only add their statistics (:366-374); the Genotyper
+// here holds all samples, which is the same sums.  `ph`: the phasing flags of call() (caller.cpp:439-479).
+inline std::string sites(Genotyper const & g, std::string const & contig, std::map<std::pair<uint16_t, uint16_t>, std::map<std::pair<uint16_t, uint16_t>, int8_t>> const & ph)
+{
+  constexpr int8_t IS_ANY_HAP_SUPPORT = 1, IS_ANY_ANTI_HAP_SUPPORT = 2; // include/graphtyper/constants.hpp.in:56-57
+  WriteOptions pool_options;
+  std::vector<Variant> variants = haplotype_variants(g, pool_options);
+  for (std::size_t h = 0; h < variants.size(); ++h)
+  {
+    variants[h].hap_id = static_cast<int32_t>(h); // hts_parallel_reader.cpp:952
+    variants[h].suffix_id.clear();
+    variants[h].scan_calls(); // :957-961
+    variants[h].calls.clear();
+  }
+  WriteOptions o; // vcf.sample_names.clear(): only variant sites (:337)
+  o.contig = contig;
+  std::ostringstream out;
+  write_column_line(out, o); // write_header(true): the column line ends at INFO
+  long var_id = 0;
+  std::unordered_map<int32_t, long> hap_id2var_id; // :311-320
+  for (Variant const & var : variants)
+  {
+    hap_id2var_id.emplace(var.hap_id, var_id);
+    var_id += static_cast<long>(var.seqs.size()) - 1l;
+  }
+  var_id = 0;
+  for (Variant & var : variants) // :340-470
+  {
+    std::vector<int8_t> const is_good_alt = var.generate_infos(g.graph.is_sv_graph);
+    for (long a = 0; a < static_cast<long>(var.seqs.size()) - 1l; ++a)
+    {
+      ++var_id;
+      if (is_good_alt[static_cast<std::size_t>(a)] == 0)
+        continue;
+      Variant new_var;
+      new_var.abs_pos = var.abs_pos;
+      new_var.seqs.push_back(var.seqs[0]);
+      new_var.seqs.push_back(var.seqs[static_cast<std::size_t>(a) + 1]);
+      new_var.infos["GT_ID"] = std::to_string(var_id);
+      std::ostringstream ss_anti, ss_hap;
+      bool is_anti_empty = true, is_hap_empty = true;
+      for (long a2 = a + 1; a2 < static_cast<long>(var.seqs.size()) - 1l; ++a2) // other alleles of this variant are anti alleles
+      {
+        if (is_good_alt[static_cast<std::size_t>(a2)] == 0)
+          continue;
+        if (!is_anti_empty)
+          ss_anti << ",";
+        ss_anti << (var_id + a2 - a);
+        is_anti_empty = false;
+      }
+      auto find_it = ph.find(std::make_pair(static_cast<uint16_t>(var.hap_id), static_cast<uint16_t>(a + 1)));
+      if (find_it != ph.end())
+        for (auto const & other : find_it->second)
+        {
+          int32_t const other_hap_id = other.first.first, other_allele = other.first.second;
+          if (other_allele == 0)
+            continue;
+          int8_t const flags = other.second;
+          if (flags != IS_ANY_HAP_SUPPORT && flags != IS_ANY_ANTI_HAP_SUPPORT)
+            continue;
+          long const var_id_other = hap_id2var_id.at(other_hap_id) + other_allele;
+          if (flags == IS_ANY_HAP_SUPPORT)
+          {
+            if (!is_hap_empty)
+              ss_hap << ",";
+            ss_hap << var_id_other;
+            is_hap_empty = false;
+          }
+          else
+          {
+            if (!is_anti_empty)
+              ss_anti << ",";
+            ss_anti << var_id_other;
+            is_anti_empty = false;
+          }
+        }
+      if (!is_anti_empty)
+        new_var.infos["GT_ANTI_HAPLOTYPE"] = ss_anti.str();
+      if (!is_hap_empty)
+        new_var.infos["GT_HAPLOTYPE"] = ss_hap.str();
+      write_record(out, new_var, o, g.graph.is_sv_graph); // ("", no FILTER_ZERO_QUAL, genotypes dropped)
+    }
+  }
+  return out.str();
 }
 
 inline std::string records(Genotyper const & g, WriteOptions const & o)

@@ -278,6 +278,15 @@ class OracleGenotyper:
         L.gto_vcf_records(*args, buf, C.c_long(n))
         return buf.raw[:n]
 
+    def vcf_sites(self, contig):
+        """oracle/gto_vcf.hpp sites(): vcf_merge_and_filter's records (column line first) with the genotyper's own `ph`"""
+        L = lib()
+        L.gto_vcf_sites.restype = C.c_long
+        n = L.gto_vcf_sites(C.c_void_p(self.g), contig.encode(), None, C.c_long(0))
+        buf = C.create_string_buffer(n + 1)
+        L.gto_vcf_sites(C.c_void_p(self.g), contig.encode(), buf, C.c_long(n))
+        return buf.raw[:n]
+
     def vcf_records_sv(self, contig, sample_names, sv_table, reference, first_pos, region_begin=0, region_end=0xFFFFFFFF):
         """oracle/gto_sv.hpp: the VCF records of an SV graph's calls (reformat_sv_vcf_records + the merge of genotype_sv) as bytes;
         reference / first_pos: the region's reference sequence and the 1-based position of its first base"""

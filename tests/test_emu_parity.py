@@ -234,6 +234,14 @@ def run_stream(backend, oracle, codes, rec, n_samples, n_rg=1):
             if not kw:
                 run_stream.vcf_full = got_vcf
         run_stream.vcf = got_vcf
+        # the sites the next iteration's graph is built from: vcf_merge_and_filter (vcf_operations.cpp:278-478) with the flags above
+        got_sites = backend.ctx.vcf_sites("chrT", n_samples, acc.gt_cov, acc.stat_u64, acc.stat_u32, phred, calls, ph)
+        want_sites = og.vcf_sites("chrT")
+        if got_sites != want_sites:
+            gl, wl = got_sites.split(b"\n"), want_sites.split(b"\n")
+            bad = [i for i in range(min(len(gl), len(wl))) if gl[i] != wl[i]]
+            raise AssertionError("sites differ (%d vs %d lines), first at line %s:\n%r\n%r" % (len(gl), len(wl), bad[:1], gl[bad[0]] if bad else b"", wl[bad[0]] if bad else b""))
+        run_stream.sites = got_sites
     return want
 
 
