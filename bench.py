@@ -43,6 +43,8 @@ ALGO_BYTES_PER_READ = 3296  # B(L) = 86 + 796*n_k + (L - 31*n_k)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 USE_TASK_FLAGS = os.environ.get("GTX_BENCH_FLAGS", "1") != "0"  # the dense side array of the records (A/B switch)
 USE_ITEM_WORDS = os.environ.get("GTX_BENCH_ITEM_WORDS", "1") != "0"  # gtx_score_batch_words (0: gtx_score_batch_flags; A/B)
+# dense records of the position-hinted pass (gtx_align_batch_planes_compact / gtx_score_batch_compact; 0: every record in its slot; A/B)
+USE_COMPACT = os.environ.get("GTX_BENCH_COMPACT", "1") != "0" and USE_TASK_FLAGS and os.environ.get("GTX_BENCH_PLANES", "1") != "0"
 PLANE_INPUT = os.environ.get("GTX_BENCH_PLANES", "1") != "0"    # reads resident as plane rows (0: BAM nibble rows, repacked inside every call)
 REC_WORDS = int(os.environ.get("GTX_BENCH_REC_WORDS", "64"))  # uint32 words of a record slot (rec_words of gtx_align_batch; A/B switch)
 REGION_BEGIN = 1000000      # chr20:1000001-2000000
@@ -302,13 +304,15 @@ class Workload:
         # further lanes (--lanes): a step is still align -> score -> calls in stream order, but step k runs on lane k mod
         # lanes with that lane's stream, records and accumulators, so that the short queues at the end of one step (express,
         # general, scoring: latency-bound, the chip mostly idle) run beside the position-hinted pass of the next
+        self.d_compact = torch.zeros(n * 8, dtype=torch.int32, device=device) if USE_COMPACT else None
         self.lanes = [dict(stream=self.stream, sp=self.sp, buf=self.buf, d_rec=self.d_rec, d_flags=self.d_flags, d_phred=self.d_phred,
-                           d_calls=self.d_calls)]
+                           d_calls=self.d_calls, d_compact=self.d_compact)]
         for _ in range(1, max(1, lanes)):
             lane = dict(stream=torch.cuda.Stream(device=device), buf=gtx.ScoreBuffers(),
                         d_rec=torch.zeros(n * 2 * REC_WORDS, dtype=torch.int32, device=device),
                         d_flags=torch.zeros(n * 2, dtype=torch.uint8, device=device) if USE_TASK_FLAGS else None,
-                        d_phred=torch.zeros_like(self.d_phred), d_calls=torch.zeros_like(self.d_calls))
+                        d_phred=torch.zeros_like(self.d_phred), d_calls=torch.zeros_like(self.d_calls),
+                        d_compact=torch.zeros(n * 8, dtype=torch.int32, device=device) if USE_COMPACT else None)
             lane["sp"] = C.c_void_p(lane["stream"].cuda_stream)
             gtx.check(self.L.gtx_scores_alloc(ctx.h, n_samples, conn_cap, C.byref(lane["buf"]), C.byref(reduced)))
             self.lanes.append(lane)
@@ -412,9 +416,13 @@ class Workload:
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(stream)
             fl = d_flags.data_ptr() if d_flags is not None else None
-            gtx.check(self.align_fn(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, d_rec.data_ptr(), REC_WORDS, fl, sp))
+            if ln["d_compact"] is not None:
+                gtx.check(L.gtx_align_batch_planes_compact(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, d_rec.data_ptr(), REC_WORDS,
+                                                           ln["d_compact"].data_ptr(), fl, sp, None, None, None))
+            else:
+                gtx.check(self.align_fn(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, d_rec.data_ptr(), REC_WORDS, fl, sp))
             e1.record(stream)
-            self._score_call(d_items, d_rec, fl, buf, sp)
+            self._score_call(d_items, d_rec, fl, buf, sp, ln["d_compact"])
             if self.comm is not None or self.dist is not None:
                 assert lane == 0  # (one communicator: the exchange steps of two streams must not interleave)
                 self._reduce(ln, stream, sp)
@@ -422,9 +430,12 @@ class Workload:
             gtx.check(L.gtx_calls_batch(ctx.h, C.byref(buf), ln["d_phred"].data_ptr(), ln["d_calls"].data_ptr(), sp))
         return e0, e1
 
-    def _score_call(self, d_items, d_rec, fl, buf, sp):
+    def _score_call(self, d_items, d_rec, fl, buf, sp, d_compact=None):
         w = self.words.get(int(d_items.data_ptr()))
-        if w is not None and fl is not None:
+        if d_compact is not None:
+            self.gtx.check(self.L.gtx_score_batch_compact(self.ctx.h, d_items.data_ptr(), w.data_ptr() if w is not None else None, self.n, d_rec.data_ptr(),
+                                                          REC_WORDS, d_compact.data_ptr(), fl, C.byref(buf), sp))
+        elif w is not None and fl is not None:
             self.gtx.check(self.L.gtx_score_batch_words(self.ctx.h, d_items.data_ptr(), w.data_ptr(), self.n, d_rec.data_ptr(), REC_WORDS, fl, C.byref(buf), sp))
         else:
             self.gtx.check(self.L.gtx_score_batch_flags(self.ctx.h, d_items.data_ptr(), self.n, d_rec.data_ptr(), REC_WORDS, fl, C.byref(buf), sp))
@@ -438,7 +449,7 @@ class Workload:
                 stream.wait_event(ev)
             fl = ln["d_flags"].data_ptr() if ln["d_flags"] is not None else None
             gtx.check(L.gtx_scores_zero(ctx.h, C.byref(ln["buf"]), sp))
-            self._score_call(ln["items"], ln["d_rec"], fl, ln["buf"], sp)
+            self._score_call(ln["items"], ln["d_rec"], fl, ln["buf"], sp, ln["d_compact"])
             self._reduce(ln, stream, sp)
             gtx.check(L.gtx_calls_batch(ctx.h, C.byref(ln["buf"]), ln["d_phred"].data_ptr(), ln["d_calls"].data_ptr(), sp))
             ln["scored"].record(stream)
@@ -490,9 +501,14 @@ class Workload:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(H)
                 fl = ln["d_flags"].data_ptr() if ln["d_flags"] is not None else None
-                gtx.check(L.gtx_align_batch_planes_staged(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, ln["d_rec"].data_ptr(),
-                                                          REC_WORDS, fl, spH, C.c_void_p(ln["front"].cuda_event), spT,
-                                                          C.c_void_p(ln["aligned"].cuda_event)))
+                if ln["d_compact"] is not None:
+                    gtx.check(L.gtx_align_batch_planes_compact(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, ln["d_rec"].data_ptr(),
+                                                               REC_WORDS, ln["d_compact"].data_ptr(), fl, spH, C.c_void_p(ln["front"].cuda_event), spT,
+                                                               C.c_void_p(ln["aligned"].cuda_event)))
+                else:
+                    gtx.check(L.gtx_align_batch_planes_staged(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, ln["d_rec"].data_ptr(),
+                                                              REC_WORDS, fl, spH, C.c_void_p(ln["front"].cuda_event), spT,
+                                                              C.c_void_p(ln["aligned"].cuda_event)))
             with torch.cuda.stream(T):
                 e1.record(T)
             ln["items"] = d_items
@@ -609,7 +625,12 @@ class Workload:
     def result_facts(self):
         """sanity on the results of the last step: every record must be a result, not an overflow"""
         gtx, ctx = self.gtx, self.ctx
-        rec_head = self.d_rec.view(self.n * 2, REC_WORDS)[:, 0]
+        rec_head = self.d_rec.view(self.n * 2, REC_WORDS)[:, 0].clone()
+        compact_records = 0
+        if self.d_compact is not None:  # (the records the position-hinted pass left in the dense array: their headers are there)
+            is_compact = (self.d_flags[0::2] & 2) != 0
+            rec_head[0::2] = self.torch.where(is_compact, self.d_compact.view(self.n, 8)[:, 0], rec_head[0::2])
+            compact_records = int(is_compact.sum().item())
         cc = gtx.download(self.buf.d_conn_count, np.uint32, 2)
         # VCF text of the region from the last step's results (host side, outside the timed region)
         t0 = time.perf_counter()
@@ -626,7 +647,7 @@ class Workload:
                 "reads_overflowed": int((((rec_head >> 16) & gtx.ST_ERROR_MASK) != 0).sum().item()),
                 "reads_overflowed_by_kind": {name: int((((rec_head >> 16) & bit) != 0).sum().item())
                                              for name, bit in (("labels", 1), ("paths", 2), ("walk", 4), ("record_arena_full", 8))},
-                "records_in_the_arena": int((((rec_head >> 16) & gtx.ST_EXTERNAL) != 0).sum().item()),
+                "records_in_the_arena": int((((rec_head >> 16) & gtx.ST_EXTERNAL) != 0).sum().item()), "records_in_the_dense_array": compact_records,
                 "nonref_genotype_calls": int((calls["gt_second"] > 0).sum()), "score_items_refused": ctx.error_count(),
                 "connections_logged": int(cc[0]), "connections_dropped": int(cc[1])}
 
@@ -1495,7 +1516,7 @@ def main(argv=None):
            "samples": n_samples, "reads_per_rank": per_rank,
            "reads_per_gpu": n, "index_keys": n_keys, "index_labels": n_labels, "haplotypes": ctx.n_hap,
            "ctx_create_s": round(t_ctx_warm, 3), "ctx_create_first_s": round(t_ctx, 3),
-           "position_hint": not args.no_hint, "task_flags_side_array": USE_TASK_FLAGS,
+           "position_hint": not args.no_hint, "task_flags_side_array": USE_TASK_FLAGS, "dense_records": USE_COMPACT,
            "read_layout": "bit planes (gtx_align_batch_planes; repacked once from BAM nibbles by gtx_reads_to_planes before the timed region)" if PLANE_INPUT else "BAM nibbles (gtx_align_batch_flags repacks them inside every call)", "resident_read_sets": len(w.sets),
            "streams": {"steps_in_flight": w.used_lanes, "schedule": ("staggered" if w.staggered else "lanes") if w.used_lanes > 1 else "one step at a time",
                        "calibration": w.calibration,

@@ -369,7 +369,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
                                             gtx_read_meta const * __restrict__ meta, uint32_t n_reads, uint32_t * __restrict__ records,
                                             uint32_t rec_words, uint32_t force_both, uint32_t * __restrict__ queue1, uint32_t * __restrict__ queue2,
                                             unsigned long long * queue_counts /* queue 2's fill count (low word), queue 1's (high word) */,
-                                            uint32_t decline_all, uint8_t * __restrict__ task_flags)
+                                            uint32_t decline_all, uint8_t * __restrict__ task_flags, uint32_t * __restrict__ compact)
 {
   // The 64 reads of a wavefront lie side by side in memory: their bases (80 B each: five 16-byte groups of four plane words,
   // graph_dev.hpp) and their meta records (20 B each) are fetched with coalesced loads -- 1 KB and 256 B per instruction
@@ -417,6 +417,8 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
   WaveHip::lds_sync();
   bool fwd = false, fwd2 = false, rev = false, staged_rec = false; // forward task to the express pass / straight to the general pass, reverse task
   uint32_t fwd_flag = 0;
+  // (dense records: whole wavefronts only -- the block of 64 compact records is written as two stores over whole lines)
+  bool const compact_wave = compact != nullptr && task_flags != nullptr && full;
   static_assert(HINT_STAGE_WORDS == 16 && HINT_STAGE_WORDS * 4 <= ROW_BYTES, "a staged record is four 16-byte parts inside the read's row");
   if (read < n_reads)
   {
@@ -481,6 +483,13 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
       fwd2 = where == HINT_TO_GENERAL;
       staged_rec = where == 2;
       fwd_flag = (where == 0 || where == HINT_TO_GENERAL) ? 0u : ((where == 2 ? row[1] : rec_at()[1]) >> 31);
+      // (dense records, gtx_align_batch_planes_compact: a staged record of at most GTX_COMPACT_WORDS words -- no path, or one
+      //  without a variant site -- leaves through the wavefront's block of the compact array below, not through its slot)
+      if (compact_wave && staged_rec && (row[0] & 0xFFFFu) <= 1u && fwd_flag == 0)
+      {
+        staged_rec = false;
+        fwd_flag = GTX_TASK_COMPACT;
+      }
     }
     // the dense side array (gtx_align_batch_flags): what this pass settles -- the forward task it finished, the reverse
     // task that is not aligned at all; the queued tasks get theirs from gtx_task_flags_fixup_kernel behind the last pass
@@ -490,6 +499,21 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
         task_flags[2ull * read] = static_cast<uint8_t>(fwd_flag);
       if (!rev)
         task_flags[2ull * read + 1] = 0;
+    }
+  }
+  if (compact_wave)
+  {
+    // The wavefront's 64 compact records are 2 KB side by side: lane l of store k carries bytes [16 (64 k + l), + 16) of the block --
+    // the half (l & 1) of the record of read 32 k + l / 2, out of that read's row in LDS.  Every read's eight words leave, whatever
+    // they are (a record that went to its slot, a declined read's bases): whole lines, no partial write; GTX_TASK_COMPACT says
+    // which ones are records.
+    WaveHip::lds_sync();
+    uint4_t * dst = reinterpret_cast<uint4_t *>(compact + static_cast<uint64_t>(wave_first) * GTX_COMPACT_WORDS);
+#pragma unroll
+    for (uint32_t k = 0; k < 2; ++k)
+    {
+      uint32_t const r = 32u * k + (lane >> 1);
+      stream_store(dst + 64u * k + lane, s_seq[wave][r * ROW_PITCH + (lane & 1u)]);
     }
   }
   {
@@ -511,10 +535,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
           uint4_t const v = s_seq[wave][r * ROW_PITCH + part];
           uint32_t const rd = wave_first + r;
           uint32_t * dst = records + static_cast<uint64_t>(GTX_HINT_REC_SLOT(rd)) * 2 * rec_words;
-#ifdef GTX_X_HALF_REC_STORE /* (experiment build: what a 32-byte record would cost -- the first two parts of four, of a slot half as wide) */
-          if (part < 2)
-            stream_store(reinterpret_cast<uint4_t *>(records + static_cast<uint64_t>(GTX_HINT_REC_SLOT(rd)) * 8 + 4 * part), v);
-#elif !defined(GTX_X_NO_REC_STORE) /* (experiment build: the kernel without its record stores) */
+#ifndef GTX_X_NO_REC_STORE /* (experiment build: the kernel without its record stores) */
           stream_store(reinterpret_cast<uint4_t *>(dst + 4 * part), v);
 #endif
         }
@@ -566,8 +587,9 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
 #define GTX_HINTED_ARGS                                                                                                            \
   GraphView g, IndexView ix, uint8_t const *__restrict__ seq, uint32_t seq_stride, gtx_read_meta const *__restrict__ meta,         \
     uint32_t n_reads, uint32_t *__restrict__ records, uint32_t rec_words, uint32_t force_both, uint32_t *__restrict__ queue1,      \
-    uint32_t *__restrict__ queue2, unsigned long long *queue_counts, uint32_t decline_all, uint8_t *__restrict__ task_flags
-#define GTX_HINTED_PASS(W, ...) hinted_pass<W, __VA_ARGS__>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, queue1, queue2, queue_counts, decline_all, task_flags)
+    uint32_t *__restrict__ queue2, unsigned long long *queue_counts, uint32_t decline_all, uint8_t *__restrict__ task_flags,       \
+    uint32_t *__restrict__ compact
+#define GTX_HINTED_PASS(W, ...) hinted_pass<W, __VA_ARGS__>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, queue1, queue2, queue_counts, decline_all, task_flags, compact)
 
 #ifndef GTX_HINT_VGPRS
 #define GTX_HINT_VGPRS 80
@@ -1598,7 +1620,8 @@ static gtx_ctx::ExactSlot const * exact_slot_for_call(gtx_ctx & c, bool * wait)
 
 static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
                         uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, hipStream_t st, hipEvent_t front_event = nullptr,
-                        hipStream_t tail_stream = nullptr, hipEvent_t done_event = nullptr, hipStream_t * last_stream = nullptr);
+                        hipStream_t tail_stream = nullptr, hipEvent_t done_event = nullptr, hipStream_t * last_stream = nullptr,
+                        uint32_t * d_compact = nullptr);
 
 // BAM nibble rows: repacked into plane rows in the call's scratch, then the same kernels
 extern "C" int gtx_align_batch_flags(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta,
@@ -1637,9 +1660,34 @@ extern "C" int gtx_align_batch_planes(gtx_ctx * c, const uint8_t * d_planes, uin
   return gtx_align_batch_planes_staged(c, d_planes, plane_stride, d_meta, n_reads, d_records, rec_words, d_task_flags, stream, nullptr, nullptr, nullptr);
 }
 
+static int align_batch_planes_staged(gtx_ctx * c, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
+                                     uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream, void * front_event,
+                                     void * tail_stream, void * done_event, uint32_t * d_compact);
+
 extern "C" int gtx_align_batch_planes_staged(gtx_ctx * c, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta,
                                              uint32_t n_reads, uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream,
                                              void * front_event, void * tail_stream, void * done_event)
+{
+  return align_batch_planes_staged(c, d_planes, plane_stride, d_meta, n_reads, d_records, rec_words, d_task_flags, stream, front_event, tail_stream,
+                                   done_event, nullptr);
+}
+
+extern "C" int gtx_align_batch_planes_compact(gtx_ctx * c, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta,
+                                              uint32_t n_reads, uint32_t * d_records, uint32_t rec_words, uint32_t * d_compact, uint8_t * d_task_flags,
+                                              void * stream, void * front_event, void * tail_stream, void * done_event)
+{
+  if (n_reads != 0 && (!d_compact || !d_task_flags || (reinterpret_cast<uintptr_t>(d_compact) & 15u) != 0))
+  {
+    g_last_error = "gtx_align_batch_planes_compact: needs d_task_flags and a 16-byte aligned d_compact";
+    return GTX_ERR_ARG;
+  }
+  return align_batch_planes_staged(c, d_planes, plane_stride, d_meta, n_reads, d_records, rec_words, d_task_flags, stream, front_event, tail_stream,
+                                   done_event, d_compact);
+}
+
+static int align_batch_planes_staged(gtx_ctx * c, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
+                                     uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream, void * front_event,
+                                     void * tail_stream, void * done_event, uint32_t * d_compact)
 {
   if (!c || rec_words < 8 || plane_stride == 0 || (plane_stride % PLANE_GROUP_BYTES) != 0 || (reinterpret_cast<uintptr_t>(d_planes) & 15u) != 0 ||
       (n_reads != 0 && (!d_planes || !d_meta || !d_records)))
@@ -1678,7 +1726,7 @@ extern "C" int gtx_align_batch_planes_staged(gtx_ctx * c, const uint8_t * d_plan
   hipStream_t last = st;
   int const rc = align_planes(c, hold.s, d_planes, plane_stride, d_meta, n_reads, d_records, rec_words, d_task_flags, st,
                               static_cast<hipEvent_t>(front_event), std::getenv("GTX_PARTS") ? nullptr : static_cast<hipStream_t>(tail_stream),
-                              static_cast<hipEvent_t>(done_event), &last);
+                              static_cast<hipEvent_t>(done_event), &last, d_compact);
   hold.stream = last; // (the stream the call's last launch is on)
   return rc;
 }
@@ -1686,7 +1734,7 @@ extern "C" int gtx_align_batch_planes_staged(gtx_ctx * c, const uint8_t * d_plan
 // the passes over plane rows (d_seq / seq_stride: the plane rows and their pitch)
 static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
                         uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, hipStream_t st, hipEvent_t front_event, hipStream_t tail_stream,
-                        hipEvent_t done_event, hipStream_t * last_stream)
+                        hipEvent_t done_event, hipStream_t * last_stream, uint32_t * d_compact)
 {
   // (the pass counters and, behind them, the state of the HBM-table and wide-site passes: one reset)
   if (!hip_ok(hipMemsetAsync(s->d_counters, 0, (8 * CallScratch::MAX_PARTS + (s->d_big_state ? 48 : 0)) * sizeof(uint32_t), st), "task counter reset"))
@@ -1867,7 +1915,8 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
                            | (eh && eh[0] == 'x' ? 2u : 0u)
 #endif
                            ,
-                         d_task_flags ? d_task_flags + 2ull * first : static_cast<uint8_t *>(nullptr));
+                         d_task_flags ? d_task_flags + 2ull * first : static_cast<uint8_t *>(nullptr),
+                         d_compact ? d_compact + static_cast<uint64_t>(first) * GTX_COMPACT_WORDS : static_cast<uint32_t *>(nullptr));
       if (!hip_ok(hipGetLastError(), "gtx_align_hinted_kernel launch"))
         return GTX_ERR_HIP;
       mark(part, 1, st);
@@ -2145,7 +2194,7 @@ extern "C" int gtx_score_batch(gtx_ctx * c, const gtx_score_item * d_items, uint
 }
 
 static int score_batch(gtx_ctx * c, const gtx_score_item * d_items, const uint32_t * d_item_words, uint32_t n_items, const uint32_t * d_records,
-                       uint32_t rec_words, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream);
+                       uint32_t rec_words, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream, const uint32_t * d_compact = nullptr);
 
 extern "C" int gtx_score_batch_flags(gtx_ctx * c, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records,
                                      uint32_t rec_words, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream)
@@ -2165,6 +2214,18 @@ extern "C" int gtx_score_batch_words(gtx_ctx * c, const gtx_score_item * d_items
   return score_batch(c, d_items, d_item_words, n_items, d_records, rec_words, d_task_flags, acc, stream);
 }
 
+extern "C" int gtx_score_batch_compact(gtx_ctx * c, const gtx_score_item * d_items, const uint32_t * d_item_words, uint32_t n_items,
+                                       const uint32_t * d_records, uint32_t rec_words, const uint32_t * d_compact, const uint8_t * d_task_flags,
+                                       const gtx_score_buffers * acc, void * stream)
+{
+  if (!d_compact || !d_task_flags)
+  {
+    g_last_error = "gtx_score_batch_compact: needs the compact records and the side array gtx_align_batch_planes_compact filled";
+    return GTX_ERR_ARG;
+  }
+  return score_batch(c, d_items, d_item_words, n_items, d_records, rec_words, d_task_flags, acc, stream, d_compact);
+}
+
 // gtx_score_batch_words' compact form of the items (host)
 extern "C" int gtx_item_words(const gtx_score_item * items, uint32_t n_items, uint32_t * words)
 {
@@ -2181,7 +2242,7 @@ extern "C" int gtx_item_words(const gtx_score_item * items, uint32_t n_items, ui
 }
 
 static int score_batch(gtx_ctx * c, const gtx_score_item * d_items, const uint32_t * d_item_words, uint32_t n_items, const uint32_t * d_records,
-                       uint32_t rec_words, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream)
+                       uint32_t rec_words, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream, const uint32_t * d_compact)
 {
   if (!c || !d_items || !d_records || !acc || !acc->d_log_score || !acc->d_gt_cov || !acc->d_hap_u32 || !acc->d_stat_u64 ||
       !acc->d_stat_u32 || !acc->d_conn_log || !acc->d_conn_count)
@@ -2215,6 +2276,8 @@ static int score_batch(gtx_ctx * c, const gtx_score_item * d_items, const uint32
   a.conn_count = acc->d_conn_count;
   a.conn_near = acc->d_conn_near;
   a.big_records = c->d_big_records;
+  a.compact = d_compact;
+  a.compact_flags = d_compact ? d_task_flags : nullptr;
   a.ref_depth = c->params.is_sv_graph ? acc->d_ref_depth : nullptr;
   a.ref_depth_len = acc->ref_depth_len;
   if (a.ref_depth && a.ref_depth_len != c->graph.ref_order.back() + c->graph.ref_len.back() - c->graph.ref_order.front())
@@ -2263,25 +2326,36 @@ static int score_batch(gtx_ctx * c, const gtx_score_item * d_items, const uint32
 }
 
 // Sequential replay of the cells that reached the saturation guard of explain_to_score (score_replay.hpp).
+static int scores_replay(gtx_ctx * c, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records, uint32_t rec_words,
+                         const gtx_score_buffers * acc, void * stream, uint64_t * n_replayed, uint64_t * n_unsupported, const uint32_t * d_compact,
+                         const uint8_t * d_task_flags);
+
 extern "C" int gtx_scores_replay(gtx_ctx * c, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records,
                                  uint32_t rec_words, const gtx_score_buffers * acc, void * stream, uint64_t * n_replayed,
                                  uint64_t * n_unsupported)
 {
-  if (!c || !acc || !acc->d_log_score || !acc->d_hap_u32 || (n_items && (!d_items || !d_records)))
+  return scores_replay(c, d_items, n_items, d_records, rec_words, acc, stream, n_replayed, n_unsupported, nullptr, nullptr);
+}
+
+extern "C" int gtx_scores_replay_compact(gtx_ctx * c, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records,
+                                         uint32_t rec_words, const uint32_t * d_compact, const uint8_t * d_task_flags,
+                                         const gtx_score_buffers * acc, void * stream, uint64_t * n_replayed, uint64_t * n_unsupported)
+{
+  if (!d_compact || !d_task_flags)
   {
-    g_last_error = "gtx_scores_replay: bad argument";
+    g_last_error = "gtx_scores_replay_compact: needs the compact records and their side array";
     return GTX_ERR_ARG;
   }
-  if (c->device < 0)
-  {
-    g_last_error = "context was created without a device (libgtx has no CPU path)";
-    return GTX_ERR_NO_DEVICE;
-  }
-  if (n_replayed)
-    *n_replayed = 0;
-  if (n_unsupported)
-    *n_unsupported = 0;
-  hipStream_t const st = static_cast<hipStream_t>(stream);
+  return scores_replay(c, d_items, n_items, d_records, rec_words, acc, stream, n_replayed, n_unsupported, d_compact, d_task_flags);
+}
+
+// the calls of explain_to_score on the cells of `acc` that stand at the guard, logged by a pass over the items (any order)
+static int replay_collect(gtx_ctx * c, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records, uint32_t rec_words,
+                          const gtx_score_buffers * acc, hipStream_t st, const uint32_t * d_compact, const uint8_t * d_task_flags,
+                          std::vector<ReplayEntry> & log, uint64_t & unsupported)
+{
+  log.clear();
+  unsupported = 0;
   if (!hip_ok(hipSetDevice(c->device), "hipSetDevice") || !hip_ok(hipStreamSynchronize(st), "stream synchronize"))
     return GTX_ERR_HIP;
   HostGraph const & g = c->graph;
@@ -2290,7 +2364,7 @@ extern "C" int gtx_scores_replay(gtx_ctx * c, const gtx_score_item * d_items, ui
   if (!hip_ok(hipMemcpy(cells.data(), acc->d_hap_u32, cells.size() * sizeof(uint32_t), hipMemcpyDeviceToHost), "cells"))
     return GTX_ERR_HIP;
   std::vector<uint32_t> marked((n_cells + 31) / 32, 0u);
-  uint64_t n_marked = 0, unsupported = 0;
+  uint64_t n_marked = 0;
   for (uint64_t cell = 0; cell < n_cells; ++cell)
   {
     uint32_t const m = cells[4 * cell];
@@ -2304,9 +2378,7 @@ extern "C" int gtx_scores_replay(gtx_ctx * c, const gtx_score_item * d_items, ui
     marked[cell >> 5] |= 1u << (cell & 31u);
     ++n_marked;
   }
-  if (n_unsupported)
-    *n_unsupported = unsupported;
-  if (n_marked == 0)
+  if (n_marked == 0 || n_items == 0)
     return GTX_OK;
   ScratchHold hold{*c, scratch_acquire(*c, st), st, false};
   CallScratch * s = hold.s;
@@ -2319,7 +2391,6 @@ extern "C" int gtx_scores_replay(gtx_ctx * c, const gtx_score_item * d_items, ui
   uint32_t * d_count = nullptr;
   ReplayEntry * d_log = nullptr;
   uint32_t cap = 1u << 20;
-  std::vector<ReplayEntry> log;
   bool ok = dev_alloc(d_marked, marked.size(), "replay bitmap") && dev_alloc(d_count, 1, "replay count") &&
             hip_ok(hipMemcpy(d_marked, marked.data(), marked.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "replay bitmap");
   for (int attempt = 0; ok && attempt < 2; ++attempt) // (a second launch when the log was too small)
@@ -2339,6 +2410,8 @@ extern "C" int gtx_scores_replay(gtx_ctx * c, const gtx_score_item * d_items, ui
     a.conn_count = acc->d_conn_count;
     a.conn_near = acc->d_conn_near;
     a.big_records = c->d_big_records;
+    a.compact = d_compact;
+    a.compact_flags = d_compact ? d_task_flags : nullptr;
     a.replay_cells = d_marked;
     a.replay_log = d_log;
     a.replay_count = d_count;
@@ -2369,25 +2442,129 @@ extern "C" int gtx_scores_replay(gtx_ctx * c, const gtx_score_item * d_items, ui
       ok = false;
     }
   }
-  if (ok)
-  {
-    std::vector<ReplayedCell> const done = replay_cells(g, log);
-    for (ReplayedCell const & rc : done)
-    {
-      uint32_t const h = rc.cell % g.n_hap, sample = rc.cell / g.n_hap;
-      uint32_t const head = rc.max_log_score | GTX_CELL_REPLAYED;
-      ok = ok && hip_ok(hipMemcpy(acc->d_hap_u32 + 4ull * rc.cell, &head, sizeof(head), hipMemcpyHostToDevice), "replayed cell") &&
-           hip_ok(hipMemcpy(acc->d_log_score + static_cast<uint64_t>(sample) * g.total_tri + g.tri_off[h], rc.log_score.data(),
-                            rc.log_score.size() * sizeof(uint32_t), hipMemcpyHostToDevice),
-                  "replayed scores");
-    }
-    if (n_replayed)
-      *n_replayed = done.size();
-  }
   for (void * p : {static_cast<void *>(d_marked), static_cast<void *>(d_count), static_cast<void *>(d_log)})
     if (p)
       (void)gtx::dev_free(p);
   return ok ? GTX_OK : GTX_ERR_HIP;
+}
+
+// the logged calls replayed one by one in call order (score_replay.hpp), the exact rows stored back into `acc`
+static int replay_store(gtx_ctx * c, const gtx_score_buffers * acc, std::vector<ReplayEntry> & log, uint64_t * n_replayed)
+{
+  HostGraph const & g = c->graph;
+  uint64_t const n_cells = static_cast<uint64_t>(acc->n_samples) * g.n_hap;
+  for (ReplayEntry const & e : log)
+    if (e.cell >= n_cells || g.ref_nvar[e.cell % g.n_hap] > 64)
+    {
+      g_last_error = "gtx_scores_replay_apply: an entry names a cell the block does not have";
+      return GTX_ERR_ARG;
+    }
+  std::vector<ReplayedCell> const done = replay_cells(g, log);
+  bool ok = true;
+  for (ReplayedCell const & rc : done)
+  {
+    uint32_t const h = rc.cell % g.n_hap, sample = rc.cell / g.n_hap;
+    uint32_t const head = rc.max_log_score | GTX_CELL_REPLAYED;
+    ok = ok && hip_ok(hipMemcpy(acc->d_hap_u32 + 4ull * rc.cell, &head, sizeof(head), hipMemcpyHostToDevice), "replayed cell") &&
+         hip_ok(hipMemcpy(acc->d_log_score + static_cast<uint64_t>(sample) * g.total_tri + g.tri_off[h], rc.log_score.data(),
+                          rc.log_score.size() * sizeof(uint32_t), hipMemcpyHostToDevice),
+                "replayed scores");
+  }
+  if (n_replayed)
+    *n_replayed = done.size();
+  return ok ? GTX_OK : GTX_ERR_HIP;
+}
+
+static int scores_replay(gtx_ctx * c, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records, uint32_t rec_words,
+                         const gtx_score_buffers * acc, void * stream, uint64_t * n_replayed, uint64_t * n_unsupported, const uint32_t * d_compact,
+                         const uint8_t * d_task_flags)
+{
+  if (!c || !acc || !acc->d_log_score || !acc->d_hap_u32 || (n_items && (!d_items || !d_records)))
+  {
+    g_last_error = "gtx_scores_replay: bad argument";
+    return GTX_ERR_ARG;
+  }
+  if (c->device < 0)
+  {
+    g_last_error = "context was created without a device (libgtx has no CPU path)";
+    return GTX_ERR_NO_DEVICE;
+  }
+  if (n_replayed)
+    *n_replayed = 0;
+  if (n_unsupported)
+    *n_unsupported = 0;
+  std::vector<ReplayEntry> log;
+  uint64_t unsupported = 0;
+  int rc = replay_collect(c, d_items, n_items, d_records, rec_words, acc, static_cast<hipStream_t>(stream), d_compact, d_task_flags, log, unsupported);
+  if (n_unsupported)
+    *n_unsupported = unsupported;
+  if (rc != GTX_OK || log.empty())
+    return rc;
+  return replay_store(c, acc, log, n_replayed);
+}
+
+// ---- the same in two halves for reads sharded over ranks: every rank logs what ITS items did to the cells that stand
+// at the guard in the block summed over all ranks, the hosts exchange the logs, and whoever makes the calls replays them all.
+static_assert(sizeof(gtx_replay_entry) == sizeof(ReplayEntry), "gtx_replay_entry is ReplayEntry");
+extern "C" int gtx_scores_replay_log(gtx_ctx * c, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records, uint32_t rec_words,
+                                     const uint32_t * d_compact, const uint8_t * d_task_flags, const gtx_score_buffers * acc, uint32_t item_base,
+                                     void * stream, gtx_replay_entry * out, uint64_t cap, uint64_t * n, uint64_t * n_unsupported)
+{
+  if (!c || !n || !acc || !acc->d_log_score || !acc->d_hap_u32 || (n_items && (!d_items || !d_records)) || (cap && !out) || (d_compact && !d_task_flags))
+  {
+    g_last_error = "gtx_scores_replay_log: bad argument";
+    return GTX_ERR_ARG;
+  }
+  *n = 0;
+  if (n_unsupported)
+    *n_unsupported = 0;
+  if (c->device < 0)
+  {
+    g_last_error = "context was created without a device (libgtx has no CPU path)";
+    return GTX_ERR_NO_DEVICE;
+  }
+  std::vector<ReplayEntry> log;
+  uint64_t unsupported = 0;
+  int const rc = replay_collect(c, d_items, n_items, d_records, rec_words, acc, static_cast<hipStream_t>(stream), d_compact, d_task_flags, log, unsupported);
+  if (n_unsupported)
+    *n_unsupported = unsupported;
+  if (rc != GTX_OK)
+    return rc;
+  *n = log.size();
+  if (log.size() > cap)
+  {
+    g_last_error = "gtx_scores_replay_log: " + std::to_string(log.size()) + " entries, room for " + std::to_string(cap);
+    return GTX_ERR_CAPACITY;
+  }
+  for (ReplayEntry & e : log)
+    e.item += item_base; // (the item's place in the region's sequence over all ranks)
+  if (!log.empty())
+    std::memcpy(out, log.data(), log.size() * sizeof(ReplayEntry));
+  return GTX_OK;
+}
+
+extern "C" int gtx_scores_replay_apply(gtx_ctx * c, const gtx_score_buffers * acc, const gtx_replay_entry * entries, uint64_t n_entries, void * stream,
+                                       uint64_t * n_replayed)
+{
+  if (!c || !acc || !acc->d_log_score || !acc->d_hap_u32 || (n_entries && !entries))
+  {
+    g_last_error = "gtx_scores_replay_apply: bad argument";
+    return GTX_ERR_ARG;
+  }
+  if (n_replayed)
+    *n_replayed = 0;
+  if (c->device < 0)
+  {
+    g_last_error = "context was created without a device (libgtx has no CPU path)";
+    return GTX_ERR_NO_DEVICE;
+  }
+  if (n_entries == 0)
+    return GTX_OK;
+  if (!hip_ok(hipSetDevice(c->device), "hipSetDevice") || !hip_ok(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "stream synchronize"))
+    return GTX_ERR_HIP;
+  std::vector<ReplayEntry> log(n_entries);
+  std::memcpy(log.data(), entries, n_entries * sizeof(ReplayEntry));
+  return replay_store(c, acc, log, n_replayed);
 }
 
 extern "C" int gtx_ctx_big_records(gtx_ctx * c, const uint32_t ** d_words, uint64_t * capacity_words, uint64_t * used_words,

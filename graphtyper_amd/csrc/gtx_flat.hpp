@@ -146,11 +146,12 @@ struct IndexView
   //     bits 8..15      min(255, bases of that node in front of the position);
   //     bits 21..26     HINT_SNP_GROUP, reference base and allele count of the SNP under K_i (see below).
   // filt[side]: blocked Bloom filter over every indexed key's 16 first (side 0) / last (side 1) bases in nibble form (four
-  //   bits of one word per half): a clear bit proves that no indexed key has that half.  Behind its 2^filt_log2 words lies a
-  //   FIRST LEVEL of 2^filt1_log2 words (filt1_log2 = 0: none) over the same halves, three bits of one word per half: small enough to
-  //   stay in an XCD's L2 beside the read stream, it answers most probes ("absent") without the visit to the large filter, whose
-  //   8 MB at cfg2 no L2 holds -- every probe there is a 64-byte fetch over the fabric, half of what the pass fetched beyond its
-  //   compulsory bytes.  Only a first-level "maybe" (a real member, or ~3-15 % of the absent halves) looks at the large one.
+  //   bits of one word per half): a clear bit proves that no indexed key has that half.
+  //   (Round 5, measured and dropped: a first level of an eighth / a quarter / a sixteenth of the words in front of it -- small enough
+  //    to stay in an XCD's L2, where the 8 MB of cfg2's two filters are a 64-byte fetch over the fabric per probe, 47 of the 157
+  //    bytes the pass fetches per read -- answered 85-97 % of the probes without that fetch and made the pass SLOWER, 0.406 ->
+  //    0.425-0.443 ms alone, the step in flight unchanged: its hashes and its second round trip cost more than the bytes saved.
+  //    Without any filter load the pass takes 0.372 ms -- the ceiling of anything done to them.)
   // tail_info[i]: the site behind the reference node position i lies in, when a walk from i may cross it the simple way
   //   (a SNP: 2..4 alleles of one base A/C/G/T each; not in an SV graph):  x = HINT_TAIL_OK | alleles << 2 (count, 3 bits) |
   //   min(255, length of the reference node behind the site) << 8 | the alleles' nibble codes << 16 (4 bits each);
@@ -159,7 +160,7 @@ struct IndexView
   const uint2_t * pos_flags;
   const uint2_t * tail_info;
   const uint32_t * filt[2];
-  uint32_t hint_first, n_hint, filt_log2 /* log2 of the number of words */, filt1_log2 /* ... of the first level behind them; 0 = none */;
+  uint32_t hint_first, n_hint, filt_log2 /* log2 of the number of words */, pad_hint;
   // ---- allele windows (dense build of the pass).  A read that carries another allele than the reference's at a site does not
   // lie on the linear reference; for the alternative alleles of the sites where that matters (HintWindow) the three tables
   // above continue, behind position win_base, with one window of HINT_WIN_STRIDE positions per (site, allele): the
@@ -250,15 +251,6 @@ inline void hint_filter_slot_of(uint32_t h, uint32_t h2, uint32_t log2_words, ui
   // chance hit of a half that occurs nowhere rare; with two bits it was ~1 % of the probes: 8 % of what the pass declined at cfg2)
   mask = (1u << (h2 >> 27)) | (1u << ((h2 >> 22) & 31u)) | (1u << ((h2 >> 17) & 31u)) | (1u << ((h2 >> 12) & 31u));
 }
-// the first level's word (an index into the same array, behind the 2^log2_words words of the large filter) and its three bits
-#if defined(__HIPCC__)
-__host__ __device__
-#endif
-inline void hint_filter_slot1_of(uint32_t h, uint32_t h2, uint32_t log2_words, uint32_t log2_first, uint32_t & word, uint32_t & mask)
-{
-  word = (1u << log2_words) + (h >> (32 - log2_first));
-  mask = (1u << ((h2 >> 7) & 31u)) | (1u << ((h2 >> 2) & 31u)) | (1u << ((h2 ^ (h2 >> 29) ^ (h >> 3)) & 31u));
-}
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
@@ -268,18 +260,6 @@ inline void hint_filter_slot(uint32_t w0, uint32_t w1, uint32_t log2_words, uint
   hint_filter_hash(w0, w1, h, h2);
   hint_filter_slot_of(h, h2, log2_words, word, mask);
 }
-// log2 of the first level's words for a large filter of 2^log2_words (0: no first level -- small filters are in the L2 themselves).
-// GTX_FILTER1_SHIFT: how many times smaller (default 3: an eighth -- 4 bits per key; 0: none).
-inline uint32_t hint_filter_first_log2(uint32_t log2_words)
-{
-  // (GTX_FILTER1_MIN: the smallest first level, default 2^16 words -- below that the large filter is in the L2 itself; the tests set
-  //  5 so that their small graphs have one)
-  char const * e = std::getenv("GTX_FILTER1_SHIFT");
-  char const * m = std::getenv("GTX_FILTER1_MIN");
-  uint32_t const shift = e ? static_cast<uint32_t>(std::atoi(e)) : 3u, least = m ? static_cast<uint32_t>(std::atoi(m)) : 16u;
-  return (shift == 0 || shift > 8 || least < 5 || log2_words < least + shift) ? 0u : log2_words - shift;
-}
-inline uint64_t hint_filter_words(uint32_t log2_words, uint32_t log2_first) { return (1ull << log2_words) + (log2_first ? (1ull << log2_first) : 0ull); }
 
 struct HostGraph
 {
@@ -323,7 +303,7 @@ struct HostIndex
   // position-hinted pass (IndexView::refp ...)
   std::vector<uint32_t> refp, filt[2];
   std::vector<uint2_t> pos_flags, tail_info;
-  uint32_t hint_first = 0, n_hint = 0, filt_log2 = 0, filt1_log2 = 0;
+  uint32_t hint_first = 0, n_hint = 0, filt_log2 = 0;
   std::vector<HintWindow> win;
   std::vector<uint32_t> site_win;
   uint32_t win_base = 0;

@@ -609,7 +609,6 @@ IndexView HostIndex::view(uint32_t max_index_labels, uint32_t half_bucket_cap) c
   ix.hint_first = hint_first;
   ix.n_hint = n_hint;
   ix.filt_log2 = filt_log2;
-  ix.filt1_log2 = filt1_log2;
   ix.win = win.data();
   ix.site_win = site_win.data();
   ix.win_base = win_base;
@@ -715,7 +714,6 @@ static void build_hints(HostGraph const & g, HostIndex & out)
   out.hint_first = gt.hint_first;
   out.n_hint = gt.n;
   out.filt_log2 = 0;
-  out.filt1_log2 = 0;
   if (gt.n == 0)
   {
     out.refp.assign(32, 0);
@@ -839,24 +837,16 @@ static void build_hints(HostGraph const & g, HostIndex & out)
   uint32_t fl = 5;
   while ((1ull << fl) < nk + 1 && fl < 28)
     ++fl;
-  uint32_t const fl1 = hint_filter_first_log2(fl); // (the first level behind the large filter's words: IndexView::filt)
   out.filt_log2 = fl;
-  out.filt1_log2 = fl1;
-  out.filt[0].assign(hint_filter_words(fl, fl1), 0);
-  out.filt[1].assign(hint_filter_words(fl, fl1), 0);
+  out.filt[0].assign(1ull << fl, 0);
+  out.filt[1].assign(1ull << fl, 0);
   for (std::size_t k = 0; k < nk; ++k)
     for (uint32_t side = 0; side < 2; ++side)
     {
-      uint32_t w0, w1, h, h2, word, mask;
+      uint32_t w0, w1, word, mask;
       hint_half_planes(static_cast<uint32_t>(side == 0 ? out.keys[k] >> 32 : out.keys[k]), w0, w1);
-      hint_filter_hash(w0, w1, h, h2);
-      hint_filter_slot_of(h, h2, fl, word, mask);
+      hint_filter_slot(w0, w1, fl, word, mask);
       out.filt[side][word] |= mask;
-      if (fl1)
-      {
-        hint_filter_slot1_of(h, h2, fl, fl1, word, mask);
-        out.filt[side][word] |= mask;
-      }
     }
   // per position
   GraphView const gv = g.view();

@@ -283,7 +283,7 @@ __global__ void k_half_tables(uint64_t const * pk, uint32_t const * key_off, uin
   }
 }
 
-__global__ void k_judge_keys(HintKeys t, uint32_t * nb, uint8_t * nb_same, uint32_t * filt0, uint32_t * filt1, uint32_t filt_log2, uint32_t first_log2,
+__global__ void k_judge_keys(HintKeys t, uint32_t * nb, uint8_t * nb_same, uint32_t * filt0, uint32_t * filt1, uint32_t filt_log2,
                              uint64_t const * pk, IndexSlot * slots, uint32_t log2_cap)
 {
   uint32_t const k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -313,16 +313,10 @@ __global__ void k_judge_keys(HintKeys t, uint32_t * nb, uint8_t * nb_same, uint3
   }
   for (uint32_t side = 0; side < 2; ++side)
   {
-    uint32_t w0, w1, h, h2, word, mask;
+    uint32_t w0, w1, word, mask;
     hint_half_planes(static_cast<uint32_t>(side == 0 ? t.keys[k] >> 32 : t.keys[k]), w0, w1);
-    hint_filter_hash(w0, w1, h, h2);
-    hint_filter_slot_of(h, h2, filt_log2, word, mask);
+    hint_filter_slot(w0, w1, filt_log2, word, mask);
     atomicOr((side == 0 ? filt0 : filt1) + word, mask);
-    if (first_log2) // (the first level, behind the large filter's words)
-    {
-      hint_filter_slot1_of(h, h2, filt_log2, first_log2, word, mask);
-      atomicOr((side == 0 ? filt0 : filt1) + word, mask);
-    }
   }
 }
 
@@ -701,8 +695,7 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<Em
   uint32_t const hint_first = R ? c.graph.ref_order[0] - 1 : 0; // order = 1-based contig position
   uint32_t const hint_n = (R == 0 || R - 1 >= HINT_NO_SITE) ? 0u : c.graph.ref_order[R - 1] + c.graph.ref_len[R - 1] - c.graph.ref_order[0];
   bool const hints = hint_n != 0;
-  uint32_t const fl1 = hints ? hint_filter_first_log2(fl) : 0u;
-  uint32_t *d_f0 = pool.get<uint32_t>(hints ? hint_filter_words(fl, fl1) : 1, "filter 0", true), *d_f1 = pool.get<uint32_t>(hints ? hint_filter_words(fl, fl1) : 1, "filter 1", true);
+  uint32_t *d_f0 = pool.get<uint32_t>(hints ? (1ull << fl) : 1, "filter 0", true), *d_f1 = pool.get<uint32_t>(hints ? (1ull << fl) : 1, "filter 1", true);
   // (the allele windows continue the per-position tables behind win_base: gtx_flat.hpp)
   std::vector<HintWindow> win;
   std::vector<uint32_t> site_win;
@@ -733,7 +726,7 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<Em
     if (n_keys)
     {
       char const * nbk = std::getenv("GTX_NB_KNOWN"); // test switch: 0 = no slot gets SLOT_NB_KNOWN
-      hipLaunchKernelGGL(k_judge_keys, dim3(blocks_for(n_keys)), dim3(TB), 0, nullptr, t, d_nb, d_same, d_f0, d_f1, fl, fl1, d_pk,
+      hipLaunchKernelGGL(k_judge_keys, dim3(blocks_for(n_keys)), dim3(TB), 0, nullptr, t, d_nb, d_same, d_f0, d_f1, fl, d_pk,
                          (nbk && nbk[0] == '0') ? static_cast<IndexSlot *>(nullptr) : d_slots, log2_cap);
     }
     hipLaunchKernelGGL(k_position_flags, dim3(blocks_for(hint_n)), dim3(TB), 0, nullptr, c.dev_graph, t, d_nb, d_same, d_base, d_room, d_back, hint_n, d_flags);
@@ -765,7 +758,6 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<Em
   ix.hint_first = hint_first;
   ix.n_hint = hint_n;
   ix.filt_log2 = hints ? fl : 0;
-  ix.filt1_log2 = fl1;
   ix.win = n_win ? pool.keep(d_win, c.dev_allocs) : nullptr;
   ix.site_win = n_win ? pool.keep(d_site_win, c.dev_allocs) : nullptr;
   ix.win_base = win_base;
@@ -812,7 +804,7 @@ int download_index(gtx_ctx & c)
 int download_hint_table(gtx_ctx const & c, int which, void * out, uint64_t cap_bytes, uint64_t * bytes)
 {
   IndexView const & ix = c.dev_index;
-  uint64_t const filt_words = ix.n_hint ? hint_filter_words(ix.filt_log2, ix.filt1_log2) : 1;
+  uint64_t const filt_words = ix.n_hint ? (1ull << ix.filt_log2) : 1;
   void const * src = nullptr;
   uint64_t n = 0;
   switch (which)

@@ -557,32 +557,6 @@ GTX_DEV void hint_probe_slot(IndexView const & ix, uint32_t verdict, Row row, ui
   }
 }
 
-// The first level of the filters (gtx_flat.hpp: IndexView::filt): the same question asked of a table small enough to stay in the
-// L2 -- where to look ...
-template <uint32_t I, uint32_t SIDE, class Row>
-GTX_DEV void hint_probe_slot1(IndexView const & ix, uint32_t verdict, Row row, uint32_t & word, uint32_t & mask)
-{
-  word = 0;
-  mask = 0;
-  if (verdict & (SIDE == 0 ? HK_NEED_LEFT : HK_NEED_RIGHT))
-  {
-    uint32_t w0, w1, h, h2;
-    plane_extract16<(K - 1) * I + 16 * SIDE>(row, w0, w1);
-    hint_filter_hash(w0, w1, h, h2);
-    hint_filter_slot1_of(h, h2, ix.filt_log2, ix.filt1_log2, word, mask);
-  }
-}
-
-// ... and what its words say: a half it does not know occurs in no indexed key, and the large filter need not be asked about it
-GTX_DEV uint32_t hint_probe_first(uint32_t verdict, uint32_t left_word, uint32_t left_mask, uint32_t right_word, uint32_t right_mask)
-{
-  if ((verdict & HK_NEED_LEFT) && (left_word & left_mask) != left_mask)
-    verdict &= ~HK_NEED_LEFT;
-  if ((verdict & HK_NEED_RIGHT) && (right_word & right_mask) != right_mask)
-    verdict &= ~HK_NEED_RIGHT;
-  return verdict;
-}
-
 // ... and what the looked-up filter words say: the verdict stands, or the k-mer is declined
 GTX_DEV uint32_t hint_probe_verdict(uint32_t verdict, uint32_t left_word, uint32_t left_mask, uint32_t right_word, uint32_t right_mask)
 {
@@ -801,30 +775,6 @@ GTX_DEV uint32_t hinted_on_path(GraphView const & g, IndexView const & ix, Row r
   if ((k0 & 3u) == HINT_K_DECLINE || (k1 & 3u) == HINT_K_DECLINE || (k2 & 3u) == HINT_K_DECLINE || (k3 & 3u) == HINT_K_DECLINE ||
       (k4 & 3u) == HINT_K_DECLINE)
     return false;
-  if (ix.filt1_log2 != 0 && ((k0 | k1 | k2 | k3 | k4) & (HK_NEED_LEFT | HK_NEED_RIGHT)))
-  {
-    // ---- the first level of the filters, all k-mers together: one round trip, into the L2
-    uint32_t wl0, ml0, wr0, mr0, wl1, ml1, wr1, mr1, wl2, ml2, wr2, mr2, wl3, ml3, wr3, mr3, wl4, ml4, wr4, mr4;
-    hint_probe_slot1<0, 0>(ix, k0, row, wl0, ml0);
-    hint_probe_slot1<0, 1>(ix, k0, row, wr0, mr0);
-    hint_probe_slot1<1, 0>(ix, k1, row, wl1, ml1);
-    hint_probe_slot1<1, 1>(ix, k1, row, wr1, mr1);
-    hint_probe_slot1<2, 0>(ix, k2, row, wl2, ml2);
-    hint_probe_slot1<2, 1>(ix, k2, row, wr2, mr2);
-    hint_probe_slot1<3, 0>(ix, k3, row, wl3, ml3);
-    hint_probe_slot1<3, 1>(ix, k3, row, wr3, mr3);
-    hint_probe_slot1<4, 0>(ix, k4, row, wl4, ml4);
-    hint_probe_slot1<4, 1>(ix, k4, row, wr4, mr4);
-    uint32_t const * fl = ix.filt[0];
-    uint32_t const * fr = ix.filt[1];
-    uint32_t const xl0 = fl[wl0], xr0 = fr[wr0], xl1 = fl[wl1], xr1 = fr[wr1], xl2 = fl[wl2], xr2 = fr[wr2], xl3 = fl[wl3], xr3 = fr[wr3],
-                   xl4 = fl[wl4], xr4 = fr[wr4];
-    k0 = hint_probe_first(k0, xl0, ml0, xr0, mr0);
-    k1 = hint_probe_first(k1, xl1, ml1, xr1, mr1);
-    k2 = hint_probe_first(k2, xl2, ml2, xr2, mr2);
-    k3 = hint_probe_first(k3, xl3, ml3, xr3, mr3);
-    k4 = hint_probe_first(k4, xl4, ml4, xr4, mr4);
-  }
   if ((k0 | k1 | k2 | k3 | k4) & (HK_NEED_LEFT | HK_NEED_RIGHT))
   {
     // ---- the filter probes of all k-mers together: one round trip

@@ -46,12 +46,14 @@ struct Geno // one GenotypePaths as seen by the scorer
   bool wide;        // GTX_REC_WIDE: allele sets of GTX_WIDE_MASK_WORDS words
 };
 
-GTX_DEV Geno geno_of(uint32_t const * records, uint32_t rec_words, uint32_t const * big_records, uint32_t align_index,
-                     uint32_t orient)
+template <class Acc>
+GTX_DEV Geno geno_of(uint32_t const * records, uint32_t rec_words, Acc const & acc, uint32_t align_index, uint32_t orient)
 {
   Geno g;
   g.rec = records + (static_cast<uint64_t>(align_index) * 2 + orient) * rec_words;
-  g.body = ((g.rec[0] >> 16) & GTX_ST_EXTERNAL) ? big_records + g.rec[2] : g.rec + 2;
+  if (orient == 0 && acc.compact && (acc.compact_flags[2ull * align_index] & GTX_TASK_COMPACT))
+    g.rec = acc.compact + static_cast<uint64_t>(align_index) * GTX_COMPACT_WORDS; // (a record of at most that many words: never external)
+  g.body = ((g.rec[0] >> 16) & GTX_ST_EXTERNAL) ? acc.big_records + g.rec[2] : g.rec + 2;
   g.n_paths = g.rec[0] & 0xFFFFu;
   g.longest = g.rec[1] & 0xFFFFu;
   g.read_len = (g.rec[1] >> 16) & 0x3FFFu;
@@ -285,6 +287,10 @@ struct ScoreAcc // device pointers, see gtx_score_buffers in include/gtx.h
   uint32_t * conn_count;
   uint32_t * conn_near; // NULL: every connection is logged
   uint32_t const * big_records; // the context's arena for records longer than rec_words
+  // dense records of the position-hinted pass (gtx_align_batch_planes_compact): GTX_COMPACT_WORDS words per read; a task whose
+  // byte of the side array carries GTX_TASK_COMPACT has its record there, not in its slot
+  uint32_t const * compact = nullptr;
+  uint8_t const * compact_flags = nullptr;
   uint32_t * ref_depth = nullptr; // SV calling: [n_samples][ref_depth_len + 1] difference array of ReferenceDepth (NULL: not kept)
   uint32_t ref_depth_len = 0;
   // replay mode (gtx_scores_replay): nothing is added to the accumulators; instead every explain_to_score call on a marked
@@ -686,8 +692,8 @@ GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_
     // update_unpaired_read_paths (alignment.cpp:365-455).  clipped_count() returns 0/1, so IS_CLIPPED is never set.
     gtx_rec_meta const & m = it.first;
     uint32_t const mflag = m.flag & 0x7FFFu; // (without GTX_FLAG_FORWARD_ONLY)
-    Geno fwd = geno_of(records, rec_words, acc.big_records, m.align_index, 0);
-    Geno rev = (m.flag & GTX_FLAG_FORWARD_ONLY) ? empty_orientation(fwd) : geno_of(records, rec_words, acc.big_records, m.align_index, 1);
+    Geno fwd = geno_of(records, rec_words, acc, m.align_index, 0);
+    Geno rev = (m.flag & GTX_FLAG_FORWARD_ONLY) ? empty_orientation(fwd) : geno_of(records, rec_words, acc, m.align_index, 1);
     if (!fwd.has_var && !rev.has_var)
       return true; // whichever orientation wins, it touches no variant site: nothing to add
     int const which = compare_single(fwd, rev);
@@ -720,8 +726,8 @@ GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_
     Geno & f = q[2 * r];
     Geno & v = q[2 * r + 1];
     uint32_t const mflag = m.flag & 0x7FFFu; // (without GTX_FLAG_FORWARD_ONLY)
-    f = geno_of(records, rec_words, acc.big_records, m.align_index, 0);
-    v = (m.flag & GTX_FLAG_FORWARD_ONLY) ? empty_orientation(f) : geno_of(records, rec_words, acc.big_records, m.align_index, 1);
+    f = geno_of(records, rec_words, acc, m.align_index, 0);
+    v = (m.flag & GTX_FLAG_FORWARD_ONLY) ? empty_orientation(f) : geno_of(records, rec_words, acc, m.align_index, 1);
     f.flags = (mflag & ~static_cast<uint32_t>(F_PROPER_PAIR)) & 0xFFFFu;
     if (m.mapq < 25)
       f.flags |= F_MAPQ_BAD;

@@ -21,7 +21,7 @@ ST_ERROR_MASK = 15
 # names every build of libgtx.so must export (checked by tests/test_abi.py against include/gtx.h)
 EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy", "gtx_ctx_special_positions",
            "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_ctx_near_pairs", "gtx_index_stats", "gtx_index_get", "gtx_index_dump", "gtx_ctx_hint_table",
-           "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_exact_pass_tasks", "gtx_graph_sv_table", "gtx_ctx_pass_times", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_ctx_profile_log", "gtx_records_failed", "gtx_vcf_sites", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
+           "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_exact_pass_tasks", "gtx_graph_sv_table", "gtx_ctx_pass_times", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_ctx_profile_log", "gtx_records_failed", "gtx_vcf_sites", "gtx_align_batch_planes_compact", "gtx_score_batch_compact", "gtx_scores_replay_compact", "gtx_scores_replay_log", "gtx_scores_replay_apply", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_set_coverage", "gtx_stream_finish", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
            "gtx_graph_destroy",
            "gtx_scores_alloc", "gtx_scores_zero", "gtx_scores_free", "gtx_scores_reduce", "gtx_comm_unique_id", "gtx_comm_init_rank",
@@ -149,6 +149,15 @@ def lib():
         L.gtx_ctx_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.gtx_ctx_error_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.gtx_ctx_profile.argtypes = [C.c_void_p, C.c_void_p]
+        L.gtx_align_batch_planes_compact.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gtx_score_batch_compact.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                              C.POINTER(ScoreBuffers), C.c_void_p]
+        L.gtx_scores_replay_compact.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                C.POINTER(ScoreBuffers), C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.gtx_scores_replay_log.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(ScoreBuffers),
+                                            C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.gtx_scores_replay_apply.argtypes = [C.c_void_p, C.POINTER(ScoreBuffers), C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
         L.gtx_records_failed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
         L.gtx_ctx_profile_log.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.gtx_scores_finalize.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -795,6 +804,24 @@ class Stream:
 
 
 REC_WIDE, WIDE_MASK_WORDS = 0x40000000, 80  # include/gtx.h: GTX_REC_WIDE, GTX_WIDE_MASK_WORDS
+
+
+TASK_HAS_VARIANTS, TASK_COMPACT, COMPACT_WORDS = 1, 2, 8
+REPLAY_ENTRY = np.dtype([("item", np.uint32), ("cell", np.uint32), ("order_eps", np.uint32), ("mask_lo", np.uint32), ("mask_hi", np.uint32), ("pad", np.uint32)])
+
+
+def merge_compact(records, compact, task_flags, n_reads, rec_words):
+    """the records of gtx_align_batch_planes_compact as gtx_align_batch would have left them: a task whose byte of the side array
+    carries GTX_TASK_COMPACT has its record in `compact` (8 words per read) and an untouched slot -> a copy with those records in
+    their slots (host arrays; what parse_records and the tests' comparisons read)"""
+    out = np.array(records, np.uint32).reshape(n_reads * 2, rec_words)
+    comp = np.asarray(compact, np.uint32).reshape(-1, COMPACT_WORDS)[:n_reads]
+    fl = np.asarray(task_flags, np.uint8).reshape(-1)[:2 * n_reads]
+    which = np.nonzero(fl[0::2] & TASK_COMPACT)[0]
+    assert not (fl[1::2] & TASK_COMPACT).any(), "only forward records are compact"
+    out[2 * which, :COMPACT_WORDS] = comp[which]
+    out[2 * which, COMPACT_WORDS:] = 0
+    return out.reshape(-1)
 
 
 def parse_records(words, n_reads, rec_words, hap_order, big_records=None):

@@ -342,6 +342,21 @@ int gtx_align_batch_planes(gtx_ctx *, const uint8_t * d_planes, uint32_t plane_s
 int gtx_align_batch_planes_staged(gtx_ctx *, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
                                   uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream, void * front_event,
                                   void * tail_stream, void * done_event);
+/* The same with DENSE RECORDS for what the position-hinted pass finishes.  That pass writes a record of 24 bytes for nearly
+ * every read, into slots that lie 2 * rec_words words apart: a 64-byte piece of a line per read for 24 bytes of content, two
+ * thirds of what the pass writes (rocprof WRITE_SIZE: 66 bytes per read).  d_compact (16-byte aligned, GTX_COMPACT_WORDS words
+ * per read, indexed like d_meta) receives the forward records that fit -- no path or one path without a variant site: every
+ * read that adds nothing to the accumulators -- side by side, two store instructions per wavefront over whole lines, and the
+ * task's byte of d_task_flags (required) carries GTX_TASK_COMPACT: the record is d_compact[GTX_COMPACT_WORDS * read ...], the
+ * task's slot in d_records is NOT written (it keeps what the caller left there).  Records with variant sites or several
+ * paths, everything the later passes finish, reverse orientations: in their slots as before, flag clear.  The words of
+ * d_compact that belong to other reads are written too (whole lines leave the chip; their content means nothing).
+ * Readers: gtx_score_batch_compact; a host that parses records looks at the flag first (graphtyper_amd/lib.py: parse_records). */
+#define GTX_TASK_COMPACT 2u
+#define GTX_COMPACT_WORDS 8u
+int gtx_align_batch_planes_compact(gtx_ctx *, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
+                                   uint32_t * d_records, uint32_t rec_words, uint32_t * d_compact, uint8_t * d_task_flags, void * stream,
+                                   void * front_event, void * tail_stream, void * done_event);
 
 /* Score accumulators (all uint32 / uint64, zero-initialised by the caller; sample-major):
  *   d_log_score [n_samples * total_tri]      HapSample::log_score
@@ -395,6 +410,10 @@ int gtx_score_batch_flags(gtx_ctx *, const gtx_score_item * d_items, uint32_t n_
 int gtx_item_words(const gtx_score_item * items, uint32_t n_items, uint32_t * words);
 int gtx_score_batch_words(gtx_ctx *, const gtx_score_item * d_items, const uint32_t * d_item_words, uint32_t n_items, const uint32_t * d_records,
                           uint32_t rec_words, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream);
+/* ... over the records of gtx_align_batch_planes_compact: d_compact and d_task_flags as that call filled them (d_item_words may
+ * be NULL: the stage then reads the items); same results */
+int gtx_score_batch_compact(gtx_ctx *, const gtx_score_item * d_items, const uint32_t * d_item_words, uint32_t n_items, const uint32_t * d_records,
+                            uint32_t rec_words, const uint32_t * d_compact, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream);
 
 /* number of score items the kernel refused so far because one read touched more variant sites than its table holds
  * (must be 0 for the accumulators to be complete) */
@@ -579,6 +598,32 @@ int gtx_comm_destroy(void * comm);
  * with `stream`. */
 int gtx_scores_replay(gtx_ctx *, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records, uint32_t rec_words,
                       const gtx_score_buffers * acc, void * stream, uint64_t * n_replayed, uint64_t * n_unsupported);
+/* ... over the records of gtx_align_batch_planes_compact (a pair's mate without a variant site has its record there) */
+int gtx_scores_replay_compact(gtx_ctx *, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records, uint32_t rec_words,
+                              const uint32_t * d_compact, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream,
+                              uint64_t * n_replayed, uint64_t * n_unsupported);
+
+/* The same for reads sharded over several GPUs ("detect the overflow case and replay that (haplotype, sample)
+ * sequentially").  After gtx_scores_reduce every rank's block holds the sums over all ranks, so every rank finds the same cells
+ * at the guard.  gtx_scores_replay_log: this rank's items once more against that block -- the explain_to_score calls on those
+ * cells, `item` = item_base + the item's index (item_base: where this rank's items stand in the region's sequence, i.e. the
+ * reference's call order over all ranks); *n entries into `out` (GTX_ERR_CAPACITY with *n = the number wanted when cap is too
+ * small); d_compact / d_task_flags: NULL, or the dense records of gtx_align_batch_planes_compact.  The hosts exchange the logs
+ * (they are plain data: an all-gather of bytes), and gtx_scores_replay_apply -- on the rank(s) that go on to gtx_calls_batch --
+ * replays the entries of ALL ranks in call order and stores the exact rows into its block, as gtx_scores_replay does for one
+ * process.  Both synchronise with `stream`. */
+typedef struct gtx_replay_entry
+{
+  uint32_t item, cell;       /* place in the region's item sequence; sample * n_hap + haplotype */
+  uint32_t order_eps;        /* epsilon | which read of the item << 8 */
+  uint32_t mask_lo, mask_hi; /* the alleles the read explains */
+  uint32_t pad;
+} gtx_replay_entry;
+int gtx_scores_replay_log(gtx_ctx *, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records, uint32_t rec_words,
+                          const uint32_t * d_compact, const uint8_t * d_task_flags, const gtx_score_buffers * acc, uint32_t item_base, void * stream,
+                          gtx_replay_entry * out, uint64_t cap, uint64_t * n, uint64_t * n_unsupported);
+int gtx_scores_replay_apply(gtx_ctx *, const gtx_score_buffers * acc, const gtx_replay_entry * entries, uint64_t n_entries, void * stream,
+                            uint64_t * n_replayed);
 
 /* Host-side clamp of downloaded accumulators to the reference's stored types (haplotype.cpp:19-44: u8 -> 255,
  * u16 -> 0xFFFF).  Returns the number of (haplotype,sample) cells whose max_log_score reached the sequential

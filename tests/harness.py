@@ -148,6 +148,25 @@ class GpuBackend:
         n = len(meta)
         d_seq, d_meta = self._dev(seq), self._dev(meta)
         d_rec = torch.zeros(max(n, 1) * 2 * rec_words, dtype=torch.int32, device="cuda:0")
+        self.compact = None
+        if os.environ.get("HARNESS_COMPACT") == "1" and n and seq.shape[1] <= 128:
+            # the dense records of the position-hinted pass (gtx_align_batch_planes_compact): the plane rows are made on the device, the
+            # records come back as gtx_align_batch would have left them (lib.merge_compact); score() reads them where they are
+            stride = (seq.shape[1] + 15) // 16 * 16
+            d_planes = torch.zeros(n * stride, dtype=torch.uint8, device="cuda:0")
+            gtx.check(gtx.lib().gtx_reads_to_planes(self.ctx.h, d_seq.data_ptr(), seq.shape[1], n, d_planes.data_ptr(), stride, None))
+            d_comp = torch.full((n * gtx.COMPACT_WORDS,), -1, dtype=torch.int32, device="cuda:0")
+            d_fl = torch.zeros(2 * n, dtype=torch.uint8, device="cuda:0")
+            gtx.check(gtx.lib().gtx_align_batch_planes_compact(self.ctx.h, d_planes.data_ptr(), stride, d_meta.data_ptr(), n, d_rec.data_ptr(), rec_words,
+                                                               d_comp.data_ptr(), d_fl.data_ptr(), None, None, None, None))
+            torch.cuda.synchronize()
+            raw, comp, fl = d_rec.cpu().numpy().view(np.uint32), d_comp.cpu().numpy().view(np.uint32), d_fl.cpu().numpy()
+            compact_tasks = np.nonzero(fl[0::2] & gtx.TASK_COMPACT)[0]
+            assert not raw.reshape(2 * n, rec_words)[2 * compact_tasks].any(), "a compact record's slot was written"
+            merged = gtx.merge_compact(raw, comp, fl, n, rec_words)
+            self.compact = dict(merged=merged, raw=raw.copy(), comp=comp, fl=fl, n=n, share=len(compact_tasks) / n)
+            self.d_rec = d_rec
+            return merged
         gtx.check(gtx.lib().gtx_align_batch(self.ctx.h, d_seq.data_ptr(), seq.shape[1], d_meta.data_ptr(), n, d_rec.data_ptr(),
                                             rec_words, None))
         torch.cuda.synchronize()
@@ -172,11 +191,17 @@ class GpuBackend:
         items = np.ascontiguousarray(items, gtx.SCORE_ITEM)
         acc = Accumulators(self.ctx, n_samples, near=near)
         d_items = self._dev(items)
-        d_rec = self._dev(np.ascontiguousarray(records, np.uint32))
         devs = [self._dev(a) for a in acc.arrays()]
         buf = acc.buffers([d.data_ptr() for d in devs])
-        gtx.check(gtx.lib().gtx_score_batch(self.ctx.h, d_items.data_ptr(), len(items), d_rec.data_ptr(), rec_words, C.byref(buf),
-                                            None))
+        cp = getattr(self, "compact", None)
+        if cp is not None and records is cp["merged"]:  # (the records of the compact call above: scored where the device left them)
+            d_rec, d_comp, d_fl = self._dev(cp["raw"]), self._dev(cp["comp"]), self._dev(cp["fl"])
+            gtx.check(gtx.lib().gtx_score_batch_compact(self.ctx.h, d_items.data_ptr(), None, len(items), d_rec.data_ptr(), rec_words,
+                                                        d_comp.data_ptr(), d_fl.data_ptr(), C.byref(buf), None))
+        else:
+            d_rec = self._dev(np.ascontiguousarray(records, np.uint32))
+            gtx.check(gtx.lib().gtx_score_batch(self.ctx.h, d_items.data_ptr(), len(items), d_rec.data_ptr(), rec_words, C.byref(buf),
+                                                None))
         torch.cuda.synchronize()
         assert self.ctx.error_count() == 0
         for host, dev in zip(acc.arrays(), devs):
@@ -187,12 +212,18 @@ class GpuBackend:
         torch = self.torch
         items = np.ascontiguousarray(items, gtx.SCORE_ITEM)
         d_items = self._dev(items)
-        d_rec = self._dev(np.ascontiguousarray(records, np.uint32))
         devs = [self._dev(a) for a in acc.arrays()]
         buf = acc.buffers([d.data_ptr() for d in devs])
         n, bad = C.c_uint64(), C.c_uint64()
-        gtx.check(gtx.lib().gtx_scores_replay(self.ctx.h, d_items.data_ptr(), len(items), d_rec.data_ptr(), rec_words, C.byref(buf), None,
-                                              C.byref(n), C.byref(bad)))
+        cp = getattr(self, "compact", None)
+        if cp is not None and records is cp["merged"]:
+            d_rec, d_comp, d_fl = self._dev(cp["raw"]), self._dev(cp["comp"]), self._dev(cp["fl"])
+            gtx.check(gtx.lib().gtx_scores_replay_compact(self.ctx.h, d_items.data_ptr(), len(items), d_rec.data_ptr(), rec_words, d_comp.data_ptr(),
+                                                          d_fl.data_ptr(), C.byref(buf), None, C.byref(n), C.byref(bad)))
+        else:
+            d_rec = self._dev(np.ascontiguousarray(records, np.uint32))
+            gtx.check(gtx.lib().gtx_scores_replay(self.ctx.h, d_items.data_ptr(), len(items), d_rec.data_ptr(), rec_words, C.byref(buf), None,
+                                                  C.byref(n), C.byref(bad)))
         torch.cuda.synchronize()
         assert bad.value == 0 and self.ctx.error_count() == 0
         for host, dev in zip(acc.arrays(), devs):

@@ -349,3 +349,40 @@ def test_long_reads_through_pass_0(kind, read_len):
     """reads of 161..256 bases: gtx_align_hinted_long_kernel (eight k-mers, rows of 128 bytes), records == oracle with four kinds of hints"""
     from test_long_reads import long_read_case
     long_read_case(harness.GpuBackend, kind, read_len, 6000, 0.9 if kind == "snp1k" else 0.2)
+
+
+@pytest.mark.parametrize("kind", ["snp1k", "snp100", "cfg3", "long"])
+def test_dense_records_of_pass_0(kind, monkeypatch):
+    """gtx_align_batch_planes_compact: what the position-hinted pass finishes without a variant site leaves as 32-byte records side by
+    side (d_compact, GTX_TASK_COMPACT in the side array), its slot untouched; read back as gtx_align_batch's records they are the
+    oracle's paths with four kinds of hints (harness.GpuBackend.align under HARNESS_COMPACT), all three builds of the pass"""
+    monkeypatch.setenv("HARNESS_COMPACT", "1")
+    if kind == "long":
+        from test_long_reads import long_read_case
+        long_read_case(harness.GpuBackend, "snp1k", 250, 6000, 0.9)
+        return
+    if kind == "cfg3":
+        cfg3_case(harness.GpuBackend, 6000)
+        return
+    ref, recs, codes, pos = scenarios.synthetic_case(kind, n_ref=200000, n_reads=20000, region_begin=1000000)
+    o = Oracle(ref, recs, region_begin=1000000)
+    b = harness.GpuBackend(gtx.graph_from_records(ref, recs, region_begin=1000000))
+    check_align(b, o, list(codes), pos=pos)
+    assert b.compact is not None
+    # (the last align of check_align carries foreign hints; the first one, with the right ones, is what the share is about)
+    seq, meta = gtx.pack_nibbles(codes), harness.read_meta(np.full(len(codes), 150), pos=pos)
+    b.align(seq, meta)
+    # (a SNP every 100 bases: every read carries a site, its record is not one of the dense ones)
+    assert (b.compact["share"] > 0.6) if kind == "snp1k" else (b.compact["share"] < 0.05), b.compact["share"]
+
+
+@pytest.mark.parametrize("kind", ["snp100", "snp25"])
+def test_stream_scores_over_dense_records(kind, monkeypatch):
+    """the scorer reads a mate's record where the position-hinted pass left it (gtx_score_batch_compact, gtx_scores_replay_compact):
+    pairs, duplicates, parked mates, three samples -- accumulators, calls, flags and VCF text == the oracle's"""
+    monkeypatch.setenv("HARNESS_COMPACT", "1")
+    ref, recs, codes, rec = scenarios.paired_case(kind, n_ref=100000, n_pairs=8000, region_begin=310000, n_samples=3)
+    o = Oracle(ref, recs, region_begin=310000)
+    b = harness.GpuBackend(gtx.graph_from_records(ref, recs, region_begin=310000))
+    want = run_stream(b, o, codes, rec, n_samples=3)
+    assert want.sum() > 0 and b.compact is not None
