@@ -687,10 +687,11 @@ extern "C"
     out[13] = b.more;
   }
 
-  // gtx_scores_replay over host arrays: marks the cells at the guard, logs their explain_to_score calls with the kernel
-  // source in replay mode, replays them with the library's host code (score_replay.hpp).  Returns the cells replayed.
-  long emu_score_replay(void * p, const gtx_score_item * items, uint32_t n_items, const uint32_t * records, uint32_t rec_words,
-                        const gtx_score_buffers * acc)
+  // gtx_scores_replay_log over host arrays: marks the cells at the guard of `acc` (the block summed over all ranks), logs their
+  // explain_to_score calls by `items` with the kernel source in replay mode.  Returns the number of entries (<= cap), -1 / -2 on a
+  // table or log overflow.
+  long emu_score_replay_log(void * p, const gtx_score_item * items, uint32_t n_items, const uint32_t * records, uint32_t rec_words,
+                            const gtx_score_buffers * acc, uint32_t item_base, gtx_replay_entry * out, long cap)
   {
     using namespace gtx;
     Emu & e = *static_cast<Emu *>(p);
@@ -735,9 +736,26 @@ extern "C"
       if (!score_item<WaveEmu>(g, par, items[i], records, rec_words, a, large.data(), large.data() + SCORE_MAX_HAPS_BIG, SCORE_MAX_HAPS_BIG))
         return -1;
     }
-    if (count > log.size())
+    if (count > log.size() || static_cast<long>(count) > cap)
       return -2;
-    log.resize(count);
+    static_assert(sizeof(gtx_replay_entry) == sizeof(ReplayEntry), "gtx_replay_entry is ReplayEntry");
+    for (uint32_t k = 0; k < count; ++k)
+    {
+      log[k].item += item_base;
+      std::memcpy(out + k, &log[k], sizeof(ReplayEntry));
+    }
+    return static_cast<long>(count);
+  }
+
+  // gtx_scores_replay_apply over host arrays: the entries of all ranks replayed in call order with the library's host code
+  // (score_replay.hpp), the exact rows stored into `acc`.  Returns the cells replayed.
+  long emu_score_replay_apply(void * p, const gtx_score_buffers * acc, const gtx_replay_entry * entries, long n)
+  {
+    using namespace gtx;
+    Emu & e = *static_cast<Emu *>(p);
+    std::vector<ReplayEntry> log(static_cast<size_t>(n));
+    if (n)
+      std::memcpy(log.data(), entries, static_cast<size_t>(n) * sizeof(ReplayEntry));
     std::vector<ReplayedCell> const done = replay_cells(e.graph, log);
     for (ReplayedCell const & rc : done)
     {
@@ -746,5 +764,16 @@ extern "C"
       std::copy(rc.log_score.begin(), rc.log_score.end(), acc->d_log_score + static_cast<uint64_t>(sample) * e.graph.total_tri + e.graph.tri_off[h]);
     }
     return static_cast<long>(done.size());
+  }
+
+  // gtx_scores_replay over host arrays: one process -- its own log, replayed.  Returns the cells replayed.
+  long emu_score_replay(void * p, const gtx_score_item * items, uint32_t n_items, const uint32_t * records, uint32_t rec_words,
+                        const gtx_score_buffers * acc)
+  {
+    std::vector<gtx_replay_entry> log(1u << 22);
+    long const n = emu_score_replay_log(p, items, n_items, records, rec_words, acc, 0, log.data(), static_cast<long>(log.size()));
+    if (n <= 0)
+      return n;
+    return emu_score_replay_apply(p, acc, log.data(), n);
   }
 }

@@ -118,6 +118,24 @@ class EmuBackend:
         assert n >= 0
         return int(n)
 
+    def score_replay_log(self, items, records, acc, item_base=0, rec_words=REC_WORDS):
+        """gtx_scores_replay_log on host arrays: this rank's entries (gtx.REPLAY_ENTRY) for the cells at the guard of `acc`"""
+        items = np.ascontiguousarray(items, gtx.SCORE_ITEM)
+        buf = acc.buffers([_p(a) for a in acc.arrays()])
+        out = np.zeros(1 << 20, gtx.REPLAY_ENTRY)
+        self.L.emu_score_replay_log.restype = C.c_long
+        n = self.L.emu_score_replay_log(C.c_void_p(self.h), _p(items), C.c_uint32(len(items)), _p(records), C.c_uint32(rec_words), C.byref(buf),
+                                        C.c_uint32(item_base), _p(out), C.c_long(len(out)))
+        assert n >= 0
+        return out[:n].copy()
+
+    def score_replay_apply(self, acc, entries):
+        """gtx_scores_replay_apply on the host arrays of `acc` (in place); returns the number of cells replayed"""
+        entries = np.ascontiguousarray(entries, gtx.REPLAY_ENTRY)
+        buf = acc.buffers([_p(a) for a in acc.arrays()])
+        self.L.emu_score_replay_apply.restype = C.c_long
+        return int(self.L.emu_score_replay_apply(C.c_void_p(self.h), C.byref(buf), _p(entries), C.c_long(len(entries))))
+
     def calls(self, acc, n_samples):
         """gtx_calls_batch contract on the host: (phred [n_samples * total_tri] u8, SAMPLE_CALL [n_samples * n_hap])"""
         buf = acc.buffers([_p(a) for a in acc.arrays()])
@@ -226,6 +244,30 @@ class GpuBackend:
                                                   C.byref(n), C.byref(bad)))
         torch.cuda.synchronize()
         assert bad.value == 0 and self.ctx.error_count() == 0
+        for host, dev in zip(acc.arrays(), devs):
+            host[...] = dev.cpu().numpy().view(host.dtype)
+        return int(n.value)
+
+    def score_replay_log(self, items, records, acc, item_base=0, rec_words=REC_WORDS):
+        items = np.ascontiguousarray(items, gtx.SCORE_ITEM)
+        d_items = self._dev(items)
+        d_rec = self._dev(np.ascontiguousarray(records, np.uint32))
+        devs = [self._dev(a) for a in acc.arrays()]
+        buf = acc.buffers([d.data_ptr() for d in devs])
+        out = np.zeros(1 << 20, gtx.REPLAY_ENTRY)
+        n, bad = C.c_uint64(), C.c_uint64()
+        gtx.check(gtx.lib().gtx_scores_replay_log(self.ctx.h, d_items.data_ptr(), len(items), d_rec.data_ptr(), rec_words, None, None, C.byref(buf),
+                                                  item_base, None, out.ctypes.data_as(C.c_void_p), len(out), C.byref(n), C.byref(bad)))
+        assert bad.value == 0
+        return out[:n.value].copy()
+
+    def score_replay_apply(self, acc, entries):
+        entries = np.ascontiguousarray(entries, gtx.REPLAY_ENTRY)
+        devs = [self._dev(a) for a in acc.arrays()]
+        buf = acc.buffers([d.data_ptr() for d in devs])
+        n = C.c_uint64()
+        gtx.check(gtx.lib().gtx_scores_replay_apply(self.ctx.h, C.byref(buf), entries.ctypes.data_as(C.c_void_p), len(entries), None, C.byref(n)))
+        self.torch.cuda.synchronize()
         for host, dev in zip(acc.arrays(), devs):
             host[...] = dev.cpu().numpy().view(host.dtype)
         return int(n.value)

@@ -81,3 +81,50 @@ def test_two_rank_reduce_equals_single_pass(tmp_path):
     both.conn_count[0] = len(logs) // 6
     assert int(acc.conn_count[0]) == len(logs) // 6 > 0
     assert np.array_equal(harness.canonical_scores(b.ctx, acc), harness.canonical_scores(b.ctx, both))
+
+
+def _replay_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_saturation import saturation_inputs
+    ref_s, recs, rb, codes, rec = saturation_inputs()
+    b = harness.EmuBackend(gtx.graph_from_records(ref_s, recs, region_begin=rb))
+    st = gtx.Stream(b.ctx.params, 1)
+    a_seq, a_meta, items = st.push(rec, gtx.pack_nibbles(codes))
+    records = np.load(os.path.join(tmp, "records.npy"))
+    lo, hi = shard_bounds(len(items), world, rank)
+    acc = b.score(items[lo:hi], records, 2)
+    alone = int(acc.hap_u32.reshape(2, b.ctx.n_hap, 4)[0, 1, 0])
+    tensors = [torch.from_numpy(a.view(np.int64 if a.dtype == np.uint64 else np.int32)) for a in
+               (acc.log_score, acc.gt_cov, acc.hap_u32, acc.stat_u64, acc.stat_u32, acc.conn_near)]
+    reduce_scores(dist, tensors)  # (in place: acc now holds the sums, like every rank's block behind gtx_scores_reduce)
+    assert alone < 0xFFFF < int(acc.hap_u32.reshape(2, b.ctx.n_hap, 4)[0, 1, 0])
+    mine = b.score_replay_log(items[lo:hi], records, acc, item_base=lo)  # gtx_scores_replay_log
+    logs = [None] * world
+    dist.all_gather_object(logs, mine.tobytes())  # (the entries are plain data)
+    entries = np.concatenate([np.frombuffer(x, gtx.REPLAY_ENTRY) for x in logs])
+    assert b.score_replay_apply(acc, entries) == 1  # gtx_scores_replay_apply, on every rank: the same block everywhere
+    np.save(os.path.join(tmp, "replayed_%d.npy" % rank), harness.canonical_scores(b.ctx, acc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_saturation_replay(tmp_path):
+    """reads sharded over two gloo ranks drive one (haplotype, sample) past the guard of explain_to_score only in the SUM: the ranks
+    log their calls on that cell against the summed block, exchange the logs and replay them -- every rank ends with the oracle's
+    sequential result over all reads (the bit-identity caveat of the exchange step)"""
+    gtx.build()
+    from test_saturation import saturation_inputs, oracle_scores
+    ref_s, recs, rb, codes, rec = saturation_inputs()
+    want, _ = oracle_scores(ref_s, recs, rb, codes, rec)
+    b = harness.EmuBackend(gtx.graph_from_records(ref_s, recs, region_begin=rb))
+    st = gtx.Stream(b.ctx.params, 1)
+    a_seq, a_meta, items = st.push(rec, gtx.pack_nibbles(codes))
+    np.save(tmp_path / "records.npy", b.align(a_seq, a_meta))
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_replay_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = np.load(tmp_path / ("replayed_%d.npy" % r))
+        assert len(got) == len(want) and np.array_equal(got, want), r

@@ -287,6 +287,13 @@ def test_sites_with_more_than_64_alleles_on_the_device():
     assert b.ctx.n_hap > 10
 
 
+def test_saturation_guard_is_replayed_across_two_ranks_on_the_device():
+    """gtx_scores_replay_log / gtx_scores_replay_apply: the reads sharded over two ranks' worth of blocks, the guard reached only in
+    their sum, the logs of both halves replayed in stream order == the oracle over all reads"""
+    from test_saturation import two_rank_replay_case
+    two_rank_replay_case(harness.GpuBackend)
+
+
 def test_saturation_guard_is_replayed_on_the_device():
     """gtx_scores_replay: 10 500 reads of one sample over one SNP drive max_log_score past 0xFFFF; the replayed cell equals
     the oracle's sequential explain_to_score (haplotype.cpp:560)"""
