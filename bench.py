@@ -625,6 +625,18 @@ class Workload:
                                gtx.download(self.buf.d_stat_u32, np.uint32, nh + 6 * ta), self.d_phred.cpu().numpy()[:self.n_samples * ctx.total_tri], calls)
         return text, calls
 
+    def vcf_final_text(self):
+        """gtx_vcf_records_final over the results of the last step: the records of the file genotype() ends with (vcf_merge_and_break with
+        the break-down; on a SNP graph both of the reference's modes write the same)"""
+        gtx, ctx = self.gtx, self.ctx
+        self.torch.cuda.synchronize()
+        calls = self.d_calls.cpu().numpy().view(gtx.SAMPLE_CALL)[:self.n_samples * ctx.n_hap]
+        nh, ta = ctx.n_hap, ctx.total_allele
+        return ctx.vcf_records_final("chr20", self.sample_names(),
+                                     gtx.download(self.buf.d_gt_cov, np.uint32, self.n_samples * ta), gtx.download(self.buf.d_stat_u64, np.uint64, nh + 2 * ta),
+                                     gtx.download(self.buf.d_stat_u32, np.uint32, nh + 6 * ta), self.d_phred.cpu().numpy()[:self.n_samples * ctx.total_tri], calls,
+                                     no_variant_overlapping=True)
+
     def calls_checksum(self, read_set=0):
         """One more (untimed) step over resident read set `read_set`, then the SHA-256 of the VCF text gtx_vcf_records writes
         from its results -- every site's GT, AD, DP, GQ, PL and INFO statistics of every sample.  tests/test_gpu_full_size.py
@@ -633,8 +645,11 @@ class Workload:
         self.steps_done = read_set
         self.step()
         text, _ = self.vcf_text()
+        final = self.vcf_final_text()
         return {"vcf_sha256": hashlib.sha256(text).hexdigest(), "vcf_bytes": len(text), "read_set": read_set,
-                "what": "sha256 of the region's VCF records (gtx_vcf_records, column line first) after one step over read set %d" % read_set}
+                "final_vcf_sha256": hashlib.sha256(final).hexdigest(), "final_vcf_bytes": len(final), "final_vcf_records": final.count(b"\n") - 1,
+                "what": "sha256 of the region's VCF records (gtx_vcf_records, column line first) after one step over read set %d; final_*: of the "
+                        "records of the file genotype() ends with (gtx_vcf_records_final: vcf_merge_and_break with the break-down)" % read_set}
 
     def block_digest(self, lane=0):
         """SHA-256 of the packed accumulator block of `lane` (gtx_scores_alloc: [stat_u64 | the u32 sections], what

@@ -706,7 +706,8 @@ SvRecord aggregate(SvRecord const & first, SvRecord const & second)
 
 // left-alignment of a record whose alleles start with the same base (Variant::normalize, variant.cpp:1256-1315); returns how
 // far it moved.  `ref` is the region's reference from position `first` on.
-long left_align(SvRecord & r, std::string const & ref, uint32_t first)
+template <class Rec>
+long left_align(Rec & r, std::string const & ref, uint32_t first)
 {
   auto & al = r.alleles;
   if (al.size() < 2)
@@ -1259,58 +1260,90 @@ extern "C" int gtx_vcf_records(const gtx_ctx * c, const gtx_vcf_request * rq, ch
 
 namespace
 {
-int write_sites(gtx_ctx const * c, gtx_vcf_request const * rq, uint32_t h_begin, uint32_t h_end, std::string & text, std::string & error,
-                std::vector<std::vector<int8_t>> * good)
+// One variant site as the record writer sees it: a site of the graph over the caller's arrays (fill_site), or what the break-down
+// made of one (gtx_vcf_records_final: alleles, calls and read statistics of its own).
+struct Site
+{
+  uint32_t pos = 0, cnum = 0, n_tri = 0;
+  std::vector<std::pair<const char *, uint32_t>> seqs;
+  std::vector<AlleleStats> al; // the alleles' READ statistics (what the calls add is made by emit_site)
+  uint64_t hap_mapq_squared = 0;
+  uint32_t clipped_reads = 0;
+  std::vector<CallView> calls;
+  // a derived site's own storage (seqs / calls point into it)
+  std::vector<std::string> alleles;
+  std::vector<uint8_t> own_phred;
+  std::vector<uint32_t> own_cov;
+  std::vector<gtx_sample_call> own_calls;
+};
+
+void fill_site(gtx_ctx const * c, gtx_vcf_request const * rq, uint32_t h, Site & st)
 {
   gtx::HostGraph const & g = c->graph;
   uint32_t const nh = g.n_hap, ns = rq->n_samples;
+  uint32_t const cnum = g.ref_nvar[h], v0 = g.ref_first_var[h], n_tri = cnum * (cnum + 1) / 2;
+  uint64_t const aoff = g.allele_off[h], toff = g.tri_off[h];
+  st.pos = g.var_order[v0]; // Variant::Variant(Genotype): the site's position on its contig
+  st.cnum = cnum;
+  st.n_tri = n_tri;
+  st.seqs.clear();
+  for (uint32_t a = 0; a < cnum; ++a)
+    st.seqs.emplace_back(g.dna.data() + g.var_dna[v0 + a], g.var_len[v0 + a]);
+  // ---- VarStats of the haplotype
+  st.al.assign(cnum, AlleleStats());
+  st.hap_mapq_squared = rq->stat_u64[h];
+  st.clipped_reads = rq->stat_u32[h];
+  for (uint32_t a = 0; a < cnum; ++a)
+  {
+    const uint64_t * s64 = rq->stat_u64 + nh + 2 * (aoff + a);
+    const uint32_t * s32 = rq->stat_u32 + nh + 6 * (aoff + a);
+    st.al[a].clipped_bp = s64[0];
+    st.al[a].mapq_squared = s64[1];
+    st.al[a].score_diff = s32[0];
+    st.al[a].mismatches = s32[1];
+    st.al[a].r1f = s32[2];
+    st.al[a].r1r = s32[3];
+    st.al[a].r2f = s32[4];
+    st.al[a].r2r = s32[5];
+  }
+  st.calls.resize(ns);
+  for (uint32_t s = 0; s < ns; ++s)
+  {
+    CallView & cv = st.calls[s];
+    cv.phred = rq->phred + static_cast<uint64_t>(s) * g.total_tri + toff;
+    cv.cov = rq->gt_cov + static_cast<uint64_t>(s) * g.total_allele + aoff;
+    cv.c = rq->calls + static_cast<uint64_t>(s) * nh + h;
+    cv.cnum = cnum;
+    cv.n_tri = n_tri;
+  }
+}
+
+// Variant::scan_calls + generate_infos + Vcf::write_record for one site.  good (may be NULL): receives generate_infos' verdict on
+// the alternative alleles (is_good_alt, variant.cpp:1040-1070); text_too = false: nothing else is done.  region_filter: the
+// region test of Vcf::write_records.  id_suffix: what write_records puts behind the ID of a record that shares position and type
+// with the one in front of it.
+int emit_site(gtx_vcf_request const * rq, Site const & st, bool region_filter, std::string const & id_suffix, std::string & text, std::string & error,
+              std::vector<int8_t> * good, bool text_too)
+{
+  uint32_t const ns = rq->n_samples, cnum = st.cnum, n_tri = st.n_tri, pos = st.pos;
   std::string const contig = rq->contig;
-  {
-  std::vector<AlleleStats> al;
-  std::vector<std::pair<const char *, uint32_t>> seqs;
-  std::vector<CallView> calls(ns);
+  auto const & seqs = st.seqs;
+  auto const & calls = st.calls;
+  std::vector<AlleleStats> al = st.al;
+  uint64_t const hap_mapq_squared = st.hap_mapq_squared;
+  uint32_t const clipped_reads = st.clipped_reads;
+  size_t total_len = 0;
+  for (auto const & sq : seqs)
+    total_len += sq.second;
   std::vector<double> qd_alt, aa_score;
-  for (uint32_t h = h_begin; h < h_end; ++h)
   {
-    uint32_t const cnum = g.ref_nvar[h], v0 = g.ref_first_var[h], n_tri = cnum * (cnum + 1) / 2;
-    uint64_t const aoff = g.allele_off[h], toff = g.tri_off[h];
-    uint32_t const pos = g.var_order[v0]; // Variant::Variant(Genotype): the site's position on its contig
-    seqs.clear();
-    size_t total_len = 0;
-    for (uint32_t a = 0; a < cnum; ++a)
-    {
-      seqs.emplace_back(g.dna.data() + g.var_dna[v0 + a], g.var_len[v0 + a]);
-      total_len += g.var_len[v0 + a];
-    }
-    // ---- VarStats of the haplotype + Variant::scan_calls over the samples
-    al.assign(cnum, AlleleStats());
-    uint64_t const hap_mapq_squared = rq->stat_u64[h];
-    uint32_t const clipped_reads = rq->stat_u32[h];
-    for (uint32_t a = 0; a < cnum; ++a)
-    {
-      const uint64_t * s64 = rq->stat_u64 + nh + 2 * (aoff + a);
-      const uint32_t * s32 = rq->stat_u32 + nh + 6 * (aoff + a);
-      al[a].clipped_bp = s64[0];
-      al[a].mapq_squared = s64[1];
-      al[a].score_diff = s32[0];
-      al[a].mismatches = s32[1];
-      al[a].r1f = s32[2];
-      al[a].r1r = s32[3];
-      al[a].r2f = s32[4];
-      al[a].r2r = s32[5];
-    }
     uint32_t n_genotyped = 0, n_passed = 0;
     uint64_t seqdepth = 0, qual = 0;
     uint32_t het_first = 0, het_second = 0, hom_first = 0, hom_second = 0;
     long qd_total_qual = 0, qd_total_depth = 0; // Variant::get_qual_by_depth (variant.cpp:1535-1559)
     for (uint32_t s = 0; s < ns; ++s)
     {
-      CallView & cv = calls[s];
-      cv.phred = rq->phred + static_cast<uint64_t>(s) * g.total_tri + toff;
-      cv.cov = rq->gt_cov + static_cast<uint64_t>(s) * g.total_allele + aoff;
-      cv.c = rq->calls + static_cast<uint64_t>(s) * nh + h;
-      cv.cnum = cnum;
-      cv.n_tri = n_tri;
+      CallView const & cv = calls[s];
       uint32_t const g1 = cv.c->gt_first, g2 = cv.c->gt_second, amb = cv.c->ambiguous_depth;
       if (g1 >= cnum || g2 >= cnum)
       {
@@ -1384,7 +1417,7 @@ int write_sites(gtx_ctx const * c, gtx_vcf_request const * rq, uint32_t h_begin,
     {
       // generate_infos' last step (variant.cpp:1040-1070): an alternative allele nobody's reads reached is dropped, the others are
       // held to QD per allele and to their best support in any one sample -- stricter on sites of 71 / 131 alleles and more
-      std::vector<int8_t> & out = (*good)[h];
+      std::vector<int8_t> & out = *good;
       out.assign(cnum - 1, 0);
       for (uint32_t a = 1; a < cnum; ++a)
       {
@@ -1395,15 +1428,16 @@ int write_sites(gtx_ctx const * c, gtx_vcf_request const * rq, uint32_t h_begin,
         out[a - 1] = static_cast<int8_t>(q >= 1.0 && p.max_alt_support >= 2 && (cnum < 71 || (q >= 1.5 && p.max_alt_support_ratio >= 0.2)) &&
                                          (cnum < 131 || (q >= 2.0 && p.max_alt_support_ratio >= 0.225)));
       }
-      continue;
+      if (!text_too)
+        return GTX_OK;
     }
     // ---- what is skipped (vcf.cpp:775-830, 1226-1258)
-    if (pos < rq->region_begin || pos > rq->region_end)
-      continue;
+    if (region_filter && (pos < rq->region_begin || pos > rq->region_end))
+      return GTX_OK;
     if ((ns > 0 && cnum > 80) || total_len > 16000)
-      continue;
+      return GTX_OK;
     if (rq->filter_zero_qual && qual == 0)
-      continue;
+      return GTX_OK;
     // ---- INFO (Variant::generate_infos)
     Info info;
     auto list_u = [&](char const * key, auto && get, uint32_t first)
@@ -1623,6 +1657,7 @@ int write_sites(gtx_ctx const * c, gtx_vcf_request const * rq, uint32_t h_begin,
       text += rq->variant_suffix_id;
       text += ']';
     }
+    text += id_suffix;
     for (uint32_t a = 0; a < cnum; ++a)
     {
       text += a < 2 ? '\t' : ',';
@@ -1718,10 +1753,372 @@ int write_sites(gtx_ctx const * c, gtx_vcf_request const * rq, uint32_t h_begin,
     }
     text += '\n';
   }
+  return GTX_OK;
+}
+
+int write_sites(gtx_ctx const * c, gtx_vcf_request const * rq, uint32_t h_begin, uint32_t h_end, std::string & text, std::string & error,
+                std::vector<std::vector<int8_t>> * good)
+{
+  Site st;
+  for (uint32_t h = h_begin; h < h_end; ++h)
+  {
+    fill_site(c, rq, h, st);
+    int const rc = emit_site(rq, st, true, std::string(), text, error, good ? &(*good)[h] : nullptr, good == nullptr);
+    if (rc != GTX_OK)
+      return rc;
   }
   return GTX_OK;
 }
 } // namespace
+
+// ---- the final VCF of a small-variant graph: vcf_merge_and_break with the break-down (src/typer/vcf_operations.cpp:480-732 with
+// force_no_break_down = false -- the file genotype() ends with, src/utilities/genotype.cpp:577-604).
+namespace
+{
+// SampleCall::get_gt_call / get_gq (sample_call.cpp:70-131) of a call made here (what gtx_calls_batch does for the graph's own sites)
+void recall(gtx_sample_call & c, uint8_t const * phred, uint32_t cnum)
+{
+  c.gt_first = c.gt_second = 0;
+  bool found = false, seen_zero = false, two_zeros = false;
+  uint8_t next_lowest = 255;
+  uint32_t i = 0;
+  for (uint32_t y = 0; y < cnum; ++y)
+    for (uint32_t x = 0; x <= y; ++x, ++i)
+    {
+      if (phred[i] == 0)
+      {
+        if (!found)
+        {
+          c.gt_first = static_cast<uint16_t>(x);
+          c.gt_second = static_cast<uint16_t>(y);
+          found = true;
+        }
+        if (seen_zero)
+          two_zeros = true;
+        seen_zero = true;
+      }
+      else if (phred[i] < next_lowest)
+        next_lowest = phred[i];
+    }
+  c.gq = two_zeros ? 0 : next_lowest;
+}
+
+struct Broken // a site the break-down made, with its place for left_align
+{
+  Site site;
+  std::vector<std::string> & alleles;
+  uint32_t & pos;
+  explicit Broken(Site && s) : site(std::move(s)), alleles(site.alleles), pos(site.pos) {}
+  Broken(Broken && o) noexcept : site(std::move(o.site)), alleles(site.alleles), pos(site.pos) {}
+  Broken & operator=(Broken && o) noexcept
+  {
+    site = std::move(o.site);
+    return *this;
+  }
+  void rebind() // (after the alleles changed or the site moved: the writer's views of the site's own alleles and calls)
+  {
+    site.seqs.clear();
+    for (std::string const & a : site.alleles)
+      site.seqs.emplace_back(a.data(), static_cast<uint32_t>(a.size()));
+    if (!site.own_calls.empty())
+    {
+      uint32_t const ns = static_cast<uint32_t>(site.own_calls.size());
+      site.calls.resize(ns);
+      for (uint32_t s = 0; s < ns; ++s)
+      {
+        CallView & cv = site.calls[s];
+        cv.phred = site.own_phred.data() + static_cast<size_t>(s) * site.n_tri;
+        cv.cov = site.own_cov.data() + static_cast<size_t>(s) * site.cnum;
+        cv.c = &site.own_calls[s];
+        cv.cnum = site.cnum;
+        cv.n_tri = site.n_tri;
+      }
+    }
+  }
+};
+
+// break_multi_snps (variant.cpp:1996-2111): the alleles of `st` -- all of one length, as strings in `alleles` -- position by position
+void break_multi_snps(gtx_vcf_request const * rq, Site const & st, std::vector<std::string> const & alleles, uint32_t pos, std::vector<Broken> & out)
+{
+  uint32_t const ns = rq->n_samples, cnum = st.cnum;
+  std::vector<int> ac(cnum, 0);
+  for (uint32_t s = 0; s < ns; ++s)
+  {
+    ac[st.calls[s].c->gt_first]++;
+    ac[st.calls[s].c->gt_second]++;
+  }
+  for (size_t j = 0; j < alleles[0].size(); ++j)
+  {
+    std::string new_seqs(1, alleles[0][j]);
+    std::vector<uint16_t> old_to_new(1, 0);
+    for (uint32_t k = 1; k < cnum; ++k)
+    {
+      if (ac[k] == 0)
+      {
+        old_to_new.push_back(0);
+        continue;
+      }
+      size_t const at = new_seqs.find(alleles[k][j]);
+      if (at == std::string::npos)
+      {
+        old_to_new.push_back(static_cast<uint16_t>(new_seqs.size()));
+        new_seqs.push_back(alleles[k][j]);
+      }
+      else
+        old_to_new.push_back(static_cast<uint16_t>(at));
+    }
+    if (new_seqs.size() == 1)
+      continue; // no SNP at this position
+    Site nv;
+    uint32_t const n_new = static_cast<uint32_t>(new_seqs.size()), new_tri = n_new * (n_new + 1) / 2;
+    nv.pos = pos + static_cast<uint32_t>(j);
+    nv.cnum = n_new;
+    nv.n_tri = new_tri;
+    for (char ch : new_seqs)
+      nv.alleles.emplace_back(1, ch);
+    // update_per_allele_stats (variant.cpp:34-82): the read statistics of the old alleles under the new ones
+    nv.al.assign(n_new, AlleleStats());
+    nv.hap_mapq_squared = st.hap_mapq_squared;
+    nv.clipped_reads = st.clipped_reads;
+    for (uint32_t y = 0; y < cnum; ++y)
+    {
+      AlleleStats const & o = st.al[y];
+      AlleleStats & n = nv.al[old_to_new[y]];
+      n.clipped_bp += o.clipped_bp;
+      n.mapq_squared += o.mapq_squared;
+      n.score_diff += o.score_diff;
+      n.mismatches += o.mismatches;
+      n.r1f += o.r1f;
+      n.r2f += o.r2f;
+      n.r1r += o.r1r;
+      n.r2r += o.r2r;
+    }
+    nv.own_phred.assign(static_cast<size_t>(ns) * new_tri, 255u);
+    nv.own_cov.assign(static_cast<size_t>(ns) * n_new, 0u);
+    nv.own_calls.resize(ns);
+    for (uint32_t s = 0; s < ns; ++s)
+    {
+      CallView const & cv = st.calls[s];
+      uint8_t * ph = nv.own_phred.data() + static_cast<size_t>(s) * new_tri;
+      uint32_t * cov = nv.own_cov.data() + static_cast<size_t>(s) * n_new;
+      uint32_t i = 0;
+      for (uint32_t y = 0; y < cnum; ++y)
+      {
+        for (uint32_t x = 0; x <= y; ++x, ++i)
+        {
+          uint32_t ny = old_to_new[y], nx = old_to_new[x];
+          if (nx > ny)
+            std::swap(nx, ny);
+          uint32_t const ni = nx + (ny + 1) * ny / 2;
+          ph[ni] = std::min(ph[ni], cv.phred[i]);
+        }
+        uint32_t const ny = old_to_new[y];
+        cov[ny] = cov[ny] + cv.coverage(y) < 0xFFFFu ? cov[ny] + cv.coverage(y) : 0xFFFFu;
+      }
+      gtx_sample_call & nc = nv.own_calls[s];
+      nc = *cv.c; // (ambiguous depth, the total depths, the proper-pair depth: copied)
+      recall(nc, ph, n_new);
+    }
+    out.emplace_back(std::move(nv));
+  }
+}
+} // namespace
+
+extern "C" int gtx_vcf_records_final(const gtx_ctx * c, const gtx_vcf_request * rq, int no_variant_overlapping, int no_filter_bad_alts, char * out,
+                                     uint64_t cap, uint64_t * len)
+{
+  if (!c || !rq || !len || (cap && !out) || !rq->contig || !rq->gt_cov || !rq->stat_u64 || !rq->stat_u32 || !rq->phred || !rq->calls ||
+      (rq->n_samples && !rq->sample_names))
+    return GTX_ERR_ARG;
+  gtx::HostGraph const & g = c->graph;
+  if (g.is_sv_graph)
+  {
+    gtx::g_last_error = "gtx_vcf_records_final: an SV graph's calls go through gtx_vcf_records (the SV post-processing breaks nothing down)";
+    return GTX_ERR_UNSUPPORTED;
+  }
+  uint32_t const nh = g.n_hap, ns = rq->n_samples;
+  std::string text = "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO";
+  if (ns)
+  {
+    text += "\tFORMAT";
+    for (uint32_t s = 0; s < ns; ++s)
+    {
+      text += '\t';
+      text += rq->sample_names[s];
+    }
+  }
+  text += '\n';
+  // the region's reference (add_base_in_front, Variant::normalize read it through the graph: graph.cpp get_generated_reference_genome)
+  uint32_t const first_pos = g.ref_order.empty() ? 1u : g.ref_order.front();
+  std::string ref;
+  for (size_t n = 0; n < g.ref_order.size(); ++n)
+  {
+    ref.append(g.dna.data() + g.ref_dna[n], g.ref_len[n]);
+    if (g.ref_nvar[n] > 0)
+      ref.append(g.dna.data() + g.var_dna[g.ref_first_var[n]], g.var_len[g.ref_first_var[n]]);
+  }
+  std::string error;
+  std::vector<Broken> broken; // broken_vars of the reference's loop
+  auto shape = [](Site const & s) { return static_cast<int>(s.seqs[0].second > s.seqs[1].second) + 2 * static_cast<int>(s.seqs[0].second == s.seqs[1].second); };
+  auto seqs_less = [](Site const & a, Site const & b) { return a.alleles < b.alleles; };
+  // Vcf::write_records (vcf.cpp:1161-1275) over what `broken` holds, positions [lo, hi]
+  auto write_records = [&](uint32_t lo, uint32_t hi) -> int
+  {
+    if (broken.empty())
+      return GTX_OK;
+    std::vector<size_t> order(broken.size());
+    std::iota(order.begin(), order.end(), size_t(0));
+    std::sort(order.begin(), order.end(), [&](size_t i, size_t j)
+    {
+      Site const & a = broken[i].site;
+      Site const & b = broken[j].site;
+      if (a.pos != b.pos)
+        return a.pos < b.pos;
+      if (shape(a) != shape(b))
+        return shape(a) < shape(b);
+      return seqs_less(a, b); // (equal alleles: the reference prefers the record with more INFO keys -- every record here has the same)
+    });
+    long dup = -1;
+    for (size_t k = 0; k < order.size(); ++k)
+    {
+      Site const & cur = broken[order[k]].site;
+      std::string suffix;
+      if (k > 0)
+      {
+        Site const & prev = broken[order[k - 1]].site;
+        if (cur.pos > hi)
+          break;
+        if (cur.pos < lo)
+          continue;
+        if (cur.pos == prev.pos && cur.alleles == prev.alleles)
+          continue;
+        if (cur.pos == prev.pos && std::strcmp(variant_type(cur.seqs), variant_type(prev.seqs)) == 0)
+          suffix = "." + std::to_string(++dup);
+        else
+          dup = -1;
+      }
+      else if (cur.pos < lo || cur.pos > hi)
+        continue;
+      int const rc = emit_site(rq, cur, false, suffix, text, error, nullptr, true);
+      if (rc != GTX_OK)
+        return rc;
+    }
+    return GTX_OK;
+  };
+  Site st;
+  std::vector<int8_t> good;
+  std::string scratch;
+  for (uint32_t h = 0; h < nh; ++h)
+  {
+    fill_site(c, rq, h, st);
+    for (uint32_t s = 0; s < ns; ++s)
+      if (st.calls[s].c->gt_first >= st.cnum || st.calls[s].c->gt_second >= st.cnum)
+      {
+        gtx::g_last_error = "gtx_vcf_records_final: a call names an allele the site does not have";
+        return GTX_ERR_ARG;
+      }
+    // ---- break_down_variant (variant.cpp:1652-1713; no --no_decompose, no --is_all_biallelic)
+    std::vector<Broken> made;
+    std::vector<std::string> alleles;
+    for (auto const & sq : st.seqs)
+      alleles.emplace_back(sq.first, sq.second);
+    bool const all_same_size = std::all_of(alleles.begin() + 1, alleles.end(), [&](std::string const & a) { return a.size() == alleles[0].size(); });
+    if (all_same_size)
+    {
+      uint32_t pos = st.pos;
+      bool matching = true; // Variant::is_with_matching_first_bases
+      for (size_t a = 1; a < alleles.size(); ++a)
+        matching = matching && alleles[a][0] == alleles[0][0];
+      if (!matching && pos > first_pos && pos - 1 - first_pos < ref.size()) // add_base_in_front(true): the base in front, N unless A C G T
+      {
+        char b = ref[pos - 1 - first_pos];
+        if (b != 'A' && b != 'C' && b != 'G' && b != 'T')
+          b = 'N';
+        for (std::string & a : alleles)
+          if (a != "*")
+            a.insert(a.begin(), b);
+        --pos;
+      }
+      break_multi_snps(rq, st, alleles, pos, made);
+    }
+    else if (no_variant_overlapping)
+    {
+      Site whole = st; // (views into the caller's arrays stay views; the alleles become its own: left_align may change them)
+      whole.alleles = alleles;
+      made.emplace_back(std::move(whole));
+    }
+    else
+    {
+      gtx::g_last_error = "gtx_vcf_records_final: the site at " + std::to_string(st.pos) + " has alleles of different lengths: the reference breaks it "
+                          "down with paw::Skyr (variant.cpp:2113-2190), whose source its tree does not hold -- no_variant_overlapping writes such sites whole";
+      return GTX_ERR_UNSUPPORTED;
+    }
+    // ---- normalize, judge, keep (vcf_operations.cpp:622-663)
+    bool any = false;
+    for (Broken & b : made)
+    {
+      b.rebind();
+      if (left_align(b, ref, first_pos) > 200)
+        continue;
+      b.rebind();
+      good.clear();
+      scratch.clear();
+      int const rc = emit_site(rq, b.site, false, std::string(), scratch, error, &good, false);
+      if (rc != GTX_OK)
+      {
+        gtx::g_last_error = error;
+        return rc;
+      }
+      if (!no_filter_bad_alts && std::all_of(good.begin(), good.end(), [](int8_t x) { return x == 0; }))
+        continue;
+      broken.emplace_back(std::move(b));
+      broken.back().rebind();
+      any = true;
+    }
+    if (!any)
+      continue;
+    // ---- written in windows as the loop goes (:668-716)
+    long const W = 700;
+    long min_pos = broken[0].site.pos, max_pos = broken[0].site.pos;
+    for (Broken const & b : broken)
+    {
+      min_pos = std::min<long>(min_pos, b.site.pos);
+      max_pos = std::max<long>(max_pos, b.site.pos);
+    }
+    if (min_pos + 2 * W < max_pos)
+    {
+      long const reg_end = std::min<long>(rq->region_end, max_pos - W);
+      if (reg_end >= static_cast<long>(rq->region_begin))
+      {
+        int const rc = write_records(rq->region_begin, static_cast<uint32_t>(reg_end));
+        if (rc != GTX_OK)
+        {
+          gtx::g_last_error = error;
+          return rc;
+        }
+        std::vector<Broken> rest;
+        for (Broken & b : broken)
+          if (static_cast<long>(b.site.pos) > reg_end)
+            rest.emplace_back(std::move(b));
+        broken = std::move(rest);
+        for (Broken & b : broken)
+          b.rebind();
+      }
+    }
+  }
+  {
+    int const rc = write_records(rq->region_begin, rq->region_end);
+    if (rc != GTX_OK)
+    {
+      gtx::g_last_error = error;
+      return rc;
+    }
+  }
+  *len = text.size();
+  if (out && cap)
+    std::memcpy(out, text.data(), static_cast<size_t>(std::min<uint64_t>(cap, text.size())));
+  return GTX_OK;
+}
 
 // ---- the sites a genotyping iteration hands to the next one: vcf_merge_and_filter (src/typer/vcf_operations.cpp:278-478).
 // The reference reads the pools' variants back (their calls already scanned into the statistics and cleared,

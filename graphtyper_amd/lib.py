@@ -21,7 +21,7 @@ ST_ERROR_MASK = 15
 # names every build of libgtx.so must export (checked by tests/test_abi.py against include/gtx.h)
 EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy", "gtx_ctx_special_positions",
            "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_ctx_near_pairs", "gtx_index_stats", "gtx_index_get", "gtx_index_dump", "gtx_ctx_hint_table",
-           "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_exact_pass_tasks", "gtx_graph_sv_table", "gtx_ctx_pass_times", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_ctx_profile_log", "gtx_records_failed", "gtx_vcf_sites", "gtx_align_batch_planes_compact", "gtx_score_batch_compact", "gtx_scores_replay_compact", "gtx_scores_replay_log", "gtx_scores_replay_apply", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
+           "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_exact_pass_tasks", "gtx_graph_sv_table", "gtx_ctx_pass_times", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_ctx_profile_log", "gtx_records_failed", "gtx_vcf_sites", "gtx_vcf_records_final", "gtx_align_batch_planes_compact", "gtx_score_batch_compact", "gtx_scores_replay_compact", "gtx_scores_replay_log", "gtx_scores_replay_apply", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_set_coverage", "gtx_stream_finish", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
            "gtx_graph_destroy",
            "gtx_scores_alloc", "gtx_scores_zero", "gtx_scores_free", "gtx_scores_reduce", "gtx_comm_unique_id", "gtx_comm_init_rank",
@@ -167,6 +167,7 @@ def lib():
         L.gtx_ctx_near_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.gtx_ref_depth_finalize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
         L.gtx_vcf_records.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.gtx_vcf_records_final.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.gtx_vcf_sites.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.gtx_align_batch_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.gtx_disc_create.argtypes = [C.c_char_p, C.c_uint64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
@@ -710,6 +711,22 @@ class Context:
         check(lib().gtx_vcf_records(self.h, C.byref(rq), None, C.c_uint64(0), C.byref(n)))
         buf = C.create_string_buffer(int(n.value) + 1)
         check(lib().gtx_vcf_records(self.h, C.byref(rq), buf, C.c_uint64(n.value), C.byref(n)))
+        return buf.raw[:int(n.value)]
+
+    def vcf_records_final(self, contig, sample_names, gt_cov, stat_u64, stat_u32, phred, calls, region_begin=0, region_end=0xFFFFFFFF,
+                          filter_zero_qual=False, variant_suffix_id=None, no_variant_overlapping=False, no_filter_bad_alts=False):
+        """gtx_vcf_records_final: the records (column line first) of the file genotype() ends with -- vcf_merge_and_break with the
+        variants broken down"""
+        names = (C.c_char_p * max(1, len(sample_names)))(*[n.encode() for n in sample_names])
+        keep = [np.ascontiguousarray(gt_cov, np.uint32), np.ascontiguousarray(stat_u64, np.uint64), np.ascontiguousarray(stat_u32, np.uint32),
+                np.ascontiguousarray(phred, np.uint8), np.ascontiguousarray(calls, SAMPLE_CALL)]
+        rq = VcfRequest(contig.encode(), names, len(sample_names), region_begin, region_end, int(filter_zero_qual),
+                        variant_suffix_id.encode() if variant_suffix_id else None, *[C.c_void_p(a.ctypes.data) for a in keep], None, None, 0)
+        n = C.c_uint64()
+        args = (self.h, C.byref(rq), int(no_variant_overlapping), int(no_filter_bad_alts))
+        check(lib().gtx_vcf_records_final(*args, None, C.c_uint64(0), C.byref(n)))
+        buf = C.create_string_buffer(int(n.value) + 1)
+        check(lib().gtx_vcf_records_final(*args, buf, C.c_uint64(n.value), C.byref(n)))
         return buf.raw[:int(n.value)]
 
     def vcf_sites(self, contig, n_samples, gt_cov, stat_u64, stat_u32, phred, calls, ph_rows):

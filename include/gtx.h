@@ -515,6 +515,21 @@ typedef struct gtx_vcf_request
 } gtx_vcf_request;
 int gtx_vcf_records(const gtx_ctx *, const gtx_vcf_request *, char * out, uint64_t cap, uint64_t * len);
 
+/* The records of the FINAL file of a small-variant graph: replaces vcf_merge_and_break with the break-down
+ * (src/typer/vcf_operations.cpp:480-732, force_no_break_down = false; genotype() ends with it, src/utilities/genotype.cpp:577-604).
+ * Every site goes through break_down_variant (src/typer/variant.cpp:1652-1713): alleles of one length are taken apart position by
+ * position (break_multi_snps, :1996-2111 -- a base in front first when the alleles do not start alike; only alleles somebody is
+ * called with make a SNP, the calls keep the smallest PL of the genotypes that fall together, depths and read statistics are
+ * added: update_per_allele_stats, :34-82), so a site nobody carries an alternative allele of leaves no record; what comes out is
+ * normalised (Variant::normalize, :1256-1315), judged (generate_infos: a record whose every alternative allele is bad is dropped
+ * unless no_filter_bad_alts) and written by Vcf::write_records in the reference's windows.  Alleles of DIFFERENT lengths go
+ * through paw::Skyr in the reference (break_down_skyr, :2113-2190), a library its tree does not hold: with no_variant_overlapping
+ * (the reference's --no_variant_overlapping, and the second file of --normal_and_no_variant_overlapping) such a site is written
+ * whole, as the reference writes it then; without it the call returns GTX_ERR_UNSUPPORTED when the graph has such a site.
+ * Graphs of SNPs (cfg2) have none: both modes are the reference's file.  First line: the column line.  Not for SV graphs. */
+int gtx_vcf_records_final(const gtx_ctx *, const gtx_vcf_request *, int no_variant_overlapping, int no_filter_bad_alts, char * out, uint64_t cap,
+                          uint64_t * len);
+
 /* The header in front of the records: replaces Vcf::write_header (src/typer/vcf.cpp:526-760) -- ##fileformat, ##fileDate,
  * ##source, the version / branch / SHA1 lines (the reference prints its build's constants: given here), one ##contig line per
  * contig (Graph::contigs), the ##INFO / ##FORMAT / ##FILTER description lines and the column line (with FORMAT and the sample

@@ -654,6 +654,38 @@ extern "C"
     }
   }
 
+  // the final VCF of a small-variant graph (gto_sv.hpp: records_final -- vcf_merge_and_break with the break-down).  reference /
+  // first_pos: the region's reference sequence and the 1-based position of its first base.  Returns the text length, or -1.
+  long gto_vcf_records_final(void * p, char const * contig, char const * sample_names, uint32_t region_begin, uint32_t region_end,
+                             int filter_zero_qual, char const * reference, uint32_t first_pos, int no_variant_overlapping, char * out, long cap)
+  {
+    try
+    {
+      vcf::WriteOptions o;
+      o.contig = contig;
+      std::stringstream ss(sample_names ? sample_names : "");
+      std::string n;
+      while (std::getline(ss, n, '\n'))
+        if (!n.empty())
+          o.sample_names.push_back(n);
+      o.region_begin = region_begin;
+      o.region_end = region_end;
+      o.filter_zero_qual = filter_zero_qual != 0;
+      vcf::RegionReference rr;
+      rr.reference = reference ? reference : "";
+      rr.first_pos = first_pos;
+      std::string const text = vcf::records_final(*static_cast<GenoHandle *>(p)->g, o, rr, no_variant_overlapping != 0);
+      if (out && cap > 0)
+        std::memcpy(out, text.data(), static_cast<std::size_t>(std::min<long>(cap, static_cast<long>(text.size()))));
+      return static_cast<long>(text.size());
+    }
+    catch (std::exception const & e)
+    {
+      g_error = e.what();
+      return -1;
+    }
+  }
+
   // make_call_based_on_coverage of one SV over a depth track given directly (unit tests): out = coverage[0], coverage[1], PL x 3
   int gto_coverage_call(char const * sv_table, long sv_index, uint16_t const * depth, long n_depth, uint32_t reference_offset, uint32_t * out)
   {

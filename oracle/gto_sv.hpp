@@ -12,6 +12,12 @@
 //   the merge of genotype_sv            src/utilities/genotype_sv.cpp:125 -> vcf_merge_and_break(force_no_break_down = true),
 //                                       src/typer/vcf_operations.cpp:480-700: normalize -> generate_infos -> drop when every alt is bad
 //   Vcf::write_records                  src/typer/vcf.cpp:1161-1275 (order, duplicates, the ".<n>" ID suffix)
+// and, at the end of the file, the FINAL file of a small-variant graph (records_final):
+//   update_per_allele_stats             src/typer/variant.cpp:34-82
+//   break_multi_snps                    src/typer/variant.cpp:1996-2111
+//   break_down_variant                  src/typer/variant.cpp:1652-1713 (alleles of different lengths: paw::Skyr, not in the tree -- whole with
+//                                       no_variant_overlapping, std::runtime_error without)
+//   vcf_merge_and_break                 src/typer/vcf_operations.cpp:480-732 (force_no_break_down = false, one pool; the windows of :668-716)
 //
 // Parity unpinned: the reference holds no test and no golden output for this path (its own SV tests are commented out).
 // Not restated: the site that mixes SV and non-SV alleles (find_variant_sequences, variant.cpp:1880-2240) -- records() throws.
@@ -634,6 +640,236 @@ inline std::string records_sv(Genotyper const & g, WriteOptions const & o, std::
       write_record(out, curr, o, g.graph.is_sv_graph, "." + std::to_string(dup));
     }
   }
+  return out.str();
+}
+
+// ---- the final VCF of a small-variant graph: vcf_merge_and_break with the variants broken down (src/typer/vcf_operations.cpp:480-732,
+// force_no_break_down = false -- what genotype() writes as its result, src/utilities/genotype.cpp:577-604)
+
+// update_per_allele_stats (variant.cpp:34-82): the read statistics of the old alleles added up under the new ones; everything
+// scan_calls derives from the calls starts from zero again
+inline void update_per_allele_stats(std::size_t num_seqs, std::size_t new_num_seqs, std::vector<uint16_t> const & old_to_new, Variant const & var, Variant & new_var)
+{
+  if (var.stats.per_allele.empty())
+    return;
+  new_var.stats = VarStats();
+  new_var.stats.per_allele.resize(new_num_seqs);
+  new_var.stats.read_strand.resize(new_num_seqs);
+  new_var.stats.clipped_reads = var.stats.clipped_reads;
+  new_var.stats.mapq_squared = var.stats.mapq_squared;
+  for (std::size_t y = 0; y < num_seqs; ++y)
+  {
+    auto const & oa = var.stats.per_allele[y];
+    auto & na = new_var.stats.per_allele[old_to_new[y]];
+    auto const & os = var.stats.read_strand[y];
+    auto & ns = new_var.stats.read_strand[old_to_new[y]];
+    na.clipped_bp += oa.clipped_bp;
+    na.mapq_squared += oa.mapq_squared;
+    na.score_diff += oa.score_diff;
+    na.mismatches += oa.mismatches;
+    ns.r1_forward += os.r1_forward;
+    ns.r2_forward += os.r2_forward;
+    ns.r1_reverse += os.r1_reverse;
+    ns.r2_reverse += os.r2_reverse;
+  }
+}
+
+// break_multi_snps (variant.cpp:1996-2111): alleles of one length, position by position -- the bases of the alleles somebody is
+// called with make a SNP there; the calls keep the smallest PL of the old genotypes that fall together, the depths are added
+inline std::vector<Variant> break_multi_snps(Variant && var)
+{
+  uint32_t const pos = var.abs_pos;
+  auto const & seqs = var.seqs;
+  std::vector<Variant> new_vars;
+  std::vector<int> ac(seqs.size(), 0);
+  for (SampleCall const & call : var.calls)
+  {
+    auto const gt = call.get_gt_call();
+    ac[gt.first]++;
+    ac[gt.second]++;
+  }
+  for (long j = 0; j < static_cast<long>(seqs[0].size()); ++j)
+  {
+    std::vector<char> new_seqs(1, seqs[0][static_cast<std::size_t>(j)]);
+    std::vector<uint16_t> old_to_new(1, 0);
+    for (std::size_t k = 1; k < seqs.size(); ++k)
+    {
+      if (ac[k] == 0)
+      {
+        old_to_new.push_back(0);
+        continue;
+      }
+      auto find_it = std::find(new_seqs.begin(), new_seqs.end(), seqs[k][static_cast<std::size_t>(j)]);
+      if (find_it == new_seqs.end())
+      {
+        old_to_new.push_back(static_cast<uint16_t>(new_seqs.size()));
+        new_seqs.push_back(seqs[k][static_cast<std::size_t>(j)]);
+      }
+      else
+        old_to_new.push_back(static_cast<uint16_t>(std::distance(new_seqs.begin(), find_it)));
+    }
+    if (new_seqs.size() == 1)
+      continue; // no SNP at this position
+    Variant new_var;
+    for (char c : new_seqs)
+      new_var.seqs.push_back(std::string(1, c));
+    new_var.abs_pos = pos + static_cast<uint32_t>(j);
+    new_var.infos = var.infos;
+    new_var.suffix_id = var.suffix_id;
+    std::size_t const n_new = new_var.seqs.size();
+    for (SampleCall const & call : var.calls)
+    {
+      SampleCall nc;
+      nc.phred.assign(n_new * (n_new + 1) / 2, 255u);
+      nc.coverage.assign(n_new, 0u);
+      nc.ambiguous_depth = call.ambiguous_depth;
+      nc.ref_total_depth = call.ref_total_depth;
+      nc.alt_total_depth = call.alt_total_depth;
+      nc.alt_proper_pair_depth = call.alt_proper_pair_depth;
+      for (uint32_t y = 0; y < seqs.size(); ++y)
+      {
+        for (uint32_t x = 0; x <= y; ++x)
+        {
+          uint32_t new_y = old_to_new[y], new_x = old_to_new[x];
+          if (new_x > new_y)
+            std::swap(new_x, new_y);
+          long const ni = to_index(new_x, new_y);
+          nc.phred[static_cast<std::size_t>(ni)] = std::min(nc.phred[static_cast<std::size_t>(ni)], call.phred[static_cast<std::size_t>(to_index(x, y))]);
+        }
+        uint32_t const new_y = old_to_new[y];
+        if (static_cast<uint32_t>(nc.coverage[new_y]) + static_cast<uint32_t>(call.coverage[y]) < 0xFFFFul)
+          nc.coverage[new_y] = static_cast<uint16_t>(nc.coverage[new_y] + call.coverage[y]);
+        else
+          nc.coverage[new_y] = 0xFFFFu;
+      }
+      new_var.calls.push_back(std::move(nc));
+    }
+    update_per_allele_stats(seqs.size(), n_new, old_to_new, var, new_var);
+    new_vars.push_back(std::move(new_var));
+  }
+  return new_vars;
+}
+
+// break_down_variant (variant.cpp:1652-1713) without --no_decompose / --is_all_biallelic.  Alleles of different lengths go through
+// paw::Skyr in the reference (break_down_skyr, :2113-2190), whose source is not in its tree: with no_variant_overlapping -- the
+// reference's own option, and the second file of --normal_and_no_variant_overlapping -- such a site stays whole; without it this
+// restatement refuses (std::runtime_error).
+inline std::vector<Variant> break_down_variant(Variant && var, RegionReference const & rr, bool no_variant_overlapping)
+{
+  std::vector<Variant> out;
+  if (var.seqs.size() == 2 && std::any_of(var.seqs[1].begin(), var.seqs[1].end(), [](char c) { return c == '<' || c == '[' || c == ']'; }))
+  {
+    out.push_back(std::move(var));
+    return out;
+  }
+  bool const all_same_size = std::all_of(var.seqs.begin() + 1, var.seqs.end(), [&](std::string const & s) { return s.size() == var.seqs[0].size(); });
+  if (all_same_size)
+  {
+    bool matching = true; // Variant::is_with_matching_first_bases (:1338-1352)
+    for (std::size_t i = 1; i < var.seqs.size(); ++i)
+      matching = matching && var.seqs[i][0] == var.seqs[0][0];
+    if (!matching)
+      add_base_in_front(var, rr, true); // "Add N"
+    return break_multi_snps(std::move(var));
+  }
+  if (!no_variant_overlapping)
+    throw std::runtime_error("break_down_skyr (variant.cpp:2113-2190) needs paw::Skyr, which the reference's tree does not hold");
+  out.push_back(std::move(var));
+  return out;
+}
+
+// Vcf::write_records (vcf.cpp:1161-1275) over `vars`; Variant::type is '.' on every variant of these paths
+inline void write_records(std::ostream & out, std::vector<Variant> const & vars, WriteOptions const & o, uint32_t region_begin, uint32_t region_end, bool is_sv_graph)
+{
+  if (vars.empty())
+    return;
+  std::vector<long> idx(vars.size());
+  for (std::size_t i = 0; i < idx.size(); ++i)
+    idx[i] = static_cast<long>(i);
+  std::sort(idx.begin(), idx.end(), [&](long i, long j)
+  {
+    Variant const & a = vars[static_cast<std::size_t>(i)];
+    Variant const & b = vars[static_cast<std::size_t>(j)];
+    if (a.abs_pos != b.abs_pos)
+      return a.abs_pos < b.abs_pos;
+    int const a_vt = static_cast<int>(a.seqs[0].size() > a.seqs[1].size()) + 2 * static_cast<int>(a.seqs[0].size() == a.seqs[1].size());
+    int const b_vt = static_cast<int>(b.seqs[0].size() > b.seqs[1].size()) + 2 * static_cast<int>(b.seqs[0].size() == b.seqs[1].size());
+    if (a_vt != b_vt)
+      return a_vt < b_vt;
+    return a.seqs < b.seqs || (a.seqs == b.seqs && a.infos.size() > b.infos.size());
+  });
+  auto inside = [&](uint32_t pos) { return pos >= region_begin && pos <= region_end; };
+  if (inside(vars[static_cast<std::size_t>(idx[0])].abs_pos))
+    write_record(out, vars[static_cast<std::size_t>(idx[0])], o, is_sv_graph, "");
+  long dup = -1;
+  for (std::size_t i = 1; i < idx.size(); ++i)
+  {
+    Variant const & prev = vars[static_cast<std::size_t>(idx[i - 1])];
+    Variant const & curr = vars[static_cast<std::size_t>(idx[i])];
+    if (curr.abs_pos > region_end)
+      break;
+    if (curr.abs_pos < region_begin)
+      continue;
+    if (curr.abs_pos == prev.abs_pos && curr.seqs == prev.seqs)
+      continue;
+    if (!(curr.abs_pos == prev.abs_pos && curr.determine_variant_type() == prev.determine_variant_type()))
+    {
+      write_record(out, curr, o, is_sv_graph, "");
+      dup = -1;
+    }
+    else
+    {
+      ++dup;
+      write_record(out, curr, o, is_sv_graph, "." + std::to_string(dup));
+    }
+  }
+}
+
+// vcf_merge_and_break over one pool (:480-732): the pool's variants as parallel_reader_genotype_only leaves them when it writes
+// calls (hts_parallel_reader.cpp:984-1025: add_haplotype, scan_calls), broken down, normalised, judged (a variant whose every
+// alternative allele is bad is dropped, :640-652), written in windows as the loop goes (:668-716) and at its end.
+inline std::string records_final(Genotyper const & g, WriteOptions const & o, RegionReference const & rr, bool no_variant_overlapping, bool no_filter_bad_alts = false)
+{
+  std::vector<Variant> variants = haplotype_variants(g, o);
+  for (auto & v : variants)
+    v.scan_calls();
+  std::ostringstream out;
+  write_column_line(out, o);
+  std::vector<Variant> broken_vars;
+  for (auto & var : variants)
+  {
+    std::vector<Variant> new_variants = break_down_variant(std::move(var), rr, no_variant_overlapping);
+    for (auto it = new_variants.begin(); it != new_variants.end();)
+    {
+      if (normalize(*it, rr) <= 200)
+      {
+        std::vector<int8_t> const is_good_alt = it->generate_infos(g.graph.is_sv_graph);
+        if (!no_filter_bad_alts && std::all_of(is_good_alt.begin(), is_good_alt.end(), [](int8_t x) { return x == 0; }))
+          it = new_variants.erase(it);
+        else
+          ++it;
+      }
+      else
+        it = new_variants.erase(it);
+    }
+    if (new_variants.empty())
+      continue;
+    std::move(new_variants.begin(), new_variants.end(), std::back_inserter(broken_vars));
+    long const W = 700;
+    auto mm = std::minmax_element(broken_vars.begin(), broken_vars.end(), [](Variant const & a, Variant const & b) { return a.abs_pos < b.abs_pos; });
+    long const min_abs_pos = mm.first->abs_pos, max_abs_pos = mm.second->abs_pos;
+    if (min_abs_pos + 2l * W < max_abs_pos)
+    {
+      long const reg_end = std::min(static_cast<long>(o.region_end), max_abs_pos - W);
+      if (reg_end >= static_cast<long>(o.region_begin))
+      {
+        write_records(out, broken_vars, o, o.region_begin, static_cast<uint32_t>(reg_end), g.graph.is_sv_graph);
+        broken_vars.erase(std::remove_if(broken_vars.begin(), broken_vars.end(), [&](Variant const & v) { return static_cast<long>(v.abs_pos) <= reg_end; }),
+                          broken_vars.end());
+      }
+    }
+  }
+  write_records(out, broken_vars, o, o.region_begin, o.region_end, g.graph.is_sv_graph);
   return out.str();
 }
 } // namespace vcf

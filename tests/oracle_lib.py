@@ -86,6 +86,7 @@ class Oracle:
     def __init__(self, reference, records, region_begin=0, is_sv_graph=False, hq_reads=False, force_both=False,
                  max_index_labels=75, add_all_variants=False, extend_prefix=False):
         L = lib()
+        self.reference, self.region_begin = reference, region_begin  # (what the VCF writers read through the graph: normalisation)
         self.h = L.gto_new(reference.encode(), region_begin, records_text(records).encode(), int(is_sv_graph),
                            int(hq_reads), int(force_both), max_index_labels, int(add_all_variants), int(extend_prefix))
         if not self.h:
@@ -276,6 +277,20 @@ class OracleGenotyper:
         n = L.gto_vcf_records(*args, None, C.c_long(0))
         buf = C.create_string_buffer(n + 1)
         L.gto_vcf_records(*args, buf, C.c_long(n))
+        return buf.raw[:n]
+
+    def vcf_records_final(self, contig, sample_names, reference, first_pos, region_begin=0, region_end=0xFFFFFFFF, filter_zero_qual=False,
+                          no_variant_overlapping=False):
+        """oracle/gto_sv.hpp records_final(): vcf_merge_and_break with the variants broken down -- the file genotype() writes"""
+        L = lib()
+        L.gto_vcf_records_final.restype = C.c_long
+        args = (C.c_void_p(self.g), contig.encode(), "\n".join(sample_names).encode(), C.c_uint32(region_begin), C.c_uint32(region_end),
+                C.c_int(int(filter_zero_qual)), reference.encode(), C.c_uint32(first_pos), C.c_int(int(no_variant_overlapping)))
+        n = L.gto_vcf_records_final(*args, None, C.c_long(0))
+        if n < 0:
+            raise RuntimeError(L.gto_last_error().decode())
+        buf = C.create_string_buffer(n + 1)
+        L.gto_vcf_records_final(*args, buf, C.c_long(n))
         return buf.raw[:n]
 
     def vcf_sites(self, contig):

@@ -234,6 +234,26 @@ def run_stream(backend, oracle, codes, rec, n_samples, n_rg=1):
             if not kw:
                 run_stream.vcf_full = got_vcf
         run_stream.vcf = got_vcf
+        # the file genotype() ends with: vcf_merge_and_break with the variants broken down (vcf_operations.cpp:480-732).  Sites with
+        # alleles of different lengths need paw::Skyr in the reference: both sides write them whole with no_variant_overlapping and
+        # refuse without it
+        names = ["SAMP%02d" % i for i in range(n_samples)]
+        o_ = og.o
+        for nvo in (True, False):
+            try:
+                want_final = og.vcf_records_final("chrT", names, o_.reference, o_.region_begin + 1, no_variant_overlapping=nvo)
+            except RuntimeError as e:
+                assert not nvo and "Skyr" in str(e)
+                with pytest.raises(gtx.GtxError):
+                    backend.ctx.vcf_records_final("chrT", names, acc.gt_cov, acc.stat_u64, acc.stat_u32, phred, calls, no_variant_overlapping=nvo)
+                continue
+            got_final = backend.ctx.vcf_records_final("chrT", names, acc.gt_cov, acc.stat_u64, acc.stat_u32, phred, calls, no_variant_overlapping=nvo)
+            if got_final != want_final:
+                gl, wl = got_final.split(b"\n"), want_final.split(b"\n")
+                bad = [i for i in range(min(len(gl), len(wl))) if gl[i] != wl[i]]
+                raise AssertionError("final VCF (no_variant_overlapping=%s) differs (%d vs %d lines), first at line %s:\n%r\n%r" %
+                                     (nvo, len(gl), len(wl), bad[:1], gl[bad[0]][:300] if bad else b"", wl[bad[0]][:300] if bad else b""))
+            run_stream.final = got_final
         # the sites the next iteration's graph is built from: vcf_merge_and_filter (vcf_operations.cpp:278-478) with the flags above
         got_sites = backend.ctx.vcf_sites("chrT", n_samples, acc.gt_cov, acc.stat_u64, acc.stat_u32, phred, calls, ph)
         want_sites = og.vcf_sites("chrT")

@@ -239,6 +239,11 @@ def test_cfg2_every_read_against_the_oracle():
         first = [i for i in range(min(len(gl), len(wl))) if gl[i] != wl[i]][:1]
         raise AssertionError("VCF text differs (%d vs %d lines), first at line %s" % (len(gl), len(wl), first))
     assert hashlib.sha256(want_text).hexdigest() == digest["vcf_sha256"]
+    # ... and the file genotype() ends with: vcf_merge_and_break with the variants broken down (a SNP graph: no site needs paw::Skyr)
+    final = w.vcf_final_text()
+    want_final = og.vcf_records_final("chr20", w_names(1), ref_str, REGION_BEGIN + 1)
+    assert final == want_final and hashlib.sha256(final).hexdigest() == digest["final_vcf_sha256"]
+    assert 0 < final.count(b"\n") - 1 <= len(records)
     # ... and the digest committed under tests/golden (bench.py reports `matches_pinned` against it) is the ORACLE's
     import json
     pin = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg2_vcf_digest.json")))

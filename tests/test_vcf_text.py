@@ -226,3 +226,46 @@ def test_bgzf_members():
         blob = gtx.bgzf_compress(data[:70000], level=level)
         assert blob.endswith(eof) and len(blob) > len(eof)
         assert gtx.bgzf_compress(b"", level=level, with_eof=True) == eof
+
+
+def test_final_vcf_breaks_merged_snp_clusters_down():
+    """gtx_vcf_records_final on a graph whose SNPs (one every 7 bases) were merged into sites of up to 16 alleles of up to 22 bases, all
+    of one length per site: break_multi_snps (variant.cpp:1996-2111) takes them apart position by position -- the text is the oracle's
+    (compared inside run_stream, both modes: no site here needs paw::Skyr), every record is a SNP, alleles nobody is called with are
+    gone, and a site without a called alternative allele leaves no record"""
+    rb = 310000
+    ref, recs, codes, pos = scenarios.synthetic_case("snp7", n_ref=6000, n_reads=4000, region_begin=rb, seed=3)
+    g = gtx.graph_from_records(ref, recs, region_begin=rb, add_all_variants=True)
+    assert int(g["ref_nvar"].max()) >= 8 and int(g["var_len"].max()) >= 10
+    order = np.argsort(pos, kind="stable")
+    rec = scenarios.stream_records(len(codes), pos, sample=np.arange(len(codes)) % 3)[order]
+    o = Oracle(ref, recs, region_begin=rb, add_all_variants=True)
+    b = harness.EmuBackend(g)
+    run_stream(b, o, codes[order], rec, n_samples=3)
+    names, final = _parse(run_stream.final)
+    _, whole = _parse(run_stream.vcf_full)
+    assert len(final) > len(whole) and all(len(r["ref"]) == 1 and all(len(a) == 1 for a in r["alts"]) for r in final)
+    for r in final:
+        ac = [int(x) for x in r["info"]["AC"].split(",")]
+        assert all(x > 0 for x in ac) or len(ac) == 1  # (break_multi_snps keeps the alleles somebody is called with)
+        assert ref[r["pos"] - rb - 1] == r["ref"]
+    snp_positions = {p0 + 1 for p0, rf, alts, _ in recs}
+    assert {r["pos"] for r in final} <= snp_positions
+
+
+def test_final_vcf_of_a_snp_graph_is_the_called_part_of_the_records():
+    """on a graph of bi-allelic SNPs a broken-down variant is the variant itself: the final file holds exactly the records of
+    gtx_vcf_records whose alternative allele somebody is called with and generate_infos does not call bad"""
+    rb = 310000
+    ref, recs, codes, rec = scenarios.paired_case("snp100", n_ref=6000, n_pairs=2400, region_begin=rb, n_samples=4, lowq_frac=0.03)
+    o = Oracle(ref, recs, region_begin=rb)
+    b = harness.EmuBackend(gtx.graph_from_records(ref, recs, region_begin=rb))
+    run_stream(b, o, codes, rec, n_samples=4)
+    whole = run_stream.vcf_full.split(b"\n")[1:-1]
+    final = run_stream.final.split(b"\n")[1:-1]
+    assert 0 < len(final) < len(whole) and set(final) <= set(whole)
+    dropped = [l for l in whole if l not in set(final)]
+    for l in dropped:
+        f = l.decode().split("\t")
+        info = dict(kv.split("=", 1) for kv in f[7].split(";"))
+        assert info["AC"] == "0" or float(info["QDalt"]) < 1.0 or int(info["MaxAAS"]) < 2, l[:200]
