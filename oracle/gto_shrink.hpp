@@ -12,14 +12,6 @@
 // Bases stay BAM 4-bit codes (N = 15; the reference goes through IUPAC letters), qualities stay raw phred bytes (the reference
 // adds 33 and compares against 33 + x).  The iteration order of `read_first` (std::unordered_map with the hash of :321-336) is
 // taken from the same container with the same hash: equal under the same standard library.
-// Names here <- the reference's (bamshrink.cpp): counter_name <- decimal_to_read_name_string :34-61; strip_hard_clips <- removeHardClipped
-// :64-76; quals_of_20_and_more <- countHighBaseQuality :78-81; two_level_quals <- binarizeQual :83-87; both_ends_clipped / an_end_clipped
-// <- is_clipped_both_ends / is_one_end_clipped :89-99; scores_say_keep <- process_tags :102-308; make_single <- makeUnpaired :345-356;
-// matching_bases <- countMatchingBases :358-369; cigar_shorten_back / cigar_shorten_front <- resetCigarStringEnd / resetCigarStringBegin
-// :388-482; strip_soft_clips <- removeSoftClipped :484-521; strip_n_ends <- removeNsAtEnds :523-584; clip_and_shift <- findNum2Clip
-// :567-604; trim_adapters <- removeAdapters :606-665; shrink_interval <- qualityFilterSlice2 :667-1045 (single_ok / mate_ok <- its
-// filter_unpaired / filter_paired, keep_single / finish_mate <- post_process_unpaired / post_process_paired, ready <- read_set, waiting <-
-// read_first, bins <- bin_counts, bin_cap <- max_bin_sum, origin <- first_pos, counter <- read_num).
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -51,22 +43,22 @@ struct Options // bamshrink.hpp:7-27
 
 struct CigarElement
 {
-  char op;
-  uint32_t len;
+  char operation;
+  uint32_t count;
 };
 
 struct Record // seqan::BamAlignmentRecord as far as bamshrink touches it
 {
-  std::string name;
+  std::string qName;
   uint32_t flag = 0;
-  int32_t ref_id = -1, pos = -1;
-  uint8_t mapq = 0;
+  int32_t rID = -1, beginPos = -1;
+  uint8_t mapQ = 0;
   std::vector<CigarElement> cigar;
-  int32_t mate_ref_id = -1, mate_pos = -1, tlen = 0;
+  int32_t rNextId = -1, pNext = -1, tLen = 0;
   std::vector<uint8_t> seq;  // 4-bit codes, one per base
   std::vector<uint8_t> qual; // raw phred
-  std::string aux;          // raw aux bytes
-  bool operator<(Record const & b) const { return pos < b.pos; } // :312-316
+  std::string tags;          // raw aux bytes
+  bool operator<(Record const & b) const { return beginPos < b.beginPos; } // :312-316
 };
 
 inline bool flag_multiple(Record const & r) { return r.flag & 1u; }
@@ -76,72 +68,72 @@ inline bool flag_rc(Record const & r) { return r.flag & 16u; }
 inline bool flag_next_rc(Record const & r) { return r.flag & 32u; }
 
 // :34-61
-inline char digit_char(long in)
+inline char long_to_ascii(long in)
 {
   if (in >= 31)
     ++in;
   return static_cast<char>('!' + in);
 }
 
-inline std::string counter_name(long in)
+inline std::string decimal_to_read_name_string(long in)
 {
-  long const DIGITS = 93;
+  long const CHAR_SET_SIZE = 93;
   std::string str;
-  while (in >= DIGITS)
+  while (in >= CHAR_SET_SIZE)
   {
-    long const rem = in % DIGITS;
-    in = in / DIGITS;
-    str.push_back(digit_char(rem));
+    long const rem = in % CHAR_SET_SIZE;
+    in = in / CHAR_SET_SIZE;
+    str.push_back(long_to_ascii(rem));
   }
-  str.push_back(digit_char(in));
+  str.push_back(long_to_ascii(in));
   return str;
 }
 
 // :64-76
-inline void strip_hard_clips(std::vector<CigarElement> & cigar)
+inline void removeHardClipped(std::vector<CigarElement> & cigar)
 {
   long n_cigar = static_cast<long>(cigar.size());
-  if (n_cigar >= 1 && cigar[0].op == 'H')
+  if (n_cigar >= 1 && cigar[0].operation == 'H')
   {
     cigar.erase(cigar.begin());
     --n_cigar;
   }
-  if (n_cigar >= 2 && cigar[n_cigar - 1].op == 'H')
+  if (n_cigar >= 2 && cigar[n_cigar - 1].operation == 'H')
     cigar.pop_back();
 }
 
 // :78-87
-inline long quals_of_20_and_more(std::vector<uint8_t> const & qual)
+inline long countHighBaseQuality(std::vector<uint8_t> const & qual)
 {
   return std::count_if(qual.begin(), qual.end(), [](uint8_t q) { return q >= 20; });
 }
 
-inline void two_level_quals(std::vector<uint8_t> & qual)
+inline void binarizeQual(std::vector<uint8_t> & qual)
 {
   for (auto & q : qual)
     q = q >= 24 ? ('?' - 33) : (',' - 33);
 }
 
 // :89-99
-inline bool both_ends_clipped(std::vector<CigarElement> const & cigar, long const min_clip = 15)
+inline bool is_clipped_both_ends(std::vector<CigarElement> const & cigar, long const min_clip = 15)
 {
-  return cigar.size() >= 1 && cigar.front().op == 'S' && cigar.back().op == 'S' &&
-         static_cast<long>(cigar.front().len + cigar.back().len) >= min_clip;
+  return cigar.size() >= 1 && cigar.front().operation == 'S' && cigar.back().operation == 'S' &&
+         static_cast<long>(cigar.front().count + cigar.back().count) >= min_clip;
 }
 
-inline bool an_end_clipped(std::vector<CigarElement> const & cigar, long const min_clip = 0)
+inline bool is_one_end_clipped(std::vector<CigarElement> const & cigar, long const min_clip = 0)
 {
-  return cigar.size() == 0 || (cigar.front().op == 'S' && static_cast<long>(cigar.front().len) >= min_clip) ||
-         (cigar.back().op == 'S' && static_cast<long>(cigar.back().len) >= min_clip);
+  return cigar.size() == 0 || (cigar.front().operation == 'S' && static_cast<long>(cigar.front().count) >= min_clip) ||
+         (cigar.back().operation == 'S' && static_cast<long>(cigar.back().count) >= min_clip);
 }
 
-// :102-308; true: the alignment is good.  kept: RG and the AS / XS / WS fields.
-inline bool scores_say_keep(Record const & record, std::string & kept, Options const & opts)
+// :102-308; true: the alignment is good.  new_tags: RG and the AS / XS / WS fields.
+inline bool process_tags(Record const & record, std::string & new_tags, Options const & opts)
 {
   size_t i = 0;
   int64_t as = -1, xs = -1, ws = -1;
-  std::string const & aux = record.aux;
-  size_t const tags_length = aux.size();
+  std::string const & tags = record.tags;
+  size_t const tags_length = tags.size();
   while (i < tags_length)
   {
     size_t const begin_it = i;
@@ -149,24 +141,24 @@ inline bool scores_say_keep(Record const & record, std::string & kept, Options c
     i += 3;
     if (i > tags_length)
       break; // (outside the area)
-    char const type = aux[i - 1];
-    bool tag_as = false, tag_xs = false, tag_ws = false;
-    if (aux[i - 2] == 'S')
+    char const type = tags[i - 1];
+    bool is_as = false, is_xs = false, is_ws = false;
+    if (tags[i - 2] == 'S')
     {
-      if (aux[i - 3] == 'A')
-        tag_as = true;
-      else if (aux[i - 3] == 'X')
-        tag_xs = true;
-      else if (aux[i - 3] == 'W')
-        tag_ws = true;
+      if (tags[i - 3] == 'A')
+        is_as = true;
+      else if (tags[i - 3] == 'X')
+        is_xs = true;
+      else if (tags[i - 3] == 'W')
+        is_ws = true;
     }
-    auto set_score = [&](int64_t score)
+    auto set_alignment_score = [&](int64_t score)
     {
-      if (tag_as)
+      if (is_as)
         as = score;
-      else if (tag_xs)
+      else if (is_xs)
         xs = score;
-      else if (tag_ws)
+      else if (is_ws)
         ws = score;
     };
     bool outside = false;
@@ -178,8 +170,8 @@ inline bool scores_say_keep(Record const & record, std::string & kept, Options c
         outside = true;
         return;
       }
-      std::memcpy(&num, aux.data() + i, sizeof(num));
-      set_score(static_cast<int64_t>(num));
+      std::memcpy(&num, tags.data() + i, sizeof(num));
+      set_alignment_score(static_cast<int64_t>(num));
       i += sizeof(num);
       end_it = i;
     };
@@ -188,8 +180,8 @@ inline bool scores_say_keep(Record const & record, std::string & kept, Options c
     case 'A': ++i; break;
     case 'Z':
     {
-      bool const is_rg = aux[i - 3] == 'R' && aux[i - 2] == 'G';
-      while (i < tags_length && aux[i] != '\0' && aux[i] != '\n')
+      bool const is_rg = tags[i - 3] == 'R' && tags[i - 2] == 'G';
+      while (i < tags_length && tags[i] != '\0' && tags[i] != '\n')
         ++i;
       ++i;
       if (i > tags_length)
@@ -200,7 +192,7 @@ inline bool scores_say_keep(Record const & record, std::string & kept, Options c
       if (is_rg)
       {
         end_it = i;
-        kept.append(aux, begin_it, end_it - begin_it);
+        new_tags.append(tags, begin_it, end_it - begin_it);
       }
       break;
     }
@@ -223,8 +215,8 @@ inline bool scores_say_keep(Record const & record, std::string & kept, Options c
     }
     if (outside)
       break;
-    if (tag_as || tag_xs || tag_ws)
-      kept.append(aux, begin_it, end_it - begin_it);
+    if (is_as || is_xs || is_ws)
+      new_tags.append(tags, begin_it, end_it - begin_it);
   }
   if (as != -1 && ws == -1)
     ws = as;
@@ -235,10 +227,10 @@ inline bool scores_say_keep(Record const & record, std::string & kept, Options c
     long matches = 0, indels = 0;
     for (auto const & c : record.cigar)
     {
-      if (c.op == 'M')
-        matches += c.len;
-      else if (c.op == 'D' || c.op == 'I')
-        indels += c.len + 2;
+      if (c.operation == 'M')
+        matches += c.count;
+      else if (c.operation == 'D' || c.operation == 'I')
+        indels += c.count + 2;
     }
     if (std::max(ws, as) + opts.as_filter_threshold <= matches - indels)
       return false;
@@ -258,10 +250,10 @@ struct NameHash // :321-336 (the sum is formed in 32 bits: 0x9e3779b9 is an unsi
 };
 
 // :345-356
-inline void make_single(Record & record)
+inline void makeUnpaired(Record & record)
 {
-  record.mate_pos = -1;
-  record.mate_ref_id = -1;
+  record.pNext = -1;
+  record.rNextId = -1;
   record.flag &= ~8u;
   record.flag &= ~2u;
   record.flag &= ~1u;
@@ -269,92 +261,92 @@ inline void make_single(Record & record)
 }
 
 // :358-369
-inline long matching_bases(std::vector<CigarElement> const & cg)
+inline long countMatchingBases(std::vector<CigarElement> const & cigarString)
 {
   long n = 0;
-  for (auto const & c : cg)
-    if (c.op == 'M')
-      n += c.len;
+  for (auto const & c : cigarString)
+    if (c.operation == 'M')
+      n += c.count;
   return n;
 }
 
 // :388-420
-inline void cigar_shorten_back(std::vector<CigarElement> & cg, unsigned n_gone)
+inline void resetCigarStringEnd(std::vector<CigarElement> & cigarString, unsigned nRemoved)
 {
-  if (cg.empty())
+  if (cigarString.empty())
     return;
-  if (cg.back().op == 'D')
+  if (cigarString.back().operation == 'D')
   {
-    cg.pop_back();
-    if (cg.empty())
+    cigarString.pop_back();
+    if (cigarString.empty())
       return;
   }
-  auto & tail = cg.back();
-  if (tail.len > n_gone)
-    tail.len -= n_gone;
-  else if (tail.len == n_gone)
+  auto & cigar_end = cigarString.back();
+  if (cigar_end.count > nRemoved)
+    cigar_end.count -= nRemoved;
+  else if (cigar_end.count == nRemoved)
   {
-    cg.pop_back();
-    if (!cg.empty() && cg.back().op == 'D')
-      cg.pop_back();
+    cigarString.pop_back();
+    if (!cigarString.empty() && cigarString.back().operation == 'D')
+      cigarString.pop_back();
   }
   else
   {
-    unsigned const rest = n_gone - tail.len;
-    cg.pop_back();
-    cigar_shorten_back(cg, rest);
+    unsigned const nLeft = nRemoved - cigar_end.count;
+    cigarString.pop_back();
+    resetCigarStringEnd(cigarString, nLeft);
   }
 }
 
 // :423-482: the number of reference bases taken off the front
-inline unsigned cigar_shorten_front(std::vector<CigarElement> & cg, unsigned n_gone)
+inline unsigned resetCigarStringBegin(std::vector<CigarElement> & cigarString, unsigned nRemoved)
 {
-  if (cg.empty())
+  if (cigarString.empty())
     return 0;
-  unsigned ref_gone = 0;
-  if (cg[0].op == 'D')
+  unsigned removed = 0;
+  if (cigarString[0].operation == 'D')
   {
-    ref_gone = cg[0].len;
-    cg.erase(cg.begin());
-    if (cg.empty())
-      return ref_gone;
+    removed = cigarString[0].count;
+    cigarString.erase(cigarString.begin());
+    if (cigarString.empty())
+      return removed;
   }
-  if (cg[0].len > n_gone)
+  if (cigarString[0].count > nRemoved)
   {
-    cg[0].len -= n_gone;
-    if (cg[0].op == 'M')
-      ref_gone += n_gone;
+    cigarString[0].count -= nRemoved;
+    if (cigarString[0].operation == 'M')
+      removed += nRemoved;
   }
-  else if (cg[0].len == n_gone)
+  else if (cigarString[0].count == nRemoved)
   {
-    if (cg[0].op == 'M')
-      ref_gone += cg[0].len;
-    cg.erase(cg.begin());
-    if (cg.empty())
-      return ref_gone;
-    if (cg[0].op == 'D')
+    if (cigarString[0].operation == 'M')
+      removed += cigarString[0].count;
+    cigarString.erase(cigarString.begin());
+    if (cigarString.empty())
+      return removed;
+    if (cigarString[0].operation == 'D')
     {
-      ref_gone += cg[0].len;
-      cg.erase(cg.begin());
+      removed += cigarString[0].count;
+      cigarString.erase(cigarString.begin());
     }
   }
   else
   {
-    if (cg[0].op == 'M')
-      ref_gone += cg[0].len;
-    unsigned const rest = n_gone - cg[0].len;
-    cg.erase(cg.begin());
-    if (cg.empty())
-      return ref_gone;
-    return ref_gone + cigar_shorten_front(cg, rest);
+    if (cigarString[0].operation == 'M')
+      removed += cigarString[0].count;
+    unsigned const nLeft = nRemoved - cigarString[0].count;
+    cigarString.erase(cigarString.begin());
+    if (cigarString.empty())
+      return removed;
+    return removed + resetCigarStringBegin(cigarString, nLeft);
   }
-  return ref_gone;
+  return removed;
 }
 
 inline bool long_enough(Record const & record, Options const & opts)
 {
   return !(static_cast<long>(record.seq.size()) < opts.minReadLen ||
-           (record.mapq < 25 && static_cast<long>(record.seq.size()) < opts.minReadLenMapQ0));
+           (record.mapQ < 25 && static_cast<long>(record.seq.size()) < opts.minReadLenMapQ0));
 }
 
 template <class V>
@@ -367,14 +359,14 @@ void erase_range(V & v, size_t a, size_t b)
 }
 
 // :484-521
-inline bool strip_soft_clips(Record & record, Options const & opts)
+inline bool removeSoftClipped(Record & record, Options const & opts)
 {
   long n_cigar = static_cast<long>(record.cigar.size());
   if (n_cigar >= 1)
   {
-    if (record.cigar[0].op == 'S')
+    if (record.cigar[0].operation == 'S')
     {
-      uint32_t const count = record.cigar[0].len;
+      uint32_t const count = record.cigar[0].count;
       erase_range(record.seq, 0, count);
       erase_range(record.qual, 0, count);
       record.cigar.erase(record.cigar.begin());
@@ -382,11 +374,11 @@ inline bool strip_soft_clips(Record & record, Options const & opts)
     }
     if (n_cigar >= 2)
     {
-      auto const last_el = record.cigar[n_cigar - 1];
-      if (last_el.op == 'S')
+      auto const last_cigar = record.cigar[n_cigar - 1];
+      if (last_cigar.operation == 'S')
       {
-        long const n_bases = static_cast<long>(record.seq.size());
-        long const left = std::max(0l, n_bases - static_cast<long>(last_el.len));
+        long const sequence_length = static_cast<long>(record.seq.size());
+        long const left = std::max(0l, sequence_length - static_cast<long>(last_cigar.count));
         record.seq.resize(left);
         record.qual.resize(left);
         record.cigar.pop_back();
@@ -397,106 +389,106 @@ inline bool strip_soft_clips(Record & record, Options const & opts)
 }
 
 // :523-584
-inline bool strip_n_ends(Record & record, Options const & opts)
+inline bool removeNsAtEnds(Record & record, Options const & opts)
 {
-  int n_ns = 0;
+  int nOfNs = 0;
   auto is_n = [&](long idx) { return idx >= 0 && idx < static_cast<long>(record.seq.size()) && record.seq[idx] == 15; };
   if (is_n(0))
   {
-    ++n_ns;
+    ++nOfNs;
     int idx = 1;
     while (is_n(idx) && idx < static_cast<long>(record.seq.size()) - 1)
     {
-      ++n_ns;
+      ++nOfNs;
       ++idx;
     }
-    erase_range(record.seq, 0, n_ns);
-    erase_range(record.qual, 0, n_ns);
+    erase_range(record.seq, 0, nOfNs);
+    erase_range(record.qual, 0, nOfNs);
     if (!flag_unmapped(record))
     {
-      unsigned const shift = cigar_shorten_front(record.cigar, n_ns);
-      record.pos += shift;
+      unsigned const shift = resetCigarStringBegin(record.cigar, nOfNs);
+      record.beginPos += shift;
     }
   }
   if (!long_enough(record, opts))
     return false;
-  n_ns = 0;
+  nOfNs = 0;
   if (is_n(static_cast<long>(record.seq.size()) - 1))
   {
-    ++n_ns;
+    ++nOfNs;
     int idx = static_cast<int>(record.seq.size()) - 2;
     while (is_n(idx) && idx > 0)
     {
-      ++n_ns;
+      ++nOfNs;
       --idx;
     }
-    erase_range(record.seq, record.seq.size() - n_ns, record.seq.size());
-    erase_range(record.qual, record.qual.size() - std::min<size_t>(n_ns, record.qual.size()), record.qual.size());
+    erase_range(record.seq, record.seq.size() - nOfNs, record.seq.size());
+    erase_range(record.qual, record.qual.size() - std::min<size_t>(nOfNs, record.qual.size()), record.qual.size());
     if (!flag_unmapped(record))
-      cigar_shorten_back(record.cigar, n_ns);
+      resetCigarStringEnd(record.cigar, nOfNs);
   }
   return long_enough(record, opts);
 }
 
 // :567-604: (bases to clip off the reverse read's front, positions to shift it by)
-inline std::pair<int, int> clip_and_shift(Record const & rev, int fwd_start)
+inline std::pair<int, int> findNum2Clip(Record const & recordReverse, int forwardStartPos)
 {
-  int n_clip = 0, n_shift = 0;
-  unsigned ci = 0;
-  long rev_at = rev.pos;
+  int num2clip = 0, num2shift = 0;
+  unsigned cigarIndex = 0;
+  long reverseStartPos = recordReverse.beginPos;
   unsigned n = 0;
-  auto const & cigar = rev.cigar;
-  if (!cigar.empty() && cigar[0].op == 'S')
+  auto const & cigar = recordReverse.cigar;
+  if (!cigar.empty() && cigar[0].operation == 'S')
   {
-    n_clip = cigar[0].len;
-    ++ci;
+    num2clip = cigar[0].count;
+    ++cigarIndex;
   }
-  while (ci < cigar.size())
+  while (cigarIndex < cigar.size())
   {
-    char const o = cigar[ci].op;
+    char const cigarOperation = cigar[cigarIndex].operation;
     n = 0;
-    while (rev_at < fwd_start && n < cigar[ci].len)
+    while (reverseStartPos < forwardStartPos && n < cigar[cigarIndex].count)
     {
-      if (o != 'D')
-        ++n_clip;
-      if (o != 'I')
-        ++rev_at;
+      if (cigarOperation != 'D')
+        ++num2clip;
+      if (cigarOperation != 'I')
+        ++reverseStartPos;
       ++n;
     }
-    if (rev_at == fwd_start)
+    if (reverseStartPos == forwardStartPos)
       break;
-    ++ci;
+    ++cigarIndex;
   }
-  if (ci < cigar.size() && cigar[ci].op == 'D')
-    n_shift = static_cast<int>(cigar[ci].len) - static_cast<int>(n);
-  return {n_clip, n_shift};
+  if (cigarIndex < cigar.size() && cigar[cigarIndex].operation == 'D')
+    num2shift = static_cast<int>(cigar[cigarIndex].count) - static_cast<int>(n);
+  return {num2clip, num2shift};
 }
 
 // :606-665
-inline bool trim_adapters(Record & fwd, Record & rev, Options const & opts)
+inline bool removeAdapters(Record & recordForward, Record & recordReverse, Options const & opts)
 {
-  if (strip_soft_clips(fwd, opts) && strip_soft_clips(rev, opts))
+  if (removeSoftClipped(recordForward, opts) && removeSoftClipped(recordReverse, opts))
     return false;
-  int const diff = fwd.pos - rev.pos;
-  if (diff < 0)
+  int const startPosDiff = recordForward.beginPos - recordReverse.beginPos;
+  if (startPosDiff < 0)
     return true;
-  auto const cs = clip_and_shift(rev, fwd.pos);
-  int const index = cs.first, shift = cs.second;
-  erase_range(rev.seq, 0, index);
-  erase_range(rev.qual, 0, index);
-  cigar_shorten_front(rev.cigar, index);
-  if (fwd.seq.size() > rev.seq.size() && index > 0)
+  auto const clipAndShift = findNum2Clip(recordReverse, recordForward.beginPos);
+  int const index = clipAndShift.first, shift = clipAndShift.second;
+  erase_range(recordReverse.seq, 0, index);
+  erase_range(recordReverse.qual, 0, index);
+  resetCigarStringBegin(recordReverse.cigar, index);
+  if (recordForward.seq.size() > recordReverse.seq.size() && index > 0)
   {
-    int const over = static_cast<int>(fwd.seq.size() - rev.seq.size());
-    erase_range(fwd.seq, rev.seq.size(), fwd.seq.size());
-    erase_range(fwd.qual, rev.qual.size(), fwd.qual.size());
-    cigar_shorten_back(fwd.cigar, over);
+    int const forwardClip = static_cast<int>(recordForward.seq.size() - recordReverse.seq.size());
+    erase_range(recordForward.seq, recordReverse.seq.size(), recordForward.seq.size());
+    erase_range(recordForward.qual, recordReverse.qual.size(), recordForward.qual.size());
+    resetCigarStringEnd(recordForward.cigar, forwardClip);
   }
-  rev.pos = fwd.pos;
+  recordReverse.beginPos = recordForward.beginPos;
   if (shift > 0)
-    rev.pos += shift;
-  fwd.mate_pos = rev.pos;
-  return long_enough(fwd, opts);
+    recordReverse.beginPos += shift;
+  recordForward.pNext = recordReverse.beginPos;
+  return long_enough(recordForward, opts);
 }
 
 inline void reverse_complement(Record & record) // seqan::reverseComplement on IUPAC: the 4-bit code with its bits mirrored
@@ -510,96 +502,96 @@ inline void reverse_complement(Record & record) // seqan::reverseComplement on I
 // whole file; the region of :681-699 (records of contig `rid` that overlap [begin, end), htslib's iterator: an alignment
 // without reference bases counts as one position long) is cut here.  interval: 0-based first and last position (i2, i3).
 inline void shrink_interval(Options const & opts, std::vector<Record> const & in, int32_t rid, int interval_begin, int interval_end,
-                            long & counter, bool const is_single_contig, std::vector<Record> & out)
+                            long & read_num, bool const is_single_contig, std::vector<Record> & out)
 {
   int const begin = std::max(interval_begin - (opts.maxFragLen - 100), 0);
   long const end = static_cast<long>(interval_end) + (opts.maxFragLen - 100);
-  std::multiset<Record> ready;
-  std::unordered_map<std::string, Record, NameHash> waiting;
-  long origin = -1;
-  std::vector<uint32_t> bins;
-  long const bin_cap = opts.no_filter_on_coverage ? (std::numeric_limits<int>::max() / 10)
+  std::multiset<Record> read_set;
+  std::unordered_map<std::string, Record, NameHash> read_first;
+  long first_pos = -1;
+  std::vector<uint32_t> bin_counts;
+  long const max_bin_sum = opts.no_filter_on_coverage ? (std::numeric_limits<int>::max() / 10)
                                                       : static_cast<long>(opts.avgCovByReadLen * 50.0 * 2.5);
-  long const max_frag = opts.maxFragLen;
-  auto count_at = [&](long bin) -> long { return bin >= 0 && bin < static_cast<long>(bins.size()) ? bins[bin] : 0; };
+  long const max_fragment_length = opts.maxFragLen;
+  auto count_at = [&](long bin) -> long { return bin >= 0 && bin < static_cast<long>(bin_counts.size()) ? bin_counts[bin] : 0; };
 
-  auto single_ok = [&](Record const & rec) -> bool // :716-734
+  auto filter_unpaired = [&](Record const & rec) -> bool // :716-734
   {
-    if (static_cast<long>(rec.pos + static_cast<long>(rec.seq.size())) < static_cast<long>(interval_begin) || rec.pos > interval_end)
+    if (static_cast<long>(rec.beginPos + static_cast<long>(rec.seq.size())) < static_cast<long>(interval_begin) || rec.beginPos > interval_end)
       return false;
-    if (rec.mapq < 40 || static_cast<long>(rec.seq.size()) < opts.minUnpairedReadLen || an_end_clipped(rec.cigar, 12) ||
-        both_ends_clipped(rec.cigar, 5) || matching_bases(rec.cigar) < (opts.minNumMatching + 5) ||
-        quals_of_20_and_more(rec.qual) < static_cast<long>(rec.seq.size()) / 4l)
+    if (rec.mapQ < 40 || static_cast<long>(rec.seq.size()) < opts.minUnpairedReadLen || is_one_end_clipped(rec.cigar, 12) ||
+        is_clipped_both_ends(rec.cigar, 5) || countMatchingBases(rec.cigar) < (opts.minNumMatching + 5) ||
+        countHighBaseQuality(rec.qual) < static_cast<long>(rec.seq.size()) / 4l)
       return false;
     return true;
   };
 
-  auto mate_ok = [&](Record const & rec) -> bool // :736-776
+  auto filter_paired = [&](Record const & rec) -> bool // :736-776
   {
-    if (opts.is_filtering_mapq0 && rec.mapq <= 1)
+    if (opts.is_filtering_mapq0 && rec.mapQ <= 1)
       return false;
     long const len = static_cast<long>(rec.seq.size());
-    if (rec.pos + len < static_cast<long>(interval_begin) && static_cast<long>(rec.pos) + rec.tlen < static_cast<long>(interval_begin))
+    if (rec.beginPos + len < static_cast<long>(interval_begin) && static_cast<long>(rec.beginPos) + rec.tLen < static_cast<long>(interval_begin))
       return false;
-    if (static_cast<long>(rec.pos) > static_cast<long>(interval_end) &&
-        static_cast<long>(rec.pos) + rec.tlen - len > static_cast<long>(interval_end))
+    if (static_cast<long>(rec.beginPos) > static_cast<long>(interval_end) &&
+        static_cast<long>(rec.beginPos) + rec.tLen - len > static_cast<long>(interval_end))
       return false;
     if (flag_unmapped(rec))
       return true;
-    if (len < opts.minReadLen || (rec.mapq < 55 && both_ends_clipped(rec.cigar, 12)) ||
-        (rec.mapq < 5 && an_end_clipped(rec.cigar, len / 4)) || both_ends_clipped(rec.cigar, len / 3) ||
-        matching_bases(rec.cigar) < opts.minNumMatching || quals_of_20_and_more(rec.qual) <= len / 10l)
+    if (len < opts.minReadLen || (rec.mapQ < 55 && is_clipped_both_ends(rec.cigar, 12)) ||
+        (rec.mapQ < 5 && is_one_end_clipped(rec.cigar, len / 4)) || is_clipped_both_ends(rec.cigar, len / 3) ||
+        countMatchingBases(rec.cigar) < opts.minNumMatching || countHighBaseQuality(rec.qual) <= len / 10l)
       return false;
     return true;
   };
 
-  auto keep_single = [&](Record && rec) -> void // :778-813
+  auto post_process_unpaired = [&](Record && rec) -> void // :778-813
   {
-    std::string kept;
-    if (!scores_say_keep(rec, kept, opts))
+    std::string new_tags;
+    if (!process_tags(rec, new_tags, opts))
       return;
-    if (!strip_n_ends(rec, opts))
+    if (!removeNsAtEnds(rec, opts))
       return;
-    rec.aux = std::move(kept);
-    long const bin = (rec.pos - origin) / 50l;
-    if (bin >= static_cast<long>(bins.size()))
-      bins.resize(bin + 1, 0u);
-    else if (bins[bin] >= (bin_cap / 3l))
+    rec.tags = std::move(new_tags);
+    long const bin = (rec.beginPos - first_pos) / 50l;
+    if (bin >= static_cast<long>(bin_counts.size()))
+      bin_counts.resize(bin + 1, 0u);
+    else if (bin_counts[bin] >= (max_bin_sum / 3l))
     {
-      ++bins[bin];
+      ++bin_counts[bin];
       return;
     }
-    two_level_quals(rec.qual);
-    strip_hard_clips(rec.cigar);
+    binarizeQual(rec.qual);
+    removeHardClipped(rec.cigar);
     if (opts.change_read_names)
     {
-      rec.name = counter_name(counter);
-      ++counter;
+      rec.qName = decimal_to_read_name_string(read_num);
+      ++read_num;
     }
-    ++bins[bin];
-    ready.insert(std::move(rec));
+    ++bin_counts[bin];
+    read_set.insert(std::move(rec));
   };
 
-  auto finish_mate = [&](Record & rec, long const num) -> bool // :815-840
+  auto post_process_paired = [&](Record & rec, long const num) -> bool // :815-840
   {
-    std::string kept;
-    if (!scores_say_keep(rec, kept, opts))
+    std::string new_tags;
+    if (!process_tags(rec, new_tags, opts))
       return false;
-    if (!strip_n_ends(rec, opts))
+    if (!removeNsAtEnds(rec, opts))
       return false;
-    rec.aux = std::move(kept);
-    two_level_quals(rec.qual);
-    strip_hard_clips(rec.cigar);
+    rec.tags = std::move(new_tags);
+    binarizeQual(rec.qual);
+    removeHardClipped(rec.cigar);
     if (opts.change_read_names)
-      rec.name = counter_name(num);
+      rec.qName = decimal_to_read_name_string(num);
     return true;
   };
 
-  auto write_unless_too_deep = [&](Record const & rec) // :888-903, :1022-1040
+  auto write_if_not_too_deep = [&](Record const & rec) // :888-903, :1022-1040
   {
-    long const bin1 = (rec.pos - origin) / 50l;
-    long const bin2 = (rec.mate_pos - origin) / 50l;
-    if (count_at(bin1) < (opts.SUPER_HI_DEPTH * bin_cap) || (flag_multiple(rec) && count_at(bin2) < (opts.SUPER_HI_DEPTH * bin_cap)))
+    long const bin1 = (rec.beginPos - first_pos) / 50l;
+    long const bin2 = (rec.pNext - first_pos) / 50l;
+    if (count_at(bin1) < (opts.SUPER_HI_DEPTH * max_bin_sum) || (flag_multiple(rec) && count_at(bin2) < (opts.SUPER_HI_DEPTH * max_bin_sum)))
       out.push_back(rec);
   };
 
@@ -607,61 +599,61 @@ inline void shrink_interval(Options const & opts, std::vector<Record> const & in
   {
     // readRegion: what the iterator over [begin, end) returns
     {
-      if (from_file.ref_id != rid)
+      if (from_file.rID != rid)
         continue;
       long span = 0;
       for (auto const & c : from_file.cigar)
-        if (c.op == 'M' || c.op == 'D' || c.op == 'N' || c.op == '=' || c.op == 'X')
-          span += c.len;
-      long const end_pos = static_cast<long>(from_file.pos) + (span > 0 && !flag_unmapped(from_file) ? span : 1);
-      if (end_pos <= begin || from_file.pos >= end)
+        if (c.operation == 'M' || c.operation == 'D' || c.operation == 'N' || c.operation == '=' || c.operation == 'X')
+          span += c.count;
+      long const end_pos = static_cast<long>(from_file.beginPos) + (span > 0 && !flag_unmapped(from_file) ? span : 1);
+      if (end_pos <= begin || from_file.beginPos >= end)
         continue;
     }
     Record record = from_file;
     // :849-853
-    if ((record.flag & static_cast<uint32_t>(opts.sam_flag_filter)) != 0 || (record.tlen != 0 && std::abs(record.tlen) < opts.minReadLen))
+    if ((record.flag & static_cast<uint32_t>(opts.sam_flag_filter)) != 0 || (record.tLen != 0 && std::abs(record.tLen) < opts.minReadLen))
       continue;
-    if (origin < 0) // :855-861
+    if (first_pos < 0) // :855-861
     {
-      if (record.pos < 0)
+      if (record.beginPos < 0)
         continue;
-      origin = record.pos;
+      first_pos = record.beginPos;
     }
     // :866-907
-    if (ready.size() > 0 && (record.pos > (max_frag + ready.begin()->pos + 600)))
+    if (read_set.size() > 0 && (record.beginPos > (max_fragment_length + read_set.begin()->beginPos + 600)))
     {
-      for (auto it = waiting.begin(); it != waiting.end();)
+      for (auto it = read_first.begin(); it != read_first.end();)
       {
-        if (static_cast<long>(record.pos) > (max_frag + it->second.pos + 400))
+        if (static_cast<long>(record.beginPos) > (max_fragment_length + it->second.beginPos + 400))
         {
-          make_single(it->second);
-          if (single_ok(it->second))
-            keep_single(std::move(it->second));
-          it = waiting.erase(it);
+          makeUnpaired(it->second);
+          if (filter_unpaired(it->second))
+            post_process_unpaired(std::move(it->second));
+          it = read_first.erase(it);
         }
         else
           ++it;
       }
-      auto it = ready.begin();
-      while (it != ready.end() && (record.pos > (max_frag + it->pos + 400)))
+      auto it = read_set.begin();
+      while (it != read_set.end() && (record.beginPos > (max_fragment_length + it->beginPos + 400)))
       {
-        write_unless_too_deep(*it);
+        write_if_not_too_deep(*it);
         ++it;
       }
-      ready.erase(ready.begin(), it);
+      read_set.erase(read_set.begin(), it);
     }
     // :909-922
     if (is_single_contig)
     {
-      if (record.mate_ref_id == record.ref_id)
+      if (record.rNextId == record.rID)
       {
-        record.ref_id = 0;
-        record.mate_ref_id = 0;
+        record.rID = 0;
+        record.rNextId = 0;
       }
       else
       {
-        record.ref_id = 0;
-        record.mate_ref_id = 1;
+        record.rID = 0;
+        record.rNextId = 1;
       }
     }
     // :924-929
@@ -672,84 +664,84 @@ inline void shrink_interval(Options const & opts, std::vector<Record> const & in
       record.flag ^= 16u;
     }
     // :931-937
-    if (record.ref_id != record.mate_ref_id || flag_rc(record) == flag_next_rc(record) || std::abs(record.tlen) > max_frag ||
-        (record.tlen > 0 && flag_rc(record)) || (record.tlen < 0 && !flag_rc(record)))
-      make_single(record);
+    if (record.rID != record.rNextId || flag_rc(record) == flag_next_rc(record) || std::abs(record.tLen) > max_fragment_length ||
+        (record.tLen > 0 && flag_rc(record)) || (record.tLen < 0 && !flag_rc(record)))
+      makeUnpaired(record);
     if (!flag_multiple(record)) // :939-946
     {
-      if (single_ok(record))
-        keep_single(std::move(record));
+      if (filter_unpaired(record))
+        post_process_unpaired(std::move(record));
       continue;
     }
-    if (!mate_ok(record)) // :949-950
+    if (!filter_paired(record)) // :949-950
       continue;
-    auto mate = waiting.find(record.name);
-    if (mate == waiting.end()) // :954-963
+    auto find_it = read_first.find(record.qName);
+    if (find_it == read_first.end()) // :954-963
     {
-      if (record.mate_pos >= record.pos)
+      if (record.pNext >= record.beginPos)
       {
-        std::string const key = record.name;
-        waiting[key] = std::move(record);
+        std::string const key = record.qName;
+        read_first[key] = std::move(record);
       }
       continue;
     }
-    long const bin1 = (record.pos - origin) / 50l;
-    long const bin2 = (mate->second.pos - origin) / 50l;
+    long const bin1 = (record.beginPos - first_pos) / 50l;
+    long const bin2 = (find_it->second.beginPos - first_pos) / 50l;
     {
       long const max_bin = std::max(bin1, bin2);
-      if (max_bin >= static_cast<long>(bins.size()))
-        bins.resize(max_bin + 1, 0u);
+      if (max_bin >= static_cast<long>(bin_counts.size()))
+        bin_counts.resize(max_bin + 1, 0u);
     }
-    ++bins[bin1];
-    ++bins[bin2];
-    if (bins[bin1] < bin_cap) // :979-1016
+    ++bin_counts[bin1];
+    ++bin_counts[bin2];
+    if (bin_counts[bin1] < max_bin_sum) // :979-1016
     {
-      if (bins[bin2] < bin_cap)
+      if (bin_counts[bin2] < max_bin_sum)
       {
         bool is_ok;
-        if (record.tlen == 0 ||
-            std::abs(record.tlen) > static_cast<long>(std::max(record.seq.size(), mate->second.seq.size())))
+        if (record.tLen == 0 ||
+            std::abs(record.tLen) > static_cast<long>(std::max(record.seq.size(), find_it->second.seq.size())))
           is_ok = true;
         else if (flag_rc(record))
-          is_ok = trim_adapters(mate->second, record, opts);
+          is_ok = removeAdapters(find_it->second, record, opts);
         else
-          is_ok = trim_adapters(record, mate->second, opts);
-        if (is_ok && finish_mate(record, counter) && finish_mate(mate->second, counter))
+          is_ok = removeAdapters(record, find_it->second, opts);
+        if (is_ok && post_process_paired(record, read_num) && post_process_paired(find_it->second, read_num))
         {
-          if ((!flag_unmapped(record) && !flag_unmapped(mate->second)) || (flag_unmapped(record) && single_ok(mate->second)) ||
-              (flag_unmapped(mate->second) && single_ok(record)))
+          if ((!flag_unmapped(record) && !flag_unmapped(find_it->second)) || (flag_unmapped(record) && filter_unpaired(find_it->second)) ||
+              (flag_unmapped(find_it->second) && filter_unpaired(record)))
           {
-            ++counter;
-            ready.insert(std::move(record));
-            ready.insert(std::move(mate->second));
+            ++read_num;
+            read_set.insert(std::move(record));
+            read_set.insert(std::move(find_it->second));
           }
         }
       }
-      else if (bins[bin1] < (bin_cap / 3))
+      else if (bin_counts[bin1] < (max_bin_sum / 3))
       {
-        make_single(record);
-        if (single_ok(record))
-          keep_single(std::move(record));
+        makeUnpaired(record);
+        if (filter_unpaired(record))
+          post_process_unpaired(std::move(record));
       }
     }
-    else if (bins[bin2] < (bin_cap / 3))
+    else if (bin_counts[bin2] < (max_bin_sum / 3))
     {
-      make_single(mate->second);
-      if (single_ok(mate->second))
-        keep_single(std::move(mate->second));
+      makeUnpaired(find_it->second);
+      if (filter_unpaired(find_it->second))
+        post_process_unpaired(std::move(find_it->second));
     }
-    waiting.erase(mate);
+    read_first.erase(find_it);
   }
   // :1006-1017 leftovers become unpaired
-  for (auto && rec : waiting)
+  for (auto && rec : read_first)
   {
-    make_single(rec.second);
-    if (single_ok(rec.second))
-      keep_single(std::move(rec.second));
+    makeUnpaired(rec.second);
+    if (filter_unpaired(rec.second))
+      post_process_unpaired(std::move(rec.second));
   }
-  waiting.clear();
-  for (auto const & rec : ready) // :1020-1041
-    write_unless_too_deep(rec);
+  read_first.clear();
+  for (auto const & rec : read_set) // :1020-1041
+    write_if_not_too_deep(rec);
 }
 
 // the header text of the one-interval case (:1304-1335): @HD, @RG and the interval's @SQ line
@@ -785,22 +777,22 @@ inline bool decode_records(uint8_t const * p, size_t len, std::vector<Record> & 
     Record r;
     int32_t l_seq;
     uint16_t n_cigar, flag;
-    std::memcpy(&r.ref_id, b, 4);
-    std::memcpy(&r.pos, b + 4, 4);
+    std::memcpy(&r.rID, b, 4);
+    std::memcpy(&r.beginPos, b + 4, 4);
     uint8_t const l_read_name = b[8];
-    r.mapq = b[9];
+    r.mapQ = b[9];
     std::memcpy(&n_cigar, b + 12, 2);
     std::memcpy(&flag, b + 14, 2);
     r.flag = flag;
     std::memcpy(&l_seq, b + 16, 4);
-    std::memcpy(&r.mate_ref_id, b + 20, 4);
-    std::memcpy(&r.mate_pos, b + 24, 4);
-    std::memcpy(&r.tlen, b + 28, 4);
+    std::memcpy(&r.rNextId, b + 20, 4);
+    std::memcpy(&r.pNext, b + 24, 4);
+    std::memcpy(&r.tLen, b + 28, 4);
     size_t const o_cigar = 32 + l_read_name, o_seq = o_cigar + 4ull * n_cigar, o_qual = o_seq + (static_cast<size_t>(l_seq) + 1) / 2,
                  o_aux = o_qual + static_cast<size_t>(l_seq);
     if (l_seq < 0 || o_aux > static_cast<size_t>(block))
       return false;
-    r.name.assign(reinterpret_cast<char const *>(b + 32), l_read_name ? l_read_name - 1u : 0u);
+    r.qName.assign(reinterpret_cast<char const *>(b + 32), l_read_name ? l_read_name - 1u : 0u);
     for (unsigned c = 0; c < n_cigar; ++c)
     {
       uint32_t w;
@@ -811,7 +803,7 @@ inline bool decode_records(uint8_t const * p, size_t len, std::vector<Record> & 
     for (int32_t i = 0; i < l_seq; ++i)
       r.seq[i] = (b[o_seq + i / 2] >> ((i & 1) ? 0 : 4)) & 15u;
     r.qual.assign(b + o_qual, b + o_aux);
-    r.aux.assign(reinterpret_cast<char const *>(b + o_aux), static_cast<size_t>(block) - o_aux);
+    r.tags.assign(reinterpret_cast<char const *>(b + o_aux), static_cast<size_t>(block) - o_aux);
     out.push_back(std::move(r));
   }
   return at == len;
@@ -832,37 +824,37 @@ inline void encode_record(Record const & r, std::vector<uint8_t> & out)
 {
   long span = 0;
   for (auto const & c : r.cigar)
-    if (c.op == 'M' || c.op == 'D' || c.op == 'N' || c.op == '=' || c.op == 'X')
-      span += c.len;
-  int64_t const end = static_cast<int64_t>(r.pos) + ((r.flag & 4u) || span == 0 ? 1 : span);
-  uint16_t const bin = reg2bin(r.pos < 0 ? -1 : r.pos, r.pos < 0 ? 0 : end);
-  uint8_t const l_read_name = static_cast<uint8_t>(r.name.size() + 1);
+    if (c.operation == 'M' || c.operation == 'D' || c.operation == 'N' || c.operation == '=' || c.operation == 'X')
+      span += c.count;
+  int64_t const end = static_cast<int64_t>(r.beginPos) + ((r.flag & 4u) || span == 0 ? 1 : span);
+  uint16_t const bin = reg2bin(r.beginPos < 0 ? -1 : r.beginPos, r.beginPos < 0 ? 0 : end);
+  uint8_t const l_read_name = static_cast<uint8_t>(r.qName.size() + 1);
   int32_t const l_seq = static_cast<int32_t>(r.seq.size());
-  int32_t const block = static_cast<int32_t>(32 + l_read_name + 4 * r.cigar.size() + (r.seq.size() + 1) / 2 + r.seq.size() + r.aux.size());
+  int32_t const block = static_cast<int32_t>(32 + l_read_name + 4 * r.cigar.size() + (r.seq.size() + 1) / 2 + r.seq.size() + r.tags.size());
   size_t const at = out.size();
   out.resize(at + 4 + static_cast<size_t>(block));
   uint8_t * b = out.data() + at;
   std::memcpy(b, &block, 4);
   b += 4;
-  std::memcpy(b, &r.ref_id, 4);
-  std::memcpy(b + 4, &r.pos, 4);
+  std::memcpy(b, &r.rID, 4);
+  std::memcpy(b + 4, &r.beginPos, 4);
   b[8] = l_read_name;
-  b[9] = r.mapq;
+  b[9] = r.mapQ;
   std::memcpy(b + 10, &bin, 2);
   uint16_t const n_cigar = static_cast<uint16_t>(r.cigar.size()), flag = static_cast<uint16_t>(r.flag);
   std::memcpy(b + 12, &n_cigar, 2);
   std::memcpy(b + 14, &flag, 2);
   std::memcpy(b + 16, &l_seq, 4);
-  std::memcpy(b + 20, &r.mate_ref_id, 4);
-  std::memcpy(b + 24, &r.mate_pos, 4);
-  std::memcpy(b + 28, &r.tlen, 4);
-  std::memcpy(b + 32, r.name.c_str(), l_read_name);
+  std::memcpy(b + 20, &r.rNextId, 4);
+  std::memcpy(b + 24, &r.pNext, 4);
+  std::memcpy(b + 28, &r.tLen, 4);
+  std::memcpy(b + 32, r.qName.c_str(), l_read_name);
   uint8_t * q = b + 32 + l_read_name;
   for (auto const & c : r.cigar)
   {
     char const * ops = "MIDNSHP=X";
-    char const * f = std::strchr(ops, c.op);
-    uint32_t const w = (c.len << 4) | static_cast<uint32_t>(f ? f - ops : 15);
+    char const * f = std::strchr(ops, c.operation);
+    uint32_t const w = (c.count << 4) | static_cast<uint32_t>(f ? f - ops : 15);
     std::memcpy(q, &w, 4);
     q += 4;
   }
@@ -873,6 +865,6 @@ inline void encode_record(Record const & r, std::vector<uint8_t> & out)
   for (size_t i = 0; i < r.seq.size(); ++i)
     q[i] = i < r.qual.size() ? r.qual[i] : 0xFF;
   q += r.seq.size();
-  std::memcpy(q, r.aux.data(), r.aux.size());
+  std::memcpy(q, r.tags.data(), r.tags.size());
 }
 } // namespace gto_shrink
