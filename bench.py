@@ -329,6 +329,22 @@ class Workload:
         self.dist = None       # fallback: torch.distributed on views of the packed block
         self.reduce_kind = None
 
+    def fresh_streams(self):
+        """new HIP streams (and events) for every lane and for the tails: where the runtime puts a stream on the hardware queues is
+        decided when it is made"""
+        torch = self.torch
+        torch.cuda.synchronize()
+        for ln in self.lanes:
+            ln["stream"] = torch.cuda.Stream(device=self.device)
+            ln["sp"] = C.c_void_p(ln["stream"].cuda_stream)
+        self.stream, self.sp = self.lanes[0]["stream"], self.lanes[0]["sp"]
+        self.tail_streams = [torch.cuda.Stream(device=self.device) for _ in self.tail_streams]
+        for ln in self.lanes:
+            ln["front"], ln["aligned"], ln["scored"] = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            for ev in (ln["front"], ln["aligned"], ln["scored"]):
+                ev.record(self.stream)
+        torch.cuda.synchronize()
+
     def add_reads(self, d_seq, d_pos):
         """another resident read set of the same size: the steps take the sets in turn, so that no step finds its own
         reads (or their records) in a cache"""
@@ -554,11 +570,22 @@ class Workload:
                 return (time.perf_counter() - t) / k
             t_stag = min(timed(self.steps_staggered, 2 * n_lanes) for _ in range(3))
             t_one = min(timed(lambda k: [self.step(0) for _ in range(k)], 4) for _ in range(3))
+            # (Round 5: one process in a dozen measured the staggered schedule at 2.7 ms per step, three times the one-at-a-time rate,
+            #  in all three tries -- a state of that process' streams, not of the box: the run before it on the same box had 0.75.
+            #  New streams get new places on the hardware queues: the schedule is given two more chances on fresh ones before the
+            #  run settles for one step at a time.)
+            retries = 0
+            while t_stag > t_one and retries < 2 and dist is None:
+                retries += 1
+                self.fresh_streams()
+                self.steps_staggered(2 * n_lanes)
+                self.steps_done -= 2 * n_lanes
+                t_stag = min(timed(self.steps_staggered, 2 * n_lanes) for _ in range(3))
             both = torch.tensor([t_stag, t_one], dtype=torch.float64, device=self.device)
             if dist is not None:
                 dist.all_reduce(both, op=dist.ReduceOp.MAX)
             t_stag, t_one = (float(x) for x in both.cpu())
-            self.calibration = {"staggered_ms_per_step": 1000.0 * t_stag, "one_at_a_time_ms_per_step": 1000.0 * t_one}
+            self.calibration = {"staggered_ms_per_step": 1000.0 * t_stag, "one_at_a_time_ms_per_step": 1000.0 * t_one, "fresh_stream_retries": retries}
             if t_stag > t_one:
                 stag, n_lanes = False, 1
                 self.staggered = False
@@ -1687,7 +1714,13 @@ def main(argv=None):
 # The position-hinted pass proves the outcome of those probes from per-position flags and never issues them: 20 B meta +
 # 80 B bases (plane row) + 84 B reference planes + 48 B position flags + 4 B filter word + 24 B record = 260 B (round 2's 268 B
 # minus the 8-byte header of the reverse record, which GTX_FLAG_FORWARD_ONLY reads no longer get).
-KERNEL_BYTES = {"gtx_align_hinted_kernel": 260, "gtx_align_express4_kernel": ALGO_BYTES_PER_READ, "gtx_align_kernel": ALGO_BYTES_PER_READ,
+# Bytes per read the position-hinted pass is priced with.  COMPULSORY: what has to cross the HBM interface for one read whatever the
+# kernel does -- 20 meta + 80 plane row + 24 record + 2 (its byte of the side array, its share of the queue words): the roofline's
+# `achieved`.  WITH_TABLES: the same plus what the kernel reads of the per-position tables (84 reference planes + 48 flag words + 4
+# filter word) -- bytes ten neighbouring reads share and the caches serve; rounds 2-4 priced the roofline with it (kept beside the
+# other, labelled).
+HINTED_COMPULSORY_BYTES, HINTED_BYTES_WITH_TABLES = 126, 260
+KERNEL_BYTES = {"gtx_align_hinted_kernel": HINTED_COMPULSORY_BYTES, "gtx_align_express4_kernel": ALGO_BYTES_PER_READ, "gtx_align_kernel": ALGO_BYTES_PER_READ,
                 "gtx_align_big_kernel": ALGO_BYTES_PER_READ}
 
 
@@ -1712,8 +1745,16 @@ def dominant_kernel(pass_ms, n_pass2, n, align_avg_ms, kern):
     # the whole alignment step priced as the reference's algorithm (every read at SURVEY's 3 296 B): how fast a
     # probe-per-key implementation would have to move data to keep up -- continuity with round 1, NOT a hardware fraction
     ref_equiv = ALGO_BYTES_PER_READ * n / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
+    with_tables = None
+    if name == "gtx_align_hinted_kernel" and ms > 0:
+        gbs = HINTED_BYTES_WITH_TABLES * units / (ms * 1e-3) / 1e9
+        with_tables = {"bytes_per_read": HINTED_BYTES_WITH_TABLES, "gbs": gbs, "frac": gbs / HBM_PEAK_GBS,
+                       "note": "the pricing of rounds 2-4: the compulsory bytes plus the per-position tables the kernel reads (shared by neighbouring reads, "
+                               "served by the caches) -- not a fraction of HBM bandwidth"}
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "kernel": name, "kernel_ms": ms, "units_per_launch": units, "algorithmic_bytes_per_read": per, "longest_kernel": longest,
+            "kernel": name, "kernel_ms": ms, "units_per_launch": units, "algorithmic_bytes_per_read": per,
+            "algorithmic_bytes_what": "compulsory: 20 meta + 80 plane row + 24 record + 2 side array / queue words" if name == "gtx_align_hinted_kernel" else "SURVEY 8(d)",
+            "priced_with_the_shared_tables": with_tables, "longest_kernel": longest,
             "align_kernels": passes, "align_all_kernels_ms": total_ms, "align_wall_ms": align_avg_ms,
             "reference_algorithm_equivalent": {"bytes_per_read": ALGO_BYTES_PER_READ, "gbs": ref_equiv,
                                                "note": "SURVEY 8(d) pricing (388 probes per read) of all reads over the sum of the alignment kernels; "

@@ -19,7 +19,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-KILL_SUITE = ["tests/test_oracle_truth.py", "tests/test_oracle_handworked.py", "tests/test_oracle_pinned.py", "tests/test_sv_vcf.py::test_coverage_model_hand_worked"]
+KILL_SUITE = ["tests/test_oracle_truth.py", "tests/test_oracle_handworked.py", "tests/test_oracle_pinned.py", "tests/test_sv_vcf.py::test_coverage_model_hand_worked",
+              "tests/test_oracle_vcf_truth.py"]
 
 
 def apply(mutant, oracle_dir):
