@@ -1241,6 +1241,32 @@ def extra_repeats(args, torch, gtx, synth, device, ref):
     return extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False, what, lanes=1, big_record_words=1 << 27)
 
 
+def extra_genome_like(args, torch, gtx, synth, device):
+    """The main workload's shape (one sample, SNP every 1 kb, 150-bp reads) on a reference and reads that look like a mapped human
+    sample instead of SURVEY 8(d)'s friendliest case: synth.make_genome_like_reference (order-5 Markov background, 45 % interspersed
+    repeat copies at 5-20 % divergence, 3 % STRs, segmental duplications) and synth.make_mapped_reads (0.5 % substitutions, 0.1 % N,
+    0.05 % indel errors, 3 % soft-clipped reads, 2 % wrong or shifted hints).  The figures: who finishes a read, reads/s,
+    reads_overflowed (must be 0).  The records do not depend on the hints (tests: four kinds of hints everywhere), so a wrong hint
+    costs a trip through the lookup passes, never a result."""
+    ref, stats = synth.make_genome_like_reference(REGION_LEN, seed=1999)
+    recs = synth.make_snp_records(ref, 1000, seed=7, region_begin=REGION_BEGIN)
+    n = args.extra_reads
+    made = {}
+
+    def make(seed):
+        codes, hint, st = synth.make_mapped_reads(ref, recs, n, seed=seed, region_begin=REGION_BEGIN)
+        made[seed] = st
+        return codes, hint
+    what = ("genome-like: 1 sample, %%d reads, 1 Mb of an order-5 Markov background with %.0f %%%% interspersed repeat copies (%d families, 5-20 %%%% "
+            "diverged), %.1f %%%% STRs, %.1f %%%% segmental duplications; SNP every 1 kb, max %%d alleles per site; reads with 0.5 %%%% substitutions, 0.1 %%%% N, "
+            "0.05 %%%% indel errors, 3 %%%% soft-clipped, 2 %%%% wrong / shifted position hints" %
+            (100.0 * stats["interspersed"], stats["families"], 100.0 * stats["str"], 100.0 * stats["segdup"]))
+    out = extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False, what, lanes=1, big_record_words=1 << 27, make_reads=make)
+    out["reads_made"] = made.get(5)
+    out["reference"] = stats
+    return out
+
+
 def extra_cfg5(args, torch, gtx, synth, device, n_pairs_per_sv=160, background_pairs=12000, n_samples=100, steps=10, tile=8):
     """BASELINE configs[4] as far as one GPU goes: `genotype_sv`, 100 samples over a 1 Mb SV-augmented graph -- 100 <DEL> of
     50-5 000 bp and 50 <INS> with 152-bp breakpoint alleles, from FASTA + VCF through gtx_graph_from_files -- FR pairs over every
@@ -1351,8 +1377,11 @@ def extra_cfg5(args, torch, gtx, synth, device, n_pairs_per_sv=160, background_p
     return out
 
 
-def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_all, what, lanes=None, big_record_words=0, read_len=READ_LEN):
+def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_all, what, lanes=None, big_record_words=0, read_len=READ_LEN, make_reads=None):
+    """make_reads (optional): seed -> (codes, pos) instead of synth.make_reads' clean reads"""
     n = args.extra_reads
+    if make_reads is None:
+        make_reads = lambda seed: synth.make_reads(ref, recs, n, read_len=read_len, seed=seed, region_begin=REGION_BEGIN)
     lanes = args.lanes if lanes is None else lanes
     t0 = time.time()
     graph = gtx.graph_from_records(synth.bases_to_str(ref), recs, region_begin=REGION_BEGIN, add_all_variants=add_all)
@@ -1360,7 +1389,7 @@ def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_al
     t0 = time.time()
     ctx = gtx.Context(graph, device=0, big_record_words=big_record_words)
     t_ctx = time.time() - t0
-    codes, pos = synth.make_reads(ref, recs, n, read_len=read_len, seed=5, region_begin=REGION_BEGIN)
+    codes, pos = make_reads(5)
     order = np.argsort(pos, kind="stable")
     codes, pos = codes[order], pos[order]
     d_seq = torch.from_numpy(gtx.pack_nibbles(codes)).to(device)
@@ -1370,7 +1399,7 @@ def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_al
     w.rewind = lanes == 1 and big_record_words != 0
     w.staggered = args.schedule == "staggered" and len(w.lanes) >= 2  # (the same schedule as the main workload, chosen the same way)
     if args.read_sets > 1:  # a second set of reads: the steps alternate
-        codes2, pos2 = synth.make_reads(ref, recs, n, read_len=read_len, seed=6, region_begin=REGION_BEGIN)
+        codes2, pos2 = make_reads(6)
         order2 = np.argsort(pos2, kind="stable")
         w.add_reads(torch.from_numpy(gtx.pack_nibbles(codes2[order2])).to(device), torch.from_numpy(pos2[order2]))
     steps = 9 if len(w.lanes) > 1 else 4
@@ -1699,6 +1728,10 @@ def main(argv=None):
             cfg.setdefault("extra", {})["repeats"] = extra_repeats(args, torch, gtx, synth, device, ref)
         except Exception as e:
             cfg.setdefault("extra", {})["repeats"] = {"error": repr(e)}
+        try:
+            cfg.setdefault("extra", {})["genome_like"] = extra_genome_like(args, torch, gtx, synth, device)
+        except Exception as e:
+            cfg.setdefault("extra", {})["genome_like"] = {"error": repr(e)}
         try:
             cfg.setdefault("extra", {})["cfg5"] = extra_cfg5(args, torch, gtx, synth, device)
         except Exception as e:

@@ -326,3 +326,134 @@ def write_fixed_bam(path, contig, contig_len, sample, codes, pos0, mapq=60, flag
         for m in members:
             f.write(m)
     return rec.itemsize
+
+
+def make_genome_like_reference(n, seed=1999, segdups=8, segdup_len=(5000, 20000)):
+    """A reference with the structure an i.i.d. one lacks and a human chromosome has, in the proportions of one: a background drawn from
+    an order-5 Markov chain (its transition table random but fixed, GC ~ 41 %, CpG depleted), ~45 % of the bases in copies of 24
+    interspersed repeat families (consensus of 280-320 bp -- Alu-like -- or 900-2 000 bp -- L1 fragments --, every copy 5-20 %
+    diverged from its consensus: substitutions and a few short indels, some copies truncated, half of them reverse-complemented),
+    ~3 % short tandem repeats (units of 1-6 bp, 5-40 copies, a substitution every ~60 bp), and 8 segmental duplications of 5-20 kb,
+    1-2 % diverged.  Returns (bases uint8 [n], {"interspersed": fraction, "str": fraction, "segdup": fraction, "families": k})."""
+    rng = np.random.default_rng(seed)
+    # ---- background: order-5 Markov chain
+    table = rng.dirichlet(np.array([2.9, 2.1, 2.1, 2.9]) * 3.0, size=4 ** 5)
+    cg = np.arange(4 ** 5) % 4 == 1  # context ends in C: G after it is rare (CpG depletion)
+    table[cg, 2] *= 0.25
+    table /= table.sum(1, keepdims=True)
+    cum = np.cumsum(table, axis=1)
+    u = rng.random(n)
+    ref = np.empty(n, np.uint8)
+    ref[:5] = rng.integers(0, 4, 5)
+    ctx = 0
+    for i in range(5):
+        ctx = (ctx * 4 + int(ref[i])) & 1023
+    for i in range(5, n):
+        b = int(np.searchsorted(cum[ctx], u[i]))
+        b = 3 if b > 3 else b
+        ref[i] = b
+        ctx = ((ctx * 4) + b) & 1023
+    covered = np.zeros(n, bool)
+
+    def diverge(seq, rate):
+        seq = seq.copy()
+        m = rng.random(len(seq)) < rate
+        seq[m] = (seq[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) % 4
+        out, i = [], 0
+        for at in np.nonzero(rng.random(len(seq)) < rate / 12.0)[0]:  # a short indel now and then
+            out.append(seq[i:at])
+            if rng.random() < 0.5:
+                out.append(rng.integers(0, 4, size=int(rng.integers(1, 4)), dtype=np.uint8))
+                i = at
+            else:
+                i = min(len(seq), at + int(rng.integers(1, 4)))
+        out.append(seq[i:])
+        return np.concatenate(out)
+
+    # ---- interspersed repeats
+    families = [rng.integers(0, 4, size=int(rng.integers(280, 321)) if k < 16 else int(rng.integers(900, 2001)), dtype=np.uint8) for k in range(24)]
+    target = int(0.45 * n)
+    placed = 0
+    while placed < target:
+        fam = families[int(rng.integers(0, len(families)))]
+        copy = diverge(fam, float(rng.uniform(0.05, 0.20)))
+        if rng.random() < 0.3:  # truncated at its 5' end, as retrotransposed copies are
+            copy = copy[int(rng.integers(0, len(copy) // 2)):]
+        if rng.random() < 0.5:
+            copy = (3 - copy)[::-1]
+        at = int(rng.integers(0, n - len(copy)))
+        if covered[at:at + len(copy)].any():
+            continue
+        ref[at:at + len(copy)] = copy
+        covered[at:at + len(copy)] = True
+        placed += len(copy)
+    inter = placed
+    # ---- short tandem repeats
+    strs = 0
+    while strs < int(0.03 * n):
+        unit = rng.integers(0, 4, size=int(rng.integers(1, 7)), dtype=np.uint8)
+        size = len(unit) * int(rng.integers(5, 41))
+        at = int(rng.integers(0, n - size))
+        if covered[at:at + size].any():
+            continue
+        run = np.tile(unit, size // len(unit))
+        m = rng.random(size) < 1.0 / 60.0
+        run[m] = (run[m] + 1) % 4
+        ref[at:at + size] = run
+        covered[at:at + size] = True
+        strs += size
+    # ---- segmental duplications (copied over whatever is there: they carry their repeats with them)
+    dup = 0
+    for _ in range(segdups):
+        size = int(rng.integers(segdup_len[0], segdup_len[1] + 1))
+        src, dst = int(rng.integers(0, n - size)), int(rng.integers(0, n - size))
+        if abs(src - dst) < size:
+            continue
+        seg = ref[src:src + size].copy()
+        m = rng.random(size) < float(rng.uniform(0.01, 0.02))
+        seg[m] = (seg[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) % 4
+        ref[dst:dst + size] = seg
+        dup += size
+    return ref, {"interspersed": inter / float(n), "str": strs / float(n), "segdup": dup / float(n), "families": len(families)}
+
+
+def make_mapped_reads(ref, records, n, read_len=150, seed=123, err=0.005, n_rate=0.001, indel_err=0.0005, clip_frac=0.03, bad_hint_frac=0.02,
+                      region_begin=0):
+    """Reads as a mapper hands them over (make_reads draws the clean case): substitutions and Ns as there, plus per base `indel_err`
+    single-base insertions / deletions (the read stays read_len long: bases behind the event shift), `clip_frac` of the reads with
+    5-30 bases of foreign sequence at one end (a soft clip: the mapper's POS is the first ALIGNED base, so the read's first base lies
+    that many positions in front of it -- the hint is made the way gtx_stream_push makes it, POS minus the leading clip), and
+    `bad_hint_frac` of the hints wrong: half of them off by 1-40 positions, half somewhere else in the region.  Returns (codes,
+    hint pos0, {"indel_reads": k, "clipped": k, "bad_hints": k})."""
+    rng = np.random.default_rng(seed)
+    codes, pos = make_reads(ref, records, n, read_len=read_len + 8, seed=seed, err=err, n_rate=n_rate, region_begin=region_begin)
+    out = codes[:, :read_len].copy()
+    # ---- indel errors: one event per affected read
+    has = np.nonzero(rng.random(n) < 1.0 - (1.0 - indel_err) ** read_len)[0]
+    if len(has):
+        at = rng.integers(1, read_len - 1, size=len(has))
+        ins = rng.random(len(has)) < 0.5
+        j = np.arange(read_len)[None, :]
+        src = np.where(ins[:, None], j - (j > at[:, None]), j + (j >= at[:, None]))  # an inserted base shifts what follows back, a deleted one forward
+        rows = codes[has[:, None], src]
+        new_base = _CODE_OF_BASE[rng.integers(0, 4, size=len(has))]
+        rows[ins, at[ins]] = new_base[ins]
+        out[has] = rows
+    # ---- soft clips
+    clipped = np.nonzero(rng.random(n) < clip_frac)[0]
+    if len(clipped):
+        k = rng.integers(5, 31, size=len(clipped))
+        front = rng.random(len(clipped)) < 0.5
+        j = np.arange(read_len)[None, :]
+        mask = np.where(front[:, None], j < k[:, None], j >= read_len - k[:, None])  # (the other bases keep their places: the hint stays the read's first base)
+        junk = _CODE_OF_BASE[rng.integers(0, 4, size=(len(clipped), read_len))]
+        out[clipped] = np.where(mask, junk, out[clipped])
+    # ---- wrong hints
+    hint = pos.copy()
+    bad = np.nonzero(rng.random(n) < bad_hint_frac)[0]
+    near = bad[: len(bad) // 2]
+    hint[near] += rng.integers(1, 41, size=len(near)) * rng.choice([-1, 1], size=len(near))
+    far = bad[len(bad) // 2:]
+    hint[far] = rng.integers(0, len(ref) - read_len, size=len(far)) + region_begin
+    hint = np.clip(hint, region_begin, region_begin + len(ref) - read_len)
+    return out, hint, {"indel_reads": int(len(has)), "clipped": int(len(clipped)), "bad_hints": int(len(bad))}
