@@ -30,6 +30,12 @@ constexpr uint64_t PROF_LOG_ENTRIES = 1u << 16, PROF_LOG_ENTRY = 16;
 constexpr uint64_t PROF_LOG_ENTRIES = 0, PROF_LOG_ENTRY = 16;
 #endif
 constexpr uint64_t PROF_WORDS = 40 + PROF_LOG_ENTRIES * PROF_LOG_ENTRY;
+#ifndef GTX_BIG_BLOCKS_PER_CU
+#define GTX_BIG_BLOCKS_PER_CU 8u // workgroups (one wavefront, one workspace of 0.7 MB in HBM each) of the HBM-table pass per CU: 1.4 GB per call scratch
+#endif
+#ifndef GTX_EXACT_PARTS_MAX
+#define GTX_EXACT_PARTS_MAX 1024u // the most parts the exact pass' first launch cuts its slab into
+#endif
 
 // Scoring adds small integers to per-(haplotype, sample) counters, and the reads of a workgroup -- neighbours in a
 // position-sorted stream -- hit the same few counters: 1 500 reads deep, every counter of a site would take thousands of
@@ -1434,7 +1440,14 @@ int ctx_upload(gtx_ctx & c, int device)
   if (ok && !c.params.no_second_pass)
   {
     // HBM-table pass: one workspace per workgroup (one workgroup per CU is plenty for the few queued reads), arena
-    c.big_blocks = have_prop ? static_cast<uint32_t>(prop.multiProcessorCount) : 256u;
+    // (GTX_BIG_BLOCKS_PER_CU: A/B switch.  One workgroup per CU was "plenty for the few queued reads" of an i.i.d. reference; on a
+    //  reference with repeats tens of thousands of tasks come this far, every one a chain of dependent round trips to HBM, and the
+    //  pass' throughput is the number of tasks in flight)
+    {
+      char const * bb = std::getenv("GTX_BIG_BLOCKS_PER_CU");
+      uint32_t const per_cu = bb && std::atoi(bb) > 0 ? static_cast<uint32_t>(std::min(std::atoi(bb), 16)) : GTX_BIG_BLOCKS_PER_CU;
+      c.big_blocks = (have_prop ? static_cast<uint32_t>(prop.multiProcessorCount) : 256u) * per_cu;
+    }
     c.big_record_words = c.params.big_record_words ? c.params.big_record_words : (16ull << 20);
     // exact pass: the slab of a call in flight, and the walk candidates one task of this graph can have alive
     {
@@ -1443,12 +1456,14 @@ int ctx_upload(gtx_ctx & c, int device)
         widest = std::max(widest, n);
       c.exact_cand_cap = exact::exact_cand_cap(widest);
       char const * xm = std::getenv("GTX_EXACT_PASS_MB");
-      uint64_t mb = c.params.exact_pass_mb ? c.params.exact_pass_mb : (xm && std::atol(xm) > 0) ? static_cast<uint64_t>(std::atol(xm)) : (c.has_wide_sites ? 1024u : 512u);
+      uint64_t mb = c.params.exact_pass_mb ? c.params.exact_pass_mb : (xm && std::atol(xm) > 0) ? static_cast<uint64_t>(std::atol(xm)) : (c.has_wide_sites ? 4096u : 2048u);
       c.exact_slab_bytes = mb << 20;
-      // at most 256 parts, none smaller than 2 MB (32 MB where allele sets are wide); the kernel makes as many as there are tasks:
+      // at most 1 024 parts, none smaller than 2 MB (32 MB where allele sets are wide); the kernel makes as many as there are tasks:
       // the tasks that come this far come in bulk -- every read over one long repeat -- and what one task takes is milliseconds
       // of dependent round trips
-      c.exact_parts = static_cast<uint32_t>(std::min<uint64_t>(256u, std::max<uint64_t>(1u, mb / (c.has_wide_sites ? 32u : 2u))));
+      char const * xq = std::getenv("GTX_EXACT_PARTS_MAX"); // (A/B switch: the most parts of the first launch)
+      uint64_t const most_parts = xq && std::atol(xq) > 0 ? static_cast<uint64_t>(std::min<long>(std::atol(xq), 4096)) : GTX_EXACT_PARTS_MAX;
+      c.exact_parts = static_cast<uint32_t>(std::min<uint64_t>(most_parts, std::max<uint64_t>(1u, mb / (c.has_wide_sites ? 32u : 2u))));
       if (char const * xp = std::getenv("GTX_EXACT_PARTS")) // (tests: smaller parts, so that tasks reach the launch with the whole slab)
         if (std::atol(xp) > 0)
         {

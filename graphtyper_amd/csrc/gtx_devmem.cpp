@@ -61,7 +61,7 @@ hipError_t dev_malloc(void ** p, size_t bytes)
     if (c.limit == 0)
     {
       char const * env = std::getenv("GTX_DEVICE_CACHE_MB");
-      long long const mb = env ? std::atoll(env) : 8192; // (a negative value keeps nothing: it must not become a huge unsigned limit)
+      long long const mb = env ? std::atoll(env) : 32768; // (32 GB of 288: a context in flight holds 1.4 GB of workspaces per call scratch and 2 GB slabs) // (a negative value keeps nothing: it must not become a huge unsigned limit)
       c.limit = static_cast<size_t>(mb < 0 ? 0 : mb) << 20;
       if (c.limit == 0)
         c.limit = 1; // (0 MB: nothing is kept)

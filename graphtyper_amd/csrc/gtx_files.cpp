@@ -804,7 +804,11 @@ extern "C" int gtx_graph_from_files(const char * fasta_path, const char * vcf_pa
     {
       indexed = true;
       if (any)
+      {
         z = gtx::gz_open_at(vcf_path, voffset);
+        if (!z) // (the offset is not a member's start: an index that does not belong to this file -- the whole file is read)
+          indexed = false;
+      }
     }
     if (!indexed)
       z = gzopen(vcf_path, "rb"); // reads plain text as well; bgzip files are concatenated gzip members

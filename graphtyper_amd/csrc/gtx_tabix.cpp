@@ -22,6 +22,7 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 namespace gtx
@@ -248,6 +249,13 @@ bool tabix_start(std::string const & vcf_path, std::string const & chrom, int64_
       return false;
     csi = true;
   }
+  // An index older than its file describes another file: the VCF was written again and the offsets mean nothing (records of the
+  // region would silently be left out of the graph).  Not usable -- the caller scans the file.
+  {
+    struct stat sv{}, si{};
+    if (::stat(vcf_path.c_str(), &sv) != 0 || ::stat((vcf_path + (csi ? ".csi" : ".tbi")).c_str(), &si) != 0 || si.st_mtime < sv.st_mtime)
+      return false;
+  }
   Cursor c{raw};
   char magic[4];
   for (char & m : magic)
@@ -356,7 +364,10 @@ gzFile gz_open_at(std::string const & path, uint64_t voffset)
   int const fd = ::open(path.c_str(), O_RDONLY);
   if (fd < 0)
     return nullptr;
-  if (::lseek(fd, static_cast<off_t>(voffset >> 16), SEEK_SET) < 0)
+  // (what the index points at has to be the start of a BGZF member: gzip magic, the extra field with the BC subfield)
+  uint8_t h[18];
+  if (::lseek(fd, static_cast<off_t>(voffset >> 16), SEEK_SET) < 0 || ::read(fd, h, 18) != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4) ||
+      h[12] != 'B' || h[13] != 'C' || ::lseek(fd, static_cast<off_t>(voffset >> 16), SEEK_SET) < 0)
   {
     ::close(fd);
     return nullptr;

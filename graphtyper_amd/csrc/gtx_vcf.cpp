@@ -505,6 +505,10 @@ bool call_from_depth(SvEntry const & sv, uint32_t const * depth, uint32_t n_dept
       call.ad = {u16(std::lround(centre)), 0};
     else if (gain >= 2 * m_in)
       call.ad = {0, u16(std::lround(centre))};
+    else if (m_out == 0)
+      // (no depth at all on the flanks: the reference divides by it, sample_call.cpp:338 -- (1 - inf) * centre, rounded and clamped,
+      //  is 0 on the machines it runs on; said here instead of left to lround(-inf))
+      call.ad = {0, u16(static_cast<long>(centre))};
     else
     {
       uint16_t const r = u16(std::lround((1.0 - static_cast<double>(gain) / static_cast<double>(m_out)) * centre));

@@ -158,7 +158,7 @@ typedef struct gtx_params
   uint32_t big_record_words;             /* capacity of the big-record arena in uint32 words, 0 = 16 Mi */
   uint32_t exact_pass_mb;                /* MiB of HBM per slab of the exact alignment pass, of which a context makes one per batch in flight, up to four (gtx_align_batch: the
                                           * pass whose tables have no fixed size), 0 = the GTX_EXACT_PASS_MB environment
-                                          * variable, else 512 (1024 for a graph with a site of more than 64 alleles) */
+                                          * variable, else 2048 (4096 for a graph with a site of more than 64 alleles): up to 1 024 tasks of a repeat side by side */
 } gtx_params;
 
 /* One KmerLabel (include/graphtyper/index/kmer_label.hpp:13-41) */

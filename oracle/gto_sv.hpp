@@ -224,6 +224,13 @@ inline SampleCall make_call_based_on_coverage(long pn_index, SV const & sv, Refe
       call.coverage.push_back(0);
       call.coverage.push_back(get_uint16(std::lround(cmed)));
     }
+    else if (median_out == 0)
+    {
+      // sample_call.cpp:338 divides by median_out; with no depth on the flanks that is (1 - inf) * cmed, whose rounding is undefined
+      // in C++ and 0 after get_uint16's clamp on the machines the reference runs on: said here, the second value as the line below
+      call.coverage.push_back(0);
+      call.coverage.push_back(get_uint16(static_cast<long>(cmed)));
+    }
     else
     {
       double const frac = static_cast<double>(dmed) / static_cast<double>(median_out);

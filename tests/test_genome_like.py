@@ -33,5 +33,7 @@ def test_genome_like_reads_on_the_emulation():
 
 @pytest.mark.gpu
 def test_genome_like_reads_on_the_device():
+    import torch  # (before libgtx is loaded: one HIP runtime in the process, torch's)
+    assert torch.cuda.is_available()
     share = genome_like_case(harness.GpuBackend, n_ref=400000, n_reads=20000)
     assert 0.2 < share < 0.99, share

@@ -121,6 +121,8 @@ def test_sites_of_an_unobserved_region_are_empty():
 def test_second_iteration_on_the_device(kind):
     """the same loop through the C ABI on the GPU: iteration 1's sites (== the oracle's) make iteration 2's graph and index, built on
     the device; its alignments, scores, calls, VCF text and sites equal the oracle's of that graph"""
+    import torch  # (before libgtx is loaded: one HIP runtime in the process, torch's)
+    assert torch.cuda.is_available()
     rb = 310000
     ref, recs, codes, rec, n_samples, b, text = first_iteration(kind, harness.GpuBackend, rb)
     sites = parse_sites(text)
