@@ -1204,7 +1204,9 @@ static std::unique_ptr<CallScratch> scratch_new(gtx_ctx & c)
   {
     s->d_big_state = s->d_counters + 8 * CallScratch::MAX_PARTS;
     void * ws = nullptr;
-    ok = ok && hip_ok(gtx::dev_malloc(&ws, static_cast<size_t>(c.big_blocks) * sizeof(big::AlignWorkspace)), "second-pass workspaces");
+    // (workspaces for a small batch -- one workgroup per CU; a large batch grows them to c.big_blocks: align_planes)
+    s->big_blocks = std::min<uint32_t>(c.big_blocks, static_cast<uint32_t>(c.n_cu > 0 ? c.n_cu : 256));
+    ok = ok && hip_ok(gtx::dev_malloc(&ws, static_cast<size_t>(s->big_blocks) * sizeof(big::AlignWorkspace)), "second-pass workspaces");
     s->d_big_ws = ws;
     if (ok && c.has_wide_sites)
     {
@@ -1458,6 +1460,7 @@ int ctx_upload(gtx_ctx & c, int device)
       char const * xm = std::getenv("GTX_EXACT_PASS_MB");
       uint64_t mb = c.params.exact_pass_mb ? c.params.exact_pass_mb : (xm && std::atol(xm) > 0) ? static_cast<uint64_t>(std::atol(xm)) : (c.has_wide_sites ? 4096u : 2048u);
       c.exact_slab_bytes = mb << 20;
+      c.exact_mb_given = c.params.exact_pass_mb != 0 || (xm && std::atol(xm) > 0);
       // at most 1 024 parts, none smaller than 2 MB (32 MB where allele sets are wide); the kernel makes as many as there are tasks:
       // the tasks that come this far come in bulk -- every read over one long repeat -- and what one task takes is milliseconds
       // of dependent round trips
@@ -1605,29 +1608,50 @@ extern "C" int gtx_reads_to_planes(gtx_ctx * c, const uint8_t * d_seq, uint32_t 
 
 // the slab a call's exact launches use (gtx_ctx::exact_slot); c.exact_mutex is held by the caller.  *wait: the call's stream has
 // to wait for the slab's event first (every slab is busy)
-static gtx_ctx::ExactSlot const * exact_slot_for_call(gtx_ctx & c, bool * wait)
+// The slab a call of `n_reads` reads gets.  A large batch (a whole region's reads of a sample: HBM_SMALL_BATCH and more) gets the
+// context's slab -- 2 GB by default, up to 1 024 tasks of a repeat side by side --, a small one (a 50 kb region, a chunk of a host
+// thread's stream) a quarter of it: a context that lives for a millisecond must not pay for 2 GB, and the tasks of a small batch
+// that come this far are few.  (gtx_params::exact_pass_mb given: always that.)  A slot is as large as the first call that made it
+// needed; a larger call takes an idle slot that is large enough, makes one, or makes do with the one it has to wait for -- the
+// launches are told the bytes they really have.
+static uint64_t exact_slab_for(gtx_ctx const & c, uint32_t n_reads)
+{
+  if (c.exact_mb_given || n_reads >= gtx_ctx::HBM_SMALL_BATCH)
+    return c.exact_slab_bytes;
+  return std::max<uint64_t>(c.exact_slab_bytes / 4, 64ull << 20);
+}
+
+static gtx_ctx::ExactSlot const * exact_slot_for_call(gtx_ctx & c, uint64_t want, bool * wait)
 {
   *wait = false;
+  gtx_ctx::ExactSlot * idle_small = nullptr;
   for (int k = 0; k < c.n_exact_slots; ++k)
     if (hipEventQuery(static_cast<hipEvent_t>(c.exact_slot[k].idle)) == hipSuccess)
-      return &c.exact_slot[k];
+    {
+      if (c.exact_slot[k].bytes >= want)
+        return &c.exact_slot[k];
+      idle_small = &c.exact_slot[k];
+    }
   if (c.n_exact_slots < gtx_ctx::EXACT_SLOTS)
   {
     void * p = nullptr;
     hipEvent_t ev = nullptr;
-    bool ok = hip_ok(gtx::dev_malloc(&p, c.exact_slab_bytes), "exact pass slab");
+    bool ok = hip_ok(gtx::dev_malloc(&p, want), "exact pass slab");
     if (ok)
       c.dev_allocs.push_back(p);
     ok = ok && hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "exact pass event");
     if (ok)
     {
       c.exact_slot[c.n_exact_slots].slab = static_cast<uint8_t *>(p);
+      c.exact_slot[c.n_exact_slots].bytes = want;
       c.exact_slot[c.n_exact_slots].idle = ev;
       return &c.exact_slot[c.n_exact_slots++];
     }
     if (c.n_exact_slots == 0)
       return nullptr;
   }
+  if (idle_small)
+    return idle_small; // (smaller than asked for, but free now)
   *wait = true;
   c.next_exact_slot = (c.next_exact_slot + 1) % c.n_exact_slots;
   return &c.exact_slot[c.next_exact_slot];
@@ -2010,7 +2034,17 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     a.big_tasks = s->d_big_tasks;
     a.big_task_cap = s->big_task_cap;
     a.big_state = s->d_big_state;
-    a.big_blocks = c->big_blocks;
+    // (a large batch: the HBM-table pass with all its workgroups -- the workspaces grow once, the scratch is this call's)
+    if (n_reads >= gtx_ctx::HBM_SMALL_BATCH && s->big_blocks < c->big_blocks)
+    {
+      void * ws = nullptr;
+      if (!hip_ok(gtx::dev_malloc(&ws, static_cast<size_t>(c->big_blocks) * big_workspace_bytes()), "second-pass workspaces"))
+        return GTX_ERR_HIP;
+      (void)gtx::dev_free(s->d_big_ws);
+      s->d_big_ws = ws;
+      s->big_blocks = c->big_blocks;
+    }
+    a.big_blocks = n_reads >= gtx_ctx::HBM_SMALL_BATCH ? s->big_blocks : std::min<uint32_t>(s->big_blocks, static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256));
     a.big_ws = s->d_big_ws;
     a.wide_tasks = s->d_wide_tasks;
     a.wide_state = s->d_wide_state;
@@ -2034,12 +2068,15 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
       // critical section (the next call's wait has to see this call's record)
       std::lock_guard<std::mutex> lock(c->exact_mutex);
       bool wait = false;
-      gtx_ctx::ExactSlot const * slot = exact_slot_for_call(*c, &wait);
+      gtx_ctx::ExactSlot const * slot = exact_slot_for_call(*c, exact_slab_for(*c, n_reads), &wait);
       if (!slot)
         return GTX_ERR_HIP;
       if (wait)
         (void)hipStreamWaitEvent(sg, static_cast<hipEvent_t>(slot->idle), 0);
       a.exact_slab = slot->slab;
+      a.exact_slab_bytes = slot->bytes;
+      if (!c->exact_fixed_parts) // (as many parts as the slab has room for: none smaller than 2 MB, 32 MB where allele sets are wide)
+        a.exact_parts = static_cast<uint32_t>(std::min<uint64_t>(c->exact_parts, std::max<uint64_t>(1u, (slot->bytes >> 20) / (c->has_wide_sites ? 32u : 2u))));
       what = launch_exact_passes(a, sg);
       (void)hipEventRecord(static_cast<hipEvent_t>(slot->idle), sg);
     }

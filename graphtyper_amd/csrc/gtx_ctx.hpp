@@ -53,6 +53,7 @@ struct CallScratch
   uint32_t big_task_cap = 0;
   uint32_t * d_big_state = nullptr; // [0] tasks queued, [1] claim cursor, [3] tasks dropped (list full)
   void * d_big_ws = nullptr;
+  uint32_t big_blocks = 0;   // workspaces d_big_ws holds (grown to gtx_ctx::big_blocks by the first large batch)
   // wide-site pass (graphs with a site of more than 64 alleles only): tasks that met an allele number >= 64
   uint32_t * d_wide_tasks = nullptr;
   uint32_t * d_wide_state = nullptr; // inside d_big_state's allocation (same layout)
@@ -90,7 +91,9 @@ struct gtx_ctx
   int express4_wide_blocks_per_cu = 8;
   uint32_t score_blocks_per_cu = 8;  // resident 256-thread workgroups of gtx_score_kernel per CU
   bool express4_wide = false; // pass 1 runs gtx_align_express4_wide_kernel (express4_prefers_wide, gtx_flat.hpp)
-  uint32_t big_blocks = 0;
+  uint32_t big_blocks = 0;       // workgroups (= workspaces) of the HBM-table pass for a large batch; a small one gets n_cu (HBM_SMALL_BATCH)
+  static constexpr uint32_t HBM_SMALL_BATCH = 1u << 20; // reads: below this a call takes the small configuration of the passes behind the general one
+  bool exact_mb_given = false;   // gtx_params::exact_pass_mb / GTX_EXACT_PASS_MB: every call gets that slab
   bool has_wide_sites = false; // some site has more than 64 alleles: the wide-site passes (alignment, scoring) exist
   // slab of the exact alignment pass (gtx_params::exact_pass_mb / GTX_EXACT_PASS_MB).  The context owns up to EXACT_SLOTS of them,
   // each with an event behind the exact launches of the last call that used it.  A call takes the first slab whose event is
@@ -102,6 +105,7 @@ struct gtx_ctx
   struct ExactSlot
   {
     uint8_t * slab = nullptr;
+    uint64_t bytes = 0;    // (a slot made for a small batch is a quarter of the size: see exact_slab_for)
     void * idle = nullptr; // hipEvent_t behind the slab's last exact launches
   };
   static constexpr int EXACT_SLOTS = 4;

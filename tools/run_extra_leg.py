@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One `extra` leg of bench.py on its own (for kernel traces: rocprofv3 --kernel-trace --stats -- python tools/run_extra_leg.py repeats).
-Usage: python tools/run_extra_leg.py {repeats|genome_like|long_reads|cfg5|cfg3|clusters|pipeline|pipeline64|shrink} [bench.py arguments]"""
+Usage: python tools/run_extra_leg.py {repeats|regions|genome_like|long_reads|cfg5|cfg3|clusters|pipeline|pipeline64|shrink} [bench.py arguments]"""
 import json
 import os
 import sys
@@ -26,6 +26,8 @@ elif leg in ("pipeline", "pipeline64"):  # BAM files -> VCF text on 16 / 64 host
     out.pop("what", None)
 elif leg == "shrink":
     out = bench.extra_shrink(args, torch, gtx, synth, device, ref, records)
+elif leg == "regions":
+    out = bench.extra_regions(args, torch, gtx, synth, device, ref)
 elif leg == "genome_like":
     out = bench.extra_genome_like(args, torch, gtx, synth, device)
 elif leg == "cfg5":
