@@ -1264,6 +1264,19 @@ def extra_genome_like(args, torch, gtx, synth, device):
     out = extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False, what, lanes=1, big_record_words=1 << 27, make_reads=make)
     out["reads_made"] = made.get(5)
     out["reference"] = stats
+    if not args.no_cpu_baseline:  # the oracle on a sample of THESE reads, one host core: what the device rate of this leg stands beside
+        try:
+            from oracle_lib import Oracle, pack_reads
+            codes, hint, _ = synth.make_mapped_reads(ref, recs, 20000, seed=5, region_begin=REGION_BEGIN)
+            order = np.argsort(hint, kind="stable")
+            g = Oracle(synth.bases_to_str(ref), recs, region_begin=REGION_BEGIN).genotyper(1, 1)
+            packed = pack_reads(list(codes[order]))
+            t0 = time.perf_counter()
+            g.push(None, pos=np.ascontiguousarray(hint[order], np.int64), packed=packed)
+            one = time.perf_counter() - t0
+            out["cpu_oracle"] = {"reads_per_s": 20000 / one, "cores": 1, "sample": "20 000 reads of this leg's kind through oracle/, 1 thread, %.1f s" % one}
+        except Exception as e:
+            out["cpu_oracle"] = {"error": repr(e)}
     return out
 
 
