@@ -202,6 +202,7 @@ def test_cfg2_every_read_against_the_oracle():
     assert ctx.error_count() == 0
     text, calls = w.vcf_text()
     assert hashlib.sha256(text).hexdigest() == digest["vcf_sha256"]
+    final = w.vcf_final_text()
     # the product's accumulators in the oracle's canonical form
     acc = harness.Accumulators(ctx, 1, conn_cap=1)
     nh, ta = ctx.n_hap, ctx.total_allele
@@ -240,7 +241,6 @@ def test_cfg2_every_read_against_the_oracle():
         raise AssertionError("VCF text differs (%d vs %d lines), first at line %s" % (len(gl), len(wl), first))
     assert hashlib.sha256(want_text).hexdigest() == digest["vcf_sha256"]
     # ... and the file genotype() ends with: vcf_merge_and_break with the variants broken down (a SNP graph: no site needs paw::Skyr)
-    final = w.vcf_final_text()
     want_final = og.vcf_records_final("chr20", w_names(1), ref_str, REGION_BEGIN + 1)
     assert final == want_final and hashlib.sha256(final).hexdigest() == digest["final_vcf_sha256"]
     assert 0 < final.count(b"\n") - 1 <= len(records)
