@@ -1022,7 +1022,8 @@ def extra_regions(args, torch, gtx, synth, device, ref, n_regions=20, region_len
     plane rows before the clock starts).  Per region: gtx_graph_build -> gtx_ctx_create (index build) -> gtx_align_batch_planes
     -> gtx_score_batch_flags -> gtx_calls_batch -> download -> gtx_vcf_records.  Once one region after the other, once with
     the next region's graph + context built on a second host thread while the current region's reads run, once with two
-    builder threads ahead and the VCF text of the region before on a thread of its own."""
+    builder threads ahead and the VCF text of the region before on a thread of its own, and once by gtx_regions_run -- the same
+    six calls per region on the library's own stage threads (the variant records handed over as gtx_record arrays)."""
     import threading
     L = gtx.lib()
     n = depth * n_samples * region_len // READ_LEN
@@ -1183,19 +1184,54 @@ def extra_regions(args, torch, gtx, synth, device, ref, n_regions=20, region_len
             raise errors[0]
         return time.perf_counter() - t0, t, texts
 
+    def run_in_the_library(builders, device_threads, text_threads, times=1):
+        """the same six calls per region made by gtx_regions_run's own threads (no interpreter between the stages); times > 1: the
+        20 regions that many times over in one call (what a chromosome's 1 200 regions are to the stages: the pipeline stays full)"""
+        if first:
+            run(False)
+        jobs = gtx.RegionJobs([dict(reference=q["ref_str"], region_begin=q["rb"], records=q["recs"], d_planes=q["d_planes"].data_ptr(), plane_stride=80,
+                                    d_meta=q["d_meta"].data_ptr(), n_reads=n, d_items=q["d_items"].data_ptr(), n_items=n) for q in regions * times])
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            texts_l, st = jobs.run(names, contig="chr20", device=device.index or 0, rec_words=REC_WORDS, builders=builders, device_threads=device_threads,
+                                   text_threads=text_threads)
+            wall = time.perf_counter() - t0
+            if best is None or wall < best[0]:
+                best = (wall, st, texts_l)
+        return best
+
     run(False)  # (warm-up: module load, first scratch, allocator)
     wall_seq, t_seq, texts = run(False)
     wall_two, t_two, texts2 = run(True)
-    wall_ovl, t_ovl, texts3 = run_three_stages()
-    if wall_two < wall_ovl:  # (what is reported is the faster of the two overlapped forms)
-        wall_ovl, t_ovl, texts3 = wall_two, t_two, texts2
+    wall_three, t_three, texts3 = run_three_stages()
+    wall_ovl = min(wall_two, wall_three)  # (what is reported is the fastest of the overlapped forms)
+    in_lib = {}
+    texts4 = texts
+    shapes = [(4, 2, 3), (6, 2, 4), (8, 3, 4), (2, 1, 1)]
+    if os.environ.get("GTX_REGIONS_THREADS"):
+        shapes = [tuple(int(x) for x in os.environ["GTX_REGIONS_THREADS"].split(","))]
+    for shape in shapes:
+        wall_l, st_l, tx = run_in_the_library(*shape)
+        in_lib["%d builders, %d device threads, %d text threads" % shape] = {
+            "regions_per_s": n_regions / wall_l, "wall_s": wall_l, "stage_s": {k: round(v, 4) for k, v in st_l.items() if k.endswith("_s") and k != "wall_s"},
+            "same_text": bool(tx == texts)}
+        if wall_l < wall_ovl:
+            wall_ovl, texts4 = wall_l, tx
+    best_shape = max(shapes, key=lambda sh: in_lib["%d builders, %d device threads, %d text threads" % sh]["regions_per_s"])
+    wall_many, st_many, tx_many = run_in_the_library(*best_shape, times=10)
+    in_lib["the 20 regions ten times over in one call, %d builders, %d device threads, %d text threads" % best_shape] = {
+        "regions_per_s": 10 * n_regions / wall_many, "wall_s": wall_many, "stage_s": {k: round(v, 4) for k, v in st_many.items() if k.endswith("_s") and k != "wall_s"},
+        "same_text": bool(tx_many == texts * 10)}
     return {"what": "%d consecutive %d bp regions, %d samples at %dx (%d reads per region, resident as plane rows): variant records -> gtx_graph_build -> "
                     "gtx_ctx_create -> align + score + calls -> VCF text, wall clock" % (n_regions, region_len, n_samples, depth, n),
             "regions_per_s": n_regions / wall_ovl, "reads_per_s": n_regions * n / wall_ovl, "wall_s": wall_ovl,
             "one_after_the_other": {"regions_per_s": n_regions / wall_seq, "wall_s": wall_seq, "stage_s": {k: round(v, 4) for k, v in t_seq.items()}},
             "next_region_built_on_a_second_host_thread": {"regions_per_s": n_regions / wall_two, "wall_s": wall_two, "stage_s": {k: round(v, 4) for k, v in t_two.items()}},
-            "contexts_two_ahead_and_vcf_text_on_its_own_thread": {"wall_s": wall_ovl, "stage_s": {k: round(v, 4) for k, v in t_ovl.items()}},
-            "vcf_bytes": sum(len(x) for x in texts), "same_text_both_ways": bool(texts == texts2 and texts == texts3),
+            "contexts_two_ahead_and_vcf_text_on_its_own_thread": {"regions_per_s": n_regions / wall_three, "wall_s": wall_three, "stage_s": {k: round(v, 4) for k, v in t_three.items()}},
+            "inside_the_library_gtx_regions_run": in_lib,
+            "vcf_bytes": sum(len(x) for x in texts), "same_text_both_ways": bool(texts == texts2 and texts == texts3 and texts == texts4),
             "ms_per_region": {k: round(1e3 * v / n_regions, 3) for k, v in t_seq.items()}}
 
 

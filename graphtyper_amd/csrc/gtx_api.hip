@@ -1372,21 +1372,65 @@ int ctx_upload(gtx_ctx & c, int device)
   HostGraph const & h = c.graph;
   GraphView v = h.view();
   bool ok = true;
-  ok = ok && upload(c.dev_allocs, v.ref_order, h.ref_order.data(), h.ref_order.size(), "ref_order");
-  ok = ok && upload(c.dev_allocs, v.ref_len, h.ref_len.data(), h.ref_len.size(), "ref_len");
-  ok = ok && upload(c.dev_allocs, v.ref_dna, h.ref_dna.data(), h.ref_dna.size(), "ref_dna");
-  ok = ok && upload(c.dev_allocs, v.ref_nvar, h.ref_nvar.data(), h.ref_nvar.size(), "ref_nvar");
-  ok = ok && upload(c.dev_allocs, v.ref_first_var, h.ref_first_var.data(), h.ref_first_var.size(), "ref_first_var");
-  ok = ok && upload(c.dev_allocs, v.var_order, h.var_order.data(), h.var_order.size(), "var_order");
-  ok = ok && upload(c.dev_allocs, v.var_len, h.var_len.data(), h.var_len.size(), "var_len");
-  ok = ok && upload(c.dev_allocs, v.var_dna, h.var_dna.data(), h.var_dna.size(), "var_dna");
-  ok = ok && upload(c.dev_allocs, v.var_out_ref, h.var_out_ref.data(), h.var_out_ref.size(), "var_out_ref");
-  ok = ok && upload(c.dev_allocs, v.site_ref_reach, h.site_ref_reach.data(), h.site_ref_reach.size(), "site_ref_reach");
-  ok = ok && upload(c.dev_allocs, v.site_special_base, h.site_special_base.data(), h.site_special_base.size(), "site_special_base");
-  ok = ok && upload(c.dev_allocs, v.special_ref_reach, h.special_ref_reach.data(), h.special_ref_reach.size(), "special_ref_reach");
-  ok = ok && upload(c.dev_allocs, v.special_actual, h.special_actual.data(), h.special_actual.size(), "special_actual");
-  ok = ok && upload(c.dev_allocs, v.pos_bucket, h.pos_bucket.data(), h.pos_bucket.size(), "pos_bucket");
-  ok = ok && upload(c.dev_allocs, v.dna, h.codes.data(), h.codes.size(), "dna codes");
+  // the node tables travel as ONE block: one allocation, one copy on the context's build stream (they were 19 of each, and a
+  // region's context is made in well under a millisecond: the calls were a third of it)
+  hipStream_t const bs = gtx::tls_build_stream;
+  std::vector<uint8_t> & stage = c.upload_stage; // (lives until the stream has been waited for: gtx_ctx_create drops it)
+  size_t cursor = 0;
+  auto room = [&](size_t bytes) { size_t const at = cursor; cursor += (std::max<size_t>(bytes, 1) + 255) / 256 * 256; return at; };
+  struct Piece { size_t at; void const * src; size_t bytes; };
+  std::vector<Piece> pieces;
+  auto place = [&](void const * src, size_t bytes) { pieces.push_back({room(bytes), src, bytes}); return pieces.back().at; };
+  size_t const at_ref_order = place(h.ref_order.data(), h.ref_order.size() * sizeof(h.ref_order[0]));
+  size_t const at_ref_len = place(h.ref_len.data(), h.ref_len.size() * sizeof(h.ref_len[0]));
+  size_t const at_ref_dna = place(h.ref_dna.data(), h.ref_dna.size() * sizeof(h.ref_dna[0]));
+  size_t const at_ref_nvar = place(h.ref_nvar.data(), h.ref_nvar.size() * sizeof(h.ref_nvar[0]));
+  size_t const at_ref_first_var = place(h.ref_first_var.data(), h.ref_first_var.size() * sizeof(h.ref_first_var[0]));
+  size_t const at_var_order = place(h.var_order.data(), h.var_order.size() * sizeof(h.var_order[0]));
+  size_t const at_var_len = place(h.var_len.data(), h.var_len.size() * sizeof(h.var_len[0]));
+  size_t const at_var_dna = place(h.var_dna.data(), h.var_dna.size() * sizeof(h.var_dna[0]));
+  size_t const at_var_out_ref = place(h.var_out_ref.data(), h.var_out_ref.size() * sizeof(h.var_out_ref[0]));
+  size_t const at_site_ref_reach = place(h.site_ref_reach.data(), h.site_ref_reach.size() * sizeof(h.site_ref_reach[0]));
+  size_t const at_site_special_base = place(h.site_special_base.data(), h.site_special_base.size() * sizeof(h.site_special_base[0]));
+  size_t const at_special_ref_reach = place(h.special_ref_reach.data(), h.special_ref_reach.size() * sizeof(h.special_ref_reach[0]));
+  size_t const at_special_actual = place(h.special_actual.data(), h.special_actual.size() * sizeof(h.special_actual[0]));
+  size_t const at_pos_bucket = place(h.pos_bucket.data(), h.pos_bucket.size() * sizeof(h.pos_bucket[0]));
+  size_t const at_codes = place(h.codes.data(), h.codes.size() * sizeof(h.codes[0]));
+  size_t const at_tri_off = place(h.tri_off.data(), h.tri_off.size() * sizeof(h.tri_off[0]));
+  size_t const at_allele_off = place(h.allele_off.data(), h.allele_off.size() * sizeof(h.allele_off[0]));
+  size_t const at_near_last = place(h.near_last.data(), h.near_last.size() * sizeof(h.near_last[0]));
+  size_t const at_near_off = place(h.near_off.data(), h.near_off.size() * sizeof(h.near_off[0]));
+  stage.assign(cursor, 0);
+  for (Piece const & pc : pieces)
+    if (pc.bytes)
+      std::memcpy(stage.data() + pc.at, pc.src, pc.bytes);
+  void * block = nullptr;
+  ok = hip_ok(gtx::dev_malloc(&block, cursor), "graph tables");
+  if (ok)
+  {
+    c.dev_allocs.push_back(block);
+    ok = hip_ok(hipMemcpyAsync(block, stage.data(), cursor, hipMemcpyHostToDevice, bs), "graph tables");
+    auto at = [&](auto const *& dst, size_t off) { dst = reinterpret_cast<std::remove_reference_t<decltype(dst)>>(static_cast<uint8_t *>(block) + off); };
+    at(v.ref_order, at_ref_order);
+    at(v.ref_len, at_ref_len);
+    at(v.ref_dna, at_ref_dna);
+    at(v.ref_nvar, at_ref_nvar);
+    at(v.ref_first_var, at_ref_first_var);
+    at(v.var_order, at_var_order);
+    at(v.var_len, at_var_len);
+    at(v.var_dna, at_var_dna);
+    at(v.var_out_ref, at_var_out_ref);
+    at(v.site_ref_reach, at_site_ref_reach);
+    at(v.site_special_base, at_site_special_base);
+    at(v.special_ref_reach, at_special_ref_reach);
+    at(v.special_actual, at_special_actual);
+    at(v.pos_bucket, at_pos_bucket);
+    at(v.dna, at_codes);
+    at(v.tri_off, at_tri_off);
+    at(v.allele_off, at_allele_off);
+    at(v.near_last, at_near_last);
+    at(v.near_off, at_near_off);
+  }
   if (ok && h.pos_table_len != 0)
   {
     // position -> where its base is, how far its reference node goes on and back, which node it is: made here from the
@@ -1407,15 +1451,11 @@ int ctx_upload(gtx_ctx & c, int device)
       v.pos_back = static_cast<uint8_t *>(pb);
       v.pos_node = static_cast<uint32_t *>(pn);
       v.n_pos_info = n;
-      hipLaunchKernelGGL(gtx_pos_tables_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, v, n, static_cast<uint32_t *>(pi),
+      hipLaunchKernelGGL(gtx_pos_tables_kernel, dim3((n + 255u) / 256u), dim3(256), 0, bs, v, n, static_cast<uint32_t *>(pi),
                          static_cast<uint8_t *>(pb), static_cast<uint32_t *>(pn));
       ok = hip_ok(hipGetLastError(), "gtx_pos_tables_kernel launch");
     }
   }
-  ok = ok && upload(c.dev_allocs, v.tri_off, h.tri_off.data(), h.tri_off.size(), "tri_off");
-  ok = ok && upload(c.dev_allocs, v.allele_off, h.allele_off.data(), h.allele_off.size(), "allele_off");
-  ok = ok && upload(c.dev_allocs, v.near_last, h.near_last.data(), h.near_last.size(), "near_last");
-  ok = ok && upload(c.dev_allocs, v.near_off, h.near_off.data(), h.near_off.size(), "near_off");
   lap("graph tables");
   void * pf = nullptr;
   ok = ok && hip_ok(gtx::dev_malloc(&pf, PROF_WORDS * sizeof(unsigned long long)), "profile counters");
@@ -1520,7 +1560,8 @@ void ctx_release_device(gtx_ctx & c)
   if (c.device >= 0)
   {
     (void)hipSetDevice(c.device);
-    (void)hipDeviceSynchronize();
+    if (!c.quiet) // (gtx_regions_run has waited for the one stream that used the context: no reason to wait for the other regions')
+      (void)hipDeviceSynchronize();
   }
   for (auto & s : c.pool)
     scratch_free(*s);

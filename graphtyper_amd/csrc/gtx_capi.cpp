@@ -13,6 +13,7 @@
 #include <unordered_map>
 
 #include "gtx_ctx.hpp"
+#include "gtx_devmem.hpp"
 #include "graph_dev.hpp"
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -92,6 +93,9 @@ extern "C"
         gtx::g_last_error = "gtx_ctx_create: more than 2^31 k-mer labels in one region";
         return GTX_ERR_UNSUPPORTED;
       }
+      // (everything the device does for this context is ordered on a stream of this call's own: gtx_devmem.hpp)
+      (void)hipSetDevice(device); // (a bad index is ctx_upload's to report)
+      gtx::BuildStreamScope build_stream;
       int rc = ctx_upload(*c, device);
       lap("graph upload + scratch");
       if (rc == GTX_OK)
@@ -102,6 +106,7 @@ extern "C"
         ctx_release_device(*c);
         return rc;
       }
+      std::vector<uint8_t>().swap(c->upload_stage); // (the index build ended with a wait for the stream: the copy has been made)
       (void)hb;
     }
     *out = c.release();

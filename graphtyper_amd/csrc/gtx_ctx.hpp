@@ -84,6 +84,8 @@ struct gtx_ctx
   int device = -1; // -1: inspection-only context (no device entry point works)
   int n_cu = 0;
   std::vector<void *> dev_allocs;
+  bool quiet = false; // set by a caller that knows every launch on this context has completed (ctx_release_device then does not wait for the device)
+  std::vector<uint8_t> upload_stage; // host source of the graph tables' one asynchronous copy (ctx_upload); empty once the context is made
   gtx::GraphView dev_graph{};
   gtx::IndexView dev_index{};
   uint32_t * d_error_flag = nullptr;

@@ -110,6 +110,61 @@ hipError_t dev_free(void * p)
   return hipFree(p);
 }
 
+thread_local hipStream_t tls_build_stream = nullptr;
+
+namespace
+{
+struct StreamPool
+{
+  std::mutex m;
+  std::map<int, std::vector<hipStream_t>> idle; // per device; the streams live as long as the process
+};
+StreamPool & stream_pool()
+{
+  static StreamPool * p = new StreamPool;
+  return *p;
+}
+} // namespace
+
+BuildStreamScope::BuildStreamScope()
+{
+  before = tls_build_stream;
+  char const * off = std::getenv("GTX_BUILD_STREAM");
+  if ((off && off[0] == '0') || hipGetDevice(&device) != hipSuccess)
+  {
+    device = -1;
+    return;
+  }
+  {
+    StreamPool & sp = stream_pool();
+    std::lock_guard<std::mutex> lock(sp.m);
+    auto & v = sp.idle[device];
+    if (!v.empty())
+    {
+      stream = v.back();
+      v.pop_back();
+    }
+  }
+  if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess)
+  {
+    stream = nullptr;
+    device = -1;
+    return;
+  }
+  tls_build_stream = stream;
+}
+
+BuildStreamScope::~BuildStreamScope()
+{
+  tls_build_stream = before;
+  if (!stream)
+    return;
+  (void)hipStreamSynchronize(stream);
+  StreamPool & sp = stream_pool();
+  std::lock_guard<std::mutex> lock(sp.m);
+  sp.idle[device].push_back(stream);
+}
+
 void dev_cache_release()
 {
   DevCache & c = cache();

@@ -18,10 +18,28 @@ hipError_t dev_free(void * p);                  // back to the cache (NULL is fi
 // Zeroes device memory and returns when it IS zero.  (hipMemset on device memory returns before the fill has run, and the fill
 // runs on the null stream: a kernel on a non-blocking stream -- every stream PyTorch makes -- is not ordered behind it, so a
 // counter block "zeroed" by a plain hipMemset can be cleared in the middle of the first call that counts in it.)
+// The stream of the context that is being made on this thread (gtx_ctx_create: uploads, the index build's kernels, the zeroing of
+// what it allocates), nullptr outside of one: the work of making a context is ordered on a stream of its own, so that host
+// threads that make contexts side by side (gtx_regions_run's builders) neither queue behind each other on the null stream nor
+// wait for the regions that are running on other streams.
+extern thread_local hipStream_t tls_build_stream;
 inline hipError_t dev_zero(void * p, size_t bytes)
 {
-  hipError_t const e = hipMemsetAsync(p, 0, bytes, nullptr);
-  return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+  hipError_t const e = hipMemsetAsync(p, 0, bytes, tls_build_stream);
+  return e != hipSuccess ? e : hipStreamSynchronize(tls_build_stream);
 }
+// the same without the wait: for memory whose first user is a later launch on tls_build_stream
+inline hipError_t dev_zero_async(void * p, size_t bytes) { return hipMemsetAsync(p, 0, bytes, tls_build_stream); }
+// A non-blocking stream of the current device from a process-wide pool becomes this thread's tls_build_stream for the scope's
+// life (GTX_BUILD_STREAM=0: the null stream, as before round 5 -- A/B).  The scope's end waits for the stream.
+struct BuildStreamScope
+{
+  hipStream_t stream = nullptr, before = nullptr;
+  int device = -1;
+  BuildStreamScope();
+  ~BuildStreamScope();
+  BuildStreamScope(BuildStreamScope const &) = delete;
+  BuildStreamScope & operator=(BuildStreamScope const &) = delete;
+};
 void dev_cache_release();                       // hipFree everything the cache holds
 } // namespace gtx

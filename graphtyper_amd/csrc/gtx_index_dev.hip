@@ -51,7 +51,7 @@ struct Pool
       return nullptr;
     fine = ok_hip(gtx::dev_malloc(&p, (n ? n : 1) * sizeof(T)), what);
     if (fine && zero)
-      fine = ok_hip(gtx::dev_zero(p, (n ? n : 1) * sizeof(T)), what);
+      fine = ok_hip(gtx::dev_zero_async(p, (n ? n : 1) * sizeof(T)), what); // (its first user is a later launch on the same stream)
     if (p)
       temps.push_back(p);
     return static_cast<T *>(p);
@@ -70,7 +70,7 @@ struct Pool
   ~Pool()
   {
     if (!temps.empty())
-      (void)hipDeviceSynchronize(); // (on an error path kernels may still be writing to them; freed blocks are handed out again)
+      (void)hipStreamSynchronize(gtx::tls_build_stream); // (on an error path kernels may still be writing to them; freed blocks are handed out again)
     for (void * p : temps)
       (void)gtx::dev_free(p);
   }
@@ -495,7 +495,8 @@ template <class T>
 bool to_device(Pool & pool, T *& d, std::vector<T> const & h, char const * what)
 {
   d = pool.get<T>(h.size(), what);
-  return pool.fine && (h.empty() || ok_hip(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice), what));
+  // (asynchronous: `h` has to live until the stream has been waited for -- build_index_device's host vectors are declared in front of its pool)
+  return pool.fine && (h.empty() || ok_hip(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, gtx::tls_build_stream), what));
 }
 
 // rocPRIM primitives with their temporary storage
@@ -506,7 +507,7 @@ bool sort_pairs(Pool & pool, K const * kin, K * kout, V const * vin, V * vout, u
   if (!ok_hip(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0u, bits), "radix sort (size)"))
     return false;
   void * tmp = pool.get<uint8_t>(bytes, "radix sort storage");
-  return pool.fine && ok_hip(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0u, bits), "radix sort");
+  return pool.fine && ok_hip(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, n, 0u, bits, gtx::tls_build_stream), "radix sort");
 }
 
 bool exclusive_sum(Pool & pool, uint32_t const * in, uint32_t * out, uint32_t n)
@@ -515,7 +516,7 @@ bool exclusive_sum(Pool & pool, uint32_t const * in, uint32_t * out, uint32_t n)
   if (!ok_hip(rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, n, rocprim::plus<uint32_t>()), "scan (size)"))
     return false;
   void * tmp = pool.get<uint8_t>(bytes, "scan storage");
-  return pool.fine && ok_hip(rocprim::exclusive_scan(tmp, bytes, in, out, 0u, n, rocprim::plus<uint32_t>()), "scan");
+  return pool.fine && ok_hip(rocprim::exclusive_scan(tmp, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), gtx::tls_build_stream), "scan");
 }
 
 bool running_max(Pool & pool, uint32_t const * in, uint32_t * out, uint32_t n)
@@ -524,7 +525,7 @@ bool running_max(Pool & pool, uint32_t const * in, uint32_t * out, uint32_t n)
   if (!ok_hip(rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::maximum<uint32_t>()), "max scan (size)"))
     return false;
   void * tmp = pool.get<uint8_t>(bytes, "max scan storage");
-  return pool.fine && ok_hip(rocprim::inclusive_scan(tmp, bytes, in, out, n, rocprim::maximum<uint32_t>()), "max scan");
+  return pool.fine && ok_hip(rocprim::inclusive_scan(tmp, bytes, in, out, n, rocprim::maximum<uint32_t>(), gtx::tls_build_stream), "max scan");
 }
 
 // begin index and size of every element's group, from its head flags
@@ -535,10 +536,10 @@ bool groups_of(Pool & pool, uint32_t const * head, uint32_t n, uint32_t *& begin
   count = pool.get<uint32_t>(n, "group counts", true);
   if (!pool.fine)
     return false;
-  hipLaunchKernelGGL(k_group_begin_seed, dim3(blocks_for(n)), dim3(TB), 0, nullptr, head, n, seed);
+  hipLaunchKernelGGL(k_group_begin_seed, dim3(blocks_for(n)), dim3(TB), 0, gtx::tls_build_stream, head, n, seed);
   if (!running_max(pool, seed, begin, n))
     return false;
-  hipLaunchKernelGGL(k_group_count, dim3(blocks_for(n)), dim3(TB), 0, nullptr, begin, n, count);
+  hipLaunchKernelGGL(k_group_count, dim3(blocks_for(n)), dim3(TB), 0, gtx::tls_build_stream, begin, n, count);
   return ok_hip(hipGetLastError(), "group kernels");
 }
 } // namespace
@@ -548,6 +549,12 @@ bool groups_of(Pool & pool, uint32_t const * head, uint32_t n, uint32_t *& begin
 // keys / key_off / labels for the inspection entry points).
 int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<EmitRun> const & runs)
 {
+  // (host sources of asynchronous copies: declared in front of the pool, whose destructor waits for the stream)
+  std::vector<uint64_t> h_keys;
+  std::vector<gtx_label> h_labels;
+  std::vector<HintWindow> win;
+  std::vector<uint32_t> site_win;
+  hipStream_t const bs = gtx::tls_build_stream;
   Pool pool;
   uint32_t const n_listed = static_cast<uint32_t>(em.size());
   uint64_t const n_run_kmers = runs.empty() ? 0ull : static_cast<uint64_t>(runs.back().dev_before) + runs.back().count;
@@ -570,21 +577,21 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<Em
     return GTX_ERR_HIP;
   if (runs.empty())
   {
-    std::vector<uint64_t> h_keys(E);
-    std::vector<gtx_label> h_labels(E);
+    h_keys.resize(E);
+    h_labels.resize(E);
     for (uint32_t i = 0; i < E; ++i)
     {
       h_keys[i] = em[i].key;
       h_labels[i] = em[i].label;
     }
-    if (E != 0 && (!ok_hip(hipMemcpy(d_keys_in, h_keys.data(), E * sizeof(uint64_t), hipMemcpyHostToDevice), "emitted keys") ||
-                   !ok_hip(hipMemcpy(d_labels_in, h_labels.data(), E * sizeof(gtx_label), hipMemcpyHostToDevice), "emitted labels")))
+    if (E != 0 && (!ok_hip(hipMemcpyAsync(d_keys_in, h_keys.data(), E * sizeof(uint64_t), hipMemcpyHostToDevice, bs), "emitted keys") ||
+                   !ok_hip(hipMemcpyAsync(d_labels_in, h_labels.data(), E * sizeof(gtx_label), hipMemcpyHostToDevice, bs), "emitted labels")))
       return GTX_ERR_HIP;
   }
   else
   {
-    std::vector<uint64_t> h_keys(n_listed);
-    std::vector<gtx_label> h_labels(n_listed);
+    h_keys.resize(n_listed);
+    h_labels.resize(n_listed);
     for (uint32_t i = 0; i < n_listed; ++i)
     {
       h_keys[i] = em[i].key;
@@ -597,10 +604,10 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<Em
         !to_device(pool, d_runs, runs, "k-mer runs"))
       return GTX_ERR_HIP;
     uint32_t const n_runs = static_cast<uint32_t>(runs.size());
-    hipLaunchKernelGGL(k_emit_runs, dim3(blocks_for(n_run_kmers)), dim3(TB), 0, nullptr, c.dev_graph, d_runs, n_runs,
+    hipLaunchKernelGGL(k_emit_runs, dim3(blocks_for(n_run_kmers)), dim3(TB), 0, gtx::tls_build_stream, c.dev_graph, d_runs, n_runs,
                        static_cast<uint32_t>(n_run_kmers), d_keys_in, d_labels_in);
     if (n_listed)
-      hipLaunchKernelGGL(k_place_listed, dim3(blocks_for(n_listed)), dim3(TB), 0, nullptr, d_runs, n_runs, d_lkeys, d_llabels, n_listed, d_keys_in,
+      hipLaunchKernelGGL(k_place_listed, dim3(blocks_for(n_listed)), dim3(TB), 0, gtx::tls_build_stream, d_runs, n_runs, d_lkeys, d_llabels, n_listed, d_keys_in,
                          d_labels_in);
   }
   uint32_t n_keys = 0;
@@ -611,26 +618,26 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<Em
   if (E != 0)
   {
     // ---- group by key, keeping the emission order inside a key
-    hipLaunchKernelGGL(k_iota, dim3(blocks_for(E)), dim3(TB), 0, nullptr, d_iota, E);
+    hipLaunchKernelGGL(k_iota, dim3(blocks_for(E)), dim3(TB), 0, gtx::tls_build_stream, d_iota, E);
     if (!sort_pairs(pool, d_keys_in, d_sorted, d_iota, d_perm, E, 64))
       return GTX_ERR_HIP;
     uint32_t *d_head = pool.get<uint32_t>(E, "key heads"), *d_kidx = pool.get<uint32_t>(E, "key numbers");
     if (!pool.fine)
       return GTX_ERR_HIP;
-    hipLaunchKernelGGL(k_heads, dim3(blocks_for(E)), dim3(TB), 0, nullptr, d_sorted, E, 0u, ~0ull, d_head);
+    hipLaunchKernelGGL(k_heads, dim3(blocks_for(E)), dim3(TB), 0, gtx::tls_build_stream, d_sorted, E, 0u, ~0ull, d_head);
     if (!exclusive_sum(pool, d_head, d_kidx, E))
       return GTX_ERR_HIP;
     uint32_t last_idx = 0, last_head = 0;
-    if (!ok_hip(hipMemcpy(&last_idx, d_kidx + (E - 1), 4, hipMemcpyDeviceToHost), "key count") ||
-        !ok_hip(hipMemcpy(&last_head, d_head + (E - 1), 4, hipMemcpyDeviceToHost), "key count"))
+    if (!ok_hip(hipMemcpyAsync(&last_idx, d_kidx + (E - 1), 4, hipMemcpyDeviceToHost, bs), "key count") ||
+        !ok_hip(hipMemcpyAsync(&last_head, d_head + (E - 1), 4, hipMemcpyDeviceToHost, bs), "key count") || !ok_hip(hipStreamSynchronize(bs), "key count"))
       return GTX_ERR_HIP;
     n_keys = last_idx + last_head;
     d_keys = pool.get<uint64_t>(n_keys, "keys");
     d_key_off = pool.get<uint32_t>(n_keys + 1, "key offsets");
     if (!pool.fine)
       return GTX_ERR_HIP;
-    hipLaunchKernelGGL(k_unique, dim3(blocks_for(E)), dim3(TB), 0, nullptr, d_sorted, d_head, d_kidx, E, d_keys, d_key_off, n_keys);
-    hipLaunchKernelGGL(k_labels, dim3(blocks_for(E)), dim3(TB), 0, nullptr, c.dev_graph, d_labels_in, d_perm, E, d_labels_sorted, d_dev_labels);
+    hipLaunchKernelGGL(k_unique, dim3(blocks_for(E)), dim3(TB), 0, gtx::tls_build_stream, d_sorted, d_head, d_kidx, E, d_keys, d_key_off, n_keys);
+    hipLaunchKernelGGL(k_labels, dim3(blocks_for(E)), dim3(TB), 0, gtx::tls_build_stream, c.dev_graph, d_labels_in, d_perm, E, d_labels_sorted, d_dev_labels);
   }
   else
   {
@@ -647,7 +654,7 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<Em
   if (!pool.fine)
     return GTX_ERR_HIP;
   if (n_keys)
-    hipLaunchKernelGGL(k_exact_table, dim3(blocks_for(n_keys)), dim3(TB), 0, nullptr, d_keys, d_key_off, d_dev_labels, n_keys, d_pk, d_slots, log2_cap,
+    hipLaunchKernelGGL(k_exact_table, dim3(blocks_for(n_keys)), dim3(TB), 0, gtx::tls_build_stream, d_keys, d_key_off, d_dev_labels, n_keys, d_pk, d_slots, log2_cap,
                        d_several);
   // ---- groups by the first 16 bases (key order) and by the last 16 bases (a second stable sort)
   uint32_t hl = 2;
@@ -666,24 +673,24 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<Em
     uint32_t * d_lhead = pool.get<uint32_t>(n_keys, "left heads");
     if (!pool.fine)
       return GTX_ERR_HIP;
-    hipLaunchKernelGGL(k_heads, dim3(blocks_for(n_keys)), dim3(TB), 0, nullptr, d_keys, n_keys, 32u, 0xFFFFFFFFull, d_lhead);
+    hipLaunchKernelGGL(k_heads, dim3(blocks_for(n_keys)), dim3(TB), 0, gtx::tls_build_stream, d_keys, n_keys, 32u, 0xFFFFFFFFull, d_lhead);
     if (!groups_of(pool, d_lhead, n_keys, d_lbegin, d_lcount))
       return GTX_ERR_HIP;
-    hipLaunchKernelGGL(k_left_groups, dim3(blocks_for(n_keys)), dim3(TB), 0, nullptr, d_lbegin, d_lcount, n_keys, d_lsize);
+    hipLaunchKernelGGL(k_left_groups, dim3(blocks_for(n_keys)), dim3(TB), 0, gtx::tls_build_stream, d_lbegin, d_lcount, n_keys, d_lsize);
     uint32_t *d_low = pool.get<uint32_t>(n_keys, "low halves"), *d_low_sorted = pool.get<uint32_t>(n_keys, "low halves sorted"),
              *d_kiota = pool.get<uint32_t>(n_keys, "key iota");
     d_rhead = pool.get<uint32_t>(n_keys, "right heads");
     if (!pool.fine)
       return GTX_ERR_HIP;
-    hipLaunchKernelGGL(k_low_keys, dim3(blocks_for(n_keys)), dim3(TB), 0, nullptr, d_keys, n_keys, d_low);
-    hipLaunchKernelGGL(k_iota, dim3(blocks_for(n_keys)), dim3(TB), 0, nullptr, d_kiota, n_keys);
+    hipLaunchKernelGGL(k_low_keys, dim3(blocks_for(n_keys)), dim3(TB), 0, gtx::tls_build_stream, d_keys, n_keys, d_low);
+    hipLaunchKernelGGL(k_iota, dim3(blocks_for(n_keys)), dim3(TB), 0, gtx::tls_build_stream, d_kiota, n_keys);
     if (!sort_pairs(pool, d_low, d_low_sorted, d_kiota, d_rorder, n_keys, 32))
       return GTX_ERR_HIP;
-    hipLaunchKernelGGL(k_heads32, dim3(blocks_for(n_keys)), dim3(TB), 0, nullptr, d_low_sorted, n_keys, d_rhead);
+    hipLaunchKernelGGL(k_heads32, dim3(blocks_for(n_keys)), dim3(TB), 0, gtx::tls_build_stream, d_low_sorted, n_keys, d_rhead);
     if (!groups_of(pool, d_rhead, n_keys, d_rgbegin, d_rcount))
       return GTX_ERR_HIP;
-    hipLaunchKernelGGL(k_right_groups, dim3(blocks_for(n_keys)), dim3(TB), 0, nullptr, d_rorder, d_rgbegin, d_rcount, n_keys, d_rbegin, d_rsize);
-    hipLaunchKernelGGL(k_half_tables, dim3(blocks_for(n_keys)), dim3(TB), 0, nullptr, d_pk, d_key_off, d_lbegin, d_lsize, d_rorder, d_rhead, d_rgbegin,
+    hipLaunchKernelGGL(k_right_groups, dim3(blocks_for(n_keys)), dim3(TB), 0, gtx::tls_build_stream, d_rorder, d_rgbegin, d_rcount, n_keys, d_rbegin, d_rsize);
+    hipLaunchKernelGGL(k_half_tables, dim3(blocks_for(n_keys)), dim3(TB), 0, gtx::tls_build_stream, d_pk, d_key_off, d_lbegin, d_lsize, d_rorder, d_rhead, d_rgbegin,
                        d_rcount, n_keys, d_hlist, d_hslots, hl);
   }
   // ---- tables of the position-hinted pass
@@ -697,8 +704,6 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<Em
   bool const hints = hint_n != 0;
   uint32_t *d_f0 = pool.get<uint32_t>(hints ? (1ull << fl) : 1, "filter 0", true), *d_f1 = pool.get<uint32_t>(hints ? (1ull << fl) : 1, "filter 1", true);
   // (the allele windows continue the per-position tables behind win_base: gtx_flat.hpp)
-  std::vector<HintWindow> win;
-  std::vector<uint32_t> site_win;
   if (hints)
     hint_list_windows(c.graph, win, site_win);
   uint32_t const n_win = static_cast<uint32_t>(win.size()), win_base = hint_win_base(hint_n);
@@ -721,27 +726,27 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<Em
     uint8_t * d_same = pool.get<uint8_t>(n_keys, "neighbour verdicts");
     if (!pool.fine)
       return GTX_ERR_HIP;
-    hipLaunchKernelGGL(k_hint_graph, dim3((hint_n + TB - 1) / TB), dim3(TB), 0, nullptr, c.dev_graph, hint_n, d_base, d_room, d_back, d_tail, d_refp);
+    hipLaunchKernelGGL(k_hint_graph, dim3((hint_n + TB - 1) / TB), dim3(TB), 0, gtx::tls_build_stream, c.dev_graph, hint_n, d_base, d_room, d_back, d_tail, d_refp);
     HintKeys const t{d_keys, d_key_off, d_dev_labels, n_keys, d_lbegin, d_lsize, d_rorder, d_rbegin, d_rsize};
     if (n_keys)
     {
       char const * nbk = std::getenv("GTX_NB_KNOWN"); // test switch: 0 = no slot gets SLOT_NB_KNOWN
-      hipLaunchKernelGGL(k_judge_keys, dim3(blocks_for(n_keys)), dim3(TB), 0, nullptr, t, d_nb, d_same, d_f0, d_f1, fl, d_pk,
+      hipLaunchKernelGGL(k_judge_keys, dim3(blocks_for(n_keys)), dim3(TB), 0, gtx::tls_build_stream, t, d_nb, d_same, d_f0, d_f1, fl, d_pk,
                          (nbk && nbk[0] == '0') ? static_cast<IndexSlot *>(nullptr) : d_slots, log2_cap);
     }
-    hipLaunchKernelGGL(k_position_flags, dim3(blocks_for(hint_n)), dim3(TB), 0, nullptr, c.dev_graph, t, d_nb, d_same, d_base, d_room, d_back, hint_n, d_flags);
+    hipLaunchKernelGGL(k_position_flags, dim3(blocks_for(hint_n)), dim3(TB), 0, gtx::tls_build_stream, c.dev_graph, t, d_nb, d_same, d_base, d_room, d_back, hint_n, d_flags);
     if (n_win)
     {
       uint32_t const cells = n_win * HINT_WIN_STRIDE;
-      hipLaunchKernelGGL(k_window_cells, dim3((cells + TB - 1) / TB), dim3(TB), 0, nullptr, c.dev_graph, d_win, n_win, win_base, hint_n, d_base, d_room, d_back,
+      hipLaunchKernelGGL(k_window_cells, dim3((cells + TB - 1) / TB), dim3(TB), 0, gtx::tls_build_stream, c.dev_graph, d_win, n_win, win_base, hint_n, d_base, d_room, d_back,
                          d_tail, d_refp);
-      hipLaunchKernelGGL(k_window_flags, dim3((cells + TB - 1) / TB), dim3(TB), 0, nullptr, c.dev_graph, t, d_nb, d_same, d_base, d_room, d_back,
+      hipLaunchKernelGGL(k_window_flags, dim3((cells + TB - 1) / TB), dim3(TB), 0, gtx::tls_build_stream, c.dev_graph, t, d_nb, d_same, d_base, d_room, d_back,
                          static_cast<uint32_t>(hint_total), hint_n, d_win, n_win, win_base, d_flags);
     }
   }
   uint32_t several = 0;
-  if (!ok_hip(hipGetLastError(), "kernels") || !ok_hip(hipDeviceSynchronize(), "kernels") ||
-      !ok_hip(hipMemcpy(&several, d_several, 4, hipMemcpyDeviceToHost), "several-label counter"))
+  if (!ok_hip(hipGetLastError(), "kernels") || !ok_hip(hipMemcpyAsync(&several, d_several, 4, hipMemcpyDeviceToHost, bs), "several-label counter") ||
+      !ok_hip(hipStreamSynchronize(bs), "kernels"))
     return GTX_ERR_HIP;
   // ---- hand over
   ix.slots = pool.keep(d_slots, c.dev_allocs);

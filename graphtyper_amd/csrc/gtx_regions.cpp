@@ -1,0 +1,382 @@
+// gtx_regions.cpp -- region after region, inside the library.
+//
+// gtx_regions_run replaces the loop of genotype_regions (src/utilities/genotype.cpp:735-738: "Genotype regions serially", every
+// region a call of genotype(), :406-604) for the last iteration of a region -- the one whose graph is made of the variant records
+// the iterations before have agreed on:
+//   records -> gtx_graph_build -> gtx_ctx_create (flatten + index; builder threads, several regions ahead)
+//           -> gtx_align_batch_planes -> gtx_score_batch_flags -> gtx_calls_batch -> accumulators to the host (device threads,
+//              a stream each)
+//           -> gtx_vcf_records (text threads)
+// The reference runs the regions one after the other with its threads inside a region; a region's device work here is a third of
+// a millisecond and what the host does around it three times that, so the stages of DIFFERENT regions overlap instead: each
+// region is a job that goes through the three stages on whichever thread of the stage is free.  Every job's text depends on that
+// job's inputs only (tests/test_regions_run.py: the same bytes as the stages called one by one).
+#include "gtx_ctx.hpp"
+#include "gtx_devmem.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace
+{
+double seconds_since(std::chrono::steady_clock::time_point t0)
+{
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// what a job carries from one stage to the next
+struct Built
+{
+  uint32_t job = 0;
+  gtx_ctx * ctx = nullptr;
+};
+
+struct Scored
+{
+  uint32_t job = 0;
+  gtx_ctx * ctx = nullptr;
+  std::vector<uint32_t> gt_cov, stat_u32;
+  std::vector<uint64_t> stat_u64;
+  std::vector<uint8_t> phred;
+  std::vector<gtx_sample_call> calls;
+};
+
+// a bounded queue between two stages; close() after the producers are done lets the consumers run dry and leave
+template <class T>
+class Channel
+{
+  std::mutex m;
+  std::condition_variable not_empty, not_full;
+  std::deque<T> q;
+  size_t cap;
+  bool closed = false;
+
+public:
+  explicit Channel(size_t cap_) : cap(cap_) {}
+  void put(T && v)
+  {
+    std::unique_lock<std::mutex> lock(m);
+    not_full.wait(lock, [&] { return q.size() < cap; });
+    q.push_back(std::move(v));
+    not_empty.notify_one();
+  }
+  bool get(T & out)
+  {
+    std::unique_lock<std::mutex> lock(m);
+    not_empty.wait(lock, [&] { return !q.empty() || closed; });
+    if (q.empty())
+      return false;
+    out = std::move(q.front());
+    q.pop_front();
+    not_full.notify_one();
+    return true;
+  }
+  void close()
+  {
+    std::lock_guard<std::mutex> lock(m);
+    closed = true;
+    not_empty.notify_all();
+  }
+};
+
+void fail(gtx_region_job & j, int status, std::string const & what, std::mutex & m, std::string & first_error, int & first_status)
+{
+  j.status = status;
+  std::lock_guard<std::mutex> lock(m);
+  if (first_status == GTX_OK)
+  {
+    first_status = status;
+    first_error = what;
+  }
+}
+} // namespace
+
+extern "C" int gtx_regions_run(gtx_region_job * jobs, uint32_t n_jobs, const gtx_params * params, int device, const char * contig,
+                               const char * const * sample_names, uint32_t n_samples, uint32_t rec_words, uint32_t conn_cap,
+                               uint32_t n_builders, uint32_t n_device_threads, uint32_t n_text_threads, gtx_regions_stats * stats)
+{
+  using gtx::g_last_error;
+  if ((!jobs && n_jobs) || !params || !contig || n_samples == 0 || !sample_names || rec_words < 8)
+  {
+    g_last_error = "gtx_regions_run: bad argument";
+    return GTX_ERR_ARG;
+  }
+  if (device < 0)
+  {
+    g_last_error = "gtx_regions_run: no device given (libgtx has no CPU path)";
+    return GTX_ERR_NO_DEVICE;
+  }
+  auto const t_all = std::chrono::steady_clock::now();
+  n_builders = std::max(1u, std::min(n_builders ? n_builders : 4u, std::max(1u, n_jobs)));
+  n_device_threads = std::max(1u, std::min(n_device_threads ? n_device_threads : 2u, std::max(1u, n_jobs)));
+  n_text_threads = std::max(1u, std::min(n_text_threads ? n_text_threads : 3u, std::max(1u, n_jobs)));
+  uint64_t max_reads = 0;
+  for (uint32_t k = 0; k < n_jobs; ++k)
+  {
+    gtx_region_job & j = jobs[k];
+    j.text = nullptr;
+    j.text_len = 0;
+    j.status = GTX_OK;
+    if (!j.reference || (j.n_records && !j.records) || (j.n_reads && (!j.d_planes || !j.d_meta)) || (j.n_items && !j.d_items) || j.n_reads > 0x7FFFFFFFull ||
+        j.n_items > 0x7FFFFFFFull)
+    {
+      g_last_error = "gtx_regions_run: job " + std::to_string(k) + " lacks an input";
+      return GTX_ERR_ARG;
+    }
+    max_reads = std::max(max_reads, j.n_reads);
+  }
+  std::mutex err_m;
+  std::string first_error;
+  int first_status = GTX_OK;
+  std::atomic<uint32_t> next_job{0};
+  Channel<Built> built(2 * n_builders);
+  Channel<Scored> scored(2 * n_text_threads);
+  std::mutex stat_m;
+  gtx_regions_stats s{};
+
+  auto builder = [&]
+  {
+    double t_graph = 0, t_ctx = 0;
+    for (;;)
+    {
+      uint32_t const k = next_job.fetch_add(1);
+      if (k >= n_jobs)
+        break;
+      gtx_region_job & j = jobs[k];
+      auto t0 = std::chrono::steady_clock::now();
+      gtx_graph * g = nullptr;
+      int rc = gtx_graph_build(j.reference, j.reference_len, j.region_begin, j.region_end, j.records, j.n_records, j.add_all_variants, params->is_sv_graph, 0, &g);
+      gtx_graph_view view{};
+      if (rc == GTX_OK)
+        rc = gtx_graph_get_view(g, &view);
+      t_graph += seconds_since(t0);
+      t0 = std::chrono::steady_clock::now();
+      gtx_ctx * c = nullptr;
+      if (rc == GTX_OK)
+        rc = gtx_ctx_create(&view, params, device, &c);
+      if (g)
+        gtx_graph_destroy(g); // (the context holds its own flat copy)
+      t_ctx += seconds_since(t0);
+      if (rc != GTX_OK)
+      {
+        fail(j, rc, "gtx_regions_run: job " + std::to_string(k) + ": " + gtx_last_error(), err_m, first_error, first_status);
+        continue;
+      }
+      Built b;
+      b.job = k;
+      b.ctx = c;
+      built.put(std::move(b));
+    }
+    std::lock_guard<std::mutex> lock(stat_m);
+    s.graph_build_s += t_graph;
+    s.ctx_create_s += t_ctx;
+  };
+
+  auto device_worker = [&]
+  {
+    double t_dev = 0;
+    uint64_t failed_total = 0, refused_total = 0, dropped_total = 0;
+    hipStream_t st = nullptr;
+    void *d_rec = nullptr, *d_fl = nullptr;
+    size_t const rec_bytes = static_cast<size_t>(std::max<uint64_t>(max_reads, 1)) * 2 * rec_words * 4, fl_bytes = static_cast<size_t>(std::max<uint64_t>(max_reads, 1)) * 2;
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+              gtx::dev_malloc(&d_rec, rec_bytes) == hipSuccess && gtx::dev_malloc(&d_fl, fl_bytes) == hipSuccess;
+    Built b;
+    while (built.get(b))
+    {
+      gtx_region_job & j = jobs[b.job];
+      gtx_ctx * c = b.ctx;
+      auto const t0 = std::chrono::steady_clock::now();
+      Scored out;
+      out.job = b.job;
+      out.ctx = c;
+      gtx_score_buffers acc{};
+      void *d_phred = nullptr, *d_calls = nullptr;
+      int rc = ok ? GTX_OK : GTX_ERR_HIP;
+      std::string what = ok ? "" : "gtx_regions_run: a device thread could not get its stream / record slots";
+      gtx_score_layout lay{};
+      if (rc == GTX_OK)
+        rc = gtx_ctx_score_layout(c, &lay);
+      uint64_t const n_phred = static_cast<uint64_t>(n_samples) * lay.total_tri, n_calls = static_cast<uint64_t>(n_samples) * lay.n_hap;
+      if (rc == GTX_OK && (rc = gtx_scores_alloc(c, n_samples, conn_cap, &acc, nullptr)) != GTX_OK)
+        what = gtx_last_error();
+      if (rc == GTX_OK && (gtx::dev_malloc(&d_phred, std::max<uint64_t>(n_phred, 1)) != hipSuccess ||
+                           gtx::dev_malloc(&d_calls, std::max<uint64_t>(n_calls, 1) * sizeof(gtx_sample_call)) != hipSuccess))
+      {
+        rc = GTX_ERR_HIP;
+        what = "gtx_regions_run: device memory for the calls";
+      }
+      // (the slots are recycled from region to region: a read without a task must not show the region before's record)
+      if (rc == GTX_OK && (hipMemsetAsync(d_rec, 0, static_cast<size_t>(j.n_reads) * 2 * rec_words * 4, st) != hipSuccess ||
+                           hipMemsetAsync(d_fl, 0, static_cast<size_t>(j.n_reads) * 2, st) != hipSuccess))
+      {
+        rc = GTX_ERR_HIP;
+        what = "gtx_regions_run: hipMemsetAsync";
+      }
+      if (rc == GTX_OK && j.n_reads &&
+          (rc = gtx_align_batch_planes(c, j.d_planes, j.plane_stride, j.d_meta, static_cast<uint32_t>(j.n_reads), static_cast<uint32_t *>(d_rec), rec_words,
+                                       static_cast<uint8_t *>(d_fl), st)) != GTX_OK)
+        what = gtx_last_error();
+      if (rc == GTX_OK && j.n_items &&
+          (rc = gtx_score_batch_flags(c, j.d_items, static_cast<uint32_t>(j.n_items), static_cast<uint32_t const *>(d_rec), rec_words, static_cast<uint8_t const *>(d_fl), &acc,
+                                      st)) != GTX_OK)
+        what = gtx_last_error();
+      if (rc == GTX_OK && (rc = gtx_calls_batch(c, &acc, static_cast<uint8_t *>(d_phred), static_cast<gtx_sample_call *>(d_calls), st)) != GTX_OK)
+        what = gtx_last_error();
+      if (rc == GTX_OK)
+      {
+        out.gt_cov.resize(static_cast<size_t>(n_samples) * lay.total_allele);
+        out.stat_u64.resize(static_cast<size_t>(lay.n_hap) + 2ull * lay.total_allele);
+        out.stat_u32.resize(static_cast<size_t>(lay.n_hap) + 6ull * lay.total_allele);
+        out.phred.resize(n_phred);
+        out.calls.resize(n_calls);
+        uint32_t conn[2] = {0, 0};
+        auto down = [&](void * dst, void const * src, size_t bytes) { return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) == hipSuccess; };
+        if (!down(out.gt_cov.data(), acc.d_gt_cov, out.gt_cov.size() * 4) || !down(out.stat_u64.data(), acc.d_stat_u64, out.stat_u64.size() * 8) ||
+            !down(out.stat_u32.data(), acc.d_stat_u32, out.stat_u32.size() * 4) || !down(out.phred.data(), d_phred, out.phred.size()) ||
+            !down(out.calls.data(), d_calls, out.calls.size() * sizeof(gtx_sample_call)) || !down(conn, acc.d_conn_count, sizeof conn) ||
+            hipStreamSynchronize(st) != hipSuccess)
+        {
+          rc = GTX_ERR_HIP;
+          what = "gtx_regions_run: device to host copy";
+        }
+        // what a capacity limit dropped makes the text a wrong result: the job fails instead
+        uint64_t failed = 0;
+        uint32_t refused = 0;
+        if (rc == GTX_OK && j.n_reads && (rc = gtx_records_failed(c, static_cast<uint32_t const *>(d_rec), rec_words, j.n_reads, st, &failed)) != GTX_OK)
+          what = gtx_last_error();
+        if (rc == GTX_OK)
+          (void)gtx_ctx_error_count(c, &refused);
+        if (rc == GTX_OK && (failed || refused || conn[1]))
+        {
+          rc = GTX_ERR_CAPACITY;
+          what = "gtx_regions_run: job " + std::to_string(b.job) + " is incomplete -- " + std::to_string(failed) + " records with a table-overflow status, " +
+                 std::to_string(refused) + " score items refused, " + std::to_string(conn[1]) + " connections beyond the log";
+          failed_total += failed;
+          refused_total += refused;
+          dropped_total += conn[1];
+        }
+      }
+      if (st)
+        (void)hipStreamSynchronize(st); // (nothing of this region may still run when its blocks go back to the cache)
+      (void)gtx::dev_free(d_phred);
+      (void)gtx::dev_free(d_calls);
+      (void)gtx::dev_free(acc.d_stat_u64);
+      t_dev += seconds_since(t0);
+      if (rc != GTX_OK)
+      {
+        fail(j, rc, what, err_m, first_error, first_status);
+        gtx_ctx_destroy(c);
+        continue;
+      }
+      scored.put(std::move(out));
+    }
+    if (st)
+    {
+      (void)hipStreamSynchronize(st);
+      (void)hipStreamDestroy(st);
+    }
+    (void)gtx::dev_free(d_rec);
+    (void)gtx::dev_free(d_fl);
+    std::lock_guard<std::mutex> lock(stat_m);
+    s.device_s += t_dev;
+    s.records_failed += failed_total;
+    s.score_items_refused += refused_total;
+    s.connections_dropped += dropped_total;
+  };
+
+  auto texter = [&]
+  {
+    double t_text = 0;
+    (void)hipSetDevice(device); // (gtx_ctx_destroy gives the context's device memory back)
+    Scored sc;
+    while (scored.get(sc))
+    {
+      gtx_region_job & j = jobs[sc.job];
+      auto const t0 = std::chrono::steady_clock::now();
+      gtx_vcf_request rq{};
+      rq.contig = contig;
+      rq.sample_names = sample_names;
+      rq.n_samples = n_samples;
+      rq.region_begin = j.vcf_begin;
+      rq.region_end = j.vcf_end;
+      rq.filter_zero_qual = j.filter_zero_qual;
+      rq.gt_cov = sc.gt_cov.data();
+      rq.stat_u64 = sc.stat_u64.data();
+      rq.stat_u32 = sc.stat_u32.data();
+      rq.phred = sc.phred.data();
+      rq.calls = sc.calls.data();
+      gtx_score_layout lay{};
+      (void)gtx_ctx_score_layout(sc.ctx, &lay);
+      uint64_t cap = 4096 + static_cast<uint64_t>(lay.n_hap) * (600 + 40ull * n_samples), len = 0;
+      char * text = static_cast<char *>(std::malloc(cap));
+      int rc = text ? gtx_vcf_records(sc.ctx, &rq, text, cap, &len) : GTX_ERR_CAPACITY;
+      if (rc == GTX_OK && len > cap) // (the estimate was short: once more with what it takes)
+      {
+        std::free(text);
+        cap = len;
+        text = static_cast<char *>(std::malloc(cap));
+        rc = text ? gtx_vcf_records(sc.ctx, &rq, text, cap, &len) : GTX_ERR_CAPACITY;
+      }
+      sc.ctx->quiet = true; // (its device thread waited for the stream the region ran on)
+      gtx_ctx_destroy(sc.ctx);
+      t_text += seconds_since(t0);
+      if (rc != GTX_OK)
+      {
+        std::free(text);
+        fail(j, rc, "gtx_regions_run: job " + std::to_string(sc.job) + ": " + (text ? gtx_last_error() : "out of memory"), err_m, first_error, first_status);
+        continue;
+      }
+      j.text = text;
+      j.text_len = len;
+    }
+    std::lock_guard<std::mutex> lock(stat_m);
+    s.vcf_text_s += t_text;
+  };
+
+  std::vector<std::thread> builders, devs, texters;
+  for (uint32_t t = 0; t < n_text_threads; ++t)
+    texters.emplace_back(texter);
+  for (uint32_t t = 0; t < n_device_threads; ++t)
+    devs.emplace_back(device_worker);
+  for (uint32_t t = 0; t < n_builders; ++t)
+    builders.emplace_back(builder);
+  for (auto & t : builders)
+    t.join();
+  built.close();
+  for (auto & t : devs)
+    t.join();
+  scored.close();
+  for (auto & t : texters)
+    t.join();
+  s.n_builders = n_builders;
+  s.n_device_threads = n_device_threads;
+  s.n_text_threads = n_text_threads;
+  s.wall_s = seconds_since(t_all);
+  if (stats)
+    *stats = s;
+  if (first_status != GTX_OK)
+    g_last_error = first_error;
+  return first_status;
+}
+
+extern "C" void gtx_regions_free(gtx_region_job * jobs, uint32_t n_jobs)
+{
+  for (uint32_t k = 0; jobs && k < n_jobs; ++k)
+  {
+    std::free(jobs[k].text);
+    jobs[k].text = nullptr;
+    jobs[k].text_len = 0;
+  }
+}

@@ -29,7 +29,7 @@ EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy"
            "gtx_reads_sample_name", "gtx_reads_next", "gtx_reads_close", "gtx_align_batch_flags", "gtx_score_batch_flags", "gtx_score_batch_words", "gtx_item_words",
            "gtx_pack_planes", "gtx_reads_to_planes", "gtx_align_batch_planes", "gtx_align_batch_planes_staged", "gtx_stream_set_planes", "gtx_device_cache_release",
            "gtx_disc_create", "gtx_disc_destroy", "gtx_disc_events_batch", "gtx_disc_first_pass", "gtx_vcf_header", "gtx_bgzf_compress",
-           "gtx_shrink_params_default", "gtx_bam_shrink", "gtx_inflate_raw", "gtx_tabix_build", "gtx_tabix_start", "gtx_pipeline_run", "gtx_bam_shrink_multi", "gtx_disc_first_pass_haplotypes", "gtx_disc_merge"]
+           "gtx_shrink_params_default", "gtx_bam_shrink", "gtx_inflate_raw", "gtx_tabix_build", "gtx_tabix_start", "gtx_pipeline_run", "gtx_regions_run", "gtx_regions_free", "gtx_bam_shrink_multi", "gtx_disc_first_pass_haplotypes", "gtx_disc_merge"]
 
 
 class GraphView(C.Structure):
@@ -45,6 +45,12 @@ class PipelineStats(C.Structure):
                 ("enqueue_s", C.c_double), ("slowest_thread_s", C.c_double), ("loop_s", C.c_double), ("wall_s", C.c_double),
                 ("n_samples", C.c_uint32), ("n_threads", C.c_uint32), ("records_failed", C.c_uint64), ("score_items_refused", C.c_uint64),
                 ("connections_dropped", C.c_uint64)]
+
+
+class RegionsStats(C.Structure):
+    _fields_ = [("graph_build_s", C.c_double), ("ctx_create_s", C.c_double), ("device_s", C.c_double), ("vcf_text_s", C.c_double), ("wall_s", C.c_double),
+                ("n_builders", C.c_uint32), ("n_device_threads", C.c_uint32), ("n_text_threads", C.c_uint32), ("reserved", C.c_uint32),
+                ("records_failed", C.c_uint64), ("score_items_refused", C.c_uint64), ("connections_dropped", C.c_uint64)]
 
 
 class ShrinkParams(C.Structure):
@@ -202,6 +208,10 @@ def lib():
         L.gtx_reads_close.restype = None
         L.gtx_bam_shrink_multi.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(ShrinkParams), C.c_char_p, C.POINTER(ShrinkStats)]
         L.gtx_inflate_raw.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.gtx_regions_run.argtypes = [C.POINTER(RegionJob), C.c_uint32, C.POINTER(Params), C.c_int, C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32, C.c_uint32,
+                                      C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(RegionsStats)]
+        L.gtx_regions_free.argtypes = [C.POINTER(RegionJob), C.c_uint32]
+        L.gtx_regions_free.restype = None
         L.gtx_pipeline_run.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64,
                                        C.POINTER(ScoreBuffers), C.POINTER(PipelineStats)]
         L.gtx_tabix_build.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
@@ -299,6 +309,14 @@ class _Record(C.Structure):
     _fields_ = [("pos", C.c_uint32), ("n_alleles", C.c_uint32), ("alleles", C.POINTER(_Allele)), ("is_sv", C.c_int32)]
 
 
+class RegionJob(C.Structure):
+    _fields_ = [("reference", C.c_char_p), ("reference_len", C.c_uint64), ("region_begin", C.c_int64), ("region_end", C.c_int64),
+                ("records", C.POINTER(_Record)), ("n_records", C.c_uint32), ("add_all_variants", C.c_int32), ("d_planes", C.c_void_p),
+                ("plane_stride", C.c_uint32), ("d_meta", C.c_void_p), ("n_reads", C.c_uint64), ("d_items", C.c_void_p), ("n_items", C.c_uint64),
+                ("vcf_begin", C.c_uint32), ("vcf_end", C.c_uint32), ("filter_zero_qual", C.c_int32), ("status", C.c_int32),
+                ("text", C.c_void_p), ("text_len", C.c_uint64)]
+
+
 def _explicit_events(info, n_alts):
     """test syntax used by tests/test_graph_vectors.py: RE= / RA= (reference allele events / anti events),
     E<i>= / A<i>= (alt i); comma separated integers"""
@@ -319,12 +337,8 @@ def _explicit_events(info, n_alts):
     return ev
 
 
-def graph_from_records(reference, records, region_begin=0, region_end=0xFFFFFFFF, add_all_variants=False,
-                       extend_prefix=False, is_sv_graph=False):
-    """reference: str of the region; records: [(pos0, ref, [alts], info)] sorted by pos0 (contig coordinates, 0-based).
-    Calls gtx_graph_build (C++: filters, record merging, node emission) and returns the node tables as numpy arrays laid
-    out as gtx_graph_view expects."""
-    L = lib()
+def records_array(records):
+    """[(pos0, ref, [alts], info)] -> (array of gtx_record, what it points into: keep both alive while the array is in use)"""
     keep = []
     recs = (_Record * max(len(records), 1))()
     for i, (pos, ref, alts, info) in enumerate(records):
@@ -343,6 +357,16 @@ def graph_from_records(reference, records, region_begin=0, region_end=0xFFFFFFFF
             als[j] = _Allele(b, len(b), e, len(ev[j][0]), a, len(ev[j][1]))
         keep.append(als)
         recs[i] = _Record(pos, len(alts) + 1, als, 0)
+    return recs, keep
+
+
+def graph_from_records(reference, records, region_begin=0, region_end=0xFFFFFFFF, add_all_variants=False,
+                       extend_prefix=False, is_sv_graph=False):
+    """reference: str of the region; records: [(pos0, ref, [alts], info)] sorted by pos0 (contig coordinates, 0-based).
+    Calls gtx_graph_build (C++: filters, record merging, node emission) and returns the node tables as numpy arrays laid
+    out as gtx_graph_view expects."""
+    L = lib()
+    recs, keep = records_array(records)
     h = C.c_void_p()
     refb = reference.encode()
     check(L.gtx_graph_build(refb, len(refb), region_begin, region_end, recs, len(records), int(add_all_variants),
@@ -520,6 +544,44 @@ def pipeline_run(ctx, paths, n_threads, buf, rec_words, record_slots_per_thread,
     check(lib().gtx_pipeline_run(ctx.h, arr, len(paths), n_threads, region.encode() if region else None, chunk, rec_words, record_slots_per_thread,
                                  C.byref(buf), C.byref(st)))
     return {k: getattr(st, k) for k, _ in PipelineStats._fields_}
+
+
+class RegionJobs:
+    """the job array of gtx_regions_run.  regions: dicts with reference (str), region_begin, records [(pos0, ref, [alts], info)],
+    d_planes / d_meta / d_items (device pointers as int), plane_stride, n_reads, n_items and optionally region_end, add_all_variants,
+    vcf_begin, vcf_end, filter_zero_qual.  Built once (the conversion of the records is the caller's staging), run any number of times."""
+
+    def __init__(self, regions):
+        self.n = len(regions)
+        self.jobs = (RegionJob * max(self.n, 1))()
+        self.keep = []
+        for k, r in enumerate(regions):
+            recs, keep = records_array(r["records"])
+            refb = r["reference"].encode()
+            self.keep.extend([recs, keep, refb])
+            j = self.jobs[k]
+            j.reference, j.reference_len = refb, len(refb)
+            j.region_begin, j.region_end = r["region_begin"], r.get("region_end", 0xFFFFFFFF)
+            j.records, j.n_records = recs, len(r["records"])
+            j.add_all_variants = int(r.get("add_all_variants", False))
+            j.d_planes, j.plane_stride, j.d_meta, j.n_reads = r["d_planes"], r["plane_stride"], r["d_meta"], r["n_reads"]
+            j.d_items, j.n_items = r["d_items"], r["n_items"]
+            j.vcf_begin, j.vcf_end = r.get("vcf_begin", 0), r.get("vcf_end", 0xFFFFFFFF)
+            j.filter_zero_qual = int(r.get("filter_zero_qual", False))
+
+    def run(self, sample_names, contig="chr1", device=0, rec_words=8, conn_cap=1 << 16, builders=0, device_threads=0, text_threads=0, params=None):
+        """gtx_regions_run -> ([text of job k as bytes, or None where the job failed], statistics as a dict); raises on the first failing job's status"""
+        L = lib()
+        names = (C.c_char_p * max(1, len(sample_names)))(*[n.encode() for n in sample_names])
+        params = params or Params(75, 0, 0, 0, 0, 3840, 0, 0, 0)
+        st = RegionsStats()
+        rc = L.gtx_regions_run(self.jobs, self.n, C.byref(params), device, contig.encode(), names, len(sample_names), rec_words, conn_cap, builders,
+                               device_threads, text_threads, C.byref(st))
+        texts = [C.string_at(self.jobs[k].text, self.jobs[k].text_len) if self.jobs[k].text else None for k in range(self.n)]
+        self.status = [int(self.jobs[k].status) for k in range(self.n)]
+        L.gtx_regions_free(self.jobs, self.n)
+        check(rc)
+        return texts, {k: getattr(st, k) for k, _ in RegionsStats._fields_ if k != "reserved"}
 
 
 def tabix_build(vcf_gz, min_shift=0, index_path=None):

@@ -774,6 +774,55 @@ typedef struct gtx_pipeline_stats
 int gtx_pipeline_run(gtx_ctx *, const char * const * bam_paths, uint32_t n_paths, uint32_t n_threads, const char * region, uint32_t chunk,
                      uint32_t rec_words, uint64_t record_slots_per_thread, const gtx_score_buffers * acc, gtx_pipeline_stats * stats);
 
+/* ---- region after region, inside the library.  gtx_regions_run replaces the loop of genotype_regions
+ * (src/utilities/genotype.cpp:735-738, "Genotype regions serially": every region a call of genotype(), :406-604) for the last
+ * iteration of each region -- the graph made of the variant records the iterations before agreed on, the reads genotyped on it,
+ * the region's VCF records written: per job gtx_graph_build -> gtx_ctx_create -> gtx_align_batch_planes ->
+ * gtx_score_batch_flags -> gtx_calls_batch -> gtx_vcf_records.  The reference keeps its threads inside one region; a 50 kb
+ * region is a third of a millisecond of device work here and three times that of host work around it, so the library overlaps
+ * the stages of DIFFERENT regions: n_builders host threads make graphs and contexts ahead (0 = 4), n_device_threads threads
+ * with a stream each run the reads (0 = 2), n_text_threads write the text (0 = 3).  A job's text depends on that job's inputs
+ * only -- the same bytes as the six calls made one after the other.
+ * Per job, in: the region's reference and records as for gtx_graph_build; the reads RESIDENT on `device` as plane rows
+ * (gtx_reads_to_planes / gtx_stream_push) with their gtx_read_meta, the score items (gtx_stream_push's, align_index counted
+ * from the job's first read); vcf_begin / vcf_end / filter_zero_qual as in gtx_vcf_request.  Out: text (column line first;
+ * malloc'ed by the library, released by gtx_regions_free), text_len, status.
+ * rec_words: words of a record slot (>= 8); conn_cap: as for gtx_scores_alloc.  A job whose records, score items or connections
+ * ran into a capacity limit fails with GTX_ERR_CAPACITY (no text); the call returns the first failing job's status and goes
+ * on with the others.  Small-variant graphs (params->is_sv_graph = 0). */
+typedef struct gtx_region_job
+{
+  const char * reference;            /* [reference_len] the region's bases, reference[0] at contig position region_begin */
+  uint64_t reference_len;
+  int64_t region_begin, region_end;  /* 0-based, [begin, end) */
+  const gtx_record * records;        /* sorted by pos */
+  uint32_t n_records;
+  int32_t add_all_variants;
+  const uint8_t * d_planes;          /* device: [n_reads] plane rows */
+  uint32_t plane_stride;
+  const gtx_read_meta * d_meta;      /* device: [n_reads] */
+  uint64_t n_reads;
+  const gtx_score_item * d_items;    /* device: [n_items] */
+  uint64_t n_items;
+  uint32_t vcf_begin, vcf_end;       /* gtx_vcf_request::region_begin / region_end (1-based, inclusive) */
+  int32_t filter_zero_qual;
+  int32_t status;                    /* out */
+  char * text;                       /* out */
+  uint64_t text_len;                 /* out */
+} gtx_region_job;
+typedef struct gtx_regions_stats
+{
+  double graph_build_s, ctx_create_s, device_s, vcf_text_s; /* summed over the threads of each stage */
+  double wall_s;
+  uint32_t n_builders, n_device_threads, n_text_threads;
+  uint32_t reserved;
+  uint64_t records_failed, score_items_refused, connections_dropped; /* summed over the jobs that failed with GTX_ERR_CAPACITY */
+} gtx_regions_stats;
+int gtx_regions_run(gtx_region_job * jobs, uint32_t n_jobs, const gtx_params * params, int device, const char * contig,
+                    const char * const * sample_names, uint32_t n_samples, uint32_t rec_words, uint32_t conn_cap,
+                    uint32_t n_builders, uint32_t n_device_threads, uint32_t n_text_threads, gtx_regions_stats * stats);
+void gtx_regions_free(gtx_region_job * jobs, uint32_t n_jobs);
+
 /* ---- the read pre-filter in front of the ingest (host).  gtx_bam_shrink replaces gyper::bamshrink / bamshrink_multi
  * (src/utilities/bamshrink.cpp:1248-1371; the work is qualityFilterSlice2, :667-1045): from a coordinate-sorted BAM file it
  * writes a BAM file with the records around the intervals that the caller is going to look at -- pairs and single reads that
