@@ -936,6 +936,78 @@ extern "C"
   long gto_get_num_kmers(long len) { return static_cast<long>(get_num_kmers(static_cast<std::size_t>(len))); }
   long gto_ith_kmer_offset(long len, long i) { return static_cast<long>(get_ith_kmer_offset(len, i)); }
 
+  // ---- entry points for the hand-worked vectors of tests/test_oracle_handworked_pairs.py: the functions below have no state
+  // but their arguments, so a vector is a row of numbers and the value the reference's text gives for it.
+  // A GenotypePaths of the comparison functions as 7 numbers: read_length, longest_path_length, number of paths, mismatches of
+  // paths[0], mismatches of the other paths, and per path the number of allele sets without / with the reference allele.
+  static GenotypePaths geno_of(uint32_t const * d)
+  {
+    GenotypePaths g(0, d[0]);
+    g.longest_path_length = d[1];
+    for (uint32_t i = 0; i < d[2]; ++i)
+    {
+      Path p;
+      p.mismatches = static_cast<uint16_t>(i == 0 ? d[3] : d[4]);
+      for (uint32_t k = 0; k < d[5]; ++k)
+      {
+        p.var_order.push_back(100 + k);
+        p.nums.push_back({1});
+      }
+      for (uint32_t k = 0; k < d[6]; ++k)
+      {
+        p.var_order.push_back(200 + k);
+        p.nums.push_back({0, 1});
+      }
+      g.paths.push_back(p);
+    }
+    return g;
+  }
+  // compare_pair_of_genotype_paths(geno1, geno2) (genotype_paths.cpp:943-974); d = 2 x 7 numbers
+  int gto_compare_two(uint32_t const * d)
+  {
+    GenotypePaths a = geno_of(d), b = geno_of(d + 7);
+    return compare_pair_of_genotype_paths(a, b);
+  }
+  // compare_pair_of_genotype_paths(pair1, pair2) (genotype_paths.cpp:976-1169); d = 4 x 7 numbers: pair1.first, pair1.second,
+  // pair2.first, pair2.second
+  int gto_compare_pairs(uint32_t const * d)
+  {
+    GenotypePaths a1 = geno_of(d), a2 = geno_of(d + 7), b1 = geno_of(d + 14), b2 = geno_of(d + 21);
+    return compare_pair_of_genotype_paths(std::make_pair(&a1, &a2), std::make_pair(&b1, &b2));
+  }
+  // the record filter of SV calling (hts_parallel_reader.cpp:528-568)
+  int gto_is_good_read(uint32_t flag, int32_t tid, int32_t mtid, int64_t pos, int64_t mpos, uint32_t mapq, uint32_t n_cigar, uint32_t cigar_front,
+                       uint32_t cigar_back)
+  {
+    ReadRecord r;
+    r.flag = static_cast<uint16_t>(flag);
+    r.tid = tid;
+    r.mtid = mtid;
+    r.pos = pos;
+    r.mpos = mpos;
+    r.mapq = static_cast<uint8_t>(mapq);
+    r.n_cigar = n_cigar;
+    r.cigar_front = cigar_front;
+    r.cigar_back = cigar_back;
+    return Genotyper::is_good_read(r) ? 1 : 0;
+  }
+  // State of one (haplotype, sample) cell set by hand, for the phase flags (hts_parallel_reader.cpp:782-904 reads nothing else):
+  // gt_coverage (n_cov > 0) and the support vector of the connections from allele1 of this haplotype to haplotype hap2
+  // (n_support > 0).  Returns the haplotype's variant order (gt.id), -1 when hap / sample are out of range.
+  long gto_genotyper_poke(void * p, long hap, long sample, uint16_t const * gt_cov, long n_cov, long allele1, long hap2, uint16_t const * support,
+                          long n_support)
+  {
+    auto & haps = static_cast<GenoHandle *>(p)->g->writer.haplotypes;
+    if (hap < 0 || hap >= static_cast<long>(haps.size()) || sample < 0 || sample >= static_cast<long>(haps[hap].hap_samples.size()))
+      return -1;
+    HapSample & hs = haps[hap].hap_samples[sample];
+    if (n_cov > 0)
+      hs.gt_coverage.assign(gt_cov, gt_cov + n_cov);
+    if (n_support > 0 && allele1 >= 0 && allele1 < static_cast<long>(hs.connections.size()))
+      hs.connections[allele1][static_cast<uint16_t>(hap2)] = std::vector<uint16_t>(support, support + n_support);
+    return static_cast<long>(haps[hap].id) * 65536 + haps[hap].num;
+  }
+
   // Path(p1,p2) of two id-less labels (test/typer/test_path.cpp:50-65); out: size,start,end,n_var_order,n_nums
   void gto_path_merge_two_ref_labels(uint32_t s1, uint32_t e1, uint32_t rs1, uint32_t re1, uint32_t s2, uint32_t e2, uint32_t rs2,
                                      uint32_t re2, uint32_t * out)

@@ -118,9 +118,13 @@ def main():
     ap.add_argument("--file", nargs="*", default=["gto.hpp", "gto_vcf.hpp", "gto_sv.hpp"])
     ap.add_argument("--limit", type=int, default=0)
     ap.add_argument("--every", type=int, default=1, help="take every K-th mutant (a sample)")
+    ap.add_argument("--lines", default="", help="A-B: only the mutants on these lines (a look at one function)")
     ap.add_argument("--list", action="store_true")
     a = ap.parse_args()
     mutants = [m for f in a.file for m in mutants_of(f)][::a.every]
+    if a.lines:
+        lo, hi = (int(x) for x in a.lines.split("-"))
+        mutants = [m for m in mutants if lo <= m["line"] <= hi]
     if a.limit:
         mutants = mutants[:a.limit]
     if a.list:
@@ -146,7 +150,7 @@ def main():
     survivors = [dict(id=r["id"], func=r["func"], change="%s -> %s" % (r["find"], r["replace"]), text=r["text"]) for r in results if r["status"] == "SURVIVED"]
     out = dict(kill_suite=run_audit.KILL_SUITE, every=a.every, total=len(results), killed=sum(r["status"] == "killed" for r in results),
                survived=len(survivors), does_not_compile=sum(r["status"] == "does not compile" for r in results), per_function=by_file, survivors=survivors)
-    name = "audit_auto.json" if a.every == 1 and not a.limit and len(a.file) == 3 else "audit_auto_partial.json"
+    name = "audit_auto.json" if a.every == 1 and not a.limit and not a.lines and len(a.file) == 3 else "audit_auto_partial.json"
     json.dump(out, open(os.path.join(HERE, name), "w"), indent=1)
     open(os.path.join(HERE, name), "a").write("\n")
     print("%d mutants: %d killed, %d survived, %d do not compile  (%.0f s) -> %s" % (out["total"], out["killed"], out["survived"], out["does_not_compile"], time.time() - t0, name))

@@ -1,0 +1,284 @@
+"""Hand-worked vectors for three functions of the oracle that the mechanical mutation audit (tests/oracle_mutants/run_auto.py) found
+NO ground-truth test for -- every mutant of them survived:
+  compare_pair_of_genotype_paths, both forms (src/typer/genotype_paths.cpp:943-974 and :976-1169),
+  the record filter of SV calling (src/utilities/hts_parallel_reader.cpp:528-568),
+  the phase flags between alleles of sites less than 100 bp apart (src/utilities/hts_parallel_reader.cpp:782-904).
+Each is a function of a handful of numbers; every expected value below was worked out from the REFERENCE's text for those numbers
+(the comment beside a row says which branch of the reference it takes), not read off the oracle.  This file is part of the kill
+suite of the audit: a misreading of one comparison or constant of these functions in oracle/gto.hpp has to fail here."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from oracle_lib import Oracle
+
+P = 150  # read length of every vector
+
+
+def g(longest, n_paths=1, mm0=0, mm_rest=None, alt=0, ref=0, read_length=P):
+    return [read_length, longest, n_paths, mm0, mm0 if mm_rest is None else mm_rest, alt, ref]
+
+
+NONE = g(140, n_paths=0)  # no paths: its longest_path_size() is not looked at (the reference asks paths.size() > 0 first)
+
+
+def _two(a, b):
+    L = oracle_lib.lib()
+    d = np.array(a + b, np.uint32)
+    return int(L.gto_compare_two(d.ctypes.data_as(C.c_void_p)))
+
+
+def _pairs(a1, a2, b1, b2):
+    L = oracle_lib.lib()
+    d = np.array(a1 + a2 + b1 + b2, np.uint32)
+    return int(L.gto_compare_pairs(d.ctypes.data_as(C.c_void_p)))
+
+
+# genotype_paths.cpp:943-974 -- MINIMUM_PATH_SIZE 94, strictly greater
+TWO = [
+    (g(100), g(99), 1),                       # longer and > 94
+    (g(95), g(94), 1),
+    (g(94), g(93), 0),                        # longer but not > 94; not equal: 0
+    (g(94), g(95), 2),
+    (g(93), g(94), 0),
+    (g(95, mm0=1), g(95, mm0=2), 1),          # equal, > 94: fewer mismatches in paths[0]
+    (g(95, mm0=2), g(95, mm0=1), 2),
+    (g(95, mm0=1), g(95, mm0=1), 1),          # all equal: 1
+    (g(94), g(94), 0),                        # equal but not > 94
+    (g(90, mm0=3), g(90, mm0=0), 0),
+    (g(95, n_paths=2, mm0=1, mm_rest=5), g(95, n_paths=2, mm0=2, mm_rest=0), 1),  # paths[0] only
+]
+
+
+@pytest.mark.parametrize("k", range(len(TWO)))
+def test_compare_two_genotype_paths(k):
+    a, b, want = TWO[k]
+    assert _two(a, b) == want
+
+
+# genotype_paths.cpp:976-1169.  (pair1.first, pair1.second, pair2.first, pair2.second, value)
+PAIRS = [
+    # -- :1013-1086, a perfect match: TOTAL_MATCHES >= read length for BOTH reads of a pair
+    (g(150, mm0=3), g(150, mm0=3), g(160), g(100), 1),           # A  only pair 1 perfect (pair 2's second read is not): 1, whatever is longer
+    (g(160), g(100), g(150, mm0=3), g(150, mm0=3), 2),           # B  only pair 2 perfect
+    (g(150), g(100), g(160), g(100), 2),                         #    one read of each at its length: nobody perfect; longest match decides (:1088)
+    (g(160), g(100), g(150), g(100), 1),
+    # both perfect: sum of paths[0].mismatches (:1025-1035)
+    (g(150, 2, 1, 9), g(150, 2, 1, 9), g(150, 2, 2, 0, alt=1), g(150, 2, 2, 0, alt=1), 1),   # C  2 < 4
+    (g(150, 2, 2, 0, alt=1), g(150, 2, 2, 0, alt=1), g(150, 2, 1, 9), g(150, 2, 1, 9), 2),   # C' 4 > 2
+    # ... then the number of paths (:1038-1048)
+    (g(150, 1, alt=0), g(150, 1), g(150, 1, alt=1), g(150, 2, alt=1), 1),                    # D  2 paths < 3 paths
+    (g(150, 1, alt=1), g(150, 2, alt=1), g(150, 1, alt=0), g(150, 1), 2),                    # D'
+    # ... then the alleles sets that do NOT hold the reference allele, pair 1 on a tie or MORE of them (:1050-1077)
+    (g(150, 1, alt=2), g(150, 1), g(150, 1, ref=3), g(150, 1), 1),                           # E  2 >= 0
+    (g(150, 1, ref=3), g(150, 1), g(150, 1, alt=2), g(150, 1), 2),                           # E' 0 >= 2 is false
+    (g(150, 1), g(150, 1), g(150, 1), g(150, 1), 1),                                         # F  0 >= 0
+    (g(150, 1, alt=1, ref=1), g(150, 1), g(150, 1, alt=1), g(150, 1, ref=2), 1),             #    1 >= 1
+    # -- :1088-1095, the longest match of a pair, at least 94
+    (g(90), g(80), g(94), g(70), 2),                             # 94 >= 94 and longer
+    (g(90), g(80), g(93), g(70), 1),                             # nobody reaches 94, nobody empty: the last line, 1
+    (g(100), g(80), g(95), g(70), 1),
+    (g(95), g(70), g(100), g(80), 2),
+    (g(94), g(10), g(90), g(90), 1),
+    # -- :1096-1152, the same longest match: mismatches of the reads that HAVE that match (at most 10), then the shorter read
+    (g(100, mm0=0), g(95, mm0=5), g(100, mm0=2), g(95, mm0=9), 1),                           # H  0 < 2
+    (g(100, mm0=4), g(95, mm0=0), g(100, mm0=2), g(95, mm0=9), 2),                           # I  4 > 2 (the 0 of the shorter read does not count)
+    (g(100, mm0=2), g(95, mm0=9), g(100, mm0=0), g(95, mm0=5), 2),                           # J
+    (g(100, mm0=2), g(95, mm0=9), g(100, mm0=4), g(95, mm0=0), 1),                           # K
+    (g(100, 2, 0, 7), g(95, mm0=5), g(100, mm0=2), g(95, mm0=9), 1),                         #    paths[0] of the first read
+    (g(100, mm0=3), g(100, 2, 1, 8), g(100, mm0=2), g(100, mm0=2), 1),                       # L  min(3, 1) = 1 < 2
+    (g(100, mm0=2), g(95, mm0=9), g(100, 2, 0, 7), g(95, mm0=5), 2),
+    (g(100, mm0=2), g(100, mm0=2), g(100, mm0=3), g(100, 2, 1, 8), 2),
+    (g(100, mm0=12), g(100, mm0=12), g(100, mm0=11), g(100, mm0=11), 0),                     #    both capped at 10; the shorter reads alike: 0
+    (g(100, mm0=12), g(100, mm0=12), g(100, mm0=9), g(100, mm0=11), 2),                      #    10 > 9
+    (g(100), g(100), g(100), g(100), 0),                                                     # G  everything alike: 0 (both are thrown away)
+    (g(94), g(94), g(94), g(94), 0),                                                         #    94 is enough to be here
+    (g(100), g(90), g(100), g(95), 1),                                                       # N  the pair with the SHORTER worse read: 1 (:1143-1144)
+    (g(100), g(95), g(100), g(90), 2),                                                       # N'
+    (NONE, g(100), NONE, g(100), 0),                                                         #    a read without paths counts as 0: 0 == 0
+    (NONE, g(100), g(1), g(100), 1),                                                         #    0 < 1
+    (g(1), g(100), NONE, g(100), 2),
+    # -- :1154-1165, one pair without any path, the other with 63 in both reads
+    (g(70), g(70), NONE, NONE, 1),                                                           # P
+    (NONE, NONE, g(70), g(70), 2),                                                           # Q
+    (NONE, NONE, g(63), g(70), 2),
+    (NONE, NONE, g(70), g(63), 2),
+    (NONE, NONE, g(62), g(70), 1),                                                           #    62 < 63: the last line, 1 ("needed for sv calling")
+    (NONE, NONE, g(70), g(62), 1),
+    (g(50), g(50), g(70), g(70), 1),                                                         #    pair 1 is not empty
+    (g(50), g(50), g(10), g(70), 1),
+    (g(50), g(50), g(40), g(40), 1),
+]
+
+
+@pytest.mark.parametrize("k", range(len(PAIRS)))
+def test_compare_pairs_of_genotype_paths(k):
+    a1, a2, b1, b2, want = PAIRS[k]
+    assert _pairs(a1, a2, b1, b2) == want
+
+
+# ---- hts_parallel_reader.cpp:528-568.  BAM CIGAR words: length << 4 | operation, M = 0, S = 4
+def M(n):
+    return n << 4
+
+
+def S(n):
+    return n << 4 | 4
+
+
+UNMAPPED = 4
+# (flag, tid, mtid, pos, mpos, mapq, n_cigar, first cigar word, last cigar word, good?)
+READS = [
+    (0, 0, 0, 1000, 1300, 60, 1, M(151), M(151), True),
+    (UNMAPPED, 0, 0, 1000, 1300, 60, 1, M(151), M(151), False),
+    (1 | UNMAPPED, 0, 0, 1000, 1300, 60, 1, M(151), M(151), False),
+    # mapping quality <= 15 with the mate on another contig or more than 200 000 away
+    (0, 0, 1, 1000, 1300, 15, 1, M(151), M(151), False),
+    (0, 0, 1, 1000, 1300, 16, 1, M(151), M(151), True),
+    (0, 0, 0, 1000, 1300, 15, 1, M(151), M(151), True),
+    (0, 0, 0, 1000, 201001, 15, 1, M(151), M(151), False),
+    (0, 0, 0, 1000, 201000, 15, 1, M(151), M(151), True),   # exactly 200 000: not far
+    (0, 0, 0, 201001, 1000, 15, 1, M(151), M(151), False),  # std::abs
+    (0, 0, 0, 1000, 900000, 60, 1, M(151), M(151), True),
+    (0, 0, 1, 1000, 1300, 0, 1, M(151), M(151), False),
+    # two or more CIGAR operations: clipped at both ends, or at one end by 12 or more with mapping quality <= 15
+    (0, 0, 0, 1000, 1300, 60, 2, S(5), S(5), False),        # both ends, however short
+    (0, 0, 0, 1000, 1300, 60, 3, S(1), S(1), False),
+    (0, 0, 0, 1000, 1300, 15, 2, S(12), M(139), False),
+    (0, 0, 0, 1000, 1300, 16, 2, S(12), M(139), True),
+    (0, 0, 0, 1000, 1300, 15, 2, S(11), M(140), True),
+    (0, 0, 0, 1000, 1300, 15, 2, M(139), S(12), False),
+    (0, 0, 0, 1000, 1300, 15, 2, M(140), S(11), True),
+    (0, 0, 0, 1000, 1300, 60, 2, S(60), M(91), True),
+    (0, 0, 0, 1000, 1300, 60, 2, M(91), S(60), True),
+    (0, 0, 0, 1000, 1300, 15, 2, M(100), M(51), True),      # (an insertion between them, say): nothing clipped
+    (0, 0, 0, 1000, 1300, 60, 2, M(100), S(5), True),
+    (0, 0, 0, 1000, 1300, 60, 2, S(5), M(146), True),
+    (0, 0, 0, 1000, 1300, 60, 1, S(5), S(5), True),         # one operation: the words are not looked at
+    (0, 0, 0, 1000, 1300, 15, 1, S(12), S(12), True),
+]
+
+
+@pytest.mark.parametrize("k", range(len(READS)))
+def test_record_filter_of_sv_calling(k):
+    flag, tid, mtid, pos, mpos, mapq, n_cigar, front, back, want = READS[k]
+    L = oracle_lib.lib()
+    L.gto_is_good_read.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    assert bool(L.gto_is_good_read(flag, tid, mtid, pos, mpos, mapq, n_cigar, front, back)) == want
+
+
+# ---- hts_parallel_reader.cpp:782-904
+HAP, ANTI = 1, 2  # include/graphtyper/constants.hpp.in:56-57
+
+
+_ORACLES = {}
+
+
+def _genotyper(positions, n_samples=2, alts=None):
+    """a fresh genotyper over SNP sites at `positions` (alts: site -> number of alternative alleles)"""
+    from graphtyper_amd import synth
+    key = (tuple(positions), tuple(sorted((alts or {}).items())))
+    if key not in _ORACLES:
+        rb = 50000
+        ref = synth.make_reference(1200, seed=12)
+        recs = []
+        for k, p in enumerate(positions):
+            a = [("ACGT"[(ref[p] + 1 + j) % 4]) for j in range((alts or {}).get(k, 1))]
+            recs.append((rb + p, "ACGT"[ref[p]], a, None))
+        _ORACLES[key] = Oracle(synth.bases_to_str(ref), recs, region_begin=rb)
+    return _ORACLES[key].genotyper(n_samples, 1)
+
+
+def _poke(og, hap, sample, cov=None, allele1=0, hap2=0, support=None):
+    L = oracle_lib.lib()
+    L.gto_genotyper_poke.restype = C.c_long
+    cov = np.array(cov if cov is not None else [], np.uint16)
+    sup = np.array(support if support is not None else [], np.uint16)
+    r = L.gto_genotyper_poke(C.c_void_p(og.g), C.c_long(hap), C.c_long(sample), cov.ctypes.data_as(C.c_void_p), C.c_long(len(cov)), C.c_long(allele1),
+                             C.c_long(hap2), sup.ctypes.data_as(C.c_void_p), C.c_long(len(sup)))
+    assert r >= 0
+    return r >> 16, r & 0xFFFF  # (variant order, number of alleles)
+
+
+def _flags(cov0, cov1, support, sample=0):
+    """sites 0 and 1 forty bases apart; depths of the sample at both, `support` reads of allele 1 of site 0 over the alleles of site 1"""
+    og = _genotyper([300, 340])
+    _poke(og, 0, sample, cov0, 1, 1, support)
+    _poke(og, 1, sample, cov1)
+    return [tuple(int(x) for x in r) for r in og.phase_flags()]
+
+
+NO_FLAG = [(0, 1, 0xFFFF, 0xFFFF, 0)]  # the outer key exists as soon as there is a connection
+
+
+def flag(v):
+    return [(0, 1, 1, 1, v)]
+
+
+# (depths at site 0, depths at site 1, support of (site 0 allele 1) x (alleles of site 1), rows)
+PHASE = [
+    ([5, 5], [5, 5], [0, 5], flag(HAP)),          # both clearly seen (>= 4 reads), 5 of 5 > 0.78
+    ([5, 5], [5, 5], [4, 1], flag(ANTI)),         # 1 of 5 = 0.2 < 0.22
+    ([5, 5], [5, 5], [2, 3], NO_FLAG),            # 0.6: ambiguous
+    ([5, 5], [5, 5], [1, 4], flag(HAP)),          # 0.8
+    ([5, 5], [5, 5], [0, 2], NO_FLAG),            # total support <= 2: cannot determine
+    ([5, 5], [5, 5], [0, 3], flag(HAP)),
+    ([5, 5], [5, 5], [11, 39], NO_FLAG),          # 39 / 50 = 0.78 is not > 0.78
+    ([5, 5], [5, 5], [10, 40], flag(HAP)),
+    ([5, 5], [5, 5], [39, 11], NO_FLAG),          # 11 / 50 = 0.22 is not < 0.22
+    ([5, 5], [5, 5], [40, 10], flag(ANTI)),
+    ([10, 2], [10, 1], [0, 5], NO_FLAG),          # neither allele seen (<= 2 reads): nothing to say
+    ([10, 2], [5, 5], [0, 1], flag(ANTI)),        # one not seen, the other clearly: they are not on one haplotype (whatever the support)
+    ([5, 5], [10, 2], [0, 1], flag(ANTI)),
+    ([12, 4], [5, 5], [0, 5], flag(HAP)),         # 4 reads are "clearly seen" (4 / 16 = 0.25 alone would not be)
+    ([5, 5], [12, 4], [0, 5], flag(HAP)),
+    ([13, 3], [5, 5], [0, 5], flag(ANTI)),        # 3 of 16 = 0.19 < 0.22: not seen
+    ([9, 3], [5, 5], [0, 5], NO_FLAG),            # 3 of 12 = 0.25: neither clearly seen nor not seen -- no haplotype support ...
+    ([9, 3], [5, 5], [5, 1], flag(ANTI)),         # ... but 1 / 6 < 0.22 still is anti support
+    ([5, 5], [9, 3], [0, 5], NO_FLAG),
+    ([7, 3], [5, 5], [0, 5], flag(HAP)),          # 3 of 10 = 0.3 >= 0.28: clearly seen by share
+    ([5, 5], [7, 3], [0, 5], flag(HAP)),
+    ([5, 2], [5, 5], [0, 5], flag(ANTI)),         # 2 reads are "not seen" whatever their share (2 / 7 = 0.29)
+    ([5, 5], [5, 2], [0, 5], flag(ANTI)),
+    ([39, 11], [5, 5], [0, 5], flag(HAP)),        # 11 / 50 = 0.22 is not < 0.22: seen (and >= 4: clearly)
+    ([5, 5], [39, 11], [0, 5], flag(HAP)),
+    ([40, 10], [5, 5], [0, 5], flag(ANTI)),       # 0.2 < 0.22 although 10 reads: not seen AND clearly seen -- with the other clearly seen: anti
+    ([96, 4], [96, 4], [0, 5], NO_FLAG),          # both "not seen" by share: nothing, although both have 4 reads
+]
+
+
+@pytest.mark.parametrize("k", range(len(PHASE)))
+def test_phase_flags_of_two_sites(k):
+    cov0, cov1, support, want = PHASE[k]
+    assert _flags(cov0, cov1, support) == want
+    assert _flags(cov0, cov1, support, sample=1) == want  # (any sample's evidence sets the flag)
+
+
+def test_phase_flags_stop_at_100_positions():
+    og = _genotyper([300, 340, 400])
+    orders = [_poke(og, h, 0, [5, 5])[0] for h in range(3)]
+    assert orders[1] - orders[0] == 40 and orders[2] - orders[0] == 100
+    _poke(og, 0, 0, None, 1, 2, [0, 5])   # site 0 -> site 2: exactly 100 apart, not looked at
+    assert len(og.phase_flags()) == 0
+    _poke(og, 1, 0, None, 1, 2, [0, 5])   # site 1 -> site 2: 60 apart
+    assert [tuple(int(x) for x in r) for r in og.phase_flags()] == [(1, 1, 2, 1, HAP)]
+    og = _genotyper([300, 340, 399])
+    for h in range(3):
+        _poke(og, h, 0, [5, 5])
+    _poke(og, 0, 0, None, 1, 2, [0, 5])   # 99 apart: looked at
+    assert [tuple(int(x) for x in r) for r in og.phase_flags()] == [(0, 1, 2, 1, HAP)]
+
+
+def test_phase_flags_of_a_site_with_two_alternative_alleles():
+    """every alternative allele of both sites is a row of its own; the reference allele of neither is looked at; flags of several
+    samples are OR-ed"""
+    og = _genotyper([300, 340], alts={1: 2})
+    assert _poke(og, 1, 0, [4, 4, 4])[1] == 3
+    _poke(og, 0, 0, [5, 5], 1, 1, [0, 9, 1])          # allele 1 of site 1: 0.9 -> HAP; allele 2: 0.1 -> ANTI
+    _poke(og, 0, 0, None, 0, 1, [9, 0, 0])            # connections of the REFERENCE allele of site 0: skipped
+    assert [tuple(int(x) for x in r) for r in og.phase_flags()] == [(0, 1, 1, 1, HAP), (0, 1, 1, 2, ANTI)]
+    _poke(og, 0, 1, [5, 5], 1, 1, [0, 1, 9])          # a second sample sees it the other way round
+    _poke(og, 1, 1, [4, 4, 4])
+    assert [tuple(int(x) for x in r) for r in og.phase_flags()] == [(0, 1, 1, 1, HAP | ANTI), (0, 1, 1, 2, HAP | ANTI)]
