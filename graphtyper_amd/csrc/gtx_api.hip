@@ -44,11 +44,25 @@ constexpr uint64_t PROF_WORDS = 40 + PROF_LOG_ENTRIES * PROF_LOG_ENTRY;
 #ifndef GTX_SCORE_THREADS
 #define GTX_SCORE_THREADS 64 // threads of a gtx_score_kernel workgroup: one wavefront goes wherever a slot is beside another batch's queues (cfg2, steps in flight: 256 / 128 / 64 threads = 0.798 / 0.788 / 0.783 ms per step; alone the same)
 #endif
+#ifndef GTX_WAVE_GROUP_MIN
+#define GTX_WAVE_GROUP_MIN 4
+#endif
+#ifndef GTX_SCORE_TABLE_LOG2
+#define GTX_SCORE_TABLE_LOG2 8
+#endif
+#ifndef GTX_SCORE_CHUNK_MAX
+#define GTX_SCORE_CHUNK_MAX 64 // items of one workgroup between two flushes of its table; at most 1 024 (the 32-bit sums of the table: 1 024 x 2 reads x 255^2)
+#endif
+// The table: 32-bit keys -- the counter's word offset from the lowest accumulator address (gtx_scores_alloc puts them in one block),
+// bit 31 = the counter is 64 bits wide -- and 32-bit sums, 8 KB for 1 024 entries.  A workgroup scores a CONTIGUOUS run of the work
+// queue (neighbours in the stream: the same two or three sites, the same samples over and over) and flushes once at its end:
+// round 4 flushed after every 64 items, where 30 samples leave two items per counter.
 struct ScoreCombiner
 {
-  static constexpr uint32_t N = 4 * GTX_SCORE_THREADS, PROBES = 8; // (four entries per thread of the workgroup)
-  unsigned long long key[N]; // counter address | 1 when the counter is 64 bits wide; 0 = free
-  unsigned long long val[N];
+  static constexpr uint32_t LOG2N = GTX_SCORE_TABLE_LOG2, N = 1u << LOG2N, PROBES = 8, EMPTY = 0xFFFFFFFFu;
+  uint32_t key[N];
+  uint32_t val[N];
+  unsigned long long base; // the lowest accumulator address
 };
 
 struct WaveHipCombine : WaveHip
@@ -58,21 +72,25 @@ struct WaveHipCombine : WaveHip
     __shared__ ScoreCombiner t;
     return t;
   }
-  static __device__ inline bool combine(unsigned long long key, unsigned long long v)
+  static __device__ inline bool combine(unsigned long long address, bool is64, unsigned long long v)
   {
     ScoreCombiner & t = table();
-    uint32_t h = static_cast<uint32_t>((key * 0x9E3779B97F4A7C15ull) >> 54) & (ScoreCombiner::N - 1);
+    unsigned long long const d = address - t.base;
+    if ((d >> 33) != 0ull || (v >> 26) != 0ull) // (not within 8 GB above the base, or an addend the 32-bit sum has no room for: straight to memory)
+      return false;
+    uint32_t const key = static_cast<uint32_t>(d >> 2) | (is64 ? 0x80000000u : 0u);
+    uint32_t h = (key * 0x9E3779B1u) >> (32u - ScoreCombiner::LOG2N);
     for (uint32_t probe = 0; probe < ScoreCombiner::PROBES; ++probe)
     {
-      unsigned long long const old = atomicCAS(&t.key[h], 0ull, key);
-      if (old == 0ull || old == key)
+      uint32_t const old = atomicCAS(&t.key[h], ScoreCombiner::EMPTY, key);
+      if (old == ScoreCombiner::EMPTY || old == key)
       {
-        atomicAdd(&t.val[h], v);
+        atomicAdd(&t.val[h], static_cast<uint32_t>(v));
         return true;
       }
       h = (h + 1u) & (ScoreCombiner::N - 1);
     }
-    return false; // crowded (many samples in one workgroup): straight to memory
+    return false; // crowded (many samples in one run): straight to memory
   }
   // The lanes that are here together with the same (counter, addend) -- neighbours in the stream see the same site with the
   // same alleles and the same epsilon -- send ONE add of addend x lanes through their first lane: 64 same-address LDS
@@ -84,6 +102,10 @@ struct WaveHipCombine : WaveHip
     sum = v;
     return true;
 #else
+    // (groups are formed while they are worth it: one sample deep, a wavefront's lanes make two or three large ones; thirty samples
+    //  wide, nearly every lane has a counter of its own, and forming 64 groups of one -- a round of readfirstlanes and a ballot
+    //  each, for every one of an item's fifteen adds -- was HALF of the kernel on cfg3.  The first group of fewer than
+    //  GTX_WAVE_GROUP_MIN lanes is the last one: the lanes left over add for themselves)
     uint32_t const lane = threadIdx.x & 63u;
     for (;;)
     {
@@ -91,35 +113,47 @@ struct WaveHipCombine : WaveHip
       uint32_t const v_lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)), v_hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
       bool const same = key == ((static_cast<unsigned long long>(k_hi) << 32) | k_lo) && v == ((static_cast<unsigned long long>(v_hi) << 32) | v_lo);
       unsigned long long const group = __ballot(same);
+      uint32_t const members = static_cast<uint32_t>(__builtin_popcountll(group));
       if (same)
       {
-        sum = v * static_cast<unsigned long long>(__builtin_popcountll(group));
+        sum = v * static_cast<unsigned long long>(members);
         return lane == static_cast<uint32_t>(__builtin_ctzll(group));
       }
+      if (members < GTX_WAVE_GROUP_MIN)
+        break;
     }
+    sum = v;
+    return true;
 #endif
   }
+#if defined(GTX_EXPERIMENT) && defined(GTX_X_SCORE_NO_ADDS) // (experiment builds only, wrong results: what the kernel takes without its adds)
+  static __device__ inline void atomic_add_u32(uint32_t *, uint32_t) {}
+  static __device__ inline void atomic_add_u64(unsigned long long *, unsigned long long) {}
+#else
   static __device__ inline void atomic_add_u32(uint32_t * p, uint32_t v)
   {
     unsigned long long sum;
-    if (wave_group(reinterpret_cast<unsigned long long>(p), v, sum) && !combine(reinterpret_cast<unsigned long long>(p), sum))
+    if (wave_group(reinterpret_cast<unsigned long long>(p), v, sum) && !combine(reinterpret_cast<unsigned long long>(p), false, sum))
       atomicAdd(p, static_cast<uint32_t>(sum));
   }
   static __device__ inline void atomic_add_u64(unsigned long long * p, unsigned long long v)
   {
     unsigned long long sum;
-    if (wave_group(reinterpret_cast<unsigned long long>(p), v, sum) && !combine(reinterpret_cast<unsigned long long>(p) | 1ull, sum))
+    if (wave_group(reinterpret_cast<unsigned long long>(p), v, sum) && !combine(reinterpret_cast<unsigned long long>(p), true, sum))
       atomicAdd(p, sum);
   }
+#endif
   // all threads of the workgroup
-  static __device__ inline void clear()
+  static __device__ inline void clear(unsigned long long base)
   {
     ScoreCombiner & t = table();
     for (uint32_t i = threadIdx.x; i < ScoreCombiner::N; i += blockDim.x)
     {
-      t.key[i] = 0;
+      t.key[i] = ScoreCombiner::EMPTY;
       t.val[i] = 0;
     }
+    if (threadIdx.x == 0)
+      t.base = base;
     __syncthreads();
   }
   static __device__ inline void flush()
@@ -128,15 +162,19 @@ struct WaveHipCombine : WaveHip
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < ScoreCombiner::N; i += blockDim.x)
     {
-      unsigned long long const k = t.key[i];
-      if (k != 0ull)
+      uint32_t const k = t.key[i];
+      if (k != ScoreCombiner::EMPTY)
       {
-        unsigned long long const v = t.val[i];
-        if (k & 1ull)
-          atomicAdd(reinterpret_cast<unsigned long long *>(k & ~1ull), v);
+        uint32_t const v = t.val[i];
+        unsigned long long const address = t.base + (static_cast<unsigned long long>(k & 0x7FFFFFFFu) << 2);
+#if defined(GTX_EXPERIMENT) && defined(GTX_X_SCORE_NO_FLUSH) // (experiment builds only, wrong results: the table is summed into, nothing reaches memory)
+        if (v == 0xFFFFFFFFu && address == 1ull)
+#endif
+        if (k & 0x80000000u)
+          atomicAdd(reinterpret_cast<unsigned long long *>(address), static_cast<unsigned long long>(v));
         else
-          atomicAdd(reinterpret_cast<uint32_t *>(k), static_cast<uint32_t>(v));
-        t.key[i] = 0;
+          atomicAdd(reinterpret_cast<uint32_t *>(address), v);
+        t.key[i] = ScoreCombiner::EMPTY;
         t.val[i] = 0;
       }
     }
@@ -1005,25 +1043,69 @@ __global__ __launch_bounds__(GTX_SCORE_THREADS) GTX_SCORE_ATTR void gtx_score_ke
                                                         uint32_t * error_flag, uint32_t * __restrict__ big_queue,
                                                         uint32_t big_queue_cap, uint32_t * big_state)
 {
+  constexpr uint32_t SCORE_STAGE_WORDS = 16, SCORE_STAGE_PITCH = SCORE_STAGE_WORDS + 1; // (an odd pitch: a word of every lane's row in a bank of its own)
+  __shared__ uint32_t s_stage[GTX_SCORE_THREADS * SCORE_STAGE_PITCH];
   uint32_t const n_work = work_count[0];
-  WaveHipCombine::clear();
-  // (every thread of the workgroup makes the same number of visits: the table is flushed after each)
-  for (uint32_t first = blockIdx.x * blockDim.x; first < n_work; first += gridDim.x * blockDim.x)
+  WaveHipCombine::clear(acc.combine_base);
+  // a workgroup's share of the queue in one piece (every thread of the workgroup makes the same visits: the table is flushed
+  // behind the piece; queues of more than GTX_SCORE_CHUNK_MAX items per workgroup are taken in several pieces)
+  uint32_t per = (n_work + gridDim.x - 1u) / gridDim.x;
+  per = (per + blockDim.x - 1u) / blockDim.x * blockDim.x;
+  per = per > GTX_SCORE_CHUNK_MAX ? GTX_SCORE_CHUNK_MAX : per;
+  for (uint32_t piece = blockIdx.x * per; piece < n_work; piece += gridDim.x * per)
+  {
+  uint32_t const piece_end = piece + per < n_work ? piece + per : n_work;
+  for (uint32_t first = piece; first < piece_end; first += blockDim.x)
   {
     uint32_t const w = first + threadIdx.x;
 #ifdef GTX_PROF // (profiling build: cycles of a visit's three parts, lane 0 of every workgroup: [25] item fetch, [26] scoring, [27] flush, [28] visits)
     unsigned long long const t0 = clock64();
     unsigned long long t1 = t0, t2 = t0;
 #endif
-    if (w < n_work)
+    if (w < piece_end)
     {
       uint32_t const i = work_queue[w];
       gtx_score_item const it = items[i];
 #ifdef GTX_PROF
       t1 = clock64() + (it.sample & 0u); // (behind the loads)
 #endif
+      // The record of the item's (first) read, forward orientation, fetched in ONE round trip and parsed from LDS: the parser
+      // walks it word by word, every look a dependent load (PMC, cfg3: 68 vector loads per visit, each waited for -- the
+      // kernel's time is their latencies in a row).  Records that are longer than the copy, in the arena or wide stay where they are.
+      ScoreAcc mine = acc;
+#ifndef GTX_NO_SCORE_STAGING
+      if ((rec_words & 3u) == 0u)
+      {
+        uint32_t const ai = it.first.align_index;
+        bool const dense = acc.compact && (acc.compact_flags[2ull * ai] & GTX_TASK_COMPACT);
+        uint32_t const * const src = dense ? acc.compact + static_cast<uint64_t>(ai) * GTX_COMPACT_WORDS : records + static_cast<uint64_t>(ai) * 2 * rec_words;
+        uint32_t const have = dense ? GTX_COMPACT_WORDS : (rec_words < SCORE_STAGE_WORDS ? rec_words : SCORE_STAGE_WORDS);
+        uint4_t const * const q = reinterpret_cast<uint4_t const *>(src);
+        uint4_t x[SCORE_STAGE_WORDS / 4];
+#pragma unroll
+        for (uint32_t k = 0; k < SCORE_STAGE_WORDS / 4; ++k)
+          x[k] = 4 * k < have ? q[k] : uint4_t{0, 0, 0, 0};
+        uint32_t const n_paths = x[0].x & 0xFFFFu, nvar = x[1].y >> 16;
+        bool const whole = ((x[0].x >> 16) & GTX_ST_EXTERNAL) == 0u && (x[0].y & GTX_REC_WIDE) == 0u &&
+                           (n_paths == 0 || (n_paths == 1 && 6u + 3u * nvar <= have));
+        if (whole)
+        {
+          uint32_t * const row = s_stage + threadIdx.x * SCORE_STAGE_PITCH;
+#pragma unroll
+          for (uint32_t k = 0; k < SCORE_STAGE_WORDS / 4; ++k)
+          {
+            row[4 * k + 0] = x[k].x;
+            row[4 * k + 1] = x[k].y;
+            row[4 * k + 2] = x[k].z;
+            row[4 * k + 3] = x[k].w;
+          }
+          mine.staged_from = src;
+          mine.staged_copy = row;
+        }
+      }
+#endif
       RecentHap r1[SCORE_MAX_HAPS], r2[SCORE_MAX_HAPS];
-      if (!score_item<WaveHipCombine>(g, par, it, records, rec_words, acc, r1, r2, SCORE_MAX_HAPS))
+      if (!score_item<WaveHipCombine>(g, par, it, records, rec_words, mine, r1, r2, SCORE_MAX_HAPS))
       {
         // a read of this item touches more variant sites than the tables above hold (long results of the alignment's
         // last pass): nothing was added yet, queue the item for gtx_score_big_kernel
@@ -1037,15 +1119,22 @@ __global__ __launch_bounds__(GTX_SCORE_THREADS) GTX_SCORE_ATTR void gtx_score_ke
       t2 = clock64();
 #endif
     }
-    WaveHipCombine::flush();
 #ifdef GTX_PROF
-    if (threadIdx.x == 0 && w < n_work)
+    if (threadIdx.x == 0 && w < piece_end)
     {
       atomicAdd(g.prof + 25, t1 - t0);
       atomicAdd(g.prof + 26, t2 - t1);
-      atomicAdd(g.prof + 27, clock64() - t2);
       atomicAdd(g.prof + 28, 1ull);
     }
+#endif
+  }
+#ifdef GTX_PROF
+  unsigned long long const t3 = clock64();
+#endif
+  WaveHipCombine::flush();
+#ifdef GTX_PROF
+  if (threadIdx.x == 0)
+    atomicAdd(g.prof + 27, clock64() - t3);
 #endif
   }
 }
@@ -1521,6 +1610,10 @@ int ctx_upload(gtx_ctx & c, int device)
       c.dev_allocs.push_back(p);
       c.d_big_records = static_cast<uint32_t *>(p);
     }
+    if (ok && hipHostMalloc(reinterpret_cast<void **>(&c.h_big_seen), 64) == hipSuccess)
+      *c.h_big_seen = 0xFFFFFFFFu;
+    else
+      c.h_big_seen = nullptr; // (without it the pass is launched whole)
     ok = ok && hip_ok(gtx::dev_malloc(&p, sizeof(unsigned long long)), "arena cursor");
     if (ok)
     {
@@ -1562,6 +1655,11 @@ void ctx_release_device(gtx_ctx & c)
     (void)hipSetDevice(c.device);
     if (!c.quiet) // (gtx_regions_run has waited for the one stream that used the context: no reason to wait for the other regions')
       (void)hipDeviceSynchronize();
+  }
+  if (c.h_big_seen)
+  {
+    (void)hipHostFree(c.h_big_seen);
+    c.h_big_seen = nullptr;
   }
   for (auto & s : c.pool)
     scratch_free(*s);
@@ -2086,6 +2184,15 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
       s->big_blocks = c->big_blocks;
     }
     a.big_blocks = n_reads >= gtx_ctx::HBM_SMALL_BATCH ? s->big_blocks : std::min<uint32_t>(s->big_blocks, static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256));
+    if (c->h_big_seen)
+    {
+      // (tasks are claimed one by one from the queue: any number of workgroups does them all -- fewer only take longer when the
+      //  guess is too low, and the next call knows better)
+      uint32_t const seen = *static_cast<uint32_t volatile *>(c->h_big_seen);
+      static bool const adaptive = !(std::getenv("GTX_BIG_GRID_ADAPTIVE") && std::getenv("GTX_BIG_GRID_ADAPTIVE")[0] == '0'); // (A/B switch)
+      if (adaptive && seen != 0xFFFFFFFFu)
+        a.big_blocks = static_cast<uint32_t>(std::min<uint64_t>(a.big_blocks, 2ull * seen + 32u));
+    }
     a.big_ws = s->d_big_ws;
     a.wide_tasks = s->d_wide_tasks;
     a.wide_state = s->d_wide_state;
@@ -2103,6 +2210,8 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     a.arena_words = c->big_record_words;
     a.arena_cursor = c->d_arena_cursor;
     char const * what = launch_hbm_passes(a, sg);
+    if (!what && c->h_big_seen)
+      (void)hipMemcpyAsync(c->h_big_seen, s->d_big_state, sizeof(uint32_t), hipMemcpyDeviceToHost, sg);
     if (!what)
     {
       // the exact launches, with one of the context's slabs: chosen, waited for if need be, used and marked busy again in one
@@ -2369,6 +2478,15 @@ static int score_batch(gtx_ctx * c, const gtx_score_item * d_items, const uint32
   a.conn_count = acc->d_conn_count;
   a.conn_near = acc->d_conn_near;
   a.big_records = c->d_big_records;
+  {
+    // (the scoring kernel's table names a counter by its distance from the lowest of these: score_core.hpp)
+    unsigned long long base = reinterpret_cast<unsigned long long>(a.log_score);
+    for (void const * p : {static_cast<void const *>(a.gt_cov), static_cast<void const *>(a.hap_u32), static_cast<void const *>(a.stat_u64),
+                           static_cast<void const *>(a.stat_u32), static_cast<void const *>(a.conn_near)})
+      if (p)
+        base = std::min(base, reinterpret_cast<unsigned long long>(p));
+    a.combine_base = base & ~7ull;
+  }
   a.compact = d_compact;
   a.compact_flags = d_compact ? d_task_flags : nullptr;
   a.ref_depth = c->params.is_sv_graph ? acc->d_ref_depth : nullptr;

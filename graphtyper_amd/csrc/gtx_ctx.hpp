@@ -94,6 +94,11 @@ struct gtx_ctx
   uint32_t score_blocks_per_cu = 8;  // resident 256-thread workgroups of gtx_score_kernel per CU
   bool express4_wide = false; // pass 1 runs gtx_align_express4_wide_kernel (express4_prefers_wide, gtx_flat.hpp)
   uint32_t big_blocks = 0;       // workgroups (= workspaces) of the HBM-table pass for a large batch; a small one gets n_cu (HBM_SMALL_BATCH)
+  // What the HBM-table pass of the call before found in its queue, copied to pinned host memory behind that pass (asynchronously:
+  // the value read here may be a call or two old): the pass is launched with as many workgroups as that many tasks can use
+  // instead of all of them -- nearly every batch queues nothing, and 2 048 wavefronts of 128 registers that only look at an empty
+  // queue waited a quarter of a millisecond for room beside the other stream's kernels.  0xFFFFFFFF: nothing seen yet.
+  uint32_t * h_big_seen = nullptr;
   static constexpr uint32_t HBM_SMALL_BATCH = 1u << 20; // reads: below this a call takes the small configuration of the passes behind the general one
   bool exact_mb_given = false;   // gtx_params::exact_pass_mb / GTX_EXACT_PASS_MB: every call gets that slab
   bool has_wide_sites = false; // some site has more than 64 alleles: the wide-site passes (alignment, scoring) exist

@@ -30,6 +30,8 @@ namespace gtx
                                              unsigned long long arena_words, unsigned long long * arena_cursor,                    \
                                              uint32_t * __restrict__ next_tasks, uint32_t next_cap, uint32_t * next_state)         \
   {                                                                                                                                \
+    if (big_state[0] == 0) /* (nearly every batch: nothing reached this pass -- leave before the workspace is touched) */          \
+      return;                                                                                                                      \
     NS::AlignWorkspace & ws = workspaces[blockIdx.x];                                                                              \
     /* the dense start / end tables of the chaining's searches live in LDS (align_core.inl: PpKeyTables) */                       \
     __shared__ uint32_t s_pp_keys[2][NS::AlignCfg::MAXPP];                                                                         \

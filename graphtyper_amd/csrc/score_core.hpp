@@ -53,6 +53,8 @@ GTX_DEV Geno geno_of(uint32_t const * records, uint32_t rec_words, Acc const & a
   g.rec = records + (static_cast<uint64_t>(align_index) * 2 + orient) * rec_words;
   if (orient == 0 && acc.compact && (acc.compact_flags[2ull * align_index] & GTX_TASK_COMPACT))
     g.rec = acc.compact + static_cast<uint64_t>(align_index) * GTX_COMPACT_WORDS; // (a record of at most that many words: never external)
+  if (g.rec == acc.staged_from)
+    g.rec = acc.staged_copy; // (the scoring kernel has fetched this record in one go: every word the parser looks at is in the copy)
   g.body = ((g.rec[0] >> 16) & GTX_ST_EXTERNAL) ? acc.big_records + g.rec[2] : g.rec + 2;
   g.n_paths = g.rec[0] & 0xFFFFu;
   g.longest = g.rec[1] & 0xFFFFu;
@@ -250,16 +252,39 @@ struct AlleleSet
   }
 };
 
-template <uint32_t NW>
-struct RecentHapT // one entry of `recent_ids` + the haplotype's transient explains/coverage (vcf_writer.cpp:519-585)
+template <uint32_t NW_>
+struct RecentHapT // one entry of `recent_ids` + the haplotype's transient explains/coverage (vcf_writer.cpp:519-585); 16 bytes where NW = 1
 {
+  static constexpr uint32_t NW = NW_;
   uint32_t site;
-  uint32_t coverage;
-  AlleleSet<NW> explains;
-  bool overlapping;
+  uint16_t coverage; // an allele number (< 64 x NW) or one of NO_COVERAGE / MULTI_ALT_COVERAGE / MULTI_REF_COVERAGE
+  uint16_t overlapping;
+  AlleleSet<NW_> explains;
 };
 using RecentHap = RecentHapT<1>;
 using RecentHapWide = RecentHapT<GTX_WIDE_MASK_WORDS / 2>;
+
+// Where the entries of one read live.  PtrTable: an array (per-thread arrays of the scoring kernel, the HBM tables of the second
+// scoring pass, host vectors of the emulation).  StridedTable: entry j of THIS lane at base[j * STRIDE] -- tables in LDS, entry by
+// entry across the lanes of a workgroup.  (Measured for the scoring kernel, round 5: 8 entries x 64 lanes x 16 B of LDS instead of
+// the per-thread arrays in scratch memory -- cfg3 0.743 ms against 0.674, cfg2 0.232 against 0.185: the LDS costs a wavefront per
+// SIMD, and the scratch accesses were not what the kernel waits for.  The kernel keeps its arrays.)
+template <class RH>
+struct PtrTable
+{
+  using entry = RH;
+  RH * p;
+  GTX_DEV RH & operator[](uint32_t j) const { return p[j]; }
+  GTX_DEV PtrTable after(uint32_t n) const { return PtrTable{p + n}; }
+};
+template <class RH, uint32_t STRIDE>
+struct StridedTable
+{
+  using entry = RH;
+  RH * p;
+  GTX_DEV RH & operator[](uint32_t j) const { return p[j * STRIDE]; }
+  GTX_DEV StridedTable after(uint32_t n) const { return StridedTable{p + n * STRIDE}; }
+};
 
 GTX_DEV uint32_t add_coverage(uint32_t coverage, uint32_t c) // haplotype.cpp:180-227
 {
@@ -287,6 +312,10 @@ struct ScoreAcc // device pointers, see gtx_score_buffers in include/gtx.h
   uint32_t * conn_count;
   uint32_t * conn_near; // NULL: every connection is logged
   uint32_t const * big_records; // the context's arena for records longer than rec_words
+  // a record the caller has copied (whole, in one round trip) to faster memory: geno_of reads the copy (per thread; NULL: none)
+  uint32_t const * staged_from = nullptr;
+  uint32_t const * staged_copy = nullptr;
+  unsigned long long combine_base = 0; // the lowest address of the accumulators above (the scoring kernel's LDS table keys counters by their distance from it)
   // dense records of the position-hinted pass (gtx_align_batch_planes_compact): GTX_COMPACT_WORDS words per read; a task whose
   // byte of the side array carries GTX_TASK_COMPACT has its record there, not in its slot
   uint32_t const * compact = nullptr;
@@ -442,10 +471,11 @@ GTX_DEV void emit_conn(GraphView const & g, ScoreAcc const & acc, uint32_t sampl
 // push_to_haplotype_scores (vcf_writer.cpp:503-676), first half: the sites the read's paths touch with their explain
 // masks and coverage, ascending site (the reference's std::map order).  No effect on shared state.  Returns the number
 // of entries, or 0xFFFFFFFF when the read touches more than `cap` sites.
-template <uint32_t NW>
-GTX_DEV uint32_t collect_recent(GraphView const & g, Geno const & ge, RecentHapT<NW> * recent, uint32_t cap)
+template <class Tab>
+GTX_DEV uint32_t collect_recent(GraphView const & g, Geno const & ge, Tab recent, uint32_t cap)
 {
-  using RecentHap = RecentHapT<NW>;
+  using RecentHap = typename Tab::entry;
+  constexpr uint32_t NW = RecentHap::NW;
   uint32_t n = 0;
   uint32_t const * w = ge.body;
   uint32_t const mw = ge.wide ? GTX_WIDE_MASK_WORDS : 2u;
@@ -481,20 +511,22 @@ GTX_DEV uint32_t collect_recent(GraphView const & g, Geno const & ge, RecentHapT
           return 0xFFFFFFFFu;
         RecentHap & fresh = recent[n++];
         fresh.site = site;
-        fresh.coverage = NO_COVERAGE;
+        fresh.coverage = static_cast<uint16_t>(NO_COVERAGE);
         fresh.explains.clear();
-        fresh.overlapping = false;
+        fresh.overlapping = 0;
       }
       RecentHap & rh = recent[j];
-      rh.overlapping = rh.overlapping || overlapping;
+      rh.overlapping = static_cast<uint16_t>(rh.overlapping || overlapping);
       rh.explains.add_words(mask, mw);
+      uint32_t cov = rh.coverage;
       if (members == 1)
-        rh.coverage = add_coverage(rh.coverage, lowest);
+        cov = add_coverage(cov, lowest);
       else
       {
-        rh.coverage = add_coverage(rh.coverage, 1);
-        rh.coverage = add_coverage(rh.coverage, (mask[0] & 1u) ? 0u : 2u);
+        cov = add_coverage(cov, 1);
+        cov = add_coverage(cov, (mask[0] & 1u) ? 0u : 2u);
       }
+      rh.coverage = static_cast<uint16_t>(cov);
     }
   }
   // std::map order: ascending haplotype index
@@ -529,11 +561,11 @@ GTX_DEV uint32_t explain_epsilon(Geno const & ge, bool fully, bool unique, bool 
   return static_cast<uint32_t>((e > 8 ? e : 8) - 4);
 }
 
-template <class W, uint32_t NW>
+template <class W, class Tab>
 GTX_DEV void apply_recent(GraphView const & g, ScoreAcc const & acc, Geno const & ge, bool fully, bool unique, uint32_t sample,
-                          RecentHapT<NW> const * recent, uint32_t n, uint32_t order = 0)
+                          Tab recent, uint32_t n, uint32_t order = 0)
 {
-  using RecentHap = RecentHapT<NW>;
+  using RecentHap = typename Tab::entry;
   if (acc.replay_cells)
   {
     for (uint32_t a = 0; a < n; ++a)
@@ -683,19 +715,30 @@ GTX_DEV bool item_is_trivial(gtx_score_item const & it, uint32_t const * records
 
 // r1 / r2: tables of `cap` entries each.  Returns false, with nothing added to the accumulators, when a read of the item
 // touches more than `cap` variant sites (the caller then redoes the item with larger tables).
-template <class W, uint32_t NW>
+// shared: r2 is not looked at -- the second read's entries follow the first read's in r1, `cap` is the room for both.
+template <class W, class Tab>
 GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_item const & it, uint32_t const * records,
-                        uint32_t rec_words, ScoreAcc const & acc, RecentHapT<NW> * r1, RecentHapT<NW> * r2, uint32_t cap)
+                        uint32_t rec_words, ScoreAcc const & acc, Tab r1, Tab r2, uint32_t cap, bool shared = false)
 {
   if (it.second.align_index == INVALID)
   {
     // update_unpaired_read_paths (alignment.cpp:365-455).  clipped_count() returns 0/1, so IS_CLIPPED is never set.
     gtx_rec_meta const & m = it.first;
     uint32_t const mflag = m.flag & 0x7FFFu; // (without GTX_FLAG_FORWARD_ONLY)
+#ifdef GTX_PROF_SCORE // (a one-off profiling build: cycles of the parts of a single read's item, lane 0 of a workgroup, in the express pass' slots)
+    unsigned long long const ps0 = W::clock();
+#define GTX_PS(slot, since) if ((threadIdx.x & 63u) == 0) atomicAdd(g.prof + (slot), W::clock() - (since))
+#else
+#define GTX_PS(slot, since)
+#endif
     Geno fwd = geno_of(records, rec_words, acc, m.align_index, 0);
     Geno rev = (m.flag & GTX_FLAG_FORWARD_ONLY) ? empty_orientation(fwd) : geno_of(records, rec_words, acc, m.align_index, 1);
     if (!fwd.has_var && !rev.has_var)
       return true; // whichever orientation wins, it touches no variant site: nothing to add
+    GTX_PS(16, ps0 + (fwd.n_paths & 0u));
+#ifdef GTX_PROF_SCORE
+    unsigned long long const ps1 = W::clock();
+#endif
     int const which = compare_single(fwd, rev);
     if (which == 0)
       return true;
@@ -708,12 +751,26 @@ GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_
     if (par.is_segment_calling)
       return true;
     bool fully, unique;
-    if (geno_is_good(g, par, ge, fully, unique))
+    bool const good = geno_is_good(g, par, ge, fully, unique);
+    GTX_PS(17, ps1 + (good ? 0u : 0u));
+    if (good)
     {
+#ifdef GTX_PROF_SCORE
+      unsigned long long const ps2 = W::clock();
+#endif
       uint32_t const n = collect_recent(g, ge, r1, cap);
       if (n == 0xFFFFFFFFu)
         return false;
+      GTX_PS(18, ps2 + (n & 0u));
+#ifdef GTX_PROF_SCORE
+      unsigned long long const ps3 = W::clock();
+#endif
       apply_recent<W>(g, acc, ge, fully, unique, it.sample, r1, n);
+      GTX_PS(19, ps3);
+#ifdef GTX_PROF_SCORE
+      if ((threadIdx.x & 63u) == 0)
+        atomicAdd(g.prof + 31, 1ull);
+#endif
     }
     return true;
   }
@@ -779,9 +836,13 @@ GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_
   uint32_t n1 = 0, n2 = 0;
   if (good1)
     n1 = collect_recent(g, first, r1, cap);
+  if (n1 == 0xFFFFFFFFu)
+    return false;
+  if (shared)
+    r2 = r1.after(n1);
   if (good2)
-    n2 = collect_recent(g, second, r2, cap);
-  if (n1 == 0xFFFFFFFFu || n2 == 0xFFFFFFFFu)
+    n2 = collect_recent(g, second, r2, shared ? cap - n1 : cap);
+  if (n2 == 0xFFFFFFFFu)
     return false;
   if (good1)
     apply_recent<W>(g, acc, first, f1, u1, it.sample, r1, n1);
@@ -813,6 +874,14 @@ GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_
     }
   }
   return true;
+}
+
+// the same over two arrays of `cap` entries each
+template <class W, uint32_t NW>
+GTX_DEV bool score_item(GraphView const & g, ScoreParams const & par, gtx_score_item const & it, uint32_t const * records,
+                        uint32_t rec_words, ScoreAcc const & acc, RecentHapT<NW> * r1, RecentHapT<NW> * r2, uint32_t cap)
+{
+  return score_item<W>(g, par, it, records, rec_words, acc, PtrTable<RecentHapT<NW>>{r1}, PtrTable<RecentHapT<NW>>{r2}, cap, false);
 }
 
 // Genotype call of one (sample, haplotype) cell from the accumulators: get_haplotype_phred (src/typer/vcf.cpp:47-82) and
