@@ -44,6 +44,11 @@ constexpr uint64_t PROF_WORDS = 40 + PROF_LOG_ENTRIES * PROF_LOG_ENTRY;
 #ifndef GTX_SCORE_THREADS
 #define GTX_SCORE_THREADS 64 // threads of a gtx_score_kernel workgroup: one wavefront goes wherever a slot is beside another batch's queues (cfg2, steps in flight: 256 / 128 / 64 threads = 0.798 / 0.788 / 0.783 ms per step; alone the same)
 #endif
+#ifdef GTX_SCORE_ADDS_CALLED // (A/B build: one body for all of an item's adds, a call each)
+#define GTX_SCORE_ADD_INLINE __attribute__((noinline))
+#else
+#define GTX_SCORE_ADD_INLINE inline
+#endif
 #ifndef GTX_WAVE_GROUP_MIN
 #define GTX_WAVE_GROUP_MIN 4
 #endif
@@ -130,18 +135,22 @@ struct WaveHipCombine : WaveHip
   static __device__ inline void atomic_add_u32(uint32_t *, uint32_t) {}
   static __device__ inline void atomic_add_u64(unsigned long long *, unsigned long long) {}
 #else
-  static __device__ inline void atomic_add_u32(uint32_t * p, uint32_t v)
+  // (inlined, the fifteen adds of a site times the four places an item's entries are applied make the kernel 131 KB of code, twice
+  //  the instruction cache two CUs share; as ONE body and a call each -- GTX_SCORE_ADDS_CALLED -- it is 49 KB and SLOWER: cfg3
+  //  0.687 ms against 0.634, cfg2 0.160 against 0.146.  The instruction cache is not what the kernel waits for.)
+  static __device__ GTX_SCORE_ADD_INLINE void add_to(unsigned long long address, bool is64, unsigned long long v)
   {
     unsigned long long sum;
-    if (wave_group(reinterpret_cast<unsigned long long>(p), v, sum) && !combine(reinterpret_cast<unsigned long long>(p), false, sum))
-      atomicAdd(p, static_cast<uint32_t>(sum));
+    if (wave_group(address, v, sum) && !combine(address, is64, sum))
+    {
+      if (is64)
+        atomicAdd(reinterpret_cast<unsigned long long *>(address), sum);
+      else
+        atomicAdd(reinterpret_cast<uint32_t *>(address), static_cast<uint32_t>(sum));
+    }
   }
-  static __device__ inline void atomic_add_u64(unsigned long long * p, unsigned long long v)
-  {
-    unsigned long long sum;
-    if (wave_group(reinterpret_cast<unsigned long long>(p), v, sum) && !combine(reinterpret_cast<unsigned long long>(p), true, sum))
-      atomicAdd(p, sum);
-  }
+  static __device__ inline void atomic_add_u32(uint32_t * p, uint32_t v) { add_to(reinterpret_cast<unsigned long long>(p), false, v); }
+  static __device__ inline void atomic_add_u64(unsigned long long * p, unsigned long long v) { add_to(reinterpret_cast<unsigned long long>(p), true, v); }
 #endif
   // all threads of the workgroup
   static __device__ inline void clear(unsigned long long base)

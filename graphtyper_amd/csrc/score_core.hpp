@@ -606,10 +606,12 @@ GTX_DEV void apply_recent(GraphView const & g, ScoreAcc const & acc, Geno const 
   uint64_t const nh = g.n_hap;
   for (uint32_t a = 0; a < n; ++a)
   {
-    RecentHap const & rh = recent[a];
+    RecentHap const rh = recent[a];
     uint32_t const h = rh.site;
+    // (the site's three table entries in one round trip: a load behind an atomic is not moved in front of it by the compiler)
     uint32_t const cnum = g.ref_nvar[h];
     uint64_t const aoff = g.allele_off[h];
+    uint64_t const toff = g.tri_off[h];
     uint32_t const cov = rh.coverage;
     bool const unique_allele = cov < MULTI_REF_COVERAGE;
     // clipped_reads_to_stats (haplotype.cpp:229-244)
@@ -647,7 +649,7 @@ GTX_DEV void apply_recent(GraphView const & g, ScoreAcc const & acc, Geno const 
     uint32_t const eps = explain_epsilon(ge, fully, unique, rh.overlapping);
     uint32_t * cell = acc.hap_u32 + (static_cast<uint64_t>(sample) * nh + h) * 4;
     W::atomic_add_u32(cell + 0, eps);
-    uint32_t * ls = acc.log_score + static_cast<uint64_t>(sample) * g.total_tri + g.tri_off[h];
+    uint32_t * ls = acc.log_score + static_cast<uint64_t>(sample) * g.total_tri + toff;
     uint32_t idx = 0;
     for (uint32_t y = 0; y < cnum; ++y)
     {
