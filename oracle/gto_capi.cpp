@@ -991,6 +991,30 @@ extern "C"
     r.cigar_back = cigar_back;
     return Genotyper::is_good_read(r) ? 1 : 0;
   }
+  // make_bi_allelic_call (sample_call.cpp:188-253): d = ambiguous_depth, ref_total_depth, alt_total_depth, alt_proper_pair_depth,
+  // then the call's coverage (n_cov values); out = the reduced call's coverage[0], coverage[1], ambiguous_depth, ref_total_depth,
+  // alt_total_depth, alt_proper_pair_depth, phred[0..2]
+  void gto_make_bi_allelic_call(uint32_t const * d, long n_cov, uint8_t const * phred, long n_phred, long aa, uint32_t * out)
+  {
+    vcf::SampleCall oc;
+    oc.ambiguous_depth = static_cast<uint8_t>(d[0]);
+    oc.ref_total_depth = static_cast<uint16_t>(d[1]);
+    oc.alt_total_depth = static_cast<uint16_t>(d[2]);
+    oc.alt_proper_pair_depth = static_cast<uint8_t>(d[3]);
+    for (long i = 0; i < n_cov; ++i)
+      oc.coverage.push_back(static_cast<uint16_t>(d[4 + i]));
+    oc.phred.assign(phred, phred + n_phred);
+    vcf::SampleCall const c = vcf::make_bi_allelic_call(oc, aa);
+    out[0] = c.coverage[0];
+    out[1] = c.coverage[1];
+    out[2] = c.ambiguous_depth;
+    out[3] = c.ref_total_depth;
+    out[4] = c.alt_total_depth;
+    out[5] = c.alt_proper_pair_depth;
+    for (int i = 0; i < 3; ++i)
+      out[6 + i] = i < static_cast<int>(c.phred.size()) ? c.phred[i] : 0xFFFFu;
+  }
+
   // State of one (haplotype, sample) cell set by hand, for the phase flags (hts_parallel_reader.cpp:782-904 reads nothing else):
   // gt_coverage (n_cov > 0) and the support vector of the connections from allele1 of this haplotype to haplotype hap2
   // (n_support > 0).  Returns the haplotype's variant order (gt.id), -1 when hap / sample are out of range.

@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--limit", type=int, default=0)
     ap.add_argument("--every", type=int, default=1, help="take every K-th mutant (a sample)")
     ap.add_argument("--lines", default="", help="A-B: only the mutants on these lines (a look at one function)")
+    ap.add_argument("--merge", action="store_true", help="put this run's results into audit_auto.json in place of the same mutants' old ones")
     ap.add_argument("--list", action="store_true")
     a = ap.parse_args()
     mutants = [m for f in a.file for m in mutants_of(f)][::a.every]
@@ -150,7 +151,30 @@ def main():
     survivors = [dict(id=r["id"], func=r["func"], change="%s -> %s" % (r["find"], r["replace"]), text=r["text"]) for r in results if r["status"] == "SURVIVED"]
     out = dict(kill_suite=run_audit.KILL_SUITE, every=a.every, total=len(results), killed=sum(r["status"] == "killed" for r in results),
                survived=len(survivors), does_not_compile=sum(r["status"] == "does not compile" for r in results), per_function=by_file, survivors=survivors)
+    if a.merge:  # the mutants of this run replace their entries in audit_auto.json (after a new vector: only its function is run again)
+        full = json.load(open(os.path.join(HERE, "audit_auto.json")))
+        done = {r["id"] for r in results}
+        before = {s["id"] for s in full["survivors"]}
+        full["survivors"] = sorted([s for s in full["survivors"] if s["id"] not in done] + survivors, key=lambda s: (s["id"].split(":")[0], int(s["id"].split(":")[1]), int(s["id"].split(":")[2])))
+        for r in results:
+            d = full["per_function"][r["file"]][r["func"]]
+            was = "survived" if r["id"] in before else None
+            now = {"killed": "killed", "SURVIVED": "survived"}.get(r["status"])
+            if was == "survived" and now == "killed":
+                d["survived"] -= 1
+                d["killed"] += 1
+            elif was is None and now == "survived":  # (was killed or did not compile)
+                d["survived"] += 1
+                d["killed"] -= 1
+        full["killed"] = sum(c["killed"] for f in full["per_function"].values() for c in f.values())
+        full["survived"] = len(full["survivors"])
+        full["kill_suite"] = run_audit.KILL_SUITE
+        json.dump(full, open(os.path.join(HERE, "audit_auto.json"), "w"), indent=1)
+        open(os.path.join(HERE, "audit_auto.json"), "a").write("\n")
+        print("merged into audit_auto.json: %d killed, %d survived" % (full["killed"], full["survived"]))
     name = "audit_auto.json" if a.every == 1 and not a.limit and not a.lines and len(a.file) == 3 else "audit_auto_partial.json"
+    if a.merge:
+        name = "audit_auto_partial.json"
     json.dump(out, open(os.path.join(HERE, name), "w"), indent=1)
     open(os.path.join(HERE, name), "a").write("\n")
     print("%d mutants: %d killed, %d survived, %d do not compile  (%.0f s) -> %s" % (out["total"], out["killed"], out["survived"], out["does_not_compile"], time.time() - t0, name))

@@ -282,3 +282,40 @@ def test_phase_flags_of_a_site_with_two_alternative_alleles():
     _poke(og, 0, 1, [5, 5], 1, 1, [0, 1, 9])          # a second sample sees it the other way round
     _poke(og, 1, 1, [4, 4, 4])
     assert [tuple(int(x) for x in r) for r in og.phase_flags()] == [(0, 1, 1, 1, HAP | ANTI), (0, 1, 1, 2, HAP | ANTI)]
+
+
+# ---- make_bi_allelic_call (src/typer/sample_call.cpp:188-253): a call over several alternative alleles reduced to the reference
+# allele and ONE of them.  (ambiguous_depth, ref_total_depth, alt_total_depth, alt_proper_pair_depth, coverage, the allele kept)
+# -> (coverage, ambiguous_depth, ref_total_depth, alt_total_depth, alt_proper_pair_depth, phred), each worked through the text:
+#   ambiguous_depth_alt = min(ambiguous, cov[0] + ambiguous - ref_total) leaves `ambiguous`; cov_aa = alt_total - ambiguous, minus every
+#   OTHER alternative allele's coverage (which also leave alt_total and alt_proper_pair, floored at 0); phred of 0/0 = 24 per proper
+#   alt read + 12 per other alt read, of 0/1 = 3 per read, of 1/1 = 24 per reference read, minus the smallest, capped at 255.
+BI = [
+    ((3, 12, 13, 9, [10, 4, 6], 0), ([10, 5], 2, 12, 7, 3, [51, 0, 195])),   # 1 + ambiguity leaves; allele 2's six reads leave; 3 x 24 + 2 x 12 = 96 | 45 | 240
+    ((3, 12, 13, 9, [10, 4, 6], 1), ([10, 7], 2, 12, 9, 5, [93, 0, 189])),   # allele 1's four leave: 5 x 24 + 2 x 12 = 144 | 51 | 240
+    ((0, 2, 5, 3, [2, 20, 1], 1), ([2, 0], 0, 2, 0, 0, [0, 6, 48])),          # a depth that overflowed: everything floors at 0
+    ((0, 0, 30, 30, [0, 30, 0], 0), ([0, 30], 0, 0, 30, 30, [255, 90, 0])),   # 720 is capped
+    ((4, 20, 9, 1, [5, 3, 2], 0), ([5, 0], 15, 20, 7, 0, [0, 15, 120])),      # cov[0] + ambiguous - ref_total = -11: the ambiguous depth GROWS by 11
+    ((0, 1, 9, 9, [1, 2, 3, 4], 1), ([1, 3], 0, 1, 3, 3, [60, 0, 12])),       # four alleles: 1 and 3 leave; 72 | 12 | 24
+]
+
+
+@pytest.mark.parametrize("k", range(len(BI)))
+def test_make_bi_allelic_call(k):
+    (amb, ref_total, alt_total, alt_proper, cov, aa), (want_cov, w_amb, w_ref, w_alt, w_proper, w_phred) = BI[k]
+    L = oracle_lib.lib()
+    d = np.array([amb, ref_total, alt_total, alt_proper] + cov, np.uint32)
+    phred = np.zeros(len(cov) * (len(cov) + 1) // 2, np.uint8)
+    out = np.zeros(9, np.uint32)
+    L.gto_make_bi_allelic_call(d.ctypes.data_as(C.c_void_p), C.c_long(len(cov)), phred.ctypes.data_as(C.c_void_p), C.c_long(len(phred)), C.c_long(aa),
+                               out.ctypes.data_as(C.c_void_p))
+    assert out.tolist() == want_cov + [w_amb, w_ref, w_alt, w_proper] + w_phred
+
+
+def test_a_bi_allelic_call_is_returned_as_it_is():
+    L = oracle_lib.lib()
+    d = np.array([7, 9, 11, 5, 7, 8], np.uint32)
+    phred = np.array([1, 2, 3], np.uint8)
+    out = np.zeros(9, np.uint32)
+    L.gto_make_bi_allelic_call(d.ctypes.data_as(C.c_void_p), C.c_long(2), phred.ctypes.data_as(C.c_void_p), C.c_long(3), C.c_long(0), out.ctypes.data_as(C.c_void_p))
+    assert out.tolist() == [7, 8, 7, 9, 11, 5, 1, 2, 3]
