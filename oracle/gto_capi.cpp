@@ -991,6 +991,50 @@ extern "C"
     r.cigar_back = cigar_back;
     return Genotyper::is_good_read(r) ? 1 : 0;
   }
+  // are_genotype_paths_good (vcf_writer.cpp:28-60) of a GenotypePaths given as numbers: per path start, end, read_start_index,
+  // read_end_index, mismatches; the graph (is_sv_graph) and the options (hq_reads) are the genotyper's
+  int gto_paths_good(void * p, long read_length, long n_paths, uint32_t const * d)
+  {
+    auto & writer = static_cast<GenoHandle *>(p)->g->writer;
+    GenotypePaths geno(0, static_cast<std::size_t>(read_length));
+    for (long i = 0; i < n_paths; ++i)
+    {
+      Path path;
+      path.start = d[5 * i];
+      path.end = d[5 * i + 1];
+      path.read_start_index = static_cast<uint16_t>(d[5 * i + 2]);
+      path.read_end_index = static_cast<uint16_t>(d[5 * i + 3]);
+      path.mismatches = static_cast<uint16_t>(d[5 * i + 4]);
+      geno.paths.push_back(path);
+    }
+    return writer.are_genotype_paths_good(geno) ? 1 : 0;
+  }
+
+  // the coverage filter of SV calling (hts_parallel_reader.cpp:594-633) over records given as (position, sample), in order; the
+  // first record's position is the bins' origin.  out[i] = 1: the record is let through
+  void gto_bin_filter(void * p, long n, int64_t const * pos, int32_t const * sample, uint8_t * out)
+  {
+    auto & g = *static_cast<GenoHandle *>(p)->g;
+    g.bin_counts.clear();
+    g.first_pos = n > 0 ? pos[0] : 0;
+    for (long i = 0; i < n; ++i)
+    {
+      ReadRecord r;
+      r.pos = pos[i];
+      r.sample = sample[i];
+      out[i] = g.update_bin_count(r) ? 1 : 0;
+    }
+  }
+
+  // Haplotype::add_coverage (haplotype.cpp:179-227) over a sequence of alleles, from NO_COVERAGE: the state it ends in
+  uint32_t gto_add_coverage(uint16_t const * alleles, long n)
+  {
+    Haplotype h;
+    for (long i = 0; i < n; ++i)
+      h.add_coverage(alleles[i]);
+    return h.coverage;
+  }
+
   // make_bi_allelic_call (sample_call.cpp:188-253): d = ambiguous_depth, ref_total_depth, alt_total_depth, alt_proper_pair_depth,
   // then the call's coverage (n_cov values); out = the reduced call's coverage[0], coverage[1], ambiguous_depth, ref_total_depth,
   // alt_total_depth, alt_proper_pair_depth, phred[0..2]

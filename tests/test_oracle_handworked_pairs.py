@@ -319,3 +319,157 @@ def test_a_bi_allelic_call_is_returned_as_it_is():
     out = np.zeros(9, np.uint32)
     L.gto_make_bi_allelic_call(d.ctypes.data_as(C.c_void_p), C.c_long(2), phred.ctypes.data_as(C.c_void_p), C.c_long(3), C.c_long(0), out.ctypes.data_as(C.c_void_p))
     assert out.tolist() == [7, 8, 7, 9, 11, 5, 1, 2, 3]
+
+
+# ---- are_genotype_paths_good (src/typer/vcf_writer.cpp:28-60).  A path = (start, end, read_start_index, read_end_index, mismatches);
+# its size is read_end_index - read_start_index + 1.  (graph kind, hq_reads, read length, paths, good?)
+def pth(size, mm=0, start=1000, rs=0):
+    return (start, start + size - 1, rs, rs + size - 1, mm)
+
+
+GOOD = [
+    ("snp", False, 150, [], False),                                   # no path
+    ("snp", False, 150, [pth(150, 7)], True),                         # 7 / 150 = 0.047
+    ("snp", False, 150, [pth(150, 8)], False),                        # 0.053 > 0.05
+    ("snp", False, 100, [pth(100, 5)], True),                         # exactly 0.05 is not > 0.05
+    ("snp", False, 150, [pth(149, 3, rs=1)], True),                   # not the whole read: 0.025 is the limit; 3 / 149 = 0.020
+    ("snp", False, 150, [pth(149, 4, rs=1)], False),                  # 0.027
+    ("snp", False, 150, [pth(120, 3)], True),                         # exactly 0.025
+    ("snp", False, 150, [pth(62)], False),                            # not the whole read and fewer than 63 bases
+    ("snp", False, 150, [pth(63)], True),
+    ("snp", False, 150, [pth(149, 0, 1000, 1), pth(149, 0, 2000, 1)], False),   # not the whole read, two places (neither end shared)
+    ("snp", False, 150, [pth(149, 0, 1000, 1), pth(140, 0, 1000, 1)], True),    # ... the same start: one place
+    ("snp", False, 150, [pth(149, 0, 1000, 1), pth(50, 0, 1000, 1)], True),     # paths[0] is the one that is measured
+    ("snp", False, 150, [pth(150, 0, 1000), pth(150, 0, 2000)], True),          # the whole read: two places do not matter here
+    ("snp", False, 150, [pth(150, 6)], True),                         # 0.04: fine without hq_reads / SV rules
+    ("sv", False, 100, [pth(100, 3)], True),                          # SV graph: whole read, >= 90 bases, <= 0.03
+    ("sv", False, 100, [pth(100, 4)], False),
+    ("sv", False, 150, [pth(149, 0, rs=1)], False),
+    ("sv", False, 89, [pth(89)], False),
+    ("sv", False, 90, [pth(90)], True),
+    ("snp", True, 200, [pth(200, 7)], True),                          # hq_reads: <= 0.035
+    ("snp", True, 200, [pth(200, 8)], False),                         # 0.04
+    ("snp", True, 150, [pth(149, 0, rs=1)], False),
+    ("snp", True, 89, [pth(89)], False),
+    ("snp", True, 90, [pth(90)], True),
+]
+
+_GOOD_ORACLES = {}
+
+
+@pytest.mark.parametrize("k", range(len(GOOD)))
+def test_are_genotype_paths_good(k):
+    from graphtyper_amd import synth
+    kind, hq, read_length, paths, want = GOOD[k]
+    if (kind, hq) not in _GOOD_ORACLES:
+        ref = synth.make_reference(600, seed=3)
+        recs = [(5000 + 300, "ACGT"[ref[300]], ["ACGT"[(ref[300] + 1) % 4]], None)]
+        _GOOD_ORACLES[(kind, hq)] = Oracle(synth.bases_to_str(ref), recs, region_begin=5000, is_sv_graph=(kind == "sv"), hq_reads=hq)
+    og = _GOOD_ORACLES[(kind, hq)].genotyper(1, 1)
+    d = np.array([x for p in paths for x in p] or [0], np.uint32)
+    got = oracle_lib.lib().gto_paths_good(C.c_void_p(og.g), C.c_long(read_length), C.c_long(len(paths)), d.ctypes.data_as(C.c_void_p))
+    assert bool(got) == want
+
+
+# ---- the coverage filter of SV calling (src/utilities/hts_parallel_reader.cpp:594-633): per sample, bins of 50 positions from the
+# first record's position; a bin lets max_bin_count + 1 reads through, max_bin_count = min(65535, (long)(avg_cov_by_readlen x 50 x 3 + 0.5)).
+def _bins(avg_cov, records, kind="sv", no_filter=False):
+    from graphtyper_amd import synth
+    key = (kind, False)
+    if key not in _GOOD_ORACLES:
+        ref = synth.make_reference(600, seed=3)
+        recs = [(5000 + 300, "ACGT"[ref[300]], ["ACGT"[(ref[300] + 1) % 4]], None)]
+        _GOOD_ORACLES[key] = Oracle(synth.bases_to_str(ref), recs, region_begin=5000, is_sv_graph=(kind == "sv"), hq_reads=False)
+    og = _GOOD_ORACLES[key].genotyper(max(s for _, s in records) + 1, 1)
+    og.set_coverage(avg_cov, no_filter_on_coverage=no_filter)
+    pos = np.array([p for p, _ in records], np.int64)
+    sample = np.array([s for _, s in records], np.int32)
+    out = np.zeros(len(records), np.uint8)
+    oracle_lib.lib().gto_bin_filter(C.c_void_p(og.g), C.c_long(len(records)), pos.ctypes.data_as(C.c_void_p), sample.ctypes.data_as(C.c_void_p),
+                                    out.ctypes.data_as(C.c_void_p))
+    return out.tolist()
+
+
+def test_coverage_filter_of_sv_calling():
+    # 0.02 x 150 + 0.5 = 3.5 -> 3: the first read makes the bin (count 1), reads come through while the count is not > 3 (it reaches
+    # 4), the fifth and sixth are dropped; position 1050 is the next bin
+    seq = [(1000, 0), (1010, 0), (1020, 0), (1030, 0), (1040, 0), (1049, 0), (1050, 0)]
+    assert _bins([0.02], seq) == [1, 1, 1, 1, 0, 0, 1]
+    # every sample counts for itself (sample 1: 0.0134 x 150 + 0.5 = 2.51 -> 2: three reads per bin)
+    mixed = [(1000, 0), (1000, 1), (1001, 1), (1002, 0), (1003, 1), (1004, 1), (1005, 0), (1006, 0), (1007, 0)]
+    assert _bins([0.02, 0.0134], mixed) == [1, 1, 1, 1, 1, 0, 1, 1, 0]
+    # a bin that was skipped is made with the bins up to the one that is new; its count starts at 0
+    assert _bins([0.02], [(1000, 0), (1200, 0), (1100, 0), (1101, 0), (1102, 0), (1103, 0), (1104, 0)]) == [1, 1, 1, 1, 1, 1, 0]
+    # 0.3 x 150 + 0.5 = 45.5 -> 45: 46 reads, the 47th is dropped
+    assert _bins([0.3], [(1000 + (i % 50), 0) for i in range(48)]) == [1] * 46 + [0, 0]
+    # the cap of 65535 (1000 x 150 is far above it): two reads in a bin are fine
+    assert _bins([1000.0], [(1000, 0), (1001, 0), (1002, 0)]) == [1, 1, 1]
+    # nothing known about the sample (no entry, or 0): no filter
+    assert _bins([0.02], [(1000, 1)] * 9) == [1] * 9
+    assert _bins([0.0], [(1000, 0)] * 9) == [1] * 9
+    # switched off, or not an SV graph: no filter
+    assert _bins([0.02], [(1000, 0)] * 9, no_filter=True) == [1] * 9
+    assert _bins([0.02], [(1000, 0)] * 9, kind="snp") == [1] * 9
+
+
+# ---- Haplotype::add_coverage (src/graph/haplotype.cpp:179-227): which allele the paths of ONE read cover at a site
+NO_COV, MULTI_ALT, MULTI_REF = 0xFFFF, 0xFFFE, 0xFFFD  # include/graphtyper/graph/haplotype.hpp:86-88
+COVER = [([], NO_COV), ([1], 1), ([0], 0), ([1, 1], 1), ([0, 0], 0), ([1, 2], MULTI_ALT), ([2, 1], MULTI_ALT), ([1, 0], MULTI_REF), ([0, 1], MULTI_REF),
+         ([1, 2, 3], MULTI_ALT), ([1, 2, 0], MULTI_REF), ([1, 0, 2], MULTI_REF), ([1, 2, 2], MULTI_ALT), ([0, 3, 0], MULTI_REF), ([2, 2, 0, 2], MULTI_REF)]
+
+
+@pytest.mark.parametrize("k", range(len(COVER)))
+def test_add_coverage(k):
+    seq, want = COVER[k]
+    a = np.array(seq or [0], np.uint16)
+    L = oracle_lib.lib()
+    L.gto_add_coverage.restype = C.c_uint32
+    assert L.gto_add_coverage(a.ctypes.data_as(C.c_void_p), C.c_long(len(seq))) == want
+
+
+# ---- the statistics one read leaves at the site it covers (haplotype.cpp:229-311 through push_to_haplotype_scores).
+# Three SNP sites far apart, a read of 143 bases over each, drawn with the alternative allele.  Their last 18 bases are complemented:
+# the four k-mers cover bases 0..124, the walk over the rest may take 2 + 19 / 11 = 3 mismatches and finds 18 -- the path stays at
+# 125 bases: 18 bases are "clipped".  143 is chosen because 18 x 1000 / 143 = 125 but 18 x 1001 / 143 = 126, and 1000 / 143 = 6 but
+# 1001 / 143 = 7: the scale of the per-allele statistics is pinned to the unit.
+def test_statistics_one_read_leaves():
+    from graphtyper_amd import synth
+    ref = synth.make_reference(3000, seed=21)
+    rb = 70000
+    sites = [500, 1500, 2500]
+    recs = [(rb + p, "ACGT"[ref[p]], ["ACGT"[(ref[p] + 2) % 4]], None) for p in sites]
+    og = Oracle(synth.bases_to_str(ref), recs, region_begin=rb).genotyper(1, 1)
+    reads, kw = [], dict(flags=[], mapq=[], score_diff=[], pos=[])
+
+    def read_over(site, mismatch_at, flag, mapq, score_diff):
+        s = site - 70
+        r = ref[s:s + 143].copy()
+        r[70] = (ref[site] + 2) % 4
+        if mismatch_at is not None:
+            r[mismatch_at] = (r[mismatch_at] + 1) % 4
+        r[125:] = 3 - r[125:]  # complemented: A<->T, C<->G
+        reads.append(synth._CODE_OF_BASE[r])
+        kw["flags"].append(flag); kw["mapq"].append(mapq); kw["score_diff"].append(score_diff); kw["pos"].append(s + rb)
+
+    read_over(500, 50, 0, 37, 5)          # one mismatch (in the second k-mer: found one substitution away), forward, not first in pair
+    read_over(1500, None, 0x10, 255, 0)   # no mismatch; reverse strand; mapping quality unavailable; no score difference
+    read_over(2500, None, 0x40, 60, 1)    # first in pair (alone: its mate never comes), forward
+    og.push(reads, flags=np.array(kw["flags"], np.uint16), mapq=np.array(kw["mapq"], np.uint8), score_diff=np.array(kw["score_diff"], np.uint8),
+            pos=np.array(kw["pos"], np.int64))
+    og.finish()
+    s = og.scores().tolist()
+    # per haplotype: id, num, clipped_reads, mapq_squared (lo, hi), 2 x [clipped_bp lo hi, mapq_squared lo hi, score_diff, mismatches, r1f, r1r, r2f, r2r],
+    #                then per sample max_log_score, 3 depths, gt_coverage[2], log_score[3], per allele its connections
+    per = 5 + 2 * 10 + 4 + 2 + 3 + 2
+    assert len(s) == 3 * per
+    h = [s[k * per:(k + 1) * per] for k in range(3)]
+    alt = lambda hh: hh[5 + 10:5 + 20]
+    refa = lambda hh: hh[5:5 + 10]
+    for hh in h:
+        assert hh[1] == 2 and refa(hh) == [0] * 10 and hh[5 + 20 + 4:5 + 20 + 6] == [0, 1]  # the read is counted for the alternative allele
+    assert h[0][2] == 1 and h[0][3:5] == [37 * 37, 0]
+    assert alt(h[0]) == [125, 0, 37 * 37, 0, 5, 6, 0, 0, 1, 0]   # 18 000 / 143, 1 369, score difference 5, 1 000 / 143, r2 forward
+    assert h[1][2] == 1 and h[1][3:5] == [0, 0]                  # mapping quality 255: nothing added
+    assert alt(h[1]) == [125, 0, 0, 0, 0, 0, 0, 0, 0, 1]         # r2 reverse
+    assert h[2][2] == 1 and h[2][3:5] == [3600, 0]
+    assert alt(h[2]) == [125, 0, 3600, 0, 1, 0, 1, 0, 0, 0]      # r1 forward
