@@ -20,7 +20,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 KILL_SUITE = ["tests/test_oracle_truth.py", "tests/test_oracle_handworked.py", "tests/test_oracle_pinned.py", "tests/test_sv_vcf.py::test_coverage_model_hand_worked",
-              "tests/test_oracle_vcf_truth.py", "tests/test_oracle_handworked_pairs.py", "tests/test_oracle_merge.py", "tests/test_oracle_truth_walks.py"]
+              "tests/test_oracle_vcf_truth.py", "tests/test_oracle_handworked_pairs.py", "tests/test_oracle_merge.py", "tests/test_oracle_truth_walks.py", "tests/test_oracle_truth_pairs.py"]
 
 
 def apply(mutant, oracle_dir):
