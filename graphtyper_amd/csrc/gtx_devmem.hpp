@@ -4,7 +4,7 @@
 // scratch, the HBM-table workspaces -- lives for milliseconds, and hipMalloc / hipFree (each hipFree also waits for the
 // device) of its ~50 allocations were most of what creating one cost.  Freed blocks are kept per device in size classes
 // and handed out again; nothing is returned to the driver before the cache holds more than its limit (GTX_DEVICE_CACHE_MB,
-// default 8192) or gtx_device_cache_release() is called.  A block goes back to the cache only when no kernel can still use
+// default 32768) or gtx_device_cache_release() is called.  A block goes back to the cache only when no kernel can still use
 // it: callers free after the work on it is known to be done (context destruction and the index build synchronise first).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -241,7 +241,7 @@ void gtx_ctx_destroy(gtx_ctx *);
 /* Device memory of contexts, their scratch and gtx_scores_alloc blocks comes from a process-wide cache: what a destroyed
  * context held is handed to the next one instead of going back to the driver (a region's context lives for milliseconds, and
  * hipMalloc / hipFree were most of what creating one cost).  The cache keeps at most GTX_DEVICE_CACHE_MB (environment, default
- * 8192) and is emptied by this call. */
+ * 32768) and is emptied by this call. */
 void gtx_device_cache_release(void);
 
 /* Graph facts derived at creation (Graph::create_special_positions, graph.cpp:384-407). out arrays may be NULL. */
