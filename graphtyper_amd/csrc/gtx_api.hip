@@ -2934,6 +2934,21 @@ extern "C" int gtx_records_failed(gtx_ctx * c, const uint32_t * d_records, uint3
   return GTX_OK;
 }
 
+int gtx::records_failed_enqueue(gtx_ctx * c, const uint32_t * d_records, uint32_t rec_words, uint64_t n_reads, void * stream, unsigned long long * d_count)
+{
+  if (!c || !d_count || rec_words < 8 || (n_reads && !d_records) || c->device < 0)
+    return GTX_ERR_ARG;
+  hipStream_t const st = static_cast<hipStream_t>(stream);
+  if (!hip_ok(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st), "failed-record counter"))
+    return GTX_ERR_HIP;
+  if (n_reads == 0)
+    return GTX_OK;
+  uint64_t const slots = 2ull * n_reads;
+  uint32_t const blocks = static_cast<uint32_t>(std::min<uint64_t>((slots + 255u) / 256u, 4096u));
+  hipLaunchKernelGGL(gtx_records_failed_kernel, dim3(blocks), dim3(256), 0, st, d_records, rec_words, slots, d_count);
+  return hip_ok(hipGetLastError(), "gtx_records_failed_kernel launch") ? GTX_OK : GTX_ERR_HIP;
+}
+
 // the general pass' task log of the profiling build (no entry in the normal build): up to `cap` entries of 16 words into `out`,
 // their number into *n; the log is emptied
 extern "C" int gtx_ctx_profile_log(gtx_ctx * c, uint64_t * out, uint64_t cap, uint64_t * n)

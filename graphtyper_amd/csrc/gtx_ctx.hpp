@@ -164,6 +164,10 @@ struct gtx_ctx
 namespace gtx
 {
 extern thread_local std::string g_last_error;
+// gtx_scores_alloc with the block zeroed on `stream` (no wait: for a caller whose first use of the block is on that stream)
+int scores_alloc_on(gtx_ctx * c, uint32_t n_samples, uint32_t conn_cap, gtx_score_buffers * out, uint64_t * reduced_bytes, void * stream);
+// gtx_records_failed without its wait: zeroes *d_count and queues the count on `stream`
+int records_failed_enqueue(gtx_ctx * c, const uint32_t * d_records, uint32_t rec_words, uint64_t n_reads, void * stream, unsigned long long * d_count);
 int ctx_upload(gtx_ctx & c, int device); // graph tables + per-call scratch (no index)
 void ctx_release_device(gtx_ctx & c);
 int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<EmitRun> const & runs); // gtx_index_dev.hip

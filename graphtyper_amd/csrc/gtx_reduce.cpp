@@ -123,9 +123,9 @@ bool is_packed(Sections const & s, gtx_score_buffers const & b)
 }
 } // namespace
 
-extern "C"
+// (on_stream: the block is zeroed on `stream` and the call does not wait -- for a caller whose first use of it is on that stream)
+static int scores_alloc_impl(gtx_ctx * c, uint32_t n_samples, uint32_t conn_cap, gtx_score_buffers * out, uint64_t * reduced_bytes, void * stream, bool on_stream)
 {
-  int gtx_scores_alloc(gtx_ctx * c, uint32_t n_samples, uint32_t conn_cap, gtx_score_buffers * out, uint64_t * reduced_bytes)
   {
     if (!c || !out || n_samples == 0)
     {
@@ -143,7 +143,8 @@ extern "C"
     uint64_t const reduced = s.stat_u64 * 8 + s.u32_total() * 4;
     uint64_t const bytes = reduced + 2 * 4 + static_cast<uint64_t>(conn_cap) * 6 * 4;
     void * p = nullptr;
-    if (hipSetDevice(c->device) != hipSuccess || gtx::dev_malloc(&p, bytes ? bytes : 8) != hipSuccess || gtx::dev_zero(p, bytes) != hipSuccess)
+    if (hipSetDevice(c->device) != hipSuccess || gtx::dev_malloc(&p, bytes ? bytes : 8) != hipSuccess ||
+        (on_stream ? hipMemsetAsync(p, 0, bytes, static_cast<hipStream_t>(stream)) : gtx::dev_zero(p, bytes)) != hipSuccess)
     {
       if (p)
         (void)gtx::dev_free(p);
@@ -167,6 +168,19 @@ extern "C"
     if (reduced_bytes)
       *reduced_bytes = reduced;
     return GTX_OK;
+  }
+}
+
+int gtx::scores_alloc_on(gtx_ctx * c, uint32_t n_samples, uint32_t conn_cap, gtx_score_buffers * out, uint64_t * reduced_bytes, void * stream)
+{
+  return scores_alloc_impl(c, n_samples, conn_cap, out, reduced_bytes, stream, true);
+}
+
+extern "C"
+{
+  int gtx_scores_alloc(gtx_ctx * c, uint32_t n_samples, uint32_t conn_cap, gtx_score_buffers * out, uint64_t * reduced_bytes)
+  {
+    return scores_alloc_impl(c, n_samples, conn_cap, out, reduced_bytes, nullptr, false);
   }
 
   int gtx_scores_zero(gtx_ctx * c, const gtx_score_buffers * b, void * stream)

@@ -190,8 +190,16 @@ extern "C" int gtx_regions_run(gtx_region_job * jobs, uint32_t n_jobs, const gtx
     hipStream_t st = nullptr;
     void *d_rec = nullptr, *d_fl = nullptr;
     size_t const rec_bytes = static_cast<size_t>(std::max<uint64_t>(max_reads, 1)) * 2 * rec_words * 4, fl_bytes = static_cast<size_t>(std::max<uint64_t>(max_reads, 1)) * 2;
+    void * d_failed_v = nullptr;
+    uint8_t * pinned = nullptr;
+    size_t pinned_cap = 0;
+    // (the record slots are recycled from region to region as they are: a call writes the record and the flag byte of every task
+    //  it is given, and a region's items name that region's tasks only)
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
-              gtx::dev_malloc(&d_rec, rec_bytes) == hipSuccess && gtx::dev_malloc(&d_fl, fl_bytes) == hipSuccess;
+              gtx::dev_malloc(&d_rec, rec_bytes) == hipSuccess && gtx::dev_malloc(&d_fl, fl_bytes) == hipSuccess &&
+              gtx::dev_malloc(&d_failed_v, 8) == hipSuccess && hipMemsetAsync(d_rec, 0, rec_bytes, st) == hipSuccess &&
+              hipMemsetAsync(d_fl, 0, fl_bytes, st) == hipSuccess;
+    unsigned long long * const d_failed = static_cast<unsigned long long *>(d_failed_v);
     Built b;
     while (built.get(b))
     {
@@ -209,7 +217,11 @@ extern "C" int gtx_regions_run(gtx_region_job * jobs, uint32_t n_jobs, const gtx
       if (rc == GTX_OK)
         rc = gtx_ctx_score_layout(c, &lay);
       uint64_t const n_phred = static_cast<uint64_t>(n_samples) * lay.total_tri, n_calls = static_cast<uint64_t>(n_samples) * lay.n_hap;
-      if (rc == GTX_OK && (rc = gtx_scores_alloc(c, n_samples, conn_cap, &acc, nullptr)) != GTX_OK)
+      // Everything of a region is queued on the thread's stream and waited for ONCE: the accumulator block zeroed on the stream, the
+      // three launches' work, the count of records that are a table-overflow status, and the results -- into one pinned buffer (a copy
+      // into pageable memory waits for the device before it returns: six of them, the overflow count's own wait and the error flag's
+      // were eight round trips per region; a device thread spent 1.2 ms on a region whose kernels take 0.3).
+      if (rc == GTX_OK && (rc = gtx::scores_alloc_on(c, n_samples, conn_cap, &acc, nullptr, st)) != GTX_OK)
         what = gtx_last_error();
       if (rc == GTX_OK && (gtx::dev_malloc(&d_phred, std::max<uint64_t>(n_phred, 1)) != hipSuccess ||
                            gtx::dev_malloc(&d_calls, std::max<uint64_t>(n_calls, 1) * sizeof(gtx_sample_call)) != hipSuccess))
@@ -217,9 +229,7 @@ extern "C" int gtx_regions_run(gtx_region_job * jobs, uint32_t n_jobs, const gtx
         rc = GTX_ERR_HIP;
         what = "gtx_regions_run: device memory for the calls";
       }
-      // (the slots are recycled from region to region: a read without a task must not show the region before's record)
-      if (rc == GTX_OK && (hipMemsetAsync(d_rec, 0, static_cast<size_t>(j.n_reads) * 2 * rec_words * 4, st) != hipSuccess ||
-                           hipMemsetAsync(d_fl, 0, static_cast<size_t>(j.n_reads) * 2, st) != hipSuccess))
+      if (rc == GTX_OK && j.n_reads && hipMemsetAsync(d_fl, 0, static_cast<size_t>(j.n_reads) * 2, st) != hipSuccess) // (the side bytes: two per read, all of them looked at)
       {
         rc = GTX_ERR_HIP;
         what = "gtx_regions_run: hipMemsetAsync";
@@ -234,38 +244,61 @@ extern "C" int gtx_regions_run(gtx_region_job * jobs, uint32_t n_jobs, const gtx
         what = gtx_last_error();
       if (rc == GTX_OK && (rc = gtx_calls_batch(c, &acc, static_cast<uint8_t *>(d_phred), static_cast<gtx_sample_call *>(d_calls), st)) != GTX_OK)
         what = gtx_last_error();
+      if (rc == GTX_OK && j.n_reads && (rc = gtx::records_failed_enqueue(c, static_cast<uint32_t const *>(d_rec), rec_words, j.n_reads, st, d_failed)) != GTX_OK)
+        what = gtx_last_error();
       if (rc == GTX_OK)
       {
-        out.gt_cov.resize(static_cast<size_t>(n_samples) * lay.total_allele);
-        out.stat_u64.resize(static_cast<size_t>(lay.n_hap) + 2ull * lay.total_allele);
-        out.stat_u32.resize(static_cast<size_t>(lay.n_hap) + 6ull * lay.total_allele);
-        out.phred.resize(n_phred);
-        out.calls.resize(n_calls);
-        uint32_t conn[2] = {0, 0};
-        auto down = [&](void * dst, void const * src, size_t bytes) { return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) == hipSuccess; };
-        if (!down(out.gt_cov.data(), acc.d_gt_cov, out.gt_cov.size() * 4) || !down(out.stat_u64.data(), acc.d_stat_u64, out.stat_u64.size() * 8) ||
-            !down(out.stat_u32.data(), acc.d_stat_u32, out.stat_u32.size() * 4) || !down(out.phred.data(), d_phred, out.phred.size()) ||
-            !down(out.calls.data(), d_calls, out.calls.size() * sizeof(gtx_sample_call)) || !down(conn, acc.d_conn_count, sizeof conn) ||
+        size_t const b_cov = static_cast<size_t>(n_samples) * lay.total_allele * 4, b_u64 = (static_cast<size_t>(lay.n_hap) + 2ull * lay.total_allele) * 8,
+                     b_u32 = (static_cast<size_t>(lay.n_hap) + 6ull * lay.total_allele) * 4, b_phred = n_phred, b_calls = n_calls * sizeof(gtx_sample_call);
+        auto up = [](size_t x) { return (x + 63) & ~static_cast<size_t>(63); };
+        size_t const o_cov = 64, o_u64 = o_cov + up(b_cov), o_u32 = o_u64 + up(b_u64), o_phred = o_u32 + up(b_u32), o_calls = o_phred + up(b_phred),
+                     total = o_calls + up(b_calls);
+        if (total > pinned_cap)
+        {
+          if (pinned)
+            (void)hipHostFree(pinned);
+          pinned = nullptr;
+          pinned_cap = 0;
+          if (hipHostMalloc(reinterpret_cast<void **>(&pinned), 2 * total) == hipSuccess)
+            pinned_cap = 2 * total;
+        }
+        // ([0..1] connections appended / dropped, [2] the context's error flag, [4..5] the failed-record count)
+        auto down = [&](size_t at, void const * src, size_t bytes) { return bytes == 0 || hipMemcpyAsync(pinned + at, src, bytes, hipMemcpyDeviceToHost, st) == hipSuccess; };
+        if (!pinned || !down(0, acc.d_conn_count, 8) || !down(8, c->d_error_flag, 4) || !(j.n_reads == 0 || down(16, d_failed, 8)) || !down(o_cov, acc.d_gt_cov, b_cov) ||
+            !down(o_u64, acc.d_stat_u64, b_u64) || !down(o_u32, acc.d_stat_u32, b_u32) || !down(o_phred, d_phred, b_phred) || !down(o_calls, d_calls, b_calls) ||
             hipStreamSynchronize(st) != hipSuccess)
         {
           rc = GTX_ERR_HIP;
           what = "gtx_regions_run: device to host copy";
         }
-        // what a capacity limit dropped makes the text a wrong result: the job fails instead
-        uint64_t failed = 0;
-        uint32_t refused = 0;
-        if (rc == GTX_OK && j.n_reads && (rc = gtx_records_failed(c, static_cast<uint32_t const *>(d_rec), rec_words, j.n_reads, st, &failed)) != GTX_OK)
-          what = gtx_last_error();
-        if (rc == GTX_OK)
-          (void)gtx_ctx_error_count(c, &refused);
-        if (rc == GTX_OK && (failed || refused || conn[1]))
+        else
         {
-          rc = GTX_ERR_CAPACITY;
-          what = "gtx_regions_run: job " + std::to_string(b.job) + " is incomplete -- " + std::to_string(failed) + " records with a table-overflow status, " +
-                 std::to_string(refused) + " score items refused, " + std::to_string(conn[1]) + " connections beyond the log";
-          failed_total += failed;
-          refused_total += refused;
-          dropped_total += conn[1];
+          out.gt_cov.resize(b_cov / 4);
+          out.stat_u64.resize(b_u64 / 8);
+          out.stat_u32.resize(b_u32 / 4);
+          out.phred.resize(b_phred);
+          out.calls.resize(n_calls);
+          std::memcpy(out.gt_cov.data(), pinned + o_cov, b_cov);
+          std::memcpy(out.stat_u64.data(), pinned + o_u64, b_u64);
+          std::memcpy(out.stat_u32.data(), pinned + o_u32, b_u32);
+          std::memcpy(out.phred.data(), pinned + o_phred, b_phred);
+          std::memcpy(out.calls.data(), pinned + o_calls, b_calls);
+          // what a capacity limit dropped makes the text a wrong result: the job fails instead
+          uint32_t conn[2], refused = 0;
+          uint64_t failed = 0;
+          std::memcpy(conn, pinned, 8);
+          std::memcpy(&refused, pinned + 8, 4);
+          if (j.n_reads)
+            std::memcpy(&failed, pinned + 16, 8);
+          if (failed || refused || conn[1])
+          {
+            rc = GTX_ERR_CAPACITY;
+            what = "gtx_regions_run: job " + std::to_string(b.job) + " is incomplete -- " + std::to_string(failed) + " records with a table-overflow status, " +
+                   std::to_string(refused) + " score items refused, " + std::to_string(conn[1]) + " connections beyond the log";
+            failed_total += failed;
+            refused_total += refused;
+            dropped_total += conn[1];
+          }
         }
       }
       if (st)
@@ -289,6 +322,9 @@ extern "C" int gtx_regions_run(gtx_region_job * jobs, uint32_t n_jobs, const gtx
     }
     (void)gtx::dev_free(d_rec);
     (void)gtx::dev_free(d_fl);
+    (void)gtx::dev_free(d_failed_v);
+    if (pinned)
+      (void)hipHostFree(pinned);
     std::lock_guard<std::mutex> lock(stat_m);
     s.device_s += t_dev;
     s.records_failed += failed_total;
