@@ -51,25 +51,33 @@ def _more_relations(records, n_samples):
         assert [int(x) for x in info["NHet"].split(",")] == nhet and [int(x) for x in info["NHomAlt"].split(",")] == nhomalt
         assert [int(x) for x in info["NHomRef"].split(",")] == [n_samples - h - m for h, m in zip(nhet, nhomalt)]
         assert int(info["PASS_AN"]) <= int(info["AN"]) and int(info["AN"]) == 2 * sum(genotyped)
+        g4 = lambda x: "%.4g" % x  # (the reference writes these through a stream with precision 4: four significant digits, as TEXT)
         if int(info["AN"]):
-            assert abs(float(info["PASS_ratio"]) - int(info["PASS_AN"]) / int(info["AN"])) < 1e-3
-            for a, af in enumerate(info["AF"].split(",")):
-                assert abs(float(af) - int(info["AC"].split(",")[a]) / int(info["AN"])) < 1e-3
+            assert info["PASS_ratio"] == g4(int(info["PASS_AN"]) / int(info["AN"]))
+            assert info["AF"].split(",") == [g4(int(ac) / int(info["AN"])) for ac in info["AC"].split(",")]
         assert int(info["RefLen"]) == len(r["ref"])
+        # MaxAASR: the largest share of a sample's unique depth an alternative allele has (scan_calls, variant.cpp:300-312), as text
+        tot = ad.sum(axis=1)
+        assert info["MaxAASR"].split(",") == ["%.4g" % max([ad[s, a] / tot[s] for s in range(len(ad)) if tot[s] > 0] or [0.0]) for a in range(1, n_all)]
+        # MQ: the root of the mean squared mapping quality, rounded half away from zero (variant.cpp:810-830)
+        if "MQsquared" in info:
+            assert info["MQ"] == (str(int(np.floor(np.sqrt(int(info["MQsquared"]) / int(info["SeqDepth"])) + 0.5))) if int(info["SeqDepth"]) else "0")
         # the strand counts of the alleles add up to the two totals
         sbf, sbr = [int(x) for x in info["SBF"].split(",")], [int(x) for x in info["SBR"].split(",")]
         assert sbf == [a + b for a, b in zip(map(int, info["SBF1"].split(",")), map(int, info["SBF2"].split(",")))]
         assert sbr == [a + b for a, b in zip(map(int, info["SBR1"].split(",")), map(int, info["SBR2"].split(",")))]
         if sum(sbf) + sum(sbr):
-            assert abs(float(info["SB"]) - sum(sbf) / (sum(sbf) + sum(sbr))) < 1e-3
+            assert info["SB"] == g4(sum(sbf) / (sum(sbf) + sum(sbr)))
+        # SBAlt: the same over the alternative alleles only (variant.cpp:704-720)
+        assert info["SBAlt"] == (g4(sum(sbf[1:]) / (sum(sbf[1:]) + sum(sbr[1:]))) if sum(sbf[1:]) + sum(sbr[1:]) else "-1")
         het = [(g, row) for g, row in zip(gts, ad) if g[0] != g[1]]
         if het and info["ABHet"] != "-1":
             first, second = sum(int(row[g[0]]) for g, row in het), sum(int(row[g[1]]) for g, row in het)
-            assert abs(float(info["ABHet"]) - second / (first + second)) < 1e-3
+            assert info["ABHet"] == g4(second / (first + second))
         hom = [(g, row) for g, row in zip(gts, ad) if g[0] == g[1]]
         if info["ABHom"] != "-1":
             called, total = sum(int(row[g[0]]) for g, row in hom), sum(int(row.sum()) for g, row in hom)
-            assert abs(float(info["ABHom"]) - called / total) < 1e-3
+            assert info["ABHom"] == g4(called / total)
         if int(info["AN"]) >= 6:
             assert ("LowABHom" in r["filt"]) == (info["ABHom"] != "-1" and float(info["ABHom"]) < 0.85)
 
