@@ -1,8 +1,8 @@
 #!/bin/bash
-# Kernel trace of the main workload (no extra legs), the top kernels printed: bash tools/trace_main_stats.sh [tag]   (GTX_LIB selects the build)
-tag=${1:-main}
+# Kernel trace of the main workload (no extra legs), the top kernels printed: bash tools/trace_main_stats.sh [tag] [bench.py arguments]   (GTX_LIB selects the build)
+tag=${1:-main}; shift
 export TMPDIR=/tmp; R=$PWD; mkdir -p $R/gpurun_out/trace_$tag; cd /tmp
-timeout 250 rocprofv3 --output-format csv --kernel-trace --stats -d $R/gpurun_out/trace_$tag -o main -- python $R/bench.py --no-cpu-baseline --no-extra > $R/gpurun_out/trace_$tag/bench.log 2>&1
+timeout 250 rocprofv3 --output-format csv --kernel-trace --stats -d $R/gpurun_out/trace_$tag -o main -- python $R/bench.py --no-cpu-baseline --no-extra "$@" > $R/gpurun_out/trace_$tag/bench.log 2>&1
 cd $R
 f=$(find gpurun_out/trace_$tag -name "*kernel_stats.csv" | head -1)
 python - "$f" gpurun_out/trace_$tag/bench.log <<PY
