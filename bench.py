@@ -1273,8 +1273,14 @@ def extra_repeats(args, torch, gtx, synth, device, ref):
             "arrays of a 171-bp unit, %d near-duplicate 300-bp segments: %.1f %%%% of the region), SNP every 1 kb, max %%d alleles per site" %
             (len(spots), sum(s[0] == "homopolymer" for s in spots), sum(s[0] == "tandem" for s in spots), sum(s[0] == "array" for s in spots),
              sum(s[0] == "near-duplicate" for s in spots), 100.0 * covered / len(ref)))
-    # (one step at a time, the arena rewound per step and sized for it: reads in repeats have records of hundreds of paths)
-    return extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False, what, lanes=1, big_record_words=1 << 27)
+    # (three steps in flight, each on a stream of its own: the HBM-table and exact passes are chains of round trips on a few thousand
+    #  wavefronts, and three steps' worth of them overlap -- 20 ms per step against 30 one at a time.  The arena of the long records is
+    #  the context's: with steps in flight it is sized for all the steps of the leg and not started over between them -- a host's
+    #  regions in flight are contexts of their own, gtx_regions_run.  GTX_BENCH_REPEATS_LANES=1: one step at a time, the arena
+    #  started over per step.)
+    lanes = int(os.environ.get("GTX_BENCH_REPEATS_LANES", "3"))
+    return extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False, what, lanes=lanes, big_record_words=(1 << 27) if lanes == 1 else (1 << 30),
+                          schedule="lanes" if lanes > 1 else None)
 
 
 def extra_genome_like(args, torch, gtx, synth, device):
@@ -1297,7 +1303,9 @@ def extra_genome_like(args, torch, gtx, synth, device):
             "diverged), %.1f %%%% STRs, %.1f %%%% segmental duplications; SNP every 1 kb, max %%d alleles per site; reads with 0.5 %%%% substitutions, 0.1 %%%% N, "
             "0.05 %%%% indel errors, 3 %%%% soft-clipped, 2 %%%% wrong / shifted position hints" %
             (100.0 * stats["interspersed"], stats["families"], 100.0 * stats["str"], 100.0 * stats["segdup"]))
-    out = extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False, what, lanes=1, big_record_words=1 << 27, make_reads=make)
+    lanes = int(os.environ.get("GTX_BENCH_REPEATS_LANES", "3"))  # (as in extra_repeats: steps in flight, each on a stream of its own)
+    out = extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False, what, lanes=lanes, big_record_words=(1 << 27) if lanes == 1 else (1 << 30),
+                         make_reads=make, schedule="lanes" if lanes > 1 else None)
     out["reads_made"] = made.get(5)
     out["reference"] = stats
     if not args.no_cpu_baseline:  # the oracle on a sample of THESE reads, one host core: what the device rate of this leg stands beside
@@ -1426,8 +1434,11 @@ def extra_cfg5(args, torch, gtx, synth, device, n_pairs_per_sv=160, background_p
     return out
 
 
-def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_all, what, lanes=None, big_record_words=0, read_len=READ_LEN, make_reads=None):
-    """make_reads (optional): seed -> (codes, pos) instead of synth.make_reads' clean reads"""
+def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_all, what, lanes=None, big_record_words=0, read_len=READ_LEN, make_reads=None,
+                   schedule=None):
+    """make_reads (optional): seed -> (codes, pos) instead of synth.make_reads' clean reads; schedule "lanes": whole steps in flight, each
+    on a stream of its own (for inputs whose time is in the passes behind the position-hinted one: chains of round trips that leave
+    most of the chip idle -- three steps' worth of them overlap)"""
     n = args.extra_reads
     if make_reads is None:
         make_reads = lambda seed: synth.make_reads(ref, recs, n, read_len=read_len, seed=seed, region_begin=REGION_BEGIN)
@@ -1446,7 +1457,7 @@ def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_al
     w = Workload(torch, gtx, ctx, device, d_seq, torch.from_numpy(pos), n_samples, samples=samples if n_samples > 1 else None,
                  hint=not args.no_hint, lanes=lanes, read_len=read_len)
     w.rewind = lanes == 1 and big_record_words != 0
-    w.staggered = args.schedule == "staggered" and len(w.lanes) >= 2  # (the same schedule as the main workload, chosen the same way)
+    w.staggered = (schedule or args.schedule) == "staggered" and len(w.lanes) >= 2  # (the same schedule as the main workload, chosen the same way)
     if args.read_sets > 1:  # a second set of reads: the steps alternate
         codes2, pos2 = make_reads(6)
         order2 = np.argsort(pos2, kind="stable")
@@ -1476,12 +1487,24 @@ def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_al
         for k, nm in enumerate(names):
             sys.stderr.write("  %-22s %10.0f  %5.1f%%\n" % (nm, prof[16 + k] / float(prof[31]), 100.0 * prof[16 + k] / tot))
     exact = ctx.exact_pass_tasks()
+    one_at_a_time_ms = None
+    if schedule == "lanes" and w.used_lanes > 1:  # (beside it: the same steps one at a time, the arena started over first)
+        torch.cuda.synchronize()
+        gtx.check(gtx.lib().gtx_ctx_big_records_rewind(ctx.h, None))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            w.step(0)
+        torch.cuda.synchronize()
+        one_at_a_time_ms = 1000.0 * (time.perf_counter() - t0) / 3
     w.close()
     what = what % (n, int(ctx.hap_cnum.max()))
     kt = ctx.kernel_times()
     out = {"workload": what, "align_kernels": {k[0]: {"ms": k[1], "tasks_completed": k[2]} for k in kt},
            "reads_per_s": n * steps / dt, "ms_per_step": 1000.0 * dt / steps, "steps": steps,
-           "schedule": ("staggered, %d steps in flight" % w.used_lanes) if (w.staggered and w.used_lanes > 1) else "one step at a time",
+           "schedule": ("staggered, %d steps in flight" % w.used_lanes) if (w.staggered and w.used_lanes > 1) else
+                       ("%d steps in flight, each on a stream of its own" % w.used_lanes) if w.used_lanes > 1 else "one step at a time",
+           "one_at_a_time_ms_per_step": one_at_a_time_ms,
            "calibration": w.calibration, "resident_read_sets": len(w.sets), "sites": int(ctx.n_hap), "ctx_create_s": round(t_ctx, 3),
            "graph_build_s": round(t_graph, 3),
            "align_passes_ms": {"express": ms[0], "general": ms[1], "hbm_tables": ms[2]},

@@ -3,6 +3,9 @@
 // GTX_WIDE_MASK_WORDS words) and the exact pass, gtx_align_exact(_wide)_kernel, whose tables have no fixed size.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "gtx_ctx.hpp"
 #include "wave_hip.hpp"
 #include "align_core.hpp"
@@ -108,7 +111,10 @@ namespace gtx
 // with the whole slab for what did not fit a part (its queue is the first launch's next_tasks).
 // (at most one workgroup of this pass per CU, usually none with work: no register diet -- all the registers a wavefront can name)
 #define GTX_EXACT_PASS_ATTR __attribute__((amdgpu_waves_per_eu(1, 2)))
-constexpr uint32_t EXACT_LDS_KEYS = 4096; // paths whose dense start / end tables fit the exact pass' 32 KB of LDS
+#ifndef GTX_EXACT_LDS_KEYS
+#define GTX_EXACT_LDS_KEYS 4096
+#endif
+constexpr uint32_t EXACT_LDS_KEYS = GTX_EXACT_LDS_KEYS; // paths whose dense start / end tables fit the exact pass' 32 KB of LDS
 #define GTX_EXACT_PASS_KERNEL(NAME, NS)                                                                                            \
   __global__ __launch_bounds__(64) GTX_EXACT_PASS_ATTR void NAME(GraphView g, IndexView ix, uint8_t const * __restrict__ seq, uint32_t seq_stride, \
                                              gtx_read_meta const * __restrict__ meta, uint32_t * __restrict__ records,             \
@@ -213,7 +219,18 @@ char const * launch_exact_passes(HbmPassArgs const & a, hipStream_t stream)
   uint32_t * const st1 = a.exact_state, * const st2 = st1 + 8, * const st3 = st2 + 8, * const st4 = st3 + 8;
   auto kernel = a.wide_sites ? gtx_align_exact_wide_kernel : gtx_align_exact_kernel;
   unsigned long long const slab_bytes = a.exact_slab_bytes, min_part = slab_bytes / a.exact_parts;
-  uint32_t const large_parts = a.exact_fixed_parts ? 1u : CallScratch::EXACT_LARGE_PARTS;
+  // (the second launch: parts of at least 16 MB -- 32 of them in a 512 MB slab, 128 in the 2 GB slab of a large batch: on a reference
+  //  with repeats two hundred tasks come this far, and 32 parts took them in six rounds of a millisecond each)
+  static uint32_t const large_parts_env = []
+  {
+    char const * e = std::getenv("GTX_EXACT_LARGE_PARTS"); // (A/B switch)
+    return e && std::atoi(e) > 0 ? static_cast<uint32_t>(std::min(std::atoi(e), 1024)) : 0u;
+  }();
+  // (graphs with sites of more than 64 alleles keep 32: a walk's candidate table alone can be tens of megabytes there)
+  uint32_t const large_parts = a.exact_fixed_parts ? 1u
+                               : large_parts_env ? large_parts_env
+                               : a.wide_sites    ? CallScratch::EXACT_LARGE_PARTS
+                                                 : static_cast<uint32_t>(std::min<unsigned long long>(256ull, std::max<unsigned long long>(CallScratch::EXACT_LARGE_PARTS, slab_bytes >> 24)));
   hipLaunchKernelGGL(kernel, dim3(a.exact_parts), dim3(64), 0, stream, a.g, a.ix, a.seq, a.seq_stride, a.meta, a.records, a.rec_words, q1,
                      CallScratch::EXACT_TASK_CAP, st1, a.exact_slab, slab_bytes, min_part, a.exact_fixed_parts ? 1u : 0u, a.exact_part_cand_cap,
                      CallScratch::EXACT_PART_SITES, a.arena, arena_words, a.arena_cursor, q2, CallScratch::EXACT_TASK_CAP, st2);

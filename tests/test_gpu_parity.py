@@ -322,6 +322,62 @@ def test_batches_in_flight_equal_one_at_a_time():
                                            C.c_void_p(H.cuda_stream), None, C.c_void_p(T.cuda_stream), None) != 0
 
 
+@pytest.mark.parametrize("kind", ["repeat", "satellite"])
+def test_whole_calls_in_flight_on_streams_of_their_own(kind):
+    """bench.py's schedule for repeat-rich input: three gtx_align_batch_planes calls on one context, each on a stream of its own with
+    its own record slots, in flight together -- the HBM-table and exact passes of one beside the front passes of another, all of
+    them taking places in ONE arena.  Every call leaves what it leaves alone (records in the arena compared parsed: their offsets
+    are handed out in whatever order the workgroups finish)."""
+    import ctypes as C
+    import torch
+    ref, recs, codes, pos = scenarios.synthetic_case(kind, n_ref=60000, n_reads=1800, region_begin=1000000, seed=11)
+    ctx = gtx.Context(gtx.graph_from_records(ref, recs, region_begin=1000000), device=0)
+    L = gtx.lib()
+    seq, lens = harness.pack_ragged(list(codes))
+    meta = harness.read_meta(lens, pos=pos)
+    stride = (seq.shape[1] + 15) // 16 * 16
+    planes = gtx.pack_planes(seq, stride)
+    parts = [(0, 600), (600, 1200), (1200, 1800)]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to("cuda:0")
+
+    def parsed(d_rec, n):
+        words = d_rec.cpu().numpy().view(np.uint32).copy().reshape(-1, harness.REC_WORDS)
+        arena, _ = ctx.big_records()
+        assert not ((words[:, 0] >> 16) & gtx.ST_ERROR_MASK).any()
+        ext = np.nonzero(((words[:, 0] >> 16) & gtx.ST_EXTERNAL) != 0)[0]
+        long_reads = np.unique(ext // 2)
+        body = gtx.parse_records(words.reshape(-1, 2 * harness.REC_WORDS)[long_reads].reshape(-1), len(long_reads), harness.REC_WORDS, ctx.hap_order,
+                                 np.asarray(arena))
+        words[ext, 2] = 0
+        return words, list(long_reads), body
+
+    want = []
+    for a, b in parts:  # one at a time
+        d_p, d_m = dev(planes[a:b]), dev(meta[a:b])
+        d_rec = torch.zeros((b - a) * 2 * harness.REC_WORDS, dtype=torch.int32, device="cuda:0")
+        d_fl = torch.zeros((b - a) * 2, dtype=torch.uint8, device="cuda:0")
+        ctx.rewind_big_records()
+        gtx.check(L.gtx_align_batch_planes(ctx.h, d_p.data_ptr(), stride, d_m.data_ptr(), b - a, d_rec.data_ptr(), harness.REC_WORDS, d_fl.data_ptr(), None))
+        torch.cuda.synchronize()
+        want.append(parsed(d_rec, b - a) + (d_fl.cpu().numpy().copy(),))
+    assert sum(len(w[1]) for w in want) > 20  # (records in the arena: what the passes behind the general one write)
+    for _ in range(3):
+        ctx.rewind_big_records()
+        streams = [torch.cuda.Stream() for _ in parts]
+        held = []
+        for a, b in parts:
+            held.append((dev(planes[a:b]), dev(meta[a:b]), torch.zeros((b - a) * 2 * harness.REC_WORDS, dtype=torch.int32, device="cuda:0"),
+                         torch.zeros((b - a) * 2, dtype=torch.uint8, device="cuda:0")))
+        torch.cuda.synchronize()
+        for (a, b), (d_p, d_m, d_rec, d_fl), st in zip(parts, held, streams):
+            gtx.check(L.gtx_align_batch_planes(ctx.h, d_p.data_ptr(), stride, d_m.data_ptr(), b - a, d_rec.data_ptr(), harness.REC_WORDS, d_fl.data_ptr(),
+                                               C.c_void_p(st.cuda_stream)))
+        torch.cuda.synchronize()
+        for (a, b), (_, _, d_rec, d_fl), (w_words, w_long, w_body, w_fl) in zip(parts, held, want):
+            words, long_reads, body = parsed(d_rec, b - a)
+            assert np.array_equal(words, w_words) and long_reads == w_long and body == w_body and np.array_equal(d_fl.cpu().numpy(), w_fl)
+
+
 @pytest.mark.parametrize("kind", ["cfg3", "cluster", "snp25"])
 def test_both_builds_of_pass_0_write_the_same_records(kind, monkeypatch):
     """gtx_align_hinted_kernel and gtx_align_hinted_dense_kernel (GTX_HINT_BUILD) on one context: the same record words,
