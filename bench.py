@@ -1290,11 +1290,11 @@ def extra_repeats(args, torch, gtx, synth, device, ref):
              sum(s[0] == "near-duplicate" for s in spots), 100.0 * covered / len(ref)))
     # (three steps in flight, each on a stream of its own: the HBM-table and exact passes are chains of round trips on a few thousand
     #  wavefronts, and three steps' worth of them overlap -- 20 ms per step against 30 one at a time.  The arena of the long records is
-    #  the context's: with steps in flight it is sized for all the steps of the leg and not started over between them -- a host's
+    #  the context's: with steps in flight it is sized for all the steps of the leg (1 GB) and not started over between them -- a host's
     #  regions in flight are contexts of their own, gtx_regions_run.  GTX_BENCH_REPEATS_LANES=1: one step at a time, the arena
     #  started over per step.)
     lanes = int(os.environ.get("GTX_BENCH_REPEATS_LANES", "3"))
-    return extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False, what, lanes=lanes, big_record_words=(1 << 27) if lanes == 1 else (1 << 30),
+    return extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False, what, lanes=lanes, big_record_words=(1 << 27) if lanes == 1 else (1 << 28),
                           schedule="lanes" if lanes > 1 else None)
 
 
@@ -1319,7 +1319,7 @@ def extra_genome_like(args, torch, gtx, synth, device):
             "0.05 %%%% indel errors, 3 %%%% soft-clipped, 2 %%%% wrong / shifted position hints" %
             (100.0 * stats["interspersed"], stats["families"], 100.0 * stats["str"], 100.0 * stats["segdup"]))
     lanes = int(os.environ.get("GTX_BENCH_REPEATS_LANES", "3"))  # (as in extra_repeats: steps in flight, each on a stream of its own)
-    out = extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False, what, lanes=lanes, big_record_words=(1 << 27) if lanes == 1 else (1 << 30),
+    out = extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False, what, lanes=lanes, big_record_words=(1 << 27) if lanes == 1 else (1 << 28),
                          make_reads=make, schedule="lanes" if lanes > 1 else None)
     out["reads_made"] = made.get(5)
     out["reference"] = stats
