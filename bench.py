@@ -285,6 +285,12 @@ class Workload:
         self.stride = (int(d_seq.shape[1]) + 15) // 16 * 16  # pitch of the plane rows
         self.hint, self.samples, self.read_len = hint, samples, read_len
         self.rewind = False  # step(): rewind the context's big-record arena first (one step at a time only: the arena is the context's)
+        # run(): may the calibration settle for whole steps in flight on streams of their own?  The legs may.  The main workload keeps
+        # the staggered schedule: there a launch of the position-hinted pass shares the chip with the short queues of its neighbours
+        # only and its own time is what the roofline prices (0.40 ms against 0.36 alone); with whole steps in flight three of those
+        # launches overlap EACH OTHER, a launch takes 0.93 ms from its first workgroup to its last, and a per-launch roofline says
+        # nothing about the kernel any more -- the faster schedule is reported beside the line (config.extra.whole_steps_in_flight).
+        self.allow_whole_steps = False
         self.sets = []   # resident read sets (bases, meta, score items); step k works on set k mod len(sets)
         self.words = {}  # items' data_ptr -> their compact form (gtx_score_batch_words), or None
         self.steps_done = 0
@@ -598,7 +604,7 @@ class Workload:
             self.calibration = {"staggered_ms_per_step": 1000.0 * t_stag, "one_at_a_time_ms_per_step": 1000.0 * t_one, "fresh_stream_retries": retries}
             if t_lanes != float("inf"):
                 self.calibration["whole_steps_on_streams_of_their_own_ms_per_step"] = 1000.0 * t_lanes
-            if t_lanes < t_stag and t_lanes < t_one:
+            if self.allow_whole_steps and t_lanes < t_stag and t_lanes < t_one:
                 stag = False
                 self.staggered = False
             elif t_stag > t_one:
@@ -1516,6 +1522,7 @@ def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_al
     w = Workload(torch, gtx, ctx, device, d_seq, torch.from_numpy(pos), n_samples, samples=samples if n_samples > 1 else None,
                  hint=not args.no_hint, lanes=lanes, read_len=read_len)
     w.rewind = lanes == 1 and big_record_words != 0
+    w.allow_whole_steps = True
     w.staggered = (schedule or args.schedule) == "staggered" and len(w.lanes) >= 2  # (the same schedule as the main workload, chosen the same way)
     if args.read_sets > 1:  # a second set of reads: the steps alternate
         codes2, pos2 = make_reads(6)
@@ -1793,6 +1800,18 @@ def main(argv=None):
             w.calibration, w.staggered = calib, stag
         except Exception as e:
             cfg.setdefault("extra", {})["long_run"] = {"error": repr(e)}
+        try:  # the same workload with WHOLE steps in flight, each on its lane's stream (see Workload.allow_whole_steps)
+            if len(w.lanes) > 1:
+                calib, stag = w.calibration, w.staggered
+                w.staggered = False
+                dt_w, _ = w.run(300, 3, None)
+                cfg.setdefault("extra", {})["whole_steps_in_flight"] = {
+                    "steps": 300, "ms_per_step": 1000.0 * dt_w / 300, "reads_per_s": n * 300 / dt_w,
+                    "schedule": "%d steps in flight, each on a stream of its own" % w.used_lanes,
+                    "position_hinted_pass_ms_per_launch": (ctx.kernel_times() or [(None, None)])[0][1]}
+                w.calibration, w.staggered = calib, stag
+        except Exception as e:
+            cfg.setdefault("extra", {})["whole_steps_in_flight"] = {"error": repr(e)}
         try:  # BASELINE configs[3] as far as one GPU goes: the reads of 1000 samples, every rank's share of cfg4
             w4 = Workload(torch, gtx, ctx, device, d_seq, d_pos, 1000, samples=np.random.default_rng(4242).integers(0, 1000, size=n).astype(np.uint32),
                           hint=not args.no_hint, lanes=args.lanes)

@@ -641,8 +641,19 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
   GraphView g, IndexView ix, uint8_t const *__restrict__ seq, uint32_t seq_stride, gtx_read_meta const *__restrict__ meta,         \
     uint32_t n_reads, uint32_t *__restrict__ records, uint32_t rec_words, uint32_t force_both, uint32_t *__restrict__ queue1,      \
     uint32_t *__restrict__ queue2, unsigned long long *queue_counts, uint32_t decline_all, uint8_t *__restrict__ task_flags,       \
-    uint32_t *__restrict__ compact
-#define GTX_HINTED_PASS(W, ...) hinted_pass<W, __VA_ARGS__>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, queue1, queue2, queue_counts, decline_all, task_flags, compact)
+    uint32_t *__restrict__ compact, unsigned long long *span
+// (span, timed calls only: [0] = the largest ~(wall clock) a workgroup saw at its start, [1] = the largest wall clock at an end -- the
+//  launch's own time from its first workgroup's start to its last one's end, which is what rocprofv3 reports for it.  HIP events
+//  around the launch measure that only while the launch does not wait for room: with whole steps in flight on streams of their
+//  own the interval between the events was 0.98 ms for a launch that runs 0.45.
+//  Workgroup 0 gives the start, one workgroup in sixteen of the last 1 024 the end -- workgroups start and finish in the order of
+//  their numbers to within a few microseconds, and 78 000 atomics on one word, one per workgroup's start and end, took 0.6 ms.)
+#define GTX_HINTED_PASS(W, ...)                                                                                                    \
+  if (span && threadIdx.x == 0 && blockIdx.x == 0)                                                                                 \
+    atomicMax(span, ~static_cast<unsigned long long>(wall_clock64()));                                                             \
+  hinted_pass<W, __VA_ARGS__>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, queue1, queue2, queue_counts, decline_all, task_flags, compact); \
+  if (span && threadIdx.x == 0 && blockIdx.x + 1024u >= gridDim.x && ((blockIdx.x & 15u) == 15u || blockIdx.x + 1u == gridDim.x))   \
+    atomicMax(span + 1, static_cast<unsigned long long>(wall_clock64()))
 
 #ifndef GTX_HINT_VGPRS
 #define GTX_HINT_VGPRS 80
@@ -1287,6 +1298,8 @@ static void scratch_free(CallScratch & s)
     (void)hipStreamDestroy(static_cast<hipStream_t>(s.side_stream));
   if (s.done)
     (void)hipEventDestroy(static_cast<hipEvent_t>(s.done));
+  if (s.h_span)
+    (void)hipHostFree(s.h_span);
   s = CallScratch();
 }
 
@@ -1297,7 +1310,11 @@ static std::unique_ptr<CallScratch> scratch_new(gtx_ctx & c)
   bool ok = hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "scratch event");
   if (ok)
     s->done = ev;
-  ok = ok && dev_alloc(s->d_counters, 8 * CallScratch::MAX_PARTS + 48, "task counters + second-pass state", true); // (+ big, wide, exact x 3: 8 words each)
+  ok = ok && dev_alloc(s->d_counters, 8 * CallScratch::MAX_PARTS + 48 + 4, "task counters + second-pass state", true); // (+ big, wide, exact x 3: 8 words each; + the span of pass 0)
+  if (ok)
+  {
+    s->d_span = reinterpret_cast<unsigned long long *>(s->d_counters + 8 * CallScratch::MAX_PARTS + 48); // (its pinned home is made by the first timed call)
+  }
   if (ok && !c.params.no_second_pass)
   {
     s->d_big_state = s->d_counters + 8 * CallScratch::MAX_PARTS;
@@ -1577,6 +1594,10 @@ int ctx_upload(gtx_ctx & c, int device)
   lap("device properties");
   if (have_prop)
     c.n_cu = prop.multiProcessorCount;
+  {
+    int khz = 0;
+    c.wall_clock_khz = hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0 ? static_cast<uint32_t>(khz) : 100000u;
+  }
   if (ok && !c.params.no_second_pass)
   {
     // HBM-table pass: one workspace per workgroup (one workgroup per CU is plenty for the few queued reads), arena
@@ -1924,7 +1945,7 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
                         hipEvent_t done_event, hipStream_t * last_stream, uint32_t * d_compact)
 {
   // (the pass counters and, behind them, the state of the HBM-table and wide-site passes: one reset)
-  if (!hip_ok(hipMemsetAsync(s->d_counters, 0, (8 * CallScratch::MAX_PARTS + (s->d_big_state ? 48 : 0)) * sizeof(uint32_t), st), "task counter reset"))
+  if (!hip_ok(hipMemsetAsync(s->d_counters, 0, (8 * CallScratch::MAX_PARTS + 48 + 4) * sizeof(uint32_t), st), "task counter reset"))
     return GTX_ERR_HIP;
   // queues: room for every task (a graph on which no read is simple sends them all)
   if (!grow(s->d_queue, s->queue_cap, 2ull * n_reads, "pass-2 queue") || !grow(s->d_queue1, s->queue1_cap, n_reads, "pass-1 queue"))
@@ -2010,6 +2031,13 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
   if (timed && s->ring_used >= CallScratch::TIME_RING)
     timed = false;
   uint32_t const slot = timed ? s->ring_used : 0u;
+  if (timed && !s->h_span) // (pinned: only a host that asks for kernel times pays for it; without it pass 0's time is the interval between its events)
+  {
+    if (hipHostMalloc(reinterpret_cast<void **>(&s->h_span), CallScratch::TIME_RING * 2 * sizeof(unsigned long long)) != hipSuccess)
+      s->h_span = nullptr;
+  }
+  if (timed && s->h_span)
+    s->h_span[2 * slot] = s->h_span[2 * slot + 1] = 0ull;
   if (timed && !s->time_ring[slot][0][0])
     for (uint32_t p = 0; p < (parts > 1 ? CallScratch::MAX_PARTS : 1u); ++p)
       for (auto & e : s->time_ring[slot][p])
@@ -2103,9 +2131,12 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
 #endif
                            ,
                          d_task_flags ? d_task_flags + 2ull * first : static_cast<uint8_t *>(nullptr),
-                         d_compact ? d_compact + static_cast<uint64_t>(first) * GTX_COMPACT_WORDS : static_cast<uint32_t *>(nullptr));
+                         d_compact ? d_compact + static_cast<uint64_t>(first) * GTX_COMPACT_WORDS : static_cast<uint32_t *>(nullptr),
+                         timed && s->h_span ? s->d_span : static_cast<unsigned long long *>(nullptr));
       if (!hip_ok(hipGetLastError(), "gtx_align_hinted_kernel launch"))
         return GTX_ERR_HIP;
+      if (timed && s->h_span && first + step >= n_reads) // (the call's launches of the pass have added to the span: home with it)
+        (void)hipMemcpyAsync(s->h_span + 2 * slot, s->d_span, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
       mark(part, 1, st);
       // (gtx_align_batch_planes_staged: from here on the call is short queues -- the caller's other streams may come in;
       //  GTX_STAGED_FRONT=express: the express pass stays on the caller's stream as well and the front event is recorded behind it)
@@ -2335,7 +2366,15 @@ static int kernel_times(gtx_ctx * c, float * ms, uint32_t * tasks)
         float d = 0.0f;
         auto ev = [&](int k) { return static_cast<hipEvent_t>(u->time_ring[slot][p][k]); };
         if (hipEventElapsedTime(&d, ev(0), ev(1)) == hipSuccess)
+        {
+          // (the position-hinted pass by its own clock where the call brought it home: gtx_align_hinted_kernel's span)
+          unsigned long long const t0 = u->h_span ? ~u->h_span[2 * slot] : 0ull, t1 = u->h_span ? u->h_span[2 * slot + 1] : 0ull;
+          if (p == 0 && u->h_span && u->h_span[2 * slot + 1] != 0ull && t1 > t0 && c->wall_clock_khz > 0)
+            d = static_cast<float>(static_cast<double>(t1 - t0) / static_cast<double>(c->wall_clock_khz));
+          else if (p != 0 && u->h_span && u->h_span[2 * slot + 1] != 0ull)
+            d = 0.0f; // (the span covers all parts of the call)
           sum[0] += d;
+        }
         if (hipEventElapsedTime(&d, ev(1), ev(2)) == hipSuccess)
           sum[1] += d;
         if (hipEventElapsedTime(&d, ev(3), ev(4)) == hipSuccess)

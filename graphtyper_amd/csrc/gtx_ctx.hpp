@@ -47,6 +47,8 @@ struct CallScratch
   uint32_t ring_used = 0;              // calls recorded in epoch ring_epoch (the first TIME_RING of them are kept)
   uint32_t ring_epoch = 0;             // gtx_ctx::time_epoch of the slots above
   bool timed = false;                  // the last call was timed (its slot: ring_used - 1)
+  unsigned long long * d_span = nullptr; // behind d_counters: the position-hinted pass' own clock (gtx_api.hip: GTX_HINTED_PASS), reset with the counters
+  unsigned long long * h_span = nullptr; // pinned, [TIME_RING][2]: the spans of the timed calls
   uint32_t timed_reads = 0;
   // HBM-table pass (reads that overflowed the LDS-sized tables)
   uint32_t * d_big_tasks = nullptr;
@@ -83,6 +85,7 @@ struct gtx_ctx
   gtx::HostIndex index;
   int device = -1; // -1: inspection-only context (no device entry point works)
   int n_cu = 0;
+  uint32_t wall_clock_khz = 100000; // the rate of wall_clock64() (hipDeviceAttributeWallClockRate)
   std::vector<void *> dev_allocs;
   bool quiet = false; // set by a caller that knows every launch on this context has completed (ctx_release_device then does not wait for the device)
   std::vector<uint8_t> upload_stage; // host source of the graph tables' one asynchronous copy (ctx_upload); empty once the context is made

@@ -11,6 +11,6 @@ for r in list(csv.DictReader(open(sys.argv[1])))[:7]:
     print(r["Name"][:58].ljust(58), r["Calls"].rjust(6), ("%.1f" % (float(r["AverageNs"]) / 1e3)).rjust(10), "us")
 for l in open(sys.argv[2]):
     if l.startswith("{"):
-        d = json.loads(l); print("ms_per_step", round(d["ms_per_step"], 4), "under trace")
+        d = json.loads(l); print("ms_per_step", round(d["ms_per_step"], 4), "under trace;", d["config"]["streams"]["schedule"], "; bench.py says the dominant kernel takes", round(d["roofline"]["kernel_ms"], 4), "ms, frac", round(d["roofline"]["frac"], 3))
 PY
 find gpurun_out/trace_$tag -type f ! -name "*stats.csv" ! -name "*.log" -delete
