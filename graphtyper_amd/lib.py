@@ -5,6 +5,7 @@ inside libgtx's HIP kernels.  There is no CPU path: without the built library or
 """
 import ctypes as C
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -128,6 +129,15 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libgtx.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        # A process that uses PyTorch as well has to have PyTorch's HIP runtime in it FIRST: libgtx.so names libamdhip64 by its
+        # soname, and with torch already loaded that resolves to the runtime torch brought -- one runtime for both.  The other way
+        # round the process holds two, and the library's own sees no device ("no HIP device visible").  Whoever binds the library
+        # from Python gets the order right here; a C or C++ host has one runtime anyway.
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         L.gtx_strerror.restype = C.c_char_p
         L.gtx_strerror.argtypes = [C.c_int]
