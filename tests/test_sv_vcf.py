@@ -64,6 +64,52 @@ def test_coverage_model_hand_worked():
         coverage_call(sv_line("DEL", 5001, 40), depth)
 
 
+def test_coverage_model_hand_worked_duplications_sizes_and_points():
+    """the rest of make_call_based_on_coverage by hand: <DUP> / <INV> (coverage from the medians' mean and difference,
+    sample_call.cpp:315-338), the sizes at which the likelihoods are scaled (<= 100, > 1000), the 190 000-base limit behind which no
+    point is taken after the SV, and WHICH positions the points are (20 bases off the ends, every 20 bases outside: 51 in front, 50
+    behind; 101 inside at i x (size - 40) / 102)"""
+    flat = lambda inside, outside, size, n=20000: (lambda d: (d.__setitem__(slice(5000, 5000 + size), inside), d)[1])(np.full(n, outside, np.uint16))
+    # no duplication: medians equal -> the mean 30 for the reference, 0; 0 / 90 / 360, x 3/2 for 2 000 bases -> 0, 135, 540 (written 255)
+    assert coverage_call(sv_line("DUP", 5001, 2000), flat(30, 30, 2000)) == [30, 0, 0, 135, 255]
+    # heterozygous: inside 45, outside 30: mean 37.5, difference 15 = half of the outside: (1 - 0.5) x 37.5 = 18.75 -> 19, and 37.5 - 19 -> 18;
+    # 216 / 111 / 228 -> 105, 0, 117 -> x 3/2 (integer) -> 157, 0, 175
+    assert coverage_call(sv_line("DUP", 5001, 2000), flat(45, 30, 2000)) == [19, 18, 157, 0, 175]
+    assert coverage_call(sv_line("INV", 5001, 2000), flat(45, 30, 2000)) == [19, 18, 157, 0, 175]
+    # homozygous: inside 60 = twice the outside: the fraction is 1 -> 0 and 45; 540 / 135 / 0 -> 810 (255), 202, 0
+    assert coverage_call(sv_line("DUP", 5001, 2000), flat(60, 30, 2000)) == [0, 45, 255, 202, 0]
+    # fewer reads inside than outside: the mean for the reference, 0
+    assert coverage_call(sv_line("DUP", 5001, 2000), flat(20, 30, 2000)) == [25, 0, 0, 112, 255]
+    # the scaling by size: x 2/3 up to 100 bases, nothing up to 1 000, x 3/2 above (a heterozygous deletion: 90, 0, 90 unscaled)
+    assert coverage_call(sv_line("DEL", 5001, 100), flat(15, 30, 100)) == [15, 15, 60, 0, 60]
+    assert coverage_call(sv_line("DEL", 5001, 101), flat(15, 30, 101)) == [15, 15, 90, 0, 90]
+    assert coverage_call(sv_line("DEL", 5001, 1001), flat(15, 30, 1001)) == [15, 15, 135, 0, 135]
+    # 190 000 bases and more: the end is taken 190 000 behind the begin and NO point is taken after the SV.  In front: the 26 points
+    # next to the SV see 30 reads, the 25 beyond them 10; behind the SV 10.  With the 50 points behind, 75 of 101 are 10 -> outside 10,
+    # AD 5,5, 60 / 30 / 60 -> 30, 0, 30 -> x 3/2; without them the median of the 51 in front is 30 -> AD 5,25, 300 / 90 / 60 -> 240, 30, 0 -> x 3/2
+    big = np.full(400000, 10, np.uint16)
+    big[5000 - 20 * 26 - 1:5000] = 30
+    for size, want in ((189999, [5, 5, 45, 0, 45]), (190000, [5, 25, 255, 45, 0]), (250000, [5, 25, 255, 45, 0])):
+        d = big.copy()
+        d[5000:5000 + size] = 5
+        d[5000 + size:] = 10
+        assert coverage_call(sv_line("DEL", 5001, size), d) == want, size
+    # the points outside: 20, 40, ... bases off the ends.  51 in front of which only the FIRST (begin - 20) sees reads, 50 behind which
+    # all do: 51 of 101 values are 30 -> the median is 30 (AD 0,30); a point at begin - 21 instead, or one point more on either side, and it is 0
+    d = np.zeros(20000, np.uint16)
+    d[5001 - 20 - 1:5000] = 30          # positions begin - 20 .. begin - 1
+    d[6000:7001] = 30                   # the end is begin + size = 6001: the 50 points behind it are 6021 .. 7001 (indices 6020 .. 7000)
+    assert coverage_call(sv_line("DEL", 5001, 1000), d)[:2] == [0, 30]
+    d2 = d.copy()
+    d2[5001 - 20 - 1] = 0               # nobody at begin - 20: 50 of 101
+    assert coverage_call(sv_line("DEL", 5001, 1000), d2)[:2] == [0, 0]
+    # the points inside: begin + 20 + i x (size - 40) / 102.  size 1 060: begin + 20 + 10 i, i = 1 .. 101; the depth grows by one every
+    # ten bases (position begin + k -> k // 10), so point i sees 2 + i reads and the median is point 51's: 53
+    d = np.full(20000, 200, np.uint16)
+    d[5000:5000 + 1060] = np.arange(1060) // 10
+    assert coverage_call(sv_line("DEL", 5001, 1060), d)[:2] == [53, 147]
+
+
 def test_small_sv_graph_vcf_equals_the_oracle(tmp_path):
     """the product's SV post-processing (gtx_vcf.cpp: sv_graph_records) against the oracle's on a small cfg5-like input, through
     the host emulation of the kernels (the `-m gpu` suite runs the same case through libgtx at cfg5's size)"""
