@@ -473,3 +473,41 @@ def test_statistics_one_read_leaves():
     assert alt(h[1]) == [125, 0, 0, 0, 0, 0, 0, 0, 0, 1]         # r2 reverse
     assert h[2][2] == 1 and h[2][3:5] == [3600, 0]
     assert alt(h[2]) == [125, 0, 3600, 0, 1, 0, 1, 0, 0, 0]      # r1 forward
+
+
+# ---- how many mismatches a walk at a read's end may take: min(2 + (walked bases incl. the anchor) / 11, 7)
+# (src/typer/genotype_paths.cpp:483-621).  One read over one SNP site that lies in the WALKED part of the read, drawn with the
+# alternative allele and a counted number of substitutions in that part (two or more in every k-mer that has to be lost: a k-mer one
+# substitution away is still found in the index): the read is counted for the allele exactly when the walk's budget holds them.
+WALKS = [
+    # (read length, the site's offset in the read, offsets of the substitutions, counted?)
+    (151, 10, [2, 6, 18, 26], True),                      # the first k-mer lost: 32 bases walked back, 2 + 32 / 11 = 4 allowed
+    (151, 10, [2, 6, 18, 26, 29], False),                 # 5 > 4
+    (157, 140, [128, 133, 138, 146, 151], True),          # the last 33 bases walked forward (bases 124 .. 156): 2 + 33 / 11 = 5
+    (157, 140, [128, 133, 138, 146, 151, 155], False),    # 6 > 5
+    (151, 140, [128, 133, 138, 146], True),               # 27 bases: 2 + 27 / 11 = 4
+    (151, 140, [128, 133, 138, 146, 149], False),
+    (200, 40, [5, 12, 20, 36, 50, 70, 85], True),         # three k-mers lost: 94 bases walked back, 2 + 8 = 10 but never more than 7
+    (200, 40, [5, 12, 20, 36, 50, 70, 85, 90], False),    # 8 > 7
+]
+
+
+@pytest.mark.parametrize("k", range(len(WALKS)))
+def test_mismatches_a_walk_may_take(k):
+    from graphtyper_amd import synth
+    read_len, site_at, errors, counted = WALKS[k]
+    ref = synth.make_reference(1200, seed=55)
+    rb, site = 30000, 600
+    key = ("walk budget",)
+    if key not in _ORACLES:
+        _ORACLES[key] = Oracle(synth.bases_to_str(ref), [(rb + site, "ACGT"[ref[site]], ["ACGT"[(ref[site] + 2) % 4]], None)], region_begin=rb)
+    og = _ORACLES[key].genotyper(1, 1)
+    s = site - site_at
+    r = ref[s:s + read_len].copy()
+    r[site_at] = (ref[site] + 2) % 4
+    for e in errors:
+        r[e] = (r[e] + 1) % 4
+    og.push([synth._CODE_OF_BASE[r]], pos=np.array([s + rb], np.int64))
+    og.finish()
+    sc = og.scores().tolist()
+    assert len(sc) == 25 + 9 + 2 and sc[25 + 4:25 + 6] == ([0, 1] if counted else [0, 0])
