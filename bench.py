@@ -597,6 +597,22 @@ class Workload:
                 whole_steps(n_lanes)
                 self.steps_done -= n_lanes
                 t_lanes = min(timed(whole_steps, 2 * n_lanes) for _ in range(3))
+                # (the same remedy as above where this schedule is allowed and did not come out clearly ahead: on one box in three
+                #  it ran cfg3 at 1.69 ms per step instead of 1.45 -- where the runtime puts three streams on the hardware queues)
+                lane_retries = 0
+                while self.allow_whole_steps and t_lanes > 0.93 * min(t_stag, t_one) and lane_retries < 2 and dist is None:
+                    lane_retries += 1
+                    self.fresh_streams()
+                    whole_steps(2 * n_lanes)
+                    self.steps_done -= 2 * n_lanes
+                    t_again = min(timed(whole_steps, 2 * n_lanes) for _ in range(3))
+                    if t_again < t_lanes:
+                        t_lanes = t_again
+                    else:  # (no better: the staggered figure above belongs to the streams before -- measure it on these)
+                        self.steps_staggered(2 * n_lanes)
+                        self.steps_done -= 2 * n_lanes
+                        t_stag = min(timed(self.steps_staggered, 2 * n_lanes) for _ in range(3))
+                retries += lane_retries
             both = torch.tensor([t_stag, t_one], dtype=torch.float64, device=self.device)
             if dist is not None:
                 dist.all_reduce(both, op=dist.ReduceOp.MAX)
