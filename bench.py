@@ -1442,10 +1442,10 @@ def extra_cfg5(args, torch, gtx, synth, device, n_pairs_per_sv=160, background_p
     dt_one = time.perf_counter() - t0
     kt = ctx.kernel_times()
     calls_one = d_calls.cpu().numpy().copy()
-    # Three steps in flight, each with records, accumulator block and stream of its own (round 5: the SV graph's reads spend their
+    # Four steps in flight, each with records, accumulator block and stream of its own (round 5: the SV graph's reads spend their
     # time in the general pass and behind it, chains of round trips that leave most of the chip idle).  The arena is the context's:
     # it is started over once, in front of the steps, and holds what all of them put there.
-    n_lanes = 3
+    n_lanes = int(os.environ.get("GTX_BENCH_CFG5_LANES", "4"))  # (3: 1.55-1.59 ms per step, 4: 1.43, 6: 1.56)
     lanes = [dict(stream=stream, sp=sp, d_rec=d_rec, buf=buf, d_phred=d_phred, d_calls=d_calls)]
     for _ in range(1, n_lanes):
         b2 = gtx.ScoreBuffers()
@@ -1500,7 +1500,7 @@ def extra_cfg5(args, torch, gtx, synth, device, n_pairs_per_sv=160, background_p
                        "(100 <DEL> 50-5000 bp, 50 <INS> with breakpoint alleles: %d sites, %d SV table entries)" %
                        (n_samples, tile, len(rec), n_align, n_items, nh, sv_table.count("\n")),
            "reads_per_s": tile * len(rec) * steps / dt, "ms_per_step": 1000.0 * dt / steps, "steps": steps,
-           "schedule": "3 steps in flight, each on a stream of its own" if in_flight else "one step at a time",
+           "schedule": ("%d steps in flight, each on a stream of its own" % n_lanes) if in_flight else "one step at a time",
            "one_at_a_time_ms_per_step": 1000.0 * dt_one / steps, "in_flight_ms_per_step": 1000.0 * dt_flight / steps,
            "steps_in_flight_leave_the_same_calls": same_calls,
            "align_kernels": {k[0]: {"ms": k[1], "tasks_completed": k[2]} for k in kt},
