@@ -1035,6 +1035,42 @@ extern "C"
     return h.coverage;
   }
 
+  // Graph::get_locations_of_a_position (graph.cpp:1154-1185; how = 2: the position may be a special one and is translated) or
+  // get_locations_of_an_actual_position (graph.cpp:931-1029; how = 0 / 1 = is_special) for a path given as its variant orders and
+  // the allele sets beside them (bit a of mask k: allele a at var_order[k]), with the path's start and end.  out: type ('R' / 'V'), node, node order, offset per
+  // location; returns their number.
+  long gto_locations(void * p, uint32_t pos, int how, uint32_t path_start, uint32_t path_end, long n_vars, uint32_t const * var_order, uint32_t const * masks,
+                     uint32_t * out, long cap)
+  {
+    auto const & g = static_cast<Handle *>(p)->graph;
+    Path path;
+    path.start = path_start; // (a path whose start is its end is "empty", path.cpp:198-201: every allele at its variant orders counts)
+    path.end = path_end;
+    for (long k = 0; k < n_vars; ++k)
+    {
+      path.var_order.push_back(var_order[k]);
+      std::set<uint16_t> s;
+      for (uint16_t a = 0; a < 32; ++a)
+        if ((masks[k] >> a) & 1u)
+          s.insert(a);
+      path.nums.push_back(s);
+    }
+    std::vector<Location> const locs = how == 2 ? g.get_locations_of_a_position(pos, path) : g.get_locations_of_an_actual_position(pos, path, how == 1);
+    long n = 0;
+    for (auto const & l : locs)
+    {
+      if (n < cap)
+      {
+        out[4 * n] = static_cast<uint32_t>(l.node_type);
+        out[4 * n + 1] = l.node_index;
+        out[4 * n + 2] = l.node_order;
+        out[4 * n + 3] = l.offset;
+      }
+      ++n;
+    }
+    return n;
+  }
+
   // make_bi_allelic_call (sample_call.cpp:188-253): d = ambiguous_depth, ref_total_depth, alt_total_depth, alt_proper_pair_depth,
   // then the call's coverage (n_cov values); out = the reduced call's coverage[0], coverage[1], ambiguous_depth, ref_total_depth,
   // alt_total_depth, alt_proper_pair_depth, phred[0..2]

@@ -511,3 +511,75 @@ def test_mismatches_a_walk_may_take(k):
     og.finish()
     sc = og.scores().tolist()
     assert len(sc) == 25 + 9 + 2 and sc[25 + 4:25 + 6] == ([0, 1] if counted else [0, 0])
+
+
+# ---- where in the graph a position is: Graph::get_locations_of_a_position / get_locations_of_an_actual_position (src/graph/graph.cpp:
+# 931-1029, 1154-1185) and the special positions of alleles that reach beyond their site's reference allele (graph.cpp:1759-1803).
+# The graph: 60 reference bases at orders 1001 .. 1060, a SNP at 1011, the insertion A -> AGTC at 1031:
+#   reference node 0 = 1001 .. 1010 | variant nodes 0, 1 (order 1011) | reference node 1 = 1012 .. 1030 | variant nodes 2 (A), 3 (AGTC:
+#   1031 .. 1034, of which 1032 .. 1034 lie behind the reference allele's reach and are the special positions SPECIAL_START + 0 .. 2) |
+#   reference node 2 = 1032 .. 1060.
+SPECIAL = 0xD0000000  # include/graphtyper/constants.hpp.in:33
+R, V = ord("R"), ord("V")
+ALT, REF, BOTH = 2, 1, 3  # allele sets as masks
+
+
+def _locations(o, pos, how, var_order=(), masks=(), start=5, end=9):
+    L = oracle_lib.lib()
+    L.gto_locations.restype = C.c_long
+    vo, mk = np.array(list(var_order) or [0], np.uint32), np.array(list(masks) or [0], np.uint32)
+    out = np.zeros(4 * 16, np.uint32)
+    n = L.gto_locations(C.c_void_p(o.h), C.c_uint32(pos), C.c_int(how), C.c_uint32(start), C.c_uint32(end), C.c_long(len(var_order)), vo.ctypes.data_as(C.c_void_p),
+                        mk.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_long(16))
+    return [tuple(int(x) for x in out[4 * k:4 * k + 4]) for k in range(n)]
+
+
+def test_locations_of_positions_by_hand():
+    from graphtyper_amd import synth
+    ref = synth.make_reference(60, seed=8)
+    rb = 1000
+    s = synth.bases_to_str(ref)
+    recs = [(rb + 10, s[10], ["ACGT"[(ref[10] + 1) % 4]], None), (rb + 30, s[30], [s[30] + "GTC" if s[31] != "G" else s[30] + "CTA"], None)]
+    o = Oracle(s, recs, region_begin=rb)
+    loc = lambda pos, var_order=(), masks=(), **kw: _locations(o, pos, 2, var_order, masks, **kw)
+    assert loc(1005) == [(R, 0, 1001, 4)] and loc(1001) == [(R, 0, 1001, 0)] and loc(1000) == []           # in front of the graph: nothing
+    assert loc(1012) == [(R, 1, 1012, 0)] and loc(1030) == [(R, 1, 1012, 18)] and loc(1060) == [(R, 2, 1032, 28)]
+    assert loc(1070) == []                                                                                 # behind it
+    # the SNP's position: the variant nodes of the alleles the path holds there, and only if the path names the site
+    assert loc(1011, [1011], [ALT]) == [(V, 1, 1011, 0)]
+    assert loc(1011, [1011], [REF]) == [(V, 0, 1011, 0)]
+    assert loc(1011, [1011], [BOTH]) == [(V, 0, 1011, 0), (V, 1, 1011, 0)]
+    assert loc(1011) == [] and loc(1011, [1031], [ALT]) == []
+    assert loc(1011, [1031, 1011], [REF, ALT]) == [(V, 1, 1011, 0)]                                         # the set beside ITS order
+    assert loc(1011, [1011], [ALT], start=7, end=7) == [(V, 0, 1011, 0), (V, 1, 1011, 0)]                   # an "empty" path (start = end): every allele
+    # the insertion: its first base is an ordinary position ...
+    assert loc(1031, [1031], [ALT]) == [(V, 3, 1031, 0)] and loc(1031, [1031], [REF]) == [(V, 2, 1031, 0)]
+    # ... the bases behind the reference allele's reach are special positions; the same NUMBER as an ordinary position is the reference
+    assert loc(SPECIAL + 0, [1031], [ALT]) == [(V, 3, 1031, 1)]
+    assert loc(SPECIAL + 1, [1031], [ALT]) == [(V, 3, 1031, 2)] and loc(SPECIAL + 2, [1031], [ALT]) == [(V, 3, 1031, 3)]
+    assert loc(1033) == [(R, 2, 1032, 1)] and loc(1033, [1031], [ALT]) == [(R, 2, 1032, 1)]
+    assert loc(SPECIAL + 1, [1031], [REF]) == [] and loc(SPECIAL + 1) == [] and loc(SPECIAL + 1, [1011], [ALT]) == []
+    assert loc(SPECIAL + 3, [1031], [ALT]) == []                                                           # no such special position: an ordinary number far away
+    # the same through get_locations_of_an_actual_position with is_special given
+    assert _locations(o, 1033, 1, [1031], [ALT]) == [(V, 3, 1031, 2)] and _locations(o, 1033, 0, [1031], [ALT]) == [(R, 2, 1032, 1)]
+    # a graph of one reference node
+    o1 = Oracle(s, [], region_begin=rb)
+    assert _locations(o1, 1042, 2) == [(R, 0, 1001, 41)] and _locations(o1, 1000, 2) == []
+
+
+def test_locations_inside_a_long_deletion():
+    """variant nodes are looked for behind a reference node only while that node's reach + 1000 is beyond the position (1 000 000 in an
+    SV graph): 998 bases into the reference allele of a 1 500-base deletion the allele is found, 999 bases in it is not"""
+    from graphtyper_amd import synth
+    ref = synth.make_reference(3000, seed=9)
+    rb, at = 7000, 500
+    s = synth.bases_to_str(ref)
+    recs = [(rb + at, s[at:at + 1501], [s[at]], None)]
+    order = rb + at + 1  # of the site's variant nodes; the reference node in front of it reaches order - 1
+    for sv, found_at_1200 in ((False, False), (True, True)):
+        o = Oracle(s, recs, region_begin=rb, is_sv_graph=sv)
+        assert _locations(o, order + 900, 2, [order], [REF]) == [(V, 0, order, 900)]
+        assert _locations(o, order + 998, 2, [order], [REF]) == [(V, 0, order, 998)]
+        assert _locations(o, order + 999, 2, [order], [REF]) == ([(V, 0, order, 999)] if sv else [])
+        assert _locations(o, order + 1200, 2, [order], [REF]) == ([(V, 0, order, 1200)] if found_at_1200 else [])
+        assert _locations(o, order + 900, 2, [order], [ALT]) == []   # the deletion's own allele is one base long
