@@ -1071,6 +1071,66 @@ extern "C"
     return n;
   }
 
+  // Graph::get_labels_forward / get_labels_backward (graph.cpp:1187-1439 / 1441-1701) from one location: the labels (start, end, variant
+  // node or 0xFFFFFFFF) of the candidates that tie the fewest mismatches; *max_mismatches goes in as the budget and comes out as their count
+  long gto_walk_labels(void * p, int backward, int type, uint32_t node, uint32_t order, uint32_t offset, char const * read, uint32_t * max_mismatches,
+                       uint32_t * out, long cap)
+  {
+    auto const & g = static_cast<Handle *>(p)->graph;
+    Location loc;
+    loc.node_type = static_cast<char>(type);
+    loc.node_index = node;
+    loc.node_order = order;
+    loc.offset = offset;
+    std::string const rd(read);
+    std::vector<KmerLabel> const labels = backward ? g.get_labels_backward(loc, rd, *max_mismatches) : g.get_labels_forward(loc, rd, *max_mismatches);
+    long n = 0;
+    for (auto const & l : labels)
+    {
+      if (n < cap)
+      {
+        out[3 * n] = l.start_index;
+        out[3 * n + 1] = l.end_index;
+        out[3 * n + 2] = l.variant_id;
+      }
+      ++n;
+    }
+    return n;
+  }
+
+  // Graph::iterative_dfs (graph.cpp:1703-1754): the walk from every start location (four words each: type, node, order, offset) --
+  // or, from one start of type 'U', back from every end location -- keeping the labels of the fewest mismatches
+  long gto_walk_between(void * p, long n_starts, uint32_t const * starts, long n_ends, uint32_t const * ends, char const * read, uint32_t * max_mismatches,
+                        uint32_t * out, long cap)
+  {
+    auto const & g = static_cast<Handle *>(p)->graph;
+    auto locations = [](long n, uint32_t const * w)
+    {
+      std::vector<Location> v(static_cast<std::size_t>(n));
+      for (long i = 0; i < n; ++i)
+      {
+        v[i].node_type = static_cast<char>(w[4 * i]);
+        v[i].node_index = w[4 * i + 1];
+        v[i].node_order = w[4 * i + 2];
+        v[i].offset = w[4 * i + 3];
+      }
+      return v;
+    };
+    std::vector<KmerLabel> const labels = g.iterative_dfs(locations(n_starts, starts), locations(n_ends, ends), std::string(read), *max_mismatches);
+    long n = 0;
+    for (auto const & l : labels)
+    {
+      if (n < cap)
+      {
+        out[3 * n] = l.start_index;
+        out[3 * n + 1] = l.end_index;
+        out[3 * n + 2] = l.variant_id;
+      }
+      ++n;
+    }
+    return n;
+  }
+
   // make_bi_allelic_call (sample_call.cpp:188-253): d = ambiguous_depth, ref_total_depth, alt_total_depth, alt_proper_pair_depth,
   // then the call's coverage (n_cov values); out = the reduced call's coverage[0], coverage[1], ambiguous_depth, ref_total_depth,
   // alt_total_depth, alt_proper_pair_depth, phred[0..2]

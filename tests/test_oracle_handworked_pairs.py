@@ -583,3 +583,188 @@ def test_locations_inside_a_long_deletion():
         assert _locations(o, order + 999, 2, [order], [REF]) == ([(V, 0, order, 999)] if sv else [])
         assert _locations(o, order + 1200, 2, [order], [REF]) == ([(V, 0, order, 1200)] if found_at_1200 else [])
         assert _locations(o, order + 900, 2, [order], [ALT]) == []   # the deletion's own allele is one base long
+
+
+# ---- the walks themselves: Graph::get_labels_forward / get_labels_backward (src/graph/graph.cpp:1187-1701) from one location over the
+# graph above (SNP at 1011, insertion A -> A + three bases at 1031).  A label = (start, end, variant node); positions inside the
+# insertion behind the reference allele's reach are special ones.  At a site the LAST allele extends the candidate in place and the
+# others branch off behind it: of two alleles that tie, the alternative one's label comes first.
+NONE = 0xFFFFFFFF
+
+
+def _walk(o, backward, loc, read, budget):
+    L = oracle_lib.lib()
+    L.gto_walk_labels.restype = C.c_long
+    mm = C.c_uint32(budget)
+    out = np.zeros(3 * 16, np.uint32)
+    n = L.gto_walk_labels(C.c_void_p(o.h), C.c_int(int(backward)), C.c_int(loc[0]), C.c_uint32(loc[1]), C.c_uint32(loc[2]), C.c_uint32(loc[3]), read.encode(),
+                          C.byref(mm), out.ctypes.data_as(C.c_void_p), C.c_long(16))
+    return [tuple(int(x) for x in out[3 * k:3 * k + 3]) for k in range(n)], int(mm.value)
+
+
+def test_walks_from_one_location_by_hand():
+    from graphtyper_amd import synth
+    ref = synth.make_reference(60, seed=8)
+    rb = 1000
+    s = synth.bases_to_str(ref)
+    alt = "ACGT"[(ref[10] + 1) % 4]
+    third = "ACGT"[(ref[10] + 2) % 4]
+    ins = "GTC" if s[31] != "G" and s[30] != "C" else "CTA" if s[31] != "C" and s[30] != "A" else "TGG"
+    assert ins[0] != s[31] and ins[-1] != s[30]  # (the insertion cannot be read as the bases behind it, nor its end as the base in front)
+    o = Oracle(s, [(rb + 10, s[10], [alt], None), (rb + 30, s[30], [s[30] + ins], None)], region_begin=rb)
+    fwd = lambda loc, read, budget: _walk(o, False, loc, read, budget)
+    bwd = lambda loc, read, budget: _walk(o, True, loc, read, budget)
+    # forward from order 1006 (reference node 0, offset 5) over the SNP: 20 bases, 1006 .. 1025
+    with_alt, with_ref, with_third = s[5:10] + alt + s[11:25], s[5:25], s[5:10] + third + s[11:25]
+    assert fwd((R, 0, 1001, 5), with_alt, 0) == ([(1006, 1025, 1)], 0)
+    assert fwd((R, 0, 1001, 5), with_ref, 0) == ([(1006, 1025, 0)], 0)
+    assert fwd((R, 0, 1001, 5), with_alt, 1) == ([(1006, 1025, 1)], 0)              # the budget comes back as what was used
+    assert fwd((R, 0, 1001, 5), with_third, 1) == ([(1006, 1025, 1), (1006, 1025, 0)], 1)
+    assert fwd((R, 0, 1001, 5), with_third, 0) == ([], 0)
+    # inside one reference node: no variant
+    assert fwd((R, 0, 1001, 2), s[2:7], 0) == ([(1003, 1007, NONE)], 0)
+    assert fwd((R, 0, 1001, 2), s[2:6] + "ACGT"[(ref[6] + 1) % 4], 2) == ([(1003, 1007, NONE)], 1)
+    # forward from 1025 through the insertion and four bases behind it (6 + 4 + 4 = 14 bases): the end is 1035 in reference node 2
+    through = s[24:30] + s[30] + ins + s[31:35]
+    assert fwd((R, 1, 1012, 13), through, 0) == ([(1025, 1035, 3)], 0)
+    assert fwd((R, 1, 1012, 13), s[24:38], 0) == ([(1025, 1038, 2)], 0)             # the same 14 bases of the reference: its allele
+    # ... ending INSIDE the insertion (6 + A + one inserted base): the end is the first special position
+    assert fwd((R, 1, 1012, 13), s[24:30] + s[30] + ins[0], 0) == ([(1025, SPECIAL + 0, 3)], 0)
+    assert fwd((R, 1, 1012, 13), s[24:30] + s[30] + ins, 0) == ([(1025, SPECIAL + 2, 3)], 0)
+    # ... starting inside it (the insertion's third base, offset 2 of variant node 3): the START is a special position
+    assert fwd((V, 3, 1031, 2), ins[1:] + s[31:35], 0) == ([(SPECIAL + 1, 1035, 3)], 0)
+    assert fwd((V, 3, 1031, 0), s[30] + ins[:2], 0) == ([(1031, SPECIAL + 1, 3)], 0)
+    # backward from 1022 (reference node 1, offset 10) over the SNP: 17 bases, 1006 .. 1022
+    assert bwd((R, 1, 1012, 10), s[5:10] + alt + s[11:22], 0) == ([(1006, 1022, 1)], 0)
+    assert bwd((R, 1, 1012, 10), s[5:22], 0) == ([(1006, 1022, 0)], 0)
+    assert bwd((R, 1, 1012, 10), s[5:10] + third + s[11:22], 1) == ([(1006, 1022, 1), (1006, 1022, 0)], 1)
+    assert bwd((R, 1, 1012, 10), s[5:10] + third + s[11:22], 0) == ([], 0)
+    assert bwd((R, 1, 1012, 10), s[13:22], 0) == ([(1014, 1022, NONE)], 0)          # nine bases: inside the node
+    # backward from 1035 (reference node 2, offset 3) through the insertion
+    assert bwd((R, 2, 1032, 3), through, 0) == ([(1025, 1035, 3)], 0)
+    assert bwd((R, 2, 1032, 3), s[21:35], 0) == ([(1022, 1035, 2)], 0)
+    assert bwd((R, 2, 1032, 3), ins[1:] + s[31:35], 0) == ([(SPECIAL + 1, 1035, 3)], 0)   # starting inside it
+    # ... and from inside it (its third base) back into reference node 1: 4 + A + two inserted bases
+    assert bwd((V, 3, 1031, 2), s[26:30] + s[30] + ins[:2], 0) == ([(1027, SPECIAL + 1, 3)], 0)
+
+
+def _walk_between(o, starts, ends, read, budget, cap=4096):
+    L = oracle_lib.lib()
+    L.gto_walk_between.restype = C.c_long
+    mm = C.c_uint32(budget)
+    out = np.zeros(3 * cap, np.uint32)
+    a, b = np.array(starts, np.uint32).reshape(-1, 4), np.array(ends, np.uint32).reshape(-1, 4)
+    n = L.gto_walk_between(C.c_void_p(o.h), C.c_long(len(a)), a.ctypes.data_as(C.c_void_p), C.c_long(len(b)), b.ctypes.data_as(C.c_void_p), read.encode(),
+                           C.byref(mm), out.ctypes.data_as(C.c_void_p), C.c_long(cap))
+    return [tuple(int(x) for x in out[3 * k:3 * k + 3]) for k in range(min(n, cap))], int(mm.value)
+
+
+def test_walks_that_end_with_a_node_and_walks_from_several_locations_by_hand():
+    from graphtyper_amd import synth
+    ref = synth.make_reference(60, seed=8)
+    rb = 1000
+    s = synth.bases_to_str(ref)
+    other = lambda i, k=1: "ACGT"[(ref[i] + k) % 4]
+    ins = "GTC" if s[31] != "G" and s[30] != "C" else "CTA" if s[31] != "C" and s[30] != "A" else "TGG"
+    o = Oracle(s, [(rb + 10, s[10], [other(10)], None), (rb + 30, s[30], [s[30] + ins], None)], region_begin=rb)
+    # the last two bases of the insertion and nothing else: both ends are special positions, whichever way it is walked
+    assert _walk(o, False, (V, 3, 1031, 2), ins[1:], 0) == ([(SPECIAL + 1, SPECIAL + 2, 3)], 0)
+    assert _walk(o, True, (V, 3, 1031, 3), ins[1:], 0) == ([(SPECIAL + 1, SPECIAL + 2, 3)], 0)
+    assert _walk(o, False, (V, 1, 1011, 0), other(10), 0) == ([(1011, 1011, 1)], 0)
+    assert _walk(o, True, (V, 1, 1011, 0), other(10), 0) == ([(1011, 1011, 1)], 0)
+    # up to the last base of a reference node / from its first one: no site is entered
+    assert _walk(o, False, (R, 0, 1001, 5), s[5:10], 0) == ([(1006, 1010, NONE)], 0)
+    assert _walk(o, True, (R, 1, 1012, 4), s[11:16], 0) == ([(1012, 1016, NONE)], 0)
+    # iterative_dfs over the two locations of order 1011 (one per allele): labels of as few mismatches are added to those there are,
+    # labels of fewer replace them
+    at_site = [(V, 0, 1011, 0), (V, 1, 1011, 0)]
+    nowhere = [(ord("U"), 0, 0, 0)]
+    assert _walk_between(o, at_site, nowhere, other(10, 2) + s[11:20], 1) == ([(1011, 1020, 0), (1011, 1020, 1)], 1)
+    assert _walk_between(o, at_site, nowhere, other(10) + s[11:20], 1) == ([(1011, 1020, 1)], 0)
+    assert _walk_between(o, at_site, nowhere, s[10:20], 1) == ([(1011, 1020, 0)], 0)
+    assert _walk_between(o, at_site, nowhere, other(10, 2) + s[11:20], 0) == ([], 0)
+    # ... from an unavailable start: back from every end
+    assert _walk_between(o, nowhere, at_site, s[5:10] + other(10, 2), 1) == ([(1006, 1011, 0), (1006, 1011, 1)], 1)
+    assert _walk_between(o, nowhere, at_site, s[5:10] + other(10), 1) == ([(1006, 1011, 1)], 0)
+    # ... and not at all from more than 1 024 locations on either side (MAX_LOCATIONS, graph.cpp:1712)
+    one = (R, 0, 1001, 2)
+    got, mm = _walk_between(o, [one] * 1024, nowhere, s[2:7], 0)
+    assert got == [(1003, 1007, NONE)] * 1024 and mm == 0
+    assert _walk_between(o, [one] * 1025, nowhere, s[2:7], 0) == ([], 0)
+    assert _walk_between(o, [one], nowhere * 1025, s[2:7], 0) == ([], 0)
+    assert _walk_between(o, [one], nowhere * 1024, s[2:7], 0) == ([(1003, 1007, NONE)], 0)
+
+
+def test_walks_over_three_sites_in_five_bases_by_hand():
+    """SNP at 1011, A -> A + three bases at 1013, SNP at 1015: reference nodes 1001..1010, 1012, 1014, 1016..1060.  The inserted
+    bases are the reference's base behind the site, the second SNP's alternative allele and the base behind that: a read with the
+    insertion reads as well as reference allele + second SNP."""
+    from graphtyper_amd import synth
+    ref = synth.make_reference(60, seed=8)
+    rb = 1000
+    s = synth.bases_to_str(ref)
+    other = lambda i, k=1: "ACGT"[(ref[i] + k) % 4]
+    ins = s[13] + other(14) + s[15]
+    o = Oracle(s, [(rb + 10, s[10], [other(10)], None), (rb + 12, s[12], [s[12] + ins], None), (rb + 14, s[14], [other(14)], None)], region_begin=rb)
+    g = o.graph()
+    assert g["ref_order"].tolist() == [1001, 1012, 1014, 1016] and g["var_order"].tolist() == [1011, 1011, 1013, 1013, 1015, 1015]
+    read = s[5:10] + other(10) + s[11] + s[12] + ins  # 5 + 1 + 1 + 4 = 11 bases: it ends with the insertion
+    # first the candidate through the insertion is complete (eleven bases, its end the third special position) while the one through
+    # the reference allele has nine and goes on over the second SNP to 1016; both read without a mismatch
+    assert _walk(o, False, (R, 0, 1001, 5), read, 0) == ([(1006, SPECIAL + 2, 1), (1006, SPECIAL + 2, 3), (1006, 1016, 1), (1006, 1016, 2), (1006, 1016, 5)], 0)
+    # one base more decides: the base behind the insertion is the reference's at 1014, the base behind 1016 is the one at 1017
+    assert _walk(o, False, (R, 0, 1001, 5), read + s[13], 0)[0] in ([(1006, 1014, 1), (1006, 1014, 3)], [(1006, 1014, 1), (1006, 1014, 3), (1006, 1017, 1), (1006, 1017, 2), (1006, 1017, 5)])
+    assert (s[13] == s[16]) == (len(_walk(o, False, (R, 0, 1001, 5), read + s[13], 0)[0]) == 5)
+    # backward from 1016 (first base of the last reference node) with the second SNP's alternative allele, 11 bases: over the reference
+    # allele of the insertion site it starts at 1006; over the insertion (whose last two bases read the same) three bases later
+    back = s[5:10] + other(10) + s[11] + s[12] + s[13] + other(14) + s[15]
+    assert back == read
+    assert _walk(o, True, (R, 3, 1016, 0), back, 0) == ([(1006, 1016, 5), (1006, 1016, 2), (1006, 1016, 1)], 0)
+    # ... from the last base of the insertion itself
+    assert _walk(o, True, (V, 3, 1013, 3), back, 0) == ([(1006, SPECIAL + 2, 3), (1006, SPECIAL + 2, 1)], 0)
+    # ... seven bases back from 1016 with two mismatches allowed: the candidate over the insertion is complete at the site (it starts
+    # with the site's first base), the one over the reference allele goes on over the first SNP with one mismatch, then two
+    assert _walk(o, True, (R, 3, 1016, 0), s[12] + ins + s[13:16], 2) == ([(1013, 1016, 4), (1013, 1016, 3)], 0)
+    # a read longer than what is in front of the location
+    assert _walk(o, True, (R, 0, 1001, 3), "AA" + s[0:4], 2) == ([], 2)
+
+
+def test_walks_over_eight_sites_stop_at_128_candidates():
+    """SNPs at every second base 1011 .. 1025; a read over all of them.  Every site doubles the candidates within the mismatch budget;
+    at 128 of them the walk gives up (MAX_VAR_AND_REFS, graph.cpp:1246 and :1500) -- after seven sites, when none is long enough yet.
+    With six mismatches allowed 127 candidates are left after seven sites and the walk ends with the one without a mismatch."""
+    from graphtyper_amd import synth
+    ref = synth.make_reference(60, seed=8)
+    rb = 1000
+    s = synth.bases_to_str(ref)
+    o = Oracle(s, [(rb + p, s[p], ["ACGT"[(ref[p] + 1) % 4]], None) for p in range(10, 26, 2)], region_begin=rb)
+    assert o.graph()["ref_order"].tolist() == [1001, 1012, 1014, 1016, 1018, 1020, 1022, 1024, 1026]
+    along = [(1006, 1030, v) for v in range(0, 16, 2)]
+    for budget, labels in ((0, along), (1, along), (6, along), (7, []), (8, []), (25, [])):
+        assert _walk(o, False, (R, 0, 1001, 5), s[5:30], budget) == (labels, 0 if labels else budget)
+        assert _walk(o, True, (R, 8, 1026, 4), s[5:30], budget) == (labels[::-1], 0 if labels else budget)
+    # the alternative alleles of the third and the last site
+    v = list(s[5:30])
+    v[14 - 5], v[24 - 5] = "ACGT"[(ref[14] + 1) % 4], "ACGT"[(ref[24] + 1) % 4]
+    mixed = [(1006, 1030, x) for x in (0, 2, 5, 6, 8, 10, 12, 15)]
+    assert sorted(_walk(o, False, (R, 0, 1001, 5), "".join(v), 2)[0]) == mixed
+    assert sorted(_walk(o, True, (R, 8, 1026, 4), "".join(v), 2)[0]) == mixed
+
+
+def test_a_walk_that_ends_with_the_middle_allele_of_three():
+    """reference A, alternatives A + three bases and T at 1012 (alleles are kept sorted: the insertion is the second of three, so its
+    candidate branches off instead of being grown in place); ending with its last base, its end is the third special position"""
+    from graphtyper_amd import synth
+    ref = synth.make_reference(60, seed=8)
+    rb = 1000
+    s = synth.bases_to_str(ref)
+    assert s[11] == "A"
+    ins = "".join("ACGT"[(ref[12 + k] + 1) % 4] for k in range(3))
+    o = Oracle(s, [(rb + 11, "A", ["A" + ins, "T"], None)], region_begin=rb)
+    g = o.graph()
+    assert g["var_order"].tolist() == [1012] * 3 and g["var_len"].tolist() == [1, 4, 1]
+    assert _walk(o, False, (R, 0, 1001, 6), s[6:11] + "A" + ins, 0) == ([(1007, SPECIAL + 2, 1)], 0)
+    assert _walk(o, False, (R, 0, 1001, 6), s[6:11] + "A" + ins + s[12:14], 0) == ([(1007, 1014, 1)], 0)
+    assert _walk(o, False, (R, 0, 1001, 6), s[6:11] + "T" + s[12:14], 0) == ([(1007, 1014, 2)], 0)
+    assert _walk(o, True, (R, 1, 1013, 2), "A" + ins + s[12:15], 0) == ([(1012, 1015, 1)], 0)
+    assert _walk(o, True, (R, 1, 1013, 2), ins[1:] + s[12:15], 0) == ([(SPECIAL + 1, 1015, 1)], 0)
