@@ -1098,6 +1098,80 @@ extern "C"
     return n;
   }
 
+  // the steps of GenotypePaths (genotype_paths.cpp) over paths given as numbers -- per path start, end, read_start_index,
+  // read_end_index, mismatches, the number of variant orders, then (order, bit a = allele a) per order -- and back in the same form.
+  // op 0: walk_read_ends(seq, arg), 1: walk_read_starts(seq, arg), 2: remove_support_from_read_ends, 3: remove_fully_special_paths,
+  // 4: remove_short_paths, 5: remove_paths_with_too_many_mismatches, 6: remove_non_ref_paths_when_read_matches_ref.
+  // longest < 0: the longest path's length is taken from the paths.  Returns the number of words written (or needed).
+  long gto_paths_op(void * p, int op, char const * seq, int arg, long read_length, long longest, long n_paths, uint32_t const * d, uint32_t * out, long cap)
+  {
+    auto const & g = static_cast<Handle *>(p)->graph;
+    GenotypePaths geno(0, static_cast<std::size_t>(read_length));
+    for (long i = 0; i < n_paths; ++i)
+    {
+      Path path;
+      path.start = d[0];
+      path.end = d[1];
+      path.read_start_index = static_cast<uint16_t>(d[2]);
+      path.read_end_index = static_cast<uint16_t>(d[3]);
+      path.mismatches = static_cast<uint16_t>(d[4]);
+      uint32_t const nv = d[5];
+      d += 6;
+      for (uint32_t k = 0; k < nv; ++k, d += 2)
+      {
+        path.var_order.push_back(d[0]);
+        std::set<uint16_t> s;
+        for (uint16_t a = 0; a < 32; ++a)
+          if ((d[1] >> a) & 1u)
+            s.insert(a);
+        path.nums.push_back(s);
+      }
+      geno.paths.push_back(path);
+    }
+    if (longest < 0)
+      geno.update_longest_path_size();
+    else
+      geno.longest_path_length = static_cast<uint32_t>(longest);
+    switch (op)
+    {
+    case 0: geno.walk_read_ends(std::string(seq), arg, g); break;
+    case 1: geno.walk_read_starts(std::string(seq), arg, g); break;
+    case 2: geno.remove_support_from_read_ends(g); break;
+    case 3: geno.remove_fully_special_paths(g); break;
+    case 4: geno.remove_short_paths(); break;
+    case 5: geno.remove_paths_with_too_many_mismatches(); break;
+    case 6: geno.remove_non_ref_paths_when_read_matches_ref(g); break;
+    default: return -1;
+    }
+    long n = 0;
+    auto put = [&](uint32_t w)
+    {
+      if (n < cap)
+        out[n] = w;
+      ++n;
+    };
+    put(static_cast<uint32_t>(geno.paths.size()));
+    put(geno.longest_path_length);
+    for (auto const & path : geno.paths)
+    {
+      put(path.start);
+      put(path.end);
+      put(path.read_start_index);
+      put(path.read_end_index);
+      put(path.mismatches);
+      put(static_cast<uint32_t>(path.var_order.size()));
+      for (std::size_t k = 0; k < path.var_order.size(); ++k)
+      {
+        put(path.var_order[k]);
+        uint32_t m = 0;
+        for (uint16_t a : path.nums[k])
+          m |= 1u << a;
+        put(m);
+      }
+    }
+    return n;
+  }
+
   // Graph::iterative_dfs (graph.cpp:1703-1754): the walk from every start location (four words each: type, node, order, offset) --
   // or, from one start of type 'U', back from every end location -- keeping the labels of the fewest mismatches
   long gto_walk_between(void * p, long n_starts, uint32_t const * starts, long n_ends, uint32_t const * ends, char const * read, uint32_t * max_mismatches,

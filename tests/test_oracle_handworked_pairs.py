@@ -768,3 +768,174 @@ def test_a_walk_that_ends_with_the_middle_allele_of_three():
     assert _walk(o, False, (R, 0, 1001, 6), s[6:11] + "T" + s[12:14], 0) == ([(1007, 1014, 2)], 0)
     assert _walk(o, True, (R, 1, 1013, 2), "A" + ins + s[12:15], 0) == ([(1012, 1015, 1)], 0)
     assert _walk(o, True, (R, 1, 1013, 2), ins[1:] + s[12:15], 0) == ([(SPECIAL + 1, 1015, 1)], 0)
+
+
+# ---- the steps of GenotypePaths (src/typer/genotype_paths.cpp) over paths written down as numbers.  A path here:
+# (start, end, read_start_index, read_end_index, mismatches, [(variant order, allele bits), ...])
+def _paths_op(o, op, paths, seq="", arg=-1, read_length=None, longest=-1):
+    L = oracle_lib.lib()
+    L.gto_paths_op.restype = C.c_long
+    words = []
+    for p in paths:
+        words += list(p[:5]) + [len(p[5])] + [w for pair in p[5] for w in pair]
+    d = np.array(words + [0], np.uint32)
+    out = np.zeros(1 << 16, np.uint32)
+    n = L.gto_paths_op(C.c_void_p(o.h), C.c_int(op), seq.encode(), C.c_int(arg), C.c_long(len(seq) if read_length is None else read_length), C.c_long(longest),
+                       C.c_long(len(paths)), d.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_long(len(out)))
+    assert 2 <= n <= len(out)
+    got, k = [], 2
+    for _ in range(int(out[0])):
+        nv = int(out[k + 5])
+        got.append(tuple(int(x) for x in out[k:k + 5]) + ([(int(out[k + 6 + 2 * i]), int(out[k + 7 + 2 * i])) for i in range(nv)],))
+        k += 6 + 2 * nv
+    assert k == n
+    return got, int(out[1])
+
+
+WALK_ENDS, WALK_STARTS, READ_ENDS, FULLY_SPECIAL, SHORT, MISMATCHES = 0, 1, 2, 3, 4, 5
+
+
+def _tiny():
+    from graphtyper_amd import synth
+    ref = synth.make_reference(60, seed=8)
+    s = synth.bases_to_str(ref)
+    other = lambda i, k=1: "ACGT"[(ref[i] + k) % 4]
+    ins = "GTC" if s[31] != "G" and s[30] != "C" else "CTA" if s[31] != "C" and s[30] != "A" else "TGG"
+    return s, other, ins, Oracle(s, [(1010, s[10], [other(10)], None), (1030, s[30], [s[30] + ins], None)], region_begin=1000)
+
+
+def test_a_seed_is_walked_to_the_end_of_the_read_by_hand():
+    """walk_read_ends (genotype_paths.cpp:483-553): a 20-base read over the SNP at 1011, its first six bases seeded (1003 .. 1008)"""
+    s, other, ins, o = _tiny()
+    seed = (1003, 1008, 0, 5, 0, [])
+    with_alt, with_third = s[2:10] + other(10) + s[11:22], s[2:10] + other(10, 2) + s[11:22]
+    assert _paths_op(o, WALK_ENDS, [seed], with_alt) == ([(1003, 1022, 0, 19, 0, [(1011, 0b10)])], 20)
+    assert _paths_op(o, WALK_ENDS, [seed], s[2:22]) == ([(1003, 1022, 0, 19, 0, [(1011, 0b01)])], 20)
+    # a third base at the site: one mismatch whichever allele, so both are in the path's set; not with no mismatch allowed (the
+    # default, for a negative argument, is 2 + one per eleven bases left, here 2 + 15 / 11 = 3)
+    assert _paths_op(o, WALK_ENDS, [seed], with_third) == ([(1003, 1022, 0, 19, 1, [(1011, 0b11)])], 20)
+    assert _paths_op(o, WALK_ENDS, [seed], with_third, arg=1) == ([(1003, 1022, 0, 19, 1, [(1011, 0b11)])], 20)
+    assert _paths_op(o, WALK_ENDS, [seed], with_third, arg=0) == ([seed], 6)
+    # four mismatches in the fifteen bases: one more than the default
+    four = list(with_third)
+    for i in (12, 14, 16):
+        four[i] = "ACGT"[("ACGT".index(four[i]) + 1) % 4]
+    assert _paths_op(o, WALK_ENDS, [seed], "".join(four)) == ([seed], 6)
+    assert _paths_op(o, WALK_ENDS, [seed], "".join(four), arg=4) == ([(1003, 1022, 0, 19, 4, [(1011, 0b11)])], 20)
+    # nothing is walked when the FIRST path is the whole read already
+    whole = (1003, 1022, 0, 19, 0, [(1011, 0b10)])
+    assert _paths_op(o, WALK_ENDS, [whole, seed], with_alt) == ([whole, seed], 20)
+    # of two seeds the one that gets to the end with fewer mismatches is extended: the second one here lies one base to the right
+    # of where the read is (every base behind it is a mismatch but for chance), the third where it belongs
+    shifted = (1004, 1009, 0, 5, 0, [])
+    got, _ = _paths_op(o, WALK_ENDS, [shifted, seed], with_alt)
+    assert got == [shifted, (1003, 1022, 0, 19, 0, [(1011, 0b10)])]
+    # 64 seeds are walked with mismatches, 65 without; 256 are walked, 257 not at all.  Every walk's labels are added in turn: the
+    # first turn extends every seed that ends where it starts, the later ones find no seed left and add the walked part by itself
+    walked, part = (1003, 1022, 0, 19, 1, [(1011, 0b11)]), (1008, 1022, 5, 19, 1, [(1011, 0b11)])
+    assert _paths_op(o, WALK_ENDS, [seed] * 64, with_third) == ([walked] * 64 + [part] * 63, 20)
+    assert _paths_op(o, WALK_ENDS, [seed] * 65, with_third) == ([seed] * 65, 6)
+    walked, part = (1003, 1022, 0, 19, 0, [(1011, 0b10)]), (1008, 1022, 5, 19, 0, [(1011, 0b10)])
+    assert _paths_op(o, WALK_ENDS, [seed] * 256, with_alt) == ([walked] * 256 + [part] * 255, 20)
+    assert _paths_op(o, WALK_ENDS, [seed] * 257, with_alt) == ([seed] * 257, 6)
+
+
+def test_a_seed_is_walked_to_the_start_of_the_read_by_hand():
+    """walk_read_starts (genotype_paths.cpp:555-621) and add_prev_kmer_labels (:233-292): the same read, its last six bases seeded"""
+    s, other, ins, o = _tiny()
+    seed = (1017, 1022, 14, 19, 0, [])
+    with_alt, with_third = s[2:10] + other(10) + s[11:22], s[2:10] + other(10, 2) + s[11:22]
+    whole = (1003, 1022, 0, 19, 0, [(1011, 0b10)])
+    assert _paths_op(o, WALK_STARTS, [seed], with_alt) == ([whole], 20)
+    assert _paths_op(o, WALK_STARTS, [seed], with_third) == ([(1003, 1022, 0, 19, 1, [(1011, 0b11)])], 20)
+    assert _paths_op(o, WALK_STARTS, [seed], with_third, arg=0) == ([seed], 6)
+    assert _paths_op(o, WALK_STARTS, [whole, seed], with_alt) == ([whole, seed], 20)
+    # a seed that starts with the read's second base is walked one base back; one that starts with its first is left alone
+    assert _paths_op(o, WALK_STARTS, [(1004, 1022, 1, 19, 0, [(1011, 0b10)])], with_alt) == ([whole], 20)
+    assert _paths_op(o, WALK_STARTS, [(1003, 1008, 0, 5, 0, [])], with_alt) == ([(1003, 1008, 0, 5, 0, [])], 6)
+    # two seeds that get to the start without a mismatch are both extended
+    longer = (1015, 1022, 12, 19, 0, [])
+    assert _paths_op(o, WALK_STARTS, [seed, longer], with_alt) == ([whole, whole], 20)
+    # a seed with the same place in the read but elsewhere in the graph is not joined to the first one's walk
+    elsewhere = (1041, 1046, 14, 19, 0, [])
+    assert _paths_op(o, WALK_STARTS, [seed, elsewhere], with_alt) == ([whole, elsewhere], 20)
+    assert _paths_op(o, WALK_STARTS, [elsewhere, seed], with_alt) == ([elsewhere, whole], 20)
+    # eleven bases in front of the seed allow 2 + 11 / 11 = 3 mismatches, ten allow two
+    three = list(with_alt)
+    for i in (1, 4, 6):
+        three[i] = "ACGT"[("ACGT".index(three[i]) + 1) % 4]
+    assert _paths_op(o, WALK_STARTS, [(1013, 1022, 10, 19, 0, [])], "".join(three)) == ([(1003, 1022, 0, 19, 3, [(1011, 0b10)])], 20)
+    assert _paths_op(o, WALK_STARTS, [(1012, 1022, 9, 19, 0, [])], "".join(three)) == ([(1012, 1022, 9, 19, 0, [])], 11)
+    # the numbers of seeds, as at the other end
+    walked, part = (1003, 1022, 0, 19, 1, [(1011, 0b11)]), (1003, 1017, 0, 14, 1, [(1011, 0b11)])
+    assert _paths_op(o, WALK_STARTS, [seed] * 64, with_third) == ([walked] * 64 + [part] * 63, 20)
+    assert _paths_op(o, WALK_STARTS, [seed] * 65, with_third) == ([seed] * 65, 6)
+    part = (1003, 1017, 0, 14, 0, [(1011, 0b10)])
+    assert _paths_op(o, WALK_STARTS, [seed] * 256, with_alt) == ([whole] * 256 + [part] * 255, 20)
+    assert _paths_op(o, WALK_STARTS, [seed] * 257, with_alt) == ([seed] * 257, 6)
+
+
+def test_no_more_than_seven_mismatches_are_walked_over():
+    """the budget of a walk is min(2 + bases / 11, 7): seventy bases with seven mismatches are walked, with eight they are not"""
+    from graphtyper_amd import synth
+    ref = synth.make_reference(120, seed=9)
+    s = synth.bases_to_str(ref)
+    o = Oracle(s, [(1010, s[10], ["ACGT"[(ref[10] + 1) % 4]], None)], region_begin=1000)
+    read = list(s[2:82])
+    spots = (14, 22, 30, 38, 46, 54, 62, 70)
+    for n in (7, 8):
+        r = list(read)
+        for i in spots[:n]:
+            r[i] = "ACGT"[("ACGT".index(r[i]) + 1) % 4]
+        seed = (1003, 1008, 0, 5, 0, [])
+        want = ([(1003, 1082, 0, 79, 7, [(1011, 0b01)])], 80) if n == 7 else ([seed], 6)
+        assert _paths_op(o, WALK_ENDS, [seed], "".join(r)) == want
+        r = list(read)
+        for i in spots[:n]:
+            r[79 - i] = "ACGT"[("ACGT".index(r[79 - i]) + 1) % 4]
+        seed = (1077, 1082, 74, 79, 0, [])
+        want = ([(1003, 1082, 0, 79, 7, [(1011, 0b01)])], 80) if n == 7 else ([seed], 6)
+        assert _paths_op(o, WALK_STARTS, [seed], "".join(r)) == want
+
+
+def test_support_at_the_ends_of_a_read_by_hand():
+    """remove_support_from_read_ends (genotype_paths.cpp:382-432) and its neighbours on a graph with A -> A + six bases at 1031 (special
+    positions +0 .. +5 for 1032 .. 1037) and a SNP at 1034"""
+    from graphtyper_amd import synth
+    ref = synth.make_reference(60, seed=8)
+    s = synth.bases_to_str(ref)
+    o = Oracle(s, [(1030, s[30], [s[30] + "".join("ACGT"[(ref[31 + k] + 1) % 4] for k in range(6))], None), (1033, s[33], ["ACGT"[(ref[33] + 1) % 4]], None)],
+               region_begin=1000)
+    g = o.graph()
+    assert g["actual_poses"].tolist() == [1032, 1033, 1034, 1035, 1036, 1037] and g["ref_reach_poses"].tolist() == [1031] * 6
+    ins, snp = (1031, 0b10), (1034, 0b10)
+    none = lambda v: (v[0], 0)
+    run = lambda p: _paths_op(o, READ_ENDS, [p], read_length=30)[0][0]
+    # a read that ends in the insertion no more than four bases behind the site supports no allele there
+    assert run((1010, SPECIAL + 2, 0, 24, 0, [ins])) == (1010, SPECIAL + 2, 0, 24, 0, [none(ins)])
+    assert run((1010, SPECIAL + 3, 0, 25, 0, [ins])) == (1010, SPECIAL + 3, 0, 25, 0, [none(ins)])
+    assert run((1010, SPECIAL + 4, 0, 26, 0, [ins])) == (1010, SPECIAL + 4, 0, 26, 0, [ins])
+    assert run((1010, 1033, 0, 29, 0, [ins])) == (1010, 1033, 0, 29, 0, [ins])                      # it ends behind the insertion
+    assert run((1010, SPECIAL + 2, 0, 24, 0, [])) == (1010, SPECIAL + 2, 0, 24, 0, [])
+    # a read that starts in the insertion supports it if four bases on it is still inside: from the second inserted base, not the third
+    assert run((SPECIAL + 1, 1040, 0, 12, 0, [ins, snp])) == (SPECIAL + 1, 1040, 0, 12, 0, [ins, snp])
+    assert run((SPECIAL + 2, 1040, 0, 11, 0, [ins, snp])) == (SPECIAL + 2, 1040, 0, 11, 0, [none(ins), snp])
+    assert run((SPECIAL + 2, 1040, 0, 11, 0, [snp, ins])) == (SPECIAL + 2, 1040, 0, 11, 0, [snp, none(ins)])
+    assert run((SPECIAL + 1, 1036, 0, 8, 0, [ins, snp])) == (SPECIAL + 1, 1036, 0, 8, 0, [ins, snp])  # (an end within four bases of the SNP, not special)
+    # both ends in it
+    assert run((SPECIAL + 0, SPECIAL + 5, 0, 5, 0, [ins])) == (SPECIAL + 0, SPECIAL + 5, 0, 5, 0, [ins])
+    assert run((SPECIAL + 2, SPECIAL + 5, 0, 3, 0, [ins])) == (SPECIAL + 2, SPECIAL + 5, 0, 3, 0, [none(ins)])
+    # remove_fully_special_paths (:476-481): a path whose ends belong to one place of the reference goes
+    inside, into, single = (SPECIAL + 0, SPECIAL + 5, 0, 5, 0, [ins]), (1025, SPECIAL + 1, 0, 8, 0, [ins]), (1020, 1020, 3, 3, 0, [])
+    assert _paths_op(o, FULLY_SPECIAL, [inside, into, single], read_length=30)[0] == [into]
+    # remove_short_paths (:824-834): the paths shorter than the longest go, unless that is one base
+    a, b, c = (1003, 1004, 0, 1, 0, []), (1010, 1010, 0, 0, 0, []), (1020, 1024, 3, 7, 0, [])
+    assert _paths_op(o, SHORT, [a, b], read_length=30) == ([a], 2)
+    assert _paths_op(o, SHORT, [a, c, b], read_length=30) == ([c], 5)
+    assert _paths_op(o, SHORT, [a, c, b], read_length=30, longest=1) == ([a, c, b], 1)
+    assert _paths_op(o, SHORT, [], read_length=30) == ([], 0)
+    # remove_paths_with_too_many_mismatches (:360-380): the paths with more than the fewest -- and more than ten in any case
+    m = lambda k: (1003, 1022, 0, 19, k, [])
+    assert _paths_op(o, MISMATCHES, [m(3), m(2), m(4), m(2)], read_length=20)[0] == [m(2), m(2)]
+    assert _paths_op(o, MISMATCHES, [m(10), m(11)], read_length=20)[0] == [m(10)]
+    assert _paths_op(o, MISMATCHES, [m(11), m(12)], read_length=20)[0] == []
