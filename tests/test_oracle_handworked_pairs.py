@@ -939,3 +939,107 @@ def test_support_at_the_ends_of_a_read_by_hand():
     assert _paths_op(o, MISMATCHES, [m(3), m(2), m(4), m(2)], read_length=20)[0] == [m(2), m(2)]
     assert _paths_op(o, MISMATCHES, [m(10), m(11)], read_length=20)[0] == [m(10)]
     assert _paths_op(o, MISMATCHES, [m(11), m(12)], read_length=20)[0] == []
+
+
+@pytest.mark.parametrize("offset,overlapping", [(2, False), (3, True), (40, True), (146, True), (147, False), (150, False)])
+def test_a_site_within_three_bases_of_a_read_end_counts_one_less(offset, overlapping):
+    """push_to_haplotype_scores (vcf_writer.cpp:503-676): a read "overlaps" a site when it starts three bases or more in front of it
+    and ends more than three behind; one that does not adds 2 ^ -1 less (explain_to_score, haplotype.cpp:482).  One read of 151 bases,
+    no mismatch, the alternative allele at the given offset: epsilon exponent 12 -> 8 for alt/alt, 7 for ref/alt; 7 and 6 at the edge"""
+    from graphtyper_amd import synth
+    ref = synth.make_reference(1200, seed=5)
+    rb, site = 30000, 600
+    og = Oracle(synth.bases_to_str(ref), [(rb + site, "ACGT"[ref[site]], ["ACGT"[(ref[site] + 1) % 4]], None)], region_begin=rb).genotyper(1, 1)
+    s0 = site - offset
+    r = ref[s0:s0 + 151].copy()
+    r[offset] = (ref[site] + 1) % 4
+    og.push([synth._CODE_OF_BASE[r]], flags=np.zeros(1, np.uint16), mapq=np.full(1, 60, np.uint8), score_diff=np.zeros(1, np.uint8), pos=np.array([s0 + rb], np.int64))
+    og.finish()
+    s = og.scores().tolist()
+    eps = 8 if overlapping else 7
+    assert s[25:34] == [eps, 0, 0, 0, 0, 1, 0, eps - 1, eps]
+
+
+def test_a_read_one_base_from_two_alternative_alleles_and_two_from_the_reference():
+    """a site of two bases with two alternative alleles that share their first base; a read with that base and a fourth second base
+    is one mismatch from either: one path with both in its set, counted as ambiguous between ALTERNATIVE alleles
+    (vcf_writer.cpp:503-676, haplotype.cpp:180-227 and :315-361), 2 ^ -(12 - 1) -> 7 for every genotype of the two, 6 with the
+    reference allele, nothing for ref/ref"""
+    from graphtyper_amd import synth
+    ref = synth.make_reference(1200, seed=5)
+    rb, site = 30000, 600
+    b = lambda i, k: "ACGT"[(ref[i] + k) % 4]
+    recs = [(rb + site, b(site, 0) + b(site + 1, 0), [b(site, 1) + b(site + 1, 1), b(site, 1) + b(site + 1, 2)], None)]
+    o = Oracle(synth.bases_to_str(ref), recs, region_begin=rb)
+    assert o.graph()["var_len"].tolist() == [2, 2, 2]
+    for second, want in ((3, [7, 1, 1, 0, 0, 0, 0, 0, 6, 7, 6, 7, 7]),      # max_log_score, ambiguous, ambiguous alt, proper pairs, coverage x 3, 6 cells
+                         (1, [8, 0, 0, 0, 0, 1, 0, 0, 7, 8, 0, 7, 0]),      # the first alternative allele itself
+                         (2, [8, 0, 0, 0, 0, 0, 1, 0, 0, 0, 7, 7, 8])):
+        og = o.genotyper(1, 1)
+        s0 = site - 70
+        r = ref[s0:s0 + 151].copy()
+        r[70], r[71] = (ref[site] + 1) % 4, (ref[site + 1] + second) % 4
+        og.push([synth._CODE_OF_BASE[r]], flags=np.zeros(1, np.uint16), mapq=np.full(1, 60, np.uint8), score_diff=np.zeros(1, np.uint8), pos=np.array([s0 + rb], np.int64))
+        og.finish()
+        s = og.scores().tolist()
+        assert s[1] == 3 and s[5 + 30:5 + 30 + 13] == want, (second, s)
+
+
+@pytest.mark.parametrize("n_alts,times", [(1, 1), (2, 2)])
+def test_links_of_an_ambiguous_site_to_the_next_one(n_alts, times):
+    """vcf_writer.cpp:560-640: every allele a read may have at one site is linked to what it has at the later sites -- once, but
+    6 / (n1 x n2) times when the two sets hold three combinations or more (three alleles x one: twice).  One read with a base no
+    allele of the first site has (one mismatch from each: all of them in its set) and the alternative allele of a second site"""
+    from graphtyper_amd import synth
+    ref = synth.make_reference(1200, seed=5)
+    rb, a, b = 30000, 600, 640
+    recs = [(rb + a, "ACGT"[ref[a]], ["ACGT"[(ref[a] + k) % 4] for k in range(1, n_alts + 1)], None), (rb + b, "ACGT"[ref[b]], ["ACGT"[(ref[b] + 1) % 4]], None)]
+    og = Oracle(synth.bases_to_str(ref), recs, region_begin=rb).genotyper(1, 1)
+    s0 = a - 70
+    r = ref[s0:s0 + 151].copy()
+    r[70], r[70 + b - a] = (ref[a] + 3) % 4, (ref[b] + 1) % 4
+    og.push([synth._CODE_OF_BASE[r]], flags=np.zeros(1, np.uint16), mapq=np.full(1, 60, np.uint8), score_diff=np.zeros(1, np.uint8), pos=np.array([s0 + rb], np.int64))
+    og.finish()
+    s = og.scores().tolist()
+    n = n_alts + 1
+    first = 5 + 10 * n + 4 + n + n * (n + 1) // 2 + 4 * n
+    h0, h1 = s[:first], s[first:]
+    assert h0[1] == n and h1[1] == 2 and len(h1) == 25 + 9 + 2
+    assert h0[5 + 10 * n:5 + 10 * n + 4 + n] == [7, 1, 0, 0] + [0] * n          # ambiguous, the reference allele among them
+    assert h0[5 + 10 * n + 4 + n:-4 * n] == [7] * (n * (n + 1) // 2)
+    assert h0[-4 * n:] == [1, 1, 0, times] * n                                 # per allele: one site linked, haplotype 1, its alleles' counts
+    assert h1[25:] == [7, 0, 0, 0, 0, 1, 0, 6, 7, 0, 0]
+
+
+def test_which_orientations_of_a_read_are_looked_for():
+    """align_read (alignment.cpp:331-363): a read shorter than 2 x 32 - 1 bases is not aligned; the read as it is stored is always
+    looked for; its reverse complement only when the read is half of a pair and does not face its mate on the same contig less
+    than 1 200 bases away.  A read that IS the reverse complement of 100 reference bases over a SNP: found in the second orientation or not
+    at all"""
+    from graphtyper_amd import synth
+    ref = synth.make_reference(1200, seed=5)
+    rb, site = 30000, 600
+    o = Oracle(synth.bases_to_str(ref), [(rb + site, "ACGT"[ref[site]], ["ACGT"[(ref[site] + 1) % 4]], None)], region_begin=rb)
+    there = ref[560:660]
+    back = (3 - there)[::-1]
+    whole = dict(start=rb + 561, end=rb + 660, rs=0, re=99, mm=0, vars=[(rb + 601, (0,))])
+    nothing = dict(longest=0, paths=[])
+    found = dict(longest=100, paths=[whole])
+    code = lambda a: synth._CODE_OF_BASE[a]
+    PAIRED, REVERSED, MATE_REVERSED = 1, 16, 32
+    assert o.align([code(there)]) == [(found, nothing)]
+    assert o.align([code(back)]) == [(nothing, nothing)]                       # (not half of a pair: one orientation)
+    cases = [  # flag, tid, mtid, isize, is the reverse complement looked for?
+        (0, 0, 0, 0, False), (PAIRED | MATE_REVERSED, 0, 0, 300, False), (PAIRED | REVERSED, 0, 0, -300, False),
+        (PAIRED | MATE_REVERSED, 0, 0, 1199, False), (PAIRED | MATE_REVERSED, 0, 0, 1200, True),
+        (PAIRED | REVERSED, 0, 0, -1199, False), (PAIRED | REVERSED, 0, 0, -1200, True),
+        (PAIRED | MATE_REVERSED, 0, 1, 300, True), (PAIRED, 0, 0, 300, True), (PAIRED | REVERSED | MATE_REVERSED, 0, 0, 300, True),
+    ]
+    for flag, tid, mtid, isize, both in cases:
+        got = o.align([code(back)], flags=[flag], tid=[tid], mtid=[mtid], isize=[isize])
+        assert got == [(nothing, found if both else nothing)], (flag, tid, mtid, isize)
+        got = o.align([code(there)], flags=[flag], tid=[tid], mtid=[mtid], isize=[isize])
+        assert got == [(found, nothing)]
+    # 63 bases are aligned (two k-mers that share a base), 62 are not
+    assert o.align([code(ref[570:633])]) == [(dict(longest=63, paths=[dict(start=rb + 571, end=rb + 633, rs=0, re=62, mm=0, vars=[(rb + 601, (0,))])]), nothing)]
+    assert o.align([code(ref[570:632])]) == [(nothing, nothing)]

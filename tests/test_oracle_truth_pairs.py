@@ -102,3 +102,26 @@ def test_one_pair_with_mapping_qualities_24_and_25():
             assert h[3:5] == [mapqs[k] ** 2, 0]
             strand = h[5 + 10 + 6:5 + 20]  # r1 forward, r1 reverse, r2 forward, r2 reverse of the alternative allele
             assert strand == ([1, 0, 0, 0] if k == 0 else [0, 0, 0, 1])
+
+
+def test_one_pair_whose_mates_both_hold_the_site():
+    """a fragment of 200 bases: both mates read the alternative allele of the one site.  Each is counted (coverage 2, 2 x 8 for
+    alt/alt); a site is not linked to itself (vcf_writer.cpp:186-227 links keys of LATER sites only)"""
+    ref = synth.make_reference(2400, seed=33)
+    rb, site = 90000, 600
+    recs = [(rb + site, "ACGT"[ref[site]], ["ACGT"[(ref[site] + 1) % 4]], None)]
+    hap = ref.copy()
+    hap[site] = (ref[site] + 1) % 4
+    og = Oracle(synth.bases_to_str(ref), recs, region_begin=rb).genotyper(1, 1)
+    s1, s2 = site - 120, site - 120 + 200 - READ_LEN
+    reads = [synth._CODE_OF_BASE[hap[s1:s1 + READ_LEN]], synth._CODE_OF_BASE[hap[s2:s2 + READ_LEN]]]
+    og.push(reads, flags=np.array([PAIRED | PROPER | MATE_REVERSED | FIRST, PAIRED | PROPER | REVERSED | SECOND], np.uint16), tid=np.zeros(2, np.int32),
+            mtid=np.zeros(2, np.int32), pos=np.array([s1 + rb, s2 + rb], np.int64), isize=np.array([200, -200], np.int64),
+            mapq=np.array([60, 60], np.uint8), score_diff=np.zeros(2, np.uint8), name=np.array([7, 7], np.uint64), sample=np.zeros(2, np.int32),
+            rg=np.zeros(2, np.int32))
+    og.finish()
+    s = og.scores().tolist()
+    assert len(s) == 25 + 9 + 2
+    assert s[25:] == [16, 0, 0, 2, 0, 2, 0, 14, 16, 0, 0]
+    assert s[3:5] == [2 * 3600, 0] and s[5 + 10 + 6:5 + 20] == [1, 0, 0, 1]  # mate 1 forward, mate 2 reverse
+
