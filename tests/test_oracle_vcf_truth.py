@@ -180,3 +180,138 @@ def test_a_40x_sample_is_called_as_it_was_simulated():
     want = [recs[k][0] + 1 for k in range(len(recs)) if kind[k] > 0 and inner(k)]
     got = [r["pos"] for r in final if 200 <= r["pos"] - rb - 1 <= n_ref - 200]
     assert got == want and len(want) > 50
+
+
+# ---- two records worked out by hand, every INFO key (src/graph/variant.cpp:230-1096, var_stats.cpp:53-141, logistic_constants.hpp).
+# A read of 151 bases without mismatch adds 2^-(12-4) to the genotypes that hold its allele twice, one less to those that hold it once
+# (haplotype.cpp:462-585): with r reference and a alternative reads ref/ref = 8 r, ref/alt = 7 (r + a), alt/alt = 8 a, and the phred
+# value of a genotype is 3.0103 x (the best - its own), rounded, 255 at most.
+def _one_site_records(n_alts, rows, n_samples=3):
+    import numpy as np
+    from graphtyper_amd import synth
+    from oracle_lib import Oracle
+    from test_vcf_text import _parse
+    ref = synth.make_reference(1200, seed=5)
+    rb, site = 30000, 600
+    o = Oracle(synth.bases_to_str(ref), [(rb + site, "ACGT"[ref[site]], ["ACGT"[(ref[site] + k) % 4] for k in range(1, n_alts + 1)], None)], region_begin=rb)
+    og = o.genotyper(n_samples, 1)
+    s0 = site - 75
+    reads = []
+    for sample, allele, flag, mapq, score_diff, mismatches, *clipped in rows:
+        r = ref[s0:s0 + 151].copy()
+        r[75] = (ref[site] + allele) % 4
+        if clipped:
+            r[151 - clipped[0]:] = 3 - r[151 - clipped[0]:]  # complemented: no k-mer of it is found and no walk gets through it
+        for p in (10, 50, 110, 140)[:mismatches]:  # one in a k-mer at most: the k-mer is still found, one substitution away
+            r[p] = (r[p] + 1) % 4
+        reads.append(synth._CODE_OF_BASE[r])
+    n = len(rows)
+    og.push(reads, flags=np.array([r[2] for r in rows], np.uint16), mapq=np.array([r[3] for r in rows], np.uint8), score_diff=np.array([r[4] for r in rows], np.uint8),
+            pos=np.full(n, s0 + rb, np.int64), sample=np.array([r[0] for r in rows], np.int32), rg=np.zeros(n, np.int32))
+    og.finish()
+    _, records = _parse(og.vcf_records("chrT", ["A", "B", "C"][:n_samples]))
+    assert len(records) == 1
+    return records[0]
+
+
+def _sigmoid(x):
+    import math
+    return 1.0 / (1.0 + math.exp(-x))
+
+
+def test_every_info_key_of_a_record_with_one_alternative_allele_by_hand():
+    F, R = 0, 16
+    rows = [(0, 0, F, 60, 0, 0), (0, 0, R, 60, 0, 0), (0, 1, F, 60, 5, 0), (0, 1, F, 60, 0, 0)]                 # A: 2 + 2
+    rows += [(1, 0, F, 60, 0, 0)] * 3 + [(1, 0, R, 60, 0, 0)]                                                  # B: 4 + 0
+    rows += [(2, 1, F, 60, 3, 0)] + [(2, 1, F, 60, 0, 0)] * 4 + [(2, 1, R, 30, 0, 0)] + [(2, 1, R, 60, 0, 0)] * 6  # C: 0 + 12
+    r = _one_site_records(1, rows)
+    # A: 16 / 28 / 16 -> PL 36, 0, 36; B: 32 / 28 / 0 -> 0, 12, 96; C: 0 / 84 / 96 -> 289 -> 255, 36, 0.  In the text PL and GQ are
+    # binned (binned_pl.hpp: 33-37 are written as 35, 80-112 as 99); QUAL and the INFO keys use the values themselves
+    assert r["samples"] == [["0/1", "2,2", "0", "4", "35", "35,0,35"], ["0/0", "4,0", "0", "4", "12", "0,12,99"], ["1/1", "0,12", "0", "12", "35", "255,35,0"]]
+    assert r["qual"] == 36 + 0 + 255 and r["filt"] == "PASS"
+    qd = (36 + 250) / (2 + 10)   # per sample with PL[0] > 0: min(25 x depth, PL[0]) over depth = min(10, alternative reads): A 36 / 2, C 250 / 10
+    want = {
+        "AC": "3", "AN": "6", "AF": "0.5", "NHomRef": "1", "NHet": "1", "NHomAlt": "1", "PexcessHet": "1",
+        "PASS_AC": "3", "PASS_AN": "4", "PASS_ratio": "0.6667",              # GQ 36, 12, 36: A and C pass (>= 30)
+        "MaxAAS": "12", "MaxAASR": "1", "SeqDepth": "20", "RefLen": "1", "VarType": "SG",
+        "ABHet": "0.5", "ABHetMulti": "0.5,0.5", "ABHom": "1", "ABHomMulti": "1,1",
+        "SBF": "4,7", "SBR": "2,7", "SBF1": "0,0", "SBF2": "4,7", "SBR1": "0,0", "SBR2": "2,7", "SB": "0.55", "SBAlt": "0.5",
+        "MQsquared": str(19 * 3600 + 900), "MQ": "59", "MQSal": "21600,47700", "MQalt": "58",   # sqrt(69300 / 20) = 58.9, sqrt(47700 / 14) = 58.4
+        "SDal": "0,8", "SDalt": "0.571429", "MMal": "0,0", "MMalt": "0", "CR": "0", "CRal": "0,0", "CRalt": "0",
+        "QD": "23.83", "QDalt": "23.83",
+        # logistic_constants.hpp:52-92: ABHom 1 is in the last bin; no strand bias (7 of 14 reverse); score difference round(8 / 14) = 1
+        "AAScore": "%.4g" % _sigmoid(-6.347426707 + 3.930106559 + 1 * 0.014572295 + qd * 0.065221319 + 58 * 0.055973424),
+        # :8-50: ABHet 0.5 and SBAlt 0.5 are in the bins without a term; every sample is genotyped
+        "LOGF": "%.4g" % _sigmoid(-29.28908 + 1.0 * 23.12909 + 59 * 0.01024 + (2 / 3) * 0.85320 + 1.0 * 4.91178 + qd * 0.23215),
+    }
+    assert r["info"] == want
+
+
+def test_every_info_key_of_a_record_with_two_alternative_alleles_by_hand():
+    """A without a read; B 3 x reference + 1 x first alternative; C 1 x first + 5 x second alternative, those five with four mismatches
+    (2^-(8-4) each) and a score difference of 2"""
+    F, R = 0, 16
+    rows = [(1, 0, F, 60, 0, 0)] * 2 + [(1, 0, R, 60, 0, 0), (1, 1, R, 60, 7, 0)]
+    rows += [(2, 1, F, 60, 0, 0)] + [(2, 2, F, 60, 2, 4)] * 4 + [(2, 2, R, 60, 2, 4)]
+    r = _one_site_records(2, rows)
+    # genotypes in the order 0/0 0/1 1/1 0/2 1/2 2/2.  B: 24 28 8 21 7 0 -> PL 12 0 60 21 63 84.  C: 0 7 8 15 22 20 -> 66 45 42 21 0 6
+    # (written in the bins of binned_pl.hpp: 18-22 as 20, 38-44 as 40, 45-54 as 50, 55-67 as 60, 80-112 as 99; no PL: no genotype)
+    assert r["samples"] == [["./.", "0,0,0", "0", "0", "0", "0,0,0,0,0,0"], ["0/1", "3,1,0", "0", "4", "12", "12,0,60,20,60,99"],
+                            ["1/2", "0,1,5", "0", "6", "6", "60,50,40,20,0,6"]]
+    assert r["qual"] == 12 + 66
+    qd = (12 + 66) / (1 + 6)
+    aa2 = _sigmoid(-6.347426707 + 2.214801195 + 0.6 * -0.25233400 + 2.6 * -0.04129973 + 2 * 0.014572295 + 8.4 * 0.065221319 + 60 * 0.055973424)
+    aa2 *= (1.0 - (2.6 - 1.5) / 20.0) * (1.0 - (2.6 - 2.5) / 40.0)   # more than 1.5 mismatches per read (x 100 / 151), more than 2.5 with the clipped bases
+    want = {
+        "AC": "2,1", "AN": "4", "AF": "0.5,0.25",                        # 0/0 (not genotyped: no PL), 0/1, 1/2 over two genotyped samples
+        "NHomRef": "1,2", "NHet": "2,1", "NHomAlt": "0,0", "PexcessHet": "0.8,1",
+        "PASS_AC": "0,0", "PASS_AN": "0", "PASS_ratio": "0",             # GQ 0, 12, 6
+        "MaxAAS": "1,5", "MaxAASR": "0.25,0.8333", "SeqDepth": "10", "RefLen": "1", "VarType": "SG",
+        "ABHet": "0.6",                                                  # second called allele over both: (1 + 5) / (3 + 1 + 1 + 5)
+        "ABHetMulti": "0.25,0.8,0.1667",                                 # reads NOT of the allele over all, in the samples called with it: 1/4, (3 + 5)/10, 1/6
+        "ABHom": "-1", "ABHomMulti": "-1,-1,-1",                         # the one homozygous call has no read
+        "SBF": "2,1,4", "SBR": "1,1,1", "SBF1": "0,0,0", "SBF2": "2,1,4", "SBR1": "0,0,0", "SBR2": "1,1,1", "SB": "0.7", "SBAlt": "0.7143",
+        "MQsquared": "36000", "MQ": "60", "MQSal": "10800,7200,18000", "MQalt": "60,60",
+        "SDal": "0,7,10", "SDalt": "3.5,2", "MMal": "0,0,130", "MMalt": "0,2.6",   # 4 x 1000 / 151 = 26 per read
+        "CR": "0", "CRal": "0,0,0", "CRalt": "0,0",
+        "QD": "11.14",
+        "QDalt": "9,8.4",   # first: B min(25, lowest PL without it = 12) + C min(25, 6) over 1 + 1 reads; second: C min(125, 42) over 5
+        "AAScore": "0,%.4g" % aa2,                                       # the first has no sample with two reads
+        # ABHom unknown counts as 0.985; ABHet 0.6 and SBAlt 0.71 have terms; two of three samples genotyped; none passes
+        "LOGF": "%.4g" % _sigmoid(-29.28908 + 0.985 * 23.12909 + 60 * 0.01024 + (2 / 3) * 4.91178 + qd * 0.23215 - 1.05013 - 0.41332),
+    }
+    assert r["info"] == want
+
+
+@pytest.mark.parametrize("n_reads", [1, 2])
+def test_every_info_key_of_a_record_with_one_sample_and_one_or_two_reads_by_hand(n_reads):
+    """the smallest records: one sample, one or two reads of the alternative allele (forward, mapping quality 40, score difference 4).
+    alt/alt 8 n, ref/alt 7 n, ref/ref 0 -> PL 24 n, 3 n, 0; an allele needs a sample with two reads for an AAScore"""
+    r = _one_site_records(1, [(0, 1, 0, 40, 4, 0)] * n_reads, n_samples=1)
+    n = n_reads
+    assert r["samples"] == [["1/1", "0,%d" % n, "0", str(n), "3" if n == 1 else "6", "25,3,0" if n == 1 else "50,6,0"]] and r["qual"] == 24 * n
+    aa = 0.0 if n == 1 else _sigmoid(-6.347426707 + 3.930106559 + 1.0 * -0.25233400 + 4 * 0.014572295 + 24.0 * 0.065221319 + 40 * 0.055973424)  # every read forward
+    want = {
+        "AC": "2", "AN": "2", "AF": "1", "NHomRef": "0", "NHet": "0", "NHomAlt": "1", "PexcessHet": "1", "PASS_AC": "0", "PASS_AN": "0", "PASS_ratio": "0",
+        "MaxAAS": str(n), "MaxAASR": "1", "SeqDepth": str(n), "RefLen": "1", "VarType": "SG",
+        "ABHet": "-1", "ABHetMulti": "-1,-1", "ABHom": "1", "ABHomMulti": "-1,1",
+        "SBF": "0,%d" % n, "SBR": "0,0", "SBF1": "0,0", "SBF2": "0,%d" % n, "SBR1": "0,0", "SBR2": "0,0", "SB": "1", "SBAlt": "1",
+        "MQsquared": str(1600 * n), "MQ": "40", "MQSal": "0,%d" % (1600 * n), "MQalt": "40",
+        "SDal": "0,%d" % (4 * n), "SDalt": "4", "MMal": "0,0", "MMalt": "0", "CR": "0", "CRal": "0,0", "CRalt": "0",
+        "QD": "24", "QDalt": "24", "AAScore": "%.4g" % aa,
+        "LOGF": "%.4g" % _sigmoid(-29.28908 + 23.12909 + 40 * 0.01024 + 4.91178 + 24.0 * 0.23215 - 1.60844),  # SBAlt 1: the last bin; no heterozygous call: ABHet counts as 0.5
+    }
+    assert r["info"] == want
+
+
+def test_the_info_keys_of_clipped_reads_by_hand():
+    """three reads of the alternative allele, the last 26 bases of two of them unalignable: those count 2^-(12-3-4) = 5 (4 for ref/alt),
+    alt/alt 8 + 5 + 5, ref/alt 7 + 4 + 4 -> PL 54, 9, 0; CR is their number, CRal 26 x 1000 / 151 = 172 per read"""
+    r = _one_site_records(1, [(0, 1, 0, 60, 0, 0), (0, 1, 0, 60, 0, 0, 26), (0, 1, 0, 60, 0, 0, 26)], n_samples=1)
+    assert r["samples"] == [["1/1", "0,3", "0", "3", "9", "50,9,0"]] and r["qual"] == 54
+    cr = 344 / 3 / 10.0
+    aa = _sigmoid(-6.347426707 + 3.930106559 + 1.0 * -0.25233400 + 18.0 * 0.065221319 + cr * -0.01934834 + 60 * 0.055973424) * (1.0 - (cr - 2.5) / 40.0)
+    i = r["info"]
+    assert (i["CR"], i["CRal"], i["CRalt"], i["QD"], i["QDalt"], i["SeqDepth"], i["MaxAAS"]) == ("2", "0,344", "11.4667", "18", "18", "3", "3")
+    assert i["AAScore"] == "%.4g" % aa
+    assert i["LOGF"] == "%.4g" % _sigmoid(-29.28908 + 23.12909 + (2 / 3) * -10.22658 + 60 * 0.01024 + 4.91178 + 18.0 * 0.23215 - 1.60844)
