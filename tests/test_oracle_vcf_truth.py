@@ -315,3 +315,56 @@ def test_the_info_keys_of_clipped_reads_by_hand():
     assert (i["CR"], i["CRal"], i["CRalt"], i["QD"], i["QDalt"], i["SeqDepth"], i["MaxAAS"]) == ("2", "0,344", "11.4667", "18", "18", "3", "3")
     assert i["AAScore"] == "%.4g" % aa
     assert i["LOGF"] == "%.4g" % _sigmoid(-29.28908 + 23.12909 + (2 / 3) * -10.22658 + 60 * 0.01024 + 4.91178 + 18.0 * 0.23215 - 1.60844)
+
+
+def _two_base_site(alts, rows):
+    """a site whose reference allele is the two bases at 30601; rows = (sample, allele) per read"""
+    from graphtyper_amd import synth
+    ref = synth.make_reference(1200, seed=5)
+    s = synth.bases_to_str(ref)
+    rb, site = 30000, 600
+    assert s[site:site + 2] == "TT"
+    og = Oracle(s, [(rb + site, "TT", alts, None)], region_begin=rb).genotyper(2, 1)
+    s0 = site - 75
+    reads = []
+    for _, a in rows:
+        r = ref[s0:s0 + 151].copy()
+        if a:
+            r[75], r[76] = ("ACGT".index(c) for c in alts[a - 1])
+        reads.append(synth._CODE_OF_BASE[r])
+    n = len(rows)
+    og.push(reads, flags=np.zeros(n, np.uint16), mapq=np.full(n, 60, np.uint8), score_diff=np.zeros(n, np.uint8), pos=np.full(n, s0 + rb, np.int64),
+            sample=np.array([r[0] for r in rows], np.int32), rg=np.zeros(n, np.int32))
+    og.finish()
+    return _parse(og.vcf_records("chrT", ["A", "B"]))[1], _parse(og.vcf_records_final("chrT", ["A", "B"], s, rb + 1))[1]
+
+
+def test_a_site_of_two_bases_is_taken_apart_by_hand():
+    """break_down_variant / break_multi_snps (variant.cpp:1652-1713, :1996-2111).  TT -> AA, TA; A: 2 x TT + 2 x AA, B: 3 x TA.
+    Genotypes 0/0 0/1 1/1 0/2 1/2 2/2 -- A: 16 28 16 14 14 0 -> PL 36 0 36 42 42 84; B: 0 0 0 21 21 24 -> 72 72 72 9 9 0.
+    First base: T, A, T -> alleles T, A with the third allele counted as the reference; second base: T, A, A.  A new genotype gets
+    the smallest PL of the old ones that become it, a new allele the reads of the old ones"""
+    rows = [(0, 0), (0, 0), (0, 1), (0, 1), (1, 2), (1, 2), (1, 2)]
+    whole, final = _two_base_site(["AA", "TA"], rows)
+    assert [(r["pos"], r["ref"], r["alts"], r["qual"]) for r in whole] == [(30601, "TT", ["AA", "TA"], 36 + 72)]
+    assert whole[0]["samples"] == [["0/1", "2,2,0", "0", "4", "35", "35,0,35,40,40,99"], ["2/2", "0,0,3", "0", "3", "9", "75,75,75,9,9,0"]]
+    assert [(r["pos"], r["ref"], r["alts"], r["qual"], r["id"]) for r in final] == [(30601, "T", ["A"], 36, "chrT:30601:SG"), (30602, "T", ["A"], 36 + 72, "chrT:30602:SG")]
+    first, second = final
+    assert first["samples"] == [["0/1", "2,2", "0", "4", "35", "35,0,35"], ["0/0", "3,0", "0", "3", "9", "0,9,75"]]        # B: min(72, 9, 0), min(72, 9), 72
+    assert second["samples"] == [["0/1", "2,2", "0", "4", "35", "35,0,35"], ["1/1", "0,3", "0", "3", "9", "75,9,0"]]
+    keys = ("AC", "AN", "MaxAAS", "SBF", "MQSal", "NHomRef", "NHet", "NHomAlt", "SeqDepth", "ABHomMulti", "QD")
+    assert [first["info"][k] for k in keys] == ["1", "4", "2", "5,2", "18000,7200", "1", "1", "0", "7", "1,-1", "18"]       # QD: A alone, 36 / 2
+    assert [second["info"][k] for k in keys] == ["3", "4", "3", "2,5", "7200,18000", "0", "1", "1", "7", "-1,1", "21.6"]   # (36 + 72) / (2 + 3)
+
+
+def test_a_site_of_two_bases_whose_alleles_start_alike_by_hand():
+    """TT -> TA, TC: nothing differs at the first base, the second one has three alleles and the calls stay as they are"""
+    rows = [(0, 0), (0, 0), (0, 1), (0, 1), (1, 2), (1, 2), (1, 2)]
+    whole, final = _two_base_site(["TA", "TC"], rows)
+    assert [(r["pos"], r["ref"], r["alts"]) for r in whole] == [(30601, "TT", ["TA", "TC"])]
+    assert [(r["pos"], r["ref"], r["alts"], r["qual"]) for r in final] == [(30602, "T", ["A", "C"], 36 + 72)]
+    assert final[0]["samples"] == whole[0]["samples"] == [["0/1", "2,2,0", "0", "4", "35", "35,0,35,40,40,99"], ["2/2", "0,0,3", "0", "3", "9", "75,75,75,9,9,0"]]
+    # an allele nobody is called with is left out: without B's reads the third allele goes, and its PL with it
+    whole, final = _two_base_site(["TA", "TC"], rows[:4])
+    assert whole[0]["alts"] == ["TA", "TC"] and whole[0]["samples"][0] == ["0/1", "2,2,0", "0", "4", "35", "35,0,35,40,40,99"]
+    assert [(r["pos"], r["ref"], r["alts"]) for r in final] == [(30602, "T", ["A"])] and final[0]["samples"][0] == ["0/1", "2,2", "0", "4", "35", "35,0,35"]
