@@ -63,7 +63,9 @@ def mutants_of(path_rel):
     for a, b in spans:
         for ln in range(a, b):
             raw = lines[ln]
-            m = re.match(r"^\s*(?:inline |static |template.*|)[A-Za-z_:<>,&\* ]*?([A-Za-z_][A-Za-z_0-9:]*)\(.*\)\s*(?:const)?\s*(?://.*)?$", raw)
+            m = re.match(r"^\s*(?:inline |static |template.*|)[A-Za-z_0-9:<>,&\* ]*?([A-Za-z_][A-Za-z_0-9:]*)\(.*\)\s*(?:const)?\s*(?://.*)?$", raw)
+            if not m:  # a signature that goes on in the next line
+                m = re.match(r"^(?:inline |static )[A-Za-z_0-9:<>,&\* ]*?([A-Za-z_][A-Za-z_0-9:]*)\([^()]*,\s*$", raw)
             if m and not raw.strip().startswith(("if", "for", "while", "return", "else", "switch")) and ";" not in strip_comment(raw):
                 func = m.group(1)
             code = strip_comment(raw)
@@ -121,11 +123,15 @@ def main():
     ap.add_argument("--lines", default="", help="A-B: only the mutants on these lines (a look at one function)")
     ap.add_argument("--merge", action="store_true", help="put this run's results into audit_auto.json in place of the same mutants' old ones")
     ap.add_argument("--list", action="store_true")
+    ap.add_argument("--ids", default="", help="a file with mutant ids, one per line: only those")
     a = ap.parse_args()
     mutants = [m for f in a.file for m in mutants_of(f)][::a.every]
     if a.lines:
         lo, hi = (int(x) for x in a.lines.split("-"))
         mutants = [m for m in mutants if lo <= m["line"] <= hi]
+    if a.ids:
+        wanted = set(open(a.ids).read().split())
+        mutants = [m for m in mutants if m["id"] in wanted]
     if a.limit:
         mutants = mutants[:a.limit]
     if a.list:
@@ -172,7 +178,7 @@ def main():
         json.dump(full, open(os.path.join(HERE, "audit_auto.json"), "w"), indent=1)
         open(os.path.join(HERE, "audit_auto.json"), "a").write("\n")
         print("merged into audit_auto.json: %d killed, %d survived" % (full["killed"], full["survived"]))
-    name = "audit_auto.json" if a.every == 1 and not a.limit and not a.lines and len(a.file) == 3 else "audit_auto_partial.json"
+    name = "audit_auto.json" if a.every == 1 and not a.limit and not a.lines and not a.ids and len(a.file) == 3 else "audit_auto_partial.json"
     if a.merge:
         name = "audit_auto_partial.json"
     json.dump(out, open(os.path.join(HERE, name), "w"), indent=1)

@@ -1043,3 +1043,24 @@ def test_which_orientations_of_a_read_are_looked_for():
     # 63 bases are aligned (two k-mers that share a base), 62 are not
     assert o.align([code(ref[570:633])]) == [(dict(longest=63, paths=[dict(start=rb + 571, end=rb + 633, rs=0, re=62, mm=0, vars=[(rb + 601, (0,))])]), nothing)]
     assert o.align([code(ref[570:632])]) == [(nothing, nothing)]
+
+
+def test_paths_elsewhere_go_when_the_read_matches_the_reference_by_hand():
+    """remove_non_ref_paths_when_read_matches_ref (genotype_paths.cpp:460-474) with all_paths_unique (:219-231): paths are "unique"
+    unless one of them differs from the first in BOTH its start and its end; when they are not and one of them holds reference alleles
+    only, the others go"""
+    s, other, ins, o = _tiny()
+    NON_REF = 6
+    ref_path, alt_path = (1003, 1040, 0, 37, 0, [(1011, 0b01)]), (1003, 1041, 0, 37, 0, [(1011, 0b10)])
+    assert _paths_op(o, NON_REF, [ref_path, alt_path], read_length=38)[0] == [ref_path, alt_path]            # one start
+    moved = (1002, 1040, 0, 37, 0, [(1011, 0b10)])
+    assert _paths_op(o, NON_REF, [ref_path, moved], read_length=38)[0] == [ref_path, moved]                  # one end
+    far = (1002, 1041, 0, 37, 0, [(1011, 0b10)])
+    assert _paths_op(o, NON_REF, [ref_path, far], read_length=38)[0] == [ref_path]
+    assert _paths_op(o, NON_REF, [far, ref_path], read_length=38)[0] == [ref_path]
+    assert _paths_op(o, NON_REF, [alt_path, far], read_length=38)[0] == [alt_path, far]                      # no path of the reference
+    either = (1002, 1042, 0, 37, 0, [(1011, 0b11)])
+    assert _paths_op(o, NON_REF, [alt_path, either], read_length=38)[0] == [either]                          # (a set with the reference allele counts)
+    # positions inside the insertion at 1031 count as the site itself
+    inside, at_site = (SPECIAL + 1, 1050, 0, 20, 0, [(1031, 0b10)]), (1031, 1049, 0, 20, 0, [(1031, 0b01)])
+    assert _paths_op(o, NON_REF, [inside, at_site], read_length=21)[0] == [inside, at_site]
