@@ -186,7 +186,7 @@ def test_a_40x_sample_is_called_as_it_was_simulated():
 # A read of 151 bases without mismatch adds 2^-(12-4) to the genotypes that hold its allele twice, one less to those that hold it once
 # (haplotype.cpp:462-585): with r reference and a alternative reads ref/ref = 8 r, ref/alt = 7 (r + a), alt/alt = 8 a, and the phred
 # value of a genotype is 3.0103 x (the best - its own), rounded, 255 at most.
-def _one_site_records(n_alts, rows, n_samples=3):
+def _one_site_records(n_alts, rows, n_samples=3, final=False):
     import numpy as np
     from graphtyper_amd import synth
     from oracle_lib import Oracle
@@ -211,6 +211,8 @@ def _one_site_records(n_alts, rows, n_samples=3):
     og.finish()
     _, records = _parse(og.vcf_records("chrT", ["A", "B", "C"][:n_samples]))
     assert len(records) == 1
+    if final:
+        return records[0], _parse(og.vcf_records_final("chrT", ["A", "B", "C"][:n_samples], synth.bases_to_str(ref), rb + 1))[1]
     return records[0]
 
 
@@ -368,3 +370,18 @@ def test_a_site_of_two_bases_whose_alleles_start_alike_by_hand():
     whole, final = _two_base_site(["TA", "TC"], rows[:4])
     assert whole[0]["alts"] == ["TA", "TC"] and whole[0]["samples"][0] == ["0/1", "2,2,0", "0", "4", "35", "35,0,35,40,40,99"]
     assert [(r["pos"], r["ref"], r["alts"]) for r in final] == [(30602, "T", ["A"])] and final[0]["samples"][0] == ["0/1", "2,2", "0", "4", "35", "35,0,35"]
+
+
+def test_a_site_whose_allele_no_sample_has_two_reads_of_is_not_in_the_final_file():
+    """variant.cpp:1036-1063 with vcf_operations.cpp:480-732: an alternative allele is "good" when some sample has two reads of it (and
+    its QD is 1 or more); a record without a good one is left out of the file genotype() writes"""
+    one, final = _one_site_records(1, [(0, 1, 0, 60, 0, 0)], n_samples=1, final=True)
+    assert one["info"]["MaxAAS"] == "1" and final == []
+    two, final = _one_site_records(1, [(0, 1, 0, 60, 0, 0)] * 2, n_samples=1, final=True)
+    assert two["info"]["MaxAAS"] == "2" and [(r["pos"], r["samples"]) for r in final] == [(30601, two["samples"])]
+    # one read in each of two samples is not two reads in one
+    spread, final = _one_site_records(1, [(0, 1, 0, 60, 0, 0), (1, 1, 0, 60, 0, 0)], n_samples=2, final=True)
+    assert spread["info"]["MaxAAS"] == "1" and spread["info"]["AC"] == "4" and final == []
+    # of two alternative alleles one good one keeps the record, with both
+    both, final = _one_site_records(2, [(0, 1, 0, 60, 0, 0)] * 2 + [(0, 2, 0, 60, 0, 0)], n_samples=1, final=True)
+    assert both["info"]["MaxAAS"] == "2,1" and [r["alts"] for r in final] == [both["alts"]]
