@@ -80,6 +80,13 @@ def test_coverage_model_hand_worked_duplications_sizes_and_points():
     assert coverage_call(sv_line("DUP", 5001, 2000), flat(60, 30, 2000)) == [0, 45, 255, 202, 0]
     # fewer reads inside than outside: the mean for the reference, 0
     assert coverage_call(sv_line("DUP", 5001, 2000), flat(20, 30, 2000)) == [25, 0, 0, 112, 255]
+    # one read more inside than outside (11 and 10): mean 10.5, a tenth of the outside -> 0.9 x 10.5 = 9.45 -> 9 and 10.5 - 9 -> 1;
+    # 12 / 30 / 108 -> 0, 18, 96 -> x 3/2
+    assert coverage_call(sv_line("DUP", 5001, 2000), flat(11, 10, 2000)) == [9, 1, 0, 27, 144]
+    # no read beside the duplication and 8 inside: the reference divides by the outside's median here; what its machines make of that
+    # is 0 and the mean (4): 48 / 12 / 0 -> x 3/2
+    assert coverage_call(sv_line("DUP", 5001, 2000), flat(8, 0, 2000)) == [0, 4, 72, 18, 0]
+    assert coverage_call(sv_line("DUP", 5001, 2000), flat(8, 1, 2000)) == [0, 4, 72, 18, 0]   # (one read outside: (1 - 7 / 1) x 4.5 is negative -> 0, and 4.5 -> 4)
     # the scaling by size: x 2/3 up to 100 bases, nothing up to 1 000, x 3/2 above (a heterozygous deletion: 90, 0, 90 unscaled)
     assert coverage_call(sv_line("DEL", 5001, 100), flat(15, 30, 100)) == [15, 15, 60, 0, 60]
     assert coverage_call(sv_line("DEL", 5001, 101), flat(15, 30, 101)) == [15, 15, 90, 0, 90]
