@@ -12,6 +12,7 @@
 #include "gtx_ctx.hpp"
 
 #include <algorithm>
+#include <charconv>
 #include <zlib.h>
 #include <cmath>
 #include <cstdio>
@@ -57,11 +58,57 @@ void put_u(std::string & s, uint64_t v) // (most of a VCF line is small integers
   s.append(b + n, static_cast<size_t>(24 - n));
 }
 
-void put_g(std::string & s, double v, int precision) // ostream << double at that precision, default float format
+// ostream << double at that precision, default float format (= printf's %.*g).  Most of what a record holds is a whole number
+// below 10^precision, which that format writes as its digits; the rest goes through std::to_chars, which is specified to give
+// printf's characters (compared with snprintf over 1.8 x 10^8 values -- every a / b up to 3 000, random bit patterns, the
+// neighbours of the places where the notation changes -- when it replaced it: a record's text was a third snprintf)
+void put_g(std::string & s, double v, int precision)
 {
-  char b[40];
-  int const n = std::snprintf(b, sizeof(b), "%.*g", precision, v);
-  s.append(b, static_cast<size_t>(n));
+  static double const below[] = {1, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9};
+  if (!std::isfinite(v) || precision < 1 || precision > 9)
+  {
+    char b[40];
+    int const n = std::snprintf(b, sizeof(b), "%.*g", precision, v);
+    s.append(b, static_cast<size_t>(n));
+    return;
+  }
+  if (!std::signbit(v) && v < below[precision])
+  {
+    uint64_t const u = static_cast<uint64_t>(v);
+    if (static_cast<double>(u) == v)
+    {
+      put_u(s, u);
+      return;
+    }
+  }
+  char b[48];
+  auto const r = std::to_chars(b, b + sizeof(b), v, std::chars_format::general, precision);
+  s.append(b, static_cast<size_t>(r.ptr - b));
+}
+
+// digits behind p; returns the place behind them (the sample columns of a record are written into room made beforehand)
+inline char * put_u_at(char * p, uint32_t v)
+{
+  if (v < 10)
+  {
+    *p++ = static_cast<char>('0' + v);
+    return p;
+  }
+  if (v < 100)
+  {
+    *p++ = static_cast<char>('0' + v / 10);
+    *p++ = static_cast<char>('0' + v % 10);
+    return p;
+  }
+  char b[12];
+  int n = 12;
+  do
+  {
+    b[--n] = static_cast<char>('0' + v % 10);
+    v /= 10;
+  } while (v != 0);
+  std::memcpy(p, b + n, static_cast<size_t>(12 - n));
+  return p + (12 - n);
 }
 
 struct AlleleStats // VarStatsPerAllele + ReadStrand (var_stats.hpp:15-33, read_strand.hpp)
@@ -165,9 +212,10 @@ double model_aa_score(double abhom, double sb, double mm, long sd, double qd, do
   return 1.0 / (1.0 + std::exp(-pwr));
 }
 
-struct Info
+struct Info // the reference's std::map<std::string, std::string> of a record: keys (string literals here) in the order they are made
 {
-  std::vector<std::pair<std::string, std::string>> kv;
+  std::vector<std::pair<char const *, std::string>> kv;
+  Info() { kv.reserve(48); }
   std::string & operator[](char const * k)
   {
     kv.emplace_back(k, std::string());
@@ -176,9 +224,32 @@ struct Info
   std::string const * find(char const * k) const
   {
     for (auto const & e : kv)
-      if (e.first == k)
+      if (std::strcmp(e.first, k) == 0)
         return &e.second;
     return nullptr;
+  }
+  // The places of kv in the map's order (std::string's: bytes as unsigned).  One record after the other makes the same keys in the
+  // same order, so the order found for the record before is checked (the literals' addresses) and used again; sorting the pairs
+  // themselves was a fifth of a record's time.
+  std::vector<uint16_t> const & sorted() const
+  {
+    static thread_local std::vector<char const *> keys;
+    static thread_local std::vector<uint16_t> order;
+    bool same = keys.size() == kv.size();
+    for (size_t i = 0; same && i < kv.size(); ++i)
+      same = keys[i] == kv[i].first;
+    if (!same)
+    {
+      keys.resize(kv.size());
+      order.resize(kv.size());
+      for (size_t i = 0; i < kv.size(); ++i)
+      {
+        keys[i] = kv[i].first;
+        order[i] = static_cast<uint16_t>(i);
+      }
+      std::stable_sort(order.begin(), order.end(), [&](uint16_t a, uint16_t b) { return std::strcmp(keys[a], keys[b]) < 0; });
+    }
+    return order;
   }
 };
 
@@ -1644,7 +1715,7 @@ int emit_site(gtx_vcf_request const * rq, Site const & st, bool region_filter, s
       double const gt_yield = static_cast<double>(n_genotyped) / static_cast<double>(ns);
       put_g(info["LOGF"], model_logf(ab_hom, cr_by_seqdepth, static_cast<double>(mq), pass_ratio, gt_yield, qd, abhet_bin, sbalt_bin), 4);
     }
-    std::sort(info.kv.begin(), info.kv.end(), [](auto const & a, auto const & b) { return a.first < b.first; });
+    std::vector<uint16_t> const & info_order = info.sorted();
     // ---- the record (Vcf::write_record)
     text += contig;
     text += '\t';
@@ -1711,49 +1782,64 @@ int emit_site(gtx_vcf_request const * rq, Site const & st, bool region_filter, s
         text += "PASS";
     }
     text += '\t';
-    for (size_t i = 0; i < info.kv.size(); ++i)
+    for (size_t i = 0; i < info_order.size(); ++i)
     {
+      auto const & e = info.kv[info_order[i]];
       if (i)
         text += ';';
-      text += info.kv[i].first;
-      if (!info.kv[i].second.empty())
+      text += e.first;
+      if (!e.second.empty())
       {
         text += '=';
-        text += info.kv[i].second;
+        text += e.second;
       }
     }
     if (ns)
     {
       text += "\tGT:AD:MD:DP:GQ:PL";
+      // (the columns are most of a record's bytes: written into room made for the longest they can be -- a tab, two alleles and a
+      //  slash, a depth per allele, three numbers, a value per genotype, each behind a separator -- and cut to what was written)
+      size_t const room = 64 + 11 * static_cast<size_t>(cnum) + 4 * static_cast<size_t>(n_tri);
+      size_t const at = text.size();
+      text.resize(at + room * ns + 1);
+      char * p = &text[at];
       for (uint32_t s = 0; s < ns; ++s)
       {
         CallView const & cv = calls[s];
-        text += '\t';
+        *p++ = '\t';
         if (!cv.any_pl())
-          text += "./.";
+        {
+          *p++ = '.';
+          *p++ = '/';
+          *p++ = '.';
+        }
         else
         {
-          put_u(text, cv.c->gt_first);
-          text += '/';
-          put_u(text, cv.c->gt_second);
+          p = put_u_at(p, cv.c->gt_first);
+          *p++ = '/';
+          p = put_u_at(p, cv.c->gt_second);
         }
+        uint32_t unique = 0;
         for (uint32_t a = 0; a < cnum; ++a)
         {
-          text += a ? ',' : ':';
-          put_u(text, cv.coverage(a));
+          *p++ = a ? ',' : ':';
+          uint32_t const d = cv.coverage(a);
+          unique += d;
+          p = put_u_at(p, d);
         }
-        text += ':';
-        put_u(text, cv.c->ambiguous_depth);
-        text += ':';
-        put_u(text, cv.unique_depth() + cv.c->ambiguous_depth);
-        text += ':';
-        put_u(text, std::min<uint16_t>(99, BINNED.v[cv.c->gq]));
+        *p++ = ':';
+        p = put_u_at(p, cv.c->ambiguous_depth);
+        *p++ = ':';
+        p = put_u_at(p, unique + cv.c->ambiguous_depth);
+        *p++ = ':';
+        p = put_u_at(p, std::min<uint16_t>(99, BINNED.v[cv.c->gq]));
         for (uint32_t i = 0; i < n_tri; ++i)
         {
-          text += i ? ',' : ':';
-          put_u(text, BINNED.v[cv.phred[i]]);
+          *p++ = i ? ',' : ':';
+          p = put_u_at(p, BINNED.v[cv.phred[i]]);
         }
       }
+      text.resize(static_cast<size_t>(p - text.data()));
     }
     text += '\n';
   }
