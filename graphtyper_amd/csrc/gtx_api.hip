@@ -1640,7 +1640,7 @@ int ctx_upload(gtx_ctx & c, int device)
       c.dev_allocs.push_back(p);
       c.d_big_records = static_cast<uint32_t *>(p);
     }
-    if (ok && hipHostMalloc(reinterpret_cast<void **>(&c.h_big_seen), 64) == hipSuccess)
+    if (ok && (c.h_big_seen = static_cast<uint32_t *>(gtx::pinned_slot_get())) != nullptr)
       *c.h_big_seen = 0xFFFFFFFFu;
     else
       c.h_big_seen = nullptr; // (without it the pass is launched whole)
@@ -1688,7 +1688,7 @@ void ctx_release_device(gtx_ctx & c)
   }
   if (c.h_big_seen)
   {
-    (void)hipHostFree(c.h_big_seen);
+    gtx::pinned_slot_put(c.h_big_seen);
     c.h_big_seen = nullptr;
   }
   for (auto & s : c.pool)

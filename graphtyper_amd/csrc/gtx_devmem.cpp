@@ -185,6 +185,36 @@ void dev_cache_release()
   for (void * p : all)
     (void)hipFree(p);
 }
+namespace
+{
+std::mutex g_pinned_m;
+std::vector<void *> g_pinned_free;
+} // namespace
+
+void * pinned_slot_get()
+{
+  std::lock_guard<std::mutex> lock(g_pinned_m);
+  if (g_pinned_free.empty())
+  {
+    size_t constexpr PAGE = 4096, SLOT = 64;
+    void * page = nullptr;
+    if (hipHostMalloc(&page, PAGE) != hipSuccess || !page)
+      return nullptr;
+    for (size_t k = 0; k < PAGE / SLOT; ++k)
+      g_pinned_free.push_back(static_cast<char *>(page) + k * SLOT);
+  }
+  void * p = g_pinned_free.back();
+  g_pinned_free.pop_back();
+  return p;
+}
+
+void pinned_slot_put(void * p)
+{
+  if (!p)
+    return;
+  std::lock_guard<std::mutex> lock(g_pinned_m);
+  g_pinned_free.push_back(p);
+}
 } // namespace gtx
 
 extern "C" void gtx_device_cache_release(void) { gtx::dev_cache_release(); }

@@ -42,4 +42,9 @@ struct BuildStreamScope
   BuildStreamScope & operator=(BuildStreamScope const &) = delete;
 };
 void dev_cache_release();                       // hipFree everything the cache holds
+// A 64-byte slot of pinned host memory (a word the device writes and a later call reads, per context): cut from pages that are
+// pinned once and kept for the life of the process -- hipHostMalloc / hipHostFree per context were most of what making and
+// destroying a small region's context cost its host thread, and the free waits for the device.  nullptr when nothing can be pinned.
+void * pinned_slot_get();
+void pinned_slot_put(void * p);
 } // namespace gtx
