@@ -14,6 +14,8 @@
 #include <string>
 
 #include "gtx_ctx.hpp"
+
+#include <map>
 #include "gtx_devmem.hpp"
 #include "wave_hip.hpp"
 #include "align_core.hpp"
@@ -1459,6 +1461,45 @@ __global__ __launch_bounds__(256) void gtx_pos_tables_kernel(GraphView g, uint32
   pos_node[i] = inside ? lo : INVALID;
 }
 
+struct DeviceFacts
+{
+  bool have_prop = false;
+  int n_cu = 0;
+  uint32_t wall_clock_khz = 100000u;
+  int align_blocks_per_cu = 0, express_blocks_per_cu = 0, express4_blocks_per_cu = 0, express4_wide_blocks_per_cu = 0, score_blocks_per_cu = 0;
+};
+
+// asked of the runtime the first time a context is made on the device (which is current: ctx_upload has set it)
+static DeviceFacts const & device_facts(int device)
+{
+  static std::mutex m;
+  static std::map<int, DeviceFacts> known;
+  std::lock_guard<std::mutex> lock(m);
+  auto it = known.find(device);
+  if (it != known.end())
+    return it->second;
+  DeviceFacts f;
+  hipDeviceProp_t prop;
+  f.have_prop = hipGetDeviceProperties(&prop, device) == hipSuccess;
+  if (f.have_prop)
+    f.n_cu = prop.multiProcessorCount;
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0)
+    f.wall_clock_khz = static_cast<uint32_t>(khz);
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_kernel, 64, 0) == hipSuccess && per_cu > 0)
+    f.align_blocks_per_cu = per_cu;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express_kernel, 64, 0) == hipSuccess && per_cu > 0)
+    f.express_blocks_per_cu = per_cu;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express4_kernel, 64, 0) == hipSuccess && per_cu > 0)
+    f.express4_blocks_per_cu = per_cu;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express4_wide_kernel, 64, 0) == hipSuccess && per_cu > 0)
+    f.express4_wide_blocks_per_cu = per_cu;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_score_kernel, GTX_SCORE_THREADS, 0) == hipSuccess && per_cu > 0)
+    f.score_blocks_per_cu = per_cu;
+  return known.emplace(device, f).first->second;
+}
+
 int ctx_upload(gtx_ctx & c, int device)
 {
   int n_dev = 0;
@@ -1589,15 +1630,15 @@ int ctx_upload(gtx_ctx & c, int device)
     ok = hip_ok(gtx::dev_zero(ef, sizeof(uint32_t)), "error flag");
   }
   lap("counters");
-  hipDeviceProp_t prop;
-  bool const have_prop = hipGetDeviceProperties(&prop, device) == hipSuccess;
+  // (what the runtime says about the device and the kernels does not change between contexts: asked once per device -- these
+  //  calls take the runtime's lock, which the builder threads of gtx_regions_run share with every launch)
+  DeviceFacts const & facts = device_facts(device);
+  struct { int multiProcessorCount; } prop{facts.n_cu};
+  bool const have_prop = facts.have_prop;
   lap("device properties");
   if (have_prop)
     c.n_cu = prop.multiProcessorCount;
-  {
-    int khz = 0;
-    c.wall_clock_khz = hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0 ? static_cast<uint32_t>(khz) : 100000u;
-  }
+  c.wall_clock_khz = facts.wall_clock_khz;
   if (ok && !c.params.no_second_pass)
   {
     // HBM-table pass: one workspace per workgroup (one workgroup per CU is plenty for the few queued reads), arena
@@ -1656,18 +1697,17 @@ int ctx_upload(gtx_ctx & c, int device)
     return GTX_ERR_HIP;
   lap("second-pass arena");
   c.dev_graph = v;
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_kernel, 64, 0) == hipSuccess && per_cu > 0)
-    c.align_blocks_per_cu = per_cu;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express_kernel, 64, 0) == hipSuccess && per_cu > 0)
-    c.express_blocks_per_cu = per_cu;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express4_kernel, 64, 0) == hipSuccess && per_cu > 0)
-    c.express4_blocks_per_cu = per_cu;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_align_express4_wide_kernel, 64, 0) == hipSuccess && per_cu > 0)
-    c.express4_wide_blocks_per_cu = per_cu;
+  if (facts.align_blocks_per_cu > 0)
+    c.align_blocks_per_cu = facts.align_blocks_per_cu;
+  if (facts.express_blocks_per_cu > 0)
+    c.express_blocks_per_cu = facts.express_blocks_per_cu;
+  if (facts.express4_blocks_per_cu > 0)
+    c.express4_blocks_per_cu = facts.express4_blocks_per_cu;
+  if (facts.express4_wide_blocks_per_cu > 0)
+    c.express4_wide_blocks_per_cu = facts.express4_wide_blocks_per_cu;
   // (the scoring grid is what is resident, no more: 1.28 ms per cfg2 step against 1.32 with 8 workgroups per CU)
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gtx_score_kernel, GTX_SCORE_THREADS, 0) == hipSuccess && per_cu > 0)
-    c.score_blocks_per_cu = per_cu;
+  if (facts.score_blocks_per_cu > 0)
+    c.score_blocks_per_cu = facts.score_blocks_per_cu;
   lap("occupancy queries");
   // the first scratch now, so that the first call does not pay for it
   auto s = scratch_new(c);
