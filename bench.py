@@ -1246,7 +1246,7 @@ def extra_regions(args, torch, gtx, synth, device, ref, n_regions=20, region_len
     wall_ovl = min(wall_two, wall_three)  # (what is reported is the fastest of the overlapped forms)
     in_lib = {}
     texts4 = texts
-    shapes = [(4, 2, 3), (6, 2, 4), (8, 3, 4), (2, 1, 1)]
+    shapes = [(4, 2, 3), (6, 2, 4), (8, 3, 4), (10, 3, 2), (2, 1, 1)]  # (builders, device threads, text threads; the text stage is the cheap one since round 5)
     if os.environ.get("GTX_REGIONS_THREADS"):
         shapes = [tuple(int(x) for x in os.environ["GTX_REGIONS_THREADS"].split(","))]
     for shape in shapes:
