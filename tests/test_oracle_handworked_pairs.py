@@ -1064,3 +1064,54 @@ def test_paths_elsewhere_go_when_the_read_matches_the_reference_by_hand():
     # positions inside the insertion at 1031 count as the site itself
     inside, at_site = (SPECIAL + 1, 1050, 0, 20, 0, [(1031, 0b10)]), (1031, 1049, 0, 20, 0, [(1031, 0b01)])
     assert _paths_op(o, NON_REF, [inside, at_site], read_length=21)[0] == [inside, at_site]
+
+
+@pytest.mark.parametrize("flag,counted", [(0, True), (4, True), (0x10, True), (0x100, False), (0x200, False), (0x400, False), (0x800, False), (0x404, False)])
+def test_which_records_are_let_in_by_their_flags(flag, counted):
+    """Genotyper::push (hts_parallel_reader.cpp:226-243 with Options::sam_flag_filter = 0xF00): secondary, failed, duplicate and
+    supplementary records are left out; what is_good_read says (here: an unmapped record is not good) matters on SV graphs only"""
+    from graphtyper_amd import synth
+    ref = synth.make_reference(1200, seed=5)
+    rb, site = 30000, 600
+    og = Oracle(synth.bases_to_str(ref), [(rb + site, "ACGT"[ref[site]], ["ACGT"[(ref[site] + 1) % 4]], None)], region_begin=rb).genotyper(1, 1)
+    s0 = site - 70
+    r = ref[s0:s0 + 151].copy()
+    r[70] = (ref[site] + 1) % 4
+    og.push([synth._CODE_OF_BASE[r]], flags=np.array([flag], np.uint16), mapq=np.full(1, 60, np.uint8), score_diff=np.zeros(1, np.uint8), pos=np.array([s0 + rb], np.int64))
+    og.finish()
+    assert og.scores().tolist()[25:34] == ([8, 0, 0, 0, 0, 1, 0, 7, 8] if counted else [0] * 9)
+
+
+def test_255_is_as_far_as_the_small_depths_count():
+    """coverage_to_gts (haplotype.cpp:315-361 with :19-44): the depth of reads that fit several alleles is eight bits wide and stays
+    at 255; 256 reads with a base no allele has"""
+    from graphtyper_amd import synth
+    ref = synth.make_reference(1200, seed=5)
+    rb, site = 30000, 600
+    og = Oracle(synth.bases_to_str(ref), [(rb + site, "ACGT"[ref[site]], ["ACGT"[(ref[site] + 1) % 4]], None)], region_begin=rb).genotyper(1, 1)
+    s0 = site - 70
+    r = ref[s0:s0 + 151].copy()
+    r[70] = (ref[site] + 3) % 4
+    n = 256
+    og.push([synth._CODE_OF_BASE[r]] * n, flags=np.zeros(n, np.uint16), mapq=np.full(n, 60, np.uint8), score_diff=np.zeros(n, np.uint8), pos=np.full(n, s0 + rb, np.int64))
+    og.finish()
+    assert og.scores().tolist()[25:34] == [7 * n, 255, 0, 0, 0, 0, 7 * n, 7 * n, 7 * n]
+
+
+def test_a_read_that_sits_512_times_in_the_reference_is_not_aligned():
+    """find_genotype_paths_of_one_of_the_sequences (alignment.cpp:35-49): when none of a read's k-mers has fewer than 512 places
+    (MAX_UNIQUE_KMER_POSITIONS) the read is given up.  A reference of 511 / 512 copies of 125 bases and a read that is one copy"""
+    from graphtyper_amd import synth
+    unit = synth.make_reference(125, seed=77)
+    tail = synth.make_reference(400, seed=78)
+    for copies in (511, 512):
+        ref = np.concatenate([np.tile(unit, copies), tail])
+        rb = 0
+        p = 125 * copies + 200
+        o = Oracle(synth.bases_to_str(ref), [(rb + p, "ACGT"[ref[p]], ["ACGT"[(ref[p] + 1) % 4]], None)], region_begin=rb)
+        fwd, rev = o.align([synth._CODE_OF_BASE[unit]])[0]
+        assert rev["paths"] == []
+        if copies == 512:
+            assert fwd["paths"] == []
+        else:  # one path per copy, the four k-mers chained (bases 0 .. 124); more than 256 seeds: nothing is walked
+            assert sorted((q["start"], q["end"], q["rs"], q["re"], q["mm"]) for q in fwd["paths"]) == [(125 * k + 1, 125 * k + 125, 0, 124, 0) for k in range(511)]

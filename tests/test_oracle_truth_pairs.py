@@ -125,3 +125,25 @@ def test_one_pair_whose_mates_both_hold_the_site():
     assert s[25:] == [16, 0, 0, 2, 0, 2, 0, 14, 16, 0, 0]
     assert s[3:5] == [2 * 3600, 0] and s[5 + 10 + 6:5 + 20] == [1, 0, 0, 1]  # mate 1 forward, mate 2 reverse
 
+
+
+def test_a_proper_pair_with_the_reference_allele_is_no_alternative_proper_pair():
+    """coverage_to_gts (haplotype.cpp:315-361): alt_proper_pair_depth counts the reads of proper pairs that hold an ALTERNATIVE allele"""
+    ref = synth.make_reference(2400, seed=33)
+    rb = 90000
+    sites = [600, 1100]
+    recs = [(rb + p, "ACGT"[ref[p]], ["ACGT"[(ref[p] + 1) % 4]], None) for p in sites]
+    og = Oracle(synth.bases_to_str(ref), recs, region_begin=rb).genotyper(1, 1)
+    s1, s2 = 600 - 75, 1100 - 75
+    frag = s2 + READ_LEN - s1
+    reads = [synth._CODE_OF_BASE[ref[s1:s1 + READ_LEN]], synth._CODE_OF_BASE[ref[s2:s2 + READ_LEN]]]
+    og.push(reads, flags=np.array([PAIRED | PROPER | MATE_REVERSED | FIRST, PAIRED | PROPER | REVERSED | SECOND], np.uint16), tid=np.zeros(2, np.int32),
+            mtid=np.zeros(2, np.int32), pos=np.array([s1 + rb, s2 + rb], np.int64), isize=np.array([frag, -frag], np.int64),
+            mapq=np.array([60, 60], np.uint8), score_diff=np.zeros(2, np.uint8), name=np.array([7, 7], np.uint64), sample=np.zeros(2, np.int32),
+            rg=np.zeros(2, np.int32))
+    og.finish()
+    s = og.scores().tolist()
+    first = 25 + 9 + 5
+    assert len(s) == first + 25 + 9 + 2
+    for h in (s[:first], s[first:]):
+        assert h[25:34] == [8, 0, 0, 0, 1, 0, 8, 7, 0]
