@@ -829,3 +829,55 @@ def test_neighbour_flag_of_the_index_changes_nothing(monkeypatch):
     differ = a != c
     differ[external, 2:] = False
     assert not differ.any()
+
+
+def many_places_case(Backend):
+    """a read with 511 places in the reference is 511 paths (a record in the arena); with 512 places in every k-mer it is given up
+    (MAX_UNIQUE_KMER_POSITIONS, alignment.cpp:35-49) -- the boundary worked out by hand in tests/test_oracle_handworked_pairs.py"""
+    from graphtyper_amd import synth
+    unit, tail = synth.make_reference(125, seed=77), synth.make_reference(400, seed=78)
+    counts = []
+    for copies in (511, 512):
+        ref = np.concatenate([np.tile(unit, copies), tail])
+        p = 125 * copies + 200
+        recs = [(p, "ACGT"[ref[p]], ["ACGT"[(ref[p] + 1) % 4]], None)]
+        s = synth.bases_to_str(ref)
+        b = Backend(gtx.graph_from_records(s, recs, region_begin=0))
+        reads = [synth._CODE_OF_BASE[unit]] * 2 + [synth._CODE_OF_BASE[ref[p - 70:p + 81]]]
+        check_align(b, Oracle(s, recs, region_begin=0), reads)
+        seq, lens = harness.pack_ragged(reads)
+        rec = b.align(seq, harness.read_meta(lens, None, None, None, None, None))
+        got = gtx.parse_records(rec, len(reads), harness.REC_WORDS, b.ctx.hap_order, b.big_records()[0])
+        counts.append([len(g[0]["paths"]) for g in got])
+    return counts
+
+
+def test_a_read_with_511_and_with_512_places():
+    assert many_places_case(harness.EmuBackend) == [[511, 511, 1], [0, 0, 1]]
+
+
+def small_depths_case(Backend):
+    """256 reads that fit both alleles of one site (a base neither has) and 44 of its alternative allele: the eight-bit depth of
+    ambiguous reads stays at 255 (haplotype.cpp:19-44; by hand in tests/test_oracle_handworked_pairs.py); three more sites so that the
+    calls are not all alike.  Accumulators, calls, phase flags and the VCF text against the oracle's."""
+    from graphtyper_amd import synth
+    ref = synth.make_reference(3000, seed=5)
+    rb = 30000
+    recs = [(rb + p, "ACGT"[ref[p]], ["ACGT"[(ref[p] + 1) % 4]], None) for p in (600, 1200, 1700, 2200)]
+
+    def read(site, k):
+        r = ref[site - 70:site + 81].copy()
+        r[70] = (ref[site] + k) % 4
+        return site - 70, synth._CODE_OF_BASE[r]
+
+    rows = [read(600, 3)] * 256 + [read(600, 1)] * 44 + [read(1200, 0)] * 2 + [read(1200, 1)] + [read(1700, 1)] * 3 + [read(2200, 0)] + [read(2200, 1)] * 5
+    codes, pos = np.array([r[1] for r in rows]), np.array([r[0] + rb for r in rows])
+    rec = scenarios.stream_records(len(rows), pos, sample=np.zeros(len(rows), int))
+    s = synth.bases_to_str(ref)
+    run_stream(Backend(gtx.graph_from_records(s, recs, region_begin=rb)), Oracle(s, recs, region_begin=rb), codes, rec, n_samples=1)
+    first = run_stream.vcf_full.decode().split("\n")[1].split("\t")
+    return first[9]
+
+
+def test_the_small_depths_stop_at_255():
+    assert small_depths_case(harness.EmuBackend).split(":")[:4] == ["1/1", "0,44", "255", "299"]  # GT, AD, MD (ambiguous reads), DP
