@@ -2238,6 +2238,11 @@ GTX_DEV uint32_t hamming1_finish(IndexView const & ix, AlignWorkspace & ws, uint
     total += GTX_U(static_cast<uint32_t>(cand[a] >> 32)) & 0xFFFFFFu;
   if (total > ix.max_index_labels)
     return 0;
+  // (a list the reference keeps -- 75 labels or fewer -- that this pass' table does not hold: 0xFFFFFFFF, the caller sends the task
+  //  on.  Round 5: seven or eight SNP sites under one k-mer give its 96 neighbours 49 / 64 labels; they were written past the
+  //  table's 40 entries into what lies behind it in the workspace, and the task's record was nonsense without a status.)
+  if (total > cap_lbl(ws))
+    return 0xFFFFFFFFu;
   uint32_t done = 0;
   for (uint32_t a = 0; a < ncand; ++a)
   {
@@ -2923,6 +2928,11 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
           n_lbl = hamming1_from_cache<W>(ix, ws, i, q);
         else if (!use_halves || !hamming1_by_halves<W>(ix, ws, q, n_lbl))
           n_lbl = probe_list<W>(ix, ws, true, q, 96, status);
+        if (n_lbl == 0xFFFFFFFFu) // (hamming1_finish: more labels than the table holds)
+        {
+          n_lbl = 0;
+          status |= GTX_ST_LABEL_OVERFLOW;
+        }
         if (status)
           break;
       }

@@ -881,3 +881,39 @@ def small_depths_case(Backend):
 
 def test_the_small_depths_stop_at_255():
     assert small_depths_case(harness.EmuBackend).split(":")[:4] == ["1/1", "0,44", "255", "299"]  # GT, AD, MD (ambiguous reads), DP
+
+
+def rows_of_sites_case(Backend, n_reads=200):
+    """seven and eight SNP sites under one k-mer (every third / every second base, not merged into one site): the 96 neighbours of
+    such a k-mer hold 49 / 64 labels -- a list the reference keeps (75 or fewer) that the general pass' table of 40 does not hold.
+    Round 5: hamming1_finish wrote them past the table and the task's record was nonsense WITHOUT a status (20 % of the reads over
+    such a row); now the task goes on to the pass with the large tables.  Error-free reads and reads with up to six substitutions."""
+    from graphtyper_amd import synth
+    ref = synth.make_reference(4000, seed=21)
+    rb = 5000
+    s = synth.bases_to_str(ref)
+    rng = np.random.default_rng(3)
+    n = 0
+    for first, step, count in ((2000, 3, 7), (2000, 3, 8), (1000, 2, 8), (2000, 3, 9)):
+        sites = list(range(first, first + step * count, step))
+        recs = [(rb + p, "ACGT"[ref[p]], ["ACGT"[(ref[p] + 1) % 4]], None) for p in sites]
+        reads, pos = [], []
+        for i in range(n_reads):
+            s0 = sites[0] - int(rng.integers(0, 140))
+            r = ref[s0:s0 + 151].copy()
+            for p in sites:
+                if s0 <= p < s0 + 151 and rng.random() < 0.5:
+                    r[p - s0] = (ref[p] + 1) % 4
+            if i % 3 == 2:
+                for _ in range(int(rng.integers(1, 7))):
+                    q = int(rng.integers(0, 151))
+                    r[q] = (r[q] + int(rng.integers(1, 4))) % 4
+            reads.append(synth._CODE_OF_BASE[r])
+            pos.append(s0 + rb)
+        check_align(Backend(gtx.graph_from_records(s, recs, region_begin=rb)), Oracle(s, recs, region_begin=rb), reads, pos=np.array(pos))
+        n += len(reads)
+    return n
+
+
+def test_rows_of_seven_and_eight_snp_sites():
+    assert rows_of_sites_case(harness.EmuBackend) == 800
