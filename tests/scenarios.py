@@ -71,6 +71,15 @@ def synthetic_case(kind, n_ref=40000, n_reads=300, seed=0, region_begin=1000000,
         recs = synth.make_cfg3_records(ref, 100, seed=seed + 14, region_begin=region_begin)
     elif kind == "snp7":  # > 8 variant sites per read and wide graph walks: second-pass territory
         recs = synth.make_snp_records(ref, 7, seed=seed + 9, region_begin=region_begin)
+    elif kind == "rows":  # rows of 6..10 SNP sites every second, third or fourth base, a row every 300 bases: seven or eight
+        # separate sites under one k-mer give its neighbours 49 / 64 labels (round 5: more than the general pass' table held)
+        rng = np.random.default_rng(seed + 21)
+        recs = []
+        for at in range(200, n_ref - 200, 300):
+            step, count = int(rng.integers(2, 5)), int(rng.integers(6, 11))
+            for p in range(at, at + step * count, step):
+                alts = ["ACGT"[(ref[p] + k) % 4] for k in range(1, int(rng.integers(1, 3)) + 1)]
+                recs.append((region_begin + p, "ACGT"[ref[p]], alts, None))
     elif kind == "repeat":
         # tandem repeat: 24 copies (16 of them diverged by 1.5 %) of a 180 bp unit in the middle of the region -> a read from it seeds at
         # dozens of places, results have more paths than a record slot holds

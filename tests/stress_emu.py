@@ -25,7 +25,7 @@ from test_emu_parity import check_align, run_stream  # noqa: E402
 def align_seed(seed):
     rng = np.random.default_rng(seed)
     n = 0
-    for kind in ["snp1k", "snp25", "indel", "cluster", "snp100", "snp7", "cfg3", "satellite", "repeat", "neardup"]:
+    for kind in ["snp1k", "snp25", "indel", "cluster", "snp100", "snp7", "rows", "cfg3", "satellite", "repeat", "neardup"]:
         err = float(rng.choice([0.0, 0.005, 0.03]))
         n_rate = float(rng.choice([0.0, 0.001, 0.01]))
         read_len = int(rng.choice([100, 125, 150, 151, 187, 200, 250, 256]))  # (> 160: the eight-k-mer build of pass 0)
