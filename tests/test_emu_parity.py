@@ -917,3 +917,19 @@ def rows_of_sites_case(Backend, n_reads=200):
 
 def test_rows_of_seven_and_eight_snp_sites():
     assert rows_of_sites_case(harness.EmuBackend) == 800
+
+
+def rows_stream_case(Backend, add_all_variants, seed=0):
+    """the stream through scoring, calls, phase flags and the VCF text over rows of 6 .. 10 adjacent SNP sites (scenarios: "rows"),
+    the sites kept apart or merged by add_all_variants"""
+    rb = 1000000
+    ref, recs, codes, pos = scenarios.synthetic_case("rows", n_ref=9000, n_reads=3000, region_begin=rb, seed=seed)
+    order = np.argsort(pos, kind="stable")
+    rec = scenarios.stream_records(len(codes), pos, sample=np.arange(len(codes)) % 3)[order]
+    run_stream(Backend(gtx.graph_from_records(ref, recs, region_begin=rb, add_all_variants=add_all_variants)),
+               Oracle(ref, recs, region_begin=rb, add_all_variants=add_all_variants), codes[order], rec, n_samples=3)
+
+
+@pytest.mark.parametrize("add_all_variants", [False, True])
+def test_stream_over_rows_of_sites(add_all_variants):
+    rows_stream_case(harness.EmuBackend, add_all_variants)
