@@ -58,3 +58,24 @@ def test_two_ranks_run_the_cfg4_shape():
     assert j["scaling"] == "strong" and j["config"]["reads_per_rank"] == [40_000_001, 40_000_000] and j["reduce_ok"] is True
     p, lines = _run(["--dry-run", "--steps", "1"])  # one GPU stays cfg2
     assert json.loads(lines[-1])["config"]["samples"] == 1 and json.loads(lines[-1])["scaling"] == "weak"
+
+
+def test_the_line_of_stdout_fits_the_drivers_tail():
+    """The driver keeps a bounded tail of the run's output: round 4's 17 KB line was parsed, round 5's 24 KB line was not
+    (BENCH_r05.json: "parsed": null).  The line of stdout is the compact one -- the contract's keys, `roofline`,
+    `cpu_baseline`, every extra leg as a few numbers -- made here from round 5's whole record."""
+    sys.path.insert(0, ROOT)
+    import bench
+    out = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+    line = bench.compact_line(out)
+    text = json.dumps(line)
+    assert len(text) < 6000, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in line and line[k] == (out[k] if k not in ("config", "roofline", "cpu_baseline") else line[k])
+    assert line["config"]["workload"].startswith("cfg2: 1 sample, 10000000 synthetic 150 bp reads")
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert line["roofline"][k] == out["roofline"][k]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert line["cpu_baseline"][k] == out["cpu_baseline"][k]
+    assert set(line["config"]["extra"]) == set(out["config"]["extra"])

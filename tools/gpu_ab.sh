@@ -6,6 +6,7 @@
 #   --leg <name>   run one extra leg alone instead (tools/run_extra_leg.py: cfg3 | clusters | repeats | cfg5)
 #   --rounds <n>   rounds (default 2)
 set -u
+export GTX_BENCH_FULL_LINE=1  # bench.py prints its whole record (the default line is the compact one the driver parses)
 extra=0; leg=""; rounds=2
 while [ $# -gt 0 ]; do
   case "$1" in

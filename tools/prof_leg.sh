@@ -1,6 +1,7 @@
 #!/bin/bash
 # Phase cycle counters of one extra leg (profiling build): bash tools/prof_leg.sh {cfg3|clusters|repeats|cfg5} [bench.py arguments]
 set -u
+export GTX_BENCH_FULL_LINE=1  # bench.py prints its whole record (the default line is the compact one the driver parses)
 leg=${1:-cfg3}; shift
 mkdir -p gpurun_out
 GTX_LIB=libgtx_prof.so python tools/run_extra_leg.py "$leg" --no-cpu-baseline "$@" > gpurun_out/prof_${leg}.json 2> gpurun_out/prof_${leg}.txt

@@ -3,6 +3,7 @@
 # 1) kernel trace + stats of the bench command (default schedule: steps in flight); 2) PMC passes (own runs, no trace domains,
 #    one step at a time: counters are per kernel) for instruction mix and HBM bytes.
 set -u
+export GTX_BENCH_FULL_LINE=1  # bench.py prints its whole record (the default line is the compact one the driver parses)
 TAG=${1:-r02}
 READS=${2:-10000000}
 OUT=$PWD/gpurun_out/prof_$TAG

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Kernel trace of one extra leg of bench.py.  Usage: gpurun -- 'bash tools/trace_leg.sh repeats [bench.py arguments]'
 set -u
+export GTX_BENCH_FULL_LINE=1  # bench.py prints its whole record (the default line is the compact one the driver parses)
 LEG=${1:-repeats}; shift
 OUT=$PWD/gpurun_out/trace_$LEG
 rm -rf $OUT; mkdir -p $OUT

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Kernel trace of the main workload (no extra legs), the top kernels printed: bash tools/trace_main_stats.sh [tag] [bench.py arguments]   (GTX_LIB selects the build)
+export GTX_BENCH_FULL_LINE=1  # bench.py prints its whole record (the default line is the compact one the driver parses)
 tag=${1:-main}; shift
 export TMPDIR=/tmp; R=$PWD; mkdir -p $R/gpurun_out/trace_$tag; cd /tmp
 timeout 250 rocprofv3 --output-format csv --kernel-trace --stats -d $R/gpurun_out/trace_$tag -o main -- python $R/bench.py --no-cpu-baseline --no-extra "$@" > $R/gpurun_out/trace_$tag/bench.log 2>&1

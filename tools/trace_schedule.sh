@@ -1,6 +1,7 @@
 #!/bin/bash
 # Kernel trace (start / end of every launch, per queue) of a short bench run: bash tools/trace_schedule.sh [bench args]
 set -u
+export GTX_BENCH_FULL_LINE=1  # bench.py prints its whole record (the default line is the compact one the driver parses)
 OUT=$PWD/gpurun_out/sched
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
