@@ -58,8 +58,14 @@ constexpr uint64_t PROF_WORDS = 40 + PROF_LOG_ENTRIES * PROF_LOG_ENTRY;
 #define GTX_SCORE_TABLE_LOG2 8
 #endif
 #ifndef GTX_SCORE_CHUNK_MAX
-#define GTX_SCORE_CHUNK_MAX 64 // items of one workgroup between two flushes of its table; at most 1 024 (the 32-bit sums of the table: 1 024 x 2 reads x 255^2)
+#define GTX_SCORE_CHUNK_MAX 64 // items of one workgroup between two flushes of its table; at most 1 024
 #endif
+// What one add may bring to a 32-bit sum of the table: between two flushes a slot sees at most GTX_SCORE_CHUNK_MAX items, an item
+// adds to one counter at most SCORE_ADDS_PER_ITEM times (two reads, a read once or twice -- the bound has room for eight), so sums
+// of addends below this cannot wrap; a larger addend (a wavefront group's sum of squares, say) goes straight to memory.
+constexpr uint32_t SCORE_ADDS_PER_ITEM = 8;
+static_assert(GTX_SCORE_CHUNK_MAX >= 1 && GTX_SCORE_CHUNK_MAX <= 1024, "GTX_SCORE_CHUNK_MAX: 1 .. 1 024");
+constexpr unsigned long long SCORE_COMBINE_ADDEND_LIMIT = (1ull << 32) / (static_cast<unsigned long long>(GTX_SCORE_CHUNK_MAX) * SCORE_ADDS_PER_ITEM);
 // The table: 32-bit keys -- the counter's word offset from the lowest accumulator address (gtx_scores_alloc puts them in one block),
 // bit 31 = the counter is 64 bits wide -- and 32-bit sums, 8 KB for 1 024 entries.  A workgroup scores a CONTIGUOUS run of the work
 // queue (neighbours in the stream: the same two or three sites, the same samples over and over) and flushes once at its end:
@@ -83,7 +89,7 @@ struct WaveHipCombine : WaveHip
   {
     ScoreCombiner & t = table();
     unsigned long long const d = address - t.base;
-    if ((d >> 33) != 0ull || (v >> 26) != 0ull) // (not within 8 GB above the base, or an addend the 32-bit sum has no room for: straight to memory)
+    if ((d >> 33) != 0ull || v >= SCORE_COMBINE_ADDEND_LIMIT) // (not within 8 GB above the base, or an addend the 32-bit sum has no room for: straight to memory)
       return false;
     uint32_t const key = static_cast<uint32_t>(d >> 2) | (is64 ? 0x80000000u : 0u);
     uint32_t h = (key * 0x9E3779B1u) >> (32u - ScoreCombiner::LOG2N);
@@ -1001,6 +1007,14 @@ __global__ __launch_bounds__(256) void gtx_records_failed_kernel(uint32_t const 
     mine += __shfl_xor(mine, d);
   if ((threadIdx.x & 63u) == 0 && mine)
     atomicAdd(count, mine);
+}
+
+// the header word of every slot back to zero (gtx_regions_run recycles its slots from region to region: the reverse slot of a
+// GTX_FLAG_FORWARD_ONLY read is never written by a call and would keep what an earlier region's read left there)
+__global__ __launch_bounds__(256) void gtx_records_clear_kernel(uint32_t * __restrict__ records, uint32_t rec_words, uint64_t n_slots)
+{
+  for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < n_slots; t += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+    records[t * rec_words] = 0u;
 }
 
 __global__ __launch_bounds__(TRIAGE_THREADS) void gtx_score_triage_kernel(gtx_score_item const * __restrict__ items, uint32_t n_items,
@@ -2259,6 +2273,12 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
       void * ws = nullptr;
       if (!hip_ok(gtx::dev_malloc(&ws, static_cast<size_t>(c->big_blocks) * big_workspace_bytes()), "second-pass workspaces"))
         return GTX_ERR_HIP;
+      // (the scratch came back to this stream in stream order only -- scratch_acquire does not wait for the host: an earlier,
+      //  small call's HBM-table pass may still be running on the old block, and a block goes back to the cache only when no
+      //  kernel can still use it, gtx_devmem.hpp: another context's thread could be handed it for another stream.  Once per
+      //  scratch, at its first large batch.)
+      if (s->d_big_ws && s->used && s->done)
+        (void)hipEventSynchronize(static_cast<hipEvent_t>(s->done));
       (void)gtx::dev_free(s->d_big_ws);
       s->d_big_ws = ws;
       s->big_blocks = c->big_blocks;
@@ -3011,6 +3031,18 @@ extern "C" int gtx_records_failed(gtx_ctx * c, const uint32_t * d_records, uint3
     return GTX_ERR_HIP;
   *out = n;
   return GTX_OK;
+}
+
+int gtx::records_clear_enqueue(gtx_ctx * c, uint32_t * d_records, uint32_t rec_words, uint64_t n_reads, void * stream)
+{
+  if (!c || rec_words < 8 || (n_reads && !d_records) || c->device < 0)
+    return GTX_ERR_ARG;
+  if (n_reads == 0)
+    return GTX_OK;
+  uint64_t const slots = 2ull * n_reads;
+  uint32_t const blocks = static_cast<uint32_t>(std::min<uint64_t>((slots + 255u) / 256u, 4096u));
+  hipLaunchKernelGGL(gtx_records_clear_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_records, rec_words, slots);
+  return hip_ok(hipGetLastError(), "gtx_records_clear_kernel launch") ? GTX_OK : GTX_ERR_HIP;
 }
 
 int gtx::records_failed_enqueue(gtx_ctx * c, const uint32_t * d_records, uint32_t rec_words, uint64_t n_reads, void * stream, unsigned long long * d_count)

@@ -169,6 +169,8 @@ namespace gtx
 extern thread_local std::string g_last_error;
 // gtx_scores_alloc with the block zeroed on `stream` (no wait: for a caller whose first use of the block is on that stream)
 int scores_alloc_on(gtx_ctx * c, uint32_t n_samples, uint32_t conn_cap, gtx_score_buffers * out, uint64_t * reduced_bytes, void * stream);
+// zeroes the header word of the 2 * n_reads record slots on `stream` (slots recycled from one region to the next)
+int records_clear_enqueue(gtx_ctx * c, uint32_t * d_records, uint32_t rec_words, uint64_t n_reads, void * stream);
 // gtx_records_failed without its wait: zeroes *d_count and queues the count on `stream`
 int records_failed_enqueue(gtx_ctx * c, const uint32_t * d_records, uint32_t rec_words, uint64_t n_reads, void * stream, unsigned long long * d_count);
 int ctx_upload(gtx_ctx & c, int device); // graph tables + per-call scratch (no index)

@@ -90,6 +90,26 @@ public:
   }
 };
 
+// a stage thread ran out of host memory (or anything else was thrown) in the middle of a job: the job fails with a message that
+// needs no allocation to speak of, the thread goes on with the next one -- nothing may cross the C boundary or end the process
+void fail_thrown(gtx_region_job & j, std::mutex & m, std::string & first_error, int & first_status) noexcept
+{
+  j.status = GTX_ERR_CAPACITY;
+  try
+  {
+    std::lock_guard<std::mutex> lock(m);
+    if (first_status == GTX_OK)
+    {
+      first_status = GTX_ERR_CAPACITY;
+      first_error.assign("gtx_regions_run: a job failed for lack of host memory");
+    }
+  }
+  catch (...)
+  {
+    first_status = GTX_ERR_CAPACITY;
+  }
+}
+
 void fail(gtx_region_job & j, int status, std::string const & what, std::mutex & m, std::string & first_error, int & first_status)
 {
   j.status = status;
@@ -154,6 +174,9 @@ extern "C" int gtx_regions_run(gtx_region_job * jobs, uint32_t n_jobs, const gtx
       if (k >= n_jobs)
         break;
       gtx_region_job & j = jobs[k];
+      gtx_ctx * c = nullptr;
+      try
+      {
       auto t0 = std::chrono::steady_clock::now();
       gtx_graph * g = nullptr;
       int rc = gtx_graph_build(j.reference, j.reference_len, j.region_begin, j.region_end, j.records, j.n_records, j.add_all_variants, params->is_sv_graph, 0, &g);
@@ -162,7 +185,6 @@ extern "C" int gtx_regions_run(gtx_region_job * jobs, uint32_t n_jobs, const gtx
         rc = gtx_graph_get_view(g, &view);
       t_graph += seconds_since(t0);
       t0 = std::chrono::steady_clock::now();
-      gtx_ctx * c = nullptr;
       if (rc == GTX_OK)
         rc = gtx_ctx_create(&view, params, device, &c);
       if (g)
@@ -177,6 +199,14 @@ extern "C" int gtx_regions_run(gtx_region_job * jobs, uint32_t n_jobs, const gtx
       b.job = k;
       b.ctx = c;
       built.put(std::move(b));
+      c = nullptr; // (the device stage's from here on)
+      }
+      catch (...)
+      {
+        if (c)
+          gtx_ctx_destroy(c);
+        fail_thrown(j, err_m, first_error, first_status);
+      }
     }
     std::lock_guard<std::mutex> lock(stat_m);
     s.graph_build_s += t_graph;
@@ -193,8 +223,10 @@ extern "C" int gtx_regions_run(gtx_region_job * jobs, uint32_t n_jobs, const gtx
     void * d_failed_v = nullptr;
     uint8_t * pinned = nullptr;
     size_t pinned_cap = 0;
-    // (the record slots are recycled from region to region as they are: a call writes the record and the flag byte of every task
-    //  it is given, and a region's items name that region's tasks only)
+    // (the record slots are recycled from region to region: a call writes the record and the flag byte of every task it is
+    //  given and a region's items name that region's tasks only -- but the reverse slot of a GTX_FLAG_FORWARD_ONLY read is no task,
+    //  and the count of failed records looks at every slot: the header words are zeroed on the stream in front of every region,
+    //  so that a table-overflow status one region's read left there is not counted against the regions behind it)
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
               gtx::dev_malloc(&d_rec, rec_bytes) == hipSuccess && gtx::dev_malloc(&d_fl, fl_bytes) == hipSuccess &&
               gtx::dev_malloc(&d_failed_v, 8) == hipSuccess && hipMemsetAsync(d_rec, 0, rec_bytes, st) == hipSuccess &&
@@ -205,12 +237,15 @@ extern "C" int gtx_regions_run(gtx_region_job * jobs, uint32_t n_jobs, const gtx
     {
       gtx_region_job & j = jobs[b.job];
       gtx_ctx * c = b.ctx;
+      void *d_phred = nullptr, *d_calls = nullptr;
+      gtx_score_buffers acc{};
+      bool blocks_held = true; // (d_phred, d_calls and the accumulator block are this iteration's until they went back to the cache)
+      try
+      {
       auto const t0 = std::chrono::steady_clock::now();
       Scored out;
       out.job = b.job;
       out.ctx = c;
-      gtx_score_buffers acc{};
-      void *d_phred = nullptr, *d_calls = nullptr;
       int rc = ok ? GTX_OK : GTX_ERR_HIP;
       std::string what = ok ? "" : "gtx_regions_run: a device thread could not get its stream / record slots";
       gtx_score_layout lay{};
@@ -234,6 +269,8 @@ extern "C" int gtx_regions_run(gtx_region_job * jobs, uint32_t n_jobs, const gtx
         rc = GTX_ERR_HIP;
         what = "gtx_regions_run: hipMemsetAsync";
       }
+      if (rc == GTX_OK && j.n_reads && (rc = gtx::records_clear_enqueue(c, static_cast<uint32_t *>(d_rec), rec_words, j.n_reads, st)) != GTX_OK)
+        what = gtx_last_error();
       if (rc == GTX_OK && j.n_reads &&
           (rc = gtx_align_batch_planes(c, j.d_planes, j.plane_stride, j.d_meta, static_cast<uint32_t>(j.n_reads), static_cast<uint32_t *>(d_rec), rec_words,
                                        static_cast<uint8_t *>(d_fl), st)) != GTX_OK)
@@ -306,14 +343,32 @@ extern "C" int gtx_regions_run(gtx_region_job * jobs, uint32_t n_jobs, const gtx
       (void)gtx::dev_free(d_phred);
       (void)gtx::dev_free(d_calls);
       (void)gtx::dev_free(acc.d_stat_u64);
+      blocks_held = false;
       t_dev += seconds_since(t0);
       if (rc != GTX_OK)
       {
-        fail(j, rc, what, err_m, first_error, first_status);
         gtx_ctx_destroy(c);
+        c = nullptr;
+        fail(j, rc, what, err_m, first_error, first_status);
         continue;
       }
       scored.put(std::move(out));
+      c = nullptr; // (the text stage's from here on)
+      }
+      catch (...)
+      {
+        if (st)
+          (void)hipStreamSynchronize(st);
+        if (blocks_held)
+        {
+          (void)gtx::dev_free(d_phred);
+          (void)gtx::dev_free(d_calls);
+          (void)gtx::dev_free(acc.d_stat_u64);
+        }
+        if (c)
+          gtx_ctx_destroy(c);
+        fail_thrown(j, err_m, first_error, first_status);
+      }
     }
     if (st)
     {
@@ -340,6 +395,10 @@ extern "C" int gtx_regions_run(gtx_region_job * jobs, uint32_t n_jobs, const gtx
     while (scored.get(sc))
     {
       gtx_region_job & j = jobs[sc.job];
+      char * text = nullptr;
+      bool ctx_held = true;
+      try
+      {
       auto const t0 = std::chrono::steady_clock::now();
       gtx_vcf_request rq{};
       rq.contig = contig;
@@ -356,7 +415,7 @@ extern "C" int gtx_regions_run(gtx_region_job * jobs, uint32_t n_jobs, const gtx
       gtx_score_layout lay{};
       (void)gtx_ctx_score_layout(sc.ctx, &lay);
       uint64_t cap = 4096 + static_cast<uint64_t>(lay.n_hap) * (600 + 40ull * n_samples), len = 0;
-      char * text = static_cast<char *>(std::malloc(cap));
+      text = static_cast<char *>(std::malloc(cap));
       int rc = text ? gtx_vcf_records(sc.ctx, &rq, text, cap, &len) : GTX_ERR_CAPACITY;
       if (rc == GTX_OK && len > cap) // (the estimate was short: once more with what it takes)
       {
@@ -367,27 +426,58 @@ extern "C" int gtx_regions_run(gtx_region_job * jobs, uint32_t n_jobs, const gtx
       }
       sc.ctx->quiet = true; // (its device thread waited for the stream the region ran on)
       gtx_ctx_destroy(sc.ctx);
+      ctx_held = false;
       t_text += seconds_since(t0);
       if (rc != GTX_OK)
       {
+        bool const had_text = text != nullptr;
         std::free(text);
-        fail(j, rc, "gtx_regions_run: job " + std::to_string(sc.job) + ": " + (text ? gtx_last_error() : "out of memory"), err_m, first_error, first_status);
+        text = nullptr;
+        fail(j, rc, "gtx_regions_run: job " + std::to_string(sc.job) + ": " + (had_text ? gtx_last_error() : "out of memory"), err_m, first_error, first_status);
         continue;
       }
       j.text = text;
       j.text_len = len;
+      }
+      catch (...)
+      {
+        std::free(text);
+        if (ctx_held)
+        {
+          sc.ctx->quiet = true;
+          gtx_ctx_destroy(sc.ctx);
+        }
+        fail_thrown(j, err_m, first_error, first_status);
+      }
     }
     std::lock_guard<std::mutex> lock(stat_m);
     s.vcf_text_s += t_text;
   };
 
+  // (a stage runs with the threads that could be started; a stage without any thread ends the call -- the stages before it are
+  //  not started, so nobody waits for room in a queue nobody empties)
   std::vector<std::thread> builders, devs, texters;
-  for (uint32_t t = 0; t < n_text_threads; ++t)
-    texters.emplace_back(texter);
-  for (uint32_t t = 0; t < n_device_threads; ++t)
-    devs.emplace_back(device_worker);
-  for (uint32_t t = 0; t < n_builders; ++t)
-    builders.emplace_back(builder);
+  auto start = [](std::vector<std::thread> & v, uint32_t n, auto & body)
+  {
+    try
+    {
+      v.reserve(n);
+      for (uint32_t t = 0; t < n; ++t)
+        v.emplace_back(body);
+    }
+    catch (...)
+    {
+    }
+    return !v.empty();
+  };
+  bool const started = start(texters, n_text_threads, texter) && start(devs, n_device_threads, device_worker) && start(builders, n_builders, builder);
+  if (!started)
+  {
+    for (uint32_t k = 0; k < n_jobs; ++k)
+      jobs[k].status = GTX_ERR_CAPACITY;
+    first_status = GTX_ERR_CAPACITY;
+    first_error = "gtx_regions_run: the stage threads could not be started";
+  }
   for (auto & t : builders)
     t.join();
   built.close();

@@ -132,8 +132,9 @@ def lib():
         # A process that uses PyTorch as well has to have PyTorch's HIP runtime in it FIRST: libgtx.so names libamdhip64 by its
         # soname, and with torch already loaded that resolves to the runtime torch brought -- one runtime for both.  The other way
         # round the process holds two, and the library's own sees no device ("no HIP device visible").  Whoever binds the library
-        # from Python gets the order right here; a C or C++ host has one runtime anyway.
-        if "torch" not in sys.modules:
+        # from Python gets the order right here; a C or C++ host has one runtime anyway.  GTX_NO_TORCH=1: a process that will never
+        # use PyTorch (and does not want its two seconds of import) loads the library alone.
+        if "torch" not in sys.modules and not os.environ.get("GTX_NO_TORCH"):
             try:
                 import torch  # noqa: F401
             except ImportError:
@@ -589,6 +590,7 @@ class RegionJobs:
                                device_threads, text_threads, C.byref(st))
         texts = [C.string_at(self.jobs[k].text, self.jobs[k].text_len) if self.jobs[k].text else None for k in range(self.n)]
         self.status = [int(self.jobs[k].status) for k in range(self.n)]
+        self.texts = texts  # (kept for a caller that catches the first failing job's error: the other jobs have theirs)
         L.gtx_regions_free(self.jobs, self.n)
         check(rc)
         return texts, {k: getattr(st, k) for k, _ in RegionsStats._fields_ if k != "reserved"}

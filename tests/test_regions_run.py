@@ -140,3 +140,28 @@ def test_a_job_beyond_a_capacity_limit_fails_and_the_others_do_not():
     assert jobs.status == [0, 5, 0]
     got, st = jobs.run(names, contig="chr20", rec_words=bench.REC_WORDS, conn_cap=1 << 20)  # with room for them: every job has its text
     assert got == want and st["connections_dropped"] == 0
+
+
+@pytest.mark.gpu
+def test_a_failed_record_of_one_region_is_not_counted_against_the_next():
+    """A device thread recycles its record slots from region to region, and the reverse slot of a GTX_FLAG_FORWARD_ONLY read is
+    never written (gtx.h, gtx_records_failed): region 0 has reads in both orientations that are longer than the passes take -- a
+    table-overflow status in both of their slots, the job fails -- and region 1's forward-only reads at the same indices must not
+    inherit the status of the reverse slots (advisor, round 5: every later region of the thread failed with GTX_ERR_CAPACITY)."""
+    import torch
+    import bench
+    device = torch.device("cuda", 0)
+    n_reads, names = 20000, ["A", "B"]
+    regions = _regions(torch, device, 3, 20000, n_reads, len(names), snp_every=[500, 500, 500], seed=9)
+    want = _one_by_one(torch, device, regions, names, n_reads)
+    meta = regions[0]["d_meta"].cpu().numpy().view(gtx.READ_META).reshape(-1).copy()
+    meta["flag"][[3, 700, 19999]] = 0
+    meta["l_qseq"][[3, 700, 19999]] = 300
+    regions[0]["d_meta"] = torch.from_numpy(meta.view(np.uint8).reshape(n_reads, -1).copy()).to(device)
+    jobs = gtx.RegionJobs([dict(reference=r["ref_str"], region_begin=r["rb"], records=r["recs"], add_all_variants=r["add_all"], d_planes=r["d_planes"].data_ptr(),
+                                plane_stride=80, d_meta=r["d_meta"].data_ptr(), n_reads=n_reads, d_items=r["d_items"].data_ptr(), n_items=n_reads) for r in regions])
+    with pytest.raises(gtx.GtxError) as e:
+        jobs.run(names, contig="chr20", rec_words=bench.REC_WORDS, builders=1, device_threads=1, text_threads=1)
+    assert e.value.status == 5 and "6 records with a table-overflow status" in str(e.value)
+    assert jobs.status == [5, 0, 0]
+    assert jobs.texts[0] is None and jobs.texts[1:] == want[1:]
