@@ -73,7 +73,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the cfg3-like extra workload")
     ap.add_argument("--no-reduce-check", action="store_true", help="N > 1: skip the check of the summed block against one GPU (rank 0 redoes every rank's reads)")
-    ap.add_argument("--lanes", type=int, default=3, help="steps in flight (each with its own records and accumulators); 1 = one after the other")
+    ap.add_argument("--lanes", type=int, default=3, help="steps in flight (each with its own records and accumulators); 1 = one after the other.  "
+                    "Staggered schedule with four and more lanes: the last lane is the host's slack (Workload.steps_staggered)")
     ap.add_argument("--schedule", choices=["staggered", "lanes"], default="staggered",
                     help="staggered = one stream carries the position-hinted pass of step k and then the scoring of step k-lanes+1, a second "
                          "one the short queues behind every position-hinted pass; lanes = step k entirely on stream k mod lanes")
@@ -503,6 +504,14 @@ class Workload:
         spH = C.c_void_p(H.cuda_stream)
         evs, flight = [], []
         n_l = len(self.lanes)
+        # How far the scoring of a step trails its position-hinted pass: n_l - 1 steps with three lanes (rounds 3-5).  The host
+        # paces itself on the lane it is about to reuse (below), and with depth = lanes that lane's scoring is the LAST thing queued
+        # on H.  Round 6 asked whether the 45 us between `calls` and the next position-hinted pass (kernel trace) were the host
+        # waking up: with four lanes and the same depth of three -- the lane the host waits for scored a whole step earlier -- the
+        # step is the same (0.729 against 0.728 ms): the gap was the counter reset in front of the pass and the packets around it
+        # (gone since: CallScratch::d_counter_sets), not the host.  Three lanes stay the default.  (GTX_BENCH_DEPTH: A/B)
+        depth = int(os.environ.get("GTX_BENCH_DEPTH", "0")) or (n_l - 1 if n_l >= 4 else n_l)
+        depth = max(1, min(depth, n_l))
         pace = os.environ.get("GTX_BENCH_PACE", "1") != "0"
         score_on = os.environ.get("GTX_BENCH_SCORE_ON", "H")
         if score_on == "S" and not hasattr(self, "score_stream"):
@@ -542,7 +551,7 @@ class Workload:
                 self._score(ln, self.score_stream, [ln["aligned"]])
                 continue
             flight.append(ln)
-            if len(flight) == n_l:  # (the oldest step in flight: its queues had the last n_l - 1 position-hinted passes to drain)
+            if len(flight) == depth:  # (the oldest step in flight: its queues had the last depth - 1 position-hinted passes to drain)
                 old = flight.pop(0)
                 self._score(old, H, [old["aligned"]])
         for old in flight:

@@ -1021,8 +1021,12 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void gtx_score_triage_kernel(gtx_sc
                                                                           uint32_t const * __restrict__ records, uint32_t rec_words,
                                                                           uint32_t * __restrict__ work_queue, uint32_t * work_count,
                                                                           uint32_t keeps_depth, uint8_t const * __restrict__ task_flags,
-                                                                          uint32_t const * __restrict__ item_words)
+                                                                          uint32_t const * __restrict__ item_words, uint32_t * __restrict__ zero_next)
 {
+  // (the state words of the NEXT scoring call on this scratch -- CallScratch::d_score_state, two sets used in turn: no memset in
+  //  front of this launch)
+  if (zero_next && blockIdx.x == 0 && threadIdx.x < 4)
+    zero_next[threadIdx.x] = 0u;
   // one queue append per WORKGROUP (a device counter takes a few hundred million returning atomics a second: one per
   // wavefront -- 156 k per 10 M items -- set the pace of this kernel)
   __shared__ uint32_t s_count[TRIAGE_PER_THREAD][TRIAGE_THREADS / 64], s_base;
@@ -1073,13 +1077,66 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void gtx_score_triage_kernel(gtx_sc
 #else
 #define GTX_SCORE_ATTR
 #endif
+// one item of the scoring kernels' visits (lane = item): the record staged through LDS, score_item, the second pass' queue
+constexpr uint32_t SCORE_STAGE_WORDS = 16, SCORE_STAGE_PITCH = SCORE_STAGE_WORDS + 1; // (an odd pitch: a word of every lane's row in a bank of its own)
+__device__ __forceinline__ void score_visit(GraphView const & g, ScoreParams const & par, gtx_score_item const & it, uint32_t i, uint32_t const * __restrict__ records,
+                                            uint32_t rec_words, ScoreAcc const & acc, uint32_t * s_stage, uint32_t * error_flag, uint32_t * __restrict__ big_queue,
+                                            uint32_t big_queue_cap, uint32_t * big_state)
+{
+  // The record of the item's (first) read, forward orientation, fetched in ONE round trip and parsed from LDS: the parser
+  // walks it word by word, every look a dependent load (PMC, cfg3: 68 vector loads per visit, each waited for -- the
+  // kernel's time is their latencies in a row).  Records that are longer than the copy, in the arena or wide stay where they are.
+  ScoreAcc mine = acc;
+#ifndef GTX_NO_SCORE_STAGING
+  if ((rec_words & 3u) == 0u)
+  {
+    uint32_t const ai = it.first.align_index;
+    bool const dense = acc.compact && (acc.compact_flags[2ull * ai] & GTX_TASK_COMPACT);
+    uint32_t const * const src = dense ? acc.compact + static_cast<uint64_t>(ai) * GTX_COMPACT_WORDS : records + static_cast<uint64_t>(ai) * 2 * rec_words;
+    uint32_t const have = dense ? GTX_COMPACT_WORDS : (rec_words < SCORE_STAGE_WORDS ? rec_words : SCORE_STAGE_WORDS);
+    uint4_t const * const q = reinterpret_cast<uint4_t const *>(src);
+    uint4_t x[SCORE_STAGE_WORDS / 4];
+#pragma unroll
+    for (uint32_t k = 0; k < SCORE_STAGE_WORDS / 4; ++k)
+      x[k] = 4 * k < have ? q[k] : uint4_t{0, 0, 0, 0};
+    uint32_t const n_paths = x[0].x & 0xFFFFu, nvar = x[1].y >> 16;
+    bool const whole = ((x[0].x >> 16) & GTX_ST_EXTERNAL) == 0u && (x[0].y & GTX_REC_WIDE) == 0u &&
+                       (n_paths == 0 || (n_paths == 1 && 6u + 3u * nvar <= have));
+    if (whole)
+    {
+      uint32_t * const row = s_stage + threadIdx.x * SCORE_STAGE_PITCH;
+#pragma unroll
+      for (uint32_t k = 0; k < SCORE_STAGE_WORDS / 4; ++k)
+      {
+        row[4 * k + 0] = x[k].x;
+        row[4 * k + 1] = x[k].y;
+        row[4 * k + 2] = x[k].z;
+        row[4 * k + 3] = x[k].w;
+      }
+      mine.staged_from = src;
+      mine.staged_copy = row;
+    }
+  }
+#endif
+  RecentHap r1[SCORE_MAX_HAPS], r2[SCORE_MAX_HAPS];
+  if (!score_item<WaveHipCombine>(g, par, it, records, rec_words, mine, r1, r2, SCORE_MAX_HAPS))
+  {
+    // a read of this item touches more variant sites than the tables above hold (long results of the alignment's
+    // last pass): nothing was added yet, queue the item for gtx_score_big_kernel
+    uint32_t const slot = big_queue ? atomicAdd(big_state, 1u) : big_queue_cap;
+    if (slot < big_queue_cap)
+      big_queue[slot] = i;
+    else
+      atomicAdd(error_flag, 1u);
+  }
+}
+
 __global__ __launch_bounds__(GTX_SCORE_THREADS) GTX_SCORE_ATTR void gtx_score_kernel(GraphView g, ScoreParams par, gtx_score_item const * __restrict__ items,
                                                         uint32_t const * __restrict__ work_queue, uint32_t const * work_count,
                                                         uint32_t const * __restrict__ records, uint32_t rec_words, ScoreAcc acc,
                                                         uint32_t * error_flag, uint32_t * __restrict__ big_queue,
                                                         uint32_t big_queue_cap, uint32_t * big_state)
 {
-  constexpr uint32_t SCORE_STAGE_WORDS = 16, SCORE_STAGE_PITCH = SCORE_STAGE_WORDS + 1; // (an odd pitch: a word of every lane's row in a bank of its own)
   __shared__ uint32_t s_stage[GTX_SCORE_THREADS * SCORE_STAGE_PITCH];
   uint32_t const n_work = work_count[0];
   WaveHipCombine::clear(acc.combine_base);
@@ -1105,52 +1162,7 @@ __global__ __launch_bounds__(GTX_SCORE_THREADS) GTX_SCORE_ATTR void gtx_score_ke
 #ifdef GTX_PROF
       t1 = clock64() + (it.sample & 0u); // (behind the loads)
 #endif
-      // The record of the item's (first) read, forward orientation, fetched in ONE round trip and parsed from LDS: the parser
-      // walks it word by word, every look a dependent load (PMC, cfg3: 68 vector loads per visit, each waited for -- the
-      // kernel's time is their latencies in a row).  Records that are longer than the copy, in the arena or wide stay where they are.
-      ScoreAcc mine = acc;
-#ifndef GTX_NO_SCORE_STAGING
-      if ((rec_words & 3u) == 0u)
-      {
-        uint32_t const ai = it.first.align_index;
-        bool const dense = acc.compact && (acc.compact_flags[2ull * ai] & GTX_TASK_COMPACT);
-        uint32_t const * const src = dense ? acc.compact + static_cast<uint64_t>(ai) * GTX_COMPACT_WORDS : records + static_cast<uint64_t>(ai) * 2 * rec_words;
-        uint32_t const have = dense ? GTX_COMPACT_WORDS : (rec_words < SCORE_STAGE_WORDS ? rec_words : SCORE_STAGE_WORDS);
-        uint4_t const * const q = reinterpret_cast<uint4_t const *>(src);
-        uint4_t x[SCORE_STAGE_WORDS / 4];
-#pragma unroll
-        for (uint32_t k = 0; k < SCORE_STAGE_WORDS / 4; ++k)
-          x[k] = 4 * k < have ? q[k] : uint4_t{0, 0, 0, 0};
-        uint32_t const n_paths = x[0].x & 0xFFFFu, nvar = x[1].y >> 16;
-        bool const whole = ((x[0].x >> 16) & GTX_ST_EXTERNAL) == 0u && (x[0].y & GTX_REC_WIDE) == 0u &&
-                           (n_paths == 0 || (n_paths == 1 && 6u + 3u * nvar <= have));
-        if (whole)
-        {
-          uint32_t * const row = s_stage + threadIdx.x * SCORE_STAGE_PITCH;
-#pragma unroll
-          for (uint32_t k = 0; k < SCORE_STAGE_WORDS / 4; ++k)
-          {
-            row[4 * k + 0] = x[k].x;
-            row[4 * k + 1] = x[k].y;
-            row[4 * k + 2] = x[k].z;
-            row[4 * k + 3] = x[k].w;
-          }
-          mine.staged_from = src;
-          mine.staged_copy = row;
-        }
-      }
-#endif
-      RecentHap r1[SCORE_MAX_HAPS], r2[SCORE_MAX_HAPS];
-      if (!score_item<WaveHipCombine>(g, par, it, records, rec_words, mine, r1, r2, SCORE_MAX_HAPS))
-      {
-        // a read of this item touches more variant sites than the tables above hold (long results of the alignment's
-        // last pass): nothing was added yet, queue the item for gtx_score_big_kernel
-        uint32_t const slot = big_queue ? atomicAdd(big_state, 1u) : big_queue_cap;
-        if (slot < big_queue_cap)
-          big_queue[slot] = i;
-        else
-          atomicAdd(error_flag, 1u);
-      }
+      score_visit(g, par, it, i, records, rec_words, acc, s_stage, error_flag, big_queue, big_queue_cap, big_state);
 #ifdef GTX_PROF
       t2 = clock64();
 #endif
@@ -1175,6 +1187,10 @@ __global__ __launch_bounds__(GTX_SCORE_THREADS) GTX_SCORE_ATTR void gtx_score_ke
   }
 }
 
+// (Round 6, the same question again with the 4-byte item words: a one-wave workgroup walking groups of 64 neighbouring items -- group
+//  b, b + G, ... --, four or sixteen groups' item words and side bytes in flight together, scoring the groups with work where they
+//  lie: 0.744 / 0.758 ms per cfg2 step against 0.729 with the two launches.  The scoring code's registers leave five wavefronts per
+//  SIMD to do the streaming the triage kernel does with eight of a fifth the size.)
 // (Both stages in one launch -- a workgroup takes 1 024 items, keeps those with work in an LDS list and scores the list: no
 //  work queue through memory, one launch less -- measured slower, 1.36 ms per cfg2 step against 1.27: the triage streams
 //  400 MB and wants every wave slot, the scoring code's registers leave it 5 of 8.  Two kernels stay.)
@@ -1297,7 +1313,7 @@ static bool dev_alloc(T *& dst, size_t n, char const * what, bool zero = false)
 static void scratch_free(CallScratch & s)
 {
   // (d_big_state lies behind d_counters in one allocation: one reset for both)
-  void * ptrs[] = {s.d_counters, s.d_queue1, s.d_queue, s.d_big_tasks, s.d_big_ws, s.d_score_state, s.d_score_queue,
+  void * ptrs[] = {s.d_counter_sets, s.d_queue1, s.d_queue, s.d_big_tasks, s.d_big_ws, s.d_score_state, s.d_score_queue,
                    s.d_score_tables, s.d_score_work, s.d_wide_tasks, s.d_wide_ws, s.d_planes, s.d_exact_tasks};
   for (void * p : ptrs)
     if (p)
@@ -1319,6 +1335,17 @@ static void scratch_free(CallScratch & s)
   s = CallScratch();
 }
 
+// d_counters and the pointers into it name set k of the scratch's two (gtx_ctx.hpp)
+static void counter_set_select(CallScratch & s, uint32_t k)
+{
+  s.counter_set = k;
+  s.d_counters = s.d_counter_sets + static_cast<size_t>(k) * CallScratch::COUNTER_PITCH;
+  s.d_span = reinterpret_cast<unsigned long long *>(s.d_counters + 8 * CallScratch::MAX_PARTS + 48); // (its pinned home is made by the first timed call)
+  s.d_big_state = s.has_big ? s.d_counters + 8 * CallScratch::MAX_PARTS : nullptr;
+  s.d_wide_state = s.has_wide ? s.d_big_state + 8 : nullptr;
+  s.d_exact_state = s.has_big ? s.d_big_state + 16 : nullptr;
+}
+
 static std::unique_ptr<CallScratch> scratch_new(gtx_ctx & c)
 {
   auto s = std::make_unique<CallScratch>();
@@ -1326,14 +1353,14 @@ static std::unique_ptr<CallScratch> scratch_new(gtx_ctx & c)
   bool ok = hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "scratch event");
   if (ok)
     s->done = ev;
-  ok = ok && dev_alloc(s->d_counters, 8 * CallScratch::MAX_PARTS + 48 + 4, "task counters + second-pass state", true); // (+ big, wide, exact x 3: 8 words each; + the span of pass 0)
+  static_assert(CallScratch::COUNTER_WORDS == 8 * CallScratch::MAX_PARTS + 48 + 4 && CallScratch::COUNTER_WORDS <= CallScratch::COUNTER_PITCH, "counter sets");
+  ok = ok && dev_alloc(s->d_counter_sets, 2 * CallScratch::COUNTER_PITCH, "task counters + second-pass state", true); // (two sets: gtx_ctx.hpp)
+  s->has_big = !c.params.no_second_pass;
+  s->has_wide = s->has_big && c.has_wide_sites;
   if (ok)
-  {
-    s->d_span = reinterpret_cast<unsigned long long *>(s->d_counters + 8 * CallScratch::MAX_PARTS + 48); // (its pinned home is made by the first timed call)
-  }
+    counter_set_select(*s, 0);
   if (ok && !c.params.no_second_pass)
   {
-    s->d_big_state = s->d_counters + 8 * CallScratch::MAX_PARTS;
     void * ws = nullptr;
     // (workspaces for a small batch -- one workgroup per CU; a large batch grows them to c.big_blocks: align_planes)
     s->big_blocks = std::min<uint32_t>(c.big_blocks, static_cast<uint32_t>(c.n_cu > 0 ? c.n_cu : 256));
@@ -1341,16 +1368,14 @@ static std::unique_ptr<CallScratch> scratch_new(gtx_ctx & c)
     s->d_big_ws = ws;
     if (ok && c.has_wide_sites)
     {
-      s->d_wide_state = s->d_big_state + 8;
       ok = ok && dev_alloc(s->d_wide_tasks, CallScratch::WIDE_TASK_CAP, "wide-site pass queue");
       void * wws = nullptr;
       ok = ok && hip_ok(gtx::dev_malloc(&wws, static_cast<size_t>(CallScratch::WIDE_BLOCKS) * sizeof(wide::AlignWorkspace)), "wide-site pass workspaces");
       s->d_wide_ws = wws;
     }
     // the exact pass: two queues (what did not fit the tables above; what did not fit a part of the slab) and the slab
-    s->d_exact_state = s->d_big_state + 16;
     ok = ok && dev_alloc(s->d_exact_tasks, 3 * static_cast<size_t>(CallScratch::EXACT_TASK_CAP), "exact pass queues");
-    ok = ok && dev_alloc(s->d_score_state, 4, "second-pass score state", true); // ([2]: the work queue's count, reset with the rest)
+    ok = ok && dev_alloc(s->d_score_state, 8, "second-pass score state", true); // (two sets of four words; [2]: the work queue's count)
     ok = ok && dev_alloc(s->d_score_queue, gtx_ctx::SCORE_QUEUE_CAP, "second-pass score queue");
     if (c.has_wide_sites)
     {
@@ -1998,9 +2023,16 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
                         uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, hipStream_t st, hipEvent_t front_event, hipStream_t tail_stream,
                         hipEvent_t done_event, hipStream_t * last_stream, uint32_t * d_compact)
 {
-  // (the pass counters and, behind them, the state of the HBM-table and wide-site passes: one reset)
-  if (!hip_ok(hipMemsetAsync(s->d_counters, 0, (8 * CallScratch::MAX_PARTS + 48 + 4) * sizeof(uint32_t), st), "task counter reset"))
-    return GTX_ERR_HIP;
+  // (the pass counters and, behind them, the state of the HBM-table and wide-site passes: the set the last call left zeroed --
+  //  CallScratch::d_counter_sets; after a call that failed on its way the set is zeroed here, as every call did before round 6)
+  {
+    uint32_t const use = s->counter_set ^ 1u;
+    if (!s->spare_set_clean &&
+        !hip_ok(hipMemsetAsync(s->d_counter_sets + static_cast<size_t>(use) * CallScratch::COUNTER_PITCH, 0, CallScratch::COUNTER_PITCH * sizeof(uint32_t), st), "task counter reset"))
+      return GTX_ERR_HIP;
+    counter_set_select(*s, use);
+    s->spare_set_clean = false;
+  }
   // queues: room for every task (a graph on which no read is simple sends them all)
   if (!grow(s->d_queue, s->queue_cap, 2ull * n_reads, "pass-2 queue") || !grow(s->d_queue1, s->queue1_cap, n_reads, "pass-1 queue"))
     return GTX_ERR_HIP;
@@ -2189,8 +2221,6 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
                          timed && s->h_span ? s->d_span : static_cast<unsigned long long *>(nullptr));
       if (!hip_ok(hipGetLastError(), "gtx_align_hinted_kernel launch"))
         return GTX_ERR_HIP;
-      if (timed && s->h_span && first + step >= n_reads) // (the call's launches of the pass have added to the span: home with it)
-        (void)hipMemcpyAsync(s->h_span + 2 * slot, s->d_span, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
       mark(part, 1, st);
       // (gtx_align_batch_planes_staged: from here on the call is short queues -- the caller's other streams may come in;
       //  GTX_STAGED_FRONT=express: the express pass stays on the caller's stream as well and the front event is recorded behind it)
@@ -2210,6 +2240,10 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
                          counters + 4, static_cast<uint32_t>(force != 0) | (express_goal << 8));
       if (first + step >= n_reads && front_with_express)
         front_done();
+      // (the call's launches of the position-hinted pass have added to the span: home with it -- on the stream of the short queues,
+      //  behind the express launch: on the caller's stream the copy sat between the pass and whatever the caller queues behind it)
+      if (timed && s->h_span && first + step >= n_reads)
+        (void)hipMemcpyAsync(s->h_span + 2 * slot, s->d_span, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s1);
     }
     else
     {
@@ -2359,6 +2393,10 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
   mark(0, 5, sg);
   if (done_event)
     (void)hipEventRecord(done_event, sg);
+  // the other set of counters, zeroed for the next call behind this call's last launch (the scratch is handed on in the order of
+  // that stream, or when the event recorded behind this is through: scratch_release)
+  s->spare_set_clean = hipMemsetAsync(s->d_counter_sets + static_cast<size_t>(s->counter_set ^ 1u) * CallScratch::COUNTER_PITCH, 0,
+                                      CallScratch::COUNTER_PITCH * sizeof(uint32_t), sg) == hipSuccess;
   if (last_stream)
     *last_stream = sg;
   if (parts > 1)
@@ -2608,35 +2646,47 @@ static int score_batch(gtx_ctx * c, const gtx_score_item * d_items, const uint32
                   static_cast<uint32_t>(c->params.is_segment_calling != 0), 0};
   uint32_t const blocks = (n_items + GTX_SCORE_THREADS - 1u) / GTX_SCORE_THREADS;
   bool const second_pass = s->d_score_state != nullptr;
-  if (second_pass && !hip_ok(hipMemsetAsync(s->d_score_state, 0, 3 * sizeof(uint32_t), st), "second-pass state + work count reset"))
-    return GTX_ERR_HIP;
+  // the state of the second pass and the work queue's count: the set of four words the last call's triage kernel zeroed (zeroed
+  // here after a call whose triage launch failed)
+  uint32_t * score_state = nullptr, * score_state_next = nullptr;
+  if (second_pass)
+  {
+    uint32_t const use = s->score_set ^ 1u;
+    score_state = s->d_score_state + 4u * use;
+    score_state_next = s->d_score_state + 4u * (use ^ 1u);
+    if (!s->score_spare_clean && !hip_ok(hipMemsetAsync(score_state, 0, 4 * sizeof(uint32_t), st), "second-pass state + work count reset"))
+      return GTX_ERR_HIP;
+    s->score_set = use;
+    s->score_spare_clean = false;
+  }
   // work queue of stage 2: room for every item ([0] = count, [1..] = item indices)
   uint64_t cap = s->score_work_cap ? static_cast<uint64_t>(s->score_work_cap) + 1 : 0;
   if (!grow(s->d_score_work, cap, static_cast<uint64_t>(n_items) + 1, "score work queue"))
     return GTX_ERR_HIP;
   s->score_work_cap = static_cast<uint32_t>(cap - 1);
-  uint32_t * const work_count = second_pass ? s->d_score_state + 2 : s->d_score_work; // (one reset where the second-pass state exists)
+  uint32_t * const work_count = second_pass ? score_state + 2 : s->d_score_work;
   if (!second_pass && !hip_ok(hipMemsetAsync(s->d_score_work, 0, sizeof(uint32_t), st), "score work queue reset"))
     return GTX_ERR_HIP;
   hipLaunchKernelGGL(gtx_score_triage_kernel, dim3((n_items + TRIAGE_THREADS * TRIAGE_PER_THREAD - 1) / (TRIAGE_THREADS * TRIAGE_PER_THREAD)), dim3(TRIAGE_THREADS), 0, st, d_items, n_items, d_records, rec_words, s->d_score_work + 1,
-                     work_count, static_cast<uint32_t>(a.ref_depth != nullptr), d_task_flags, d_item_words);
+                     work_count, static_cast<uint32_t>(a.ref_depth != nullptr), d_task_flags, d_item_words, score_state_next);
   if (!hip_ok(hipGetLastError(), "gtx_score_triage_kernel launch"))
     return GTX_ERR_HIP;
+  s->score_spare_clean = second_pass;
   uint32_t const work_blocks = std::min<uint32_t>(blocks, static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256) * c->score_blocks_per_cu);
   hipLaunchKernelGGL(gtx_score_kernel, dim3(work_blocks), dim3(GTX_SCORE_THREADS), 0, st, c->dev_graph, par, d_items, s->d_score_work + 1, work_count,
                      d_records, rec_words, a, c->d_error_flag, second_pass ? s->d_score_queue : nullptr,
-                     second_pass ? gtx_ctx::SCORE_QUEUE_CAP : 0u, s->d_score_state);
+                     second_pass ? gtx_ctx::SCORE_QUEUE_CAP : 0u, score_state);
   if (!hip_ok(hipGetLastError(), "gtx_score_kernel launch"))
     return GTX_ERR_HIP;
   if (second_pass)
   {
     if (c->has_wide_sites)
       hipLaunchKernelGGL(gtx_score_wide_kernel, dim3(gtx_ctx::SCORE_BIG_THREADS / 64), dim3(64), 0, st, c->dev_graph, par, d_items, d_records,
-                         rec_words, a, c->d_error_flag, s->d_score_queue, gtx_ctx::SCORE_QUEUE_CAP, s->d_score_state,
+                         rec_words, a, c->d_error_flag, s->d_score_queue, gtx_ctx::SCORE_QUEUE_CAP, score_state,
                          static_cast<RecentHapWide *>(s->d_score_tables));
     else
       hipLaunchKernelGGL(gtx_score_big_kernel, dim3(gtx_ctx::SCORE_BIG_THREADS / 64), dim3(64), 0, st, c->dev_graph, par, d_items, d_records,
-                         rec_words, a, c->d_error_flag, s->d_score_queue, gtx_ctx::SCORE_QUEUE_CAP, s->d_score_state,
+                         rec_words, a, c->d_error_flag, s->d_score_queue, gtx_ctx::SCORE_QUEUE_CAP, score_state,
                          static_cast<RecentHap *>(s->d_score_tables));
     if (!hip_ok(hipGetLastError(), "gtx_score_big_kernel launch"))
       return GTX_ERR_HIP;

@@ -29,6 +29,15 @@ struct CallScratch
   // [5] forward tasks pass 2 did (those beyond [4] came straight from the position-hinted pass); [2] and [3] are one 64-bit
   // word for that pass' single add per workgroup
   uint32_t * d_counters = nullptr;
+  // TWO sets of them (round 6): a call counts in the set the call before it did not use and zeroes that one, behind its last
+  // launch on its last stream, for the call after it -- the reset used to be a hipMemsetAsync in FRONT of the position-hinted pass
+  // on the caller's stream: a fill kernel and the gaps around it, 25 us of an idle chip per step of 0.72 ms.  d_counters and
+  // the pointers into the set (d_big_state, d_wide_state, d_exact_state, d_span) name the set of the last call.
+  static constexpr uint32_t COUNTER_WORDS = 8 * 8 + 48 + 4, COUNTER_PITCH = 128; // (8 words x MAX_PARTS; big, wide, exact x 3: 8 words each; span: 2 x 64 bits)
+  uint32_t * d_counter_sets = nullptr; // [2][COUNTER_PITCH]
+  uint32_t counter_set = 0;            // the set of the last call
+  bool spare_set_clean = true;         // the other one is zero (false after a call that failed on its way)
+  bool has_big = false, has_wide = false;
   uint8_t * d_planes = nullptr;  // plane rows of a batch that came as BAM nibbles (gtx_align_batch; grow-only)
   uint64_t planes_cap = 0;
   uint32_t * d_queue1 = nullptr; // reads whose forward task the position-hinted pass declined (grow-only)
@@ -70,7 +79,9 @@ struct CallScratch
   static constexpr uint32_t EXACT_PART_SITES = 24;       // variant sites a path has room for while a task has a small part of the slab
   static constexpr uint32_t EXACT_PART_CANDIDATES = 8256; // ... and walk candidates (128 live sequences x 64 alleles + a round's slack)
   // second scoring pass (items whose reads touch more variant sites than the main pass' tables hold)
-  uint32_t * d_score_state = nullptr; // [0] items queued
+  uint32_t * d_score_state = nullptr; // two sets of 4 words, used in turn ([0] items queued, [2] the work queue's count): the triage kernel of a call zeroes the other set
+  uint32_t score_set = 0;
+  bool score_spare_clean = true;
   uint32_t * d_score_queue = nullptr;
   void * d_score_tables = nullptr;
   uint32_t * d_score_work = nullptr; // [0] number of items the triage kernel found worth scoring, [1..] their indices (grow-only)

@@ -193,8 +193,13 @@ extern "C"
       g_last_error = "gtx_scores_zero: buffers were not made by gtx_scores_alloc";
       return GTX_ERR_ARG;
     }
-    // (the log's content is defined by its count words)
-    if (hipMemsetAsync(b->d_stat_u64, 0, s.stat_u64 * 8 + s.u32_total() * 4 + 2 * 4, static_cast<hipStream_t>(stream)) != hipSuccess)
+    // (the log's content is defined by its count words -- so a few bytes of its first entry may be zeroed with them: the size is
+    //  rounded up to sixteen bytes where the log has an entry's room, and the runtime makes ONE fill kernel of it instead of an
+    //  aligned one and a tail; the block itself is aligned by the allocator)
+    uint64_t bytes = s.stat_u64 * 8 + s.u32_total() * 4 + 2 * 4;
+    if (b->conn_cap >= 1)
+      bytes = (bytes + 15u) & ~static_cast<uint64_t>(15u);
+    if (hipMemsetAsync(b->d_stat_u64, 0, bytes, static_cast<hipStream_t>(stream)) != hipSuccess)
     {
       g_last_error = "gtx_scores_zero: hipMemsetAsync failed";
       return GTX_ERR_HIP;
