@@ -157,6 +157,7 @@ struct gtx_ctx
   // drops the slots of an older epoch when it records again; a query reads the current epoch only, as often as it likes)
   uint32_t time_epoch = 0;
   bool epoch_queried = false;
+  uint32_t timed_seq = 0;  // calls since the context was made, counted for GTX_TIME_EVERY
   // index facts of a device-built index (gtx_index_dev.hip); its keys / labels in reference order stay on the device and
   // are downloaded into `index` when an inspection entry point asks for them
   uint32_t n_keys = 0, n_labels = 0;
