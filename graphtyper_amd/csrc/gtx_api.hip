@@ -1034,14 +1034,55 @@ __global__ __launch_bounds__(TRIAGE_THREADS) void gtx_score_triage_kernel(gtx_sc
   uint32_t const first = blockIdx.x * (TRIAGE_THREADS * TRIAGE_PER_THREAD);
   bool work[TRIAGE_PER_THREAD];
   unsigned long long mask[TRIAGE_PER_THREAD];
+  // Three rounds, each round's loads independent of one another: the item words, then the side bytes they name, then -- only for
+  // items that are not one forward-only read, none in most batches -- the items themselves.  (Written as one loop -- word, branch
+  // on it, side byte -- the sixteen pairs of loads of a thread were sixteen pairs of round trips one after the other: 52 us for
+  // 10 M items, a kernel that moves 60 MB; round 6.)
+  uint32_t word[TRIAGE_PER_THREAD];
 #pragma unroll
   for (uint32_t k = 0; k < TRIAGE_PER_THREAD; ++k)
   {
     uint32_t const i = first + k * TRIAGE_THREADS + threadIdx.x;
     // (gtx_score_batch_words: the read of an item of one forward-only read is in the compact array -- 4 bytes instead of 40)
-    uint32_t const w = item_words && i < n_items ? item_words[i] : GTX_ITEM_WORD_FULL;
-    work[k] = i < n_items && (w != GTX_ITEM_WORD_FULL ? (task_flags[2ull * w] & GTX_TASK_HAS_VARIANTS) != 0
-                                                      : !item_is_trivial(items[i], records, rec_words, keeps_depth != 0, task_flags));
+    word[k] = item_words && i < n_items ? item_words[i] : GTX_ITEM_WORD_FULL;
+  }
+  bool any_full = false;
+  if (task_flags)
+  {
+    uint8_t side[TRIAGE_PER_THREAD];
+#pragma unroll
+    for (uint32_t k = 0; k < TRIAGE_PER_THREAD; ++k)
+      side[k] = task_flags[word[k] != GTX_ITEM_WORD_FULL ? 2ull * word[k] : 0ull]; // (a full item's byte is not looked at: any address that can be read)
+#pragma unroll
+    for (uint32_t k = 0; k < TRIAGE_PER_THREAD; ++k)
+    {
+      work[k] = word[k] != GTX_ITEM_WORD_FULL && (side[k] & GTX_TASK_HAS_VARIANTS) != 0;
+      any_full = any_full || (word[k] == GTX_ITEM_WORD_FULL && first + k * TRIAGE_THREADS + threadIdx.x < n_items);
+    }
+  }
+  else
+  {
+#pragma unroll
+    for (uint32_t k = 0; k < TRIAGE_PER_THREAD; ++k)
+    {
+      work[k] = false;
+      any_full = any_full || first + k * TRIAGE_THREADS + threadIdx.x < n_items; // (without the side array no item has a word)
+    }
+  }
+  if (__ballot(any_full) != 0ull)
+  {
+    // (one copy of the item's test, the word read again: this loop is not unrolled -- sixteen copies cost 38 registers)
+    uint32_t full_work = 0;
+#pragma unroll 1
+    for (uint32_t k = 0; k < TRIAGE_PER_THREAD; ++k)
+    {
+      uint32_t const i = first + k * TRIAGE_THREADS + threadIdx.x;
+      if (i < n_items && (!task_flags || !item_words || item_words[i] == GTX_ITEM_WORD_FULL))
+        full_work |= static_cast<uint32_t>(!item_is_trivial(items[i], records, rec_words, keeps_depth != 0, task_flags)) << k;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < TRIAGE_PER_THREAD; ++k)
+      work[k] = work[k] || ((full_work >> k) & 1u) != 0u;
   }
 #pragma unroll
   for (uint32_t k = 0; k < TRIAGE_PER_THREAD; ++k)
