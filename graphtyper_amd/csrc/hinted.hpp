@@ -41,6 +41,15 @@ void hint_note(uint32_t code);
 #define GTX_HINT_NOTE(code) ((void)0)
 #endif
 
+// (experiment builds only, -DGTX_X_STOP_AT=n: hinted_on_path ends behind its n-th part with a value that hangs on what the part
+//  computed -- wrong results by design; the kernel's instruction counters then say what the parts up to there cost.  tools/pmc_main.sh)
+#ifdef GTX_X_STOP_AT
+#define GTX_X_STOP(n, v)                                                                                                          \
+  if (GTX_X_STOP_AT == (n))                                                                                                      \
+  return static_cast<uint32_t>((v) == 0xA5A5A5A5u ? 2u : 0u)
+#else
+#define GTX_X_STOP(n, v) ((void)0)
+#endif
 constexpr uint32_t HINT_MAX_READ = 160; // bases (20 words); longer reads are left to express4
 constexpr uint32_t HINT_WORDS = HINT_MAX_READ / 8;
 
@@ -763,8 +772,10 @@ GTX_DEV uint32_t hinted_on_path(GraphView const & g, IndexView const & ix, Row r
   uint2_t const f4 = ix.pos_flags[idx + (n_k > 4 ? 4 * (K - 1) : 0u)];
   uint32_t const y_end = ix.pos_flags[idx + (K - 1) * n_k].y; // the position behind the last k-mer (31 n_k <= L - 1: inside the read)
   uint2_t const t_end = ix.tail_info[idx + (K - 1) * n_k];    // ... and the site behind its reference node
+  GTX_X_STOP(0, f0.x ^ f1.y ^ f2.x ^ f3.y ^ f4.x ^ y_end ^ t_end.x ^ t_end.y ^ refw[0]);
   hint_compare(row, seq_stride, refw, sh, L, h);
   mm_all = hc_all(h);
+  GTX_X_STOP(1, h.k[0] ^ h.k[1] ^ h.k[2] ^ h.k[3] ^ h.k[4] ^ h.upto ^ h.more ^ f0.x ^ f1.y ^ f2.x ^ f3.y ^ f4.x ^ y_end ^ t_end.x);
   // ---- every k-mer: the label of its place, no label at all, or not provable
   uint32_t const none = hk_make(HINT_K_HOLE, HINT_NO_SITE, 0u, false, false);
   uint32_t amb2 = 0; // k-mers with one ambiguous base in each half: three more filter probes (below)
@@ -775,6 +786,7 @@ GTX_DEV uint32_t hinted_on_path(GraphView const & g, IndexView const & ix, Row r
   if ((k0 & 3u) == HINT_K_DECLINE || (k1 & 3u) == HINT_K_DECLINE || (k2 & 3u) == HINT_K_DECLINE || (k3 & 3u) == HINT_K_DECLINE ||
       (k4 & 3u) == HINT_K_DECLINE)
     return false;
+  GTX_X_STOP(2, k0 ^ (k1 << 1) ^ (k2 << 2) ^ (k3 << 3) ^ (k4 << 4) ^ amb2 ^ h.upto ^ h.more ^ y_end ^ t_end.x);
   if ((k0 | k1 | k2 | k3 | k4) & (HK_NEED_LEFT | HK_NEED_RIGHT))
   {
     // ---- the filter probes of all k-mers together: one round trip
@@ -853,6 +865,7 @@ GTX_DEV uint32_t hinted_on_path(GraphView const & g, IndexView const & ix, Row r
       return false;
     }
   }
+  GTX_X_STOP(3, k0 ^ (k1 << 1) ^ (k2 << 2) ^ (k3 << 3) ^ (k4 << 4) ^ amb2 ^ h.upto ^ h.more ^ y_end ^ t_end.x);
   auto bits = [&](uint32_t flag, uint32_t want) // one bit per k-mer
   {
     return ((k0 & flag) == want ? 1u : 0u) | ((k1 & flag) == want ? 2u : 0u) | ((k2 & flag) == want ? 4u : 0u) | ((k3 & flag) == want ? 8u : 0u) |
@@ -962,6 +975,7 @@ GTX_DEV uint32_t hinted_on_path(GraphView const & g, IndexView const & ix, Row r
   }
   uint32_t const run = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
   uint32_t mism = static_cast<uint32_t>(__builtin_popcount(mmk & run));
+  GTX_X_STOP(4, lo ^ (hi << 3) ^ (mism << 6) ^ (two_rs << 9) ^ (two_re << 17) ^ (two_mism << 25) ^ k0 ^ k1 ^ k2 ^ k3 ^ k4 ^ h.upto ^ h.more ^ y_end ^ t_end.x ^ static_cast<uint32_t>(decided) ^ static_cast<uint32_t>(par_start));
   // ---- the read in front of the run and behind it: the walks' shortcut, both inside the reference node the path touches
   uint32_t const prs = (K - 1) * lo, pre = (K - 1) * (hi + 1);
   uint32_t start = order_of(idx + prs), rs = prs;
@@ -1147,6 +1161,7 @@ GTX_DEV uint32_t hinted_on_path(GraphView const & g, IndexView const & ix, Row r
     else
       tail_mask = tail_mask2 = 0; // (the path stays as it is: no site from the walk)
   }
+  GTX_X_STOP(5, start ^ (end << 1) ^ (rs << 3) ^ (re << 11) ^ (mism << 20) ^ tail_site ^ tail_mask ^ tail_mask2 ^ head_site ^ head_mask ^ k0 ^ k1 ^ k2 ^ k3 ^ k4);
   // ---- variant sites of the path, most recent k-mer first (Path(p1, p2), path.cpp:38-82); a site under two
   //      neighbouring k-mers is one entry (the same base, hence the same allele)
   uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0; // site << 16 | allele mask (named registers: an indexed array would live in scratch)
