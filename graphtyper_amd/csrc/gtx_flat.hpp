@@ -209,6 +209,14 @@ constexpr uint32_t HINT_SNP_GROUP = 1u << 21, HINT_REFB_SHIFT = 22u, HINT_NV_SHI
 // least 4, 3 = at least 8 or there is none.  A read k-mer m substitutions from K_i inside one half can only meet keys of the
 // other half's group, and those are within m (exact hit) / m + 1 (Hamming-1 neighbour) of K_i: HINT_FAR_NEED(m) rules them out.
 constexpr uint32_t HINT_FAR_LEFT_SHIFT = 27u, HINT_FAR_RIGHT_SHIFT = 29u;
+// y bit 31, HINT_NEAR_FREE (round 6): the half-key filters say "absent" for EVERY 16-mer that is one substitution away from the first
+// or from the last 16 bases of the reference k-mer at the position (2 x 16 x 3 probes, made once when the tables are built).  A read
+// k-mer whose half differs from the reference's there in exactly one unambiguous base would probe one of those 96: the answer is
+// known, the probe -- a random 4-byte look into an 8 MB table, a sector of traffic per look and a quarter of what the
+// position-hinted pass fetched -- is not made.  The pass decides exactly what it decided with the probe (the flag IS the probes'
+// outcome); where a variant is in the filter (a SNP's other allele, a chance hit: 2-3 % of the positions) the flag is clear and
+// the probe is made as before.
+constexpr uint32_t HINT_NEAR_FREE = 1u << 31;
 #if defined(__HIPCC__)
 __host__ __device__
 #endif

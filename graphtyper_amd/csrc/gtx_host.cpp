@@ -848,19 +848,23 @@ static void build_hints(HostGraph const & g, HostIndex & out)
       hint_filter_slot(w0, w1, fl, word, mask);
       out.filt[side][word] |= mask;
     }
-  // per position
+  // per position (the flags look at the filters: HINT_NEAR_FREE)
+  HintKeys tf = t;
+  tf.filt0 = out.filt[0].data();
+  tf.filt1 = out.filt[1].data();
+  tf.filt_log2 = fl;
   GraphView const gv = g.view();
   out.pos_flags.assign(total, uint2_t{0, 0}); // (every position of the linear reference and of the windows is written below; the padding stays 0)
   parallel_slices(n, host_threads(), [&](unsigned, std::size_t b, std::size_t e) {
     for (std::size_t p = b; p < e; ++p)
-      out.pos_flags[p] = hint_position_flags(gv, t, nb.data(), nb_same.data(), base.data(), room.data(), back.data(), n, static_cast<uint32_t>(p));
+      out.pos_flags[p] = hint_position_flags(gv, tf, nb.data(), nb_same.data(), base.data(), room.data(), back.data(), n, static_cast<uint32_t>(p));
   });
   parallel_slices(n_win, host_threads(), [&](unsigned, std::size_t b, std::size_t e) {
     for (std::size_t w = b; w < e; ++w)
       for (uint32_t local = 0; local < HINT_WIN_STRIDE; ++local)
       {
         uint32_t const p = out.win_base + static_cast<uint32_t>(w) * HINT_WIN_STRIDE + local;
-        out.pos_flags[p] = hint_window_flags(gv, t, nb.data(), nb_same.data(), base.data(), room.data(), back.data(), static_cast<uint32_t>(total),
+        out.pos_flags[p] = hint_window_flags(gv, tf, nb.data(), nb_same.data(), base.data(), room.data(), back.data(), static_cast<uint32_t>(total),
                                              out.pos_flags.data(), n, out.win[w], local, p);
       }
   });

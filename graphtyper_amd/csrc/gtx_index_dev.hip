@@ -734,13 +734,18 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<Em
       hipLaunchKernelGGL(k_judge_keys, dim3(blocks_for(n_keys)), dim3(TB), 0, gtx::tls_build_stream, t, d_nb, d_same, d_f0, d_f1, fl, d_pk,
                          (nbk && nbk[0] == '0') ? static_cast<IndexSlot *>(nullptr) : d_slots, log2_cap);
     }
-    hipLaunchKernelGGL(k_position_flags, dim3(blocks_for(hint_n)), dim3(TB), 0, gtx::tls_build_stream, c.dev_graph, t, d_nb, d_same, d_base, d_room, d_back, hint_n, d_flags);
+    // (the flags look at the filters k_judge_keys has just filled, in stream order: HINT_NEAR_FREE)
+    HintKeys tf = t;
+    tf.filt0 = d_f0;
+    tf.filt1 = d_f1;
+    tf.filt_log2 = fl;
+    hipLaunchKernelGGL(k_position_flags, dim3(blocks_for(hint_n)), dim3(TB), 0, gtx::tls_build_stream, c.dev_graph, tf, d_nb, d_same, d_base, d_room, d_back, hint_n, d_flags);
     if (n_win)
     {
       uint32_t const cells = n_win * HINT_WIN_STRIDE;
       hipLaunchKernelGGL(k_window_cells, dim3((cells + TB - 1) / TB), dim3(TB), 0, gtx::tls_build_stream, c.dev_graph, d_win, n_win, win_base, hint_n, d_base, d_room, d_back,
                          d_tail, d_refp);
-      hipLaunchKernelGGL(k_window_flags, dim3((cells + TB - 1) / TB), dim3(TB), 0, gtx::tls_build_stream, c.dev_graph, t, d_nb, d_same, d_base, d_room, d_back,
+      hipLaunchKernelGGL(k_window_flags, dim3((cells + TB - 1) / TB), dim3(TB), 0, gtx::tls_build_stream, c.dev_graph, tf, d_nb, d_same, d_base, d_room, d_back,
                          static_cast<uint32_t>(hint_total), hint_n, d_win, n_win, win_base, d_flags);
     }
   }

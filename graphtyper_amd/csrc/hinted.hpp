@@ -361,7 +361,7 @@ GTX_DEV uint32_t hk_make(uint32_t kind, uint32_t site, uint32_t allele, bool mm,
 constexpr uint32_t HK_NEED_LEFT = 64u, HK_NEED_RIGHT = 128u;
 
 template <uint32_t I, bool DENSE, class Row, class Counts>
-GTX_DEV uint32_t hint_kmer(uint2_t const f, Row row, Counts const & h, uint32_t & amb2) // (Counts: HintCounts, or hinted_long.hpp's for eight k-mers)
+GTX_DEV uint32_t hint_kmer_judge(uint2_t const f, Row row, Counts const & h, uint32_t & amb2) // (Counts: HintCounts, or hinted_long.hpp's for eight k-mers)
 {
   constexpr uint32_t A = (K - 1) * I;
   uint32_t mis = hc_get(h.k[I], HC_MIS), mis_left = hc_get(h.k[I], HC_MIS_LEFT);
@@ -550,6 +550,27 @@ GTX_DEV uint32_t hint_kmer(uint2_t const f, Row row, Counts const & h, uint32_t 
   }
   GTX_HINT_NOTE(ok ? 0 : 12);
   return hk_make(ok ? HINT_K_HOLE : HINT_K_DECLINE, site, 0u, false, true) | (ok ? need : 0u);
+}
+
+// ... and the probes whose answer the tables already hold (HINT_NEAR_FREE, gtx_flat.hpp): a half of the read's k-mer that differs
+// from the reference's in exactly one unambiguous base and holds no ambiguous one IS one of the 48 neighbours of that half the
+// filter was asked about when the flags were made -- absent, every one of them.  The verdict no longer hangs on that half.
+template <uint32_t I, bool DENSE, class Row, class Counts>
+GTX_DEV uint32_t hint_kmer(uint2_t const f, Row row, Counts const & h, uint32_t & amb2)
+{
+  uint32_t v = hint_kmer_judge<I, DENSE>(f, row, h, amb2);
+#ifndef GTX_NO_NEAR_FREE // (A/B build: every probe is made)
+  if ((v & (HK_NEED_LEFT | HK_NEED_RIGHT)) != 0 && (f.y & HINT_NEAR_FREE) != 0)
+  {
+    uint32_t const mis_left = hc_get(h.k[I], HC_MIS_LEFT), mis_right = hc_get(h.k[I], HC_MIS) - mis_left;
+    uint32_t const amb_left = hc_get(h.k[I], HC_AMB_LEFT), amb_right = hc_get(h.k[I], HC_AMB) - amb_left;
+    if (mis_left == 1 && amb_left == 0)
+      v &= ~HK_NEED_LEFT;
+    if (mis_right == 1 && amb_right == 0)
+      v &= ~HK_NEED_RIGHT;
+  }
+#endif
+  return v;
 }
 
 // filter probe of one half of k-mer I when the verdict hangs on it: where to look ...

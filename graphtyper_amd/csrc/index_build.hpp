@@ -27,7 +27,24 @@ struct HintKeys
   uint32_t const * rorder;
   uint32_t const * rbegin;
   uint32_t const * rsize;
+  // the half-key filters, once they are made (hint_flags_at: HINT_NEAR_FREE; nullptr while they are not: the bit stays clear)
+  uint32_t const * filt0 = nullptr;
+  uint32_t const * filt1 = nullptr;
+  uint32_t filt_log2 = 0;
 };
+
+// 16 bases (2 bits each, first base in the top bits) as the two planes the kernel hashes (hint_filter_slot): bit j of
+// w0 / w1 = low / high bit of base j
+GTX_HD void hint_half_planes(uint32_t half, uint32_t & w0, uint32_t & w1)
+{
+  w0 = w1 = 0;
+  for (uint32_t j = 0; j < 16; ++j)
+  {
+    uint32_t const two = (half >> (30 - 2 * j)) & 3u;
+    w0 |= (two & 1u) << j;
+    w1 |= (two >> 1) << j;
+  }
+}
 
 GTX_HD bool hint_distance1(uint64_t a, uint64_t b) // exactly one base differs
 {
@@ -219,6 +236,26 @@ GTX_HD uint2_t hint_flags_at(GraphView const & g, HintKeys const & t, uint32_t c
     uint32_t const c = base[p + j];
     valid = hint_is_acgt(c);
     key = (key << 2) | hint_two_bits(c);
+  }
+  // nobody a substitution away from one of the reference k-mer's halves is in the filters (HINT_NEAR_FREE, gtx_flat.hpp)
+  if (valid && t.filt0 && t.filt1)
+  {
+    bool near_free = true;
+    for (uint32_t side = 0; side < 2 && near_free; ++side)
+    {
+      uint32_t p0, p1; // the half as the two planes the kernel hashes: base j at bit j
+      hint_half_planes(static_cast<uint32_t>(side == 0 ? key >> 32 : key), p0, p1);
+      uint32_t const * const f = side == 0 ? t.filt0 : t.filt1;
+      for (uint32_t j = 0; j < 16 && near_free; ++j)
+        for (uint32_t d = 1; d < 4 && near_free; ++d) // (base j becomes another one: its two bits change by d)
+        {
+          uint32_t word, mask;
+          hint_filter_slot(p0 ^ ((d & 1u) << j), p1 ^ ((d >> 1) << j), t.filt_log2, word, mask);
+          near_free = (f[word] & mask) != mask;
+        }
+    }
+    if (near_free)
+      y |= HINT_NEAR_FREE;
   }
   uint32_t k = 0;
   bool const found = valid && hint_find_key(t, key, k);
@@ -419,19 +456,6 @@ GTX_HD uint2_t hint_window_flags(GraphView const & g, HintKeys const & t, uint32
     return m < n_main ? main_flags[m] : none;
   }
   return hint_flags_at(g, t, nb, nb_same, base, room, back, n_total, p, hint_win_order(g, w, local), hint_win_order(g, w, local + K - 1), false);
-}
-
-// 16 bases (2 bits each, first base in the top bits) as the two planes the kernel hashes (hint_filter_slot): bit j of
-// w0 / w1 = low / high bit of base j
-GTX_HD void hint_half_planes(uint32_t half, uint32_t & w0, uint32_t & w1)
-{
-  w0 = w1 = 0;
-  for (uint32_t j = 0; j < 16; ++j)
-  {
-    uint32_t const two = (half >> (30 - 2 * j)) & 3u;
-    w0 |= (two & 1u) << j;
-    w1 |= (two >> 1) << j;
-  }
 }
 
 } // namespace gtx
