@@ -578,7 +578,14 @@ class Workload:
         n_lanes = len(self.lanes) if (stag or not exchange) else 1
         # (setup, not steps of the run: the first calls that are in flight together allocate their scratch inside the library)
         self.calibration = None
-        if stag:
+        if stag and os.environ.get("GTX_BENCH_CALIBRATE", "1") == "0":
+            # (tools/profile.sh: under a kernel trace the calibration's other schedules -- whole steps in flight: three launches of the
+            #  position-hinted pass side by side, a millisecond each -- would be in the trace's averages)
+            self.steps_staggered(2 * n_lanes)
+            self.steps_done -= 2 * n_lanes
+            torch.cuda.synchronize()
+            self.calibration = {"skipped": "GTX_BENCH_CALIBRATE=0: the staggered schedule as it is"}
+        elif stag:
             self.steps_staggered(2 * n_lanes)  # (twice round: every lane's scratch and the context's exact-pass slabs exist afterwards)
             self.steps_done -= 2 * n_lanes
             torch.cuda.synchronize()

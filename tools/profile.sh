@@ -11,7 +11,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
-timeout 170 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o bench -- python $REPO/bench.py --reads $READS --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $OUT/bench_trace.log 2>&1
+# (the staggered schedule alone, twenty timed steps: the calibration's whole-steps schedule overlaps launches of one kernel with each other)
+GTX_BENCH_CALIBRATE=0 timeout 170 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o bench -- python $REPO/bench.py --reads $READS --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $OUT/bench_trace.log 2>&1
 timeout 170 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $OUT/pmc_sq -o bench -- python $REPO/bench.py --reads $READS --steps 1 --warmup 0 --lanes 1 --no-cpu-baseline --no-extra > $OUT/bench_pmc_sq.log 2>&1
 timeout 170 rocprofv3 --output-format csv --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT -d $OUT/pmc_sq2 -o bench -- python $REPO/bench.py --reads $READS --steps 1 --warmup 0 --lanes 1 --no-cpu-baseline --no-extra > $OUT/bench_pmc_sq2.log 2>&1
 timeout 170 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o bench -- python $REPO/bench.py --reads $READS --steps 1 --warmup 0 --lanes 1 --no-cpu-baseline --no-extra > $OUT/bench_pmc_fetch.log 2>&1
