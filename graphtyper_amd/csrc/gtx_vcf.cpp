@@ -2139,6 +2139,14 @@ extern "C" int gtx_vcf_records_final(const gtx_ctx * c, const gtx_vcf_request * 
     }
     else
     {
+      // (break_down_skyr, variant.cpp:2113-2190: an alternative allele nobody is called with is handed to paw::Skyr as the
+      //  reference allele, :2137-2155 -- when that is all of them there is nothing to find and the site leaves no record: the one
+      //  case that does not hang on the absent library)
+      bool carried = false;
+      for (uint32_t s = 0; s < ns && !carried; ++s)
+        carried = st.calls[s].c->gt_first != 0 || st.calls[s].c->gt_second != 0;
+      if (!carried)
+        continue;
       gtx::g_last_error = "gtx_vcf_records_final: the site at " + std::to_string(st.pos) + " has alleles of different lengths: the reference breaks it "
                           "down with paw::Skyr (variant.cpp:2113-2190), whose source its tree does not hold -- no_variant_overlapping writes such sites whole";
       return GTX_ERR_UNSUPPORTED;

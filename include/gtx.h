@@ -525,7 +525,10 @@ int gtx_vcf_records(const gtx_ctx *, const gtx_vcf_request *, char * out, uint64
  * unless no_filter_bad_alts) and written by Vcf::write_records in the reference's windows.  Alleles of DIFFERENT lengths go
  * through paw::Skyr in the reference (break_down_skyr, :2113-2190), a library its tree does not hold: with no_variant_overlapping
  * (the reference's --no_variant_overlapping, and the second file of --normal_and_no_variant_overlapping) such a site is written
- * whole, as the reference writes it then; without it the call returns GTX_ERR_UNSUPPORTED when the graph has such a site.
+ * whole, as the reference writes it then; without it the call returns GTX_ERR_UNSUPPORTED when the graph has such a site that
+ * SOMEBODY IS CALLED WITH AN ALTERNATIVE ALLELE OF (a site nobody carries is handed to paw::Skyr as the reference allele throughout,
+ * :2137-2155, and leaves no record: that case is made).  A host that wants the reference's default file for a region with carried
+ * indels has to take the no_variant_overlapping one and decompose those sites itself.
  * Graphs of SNPs (cfg2) have none: both modes are the reference's file.  First line: the column line.  Not for SV graphs. */
 int gtx_vcf_records_final(const gtx_ctx *, const gtx_vcf_request *, int no_variant_overlapping, int no_filter_bad_alts, char * out, uint64_t cap,
                           uint64_t * len);

@@ -760,7 +760,8 @@ inline std::vector<Variant> break_multi_snps(Variant && var)
 // break_down_variant (variant.cpp:1652-1713) without --no_decompose / --is_all_biallelic.  Alleles of different lengths go through
 // paw::Skyr in the reference (break_down_skyr, :2113-2190), whose source is not in its tree: with no_variant_overlapping -- the
 // reference's own option, and the second file of --normal_and_no_variant_overlapping -- such a site stays whole; without it this
-// restatement refuses (std::runtime_error).
+// restatement refuses (std::runtime_error) -- unless nobody is called with an alternative allele of the site: then Skyr is handed
+// the reference allele throughout and the site leaves no record (below).
 inline std::vector<Variant> break_down_variant(Variant && var, RegionReference const & rr, bool no_variant_overlapping)
 {
   std::vector<Variant> out;
@@ -780,7 +781,22 @@ inline std::vector<Variant> break_down_variant(Variant && var, RegionReference c
     return break_multi_snps(std::move(var));
   }
   if (!no_variant_overlapping)
+  {
+    // break_down_skyr (variant.cpp:2113-2190) counts who is called with which allele (:2137-2147) and hands paw::Skyr the reference
+    // allele in place of every alternative allele nobody is called with (:2151-2155).  When that is ALL of them the sequences are
+    // alike, there is nothing to find and the loop over skyr.vars (:2162) makes no variant: the one case of that function that
+    // does not hang on the absent library's alignment.
+    std::vector<int> ac(var.seqs.size(), 0);
+    for (auto const & call : var.calls)
+    {
+      auto const gt = call.get_gt_call();
+      ac[gt.first]++;
+      ac[gt.second]++;
+    }
+    if (std::all_of(ac.begin() + 1, ac.end(), [](int n) { return n == 0; }))
+      return out;
     throw std::runtime_error("break_down_skyr (variant.cpp:2113-2190) needs paw::Skyr, which the reference's tree does not hold");
+  }
   out.push_back(std::move(var));
   return out;
 }

@@ -239,6 +239,7 @@ def run_stream(backend, oracle, codes, rec, n_samples, n_rg=1):
         # refuse without it
         names = ["SAMP%02d" % i for i in range(n_samples)]
         o_ = og.o
+        run_stream.final_by_mode = {}
         for nvo in (True, False):
             try:
                 want_final = og.vcf_records_final("chrT", names, o_.reference, o_.region_begin + 1, no_variant_overlapping=nvo)
@@ -254,6 +255,7 @@ def run_stream(backend, oracle, codes, rec, n_samples, n_rg=1):
                 raise AssertionError("final VCF (no_variant_overlapping=%s) differs (%d vs %d lines), first at line %s:\n%r\n%r" %
                                      (nvo, len(gl), len(wl), bad[:1], gl[bad[0]][:300] if bad else b"", wl[bad[0]][:300] if bad else b""))
             run_stream.final = got_final
+            run_stream.final_by_mode[nvo] = got_final
         # the sites the next iteration's graph is built from: vcf_merge_and_filter (vcf_operations.cpp:278-478) with the flags above
         got_sites = backend.ctx.vcf_sites("chrT", n_samples, acc.gt_cov, acc.stat_u64, acc.stat_u32, phred, calls, ph)
         want_sites = og.vcf_sites("chrT")

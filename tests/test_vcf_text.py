@@ -269,3 +269,33 @@ def test_final_vcf_of_a_snp_graph_is_the_called_part_of_the_records():
         f = l.decode().split("\t")
         info = dict(kv.split("=", 1) for kv in f[7].split(";"))
         assert info["AC"] == "0" or float(info["QDalt"]) < 1.0 or int(info["MaxAAS"]) < 2, l[:200]
+
+
+def test_final_vcf_of_indel_sites_nobody_carries():
+    """break_down_skyr (variant.cpp:2113-2190) hands paw::Skyr the reference allele in place of every alternative allele nobody is
+    called with (:2137-2155): when that is all of a site's alleles there is nothing to find and the site leaves no record -- the one
+    case of that function that does not hang on the absent library.  A SNP graph with two deletions and an insertion that none of the
+    reads carries: the final file WITHOUT no_variant_overlapping is made (it was refused), equals the oracle's (inside run_stream)
+    and holds no record at those sites; a site somebody carries is still refused (test_emu_parity's indel scenarios)."""
+    rb = 310000
+    ref, recs, codes, rec = scenarios.paired_case("snp100", n_ref=6000, n_pairs=2400, region_begin=rb, n_samples=4, lowq_frac=0.03)
+    snps = {p0 for p0, _, _, _ in recs}
+    extra = []
+    for p0, kind in ((rb + 1234, "del"), (rb + 2950, "ins"), (rb + 4321, "del")):
+        while any(abs(p0 - q) < 40 for q in snps):
+            p0 += 1
+        at = p0 - rb
+        if kind == "del":
+            extra.append((p0, ref[at:at + 5], [ref[at]], None))
+        else:
+            extra.append((p0, ref[at], [ref[at] + "GATTACA"], None))
+    recs2 = sorted(list(recs) + extra, key=lambda r: r[0])
+    o = Oracle(ref, recs2, region_begin=rb)
+    b = harness.EmuBackend(gtx.graph_from_records(ref, recs2, region_begin=rb))
+    run_stream(b, o, codes, rec, n_samples=4)  # (compares gtx_vcf_records_final with the oracle's in both modes; neither may refuse)
+    assert set(run_stream.final_by_mode) == {True, False}, "the mode without no_variant_overlapping was refused"
+    final = run_stream.final_by_mode[False].split(b"\n")[1:-1]
+    whole = run_stream.vcf_full.split(b"\n")[1:-1]
+    at = {int(l.split(b"\t")[1]) for l in final}
+    assert len(final) > 10 and not any(p0 + 1 in at for p0, _, _, _ in extra)
+    assert any(int(l.split(b"\t")[1]) == extra[0][0] + 1 for l in whole)  # (the whole records have the sites)
