@@ -41,6 +41,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ALGO_BYTES_PER_READ = 3296  # B(L) = 86 + 796*n_k + (L - 31*n_k) at L=150, n_k=4
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+EXCHANGE_STREAM = os.environ.get("GTX_BENCH_EXCHANGE_STREAM", "1") != "0"  # N > 1, staggered schedule: the exchange and the calls on a stream of their own
 # Timing is sampled: ONE step in four carries the events that time it -- the pair around an align call here, the library's events
 # around every launch of the call (GTX_TIME_EVERY, read by libgtx when it is loaded; gtx_ctx_kernel_times gives the means over the
 # timed calls).  An event is a packet the stream carries between two kernels: with every call timed the cfg2 step took 0.712 ms,
@@ -477,8 +478,29 @@ class Workload:
             for ev in after:
                 stream.wait_event(ev)
             fl = ln["d_flags"].data_ptr() if ln["d_flags"] is not None else None
+            exchange = self.comm is not None or self.dist is not None
+            if exchange and EXCHANGE_STREAM:
+                stream.wait_event(ln["scored"])  # (the lane's block was last read by the calls of its step before, on the exchange's stream)
             gtx.check(L.gtx_scores_zero(ctx.h, C.byref(ln["buf"]), sp))  # (on the tail stream behind the step's short queues instead: 0.737 against 0.712 ms per step)
             self._score_call(ln["items"], ln["d_rec"], fl, ln["buf"], sp, ln["d_compact"])
+            if exchange and EXCHANGE_STREAM:
+                # N > 1: the sum over the ranks and the calls from the summed block go to a stream of their own -- the exchange is
+                # 36 MB over xGMI (cfg4: 1000 samples), link-bound and all but idle on the CUs, and on the stream that carries the
+                # position-hinted passes it held the next one back for its whole length.  One communicator, one stream: the
+                # exchange steps of the steps keep their order.  (GTX_BENCH_EXCHANGE_STREAM=0: on the scoring's stream, as before.)
+                if not hasattr(self, "exchange_stream"):
+                    self.exchange_stream = torch.cuda.Stream(device=self.device)
+                    self.exchange_ready = [torch.cuda.Event() for _ in self.lanes]
+                R = self.exchange_stream
+                ready = self.exchange_ready[self.lanes.index(ln)]
+                ready.record(stream)
+                with torch.cuda.stream(R):
+                    R.wait_event(ready)
+                    spR = C.c_void_p(R.cuda_stream)
+                    self._reduce(ln, R, spR)
+                    gtx.check(L.gtx_calls_batch(ctx.h, C.byref(ln["buf"]), ln["d_phred"].data_ptr(), ln["d_calls"].data_ptr(), spR))
+                    ln["scored"].record(R)
+                return
             self._reduce(ln, stream, sp)
             gtx.check(L.gtx_calls_batch(ctx.h, C.byref(ln["buf"]), ln["d_phred"].data_ptr(), ln["d_calls"].data_ptr(), sp))
             ln["scored"].record(stream)
@@ -1703,6 +1725,15 @@ def main(argv=None):
         w.steps_done = 0
         w.step(0)
         summed = w.block_digest(0)
+        # ... and the same read set through the schedule the timed steps ran: the exchange there is on a stream of its own
+        # (Workload._score), which the step above does not touch
+        summed_staggered = None
+        if w.staggered and len(w.lanes) >= 2:
+            w.steps_done = 0
+            w.steps_staggered(1)
+            torch.cuda.synchronize()
+            w.steps_done = 0
+            summed_staggered = w.block_digest(0)
         # (the one order-dependent step of the scoring, across ranks: nothing to do at cfg4's 12x per sample, but it is the path
         #  a deeper job takes -- tests/test_saturation.py, tests/test_dist_gloo.py hold it to the oracle)
         replayed = None
@@ -1733,8 +1764,9 @@ def main(argv=None):
             alone = hashlib.sha256(sum64.tobytes() + sum32.tobytes()).hexdigest()
             reduce_check = {"what": "block of read set 0 summed over the ranks (gtx_scores_reduce) against the same %d read sets run one after the other "
                                     "on rank 0's GPU and added on the host, no exchange" % world,
-                            "summed_sha256": summed, "one_gpu_sha256": alone, "equal": summed == alone, "saturation_guard_replay_across_ranks": replayed, "seconds": round(time.perf_counter() - t0, 2)}
-            if summed != alone:
+                            "summed_sha256": summed, "one_gpu_sha256": alone, "equal": summed == alone and summed_staggered in (None, alone),
+                            "summed_in_the_timed_schedule_sha256": summed_staggered, "saturation_guard_replay_across_ranks": replayed, "seconds": round(time.perf_counter() - t0, 2)}
+            if summed != alone or summed_staggered not in (None, alone):
                 sys.stderr.write("[bench] THE SUMMED BLOCK DIFFERS from the one-GPU block of the same reads\n")
         dist.barrier()
 
