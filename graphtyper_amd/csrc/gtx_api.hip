@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_WIDE_WAV
 #else
 #define GTX_HINT_REC_SLOT(read) (read)
 #endif
-template <uint32_t WAVES, bool DENSE, uint32_t NK = AlignCfg::KC>
+template <uint32_t WAVES, bool DENSE, uint32_t NK = AlignCfg::KC, bool META_LDS = true>
 __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const & ix, uint8_t const * __restrict__ seq, uint32_t seq_stride,
                                             gtx_read_meta const * __restrict__ meta, uint32_t n_reads, uint32_t * __restrict__ records,
                                             uint32_t rec_words, uint32_t force_both, uint32_t * __restrict__ queue1, uint32_t * __restrict__ queue2,
@@ -440,20 +440,38 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
   // (rows of 128 bytes -- the eight-k-mer build -- lie one vector apart: 32-word rows would put every lane's word on two banks)
   constexpr uint32_t ROW_PITCH = NK == AlignCfg::KC ? ROW_VEC : ROW_VEC + 1;
   __shared__ uint4_t s_seq[WAVES][64 * ROW_PITCH];
-  __shared__ uint32_t s_meta[WAVES][64 * META_WORDS];
-  __shared__ uint32_t s_count[2][WAVES], s_base[2];
+  // (META_LDS = false, the lean build: every lane fetches its own meta record -- twenty bytes at a stride of twenty, the
+  //  wavefront's 1 280 bytes still ten whole lines -- and the workgroup's 5 KB of LDS for them are not taken: 20.5 KB per
+  //  workgroup are SEVEN workgroups per CU where 25.6 were six, and the kernel's 67 registers allow seven wavefronts per SIMD)
+  __shared__ uint32_t s_meta[META_LDS ? WAVES : 1][META_LDS ? 64 * META_WORDS : 1];
+  // (the queue appends' few words live in the rows the wavefronts are through with by then -- wavefront w's two counts in the
+  //  first words of its own rows, the workgroup's two bases behind wavefront 0's counts: with no LDS besides the rows a workgroup
+  //  of the lean build takes 20 KB exactly and eight of them fit a CU)
+  auto s_count = [&](uint32_t q, uint32_t w) -> uint32_t & { return reinterpret_cast<uint32_t *>(&s_seq[w][0])[q]; };
+  auto s_base = [&](uint32_t q) -> uint32_t & { return reinterpret_cast<uint32_t *>(&s_seq[0][0])[2 + q]; };
   static_assert(sizeof(gtx_read_meta) % 4 == 0, "meta records are staged word-wise");
   uint32_t const lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t const wave_first = blockIdx.x * blockDim.x + wave * 64u;
   uint32_t const read = wave_first + lane;
   bool const full = wave_first + 64u <= n_reads; // (uniform per wavefront)
   bool const staged = full && seq_stride == ROW_BYTES && (reinterpret_cast<uintptr_t>(seq) & 15u) == 0;
-  if (full)
+  uint32_t own_meta[META_WORDS] = {};
+  if constexpr (META_LDS)
   {
-    uint32_t const * src = reinterpret_cast<uint32_t const *>(meta + wave_first);
+    if (full)
+    {
+      uint32_t const * src = reinterpret_cast<uint32_t const *>(meta + wave_first);
+#pragma unroll
+      for (uint32_t it = 0; it < META_WORDS; ++it)
+        s_meta[wave][it * 64 + lane] = stream_load(src + it * 64 + lane);
+    }
+  }
+  else if (read < n_reads)
+  {
+    uint32_t const * src = reinterpret_cast<uint32_t const *>(meta + read);
 #pragma unroll
     for (uint32_t it = 0; it < META_WORDS; ++it)
-      s_meta[wave][it * 64 + lane] = stream_load(src + it * 64 + lane);
+      own_meta[it] = stream_load(src + it);
   }
   if (staged)
   {
@@ -484,7 +502,14 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
   if (read < n_reads)
   {
     gtx_read_meta m;
-    if (full)
+    if constexpr (!META_LDS)
+    {
+      uint32_t * mw = reinterpret_cast<uint32_t *>(&m);
+#pragma unroll
+      for (uint32_t k = 0; k < META_WORDS; ++k)
+        mw[k] = own_meta[k];
+    }
+    else if (full)
     {
       uint32_t * mw = reinterpret_cast<uint32_t *>(&m);
 #pragma unroll
@@ -554,13 +579,24 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
     }
     // the dense side array (gtx_align_batch_flags): what this pass settles -- the forward task it finished, the reverse
     // task that is not aligned at all; the queued tasks get theirs from gtx_task_flags_fixup_kernel behind the last pass
+#ifndef GTX_X_NO_FLAG_STORE /* (experiment build: the kernel without its side bytes) */
     if (task_flags)
     {
-      if (!fwd && !fwd2)
-        task_flags[2ull * read] = static_cast<uint8_t>(fwd_flag);
-      if (!rev)
-        task_flags[2ull * read + 1] = 0;
+      // (both bytes of a read in ONE store where this pass settles both -- nearly every read: a wavefront's 64 pairs are one whole
+      //  line in one instruction.  As two byte stores, each of which covers every second byte of the line, the side array cost the
+      //  pass 5 % of its time for 2 of its 165 bytes per read: experiment build without them, round 6)
+      bool const set_fwd = !fwd && !fwd2, set_rev = !rev;
+      if (set_fwd && set_rev && (reinterpret_cast<uintptr_t>(task_flags) & 1u) == 0)
+        *reinterpret_cast<uint16_t *>(task_flags + 2ull * read) = static_cast<uint16_t>(fwd_flag & 0xFFu);
+      else
+      {
+        if (set_fwd)
+          task_flags[2ull * read] = static_cast<uint8_t>(fwd_flag);
+        if (set_rev)
+          task_flags[2ull * read + 1] = 0;
+      }
     }
+#endif
   }
   if (compact_wave)
   {
@@ -574,7 +610,9 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
     for (uint32_t k = 0; k < 2; ++k)
     {
       uint32_t const r = 32u * k + (lane >> 1);
+#ifndef GTX_X_NO_COMPACT_STORE /* (experiment build: the kernel without its dense records) */
       stream_store(dst + 64u * k + lane, s_seq[wave][r * ROW_PITCH + (lane & 1u)]);
+#endif
     }
   }
   {
@@ -609,10 +647,10 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
   // queue 1's high -- and take one 64-bit add.  Every wavefront posts its counts, the first thread claims room for the
   // workgroup, every wavefront writes at its offset.
   unsigned long long const F = __ballot(fwd), R = __ballot(rev), F2 = __ballot(fwd2);
-  if (lane == 0)
+  if (lane == 0) // (a wavefront is through with its own rows here, and wavefront 0 with its own when it writes the bases)
   {
-    s_count[0][wave] = static_cast<uint32_t>(__builtin_popcountll(F));
-    s_count[1][wave] = static_cast<uint32_t>(__builtin_popcountll(R) + __builtin_popcountll(F2));
+    s_count(0, wave) = static_cast<uint32_t>(__builtin_popcountll(F));
+    s_count(1, wave) = static_cast<uint32_t>(__builtin_popcountll(R) + __builtin_popcountll(F2));
   }
   __syncthreads();
   if (threadIdx.x == 0)
@@ -620,22 +658,22 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
     uint32_t total1 = 0, total2 = 0;
     for (uint32_t w = 0; w < WAVES; ++w)
     {
-      total1 += s_count[0][w];
-      total2 += s_count[1][w];
+      total1 += s_count(0, w);
+      total2 += s_count(1, w);
     }
     unsigned long long base = 0;
     if (total1 | total2)
       base = atomicAdd(queue_counts, (static_cast<unsigned long long>(total1) << 32) | total2);
-    s_base[0] = static_cast<uint32_t>(base >> 32);
-    s_base[1] = static_cast<uint32_t>(base);
+    s_base(0) = static_cast<uint32_t>(base >> 32);
+    s_base(1) = static_cast<uint32_t>(base);
   }
   __syncthreads();
-  uint32_t off1 = s_base[0], off2 = s_base[1];
+  uint32_t off1 = s_base(0), off2 = s_base(1);
   for (uint32_t w = 0; w < WAVES; ++w)
     if (w < wave)
     {
-      off1 += s_count[0][w];
-      off2 += s_count[1][w];
+      off1 += s_count(0, w);
+      off2 += s_count(1, w);
     }
   if (fwd)
     queue1[off1 + static_cast<uint32_t>(__builtin_popcountll(F & ((1ull << lane) - 1ull)))] = read;
@@ -664,7 +702,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
     atomicMax(span + 1, static_cast<unsigned long long>(wall_clock64()))
 
 #ifndef GTX_HINT_VGPRS
-#define GTX_HINT_VGPRS 80
+#define GTX_HINT_VGPRS 72
 #endif
 #ifndef GTX_HINT_WAVES
 // Wavefronts per workgroup of the position-hinted pass.  A workgroup's LDS (6.4 KB per wavefront) is held until its last
@@ -675,9 +713,12 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
 #endif
 // (80 registers: six wavefronts per SIMD = three of these workgroups per CU, which their LDS also allows; the compiler
 // takes 83-85 when left alone -- allocated as 88: five wavefronts, two workgroups)
-__global__ __launch_bounds__(64 * GTX_HINT_WAVES) __attribute__((amdgpu_num_vgpr(GTX_HINT_VGPRS), amdgpu_waves_per_eu(6, 6))) void gtx_align_hinted_kernel(GTX_HINTED_ARGS)
+#ifndef GTX_HINT_PER_EU
+#define GTX_HINT_PER_EU 7
+#endif
+__global__ __launch_bounds__(64 * GTX_HINT_WAVES) __attribute__((amdgpu_num_vgpr(GTX_HINT_VGPRS), amdgpu_waves_per_eu(GTX_HINT_PER_EU, GTX_HINT_PER_EU))) void gtx_align_hinted_kernel(GTX_HINTED_ARGS)
 {
-  GTX_HINTED_PASS(GTX_HINT_WAVES, false);
+  GTX_HINTED_PASS(GTX_HINT_WAVES, false, AlignCfg::KC, GTX_HINT_PER_EU <= 6);
 }
 
 #ifndef GTX_HINT_DENSE_WAVES

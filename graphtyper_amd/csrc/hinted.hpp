@@ -115,6 +115,21 @@ GTX_DEV void plane_extract16(Row row, uint32_t & lo, uint32_t & hi)
   hi = p2 | p3;
 }
 
+// ... from a base A known at run time only (A + 15 inside the row's groups of 32 bases; `groups`: how many the row has)
+template <class Row>
+GTX_DEV void plane_extract16_at(Row row, uint32_t A, uint32_t & lo, uint32_t & hi, uint32_t groups = HINT_MAX_READ / 32)
+{
+  uint32_t const W = A >> 5, S = A & 31u, N = W + 1u < groups ? W + 1u : W; // (the last group is looked at with S <= 16 only)
+  uint32_t const a1 = row[4 * W + 1], a2 = row[4 * W + 2], a3 = row[4 * W + 3], n1 = row[4 * N + 1], n2 = row[4 * N + 2], n3 = row[4 * N + 3];
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t const p1 = __builtin_amdgcn_alignbit(n1, a1, S), p2 = __builtin_amdgcn_alignbit(n2, a2, S), p3 = __builtin_amdgcn_alignbit(n3, a3, S);
+#else
+  uint32_t const p1 = S == 0 ? a1 : (a1 >> S) | (n1 << (32 - S)), p2 = S == 0 ? a2 : (a2 >> S) | (n2 << (32 - S)), p3 = S == 0 ? a3 : (a3 >> S) | (n3 << (32 - S));
+#endif
+  lo = (p1 | p3) & 0xFFFFu;
+  hi = (p2 | p3) & 0xFFFFu;
+}
+
 // What the compare of the read with the reference under it says, summed while the words stream by.  Packed (the pass is
 // bound by memory latency times resident waves: registers are occupancy):
 //   k[I]   per k-mer, 6 bits each: substitutions among its unambiguous bases, ... in its 16 first bases, ambiguous bases,
@@ -810,33 +825,38 @@ GTX_DEV uint32_t hinted_on_path(GraphView const & g, IndexView const & ix, Row r
   GTX_X_STOP(2, k0 ^ (k1 << 1) ^ (k2 << 2) ^ (k3 << 3) ^ (k4 << 4) ^ amb2 ^ h.upto ^ h.more ^ y_end ^ t_end.x);
   if ((k0 | k1 | k2 | k3 | k4) & (HK_NEED_LEFT | HK_NEED_RIGHT))
   {
-    // ---- the filter probes of all k-mers together: one round trip
-    uint32_t wl0, ml0, wr0, mr0, wl1, ml1, wr1, mr1, wl2, ml2, wr2, mr2, wl3, ml3, wr3, mr3, wl4, ml4, wr4, mr4;
-    hint_probe_slot<0, 0>(ix, k0, row, wl0, ml0);
-    hint_probe_slot<0, 1>(ix, k0, row, wr0, mr0);
-    hint_probe_slot<1, 0>(ix, k1, row, wl1, ml1);
-    hint_probe_slot<1, 1>(ix, k1, row, wr1, mr1);
-    hint_probe_slot<2, 0>(ix, k2, row, wl2, ml2);
-    hint_probe_slot<2, 1>(ix, k2, row, wr2, mr2);
-    hint_probe_slot<3, 0>(ix, k3, row, wl3, ml3);
-    hint_probe_slot<3, 1>(ix, k3, row, wr3, mr3);
-    hint_probe_slot<4, 0>(ix, k4, row, wl4, ml4);
-    hint_probe_slot<4, 1>(ix, k4, row, wr4, mr4);
-    uint32_t const * fl = ix.filt[0];
-    uint32_t const * fr = ix.filt[1];
-#ifdef GTX_X_NO_FILTER /* (experiment build: the kernel without its filter loads -- every probed half "absent") */
-    (void)fl;
-    (void)fr;
-    uint32_t const xl0 = 0, xr0 = 0, xl1 = 0, xr1 = 0, xl2 = 0, xr2 = 0, xl3 = 0, xr3 = 0, xl4 = 0, xr4 = 0;
-#else
-    uint32_t const xl0 = fl[wl0], xr0 = fr[wr0], xl1 = fl[wl1], xr1 = fr[wr1], xl2 = fl[wl2], xr2 = fr[wr2], xl3 = fl[wl3], xr3 = fr[wr3],
-                   xl4 = fl[wl4], xr4 = fr[wr4];
+    // ---- the filter probes.  The pass is bound by the vector instructions a wavefront issues (four cycles each on gfx950: a
+    //      wavefront's 1 300 are its whole life with six of them per SIMD -- tools/ubench/valu_rate.hip), and a wavefront executes
+    //      what ANY of its lanes asks for: with HINT_NEAR_FREE three lanes in a hundred still hang on a probe, nearly always on
+    //      one, but the ten slots written out side by side (k-mer x half, 28 instructions each) ran in every wavefront.  Now a
+    //      lane takes its needed halves one after the other, base offset and filter chosen at run time: one slot's instructions
+    //      per round, as many rounds as the wavefront's neediest lane has halves (one, rarely two).
+    uint32_t need = ((k0 >> 6) & 3u) | (((k1 >> 6) & 3u) << 2) | (((k2 >> 6) & 3u) << 4) | (((k3 >> 6) & 3u) << 6) | (((k4 >> 6) & 3u) << 8);
+    static_assert(HK_NEED_LEFT == 64u && HK_NEED_RIGHT == 128u, "bit 2 I + side of `need`");
+    bool maybe = false;
+#ifndef GTX_X_NO_FILTER /* (experiment build: the kernel without its filter loads -- every probed half "absent") */
+    while (need != 0)
+    {
+      // (two halves a round, their loads in flight together: one half a round made a lane with two needed halves -- one wavefront
+      //  in two has such a lane -- wait for two round trips one after the other, and the wavefront with it)
+      uint32_t const j0 = static_cast<uint32_t>(__builtin_ctz(need)); // k-mer j / 2, half j % 2
+      need &= need - 1u;
+      uint32_t const j1 = need != 0 ? static_cast<uint32_t>(__builtin_ctz(need)) : j0;
+      need &= need - 1u; // (0 stays 0)
+      uint32_t a0, a1, b0, b1, word0, mask0, word1, mask1;
+      plane_extract16_at(row, (K - 1) * (j0 >> 1) + 16u * (j0 & 1u), a0, a1);
+      plane_extract16_at(row, (K - 1) * (j1 >> 1) + 16u * (j1 & 1u), b0, b1);
+      hint_filter_slot(a0, a1, ix.filt_log2, word0, mask0);
+      hint_filter_slot(b0, b1, ix.filt_log2, word1, mask1);
+      uint32_t const x0 = ix.filt[j0 & 1u][word0], x1 = ix.filt[j1 & 1u][word1];
+      maybe = maybe || (x0 & mask0) == mask0 || (x1 & mask1) == mask1;
+    }
 #endif
-    k0 = hint_probe_verdict(k0, xl0, ml0, xr0, mr0);
-    k1 = hint_probe_verdict(k1, xl1, ml1, xr1, mr1);
-    k2 = hint_probe_verdict(k2, xl2, ml2, xr2, mr2);
-    k3 = hint_probe_verdict(k3, xl3, ml3, xr3, mr3);
-    k4 = hint_probe_verdict(k4, xl4, ml4, xr4, mr4);
+    if (maybe)
+    {
+      GTX_HINT_NOTE(4); // a half that has to be absent may occur in the index (a variant allele, or a filter collision)
+      return false;
+    }
   }
   if ((k0 & 3u) == HINT_K_DECLINE || (k1 & 3u) == HINT_K_DECLINE || (k2 & 3u) == HINT_K_DECLINE || (k3 & 3u) == HINT_K_DECLINE ||
       (k4 & 3u) == HINT_K_DECLINE)
@@ -901,39 +921,18 @@ GTX_DEV uint32_t hinted_on_path(GraphView const & g, IndexView const & ix, Row r
   uint32_t two_rs = 0, two_re = 0, two_mism = 0;
   if (labelled != (1u << n_k) - 1u)
   {
-    uint32_t best_lo = 0, best_len = 0, second = 0, second_lo = 0, n_best = 0, cur_lo = 0, cur_len = 0;
-#pragma unroll
-    for (uint32_t k = 0; k <= AlignCfg::KC; ++k)
-    {
-      if (k < n_k && ((labelled >> k) & 1u))
-      {
-        cur_lo = cur_len == 0 ? k : cur_lo;
-        ++cur_len;
-      }
-      else
-      {
-        if (cur_len > best_len)
-        {
-          second = best_len;
-          second_lo = best_lo;
-          best_len = cur_len;
-          best_lo = cur_lo;
-          n_best = 1;
-        }
-        else if (cur_len != 0 && cur_len == best_len)
-        {
-          second = cur_len;
-          second_lo = cur_lo;
-          ++n_best;
-        }
-        else if (cur_len > second)
-        {
-          second = cur_len;
-          second_lo = cur_lo;
-        }
-        cur_len = 0;
-      }
-    }
+    // (the runs of the five-bit word by its shifted conjunctions -- bit i of x_m: k-mers i .. i + m are all labelled -- instead
+    //  of a walk over the k-mers with the best and the second-best run carried along: 20 instructions for 90, in every
+    //  wavefront that has a lane with a label-less k-mer, which is nearly every one.  Bits at and above n_k are clear: those
+    //  k-mers were given the verdict `none`.)
+    uint32_t const x0 = labelled, x1 = x0 & (x0 >> 1), x2 = x1 & (x1 >> 1), x3 = x2 & (x2 >> 1), x4 = x3 & (x3 >> 1);
+    static_assert(AlignCfg::KC == 5, "runs of up to five k-mers");
+    uint32_t const deepest = x4 ? x4 : x3 ? x3 : x2 ? x2 : x1 ? x1 : x0; // one bit per longest run, at its first k-mer
+    uint32_t const best_len = (x0 != 0 ? 1u : 0u) + (x1 != 0 ? 1u : 0u) + (x2 != 0 ? 1u : 0u) + (x3 != 0 ? 1u : 0u) + (x4 != 0 ? 1u : 0u);
+    uint32_t const n_best = static_cast<uint32_t>(__builtin_popcount(deepest));
+    uint32_t best_lo = deepest ? static_cast<uint32_t>(__builtin_ctz(deepest)) : 0u;                  // the first of the longest runs ...
+    uint32_t const second_lo = deepest ? 31u - static_cast<uint32_t>(__builtin_clz(deepest)) : 0u; // ... and the last one (looked at when there are two)
+    uint32_t const second = (best_len == 0 || n_best >= 2) ? best_len : 0u; // (only "as long as the best one" is asked below)
     if (best_len <= second)
     {
       // Two runs A (in front) and B of one length: both chains survive the first remove_short_paths and both are walked, A
