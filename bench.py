@@ -52,6 +52,10 @@ USE_TASK_FLAGS = os.environ.get("GTX_BENCH_FLAGS", "1") != "0"  # the dense side
 USE_ITEM_WORDS = os.environ.get("GTX_BENCH_ITEM_WORDS", "1") != "0"  # gtx_score_batch_words (0: gtx_score_batch_flags; A/B)
 # dense records of the position-hinted pass (gtx_align_batch_planes_compact / gtx_score_batch_compact; 0: every record in its slot; A/B)
 USE_COMPACT = os.environ.get("GTX_BENCH_COMPACT", "1") != "0" and USE_TASK_FLAGS and os.environ.get("GTX_BENCH_PLANES", "1") != "0"
+# gtx_align_batch_planes_triaged + gtx_score_batch_queued: the scorer's first stage behind the alignment's short queues, on their stream (0: in front of the scoring; A/B)
+USE_TRIAGED = os.environ.get("GTX_BENCH_TRIAGED", "1") != "0" and USE_COMPACT and USE_ITEM_WORDS
+# (every item of the bench's read sets is one unpaired read, item i = read i -- add_reads --: the reads' bits instead of side bytes and item words; 0: A/B)
+TRIAGE_FLAGS = 1 if os.environ.get("GTX_BENCH_TRIAGE_READS", "1") != "0" else 0  # GTX_TRIAGE_ITEMS_ARE_READS
 PLANE_INPUT = os.environ.get("GTX_BENCH_PLANES", "1") != "0"    # reads resident as plane rows (0: BAM nibble rows, repacked inside every call)
 REC_WORDS = int(os.environ.get("GTX_BENCH_REC_WORDS", "64"))  # uint32 words of a record slot (rec_words of gtx_align_batch; A/B switch)
 REGION_BEGIN = 1000000      # chr20:1000001-2000000
@@ -319,14 +323,17 @@ class Workload:
         # lanes with that lane's stream, records and accumulators, so that the short queues at the end of one step (express,
         # general, scoring: latency-bound, the chip mostly idle) run beside the position-hinted pass of the next
         self.d_compact = torch.zeros(n * 8, dtype=torch.int32, device=device) if USE_COMPACT else None
+        # (the work queue of the scorer's second stage, filled behind the alignment: gtx_align_batch_planes_triaged)
+        self.d_work = torch.zeros(n + gtx.WORK_HEADER_WORDS, dtype=torch.int32, device=device) if USE_TRIAGED else None
         self.lanes = [dict(stream=self.stream, sp=self.sp, buf=self.buf, d_rec=self.d_rec, d_flags=self.d_flags, d_phred=self.d_phred,
-                           d_calls=self.d_calls, d_compact=self.d_compact)]
+                           d_calls=self.d_calls, d_compact=self.d_compact, d_work=self.d_work)]
         for _ in range(1, max(1, lanes)):
             lane = dict(stream=torch.cuda.Stream(device=device), buf=gtx.ScoreBuffers(),
                         d_rec=torch.zeros(n * 2 * REC_WORDS, dtype=torch.int32, device=device),
                         d_flags=torch.zeros(n * 2, dtype=torch.uint8, device=device) if USE_TASK_FLAGS else None,
                         d_phred=torch.zeros_like(self.d_phred), d_calls=torch.zeros_like(self.d_calls),
-                        d_compact=torch.zeros(n * 8, dtype=torch.int32, device=device) if USE_COMPACT else None)
+                        d_compact=torch.zeros(n * 8, dtype=torch.int32, device=device) if USE_COMPACT else None,
+                        d_work=torch.zeros(n + gtx.WORK_HEADER_WORDS, dtype=torch.int32, device=device) if USE_TRIAGED else None)
             lane["sp"] = C.c_void_p(lane["stream"].cuda_stream)
             gtx.check(self.L.gtx_scores_alloc(ctx.h, n_samples, conn_cap, C.byref(lane["buf"]), C.byref(reduced)))
             self.lanes.append(lane)
@@ -446,13 +453,19 @@ class Workload:
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(stream)
             fl = d_flags.data_ptr() if d_flags is not None else None
-            if ln["d_compact"] is not None:
+            w = self.words.get(int(d_items.data_ptr()))
+            triaged = ln["d_work"] is not None and w is not None
+            if triaged:
+                gtx.check(L.gtx_align_batch_planes_triaged(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, d_rec.data_ptr(), REC_WORDS,
+                                                           ln["d_compact"].data_ptr(), fl, d_items.data_ptr(), w.data_ptr(), self.n, TRIAGE_FLAGS, ln["d_work"].data_ptr(),
+                                                           sp, None, None, None))
+            elif ln["d_compact"] is not None:
                 gtx.check(L.gtx_align_batch_planes_compact(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, d_rec.data_ptr(), REC_WORDS,
                                                            ln["d_compact"].data_ptr(), fl, sp, None, None, None))
             else:
                 gtx.check(self.align_fn(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, d_rec.data_ptr(), REC_WORDS, fl, sp))
             e1.record(stream)
-            self._score_call(d_items, d_rec, fl, buf, sp, ln["d_compact"])
+            self._score_call(d_items, d_rec, fl, buf, sp, ln["d_compact"], ln["d_work"] if triaged else None)
             if self.comm is not None or self.dist is not None:
                 assert lane == 0  # (one communicator: the exchange steps of two streams must not interleave)
                 self._reduce(ln, stream, sp)
@@ -460,9 +473,12 @@ class Workload:
             gtx.check(L.gtx_calls_batch(ctx.h, C.byref(buf), ln["d_phred"].data_ptr(), ln["d_calls"].data_ptr(), sp))
         return e0, e1
 
-    def _score_call(self, d_items, d_rec, fl, buf, sp, d_compact=None):
+    def _score_call(self, d_items, d_rec, fl, buf, sp, d_compact=None, d_work=None):
         w = self.words.get(int(d_items.data_ptr()))
-        if d_compact is not None:
+        if d_work is not None:  # (the first stage ran behind the alignment: gtx_align_batch_planes_triaged)
+            self.gtx.check(self.L.gtx_score_batch_queued(self.ctx.h, d_items.data_ptr(), self.n, d_rec.data_ptr(), REC_WORDS, d_compact.data_ptr(), fl,
+                                                         d_work.data_ptr(), C.byref(buf), sp))
+        elif d_compact is not None:
             self.gtx.check(self.L.gtx_score_batch_compact(self.ctx.h, d_items.data_ptr(), w.data_ptr() if w is not None else None, self.n, d_rec.data_ptr(),
                                                           REC_WORDS, d_compact.data_ptr(), fl, C.byref(buf), sp))
         elif w is not None and fl is not None:
@@ -482,7 +498,7 @@ class Workload:
             if exchange and EXCHANGE_STREAM:
                 stream.wait_event(ln["scored"])  # (the lane's block was last read by the calls of its step before, on the exchange's stream)
             gtx.check(L.gtx_scores_zero(ctx.h, C.byref(ln["buf"]), sp))  # (on the tail stream behind the step's short queues instead: 0.737 against 0.712 ms per step)
-            self._score_call(ln["items"], ln["d_rec"], fl, ln["buf"], sp, ln["d_compact"])
+            self._score_call(ln["items"], ln["d_rec"], fl, ln["buf"], sp, ln["d_compact"], ln["d_work"] if ln.get("triaged") else None)
             if exchange and EXCHANGE_STREAM:
                 # N > 1: the sum over the ranks and the calls from the summed block go to a stream of their own -- the exchange is
                 # 36 MB over xGMI (cfg4: 1000 samples), link-bound and all but idle on the CUs, and on the stream that carries the
@@ -562,7 +578,14 @@ class Workload:
                 if sample:
                     e0.record(H)
                 fl = ln["d_flags"].data_ptr() if ln["d_flags"] is not None else None
-                if ln["d_compact"] is not None:
+                w = self.words.get(int(d_items.data_ptr()))
+                ln["triaged"] = ln["d_work"] is not None and w is not None
+                if ln["triaged"]:
+                    gtx.check(L.gtx_align_batch_planes_triaged(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, ln["d_rec"].data_ptr(),
+                                                               REC_WORDS, ln["d_compact"].data_ptr(), fl, d_items.data_ptr(), w.data_ptr(), self.n, TRIAGE_FLAGS,
+                                                               ln["d_work"].data_ptr(), spH, C.c_void_p(ln["front"].cuda_event), spT,
+                                                               C.c_void_p(ln["aligned"].cuda_event)))
+                elif ln["d_compact"] is not None:
                     gtx.check(L.gtx_align_batch_planes_compact(ctx.h, d_seq.data_ptr(), self.stride, d_meta.data_ptr(), self.n, ln["d_rec"].data_ptr(),
                                                                REC_WORDS, ln["d_compact"].data_ptr(), fl, spH, C.c_void_p(ln["front"].cuda_event), spT,
                                                                C.c_void_p(ln["aligned"].cuda_event)))

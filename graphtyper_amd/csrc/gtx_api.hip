@@ -430,7 +430,8 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
                                             gtx_read_meta const * __restrict__ meta, uint32_t n_reads, uint32_t * __restrict__ records,
                                             uint32_t rec_words, uint32_t force_both, uint32_t * __restrict__ queue1, uint32_t * __restrict__ queue2,
                                             unsigned long long * queue_counts /* queue 2's fill count (low word), queue 1's (high word) */,
-                                            uint32_t decline_all, uint8_t * __restrict__ task_flags, uint32_t * __restrict__ compact)
+                                            uint32_t decline_all, uint8_t * __restrict__ task_flags, uint32_t * __restrict__ compact,
+                                            unsigned long long * __restrict__ var_mask)
 {
   // The 64 reads of a wavefront lie side by side in memory: their bases (80 B each: five 16-byte groups of four plane words,
   // graph_dev.hpp) and their meta records (20 B each) are fetched with coalesced loads -- 1 KB and 256 B per instruction
@@ -598,6 +599,14 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
     }
 #endif
   }
+  if (var_mask)
+  {
+    // (gtx_align_batch_planes_triaged: which of the wavefront's reads left this pass with a forward record that carries a variant
+    //  site, one word -- what the scorer's first stage otherwise gathers from ten million side bytes)
+    unsigned long long const V = __ballot(read < n_reads && !fwd && !fwd2 && (fwd_flag & GTX_TASK_HAS_VARIANTS) != 0u);
+    if (lane == 0 && wave_first < n_reads)
+      var_mask[wave_first >> 6] = V;
+  }
   if (compact_wave)
   {
     // The wavefront's 64 compact records are 2 KB side by side: lane l of store k carries bytes [16 (64 k + l), + 16) of the block --
@@ -687,7 +696,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
   GraphView g, IndexView ix, uint8_t const *__restrict__ seq, uint32_t seq_stride, gtx_read_meta const *__restrict__ meta,         \
     uint32_t n_reads, uint32_t *__restrict__ records, uint32_t rec_words, uint32_t force_both, uint32_t *__restrict__ queue1,      \
     uint32_t *__restrict__ queue2, unsigned long long *queue_counts, uint32_t decline_all, uint8_t *__restrict__ task_flags,       \
-    uint32_t *__restrict__ compact, unsigned long long *span
+    uint32_t *__restrict__ compact, unsigned long long *span, unsigned long long *__restrict__ var_mask
 // (span, timed calls only: [0] = the largest ~(wall clock) a workgroup saw at its start, [1] = the largest wall clock at an end -- the
 //  launch's own time from its first workgroup's start to its last one's end, which is what rocprofv3 reports for it.  HIP events
 //  around the launch measure that only while the launch does not wait for room: with whole steps in flight on streams of their
@@ -697,7 +706,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
 #define GTX_HINTED_PASS(W, ...)                                                                                                    \
   if (span && threadIdx.x == 0 && blockIdx.x == 0)                                                                                 \
     atomicMax(span, ~static_cast<unsigned long long>(wall_clock64()));                                                             \
-  hinted_pass<W, __VA_ARGS__>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, queue1, queue2, queue_counts, decline_all, task_flags, compact); \
+  hinted_pass<W, __VA_ARGS__>(g, ix, seq, seq_stride, meta, n_reads, records, rec_words, force_both, queue1, queue2, queue_counts, decline_all, task_flags, compact, var_mask); \
   if (span && threadIdx.x == 0 && blockIdx.x + 1024u >= gridDim.x && ((blockIdx.x & 15u) == 15u || blockIdx.x + 1u == gridDim.x))   \
     atomicMax(span + 1, static_cast<unsigned long long>(wall_clock64()))
 
@@ -1009,13 +1018,61 @@ __global__ __launch_bounds__(256) void gtx_planes_kernel(uint8_t const * __restr
 __global__ __launch_bounds__(256) void gtx_task_flags_fixup_kernel(uint32_t const * __restrict__ records, uint32_t rec_words,
                                                                    uint8_t * __restrict__ task_flags, uint32_t const * __restrict__ queue1,
                                                                    uint32_t const * queue1_count, uint32_t const * __restrict__ queue2,
-                                                                   uint32_t const * queue2_count)
+                                                                   uint32_t const * queue2_count, unsigned long long * __restrict__ var_mask)
 {
   uint32_t const n1 = queue1 ? queue1_count[0] : 0u, n2 = queue2_count[0];
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += gridDim.x * blockDim.x)
   {
     uint32_t const task = i < n1 ? 2u * queue1[i] : queue2[i - n1];
-    task_flags[task] = static_cast<uint8_t>(records[static_cast<uint64_t>(task) * rec_words + 1] >> 31);
+    uint8_t const f = static_cast<uint8_t>(records[static_cast<uint64_t>(task) * rec_words + 1] >> 31);
+    task_flags[task] = f;
+    // (the position-hinted pass left the read's bit clear; a forward task of its queue is also a forward task of the general
+    //  pass' queue when it went there: the same bit twice)
+    if (var_mask && (task & 1u) == 0u && f != 0)
+      atomicOr(var_mask + (task >> 7), 1ull << ((task >> 1) & 63u));
+  }
+}
+
+// ... the bits of every read from the side array (batches aligned without the position-hinted pass)
+__global__ __launch_bounds__(256) void gtx_var_masks_kernel(uint8_t const * __restrict__ task_flags, uint32_t n_reads, unsigned long long * __restrict__ var_mask)
+{
+  uint32_t const read = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long const V = __ballot(read < n_reads && (task_flags[2ull * (read < n_reads ? read : 0u)] & GTX_TASK_HAS_VARIANTS) != 0u);
+  if ((threadIdx.x & 63u) == 0 && (read & ~63u) < n_reads)
+    var_mask[read >> 6] = V;
+}
+
+// The scorer's first stage where item i is read i (gtx_align_batch_planes_triaged, GTX_TRIAGE_ITEMS_ARE_READS): the set bits of the
+// reads' words as item numbers, one queue append per workgroup (256 words: 16 384 reads).
+__global__ __launch_bounds__(256) void gtx_mask_triage_kernel(unsigned long long const * __restrict__ var_mask, uint32_t n_words,
+                                                              uint32_t * __restrict__ work_queue, uint32_t * work_count)
+{
+  __shared__ uint32_t s_wave[4], s_base;
+  uint32_t const t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  unsigned long long m = t < n_words ? var_mask[t] : 0ull;
+  uint32_t const mine = static_cast<uint32_t>(__builtin_popcountll(m));
+  uint32_t incl = mine; // inclusive prefix over the wavefront
+  for (uint32_t d = 1; d < 64; d <<= 1)
+  {
+    uint32_t const up = __shfl_up(incl, d);
+    incl += lane >= d ? up : 0u;
+  }
+  if (lane == 63)
+    s_wave[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    uint32_t const total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    s_base = total ? atomicAdd(work_count, total) : 0u;
+  }
+  __syncthreads();
+  uint32_t at = s_base + incl - mine;
+  for (uint32_t w = 0; w < wave; ++w)
+    at += s_wave[w];
+  while (m != 0)
+  {
+    work_queue[at++] = 64u * t + static_cast<uint32_t>(__builtin_ctzll(m));
+    m &= m - 1ull;
   }
 }
 
@@ -1293,8 +1350,11 @@ GTX_DEV void score_big_pass(GraphView const & g, ScoreParams const & par, gtx_sc
 __global__ __launch_bounds__(64) void gtx_score_big_kernel(GraphView g, ScoreParams par, gtx_score_item const * __restrict__ items,
                                                            uint32_t const * __restrict__ records, uint32_t rec_words, ScoreAcc acc,
                                                            uint32_t * error_flag, uint32_t const * __restrict__ big_queue,
-                                                           uint32_t big_queue_cap, uint32_t const * big_state, RecentHap * tables)
+                                                           uint32_t big_queue_cap, uint32_t const * big_state, RecentHap * tables,
+                                                           uint32_t * __restrict__ zero_next)
 {
+  if (zero_next && blockIdx.x == 0 && threadIdx.x < 4) // (gtx_score_batch_queued: no first stage in the call to do this)
+    zero_next[threadIdx.x] = 0u;
   score_big_pass<RecentHap, SCORE_MAX_HAPS_BIG>(g, par, items, records, rec_words, acc, error_flag, big_queue, big_queue_cap, big_state, tables);
 }
 
@@ -1303,8 +1363,11 @@ __global__ __launch_bounds__(64) void gtx_score_big_kernel(GraphView g, ScorePar
 __global__ __launch_bounds__(64) void gtx_score_wide_kernel(GraphView g, ScoreParams par, gtx_score_item const * __restrict__ items,
                                                             uint32_t const * __restrict__ records, uint32_t rec_words, ScoreAcc acc,
                                                             uint32_t * error_flag, uint32_t const * __restrict__ big_queue,
-                                                            uint32_t big_queue_cap, uint32_t const * big_state, RecentHapWide * tables)
+                                                            uint32_t big_queue_cap, uint32_t const * big_state, RecentHapWide * tables,
+                                                            uint32_t * __restrict__ zero_next)
 {
+  if (zero_next && blockIdx.x == 0 && threadIdx.x < 4)
+    zero_next[threadIdx.x] = 0u;
   score_big_pass<RecentHapWide, SCORE_MAX_HAPS_WIDE>(g, par, items, records, rec_words, acc, error_flag, big_queue, big_queue_cap, big_state,
                                                      tables);
 }
@@ -1396,7 +1459,7 @@ static void scratch_free(CallScratch & s)
 {
   // (d_big_state lies behind d_counters in one allocation: one reset for both)
   void * ptrs[] = {s.d_counter_sets, s.d_queue1, s.d_queue, s.d_big_tasks, s.d_big_ws, s.d_score_state, s.d_score_queue,
-                   s.d_score_tables, s.d_score_work, s.d_wide_tasks, s.d_wide_ws, s.d_planes, s.d_exact_tasks};
+                   s.d_score_tables, s.d_score_work, s.d_var_masks, s.d_wide_tasks, s.d_wide_ws, s.d_planes, s.d_exact_tasks};
   for (void * p : ptrs)
     if (p)
       (void)gtx::dev_free(p);
@@ -1987,10 +2050,19 @@ static gtx_ctx::ExactSlot const * exact_slot_for_call(gtx_ctx & c, uint64_t want
   return &c.exact_slot[c.next_exact_slot];
 }
 
+// gtx_align_batch_planes_triaged: the scorer's first stage behind the call's last alignment launch, on that launch's stream
+struct TriageRequest
+{
+  gtx_score_item const * d_items;
+  uint32_t const * d_item_words;
+  uint32_t n_items;
+  uint32_t * d_work; // [0] = count, [GTX_WORK_HEADER_WORDS ...] = the items with work
+  bool items_are_reads; // GTX_TRIAGE_ITEMS_ARE_READS: item i is read i, alone and aligned forward only
+};
 static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
                         uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, hipStream_t st, hipEvent_t front_event = nullptr,
                         hipStream_t tail_stream = nullptr, hipEvent_t done_event = nullptr, hipStream_t * last_stream = nullptr,
-                        uint32_t * d_compact = nullptr);
+                        uint32_t * d_compact = nullptr, TriageRequest const * triage = nullptr);
 
 // BAM nibble rows: repacked into plane rows in the call's scratch, then the same kernels
 extern "C" int gtx_align_batch_flags(gtx_ctx * c, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta,
@@ -2031,7 +2103,7 @@ extern "C" int gtx_align_batch_planes(gtx_ctx * c, const uint8_t * d_planes, uin
 
 static int align_batch_planes_staged(gtx_ctx * c, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
                                      uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream, void * front_event,
-                                     void * tail_stream, void * done_event, uint32_t * d_compact);
+                                     void * tail_stream, void * done_event, uint32_t * d_compact, TriageRequest const * triage = nullptr);
 
 extern "C" int gtx_align_batch_planes_staged(gtx_ctx * c, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta,
                                              uint32_t n_reads, uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream,
@@ -2054,9 +2126,33 @@ extern "C" int gtx_align_batch_planes_compact(gtx_ctx * c, const uint8_t * d_pla
                                    done_event, d_compact);
 }
 
+extern "C" int gtx_align_batch_planes_triaged(gtx_ctx * c, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta,
+                                              uint32_t n_reads, uint32_t * d_records, uint32_t rec_words, uint32_t * d_compact, uint8_t * d_task_flags,
+                                              const gtx_score_item * d_items, const uint32_t * d_item_words, uint32_t n_items, uint32_t triage_flags,
+                                              uint32_t * d_work, void * stream, void * front_event, void * tail_stream, void * done_event)
+{
+  bool const are_reads = (triage_flags & GTX_TRIAGE_ITEMS_ARE_READS) != 0;
+  if (!d_task_flags || (!d_items && !are_reads) || !d_work || (reinterpret_cast<uintptr_t>(d_work) & 15u) != 0 ||
+      (d_compact && (reinterpret_cast<uintptr_t>(d_compact) & 15u) != 0) || (are_reads && n_items != n_reads) || (triage_flags & ~GTX_TRIAGE_ITEMS_ARE_READS) != 0)
+  {
+    g_last_error = "gtx_align_batch_planes_triaged: needs d_task_flags, the items (or GTX_TRIAGE_ITEMS_ARE_READS with n_items == n_reads) and a 16-byte "
+                   "aligned d_work (and d_compact, when given, 16-byte aligned)";
+    return GTX_ERR_ARG;
+  }
+  if (are_reads && c && c->params.is_sv_graph)
+  {
+    // (an SV graph's scorer also visits the reads without a variant site -- the reference depth -- which the reads' bits do not name)
+    g_last_error = "gtx_align_batch_planes_triaged: GTX_TRIAGE_ITEMS_ARE_READS is not for SV graphs (every read adds to the reference depth)";
+    return GTX_ERR_UNSUPPORTED;
+  }
+  TriageRequest const t{d_items, d_item_words, n_items, d_work, are_reads};
+  return align_batch_planes_staged(c, d_planes, plane_stride, d_meta, n_reads, d_records, rec_words, d_task_flags, stream, front_event, tail_stream,
+                                   done_event, d_compact, &t);
+}
+
 static int align_batch_planes_staged(gtx_ctx * c, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
                                      uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, void * stream, void * front_event,
-                                     void * tail_stream, void * done_event, uint32_t * d_compact)
+                                     void * tail_stream, void * done_event, uint32_t * d_compact, TriageRequest const * triage)
 {
   if (!c || rec_words < 8 || plane_stride == 0 || (plane_stride % PLANE_GROUP_BYTES) != 0 || (reinterpret_cast<uintptr_t>(d_planes) & 15u) != 0 ||
       (n_reads != 0 && (!d_planes || !d_meta || !d_records)))
@@ -2077,9 +2173,11 @@ static int align_batch_planes_staged(gtx_ctx * c, const uint8_t * d_planes, uint
   }
   if (n_reads == 0)
   {
-    if ((front_event || done_event) && !hip_ok(hipSetDevice(c->device), "hipSetDevice"))
+    if ((front_event || done_event || triage) && !hip_ok(hipSetDevice(c->device), "hipSetDevice"))
       return GTX_ERR_HIP;
     if (front_event && !hip_ok(hipEventRecord(static_cast<hipEvent_t>(front_event), st), "front event"))
+      return GTX_ERR_HIP;
+    if (triage && !hip_ok(hipMemsetAsync(triage->d_work, 0, GTX_WORK_HEADER_WORDS * sizeof(uint32_t), st), "work queue reset")) // (no read: no item has work)
       return GTX_ERR_HIP;
     if (done_event && !hip_ok(hipEventRecord(static_cast<hipEvent_t>(done_event), st), "done event"))
       return GTX_ERR_HIP;
@@ -2095,7 +2193,7 @@ static int align_batch_planes_staged(gtx_ctx * c, const uint8_t * d_planes, uint
   hipStream_t last = st;
   int const rc = align_planes(c, hold.s, d_planes, plane_stride, d_meta, n_reads, d_records, rec_words, d_task_flags, st,
                               static_cast<hipEvent_t>(front_event), std::getenv("GTX_PARTS") ? nullptr : static_cast<hipStream_t>(tail_stream),
-                              static_cast<hipEvent_t>(done_event), &last, d_compact);
+                              static_cast<hipEvent_t>(done_event), &last, d_compact, triage);
   hold.stream = last; // (the stream the call's last launch is on)
   return rc;
 }
@@ -2103,7 +2201,7 @@ static int align_batch_planes_staged(gtx_ctx * c, const uint8_t * d_planes, uint
 // the passes over plane rows (d_seq / seq_stride: the plane rows and their pitch)
 static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uint32_t seq_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
                         uint32_t * d_records, uint32_t rec_words, uint8_t * d_task_flags, hipStream_t st, hipEvent_t front_event, hipStream_t tail_stream,
-                        hipEvent_t done_event, hipStream_t * last_stream, uint32_t * d_compact)
+                        hipEvent_t done_event, hipStream_t * last_stream, uint32_t * d_compact, TriageRequest const * triage)
 {
   // (the pass counters and, behind them, the state of the HBM-table and wide-site passes: the set the last call left zeroed --
   //  CallScratch::d_counter_sets; after a call that failed on its way the set is zeroed here, as every call did before round 6)
@@ -2249,6 +2347,15 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
         *last_stream = tail_stream;
     }
   };
+  // (gtx_align_batch_planes_triaged where item i is read i: a bit per read, written by the position-hinted pass, completed behind
+  //  the last pass)
+  unsigned long long * var_masks = nullptr;
+  if (triage && triage->items_are_reads)
+  {
+    if (!grow(s->d_var_masks, s->var_mask_cap, (static_cast<uint64_t>(n_reads) + 63u) / 64u, "variant-site bits of the reads"))
+      return GTX_ERR_HIP;
+    var_masks = s->d_var_masks;
+  }
   auto mark = [&](uint32_t part, int k, hipStream_t on)
   {
     if (timed)
@@ -2305,7 +2412,8 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
                            ,
                          d_task_flags ? d_task_flags + 2ull * first : static_cast<uint8_t *>(nullptr),
                          d_compact ? d_compact + static_cast<uint64_t>(first) * GTX_COMPACT_WORDS : static_cast<uint32_t *>(nullptr),
-                         timed && s->h_span ? s->d_span : static_cast<unsigned long long *>(nullptr));
+                         timed && s->h_span ? s->d_span : static_cast<unsigned long long *>(nullptr),
+                         var_masks ? var_masks + first / 64u : static_cast<unsigned long long *>(nullptr));
       if (!hip_ok(hipGetLastError(), "gtx_align_hinted_kernel launch"))
         return GTX_ERR_HIP;
       mark(part, 1, st);
@@ -2470,10 +2578,39 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
       uint8_t * flags_part = d_task_flags + 2ull * first;
       if (hinted)
         hipLaunchKernelGGL(gtx_task_flags_fixup_kernel, dim3(n_cu * 4u), dim3(256), 0, sg, rec_part, rec_words, flags_part, s->d_queue1 + first,
-                           counters + 3, s->d_queue + 2ull * first, counters + 2);
+                           counters + 3, s->d_queue + 2ull * first, counters + 2,
+                           var_masks ? var_masks + first / 64u : static_cast<unsigned long long *>(nullptr));
       else
+      {
         hipLaunchKernelGGL(gtx_task_flags_all_kernel, dim3((2u * n + 255u) / 256u), dim3(256), 0, sg, rec_part, rec_words, flags_part, 2u * n);
+        if (var_masks)
+          hipLaunchKernelGGL(gtx_var_masks_kernel, dim3((n + 255u) / 256u), dim3(256), 0, sg, flags_part, n, var_masks + first / 64u);
+      }
       if (!hip_ok(hipGetLastError(), "task flags launch"))
+        return GTX_ERR_HIP;
+    }
+  }
+  if (triage)
+  {
+    // The scorer's first stage (which items' reads carry a variant site: the side array, complete behind the launch above, and
+    // the items' words) HERE, behind the short queues on their stream, instead of in front of the scoring on the stream that
+    // carries the position-hinted passes: 37 us of a 650 us step there, nothing here -- the queues' stream is idle half of the time.
+    if (!hip_ok(hipMemsetAsync(triage->d_work, 0, GTX_WORK_HEADER_WORDS * sizeof(uint32_t), sg), "work queue reset"))
+      return GTX_ERR_HIP;
+    if (var_masks)
+    {
+      uint32_t const n_words = (n_reads + 63u) / 64u;
+      hipLaunchKernelGGL(gtx_mask_triage_kernel, dim3((n_words + 255u) / 256u), dim3(256), 0, sg, var_masks, n_words, triage->d_work + GTX_WORK_HEADER_WORDS,
+                         triage->d_work);
+      if (!hip_ok(hipGetLastError(), "gtx_mask_triage_kernel launch"))
+        return GTX_ERR_HIP;
+    }
+    else if (triage->n_items)
+    {
+      hipLaunchKernelGGL(gtx_score_triage_kernel, dim3((triage->n_items + TRIAGE_THREADS * TRIAGE_PER_THREAD - 1) / (TRIAGE_THREADS * TRIAGE_PER_THREAD)),
+                         dim3(TRIAGE_THREADS), 0, sg, triage->d_items, triage->n_items, d_records, rec_words, triage->d_work + GTX_WORK_HEADER_WORDS, triage->d_work,
+                         static_cast<uint32_t>(c->params.is_sv_graph != 0), d_task_flags, triage->d_item_words, static_cast<uint32_t *>(nullptr));
+      if (!hip_ok(hipGetLastError(), "gtx_score_triage_kernel launch (behind the alignment)"))
         return GTX_ERR_HIP;
     }
   }
@@ -2629,7 +2766,8 @@ extern "C" int gtx_score_batch(gtx_ctx * c, const gtx_score_item * d_items, uint
 }
 
 static int score_batch(gtx_ctx * c, const gtx_score_item * d_items, const uint32_t * d_item_words, uint32_t n_items, const uint32_t * d_records,
-                       uint32_t rec_words, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream, const uint32_t * d_compact = nullptr);
+                       uint32_t rec_words, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream, const uint32_t * d_compact = nullptr,
+                       const uint32_t * d_work = nullptr);
 
 extern "C" int gtx_score_batch_flags(gtx_ctx * c, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records,
                                      uint32_t rec_words, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream)
@@ -2661,6 +2799,19 @@ extern "C" int gtx_score_batch_compact(gtx_ctx * c, const gtx_score_item * d_ite
   return score_batch(c, d_items, d_item_words, n_items, d_records, rec_words, d_task_flags, acc, stream, d_compact);
 }
 
+// stage 2 alone, over the work queue gtx_align_batch_planes_triaged left
+extern "C" int gtx_score_batch_queued(gtx_ctx * c, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records, uint32_t rec_words,
+                                      const uint32_t * d_compact, const uint8_t * d_task_flags, const uint32_t * d_work,
+                                      const gtx_score_buffers * acc, void * stream)
+{
+  if (!d_work || !d_task_flags || (reinterpret_cast<uintptr_t>(d_work) & 15u) != 0)
+  {
+    g_last_error = "gtx_score_batch_queued: needs the work queue and the side array of gtx_align_batch_planes_triaged";
+    return GTX_ERR_ARG;
+  }
+  return score_batch(c, d_items, nullptr, n_items, d_records, rec_words, d_task_flags, acc, stream, d_compact, d_work);
+}
+
 // gtx_score_batch_words' compact form of the items (host)
 extern "C" int gtx_item_words(const gtx_score_item * items, uint32_t n_items, uint32_t * words)
 {
@@ -2677,7 +2828,8 @@ extern "C" int gtx_item_words(const gtx_score_item * items, uint32_t n_items, ui
 }
 
 static int score_batch(gtx_ctx * c, const gtx_score_item * d_items, const uint32_t * d_item_words, uint32_t n_items, const uint32_t * d_records,
-                       uint32_t rec_words, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream, const uint32_t * d_compact)
+                       uint32_t rec_words, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream, const uint32_t * d_compact,
+                       const uint32_t * d_work)
 {
   if (!c || !d_items || !d_records || !acc || !acc->d_log_score || !acc->d_gt_cov || !acc->d_hap_u32 || !acc->d_stat_u64 ||
       !acc->d_stat_u32 || !acc->d_conn_log || !acc->d_conn_count)
@@ -2751,32 +2903,46 @@ static int score_batch(gtx_ctx * c, const gtx_score_item * d_items, const uint32
   if (!grow(s->d_score_work, cap, static_cast<uint64_t>(n_items) + 1, "score work queue"))
     return GTX_ERR_HIP;
   s->score_work_cap = static_cast<uint32_t>(cap - 1);
-  uint32_t * const work_count = second_pass ? score_state + 2 : s->d_score_work;
-  if (!second_pass && !hip_ok(hipMemsetAsync(s->d_score_work, 0, sizeof(uint32_t), st), "score work queue reset"))
-    return GTX_ERR_HIP;
-  hipLaunchKernelGGL(gtx_score_triage_kernel, dim3((n_items + TRIAGE_THREADS * TRIAGE_PER_THREAD - 1) / (TRIAGE_THREADS * TRIAGE_PER_THREAD)), dim3(TRIAGE_THREADS), 0, st, d_items, n_items, d_records, rec_words, s->d_score_work + 1,
-                     work_count, static_cast<uint32_t>(a.ref_depth != nullptr), d_task_flags, d_item_words, score_state_next);
-  if (!hip_ok(hipGetLastError(), "gtx_score_triage_kernel launch"))
-    return GTX_ERR_HIP;
-  s->score_spare_clean = second_pass;
+  uint32_t const * work_count = second_pass ? score_state + 2 : s->d_score_work;
+  uint32_t const * work_queue = s->d_score_work + 1;
+  if (d_work)
+  {
+    // (gtx_score_batch_queued: the first stage ran behind the alignment -- the queue is the caller's; the second pass' state for
+    //  the next call on this scratch is zeroed by the launch that ends this call, below)
+    work_count = d_work;
+    work_queue = d_work + GTX_WORK_HEADER_WORDS;
+  }
+  else
+  {
+    if (!second_pass && !hip_ok(hipMemsetAsync(s->d_score_work, 0, sizeof(uint32_t), st), "score work queue reset"))
+      return GTX_ERR_HIP;
+    hipLaunchKernelGGL(gtx_score_triage_kernel, dim3((n_items + TRIAGE_THREADS * TRIAGE_PER_THREAD - 1) / (TRIAGE_THREADS * TRIAGE_PER_THREAD)), dim3(TRIAGE_THREADS), 0, st, d_items, n_items, d_records, rec_words, s->d_score_work + 1,
+                       second_pass ? score_state + 2 : s->d_score_work, static_cast<uint32_t>(a.ref_depth != nullptr), d_task_flags, d_item_words, score_state_next);
+    if (!hip_ok(hipGetLastError(), "gtx_score_triage_kernel launch"))
+      return GTX_ERR_HIP;
+    s->score_spare_clean = second_pass;
+  }
   uint32_t const work_blocks = std::min<uint32_t>(blocks, static_cast<uint32_t>(c->n_cu > 0 ? c->n_cu : 256) * c->score_blocks_per_cu);
-  hipLaunchKernelGGL(gtx_score_kernel, dim3(work_blocks), dim3(GTX_SCORE_THREADS), 0, st, c->dev_graph, par, d_items, s->d_score_work + 1, work_count,
+  hipLaunchKernelGGL(gtx_score_kernel, dim3(work_blocks), dim3(GTX_SCORE_THREADS), 0, st, c->dev_graph, par, d_items, work_queue, work_count,
                      d_records, rec_words, a, c->d_error_flag, second_pass ? s->d_score_queue : nullptr,
                      second_pass ? gtx_ctx::SCORE_QUEUE_CAP : 0u, score_state);
   if (!hip_ok(hipGetLastError(), "gtx_score_kernel launch"))
     return GTX_ERR_HIP;
   if (second_pass)
   {
+    uint32_t * const zero_next = d_work ? score_state_next : nullptr; // (the set the next call on this scratch uses: nobody reads it in this call)
     if (c->has_wide_sites)
       hipLaunchKernelGGL(gtx_score_wide_kernel, dim3(gtx_ctx::SCORE_BIG_THREADS / 64), dim3(64), 0, st, c->dev_graph, par, d_items, d_records,
                          rec_words, a, c->d_error_flag, s->d_score_queue, gtx_ctx::SCORE_QUEUE_CAP, score_state,
-                         static_cast<RecentHapWide *>(s->d_score_tables));
+                         static_cast<RecentHapWide *>(s->d_score_tables), zero_next);
     else
       hipLaunchKernelGGL(gtx_score_big_kernel, dim3(gtx_ctx::SCORE_BIG_THREADS / 64), dim3(64), 0, st, c->dev_graph, par, d_items, d_records,
                          rec_words, a, c->d_error_flag, s->d_score_queue, gtx_ctx::SCORE_QUEUE_CAP, score_state,
-                         static_cast<RecentHap *>(s->d_score_tables));
+                         static_cast<RecentHap *>(s->d_score_tables), zero_next);
     if (!hip_ok(hipGetLastError(), "gtx_score_big_kernel launch"))
       return GTX_ERR_HIP;
+    if (d_work)
+      s->score_spare_clean = true;
   }
   return GTX_OK;
 }

@@ -86,6 +86,10 @@ struct CallScratch
   void * d_score_tables = nullptr;
   uint32_t * d_score_work = nullptr; // [0] number of items the triage kernel found worth scoring, [1..] their indices (grow-only)
   uint32_t score_work_cap = 0;
+  // gtx_align_batch_planes_triaged, items that are the batch's reads: a bit per read (a word per wavefront of the position-hinted
+  // pass) -- the forward record carries a variant site (grow-only)
+  unsigned long long * d_var_masks = nullptr;
+  uint64_t var_mask_cap = 0;
 };
 } // namespace gtx
 

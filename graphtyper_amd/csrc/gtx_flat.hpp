@@ -5,6 +5,8 @@
 // (include/graphtyper/index/ph_index.hpp:14-36).  Here both are flat arrays so that one upload puts them in HBM and a
 // wavefront can address them with plain offsets.
 #pragma once
+#include <algorithm>
+#include <cstdlib>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -233,6 +235,23 @@ constexpr uint32_t HINT_TAIL_OK = 1u, HINT_TAIL_NALL_SHIFT = 2u, HINT_TAIL_NEXT_
 constexpr uint32_t HINT_HE_CAP = 16, HINT_NB_MAX = 16;
 
 // hash of a 16-base half as two bit planes of its 2-bit codes (A0 C1 G2 T3): w0 = the low bits, w1 = the high bits, base j of
+// Words of a half-key filter for n_keys indexed keys, as a power of two: 128 bits per key and side (round 6; 32 before).  A
+// probe looks at four bits of ONE word, and with a key per word on average one probe in three hundred of a half that occurs
+// nowhere met four set bits in a word that two or three keys share (cfg2: a third of what the position-hinted pass sent on,
+// 7 k reads of 10 M), and one position in four failed HINT_NEAR_FREE for one of its 96 neighbours; with a key per four words it
+// is one probe in five thousand and one position in fifty.  32 MB for both filters of a 1 Mb region's million keys.
+// (GTX_FILTER_BITS_LOG2: A/B switch, 5 = the old size)
+inline uint32_t hint_filter_log2_words(uint64_t n_keys)
+{
+  uint32_t fl = 5;
+  while ((1ull << fl) < n_keys + 1 && fl < 28)
+    ++fl;
+  uint32_t extra = 2;
+  if (char const * e = std::getenv("GTX_FILTER_BITS_LOG2"))
+    extra = static_cast<uint32_t>(std::max(5, std::min(9, std::atoi(e))) - 5);
+  return std::min<uint32_t>(fl + extra, 28u);
+}
+
 // the half at bit j (what a read in plane form yields with two shifts) -> (word, mask of up to four bits) of the blocked
 // Bloom filter
 #if defined(__HIPCC__)

@@ -834,9 +834,7 @@ static void build_hints(HostGraph const & g, HostIndex & out)
         }
     });
   // filters over the halves of every indexed key (nibble form, as the kernel hashes them): 32 bits per key and side
-  uint32_t fl = 5;
-  while ((1ull << fl) < nk + 1 && fl < 28)
-    ++fl;
+  uint32_t const fl = hint_filter_log2_words(nk);
   out.filt_log2 = fl;
   out.filt[0].assign(1ull << fl, 0);
   out.filt[1].assign(1ull << fl, 0);

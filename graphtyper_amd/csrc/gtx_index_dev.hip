@@ -694,9 +694,7 @@ int build_index_device(gtx_ctx & c, std::vector<Emit> const & em, std::vector<Em
                        d_rcount, n_keys, d_hlist, d_hslots, hl);
   }
   // ---- tables of the position-hinted pass
-  uint32_t fl = 5;
-  while ((1ull << fl) < static_cast<uint64_t>(n_keys) + 1 && fl < 28)
-    ++fl;
+  uint32_t const fl = hint_filter_log2_words(static_cast<uint64_t>(n_keys));
   // (the graph's own part of them -- gtx_host.cpp: hint_graph_tables is the host's form -- is made here as well)
   uint32_t const R = static_cast<uint32_t>(c.graph.ref_order.size());
   uint32_t const hint_first = R ? c.graph.ref_order[0] - 1 : 0; // order = 1-based contig position

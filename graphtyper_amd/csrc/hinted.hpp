@@ -512,6 +512,18 @@ GTX_DEV uint32_t hint_kmer_judge(uint2_t const f, Row row, Counts const & h, uin
     amb2 |= 1u << I;
     return hk_make(amb_out == 0 ? HINT_K_LABEL : HINT_K_HOLE, site, allele, false, true) | own_set;
   }
+  // Ambiguous bases AND substitutions: a multi-key list (exact lookups only, kmer_help_functions.cpp:97-119) every key of which
+  // carries the half that holds no ambiguous base unchanged.  When that half has a substitution it is one concrete 16-mer, and if
+  // it occurs in no indexed key (filter probe by the caller, or HINT_NEAR_FREE) none of the list's keys is indexed, whatever the
+  // other half holds -- any number of ambiguous bases, further substitutions: the k-mer has no label.  (Round 6: with an N and a
+  // substitution in one half and a substitution in the other the k-mer was sent on -- a third of what this pass declined at cfg2.)
+  if (amb != 0 && mis != 0)
+  {
+    if (mis_left != 0 && amb_left == 0)
+      return hk_make(HINT_K_HOLE, site, 0u, false, true) | HK_NEED_LEFT;
+    if (mis_right != 0 && amb_right == 0)
+      return hk_make(HINT_K_HOLE, site, 0u, false, true) | HK_NEED_RIGHT;
+  }
   if (amb > 1)
   {
     GTX_HINT_NOTE(7);

@@ -22,7 +22,7 @@ ST_ERROR_MASK = 15
 # names every build of libgtx.so must export (checked by tests/test_abi.py against include/gtx.h)
 EXPORTS = ["gtx_strerror", "gtx_last_error", "gtx_ctx_create", "gtx_ctx_destroy", "gtx_ctx_special_positions",
            "gtx_ctx_score_layout", "gtx_ctx_haplotypes", "gtx_ctx_near_pairs", "gtx_index_stats", "gtx_index_get", "gtx_index_dump", "gtx_ctx_hint_table",
-           "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_exact_pass_tasks", "gtx_graph_sv_table", "gtx_ctx_pass_times", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_ctx_profile_log", "gtx_records_failed", "gtx_vcf_sites", "gtx_vcf_records_final", "gtx_align_batch_planes_compact", "gtx_score_batch_compact", "gtx_scores_replay_compact", "gtx_scores_replay_log", "gtx_scores_replay_apply", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
+           "gtx_align_batch", "gtx_score_batch", "gtx_calls_batch", "gtx_ctx_big_records", "gtx_ctx_big_records_rewind", "gtx_ctx_exact_pass_tasks", "gtx_graph_sv_table", "gtx_ctx_pass_times", "gtx_ctx_error_count", "gtx_ctx_profile", "gtx_ctx_profile_log", "gtx_records_failed", "gtx_vcf_sites", "gtx_vcf_records_final", "gtx_align_batch_planes_compact", "gtx_score_batch_compact", "gtx_align_batch_planes_triaged", "gtx_score_batch_queued", "gtx_scores_replay_compact", "gtx_scores_replay_log", "gtx_scores_replay_apply", "gtx_scores_finalize", "gtx_phase_flags", "gtx_stream_create",
            "gtx_stream_destroy", "gtx_stream_push", "gtx_stream_set_coverage", "gtx_stream_finish", "gtx_stream_counts", "gtx_graph_build", "gtx_graph_from_files", "gtx_graph_get_view",
            "gtx_graph_destroy",
            "gtx_scores_alloc", "gtx_scores_zero", "gtx_scores_free", "gtx_scores_reduce", "gtx_comm_unique_id", "gtx_comm_init_rank",
@@ -170,6 +170,10 @@ def lib():
                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gtx_score_batch_compact.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                               C.POINTER(ScoreBuffers), C.c_void_p]
+        L.gtx_align_batch_planes_triaged.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gtx_score_batch_queued.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.POINTER(ScoreBuffers), C.c_void_p]
         L.gtx_scores_replay_compact.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                                 C.POINTER(ScoreBuffers), C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.gtx_scores_replay_log.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(ScoreBuffers),
@@ -898,6 +902,8 @@ REC_WIDE, WIDE_MASK_WORDS = 0x40000000, 80  # include/gtx.h: GTX_REC_WIDE, GTX_W
 
 
 TASK_HAS_VARIANTS, TASK_COMPACT, COMPACT_WORDS = 1, 2, 8
+WORK_HEADER_WORDS = 4  # GTX_WORK_HEADER_WORDS: gtx_align_batch_planes_triaged's queue starts behind them
+TRIAGE_ITEMS_ARE_READS = 1  # GTX_TRIAGE_ITEMS_ARE_READS
 REPLAY_ENTRY = np.dtype([("item", np.uint32), ("cell", np.uint32), ("order_eps", np.uint32), ("mask_lo", np.uint32), ("mask_hi", np.uint32), ("pad", np.uint32)])
 
 

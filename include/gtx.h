@@ -414,6 +414,32 @@ int gtx_score_batch_words(gtx_ctx *, const gtx_score_item * d_items, const uint3
  * be NULL: the stage then reads the items); same results */
 int gtx_score_batch_compact(gtx_ctx *, const gtx_score_item * d_items, const uint32_t * d_item_words, uint32_t n_items, const uint32_t * d_records,
                             uint32_t rec_words, const uint32_t * d_compact, const uint8_t * d_task_flags, const gtx_score_buffers * acc, void * stream);
+/* THE SCORER'S FIRST STAGE BEHIND THE ALIGNMENT (round 6).  update_haplotype_scores_geno (vcf_writer.cpp:88-250) looks at every read;
+ * the scorer's first stage finds the few whose records carry a variant site (the side array + the items' words: 5 bytes per
+ * item) and leaves their items in a queue for the second stage.  gtx_score_batch_* run it in front of the scoring, on the
+ * caller's stream -- for a host that keeps batches in flight (gtx_align_batch_planes_staged) that is the stream of the
+ * position-hinted passes, the one that sets the step's time.  gtx_align_batch_planes_triaged is gtx_align_batch_planes_compact
+ * (d_compact may be NULL: every record in its slot) that ALSO runs that stage, behind its last alignment launch and on that
+ * launch's stream (the tail stream, idle half of the time), into d_work: GTX_WORK_HEADER_WORDS + n_items words, 16-byte aligned,
+ * [0] = number of items with work, [GTX_WORK_HEADER_WORDS ...] = their indices (any order).  d_items / d_item_words (the latter
+ * may be NULL) as for gtx_score_batch_words; the items must name reads of THIS batch.  done_event is behind the stage.
+ * gtx_score_batch_queued scores the items of that queue: the second stage alone; same accumulators as gtx_score_batch_compact
+ * over the same records (the order in which items are scored never matters below the saturation guard).  On an SV graph the
+ * queue also holds the items that only add to the reference depth.
+ * triage_flags: GTX_TRIAGE_ITEMS_ARE_READS -- the caller's promise that item i is read i of this batch, alone and aligned forward
+ * only (first.align_index == i, GTX_FLAG_FORWARD_ONLY, no second read: what gtx_stream_push makes of a batch of unpaired
+ * records), n_items == n_reads; d_items and d_item_words are not looked at (may be NULL).  The position-hinted pass then leaves
+ * one bit per read (a word per wavefront) and the stage reads those, 1/40 of the side bytes and item words, which makes it
+ * cheap enough to run beside the next batch's position-hinted pass.  Not for SV graphs (GTX_ERR_UNSUPPORTED). */
+#define GTX_WORK_HEADER_WORDS 4u
+#define GTX_TRIAGE_ITEMS_ARE_READS 1u
+int gtx_align_batch_planes_triaged(gtx_ctx *, const uint8_t * d_planes, uint32_t plane_stride, const gtx_read_meta * d_meta, uint32_t n_reads,
+                                   uint32_t * d_records, uint32_t rec_words, uint32_t * d_compact, uint8_t * d_task_flags,
+                                   const gtx_score_item * d_items, const uint32_t * d_item_words, uint32_t n_items, uint32_t triage_flags,
+                                   uint32_t * d_work, void * stream, void * front_event, void * tail_stream, void * done_event);
+int gtx_score_batch_queued(gtx_ctx *, const gtx_score_item * d_items, uint32_t n_items, const uint32_t * d_records, uint32_t rec_words,
+                           const uint32_t * d_compact, const uint8_t * d_task_flags, const uint32_t * d_work, const gtx_score_buffers * acc,
+                           void * stream);
 
 /* number of score items the kernel refused so far because one read touched more variant sites than its table holds
  * (must be 0 for the accumulators to be complete) */

@@ -182,7 +182,8 @@ class GpuBackend:
             compact_tasks = np.nonzero(fl[0::2] & gtx.TASK_COMPACT)[0]
             assert not raw.reshape(2 * n, rec_words)[2 * compact_tasks].any(), "a compact record's slot was written"
             merged = gtx.merge_compact(raw, comp, fl, n, rec_words)
-            self.compact = dict(merged=merged, raw=raw.copy(), comp=comp, fl=fl, n=n, share=len(compact_tasks) / n)
+            self.compact = dict(merged=merged, raw=raw.copy(), comp=comp, fl=fl, n=n, share=len(compact_tasks) / n,
+                                d_planes=d_planes, d_meta=d_meta, stride=stride)
             self.d_rec = d_rec
             return merged
         gtx.check(gtx.lib().gtx_align_batch(self.ctx.h, d_seq.data_ptr(), seq.shape[1], d_meta.data_ptr(), n, d_rec.data_ptr(),
@@ -214,8 +215,43 @@ class GpuBackend:
         cp = getattr(self, "compact", None)
         if cp is not None and records is cp["merged"]:  # (the records of the compact call above: scored where the device left them)
             d_rec, d_comp, d_fl = self._dev(cp["raw"]), self._dev(cp["comp"]), self._dev(cp["fl"])
-            gtx.check(gtx.lib().gtx_score_batch_compact(self.ctx.h, d_items.data_ptr(), None, len(items), d_rec.data_ptr(), rec_words,
-                                                        d_comp.data_ptr(), d_fl.data_ptr(), C.byref(buf), None))
+            if os.environ.get("HARNESS_TRIAGED") == "1":
+                # gtx_align_batch_planes_triaged + gtx_score_batch_queued: the same reads aligned once more with the items at hand -- the
+                # scorer's first stage runs behind the alignment, on a second stream --, the same records, the second stage alone
+                n = cp["n"]
+                words = np.zeros(len(items), np.uint32)
+                gtx.check(gtx.lib().gtx_item_words(items.ctypes.data_as(C.c_void_p), len(items), words.ctypes.data_as(C.c_void_p)))
+                use_words = os.environ.get("HARNESS_TRIAGED_WORDS", "1") == "1"
+                d_words = self._dev(words)
+                d_rec2 = torch.zeros(max(n, 1) * 2 * rec_words, dtype=torch.int32, device="cuda:0")
+                d_comp2 = torch.full((n * gtx.COMPACT_WORDS,), -1, dtype=torch.int32, device="cuda:0")
+                d_fl2 = torch.zeros(2 * n, dtype=torch.uint8, device="cuda:0")
+                d_work = torch.full((len(items) + gtx.WORK_HEADER_WORDS,), -1, dtype=torch.int32, device="cuda:0")
+                front, done = torch.cuda.Event(), torch.cuda.Event()
+                tail = torch.cuda.Stream()
+                front.record()
+                done.record()
+                torch.cuda.synchronize()
+                gtx.check(gtx.lib().gtx_align_batch_planes_triaged(self.ctx.h, cp["d_planes"].data_ptr(), cp["stride"], cp["d_meta"].data_ptr(), n, d_rec2.data_ptr(),
+                                                                   rec_words, d_comp2.data_ptr(), d_fl2.data_ptr(), d_items.data_ptr(),
+                                                                   d_words.data_ptr() if use_words else None, len(items),
+                                                                   gtx.TRIAGE_ITEMS_ARE_READS if os.environ.get("HARNESS_TRIAGED_READS") == "1" else 0, d_work.data_ptr(), None,
+                                                                   C.c_void_p(front.cuda_event), C.c_void_p(tail.cuda_stream), C.c_void_p(done.cuda_event)))
+                torch.cuda.current_stream().wait_event(done)
+                gtx.check(gtx.lib().gtx_score_batch_queued(self.ctx.h, d_items.data_ptr(), len(items), d_rec2.data_ptr(), rec_words, d_comp2.data_ptr(),
+                                                           d_fl2.data_ptr(), d_work.data_ptr(), C.byref(buf), None))
+                torch.cuda.synchronize()
+                fl2 = d_fl2.cpu().numpy()
+                assert np.array_equal(fl2, cp["fl"]), "the side array of the second alignment differs"
+                merged2 = gtx.merge_compact(d_rec2.cpu().numpy().view(np.uint32), d_comp2.cpu().numpy().view(np.uint32), fl2, n, rec_words)
+                assert np.array_equal(merged2, cp["merged"]), "the records of the second alignment differ"
+                work = d_work.cpu().numpy().view(np.uint32)
+                queued = work[gtx.WORK_HEADER_WORDS:gtx.WORK_HEADER_WORDS + int(work[0])]
+                assert int(work[0]) <= len(items) and len(np.unique(queued)) == len(queued) and (queued < len(items)).all()
+                self.triaged = dict(queued=np.sort(queued), words=words)
+            else:
+                gtx.check(gtx.lib().gtx_score_batch_compact(self.ctx.h, d_items.data_ptr(), None, len(items), d_rec.data_ptr(), rec_words,
+                                                            d_comp.data_ptr(), d_fl.data_ptr(), C.byref(buf), None))
         else:
             d_rec = self._dev(np.ascontiguousarray(records, np.uint32))
             gtx.check(gtx.lib().gtx_score_batch(self.ctx.h, d_items.data_ptr(), len(items), d_rec.data_ptr(), rec_words, C.byref(buf),

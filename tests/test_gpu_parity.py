@@ -432,13 +432,66 @@ def test_dense_records_of_pass_0(kind, monkeypatch):
     assert (b.compact["share"] > 0.6) if kind == "snp1k" else (b.compact["share"] < 0.05), b.compact["share"]
 
 
+@pytest.mark.parametrize("triaged", ["", "words", "items"])
 @pytest.mark.parametrize("kind", ["snp100", "snp25"])
-def test_stream_scores_over_dense_records(kind, monkeypatch):
+def test_stream_scores_over_dense_records(kind, triaged, monkeypatch):
     """the scorer reads a mate's record where the position-hinted pass left it (gtx_score_batch_compact, gtx_scores_replay_compact):
-    pairs, duplicates, parked mates, three samples -- accumulators, calls, flags and VCF text == the oracle's"""
+    pairs, duplicates, parked mates, three samples -- accumulators, calls, flags and VCF text == the oracle's; `triaged`: the
+    scorer's first stage behind the alignment on a second stream, the second stage alone over its queue
+    (gtx_align_batch_planes_triaged, gtx_score_batch_queued), with and without the items' words"""
     monkeypatch.setenv("HARNESS_COMPACT", "1")
+    if triaged:
+        monkeypatch.setenv("HARNESS_TRIAGED", "1")
+        monkeypatch.setenv("HARNESS_TRIAGED_WORDS", "1" if triaged == "words" else "0")
     ref, recs, codes, rec = scenarios.paired_case(kind, n_ref=100000, n_pairs=8000, region_begin=310000, n_samples=3)
     o = Oracle(ref, recs, region_begin=310000)
     b = harness.GpuBackend(gtx.graph_from_records(ref, recs, region_begin=310000))
     want = run_stream(b, o, codes, rec, n_samples=3)
     assert want.sum() > 0 and b.compact is not None
+    assert not triaged or b.triaged["queued"].size > 0
+
+
+@pytest.mark.parametrize("kind", ["snp1k", "snp100", "cfg3"])
+def test_first_scoring_stage_behind_the_alignment(kind, monkeypatch):
+    """gtx_align_batch_planes_triaged + gtx_score_batch_queued over unpaired reads (item i = read i), a third of them with a missing or
+    shifted hint (their records come from the passes behind the position-hinted one): the accumulators of gtx_score_batch_compact,
+    whichever way the first stage learns of the reads with a variant site -- the items' words, the items, the reads' bits
+    (GTX_TRIAGE_ITEMS_ARE_READS) -- and the same queue all three times"""
+    monkeypatch.setenv("HARNESS_COMPACT", "1")
+    ref, recs, codes, pos = scenarios.synthetic_case(kind, n_ref=200000, n_reads=20000, region_begin=1000000, seed=5)
+    b = harness.GpuBackend(gtx.graph_from_records(ref, recs, region_begin=1000000, add_all_variants=kind == "cfg3"))
+    n = len(codes)
+    hint = np.array(pos, np.int64)
+    rng = np.random.default_rng(7)
+    hint[rng.random(n) < 0.15] = -1
+    shifted = rng.random(n) < 0.15
+    hint[shifted & (hint >= 0)] += 1
+    meta = harness.read_meta(np.full(n, 150), flags=np.full(n, gtx.FLAG_FORWARD_ONLY), pos=hint)
+    records = b.align(gtx.pack_nibbles(codes), meta)
+    assert b.compact is not None
+    items = np.zeros(n, gtx.SCORE_ITEM)
+    items["first"]["align_index"] = np.arange(n, dtype=np.uint32)
+    items["first"]["mapq"] = 60
+    items["first"]["flag"] = gtx.FLAG_FORWARD_ONLY
+    items["first"]["pos"] = pos
+    items["second"]["align_index"] = gtx.INVALID_ID
+    want = harness.canonical_scores(b.ctx, b.score(items, records))  # (the connection log is a list in the order the items were scored)
+    assert want.sum() > 0
+    queues = []
+    for mode in ("words", "items", "reads"):
+        monkeypatch.setenv("HARNESS_TRIAGED", "1")
+        monkeypatch.setenv("HARNESS_TRIAGED_WORDS", "0" if mode == "items" else "1")
+        monkeypatch.setenv("HARNESS_TRIAGED_READS", "1" if mode == "reads" else "0")
+        got = harness.canonical_scores(b.ctx, b.score(items, records))
+        assert np.array_equal(want, got), mode
+        queues.append(b.triaged["queued"])
+    assert len(queues[0]) > 0 and np.array_equal(queues[0], queues[1]) and np.array_equal(queues[0], queues[2])
+    # (the queue is the reads whose forward record carries a variant site: the side array says which)
+    assert np.array_equal(queues[0], np.nonzero(b.compact["fl"][0::2] & gtx.TASK_HAS_VARIANTS)[0])
+
+
+def test_ambiguous_bases_beside_substitutions():
+    """(the emulation's case on the device, more reads)"""
+    from test_emu_parity import ambiguous_beside_substitutions_case
+    done = ambiguous_beside_substitutions_case(harness.GpuBackend, 6000)
+    assert done["snp1k"] > 1500, done
