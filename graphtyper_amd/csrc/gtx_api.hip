@@ -578,6 +578,14 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
         fwd_flag = GTX_TASK_COMPACT;
       }
     }
+    // (decline_all & 4, SV graphs: what this pass declines goes straight to the general pass.  The express pass finishes next to
+    //  none of the reads of an SV graph -- breakpoint alleles are not its cases: cfg5, 624 of 184 k -- but looked every one of them
+    //  up first: 0.66 ms of a 2.1 ms step.)
+    if ((decline_all & 4u) != 0 && fwd)
+    {
+      fwd = false;
+      fwd2 = true;
+    }
     // the dense side array (gtx_align_batch_flags): what this pass settles -- the forward task it finished, the reverse
     // task that is not aligned at all; the queued tasks get theirs from gtx_task_flags_fixup_kernel behind the last pass
 #ifndef GTX_X_NO_FLAG_STORE /* (experiment build: the kernel without its side bytes) */
@@ -2398,6 +2406,8 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     {
       // pass 0: one read per lane from the position hint; what it declines is queued for pass 1.  (GTX_HINT=decline: the
       // pass runs but declines everything -- a test of the queue plumbing)
+      static bool const sv_express = std::getenv("GTX_SV_EXPRESS") && std::getenv("GTX_SV_EXPRESS")[0] == '1'; // (A/B switch: the express pass on SV graphs as well)
+      bool const sv_skips_express = c->params.is_sv_graph != 0 && !sv_express && force == 0;
       char const * hb = std::getenv("GTX_HINT_BUILD"); // (test switch: lean | dense build of pass 0; default: dense beside the wide express pass)
       bool const hint_dense = hb && hb[0] == 'd' ? true : hb && hb[0] == 'l' ? false : c->express4_wide;
       uint32_t const hint_threads = 64u * GTX_HINT_WAVES;
@@ -2405,7 +2415,7 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
       hipLaunchKernelGGL(hint_long ? gtx_align_hinted_long_kernel : hint_dense ? gtx_align_hinted_dense_kernel : gtx_align_hinted_kernel,
                          dim3((n + hint_threads - 1u) / hint_threads), dim3(hint_threads), 0, st, c->dev_graph, c->dev_index, seq, seq_stride,
                          meta, n, records, rec_words, force_both, queue1, queue2, reinterpret_cast<unsigned long long *>(counters + 2),
-                         static_cast<uint32_t>(force != 0 || (eh && eh[0] == 'd'))
+                         static_cast<uint32_t>(force != 0 || (eh && eh[0] == 'd')) | (sv_skips_express ? 4u : 0u)
 #ifdef GTX_PROF
                            | (eh && eh[0] == 'x' ? 2u : 0u)
 #endif
