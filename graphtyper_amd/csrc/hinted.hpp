@@ -850,17 +850,24 @@ GTX_DEV uint32_t hinted_on_path(GraphView const & g, IndexView const & ix, Row r
     while (need != 0)
     {
       // (two halves a round, their loads in flight together: one half a round made a lane with two needed halves -- one wavefront
-      //  in two has such a lane -- wait for two round trips one after the other, and the wavefront with it)
+      //  in two had such a lane -- wait for two round trips one after the other, and the wavefront with it.  The second half's
+      //  slot is worked out by the lanes that have one: a wavefront without such a lane -- most, with filters of 128 bits per
+      //  key -- branches round it)
       uint32_t const j0 = static_cast<uint32_t>(__builtin_ctz(need)); // k-mer j / 2, half j % 2
       need &= need - 1u;
-      uint32_t const j1 = need != 0 ? static_cast<uint32_t>(__builtin_ctz(need)) : j0;
-      need &= need - 1u; // (0 stays 0)
-      uint32_t a0, a1, b0, b1, word0, mask0, word1, mask1;
+      uint32_t a0, a1, word0, mask0, x1 = 0, mask1 = 1u;
       plane_extract16_at(row, (K - 1) * (j0 >> 1) + 16u * (j0 & 1u), a0, a1);
-      plane_extract16_at(row, (K - 1) * (j1 >> 1) + 16u * (j1 & 1u), b0, b1);
       hint_filter_slot(a0, a1, ix.filt_log2, word0, mask0);
-      hint_filter_slot(b0, b1, ix.filt_log2, word1, mask1);
-      uint32_t const x0 = ix.filt[j0 & 1u][word0], x1 = ix.filt[j1 & 1u][word1];
+      uint32_t const x0 = ix.filt[j0 & 1u][word0];
+      if (need != 0)
+      {
+        uint32_t const j1 = static_cast<uint32_t>(__builtin_ctz(need));
+        need &= need - 1u;
+        uint32_t b0, b1, word1;
+        plane_extract16_at(row, (K - 1) * (j1 >> 1) + 16u * (j1 & 1u), b0, b1);
+        hint_filter_slot(b0, b1, ix.filt_log2, word1, mask1);
+        x1 = ix.filt[j1 & 1u][word1];
+      }
       maybe = maybe || (x0 & mask0) == mask0 || (x1 & mask1) == mask1;
     }
 #endif
