@@ -650,8 +650,12 @@ class Workload:
             #  in all three tries -- a state of that process' streams, not of the box: the run before it on the same box had 0.75.
             #  New streams get new places on the hardware queues: the schedule is given two more chances on fresh ones before the
             #  run settles for one step at a time.)
+            # (Round 6: one process in ten still ran it at the one-at-a-time rate AFTER winning the comparison by a hair -- 0.7645 against
+            #  0.771 ms, where a schedule whose streams overlap takes 0.59: the headline of that process was 12.97 G reads/s instead of
+            #  16.9.  "Faster" is not the test: the schedule has to be clearly faster than one step at a time -- at least a tenth -- or its
+            #  streams share a hardware queue; up to six sets of fresh streams are tried, which leaves one process in a million.)
             retries = 0
-            while t_stag > t_one and retries < 2 and dist is None:
+            while t_stag > 0.9 * t_one and retries < 6 and dist is None:
                 retries += 1
                 self.fresh_streams()
                 self.steps_staggered(2 * n_lanes)
@@ -690,9 +694,13 @@ class Workload:
             self.calibration = {"staggered_ms_per_step": 1000.0 * t_stag, "one_at_a_time_ms_per_step": 1000.0 * t_one, "fresh_stream_retries": retries}
             if t_lanes != float("inf"):
                 self.calibration["whole_steps_on_streams_of_their_own_ms_per_step"] = 1000.0 * t_lanes
-            if self.allow_whole_steps and t_lanes < t_stag and t_lanes < t_one:
+            # (... and a process whose staggered schedule still does not overlap after that takes whole steps in flight when THEY do)
+            misfired = t_stag > 0.9 * t_one and t_lanes < 0.95 * min(t_stag, t_one)
+            if (self.allow_whole_steps or misfired) and t_lanes < t_stag and t_lanes < t_one:
                 stag = False
                 self.staggered = False
+                if misfired:
+                    self.calibration["staggered_schedule_did_not_overlap"] = "whole steps in flight on streams of their own run the timed region"
             elif t_stag > t_one:
                 stag, n_lanes = False, 1
                 self.staggered = False
