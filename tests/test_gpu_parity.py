@@ -8,6 +8,7 @@ import pytest
 
 import harness
 import scenarios
+import ctypes as C
 from graphtyper_amd import lib as gtx
 from oracle_lib import Oracle, encode
 from test_emu_parity import check_align, five_kmer_case, cfg3_case, neardup_case, direct_probes_case, n_runs_case, three_n_case, sv_deletion_case, edge_case, express_variants_case, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case, satellite_case, homopolymer_case, dinucleotide_case
@@ -495,3 +496,55 @@ def test_ambiguous_bases_beside_substitutions():
     from test_emu_parity import ambiguous_beside_substitutions_case
     done = ambiguous_beside_substitutions_case(harness.GpuBackend, 6000)
     assert done["snp1k"] > 1500, done
+
+
+def test_arguments_of_the_triaged_entry_points():
+    """gtx_align_batch_planes_triaged / gtx_score_batch_queued refuse what they cannot do: no side array, no items without
+    GTX_TRIAGE_ITEMS_ARE_READS, a queue that is not 16-byte aligned, n_items != n_reads with that flag, an unknown flag bit; an
+    empty batch leaves an empty queue"""
+    import torch
+    ref, recs, codes, pos = scenarios.synthetic_case("snp1k", n_ref=30000, n_reads=256, region_begin=1000000, seed=3)
+    b = harness.GpuBackend(gtx.graph_from_records(ref, recs, region_begin=1000000))
+    L, n = gtx.lib(), len(codes)
+    seq = gtx.pack_nibbles(codes)
+    stride = (seq.shape[1] + 15) // 16 * 16
+    d_seq = b._dev(seq)
+    d_planes = torch.zeros(n * stride, dtype=torch.uint8, device="cuda:0")
+    gtx.check(L.gtx_reads_to_planes(b.ctx.h, d_seq.data_ptr(), seq.shape[1], n, d_planes.data_ptr(), stride, None))
+    d_meta = b._dev(harness.read_meta(np.full(n, 150), flags=np.full(n, gtx.FLAG_FORWARD_ONLY), pos=pos))
+    d_rec = torch.zeros(n * 2 * harness.REC_WORDS, dtype=torch.int32, device="cuda:0")
+    d_comp = torch.zeros(n * gtx.COMPACT_WORDS, dtype=torch.int32, device="cuda:0")
+    d_fl = torch.zeros(2 * n, dtype=torch.uint8, device="cuda:0")
+    d_work = torch.full((n + gtx.WORK_HEADER_WORDS + 4,), -1, dtype=torch.int32, device="cuda:0")
+    items = np.zeros(n, gtx.SCORE_ITEM)
+    items["first"]["align_index"] = np.arange(n, dtype=np.uint32)
+    items["first"]["flag"] = gtx.FLAG_FORWARD_ONLY
+    items["second"]["align_index"] = gtx.INVALID_ID
+    d_items = b._dev(items)
+
+    def call(fl=d_fl.data_ptr(), it=d_items.data_ptr(), n_items=n, flags=0, work=d_work.data_ptr(), n_reads=n):
+        return L.gtx_align_batch_planes_triaged(b.ctx.h, d_planes.data_ptr(), stride, d_meta.data_ptr(), n_reads, d_rec.data_ptr(), harness.REC_WORDS,
+                                                d_comp.data_ptr(), fl, it, None, n_items, flags, work, None, None, None, None)
+
+    assert call(fl=None) == 1
+    assert call(it=None) == 1
+    assert call(work=d_work.data_ptr() + 4) == 1
+    assert call(flags=gtx.TRIAGE_ITEMS_ARE_READS, n_items=n - 1) == 1
+    assert call(flags=2) == 1
+    assert call(it=None, flags=gtx.TRIAGE_ITEMS_ARE_READS) == 0  # (the items are not looked at)
+    torch.cuda.synchronize()
+    by_bits = d_work.cpu().numpy().view(np.uint32).copy()
+    assert call() == 0
+    torch.cuda.synchronize()
+    by_items = d_work.cpu().numpy().view(np.uint32)
+    k = int(by_bits[0])
+    assert 0 < k == int(by_items[0]) < n
+    assert np.array_equal(np.sort(by_bits[gtx.WORK_HEADER_WORDS:gtx.WORK_HEADER_WORDS + k]), np.sort(by_items[gtx.WORK_HEADER_WORDS:gtx.WORK_HEADER_WORDS + k]))
+    assert call(n_reads=0, n_items=0) == 0
+    torch.cuda.synchronize()
+    assert int(d_work.cpu().numpy().view(np.uint32)[0]) == 0
+    acc = harness.Accumulators(b.ctx, 1)
+    devs = [b._dev(a) for a in acc.arrays()]
+    buf = acc.buffers([d.data_ptr() for d in devs])
+    assert L.gtx_score_batch_queued(b.ctx.h, d_items.data_ptr(), n, d_rec.data_ptr(), harness.REC_WORDS, d_comp.data_ptr(), d_fl.data_ptr(), None, C.byref(buf), None) == 1
+    assert L.gtx_score_batch_queued(b.ctx.h, d_items.data_ptr(), n, d_rec.data_ptr(), harness.REC_WORDS, d_comp.data_ptr(), None, d_work.data_ptr(), C.byref(buf), None) == 1
