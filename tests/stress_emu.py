@@ -3,7 +3,9 @@
 emulation against the oracle over seeds x graph shapes x error / N rates x read lengths x region offsets, for both builds
 of pass 1; with --stream also the scoring path (gtx_stream -> align -> score -> calls -> phase flags).
     python tests/stress_emu.py 100 110            # alignment, seeds 100..109
-    python tests/stress_emu.py --stream 300 310"""
+    python tests/stress_emu.py --stream 300 310
+    python tests/stress_emu.py --gpu 700 704      # the same cases through the C ABI on the device (dense records; --stream: the
+                                                  # scorer's first stage behind the alignment for every second case)"""
 import argparse
 import os
 import sys
@@ -20,6 +22,9 @@ import scenarios  # noqa: E402
 from graphtyper_amd import lib as gtx  # noqa: E402
 from oracle_lib import Oracle  # noqa: E402
 from test_emu_parity import check_align, run_stream  # noqa: E402
+
+
+BACKEND = harness.EmuBackend
 
 
 def align_seed(seed):
@@ -51,7 +56,7 @@ def align_seed(seed):
                 # position hints: right for most reads, a few bases off or absent for the others; check_align also runs
                 # the batch without hints, with shifted hints and with other reads' hints (records must not depend on them)
                 hint = np.where(rng.random(len(pos)) < 0.9, pos, np.where(rng.random(len(pos)) < 0.5, pos + rng.integers(-3, 4, size=len(pos)), -1))
-                check_align(harness.EmuBackend(g), o, reads, flags=flags, isize=isize, pos=hint)
+                check_align(BACKEND(g), o, reads, flags=flags, isize=isize, pos=hint)
             except AssertionError:
                 print("FAIL", dict(seed=seed, kind=kind, mode=mode, err=err, n_rate=n_rate, read_len=read_len, region_begin=rb), flush=True)
                 raise
@@ -72,7 +77,10 @@ def stream_seed(seed):
             os.environ["GTX_EXPRESS4"] = mode
             os.environ["GTX_HINT_BUILD"] = "dense" if mode == "wide" else "lean"
             try:
-                run_stream(harness.EmuBackend(gtx.graph_from_records(ref, recs, region_begin=rb)), o, codes, rec, n_samples=ns)
+                if BACKEND is not harness.EmuBackend:
+                    os.environ["HARNESS_TRIAGED"] = "1" if (n + seed) % 2 else "0"
+                    os.environ["HARNESS_TRIAGED_WORDS"] = "1" if seed % 2 else "0"
+                run_stream(BACKEND(gtx.graph_from_records(ref, recs, region_begin=rb)), o, codes, rec, n_samples=ns)
             except AssertionError as e:
                 if str(e) == "":  # run_stream's "not vacuous" check on a small case: not a parity failure
                     continue
@@ -87,8 +95,15 @@ def main():
     ap.add_argument("first", type=int)
     ap.add_argument("last", type=int)
     ap.add_argument("--stream", action="store_true")
+    ap.add_argument("--gpu", action="store_true", help="through the C ABI on cuda:0 instead of the host emulation")
     a = ap.parse_args()
-    gtx.build()
+    if a.gpu:
+        global BACKEND
+        BACKEND = harness.GpuBackend
+        os.environ["HARNESS_COMPACT"] = "1"
+        os.environ["HARNESS_SHORT_READS"] = "1"
+    else:
+        gtx.build()
     t0, n = time.time(), 0
     for seed in range(a.first, a.last):
         n += stream_seed(seed) if a.stream else align_seed(seed)
