@@ -1636,6 +1636,8 @@ def extra_workload(args, torch, gtx, synth, device, ref, recs, n_samples, add_al
             sys.stderr.write("  %-22s %10.0f  %5.1f%%\n" % (nm, prof[k] / float(prof[15]), 100.0 * prof[k] / tot))
         sys.stderr.write("  longest task %d cycles (task %d); tasks over 100 k / 200 k / 400 k cycles: %d / %d / %d (all launches of the run)\n" %
                          (int(prof[10]) >> 32, int(prof[10]) & 0xFFFFFFFF, prof[11], prof[12], prof[13]))
+        sys.stderr.write("  handed to the HBM-table pass for: labels %d, paths %d, walk %d, record %d (a task may name several)\n" %
+                         (int(prof[29]) & 0xFFFFFFFF, int(prof[29]) >> 32, int(prof[30]) & 0xFFFFFFFF, int(prof[30]) >> 32))
     if prof[28] > 0:
         sys.stderr.write("cfg3-like: scoring kernel, cycles per visit of a workgroup's first lane (profiling build), %d visits: item fetch %.0f, scoring %.0f, flush %.0f\n" %
                          (prof[28], prof[25] / float(prof[28]), prof[26] / float(prof[28]), prof[27] / float(prof[28])))

@@ -1847,6 +1847,7 @@ GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, ui
   // of the last such walk stay in wb.dfs_out; a second identical request reuses them (the budget can only have shrunk
   // to that walk's own mismatch count or below: same labels or none).
   uint32_t memo_anchor = INVALID, memo_idx = 0, memo_nl = 0, memo_mm = 0;
+  GTX_PROF_WBEGIN
   for (uint32_t i = 0; i < n_paths; ++i)
   {
     DPath const & path = ws.paths[i];
@@ -1961,15 +1962,18 @@ GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, ui
         }
       }
     }
+    GTX_PROF_WTICK(2)
     if (!shortcut)
     {
       uint32_t const n_locs = get_locations<W>(g, anchor, path, wb.locs, AlignCfg::LOC_CAP, status);
       W::lds_sync();
+      GTX_PROF_WTICK(3)
       if (status)
         return;
       if (n_locs == 0 || n_locs > MAX_NUM_LOCATIONS_PER_PATH)
         continue;
       nl = iterative_dfs<W>(g, ws, n_locs, starts, sr, mm, status);
+      GTX_PROF_WTICK(4)
       if (status)
         return;
       // remember the walk when its start did not depend on the path: one location, inside a reference node
@@ -2023,6 +2027,7 @@ GTX_DEV void walk_read(GraphView const & g, AlignWorkspace & ws, bool starts, ui
     if (status)
       return;
   }
+  GTX_PROF_WTICK(5)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2912,9 +2917,9 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
         if (status)
           break;
       }
-      GTX_PROF_TICK(2)
+      GTX_PROF_TICKA(2)
       add_kmer_labels<W>(ws, exact_labels, n_lbl, rs, re, 0, false, n_paths, longest, status);
-      GTX_PROF_TICK(3)
+      GTX_PROF_TICKA(3)
       if (status)
         break;
       // Hamming-1 list: the 96 neighbours of a unique exact key, else the exact list again
@@ -2936,9 +2941,9 @@ GTX_DEV uint32_t align_paths(GraphView const & g, IndexView const & ix, AlignWor
         if (status)
           break;
       }
-      GTX_PROF_TICK(4)
+      GTX_PROF_TICKA(4)
       add_kmer_labels<W>(ws, ws.lbl, n_lbl, rs, re, 1, false, n_paths, longest, status);
-      GTX_PROF_TICK(5)
+      GTX_PROF_TICKA(5)
     }
     if (!status && !(seeded && finish_single_path<W>(Here{}, g, ws, n_paths, longest)))
     {

@@ -158,6 +158,17 @@ constexpr uint32_t GTX_ST_WIDE_ALLELE = 32u;
 #define GTX_PROF_RESET
 #define GTX_PROF_TICK(k)
 #endif
+// (a one-off profiling build, -DGTX_PROF -DGTX_PROF_WALK: the walks' parts in slots 2..5 -- 2 the path's geometry and the shortcuts, 3
+//  get_locations, 4 iterative_dfs, 5 the lists' copies and their chaining --, what those slots hold otherwise goes to slot 1)
+#if defined(GTX_PROF) && defined(GTX_PROF_WALK)
+#define GTX_PROF_TICKA(k) GTX_PROF_TICK(1)
+#define GTX_PROF_WBEGIN GTX_PROF_BEGIN
+#define GTX_PROF_WTICK(k) GTX_PROF_TICK(k)
+#else
+#define GTX_PROF_TICKA(k) GTX_PROF_TICK(k)
+#define GTX_PROF_WBEGIN
+#define GTX_PROF_WTICK(k)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // graph helpers

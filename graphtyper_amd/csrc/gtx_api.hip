@@ -971,6 +971,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GTX_GENERAL_
         big_tasks[slot] = task_base + task; // (the HBM-table pass runs once over the whole batch)
       else
         atomicAdd(big_state + 3, 1u);
+#ifdef GTX_PROF // (profiling build: why the tasks leave this pass -- [29] = labels | paths << 32, [30] = walk | record << 32)
+      atomicAdd(g.prof + 29, ((st & GTX_ST_LABEL_OVERFLOW) ? 1ull : 0ull) | ((st & GTX_ST_PATH_OVERFLOW) ? 1ull << 32 : 0ull));
+      atomicAdd(g.prof + 30, ((st & GTX_ST_DFS_OVERFLOW) ? 1ull : 0ull) | ((st & GTX_ST_RECORD_OVERFLOW) ? 1ull << 32 : 0ull));
+#endif
     }
   }
   if (n_forward && (threadIdx.x & 63u) == 0)
