@@ -317,7 +317,10 @@ class Workload:
         self.reduced_bytes = int(reduced.value)
         self.d_phred = torch.zeros(max(n_samples * ctx.total_tri, 1), dtype=torch.uint8, device=device)
         self.d_calls = torch.zeros(max(n_samples * ctx.n_hap, 1) * gtx.SAMPLE_CALL.itemsize, dtype=torch.uint8, device=device)
-        self.stream = torch.cuda.Stream(device=device)
+        # (GTX_BENCH_PRIO, an A/B switch: "H" gives the stream of the position-hinted passes the higher HIP priority, "T" the tails' --
+        #  with GTX_BENCH_SCORE_ON=S the scoring then runs beside them on a stream of the default priority and takes what they leave)
+        self.prio = os.environ.get("GTX_BENCH_PRIO", "")
+        self.stream = torch.cuda.Stream(device=device, priority=-1 if "H" in self.prio else 0)
         self.sp = C.c_void_p(self.stream.cuda_stream)
         # further lanes (--lanes): a step is still align -> score -> calls in stream order, but step k runs on lane k mod
         # lanes with that lane's stream, records and accumulators, so that the short queues at the end of one step (express,
@@ -339,7 +342,7 @@ class Workload:
             self.lanes.append(lane)
         # (staggered schedule: the short queues behind every position-hinted pass; GTX_BENCH_TAILS=2: those of consecutive steps on
         #  two streams -- measured the same)
-        self.tail_streams = [torch.cuda.Stream(device=device) for _ in range(max(1, int(os.environ.get("GTX_BENCH_TAILS", "1"))))]
+        self.tail_streams = [torch.cuda.Stream(device=device, priority=-1 if "T" in self.prio else 0) for _ in range(max(1, int(os.environ.get("GTX_BENCH_TAILS", "1"))))]
         for ln in self.lanes:
             ln["front"], ln["aligned"], ln["scored"] = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
             for ev in (ln["front"], ln["aligned"], ln["scored"]):
@@ -355,11 +358,11 @@ class Workload:
         decided when it is made"""
         torch = self.torch
         torch.cuda.synchronize()
-        for ln in self.lanes:
-            ln["stream"] = torch.cuda.Stream(device=self.device)
+        for k, ln in enumerate(self.lanes):
+            ln["stream"] = torch.cuda.Stream(device=self.device, priority=-1 if (k == 0 and "H" in self.prio) else 0)
             ln["sp"] = C.c_void_p(ln["stream"].cuda_stream)
         self.stream, self.sp = self.lanes[0]["stream"], self.lanes[0]["sp"]
-        self.tail_streams = [torch.cuda.Stream(device=self.device) for _ in self.tail_streams]
+        self.tail_streams = [torch.cuda.Stream(device=self.device, priority=-1 if "T" in self.prio else 0) for _ in self.tail_streams]
         for ln in self.lanes:
             ln["front"], ln["aligned"], ln["scored"] = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
             for ev in (ln["front"], ln["aligned"], ln["scored"]):

@@ -733,9 +733,17 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
 #ifndef GTX_HINT_PER_EU
 #define GTX_HINT_PER_EU 7
 #endif
-__global__ __launch_bounds__(64 * GTX_HINT_WAVES) __attribute__((amdgpu_num_vgpr(GTX_HINT_VGPRS), amdgpu_waves_per_eu(GTX_HINT_PER_EU, GTX_HINT_PER_EU))) void gtx_align_hinted_kernel(GTX_HINTED_ARGS)
+// (round 6, third session: the lean build in workgroups of TWO wavefronts -- fourteen of 10 KB per CU.  A/B on one box, the cfg2 step
+//  in flight: 8 / 4 / 2 / 1 wavefronts = 0.657 / 0.590 / 0.582 / 0.605 ms, the pass itself 0.46 / 0.407 / 0.394 / 0.329: the smaller the
+//  workgroup the sooner a retiring one's room is taken again -- and with one-wave workgroups it is always this pass that takes it:
+//  the short queues beside it get no wavefront in (express 0.18 -> 0.55 ms, a higher priority for their stream changes nothing) and
+//  the scoring waits for them.  The dense and the eight-k-mer builds stay at four: cfg3 is 2 % slower with two.)
+#ifndef GTX_HINT_WAVES_LEAN
+#define GTX_HINT_WAVES_LEAN 2
+#endif
+__global__ __launch_bounds__(64 * GTX_HINT_WAVES_LEAN) __attribute__((amdgpu_num_vgpr(GTX_HINT_VGPRS), amdgpu_waves_per_eu(GTX_HINT_PER_EU, GTX_HINT_PER_EU))) void gtx_align_hinted_kernel(GTX_HINTED_ARGS)
 {
-  GTX_HINTED_PASS(GTX_HINT_WAVES, false, AlignCfg::KC, GTX_HINT_PER_EU <= 6);
+  GTX_HINTED_PASS(GTX_HINT_WAVES_LEAN, false, AlignCfg::KC, GTX_HINT_PER_EU <= 6);
 }
 
 #ifndef GTX_HINT_DENSE_WAVES
@@ -2414,8 +2422,8 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
       bool const sv_skips_express = c->params.is_sv_graph != 0 && !sv_express && force == 0;
       char const * hb = std::getenv("GTX_HINT_BUILD"); // (test switch: lean | dense build of pass 0; default: dense beside the wide express pass)
       bool const hint_dense = hb && hb[0] == 'd' ? true : hb && hb[0] == 'l' ? false : c->express4_wide;
-      uint32_t const hint_threads = 64u * GTX_HINT_WAVES;
       bool const hint_long = seq_stride > HintGeom<AlignCfg::KC>::ROW_BYTES; // (rows for reads of more than 160 bases: the eight-k-mer build)
+      uint32_t const hint_threads = 64u * ((hint_long || hint_dense) ? GTX_HINT_WAVES : GTX_HINT_WAVES_LEAN);
       hipLaunchKernelGGL(hint_long ? gtx_align_hinted_long_kernel : hint_dense ? gtx_align_hinted_dense_kernel : gtx_align_hinted_kernel,
                          dim3((n + hint_threads - 1u) / hint_threads), dim3(hint_threads), 0, st, c->dev_graph, c->dev_index, seq, seq_stride,
                          meta, n, records, rec_words, force_both, queue1, queue2, reinterpret_cast<unsigned long long *>(counters + 2),
