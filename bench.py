@@ -84,7 +84,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the cfg3-like extra workload")
     ap.add_argument("--no-reduce-check", action="store_true", help="N > 1: skip the check of the summed block against one GPU (rank 0 redoes every rank's reads)")
-    ap.add_argument("--lanes", type=int, default=3, help="steps in flight (each with its own records and accumulators); 1 = one after the other.  "
+    ap.add_argument("--lanes", type=int, default=4, help="steps in flight (each with its own records and accumulators); 1 = one after the other.  "
                     "Staggered schedule with four and more lanes: the last lane is the host's slack (Workload.steps_staggered)")
     ap.add_argument("--schedule", choices=["staggered", "lanes"], default="staggered",
                     help="staggered = one stream carries the position-hinted pass of step k and then the scoring of step k-lanes+1, a second "
@@ -303,6 +303,7 @@ class Workload:
         # launches overlap EACH OTHER, a launch takes 0.93 ms from its first workgroup to its last, and a per-launch roofline says
         # nothing about the kernel any more -- the faster schedule is reported beside the line (config.extra.whole_steps_in_flight).
         self.allow_whole_steps = False
+        self.whole_lanes = None  # the most steps in flight when WHOLE steps are (None: as many as there are lanes; cfg2: three beat four)
         self.sets = []   # resident read sets (bases, meta, score items); step k works on set k mod len(sets)
         self.words = {}  # items' data_ptr -> their compact form (gtx_score_batch_words), or None
         self.steps_done = 0
@@ -668,9 +669,11 @@ class Workload:
             #  tails of three steps overlap better that way: cfg3 1.50 ms per step against 1.68 staggered; on cfg2 it is the slower one)
             t_lanes = float("inf")
             if not exchange:
+                n_whole = min(n_lanes, self.whole_lanes or n_lanes)
+
                 def whole_steps(k):
                     for i in range(k):
-                        self.step(i % n_lanes)
+                        self.step(i % n_whole)
                 whole_steps(n_lanes)
                 self.steps_done -= n_lanes
                 t_lanes = min(timed(whole_steps, 2 * n_lanes) for _ in range(3))
@@ -711,6 +714,7 @@ class Workload:
             if warmup:
                 self.steps_staggered(warmup)
         else:
+            n_lanes = min(n_lanes, self.whole_lanes or n_lanes)
             for lane in range(1, n_lanes):
                 self.step(lane)
                 self.steps_done -= 1
@@ -1913,7 +1917,9 @@ def main(argv=None):
             if len(w.lanes) > 1:
                 calib, stag = w.calibration, w.staggered
                 w.staggered = False
+                w.whole_lanes = 3  # (four whole steps in flight are four launches of the position-hinted pass side by side: 0.57 ms per step against 0.52)
                 dt_w, _ = w.run(300, 3, None)
+                w.whole_lanes = None
                 cfg.setdefault("extra", {})["whole_steps_in_flight"] = {
                     "steps": 300, "ms_per_step": 1000.0 * dt_w / 300, "reads_per_s": n * 300 / dt_w,
                     "schedule": "%d steps in flight, each on a stream of its own" % w.used_lanes,

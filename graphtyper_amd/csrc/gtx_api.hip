@@ -1035,6 +1035,21 @@ __global__ __launch_bounds__(256) void gtx_planes_kernel(uint8_t const * __restr
 // The others are appended to a work queue, one atomic per wavefront.
 // The dense side array of gtx_align_batch_flags for the tasks a queue names (queue1: reads whose forward task the
 // position-hinted pass declined; queue2: the tasks of the general pass): one header read per queued task, behind the last pass.
+// What the passes behind the general one were sent in this batch, written straight into the context's pinned words for the next
+// batch's launch sizes ([0]: tasks that left the general pass, [2]: tasks that reached the exact pass).  A kernel of one wavefront and
+// not a copy: the runtime's copy of four bytes is a kernel with workgroups of 1 024 threads, and on the stream of the short queues --
+// beside the position-hinted pass of the next batch -- such a workgroup waited for that pass' end (190 us in the trace; the 512-thread
+// copy this replaces took 9-14 us).
+__global__ __launch_bounds__(64) void gtx_seen_kernel(uint32_t * __restrict__ seen, uint32_t const * __restrict__ big_state, uint32_t const * __restrict__ exact_state)
+{
+  if (threadIdx.x == 0)
+  {
+    __hip_atomic_store(seen + 0, big_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (exact_state)
+      __hip_atomic_store(seen + 2, exact_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 __global__ __launch_bounds__(256) void gtx_task_flags_fixup_kernel(uint32_t const * __restrict__ records, uint32_t rec_words,
                                                                    uint8_t * __restrict__ task_flags, uint32_t const * __restrict__ queue1,
                                                                    uint32_t const * queue1_count, uint32_t const * __restrict__ queue2,
@@ -1886,7 +1901,7 @@ int ctx_upload(gtx_ctx & c, int device)
       c.d_big_records = static_cast<uint32_t *>(p);
     }
     if (ok && (c.h_big_seen = static_cast<uint32_t *>(gtx::pinned_slot_get())) != nullptr)
-      *c.h_big_seen = 0xFFFFFFFFu;
+      c.h_big_seen[0] = c.h_big_seen[2] = 0xFFFFFFFFu; // ([0]: tasks that left the general pass in the last batch, [2]: tasks that reached the exact pass)
     else
       c.h_big_seen = nullptr; // (without it the pass is launched whole)
     ok = ok && hip_ok(gtx::dev_malloc(&p, sizeof(unsigned long long)), "arena cursor");
@@ -2561,8 +2576,7 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
     a.arena_words = c->big_record_words;
     a.arena_cursor = c->d_arena_cursor;
     char const * what = launch_hbm_passes(a, sg);
-    if (!what && c->h_big_seen)
-      (void)hipMemcpyAsync(c->h_big_seen, s->d_big_state, sizeof(uint32_t), hipMemcpyDeviceToHost, sg);
+
     if (!what)
     {
       // the exact launches, with one of the context's slabs: chosen, waited for if need be, used and marked busy again in one
@@ -2578,7 +2592,17 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
       a.exact_slab_bytes = slot->bytes;
       if (!c->exact_fixed_parts) // (as many parts as the slab has room for: none smaller than 2 MB, 32 MB where allele sets are wide)
         a.exact_parts = static_cast<uint32_t>(std::min<uint64_t>(c->exact_parts, std::max<uint64_t>(1u, (slot->bytes >> 20) / (c->has_wide_sites ? 32u : 2u))));
+      // (the launches' grids by what the batch before sent this way -- tasks are claimed one by one, any number of workgroups does
+      //  them all: a workgroup of the pass wants 32 KB of LDS, and beside the position-hinted pass of the next batch a thousand of them
+      //  waited for that pass' end to find an empty queue -- 150-200 us on the stream of the short queues, the scoring behind them)
+      {
+        static bool const adaptive = !(std::getenv("GTX_BIG_GRID_ADAPTIVE") && std::getenv("GTX_BIG_GRID_ADAPTIVE")[0] == '0');
+        uint32_t const seen_exact = c->h_big_seen ? static_cast<uint32_t volatile *>(c->h_big_seen)[2] : 0xFFFFFFFFu;
+        a.exact_grid_limit = (!adaptive || c->exact_fixed_parts || seen_exact == 0xFFFFFFFFu) ? 0u : 2u * seen_exact + 4u;
+      }
       what = launch_exact_passes(a, sg);
+      if (!what && c->h_big_seen)
+        hipLaunchKernelGGL(gtx_seen_kernel, dim3(1), dim3(64), 0, sg, c->h_big_seen, s->d_big_state, s->d_exact_state);
       (void)hipEventRecord(static_cast<hipEvent_t>(slot->idle), sg);
     }
     if (what)
@@ -2599,7 +2623,10 @@ static int align_planes(gtx_ctx * c, CallScratch * s, const uint8_t * d_seq, uin
       uint32_t const * rec_part = d_records + static_cast<uint64_t>(first) * 2 * rec_words;
       uint8_t * flags_part = d_task_flags + 2ull * first;
       if (hinted)
-        hipLaunchKernelGGL(gtx_task_flags_fixup_kernel, dim3(n_cu * 4u), dim3(256), 0, sg, rec_part, rec_words, flags_part, s->d_queue1 + first,
+        // (one-wave workgroups: behind the short queues this launch stands beside the position-hinted pass of the NEXT batch, whose
+        //  workgroups of two wavefronts take every pair of slots a retiring one frees -- a workgroup of four wavefronts waited for that
+        //  pass' end, 130-180 us in the trace of the staggered schedule, and the scoring of this batch with it)
+        hipLaunchKernelGGL(gtx_task_flags_fixup_kernel, dim3(n_cu * 16u), dim3(64), 0, sg, rec_part, rec_words, flags_part, s->d_queue1 + first,
                            counters + 3, s->d_queue + 2ull * first, counters + 2,
                            var_masks ? var_masks + first / 64u : static_cast<unsigned long long *>(nullptr));
       else

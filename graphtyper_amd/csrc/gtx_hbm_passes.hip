@@ -110,20 +110,24 @@ namespace gtx
 // workgroup's part of a slab of HBM at run time.  Launched twice: EXACT_PARTS workgroups with a part each, then one workgroup
 // with the whole slab for what did not fit a part (its queue is the first launch's next_tasks).
 // (at most one workgroup of this pass per CU, usually none with work: no register diet -- all the registers a wavefront can name)
+#ifdef GTX_EXACT_PASS_WAVES // (A/B builds: registers for that many wavefronts per SIMD)
+#define GTX_EXACT_PASS_ATTR __attribute__((amdgpu_waves_per_eu(GTX_EXACT_PASS_WAVES, GTX_EXACT_PASS_WAVES)))
+#else
 #define GTX_EXACT_PASS_ATTR __attribute__((amdgpu_waves_per_eu(1, 2)))
+#endif
 #ifndef GTX_EXACT_LDS_KEYS
 #define GTX_EXACT_LDS_KEYS 4096
 #endif
 constexpr uint32_t EXACT_LDS_KEYS = GTX_EXACT_LDS_KEYS; // paths whose dense start / end tables fit the exact pass' 32 KB of LDS
-#define GTX_EXACT_PASS_KERNEL(NAME, NS)                                                                                            \
-  __global__ __launch_bounds__(64) GTX_EXACT_PASS_ATTR void NAME(GraphView g, IndexView ix, uint8_t const * __restrict__ seq, uint32_t seq_stride, \
+#define GTX_EXACT_PASS_KERNEL(NAME, NS, ATTR)                                                                                      \
+  __global__ __launch_bounds__(64) ATTR void NAME(GraphView g, IndexView ix, uint8_t const * __restrict__ seq, uint32_t seq_stride,\
                                              gtx_read_meta const * __restrict__ meta, uint32_t * __restrict__ records,             \
                                              uint32_t rec_words, uint32_t const * __restrict__ big_tasks, uint32_t big_task_cap,   \
                                              uint32_t * big_state, uint8_t * slab, unsigned long long part_bytes /* the slab's */,   \
                                              unsigned long long min_part_bytes, uint32_t fixed_parts, uint32_t cand_cap, uint32_t cap_v, \
                                              uint32_t * __restrict__ arena,                                                        \
                                              unsigned long long arena_words, unsigned long long * arena_cursor,                    \
-                                             uint32_t * __restrict__ next_tasks, uint32_t next_cap, uint32_t * next_state)         \
+                                             uint32_t * __restrict__ next_tasks, uint32_t next_cap, uint32_t * next_state, uint32_t lds_keys)\
   {                                                                                                                                \
     if (big_state[0] == 0) /* (nearly every batch: nothing reached this pass) */                                                   \
       return;                                                                                                                      \
@@ -158,11 +162,11 @@ constexpr uint32_t EXACT_LDS_KEYS = GTX_EXACT_LDS_KEYS; // paths whose dense sta
       return;                                                                                                                      \
     }                                                                                                                              \
     /* (the dense start / end tables in LDS when the part's paths fit there, else where exact_setup put them in the slab) */       \
-    __shared__ uint32_t s_pp_keys[2][EXACT_LDS_KEYS];                                                                              \
-    if (ws.cap_p <= EXACT_LDS_KEYS)                                                                                                \
+    extern __shared__ uint32_t s_pp_keys[]; /* 2 x lds_keys words: the launch sizes them */                                        \
+    if (ws.cap_p <= lds_keys)                                                                                                      \
     {                                                                                                                              \
-      ws.pp_start = s_pp_keys[0];                                                                                                  \
-      ws.pp_end = s_pp_keys[1];                                                                                                    \
+      ws.pp_start = s_pp_keys;                                                                                                     \
+      ws.pp_end = s_pp_keys + lds_keys;                                                                                            \
     }                                                                                                                              \
     WaveHipMem::mem_sync();                                                                                                        \
     GTX_HBM_PASS_BODY(NS)                                                                                                          \
@@ -178,8 +182,15 @@ constexpr uint32_t EXACT_LDS_KEYS = GTX_EXACT_LDS_KEYS; // paths whose dense sta
 #endif
 GTX_HBM_PASS_KERNEL(gtx_align_big_kernel, big)
 GTX_HBM_PASS_KERNEL(gtx_align_wide_kernel, wide)
-GTX_EXACT_PASS_KERNEL(gtx_align_exact_kernel, exact)
-GTX_EXACT_PASS_KERNEL(gtx_align_exact_wide_kernel, exactw)
+GTX_EXACT_PASS_KERNEL(gtx_align_exact_kernel, exact, GTX_EXACT_PASS_ATTR)
+GTX_EXACT_PASS_KERNEL(gtx_align_exact_wide_kernel, exactw, GTX_EXACT_PASS_ATTR)
+// ... and a build of it that can be PLACED beside a full chip -- registers for four wavefronts per SIMD (128, what the HBM-table
+// pass takes; the pass' own 186 need three wavefronts of the position-hinted pass to retire on one SIMD and nobody to take their
+// room), launched with 2 KB of LDS instead of 32 (a CU that holds fourteen workgroups of that pass has 20 KB left) -- for the batch
+// whose predecessor sent nothing this way: its four workgroups find the empty queue in 5 us instead of waiting 100-200 us for the
+// position-hinted pass of the next batch to end (round 6, kernel trace of the staggered schedule).  A task that does come is done, slowly.
+GTX_EXACT_PASS_KERNEL(gtx_align_exact_light_kernel, exact, __attribute__((amdgpu_waves_per_eu(4, 4))))
+GTX_EXACT_PASS_KERNEL(gtx_align_exact_wide_light_kernel, exactw, __attribute__((amdgpu_waves_per_eu(4, 4))))
 
 
 uint64_t big_workspace_bytes() { return sizeof(big::AlignWorkspace); }
@@ -217,7 +228,12 @@ char const * launch_exact_passes(HbmPassArgs const & a, hipStream_t stream)
   //  of the graph's widest site)
   uint32_t * const q1 = a.exact_tasks, * const q2 = q1 + CallScratch::EXACT_TASK_CAP, * const q3 = q2 + CallScratch::EXACT_TASK_CAP;
   uint32_t * const st1 = a.exact_state, * const st2 = st1 + 8, * const st3 = st2 + 8, * const st4 = st3 + 8;
-  auto kernel = a.wide_sites ? gtx_align_exact_wide_kernel : gtx_align_exact_kernel;
+  // (nothing expected -- the batch before sent no task here: the build that can be placed beside a full chip, four workgroups a launch)
+  bool const light = a.exact_grid_limit != 0 && a.exact_grid_limit <= 4u;
+  auto kernel = light ? (a.wide_sites ? gtx_align_exact_wide_light_kernel : gtx_align_exact_light_kernel)
+                      : (a.wide_sites ? gtx_align_exact_wide_kernel : gtx_align_exact_kernel);
+  uint32_t const lds_keys = light ? 256u : EXACT_LDS_KEYS;
+  size_t const lds_bytes = 2u * lds_keys * sizeof(uint32_t);
   unsigned long long const slab_bytes = a.exact_slab_bytes, min_part = slab_bytes / a.exact_parts;
   // (the second launch: parts of at least 16 MB -- 32 of them in a 512 MB slab, 128 in the 2 GB slab of a large batch: on a reference
   //  with repeats two hundred tasks come this far, and 32 parts took them in six rounds of a millisecond each)
@@ -231,15 +247,17 @@ char const * launch_exact_passes(HbmPassArgs const & a, hipStream_t stream)
                                : large_parts_env ? large_parts_env
                                : a.wide_sites    ? CallScratch::EXACT_LARGE_PARTS
                                                  : static_cast<uint32_t>(std::min<unsigned long long>(256ull, std::max<unsigned long long>(CallScratch::EXACT_LARGE_PARTS, slab_bytes >> 24)));
-  hipLaunchKernelGGL(kernel, dim3(a.exact_parts), dim3(64), 0, stream, a.g, a.ix, a.seq, a.seq_stride, a.meta, a.records, a.rec_words, q1,
+  uint32_t const grid1 = a.exact_grid_limit ? std::min<uint32_t>(a.exact_parts, a.exact_grid_limit) : a.exact_parts;
+  uint32_t const grid2 = a.exact_grid_limit ? std::min<uint32_t>(large_parts, a.exact_grid_limit) : large_parts;
+  hipLaunchKernelGGL(kernel, dim3(grid1), dim3(64), lds_bytes, stream, a.g, a.ix, a.seq, a.seq_stride, a.meta, a.records, a.rec_words, q1,
                      CallScratch::EXACT_TASK_CAP, st1, a.exact_slab, slab_bytes, min_part, a.exact_fixed_parts ? 1u : 0u, a.exact_part_cand_cap,
-                     CallScratch::EXACT_PART_SITES, a.arena, arena_words, a.arena_cursor, q2, CallScratch::EXACT_TASK_CAP, st2);
-  hipLaunchKernelGGL(kernel, dim3(large_parts), dim3(64), 0, stream, a.g, a.ix, a.seq, a.seq_stride, a.meta, a.records, a.rec_words, q2,
+                     CallScratch::EXACT_PART_SITES, a.arena, arena_words, a.arena_cursor, q2, CallScratch::EXACT_TASK_CAP, st2, lds_keys);
+  hipLaunchKernelGGL(kernel, dim3(grid2), dim3(64), lds_bytes, stream, a.g, a.ix, a.seq, a.seq_stride, a.meta, a.records, a.rec_words, q2,
                      CallScratch::EXACT_TASK_CAP, st2, a.exact_slab, slab_bytes, slab_bytes / large_parts, 0u, a.exact_cand_cap,
-                     CallScratch::EXACT_LARGE_SITES, a.arena, arena_words, a.arena_cursor, q3, CallScratch::EXACT_TASK_CAP, st3);
+                     CallScratch::EXACT_LARGE_SITES, a.arena, arena_words, a.arena_cursor, q3, CallScratch::EXACT_TASK_CAP, st3, lds_keys);
   // (what even the whole slab cannot hold is counted in st4: a queue of capacity 0)
-  hipLaunchKernelGGL(kernel, dim3(1), dim3(64), 0, stream, a.g, a.ix, a.seq, a.seq_stride, a.meta, a.records, a.rec_words, q3, CallScratch::EXACT_TASK_CAP,
-                     st3, a.exact_slab, slab_bytes, 0ull, 0u, a.exact_cand_cap, exact::AlignCfg::MAXV, a.arena, arena_words, a.arena_cursor, q3, 0u, st4);
+  hipLaunchKernelGGL(kernel, dim3(1), dim3(64), lds_bytes, stream, a.g, a.ix, a.seq, a.seq_stride, a.meta, a.records, a.rec_words, q3, CallScratch::EXACT_TASK_CAP,
+                     st3, a.exact_slab, slab_bytes, 0ull, 0u, a.exact_cand_cap, exact::AlignCfg::MAXV, a.arena, arena_words, a.arena_cursor, q3, 0u, st4, lds_keys);
   if (hipGetLastError() != hipSuccess)
     return "gtx_align_exact_kernel launch";
   return nullptr;

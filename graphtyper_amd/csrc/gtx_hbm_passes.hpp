@@ -38,6 +38,7 @@ struct HbmPassArgs
   uint32_t exact_part_cand_cap; // ... of a task that has a part of it
   uint32_t exact_parts;         // workgroups of the first launch
   bool exact_fixed_parts;       // (test switch) always that many parts, however few tasks there are
+  uint32_t exact_grid_limit = 0; // the most workgroups of an exact launch (0: no limit) -- what the batch before sent this way, and a few
   bool wide_sites;
   // big-record arena
   uint32_t * arena;
