@@ -501,7 +501,8 @@ class Workload:
             exchange = self.comm is not None or self.dist is not None
             if exchange and EXCHANGE_STREAM:
                 stream.wait_event(ln["scored"])  # (the lane's block was last read by the calls of its step before, on the exchange's stream)
-            gtx.check(L.gtx_scores_zero(ctx.h, C.byref(ln["buf"]), sp))  # (on the tail stream behind the step's short queues instead: 0.737 against 0.712 ms per step)
+            if not ln.pop("zeroed", False):  # (steps_staggered has zeroed the block on the tail stream, in front of the step's short queues)
+                gtx.check(L.gtx_scores_zero(ctx.h, C.byref(ln["buf"]), sp))  # (on the tail stream BEHIND the step's short queues: 0.737 against 0.712 ms per step, round 6's first session)
             self._score_call(ln["items"], ln["d_rec"], fl, ln["buf"], sp, ln["d_compact"], ln["d_work"] if ln.get("triaged") else None)
             if exchange and EXCHANGE_STREAM:
                 # N > 1: the sum over the ranks and the calls from the summed block go to a stream of their own -- the exchange is
@@ -562,6 +563,7 @@ class Workload:
         depth = max(1, min(depth, n_l))
         pace = os.environ.get("GTX_BENCH_PACE", "1") != "0"
         score_on = os.environ.get("GTX_BENCH_SCORE_ON", "H")
+        zero_on_tail = os.environ.get("GTX_BENCH_ZERO_ON", "H") == "T" and pace  # (A/B switch, round 6: "T" zeroes the lane's block on the tail stream in front of the step -- 0.571 against 0.569 ms, no gain: "H", in front of the scoring, stays)
         if score_on == "S" and not hasattr(self, "score_stream"):
             self.score_stream = torch.cuda.Stream(device=self.device)
         for _ in range(steps):
@@ -576,6 +578,13 @@ class Workload:
             spT = C.c_void_p(T.cuda_stream)
             d_seq, d_meta, d_items = self.sets[self.steps_done % len(self.sets)]
             self.steps_done += 1
+            if zero_on_tail:
+                # the lane's accumulators are zeroed on the tail stream IN FRONT of the step's short queues (the host has waited for the
+                # lane's last calls above; the step's `aligned` event lies behind it): a fill and the packets around it off the stream
+                # that carries the position-hinted passes and the scoring
+                with torch.cuda.stream(T):
+                    gtx.check(L.gtx_scores_zero(ctx.h, C.byref(ln["buf"]), spT))
+                ln["zeroed"] = True
             with torch.cuda.stream(H):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 sample = self.steps_done % EV_EVERY == 0  # (the wall time of an align call from one step in EV_EVERY: an event is a packet between two kernels)

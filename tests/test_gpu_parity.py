@@ -9,7 +9,7 @@ import pytest
 import harness
 import scenarios
 import ctypes as C
-from graphtyper_amd import lib as gtx
+from graphtyper_amd import lib as gtx, synth
 from oracle_lib import Oracle, encode
 from test_emu_parity import check_align, five_kmer_case, cfg3_case, neardup_case, direct_probes_case, n_runs_case, three_n_case, sv_deletion_case, edge_case, express_variants_case, forced_second_pass_case, iupac_case, run_stream, second_pass_case, sv_stream_case, satellite_case, homopolymer_case, dinucleotide_case
 
@@ -121,6 +121,29 @@ def test_exact_pass_with_the_whole_slab(monkeypatch):
 
 def test_reads_in_a_long_homopolymer():
     homopolymer_case(harness.GpuBackend)
+
+
+def test_exact_tasks_behind_batches_that_had_none():
+    """The exact pass' launches are sized by what the batch before sent there, and behind a batch that sent NOTHING they use the
+    build of the pass that can be placed beside a full chip (gtx_align_exact_light_kernel: 128 registers, 2 KB of LDS, four
+    workgroups).  A batch whose reads do reach the pass then is done by that build: same records, nothing refused -- and the batch
+    behind it gets the full build again."""
+    ref = synth.make_reference(20000, seed=3)
+    ref[10000:10280] = 1
+    recs = synth.make_snp_records(ref, 50, seed=4, region_begin=1000)
+    refs = synth.bases_to_str(ref)
+    o = Oracle(refs, recs, region_begin=1000)
+    b = harness.GpuBackend(gtx.graph_from_records(refs, recs, region_begin=1000))
+    easy, epos = synth.make_reads(ref[2000:6000], [r for r in recs if 2000 < r[0] - 1000 < 5998], 800, read_len=150, seed=11, region_begin=1000 + 2000)
+    eseq, elens = harness.pack_ragged(list(easy))
+    for _ in range(2):  # (the second of these calls is already sized by the first)
+        b.align(eseq, harness.read_meta(elens, pos=epos))
+        assert b.exact_pass_tasks()[0] == 0
+    hard, hpos = synth.make_reads(ref[9700:10580], [r for r in recs if 9700 < r[0] - 1000 < 10578], 1500, read_len=150, seed=9, err=0, n_rate=0,
+                                  region_begin=1000 + 9700, rev_frac=0.0)
+    check_align(b, o, list(hard), pos=hpos, allow_overflow=False)  # (its first call meets the light build, the others the full one)
+    assert b.exact_pass_tasks()[0] >= 15 and b.exact_pass_tasks()[3] == 0
+    check_align(b, o, list(easy), pos=epos, allow_overflow=False)
 
 
 def test_reads_in_copies_of_a_dinucleotide_repeat():
