@@ -726,7 +726,11 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
 // wavefront is through: with 16-wave workgroups one fits a CU and every workgroup's start (nothing to overlap the first
 // loads with) and end are paid with idle SIMDs; several small workgroups per CU overlap them (cfg2: 16 waves 0.845 ms,
 // 8 waves 0.77-0.78, 4 waves with 80 registers -- six resident workgroups -- 0.755).
-#define GTX_HINT_WAVES 4
+// (Round 6, third session -- the dense and the eight-k-mer builds in ONE-wave workgroups: on the graphs that get them whole steps are
+//  in flight, and a workgroup of four wavefronts with 25 KB of LDS is the last to be placed among the one-wave workgroups of the other
+//  steps' express, general and scoring kernels -- cfg3 1.27-1.31 -> 1.35-1.38 G reads/s, 2 x 250 reads 6.06-6.23 -> 6.33-6.47 in three /
+//  two A/B rounds on one box, the cluster graph the same.  The lean build: GTX_HINT_WAVES_LEAN, below.)
+#define GTX_HINT_WAVES 1
 #endif
 // (80 registers: six wavefronts per SIMD = three of these workgroups per CU, which their LDS also allows; the compiler
 // takes 83-85 when left alone -- allocated as 88: five wavefronts, two workgroups)
@@ -737,7 +741,7 @@ __device__ __forceinline__ void hinted_pass(GraphView const & g, IndexView const
 //  in flight: 8 / 4 / 2 / 1 wavefronts = 0.657 / 0.590 / 0.582 / 0.605 ms, the pass itself 0.46 / 0.407 / 0.394 / 0.329: the smaller the
 //  workgroup the sooner a retiring one's room is taken again -- and with one-wave workgroups it is always this pass that takes it:
 //  the short queues beside it get no wavefront in (express 0.18 -> 0.55 ms, a higher priority for their stream changes nothing) and
-//  the scoring waits for them.  The dense and the eight-k-mer builds stay at four: cfg3 is 2 % slower with two.)
+//  the scoring waits for them.)
 #ifndef GTX_HINT_WAVES_LEAN
 #define GTX_HINT_WAVES_LEAN 2
 #endif
