@@ -1404,12 +1404,13 @@ def extra_repeats(args, torch, gtx, synth, device, ref):
             "arrays of a 171-bp unit, %d near-duplicate 300-bp segments: %.1f %%%% of the region), SNP every 1 kb, max %%d alleles per site" %
             (len(spots), sum(s[0] == "homopolymer" for s in spots), sum(s[0] == "tandem" for s in spots), sum(s[0] == "array" for s in spots),
              sum(s[0] == "near-duplicate" for s in spots), 100.0 * covered / len(ref)))
-    # (three steps in flight, each on a stream of its own: the HBM-table and exact passes are chains of round trips on a few thousand
-    #  wavefronts, and three steps' worth of them overlap -- 20 ms per step against 30 one at a time.  The arena of the long records is
+    # (steps in flight, each on a stream of its own: the HBM-table and exact passes are chains of round trips on a few thousand
+    #  wavefronts, and several steps' worth of them overlap -- 20 ms per step against 30 one at a time; 3 / 4 / 5 / 6 steps in flight =
+    #  98.0 / 96.5 / 100.3 / 101.0 M reads/s here, 260 / 261 / 266 / 266 M on the genome-like leg: six since round 6's third session.  The arena of the long records is
     #  the context's: with steps in flight it is sized for all the steps of the leg (1 GB) and not started over between them -- a host's
     #  regions in flight are contexts of their own, gtx_regions_run.  GTX_BENCH_REPEATS_LANES=1: one step at a time, the arena
     #  started over per step.)
-    lanes = int(os.environ.get("GTX_BENCH_REPEATS_LANES", "3"))
+    lanes = int(os.environ.get("GTX_BENCH_REPEATS_LANES", "6"))
     return extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False, what, lanes=lanes, big_record_words=(1 << 27) if lanes == 1 else (1 << 28),
                           schedule="lanes" if lanes > 1 else None)
 
@@ -1434,7 +1435,7 @@ def extra_genome_like(args, torch, gtx, synth, device):
             "diverged), %.1f %%%% STRs, %.1f %%%% segmental duplications; SNP every 1 kb, max %%d alleles per site; reads with 0.5 %%%% substitutions, 0.1 %%%% N, "
             "0.05 %%%% indel errors, 3 %%%% soft-clipped, 2 %%%% wrong / shifted position hints" %
             (100.0 * stats["interspersed"], stats["families"], 100.0 * stats["str"], 100.0 * stats["segdup"]))
-    lanes = int(os.environ.get("GTX_BENCH_REPEATS_LANES", "3"))  # (as in extra_repeats: steps in flight, each on a stream of its own)
+    lanes = int(os.environ.get("GTX_BENCH_REPEATS_LANES", "6"))  # (as in extra_repeats: steps in flight, each on a stream of its own)
     out = extra_workload(args, torch, gtx, synth, device, ref, recs, 1, False, what, lanes=lanes, big_record_words=(1 << 27) if lanes == 1 else (1 << 28),
                          make_reads=make, schedule="lanes" if lanes > 1 else None)
     out["reads_made"] = made.get(5)
